@@ -1,0 +1,684 @@
+/*
+ * hark_oracle.c -- CPU restatement of HarkDB's operator bodies.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, the smoke
+ * check in __graft_entry__.py and the cpu_baseline leg of bench.py may load
+ * it.  The product path (harkdb_amd + libhark.so) never links or calls it.
+ *
+ * What it restates (paths relative to the reference checkout):
+ *   futhark/select.fut:9-23            -> ora_select
+ *   futhark/groupby.fut:8-62           -> ora_rsort_step_rows, ora_rsort_rows,
+ *                                         ora_mk_flags, ora_type_func,
+ *                                         ora_merge, ora_groupby,
+ *                                         ora_groupby_call
+ *   futhark/join.fut:9-75              -> ora_join (+ helpers)
+ *   futhark/lib/github.com/diku-dk/segmented/segmented.fut:7-103
+ *                                      -> ora_segmented_scan/_reduce,
+ *                                         ora_replicated_iota,
+ *                                         ora_segmented_iota, ora_expand*,
+ *   futhark/main.fut:7-9               -> ora_query_sel, ora_query_groupby
+ *
+ * Evaluation order: every Futhark `scan` / `reduce` is evaluated as a
+ * SEQUENTIAL LEFT FOLD seeded with the neutral element, which is what the
+ * reference's shipped backend (`futhark c`, setup.sh:12) does.  That matters:
+ * the `ne` handed to segmented_reduce at groupby.fut:58 is not a true neutral
+ * element of `merge`, so only the sequential order is well defined.
+ *
+ * Parity status: the reference cannot be compiled or imported in the build
+ * container (no futhark compiler, no futhark_ffi).  The primitives are pinned
+ * by the 18 known-answer vectors of segmented_tests.fut:5-72
+ * (tests/golden/segmented_kat.json).  The operator level (select / groupby /
+ * join) has NO result-pinning test in the reference (test.py:7-8 only
+ * prints): operator parity is "pinned by hand-derived goldens"
+ * (tests/golden/operators.json), not by reference output.
+ *
+ * The second half of the file holds SQL-semantics oracles for clauses the
+ * reference does not implement (WHERE, COUNT, AVG, f32, i64, SORT BY,
+ * HAVING): PARITY UNPINNED BY THE REFERENCE, semantics defined by this build.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+
+#define ORA_OK 0
+#define ORA_EBOUNDS 1 /* Futhark bounds-check failure (entry returns non-zero) */
+#define ORA_ENOMEM 2
+#define ORA_EARG 3
+
+/* ------------------------------------------------------------------ */
+/* Generic sequential SOACs                                            */
+/* ------------------------------------------------------------------ */
+
+/* Binary operator over opaque elements: out = op(a, b).  out may alias
+ * neither a nor b. */
+typedef void (*ora_binop)(void *ctx, const void *a, const void *b, void *out);
+
+/* segmented.fut:7-13.
+ *   scan (\(xf,x) (yf,y) -> (xf||yf, if yf then y else x `op` y)) (false,ne)
+ * evaluated left to right.  `as` and `out` are n elements of `esz` bytes. */
+int ora_segmented_scan(ora_binop op, void *ctx, const void *ne, size_t esz,
+                       const uint8_t *flags, const void *as, int64_t n,
+                       void *out)
+{
+    if (n < 0) return ORA_EARG;
+    uint8_t *acc = (uint8_t *)malloc(esz ? esz : 1);
+    uint8_t *tmp = (uint8_t *)malloc(esz ? esz : 1);
+    if (!acc || !tmp) { free(acc); free(tmp); return ORA_ENOMEM; }
+    memcpy(acc, ne, esz);                 /* (false, ne) */
+    for (int64_t i = 0; i < n; i++) {
+        const uint8_t *y = (const uint8_t *)as + (size_t)i * esz;
+        if (flags[i]) {
+            memcpy(acc, y, esz);          /* if y_flag then y */
+        } else {
+            op(ctx, acc, y, tmp);         /* else x `op` y */
+            memcpy(acc, tmp, esz);
+        }
+        memcpy((uint8_t *)out + (size_t)i * esz, acc, esz);
+    }
+    free(acc); free(tmp);
+    return ORA_OK;
+}
+
+/* segmented.fut:20-37.  Returns the number of segments in *n_out and a
+ * malloc'd result in *out (caller frees; NULL when empty). */
+int ora_segmented_reduce(ora_binop op, void *ctx, const void *ne, size_t esz,
+                         const uint8_t *flags, const void *as, int64_t n,
+                         void **out, int64_t *n_out)
+{
+    *out = NULL; *n_out = 0;
+    if (n < 0) return ORA_EARG;
+    if (n == 0) return ORA_OK;                       /* :29 */
+    uint8_t *scanned = (uint8_t *)malloc((size_t)n * esz);
+    int32_t *offs = (int32_t *)malloc((size_t)n * sizeof(int32_t));
+    uint8_t *ends = (uint8_t *)malloc((size_t)n);
+    if (!scanned || !offs || !ends) { free(scanned); free(offs); free(ends); return ORA_ENOMEM; }
+    int rc = ora_segmented_scan(op, ctx, ne, esz, flags, as, n, scanned); /* :24 */
+    if (rc) { free(scanned); free(offs); free(ends); return rc; }
+    for (int64_t i = 0; i < n; i++) ends[i] = flags[(i + 1) % n];         /* :26 rotate 1 */
+    int32_t run = 0;
+    for (int64_t i = 0; i < n; i++) { run += ends[i] ? 1 : 0; offs[i] = run; } /* :28 */
+    int64_t nseg = offs[n - 1];                                           /* :29 */
+    uint8_t *res = (uint8_t *)malloc((size_t)(nseg ? nseg : 1) * esz);
+    if (!res) { free(scanned); free(offs); free(ends); return ORA_ENOMEM; }
+    for (int64_t g = 0; g < nseg; g++) memcpy(res + (size_t)g * esz, ne, esz); /* :33 */
+    for (int64_t i = 0; i < n; i++) {                                     /* :36-37 */
+        int64_t idx = ends[i] ? (int64_t)offs[i] - 1 : -1;
+        if (idx >= 0 && idx < nseg)   /* scatter drops out-of-range writes */
+            memcpy(res + (size_t)idx * esz, scanned + (size_t)i * esz, esz);
+    }
+    free(scanned); free(offs); free(ends);
+    if (nseg == 0) { free(res); res = NULL; }
+    *out = res; *n_out = nseg;
+    return ORA_OK;
+}
+
+static void op_add_i32(void *ctx, const void *a, const void *b, void *out)
+{
+    (void)ctx;
+    *(int32_t *)out = (int32_t)((uint32_t)*(const int32_t *)a + (uint32_t)*(const int32_t *)b);
+}
+
+/* Entry points used by the KATs (segmented_tests.fut:14-15, :24-25). */
+int ora_segmented_scan_add_i32(const uint8_t *flags, const int32_t *as, int64_t n, int32_t *out)
+{
+    int32_t ne = 0;
+    return ora_segmented_scan(op_add_i32, NULL, &ne, sizeof ne, flags, as, n, out);
+}
+
+int ora_segmented_reduce_add_i32(const uint8_t *flags, const int32_t *as, int64_t n,
+                                 int32_t *out, int64_t *n_out)
+{
+    int32_t ne = 0; void *res = NULL;
+    int rc = ora_segmented_reduce(op_add_i32, NULL, &ne, sizeof ne, flags, as, n, &res, n_out);
+    if (rc) return rc;
+    if (*n_out) memcpy(out, res, (size_t)*n_out * sizeof(int32_t));
+    free(res);
+    return ORA_OK;
+}
+
+/* segmented.fut:44-50.  out must hold sum(reps) entries; *n_out = sum. */
+int ora_replicated_iota(const int32_t *reps, int64_t n, int32_t *out, int64_t *n_out)
+{
+    *n_out = 0;
+    if (n < 0) return ORA_EARG;
+    int32_t *s1 = (int32_t *)malloc((size_t)(n ? n : 1) * sizeof(int32_t));
+    int32_t *s2 = (int32_t *)malloc((size_t)(n ? n : 1) * sizeof(int32_t));
+    if (!s1 || !s2) { free(s1); free(s2); return ORA_ENOMEM; }
+    int32_t run = 0;
+    for (int64_t i = 0; i < n; i++) { run += reps[i]; s1[i] = run; }       /* :45 */
+    for (int64_t i = 0; i < n; i++)                                         /* :46-47 */
+        s2[i] = (i == 0) ? 0 : s1[(i - 1 + n) % n];
+    int64_t total = 0;
+    for (int64_t i = 0; i < n; i++) total += reps[i];                       /* reduce (+) 0 reps */
+    if (total < 0) { free(s1); free(s2); return ORA_EBOUNDS; }
+    int32_t *tmp = (int32_t *)calloc((size_t)(total ? total : 1), sizeof(int32_t));
+    uint8_t *fl = (uint8_t *)malloc((size_t)(total ? total : 1));
+    if (!tmp || !fl) { free(s1); free(s2); free(tmp); free(fl); return ORA_ENOMEM; }
+    for (int64_t i = 0; i < n; i++) {                                       /* :48 reduce_by_index max */
+        int64_t d = s2[i];
+        if (d >= 0 && d < total && (int32_t)i > tmp[d]) tmp[d] = (int32_t)i;
+    }
+    for (int64_t j = 0; j < total; j++) fl[j] = tmp[j] > 0;                 /* :49 */
+    int rc = ora_segmented_scan_add_i32(fl, tmp, total, out);               /* :50 */
+    free(s1); free(s2); free(tmp); free(fl);
+    *n_out = total;
+    return rc;
+}
+
+/* segmented.fut:58-60 */
+int ora_segmented_iota(const uint8_t *flags, int64_t n, int32_t *out)
+{
+    int32_t *ones = (int32_t *)malloc((size_t)(n ? n : 1) * sizeof(int32_t));
+    if (!ones) return ORA_ENOMEM;
+    for (int64_t i = 0; i < n; i++) ones[i] = 1;
+    int rc = ora_segmented_scan_add_i32(flags, ones, n, out);
+    for (int64_t i = 0; i < n; i++) out[i] -= 1;
+    free(ones);
+    return rc;
+}
+
+/* segmented.fut:70-74, specialised only in how `sz`/`get` are supplied:
+ * szs[i] = sz(arr[i]) is passed in; the caller applies `get arr[i] j` to the
+ * returned (idxs, iotas).  Both outputs hold sum(szs) entries. */
+int ora_expand_indices(const int32_t *szs, int64_t n, int32_t *idxs, int32_t *iotas, int64_t *n_out)
+{
+    int rc = ora_replicated_iota(szs, n, idxs, n_out);                      /* :72 */
+    if (rc) return rc;
+    int64_t t = *n_out;
+    uint8_t *fl = (uint8_t *)malloc((size_t)(t ? t : 1));
+    if (!fl) return ORA_ENOMEM;
+    for (int64_t j = 0; j < t; j++)                                         /* :73 rotate (-1) */
+        fl[j] = idxs[j] != idxs[(j - 1 + t) % t];
+    rc = ora_segmented_iota(fl, t, iotas);
+    free(fl);
+    return rc;
+}
+
+/* KAT entries segmented_tests.fut:55-56, :63-64, :71-72 (sz = id, get = x*i). */
+int ora_test_expand(const int32_t *arr, int64_t n, int32_t *out, int64_t *n_out)
+{
+    int64_t cap = 0;
+    for (int64_t i = 0; i < n; i++) cap += arr[i];
+    int32_t *idxs = (int32_t *)malloc((size_t)(cap ? cap : 1) * 4);
+    int32_t *iotas = (int32_t *)malloc((size_t)(cap ? cap : 1) * 4);
+    if (!idxs || !iotas) { free(idxs); free(iotas); return ORA_ENOMEM; }
+    int rc = ora_expand_indices(arr, n, idxs, iotas, n_out);
+    if (!rc) for (int64_t j = 0; j < *n_out; j++) out[j] = arr[idxs[j]] * iotas[j];
+    free(idxs); free(iotas);
+    return rc;
+}
+
+/* segmented.fut:84-91 with sz/get supplied as arrays szs[] and a value
+ * callback evaluated by the caller; kept only because the reference's KATs
+ * cover it (HarkDB itself never calls it). */
+static int expand_reduce_szs(const int32_t *szs, const int32_t *src, const uint8_t *src_is_ne,
+                             int64_t n, int32_t *out, int64_t *n_out)
+{
+    int64_t cap = 0;
+    for (int64_t i = 0; i < n; i++) cap += szs[i];
+    int32_t *idxs = (int32_t *)malloc((size_t)(cap ? cap : 1) * 4);
+    int32_t *iotas = (int32_t *)malloc((size_t)(cap ? cap : 1) * 4);
+    int32_t *vs = (int32_t *)malloc((size_t)(cap ? cap : 1) * 4);
+    uint8_t *fl = (uint8_t *)malloc((size_t)(cap ? cap : 1));
+    if (!idxs || !iotas || !vs || !fl) { free(idxs); free(iotas); free(vs); free(fl); return ORA_ENOMEM; }
+    int64_t t = 0;
+    int rc = ora_replicated_iota(szs, n, idxs, &t);                         /* :87 */
+    if (!rc) {
+        for (int64_t j = 0; j < t; j++) fl[j] = idxs[j] != idxs[(j - 1 + t) % t]; /* :88 */
+        rc = ora_segmented_iota(fl, t, iotas);                              /* :89 */
+    }
+    if (!rc) {
+        for (int64_t j = 0; j < t; j++)                                     /* :90 */
+            vs[j] = (src_is_ne && src_is_ne[idxs[j]]) ? 0 : src[idxs[j]] * iotas[j];
+        rc = ora_segmented_reduce_add_i32(fl, vs, t, out, n_out);           /* :91 */
+    }
+    free(idxs); free(iotas); free(vs); free(fl);
+    return rc;
+}
+
+int ora_test_expand_reduce(const int32_t *arr, int64_t n, int32_t *out, int64_t *n_out)
+{
+    return expand_reduce_szs(arr, arr, NULL, n, out, n_out);
+}
+
+/* segmented.fut:97-103 */
+int ora_test_expand_outer_reduce(const int32_t *arr, int64_t n, int32_t *out, int64_t *n_out)
+{
+    int32_t *szs = (int32_t *)malloc((size_t)(n ? n : 1) * 4);
+    uint8_t *isne = (uint8_t *)malloc((size_t)(n ? n : 1));
+    if (!szs || !isne) { free(szs); free(isne); return ORA_ENOMEM; }
+    for (int64_t i = 0; i < n; i++) { szs[i] = arr[i] == 0 ? 1 : arr[i]; isne[i] = arr[i] == 0; }
+    int rc = expand_reduce_szs(szs, arr, isne, n, out, n_out);
+    free(szs); free(isne);
+    return rc;
+}
+
+/* ------------------------------------------------------------------ */
+/* select.fut                                                          */
+/* ------------------------------------------------------------------ */
+
+/* select.fut:9-11, :17-20, :23 and main.fut:7.  db is row-major [n][m] i32;
+ * out is row-major [n][k]. */
+int ora_query_sel(const int32_t *db, int64_t n, int64_t m,
+                  const int32_t *cols, int64_t k, int32_t *out)
+{
+    for (int64_t j = 0; j < k; j++)
+        if (cols[j] < 0 || cols[j] >= m) return n > 0 ? ORA_EBOUNDS : ORA_OK;
+    for (int64_t r = 0; r < n; r++)               /* map (sel cols) db */
+        for (int64_t j = 0; j < k; j++)           /* map (\i -> row[i]) cols */
+            out[r * k + j] = db[r * m + cols[j]];
+    return ORA_OK;
+}
+
+/* ------------------------------------------------------------------ */
+/* groupby.fut                                                         */
+/* ------------------------------------------------------------------ */
+
+/* groupby.fut:8-18: one stable 1-bit split of whole rows keyed on column 0.
+ * xs and out are row-major [n][s] u32 and must not alias. */
+static int rsort_step_generic(const uint8_t *xs, uint8_t *out, int64_t n, size_t rowb,
+                              const uint32_t *key_of_row_stride, size_t key_stride_b, int bitn,
+                              int32_t *bits1, int32_t *idxs)
+{
+    /* bits1 = (key >> bitn) & 1 (:10); bits0 = 1 - bits1 (:11) */
+    for (int64_t i = 0; i < n; i++) {
+        uint32_t key = *(const uint32_t *)((const uint8_t *)key_of_row_stride + (size_t)i * key_stride_b);
+        bits1[i] = (int32_t)(key >> (uint32_t)bitn) & 1;
+    }
+    int32_t sc0 = 0, sc1 = 0, offs = 0;
+    for (int64_t i = 0; i < n; i++) offs += 1 - bits1[i];                  /* :14 reduce (+) 0 bits0 */
+    for (int64_t i = 0; i < n; i++) {
+        int32_t b1 = bits1[i], b0 = 1 - b1;
+        sc0 += b0;                                                         /* :12 scan (+) 0 bits0 */
+        sc1 += b1;                                                         /* :13 scan (+) 0 bits1 */
+        int32_t i0 = b0 * sc0;                                             /* :12 */
+        int32_t i1 = b1 * (sc1 + offs);                                    /* :15 */
+        idxs[i] = i0 + i1 - 1;                                             /* :16-17 */
+    }
+    memcpy(out, xs, (size_t)n * rowb);                                     /* :18 copy xs */
+    for (int64_t i = 0; i < n; i++)                                        /* :18 scatter */
+        if (idxs[i] >= 0 && idxs[i] < n)
+            memcpy(out + (size_t)idxs[i] * rowb, xs + (size_t)i * rowb, rowb);
+    return ORA_OK;
+}
+
+/* groupby.fut:21-22: 32 passes, least-significant bit first.  Sorts in
+ * place (uses a scratch copy internally). */
+int ora_rsort_rows(uint32_t *rows, int64_t n, int64_t s)
+{
+    if (n <= 0 || s <= 0) return ORA_OK;
+    size_t rowb = (size_t)s * 4;
+    uint8_t *tmp = (uint8_t *)malloc((size_t)n * rowb);
+    int32_t *bits1 = (int32_t *)malloc((size_t)n * 4);
+    int32_t *idxs = (int32_t *)malloc((size_t)n * 4);
+    if (!tmp || !bits1 || !idxs) { free(tmp); free(bits1); free(idxs); return ORA_ENOMEM; }
+    uint8_t *a = (uint8_t *)rows, *b = tmp;
+    for (int bit = 0; bit < 32; bit++) {
+        rsort_step_generic(a, b, n, rowb, (const uint32_t *)a, rowb, bit, bits1, idxs);
+        uint8_t *t = a; a = b; b = t;
+    }
+    /* 32 swaps: result is back in `rows`. */
+    free(tmp); free(bits1); free(idxs);
+    return ORA_OK;
+}
+
+/* groupby.fut:26-33 */
+void ora_mk_flags(const uint32_t *row_ids, int64_t stride, int64_t n, uint32_t *out)
+{
+    for (int64_t i = 0; i < n; i++)
+        out[i] = (i == 0) ? 1u : (row_ids[(i - 1) * stride] != row_ids[i * stride] ? 1u : 0u);
+}
+
+/* groupby.fut:35-41 */
+uint32_t ora_type_func(int32_t typ, uint32_t v1, uint32_t v2)
+{
+    switch (typ) {
+    case 1: return v1 * v2;                    /* wraps mod 2^32 */
+    case 2: return v1 + v2;
+    case 3: return v1 > v2 ? v1 : v2;
+    case 4: return v1 < v2 ? v1 : v2;
+    default: return v1 < v2 ? v1 : v2;         /* :41 "case _" */
+    }
+}
+
+struct merge_ctx { const int32_t *t_cols; int64_t t; int64_t s; int err; };
+
+/* groupby.fut:45-48 */
+static void op_merge(void *vctx, const void *va, const void *vb, void *vout)
+{
+    struct merge_ctx *c = (struct merge_ctx *)vctx;
+    const uint32_t *a = (const uint32_t *)va, *b = (const uint32_t *)vb;
+    uint32_t *o = (uint32_t *)vout;
+    for (int64_t i = 0; i < c->s; i++) {
+        if (i == 0) o[i] = a[i];
+        else if (i - 1 >= c->t) { c->err = 1; o[i] = 0; }   /* s_cols_t[i-1] out of bounds */
+        else o[i] = ora_type_func(c->t_cols[i - 1], a[i], b[i]);
+    }
+}
+
+/* groupby.fut:51-58.  cols has s entries (cols[0] is the key column).
+ * *out is malloc'd row-major [G][s]; caller frees with ora_free. */
+int ora_groupby(const uint32_t *db, int64_t n, int64_t m,
+                const int32_t *cols, int64_t s, const int32_t *t_cols, int64_t t,
+                uint32_t **out, int64_t *g_out)
+{
+    *out = NULL; *g_out = 0;
+    if (n < 0 || m < 0 || s < 0) return ORA_EARG;
+    if (n == 0) return ORA_OK;
+    if (s == 0) return ORA_EBOUNDS;              /* sorted_rows[:,0] on zero-width rows */
+    for (int64_t j = 0; j < s; j++) if (cols[j] < 0 || cols[j] >= m) return ORA_EBOUNDS;
+    uint32_t *keep = (uint32_t *)malloc((size_t)n * (size_t)s * 4);
+    uint32_t *flagw = (uint32_t *)malloc((size_t)n * 4);
+    uint8_t *flag = (uint8_t *)malloc((size_t)n);
+    uint32_t *ne = (uint32_t *)calloc((size_t)s, 4);                       /* replicate s 0 */
+    if (!keep || !flagw || !flag || !ne) { free(keep); free(flagw); free(flag); free(ne); return ORA_ENOMEM; }
+    for (int64_t r = 0; r < n; r++)                                        /* :52-53 */
+        for (int64_t j = 0; j < s; j++) keep[r * s + j] = db[r * m + cols[j]];
+    int rc = ora_rsort_rows(keep, n, s);                                   /* :54 */
+    if (!rc) {
+        ora_mk_flags(keep, s, n, flagw);                                   /* :55 */
+        for (int64_t i = 0; i < n; i++) flag[i] = flagw[i] == 1;           /* :56 */
+        struct merge_ctx mc = { t_cols, t, s, 0 };                         /* :57 */
+        void *res = NULL;
+        rc = ora_segmented_reduce(op_merge, &mc, ne, (size_t)s * 4, flag, keep, n, &res, g_out); /* :58 */
+        if (!rc && mc.err) { free(res); res = NULL; *g_out = 0; rc = ORA_EBOUNDS; }
+        *out = (uint32_t *)res;
+    }
+    free(keep); free(flagw); free(flag); free(ne);
+    return rc;
+}
+
+/* groupby.fut:60-62 and main.fut:9 */
+int ora_query_groupby(const uint32_t *db, int64_t n, int64_t m, int32_t g_col,
+                      const int32_t *s_cols, int64_t ns, const int32_t *t_cols, int64_t nt,
+                      uint32_t **out, int64_t *g_out)
+{
+    int32_t *cols = (int32_t *)malloc((size_t)(ns + 1) * 4);
+    if (!cols) return ORA_ENOMEM;
+    cols[0] = g_col;                                                       /* concat [g_col] s_cols */
+    for (int64_t j = 0; j < ns; j++) cols[j + 1] = s_cols[j];
+    int rc = ora_groupby(db, n, m, cols, ns + 1, t_cols, nt, out, g_out);
+    free(cols);
+    return rc;
+}
+
+void ora_free(void *p) { free(p); }
+
+/* ------------------------------------------------------------------ */
+/* join.fut                                                            */
+/* ------------------------------------------------------------------ */
+
+typedef struct { uint32_t key; int32_t tag; int32_t row; } ora_triple;
+
+/* join.fut:37-41.  arr = (tag,row) pairs of one key segment. */
+static int generate_pairs(const ora_triple *seg, int64_t len,
+                          int32_t **p1, int32_t **p2, int64_t *np, int64_t *cap)
+{
+    /* partition (\x -> x.0 == 1): stable, tag-1 rows first (:38) */
+    int32_t *arr1 = (int32_t *)malloc((size_t)(len ? len : 1) * 4);
+    int32_t *arr2 = (int32_t *)malloc((size_t)(len ? len : 1) * 4);
+    if (!arr1 || !arr2) { free(arr1); free(arr2); return ORA_ENOMEM; }
+    int64_t n1 = 0, n2 = 0;
+    for (int64_t i = 0; i < len; i++) {
+        if (seg[i].tag == 1) arr1[n1++] = seg[i].row; else arr2[n2++] = seg[i].row;
+    }
+    /* expand (\_ -> length arr2) (\x i -> (x, arr2[i])) arr1 (:41) */
+    int rc = ORA_OK;
+    int64_t total = n1 * n2;
+    if (total > 0) {
+        int32_t *szs = (int32_t *)malloc((size_t)n1 * 4);
+        int32_t *idxs = (int32_t *)malloc((size_t)total * 4);
+        int32_t *iotas = (int32_t *)malloc((size_t)total * 4);
+        if (!szs || !idxs || !iotas) { free(szs); free(idxs); free(iotas); free(arr1); free(arr2); return ORA_ENOMEM; }
+        for (int64_t i = 0; i < n1; i++) szs[i] = (int32_t)n2;
+        int64_t t = 0;
+        rc = ora_expand_indices(szs, n1, idxs, iotas, &t);
+        if (!rc) {
+            if (*np + t > *cap) {
+                int64_t nc = (*np + t) * 2;
+                int32_t *q1 = (int32_t *)realloc(*p1, (size_t)nc * 4);
+                int32_t *q2 = (int32_t *)realloc(*p2, (size_t)nc * 4);
+                if (!q1 || !q2) { rc = ORA_ENOMEM; if (q1) *p1 = q1; if (q2) *p2 = q2; }
+                else { *p1 = q1; *p2 = q2; *cap = nc; }
+            }
+            if (!rc) for (int64_t j = 0; j < t; j++) {                     /* concat acc ... (:68) */
+                if (iotas[j] < 0 || iotas[j] >= n2) { rc = ORA_EBOUNDS; break; }
+                (*p1)[*np] = arr1[idxs[j]];
+                (*p2)[*np] = arr2[iotas[j]];
+                (*np)++;
+            }
+        }
+        free(szs); free(idxs); free(iotas);
+    }
+    free(arr1); free(arr2);
+    return rc;
+}
+
+/* join.fut:52-75.  db1 [n][m], db2 [s][t] row-major u32.  Output row-major
+ * [P][l+k]: cols1 of the left row followed by cols2 of the right row. */
+int ora_join(const uint32_t *db1, int64_t n, int64_t m,
+             const uint32_t *db2, int64_t s, int64_t t,
+             int32_t col1, int32_t col2,
+             const int32_t *cols1, int64_t l, const int32_t *cols2, int64_t k,
+             uint32_t **out, int64_t *p_out)
+{
+    *out = NULL; *p_out = 0;
+    if (n < 0 || s < 0) return ORA_EARG;
+    if ((n > 0 && (col1 < 0 || col1 >= m)) || (s > 0 && (col2 < 0 || col2 >= t))) return ORA_EBOUNDS;
+    int64_t tot = n + s;
+    ora_triple *a = (ora_triple *)malloc((size_t)(tot ? tot : 1) * sizeof(ora_triple));
+    ora_triple *b = (ora_triple *)malloc((size_t)(tot ? tot : 1) * sizeof(ora_triple));
+    int32_t *bits1 = (int32_t *)malloc((size_t)(tot ? tot : 1) * 4);
+    int32_t *idxs = (int32_t *)malloc((size_t)(tot ? tot : 1) * 4);
+    int32_t *flags = (int32_t *)malloc((size_t)(tot ? tot : 1) * 4);
+    uint8_t *fl = (uint8_t *)malloc((size_t)(tot ? tot : 1));
+    int32_t *ones = (int32_t *)malloc((size_t)(tot ? tot : 1) * 4);
+    int32_t *f_lens = (int32_t *)malloc((size_t)(tot ? tot : 1) * 4);
+    int32_t *f_l = NULL, *p_lens = NULL, *p1 = NULL, *p2 = NULL;
+    int rc = ORA_OK;
+    if (!a || !b || !bits1 || !idxs || !flags || !fl || !ones || !f_lens) { rc = ORA_ENOMEM; goto done; }
+    for (int64_t i = 0; i < n; i++) { a[i].key = db1[i * m + col1]; a[i].tag = 1; a[i].row = (int32_t)i; } /* :55 */
+    for (int64_t i = 0; i < s; i++) { a[n + i].key = db2[i * t + col2]; a[n + i].tag = 2; a[n + i].row = (int32_t)i; } /* :56-57 */
+    {   /* :58 rsort (join.fut:9-23) */
+        ora_triple *x = a, *y = b;
+        for (int bit = 0; bit < 32; bit++) {
+            rsort_step_generic((const uint8_t *)x, (uint8_t *)y, tot, sizeof(ora_triple),
+                               &x[0].key, sizeof(ora_triple), bit, bits1, idxs);
+            ora_triple *tmp = x; x = y; y = tmp;
+        }
+        /* even number of swaps: sorted data is in `a`. */
+    }
+    for (int64_t i = 0; i < tot; i++)                                      /* :59, :27-34 */
+        flags[i] = (i == 0) ? 1 : (a[i - 1].key != a[i].key ? 1 : 0);
+    for (int64_t i = 0; i < tot; i++) { fl[i] = flags[i] == 1; ones[i] = 1; }
+    int64_t nseg = 0;
+    rc = ora_segmented_reduce_add_i32(fl, ones, tot, f_lens, &nseg);       /* :60, :43 */
+    if (rc) goto done;
+    f_l = (int32_t *)malloc((size_t)(nseg ? nseg : 1) * 4);
+    p_lens = (int32_t *)malloc((size_t)(nseg ? nseg : 1) * 4);
+    if (!f_l || !p_lens) { rc = ORA_ENOMEM; goto done; }
+    { int32_t run = 0; for (int64_t g = 0; g < nseg; g++) { run += f_lens[g]; f_l[g] = run; } } /* :61 */
+    for (int64_t g = 0; g < nseg; g++) p_lens[g] = f_l[(g - 1 + nseg) % nseg];  /* :63 rotate (-1) */
+    if (nseg > 0) p_lens[0] = 0;                                           /* :63 scatter [0] [0] */
+    {
+        int64_t np = 0, cap = 0;
+        for (int64_t g = 0; g < nseg && !rc; g++) {                        /* :67-68 */
+            int64_t lo = p_lens[g], hi = f_l[g];
+            if (lo < 0 || hi > tot || lo > hi) { rc = ORA_EBOUNDS; break; }
+            rc = generate_pairs(a + lo, hi - lo, &p1, &p2, &np, &cap);
+        }
+        if (rc) goto done;
+        for (int64_t j = 0; j < l; j++) if (np > 0 && (cols1[j] < 0 || cols1[j] >= m)) { rc = ORA_EBOUNDS; goto done; }
+        for (int64_t j = 0; j < k; j++) if (np > 0 && (cols2[j] < 0 || cols2[j] >= t)) { rc = ORA_EBOUNDS; goto done; }
+        int64_t w = l + k;
+        uint32_t *res = NULL;
+        if (np > 0 && w > 0) {
+            res = (uint32_t *)malloc((size_t)np * (size_t)w * 4);
+            if (!res) { rc = ORA_ENOMEM; goto done; }
+            for (int64_t i = 0; i < np; i++) {                             /* :69-75 */
+                for (int64_t j = 0; j < l; j++) res[i * w + j] = db1[(int64_t)p1[i] * m + cols1[j]];
+                for (int64_t j = 0; j < k; j++) res[i * w + l + j] = db2[(int64_t)p2[i] * t + cols2[j]];
+            }
+        }
+        *out = res; *p_out = np;
+    }
+done:
+    free(a); free(b); free(bits1); free(idxs); free(flags); free(fl); free(ones); free(f_lens);
+    free(f_l); free(p_lens); free(p1); free(p2);
+    return rc;
+}
+
+/* ================================================================== */
+/* SQL-semantics oracles for clauses NOT IN THE REFERENCE.             */
+/* PARITY UNPINNED BY THE REFERENCE: these define the build's own      */
+/* semantics for WHERE / COUNT / f32 SUM / SORT BY */
+/* ================================================================== */
+
+/* Synthetic column generator shared with the device:
+ * h = splitmix64(seed + i); k = h mod G; p = ((h>>20)&0xFFFFFF)/2^24;
+ * v exact = float((h>>44)&15); v tol = ((h>>40)&0xFFFFFF)/2^24. */
+static inline uint64_t splitmix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+void ora_gen_columns(uint64_t seed, int64_t first_row, int64_t n, uint32_t G, int exact,
+                     float *p, int32_t *k, float *v)
+{
+    for (int64_t i = 0; i < n; i++) {
+        uint64_t h = splitmix64(seed + (uint64_t)(first_row + i));
+        if (k) k[i] = (int32_t)(h % G);
+        if (p) p[i] = (float)((h >> 20) & 0xFFFFFF) * (1.0f / 16777216.0f);
+        if (v) v[i] = exact ? (float)((h >> 44) & 15) : (float)((h >> 40) & 0xFFFFFF) * (1.0f / 16777216.0f);
+    }
+}
+
+/* Comparison opcodes shared with include/hark.h (HARK_CMP_*). */
+enum { CMP_GT = 0, CMP_GE = 1, CMP_LT = 2, CMP_LE = 3, CMP_EQ = 4, CMP_NE = 5 };
+
+static inline int cmp_f32(int op, float a, float b)
+{
+    switch (op) { case CMP_GT: return a > b; case CMP_GE: return a >= b; case CMP_LT: return a < b;
+                  case CMP_LE: return a <= b; case CMP_EQ: return a == b; default: return a != b; }
+}
+static inline int cmp_i64(int op, int64_t a, int64_t b)
+{
+    switch (op) { case CMP_GT: return a > b; case CMP_GE: return a >= b; case CMP_LT: return a < b;
+                  case CMP_LE: return a <= b; case CMP_EQ: return a == b; default: return a != b; }
+}
+
+/* WHERE col <op> c: ascending row indices of qualifying rows (the
+ * order-preserving compaction Futhark's `filter` gives; select.fut:18 stub). */
+int64_t ora_filter_f32(const float *col, int64_t n, int op, float c, int64_t *idx_out)
+{
+    int64_t cnt = 0;
+    for (int64_t i = 0; i < n; i++) if (cmp_f32(op, col[i], c)) idx_out[cnt++] = i;
+    return cnt;
+}
+int64_t ora_filter_i32(const int32_t *col, int64_t n, int op, int32_t c, int64_t *idx_out)
+{
+    int64_t cnt = 0;
+    for (int64_t i = 0; i < n; i++) if (cmp_i64(op, col[i], c)) idx_out[cnt++] = i;
+    return cnt;
+}
+int64_t ora_filter_u32(const uint32_t *col, int64_t n, int op, uint32_t c, int64_t *idx_out)
+{
+    int64_t cnt = 0;
+    for (int64_t i = 0; i < n; i++) if (cmp_i64(op, (int64_t)col[i], (int64_t)c)) idx_out[cnt++] = i;
+    return cnt;
+}
+int64_t ora_filter_i64(const int64_t *col, int64_t n, int op, int64_t c, int64_t *idx_out)
+{
+    int64_t cnt = 0;
+    for (int64_t i = 0; i < n; i++) if (cmp_i64(op, col[i], c)) idx_out[cnt++] = i;
+    return cnt;
+}
+
+/* SELECT k, SUM(v), COUNT(*) FROM t WHERE p <op> thr GROUP BY k, keys dense in
+ * [0,G).  sum32 = sequential f32 left fold in table order (what a sequential
+ * C backend computes); sum64 = the same fold in double (the tolerance
+ * anchor).  Rows with a key outside [0,G) are a bounds error. */
+int ora_filter_groupby_dense_f32(const float *p, const int32_t *k, const float *v, int64_t n,
+                                 int op, float thr, int64_t G,
+                                 float *sum32, double *sum64, int64_t *count)
+{
+    for (int64_t g = 0; g < G; g++) { if (sum32) sum32[g] = 0.0f; if (sum64) sum64[g] = 0.0; count[g] = 0; }
+    for (int64_t i = 0; i < n; i++) {
+        if (p && !cmp_f32(op, p[i], thr)) continue;
+        int64_t key = k[i];
+        if (key < 0 || key >= G) return ORA_EBOUNDS;
+        if (sum32) sum32[key] += v[i];
+        if (sum64) sum64[key] += (double)v[i];
+        count[key] += 1;
+    }
+    return ORA_OK;
+}
+
+/* The same query evaluated with THE REFERENCE'S ALGORITHM (the cpu_baseline
+ * "port" leg): Futhark `filter` -> materialise [key, v-bits, 1] rows
+ * (groupby.fut:52-53) -> 32 x 1-bit stable split (groupby.fut:8-22) -> head
+ * flags (:26-33) -> sequential segmented fold (segmented.fut:7-37) with
+ * merge = (first key, f32 +, u32 +).  Output rows ascending by unsigned key:
+ * keys[g], sums[g], counts[g]; returns group count in *g_out. */
+struct fsum_ctx { int dummy; };
+static void op_merge_fsum(void *ctx, const void *va, const void *vb, void *vout)
+{
+    (void)ctx;
+    const uint32_t *a = (const uint32_t *)va, *b = (const uint32_t *)vb;
+    uint32_t *o = (uint32_t *)vout;
+    float fa, fb; memcpy(&fa, &a[1], 4); memcpy(&fb, &b[1], 4);
+    float fs = fa + fb;
+    o[0] = a[0]; memcpy(&o[1], &fs, 4); o[2] = a[2] + b[2];
+}
+
+int ora_filter_groupby_refalgo_f32(const float *p, const int32_t *k, const float *v, int64_t n,
+                                   int op, float thr,
+                                   uint32_t **keys, float **sums, uint32_t **counts, int64_t *g_out)
+{
+    *keys = NULL; *sums = NULL; *counts = NULL; *g_out = 0;
+    uint32_t *keep = (uint32_t *)malloc((size_t)(n ? n : 1) * 12);
+    if (!keep) return ORA_ENOMEM;
+    int64_t c = 0;
+    for (int64_t i = 0; i < n; i++) {                   /* filter + materialise */
+        if (p && !cmp_f32(op, p[i], thr)) continue;
+        keep[c * 3] = (uint32_t)k[i]; memcpy(&keep[c * 3 + 1], &v[i], 4); keep[c * 3 + 2] = 1u; c++;
+    }
+    if (c == 0) { free(keep); return ORA_OK; }
+    int rc = ora_rsort_rows(keep, c, 3);
+    if (rc) { free(keep); return rc; }
+    uint8_t *flag = (uint8_t *)malloc((size_t)c);
+    if (!flag) { free(keep); return ORA_ENOMEM; }
+    for (int64_t i = 0; i < c; i++) flag[i] = (i == 0) || keep[(i - 1) * 3] != keep[i * 3];
+    uint32_t ne[3] = {0, 0, 0};
+    void *res = NULL; int64_t g = 0;
+    rc = ora_segmented_reduce(op_merge_fsum, NULL, ne, 12, flag, keep, c, &res, &g);
+    free(flag); free(keep);
+    if (rc) return rc;
+    uint32_t *kk = (uint32_t *)malloc((size_t)(g ? g : 1) * 4);
+    float *ss = (float *)malloc((size_t)(g ? g : 1) * 4);
+    uint32_t *cc = (uint32_t *)malloc((size_t)(g ? g : 1) * 4);
+    if (!kk || !ss || !cc) { free(kk); free(ss); free(cc); free(res); return ORA_ENOMEM; }
+    const uint32_t *r = (const uint32_t *)res;
+    for (int64_t i = 0; i < g; i++) { kk[i] = r[i * 3]; memcpy(&ss[i], &r[i * 3 + 1], 4); cc[i] = r[i * 3 + 2]; }
+    free(res);
+    *keys = kk; *sums = ss; *counts = cc; *g_out = g;
+    return ORA_OK;
+}
+
+/* Stable ascending argsort by an unsigned 32-bit key (the order
+ * groupby.fut:21-22 produces), for SORT BY parity. */
+int ora_argsort_u32(const uint32_t *keys, int64_t n, int64_t *perm)
+{
+    uint32_t *rows = (uint32_t *)malloc((size_t)(n ? n : 1) * 8);
+    if (!rows) return ORA_ENOMEM;
+    if (n > 0xFFFFFFFFll) { free(rows); return ORA_EARG; }
+    for (int64_t i = 0; i < n; i++) { rows[i * 2] = keys[i]; rows[i * 2 + 1] = (uint32_t)i; }
+    int rc = ora_rsort_rows(rows, n, 2);
+    if (!rc) for (int64_t i = 0; i < n; i++) perm[i] = rows[i * 2 + 1];
+    free(rows);
+    return rc;
+}
