@@ -1,0 +1,99 @@
+"""ctypes binding of libhark.so (include/hark.h).
+
+This is the seam the reference fills with `futhark_ffi.Futhark(_main)`
+(FutharkContext.py:31-41).  There is NO CPU fallback: if the HIP library is
+missing or no GPU is visible the import / context creation raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhark.so")
+
+OK, EBOUNDS, ENOMEM, EARG, EHIP, EUNSUPPORTED = range(6)
+I32, U32, F32, I64 = range(4)
+NP_OF = {I32: np.int32, U32: np.uint32, F32: np.float32, I64: np.int64}
+DT_OF = {np.dtype(np.int32): I32, np.dtype(np.uint32): U32, np.dtype(np.float32): F32, np.dtype(np.int64): I64}
+CMP = {">": 0, ">=": 1, "<": 2, "<=": 3, "=": 4, "==": 4, "!=": 5, "<>": 5}
+AGG = {"key": 0, "prod": 1, "sum": 2, "max": 3, "min": 4, "count": 5, "avg": 6}
+
+
+class HarkError(Exception):
+    """Raised for every non-zero status from libhark.so (the reference raises
+    plain Exception for its own failures, parse.py:33 etc.)."""
+
+    def __init__(self, code, msg):
+        super().__init__(f"[hark {code}] {msg}")
+        self.code = code
+
+
+_vp, _i32, _i64, _u64, _u32, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_uint32, C.c_float
+_pp = C.POINTER(C.c_void_p)
+
+# name -> (restype, argtypes); every symbol include/hark.h declares.
+SIGNATURES = {
+    "hark_version": (C.c_int, []),
+    "hark_context_new": (C.c_int, [_pp, C.c_int]),
+    "hark_context_free": (None, [_vp]),
+    "hark_context_sync": (C.c_int, [_vp]),
+    "hark_context_get_error": (C.c_char_p, [_vp]),
+    "hark_context_set_stream": (C.c_int, [_vp, _vp]),
+    "hark_table_new_2d": (C.c_int, [_vp, _pp, _vp, C.c_int, _i64, _i64, _i64, _i64]),
+    "hark_table_new_columns": (C.c_int, [_vp, _pp, _i64, _i64, C.POINTER(_i32), _pp]),
+    "hark_table_from_device": (C.c_int, [_vp, _pp, _i64, _i64, C.POINTER(_i32), _pp]),
+    "hark_table_shape": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
+    "hark_table_dtype": (C.c_int, [_vp, _i64]),
+    "hark_table_column_device": (_vp, [_vp, _i64]),
+    "hark_table_free": (C.c_int, [_vp, _vp]),
+    "hark_result_shape": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
+    "hark_result_dtype": (C.c_int, [_vp, _i64]),
+    "hark_result_values_2d": (C.c_int, [_vp, _vp, _vp, C.c_int]),
+    "hark_result_column": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "hark_result_column_device": (_vp, [_vp, _i64]),
+    "hark_result_free": (C.c_int, [_vp, _vp]),
+    "hark_entry_query_sel": (C.c_int, [_vp, _pp, _vp, C.POINTER(_i32), _i64]),
+    "hark_entry_query_groupby": (C.c_int, [_vp, _pp, _vp, _i32, C.POINTER(_i32), _i64, C.POINTER(_i32), _i64]),
+    "hark_entry_join": (C.c_int, [_vp, _pp, _vp, _vp, _i32, _i32, C.POINTER(_i32), _i64, C.POINTER(_i32), _i64]),
+    "hark_entry_filter_sel": (C.c_int, [_vp, _pp, _vp, _i32, _i32, _vp, C.POINTER(_i32), _i64, _i32]),
+    "hark_entry_filter_groupby": (C.c_int, [_vp, _pp, _vp, _i32, _i32, _vp, _i32, C.POINTER(_i32), C.POINTER(_i32), _i64]),
+    "hark_entry_sort": (C.c_int, [_vp, _pp, _vp, _i32, _i32, C.POINTER(_i32), _i64]),
+    "hark_op_gen_columns": (C.c_int, [_vp, _u64, _i64, _i64, _u32, _i32, _vp, _vp, _vp]),
+    "hark_fgb_plan_new": (C.c_int, [_vp, _pp, _i64, _i64]),
+    "hark_fgb_plan_free": (C.c_int, [_vp, _vp]),
+    "hark_fgb_plan_set": (C.c_int, [_vp, C.c_char_p, _i64]),
+    "hark_op_filter_groupby_dense_f32": (C.c_int, [_vp, _vp, _vp, _i32, _f32, _vp, _vp, _i64, _vp, _vp]),
+    "hark_fgb_check": (C.c_int, [_vp, _vp]),
+    "hark_op_zero": (C.c_int, [_vp, _vp, _i64]),
+    "hark_dev_alloc": (C.c_int, [_vp, _pp, _i64]),
+    "hark_dev_free": (C.c_int, [_vp, _vp]),
+    "hark_dev_upload": (C.c_int, [_vp, _vp, _vp, _i64]),
+    "hark_dev_download": (C.c_int, [_vp, _vp, _vp, _i64]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen libhark.so and bind every declared symbol.  Raises ImportError
+    with build instructions when the library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `make -C harkdb_amd/csrc` "
+            "(or python -c 'import __graft_entry__ as g; g.build()').  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def i32_array(seq):
+    a = np.ascontiguousarray(np.asarray(seq, dtype=np.int64).astype(np.int32))
+    return a, a.ctypes.data_as(C.POINTER(_i32))

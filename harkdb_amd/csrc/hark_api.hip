@@ -1,0 +1,282 @@
+// hark_api.hip -- context / table / result objects of the C ABI (include/hark.h)
+// and the entry points that only orchestrate kernels from the k_*.hip units.
+#include "hark_internal.h"
+#include <stdarg.h>
+
+int hark_fail(hark_context *ctx, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+int hark_alloc(hark_context *ctx, void **out, size_t bytes)
+{
+    *out = nullptr;
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMalloc(out, bytes);
+    if (e != hipSuccess) {
+        *out = nullptr;
+        return hark_fail(ctx, e == hipErrorOutOfMemory ? HARK_ENOMEM : HARK_EHIP,
+                         "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+    }
+    return HARK_OK;
+}
+
+int hark_read_words(hark_context *ctx, const void *dev, int64_t *host, int count)
+{
+    if (count > 64) return hark_fail(ctx, HARK_EARG, "hark_read_words: count > 64");
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pin, dev, (size_t)count * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(host, ctx->h_pin, (size_t)count * 8);
+    return HARK_OK;
+}
+
+extern "C" {
+
+int hark_version(void) { return 100; }
+
+int hark_context_new(hark_context **out, int device)
+{
+    if (!out) return HARK_EARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return HARK_EHIP;   // no GPU: fail loudly
+    if (device < 0 || device >= ndev) return HARK_EARG;
+    if (hipSetDevice(device) != hipSuccess) return HARK_EHIP;
+    hark_context *ctx = new hark_context();
+    ctx->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+        ctx->num_cu = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return HARK_EHIP; }
+    ctx->stream = ctx->own_stream;
+    if (hipMalloc((void **)&ctx->d_err, 64) != hipSuccess ||
+        hipHostMalloc((void **)&ctx->h_pin, 64 * 8) != hipSuccess) {
+        hark_context_free(ctx);
+        return HARK_EHIP;
+    }
+    hipMemset(ctx->d_err, 0, 64);
+    *out = ctx;
+    return HARK_OK;
+}
+
+void hark_context_free(hark_context *ctx)
+{
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    if (ctx->d_err) hipFree(ctx->d_err);
+    if (ctx->h_pin) hipHostFree(ctx->h_pin);
+    if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+int hark_context_sync(hark_context *ctx)
+{
+    if (!ctx) return HARK_EARG;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return HARK_OK;
+}
+
+const char *hark_context_get_error(hark_context *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int hark_context_set_stream(hark_context *ctx, void *hip_stream)
+{
+    if (!ctx) return HARK_EARG;
+    ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    return HARK_OK;
+}
+
+// ---- device memory helpers -------------------------------------------------
+int hark_dev_alloc(hark_context *ctx, void **out, int64_t bytes)
+{
+    if (!ctx || !out || bytes < 0) return HARK_EARG;
+    return hark_alloc(ctx, out, (size_t)bytes);
+}
+int hark_dev_free(hark_context *ctx, void *dev)
+{
+    if (!ctx) return HARK_EARG;
+    if (!dev) return HARK_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipFree(dev));
+    return HARK_OK;
+}
+int hark_dev_upload(hark_context *ctx, void *dev, const void *host, int64_t bytes)
+{
+    if (!ctx || bytes < 0 || (bytes && (!dev || !host))) return HARK_EARG;
+    if (!bytes) return HARK_OK;
+    HIP_TRY(ctx, hipMemcpyAsync(dev, host, (size_t)bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return HARK_OK;
+}
+int hark_dev_download(hark_context *ctx, void *host, const void *dev, int64_t bytes)
+{
+    if (!ctx || bytes < 0 || (bytes && (!dev || !host))) return HARK_EARG;
+    if (!bytes) return HARK_OK;
+    HIP_TRY(ctx, hipMemcpyAsync(host, dev, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return HARK_OK;
+}
+int hark_op_zero(hark_context *ctx, void *dev, int64_t bytes)
+{
+    if (!ctx || bytes < 0 || (bytes && !dev)) return HARK_EARG;
+    if (!bytes) return HARK_OK;
+    HIP_TRY(ctx, hipMemsetAsync(dev, 0, (size_t)bytes, ctx->stream));
+    return HARK_OK;
+}
+
+// ---- tables ------------------------------------------------------------------
+static bool dtype_ok(int d) { return d == HARK_I32 || d == HARK_U32 || d == HARK_F32 || d == HARK_I64; }
+
+static void table_release(hark_table *t)
+{
+    for (auto &c : t->cols) if (c.owned && c.data) hipFree(c.data);
+    delete t;
+}
+
+int hark_table_new_columns(hark_context *ctx, hark_table **out, int64_t n, int64_t m,
+                           const int32_t *dtypes, const void *const *host_cols)
+{
+    if (!ctx || !out) return HARK_EARG;
+    *out = nullptr;
+    if (n < 0 || m < 0 || (m && (!dtypes || !host_cols))) return hark_fail(ctx, HARK_EARG, "table_new_columns: bad shape");
+    hark_table *t = new hark_table();
+    t->n = n; t->m = m;
+    t->cols.resize((size_t)m);
+    for (int64_t j = 0; j < m; j++) {
+        if (!dtype_ok(dtypes[j]) || (n && !host_cols[j])) { table_release(t); return hark_fail(ctx, HARK_EARG, "table_new_columns: bad column %lld", (long long)j); }
+        t->cols[j].dtype = dtypes[j];
+        size_t bytes = (size_t)n * hark_dtype_size(dtypes[j]);
+        int rc = hark_alloc(ctx, &t->cols[j].data, bytes);
+        if (rc) { table_release(t); return rc; }
+        if (bytes) {
+            hipError_t e = hipMemcpyAsync(t->cols[j].data, host_cols[j], bytes, hipMemcpyHostToDevice, ctx->stream);
+            if (e != hipSuccess) { table_release(t); return hark_fail(ctx, HARK_EHIP, "upload failed: %s", hipGetErrorString(e)); }
+        }
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // host buffers may be released by the caller
+    *out = t;
+    return HARK_OK;
+}
+
+int hark_table_new_2d(hark_context *ctx, hark_table **out, const void *host, int dtype,
+                      int64_t n, int64_t m, int64_t row_stride, int64_t col_stride)
+{
+    if (!ctx || !out) return HARK_EARG;
+    *out = nullptr;
+    if (n < 0 || m < 0 || !dtype_ok(dtype) || (n && m && !host)) return hark_fail(ctx, HARK_EARG, "table_new_2d: bad argument");
+    const size_t es = hark_dtype_size(dtype);
+    std::vector<int32_t> dts((size_t)m, dtype);
+    std::vector<const void *> ptrs((size_t)m, nullptr);
+    std::vector<char> staging;
+    const char *base = static_cast<const char *>(host);
+    if (row_stride == 1 || n <= 1) {                 // F order: every column is already contiguous
+        for (int64_t j = 0; j < m; j++) ptrs[j] = base + (size_t)j * (size_t)col_stride * es;
+    } else {                                         // gather each column on the host (ingest, not the hot path)
+        staging.resize((size_t)n * (size_t)m * es);
+        for (int64_t j = 0; j < m; j++) {
+            char *dst = staging.data() + (size_t)j * (size_t)n * es;
+            const char *src = base + (size_t)j * (size_t)col_stride * es;
+            if (es == 4) for (int64_t r = 0; r < n; r++) reinterpret_cast<uint32_t *>(dst)[r] = *reinterpret_cast<const uint32_t *>(src + (size_t)r * (size_t)row_stride * es);
+            else for (int64_t r = 0; r < n; r++) reinterpret_cast<uint64_t *>(dst)[r] = *reinterpret_cast<const uint64_t *>(src + (size_t)r * (size_t)row_stride * es);
+            ptrs[j] = dst;
+        }
+    }
+    return hark_table_new_columns(ctx, out, n, m, dts.data(), ptrs.data());
+}
+
+int hark_table_from_device(hark_context *ctx, hark_table **out, int64_t n, int64_t m,
+                           const int32_t *dtypes, void *const *dev_cols)
+{
+    if (!ctx || !out) return HARK_EARG;
+    *out = nullptr;
+    if (n < 0 || m < 0 || (m && (!dtypes || !dev_cols))) return hark_fail(ctx, HARK_EARG, "table_from_device: bad shape");
+    hark_table *t = new hark_table();
+    t->n = n; t->m = m;
+    t->cols.resize((size_t)m);
+    for (int64_t j = 0; j < m; j++) {
+        if (!dtype_ok(dtypes[j]) || (n && !dev_cols[j]) || (reinterpret_cast<uintptr_t>(dev_cols[j]) & 15u)) {
+            delete t;
+            return hark_fail(ctx, HARK_EARG, "table_from_device: column %lld is null, misaligned or of unknown dtype", (long long)j);
+        }
+        t->cols[j].dtype = dtypes[j]; t->cols[j].data = dev_cols[j]; t->cols[j].owned = false;
+    }
+    *out = t;
+    return HARK_OK;
+}
+
+int hark_table_shape(const hark_table *t, int64_t *n, int64_t *m)
+{
+    if (!t) return HARK_EARG;
+    if (n) *n = t->n;
+    if (m) *m = t->m;
+    return HARK_OK;
+}
+int hark_table_dtype(const hark_table *t, int64_t col) { return (!t || col < 0 || col >= t->m) ? -1 : t->cols[col].dtype; }
+void *hark_table_column_device(const hark_table *t, int64_t col) { return (!t || col < 0 || col >= t->m) ? nullptr : t->cols[col].data; }
+
+int hark_table_free(hark_context *ctx, hark_table *t)
+{
+    if (!t) return HARK_OK;
+    if (ctx) hipStreamSynchronize(ctx->stream);
+    table_release(t);
+    return HARK_OK;
+}
+
+// ---- results -----------------------------------------------------------------
+int hark_result_shape(const hark_result *r, int64_t *n, int64_t *m)
+{
+    if (!r) return HARK_EARG;
+    if (n) *n = r->n;
+    if (m) *m = (int64_t)r->cols.size();
+    return HARK_OK;
+}
+int hark_result_dtype(const hark_result *r, int64_t col) { return (!r || col < 0 || col >= (int64_t)r->cols.size()) ? -1 : r->cols[col].dtype; }
+void *hark_result_column_device(const hark_result *r, int64_t col) { return (!r || col < 0 || col >= (int64_t)r->cols.size()) ? nullptr : r->cols[col].data; }
+
+int hark_result_column(hark_context *ctx, const hark_result *r, int64_t col, void *host_out)
+{
+    if (!ctx || !r || col < 0 || col >= (int64_t)r->cols.size()) return HARK_EARG;
+    size_t bytes = (size_t)r->n * hark_dtype_size(r->cols[col].dtype);
+    if (!bytes) return HARK_OK;
+    if (!host_out) return HARK_EARG;
+    HIP_TRY(ctx, hipMemcpyAsync(host_out, r->cols[col].data, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return HARK_OK;
+}
+
+int hark_result_free(hark_context *ctx, hark_result *r)
+{
+    if (!r) return HARK_OK;
+    if (ctx) hipStreamSynchronize(ctx->stream);
+    for (auto &c : r->cols) if (c.owned && c.data) hipFree(c.data);
+    delete r;
+    return HARK_OK;
+}
+
+// ---- raw operators -------------------------------------------------------------
+int hark_op_gen_columns(hark_context *ctx, uint64_t seed, int64_t first_row, int64_t n,
+                        uint32_t G, int32_t exact, float *p, int32_t *k, float *v)
+{
+    if (!ctx) return HARK_EARG;
+    return k_gen_columns(ctx, seed, first_row, n, G, exact, p, k, v);
+}
+
+int hark_op_filter_groupby_dense_f32(hark_context *ctx, hark_fgb_plan *plan,
+                                     const float *p, int32_t cmp, float thr,
+                                     const int32_t *k, const float *v, int64_t n,
+                                     float *sum, int64_t *count)
+{
+    if (!ctx || !plan) return HARK_EARG;
+    if (n < 0 || (n && (!k || !v || !sum || !count))) return hark_fail(ctx, HARK_EARG, "filter_groupby: null column or output");
+    if (plan->max_rows && n > plan->max_rows) return hark_fail(ctx, HARK_EARG, "filter_groupby: n exceeds the plan's max_rows");
+    if (n > 0xFFFFFFFFll) return hark_fail(ctx, HARK_EARG, "filter_groupby: at most 2^32-1 rows per call (shard larger tables)");
+    return k_fgb_dense_f32(ctx, plan, p, cmp, thr, k, v, n, sum, count);
+}
+
+} // extern "C"

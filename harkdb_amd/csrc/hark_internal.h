@@ -1,0 +1,92 @@
+// Internal declarations shared by the libhark.so translation units.
+// gfx950 (MI355X) only: wave = 64 lanes, 256 CUs in 8 XCDs, 160 KiB LDS/CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/hark.h"
+
+#define HARK_WAVE 64
+#define HARK_NUM_CU 256
+
+struct hark_context {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;   // the stream entries launch on
+    std::string err;
+    int32_t *d_err = nullptr;       // device-side sticky error word (bounds failures)
+    int32_t *h_pin = nullptr;       // pinned scratch for small D2H reads (64 x i64)
+    int num_cu = HARK_NUM_CU;
+};
+
+struct hark_column {
+    void *data = nullptr;
+    int32_t dtype = HARK_I32;
+    bool owned = true;
+};
+
+struct hark_table {
+    int64_t n = 0, m = 0;
+    std::vector<hark_column> cols;
+};
+
+struct hark_result {
+    int64_t n = 0;
+    std::vector<hark_column> cols;
+};
+
+static inline size_t hark_dtype_size(int dtype) { return dtype == HARK_I64 ? 8 : 4; }
+
+int hark_fail(hark_context *ctx, int code, const char *fmt, ...);
+
+#define HIP_TRY(ctx, call)                                                              \
+    do {                                                                                \
+        hipError_t e__ = (call);                                                        \
+        if (e__ != hipSuccess)                                                          \
+            return hark_fail((ctx), HARK_EHIP, "%s failed: %s (%s:%d)", #call,          \
+                             hipGetErrorString(e__), __FILE__, __LINE__);               \
+    } while (0)
+
+#define HARK_TRY(call)                 \
+    do {                               \
+        int rc__ = (call);             \
+        if (rc__ != HARK_OK) return rc__; \
+    } while (0)
+
+// Device allocation that records failures in the context.
+int hark_alloc(hark_context *ctx, void **out, size_t bytes);
+// Reads `count` 8-byte words from the device after draining the stream.
+int hark_read_words(hark_context *ctx, const void *dev, int64_t *host, int count);
+
+// ---- kernel launchers implemented in the k_*.hip units -------------------
+// (all stream-ordered on ctx->stream; none allocates)
+
+// k_fgb.hip
+struct hark_fgb_plan {
+    int64_t max_rows = 0, G = 0;
+    int64_t algo = 0;          // 0 auto, 1 lds, 2 atomic, 3 partition
+    int64_t chunk_rows = 0;    // partition path: rows per chunk (0 = auto)
+    int64_t grid = 0;          // 0 = auto
+    int64_t shift = 0;         // partition path: bucket = key >> shift
+    int64_t P = 0;             // number of buckets
+    int64_t cap = 0;           // pairs per bucket in the partition buffer
+    int64_t tile_rows = 0;
+    uint2 *pbuf = nullptr;     // [P][cap] (key, value-bits) pairs
+    uint32_t *cursor = nullptr;// [P]
+    uint32_t *cnt32 = nullptr; // [G] u32 partial counts (folded to i64 at the end of a call)
+    int32_t *err = nullptr;    // device sticky error word
+};
+
+int k_gen_columns(hark_context *ctx, uint64_t seed, int64_t first_row, int64_t n, uint32_t G,
+                  int exact, float *p, int32_t *k, float *v);
+int k_fgb_dense_f32(hark_context *ctx, hark_fgb_plan *plan, const float *p, int cmp, float thr,
+                    const int32_t *k, const float *v, int64_t n, float *sum, int64_t *count);
+
+// k_select.hip
+int k_gather_columns(hark_context *ctx, const hark_table *db, const int32_t *cols, int64_t k,
+                     hark_result *res);

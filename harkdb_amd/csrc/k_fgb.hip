@@ -1,0 +1,541 @@
+// k_fgb.hip -- fused WHERE -> GROUP BY (SUM f32, COUNT) over a dense key domain.
+//
+// Replaces, for the headline query of BASELINE.json
+//     SELECT k, SUM(v), COUNT(*) FROM t WHERE p <cmp> thr GROUP BY k
+// the reference pipeline  filter -> materialise (groupby.fut:52-53) -> 32 x
+// 1-bit radix split of whole rows (groupby.fut:8-22) -> head flags (:26-33)
+// -> segmented scan + tail scatter (segmented.fut:7-37).  That pipeline moves
+// every row ~32 times; here each referenced byte is read from HBM once:
+//
+//   algorithmic bytes = 12 B/row (p, k, v)  +  16 B/group (key, sum, count).
+//
+// Three device paths, chosen by the number of groups G:
+//   LDS   (G*8 B fits one workgroup's LDS): every workgroup keeps a private
+//         [G] (sum,count) table in LDS (replicated per lane for tiny G so
+//         ds_add never bank-conflicts), streams its rows with 16-byte loads,
+//         and flushes once with contiguous global atomics.
+//   PART  (large G, e.g. 2^20): scattered global atomics run ~17x below the
+//         contiguous atomic rate on gfx950 (they execute at the memory side),
+//         so rows are first routed by key range: a workgroup stages the
+//         surviving (key,value) pairs of an 8192-row tile in LDS, bucket-sorts
+//         them there (ds_add_rtn rank + scan), and writes each bucket's run
+//         to that bucket's region; a second kernel gives every bucket to one
+//         workgroup that folds it into an LDS-resident slice of the table and
+//         adds the slice to the global table with plain stores (it owns the
+//         key range).  Work is chunked so the pair buffer stays in the
+//         256 MiB Infinity Cache.
+//   ATOM  one global atomic pair per surviving row; kept as the fallback for
+//         bucket overflow (skewed keys) and as a measured baseline.
+#include "hark_internal.h"
+#include <type_traits>
+
+namespace {
+
+constexpr int kVec = 4;                 // rows per 16-byte load
+constexpr uint32_t kInvalidKey = 0xFFFFFFFFu;
+
+template <int OP>
+__device__ __forceinline__ bool cmp_f32(float a, float b)
+{
+    if constexpr (OP == HARK_CMP_GT) return a > b;
+    else if constexpr (OP == HARK_CMP_GE) return a >= b;
+    else if constexpr (OP == HARK_CMP_LT) return a < b;
+    else if constexpr (OP == HARK_CMP_LE) return a <= b;
+    else if constexpr (OP == HARK_CMP_EQ) return a == b;
+    else if constexpr (OP == HARK_CMP_NE) return a != b;
+    else return true;                   // OP == -1: no predicate
+}
+constexpr int kNoPred = -1;
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__global__ void gen_columns_kernel(uint64_t seed, int64_t first_row, int64_t n, uint32_t G, int pow2,
+                                   int exact, float *__restrict__ p, int32_t *__restrict__ k,
+                                   float *__restrict__ v)
+{
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        uint64_t h = splitmix64(seed + (uint64_t)(first_row + i));
+        if (k) k[i] = pow2 ? (int32_t)(h & (uint64_t)(G - 1)) : (int32_t)(h % (uint64_t)G);
+        if (p) p[i] = (float)((h >> 20) & 0xFFFFFF) * (1.0f / 16777216.0f);
+        if (v) v[i] = exact ? (float)((h >> 44) & 15) : (float)((h >> 40) & 0xFFFFFF) * (1.0f / 16777216.0f);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// LDS-privatised path
+// ---------------------------------------------------------------------------
+// Dynamic LDS: float s_sum[G << RL]; uint32 s_cnt[G << RL].  Replica of a key
+// for lane l is (key << RL) | (l & (R-1)); with R = 32 the bank is the lane id,
+// so a wave's ds_add is conflict-free whatever the keys are.
+template <int OP>
+__global__ __launch_bounds__(1024) void fgb_lds_kernel(
+    const float *__restrict__ p, const int32_t *__restrict__ k, const float *__restrict__ v,
+    int64_t n, float thr, int G, int RL, float *__restrict__ gsum,
+    unsigned long long *__restrict__ gcnt, int32_t *__restrict__ err)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int slots = G << RL;
+    float *s_sum = reinterpret_cast<float *>(lds_raw);
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(lds_raw) + slots;
+    for (int i = threadIdx.x; i < slots; i += blockDim.x) { s_sum[i] = 0.0f; s_cnt[i] = 0u; }
+    __syncthreads();
+
+    const uint32_t rep = threadIdx.x & ((1u << RL) - 1u);
+    const int64_t nvec = n / kVec;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const float4 *p4 = reinterpret_cast<const float4 *>(p);
+    const int4 *k4 = reinterpret_cast<const int4 *>(k);
+    const float4 *v4 = reinterpret_cast<const float4 *>(v);
+    bool bad = false;
+
+    auto row = [&](float pv, int32_t key, float val) {
+        if (cmp_f32<OP>(pv, thr)) {
+            if ((uint32_t)key < (uint32_t)G) {
+                uint32_t s = ((uint32_t)key << RL) | rep;
+                unsafeAtomicAdd(&s_sum[s], val);
+                atomicAdd(&s_cnt[s], 1u);
+            } else bad = true;
+        }
+    };
+
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // two independent 16-byte loads per column in flight per lane
+    for (; i + stride < nvec; i += 2 * stride) {
+        float4 pa = OP == kNoPred ? float4{0, 0, 0, 0} : p4[i];
+        float4 pb = OP == kNoPred ? float4{0, 0, 0, 0} : p4[i + stride];
+        int4 ka = k4[i], kb = k4[i + stride];
+        float4 va = v4[i], vb = v4[i + stride];
+        row(pa.x, ka.x, va.x); row(pa.y, ka.y, va.y); row(pa.z, ka.z, va.z); row(pa.w, ka.w, va.w);
+        row(pb.x, kb.x, vb.x); row(pb.y, kb.y, vb.y); row(pb.z, kb.z, vb.z); row(pb.w, kb.w, vb.w);
+    }
+    for (; i < nvec; i += stride) {
+        float4 pa = OP == kNoPred ? float4{0, 0, 0, 0} : p4[i];
+        int4 ka = k4[i];
+        float4 va = v4[i];
+        row(pa.x, ka.x, va.x); row(pa.y, ka.y, va.y); row(pa.z, ka.z, va.z); row(pa.w, ka.w, va.w);
+    }
+    // ragged tail (n % 4 rows) by the first lanes of block 0
+    if (blockIdx.x == 0) {
+        int64_t t = nvec * kVec + threadIdx.x;
+        if (t < n) row(OP == kNoPred ? 0.0f : p[t], k[t], v[t]);
+    }
+    if (bad) *err = HARK_EBOUNDS;
+    __syncthreads();
+
+    const int R = 1 << RL;
+    for (int g = threadIdx.x; g < G; g += blockDim.x) {
+        float s = 0.0f; uint32_t c = 0;
+        for (int r = 0; r < R; r++) { s += s_sum[(g << RL) + r]; c += s_cnt[(g << RL) + r]; }
+        if (c) {
+            unsafeAtomicAdd(&gsum[g], s);
+            atomicAdd(&gcnt[g], (unsigned long long)c);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Global-atomic path (fallback + baseline)
+// ---------------------------------------------------------------------------
+template <int OP>
+__global__ __launch_bounds__(256) void fgb_atomic_kernel(
+    const float *__restrict__ p, const int32_t *__restrict__ k, const float *__restrict__ v,
+    int64_t n, float thr, int64_t G, float *__restrict__ gsum,
+    unsigned long long *__restrict__ gcnt, int32_t *__restrict__ err)
+{
+    const int64_t nvec = n / kVec;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const float4 *p4 = reinterpret_cast<const float4 *>(p);
+    const int4 *k4 = reinterpret_cast<const int4 *>(k);
+    const float4 *v4 = reinterpret_cast<const float4 *>(v);
+    bool bad = false;
+    auto row = [&](float pv, int32_t key, float val) {
+        if (cmp_f32<OP>(pv, thr)) {
+            if ((uint64_t)(uint32_t)key < (uint64_t)G && key >= 0) {
+                unsafeAtomicAdd(&gsum[key], val);
+                atomicAdd(&gcnt[key], 1ull);
+            } else bad = true;
+        }
+    };
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+        float4 pa = OP == kNoPred ? float4{0, 0, 0, 0} : p4[i];
+        int4 ka = k4[i];
+        float4 va = v4[i];
+        row(pa.x, ka.x, va.x); row(pa.y, ka.y, va.y); row(pa.z, ka.z, va.z); row(pa.w, ka.w, va.w);
+    }
+    if (blockIdx.x == 0) {
+        int64_t t = nvec * kVec + threadIdx.x;
+        if (t < n) row(OP == kNoPred ? 0.0f : p[t], k[t], v[t]);
+    }
+    if (bad) *err = HARK_EBOUNDS;
+}
+
+// ---------------------------------------------------------------------------
+// Partition path, kernel 1: route surviving (key,value) pairs by key range
+// ---------------------------------------------------------------------------
+constexpr int kPartThreads = 512;
+constexpr int kRowsPerThread = 16;                       // 4 x 16-byte loads per column
+constexpr int kTileRows = kPartThreads * kRowsPerThread; // 8192 rows -> 64 KiB of staged pairs
+constexpr int kMaxBuckets = 1024;
+
+// LDS: uint2 stage[kTileRows]; int cnt[P]; int off[P]; int delta[P]; int fit[P]; int wsum[8]
+template <int OP>
+__global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
+    const float *__restrict__ p, const int32_t *__restrict__ k, const float *__restrict__ v,
+    int64_t row0, int64_t row1, float thr, int64_t G, int shift, int P,
+    uint2 *__restrict__ pbuf, uint32_t *__restrict__ cursor, uint32_t cap,
+    float *__restrict__ gsum, unsigned long long *__restrict__ gcnt, int32_t *__restrict__ err)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    uint2 *stage = reinterpret_cast<uint2 *>(lds_raw);
+    int *s_cnt = reinterpret_cast<int *>(lds_raw + sizeof(uint2) * kTileRows);
+    int *s_off = s_cnt + P;
+    int *s_delta = s_off + P;
+    int *s_fit = s_delta + P;
+    int *s_wsum = s_fit + P;                              // per-wave scan carries
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int64_t ntiles = (row1 - row0 + kTileRows - 1) / kTileRows;
+    bool bad = false;
+
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        for (int b = tid; b < P; b += kPartThreads) s_cnt[b] = 0;
+        __syncthreads();
+
+        // rows of this thread: 4 groups of 4 consecutive rows, group g at
+        // tile_base + (g*512 + tid)*4 -> each wave-instruction reads 1 KiB.
+        const int64_t tbase = row0 + tile * kTileRows;
+        uint32_t keys[kRowsPerThread];
+        float vals[kRowsPerThread];
+        int rank[kRowsPerThread];
+        float4 pr[4]; int4 kr[4]; float4 vr[4];
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            int64_t r = tbase + ((int64_t)g * kPartThreads + tid) * kVec;
+            if (r + kVec <= row1) {
+                pr[g] = OP == kNoPred ? float4{0, 0, 0, 0} : *reinterpret_cast<const float4 *>(p + r);
+                kr[g] = *reinterpret_cast<const int4 *>(k + r);
+                vr[g] = *reinterpret_cast<const float4 *>(v + r);
+            } else {                                   // ragged end of the table: scalar loads
+                float pp[4] = {0, 0, 0, 0}; int kk[4] = {0, 0, 0, 0}; float vv[4] = {0, 0, 0, 0};
+                for (int j = 0; j < kVec; j++) if (r + j < row1) {
+                    pp[j] = OP == kNoPred ? 0.0f : p[r + j]; kk[j] = k[r + j]; vv[j] = v[r + j];
+                }
+                pr[g] = float4{pp[0], pp[1], pp[2], pp[3]};
+                kr[g] = int4{kk[0], kk[1], kk[2], kk[3]};
+                vr[g] = float4{vv[0], vv[1], vv[2], vv[3]};
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const float pv[4] = {pr[g].x, pr[g].y, pr[g].z, pr[g].w};
+            const int kv[4] = {kr[g].x, kr[g].y, kr[g].z, kr[g].w};
+            const float vv[4] = {vr[g].x, vr[g].y, vr[g].z, vr[g].w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int q = g * 4 + j;
+                const int64_t r = tbase + ((int64_t)g * kPartThreads + tid) * kVec + j;
+                bool keep = r < row1 && cmp_f32<OP>(pv[j], thr);
+                uint32_t key = (uint32_t)kv[j];
+                if (keep && !(kv[j] >= 0 && (int64_t)key < G)) { bad = true; keep = false; }
+                keys[q] = key; vals[q] = vv[j];
+                rank[q] = keep ? atomicAdd(&s_cnt[key >> shift], 1) : -1;   // ds_add_rtn_u32
+            }
+        }
+        __syncthreads();
+
+        // exclusive scan of s_cnt[0..P) (P <= 1024: two buckets per thread)
+        {
+            int b0 = tid * 2, b1 = tid * 2 + 1;
+            int c0 = b0 < P ? s_cnt[b0] : 0, c1 = b1 < P ? s_cnt[b1] : 0;
+            int x = c0 + c1, incl = x;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { int y = __shfl_up(incl, d, 64); if (lane >= d) incl += y; }
+            if (lane == 63) s_wsum[wave] = incl;
+            __syncthreads();
+            int carry = 0;
+            for (int w = 0; w < wave; w++) carry += s_wsum[w];
+            int excl = carry + incl - x;
+            if (b0 < P) {
+                s_off[b0] = excl;
+                int fit = 0, delta = 0;
+                if (c0 > 0) {
+                    uint32_t g0 = atomicAdd(&cursor[b0], (uint32_t)c0);
+                    fit = g0 >= cap ? 0 : (int)min((uint32_t)c0, cap - g0);
+                    delta = (int)g0 - excl;
+                }
+                s_fit[b0] = fit; s_delta[b0] = delta;
+            }
+            if (b1 < P) {
+                s_off[b1] = excl + c0;
+                int fit = 0, delta = 0;
+                if (c1 > 0) {
+                    uint32_t g1 = atomicAdd(&cursor[b1], (uint32_t)c1);
+                    fit = g1 >= cap ? 0 : (int)min((uint32_t)c1, cap - g1);
+                    delta = (int)g1 - (excl + c0);
+                }
+                s_fit[b1] = fit; s_delta[b1] = delta;
+            }
+        }
+        __syncthreads();
+        int total = 0;
+        for (int w = 0; w < kPartThreads / 64; w++) total += s_wsum[w];
+
+#pragma unroll
+        for (int q = 0; q < kRowsPerThread; q++) {
+            if (rank[q] >= 0) {
+                const uint32_t b = keys[q] >> shift;
+                const int slot = s_off[b] + rank[q];
+                if (rank[q] < s_fit[b]) {
+                    stage[slot] = uint2{keys[q], __float_as_uint(vals[q])};
+                } else {                      // bucket region full (skewed keys): direct atomics
+                    stage[slot] = uint2{kInvalidKey, 0u};
+                    unsafeAtomicAdd(&gsum[keys[q]], vals[q]);
+                    atomicAdd(&gcnt[keys[q]], 1ull);
+                }
+            }
+        }
+        __syncthreads();
+        for (int slot = tid; slot < total; slot += kPartThreads) {
+            uint2 pr2 = stage[slot];
+            if (pr2.x != kInvalidKey) {
+                const uint32_t b = pr2.x >> shift;
+                pbuf[(size_t)b * cap + (uint32_t)(s_delta[b] + slot)] = pr2;
+            }
+        }
+        __syncthreads();
+    }
+    if (bad) *err = HARK_EBOUNDS;
+}
+
+// ---------------------------------------------------------------------------
+// Partition path, kernel 2: one workgroup folds one bucket into its table slice
+// ---------------------------------------------------------------------------
+// LDS: float s_sum[KPB]; uint32 s_cnt[KPB], KPB = 1 << shift keys per bucket.
+__global__ __launch_bounds__(1024) void fgb_agg_kernel(
+    const uint2 *__restrict__ pbuf, uint32_t *__restrict__ cursor, uint32_t cap, int shift,
+    int64_t G, float *__restrict__ gsum, unsigned long long *__restrict__ gcnt)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int KPB = 1 << shift;
+    float *s_sum = reinterpret_cast<float *>(lds_raw);
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(lds_raw) + KPB;
+    const int b = blockIdx.x;
+    const uint32_t count = min(cursor[b], cap);
+    if (count == 0) return;                                 // uniform across the workgroup
+    for (int i = threadIdx.x; i < KPB; i += blockDim.x) { s_sum[i] = 0.0f; s_cnt[i] = 0u; }
+    __syncthreads();
+    const uint2 *src = pbuf + (size_t)b * cap;              // cap is even -> 16-byte aligned
+    const uint4 *src4 = reinterpret_cast<const uint4 *>(src);
+    const uint32_t mask = (uint32_t)KPB - 1u;
+    const uint32_t npair2 = count / 2;
+    for (uint32_t i = threadIdx.x; i < npair2; i += blockDim.x) {
+        uint4 q = src4[i];
+        unsafeAtomicAdd(&s_sum[q.x & mask], __uint_as_float(q.y)); atomicAdd(&s_cnt[q.x & mask], 1u);
+        unsafeAtomicAdd(&s_sum[q.z & mask], __uint_as_float(q.w)); atomicAdd(&s_cnt[q.z & mask], 1u);
+    }
+    if ((count & 1u) && threadIdx.x == 0) {
+        uint2 q = src[count - 1];
+        unsafeAtomicAdd(&s_sum[q.x & mask], __uint_as_float(q.y)); atomicAdd(&s_cnt[q.x & mask], 1u);
+    }
+    __syncthreads();
+    const int64_t kbase = (int64_t)b << shift;
+    for (int i = threadIdx.x; i < KPB; i += blockDim.x) {
+        uint32_t c = s_cnt[i];
+        if (c && kbase + i < G) {                           // this workgroup owns [kbase, kbase+KPB)
+            gsum[kbase + i] += s_sum[i];
+            gcnt[kbase + i] += (unsigned long long)c;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) cursor[b] = 0;                    // ready for the next chunk
+}
+
+template <typename F>
+int dispatch_op(int cmp, bool has_pred, F &&f)
+{
+    if (!has_pred) return f(std::integral_constant<int, kNoPred>{});
+    switch (cmp) {
+    case HARK_CMP_GT: return f(std::integral_constant<int, HARK_CMP_GT>{});
+    case HARK_CMP_GE: return f(std::integral_constant<int, HARK_CMP_GE>{});
+    case HARK_CMP_LT: return f(std::integral_constant<int, HARK_CMP_LT>{});
+    case HARK_CMP_LE: return f(std::integral_constant<int, HARK_CMP_LE>{});
+    case HARK_CMP_EQ: return f(std::integral_constant<int, HARK_CMP_EQ>{});
+    case HARK_CMP_NE: return f(std::integral_constant<int, HARK_CMP_NE>{});
+    default: return HARK_EARG;
+    }
+}
+
+constexpr int64_t kLdsBudget = 64 * 1024;   // per-workgroup table budget (2 workgroups/CU)
+
+} // namespace
+
+int k_gen_columns(hark_context *ctx, uint64_t seed, int64_t first_row, int64_t n, uint32_t G,
+                  int exact, float *p, int32_t *k, float *v)
+{
+    if (n < 0 || G == 0) return hark_fail(ctx, HARK_EARG, "gen_columns: n < 0 or G == 0");
+    if (n == 0) return HARK_OK;
+    int pow2 = (G & (G - 1)) == 0;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > ctx->num_cu * 16) blocks = ctx->num_cu * 16;
+    gen_columns_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(seed, first_row, n, G, pow2, exact, p, k, v);
+    HIP_TRY(ctx, hipGetLastError());
+    return HARK_OK;
+}
+
+int hark_fgb_plan_new(hark_context *ctx, hark_fgb_plan **out, int64_t max_rows, int64_t G)
+{
+    if (!ctx || !out) return HARK_EARG;
+    *out = nullptr;
+    if (max_rows < 0 || G <= 0 || G > (int64_t)1 << 31)
+        return hark_fail(ctx, HARK_EARG, "fgb_plan_new: need max_rows >= 0 and 0 < G <= 2^31 (got %lld, %lld)",
+                         (long long)max_rows, (long long)G);
+    hark_fgb_plan *pl = new hark_fgb_plan();
+    pl->max_rows = max_rows; pl->G = G;
+    pl->tile_rows = kTileRows;
+    int rc = hark_alloc(ctx, (void **)&pl->err, sizeof(int32_t));
+    if (rc) { delete pl; return rc; }
+    hipMemsetAsync(pl->err, 0, sizeof(int32_t), ctx->stream);
+    *out = pl;
+    return HARK_OK;
+}
+
+int hark_fgb_plan_free(hark_context *ctx, hark_fgb_plan *pl)
+{
+    if (!pl) return HARK_OK;
+    if (ctx) hipStreamSynchronize(ctx->stream);
+    if (pl->pbuf) hipFree(pl->pbuf);
+    if (pl->cursor) hipFree(pl->cursor);
+    if (pl->err) hipFree(pl->err);
+    delete pl;
+    return HARK_OK;
+}
+
+int hark_fgb_plan_set(hark_fgb_plan *pl, const char *key, int64_t value)
+{
+    if (!pl || !key) return HARK_EARG;
+    if (!strcmp(key, "algo")) { if (value < 0 || value > 3) return HARK_EARG; pl->algo = value; }
+    else if (!strcmp(key, "chunk_rows")) { if (value < 0) return HARK_EARG; pl->chunk_rows = value; }
+    else if (!strcmp(key, "grid")) { if (value < 0) return HARK_EARG; pl->grid = value; }
+    else if (!strcmp(key, "shift")) { if (value < 0 || value > 13) return HARK_EARG; pl->shift = value; }
+    else return HARK_EARG;
+    // partition geometry depends on the knobs: drop buffers so they are re-sized
+    if (pl->pbuf) { hipFree(pl->pbuf); pl->pbuf = nullptr; }
+    if (pl->cursor) { hipFree(pl->cursor); pl->cursor = nullptr; }
+    return HARK_OK;
+}
+
+static int plan_prepare_partition(hark_context *ctx, hark_fgb_plan *pl)
+{
+    if (pl->pbuf) return HARK_OK;
+    // bucket = key >> shift; KPB = 1 << shift keys per bucket, 8 B of LDS each.
+    int shift = pl->shift ? (int)pl->shift : 12;
+    while ((((pl->G - 1) >> shift) + 1) > kMaxBuckets) shift++;
+    if (((int64_t)8 << shift) > kLdsBudget)
+        return hark_fail(ctx, HARK_EUNSUPPORTED, "fgb: G = %lld needs more than %d buckets of <= %lld keys",
+                         (long long)pl->G, kMaxBuckets, (long long)(kLdsBudget / 8));
+    pl->shift = shift;
+    pl->P = ((pl->G - 1) >> shift) + 1;
+    int64_t chunk = pl->chunk_rows ? pl->chunk_rows : (int64_t)16 << 20;
+    chunk = (chunk + kTileRows - 1) / kTileRows * kTileRows;
+    if (chunk > pl->max_rows && pl->max_rows > 0) chunk = (pl->max_rows + kTileRows - 1) / kTileRows * kTileRows;
+    pl->chunk_rows = chunk;
+    // room for 1.5x the uniform share of a chunk with every row surviving, + one tile
+    int64_t cap = chunk / pl->P * 3 / 2 + kTileRows;
+    cap = (cap + 1) & ~(int64_t)1;
+    if (cap > 0xFFFFFFF0ll) return hark_fail(ctx, HARK_EARG, "fgb: chunk too large");
+    pl->cap = cap;
+    HARK_TRY(hark_alloc(ctx, (void **)&pl->pbuf, (size_t)pl->P * (size_t)cap * sizeof(uint2)));
+    HARK_TRY(hark_alloc(ctx, (void **)&pl->cursor, (size_t)pl->P * sizeof(uint32_t)));
+    HIP_TRY(ctx, hipMemsetAsync(pl->cursor, 0, (size_t)pl->P * sizeof(uint32_t), ctx->stream));
+    return HARK_OK;
+}
+
+int k_fgb_dense_f32(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cmp, float thr,
+                    const int32_t *k, const float *v, int64_t n, float *sum, int64_t *count)
+{
+    if (n == 0) return HARK_OK;
+    const int64_t G = pl->G;
+    auto misaligned = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) != 0; };
+    if ((p && misaligned(p)) || misaligned(k) || misaligned(v))
+        return hark_fail(ctx, HARK_EARG, "fgb: columns must be 16-byte aligned");
+    unsigned long long *gcnt = reinterpret_cast<unsigned long long *>(count);
+    int algo = (int)pl->algo;
+    if (algo == 0) algo = (G * 8 <= kLdsBudget) ? 1 : 3;
+    if (algo == 1 && G * 8 > 160 * 1024 - 1024)
+        return hark_fail(ctx, HARK_EUNSUPPORTED, "fgb: LDS path needs G*8 <= 159 KiB");
+    hipStream_t st = ctx->stream;
+
+    if (algo == 1) {
+        // replicate the table per lane while it stays under 16 KiB (tiny G)
+        int RL = 0;
+        while (RL < 5 && (G << (RL + 1)) * 8 <= 16 * 1024) RL++;
+        size_t lds = (size_t)(G << RL) * 8;
+        int wg_per_cu = lds <= 40 * 1024 ? 2 : 1;
+        int64_t grid = pl->grid ? pl->grid : (int64_t)ctx->num_cu * wg_per_cu;
+        int64_t need = (n / kVec + 1023) / 1024;
+        if (grid > need) grid = need > 0 ? need : 1;
+        return dispatch_op(cmp, p != nullptr, [&](auto op) -> int {
+            constexpr int OP = decltype(op)::value;
+            if (lds > 64 * 1024)
+                HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_lds_kernel<OP>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            fgb_lds_kernel<OP><<<dim3((unsigned)grid), dim3(1024), lds, st>>>(p, k, v, n, thr, (int)G, RL, sum, gcnt, pl->err);
+            HIP_TRY(ctx, hipGetLastError());
+            return HARK_OK;
+        });
+    }
+    if (algo == 2) {
+        int64_t grid = pl->grid ? pl->grid : (int64_t)ctx->num_cu * 8;
+        int64_t need = (n / kVec + 255) / 256;
+        if (grid > need) grid = need > 0 ? need : 1;
+        return dispatch_op(cmp, p != nullptr, [&](auto op) -> int {
+            constexpr int OP = decltype(op)::value;
+            fgb_atomic_kernel<OP><<<dim3((unsigned)grid), dim3(256), 0, st>>>(p, k, v, n, thr, G, sum, gcnt, pl->err);
+            HIP_TRY(ctx, hipGetLastError());
+            return HARK_OK;
+        });
+    }
+    // algo 3: partition + per-bucket LDS aggregation, chunked
+    HARK_TRY(plan_prepare_partition(ctx, pl));
+    const int P = (int)pl->P, shift = (int)pl->shift;
+    const size_t lds_part = sizeof(uint2) * kTileRows + sizeof(int) * (4 * (size_t)P + 8);
+    const size_t lds_agg = (size_t)8 << shift;
+    return dispatch_op(cmp, p != nullptr, [&](auto op) -> int {
+        constexpr int OP = decltype(op)::value;
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_part_kernel<OP>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part));
+        for (int64_t r0 = 0; r0 < n; r0 += pl->chunk_rows) {
+            int64_t r1 = r0 + pl->chunk_rows < n ? r0 + pl->chunk_rows : n;
+            int64_t ntiles = (r1 - r0 + kTileRows - 1) / kTileRows;
+            int64_t grid = pl->grid ? pl->grid : (int64_t)ctx->num_cu * 2;
+            if (grid > ntiles) grid = ntiles;
+            fgb_part_kernel<OP><<<dim3((unsigned)grid), dim3(kPartThreads), lds_part, st>>>(
+                p, k, v, r0, r1, thr, G, shift, P, pl->pbuf, pl->cursor, (uint32_t)pl->cap, sum, gcnt, pl->err);
+            HIP_TRY(ctx, hipGetLastError());
+            fgb_agg_kernel<<<dim3((unsigned)P), dim3(1024), lds_agg, st>>>(
+                pl->pbuf, pl->cursor, (uint32_t)pl->cap, shift, G, sum, gcnt);
+            HIP_TRY(ctx, hipGetLastError());
+        }
+        return HARK_OK;
+    });
+}
+
+int hark_fgb_check(hark_context *ctx, hark_fgb_plan *pl)
+{
+    if (!ctx || !pl) return HARK_EARG;
+    int32_t e = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&e, pl->err, sizeof e, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (e != 0) {
+        HIP_TRY(ctx, hipMemsetAsync(pl->err, 0, sizeof(int32_t), ctx->stream));
+        return hark_fail(ctx, e, "filter_groupby: a surviving row has a key outside [0, %lld)", (long long)pl->G);
+    }
+    return HARK_OK;
+}

@@ -1,0 +1,387 @@
+// k_select.hip -- projection and WHERE compaction.
+//
+//   hark_entry_query_sel   replaces futhark/select.fut:9-23 (`map (sel cols) db`):
+//       the reference gathers k of m words out of every row-major row; with
+//       one HBM buffer per column the projection is k coalesced column copies
+//       (4 B read + 4 B written per selected cell, nothing else touched).
+//   hark_entry_filter_sel  is the WHERE the reference only sketches
+//       (select.fut:18 `-- let rows_to_keep = filter f db`): order-preserving
+//       stream compaction = per-lane predicate -> wave64 ballot + popcount
+//       prefix -> workgroup scan -> global offsets from a scan of per-tile
+//       counts.  Indices come out ascending, bit-exact with a sequential
+//       filter.
+#include "hark_internal.h"
+
+namespace {
+
+constexpr int kMaxCols = 32;            // columns handled per launch
+constexpr int kTile = 4096;             // rows per workgroup tile (256 threads x 16 rows)
+constexpr int kThreads = 256;
+
+struct ColSet {
+    const void *src[kMaxCols];
+    void *dst[kMaxCols];
+    int32_t esz[kMaxCols];              // 4 or 8
+    int32_t ncols;
+};
+
+// ---- projection: coalesced per-column copy ---------------------------------
+__global__ __launch_bounds__(256) void copy_columns_kernel(ColSet cs, int64_t n)
+{
+    const int col = blockIdx.y;
+    const int64_t bytes = n * cs.esz[col];
+    const int64_t nvec = bytes / 16;
+    const uint4 *s4 = static_cast<const uint4 *>(cs.src[col]);
+    uint4 *d4 = static_cast<uint4 *>(cs.dst[col]);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + stride < nvec; i += 2 * stride) {      // two 16-byte loads in flight per lane
+        uint4 a = s4[i], b = s4[i + stride];
+        d4[i] = a; d4[i + stride] = b;
+    }
+    for (; i < nvec; i += stride) d4[i] = s4[i];
+    if (blockIdx.x == 0) {                            // tail bytes (n*esz not a multiple of 16)
+        const uint32_t *s1 = static_cast<const uint32_t *>(cs.src[col]);
+        uint32_t *d1 = static_cast<uint32_t *>(cs.dst[col]);
+        for (int64_t w = nvec * 4 + threadIdx.x; w < bytes / 4; w += blockDim.x) d1[w] = s1[w];
+    }
+}
+
+// ---- predicate ----------------------------------------------------------------
+union Const64 { int64_t i; float f; uint32_t u; };
+
+template <typename T>
+__device__ __forceinline__ bool cmp_val(int op, T a, T b)
+{
+    switch (op) {
+    case HARK_CMP_GT: return a > b;
+    case HARK_CMP_GE: return a >= b;
+    case HARK_CMP_LT: return a < b;
+    case HARK_CMP_LE: return a <= b;
+    case HARK_CMP_EQ: return a == b;
+    default: return a != b;
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ T const_as(Const64 c);
+template <> __device__ __forceinline__ float const_as<float>(Const64 c) { return c.f; }
+template <> __device__ __forceinline__ int32_t const_as<int32_t>(Const64 c) { return (int32_t)c.i; }
+template <> __device__ __forceinline__ uint32_t const_as<uint32_t>(Const64 c) { return c.u; }
+template <> __device__ __forceinline__ int64_t const_as<int64_t>(Const64 c) { return c.i; }
+
+// 16 rows per thread as 4 groups of 4 consecutive rows; group g of thread t
+// covers rows tile*kTile + (g*256 + t)*4 .. +3, so a wave reads 1 KiB per load.
+// Returns the 16-bit survivor mask in THREAD-LOCAL order (bit g*4+j).
+template <typename T>
+__device__ __forceinline__ uint32_t eval_tile(const T *__restrict__ col, int64_t n, int64_t tile, int op, T c)
+{
+    uint32_t mask = 0;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const int64_t r = tile * kTile + ((int64_t)g * kThreads + threadIdx.x) * 4;
+        if (r + 4 <= n) {
+            T x[4];
+            if constexpr (sizeof(T) == 4) {
+                uint4 q = *reinterpret_cast<const uint4 *>(col + r);
+                memcpy(x, &q, 16);
+            } else {
+                uint4 q0 = *reinterpret_cast<const uint4 *>(col + r), q1 = *reinterpret_cast<const uint4 *>(col + r + 2);
+                memcpy(x, &q0, 16); memcpy(x + 2, &q1, 16);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) mask |= (uint32_t)cmp_val<T>(op, x[j], c) << (g * 4 + j);
+        } else {
+            for (int j = 0; j < 4; j++) if (r + j < n) mask |= (uint32_t)cmp_val<T>(op, col[r + j], c) << (g * 4 + j);
+        }
+    }
+    return mask;
+}
+
+// Pass 1: survivors per (tile, group) -- 4 counts per tile, because the rows of
+// group g precede the rows of group g+1 in table order.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void filter_count_kernel(const T *__restrict__ col, int64_t n, int op, Const64 c,
+                                                                uint32_t *__restrict__ counts)
+{
+    __shared__ uint32_t s_cnt[4];
+    if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t tile = blockIdx.x;
+    const uint32_t mask = eval_tile<T>(col, n, tile, op, const_as<T>(c));
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        uint32_t cnt = __popc((mask >> (g * 4)) & 15u);
+        for (int d = 32; d > 0; d >>= 1) cnt += __shfl_down(cnt, d, 64);
+        if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&s_cnt[g], cnt);
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) counts[tile * 4 + threadIdx.x] = s_cnt[threadIdx.x];
+}
+
+// Pass 2: exclusive scan of the per-(tile,group) counts, single workgroup.
+__global__ __launch_bounds__(1024) void scan_counts_kernel(const uint32_t *__restrict__ counts, int64_t m,
+                                                           int64_t *__restrict__ offsets, int64_t *__restrict__ total)
+{
+    __shared__ int64_t s_wave[16];
+    __shared__ int64_t s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t base = 0; base < m; base += 1024) {
+        int64_t i = base + threadIdx.x;
+        int64_t x = i < m ? (int64_t)counts[i] : 0, incl = x;
+        for (int d = 1; d < 64; d <<= 1) { int64_t y = __shfl_up(incl, d, 64); if (lane >= d) incl += y; }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        int64_t carry = s_carry;
+        for (int w = 0; w < wave; w++) carry += s_wave[w];
+        if (i < m) offsets[i] = carry + incl - x;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = carry + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = s_carry;
+}
+
+// Pass 3: re-evaluate, rank inside the (tile,group) with ballot + popcount,
+// write row indices and the projected columns at the compacted position.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void filter_scatter_kernel(const T *__restrict__ col, int64_t n, int op, Const64 c,
+                                                                  const int64_t *__restrict__ offsets,
+                                                                  int64_t *__restrict__ row_index, ColSet cs)
+{
+    __shared__ uint32_t s_wcnt[4][4];                 // [group][wave]
+    const int64_t tile = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t mask = eval_tile<T>(col, n, tile, op, const_as<T>(c));
+    uint32_t lane_excl[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const uint32_t cnt = __popc((mask >> (g * 4)) & 15u);
+        uint32_t incl = cnt;
+        for (int d = 1; d < 64; d <<= 1) { uint32_t y = __shfl_up(incl, d, 64); if (lane >= d) incl += y; }
+        lane_excl[g] = incl - cnt;
+        if (lane == 63) s_wcnt[g][wave] = incl;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const uint32_t m4 = (mask >> (g * 4)) & 15u;
+        if (!m4) continue;
+        int64_t pos = offsets[tile * 4 + g] + lane_excl[g];
+        for (int w = 0; w < wave; w++) pos += s_wcnt[g][w];
+        const int64_t r = tile * kTile + ((int64_t)g * kThreads + threadIdx.x) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (m4 & (1u << j)) {
+                if (row_index) row_index[pos] = r + j;
+                for (int cidx = 0; cidx < cs.ncols; cidx++) {
+                    if (cs.esz[cidx] == 4) static_cast<uint32_t *>(cs.dst[cidx])[pos] = static_cast<const uint32_t *>(cs.src[cidx])[r + j];
+                    else static_cast<uint64_t *>(cs.dst[cidx])[pos] = static_cast<const uint64_t *>(cs.src[cidx])[r + j];
+                }
+                pos++;
+            }
+        }
+    }
+}
+
+// ---- row-major copy-out (futhark_values_*_2d) -----------------------------------
+// out[r*m + j] = column j, converted to 4-byte or 8-byte integers.
+__global__ __launch_bounds__(256) void interleave_kernel(ColSet cs, int64_t n, int out_esz, int sign_extend_mask, void *__restrict__ out)
+{
+    const int m = cs.ncols;
+    const int64_t total = n * m;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t r = i / m; const int j = (int)(i - r * m);
+        if (out_esz == 4) {
+            uint32_t x = cs.esz[j] == 4 ? static_cast<const uint32_t *>(cs.src[j])[r] : (uint32_t)static_cast<const uint64_t *>(cs.src[j])[r];
+            static_cast<uint32_t *>(out)[i] = x;
+        } else {
+            uint64_t x;
+            if (cs.esz[j] == 8) x = static_cast<const uint64_t *>(cs.src[j])[r];
+            else {
+                uint32_t w = static_cast<const uint32_t *>(cs.src[j])[r];
+                x = (sign_extend_mask >> j) & 1 ? (uint64_t)(int64_t)(int32_t)w : (uint64_t)w;
+            }
+            static_cast<uint64_t *>(out)[i] = x;
+        }
+    }
+}
+
+void result_release(hark_result *r)
+{
+    for (auto &c : r->cols) if (c.owned && c.data) hipFree(c.data);
+    delete r;
+}
+
+int check_cols(hark_context *ctx, const hark_table *db, const int32_t *cols, int64_t k, const char *who)
+{
+    if (k < 0 || (k && !cols)) return hark_fail(ctx, HARK_EARG, "%s: bad column list", who);
+    for (int64_t j = 0; j < k; j++)
+        if (cols[j] < 0 || cols[j] >= db->m)
+            return hark_fail(ctx, HARK_EBOUNDS, "%s: index %d out of bounds for a table with %lld columns", who, cols[j], (long long)db->m);
+    return HARK_OK;
+}
+
+} // namespace
+
+int k_gather_columns(hark_context *ctx, const hark_table *db, const int32_t *cols, int64_t k, hark_result *res)
+{
+    res->n = db->n;
+    res->cols.resize((size_t)k);
+    for (int64_t j = 0; j < k; j++) {
+        res->cols[j].dtype = db->cols[cols[j]].dtype;
+        HARK_TRY(hark_alloc(ctx, &res->cols[j].data, (size_t)db->n * hark_dtype_size(res->cols[j].dtype)));
+    }
+    if (db->n == 0) return HARK_OK;
+    for (int64_t j0 = 0; j0 < k; j0 += kMaxCols) {
+        ColSet cs{};
+        cs.ncols = (int)((k - j0 < kMaxCols) ? k - j0 : kMaxCols);
+        for (int c = 0; c < cs.ncols; c++) {
+            cs.src[c] = db->cols[cols[j0 + c]].data;
+            cs.dst[c] = res->cols[j0 + c].data;
+            cs.esz[c] = (int32_t)hark_dtype_size(res->cols[j0 + c].dtype);
+        }
+        int64_t blocks = (db->n * 8 / 16 + 255) / 256 / 2 + 1;
+        int64_t cap = (int64_t)ctx->num_cu * 8 / cs.ncols + 1;
+        if (blocks > cap) blocks = cap;
+        copy_columns_kernel<<<dim3((unsigned)blocks, (unsigned)cs.ncols), dim3(256), 0, ctx->stream>>>(cs, db->n);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    return HARK_OK;
+}
+
+extern "C" {
+
+int hark_entry_query_sel(hark_context *ctx, hark_result **out, const hark_table *db, const int32_t *cols, int64_t k)
+{
+    if (!ctx || !out || !db) return HARK_EARG;
+    *out = nullptr;
+    // select.fut:10 `row[i]` is bounds-checked per row: with zero rows nothing is evaluated.
+    if (db->n > 0) HARK_TRY(check_cols(ctx, db, cols, k, "query_sel"));
+    hark_result *res = new hark_result();
+    if (db->n == 0) {
+        res->n = 0; res->cols.resize((size_t)k);
+        for (int64_t j = 0; j < k; j++) { res->cols[j].dtype = HARK_I32; res->cols[j].data = nullptr; res->cols[j].owned = false; }
+        *out = res; return HARK_OK;
+    }
+    int rc = k_gather_columns(ctx, db, cols, k, res);
+    if (rc) { result_release(res); return rc; }
+    *out = res;
+    return HARK_OK;
+}
+
+int hark_entry_filter_sel(hark_context *ctx, hark_result **out, const hark_table *db, int32_t where_col, int32_t cmp,
+                          const void *constant, const int32_t *cols, int64_t k, int32_t want_row_index)
+{
+    if (!ctx || !out || !db || !constant) return HARK_EARG;
+    *out = nullptr;
+    HARK_TRY(check_cols(ctx, db, cols, k, "filter_sel"));
+    HARK_TRY(check_cols(ctx, db, &where_col, 1, "filter_sel(where)"));
+    if (cmp < HARK_CMP_GT || cmp > HARK_CMP_NE) return hark_fail(ctx, HARK_EARG, "filter_sel: unknown comparison %d", cmp);
+    if (k > kMaxCols) return hark_fail(ctx, HARK_EUNSUPPORTED, "filter_sel: at most %d projected columns", kMaxCols);
+    const int wdt = db->cols[where_col].dtype;
+    Const64 c{}; c.i = 0;
+    switch (wdt) {
+    case HARK_F32: c.f = *static_cast<const float *>(constant); break;
+    case HARK_I32: c.i = *static_cast<const int32_t *>(constant); break;
+    case HARK_U32: c.u = *static_cast<const uint32_t *>(constant); break;
+    default: c.i = *static_cast<const int64_t *>(constant); break;
+    }
+    const int64_t n = db->n;
+    const int64_t ntiles = (n + kTile - 1) / kTile;
+    if (ntiles > 0x7FFFFFFF) return hark_fail(ctx, HARK_EARG, "filter_sel: table too large for one call");
+    hark_result *res = new hark_result();
+    const int extra = want_row_index ? 1 : 0;
+    res->cols.resize((size_t)(k + extra));
+    if (extra) res->cols[0].dtype = HARK_I64;
+    for (int64_t j = 0; j < k; j++) res->cols[j + extra].dtype = db->cols[cols[j]].dtype;
+    int64_t total = 0;
+    uint32_t *counts = nullptr; int64_t *offsets = nullptr;
+    int rc = HARK_OK;
+    if (n > 0) {
+        rc = hark_alloc(ctx, (void **)&counts, (size_t)ntiles * 4 * sizeof(uint32_t));
+        if (!rc) rc = hark_alloc(ctx, (void **)&offsets, ((size_t)ntiles * 4 + 1) * sizeof(int64_t));
+        if (!rc) {
+            const void *wc = db->cols[where_col].data;
+            hipStream_t st = ctx->stream;
+            dim3 grid((unsigned)ntiles), block(kThreads);
+            switch (wdt) {
+            case HARK_F32: filter_count_kernel<float><<<grid, block, 0, st>>>(static_cast<const float *>(wc), n, cmp, c, counts); break;
+            case HARK_I32: filter_count_kernel<int32_t><<<grid, block, 0, st>>>(static_cast<const int32_t *>(wc), n, cmp, c, counts); break;
+            case HARK_U32: filter_count_kernel<uint32_t><<<grid, block, 0, st>>>(static_cast<const uint32_t *>(wc), n, cmp, c, counts); break;
+            default: filter_count_kernel<int64_t><<<grid, block, 0, st>>>(static_cast<const int64_t *>(wc), n, cmp, c, counts); break;
+            }
+            scan_counts_kernel<<<1, 1024, 0, st>>>(counts, ntiles * 4, offsets, offsets + ntiles * 4);
+            if (hipGetLastError() != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "filter_sel: launch failed");
+            if (!rc) rc = hark_read_words(ctx, offsets + ntiles * 4, &total, 1);
+        }
+    }
+    if (!rc) {
+        res->n = total;
+        for (auto &col : res->cols) {
+            rc = hark_alloc(ctx, &col.data, (size_t)total * hark_dtype_size(col.dtype));
+            if (rc) break;
+        }
+    }
+    if (!rc && total > 0) {
+        ColSet cs{};
+        cs.ncols = (int)k;
+        for (int64_t j = 0; j < k; j++) {
+            cs.src[j] = db->cols[cols[j]].data; cs.dst[j] = res->cols[j + extra].data;
+            cs.esz[j] = (int32_t)hark_dtype_size(res->cols[j + extra].dtype);
+        }
+        int64_t *ridx = extra ? static_cast<int64_t *>(res->cols[0].data) : nullptr;
+        const void *wc = db->cols[where_col].data;
+        hipStream_t st = ctx->stream;
+        dim3 grid((unsigned)ntiles), block(kThreads);
+        switch (wdt) {
+        case HARK_F32: filter_scatter_kernel<float><<<grid, block, 0, st>>>(static_cast<const float *>(wc), n, cmp, c, offsets, ridx, cs); break;
+        case HARK_I32: filter_scatter_kernel<int32_t><<<grid, block, 0, st>>>(static_cast<const int32_t *>(wc), n, cmp, c, offsets, ridx, cs); break;
+        case HARK_U32: filter_scatter_kernel<uint32_t><<<grid, block, 0, st>>>(static_cast<const uint32_t *>(wc), n, cmp, c, offsets, ridx, cs); break;
+        default: filter_scatter_kernel<int64_t><<<grid, block, 0, st>>>(static_cast<const int64_t *>(wc), n, cmp, c, offsets, ridx, cs); break;
+        }
+        if (hipGetLastError() != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "filter_sel: launch failed");
+        if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "filter_sel: kernel failed");
+    }
+    if (counts) hipFree(counts);
+    if (offsets) hipFree(offsets);
+    if (rc) { result_release(res); return rc; }
+    *out = res;
+    return HARK_OK;
+}
+
+int hark_result_values_2d(hark_context *ctx, const hark_result *r, void *host_out, int dtype)
+{
+    if (!ctx || !r) return HARK_EARG;
+    const int64_t m = (int64_t)r->cols.size();
+    if (r->n == 0 || m == 0) return HARK_OK;
+    if (!host_out) return HARK_EARG;
+    if (m > kMaxCols) return hark_fail(ctx, HARK_EUNSUPPORTED, "values_2d: at most %d columns", kMaxCols);
+    const int out_esz = (int)hark_dtype_size(dtype);
+    ColSet cs{}; cs.ncols = (int)m;
+    int sext = 0;
+    for (int64_t j = 0; j < m; j++) {
+        const int d = r->cols[j].dtype;
+        if ((d == HARK_F32) != (dtype == HARK_F32))
+            return hark_fail(ctx, HARK_EARG, "values_2d: cannot mix f32 and integer columns in one matrix");
+        cs.src[j] = r->cols[j].data; cs.esz[j] = (int32_t)hark_dtype_size(d);
+        if (d == HARK_I32) sext |= 1 << j;
+    }
+    void *tmp = nullptr;
+    const size_t bytes = (size_t)r->n * (size_t)m * (size_t)out_esz;
+    HARK_TRY(hark_alloc(ctx, &tmp, bytes));
+    int64_t blocks = (r->n * m + 255) / 256;
+    if (blocks > (int64_t)ctx->num_cu * 8) blocks = (int64_t)ctx->num_cu * 8;
+    interleave_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(cs, r->n, out_esz, sext, tmp);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(host_out, tmp, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    hipFree(tmp);
+    if (e != hipSuccess) return hark_fail(ctx, HARK_EHIP, "values_2d: %s", hipGetErrorString(e));
+    return HARK_OK;
+}
+
+} // extern "C"

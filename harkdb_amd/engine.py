@@ -1,0 +1,268 @@
+"""Thin object layer over the C ABI: Engine (context), DeviceTable, Result.
+
+Plays the role of `futhark_ffi.Futhark` in the reference
+(FutharkContext.py:41, :65-66, :70-71): numpy in, entry call, numpy out --
+except that tables are uploaded once and stay on the GPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+
+
+class Result:
+    """Device-resident query result (futhark opaque array + from_futhark)."""
+
+    def __init__(self, eng, handle):
+        self._eng, self._h = eng, handle
+
+    @property
+    def shape(self):
+        n, m = C.c_int64(), C.c_int64()
+        self._eng._chk(self._eng.lib.hark_result_shape(self._h, C.byref(n), C.byref(m)))
+        return n.value, m.value
+
+    def dtype(self, j):
+        return _ffi.NP_OF[self._eng.lib.hark_result_dtype(self._h, j)]
+
+    def column(self, j):
+        n, _ = self.shape
+        out = np.empty(n, dtype=self.dtype(j))
+        self._eng._chk(self._eng.lib.hark_result_column(self._eng.ctx, self._h, j, out.ctypes.data))
+        return out
+
+    def columns(self):
+        return [self.column(j) for j in range(self.shape[1])]
+
+    def device_ptr(self, j):
+        return self._eng.lib.hark_result_column_device(self._h, j)
+
+    def to_numpy(self, dtype=None):
+        """Row-major [n][m] matrix like `from_futhark` (FutharkContext.py:66)."""
+        n, m = self.shape
+        if dtype is None:
+            dts = {np.dtype(self.dtype(j)) for j in range(m)} or {np.dtype(np.int32)}
+            dtype = dts.pop() if len(dts) == 1 else (np.float32 if np.dtype(np.float32) in dts else np.int64)
+        dtype = np.dtype(dtype)
+        out = np.empty((n, m), dtype=dtype)
+        if n and m:
+            self._eng._chk(self._eng.lib.hark_result_values_2d(self._eng.ctx, self._h, out.ctypes.data, _ffi.DT_OF[dtype]))
+        return out
+
+    def free(self):
+        if self._h is not None:
+            self._eng.lib.hark_result_free(self._eng.ctx, self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class DeviceTable:
+    def __init__(self, eng, handle, keepalive=None):
+        self._eng, self._h, self._keep = eng, handle, keepalive
+
+    @property
+    def shape(self):
+        n, m = C.c_int64(), C.c_int64()
+        self._eng._chk(self._eng.lib.hark_table_shape(self._h, C.byref(n), C.byref(m)))
+        return n.value, m.value
+
+    def dtype(self, j):
+        return _ffi.NP_OF[self._eng.lib.hark_table_dtype(self._h, j)]
+
+    def device_ptr(self, j):
+        return self._eng.lib.hark_table_column_device(self._h, j)
+
+    def free(self):
+        if self._h is not None:
+            self._eng.lib.hark_table_free(self._eng.ctx, self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class FgbPlan:
+    """Workspace + knobs of the fused filter->group-by (hark_fgb_plan)."""
+
+    def __init__(self, eng, max_rows, G, **knobs):
+        self._eng, self.G = eng, int(G)
+        h = C.c_void_p()
+        eng._chk(eng.lib.hark_fgb_plan_new(eng.ctx, C.byref(h), int(max_rows), int(G)))
+        self._h = h
+        for k, v in knobs.items():
+            self.set(k, v)
+
+    def set(self, key, value):
+        rc = self._eng.lib.hark_fgb_plan_set(self._h, key.encode(), int(value))
+        if rc:
+            raise _ffi.HarkError(rc, f"fgb_plan_set({key}={value}) rejected")
+
+    def run(self, p, cmp, thr, k, v, n, sum_ptr, count_ptr):
+        """All pointers are raw device addresses (ints)."""
+        self._eng._chk(self._eng.lib.hark_op_filter_groupby_dense_f32(
+            self._eng.ctx, self._h, p, _ffi.CMP[cmp] if isinstance(cmp, str) else int(cmp), float(thr), k, v, int(n),
+            sum_ptr, count_ptr))
+
+    def check(self):
+        self._eng._chk(self._eng.lib.hark_fgb_check(self._eng.ctx, self._h))
+
+    def free(self):
+        if self._h is not None:
+            self._eng.lib.hark_fgb_plan_free(self._eng.ctx, self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Engine:
+    def __init__(self, device=0):
+        self.lib = _ffi.load()
+        ctx = C.c_void_p()
+        rc = self.lib.hark_context_new(C.byref(ctx), int(device))
+        if rc:
+            raise _ffi.HarkError(rc, f"hark_context_new(device={device}) failed: no usable MI355X/HIP device "
+                                     "(libhark has no CPU fallback)")
+        self.ctx = ctx
+        self.device = int(device)
+
+    # -- plumbing --------------------------------------------------------------
+    def _chk(self, rc):
+        if rc:
+            raise _ffi.HarkError(rc, (self.lib.hark_context_get_error(self.ctx) or b"").decode())
+
+    def sync(self):
+        self._chk(self.lib.hark_context_sync(self.ctx))
+
+    def set_stream(self, raw_stream):
+        self._chk(self.lib.hark_context_set_stream(self.ctx, raw_stream))
+
+    def close(self):
+        if self.ctx is not None:
+            self.lib.hark_context_free(self.ctx)
+            self.ctx = None
+
+    # -- raw device memory -------------------------------------------------------
+    def alloc(self, nbytes):
+        p = C.c_void_p()
+        self._chk(self.lib.hark_dev_alloc(self.ctx, C.byref(p), int(nbytes)))
+        return p.value
+
+    def free(self, ptr):
+        self._chk(self.lib.hark_dev_free(self.ctx, ptr))
+
+    def upload(self, ptr, arr):
+        arr = np.ascontiguousarray(arr)
+        self._chk(self.lib.hark_dev_upload(self.ctx, ptr, arr.ctypes.data, arr.nbytes))
+
+    def download(self, ptr, n, dtype):
+        out = np.empty(n, dtype=dtype)
+        self._chk(self.lib.hark_dev_download(self.ctx, out.ctypes.data, ptr, out.nbytes))
+        return out
+
+    def zero(self, ptr, nbytes):
+        self._chk(self.lib.hark_op_zero(self.ctx, ptr, int(nbytes)))
+
+    def gen_columns(self, seed, first_row, n, G, exact, p=None, k=None, v=None):
+        self._chk(self.lib.hark_op_gen_columns(self.ctx, int(seed), int(first_row), int(n), int(G), 1 if exact else 0, p, k, v))
+
+    # -- tables ------------------------------------------------------------------
+    def table_from_matrix(self, mat, dtype):
+        """Upload an [n][m] host matrix as m device columns of `dtype`
+        (futhark_new_i32_2d / _u32_2d).  Values are converted with numpy
+        wrap-around semantics first (the reference hands int64 to an i32/u32
+        entry)."""
+        dtype = np.dtype(dtype)
+        a = np.asarray(mat)
+        if a.ndim != 2:
+            a = a.reshape(0, 0) if a.size == 0 else a.reshape(a.shape[0], -1)
+        if a.dtype != dtype:
+            a = a.astype(dtype)            # keeps F order for F-ordered input
+        if not (a.flags.c_contiguous or a.flags.f_contiguous):
+            a = np.ascontiguousarray(a)
+        n, m = a.shape
+        es = a.itemsize
+        rs, cs = (a.strides[0] // es, a.strides[1] // es) if n and m else (m, 1)
+        h = C.c_void_p()
+        self._chk(self.lib.hark_table_new_2d(self.ctx, C.byref(h), a.ctypes.data, _ffi.DT_OF[dtype], n, m, rs, cs))
+        return DeviceTable(self, h)
+
+    def table_from_columns(self, cols):
+        cols = [np.ascontiguousarray(c) for c in cols]
+        n = len(cols[0]) if cols else 0
+        dts = (C.c_int32 * len(cols))(*[_ffi.DT_OF[c.dtype] for c in cols])
+        ptrs = (C.c_void_p * len(cols))(*[c.ctypes.data for c in cols])
+        h = C.c_void_p()
+        self._chk(self.lib.hark_table_new_columns(self.ctx, C.byref(h), n, len(cols), dts, ptrs))
+        return DeviceTable(self, h)
+
+    def table_from_device(self, n, ptrs, dtypes, keepalive=None):
+        dts = (C.c_int32 * len(ptrs))(*[_ffi.DT_OF[np.dtype(d)] for d in dtypes])
+        pp = (C.c_void_p * len(ptrs))(*ptrs)
+        h = C.c_void_p()
+        self._chk(self.lib.hark_table_from_device(self.ctx, C.byref(h), int(n), len(ptrs), dts, pp))
+        return DeviceTable(self, h, keepalive)
+
+    # -- entries -------------------------------------------------------------------
+    def query_sel(self, table, cols):
+        a, p = _ffi.i32_array(cols)
+        h = C.c_void_p()
+        self._chk(self.lib.hark_entry_query_sel(self.ctx, C.byref(h), table._h, p, a.size))
+        return Result(self, h)
+
+    def query_groupby(self, table, g_col, s_cols, t_cols):
+        a, pa = _ffi.i32_array(s_cols)
+        b, pb = _ffi.i32_array(t_cols)
+        h = C.c_void_p()
+        self._chk(self.lib.hark_entry_query_groupby(self.ctx, C.byref(h), table._h, int(g_col), pa, a.size, pb, b.size))
+        return Result(self, h)
+
+    def join(self, t1, t2, col1, col2, cols1, cols2):
+        a, pa = _ffi.i32_array(cols1)
+        b, pb = _ffi.i32_array(cols2)
+        h = C.c_void_p()
+        self._chk(self.lib.hark_entry_join(self.ctx, C.byref(h), t1._h, t2._h, int(col1), int(col2), pa, a.size, pb, b.size))
+        return Result(self, h)
+
+    def _const(self, table, col, value):
+        dt = np.dtype(table.dtype(col))
+        return np.asarray([value]).astype(dt)
+
+    def filter_sel(self, table, where_col, cmp, value, cols, want_row_index=True):
+        a, pa = _ffi.i32_array(cols)
+        c = self._const(table, where_col, value)
+        h = C.c_void_p()
+        self._chk(self.lib.hark_entry_filter_sel(self.ctx, C.byref(h), table._h, int(where_col), _ffi.CMP[cmp],
+                                                 c.ctypes.data, pa, a.size, 1 if want_row_index else 0))
+        return Result(self, h)
+
+    def filter_groupby(self, table, where, g_col, aggs):
+        """where = None | (col, cmp, value); aggs = [(op_name, col), ...]."""
+        cols, pc = _ffi.i32_array([c for _, c in aggs])
+        ops, po = _ffi.i32_array([_ffi.AGG[o] for o, _ in aggs])
+        if where is None:
+            wc, cmp, c = -1, 0, np.zeros(1, dtype=np.int64)
+        else:
+            wc, cmp, c = int(where[0]), _ffi.CMP[where[1]], self._const(table, where[0], where[2])
+        h = C.c_void_p()
+        self._chk(self.lib.hark_entry_filter_groupby(self.ctx, C.byref(h), table._h, wc, cmp, c.ctypes.data,
+                                                     int(g_col), pc, po, cols.size))
+        return Result(self, h)
+
+    def sort(self, table, key_col, cols, descending=False):
+        a, pa = _ffi.i32_array(cols)
+        h = C.c_void_p()
+        self._chk(self.lib.hark_entry_sort(self.ctx, C.byref(h), table._h, int(key_col), 1 if descending else 0, pa, a.size))
+        return Result(self, h)
