@@ -269,14 +269,13 @@ int hark_op_gen_columns(hark_context *ctx, uint64_t seed, int64_t first_row, int
 
 int hark_op_filter_groupby_dense_f32(hark_context *ctx, hark_fgb_plan *plan,
                                      const float *p, int32_t cmp, float thr,
-                                     const int32_t *k, const float *v, int64_t n,
-                                     float *sum, int64_t *count)
+                                     const int32_t *k, const float *v, int64_t n)
 {
     if (!ctx || !plan) return HARK_EARG;
-    if (n < 0 || (n && (!k || !v || !sum || !count))) return hark_fail(ctx, HARK_EARG, "filter_groupby: null column or output");
+    if (n < 0 || (n && (!k || !v))) return hark_fail(ctx, HARK_EARG, "filter_groupby: null column");
     if (plan->max_rows && n > plan->max_rows) return hark_fail(ctx, HARK_EARG, "filter_groupby: n exceeds the plan's max_rows");
     if (n > 0xFFFFFFFFll) return hark_fail(ctx, HARK_EARG, "filter_groupby: at most 2^32-1 rows per call (shard larger tables)");
-    return k_fgb_dense_f32(ctx, plan, p, cmp, thr, k, v, n, sum, count);
+    return k_fgb_dense_f32(ctx, plan, p, cmp, thr, k, v, n);
 }
 
 } // extern "C"

@@ -74,18 +74,21 @@ struct hark_fgb_plan {
     int64_t grid = 0;          // 0 = auto
     int64_t shift = 0;         // partition path: bucket = key >> shift
     int64_t P = 0;             // number of buckets
-    int64_t cap = 0;           // pairs per bucket in the partition buffer
+    int64_t nwg = 0;           // producer workgroups (= slabs per bucket)
+    int64_t cap = 0;           // pairs per (bucket, workgroup) slab
+    int64_t slack_pct = 0;     // slab capacity as % of the uniform share (0 = default)
     int64_t tile_rows = 0;
-    uint2 *pbuf = nullptr;     // [P][cap] (key, value-bits) pairs
-    uint32_t *cursor = nullptr;// [P]
-    uint32_t *cnt32 = nullptr; // [G] u32 partial counts (folded to i64 at the end of a call)
+    uint2 *pbuf = nullptr;     // [P][nwg][cap] (key, value-bits) pairs
+    uint32_t *counts = nullptr;// [P][nwg] pairs in each slab
+    double *acc_sum = nullptr; // [G]
+    unsigned long long *acc_cnt = nullptr; // [G]
     int32_t *err = nullptr;    // device sticky error word
 };
 
 int k_gen_columns(hark_context *ctx, uint64_t seed, int64_t first_row, int64_t n, uint32_t G,
                   int exact, float *p, int32_t *k, float *v);
 int k_fgb_dense_f32(hark_context *ctx, hark_fgb_plan *plan, const float *p, int cmp, float thr,
-                    const int32_t *k, const float *v, int64_t n, float *sum, int64_t *count);
+                    const int32_t *k, const float *v, int64_t n);
 
 // k_select.hip
 int k_gather_columns(hark_context *ctx, const hark_table *db, const int32_t *cols, int64_t k,

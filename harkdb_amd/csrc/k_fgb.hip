@@ -9,23 +9,30 @@
 //
 //   algorithmic bytes = 12 B/row (p, k, v)  +  16 B/group (key, sum, count).
 //
+// Accumulators are f64 sums + integer counts.  Measured on gfx950 (tools/
+// ldsbench.hip): ds_add_f32 retires ~0.4 lanes/clk/CU, ds_add_f64 ~3.5,
+// ds_add_u32 ~10, so sums are accumulated in double (which also makes the
+// result independent of accumulation order to ~1e-16, far inside the 1e-5 bar)
+// and rounded to f32 once at the end (hark_fgb_finish).
+//
 // Three device paths, chosen by the number of groups G:
-//   LDS   (G*8 B fits one workgroup's LDS): every workgroup keeps a private
-//         [G] (sum,count) table in LDS (replicated per lane for tiny G so
-//         ds_add never bank-conflicts), streams its rows with 16-byte loads,
-//         and flushes once with contiguous global atomics.
-//   PART  (large G, e.g. 2^20): scattered global atomics run ~17x below the
-//         contiguous atomic rate on gfx950 (they execute at the memory side),
-//         so rows are first routed by key range: a workgroup stages the
-//         surviving (key,value) pairs of an 8192-row tile in LDS, bucket-sorts
-//         them there (ds_add_rtn rank + scan), and writes each bucket's run
-//         to that bucket's region; a second kernel gives every bucket to one
-//         workgroup that folds it into an LDS-resident slice of the table and
-//         adds the slice to the global table with plain stores (it owns the
-//         key range).  Work is chunked so the pair buffer stays in the
-//         256 MiB Infinity Cache.
-//   ATOM  one global atomic pair per surviving row; kept as the fallback for
-//         bucket overflow (skewed keys) and as a measured baseline.
+//   LDS   (12 B x G fits a workgroup's LDS): every workgroup keeps a private
+//         (sum,count) table in LDS (replicated per lane for tiny G to spread
+//         same-address atomics), streams its rows with 16-byte loads and
+//         flushes once with contiguous global atomics.
+//   PART  (large G, e.g. 2^20): scattered global atomics retire ~21-27 G/s
+//         on gfx950 (tools/ubench.hip: they execute at the memory side, one
+//         64-byte request per lane), 20x too slow.  So rows are routed by key
+//         range first.  PRODUCER: a workgroup stages the surviving (key,value)
+//         pairs of an 8192-row tile in LDS, bucket-sorts them there
+//         (ds_add_rtn rank + scan) and appends each bucket's run to its OWN
+//         slab of that bucket -- cursors are workgroup-private, so there are no
+//         global atomics and consecutive tiles extend the same lines in L2.
+//         CONSUMER: one workgroup per bucket folds the bucket's slabs into an
+//         LDS-resident slice of the table and adds the slice to the global
+//         table with plain stores (it owns the key range).
+//   ATOM  one global atomic pair per surviving row; the fallback for slab
+//         overflow (heavily skewed keys) and a measured baseline.
 #include "hark_internal.h"
 #include <type_traits>
 
@@ -33,6 +40,7 @@ namespace {
 
 constexpr int kVec = 4;                 // rows per 16-byte load
 constexpr uint32_t kInvalidKey = 0xFFFFFFFFu;
+constexpr int kNoPred = -1;
 
 template <int OP>
 __device__ __forceinline__ bool cmp_f32(float a, float b)
@@ -43,9 +51,8 @@ __device__ __forceinline__ bool cmp_f32(float a, float b)
     else if constexpr (OP == HARK_CMP_LE) return a <= b;
     else if constexpr (OP == HARK_CMP_EQ) return a == b;
     else if constexpr (OP == HARK_CMP_NE) return a != b;
-    else return true;                   // OP == -1: no predicate
+    else return true;                   // kNoPred
 }
-constexpr int kNoPred = -1;
 
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x)
 {
@@ -71,20 +78,19 @@ __global__ void gen_columns_kernel(uint64_t seed, int64_t first_row, int64_t n, 
 // ---------------------------------------------------------------------------
 // LDS-privatised path
 // ---------------------------------------------------------------------------
-// Dynamic LDS: float s_sum[G << RL]; uint32 s_cnt[G << RL].  Replica of a key
-// for lane l is (key << RL) | (l & (R-1)); with R = 32 the bank is the lane id,
-// so a wave's ds_add is conflict-free whatever the keys are.
+// Dynamic LDS: double s_sum[G << RL]; uint32 s_cnt[G << RL].  The replica of a
+// key used by lane l is (key << RL) | (l & (R-1)).
 template <int OP>
 __global__ __launch_bounds__(1024) void fgb_lds_kernel(
     const float *__restrict__ p, const int32_t *__restrict__ k, const float *__restrict__ v,
-    int64_t n, float thr, int G, int RL, float *__restrict__ gsum,
+    int64_t n, float thr, int G, int RL, double *__restrict__ gsum,
     unsigned long long *__restrict__ gcnt, int32_t *__restrict__ err)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int slots = G << RL;
-    float *s_sum = reinterpret_cast<float *>(lds_raw);
-    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(lds_raw) + slots;
-    for (int i = threadIdx.x; i < slots; i += blockDim.x) { s_sum[i] = 0.0f; s_cnt[i] = 0u; }
+    double *s_sum = reinterpret_cast<double *>(lds_raw);
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(lds_raw + sizeof(double) * slots);
+    for (int i = threadIdx.x; i < slots; i += blockDim.x) { s_sum[i] = 0.0; s_cnt[i] = 0u; }
     __syncthreads();
 
     const uint32_t rep = threadIdx.x & ((1u << RL) - 1u);
@@ -99,8 +105,8 @@ __global__ __launch_bounds__(1024) void fgb_lds_kernel(
         if (cmp_f32<OP>(pv, thr)) {
             if ((uint32_t)key < (uint32_t)G) {
                 uint32_t s = ((uint32_t)key << RL) | rep;
-                unsafeAtomicAdd(&s_sum[s], val);
-                atomicAdd(&s_cnt[s], 1u);
+                unsafeAtomicAdd(&s_sum[s], (double)val);      // ds_add_f64
+                atomicAdd(&s_cnt[s], 1u);                     // ds_add_u32
             } else bad = true;
         }
     };
@@ -131,10 +137,10 @@ __global__ __launch_bounds__(1024) void fgb_lds_kernel(
 
     const int R = 1 << RL;
     for (int g = threadIdx.x; g < G; g += blockDim.x) {
-        float s = 0.0f; uint32_t c = 0;
+        double s = 0.0; uint32_t c = 0;
         for (int r = 0; r < R; r++) { s += s_sum[(g << RL) + r]; c += s_cnt[(g << RL) + r]; }
         if (c) {
-            unsafeAtomicAdd(&gsum[g], s);
+            unsafeAtomicAdd(&gsum[g], s);                     // global_atomic_add_f64, contiguous
             atomicAdd(&gcnt[g], (unsigned long long)c);
         }
     }
@@ -146,7 +152,7 @@ __global__ __launch_bounds__(1024) void fgb_lds_kernel(
 template <int OP>
 __global__ __launch_bounds__(256) void fgb_atomic_kernel(
     const float *__restrict__ p, const int32_t *__restrict__ k, const float *__restrict__ v,
-    int64_t n, float thr, int64_t G, float *__restrict__ gsum,
+    int64_t n, float thr, int64_t G, double *__restrict__ gsum,
     unsigned long long *__restrict__ gcnt, int32_t *__restrict__ err)
 {
     const int64_t nvec = n / kVec;
@@ -157,8 +163,8 @@ __global__ __launch_bounds__(256) void fgb_atomic_kernel(
     bool bad = false;
     auto row = [&](float pv, int32_t key, float val) {
         if (cmp_f32<OP>(pv, thr)) {
-            if ((uint64_t)(uint32_t)key < (uint64_t)G && key >= 0) {
-                unsafeAtomicAdd(&gsum[key], val);
+            if (key >= 0 && (int64_t)key < G) {
+                unsafeAtomicAdd(&gsum[key], (double)val);
                 atomicAdd(&gcnt[key], 1ull);
             } else bad = true;
         }
@@ -177,20 +183,21 @@ __global__ __launch_bounds__(256) void fgb_atomic_kernel(
 }
 
 // ---------------------------------------------------------------------------
-// Partition path, kernel 1: route surviving (key,value) pairs by key range
+// Partition path, PRODUCER: route surviving (key,value) pairs by key range
 // ---------------------------------------------------------------------------
 constexpr int kPartThreads = 512;
 constexpr int kRowsPerThread = 16;                       // 4 x 16-byte loads per column
 constexpr int kTileRows = kPartThreads * kRowsPerThread; // 8192 rows -> 64 KiB of staged pairs
 constexpr int kMaxBuckets = 1024;
 
-// LDS: uint2 stage[kTileRows]; int cnt[P]; int off[P]; int delta[P]; int fit[P]; int wsum[8]
+// Slab of (bucket b, workgroup w): pbuf[(b*nwg + w)*cap .. +cap).
+// LDS: uint2 stage[kTileRows]; int cnt[P], off[P], delta[P], fit[P], cur[P]; int wsum[8]
 template <int OP>
 __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
     const float *__restrict__ p, const int32_t *__restrict__ k, const float *__restrict__ v,
     int64_t row0, int64_t row1, float thr, int64_t G, int shift, int P,
-    uint2 *__restrict__ pbuf, uint32_t *__restrict__ cursor, uint32_t cap,
-    float *__restrict__ gsum, unsigned long long *__restrict__ gcnt, int32_t *__restrict__ err)
+    uint2 *__restrict__ pbuf, uint32_t *__restrict__ counts, uint32_t cap,
+    double *__restrict__ gsum, unsigned long long *__restrict__ gcnt, int32_t *__restrict__ err)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     uint2 *stage = reinterpret_cast<uint2 *>(lds_raw);
@@ -198,18 +205,21 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
     int *s_off = s_cnt + P;
     int *s_delta = s_off + P;
     int *s_fit = s_delta + P;
-    int *s_wsum = s_fit + P;                              // per-wave scan carries
+    int *s_cur = s_fit + P;                               // this workgroup's fill of each bucket slab
+    int *s_wsum = s_cur + P;                              // per-wave scan carries
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
+    const int nwg = gridDim.x, wg = blockIdx.x;
     const int64_t ntiles = (row1 - row0 + kTileRows - 1) / kTileRows;
     bool bad = false;
+    for (int b = tid; b < P; b += kPartThreads) s_cur[b] = 0;
 
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (int64_t tile = wg; tile < ntiles; tile += nwg) {
         for (int b = tid; b < P; b += kPartThreads) s_cnt[b] = 0;
         __syncthreads();
 
         // rows of this thread: 4 groups of 4 consecutive rows, group g at
-        // tile_base + (g*512 + tid)*4 -> each wave-instruction reads 1 KiB.
+        // tile_base + (g*512 + tid)*4 -> every wave-instruction reads 1 KiB.
         const int64_t tbase = row0 + tile * kTileRows;
         uint32_t keys[kRowsPerThread];
         float vals[kRowsPerThread];
@@ -250,37 +260,29 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
         }
         __syncthreads();
 
-        // exclusive scan of s_cnt[0..P) (P <= 1024: two buckets per thread)
+        // exclusive scan of s_cnt[0..P) (P <= 1024: two buckets per thread), and
+        // reservation of room in this workgroup's slabs (private cursors).
         {
-            int b0 = tid * 2, b1 = tid * 2 + 1;
-            int c0 = b0 < P ? s_cnt[b0] : 0, c1 = b1 < P ? s_cnt[b1] : 0;
-            int x = c0 + c1, incl = x;
+            const int b0 = tid * 2, b1 = tid * 2 + 1;
+            const int c0 = b0 < P ? s_cnt[b0] : 0, c1 = b1 < P ? s_cnt[b1] : 0;
+            const int x = c0 + c1;
+            int incl = x;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) { int y = __shfl_up(incl, d, 64); if (lane >= d) incl += y; }
             if (lane == 63) s_wsum[wave] = incl;
             __syncthreads();
             int carry = 0;
             for (int w = 0; w < wave; w++) carry += s_wsum[w];
-            int excl = carry + incl - x;
+            const int excl = carry + incl - x;
             if (b0 < P) {
-                s_off[b0] = excl;
-                int fit = 0, delta = 0;
-                if (c0 > 0) {
-                    uint32_t g0 = atomicAdd(&cursor[b0], (uint32_t)c0);
-                    fit = g0 >= cap ? 0 : (int)min((uint32_t)c0, cap - g0);
-                    delta = (int)g0 - excl;
-                }
-                s_fit[b0] = fit; s_delta[b0] = delta;
+                const int cur = s_cur[b0];
+                const int fit = min(c0, (int)cap - cur);
+                s_off[b0] = excl; s_fit[b0] = fit; s_delta[b0] = cur - excl; s_cur[b0] = cur + fit;
             }
             if (b1 < P) {
-                s_off[b1] = excl + c0;
-                int fit = 0, delta = 0;
-                if (c1 > 0) {
-                    uint32_t g1 = atomicAdd(&cursor[b1], (uint32_t)c1);
-                    fit = g1 >= cap ? 0 : (int)min((uint32_t)c1, cap - g1);
-                    delta = (int)g1 - (excl + c0);
-                }
-                s_fit[b1] = fit; s_delta[b1] = delta;
+                const int cur = s_cur[b1];
+                const int fit = min(c1, (int)cap - cur);
+                s_off[b1] = excl + c0; s_fit[b1] = fit; s_delta[b1] = cur - (excl + c0); s_cur[b1] = cur + fit;
             }
         }
         __syncthreads();
@@ -294,67 +296,82 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
                 const int slot = s_off[b] + rank[q];
                 if (rank[q] < s_fit[b]) {
                     stage[slot] = uint2{keys[q], __float_as_uint(vals[q])};
-                } else {                      // bucket region full (skewed keys): direct atomics
+                } else {                      // slab full (skewed keys): direct atomics
                     stage[slot] = uint2{kInvalidKey, 0u};
-                    unsafeAtomicAdd(&gsum[keys[q]], vals[q]);
+                    unsafeAtomicAdd(&gsum[keys[q]], (double)vals[q]);
                     atomicAdd(&gcnt[keys[q]], 1ull);
                 }
             }
         }
         __syncthreads();
         for (int slot = tid; slot < total; slot += kPartThreads) {
-            uint2 pr2 = stage[slot];
+            const uint2 pr2 = stage[slot];
             if (pr2.x != kInvalidKey) {
                 const uint32_t b = pr2.x >> shift;
-                pbuf[(size_t)b * cap + (uint32_t)(s_delta[b] + slot)] = pr2;
+                pbuf[((size_t)b * nwg + wg) * cap + (uint32_t)(s_delta[b] + slot)] = pr2;
             }
         }
         __syncthreads();
     }
+    __syncthreads();
+    for (int b = tid; b < P; b += kPartThreads) counts[(size_t)b * nwg + wg] = (uint32_t)s_cur[b];
     if (bad) *err = HARK_EBOUNDS;
 }
 
 // ---------------------------------------------------------------------------
-// Partition path, kernel 2: one workgroup folds one bucket into its table slice
+// Partition path, CONSUMER: one workgroup folds one bucket into its table slice
 // ---------------------------------------------------------------------------
-// LDS: float s_sum[KPB]; uint32 s_cnt[KPB], KPB = 1 << shift keys per bucket.
+// LDS: double s_sum[KPB]; uint32 s_cnt[KPB], KPB = 1 << shift keys per bucket.
 __global__ __launch_bounds__(1024) void fgb_agg_kernel(
-    const uint2 *__restrict__ pbuf, uint32_t *__restrict__ cursor, uint32_t cap, int shift,
-    int64_t G, float *__restrict__ gsum, unsigned long long *__restrict__ gcnt)
+    const uint2 *__restrict__ pbuf, const uint32_t *__restrict__ counts, uint32_t cap, int nwg, int shift,
+    int64_t G, double *__restrict__ gsum, unsigned long long *__restrict__ gcnt)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int KPB = 1 << shift;
-    float *s_sum = reinterpret_cast<float *>(lds_raw);
-    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(lds_raw) + KPB;
+    double *s_sum = reinterpret_cast<double *>(lds_raw);
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(lds_raw + sizeof(double) * KPB);
     const int b = blockIdx.x;
-    const uint32_t count = min(cursor[b], cap);
-    if (count == 0) return;                                 // uniform across the workgroup
-    for (int i = threadIdx.x; i < KPB; i += blockDim.x) { s_sum[i] = 0.0f; s_cnt[i] = 0u; }
+    for (int i = threadIdx.x; i < KPB; i += blockDim.x) { s_sum[i] = 0.0; s_cnt[i] = 0u; }
     __syncthreads();
-    const uint2 *src = pbuf + (size_t)b * cap;              // cap is even -> 16-byte aligned
-    const uint4 *src4 = reinterpret_cast<const uint4 *>(src);
     const uint32_t mask = (uint32_t)KPB - 1u;
-    const uint32_t npair2 = count / 2;
-    for (uint32_t i = threadIdx.x; i < npair2; i += blockDim.x) {
-        uint4 q = src4[i];
-        unsafeAtomicAdd(&s_sum[q.x & mask], __uint_as_float(q.y)); atomicAdd(&s_cnt[q.x & mask], 1u);
-        unsafeAtomicAdd(&s_sum[q.z & mask], __uint_as_float(q.w)); atomicAdd(&s_cnt[q.z & mask], 1u);
-    }
-    if ((count & 1u) && threadIdx.x == 0) {
-        uint2 q = src[count - 1];
-        unsafeAtomicAdd(&s_sum[q.x & mask], __uint_as_float(q.y)); atomicAdd(&s_cnt[q.x & mask], 1u);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    auto add = [&](uint32_t key, uint32_t vbits) {
+        unsafeAtomicAdd(&s_sum[key & mask], (double)__uint_as_float(vbits));
+        atomicAdd(&s_cnt[key & mask], 1u);
+    };
+    // each wave walks whole slabs: 2 pairs (16 bytes) per lane per load, 2 loads in flight
+    for (int w = wave; w < nwg; w += nwaves) {
+        const uint32_t count = min(counts[(size_t)b * nwg + w], cap);
+        const uint2 *src = pbuf + ((size_t)b * nwg + w) * cap;         // cap is even -> 16-byte aligned
+        const uint4 *src4 = reinterpret_cast<const uint4 *>(src);
+        const uint32_t n2 = count / 2;
+        uint32_t i = lane;
+        for (; i + 64 < n2; i += 128) {
+            const uint4 q0 = src4[i], q1 = src4[i + 64];
+            add(q0.x, q0.y); add(q0.z, q0.w); add(q1.x, q1.y); add(q1.z, q1.w);
+        }
+        for (; i < n2; i += 64) { const uint4 q = src4[i]; add(q.x, q.y); add(q.z, q.w); }
+        if ((count & 1u) && lane == 0) { const uint2 q = src[count - 1]; add(q.x, q.y); }
     }
     __syncthreads();
     const int64_t kbase = (int64_t)b << shift;
     for (int i = threadIdx.x; i < KPB; i += blockDim.x) {
-        uint32_t c = s_cnt[i];
+        const uint32_t c = s_cnt[i];
         if (c && kbase + i < G) {                           // this workgroup owns [kbase, kbase+KPB)
             gsum[kbase + i] += s_sum[i];
             gcnt[kbase + i] += (unsigned long long)c;
         }
     }
-    __syncthreads();
-    if (threadIdx.x == 0) cursor[b] = 0;                    // ready for the next chunk
+}
+
+__global__ __launch_bounds__(256) void fgb_finish_kernel(const double *__restrict__ acc_sum, const unsigned long long *__restrict__ acc_cnt,
+                                                         int64_t G, float *__restrict__ sum_out, int64_t *__restrict__ cnt_out)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < G; g += stride) {
+        if (sum_out) sum_out[g] = (float)acc_sum[g];
+        if (cnt_out) cnt_out[g] = (int64_t)acc_cnt[g];
+    }
 }
 
 template <typename F>
@@ -372,7 +389,8 @@ int dispatch_op(int cmp, bool has_pred, F &&f)
     }
 }
 
-constexpr int64_t kLdsBudget = 64 * 1024;   // per-workgroup table budget (2 workgroups/CU)
+constexpr int64_t kLdsTableBudget = 96 * 1024;   // LDS path: 12 B per group -> G <= 8192
+constexpr int64_t kAggTableBudget = 96 * 1024;   // consumer: 12 B per key of a bucket
 
 } // namespace
 
@@ -389,6 +407,12 @@ int k_gen_columns(hark_context *ctx, uint64_t seed, int64_t first_row, int64_t n
     return HARK_OK;
 }
 
+static void plan_drop_partition(hark_fgb_plan *pl)
+{
+    if (pl->pbuf) { hipFree(pl->pbuf); pl->pbuf = nullptr; }
+    if (pl->counts) { hipFree(pl->counts); pl->counts = nullptr; }
+}
+
 int hark_fgb_plan_new(hark_context *ctx, hark_fgb_plan **out, int64_t max_rows, int64_t G)
 {
     if (!ctx || !out) return HARK_EARG;
@@ -400,8 +424,12 @@ int hark_fgb_plan_new(hark_context *ctx, hark_fgb_plan **out, int64_t max_rows, 
     pl->max_rows = max_rows; pl->G = G;
     pl->tile_rows = kTileRows;
     int rc = hark_alloc(ctx, (void **)&pl->err, sizeof(int32_t));
-    if (rc) { delete pl; return rc; }
+    if (!rc) rc = hark_alloc(ctx, (void **)&pl->acc_sum, (size_t)G * sizeof(double));
+    if (!rc) rc = hark_alloc(ctx, (void **)&pl->acc_cnt, (size_t)G * sizeof(unsigned long long));
+    if (rc) { hark_fgb_plan_free(ctx, pl); return rc; }
     hipMemsetAsync(pl->err, 0, sizeof(int32_t), ctx->stream);
+    hipMemsetAsync(pl->acc_sum, 0, (size_t)G * sizeof(double), ctx->stream);
+    hipMemsetAsync(pl->acc_cnt, 0, (size_t)G * sizeof(unsigned long long), ctx->stream);
     *out = pl;
     return HARK_OK;
 }
@@ -410,9 +438,10 @@ int hark_fgb_plan_free(hark_context *ctx, hark_fgb_plan *pl)
 {
     if (!pl) return HARK_OK;
     if (ctx) hipStreamSynchronize(ctx->stream);
-    if (pl->pbuf) hipFree(pl->pbuf);
-    if (pl->cursor) hipFree(pl->cursor);
+    plan_drop_partition(pl);
     if (pl->err) hipFree(pl->err);
+    if (pl->acc_sum) hipFree(pl->acc_sum);
+    if (pl->acc_cnt) hipFree(pl->acc_cnt);
     delete pl;
     return HARK_OK;
 }
@@ -422,120 +451,145 @@ int hark_fgb_plan_set(hark_fgb_plan *pl, const char *key, int64_t value)
     if (!pl || !key) return HARK_EARG;
     if (!strcmp(key, "algo")) { if (value < 0 || value > 3) return HARK_EARG; pl->algo = value; }
     else if (!strcmp(key, "chunk_rows")) { if (value < 0) return HARK_EARG; pl->chunk_rows = value; }
-    else if (!strcmp(key, "grid")) { if (value < 0) return HARK_EARG; pl->grid = value; }
+    else if (!strcmp(key, "grid")) { if (value < 0 || value > 65535) return HARK_EARG; pl->grid = value; }
     else if (!strcmp(key, "shift")) { if (value < 0 || value > 13) return HARK_EARG; pl->shift = value; }
+    else if (!strcmp(key, "slack_pct")) { if (value < 0 || value > 10000) return HARK_EARG; pl->slack_pct = value; }
     else return HARK_EARG;
-    // partition geometry depends on the knobs: drop buffers so they are re-sized
-    if (pl->pbuf) { hipFree(pl->pbuf); pl->pbuf = nullptr; }
-    if (pl->cursor) { hipFree(pl->cursor); pl->cursor = nullptr; }
+    plan_drop_partition(pl);     // partition geometry depends on the knobs
+    return HARK_OK;
+}
+
+int hark_fgb_reset(hark_context *ctx, hark_fgb_plan *pl)
+{
+    if (!ctx || !pl) return HARK_EARG;
+    HIP_TRY(ctx, hipMemsetAsync(pl->acc_sum, 0, (size_t)pl->G * sizeof(double), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(pl->acc_cnt, 0, (size_t)pl->G * sizeof(unsigned long long), ctx->stream));
+    return HARK_OK;
+}
+
+int hark_fgb_acc_device(hark_fgb_plan *pl, void **sum_f64, void **count_i64)
+{
+    if (!pl) return HARK_EARG;
+    if (sum_f64) *sum_f64 = pl->acc_sum;
+    if (count_i64) *count_i64 = pl->acc_cnt;
     return HARK_OK;
 }
 
 static int plan_prepare_partition(hark_context *ctx, hark_fgb_plan *pl)
 {
     if (pl->pbuf) return HARK_OK;
-    // bucket = key >> shift; KPB = 1 << shift keys per bucket, 8 B of LDS each.
+    // bucket = key >> shift; KPB = 1 << shift keys per bucket, 12 B of LDS each in the consumer.
     int shift = pl->shift ? (int)pl->shift : 12;
     while ((((pl->G - 1) >> shift) + 1) > kMaxBuckets) shift++;
-    if (((int64_t)8 << shift) > kLdsBudget)
+    if (((int64_t)12 << shift) > kAggTableBudget)
         return hark_fail(ctx, HARK_EUNSUPPORTED, "fgb: G = %lld needs more than %d buckets of <= %lld keys",
-                         (long long)pl->G, kMaxBuckets, (long long)(kLdsBudget / 8));
+                         (long long)pl->G, kMaxBuckets, (long long)(kAggTableBudget / 12));
     pl->shift = shift;
     pl->P = ((pl->G - 1) >> shift) + 1;
-    int64_t chunk = pl->chunk_rows ? pl->chunk_rows : (int64_t)16 << 20;
+    pl->nwg = pl->grid ? pl->grid : (int64_t)ctx->num_cu * 2;
+    int64_t chunk = pl->chunk_rows ? pl->chunk_rows : (int64_t)1 << 28;
     chunk = (chunk + kTileRows - 1) / kTileRows * kTileRows;
-    if (chunk > pl->max_rows && pl->max_rows > 0) chunk = (pl->max_rows + kTileRows - 1) / kTileRows * kTileRows;
+    if (pl->max_rows > 0 && chunk > pl->max_rows) chunk = (pl->max_rows + kTileRows - 1) / kTileRows * kTileRows;
     pl->chunk_rows = chunk;
-    // room for 1.5x the uniform share of a chunk with every row surviving, + one tile
-    int64_t cap = chunk / pl->P * 3 / 2 + kTileRows;
+    // a (bucket, workgroup) slab holds slack x the uniform share of a chunk in which every
+    // row survives, plus room for the fluctuation of a few tiles
+    const int64_t slack = pl->slack_pct ? pl->slack_pct : 130;
+    int64_t cap = chunk / (pl->P * pl->nwg) * slack / 100 + 256;
     cap = (cap + 1) & ~(int64_t)1;
-    if (cap > 0xFFFFFFF0ll) return hark_fail(ctx, HARK_EARG, "fgb: chunk too large");
+    if (cap > 0x7FFFFFF0ll) return hark_fail(ctx, HARK_EARG, "fgb: chunk too large");
     pl->cap = cap;
-    HARK_TRY(hark_alloc(ctx, (void **)&pl->pbuf, (size_t)pl->P * (size_t)cap * sizeof(uint2)));
-    HARK_TRY(hark_alloc(ctx, (void **)&pl->cursor, (size_t)pl->P * sizeof(uint32_t)));
-    HIP_TRY(ctx, hipMemsetAsync(pl->cursor, 0, (size_t)pl->P * sizeof(uint32_t), ctx->stream));
+    HARK_TRY(hark_alloc(ctx, (void **)&pl->pbuf, (size_t)pl->P * (size_t)pl->nwg * (size_t)cap * sizeof(uint2)));
+    HARK_TRY(hark_alloc(ctx, (void **)&pl->counts, (size_t)pl->P * (size_t)pl->nwg * sizeof(uint32_t)));
     return HARK_OK;
 }
 
 int k_fgb_dense_f32(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cmp, float thr,
-                    const int32_t *k, const float *v, int64_t n, float *sum, int64_t *count)
+                    const int32_t *k, const float *v, int64_t n)
 {
     if (n == 0) return HARK_OK;
     const int64_t G = pl->G;
     auto misaligned = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) != 0; };
     if ((p && misaligned(p)) || misaligned(k) || misaligned(v))
         return hark_fail(ctx, HARK_EARG, "fgb: columns must be 16-byte aligned");
-    unsigned long long *gcnt = reinterpret_cast<unsigned long long *>(count);
+    double *gsum = pl->acc_sum;
+    unsigned long long *gcnt = pl->acc_cnt;
     int algo = (int)pl->algo;
-    if (algo == 0) algo = (G * 8 <= kLdsBudget) ? 1 : 3;
-    if (algo == 1 && G * 8 > 160 * 1024 - 1024)
-        return hark_fail(ctx, HARK_EUNSUPPORTED, "fgb: LDS path needs G*8 <= 159 KiB");
+    if (algo == 0) algo = (G * 12 <= kLdsTableBudget) ? 1 : 3;
+    if (algo == 1 && G * 12 > 159 * 1024)
+        return hark_fail(ctx, HARK_EUNSUPPORTED, "fgb: LDS path needs 12*G <= 159 KiB");
     hipStream_t st = ctx->stream;
 
     if (algo == 1) {
-        // replicate the table per lane while it stays under 16 KiB (tiny G)
+        // replicate the table per lane while it stays under 24 KiB (tiny G)
         int RL = 0;
-        while (RL < 5 && (G << (RL + 1)) * 8 <= 16 * 1024) RL++;
-        size_t lds = (size_t)(G << RL) * 8;
-        int wg_per_cu = lds <= 40 * 1024 ? 2 : 1;
+        while (RL < 5 && (G << (RL + 1)) * 12 <= 24 * 1024) RL++;
+        const size_t lds = (size_t)(G << RL) * 12;
+        const int wg_per_cu = lds <= 64 * 1024 ? 2 : 1;
         int64_t grid = pl->grid ? pl->grid : (int64_t)ctx->num_cu * wg_per_cu;
-        int64_t need = (n / kVec + 1023) / 1024;
+        const int64_t need = (n / kVec + 1023) / 1024;
         if (grid > need) grid = need > 0 ? need : 1;
         return dispatch_op(cmp, p != nullptr, [&](auto op) -> int {
             constexpr int OP = decltype(op)::value;
             if (lds > 64 * 1024)
                 HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_lds_kernel<OP>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            fgb_lds_kernel<OP><<<dim3((unsigned)grid), dim3(1024), lds, st>>>(p, k, v, n, thr, (int)G, RL, sum, gcnt, pl->err);
+            fgb_lds_kernel<OP><<<dim3((unsigned)grid), dim3(1024), lds, st>>>(p, k, v, n, thr, (int)G, RL, gsum, gcnt, pl->err);
             HIP_TRY(ctx, hipGetLastError());
             return HARK_OK;
         });
     }
     if (algo == 2) {
         int64_t grid = pl->grid ? pl->grid : (int64_t)ctx->num_cu * 8;
-        int64_t need = (n / kVec + 255) / 256;
+        const int64_t need = (n / kVec + 255) / 256;
         if (grid > need) grid = need > 0 ? need : 1;
         return dispatch_op(cmp, p != nullptr, [&](auto op) -> int {
             constexpr int OP = decltype(op)::value;
-            fgb_atomic_kernel<OP><<<dim3((unsigned)grid), dim3(256), 0, st>>>(p, k, v, n, thr, G, sum, gcnt, pl->err);
+            fgb_atomic_kernel<OP><<<dim3((unsigned)grid), dim3(256), 0, st>>>(p, k, v, n, thr, G, gsum, gcnt, pl->err);
             HIP_TRY(ctx, hipGetLastError());
             return HARK_OK;
         });
     }
     // algo 3: partition + per-bucket LDS aggregation, chunked
     HARK_TRY(plan_prepare_partition(ctx, pl));
-    const int P = (int)pl->P, shift = (int)pl->shift;
-    const size_t lds_part = sizeof(uint2) * kTileRows + sizeof(int) * (4 * (size_t)P + 8);
-    const size_t lds_agg = (size_t)8 << shift;
+    const int P = (int)pl->P, shift = (int)pl->shift, nwg = (int)pl->nwg;
+    const size_t lds_part = sizeof(uint2) * kTileRows + sizeof(int) * (5 * (size_t)P + 8);
+    const size_t lds_agg = (size_t)12 << shift;
     return dispatch_op(cmp, p != nullptr, [&](auto op) -> int {
         constexpr int OP = decltype(op)::value;
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_part_kernel<OP>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part));
+        if (lds_agg > 64 * 1024)
+            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_agg_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_agg));
         for (int64_t r0 = 0; r0 < n; r0 += pl->chunk_rows) {
-            int64_t r1 = r0 + pl->chunk_rows < n ? r0 + pl->chunk_rows : n;
-            int64_t ntiles = (r1 - r0 + kTileRows - 1) / kTileRows;
-            int64_t grid = pl->grid ? pl->grid : (int64_t)ctx->num_cu * 2;
-            if (grid > ntiles) grid = ntiles;
-            fgb_part_kernel<OP><<<dim3((unsigned)grid), dim3(kPartThreads), lds_part, st>>>(
-                p, k, v, r0, r1, thr, G, shift, P, pl->pbuf, pl->cursor, (uint32_t)pl->cap, sum, gcnt, pl->err);
+            const int64_t r1 = r0 + pl->chunk_rows < n ? r0 + pl->chunk_rows : n;
+            fgb_part_kernel<OP><<<dim3((unsigned)nwg), dim3(kPartThreads), lds_part, st>>>(
+                p, k, v, r0, r1, thr, G, shift, P, pl->pbuf, pl->counts, (uint32_t)pl->cap, gsum, gcnt, pl->err);
             HIP_TRY(ctx, hipGetLastError());
             fgb_agg_kernel<<<dim3((unsigned)P), dim3(1024), lds_agg, st>>>(
-                pl->pbuf, pl->cursor, (uint32_t)pl->cap, shift, G, sum, gcnt);
+                pl->pbuf, pl->counts, (uint32_t)pl->cap, nwg, shift, G, gsum, gcnt);
             HIP_TRY(ctx, hipGetLastError());
         }
         return HARK_OK;
     });
 }
 
-int hark_fgb_check(hark_context *ctx, hark_fgb_plan *pl)
+int hark_fgb_finish(hark_context *ctx, hark_fgb_plan *pl, float *sum_out, int64_t *count_out)
 {
     if (!ctx || !pl) return HARK_EARG;
-    int32_t e = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&e, pl->err, sizeof e, hipMemcpyDeviceToHost, ctx->stream));
+    int64_t blocks = (pl->G + 255) / 256;
+    if (blocks > (int64_t)ctx->num_cu * 4) blocks = (int64_t)ctx->num_cu * 4;
+    if (sum_out || count_out) {
+        fgb_finish_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(pl->acc_sum, pl->acc_cnt, pl->G, sum_out, count_out);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    int32_t *e = reinterpret_cast<int32_t *>(ctx->h_pin);
+    HIP_TRY(ctx, hipMemcpyAsync(e, pl->err, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (e != 0) {
+    if (*e != 0) {
+        const int code = *e;
         HIP_TRY(ctx, hipMemsetAsync(pl->err, 0, sizeof(int32_t), ctx->stream));
-        return hark_fail(ctx, e, "filter_groupby: a surviving row has a key outside [0, %lld)", (long long)pl->G);
+        return hark_fail(ctx, code, "filter_groupby: a surviving row has a key outside [0, %lld)", (long long)pl->G);
     }
     return HARK_OK;
 }

@@ -1,0 +1,312 @@
+// k_sort.hip -- stable LSD radix sort of (u32 key, u32 payload) pairs, 8-bit
+// digits (4 passes), plus the key transforms that reduce i32 / f32 / i64 and
+// descending orders to it.
+//
+// Replaces the reference's `rsort`: 32 passes of a 1-bit stable split, each
+// with two scans, a reduce and a scatter of whole rows (groupby.fut:8-22,
+// join.fut:9-23).  Same result (stable, ascending UNSIGNED key), 8x fewer
+// passes, and only (key, row id) moves -- rows are gathered once at the end.
+//
+// One pass = three launches over a fixed decomposition of the input into
+// `nblk` contiguous slices (one workgroup each):
+//   1. digit_hist_kernel   per-slice 256-bin digit histogram -> hist[bin][blk]
+//   2. scan_hist_kernel    exclusive scan in (bin, blk) order = first output
+//                          position of every (digit, slice)
+//   3. digit_scatter_kernel walks its slice in 4096-key tiles; inside a tile a
+//      wave ranks each key among equal digits with a wave64 ballot match (8
+//      ballots + popcount of the lower lanes), waves are chained by a prefix
+//      over per-wave digit counts, keys are staged digit-sorted in LDS and
+//      written out as contiguous runs.  Positions are assigned strictly in
+//      input order, so the pass is stable.
+#include "hark_internal.h"
+
+namespace {
+
+constexpr int kSortThreads = 256;
+constexpr int kSortWaves = kSortThreads / 64;
+constexpr int kRounds = 16;                              // 64-key rounds per wave per tile
+constexpr int kSortTile = kSortThreads * kRounds;        // 4096 keys
+constexpr int kBins = 256;
+
+// Lanes of the wave whose digit equals this lane's digit (among `valid` lanes).
+__device__ __forceinline__ uint64_t match_digit(uint32_t d, bool valid)
+{
+    uint64_t m = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+        const bool bit = (d >> b) & 1u;
+        const uint64_t vote = __ballot(bit);
+        m &= bit ? vote : ~vote;
+    }
+    return m;
+}
+
+__device__ __forceinline__ uint64_t lanemask_lt()
+{
+    const uint32_t lane = threadIdx.x & 63;
+    return lane == 0 ? 0ull : (~0ull >> (64 - lane));
+}
+
+__global__ __launch_bounds__(kSortThreads) void digit_hist_kernel(const uint32_t *__restrict__ keys, int64_t n, int64_t slice,
+                                                                  int shift, uint32_t xor_mask, uint32_t *__restrict__ hist, int nblk)
+{
+    __shared__ uint32_t s_hist[kBins];
+    s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t lo = (int64_t)blockIdx.x * slice;
+    const int64_t hi = lo + slice < n ? lo + slice : n;
+    for (int64_t base = lo; base < hi; base += kSortThreads) {
+        const int64_t i = base + threadIdx.x;
+        const bool valid = i < hi;
+        const uint32_t d = valid ? (((keys[i] ^ xor_mask) >> shift) & 255u) : 0u;
+        const uint64_t peers = match_digit(d, valid);           // one LDS add per distinct digit per wave
+        if (valid && (peers & lanemask_lt()) == 0) atomicAdd(&s_hist[d], (uint32_t)__popcll(peers));
+    }
+    __syncthreads();
+    hist[(size_t)threadIdx.x * nblk + blockIdx.x] = s_hist[threadIdx.x];
+}
+
+// Exclusive scan of m = 256*nblk counters by one workgroup (m <= ~1M).
+__global__ __launch_bounds__(1024) void scan_hist_kernel(uint32_t *__restrict__ hist, int64_t m)
+{
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t base = 0; base < m; base += 4096) {             // 4 counters per thread per step
+        const int64_t i = base + (int64_t)threadIdx.x * 4;
+        uint32_t x[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) x[j] = i + j < m ? hist[i + j] : 0u;
+        const uint32_t tsum = x[0] + x[1] + x[2] + x[3];
+        uint32_t incl = tsum;
+        for (int d = 1; d < 64; d <<= 1) { uint32_t y = __shfl_up(incl, d, 64); if (lane >= d) incl += y; }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t run = s_carry;
+        for (int w = 0; w < wave; w++) run += s_wave[w];
+        run += incl - tsum;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { if (i + j < m) hist[i + j] = run; run += x[j]; }
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = run;
+        __syncthreads();
+    }
+}
+
+// vals_in == nullptr means "payload = input position" (first pass of an argsort).
+__global__ __launch_bounds__(kSortThreads) void digit_scatter_kernel(
+    const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+    uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
+    int64_t n, int64_t slice, int shift, uint32_t xor_mask, const uint32_t *__restrict__ hist, int nblk)
+{
+    __shared__ uint32_t s_key[kSortTile];
+    __shared__ uint32_t s_val[kSortTile];
+    __shared__ uint32_t s_wcnt[kSortWaves][kBins];      // per-wave digit counts of the tile
+    __shared__ uint32_t s_wbase[kSortWaves][kBins];     // tile-local start of (wave, digit)
+    __shared__ uint32_t s_tstart[kBins];                // tile-local start of each digit
+    __shared__ int64_t s_gpos[kBins];                   // global position of the next key of each digit
+    __shared__ uint32_t s_scan[kSortWaves];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t lo = (int64_t)blockIdx.x * slice;
+    const int64_t hi = lo + slice < n ? lo + slice : n;
+    s_gpos[tid] = (int64_t)hist[(size_t)tid * nblk + blockIdx.x];
+    const uint64_t lt = lanemask_lt();
+
+    for (int64_t tbase = lo; tbase < hi; tbase += kSortTile) {
+#pragma unroll
+        for (int w = 0; w < kSortWaves; w++) s_wcnt[w][tid] = 0;
+        __syncthreads();
+        // ---- rank inside the wave's contiguous 1024-key chunk -----------------
+        uint32_t key[kRounds], val[kRounds], rank[kRounds];
+        const int64_t wbase = tbase + (int64_t)wave * (64 * kRounds);
+#pragma unroll
+        for (int r = 0; r < kRounds; r++) {
+            const int64_t i = wbase + r * 64 + lane;
+            const bool valid = i < hi;
+            key[r] = valid ? keys_in[i] : 0u;
+            val[r] = valid ? (vals_in ? vals_in[i] : (uint32_t)i) : 0u;
+            rank[r] = valid ? 0u : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int r = 0; r < kRounds; r++) {
+            const bool valid = rank[r] != 0xFFFFFFFFu;
+            const uint32_t d = ((key[r] ^ xor_mask) >> shift) & 255u;
+            const uint64_t peers = match_digit(d, valid);
+            if (valid) {
+                const uint32_t before = s_wcnt[wave][d];            // count from earlier rounds (wave-private row)
+                rank[r] = before + (uint32_t)__popcll(peers & lt);
+                if ((peers & lt) == 0) s_wcnt[wave][d] = before + (uint32_t)__popcll(peers);
+            }
+            // the leader's store above must land before the next round's loads of the same row
+            __builtin_amdgcn_wave_barrier();
+        }
+        __syncthreads();
+        // ---- chain the waves, lay the digits out in the tile -------------------
+        uint32_t tcnt = 0;
+        {
+            uint32_t run = 0;
+#pragma unroll
+            for (int w = 0; w < kSortWaves; w++) { s_wbase[w][tid] = run; run += s_wcnt[w][tid]; }
+            tcnt = run;                                             // keys of digit `tid` in this tile
+            uint32_t incl = tcnt;
+            for (int d = 1; d < 64; d <<= 1) { uint32_t y = __shfl_up(incl, d, 64); if (lane >= d) incl += y; }
+            if (lane == 63) s_scan[wave] = incl;
+            __syncthreads();
+            uint32_t carry = 0;
+            for (int w = 0; w < wave; w++) carry += s_scan[w];
+            s_tstart[tid] = carry + incl - tcnt;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < kRounds; r++) {
+            if (rank[r] != 0xFFFFFFFFu) {
+                const uint32_t d = ((key[r] ^ xor_mask) >> shift) & 255u;
+                const uint32_t slot = s_tstart[d] + s_wbase[wave][d] + rank[r];
+                s_key[slot] = key[r]; s_val[slot] = val[r];
+            }
+        }
+        __syncthreads();
+        // ---- write digit runs ---------------------------------------------------
+        const int tile_n = (int)((hi - tbase) < kSortTile ? (hi - tbase) : kSortTile);
+        for (int slot = tid; slot < tile_n; slot += kSortThreads) {
+            const uint32_t kk = s_key[slot];
+            const uint32_t d = ((kk ^ xor_mask) >> shift) & 255u;
+            const int64_t pos = s_gpos[d] + (slot - (int)s_tstart[d]);
+            keys_out[pos] = kk; vals_out[pos] = s_val[slot];
+        }
+        __syncthreads();
+        s_gpos[tid] += tcnt;
+        // (the __syncthreads at the top of the next tile orders this update)
+    }
+}
+
+__global__ __launch_bounds__(256) void transform_keys_kernel(const void *__restrict__ src, int dtype, int part, uint32_t *__restrict__ dst, int64_t n)
+{
+    // part 0: the (only / low) 32-bit sort word, part 1: the high word of an i64.
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        uint32_t w;
+        if (dtype == HARK_I64) {
+            const uint64_t x = static_cast<const uint64_t *>(src)[i] ^ 0x8000000000000000ull;
+            w = part ? (uint32_t)(x >> 32) : (uint32_t)x;
+        } else {
+            w = static_cast<const uint32_t *>(src)[i];
+            if (dtype == HARK_I32) w ^= 0x80000000u;
+            else if (dtype == HARK_F32) w ^= (w & 0x80000000u) ? 0xFFFFFFFFu : 0x80000000u;   // total order, -0 < +0
+        }
+        dst[i] = w;
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_u32_kernel(const uint32_t *__restrict__ src, const uint32_t *__restrict__ idx,
+                                                         uint32_t *__restrict__ dst, int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[idx[i]];
+}
+
+__global__ __launch_bounds__(256) void gather_u64_kernel(const uint64_t *__restrict__ src, const uint32_t *__restrict__ idx,
+                                                         uint64_t *__restrict__ dst, int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[idx[i]];
+}
+
+} // namespace
+
+// Workspace bytes for sorting n pairs.
+size_t k_sort_workspace_bytes(int64_t n, int num_cu)
+{
+    int64_t nblk = (n + kSortTile - 1) / kSortTile;
+    if (nblk > (int64_t)num_cu * 8) nblk = (int64_t)num_cu * 8;
+    if (nblk < 1) nblk = 1;
+    return (size_t)kBins * (size_t)nblk * sizeof(uint32_t);
+}
+
+// Stable sort of n (key, val) pairs ascending by (key ^ xor_mask) as unsigned.
+// keys/vals hold the input and receive the output; keys_tmp/vals_tmp are
+// scratch of the same size.  vals_is_iota: payload of the input is the position
+// (vals need not be initialised).  n < 2^32.
+int k_sort_pairs_u32(hark_context *ctx, uint32_t *keys, uint32_t *vals, uint32_t *keys_tmp, uint32_t *vals_tmp,
+                     int64_t n, uint32_t xor_mask, bool vals_is_iota, uint32_t *hist_ws)
+{
+    if (n <= 0) return HARK_OK;
+    if (n > 0xFFFFFFFFll) return hark_fail(ctx, HARK_EARG, "sort: at most 2^32-1 rows");
+    int64_t nblk = (n + kSortTile - 1) / kSortTile;
+    if (nblk > (int64_t)ctx->num_cu * 8) nblk = (int64_t)ctx->num_cu * 8;
+    int64_t slice = (n + nblk - 1) / nblk;
+    slice = (slice + kSortTile - 1) / kSortTile * kSortTile;      // whole tiles per slice
+    nblk = (n + slice - 1) / slice;
+    hipStream_t st = ctx->stream;
+    uint32_t *kin = keys, *vin = vals, *kout = keys_tmp, *vout = vals_tmp;
+    for (int pass = 0; pass < 4; pass++) {
+        const int shift = pass * 8;
+        digit_hist_kernel<<<dim3((unsigned)nblk), dim3(kSortThreads), 0, st>>>(kin, n, slice, shift, xor_mask, hist_ws, (int)nblk);
+        scan_hist_kernel<<<1, 1024, 0, st>>>(hist_ws, (int64_t)kBins * nblk);
+        digit_scatter_kernel<<<dim3((unsigned)nblk), dim3(kSortThreads), 0, st>>>(
+            kin, (pass == 0 && vals_is_iota) ? nullptr : vin, kout, vout, n, slice, shift, xor_mask, hist_ws, (int)nblk);
+        HIP_TRY(ctx, hipGetLastError());
+        uint32_t *t = kin; kin = kout; kout = t;
+        t = vin; vin = vout; vout = t;
+    }
+    // four passes: the result is back in keys / vals
+    return HARK_OK;
+}
+
+int k_transform_keys(hark_context *ctx, const void *src, int dtype, int part, uint32_t *dst, int64_t n)
+{
+    if (n <= 0) return HARK_OK;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > (int64_t)ctx->num_cu * 16) blocks = (int64_t)ctx->num_cu * 16;
+    transform_keys_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(src, dtype, part, dst, n);
+    HIP_TRY(ctx, hipGetLastError());
+    return HARK_OK;
+}
+
+int k_gather(hark_context *ctx, const void *src, int esz, const uint32_t *idx, void *dst, int64_t n)
+{
+    if (n <= 0) return HARK_OK;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > (int64_t)ctx->num_cu * 16) blocks = (int64_t)ctx->num_cu * 16;
+    if (esz == 4) gather_u32_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(static_cast<const uint32_t *>(src), idx, static_cast<uint32_t *>(dst), n);
+    else gather_u64_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(static_cast<const uint64_t *>(src), idx, static_cast<uint64_t *>(dst), n);
+    HIP_TRY(ctx, hipGetLastError());
+    return HARK_OK;
+}
+
+// Stable argsort of a column of any supported dtype.  On return *perm_out
+// (hipMalloc'd, n x u32, caller frees) lists row ids in sorted order; if
+// sorted_keys_out is non-null it receives the sorted 32-bit sort words of the
+// column (u32/i32/f32 only; transformed: use for equality tests only).
+int k_argsort_column(hark_context *ctx, const void *col, int dtype, int64_t n, bool descending,
+                     uint32_t **perm_out, uint32_t **sorted_words_out)
+{
+    *perm_out = nullptr;
+    if (sorted_words_out) *sorted_words_out = nullptr;
+    if (n <= 0) return HARK_OK;
+    uint32_t *k0 = nullptr, *k1 = nullptr, *v0 = nullptr, *v1 = nullptr, *ws = nullptr;
+    const size_t b = (size_t)n * 4;
+    int rc = hark_alloc(ctx, (void **)&k0, b);
+    if (!rc) rc = hark_alloc(ctx, (void **)&k1, b);
+    if (!rc) rc = hark_alloc(ctx, (void **)&v0, b);
+    if (!rc) rc = hark_alloc(ctx, (void **)&v1, b);
+    if (!rc) rc = hark_alloc(ctx, (void **)&ws, k_sort_workspace_bytes(n, ctx->num_cu));
+    const uint32_t xm = descending ? 0xFFFFFFFFu : 0u;
+    if (!rc) rc = k_transform_keys(ctx, col, dtype, 0, k0, n);
+    if (!rc) rc = k_sort_pairs_u32(ctx, k0, v0, k1, v1, n, xm, true, ws);
+    if (!rc && dtype == HARK_I64) {
+        // LSD over 64 bits: after the low word, sort (stably) by the high word
+        // gathered through the current permutation.
+        rc = k_transform_keys(ctx, col, dtype, 1, k1, n);
+        if (!rc) rc = k_gather(ctx, k1, 4, v0, k0, n);
+        if (!rc) rc = k_sort_pairs_u32(ctx, k0, v0, k1, v1, n, xm, false, ws);
+    }
+    if (rc == HARK_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "sort kernels failed");
+    hipFree(k1); hipFree(v1); hipFree(ws);
+    if (rc) { hipFree(k0); hipFree(v0); return rc; }
+    *perm_out = v0;
+    if (sorted_words_out && dtype != HARK_I64) *sorted_words_out = k0; else hipFree(k0);
+    return HARK_OK;
+}

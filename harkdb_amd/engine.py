@@ -106,14 +106,22 @@ class FgbPlan:
         if rc:
             raise _ffi.HarkError(rc, f"fgb_plan_set({key}={value}) rejected")
 
-    def run(self, p, cmp, thr, k, v, n, sum_ptr, count_ptr):
-        """All pointers are raw device addresses (ints)."""
-        self._eng._chk(self._eng.lib.hark_op_filter_groupby_dense_f32(
-            self._eng.ctx, self._h, p, _ffi.CMP[cmp] if isinstance(cmp, str) else int(cmp), float(thr), k, v, int(n),
-            sum_ptr, count_ptr))
+    def reset(self):
+        self._eng._chk(self._eng.lib.hark_fgb_reset(self._eng.ctx, self._h))
 
-    def check(self):
-        self._eng._chk(self._eng.lib.hark_fgb_check(self._eng.ctx, self._h))
+    def run(self, p, cmp, thr, k, v, n):
+        """Accumulate one batch.  All pointers are raw device addresses (ints)."""
+        self._eng._chk(self._eng.lib.hark_op_filter_groupby_dense_f32(
+            self._eng.ctx, self._h, p, _ffi.CMP[cmp] if isinstance(cmp, str) else int(cmp), float(thr), k, v, int(n)))
+
+    def acc_ptrs(self):
+        """(device address of double[G] sums, device address of int64[G] counts)."""
+        s, c = C.c_void_p(), C.c_void_p()
+        self._eng._chk(self._eng.lib.hark_fgb_acc_device(self._h, C.byref(s), C.byref(c)))
+        return s.value, c.value
+
+    def finish(self, sum_ptr=None, count_ptr=None):
+        self._eng._chk(self._eng.lib.hark_fgb_finish(self._eng.ctx, self._h, sum_ptr, count_ptr))
 
     def free(self):
         if self._h is not None:

@@ -21,10 +21,9 @@ def _run(eng, n, G, exact, cmp=">", thr=0.5, use_pred=True, first_row=0, **knobs
     p, k, v = eng.alloc(max(n, 1) * 4), eng.alloc(max(n, 1) * 4), eng.alloc(max(n, 1) * 4)
     eng.gen_columns(SEED, first_row, n, G, exact, p, k, v)
     s, c = eng.alloc(G * 4), eng.alloc(G * 8)
-    eng.zero(s, G * 4); eng.zero(c, G * 8)
     plan = FgbPlan(eng, n, G, **knobs)
-    plan.run(p if use_pred else None, cmp, thr, k, v, n, s, c)
-    plan.check()
+    plan.run(p if use_pred else None, cmp, thr, k, v, n)
+    plan.finish(s, c)
     out = eng.download(s, G, np.float32), eng.download(c, G, np.int64)
     plan.free()
     for ptr in (p, k, v, s, c):
@@ -49,15 +48,19 @@ def test_exact_values_bit_exact(eng, oracle, G, algo, n):
 
 @pytest.mark.parametrize("G,algo", [(16, 1), (4096, 1), (1 << 20, 3)])
 def test_uniform_values_tolerance(eng, oracle, G, algo):
-    """Uniform [0,1) values: f32 sums in device order within 1e-5 relative of
-    the f64 fold; the sequential-f32 oracle is held to the same bar."""
+    """Uniform [0,1) values.  Tolerance stated by BASELINE.json: 1e-5 relative.
+    The device accumulates in f64 and rounds once, so it is held to 1e-6 of the
+    f64 fold; the sequential f32 fold (what a sequential-C backend computes) is
+    itself only ~1e-5 accurate on 1e5-row groups, so device-vs-f32-fold is
+    checked at 1e-5 + the fold's own error."""
     n = 3_000_017
     gs, gc = _run(eng, n, G, False, algo=algo)
     s32, s64, cnt = _oracle(oracle, n, G, False)
     assert np.array_equal(gc, cnt)
-    tol = 1e-5 * np.maximum(np.abs(s64), 1e-30)
-    assert np.all(np.abs(gs.astype(np.float64) - s64) <= tol)
-    assert np.all(np.abs(s32.astype(np.float64) - s64) <= tol)
+    ref = np.maximum(np.abs(s64), 1e-30)
+    assert np.all(np.abs(gs.astype(np.float64) - s64) <= 1e-6 * ref)
+    fold_err = np.abs(s32.astype(np.float64) - s64)
+    assert np.all(np.abs(gs.astype(np.float64) - s32.astype(np.float64)) <= 1e-5 * ref + fold_err)
 
 
 @pytest.mark.parametrize("cmp", [">", ">=", "<", "<=", "=", "!="])
@@ -83,13 +86,12 @@ def test_accumulates_across_calls(eng, oracle):
     n, G = 500_000, 1 << 20
     p, k, v = eng.alloc(n * 4), eng.alloc(n * 4), eng.alloc(n * 4)
     s, c = eng.alloc(G * 4), eng.alloc(G * 8)
-    eng.zero(s, G * 4); eng.zero(c, G * 8)
     plan = FgbPlan(eng, n, G, algo=3)
     for shard in range(2):
         eng.gen_columns(SEED, shard * n, n, G, True, p, k, v)
-        plan.run(p, ">", 0.5, k, v, n, s, c)
+        plan.run(p, ">", 0.5, k, v, n)
         eng.sync()
-    plan.check()
+    plan.finish(s, c)
     gs, gc = eng.download(s, G, np.float32), eng.download(c, G, np.int64)
     s32, _, cnt = _oracle(oracle, 2 * n, G, True)
     assert np.array_equal(gc, cnt) and np.array_equal(gs, s32)
@@ -108,10 +110,9 @@ def test_skewed_keys_overflow_path(eng, oracle):
     p, k, v = eng.alloc(n * 4), eng.alloc(n * 4), eng.alloc(n * 4)
     eng.upload(p, pp); eng.upload(k, kk); eng.upload(v, vv)
     s, c = eng.alloc(G * 4), eng.alloc(G * 8)
-    eng.zero(s, G * 4); eng.zero(c, G * 8)
-    plan = FgbPlan(eng, n, G, algo=3)
-    plan.run(p, ">", 0.5, k, v, n, s, c)
-    plan.check()
+    plan = FgbPlan(eng, n, G, algo=3, slack_pct=1)
+    plan.run(p, ">", 0.5, k, v, n)
+    plan.finish(s, c)
     gs, gc = eng.download(s, G, np.float32), eng.download(c, G, np.int64)
     s32, _, cnt = oracle.filter_groupby_dense_f32(pp, kk, vv, ">", 0.5, G)
     assert np.array_equal(gc, cnt) and np.array_equal(gs, s32)
@@ -126,10 +127,9 @@ def test_key_out_of_range_is_bounds_error(eng):
     p, k, v = eng.alloc(n * 4), eng.alloc(n * 4), eng.alloc(n * 4)
     eng.upload(p, np.ones(n, np.float32)); eng.upload(k, kk); eng.upload(v, np.ones(n, np.float32))
     s, c = eng.alloc(G * 4), eng.alloc(G * 8)
-    eng.zero(s, G * 4); eng.zero(c, G * 8)
     plan = FgbPlan(eng, n, G)
-    plan.run(p, ">", 0.5, k, v, n, s, c)
+    plan.run(p, ">", 0.5, k, v, n)
     with pytest.raises(HarkError) as ei:
-        plan.check()
+        plan.finish(s, c)
     assert ei.value.code == EBOUNDS
     plan.free()

@@ -21,12 +21,11 @@ def run(G, reps=5, **knobs):
     plan = FgbPlan(eng, N, G, **knobs)
     ts = []
     for r in range(reps + 1):
-        eng.zero(s, G * 4); eng.zero(c, G * 8); eng.sync()
+        plan.reset(); eng.sync()
         t0 = time.perf_counter()
-        plan.run(p, ">", 0.5, k, v, N, s, c)
-        eng.sync()
+        plan.run(p, ">", 0.5, k, v, N)
+        plan.finish(s, c)
         ts.append((time.perf_counter() - t0) * 1e3)
-    plan.check()
     cnt = eng.download(c, G, np.int64)
     sm = eng.download(s, G, np.float32)
     ts = sorted(ts[1:])
@@ -39,11 +38,11 @@ def run(G, reps=5, **knobs):
 
 
 print(f"N = {N} rows ({N * 12 / 1e9:.2f} GB)")
-for G in (16, 256, 4096):
+for G in (16, 256, 4096, 8192):
     run(G, algo=1)
-run(8192, algo=1)
 run(1 << 20, reps=2, algo=2)
-for chunk in (8 << 20, 16 << 20, 64 << 20, N):
-    run(1 << 20, algo=3, chunk_rows=chunk)
-run(1 << 20, algo=3, chunk_rows=16 << 20, shift=10)
-run(1 << 20, algo=3, chunk_rows=16 << 20, shift=13)
+for chunk in (1 << 26, 1 << 28, 1 << 30):
+    if chunk <= N or chunk == 1 << 26:
+        run(1 << 20, algo=3, chunk_rows=chunk)
+run(1 << 20, algo=3, chunk_rows=1 << 28, shift=11)
+run(1 << 20, algo=3, chunk_rows=1 << 28, shift=13)
