@@ -39,7 +39,6 @@
 namespace {
 
 constexpr int kVec = 4;                 // rows per 16-byte load
-constexpr uint32_t kInvalidKey = 0xFFFFFFFFu;
 constexpr int kNoPred = -1;
 
 template <int OP>
@@ -185,136 +184,136 @@ __global__ __launch_bounds__(256) void fgb_atomic_kernel(
 // ---------------------------------------------------------------------------
 // Partition path, PRODUCER: route surviving (key,value) pairs by key range
 // ---------------------------------------------------------------------------
+// Software write-combining.  Every bucket owns a small circular queue in LDS
+// (kQ pairs).  A batch of rows is enqueued with one returning LDS atomic per
+// surviving row (ds_add_rtn_u32 on the bucket's fill count), then 8-lane groups
+// sweep the buckets and store every complete 128-byte line (16 pairs, one
+// dwordx4 per lane) to the workgroup's slab of that bucket.  Only whole, aligned
+// lines ever leave the CU (appending the ~16-pair runs of a tile directly cost
+// 2.2x the time of the same stores made contiguous: half-written lines get
+// evicted), there is no sort of the tile, and two barriers per batch.
+// A pair that finds its queue full stays in its lane and retries after the
+// flush, so skewed keys slow the producer down but cannot overflow LDS; a full
+// SLAB (heavier skew than the plan's slack) falls back to direct atomics.
+constexpr int kLine = 16;                                // pairs per 128-byte line
+constexpr int kQ = 32;                                   // queue capacity per bucket (pairs)
 constexpr int kPartThreads = 512;
-constexpr int kRowsPerThread = 16;                       // 4 x 16-byte loads per column
-constexpr int kTileRows = kPartThreads * kRowsPerThread; // 8192 rows -> 64 KiB of staged pairs
-constexpr int kMaxBuckets = 1024;
+constexpr int kBatchRows = kPartThreads * kVec;          // 2048 rows per batch
+constexpr int kMaxBuckets = 256;                         // 256 * kQ * 8 B = 64 KiB of queues
+constexpr int kTileRows = 8192;                          // chunk granularity (multiple of kBatchRows)
 
-// Slab of (bucket b, workgroup w): pbuf[(b*nwg + w)*cap .. +cap).
-// LDS: uint2 stage[kTileRows]; int cnt[P], off[P], delta[P], fit[P], cur[P]; int wsum[8]
+static size_t part_lds_bytes(int P) { return sizeof(uint2) * (size_t)P * kQ + sizeof(int) * 3 * (size_t)P; }
+
 template <int OP>
 __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
     const float *__restrict__ p, const int32_t *__restrict__ k, const float *__restrict__ v,
     int64_t row0, int64_t row1, float thr, int64_t G, int shift, int P,
     uint2 *__restrict__ pbuf, uint32_t *__restrict__ counts, uint32_t cap,
-    double *__restrict__ gsum, unsigned long long *__restrict__ gcnt, int32_t *__restrict__ err)
+    double *__restrict__ gsum, unsigned long long *__restrict__ gcnt, int32_t *__restrict__ err, int ablate)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    uint2 *stage = reinterpret_cast<uint2 *>(lds_raw);
-    int *s_cnt = reinterpret_cast<int *>(lds_raw + sizeof(uint2) * kTileRows);
-    int *s_off = s_cnt + P;
-    int *s_delta = s_off + P;
-    int *s_fit = s_delta + P;
-    int *s_cur = s_fit + P;                               // this workgroup's fill of each bucket slab
-    int *s_wsum = s_cur + P;                              // per-wave scan carries
+    uint2 *queue = reinterpret_cast<uint2 *>(lds_raw);                 // [P][kQ]
+    int *s_cnt = reinterpret_cast<int *>(queue + (size_t)P * kQ);      // pairs queued per bucket
+    int *s_head = s_cnt + P;                                           // queue index of the oldest pair (multiple of kLine)
+    int *s_lcur = s_head + P;                                          // lines already stored in this workgroup's slab
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
     const int nwg = gridDim.x, wg = blockIdx.x;
-    const int64_t ntiles = (row1 - row0 + kTileRows - 1) / kTileRows;
+    const int64_t nbatch = (row1 - row0 + kBatchRows - 1) / kBatchRows;
+    const int cap_lines = (int)(cap / kLine) - 1;                      // the last line is kept for the final partial flush
     bool bad = false;
-    for (int b = tid; b < P; b += kPartThreads) s_cur[b] = 0;
-
-    for (int64_t tile = wg; tile < ntiles; tile += nwg) {
-        for (int b = tid; b < P; b += kPartThreads) s_cnt[b] = 0;
-        __syncthreads();
-
-        // rows of this thread: 4 groups of 4 consecutive rows, group g at
-        // tile_base + (g*512 + tid)*4 -> every wave-instruction reads 1 KiB.
-        const int64_t tbase = row0 + tile * kTileRows;
-        uint32_t keys[kRowsPerThread];
-        float vals[kRowsPerThread];
-        int rank[kRowsPerThread];
-        float4 pr[4]; int4 kr[4]; float4 vr[4];
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-            int64_t r = tbase + ((int64_t)g * kPartThreads + tid) * kVec;
-            if (r + kVec <= row1) {
-                pr[g] = OP == kNoPred ? float4{0, 0, 0, 0} : *reinterpret_cast<const float4 *>(p + r);
-                kr[g] = *reinterpret_cast<const int4 *>(k + r);
-                vr[g] = *reinterpret_cast<const float4 *>(v + r);
-            } else {                                   // ragged end of the table: scalar loads
-                float pp[4] = {0, 0, 0, 0}; int kk[4] = {0, 0, 0, 0}; float vv[4] = {0, 0, 0, 0};
-                for (int j = 0; j < kVec; j++) if (r + j < row1) {
-                    pp[j] = OP == kNoPred ? 0.0f : p[r + j]; kk[j] = k[r + j]; vv[j] = v[r + j];
-                }
-                pr[g] = float4{pp[0], pp[1], pp[2], pp[3]};
-                kr[g] = int4{kk[0], kk[1], kk[2], kk[3]};
-                vr[g] = float4{vv[0], vv[1], vv[2], vv[3]};
-            }
-        }
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-            const float pv[4] = {pr[g].x, pr[g].y, pr[g].z, pr[g].w};
-            const int kv[4] = {kr[g].x, kr[g].y, kr[g].z, kr[g].w};
-            const float vv[4] = {vr[g].x, vr[g].y, vr[g].z, vr[g].w};
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int q = g * 4 + j;
-                const int64_t r = tbase + ((int64_t)g * kPartThreads + tid) * kVec + j;
-                bool keep = r < row1 && cmp_f32<OP>(pv[j], thr);
-                uint32_t key = (uint32_t)kv[j];
-                if (keep && !(kv[j] >= 0 && (int64_t)key < G)) { bad = true; keep = false; }
-                keys[q] = key; vals[q] = vv[j];
-                rank[q] = keep ? atomicAdd(&s_cnt[key >> shift], 1) : -1;   // ds_add_rtn_u32
-            }
-        }
-        __syncthreads();
-
-        // exclusive scan of s_cnt[0..P) (P <= 1024: two buckets per thread), and
-        // reservation of room in this workgroup's slabs (private cursors).
-        {
-            const int b0 = tid * 2, b1 = tid * 2 + 1;
-            const int c0 = b0 < P ? s_cnt[b0] : 0, c1 = b1 < P ? s_cnt[b1] : 0;
-            const int x = c0 + c1;
-            int incl = x;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { int y = __shfl_up(incl, d, 64); if (lane >= d) incl += y; }
-            if (lane == 63) s_wsum[wave] = incl;
-            __syncthreads();
-            int carry = 0;
-            for (int w = 0; w < wave; w++) carry += s_wsum[w];
-            const int excl = carry + incl - x;
-            if (b0 < P) {
-                const int cur = s_cur[b0];
-                const int fit = min(c0, (int)cap - cur);
-                s_off[b0] = excl; s_fit[b0] = fit; s_delta[b0] = cur - excl; s_cur[b0] = cur + fit;
-            }
-            if (b1 < P) {
-                const int cur = s_cur[b1];
-                const int fit = min(c1, (int)cap - cur);
-                s_off[b1] = excl + c0; s_fit[b1] = fit; s_delta[b1] = cur - (excl + c0); s_cur[b1] = cur + fit;
-            }
-        }
-        __syncthreads();
-        int total = 0;
-        for (int w = 0; w < kPartThreads / 64; w++) total += s_wsum[w];
-
-#pragma unroll
-        for (int q = 0; q < kRowsPerThread; q++) {
-            if (rank[q] >= 0) {
-                const uint32_t b = keys[q] >> shift;
-                const int slot = s_off[b] + rank[q];
-                if (rank[q] < s_fit[b]) {
-                    stage[slot] = uint2{keys[q], __float_as_uint(vals[q])};
-                } else {                      // slab full (skewed keys): direct atomics
-                    stage[slot] = uint2{kInvalidKey, 0u};
-                    unsafeAtomicAdd(&gsum[keys[q]], (double)vals[q]);
-                    atomicAdd(&gcnt[keys[q]], 1ull);
-                }
-            }
-        }
-        __syncthreads();
-        for (int slot = tid; slot < total; slot += kPartThreads) {
-            const uint2 pr2 = stage[slot];
-            if (pr2.x != kInvalidKey) {
-                const uint32_t b = pr2.x >> shift;
-                pbuf[((size_t)b * nwg + wg) * cap + (uint32_t)(s_delta[b] + slot)] = pr2;
-            }
-        }
-        __syncthreads();
-    }
+    for (int b = tid; b < P; b += kPartThreads) { s_cnt[b] = 0; s_head[b] = 0; s_lcur[b] = 0; }
     __syncthreads();
-    for (int b = tid; b < P; b += kPartThreads) counts[(size_t)b * nwg + wg] = (uint32_t)s_cur[b];
+
+    auto load = [&](int64_t batch, float4 &pr, int4 &kr, float4 &vr) {
+        const int64_t r = row0 + batch * kBatchRows + (int64_t)tid * kVec;
+        if (r + kVec <= row1) {
+            pr = OP == kNoPred ? float4{0, 0, 0, 0} : *reinterpret_cast<const float4 *>(p + r);
+            kr = *reinterpret_cast<const int4 *>(k + r);
+            vr = *reinterpret_cast<const float4 *>(v + r);
+        } else {                                                       // ragged end of the table
+            float pp[4] = {0, 0, 0, 0}; int kk[4] = {0, 0, 0, 0}; float vv[4] = {0, 0, 0, 0};
+            for (int j = 0; j < kVec; j++) if (r + j < row1) {
+                pp[j] = OP == kNoPred ? 0.0f : p[r + j]; kk[j] = k[r + j]; vv[j] = v[r + j];
+            }
+            pr = float4{pp[0], pp[1], pp[2], pp[3]}; kr = int4{kk[0], kk[1], kk[2], kk[3]}; vr = float4{vv[0], vv[1], vv[2], vv[3]};
+        }
+    };
+
+    float4 npr; int4 nkr; float4 nvr;
+    if ((int64_t)wg < nbatch) load(wg, npr, nkr, nvr);
+    for (int64_t batch = wg; batch < nbatch; batch += nwg) {
+        const float4 pr = npr; const int4 kr = nkr; const float4 vr = nvr;
+        if (batch + nwg < nbatch) load(batch + nwg, npr, nkr, nvr);       // next batch's loads fly during this one
+        const float pv[4] = {pr.x, pr.y, pr.z, pr.w};
+        const int kv[4] = {kr.x, kr.y, kr.z, kr.w};
+        const float vv[4] = {vr.x, vr.y, vr.z, vr.w};
+        const int64_t r = row0 + batch * kBatchRows + (int64_t)tid * kVec;
+        uint32_t pending = 0;
+#pragma unroll
+        for (int j = 0; j < kVec; j++) {
+            bool keep = r + j < row1 && cmp_f32<OP>(pv[j], thr);
+            if (keep && !(kv[j] >= 0 && (int64_t)(uint32_t)kv[j] < G)) { bad = true; keep = false; }
+            if (keep) pending |= 1u << j;
+        }
+        if (ablate & 4) { asm volatile("" :: "v"(pending), "v"(vv[0]), "v"(vv[1]), "v"(vv[2]), "v"(vv[3])); pending = 0; }
+        bool again;
+        int rounds = 0;
+        do {
+            // ---- enqueue: one returning LDS atomic per surviving row
+#pragma unroll
+            for (int j = 0; j < kVec; j++) {
+                if (pending & (1u << j)) {
+                    const uint32_t key = (uint32_t)kv[j], b = key >> shift;
+                    const int pos = atomicAdd(&s_cnt[b], 1);
+                    if (pos < kQ) {
+                        queue[b * kQ + ((s_head[b] + pos) & (kQ - 1))] = uint2{key, __float_as_uint(vv[j])};
+                        pending &= ~(1u << j);
+                    } else atomicSub(&s_cnt[b], 1);                       // queue full: retry after the flush
+                }
+            }
+            __syncthreads();
+            // ---- flush: 8 lanes per bucket store its complete lines, 16 bytes per lane
+            if (!(ablate & 2))
+            for (int b = tid >> 3; b < P; b += kPartThreads / 8) {
+                const int cnt = s_cnt[b];
+                const int lines = cnt / kLine;
+                if (lines) {
+                    const int i = tid & 7, head = s_head[b], lc = s_lcur[b];
+                    for (int q = 0; q < lines; q++) {
+                        const uint4 two = *reinterpret_cast<const uint4 *>(&queue[b * kQ + ((head + q * kLine) & (kQ - 1)) + 2 * i]);
+                        if (lc + q < cap_lines) {
+                            if (!(ablate & 1))
+                                *reinterpret_cast<uint4 *>(&pbuf[((size_t)b * nwg + wg) * cap + (size_t)(lc + q) * kLine + 2 * i]) = two;
+                        } else {                                           // slab full: direct atomics
+                            unsafeAtomicAdd(&gsum[two.x], (double)__uint_as_float(two.y)); atomicAdd(&gcnt[two.x], 1ull);
+                            unsafeAtomicAdd(&gsum[two.z], (double)__uint_as_float(two.w)); atomicAdd(&gcnt[two.z], 1ull);
+                        }
+                    }
+                    if (i == 0) {
+                        s_cnt[b] = cnt - lines * kLine;
+                        s_head[b] = (head + lines * kLine) & (kQ - 1);
+                        s_lcur[b] = min(lc + lines, cap_lines);
+                    }
+                }
+            }
+            if (++rounds >= 96 || (ablate & 2)) {                         // bounded: leftovers go through direct atomics
+#pragma unroll
+                for (int j = 0; j < kVec; j++)
+                    if ((pending & (1u << j)) && !(ablate & 2)) {
+                        unsafeAtomicAdd(&gsum[(uint32_t)kv[j]], (double)vv[j]); atomicAdd(&gcnt[(uint32_t)kv[j]], 1ull);
+                    }
+                pending = 0;
+            }
+            again = __syncthreads_or(pending != 0);
+        } while (again);
+    }
+    // ---- final flush: what is left (< kLine pairs per bucket) goes out as one partial line
+    for (int b = tid; b < P; b += kPartThreads) {
+        const int l = s_cnt[b], head = s_head[b];
+        const size_t base = ((size_t)b * nwg + wg) * cap + (size_t)s_lcur[b] * kLine;
+        for (int j = 0; j < l; j++) pbuf[base + j] = queue[b * kQ + ((head + j) & (kQ - 1))];
+        counts[(size_t)b * nwg + wg] = (uint32_t)(s_lcur[b] * kLine + l);
+    }
     if (bad) *err = HARK_EBOUNDS;
 }
 
@@ -454,6 +453,8 @@ int hark_fgb_plan_set(hark_fgb_plan *pl, const char *key, int64_t value)
     else if (!strcmp(key, "grid")) { if (value < 0 || value > 65535) return HARK_EARG; pl->grid = value; }
     else if (!strcmp(key, "shift")) { if (value < 0 || value > 13) return HARK_EARG; pl->shift = value; }
     else if (!strcmp(key, "slack_pct")) { if (value < 0 || value > 10000) return HARK_EARG; pl->slack_pct = value; }
+    else if (!strcmp(key, "variant")) { if (value < 0 || value > 3) return HARK_EARG; pl->variant = value; return HARK_OK; }
+    else if (!strcmp(key, "ablate")) { pl->ablate = value; return HARK_OK; }   // timing experiments only: wrong results
     else return HARK_EARG;
     plan_drop_partition(pl);     // partition geometry depends on the knobs
     return HARK_OK;
@@ -495,7 +496,7 @@ static int plan_prepare_partition(hark_context *ctx, hark_fgb_plan *pl)
     // row survives, plus room for the fluctuation of a few tiles
     const int64_t slack = pl->slack_pct ? pl->slack_pct : 130;
     int64_t cap = chunk / (pl->P * pl->nwg) * slack / 100 + 256;
-    cap = (cap + 1) & ~(int64_t)1;
+    cap = (cap + kLine - 1) / kLine * kLine + 2 * kLine;      // whole 128-byte lines; one spare for the final flush
     if (cap > 0x7FFFFFF0ll) return hark_fail(ctx, HARK_EARG, "fgb: chunk too large");
     pl->cap = cap;
     HARK_TRY(hark_alloc(ctx, (void **)&pl->pbuf, (size_t)pl->P * (size_t)pl->nwg * (size_t)cap * sizeof(uint2)));
@@ -552,19 +553,19 @@ int k_fgb_dense_f32(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cm
     // algo 3: partition + per-bucket LDS aggregation, chunked
     HARK_TRY(plan_prepare_partition(ctx, pl));
     const int P = (int)pl->P, shift = (int)pl->shift, nwg = (int)pl->nwg;
-    const size_t lds_part = sizeof(uint2) * kTileRows + sizeof(int) * (5 * (size_t)P + 8);
     const size_t lds_agg = (size_t)12 << shift;
     return dispatch_op(cmp, p != nullptr, [&](auto op) -> int {
         constexpr int OP = decltype(op)::value;
-        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_part_kernel<OP>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part));
         if (lds_agg > 64 * 1024)
             HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_agg_kernel),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_agg));
+        const size_t lds_part = part_lds_bytes(P);
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_part_kernel<OP>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part));
         for (int64_t r0 = 0; r0 < n; r0 += pl->chunk_rows) {
             const int64_t r1 = r0 + pl->chunk_rows < n ? r0 + pl->chunk_rows : n;
             fgb_part_kernel<OP><<<dim3((unsigned)nwg), dim3(kPartThreads), lds_part, st>>>(
-                p, k, v, r0, r1, thr, G, shift, P, pl->pbuf, pl->counts, (uint32_t)pl->cap, gsum, gcnt, pl->err);
+                p, k, v, r0, r1, thr, G, shift, P, pl->pbuf, pl->counts, (uint32_t)pl->cap, gsum, gcnt, pl->err, (int)pl->ablate);
             HIP_TRY(ctx, hipGetLastError());
             fgb_agg_kernel<<<dim3((unsigned)P), dim3(1024), lds_agg, st>>>(
                 pl->pbuf, pl->counts, (uint32_t)pl->cap, nwg, shift, G, gsum, gcnt);
