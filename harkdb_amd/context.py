@@ -1,0 +1,170 @@
+"""FutharkContext: the user-facing surface of HarkDB, MI355X edition.
+
+Mirrors the reference's FutharkContext.py:38-71 method for method:
+
+    fc = FutharkContext()
+    fc.create_table('game_1', 'data.csv' | DataFrame | ndarray)
+    fc.sql("select col1, max(col3) from game_1 group by col1")  -> numpy array
+    fc.drop_table('game_1')
+
+What differs underneath: `create_table` uploads the table ONCE into per-column
+HBM buffers (the reference keeps a host array and re-passes it through the FFI
+on every query, FutharkContext.py:62-70), and `sql` dispatches to the HIP entry
+points of libhark.so (include/hark.h) instead of a Futhark-generated module.
+
+Result shape.  For the two statement forms the reference implements, `sql`
+returns exactly what the reference returns:
+  * projection           -> int32 [n][k]                    (select.fut:23)
+  * GROUP BY with prod/sum/max/min over integer columns
+                         -> uint32 [G][1+k], LEADING KEY COLUMN, ascending
+                            unsigned key                    (groupby.fut:51-62)
+Anything the reference cannot express (WHERE, HAVING, ORDER BY, LIMIT, COUNT,
+AVG, float / int64 columns, or `sql_mode=True`) takes the SQL-typed path and
+returns exactly the select list.
+"""
+import numpy as np
+
+from . import _ffi
+from .engine import Engine
+from .parse import sql_parse
+from .table import Table
+
+_AGG_NAME = {"key": "key", "prod": "prod", "sum": "sum", "max": "max", "min": "min", "count": "count", "avg": "avg"}
+
+
+class FutharkContext:
+
+    def __init__(self, device=0, sql_mode=False):
+        self.FutEnv = Engine(device)          # FutharkContext.py:41 `self.FutEnv = Futhark(_main)`
+        self.tables = {}                      # FutharkContext.py:42
+        self.sql_mode = sql_mode
+
+    # FutharkContext.py:44-50
+    def create_table(self, table_name, table):
+        """Stores a table and uploads it to the GPU, one buffer per column."""
+        table = Table(table_name, table)
+        table._device = self.FutEnv.table_from_columns(table.host_columns())
+        self.tables[table_name] = table
+
+    # FutharkContext.py:52-53
+    def drop_table(self, table_name):
+        t = self.tables.pop(table_name)
+        if t._device is not None:
+            t._device.free()
+
+    # FutharkContext.py:55-71
+    def sql(self, sql_statement):
+        names, cols = self.sql_columns(sql_statement)
+        if not cols:
+            return np.empty((0, 0), dtype=np.int32)
+        dts = {c.dtype for c in cols}
+        dtype = dts.pop() if len(dts) == 1 else np.result_type(*[c.dtype for c in cols])
+        return np.stack([c.astype(dtype, copy=False) for c in cols], axis=1)
+
+    def sql_columns(self, sql_statement):
+        """Like sql() but returns (column names, list of typed numpy columns)."""
+        val_dic = sql_parse(self.tables, sql_statement)                    # FutharkContext.py:61
+        table = self.tables[val_dic["table_name"]]
+        dev, eng = table._device, self.FutEnv
+        schema = table.get_schema()
+        extended = val_dic["extended"] or self.sql_mode
+        int32ish = all(dev.dtype(j) in (np.int32, np.uint32) for j in range(dev.shape[1]))
+
+        if "groupbys" not in val_dic:                                      # FutharkContext.py:64-66
+            sel_cols = val_dic["select"]
+            names = [schema[c] for c in sel_cols]
+            if not extended:
+                res = eng.query_sel(dev, sel_cols)
+                return names, res.columns()
+            return names, self._select_extended(dev, val_dic)
+
+        # FutharkContext.py:67-71
+        if not extended and int32ish:
+            res = eng.query_groupby(dev, val_dic["g_col"], val_dic["select"], val_dic["groupbys"])
+            cols = [c.view(np.uint32) for c in res.columns()]
+            names = [schema[val_dic["g_col"]]] + [f"{_AGG_NAME[i[0]]}({schema[i[1]]})" if i[0] != "key" else schema[i[1]]
+                                                  for i in val_dic["items"]]
+            return names, cols
+        return self._groupby_extended(dev, schema, val_dic)
+
+    # ---- extension paths ---------------------------------------------------------
+    def _filtered(self, dev, where, need_cols):
+        """Apply an AND-list of predicates on the device; returns (table-like, column map)."""
+        eng = self.FutEnv
+        cur, cmap = dev, {c: c for c in range(dev.shape[1])}
+        keep = None
+        for i, (col, cmp, value) in enumerate(where):
+            later = {c for c, _, _ in where[i + 1:]}
+            proj = sorted(set(need_cols) | later)
+            res = eng.filter_sel(cur, cmap[col], cmp, value, [cmap[c] for c in proj], want_row_index=False)
+            n = res.shape[0]
+            cur = eng.table_from_device(n, [res.device_ptr(j) for j in range(len(proj))],
+                                        [res.dtype(j) for j in range(len(proj))], keepalive=(res, keep))
+            keep = cur
+            cmap = {c: j for j, c in enumerate(proj)}
+        return cur, cmap
+
+    def _select_extended(self, dev, ir):
+        eng = self.FutEnv
+        sel = ir["select"]
+        need = set(sel)
+        ob = ir.get("orderby")
+        if ob:
+            need.add(ob[0][1])
+        cur, cmap = self._filtered(dev, ir.get("where", []), need) if ir.get("where") else (dev, {c: c for c in range(dev.shape[1])})
+        if ob:
+            res = eng.sort(cur, cmap[ob[0][1]], [cmap[c] for c in sel], descending=ob[1])
+        else:
+            res = eng.query_sel(cur, [cmap[c] for c in sel])
+        cols = res.columns()
+        if "limit" in ir:
+            cols = [c[: ir["limit"]] for c in cols]
+        return cols
+
+    def _groupby_extended(self, dev, schema, ir):
+        eng = self.FutEnv
+        g_col, items = ir["g_col"], list(ir["items"])
+        # every aggregate the query mentions (select list, HAVING, ORDER BY), deduplicated
+        aggs = []
+
+        def agg_slot(spec):
+            if spec[0] == "key":
+                return 0
+            if spec[0] == "col":
+                raise Exception(f"{schema[spec[1]]} is not an aggregation function or the columns thats grouped on")
+            if spec not in aggs:
+                aggs.append(spec)
+            return 1 + aggs.index(spec)
+
+        out_slots = [agg_slot(i) for i in items]
+        having = [(agg_slot(s), cmp, v) for s, cmp, v in ir.get("having", [])]
+        order = (agg_slot(ir["orderby"][0]), ir["orderby"][1]) if "orderby" in ir else None
+
+        where = ir.get("where", [])
+        need = {g_col} | {c for _, c in aggs if c is not None}
+        cur, cmap = dev, {c: c for c in range(dev.shape[1])}
+        first = None
+        if len(where) == 1:
+            first = (where[0][0], where[0][1], where[0][2])
+        elif len(where) > 1:
+            cur, cmap = self._filtered(dev, where, need)
+        res = eng.filter_groupby(cur, None if first is None else (cmap[first[0]], first[1], first[2]), cmap[g_col],
+                                 [(f, 0 if c is None else cmap[c]) for f, c in aggs])
+        # HAVING / ORDER BY run on the G-row result, still on the device
+        keep = [res]
+        for slot, cmp, v in having:
+            m = res.shape[1]
+            t = eng.table_from_device(res.shape[0], [res.device_ptr(j) for j in range(m)], [res.dtype(j) for j in range(m)], keepalive=res)
+            res = eng.filter_sel(t, slot, cmp, v, list(range(m)), want_row_index=False)
+            keep += [t, res]
+        if order is not None:
+            m = res.shape[1]
+            t = eng.table_from_device(res.shape[0], [res.device_ptr(j) for j in range(m)], [res.dtype(j) for j in range(m)], keepalive=res)
+            res = eng.sort(t, order[0], list(range(m)), descending=order[1])
+            keep += [t, res]
+        cols = res.columns()
+        out = [cols[s] for s in out_slots]
+        if "limit" in ir:
+            out = [c[: ir["limit"]] for c in out]
+        names = [schema[c] if f == "key" else f"{f}({'*' if c is None else schema[c]})" for f, c in items]
+        return names, out

@@ -93,5 +93,7 @@ int k_fgb_dense_f32(hark_context *ctx, hark_fgb_plan *plan, const float *p, int 
                     const int32_t *k, const float *v, int64_t n);
 
 // k_select.hip
+int k_groupby_typed(hark_context *ctx, const hark_table *db, int32_t g_col, const int32_t *agg_cols,
+                    const int32_t *agg_ops, int64_t n_aggs, hark_result *res);
 int k_gather_columns(hark_context *ctx, const hark_table *db, const int32_t *cols, int64_t k,
                      hark_result *res);

@@ -1,0 +1,495 @@
+// k_groupby.hip -- GROUP BY over arbitrary (sparse) keys.
+//
+//   hark_entry_query_groupby   the reference's entry (main.fut:9 ->
+//       groupby.fut:51-62): u32 keys in ascending UNSIGNED order, one u32
+//       column per opcode of `type_func` (groupby.fut:35-41), a leading key
+//       column.  The reference materialises rows, sorts them with 32 one-bit
+//       passes and runs a segmented scan with `merge`; every opcode is
+//       commutative and associative on u32 (wrapping *, +, max, min), so the
+//       fold order does not show in the result and any reduction tree is
+//       bit-exact with the sequential fold.
+//   hark_entry_filter_groupby  the SQL-typed extension (WHERE + typed keys and
+//       aggregates, COUNT/AVG), with the fused dense-key kernels of k_fgb.hip
+//       behind it when the query has that shape.
+//
+// Device plan for both: stable argsort of the key column (k_sort.hip, 4 x
+// 8-bit passes over (key, row id) only) -> head flags -> prefix sum = group
+// ids -> per aggregate a gather through the permutation and a wave64 segmented
+// scan whose run tails are combined into 64-bit accumulators with one atomic
+// per (wave, group) -> typed finalisation.
+#include "hark_internal.h"
+
+int k_argsort_column(hark_context *ctx, const void *col, int dtype, int64_t n, bool descending,
+                     uint32_t **perm_out, uint32_t **sorted_words_out);
+int k_gather(hark_context *ctx, const void *src, int esz, const uint32_t *idx, void *dst, int64_t n);
+int k_exclusive_scan_u32(hark_context *ctx, const uint32_t *in, int64_t n, uint32_t *out32, int64_t *out64, int64_t *total_host);
+
+namespace {
+
+typedef unsigned long long u64;
+enum { ACC_U64 = 0, ACC_I64 = 1, ACC_F64 = 2 };
+enum { OP_SUM = 0, OP_PROD = 1, OP_MAX = 2, OP_MIN = 3 };
+
+__device__ __forceinline__ u64 d2u(double d) { return (u64)__double_as_longlong(d); }
+__device__ __forceinline__ double u2d(u64 u) { return __longlong_as_double((long long)u); }
+
+__device__ __forceinline__ u64 combine(int kind, int op, u64 a, u64 b)
+{
+    if (kind == ACC_F64) {
+        const double x = u2d(a), y = u2d(b);
+        switch (op) {
+        case OP_SUM: return d2u(x + y);
+        case OP_PROD: return d2u(x * y);
+        case OP_MAX: return d2u(x > y ? x : y);
+        default: return d2u(x < y ? x : y);
+        }
+    }
+    switch (op) {
+    case OP_SUM: return a + b;
+    case OP_PROD: return a * b;
+    case OP_MAX: return kind == ACC_I64 ? ((long long)a > (long long)b ? a : b) : (a > b ? a : b);
+    default: return kind == ACC_I64 ? ((long long)a < (long long)b ? a : b) : (a < b ? a : b);
+    }
+}
+
+__host__ __device__ inline u64 identity_of(int kind, int op)
+{
+    if (kind == ACC_F64) {
+        const double v = op == OP_SUM ? 0.0 : op == OP_PROD ? 1.0 : op == OP_MAX ? -__builtin_huge_val() : __builtin_huge_val();
+        u64 u; memcpy(&u, &v, 8); return u;
+    }
+    if (op == OP_SUM) return 0;
+    if (op == OP_PROD) return 1;
+    if (op == OP_MAX) return kind == ACC_I64 ? 0x8000000000000000ull : 0ull;
+    return kind == ACC_I64 ? 0x7FFFFFFFFFFFFFFFull : ~0ull;
+}
+
+__device__ __forceinline__ void atomic_combine(int kind, int op, u64 *dst, u64 x)
+{
+    if (op == OP_SUM && kind != ACC_F64) { atomicAdd(dst, x); return; }
+    if (op == OP_SUM) { unsafeAtomicAdd(reinterpret_cast<double *>(dst), u2d(x)); return; }
+    u64 old = *dst, assumed;
+    do {
+        assumed = old;
+        const u64 want = combine(kind, op, assumed, x);
+        if (want == assumed) break;
+        old = atomicCAS(dst, assumed, want);
+    } while (old != assumed);
+}
+
+// value of row `r` of a column, widened to the accumulator representation
+__device__ __forceinline__ u64 load_as_acc(const void *col, int dtype, uint32_t r, int kind)
+{
+    if (kind == ACC_F64) {                       // SUM/AVG/MIN/MAX of f32, AVG of integers
+        switch (dtype) {
+        case HARK_I32: return d2u((double)static_cast<const int32_t *>(col)[r]);
+        case HARK_U32: return d2u((double)static_cast<const uint32_t *>(col)[r]);
+        case HARK_F32: return d2u((double)static_cast<const float *>(col)[r]);
+        default: return d2u((double)static_cast<const long long *>(col)[r]);
+        }
+    }
+    switch (dtype) {
+    case HARK_I32: return (u64)(long long)static_cast<const int32_t *>(col)[r];
+    case HARK_U32: return (u64)static_cast<const uint32_t *>(col)[r];
+    case HARK_F32: return d2u((double)static_cast<const float *>(col)[r]);
+    default: return static_cast<const u64 *>(col)[r];
+    }
+}
+
+__global__ __launch_bounds__(256) void fill_u64_kernel(u64 *__restrict__ dst, int64_t n, u64 v)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = v;
+}
+
+// flags[i] = first row of a run of equal keys (groupby.fut:26-33 mk_flags), on
+// the key column gathered into sorted order (4- or 8-byte elements).
+__global__ __launch_bounds__(256) void head_flags_kernel(const void *__restrict__ sorted_keys, int esz, int64_t n, uint32_t *__restrict__ flags)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        bool head = i == 0;
+        if (!head) {
+            if (esz == 4) head = static_cast<const uint32_t *>(sorted_keys)[i] != static_cast<const uint32_t *>(sorted_keys)[i - 1];
+            else head = static_cast<const u64 *>(sorted_keys)[i] != static_cast<const u64 *>(sorted_keys)[i - 1];
+        }
+        flags[i] = head ? 1u : 0u;
+    }
+}
+
+// seg[i] = (exclusive scan of flags)[i] + flags[i] - 1, in place over the scan;
+// head rows also emit the group's key.
+__global__ __launch_bounds__(256) void seg_ids_kernel(uint32_t *__restrict__ seg, const uint32_t *__restrict__ flags, int64_t n,
+                                                      const void *__restrict__ sorted_keys, int esz, void *__restrict__ out_keys)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t f = flags[i], s = seg[i] + f - 1u;
+        seg[i] = s;
+        if (f) {
+            if (esz == 4) static_cast<uint32_t *>(out_keys)[s] = static_cast<const uint32_t *>(sorted_keys)[i];
+            else static_cast<u64 *>(out_keys)[s] = static_cast<const u64 *>(sorted_keys)[i];
+        }
+    }
+}
+
+// Segmented reduction of col[perm[i]] by seg[i] (seg ascending).  count_mode:
+// every row contributes 1 (COUNT).
+__global__ __launch_bounds__(256) void seg_reduce_kernel(const void *__restrict__ col, int dtype, const uint32_t *__restrict__ perm,
+                                                         const uint32_t *__restrict__ seg, int64_t n, int kind, int op, int count_mode,
+                                                         u64 *__restrict__ acc)
+{
+    const int lane = threadIdx.x & 63;
+    const u64 ident = identity_of(kind, op);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < n; base += stride) {
+        const int64_t i = base + threadIdx.x;
+        const bool valid = i < n;
+        uint32_t s = valid ? seg[i] : 0xFFFFFFFFu;
+        u64 x = ident;
+        if (valid) x = count_mode ? 1ull : load_as_acc(col, dtype, perm[i], kind);
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const u64 y = __shfl_up(x, d, 64);
+            const uint32_t sy = __shfl_up(s, d, 64);
+            if (lane >= d && sy == s) x = combine(kind, op, y, x);
+        }
+        const uint32_t sn = __shfl_down(s, 1, 64);
+        if (valid && (lane == 63 || sn != s)) atomic_combine(kind, op, &acc[s], x);
+    }
+}
+
+// out dtype conversions of the 64-bit accumulators
+__global__ __launch_bounds__(256) void finalize_kernel(const u64 *__restrict__ acc, const u64 *__restrict__ cnt, int64_t G, int kind,
+                                                       int out_dtype, int avg, void *__restrict__ out)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < G; g += stride) {
+        const u64 a = acc[g];
+        if (avg) { static_cast<float *>(out)[g] = (float)(u2d(a) / (double)cnt[g]); continue; }
+        switch (out_dtype) {
+        case HARK_F32: static_cast<float *>(out)[g] = kind == ACC_F64 ? (float)u2d(a) : (float)(long long)a; break;
+        case HARK_I64: static_cast<u64 *>(out)[g] = kind == ACC_F64 ? (u64)(long long)u2d(a) : a; break;
+        default: static_cast<uint32_t *>(out)[g] = (uint32_t)a; break;     // I32 / U32: wrap to 32 bits
+        }
+    }
+}
+
+int grid_for(hark_context *ctx, int64_t n)
+{
+    int64_t b = (n + 255) / 256;
+    const int64_t cap = (int64_t)ctx->num_cu * 16;
+    if (b > cap) b = cap;
+    return (int)(b < 1 ? 1 : b);
+}
+
+void result_release(hark_result *r)
+{
+    for (auto &c : r->cols) if (c.owned && c.data) hipFree(c.data);
+    delete r;
+}
+
+struct AggSpec { int col; int op; int kind; int out_dtype; int count_mode; int avg; };
+
+// Everything after argument checking, shared by both entries.  Keys of
+// `key_dtype` are ordered by k_argsort_column's total order for that dtype.
+int grouped_aggregate(hark_context *ctx, const hark_table *db, int key_col, int key_dtype,
+                      const std::vector<AggSpec> &aggs, hark_result *res, int64_t *G_out)
+{
+    const int64_t n = db->n;
+    const int kesz = (int)hark_dtype_size(key_dtype);
+    uint32_t *perm = nullptr, *flags = nullptr, *seg = nullptr;
+    void *sorted_keys = nullptr;
+    u64 *acc = nullptr, *cnt = nullptr;
+    int64_t G = 0;
+    hipStream_t st = ctx->stream;
+    int rc = k_argsort_column(ctx, db->cols[key_col].data, key_dtype, n, false, &perm, nullptr);
+    if (!rc) rc = hark_alloc(ctx, &sorted_keys, (size_t)n * kesz);
+    if (!rc) rc = k_gather(ctx, db->cols[key_col].data, kesz, perm, sorted_keys, n);
+    if (!rc) rc = hark_alloc(ctx, (void **)&flags, (size_t)n * 4);
+    if (!rc) rc = hark_alloc(ctx, (void **)&seg, (size_t)n * 4);
+    if (!rc) {
+        head_flags_kernel<<<grid_for(ctx, n), 256, 0, st>>>(sorted_keys, kesz, n, flags);
+        rc = k_exclusive_scan_u32(ctx, flags, n, seg, nullptr, &G);
+    }
+    if (!rc) {
+        res->n = G;
+        res->cols.resize(1 + aggs.size());
+        res->cols[0].dtype = key_dtype;
+        rc = hark_alloc(ctx, &res->cols[0].data, (size_t)G * kesz);
+        for (size_t j = 0; j < aggs.size() && !rc; j++) {
+            res->cols[1 + j].dtype = aggs[j].out_dtype;
+            rc = hark_alloc(ctx, &res->cols[1 + j].data, (size_t)G * hark_dtype_size(aggs[j].out_dtype));
+        }
+    }
+    if (!rc) {
+        seg_ids_kernel<<<grid_for(ctx, n), 256, 0, st>>>(seg, flags, n, sorted_keys, kesz, res->cols[0].data);
+        rc = hark_alloc(ctx, (void **)&acc, (size_t)G * 8);
+        if (!rc) rc = hark_alloc(ctx, (void **)&cnt, (size_t)G * 8);
+    }
+    for (size_t j = 0; j < aggs.size() && !rc; j++) {
+        const AggSpec &a = aggs[j];
+        const int col_dtype = a.count_mode ? HARK_I32 : db->cols[a.col].dtype;
+        const void *col = a.count_mode ? nullptr : db->cols[a.col].data;
+        fill_u64_kernel<<<grid_for(ctx, G), 256, 0, st>>>(acc, G, identity_of(a.kind, a.op));
+        seg_reduce_kernel<<<grid_for(ctx, n), 256, 0, st>>>(col, col_dtype, perm, seg, n, a.kind, a.op, a.count_mode, acc);
+        if (a.avg) {
+            fill_u64_kernel<<<grid_for(ctx, G), 256, 0, st>>>(cnt, G, 0ull);
+            seg_reduce_kernel<<<grid_for(ctx, n), 256, 0, st>>>(nullptr, HARK_I32, perm, seg, n, ACC_U64, OP_SUM, 1, cnt);
+        }
+        finalize_kernel<<<grid_for(ctx, G), 256, 0, st>>>(acc, cnt, G, a.kind, a.out_dtype, a.avg, res->cols[1 + j].data);
+        if (hipGetLastError() != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "groupby: launch failed");
+    }
+    if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "groupby: kernels failed");
+    hipFree(perm); hipFree(flags); hipFree(seg); hipFree(sorted_keys); hipFree(acc); hipFree(cnt);
+    *G_out = G;
+    return rc;
+}
+
+int kind_of(int dtype) { return dtype == HARK_F32 ? ACC_F64 : dtype == HARK_U32 ? ACC_U64 : ACC_I64; }
+
+} // namespace
+
+extern "C" {
+
+int hark_entry_query_groupby(hark_context *ctx, hark_result **out, const hark_table *db, int32_t g_col,
+                             const int32_t *s_cols, int64_t ns, const int32_t *t_cols, int64_t nt)
+{
+    if (!ctx || !out || !db) return HARK_EARG;
+    *out = nullptr;
+    if (ns < 0 || nt < 0 || (ns && !s_cols) || (nt && !t_cols)) return hark_fail(ctx, HARK_EARG, "query_groupby: bad column lists");
+    hark_result *res = new hark_result();
+    if (db->n == 0) {                                   // segmented.fut:29: empty in, empty out
+        res->n = 0; res->cols.resize((size_t)ns + 1);
+        for (auto &c : res->cols) { c.dtype = HARK_U32; c.data = nullptr; c.owned = false; }
+        *out = res; return HARK_OK;
+    }
+    // `row[i]` in keep_fun (groupby.fut:52) is bounds-checked for every row
+    for (int64_t j = -1; j < ns; j++) {
+        const int c = j < 0 ? g_col : s_cols[j];
+        if (c < 0 || c >= db->m) { delete res; return hark_fail(ctx, HARK_EBOUNDS, "query_groupby: index %d out of bounds for a table with %lld columns", c, (long long)db->m); }
+        if (db->cols[c].dtype != HARK_I32 && db->cols[c].dtype != HARK_U32) { delete res; return hark_fail(ctx, HARK_EUNSUPPORTED, "query_groupby: column %d is not a 32-bit integer column (groupby.fut:51 is u32)", c); }
+    }
+    std::vector<AggSpec> aggs;
+    for (int64_t j = 0; j < ns; j++) {
+        // opcode table of type_func (groupby.fut:35-41); anything else -> u32.min.
+        // A missing opcode (nt < ns) is only an error if `merge` ever runs (checked below).
+        const int t = j < nt ? t_cols[j] : 4;
+        const int op = t == 1 ? OP_PROD : t == 2 ? OP_SUM : t == 3 ? OP_MAX : OP_MIN;
+        aggs.push_back(AggSpec{s_cols[j], op, ACC_U64, HARK_U32, 0, 0});
+    }
+    // u32 view of every column: groupby.fut:51 types the whole table as u32
+    hark_table view = *db;
+    for (auto &c : view.cols) { c.owned = false; if (c.dtype == HARK_I32) c.dtype = HARK_U32; }
+    int64_t G = 0;
+    int rc = grouped_aggregate(ctx, &view, g_col, HARK_U32, aggs, res, &G);
+    if (!rc && nt < ns && G < db->n)                    // some group has two rows: merge indexes t_cols[i-1] out of bounds
+        rc = hark_fail(ctx, HARK_EBOUNDS, "query_groupby: %lld aggregate opcodes for %lld select columns", (long long)nt, (long long)ns);
+    if (rc) { result_release(res); return rc; }
+    *out = res;
+    return HARK_OK;
+}
+
+} // extern "C"
+
+// ---- SQL-typed GROUP BY on an already filtered table (used by hark_entry_filter_groupby)
+int k_groupby_typed(hark_context *ctx, const hark_table *db, int32_t g_col, const int32_t *agg_cols,
+                    const int32_t *agg_ops, int64_t n_aggs, hark_result *res)
+{
+    std::vector<AggSpec> aggs;
+    for (int64_t j = 0; j < n_aggs; j++) {
+        const int op = agg_ops[j];
+        if (op == HARK_AGG_COUNT) { aggs.push_back(AggSpec{-1, OP_SUM, ACC_U64, HARK_I64, 1, 0}); continue; }
+        const int c = agg_cols[j];
+        if (c < 0 || c >= db->m) return hark_fail(ctx, HARK_EBOUNDS, "filter_groupby: aggregate column %d out of bounds", c);
+        const int dt = db->cols[c].dtype, kind = kind_of(dt);
+        switch (op) {
+        case HARK_AGG_SUM: aggs.push_back(AggSpec{c, OP_SUM, kind, dt == HARK_F32 ? HARK_F32 : HARK_I64, 0, 0}); break;
+        case HARK_AGG_PROD: aggs.push_back(AggSpec{c, OP_PROD, kind, dt, 0, 0}); break;
+        case HARK_AGG_MAX: aggs.push_back(AggSpec{c, OP_MAX, kind, dt, 0, 0}); break;
+        case HARK_AGG_MIN: case HARK_AGG_KEY: aggs.push_back(AggSpec{c, OP_MIN, kind, dt, 0, 0}); break;
+        case HARK_AGG_AVG: {
+            // AVG = f64 sum / count, returned as f32
+            AggSpec a{c, OP_SUM, ACC_F64, HARK_F32, 0, 1};
+            aggs.push_back(a);
+            break;
+        }
+        default: return hark_fail(ctx, HARK_EARG, "filter_groupby: unknown aggregate opcode %d", op);
+        }
+    }
+    int64_t G = 0;
+    return grouped_aggregate(ctx, db, g_col, db->cols[g_col].dtype, aggs, res, &G);
+}
+
+// ---------------------------------------------------------------------------
+// hark_entry_filter_groupby: WHERE -> GROUP BY with SQL-typed outputs
+// ---------------------------------------------------------------------------
+namespace {
+
+__global__ __launch_bounds__(256) void minmax_u32_kernel(const uint32_t *__restrict__ col, int64_t n, int is_signed,
+                                                         unsigned long long *__restrict__ out /* [0]=min, [1]=max (biased) */)
+{
+    // values are biased by 2^31 when signed so that one unsigned min/max serves both
+    uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+    const uint32_t bias = is_signed ? 0x80000000u : 0u;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t x = col[i] ^ bias;
+        lo = x < lo ? x : lo; hi = x > hi ? x : hi;
+    }
+    for (int d = 32; d > 0; d >>= 1) {
+        const uint32_t a = __shfl_down(lo, d, 64), b = __shfl_down(hi, d, 64);
+        lo = a < lo ? a : lo; hi = b > hi ? b : hi;
+    }
+    if ((threadIdx.x & 63) == 0) { atomicMin(&out[0], (unsigned long long)lo); atomicMax(&out[1], (unsigned long long)hi); }
+}
+
+__global__ __launch_bounds__(256) void nonzero_flags_kernel(const unsigned long long *__restrict__ cnt, int64_t G, uint32_t *__restrict__ flags)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < G; g += stride) flags[g] = cnt[g] ? 1u : 0u;
+}
+
+// mode 0: key (= group index), 1: SUM -> f32, 2: COUNT -> i64, 3: AVG -> f32
+__global__ __launch_bounds__(256) void dense_emit_kernel(const double *__restrict__ acc_sum, const unsigned long long *__restrict__ acc_cnt,
+                                                         const uint32_t *__restrict__ pos, int64_t G, int mode, void *__restrict__ out)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < G; g += stride) {
+        const unsigned long long c = acc_cnt[g];
+        if (!c) continue;
+        const uint32_t o = pos[g];
+        if (mode == 0) static_cast<uint32_t *>(out)[o] = (uint32_t)g;
+        else if (mode == 1) static_cast<float *>(out)[o] = (float)acc_sum[g];
+        else if (mode == 2) static_cast<long long *>(out)[o] = (long long)c;
+        else static_cast<float *>(out)[o] = (float)(acc_sum[g] / (double)c);
+    }
+}
+
+constexpr int64_t kDenseMaxGroups = (int64_t)1 << 21;      // limit of the partition path of k_fgb.hip
+
+// Dense shape: 32-bit integer key with 0 <= key < 2^21, aggregates drawn from
+// {SUM(v), AVG(v), COUNT} over ONE f32 column v, filter absent or on an f32 column.
+int try_dense(hark_context *ctx, const hark_table *db, int32_t where_col, int32_t cmp, const void *constant,
+              int32_t g_col, const int32_t *agg_cols, const int32_t *agg_ops, int64_t n_aggs, hark_result *res, bool *used)
+{
+    *used = false;
+    const int kdt = db->cols[g_col].dtype;
+    if (kdt != HARK_I32 && kdt != HARK_U32) return HARK_OK;
+    if (where_col >= 0 && db->cols[where_col].dtype != HARK_F32) return HARK_OK;
+    int vcol = -1;
+    for (int64_t j = 0; j < n_aggs; j++) {
+        if (agg_ops[j] == HARK_AGG_COUNT) continue;
+        if (agg_ops[j] != HARK_AGG_SUM && agg_ops[j] != HARK_AGG_AVG) return HARK_OK;
+        if (db->cols[agg_cols[j]].dtype != HARK_F32) return HARK_OK;
+        if (vcol >= 0 && vcol != agg_cols[j]) return HARK_OK;
+        vcol = agg_cols[j];
+    }
+    // column statistic: key range
+    unsigned long long *mm = nullptr;
+    HARK_TRY(hark_alloc(ctx, (void **)&mm, 16));
+    const unsigned long long init[2] = {~0ull, 0ull};
+    int rc = HARK_OK;
+    if (hipMemcpyAsync(mm, init, 16, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "stats upload failed");
+    int64_t blocks = (db->n + 255) / 256; if (blocks > (int64_t)ctx->num_cu * 8) blocks = (int64_t)ctx->num_cu * 8;
+    int64_t lohi[2] = {0, 0};
+    if (!rc) {
+        minmax_u32_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(static_cast<const uint32_t *>(db->cols[g_col].data), db->n, kdt == HARK_I32, mm);
+        rc = hark_read_words(ctx, mm, lohi, 2);
+    }
+    hipFree(mm);
+    if (rc) return rc;
+    const int64_t bias = kdt == HARK_I32 ? ((int64_t)1 << 31) : 0;
+    const int64_t kmin = lohi[0] - bias, kmax = lohi[1] - bias;
+    if (kmin < 0 || kmax >= kDenseMaxGroups) return HARK_OK;
+    const int64_t G = kmax + 1;
+
+    hark_fgb_plan *plan = nullptr;
+    HARK_TRY(hark_fgb_plan_new(ctx, &plan, db->n, G));
+    const float *p = where_col >= 0 ? static_cast<const float *>(db->cols[where_col].data) : nullptr;
+    const float thr = where_col >= 0 ? *static_cast<const float *>(constant) : 0.0f;
+    // COUNT-only queries still need a value stream: any 4-byte column does (its sum is never read)
+    const float *v = static_cast<const float *>(db->cols[vcol >= 0 ? vcol : g_col].data);
+    uint32_t *flags = nullptr, *pos = nullptr;
+    int64_t ngroups = 0;
+    rc = k_fgb_dense_f32(ctx, plan, p, cmp, thr, static_cast<const int32_t *>(db->cols[g_col].data), v, db->n);
+    if (!rc) rc = hark_fgb_finish(ctx, plan, nullptr, nullptr);
+    if (!rc) rc = hark_alloc(ctx, (void **)&flags, (size_t)G * 4);
+    if (!rc) rc = hark_alloc(ctx, (void **)&pos, (size_t)G * 4);
+    if (!rc) {
+        nonzero_flags_kernel<<<grid_for(ctx, G), 256, 0, ctx->stream>>>(plan->acc_cnt, G, flags);
+        rc = k_exclusive_scan_u32(ctx, flags, G, pos, nullptr, &ngroups);
+    }
+    if (!rc) {
+        res->n = ngroups;
+        res->cols.resize((size_t)n_aggs + 1);
+        for (int64_t j = -1; j < n_aggs && !rc; j++) {
+            hark_column &c = res->cols[(size_t)(j + 1)];
+            const int mode = j < 0 ? 0 : agg_ops[j] == HARK_AGG_SUM ? 1 : agg_ops[j] == HARK_AGG_COUNT ? 2 : 3;
+            c.dtype = mode == 0 ? kdt : mode == 2 ? HARK_I64 : HARK_F32;
+            rc = hark_alloc(ctx, &c.data, (size_t)ngroups * hark_dtype_size(c.dtype));
+            if (!rc) dense_emit_kernel<<<grid_for(ctx, G), 256, 0, ctx->stream>>>(plan->acc_sum, plan->acc_cnt, pos, G, mode, c.data);
+        }
+        if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "filter_groupby: kernels failed");
+    }
+    hipFree(flags); hipFree(pos);
+    hark_fgb_plan_free(ctx, plan);
+    *used = rc == HARK_OK;
+    return rc;
+}
+
+} // namespace
+
+extern "C" int hark_entry_filter_groupby(hark_context *ctx, hark_result **out, const hark_table *db, int32_t where_col, int32_t cmp,
+                                         const void *constant, int32_t g_col, const int32_t *agg_cols, const int32_t *agg_ops,
+                                         int64_t n_aggs)
+{
+    if (!ctx || !out || !db) return HARK_EARG;
+    *out = nullptr;
+    if (n_aggs < 0 || (n_aggs && (!agg_cols || !agg_ops))) return hark_fail(ctx, HARK_EARG, "filter_groupby: bad aggregate list");
+    if (g_col < 0 || g_col >= db->m) return hark_fail(ctx, HARK_EBOUNDS, "filter_groupby: group column %d out of bounds", g_col);
+    if (where_col >= db->m) return hark_fail(ctx, HARK_EBOUNDS, "filter_groupby: where column %d out of bounds", where_col);
+    if (where_col >= 0 && (!constant || cmp < HARK_CMP_GT || cmp > HARK_CMP_NE)) return hark_fail(ctx, HARK_EARG, "filter_groupby: bad predicate");
+    for (int64_t j = 0; j < n_aggs; j++) {
+        if (agg_ops[j] < HARK_AGG_KEY || agg_ops[j] > HARK_AGG_AVG) return hark_fail(ctx, HARK_EARG, "filter_groupby: unknown aggregate opcode %d", agg_ops[j]);
+        if (agg_ops[j] != HARK_AGG_COUNT && (agg_cols[j] < 0 || agg_cols[j] >= db->m))
+            return hark_fail(ctx, HARK_EBOUNDS, "filter_groupby: aggregate column %d out of bounds", agg_cols[j]);
+    }
+    hark_result *res = new hark_result();
+    int rc = HARK_OK;
+    bool done = false;
+    if (db->n > 0) rc = try_dense(ctx, db, where_col, cmp, constant, g_col, agg_cols, agg_ops, n_aggs, res, &done);
+    if (!rc && !done) {
+        // generic path: compact the referenced columns, then sort-based typed aggregation
+        for (auto &c : res->cols) if (c.owned && c.data) hipFree(c.data);
+        res->cols.clear();
+        const hark_table *src = db;
+        hark_result *kept = nullptr;
+        hark_table view;
+        std::vector<int32_t> remap((size_t)db->m, -1), need;
+        int32_t g2 = g_col;
+        std::vector<int32_t> cols2(agg_cols, agg_cols + n_aggs);
+        if (where_col >= 0 && db->n > 0) {
+            auto want = [&](int c) { if (remap[c] < 0) { remap[c] = (int32_t)need.size(); need.push_back(c); } return remap[c]; };
+            g2 = want(g_col);
+            for (int64_t j = 0; j < n_aggs; j++) cols2[j] = agg_ops[j] == HARK_AGG_COUNT ? 0 : want(agg_cols[j]);
+            rc = hark_entry_filter_sel(ctx, &kept, db, where_col, cmp, constant, need.data(), (int64_t)need.size(), 0);
+            if (!rc) {
+                view.n = kept->n; view.m = (int64_t)kept->cols.size(); view.cols = kept->cols;
+                for (auto &c : view.cols) c.owned = false;
+                src = &view;
+            }
+        }
+        if (!rc) {
+            if (src->n == 0) {                       // typed empty result
+                res->n = 0; res->cols.resize((size_t)n_aggs + 1);
+                for (auto &c : res->cols) { c.dtype = HARK_I64; c.data = nullptr; c.owned = false; }
+                res->cols[0].dtype = db->cols[g_col].dtype;
+            } else rc = k_groupby_typed(ctx, src, g2, cols2.data(), agg_ops, n_aggs, res);
+        }
+        if (kept) hark_result_free(ctx, kept);
+    }
+    if (rc) { for (auto &c : res->cols) if (c.owned && c.data) hipFree(c.data); delete res; return rc; }
+    *out = res;
+    return HARK_OK;
+}

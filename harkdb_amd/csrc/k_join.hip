@@ -1,0 +1,169 @@
+// k_join.hip -- inner equi-join on one u32 key per side, and ORDER BY.
+//
+//   hark_entry_join  replaces futhark/join.fut:52-75.  The reference tags and
+//       concatenates both key columns, sorts the (key, tag, row) triples with
+//       32 one-bit passes (join.fut:9-23, :58), finds key segments (:59-63) and
+//       then runs a SEQUENTIAL loop over the distinct keys that builds each
+//       cross product with partition + expand and concat-s it to the
+//       accumulator (:64-68).  Output order: ascending unsigned key, then left
+//       row id, then right row id.
+//       Here: both sides are argsorted independently (stable, so row ids stay
+//       ascending inside a key), every left row binary-searches its match
+//       range in the sorted right keys (count phase), a prefix sum gives each
+//       left row its output offset, and one thread per OUTPUT row finds its
+//       left row by binary search in the offsets (write phase).  That yields
+//       exactly the reference's order with no sequential step, and skewed keys
+//       cost nothing extra because work is split by output row.
+//   hark_entry_sort  ORDER BY one column (README.md:15 lists it; the reference
+//       has no implementation): stable argsort + gather of the projected columns.
+#include "hark_internal.h"
+
+int k_argsort_column(hark_context *ctx, const void *col, int dtype, int64_t n, bool descending,
+                     uint32_t **perm_out, uint32_t **sorted_words_out);
+int k_gather(hark_context *ctx, const void *src, int esz, const uint32_t *idx, void *dst, int64_t n);
+int k_exclusive_scan_u32(hark_context *ctx, const uint32_t *in, int64_t n, uint32_t *out32, int64_t *out64, int64_t *total_host);
+
+namespace {
+
+__global__ __launch_bounds__(256) void join_count_kernel(const uint32_t *__restrict__ lkeys, int64_t n,
+                                                         const uint32_t *__restrict__ rkeys, int64_t s,
+                                                         uint32_t *__restrict__ lb_out, uint32_t *__restrict__ cnt_out)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t key = lkeys[i];
+        int64_t lo = 0, hi = s;                       // lower bound
+        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (rkeys[mid] < key) lo = mid + 1; else hi = mid; }
+        const int64_t lb = lo;
+        hi = s;                                       // upper bound
+        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (rkeys[mid] <= key) lo = mid + 1; else hi = mid; }
+        lb_out[i] = (uint32_t)lb;
+        cnt_out[i] = (uint32_t)(lo - lb);
+    }
+}
+
+__global__ __launch_bounds__(256) void join_expand_kernel(const int64_t *__restrict__ offs, int64_t n, const uint32_t *__restrict__ lb,
+                                                          const uint32_t *__restrict__ lperm, const uint32_t *__restrict__ rperm,
+                                                          int64_t P, uint32_t *__restrict__ lrow, uint32_t *__restrict__ rrow)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < P; o += stride) {
+        int64_t lo = 0, hi = n;                       // last i with offs[i] <= o
+        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (offs[mid] <= o) lo = mid + 1; else hi = mid; }
+        const int64_t i = lo - 1;
+        lrow[o] = lperm[i];
+        rrow[o] = rperm[lb[i] + (o - offs[i])];
+    }
+}
+
+int grid_for(hark_context *ctx, int64_t n)
+{
+    int64_t b = (n + 255) / 256;
+    const int64_t cap = (int64_t)ctx->num_cu * 16;
+    if (b > cap) b = cap;
+    return (int)(b < 1 ? 1 : b);
+}
+
+void result_release(hark_result *r)
+{
+    for (auto &c : r->cols) if (c.owned && c.data) hipFree(c.data);
+    delete r;
+}
+
+bool is_u32ish(int d) { return d == HARK_I32 || d == HARK_U32; }
+
+} // namespace
+
+extern "C" {
+
+int hark_entry_join(hark_context *ctx, hark_result **out, const hark_table *db1, const hark_table *db2,
+                    int32_t col1, int32_t col2, const int32_t *cols1, int64_t l, const int32_t *cols2, int64_t k)
+{
+    if (!ctx || !out || !db1 || !db2) return HARK_EARG;
+    *out = nullptr;
+    if (l < 0 || k < 0 || (l && !cols1) || (k && !cols2)) return hark_fail(ctx, HARK_EARG, "join: bad column lists");
+    const int64_t n = db1->n, s = db2->n;
+    // db1[:, col1] / db2[:, col2] (join.fut:55-56) are checked even for empty outputs when the side has rows
+    if ((n > 0 && (col1 < 0 || col1 >= db1->m)) || (s > 0 && (col2 < 0 || col2 >= db2->m)))
+        return hark_fail(ctx, HARK_EBOUNDS, "join: key column out of bounds");
+    if ((n > 0 && !is_u32ish(db1->cols[col1].dtype)) || (s > 0 && !is_u32ish(db2->cols[col2].dtype)))
+        return hark_fail(ctx, HARK_EUNSUPPORTED, "join: key columns must be 32-bit integers (join.fut:52 is u32)");
+    if (n + s > 0xFFFFFFFFll) return hark_fail(ctx, HARK_EARG, "join: at most 2^32-1 rows in total");
+    hark_result *res = new hark_result();
+    res->n = 0; res->cols.resize((size_t)(l + k));
+    for (auto &c : res->cols) { c.dtype = HARK_U32; c.data = nullptr; c.owned = false; }
+    if (n == 0 || s == 0) { *out = res; return HARK_OK; }
+
+    uint32_t *lperm = nullptr, *lkeys = nullptr, *rperm = nullptr, *rkeys = nullptr;
+    uint32_t *lb = nullptr, *cnt = nullptr, *lrow = nullptr, *rrow = nullptr;
+    int64_t *offs = nullptr;
+    int64_t P = 0;
+    hipStream_t st = ctx->stream;
+    // keys as u32 whatever the declared signedness (join.fut:52 types both tables u32)
+    int rc = k_argsort_column(ctx, db1->cols[col1].data, HARK_U32, n, false, &lperm, &lkeys);
+    if (!rc) rc = k_argsort_column(ctx, db2->cols[col2].data, HARK_U32, s, false, &rperm, &rkeys);
+    if (!rc) rc = hark_alloc(ctx, (void **)&lb, (size_t)n * 4);
+    if (!rc) rc = hark_alloc(ctx, (void **)&cnt, (size_t)n * 4);
+    if (!rc) rc = hark_alloc(ctx, (void **)&offs, (size_t)n * 8);
+    if (!rc) {
+        join_count_kernel<<<grid_for(ctx, n), 256, 0, st>>>(lkeys, n, rkeys, s, lb, cnt);
+        rc = k_exclusive_scan_u32(ctx, cnt, n, nullptr, offs, &P);
+    }
+    if (!rc && P > 0) {
+        // select cols1 db1[r1,:] / select cols2 db2[r2,:] (join.fut:69-70) run only when there are pairs
+        for (int64_t j = 0; j < l && !rc; j++)
+            if (cols1[j] < 0 || cols1[j] >= db1->m) rc = hark_fail(ctx, HARK_EBOUNDS, "join: cols1[%lld] = %d out of bounds", (long long)j, cols1[j]);
+            else if (hark_dtype_size(db1->cols[cols1[j]].dtype) != 4) rc = hark_fail(ctx, HARK_EUNSUPPORTED, "join: 32-bit columns only");
+        for (int64_t j = 0; j < k && !rc; j++)
+            if (cols2[j] < 0 || cols2[j] >= db2->m) rc = hark_fail(ctx, HARK_EBOUNDS, "join: cols2[%lld] = %d out of bounds", (long long)j, cols2[j]);
+            else if (hark_dtype_size(db2->cols[cols2[j]].dtype) != 4) rc = hark_fail(ctx, HARK_EUNSUPPORTED, "join: 32-bit columns only");
+        if (!rc) rc = hark_alloc(ctx, (void **)&lrow, (size_t)P * 4);
+        if (!rc) rc = hark_alloc(ctx, (void **)&rrow, (size_t)P * 4);
+        if (!rc) {
+            join_expand_kernel<<<grid_for(ctx, P), 256, 0, st>>>(offs, n, lb, lperm, rperm, P, lrow, rrow);
+            if (hipGetLastError() != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: launch failed");
+        }
+        res->n = P;
+        for (int64_t j = 0; j < l + k && !rc; j++) {
+            const hark_table *t = j < l ? db1 : db2;
+            const int c = j < l ? cols1[j] : cols2[j - l];
+            res->cols[j].dtype = t->cols[c].dtype; res->cols[j].owned = true;
+            rc = hark_alloc(ctx, &res->cols[j].data, (size_t)P * 4);
+            if (!rc) rc = k_gather(ctx, t->cols[c].data, 4, j < l ? lrow : rrow, res->cols[j].data, P);
+        }
+        if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: kernels failed");
+    }
+    hipFree(lperm); hipFree(lkeys); hipFree(rperm); hipFree(rkeys); hipFree(lb); hipFree(cnt); hipFree(offs); hipFree(lrow); hipFree(rrow);
+    if (rc) { result_release(res); return rc; }
+    *out = res;
+    return HARK_OK;
+}
+
+int hark_entry_sort(hark_context *ctx, hark_result **out, const hark_table *db, int32_t key_col, int32_t descending,
+                    const int32_t *cols, int64_t k)
+{
+    if (!ctx || !out || !db) return HARK_EARG;
+    *out = nullptr;
+    if (k < 0 || (k && !cols)) return hark_fail(ctx, HARK_EARG, "sort: bad column list");
+    if (key_col < 0 || key_col >= db->m) return hark_fail(ctx, HARK_EBOUNDS, "sort: key column %d out of bounds", key_col);
+    for (int64_t j = 0; j < k; j++)
+        if (cols[j] < 0 || cols[j] >= db->m) return hark_fail(ctx, HARK_EBOUNDS, "sort: column %d out of bounds", cols[j]);
+    hark_result *res = new hark_result();
+    res->n = db->n; res->cols.resize((size_t)k);
+    for (int64_t j = 0; j < k; j++) { res->cols[j].dtype = db->cols[cols[j]].dtype; res->cols[j].data = nullptr; res->cols[j].owned = db->n > 0; }
+    if (db->n == 0) { *out = res; return HARK_OK; }
+    uint32_t *perm = nullptr;
+    int rc = k_argsort_column(ctx, db->cols[key_col].data, db->cols[key_col].dtype, db->n, descending != 0, &perm, nullptr);
+    for (int64_t j = 0; j < k && !rc; j++) {
+        const int esz = (int)hark_dtype_size(res->cols[j].dtype);
+        rc = hark_alloc(ctx, &res->cols[j].data, (size_t)db->n * esz);
+        if (!rc) rc = k_gather(ctx, db->cols[cols[j]].data, esz, perm, res->cols[j].data, db->n);
+    }
+    if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "sort: kernels failed");
+    hipFree(perm);
+    if (rc) { result_release(res); return rc; }
+    *out = res;
+    return HARK_OK;
+}
+
+} // extern "C"

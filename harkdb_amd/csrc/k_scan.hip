@@ -1,0 +1,104 @@
+// k_scan.hip -- device-wide exclusive prefix sum of u32 counts (to u32 or i64).
+//
+// The reference leans on Futhark's `scan (+)` everywhere (groupby.fut:12-13,
+// segmented.fut:28, join.fut:61); here one three-launch scan serves head-flag
+// numbering, join output offsets and compaction offsets:
+//   tile sums (4096 elements per workgroup) -> single-workgroup scan of the
+//   sums -> per-tile rescan that adds the tile's offset.
+#include "hark_internal.h"
+
+namespace {
+
+constexpr int kScanThreads = 256;
+constexpr int kScanPer = 16;
+constexpr int kScanTile = kScanThreads * kScanPer;
+
+__device__ __forceinline__ unsigned long long block_exclusive(unsigned long long x, unsigned long long *s_wave, unsigned long long *total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    unsigned long long incl = x;
+    for (int d = 1; d < 64; d <<= 1) { unsigned long long y = __shfl_up(incl, d, 64); if (lane >= d) incl += y; }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    unsigned long long carry = 0, tot = 0;
+    for (int w = 0; w < nw; w++) { if (w < wave) carry += s_wave[w]; tot += s_wave[w]; }
+    if (total) *total = tot;
+    __syncthreads();
+    return carry + incl - x;
+}
+
+__global__ __launch_bounds__(kScanThreads) void tile_sums_kernel(const uint32_t *__restrict__ in, int64_t n, unsigned long long *__restrict__ sums)
+{
+    __shared__ unsigned long long s_wave[kScanThreads / 64];
+    const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanPer;
+    unsigned long long x = 0;
+#pragma unroll
+    for (int j = 0; j < kScanPer; j++) if (base + j < n) x += in[base + j];
+    unsigned long long tot;
+    block_exclusive(x, s_wave, &tot);
+    if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(1024) void scan_sums_kernel(unsigned long long *__restrict__ sums, int64_t m, unsigned long long *__restrict__ total)
+{
+    __shared__ unsigned long long s_wave[16];
+    __shared__ unsigned long long s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < m; base += 1024) {
+        const int64_t i = base + threadIdx.x;
+        const unsigned long long x = i < m ? sums[i] : 0;
+        unsigned long long tot;
+        const unsigned long long excl = block_exclusive(x, s_wave, &tot);
+        const unsigned long long carry = s_carry;
+        if (i < m) sums[i] = carry + excl;
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry = carry + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = s_carry;
+}
+
+__global__ __launch_bounds__(kScanThreads) void scan_apply_kernel(const uint32_t *__restrict__ in, int64_t n, const unsigned long long *__restrict__ offs,
+                                                                  uint32_t *__restrict__ out32, int64_t *__restrict__ out64)
+{
+    __shared__ unsigned long long s_wave[kScanThreads / 64];
+    const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanPer;
+    uint32_t v[kScanPer];
+    unsigned long long x = 0;
+#pragma unroll
+    for (int j = 0; j < kScanPer; j++) { v[j] = base + j < n ? in[base + j] : 0u; x += v[j]; }
+    unsigned long long run = offs[blockIdx.x] + block_exclusive(x, s_wave, nullptr);
+#pragma unroll
+    for (int j = 0; j < kScanPer; j++) {
+        if (base + j < n) {
+            if (out32) out32[base + j] = (uint32_t)run;
+            if (out64) out64[base + j] = (int64_t)run;
+        }
+        run += v[j];
+    }
+}
+
+} // namespace
+
+// Exclusive scan of in[0..n).  Either output may be null.  *total_host receives
+// the sum (this call synchronises the stream).  in/out may alias.
+int k_exclusive_scan_u32(hark_context *ctx, const uint32_t *in, int64_t n, uint32_t *out32, int64_t *out64, int64_t *total_host)
+{
+    if (total_host) *total_host = 0;
+    if (n <= 0) return HARK_OK;
+    const int64_t nt = (n + kScanTile - 1) / kScanTile;
+    unsigned long long *sums = nullptr;
+    HARK_TRY(hark_alloc(ctx, (void **)&sums, (size_t)(nt + 1) * sizeof(unsigned long long)));
+    hipStream_t st = ctx->stream;
+    tile_sums_kernel<<<dim3((unsigned)nt), dim3(kScanThreads), 0, st>>>(in, n, sums);
+    scan_sums_kernel<<<1, 1024, 0, st>>>(sums, nt, sums + nt);
+    scan_apply_kernel<<<dim3((unsigned)nt), dim3(kScanThreads), 0, st>>>(in, n, sums, out32, out64);
+    int rc = HARK_OK;
+    if (hipGetLastError() != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "scan: launch failed");
+    int64_t tot = 0;
+    if (!rc) rc = hark_read_words(ctx, sums + nt, &tot, 1);
+    hipFree(sums);
+    if (total_host) *total_host = tot;
+    return rc;
+}

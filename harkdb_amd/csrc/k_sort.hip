@@ -194,7 +194,10 @@ __global__ __launch_bounds__(256) void transform_keys_kernel(const void *__restr
         } else {
             w = static_cast<const uint32_t *>(src)[i];
             if (dtype == HARK_I32) w ^= 0x80000000u;
-            else if (dtype == HARK_F32) w ^= (w & 0x80000000u) ? 0xFFFFFFFFu : 0x80000000u;   // total order, -0 < +0
+            else if (dtype == HARK_F32) {
+                if (w == 0x80000000u) w = 0u;                                  // -0.0 == +0.0
+                w ^= (w & 0x80000000u) ? 0xFFFFFFFFu : 0x80000000u;            // IEEE order as unsigned order
+            }
         }
         dst[i] = w;
     }

@@ -1,0 +1,143 @@
+"""SQL statement -> planner IR.  Mirrors the reference's parse.py:9-91.
+
+For the statements the reference understands the IR is identical
+(SURVEY.md 8(b)):
+    "select col1, col3 from game_1"
+        -> {"table": <data>, "select": [0, 2]}                         (parse.py:58)
+    "select col1, max(col3) from game_1 group by col1"
+        -> {"select": [0, 2], "groupbys": [0, 3], "table": <data>, "g_col": 0}   (parse.py:90)
+Extension clauses add keys ("where", "having", "orderby", "limit", "items",
+"extended"); the reference ignores those clauses (parse.py only reads the
+`select`, `from` and `groupby` keys).
+"""
+from .sqlfront import parse, AGGREGATES
+
+# parse.py:81 -- the reference's opcode table, plus the extensions of include/hark.h
+funcToFut = {"prod": 1, "sum": 2, "max": 3, "min": 4}
+EXT_FUNCS = {"count": 5, "avg": 6}
+_CMP_SQL = {"gt": ">", "gte": ">=", "lt": "<", "lte": "<=", "eq": "=", "neq": "!="}
+
+
+def getIndex(elements, value):
+    # parse.py:9-13
+    for i, v in enumerate(elements):
+        if v == value:
+            return i
+    return -1
+
+
+def _col(columns, name, table_name):
+    idx = getIndex(columns, name)
+    if idx < 0:
+        raise Exception(f"{name} is not in the schema of table {table_name}")     # parse.py:54
+    return idx
+
+
+def _conditions(tree):
+    if tree is None:
+        return []
+    return tree["and"] if "and" in tree else [tree]
+
+
+def sql_parse(tables, sql_statement):
+    """Parses an SQL statement (parse.py:16)."""
+    js_obj = parse(sql_statement)                                       # parse.py:27
+    table_name = js_obj["from"]
+    if table_name in tables:                                            # parse.py:30-33
+        table = tables[table_name]
+    else:
+        raise Exception(f"{table_name} is not in tables")
+    columns = table.get_schema()                                        # parse.py:40
+    select_pairs = js_obj["select"]
+    if isinstance(select_pairs, (dict, str)):                           # one item / "*": the reference
+        select_pairs = [select_pairs]                                   # breaks here (TypeError, parse.py:50)
+    ir = {"table": table.get_data(), "table_name": table_name, "extended": False}
+
+    # ---- WHERE (extension; the reference ignores the key) ------------------
+    where = []
+    for cond in _conditions(js_obj.get("where")):
+        (op, (lhs, rhs)), = cond.items()
+        if not isinstance(lhs, str) or not isinstance(rhs, (int, float)):
+            raise Exception("WHERE supports `column <op> number` comparisons (joined by AND)")
+        where.append((_col(columns, lhs, table_name), _CMP_SQL[op], rhs))
+    if where:
+        ir["where"] = where
+        ir["extended"] = True
+
+    if "groupby" not in js_obj.keys():                                  # parse.py:42
+        fut_cols_selects, items = [], []
+        for pair in select_pairs:
+            if pair == "*":
+                fut_cols_selects += list(range(len(columns)))
+                items += [("col", i) for i in range(len(columns))]
+            elif "value" in pair:                                       # parse.py:50
+                if not isinstance(pair["value"], str):
+                    raise Exception("aggregates need a GROUP BY clause")
+                idx = _col(columns, pair["value"], table_name)
+                fut_cols_selects += [idx]
+                items.append(("col", idx))
+        ir["select"] = fut_cols_selects                                 # parse.py:58
+        ir["items"] = items
+    else:                                                               # parse.py:60
+        fut_cols_selects, typ_cols_selects, items = [], [], []
+        g_col_name = js_obj["groupby"]["value"]                         # parse.py:66
+        g_col = getIndex(columns, g_col_name)
+        if g_col < 0:
+            raise Exception(f"{g_col_name} is not in the schema of table {table_name}")
+        for dic in select_pairs:                                        # parse.py:72
+            if dic == "*":
+                raise Exception("* is not allowed with GROUP BY")
+            if dic["value"] == g_col_name:                              # parse.py:73-75
+                fut_cols_selects += [g_col]
+                typ_cols_selects += [0]
+                items.append(("key", g_col))
+            elif isinstance(dic["value"], str):                         # parse.py:76-78
+                bad_col_name = dic["value"]
+                raise Exception(f"{bad_col_name} is not an aggregation function or the columns thats grouped on")
+            else:
+                (agg_func, agg_col_name), = dic["value"].items()
+                if agg_func in funcToFut:                               # parse.py:82-89
+                    agg_col = _col(columns, agg_col_name, table_name)
+                    fut_cols_selects += [agg_col]
+                    typ_cols_selects += [funcToFut[agg_func]]
+                    items.append((agg_func, agg_col))
+                elif agg_func in EXT_FUNCS:                             # extension: COUNT / AVG
+                    agg_col = None if agg_col_name == "*" else _col(columns, agg_col_name, table_name)
+                    items.append((agg_func, agg_col))
+                    ir["extended"] = True
+                else:                                                   # the reference drops these silently
+                    raise Exception(f"{agg_func} is not a supported aggregation function {AGGREGATES}")
+        ir["select"] = fut_cols_selects                                 # parse.py:90
+        ir["groupbys"] = typ_cols_selects
+        ir["g_col"] = g_col
+        ir["items"] = items
+
+    # ---- HAVING / ORDER BY / LIMIT (extensions) ------------------------------
+    def spec_of(term):
+        """A key / aggregate reference in HAVING or ORDER BY -> the matching item."""
+        if isinstance(term, str):
+            idx = _col(columns, term, table_name)
+            return ("key", idx) if "groupby" in js_obj and idx == ir["g_col"] else ("col", idx)
+        (f, c), = term.items()
+        if f not in funcToFut and f not in EXT_FUNCS:
+            raise Exception(f"{f} is not a supported aggregation function {AGGREGATES}")
+        return (f, None if c == "*" else _col(columns, c, table_name))
+
+    having = []
+    for cond in _conditions(js_obj.get("having")):
+        (op, (lhs, rhs)), = cond.items()
+        if not isinstance(rhs, (int, float)):
+            raise Exception("HAVING supports `aggregate <op> number` comparisons")
+        having.append((spec_of(lhs), _CMP_SQL[op], rhs))
+    if having:
+        if "groupby" not in js_obj:
+            raise Exception("HAVING needs a GROUP BY clause")
+        ir["having"] = having
+        ir["extended"] = True
+    if "orderby" in js_obj:
+        ir["orderby"] = (spec_of(js_obj["orderby"]["value"]), js_obj["orderby"].get("sort") == "desc")
+        ir["extended"] = True
+    if "limit" in js_obj:
+        ir["limit"] = int(js_obj["limit"])
+        ir["extended"] = True
+    return ir

@@ -1,0 +1,157 @@
+"""A small SQL front end that produces the parse tree `parse.py` consumes.
+
+The reference calls `moz_sql_parser.parse` (parse.py:6, :27), an unpinned
+third-party package that is not available here.  This module produces the same
+JSON shape for the statements HarkDB understands (shape taken from parse.py's
+own indexing: parse.py:29, :46-51, :66, :72-84):
+
+    {"select": [{"value": "col1"}, {"value": {"max": "col3"}}],   # one item -> a dict, "*" -> "*"
+     "from": "game_1",
+     "where": {"gt": ["col2", 4]},
+     "groupby": {"value": "col1"},
+     "having": {"gte": [{"sum": "col3"}, 10]},
+     "orderby": {"value": "col1", "sort": "desc"},
+     "limit": 10}
+"""
+import re
+
+_TOKEN = re.compile(r"""\s*(?:
+    (?P<num>[-+]?(?:\d+\.\d*|\.\d+|\d+)(?:[eE][-+]?\d+)?)
+  | (?P<id>[A-Za-z_][A-Za-z_0-9]*(?:\.[A-Za-z_][A-Za-z_0-9]*)?)
+  | (?P<qid>"[^"]+"|`[^`]+`)
+  | (?P<op><=|>=|<>|!=|==|=|<|>)
+  | (?P<punct>[(),*])
+)""", re.X)
+
+_CMP = {">": "gt", ">=": "gte", "<": "lt", "<=": "lte", "=": "eq", "==": "eq", "!=": "neq", "<>": "neq"}
+_FLIP = {"gt": "lt", "gte": "lte", "lt": "gt", "lte": "gte", "eq": "eq", "neq": "neq"}
+AGGREGATES = ("prod", "sum", "max", "min", "count", "avg")
+_KEYWORDS = {"select", "from", "where", "group", "by", "having", "order", "limit", "asc", "desc", "as", "and"}
+
+
+class SqlSyntaxError(Exception):
+    pass
+
+
+def _tokenize(text):
+    pos, out = 0, []
+    text = text.strip().rstrip(";")
+    while pos < len(text):
+        m = _TOKEN.match(text, pos)
+        if not m or m.end() == pos:
+            raise SqlSyntaxError(f"cannot tokenize SQL at: {text[pos:pos + 20]!r}")
+        pos = m.end()
+        if m.group("num") is not None:
+            s = m.group("num")
+            out.append(("num", float(s) if any(c in s for c in ".eE") else int(s)))
+        elif m.group("id") is not None:
+            w = m.group("id")
+            out.append(("kw", w.lower()) if w.lower() in _KEYWORDS else ("id", w))
+        elif m.group("qid") is not None:
+            out.append(("id", m.group("qid")[1:-1]))
+        elif m.group("op") is not None:
+            out.append(("op", m.group("op")))
+        else:
+            out.append(("punct", m.group("punct")))
+    return out
+
+
+class _Parser:
+    def __init__(self, toks):
+        self.t, self.i = toks, 0
+
+    def peek(self, kind=None, val=None):
+        if self.i >= len(self.t):
+            return False
+        k, v = self.t[self.i]
+        return (kind is None or k == kind) and (val is None or v == val)
+
+    def take(self, kind=None, val=None):
+        if not self.peek(kind, val):
+            got = self.t[self.i] if self.i < len(self.t) else "end of statement"
+            raise SqlSyntaxError(f"expected {val or kind}, got {got}")
+        tok = self.t[self.i]
+        self.i += 1
+        return tok[1]
+
+    def term(self):
+        """column | agg(column) | agg(*) | number  ->  moz-style value."""
+        if self.peek("num"):
+            return self.take("num")
+        if self.peek("punct", "*"):
+            self.take()
+            return "*"
+        name = self.take("id")
+        if self.peek("punct", "("):
+            self.take()
+            arg = self.term()
+            self.take("punct", ")")
+            return {name.lower(): arg}
+        return name
+
+    def comparison(self):
+        lhs = self.term()
+        op = _CMP[self.take("op")]
+        rhs = self.term()
+        if isinstance(lhs, (int, float)) and not isinstance(rhs, (int, float)):
+            lhs, rhs, op = rhs, lhs, _FLIP[op]
+        return {op: [lhs, rhs]}
+
+    def condition(self):
+        c = self.comparison()
+        if self.peek("kw", "and"):
+            terms = [c]
+            while self.peek("kw", "and"):
+                self.take()
+                terms.append(self.comparison())
+            return {"and": terms}
+        return c
+
+    def statement(self):
+        self.take("kw", "select")
+        items = []
+        while True:
+            v = self.term()
+            item = v if v == "*" else {"value": v}
+            if self.peek("kw", "as"):
+                self.take()
+                item["name"] = self.take("id")
+            items.append(item)
+            if self.peek("punct", ","):
+                self.take()
+                continue
+            break
+        tree = {"select": items[0] if len(items) == 1 else items}
+        self.take("kw", "from")
+        tree["from"] = self.take("id")
+        if self.peek("kw", "where"):
+            self.take()
+            tree["where"] = self.condition()
+        if self.peek("kw", "group"):
+            self.take()
+            self.take("kw", "by")
+            tree["groupby"] = {"value": self.take("id")}
+        if self.peek("kw", "having"):
+            self.take()
+            tree["having"] = self.condition()
+        if self.peek("kw", "order"):
+            self.take()
+            self.take("kw", "by")
+            ob = {"value": self.term()}
+            if self.peek("kw", "desc"):
+                self.take()
+                ob["sort"] = "desc"
+            elif self.peek("kw", "asc"):
+                self.take()
+            tree["orderby"] = ob
+        if self.peek("kw", "limit"):
+            self.take()
+            tree["limit"] = self.take("num")
+        if self.i != len(self.t):
+            raise SqlSyntaxError(f"unexpected trailing tokens: {self.t[self.i:]}")
+        return tree
+
+
+def parse(sql_statement):
+    """Stand-in for `moz_sql_parser.parse` (parse.py:27)."""
+    return _Parser(_tokenize(sql_statement)).statement()

@@ -1,0 +1,115 @@
+"""GPU parity of the reference entry points query_groupby (groupby.fut) and
+join (join.fut), plus SORT BY, against the CPU oracle: bit-exact."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, resolve_table, expand_runs
+
+pytestmark = pytest.mark.gpu
+OPS = load_golden("operators.json")
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from harkdb_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.mark.parametrize("case", OPS["query_groupby"], ids=lambda c: c["id"])
+def test_query_groupby_golden(eng, case):
+    t = eng.table_from_matrix(resolve_table(case["table"]), np.uint32)
+    out = eng.query_groupby(t, case["g_col"], case["s_cols"], case["t_cols"]).to_numpy(np.uint32)
+    assert out.tolist() == case["out"]
+
+
+@pytest.mark.parametrize("n,nkeys", [(1, 1), (63, 5), (64, 64), (4097, 3), (100_003, 1000), (300_000, 1), (262_144, 262_144)])
+def test_query_groupby_matches_oracle(eng, oracle, n, nkeys):
+    rng = np.random.default_rng(n * 31 + nkeys)
+    db = rng.integers(0, 2**32, size=(n, 6), dtype=np.uint64).astype(np.uint32)
+    keys = rng.integers(0, 2**32, size=nkeys, dtype=np.uint64).astype(np.uint32)   # sparse keys, sign bit included
+    db[:, 2] = keys[rng.integers(0, nkeys, size=n)] if nkeys < n else rng.permutation(n).astype(np.uint32) * 7919
+    s_cols, t_cols = [0, 1, 3, 4, 5, 2], [2, 1, 3, 4, 9, 0]      # sum, prod, max, min, `case _` (min), key
+    t = eng.table_from_matrix(db, np.uint32)
+    got = eng.query_groupby(t, 2, s_cols, t_cols).to_numpy(np.uint32)
+    exp = oracle.query_groupby(db, 2, s_cols, t_cols)
+    assert got.shape == exp.shape and np.array_equal(got, exp)
+
+
+def test_query_groupby_int32_table_is_viewed_as_u32(eng, oracle):
+    """The Python layer uploads int32 columns; groupby.fut:51 reads them as u32."""
+    rng = np.random.default_rng(3)
+    db = rng.integers(-50, 50, size=(5000, 3)).astype(np.int64)
+    t = eng.table_from_matrix(db, np.int32)
+    got = eng.query_groupby(t, 0, [1, 2], [3, 2]).to_numpy(np.uint32)
+    assert np.array_equal(got, oracle.query_groupby(db, 0, [1, 2], [3, 2]))
+    assert got[-1, 0] == np.uint32(-1 & 0xFFFFFFFF)               # negative keys sort last
+
+
+def test_query_groupby_errors(eng):
+    from harkdb_amd._ffi import HarkError, EBOUNDS
+    db = np.arange(12).reshape(3, 4)
+    db[1, 0] = 0
+    t = eng.table_from_matrix(db, np.uint32)
+    for args in [(9, [1], [2]), (0, [1, 4], [2, 2]), (0, [1, 2], [2])]:
+        with pytest.raises(HarkError) as ei:
+            eng.query_groupby(t, *args)
+        assert ei.value.code == EBOUNDS
+    # all keys distinct: `merge` never runs, a short t_cols is not an error (as in the sequential fold)
+    t2 = eng.table_from_matrix(np.arange(12).reshape(3, 4), np.uint32)
+    assert eng.query_groupby(t2, 0, [1, 2], [2]).to_numpy(np.uint32).tolist() == [[0, 1, 2], [4, 5, 6], [8, 9, 10]]
+
+
+@pytest.mark.parametrize("case", OPS["join"], ids=lambda c: c["id"])
+def test_join_golden(eng, case):
+    t1 = eng.table_from_matrix(resolve_table(case["db1"]), np.uint32)
+    t2 = eng.table_from_matrix(resolve_table(case["db2"]), np.uint32)
+    out = eng.join(t1, t2, case["col1"], case["col2"], case["cols1"], case["cols2"]).to_numpy(np.uint32)
+    w = len(case["cols1"]) + len(case["cols2"])
+    exp = expand_runs(case["out_runs"], w) if "out_runs" in case else np.asarray(case["out"], dtype=np.int64).reshape(-1, w)
+    assert out.astype(np.int64).tolist() == exp.tolist()
+
+
+@pytest.mark.parametrize("n,s,nkeys", [(1, 1, 1), (50, 70, 9), (5000, 300, 40), (3000, 3000, 3000), (20_000, 1000, 200_000)])
+def test_join_matches_oracle(eng, oracle, n, s, nkeys):
+    rng = np.random.default_rng(n + s)
+    a = rng.integers(0, 2**32, size=(n, 3), dtype=np.uint64).astype(np.uint32)
+    b = rng.integers(0, 2**32, size=(s, 4), dtype=np.uint64).astype(np.uint32)
+    pool = rng.integers(0, 2**32, size=nkeys, dtype=np.uint64).astype(np.uint32)
+    a[:, 1] = pool[rng.integers(0, nkeys, size=n)]
+    b[:, 3] = pool[rng.integers(0, nkeys, size=s)]
+    t1, t2 = eng.table_from_matrix(a, np.uint32), eng.table_from_matrix(b, np.uint32)
+    got = eng.join(t1, t2, 1, 3, [0, 1, 2], [3, 0]).to_numpy(np.uint32)
+    exp = oracle.join(a, b, 1, 3, [0, 1, 2], [3, 0])
+    assert got.shape == exp.shape and np.array_equal(got, exp)
+
+
+def test_join_empty_sides(eng):
+    t1 = eng.table_from_matrix(np.zeros((0, 2)), np.uint32)
+    t2 = eng.table_from_matrix(np.arange(6).reshape(3, 2), np.uint32)
+    assert eng.join(t1, t2, 0, 0, [0], [1]).shape == (0, 2)
+    assert eng.join(t2, t1, 0, 0, [0], [1]).shape == (0, 2)
+
+
+@pytest.mark.parametrize("dtype", [np.uint32, np.int32, np.float32, np.int64])
+@pytest.mark.parametrize("descending", [False, True])
+@pytest.mark.parametrize("n", [0, 1, 4096, 150_001])
+def test_sort_is_stable_and_ordered(eng, oracle, dtype, descending, n):
+    rng = np.random.default_rng(n + 5)
+    if dtype == np.float32:
+        key = (rng.standard_normal(n) * 3).round(1).astype(np.float32)
+    elif dtype == np.int64:
+        key = rng.integers(-5, 5, size=n) * (2**33) + rng.integers(-2, 2, size=n)
+    elif dtype == np.int32:
+        key = rng.integers(-300, 300, size=n).astype(np.int32)
+    else:
+        key = rng.integers(0, 2**32, size=n, dtype=np.uint64).astype(np.uint32) & np.uint32(0xFF0000FF)
+    rowid = np.arange(n, dtype=np.int32)
+    t = eng.table_from_columns([np.ascontiguousarray(key.astype(dtype)), rowid])
+    res = eng.sort(t, 0, [0, 1], descending=descending)
+    k2, r2 = res.column(0), res.column(1)
+    perm = np.argsort(-key.astype(np.float64) if descending and dtype != np.int64 else (key if not descending else -key), kind="stable")
+    assert np.array_equal(r2, rowid[perm]) and np.array_equal(k2, key.astype(dtype)[perm])
+    if dtype == np.uint32 and not descending:
+        assert np.array_equal(r2, oracle.argsort_u32(key).astype(np.int32))    # the reference's 32-pass sort order

@@ -1,0 +1,111 @@
+"""The Python surface (FutharkContext.create_table / sql) end to end on the GPU.
+Reference statements reproduce the Appendix-A goldens; extension clauses are
+checked against pandas on the same data."""
+import numpy as np
+import pandas as pd
+import pytest
+
+from conftest import GOLDEN, load_golden
+
+pytestmark = pytest.mark.gpu
+OPS = load_golden("operators.json")
+
+
+@pytest.fixture(scope="module")
+def fc():
+    from harkdb_amd import FutharkContext
+    c = FutharkContext()
+    c.create_table("game_1", f"{GOLDEN}/data.csv")
+    rng = np.random.default_rng(0)
+    n = 200_000
+    df = pd.DataFrame({"k": rng.integers(0, 1000, n).astype(np.int32), "p": rng.random(n).astype(np.float32),
+                       "v": rng.integers(0, 16, n).astype(np.float32), "w": rng.integers(-100, 100, n).astype(np.int32),
+                       "big": rng.integers(-2**40, 2**40, n).astype(np.int64)})
+    c.create_table("t", df)
+    c._df = df
+    return c
+
+
+def test_readme_projection(fc):
+    # README.md:42 / config C1 -> golden G1
+    out = fc.sql("select col1, col3 from game_1")
+    assert out.dtype == np.int32 and out.tolist() == OPS["query_sel"][0]["out"]
+
+
+def test_test_py_groupby(fc):
+    # test.py:7 -> golden G2: leading key column, u32
+    out = fc.sql("select col1,  max(col3) from game_1 group by col1")
+    assert out.dtype == np.uint32 and out.tolist() == OPS["query_groupby"][0]["out"]
+    out = fc.sql("select sum(col7), prod(col7), min(col7) from game_1 group by col1")
+    assert out.tolist() == OPS["query_groupby"][2]["out"]
+
+
+def test_reference_errors_surface(fc):
+    with pytest.raises(Exception, match="nope is not in tables"):
+        fc.sql("select col1 from nope")
+    with pytest.raises(Exception, match="is not in the schema"):
+        fc.sql("select colx from game_1")
+
+
+def test_where_projection(fc):
+    df = fc._df
+    out = fc.sql("select k, w from t where p > 0.5")
+    exp = df[df.p > 0.5][["k", "w"]].to_numpy()
+    assert np.array_equal(out, exp)
+    out = fc.sql("select k, w from t where p > 0.5 and w < 0 and k >= 500")
+    exp = df[(df.p > 0.5) & (df.w < 0) & (df.k >= 500)][["k", "w"]].to_numpy()
+    assert np.array_equal(out, exp)
+
+
+def test_headline_query_dense_path(fc):
+    df = fc._df
+    names, cols = fc.sql_columns("select k, sum(v), count(*), avg(v) from t where p > 0.5 group by k")
+    g = df[df.p > 0.5].groupby("k")
+    assert names == ["k", "sum(v)", "count(*)", "avg(v)"]
+    assert np.array_equal(cols[0], g.v.sum().index.to_numpy()) and cols[0].dtype == np.int32
+    assert np.array_equal(cols[1], g.v.sum().to_numpy().astype(np.float32))          # integer-valued: exact
+    assert np.array_equal(cols[2], g.v.count().to_numpy()) and cols[2].dtype == np.int64
+    assert np.allclose(cols[3], g.v.mean().to_numpy(), rtol=1e-6)
+
+
+def test_generic_typed_groupby(fc):
+    df = fc._df
+    names, cols = fc.sql_columns("select k, sum(w), min(big), max(p), count(*), avg(w) from t where w <> 0 group by k")
+    g = df[df.w != 0].groupby("k")
+    assert np.array_equal(cols[0], np.asarray(g.w.sum().index))
+    assert np.array_equal(cols[1], g.w.sum().to_numpy()) and cols[1].dtype == np.int64
+    assert np.array_equal(cols[2], g.big.min().to_numpy()) and cols[2].dtype == np.int64
+    assert np.array_equal(cols[3], g.p.max().to_numpy()) and cols[3].dtype == np.float32
+    assert np.array_equal(cols[4], g.w.count().to_numpy())
+    assert np.allclose(cols[5], g.w.mean().to_numpy(), rtol=1e-6)
+
+
+def test_groupby_negative_and_int64_keys(fc):
+    df = fc._df
+    _, cols = fc.sql_columns("select w, count(*) from t group by w")
+    g = df.groupby("w").size()
+    assert np.array_equal(cols[0], g.index.to_numpy()) and np.array_equal(cols[1], g.to_numpy())   # signed ascending
+    _, cols = fc.sql_columns("select big, sum(v) from t where big > 0 group by big")
+    g = df[df.big > 0].groupby("big").v.sum()
+    assert np.array_equal(cols[0], g.index.to_numpy()) and np.allclose(cols[1], g.to_numpy())
+
+
+def test_having_order_limit(fc):
+    df = fc._df
+    out = fc.sql_columns("select k, sum(v) from t where p > 0.5 group by k having count(*) >= 100 order by sum(v) desc limit 10")[1]
+    g = df[df.p > 0.5].groupby("k").agg(s=("v", "sum"), c=("v", "count")).reset_index()
+    g = g[g.c >= 100].sort_values("s", ascending=False, kind="stable").head(10)
+    assert np.array_equal(out[0], g.k.to_numpy()) and np.array_equal(out[1], g.s.to_numpy().astype(np.float32))
+    out = fc.sql("select w, k from t where p < 0.01 order by w limit 50")
+    exp = df[df.p < 0.01].sort_values("w", kind="stable")[["w", "k"]].head(50).to_numpy()
+    assert np.array_equal(out, exp)
+
+
+def test_sql_mode_returns_select_list_only():
+    from harkdb_amd import FutharkContext
+    c = FutharkContext(sql_mode=True)
+    c.create_table("game_1", f"{GOLDEN}/data.csv")
+    names, cols = c.sql_columns("select col1, max(col3) from game_1 group by col1")
+    assert names == ["col1", "max(col3)"] and [x.tolist() for x in cols] == [[0, 1, 6], [0, 3, 6]]
+    c.drop_table("game_1")
+    assert "game_1" not in c.tables

@@ -1,0 +1,95 @@
+"""Host logic (no GPU): the SQL front end, the planner IR (parse.py:58, :90)
+and table ingest (table.py:8-80)."""
+import numpy as np
+import pandas as pd
+import pytest
+
+from conftest import GOLDEN
+from harkdb_amd.parse import sql_parse
+from harkdb_amd.sqlfront import parse, SqlSyntaxError
+from harkdb_amd.table import Table
+
+
+@pytest.fixture(scope="module")
+def tables():
+    return {"game_1": Table("game_1", f"{GOLDEN}/data.csv")}
+
+
+def test_parse_tree_shapes():
+    assert parse("select col1, col3 from game_1") == {"select": [{"value": "col1"}, {"value": "col3"}], "from": "game_1"}
+    assert parse("select col1,  max(col3) from game_1 group by col1") == {
+        "select": [{"value": "col1"}, {"value": {"max": "col3"}}], "from": "game_1", "groupby": {"value": "col1"}}
+    assert parse("select col1 from t")["select"] == {"value": "col1"}          # one item -> dict (moz shape)
+    assert parse("SELECT * FROM t WHERE val > 4") == {"select": "*", "from": "t", "where": {"gt": ["val", 4]}}
+    assert parse("select a from t where 4 < a")["where"] == {"gt": ["a", 4]}   # literal on the left is flipped
+    t = parse("select k, sum(v), count(*) from t where p >= .5 group by k having sum(v) > 1e3 order by k desc limit 7;")
+    assert t["where"] == {"gte": ["p", 0.5]} and t["having"] == {"gt": [{"sum": "v"}, 1000.0]}
+    assert t["orderby"] == {"value": "k", "sort": "desc"} and t["limit"] == 7
+
+
+@pytest.mark.parametrize("bad", ["selec a from t", "select a from", "select a from t where", "select a from t group k",
+                                 "select a from t limit", "select a, from t", "select a from t extra"])
+def test_syntax_errors(bad):
+    with pytest.raises(SqlSyntaxError):
+        parse(bad)
+
+
+def test_reference_ir_projection(tables):
+    ir = sql_parse(tables, "select col1, col3 from game_1")
+    assert ir["select"] == [0, 2] and "groupbys" not in ir and not ir["extended"]
+    assert ir["table"] is tables["game_1"].get_data()
+
+
+def test_reference_ir_groupby(tables):
+    ir = sql_parse(tables, "select col1,  max(col3) from game_1 group by col1")
+    assert (ir["select"], ir["groupbys"], ir["g_col"]) == ([0, 2], [0, 3], 0) and not ir["extended"]
+    ir = sql_parse(tables, "select prod(col2), sum(col3), min(col4) from game_1 group by col8")
+    assert (ir["select"], ir["groupbys"], ir["g_col"]) == ([1, 2, 3], [1, 2, 4], 7)
+
+
+def test_reference_errors(tables):
+    with pytest.raises(Exception, match="nope is not in tables"):                 # parse.py:33
+        sql_parse(tables, "select col1 from nope")
+    with pytest.raises(Exception, match="colx is not in the schema of table game_1"):   # parse.py:54
+        sql_parse(tables, "select colx, col1 from game_1")
+    with pytest.raises(Exception, match="colx is not in the schema of table game_1"):   # parse.py:69
+        sql_parse(tables, "select max(col1) from game_1 group by colx")
+    with pytest.raises(Exception, match="col2 is not an aggregation function"):   # parse.py:78
+        sql_parse(tables, "select col1, col2 from game_1 group by col1")
+    with pytest.raises(Exception, match="colx is not in the schema"):             # parse.py:87
+        sql_parse(tables, "select col1, max(colx) from game_1 group by col1")
+
+
+def test_extension_ir(tables):
+    ir = sql_parse(tables, "select col1, count(*), avg(col3) from game_1 where col2 > 1 and col3 <= 6 group by col1 "
+                           "having count(*) >= 2 order by avg(col3) desc limit 3")
+    assert ir["extended"] and ir["where"] == [(1, ">", 1), (2, "<=", 6)]
+    assert ir["items"] == [("key", 0), ("count", None), ("avg", 2)]
+    assert ir["having"] == [(("count", None), ">=", 2)] and ir["orderby"] == (("avg", 2), True) and ir["limit"] == 3
+    assert sql_parse(tables, "select * from game_1")["select"] == list(range(8))
+    assert sql_parse(tables, "select col2 from game_1")["select"] == [1]          # single item works (reference: TypeError)
+    with pytest.raises(Exception, match="median is not a supported aggregation"):
+        sql_parse(tables, "select col1, median(col2) from game_1 group by col1")
+
+
+def test_table_ingest_csv():
+    t = Table("g", f"{GOLDEN}/data.csv")
+    assert t.get_name() == "g" and t.get_schema() == [f"col{i}" for i in range(1, 9)]
+    assert t.get_data().shape == (7, 8) and t.get_data()[6].tolist() == [1, 2, 3, 4, 5, 3, 2, 1]
+    assert all(c.dtype == np.int32 and c.flags.c_contiguous for c in t.host_columns())
+
+
+def test_table_ingest_ndarray_dataframe_txt(tmp_path):
+    a = np.arange(12, dtype=np.int64).reshape(4, 3)
+    t = Table("a", a)
+    assert t.get_schema() == ["col1", "col2", "col3"]            # shape[1] columns (reference: shape[0], a bug)
+    df = pd.DataFrame({"k": [1, 2, 3], "v": [0.5, 1.5, 2.5], "big": [2**40, 1, 2]})
+    cols = Table("d", df).host_columns()
+    assert [c.dtype for c in cols] == [np.int32, np.float32, np.int64]
+    np.savetxt(tmp_path / "x.txt", a)
+    tt = Table("x", str(tmp_path / "x.txt"))
+    assert tt.get_schema() == ["c1", "c2", "c3"] and tt.get_data().shape == (4, 3)
+    with pytest.raises(Exception, match="do not support"):
+        Table("bad", "file.parquet")
+    with pytest.raises(Exception, match="not in a file"):
+        Table("bad", 42)
