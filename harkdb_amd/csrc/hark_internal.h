@@ -79,7 +79,9 @@ struct hark_fgb_plan {
     int64_t slack_pct = 0;     // slab capacity as % of the uniform share (0 = default)
     int64_t tile_rows = 0;
     int64_t ablate = 0;        // timing experiments only
-    int64_t variant = 0;       // producer geometry (threads x rows/thread)
+    int64_t variant = 0;       // (unused)
+    int64_t timing = 0;        // record HIP events around every kernel launch
+    std::vector<hipEvent_t> ev; std::vector<int> ev_kind; size_t ev_used = 0;
     uint2 *pbuf = nullptr;     // [P][nwg][cap] (key, value-bits) pairs
     uint32_t *counts = nullptr;// [P][nwg] pairs in each slab
     double *acc_sum = nullptr; // [G]

@@ -388,6 +388,22 @@ int dispatch_op(int cmp, bool has_pred, F &&f)
     }
 }
 
+// Optional live timing: HIP events recorded on the launch stream around every kernel of the path.
+struct TimedLaunch {
+    hark_fgb_plan *pl; hipStream_t st; int kind; size_t slot = 0; bool on = false;
+    TimedLaunch(hark_fgb_plan *pl_, hipStream_t st_, int kind_) : pl(pl_), st(st_), kind(kind_)
+    {
+        if (!pl->timing) return;
+        if (pl->ev_used + 2 > pl->ev.size()) {
+            for (int i = 0; i < 2; i++) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; pl->ev.push_back(e); }
+            pl->ev_kind.resize(pl->ev.size() / 2);
+        }
+        slot = pl->ev_used; pl->ev_used += 2; pl->ev_kind[slot / 2] = kind; on = true;
+        hipEventRecord(pl->ev[slot], st);
+    }
+    ~TimedLaunch() { if (on) hipEventRecord(pl->ev[slot + 1], st); }
+};
+
 constexpr int64_t kLdsTableBudget = 96 * 1024;   // LDS path: 12 B per group -> G <= 8192
 constexpr int64_t kAggTableBudget = 96 * 1024;   // consumer: 12 B per key of a bucket
 
@@ -441,6 +457,7 @@ int hark_fgb_plan_free(hark_context *ctx, hark_fgb_plan *pl)
     if (pl->err) hipFree(pl->err);
     if (pl->acc_sum) hipFree(pl->acc_sum);
     if (pl->acc_cnt) hipFree(pl->acc_cnt);
+    for (auto e : pl->ev) hipEventDestroy(e);
     delete pl;
     return HARK_OK;
 }
@@ -453,6 +470,7 @@ int hark_fgb_plan_set(hark_fgb_plan *pl, const char *key, int64_t value)
     else if (!strcmp(key, "grid")) { if (value < 0 || value > 65535) return HARK_EARG; pl->grid = value; }
     else if (!strcmp(key, "shift")) { if (value < 0 || value > 13) return HARK_EARG; pl->shift = value; }
     else if (!strcmp(key, "slack_pct")) { if (value < 0 || value > 10000) return HARK_EARG; pl->slack_pct = value; }
+    else if (!strcmp(key, "timing")) { pl->timing = value; return HARK_OK; }
     else if (!strcmp(key, "variant")) { if (value < 0 || value > 3) return HARK_EARG; pl->variant = value; return HARK_OK; }
     else if (!strcmp(key, "ablate")) { pl->ablate = value; return HARK_OK; }   // timing experiments only: wrong results
     else return HARK_EARG;
@@ -534,6 +552,7 @@ int k_fgb_dense_f32(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cm
             if (lds > 64 * 1024)
                 HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_lds_kernel<OP>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            TimedLaunch tl(pl, st, 0);
             fgb_lds_kernel<OP><<<dim3((unsigned)grid), dim3(1024), lds, st>>>(p, k, v, n, thr, (int)G, RL, gsum, gcnt, pl->err);
             HIP_TRY(ctx, hipGetLastError());
             return HARK_OK;
@@ -545,6 +564,7 @@ int k_fgb_dense_f32(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cm
         if (grid > need) grid = need > 0 ? need : 1;
         return dispatch_op(cmp, p != nullptr, [&](auto op) -> int {
             constexpr int OP = decltype(op)::value;
+            TimedLaunch tl(pl, st, 0);
             fgb_atomic_kernel<OP><<<dim3((unsigned)grid), dim3(256), 0, st>>>(p, k, v, n, thr, G, gsum, gcnt, pl->err);
             HIP_TRY(ctx, hipGetLastError());
             return HARK_OK;
@@ -564,11 +584,17 @@ int k_fgb_dense_f32(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cm
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part));
         for (int64_t r0 = 0; r0 < n; r0 += pl->chunk_rows) {
             const int64_t r1 = r0 + pl->chunk_rows < n ? r0 + pl->chunk_rows : n;
-            fgb_part_kernel<OP><<<dim3((unsigned)nwg), dim3(kPartThreads), lds_part, st>>>(
-                p, k, v, r0, r1, thr, G, shift, P, pl->pbuf, pl->counts, (uint32_t)pl->cap, gsum, gcnt, pl->err, (int)pl->ablate);
+            {
+                TimedLaunch tl(pl, st, 1);
+                fgb_part_kernel<OP><<<dim3((unsigned)nwg), dim3(kPartThreads), lds_part, st>>>(
+                    p, k, v, r0, r1, thr, G, shift, P, pl->pbuf, pl->counts, (uint32_t)pl->cap, gsum, gcnt, pl->err, (int)pl->ablate);
+            }
             HIP_TRY(ctx, hipGetLastError());
-            fgb_agg_kernel<<<dim3((unsigned)P), dim3(1024), lds_agg, st>>>(
-                pl->pbuf, pl->counts, (uint32_t)pl->cap, nwg, shift, G, gsum, gcnt);
+            {
+                TimedLaunch tl(pl, st, 2);
+                fgb_agg_kernel<<<dim3((unsigned)P), dim3(1024), lds_agg, st>>>(
+                    pl->pbuf, pl->counts, (uint32_t)pl->cap, nwg, shift, G, gsum, gcnt);
+            }
             HIP_TRY(ctx, hipGetLastError());
         }
         return HARK_OK;
@@ -592,5 +618,22 @@ int hark_fgb_finish(hark_context *ctx, hark_fgb_plan *pl, float *sum_out, int64_
         HIP_TRY(ctx, hipMemsetAsync(pl->err, 0, sizeof(int32_t), ctx->stream));
         return hark_fail(ctx, code, "filter_groupby: a surviving row has a key outside [0, %lld)", (long long)pl->G);
     }
+    return HARK_OK;
+}
+
+// Sum of the event-timed kernel durations since the last call, by kernel kind
+// (0 = single-kernel path, 1 = partition producer, 2 = partition consumer).
+int hark_fgb_timing(hark_context *ctx, hark_fgb_plan *pl, double *ms_by_kind, int64_t *launches_by_kind)
+{
+    if (!ctx || !pl || !ms_by_kind || !launches_by_kind) return HARK_EARG;
+    for (int i = 0; i < 3; i++) { ms_by_kind[i] = 0.0; launches_by_kind[i] = 0; }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t s = 0; s + 1 < pl->ev_used; s += 2) {
+        float ms = 0.0f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, pl->ev[s], pl->ev[s + 1]));
+        const int kind = pl->ev_kind[s / 2];
+        ms_by_kind[kind] += ms; launches_by_kind[kind] += 1;
+    }
+    pl->ev_used = 0;
     return HARK_OK;
 }

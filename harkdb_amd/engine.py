@@ -123,6 +123,13 @@ class FgbPlan:
     def finish(self, sum_ptr=None, count_ptr=None):
         self._eng._chk(self._eng.lib.hark_fgb_finish(self._eng.ctx, self._h, sum_ptr, count_ptr))
 
+    def timing(self):
+        """({kind: ms}, {kind: launches}) since the last call; needs set('timing', 1)."""
+        ms, cnt = (C.c_double * 3)(), (C.c_int64 * 3)()
+        self._eng._chk(self._eng.lib.hark_fgb_timing(self._eng.ctx, self._h, ms, cnt))
+        kinds = ("single", "producer", "consumer")
+        return {k: ms[i] for i, k in enumerate(kinds)}, {k: cnt[i] for i, k in enumerate(kinds)}
+
     def free(self):
         if self._h is not None:
             self._eng.lib.hark_fgb_plan_free(self._eng.ctx, self._h)

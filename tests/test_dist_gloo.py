@@ -1,0 +1,76 @@
+"""N>1 host logic under gloo, world_size 2, on CPU: row-range sharding, the
+all-reduce merge of dense GROUP BY partials and the offset exchange for
+order-preserving filters.  Per-shard partials come from the oracle (test
+infrastructure); the merge code under test is harkdb_amd.dist."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SEED = 0x4861726B4442
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n, G, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from harkdb_amd import dist as hd
+    from oracle import oracle as ora
+    r, _, w = hd.init_process_group("cpu")
+    lo, hi = hd.shard_range(n, r, w)
+    p, k, v = ora.gen_columns(SEED, lo, hi - lo, G, True)
+    _, s64, cnt = ora.filter_groupby_dense_f32(p, k, v, ">", 0.5, G)
+    sum_t, cnt_t = torch.from_numpy(s64.copy()), torch.from_numpy(cnt.copy())
+    hd.allreduce_partials(sum_t, cnt_t)
+    idx = ora.filter_indices(p, ">", 0.5)
+    off, total = hd.shard_offsets(len(idx))
+    gidx = hd.global_row_index(idx, r, n, w)
+    mn, mx = torch.tensor([float(v.min())]), torch.tensor([float(v.max())])
+    hd.allreduce_minmax(mn, mx)
+    q.put((r, sum_t.numpy(), cnt_t.numpy(), off, total, gidx, (lo, hi), mn.item(), mx.item()))
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,G", [(100_003, 1 << 12), (7, 16)])
+def test_two_rank_merge_matches_single(oracle, n, G):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, G, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    outs = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    p, k, v = oracle.gen_columns(SEED, 0, n, G, True)
+    _, s64, cnt = oracle.filter_groupby_dense_f32(p, k, v, ">", 0.5, G)
+    idx = oracle.filter_indices(p, ">", 0.5)
+    for r, s, c, off, total, gidx, (lo, hi), mn, mx in outs:
+        assert np.array_equal(s, s64) and np.array_equal(c, cnt)        # every rank holds the merged table
+        assert total == len(idx)
+        assert np.array_equal(idx[off: off + len(gidx)], gidx)          # shard results concatenate in rank order
+        assert mn == v.min() and mx == v.max()
+    assert outs[0][6][0] == 0 and outs[0][6][1] == outs[1][6][0] and outs[1][6][1] == n
+
+
+def test_shard_range_properties():
+    from harkdb_amd.dist import shard_range
+    for n in (0, 1, 5, 1000, 10**9 + 7):
+        for world in (1, 2, 4, 8):
+            rs = [shard_range(n, r, world) for r in range(world)]
+            assert rs[0][0] == 0 and rs[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(rs, rs[1:]))
+            assert all(lo % 4 == 0 for lo, hi in rs if lo < n)
