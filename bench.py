@@ -38,7 +38,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", type=float, default=1e9, help="rows per GPU")
     ap.add_argument("--groups", type=int, default=1 << 20)
-    ap.add_argument("--cpu-rows", type=float, default=4e7, help="rows of the CPU baseline sample (0 disables)")
+    ap.add_argument("--cpu-rows", type=float, default=1.5e8, help="rows of the CPU baseline sample (0 disables)")
     ap.add_argument("--exact", type=int, default=1, help="1: integer-valued v (bit-exact check), 0: uniform [0,1)")
     ap.add_argument("--algo", type=int, default=0)
     ap.add_argument("--chunk-rows", type=int, default=0)
