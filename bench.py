@@ -97,7 +97,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -111,7 +111,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     ms_by_kind, launches = plan.timing()
@@ -119,13 +119,13 @@ def main():
     # ---- size-independent checks on the full-size result (rank-local where possible)
     survivors_local = int((p > 0.5).sum().item())
     st = torch.tensor([survivors_local], dtype=torch.int64, device=dev)
-    if world > 1:
+    if dist.is_initialized():
         dist.all_reduce(st)
     total_cnt = int(cnt_out.sum().item())
     check = {"count_checksum": total_cnt == int(st.item())}
     if a.exact:                                               # integer-valued v: the f64 checksum of sums is exact
         sv = torch.where(p > 0.5, v, torch.zeros_like(v)).to(torch.float64).sum()
-        if world > 1:
+        if dist.is_initialized():
             dist.all_reduce(sv)
         check["sum_checksum"] = float(sum_out.to(torch.float64).sum().item()) == float(sv.item())
 
@@ -165,7 +165,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

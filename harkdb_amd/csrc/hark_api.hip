@@ -14,17 +14,69 @@ int hark_fail(hark_context *ctx, int code, const char *fmt, ...)
     return code;
 }
 
+// ---- caching device allocator ---------------------------------------------------
+// Every entry allocates its result columns and scratch; hipMalloc/hipFree cost
+// 0.1-1 ms each and hipFree synchronises the device, which would dominate a
+// sub-millisecond query.  Freed blocks are kept per context and handed out again
+// (best fit within 25 %).  Reuse is safe without events because a context runs
+// everything on ONE stream: a block freed by the host is only touched again by
+// work enqueued later on that same stream.
+static size_t pool_round(size_t bytes)
+{
+    if (bytes == 0) bytes = 16;
+    const size_t g = bytes <= (1u << 20) ? 4096 : (2u << 20);
+    return (bytes + g - 1) / g * g;
+}
+
+static void pool_trim(hark_context *ctx)
+{
+    for (auto &kv : ctx->pool_free) hipFree(kv.second);
+    ctx->pool_free.clear();
+    ctx->pool_cached = 0;
+}
+
 int hark_alloc(hark_context *ctx, void **out, size_t bytes)
 {
     *out = nullptr;
-    if (bytes == 0) bytes = 16;
-    hipError_t e = hipMalloc(out, bytes);
+    const size_t size = pool_round(bytes);
+    if (ctx) {
+        auto it = ctx->pool_free.lower_bound(size);
+        if (it != ctx->pool_free.end() && it->first <= size + size / 4 + 4096) {
+            *out = it->second;
+            ctx->pool_cached -= it->first;
+            ctx->pool_live[*out] = it->first;
+            ctx->pool_free.erase(it);
+            return HARK_OK;
+        }
+    }
+    hipError_t e = hipMalloc(out, size);
+    if (e == hipErrorOutOfMemory && ctx && !ctx->pool_free.empty()) {     // give cached blocks back and retry
+        (void)hipGetLastError();
+        hipStreamSynchronize(ctx->stream);
+        pool_trim(ctx);
+        e = hipMalloc(out, size);
+    }
     if (e != hipSuccess) {
         *out = nullptr;
+        (void)hipGetLastError();
         return hark_fail(ctx, e == hipErrorOutOfMemory ? HARK_ENOMEM : HARK_EHIP,
-                         "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+                         "hipMalloc(%zu bytes) failed: %s", size, hipGetErrorString(e));
     }
+    if (ctx) ctx->pool_live[*out] = size;
     return HARK_OK;
+}
+
+void hark_free(hark_context *ctx, void *ptr)
+{
+    if (!ptr) return;
+    if (!ctx) { hipFree(ptr); return; }
+    auto it = ctx->pool_live.find(ptr);
+    if (it == ctx->pool_live.end()) { hipFree(ptr); return; }              // not ours (should not happen)
+    const size_t size = it->second;
+    ctx->pool_live.erase(it);
+    if (ctx->pool_cached + size > ctx->pool_limit) { hipStreamSynchronize(ctx->stream); hipFree(ptr); return; }
+    ctx->pool_free.emplace(size, ptr);
+    ctx->pool_cached += size;
 }
 
 int hark_read_words(hark_context *ctx, const void *dev, int64_t *host, int count)
@@ -70,6 +122,7 @@ void hark_context_free(hark_context *ctx)
     if (!ctx) return;
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    pool_trim(ctx);
     if (ctx->d_err) hipFree(ctx->d_err);
     if (ctx->h_pin) hipHostFree(ctx->h_pin);
     if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
@@ -88,6 +141,7 @@ const char *hark_context_get_error(hark_context *ctx) { return ctx ? ctx->err.c_
 int hark_context_set_stream(hark_context *ctx, void *hip_stream)
 {
     if (!ctx) return HARK_EARG;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // pooled blocks are ordered by ONE stream: drain the old one
     ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own_stream;
     return HARK_OK;
 }
@@ -102,8 +156,7 @@ int hark_dev_free(hark_context *ctx, void *dev)
 {
     if (!ctx) return HARK_EARG;
     if (!dev) return HARK_OK;
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    HIP_TRY(ctx, hipFree(dev));
+    hark_free(ctx, dev);
     return HARK_OK;
 }
 int hark_dev_upload(hark_context *ctx, void *dev, const void *host, int64_t bytes)
@@ -133,9 +186,9 @@ int hark_op_zero(hark_context *ctx, void *dev, int64_t bytes)
 // ---- tables ------------------------------------------------------------------
 static bool dtype_ok(int d) { return d == HARK_I32 || d == HARK_U32 || d == HARK_F32 || d == HARK_I64; }
 
-static void table_release(hark_table *t)
+static void table_release(hark_context *ctx, hark_table *t)
 {
-    for (auto &c : t->cols) if (c.owned && c.data) hipFree(c.data);
+    for (auto &c : t->cols) if (c.owned && c.data) hark_free(ctx, c.data);
     delete t;
 }
 
@@ -149,14 +202,14 @@ int hark_table_new_columns(hark_context *ctx, hark_table **out, int64_t n, int64
     t->n = n; t->m = m;
     t->cols.resize((size_t)m);
     for (int64_t j = 0; j < m; j++) {
-        if (!dtype_ok(dtypes[j]) || (n && !host_cols[j])) { table_release(t); return hark_fail(ctx, HARK_EARG, "table_new_columns: bad column %lld", (long long)j); }
+        if (!dtype_ok(dtypes[j]) || (n && !host_cols[j])) { table_release(ctx, t); return hark_fail(ctx, HARK_EARG, "table_new_columns: bad column %lld", (long long)j); }
         t->cols[j].dtype = dtypes[j];
         size_t bytes = (size_t)n * hark_dtype_size(dtypes[j]);
         int rc = hark_alloc(ctx, &t->cols[j].data, bytes);
-        if (rc) { table_release(t); return rc; }
+        if (rc) { table_release(ctx, t); return rc; }
         if (bytes) {
             hipError_t e = hipMemcpyAsync(t->cols[j].data, host_cols[j], bytes, hipMemcpyHostToDevice, ctx->stream);
-            if (e != hipSuccess) { table_release(t); return hark_fail(ctx, HARK_EHIP, "upload failed: %s", hipGetErrorString(e)); }
+            if (e != hipSuccess) { table_release(ctx, t); return hark_fail(ctx, HARK_EHIP, "upload failed: %s", hipGetErrorString(e)); }
         }
     }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // host buffers may be released by the caller
@@ -223,8 +276,7 @@ void *hark_table_column_device(const hark_table *t, int64_t col) { return (!t ||
 int hark_table_free(hark_context *ctx, hark_table *t)
 {
     if (!t) return HARK_OK;
-    if (ctx) hipStreamSynchronize(ctx->stream);
-    table_release(t);
+    table_release(ctx, t);
     return HARK_OK;
 }
 
@@ -253,8 +305,7 @@ int hark_result_column(hark_context *ctx, const hark_result *r, int64_t col, voi
 int hark_result_free(hark_context *ctx, hark_result *r)
 {
     if (!r) return HARK_OK;
-    if (ctx) hipStreamSynchronize(ctx->stream);
-    for (auto &c : r->cols) if (c.owned && c.data) hipFree(c.data);
+    for (auto &c : r->cols) if (c.owned && c.data) hark_free(ctx, c.data);
     delete r;
     return HARK_OK;
 }

@@ -8,6 +8,8 @@
 #include <string.h>
 #include <string>
 #include <vector>
+#include <map>
+#include <unordered_map>
 
 #include "../../include/hark.h"
 
@@ -22,6 +24,10 @@ struct hark_context {
     int32_t *d_err = nullptr;       // device-side sticky error word (bounds failures)
     int32_t *h_pin = nullptr;       // pinned scratch for small D2H reads (64 x i64)
     int num_cu = HARK_NUM_CU;
+    // caching allocator (hark_alloc / hark_free)
+    std::multimap<size_t, void *> pool_free;
+    std::unordered_map<void *, size_t> pool_live;
+    size_t pool_cached = 0, pool_limit = (size_t)64 << 30;
 };
 
 struct hark_column {
@@ -60,6 +66,7 @@ int hark_fail(hark_context *ctx, int code, const char *fmt, ...);
 
 // Device allocation that records failures in the context.
 int hark_alloc(hark_context *ctx, void **out, size_t bytes);
+void hark_free(hark_context *ctx, void *ptr);
 // Reads `count` 8-byte words from the device after draining the stream.
 int hark_read_words(hark_context *ctx, const void *dev, int64_t *host, int count);
 
@@ -68,6 +75,7 @@ int hark_read_words(hark_context *ctx, const void *dev, int64_t *host, int count
 
 // k_fgb.hip
 struct hark_fgb_plan {
+    hark_context *ctx = nullptr;
     int64_t max_rows = 0, G = 0;
     int64_t algo = 0;          // 0 auto, 1 lds, 2 atomic, 3 partition
     int64_t chunk_rows = 0;    // partition path: rows per chunk (0 = auto)

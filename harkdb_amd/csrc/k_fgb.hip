@@ -424,8 +424,8 @@ int k_gen_columns(hark_context *ctx, uint64_t seed, int64_t first_row, int64_t n
 
 static void plan_drop_partition(hark_fgb_plan *pl)
 {
-    if (pl->pbuf) { hipFree(pl->pbuf); pl->pbuf = nullptr; }
-    if (pl->counts) { hipFree(pl->counts); pl->counts = nullptr; }
+    if (pl->pbuf) { hark_free(pl->ctx, pl->pbuf); pl->pbuf = nullptr; }
+    if (pl->counts) { hark_free(pl->ctx, pl->counts); pl->counts = nullptr; }
 }
 
 int hark_fgb_plan_new(hark_context *ctx, hark_fgb_plan **out, int64_t max_rows, int64_t G)
@@ -436,7 +436,7 @@ int hark_fgb_plan_new(hark_context *ctx, hark_fgb_plan **out, int64_t max_rows, 
         return hark_fail(ctx, HARK_EARG, "fgb_plan_new: need max_rows >= 0 and 0 < G <= 2^31 (got %lld, %lld)",
                          (long long)max_rows, (long long)G);
     hark_fgb_plan *pl = new hark_fgb_plan();
-    pl->max_rows = max_rows; pl->G = G;
+    pl->max_rows = max_rows; pl->G = G; pl->ctx = ctx;
     pl->tile_rows = kTileRows;
     int rc = hark_alloc(ctx, (void **)&pl->err, sizeof(int32_t));
     if (!rc) rc = hark_alloc(ctx, (void **)&pl->acc_sum, (size_t)G * sizeof(double));
@@ -454,9 +454,9 @@ int hark_fgb_plan_free(hark_context *ctx, hark_fgb_plan *pl)
     if (!pl) return HARK_OK;
     if (ctx) hipStreamSynchronize(ctx->stream);
     plan_drop_partition(pl);
-    if (pl->err) hipFree(pl->err);
-    if (pl->acc_sum) hipFree(pl->acc_sum);
-    if (pl->acc_cnt) hipFree(pl->acc_cnt);
+    hark_free(ctx, pl->err);
+    hark_free(ctx, pl->acc_sum);
+    hark_free(ctx, pl->acc_cnt);
     for (auto e : pl->ev) hipEventDestroy(e);
     delete pl;
     return HARK_OK;

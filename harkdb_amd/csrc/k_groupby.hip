@@ -183,9 +183,9 @@ int grid_for(hark_context *ctx, int64_t n)
     return (int)(b < 1 ? 1 : b);
 }
 
-void result_release(hark_result *r)
+void result_release(hark_context *ctx, hark_result *r)
 {
-    for (auto &c : r->cols) if (c.owned && c.data) hipFree(c.data);
+    for (auto &c : r->cols) if (c.owned && c.data) hark_free(ctx, c.data);
     delete r;
 }
 
@@ -241,7 +241,7 @@ int grouped_aggregate(hark_context *ctx, const hark_table *db, int key_col, int 
         if (hipGetLastError() != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "groupby: launch failed");
     }
     if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "groupby: kernels failed");
-    hipFree(perm); hipFree(flags); hipFree(seg); hipFree(sorted_keys); hipFree(acc); hipFree(cnt);
+    hark_free(ctx, perm); hark_free(ctx, flags); hark_free(ctx, seg); hark_free(ctx, sorted_keys); hark_free(ctx, acc); hark_free(ctx, cnt);
     *G_out = G;
     return rc;
 }
@@ -285,7 +285,7 @@ int hark_entry_query_groupby(hark_context *ctx, hark_result **out, const hark_ta
     int rc = grouped_aggregate(ctx, &view, g_col, HARK_U32, aggs, res, &G);
     if (!rc && nt < ns && G < db->n)                    // some group has two rows: merge indexes t_cols[i-1] out of bounds
         rc = hark_fail(ctx, HARK_EBOUNDS, "query_groupby: %lld aggregate opcodes for %lld select columns", (long long)nt, (long long)ns);
-    if (rc) { result_release(res); return rc; }
+    if (rc) { result_release(ctx, res); return rc; }
     *out = res;
     return HARK_OK;
 }
@@ -397,7 +397,7 @@ int try_dense(hark_context *ctx, const hark_table *db, int32_t where_col, int32_
         minmax_u32_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(static_cast<const uint32_t *>(db->cols[g_col].data), db->n, kdt == HARK_I32, mm);
         rc = hark_read_words(ctx, mm, lohi, 2);
     }
-    hipFree(mm);
+    hark_free(ctx, mm);
     if (rc) return rc;
     const int64_t bias = kdt == HARK_I32 ? ((int64_t)1 << 31) : 0;
     const int64_t kmin = lohi[0] - bias, kmax = lohi[1] - bias;
@@ -432,7 +432,7 @@ int try_dense(hark_context *ctx, const hark_table *db, int32_t where_col, int32_
         }
         if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "filter_groupby: kernels failed");
     }
-    hipFree(flags); hipFree(pos);
+    hark_free(ctx, flags); hark_free(ctx, pos);
     hark_fgb_plan_free(ctx, plan);
     *used = rc == HARK_OK;
     return rc;
@@ -461,7 +461,7 @@ extern "C" int hark_entry_filter_groupby(hark_context *ctx, hark_result **out, c
     if (db->n > 0) rc = try_dense(ctx, db, where_col, cmp, constant, g_col, agg_cols, agg_ops, n_aggs, res, &done);
     if (!rc && !done) {
         // generic path: compact the referenced columns, then sort-based typed aggregation
-        for (auto &c : res->cols) if (c.owned && c.data) hipFree(c.data);
+        for (auto &c : res->cols) if (c.owned && c.data) hark_free(ctx, c.data);
         res->cols.clear();
         const hark_table *src = db;
         hark_result *kept = nullptr;
@@ -489,7 +489,7 @@ extern "C" int hark_entry_filter_groupby(hark_context *ctx, hark_result **out, c
         }
         if (kept) hark_result_free(ctx, kept);
     }
-    if (rc) { for (auto &c : res->cols) if (c.owned && c.data) hipFree(c.data); delete res; return rc; }
+    if (rc) { for (auto &c : res->cols) if (c.owned && c.data) hark_free(ctx, c.data); delete res; return rc; }
     *out = res;
     return HARK_OK;
 }

@@ -64,9 +64,9 @@ int grid_for(hark_context *ctx, int64_t n)
     return (int)(b < 1 ? 1 : b);
 }
 
-void result_release(hark_result *r)
+void result_release(hark_context *ctx, hark_result *r)
 {
-    for (auto &c : r->cols) if (c.owned && c.data) hipFree(c.data);
+    for (auto &c : r->cols) if (c.owned && c.data) hark_free(ctx, c.data);
     delete r;
 }
 
@@ -133,8 +133,8 @@ int hark_entry_join(hark_context *ctx, hark_result **out, const hark_table *db1,
         }
         if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: kernels failed");
     }
-    hipFree(lperm); hipFree(lkeys); hipFree(rperm); hipFree(rkeys); hipFree(lb); hipFree(cnt); hipFree(offs); hipFree(lrow); hipFree(rrow);
-    if (rc) { result_release(res); return rc; }
+    hark_free(ctx, lperm); hark_free(ctx, lkeys); hark_free(ctx, rperm); hark_free(ctx, rkeys); hark_free(ctx, lb); hark_free(ctx, cnt); hark_free(ctx, offs); hark_free(ctx, lrow); hark_free(ctx, rrow);
+    if (rc) { result_release(ctx, res); return rc; }
     *out = res;
     return HARK_OK;
 }
@@ -160,8 +160,8 @@ int hark_entry_sort(hark_context *ctx, hark_result **out, const hark_table *db, 
         if (!rc) rc = k_gather(ctx, db->cols[cols[j]].data, esz, perm, res->cols[j].data, db->n);
     }
     if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "sort: kernels failed");
-    hipFree(perm);
-    if (rc) { result_release(res); return rc; }
+    hark_free(ctx, perm);
+    if (rc) { result_release(ctx, res); return rc; }
     *out = res;
     return HARK_OK;
 }

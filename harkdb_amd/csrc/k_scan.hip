@@ -98,7 +98,7 @@ int k_exclusive_scan_u32(hark_context *ctx, const uint32_t *in, int64_t n, uint3
     if (hipGetLastError() != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "scan: launch failed");
     int64_t tot = 0;
     if (!rc) rc = hark_read_words(ctx, sums + nt, &tot, 1);
-    hipFree(sums);
+    hark_free(ctx, sums);
     if (total_host) *total_host = tot;
     return rc;
 }

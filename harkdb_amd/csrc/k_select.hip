@@ -210,9 +210,9 @@ __global__ __launch_bounds__(256) void interleave_kernel(ColSet cs, int64_t n, i
     }
 }
 
-void result_release(hark_result *r)
+void result_release(hark_context *ctx, hark_result *r)
 {
-    for (auto &c : r->cols) if (c.owned && c.data) hipFree(c.data);
+    for (auto &c : r->cols) if (c.owned && c.data) hark_free(ctx, c.data);
     delete r;
 }
 
@@ -268,7 +268,7 @@ int hark_entry_query_sel(hark_context *ctx, hark_result **out, const hark_table 
         *out = res; return HARK_OK;
     }
     int rc = k_gather_columns(ctx, db, cols, k, res);
-    if (rc) { result_release(res); return rc; }
+    if (rc) { result_release(ctx, res); return rc; }
     *out = res;
     return HARK_OK;
 }
@@ -346,9 +346,9 @@ int hark_entry_filter_sel(hark_context *ctx, hark_result **out, const hark_table
         if (hipGetLastError() != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "filter_sel: launch failed");
         if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "filter_sel: kernel failed");
     }
-    if (counts) hipFree(counts);
-    if (offsets) hipFree(offsets);
-    if (rc) { result_release(res); return rc; }
+    if (counts) hark_free(ctx, counts);
+    if (offsets) hark_free(ctx, offsets);
+    if (rc) { result_release(ctx, res); return rc; }
     *out = res;
     return HARK_OK;
 }
@@ -379,7 +379,7 @@ int hark_result_values_2d(hark_context *ctx, const hark_result *r, void *host_ou
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(host_out, tmp, bytes, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    hipFree(tmp);
+    hark_free(ctx, tmp);
     if (e != hipSuccess) return hark_fail(ctx, HARK_EHIP, "values_2d: %s", hipGetErrorString(e));
     return HARK_OK;
 }

@@ -307,9 +307,9 @@ int k_argsort_column(hark_context *ctx, const void *col, int dtype, int64_t n, b
         if (!rc) rc = k_sort_pairs_u32(ctx, k0, v0, k1, v1, n, xm, false, ws);
     }
     if (rc == HARK_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "sort kernels failed");
-    hipFree(k1); hipFree(v1); hipFree(ws);
-    if (rc) { hipFree(k0); hipFree(v0); return rc; }
+    hark_free(ctx, k1); hark_free(ctx, v1); hark_free(ctx, ws);
+    if (rc) { hark_free(ctx, k0); hark_free(ctx, v0); return rc; }
     *perm_out = v0;
-    if (sorted_words_out && dtype != HARK_I64) *sorted_words_out = k0; else hipFree(k0);
+    if (sorted_words_out && dtype != HARK_I64) *sorted_words_out = k0; else hark_free(ctx, k0);
     return HARK_OK;
 }

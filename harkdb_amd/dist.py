@@ -36,7 +36,7 @@ def init_process_group(device_type=None):
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
     if device_type is None:
         device_type = "cuda" if torch.cuda.is_available() else "cpu"
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or "RANK" in os.environ) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if device_type == "cuda":
@@ -65,7 +65,7 @@ def allreduce_partials(sum_t, cnt_t, group=None):
     """Merge per-shard dense GROUP BY partials in place: SUM over ranks of the
     f64 sums and of the i64 counts (the RCCL all-reduce of SURVEY.md 8(e))."""
     import torch.distributed as dist
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_initialized():          # also with one rank: keeps the single-GPU run on the same code path
         dist.all_reduce(sum_t, op=dist.ReduceOp.SUM, group=group)
         dist.all_reduce(cnt_t, op=dist.ReduceOp.SUM, group=group)
     return sum_t, cnt_t

@@ -1,21 +1,35 @@
+"""A/B timing of fused filter->group-by configurations with the library's own HIP-event timers.
+Interleaved rounds (config order repeated R times) so clock drift hits every arm alike.
+Usage: python tools/fgb_ablate.py [N] ["k=v,k=v;k=v,..."]"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from harkdb_amd.engine import Engine, FgbPlan
-N, G = 1 << 28, 1 << 20
+
+N = int(float(sys.argv[1])) if len(sys.argv) > 1 else 1 << 28
+G = 1 << 20
+spec = sys.argv[2] if len(sys.argv) > 2 else "grid=512;grid=1024"
+configs = [dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in c.split(",") if kv) for c in spec.split(";")]
+R = 8
 eng = Engine(0)
 p, k, v = eng.alloc(N * 4), eng.alloc(N * 4), eng.alloc(N * 4)
 eng.gen_columns(0x4861726B4442, 0, N, G, True, p, k, v)
-configs = []
-for grid in (256, 512):
-    for ab in (0, 1, 2, 6):
-        configs.append((0, grid, 12, ab))
-configs.append((0, 512, 13, 0))
-for variant, grid, shift, ab in configs:
-    plan = FgbPlan(eng, N, G, algo=3, chunk_rows=N, grid=grid, shift=shift)
-    plan.set("variant", variant); plan.set("ablate", ab)
-    ts = []
-    for r in range(4):
-        plan.reset(); eng.sync(); t0 = time.perf_counter(); plan.run(p, ">", 0.5, k, v, N); eng.sync(); ts.append((time.perf_counter() - t0) * 1e3)
-    print(f"variant={variant} grid={grid} shift={shift} ablate={ab}: {min(ts[1:]):.3f} ms (producer+consumer)", flush=True)
-    plan.free()
+plans = []
+for c in configs:
+    g = c.pop("G", G)
+    pl = FgbPlan(eng, N, g, algo=c.pop("algo", 3), chunk_rows=c.pop("chunk_rows", N))
+    for kk, vv in c.items():
+        pl.set(kk, vv)
+    pl.set("timing", 1)
+    plans.append(pl)
+res = [[] for _ in plans]
+for r in range(R + 1):
+    for i, pl in enumerate(plans):
+        pl.reset(); pl.run(p, ">", 0.5, k, v, N); ms, cnt = pl.timing()
+        if r:
+            res[i].append((ms["producer"] + ms["single"], ms["consumer"]))
+for c, rr in zip(spec.split(";"), res):
+    a = np.array(rr)
+    tot = a.sum(axis=1)
+    print(f"{c:40s} producer min {a[:,0].min():7.3f} med {np.median(a[:,0]):7.3f} | consumer min {a[:,1].min():7.3f} med {np.median(a[:,1]):7.3f} | "
+          f"total min {tot.min():7.3f} med {np.median(tot):7.3f} ms  -> {(12*N+16*G)/np.median(tot)/1e9/8:.3f} of 8 TB/s", flush=True)

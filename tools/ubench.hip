@@ -86,6 +86,34 @@ __global__ void read1_kernel(const uint4 *__restrict__ buf, int64_t nvec, uint32
     if (acc == 0x12345678u) out[0] = acc;
 }
 
+__global__ void reread_kernel(const uint4 *__restrict__ buf, int64_t nvec, int passes, uint32_t *__restrict__ out)
+{
+    uint32_t acc = 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int p = 0; p < passes; p++) {
+        int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        for (; i + stride < nvec; i += 2 * stride) { uint4 x = buf[i], y = buf[i + stride]; acc += x.x ^ x.w ^ y.y ^ y.z; }
+        for (; i < nvec; i += stride) { uint4 x = buf[i]; acc += x.x ^ x.w; }
+    }
+    if (acc == 0x12345678u) out[0] = acc;
+}
+
+// streams three columns and, per 3 vectors read, writes one vector into / reads one vector from a small ring buffer
+__global__ void mixed_kernel(const uint4 *__restrict__ a, const uint4 *__restrict__ b, const uint4 *__restrict__ c, int64_t nvec,
+                             uint4 *__restrict__ ring, int64_t ringvec, uint32_t *__restrict__ out)
+{
+    uint32_t acc = 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+        uint4 x = a[i], y = b[i], z = c[i];
+        const int64_t r = (i / 3) % ringvec;
+        if (i % 3 == 0) ring[r] = uint4{x.x, y.y, z.z, x.w};
+        else if (i % 3 == 1) { uint4 q = ring[(r + ringvec / 2) % ringvec]; acc += q.x ^ q.w; }
+        acc += x.x ^ y.y ^ z.z;
+    }
+    if (acc == 0x12345678u) out[0] = acc;
+}
+
 template <typename F>
 static double time_ms(F &&launch, int reps = 7)
 {
@@ -155,6 +183,27 @@ int main(int argc, char **argv)
         double tro = time_ms([&] { read1_kernel<<<2048, 256>>>(buf, nvec, out); }, 5);
         printf("  W=%5d MiB: write %.3f ms (%.2f TB/s) | write+read %.3f ms | read-only (warm) %.3f ms (%.2f TB/s)\n", W, tw,
                nvec * 16 / tw / 1e9, tr, tro, nvec * 16 / tro / 1e9);
+        CK(hipFree(buf));
+    }
+    printf("\n[5] in-kernel repeated read of a W-MiB buffer (Infinity Cache bandwidth), 16 passes\n");
+    for (int W : {32, 64, 128, 192, 256, 384, 1024}) {
+        int64_t nvec = (int64_t)W * 1048576 / 16;
+        uint4 *buf; CK(hipMalloc(&buf, nvec * 16));
+        write_kernel<<<2048, 256>>>(buf, nvec);
+        for (int grid : {512, 2048}) {
+            double t = time_ms([&] { reread_kernel<<<grid, 256>>>(buf, nvec, 16, out); }, 3);
+            printf("  W=%5d MiB grid=%4d: %.3f ms for 16 passes -> %.2f TB/s\n", W, grid, t, 16.0 * nvec * 16 / t / 1e9);
+        }
+        CK(hipFree(buf));
+    }
+    printf("\n[6] read 3 GB stream + concurrently re-read/overwrite a 128 MiB buffer (does the stream evict it?)\n");
+    {
+        int64_t nvec = (int64_t)128 * 1048576 / 16;
+        uint4 *buf; CK(hipMalloc(&buf, nvec * 16));
+        write_kernel<<<2048, 256>>>(buf, nvec);
+        double t0 = time_ms([&] { read3_kernel<2><<<512, 256>>>((uint4 *)a, (uint4 *)b, (uint4 *)c, N / 4, out); });
+        double t1 = time_ms([&] { mixed_kernel<<<512, 256>>>((uint4 *)a, (uint4 *)b, (uint4 *)c, N / 4, buf, nvec, out); });
+        printf("  stream only %.3f ms; stream + write&read of 128 MiB x%d rounds: %.3f ms (extra bytes %.2f GB)\n", t0, (int)(N / 4 / (nvec)), t1, 2.0 * (N / 4) * 16 / 3 / 1e9);
         CK(hipFree(buf));
     }
     printf("done\n");
