@@ -11,6 +11,7 @@
 //       counts.  Indices come out ascending, bit-exact with a sequential
 //       filter.
 #include "hark_internal.h"
+int k_exclusive_scan_u32(hark_context *ctx, const uint32_t *in, int64_t n, uint32_t *out32, int64_t *out64, int64_t *total_host);
 
 namespace {
 
@@ -98,63 +99,38 @@ __device__ __forceinline__ uint32_t eval_tile(const T *__restrict__ col, int64_t
     return mask;
 }
 
-// Pass 1: survivors per (tile, group) -- 4 counts per tile, because the rows of
-// group g precede the rows of group g+1 in table order.
+// Pass 1: evaluate the predicate once.  Every thread keeps the 16-bit survivor
+// mask of its 16 rows in `masks` (2 B per 16 rows = 0.125 B/row, so pass 2 never
+// re-reads the predicate column) and the tile's survivor count goes to `counts`.
 template <typename T>
 __global__ __launch_bounds__(kThreads) void filter_count_kernel(const T *__restrict__ col, int64_t n, int op, Const64 c,
-                                                                uint32_t *__restrict__ counts)
+                                                                uint16_t *__restrict__ masks, uint32_t *__restrict__ counts)
 {
-    __shared__ uint32_t s_cnt[4];
-    if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
+    __shared__ uint32_t s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
     __syncthreads();
     const int64_t tile = blockIdx.x;
     const uint32_t mask = eval_tile<T>(col, n, tile, op, const_as<T>(c));
-#pragma unroll
-    for (int g = 0; g < 4; g++) {
-        uint32_t cnt = __popc((mask >> (g * 4)) & 15u);
-        for (int d = 32; d > 0; d >>= 1) cnt += __shfl_down(cnt, d, 64);
-        if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&s_cnt[g], cnt);
-    }
+    masks[tile * kThreads + threadIdx.x] = (uint16_t)mask;
+    uint32_t cnt = __popc(mask);
+    for (int d = 32; d > 0; d >>= 1) cnt += __shfl_down(cnt, d, 64);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&s_cnt, cnt);
     __syncthreads();
-    if (threadIdx.x < 4) counts[tile * 4 + threadIdx.x] = s_cnt[threadIdx.x];
+    if (threadIdx.x == 0) counts[tile] = s_cnt;
 }
 
-// Pass 2: exclusive scan of the per-(tile,group) counts, single workgroup.
-__global__ __launch_bounds__(1024) void scan_counts_kernel(const uint32_t *__restrict__ counts, int64_t m,
-                                                           int64_t *__restrict__ offsets, int64_t *__restrict__ total)
-{
-    __shared__ int64_t s_wave[16];
-    __shared__ int64_t s_carry;
-    if (threadIdx.x == 0) s_carry = 0;
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int64_t base = 0; base < m; base += 1024) {
-        int64_t i = base + threadIdx.x;
-        int64_t x = i < m ? (int64_t)counts[i] : 0, incl = x;
-        for (int d = 1; d < 64; d <<= 1) { int64_t y = __shfl_up(incl, d, 64); if (lane >= d) incl += y; }
-        if (lane == 63) s_wave[wave] = incl;
-        __syncthreads();
-        int64_t carry = s_carry;
-        for (int w = 0; w < wave; w++) carry += s_wave[w];
-        if (i < m) offsets[i] = carry + incl - x;
-        __syncthreads();
-        if (threadIdx.x == 1023) s_carry = carry + incl;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) *total = s_carry;
-}
-
-// Pass 3: re-evaluate, rank inside the (tile,group) with ballot + popcount,
-// write row indices and the projected columns at the compacted position.
-template <typename T>
-__global__ __launch_bounds__(kThreads) void filter_scatter_kernel(const T *__restrict__ col, int64_t n, int op, Const64 c,
+// Pass 2: rank the survivors inside the tile (popcount prefix over lanes, waves
+// and the four 1024-row groups), compact each output column through LDS and
+// write it with unit-stride stores starting at the tile's global offset.
+__global__ __launch_bounds__(kThreads) void filter_scatter_kernel(const uint16_t *__restrict__ masks, int64_t n,
                                                                   const int64_t *__restrict__ offsets,
                                                                   int64_t *__restrict__ row_index, ColSet cs)
 {
-    __shared__ uint32_t s_wcnt[4][4];                 // [group][wave]
+    __shared__ uint64_t s_stage[kTile];               // 32 KiB: one compacted column of the tile
+    __shared__ uint32_t s_wcnt[4][4];                 // [group][wave] survivors
     const int64_t tile = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t mask = eval_tile<T>(col, n, tile, op, const_as<T>(c));
+    const uint32_t mask = masks[tile * kThreads + threadIdx.x];
     uint32_t lane_excl[4];
 #pragma unroll
     for (int g = 0; g < 4; g++) {
@@ -165,24 +141,54 @@ __global__ __launch_bounds__(kThreads) void filter_scatter_kernel(const T *__res
         if (lane == 63) s_wcnt[g][wave] = incl;
     }
     __syncthreads();
+    // tile-local position of this thread's first survivor in each group
+    uint32_t pos[4], run = 0;
 #pragma unroll
     for (int g = 0; g < 4; g++) {
-        const uint32_t m4 = (mask >> (g * 4)) & 15u;
-        if (!m4) continue;
-        int64_t pos = offsets[tile * 4 + g] + lane_excl[g];
-        for (int w = 0; w < wave; w++) pos += s_wcnt[g][w];
-        const int64_t r = tile * kTile + ((int64_t)g * kThreads + threadIdx.x) * 4;
+        uint32_t before = 0, total = 0;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            if (m4 & (1u << j)) {
-                if (row_index) row_index[pos] = r + j;
-                for (int cidx = 0; cidx < cs.ncols; cidx++) {
-                    if (cs.esz[cidx] == 4) static_cast<uint32_t *>(cs.dst[cidx])[pos] = static_cast<const uint32_t *>(cs.src[cidx])[r + j];
-                    else static_cast<uint64_t *>(cs.dst[cidx])[pos] = static_cast<const uint64_t *>(cs.src[cidx])[r + j];
-                }
-                pos++;
+        for (int w = 0; w < 4; w++) { const uint32_t x = s_wcnt[g][w]; if (w < wave) before += x; total += x; }
+        pos[g] = run + before + lane_excl[g];
+        run += total;
+    }
+    const uint32_t tile_total = run;
+    const int64_t out0 = offsets[tile];
+    const int ncols = cs.ncols + (row_index ? 1 : 0);
+    for (int cidx = 0; cidx < ncols; cidx++) {
+        const bool is_index = row_index && cidx == cs.ncols;
+        const int esz = is_index ? 8 : cs.esz[cidx];
+        uint32_t *s32 = reinterpret_cast<uint32_t *>(s_stage);
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const uint32_t m4 = (mask >> (g * 4)) & 15u;
+            if (!m4) continue;
+            const int64_t r = tile * kTile + ((int64_t)g * kThreads + threadIdx.x) * 4;
+            uint32_t q = pos[g];
+            if (is_index) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) if (m4 & (1u << j)) s_stage[q++] = (uint64_t)(r + j);
+            } else if (esz == 4) {
+                const uint32_t *src = static_cast<const uint32_t *>(cs.src[cidx]);
+                uint32_t x[4];
+                if (r + 4 <= n) { const uint4 v4 = *reinterpret_cast<const uint4 *>(src + r); x[0] = v4.x; x[1] = v4.y; x[2] = v4.z; x[3] = v4.w; }
+                else for (int j = 0; j < 4; j++) x[j] = r + j < n ? src[r + j] : 0u;
+#pragma unroll
+                for (int j = 0; j < 4; j++) if (m4 & (1u << j)) s32[q++] = x[j];
+            } else {
+                const uint64_t *src = static_cast<const uint64_t *>(cs.src[cidx]);
+#pragma unroll
+                for (int j = 0; j < 4; j++) if (m4 & (1u << j)) s_stage[q++] = src[r + j];
             }
         }
+        __syncthreads();
+        if (esz == 4) {
+            uint32_t *dst = static_cast<uint32_t *>(cs.dst[cidx]) + out0;
+            for (uint32_t i = threadIdx.x; i < tile_total; i += kThreads) dst[i] = s32[i];
+        } else {
+            uint64_t *dst = (is_index ? reinterpret_cast<uint64_t *>(row_index) : static_cast<uint64_t *>(cs.dst[cidx])) + out0;
+            for (uint32_t i = threadIdx.x; i < tile_total; i += kThreads) dst[i] = s_stage[i];
+        }
+        __syncthreads();
     }
 }
 
@@ -299,24 +305,24 @@ int hark_entry_filter_sel(hark_context *ctx, hark_result **out, const hark_table
     if (extra) res->cols[0].dtype = HARK_I64;
     for (int64_t j = 0; j < k; j++) res->cols[j + extra].dtype = db->cols[cols[j]].dtype;
     int64_t total = 0;
-    uint32_t *counts = nullptr; int64_t *offsets = nullptr;
+    uint32_t *counts = nullptr; int64_t *offsets = nullptr; uint16_t *masks = nullptr;
     int rc = HARK_OK;
     if (n > 0) {
-        rc = hark_alloc(ctx, (void **)&counts, (size_t)ntiles * 4 * sizeof(uint32_t));
-        if (!rc) rc = hark_alloc(ctx, (void **)&offsets, ((size_t)ntiles * 4 + 1) * sizeof(int64_t));
+        rc = hark_alloc(ctx, (void **)&counts, (size_t)ntiles * sizeof(uint32_t));
+        if (!rc) rc = hark_alloc(ctx, (void **)&offsets, (size_t)ntiles * sizeof(int64_t));
+        if (!rc) rc = hark_alloc(ctx, (void **)&masks, (size_t)ntiles * kThreads * sizeof(uint16_t));
         if (!rc) {
             const void *wc = db->cols[where_col].data;
             hipStream_t st = ctx->stream;
             dim3 grid((unsigned)ntiles), block(kThreads);
             switch (wdt) {
-            case HARK_F32: filter_count_kernel<float><<<grid, block, 0, st>>>(static_cast<const float *>(wc), n, cmp, c, counts); break;
-            case HARK_I32: filter_count_kernel<int32_t><<<grid, block, 0, st>>>(static_cast<const int32_t *>(wc), n, cmp, c, counts); break;
-            case HARK_U32: filter_count_kernel<uint32_t><<<grid, block, 0, st>>>(static_cast<const uint32_t *>(wc), n, cmp, c, counts); break;
-            default: filter_count_kernel<int64_t><<<grid, block, 0, st>>>(static_cast<const int64_t *>(wc), n, cmp, c, counts); break;
+            case HARK_F32: filter_count_kernel<float><<<grid, block, 0, st>>>(static_cast<const float *>(wc), n, cmp, c, masks, counts); break;
+            case HARK_I32: filter_count_kernel<int32_t><<<grid, block, 0, st>>>(static_cast<const int32_t *>(wc), n, cmp, c, masks, counts); break;
+            case HARK_U32: filter_count_kernel<uint32_t><<<grid, block, 0, st>>>(static_cast<const uint32_t *>(wc), n, cmp, c, masks, counts); break;
+            default: filter_count_kernel<int64_t><<<grid, block, 0, st>>>(static_cast<const int64_t *>(wc), n, cmp, c, masks, counts); break;
             }
-            scan_counts_kernel<<<1, 1024, 0, st>>>(counts, ntiles * 4, offsets, offsets + ntiles * 4);
             if (hipGetLastError() != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "filter_sel: launch failed");
-            if (!rc) rc = hark_read_words(ctx, offsets + ntiles * 4, &total, 1);
+            if (!rc) rc = k_exclusive_scan_u32(ctx, counts, ntiles, nullptr, offsets, &total);
         }
     }
     if (!rc) {
@@ -334,20 +340,11 @@ int hark_entry_filter_sel(hark_context *ctx, hark_result **out, const hark_table
             cs.esz[j] = (int32_t)hark_dtype_size(res->cols[j + extra].dtype);
         }
         int64_t *ridx = extra ? static_cast<int64_t *>(res->cols[0].data) : nullptr;
-        const void *wc = db->cols[where_col].data;
-        hipStream_t st = ctx->stream;
-        dim3 grid((unsigned)ntiles), block(kThreads);
-        switch (wdt) {
-        case HARK_F32: filter_scatter_kernel<float><<<grid, block, 0, st>>>(static_cast<const float *>(wc), n, cmp, c, offsets, ridx, cs); break;
-        case HARK_I32: filter_scatter_kernel<int32_t><<<grid, block, 0, st>>>(static_cast<const int32_t *>(wc), n, cmp, c, offsets, ridx, cs); break;
-        case HARK_U32: filter_scatter_kernel<uint32_t><<<grid, block, 0, st>>>(static_cast<const uint32_t *>(wc), n, cmp, c, offsets, ridx, cs); break;
-        default: filter_scatter_kernel<int64_t><<<grid, block, 0, st>>>(static_cast<const int64_t *>(wc), n, cmp, c, offsets, ridx, cs); break;
-        }
+        filter_scatter_kernel<<<dim3((unsigned)ntiles), dim3(kThreads), 0, ctx->stream>>>(masks, n, offsets, ridx, cs);
         if (hipGetLastError() != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "filter_sel: launch failed");
         if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "filter_sel: kernel failed");
     }
-    if (counts) hark_free(ctx, counts);
-    if (offsets) hark_free(ctx, offsets);
+    hark_free(ctx, counts); hark_free(ctx, offsets); hark_free(ctx, masks);
     if (rc) { result_release(ctx, res); return rc; }
     *out = res;
     return HARK_OK;
