@@ -10,8 +10,8 @@
 // One pass = three launches over a fixed decomposition of the input into
 // `nblk` contiguous slices (one workgroup each):
 //   1. digit_hist_kernel   per-slice 256-bin digit histogram -> hist[bin][blk]
-//   2. scan_hist_kernel    exclusive scan in (bin, blk) order = first output
-//                          position of every (digit, slice)
+//   2. scan_hist_rows_kernel  per-digit exclusive scan over the slices (+ digit totals;
+//                          the scatter kernel prefixes the 256 totals itself)
 //   3. digit_scatter_kernel walks its slice in 4096-key tiles; inside a tile a
 //      wave ranks each key among equal digits with a wave64 ballot match (8
 //      ballots + popcount of the lower lanes), waves are chained by a prefix
@@ -50,35 +50,43 @@ __device__ __forceinline__ uint64_t lanemask_lt()
 __global__ __launch_bounds__(kSortThreads) void digit_hist_kernel(const uint32_t *__restrict__ keys, int64_t n, int64_t slice,
                                                                   int shift, uint32_t xor_mask, uint32_t *__restrict__ hist, int nblk)
 {
+    // plain ds_add_u32 per key (~10 lanes/clk/CU on gfx950); the slice starts on a
+    // multiple of 4096 keys, so 16-byte loads are aligned
     __shared__ uint32_t s_hist[kBins];
     s_hist[threadIdx.x] = 0;
     __syncthreads();
     const int64_t lo = (int64_t)blockIdx.x * slice;
     const int64_t hi = lo + slice < n ? lo + slice : n;
-    for (int64_t base = lo; base < hi; base += kSortThreads) {
-        const int64_t i = base + threadIdx.x;
-        const bool valid = i < hi;
-        const uint32_t d = valid ? (((keys[i] ^ xor_mask) >> shift) & 255u) : 0u;
-        const uint64_t peers = match_digit(d, valid);           // one LDS add per distinct digit per wave
-        if (valid && (peers & lanemask_lt()) == 0) atomicAdd(&s_hist[d], (uint32_t)__popcll(peers));
+    const int64_t nvec = (hi - lo) / 4;
+    const uint4 *k4 = reinterpret_cast<const uint4 *>(keys + lo);
+    for (int64_t i = threadIdx.x; i < nvec; i += kSortThreads) {
+        const uint4 q = k4[i];
+        atomicAdd(&s_hist[((q.x ^ xor_mask) >> shift) & 255u], 1u);
+        atomicAdd(&s_hist[((q.y ^ xor_mask) >> shift) & 255u], 1u);
+        atomicAdd(&s_hist[((q.z ^ xor_mask) >> shift) & 255u], 1u);
+        atomicAdd(&s_hist[((q.w ^ xor_mask) >> shift) & 255u], 1u);
     }
+    for (int64_t i = lo + nvec * 4 + threadIdx.x; i < hi; i += kSortThreads)
+        atomicAdd(&s_hist[((keys[i] ^ xor_mask) >> shift) & 255u], 1u);
     __syncthreads();
     hist[(size_t)threadIdx.x * nblk + blockIdx.x] = s_hist[threadIdx.x];
 }
 
-// Exclusive scan of m = 256*nblk counters by one workgroup (m <= ~1M).
-__global__ __launch_bounds__(1024) void scan_hist_kernel(uint32_t *__restrict__ hist, int64_t m)
+// Exclusive scan of each digit's row hist[d][0..nblk) (one workgroup per digit)
+// plus the row total; the scatter kernel adds the prefix over digit totals itself.
+__global__ __launch_bounds__(256) void scan_hist_rows_kernel(uint32_t *__restrict__ hist, int nblk, uint32_t *__restrict__ row_total)
 {
-    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_carry;
     if (threadIdx.x == 0) s_carry = 0;
     __syncthreads();
+    uint32_t *row = hist + (size_t)blockIdx.x * nblk;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int64_t base = 0; base < m; base += 4096) {             // 4 counters per thread per step
-        const int64_t i = base + (int64_t)threadIdx.x * 4;
+    for (int base = 0; base < nblk; base += 1024) {               // 4 counters per thread per step
+        const int i = base + threadIdx.x * 4;
         uint32_t x[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) x[j] = i + j < m ? hist[i + j] : 0u;
+        for (int j = 0; j < 4; j++) x[j] = i + j < nblk ? row[i + j] : 0u;
         const uint32_t tsum = x[0] + x[1] + x[2] + x[3];
         uint32_t incl = tsum;
         for (int d = 1; d < 64; d <<= 1) { uint32_t y = __shfl_up(incl, d, 64); if (lane >= d) incl += y; }
@@ -88,18 +96,20 @@ __global__ __launch_bounds__(1024) void scan_hist_kernel(uint32_t *__restrict__ 
         for (int w = 0; w < wave; w++) run += s_wave[w];
         run += incl - tsum;
 #pragma unroll
-        for (int j = 0; j < 4; j++) { if (i + j < m) hist[i + j] = run; run += x[j]; }
+        for (int j = 0; j < 4; j++) { if (i + j < nblk) row[i + j] = run; run += x[j]; }
         __syncthreads();
-        if (threadIdx.x == 1023) s_carry = run;
+        if (threadIdx.x == 255) s_carry = run;
         __syncthreads();
     }
+    if (threadIdx.x == 0) row_total[blockIdx.x] = s_carry;
 }
 
 // vals_in == nullptr means "payload = input position" (first pass of an argsort).
 __global__ __launch_bounds__(kSortThreads) void digit_scatter_kernel(
     const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
     uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
-    int64_t n, int64_t slice, int shift, uint32_t xor_mask, const uint32_t *__restrict__ hist, int nblk)
+    int64_t n, int64_t slice, int shift, uint32_t xor_mask, const uint32_t *__restrict__ hist, int nblk,
+    const uint32_t *__restrict__ row_total)
 {
     __shared__ uint32_t s_key[kSortTile];
     __shared__ uint32_t s_val[kSortTile];
@@ -111,7 +121,17 @@ __global__ __launch_bounds__(kSortThreads) void digit_scatter_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t lo = (int64_t)blockIdx.x * slice;
     const int64_t hi = lo + slice < n ? lo + slice : n;
-    s_gpos[tid] = (int64_t)hist[(size_t)tid * nblk + blockIdx.x];
+    {   // first output position of (digit tid, this slice) = digits before + this digit's earlier slices
+        const uint32_t tot = row_total[tid];
+        uint32_t incl = tot;
+        for (int d = 1; d < 64; d <<= 1) { uint32_t y = __shfl_up(incl, d, 64); if (lane >= d) incl += y; }
+        if (lane == 63) s_scan[wave] = incl;
+        __syncthreads();
+        uint32_t carry = 0;
+        for (int w = 0; w < wave; w++) carry += s_scan[w];
+        s_gpos[tid] = (int64_t)(carry + incl - tot) + (int64_t)hist[(size_t)tid * nblk + blockIdx.x];
+        __syncthreads();
+    }
     const uint64_t lt = lanemask_lt();
 
     for (int64_t tbase = lo; tbase < hi; tbase += kSortTile) {
@@ -225,7 +245,7 @@ size_t k_sort_workspace_bytes(int64_t n, int num_cu)
     int64_t nblk = (n + kSortTile - 1) / kSortTile;
     if (nblk > (int64_t)num_cu * 8) nblk = (int64_t)num_cu * 8;
     if (nblk < 1) nblk = 1;
-    return (size_t)kBins * (size_t)nblk * sizeof(uint32_t);
+    return (size_t)kBins * ((size_t)nblk + 1) * sizeof(uint32_t);      // histograms + the 256 digit totals
 }
 
 // Stable sort of n (key, val) pairs ascending by (key ^ xor_mask) as unsigned.
@@ -247,9 +267,10 @@ int k_sort_pairs_u32(hark_context *ctx, uint32_t *keys, uint32_t *vals, uint32_t
     for (int pass = 0; pass < 4; pass++) {
         const int shift = pass * 8;
         digit_hist_kernel<<<dim3((unsigned)nblk), dim3(kSortThreads), 0, st>>>(kin, n, slice, shift, xor_mask, hist_ws, (int)nblk);
-        scan_hist_kernel<<<1, 1024, 0, st>>>(hist_ws, (int64_t)kBins * nblk);
+        scan_hist_rows_kernel<<<kBins, 256, 0, st>>>(hist_ws, (int)nblk, hist_ws + (size_t)kBins * nblk);
         digit_scatter_kernel<<<dim3((unsigned)nblk), dim3(kSortThreads), 0, st>>>(
-            kin, (pass == 0 && vals_is_iota) ? nullptr : vin, kout, vout, n, slice, shift, xor_mask, hist_ws, (int)nblk);
+            kin, (pass == 0 && vals_is_iota) ? nullptr : vin, kout, vout, n, slice, shift, xor_mask, hist_ws, (int)nblk,
+            hist_ws + (size_t)kBins * nblk);
         HIP_TRY(ctx, hipGetLastError());
         uint32_t *t = kin; kin = kout; kout = t;
         t = vin; vin = vout; vout = t;
