@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from harkdb_amd.engine import Engine, FgbPlan
 
 N = int(float(sys.argv[1])) if len(sys.argv) > 1 else 1 << 28
-G = 1 << 20
+G = int(sys.argv[3]) if len(sys.argv) > 3 else 1 << 20
 spec = sys.argv[2] if len(sys.argv) > 2 else "grid=512;grid=1024"
 configs = [dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in c.split(",") if kv) for c in spec.split(";")]
 R = 8
