@@ -139,6 +139,16 @@ def main():
         alg_bytes = 12.0 * rows_per_launch + (16.0 * G if dom != "producer" else 0.0)
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
         kernel_name = {"single": "fgb_lds_kernel", "producer": "fgb_part_kernel", "consumer": "fgb_agg_kernel"}[dom]
+        # HBM traffic of the dominant kernel from the committed PMC passes of this same workload
+        # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled per the gfx950 note)
+        traffic, traffic_src = None, None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_fgb.json")))
+            if pmc["config"]["rows_per_gpu"] == N and pmc["config"]["groups"] == G and not a.algo and not a.chunk_rows:
+                traffic = pmc["kernels"][kernel_name]["hbm_bytes_per_launch_corrected"]
+                traffic_src = "profiles/r01_pmc_fgb.json"
+        except Exception:
+            pass
         path_bytes = 12.0 * N + 16.0 * G
         kernels_ms = sum(ms_by_kind.values()) / a.steps
         out = {
@@ -150,7 +160,7 @@ def main():
                        "rows_per_gpu": N, "groups": G, "selectivity": 0.5, "columns": "p f32, k i32, v f32 (HBM-resident)",
                        "exact_values": bool(a.exact), "merge": "RCCL all-reduce of f64 sums + i64 counts" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": dom_ms, "launches": dom_launches, "algorithmic_bytes_per_launch": alg_bytes},
             "hot_path": {"kernel_ms_per_step": kernels_ms, "by_kernel_ms_per_step": {kk: ms_by_kind[kk] / a.steps for kk in ms_by_kind},
                          "algorithmic_GBps_per_gpu": path_bytes / (kernels_ms * 1e-3) / 1e9,

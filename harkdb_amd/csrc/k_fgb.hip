@@ -498,7 +498,10 @@ static int plan_prepare_partition(hark_context *ctx, hark_fgb_plan *pl)
 {
     if (pl->pbuf) return HARK_OK;
     // bucket = key >> shift; KPB = 1 << shift keys per bucket, 12 B of LDS each in the consumer.
-    int shift = pl->shift ? (int)pl->shift : 12;
+    // default: ~256 buckets (one consumer workgroup per CU), i.e. shift = ceil(log2 G) - 8 in [4, 13]
+    int lg = 0;
+    while (((int64_t)1 << lg) < pl->G) lg++;
+    int shift = pl->shift ? (int)pl->shift : (lg - 8 < 4 ? 4 : (lg - 8 > 13 ? 13 : lg - 8));
     while ((((pl->G - 1) >> shift) + 1) > kMaxBuckets) shift++;
     if (((int64_t)12 << shift) > kAggTableBudget)
         return hark_fail(ctx, HARK_EUNSUPPORTED, "fgb: G = %lld needs more than %d buckets of <= %lld keys",
@@ -533,7 +536,9 @@ int k_fgb_dense_f32(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cm
     double *gsum = pl->acc_sum;
     unsigned long long *gcnt = pl->acc_cnt;
     int algo = (int)pl->algo;
-    if (algo == 0) algo = (G * 12 <= kLdsTableBudget) ? 1 : 3;
+    // auto: LDS tables while 12 B x G fits a workgroup; the partition path up to 256 buckets x 8192 keys;
+    // beyond that (G > 2^21) one global atomic pair per surviving row (slow, but any G works)
+    if (algo == 0) algo = (G * 12 <= kLdsTableBudget) ? 1 : (G <= (int64_t)kMaxBuckets * (kAggTableBudget / 12)) ? 3 : 2;
     if (algo == 1 && G * 12 > 159 * 1024)
         return hark_fail(ctx, HARK_EUNSUPPORTED, "fgb: LDS path needs 12*G <= 159 KiB");
     hipStream_t st = ctx->stream;

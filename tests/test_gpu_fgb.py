@@ -71,6 +71,14 @@ def test_all_comparisons(eng, oracle, cmp):
     assert np.array_equal(gc, cnt) and np.array_equal(gs, s32)
 
 
+def test_huge_key_domain_falls_back_to_atomics(eng, oracle):
+    """G > 2^21 exceeds the partition geometry: the plan picks the atomic path by itself."""
+    n, G = 400_000, 3_000_000
+    gs, gc = _run(eng, n, G, True)
+    s32, _, cnt = _oracle(oracle, n, G, True)
+    assert np.array_equal(gc, cnt) and np.array_equal(gs, s32)
+
+
 @pytest.mark.parametrize("algo,G", [(1, 1000), (2, 1 << 20), (3, 1 << 20)])
 def test_no_predicate(eng, oracle, algo, G):
     n = 777_777
