@@ -64,6 +64,8 @@ class FutharkContext:
     def sql_columns(self, sql_statement):
         """Like sql() but returns (column names, list of typed numpy columns)."""
         val_dic = sql_parse(self.tables, sql_statement)                    # FutharkContext.py:61
+        if val_dic.get("join"):
+            return self._join(val_dic)
         table = self.tables[val_dic["table_name"]]
         dev, eng = table._device, self.FutEnv
         schema = table.get_schema()
@@ -88,6 +90,20 @@ class FutharkContext:
         return self._groupby_extended(dev, schema, val_dic)
 
     # ---- extension paths ---------------------------------------------------------
+    def _join(self, ir):
+        """Two-table FROM -> `entry join` (futhark/join.fut:52-75): rows ordered by
+        (unsigned key, left row, right row); columns re-ordered to the select list."""
+        t1, t2 = (self.tables[n] for n in ir["tables"])
+        res = self.FutEnv.join(t1._device, t2._device, ir["col1"], ir["col2"], ir["cols1"], ir["cols2"])
+        cols = res.columns()
+        left_pos = {c: i for i, c in reversed(list(enumerate(ir["cols1"])))}
+        right_pos = {c: len(ir["cols1"]) + i for i, c in reversed(list(enumerate(ir["cols2"])))}
+        out = [cols[left_pos[c] if s == 0 else right_pos[c]] for s, c in ir["order"]]
+        names = [f"{ir['tables'][s]}.{(t1 if s == 0 else t2).get_schema()[c]}" for s, c in ir["order"]]
+        if "limit" in ir:
+            out = [c[: ir["limit"]] for c in out]
+        return names, out
+
     def _filtered(self, dev, where, need_cols):
         """Apply an AND-list of predicates on the device; returns (table-like, column map)."""
         eng = self.FutEnv

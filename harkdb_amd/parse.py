@@ -42,6 +42,8 @@ def _conditions(tree):
 def sql_parse(tables, sql_statement):
     """Parses an SQL statement (parse.py:16)."""
     js_obj = parse(sql_statement)                                       # parse.py:27
+    if isinstance(js_obj["from"], list):                                # two-table FROM (extension; SURVEY.md 8(f) 3)
+        return _join_parse(tables, js_obj)
     table_name = js_obj["from"]
     if table_name in tables:                                            # parse.py:30-33
         table = tables[table_name]
@@ -140,4 +142,53 @@ def sql_parse(tables, sql_statement):
     if "limit" in js_obj:
         ir["limit"] = int(js_obj["limit"])
         ir["extended"] = True
+    return ir
+
+
+def _qualified(name, names, tables):
+    """`table.column` -> (side, column index); a bare column must be unambiguous."""
+    if "." in name:
+        t, c = name.split(".", 1)
+        if t not in names:
+            raise Exception(f"{t} is not in tables")
+        side = names.index(t)
+        return side, _col(tables[t].get_schema(), c, t)
+    hits = [(i, getIndex(tables[t].get_schema(), name)) for i, t in enumerate(names)]
+    hits = [(i, j) for i, j in hits if j >= 0]
+    if len(hits) != 1:
+        raise Exception(f"{name} is {'ambiguous' if hits else 'not in the schema of table ' + ' or '.join(names)}")
+    return hits[0]
+
+
+def _join_parse(tables, js_obj):
+    """select a.x, b.y from a join b on a.k = b.k  ->  the arguments of `entry join`
+    (futhark/join.fut:52-54): col1, col2, cols1, cols2 (+ the select order)."""
+    left, j = js_obj["from"]
+    right = j["inner join"]
+    for t in (left, right):
+        if t not in tables:
+            raise Exception(f"{t} is not in tables")                    # parse.py:33
+    for clause in ("where", "groupby", "having", "orderby"):
+        if clause in js_obj:
+            raise Exception(f"{clause} is not supported together with JOIN")
+    names = [left, right]
+    (s1, c1), (s2, c2) = (_qualified(x, names, tables) for x in j["on"]["eq"])
+    if s1 == s2:
+        raise Exception("JOIN ... ON must compare a column of each table")
+    if s1 == 1:
+        c1, c2 = c2, c1
+    sel = js_obj["select"]
+    sel = [sel] if isinstance(sel, (dict, str)) else sel
+    order = []                                                          # (side, column) in select-list order
+    for item in sel:
+        if item == "*":
+            order += [(0, i) for i in range(len(tables[left].get_schema()))] + [(1, i) for i in range(len(tables[right].get_schema()))]
+        elif isinstance(item["value"], str):
+            order.append(_qualified(item["value"], names, tables))
+        else:
+            raise Exception("aggregates are not supported together with JOIN")
+    ir = {"join": True, "tables": names, "col1": c1, "col2": c2, "extended": True,
+          "cols1": [c for s, c in order if s == 0], "cols2": [c for s, c in order if s == 1], "order": order}
+    if "limit" in js_obj:
+        ir["limit"] = int(js_obj["limit"])
     return ir

@@ -12,6 +12,7 @@ own indexing: parse.py:29, :46-51, :66, :72-84):
      "having": {"gte": [{"sum": "col3"}, 10]},
      "orderby": {"value": "col1", "sort": "desc"},
      "limit": 10}
+    two tables:  "from": ["a", {"inner join": "b", "on": {"eq": ["a.k", "b.k"]}}]
 """
 import re
 
@@ -26,7 +27,7 @@ _TOKEN = re.compile(r"""\s*(?:
 _CMP = {">": "gt", ">=": "gte", "<": "lt", "<=": "lte", "=": "eq", "==": "eq", "!=": "neq", "<>": "neq"}
 _FLIP = {"gt": "lt", "gte": "lte", "lt": "gt", "lte": "gte", "eq": "eq", "neq": "neq"}
 AGGREGATES = ("prod", "sum", "max", "min", "count", "avg")
-_KEYWORDS = {"select", "from", "where", "group", "by", "having", "order", "limit", "asc", "desc", "as", "and"}
+_KEYWORDS = {"select", "from", "where", "group", "by", "having", "order", "limit", "asc", "desc", "as", "and", "join", "inner", "on"}
 
 
 class SqlSyntaxError(Exception):
@@ -124,6 +125,18 @@ class _Parser:
         tree = {"select": items[0] if len(items) == 1 else items}
         self.take("kw", "from")
         tree["from"] = self.take("id")
+        if self.peek("kw", "inner") or self.peek("kw", "join"):
+            # moz-style: "from": [left, {"inner join": right, "on": {"eq": [l, r]}}]
+            if self.peek("kw", "inner"):
+                self.take()
+            self.take("kw", "join")
+            right = self.take("id")
+            self.take("kw", "on")
+            lhs = self.take("id")
+            if self.take("op") not in ("=", "=="):
+                raise SqlSyntaxError("JOIN ... ON supports equality only")
+            rhs = self.take("id")
+            tree["from"] = [tree["from"], {"inner join": right, "on": {"eq": [lhs, rhs]}}]
         if self.peek("kw", "where"):
             self.take()
             tree["where"] = self.condition()

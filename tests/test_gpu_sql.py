@@ -109,3 +109,19 @@ def test_sql_mode_returns_select_list_only():
     assert names == ["col1", "max(col3)"] and [x.tolist() for x in cols] == [[0, 1, 6], [0, 3, 6]]
     c.drop_table("game_1")
     assert "game_1" not in c.tables
+
+
+def test_join_statement(fc, oracle):
+    """Two-table FROM -> join.fut semantics (golden G9: self-join of data.csv on col1)."""
+    fc.create_table("game_2", f"{GOLDEN}/data.csv")
+    out = fc.sql("select game_1.col1, game_1.col3, game_2.col8 from game_1 join game_2 on game_1.col1 = game_2.col1")
+    exp = [[0, 0, 0]] * 16 + [[1, 3, 1]] + [[6, 6, 6]] * 4
+    assert out.tolist() == exp
+    # select order interleaves the sides; result equals the oracle's join re-ordered
+    rng = np.random.default_rng(9)
+    a = rng.integers(0, 50, size=(3000, 3)).astype(np.int64)
+    b = rng.integers(0, 50, size=(2000, 2)).astype(np.int64)
+    fc.create_table("a", a); fc.create_table("b", b)
+    out = fc.sql("select b.col2, a.col3, a.col1 from a join b on a.col2 = b.col1")
+    ref = oracle.join(a, b, 1, 0, [2, 0], [1])
+    assert np.array_equal(out, ref[:, [2, 0, 1]].astype(out.dtype))

@@ -93,3 +93,16 @@ def test_table_ingest_ndarray_dataframe_txt(tmp_path):
         Table("bad", "file.parquet")
     with pytest.raises(Exception, match="not in a file"):
         Table("bad", 42)
+
+
+def test_join_parse_tree_and_ir(tables):
+    t = parse("select a.x, b.y from a join b on a.k = b.k")
+    assert t["from"] == ["a", {"inner join": "b", "on": {"eq": ["a.k", "b.k"]}}]
+    two = {"l": tables["game_1"], "r": Table("r", np.arange(6).reshape(3, 2))}
+    ir = sql_parse(two, "select r.col2, l.col3, l.col1 from l inner join r on r.col1 = l.col8")
+    assert ir["join"] and ir["tables"] == ["l", "r"] and (ir["col1"], ir["col2"]) == (7, 0)
+    assert ir["cols1"] == [2, 0] and ir["cols2"] == [1] and ir["order"] == [(1, 1), (0, 2), (0, 0)]
+    with pytest.raises(Exception, match="ambiguous"):
+        sql_parse(two, "select col1 from l join r on l.col1 = r.col1")
+    with pytest.raises(Exception, match="zzz is not in tables"):
+        sql_parse(two, "select l.col1 from l join zzz on l.col1 = zzz.col1")
