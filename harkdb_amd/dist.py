@@ -117,3 +117,138 @@ class ShardedFgb:
         self.plan.run(p, cmp, thr, k, v, n)
         allreduce_partials(self.sum_t, self.cnt_t)
         self.plan.finish(sum_out, count_out)
+
+
+# ---------------------------------------------------------------------------
+# Sharded SQL surface: FutharkContext over row-range shards
+# ---------------------------------------------------------------------------
+def gather_columns(cols, group=None):
+    """Concatenate per-rank result columns in rank order on every rank
+    (variable-length: object all_gather; results of a filter are small next to
+    the table, and the row order is the unsharded table's order)."""
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return cols
+    parts = [None] * dist.get_world_size(group)
+    dist.all_gather_object(parts, cols, group=group)
+    return [np.concatenate([p[j] for p in parts]) for j in range(len(cols))]
+
+
+_MERGE = {"sum": np.add, "count": np.add, "min": np.minimum, "max": np.maximum, "prod": np.multiply}
+
+
+def merge_grouped(keys, aggs, funcs, group=None):
+    """Merge per-rank GROUP BY results over sparse keys: gather (key, partial
+    aggregate) rows from every rank and fold equal keys.  `funcs[j]` names how
+    partials of aggregate j combine ("sum", "count", "min", "max", "prod");
+    AVG must be carried as a (sum, count) pair by the caller.  Returns keys
+    ascending."""
+    keys, aggs = gather_columns([keys], group)[0], gather_columns(list(aggs), group)
+    order = np.argsort(keys, kind="stable")
+    keys, aggs = keys[order], [a[order] for a in aggs]
+    heads = np.ones(len(keys), dtype=bool)
+    heads[1:] = keys[1:] != keys[:-1]
+    starts = np.flatnonzero(heads)
+    out = [_MERGE[f].reduceat(a, starts) if len(a) else a for a, f in zip(aggs, funcs)]
+    return keys[heads], out
+
+
+class ShardedFutharkContext:
+    """FutharkContext whose tables are row-range shards, one rank per GPU.
+
+    create_table() takes the FULL host table on every rank and keeps only this
+    rank's rows (shard_range); sql() runs the local operators on the shard and
+    merges: projection / WHERE results concatenate in rank order, GROUP BY
+    partials are all-reduced (dense keys, device side) or merged by key."""
+
+    def __init__(self, device=None):
+        import torch
+        from .context import FutharkContext
+        self.rank, local, self.world = init_process_group()
+        self.device = torch.device("cuda", local if device is None else device)
+        self.local = FutharkContext(device=self.device.index, sql_mode=True)
+        self.rows = {}
+
+    def create_table(self, table_name, table):
+        from .table import Table
+        full = Table(table_name, table)
+        n = full.get_data().shape[0]
+        lo, hi = shard_range(n, self.rank, self.world)
+        cols = [c[lo:hi] for c in full.host_columns()]
+        import pandas as pd
+        self.local.create_table(table_name, pd.DataFrame({h: c for h, c in zip(full.get_schema(), cols)}))
+        self.rows[table_name] = (n, lo, hi)
+
+    def drop_table(self, table_name):
+        self.local.drop_table(table_name)
+        self.rows.pop(table_name)
+
+    def sql(self, sql_statement):
+        names, cols = self.sql_columns(sql_statement)
+        dtype = np.result_type(*[c.dtype for c in cols]) if cols else np.int32
+        return np.stack([c.astype(dtype, copy=False) for c in cols], axis=1) if cols else np.empty((0, 0), dtype)
+
+    def sql_columns(self, sql_statement):
+        from .parse import sql_parse
+        ir = sql_parse(self.local.tables, sql_statement)
+        if ir.get("join"):
+            raise Exception("JOIN over sharded tables needs the all-to-all repartition (not built yet)")
+        if "groupbys" not in ir:
+            if "orderby" in ir:
+                raise Exception("ORDER BY over sharded tables needs the sample-sort exchange (not built yet)")
+            limit = ir.pop("limit", None)
+            stmt = sql_statement if limit is None else sql_statement[: sql_statement.lower().rindex("limit")]
+            names, cols = self.local.sql_columns(stmt)
+            cols = gather_columns(cols)
+            return names, ([c[:limit] for c in cols] if limit is not None else cols)
+        return self._groupby(ir)
+
+    def _groupby(self, ir):
+        """Local typed GROUP BY on the shard (AVG split into SUM and COUNT),
+        merge by key, then HAVING / ORDER BY / LIMIT on the merged G rows."""
+        schema = self.local.tables[ir["table_name"]].get_schema()
+        specs = []                       # partial aggregates to compute locally: (func, col)
+
+        def slot(spec):
+            if spec[0] == "key":
+                return ("key",)
+            if spec[0] == "col":
+                raise Exception(f"{schema[spec[1]]} is not an aggregation function or the columns thats grouped on")
+            if spec[0] == "avg":
+                return ("avg", slot(("sum", spec[1]))[1], slot(("count", None))[1])
+            if spec not in specs:
+                specs.append(spec)
+            return ("agg", specs.index(spec))
+
+        items = [slot(i) for i in ir["items"]]
+        having = [(slot(s), cmp, v) for s, cmp, v in ir.get("having", [])]
+        order = (slot(ir["orderby"][0]), ir["orderby"][1]) if "orderby" in ir else None
+        sel = ", ".join([schema[ir["g_col"]]] + [f"{f}({'*' if c is None else schema[c]})" for f, c in specs])
+        where = " and ".join(f"{schema[c]} {cmp} {v!r}" for c, cmp, v in ir.get("where", []))
+        stmt = f"select {sel} from {ir['table_name']}" + (f" where {where}" if where else "") + f" group by {schema[ir['g_col']]}"
+        _, cols = self.local.sql_columns(stmt)
+        widen = [c.astype(np.float64) if c.dtype == np.float32 else c for c in cols[1:]]     # merge f32 partial sums in f64
+        keys, merged = merge_grouped(cols[0], widen, [f for f, _ in specs])
+
+        def value(s):
+            if s[0] == "key":
+                return keys
+            if s[0] == "agg":
+                f, c = specs[s[1]]
+                return merged[s[1]].astype(np.float32) if cols[1 + s[1]].dtype == np.float32 else merged[s[1]]
+            return (merged[s[1]] / merged[s[2]]).astype(np.float32)
+
+        keep = np.ones(len(keys), dtype=bool)
+        ops = {">": np.greater, ">=": np.greater_equal, "<": np.less, "<=": np.less_equal, "=": np.equal, "!=": np.not_equal}
+        for s, cmp, v in having:
+            keep &= ops[cmp](value(s), v)
+        out = [value(s)[keep] for s in items]
+        if order is not None:
+            ov = value(order[0])[keep]
+            perm = np.argsort(-ov if order[1] else ov, kind="stable") if ov.dtype.kind != "u" else \
+                np.argsort((ov.max(initial=0) - ov) if order[1] else ov, kind="stable")
+            out = [c[perm] for c in out]
+        if "limit" in ir:
+            out = [c[: ir["limit"]] for c in out]
+        names = [schema[c] if f == "key" else f"{f}({'*' if c is None else schema[c]})" for f, c in ir["items"]]
+        return names, out

@@ -74,3 +74,43 @@ def test_shard_range_properties():
             assert rs[0][0] == 0 and rs[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(rs, rs[1:]))
             assert all(lo % 4 == 0 for lo, hi in rs if lo < n)
+
+
+def _merge_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from harkdb_amd import dist as hd
+    hd.init_process_group("cpu")
+    rng = np.random.default_rng(100 + rank)
+    keys = np.unique(rng.integers(-50, 50, size=40)).astype(np.int32)            # per-rank GROUP BY result, keys ascending
+    s = rng.integers(0, 1000, size=len(keys)).astype(np.int64)
+    c = rng.integers(1, 9, size=len(keys)).astype(np.int64)
+    mn = rng.random(len(keys)).astype(np.float32)
+    k2, (s2, c2, mn2) = hd.merge_grouped(keys, [s, c, mn], ["sum", "count", "min"])
+    g = hd.gather_columns([keys])[0]
+    q.put((rank, keys, s, c, mn, k2, s2, c2, mn2, g))
+    import torch.distributed as dist
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_merge_grouped_and_gather_two_ranks():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_merge_worker, args=(r, world, port, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    outs = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    allk = np.concatenate([o[1] for o in outs])
+    exp_keys = np.unique(allk)
+    for o in outs:
+        assert np.array_equal(o[5], exp_keys)
+        for j, key in enumerate(exp_keys):
+            ss = sum(int(x[2][x[1] == key].sum()) for x in outs)
+            cc = sum(int(x[3][x[1] == key].sum()) for x in outs)
+            mm = min(float(x[4][x[1] == key].min()) for x in outs if (x[1] == key).any())
+            assert o[6][j] == ss and o[7][j] == cc and o[8][j] == np.float32(mm)
+        assert np.array_equal(o[9], allk)                                        # rank-order concatenation
