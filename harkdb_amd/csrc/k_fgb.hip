@@ -197,8 +197,8 @@ __global__ __launch_bounds__(256) void fgb_atomic_kernel(
 // SLAB (heavier skew than the plan's slack) falls back to direct atomics.
 constexpr int kLine = 16;                                // pairs per 128-byte line
 constexpr int kQ = 32;                                   // queue capacity per bucket (pairs)
-constexpr int kPartThreads = 512;
-constexpr int kBatchRows = kPartThreads * kVec;          // 2048 rows per batch
+constexpr int kPartThreads = 1024;
+constexpr int kBatchRows = kPartThreads * kVec;          // 4096 rows per batch
 constexpr int kMaxBuckets = 256;                         // 256 * kQ * 8 B = 64 KiB of queues
 constexpr int kTileRows = 8192;                          // chunk granularity (multiple of kBatchRows)
 
@@ -527,7 +527,7 @@ static int plan_prepare_partition(hark_context *ctx, hark_fgb_plan *pl)
                          (long long)pl->G, kMaxBuckets, (long long)(kAggTableBudget / 12));
     pl->shift = shift;
     pl->P = ((pl->G - 1) >> shift) + 1;
-    pl->nwg = pl->grid ? pl->grid : (int64_t)ctx->num_cu * 2;
+    pl->nwg = pl->grid ? pl->grid : (int64_t)ctx->num_cu;       // one 1024-thread producer per CU (profiles/r01_notes.md)
     int64_t chunk = pl->chunk_rows ? pl->chunk_rows : (int64_t)1 << 28;
     chunk = (chunk + kTileRows - 1) / kTileRows * kTileRows;
     if (pl->max_rows > 0 && chunk > pl->max_rows) chunk = (pl->max_rows + kTileRows - 1) / kTileRows * kTileRows;
