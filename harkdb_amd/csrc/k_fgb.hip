@@ -248,11 +248,7 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
         }
     };
 
-    float4 npr; int4 nkr; float4 nvr;
-    if ((int64_t)wg < nbatch) load(wg, npr, nkr, nvr);
-    for (int64_t batch = wg; batch < nbatch; batch += nwg) {
-        const float4 pr = npr; const int4 kr = nkr; const float4 vr = nvr;
-        if (batch + nwg < nbatch) load(batch + nwg, npr, nkr, nvr);       // next batch's loads fly during this one
+    auto process = [&](int64_t batch, const float4 pr, const int4 kr, const float4 vr) {
         const float pv[4] = {pr.x, pr.y, pr.z, pr.w};
         const int kv[4] = {kr.x, kr.y, kr.z, kr.w};
         const float vv[4] = {vr.x, vr.y, vr.z, vr.w};
@@ -319,6 +315,23 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
             }
             again = __syncthreads_or(pending != 0);
         } while (again);
+    };
+
+    // two batches of loads stay in flight per lane while a batch is enqueued and flushed
+    float4 pA, vA, pB, vB; int4 kA, kB;
+    if ((int64_t)wg < nbatch) load(wg, pA, kA, vA);
+    if ((int64_t)wg + nwg < nbatch) load((int64_t)wg + nwg, pB, kB, vB);
+    for (int64_t batch = wg; batch < nbatch; batch += 2 * (int64_t)nwg) {
+        {
+            const float4 pr = pA, vr = vA; const int4 kr = kA;
+            if (batch + 2 * (int64_t)nwg < nbatch) load(batch + 2 * (int64_t)nwg, pA, kA, vA);
+            process(batch, pr, kr, vr);
+        }
+        if (batch + nwg < nbatch) {
+            const float4 pr = pB, vr = vB; const int4 kr = kB;
+            if (batch + 3 * (int64_t)nwg < nbatch) load(batch + 3 * (int64_t)nwg, pB, kB, vB);
+            process(batch + nwg, pr, kr, vr);
+        }
     }
     // ---- final flush: what is left (< kLine pairs per bucket) goes out as one partial line
     for (int b = tid; b < P; b += kPartThreads) {
@@ -527,7 +540,7 @@ static int plan_prepare_partition(hark_context *ctx, hark_fgb_plan *pl)
                          (long long)pl->G, kMaxBuckets, (long long)(kAggTableBudget / 12));
     pl->shift = shift;
     pl->P = ((pl->G - 1) >> shift) + 1;
-    pl->nwg = pl->grid ? pl->grid : (int64_t)ctx->num_cu;       // one 1024-thread producer per CU (profiles/r01_notes.md)
+    pl->nwg = pl->grid ? pl->grid : (int64_t)ctx->num_cu * 2;   // two 1024-thread producers per CU (profiles/r01_notes.md)
     int64_t chunk = pl->chunk_rows ? pl->chunk_rows : (int64_t)1 << 28;
     chunk = (chunk + kTileRows - 1) / kTileRows * kTileRows;
     if (pl->max_rows > 0 && chunk > pl->max_rows) chunk = (pl->max_rows + kTileRows - 1) / kTileRows * kTileRows;
