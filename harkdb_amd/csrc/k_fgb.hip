@@ -541,7 +541,7 @@ static int plan_prepare_partition(hark_context *ctx, hark_fgb_plan *pl)
     pl->shift = shift;
     pl->P = ((pl->G - 1) >> shift) + 1;
     pl->nwg = pl->grid ? pl->grid : (int64_t)ctx->num_cu * 2;   // two 1024-thread producers per CU (profiles/r01_notes.md)
-    int64_t chunk = pl->chunk_rows ? pl->chunk_rows : (int64_t)1 << 28;
+    int64_t chunk = pl->chunk_rows ? pl->chunk_rows : (int64_t)1 << 30;   // 10.4 GB of slabs per 2^30 rows; fewer, longer slabs
     chunk = (chunk + kTileRows - 1) / kTileRows * kTileRows;
     if (pl->max_rows > 0 && chunk > pl->max_rows) chunk = (pl->max_rows + kTileRows - 1) / kTileRows * kTileRows;
     pl->chunk_rows = chunk;
