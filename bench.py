@@ -144,7 +144,8 @@ def main():
         traffic, traffic_src = None, None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_fgb.json")))
-            if pmc["config"]["rows_per_gpu"] == N and pmc["config"]["groups"] == G and not a.algo and not a.chunk_rows:
+            if (pmc["config"]["rows_per_gpu"] == N and pmc["config"]["groups"] == G and not a.algo and not a.chunk_rows
+                    and dom_launches == a.steps * pmc["config"]["producer_launches_per_step"]):
                 traffic = pmc["kernels"][kernel_name]["hbm_bytes_per_launch_corrected"]
                 traffic_src = "profiles/r01_pmc_fgb.json"
         except Exception:
