@@ -89,6 +89,7 @@ struct hark_fgb_plan {
     int64_t ablate = 0;        // timing experiments only
     int64_t variant = 0;       // (unused)
     int64_t timing = 0;        // record HIP events around every kernel launch
+    int64_t vop = 0;           // value operator: 0 f32 sum (f64 acc), 1..4 u32 sum/max/min/prod
     std::vector<hipEvent_t> ev; std::vector<int> ev_kind; size_t ev_used = 0;
     uint2 *pbuf = nullptr;     // [P][nwg][cap] (key, value-bits) pairs
     uint32_t *counts = nullptr;// [P][nwg] pairs in each slab

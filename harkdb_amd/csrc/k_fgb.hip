@@ -53,6 +53,65 @@ __device__ __forceinline__ bool cmp_f32(float a, float b)
     else return true;                   // kNoPred
 }
 
+// ---- value operators of the accumulators ------------------------------------
+// One 8-byte slot per group (+ a count).  F32SUM keeps a double; the u32 operators
+// of the reference's type_func (groupby.fut:35-41: wrapping +, *, max, min) keep the
+// value in the low word.  LDS forms: ds_add_f64 / ds_add_u32 / ds_max_u32 / ds_min_u32
+// (native, 3.5-11 lanes/clk), product by an LDS compare-and-swap loop.
+typedef unsigned long long u64;
+enum { VOP_F32SUM = 0, VOP_U32SUM = 1, VOP_U32MAX = 2, VOP_U32MIN = 3, VOP_U32PROD = 4 };
+
+__host__ __device__ inline u64 vop_identity(int vop)
+{
+    return vop == VOP_U32MIN ? 0xFFFFFFFFull : vop == VOP_U32PROD ? 1ull : 0ull;    // 0.0 has all-zero bits
+}
+
+__device__ __forceinline__ u64 vop_merge(int vop, u64 a, u64 b)
+{
+    switch (vop) {
+    case VOP_F32SUM: return (u64)__double_as_longlong(__longlong_as_double((long long)a) + __longlong_as_double((long long)b));
+    case VOP_U32SUM: return (uint32_t)((uint32_t)a + (uint32_t)b);
+    case VOP_U32MAX: return (uint32_t)a > (uint32_t)b ? (uint32_t)a : (uint32_t)b;
+    case VOP_U32MIN: return (uint32_t)a < (uint32_t)b ? (uint32_t)a : (uint32_t)b;
+    default: return (uint32_t)((uint32_t)a * (uint32_t)b);
+    }
+}
+
+// combine the value `x` (raw 32 bits of the column element) into an 8-byte slot with atomics;
+// works on LDS and on global memory (the compiler picks ds_* or global_* from the address space)
+template <int VOP>
+__device__ __forceinline__ void vop_atomic(u64 *slot, uint32_t x)
+{
+    uint32_t *lo = reinterpret_cast<uint32_t *>(slot);
+    if constexpr (VOP == VOP_F32SUM) unsafeAtomicAdd(reinterpret_cast<double *>(slot), (double)__uint_as_float(x));
+    else if constexpr (VOP == VOP_U32SUM) atomicAdd(lo, x);
+    else if constexpr (VOP == VOP_U32MAX) atomicMax(lo, x);
+    else if constexpr (VOP == VOP_U32MIN) atomicMin(lo, x);
+    else {
+        uint32_t old = *lo, assumed;
+        do { assumed = old; old = atomicCAS(lo, assumed, assumed * x); } while (old != assumed);
+    }
+}
+
+// same with an already-accumulated partial (slot value `part`) instead of a column element
+template <int VOP>
+__device__ __forceinline__ void vop_atomic_partial(u64 *slot, u64 part)
+{
+    if constexpr (VOP == VOP_F32SUM) unsafeAtomicAdd(reinterpret_cast<double *>(slot), __longlong_as_double((long long)part));
+    else vop_atomic<VOP>(slot, (uint32_t)part);
+}
+
+__device__ __forceinline__ void vop_atomic_rt(int vop, u64 *slot, uint32_t x)
+{
+    switch (vop) {
+    case VOP_F32SUM: vop_atomic<VOP_F32SUM>(slot, x); break;
+    case VOP_U32SUM: vop_atomic<VOP_U32SUM>(slot, x); break;
+    case VOP_U32MAX: vop_atomic<VOP_U32MAX>(slot, x); break;
+    case VOP_U32MIN: vop_atomic<VOP_U32MIN>(slot, x); break;
+    default: vop_atomic<VOP_U32PROD>(slot, x); break;
+    }
+}
+
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x)
 {
     x += 0x9E3779B97F4A7C15ull;
@@ -77,19 +136,19 @@ __global__ void gen_columns_kernel(uint64_t seed, int64_t first_row, int64_t n, 
 // ---------------------------------------------------------------------------
 // LDS-privatised path
 // ---------------------------------------------------------------------------
-// Dynamic LDS: double s_sum[G << RL]; uint32 s_cnt[G << RL].  The replica of a
-// key used by lane l is (key << RL) | (l & (R-1)).
-template <int OP>
+// Dynamic LDS: u64 s_sum[G << RL] (8-byte value slots); uint32 s_cnt[G << RL].  The
+// replica of a key used by lane l is (key << RL) | (l & (R-1)).
+template <int OP, int VOP>
 __global__ __launch_bounds__(1024) void fgb_lds_kernel(
     const float *__restrict__ p, const int32_t *__restrict__ k, const float *__restrict__ v,
-    int64_t n, float thr, int G, int RL, double *__restrict__ gsum,
+    int64_t n, float thr, int G, int RL, u64 *__restrict__ gsum,
     unsigned long long *__restrict__ gcnt, int32_t *__restrict__ err)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int slots = G << RL;
-    double *s_sum = reinterpret_cast<double *>(lds_raw);
-    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(lds_raw + sizeof(double) * slots);
-    for (int i = threadIdx.x; i < slots; i += blockDim.x) { s_sum[i] = 0.0; s_cnt[i] = 0u; }
+    u64 *s_sum = reinterpret_cast<u64 *>(lds_raw);
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(lds_raw + sizeof(u64) * slots);
+    for (int i = threadIdx.x; i < slots; i += blockDim.x) { s_sum[i] = vop_identity(VOP); s_cnt[i] = 0u; }
     __syncthreads();
 
     const uint32_t rep = threadIdx.x & ((1u << RL) - 1u);
@@ -104,8 +163,8 @@ __global__ __launch_bounds__(1024) void fgb_lds_kernel(
         if (cmp_f32<OP>(pv, thr)) {
             if ((uint32_t)key < (uint32_t)G) {
                 uint32_t s = ((uint32_t)key << RL) | rep;
-                unsafeAtomicAdd(&s_sum[s], (double)val);      // ds_add_f64
-                atomicAdd(&s_cnt[s], 1u);                     // ds_add_u32
+                vop_atomic<VOP>(&s_sum[s], __float_as_uint(val));   // ds_add_f64 / ds_{add,max,min}_u32
+                atomicAdd(&s_cnt[s], 1u);                           // ds_add_u32
             } else bad = true;
         }
     };
@@ -136,10 +195,10 @@ __global__ __launch_bounds__(1024) void fgb_lds_kernel(
 
     const int R = 1 << RL;
     for (int g = threadIdx.x; g < G; g += blockDim.x) {
-        double s = 0.0; uint32_t c = 0;
-        for (int r = 0; r < R; r++) { s += s_sum[(g << RL) + r]; c += s_cnt[(g << RL) + r]; }
+        u64 s = vop_identity(VOP); uint32_t c = 0;
+        for (int r = 0; r < R; r++) { s = vop_merge(VOP, s, s_sum[(g << RL) + r]); c += s_cnt[(g << RL) + r]; }
         if (c) {
-            unsafeAtomicAdd(&gsum[g], s);                     // global_atomic_add_f64, contiguous
+            vop_atomic_partial<VOP>(&gsum[g], s);             // contiguous global atomics (global_atomic_add_f64 ...)
             atomicAdd(&gcnt[g], (unsigned long long)c);
         }
     }
@@ -151,8 +210,8 @@ __global__ __launch_bounds__(1024) void fgb_lds_kernel(
 template <int OP>
 __global__ __launch_bounds__(256) void fgb_atomic_kernel(
     const float *__restrict__ p, const int32_t *__restrict__ k, const float *__restrict__ v,
-    int64_t n, float thr, int64_t G, double *__restrict__ gsum,
-    unsigned long long *__restrict__ gcnt, int32_t *__restrict__ err)
+    int64_t n, float thr, int64_t G, u64 *__restrict__ gsum,
+    unsigned long long *__restrict__ gcnt, int32_t *__restrict__ err, int vop)
 {
     const int64_t nvec = n / kVec;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -163,7 +222,7 @@ __global__ __launch_bounds__(256) void fgb_atomic_kernel(
     auto row = [&](float pv, int32_t key, float val) {
         if (cmp_f32<OP>(pv, thr)) {
             if (key >= 0 && (int64_t)key < G) {
-                unsafeAtomicAdd(&gsum[key], (double)val);
+                vop_atomic_rt(vop, &gsum[key], __float_as_uint(val));
                 atomicAdd(&gcnt[key], 1ull);
             } else bad = true;
         }
@@ -209,7 +268,7 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
     const float *__restrict__ p, const int32_t *__restrict__ k, const float *__restrict__ v,
     int64_t row0, int64_t row1, float thr, int64_t G, int shift, int P,
     uint2 *__restrict__ pbuf, uint32_t *__restrict__ counts, uint32_t cap,
-    double *__restrict__ gsum, unsigned long long *__restrict__ gcnt, int32_t *__restrict__ err, int ablate)
+    u64 *__restrict__ gsum, unsigned long long *__restrict__ gcnt, int32_t *__restrict__ err, int ablate, int vop)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     uint2 *queue = reinterpret_cast<uint2 *>(lds_raw);                 // [P][kQ]
@@ -294,8 +353,8 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
                                 if (!(ablate & 32)) __builtin_nontemporal_store(u4v{two.x, two.y, two.z, two.w}, reinterpret_cast<u4v *>(dst)); else *dst = two;
                             }
                         } else {                                           // slab full: direct atomics
-                            unsafeAtomicAdd(&gsum[two.x], (double)__uint_as_float(two.y)); atomicAdd(&gcnt[two.x], 1ull);
-                            unsafeAtomicAdd(&gsum[two.z], (double)__uint_as_float(two.w)); atomicAdd(&gcnt[two.z], 1ull);
+                            vop_atomic_rt(vop, &gsum[two.x], two.y); atomicAdd(&gcnt[two.x], 1ull);
+                            vop_atomic_rt(vop, &gsum[two.z], two.w); atomicAdd(&gcnt[two.z], 1ull);
                         }
                     }
                     if (i == 0) {
@@ -309,7 +368,7 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
 #pragma unroll
                 for (int j = 0; j < kVec; j++)
                     if ((pending & (1u << j)) && !(ablate & 2)) {
-                        unsafeAtomicAdd(&gsum[(uint32_t)kv[j]], (double)vv[j]); atomicAdd(&gcnt[(uint32_t)kv[j]], 1ull);
+                        vop_atomic_rt(vop, &gsum[(uint32_t)kv[j]], __float_as_uint(vv[j])); atomicAdd(&gcnt[(uint32_t)kv[j]], 1ull);
                     }
                 pending = 0;
             }
@@ -346,10 +405,11 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
 // ---------------------------------------------------------------------------
 // Partition path, CONSUMER: one workgroup folds one bucket into its table slice
 // ---------------------------------------------------------------------------
-// LDS: double s_sum[KPB]; uint32 s_cnt[KPB], KPB = 1 << shift keys per bucket.
+// LDS: u64 s_sum[KPB] (8-byte value slots); uint32 s_cnt[KPB], KPB = 1 << shift keys per bucket.
+template <int VOP>
 __global__ __launch_bounds__(1024) void fgb_agg_kernel(
     const uint2 *__restrict__ pbuf, const uint32_t *__restrict__ counts, uint32_t cap, int nwg, int shift,
-    int64_t G, double *__restrict__ gsum, unsigned long long *__restrict__ gcnt, int ablate)
+    int64_t G, u64 *__restrict__ gsum, unsigned long long *__restrict__ gcnt, int ablate)
 {
     typedef unsigned int u4v __attribute__((ext_vector_type(4)));
     auto ld = [&](const uint4 *q) -> uint4 {
@@ -359,15 +419,15 @@ __global__ __launch_bounds__(1024) void fgb_agg_kernel(
     };
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int KPB = 1 << shift;
-    double *s_sum = reinterpret_cast<double *>(lds_raw);
-    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(lds_raw + sizeof(double) * KPB);
+    u64 *s_sum = reinterpret_cast<u64 *>(lds_raw);
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(lds_raw + sizeof(u64) * KPB);
     const int b = blockIdx.x;
-    for (int i = threadIdx.x; i < KPB; i += blockDim.x) { s_sum[i] = 0.0; s_cnt[i] = 0u; }
+    for (int i = threadIdx.x; i < KPB; i += blockDim.x) { s_sum[i] = vop_identity(VOP); s_cnt[i] = 0u; }
     __syncthreads();
     const uint32_t mask = (uint32_t)KPB - 1u;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     auto add = [&](uint32_t key, uint32_t vbits) {
-        unsafeAtomicAdd(&s_sum[key & mask], (double)__uint_as_float(vbits));
+        vop_atomic<VOP>(&s_sum[key & mask], vbits);
         atomicAdd(&s_cnt[key & mask], 1u);
     };
     // each wave walks whole slabs: 2 pairs (16 bytes) per lane per load, 2 loads in flight
@@ -389,7 +449,7 @@ __global__ __launch_bounds__(1024) void fgb_agg_kernel(
     for (int i = threadIdx.x; i < KPB; i += blockDim.x) {
         const uint32_t c = s_cnt[i];
         if (c && kbase + i < G) {                           // this workgroup owns [kbase, kbase+KPB)
-            gsum[kbase + i] += s_sum[i];
+            gsum[kbase + i] = vop_merge(VOP, gsum[kbase + i], s_sum[i]);
             gcnt[kbase + i] += (unsigned long long)c;
         }
     }
@@ -402,6 +462,35 @@ __global__ __launch_bounds__(256) void fgb_finish_kernel(const double *__restric
     for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < G; g += stride) {
         if (sum_out) sum_out[g] = (float)acc_sum[g];
         if (cnt_out) cnt_out[g] = (int64_t)acc_cnt[g];
+    }
+}
+
+__global__ __launch_bounds__(256) void fgb_finish_u32_kernel(const u64 *__restrict__ acc, const unsigned long long *__restrict__ acc_cnt,
+                                                             int64_t G, uint32_t *__restrict__ val_out, int64_t *__restrict__ cnt_out)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < G; g += stride) {
+        if (val_out) val_out[g] = (uint32_t)acc[g];
+        if (cnt_out) cnt_out[g] = (int64_t)acc_cnt[g];
+    }
+}
+
+__global__ __launch_bounds__(256) void fgb_fill_kernel(u64 *__restrict__ dst, int64_t n, u64 v)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = v;
+}
+
+template <typename F>
+int dispatch_vop(int vop, F &&f)
+{
+    switch (vop) {
+    case VOP_F32SUM: return f(std::integral_constant<int, VOP_F32SUM>{});
+    case VOP_U32SUM: return f(std::integral_constant<int, VOP_U32SUM>{});
+    case VOP_U32MAX: return f(std::integral_constant<int, VOP_U32MAX>{});
+    case VOP_U32MIN: return f(std::integral_constant<int, VOP_U32MIN>{});
+    case VOP_U32PROD: return f(std::integral_constant<int, VOP_U32PROD>{});
+    default: return HARK_EARG;
     }
 }
 
@@ -503,6 +592,7 @@ int hark_fgb_plan_set(hark_fgb_plan *pl, const char *key, int64_t value)
     else if (!strcmp(key, "shift")) { if (value < 0 || value > 13) return HARK_EARG; pl->shift = value; }
     else if (!strcmp(key, "slack_pct")) { if (value < 0 || value > 10000) return HARK_EARG; pl->slack_pct = value; }
     else if (!strcmp(key, "timing")) { pl->timing = value; return HARK_OK; }
+    else if (!strcmp(key, "vop")) { if (value < 0 || value > 4) return HARK_EARG; pl->vop = value; return HARK_OK; }   // reset afterwards
     else if (!strcmp(key, "variant")) { if (value < 0 || value > 3) return HARK_EARG; pl->variant = value; return HARK_OK; }
     else if (!strcmp(key, "ablate")) { pl->ablate = value; return HARK_OK; }   // timing experiments only: wrong results
     else return HARK_EARG;
@@ -513,7 +603,14 @@ int hark_fgb_plan_set(hark_fgb_plan *pl, const char *key, int64_t value)
 int hark_fgb_reset(hark_context *ctx, hark_fgb_plan *pl)
 {
     if (!ctx || !pl) return HARK_EARG;
-    HIP_TRY(ctx, hipMemsetAsync(pl->acc_sum, 0, (size_t)pl->G * sizeof(double), ctx->stream));
+    const u64 ident = vop_identity((int)pl->vop);
+    if (ident == 0) HIP_TRY(ctx, hipMemsetAsync(pl->acc_sum, 0, (size_t)pl->G * sizeof(double), ctx->stream));
+    else {
+        int64_t blocks = (pl->G + 255) / 256;
+        if (blocks > (int64_t)ctx->num_cu * 4) blocks = (int64_t)ctx->num_cu * 4;
+        fgb_fill_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(reinterpret_cast<u64 *>(pl->acc_sum), pl->G, ident);
+        HIP_TRY(ctx, hipGetLastError());
+    }
     HIP_TRY(ctx, hipMemsetAsync(pl->acc_cnt, 0, (size_t)pl->G * sizeof(unsigned long long), ctx->stream));
     return HARK_OK;
 }
@@ -565,7 +662,9 @@ int k_fgb_dense_f32(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cm
     auto misaligned = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) != 0; };
     if ((p && misaligned(p)) || misaligned(k) || misaligned(v))
         return hark_fail(ctx, HARK_EARG, "fgb: columns must be 16-byte aligned");
-    double *gsum = pl->acc_sum;
+    u64 *gsum = reinterpret_cast<u64 *>(pl->acc_sum);
+    const int vop = (int)pl->vop;
+    if (vop != VOP_F32SUM && p) return hark_fail(ctx, HARK_EARG, "fgb: the u32 operators take no predicate");
     unsigned long long *gcnt = pl->acc_cnt;
     int algo = (int)pl->algo;
     // auto: LDS tables while 12 B x G fits a workgroup; the partition path up to 256 buckets x 8192 keys;
@@ -584,16 +683,19 @@ int k_fgb_dense_f32(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cm
         int64_t grid = pl->grid ? pl->grid : (int64_t)ctx->num_cu;
         const int64_t need = (n / kVec + 1023) / 1024;
         if (grid > need) grid = need > 0 ? need : 1;
-        return dispatch_op(cmp, p != nullptr, [&](auto op) -> int {
-            constexpr int OP = decltype(op)::value;
+        auto launch = [&](auto op, auto vopc) -> int {
+            constexpr int OP = decltype(op)::value, VOP = decltype(vopc)::value;
             if (lds > 64 * 1024)
-                HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_lds_kernel<OP>),
+                HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_lds_kernel<OP, VOP>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             TimedLaunch tl(pl, st, 0);
-            fgb_lds_kernel<OP><<<dim3((unsigned)grid), dim3(1024), lds, st>>>(p, k, v, n, thr, (int)G, RL, gsum, gcnt, pl->err);
+            fgb_lds_kernel<OP, VOP><<<dim3((unsigned)grid), dim3(1024), lds, st>>>(p, k, v, n, thr, (int)G, RL, gsum, gcnt, pl->err);
             HIP_TRY(ctx, hipGetLastError());
             return HARK_OK;
-        });
+        };
+        if (vop == VOP_F32SUM)
+            return dispatch_op(cmp, p != nullptr, [&](auto op) -> int { return launch(op, std::integral_constant<int, VOP_F32SUM>{}); });
+        return dispatch_vop(vop, [&](auto vopc) -> int { return launch(std::integral_constant<int, kNoPred>{}, vopc); });
     }
     if (algo == 2) {
         int64_t grid = pl->grid ? pl->grid : (int64_t)ctx->num_cu * 8;
@@ -602,7 +704,7 @@ int k_fgb_dense_f32(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cm
         return dispatch_op(cmp, p != nullptr, [&](auto op) -> int {
             constexpr int OP = decltype(op)::value;
             TimedLaunch tl(pl, st, 0);
-            fgb_atomic_kernel<OP><<<dim3((unsigned)grid), dim3(256), 0, st>>>(p, k, v, n, thr, G, gsum, gcnt, pl->err);
+            fgb_atomic_kernel<OP><<<dim3((unsigned)grid), dim3(256), 0, st>>>(p, k, v, n, thr, G, gsum, gcnt, pl->err, vop);
             HIP_TRY(ctx, hipGetLastError());
             return HARK_OK;
         });
@@ -613,9 +715,14 @@ int k_fgb_dense_f32(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cm
     const size_t lds_agg = (size_t)12 << shift;
     return dispatch_op(cmp, p != nullptr, [&](auto op) -> int {
         constexpr int OP = decltype(op)::value;
-        if (lds_agg > 64 * 1024)
-            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_agg_kernel),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_agg));
+        if (lds_agg > 64 * 1024) {
+            int rc = dispatch_vop(vop, [&](auto vopc) -> int {
+                HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_agg_kernel<decltype(vopc)::value>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_agg));
+                return HARK_OK;
+            });
+            if (rc) return rc;
+        }
         const size_t lds_part = part_lds_bytes(P);
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_part_kernel<OP>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part));
@@ -624,13 +731,17 @@ int k_fgb_dense_f32(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cm
             {
                 TimedLaunch tl(pl, st, 1);
                 fgb_part_kernel<OP><<<dim3((unsigned)nwg), dim3(kPartThreads), lds_part, st>>>(
-                    p, k, v, r0, r1, thr, G, shift, P, pl->pbuf, pl->counts, (uint32_t)pl->cap, gsum, gcnt, pl->err, (int)pl->ablate);
+                    p, k, v, r0, r1, thr, G, shift, P, pl->pbuf, pl->counts, (uint32_t)pl->cap, gsum, gcnt, pl->err, (int)pl->ablate, vop);
             }
             HIP_TRY(ctx, hipGetLastError());
             {
                 TimedLaunch tl(pl, st, 2);
-                fgb_agg_kernel<<<dim3((unsigned)P), dim3(1024), lds_agg, st>>>(
-                    pl->pbuf, pl->counts, (uint32_t)pl->cap, nwg, shift, G, gsum, gcnt, (int)pl->ablate);
+                int rc = dispatch_vop(vop, [&](auto vopc) -> int {
+                    fgb_agg_kernel<decltype(vopc)::value><<<dim3((unsigned)P), dim3(1024), lds_agg, st>>>(
+                        pl->pbuf, pl->counts, (uint32_t)pl->cap, nwg, shift, G, gsum, gcnt, (int)pl->ablate);
+                    return HARK_OK;
+                });
+                if (rc) return rc;
             }
             HIP_TRY(ctx, hipGetLastError());
         }
@@ -638,9 +749,46 @@ int k_fgb_dense_f32(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cm
     });
 }
 
+static int fgb_check_err(hark_context *ctx, hark_fgb_plan *pl)
+{
+    int32_t *e = reinterpret_cast<int32_t *>(ctx->h_pin);
+    HIP_TRY(ctx, hipMemcpyAsync(e, pl->err, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (*e != 0) {
+        const int code = *e;
+        HIP_TRY(ctx, hipMemsetAsync(pl->err, 0, sizeof(int32_t), ctx->stream));
+        return hark_fail(ctx, code, "filter_groupby: a surviving row has a key outside [0, %lld)", (long long)pl->G);
+    }
+    return HARK_OK;
+}
+
+// u32 flavour of the raw operator: opcode of the plan ("vop" knob: 1 sum, 2 max, 3 min, 4 prod;
+// wrapping arithmetic as in groupby.fut:35-41), no predicate.
+int hark_op_groupby_dense_u32(hark_context *ctx, hark_fgb_plan *pl, const uint32_t *k, const uint32_t *v, int64_t n)
+{
+    if (!ctx || !pl) return HARK_EARG;
+    if (pl->vop == VOP_F32SUM) return hark_fail(ctx, HARK_EARG, "groupby_dense_u32: set the plan's \"vop\" to a u32 operator first");
+    if (n < 0 || (n && (!k || !v))) return hark_fail(ctx, HARK_EARG, "groupby_dense_u32: null column");
+    if (n > 0xFFFFFFFFll || (pl->max_rows && n > pl->max_rows)) return hark_fail(ctx, HARK_EARG, "groupby_dense_u32: too many rows for this plan");
+    return k_fgb_dense_f32(ctx, pl, nullptr, 0, 0.0f, reinterpret_cast<const int32_t *>(k), reinterpret_cast<const float *>(v), n);
+}
+
+int hark_fgb_finish_u32(hark_context *ctx, hark_fgb_plan *pl, uint32_t *val_out, int64_t *count_out)
+{
+    if (!ctx || !pl) return HARK_EARG;
+    if (val_out || count_out) {
+        int64_t blocks = (pl->G + 255) / 256;
+        if (blocks > (int64_t)ctx->num_cu * 4) blocks = (int64_t)ctx->num_cu * 4;
+        fgb_finish_u32_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(reinterpret_cast<const u64 *>(pl->acc_sum), pl->acc_cnt, pl->G, val_out, count_out);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    return fgb_check_err(ctx, pl);
+}
+
 int hark_fgb_finish(hark_context *ctx, hark_fgb_plan *pl, float *sum_out, int64_t *count_out)
 {
     if (!ctx || !pl) return HARK_EARG;
+    if (pl->vop != VOP_F32SUM) return hark_fail(ctx, HARK_EARG, "fgb_finish: this plan accumulates a u32 operator, use hark_fgb_finish_u32");
     int64_t blocks = (pl->G + 255) / 256;
     if (blocks > (int64_t)ctx->num_cu * 4) blocks = (int64_t)ctx->num_cu * 4;
     if (sum_out || count_out) {

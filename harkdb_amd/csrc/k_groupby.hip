@@ -248,6 +248,10 @@ int grouped_aggregate(hark_context *ctx, const hark_table *db, int key_col, int 
 
 int kind_of(int dtype) { return dtype == HARK_F32 ? ACC_F64 : dtype == HARK_U32 ? ACC_U64 : ACC_I64; }
 
+// defined at the end of this file: the fused dense-key kernels of k_fgb.hip behind the reference entry
+int ref_groupby_dense(hark_context *ctx, const hark_table *view, int g_col, const std::vector<AggSpec> &aggs,
+                      hark_result *res, int64_t *G_out, bool *used);
+
 } // namespace
 
 extern "C" {
@@ -282,7 +286,9 @@ int hark_entry_query_groupby(hark_context *ctx, hark_result **out, const hark_ta
     hark_table view = *db;
     for (auto &c : view.cols) { c.owned = false; if (c.dtype == HARK_I32) c.dtype = HARK_U32; }
     int64_t G = 0;
-    int rc = grouped_aggregate(ctx, &view, g_col, HARK_U32, aggs, res, &G);
+    bool dense = false;
+    int rc = ref_groupby_dense(ctx, &view, g_col, aggs, res, &G, &dense);   // keys < 2^21: fused kernels, no sort
+    if (!rc && !dense) rc = grouped_aggregate(ctx, &view, g_col, HARK_U32, aggs, res, &G);
     if (!rc && nt < ns && G < db->n)                    // some group has two rows: merge indexes t_cols[i-1] out of bounds
         rc = hark_fail(ctx, HARK_EBOUNDS, "query_groupby: %lld aggregate opcodes for %lld select columns", (long long)nt, (long long)ns);
     if (rc) { result_release(ctx, res); return rc; }
@@ -493,3 +499,81 @@ extern "C" int hark_entry_filter_groupby(hark_context *ctx, hark_result **out, c
     *out = res;
     return HARK_OK;
 }
+
+
+// ---------------------------------------------------------------------------
+// Reference entry over dense keys: one fused pass per aggregate column
+// ---------------------------------------------------------------------------
+namespace {
+
+__global__ __launch_bounds__(256) void dense_emit_u32_kernel(const uint32_t *__restrict__ vals, const unsigned long long *__restrict__ acc_cnt,
+                                                             const uint32_t *__restrict__ pos, int64_t G, uint32_t *__restrict__ out)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < G; g += stride)
+        if (acc_cnt[g]) out[pos[g]] = vals ? vals[g] : (uint32_t)g;
+}
+
+int ref_groupby_dense(hark_context *ctx, const hark_table *view, int g_col, const std::vector<AggSpec> &aggs,
+                      hark_result *res, int64_t *G_out, bool *used)
+{
+    *used = false;
+    const int64_t n = view->n;
+    const uint32_t *keys = static_cast<const uint32_t *>(view->cols[g_col].data);
+    // column statistic: largest key (unsigned)
+    unsigned long long *mm = nullptr;
+    HARK_TRY(hark_alloc(ctx, (void **)&mm, 16));
+    const unsigned long long init[2] = {~0ull, 0ull};
+    int rc = hipMemcpyAsync(mm, init, 16, hipMemcpyHostToDevice, ctx->stream) == hipSuccess ? HARK_OK : hark_fail(ctx, HARK_EHIP, "stats upload failed");
+    int64_t lohi[2] = {0, 0};
+    if (!rc) {
+        minmax_u32_kernel<<<grid_for(ctx, n), 256, 0, ctx->stream>>>(keys, n, 0, mm);
+        rc = hark_read_words(ctx, mm, lohi, 2);
+    }
+    hark_free(ctx, mm);
+    if (rc) return rc;
+    const int64_t G = lohi[1] + 1;
+    if (G > kDenseMaxGroups || G > 8 * n + 4096) return HARK_OK;       // sparse or huge key domain: sort-based path
+
+    hark_fgb_plan *plan = nullptr;
+    HARK_TRY(hark_fgb_plan_new(ctx, &plan, n, G));
+    std::vector<uint32_t *> vals(aggs.size(), nullptr);
+    uint32_t *flags = nullptr, *pos = nullptr;
+    int64_t ngroups = 0;
+    const size_t runs = aggs.empty() ? 1 : aggs.size();                 // no aggregate: one pass just for the counts
+    for (size_t j = 0; j < runs && !rc; j++) {
+        const int vop = aggs.empty() ? 3 : aggs[j].op == OP_SUM ? 1 : aggs[j].op == OP_MAX ? 2 : aggs[j].op == OP_MIN ? 3 : 4;
+        const uint32_t *col = aggs.empty() ? keys : static_cast<const uint32_t *>(view->cols[aggs[j].col].data);
+        rc = hark_fgb_plan_set(plan, "vop", vop);
+        if (!rc) rc = hark_fgb_reset(ctx, plan);
+        if (!rc) rc = hark_op_groupby_dense_u32(ctx, plan, keys, col, n);
+        if (!rc && !aggs.empty()) rc = hark_alloc(ctx, (void **)&vals[j], (size_t)G * 4);
+        if (!rc) rc = hark_fgb_finish_u32(ctx, plan, aggs.empty() ? nullptr : vals[j], nullptr);
+    }
+    if (!rc) rc = hark_alloc(ctx, (void **)&flags, (size_t)G * 4);
+    if (!rc) rc = hark_alloc(ctx, (void **)&pos, (size_t)G * 4);
+    if (!rc) {
+        nonzero_flags_kernel<<<grid_for(ctx, G), 256, 0, ctx->stream>>>(plan->acc_cnt, G, flags);
+        rc = k_exclusive_scan_u32(ctx, flags, G, pos, nullptr, &ngroups);
+    }
+    if (!rc) {
+        res->n = ngroups;
+        res->cols.resize(aggs.size() + 1);
+        for (size_t j = 0; j <= aggs.size() && !rc; j++) {
+            res->cols[j].dtype = HARK_U32;
+            rc = hark_alloc(ctx, &res->cols[j].data, (size_t)ngroups * 4);
+            if (!rc) dense_emit_u32_kernel<<<grid_for(ctx, G), 256, 0, ctx->stream>>>(j == 0 ? nullptr : vals[j - 1], plan->acc_cnt, pos, G,
+                                                                                    static_cast<uint32_t *>(res->cols[j].data));
+        }
+        if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "query_groupby: kernels failed");
+    }
+    for (auto v : vals) hark_free(ctx, v);
+    hark_free(ctx, flags); hark_free(ctx, pos);
+    hark_fgb_plan_free(ctx, plan);
+    if (rc) { for (auto &c : res->cols) { if (c.owned && c.data) hark_free(ctx, c.data); } res->cols.clear(); return rc; }
+    *G_out = ngroups;
+    *used = true;
+    return HARK_OK;
+}
+
+} // namespace

@@ -37,6 +37,22 @@ def test_query_groupby_matches_oracle(eng, oracle, n, nkeys):
     assert got.shape == exp.shape and np.array_equal(got, exp)
 
 
+@pytest.mark.parametrize("n,G", [(7, 7), (200_000, 5000), (300_000, 1 << 20), (1_000_000, 70_000)])
+def test_query_groupby_dense_keys_fused_path(eng, oracle, n, G):
+    """Keys below 2^21 take the fused dense kernels (LDS tables or partition + LDS),
+    one pass per aggregate; result must still be the reference's, bit for bit."""
+    rng = np.random.default_rng(n + G)
+    db = rng.integers(0, 2**32, size=(n, 5), dtype=np.uint64).astype(np.uint32)
+    db[:, 0] = rng.integers(0, G, size=n)
+    db[:, 4] = rng.integers(0, 4, size=n) * 2 + 1                  # small odd factors: products stay interesting mod 2^32
+    s_cols, t_cols = [1, 4, 2, 3, 0], [2, 1, 3, 4, 0]
+    t = eng.table_from_matrix(db, np.uint32)
+    got = eng.query_groupby(t, 0, s_cols, t_cols).to_numpy(np.uint32)
+    exp = oracle.query_groupby(db, 0, s_cols, t_cols)
+    assert got.shape == exp.shape and np.array_equal(got, exp)
+    assert np.array_equal(eng.query_groupby(t, 0, [], []).to_numpy(np.uint32), exp[:, :1])   # key column only
+
+
 def test_query_groupby_int32_table_is_viewed_as_u32(eng, oracle):
     """The Python layer uploads int32 columns; groupby.fut:51 reads them as u32."""
     rng = np.random.default_rng(3)
