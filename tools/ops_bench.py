@@ -35,7 +35,11 @@ k = eng.alloc(N * 4); a = eng.alloc(N * 4)
 eng.gen_columns(SEED, 0, N, 1 << 20, True, None, k, None)
 eng.gen_columns(SEED + 9, 0, N, 1 << 16, True, None, a, None)
 tu = eng.table_from_device(N, [k, a], [np.uint32, np.uint32])
-timeit("query_groupby(key 2^20 groups; sum, max) [sort-based, any keys]", lambda: eng.query_groupby(tu, 0, [1, 1], [2, 3]), 12 * N)
+timeit("query_groupby(dense key, 2^20 groups; sum, max) [fused kernels]", lambda: eng.query_groupby(tu, 0, [1, 1], [2, 3]), 12 * N)
+ks = eng.alloc(N * 4)
+eng.gen_columns(SEED + 11, 0, N, 1 << 31, True, None, ks, None)
+tsparse = eng.table_from_device(N, [ks, a], [np.uint32, np.uint32])
+timeit("query_groupby(sparse key up to 2^31; sum, max) [sort-based]", lambda: eng.query_groupby(tsparse, 0, [1, 1], [2, 3]), 12 * N)
 timeit("sort by u32 key, 2 columns", lambda: eng.sort(tu, 0, [0, 1]), 16 * N)
 M = N // 10
 kb = eng.alloc(M * 4); vb = eng.alloc(M * 4)
