@@ -61,6 +61,27 @@ class FutharkContext:
         dtype = dts.pop() if len(dts) == 1 else np.result_type(*[c.dtype for c in cols])
         return np.stack([c.astype(dtype, copy=False) for c in cols], axis=1)
 
+    def sql_result(self, sql_statement):
+        """A plain `select key, agg... from t [where ...] group by key` evaluated to a
+        DEVICE-resident Result ([key, aggregates in select order]); used by the sharded
+        context, which exchanges the partial aggregates between GPUs without a host trip."""
+        ir = sql_parse(self.tables, sql_statement)
+        if "groupbys" not in ir or any(k in ir for k in ("having", "orderby", "limit")) or ir["items"][0][0] != "key":
+            raise Exception("sql_result supports `select <key>, <aggregates> from t [where] group by <key>`")
+        dev = self.tables[ir["table_name"]]._device
+        aggs = [i for i in ir["items"][1:]]
+        where = ir.get("where", [])
+        cur, cmap = dev, {c: c for c in range(dev.shape[1])}
+        first = None
+        if len(where) == 1:
+            first = where[0]
+        elif len(where) > 1:
+            cur, cmap = self._filtered(dev, where, {ir["g_col"]} | {c for _, c in aggs if c is not None})
+        res = self.FutEnv.filter_groupby(cur, None if first is None else (cmap[first[0]], first[1], first[2]), cmap[ir["g_col"]],
+                                         [(f, 0 if c is None else cmap[c]) for f, c in aggs])
+        schema = self.tables[ir["table_name"]].get_schema()
+        return [schema[ir["g_col"]]] + [f"{f}({'*' if c is None else schema[c]})" for f, c in aggs], res
+
     def sql_columns(self, sql_statement):
         """Like sql() but returns (column names, list of typed numpy columns)."""
         val_dic = sql_parse(self.tables, sql_statement)                    # FutharkContext.py:61

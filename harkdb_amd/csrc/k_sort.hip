@@ -253,7 +253,7 @@ size_t k_sort_workspace_bytes(int64_t n, int num_cu)
 // scratch of the same size.  vals_is_iota: payload of the input is the position
 // (vals need not be initialised).  n < 2^32.
 int k_sort_pairs_u32(hark_context *ctx, uint32_t *keys, uint32_t *vals, uint32_t *keys_tmp, uint32_t *vals_tmp,
-                     int64_t n, uint32_t xor_mask, bool vals_is_iota, uint32_t *hist_ws)
+                     int64_t n, uint32_t xor_mask, bool vals_is_iota, uint32_t *hist_ws, int passes = 4)
 {
     if (n <= 0) return HARK_OK;
     if (n > 0xFFFFFFFFll) return hark_fail(ctx, HARK_EARG, "sort: at most 2^32-1 rows");
@@ -264,7 +264,7 @@ int k_sort_pairs_u32(hark_context *ctx, uint32_t *keys, uint32_t *vals, uint32_t
     nblk = (n + slice - 1) / slice;
     hipStream_t st = ctx->stream;
     uint32_t *kin = keys, *vin = vals, *kout = keys_tmp, *vout = vals_tmp;
-    for (int pass = 0; pass < 4; pass++) {
+    for (int pass = 0; pass < passes; pass++) {
         const int shift = pass * 8;
         digit_hist_kernel<<<dim3((unsigned)nblk), dim3(kSortThreads), 0, st>>>(kin, n, slice, shift, xor_mask, hist_ws, (int)nblk);
         scan_hist_rows_kernel<<<kBins, 256, 0, st>>>(hist_ws, (int)nblk, hist_ws + (size_t)kBins * nblk);
@@ -275,7 +275,7 @@ int k_sort_pairs_u32(hark_context *ctx, uint32_t *keys, uint32_t *vals, uint32_t
         uint32_t *t = kin; kin = kout; kout = t;
         t = vin; vin = vout; vout = t;
     }
-    // four passes: the result is back in keys / vals
+    // an even number of passes leaves the result in keys / vals, an odd number in keys_tmp / vals_tmp
     return HARK_OK;
 }
 
@@ -334,3 +334,77 @@ int k_argsort_column(hark_context *ctx, const void *col, int dtype, int64_t n, b
     if (sorted_words_out && dtype != HARK_I64) *sorted_words_out = k0; else hark_free(ctx, k0);
     return HARK_OK;
 }
+
+
+// ---------------------------------------------------------------------------
+// Hash partitioning of rows for the multi-GPU repartition (all-to-all) and gathers
+// ---------------------------------------------------------------------------
+namespace {
+
+__device__ __forceinline__ uint32_t mix32(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
+
+__global__ __launch_bounds__(256) void hash_dest_kernel(const void *__restrict__ col, int esz, int64_t n, uint32_t nparts, uint32_t *__restrict__ dest)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        uint32_t h;
+        if (esz == 4) h = mix32(static_cast<const uint32_t *>(col)[i]);
+        else { const uint64_t x = static_cast<const uint64_t *>(col)[i]; h = mix32((uint32_t)x ^ mix32((uint32_t)(x >> 32))); }
+        dest[i] = (uint32_t)(((uint64_t)h * nparts) >> 32);          // uniform in [0, nparts)
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+// Rows of a key column -> destination part = hash(key) * nparts >> 32 (equal keys, equal
+// part, on every rank).  perm_out (device, n x u32) lists the row ids grouped by part,
+// rows of one part in table order; counts_host[nparts] receives the part sizes.
+int hark_op_partition_by_hash(hark_context *ctx, const void *key_col, int32_t dtype, int64_t n, int32_t nparts,
+                              uint32_t *perm_out, int64_t *counts_host)
+{
+    if (!ctx || n < 0 || nparts < 1 || nparts > 256 || !counts_host || (n && (!key_col || !perm_out))) return HARK_EARG;
+    for (int i = 0; i < nparts; i++) counts_host[i] = 0;
+    if (n == 0) return HARK_OK;
+    if (n > 0xFFFFFFFFll) return hark_fail(ctx, HARK_EARG, "partition_by_hash: at most 2^32-1 rows");
+    uint32_t *dest = nullptr, *dtmp = nullptr, *vtmp = nullptr, *ws = nullptr;
+    int rc = hark_alloc(ctx, (void **)&dest, (size_t)n * 4);
+    if (!rc) rc = hark_alloc(ctx, (void **)&dtmp, (size_t)n * 4);
+    if (!rc) rc = hark_alloc(ctx, (void **)&vtmp, (size_t)n * 4);
+    if (!rc) rc = hark_alloc(ctx, (void **)&ws, k_sort_workspace_bytes(n, ctx->num_cu));
+    if (!rc) {
+        int64_t blocks = (n + 255) / 256;
+        if (blocks > (int64_t)ctx->num_cu * 16) blocks = (int64_t)ctx->num_cu * 16;
+        hash_dest_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(key_col, (int)hark_dtype_size(dtype), n, (uint32_t)nparts, dest);
+        // one stable 8-bit pass on the part id; the permutation lands in perm_out (the "tmp" side)
+        rc = k_sort_pairs_u32(ctx, dest, vtmp, dtmp, perm_out, n, 0u, true, ws, 1);
+    }
+    if (!rc) {
+        // the digit totals of the pass are the part sizes (ws: 256*nblk histogram, then 256 totals)
+        int64_t nblk = (n + kSortTile - 1) / kSortTile;
+        if (nblk > (int64_t)ctx->num_cu * 8) nblk = (int64_t)ctx->num_cu * 8;
+        int64_t slice = (n + nblk - 1) / nblk;
+        slice = (slice + kSortTile - 1) / kSortTile * kSortTile;
+        nblk = (n + slice - 1) / slice;
+        std::vector<uint32_t> tot(256);
+        if (hipMemcpyAsync(tot.data(), ws + (size_t)kBins * nblk, 256 * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "partition_by_hash: reading part sizes failed");
+        else for (int i = 0; i < nparts; i++) counts_host[i] = tot[i];
+    }
+    hark_free(ctx, dest); hark_free(ctx, dtmp); hark_free(ctx, vtmp); hark_free(ctx, ws);
+    return rc;
+}
+
+// dst[i] = src[idx[i]] for 4- or 8-byte elements (device pointers).
+int hark_op_gather(hark_context *ctx, const void *src, int32_t dtype, const uint32_t *idx, void *dst, int64_t n)
+{
+    if (!ctx || n < 0 || (n && (!src || !idx || !dst))) return HARK_EARG;
+    return k_gather(ctx, src, (int)hark_dtype_size(dtype), idx, dst, n);
+}
+
+} // extern "C"

@@ -153,6 +153,52 @@ def merge_grouped(keys, aggs, funcs, group=None):
     return keys[heads], out
 
 
+# ---------------------------------------------------------------------------
+# Repartition by key hash: the all-to-all of SURVEY.md 8(e) (join, sparse GROUP BY)
+# ---------------------------------------------------------------------------
+def exchange_columns(send_cols, send_counts, group=None):
+    """All-to-all of row-partitioned columns.  Every tensor of `send_cols` holds
+    this rank's rows GROUPED BY DESTINATION RANK (send_counts[r] rows for rank
+    r, in rank order).  Returns (received tensors, received counts per source)."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        return list(send_cols), list(send_counts)
+    dev = send_cols[0].device if send_cols else "cpu"
+    cnt = torch.tensor(list(send_counts), dtype=torch.int64, device=dev)
+    rc = torch.empty_like(cnt)
+    dist.all_to_all_single(rc, cnt, group=group)
+    recv_counts = [int(x) for x in rc.tolist()]
+    out = []
+    for c in send_cols:
+        r = torch.empty(sum(recv_counts), dtype=c.dtype, device=c.device)
+        dist.all_to_all_single(r, c.contiguous(), output_split_sizes=recv_counts, input_split_sizes=list(send_counts), group=group)
+        out.append(r)
+    return out, recv_counts
+
+
+_TORCH_OF = {"int32": "int32", "uint32": "int32", "float32": "float32", "int64": "int64"}     # uint32 travels as its bit pattern
+
+
+def repartition_device(eng, ptrs, dtypes, n, key_index, device, world, group=None):
+    """Hash-partition n rows held in device columns (raw pointers `ptrs`) by column
+    `key_index` on the GPU (hark_op_partition_by_hash + hark_op_gather) and
+    all-to-all them.  Returns (torch tensors owning the received columns, rows)."""
+    import torch
+    perm = torch.empty(max(n, 1), dtype=torch.int32, device=device)
+    counts = eng.partition_by_hash(ptrs[key_index], dtypes[key_index], n, world, perm.data_ptr())
+    send = []
+    for ptr, dt in zip(ptrs, dtypes):
+        buf = torch.empty(max(n, 1), dtype=getattr(torch, _TORCH_OF[np.dtype(dt).name]), device=device)[:n]
+        eng.gather(ptr, dt, perm.data_ptr(), buf.data_ptr(), n)
+        send.append(buf)
+    recv, rc = exchange_columns(send, counts, group)
+    return recv, sum(rc)
+
+
+_SECOND_LEVEL = {"sum": "sum", "count": "sum", "min": "min", "max": "max", "prod": "prod"}
+
+
 class ShardedFutharkContext:
     """FutharkContext whose tables are row-range shards, one rank per GPU.
 
@@ -161,13 +207,18 @@ class ShardedFutharkContext:
     merges: projection / WHERE results concatenate in rank order, GROUP BY
     partials are all-reduced (dense keys, device side) or merged by key."""
 
-    def __init__(self, device=None):
+    def __init__(self, device=None, device_exchange=None):
         import torch
         from .context import FutharkContext
         self.rank, local, self.world = init_process_group()
         self.device = torch.device("cuda", local if device is None else device)
+        torch.cuda.set_device(self.device)
         self.local = FutharkContext(device=self.device.index, sql_mode=True)
+        # kernels, gathers and RCCL collectives are ordered by ONE stream
+        self.local.FutEnv.set_stream(torch.cuda.current_stream().cuda_stream)
         self.rows = {}
+        # sparse GROUP BY / JOIN exchange rows with an RCCL all-to-all when there is more than one rank
+        self.device_exchange = (self.world > 1) if device_exchange is None else bool(device_exchange)
 
     def create_table(self, table_name, table):
         from .table import Table
@@ -192,7 +243,7 @@ class ShardedFutharkContext:
         from .parse import sql_parse
         ir = sql_parse(self.local.tables, sql_statement)
         if ir.get("join"):
-            raise Exception("JOIN over sharded tables needs the all-to-all repartition (not built yet)")
+            return self._join(ir)
         if "groupbys" not in ir:
             if "orderby" in ir:
                 raise Exception("ORDER BY over sharded tables needs the sample-sort exchange (not built yet)")
@@ -226,9 +277,14 @@ class ShardedFutharkContext:
         sel = ", ".join([schema[ir["g_col"]]] + [f"{f}({'*' if c is None else schema[c]})" for f, c in specs])
         where = " and ".join(f"{schema[c]} {cmp} {v!r}" for c, cmp, v in ir.get("where", []))
         stmt = f"select {sel} from {ir['table_name']}" + (f" where {where}" if where else "") + f" group by {schema[ir['g_col']]}"
-        _, cols = self.local.sql_columns(stmt)
-        widen = [c.astype(np.float64) if c.dtype == np.float32 else c for c in cols[1:]]     # merge f32 partial sums in f64
-        keys, merged = merge_grouped(cols[0], widen, [f for f, _ in specs])
+        if self.device_exchange:
+            cols = self._groupby_exchange(stmt, specs)
+            order_k = np.argsort(cols[0], kind="stable")
+            keys, merged = cols[0][order_k], [c[order_k] for c in cols[1:]]      # every key lives on exactly one rank now
+        else:
+            _, cols = self.local.sql_columns(stmt)
+            widen = [c.astype(np.float64) if c.dtype == np.float32 else c for c in cols[1:]]     # merge f32 partial sums in f64
+            keys, merged = merge_grouped(cols[0], widen, [f for f, _ in specs])
 
         def value(s):
             if s[0] == "key":
@@ -251,4 +307,49 @@ class ShardedFutharkContext:
         if "limit" in ir:
             out = [c[: ir["limit"]] for c in out]
         names = [schema[c] if f == "key" else f"{f}({'*' if c is None else schema[c]})" for f, c in ir["items"]]
+        return names, out
+
+    # ---- RCCL all-to-all paths ------------------------------------------------------
+    def _result_as_table(self, res):
+        eng = self.local.FutEnv
+        n, m = res.shape
+        return eng.table_from_device(n, [res.device_ptr(j) for j in range(m)], [res.dtype(j) for j in range(m)], keepalive=res)
+
+    def _groupby_exchange(self, stmt, specs):
+        """Local partial aggregates -> all-to-all by hash(key) -> second-level
+        aggregation of the partials on the owner rank -> gather of the owners' rows."""
+        eng = self.local.FutEnv
+        names, res = self.local.sql_result(stmt)                    # device-resident [key, partial...]
+        n, m = res.shape
+        dts = [res.dtype(j) for j in range(m)]
+        recv, nrecv = repartition_device(eng, [res.device_ptr(j) for j in range(m)], dts, n, 0, self.device, self.world)
+        t = eng.table_from_device(nrecv, [c.data_ptr() for c in recv], dts, keepalive=recv)
+        res2 = eng.filter_groupby(t, None, 0, [(_SECOND_LEVEL[f], 1 + j) for j, (f, _) in enumerate(specs)])
+        return gather_columns(res2.columns())
+
+    def _join(self, ir):
+        """Both sides are hash-partitioned by the join key and exchanged; every rank
+        joins what it owns.  Row order follows (owner rank, key, left row, right row)."""
+        eng = self.local.FutEnv
+        sides = []
+        for tname, kcol, cols in ((ir["tables"][0], ir["col1"], ir["cols1"]), (ir["tables"][1], ir["col2"], ir["cols2"])):
+            dev = self.local.tables[tname]._device
+            need = [kcol] + [c for c in dict.fromkeys(cols) if c != kcol]
+            n = dev.shape[0]
+            ptrs, dts = [dev.device_ptr(c) for c in need], [dev.dtype(c) for c in need]
+            if self.device_exchange:
+                recv, nrecv = repartition_device(eng, ptrs, dts, n, 0, self.device, self.world)
+                t = eng.table_from_device(nrecv, [c.data_ptr() for c in recv], dts, keepalive=recv)
+            else:
+                t = eng.table_from_device(n, ptrs, dts, keepalive=dev)
+            sides.append((t, {c: i for i, c in enumerate(need)}))
+        (t1, m1), (t2, m2) = sides
+        res = eng.join(t1, t2, 0, 0, [m1[c] for c in ir["cols1"]], [m2[c] for c in ir["cols2"]])
+        cols = gather_columns(res.columns())
+        left_pos = {c: i for i, c in reversed(list(enumerate(ir["cols1"])))}
+        right_pos = {c: len(ir["cols1"]) + i for i, c in reversed(list(enumerate(ir["cols2"])))}
+        out = [cols[left_pos[c] if s == 0 else right_pos[c]] for s, c in ir["order"]]
+        names = [f"{ir['tables'][s]}.{self.local.tables[ir['tables'][s]].get_schema()[c]}" for s, c in ir["order"]]
+        if "limit" in ir:
+            out = [c[: ir["limit"]] for c in out]
         return names, out

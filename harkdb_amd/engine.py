@@ -198,6 +198,15 @@ class Engine:
     def gen_columns(self, seed, first_row, n, G, exact, p=None, k=None, v=None):
         self._chk(self.lib.hark_op_gen_columns(self.ctx, int(seed), int(first_row), int(n), int(G), 1 if exact else 0, p, k, v))
 
+    def partition_by_hash(self, key_ptr, dtype, n, nparts, perm_ptr):
+        """Row ids grouped by hash(key) part into perm_ptr (device u32[n]); returns the part sizes."""
+        counts = (C.c_int64 * int(nparts))()
+        self._chk(self.lib.hark_op_partition_by_hash(self.ctx, key_ptr, _ffi.DT_OF[np.dtype(dtype)], int(n), int(nparts), perm_ptr, counts))
+        return list(counts)
+
+    def gather(self, src_ptr, dtype, idx_ptr, dst_ptr, n):
+        self._chk(self.lib.hark_op_gather(self.ctx, src_ptr, _ffi.DT_OF[np.dtype(dtype)], idx_ptr, dst_ptr, int(n)))
+
     # -- tables ------------------------------------------------------------------
     def table_from_matrix(self, mat, dtype):
         """Upload an [n][m] host matrix as m device columns of `dtype`

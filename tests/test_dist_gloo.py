@@ -114,3 +114,41 @@ def test_merge_grouped_and_gather_two_ranks():
             mm = min(float(x[4][x[1] == key].min()) for x in outs if (x[1] == key).any())
             assert o[6][j] == ss and o[7][j] == cc and o[8][j] == np.float32(mm)
         assert np.array_equal(o[9], allk)                                        # rank-order concatenation
+
+
+def _exchange_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from harkdb_amd import dist as hd
+    hd.init_process_group("cpu")
+    rng = np.random.default_rng(7 + rank)
+    n = 1000 + 37 * rank
+    keys = rng.integers(0, 500, size=n).astype(np.int64)
+    vals = rng.random(n).astype(np.float32)
+    dest = (keys * 2654435761 % 2**32 * world >> 32).astype(np.int64)       # any deterministic key -> rank map
+    order = np.argsort(dest, kind="stable")
+    counts = np.bincount(dest, minlength=world).tolist()
+    recv, rc = hd.exchange_columns([torch.from_numpy(keys[order]), torch.from_numpy(vals[order])], counts)
+    q.put((rank, keys, vals, dest, recv[0].numpy(), recv[1].numpy(), rc))
+    import torch.distributed as dist
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_exchange_columns_all_to_all_two_ranks():
+    """The repartition exchange: every row reaches the rank its key hashes to,
+    rows from source rank 0 before rows from source rank 1, order inside a source kept."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    outs = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    for me, o in enumerate(outs):
+        exp_k = np.concatenate([src[1][src[3] == me] for src in outs])
+        exp_v = np.concatenate([src[2][src[3] == me] for src in outs])
+        assert np.array_equal(o[4], exp_k) and np.array_equal(o[5], exp_v)
+        assert o[6] == [int((src[3] == me).sum()) for src in outs]

@@ -49,3 +49,25 @@ def test_sharded_groupby_having_order(sfc):
     assert np.array_equal(cols[0], g.k.to_numpy()) and np.array_equal(cols[1], g.s.to_numpy().astype(np.float32))
     assert np.array_equal(cols[2], g.c.to_numpy()) and np.allclose(cols[3], g.a.to_numpy(), rtol=1e-6)
     assert np.array_equal(cols[4], g.m.to_numpy())
+
+
+def test_sharded_device_exchange_paths(sfc, oracle):
+    """The RCCL all-to-all repartition (hash partition + gather on the GPU, all_to_all_single,
+    second-level aggregation / local join), forced on with one rank."""
+    df = sfc._df
+    sfc.device_exchange = True
+    try:
+        names, cols = sfc.sql_columns("select w, sum(v), count(*), max(k), avg(v) from t where p > 0.25 group by w")
+        g = df[df.p > 0.25].groupby("w").agg(s=("v", "sum"), c=("v", "count"), m=("k", "max"), a=("v", "mean")).reset_index()
+        assert np.array_equal(cols[0], g.w.to_numpy()) and np.array_equal(cols[1], g.s.to_numpy().astype(np.float32))
+        assert np.array_equal(cols[2], g.c.to_numpy()) and np.array_equal(cols[3], g.m.to_numpy())
+        assert np.allclose(cols[4], g.a.to_numpy(), rtol=1e-6)
+        rng = np.random.default_rng(3)
+        a = rng.integers(0, 40, size=(3000, 3)).astype(np.int64)
+        b = rng.integers(0, 40, size=(500, 2)).astype(np.int64)
+        sfc.create_table("a", a); sfc.create_table("b", b)
+        out = sfc.sql("select a.col1, b.col2, a.col3 from a join b on a.col2 = b.col1")
+        ref = oracle.join(a, b, 1, 0, [0, 2], [1])[:, [0, 2, 1]]
+        assert np.array_equal(out[np.lexsort(out.T[::-1])], ref[np.lexsort(ref.T[::-1])].astype(out.dtype))   # same multiset of rows
+    finally:
+        sfc.device_exchange = False
