@@ -89,7 +89,8 @@ struct hark_fgb_plan {
     int64_t ablate = 0;        // timing experiments only
     int64_t variant = 0;       // (unused)
     int64_t timing = 0;        // record HIP events around every kernel launch
-    int64_t vop = 0;           // value operator: 0 f32 sum (f64 acc), 1..4 u32 sum/max/min/prod
+    int64_t vop = 0;           // value operator: 0 f32 sum (f64 acc), 1..4 u32 sum/max/min/prod, 5 u32 -> u64 sum
+    int64_t xform = 0;         // 0 none, 1 i32 -> ordered u32, 2 f32 -> ordered u32
     std::vector<hipEvent_t> ev; std::vector<int> ev_kind; size_t ev_used = 0;
     uint2 *pbuf = nullptr;     // [P][nwg][cap] (key, value-bits) pairs
     uint32_t *counts = nullptr;// [P][nwg] pairs in each slab
@@ -100,6 +101,7 @@ struct hark_fgb_plan {
 
 int k_gen_columns(hark_context *ctx, uint64_t seed, int64_t first_row, int64_t n, uint32_t G,
                   int exact, float *p, int32_t *k, float *v);
+int hark_fgb_finish_typed(hark_context *ctx, hark_fgb_plan *pl, int32_t kind, const uint32_t *pos, void *out);
 int k_fgb_dense_f32(hark_context *ctx, hark_fgb_plan *plan, const float *p, int cmp, float thr,
                     const int32_t *k, const float *v, int64_t n);
 

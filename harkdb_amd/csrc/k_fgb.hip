@@ -59,7 +59,17 @@ __device__ __forceinline__ bool cmp_f32(float a, float b)
 // value in the low word.  LDS forms: ds_add_f64 / ds_add_u32 / ds_max_u32 / ds_min_u32
 // (native, 3.5-11 lanes/clk), product by an LDS compare-and-swap loop.
 typedef unsigned long long u64;
-enum { VOP_F32SUM = 0, VOP_U32SUM = 1, VOP_U32MAX = 2, VOP_U32MIN = 3, VOP_U32PROD = 4 };
+enum { VOP_F32SUM = 0, VOP_U32SUM = 1, VOP_U32MAX = 2, VOP_U32MIN = 3, VOP_U32PROD = 4, VOP_U32SUM64 = 5 };
+// Value transform applied to the raw 32 bits before accumulation, so that the unsigned
+// operators also serve signed and floating-point columns: 1 = i32 -> order-preserving u32
+// (x ^ 2^31), 2 = f32 -> order-preserving u32.  hark_fgb_finish_typed decodes.
+enum { XF_NONE = 0, XF_I32_ORDER = 1, XF_F32_ORDER = 2 };
+__device__ __forceinline__ uint32_t apply_xf(int xf, uint32_t x)
+{
+    if (xf == XF_I32_ORDER) return x ^ 0x80000000u;
+    if (xf == XF_F32_ORDER) { if (x == 0x80000000u) x = 0u; return x ^ ((x & 0x80000000u) ? 0xFFFFFFFFu : 0x80000000u); }
+    return x;
+}
 
 __host__ __device__ inline u64 vop_identity(int vop)
 {
@@ -73,6 +83,7 @@ __device__ __forceinline__ u64 vop_merge(int vop, u64 a, u64 b)
     case VOP_U32SUM: return (uint32_t)((uint32_t)a + (uint32_t)b);
     case VOP_U32MAX: return (uint32_t)a > (uint32_t)b ? (uint32_t)a : (uint32_t)b;
     case VOP_U32MIN: return (uint32_t)a < (uint32_t)b ? (uint32_t)a : (uint32_t)b;
+    case VOP_U32SUM64: return a + b;
     default: return (uint32_t)((uint32_t)a * (uint32_t)b);
     }
 }
@@ -87,6 +98,7 @@ __device__ __forceinline__ void vop_atomic(u64 *slot, uint32_t x)
     else if constexpr (VOP == VOP_U32SUM) atomicAdd(lo, x);
     else if constexpr (VOP == VOP_U32MAX) atomicMax(lo, x);
     else if constexpr (VOP == VOP_U32MIN) atomicMin(lo, x);
+    else if constexpr (VOP == VOP_U32SUM64) atomicAdd(slot, (u64)x);            // ds_add_u64 / global_atomic_add_x2
     else {
         uint32_t old = *lo, assumed;
         do { assumed = old; old = atomicCAS(lo, assumed, assumed * x); } while (old != assumed);
@@ -98,6 +110,7 @@ template <int VOP>
 __device__ __forceinline__ void vop_atomic_partial(u64 *slot, u64 part)
 {
     if constexpr (VOP == VOP_F32SUM) unsafeAtomicAdd(reinterpret_cast<double *>(slot), __longlong_as_double((long long)part));
+    else if constexpr (VOP == VOP_U32SUM64) atomicAdd(slot, part);
     else vop_atomic<VOP>(slot, (uint32_t)part);
 }
 
@@ -108,6 +121,7 @@ __device__ __forceinline__ void vop_atomic_rt(int vop, u64 *slot, uint32_t x)
     case VOP_U32SUM: vop_atomic<VOP_U32SUM>(slot, x); break;
     case VOP_U32MAX: vop_atomic<VOP_U32MAX>(slot, x); break;
     case VOP_U32MIN: vop_atomic<VOP_U32MIN>(slot, x); break;
+    case VOP_U32SUM64: vop_atomic<VOP_U32SUM64>(slot, x); break;
     default: vop_atomic<VOP_U32PROD>(slot, x); break;
     }
 }
@@ -142,7 +156,7 @@ template <int OP, int VOP>
 __global__ __launch_bounds__(1024) void fgb_lds_kernel(
     const float *__restrict__ p, const int32_t *__restrict__ k, const float *__restrict__ v,
     int64_t n, float thr, int G, int RL, u64 *__restrict__ gsum,
-    unsigned long long *__restrict__ gcnt, int32_t *__restrict__ err)
+    unsigned long long *__restrict__ gcnt, int32_t *__restrict__ err, int xf)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int slots = G << RL;
@@ -163,7 +177,7 @@ __global__ __launch_bounds__(1024) void fgb_lds_kernel(
         if (cmp_f32<OP>(pv, thr)) {
             if ((uint32_t)key < (uint32_t)G) {
                 uint32_t s = ((uint32_t)key << RL) | rep;
-                vop_atomic<VOP>(&s_sum[s], __float_as_uint(val));   // ds_add_f64 / ds_{add,max,min}_u32
+                vop_atomic<VOP>(&s_sum[s], apply_xf(xf, __float_as_uint(val)));   // ds_add_f64 / ds_{add,max,min}_u32
                 atomicAdd(&s_cnt[s], 1u);                           // ds_add_u32
             } else bad = true;
         }
@@ -211,7 +225,7 @@ template <int OP>
 __global__ __launch_bounds__(256) void fgb_atomic_kernel(
     const float *__restrict__ p, const int32_t *__restrict__ k, const float *__restrict__ v,
     int64_t n, float thr, int64_t G, u64 *__restrict__ gsum,
-    unsigned long long *__restrict__ gcnt, int32_t *__restrict__ err, int vop)
+    unsigned long long *__restrict__ gcnt, int32_t *__restrict__ err, int vop, int xf)
 {
     const int64_t nvec = n / kVec;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -222,7 +236,7 @@ __global__ __launch_bounds__(256) void fgb_atomic_kernel(
     auto row = [&](float pv, int32_t key, float val) {
         if (cmp_f32<OP>(pv, thr)) {
             if (key >= 0 && (int64_t)key < G) {
-                vop_atomic_rt(vop, &gsum[key], __float_as_uint(val));
+                vop_atomic_rt(vop, &gsum[key], apply_xf(xf, __float_as_uint(val)));
                 atomicAdd(&gcnt[key], 1ull);
             } else bad = true;
         }
@@ -268,7 +282,7 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
     const float *__restrict__ p, const int32_t *__restrict__ k, const float *__restrict__ v,
     int64_t row0, int64_t row1, float thr, int64_t G, int shift, int P,
     uint2 *__restrict__ pbuf, uint32_t *__restrict__ counts, uint32_t cap,
-    u64 *__restrict__ gsum, unsigned long long *__restrict__ gcnt, int32_t *__restrict__ err, int ablate, int vop)
+    u64 *__restrict__ gsum, unsigned long long *__restrict__ gcnt, int32_t *__restrict__ err, int ablate, int vop, int xf)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     uint2 *queue = reinterpret_cast<uint2 *>(lds_raw);                 // [P][kQ]
@@ -330,7 +344,7 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
                     const uint32_t key = (uint32_t)kv[j], b = key >> shift;
                     const int pos = atomicAdd(&s_cnt[b], 1);
                     if (pos < kQ) {
-                        queue[b * kQ + ((s_head[b] + pos) & (kQ - 1))] = uint2{key, __float_as_uint(vv[j])};
+                        queue[b * kQ + ((s_head[b] + pos) & (kQ - 1))] = uint2{key, apply_xf(xf, __float_as_uint(vv[j]))};
                         pending &= ~(1u << j);
                     } else atomicSub(&s_cnt[b], 1);                       // queue full: retry after the flush
                 }
@@ -368,7 +382,7 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
 #pragma unroll
                 for (int j = 0; j < kVec; j++)
                     if ((pending & (1u << j)) && !(ablate & 2)) {
-                        vop_atomic_rt(vop, &gsum[(uint32_t)kv[j]], __float_as_uint(vv[j])); atomicAdd(&gcnt[(uint32_t)kv[j]], 1ull);
+                        vop_atomic_rt(vop, &gsum[(uint32_t)kv[j]], apply_xf(xf, __float_as_uint(vv[j]))); atomicAdd(&gcnt[(uint32_t)kv[j]], 1ull);
                     }
                 pending = 0;
             }
@@ -481,6 +495,36 @@ __global__ __launch_bounds__(256) void fgb_fill_kernel(u64 *__restrict__ dst, in
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = v;
 }
 
+// Typed read-out of the accumulators.  kind: 0 f32 <- f64 sum | 1 u32 <- low word | 2 i32 <- ordered u32 |
+// 3 f32 <- ordered u32 | 4 i64 <- u64 sum | 5 i64 <- u64 sum of ordered i32 (minus count * 2^31) |
+// 7/8/9 f32 average from the sums of kinds 0/4/5.  pos != NULL compacts: only groups with a
+// non-zero count are written, at out[pos[g]]; key_out (optional) receives g there.
+__global__ __launch_bounds__(256) void fgb_decode_kernel(const u64 *__restrict__ acc, const unsigned long long *__restrict__ cnt, int64_t G, int kind,
+                                                         const uint32_t *__restrict__ pos, void *__restrict__ out)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < G; g += stride) {
+        const unsigned long long c = cnt[g];
+        if (pos && !c) continue;
+        const int64_t o = pos ? (int64_t)pos[g] : g;
+        const u64 a = acc[g];
+        const uint32_t lo = (uint32_t)a;
+        switch (kind) {
+        case 0: static_cast<float *>(out)[o] = (float)__longlong_as_double((long long)a); break;
+        case 1: static_cast<uint32_t *>(out)[o] = lo; break;
+        case 2: static_cast<uint32_t *>(out)[o] = lo ^ 0x80000000u; break;
+        case 3: static_cast<uint32_t *>(out)[o] = (lo & 0x80000000u) ? (lo ^ 0x80000000u) : ~lo; break;
+        case 4: static_cast<long long *>(out)[o] = (long long)a; break;
+        case 5: static_cast<long long *>(out)[o] = (long long)(a - (c << 31)); break;
+        case 7: static_cast<float *>(out)[o] = (float)(__longlong_as_double((long long)a) / (double)c); break;
+        case 8: static_cast<float *>(out)[o] = (float)((double)a / (double)c); break;
+        case 9: static_cast<float *>(out)[o] = (float)((double)(long long)(a - (c << 31)) / (double)c); break;
+        case 10: static_cast<uint32_t *>(out)[o] = (uint32_t)g; break;                    // the key itself
+        default: static_cast<long long *>(out)[o] = (long long)c; break;                   // 11: the count
+        }
+    }
+}
+
 template <typename F>
 int dispatch_vop(int vop, F &&f)
 {
@@ -490,6 +534,7 @@ int dispatch_vop(int vop, F &&f)
     case VOP_U32MAX: return f(std::integral_constant<int, VOP_U32MAX>{});
     case VOP_U32MIN: return f(std::integral_constant<int, VOP_U32MIN>{});
     case VOP_U32PROD: return f(std::integral_constant<int, VOP_U32PROD>{});
+    case VOP_U32SUM64: return f(std::integral_constant<int, VOP_U32SUM64>{});
     default: return HARK_EARG;
     }
 }
@@ -592,7 +637,8 @@ int hark_fgb_plan_set(hark_fgb_plan *pl, const char *key, int64_t value)
     else if (!strcmp(key, "shift")) { if (value < 0 || value > 13) return HARK_EARG; pl->shift = value; }
     else if (!strcmp(key, "slack_pct")) { if (value < 0 || value > 10000) return HARK_EARG; pl->slack_pct = value; }
     else if (!strcmp(key, "timing")) { pl->timing = value; return HARK_OK; }
-    else if (!strcmp(key, "vop")) { if (value < 0 || value > 4) return HARK_EARG; pl->vop = value; return HARK_OK; }   // reset afterwards
+    else if (!strcmp(key, "vop")) { if (value < 0 || value > 5) return HARK_EARG; pl->vop = value; return HARK_OK; }   // reset afterwards
+    else if (!strcmp(key, "xform")) { if (value < 0 || value > 2) return HARK_EARG; pl->xform = value; return HARK_OK; }
     else if (!strcmp(key, "variant")) { if (value < 0 || value > 3) return HARK_EARG; pl->variant = value; return HARK_OK; }
     else if (!strcmp(key, "ablate")) { pl->ablate = value; return HARK_OK; }   // timing experiments only: wrong results
     else return HARK_EARG;
@@ -664,7 +710,7 @@ int k_fgb_dense_f32(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cm
         return hark_fail(ctx, HARK_EARG, "fgb: columns must be 16-byte aligned");
     u64 *gsum = reinterpret_cast<u64 *>(pl->acc_sum);
     const int vop = (int)pl->vop;
-    if (vop != VOP_F32SUM && p) return hark_fail(ctx, HARK_EARG, "fgb: the u32 operators take no predicate");
+    if (vop != VOP_F32SUM && p) return hark_fail(ctx, HARK_EARG, "fgb: only the f32 sum takes a fused predicate (filter first)");
     unsigned long long *gcnt = pl->acc_cnt;
     int algo = (int)pl->algo;
     // auto: LDS tables while 12 B x G fits a workgroup; the partition path up to 256 buckets x 8192 keys;
@@ -689,7 +735,7 @@ int k_fgb_dense_f32(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cm
                 HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_lds_kernel<OP, VOP>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             TimedLaunch tl(pl, st, 0);
-            fgb_lds_kernel<OP, VOP><<<dim3((unsigned)grid), dim3(1024), lds, st>>>(p, k, v, n, thr, (int)G, RL, gsum, gcnt, pl->err);
+            fgb_lds_kernel<OP, VOP><<<dim3((unsigned)grid), dim3(1024), lds, st>>>(p, k, v, n, thr, (int)G, RL, gsum, gcnt, pl->err, (int)pl->xform);
             HIP_TRY(ctx, hipGetLastError());
             return HARK_OK;
         };
@@ -704,7 +750,7 @@ int k_fgb_dense_f32(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cm
         return dispatch_op(cmp, p != nullptr, [&](auto op) -> int {
             constexpr int OP = decltype(op)::value;
             TimedLaunch tl(pl, st, 0);
-            fgb_atomic_kernel<OP><<<dim3((unsigned)grid), dim3(256), 0, st>>>(p, k, v, n, thr, G, gsum, gcnt, pl->err, vop);
+            fgb_atomic_kernel<OP><<<dim3((unsigned)grid), dim3(256), 0, st>>>(p, k, v, n, thr, G, gsum, gcnt, pl->err, vop, (int)pl->xform);
             HIP_TRY(ctx, hipGetLastError());
             return HARK_OK;
         });
@@ -731,7 +777,7 @@ int k_fgb_dense_f32(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cm
             {
                 TimedLaunch tl(pl, st, 1);
                 fgb_part_kernel<OP><<<dim3((unsigned)nwg), dim3(kPartThreads), lds_part, st>>>(
-                    p, k, v, r0, r1, thr, G, shift, P, pl->pbuf, pl->counts, (uint32_t)pl->cap, gsum, gcnt, pl->err, (int)pl->ablate, vop);
+                    p, k, v, r0, r1, thr, G, shift, P, pl->pbuf, pl->counts, (uint32_t)pl->cap, gsum, gcnt, pl->err, (int)pl->ablate, vop, (int)pl->xform);
             }
             HIP_TRY(ctx, hipGetLastError());
             {
@@ -767,7 +813,6 @@ static int fgb_check_err(hark_context *ctx, hark_fgb_plan *pl)
 int hark_op_groupby_dense_u32(hark_context *ctx, hark_fgb_plan *pl, const uint32_t *k, const uint32_t *v, int64_t n)
 {
     if (!ctx || !pl) return HARK_EARG;
-    if (pl->vop == VOP_F32SUM) return hark_fail(ctx, HARK_EARG, "groupby_dense_u32: set the plan's \"vop\" to a u32 operator first");
     if (n < 0 || (n && (!k || !v))) return hark_fail(ctx, HARK_EARG, "groupby_dense_u32: null column");
     if (n > 0xFFFFFFFFll || (pl->max_rows && n > pl->max_rows)) return hark_fail(ctx, HARK_EARG, "groupby_dense_u32: too many rows for this plan");
     return k_fgb_dense_f32(ctx, pl, nullptr, 0, 0.0f, reinterpret_cast<const int32_t *>(k), reinterpret_cast<const float *>(v), n);
@@ -821,4 +866,14 @@ int hark_fgb_timing(hark_context *ctx, hark_fgb_plan *pl, double *ms_by_kind, in
     }
     pl->ev_used = 0;
     return HARK_OK;
+}
+
+int hark_fgb_finish_typed(hark_context *ctx, hark_fgb_plan *pl, int32_t kind, const uint32_t *pos, void *out)
+{
+    if (!ctx || !pl || !out || kind < 0 || kind > 11 || kind == 6) return HARK_EARG;
+    int64_t blocks = (pl->G + 255) / 256;
+    if (blocks > (int64_t)ctx->num_cu * 4) blocks = (int64_t)ctx->num_cu * 4;
+    fgb_decode_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(reinterpret_cast<const u64 *>(pl->acc_sum), pl->acc_cnt, pl->G, kind, pos, out);
+    HIP_TRY(ctx, hipGetLastError());
+    return fgb_check_err(ctx, pl);
 }

@@ -356,90 +356,131 @@ __global__ __launch_bounds__(256) void nonzero_flags_kernel(const unsigned long 
     for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < G; g += stride) flags[g] = cnt[g] ? 1u : 0u;
 }
 
-// mode 0: key (= group index), 1: SUM -> f32, 2: COUNT -> i64, 3: AVG -> f32
-__global__ __launch_bounds__(256) void dense_emit_kernel(const double *__restrict__ acc_sum, const unsigned long long *__restrict__ acc_cnt,
-                                                         const uint32_t *__restrict__ pos, int64_t G, int mode, void *__restrict__ out)
+constexpr int64_t kDenseMaxGroups = (int64_t)1 << 21;      // limit of the partition path of k_fgb.hip
+
+// How one SQL aggregate maps onto a fused dense pass: accumulate operator, value transform,
+// read-out kind (fgb_decode_kernel) and result dtype.
+struct DensePass { int vop, xf, col, kind, out_dtype; bool count_only; };
+
+bool dense_plan_for(int op, int dt, int col, DensePass *out)
 {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < G; g += stride) {
-        const unsigned long long c = acc_cnt[g];
-        if (!c) continue;
-        const uint32_t o = pos[g];
-        if (mode == 0) static_cast<uint32_t *>(out)[o] = (uint32_t)g;
-        else if (mode == 1) static_cast<float *>(out)[o] = (float)acc_sum[g];
-        else if (mode == 2) static_cast<long long *>(out)[o] = (long long)c;
-        else static_cast<float *>(out)[o] = (float)(acc_sum[g] / (double)c);
+    const bool f = dt == HARK_F32, i = dt == HARK_I32, u = dt == HARK_U32;
+    if (op == HARK_AGG_COUNT) { *out = DensePass{-1, 0, -1, 11, HARK_I64, true}; return true; }
+    if (!f && !i && !u) return false;                        // 8-byte columns: sort-based path
+    switch (op) {
+    case HARK_AGG_SUM: *out = f ? DensePass{0, 0, col, 0, HARK_F32, false} : i ? DensePass{5, 1, col, 5, HARK_I64, false} : DensePass{5, 0, col, 4, HARK_I64, false}; return true;
+    case HARK_AGG_AVG: *out = f ? DensePass{0, 0, col, 7, HARK_F32, false} : i ? DensePass{5, 1, col, 9, HARK_F32, false} : DensePass{5, 0, col, 8, HARK_F32, false}; return true;
+    case HARK_AGG_MAX: *out = f ? DensePass{2, 2, col, 3, HARK_F32, false} : i ? DensePass{2, 1, col, 2, HARK_I32, false} : DensePass{2, 0, col, 1, HARK_U32, false}; return true;
+    case HARK_AGG_MIN: case HARK_AGG_KEY:
+        *out = f ? DensePass{3, 2, col, 3, HARK_F32, false} : i ? DensePass{3, 1, col, 2, HARK_I32, false} : DensePass{3, 0, col, 1, HARK_U32, false}; return true;
+    case HARK_AGG_PROD: if (f) return false; *out = DensePass{4, 0, col, 1, dt, false}; return true;      // wrapping 32-bit product
+    default: return false;
     }
 }
 
-constexpr int64_t kDenseMaxGroups = (int64_t)1 << 21;      // limit of the partition path of k_fgb.hip
-
-// Dense shape: 32-bit integer key with 0 <= key < 2^21, aggregates drawn from
-// {SUM(v), AVG(v), COUNT} over ONE f32 column v, filter absent or on an f32 column.
+// Dense shape: 32-bit integer key with 0 <= key < 2^21 and aggregates over 4-byte columns.
+// One fused pass (k_fgb.hip) per distinct (operator, column); a single f32 predicate is fused
+// into the pass when every pass is an f32 sum, otherwise the referenced columns are compacted first.
 int try_dense(hark_context *ctx, const hark_table *db, int32_t where_col, int32_t cmp, const void *constant,
               int32_t g_col, const int32_t *agg_cols, const int32_t *agg_ops, int64_t n_aggs, hark_result *res, bool *used)
 {
     *used = false;
     const int kdt = db->cols[g_col].dtype;
     if (kdt != HARK_I32 && kdt != HARK_U32) return HARK_OK;
-    if (where_col >= 0 && db->cols[where_col].dtype != HARK_F32) return HARK_OK;
-    int vcol = -1;
+    std::vector<DensePass> plan_of((size_t)n_aggs);
+    bool all_f32sum = true;
     for (int64_t j = 0; j < n_aggs; j++) {
-        if (agg_ops[j] == HARK_AGG_COUNT) continue;
-        if (agg_ops[j] != HARK_AGG_SUM && agg_ops[j] != HARK_AGG_AVG) return HARK_OK;
-        if (db->cols[agg_cols[j]].dtype != HARK_F32) return HARK_OK;
-        if (vcol >= 0 && vcol != agg_cols[j]) return HARK_OK;
-        vcol = agg_cols[j];
+        const int c = agg_ops[j] == HARK_AGG_COUNT ? 0 : agg_cols[j];
+        if (!dense_plan_for(agg_ops[j], db->cols[c].dtype, c, &plan_of[j])) return HARK_OK;
+        if (!plan_of[j].count_only && plan_of[j].vop != 0) all_f32sum = false;
     }
     // column statistic: key range
     unsigned long long *mm = nullptr;
     HARK_TRY(hark_alloc(ctx, (void **)&mm, 16));
     const unsigned long long init[2] = {~0ull, 0ull};
-    int rc = HARK_OK;
-    if (hipMemcpyAsync(mm, init, 16, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "stats upload failed");
-    int64_t blocks = (db->n + 255) / 256; if (blocks > (int64_t)ctx->num_cu * 8) blocks = (int64_t)ctx->num_cu * 8;
+    int rc = hipMemcpyAsync(mm, init, 16, hipMemcpyHostToDevice, ctx->stream) == hipSuccess ? HARK_OK : hark_fail(ctx, HARK_EHIP, "stats upload failed");
     int64_t lohi[2] = {0, 0};
     if (!rc) {
-        minmax_u32_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(static_cast<const uint32_t *>(db->cols[g_col].data), db->n, kdt == HARK_I32, mm);
+        minmax_u32_kernel<<<grid_for(ctx, db->n), 256, 0, ctx->stream>>>(static_cast<const uint32_t *>(db->cols[g_col].data), db->n, kdt == HARK_I32, mm);
         rc = hark_read_words(ctx, mm, lohi, 2);
     }
     hark_free(ctx, mm);
     if (rc) return rc;
     const int64_t bias = kdt == HARK_I32 ? ((int64_t)1 << 31) : 0;
     const int64_t kmin = lohi[0] - bias, kmax = lohi[1] - bias;
-    if (kmin < 0 || kmax >= kDenseMaxGroups) return HARK_OK;
+    if (kmin < 0 || kmax >= kDenseMaxGroups || kmax + 1 > 8 * db->n + 4096) return HARK_OK;
     const int64_t G = kmax + 1;
 
+    // WHERE: fused when possible, otherwise compact the referenced columns first
+    const hark_table *src = db;
+    hark_result *kept = nullptr;
+    hark_table view;
+    std::vector<int32_t> remap((size_t)db->m, -1), need;
+    int32_t g2 = g_col;
+    const bool fuse_pred = where_col >= 0 && all_f32sum && db->cols[where_col].dtype == HARK_F32;
+    if (where_col >= 0 && !fuse_pred) {
+        auto want = [&](int c) { if (remap[c] < 0) { remap[c] = (int32_t)need.size(); need.push_back(c); } return remap[c]; };
+        g2 = want(g_col);
+        for (auto &pp : plan_of) if (!pp.count_only) pp.col = want(pp.col);
+        HARK_TRY(hark_entry_filter_sel(ctx, &kept, db, where_col, cmp, constant, need.data(), (int64_t)need.size(), 0));
+        view.n = kept->n; view.m = (int64_t)kept->cols.size(); view.cols = kept->cols;
+        for (auto &c : view.cols) c.owned = false;
+        src = &view;
+    }
+    const float *p = fuse_pred ? static_cast<const float *>(src->cols[where_col].data) : nullptr;
+    const float thr = fuse_pred ? *static_cast<const float *>(constant) : 0.0f;
+    const int32_t *keys = static_cast<const int32_t *>(src->cols[g2].data);
+
     hark_fgb_plan *plan = nullptr;
-    HARK_TRY(hark_fgb_plan_new(ctx, &plan, db->n, G));
-    const float *p = where_col >= 0 ? static_cast<const float *>(db->cols[where_col].data) : nullptr;
-    const float thr = where_col >= 0 ? *static_cast<const float *>(constant) : 0.0f;
-    // COUNT-only queries still need a value stream: any 4-byte column does (its sum is never read)
-    const float *v = static_cast<const float *>(db->cols[vcol >= 0 ? vcol : g_col].data);
+    rc = hark_fgb_plan_new(ctx, &plan, src->n > 0 ? src->n : 1, G);
     uint32_t *flags = nullptr, *pos = nullptr;
-    int64_t ngroups = 0;
-    rc = k_fgb_dense_f32(ctx, plan, p, cmp, thr, static_cast<const int32_t *>(db->cols[g_col].data), v, db->n);
-    if (!rc) rc = hark_fgb_finish(ctx, plan, nullptr, nullptr);
-    if (!rc) rc = hark_alloc(ctx, (void **)&flags, (size_t)G * 4);
-    if (!rc) rc = hark_alloc(ctx, (void **)&pos, (size_t)G * 4);
-    if (!rc) {
-        nonzero_flags_kernel<<<grid_for(ctx, G), 256, 0, ctx->stream>>>(plan->acc_cnt, G, flags);
-        rc = k_exclusive_scan_u32(ctx, flags, G, pos, nullptr, &ngroups);
-    }
-    if (!rc) {
-        res->n = ngroups;
-        res->cols.resize((size_t)n_aggs + 1);
-        for (int64_t j = -1; j < n_aggs && !rc; j++) {
-            hark_column &c = res->cols[(size_t)(j + 1)];
-            const int mode = j < 0 ? 0 : agg_ops[j] == HARK_AGG_SUM ? 1 : agg_ops[j] == HARK_AGG_COUNT ? 2 : 3;
-            c.dtype = mode == 0 ? kdt : mode == 2 ? HARK_I64 : HARK_F32;
-            rc = hark_alloc(ctx, &c.data, (size_t)ngroups * hark_dtype_size(c.dtype));
-            if (!rc) dense_emit_kernel<<<grid_for(ctx, G), 256, 0, ctx->stream>>>(plan->acc_sum, plan->acc_cnt, pos, G, mode, c.data);
+    int64_t ngroups = -1;
+    std::vector<char> done((size_t)n_aggs, 0);
+    auto run_pass = [&](int vop, int xf, const void *col) -> int {
+        int r = hark_fgb_plan_set(plan, "vop", vop);
+        if (!r) r = hark_fgb_plan_set(plan, "xform", xf);
+        if (!r) r = hark_fgb_reset(ctx, plan);
+        if (!r && src->n > 0) r = k_fgb_dense_f32(ctx, plan, p, cmp, thr, keys, static_cast<const float *>(col), src->n);
+        if (!r && ngroups < 0) {                              // the first pass also yields the group set
+            r = hark_alloc(ctx, (void **)&flags, (size_t)G * 4);
+            if (!r) r = hark_alloc(ctx, (void **)&pos, (size_t)G * 4);
+            if (!r) {
+                nonzero_flags_kernel<<<grid_for(ctx, G), 256, 0, ctx->stream>>>(plan->acc_cnt, G, flags);
+                r = k_exclusive_scan_u32(ctx, flags, G, pos, nullptr, &ngroups);
+            }
+            if (!r) {
+                res->n = ngroups;
+                res->cols.resize((size_t)n_aggs + 1);
+                res->cols[0].dtype = kdt;
+                r = hark_alloc(ctx, &res->cols[0].data, (size_t)ngroups * 4);
+                if (!r) r = hark_fgb_finish_typed(ctx, plan, 10, pos, res->cols[0].data);
+                for (int64_t j = 0; j < n_aggs && !r; j++) {
+                    res->cols[(size_t)j + 1].dtype = plan_of[j].out_dtype;
+                    r = hark_alloc(ctx, &res->cols[(size_t)j + 1].data, (size_t)ngroups * hark_dtype_size(plan_of[j].out_dtype));
+                }
+            }
         }
-        if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "filter_groupby: kernels failed");
+        return r;
+    };
+    for (int64_t j = 0; j < n_aggs && !rc; j++) {
+        if (done[j] || plan_of[j].count_only) continue;
+        rc = run_pass(plan_of[j].vop, plan_of[j].xf, src->cols[plan_of[j].col].data);
+        for (int64_t q = j; q < n_aggs && !rc; q++)           // every aggregate this pass serves
+            if (!done[q] && (plan_of[q].count_only || (plan_of[q].vop == plan_of[j].vop && plan_of[q].xf == plan_of[j].xf && plan_of[q].col == plan_of[j].col))) {
+                rc = hark_fgb_finish_typed(ctx, plan, plan_of[q].kind, pos, res->cols[(size_t)q + 1].data);
+                done[q] = 1;
+            }
     }
+    if (!rc && ngroups < 0) {                                 // COUNT only (or no aggregate): one pass over the key column
+        rc = run_pass(3, 0, keys);
+        for (int64_t q = 0; q < n_aggs && !rc; q++) rc = hark_fgb_finish_typed(ctx, plan, plan_of[q].kind, pos, res->cols[(size_t)q + 1].data);
+    } else
+        for (int64_t q = 0; q < n_aggs && !rc; q++)           // COUNTs that came before the first value pass
+            if (!done[q]) rc = hark_fgb_finish_typed(ctx, plan, plan_of[q].kind, pos, res->cols[(size_t)q + 1].data);
+    if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "filter_groupby: kernels failed");
     hark_free(ctx, flags); hark_free(ctx, pos);
-    hark_fgb_plan_free(ctx, plan);
+    if (plan) hark_fgb_plan_free(ctx, plan);
+    if (kept) hark_result_free(ctx, kept);
     *used = rc == HARK_OK;
     return rc;
 }

@@ -80,6 +80,28 @@ def test_generic_typed_groupby(fc):
     assert np.allclose(cols[5], g.w.mean().to_numpy(), rtol=1e-6)
 
 
+@pytest.mark.parametrize("where", ["", "where w <> 0", "where p <= 0.75"])
+def test_dense_typed_aggregates_fused_path(fc, where):
+    """Dense i32 key + aggregates over 4-byte columns: one fused pass per (operator, column)
+    (u64 sums, order-preserving transforms for signed / float min-max); an integer predicate
+    compacts first, a float predicate is fused only for pure f32 sums."""
+    df = fc._df
+    sel = df if not where else df[df.w != 0] if "w <>" in where else df[df.p <= 0.75]
+    names, cols = fc.sql_columns(f"select k, sum(w), min(w), max(w), max(p), min(p), avg(w), count(*), sum(v), prod(w) from t {where} group by k")
+    g = sel.groupby("k")
+    assert np.array_equal(cols[0], np.asarray(g.w.sum().index)) and cols[0].dtype == np.int32
+    assert np.array_equal(cols[1], g.w.sum().to_numpy()) and cols[1].dtype == np.int64
+    assert np.array_equal(cols[2], g.w.min().to_numpy()) and cols[2].dtype == np.int32
+    assert np.array_equal(cols[3], g.w.max().to_numpy())
+    assert np.array_equal(cols[4], g.p.max().to_numpy()) and cols[4].dtype == np.float32
+    assert np.array_equal(cols[5], g.p.min().to_numpy())
+    assert np.allclose(cols[6], g.w.mean().to_numpy(), rtol=1e-6, atol=1e-7)
+    assert np.array_equal(cols[7], g.w.count().to_numpy()) and cols[7].dtype == np.int64
+    assert np.array_equal(cols[8], g.v.sum().to_numpy().astype(np.float32))
+    prod = g.w.apply(lambda x: int(np.prod(x.to_numpy().astype(object)) % 2**32)).to_numpy().astype(np.uint32).view(np.int32)
+    assert np.array_equal(cols[9], prod)
+
+
 def test_groupby_negative_and_int64_keys(fc):
     df = fc._df
     _, cols = fc.sql_columns("select w, count(*) from t group by w")
