@@ -46,6 +46,15 @@ class FutharkContext:
         table._device = self.FutEnv.table_from_columns(table.host_columns())
         self.tables[table_name] = table
 
+    def create_table_from_device(self, table_name, schema, ptrs, dtypes, n, keepalive=None):
+        """Register n-row columns that already live in HBM (raw device addresses,
+        16-byte aligned) as a table, without a host round trip."""
+        t = Table.__new__(Table)
+        t._table_name, t._schema, t._frame = table_name, list(schema), None
+        t._data = np.empty((0, len(schema)), dtype=np.float32)          # no host copy exists
+        t._device = self.FutEnv.table_from_device(n, list(ptrs), list(dtypes), keepalive=keepalive)
+        self.tables[table_name] = t
+
     # FutharkContext.py:52-53
     def drop_table(self, table_name):
         t = self.tables.pop(table_name)

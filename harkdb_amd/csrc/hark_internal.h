@@ -34,6 +34,9 @@ struct hark_column {
     void *data = nullptr;
     int32_t dtype = HARK_I32;
     bool owned = true;
+    // column statistic, filled on first use (tables are immutable): value range of a 32-bit integer column
+    mutable bool has_range[2] = {false, false};            // [0] read as unsigned, [1] read as signed
+    mutable int64_t range_min[2] = {0, 0}, range_max[2] = {0, 0};
 };
 
 struct hark_table {

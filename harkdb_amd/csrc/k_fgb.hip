@@ -114,6 +114,18 @@ __device__ __forceinline__ void vop_atomic_partial(u64 *slot, u64 part)
     else vop_atomic<VOP>(slot, (uint32_t)part);
 }
 
+__device__ __forceinline__ void vop_atomic_partial_rt(int vop, u64 *slot, u64 part)
+{
+    switch (vop) {
+    case VOP_F32SUM: vop_atomic_partial<VOP_F32SUM>(slot, part); break;
+    case VOP_U32SUM: vop_atomic_partial<VOP_U32SUM>(slot, part); break;
+    case VOP_U32MAX: vop_atomic_partial<VOP_U32MAX>(slot, part); break;
+    case VOP_U32MIN: vop_atomic_partial<VOP_U32MIN>(slot, part); break;
+    case VOP_U32SUM64: vop_atomic_partial<VOP_U32SUM64>(slot, part); break;
+    default: vop_atomic_partial<VOP_U32PROD>(slot, part); break;
+    }
+}
+
 __device__ __forceinline__ void vop_atomic_rt(int vop, u64 *slot, uint32_t x)
 {
     switch (vop) {
@@ -152,12 +164,15 @@ __global__ void gen_columns_kernel(uint64_t seed, int64_t first_row, int64_t n, 
 // ---------------------------------------------------------------------------
 // Dynamic LDS: u64 s_sum[G << RL] (8-byte value slots); uint32 s_cnt[G << RL].  The
 // replica of a key used by lane l is (key << RL) | (l & (R-1)).
-template <int OP, int VOP>
+// FSUM: the f32-sum operator is compiled in (the headline path: a run-time operator switch in
+// the row loop costs 7 % there); otherwise the operator is the wave-uniform run-time `vop`.
+template <int OP, bool FSUM>
 __global__ __launch_bounds__(1024) void fgb_lds_kernel(
     const float *__restrict__ p, const int32_t *__restrict__ k, const float *__restrict__ v,
     int64_t n, float thr, int G, int RL, u64 *__restrict__ gsum,
-    unsigned long long *__restrict__ gcnt, int32_t *__restrict__ err, int xf)
+    unsigned long long *__restrict__ gcnt, int32_t *__restrict__ err, int xf, int vop_rt)
 {
+    const int VOP = FSUM ? (int)VOP_F32SUM : vop_rt;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int slots = G << RL;
     u64 *s_sum = reinterpret_cast<u64 *>(lds_raw);
@@ -177,7 +192,8 @@ __global__ __launch_bounds__(1024) void fgb_lds_kernel(
         if (cmp_f32<OP>(pv, thr)) {
             if ((uint32_t)key < (uint32_t)G) {
                 uint32_t s = ((uint32_t)key << RL) | rep;
-                vop_atomic<VOP>(&s_sum[s], apply_xf(xf, __float_as_uint(val)));   // ds_add_f64 / ds_{add,max,min}_u32
+                if constexpr (FSUM) vop_atomic<VOP_F32SUM>(&s_sum[s], __float_as_uint(val));      // ds_add_f64
+                else vop_atomic_rt(VOP, &s_sum[s], apply_xf(xf, __float_as_uint(val)));            // ds_{add,max,min}_u32 / ds_add_u64
                 atomicAdd(&s_cnt[s], 1u);                           // ds_add_u32
             } else bad = true;
         }
@@ -212,7 +228,8 @@ __global__ __launch_bounds__(1024) void fgb_lds_kernel(
         u64 s = vop_identity(VOP); uint32_t c = 0;
         for (int r = 0; r < R; r++) { s = vop_merge(VOP, s, s_sum[(g << RL) + r]); c += s_cnt[(g << RL) + r]; }
         if (c) {
-            vop_atomic_partial<VOP>(&gsum[g], s);             // contiguous global atomics (global_atomic_add_f64 ...)
+            if constexpr (FSUM) vop_atomic_partial<VOP_F32SUM>(&gsum[g], s);   // contiguous global_atomic_add_f64
+            else vop_atomic_partial_rt(VOP, &gsum[g], s);
             atomicAdd(&gcnt[g], (unsigned long long)c);
         }
     }
@@ -710,7 +727,6 @@ int k_fgb_dense_f32(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cm
         return hark_fail(ctx, HARK_EARG, "fgb: columns must be 16-byte aligned");
     u64 *gsum = reinterpret_cast<u64 *>(pl->acc_sum);
     const int vop = (int)pl->vop;
-    if (vop != VOP_F32SUM && p) return hark_fail(ctx, HARK_EARG, "fgb: only the f32 sum takes a fused predicate (filter first)");
     unsigned long long *gcnt = pl->acc_cnt;
     int algo = (int)pl->algo;
     // auto: LDS tables while 12 B x G fits a workgroup; the partition path up to 256 buckets x 8192 keys;
@@ -729,19 +745,20 @@ int k_fgb_dense_f32(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cm
         int64_t grid = pl->grid ? pl->grid : (int64_t)ctx->num_cu;
         const int64_t need = (n / kVec + 1023) / 1024;
         if (grid > need) grid = need > 0 ? need : 1;
-        auto launch = [&](auto op, auto vopc) -> int {
-            constexpr int OP = decltype(op)::value, VOP = decltype(vopc)::value;
+        auto launch = [&](auto op, auto fsum) -> int {
+            constexpr int OP = decltype(op)::value;
+            constexpr bool FSUM = decltype(fsum)::value;
             if (lds > 64 * 1024)
-                HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_lds_kernel<OP, VOP>),
+                HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_lds_kernel<OP, FSUM>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             TimedLaunch tl(pl, st, 0);
-            fgb_lds_kernel<OP, VOP><<<dim3((unsigned)grid), dim3(1024), lds, st>>>(p, k, v, n, thr, (int)G, RL, gsum, gcnt, pl->err, (int)pl->xform);
+            fgb_lds_kernel<OP, FSUM><<<dim3((unsigned)grid), dim3(1024), lds, st>>>(p, k, v, n, thr, (int)G, RL, gsum, gcnt, pl->err, (int)pl->xform, vop);
             HIP_TRY(ctx, hipGetLastError());
             return HARK_OK;
         };
-        if (vop == VOP_F32SUM)
-            return dispatch_op(cmp, p != nullptr, [&](auto op) -> int { return launch(op, std::integral_constant<int, VOP_F32SUM>{}); });
-        return dispatch_vop(vop, [&](auto vopc) -> int { return launch(std::integral_constant<int, kNoPred>{}, vopc); });
+        if (vop == VOP_F32SUM && pl->xform == 0)
+            return dispatch_op(cmp, p != nullptr, [&](auto op) -> int { return launch(op, std::true_type{}); });
+        return dispatch_op(cmp, p != nullptr, [&](auto op) -> int { return launch(op, std::false_type{}); });
     }
     if (algo == 2) {
         int64_t grid = pl->grid ? pl->grid : (int64_t)ctx->num_cu * 8;

@@ -249,8 +249,8 @@ int grouped_aggregate(hark_context *ctx, const hark_table *db, int key_col, int 
 int kind_of(int dtype) { return dtype == HARK_F32 ? ACC_F64 : dtype == HARK_U32 ? ACC_U64 : ACC_I64; }
 
 // defined at the end of this file: the fused dense-key kernels of k_fgb.hip behind the reference entry
-int ref_groupby_dense(hark_context *ctx, const hark_table *view, int g_col, const std::vector<AggSpec> &aggs,
-                      hark_result *res, int64_t *G_out, bool *used);
+int ref_groupby_dense(hark_context *ctx, const hark_table *view, const hark_table *stats_owner, int g_col,
+                      const std::vector<AggSpec> &aggs, hark_result *res, int64_t *G_out, bool *used);
 
 } // namespace
 
@@ -287,7 +287,7 @@ int hark_entry_query_groupby(hark_context *ctx, hark_result **out, const hark_ta
     for (auto &c : view.cols) { c.owned = false; if (c.dtype == HARK_I32) c.dtype = HARK_U32; }
     int64_t G = 0;
     bool dense = false;
-    int rc = ref_groupby_dense(ctx, &view, g_col, aggs, res, &G, &dense);   // keys < 2^21: fused kernels, no sort
+    int rc = ref_groupby_dense(ctx, &view, db, g_col, aggs, res, &G, &dense);   // keys < 2^21: fused kernels, no sort
     if (!rc && !dense) rc = grouped_aggregate(ctx, &view, g_col, HARK_U32, aggs, res, &G);
     if (!rc && nt < ns && G < db->n)                    // some group has two rows: merge indexes t_cols[i-1] out of bounds
         rc = hark_fail(ctx, HARK_EBOUNDS, "query_groupby: %lld aggregate opcodes for %lld select columns", (long long)nt, (long long)ns);
@@ -350,6 +350,33 @@ __global__ __launch_bounds__(256) void minmax_u32_kernel(const uint32_t *__restr
     if ((threadIdx.x & 63) == 0) { atomicMin(&out[0], (unsigned long long)lo); atomicMax(&out[1], (unsigned long long)hi); }
 }
 
+int grid_for(hark_context *ctx, int64_t n);
+
+// [min, max] of a 32-bit integer column (as signed for I32, unsigned otherwise); cached in the column.
+int column_range(hark_context *ctx, const hark_table *t, int col, bool as_signed, int64_t *lo, int64_t *hi)
+{
+    const hark_column &c = t->cols[col];
+    const int w = as_signed ? 1 : 0;
+    if (!c.has_range[w] || t->n == 0) {
+        unsigned long long *mm = nullptr;
+        HARK_TRY(hark_alloc(ctx, (void **)&mm, 16));
+        const unsigned long long init[2] = {~0ull, 0ull};
+        int rc = hipMemcpyAsync(mm, init, 16, hipMemcpyHostToDevice, ctx->stream) == hipSuccess ? HARK_OK : hark_fail(ctx, HARK_EHIP, "stats upload failed");
+        int64_t lohi[2] = {0, 0};
+        if (!rc) {
+            if (t->n > 0) minmax_u32_kernel<<<grid_for(ctx, t->n), 256, 0, ctx->stream>>>(static_cast<const uint32_t *>(c.data), t->n, as_signed ? 1 : 0, mm);
+            rc = hark_read_words(ctx, mm, lohi, 2);
+        }
+        hark_free(ctx, mm);
+        if (rc) return rc;
+        const int64_t bias = as_signed ? ((int64_t)1 << 31) : 0;
+        c.range_min[w] = lohi[0] - bias; c.range_max[w] = lohi[1] - bias;
+        c.has_range[w] = t->n > 0;
+    }
+    *lo = c.range_min[w]; *hi = c.range_max[w];
+    return HARK_OK;
+}
+
 __global__ __launch_bounds__(256) void nonzero_flags_kernel(const unsigned long long *__restrict__ cnt, int64_t G, uint32_t *__restrict__ flags)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -379,8 +406,8 @@ bool dense_plan_for(int op, int dt, int col, DensePass *out)
 }
 
 // Dense shape: 32-bit integer key with 0 <= key < 2^21 and aggregates over 4-byte columns.
-// One fused pass (k_fgb.hip) per distinct (operator, column); a single f32 predicate is fused
-// into the pass when every pass is an f32 sum, otherwise the referenced columns are compacted first.
+// One fused pass (k_fgb.hip) per distinct (operator, column); an f32 predicate is fused into every
+// pass, a predicate on another dtype compacts the referenced columns first.
 int try_dense(hark_context *ctx, const hark_table *db, int32_t where_col, int32_t cmp, const void *constant,
               int32_t g_col, const int32_t *agg_cols, const int32_t *agg_ops, int64_t n_aggs, hark_result *res, bool *used)
 {
@@ -388,26 +415,14 @@ int try_dense(hark_context *ctx, const hark_table *db, int32_t where_col, int32_
     const int kdt = db->cols[g_col].dtype;
     if (kdt != HARK_I32 && kdt != HARK_U32) return HARK_OK;
     std::vector<DensePass> plan_of((size_t)n_aggs);
-    bool all_f32sum = true;
     for (int64_t j = 0; j < n_aggs; j++) {
         const int c = agg_ops[j] == HARK_AGG_COUNT ? 0 : agg_cols[j];
         if (!dense_plan_for(agg_ops[j], db->cols[c].dtype, c, &plan_of[j])) return HARK_OK;
-        if (!plan_of[j].count_only && plan_of[j].vop != 0) all_f32sum = false;
     }
-    // column statistic: key range
-    unsigned long long *mm = nullptr;
-    HARK_TRY(hark_alloc(ctx, (void **)&mm, 16));
-    const unsigned long long init[2] = {~0ull, 0ull};
-    int rc = hipMemcpyAsync(mm, init, 16, hipMemcpyHostToDevice, ctx->stream) == hipSuccess ? HARK_OK : hark_fail(ctx, HARK_EHIP, "stats upload failed");
-    int64_t lohi[2] = {0, 0};
-    if (!rc) {
-        minmax_u32_kernel<<<grid_for(ctx, db->n), 256, 0, ctx->stream>>>(static_cast<const uint32_t *>(db->cols[g_col].data), db->n, kdt == HARK_I32, mm);
-        rc = hark_read_words(ctx, mm, lohi, 2);
-    }
-    hark_free(ctx, mm);
-    if (rc) return rc;
-    const int64_t bias = kdt == HARK_I32 ? ((int64_t)1 << 31) : 0;
-    const int64_t kmin = lohi[0] - bias, kmax = lohi[1] - bias;
+    // column statistic: key range (computed once per column, then cached)
+    int64_t kmin = 0, kmax = 0;
+    HARK_TRY(column_range(ctx, db, g_col, kdt == HARK_I32, &kmin, &kmax));
+    int rc = HARK_OK;
     if (kmin < 0 || kmax >= kDenseMaxGroups || kmax + 1 > 8 * db->n + 4096) return HARK_OK;
     const int64_t G = kmax + 1;
 
@@ -417,7 +432,7 @@ int try_dense(hark_context *ctx, const hark_table *db, int32_t where_col, int32_
     hark_table view;
     std::vector<int32_t> remap((size_t)db->m, -1), need;
     int32_t g2 = g_col;
-    const bool fuse_pred = where_col >= 0 && all_f32sum && db->cols[where_col].dtype == HARK_F32;
+    const bool fuse_pred = where_col >= 0 && db->cols[where_col].dtype == HARK_F32;     // an f32 predicate rides in every pass
     if (where_col >= 0 && !fuse_pred) {
         auto want = [&](int c) { if (remap[c] < 0) { remap[c] = (int32_t)need.size(); need.push_back(c); } return remap[c]; };
         g2 = want(g_col);
@@ -555,25 +570,17 @@ __global__ __launch_bounds__(256) void dense_emit_u32_kernel(const uint32_t *__r
         if (acc_cnt[g]) out[pos[g]] = vals ? vals[g] : (uint32_t)g;
 }
 
-int ref_groupby_dense(hark_context *ctx, const hark_table *view, int g_col, const std::vector<AggSpec> &aggs,
-                      hark_result *res, int64_t *G_out, bool *used)
+int ref_groupby_dense(hark_context *ctx, const hark_table *view, const hark_table *stats_owner, int g_col,
+                      const std::vector<AggSpec> &aggs, hark_result *res, int64_t *G_out, bool *used)
 {
     *used = false;
     const int64_t n = view->n;
     const uint32_t *keys = static_cast<const uint32_t *>(view->cols[g_col].data);
-    // column statistic: largest key (unsigned)
-    unsigned long long *mm = nullptr;
-    HARK_TRY(hark_alloc(ctx, (void **)&mm, 16));
-    const unsigned long long init[2] = {~0ull, 0ull};
-    int rc = hipMemcpyAsync(mm, init, 16, hipMemcpyHostToDevice, ctx->stream) == hipSuccess ? HARK_OK : hark_fail(ctx, HARK_EHIP, "stats upload failed");
-    int64_t lohi[2] = {0, 0};
-    if (!rc) {
-        minmax_u32_kernel<<<grid_for(ctx, n), 256, 0, ctx->stream>>>(keys, n, 0, mm);
-        rc = hark_read_words(ctx, mm, lohi, 2);
-    }
-    hark_free(ctx, mm);
-    if (rc) return rc;
-    const int64_t G = lohi[1] + 1;
+    // column statistic: largest key (unsigned), cached in the column
+    int64_t kmin = 0, kmax = 0;
+    HARK_TRY(column_range(ctx, stats_owner, g_col, false, &kmin, &kmax));     // cached on the caller's table
+    int rc = HARK_OK;
+    const int64_t G = kmax + 1;
     if (G > kDenseMaxGroups || G > 8 * n + 4096) return HARK_OK;       // sparse or huge key domain: sort-based path
 
     hark_fgb_plan *plan = nullptr;
