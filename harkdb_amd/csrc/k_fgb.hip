@@ -292,7 +292,16 @@ constexpr int kBatchRows = kPartThreads * kVec;          // 4096 rows per batch
 constexpr int kMaxBuckets = 256;                         // 256 * kQ * 8 B = 64 KiB of queues
 constexpr int kTileRows = 8192;                          // chunk granularity (multiple of kBatchRows)
 
-static size_t part_lds_bytes(int P) { return sizeof(uint2) * (size_t)P * kQ + sizeof(int) * 3 * (size_t)P; }
+// Heavy-hitter cache: a direct-mapped LDS table of kHot (key, partial value, count) entries per
+// workgroup.  A surviving row whose key owns its slot is folded there and never enters a queue;
+// a slot is claimed by the first key that hashes to it.  With uniform keys it costs one LDS read
+// per row; with skewed keys (tools/skew_bench.py: one hot key ran 700x slower without it) the hot
+// keys are absorbed on chip.  Entries are added to the global table once, at the end of the kernel.
+constexpr int kHotBits = 9, kHot = 1 << kHotBits;
+constexpr uint32_t kHotEmpty = 0xFFFFFFFFu;
+constexpr int kHotProbeBatches = 4;                      // a workgroup keeps the cache on only if > 1/16 of its first rows hit it
+constexpr int kRetryRounds = 8;                          // queue-full retries per batch before direct atomics
+static size_t part_lds_bytes(int P) { return sizeof(uint2) * (size_t)P * kQ + sizeof(int) * 3 * (size_t)P + (size_t)kHot * 16 + 16; }
 
 template <int OP>
 __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
@@ -306,12 +315,19 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
     int *s_cnt = reinterpret_cast<int *>(queue + (size_t)P * kQ);      // pairs queued per bucket
     int *s_head = s_cnt + P;                                           // queue index of the oldest pair (multiple of kLine)
     int *s_lcur = s_head + P;                                          // lines already stored in this workgroup's slab
+    u64 *h_val = reinterpret_cast<u64 *>(s_lcur + P + ((3 * P) & 1));         // [kHot] heavy-hitter partial values (8-byte aligned)
+    uint32_t *h_key = reinterpret_cast<uint32_t *>(h_val + kHot);             // [kHot] owning key or kHotEmpty
+    uint32_t *h_cnt = h_key + kHot;                                           // [kHot]
+    uint32_t *h_stat = h_cnt + kHot;                                          // [0] hits, [1] surviving rows seen, [2] cache switched off
     const int tid = threadIdx.x;
     const int nwg = gridDim.x, wg = blockIdx.x;
     const int64_t nbatch = (row1 - row0 + kBatchRows - 1) / kBatchRows;
     const int cap_lines = (int)(cap / kLine) - 1;                      // the last line is kept for the final partial flush
     bool bad = false;
     for (int b = tid; b < P; b += kPartThreads) { s_cnt[b] = 0; s_head[b] = 0; s_lcur[b] = 0; }
+    for (int h = tid; h < kHot; h += kPartThreads) { h_val[h] = vop_identity(vop); h_key[h] = kHotEmpty; h_cnt[h] = 0u; }
+    if (tid < 4) h_stat[tid] = 0u;
+    int batches_done = 0;
     __syncthreads();
 
     auto load = [&](int64_t batch, float4 &pr, int4 &kr, float4 &vr) {
@@ -351,6 +367,31 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
             if (keep) pending |= 1u << j;
         }
         if (ablate & 4) { asm volatile("" :: "v"(pending), "v"(vv[0]), "v"(vv[1]), "v"(vv[2]), "v"(vv[3])); pending = 0; }
+        // ---- heavy hitters: rows whose key owns its cache slot are folded in LDS right here
+        const bool hot_on = !(ablate & 128) && h_stat[2] == 0u;                  // workgroup-uniform
+        const bool probing = hot_on && batches_done < kHotProbeBatches;
+        uint32_t seen = __popc(pending), hits = 0;
+        if (hot_on)
+#pragma unroll
+        for (int j = 0; j < kVec; j++) {
+            if (pending & (1u << j)) {
+                const uint32_t key = (uint32_t)kv[j], h = (key * 0x9E3779B1u) >> (32 - kHotBits);
+                uint32_t owner = h_key[h];
+                bool claimed = false;
+                if (owner == kHotEmpty) { owner = atomicCAS(&h_key[h], kHotEmpty, key); if (owner == kHotEmpty) { owner = key; claimed = true; } }
+                if (owner == key) {
+                    vop_atomic_rt(vop, &h_val[h], apply_xf(xf, __float_as_uint(vv[j])));
+                    atomicAdd(&h_cnt[h], 1u);
+                    pending &= ~(1u << j);
+                    hits += claimed ? 0u : 1u;                      // a claim is not evidence of skew, a repeat is
+                }
+            }
+        }
+        if (probing) {                                                            // wave-aggregated statistics of the probe phase
+            for (int d = 32; d > 0; d >>= 1) { seen += __shfl_down(seen, d, 64); hits += __shfl_down(hits, d, 64); }
+            if ((tid & 63) == 0) { atomicAdd(&h_stat[0], hits); atomicAdd(&h_stat[1], seen); }
+        }
+        batches_done++;
         bool again;
         int rounds = 0;
         do {
@@ -395,7 +436,7 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
                     }
                 }
             }
-            if (++rounds >= 96 || (ablate & 2)) {                         // bounded: leftovers go through direct atomics
+            if (++rounds >= kRetryRounds || (ablate & 2)) {                         // bounded: leftovers go through direct atomics
 #pragma unroll
                 for (int j = 0; j < kVec; j++)
                     if ((pending & (1u << j)) && !(ablate & 2)) {
@@ -405,23 +446,21 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
             }
             again = __syncthreads_or(pending != 0);
         } while (again);
+        if (batches_done == kHotProbeBatches && tid == 0 && h_stat[0] * 16u < h_stat[1]) h_stat[2] = 1u;   // keys are not skewed: stop probing the cache
+        // (read by every thread at the top of the next batch, behind that batch's barriers... the flag only ever goes 0 -> 1,
+        //  and a batch that still sees 0 merely does one more round of lookups)
     };
 
     // two batches of loads stay in flight per lane while a batch is enqueued and flushed
+    // (one call site of `process`: the register sets rotate, the body is not duplicated)
     float4 pA, vA, pB, vB; int4 kA, kB;
     if ((int64_t)wg < nbatch) load(wg, pA, kA, vA);
     if ((int64_t)wg + nwg < nbatch) load((int64_t)wg + nwg, pB, kB, vB);
-    for (int64_t batch = wg; batch < nbatch; batch += 2 * (int64_t)nwg) {
-        {
-            const float4 pr = pA, vr = vA; const int4 kr = kA;
-            if (batch + 2 * (int64_t)nwg < nbatch) load(batch + 2 * (int64_t)nwg, pA, kA, vA);
-            process(batch, pr, kr, vr);
-        }
-        if (batch + nwg < nbatch) {
-            const float4 pr = pB, vr = vB; const int4 kr = kB;
-            if (batch + 3 * (int64_t)nwg < nbatch) load(batch + 3 * (int64_t)nwg, pB, kB, vB);
-            process(batch + nwg, pr, kr, vr);
-        }
+    for (int64_t batch = wg; batch < nbatch; batch += nwg) {
+        const float4 pr = pA, vr = vA; const int4 kr = kA;
+        pA = pB; vA = vB; kA = kB;
+        if (batch + 2 * (int64_t)nwg < nbatch) load(batch + 2 * (int64_t)nwg, pB, kB, vB);
+        process(batch, pr, kr, vr);
     }
     // ---- final flush: what is left (< kLine pairs per bucket) goes out as one partial line
     for (int b = tid; b < P; b += kPartThreads) {
@@ -429,6 +468,11 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
         const size_t base = ((size_t)b * nwg + wg) * cap + (size_t)s_lcur[b] * kLine;
         for (int j = 0; j < l; j++) pbuf[base + j] = queue[b * kQ + ((head + j) & (kQ - 1))];
         counts[(size_t)b * nwg + wg] = (uint32_t)(s_lcur[b] * kLine + l);
+    }
+    // ---- the heavy hitters join the global table (one atomic pair per occupied entry)
+    for (int h = tid; h < kHot; h += kPartThreads) {
+        const uint32_t c = h_cnt[h];
+        if (c) { vop_atomic_partial_rt(vop, &gsum[h_key[h]], h_val[h]); atomicAdd(&gcnt[h_key[h]], (unsigned long long)c); }
     }
     if (bad) *err = HARK_EBOUNDS;
 }

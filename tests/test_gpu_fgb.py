@@ -127,6 +127,34 @@ def test_skewed_keys_overflow_path(eng, oracle):
     plan.free()
 
 
+@pytest.mark.parametrize("shape", ["one_key", "one_bucket", "hot16"])
+def test_skew_shapes_partition_path(eng, oracle, shape):
+    """Heavy hitters are folded in the producer's LDS cache, full queues retry and then
+    fall back to atomics: whatever the key distribution, the result is exact."""
+    from harkdb_amd.engine import FgbPlan
+    n, G = 2_000_003, 1 << 20
+    rng = np.random.default_rng(11)
+    if shape == "one_key":
+        kk = np.full(n, 123_456, dtype=np.int32)
+    elif shape == "one_bucket":
+        kk = rng.integers(8192, 12288, size=n).astype(np.int32)
+    else:
+        kk = np.where(rng.random(n) < 0.9, rng.integers(0, 16, n) * 4099, rng.integers(0, G, n)).astype(np.int32)
+    pp = rng.random(n, dtype=np.float32)
+    vv = rng.integers(0, 16, size=n).astype(np.float32)
+    p, k, v = eng.alloc(n * 4), eng.alloc(n * 4), eng.alloc(n * 4)
+    eng.upload(p, pp); eng.upload(k, kk); eng.upload(v, vv)
+    s, c = eng.alloc(G * 4), eng.alloc(G * 8)
+    plan = FgbPlan(eng, n, G, algo=3)
+    plan.run(p, ">", 0.5, k, v, n)
+    plan.finish(s, c)
+    s32, _, cnt = oracle.filter_groupby_dense_f32(pp, kk, vv, ">", 0.5, G)
+    assert np.array_equal(eng.download(c, G, np.int64), cnt) and np.array_equal(eng.download(s, G, np.float32), s32)
+    plan.free()
+    for ptr in (p, k, v, s, c):
+        eng.free(ptr)
+
+
 def test_key_out_of_range_is_bounds_error(eng):
     from harkdb_amd._ffi import HarkError, EBOUNDS
     from harkdb_amd.engine import FgbPlan
