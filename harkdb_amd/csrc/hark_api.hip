@@ -88,6 +88,41 @@ int hark_read_words(hark_context *ctx, const void *dev, int64_t *host, int count
     return HARK_OK;
 }
 
+// A hipMemcpy into pageable memory is staged by the runtime in small pieces; results of
+// a query are typically a few MB, so they go through two 8 MiB pinned buffers instead:
+// the copy engine fills one while the host drains the other.
+static constexpr size_t kBounce = (size_t)8 << 20;
+
+int hark_d2h(hark_context *ctx, void *host, const void *dev, size_t bytes)
+{
+    if (!bytes) return HARK_OK;
+    if (bytes <= 65536) {
+        HIP_TRY(ctx, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return HARK_OK;
+    }
+    for (int i = 0; i < 2; i++) {
+        if (!ctx->bounce[i]) HIP_TRY(ctx, hipHostMalloc((void **)&ctx->bounce[i], kBounce));
+        if (!ctx->bounce_ev[i]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->bounce_ev[i], hipEventDisableTiming));
+    }
+    const size_t nchunk = (bytes + kBounce - 1) / kBounce;
+    const char *src = static_cast<const char *>(dev);
+    char *dst = static_cast<char *>(host);
+    for (size_t c = 0; c <= nchunk; c++) {
+        if (c < nchunk) {
+            const size_t len = c + 1 < nchunk ? kBounce : bytes - c * kBounce;
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->bounce[c & 1], src + c * kBounce, len, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipEventRecord(ctx->bounce_ev[c & 1], ctx->stream));
+        }
+        if (c > 0) {
+            const size_t q = c - 1, len = q + 1 < nchunk ? kBounce : bytes - q * kBounce;
+            HIP_TRY(ctx, hipEventSynchronize(ctx->bounce_ev[q & 1]));
+            memcpy(dst + q * kBounce, ctx->bounce[q & 1], len);
+        }
+    }
+    return HARK_OK;
+}
+
 extern "C" {
 
 int hark_version(void) { return 100; }
@@ -125,6 +160,7 @@ void hark_context_free(hark_context *ctx)
     pool_trim(ctx);
     if (ctx->d_err) hipFree(ctx->d_err);
     if (ctx->h_pin) hipHostFree(ctx->h_pin);
+    for (int i = 0; i < 2; i++) { if (ctx->bounce[i]) hipHostFree(ctx->bounce[i]); if (ctx->bounce_ev[i]) hipEventDestroy(ctx->bounce_ev[i]); }
     if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -170,10 +206,7 @@ int hark_dev_upload(hark_context *ctx, void *dev, const void *host, int64_t byte
 int hark_dev_download(hark_context *ctx, void *host, const void *dev, int64_t bytes)
 {
     if (!ctx || bytes < 0 || (bytes && (!dev || !host))) return HARK_EARG;
-    if (!bytes) return HARK_OK;
-    HIP_TRY(ctx, hipMemcpyAsync(host, dev, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return HARK_OK;
+    return hark_d2h(ctx, host, dev, (size_t)bytes);
 }
 int hark_op_zero(hark_context *ctx, void *dev, int64_t bytes)
 {
@@ -297,9 +330,7 @@ int hark_result_column(hark_context *ctx, const hark_result *r, int64_t col, voi
     size_t bytes = (size_t)r->n * hark_dtype_size(r->cols[col].dtype);
     if (!bytes) return HARK_OK;
     if (!host_out) return HARK_EARG;
-    HIP_TRY(ctx, hipMemcpyAsync(host_out, r->cols[col].data, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return HARK_OK;
+    return hark_d2h(ctx, host_out, r->cols[col].data, bytes);
 }
 
 int hark_result_free(hark_context *ctx, hark_result *r)

@@ -24,6 +24,9 @@ struct hark_context {
     int32_t *d_err = nullptr;       // device-side sticky error word (bounds failures)
     int32_t *h_pin = nullptr;       // pinned scratch for small D2H reads (64 x i64)
     int num_cu = HARK_NUM_CU;
+    // pinned double buffer for device -> pageable-host copies (hark_d2h)
+    char *bounce[2] = {nullptr, nullptr};
+    hipEvent_t bounce_ev[2] = {nullptr, nullptr};
     // caching allocator (hark_alloc / hark_free)
     std::multimap<size_t, void *> pool_free;
     std::unordered_map<void *, size_t> pool_live;
@@ -72,6 +75,8 @@ int hark_alloc(hark_context *ctx, void **out, size_t bytes);
 void hark_free(hark_context *ctx, void *ptr);
 // Reads `count` 8-byte words from the device after draining the stream.
 int hark_read_words(hark_context *ctx, const void *dev, int64_t *host, int count);
+// Device -> host copy of any size through pinned bounce buffers, synchronous on return.
+int hark_d2h(hark_context *ctx, void *host, const void *dev, size_t bytes);
 
 // ---- kernel launchers implemented in the k_*.hip units -------------------
 // (all stream-ordered on ctx->stream; none allocates)

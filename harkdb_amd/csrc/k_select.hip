@@ -374,11 +374,9 @@ int hark_result_values_2d(hark_context *ctx, const hark_result *r, void *host_ou
     if (blocks > (int64_t)ctx->num_cu * 8) blocks = (int64_t)ctx->num_cu * 8;
     interleave_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(cs, r->n, out_esz, sext, tmp);
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(host_out, tmp, bytes, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    int rc = e == hipSuccess ? hark_d2h(ctx, host_out, tmp, bytes) : hark_fail(ctx, HARK_EHIP, "values_2d: %s", hipGetErrorString(e));
     hark_free(ctx, tmp);
-    if (e != hipSuccess) return hark_fail(ctx, HARK_EHIP, "values_2d: %s", hipGetErrorString(e));
-    return HARK_OK;
+    return rc;
 }
 
 } // extern "C"
