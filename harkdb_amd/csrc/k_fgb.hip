@@ -700,7 +700,6 @@ int hark_fgb_plan_set(hark_fgb_plan *pl, const char *key, int64_t value)
     else if (!strcmp(key, "timing")) { pl->timing = value; return HARK_OK; }
     else if (!strcmp(key, "vop")) { if (value < 0 || value > 5) return HARK_EARG; pl->vop = value; return HARK_OK; }   // reset afterwards
     else if (!strcmp(key, "xform")) { if (value < 0 || value > 2) return HARK_EARG; pl->xform = value; return HARK_OK; }
-    else if (!strcmp(key, "variant")) { if (value < 0 || value > 3) return HARK_EARG; pl->variant = value; return HARK_OK; }
     else if (!strcmp(key, "ablate")) { pl->ablate = value; return HARK_OK; }   // timing experiments only: wrong results
     else return HARK_EARG;
     plan_drop_partition(pl);     // partition geometry depends on the knobs
