@@ -25,20 +25,51 @@ int k_exclusive_scan_u32(hark_context *ctx, const uint32_t *in, int64_t n, uint3
 
 namespace {
 
+// Each thread owns kChunk consecutive (sorted) left keys: one binary search positions it in
+// the sorted right keys, then it walks both sides forward -- sequential reads instead of
+// one full binary search per left row.
+constexpr int kJoinChunk = 8;
 __global__ __launch_bounds__(256) void join_count_kernel(const uint32_t *__restrict__ lkeys, int64_t n,
                                                          const uint32_t *__restrict__ rkeys, int64_t s,
                                                          uint32_t *__restrict__ lb_out, uint32_t *__restrict__ cnt_out)
 {
+    const int64_t nchunks = (n + kJoinChunk - 1) / kJoinChunk;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uint32_t key = lkeys[i];
-        int64_t lo = 0, hi = s;                       // lower bound
-        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (rkeys[mid] < key) lo = mid + 1; else hi = mid; }
-        const int64_t lb = lo;
-        hi = s;                                       // upper bound
-        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (rkeys[mid] <= key) lo = mid + 1; else hi = mid; }
-        lb_out[i] = (uint32_t)lb;
-        cnt_out[i] = (uint32_t)(lo - lb);
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < nchunks; c += stride) {
+        const int64_t i0 = c * kJoinChunk, i1 = i0 + kJoinChunk < n ? i0 + kJoinChunk : n;
+        const uint32_t first = lkeys[i0];
+        int64_t lo = 0, hi = s;                       // lower bound of the chunk's first key
+        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (rkeys[mid] < first) lo = mid + 1; else hi = mid; }
+        int64_t lb = lo, ub = lo;
+        uint32_t prev = first;
+        {   // upper bound of the first key
+            int64_t a = lo, b = s;
+            while (a < b) { const int64_t mid = (a + b) >> 1; if (rkeys[mid] <= first) a = mid + 1; else b = mid; }
+            ub = a;
+        }
+        for (int64_t i = i0; i < i1; i++) {
+            const uint32_t key = lkeys[i];
+            if (key != prev) {                        // left keys ascend: continue from the previous upper bound
+                lb = ub;
+                int steps = 0;
+                while (lb < s && rkeys[lb] < key && steps < 16) { lb++; steps++; }
+                if (lb < s && rkeys[lb] < key) {                     // far away: binary search the rest
+                    int64_t a = lb, b = s;
+                    while (a < b) { const int64_t mid = (a + b) >> 1; if (rkeys[mid] < key) a = mid + 1; else b = mid; }
+                    lb = a;
+                }
+                ub = lb; steps = 0;
+                while (ub < s && rkeys[ub] == key && steps < 16) { ub++; steps++; }
+                if (ub < s && rkeys[ub] == key) {                    // a long run of equal right keys
+                    int64_t a = ub, b = s;
+                    while (a < b) { const int64_t mid = (a + b) >> 1; if (rkeys[mid] <= key) a = mid + 1; else b = mid; }
+                    ub = a;
+                }
+                prev = key;
+            }
+            lb_out[i] = (uint32_t)lb;
+            cnt_out[i] = (uint32_t)(ub - lb);
+        }
     }
 }
 
@@ -106,7 +137,7 @@ int hark_entry_join(hark_context *ctx, hark_result **out, const hark_table *db1,
     if (!rc) rc = hark_alloc(ctx, (void **)&cnt, (size_t)n * 4);
     if (!rc) rc = hark_alloc(ctx, (void **)&offs, (size_t)n * 8);
     if (!rc) {
-        join_count_kernel<<<grid_for(ctx, n), 256, 0, st>>>(lkeys, n, rkeys, s, lb, cnt);
+        join_count_kernel<<<grid_for(ctx, (n + kJoinChunk - 1) / kJoinChunk), 256, 0, st>>>(lkeys, n, rkeys, s, lb, cnt);
         rc = k_exclusive_scan_u32(ctx, cnt, n, nullptr, offs, &P);
     }
     if (!rc && P > 0) {
