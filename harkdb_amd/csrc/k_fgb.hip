@@ -299,7 +299,7 @@ constexpr int kTileRows = 8192;                          // chunk granularity (m
 // keys are absorbed on chip.  Entries are added to the global table once, at the end of the kernel.
 constexpr int kHotBits = 9, kHot = 1 << kHotBits;
 constexpr uint32_t kHotEmpty = 0xFFFFFFFFu;
-constexpr int kHotProbeBatches = 4;                      // a workgroup keeps the cache on only if > 1/16 of its first rows hit it
+constexpr int kHotProbeBatches = 2;                      // a workgroup keeps the cache on only if > 1/16 of its first rows hit it
 constexpr int kRetryRounds = 8;                          // queue-full retries per batch before direct atomics
 static size_t part_lds_bytes(int P) { return sizeof(uint2) * (size_t)P * kQ + sizeof(int) * 3 * (size_t)P + (size_t)kHot * 16 + 16; }
 
@@ -446,9 +446,17 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
             }
             again = __syncthreads_or(pending != 0);
         } while (again);
-        if (batches_done == kHotProbeBatches && tid == 0 && h_stat[0] * 16u < h_stat[1]) h_stat[2] = 1u;   // keys are not skewed: stop probing the cache
-        // (read by every thread at the top of the next batch, behind that batch's barriers... the flag only ever goes 0 -> 1,
-        //  and a batch that still sees 0 merely does one more round of lookups)
+        if (batches_done == kHotProbeBatches && h_stat[0] * 16u < h_stat[1]) {   // workgroup-uniform: keys are not skewed
+            // stop probing, and hand the few rows the cache absorbed to the global table now, while
+            // the rest of the chip is still streaming, instead of at the tail of the kernel
+            __syncthreads();
+            for (int h = tid; h < kHot; h += kPartThreads) {
+                const uint32_t c = h_cnt[h];
+                if (c) { vop_atomic_partial_rt(vop, &gsum[h_key[h]], h_val[h]); atomicAdd(&gcnt[h_key[h]], (unsigned long long)c); h_cnt[h] = 0u; }
+            }
+            if (tid == 0) h_stat[2] = 1u;
+            __syncthreads();
+        }
     };
 
     // two batches of loads stay in flight per lane while a batch is enqueued and flushed
