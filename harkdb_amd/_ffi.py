@@ -87,6 +87,25 @@ SIGNATURES = {
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so.  If libhark.so pulls in the
+    system copy first, a later `import torch` in the same process fails to find a GPU
+    ("No HIP GPUs are available", reproduced with libhark loaded before torch).  Loading
+    torch's copy first (without importing torch) makes both sides use one runtime."""
+    if os.environ.get("HARK_SYSTEM_HIP"):
+        return
+    import importlib.util
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """dlopen libhark.so and bind every declared symbol.  Raises ImportError
     with build instructions when the library has not been built."""
@@ -97,6 +116,7 @@ def load():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `make -C harkdb_amd/csrc` "
             "(or python -c 'import __graft_entry__ as g; g.build()').  There is no CPU fallback.")
+    _share_hip_runtime_with_torch()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported

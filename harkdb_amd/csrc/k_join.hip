@@ -29,26 +29,27 @@ namespace {
 // the sorted right keys, then it walks both sides forward -- sequential reads instead of
 // one full binary search per left row.
 constexpr int kJoinChunk = 8;
-__global__ __launch_bounds__(256) void join_count_kernel(const uint32_t *__restrict__ lkeys, int64_t n,
-                                                         const uint32_t *__restrict__ rkeys, int64_t s,
+template <typename K>
+__global__ __launch_bounds__(256) void join_count_kernel(const K *__restrict__ lkeys, int64_t n,
+                                                         const K *__restrict__ rkeys, int64_t s,
                                                          uint32_t *__restrict__ lb_out, uint32_t *__restrict__ cnt_out)
 {
     const int64_t nchunks = (n + kJoinChunk - 1) / kJoinChunk;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < nchunks; c += stride) {
         const int64_t i0 = c * kJoinChunk, i1 = i0 + kJoinChunk < n ? i0 + kJoinChunk : n;
-        const uint32_t first = lkeys[i0];
+        const K first = lkeys[i0];
         int64_t lo = 0, hi = s;                       // lower bound of the chunk's first key
         while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (rkeys[mid] < first) lo = mid + 1; else hi = mid; }
         int64_t lb = lo, ub = lo;
-        uint32_t prev = first;
+        K prev = first;
         {   // upper bound of the first key
             int64_t a = lo, b = s;
             while (a < b) { const int64_t mid = (a + b) >> 1; if (rkeys[mid] <= first) a = mid + 1; else b = mid; }
             ub = a;
         }
         for (int64_t i = i0; i < i1; i++) {
-            const uint32_t key = lkeys[i];
+            const K key = lkeys[i];
             if (key != prev) {                        // left keys ascend: continue from the previous upper bound
                 lb = ub;
                 int steps = 0;
@@ -87,6 +88,14 @@ __global__ __launch_bounds__(256) void join_expand_kernel(const int64_t *__restr
     }
 }
 
+// i64 keys gathered into sorted order, biased so that unsigned comparison is signed order
+__global__ __launch_bounds__(256) void gather_biased_i64_kernel(const uint64_t *__restrict__ src, const uint32_t *__restrict__ perm,
+                                                                uint64_t *__restrict__ dst, int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[perm[i]] ^ 0x8000000000000000ull;
+}
+
 int grid_for(hark_context *ctx, int64_t n)
 {
     int64_t b = (n + 255) / 256;
@@ -117,8 +126,10 @@ int hark_entry_join(hark_context *ctx, hark_result **out, const hark_table *db1,
     // db1[:, col1] / db2[:, col2] (join.fut:55-56) are checked even for empty outputs when the side has rows
     if ((n > 0 && (col1 < 0 || col1 >= db1->m)) || (s > 0 && (col2 < 0 || col2 >= db2->m)))
         return hark_fail(ctx, HARK_EBOUNDS, "join: key column out of bounds");
-    if ((n > 0 && !is_u32ish(db1->cols[col1].dtype)) || (s > 0 && !is_u32ish(db2->cols[col2].dtype)))
-        return hark_fail(ctx, HARK_EUNSUPPORTED, "join: key columns must be 32-bit integers (join.fut:52 is u32)");
+    // join.fut:52 types both keys u32; i64 keys (BASELINE configs[3]) are an extension: signed key order
+    const bool k64 = n > 0 && s > 0 && db1->cols[col1].dtype == HARK_I64 && db2->cols[col2].dtype == HARK_I64;
+    if (!k64 && ((n > 0 && !is_u32ish(db1->cols[col1].dtype)) || (s > 0 && !is_u32ish(db2->cols[col2].dtype))))
+        return hark_fail(ctx, HARK_EUNSUPPORTED, "join: key columns must both be 32-bit integers (join.fut:52 is u32) or both i64");
     if (n + s > 0xFFFFFFFFll) return hark_fail(ctx, HARK_EARG, "join: at most 2^32-1 rows in total");
     hark_result *res = new hark_result();
     res->n = 0; res->cols.resize((size_t)(l + k));
@@ -131,23 +142,33 @@ int hark_entry_join(hark_context *ctx, hark_result **out, const hark_table *db1,
     int64_t P = 0;
     hipStream_t st = ctx->stream;
     // keys as u32 whatever the declared signedness (join.fut:52 types both tables u32)
-    int rc = k_argsort_column(ctx, db1->cols[col1].data, HARK_U32, n, false, &lperm, &lkeys);
-    if (!rc) rc = k_argsort_column(ctx, db2->cols[col2].data, HARK_U32, s, false, &rperm, &rkeys);
+    uint64_t *lk64 = nullptr, *rk64 = nullptr;
+    int rc = k_argsort_column(ctx, db1->cols[col1].data, k64 ? HARK_I64 : HARK_U32, n, false, &lperm, k64 ? nullptr : &lkeys);
+    if (!rc) rc = k_argsort_column(ctx, db2->cols[col2].data, k64 ? HARK_I64 : HARK_U32, s, false, &rperm, k64 ? nullptr : &rkeys);
+    if (!rc && k64) {
+        rc = hark_alloc(ctx, (void **)&lk64, (size_t)n * 8);
+        if (!rc) rc = hark_alloc(ctx, (void **)&rk64, (size_t)s * 8);
+        if (!rc) {
+            gather_biased_i64_kernel<<<grid_for(ctx, n), 256, 0, st>>>(static_cast<const uint64_t *>(db1->cols[col1].data), lperm, lk64, n);
+            gather_biased_i64_kernel<<<grid_for(ctx, s), 256, 0, st>>>(static_cast<const uint64_t *>(db2->cols[col2].data), rperm, rk64, s);
+        }
+    }
     if (!rc) rc = hark_alloc(ctx, (void **)&lb, (size_t)n * 4);
     if (!rc) rc = hark_alloc(ctx, (void **)&cnt, (size_t)n * 4);
     if (!rc) rc = hark_alloc(ctx, (void **)&offs, (size_t)n * 8);
     if (!rc) {
-        join_count_kernel<<<grid_for(ctx, (n + kJoinChunk - 1) / kJoinChunk), 256, 0, st>>>(lkeys, n, rkeys, s, lb, cnt);
+        if (k64) join_count_kernel<uint64_t><<<grid_for(ctx, (n + kJoinChunk - 1) / kJoinChunk), 256, 0, st>>>(lk64, n, rk64, s, lb, cnt);
+        else join_count_kernel<uint32_t><<<grid_for(ctx, (n + kJoinChunk - 1) / kJoinChunk), 256, 0, st>>>(lkeys, n, rkeys, s, lb, cnt);
         rc = k_exclusive_scan_u32(ctx, cnt, n, nullptr, offs, &P);
     }
     if (!rc && P > 0) {
         // select cols1 db1[r1,:] / select cols2 db2[r2,:] (join.fut:69-70) run only when there are pairs
         for (int64_t j = 0; j < l && !rc; j++)
             if (cols1[j] < 0 || cols1[j] >= db1->m) rc = hark_fail(ctx, HARK_EBOUNDS, "join: cols1[%lld] = %d out of bounds", (long long)j, cols1[j]);
-            else if (hark_dtype_size(db1->cols[cols1[j]].dtype) != 4) rc = hark_fail(ctx, HARK_EUNSUPPORTED, "join: 32-bit columns only");
+
         for (int64_t j = 0; j < k && !rc; j++)
             if (cols2[j] < 0 || cols2[j] >= db2->m) rc = hark_fail(ctx, HARK_EBOUNDS, "join: cols2[%lld] = %d out of bounds", (long long)j, cols2[j]);
-            else if (hark_dtype_size(db2->cols[cols2[j]].dtype) != 4) rc = hark_fail(ctx, HARK_EUNSUPPORTED, "join: 32-bit columns only");
+
         if (!rc) rc = hark_alloc(ctx, (void **)&lrow, (size_t)P * 4);
         if (!rc) rc = hark_alloc(ctx, (void **)&rrow, (size_t)P * 4);
         if (!rc) {
@@ -159,11 +180,13 @@ int hark_entry_join(hark_context *ctx, hark_result **out, const hark_table *db1,
             const hark_table *t = j < l ? db1 : db2;
             const int c = j < l ? cols1[j] : cols2[j - l];
             res->cols[j].dtype = t->cols[c].dtype; res->cols[j].owned = true;
-            rc = hark_alloc(ctx, &res->cols[j].data, (size_t)P * 4);
-            if (!rc) rc = k_gather(ctx, t->cols[c].data, 4, j < l ? lrow : rrow, res->cols[j].data, P);
+            const int esz = (int)hark_dtype_size(t->cols[c].dtype);
+            rc = hark_alloc(ctx, &res->cols[j].data, (size_t)P * esz);
+            if (!rc) rc = k_gather(ctx, t->cols[c].data, esz, j < l ? lrow : rrow, res->cols[j].data, P);
         }
         if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: kernels failed");
     }
+    hark_free(ctx, lk64); hark_free(ctx, rk64);
     hark_free(ctx, lperm); hark_free(ctx, lkeys); hark_free(ctx, rperm); hark_free(ctx, rkeys); hark_free(ctx, lb); hark_free(ctx, cnt); hark_free(ctx, offs); hark_free(ctx, lrow); hark_free(ctx, rrow);
     if (rc) { result_release(ctx, res); return rc; }
     *out = res;

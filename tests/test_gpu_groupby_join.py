@@ -101,6 +101,30 @@ def test_join_matches_oracle(eng, oracle, n, s, nkeys):
     assert got.shape == exp.shape and np.array_equal(got, exp)
 
 
+def test_join_i64_keys_extension(eng):
+    """BASELINE configs[3] joins on an i64 key: same sort-merge, signed key order, any column width."""
+    rng = np.random.default_rng(21)
+    n, s = 20_000, 3_000
+    pool = rng.integers(-2**62, 2**62, size=500)
+    lk, rk = pool[rng.integers(0, 500, n)], pool[rng.integers(0, 500, s)]
+    la, ra = rng.integers(0, 1000, n).astype(np.int32), rng.random(s).astype(np.float32)
+    t1 = eng.table_from_columns([lk.astype(np.int64), la])
+    t2 = eng.table_from_columns([ra, rk.astype(np.int64)])
+    res = eng.join(t1, t2, 0, 1, [0, 1], [0, 1])
+    got = [res.column(j) for j in range(4)]
+    exp = []
+    for key in np.unique(np.concatenate([lk, rk])):                # ascending signed keys, then left row, then right row
+        li, ri = np.flatnonzero(lk == key), np.flatnonzero(rk == key)
+        for i in li:
+            for j in ri:
+                exp.append((key, la[i], ra[j], rk[j]))
+    assert len(exp) == res.shape[0]
+    assert np.array_equal(got[0], np.asarray([e[0] for e in exp], dtype=np.int64)) and got[0].dtype == np.int64
+    assert np.array_equal(got[1], np.asarray([e[1] for e in exp], dtype=np.int32))
+    assert np.array_equal(got[2], np.asarray([e[2] for e in exp], dtype=np.float32))
+    assert np.array_equal(got[3], got[0])
+
+
 def test_join_empty_sides(eng):
     t1 = eng.table_from_matrix(np.zeros((0, 2)), np.uint32)
     t2 = eng.table_from_matrix(np.arange(6).reshape(3, 2), np.uint32)
