@@ -1,4 +1,4 @@
-// k_fgb.hip -- fused WHERE -> GROUP BY (SUM f32, COUNT) over a dense key domain.
+// k_fgb.hip -- fused WHERE -> GROUP BY over a dense key domain (headline: SUM f32 + COUNT).
 //
 // Replaces, for the headline query of BASELINE.json
 //     SELECT k, SUM(v), COUNT(*) FROM t WHERE p <cmp> thr GROUP BY k
@@ -23,16 +23,21 @@
 //   PART  (large G, e.g. 2^20): scattered global atomics retire ~21-27 G/s
 //         on gfx950 (tools/ubench.hip: they execute at the memory side, one
 //         64-byte request per lane), 20x too slow.  So rows are routed by key
-//         range first.  PRODUCER: a workgroup stages the surviving (key,value)
-//         pairs of an 8192-row tile in LDS, bucket-sorts them there
-//         (ds_add_rtn rank + scan) and appends each bucket's run to its OWN
-//         slab of that bucket -- cursors are workgroup-private, so there are no
-//         global atomics and consecutive tiles extend the same lines in L2.
+//         range first.  PRODUCER: every bucket (key >> shift) owns a small
+//         queue in LDS; a surviving row takes a slot with one ds_add_rtn_u32,
+//         and only complete 128-byte lines leave the CU, appended to the
+//         workgroup's OWN slab of that bucket (no global atomics, no partial
+//         lines).  Heavy hitters are folded in a small LDS cache instead.
 //         CONSUMER: one workgroup per bucket folds the bucket's slabs into an
 //         LDS-resident slice of the table and adds the slice to the global
 //         table with plain stores (it owns the key range).
 //   ATOM  one global atomic pair per surviving row; the fallback for slab
-//         overflow (heavily skewed keys) and a measured baseline.
+//         overflow / G > 2^21 and a measured baseline.
+//
+// The same kernels serve other aggregates through a run-time "value operator"
+// (u32 sum / max / min / product, u64 sum) and an order-preserving value
+// transform (signed and float min/max); see vop_* below and try_dense() in
+// k_groupby.hip.
 #include "hark_internal.h"
 #include <type_traits>
 
