@@ -143,6 +143,12 @@ __device__ __forceinline__ void vop_atomic_rt(int vop, u64 *slot, uint32_t x)
     }
 }
 
+__device__ __forceinline__ uint32_t mix32(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
+
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x)
 {
     x += 0x9E3779B97F4A7C15ull;
@@ -306,6 +312,8 @@ constexpr int kHotBits = 9, kHot = 1 << kHotBits;
 constexpr uint32_t kHotEmpty = 0xFFFFFFFFu;
 constexpr int kHotProbeBatches = 2;                      // a workgroup keeps the cache on only if > 1/16 of its first rows hit it
 constexpr int kRetryRounds = 8;                          // queue-full retries per batch before direct atomics
+constexpr int kRetryRoundsHash = 160;                    // hash mode has no atomics fallback: drain a hot bucket (4096 rows / 32 per round)
+constexpr int kErrOverflow = 100;                        // device error word: a slab or a hash table overflowed (host picks another path)
 static size_t part_lds_bytes(int P) { return sizeof(uint2) * (size_t)P * kQ + sizeof(int) * 3 * (size_t)P + (size_t)kHot * 16 + 16; }
 
 template <int OP>
@@ -313,7 +321,8 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
     const float *__restrict__ p, const int32_t *__restrict__ k, const float *__restrict__ v,
     int64_t row0, int64_t row1, float thr, int64_t G, int shift, int P,
     uint2 *__restrict__ pbuf, uint32_t *__restrict__ counts, uint32_t cap,
-    u64 *__restrict__ gsum, unsigned long long *__restrict__ gcnt, int32_t *__restrict__ err, int ablate, int vop, int xf)
+    u64 *__restrict__ gsum, unsigned long long *__restrict__ gcnt, int32_t *__restrict__ err, int ablate, int vop, int xf,
+    int hash_bits /* 0: bucket = key >> shift over a dense domain; else bucket = top bits of mix32(key), any u32 keys */)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     uint2 *queue = reinterpret_cast<uint2 *>(lds_raw);                 // [P][kQ]
@@ -328,7 +337,7 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
     const int nwg = gridDim.x, wg = blockIdx.x;
     const int64_t nbatch = (row1 - row0 + kBatchRows - 1) / kBatchRows;
     const int cap_lines = (int)(cap / kLine) - 1;                      // the last line is kept for the final partial flush
-    bool bad = false;
+    bool bad = false, overflow = false;
     for (int b = tid; b < P; b += kPartThreads) { s_cnt[b] = 0; s_head[b] = 0; s_lcur[b] = 0; }
     for (int h = tid; h < kHot; h += kPartThreads) { h_val[h] = vop_identity(vop); h_key[h] = kHotEmpty; h_cnt[h] = 0u; }
     if (tid < 4) h_stat[tid] = 0u;
@@ -368,12 +377,12 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
 #pragma unroll
         for (int j = 0; j < kVec; j++) {
             bool keep = r + j < row1 && cmp_f32<OP>(pv[j], thr);
-            if (keep && !(kv[j] >= 0 && (int64_t)(uint32_t)kv[j] < G)) { bad = true; keep = false; }
+            if (keep && !hash_bits && !(kv[j] >= 0 && (int64_t)(uint32_t)kv[j] < G)) { bad = true; keep = false; }
             if (keep) pending |= 1u << j;
         }
         if (ablate & 4) { asm volatile("" :: "v"(pending), "v"(vv[0]), "v"(vv[1]), "v"(vv[2]), "v"(vv[3])); pending = 0; }
         // ---- heavy hitters: rows whose key owns its cache slot are folded in LDS right here
-        const bool hot_on = !(ablate & 128) && h_stat[2] == 0u;                  // workgroup-uniform
+        const bool hot_on = !(ablate & 128) && !hash_bits && h_stat[2] == 0u;    // workgroup-uniform (the cache feeds the dense table)
         const bool probing = hot_on && batches_done < kHotProbeBatches;
         uint32_t seen = __popc(pending), hits = 0;
         if (hot_on)
@@ -404,7 +413,7 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
 #pragma unroll
             for (int j = 0; j < kVec; j++) {
                 if (pending & (1u << j)) {
-                    const uint32_t key = (uint32_t)kv[j], b = key >> shift;
+                    const uint32_t key = (uint32_t)kv[j], b = hash_bits ? mix32(key) >> (32 - hash_bits) : key >> shift;
                     const int pos = atomicAdd(&s_cnt[b], 1);
                     if (pos < kQ) {
                         queue[b * kQ + ((s_head[b] + pos) & (kQ - 1))] = uint2{key, apply_xf(xf, __float_as_uint(vv[j]))};
@@ -429,6 +438,8 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
                                 typedef unsigned int u4v __attribute__((ext_vector_type(4)));
                                 if (!(ablate & 32)) __builtin_nontemporal_store(u4v{two.x, two.y, two.z, two.w}, reinterpret_cast<u4v *>(dst)); else *dst = two;
                             }
+                        } else if (hash_bits) {                            // slab full, no dense table to fall back to
+                            overflow = true;
                         } else {                                           // slab full: direct atomics
                             vop_atomic_rt(vop, &gsum[two.x], two.y); atomicAdd(&gcnt[two.x], 1ull);
                             vop_atomic_rt(vop, &gsum[two.z], two.w); atomicAdd(&gcnt[two.z], 1ull);
@@ -441,7 +452,8 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
                     }
                 }
             }
-            if (++rounds >= kRetryRounds || (ablate & 2)) {                         // bounded: leftovers go through direct atomics
+            if (++rounds >= (hash_bits ? kRetryRoundsHash : kRetryRounds) || (ablate & 2)) {   // bounded: leftovers go through direct atomics
+                if (hash_bits && pending) { overflow = true; pending = 0; }
 #pragma unroll
                 for (int j = 0; j < kVec; j++)
                     if ((pending & (1u << j)) && !(ablate & 2)) {
@@ -488,6 +500,7 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
         if (c) { vop_atomic_partial_rt(vop, &gsum[h_key[h]], h_val[h]); atomicAdd(&gcnt[h_key[h]], (unsigned long long)c); }
     }
     if (bad) *err = HARK_EBOUNDS;
+    if (overflow) *err = kErrOverflow;
 }
 
 // ---------------------------------------------------------------------------
@@ -540,6 +553,83 @@ __global__ __launch_bounds__(1024) void fgb_agg_kernel(
             gsum[kbase + i] = vop_merge(VOP, gsum[kbase + i], s_sum[i]);
             gcnt[kbase + i] += (unsigned long long)c;
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Hash flavour of the consumer: arbitrary u32 keys ("LDS-staged hash buckets")
+// ---------------------------------------------------------------------------
+// The producer routed pairs by the top bits of mix32(key).  One workgroup per bucket builds an
+// open-addressing table in LDS: 64-bit tag (key | 2^32, 0 = empty) claimed with ds_cmpst_b64,
+// value slot and count updated with the same LDS atomics as the dense path.  A bucket with more
+// distinct keys than the table holds is processed in R rounds, round r taking the keys with
+// mix32(key ^ salt) % R == r (the slabs are re-read, the table is emitted after every round).
+constexpr int kHashCap = 8192;                           // entries of 16 B (tag+count word, value slot) = 128 KiB of LDS
+constexpr int kHashFill = 3072;                          // distinct keys per round and bucket (load <= 0.375: probe chains stay short;
+                                                         // a wave waits for its longest chain, so the load factor is what matters)
+constexpr u64 kTagMask = 0x1FFFFFFFFull;                 // low 33 bits: key | 2^32 (0 = empty); the upper 31 bits count the rows
+
+template <int VOP>
+__global__ __launch_bounds__(1024) void fgb_agg_hash_kernel(
+    const uint2 *__restrict__ pbuf, const uint32_t *__restrict__ counts, uint32_t cap, int nwg, uint32_t Rmask, uint32_t r,
+    uint32_t *__restrict__ out_key, u64 *__restrict__ out_val, u64 *__restrict__ out_cnt, unsigned long long *__restrict__ out_cursor,
+    unsigned long long out_cap, int32_t *__restrict__ err)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    u64 *t_tag = reinterpret_cast<u64 *>(lds_raw);
+    u64 *t_val = t_tag + kHashCap;
+    __shared__ uint32_t s_used, s_emit;
+    __shared__ unsigned long long s_base;
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < kHashCap; i += blockDim.x) { t_tag[i] = 0ull; t_val[i] = vop_identity(VOP); }
+    if (threadIdx.x == 0) { s_used = 0u; s_emit = 0u; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    bool overflow = false;
+    auto add = [&](uint32_t key, uint32_t vbits) {
+        if ((mix32(key ^ 0x9E3779B9u) & Rmask) != r) return;                 // not this round's share of the key space
+        const u64 tag = (u64)key | (1ull << 32);
+        uint32_t h = (mix32(key) * 0x9E3779B1u) >> 19;                       // 13 bits, independent of the bucket bits
+        for (int step = 0; step < kHashCap; step++, h = (h + 1) & (kHashCap - 1)) {
+            u64 cur = t_tag[h] & kTagMask;
+            if (cur == 0ull) {
+                if (s_used >= (uint32_t)kHashFill) { overflow = true; return; }
+                cur = atomicCAS(&t_tag[h], 0ull, tag) & kTagMask;           // ds_cmpst_rtn_b64
+                if (cur == 0ull) { atomicAdd(&s_used, 1u); cur = tag; }
+            }
+            if (cur == tag) { vop_atomic<VOP>(&t_val[h], vbits); atomicAdd(&t_tag[h], 1ull << 33); return; }   // count rides in the tag word
+        }
+        overflow = true;
+    };
+    for (int w = wave; w < nwg; w += nwaves) {
+        if (__any(overflow)) break;                                          // this round is void anyway: stop reading
+        const uint32_t count = min(counts[(size_t)b * nwg + w], cap);
+        const uint2 *src = pbuf + ((size_t)b * nwg + w) * cap;
+        const uint4 *src4 = reinterpret_cast<const uint4 *>(src);
+        const uint32_t n2 = count / 2;
+        uint32_t i = lane;
+        for (; i + 64 < n2; i += 128) {
+            const uint4 q0 = src4[i], q1 = src4[i + 64];
+            add(q0.x, q0.y); add(q0.z, q0.w); add(q1.x, q1.y); add(q1.z, q1.w);
+        }
+        for (; i < n2; i += 64) { const uint4 q = src4[i]; add(q.x, q.y); add(q.z, q.w); }
+        if ((count & 1u) && lane == 0) { const uint2 q = src[count - 1]; add(q.x, q.y); }
+    }
+    if (overflow) *err = kErrOverflow;
+    __syncthreads();
+    // emit the occupied entries: reserve a range of the output with one global atomic per workgroup
+    uint32_t mine = 0;
+    for (int i = threadIdx.x; i < kHashCap; i += blockDim.x) mine += (t_tag[i] >> 33) ? 1u : 0u;
+    uint32_t pos = mine ? atomicAdd(&s_emit, mine) : 0u;
+    __syncthreads();
+    if (threadIdx.x == 0) s_base = s_emit ? atomicAdd(out_cursor, (unsigned long long)s_emit) : 0ull;
+    __syncthreads();
+    for (int i = threadIdx.x; i < kHashCap; i += blockDim.x) {
+        const u64 tc = t_tag[i];
+        if (!(tc >> 33)) continue;
+        const unsigned long long o = s_base + pos++;
+        if (o < out_cap) { out_key[o] = (uint32_t)tc; out_val[o] = t_val[i]; out_cnt[o] = tc >> 33; }
+        else *err = kErrOverflow;
     }
 }
 
@@ -850,7 +940,7 @@ int k_fgb_dense_f32(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cm
             {
                 TimedLaunch tl(pl, st, 1);
                 fgb_part_kernel<OP><<<dim3((unsigned)nwg), dim3(kPartThreads), lds_part, st>>>(
-                    p, k, v, r0, r1, thr, G, shift, P, pl->pbuf, pl->counts, (uint32_t)pl->cap, gsum, gcnt, pl->err, (int)pl->ablate, vop, (int)pl->xform);
+                    p, k, v, r0, r1, thr, G, shift, P, pl->pbuf, pl->counts, (uint32_t)pl->cap, gsum, gcnt, pl->err, (int)pl->ablate, vop, (int)pl->xform, 0);
             }
             HIP_TRY(ctx, hipGetLastError());
             {
@@ -949,4 +1039,99 @@ int hark_fgb_finish_typed(hark_context *ctx, hark_fgb_plan *pl, int32_t kind, co
     fgb_decode_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(reinterpret_cast<const u64 *>(pl->acc_sum), pl->acc_cnt, pl->G, kind, pos, out);
     HIP_TRY(ctx, hipGetLastError());
     return fgb_check_err(ctx, pl);
+}
+
+// GROUP BY over arbitrary u32 keys with one value operator: hash-partition (producer in hash
+// mode) + LDS hash tables (fgb_agg_hash_kernel).  Returns UNORDERED (key, value slot, count)
+// arrays on the device (caller frees with hark_free) and the number of groups.  *fits is false
+// when the data overflowed the geometry (heavy skew, or more distinct keys than 64 rounds hold):
+// the caller then uses the sort-based path.
+int k_fgb_hash_u32(hark_context *ctx, const uint32_t *k, const uint32_t *v, int64_t n, int vop, int xf,
+                   uint32_t **keys_out, unsigned long long **vals_out, unsigned long long **cnts_out, int64_t *G_out, bool *fits,
+                   uint32_t *rounds_hint /* in: 0 or the R a previous pass over the SAME key column needed; out: the R used */)
+{
+    *keys_out = nullptr; *vals_out = nullptr; *cnts_out = nullptr; *G_out = 0; *fits = false;
+    if (n <= 0 || n > 0xFFFFFFFFll) return HARK_OK;
+    const int hash_bits = 8, P = 1 << hash_bits, nwg = ctx->num_cu * 2;
+    int64_t cap = n / ((int64_t)P * nwg) * 130 / 100 + 256;
+    cap = (cap + kLine - 1) / kLine * kLine + 2 * kLine;
+    uint2 *pbuf = nullptr; uint32_t *counts = nullptr; int32_t *err = nullptr; unsigned long long *cursor = nullptr;
+    uint32_t *okey = nullptr; u64 *oval = nullptr, *ocnt = nullptr;
+    hipStream_t st = ctx->stream;
+    int rc = hark_alloc(ctx, (void **)&pbuf, (size_t)P * nwg * (size_t)cap * sizeof(uint2));
+    if (!rc) rc = hark_alloc(ctx, (void **)&counts, (size_t)P * nwg * sizeof(uint32_t));
+    if (!rc) rc = hark_alloc(ctx, (void **)&err, 16);
+    if (!rc) rc = hark_alloc(ctx, (void **)&cursor, 16);
+    auto read_err = [&](int32_t *e) -> int {
+        int64_t w = 0;
+        int r2 = hark_read_words(ctx, err, &w, 1);
+        *e = (int32_t)w;
+        return r2;
+    };
+    int32_t e = 0;
+    uint32_t used_R = 1;
+    if (!rc) {
+        hipMemsetAsync(err, 0, 16, st);
+        const size_t lds_part = part_lds_bytes(P);
+        rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_part_kernel<kNoPred>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part) == hipSuccess
+                 ? HARK_OK : hark_fail(ctx, HARK_EHIP, "hash group-by: LDS attribute failed");
+        if (!rc) {
+            fgb_part_kernel<kNoPred><<<dim3((unsigned)nwg), dim3(kPartThreads), lds_part, st>>>(
+                nullptr, reinterpret_cast<const int32_t *>(k), reinterpret_cast<const float *>(v), 0, n, 0.0f, (int64_t)1 << 32, 0, P,
+                pbuf, counts, (uint32_t)cap, nullptr, nullptr, err, 0, vop, xf, hash_bits);
+            rc = read_err(&e);
+        }
+    }
+    if (!rc && e == 0) {
+        const size_t lds_hash = (size_t)kHashCap * 16;
+        // run all rounds of an R-round aggregation; e != 0 afterwards means some table overflowed
+        auto run_rounds = [&](uint32_t R, uint32_t r_begin, uint32_t r_end) -> int {
+            const unsigned long long out_cap = (unsigned long long)P * kHashFill * (r_end - r_begin);
+            hark_free(ctx, okey); hark_free(ctx, oval); hark_free(ctx, ocnt); okey = nullptr; oval = nullptr; ocnt = nullptr;
+            int r2 = hark_alloc(ctx, (void **)&okey, (size_t)out_cap * 4);
+            if (!r2) r2 = hark_alloc(ctx, (void **)&oval, (size_t)out_cap * 8);
+            if (!r2) r2 = hark_alloc(ctx, (void **)&ocnt, (size_t)out_cap * 8);
+            if (r2) return r2;
+            hipMemsetAsync(cursor, 0, 16, st); hipMemsetAsync(err, 0, 16, st);
+            r2 = dispatch_vop(vop, [&](auto vopc) -> int {
+                constexpr int VOP = decltype(vopc)::value;
+                HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_agg_hash_kernel<VOP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hash));
+                for (uint32_t r = r_begin; r < r_end; r++)
+                    fgb_agg_hash_kernel<VOP><<<dim3((unsigned)P), dim3(1024), lds_hash, st>>>(pbuf, counts, (uint32_t)cap, nwg, R - 1, r, okey, oval, ocnt, cursor, out_cap, err);   // R is a power of two
+                HIP_TRY(ctx, hipGetLastError());
+                return HARK_OK;
+            });
+            if (!r2) r2 = read_err(&e);
+            return r2;
+        };
+        const uint32_t hint = rounds_hint ? *rounds_hint : 0u;
+        used_R = hint ? hint : 1u;
+        rc = run_rounds(used_R, 0, used_R);
+        if (!rc && e != 0 && !hint) {
+            // too many distinct keys for one round: estimate them from ONE round of a 64-round split (a 1/64 sample
+            // of the key space), then run exactly the number of rounds that needs -- or give up right away
+            rc = run_rounds(64, 0, 1);
+            int64_t sample = 0;
+            if (!rc && e == 0) rc = hark_read_words(ctx, cursor, &sample, 1);
+            if (!rc && e == 0) {
+                const double per_bucket = 64.0 * (double)sample / P * 1.3;
+                uint32_t R = 2;
+                while (R < 64 && per_bucket > (double)kHashFill * R) R *= 2;
+                if (per_bucket > (double)kHashFill * 64) e = kErrOverflow;            // would not fit 64 rounds: sort-based path
+                else {
+                    rc = run_rounds(R, 0, R); used_R = R;
+                    if (!rc && e != 0 && R < 64) { rc = run_rounds(R * 2, 0, R * 2); used_R = R * 2; }   // one retry for uneven buckets
+                }
+            }
+        }
+    }
+    if (!rc && e == 0) {
+        int64_t G = 0;
+        rc = hark_read_words(ctx, cursor, &G, 1);
+        if (!rc) { *keys_out = okey; *vals_out = oval; *cnts_out = ocnt; *G_out = G; *fits = true; okey = nullptr; oval = nullptr; ocnt = nullptr; }
+        if (!rc && rounds_hint) *rounds_hint = used_R;
+    }
+    hark_free(ctx, pbuf); hark_free(ctx, counts); hark_free(ctx, err); hark_free(ctx, cursor);
+    hark_free(ctx, okey); hark_free(ctx, oval); hark_free(ctx, ocnt);
+    return rc;
 }

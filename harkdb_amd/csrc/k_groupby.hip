@@ -252,6 +252,9 @@ int kind_of(int dtype) { return dtype == HARK_F32 ? ACC_F64 : dtype == HARK_U32 
 int ref_groupby_dense(hark_context *ctx, const hark_table *view, const hark_table *stats_owner, int g_col,
                       const std::vector<AggSpec> &aggs, hark_result *res, int64_t *G_out, bool *used);
 
+int ref_groupby_hash(hark_context *ctx, const hark_table *view, int g_col, const std::vector<AggSpec> &aggs,
+                     hark_result *res, int64_t *G_out, bool *used);
+
 } // namespace
 
 extern "C" {
@@ -288,7 +291,8 @@ int hark_entry_query_groupby(hark_context *ctx, hark_result **out, const hark_ta
     int64_t G = 0;
     bool dense = false;
     int rc = ref_groupby_dense(ctx, &view, db, g_col, aggs, res, &G, &dense);   // keys < 2^21: fused kernels, no sort
-    if (!rc && !dense) rc = grouped_aggregate(ctx, &view, g_col, HARK_U32, aggs, res, &G);
+    if (!rc && !dense) rc = ref_groupby_hash(ctx, &view, g_col, aggs, res, &G, &dense);   // sparse keys: LDS hash buckets
+    if (!rc && !dense) rc = grouped_aggregate(ctx, &view, g_col, HARK_U32, aggs, res, &G);  // last resort: sort-based
     if (!rc && nt < ns && G < db->n)                    // some group has two rows: merge indexes t_cols[i-1] out of bounds
         rc = hark_fail(ctx, HARK_EBOUNDS, "query_groupby: %lld aggregate opcodes for %lld select columns", (long long)nt, (long long)ns);
     if (rc) { result_release(ctx, res); return rc; }
@@ -620,6 +624,69 @@ int ref_groupby_dense(hark_context *ctx, const hark_table *view, const hark_tabl
     hark_fgb_plan_free(ctx, plan);
     if (rc) { for (auto &c : res->cols) { if (c.owned && c.data) hark_free(ctx, c.data); } res->cols.clear(); return rc; }
     *G_out = ngroups;
+    *used = true;
+    return HARK_OK;
+}
+
+} // namespace
+
+
+// ---------------------------------------------------------------------------
+// Reference entry over sparse keys: hash partition + LDS hash tables, one pass per aggregate
+// ---------------------------------------------------------------------------
+namespace {
+
+constexpr int64_t kHashMinRows = (int64_t)1 << 18;          // below this the sort-based path is as good
+
+__global__ __launch_bounds__(256) void gather_low32_kernel(const unsigned long long *__restrict__ vals, const uint32_t *__restrict__ perm,
+                                                           uint32_t *__restrict__ out, int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = (uint32_t)vals[perm[i]];
+}
+
+int ref_groupby_hash(hark_context *ctx, const hark_table *view, int g_col, const std::vector<AggSpec> &aggs,
+                     hark_result *res, int64_t *G_out, bool *used)
+{
+    *used = false;
+    const int64_t n = view->n;
+    if (n < kHashMinRows) return HARK_OK;
+    const uint32_t *keys = static_cast<const uint32_t *>(view->cols[g_col].data);
+    const size_t runs = aggs.empty() ? 1 : aggs.size();
+    int64_t G = -1;
+    int rc = HARK_OK;
+    bool ok = true;
+    uint32_t rounds = 0;                                     // table rounds the key column needs: found by the first pass, reused
+    for (size_t j = 0; j < runs && !rc && ok; j++) {
+        const int vop = aggs.empty() ? 3 : aggs[j].op == OP_SUM ? 1 : aggs[j].op == OP_MAX ? 2 : aggs[j].op == OP_MIN ? 3 : 4;
+        const uint32_t *col = aggs.empty() ? keys : static_cast<const uint32_t *>(view->cols[aggs[j].col].data);
+        uint32_t *hk = nullptr, *perm = nullptr; unsigned long long *hv = nullptr, *hc = nullptr;
+        int64_t Gj = 0;
+        rc = k_fgb_hash_u32(ctx, keys, col, n, vop, 0, &hk, &hv, &hc, &Gj, &ok, &rounds);
+        if (!rc && ok) {
+            if (G < 0) {
+                G = Gj;
+                res->n = G;
+                res->cols.resize(aggs.size() + 1);
+                for (auto &c : res->cols) { c.dtype = HARK_U32; c.data = nullptr; c.owned = true; }
+                for (size_t q = 0; q <= aggs.size() && !rc; q++) rc = hark_alloc(ctx, &res->cols[q].data, (size_t)G * 4);
+            } else if (Gj != G) rc = hark_fail(ctx, HARK_EHIP, "query_groupby: inconsistent group counts between passes");
+            // the passes emit in table order of the hash buckets: bring every pass into ascending key order
+            if (!rc) rc = k_argsort_column(ctx, hk, HARK_U32, G, false, &perm, nullptr);
+            if (!rc && G > 0) {
+                if (j == 0) rc = k_gather(ctx, hk, 4, perm, res->cols[0].data, G);
+                if (!rc && !aggs.empty()) gather_low32_kernel<<<grid_for(ctx, G), 256, 0, ctx->stream>>>(hv, perm, static_cast<uint32_t *>(res->cols[j + 1].data), G);
+            }
+        }
+        hark_free(ctx, hk); hark_free(ctx, hv); hark_free(ctx, hc); hark_free(ctx, perm);
+    }
+    if (!rc && ok && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "query_groupby: kernels failed");
+    if (rc || !ok) {
+        for (auto &c : res->cols) if (c.owned && c.data) hark_free(ctx, c.data);
+        res->cols.clear(); res->n = 0;
+        return rc;
+    }
+    *G_out = G;
     *used = true;
     return HARK_OK;
 }

@@ -53,6 +53,23 @@ def test_query_groupby_dense_keys_fused_path(eng, oracle, n, G):
     assert np.array_equal(eng.query_groupby(t, 0, [], []).to_numpy(np.uint32), exp[:, :1])   # key column only
 
 
+@pytest.mark.parametrize("n,ndistinct", [(400_000, 1000), (2_000_000, 500_000), (3_000_000, 3_000_000), (600_000, 3)])
+def test_query_groupby_sparse_keys_hash_path(eng, oracle, n, ndistinct):
+    """Sparse u32 keys (anywhere in [0, 2^32)) with >= 2^18 rows: hash partition + LDS hash
+    tables (several rounds when a bucket holds more distinct keys than its table); heavy skew
+    overflows the slabs and falls back to the sort-based path.  Same result either way."""
+    rng = np.random.default_rng(n + ndistinct)
+    pool = rng.integers(0, 2**32, size=ndistinct, dtype=np.uint64).astype(np.uint32)
+    db = rng.integers(0, 2**32, size=(n, 4), dtype=np.uint64).astype(np.uint32)
+    db[:, 1] = pool[rng.integers(0, ndistinct, size=n)] if ndistinct < n else rng.permutation(pool)
+    db[:, 3] = rng.integers(0, 3, size=n) * 2 + 1
+    s_cols, t_cols = [0, 2, 3, 0], [2, 3, 1, 4]
+    t = eng.table_from_matrix(db, np.uint32)
+    got = eng.query_groupby(t, 1, s_cols, t_cols).to_numpy(np.uint32)
+    exp = oracle.query_groupby(db, 1, s_cols, t_cols)
+    assert got.shape == exp.shape and np.array_equal(got, exp)
+
+
 def test_query_groupby_int32_table_is_viewed_as_u32(eng, oracle):
     """The Python layer uploads int32 columns; groupby.fut:51 reads them as u32."""
     rng = np.random.default_rng(3)

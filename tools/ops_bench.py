@@ -39,7 +39,10 @@ timeit("query_groupby(dense key, 2^20 groups; sum, max) [fused kernels]", lambda
 ks = eng.alloc(N * 4)
 eng.gen_columns(SEED + 11, 0, N, 1 << 31, True, None, ks, None)
 tsparse = eng.table_from_device(N, [ks, a], [np.uint32, np.uint32])
-timeit("query_groupby(sparse key up to 2^31; sum, max) [sort-based]", lambda: eng.query_groupby(tsparse, 0, [1, 1], [2, 3]), 12 * N)
+timeit("query_groupby(~1e8 distinct sparse keys; sum, max) [falls back to sort]", lambda: eng.query_groupby(tsparse, 0, [1, 1], [2, 3]), 12 * N)
+hk = (np.random.default_rng(1).integers(0, 1 << 21, size=N, dtype=np.int64) * 2654435761 % (1 << 32)).astype(np.uint32)
+eng.upload(ks, hk)
+timeit("query_groupby(2^21 distinct keys spread over [0,2^32); sum, max) [LDS hash buckets]", lambda: eng.query_groupby(tsparse, 0, [1, 1], [2, 3]), 12 * N)
 timeit("sort by u32 key, 2 columns", lambda: eng.sort(tu, 0, [0, 1]), 16 * N)
 M = N // 10
 kb = eng.alloc(M * 4); vb = eng.alloc(M * 4)
