@@ -116,6 +116,8 @@ int k_fgb_hash_u32(hark_context *ctx, const uint32_t *k, const uint32_t *v, int6
                    uint32_t **keys_out, unsigned long long **vals_out, unsigned long long **cnts_out, int64_t *G_out, bool *fits,
                    uint32_t *rounds_hint);
 
+int k_fgb_decode(hark_context *ctx, const unsigned long long *acc, const unsigned long long *cnt, int64_t G, int kind, void *out);
+
 // k_select.hip
 int k_groupby_typed(hark_context *ctx, const hark_table *db, int32_t g_col, const int32_t *agg_cols,
                     const int32_t *agg_ops, int64_t n_aggs, hark_result *res);

@@ -1135,3 +1135,14 @@ int k_fgb_hash_u32(hark_context *ctx, const uint32_t *k, const uint32_t *v, int6
     hark_free(ctx, okey); hark_free(ctx, oval); hark_free(ctx, ocnt);
     return rc;
 }
+
+// Typed read-out (fgb_decode_kernel kinds) of plain accumulator arrays, e.g. the sorted output of k_fgb_hash_u32.
+int k_fgb_decode(hark_context *ctx, const unsigned long long *acc, const unsigned long long *cnt, int64_t G, int kind, void *out)
+{
+    if (G <= 0) return HARK_OK;
+    int64_t blocks = (G + 255) / 256;
+    if (blocks > (int64_t)ctx->num_cu * 4) blocks = (int64_t)ctx->num_cu * 4;
+    fgb_decode_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(acc, cnt, G, kind, nullptr, out);
+    HIP_TRY(ctx, hipGetLastError());
+    return HARK_OK;
+}

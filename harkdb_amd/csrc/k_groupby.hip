@@ -504,6 +504,93 @@ int try_dense(hark_context *ctx, const hark_table *db, int32_t where_col, int32_
     return rc;
 }
 
+// Sparse 32-bit integer keys: the LDS hash-bucket pipeline of k_fgb.hip, one pass per distinct
+// (operator, column), results brought into ascending key order (signed for I32).  A WHERE is
+// applied by compacting the referenced columns first.
+int try_hash(hark_context *ctx, const hark_table *db, int32_t where_col, int32_t cmp, const void *constant,
+             int32_t g_col, const int32_t *agg_cols, const int32_t *agg_ops, int64_t n_aggs, hark_result *res, bool *used)
+{
+    *used = false;
+    const int kdt = db->cols[g_col].dtype;
+    if ((kdt != HARK_I32 && kdt != HARK_U32) || db->n < ((int64_t)1 << 18)) return HARK_OK;
+    std::vector<DensePass> plan_of((size_t)n_aggs);
+    for (int64_t j = 0; j < n_aggs; j++) {
+        const int c = agg_ops[j] == HARK_AGG_COUNT ? 0 : agg_cols[j];
+        if (!dense_plan_for(agg_ops[j], db->cols[c].dtype, c, &plan_of[j])) return HARK_OK;
+    }
+    const hark_table *src = db;
+    hark_result *kept = nullptr;
+    hark_table view;
+    std::vector<int32_t> remap((size_t)db->m, -1), need;
+    int32_t g2 = g_col;
+    if (where_col >= 0) {
+        auto want = [&](int c) { if (remap[c] < 0) { remap[c] = (int32_t)need.size(); need.push_back(c); } return remap[c]; };
+        g2 = want(g_col);
+        for (auto &pp : plan_of) if (!pp.count_only) pp.col = want(pp.col);
+        HARK_TRY(hark_entry_filter_sel(ctx, &kept, db, where_col, cmp, constant, need.data(), (int64_t)need.size(), 0));
+        view.n = kept->n; view.m = (int64_t)kept->cols.size(); view.cols = kept->cols;
+        for (auto &c : view.cols) c.owned = false;
+        src = &view;
+    }
+    const uint32_t *keys = static_cast<const uint32_t *>(src->cols[g2].data);
+    int rc = HARK_OK;
+    bool ok = src->n > 0;
+    int64_t G = -1;
+    uint32_t rounds = 0;
+    std::vector<char> done((size_t)n_aggs, 0);
+    unsigned long long *accg = nullptr, *cntg = nullptr;
+    auto run_pass = [&](int vop, int xf, const void *col) -> int {
+        uint32_t *hk = nullptr, *perm = nullptr; unsigned long long *hv = nullptr, *hc = nullptr;
+        int64_t Gj = 0;
+        int r = k_fgb_hash_u32(ctx, keys, static_cast<const uint32_t *>(col), src->n, vop, xf, &hk, &hv, &hc, &Gj, &ok, &rounds);
+        if (!r && ok) {
+            if (G < 0) {
+                G = Gj; res->n = G;
+                res->cols.resize((size_t)n_aggs + 1);
+                res->cols[0].dtype = kdt;
+                r = hark_alloc(ctx, &res->cols[0].data, (size_t)G * 4);
+                for (int64_t j = 0; j < n_aggs && !r; j++) {
+                    res->cols[(size_t)j + 1].dtype = plan_of[j].out_dtype;
+                    r = hark_alloc(ctx, &res->cols[(size_t)j + 1].data, (size_t)G * hark_dtype_size(plan_of[j].out_dtype));
+                }
+                if (!r) r = hark_alloc(ctx, (void **)&accg, (size_t)G * 8);
+                if (!r) r = hark_alloc(ctx, (void **)&cntg, (size_t)G * 8);
+            } else if (Gj != G) r = hark_fail(ctx, HARK_EHIP, "filter_groupby: inconsistent group counts between passes");
+            if (!r) r = k_argsort_column(ctx, hk, kdt, G, false, &perm, nullptr);       // SQL order: signed for I32
+            if (!r && G > 0) {
+                r = k_gather(ctx, hk, 4, perm, res->cols[0].data, G);
+                if (!r) r = k_gather(ctx, hv, 8, perm, accg, G);
+                if (!r) r = k_gather(ctx, hc, 8, perm, cntg, G);
+            }
+        }
+        hark_free(ctx, hk); hark_free(ctx, hv); hark_free(ctx, hc); hark_free(ctx, perm);
+        return r;
+    };
+    for (int64_t j = 0; j < n_aggs && !rc && ok; j++) {
+        if (done[j] || plan_of[j].count_only) continue;
+        rc = run_pass(plan_of[j].vop, plan_of[j].xf, src->cols[plan_of[j].col].data);
+        for (int64_t q = 0; q < n_aggs && !rc && ok; q++)
+            if (!done[q] && (plan_of[q].count_only || (plan_of[q].vop == plan_of[j].vop && plan_of[q].xf == plan_of[j].xf && plan_of[q].col == plan_of[j].col))) {
+                rc = k_fgb_decode(ctx, accg, cntg, G, plan_of[q].kind, res->cols[(size_t)q + 1].data);
+                done[q] = 1;
+            }
+    }
+    if (!rc && ok && G < 0) {                                  // COUNT only / no aggregate
+        rc = run_pass(3, 0, keys);
+        for (int64_t q = 0; q < n_aggs && !rc && ok; q++) rc = k_fgb_decode(ctx, accg, cntg, G, plan_of[q].kind, res->cols[(size_t)q + 1].data);
+    }
+    if (!rc && ok && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "filter_groupby: kernels failed");
+    hark_free(ctx, accg); hark_free(ctx, cntg);
+    if (kept) hark_result_free(ctx, kept);
+    if (rc || !ok) {
+        for (auto &c : res->cols) if (c.owned && c.data) hark_free(ctx, c.data);
+        res->cols.clear(); res->n = 0;
+        return rc;
+    }
+    *used = true;
+    return HARK_OK;
+}
+
 } // namespace
 
 extern "C" int hark_entry_filter_groupby(hark_context *ctx, hark_result **out, const hark_table *db, int32_t where_col, int32_t cmp,
@@ -525,6 +612,7 @@ extern "C" int hark_entry_filter_groupby(hark_context *ctx, hark_result **out, c
     int rc = HARK_OK;
     bool done = false;
     if (db->n > 0) rc = try_dense(ctx, db, where_col, cmp, constant, g_col, agg_cols, agg_ops, n_aggs, res, &done);
+    if (!rc && !done && db->n > 0) rc = try_hash(ctx, db, where_col, cmp, constant, g_col, agg_cols, agg_ops, n_aggs, res, &done);
     if (!rc && !done) {
         // generic path: compact the referenced columns, then sort-based typed aggregation
         for (auto &c : res->cols) if (c.owned && c.data) hark_free(ctx, c.data);

@@ -102,6 +102,28 @@ def test_dense_typed_aggregates_fused_path(fc, where):
     assert np.array_equal(cols[9], prod)
 
 
+@pytest.mark.parametrize("where", ["", "where w <> 0"])
+def test_sparse_int_keys_hash_path(where):
+    """Sparse signed 32-bit keys on >= 2^18 rows: LDS hash buckets, typed read-out, signed key order."""
+    from harkdb_amd import FutharkContext
+    c = FutharkContext()
+    rng = np.random.default_rng(4)
+    n = 400_000
+    pool = rng.integers(-2**31, 2**31, size=50_000)
+    df = pd.DataFrame({"k": pool[rng.integers(0, len(pool), n)].astype(np.int32), "p": rng.random(n).astype(np.float32),
+                       "v": rng.integers(0, 16, n).astype(np.float32), "w": rng.integers(-100, 100, n).astype(np.int32)})
+    c.create_table("s", df)
+    sel = df if not where else df[df.w != 0]
+    names, cols = c.sql_columns(f"select k, sum(w), min(p), count(*), avg(v), max(w) from s {where} group by k")
+    g = sel.groupby("k")
+    assert np.array_equal(cols[0], np.asarray(g.w.sum().index)) and cols[0].dtype == np.int32       # ascending signed
+    assert np.array_equal(cols[1], g.w.sum().to_numpy()) and cols[1].dtype == np.int64
+    assert np.array_equal(cols[2], g.p.min().to_numpy())
+    assert np.array_equal(cols[3], g.w.count().to_numpy())
+    assert np.allclose(cols[4], g.v.mean().to_numpy(), rtol=1e-6)
+    assert np.array_equal(cols[5], g.w.max().to_numpy())
+
+
 def test_groupby_negative_and_int64_keys(fc):
     df = fc._df
     _, cols = fc.sql_columns("select w, count(*) from t group by w")
