@@ -114,6 +114,25 @@ __global__ void mixed_kernel(const uint4 *__restrict__ a, const uint4 *__restric
     if (acc == 0x12345678u) out[0] = acc;
 }
 
+// reads three columns and writes one third of the volume back as a plain stream (the producer's 3:1 mix, no scatter)
+template <bool NT>
+__global__ void read3_write1_kernel(const uint4 *__restrict__ a, const uint4 *__restrict__ b, const uint4 *__restrict__ c, int64_t nvec,
+                                    uint4 *__restrict__ dst)
+{
+    typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+        uint4 x, y, z;
+        if (NT) {
+            u4v t0 = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(a + i)), t1 = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(b + i)),
+                t2 = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(c + i));
+            x = uint4{t0.x, t0.y, t0.z, t0.w}; y = uint4{t1.x, t1.y, t1.z, t1.w}; z = uint4{t2.x, t2.y, t2.z, t2.w};
+        } else { x = a[i]; y = b[i]; z = c[i]; }
+        const uint4 o{x.x ^ y.y, y.x ^ z.z, z.x ^ x.w, x.y ^ y.w};
+        if (NT) __builtin_nontemporal_store(u4v{o.x, o.y, o.z, o.w}, reinterpret_cast<u4v *>(dst + i)); else dst[i] = o;
+    }
+}
+
 template <typename F>
 static double time_ms(F &&launch, int reps = 7)
 {
@@ -205,6 +224,16 @@ int main(int argc, char **argv)
         double t1 = time_ms([&] { mixed_kernel<<<512, 256>>>((uint4 *)a, (uint4 *)b, (uint4 *)c, N / 4, buf, nvec, out); });
         printf("  stream only %.3f ms; stream + write&read of 128 MiB x%d rounds: %.3f ms (extra bytes %.2f GB)\n", t0, (int)(N / 4 / (nvec)), t1, 2.0 * (N / 4) * 16 / 3 / 1e9);
         CK(hipFree(buf));
+    }
+    printf("\n[7] streaming mix of the partition producer: read 3 columns, write 1 column-equivalent (contiguous)\n");
+    {
+        uint4 *dst; CK(hipMalloc(&dst, N * 4));
+        for (int grid : {256, 512, 2048}) {
+            double t0 = time_ms([&] { read3_write1_kernel<false><<<grid, 1024>>>((uint4 *)a, (uint4 *)b, (uint4 *)c, N / 4, dst); });
+            double t1 = time_ms([&] { read3_write1_kernel<true><<<grid, 1024>>>((uint4 *)a, (uint4 *)b, (uint4 *)c, N / 4, dst); });
+            printf("  grid=%4d x1024: plain %.3f ms (%.2f TB/s total) | non-temporal %.3f ms (%.2f TB/s total)\n", grid, t0, N * 16 / t0 / 1e9, t1, N * 16 / t1 / 1e9);
+        }
+        CK(hipFree(dst));
     }
     printf("done\n");
     return 0;
