@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhark.so")
+LIB_PATH = os.environ.get("HARK_LIB") or os.path.join(_HERE, "libhark.so")    # HARK_LIB: A/B builds on one box
 
 OK, EBOUNDS, ENOMEM, EARG, EHIP, EUNSUPPORTED = range(6)
 I32, U32, F32, I64 = range(4)

@@ -297,10 +297,10 @@ __global__ __launch_bounds__(256) void fgb_atomic_kernel(
 // flush, so skewed keys slow the producer down but cannot overflow LDS; a full
 // SLAB (heavier skew than the plan's slack) falls back to direct atomics.
 constexpr int kLine = 16;                                // pairs per 128-byte line
-constexpr int kQ = 32;                                   // queue capacity per bucket (pairs)
+constexpr int kQ = 64;                                   // queue capacity per bucket (pairs)
 constexpr int kPartThreads = 1024;
 constexpr int kBatchRows = kPartThreads * kVec;          // 4096 rows per batch
-constexpr int kMaxBuckets = 256;                         // 256 * kQ * 8 B = 64 KiB of queues
+constexpr int kMaxBuckets = 256;                         // 256 * kQ * 8 B = 128 KiB of queues (one workgroup per CU)
 constexpr int kTileRows = 8192;                          // chunk granularity (multiple of kBatchRows)
 
 // Heavy-hitter cache: a direct-mapped LDS table of kHot (key, partial value, count) entries per
@@ -846,7 +846,7 @@ static int plan_prepare_partition(hark_context *ctx, hark_fgb_plan *pl)
                          (long long)pl->G, kMaxBuckets, (long long)(kAggTableBudget / 12));
     pl->shift = shift;
     pl->P = ((pl->G - 1) >> shift) + 1;
-    pl->nwg = pl->grid ? pl->grid : (int64_t)ctx->num_cu * 2;   // two 1024-thread producers per CU (profiles/r01_notes.md)
+    pl->nwg = pl->grid ? pl->grid : (int64_t)ctx->num_cu;       // one 1024-thread producer per CU: it needs ~110 VGPRs, so only one is resident anyway
     int64_t chunk = pl->chunk_rows ? pl->chunk_rows : (int64_t)1 << 30;   // 10.4 GB of slabs per 2^30 rows; fewer, longer slabs
     chunk = (chunk + kTileRows - 1) / kTileRows * kTileRows;
     if (pl->max_rows > 0 && chunk > pl->max_rows) chunk = (pl->max_rows + kTileRows - 1) / kTileRows * kTileRows;
@@ -1052,7 +1052,7 @@ int k_fgb_hash_u32(hark_context *ctx, const uint32_t *k, const uint32_t *v, int6
 {
     *keys_out = nullptr; *vals_out = nullptr; *cnts_out = nullptr; *G_out = 0; *fits = false;
     if (n <= 0 || n > 0xFFFFFFFFll) return HARK_OK;
-    const int hash_bits = 8, P = 1 << hash_bits, nwg = ctx->num_cu * 2;
+    const int hash_bits = 8, P = 1 << hash_bits, nwg = ctx->num_cu;
     int64_t cap = n / ((int64_t)P * nwg) * 130 / 100 + 256;
     cap = (cap + kLine - 1) / kLine * kLine + 2 * kLine;
     uint2 *pbuf = nullptr; uint32_t *counts = nullptr; int32_t *err = nullptr; unsigned long long *cursor = nullptr;
