@@ -311,6 +311,7 @@ constexpr int kTileRows = 8192;                          // chunk granularity (m
 constexpr int kHotBits = 9, kHot = 1 << kHotBits;
 constexpr uint32_t kHotEmpty = 0xFFFFFFFFu;
 constexpr int kHotProbeBatches = 2;                      // a workgroup keeps the cache on only if > 1/16 of its first rows hit it
+constexpr int kFlushPeriod = 4;                          // batches between queue sweeps (64-pair queues, ~8 new pairs per bucket and batch)
 constexpr int kRetryRounds = 8;                          // queue-full retries per batch before direct atomics
 constexpr int kRetryRoundsHash = 160;                    // hash mode has no atomics fallback: drain a hot bucket (4096 rows / 32 per round)
 constexpr int kErrOverflow = 100;                        // device error word: a slab or a hash table overflowed (host picks another path)
@@ -337,6 +338,7 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
     const int nwg = gridDim.x, wg = blockIdx.x;
     const int64_t nbatch = (row1 - row0 + kBatchRows - 1) / kBatchRows;
     const int cap_lines = (int)(cap / kLine) - 1;                      // the last line is kept for the final partial flush
+    const int flush_period = ((ablate >> 12) & 15) ? ((ablate >> 12) & 15) : kFlushPeriod;
     bool bad = false, overflow = false;
     for (int b = tid; b < P; b += kPartThreads) { s_cnt[b] = 0; s_head[b] = 0; s_lcur[b] = 0; }
     for (int h = tid; h < kHot; h += kPartThreads) { h_val[h] = vop_identity(vop); h_key[h] = kHotEmpty; h_cnt[h] = 0u; }
@@ -368,7 +370,7 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
         }
     };
 
-    auto process = [&](int64_t batch, const float4 pr, const int4 kr, const float4 vr) {
+    auto process = [&](int64_t batch, const float4 pr, const int4 kr, const float4 vr, const bool flush_now) {
         const float pv[4] = {pr.x, pr.y, pr.z, pr.w};
         const int kv[4] = {kr.x, kr.y, kr.z, kr.w};
         const float vv[4] = {vr.x, vr.y, vr.z, vr.w};
@@ -421,7 +423,11 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
                     } else atomicSub(&s_cnt[b], 1);                       // queue full: retry after the flush
                 }
             }
-            __syncthreads();
+            // one barrier orders the enqueues before the sweep and tells whether any queue was full; with 64-pair
+            // queues a sweep every second batch is enough (avg 8 new pairs per bucket and batch), which also
+            // saves the second barrier of the batches in between
+            const bool full = __syncthreads_or(pending != 0);
+            if (!(full || flush_now || (ablate & 256))) break;
             // ---- flush: 8 lanes per bucket store its complete lines, 16 bytes per lane
             if (!(ablate & 2))
             for (int b = tid >> 3; b < P; b += kPartThreads / 8) {
@@ -485,7 +491,7 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
         const float4 pr = pA, vr = vA; const int4 kr = kA;
         pA = pB; vA = vB; kA = kB;
         if (batch + 2 * (int64_t)nwg < nbatch) load(batch + 2 * (int64_t)nwg, pB, kB, vB);
-        process(batch, pr, kr, vr);
+        process(batch, pr, kr, vr, (batches_done % flush_period) == flush_period - 1 || batch + nwg >= nbatch);   // sweep every flush_period-th batch and on the last one
     }
     // ---- final flush: what is left (< kLine pairs per bucket) goes out as one partial line
     for (int b = tid; b < P; b += kPartThreads) {
