@@ -82,3 +82,27 @@ def test_sort_hundred_million_rows(eng):
     assert np.all(np.diff(rs)[dk == 0] > 0)                                # stable: row ids ascend inside a key
     assert int(rs.astype(np.int64).sum()) == n * (n - 1) // 2              # a permutation (checksum)
     res.free(); eng.free(k); eng.free(rid)
+
+
+def test_shard_larger_than_2_31_rows_is_fed_in_pieces(eng):
+    """2^31 + 4100 rows in one shard (25.8 GB of columns): FgbPlan.run splits the call, the
+    accumulators merge the pieces; complement counts add up to the row count."""
+    from harkdb_amd.engine import FgbPlan
+    n, G = (1 << 31) + 4100, 1 << 20
+    p, k, v = eng.alloc(n * 4), eng.alloc(n * 4), eng.alloc(n * 4)
+    for lo in range(0, n, 1 << 30):                      # the generator entry also takes < 2^32 rows per call
+        m = min(1 << 30, n - lo)
+        eng.gen_columns(SEED, lo, m, G, True, p + 4 * lo, k + 4 * lo, v + 4 * lo)
+    s, c = eng.alloc(G * 4), eng.alloc(G * 8)
+    plan = FgbPlan(eng, 1 << 31, G)
+    tot = []
+    for cmp in (">", "<="):
+        plan.reset()
+        plan.run(p, cmp, 0.5, k, v, n)
+        plan.finish(s, c)
+        tot.append(eng.download(c, G, np.int64))
+    assert int((tot[0] + tot[1]).sum()) == n and (tot[0] + tot[1]).min() > 0
+    assert abs(int(tot[0].sum()) / n - 0.5) < 1e-3
+    plan.free()
+    for ptr in (p, k, v, s, c):
+        eng.free(ptr)
