@@ -54,7 +54,14 @@ def cpu_baseline(rows, G, exact):
     t0 = time.perf_counter()
     keys, sums, counts = ora.filter_groupby_refalgo_f32(p, k, v, ">", 0.5)
     dt = time.perf_counter() - t0
-    return {"value": rows / dt, "unit": "rows/s", "cores": 1, "kind": "port",
+    # fairness line: a multi-threaded single-pass direct-index aggregate, not the reference's algorithm
+    threads = min(os.cpu_count() or 1, 64)
+    t1 = time.perf_counter()
+    s64, cnt = ora.filter_groupby_dense_f32_mt(p, k, v, ">", 0.5, G, threads)
+    dt_mt = time.perf_counter() - t1
+    strong = {"value": rows / dt_mt, "unit": "rows/s", "cores": threads, "algorithm": "single-pass direct-index aggregate, OpenMP, private tables (oracle/hark_oracle.c ora_filter_groupby_dense_f32_mt)",
+              "agrees_with_port": bool(np.array_equal(cnt[keys.astype(np.int64)], counts.astype(np.int64)))}
+    return {"value": rows / dt, "unit": "rows/s", "cores": 1, "kind": "port", "stronger_cpu_baseline": strong,
             "sample": f"first {rows} rows of the same synthetic workload (G={G}), {dt:.2f} s, "
                       f"{int(counts.sum())} survivors, {len(keys)} groups; nproc={os.cpu_count()}",
             "algorithm": "oracle/hark_oracle.c ora_filter_groupby_refalgo_f32 = groupby.fut:8-58 + segmented.fut:7-37"}, (keys, sums, counts)

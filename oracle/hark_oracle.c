@@ -682,3 +682,46 @@ int ora_argsort_u32(const uint32_t *keys, int64_t n, int64_t *perm)
     free(rows);
     return rc;
 }
+
+/* A STRONGER CPU baseline than the reference's algorithm (BASELINE.md "fairness
+ * line"): the same query as ora_filter_groupby_dense_f32 as a single-pass
+ * direct-index aggregate on `threads` host threads (OpenMP), private tables per
+ * thread merged at the end, double sums.  Not the reference's algorithm: reported
+ * next to the 32-pass port so that the GPU speed-up is not flattered by it. */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+int ora_filter_groupby_dense_f32_mt(const float *p, const int32_t *k, const float *v, int64_t n,
+                                    int op, float thr, int64_t G, int threads, double *sum64, int64_t *count)
+{
+    if (threads < 1) threads = 1;
+    double *ts = (double *)calloc((size_t)threads * (size_t)G, sizeof(double));
+    int64_t *tc = (int64_t *)calloc((size_t)threads * (size_t)G, sizeof(int64_t));
+    if (!ts || !tc) { free(ts); free(tc); return ORA_ENOMEM; }
+    int bad = 0;
+#pragma omp parallel num_threads(threads) reduction(| : bad)
+    {
+#ifdef _OPENMP
+        const int t = omp_get_thread_num(), nt = omp_get_num_threads();
+#else
+        const int t = 0, nt = 1;
+#endif
+        double *s = ts + (size_t)t * (size_t)G;
+        int64_t *c = tc + (size_t)t * (size_t)G;
+        const int64_t lo = n * t / nt, hi = n * (t + 1) / nt;
+        for (int64_t i = lo; i < hi; i++) {
+            if (p && !cmp_f32(op, p[i], thr)) continue;
+            const int64_t key = k[i];
+            if (key < 0 || key >= G) { bad = 1; continue; }
+            s[key] += (double)v[i]; c[key] += 1;
+        }
+    }
+#pragma omp parallel for num_threads(threads)
+    for (int64_t g = 0; g < G; g++) {
+        double s = 0.0; int64_t c = 0;
+        for (int t = 0; t < threads; t++) { s += ts[(size_t)t * (size_t)G + g]; c += tc[(size_t)t * (size_t)G + g]; }
+        sum64[g] = s; count[g] = c;
+    }
+    free(ts); free(tc);
+    return bad ? ORA_EBOUNDS : ORA_OK;
+}

@@ -208,6 +208,19 @@ def filter_groupby_dense_f32(p, k, v, op, thr, G):
     return s32, s64, cnt
 
 
+def filter_groupby_dense_f32_mt(p, k, v, op, thr, G, threads):
+    """Multi-threaded single-pass direct-index aggregate (the stronger CPU baseline).  Returns (sum64, count)."""
+    k = np.ascontiguousarray(k, dtype=np.int32)
+    v = np.ascontiguousarray(v, dtype=np.float32)
+    pp = None if p is None else np.ascontiguousarray(p, dtype=np.float32)
+    s64 = np.empty(G, dtype=np.float64)
+    cnt = np.empty(G, dtype=np.int64)
+    _check(lib().ora_filter_groupby_dense_f32_mt(_p(pp, C.c_float) if pp is not None else None, _p(k, C.c_int32), _p(v, C.c_float),
+                                                 C.c_int64(k.size), CMP[op], C.c_float(thr), C.c_int64(G), C.c_int(int(threads)),
+                                                 _p(s64, C.c_double), _p(cnt, C.c_int64)))
+    return s64, cnt
+
+
 def filter_groupby_refalgo_f32(p, k, v, op, thr):
     """Same query through the reference's 32-pass sort + segmented fold."""
     k = np.ascontiguousarray(k, dtype=np.int32)

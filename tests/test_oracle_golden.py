@@ -114,3 +114,22 @@ def test_join_matches_numpy_model(oracle):
             for j in np.nonzero(b[:, 0] == key)[0]:
                 exp.append([a[i, 0], a[i, 2], b[j, 1], b[j, 0]])
     assert out.tolist() == np.asarray(exp, dtype=np.uint32).reshape(-1, 4).tolist()
+
+
+def test_cpu_baselines_agree_with_dense_oracle(oracle):
+    """bench.py's two CPU baselines (the reference-algorithm port and the
+    multi-threaded single-pass aggregate) compute the same query as the dense
+    oracle the GPU is checked against (exact-valued workload: sums are exact)."""
+    G = 1 << 12
+    p, k, v = oracle.gen_columns(7, 0, 200_000, G, True)
+    s32, s64, cnt = oracle.filter_groupby_dense_f32(p, k, v, ">", 0.5, G)
+    keys, sums, counts = oracle.filter_groupby_refalgo_f32(p, k, v, ">", 0.5)
+    live = np.nonzero(cnt)[0]
+    assert np.array_equal(keys, live.astype(np.uint32))
+    assert np.array_equal(counts.astype(np.int64), cnt[live])
+    assert np.array_equal(sums.astype(np.float64), s64[live])
+    for threads in (1, 3, 8):
+        m64, mcnt = oracle.filter_groupby_dense_f32_mt(p, k, v, ">", 0.5, G, threads)
+        assert np.array_equal(mcnt, cnt) and np.array_equal(m64, s64)
+    with pytest.raises(oracle.OracleError):
+        oracle.filter_groupby_dense_f32_mt(p, k, v, ">", 0.5, G // 2, 2)
