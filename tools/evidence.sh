@@ -1,0 +1,12 @@
+set -x
+export TMPDIR=/tmp
+O=gpurun_out/ev2; rm -rf $O; mkdir -p $O
+timeout 600 python bench.py > $O/bench_plain.json 2> $O/bench_plain.err
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 10 --warmup 3 --cpu-rows 0 > $O/bench_rocprof.json 2> $O/bench_rocprof.err
+timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --cpu-rows 0 > $O/pmc_fetch.json 2> $O/pmc_fetch.err
+timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 bench.py --steps 2 --warmup 1 --cpu-rows 0 > $O/pmc_write.json 2> $O/pmc_write.err
+timeout 600 python tools/ops_bench.py > $O/ops_bench.log 2>&1
+timeout 300 python tools/c5_bench.py > $O/c5_bench.log 2>&1
+find $O -name "*kernel_trace.csv" -size +20M -delete
+ls -R $O | head -50
+cat $O/bench_plain.json
