@@ -358,6 +358,60 @@ __global__ __launch_bounds__(256) void hash_dest_kernel(const void *__restrict__
     }
 }
 
+// Order-preserving 64-bit sort word of a key (u32 < i32 < f32 < i64 all map to unsigned order).
+__device__ __forceinline__ uint64_t order_word(const void *col, int dtype, int64_t i)
+{
+    if (dtype == HARK_I64) return static_cast<const uint64_t *>(col)[i] ^ 0x8000000000000000ull;
+    uint32_t w = static_cast<const uint32_t *>(col)[i];
+    if (dtype == HARK_I32) w ^= 0x80000000u;
+    else if (dtype == HARK_F32) {
+        if (w == 0x80000000u) w = 0u;
+        w ^= (w & 0x80000000u) ? 0xFFFFFFFFu : 0x80000000u;
+    }
+    return w;
+}
+
+// dest = number of splitters <= key (ascending) -- equal keys share a part; mirrored for descending.
+__global__ __launch_bounds__(256) void range_dest_kernel(const void *__restrict__ col, int dtype, int64_t n, const void *__restrict__ splitters,
+                                                         int nsplit, int descending, uint32_t *__restrict__ dest)
+{
+    __shared__ uint64_t s_split[256];
+    if ((int)threadIdx.x < nsplit) s_split[threadIdx.x] = order_word(splitters, dtype, threadIdx.x);
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t w = order_word(col, dtype, i);
+        int lo = 0, hi = nsplit;                                     // first splitter > w
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_split[mid] <= w) lo = mid + 1; else hi = mid; }
+        dest[i] = (uint32_t)(descending ? nsplit - lo : lo);
+    }
+}
+
+// One stable 8-bit pass on the part ids in `dest` -> perm_out grouped by part, part sizes to the host.
+int partition_by_dest(hark_context *ctx, uint32_t *dest, int64_t n, int nparts, uint32_t *perm_out, int64_t *counts_host, const char *who)
+{
+    uint32_t *dtmp = nullptr, *vtmp = nullptr, *ws = nullptr;
+    int rc = hark_alloc(ctx, (void **)&dtmp, (size_t)n * 4);
+    if (!rc) rc = hark_alloc(ctx, (void **)&vtmp, (size_t)n * 4);
+    if (!rc) rc = hark_alloc(ctx, (void **)&ws, k_sort_workspace_bytes(n, ctx->num_cu));
+    // the permutation lands in perm_out (the "tmp" side of a one-pass sort)
+    if (!rc) rc = k_sort_pairs_u32(ctx, dest, vtmp, dtmp, perm_out, n, 0u, true, ws, 1);
+    if (!rc) {
+        // the digit totals of the pass are the part sizes (ws: 256*nblk histogram, then 256 totals)
+        int64_t nblk = (n + kSortTile - 1) / kSortTile;
+        if (nblk > (int64_t)ctx->num_cu * 8) nblk = (int64_t)ctx->num_cu * 8;
+        int64_t slice = (n + nblk - 1) / nblk;
+        slice = (slice + kSortTile - 1) / kSortTile * kSortTile;
+        nblk = (n + slice - 1) / slice;
+        std::vector<uint32_t> tot(256);
+        if (hipMemcpyAsync(tot.data(), ws + (size_t)kBins * nblk, 256 * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, who);
+        else for (int i = 0; i < nparts; i++) counts_host[i] = tot[i];
+    }
+    hark_free(ctx, dtmp); hark_free(ctx, vtmp); hark_free(ctx, ws);
+    return rc;
+}
+
 } // namespace
 
 extern "C" {
@@ -372,31 +426,44 @@ int hark_op_partition_by_hash(hark_context *ctx, const void *key_col, int32_t dt
     for (int i = 0; i < nparts; i++) counts_host[i] = 0;
     if (n == 0) return HARK_OK;
     if (n > 0xFFFFFFFFll) return hark_fail(ctx, HARK_EARG, "partition_by_hash: at most 2^32-1 rows");
-    uint32_t *dest = nullptr, *dtmp = nullptr, *vtmp = nullptr, *ws = nullptr;
+    uint32_t *dest = nullptr;
     int rc = hark_alloc(ctx, (void **)&dest, (size_t)n * 4);
-    if (!rc) rc = hark_alloc(ctx, (void **)&dtmp, (size_t)n * 4);
-    if (!rc) rc = hark_alloc(ctx, (void **)&vtmp, (size_t)n * 4);
-    if (!rc) rc = hark_alloc(ctx, (void **)&ws, k_sort_workspace_bytes(n, ctx->num_cu));
     if (!rc) {
         int64_t blocks = (n + 255) / 256;
         if (blocks > (int64_t)ctx->num_cu * 16) blocks = (int64_t)ctx->num_cu * 16;
         hash_dest_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(key_col, (int)hark_dtype_size(dtype), n, (uint32_t)nparts, dest);
-        // one stable 8-bit pass on the part id; the permutation lands in perm_out (the "tmp" side)
-        rc = k_sort_pairs_u32(ctx, dest, vtmp, dtmp, perm_out, n, 0u, true, ws, 1);
+        rc = partition_by_dest(ctx, dest, n, nparts, perm_out, counts_host, "partition_by_hash: reading part sizes failed");
     }
+    hark_free(ctx, dest);
+    return rc;
+}
+
+// Range partition for the distributed ORDER BY (sample sort): part = number of splitters <= key
+// in the column's own order (u32 unsigned, i32/i64 signed, f32 IEEE with -0 == +0), so equal keys
+// share a part and parts are ordered; `descending` mirrors the part ids.  `splitters_host` holds
+// nparts-1 ascending values of the column's dtype.  Same outputs as hark_op_partition_by_hash.
+int hark_op_partition_by_range(hark_context *ctx, const void *key_col, int32_t dtype, int64_t n, int32_t nparts,
+                               const void *splitters_host, int32_t descending, uint32_t *perm_out, int64_t *counts_host)
+{
+    if (!ctx || n < 0 || nparts < 1 || nparts > 256 || !counts_host || (nparts > 1 && !splitters_host) ||
+        (n && (!key_col || !perm_out)) || hark_dtype_size(dtype) == 0) return HARK_EARG;
+    for (int i = 0; i < nparts; i++) counts_host[i] = 0;
+    if (n == 0) return HARK_OK;
+    if (n > 0xFFFFFFFFll) return hark_fail(ctx, HARK_EARG, "partition_by_range: at most 2^32-1 rows");
+    uint32_t *dest = nullptr;
+    void *split_dev = nullptr;
+    const size_t sb = (size_t)(nparts - 1) * hark_dtype_size(dtype);
+    int rc = hark_alloc(ctx, (void **)&dest, (size_t)n * 4);
+    if (!rc && sb) rc = hark_alloc(ctx, &split_dev, sb);
+    if (!rc && sb && hipMemcpyAsync(split_dev, splitters_host, sb, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+        rc = hark_fail(ctx, HARK_EHIP, "partition_by_range: splitter upload failed");
     if (!rc) {
-        // the digit totals of the pass are the part sizes (ws: 256*nblk histogram, then 256 totals)
-        int64_t nblk = (n + kSortTile - 1) / kSortTile;
-        if (nblk > (int64_t)ctx->num_cu * 8) nblk = (int64_t)ctx->num_cu * 8;
-        int64_t slice = (n + nblk - 1) / nblk;
-        slice = (slice + kSortTile - 1) / kSortTile * kSortTile;
-        nblk = (n + slice - 1) / slice;
-        std::vector<uint32_t> tot(256);
-        if (hipMemcpyAsync(tot.data(), ws + (size_t)kBins * nblk, 256 * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-            hipStreamSynchronize(ctx->stream) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "partition_by_hash: reading part sizes failed");
-        else for (int i = 0; i < nparts; i++) counts_host[i] = tot[i];
+        int64_t blocks = (n + 255) / 256;
+        if (blocks > (int64_t)ctx->num_cu * 16) blocks = (int64_t)ctx->num_cu * 16;
+        range_dest_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(key_col, dtype, n, split_dev, nparts - 1, descending ? 1 : 0, dest);
+        rc = partition_by_dest(ctx, dest, n, nparts, perm_out, counts_host, "partition_by_range: reading part sizes failed");
     }
-    hark_free(ctx, dest); hark_free(ctx, dtmp); hark_free(ctx, vtmp); hark_free(ctx, ws);
+    hark_free(ctx, dest); if (split_dev) hark_free(ctx, split_dev);
     return rc;
 }
 

@@ -180,13 +180,18 @@ def exchange_columns(send_cols, send_counts, group=None):
 _TORCH_OF = {"int32": "int32", "uint32": "int32", "float32": "float32", "int64": "int64"}     # uint32 travels as its bit pattern
 
 
-def repartition_device(eng, ptrs, dtypes, n, key_index, device, world, group=None):
-    """Hash-partition n rows held in device columns (raw pointers `ptrs`) by column
-    `key_index` on the GPU (hark_op_partition_by_hash + hark_op_gather) and
-    all-to-all them.  Returns (torch tensors owning the received columns, rows)."""
+def repartition_device(eng, ptrs, dtypes, n, key_index, device, world, group=None, splitters=None, descending=False):
+    """Partition n rows held in device columns (raw pointers `ptrs`) by column
+    `key_index` on the GPU and all-to-all them: by key hash
+    (hark_op_partition_by_hash) or, when `splitters` is given, by key range
+    (hark_op_partition_by_range: rank r receives the r-th range, rows of one
+    source in table order).  Returns (torch tensors owning the received columns, rows)."""
     import torch
     perm = torch.empty(max(n, 1), dtype=torch.int32, device=device)
-    counts = eng.partition_by_hash(ptrs[key_index], dtypes[key_index], n, world, perm.data_ptr())
+    if splitters is None:
+        counts = eng.partition_by_hash(ptrs[key_index], dtypes[key_index], n, world, perm.data_ptr())
+    else:
+        counts = eng.partition_by_range(ptrs[key_index], dtypes[key_index], n, splitters, descending, perm.data_ptr())
     send = []
     for ptr, dt in zip(ptrs, dtypes):
         buf = torch.empty(max(n, 1), dtype=getattr(torch, _TORCH_OF[np.dtype(dt).name]), device=device)[:n]
@@ -194,6 +199,37 @@ def repartition_device(eng, ptrs, dtypes, n, key_index, device, world, group=Non
         send.append(buf)
     recv, rc = exchange_columns(send, counts, group)
     return recv, sum(rc)
+
+
+# ---------------------------------------------------------------------------
+# Sample sort: the exchange of SURVEY.md 8(e) "SORT BY"
+# ---------------------------------------------------------------------------
+SAMPLES_PER_RANK = 256
+
+
+def sample_positions(n, samples=SAMPLES_PER_RANK):
+    """Evenly spaced row positions of a shard to sample its sort keys at."""
+    m = min(int(n), int(samples))
+    return (np.arange(m, dtype=np.int64) * int(n)) // max(m, 1)
+
+
+def choose_splitters(all_samples, world):
+    """world-1 ascending splitters at the quantiles of the pooled samples."""
+    a = np.sort(np.asarray(all_samples), kind="stable")
+    if world <= 1 or a.size == 0:
+        return a[:0]
+    return a[(np.arange(1, world) * a.size) // world]
+
+
+def gather_splitters(local_sample, world, group=None):
+    """All ranks pool their key samples (all-gather) and derive the SAME splitters."""
+    import torch.distributed as dist
+    local_sample = np.asarray(local_sample)
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return choose_splitters(local_sample, world)
+    parts = [None] * dist.get_world_size(group)
+    dist.all_gather_object(parts, local_sample, group=group)
+    return choose_splitters(np.concatenate([p.astype(local_sample.dtype, copy=False) for p in parts]), world)
 
 
 _SECOND_LEVEL = {"sum": "sum", "count": "sum", "min": "min", "max": "max", "prod": "prod"}
@@ -245,8 +281,8 @@ class ShardedFutharkContext:
         if ir.get("join"):
             return self._join(ir)
         if "groupbys" not in ir:
-            if "orderby" in ir:
-                raise Exception("ORDER BY over sharded tables needs the sample-sort exchange (not built yet)")
+            if "orderby" in ir and (self.world > 1 or self.device_exchange):
+                return self._orderby(ir)
             limit = ir.pop("limit", None)
             stmt = sql_statement if limit is None else sql_statement[: sql_statement.lower().rindex("limit")]
             names, cols = self.local.sql_columns(stmt)
@@ -310,6 +346,42 @@ class ShardedFutharkContext:
         return names, out
 
     # ---- RCCL all-to-all paths ------------------------------------------------------
+    def _orderby(self, ir):
+        """SELECT ... [WHERE ...] ORDER BY col [DESC] [LIMIT n] over row-range shards as a
+        sample sort: local WHERE, pooled key samples -> splitters, range partition on the
+        GPU, all-to-all, local stable radix sort, ranges concatenated in rank order.  Ties
+        keep table order: a range receives its rows by (source rank, local position)."""
+        import torch
+        eng, loc = self.local.FutEnv, self.local
+        tab = loc.tables[ir["table_name"]]
+        dev, schema = tab._device, tab.get_schema()
+        okey, desc = ir["orderby"][0][1], bool(ir["orderby"][1])
+        need = list(dict.fromkeys([okey] + list(ir["select"])))
+        if ir.get("where"):
+            cur, cmap = loc._filtered(dev, ir["where"], set(need))
+        else:
+            cur, cmap = dev, {c: c for c in need}
+        n = cur.shape[0]
+        ptrs, dts = [cur.device_ptr(cmap[c]) for c in need], [cur.dtype(cmap[c]) for c in need]
+        pos = sample_positions(n)
+        sample = np.empty(0, dtype=np.dtype(dts[0]))
+        if pos.size:
+            idx = torch.as_tensor(pos.astype(np.int32), device=self.device)
+            buf = torch.empty(pos.size, dtype=getattr(torch, _TORCH_OF[np.dtype(dts[0]).name]), device=self.device)
+            eng.gather(ptrs[0], dts[0], idx.data_ptr(), buf.data_ptr(), pos.size)
+            sample = buf.cpu().numpy().view(np.dtype(dts[0]))
+        splitters = gather_splitters(sample, self.world)
+        recv, nrecv = repartition_device(eng, ptrs, dts, n, 0, self.device, self.world, splitters=splitters, descending=desc)
+        t = eng.table_from_device(nrecv, [c.data_ptr() for c in recv], dts, keepalive=(recv, cur))
+        res = eng.sort(t, 0, [need.index(c) for c in ir["select"]], descending=desc)
+        cols = res.columns()
+        if "limit" in ir:
+            cols = [c[: ir["limit"]] for c in cols]
+        cols = gather_columns(cols)
+        if "limit" in ir:
+            cols = [c[: ir["limit"]] for c in cols]
+        return [schema[c] for c in ir["select"]], cols
+
     def _result_as_table(self, res):
         eng = self.local.FutEnv
         n, m = res.shape

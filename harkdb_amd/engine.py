@@ -204,6 +204,15 @@ class Engine:
         self._chk(self.lib.hark_op_partition_by_hash(self.ctx, key_ptr, _ffi.DT_OF[np.dtype(dtype)], int(n), int(nparts), perm_ptr, counts))
         return list(counts)
 
+    def partition_by_range(self, key_ptr, dtype, n, splitters, descending, perm_ptr):
+        """Row ids grouped by key range (part = number of splitters <= key, mirrored when
+        descending) into perm_ptr (device u32[n]); returns the len(splitters)+1 part sizes."""
+        sp = np.ascontiguousarray(splitters, dtype=np.dtype(dtype))
+        counts = (C.c_int64 * (sp.size + 1))()
+        self._chk(self.lib.hark_op_partition_by_range(self.ctx, key_ptr, _ffi.DT_OF[np.dtype(dtype)], int(n), sp.size + 1,
+                                                      sp.ctypes.data_as(C.c_void_p), 1 if descending else 0, perm_ptr, counts))
+        return list(counts)
+
     def gather(self, src_ptr, dtype, idx_ptr, dst_ptr, n):
         self._chk(self.lib.hark_op_gather(self.ctx, src_ptr, _ffi.DT_OF[np.dtype(dtype)], idx_ptr, dst_ptr, int(n)))
 

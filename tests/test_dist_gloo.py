@@ -152,3 +152,61 @@ def test_exchange_columns_all_to_all_two_ranks():
         exp_v = np.concatenate([src[2][src[3] == me] for src in outs])
         assert np.array_equal(o[4], exp_k) and np.array_equal(o[5], exp_v)
         assert o[6] == [int((src[3] == me).sum()) for src in outs]
+
+
+def _samplesort_worker(rank, world, port, descending, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from harkdb_amd import dist as hd
+    hd.init_process_group("cpu")
+    rng = np.random.default_rng(21)
+    n = 5003
+    keys_all = rng.integers(-50, 50, size=n).astype(np.int32)          # many ties: stability matters
+    rowid_all = np.arange(n, dtype=np.int64)
+    lo, hi = hd.shard_range(n, rank, world)
+    keys, rowid = keys_all[lo:hi], rowid_all[lo:hi]
+    # the protocol of ShardedFutharkContext._orderby with numpy standing in for the two device operators
+    splitters = hd.gather_splitters(keys[hd.sample_positions(len(keys), 64)], world)
+    d = np.searchsorted(splitters, keys, side="right")                 # = hark_op_partition_by_range
+    dest = (len(splitters) - d) if descending else d
+    order = np.argsort(dest, kind="stable")
+    counts = np.bincount(dest, minlength=world).tolist()
+    recv, rc = hd.exchange_columns([torch.from_numpy(keys[order]), torch.from_numpy(rowid[order])], counts)
+    rk, rr = recv[0].numpy(), recv[1].numpy()
+    perm = np.argsort(-rk.astype(np.int64) if descending else rk, kind="stable")     # = the local stable radix sort
+    cols = hd.gather_columns([rk[perm], rr[perm]])
+    q.put((rank, splitters, cols[0], cols[1]))
+    import torch.distributed as dist
+    dist.barrier(); dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("descending", [False, True])
+def test_sample_sort_exchange_two_ranks(descending):
+    """Distributed ORDER BY: pooled samples give every rank the same splitters, the range
+    exchange + local stable sort + rank-order concatenation equals one global stable sort."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_samplesort_worker, args=(r, world, port, descending, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    outs = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    rng = np.random.default_rng(21)
+    keys_all = rng.integers(-50, 50, size=5003).astype(np.int32)
+    exp = np.argsort(-keys_all.astype(np.int64) if descending else keys_all, kind="stable")
+    assert np.array_equal(outs[0][1], outs[1][1]) and len(outs[0][1]) == world - 1
+    for o in outs:
+        assert np.array_equal(o[3], exp) and np.array_equal(o[2], keys_all[exp])
+
+
+def test_choose_splitters_properties():
+    from harkdb_amd import dist as hd
+    a = np.arange(1000, dtype=np.float32)[::-1]
+    s = hd.choose_splitters(a, 8)
+    assert len(s) == 7 and np.all(np.diff(s) > 0) and s.dtype == np.float32
+    assert len(hd.choose_splitters(a, 1)) == 0 and len(hd.choose_splitters(a[:0], 4)) == 0
+    assert hd.sample_positions(10, 64).tolist() == list(range(10)) and len(hd.sample_positions(10**6, 64)) == 64
+    assert hd.sample_positions(0).size == 0

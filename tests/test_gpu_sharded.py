@@ -71,3 +71,55 @@ def test_sharded_device_exchange_paths(sfc, oracle):
         assert np.array_equal(out[np.lexsort(out.T[::-1])], ref[np.lexsort(ref.T[::-1])].astype(out.dtype))   # same multiset of rows
     finally:
         sfc.device_exchange = False
+
+
+@pytest.mark.parametrize("dtype", [np.uint32, np.int32, np.float32, np.int64])
+@pytest.mark.parametrize("descending", [False, True])
+def test_partition_by_range_matches_numpy(sfc, dtype, descending):
+    """hark_op_partition_by_range: part = number of splitters <= key in the column's own order."""
+    import torch
+    eng = sfc.local.FutEnv
+    rng = np.random.default_rng(5)
+    n = 70_001
+    if dtype == np.float32:
+        keys = (rng.standard_normal(n) * 10).astype(np.float32)
+        keys[:7] = [0.0, -0.0, np.inf, -np.inf, 1.5, -1.5, 0.0]
+    elif dtype == np.int64:
+        keys = rng.integers(-2**40, 2**40, n).astype(np.int64)
+    elif dtype == np.uint32:
+        keys = rng.integers(0, 2**32, n).astype(np.uint32)
+    else:
+        keys = rng.integers(-2**31, 2**31, n).astype(np.int32)
+    splitters = np.sort(keys[rng.integers(0, n, 5)])
+    tdt = {np.uint32: torch.int32, np.int32: torch.int32, np.float32: torch.float32, np.int64: torch.int64}[dtype]
+    kdev = torch.from_numpy(keys.view(np.int32) if dtype == np.uint32 else keys).to(sfc.device).view(tdt)
+    perm = torch.empty(n, dtype=torch.int32, device=sfc.device)
+    counts = eng.partition_by_range(kdev.data_ptr(), dtype, n, splitters, descending, perm.data_ptr())
+    d = np.searchsorted(splitters, keys, side="right")
+    dest = (len(splitters) - d) if descending else d
+    assert counts == np.bincount(dest, minlength=len(splitters) + 1).tolist()
+    assert np.array_equal(perm.cpu().numpy().view(np.uint32), np.argsort(dest, kind="stable").astype(np.uint32))
+    # no splitters: one part, identity permutation
+    counts1 = eng.partition_by_range(kdev.data_ptr(), dtype, n, splitters[:0], descending, perm.data_ptr())
+    assert counts1 == [n] and np.array_equal(perm.cpu().numpy(), np.arange(n, dtype=np.int32))
+
+
+def test_sharded_orderby_sample_sort(sfc):
+    """ORDER BY over shards (sample sort with the RCCL all-to-all, forced on with one rank)
+    equals the single-context result, ties in table order."""
+    df = sfc._df
+    sfc.device_exchange = True
+    try:
+        for stmt, ref in (
+            ("select k, w from t where p > 0.5 order by k", df[df.p > 0.5].sort_values("k", kind="stable")[["k", "w"]]),
+            ("select w, k from t order by p desc limit 50", df.sort_values("p", ascending=False, kind="stable")[["w", "k"]].head(50)),
+            ("select k from t where p > 2.0 order by k", df[df.p > 2.0][["k"]]),
+        ):
+            names, cols = sfc.sql_columns(stmt)
+            assert names == list(ref.columns)
+            for c, name in zip(cols, names):
+                assert np.array_equal(c, ref[name].to_numpy())
+            loc = sfc.local.sql_columns(stmt)[1]
+            assert all(np.array_equal(a, b) for a, b in zip(cols, loc))
+    finally:
+        sfc.device_exchange = False
