@@ -47,6 +47,19 @@ def init_process_group(device_type=None):
     return rank, local, world
 
 
+def share_stream(eng, device):
+    """Put the engine's kernels and torch (RCCL collectives, tensor ops, events) on ONE
+    stream: a torch side stream made current.  torch's default stream has handle 0, which
+    hark_context_set_stream reads as "the context's own stream" -- kernels there would not be
+    ordered against collectives, so the default stream is never shared."""
+    import torch
+    st = torch.cuda.Stream(device=device)
+    torch.cuda.set_stream(st)
+    assert st.cuda_stream != 0
+    eng.set_stream(st.cuda_stream)
+    return st
+
+
 class _DevicePtr:
     """Exposes a raw device address to torch without a copy."""
 
@@ -251,7 +264,7 @@ class ShardedFutharkContext:
         torch.cuda.set_device(self.device)
         self.local = FutharkContext(device=self.device.index, sql_mode=True)
         # kernels, gathers and RCCL collectives are ordered by ONE stream
-        self.local.FutEnv.set_stream(torch.cuda.current_stream().cuda_stream)
+        self.stream = share_stream(self.local.FutEnv, self.device)
         self.rows = {}
         # sparse GROUP BY / JOIN exchange rows with an RCCL all-to-all when there is more than one rank
         self.device_exchange = (self.world > 1) if device_exchange is None else bool(device_exchange)

@@ -167,6 +167,8 @@ class Engine:
         self._chk(self.lib.hark_context_sync(self.ctx))
 
     def set_stream(self, raw_stream):
+        """Run later entries on this hipStream_t handle; 0 / None = the context's own stream
+        (so torch's DEFAULT stream, handle 0, cannot be shared: use dist.share_stream)."""
         self._chk(self.lib.hark_context_set_stream(self.ctx, raw_stream))
 
     def close(self):
@@ -197,6 +199,10 @@ class Engine:
 
     def gen_columns(self, seed, first_row, n, G, exact, p=None, k=None, v=None):
         self._chk(self.lib.hark_op_gen_columns(self.ctx, int(seed), int(first_row), int(n), int(G), 1 if exact else 0, p, k, v))
+
+    def stream_read(self, ptr, nbytes, fold_ptr):
+        """Read nbytes once (bandwidth probe); XORs a 64-bit fold into the device u64 at fold_ptr."""
+        self._chk(self.lib.hark_op_stream_read(self.ctx, ptr, int(nbytes), fold_ptr))
 
     def partition_by_hash(self, key_ptr, dtype, n, nparts, perm_ptr):
         """Row ids grouped by hash(key) part into perm_ptr (device u32[n]); returns the part sizes."""
