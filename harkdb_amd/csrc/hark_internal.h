@@ -123,3 +123,14 @@ int k_groupby_typed(hark_context *ctx, const hark_table *db, int32_t g_col, cons
                     const int32_t *agg_ops, int64_t n_aggs, hark_result *res);
 int k_gather_columns(hark_context *ctx, const hark_table *db, const int32_t *cols, int64_t k,
                      hark_result *res);
+
+#ifdef __HIPCC__
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope fence over ALL
+// address spaces: the compiler drains vmcnt before s_barrier, so a barrier inside a streaming loop waits
+// for every global load and store the lanes still have in flight.  Where lanes exchange data through LDS
+// only, lgkmcnt(0) is enough and the global traffic keeps flowing across the barrier.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+#endif

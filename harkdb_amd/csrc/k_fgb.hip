@@ -315,7 +315,19 @@ constexpr int kFlushPeriod = 4;                          // batches between queu
 constexpr int kRetryRounds = 8;                          // queue-full retries per batch before direct atomics
 constexpr int kRetryRoundsHash = 160;                    // hash mode has no atomics fallback: drain a hot bucket (4096 rows / 32 per round)
 constexpr int kErrOverflow = 100;                        // device error word: a slab or a hash table overflowed (host picks another path)
-static size_t part_lds_bytes(int P) { return sizeof(uint2) * (size_t)P * kQ + sizeof(int) * 3 * (size_t)P + (size_t)kHot * 16 + 16; }
+static size_t part_lds_bytes(int P) { return sizeof(uint2) * (size_t)P * kQ + sizeof(int) * 3 * (size_t)P + (size_t)kHot * 16 + 32; }
+
+// Workgroup-wide OR through one LDS word and ONE lds_barrier: three slots used in rotation, the next
+// one cleared before the barrier (its last readers passed the previous barrier already).
+__device__ __forceinline__ bool wg_or(bool pred, uint32_t *flags, int &phase)
+{
+    const int s = phase;
+    phase = s == 2 ? 0 : s + 1;
+    if (__ballot(pred) != 0ull && (threadIdx.x & 63) == 0) flags[s] = 1u;
+    if (threadIdx.x == 0) flags[phase] = 0u;
+    lds_barrier();
+    return flags[s] != 0u;
+}
 
 template <int OP>
 __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
@@ -342,7 +354,9 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
     bool bad = false, overflow = false;
     for (int b = tid; b < P; b += kPartThreads) { s_cnt[b] = 0; s_head[b] = 0; s_lcur[b] = 0; }
     for (int h = tid; h < kHot; h += kPartThreads) { h_val[h] = vop_identity(vop); h_key[h] = kHotEmpty; h_cnt[h] = 0u; }
-    if (tid < 4) h_stat[tid] = 0u;
+    uint32_t *or_flags = h_stat + 4;                                          // [3] slots of wg_or
+    int or_phase = 0;
+    if (tid < 8) h_stat[tid] = 0u;
     int batches_done = 0;
     __syncthreads();
 
@@ -426,7 +440,7 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
             // one barrier orders the enqueues before the sweep and tells whether any queue was full; with 64-pair
             // queues a sweep every second batch is enough (avg 8 new pairs per bucket and batch), which also
             // saves the second barrier of the batches in between
-            const bool full = __syncthreads_or(pending != 0);
+            const bool full = wg_or(pending != 0, or_flags, or_phase);
             if (!(full || flush_now || (ablate & 256))) break;
             // ---- flush: 8 lanes per bucket store its complete lines, 16 bytes per lane
             if (!(ablate & 2))
@@ -467,7 +481,7 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
                     }
                 pending = 0;
             }
-            again = __syncthreads_or(pending != 0);
+            again = wg_or(pending != 0, or_flags, or_phase);
         } while (again);
         if (batches_done == kHotProbeBatches && h_stat[0] * 16u < h_stat[1]) {   // workgroup-uniform: keys are not skewed
             // stop probing, and hand the few rows the cache absorbed to the global table now, while

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(kThreads) void filter_scatter_kernel(const uint16_t
                 for (int j = 0; j < 4; j++) if (m4 & (1u << j)) s_stage[q++] = src[r + j];
             }
         }
-        __syncthreads();
+        lds_barrier();
         if (esz == 4) {
             uint32_t *dst = static_cast<uint32_t *>(cs.dst[cidx]) + out0;
             for (uint32_t i = threadIdx.x; i < tile_total; i += kThreads) dst[i] = s32[i];
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(kThreads) void filter_scatter_kernel(const uint16_t
             uint64_t *dst = (is_index ? reinterpret_cast<uint64_t *>(row_index) : static_cast<uint64_t *>(cs.dst[cidx])) + out0;
             for (uint32_t i = threadIdx.x; i < tile_total; i += kThreads) dst[i] = s_stage[i];
         }
-        __syncthreads();
+        lds_barrier();
     }
 }
 

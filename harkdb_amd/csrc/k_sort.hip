@@ -137,7 +137,7 @@ __global__ __launch_bounds__(kSortThreads) void digit_scatter_kernel(
     for (int64_t tbase = lo; tbase < hi; tbase += kSortTile) {
 #pragma unroll
         for (int w = 0; w < kSortWaves; w++) s_wcnt[w][tid] = 0;
-        __syncthreads();
+        lds_barrier();
         // ---- rank inside the wave's contiguous 1024-key chunk -----------------
         uint32_t key[kRounds], val[kRounds], rank[kRounds];
         const int64_t wbase = tbase + (int64_t)wave * (64 * kRounds);
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(kSortThreads) void digit_scatter_kernel(
             // the leader's store above must land before the next round's loads of the same row
             __builtin_amdgcn_wave_barrier();
         }
-        __syncthreads();
+        lds_barrier();
         // ---- chain the waves, lay the digits out in the tile -------------------
         uint32_t tcnt = 0;
         {
@@ -173,12 +173,12 @@ __global__ __launch_bounds__(kSortThreads) void digit_scatter_kernel(
             uint32_t incl = tcnt;
             for (int d = 1; d < 64; d <<= 1) { uint32_t y = __shfl_up(incl, d, 64); if (lane >= d) incl += y; }
             if (lane == 63) s_scan[wave] = incl;
-            __syncthreads();
+            lds_barrier();
             uint32_t carry = 0;
             for (int w = 0; w < wave; w++) carry += s_scan[w];
             s_tstart[tid] = carry + incl - tcnt;
         }
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int r = 0; r < kRounds; r++) {
             if (rank[r] != 0xFFFFFFFFu) {
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(kSortThreads) void digit_scatter_kernel(
                 s_key[slot] = key[r]; s_val[slot] = val[r];
             }
         }
-        __syncthreads();
+        lds_barrier();
         // ---- write digit runs ---------------------------------------------------
         const int tile_n = (int)((hi - tbase) < kSortTile ? (hi - tbase) : kSortTile);
         for (int slot = tid; slot < tile_n; slot += kSortThreads) {
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(kSortThreads) void digit_scatter_kernel(
             const int64_t pos = s_gpos[d] + (slot - (int)s_tstart[d]);
             keys_out[pos] = kk; vals_out[pos] = s_val[slot];
         }
-        __syncthreads();
+        lds_barrier();
         s_gpos[tid] += tcnt;
         // (the __syncthreads at the top of the next tile orders this update)
     }

@@ -1,5 +1,3 @@
-export TMPDIR=/tmp
-O=gpurun_out/opsprof; rm -rf $O; mkdir -p $O
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 tools/ops_bench.py > $O/ops.log 2>&1
-find $O -name "*kernel_trace.csv" -size +30M -delete
-python tools/kstats.py $O/stats 40
+timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|Error|error" | tail -5
+timeout 300 python tools/ops_bench.py 2>&1 | grep -v amdgpu.ids
+timeout 300 python tools/fgb_ablate.py 1000000000 "ablate=0;ablate=4096;ablate=8192" 1048576 2>&1 | tail -3
