@@ -315,7 +315,7 @@ constexpr int kFlushPeriod = 4;                          // batches between queu
 constexpr int kRetryRounds = 8;                          // queue-full retries per batch before direct atomics
 constexpr int kRetryRoundsHash = 160;                    // hash mode has no atomics fallback: drain a hot bucket (4096 rows / 32 per round)
 constexpr int kErrOverflow = 100;                        // device error word: a slab or a hash table overflowed (host picks another path)
-static size_t part_lds_bytes(int P) { return sizeof(uint2) * (size_t)P * kQ + sizeof(int) * 3 * (size_t)P + (size_t)kHot * 16 + 32; }
+static size_t part_lds_bytes(int P) { return sizeof(uint2) * (size_t)P * kQ + sizeof(int) * 2 * (size_t)P + 8 + (size_t)kHot * 16 + 32; }
 
 // Workgroup-wide OR through one LDS word and ONE lds_barrier: three slots used in rotation, the next
 // one cleared before the barrier (its last readers passed the previous barrier already).
@@ -329,52 +329,64 @@ __device__ __forceinline__ bool wg_or(bool pred, uint32_t *flags, int &phase)
     return flags[s] != 0u;
 }
 
-template <int OP>
+// MODE 0: dense keys, f32 sum, no value transform (the headline path: nothing of the operator is decided at
+// run time); MODE 1: dense keys, any value operator / transform (wave-uniform run-time switches);
+// MODE 2: hash mode -- bucket = top bits of mix32(key), any u32 keys, no dense table behind the slabs.
+// The kernel is bound by instruction issue (16 waves per CU, every wave-instruction costs four cycles of
+// its SIMD; tools/fgb_ablate.py with synthetic rows and no memory traffic runs at 80 % of the full time),
+// so the batch loop carries no run-time knobs: a bucket's queue state is ONE word (head << 16 | count,
+// one returning LDS atomic hands a row its slot), keys are range-checked as unsigned 32-bit, and the
+// ragged-end tests only run in the last batch.
+template <int OP, int MODE>
 __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
     const float *__restrict__ p, const int32_t *__restrict__ k, const float *__restrict__ v,
     int64_t row0, int64_t row1, float thr, int64_t G, int shift, int P,
     uint2 *__restrict__ pbuf, uint32_t *__restrict__ counts, uint32_t cap,
-    u64 *__restrict__ gsum, unsigned long long *__restrict__ gcnt, int32_t *__restrict__ err, int ablate, int vop, int xf,
-    int hash_bits /* 0: bucket = key >> shift over a dense domain; else bucket = top bits of mix32(key), any u32 keys */)
+    u64 *__restrict__ gsum, unsigned long long *__restrict__ gcnt, int32_t *__restrict__ err, int period_knob, int vop_rt, int xf_rt,
+    int hash_bits)
 {
+    constexpr bool HASH = MODE == 2;
+    const int vop = MODE == 0 ? (int)VOP_F32SUM : vop_rt;
+    const int xf = MODE == 0 ? 0 : xf_rt;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     uint2 *queue = reinterpret_cast<uint2 *>(lds_raw);                 // [P][kQ]
-    int *s_cnt = reinterpret_cast<int *>(queue + (size_t)P * kQ);      // pairs queued per bucket
-    int *s_head = s_cnt + P;                                           // queue index of the oldest pair (multiple of kLine)
-    int *s_lcur = s_head + P;                                          // lines already stored in this workgroup's slab
-    u64 *h_val = reinterpret_cast<u64 *>(s_lcur + P + ((3 * P) & 1));         // [kHot] heavy-hitter partial values (8-byte aligned)
-    uint32_t *h_key = reinterpret_cast<uint32_t *>(h_val + kHot);             // [kHot] owning key or kHotEmpty
-    uint32_t *h_cnt = h_key + kHot;                                           // [kHot]
-    uint32_t *h_stat = h_cnt + kHot;                                          // [0] hits, [1] surviving rows seen, [2] cache switched off
+    uint32_t *s_w = reinterpret_cast<uint32_t *>(queue + (size_t)P * kQ);     // [P] queue index of the oldest pair (multiple of kLine) << 16 | pairs queued
+    int *s_lcur = reinterpret_cast<int *>(s_w + P);                    // [P] lines already stored in this workgroup's slab
+    u64 *h_val = reinterpret_cast<u64 *>(s_lcur + P + ((2 * P) & 1)); // [kHot] heavy-hitter partial values (8-byte aligned)
+    uint32_t *h_key = reinterpret_cast<uint32_t *>(h_val + kHot);     // [kHot] owning key or kHotEmpty
+    uint32_t *h_cnt = h_key + kHot;                                    // [kHot]
+    uint32_t *h_stat = h_cnt + kHot;                                   // [0] hits, [1] surviving rows seen, [4..6] wg_or slots
     const int tid = threadIdx.x;
     const int nwg = gridDim.x, wg = blockIdx.x;
     const int64_t nbatch = (row1 - row0 + kBatchRows - 1) / kBatchRows;
     const int cap_lines = (int)(cap / kLine) - 1;                      // the last line is kept for the final partial flush
-    const int flush_period = ((ablate >> 12) & 15) ? ((ablate >> 12) & 15) : kFlushPeriod;
+    const int period = period_knob > 0 ? period_knob : kFlushPeriod;
+    const uint32_t Gu = (uint32_t)G;                                   // G <= 2^31: one unsigned compare rejects negative keys too
     bool bad = false, overflow = false;
-    for (int b = tid; b < P; b += kPartThreads) { s_cnt[b] = 0; s_head[b] = 0; s_lcur[b] = 0; }
+    for (int b = tid; b < P; b += kPartThreads) { s_w[b] = 0u; s_lcur[b] = 0; }
     for (int h = tid; h < kHot; h += kPartThreads) { h_val[h] = vop_identity(vop); h_key[h] = kHotEmpty; h_cnt[h] = 0u; }
-    uint32_t *or_flags = h_stat + 4;                                          // [3] slots of wg_or
-    int or_phase = 0;
     if (tid < 8) h_stat[tid] = 0u;
-    int batches_done = 0;
+    uint32_t *or_flags = h_stat + 4;
+    int or_phase = 0;
+    int batches_done = 0, since_sweep = 0;
+    bool hot_on = !HASH;                                               // workgroup-uniform; switched off after the probe unless keys repeat
     __syncthreads();
+
+    auto vbits_of = [&](float x) -> uint32_t { return MODE == 0 ? __float_as_uint(x) : apply_xf(xf, __float_as_uint(x)); };
+    auto direct = [&](uint32_t key, uint32_t vb) {
+        if (MODE == 0) vop_atomic<VOP_F32SUM>(&gsum[key], vb); else vop_atomic_rt(vop, &gsum[key], vb);
+        atomicAdd(&gcnt[key], 1ull);
+    };
 
     auto load = [&](int64_t batch, float4 &pr, int4 &kr, float4 &vr) {
         const int64_t r = row0 + batch * kBatchRows + (int64_t)tid * kVec;
-        if (r + kVec <= row1) {
-            if (!(ablate & 16)) {                                      // streamed once: non-temporal loads (-3 % producer time)
-                typedef float f4v __attribute__((ext_vector_type(4)));
-                typedef int i4v __attribute__((ext_vector_type(4)));
-                if (OP != kNoPred) { const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(p + r)); pr = float4{t.x, t.y, t.z, t.w}; }
-                else pr = float4{0, 0, 0, 0};
-                const i4v tk = __builtin_nontemporal_load(reinterpret_cast<const i4v *>(k + r)); kr = int4{tk.x, tk.y, tk.z, tk.w};
-                const f4v tv = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(v + r)); vr = float4{tv.x, tv.y, tv.z, tv.w};
-            } else {
-                pr = OP == kNoPred ? float4{0, 0, 0, 0} : *reinterpret_cast<const float4 *>(p + r);
-                kr = *reinterpret_cast<const int4 *>(k + r);
-                vr = *reinterpret_cast<const float4 *>(v + r);
-            }
+        if (r + kVec <= row1) {                                        // streamed once: non-temporal loads
+            typedef float f4v __attribute__((ext_vector_type(4)));
+            typedef int i4v __attribute__((ext_vector_type(4)));
+            if (OP != kNoPred) { const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(p + r)); pr = float4{t.x, t.y, t.z, t.w}; }
+            else pr = float4{0, 0, 0, 0};
+            const i4v tk = __builtin_nontemporal_load(reinterpret_cast<const i4v *>(k + r)); kr = int4{tk.x, tk.y, tk.z, tk.w};
+            const f4v tv = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(v + r)); vr = float4{tv.x, tv.y, tv.z, tv.w};
         } else {                                                       // ragged end of the table
             float pp[4] = {0, 0, 0, 0}; int kk[4] = {0, 0, 0, 0}; float vv[4] = {0, 0, 0, 0};
             for (int j = 0; j < kVec; j++) if (r + j < row1) {
@@ -388,111 +400,112 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
         const float pv[4] = {pr.x, pr.y, pr.z, pr.w};
         const int kv[4] = {kr.x, kr.y, kr.z, kr.w};
         const float vv[4] = {vr.x, vr.y, vr.z, vr.w};
-        const int64_t r = row0 + batch * kBatchRows + (int64_t)tid * kVec;
+        const int64_t bend = row0 + (batch + 1) * kBatchRows;          // workgroup-uniform
         uint32_t pending = 0;
+        if (bend <= row1) {
 #pragma unroll
-        for (int j = 0; j < kVec; j++) {
-            bool keep = r + j < row1 && cmp_f32<OP>(pv[j], thr);
-            if (keep && !hash_bits && !(kv[j] >= 0 && (int64_t)(uint32_t)kv[j] < G)) { bad = true; keep = false; }
-            if (keep) pending |= 1u << j;
+            for (int j = 0; j < kVec; j++) if (cmp_f32<OP>(pv[j], thr)) pending |= 1u << j;
+        } else {
+            const int64_t r = row0 + batch * kBatchRows + (int64_t)tid * kVec;
+#pragma unroll
+            for (int j = 0; j < kVec; j++) if (r + j < row1 && cmp_f32<OP>(pv[j], thr)) pending |= 1u << j;
         }
-        if (ablate & 4) { asm volatile("" :: "v"(pending), "v"(vv[0]), "v"(vv[1]), "v"(vv[2]), "v"(vv[3])); pending = 0; }
-        // ---- heavy hitters: rows whose key owns its cache slot are folded in LDS right here
-        const bool hot_on = !(ablate & 128) && !hash_bits && h_stat[2] == 0u;    // workgroup-uniform (the cache feeds the dense table)
-        const bool probing = hot_on && batches_done < kHotProbeBatches;
-        uint32_t seen = __popc(pending), hits = 0;
-        if (hot_on)
+        if (!HASH) {
+            uint32_t inr = 0;
 #pragma unroll
-        for (int j = 0; j < kVec; j++) {
-            if (pending & (1u << j)) {
-                const uint32_t key = (uint32_t)kv[j], h = (key * 0x9E3779B1u) >> (32 - kHotBits);
-                uint32_t owner = h_key[h];
-                bool claimed = false;
-                if (owner == kHotEmpty) { owner = atomicCAS(&h_key[h], kHotEmpty, key); if (owner == kHotEmpty) { owner = key; claimed = true; } }
-                if (owner == key) {
-                    vop_atomic_rt(vop, &h_val[h], apply_xf(xf, __float_as_uint(vv[j])));
-                    atomicAdd(&h_cnt[h], 1u);
-                    pending &= ~(1u << j);
-                    hits += claimed ? 0u : 1u;                      // a claim is not evidence of skew, a repeat is
+            for (int j = 0; j < kVec; j++) inr |= (uint32_t)((uint32_t)kv[j] < Gu) << j;
+            bad |= (pending & ~inr) != 0u;
+            pending &= inr;
+        }
+        // ---- heavy hitters: rows whose key owns its cache slot are folded in LDS right here
+        if (!HASH && hot_on) {
+            const bool probing = batches_done < kHotProbeBatches;
+            uint32_t seen = __popc(pending), hits = 0;
+#pragma unroll
+            for (int j = 0; j < kVec; j++) {
+                if (pending & (1u << j)) {
+                    const uint32_t key = (uint32_t)kv[j], h = (key * 0x9E3779B1u) >> (32 - kHotBits);
+                    uint32_t owner = h_key[h];
+                    bool claimed = false;
+                    if (owner == kHotEmpty) { owner = atomicCAS(&h_key[h], kHotEmpty, key); if (owner == kHotEmpty) { owner = key; claimed = true; } }
+                    if (owner == key) {
+                        vop_atomic_rt(vop, &h_val[h], vbits_of(vv[j]));
+                        atomicAdd(&h_cnt[h], 1u);
+                        pending &= ~(1u << j);
+                        hits += claimed ? 0u : 1u;                      // a claim is not evidence of skew, a repeat is
+                    }
                 }
             }
-        }
-        if (probing) {                                                            // wave-aggregated statistics of the probe phase
-            for (int d = 32; d > 0; d >>= 1) { seen += __shfl_down(seen, d, 64); hits += __shfl_down(hits, d, 64); }
-            if ((tid & 63) == 0) { atomicAdd(&h_stat[0], hits); atomicAdd(&h_stat[1], seen); }
+            if (probing) {                                                            // wave-aggregated statistics of the probe phase
+                for (int d = 32; d > 0; d >>= 1) { seen += __shfl_down(seen, d, 64); hits += __shfl_down(hits, d, 64); }
+                if ((tid & 63) == 0) { atomicAdd(&h_stat[0], hits); atomicAdd(&h_stat[1], seen); }
+            }
         }
         batches_done++;
         bool again;
         int rounds = 0;
         do {
-            // ---- enqueue: one returning LDS atomic per surviving row
+            // ---- enqueue: one returning LDS atomic per surviving row gives it the queue position and the head
 #pragma unroll
             for (int j = 0; j < kVec; j++) {
                 if (pending & (1u << j)) {
-                    const uint32_t key = (uint32_t)kv[j], b = hash_bits ? mix32(key) >> (32 - hash_bits) : key >> shift;
-                    const int pos = atomicAdd(&s_cnt[b], 1);
-                    if (pos < kQ) {
-                        queue[b * kQ + ((s_head[b] + pos) & (kQ - 1))] = uint2{key, apply_xf(xf, __float_as_uint(vv[j]))};
+                    const uint32_t key = (uint32_t)kv[j], b = HASH ? mix32(key) >> (32 - hash_bits) : key >> shift;
+                    const uint32_t old = atomicAdd(&s_w[b], 1u), pos = old & 0xFFFFu;
+                    if (pos < (uint32_t)kQ) {
+                        queue[b * kQ + (((old >> 16) + pos) & (kQ - 1))] = uint2{key, vbits_of(vv[j])};
                         pending &= ~(1u << j);
-                    } else atomicSub(&s_cnt[b], 1);                       // queue full: retry after the flush
+                    } else atomicSub(&s_w[b], 1u);                      // queue full: retry after the flush
                 }
             }
-            // one barrier orders the enqueues before the sweep and tells whether any queue was full; with 64-pair
-            // queues a sweep every second batch is enough (avg 8 new pairs per bucket and batch), which also
-            // saves the second barrier of the batches in between
+            // one barrier orders the enqueues before the sweep and tells whether any queue was full
             const bool full = wg_or(pending != 0, or_flags, or_phase);
-            if (!(full || flush_now || (ablate & 256))) break;
+            if (!(full || flush_now)) break;
             // ---- flush: 8 lanes per bucket store its complete lines, 16 bytes per lane
-            if (!(ablate & 2))
             for (int b = tid >> 3; b < P; b += kPartThreads / 8) {
-                const int cnt = s_cnt[b];
-                const int lines = cnt / kLine;
+                const uint32_t w = s_w[b];
+                const int cnt = (int)(w & 0xFFFFu), lines = cnt / kLine;
                 if (lines) {
-                    const int i = tid & 7, head = s_head[b], lc = s_lcur[b];
+                    const int i = tid & 7, head = (int)(w >> 16), lc = s_lcur[b];
                     for (int q = 0; q < lines; q++) {
                         const uint4 two = *reinterpret_cast<const uint4 *>(&queue[b * kQ + ((head + q * kLine) & (kQ - 1)) + 2 * i]);
                         if (lc + q < cap_lines) {
-                            if (!(ablate & 1))
-                            {
-                                uint4 *dst = reinterpret_cast<uint4 *>(&pbuf[((size_t)b * nwg + wg) * cap + (size_t)(lc + q) * kLine + 2 * i]);
-                                typedef unsigned int u4v __attribute__((ext_vector_type(4)));
-                                if (!(ablate & 32)) __builtin_nontemporal_store(u4v{two.x, two.y, two.z, two.w}, reinterpret_cast<u4v *>(dst)); else *dst = two;
-                            }
-                        } else if (hash_bits) {                            // slab full, no dense table to fall back to
+                            uint4 *dst = reinterpret_cast<uint4 *>(&pbuf[((size_t)b * nwg + wg) * cap + (size_t)(lc + q) * kLine + 2 * i]);
+                            typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+                            __builtin_nontemporal_store(u4v{two.x, two.y, two.z, two.w}, reinterpret_cast<u4v *>(dst));
+                        } else if (HASH) {                                 // slab full, no dense table to fall back to
                             overflow = true;
                         } else {                                           // slab full: direct atomics
-                            vop_atomic_rt(vop, &gsum[two.x], two.y); atomicAdd(&gcnt[two.x], 1ull);
-                            vop_atomic_rt(vop, &gsum[two.z], two.w); atomicAdd(&gcnt[two.z], 1ull);
+                            direct(two.x, two.y); direct(two.z, two.w);
                         }
                     }
                     if (i == 0) {
-                        s_cnt[b] = cnt - lines * kLine;
-                        s_head[b] = (head + lines * kLine) & (kQ - 1);
+                        s_w[b] = ((uint32_t)((head + lines * kLine) & (kQ - 1)) << 16) | (uint32_t)(cnt - lines * kLine);
                         s_lcur[b] = min(lc + lines, cap_lines);
                     }
                 }
             }
-            if (++rounds >= (hash_bits ? kRetryRoundsHash : kRetryRounds) || (ablate & 2)) {   // bounded: leftovers go through direct atomics
-                if (hash_bits && pending) { overflow = true; pending = 0; }
+            since_sweep = 0;
+            if (++rounds >= (HASH ? kRetryRoundsHash : kRetryRounds)) {   // bounded: leftovers go through direct atomics
+                if (HASH && pending) { overflow = true; pending = 0; }
 #pragma unroll
                 for (int j = 0; j < kVec; j++)
-                    if ((pending & (1u << j)) && !(ablate & 2)) {
-                        vop_atomic_rt(vop, &gsum[(uint32_t)kv[j]], apply_xf(xf, __float_as_uint(vv[j]))); atomicAdd(&gcnt[(uint32_t)kv[j]], 1ull);
-                    }
+                    if (pending & (1u << j)) direct((uint32_t)kv[j], vbits_of(vv[j]));
                 pending = 0;
             }
             again = wg_or(pending != 0, or_flags, or_phase);
         } while (again);
-        if (batches_done == kHotProbeBatches && h_stat[0] * 16u < h_stat[1]) {   // workgroup-uniform: keys are not skewed
-            // stop probing, and hand the few rows the cache absorbed to the global table now, while
-            // the rest of the chip is still streaming, instead of at the tail of the kernel
-            __syncthreads();
-            for (int h = tid; h < kHot; h += kPartThreads) {
-                const uint32_t c = h_cnt[h];
-                if (c) { vop_atomic_partial_rt(vop, &gsum[h_key[h]], h_val[h]); atomicAdd(&gcnt[h_key[h]], (unsigned long long)c); h_cnt[h] = 0u; }
+        if (!HASH && batches_done == kHotProbeBatches) {
+            if (h_stat[0] * 16u < h_stat[1]) {                            // workgroup-uniform: keys are not skewed
+                // stop probing, and hand the few rows the cache absorbed to the global table now, while
+                // the rest of the chip is still streaming, instead of at the tail of the kernel
+                __syncthreads();
+                for (int h = tid; h < kHot; h += kPartThreads) {
+                    const uint32_t c = h_cnt[h];
+                    if (c) { vop_atomic_partial_rt(vop, &gsum[h_key[h]], h_val[h]); atomicAdd(&gcnt[h_key[h]], (unsigned long long)c); h_cnt[h] = 0u; }
+                }
+                hot_on = false;
+                __syncthreads();
             }
-            if (tid == 0) h_stat[2] = 1u;
-            __syncthreads();
         }
     };
 
@@ -505,16 +518,18 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
         const float4 pr = pA, vr = vA; const int4 kr = kA;
         pA = pB; vA = vB; kA = kB;
         if (batch + 2 * (int64_t)nwg < nbatch) load(batch + 2 * (int64_t)nwg, pB, kB, vB);
-        process(batch, pr, kr, vr, (batches_done % flush_period) == flush_period - 1 || batch + nwg >= nbatch);   // sweep every flush_period-th batch and on the last one
+        process(batch, pr, kr, vr, ++since_sweep >= period || batch + nwg >= nbatch);   // sweep every period-th batch and on the last one
     }
     // ---- final flush: what is left (< kLine pairs per bucket) goes out as one partial line
     for (int b = tid; b < P; b += kPartThreads) {
-        const int l = s_cnt[b], head = s_head[b];
+        const uint32_t w = s_w[b];
+        const int l = (int)(w & 0xFFFFu), head = (int)(w >> 16);
         const size_t base = ((size_t)b * nwg + wg) * cap + (size_t)s_lcur[b] * kLine;
         for (int j = 0; j < l; j++) pbuf[base + j] = queue[b * kQ + ((head + j) & (kQ - 1))];
         counts[(size_t)b * nwg + wg] = (uint32_t)(s_lcur[b] * kLine + l);
     }
     // ---- the heavy hitters join the global table (one atomic pair per occupied entry)
+    if (!HASH)
     for (int h = tid; h < kHot; h += kPartThreads) {
         const uint32_t c = h_cnt[h];
         if (c) { vop_atomic_partial_rt(vop, &gsum[h_key[h]], h_val[h]); atomicAdd(&gcnt[h_key[h]], (unsigned long long)c); }
@@ -953,14 +968,20 @@ int k_fgb_dense_f32(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cm
             if (rc) return rc;
         }
         const size_t lds_part = part_lds_bytes(P);
-        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_part_kernel<OP>),
+        const bool fast = vop == VOP_F32SUM && pl->xform == 0;       // the headline operator is compiled in
+        HIP_TRY(ctx, hipFuncSetAttribute(fast ? reinterpret_cast<const void *>(&fgb_part_kernel<OP, 0>) : reinterpret_cast<const void *>(&fgb_part_kernel<OP, 1>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part));
         for (int64_t r0 = 0; r0 < n; r0 += pl->chunk_rows) {
             const int64_t r1 = r0 + pl->chunk_rows < n ? r0 + pl->chunk_rows : n;
             {
                 TimedLaunch tl(pl, st, 1);
-                fgb_part_kernel<OP><<<dim3((unsigned)nwg), dim3(kPartThreads), lds_part, st>>>(
-                    p, k, v, r0, r1, thr, G, shift, P, pl->pbuf, pl->counts, (uint32_t)pl->cap, gsum, gcnt, pl->err, (int)pl->ablate, vop, (int)pl->xform, 0);
+                const int period = (int)((pl->ablate >> 12) & 15);            // experiments: batches between sweeps (0 = default)
+                if (fast)
+                    fgb_part_kernel<OP, 0><<<dim3((unsigned)nwg), dim3(kPartThreads), lds_part, st>>>(
+                        p, k, v, r0, r1, thr, G, shift, P, pl->pbuf, pl->counts, (uint32_t)pl->cap, gsum, gcnt, pl->err, period, vop, (int)pl->xform, 0);
+                else
+                    fgb_part_kernel<OP, 1><<<dim3((unsigned)nwg), dim3(kPartThreads), lds_part, st>>>(
+                        p, k, v, r0, r1, thr, G, shift, P, pl->pbuf, pl->counts, (uint32_t)pl->cap, gsum, gcnt, pl->err, period, vop, (int)pl->xform, 0);
             }
             HIP_TRY(ctx, hipGetLastError());
             {
@@ -1093,10 +1114,10 @@ int k_fgb_hash_u32(hark_context *ctx, const uint32_t *k, const uint32_t *v, int6
     if (!rc) {
         hipMemsetAsync(err, 0, 16, st);
         const size_t lds_part = part_lds_bytes(P);
-        rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_part_kernel<kNoPred>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part) == hipSuccess
+        rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_part_kernel<kNoPred, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part) == hipSuccess
                  ? HARK_OK : hark_fail(ctx, HARK_EHIP, "hash group-by: LDS attribute failed");
         if (!rc) {
-            fgb_part_kernel<kNoPred><<<dim3((unsigned)nwg), dim3(kPartThreads), lds_part, st>>>(
+            fgb_part_kernel<kNoPred, 2><<<dim3((unsigned)nwg), dim3(kPartThreads), lds_part, st>>>(
                 nullptr, reinterpret_cast<const int32_t *>(k), reinterpret_cast<const float *>(v), 0, n, 0.0f, (int64_t)1 << 32, 0, P,
                 pbuf, counts, (uint32_t)cap, nullptr, nullptr, err, 0, vop, xf, hash_bits);
             rc = read_err(&e);
