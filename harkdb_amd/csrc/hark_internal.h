@@ -95,6 +95,7 @@ struct hark_fgb_plan {
     int64_t slack_pct = 0;     // slab capacity as % of the uniform share (0 = default)
     int64_t tile_rows = 0;
     int64_t ablate = 0;        // timing experiments only
+    int64_t pairfmt = 0;       // partition pair format: 0 auto (compact), 1: 8-byte (key, value) pairs, 2: compact 6-byte units
     int64_t timing = 0;        // record HIP events around every kernel launch
     int64_t vop = 0;           // value operator: 0 f32 sum (f64 acc), 1..4 u32 sum/max/min/prod, 5 u32 -> u64 sum
     int64_t xform = 0;         // 0 none, 1 i32 -> ordered u32, 2 f32 -> ordered u32

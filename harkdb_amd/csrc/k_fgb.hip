@@ -315,7 +315,19 @@ constexpr int kFlushPeriod = 4;                          // batches between queu
 constexpr int kRetryRounds = 8;                          // queue-full retries per batch before direct atomics
 constexpr int kRetryRoundsHash = 160;                    // hash mode has no atomics fallback: drain a hot bucket (4096 rows / 32 per round)
 constexpr int kErrOverflow = 100;                        // device error word: a slab or a hash table overflowed (host picks another path)
-static size_t part_lds_bytes(int P) { return sizeof(uint2) * (size_t)P * kQ + sizeof(int) * 2 * (size_t)P + 8 + (size_t)kHot * 16 + 32; }
+// Compact pair format (dense keys): a pair is 6 bytes, a 16-bit bucket-local key and the 32-bit value,
+// stored as UNITS of 64 pairs = 256 B of values followed by 128 B of keys -- three whole 128-byte lines, so
+// the write combining keeps its whole-line property (a 64-B + 32-B split of 16 pairs did not).  The producer
+// is at the HBM ceiling of its traffic mix, so 25 % fewer partition bytes are worth their price in LDS: rings
+// of 96 pairs (one unit + 32 of headroom) per bucket, swept every second batch.
+constexpr int kU = 64;                                   // pairs per unit
+constexpr int kUnitBytes = kU * 6;                       // 384
+constexpr int kQ6 = 96;                                  // ring capacity per bucket (pairs)
+constexpr int kFlushPeriod6 = 2;                         // batches between sweeps (every batch once a ring was found full)
+static size_t part_lds_bytes(int P, bool c6)
+{
+    return (c6 ? (size_t)6 * P * kQ6 : sizeof(uint2) * (size_t)P * kQ) + sizeof(int) * 2 * (size_t)P + 8 + (size_t)kHot * 16 + 32;
+}
 
 // Workgroup-wide OR through one LDS word and ONE lds_barrier: three slots used in rotation, the next
 // one cleared before the barrier (its last readers passed the previous barrier already).
@@ -337,7 +349,7 @@ __device__ __forceinline__ bool wg_or(bool pred, uint32_t *flags, int &phase)
 // so the batch loop carries no run-time knobs: a bucket's queue state is ONE word (head << 16 | count,
 // one returning LDS atomic hands a row its slot), keys are range-checked as unsigned 32-bit, and the
 // ragged-end tests only run in the last batch.
-template <int OP, int MODE>
+template <int OP, int MODE, bool C6>
 __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
     const float *__restrict__ p, const int32_t *__restrict__ k, const float *__restrict__ v,
     int64_t row0, int64_t row1, float thr, int64_t G, int shift, int P,
@@ -349,8 +361,12 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
     const int vop = MODE == 0 ? (int)VOP_F32SUM : vop_rt;
     const int xf = MODE == 0 ? 0 : xf_rt;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    uint2 *queue = reinterpret_cast<uint2 *>(lds_raw);                 // [P][kQ]
-    uint32_t *s_w = reinterpret_cast<uint32_t *>(queue + (size_t)P * kQ);     // [P] queue index of the oldest pair (multiple of kLine) << 16 | pairs queued
+    static_assert(!(C6 && MODE == 2), "compact pairs carry bucket-local keys: dense mode only");
+    uint2 *queue = reinterpret_cast<uint2 *>(lds_raw);                 // [P][kQ]           8-byte pairs
+    uint32_t *qv = reinterpret_cast<uint32_t *>(lds_raw);              // [P][kQ6] values   compact format
+    uint16_t *qk = reinterpret_cast<uint16_t *>(qv + (size_t)P * kQ6); // [P][kQ6] bucket-local keys
+    uint32_t *s_w = C6 ? reinterpret_cast<uint32_t *>(qk + (size_t)P * kQ6)
+                       : reinterpret_cast<uint32_t *>(queue + (size_t)P * kQ);   // [P] ring index of the oldest pair << 16 | pairs queued
     int *s_lcur = reinterpret_cast<int *>(s_w + P);                    // [P] lines already stored in this workgroup's slab
     u64 *h_val = reinterpret_cast<u64 *>(s_lcur + P + ((2 * P) & 1)); // [kHot] heavy-hitter partial values (8-byte aligned)
     uint32_t *h_key = reinterpret_cast<uint32_t *>(h_val + kHot);     // [kHot] owning key or kHotEmpty
@@ -360,7 +376,11 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
     const int nwg = gridDim.x, wg = blockIdx.x;
     const int64_t nbatch = (row1 - row0 + kBatchRows - 1) / kBatchRows;
     const int cap_lines = (int)(cap / kLine) - 1;                      // the last line is kept for the final partial flush
-    const int period = period_knob > 0 ? period_knob : kFlushPeriod;
+    const int cap_units = (int)((size_t)cap * 8 / kUnitBytes) - 1;     // compact format: same slab bytes, the last unit for the final partial flush
+    unsigned char *slab6 = reinterpret_cast<unsigned char *>(pbuf) + (size_t)wg * ((size_t)cap * 8);    // + b * nwg * cap * 8
+    const uint32_t kmask = (1u << shift) - 1u;
+    auto wrap6 = [](int x) { return x >= kQ6 ? x - kQ6 : x; };
+    int period = period_knob > 0 ? period_knob : (C6 ? kFlushPeriod6 : kFlushPeriod);
     const uint32_t Gu = (uint32_t)G;                                   // G <= 2^31: one unsigned compare rejects negative keys too
     bool bad = false, overflow = false;
     for (int b = tid; b < P; b += kPartThreads) { s_w[b] = 0u; s_lcur[b] = 0; }
@@ -368,7 +388,7 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
     if (tid < 8) h_stat[tid] = 0u;
     uint32_t *or_flags = h_stat + 4;
     int or_phase = 0;
-    int batches_done = 0, since_sweep = 0;
+    int batches_done = 0, since_sweep = 0, n_full = 0;
     bool hot_on = !HASH;                                               // workgroup-uniform; switched off after the probe unless keys repeat
     __syncthreads();
 
@@ -451,6 +471,13 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
                 if (pending & (1u << j)) {
                     const uint32_t key = (uint32_t)kv[j], b = HASH ? mix32(key) >> (32 - hash_bits) : key >> shift;
                     const uint32_t old = atomicAdd(&s_w[b], 1u), pos = old & 0xFFFFu;
+                    if (C6) {
+                        if (pos < (uint32_t)kQ6) {
+                            const int at = (int)b * kQ6 + wrap6((int)(old >> 16) + (int)pos);
+                            qv[at] = vbits_of(vv[j]); qk[at] = (uint16_t)(key & kmask);
+                            pending &= ~(1u << j);
+                        } else atomicSub(&s_w[b], 1u);
+                    } else
                     if (pos < (uint32_t)kQ) {
                         queue[b * kQ + (((old >> 16) + pos) & (kQ - 1))] = uint2{key, vbits_of(vv[j])};
                         pending &= ~(1u << j);
@@ -459,7 +486,39 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
             }
             // one barrier orders the enqueues before the sweep and tells whether any queue was full
             const bool full = wg_or(pending != 0, or_flags, or_phase);
+            if (C6 && full && ++n_full * 8 > batches_done) period = 1;    // workgroup-uniform: rings overflow in more than 1/8 of the batches (32 pairs
+                                                                          // of headroom are too few for this selectivity / skew): sweep every batch
             if (!(full || flush_now)) break;
+            // ---- flush (compact): 8 lanes per bucket store its complete unit, 3 x 16 bytes per lane
+            if (C6) {
+                typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+                for (int b = tid >> 3; b < P; b += kPartThreads / 8) {
+                    const uint32_t w = s_w[b];
+                    const int cnt = (int)(w & 0xFFFFu);
+                    if (cnt >= kU) {
+                        const int i = tid & 7, head = (int)(w >> 16), lc = s_lcur[b];
+                        const int iv0 = wrap6(head + 4 * i), iv1 = wrap6(head + 32 + 4 * i), ik = wrap6(head + 8 * i);
+                        const uint4 v0 = *reinterpret_cast<const uint4 *>(&qv[b * kQ6 + iv0]);
+                        const uint4 v1 = *reinterpret_cast<const uint4 *>(&qv[b * kQ6 + iv1]);
+                        const uint4 k0 = *reinterpret_cast<const uint4 *>(&qk[b * kQ6 + ik]);
+                        if (lc < cap_units) {
+                            unsigned char *dst = slab6 + (size_t)b * nwg * ((size_t)cap * 8) + (size_t)lc * kUnitBytes;
+                            __builtin_nontemporal_store(u4v{v0.x, v0.y, v0.z, v0.w}, reinterpret_cast<u4v *>(dst + 16 * i));
+                            __builtin_nontemporal_store(u4v{v1.x, v1.y, v1.z, v1.w}, reinterpret_cast<u4v *>(dst + 128 + 16 * i));
+                            __builtin_nontemporal_store(u4v{k0.x, k0.y, k0.z, k0.w}, reinterpret_cast<u4v *>(dst + 256 + 16 * i));
+                        } else {                                           // slab full: direct atomics
+                            const uint32_t kb = (uint32_t)b << shift;
+                            const uint32_t va[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+                            for (int q = 0; q < 8; q++) direct(kb | qk[b * kQ6 + (q < 4 ? iv0 + q : iv1 + q - 4)], va[q]);
+                        }
+                        if (i == 0) {
+                            s_w[b] = ((uint32_t)wrap6(head + kU) << 16) | (uint32_t)(cnt - kU);
+                            s_lcur[b] = min(lc + 1, cap_units);
+                        }
+                    }
+                }
+            } else
             // ---- flush: 8 lanes per bucket store its complete lines, 16 bytes per lane
             for (int b = tid >> 3; b < P; b += kPartThreads / 8) {
                 const uint32_t w = s_w[b];
@@ -524,6 +583,15 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
     for (int b = tid; b < P; b += kPartThreads) {
         const uint32_t w = s_w[b];
         const int l = (int)(w & 0xFFFFu), head = (int)(w >> 16);
+        if (C6) {                                                       // l < kU: the last sweep took every complete unit
+            unsigned char *dst = slab6 + (size_t)b * nwg * ((size_t)cap * 8) + (size_t)s_lcur[b] * kUnitBytes;
+            for (int j = 0; j < l; j++) {
+                const int at = b * kQ6 + wrap6(head + j);
+                reinterpret_cast<uint32_t *>(dst)[j] = qv[at]; reinterpret_cast<uint16_t *>(dst + 4 * kU)[j] = qk[at];
+            }
+            counts[(size_t)b * nwg + wg] = (uint32_t)(s_lcur[b] * kU + l);
+            continue;
+        }
         const size_t base = ((size_t)b * nwg + wg) * cap + (size_t)s_lcur[b] * kLine;
         for (int j = 0; j < l; j++) pbuf[base + j] = queue[b * kQ + ((head + j) & (kQ - 1))];
         counts[(size_t)b * nwg + wg] = (uint32_t)(s_lcur[b] * kLine + l);
@@ -579,6 +647,67 @@ __global__ __launch_bounds__(1024) void fgb_agg_kernel(
         }
         for (; i < n2; i += 64) { const uint4 q = ld(src4 + i); add(q.x, q.y); add(q.z, q.w); }
         if ((count & 1u) && lane == 0) { const uint2 q = src[count - 1]; add(q.x, q.y); }
+    }
+    __syncthreads();
+    const int64_t kbase = (int64_t)b << shift;
+    for (int i = threadIdx.x; i < KPB; i += blockDim.x) {
+        const uint32_t c = s_cnt[i];
+        if (c && kbase + i < G) {                           // this workgroup owns [kbase, kbase+KPB)
+            gsum[kbase + i] = vop_merge(VOP, gsum[kbase + i], s_sum[i]);
+            gcnt[kbase + i] += (unsigned long long)c;
+        }
+    }
+}
+
+// Consumer of the compact format: units of 64 pairs (256 B of values, 128 B of 16-bit local keys).
+// A 16-lane group takes a unit: 16 bytes of values + 8 bytes of keys per lane, two units in flight.
+template <int VOP>
+__global__ __launch_bounds__(1024) void fgb_agg6_kernel(
+    const unsigned char *__restrict__ pbuf, const uint32_t *__restrict__ counts, uint32_t cap, int nwg, int shift,
+    int64_t G, u64 *__restrict__ gsum, unsigned long long *__restrict__ gcnt)
+{
+    typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+    typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int KPB = 1 << shift;
+    u64 *s_sum = reinterpret_cast<u64 *>(lds_raw);
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(lds_raw + sizeof(u64) * KPB);
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < KPB; i += blockDim.x) { s_sum[i] = vop_identity(VOP); s_cnt[i] = 0u; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const uint32_t max_pairs = (uint32_t)((size_t)cap * 8 / kUnitBytes) * kU;
+    auto add = [&](uint32_t key, uint32_t vbits) {
+        vop_atomic<VOP>(&s_sum[key], vbits);
+        atomicAdd(&s_cnt[key], 1u);
+    };
+    auto add4 = [&](const u4v v, const u2v kk) {
+        add(kk.x & 0xFFFFu, v.x); add(kk.x >> 16, v.y); add(kk.y & 0xFFFFu, v.z); add(kk.y >> 16, v.w);
+    };
+    const int piece = lane & 15, sub = lane >> 4;
+    for (int w = wave; w < nwg; w += nwaves) {
+        const uint32_t count = min(counts[(size_t)b * nwg + w], max_pairs);
+        const unsigned char *src = pbuf + ((size_t)b * nwg + w) * ((size_t)cap * 8);
+        const uint32_t units = count / kU, rem = count % kU;
+        uint32_t u = sub;
+        for (; u + 4 < units; u += 8) {
+            const unsigned char *a = src + (size_t)u * kUnitBytes, *c = a + 4 * kUnitBytes;
+            const u4v va = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(a + 16 * piece));
+            const u2v ka = __builtin_nontemporal_load(reinterpret_cast<const u2v *>(a + 4 * kU + 8 * piece));
+            const u4v vc = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(c + 16 * piece));
+            const u2v kc = __builtin_nontemporal_load(reinterpret_cast<const u2v *>(c + 4 * kU + 8 * piece));
+            add4(va, ka); add4(vc, kc);
+        }
+        for (; u < units; u += 4) {
+            const unsigned char *a = src + (size_t)u * kUnitBytes;
+            const u4v va = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(a + 16 * piece));
+            const u2v ka = __builtin_nontemporal_load(reinterpret_cast<const u2v *>(a + 4 * kU + 8 * piece));
+            add4(va, ka);
+        }
+        if ((uint32_t)lane < rem) {
+            const unsigned char *a = src + (size_t)units * kUnitBytes;
+            add(reinterpret_cast<const uint16_t *>(a + 4 * kU)[lane], reinterpret_cast<const uint32_t *>(a)[lane]);
+        }
     }
     __syncthreads();
     const int64_t kbase = (int64_t)b << shift;
@@ -838,6 +967,7 @@ int hark_fgb_plan_set(hark_fgb_plan *pl, const char *key, int64_t value)
     else if (!strcmp(key, "timing")) { pl->timing = value; return HARK_OK; }
     else if (!strcmp(key, "vop")) { if (value < 0 || value > 5) return HARK_EARG; pl->vop = value; return HARK_OK; }   // reset afterwards
     else if (!strcmp(key, "xform")) { if (value < 0 || value > 2) return HARK_EARG; pl->xform = value; return HARK_OK; }
+    else if (!strcmp(key, "pairfmt")) { if (value < 0 || value > 2) return HARK_EARG; pl->pairfmt = value; return HARK_OK; }   // 0 auto, 1: 8-byte pairs, 2: compact 6-byte units
     else if (!strcmp(key, "ablate")) { pl->ablate = value; return HARK_OK; }   // timing experiments only: wrong results
     else return HARK_EARG;
     plan_drop_partition(pl);     // partition geometry depends on the knobs
@@ -967,28 +1097,41 @@ int k_fgb_dense_f32(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cm
             });
             if (rc) return rc;
         }
-        const size_t lds_part = part_lds_bytes(P);
+        const bool c6 = pl->pairfmt != 1;                             // compact 6-byte pairs unless the 8-byte format is asked for
+        const size_t lds_part = part_lds_bytes(P, c6);
         const bool fast = vop == VOP_F32SUM && pl->xform == 0;       // the headline operator is compiled in
-        HIP_TRY(ctx, hipFuncSetAttribute(fast ? reinterpret_cast<const void *>(&fgb_part_kernel<OP, 0>) : reinterpret_cast<const void *>(&fgb_part_kernel<OP, 1>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part));
+        const void *fn = fast ? (c6 ? reinterpret_cast<const void *>(&fgb_part_kernel<OP, 0, true>) : reinterpret_cast<const void *>(&fgb_part_kernel<OP, 0, false>))
+                              : (c6 ? reinterpret_cast<const void *>(&fgb_part_kernel<OP, 1, true>) : reinterpret_cast<const void *>(&fgb_part_kernel<OP, 1, false>));
+        HIP_TRY(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part));
+        if (lds_agg > 64 * 1024) {
+            int rc6 = dispatch_vop(vop, [&](auto vopc) -> int {
+                HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_agg6_kernel<decltype(vopc)::value>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_agg));
+                return HARK_OK;
+            });
+            if (rc6) return rc6;
+        }
         for (int64_t r0 = 0; r0 < n; r0 += pl->chunk_rows) {
             const int64_t r1 = r0 + pl->chunk_rows < n ? r0 + pl->chunk_rows : n;
             {
                 TimedLaunch tl(pl, st, 1);
                 const int period = (int)((pl->ablate >> 12) & 15);            // experiments: batches between sweeps (0 = default)
-                if (fast)
-                    fgb_part_kernel<OP, 0><<<dim3((unsigned)nwg), dim3(kPartThreads), lds_part, st>>>(
-                        p, k, v, r0, r1, thr, G, shift, P, pl->pbuf, pl->counts, (uint32_t)pl->cap, gsum, gcnt, pl->err, period, vop, (int)pl->xform, 0);
-                else
-                    fgb_part_kernel<OP, 1><<<dim3((unsigned)nwg), dim3(kPartThreads), lds_part, st>>>(
-                        p, k, v, r0, r1, thr, G, shift, P, pl->pbuf, pl->counts, (uint32_t)pl->cap, gsum, gcnt, pl->err, period, vop, (int)pl->xform, 0);
+#define HARK_LAUNCH_PART(MODE, C6FLAG) fgb_part_kernel<OP, MODE, C6FLAG><<<dim3((unsigned)nwg), dim3(kPartThreads), lds_part, st>>>( \
+                    p, k, v, r0, r1, thr, G, shift, P, pl->pbuf, pl->counts, (uint32_t)pl->cap, gsum, gcnt, pl->err, period, vop, (int)pl->xform, 0)
+                if (fast) { if (c6) HARK_LAUNCH_PART(0, true); else HARK_LAUNCH_PART(0, false); }
+                else { if (c6) HARK_LAUNCH_PART(1, true); else HARK_LAUNCH_PART(1, false); }
+#undef HARK_LAUNCH_PART
             }
             HIP_TRY(ctx, hipGetLastError());
             {
                 TimedLaunch tl(pl, st, 2);
                 int rc = dispatch_vop(vop, [&](auto vopc) -> int {
-                    fgb_agg_kernel<decltype(vopc)::value><<<dim3((unsigned)P), dim3(1024), lds_agg, st>>>(
-                        pl->pbuf, pl->counts, (uint32_t)pl->cap, nwg, shift, G, gsum, gcnt, (int)pl->ablate);
+                    if (c6)
+                        fgb_agg6_kernel<decltype(vopc)::value><<<dim3((unsigned)P), dim3(1024), lds_agg, st>>>(
+                            reinterpret_cast<const unsigned char *>(pl->pbuf), pl->counts, (uint32_t)pl->cap, nwg, shift, G, gsum, gcnt);
+                    else
+                        fgb_agg_kernel<decltype(vopc)::value><<<dim3((unsigned)P), dim3(1024), lds_agg, st>>>(
+                            pl->pbuf, pl->counts, (uint32_t)pl->cap, nwg, shift, G, gsum, gcnt, (int)pl->ablate);
                     return HARK_OK;
                 });
                 if (rc) return rc;
@@ -1113,11 +1256,11 @@ int k_fgb_hash_u32(hark_context *ctx, const uint32_t *k, const uint32_t *v, int6
     uint32_t used_R = 1;
     if (!rc) {
         hipMemsetAsync(err, 0, 16, st);
-        const size_t lds_part = part_lds_bytes(P);
-        rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_part_kernel<kNoPred, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part) == hipSuccess
+        const size_t lds_part = part_lds_bytes(P, false);
+        rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_part_kernel<kNoPred, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part) == hipSuccess
                  ? HARK_OK : hark_fail(ctx, HARK_EHIP, "hash group-by: LDS attribute failed");
         if (!rc) {
-            fgb_part_kernel<kNoPred, 2><<<dim3((unsigned)nwg), dim3(kPartThreads), lds_part, st>>>(
+            fgb_part_kernel<kNoPred, 2, false><<<dim3((unsigned)nwg), dim3(kPartThreads), lds_part, st>>>(
                 nullptr, reinterpret_cast<const int32_t *>(k), reinterpret_cast<const float *>(v), 0, n, 0.0f, (int64_t)1 << 32, 0, P,
                 pbuf, counts, (uint32_t)cap, nullptr, nullptr, err, 0, vop, xf, hash_bits);
             rc = read_err(&e);
