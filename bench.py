@@ -162,7 +162,7 @@ def main():
         rows_per_launch = N * a.steps / dom_launches          # a chunked producer sees chunk_rows per launch
         alg_bytes = 12.0 * rows_per_launch + (16.0 * G if dom != "producer" else 0.0)
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
-        kernel_name = {"single": "fgb_lds_kernel", "producer": "fgb_part_kernel", "consumer": "fgb_agg_kernel"}[dom]
+        kernel_name = {"single": "fgb_lds_kernel", "producer": "fgb_part_kernel", "consumer": "fgb_agg6_kernel"}[dom]
         # HBM traffic of the dominant kernel from the committed PMC passes of this same workload
         # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled per the gfx950 note)
         traffic, traffic_src = None, None

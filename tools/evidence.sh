@@ -1,6 +1,6 @@
 set -x
 export TMPDIR=/tmp
-O=gpurun_out/ev2; rm -rf $O; mkdir -p $O
+O=gpurun_out/ev2; rm -rf $O; mkdir -p $O   # gpurun merges into the local copy: stale files of earlier runs are removed below
 timeout 600 python bench.py > $O/bench_plain.json 2> $O/bench_plain.err
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 10 --warmup 3 --cpu-rows 0 > $O/bench_rocprof.json 2> $O/bench_rocprof.err
 timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --cpu-rows 0 > $O/pmc_fetch.json 2> $O/pmc_fetch.err
