@@ -15,12 +15,18 @@
 //       exactly the reference's order with no sequential step, and skewed keys
 //       cost nothing extra because work is split by output row.
 //   hark_entry_sort  ORDER BY one column (README.md:15 lists it; the reference
-//       has no implementation): stable argsort + gather of the projected columns.
+//       has no implementation): stable radix sort of the key's sort words; a u32 / i32
+//       key column in the output comes back from the sorted words, a single other 4-byte
+//       column travels with the keys as the payload, anything else is gathered through
+//       the row-id permutation.
 #include "hark_internal.h"
 
 int k_argsort_column(hark_context *ctx, const void *col, int dtype, int64_t n, bool descending,
                      uint32_t **perm_out, uint32_t **sorted_words_out);
 int k_gather(hark_context *ctx, const void *src, int esz, const uint32_t *idx, void *dst, int64_t n);
+int k_sort_column(hark_context *ctx, const void *col, int dtype, int64_t n, bool descending, const uint32_t *payload,
+                  uint32_t **vals_out, uint32_t **words_out);
+int k_untransform_keys(hark_context *ctx, const uint32_t *words, int dtype, void *dst, int64_t n);
 int k_exclusive_scan_u32(hark_context *ctx, const uint32_t *in, int64_t n, uint32_t *out32, int64_t *out64, int64_t *total_host);
 
 namespace {
@@ -206,15 +212,41 @@ int hark_entry_sort(hark_context *ctx, hark_result **out, const hark_table *db, 
     res->n = db->n; res->cols.resize((size_t)k);
     for (int64_t j = 0; j < k; j++) { res->cols[j].dtype = db->cols[cols[j]].dtype; res->cols[j].data = nullptr; res->cols[j].owned = db->n > 0; }
     if (db->n == 0) { *out = res; return HARK_OK; }
-    uint32_t *perm = nullptr;
-    int rc = k_argsort_column(ctx, db->cols[key_col].data, db->cols[key_col].dtype, db->n, descending != 0, &perm, nullptr);
+    // Output columns that ARE the (u32 / i32) key come straight from the sorted sort words; if exactly one other
+    // 4-byte column is asked for it travels with the keys as the payload (no row ids, no gather); otherwise the
+    // payload is the row id and every other column is gathered through it.
+    const int kdt = db->cols[key_col].dtype;
+    const bool key_from_words = kdt == HARK_U32 || kdt == HARK_I32;
+    int carry = -1, others = 0;
+    for (int64_t j = 0; j < k; j++) {
+        if (cols[j] == key_col && key_from_words) continue;
+        bool seen = false;
+        for (int64_t q = 0; q < j; q++) seen = seen || cols[q] == cols[j];
+        if (!seen) { others++; carry = cols[j]; }
+    }
+    const bool carried = others == 1 && kdt != HARK_I64 && hark_dtype_size(db->cols[carry].dtype) == 4;
+    uint32_t *perm = nullptr, *words = nullptr;
+    int rc = k_sort_column(ctx, db->cols[key_col].data, kdt, db->n, descending != 0,
+                           carried ? static_cast<const uint32_t *>(db->cols[carry].data) : nullptr, &perm, key_from_words ? &words : nullptr);
     for (int64_t j = 0; j < k && !rc; j++) {
         const int esz = (int)hark_dtype_size(res->cols[j].dtype);
+        if (carried && cols[j] == carry && perm) {                       // the sorted payload is the column (first use takes the buffer)
+            bool first_use = true;
+            for (int64_t q = 0; q < j; q++) first_use = first_use && cols[q] != carry;
+            if (first_use) { res->cols[j].data = perm; continue; }
+        }
         rc = hark_alloc(ctx, &res->cols[j].data, (size_t)db->n * esz);
-        if (!rc) rc = k_gather(ctx, db->cols[cols[j]].data, esz, perm, res->cols[j].data, db->n);
+        if (rc) break;
+        if (cols[j] == key_col && key_from_words) rc = k_untransform_keys(ctx, words, kdt, res->cols[j].data, db->n);
+        else if (carried && cols[j] == carry) rc = hipMemcpyAsync(res->cols[j].data, perm, (size_t)db->n * 4, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess
+                                                       ? HARK_OK : hark_fail(ctx, HARK_EHIP, "sort: copy failed");
+        else rc = k_gather(ctx, db->cols[cols[j]].data, esz, perm, res->cols[j].data, db->n);
     }
     if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "sort: kernels failed");
-    hark_free(ctx, perm);
+    bool perm_taken = false;
+    for (auto &c : res->cols) perm_taken = perm_taken || c.data == perm;
+    if (!perm_taken) hark_free(ctx, perm);
+    hark_free(ctx, words);
     if (rc) { result_release(ctx, res); return rc; }
     *out = res;
     return HARK_OK;

@@ -202,25 +202,52 @@ __global__ __launch_bounds__(kSortThreads) void digit_scatter_kernel(
     }
 }
 
-__global__ __launch_bounds__(256) void transform_keys_kernel(const void *__restrict__ src, int dtype, int part, uint32_t *__restrict__ dst, int64_t n)
+__device__ __forceinline__ uint32_t sort_word(const void *src, int dtype, int part, int64_t i)
 {
     // part 0: the (only / low) 32-bit sort word, part 1: the high word of an i64.
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        uint32_t w;
-        if (dtype == HARK_I64) {
-            const uint64_t x = static_cast<const uint64_t *>(src)[i] ^ 0x8000000000000000ull;
-            w = part ? (uint32_t)(x >> 32) : (uint32_t)x;
-        } else {
-            w = static_cast<const uint32_t *>(src)[i];
-            if (dtype == HARK_I32) w ^= 0x80000000u;
-            else if (dtype == HARK_F32) {
-                if (w == 0x80000000u) w = 0u;                                  // -0.0 == +0.0
-                w ^= (w & 0x80000000u) ? 0xFFFFFFFFu : 0x80000000u;            // IEEE order as unsigned order
-            }
-        }
-        dst[i] = w;
+    if (dtype == HARK_I64) {
+        const uint64_t x = static_cast<const uint64_t *>(src)[i] ^ 0x8000000000000000ull;
+        return part ? (uint32_t)(x >> 32) : (uint32_t)x;
     }
+    uint32_t w = static_cast<const uint32_t *>(src)[i];
+    if (dtype == HARK_I32) w ^= 0x80000000u;
+    else if (dtype == HARK_F32) {
+        if (w == 0x80000000u) w = 0u;                                  // -0.0 == +0.0
+        w ^= (w & 0x80000000u) ? 0xFFFFFFFFu : 0x80000000u;            // IEEE order as unsigned order
+    }
+    return w;
+}
+
+// dst[i] = sort word of src[i]; *diff |= bits in which any word differs from the first one (a radix pass
+// over a byte in which all keys agree is the identity permutation and is skipped).
+__global__ __launch_bounds__(256) void transform_keys_kernel(const void *__restrict__ src, int dtype, int part, uint32_t *__restrict__ dst, int64_t n,
+                                                             uint32_t *__restrict__ diff)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const uint32_t w0 = sort_word(src, dtype, part, 0);
+    uint32_t acc = 0u;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t w = sort_word(src, dtype, part, i);
+        dst[i] = w; acc |= w ^ w0;
+    }
+    if (diff) {
+        for (int d = 32; d > 0; d >>= 1) acc |= __shfl_xor(acc, d, 64);
+        if ((threadIdx.x & 63) == 0 && acc) atomicOr(diff, acc);
+    }
+}
+
+// Sorted sort words back to column values (u32 / i32 keys only: the f32 transform folds -0.0 into +0.0).
+__global__ __launch_bounds__(256) void untransform_keys_kernel(const uint32_t *__restrict__ words, int dtype, uint32_t *__restrict__ dst, int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const uint32_t flip = dtype == HARK_I32 ? 0x80000000u : 0u;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = words[i] ^ flip;
+}
+
+__global__ __launch_bounds__(256) void iota_u32_kernel(uint32_t *__restrict__ dst, int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = (uint32_t)i;
 }
 
 __global__ __launch_bounds__(256) void gather_u32_kernel(const uint32_t *__restrict__ src, const uint32_t *__restrict__ idx,
@@ -248,13 +275,23 @@ size_t k_sort_workspace_bytes(int64_t n, int num_cu)
     return (size_t)kBins * ((size_t)nblk + 1) * sizeof(uint32_t);      // histograms + the 256 digit totals
 }
 
-// Stable sort of n (key, val) pairs ascending by (key ^ xor_mask) as unsigned.
-// keys/vals hold the input and receive the output; keys_tmp/vals_tmp are
-// scratch of the same size.  vals_is_iota: payload of the input is the position
-// (vals need not be initialised).  n < 2^32.
-int k_sort_pairs_u32(hark_context *ctx, uint32_t *keys, uint32_t *vals, uint32_t *keys_tmp, uint32_t *vals_tmp,
-                     int64_t n, uint32_t xor_mask, bool vals_is_iota, uint32_t *hist_ws, int passes = 4)
+static int64_t grid256(hark_context *ctx, int64_t n)
 {
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > (int64_t)ctx->num_cu * 16) blocks = (int64_t)ctx->num_cu * 16;
+    return blocks < 1 ? 1 : blocks;
+}
+
+// Stable sort of n (key, val) pairs ascending by (key ^ xor_mask) as unsigned.  keys_a holds the input keys;
+// keys_b, vals_a, vals_b are scratch of the same size.  The payload of the input is `vals_first` (device, read
+// only, may be a table column) or, when null, the input position.  Only the 8-bit passes whose bit is set in
+// pass_mask run (bit b = byte b of the key).  On return *keys_out / *vals_out point at the buffers (among the
+// four) that hold the result.  n < 2^32.
+int k_sort_pairs_u32(hark_context *ctx, uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, uint32_t *vals_b,
+                     const uint32_t *vals_first, int64_t n, uint32_t xor_mask, uint32_t *hist_ws, uint32_t pass_mask,
+                     uint32_t **keys_out, uint32_t **vals_out)
+{
+    *keys_out = keys_a; *vals_out = vals_a;
     if (n <= 0) return HARK_OK;
     if (n > 0xFFFFFFFFll) return hark_fail(ctx, HARK_EARG, "sort: at most 2^32-1 rows");
     int64_t nblk = (n + kSortTile - 1) / kSortTile;
@@ -263,53 +300,77 @@ int k_sort_pairs_u32(hark_context *ctx, uint32_t *keys, uint32_t *vals, uint32_t
     slice = (slice + kSortTile - 1) / kSortTile * kSortTile;      // whole tiles per slice
     nblk = (n + slice - 1) / slice;
     hipStream_t st = ctx->stream;
-    uint32_t *kin = keys, *vin = vals, *kout = keys_tmp, *vout = vals_tmp;
-    for (int pass = 0; pass < passes; pass++) {
+    const uint32_t *kin = keys_a, *vin = vals_first;
+    uint32_t *kout = keys_b, *vout = vals_b;
+    bool first = true;
+    for (int pass = 0; pass < 4; pass++) {
+        if (!((pass_mask >> pass) & 1u)) continue;
         const int shift = pass * 8;
         digit_hist_kernel<<<dim3((unsigned)nblk), dim3(kSortThreads), 0, st>>>(kin, n, slice, shift, xor_mask, hist_ws, (int)nblk);
         scan_hist_rows_kernel<<<kBins, 256, 0, st>>>(hist_ws, (int)nblk, hist_ws + (size_t)kBins * nblk);
         digit_scatter_kernel<<<dim3((unsigned)nblk), dim3(kSortThreads), 0, st>>>(
-            kin, (pass == 0 && vals_is_iota) ? nullptr : vin, kout, vout, n, slice, shift, xor_mask, hist_ws, (int)nblk,
-            hist_ws + (size_t)kBins * nblk);
+            kin, vin, kout, vout, n, slice, shift, xor_mask, hist_ws, (int)nblk, hist_ws + (size_t)kBins * nblk);
         HIP_TRY(ctx, hipGetLastError());
-        uint32_t *t = kin; kin = kout; kout = t;
-        t = vin; vin = vout; vout = t;
+        *keys_out = kout; *vals_out = vout;
+        kin = kout; vin = vout;
+        kout = (kout == keys_b) ? keys_a : keys_b;
+        vout = (vout == vals_b) ? vals_a : vals_b;
+        first = false;
     }
-    // an even number of passes leaves the result in keys / vals, an odd number in keys_tmp / vals_tmp
+    if (first) {                                                   // no pass ran: the order is the input order
+        if (vals_first) HIP_TRY(ctx, hipMemcpyAsync(vals_a, vals_first, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+        else { iota_u32_kernel<<<dim3((unsigned)grid256(ctx, n)), dim3(256), 0, st>>>(vals_a, n); HIP_TRY(ctx, hipGetLastError()); }
+    }
     return HARK_OK;
 }
 
-int k_transform_keys(hark_context *ctx, const void *src, int dtype, int part, uint32_t *dst, int64_t n)
+// dst = sort words of a column; *diff_host (optional) receives the bits in which the words differ.
+int k_transform_keys(hark_context *ctx, const void *src, int dtype, int part, uint32_t *dst, int64_t n, uint32_t *diff_host)
 {
+    if (diff_host) *diff_host = 0u;
     if (n <= 0) return HARK_OK;
-    int64_t blocks = (n + 255) / 256;
-    if (blocks > (int64_t)ctx->num_cu * 16) blocks = (int64_t)ctx->num_cu * 16;
-    transform_keys_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(src, dtype, part, dst, n);
-    HIP_TRY(ctx, hipGetLastError());
-    return HARK_OK;
+    uint32_t *diff = nullptr;
+    if (diff_host) {
+        HARK_TRY(hark_alloc(ctx, (void **)&diff, 16));
+        if (hipMemsetAsync(diff, 0, 16, ctx->stream) != hipSuccess) { hark_free(ctx, diff); return hark_fail(ctx, HARK_EHIP, "sort: memset failed"); }
+    }
+    transform_keys_kernel<<<dim3((unsigned)grid256(ctx, n)), dim3(256), 0, ctx->stream>>>(src, dtype, part, dst, n, diff);
+    int rc = hipGetLastError() == hipSuccess ? HARK_OK : hark_fail(ctx, HARK_EHIP, "sort: transform failed");
+    if (!rc && diff_host) { int64_t w = 0; rc = hark_read_words(ctx, diff, &w, 1); *diff_host = (uint32_t)w; }
+    if (diff) hark_free(ctx, diff);
+    return rc;
+}
+
+static uint32_t passes_of(uint32_t diff)
+{
+    uint32_t m = 0;
+    for (int b = 0; b < 4; b++) if ((diff >> (8 * b)) & 0xFFu) m |= 1u << b;
+    return m;
 }
 
 int k_gather(hark_context *ctx, const void *src, int esz, const uint32_t *idx, void *dst, int64_t n)
 {
     if (n <= 0) return HARK_OK;
-    int64_t blocks = (n + 255) / 256;
-    if (blocks > (int64_t)ctx->num_cu * 16) blocks = (int64_t)ctx->num_cu * 16;
+    const int64_t blocks = grid256(ctx, n);
     if (esz == 4) gather_u32_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(static_cast<const uint32_t *>(src), idx, static_cast<uint32_t *>(dst), n);
     else gather_u64_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(static_cast<const uint64_t *>(src), idx, static_cast<uint64_t *>(dst), n);
     HIP_TRY(ctx, hipGetLastError());
     return HARK_OK;
 }
 
-// Stable argsort of a column of any supported dtype.  On return *perm_out
-// (hipMalloc'd, n x u32, caller frees) lists row ids in sorted order; if
-// sorted_keys_out is non-null it receives the sorted 32-bit sort words of the
-// column (u32/i32/f32 only; transformed: use for equality tests only).
-int k_argsort_column(hark_context *ctx, const void *col, int dtype, int64_t n, bool descending,
-                     uint32_t **perm_out, uint32_t **sorted_words_out)
+// Stable sort of a column of any supported dtype together with a 32-bit payload.  payload == nullptr: the
+// payload is the row id (an argsort); otherwise a device column of n 4-byte values (only for 4-byte keys), which
+// travels with the keys so that no gather is needed afterwards.  On return *vals_out (pool block, n x u32, caller
+// frees) holds the payload in sorted order; if words_out is non-null it receives the sorted 32-bit sort words
+// (u32 / i32 / f32 keys only; k_untransform_keys turns u32 / i32 words back into values).  Radix passes over key
+// bytes in which all keys agree are skipped.
+int k_sort_column(hark_context *ctx, const void *col, int dtype, int64_t n, bool descending, const uint32_t *payload,
+                  uint32_t **vals_out, uint32_t **words_out)
 {
-    *perm_out = nullptr;
-    if (sorted_words_out) *sorted_words_out = nullptr;
+    *vals_out = nullptr;
+    if (words_out) *words_out = nullptr;
     if (n <= 0) return HARK_OK;
+    if (payload && dtype == HARK_I64) return hark_fail(ctx, HARK_EARG, "sort: payload-carrying sort needs a 4-byte key");
     uint32_t *k0 = nullptr, *k1 = nullptr, *v0 = nullptr, *v1 = nullptr, *ws = nullptr;
     const size_t b = (size_t)n * 4;
     int rc = hark_alloc(ctx, (void **)&k0, b);
@@ -318,20 +379,49 @@ int k_argsort_column(hark_context *ctx, const void *col, int dtype, int64_t n, b
     if (!rc) rc = hark_alloc(ctx, (void **)&v1, b);
     if (!rc) rc = hark_alloc(ctx, (void **)&ws, k_sort_workspace_bytes(n, ctx->num_cu));
     const uint32_t xm = descending ? 0xFFFFFFFFu : 0u;
-    if (!rc) rc = k_transform_keys(ctx, col, dtype, 0, k0, n);
-    if (!rc) rc = k_sort_pairs_u32(ctx, k0, v0, k1, v1, n, xm, true, ws);
+    uint32_t diff = 0u, *ko = k0, *vo = v0;
+    if (!rc) rc = k_transform_keys(ctx, col, dtype, 0, k0, n, &diff);
+    if (!rc) rc = k_sort_pairs_u32(ctx, k0, k1, v0, v1, payload, n, xm, ws, passes_of(diff), &ko, &vo);
     if (!rc && dtype == HARK_I64) {
-        // LSD over 64 bits: after the low word, sort (stably) by the high word
-        // gathered through the current permutation.
-        rc = k_transform_keys(ctx, col, dtype, 1, k1, n);
-        if (!rc) rc = k_gather(ctx, k1, 4, v0, k0, n);
-        if (!rc) rc = k_sort_pairs_u32(ctx, k0, v0, k1, v1, n, xm, false, ws);
+        // LSD over 64 bits: after the low word, sort (stably) by the high word gathered through the current
+        // permutation; the permutation travels as the payload.
+        uint32_t *kf = (ko == k0) ? k1 : k0, *vf = (vo == v0) ? v1 : v0;           // the free buffer of each pair
+        rc = k_transform_keys(ctx, col, dtype, 1, ko, n, &diff);                   // ko's sorted low words are no longer needed
+        if (!rc) rc = k_gather(ctx, ko, 4, vo, kf, n);
+        uint32_t *ko2 = kf, *vo2 = vo;
+        // buffers: keys in kf (scratch ko), payload = vo (read only in the first pass, then ping-pong vf <-> vo)
+        if (!rc) {
+            if (passes_of(diff) == 0u) { ko2 = kf; vo2 = vo; }
+            else rc = k_sort_pairs_u32(ctx, kf, ko, vo, vf, vo, n, xm, ws, passes_of(diff), &ko2, &vo2);
+        }
+        ko = ko2; vo = vo2;
     }
     if (rc == HARK_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "sort kernels failed");
-    hark_free(ctx, k1); hark_free(ctx, v1); hark_free(ctx, ws);
-    if (rc) { hark_free(ctx, k0); hark_free(ctx, v0); return rc; }
-    *perm_out = v0;
-    if (sorted_words_out && dtype != HARK_I64) *sorted_words_out = k0; else hark_free(ctx, k0);
+    uint32_t *bufs[4] = {k0, k1, v0, v1};
+    for (uint32_t *q : bufs) {
+        if (!q) continue;
+        if (!rc && q == vo) continue;
+        if (!rc && q == ko && words_out && dtype != HARK_I64) continue;
+        hark_free(ctx, q);
+    }
+    hark_free(ctx, ws);
+    if (rc) return rc;
+    *vals_out = vo;
+    if (words_out && dtype != HARK_I64) *words_out = ko;
+    return HARK_OK;
+}
+
+int k_argsort_column(hark_context *ctx, const void *col, int dtype, int64_t n, bool descending,
+                     uint32_t **perm_out, uint32_t **sorted_words_out)
+{
+    return k_sort_column(ctx, col, dtype, n, descending, nullptr, perm_out, sorted_words_out);
+}
+
+int k_untransform_keys(hark_context *ctx, const uint32_t *words, int dtype, void *dst, int64_t n)
+{
+    if (n <= 0) return HARK_OK;
+    untransform_keys_kernel<<<dim3((unsigned)grid256(ctx, n)), dim3(256), 0, ctx->stream>>>(words, dtype, static_cast<uint32_t *>(dst), n);
+    HIP_TRY(ctx, hipGetLastError());
     return HARK_OK;
 }
 
@@ -395,7 +485,8 @@ int partition_by_dest(hark_context *ctx, uint32_t *dest, int64_t n, int nparts, 
     if (!rc) rc = hark_alloc(ctx, (void **)&vtmp, (size_t)n * 4);
     if (!rc) rc = hark_alloc(ctx, (void **)&ws, k_sort_workspace_bytes(n, ctx->num_cu));
     // the permutation lands in perm_out (the "tmp" side of a one-pass sort)
-    if (!rc) rc = k_sort_pairs_u32(ctx, dest, vtmp, dtmp, perm_out, n, 0u, true, ws, 1);
+    uint32_t *ko = nullptr, *vo = nullptr;
+    if (!rc) rc = k_sort_pairs_u32(ctx, dest, dtmp, vtmp, perm_out, nullptr, n, 0u, ws, 1u, &ko, &vo);   // one pass: the payload lands in vals_b = perm_out
     if (!rc) {
         // the digit totals of the pass are the part sizes (ws: 256*nblk histogram, then 256 totals)
         int64_t nblk = (n + kSortTile - 1) / kSortTile;

@@ -170,3 +170,43 @@ def test_sort_is_stable_and_ordered(eng, oracle, dtype, descending, n):
     assert np.array_equal(r2, rowid[perm]) and np.array_equal(k2, key.astype(dtype)[perm])
     if dtype == np.uint32 and not descending:
         assert np.array_equal(r2, oracle.argsort_u32(key).astype(np.int32))    # the reference's 32-pass sort order
+
+
+@pytest.mark.parametrize("dtype", [np.uint32, np.int32, np.float32])
+@pytest.mark.parametrize("cols", [[0], [1], [1, 0, 1, 0], [2, 1], [0, 1, 2], [2, 0, 0]])
+@pytest.mark.parametrize("descending", [False, True])
+def test_sort_projections(eng, dtype, cols, descending):
+    """Every way ORDER BY produces its columns: the key from the sorted sort words, one carried
+    payload column, gathers through the permutation, repeated columns."""
+    rng = np.random.default_rng(17)
+    n = 70_003
+    if dtype == np.float32:
+        key = rng.integers(-40, 40, size=n).astype(np.float32) / 4
+        key[::97] = -0.0
+        key[1::97] = 0.0
+    else:
+        key = rng.integers(0, 1 << 20, size=n).astype(dtype) - (dtype(1 << 19) if dtype == np.int32 else dtype(0))
+    a = rng.integers(-1000, 1000, size=n).astype(np.int32)
+    b = rng.random(n).astype(np.float32)
+    t = eng.table_from_columns([key, a, b])
+    res = eng.sort(t, 0, cols, descending=descending)
+    order = key.astype(np.float64)
+    perm = np.argsort(-order if descending else order, kind="stable")
+    src = [key, a, b]
+    for j, c in enumerate(cols):
+        got, exp = res.column(j), src[c][perm]
+        assert got.dtype == exp.dtype
+        assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), (cols, j)     # bit-exact, -0.0 stays -0.0
+
+
+@pytest.mark.parametrize("dtype", [np.uint32, np.float32, np.int64])
+def test_sort_constant_key_is_identity(eng, dtype):
+    """All keys equal: no radix pass runs, rows keep table order."""
+    n = 20_000
+    key = np.full(n, 7, dtype=dtype)
+    a = np.arange(n, dtype=np.int32)[::-1].copy()
+    t = eng.table_from_columns([key, a])
+    for cols in ([0, 1], [1], [1, 1, 0]):
+        res = eng.sort(t, 0, cols, descending=True)
+        for j, c in enumerate(cols):
+            assert np.array_equal(res.column(j), [key, a][c])
