@@ -94,6 +94,107 @@ __global__ __launch_bounds__(256) void join_expand_kernel(const int64_t *__restr
     }
 }
 
+
+// ---- semi-join pre-filter ------------------------------------------------------------
+// When the probe side is much larger than the build side, most probe rows usually have no partner.  A bitmap
+// of hashed build keys (16 bits per build key, false positives ~6 %) is tested for every probe row in TABLE
+// order; the survivors' (key, row id) pairs are compacted, order kept, and only they are sorted and merged.
+// False positives simply count zero partners, so the result is the same row for row.
+__device__ __forceinline__ uint32_t jmix32(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ uint32_t key_hash(uint32_t k) { return jmix32(k); }
+__device__ __forceinline__ uint32_t key_hash(uint64_t k) { return jmix32((uint32_t)k ^ jmix32((uint32_t)(k >> 32))); }
+
+template <typename K>
+__global__ __launch_bounds__(256) void bitmap_build_kernel(const K *__restrict__ keys, int64_t s, uint32_t *__restrict__ bitmap, uint32_t bitmask)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < s; i += stride) {
+        const uint32_t h = key_hash(keys[i]) & bitmask;
+        atomicOr(&bitmap[h >> 5], 1u << (h & 31u));
+    }
+}
+
+constexpr int kSemiThreads = 256, kSemiTile = kSemiThreads * 16;       // a thread owns 4 groups of 4 consecutive rows
+template <typename K>
+__device__ __forceinline__ uint32_t semi_mask(const K *__restrict__ keys, int64_t n, int64_t tile, const uint32_t *__restrict__ bitmap, uint32_t bitmask)
+{
+    uint32_t mask = 0;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const int64_t r = tile * kSemiTile + ((int64_t)g * kSemiThreads + threadIdx.x) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (r + j < n) {
+                const uint32_t h = key_hash(keys[r + j]) & bitmask;
+                mask |= ((bitmap[h >> 5] >> (h & 31u)) & 1u) << (g * 4 + j);
+            }
+        }
+    }
+    return mask;
+}
+
+template <typename K>
+__global__ __launch_bounds__(kSemiThreads) void semi_count_kernel(const K *__restrict__ keys, int64_t n, const uint32_t *__restrict__ bitmap, uint32_t bitmask,
+                                                                  uint16_t *__restrict__ masks, uint32_t *__restrict__ counts)
+{
+    __shared__ uint32_t s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    const int64_t tile = blockIdx.x;
+    const uint32_t mask = semi_mask<K>(keys, n, tile, bitmap, bitmask);
+    masks[tile * kSemiThreads + threadIdx.x] = (uint16_t)mask;
+    uint32_t cnt = __popc(mask);
+    for (int d = 32; d > 0; d >>= 1) cnt += __shfl_down(cnt, d, 64);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&s_cnt, cnt);
+    __syncthreads();
+    if (threadIdx.x == 0) counts[tile] = s_cnt;
+}
+
+template <typename K>
+__global__ __launch_bounds__(kSemiThreads) void semi_scatter_kernel(const K *__restrict__ keys, int64_t n, const uint16_t *__restrict__ masks,
+                                                                    const int64_t *__restrict__ offsets, K *__restrict__ out_keys, uint32_t *__restrict__ out_rows)
+{
+    __shared__ uint32_t s_wcnt[4][4];                 // [group][wave] survivors
+    const int64_t tile = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t mask = masks[tile * kSemiThreads + threadIdx.x];
+    uint32_t lane_excl[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const uint32_t cnt = __popc((mask >> (g * 4)) & 15u);
+        uint32_t incl = cnt;
+        for (int d = 1; d < 64; d <<= 1) { uint32_t y = __shfl_up(incl, d, 64); if (lane >= d) incl += y; }
+        lane_excl[g] = incl - cnt;
+        if (lane == 63) s_wcnt[g][wave] = incl;
+    }
+    __syncthreads();
+    int64_t run = offsets[tile];
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) { const uint32_t x = s_wcnt[g][w]; if (w < wave) before += x; total += x; }
+        const uint32_t m4 = (mask >> (g * 4)) & 15u;
+        if (m4) {
+            int64_t q = run + before + lane_excl[g];
+            const int64_t r = tile * kSemiTile + ((int64_t)g * kSemiThreads + threadIdx.x) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; j++) if (m4 & (1u << j)) { out_keys[q] = keys[r + j]; out_rows[q] = (uint32_t)(r + j); q++; }
+        }
+        run += total;
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_u32_via_kernel(const uint32_t *__restrict__ src, const uint32_t *__restrict__ idx, uint32_t *__restrict__ dst, int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[idx[i]];
+}
+
 // i64 keys gathered into sorted order, biased so that unsigned comparison is signed order
 __global__ __launch_bounds__(256) void gather_biased_i64_kernel(const uint64_t *__restrict__ src, const uint32_t *__restrict__ perm,
                                                                 uint64_t *__restrict__ dst, int64_t n)
@@ -149,23 +250,78 @@ int hark_entry_join(hark_context *ctx, hark_result **out, const hark_table *db1,
     hipStream_t st = ctx->stream;
     // keys as u32 whatever the declared signedness (join.fut:52 types both tables u32)
     uint64_t *lk64 = nullptr, *rk64 = nullptr;
-    int rc = k_argsort_column(ctx, db1->cols[col1].data, k64 ? HARK_I64 : HARK_U32, n, false, &lperm, k64 ? nullptr : &lkeys);
-    if (!rc) rc = k_argsort_column(ctx, db2->cols[col2].data, k64 ? HARK_I64 : HARK_U32, s, false, &rperm, k64 ? nullptr : &rkeys);
+    int rc = HARK_OK;
+    int64_t nl = n;                                   // left rows that reach the sort + merge
+    const void *lcol = db1->cols[col1].data, *rcol = db2->cols[col2].data;
+    bool filtered = false;
+    if (n >= ((int64_t)1 << 20) && n >= 4 * s) {
+        // semi-join pre-filter (see the kernels above): bitmap of 16 bits per build key, power of two, <= 2^31 bits
+        uint32_t lgb = 16;
+        while (lgb < 31 && ((int64_t)1 << lgb) < 16 * s) lgb++;
+        const uint32_t bitmask = (uint32_t)(((uint64_t)1 << lgb) - 1u);
+        const int64_t ntiles = (n + kSemiTile - 1) / kSemiTile;
+        uint32_t *bitmap = nullptr, *tcnt = nullptr; uint16_t *masks = nullptr; int64_t *toffs = nullptr;
+        void *ckeys = nullptr; uint32_t *crows = nullptr;
+        rc = hark_alloc(ctx, (void **)&bitmap, ((size_t)1 << lgb) / 8);
+        if (!rc) rc = hark_alloc(ctx, (void **)&tcnt, (size_t)ntiles * 4);
+        if (!rc) rc = hark_alloc(ctx, (void **)&toffs, (size_t)ntiles * 8);
+        if (!rc) rc = hark_alloc(ctx, (void **)&masks, (size_t)ntiles * kSemiThreads * 2);
+        int64_t n1 = 0;
+        if (!rc) {
+            hipMemsetAsync(bitmap, 0, ((size_t)1 << lgb) / 8, st);
+            if (k64) {
+                bitmap_build_kernel<uint64_t><<<grid_for(ctx, s), 256, 0, st>>>(static_cast<const uint64_t *>(rcol), s, bitmap, bitmask);
+                semi_count_kernel<uint64_t><<<dim3((unsigned)ntiles), kSemiThreads, 0, st>>>(static_cast<const uint64_t *>(lcol), n, bitmap, bitmask, masks, tcnt);
+            } else {
+                bitmap_build_kernel<uint32_t><<<grid_for(ctx, s), 256, 0, st>>>(static_cast<const uint32_t *>(rcol), s, bitmap, bitmask);
+                semi_count_kernel<uint32_t><<<dim3((unsigned)ntiles), kSemiThreads, 0, st>>>(static_cast<const uint32_t *>(lcol), n, bitmap, bitmask, masks, tcnt);
+            }
+            rc = k_exclusive_scan_u32(ctx, tcnt, ntiles, nullptr, toffs, &n1);
+        }
+        if (!rc && n1 <= n / 2) {                      // otherwise the filter does not pay: sort the whole side
+            filtered = true; nl = n1;
+            if (n1 > 0) {
+                rc = hark_alloc(ctx, &ckeys, (size_t)n1 * (k64 ? 8 : 4));
+                if (!rc) rc = hark_alloc(ctx, (void **)&crows, (size_t)n1 * 4);
+                if (!rc) {
+                    if (k64) semi_scatter_kernel<uint64_t><<<dim3((unsigned)ntiles), kSemiThreads, 0, st>>>(static_cast<const uint64_t *>(lcol), n, masks, toffs, static_cast<uint64_t *>(ckeys), crows);
+                    else semi_scatter_kernel<uint32_t><<<dim3((unsigned)ntiles), kSemiThreads, 0, st>>>(static_cast<const uint32_t *>(lcol), n, masks, toffs, static_cast<uint32_t *>(ckeys), crows);
+                    if (!k64) rc = k_sort_column(ctx, ckeys, HARK_U32, n1, false, crows, &lperm, &lkeys);      // the row ids travel with the keys
+                    else {
+                        uint32_t *pos = nullptr;                                                          // positions in the compacted arrays
+                        rc = k_argsort_column(ctx, ckeys, HARK_I64, n1, false, &pos, nullptr);
+                        if (!rc) rc = hark_alloc(ctx, (void **)&lperm, (size_t)n1 * 4);
+                        if (!rc) rc = hark_alloc(ctx, (void **)&lk64, (size_t)n1 * 8);
+                        if (!rc) {
+                            gather_u32_via_kernel<<<grid_for(ctx, n1), 256, 0, st>>>(crows, pos, lperm, n1);
+                            gather_biased_i64_kernel<<<grid_for(ctx, n1), 256, 0, st>>>(static_cast<const uint64_t *>(ckeys), pos, lk64, n1);
+                            if (hipStreamSynchronize(st) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: filter kernels failed");
+                        }
+                        hark_free(ctx, pos);
+                    }
+                }
+            }
+        }
+        if (hipStreamSynchronize(st) != hipSuccess && !rc) rc = hark_fail(ctx, HARK_EHIP, "join: filter kernels failed");
+        hark_free(ctx, bitmap); hark_free(ctx, tcnt); hark_free(ctx, toffs); hark_free(ctx, masks); hark_free(ctx, ckeys); hark_free(ctx, crows);
+    }
+    if (!rc && !filtered) rc = k_argsort_column(ctx, lcol, k64 ? HARK_I64 : HARK_U32, n, false, &lperm, k64 ? nullptr : &lkeys);
+    if (!rc) rc = k_argsort_column(ctx, rcol, k64 ? HARK_I64 : HARK_U32, s, false, &rperm, k64 ? nullptr : &rkeys);
     if (!rc && k64) {
-        rc = hark_alloc(ctx, (void **)&lk64, (size_t)n * 8);
+        if (!filtered) rc = hark_alloc(ctx, (void **)&lk64, (size_t)n * 8);
         if (!rc) rc = hark_alloc(ctx, (void **)&rk64, (size_t)s * 8);
         if (!rc) {
-            gather_biased_i64_kernel<<<grid_for(ctx, n), 256, 0, st>>>(static_cast<const uint64_t *>(db1->cols[col1].data), lperm, lk64, n);
-            gather_biased_i64_kernel<<<grid_for(ctx, s), 256, 0, st>>>(static_cast<const uint64_t *>(db2->cols[col2].data), rperm, rk64, s);
+            if (!filtered) gather_biased_i64_kernel<<<grid_for(ctx, n), 256, 0, st>>>(static_cast<const uint64_t *>(lcol), lperm, lk64, n);
+            gather_biased_i64_kernel<<<grid_for(ctx, s), 256, 0, st>>>(static_cast<const uint64_t *>(rcol), rperm, rk64, s);
         }
     }
-    if (!rc) rc = hark_alloc(ctx, (void **)&lb, (size_t)n * 4);
-    if (!rc) rc = hark_alloc(ctx, (void **)&cnt, (size_t)n * 4);
-    if (!rc) rc = hark_alloc(ctx, (void **)&offs, (size_t)n * 8);
-    if (!rc) {
-        if (k64) join_count_kernel<uint64_t><<<grid_for(ctx, (n + kJoinChunk - 1) / kJoinChunk), 256, 0, st>>>(lk64, n, rk64, s, lb, cnt);
-        else join_count_kernel<uint32_t><<<grid_for(ctx, (n + kJoinChunk - 1) / kJoinChunk), 256, 0, st>>>(lkeys, n, rkeys, s, lb, cnt);
-        rc = k_exclusive_scan_u32(ctx, cnt, n, nullptr, offs, &P);
+    if (!rc && nl > 0) rc = hark_alloc(ctx, (void **)&lb, (size_t)nl * 4);
+    if (!rc && nl > 0) rc = hark_alloc(ctx, (void **)&cnt, (size_t)nl * 4);
+    if (!rc && nl > 0) rc = hark_alloc(ctx, (void **)&offs, (size_t)nl * 8);
+    if (!rc && nl > 0) {
+        if (k64) join_count_kernel<uint64_t><<<grid_for(ctx, (nl + kJoinChunk - 1) / kJoinChunk), 256, 0, st>>>(lk64, nl, rk64, s, lb, cnt);
+        else join_count_kernel<uint32_t><<<grid_for(ctx, (nl + kJoinChunk - 1) / kJoinChunk), 256, 0, st>>>(lkeys, nl, rkeys, s, lb, cnt);
+        rc = k_exclusive_scan_u32(ctx, cnt, nl, nullptr, offs, &P);
     }
     if (!rc && P > 0) {
         // select cols1 db1[r1,:] / select cols2 db2[r2,:] (join.fut:69-70) run only when there are pairs
@@ -178,7 +334,7 @@ int hark_entry_join(hark_context *ctx, hark_result **out, const hark_table *db1,
         if (!rc) rc = hark_alloc(ctx, (void **)&lrow, (size_t)P * 4);
         if (!rc) rc = hark_alloc(ctx, (void **)&rrow, (size_t)P * 4);
         if (!rc) {
-            join_expand_kernel<<<grid_for(ctx, P), 256, 0, st>>>(offs, n, lb, lperm, rperm, P, lrow, rrow);
+            join_expand_kernel<<<grid_for(ctx, P), 256, 0, st>>>(offs, nl, lb, lperm, rperm, P, lrow, rrow);
             if (hipGetLastError() != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: launch failed");
         }
         res->n = P;

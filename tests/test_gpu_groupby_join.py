@@ -210,3 +210,57 @@ def test_sort_constant_key_is_identity(eng, dtype):
         res = eng.sort(t, 0, cols, descending=True)
         for j, c in enumerate(cols):
             assert np.array_equal(res.column(j), [key, a][c])
+
+
+def _np_join_rows(lk, rk):
+    """(left row, right row) pairs of an inner join in the reference's order: ascending key, left row, right row."""
+    ol, orr = np.argsort(lk, kind="stable"), np.argsort(rk, kind="stable")
+    sl, sr = lk[ol], rk[orr]
+    lb, ub = np.searchsorted(sr, sl, "left"), np.searchsorted(sr, sl, "right")
+    cnt = ub - lb
+    li = np.repeat(ol, cnt)
+    within = np.arange(int(cnt.sum())) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+    ri = orr[np.repeat(lb, cnt) + within]
+    return li, ri
+
+
+def test_np_join_model_matches_oracle(oracle):
+    rng = np.random.default_rng(2)
+    a = rng.integers(0, 50, size=(400, 2)).astype(np.uint32)
+    b = rng.integers(0, 50, size=(90, 2)).astype(np.uint32)
+    li, ri = _np_join_rows(a[:, 0], b[:, 1])
+    exp = oracle.join(a, b, 0, 1, [0, 1], [0, 1])
+    assert np.array_equal(np.column_stack([a[li, 0], a[li, 1], b[ri, 0], b[ri, 1]]), exp)
+
+
+@pytest.mark.parametrize("case", ["few hits", "no hits", "every probe row hits", "i64 few hits", "i64 no hits"])
+def test_join_large_probe_side_prefilter(eng, case):
+    """Probe side >= 2^20 rows and >= 4x the build side: the semi-join bitmap pre-filter runs (and is abandoned
+    when more than half of the probe rows pass).  Results are identical row for row."""
+    rng = np.random.default_rng(len(case))
+    n, s = (1 << 20) + 12_345, 60_000
+    wide = "i64" in case
+    dt = np.int64 if wide else np.uint32
+    hi = 2**62 if wide else 2**32
+    rk = rng.integers(-hi if wide else 0, hi, size=s).astype(dt)
+    if "every" in case:
+        lk = rk[rng.integers(0, s, size=n)]
+    elif "no hits" in case:
+        lk = rng.integers(-hi if wide else 0, hi, size=n).astype(dt)
+        lk = np.where(np.isin(lk, rk), lk + dt(1), lk)
+        lk = lk[~np.isin(lk, rk)][:n]
+        n = len(lk)
+    else:
+        lk = rng.integers(-hi if wide else 0, hi, size=n).astype(dt)
+        hit = rng.random(n) < 0.07
+        lk[hit] = rk[rng.integers(0, s, size=int(hit.sum()))]
+        rk[:100] = rk[100:200]                                       # duplicate build keys: several partners per probe row
+    la = np.arange(n, dtype=np.int32)
+    rb = rng.random(s).astype(np.float32)
+    t1, t2 = eng.table_from_columns([lk, la]), eng.table_from_columns([rb, rk])
+    res = eng.join(t1, t2, 0, 1, [1, 0], [0, 1])
+    li, ri = _np_join_rows(lk, rk)
+    assert res.shape[0] == len(li)
+    if len(li):
+        assert np.array_equal(res.column(0), la[li]) and np.array_equal(res.column(1), lk[li])
+        assert np.array_equal(res.column(2), rb[ri]) and np.array_equal(res.column(3), rk[ri])
