@@ -1,3 +1,4 @@
-timeout 600 python -m pytest tests/test_gpu_groupby_join.py -x -q 2>&1 | grep -E "passed|failed|Error|error|assert" | tail -8
-timeout 300 python tools/join_one.py 2>&1 | grep join
-timeout 300 python tools/ops_bench.py 2>&1 | grep -E "join"
+export TMPDIR=/tmp
+O=gpurun_out/joinprof; rm -rf $O; mkdir -p $O
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O -- python3 tools/join_one.py > $O/log.txt 2>&1
+python tools/kstats.py $O 20
