@@ -159,3 +159,75 @@ def test_table_ingest_matches_reference_output(case):
         assert case["schema"] == ["col1", "col2", "col3"] and t.get_schema() == ["col1", "col2", "col3", "col4"]
     else:
         assert t.get_schema() == case["schema"]
+
+
+# ---- the native call sites (FutharkContext.py:65-66, :70-71) against the reference's recorded calls ------------
+CALLS = json.load(open(f"{GOLDEN}/reference_calls.json"))
+
+
+class _FakeDev:
+    def __init__(self, cols):
+        self.cols = [np.asarray(c) for c in cols]
+        self.shape = (len(self.cols[0]) if self.cols else 0, len(self.cols))
+
+    def dtype(self, j):
+        return self.cols[j].dtype.type
+
+    def free(self):
+        pass
+
+
+class _FakeResult:
+    def __init__(self, ncols):
+        self.ncols = ncols
+
+    def columns(self):
+        return [np.zeros(1, dtype=np.int32) for _ in range(self.ncols)]
+
+
+class _RecordingEngine:
+    """Stands where Engine (ctypes -> libhark.so) stands; notes the entry calls FutharkContext.sql() makes."""
+    def __init__(self):
+        self.calls = []
+
+    def table_from_columns(self, cols):
+        return _FakeDev(cols)
+
+    def query_sel(self, dev, cols):
+        self.calls.append(("query_sel", dev, None, [int(c) for c in cols], None))
+        return _FakeResult(len(cols))
+
+    def query_groupby(self, dev, g_col, s_cols, t_cols):
+        self.calls.append(("query_groupby", dev, int(g_col), [int(c) for c in s_cols], [int(c) for c in t_cols]))
+        return _FakeResult(1 + len(s_cols))
+
+
+@pytest.mark.parametrize("case", [c for c in CALLS["statements"] if "sql" in c], ids=lambda c: c["sql"])
+def test_native_call_sites_match_reference(case):
+    from harkdb_amd.context import FutharkContext
+    fc = FutharkContext.__new__(FutharkContext)                       # no GPU: the engine is replaced by the recorder
+    fc.FutEnv, fc.tables, fc.sql_mode = _RecordingEngine(), {}, False
+    fc.create_table("game_1", f"{GOLDEN}/data.csv")
+    fc.sql(case["sql"])
+    ref = [c for c in case["calls"] if c["entry"] != "from_futhark"]
+    assert len(fc.FutEnv.calls) == len(ref) == 1
+    entry, dev, g_col, s_cols, t_cols = fc.FutEnv.calls[0]
+    assert entry == ref[0]["entry"]
+    args = ref[0]["args"]
+    table = args[0]["ndarray"]
+    # the reference hands the whole int64 matrix over on every call; here the same values were uploaded once, per column
+    assert list(dev.shape) == table["shape"]
+    assert np.column_stack(dev.cols).astype(np.int64).tolist() == table["values"]
+    if entry == "query_sel":
+        assert s_cols == args[1]["ndarray"]["values"]
+    else:
+        assert g_col == args[1]["value"] and s_cols == args[2]["ndarray"]["values"] and t_cols == args[3]["ndarray"]["values"]
+
+
+def test_drop_table_like_reference():
+    from harkdb_amd.context import FutharkContext
+    fc = FutharkContext.__new__(FutharkContext)
+    fc.FutEnv, fc.tables, fc.sql_mode = _RecordingEngine(), {}, False
+    fc.create_table("game_1", f"{GOLDEN}/data.csv")
+    fc.drop_table("game_1")
+    assert sorted(fc.tables) == CALLS["statements"][-1]["tables_after_drop"] == []
