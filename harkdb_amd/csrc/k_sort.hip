@@ -218,17 +218,39 @@ __device__ __forceinline__ uint32_t sort_word(const void *src, int dtype, int pa
     return w;
 }
 
+__device__ __forceinline__ uint32_t sort_word_of(uint32_t w, int dtype)
+{
+    if (dtype == HARK_I32) w ^= 0x80000000u;
+    else if (dtype == HARK_F32) {
+        if (w == 0x80000000u) w = 0u;                                  // -0.0 == +0.0
+        w ^= (w & 0x80000000u) ? 0xFFFFFFFFu : 0x80000000u;            // IEEE order as unsigned order
+    }
+    return w;
+}
+
 // dst[i] = sort word of src[i]; *diff |= bits in which any word differs from the first one (a radix pass
-// over a byte in which all keys agree is the identity permutation and is skipped).
+// over a byte in which all keys agree is the identity permutation and is skipped).  4-byte keys move as
+// 16-byte vectors (pool blocks and table columns are 16-byte aligned).
 __global__ __launch_bounds__(256) void transform_keys_kernel(const void *__restrict__ src, int dtype, int part, uint32_t *__restrict__ dst, int64_t n,
                                                              uint32_t *__restrict__ diff)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t w0 = sort_word(src, dtype, part, 0);
     uint32_t acc = 0u;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uint32_t w = sort_word(src, dtype, part, i);
-        dst[i] = w; acc |= w ^ w0;
+    if (dtype != HARK_I64 && (reinterpret_cast<uintptr_t>(src) & 15u) == 0) {
+        const uint4 *s4 = static_cast<const uint4 *>(src);
+        uint4 *d4 = reinterpret_cast<uint4 *>(dst);
+        const int64_t nvec = n / 4;
+        for (int64_t i = t0; i < nvec; i += stride) {
+            uint4 q = s4[i];
+            q.x = sort_word_of(q.x, dtype); q.y = sort_word_of(q.y, dtype); q.z = sort_word_of(q.z, dtype); q.w = sort_word_of(q.w, dtype);
+            d4[i] = q;
+            acc |= (q.x ^ w0) | (q.y ^ w0) | (q.z ^ w0) | (q.w ^ w0);
+        }
+        for (int64_t i = nvec * 4 + t0; i < n; i += stride) { const uint32_t w = sort_word(src, dtype, part, i); dst[i] = w; acc |= w ^ w0; }
+    } else {
+        for (int64_t i = t0; i < n; i += stride) { const uint32_t w = sort_word(src, dtype, part, i); dst[i] = w; acc |= w ^ w0; }
     }
     if (diff) {
         for (int d = 32; d > 0; d >>= 1) acc |= __shfl_xor(acc, d, 64);
