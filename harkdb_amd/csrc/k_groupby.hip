@@ -22,6 +22,7 @@
 int k_argsort_column(hark_context *ctx, const void *col, int dtype, int64_t n, bool descending,
                      uint32_t **perm_out, uint32_t **sorted_words_out);
 int k_gather(hark_context *ctx, const void *src, int esz, const uint32_t *idx, void *dst, int64_t n);
+int k_untransform_keys(hark_context *ctx, const uint32_t *words, int dtype, void *dst, int64_t n);
 int k_exclusive_scan_u32(hark_context *ctx, const uint32_t *in, int64_t n, uint32_t *out32, int64_t *out64, int64_t *total_host);
 
 namespace {
@@ -154,8 +155,24 @@ __global__ __launch_bounds__(256) void seg_reduce_kernel(const void *__restrict_
             const uint32_t sy = __shfl_up(s, d, 64);
             if (lane >= d && sy == s) x = combine(kind, op, y, x);
         }
-        const uint32_t sn = __shfl_down(s, 1, 64);
-        if (valid && (lane == 63 || sn != s)) atomic_combine(kind, op, &acc[s], x);
+        // A run that begins AND ends inside this wave is the whole group (seg ascends): its total is stored
+        // plainly over the identity acc was filled with; only groups that cross a wave boundary need the atomic
+        // (with mostly distinct keys that turns one atomic per row into contiguous 8-byte stores).
+        const uint32_t sn = __shfl_down(s, 1, 64), sp = __shfl_up(s, 1, 64);
+        uint32_t edge = s;                                          // lane 0: the row before the wave, lane 63: the row after
+        if (lane == 0) edge = (i > 0 && valid) ? seg[i - 1] : ~s;
+        if (lane == 63) edge = (i + 1 < n) ? seg[i + 1] : ~s;
+        const bool starts_run = lane == 0 || sp != s;
+        const uint64_t starts = __ballot(starts_run);
+        const bool lane0_is_head = __shfl((int)(edge != s), 0, 64) != 0;
+        if (valid && (lane == 63 || sn != s)) {
+            const uint64_t upto = lane == 63 ? starts : (starts & ((2ull << lane) - 1ull));
+            const int run_start = 63 - __clzll((long long)upto);                 // lane 0 always starts a run
+            const bool head_here = run_start > 0 || lane0_is_head;
+            const bool tail_here = lane < 63 || edge != s;
+            if (head_here && tail_here) acc[s] = x;
+            else atomic_combine(kind, op, &acc[s], x);
+        }
     }
 }
 
@@ -203,9 +220,14 @@ int grouped_aggregate(hark_context *ctx, const hark_table *db, int key_col, int 
     u64 *acc = nullptr, *cnt = nullptr;
     int64_t G = 0;
     hipStream_t st = ctx->stream;
-    int rc = k_argsort_column(ctx, db->cols[key_col].data, key_dtype, n, false, &perm, nullptr);
+    // integer keys come back from the sorted sort words (no random gather of the key column)
+    const bool from_words = key_dtype == HARK_U32 || key_dtype == HARK_I32;
+    uint32_t *words = nullptr;
+    int rc = k_argsort_column(ctx, db->cols[key_col].data, key_dtype, n, false, &perm, from_words ? &words : nullptr);
     if (!rc) rc = hark_alloc(ctx, &sorted_keys, (size_t)n * kesz);
-    if (!rc) rc = k_gather(ctx, db->cols[key_col].data, kesz, perm, sorted_keys, n);
+    if (!rc) rc = from_words ? k_untransform_keys(ctx, words, key_dtype, sorted_keys, n)
+                             : k_gather(ctx, db->cols[key_col].data, kesz, perm, sorted_keys, n);
+    hark_free(ctx, words);                                  // pool blocks are reused in stream order
     if (!rc) rc = hark_alloc(ctx, (void **)&flags, (size_t)n * 4);
     if (!rc) rc = hark_alloc(ctx, (void **)&seg, (size_t)n * 4);
     if (!rc) {
