@@ -23,6 +23,8 @@ int k_argsort_column(hark_context *ctx, const void *col, int dtype, int64_t n, b
                      uint32_t **perm_out, uint32_t **sorted_words_out);
 int k_gather(hark_context *ctx, const void *src, int esz, const uint32_t *idx, void *dst, int64_t n);
 int k_untransform_keys(hark_context *ctx, const uint32_t *words, int dtype, void *dst, int64_t n);
+int k_sort_column(hark_context *ctx, const void *col, int dtype, int64_t n, bool descending, const uint32_t *payload,
+                  uint32_t **vals_out, uint32_t **words_out);
 int k_exclusive_scan_u32(hark_context *ctx, const uint32_t *in, int64_t n, uint32_t *out32, int64_t *out64, int64_t *total_host);
 
 namespace {
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(256) void seg_reduce_kernel(const void *__restrict_
         const bool valid = i < n;
         uint32_t s = valid ? seg[i] : 0xFFFFFFFFu;
         u64 x = ident;
-        if (valid) x = count_mode ? 1ull : load_as_acc(col, dtype, perm[i], kind);
+        if (valid) x = count_mode ? 1ull : load_as_acc(col, dtype, perm ? perm[i] : (uint32_t)i, kind);   // perm == null: col is already in sorted order
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const u64 y = __shfl_up(x, d, 64);
@@ -223,7 +225,18 @@ int grouped_aggregate(hark_context *ctx, const hark_table *db, int key_col, int 
     // integer keys come back from the sorted sort words (no random gather of the key column)
     const bool from_words = key_dtype == HARK_U32 || key_dtype == HARK_I32;
     uint32_t *words = nullptr;
-    int rc = k_argsort_column(ctx, db->cols[key_col].data, key_dtype, n, false, &perm, from_words ? &words : nullptr);
+    // when every aggregate reads the same 4-byte column, that column travels with the keys through the sort and
+    // the segmented reductions read it in order (no row-id permutation, no random gather per aggregate)
+    int carry = -1;
+    bool one_col = from_words;                              // the keys then come back from the sort words, not through row ids
+    for (const AggSpec &a : aggs) {
+        if (a.count_mode) continue;
+        if (carry < 0) carry = a.col;
+        one_col = one_col && a.col == carry && hark_dtype_size(db->cols[a.col].dtype) == 4;
+    }
+    const bool carried = one_col && carry >= 0;
+    int rc = k_sort_column(ctx, db->cols[key_col].data, key_dtype, n, false,
+                           carried ? static_cast<const uint32_t *>(db->cols[carry].data) : nullptr, &perm, from_words ? &words : nullptr);
     if (!rc) rc = hark_alloc(ctx, &sorted_keys, (size_t)n * kesz);
     if (!rc) rc = from_words ? k_untransform_keys(ctx, words, key_dtype, sorted_keys, n)
                              : k_gather(ctx, db->cols[key_col].data, kesz, perm, sorted_keys, n);
@@ -252,9 +265,9 @@ int grouped_aggregate(hark_context *ctx, const hark_table *db, int key_col, int 
     for (size_t j = 0; j < aggs.size() && !rc; j++) {
         const AggSpec &a = aggs[j];
         const int col_dtype = a.count_mode ? HARK_I32 : db->cols[a.col].dtype;
-        const void *col = a.count_mode ? nullptr : db->cols[a.col].data;
+        const void *col = a.count_mode ? nullptr : carried ? static_cast<const void *>(perm) : db->cols[a.col].data;
         fill_u64_kernel<<<grid_for(ctx, G), 256, 0, st>>>(acc, G, identity_of(a.kind, a.op));
-        seg_reduce_kernel<<<grid_for(ctx, n), 256, 0, st>>>(col, col_dtype, perm, seg, n, a.kind, a.op, a.count_mode, acc);
+        seg_reduce_kernel<<<grid_for(ctx, n), 256, 0, st>>>(col, col_dtype, carried ? nullptr : perm, seg, n, a.kind, a.op, a.count_mode, acc);
         if (a.avg) {
             fill_u64_kernel<<<grid_for(ctx, G), 256, 0, st>>>(cnt, G, 0ull);
             seg_reduce_kernel<<<grid_for(ctx, n), 256, 0, st>>>(nullptr, HARK_I32, perm, seg, n, ACC_U64, OP_SUM, 1, cnt);
