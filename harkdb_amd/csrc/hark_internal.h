@@ -115,7 +115,7 @@ int k_fgb_dense_f32(hark_context *ctx, hark_fgb_plan *plan, const float *p, int 
 
 int k_fgb_hash_u32(hark_context *ctx, const uint32_t *k, const uint32_t *v, int64_t n, int vop, int xf,
                    uint32_t **keys_out, unsigned long long **vals_out, unsigned long long **cnts_out, int64_t *G_out, bool *fits,
-                   uint32_t *rounds_hint);
+                   uint32_t *rounds_hint, bool compact);
 
 int k_fgb_decode(hark_context *ctx, const unsigned long long *acc, const unsigned long long *cnt, int64_t G, int kind, void *out);
 

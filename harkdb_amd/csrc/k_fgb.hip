@@ -797,6 +797,98 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash_kernel(
     }
 }
 
+// Compact hash consumer for the reference's u32 operators (groupby.fut:35-41: wrapping * and +, max, min; no row
+// counts): an entry is ONE 64-bit word, value << 32 | occupied << 24 | low 24 bits of mix32(key).  Inside bucket b the
+// top 8 bits of mix32(key) are b, and mix32 is a bijection, so 24 bits identify the key (it is rebuilt by unmix32 at
+// emit time).  Twice the entries per workgroup (16384 in 128 KiB, 6144 used per round) and one LDS atomic per row:
+// ds_add_u64 of value << 32 wraps exactly like u32 addition, ds_max_u64 / ds_min_u64 order the words by value because
+// the low half is the same for every update of a slot, and a claim stores the first value, so no identity is needed.
+constexpr int kHash8Cap = 16384;
+constexpr int kHash8Fill = 6144;
+__device__ __forceinline__ uint32_t unmix32(uint32_t y)
+{
+    y ^= y >> 16; y *= 0x43021123u; y ^= (y >> 15) ^ (y >> 30); y *= 0x1D69E2A5u; y ^= y >> 16;
+    return y;
+}
+
+template <int VOP>
+__global__ __launch_bounds__(1024) void fgb_agg_hash8_kernel(
+    const uint2 *__restrict__ pbuf, const uint32_t *__restrict__ counts, uint32_t cap, int nwg, uint32_t Rmask, uint32_t r,
+    uint32_t *__restrict__ out_key, u64 *__restrict__ out_val, unsigned long long *__restrict__ out_cursor,
+    unsigned long long out_cap, int32_t *__restrict__ err)
+{
+    static_assert(VOP == VOP_U32SUM || VOP == VOP_U32MAX || VOP == VOP_U32MIN || VOP == VOP_U32PROD, "u32 operators only");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    u64 *tab = reinterpret_cast<u64 *>(lds_raw);
+    __shared__ uint32_t s_used, s_emit;
+    __shared__ unsigned long long s_base;
+    const uint32_t b = blockIdx.x;
+    for (int i = threadIdx.x; i < kHash8Cap; i += blockDim.x) tab[i] = 0ull;
+    if (threadIdx.x == 0) { s_used = 0u; s_emit = 0u; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    bool overflow = false;
+    auto add = [&](uint32_t key, uint32_t v) {
+        if ((mix32(key ^ 0x9E3779B9u) & Rmask) != r) return;                 // not this round's share of the key space
+        const uint32_t m = mix32(key);
+        const u64 tag = (u64)(m & 0xFFFFFFu) | (1ull << 24);
+        uint32_t h = (m * 0x9E3779B1u) >> 18;                                // 14 bits
+        for (int step = 0; step < kHash8Cap; step++, h = (h + 1) & (kHash8Cap - 1)) {
+            u64 cur = tab[h];
+            if (cur == 0ull) {
+                if (s_used >= (uint32_t)kHash8Fill) { overflow = true; return; }
+                cur = atomicCAS(&tab[h], 0ull, tag | ((u64)v << 32));       // the claim carries the first value
+                if (cur == 0ull) { atomicAdd(&s_used, 1u); return; }
+            }
+            if ((cur & 0x1FFFFFFull) == tag) {
+                if constexpr (VOP == VOP_U32SUM) atomicAdd(&tab[h], (u64)v << 32);
+                else if constexpr (VOP == VOP_U32MAX) atomicMax(&tab[h], tag | ((u64)v << 32));
+                else if constexpr (VOP == VOP_U32MIN) atomicMin(&tab[h], tag | ((u64)v << 32));
+                else {
+                    u64 old = cur;
+                    for (;;) {
+                        const u64 want = tag | ((u64)((uint32_t)(old >> 32) * v) << 32);
+                        const u64 got = atomicCAS(&tab[h], old, want);
+                        if (got == old) break;
+                        old = got;
+                    }
+                }
+                return;
+            }
+        }
+        overflow = true;
+    };
+    for (int w = wave; w < nwg; w += nwaves) {
+        if (__any(overflow)) break;                                          // this round is void anyway: stop reading
+        const uint32_t count = min(counts[(size_t)b * nwg + w], cap);
+        const uint2 *src = pbuf + ((size_t)b * nwg + w) * cap;
+        const uint4 *src4 = reinterpret_cast<const uint4 *>(src);
+        const uint32_t n2 = count / 2;
+        uint32_t i = lane;
+        for (; i + 64 < n2; i += 128) {
+            const uint4 q0 = src4[i], q1 = src4[i + 64];
+            add(q0.x, q0.y); add(q0.z, q0.w); add(q1.x, q1.y); add(q1.z, q1.w);
+        }
+        for (; i < n2; i += 64) { const uint4 q = src4[i]; add(q.x, q.y); add(q.z, q.w); }
+        if ((count & 1u) && lane == 0) { const uint2 q = src[count - 1]; add(q.x, q.y); }
+    }
+    if (overflow) *err = kErrOverflow;
+    __syncthreads();
+    uint32_t mine = 0;
+    for (int i = threadIdx.x; i < kHash8Cap; i += blockDim.x) mine += tab[i] ? 1u : 0u;
+    uint32_t pos = mine ? atomicAdd(&s_emit, mine) : 0u;
+    __syncthreads();
+    if (threadIdx.x == 0) s_base = s_emit ? atomicAdd(out_cursor, (unsigned long long)s_emit) : 0ull;
+    __syncthreads();
+    for (int i = threadIdx.x; i < kHash8Cap; i += blockDim.x) {
+        const u64 e = tab[i];
+        if (!e) continue;
+        const unsigned long long o = s_base + pos++;
+        if (o < out_cap) { out_key[o] = unmix32((b << 24) | (uint32_t)(e & 0xFFFFFFu)); out_val[o] = e >> 32; }
+        else *err = kErrOverflow;
+    }
+}
+
 __global__ __launch_bounds__(256) void fgb_finish_kernel(const double *__restrict__ acc_sum, const unsigned long long *__restrict__ acc_cnt,
                                                          int64_t G, float *__restrict__ sum_out, int64_t *__restrict__ cnt_out)
 {
@@ -1232,8 +1324,11 @@ int hark_fgb_finish_typed(hark_context *ctx, hark_fgb_plan *pl, int32_t kind, co
 // the caller then uses the sort-based path.
 int k_fgb_hash_u32(hark_context *ctx, const uint32_t *k, const uint32_t *v, int64_t n, int vop, int xf,
                    uint32_t **keys_out, unsigned long long **vals_out, unsigned long long **cnts_out, int64_t *G_out, bool *fits,
-                   uint32_t *rounds_hint /* in: 0 or the R a previous pass over the SAME key column needed; out: the R used */)
+                   uint32_t *rounds_hint /* in: 0 or the R a previous pass over the SAME key column needed; out: the R used */,
+                   bool compact /* u32 operators without row counts: 8-byte entries (fgb_agg_hash8_kernel); *cnts_out stays null */)
 {
+    if (compact && !(vop == VOP_U32SUM || vop == VOP_U32MAX || vop == VOP_U32MIN || vop == VOP_U32PROD)) compact = false;
+    const int fill = compact ? kHash8Fill : kHashFill;
     *keys_out = nullptr; *vals_out = nullptr; *cnts_out = nullptr; *G_out = 0; *fits = false;
     if (n <= 0 || n > 0xFFFFFFFFll) return HARK_OK;
     const int hash_bits = 8, P = 1 << hash_bits, nwg = ctx->num_cu;
@@ -1270,15 +1365,25 @@ int k_fgb_hash_u32(hark_context *ctx, const uint32_t *k, const uint32_t *v, int6
         const size_t lds_hash = (size_t)kHashCap * 16;
         // run all rounds of an R-round aggregation; e != 0 afterwards means some table overflowed
         auto run_rounds = [&](uint32_t R, uint32_t r_begin, uint32_t r_end) -> int {
-            const unsigned long long out_cap = (unsigned long long)P * kHashFill * (r_end - r_begin);
+            const unsigned long long out_cap = (unsigned long long)P * fill * (r_end - r_begin);
             hark_free(ctx, okey); hark_free(ctx, oval); hark_free(ctx, ocnt); okey = nullptr; oval = nullptr; ocnt = nullptr;
             int r2 = hark_alloc(ctx, (void **)&okey, (size_t)out_cap * 4);
             if (!r2) r2 = hark_alloc(ctx, (void **)&oval, (size_t)out_cap * 8);
-            if (!r2) r2 = hark_alloc(ctx, (void **)&ocnt, (size_t)out_cap * 8);
+            if (!r2 && !compact) r2 = hark_alloc(ctx, (void **)&ocnt, (size_t)out_cap * 8);
             if (r2) return r2;
             hipMemsetAsync(cursor, 0, 16, st); hipMemsetAsync(err, 0, 16, st);
             r2 = dispatch_vop(vop, [&](auto vopc) -> int {
                 constexpr int VOP = decltype(vopc)::value;
+                if constexpr (VOP == VOP_U32SUM || VOP == VOP_U32MAX || VOP == VOP_U32MIN || VOP == VOP_U32PROD) {
+                    if (compact) {
+                        const size_t lds8 = (size_t)kHash8Cap * 8;
+                        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_agg_hash8_kernel<VOP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
+                        for (uint32_t r = r_begin; r < r_end; r++)
+                            fgb_agg_hash8_kernel<VOP><<<dim3((unsigned)P), dim3(1024), lds8, st>>>(pbuf, counts, (uint32_t)cap, nwg, R - 1, r, okey, oval, cursor, out_cap, err);
+                        HIP_TRY(ctx, hipGetLastError());
+                        return HARK_OK;
+                    }
+                }
                 HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_agg_hash_kernel<VOP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hash));
                 for (uint32_t r = r_begin; r < r_end; r++)
                     fgb_agg_hash_kernel<VOP><<<dim3((unsigned)P), dim3(1024), lds_hash, st>>>(pbuf, counts, (uint32_t)cap, nwg, R - 1, r, okey, oval, ocnt, cursor, out_cap, err);   // R is a power of two
@@ -1300,8 +1405,8 @@ int k_fgb_hash_u32(hark_context *ctx, const uint32_t *k, const uint32_t *v, int6
             if (!rc && e == 0) {
                 const double per_bucket = 64.0 * (double)sample / P * 1.3;
                 uint32_t R = 2;
-                while (R < 64 && per_bucket > (double)kHashFill * R) R *= 2;
-                if (per_bucket > (double)kHashFill * 64) e = kErrOverflow;            // would not fit 64 rounds: sort-based path
+                while (R < 64 && per_bucket > (double)fill * R) R *= 2;
+                if (per_bucket > (double)fill * 64) e = kErrOverflow;            // would not fit 64 rounds: sort-based path
                 else {
                     rc = run_rounds(R, 0, R); used_R = R;
                     if (!rc && e != 0 && R < 64) { rc = run_rounds(R * 2, 0, R * 2); used_R = R * 2; }   // one retry for uneven buckets

@@ -577,7 +577,7 @@ int try_hash(hark_context *ctx, const hark_table *db, int32_t where_col, int32_t
     auto run_pass = [&](int vop, int xf, const void *col) -> int {
         uint32_t *hk = nullptr, *perm = nullptr; unsigned long long *hv = nullptr, *hc = nullptr;
         int64_t Gj = 0;
-        int r = k_fgb_hash_u32(ctx, keys, static_cast<const uint32_t *>(col), src->n, vop, xf, &hk, &hv, &hc, &Gj, &ok, &rounds);
+        int r = k_fgb_hash_u32(ctx, keys, static_cast<const uint32_t *>(col), src->n, vop, xf, &hk, &hv, &hc, &Gj, &ok, &rounds, false);
         if (!r && ok) {
             if (G < 0) {
                 G = Gj; res->n = G;
@@ -785,7 +785,7 @@ int ref_groupby_hash(hark_context *ctx, const hark_table *view, int g_col, const
         const uint32_t *col = aggs.empty() ? keys : static_cast<const uint32_t *>(view->cols[aggs[j].col].data);
         uint32_t *hk = nullptr, *perm = nullptr; unsigned long long *hv = nullptr, *hc = nullptr;
         int64_t Gj = 0;
-        rc = k_fgb_hash_u32(ctx, keys, col, n, vop, 0, &hk, &hv, &hc, &Gj, &ok, &rounds);
+        rc = k_fgb_hash_u32(ctx, keys, col, n, vop, 0, &hk, &hv, &hc, &Gj, &ok, &rounds, true);   // u32 operators, no counts: 8-byte table entries
         if (!rc && ok) {
             if (G < 0) {
                 G = Gj;

@@ -60,6 +60,7 @@ def test_query_groupby_sparse_keys_hash_path(eng, oracle, n, ndistinct):
     overflows the slabs and falls back to the sort-based path.  Same result either way."""
     rng = np.random.default_rng(n + ndistinct)
     pool = rng.integers(0, 2**32, size=ndistinct, dtype=np.uint64).astype(np.uint32)
+    pool[:3] = [0, 0xFFFFFFFF, 0x80000000]                         # the extreme keys are ordinary keys
     db = rng.integers(0, 2**32, size=(n, 4), dtype=np.uint64).astype(np.uint32)
     db[:, 1] = pool[rng.integers(0, ndistinct, size=n)] if ndistinct < n else rng.permutation(pool)
     db[:, 3] = rng.integers(0, 3, size=n) * 2 + 1
