@@ -352,31 +352,41 @@ int hark_op_gen_columns(hark_context *ctx, uint64_t seed, int64_t first_row, int
 }
 
 // The measured ceiling the roofline fractions are quoted beside ("fraction of
-// measured copy"): a pure read stream, 4 x 16-byte non-temporal loads in flight per lane.
-__global__ __launch_bounds__(512) void stream_read_kernel(const uint4 *__restrict__ buf, int64_t nvec, unsigned long long *__restrict__ fold)
+// measured copy"): a pure read stream over up to three buffers AT ONCE (the shape of the fused kernels'
+// input: three columns), one 1024-thread workgroup per CU, two 16-byte non-temporal loads in flight per
+// buffer and lane.
+__global__ __launch_bounds__(1024) void stream_read_kernel(const uint4 *__restrict__ b0, const uint4 *__restrict__ b1, const uint4 *__restrict__ b2,
+                                                           int64_t nvec, unsigned long long *__restrict__ fold)
 {
     typedef unsigned int u4v __attribute__((ext_vector_type(4)));
-    const u4v *q = reinterpret_cast<const u4v *>(buf);
+    const u4v *q0 = reinterpret_cast<const u4v *>(b0), *q1 = reinterpret_cast<const u4v *>(b1), *q2 = reinterpret_cast<const u4v *>(b2);
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     u4v acc = {0u, 0u, 0u, 0u};
-    for (; i + 3 * stride < nvec; i += 4 * stride) {
-        const u4v a = __builtin_nontemporal_load(q + i), b = __builtin_nontemporal_load(q + i + stride);
-        const u4v c = __builtin_nontemporal_load(q + i + 2 * stride), d = __builtin_nontemporal_load(q + i + 3 * stride);
-        acc ^= a ^ b ^ c ^ d;
+    for (; i + stride < nvec; i += 2 * stride) {
+        const u4v a0 = __builtin_nontemporal_load(q0 + i), a1 = __builtin_nontemporal_load(q0 + i + stride);
+        acc ^= a0 ^ a1;
+        if (q1) { const u4v c0 = __builtin_nontemporal_load(q1 + i), c1 = __builtin_nontemporal_load(q1 + i + stride); acc ^= c0 ^ c1; }
+        if (q2) { const u4v d0 = __builtin_nontemporal_load(q2 + i), d1 = __builtin_nontemporal_load(q2 + i + stride); acc ^= d0 ^ d1; }
     }
-    for (; i < nvec; i += stride) acc ^= __builtin_nontemporal_load(q + i);
+    for (; i < nvec; i += stride) {
+        acc ^= __builtin_nontemporal_load(q0 + i);
+        if (q1) acc ^= __builtin_nontemporal_load(q1 + i);
+        if (q2) acc ^= __builtin_nontemporal_load(q2 + i);
+    }
     unsigned long long x = ((unsigned long long)(acc.x ^ acc.z) << 32) | (acc.y ^ acc.w);
     for (int d = 32; d; d >>= 1) x ^= __shfl_xor(x, d, 64);
     if ((threadIdx.x & 63) == 0) atomicXor(fold, x);
 }
 
-int hark_op_stream_read(hark_context *ctx, const void *buf, int64_t bytes, uint64_t *fold_dev)
+int hark_op_stream_read(hark_context *ctx, const void *const *bufs, int32_t nbuf, int64_t bytes_each, uint64_t *fold_dev)
 {
-    if (!ctx || bytes < 0 || (bytes && !buf) || !fold_dev || (bytes & 15) || ((uintptr_t)buf & 15)) return HARK_EARG;
-    if (bytes == 0) return HARK_OK;
-    stream_read_kernel<<<dim3((unsigned)ctx->num_cu * 8), dim3(512), 0, ctx->stream>>>(
-        static_cast<const uint4 *>(buf), bytes / 16, reinterpret_cast<unsigned long long *>(fold_dev));
+    if (!ctx || !bufs || nbuf < 1 || nbuf > 3 || bytes_each < 0 || !fold_dev || (bytes_each & 15)) return HARK_EARG;
+    for (int j = 0; j < nbuf; j++) if (bytes_each && (!bufs[j] || ((uintptr_t)bufs[j] & 15))) return HARK_EARG;
+    if (bytes_each == 0) return HARK_OK;
+    stream_read_kernel<<<dim3((unsigned)ctx->num_cu), dim3(1024), 0, ctx->stream>>>(
+        static_cast<const uint4 *>(bufs[0]), nbuf > 1 ? static_cast<const uint4 *>(bufs[1]) : nullptr,
+        nbuf > 2 ? static_cast<const uint4 *>(bufs[2]) : nullptr, bytes_each / 16, reinterpret_cast<unsigned long long *>(fold_dev));
     HIP_TRY(ctx, hipGetLastError());
     return HARK_OK;
 }

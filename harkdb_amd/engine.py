@@ -200,9 +200,12 @@ class Engine:
     def gen_columns(self, seed, first_row, n, G, exact, p=None, k=None, v=None):
         self._chk(self.lib.hark_op_gen_columns(self.ctx, int(seed), int(first_row), int(n), int(G), 1 if exact else 0, p, k, v))
 
-    def stream_read(self, ptr, nbytes, fold_ptr):
-        """Read nbytes once (bandwidth probe); XORs a 64-bit fold into the device u64 at fold_ptr."""
-        self._chk(self.lib.hark_op_stream_read(self.ctx, ptr, int(nbytes), fold_ptr))
+    def stream_read(self, ptrs, nbytes_each, fold_ptr):
+        """Read 1..3 device buffers of nbytes_each bytes once, concurrently (bandwidth probe); XORs a
+        64-bit fold of everything read into the device u64 at fold_ptr."""
+        ptrs = [ptrs] if isinstance(ptrs, int) else list(ptrs)
+        arr = (C.c_void_p * len(ptrs))(*ptrs)
+        self._chk(self.lib.hark_op_stream_read(self.ctx, arr, len(ptrs), int(nbytes_each), fold_ptr))
 
     def partition_by_hash(self, key_ptr, dtype, n, nparts, perm_ptr):
         """Row ids grouped by hash(key) part into perm_ptr (device u32[n]); returns the part sizes."""

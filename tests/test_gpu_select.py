@@ -73,17 +73,22 @@ def test_filter_all_and_none(eng):
 
 
 @pytest.mark.parametrize("n", [0, 4, 1000, 1 << 20, (1 << 22) + 12])
-def test_stream_read_probe_reads_every_byte(eng, n):
-    """bench.py's bandwidth probe: the 64-bit XOR fold proves every 16-byte word was read once."""
-    rng = np.random.default_rng(n)
-    a = rng.integers(0, 2**32, size=n, dtype=np.uint32)
-    buf, fold = eng.alloc(max(n * 4, 16)), eng.alloc(8)
+@pytest.mark.parametrize("nbuf", [1, 2, 3])
+def test_stream_read_probe_reads_every_byte(eng, n, nbuf):
+    """bench.py's bandwidth probe: the 64-bit XOR fold proves every 16-byte word of every buffer was read once."""
+    rng = np.random.default_rng(n + nbuf)
+    bufs, exp = [], 0
+    fold = eng.alloc(8)
     eng.upload(fold, np.zeros(1, dtype=np.uint64))
-    if n:
-        eng.upload(buf, a)
-    eng.stream_read(buf, n * 4, fold)
-    got = int(eng.download(fold, 1, np.uint64)[0])
-    q = a.reshape(-1, 4)
-    exp = (int(np.bitwise_xor.reduce(q[:, 0] ^ q[:, 2])) << 32) | int(np.bitwise_xor.reduce(q[:, 1] ^ q[:, 3])) if n else 0
-    assert got == exp
-    eng.free(buf); eng.free(fold)
+    for _ in range(nbuf):
+        a = rng.integers(0, 2**32, size=n, dtype=np.uint32)
+        b = eng.alloc(max(n * 4, 16))
+        if n:
+            eng.upload(b, a)
+            q = a.reshape(-1, 4)
+            exp ^= (int(np.bitwise_xor.reduce(q[:, 0] ^ q[:, 2])) << 32) | int(np.bitwise_xor.reduce(q[:, 1] ^ q[:, 3]))
+        bufs.append(b)
+    eng.stream_read(bufs, n * 4, fold)
+    assert int(eng.download(fold, 1, np.uint64)[0]) == exp
+    for b in bufs + [fold]:
+        eng.free(b)
