@@ -39,12 +39,26 @@ def init_process_group(device_type=None):
     if (world > 1 or "RANK" in os.environ) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
+        backend = os.environ.get("HARK_DIST_BACKEND") or ("nccl" if device_type == "cuda" else "gloo")
         if device_type == "cuda":
             torch.cuda.set_device(local)
+        if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            # gloo with device tensors: a TEST arrangement (several ranks on one GPU, which RCCL refuses);
+            # collectives on device tensors are staged through the host by _host_staged below
+            dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, local, world
+
+
+def _host_staged(t):
+    """(tensor to hand to the collective, copy-back function).  RCCL takes device tensors as they are; under
+    gloo (tests: two ranks sharing one GPU) device tensors travel through the host."""
+    import torch.distributed as dist
+    if t.is_cuda and dist.get_backend() == "gloo":
+        h = t.cpu()
+        return h, lambda: t.copy_(h)
+    return t, lambda: None
 
 
 def share_stream(eng, device):
@@ -79,8 +93,10 @@ def allreduce_partials(sum_t, cnt_t, group=None):
     f64 sums and of the i64 counts (the RCCL all-reduce of SURVEY.md 8(e))."""
     import torch.distributed as dist
     if dist.is_initialized():          # also with one rank: keeps the single-GPU run on the same code path
-        dist.all_reduce(sum_t, op=dist.ReduceOp.SUM, group=group)
-        dist.all_reduce(cnt_t, op=dist.ReduceOp.SUM, group=group)
+        for t in (sum_t, cnt_t):
+            x, back = _host_staged(t)
+            dist.all_reduce(x, op=dist.ReduceOp.SUM, group=group)
+            back()
     return sum_t, cnt_t
 
 
@@ -88,8 +104,10 @@ def allreduce_minmax(min_t, max_t, group=None):
     """MIN / MAX partials (ncclMin / ncclMax)."""
     import torch.distributed as dist
     if dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(min_t, op=dist.ReduceOp.MIN, group=group)
-        dist.all_reduce(max_t, op=dist.ReduceOp.MAX, group=group)
+        for t, op in ((min_t, dist.ReduceOp.MIN), (max_t, dist.ReduceOp.MAX)):
+            x, back = _host_staged(t)
+            dist.all_reduce(x, op=op, group=group)
+            back()
     return min_t, max_t
 
 
@@ -102,6 +120,8 @@ def shard_offsets(local_count, device="cpu", group=None):
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return 0, int(local_count)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if dist.get_backend() == "gloo":
+        device = "cpu"
     mine = torch.tensor([int(local_count)], dtype=torch.int64, device=device)
     allc = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(allc, mine, group=group)
@@ -178,15 +198,18 @@ def exchange_columns(send_cols, send_counts, group=None):
     if not dist.is_initialized():
         return list(send_cols), list(send_counts)
     dev = send_cols[0].device if send_cols else "cpu"
-    cnt = torch.tensor(list(send_counts), dtype=torch.int64, device=dev)
+    staged = dist.get_backend() == "gloo" and torch.device(dev).type == "cuda"      # tests: ranks sharing one GPU
+    cdev = "cpu" if staged else dev
+    cnt = torch.tensor(list(send_counts), dtype=torch.int64, device=cdev)
     rc = torch.empty_like(cnt)
     dist.all_to_all_single(rc, cnt, group=group)
     recv_counts = [int(x) for x in rc.tolist()]
     out = []
     for c in send_cols:
-        r = torch.empty(sum(recv_counts), dtype=c.dtype, device=c.device)
-        dist.all_to_all_single(r, c.contiguous(), output_split_sizes=recv_counts, input_split_sizes=list(send_counts), group=group)
-        out.append(r)
+        src = c.contiguous().cpu() if staged else c.contiguous()
+        r = torch.empty(sum(recv_counts), dtype=c.dtype, device=cdev)
+        dist.all_to_all_single(r, src, output_split_sizes=recv_counts, input_split_sizes=list(send_counts), group=group)
+        out.append(r.to(dev) if staged else r)
     return out, recv_counts
 
 
