@@ -202,6 +202,19 @@ __global__ __launch_bounds__(kSortThreads) void digit_scatter_kernel(
     }
 }
 
+// Order-preserving 32-bit sort word of a 4-byte key: unsigned order of the words = the column's own order
+// (u32 unsigned, i32 signed, f32 IEEE with -0.0 == +0.0 and every NaN after +inf, numpy's order).
+__device__ __forceinline__ uint32_t sort_word_of(uint32_t w, int dtype)
+{
+    if (dtype == HARK_I32) w ^= 0x80000000u;
+    else if (dtype == HARK_F32) {
+        if (w == 0x80000000u) w = 0u;
+        if ((w & 0x7FFFFFFFu) > 0x7F800000u) return 0xFFFFFFFFu;
+        w ^= (w & 0x80000000u) ? 0xFFFFFFFFu : 0x80000000u;
+    }
+    return w;
+}
+
 __device__ __forceinline__ uint32_t sort_word(const void *src, int dtype, int part, int64_t i)
 {
     // part 0: the (only / low) 32-bit sort word, part 1: the high word of an i64.
@@ -209,23 +222,7 @@ __device__ __forceinline__ uint32_t sort_word(const void *src, int dtype, int pa
         const uint64_t x = static_cast<const uint64_t *>(src)[i] ^ 0x8000000000000000ull;
         return part ? (uint32_t)(x >> 32) : (uint32_t)x;
     }
-    uint32_t w = static_cast<const uint32_t *>(src)[i];
-    if (dtype == HARK_I32) w ^= 0x80000000u;
-    else if (dtype == HARK_F32) {
-        if (w == 0x80000000u) w = 0u;                                  // -0.0 == +0.0
-        w ^= (w & 0x80000000u) ? 0xFFFFFFFFu : 0x80000000u;            // IEEE order as unsigned order
-    }
-    return w;
-}
-
-__device__ __forceinline__ uint32_t sort_word_of(uint32_t w, int dtype)
-{
-    if (dtype == HARK_I32) w ^= 0x80000000u;
-    else if (dtype == HARK_F32) {
-        if (w == 0x80000000u) w = 0u;                                  // -0.0 == +0.0
-        w ^= (w & 0x80000000u) ? 0xFFFFFFFFu : 0x80000000u;            // IEEE order as unsigned order
-    }
-    return w;
+    return sort_word_of(static_cast<const uint32_t *>(src)[i], dtype);
 }
 
 // dst[i] = sort word of src[i]; *diff |= bits in which any word differs from the first one (a radix pass
@@ -470,17 +467,11 @@ __global__ __launch_bounds__(256) void hash_dest_kernel(const void *__restrict__
     }
 }
 
-// Order-preserving 64-bit sort word of a key (u32 < i32 < f32 < i64 all map to unsigned order).
+// Order-preserving 64-bit sort word of a key (the sort's own words, so range parts and the local sort agree).
 __device__ __forceinline__ uint64_t order_word(const void *col, int dtype, int64_t i)
 {
     if (dtype == HARK_I64) return static_cast<const uint64_t *>(col)[i] ^ 0x8000000000000000ull;
-    uint32_t w = static_cast<const uint32_t *>(col)[i];
-    if (dtype == HARK_I32) w ^= 0x80000000u;
-    else if (dtype == HARK_F32) {
-        if (w == 0x80000000u) w = 0u;
-        w ^= (w & 0x80000000u) ? 0xFFFFFFFFu : 0x80000000u;
-    }
-    return w;
+    return sort_word_of(static_cast<const uint32_t *>(col)[i], dtype);
 }
 
 // dest = number of splitters <= key (ascending) -- equal keys share a part; mirrored for descending.

@@ -265,3 +265,24 @@ def test_join_large_probe_side_prefilter(eng, case):
     if len(li):
         assert np.array_equal(res.column(0), la[li]) and np.array_equal(res.column(1), lk[li])
         assert np.array_equal(res.column(2), rb[ri]) and np.array_equal(res.column(3), rk[ri])
+
+
+@pytest.mark.parametrize("descending", [False, True])
+def test_sort_f32_nan_and_infinities(eng, descending):
+    """f32 keys: -inf < ... < -0.0 == +0.0 < ... < +inf < every NaN (numpy's order), stable; reversed for DESC."""
+    rng = np.random.default_rng(9)
+    n = 50_000
+    key = rng.standard_normal(n).astype(np.float32)
+    key[::41] = np.nan
+    key[1::41] = -np.nan
+    key[2::41] = np.inf
+    key[3::41] = -np.inf
+    key[4::41] = -0.0
+    rowid = np.arange(n, dtype=np.int32)
+    t = eng.table_from_columns([key, rowid])
+    res = eng.sort(t, 0, [1, 0], descending=descending)
+    rank = np.clip(key.astype(np.float64), -1e300, 1e300)
+    rank[np.isnan(key)] = 2e300                                               # NaNs tie at the far end
+    perm = np.argsort(-rank if descending else rank, kind="stable")
+    assert np.array_equal(res.column(0), rowid[perm])
+    assert np.array_equal(res.column(1).view(np.uint32), key[perm].view(np.uint32))
