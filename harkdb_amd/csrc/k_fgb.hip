@@ -24,13 +24,23 @@
 //         on gfx950 (tools/ubench.hip: they execute at the memory side, one
 //         64-byte request per lane), 20x too slow.  So rows are routed by key
 //         range first.  PRODUCER: every bucket (key >> shift) owns a small
-//         queue in LDS; a surviving row takes a slot with one ds_add_rtn_u32,
+//         ring in LDS; a surviving row takes a slot with one ds_add_rtn_u32,
 //         and only complete 128-byte lines leave the CU, appended to the
 //         workgroup's OWN slab of that bucket (no global atomics, no partial
-//         lines).  Heavy hitters are folded in a small LDS cache instead.
+//         lines): units of 64 compact pairs (u16 bucket-local key + 32-bit
+//         value, 6 B per pair) on the dense path, lines of 16 (key, value)
+//         pairs in hash mode.  Heavy hitters are folded in a small LDS cache
+//         instead.  The batch loop carries no run-time knobs and its barriers
+//         order LDS only (it was instruction-issue bound).
 //         CONSUMER: one workgroup per bucket folds the bucket's slabs into an
 //         LDS-resident slice of the table and adds the slice to the global
 //         table with plain stores (it owns the key range).
+//   HASH  arbitrary u32 keys: the producer routes by the top bits of
+//         mix32(key), one workgroup per bucket builds an open-addressing
+//         table in LDS (fgb_agg_hash_kernel: 16-byte entries with row
+//         counts; fgb_agg_hash8_kernel: 8-byte entries for the reference's
+//         u32 operators), in several rounds when a bucket holds more distinct
+//         keys than a table.
 //   ATOM  one global atomic pair per surviving row; the fallback for slab
 //         overflow / G > 2^21 and a measured baseline.
 //
