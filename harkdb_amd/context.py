@@ -170,6 +170,8 @@ class FutharkContext:
     def _groupby_extended(self, dev, schema, ir):
         eng = self.FutEnv
         g_col, items = ir["g_col"], list(ir["items"])
+        g_cols = ir.get("g_cols", [g_col])
+        multi = len(g_cols) > 1
         # every aggregate the query mentions (select list, HAVING, ORDER BY), deduplicated
         aggs = []
 
@@ -185,16 +187,35 @@ class FutharkContext:
         out_slots = [agg_slot(i) for i in items]
         having = [(agg_slot(s), cmp, v) for s, cmp, v in ir.get("having", [])]
         order = (agg_slot(ir["orderby"][0]), ir["orderby"][1]) if "orderby" in ir else None
+        host_order = None
+        if multi:
+            if any(slot == 0 for slot, _, _ in having):
+                raise Exception("HAVING on a key column is not supported with several GROUP BY keys")
+            if order is not None and order[0] == 0 and ir["orderby"][0][1] != g_cols[0]:
+                host_order, order = (ir["orderby"][0][1], order[1]), None     # a non-leading key: ordered after decoding (G rows)
 
         where = ir.get("where", [])
-        need = {g_col} | {c for _, c in aggs if c is not None}
+        need = set(g_cols) | {c for _, c in aggs if c is not None}
         cur, cmap = dev, {c: c for c in range(dev.shape[1])}
         first = None
         if len(where) == 1:
             first = (where[0][0], where[0][1], where[0][2])
+            need.add(first[0])
         elif len(where) > 1:
             cur, cmap = self._filtered(dev, where, need)
-        res = eng.filter_groupby(cur, None if first is None else (cmap[first[0]], first[1], first[2]), cmap[g_col],
+        decode = None
+        if multi:
+            # several keys -> one composite key column on the device (ascending composite = lexicographic key tuple)
+            buf, cdt, mins, spans = eng.composite_key(cur, [cmap[c] for c in g_cols])
+            cols_needed = sorted(need)
+            view = eng.table_from_device(cur.shape[0], [cur.device_ptr(cmap[c]) for c in cols_needed] + [buf.ptr],
+                                         [cur.dtype(cmap[c]) for c in cols_needed] + [cdt], keepalive=(cur, buf))
+            cmap = {c: j for j, c in enumerate(cols_needed)}
+            cur, gkey = view, len(cols_needed)
+            decode = (mins, spans, [dev.dtype(c) for c in g_cols])
+        else:
+            gkey = cmap[g_col]
+        res = eng.filter_groupby(cur, None if first is None else (cmap[first[0]], first[1], first[2]), gkey,
                                  [(f, 0 if c is None else cmap[c]) for f, c in aggs])
         # HAVING / ORDER BY run on the G-row result, still on the device
         keep = [res]
@@ -209,7 +230,19 @@ class FutharkContext:
             res = eng.sort(t, order[0], list(range(m)), descending=order[1])
             keep += [t, res]
         cols = res.columns()
-        out = [cols[s] for s in out_slots]
+        if decode is None:
+            out = [cols[s] for s in out_slots]
+        else:
+            mins, spans, kdts = decode
+            comp, keys = cols[0].astype(np.int64), {}
+            for c, mn, sp, dt in reversed(list(zip(g_cols, mins, spans, kdts))):     # last key = least significant digit
+                keys[c] = (comp % sp + mn).astype(dt)
+                comp = comp // sp
+            out = [keys[i[1]] if i[0] == "key" else cols[s] for i, s in zip(items, out_slots)]
+            if host_order is not None:
+                k = keys[host_order[0]].astype(np.int64)
+                perm = np.argsort(-k if host_order[1] else k, kind="stable")
+                out = [c[perm] for c in out]
         if "limit" in ir:
             out = [c[: ir["limit"]] for c in out]
         names = [schema[c] if f == "key" else f"{f}({'*' if c is None else schema[c]})" for f, c in items]

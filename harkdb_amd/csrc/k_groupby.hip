@@ -815,3 +815,62 @@ int ref_groupby_hash(hark_context *ctx, const hark_table *view, int g_col, const
 }
 
 } // namespace
+
+// ---------------------------------------------------------------------------
+// Multi-key GROUP BY (extension): the key columns are folded into ONE composite key column,
+// ((k1 - min1) * span2 + (k2 - min2)) * span3 + ..., whose ascending order is the lexicographic order of the key
+// tuple, so every single-key path above (dense, hash, sort-based) serves it unchanged.  The per-column [min, max]
+// are the cached column statistics; the caller decodes the composite back into the key columns (G rows).
+// ---------------------------------------------------------------------------
+namespace {
+constexpr int kMaxKeys = 4;
+struct CompositeArgs { const uint32_t *col[kMaxKeys]; int is_signed[kMaxKeys]; long long mn[kMaxKeys]; long long span[kMaxKeys]; int nk; };
+
+template <typename OUT>
+__global__ __launch_bounds__(256) void composite_key_kernel(CompositeArgs a, int64_t n, OUT *__restrict__ out)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        long long acc = 0;
+        for (int j = 0; j < a.nk; j++) {
+            const uint32_t x = a.col[j][i];
+            const long long v = a.is_signed[j] ? (long long)(int32_t)x : (long long)x;
+            acc = acc * a.span[j] + (v - a.mn[j]);
+        }
+        out[i] = (OUT)acc;
+    }
+}
+} // namespace
+
+extern "C" int hark_table_composite_key(hark_context *ctx, const hark_table *t, const int32_t *cols, int64_t nk,
+                                        void **out_dev, int32_t *out_dtype, int64_t *mins, int64_t *spans)
+{
+    if (!ctx || !t || !cols || !out_dev || !out_dtype || !mins || !spans) return HARK_EARG;
+    *out_dev = nullptr;
+    if (nk < 1 || nk > kMaxKeys) return hark_fail(ctx, HARK_EUNSUPPORTED, "composite key: 1..%d key columns", kMaxKeys);
+    CompositeArgs a{};
+    a.nk = (int)nk;
+    long double total = 1.0L;
+    for (int64_t j = 0; j < nk; j++) {
+        const int c = cols[j];
+        if (c < 0 || c >= t->m) return hark_fail(ctx, HARK_EBOUNDS, "composite key: column %d out of bounds", c);
+        const int dt = t->cols[c].dtype;
+        if (dt != HARK_I32 && dt != HARK_U32) return hark_fail(ctx, HARK_EUNSUPPORTED, "composite key: column %d is not a 32-bit integer column", c);
+        int64_t lo = 0, hi = 0;
+        if (t->n > 0) HARK_TRY(column_range(ctx, t, c, dt == HARK_I32, &lo, &hi));
+        a.col[j] = static_cast<const uint32_t *>(t->cols[c].data);
+        a.is_signed[j] = dt == HARK_I32;
+        a.mn[j] = lo; a.span[j] = hi - lo + 1;
+        mins[j] = lo; spans[j] = hi - lo + 1;
+        total *= (long double)(hi - lo + 1);
+    }
+    if (total >= 4.0e18L) return hark_fail(ctx, HARK_EUNSUPPORTED, "composite key: the key ranges multiply to more than 2^62");
+    const bool wide = total > 2147483647.0L;
+    *out_dtype = wide ? HARK_I64 : HARK_I32;
+    if (t->n == 0) return HARK_OK;
+    HARK_TRY(hark_alloc(ctx, out_dev, (size_t)t->n * (wide ? 8 : 4)));
+    if (wide) composite_key_kernel<long long><<<grid_for(ctx, t->n), 256, 0, ctx->stream>>>(a, t->n, static_cast<long long *>(*out_dev));
+    else composite_key_kernel<int32_t><<<grid_for(ctx, t->n), 256, 0, ctx->stream>>>(a, t->n, static_cast<int32_t *>(*out_dev));
+    if (hipGetLastError() != hipSuccess) { hark_free(ctx, *out_dev); *out_dev = nullptr; return hark_fail(ctx, HARK_EHIP, "composite key: launch failed"); }
+    return HARK_OK;
+}

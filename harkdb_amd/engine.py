@@ -90,6 +90,25 @@ class DeviceTable:
             pass
 
 
+class DeviceBuffer:
+    """A pool block returned by the library (freed with hark_dev_free when dropped)."""
+
+    def __init__(self, eng, ptr):
+        self._eng, self.ptr = eng, ptr
+
+    def free(self):
+        if self.ptr:
+            self._eng.free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            if self._eng.ctx is not None:
+                self.free()
+        except Exception:
+            pass
+
+
 class FgbPlan:
     """Workspace + knobs of the fused filter->group-by (hark_fgb_plan)."""
 
@@ -307,6 +326,15 @@ class Engine:
         self._chk(self.lib.hark_entry_filter_groupby(self.ctx, C.byref(h), table._h, wc, cmp, c.ctypes.data,
                                                      int(g_col), pc, po, cols.size))
         return Result(self, h)
+
+    def composite_key(self, table, key_cols):
+        """Fold several 32-bit integer key columns into one composite key column on the device.
+        Returns (DeviceBuffer owning the column, numpy dtype, mins, spans)."""
+        a, pa = _ffi.i32_array(key_cols)
+        out, dt = C.c_void_p(), C.c_int32()
+        mins, spans = (C.c_int64 * a.size)(), (C.c_int64 * a.size)()
+        self._chk(self.lib.hark_table_composite_key(self.ctx, table._h, pa, a.size, C.byref(out), C.byref(dt), mins, spans))
+        return DeviceBuffer(self, out.value), _ffi.NP_OF[dt.value], list(mins), list(spans)
 
     def sort(self, table, key_col, cols, descending=False):
         a, pa = _ffi.i32_array(cols)

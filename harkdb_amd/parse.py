@@ -82,17 +82,29 @@ def sql_parse(tables, sql_statement):
         ir["items"] = items
     else:                                                               # parse.py:60
         fut_cols_selects, typ_cols_selects, items = [], [], []
-        g_col_name = js_obj["groupby"]["value"]                         # parse.py:66
-        g_col = getIndex(columns, g_col_name)
-        if g_col < 0:
-            raise Exception(f"{g_col_name} is not in the schema of table {table_name}")
+        gb = js_obj["groupby"]
+        g_names = [g["value"] for g in gb] if isinstance(gb, list) else [gb["value"]]   # several keys: extension
+        g_col_name = g_names[0]                                         # parse.py:66
+        g_cols = []
+        for name in g_names:
+            idx = getIndex(columns, name)
+            if idx < 0:
+                raise Exception(f"{name} is not in the schema of table {table_name}")
+            if idx in g_cols:
+                raise Exception(f"{name} is grouped on twice")
+            g_cols.append(idx)
+        g_col = g_cols[0]
+        if len(g_cols) > 1:
+            ir["g_cols"] = g_cols
+            ir["extended"] = True
         for dic in select_pairs:                                        # parse.py:72
             if dic == "*":
                 raise Exception("* is not allowed with GROUP BY")
-            if dic["value"] == g_col_name:                              # parse.py:73-75
-                fut_cols_selects += [g_col]
+            if isinstance(dic["value"], str) and dic["value"] in g_names:   # parse.py:73-75
+                kc = g_cols[g_names.index(dic["value"])]
+                fut_cols_selects += [kc]
                 typ_cols_selects += [0]
-                items.append(("key", g_col))
+                items.append(("key", kc))
             elif isinstance(dic["value"], str):                         # parse.py:76-78
                 bad_col_name = dic["value"]
                 raise Exception(f"{bad_col_name} is not an aggregation function or the columns thats grouped on")
@@ -119,7 +131,7 @@ def sql_parse(tables, sql_statement):
         """A key / aggregate reference in HAVING or ORDER BY -> the matching item."""
         if isinstance(term, str):
             idx = _col(columns, term, table_name)
-            return ("key", idx) if "groupby" in js_obj and idx == ir["g_col"] else ("col", idx)
+            return ("key", idx) if "groupby" in js_obj and idx in ir.get("g_cols", [ir["g_col"]]) else ("col", idx)
         (f, c), = term.items()
         if f not in funcToFut and f not in EXT_FUNCS:
             raise Exception(f"{f} is not a supported aggregation function {AGGREGATES}")

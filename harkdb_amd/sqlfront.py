@@ -143,7 +143,11 @@ class _Parser:
         if self.peek("kw", "group"):
             self.take()
             self.take("kw", "by")
-            tree["groupby"] = {"value": self.take("id")}
+            keys = [{"value": self.take("id")}]
+            while self.peek("punct", ","):                    # several keys -> a list (moz shape), one key -> a dict
+                self.take()
+                keys.append({"value": self.take("id")})
+            tree["groupby"] = keys[0] if len(keys) == 1 else keys
         if self.peek("kw", "having"):
             self.take()
             tree["having"] = self.condition()

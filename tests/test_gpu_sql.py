@@ -169,3 +169,81 @@ def test_join_statement(fc, oracle):
     out = fc.sql("select b.col2, a.col3, a.col1 from a join b on a.col2 = b.col1")
     ref = oracle.join(a, b, 1, 0, [2, 0], [1])
     assert np.array_equal(out, ref[:, [2, 0, 1]].astype(out.dtype))
+
+
+@pytest.fixture(scope="module")
+def fc_multi():
+    from harkdb_amd import FutharkContext
+    c = FutharkContext()
+    rng = np.random.default_rng(4)
+    n = 300_000
+    df = pd.DataFrame({"a": rng.integers(-5, 6, n).astype(np.int32), "b": rng.integers(0, 40, n).astype(np.int32),
+                       "c": rng.integers(100, 103, n).astype(np.int32),
+                       "wide1": (rng.integers(0, 3000, n) * 700_001 - 2**30).astype(np.int32),
+                       "wide2": (rng.integers(0, 50, n) * 1_000_003).astype(np.int32),
+                       "p": rng.random(n).astype(np.float32), "v": rng.integers(0, 16, n).astype(np.float32),
+                       "w": rng.integers(-100, 100, n).astype(np.int32)})
+    c.create_table("m", df)
+    c._df = df
+    return c
+
+
+def _check(names, cols, exp, cols_exp):
+    assert names == list(cols_exp)
+    for got, name in zip(cols, cols_exp):
+        e = exp[cols_exp[name]].to_numpy()
+        if got.dtype.kind == "f":
+            assert np.allclose(got, e, rtol=1e-6), name
+        else:
+            assert np.array_equal(got, e), name
+
+
+def test_multi_key_groupby_dense_composite(fc_multi):
+    """Several GROUP BY keys fold into one composite key on the device (small ranges: i32 composite, dense path)."""
+    df = fc_multi._df
+    names, cols = fc_multi.sql_columns("select a, b, sum(v), count(*), max(w) from m where p > 0.25 group by a, b")
+    g = df[df.p > 0.25].groupby(["a", "b"]).agg(s=("v", "sum"), n=("v", "count"), mx=("w", "max")).reset_index()
+    _check(names, cols, g, {"a": "a", "b": "b", "sum(v)": "s", "count(*)": "n", "max(w)": "mx"})
+    # three keys, select order differs from key order, HAVING on an aggregate, ORDER BY an aggregate, LIMIT
+    names, cols = fc_multi.sql_columns("select c, avg(v), a, b from m group by a, b, c having count(*) > 200 order by avg(v) desc limit 9")
+    g = df.groupby(["a", "b", "c"]).agg(av=("v", "mean"), n=("v", "count")).reset_index()
+    g = g[g.n > 200].sort_values("av", ascending=False, kind="stable").head(9)
+    assert names == ["c", "avg(v)", "a", "b"]
+    assert np.allclose(cols[1], g.av.to_numpy(), rtol=1e-6)
+    got = pd.DataFrame({"a": cols[2], "b": cols[3], "c": cols[0]})
+    assert set(map(tuple, got.to_numpy())) == set(map(tuple, g[["a", "b", "c"]].to_numpy()))
+
+
+def test_multi_key_groupby_wide_composite_and_orders(fc_multi):
+    """Key ranges whose product exceeds 2^31: i64 composite key (sort-based path); ORDER BY the leading key
+    (device) and a non-leading key (after decoding)."""
+    df = fc_multi._df
+    names, cols = fc_multi.sql_columns("select wide1, wide2, sum(v), min(w) from m group by wide1, wide2")
+    g = df.groupby(["wide1", "wide2"]).agg(s=("v", "sum"), mn=("w", "min")).reset_index()
+    _check(names, cols, g, {"wide1": "wide1", "wide2": "wide2", "sum(v)": "s", "min(w)": "mn"})
+    names, cols = fc_multi.sql_columns("select a, b, count(*) from m group by a, b order by a desc")
+    g = df.groupby(["a", "b"]).agg(n=("v", "count")).reset_index()
+    assert np.array_equal(cols[0], np.sort(g.a.to_numpy())[::-1])                 # leading key descending
+    assert sorted(zip(cols[0], cols[1], cols[2])) == sorted(zip(g.a, g.b, g.n))
+    names, cols = fc_multi.sql_columns("select a, b, count(*) from m group by a, b order by b limit 30")
+    e = g.sort_values("b", kind="stable").head(30)
+    assert np.array_equal(cols[1], e.b.to_numpy()) and np.array_equal(cols[0], e.a.to_numpy()) and np.array_equal(cols[2], e.n.to_numpy())
+
+
+def test_multi_key_groupby_errors(fc_multi):
+    with pytest.raises(Exception, match="grouped on twice"):
+        fc_multi.sql("select a, count(*) from m group by a, a")
+    with pytest.raises(Exception, match="is not an aggregation function"):
+        fc_multi.sql("select a, w, count(*) from m group by a, b")
+    with pytest.raises(Exception, match="32-bit integer"):
+        fc_multi.sql("select a, count(*) from m group by a, p")
+    import pandas as pd
+    rng = np.random.default_rng(5)
+    huge = pd.DataFrame({"x": rng.integers(-2**31, 2**31, 1000).astype(np.int32), "y": rng.integers(-2**31, 2**31, 1000).astype(np.int32),
+                         "z": rng.integers(0, 9, 1000).astype(np.int32)})
+    fc_multi.create_table("huge", huge)
+    with pytest.raises(Exception, match="more than 2\\^62"):
+        fc_multi.sql("select x, y, count(*) from huge group by x, y, z")
+    names, cols = fc_multi.sql_columns("select x, z, count(*) from huge group by x, z")       # 2^32 * 9 still fits
+    g = huge.groupby(["x", "z"]).size().reset_index(name="n")
+    assert np.array_equal(cols[0], g.x.to_numpy()) and np.array_equal(cols[1], g.z.to_numpy()) and np.array_equal(cols[2], g.n.to_numpy())

@@ -231,3 +231,18 @@ def test_drop_table_like_reference():
     fc.create_table("game_1", f"{GOLDEN}/data.csv")
     fc.drop_table("game_1")
     assert sorted(fc.tables) == CALLS["statements"][-1]["tables_after_drop"] == []
+
+
+def test_multi_key_groupby_ir(tables):
+    """GROUP BY on several keys (extension): list-shaped parse tree, g_cols in the IR, keys usable in the select list,
+    HAVING and ORDER BY."""
+    assert parse("select a, b, sum(v) from t group by a, b")["groupby"] == [{"value": "a"}, {"value": "b"}]
+    assert parse("select a, sum(v) from t group by a")["groupby"] == {"value": "a"}       # one key keeps the dict shape
+    ir = sql_parse(tables, "select col3, col1, max(col4), count(*) from game_1 group by col1, col3 order by col3 desc limit 5")
+    assert ir["g_cols"] == [0, 2] and ir["g_col"] == 0 and ir["extended"]
+    assert ir["items"] == [("key", 2), ("key", 0), ("max", 3), ("count", None)]
+    assert ir["orderby"] == (("key", 2), True) and ir["limit"] == 5
+    with pytest.raises(Exception, match="grouped on twice"):
+        sql_parse(tables, "select col1, count(*) from game_1 group by col1, col1")
+    with pytest.raises(Exception, match="col2 is not an aggregation function"):
+        sql_parse(tables, "select col1, col2, count(*) from game_1 group by col1, col3")
