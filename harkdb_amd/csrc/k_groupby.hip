@@ -842,8 +842,18 @@ __global__ __launch_bounds__(256) void composite_key_kernel(CompositeArgs a, int
 }
 } // namespace
 
+extern "C" int hark_table_column_range(hark_context *ctx, const hark_table *t, int32_t col, int64_t *lo, int64_t *hi)
+{
+    if (!ctx || !t || !lo || !hi) return HARK_EARG;
+    if (col < 0 || col >= t->m) return hark_fail(ctx, HARK_EBOUNDS, "column_range: column %d out of bounds", col);
+    const int dt = t->cols[col].dtype;
+    if (dt != HARK_I32 && dt != HARK_U32) return hark_fail(ctx, HARK_EUNSUPPORTED, "column_range: column %d is not a 32-bit integer column", col);
+    if (t->n == 0) return hark_fail(ctx, HARK_EARG, "column_range: the table has no rows");
+    return column_range(ctx, t, col, dt == HARK_I32, lo, hi);
+}
+
 extern "C" int hark_table_composite_key(hark_context *ctx, const hark_table *t, const int32_t *cols, int64_t nk,
-                                        void **out_dev, int32_t *out_dtype, int64_t *mins, int64_t *spans)
+                                        void **out_dev, int32_t *out_dtype, int64_t *mins, int64_t *spans, int32_t given)
 {
     if (!ctx || !t || !cols || !out_dev || !out_dtype || !mins || !spans) return HARK_EARG;
     *out_dev = nullptr;
@@ -857,7 +867,10 @@ extern "C" int hark_table_composite_key(hark_context *ctx, const hark_table *t, 
         const int dt = t->cols[c].dtype;
         if (dt != HARK_I32 && dt != HARK_U32) return hark_fail(ctx, HARK_EUNSUPPORTED, "composite key: column %d is not a 32-bit integer column", c);
         int64_t lo = 0, hi = 0;
-        if (t->n > 0) HARK_TRY(column_range(ctx, t, c, dt == HARK_I32, &lo, &hi));
+        if (given) {                                          // the caller's ranges (e.g. the all-rank ranges of a sharded table)
+            if (spans[j] < 1) return hark_fail(ctx, HARK_EARG, "composite key: given span of key %lld is < 1", (long long)j);
+            lo = mins[j]; hi = mins[j] + spans[j] - 1;
+        } else if (t->n > 0) HARK_TRY(column_range(ctx, t, c, dt == HARK_I32, &lo, &hi));
         a.col[j] = static_cast<const uint32_t *>(t->cols[c].data);
         a.is_signed[j] = dt == HARK_I32;
         a.mn[j] = lo; a.span[j] = hi - lo + 1;

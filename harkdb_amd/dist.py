@@ -330,13 +330,40 @@ class ShardedFutharkContext:
         """Local typed GROUP BY on the shard (AVG split into SUM and COUNT),
         merge by key, then HAVING / ORDER BY / LIMIT on the merged G rows."""
         schema = self.local.tables[ir["table_name"]].get_schema()
-        if len(ir.get("g_cols", [])) > 1:
-            raise Exception("GROUP BY on several keys over sharded tables is not built yet (the composite key is per shard)")
+        table_name, key_name, decode = ir["table_name"], schema[ir["g_col"]], None
+        g_cols = ir.get("g_cols", [ir["g_col"]])
+        if len(g_cols) > 1:
+            # several keys: one composite key column per shard, encoded with the ranges over ALL shards so that every
+            # rank encodes alike; the single-key machinery below then runs on a temporary table with that column
+            eng, tab = self.local.FutEnv, self.local.tables[ir["table_name"]]
+            dev = tab._device
+            mine = [eng.column_range(dev, c) for c in g_cols] if dev.shape[0] > 0 else None
+            parts = [mine]
+            import torch.distributed as dist
+            if dist.is_initialized() and dist.get_world_size() > 1:
+                parts = [None] * dist.get_world_size()
+                dist.all_gather_object(parts, mine)
+            parts = [p for p in parts if p is not None]
+            mins = [min(p[j][0] for p in parts) for j in range(len(g_cols))] if parts else [0] * len(g_cols)
+            spans = [max(p[j][1] for p in parts) - mins[j] + 1 for j in range(len(g_cols))] if parts else [1] * len(g_cols)
+            buf, cdt, _, _ = eng.composite_key(dev, g_cols, ranges=(mins, spans))
+            m = dev.shape[1]
+            table_name, key_name = f"__mk_{ir['table_name']}", "__key"
+            self.local.create_table_from_device(table_name, list(schema) + [key_name], [dev.device_ptr(j) for j in range(m)] + [buf.ptr or 0],
+                                                [dev.dtype(j) for j in range(m)] + [cdt], dev.shape[0], keepalive=(dev, buf))
+            decode = (mins, spans, [dev.dtype(c) for c in g_cols])
+        try:
+            return self._groupby_merge(ir, schema, table_name, key_name, g_cols, decode)
+        finally:
+            if decode is not None:
+                self.local.drop_table(table_name)
+
+    def _groupby_merge(self, ir, schema, table_name, key_name, g_cols, decode):
         specs = []                       # partial aggregates to compute locally: (func, col)
 
         def slot(spec):
             if spec[0] == "key":
-                return ("key",)
+                return ("key", spec[1])
             if spec[0] == "col":
                 raise Exception(f"{schema[spec[1]]} is not an aggregation function or the columns thats grouped on")
             if spec[0] == "avg":
@@ -348,9 +375,9 @@ class ShardedFutharkContext:
         items = [slot(i) for i in ir["items"]]
         having = [(slot(s), cmp, v) for s, cmp, v in ir.get("having", [])]
         order = (slot(ir["orderby"][0]), ir["orderby"][1]) if "orderby" in ir else None
-        sel = ", ".join([schema[ir["g_col"]]] + [f"{f}({'*' if c is None else schema[c]})" for f, c in specs])
+        sel = ", ".join([key_name] + [f"{f}({'*' if c is None else schema[c]})" for f, c in specs])
         where = " and ".join(f"{schema[c]} {cmp} {v!r}" for c, cmp, v in ir.get("where", []))
-        stmt = f"select {sel} from {ir['table_name']}" + (f" where {where}" if where else "") + f" group by {schema[ir['g_col']]}"
+        stmt = f"select {sel} from {table_name}" + (f" where {where}" if where else "") + f" group by {key_name}"
         if self.device_exchange:
             cols = self._groupby_exchange(stmt, specs)
             order_k = np.argsort(cols[0], kind="stable")
@@ -360,9 +387,16 @@ class ShardedFutharkContext:
             widen = [c.astype(np.float64) if c.dtype == np.float32 else c for c in cols[1:]]     # merge f32 partial sums in f64
             keys, merged = merge_grouped(cols[0], widen, [f for f, _ in specs])
 
+        key_cols = {g_cols[0]: keys}
+        if decode is not None:                                           # composite -> the key columns (last key = least significant digit)
+            comp, key_cols = keys.astype(np.int64), {}
+            for c, mn, sp, dt in reversed(list(zip(g_cols, *decode))):
+                key_cols[c] = (comp % sp + mn).astype(dt)
+                comp = comp // sp
+
         def value(s):
             if s[0] == "key":
-                return keys
+                return key_cols[s[1]]
             if s[0] == "agg":
                 f, c = specs[s[1]]
                 return merged[s[1]].astype(np.float32) if cols[1 + s[1]].dtype == np.float32 else merged[s[1]]

@@ -327,14 +327,25 @@ class Engine:
                                                      int(g_col), pc, po, cols.size))
         return Result(self, h)
 
-    def composite_key(self, table, key_cols):
+    def composite_key(self, table, key_cols, ranges=None):
         """Fold several 32-bit integer key columns into one composite key column on the device.
-        Returns (DeviceBuffer owning the column, numpy dtype, mins, spans)."""
+        ranges = None (use the table's own column statistics) or (mins, spans) to encode with (sharded tables:
+        the ranges over all shards).  Returns (DeviceBuffer owning the column, numpy dtype, mins, spans)."""
         a, pa = _ffi.i32_array(key_cols)
         out, dt = C.c_void_p(), C.c_int32()
         mins, spans = (C.c_int64 * a.size)(), (C.c_int64 * a.size)()
-        self._chk(self.lib.hark_table_composite_key(self.ctx, table._h, pa, a.size, C.byref(out), C.byref(dt), mins, spans))
+        if ranges is not None:
+            for j in range(a.size):
+                mins[j], spans[j] = int(ranges[0][j]), int(ranges[1][j])
+        self._chk(self.lib.hark_table_composite_key(self.ctx, table._h, pa, a.size, C.byref(out), C.byref(dt), mins, spans,
+                                                    0 if ranges is None else 1))
         return DeviceBuffer(self, out.value), _ffi.NP_OF[dt.value], list(mins), list(spans)
+
+    def column_range(self, table, col):
+        """(min, max) of a 32-bit integer column of a non-empty device table."""
+        lo, hi = C.c_int64(), C.c_int64()
+        self._chk(self.lib.hark_table_column_range(self.ctx, table._h, int(col), C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
 
     def sort(self, table, key_col, cols, descending=False):
         a, pa = _ffi.i32_array(cols)

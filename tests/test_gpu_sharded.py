@@ -123,3 +123,19 @@ def test_sharded_orderby_sample_sort(sfc):
             assert all(np.array_equal(a, b) for a, b in zip(cols, loc))
     finally:
         sfc.device_exchange = False
+
+
+def test_sharded_multi_key_groupby(sfc):
+    """GROUP BY on several keys over shards: the composite key is encoded with the all-rank ranges; both merge paths."""
+    df = sfc._df
+    g = df[df.p > 0.5].groupby(["w", "k"]).agg(s=("v", "sum"), n=("v", "count")).reset_index()
+    for exchange in (False, True):
+        sfc.device_exchange = exchange
+        try:
+            names, cols = sfc.sql_columns("select k, w, sum(v), count(*) from t where p > 0.5 group by w, k")
+        finally:
+            sfc.device_exchange = False
+        assert names == ["k", "w", "sum(v)", "count(*)"]
+        assert np.array_equal(cols[0], g.k.to_numpy()) and np.array_equal(cols[1], g.w.to_numpy())
+        assert np.array_equal(cols[2], g.s.to_numpy().astype(np.float32)) and np.array_equal(cols[3], g.n.to_numpy())
+    assert "__mk_t" not in sfc.local.tables

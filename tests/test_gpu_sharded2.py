@@ -22,6 +22,8 @@ STATEMENTS = [
     "select w, k from t order by p desc limit 50",
     "select s, v from t where p > 0.99 order by s desc",
     "select t.k, b.y, t.w from t join b on t.w = b.x",
+    "select w, k, sum(v), count(*) from t where p > 0.5 group by k, w",
+    "select k, s, max(w), avg(v) from t group by k, s having count(*) > 1 order by max(w) desc limit 40",
 ]
 
 
