@@ -187,10 +187,11 @@ class FutharkContext:
         out_slots = [agg_slot(i) for i in items]
         having = [(agg_slot(s), cmp, v) for s, cmp, v in ir.get("having", [])]
         order = (agg_slot(ir["orderby"][0]), ir["orderby"][1]) if "orderby" in ir else None
-        host_order = None
+        host_order, host_having = None, []
         if multi:
-            if any(slot == 0 for slot, _, _ in having):
-                raise Exception("HAVING on a key column is not supported with several GROUP BY keys")
+            # conditions on key columns run on the decoded G-row result (the device only sees the composite key)
+            host_having = [(s[1], cmp, v) for s, cmp, v in ir.get("having", []) if s[0] == "key"]
+            having = [(slot, cmp, v) for (slot, cmp, v), (s, _, _) in zip(having, ir.get("having", [])) if s[0] != "key"]
             if order is not None and order[0] == 0 and ir["orderby"][0][1] != g_cols[0]:
                 host_order, order = (ir["orderby"][0][1], order[1]), None     # a non-leading key: ordered after decoding (G rows)
 
@@ -239,6 +240,13 @@ class FutharkContext:
                 keys[c] = (comp % sp + mn).astype(dt)
                 comp = comp // sp
             out = [keys[i[1]] if i[0] == "key" else cols[s] for i, s in zip(items, out_slots)]
+            if host_having:
+                ops = {">": np.greater, ">=": np.greater_equal, "<": np.less, "<=": np.less_equal, "=": np.equal, "!=": np.not_equal}
+                keep_rows = np.ones(len(comp), dtype=bool)
+                for c, cmp, v in host_having:
+                    keep_rows &= ops[cmp](keys[c], v)
+                out = [c[keep_rows] for c in out]
+                keys = {c: k[keep_rows] for c, k in keys.items()}
             if host_order is not None:
                 k = keys[host_order[0]].astype(np.int64)
                 perm = np.argsort(-k if host_order[1] else k, kind="stable")

@@ -247,3 +247,12 @@ def test_multi_key_groupby_errors(fc_multi):
     names, cols = fc_multi.sql_columns("select x, z, count(*) from huge group by x, z")       # 2^32 * 9 still fits
     g = huge.groupby(["x", "z"]).size().reset_index(name="n")
     assert np.array_equal(cols[0], g.x.to_numpy()) and np.array_equal(cols[1], g.z.to_numpy()) and np.array_equal(cols[2], g.n.to_numpy())
+
+
+def test_multi_key_groupby_having_on_key(fc_multi):
+    df = fc_multi._df
+    names, cols = fc_multi.sql_columns("select a, b, count(*) from m group by a, b having b >= 30 and count(*) > 10 order by count(*) desc limit 12")
+    g = df.groupby(["a", "b"]).agg(n=("v", "count")).reset_index()
+    g = g[(g.b >= 30) & (g.n > 10)].sort_values("n", ascending=False, kind="stable").head(12)
+    assert np.array_equal(cols[2], g.n.to_numpy())
+    assert sorted(zip(cols[0], cols[1], cols[2])) == sorted(zip(g.a, g.b, g.n))
