@@ -127,7 +127,7 @@ int hark_d2h(hark_context *ctx, void *host, const void *dev, size_t bytes)
 
 extern "C" {
 
-int hark_version(void) { return 100; }
+int hark_version(void) { return 101; }   // 1.01: partition_by_range, stream_read, composite_key, column_range
 
 int hark_context_new(hark_context **out, int device)
 {
