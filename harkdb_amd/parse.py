@@ -42,6 +42,18 @@ def _conditions(tree):
 def sql_parse(tables, sql_statement):
     """Parses an SQL statement (parse.py:16)."""
     js_obj = parse(sql_statement)                                       # parse.py:27
+    if "select_distinct" in js_obj:
+        # SELECT DISTINCT a, b  ==  SELECT a, b ... GROUP BY a, b  (extension; rows come out in ascending key order)
+        sel = js_obj.pop("select_distinct")
+        sel = [sel] if isinstance(sel, (dict, str)) else sel
+        if "groupby" in js_obj or any(s == "*" or not isinstance(s["value"], str) for s in sel):
+            raise Exception("SELECT DISTINCT takes plain columns and no GROUP BY")
+        js_obj["select"] = sel
+        keys = list(dict.fromkeys(s["value"] for s in sel))
+        js_obj["groupby"] = {"value": keys[0]} if len(keys) == 1 else [{"value": k} for k in keys]
+        distinct = True
+    else:
+        distinct = False
     if isinstance(js_obj["from"], list):                                # two-table FROM (extension; SURVEY.md 8(f) 3)
         return _join_parse(tables, js_obj)
     table_name = js_obj["from"]
@@ -125,6 +137,8 @@ def sql_parse(tables, sql_statement):
         ir["groupbys"] = typ_cols_selects
         ir["g_col"] = g_col
         ir["items"] = items
+        if distinct:
+            ir["extended"] = True
 
     # ---- HAVING / ORDER BY / LIMIT (extensions) ------------------------------
     def spec_of(term):

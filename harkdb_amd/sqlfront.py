@@ -27,7 +27,7 @@ _TOKEN = re.compile(r"""\s*(?:
 _CMP = {">": "gt", ">=": "gte", "<": "lt", "<=": "lte", "=": "eq", "==": "eq", "!=": "neq", "<>": "neq"}
 _FLIP = {"gt": "lt", "gte": "lte", "lt": "gt", "lte": "gte", "eq": "eq", "neq": "neq"}
 AGGREGATES = ("prod", "sum", "max", "min", "count", "avg")
-_KEYWORDS = {"select", "from", "where", "group", "by", "having", "order", "limit", "asc", "desc", "as", "and", "join", "inner", "on"}
+_KEYWORDS = {"select", "distinct", "from", "where", "group", "by", "having", "order", "limit", "asc", "desc", "as", "and", "join", "inner", "on"}
 
 
 class SqlSyntaxError(Exception):
@@ -110,6 +110,9 @@ class _Parser:
 
     def statement(self):
         self.take("kw", "select")
+        distinct = self.peek("kw", "distinct")
+        if distinct:
+            self.take()
         items = []
         while True:
             v = self.term()
@@ -122,7 +125,7 @@ class _Parser:
                 self.take()
                 continue
             break
-        tree = {"select": items[0] if len(items) == 1 else items}
+        tree = {"select_distinct" if distinct else "select": items[0] if len(items) == 1 else items}
         self.take("kw", "from")
         tree["from"] = self.take("id")
         if self.peek("kw", "inner") or self.peek("kw", "join"):

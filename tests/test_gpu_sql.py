@@ -256,3 +256,15 @@ def test_multi_key_groupby_having_on_key(fc_multi):
     g = g[(g.b >= 30) & (g.n > 10)].sort_values("n", ascending=False, kind="stable").head(12)
     assert np.array_equal(cols[2], g.n.to_numpy())
     assert sorted(zip(cols[0], cols[1], cols[2])) == sorted(zip(g.a, g.b, g.n))
+
+
+def test_select_distinct(fc_multi):
+    """SELECT DISTINCT = GROUP BY the selected columns (one key, or the composite key of several)."""
+    df = fc_multi._df
+    names, cols = fc_multi.sql_columns("select distinct b from m where p > 0.5")
+    assert names == ["b"] and np.array_equal(cols[0], np.sort(df[df.p > 0.5].b.unique()))
+    names, cols = fc_multi.sql_columns("select distinct c, a from m")
+    e = df[["a", "c"]].drop_duplicates().sort_values(["c", "a"])
+    assert names == ["c", "a"] and np.array_equal(cols[0], e.c.to_numpy()) and np.array_equal(cols[1], e.a.to_numpy())
+    names, cols = fc_multi.sql_columns("select distinct wide1 from m order by wide1 desc limit 5")
+    assert np.array_equal(cols[0], np.sort(df.wide1.unique())[::-1][:5])

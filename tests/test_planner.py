@@ -246,3 +246,11 @@ def test_multi_key_groupby_ir(tables):
         sql_parse(tables, "select col1, count(*) from game_1 group by col1, col1")
     with pytest.raises(Exception, match="col2 is not an aggregation function"):
         sql_parse(tables, "select col1, col2, count(*) from game_1 group by col1, col3")
+
+
+def test_select_distinct_ir(tables):
+    assert parse("select distinct col1 from game_1") == {"select_distinct": {"value": "col1"}, "from": "game_1"}
+    ir = sql_parse(tables, "select distinct col3, col1 from game_1 where col2 > 1")
+    assert ir["g_cols"] == [2, 0] and ir["items"] == [("key", 2), ("key", 0)] and ir["extended"] and ir["where"] == [(1, ">", 1)]
+    with pytest.raises(Exception, match="SELECT DISTINCT takes plain columns"):
+        sql_parse(tables, "select distinct max(col1) from game_1")
