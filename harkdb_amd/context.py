@@ -157,8 +157,21 @@ class FutharkContext:
         ob = ir.get("orderby")
         if ob:
             need.add(ob[0][1])
+        many = ir.get("orderby_all")
+        if many:
+            if any(s[0] != "col" for s, _ in many) or len({d for _, d in many}) != 1:
+                raise Exception("ORDER BY on several keys takes plain columns, all ascending or all descending")
+            need |= {s[1] for s, _ in many}
         cur, cmap = self._filtered(dev, ir.get("where", []), need) if ir.get("where") else (dev, {c: c for c in range(dev.shape[1])})
-        if ob:
+        if many:
+            # several sort keys -> one composite key column (ascending composite = lexicographic order of the tuple)
+            buf, cdt, _, _ = eng.composite_key(cur, [cmap[s[1]] for s, _ in many])
+            cols_needed = sorted(need)
+            view = eng.table_from_device(cur.shape[0], [cur.device_ptr(cmap[c]) for c in cols_needed] + [buf.ptr or 0],
+                                         [cur.dtype(cmap[c]) for c in cols_needed] + [cdt], keepalive=(cur, buf))
+            vmap = {c: j for j, c in enumerate(cols_needed)}
+            res = eng.sort(view, len(cols_needed), [vmap[c] for c in sel], descending=many[0][1])
+        elif ob:
             res = eng.sort(cur, cmap[ob[0][1]], [cmap[c] for c in sel], descending=ob[1])
         else:
             res = eng.query_sel(cur, [cmap[c] for c in sel])
@@ -169,6 +182,8 @@ class FutharkContext:
 
     def _groupby_extended(self, dev, schema, ir):
         eng = self.FutEnv
+        if ir.get("orderby_all"):
+            raise Exception("ORDER BY on several keys is not supported together with GROUP BY")
         g_col, items = ir["g_col"], list(ir["items"])
         g_cols = ir.get("g_cols", [g_col])
         multi = len(g_cols) > 1

@@ -314,6 +314,8 @@ class ShardedFutharkContext:
     def sql_columns(self, sql_statement):
         from .parse import sql_parse
         ir = sql_parse(self.local.tables, sql_statement)
+        if ir.get("orderby_all"):
+            raise Exception("ORDER BY on several keys over sharded tables is not built yet")
         if ir.get("join"):
             return self._join(ir)
         if "groupbys" not in ir:

@@ -163,7 +163,10 @@ def sql_parse(tables, sql_statement):
         ir["having"] = having
         ir["extended"] = True
     if "orderby" in js_obj:
-        ir["orderby"] = (spec_of(js_obj["orderby"]["value"]), js_obj["orderby"].get("sort") == "desc")
+        obs = js_obj["orderby"] if isinstance(js_obj["orderby"], list) else [js_obj["orderby"]]
+        ir["orderby"] = (spec_of(obs[0]["value"]), obs[0].get("sort") == "desc")
+        if len(obs) > 1:                                                # several sort keys (extension of the extension)
+            ir["orderby_all"] = [(spec_of(o["value"]), o.get("sort") == "desc") for o in obs]
         ir["extended"] = True
     if "limit" in js_obj:
         ir["limit"] = int(js_obj["limit"])

@@ -157,13 +157,19 @@ class _Parser:
         if self.peek("kw", "order"):
             self.take()
             self.take("kw", "by")
-            ob = {"value": self.term()}
-            if self.peek("kw", "desc"):
+            obs = []
+            while True:
+                ob = {"value": self.term()}
+                if self.peek("kw", "desc"):
+                    self.take()
+                    ob["sort"] = "desc"
+                elif self.peek("kw", "asc"):
+                    self.take()
+                obs.append(ob)
+                if not self.peek("punct", ","):
+                    break
                 self.take()
-                ob["sort"] = "desc"
-            elif self.peek("kw", "asc"):
-                self.take()
-            tree["orderby"] = ob
+            tree["orderby"] = obs[0] if len(obs) == 1 else obs      # several sort keys -> a list (moz shape)
         if self.peek("kw", "limit"):
             self.take()
             tree["limit"] = self.take("num")

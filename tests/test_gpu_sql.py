@@ -268,3 +268,17 @@ def test_select_distinct(fc_multi):
     assert names == ["c", "a"] and np.array_equal(cols[0], e.c.to_numpy()) and np.array_equal(cols[1], e.a.to_numpy())
     names, cols = fc_multi.sql_columns("select distinct wide1 from m order by wide1 desc limit 5")
     assert np.array_equal(cols[0], np.sort(df.wide1.unique())[::-1][:5])
+
+
+def test_order_by_several_keys(fc_multi):
+    df = fc_multi._df
+    names, cols = fc_multi.sql_columns("select a, b, w from m where p > 0.9 order by a, b, w")
+    e = df[df.p > 0.9].sort_values(["a", "b", "w"], kind="stable")
+    assert np.array_equal(cols[0], e.a.to_numpy()) and np.array_equal(cols[1], e.b.to_numpy()) and np.array_equal(cols[2], e.w.to_numpy())
+    names, cols = fc_multi.sql_columns("select v, wide1, wide2 from m order by wide1 desc, wide2 desc limit 100")
+    e = df.sort_values(["wide1", "wide2"], ascending=False, kind="stable").head(100)          # ties keep table order
+    assert np.array_equal(cols[1], e.wide1.to_numpy()) and np.array_equal(cols[2], e.wide2.to_numpy()) and np.array_equal(cols[0], e.v.to_numpy())
+    with pytest.raises(Exception, match="all ascending or all descending"):
+        fc_multi.sql("select a from m order by a, b desc")
+    with pytest.raises(Exception, match="not supported together with GROUP BY"):
+        fc_multi.sql("select a, count(*) from m group by a order by a, count(*)")

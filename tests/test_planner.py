@@ -254,3 +254,10 @@ def test_select_distinct_ir(tables):
     assert ir["g_cols"] == [2, 0] and ir["items"] == [("key", 2), ("key", 0)] and ir["extended"] and ir["where"] == [(1, ">", 1)]
     with pytest.raises(Exception, match="SELECT DISTINCT takes plain columns"):
         sql_parse(tables, "select distinct max(col1) from game_1")
+
+
+def test_order_by_several_keys_ir(tables):
+    assert parse("select a from t order by a, b desc")["orderby"] == [{"value": "a"}, {"value": "b", "sort": "desc"}]
+    assert parse("select a from t order by a desc")["orderby"] == {"value": "a", "sort": "desc"}       # one key keeps the dict shape
+    ir = sql_parse(tables, "select col1 from game_1 order by col3 desc, col2 desc limit 3")
+    assert ir["orderby"] == (("col", 2), True) and ir["orderby_all"] == [(("col", 2), True), (("col", 1), True)] and ir["limit"] == 3
