@@ -27,7 +27,7 @@ _TOKEN = re.compile(r"""\s*(?:
 _CMP = {">": "gt", ">=": "gte", "<": "lt", "<=": "lte", "=": "eq", "==": "eq", "!=": "neq", "<>": "neq"}
 _FLIP = {"gt": "lt", "gte": "lte", "lt": "gt", "lte": "gte", "eq": "eq", "neq": "neq"}
 AGGREGATES = ("prod", "sum", "max", "min", "count", "avg")
-_KEYWORDS = {"select", "distinct", "from", "where", "group", "by", "having", "order", "limit", "asc", "desc", "as", "and", "join", "inner", "on"}
+_KEYWORDS = {"select", "distinct", "from", "where", "group", "by", "having", "order", "limit", "asc", "desc", "as", "and", "join", "inner", "on", "between"}
 
 
 class SqlSyntaxError(Exception):
@@ -92,6 +92,12 @@ class _Parser:
 
     def comparison(self):
         lhs = self.term()
+        if self.peek("kw", "between"):                       # x BETWEEN a AND b  ==  x >= a AND x <= b
+            self.take()
+            lo = self.term()
+            self.take("kw", "and")
+            hi = self.term()
+            return {"and": [{"gte": [lhs, lo]}, {"lte": [lhs, hi]}]}
         op = _CMP[self.take("op")]
         rhs = self.term()
         if isinstance(lhs, (int, float)) and not isinstance(rhs, (int, float)):
@@ -99,14 +105,14 @@ class _Parser:
         return {op: [lhs, rhs]}
 
     def condition(self):
-        c = self.comparison()
-        if self.peek("kw", "and"):
-            terms = [c]
-            while self.peek("kw", "and"):
-                self.take()
-                terms.append(self.comparison())
-            return {"and": terms}
-        return c
+        terms = []
+        while True:
+            c = self.comparison()
+            terms += c["and"] if "and" in c else [c]         # BETWEEN contributes two comparisons
+            if not self.peek("kw", "and"):
+                break
+            self.take()
+        return terms[0] if len(terms) == 1 else {"and": terms}
 
     def statement(self):
         self.take("kw", "select")

@@ -282,3 +282,10 @@ def test_order_by_several_keys(fc_multi):
         fc_multi.sql("select a from m order by a, b desc")
     with pytest.raises(Exception, match="not supported together with GROUP BY"):
         fc_multi.sql("select a, count(*) from m group by a order by a, count(*)")
+
+
+def test_between(fc_multi):
+    df = fc_multi._df
+    names, cols = fc_multi.sql_columns("select a, w from m where b between 10 and 12 and p > 0.5")
+    e = df[(df.b >= 10) & (df.b <= 12) & (df.p > 0.5)]
+    assert np.array_equal(cols[0], e.a.to_numpy()) and np.array_equal(cols[1], e.w.to_numpy())

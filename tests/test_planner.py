@@ -261,3 +261,9 @@ def test_order_by_several_keys_ir(tables):
     assert parse("select a from t order by a desc")["orderby"] == {"value": "a", "sort": "desc"}       # one key keeps the dict shape
     ir = sql_parse(tables, "select col1 from game_1 order by col3 desc, col2 desc limit 3")
     assert ir["orderby"] == (("col", 2), True) and ir["orderby_all"] == [(("col", 2), True), (("col", 1), True)] and ir["limit"] == 3
+
+
+def test_between():
+    assert parse("select a from t where a between 1 and 5 and b > 2")["where"] == {"and": [{"gte": ["a", 1]}, {"lte": ["a", 5]}, {"gt": ["b", 2]}]}
+    assert parse("select a, count(*) from t group by a having count(*) between 2 and 9")["having"] == \
+        {"and": [{"gte": [{"count": "*"}, 2]}, {"lte": [{"count": "*"}, 9]}]}
