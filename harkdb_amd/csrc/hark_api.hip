@@ -396,7 +396,7 @@ int hark_op_filter_groupby_dense_f32(hark_context *ctx, hark_fgb_plan *plan,
                                      const int32_t *k, const float *v, int64_t n)
 {
     if (!ctx || !plan) return HARK_EARG;
-    if (n < 0 || (n && (!k || !v))) return hark_fail(ctx, HARK_EARG, "filter_groupby: null column");
+    if (n < 0 || (n && !k)) return hark_fail(ctx, HARK_EARG, "filter_groupby: null key column");     // v == NULL: COUNT only
     if (plan->max_rows && n > plan->max_rows) return hark_fail(ctx, HARK_EARG, "filter_groupby: n exceeds the plan's max_rows");
     if (n > 0xFFFFFFFFll) return hark_fail(ctx, HARK_EARG, "filter_groupby: at most 2^32-1 rows per call (shard larger tables)");
     return k_fgb_dense_f32(ctx, plan, p, cmp, thr, k, v, n);

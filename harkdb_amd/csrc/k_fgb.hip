@@ -187,13 +187,15 @@ __global__ void gen_columns_kernel(uint64_t seed, int64_t first_row, int64_t n, 
 // replica of a key used by lane l is (key << RL) | (l & (R-1)).
 // FSUM: the f32-sum operator is compiled in (the headline path: a run-time operator switch in
 // the row loop costs 7 % there); otherwise the operator is the wave-uniform run-time `vop`.
-template <int OP, bool FSUM>
+// VM: 0 = run-time value operator, 1 = f32 sum compiled in, 2 = COUNT only (no value column is read).
+template <int OP, int VM>
 __global__ __launch_bounds__(1024) void fgb_lds_kernel(
     const float *__restrict__ p, const int32_t *__restrict__ k, const float *__restrict__ v,
     int64_t n, float thr, int G, int RL, u64 *__restrict__ gsum,
     unsigned long long *__restrict__ gcnt, int32_t *__restrict__ err, int xf, int vop_rt)
 {
-    const int VOP = FSUM ? (int)VOP_F32SUM : vop_rt;
+    constexpr bool FSUM = VM == 1, CNT = VM == 2;
+    const int VOP = (FSUM || CNT) ? (int)VOP_F32SUM : vop_rt;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int slots = G << RL;
     u64 *s_sum = reinterpret_cast<u64 *>(lds_raw);
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(1024) void fgb_lds_kernel(
             if ((uint32_t)key < (uint32_t)G) {
                 uint32_t s = ((uint32_t)key << RL) | rep;
                 if constexpr (FSUM) vop_atomic<VOP_F32SUM>(&s_sum[s], __float_as_uint(val));      // ds_add_f64
-                else vop_atomic_rt(VOP, &s_sum[s], apply_xf(xf, __float_as_uint(val)));            // ds_{add,max,min}_u32 / ds_add_u64
+                else if constexpr (!CNT) vop_atomic_rt(VOP, &s_sum[s], apply_xf(xf, __float_as_uint(val)));   // ds_{add,max,min}_u32 / ds_add_u64
                 atomicAdd(&s_cnt[s], 1u);                           // ds_add_u32
             } else bad = true;
         }
@@ -226,20 +228,20 @@ __global__ __launch_bounds__(1024) void fgb_lds_kernel(
         float4 pa = OP == kNoPred ? float4{0, 0, 0, 0} : p4[i];
         float4 pb = OP == kNoPred ? float4{0, 0, 0, 0} : p4[i + stride];
         int4 ka = k4[i], kb = k4[i + stride];
-        float4 va = v4[i], vb = v4[i + stride];
+        float4 va = CNT ? float4{0, 0, 0, 0} : v4[i], vb = CNT ? float4{0, 0, 0, 0} : v4[i + stride];
         row(pa.x, ka.x, va.x); row(pa.y, ka.y, va.y); row(pa.z, ka.z, va.z); row(pa.w, ka.w, va.w);
         row(pb.x, kb.x, vb.x); row(pb.y, kb.y, vb.y); row(pb.z, kb.z, vb.z); row(pb.w, kb.w, vb.w);
     }
     for (; i < nvec; i += stride) {
         float4 pa = OP == kNoPred ? float4{0, 0, 0, 0} : p4[i];
         int4 ka = k4[i];
-        float4 va = v4[i];
+        float4 va = CNT ? float4{0, 0, 0, 0} : v4[i];
         row(pa.x, ka.x, va.x); row(pa.y, ka.y, va.y); row(pa.z, ka.z, va.z); row(pa.w, ka.w, va.w);
     }
     // ragged tail (n % 4 rows) by the first lanes of block 0
     if (blockIdx.x == 0) {
         int64_t t = nvec * kVec + threadIdx.x;
-        if (t < n) row(OP == kNoPred ? 0.0f : p[t], k[t], v[t]);
+        if (t < n) row(OP == kNoPred ? 0.0f : p[t], k[t], CNT ? 0.0f : v[t]);
     }
     if (bad) *err = HARK_EBOUNDS;
     __syncthreads();
@@ -250,7 +252,7 @@ __global__ __launch_bounds__(1024) void fgb_lds_kernel(
         for (int r = 0; r < R; r++) { s = vop_merge(VOP, s, s_sum[(g << RL) + r]); c += s_cnt[(g << RL) + r]; }
         if (c) {
             if constexpr (FSUM) vop_atomic_partial<VOP_F32SUM>(&gsum[g], s);   // contiguous global_atomic_add_f64
-            else vop_atomic_partial_rt(VOP, &gsum[g], s);
+            else if constexpr (!CNT) vop_atomic_partial_rt(VOP, &gsum[g], s);
             atomicAdd(&gcnt[g], (unsigned long long)c);
         }
     }
@@ -274,7 +276,7 @@ __global__ __launch_bounds__(256) void fgb_atomic_kernel(
     auto row = [&](float pv, int32_t key, float val) {
         if (cmp_f32<OP>(pv, thr)) {
             if (key >= 0 && (int64_t)key < G) {
-                vop_atomic_rt(vop, &gsum[key], apply_xf(xf, __float_as_uint(val)));
+                if (v) vop_atomic_rt(vop, &gsum[key], apply_xf(xf, __float_as_uint(val)));      // v == null: COUNT only
                 atomicAdd(&gcnt[key], 1ull);
             } else bad = true;
         }
@@ -282,12 +284,12 @@ __global__ __launch_bounds__(256) void fgb_atomic_kernel(
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
         float4 pa = OP == kNoPred ? float4{0, 0, 0, 0} : p4[i];
         int4 ka = k4[i];
-        float4 va = v4[i];
+        float4 va = v ? v4[i] : float4{0, 0, 0, 0};
         row(pa.x, ka.x, va.x); row(pa.y, ka.y, va.y); row(pa.z, ka.z, va.z); row(pa.w, ka.w, va.w);
     }
     if (blockIdx.x == 0) {
         int64_t t = nvec * kVec + threadIdx.x;
-        if (t < n) row(OP == kNoPred ? 0.0f : p[t], k[t], v[t]);
+        if (t < n) row(OP == kNoPred ? 0.0f : p[t], k[t], v ? v[t] : 0.0f);
     }
     if (bad) *err = HARK_EBOUNDS;
 }
@@ -334,9 +336,14 @@ constexpr int kU = 64;                                   // pairs per unit
 constexpr int kUnitBytes = kU * 6;                       // 384
 constexpr int kQ6 = 96;                                  // ring capacity per bucket (pairs)
 constexpr int kFlushPeriod6 = 2;                         // batches between sweeps (every batch once a ring was found full)
-static size_t part_lds_bytes(int P, bool c6)
+// COUNT-only queries (no value column at all): the partition carries bucket-local keys only, units of 64 keys = one
+// 128-byte line, rings of 128 keys; the producer does not even read a value column (8 B/row instead of 12).
+constexpr int kQ2 = 128;
+constexpr int kUnit2Bytes = kU * 2;                      // 128
+static size_t part_lds_bytes(int P, int fmt)             // fmt: 0 = 8-byte pairs, 1 = compact 6-byte pairs, 2 = keys only
 {
-    return (c6 ? (size_t)6 * P * kQ6 : sizeof(uint2) * (size_t)P * kQ) + sizeof(int) * 2 * (size_t)P + 8 + (size_t)kHot * 16 + 32;
+    const size_t q = fmt == 1 ? (size_t)6 * P * kQ6 : fmt == 2 ? (size_t)2 * P * kQ2 : sizeof(uint2) * (size_t)P * kQ;
+    return q + sizeof(int) * 2 * (size_t)P + 8 + (size_t)kHot * 16 + 32;
 }
 
 // Workgroup-wide OR through one LDS word and ONE lds_barrier: three slots used in rotation, the next
@@ -359,7 +366,7 @@ __device__ __forceinline__ bool wg_or(bool pred, uint32_t *flags, int &phase)
 // so the batch loop carries no run-time knobs: a bucket's queue state is ONE word (head << 16 | count,
 // one returning LDS atomic hands a row its slot), keys are range-checked as unsigned 32-bit, and the
 // ragged-end tests only run in the last batch.
-template <int OP, int MODE, bool C6>
+template <int OP, int MODE, int FMT>
 __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
     const float *__restrict__ p, const int32_t *__restrict__ k, const float *__restrict__ v,
     int64_t row0, int64_t row1, float thr, int64_t G, int shift, int P,
@@ -367,15 +374,17 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
     u64 *__restrict__ gsum, unsigned long long *__restrict__ gcnt, int32_t *__restrict__ err, int period_knob, int vop_rt, int xf_rt,
     int hash_bits)
 {
-    constexpr bool HASH = MODE == 2;
+    constexpr bool HASH = MODE == 2, C6 = FMT == 1, K2 = FMT == 2;
     const int vop = MODE == 0 ? (int)VOP_F32SUM : vop_rt;
     const int xf = MODE == 0 ? 0 : xf_rt;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    static_assert(!(C6 && MODE == 2), "compact pairs carry bucket-local keys: dense mode only");
+    static_assert(!((C6 || K2) && MODE == 2), "compact pairs carry bucket-local keys: dense mode only");
     uint2 *queue = reinterpret_cast<uint2 *>(lds_raw);                 // [P][kQ]           8-byte pairs
     uint32_t *qv = reinterpret_cast<uint32_t *>(lds_raw);              // [P][kQ6] values   compact format
     uint16_t *qk = reinterpret_cast<uint16_t *>(qv + (size_t)P * kQ6); // [P][kQ6] bucket-local keys
+    uint16_t *qk2 = reinterpret_cast<uint16_t *>(lds_raw);            // [P][kQ2] bucket-local keys   keys-only format
     uint32_t *s_w = C6 ? reinterpret_cast<uint32_t *>(qk + (size_t)P * kQ6)
+                  : K2 ? reinterpret_cast<uint32_t *>(qk2 + (size_t)P * kQ2)
                        : reinterpret_cast<uint32_t *>(queue + (size_t)P * kQ);   // [P] ring index of the oldest pair << 16 | pairs queued
     int *s_lcur = reinterpret_cast<int *>(s_w + P);                    // [P] lines already stored in this workgroup's slab
     u64 *h_val = reinterpret_cast<u64 *>(s_lcur + P + ((2 * P) & 1)); // [kHot] heavy-hitter partial values (8-byte aligned)
@@ -386,11 +395,11 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
     const int nwg = gridDim.x, wg = blockIdx.x;
     const int64_t nbatch = (row1 - row0 + kBatchRows - 1) / kBatchRows;
     const int cap_lines = (int)(cap / kLine) - 1;                      // the last line is kept for the final partial flush
-    const int cap_units = (int)((size_t)cap * 8 / kUnitBytes) - 1;     // compact format: same slab bytes, the last unit for the final partial flush
+    const int cap_units = (int)((size_t)cap * 8 / (K2 ? kUnit2Bytes : kUnitBytes)) - 1;   // compact formats: same slab bytes, the last unit for the final partial flush
     unsigned char *slab6 = reinterpret_cast<unsigned char *>(pbuf) + (size_t)wg * ((size_t)cap * 8);    // + b * nwg * cap * 8
     const uint32_t kmask = (1u << shift) - 1u;
     auto wrap6 = [](int x) { return x >= kQ6 ? x - kQ6 : x; };
-    int period = period_knob > 0 ? period_knob : (C6 ? kFlushPeriod6 : kFlushPeriod);
+    int period = period_knob > 0 ? period_knob : ((C6 || K2) ? kFlushPeriod6 : kFlushPeriod);
     const uint32_t Gu = (uint32_t)G;                                   // G <= 2^31: one unsigned compare rejects negative keys too
     bool bad = false, overflow = false;
     for (int b = tid; b < P; b += kPartThreads) { s_w[b] = 0u; s_lcur[b] = 0; }
@@ -404,7 +413,7 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
 
     auto vbits_of = [&](float x) -> uint32_t { return MODE == 0 ? __float_as_uint(x) : apply_xf(xf, __float_as_uint(x)); };
     auto direct = [&](uint32_t key, uint32_t vb) {
-        if (MODE == 0) vop_atomic<VOP_F32SUM>(&gsum[key], vb); else vop_atomic_rt(vop, &gsum[key], vb);
+        if (!K2) { if (MODE == 0) vop_atomic<VOP_F32SUM>(&gsum[key], vb); else vop_atomic_rt(vop, &gsum[key], vb); }
         atomicAdd(&gcnt[key], 1ull);
     };
 
@@ -416,11 +425,12 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
             if (OP != kNoPred) { const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(p + r)); pr = float4{t.x, t.y, t.z, t.w}; }
             else pr = float4{0, 0, 0, 0};
             const i4v tk = __builtin_nontemporal_load(reinterpret_cast<const i4v *>(k + r)); kr = int4{tk.x, tk.y, tk.z, tk.w};
-            const f4v tv = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(v + r)); vr = float4{tv.x, tv.y, tv.z, tv.w};
+            if (K2) vr = float4{0, 0, 0, 0};                                 // COUNT only: the value column is not read
+            else { const f4v tv = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(v + r)); vr = float4{tv.x, tv.y, tv.z, tv.w}; }
         } else {                                                       // ragged end of the table
             float pp[4] = {0, 0, 0, 0}; int kk[4] = {0, 0, 0, 0}; float vv[4] = {0, 0, 0, 0};
             for (int j = 0; j < kVec; j++) if (r + j < row1) {
-                pp[j] = OP == kNoPred ? 0.0f : p[r + j]; kk[j] = k[r + j]; vv[j] = v[r + j];
+                pp[j] = OP == kNoPred ? 0.0f : p[r + j]; kk[j] = k[r + j]; vv[j] = K2 ? 0.0f : v[r + j];
             }
             pr = float4{pp[0], pp[1], pp[2], pp[3]}; kr = int4{kk[0], kk[1], kk[2], kk[3]}; vr = float4{vv[0], vv[1], vv[2], vv[3]};
         }
@@ -459,7 +469,7 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
                     bool claimed = false;
                     if (owner == kHotEmpty) { owner = atomicCAS(&h_key[h], kHotEmpty, key); if (owner == kHotEmpty) { owner = key; claimed = true; } }
                     if (owner == key) {
-                        vop_atomic_rt(vop, &h_val[h], vbits_of(vv[j]));
+                        if (!K2) vop_atomic_rt(vop, &h_val[h], vbits_of(vv[j]));
                         atomicAdd(&h_cnt[h], 1u);
                         pending &= ~(1u << j);
                         hits += claimed ? 0u : 1u;                      // a claim is not evidence of skew, a repeat is
@@ -487,6 +497,11 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
                             qv[at] = vbits_of(vv[j]); qk[at] = (uint16_t)(key & kmask);
                             pending &= ~(1u << j);
                         } else atomicSub(&s_w[b], 1u);
+                    } else if (K2) {
+                        if (pos < (uint32_t)kQ2) {
+                            qk2[b * kQ2 + (((old >> 16) + pos) & (kQ2 - 1))] = (uint16_t)(key & kmask);
+                            pending &= ~(1u << j);
+                        } else atomicSub(&s_w[b], 1u);
                     } else
                     if (pos < (uint32_t)kQ) {
                         queue[b * kQ + (((old >> 16) + pos) & (kQ - 1))] = uint2{key, vbits_of(vv[j])};
@@ -496,7 +511,7 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
             }
             // one barrier orders the enqueues before the sweep and tells whether any queue was full
             const bool full = wg_or(pending != 0, or_flags, or_phase);
-            if (C6 && full && ++n_full * 8 > batches_done) period = 1;    // workgroup-uniform: rings overflow in more than 1/8 of the batches (32 pairs
+            if ((C6 || K2) && full && ++n_full * 8 > batches_done) period = 1;    // workgroup-uniform: rings overflow in more than 1/8 of the batches (32 pairs
                                                                           // of headroom are too few for this selectivity / skew): sweep every batch
             if (!(full || flush_now)) break;
             // ---- flush (compact): 8 lanes per bucket store its complete unit, 3 x 16 bytes per lane
@@ -524,6 +539,30 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
                         }
                         if (i == 0) {
                             s_w[b] = ((uint32_t)wrap6(head + kU) << 16) | (uint32_t)(cnt - kU);
+                            s_lcur[b] = min(lc + 1, cap_units);
+                        }
+                    }
+                }
+            } else if (K2) {
+                // ---- flush (keys only): 8 lanes per bucket store its complete unit of 64 keys, one 128-byte line
+                typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+                for (int b = tid >> 3; b < P; b += kPartThreads / 8) {
+                    const uint32_t w = s_w[b];
+                    const int cnt = (int)(w & 0xFFFFu);
+                    if (cnt >= kU) {
+                        const int i = tid & 7, head = (int)(w >> 16), lc = s_lcur[b];
+                        const int ik = (head + 8 * i) & (kQ2 - 1);
+                        const uint4 k0 = *reinterpret_cast<const uint4 *>(&qk2[b * kQ2 + ik]);
+                        if (lc < cap_units) {
+                            unsigned char *dst = slab6 + (size_t)b * nwg * ((size_t)cap * 8) + (size_t)lc * kUnit2Bytes;
+                            __builtin_nontemporal_store(u4v{k0.x, k0.y, k0.z, k0.w}, reinterpret_cast<u4v *>(dst + 16 * i));
+                        } else {                                           // slab full: direct atomics
+                            const uint32_t kb = (uint32_t)b << shift;
+#pragma unroll
+                            for (int q = 0; q < 8; q++) direct(kb | qk2[b * kQ2 + ik + q], 0u);
+                        }
+                        if (i == 0) {
+                            s_w[b] = ((uint32_t)((head + kU) & (kQ2 - 1)) << 16) | (uint32_t)(cnt - kU);
                             s_lcur[b] = min(lc + 1, cap_units);
                         }
                     }
@@ -570,7 +609,7 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
                 __syncthreads();
                 for (int h = tid; h < kHot; h += kPartThreads) {
                     const uint32_t c = h_cnt[h];
-                    if (c) { vop_atomic_partial_rt(vop, &gsum[h_key[h]], h_val[h]); atomicAdd(&gcnt[h_key[h]], (unsigned long long)c); h_cnt[h] = 0u; }
+                    if (c) { if (!K2) vop_atomic_partial_rt(vop, &gsum[h_key[h]], h_val[h]); atomicAdd(&gcnt[h_key[h]], (unsigned long long)c); h_cnt[h] = 0u; }
                 }
                 hot_on = false;
                 __syncthreads();
@@ -602,6 +641,12 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
             counts[(size_t)b * nwg + wg] = (uint32_t)(s_lcur[b] * kU + l);
             continue;
         }
+        if (K2) {
+            unsigned char *dst = slab6 + (size_t)b * nwg * ((size_t)cap * 8) + (size_t)s_lcur[b] * kUnit2Bytes;
+            for (int j = 0; j < l; j++) reinterpret_cast<uint16_t *>(dst)[j] = qk2[b * kQ2 + ((head + j) & (kQ2 - 1))];
+            counts[(size_t)b * nwg + wg] = (uint32_t)(s_lcur[b] * kU + l);
+            continue;
+        }
         const size_t base = ((size_t)b * nwg + wg) * cap + (size_t)s_lcur[b] * kLine;
         for (int j = 0; j < l; j++) pbuf[base + j] = queue[b * kQ + ((head + j) & (kQ - 1))];
         counts[(size_t)b * nwg + wg] = (uint32_t)(s_lcur[b] * kLine + l);
@@ -610,7 +655,7 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
     if (!HASH)
     for (int h = tid; h < kHot; h += kPartThreads) {
         const uint32_t c = h_cnt[h];
-        if (c) { vop_atomic_partial_rt(vop, &gsum[h_key[h]], h_val[h]); atomicAdd(&gcnt[h_key[h]], (unsigned long long)c); }
+        if (c) { if (!K2) vop_atomic_partial_rt(vop, &gsum[h_key[h]], h_val[h]); atomicAdd(&gcnt[h_key[h]], (unsigned long long)c); }
     }
     if (bad) *err = HARK_EBOUNDS;
     if (overflow) *err = kErrOverflow;
@@ -727,6 +772,49 @@ __global__ __launch_bounds__(1024) void fgb_agg6_kernel(
             gsum[kbase + i] = vop_merge(VOP, gsum[kbase + i], s_sum[i]);
             gcnt[kbase + i] += (unsigned long long)c;
         }
+    }
+}
+
+// Consumer of the keys-only format (COUNT): units of 64 bucket-local 16-bit keys = one 128-byte line; an 8-lane group
+// takes a unit (16 bytes = 8 keys per lane), two units in flight per group.
+__global__ __launch_bounds__(1024) void fgb_agg2_kernel(
+    const unsigned char *__restrict__ pbuf, const uint32_t *__restrict__ counts, uint32_t cap, int nwg, int shift,
+    int64_t G, unsigned long long *__restrict__ gcnt)
+{
+    typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int KPB = 1 << shift;
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(lds_raw);
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < KPB; i += blockDim.x) s_cnt[i] = 0u;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const uint32_t max_keys = (uint32_t)((size_t)cap * 8 / kUnit2Bytes) * kU;
+    auto add8 = [&](const u4v q) {
+        atomicAdd(&s_cnt[q.x & 0xFFFFu], 1u); atomicAdd(&s_cnt[q.x >> 16], 1u);
+        atomicAdd(&s_cnt[q.y & 0xFFFFu], 1u); atomicAdd(&s_cnt[q.y >> 16], 1u);
+        atomicAdd(&s_cnt[q.z & 0xFFFFu], 1u); atomicAdd(&s_cnt[q.z >> 16], 1u);
+        atomicAdd(&s_cnt[q.w & 0xFFFFu], 1u); atomicAdd(&s_cnt[q.w >> 16], 1u);
+    };
+    const int piece = lane & 7, sub = lane >> 3;
+    for (int w = wave; w < nwg; w += nwaves) {
+        const uint32_t count = min(counts[(size_t)b * nwg + w], max_keys);
+        const unsigned char *src = pbuf + ((size_t)b * nwg + w) * ((size_t)cap * 8);
+        const uint32_t units = count / kU, rem = count % kU;
+        uint32_t u = sub;
+        for (; u + 8 < units; u += 16) {
+            const u4v a = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(src + (size_t)u * kUnit2Bytes + 16 * piece));
+            const u4v c = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(src + (size_t)(u + 8) * kUnit2Bytes + 16 * piece));
+            add8(a); add8(c);
+        }
+        for (; u < units; u += 8) add8(__builtin_nontemporal_load(reinterpret_cast<const u4v *>(src + (size_t)u * kUnit2Bytes + 16 * piece)));
+        if ((uint32_t)lane < rem) atomicAdd(&s_cnt[reinterpret_cast<const uint16_t *>(src + (size_t)units * kUnit2Bytes)[lane]], 1u);
+    }
+    __syncthreads();
+    const int64_t kbase = (int64_t)b << shift;
+    for (int i = threadIdx.x; i < KPB; i += blockDim.x) {
+        const uint32_t c = s_cnt[i];
+        if (c && kbase + i < G) gcnt[kbase + i] += (unsigned long long)c;     // this workgroup owns [kbase, kbase+KPB)
     }
 }
 
@@ -1136,7 +1224,7 @@ int k_fgb_dense_f32(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cm
     if (n == 0) return HARK_OK;
     const int64_t G = pl->G;
     auto misaligned = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) != 0; };
-    if ((p && misaligned(p)) || misaligned(k) || misaligned(v))
+    if ((p && misaligned(p)) || misaligned(k) || (v && misaligned(v)))
         return hark_fail(ctx, HARK_EARG, "fgb: columns must be 16-byte aligned");
     u64 *gsum = reinterpret_cast<u64 *>(pl->acc_sum);
     const int vop = (int)pl->vop;
@@ -1158,20 +1246,22 @@ int k_fgb_dense_f32(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cm
         int64_t grid = pl->grid ? pl->grid : (int64_t)ctx->num_cu;
         const int64_t need = (n / kVec + 1023) / 1024;
         if (grid > need) grid = need > 0 ? need : 1;
-        auto launch = [&](auto op, auto fsum) -> int {
+        auto launch = [&](auto op, auto vm) -> int {
             constexpr int OP = decltype(op)::value;
-            constexpr bool FSUM = decltype(fsum)::value;
+            constexpr int VM = decltype(vm)::value;
             if (lds > 64 * 1024)
-                HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_lds_kernel<OP, FSUM>),
+                HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_lds_kernel<OP, VM>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             TimedLaunch tl(pl, st, 0);
-            fgb_lds_kernel<OP, FSUM><<<dim3((unsigned)grid), dim3(1024), lds, st>>>(p, k, v, n, thr, (int)G, RL, gsum, gcnt, pl->err, (int)pl->xform, vop);
+            fgb_lds_kernel<OP, VM><<<dim3((unsigned)grid), dim3(1024), lds, st>>>(p, k, v, n, thr, (int)G, RL, gsum, gcnt, pl->err, (int)pl->xform, vop);
             HIP_TRY(ctx, hipGetLastError());
             return HARK_OK;
         };
+        if (!v)                                                          // COUNT only: no value column is read
+            return dispatch_op(cmp, p != nullptr, [&](auto op) -> int { return launch(op, std::integral_constant<int, 2>{}); });
         if (vop == VOP_F32SUM && pl->xform == 0)
-            return dispatch_op(cmp, p != nullptr, [&](auto op) -> int { return launch(op, std::true_type{}); });
-        return dispatch_op(cmp, p != nullptr, [&](auto op) -> int { return launch(op, std::false_type{}); });
+            return dispatch_op(cmp, p != nullptr, [&](auto op) -> int { return launch(op, std::integral_constant<int, 1>{}); });
+        return dispatch_op(cmp, p != nullptr, [&](auto op) -> int { return launch(op, std::integral_constant<int, 0>{}); });
     }
     if (algo == 2) {
         int64_t grid = pl->grid ? pl->grid : (int64_t)ctx->num_cu * 8;
@@ -1199,11 +1289,13 @@ int k_fgb_dense_f32(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cm
             });
             if (rc) return rc;
         }
-        const bool c6 = pl->pairfmt != 1;                             // compact 6-byte pairs unless the 8-byte format is asked for
-        const size_t lds_part = part_lds_bytes(P, c6);
-        const bool fast = vop == VOP_F32SUM && pl->xform == 0;       // the headline operator is compiled in
-        const void *fn = fast ? (c6 ? reinterpret_cast<const void *>(&fgb_part_kernel<OP, 0, true>) : reinterpret_cast<const void *>(&fgb_part_kernel<OP, 0, false>))
-                              : (c6 ? reinterpret_cast<const void *>(&fgb_part_kernel<OP, 1, true>) : reinterpret_cast<const void *>(&fgb_part_kernel<OP, 1, false>));
+        const int fmt = !v ? 2 : pl->pairfmt != 1 ? 1 : 0;           // keys only (COUNT) / compact 6-byte pairs / 8-byte pairs on request
+        const bool c6 = fmt == 1;
+        const size_t lds_part = part_lds_bytes(P, fmt);
+        const bool fast = !v || (vop == VOP_F32SUM && pl->xform == 0);   // the headline operator (and COUNT) is compiled in
+        const void *fn = fmt == 2 ? reinterpret_cast<const void *>(&fgb_part_kernel<OP, 0, 2>)
+                       : fast ? (c6 ? reinterpret_cast<const void *>(&fgb_part_kernel<OP, 0, 1>) : reinterpret_cast<const void *>(&fgb_part_kernel<OP, 0, 0>))
+                              : (c6 ? reinterpret_cast<const void *>(&fgb_part_kernel<OP, 1, 1>) : reinterpret_cast<const void *>(&fgb_part_kernel<OP, 1, 0>));
         HIP_TRY(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part));
         if (lds_agg > 64 * 1024) {
             int rc6 = dispatch_vop(vop, [&](auto vopc) -> int {
@@ -1218,16 +1310,21 @@ int k_fgb_dense_f32(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cm
             {
                 TimedLaunch tl(pl, st, 1);
                 const int period = (int)((pl->ablate >> 12) & 15);            // experiments: batches between sweeps (0 = default)
-#define HARK_LAUNCH_PART(MODE, C6FLAG) fgb_part_kernel<OP, MODE, C6FLAG><<<dim3((unsigned)nwg), dim3(kPartThreads), lds_part, st>>>( \
+#define HARK_LAUNCH_PART(MODE, FMTV) fgb_part_kernel<OP, MODE, FMTV><<<dim3((unsigned)nwg), dim3(kPartThreads), lds_part, st>>>( \
                     p, k, v, r0, r1, thr, G, shift, P, pl->pbuf, pl->counts, (uint32_t)pl->cap, gsum, gcnt, pl->err, period, vop, (int)pl->xform, 0)
-                if (fast) { if (c6) HARK_LAUNCH_PART(0, true); else HARK_LAUNCH_PART(0, false); }
-                else { if (c6) HARK_LAUNCH_PART(1, true); else HARK_LAUNCH_PART(1, false); }
+                if (fmt == 2) HARK_LAUNCH_PART(0, 2);
+                else if (fast) { if (c6) HARK_LAUNCH_PART(0, 1); else HARK_LAUNCH_PART(0, 0); }
+                else { if (c6) HARK_LAUNCH_PART(1, 1); else HARK_LAUNCH_PART(1, 0); }
 #undef HARK_LAUNCH_PART
             }
             HIP_TRY(ctx, hipGetLastError());
             {
                 TimedLaunch tl(pl, st, 2);
-                int rc = dispatch_vop(vop, [&](auto vopc) -> int {
+                int rc = fmt == 2 ? [&]() -> int {
+                    fgb_agg2_kernel<<<dim3((unsigned)P), dim3(1024), (size_t)4 << shift, st>>>(
+                        reinterpret_cast<const unsigned char *>(pl->pbuf), pl->counts, (uint32_t)pl->cap, nwg, shift, G, gcnt);
+                    return HARK_OK;
+                }() : dispatch_vop(vop, [&](auto vopc) -> int {
                     if (c6)
                         fgb_agg6_kernel<decltype(vopc)::value><<<dim3((unsigned)P), dim3(1024), lds_agg, st>>>(
                             reinterpret_cast<const unsigned char *>(pl->pbuf), pl->counts, (uint32_t)pl->cap, nwg, shift, G, gsum, gcnt);
@@ -1361,11 +1458,11 @@ int k_fgb_hash_u32(hark_context *ctx, const uint32_t *k, const uint32_t *v, int6
     uint32_t used_R = 1;
     if (!rc) {
         hipMemsetAsync(err, 0, 16, st);
-        const size_t lds_part = part_lds_bytes(P, false);
-        rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_part_kernel<kNoPred, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part) == hipSuccess
+        const size_t lds_part = part_lds_bytes(P, 0);
+        rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_part_kernel<kNoPred, 2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part) == hipSuccess
                  ? HARK_OK : hark_fail(ctx, HARK_EHIP, "hash group-by: LDS attribute failed");
         if (!rc) {
-            fgb_part_kernel<kNoPred, 2, false><<<dim3((unsigned)nwg), dim3(kPartThreads), lds_part, st>>>(
+            fgb_part_kernel<kNoPred, 2, 0><<<dim3((unsigned)nwg), dim3(kPartThreads), lds_part, st>>>(
                 nullptr, reinterpret_cast<const int32_t *>(k), reinterpret_cast<const float *>(v), 0, n, 0.0f, (int64_t)1 << 32, 0, P,
                 pbuf, counts, (uint32_t)cap, nullptr, nullptr, err, 0, vop, xf, hash_bits);
             rc = read_err(&e);

@@ -525,8 +525,8 @@ int try_dense(hark_context *ctx, const hark_table *db, int32_t where_col, int32_
                 done[q] = 1;
             }
     }
-    if (!rc && ngroups < 0) {                                 // COUNT only (or no aggregate): one pass over the key column
-        rc = run_pass(3, 0, keys);
+    if (!rc && ngroups < 0) {                                 // COUNT only (or no aggregate, e.g. SELECT DISTINCT): no value column is
+        rc = run_pass(0, 0, nullptr);                         // read at all; the partition carries bucket-local keys only
         for (int64_t q = 0; q < n_aggs && !rc; q++) rc = hark_fgb_finish_typed(ctx, plan, plan_of[q].kind, pos, res->cols[(size_t)q + 1].data);
     } else
         for (int64_t q = 0; q < n_aggs && !rc; q++)           // COUNTs that came before the first value pass

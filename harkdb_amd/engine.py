@@ -131,12 +131,13 @@ class FgbPlan:
     MAX_ROWS_PER_CALL = 1 << 31      # the C entry takes < 2^32 rows; larger shards are fed in 16-byte-aligned pieces
 
     def run(self, p, cmp, thr, k, v, n):
-        """Accumulate one batch.  All pointers are raw device addresses (ints)."""
+        """Accumulate one batch.  All pointers are raw device addresses (ints); p = None: no filter,
+        v = None: COUNT only (no value column is read)."""
         op = _ffi.CMP[cmp] if isinstance(cmp, str) else int(cmp)
         for lo in range(0, int(n), self.MAX_ROWS_PER_CALL):
             m = min(self.MAX_ROWS_PER_CALL, int(n) - lo)
             self._eng._chk(self._eng.lib.hark_op_filter_groupby_dense_f32(
-                self._eng.ctx, self._h, None if p is None else p + 4 * lo, op, float(thr), k + 4 * lo, v + 4 * lo, m))
+                self._eng.ctx, self._h, None if p is None else p + 4 * lo, op, float(thr), k + 4 * lo, None if v is None else v + 4 * lo, m))
 
     def acc_ptrs(self):
         """(device address of double[G] sums, device address of int64[G] counts)."""

@@ -169,3 +169,24 @@ def test_key_out_of_range_is_bounds_error(eng):
         plan.finish(s, c)
     assert ei.value.code == EBOUNDS
     plan.free()
+
+
+@pytest.mark.parametrize("G,algo", [(16, 1), (13_000, 1), (1 << 20, 2), (1 << 20, 3), (300_000, 3)])
+@pytest.mark.parametrize("use_pred", [True, False])
+def test_count_only_no_value_column(eng, oracle, G, algo, use_pred):
+    """v = NULL: COUNT only.  No value column is read; the partition path carries bucket-local keys only."""
+    from harkdb_amd.engine import FgbPlan
+    n = 1_000_003
+    p, k, v = oracle.gen_columns(5, 0, n, G, True)
+    dp, dk = eng.alloc(n * 4), eng.alloc(n * 4)
+    eng.upload(dp, p); eng.upload(dk, k)
+    plan = FgbPlan(eng, n, G, algo=algo, chunk_rows=1 << 18)
+    plan.reset(); plan.run(dp if use_pred else None, ">", 0.5, dk, None, n)
+    ds, dc = eng.alloc(G * 4), eng.alloc(G * 8)
+    plan.finish(ds, dc)
+    keep = (p > 0.5) if use_pred else np.ones(n, bool)
+    assert np.array_equal(eng.download(dc, G, np.int64), np.bincount(k[keep], minlength=G))
+    assert not eng.download(ds, G, np.float32).any()
+    plan.free()
+    for q in (dp, dk, ds, dc):
+        eng.free(q)

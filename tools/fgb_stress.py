@@ -29,7 +29,8 @@ while time.time() < t_end:
     p = rng.random(n).astype(np.float32)
     thr = float(rng.choice([-1.0, 0.02, 0.5, 0.98, 2.0]))
     use_pred = bool(rng.random() < 0.8)
-    knobs = {"algo": 3}
+    count_only = bool(rng.random() < 0.25)                    # no value column: keys-only partition format
+    knobs = {"algo": int(rng.choice([3, 3, 3, 2])) if count_only else 3}
     if rng.random() < 0.5:
         knobs["chunk_rows"] = int(rng.choice([8192, 1 << 16, 1 << 20]))
     if rng.random() < 0.3:
@@ -41,7 +42,7 @@ while time.time() < t_end:
     plan = FgbPlan(eng, n, G, **knobs)
     dp, dk, dv = eng.alloc(max(n * 4, 16)), eng.alloc(max(n * 4, 16)), eng.alloc(max(n * 4, 16))
     eng.upload(dp, p); eng.upload(dk, k); eng.upload(dv, v)
-    plan.reset(); plan.run(dp if use_pred else None, ">", thr, dk, dv, n)
+    plan.reset(); plan.run(dp if use_pred else None, ">", thr, dk, None if count_only else dv, n)
     ds, dc = eng.alloc(G * 4), eng.alloc(G * 8)
     plan.finish(ds, dc)
     gs, gc = eng.download(ds, G, np.float32), eng.download(dc, G, np.int64)
@@ -49,10 +50,12 @@ while time.time() < t_end:
     keep = (p > thr) if use_pred else np.ones(n, bool)
     ec = np.bincount(k[keep], minlength=G).astype(np.int64)
     es = np.bincount(k[keep], weights=v[keep].astype(np.float64), minlength=G).astype(np.float32)
+    if count_only:
+        es = np.zeros(G, dtype=np.float32)
     ok = np.array_equal(gc, ec) and np.array_equal(gs, es)
     cases += 1
     if not ok:
-        print("MISMATCH", dict(G=G, n=n, dist=dist, thr=thr, use_pred=use_pred, **knobs), flush=True)
+        print("MISMATCH", dict(G=G, n=n, dist=dist, thr=thr, use_pred=use_pred, count_only=count_only, **knobs), flush=True)
         worst = True
         break
     plan.free(); eng.free(dp); eng.free(dk); eng.free(dv)
