@@ -1,0 +1,83 @@
+"""Random SQL statements through FutharkContext.sql_columns() against pandas on the same frame.
+Usage: python tools/sql_stress.py [seconds] [seed]"""
+import os, sys, time
+import numpy as np, pandas as pd
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from harkdb_amd import FutharkContext
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+fc = FutharkContext(sql_mode=True)
+OPS = {">": "gt", ">=": "ge", "<": "lt", "<=": "le", "=": "eq", "!=": "ne"}
+cases, bad, t_end = 0, None, time.time() + budget
+while time.time() < t_end and bad is None:
+    n = int(rng.choice([7, 5000, 300_000, 1_200_000]))
+    df = pd.DataFrame({
+        "a": rng.integers(-4, 5, n).astype(np.int32), "b": rng.integers(0, int(rng.choice([3, 50, 4000])), n).astype(np.int32),
+        "s": (rng.integers(0, int(rng.choice([10, 3000, 200_000])), n) * 1_000_003 % (2**31)).astype(np.int32),
+        "x": rng.integers(0, 64, n).astype(np.float32), "y": rng.integers(-1000, 1000, n).astype(np.int32), "p": rng.random(n).astype(np.float32)})
+    fc.create_table("t", df)
+    for _ in range(12):
+        where_sql, mask = "", np.ones(n, bool)
+        if rng.random() < 0.6:
+            col = str(rng.choice(["p", "y", "a"])); op = str(rng.choice(list(OPS)))
+            val = float(np.float32(rng.random())) if col == "p" else int(rng.integers(-3, 4)) if col == "a" else int(rng.integers(-900, 900))
+            where_sql = f" where {col} {op} {val!r}"
+            mask = getattr(df[col], OPS[op])(np.float32(val) if col == "p" else val).to_numpy()
+        sub = df[mask]
+        kind = rng.choice(["group", "multi", "distinct", "select"])
+        try:
+            if kind in ("group", "multi"):
+                keys = [str(rng.choice(["a", "b", "s"]))] if kind == "group" else [str(c) for c in rng.choice(["a", "b", "s"], size=2, replace=False)]
+                aggs = [("sum", "x"), ("count", "*"), ("avg", "x"), ("max", "y"), ("min", "y"), ("sum", "y"), ("max", "x")]
+                pick = [aggs[i] for i in rng.choice(len(aggs), size=int(rng.integers(1, 4)), replace=False)]
+                sel = keys + [f"{f}({c})" for f, c in pick]
+                stmt = f"select {', '.join(sel)} from t{where_sql} group by {', '.join(keys)}"
+                g = sub.groupby(keys, sort=True)
+                exp = g.size().reset_index(name="__n")[keys]
+                for f, c in pick:
+                    if f == "count":
+                        exp[f"{f}({c})"] = g.size().to_numpy()
+                    else:
+                        exp[f"{f}({c})"] = getattr(g[c], {"sum": "sum", "avg": "mean", "max": "max", "min": "min"}[f])().to_numpy()
+                if rng.random() < 0.3 and len(exp):
+                    thr = int(np.median(g.size().to_numpy()))
+                    stmt += f" having count(*) >= {thr}"
+                    exp = exp[g.size().to_numpy() >= thr]
+            elif kind == "distinct":
+                keys = [str(c) for c in rng.choice(["a", "b", "s"], size=int(rng.integers(1, 3)), replace=False)]
+                stmt = f"select distinct {', '.join(keys)} from t{where_sql}"
+                exp = sub[keys].drop_duplicates().sort_values(keys)
+            else:
+                cols = [str(c) for c in rng.choice(["a", "b", "y", "x"], size=2, replace=False)]
+                stmt = f"select {', '.join(cols)} from t{where_sql}"
+                exp = sub[cols]
+                if rng.random() < 0.6:
+                    ok = [c for c in cols if c != "x"]
+                    desc = bool(rng.random() < 0.5)
+                    stmt += " order by " + ", ".join(f"{c}{' desc' if desc else ''}" for c in ok)
+                    exp = exp.sort_values(ok, ascending=not desc, kind="stable")
+            lim = int(rng.integers(1, 50)) if rng.random() < 0.3 else None
+            if lim is not None:
+                stmt += f" limit {lim}"
+                exp = exp.head(lim)
+            names, cols_out = fc.sql_columns(stmt)
+            ok_all = names == list(exp.columns) or kind == "select" or kind == "distinct"
+            for got, name in zip(cols_out, exp.columns):
+                e = exp[name].to_numpy()
+                if len(got) != len(e):
+                    ok_all = False
+                elif got.dtype.kind == "f" or e.dtype.kind == "f":
+                    ok_all = ok_all and np.allclose(got.astype(np.float64), e.astype(np.float64), rtol=2e-6, atol=1e-6)
+                else:
+                    ok_all = ok_all and np.array_equal(got.astype(np.int64), e.astype(np.int64))
+            cases += 1
+            if not ok_all:
+                bad = (n, stmt)
+                break
+        except Exception as ex:                                  # noqa: BLE001
+            bad = (n, stmt, repr(ex)[:200])
+            break
+    fc.drop_table("t")
+print(f"{cases} random statements: {'MISMATCH ' + str(bad) if bad else 'all match pandas'}", flush=True)
+sys.exit(1 if bad else 0)
