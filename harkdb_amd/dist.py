@@ -309,7 +309,10 @@ class ShardedFutharkContext:
     def sql(self, sql_statement):
         names, cols = self.sql_columns(sql_statement)
         dtype = np.result_type(*[c.dtype for c in cols]) if cols else np.int32
-        return np.stack([c.astype(dtype, copy=False) for c in cols], axis=1) if cols else np.empty((0, 0), dtype)
+        out = np.empty((len(cols[0]) if cols else 0, len(cols)), dtype=dtype)
+        for j, c in enumerate(cols):
+            out[:, j] = c
+        return out
 
     def sql_columns(self, sql_statement):
         from .parse import sql_parse
