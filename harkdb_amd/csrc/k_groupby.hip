@@ -22,7 +22,6 @@
 int k_argsort_column(hark_context *ctx, const void *col, int dtype, int64_t n, bool descending,
                      uint32_t **perm_out, uint32_t **sorted_words_out);
 int k_gather(hark_context *ctx, const void *src, int esz, const uint32_t *idx, void *dst, int64_t n);
-int k_untransform_keys(hark_context *ctx, const uint32_t *words, int dtype, void *dst, int64_t n);
 int k_sort_column(hark_context *ctx, const void *col, int dtype, int64_t n, bool descending, const uint32_t *payload,
                   uint32_t **vals_out, uint32_t **words_out);
 int k_exclusive_scan_u32(hark_context *ctx, const uint32_t *in, int64_t n, uint32_t *out32, int64_t *out64, int64_t *total_host);
@@ -237,10 +236,12 @@ int grouped_aggregate(hark_context *ctx, const hark_table *db, int key_col, int 
     const bool carried = one_col && carry >= 0;
     int rc = k_sort_column(ctx, db->cols[key_col].data, key_dtype, n, false,
                            carried ? static_cast<const uint32_t *>(db->cols[carry].data) : nullptr, &perm, from_words ? &words : nullptr);
-    if (!rc) rc = hark_alloc(ctx, &sorted_keys, (size_t)n * kesz);
-    if (!rc) rc = from_words ? k_untransform_keys(ctx, words, key_dtype, sorted_keys, n)
-                             : k_gather(ctx, db->cols[key_col].data, kesz, perm, sorted_keys, n);
-    hark_free(ctx, words);                                  // pool blocks are reused in stream order
+    if (!rc && from_words) { sorted_keys = words; words = nullptr; }       // integer keys: the sorted words ARE the sorted keys
+    else if (!rc) {
+        rc = hark_alloc(ctx, &sorted_keys, (size_t)n * kesz);
+        if (!rc) rc = k_gather(ctx, db->cols[key_col].data, kesz, perm, sorted_keys, n);
+    }
+    hark_free(ctx, words);
     if (!rc) rc = hark_alloc(ctx, (void **)&flags, (size_t)n * 4);
     if (!rc) rc = hark_alloc(ctx, (void **)&seg, (size_t)n * 4);
     if (!rc) {

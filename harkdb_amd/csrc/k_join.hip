@@ -26,7 +26,6 @@ int k_argsort_column(hark_context *ctx, const void *col, int dtype, int64_t n, b
 int k_gather(hark_context *ctx, const void *src, int esz, const uint32_t *idx, void *dst, int64_t n);
 int k_sort_column(hark_context *ctx, const void *col, int dtype, int64_t n, bool descending, const uint32_t *payload,
                   uint32_t **vals_out, uint32_t **words_out);
-int k_untransform_keys(hark_context *ctx, const uint32_t *words, int dtype, void *dst, int64_t n);
 int k_exclusive_scan_u32(hark_context *ctx, const uint32_t *in, int64_t n, uint32_t *out32, int64_t *out64, int64_t *total_host);
 
 namespace {
@@ -399,9 +398,15 @@ int hark_entry_sort(hark_context *ctx, hark_result **out, const hark_table *db, 
             for (int64_t q = 0; q < j; q++) first_use = first_use && cols[q] != carry;
             if (first_use) { res->cols[j].data = perm; continue; }
         }
+        if (cols[j] == key_col && key_from_words && words) {             // the sorted keys are the column (first use takes the buffer)
+            bool first_use = true;
+            for (int64_t q = 0; q < j; q++) first_use = first_use && cols[q] != key_col;
+            if (first_use) { res->cols[j].data = words; continue; }
+        }
         rc = hark_alloc(ctx, &res->cols[j].data, (size_t)db->n * esz);
         if (rc) break;
-        if (cols[j] == key_col && key_from_words) rc = k_untransform_keys(ctx, words, kdt, res->cols[j].data, db->n);
+        if (cols[j] == key_col && key_from_words) rc = hipMemcpyAsync(res->cols[j].data, words, (size_t)db->n * 4, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess
+                                                          ? HARK_OK : hark_fail(ctx, HARK_EHIP, "sort: copy failed");
         else if (carried && cols[j] == carry) rc = hipMemcpyAsync(res->cols[j].data, perm, (size_t)db->n * 4, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess
                                                        ? HARK_OK : hark_fail(ctx, HARK_EHIP, "sort: copy failed");
         else rc = k_gather(ctx, db->cols[cols[j]].data, esz, perm, res->cols[j].data, db->n);
@@ -410,7 +415,9 @@ int hark_entry_sort(hark_context *ctx, hark_result **out, const hark_table *db, 
     bool perm_taken = false;
     for (auto &c : res->cols) perm_taken = perm_taken || c.data == perm;
     if (!perm_taken) hark_free(ctx, perm);
-    hark_free(ctx, words);
+    bool words_taken = false;
+    for (auto &c : res->cols) words_taken = words_taken || (words && c.data == words);
+    if (!words_taken) hark_free(ctx, words);
     if (rc) { result_release(ctx, res); return rc; }
     *out = res;
     return HARK_OK;

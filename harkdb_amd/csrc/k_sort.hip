@@ -242,25 +242,17 @@ __global__ __launch_bounds__(256) void transform_keys_kernel(const void *__restr
         for (int64_t i = t0; i < nvec; i += stride) {
             uint4 q = s4[i];
             q.x = sort_word_of(q.x, dtype); q.y = sort_word_of(q.y, dtype); q.z = sort_word_of(q.z, dtype); q.w = sort_word_of(q.w, dtype);
-            d4[i] = q;
+            if (dst) d4[i] = q;                                        // dst == null: only the difference mask is wanted
             acc |= (q.x ^ w0) | (q.y ^ w0) | (q.z ^ w0) | (q.w ^ w0);
         }
-        for (int64_t i = nvec * 4 + t0; i < n; i += stride) { const uint32_t w = sort_word(src, dtype, part, i); dst[i] = w; acc |= w ^ w0; }
+        for (int64_t i = nvec * 4 + t0; i < n; i += stride) { const uint32_t w = sort_word(src, dtype, part, i); if (dst) dst[i] = w; acc |= w ^ w0; }
     } else {
-        for (int64_t i = t0; i < n; i += stride) { const uint32_t w = sort_word(src, dtype, part, i); dst[i] = w; acc |= w ^ w0; }
+        for (int64_t i = t0; i < n; i += stride) { const uint32_t w = sort_word(src, dtype, part, i); if (dst) dst[i] = w; acc |= w ^ w0; }
     }
     if (diff) {
         for (int d = 32; d > 0; d >>= 1) acc |= __shfl_xor(acc, d, 64);
         if ((threadIdx.x & 63) == 0 && acc) atomicOr(diff, acc);
     }
-}
-
-// Sorted sort words back to column values (u32 / i32 keys only: the f32 transform folds -0.0 into +0.0).
-__global__ __launch_bounds__(256) void untransform_keys_kernel(const uint32_t *__restrict__ words, int dtype, uint32_t *__restrict__ dst, int64_t n)
-{
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const uint32_t flip = dtype == HARK_I32 ? 0x80000000u : 0u;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = words[i] ^ flip;
 }
 
 __global__ __launch_bounds__(256) void iota_u32_kernel(uint32_t *__restrict__ dst, int64_t n)
@@ -301,14 +293,15 @@ static int64_t grid256(hark_context *ctx, int64_t n)
     return blocks < 1 ? 1 : blocks;
 }
 
-// Stable sort of n (key, val) pairs ascending by (key ^ xor_mask) as unsigned.  keys_a holds the input keys;
-// keys_b, vals_a, vals_b are scratch of the same size.  The payload of the input is `vals_first` (device, read
+// Stable sort of n (key, val) pairs ascending by (key ^ xor_mask) as unsigned.  The input keys are `keys_first`
+// (device, read only, may be a table column) or, when that is null, the contents of keys_a; keys_a, keys_b,
+// vals_a, vals_b are scratch of the same size.  The payload of the input is `vals_first` (device, read
 // only, may be a table column) or, when null, the input position.  Only the 8-bit passes whose bit is set in
 // pass_mask run (bit b = byte b of the key).  On return *keys_out / *vals_out point at the buffers (among the
 // four) that hold the result.  n < 2^32.
 int k_sort_pairs_u32(hark_context *ctx, uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, uint32_t *vals_b,
                      const uint32_t *vals_first, int64_t n, uint32_t xor_mask, uint32_t *hist_ws, uint32_t pass_mask,
-                     uint32_t **keys_out, uint32_t **vals_out)
+                     uint32_t **keys_out, uint32_t **vals_out, const uint32_t *keys_first = nullptr)
 {
     *keys_out = keys_a; *vals_out = vals_a;
     if (n <= 0) return HARK_OK;
@@ -319,8 +312,8 @@ int k_sort_pairs_u32(hark_context *ctx, uint32_t *keys_a, uint32_t *keys_b, uint
     slice = (slice + kSortTile - 1) / kSortTile * kSortTile;      // whole tiles per slice
     nblk = (n + slice - 1) / slice;
     hipStream_t st = ctx->stream;
-    const uint32_t *kin = keys_a, *vin = vals_first;
-    uint32_t *kout = keys_b, *vout = vals_b;
+    const uint32_t *kin = keys_first ? keys_first : keys_a, *vin = vals_first;
+    uint32_t *kout = keys_first ? keys_a : keys_b, *vout = vals_b;   // a read-only input leaves both scratch buffers free
     bool first = true;
     for (int pass = 0; pass < 4; pass++) {
         if (!((pass_mask >> pass) & 1u)) continue;
@@ -337,6 +330,7 @@ int k_sort_pairs_u32(hark_context *ctx, uint32_t *keys_a, uint32_t *keys_b, uint
         first = false;
     }
     if (first) {                                                   // no pass ran: the order is the input order
+        if (keys_first) HIP_TRY(ctx, hipMemcpyAsync(keys_a, keys_first, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
         if (vals_first) HIP_TRY(ctx, hipMemcpyAsync(vals_a, vals_first, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
         else { iota_u32_kernel<<<dim3((unsigned)grid256(ctx, n)), dim3(256), 0, st>>>(vals_a, n); HIP_TRY(ctx, hipGetLastError()); }
     }
@@ -380,9 +374,9 @@ int k_gather(hark_context *ctx, const void *src, int esz, const uint32_t *idx, v
 // Stable sort of a column of any supported dtype together with a 32-bit payload.  payload == nullptr: the
 // payload is the row id (an argsort); otherwise a device column of n 4-byte values (only for 4-byte keys), which
 // travels with the keys so that no gather is needed afterwards.  On return *vals_out (pool block, n x u32, caller
-// frees) holds the payload in sorted order; if words_out is non-null it receives the sorted 32-bit sort words
-// (u32 / i32 / f32 keys only; k_untransform_keys turns u32 / i32 words back into values).  Radix passes over key
-// bytes in which all keys agree are skipped.
+// frees) holds the payload in sorted order; if words_out is non-null it receives the sorted keys as 32-bit words:
+// the column VALUES themselves for u32 / i32 keys, the order-preserving sort words for f32 keys (equality tests
+// only); not available for i64.  Radix passes over key bytes in which all keys agree are skipped.
 int k_sort_column(hark_context *ctx, const void *col, int dtype, int64_t n, bool descending, const uint32_t *payload,
                   uint32_t **vals_out, uint32_t **words_out)
 {
@@ -399,8 +393,16 @@ int k_sort_column(hark_context *ctx, const void *col, int dtype, int64_t n, bool
     if (!rc) rc = hark_alloc(ctx, (void **)&ws, k_sort_workspace_bytes(n, ctx->num_cu));
     const uint32_t xm = descending ? 0xFFFFFFFFu : 0u;
     uint32_t diff = 0u, *ko = k0, *vo = v0;
-    if (!rc) rc = k_transform_keys(ctx, col, dtype, 0, k0, n, &diff);
-    if (!rc) rc = k_sort_pairs_u32(ctx, k0, k1, v0, v1, payload, n, xm, ws, passes_of(diff), &ko, &vo);
+    if (dtype == HARK_U32 || dtype == HARK_I32) {
+        // integer keys are sorted as they are: the sign flip of i32 is part of the digit mask, the first pass reads the
+        // column itself, and the sorted "words" are the sorted column values (no transform pass, no inverse)
+        if (!rc) rc = k_transform_keys(ctx, col, HARK_U32, 0, nullptr, n, &diff);          // difference mask only
+        if (!rc) rc = k_sort_pairs_u32(ctx, k0, k1, v0, v1, payload, n, xm ^ (dtype == HARK_I32 ? 0x80000000u : 0u), ws, passes_of(diff), &ko, &vo,
+                                       static_cast<const uint32_t *>(col));
+    } else {
+        if (!rc) rc = k_transform_keys(ctx, col, dtype, 0, k0, n, &diff);
+        if (!rc) rc = k_sort_pairs_u32(ctx, k0, k1, v0, v1, payload, n, xm, ws, passes_of(diff), &ko, &vo);
+    }
     if (!rc && dtype == HARK_I64) {
         // LSD over 64 bits: after the low word, sort (stably) by the high word gathered through the current
         // permutation; the permutation travels as the payload.
@@ -436,13 +438,6 @@ int k_argsort_column(hark_context *ctx, const void *col, int dtype, int64_t n, b
     return k_sort_column(ctx, col, dtype, n, descending, nullptr, perm_out, sorted_words_out);
 }
 
-int k_untransform_keys(hark_context *ctx, const uint32_t *words, int dtype, void *dst, int64_t n)
-{
-    if (n <= 0) return HARK_OK;
-    untransform_keys_kernel<<<dim3((unsigned)grid256(ctx, n)), dim3(256), 0, ctx->stream>>>(words, dtype, static_cast<uint32_t *>(dst), n);
-    HIP_TRY(ctx, hipGetLastError());
-    return HARK_OK;
-}
 
 
 // ---------------------------------------------------------------------------
