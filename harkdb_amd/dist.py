@@ -93,10 +93,16 @@ def allreduce_partials(sum_t, cnt_t, group=None):
     f64 sums and of the i64 counts (the RCCL all-reduce of SURVEY.md 8(e))."""
     import torch.distributed as dist
     if dist.is_initialized():          # also with one rank: keeps the single-GPU run on the same code path
-        for t in (sum_t, cnt_t):
-            x, back = _host_staged(t)
-            dist.all_reduce(x, op=dist.ReduceOp.SUM, group=group)
-            back()
+        if sum_t.is_cuda and dist.get_backend() == "gloo":               # tests: ranks sharing one GPU
+            for t in (sum_t, cnt_t):
+                x, back = _host_staged(t)
+                dist.all_reduce(x, op=dist.ReduceOp.SUM, group=group)
+                back()
+        else:
+            # both collectives are issued before either is awaited: the second one's launch overlaps the first
+            works = [dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True) for t in (sum_t, cnt_t)]
+            for w in works:
+                w.wait()
     return sum_t, cnt_t
 
 
