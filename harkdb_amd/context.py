@@ -128,7 +128,7 @@ class FutharkContext:
         (unsigned key, left row, right row); columns re-ordered to the select list."""
         t1, t2 = (self.tables[n] for n in ir["tables"])
         res = self.FutEnv.join(t1._device, t2._device, ir["col1"], ir["col2"], ir["cols1"], ir["cols2"])
-        cols = res.columns()
+        cols = res.columns(limit=ir.get("limit"))
         left_pos = {c: i for i, c in reversed(list(enumerate(ir["cols1"])))}
         right_pos = {c: len(ir["cols1"]) + i for i, c in reversed(list(enumerate(ir["cols2"])))}
         out = [cols[left_pos[c] if s == 0 else right_pos[c]] for s, c in ir["order"]]
@@ -178,7 +178,7 @@ class FutharkContext:
             res = eng.sort(cur, cmap[ob[0][1]], [cmap[c] for c in sel], descending=ob[1])
         else:
             res = eng.query_sel(cur, [cmap[c] for c in sel])
-        cols = res.columns()
+        cols = res.columns(limit=ir.get("limit"))                      # only the first LIMIT rows cross PCIe
         if "limit" in ir:
             cols = [c[: ir["limit"]] for c in cols]
         return cols
@@ -248,7 +248,8 @@ class FutharkContext:
             t = eng.table_from_device(res.shape[0], [res.device_ptr(j) for j in range(m)], [res.dtype(j) for j in range(m)], keepalive=res)
             res = eng.sort(t, order[0], list(range(m)), descending=order[1])
             keep += [t, res]
-        cols = res.columns()
+        # only the first LIMIT rows cross PCIe (unless key conditions / orders still have to run on the decoded result)
+        cols = res.columns(limit=ir.get("limit") if not (host_having or host_order) else None)
         if decode is None:
             out = [cols[s] for s in out_slots]
         else:

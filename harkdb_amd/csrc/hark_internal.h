@@ -104,6 +104,7 @@ struct hark_fgb_plan {
     uint32_t *counts = nullptr;// [P][nwg] pairs in each slab
     double *acc_sum = nullptr; // [G]
     unsigned long long *acc_cnt = nullptr; // [G]
+    unsigned long long *acc_min = nullptr, *acc_max = nullptr;   // [G] order words of the statistics pass (allocated on first use)
     int32_t *err = nullptr;    // device sticky error word
 };
 
@@ -117,6 +118,9 @@ int k_fgb_hash_u32(hark_context *ctx, const uint32_t *k, const uint32_t *v, int6
                    uint32_t **keys_out, unsigned long long **vals_out, unsigned long long **cnts_out, int64_t *G_out, bool *fits,
                    uint32_t *rounds_hint, bool compact);
 
+int k_fgb_dense_stats(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cmp, float thr,
+                      const int32_t *k, const void *v, int64_t n, int vk, bool *ran);
+int hark_fgb_finish_typed_from(hark_context *ctx, hark_fgb_plan *pl, int32_t which, int32_t kind, const uint32_t *pos, void *out);
 int k_fgb_decode(hark_context *ctx, const unsigned long long *acc, const unsigned long long *cnt, int64_t G, int kind, void *out);
 
 // k_select.hip

@@ -372,7 +372,8 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
     int64_t row0, int64_t row1, float thr, int64_t G, int shift, int P,
     uint2 *__restrict__ pbuf, uint32_t *__restrict__ counts, uint32_t cap,
     u64 *__restrict__ gsum, unsigned long long *__restrict__ gcnt, int32_t *__restrict__ err, int period_knob, int vop_rt, int xf_rt,
-    int hash_bits)
+    int hash_bits, int strict /* dense mode without a fallback: no heavy-hitter cache, a full slab or ring reports kErrOverflow
+                                (the statistics pass: the global table cannot take single rows) */)
 {
     constexpr bool HASH = MODE == 2, C6 = FMT == 1, K2 = FMT == 2;
     const int vop = MODE == 0 ? (int)VOP_F32SUM : vop_rt;
@@ -408,7 +409,7 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
     uint32_t *or_flags = h_stat + 4;
     int or_phase = 0;
     int batches_done = 0, since_sweep = 0, n_full = 0;
-    bool hot_on = !HASH;                                               // workgroup-uniform; switched off after the probe unless keys repeat
+    bool hot_on = !HASH && !strict;                                    // workgroup-uniform; switched off after the probe unless keys repeat
     __syncthreads();
 
     auto vbits_of = [&](float x) -> uint32_t { return MODE == 0 ? __float_as_uint(x) : apply_xf(xf, __float_as_uint(x)); };
@@ -531,6 +532,8 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
                             __builtin_nontemporal_store(u4v{v0.x, v0.y, v0.z, v0.w}, reinterpret_cast<u4v *>(dst + 16 * i));
                             __builtin_nontemporal_store(u4v{v1.x, v1.y, v1.z, v1.w}, reinterpret_cast<u4v *>(dst + 128 + 16 * i));
                             __builtin_nontemporal_store(u4v{k0.x, k0.y, k0.z, k0.w}, reinterpret_cast<u4v *>(dst + 256 + 16 * i));
+                        } else if (strict) {
+                            overflow = true;
                         } else {                                           // slab full: direct atomics
                             const uint32_t kb = (uint32_t)b << shift;
                             const uint32_t va[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
@@ -593,8 +596,8 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
                 }
             }
             since_sweep = 0;
-            if (++rounds >= (HASH ? kRetryRoundsHash : kRetryRounds)) {   // bounded: leftovers go through direct atomics
-                if (HASH && pending) { overflow = true; pending = 0; }
+            if (++rounds >= ((HASH || strict) ? kRetryRoundsHash : kRetryRounds)) {   // bounded: leftovers go through direct atomics
+                if ((HASH || strict) && pending) { overflow = true; pending = 0; }
 #pragma unroll
                 for (int j = 0; j < kVec; j++)
                     if (pending & (1u << j)) direct((uint32_t)kv[j], vbits_of(vv[j]));
@@ -815,6 +818,68 @@ __global__ __launch_bounds__(1024) void fgb_agg2_kernel(
     for (int i = threadIdx.x; i < KPB; i += blockDim.x) {
         const uint32_t c = s_cnt[i];
         if (c && kbase + i < G) gcnt[kbase + i] += (unsigned long long)c;     // this workgroup owns [kbase, kbase+KPB)
+    }
+}
+
+// Statistics consumer (SUM / COUNT / AVG + MIN + MAX of ONE value column in one pass): the pairs carry the raw value
+// bits, the bucket's LDS slice holds 20 B per key -- 64-bit sum slot, row count, smallest and largest order word.
+// VK: 0 = f32 values (f64 sum), 1 = i32 (sum of the biased values, like XF_I32_ORDER), 2 = u32.
+template <int VK>
+__global__ __launch_bounds__(1024) void fgb_agg6_stats_kernel(
+    const unsigned char *__restrict__ pbuf, const uint32_t *__restrict__ counts, uint32_t cap, int nwg, int shift,
+    int64_t G, u64 *__restrict__ gsum, unsigned long long *__restrict__ gcnt, u64 *__restrict__ gmin, u64 *__restrict__ gmax)
+{
+    typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+    typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int KPB = 1 << shift;
+    u64 *s_sum = reinterpret_cast<u64 *>(lds_raw);
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(lds_raw + sizeof(u64) * KPB);
+    uint32_t *s_min = s_cnt + KPB, *s_max = s_min + KPB;
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < KPB; i += blockDim.x) { s_sum[i] = 0ull; s_cnt[i] = 0u; s_min[i] = 0xFFFFFFFFu; s_max[i] = 0u; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const uint32_t max_pairs = (uint32_t)((size_t)cap * 8 / kUnitBytes) * kU;
+    auto add = [&](uint32_t key, uint32_t raw) {
+        uint32_t w;
+        if constexpr (VK == 0) { vop_atomic<VOP_F32SUM>(&s_sum[key], raw); w = apply_xf(2, raw); }
+        else if constexpr (VK == 1) { w = raw ^ 0x80000000u; atomicAdd(&s_sum[key], (u64)w); }
+        else { w = raw; atomicAdd(&s_sum[key], (u64)w); }
+        atomicAdd(&s_cnt[key], 1u);
+        atomicMin(&s_min[key], w);
+        atomicMax(&s_max[key], w);
+    };
+    auto add4 = [&](const u4v v, const u2v kk) {
+        add(kk.x & 0xFFFFu, v.x); add(kk.x >> 16, v.y); add(kk.y & 0xFFFFu, v.z); add(kk.y >> 16, v.w);
+    };
+    const int piece = lane & 15, sub = lane >> 4;
+    for (int w = wave; w < nwg; w += nwaves) {
+        const uint32_t count = min(counts[(size_t)b * nwg + w], max_pairs);
+        const unsigned char *src = pbuf + ((size_t)b * nwg + w) * ((size_t)cap * 8);
+        const uint32_t units = count / kU, rem = count % kU;
+        for (uint32_t u = sub; u < units; u += 4) {
+            const unsigned char *a = src + (size_t)u * kUnitBytes;
+            const u4v va = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(a + 16 * piece));
+            const u2v ka = __builtin_nontemporal_load(reinterpret_cast<const u2v *>(a + 4 * kU + 8 * piece));
+            add4(va, ka);
+        }
+        if ((uint32_t)lane < rem) {
+            const unsigned char *a = src + (size_t)units * kUnitBytes;
+            add(reinterpret_cast<const uint16_t *>(a + 4 * kU)[lane], reinterpret_cast<const uint32_t *>(a)[lane]);
+        }
+    }
+    __syncthreads();
+    const int64_t kbase = (int64_t)b << shift;
+    for (int i = threadIdx.x; i < KPB; i += blockDim.x) {
+        const uint32_t c = s_cnt[i];
+        if (c && kbase + i < G) {                           // this workgroup owns [kbase, kbase+KPB)
+            gsum[kbase + i] = VK == 0 ? vop_merge(VOP_F32SUM, gsum[kbase + i], s_sum[i]) : gsum[kbase + i] + s_sum[i];
+            gcnt[kbase + i] += (unsigned long long)c;
+            const u64 mn = gmin[kbase + i], mx = gmax[kbase + i];
+            gmin[kbase + i] = mn < (u64)s_min[i] ? mn : (u64)s_min[i];
+            gmax[kbase + i] = mx > (u64)s_max[i] ? mx : (u64)s_max[i];
+        }
     }
 }
 
@@ -1141,6 +1206,7 @@ int hark_fgb_plan_free(hark_context *ctx, hark_fgb_plan *pl)
     hark_free(ctx, pl->err);
     hark_free(ctx, pl->acc_sum);
     hark_free(ctx, pl->acc_cnt);
+    hark_free(ctx, pl->acc_min); hark_free(ctx, pl->acc_max);
     for (auto e : pl->ev) hipEventDestroy(e);
     delete pl;
     return HARK_OK;
@@ -1311,7 +1377,7 @@ int k_fgb_dense_f32(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cm
                 TimedLaunch tl(pl, st, 1);
                 const int period = (int)((pl->ablate >> 12) & 15);            // experiments: batches between sweeps (0 = default)
 #define HARK_LAUNCH_PART(MODE, FMTV) fgb_part_kernel<OP, MODE, FMTV><<<dim3((unsigned)nwg), dim3(kPartThreads), lds_part, st>>>( \
-                    p, k, v, r0, r1, thr, G, shift, P, pl->pbuf, pl->counts, (uint32_t)pl->cap, gsum, gcnt, pl->err, period, vop, (int)pl->xform, 0)
+                    p, k, v, r0, r1, thr, G, shift, P, pl->pbuf, pl->counts, (uint32_t)pl->cap, gsum, gcnt, pl->err, period, vop, (int)pl->xform, 0, 0)
                 if (fmt == 2) HARK_LAUNCH_PART(0, 2);
                 else if (fast) { if (c6) HARK_LAUNCH_PART(0, 1); else HARK_LAUNCH_PART(0, 0); }
                 else { if (c6) HARK_LAUNCH_PART(1, 1); else HARK_LAUNCH_PART(1, 0); }
@@ -1424,6 +1490,77 @@ int hark_fgb_finish_typed(hark_context *ctx, hark_fgb_plan *pl, int32_t kind, co
     return fgb_check_err(ctx, pl);
 }
 
+// One pass for SUM / COUNT / AVG + MIN + MAX of ONE 4-byte value column (vk: 0 f32, 1 i32, 2 u32).  Only the partition
+// path with <= 4096 keys per bucket qualifies (20 B per key of LDS in the consumer); *ran is false otherwise, and also
+// when the data overflowed a slab or a ring (heavy skew: this pass has no single-row fallback) -- the caller then runs
+// the separate passes.  Accumulators: acc_sum / acc_cnt as usual, acc_min / acc_max as order words in 64-bit slots.
+int k_fgb_dense_stats(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cmp, float thr,
+                      const int32_t *k, const void *v, int64_t n, int vk, bool *ran)
+{
+    *ran = false;
+    const int64_t G = pl->G;
+    if (n <= 0 || pl->algo != 0 || G * 12 <= kLdsTableBudget || G > (int64_t)kMaxBuckets * 4096 || n > pl->max_rows) return HARK_OK;
+    auto misaligned = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) != 0; };
+    if ((p && misaligned(p)) || misaligned(k) || misaligned(v)) return HARK_OK;
+    HARK_TRY(plan_prepare_partition(ctx, pl));
+    const int P = (int)pl->P, shift = (int)pl->shift, nwg = (int)pl->nwg;
+    if (shift > 12) return HARK_OK;
+    if (!pl->acc_min) HARK_TRY(hark_alloc(ctx, (void **)&pl->acc_min, (size_t)G * 8));
+    if (!pl->acc_max) HARK_TRY(hark_alloc(ctx, (void **)&pl->acc_max, (size_t)G * 8));
+    hipStream_t st = ctx->stream;
+    const int64_t blocks = (G + 255) / 256 > (int64_t)ctx->num_cu * 4 ? (int64_t)ctx->num_cu * 4 : (G + 255) / 256;
+    HIP_TRY(ctx, hipMemsetAsync(pl->acc_sum, 0, (size_t)G * 8, st));
+    HIP_TRY(ctx, hipMemsetAsync(pl->acc_cnt, 0, (size_t)G * 8, st));
+    fgb_fill_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(pl->acc_min, G, 0xFFFFFFFFull);
+    HIP_TRY(ctx, hipMemsetAsync(pl->acc_max, 0, (size_t)G * 8, st));
+    u64 *gsum = reinterpret_cast<u64 *>(pl->acc_sum);
+    const size_t lds_agg = (size_t)20 << shift, lds_part = part_lds_bytes(P, 1);
+    int rc = dispatch_op(cmp, p != nullptr, [&](auto op) -> int {
+        constexpr int OP = decltype(op)::value;
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_part_kernel<OP, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part));
+        for (int64_t r0 = 0; r0 < n; r0 += pl->chunk_rows) {
+            const int64_t r1 = r0 + pl->chunk_rows < n ? r0 + pl->chunk_rows : n;
+            {
+                TimedLaunch tl(pl, st, 1);
+                fgb_part_kernel<OP, 0, 1><<<dim3((unsigned)nwg), dim3(kPartThreads), lds_part, st>>>(
+                    p, k, static_cast<const float *>(v), r0, r1, thr, G, shift, P, pl->pbuf, pl->counts, (uint32_t)pl->cap, gsum, pl->acc_cnt, pl->err, 0, 0, 0, 0, 1);
+            }
+            HIP_TRY(ctx, hipGetLastError());
+            TimedLaunch tl(pl, st, 2);
+#define HARK_STATS(VK) do { \
+                if (lds_agg > 64 * 1024) HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_agg6_stats_kernel<VK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_agg)); \
+                fgb_agg6_stats_kernel<VK><<<dim3((unsigned)P), dim3(1024), lds_agg, st>>>(reinterpret_cast<const unsigned char *>(pl->pbuf), pl->counts, \
+                    (uint32_t)pl->cap, nwg, shift, G, gsum, pl->acc_cnt, pl->acc_min, pl->acc_max); } while (0)
+            if (vk == 0) HARK_STATS(0); else if (vk == 1) HARK_STATS(1); else HARK_STATS(2);
+#undef HARK_STATS
+            HIP_TRY(ctx, hipGetLastError());
+        }
+        return HARK_OK;
+    });
+    if (rc) return rc;
+    int64_t e = 0;
+    HARK_TRY(hark_read_words(ctx, pl->err, &e, 1));                // err is an int32 in a >= 8-byte pool block
+    const int32_t code = (int32_t)(e & 0xFFFFFFFFll);
+    if (code != 0) HIP_TRY(ctx, hipMemsetAsync(pl->err, 0, sizeof(int32_t), st));
+    if (code == kErrOverflow) return HARK_OK;                      // *ran stays false: the caller runs the separate passes
+    if (code != 0) return hark_fail(ctx, code, "filter_groupby: a surviving row has a key outside [0, %lld)", (long long)G);
+    *ran = true;
+    return HARK_OK;
+}
+
+// Typed read-out of one of the plan's accumulator arrays: which = 0 acc_sum, 1 acc_min, 2 acc_max.
+int hark_fgb_finish_typed_from(hark_context *ctx, hark_fgb_plan *pl, int32_t which, int32_t kind, const uint32_t *pos, void *out)
+{
+    if (!ctx || !pl || !out || kind < 0 || kind > 11 || kind == 6 || which < 0 || which > 2) return HARK_EARG;
+    const u64 *acc = which == 0 ? reinterpret_cast<const u64 *>(pl->acc_sum) : which == 1 ? pl->acc_min : pl->acc_max;
+    if (!acc) return hark_fail(ctx, HARK_EARG, "fgb: this plan has no min/max accumulators");
+    int64_t blocks = (pl->G + 255) / 256;
+    if (blocks > (int64_t)ctx->num_cu * 4) blocks = (int64_t)ctx->num_cu * 4;
+    fgb_decode_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(acc, pl->acc_cnt, pl->G, kind, pos, out);
+    HIP_TRY(ctx, hipGetLastError());
+    return HARK_OK;
+}
+
 // GROUP BY over arbitrary u32 keys with one value operator: hash-partition (producer in hash
 // mode) + LDS hash tables (fgb_agg_hash_kernel).  Returns UNORDERED (key, value slot, count)
 // arrays on the device (caller frees with hark_free) and the number of groups.  *fits is false
@@ -1464,7 +1601,7 @@ int k_fgb_hash_u32(hark_context *ctx, const uint32_t *k, const uint32_t *v, int6
         if (!rc) {
             fgb_part_kernel<kNoPred, 2, 0><<<dim3((unsigned)nwg), dim3(kPartThreads), lds_part, st>>>(
                 nullptr, reinterpret_cast<const int32_t *>(k), reinterpret_cast<const float *>(v), 0, n, 0.0f, (int64_t)1 << 32, 0, P,
-                pbuf, counts, (uint32_t)cap, nullptr, nullptr, err, 0, vop, xf, hash_bits);
+                pbuf, counts, (uint32_t)cap, nullptr, nullptr, err, 0, vop, xf, hash_bits, 0);
             rc = read_err(&e);
         }
     }

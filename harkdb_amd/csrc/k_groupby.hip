@@ -491,32 +491,61 @@ int try_dense(hark_context *ctx, const hark_table *db, int32_t where_col, int32_
     uint32_t *flags = nullptr, *pos = nullptr;
     int64_t ngroups = -1;
     std::vector<char> done((size_t)n_aggs, 0);
+    auto group_set = [&]() -> int {                            // the first pass also yields the group set
+        if (ngroups >= 0) return HARK_OK;
+        int r = hark_alloc(ctx, (void **)&flags, (size_t)G * 4);
+        if (!r) r = hark_alloc(ctx, (void **)&pos, (size_t)G * 4);
+        if (!r) {
+            nonzero_flags_kernel<<<grid_for(ctx, G), 256, 0, ctx->stream>>>(plan->acc_cnt, G, flags);
+            r = k_exclusive_scan_u32(ctx, flags, G, pos, nullptr, &ngroups);
+        }
+        if (!r) {
+            res->n = ngroups;
+            res->cols.resize((size_t)n_aggs + 1);
+            res->cols[0].dtype = kdt;
+            r = hark_alloc(ctx, &res->cols[0].data, (size_t)ngroups * 4);
+            if (!r) r = hark_fgb_finish_typed(ctx, plan, 10, pos, res->cols[0].data);
+            for (int64_t j = 0; j < n_aggs && !r; j++) {
+                res->cols[(size_t)j + 1].dtype = plan_of[j].out_dtype;
+                r = hark_alloc(ctx, &res->cols[(size_t)j + 1].data, (size_t)ngroups * hark_dtype_size(plan_of[j].out_dtype));
+            }
+        }
+        return r;
+    };
     auto run_pass = [&](int vop, int xf, const void *col) -> int {
         int r = hark_fgb_plan_set(plan, "vop", vop);
         if (!r) r = hark_fgb_plan_set(plan, "xform", xf);
         if (!r) r = hark_fgb_reset(ctx, plan);
         if (!r && src->n > 0) r = k_fgb_dense_f32(ctx, plan, p, cmp, thr, keys, static_cast<const float *>(col), src->n);
-        if (!r && ngroups < 0) {                              // the first pass also yields the group set
-            r = hark_alloc(ctx, (void **)&flags, (size_t)G * 4);
-            if (!r) r = hark_alloc(ctx, (void **)&pos, (size_t)G * 4);
-            if (!r) {
-                nonzero_flags_kernel<<<grid_for(ctx, G), 256, 0, ctx->stream>>>(plan->acc_cnt, G, flags);
-                r = k_exclusive_scan_u32(ctx, flags, G, pos, nullptr, &ngroups);
-            }
-            if (!r) {
-                res->n = ngroups;
-                res->cols.resize((size_t)n_aggs + 1);
-                res->cols[0].dtype = kdt;
-                r = hark_alloc(ctx, &res->cols[0].data, (size_t)ngroups * 4);
-                if (!r) r = hark_fgb_finish_typed(ctx, plan, 10, pos, res->cols[0].data);
-                for (int64_t j = 0; j < n_aggs && !r; j++) {
-                    res->cols[(size_t)j + 1].dtype = plan_of[j].out_dtype;
-                    r = hark_alloc(ctx, &res->cols[(size_t)j + 1].data, (size_t)ngroups * hark_dtype_size(plan_of[j].out_dtype));
-                }
-            }
-        }
+        if (!r) r = group_set();
         return r;
     };
+    // ---- statistics pass: a column that needs two or more of {SUM/AVG, MIN, MAX} gets them (and COUNT) from ONE
+    // producer + consumer pass (k_fgb_dense_stats); it declines (ran == false) for small G, > 4096 keys per bucket or
+    // skewed data, and the separate passes below take over
+    auto cls = [](const DensePass &d) { return d.count_only ? 0 : (d.vop == 0 || d.vop == 5) ? 1 : d.vop == 2 ? 2 : d.vop == 3 ? 4 : 0; };
+    for (int64_t j = 0; j < n_aggs && !rc && src->n > 0; j++) {
+        if (done[j] || !cls(plan_of[j])) continue;
+        const int c = plan_of[j].col;
+        int classes = 0;
+        for (int64_t q = 0; q < n_aggs; q++) if (!done[q] && !plan_of[q].count_only && plan_of[q].col == c) classes |= cls(plan_of[q]);
+        if (__builtin_popcount(classes) < 2) continue;
+        const int dt = src->cols[c].dtype, vk = dt == HARK_F32 ? 0 : dt == HARK_I32 ? 1 : 2;
+        bool ran = false;
+        rc = hark_fgb_plan_set(plan, "vop", 0);
+        if (!rc) rc = hark_fgb_plan_set(plan, "xform", 0);
+        if (!rc) rc = k_fgb_dense_stats(ctx, plan, p, cmp, thr, keys, src->cols[c].data, src->n, vk, &ran);
+        if (rc || !ran) continue;
+        rc = group_set();
+        for (int64_t q = 0; q < n_aggs && !rc; q++) {
+            if (done[q]) continue;
+            const int k = cls(plan_of[q]);
+            if (plan_of[q].count_only) rc = hark_fgb_finish_typed_from(ctx, plan, 0, plan_of[q].kind, pos, res->cols[(size_t)q + 1].data);
+            else if (k && plan_of[q].col == c) rc = hark_fgb_finish_typed_from(ctx, plan, k == 1 ? 0 : k == 2 ? 2 : 1, plan_of[q].kind, pos, res->cols[(size_t)q + 1].data);
+            else continue;
+            done[q] = 1;
+        }
+    }
     for (int64_t j = 0; j < n_aggs && !rc; j++) {
         if (done[j] || plan_of[j].count_only) continue;
         rc = run_pass(plan_of[j].vop, plan_of[j].xf, src->cols[plan_of[j].col].data);

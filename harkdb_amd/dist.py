@@ -457,7 +457,7 @@ class ShardedFutharkContext:
         recv, nrecv = repartition_device(eng, ptrs, dts, n, 0, self.device, self.world, splitters=splitters, descending=desc)
         t = eng.table_from_device(nrecv, [c.data_ptr() for c in recv], dts, keepalive=(recv, cur))
         res = eng.sort(t, 0, [need.index(c) for c in ir["select"]], descending=desc)
-        cols = res.columns()
+        cols = res.columns(limit=ir.get("limit"))
         if "limit" in ir:
             cols = [c[: ir["limit"]] for c in cols]
         cols = gather_columns(cols)

@@ -26,14 +26,17 @@ class Result:
     def dtype(self, j):
         return _ffi.NP_OF[self._eng.lib.hark_result_dtype(self._h, j)]
 
-    def column(self, j):
+    def column(self, j, limit=None):
+        """Column j on the host; limit = n downloads only the first n rows (LIMIT is applied before the PCIe copy)."""
         n, _ = self.shape
+        if limit is not None and limit < n:
+            return self._eng.download(self.device_ptr(j), max(int(limit), 0), self.dtype(j))
         out = np.empty(n, dtype=self.dtype(j))
         self._eng._chk(self._eng.lib.hark_result_column(self._eng.ctx, self._h, j, out.ctypes.data))
         return out
 
-    def columns(self):
-        return [self.column(j) for j in range(self.shape[1])]
+    def columns(self, limit=None):
+        return [self.column(j, limit) for j in range(self.shape[1])]
 
     def device_ptr(self, j):
         return self._eng.lib.hark_result_column_device(self._h, j)

@@ -289,3 +289,32 @@ def test_between(fc_multi):
     names, cols = fc_multi.sql_columns("select a, w from m where b between 10 and 12 and p > 0.5")
     e = df[(df.b >= 10) & (df.b <= 12) & (df.p > 0.5)]
     assert np.array_equal(cols[0], e.a.to_numpy()) and np.array_equal(cols[1], e.w.to_numpy())
+
+
+@pytest.mark.parametrize("skew", [False, True])
+def test_statistics_of_one_column_in_one_pass(skew):
+    """SUM / AVG / MIN / MAX / COUNT of one column over a large dense key domain come from ONE producer + consumer
+    pass (k_fgb_dense_stats); with heavily skewed keys that pass declines and the separate passes give the same rows."""
+    from harkdb_amd import FutharkContext
+    rng = np.random.default_rng(8)
+    n, G = 700_000, 150_000
+    k = rng.integers(0, G, n).astype(np.int32)
+    if skew:
+        k[: n // 2] = 77                                             # half of the rows on one key
+    df = pd.DataFrame({"k": k, "p": rng.random(n).astype(np.float32), "f": (rng.integers(-500, 500, n) / 4).astype(np.float32),
+                       "i": rng.integers(-10**6, 10**6, n).astype(np.int32), "u": rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)})
+    c = FutharkContext(sql_mode=True)
+    c.create_table("t", df)
+    names, cols = c.sql_columns("select k, min(f), max(f), avg(f), sum(f), count(*), max(i), sum(i), min(i), min(u), max(u), avg(u) "
+                                "from t where p > 0.3 group by k")
+    g = df[df.p > 0.3].groupby("k").agg(mnf=("f", "min"), mxf=("f", "max"), avf=("f", "mean"), sf=("f", "sum"), n=("f", "count"),
+                                        mxi=("i", "max"), si=("i", "sum"), mni=("i", "min"), mnu=("u", "min"), mxu=("u", "max"),
+                                        avu=("u", "mean")).reset_index()
+    exp = [g.k, g.mnf, g.mxf, g.avf, g.sf, g.n, g.mxi, g.si, g.mni, g.mnu, g.mxu, g.avu]
+    assert len(cols) == len(exp)
+    for got, e, name in zip(cols, exp, names):
+        e = e.to_numpy()
+        if got.dtype.kind == "f":
+            assert np.allclose(got.astype(np.float64), e.astype(np.float64), rtol=2e-6), name
+        else:
+            assert np.array_equal(got.astype(np.int64), e.astype(np.int64)), name

@@ -15,6 +15,7 @@ while time.time() < t_end and bad is None:
     df = pd.DataFrame({
         "a": rng.integers(-4, 5, n).astype(np.int32), "b": rng.integers(0, int(rng.choice([3, 50, 4000])), n).astype(np.int32),
         "s": (rng.integers(0, int(rng.choice([10, 3000, 200_000])), n) * 1_000_003 % (2**31)).astype(np.int32),
+        "d": rng.integers(0, int(rng.choice([20_000, 300_000])), n).astype(np.int32),       # dense keys beyond the LDS path
         "x": rng.integers(0, 64, n).astype(np.float32), "y": rng.integers(-1000, 1000, n).astype(np.int32), "p": rng.random(n).astype(np.float32)})
     fc.create_table("t", df)
     for _ in range(12):
@@ -28,7 +29,7 @@ while time.time() < t_end and bad is None:
         kind = rng.choice(["group", "multi", "distinct", "select"])
         try:
             if kind in ("group", "multi"):
-                keys = [str(rng.choice(["a", "b", "s"]))] if kind == "group" else [str(c) for c in rng.choice(["a", "b", "s"], size=2, replace=False)]
+                keys = [str(rng.choice(["a", "b", "s", "d", "d"]))] if kind == "group" else [str(c) for c in rng.choice(["a", "b", "s"], size=2, replace=False)]
                 aggs = [("sum", "x"), ("count", "*"), ("avg", "x"), ("max", "y"), ("min", "y"), ("sum", "y"), ("max", "x")]
                 pick = [aggs[i] for i in rng.choice(len(aggs), size=int(rng.integers(1, 4)), replace=False)]
                 sel = keys + [f"{f}({c})" for f, c in pick]
