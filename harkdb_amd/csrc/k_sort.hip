@@ -407,15 +407,15 @@ int k_sort_column(hark_context *ctx, const void *col, int dtype, int64_t n, bool
         // LSD over 64 bits: after the low word, sort (stably) by the high word gathered through the current
         // permutation; the permutation travels as the payload.
         uint32_t *kf = (ko == k0) ? k1 : k0, *vf = (vo == v0) ? v1 : v0;           // the free buffer of each pair
-        rc = k_transform_keys(ctx, col, dtype, 1, ko, n, &diff);                   // ko's sorted low words are no longer needed
-        if (!rc) rc = k_gather(ctx, ko, 4, vo, kf, n);
-        uint32_t *ko2 = kf, *vo2 = vo;
-        // buffers: keys in kf (scratch ko), payload = vo (read only in the first pass, then ping-pong vf <-> vo)
-        if (!rc) {
-            if (passes_of(diff) == 0u) { ko2 = kf; vo2 = vo; }
-            else rc = k_sort_pairs_u32(ctx, kf, ko, vo, vf, vo, n, xm, ws, passes_of(diff), &ko2, &vo2);
+        rc = k_transform_keys(ctx, col, dtype, 1, nullptr, n, &diff);              // do the high words differ at all?
+        if (!rc && passes_of(diff) != 0u) {                                        // (counts and sums below 2^32 do not: done)
+            rc = k_transform_keys(ctx, col, dtype, 1, ko, n, nullptr);             // ko's sorted low words are no longer needed
+            if (!rc) rc = k_gather(ctx, ko, 4, vo, kf, n);
+            uint32_t *ko2 = kf, *vo2 = vo;
+            // buffers: keys in kf (scratch ko), payload = vo (read only in the first pass, then ping-pong vf <-> vo)
+            if (!rc) rc = k_sort_pairs_u32(ctx, kf, ko, vo, vf, vo, n, xm, ws, passes_of(diff), &ko2, &vo2);
+            ko = ko2; vo = vo2;
         }
-        ko = ko2; vo = vo2;
     }
     if (rc == HARK_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "sort kernels failed");
     uint32_t *bufs[4] = {k0, k1, v0, v1};
