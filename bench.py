@@ -67,8 +67,41 @@ def cpu_baseline(rows, G, exact):
             "algorithm": "oracle/hark_oracle.c ora_filter_groupby_refalgo_f32 = groupby.fut:8-58 + segmented.fut:7-37"}, (keys, sums, counts)
 
 
+def launch_ranks(a):
+    """`python bench.py --gpus N` run bare (no torchrun): start N rank processes of this same script, one per GPU,
+    with the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), and exit with the worst return code.
+    The parent has not imported torch or touched HIP, and nothing is exec'd over an initialised process."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = str(so.getsockname()[1])
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rcs = []
+    try:
+        for pr in procs:
+            rcs.append(pr.wait())
+    finally:
+        for pr in procs:                        # a rank that died leaves the others waiting in a collective
+            if pr.poll() is None:
+                try:
+                    pr.wait(timeout=30)
+                except Exception:
+                    pr.kill()
+    bad = [rc for rc in rcs if rc]
+    raise SystemExit(bad[0] if bad else 0)
+
+
 def main():
     a = parse_args()
+    if a.gpus > 1 and "RANK" not in os.environ:
+        launch_ranks(a)
     import torch
     import torch.distributed as dist
     from harkdb_amd import dist as hd
