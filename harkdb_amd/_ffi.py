@@ -40,6 +40,7 @@ SIGNATURES = {
     "hark_context_sync": (C.c_int, [_vp]),
     "hark_context_get_error": (C.c_char_p, [_vp]),
     "hark_context_set_stream": (C.c_int, [_vp, _vp]),
+    "hark_context_trim": (C.c_int, [_vp]),
     "hark_table_new_2d": (C.c_int, [_vp, _pp, _vp, C.c_int, _i64, _i64, _i64, _i64]),
     "hark_table_new_columns": (C.c_int, [_vp, _pp, _i64, _i64, C.POINTER(_i32), _pp]),
     "hark_table_from_device": (C.c_int, [_vp, _pp, _i64, _i64, C.POINTER(_i32), _pp]),
@@ -87,6 +88,50 @@ SIGNATURES = {
     "hark_dev_upload": (C.c_int, [_vp, _vp, _vp, _i64]),
     "hark_dev_download": (C.c_int, [_vp, _vp, _vp, _i64]),
 }
+
+# The generated-Futhark-C-API names (include/futhark_compat.h): what `futhark_ffi.Futhark(_main)` binds in the
+# reference (FutharkContext.py:31-41).  The package itself goes through the hark_* names above; these are bound for
+# callers (and tests) that speak the reference's FFI.
+FUTHARK_SIGNATURES = {
+    "futhark_context_config_new": (_vp, []),
+    "futhark_context_config_free": (None, [_vp]),
+    "futhark_context_config_set_debugging": (None, [_vp, C.c_int]),
+    "futhark_context_config_set_profiling": (None, [_vp, C.c_int]),
+    "futhark_context_config_set_logging": (None, [_vp, C.c_int]),
+    "futhark_context_config_set_device": (None, [_vp, C.c_char_p]),
+    "futhark_context_new": (_vp, [_vp]),
+    "futhark_context_free": (None, [_vp]),
+    "futhark_context_sync": (C.c_int, [_vp]),
+    "futhark_context_get_error": (_vp, [_vp]),               # malloc'd char*: the caller frees it
+    "futhark_context_report": (_vp, [_vp]),
+    "futhark_context_clear_caches": (C.c_int, [_vp]),
+    "futhark_context_pause_profiling": (None, [_vp]),
+    "futhark_context_unpause_profiling": (None, [_vp]),
+    "futhark_new_i32_1d": (_vp, [_vp, _vp, _i64]),
+    "futhark_free_i32_1d": (C.c_int, [_vp, _vp]),
+    "futhark_values_i32_1d": (C.c_int, [_vp, _vp, _vp]),
+    "futhark_shape_i32_1d": (C.POINTER(_i64), [_vp, _vp]),
+    "futhark_new_i32_2d": (_vp, [_vp, _vp, _i64, _i64]),
+    "futhark_free_i32_2d": (C.c_int, [_vp, _vp]),
+    "futhark_values_i32_2d": (C.c_int, [_vp, _vp, _vp]),
+    "futhark_shape_i32_2d": (C.POINTER(_i64), [_vp, _vp]),
+    "futhark_new_u32_2d": (_vp, [_vp, _vp, _i64, _i64]),
+    "futhark_free_u32_2d": (C.c_int, [_vp, _vp]),
+    "futhark_values_u32_2d": (C.c_int, [_vp, _vp, _vp]),
+    "futhark_shape_u32_2d": (C.POINTER(_i64), [_vp, _vp]),
+    "futhark_entry_query_sel": (C.c_int, [_vp, _pp, _vp, _vp]),
+    "futhark_entry_query_groupby": (C.c_int, [_vp, _pp, _vp, _i32, _vp, _vp]),
+    "futhark_entry_join": (C.c_int, [_vp, _pp, _vp, _vp, _i32, _i32, _vp, _vp]),
+}
+
+
+def bind_futhark_names(lib):
+    for name, (res, args) in FUTHARK_SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
 
 _lib = None
 

@@ -37,6 +37,7 @@ static void pool_trim(hark_context *ctx)
 
 int hark_alloc(hark_context *ctx, void **out, size_t bytes)
 {
+    hark_device_guard guard__(ctx);
     *out = nullptr;
     const size_t size = pool_round(bytes);
     if (ctx) {
@@ -81,6 +82,7 @@ void hark_free(hark_context *ctx, void *ptr)
 
 int hark_read_words(hark_context *ctx, const void *dev, int64_t *host, int count)
 {
+    hark_device_guard guard__(ctx);
     if (count > 64) return hark_fail(ctx, HARK_EARG, "hark_read_words: count > 64");
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pin, dev, (size_t)count * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -95,6 +97,7 @@ static constexpr size_t kBounce = (size_t)8 << 20;
 
 int hark_d2h(hark_context *ctx, void *host, const void *dev, size_t bytes)
 {
+    hark_device_guard guard__(ctx);
     if (!bytes) return HARK_OK;
     // measured (tools/ingest_bench.py): the bounce buffers win for results of a few MB, the
     // runtime's own staging wins for hundreds of MB (12-24 vs 8-10 GB/s at 1 GiB)
@@ -127,7 +130,7 @@ int hark_d2h(hark_context *ctx, void *host, const void *dev, size_t bytes)
 
 extern "C" {
 
-int hark_version(void) { return 101; }   // 1.01: partition_by_range, stream_read, composite_key, column_range
+int hark_version(void) { return 102; }   // 1.02: context_trim, futhark_* veneer (futhark_compat.h), hash join, multi-aggregate pass
 
 int hark_context_new(hark_context **out, int device)
 {
@@ -139,6 +142,7 @@ int hark_context_new(hark_context **out, int device)
     if (hipSetDevice(device) != hipSuccess) return HARK_EHIP;
     hark_context *ctx = new hark_context();
     ctx->device = device;
+    if (const char *lim = getenv("HARK_POOL_LIMIT_MB")) { const long long mb = atoll(lim); if (mb >= 0) ctx->pool_limit = (size_t)mb << 20; }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
         ctx->num_cu = prop.multiProcessorCount;
@@ -169,8 +173,18 @@ void hark_context_free(hark_context *ctx)
 
 int hark_context_sync(hark_context *ctx)
 {
+    hark_device_guard guard__(ctx);
     if (!ctx) return HARK_EARG;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return HARK_OK;
+}
+
+int hark_context_trim(hark_context *ctx)
+{
+    if (!ctx) return HARK_EARG;
+    hark_device_guard guard__(ctx);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    pool_trim(ctx);
     return HARK_OK;
 }
 
@@ -178,6 +192,7 @@ const char *hark_context_get_error(hark_context *ctx) { return ctx ? ctx->err.c_
 
 int hark_context_set_stream(hark_context *ctx, void *hip_stream)
 {
+    hark_device_guard guard__(ctx);
     if (!ctx) return HARK_EARG;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // pooled blocks are ordered by ONE stream: drain the old one
     ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own_stream;
@@ -187,11 +202,13 @@ int hark_context_set_stream(hark_context *ctx, void *hip_stream)
 // ---- device memory helpers -------------------------------------------------
 int hark_dev_alloc(hark_context *ctx, void **out, int64_t bytes)
 {
+    hark_device_guard guard__(ctx);
     if (!ctx || !out || bytes < 0) return HARK_EARG;
     return hark_alloc(ctx, out, (size_t)bytes);
 }
 int hark_dev_free(hark_context *ctx, void *dev)
 {
+    hark_device_guard guard__(ctx);
     if (!ctx) return HARK_EARG;
     if (!dev) return HARK_OK;
     hark_free(ctx, dev);
@@ -199,6 +216,7 @@ int hark_dev_free(hark_context *ctx, void *dev)
 }
 int hark_dev_upload(hark_context *ctx, void *dev, const void *host, int64_t bytes)
 {
+    hark_device_guard guard__(ctx);
     if (!ctx || bytes < 0 || (bytes && (!dev || !host))) return HARK_EARG;
     if (!bytes) return HARK_OK;
     HIP_TRY(ctx, hipMemcpyAsync(dev, host, (size_t)bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -207,11 +225,13 @@ int hark_dev_upload(hark_context *ctx, void *dev, const void *host, int64_t byte
 }
 int hark_dev_download(hark_context *ctx, void *host, const void *dev, int64_t bytes)
 {
+    hark_device_guard guard__(ctx);
     if (!ctx || bytes < 0 || (bytes && (!dev || !host))) return HARK_EARG;
     return hark_d2h(ctx, host, dev, (size_t)bytes);
 }
 int hark_op_zero(hark_context *ctx, void *dev, int64_t bytes)
 {
+    hark_device_guard guard__(ctx);
     if (!ctx || bytes < 0 || (bytes && !dev)) return HARK_EARG;
     if (!bytes) return HARK_OK;
     HIP_TRY(ctx, hipMemsetAsync(dev, 0, (size_t)bytes, ctx->stream));
@@ -230,6 +250,7 @@ static void table_release(hark_context *ctx, hark_table *t)
 int hark_table_new_columns(hark_context *ctx, hark_table **out, int64_t n, int64_t m,
                            const int32_t *dtypes, const void *const *host_cols)
 {
+    hark_device_guard guard__(ctx);
     if (!ctx || !out) return HARK_EARG;
     *out = nullptr;
     if (n < 0 || m < 0 || (m && (!dtypes || !host_cols))) return hark_fail(ctx, HARK_EARG, "table_new_columns: bad shape");
@@ -255,6 +276,7 @@ int hark_table_new_columns(hark_context *ctx, hark_table **out, int64_t n, int64
 int hark_table_new_2d(hark_context *ctx, hark_table **out, const void *host, int dtype,
                       int64_t n, int64_t m, int64_t row_stride, int64_t col_stride)
 {
+    hark_device_guard guard__(ctx);
     if (!ctx || !out) return HARK_EARG;
     *out = nullptr;
     if (n < 0 || m < 0 || !dtype_ok(dtype) || (n && m && !host)) return hark_fail(ctx, HARK_EARG, "table_new_2d: bad argument");
@@ -281,6 +303,7 @@ int hark_table_new_2d(hark_context *ctx, hark_table **out, const void *host, int
 int hark_table_from_device(hark_context *ctx, hark_table **out, int64_t n, int64_t m,
                            const int32_t *dtypes, void *const *dev_cols)
 {
+    hark_device_guard guard__(ctx);
     if (!ctx || !out) return HARK_EARG;
     *out = nullptr;
     if (n < 0 || m < 0 || (m && (!dtypes || !dev_cols))) return hark_fail(ctx, HARK_EARG, "table_from_device: bad shape");
@@ -310,6 +333,7 @@ void *hark_table_column_device(const hark_table *t, int64_t col) { return (!t ||
 
 int hark_table_free(hark_context *ctx, hark_table *t)
 {
+    hark_device_guard guard__(ctx);
     if (!t) return HARK_OK;
     table_release(ctx, t);
     return HARK_OK;
@@ -328,6 +352,7 @@ void *hark_result_column_device(const hark_result *r, int64_t col) { return (!r 
 
 int hark_result_column(hark_context *ctx, const hark_result *r, int64_t col, void *host_out)
 {
+    hark_device_guard guard__(ctx);
     if (!ctx || !r || col < 0 || col >= (int64_t)r->cols.size()) return HARK_EARG;
     size_t bytes = (size_t)r->n * hark_dtype_size(r->cols[col].dtype);
     if (!bytes) return HARK_OK;
@@ -337,6 +362,7 @@ int hark_result_column(hark_context *ctx, const hark_result *r, int64_t col, voi
 
 int hark_result_free(hark_context *ctx, hark_result *r)
 {
+    hark_device_guard guard__(ctx);
     if (!r) return HARK_OK;
     for (auto &c : r->cols) if (c.owned && c.data) hark_free(ctx, c.data);
     delete r;
@@ -347,6 +373,7 @@ int hark_result_free(hark_context *ctx, hark_result *r)
 int hark_op_gen_columns(hark_context *ctx, uint64_t seed, int64_t first_row, int64_t n,
                         uint32_t G, int32_t exact, float *p, int32_t *k, float *v)
 {
+    hark_device_guard guard__(ctx);
     if (!ctx) return HARK_EARG;
     return k_gen_columns(ctx, seed, first_row, n, G, exact, p, k, v);
 }
@@ -381,6 +408,7 @@ __global__ __launch_bounds__(1024) void stream_read_kernel(const uint4 *__restri
 
 int hark_op_stream_read(hark_context *ctx, const void *const *bufs, int32_t nbuf, int64_t bytes_each, uint64_t *fold_dev)
 {
+    hark_device_guard guard__(ctx);
     if (!ctx || !bufs || nbuf < 1 || nbuf > 3 || bytes_each < 0 || !fold_dev || (bytes_each & 15)) return HARK_EARG;
     for (int j = 0; j < nbuf; j++) if (bytes_each && (!bufs[j] || ((uintptr_t)bufs[j] & 15))) return HARK_EARG;
     if (bytes_each == 0) return HARK_OK;
@@ -395,6 +423,7 @@ int hark_op_filter_groupby_dense_f32(hark_context *ctx, hark_fgb_plan *plan,
                                      const float *p, int32_t cmp, float thr,
                                      const int32_t *k, const float *v, int64_t n)
 {
+    hark_device_guard guard__(ctx);
     if (!ctx || !plan) return HARK_EARG;
     if (n < 0 || (n && !k)) return hark_fail(ctx, HARK_EARG, "filter_groupby: null key column");     // v == NULL: COUNT only
     if (plan->max_rows && n > plan->max_rows) return hark_fail(ctx, HARK_EARG, "filter_groupby: n exceeds the plan's max_rows");

@@ -30,7 +30,23 @@ struct hark_context {
     // caching allocator (hark_alloc / hark_free)
     std::multimap<size_t, void *> pool_free;
     std::unordered_map<void *, size_t> pool_live;
-    size_t pool_cached = 0, pool_limit = (size_t)64 << 30;
+    // freed blocks kept for reuse up to pool_limit (HARK_POOL_LIMIT_MB; hark_context_trim gives them all back):
+    // sized so that torch / RCCL sharing the GPU with a context are not starved by its cache
+    size_t pool_cached = 0, pool_limit = (size_t)16 << 30;
+};
+
+// Every entry runs on the context's device whatever device the calling thread has current (a process may hold
+// contexts on several GPUs, and torch changes the current device under us); restores the caller's device.
+struct hark_device_guard {
+    int prev = -1;
+    explicit hark_device_guard(const hark_context *ctx)
+    {
+        int cur = -1;
+        if (ctx && hipGetDevice(&cur) == hipSuccess && cur != ctx->device) { prev = cur; (void)hipSetDevice(ctx->device); }
+    }
+    ~hark_device_guard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    hark_device_guard(const hark_device_guard &) = delete;
+    hark_device_guard &operator=(const hark_device_guard &) = delete;
 };
 
 struct hark_column {

@@ -1179,6 +1179,7 @@ static void plan_drop_partition(hark_fgb_plan *pl)
 
 int hark_fgb_plan_new(hark_context *ctx, hark_fgb_plan **out, int64_t max_rows, int64_t G)
 {
+    hark_device_guard guard__(ctx);
     if (!ctx || !out) return HARK_EARG;
     *out = nullptr;
     if (max_rows < 0 || G <= 0 || G > (int64_t)1 << 31)
@@ -1200,6 +1201,7 @@ int hark_fgb_plan_new(hark_context *ctx, hark_fgb_plan **out, int64_t max_rows, 
 
 int hark_fgb_plan_free(hark_context *ctx, hark_fgb_plan *pl)
 {
+    hark_device_guard guard__(ctx);
     if (!pl) return HARK_OK;
     if (ctx) hipStreamSynchronize(ctx->stream);
     plan_drop_partition(pl);
@@ -1232,6 +1234,7 @@ int hark_fgb_plan_set(hark_fgb_plan *pl, const char *key, int64_t value)
 
 int hark_fgb_reset(hark_context *ctx, hark_fgb_plan *pl)
 {
+    hark_device_guard guard__(ctx);
     if (!ctx || !pl) return HARK_EARG;
     const u64 ident = vop_identity((int)pl->vop);
     if (ident == 0) HIP_TRY(ctx, hipMemsetAsync(pl->acc_sum, 0, (size_t)pl->G * sizeof(double), ctx->stream));
@@ -1424,6 +1427,7 @@ static int fgb_check_err(hark_context *ctx, hark_fgb_plan *pl)
 // wrapping arithmetic as in groupby.fut:35-41), no predicate.
 int hark_op_groupby_dense_u32(hark_context *ctx, hark_fgb_plan *pl, const uint32_t *k, const uint32_t *v, int64_t n)
 {
+    hark_device_guard guard__(ctx);
     if (!ctx || !pl) return HARK_EARG;
     if (n < 0 || (n && (!k || !v))) return hark_fail(ctx, HARK_EARG, "groupby_dense_u32: null column");
     if (n > 0xFFFFFFFFll || (pl->max_rows && n > pl->max_rows)) return hark_fail(ctx, HARK_EARG, "groupby_dense_u32: too many rows for this plan");
@@ -1432,6 +1436,7 @@ int hark_op_groupby_dense_u32(hark_context *ctx, hark_fgb_plan *pl, const uint32
 
 int hark_fgb_finish_u32(hark_context *ctx, hark_fgb_plan *pl, uint32_t *val_out, int64_t *count_out)
 {
+    hark_device_guard guard__(ctx);
     if (!ctx || !pl) return HARK_EARG;
     if (val_out || count_out) {
         int64_t blocks = (pl->G + 255) / 256;
@@ -1444,6 +1449,7 @@ int hark_fgb_finish_u32(hark_context *ctx, hark_fgb_plan *pl, uint32_t *val_out,
 
 int hark_fgb_finish(hark_context *ctx, hark_fgb_plan *pl, float *sum_out, int64_t *count_out)
 {
+    hark_device_guard guard__(ctx);
     if (!ctx || !pl) return HARK_EARG;
     if (pl->vop != VOP_F32SUM) return hark_fail(ctx, HARK_EARG, "fgb_finish: this plan accumulates a u32 operator, use hark_fgb_finish_u32");
     int64_t blocks = (pl->G + 255) / 256;
@@ -1467,6 +1473,7 @@ int hark_fgb_finish(hark_context *ctx, hark_fgb_plan *pl, float *sum_out, int64_
 // (0 = single-kernel path, 1 = partition producer, 2 = partition consumer).
 int hark_fgb_timing(hark_context *ctx, hark_fgb_plan *pl, double *ms_by_kind, int64_t *launches_by_kind)
 {
+    hark_device_guard guard__(ctx);
     if (!ctx || !pl || !ms_by_kind || !launches_by_kind) return HARK_EARG;
     for (int i = 0; i < 3; i++) { ms_by_kind[i] = 0.0; launches_by_kind[i] = 0; }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1482,6 +1489,7 @@ int hark_fgb_timing(hark_context *ctx, hark_fgb_plan *pl, double *ms_by_kind, in
 
 int hark_fgb_finish_typed(hark_context *ctx, hark_fgb_plan *pl, int32_t kind, const uint32_t *pos, void *out)
 {
+    hark_device_guard guard__(ctx);
     if (!ctx || !pl || !out || kind < 0 || kind > 11 || kind == 6) return HARK_EARG;
     int64_t blocks = (pl->G + 255) / 256;
     if (blocks > (int64_t)ctx->num_cu * 4) blocks = (int64_t)ctx->num_cu * 4;
@@ -1551,6 +1559,7 @@ int k_fgb_dense_stats(hark_context *ctx, hark_fgb_plan *pl, const float *p, int 
 // Typed read-out of one of the plan's accumulator arrays: which = 0 acc_sum, 1 acc_min, 2 acc_max.
 int hark_fgb_finish_typed_from(hark_context *ctx, hark_fgb_plan *pl, int32_t which, int32_t kind, const uint32_t *pos, void *out)
 {
+    hark_device_guard guard__(ctx);
     if (!ctx || !pl || !out || kind < 0 || kind > 11 || kind == 6 || which < 0 || which > 2) return HARK_EARG;
     const u64 *acc = which == 0 ? reinterpret_cast<const u64 *>(pl->acc_sum) : which == 1 ? pl->acc_min : pl->acc_max;
     if (!acc) return hark_fail(ctx, HARK_EARG, "fgb: this plan has no min/max accumulators");

@@ -106,13 +106,22 @@ __global__ __launch_bounds__(256) void fill_u64_kernel(u64 *__restrict__ dst, in
 
 // flags[i] = first row of a run of equal keys (groupby.fut:26-33 mk_flags), on
 // the key column gathered into sorted order (4- or 8-byte elements).
-__global__ __launch_bounds__(256) void head_flags_kernel(const void *__restrict__ sorted_keys, int esz, int64_t n, uint32_t *__restrict__ flags)
+// f32 keys compare as the sort orders them (k_sort.hip sort_word_of): -0.0 == +0.0 and all NaNs are one key --
+// raw bits would split a run of [0.0, -0.0, 0.0] (which a stable sort keeps interleaved) into three groups.
+__device__ __forceinline__ uint32_t f32_key_class(uint32_t w)
+{
+    if ((w & 0x7FFFFFFFu) > 0x7F800000u) return 0x7FC00000u;
+    return w == 0x80000000u ? 0u : w;
+}
+
+__global__ __launch_bounds__(256) void head_flags_kernel(const void *__restrict__ sorted_keys, int esz, int is_f32, int64_t n, uint32_t *__restrict__ flags)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         bool head = i == 0;
         if (!head) {
-            if (esz == 4) head = static_cast<const uint32_t *>(sorted_keys)[i] != static_cast<const uint32_t *>(sorted_keys)[i - 1];
+            if (esz == 4 && is_f32) head = f32_key_class(static_cast<const uint32_t *>(sorted_keys)[i]) != f32_key_class(static_cast<const uint32_t *>(sorted_keys)[i - 1]);
+            else if (esz == 4) head = static_cast<const uint32_t *>(sorted_keys)[i] != static_cast<const uint32_t *>(sorted_keys)[i - 1];
             else head = static_cast<const u64 *>(sorted_keys)[i] != static_cast<const u64 *>(sorted_keys)[i - 1];
         }
         flags[i] = head ? 1u : 0u;
@@ -245,7 +254,7 @@ int grouped_aggregate(hark_context *ctx, const hark_table *db, int key_col, int 
     if (!rc) rc = hark_alloc(ctx, (void **)&flags, (size_t)n * 4);
     if (!rc) rc = hark_alloc(ctx, (void **)&seg, (size_t)n * 4);
     if (!rc) {
-        head_flags_kernel<<<grid_for(ctx, n), 256, 0, st>>>(sorted_keys, kesz, n, flags);
+        head_flags_kernel<<<grid_for(ctx, n), 256, 0, st>>>(sorted_keys, kesz, key_dtype == HARK_F32 ? 1 : 0, n, flags);
         rc = k_exclusive_scan_u32(ctx, flags, n, seg, nullptr, &G);
     }
     if (!rc) {
@@ -298,6 +307,7 @@ extern "C" {
 int hark_entry_query_groupby(hark_context *ctx, hark_result **out, const hark_table *db, int32_t g_col,
                              const int32_t *s_cols, int64_t ns, const int32_t *t_cols, int64_t nt)
 {
+    hark_device_guard guard__(ctx);
     if (!ctx || !out || !db) return HARK_EARG;
     *out = nullptr;
     if (ns < 0 || nt < 0 || (ns && !s_cols) || (nt && !t_cols)) return hark_fail(ctx, HARK_EARG, "query_groupby: bad column lists");

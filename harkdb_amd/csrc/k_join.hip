@@ -233,6 +233,7 @@ extern "C" {
 int hark_entry_join(hark_context *ctx, hark_result **out, const hark_table *db1, const hark_table *db2,
                     int32_t col1, int32_t col2, const int32_t *cols1, int64_t l, const int32_t *cols2, int64_t k)
 {
+    hark_device_guard guard__(ctx);
     if (!ctx || !out || !db1 || !db2) return HARK_EARG;
     *out = nullptr;
     if (l < 0 || k < 0 || (l && !cols1) || (k && !cols2)) return hark_fail(ctx, HARK_EARG, "join: bad column lists");
@@ -365,6 +366,7 @@ int hark_entry_join(hark_context *ctx, hark_result **out, const hark_table *db1,
 int hark_entry_sort(hark_context *ctx, hark_result **out, const hark_table *db, int32_t key_col, int32_t descending,
                     const int32_t *cols, int64_t k)
 {
+    hark_device_guard guard__(ctx);
     if (!ctx || !out || !db) return HARK_EARG;
     *out = nullptr;
     if (k < 0 || (k && !cols)) return hark_fail(ctx, HARK_EARG, "sort: bad column list");

@@ -168,12 +168,14 @@ extern "C" {
 
 int hark_op_segmented_scan_add_i32(hark_context *ctx, const uint8_t *flags, const int32_t *vals, int64_t n, int32_t *out)
 {
+    hark_device_guard guard__(ctx);
     if (!ctx || n < 0 || (n && (!flags || !vals || !out))) return HARK_EARG;
     return seg_scan(ctx, flags, vals, n, out, 0);
 }
 
 int hark_op_segmented_iota(hark_context *ctx, const uint8_t *flags, int64_t n, int32_t *out)
 {
+    hark_device_guard guard__(ctx);
     if (!ctx || n < 0 || (n && (!flags || !out))) return HARK_EARG;
     return seg_scan(ctx, flags, nullptr, n, out, 1);          // segmented.fut:59-60
 }
@@ -181,6 +183,7 @@ int hark_op_segmented_iota(hark_context *ctx, const uint8_t *flags, int64_t n, i
 int hark_op_segmented_reduce_add_i32(hark_context *ctx, const uint8_t *flags, const int32_t *vals, int64_t n,
                                      int32_t *out, int64_t *n_out)
 {
+    hark_device_guard guard__(ctx);
     if (!ctx || !n_out || n < 0 || (n && (!flags || !vals || !out))) return HARK_EARG;
     *n_out = 0;
     if (n == 0) return HARK_OK;                               // segmented.fut:29
@@ -207,6 +210,7 @@ int hark_op_segmented_reduce_add_i32(hark_context *ctx, const uint8_t *flags, co
 // out == NULL first: *n_out is always set).
 int hark_op_replicated_iota(hark_context *ctx, const int32_t *reps, int64_t n, int32_t *out, int64_t *n_out)
 {
+    hark_device_guard guard__(ctx);
     if (!ctx || !n_out || n < 0 || (n && !reps)) return HARK_EARG;
     *n_out = 0;
     if (n == 0) return HARK_OK;
@@ -234,6 +238,7 @@ int hark_op_replicated_iota(hark_context *ctx, const int32_t *reps, int64_t n, i
 // iotas (:73); the caller evaluates `get arr[idxs[j]] iotas[j]`.
 int hark_op_expand_indices(hark_context *ctx, const int32_t *szs, int64_t n, int32_t *idxs, int32_t *iotas, int64_t *n_out)
 {
+    hark_device_guard guard__(ctx);
     if (!ctx || !n_out) return HARK_EARG;
     HARK_TRY(hark_op_replicated_iota(ctx, szs, n, idxs, n_out));
     const int64_t t = *n_out;

@@ -263,6 +263,7 @@ extern "C" {
 
 int hark_entry_query_sel(hark_context *ctx, hark_result **out, const hark_table *db, const int32_t *cols, int64_t k)
 {
+    hark_device_guard guard__(ctx);
     if (!ctx || !out || !db) return HARK_EARG;
     *out = nullptr;
     // select.fut:10 `row[i]` is bounds-checked per row: with zero rows nothing is evaluated.
@@ -282,6 +283,7 @@ int hark_entry_query_sel(hark_context *ctx, hark_result **out, const hark_table 
 int hark_entry_filter_sel(hark_context *ctx, hark_result **out, const hark_table *db, int32_t where_col, int32_t cmp,
                           const void *constant, const int32_t *cols, int64_t k, int32_t want_row_index)
 {
+    hark_device_guard guard__(ctx);
     if (!ctx || !out || !db || !constant) return HARK_EARG;
     *out = nullptr;
     HARK_TRY(check_cols(ctx, db, cols, k, "filter_sel"));
@@ -352,6 +354,7 @@ int hark_entry_filter_sel(hark_context *ctx, hark_result **out, const hark_table
 
 int hark_result_values_2d(hark_context *ctx, const hark_result *r, void *host_out, int dtype)
 {
+    hark_device_guard guard__(ctx);
     if (!ctx || !r) return HARK_EARG;
     const int64_t m = (int64_t)r->cols.size();
     if (r->n == 0 || m == 0) return HARK_OK;

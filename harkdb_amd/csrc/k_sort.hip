@@ -451,12 +451,13 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x)
     return x;
 }
 
-__global__ __launch_bounds__(256) void hash_dest_kernel(const void *__restrict__ col, int esz, int64_t n, uint32_t nparts, uint32_t *__restrict__ dest)
+__global__ __launch_bounds__(256) void hash_dest_kernel(const void *__restrict__ col, int dtype, int64_t n, uint32_t nparts, uint32_t *__restrict__ dest)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         uint32_t h;
-        if (esz == 4) h = mix32(static_cast<const uint32_t *>(col)[i]);
+        // f32 keys hash by their sort word: -0.0 and +0.0 (one group) and all NaNs must reach the same owner rank
+        if (dtype != HARK_I64) h = mix32(dtype == HARK_F32 ? sort_word_of(static_cast<const uint32_t *>(col)[i], HARK_F32) : static_cast<const uint32_t *>(col)[i]);
         else { const uint64_t x = static_cast<const uint64_t *>(col)[i]; h = mix32((uint32_t)x ^ mix32((uint32_t)(x >> 32))); }
         dest[i] = (uint32_t)(((uint64_t)h * nparts) >> 32);          // uniform in [0, nparts)
     }
@@ -521,6 +522,7 @@ extern "C" {
 int hark_op_partition_by_hash(hark_context *ctx, const void *key_col, int32_t dtype, int64_t n, int32_t nparts,
                               uint32_t *perm_out, int64_t *counts_host)
 {
+    hark_device_guard guard__(ctx);
     if (!ctx || n < 0 || nparts < 1 || nparts > 256 || !counts_host || (n && (!key_col || !perm_out))) return HARK_EARG;
     for (int i = 0; i < nparts; i++) counts_host[i] = 0;
     if (n == 0) return HARK_OK;
@@ -530,7 +532,7 @@ int hark_op_partition_by_hash(hark_context *ctx, const void *key_col, int32_t dt
     if (!rc) {
         int64_t blocks = (n + 255) / 256;
         if (blocks > (int64_t)ctx->num_cu * 16) blocks = (int64_t)ctx->num_cu * 16;
-        hash_dest_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(key_col, (int)hark_dtype_size(dtype), n, (uint32_t)nparts, dest);
+        hash_dest_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(key_col, (int)dtype, n, (uint32_t)nparts, dest);
         rc = partition_by_dest(ctx, dest, n, nparts, perm_out, counts_host, "partition_by_hash: reading part sizes failed");
     }
     hark_free(ctx, dest);
@@ -544,6 +546,7 @@ int hark_op_partition_by_hash(hark_context *ctx, const void *key_col, int32_t dt
 int hark_op_partition_by_range(hark_context *ctx, const void *key_col, int32_t dtype, int64_t n, int32_t nparts,
                                const void *splitters_host, int32_t descending, uint32_t *perm_out, int64_t *counts_host)
 {
+    hark_device_guard guard__(ctx);
     if (!ctx || n < 0 || nparts < 1 || nparts > 256 || !counts_host || (nparts > 1 && !splitters_host) ||
         (n && (!key_col || !perm_out)) || hark_dtype_size(dtype) == 0) return HARK_EARG;
     for (int i = 0; i < nparts; i++) counts_host[i] = 0;
@@ -569,6 +572,7 @@ int hark_op_partition_by_range(hark_context *ctx, const void *key_col, int32_t d
 // dst[i] = src[idx[i]] for 4- or 8-byte elements (device pointers).
 int hark_op_gather(hark_context *ctx, const void *src, int32_t dtype, const uint32_t *idx, void *dst, int64_t n)
 {
+    hark_device_guard guard__(ctx);
     if (!ctx || n < 0 || (n && (!src || !idx || !dst))) return HARK_EARG;
     return k_gather(ctx, src, (int)hark_dtype_size(dtype), idx, dst, n);
 }

@@ -11,6 +11,50 @@ import numpy as np
 from . import _ffi
 
 
+_CANON = {"==": "=", "<>": "!="}
+
+
+def normalise_predicate(dt, cmp, value):
+    """`column <cmp> value` for a column of dtype `dt`, rewritten so that the constant is exactly representable in `dt`.
+
+    The C entries read the constant AS the column's dtype (hark.h: hark_entry_filter_sel); a plain cast would truncate a
+    fractional literal on an integer column (`x < 2.5` must keep x = 2) and wrap one outside the dtype's range
+    (`x < 3000000000` on i32 must keep every row).  Returns (cmp, 1-element array of dtype dt).  Always-true becomes
+    `>= dtype.min`, always-false `< dtype.min`."""
+    import math
+    dt = np.dtype(dt)
+    cmp = _CANON.get(cmp, cmp)
+    if cmp not in (">", ">=", "<", "<=", "=", "!="):
+        raise KeyError(cmp)
+    if dt.kind == "f":
+        return cmp, np.asarray([value]).astype(dt)
+    info = np.iinfo(dt)
+    true, false = (">=", np.asarray([info.min], dtype=dt)), ("<", np.asarray([info.min], dtype=dt))
+    if isinstance(value, (np.generic, np.ndarray)):
+        value = np.asarray(value).reshape(-1)[0].item()
+    if isinstance(value, bool):
+        value = int(value)
+    if isinstance(value, float):
+        if math.isnan(value):
+            return true if cmp == "!=" else false
+        if math.isinf(value):
+            below = value > 0                      # every column value lies below +inf
+            return true if cmp == "!=" or (below and cmp in ("<", "<=")) or (not below and cmp in (">", ">=")) else false
+        if value != math.floor(value):
+            if cmp == "=":
+                return false
+            if cmp == "!=":
+                return true
+            cmp, value = ("<=", math.floor(value)) if cmp in ("<", "<=") else (">=", math.ceil(value))
+        value = int(value)
+    value = int(value)
+    if value > info.max:
+        return true if cmp in ("<", "<=", "!=") else false
+    if value < info.min:
+        return true if cmp in (">", ">=", "!=") else false
+    return cmp, np.asarray([value], dtype=dt)
+
+
 class Result:
     """Device-resident query result (futhark opaque array + from_futhark)."""
 
@@ -306,13 +350,13 @@ class Engine:
         self._chk(self.lib.hark_entry_join(self.ctx, C.byref(h), t1._h, t2._h, int(col1), int(col2), pa, a.size, pb, b.size))
         return Result(self, h)
 
-    def _const(self, table, col, value):
-        dt = np.dtype(table.dtype(col))
-        return np.asarray([value]).astype(dt)
+    def _const(self, table, col, value, cmp=">"):
+        """(comparison, constant in the column's dtype) equivalent to `column <cmp> value` over the column's values."""
+        return normalise_predicate(np.dtype(table.dtype(col)), cmp, value)
 
     def filter_sel(self, table, where_col, cmp, value, cols, want_row_index=True):
         a, pa = _ffi.i32_array(cols)
-        c = self._const(table, where_col, value)
+        cmp, c = self._const(table, where_col, value, cmp)
         h = C.c_void_p()
         self._chk(self.lib.hark_entry_filter_sel(self.ctx, C.byref(h), table._h, int(where_col), _ffi.CMP[cmp],
                                                  c.ctypes.data, pa, a.size, 1 if want_row_index else 0))
@@ -325,7 +369,8 @@ class Engine:
         if where is None:
             wc, cmp, c = -1, 0, np.zeros(1, dtype=np.int64)
         else:
-            wc, cmp, c = int(where[0]), _ffi.CMP[where[1]], self._const(table, where[0], where[2])
+            cmp, c = self._const(table, where[0], where[2], where[1])
+            wc, cmp = int(where[0]), _ffi.CMP[cmp]
         h = C.c_void_p()
         self._chk(self.lib.hark_entry_filter_groupby(self.ctx, C.byref(h), table._h, wc, cmp, c.ctypes.data,
                                                      int(g_col), pc, po, cols.size))

@@ -31,7 +31,8 @@ def load_file(file_name, col_names=None):
     if file_name[-3:] == "csv":
         table = pd.read_csv(file_name, skipinitialspace=True)
         headers = [str(h).strip() for h in table.columns.tolist()]
-        return (table.values, headers)
+        table.columns = headers
+        return (table, headers)          # the frame itself: `.values` would upcast a mixed int/float file to float64
     if file_name[-3:] == "txt":
         table = np.loadtxt(file_name, ndmin=2)
         headers = ["c" + str(i + 1) for i in range(table.shape[1])] if col_names is None else col_names
@@ -70,14 +71,16 @@ class Table:
     def __init__(self, table_name, file_name):
         self._table_name = table_name
         table, headers = load_table(table_name, file_name)
-        table = np.asarray(table)
+        # a DataFrame (given, or read from a CSV) keeps its per-column dtypes: df.to_numpy() upcasts a mixed
+        # int/float frame to float64, which would turn integer keys above 2^24 into wrong f32 values
+        frame = file_name if isinstance(file_name, pd.DataFrame) else (table if isinstance(table, pd.DataFrame) else None)
+        table = table.to_numpy() if isinstance(table, pd.DataFrame) else np.asarray(table)
         if table.ndim != 2:
             table = table.reshape(len(table), -1) if table.size else table.reshape(0, len(headers))
         self._schema = headers
         self._data = table
         self._device = None          # filled by FutharkContext.create_table
-        # a DataFrame keeps its per-column dtypes (df.to_numpy() upcasts mixed frames to float64)
-        self._frame = file_name if isinstance(file_name, pd.DataFrame) else None
+        self._frame = frame
 
     def get_schema(self):
         return self._schema

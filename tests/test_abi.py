@@ -8,10 +8,33 @@ import pytest
 from conftest import ROOT
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "hark.h")).read()
+def declared_symbols(header="hark.h", prefix="hark_"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(hark_[a-z0-9_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(" + prefix + r"[a-z0-9_]+)\s*\(", text)))
+
+
+def test_futhark_named_api_is_declared_bound_and_exported():
+    """include/futhark_compat.h = the names `futhark c --library futhark/main.fut` generates (setup.sh:12), which
+    futhark_ffi.Futhark(_main) binds (FutharkContext.py:31-41): every one is exported by libhark.so."""
+    from harkdb_amd import _ffi
+    names = declared_symbols("futhark_compat.h", "futhark_")
+    assert set(names) == set(_ffi.FUTHARK_SIGNATURES)
+    for need in ("futhark_context_new", "futhark_new_i32_2d", "futhark_new_u32_2d", "futhark_values_i32_2d", "futhark_values_u32_2d",
+                 "futhark_shape_i32_2d", "futhark_free_u32_2d", "futhark_entry_query_sel", "futhark_entry_query_groupby"):
+        assert need in names
+    lib = _ffi.bind_futhark_names(_ffi.load())
+    for name in names:
+        assert getattr(lib, name) is not None
+
+
+def test_c_caller_compiles_against_the_headers(tmp_path):
+    """tests/abi_smoke.c (the program INTEGRATION.md shows) compiles and links with plain gcc -- no HIP or C++ in the
+    headers; it is RUN by the -m gpu suite (tests/test_gpu_abi_c.py)."""
+    import subprocess
+    subprocess.check_call(["gcc", "-O1", "-Wall", "-Werror", "-std=c99", os.path.join(ROOT, "tests", "abi_smoke.c"), "-I", os.path.join(ROOT, "include"),
+                           "-L", os.path.join(ROOT, "harkdb_amd"), "-lhark", "-Wl,-rpath," + os.path.join(ROOT, "harkdb_amd"),
+                           "-o", str(tmp_path / "abi_smoke")])
 
 
 def test_header_symbols_all_bound():

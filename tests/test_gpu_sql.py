@@ -318,3 +318,58 @@ def test_statistics_of_one_column_in_one_pass(skew):
             assert np.allclose(got.astype(np.float64), e.astype(np.float64), rtol=2e-6), name
         else:
             assert np.array_equal(got.astype(np.int64), e.astype(np.int64)), name
+
+
+# ---- round 2: literals the column's dtype cannot hold, mixed CSV ingest, -0.0 / NaN group keys ----------
+@pytest.mark.parametrize("pred,mask", [
+    ("w < 2.5", lambda d: d.w < 2.5), ("w > -0.5", lambda d: d.w > -0.5), ("w = 2.5", lambda d: d.w == 2.5), ("w != 2.5", lambda d: d.w != 2.5),
+    ("w <= -99.5", lambda d: d.w <= -99.5), ("w < 3000000000", lambda d: d.w < 3000000000), ("w > 3000000000", lambda d: d.w > 3000000000),
+    ("w >= -3000000000", lambda d: d.w >= -3000000000), ("w = 3000000000", lambda d: d.w == 3000000000),
+    ("big < 0.5", lambda d: d.big < 0.5), ("k >= 999.5", lambda d: d.k >= 999.5)])
+def test_fractional_and_out_of_range_literals(fc, pred, mask):
+    df = fc._df
+    out = fc.sql(f"select k, w from t where {pred}")
+    assert np.array_equal(out, df[mask(df)][["k", "w"]].to_numpy()), pred
+    _, cols = fc.sql_columns(f"select k, count(*) from t where {pred} group by k")
+    g = df[mask(df)].groupby("k").size()
+    assert np.array_equal(cols[0], g.index.to_numpy()) and np.array_equal(cols[1], g.to_numpy()), pred
+
+
+def test_having_with_fractional_literal(fc):
+    df = fc._df
+    _, cols = fc.sql_columns("select k, count(*) from t group by k having count(*) > 199.5")
+    g = df.groupby("k").size()
+    g = g[g > 199.5]
+    assert np.array_equal(cols[0], g.index.to_numpy()) and np.array_equal(cols[1], g.to_numpy())
+
+
+def test_mixed_csv_large_integer_keys(tmp_path):
+    from harkdb_amd import FutharkContext
+    rng = np.random.default_rng(3)
+    n = 5000
+    ids = (16777216 + rng.integers(0, 40, n)).astype(np.int64)          # above 2^24: not representable in f32
+    x = rng.random(n).round(3)
+    f = tmp_path / "mixed.csv"
+    f.write_text("id,x\n" + "\n".join(f"{i},{v}" for i, v in zip(ids, x)) + "\n")
+    c = FutharkContext(sql_mode=True)
+    c.create_table("m", str(f))
+    _, cols = c.sql_columns("select id, count(*), sum(x) from m group by id")
+    df = pd.DataFrame({"id": ids, "x": x.astype(np.float32)})
+    g = df.groupby("id").agg(c=("x", "size"), s=("x", "sum"))
+    assert cols[0].dtype == np.int32 and np.array_equal(cols[0], g.index.to_numpy())
+    assert np.array_equal(cols[1], g.c.to_numpy()) and np.allclose(cols[2], g.s.to_numpy(), rtol=1e-5)
+
+
+def test_float_keys_signed_zero_and_nan_form_single_groups():
+    """A stable sort keeps [0.0, -0.0, 0.0] interleaved; heads must compare as the sort orders (one group), likewise NaNs."""
+    from harkdb_amd import FutharkContext
+    c = FutharkContext(sql_mode=True)
+    nan2 = np.frombuffer(np.array([0x7FC00001, 0xFFC00000], dtype=np.uint32).tobytes(), dtype=np.float32)
+    key = np.array([0.0, -0.0, 0.0, 1.5, np.nan, nan2[0], -0.0, nan2[1], 1.5, -2.0], dtype=np.float32)
+    val = np.arange(1, 11, dtype=np.int32)
+    c.create_table("z", pd.DataFrame({"key": key, "val": val}))
+    _, cols = c.sql_columns("select key, sum(val), count(*) from z group by key")
+    keys, sums, cnts = cols
+    assert len(keys) == 4
+    assert keys[0] == -2.0 and keys[1] == 0.0 and keys[2] == 1.5 and np.isnan(keys[3])
+    assert sums.tolist() == [10, 1 + 2 + 3 + 7, 4 + 9, 5 + 6 + 8] and cnts.tolist() == [1, 4, 2, 3]
