@@ -11,10 +11,16 @@ Weak scaling: rank r holds rows [r*1e9, (r+1)*1e9) of an N*1e9-row table, runs
 the fused HIP kernels on its shard, the per-GPU partial aggregates (16 B x 2^20)
 are summed with an RCCL all-reduce, and the merged table is finalised.
 
+Run bare with --gpus N > 1 (no torchrun) it starts its own N rank processes.
+
 Prints ONE JSON line on rank 0 (contract in the task statement) carrying
-`roofline` (dominant kernel, HIP-event timed on the launch stream) and
-`cpu_baseline` (the oracle's port of the reference's 32-pass algorithm timed
-on one host core over a bounded sample; rank 0, N=1 only).
+  roofline      the WHOLE PATH's algorithmic bytes over the step time against the 8 TB/s HBM peak (`frac`), the
+                dominant kernel's own figure beside it (HIP events on the launch stream), and the floor of a
+                two-pass design measured in this same process (stream probes with the path's byte mix);
+  cpu_baseline  the oracle's port of the reference's 32-pass algorithm on one host core over a bounded sample
+                (rank 0, N = 1 only);
+  configs       (N = 1 only, outside the timed region) the other BASELINE configs and the small-G single-pass
+                path, each HIP-event timed (3 warm-ups, median of 10) with its algorithmic bytes and fraction.
 """
 import argparse
 import json
@@ -28,7 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 SEED = 0x4861726B4442
-HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300-6500 GB/s is what a stream reaches
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300-6900 GB/s is what a read stream reaches
 
 
 def parse_args():
@@ -42,29 +48,10 @@ def parse_args():
     ap.add_argument("--exact", type=int, default=1, help="1: integer-valued v (bit-exact check), 0: uniform [0,1)")
     ap.add_argument("--algo", type=int, default=0)
     ap.add_argument("--chunk-rows", type=int, default=0)
+    ap.add_argument("--configs", type=int, default=1, help="0: skip the extra BASELINE-config measurements (N = 1 only)")
+    ap.add_argument("--config-scale", type=float, default=1.0, help="scale the rows of the extra configs (tests)")
+    ap.add_argument("--stub", type=int, default=0, help="CPU protocol test: gloo ranks, a numpy step (no GPU, no HIP)")
     return ap.parse_args()
-
-
-def cpu_baseline(rows, G, exact):
-    """The reference's algorithm (filter -> materialise -> 32 x 1-bit stable
-    split -> head flags -> sequential segmented fold), restated in C, 1 thread."""
-    from oracle import oracle as ora
-    rows = int(rows)
-    p, k, v = ora.gen_columns(SEED, 0, rows, G, bool(exact))
-    t0 = time.perf_counter()
-    keys, sums, counts = ora.filter_groupby_refalgo_f32(p, k, v, ">", 0.5)
-    dt = time.perf_counter() - t0
-    # fairness line (BASELINE.md): a multi-threaded single-pass direct-index aggregate, not the reference's algorithm
-    threads = min(os.cpu_count() or 1, 64)
-    t1 = time.perf_counter()
-    s64, cnt = ora.filter_groupby_dense_f32_mt(p, k, v, ">", 0.5, G, threads)
-    dt_mt = time.perf_counter() - t1
-    strong = {"value": rows / dt_mt, "unit": "rows/s", "cores": threads, "algorithm": "single-pass direct-index aggregate, OpenMP, private tables (oracle/hark_oracle.c ora_filter_groupby_dense_f32_mt)",
-              "agrees_with_port": bool(np.array_equal(cnt[keys.astype(np.int64)], counts.astype(np.int64)))}
-    return {"value": rows / dt, "unit": "rows/s", "cores": 1, "kind": "port", "stronger_cpu_baseline": strong,
-            "sample": f"first {rows} rows of the same synthetic workload (G={G}), {dt:.2f} s, "
-                      f"{int(counts.sum())} survivors, {len(keys)} groups; nproc={os.cpu_count()}",
-            "algorithm": "oracle/hark_oracle.c ora_filter_groupby_refalgo_f32 = groupby.fut:8-58 + segmented.fut:7-37"}, (keys, sums, counts)
 
 
 def launch_ranks(a):
@@ -98,10 +85,221 @@ def launch_ranks(a):
     raise SystemExit(bad[0] if bad else 0)
 
 
+def cpu_baseline(rows, G, exact):
+    """The reference's algorithm (filter -> materialise -> 32 x 1-bit stable
+    split -> head flags -> sequential segmented fold), restated in C, 1 thread."""
+    from oracle import oracle as ora
+    rows = int(rows)
+    p, k, v = ora.gen_columns(SEED, 0, rows, G, bool(exact))
+    t0 = time.perf_counter()
+    keys, sums, counts = ora.filter_groupby_refalgo_f32(p, k, v, ">", 0.5)
+    dt = time.perf_counter() - t0
+    # fairness line (BASELINE.md): a multi-threaded single-pass direct-index aggregate, not the reference's algorithm
+    threads = min(os.cpu_count() or 1, 64)
+    t1 = time.perf_counter()
+    s64, cnt = ora.filter_groupby_dense_f32_mt(p, k, v, ">", 0.5, G, threads)
+    dt_mt = time.perf_counter() - t1
+    strong = {"value": rows / dt_mt, "unit": "rows/s", "cores": threads, "algorithm": "single-pass direct-index aggregate, OpenMP, private tables (oracle/hark_oracle.c ora_filter_groupby_dense_f32_mt)",
+              "agrees_with_port": bool(np.array_equal(cnt[keys.astype(np.int64)], counts.astype(np.int64)))}
+    return {"value": rows / dt, "unit": "rows/s", "cores": 1, "kind": "port", "stronger_cpu_baseline": strong,
+            "sample": f"first {rows} rows of the same synthetic workload (G={G}), {dt:.2f} s, "
+                      f"{int(counts.sum())} survivors, {len(keys)} groups; nproc={os.cpu_count()}",
+            "algorithm": "oracle/hark_oracle.c ora_filter_groupby_refalgo_f32 = groupby.fut:8-58 + segmented.fut:7-37"}, (keys, sums, counts)
+
+
+def stub_main(a):
+    """The rank protocol of main() on CPU (tests/test_bench_launcher.py): gloo ranks, a numpy aggregate as the step,
+    the same barrier / MAX-over-ranks timing and the same JSON shape.  Measures nothing."""
+    import torch
+    import torch.distributed as dist
+    from harkdb_amd import dist as hd
+    os.environ.setdefault("HARK_DIST_BACKEND", "gloo")
+    rank, local, world = hd.init_process_group("cpu")
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    N, G = int(a.rows), int(a.groups)
+    rng = np.random.default_rng(rank)
+    k = rng.integers(0, G, N)
+    p = rng.random(N)
+    sums = torch.zeros(G, dtype=torch.float64)
+    cnts = torch.zeros(G, dtype=torch.int64)
+
+    def step():
+        keep = p > 0.5
+        sums.copy_(torch.from_numpy(np.bincount(k[keep], weights=np.ones(int(keep.sum())), minlength=G)))
+        cnts.copy_(torch.from_numpy(np.bincount(k[keep], minlength=G)))
+        hd.allreduce_partials(sums, cnts)
+
+    for _ in range(a.warmup):
+        step()
+    if dist.is_initialized():
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    if dist.is_initialized():
+        dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    per_rank = [torch.zeros_like(t) for _ in range(world)]
+    if dist.is_initialized():
+        dist.all_gather(per_rank, t)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    else:
+        per_rank = [t.clone()]
+    total = torch.tensor([int((p > 0.5).sum())], dtype=torch.int64)
+    if dist.is_initialized():
+        dist.all_reduce(total)
+    if rank == 0:
+        el = float(t.item())
+        print(json.dumps({"metric": "stub", "value": N * world / (el / a.steps), "unit": "rows/s", "n_gpus": world, "steps": a.steps,
+                          "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": {"workload": "stub (CPU protocol test)"},
+                          "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1, "backend": dist.get_backend() if dist.is_initialized() else None,
+                          "ms_per_step_by_rank": [float(x.item()) / a.steps * 1e3 for x in per_rank],
+                          "check": {"count_checksum": int(cnts.sum().item()) == int(total.item())}}), flush=True)
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def event_ms(torch, fn, warm=3, reps=10):
+    """Median HIP-event time of fn() on torch's current stream (= the engine's stream after share_stream)."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def extra_configs(torch, eng, dev, a, p, k, v, N):
+    """The other BASELINE configs on one GPU (or one GPU's share of them) and the small-G single-pass path.
+    Outside the timed region; every number HIP-event timed on the launch stream, 3 warm-ups, median of 10."""
+    from harkdb_amd.engine import FgbPlan
+    out = {}
+
+    def entry(ms, alg_bytes, rows, **kw):
+        d = {"ms": ms, "algorithmic_bytes": alg_bytes, "achieved_GBps": alg_bytes / (ms * 1e-3) / 1e9,
+             "frac_of_peak": alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "rows": rows, "rows_per_s": rows / (ms * 1e-3)}
+        d.update(kw)
+        return d
+
+    # ---- the headline statement at small G (single-pass LDS path while 12 B x G fits a workgroup's LDS)
+    for name, G in (("G16", 16), ("G4096", 4096), ("G13000", 13000)):
+        eng.gen_columns(SEED, 0, N, G, bool(a.exact), None, k.data_ptr(), None)
+        so, co = torch.empty(G, dtype=torch.float32, device=dev), torch.empty(G, dtype=torch.int64, device=dev)
+        plan = FgbPlan(eng, N, G, timing=1)
+
+        def step():
+            plan.reset()
+            plan.run(p.data_ptr(), ">", 0.5, k.data_ptr(), v.data_ptr(), N)
+            plan.finish(so.data_ptr(), co.data_ptr())
+
+        ms = event_ms(torch, step)
+        kms, kl = plan.timing()
+        dom = max(kms, key=lambda kk: kms[kk])
+        ok = int(co.sum().item()) == int((p > 0.5).sum().item())
+        out[name] = entry(ms, 12.0 * N + 16.0 * G, N, groups=G, path={"single": "fgb_lds_kernel (one pass)", "producer": "partition + LDS consumer"}.get(dom, dom),
+                          kernel_ms=sum(kms.values()) / max(1, kl[dom]), count_checksum=ok, statement="SELECT k,SUM(v),COUNT(*) WHERE p>0.5 GROUP BY k")
+        plan.free()
+    del so, co
+
+    # ---- C2: WHERE filter + projection, 1e8 rows x 8 f32 columns (configs[1]): SELECT rowid, c0, c2 WHERE c1 > 0.5
+    n2 = int(1e8 * a.config_scale) // 4 * 4
+    cols = [torch.empty(n2, dtype=torch.float32, device=dev) for _ in range(8)]
+    for j in range(0, 8, 2):
+        eng.gen_columns(SEED + j, 0, n2, 1 << 20, False, cols[j].data_ptr(), None, cols[j + 1].data_ptr())
+    t8 = eng.table_from_device(n2, [c.data_ptr() for c in cols], [np.float32] * 8, keepalive=cols)
+    shape = [None]
+
+    def c2():
+        r = eng.filter_sel(t8, 1, ">", 0.5, [0, 2], want_row_index=True)
+        shape[0] = r.shape
+        r.free()
+
+    ms = event_ms(torch, c2)
+    surv = shape[0][0]
+    out["C2_filter_proj"] = entry(ms, 12.0 * n2 + 16.0 * surv, n2, survivors=surv, statement="SELECT rowid,c0,c2 FROM t8 WHERE c1>0.5 (8 f32 columns resident)",
+                                  bytes_model="read c0,c1,c2 (12 B/row) + write 2 x f32 + i64 row index per survivor")
+
+    def c1p():
+        r = eng.query_sel(t8, [0, 2])
+        r.free()
+
+    ms = event_ms(torch, c1p)
+    out["C1_projection"] = entry(ms, 16.0 * n2, n2, statement="SELECT c0,c2 FROM t8 (query_sel, main.fut:7)")
+    t8.free()
+    del cols, t8
+
+    # ---- C4: one GPU's share of the 1e9 x 1e8 join on an i64 key (configs[3]): 1.25e8 probe rows, 1.25e7 unique build keys
+    n4, s4 = int(1.25e8 * a.config_scale), int(1.25e7 * a.config_scale)
+    mul = -7046029254386353131                                                       # 0x9E3779B97F4A7C15 as i64: odd, so i -> i*mul is a bijection mod 2^64
+    bk = torch.arange(s4, dtype=torch.int64, device=dev) * mul                       # unique build keys spread over 64 bits
+    j = torch.empty((n4 + 3) // 4 * 4, dtype=torch.int32, device=dev)
+    eng.gen_columns(SEED + 21, 0, n4, 2 * s4, True, None, j.data_ptr(), None)        # half of the probe rows find a partner
+    j = j[:n4]
+    pk = j.to(torch.int64) * mul
+    prow, brow = torch.arange(n4, dtype=torch.int32, device=dev), torch.arange(s4, dtype=torch.int32, device=dev)
+    hits = int((j < s4).sum().item())
+    del j
+    tp = eng.table_from_device(n4, [pk.data_ptr(), prow.data_ptr()], [np.int64, np.int32], keepalive=(pk, prow))
+    tb = eng.table_from_device(s4, [bk.data_ptr(), brow.data_ptr()], [np.int64, np.int32], keepalive=(bk, brow))
+
+    def c4():
+        r = eng.join(tp, tb, 0, 0, [1], [1])
+        shape[0] = r.shape
+        r.free()
+
+    ms = event_ms(torch, c4, warm=2, reps=5)
+    out["C4_join_share"] = entry(ms, 12.0 * (n4 + s4) + 8.0 * hits, n4 + s4, probe_rows=n4, build_rows=s4, pairs=shape[0][0], pairs_expected=hits,
+                                 statement="probe JOIN build ON i64 key -> (probe row id, build row id), reference order (key, left row, right row)",
+                                 note="1/8 of configs[3]; over 8 GPUs the rows arrive by an all-to-all first (xGMI-bound, DESIGN.md 6)")
+    tp.free()
+    tb.free()
+    del pk, bk, prow, brow, tp, tb
+    torch.cuda.empty_cache()
+
+    # ---- C5: one GPU's share of the full pipeline (configs[4]): 5e8 rows x (i32 key + 16 f32 columns), through sql()
+    from harkdb_amd import FutharkContext
+    n5 = int(5e8 * a.config_scale) // 4 * 4
+    fc = FutharkContext.__new__(FutharkContext)
+    fc.FutEnv, fc.tables, fc.sql_mode = eng, {}, True
+    c5 = [torch.empty(n5, dtype=torch.float32, device=dev) for _ in range(16)]
+    key = torch.empty(n5, dtype=torch.int32, device=dev)
+    for jj in range(0, 16, 2):
+        eng.gen_columns(SEED + jj, 0, n5, 1 << 20, False, c5[jj].data_ptr(), key.data_ptr() if jj == 0 else None, c5[jj + 1].data_ptr())
+    fc.create_table_from_device("t", ["k"] + [f"c{q}" for q in range(16)], [key.data_ptr()] + [c.data_ptr() for c in c5],
+                                [np.int32] + [np.float32] * 16, n5, keepalive=(key, c5))
+    for name, q, ncols in (
+            ("C5_pipeline_share", "select k, sum(c3), count(*), avg(c3) from t where c1 > 0.5 group by k having count(*) > 250 order by sum(c3) desc limit 10", 3),
+            ("C5_three_aggregates", "select k, sum(c3), max(c7), min(c9), count(*) from t where c1 > 0.5 group by k having count(*) > 250 order by sum(c3) desc limit 10", 5)):
+        res = [None]
+
+        def c5q():
+            res[0] = fc.sql(q)
+
+        ms = event_ms(torch, c5q, warm=2, reps=5)
+        out[name] = entry(ms, 4.0 * ncols * n5 + 16.0 * (1 << 20), n5, referenced_columns=ncols, result_rows=int(res[0].shape[0]), statement=q,
+                          note="1/8 of configs[4] (4e9 rows x 16 f32 columns); end to end through FutharkContext.sql() incl. the LIMIT-row download")
+    fc.drop_table("t")
+    del c5, key
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     a = parse_args()
     if a.gpus > 1 and "RANK" not in os.environ:
         launch_ranks(a)
+    if a.stub:
+        return stub_main(a)
     import torch
     import torch.distributed as dist
     from harkdb_amd import dist as hd
@@ -149,28 +347,34 @@ def main():
     for _ in range(a.steps):
         step()
     fence()
-    elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    elapsed_local = time.perf_counter() - t0
+    t = torch.tensor([elapsed_local], dtype=torch.float64, device=dev)
+    per_rank = [elapsed_local]
     if dist.is_initialized():
+        gathered = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)
+        per_rank = [float(x.item()) for x in gathered]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     ms_by_kind, launches = plan.timing()
 
-    # ---- what a pure read stream of the same three columns reaches on THIS device (the practical ceiling)
+    # ---- what plain streams with the path's byte mix reach on THIS device, in this process (the practical ceilings):
+    #      [1] read the three columns once; [2] read them and write 3 B/row (the producer's mix at 50 % selectivity,
+    #      6-byte pairs); [3] read those 3 B/row back (the consumer).  [2] + [3] = the floor of ANY two-pass design.
+    nb = (N * 4) & ~255
     fold = torch.zeros(1, dtype=torch.int64, device=dev)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    scratch = torch.empty(nb * 12 // 16 + 4096, dtype=torch.uint8, device=dev)
+    cols3 = [p.data_ptr(), k.data_ptr(), v.data_ptr()]
 
-    def read_all():                                              # the three columns at once, like the fused kernels read them
-        eng.stream_read([p.data_ptr(), k.data_ptr(), v.data_ptr()], (N * 4) & ~15, fold.data_ptr())
+    def ev(fn):
+        return event_ms(torch, fn, warm=1, reps=5)
 
-    read_all()
-    torch.cuda.synchronize()
-    e0.record()
-    for _ in range(5):
-        read_all()
-    e1.record()
-    torch.cuda.synchronize()
-    stream_gbs = 5 * 3 * ((N * 4) & ~15) / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    read_ms = ev(lambda: eng.stream_read(cols3, nb, fold.data_ptr()))
+    mix_ms = ev(lambda: eng.stream_mix(cols3, nb, scratch.data_ptr(), 12))
+    back_bytes = (nb * 12 // 16) & ~15
+    back_ms = ev(lambda: eng.stream_read([scratch.data_ptr()], back_bytes, fold.data_ptr()))
+    stream_gbs = 3 * nb / (read_ms * 1e-3) / 1e9
+    del scratch
 
     # ---- size-independent checks on the full-size result (rank-local where possible)
     survivors_local = int((p > 0.5).sum().item())
@@ -193,39 +397,60 @@ def main():
         dom_ms = ms_by_kind[dom] / dom_launches
         rows_per_launch = N * a.steps / dom_launches          # a chunked producer sees chunk_rows per launch
         alg_bytes = 12.0 * rows_per_launch + (16.0 * G if dom != "producer" else 0.0)
-        achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
+        dom_achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
         kernel_name = {"single": "fgb_lds_kernel", "producer": "fgb_part_kernel", "consumer": "fgb_agg6_kernel"}[dom]
-        # HBM traffic of the dominant kernel from the committed PMC passes of this same workload
-        # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled per the gfx950 note)
+        # HBM traffic of the path's kernels from the committed PMC passes of this same workload (rocprofv3 --pmc
+        # FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled per the gfx950 note): NOT measured in this run
         traffic, traffic_src = None, None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_fgb.json")))
-            if (pmc["config"]["rows_per_gpu"] == N and pmc["config"]["groups"] == G and not a.algo and not a.chunk_rows
-                    and dom_launches == a.steps * pmc["config"]["producer_launches_per_step"]):
-                traffic = pmc["kernels"][kernel_name]["hbm_bytes_per_launch_corrected"]
-                traffic_src = "profiles/r01_pmc_fgb.json"
-        except Exception:
-            pass
+        for cand in ("r02_pmc_fgb.json", "r01_pmc_fgb.json"):
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", cand)))
+                if (pmc["config"]["rows_per_gpu"] == N and pmc["config"]["groups"] == G and not a.algo and not a.chunk_rows
+                        and dom_launches == a.steps * pmc["config"]["producer_launches_per_step"]):
+                    traffic = sum(kk["hbm_bytes_per_launch_corrected"] for kk in pmc["kernels"].values())
+                    traffic_src = "profiles/" + cand
+                    break
+            except Exception:
+                pass
         path_bytes = 12.0 * N + 16.0 * G
         kernels_ms = sum(ms_by_kind.values()) / a.steps
+        path_achieved = path_bytes / (ms_step * 1e-3) / 1e9        # per GPU: every rank moves its own 12 B/row in the same wall time
+        floor_ms = mix_ms + back_ms
         out = {
             "metric": "rows/sec, 1B-row f32 filter->group-by (SUM,COUNT), 2^20 groups",
             "value": rows_total / (elapsed / a.steps), "unit": "rows/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
+            "ms_per_step_by_rank": [x / a.steps * 1e3 for x in per_rank],
             "config": {"workload": "BASELINE configs[2] + filter: SELECT k,SUM(v),COUNT(*) FROM t WHERE p>0.5 GROUP BY k",
                        "rows_per_gpu": N, "groups": G, "selectivity": 0.5, "columns": "p f32, k i32, v f32 (HBM-resident)",
                        "exact_values": bool(a.exact), "merge": "RCCL all-reduce of f64 sums + i64 counts" if world > 1 else "none"},
-            "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+            "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": path_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": path_achieved / HBM_PEAK_GBS,
+                         "frac_is": "whole path per GPU: (12 B/row x rows + 16 B x groups) / wall time of a step / 8 TB/s",
+                         "traffic": traffic, "traffic_source": traffic_src, "traffic_measured_in_run": False,
+                         "dominant_kernel_frac": dom_achieved / HBM_PEAK_GBS, "dominant_kernel_achieved": dom_achieved,
                          "avg_launch_ms": dom_ms, "launches": dom_launches, "algorithmic_bytes_per_launch": alg_bytes,
-                         "measured_stream_read": stream_gbs, "frac_of_measured_stream_read": achieved / stream_gbs},
+                         "algorithmic_bytes_per_step": path_bytes,
+                         "measured_stream_read": stream_gbs, "frac_of_measured_stream_read": path_achieved / stream_gbs,
+                         "probes_ms": {"read_3_columns": read_ms, "read_3_columns_write_3B_per_row": mix_ms, "read_back_3B_per_row": back_ms},
+                         "two_pass_floor_ms": floor_ms, "two_pass_floor_frac_of_peak": path_bytes / (floor_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "step_over_two_pass_floor": ms_step / floor_ms,
+                         "why_two_passes": "2^20 groups x 12 B = 12 MiB of accumulators fit no LDS (160 KiB/CU) and no XCD L2 (4 MiB); "
+                                           "scattered global atomics retire ~25 G/s (DESIGN.md 3.1)"},
             "hot_path": {"kernel_ms_per_step": kernels_ms, "by_kernel_ms_per_step": {kk: ms_by_kind[kk] / a.steps for kk in ms_by_kind},
                          "algorithmic_GBps_per_gpu": path_bytes / (kernels_ms * 1e-3) / 1e9,
                          "frac_of_peak_all_kernels": path_bytes / (kernels_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "frac_of_peak_wall": path_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "check": check,
         }
+        if world == 1 and a.configs:
+            try:
+                plan.free()
+                out["configs"] = extra_configs(torch, eng, dev, a, p, k, v, N)
+            except Exception as e:                                  # the headline line must still be printed
+                out["configs"] = {"error": repr(e)}
         if world == 1 and a.cpu_rows > 0:
             base, (bk, bs, bc) = cpu_baseline(a.cpu_rows, G, a.exact)
             out["cpu_baseline"] = base

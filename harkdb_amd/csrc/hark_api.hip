@@ -419,6 +419,43 @@ int hark_op_stream_read(hark_context *ctx, const void *const *bufs, int32_t nbuf
     return HARK_OK;
 }
 
+// The traffic mix of a partition producer as a plain stream (no scatter, no LDS): read three buffers, write
+// `sixteenths`/16 of one buffer's volume contiguously, all non-temporal.  12 of 16 = the 3 B written per 12 B read
+// of the headline path at 50 % selectivity with 6-byte pairs.  What this takes is the floor of any producer with
+// that byte mix on this device (bench.py quotes the two-pass floor from it).
+__global__ __launch_bounds__(1024) void stream_mix_kernel(const uint4 *__restrict__ b0, const uint4 *__restrict__ b1, const uint4 *__restrict__ b2,
+                                                          int64_t nvec, uint4 *__restrict__ dst, int sixteenths)
+{
+    typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+    const u4v *q0 = reinterpret_cast<const u4v *>(b0), *q1 = reinterpret_cast<const u4v *>(b1), *q2 = reinterpret_cast<const u4v *>(b2);
+    u4v *out = reinterpret_cast<u4v *>(dst);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    auto emit = [&](int64_t j, const u4v x) { if ((int)(j & 15) < sixteenths) __builtin_nontemporal_store(x, out + (j >> 4) * sixteenths + (j & 15)); };
+    for (; i + stride < nvec; i += 2 * stride) {
+        const u4v a0 = __builtin_nontemporal_load(q0 + i), a1 = __builtin_nontemporal_load(q0 + i + stride);
+        const u4v c0 = __builtin_nontemporal_load(q1 + i), c1 = __builtin_nontemporal_load(q1 + i + stride);
+        const u4v d0 = __builtin_nontemporal_load(q2 + i), d1 = __builtin_nontemporal_load(q2 + i + stride);
+        emit(i, a0 ^ c0 ^ d0); emit(i + stride, a1 ^ c1 ^ d1);
+    }
+    for (; i < nvec; i += stride)
+        emit(i, __builtin_nontemporal_load(q0 + i) ^ __builtin_nontemporal_load(q1 + i) ^ __builtin_nontemporal_load(q2 + i));
+}
+
+int hark_op_stream_mix(hark_context *ctx, const void *const *bufs, int64_t bytes_each, void *dst, int32_t sixteenths)
+{
+    hark_device_guard guard__(ctx);
+    if (!ctx || !bufs || bytes_each < 0 || (bytes_each & 255) || sixteenths < 0 || sixteenths > 16) return HARK_EARG;
+    for (int j = 0; j < 3; j++) if (bytes_each && (!bufs[j] || ((uintptr_t)bufs[j] & 15))) return HARK_EARG;
+    if (bytes_each && sixteenths && (!dst || ((uintptr_t)dst & 15))) return HARK_EARG;
+    if (bytes_each == 0) return HARK_OK;
+    stream_mix_kernel<<<dim3((unsigned)ctx->num_cu), dim3(1024), 0, ctx->stream>>>(
+        static_cast<const uint4 *>(bufs[0]), static_cast<const uint4 *>(bufs[1]), static_cast<const uint4 *>(bufs[2]), bytes_each / 16,
+        static_cast<uint4 *>(dst), sixteenths);
+    HIP_TRY(ctx, hipGetLastError());
+    return HARK_OK;
+}
+
 int hark_op_filter_groupby_dense_f32(hark_context *ctx, hark_fgb_plan *plan,
                                      const float *p, int32_t cmp, float thr,
                                      const int32_t *k, const float *v, int64_t n)

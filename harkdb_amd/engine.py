@@ -274,6 +274,11 @@ class Engine:
         arr = (C.c_void_p * len(ptrs))(*ptrs)
         self._chk(self.lib.hark_op_stream_read(self.ctx, arr, len(ptrs), int(nbytes_each), fold_ptr))
 
+    def stream_mix(self, ptrs, nbytes_each, dst_ptr, sixteenths=12):
+        """Read three device buffers once and write sixteenths/16 of one buffer's volume to dst_ptr (traffic-mix probe)."""
+        arr = (C.c_void_p * 3)(*list(ptrs))
+        self._chk(self.lib.hark_op_stream_mix(self.ctx, arr, int(nbytes_each), dst_ptr, int(sixteenths)))
+
     def partition_by_hash(self, key_ptr, dtype, n, nparts, perm_ptr):
         """Row ids grouped by hash(key) part into perm_ptr (device u32[n]); returns the part sizes."""
         counts = (C.c_int64 * int(nparts))()
