@@ -31,8 +31,8 @@ struct hark_context {
     std::multimap<size_t, void *> pool_free;
     std::unordered_map<void *, size_t> pool_live;
     // freed blocks kept for reuse up to pool_limit (HARK_POOL_LIMIT_MB; hark_context_trim gives them all back):
-    // sized so that torch / RCCL sharing the GPU with a context are not starved by its cache
-    size_t pool_cached = 0, pool_limit = (size_t)16 << 30;
+    // 64 GiB of 288: re-allocating multi-GB workspaces per query costs tens of ms (measured: C5 150 ms vs 2 ms with a 16 GiB limit)
+    size_t pool_cached = 0, pool_limit = (size_t)64 << 30;
 };
 
 // Every entry runs on the context's device whatever device the calling thread has current (a process may hold

@@ -1,0 +1,423 @@
+// k_hjoin.hip -- partitioned join with the build side staged in LDS, bucket by bucket.
+//
+// Replaces the 32-pass sort of (n + s) tagged triples and the sequential per-key loop of
+// futhark/join.fut:58-68 for large probe sides (the sort-merge path of k_join.hip stays for small
+// inputs and as the fallback).  Output order is the reference's: ascending key, then left row id,
+// then right row id (join.fut:55-75).
+//
+//   1. the BUILD side (db2, s rows) is argsorted by key (stable: row ids ascend inside a key);
+//   2. P - 1 splitters are read off the sorted build keys at equal distances, so every bucket owns
+//      a contiguous slice of ~s / P sorted build entries WHATEVER the key distribution is, and
+//      buckets are ordered by key (a hash would balance as well but lose the reference's order);
+//   3. jpart_kernel streams the PROBE keys once (non-temporal, 16 B per lane), drops keys outside
+//      [min, max] of the build side, finds each row's bucket (binary search over the splitters in
+//      LDS) and routes (key, row id) through per-bucket LDS rings into workgroup-private slabs,
+//      whole 128-byte lines only -- the write-combining scheme of k_fgb.hip's producer;
+//   4. jbucket_kernel: one workgroup per bucket stages its slice of sorted build keys in LDS
+//      (<= 156 KiB; longer slices in rounds), streams the bucket's probe pairs and binary-searches
+//      each one there: a hit yields the GLOBAL rank of the first equal build entry, so a matching
+//      probe row becomes (rank, left row id), appended wave by wave to the bucket's survivor slab;
+//   5. the survivors (only the matching rows) are sorted by (rank, left row): two stable radix
+//      sorts of 32-bit words, all passes over bytes in which the words agree skipped;
+//   6. run lengths of the sorted build keys give each survivor its partner count; scan; one thread
+//      per OUTPUT row writes (left row id, right row id) -- join_expand_kernel of k_join.hip.
+// Skewed probe keys can overflow a slab: the kernel reports it and the caller falls back.
+#include "hark_internal.h"
+
+int k_sort_column(hark_context *ctx, const void *col, int dtype, int64_t n, bool descending, const uint32_t *payload,
+                  uint32_t **vals_out, uint32_t **words_out);
+
+namespace {
+
+constexpr int kJThreads = 1024;
+constexpr int kJErrOverflow = 100;
+constexpr size_t kJLdsBudget = 160 * 1024 - 512;          // one workgroup per CU owns (almost) all of its LDS
+
+struct JPair32 { uint32_t key, row; };                                    // 8 bytes: 16 per 128-byte line
+struct __attribute__((aligned(16))) JPair64 { uint64_t key; uint32_t row, pad; };   // 16 bytes: 8 per line
+
+template <typename K> struct JTraits;
+template <> struct JTraits<uint32_t> { typedef JPair32 E; static constexpr int P = 256, Q = 64, VEC = 4; };
+template <> struct JTraits<uint64_t> { typedef JPair64 E; static constexpr int P = 256, Q = 32, VEC = 2; };
+
+__device__ __forceinline__ bool jwg_or(bool pred, uint32_t *flags, int &phase)
+{
+    const int s = phase;
+    phase = s == 2 ? 0 : s + 1;
+    if (__ballot(pred) != 0ull && (threadIdx.x & 63) == 0) flags[s] = 1u;
+    if (threadIdx.x == 0) flags[phase] = 0u;
+    lds_barrier();
+    return flags[s] != 0u;
+}
+
+// bstart[b] = first sorted build position of bucket b (b = 0..P), splitters[b-1] = first key of bucket b (b = 1..P-1).
+template <typename K>
+__global__ __launch_bounds__(256) void jsplit_kernel(const K *__restrict__ rkeys, int64_t s, int P, K *__restrict__ splitters, uint32_t *__restrict__ bstart)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > P) return;
+    if (b == 0) { bstart[0] = 0u; return; }
+    if (b == P) { bstart[P] = (uint32_t)s; return; }
+    const K key = rkeys[(int64_t)b * s / P];
+    int64_t lo = 0, hi = s;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (rkeys[mid] < key) lo = mid + 1; else hi = mid; }
+    bstart[b] = (uint32_t)lo;
+    splitters[b - 1] = key;
+}
+
+// runlen[i] = number of build entries equal to rkeys[i] when i starts a run, else 0.
+template <typename K>
+__global__ __launch_bounds__(256) void jrunlen_kernel(const K *__restrict__ rkeys, int64_t s, uint32_t *__restrict__ runlen)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < s; i += stride) {
+        const K key = rkeys[i];
+        uint32_t len = 0;
+        if (i == 0 || rkeys[i - 1] != key) {
+            int64_t ub = i + 1;
+            int steps = 0;
+            while (ub < s && rkeys[ub] == key && steps < 8) { ub++; steps++; }
+            if (ub < s && rkeys[ub] == key) {
+                int64_t a = ub, b = s;
+                while (a < b) { const int64_t mid = (a + b) >> 1; if (rkeys[mid] <= key) a = mid + 1; else b = mid; }
+                ub = a;
+            }
+            len = (uint32_t)(ub - i);
+        }
+        runlen[i] = len;
+    }
+}
+
+__global__ __launch_bounds__(256) void jcnt_kernel(const uint32_t *__restrict__ rank, int64_t m, const uint32_t *__restrict__ runlen, uint32_t *__restrict__ cnt)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) cnt[i] = runlen[rank[i]];
+}
+
+// ---- probe side: range partition of (key, row id) ---------------------------------------------------------------
+// LDS: E ring[P][Q]; K split[P]; u32 s_w[P] (head << 16 | count); int s_lcur[P]; u32 flags[4].
+template <typename K>
+__global__ __launch_bounds__(kJThreads) void jpart_kernel(const K *__restrict__ keys, int64_t n, K bias, const K *__restrict__ splitters,
+                                                          const K *__restrict__ rkeys, int64_t s,
+                                                          typename JTraits<K>::E *__restrict__ slabs, uint32_t *__restrict__ counts, uint32_t cap,
+                                                          int period, int32_t *__restrict__ err)
+{
+    typedef typename JTraits<K>::E E;
+    constexpr int P = JTraits<K>::P, Q = JTraits<K>::Q, VEC = JTraits<K>::VEC;
+    constexpr int LINE = 128 / (int)sizeof(E), PER_LANE = 16 / (int)sizeof(E);          // entries per line / per 16-byte lane piece
+    constexpr int BATCH = kJThreads * VEC;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    E *ring = reinterpret_cast<E *>(lds_raw);
+    K *split = reinterpret_cast<K *>(ring + (size_t)P * Q);
+    uint32_t *s_w = reinterpret_cast<uint32_t *>(split + P);
+    int *s_lcur = reinterpret_cast<int *>(s_w + P);
+    uint32_t *flags = reinterpret_cast<uint32_t *>(s_lcur + P);
+    const int tid = threadIdx.x, wg = blockIdx.x, nwg = gridDim.x;
+    const int cap_lines = (int)(cap / LINE) - 1;                                  // the last line takes the final partial flush
+    for (int b = tid; b < P; b += kJThreads) { s_w[b] = 0u; s_lcur[b] = 0; split[b] = b < P - 1 ? splitters[b] : (K)~(K)0; }
+    if (tid < 4) flags[tid] = 0u;
+    const K kmin = rkeys[0], kmax = rkeys[s - 1];
+    __syncthreads();
+    int phase = 0, since = 0;
+    bool overflow = false;
+    const int64_t nbatch = (n + BATCH - 1) / BATCH;
+    E *myslab = slabs + (size_t)wg * cap;                                       // + b * nwg * cap
+
+    auto load = [&](int64_t batch, K (&kk)[VEC]) {
+        const int64_t r = batch * BATCH + (int64_t)tid * VEC;
+        if (r + VEC <= n) {
+            typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+            const u4v t = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(keys + r));       // VEC * sizeof(K) = 16 bytes
+            if (sizeof(K) == 4) { kk[0] = (K)t.x; kk[1 % VEC] = (K)t.y; kk[2 % VEC] = (K)t.z; kk[3 % VEC] = (K)t.w; }
+            else { kk[0] = (K)(((uint64_t)t.y << 32) | t.x); kk[1 % VEC] = (K)(((uint64_t)t.w << 32) | t.z); }
+        } else {
+            for (int j = 0; j < VEC; j++) kk[j] = r + j < n ? keys[r + j] : (K)0;
+        }
+    };
+
+    auto process = [&](int64_t batch, const K (&kraw)[VEC], bool flush_now) {
+        const int64_t r = batch * BATCH + (int64_t)tid * VEC;
+        uint32_t pending = 0;
+        K kk[VEC];
+        uint32_t bk[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; j++) {
+            kk[j] = kraw[j] ^ bias;
+            if (r + j < n && kk[j] >= kmin && kk[j] <= kmax) pending |= 1u << j;
+            // bucket = number of splitters <= key  (split[P-1] = max: never counted unless key is max itself, capped below)
+            uint32_t pos = 0;
+#pragma unroll
+            for (int step = P / 2; step > 0; step >>= 1) if (split[pos + step - 1] <= kk[j]) pos += step;
+            bk[j] = pos < (uint32_t)P ? pos : (uint32_t)(P - 1);
+        }
+        bool again;
+        do {
+#pragma unroll
+            for (int j = 0; j < VEC; j++) {
+                if (pending & (1u << j)) {
+                    const uint32_t b = bk[j];
+                    const uint32_t old = atomicAdd(&s_w[b], 1u), pos = old & 0xFFFFu;
+                    if (pos < (uint32_t)Q) {
+                        E e; e.key = kk[j]; e.row = (uint32_t)(r + j);
+                        if (sizeof(E) == 16) reinterpret_cast<uint32_t *>(&e)[3] = 0u;
+                        ring[b * Q + (((old >> 16) + pos) & (Q - 1))] = e;
+                        pending &= ~(1u << j);
+                    } else atomicSub(&s_w[b], 1u);                     // ring full: retry after the sweep
+                }
+            }
+            const bool full = jwg_or(pending != 0, flags, phase);
+            if (!(full || flush_now)) break;
+            // ---- sweep: 8 lanes per bucket store its complete 128-byte lines, 16 bytes per lane
+            for (int b = tid >> 3; b < P; b += kJThreads / 8) {
+                const uint32_t w = s_w[b];
+                const int cnt = (int)(w & 0xFFFFu), lines = cnt / LINE;
+                if (lines) {
+                    const int i = tid & 7, head = (int)(w >> 16), lc = s_lcur[b];
+                    for (int q = 0; q < lines; q++) {
+                        const uint4 piece = *reinterpret_cast<const uint4 *>(&ring[b * Q + ((head + q * LINE + PER_LANE * i) & (Q - 1))]);
+                        if (lc + q < cap_lines) {
+                            typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+                            E *dst = myslab + (size_t)b * nwg * cap + (size_t)(lc + q) * LINE + PER_LANE * i;
+                            __builtin_nontemporal_store(u4v{piece.x, piece.y, piece.z, piece.w}, reinterpret_cast<u4v *>(dst));
+                        } else overflow = true;
+                    }
+                    if (i == 0) {
+                        s_w[b] = ((uint32_t)((head + lines * LINE) & (Q - 1)) << 16) | (uint32_t)(cnt - lines * LINE);
+                        s_lcur[b] = min(lc + lines, cap_lines);
+                    }
+                }
+            }
+            since = 0;
+            again = jwg_or(pending != 0, flags, phase);
+        } while (again);
+    };
+
+    K kA[VEC], kB[VEC];
+    if ((int64_t)wg < nbatch) load(wg, kA);
+    if ((int64_t)wg + nwg < nbatch) load((int64_t)wg + nwg, kB);
+    for (int64_t batch = wg; batch < nbatch; batch += nwg) {
+        K kr[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; j++) { kr[j] = kA[j]; kA[j] = kB[j]; }
+        if (batch + 2 * (int64_t)nwg < nbatch) load(batch + 2 * (int64_t)nwg, kB);
+        process(batch, kr, ++since >= period || batch + nwg >= nbatch);
+    }
+    // ---- what is left (< LINE entries per bucket) goes out as one partial line
+    for (int b = tid; b < P; b += kJThreads) {
+        const uint32_t w = s_w[b];
+        const int l = (int)(w & 0xFFFFu), head = (int)(w >> 16);
+        E *dst = myslab + (size_t)b * nwg * cap + (size_t)s_lcur[b] * LINE;
+        for (int j = 0; j < l; j++) dst[j] = ring[b * Q + ((head + j) & (Q - 1))];
+        counts[(size_t)b * nwg + wg] = (uint32_t)(s_lcur[b] * LINE + l);
+    }
+    if (overflow) *err = kJErrOverflow;
+}
+
+// total[b] = probe pairs of bucket b; soff = exclusive scan (capacity offsets of the survivor slabs); one workgroup.
+__global__ __launch_bounds__(1024) void jtotals_kernel(const uint32_t *__restrict__ counts, int P, int nwg, int64_t *__restrict__ soff)
+{
+    __shared__ unsigned long long s_tot[1024];
+    const int b = threadIdx.x;
+    unsigned long long t = 0;
+    if (b < P) for (int w = 0; w < nwg; w++) t += counts[(size_t)b * nwg + w];
+    s_tot[b] = t;
+    __syncthreads();
+    if (b == 0) {
+        unsigned long long run = 0;
+        for (int q = 0; q < P; q++) { soff[q] = (int64_t)run; run += s_tot[q]; }
+        soff[P] = (int64_t)run;
+    }
+}
+
+// ---- one workgroup per bucket: build slice in LDS, probe pairs streamed past it --------------------------------
+template <typename K>
+__global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTraits<K>::E *__restrict__ slabs, const uint32_t *__restrict__ counts,
+                                                            uint32_t cap, int nwg, const K *__restrict__ rkeys, const uint32_t *__restrict__ bstart,
+                                                            int chunk_cap, const int64_t *__restrict__ soff, uint2 *__restrict__ surv,
+                                                            uint32_t *__restrict__ scount)
+{
+    typedef typename JTraits<K>::E E;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    K *chunk = reinterpret_cast<K *>(lds_raw);
+    __shared__ uint32_t s_n;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = kJThreads >> 6;
+    const uint32_t lo = bstart[b], hi = bstart[b + 1];
+    if (tid == 0) s_n = 0u;
+    uint2 *out = surv + soff[b];
+    for (uint32_t base = lo; base < hi; base += (uint32_t)chunk_cap) {
+        const int m = (int)min((uint32_t)chunk_cap, hi - base);
+        __syncthreads();                                             // the previous round's readers are done (and s_n is set)
+        for (int i = tid; i < m; i += kJThreads) chunk[i] = rkeys[base + i];
+        __syncthreads();
+        const K first = chunk[0], last = chunk[m - 1];
+        const bool has_prev = base > lo;
+        const K prev_last = has_prev ? rkeys[base - 1] : (K)0;         // a run continued from the previous round was matched there
+        int top = 1;
+        while (top < m) top <<= 1;
+        for (int w = wave; w < nwg; w += nwaves) {
+            const uint32_t count = min(counts[(size_t)b * nwg + w], cap);
+            const E *src = slabs + ((size_t)b * nwg + w) * cap;
+            for (uint32_t i0 = 0; i0 < count; i0 += 64) {
+                const uint32_t i = i0 + lane;
+                bool match = false;
+                uint32_t rank = 0, row = 0;
+                if (i < count) {
+                    const E e = src[i];
+                    const K key = e.key;
+                    row = e.row;
+                    if (key >= first && key <= last && !(has_prev && key == prev_last)) {
+                        int pos = 0;                                   // lower bound: number of chunk keys < key
+                        for (int step = top >> 1; step > 0; step >>= 1) if (pos + step <= m && chunk[pos + step - 1] < key) pos += step;
+                        if (pos < m && chunk[pos] == key) { match = true; rank = base + (uint32_t)pos; }
+                    }
+                }
+                const unsigned long long mask = __ballot(match);
+                if (mask) {
+                    uint32_t at = 0;
+                    if (lane == 0) at = atomicAdd(&s_n, (uint32_t)__popcll(mask));
+                    at = __shfl(at, 0, 64);
+                    if (match) out[at + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = uint2{rank, row};
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) scount[b] = s_n;
+}
+
+// survivor slabs -> two contiguous arrays (rank, left row); dst offsets = exclusive scan of scount, done by every
+// workgroup for itself (P <= 1024 values)
+__global__ __launch_bounds__(256) void jcompact_kernel(const uint2 *__restrict__ surv, const int64_t *__restrict__ soff, const uint32_t *__restrict__ scount,
+                                                       int P, uint32_t *__restrict__ rank, uint32_t *__restrict__ lrow, unsigned long long *__restrict__ total)
+{
+    __shared__ unsigned long long s_dst;
+    const int b = blockIdx.x;
+    if (threadIdx.x == 0) {
+        unsigned long long run = 0;
+        for (int q = 0; q < b; q++) run += scount[q];
+        s_dst = run;
+        if (b == P - 1) *total = run + scount[b];
+    }
+    __syncthreads();
+    const unsigned long long dst = s_dst;
+    const uint2 *src = surv + soff[b];
+    const uint32_t cnt = scount[b];
+    for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) { const uint2 e = src[i]; rank[dst + i] = e.x; lrow[dst + i] = e.y; }
+}
+
+template <typename K>
+int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K *rkeys, int64_t s,
+                    uint32_t **rank_out, uint32_t **lrow_out, int64_t *m_out, bool *used)
+{
+    typedef typename JTraits<K>::E E;
+    constexpr int P = JTraits<K>::P, Q = JTraits<K>::Q, VEC = JTraits<K>::VEC, LINE = 128 / (int)sizeof(E);
+    *used = false;
+    hipStream_t st = ctx->stream;
+    const int nwg = ctx->num_cu;
+    // slab capacity: 1.5 x the uniform share + 4 lines, a multiple of the line
+    const int64_t avg = (n + (int64_t)P * nwg - 1) / ((int64_t)P * nwg);
+    int64_t cap64 = (avg + avg / 2 + 5 * LINE + LINE - 1) / LINE * LINE;
+    if (cap64 > 0x7FFFFFF0ll) return HARK_OK;
+    const uint32_t cap = (uint32_t)cap64;
+    K *splitters = nullptr; uint32_t *bstart = nullptr, *counts = nullptr, *scount = nullptr; int32_t *err = nullptr;
+    E *slabs = nullptr; int64_t *soff = nullptr; uint2 *surv = nullptr; unsigned long long *total = nullptr;
+    uint32_t *rank = nullptr, *lrow = nullptr;
+    int rc = hark_alloc(ctx, (void **)&splitters, sizeof(K) * P);
+    if (!rc) rc = hark_alloc(ctx, (void **)&bstart, 4 * (size_t)(P + 1));
+    if (!rc) rc = hark_alloc(ctx, (void **)&counts, 4 * (size_t)P * nwg);
+    if (!rc) rc = hark_alloc(ctx, (void **)&scount, 4 * (size_t)P);
+    if (!rc) rc = hark_alloc(ctx, (void **)&soff, 8 * (size_t)(P + 1));
+    if (!rc) rc = hark_alloc(ctx, (void **)&err, 16);
+    if (!rc) rc = hark_alloc(ctx, (void **)&total, 16);
+    if (!rc) rc = hark_alloc(ctx, (void **)&slabs, sizeof(E) * (size_t)P * nwg * cap);
+    auto cleanup = [&]() {
+        hark_free(ctx, splitters); hark_free(ctx, bstart); hark_free(ctx, counts); hark_free(ctx, scount); hark_free(ctx, soff);
+        hark_free(ctx, err); hark_free(ctx, total); hark_free(ctx, slabs); hark_free(ctx, surv);
+    };
+    if (rc) { cleanup(); return rc; }
+    hipMemsetAsync(err, 0, 16, st);
+    jsplit_kernel<K><<<(P + 256) / 256, 256, 0, st>>>(rkeys, s, P, splitters, bstart);
+    const size_t lds_part = sizeof(E) * (size_t)P * Q + sizeof(K) * P + 8 * (size_t)P + 16;
+    hipError_t he = hipFuncSetAttribute(reinterpret_cast<const void *>(&jpart_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part);
+    // rows per bucket and batch = BATCH / P; sweep before a ring of Q entries (less one line of carry) can fill up
+    const int per_batch = kJThreads * VEC / P;
+    int period = (Q - LINE) / (per_batch + per_batch / 2);
+    if (period < 1) period = 1;
+    if (he == hipSuccess) {
+        jpart_kernel<K><<<dim3((unsigned)nwg), dim3(kJThreads), lds_part, st>>>(lcol, n, bias, splitters, rkeys, s, slabs, counts, cap, period, err);
+        jtotals_kernel<<<1, 1024, 0, st>>>(counts, P, nwg, soff);
+        he = hipGetLastError();
+    }
+    int64_t words[2] = {0, 0};
+    if (he != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: partition launch failed: %s", hipGetErrorString(he));
+    int64_t n_in = 0;
+    if (!rc) rc = hark_read_words(ctx, soff + P, &n_in, 1);
+    if (!rc) rc = hark_read_words(ctx, err, words, 1);
+    if (!rc && (int32_t)(words[0] & 0xFFFFFFFFll) != 0) { cleanup(); return HARK_OK; }          // a slab overflowed (skew): caller falls back
+    if (!rc && n_in > 0) rc = hark_alloc(ctx, (void **)&surv, 8 * (size_t)n_in);
+    int64_t M = 0;
+    if (!rc && n_in > 0) {
+        int chunk_cap = (int)(kJLdsBudget / sizeof(K));
+        if (const char *e = getenv("HARK_JOIN_CHUNK")) { const int c = atoi(e); if (c >= 1 && c < chunk_cap) chunk_cap = c; }   // tests: force several rounds per bucket
+        he = hipFuncSetAttribute(reinterpret_cast<const void *>(&jbucket_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(K) * (size_t)chunk_cap));
+        if (he == hipSuccess) {
+            jbucket_kernel<K><<<dim3((unsigned)P), dim3(kJThreads), sizeof(K) * (size_t)chunk_cap, st>>>(slabs, counts, cap, nwg, rkeys, bstart, chunk_cap, soff, surv, scount);
+            he = hipGetLastError();
+        }
+        if (he != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: bucket launch failed: %s", hipGetErrorString(he));
+        // an upper bound of the survivors is n_in; their number is only known after the kernel: size the arrays by n_in
+        if (!rc) rc = hark_alloc(ctx, (void **)&rank, 4 * (size_t)n_in);
+        if (!rc) rc = hark_alloc(ctx, (void **)&lrow, 4 * (size_t)n_in);
+        if (!rc) {
+            jcompact_kernel<<<dim3((unsigned)P), 256, 0, st>>>(surv, soff, scount, P, rank, lrow, total);
+            if (hipGetLastError() != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: compact launch failed");
+        }
+        if (!rc) rc = hark_read_words(ctx, total, &M, 1);
+    }
+    cleanup();
+    if (rc) { hark_free(ctx, rank); hark_free(ctx, lrow); return rc; }
+    *rank_out = rank; *lrow_out = lrow; *m_out = M; *used = true;
+    return HARK_OK;
+}
+
+} // namespace
+
+// Matching probe rows of the join as (global rank of the first equal sorted build entry, probe row id), sorted by
+// (rank, probe row), and the partner count of each.  lcol: the probe key column (u32 bit patterns, or i64 when k64);
+// rkeys: the SORTED build keys (u32, or u64 biased by 2^63 when k64).  *used = false: nothing was produced (tiny input,
+// or skew overflowed a slab) and the caller takes the sort-merge path.  Outputs are pool blocks the caller frees.
+int k_join_partitioned(hark_context *ctx, const void *lcol, bool k64, int64_t n, const void *rkeys, int64_t s,
+                       uint32_t **rank_out, uint32_t **lrow_out, uint32_t **cnt_out, int64_t *m_out, bool *used)
+{
+    *rank_out = nullptr; *lrow_out = nullptr; *cnt_out = nullptr; *m_out = 0; *used = false;
+    if (n < ((int64_t)1 << 18) || s < 4096 || n + s > 0xFFFFFFFFll) return HARK_OK;
+    if (getenv("HARK_JOIN_SORTMERGE")) return HARK_OK;                          // A/B knob
+    uint32_t *rank = nullptr, *lrow = nullptr;
+    int64_t M = 0;
+    int rc = k64 ? run_partitioned<uint64_t>(ctx, static_cast<const uint64_t *>(lcol), 0x8000000000000000ull, n, static_cast<const uint64_t *>(rkeys), s, &rank, &lrow, &M, used)
+                 : run_partitioned<uint32_t>(ctx, static_cast<const uint32_t *>(lcol), 0u, n, static_cast<const uint32_t *>(rkeys), s, &rank, &lrow, &M, used);
+    if (rc || !*used) return rc;
+    if (M == 0) { hark_free(ctx, rank); hark_free(ctx, lrow); return HARK_OK; }
+    // (rank, left row) order: stable sort by left row, then stable sort by rank (each skips the passes no byte needs)
+    uint32_t *rank1 = nullptr, *lrow1 = nullptr, *lrow2 = nullptr, *rank2 = nullptr, *runlen = nullptr, *cnt = nullptr;
+    rc = k_sort_column(ctx, lrow, HARK_U32, M, false, rank, &rank1, &lrow1);
+    hark_free(ctx, rank); hark_free(ctx, lrow);
+    if (!rc) rc = k_sort_column(ctx, rank1, HARK_U32, M, false, lrow1, &lrow2, &rank2);
+    hark_free(ctx, rank1); hark_free(ctx, lrow1);
+    if (!rc) rc = hark_alloc(ctx, (void **)&runlen, 4 * (size_t)s);
+    if (!rc) rc = hark_alloc(ctx, (void **)&cnt, 4 * (size_t)M);
+    if (!rc) {
+        int64_t g1 = (s + 255) / 256, g2 = (M + 255) / 256;
+        const int64_t gcap = (int64_t)ctx->num_cu * 16;
+        if (g1 > gcap) g1 = gcap;
+        if (g2 > gcap) g2 = gcap;
+        if (k64) jrunlen_kernel<uint64_t><<<dim3((unsigned)g1), 256, 0, ctx->stream>>>(static_cast<const uint64_t *>(rkeys), s, runlen);
+        else jrunlen_kernel<uint32_t><<<dim3((unsigned)g1), 256, 0, ctx->stream>>>(static_cast<const uint32_t *>(rkeys), s, runlen);
+        jcnt_kernel<<<dim3((unsigned)g2), 256, 0, ctx->stream>>>(rank2, M, runlen, cnt);
+        if (hipGetLastError() != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: count launch failed");
+    }
+    hark_free(ctx, runlen);
+    if (rc) { hark_free(ctx, lrow2); hark_free(ctx, rank2); hark_free(ctx, cnt); *used = false; return rc; }
+    *rank_out = rank2; *lrow_out = lrow2; *cnt_out = cnt; *m_out = M;
+    return HARK_OK;
+}

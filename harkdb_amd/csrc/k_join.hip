@@ -27,6 +27,9 @@ int k_gather(hark_context *ctx, const void *src, int esz, const uint32_t *idx, v
 int k_sort_column(hark_context *ctx, const void *col, int dtype, int64_t n, bool descending, const uint32_t *payload,
                   uint32_t **vals_out, uint32_t **words_out);
 int k_exclusive_scan_u32(hark_context *ctx, const uint32_t *in, int64_t n, uint32_t *out32, int64_t *out64, int64_t *total_host);
+// k_hjoin.hip: the partitioned path (probe side range-partitioned by splitters of the sorted build side, build slices in LDS)
+int k_join_partitioned(hark_context *ctx, const void *lcol, bool k64, int64_t n, const void *rkeys, int64_t s,
+                       uint32_t **rank_out, uint32_t **lrow_out, uint32_t **cnt_out, int64_t *m_out, bool *used);
 
 namespace {
 
@@ -261,8 +264,29 @@ int hark_entry_join(hark_context *ctx, hark_result **out, const hark_table *db1,
     int rc = HARK_OK;
     int64_t nl = n;                                   // left rows that reach the sort + merge
     const void *lcol = db1->cols[col1].data, *rcol = db2->cols[col2].data;
-    bool filtered = false;
-    if (n >= ((int64_t)1 << 20) && n >= 4 * s) {
+    bool filtered = false, partitioned = false;
+    // ---- the build side is sorted first: both paths need it
+    rc = k_argsort_column(ctx, rcol, k64 ? HARK_I64 : HARK_U32, s, false, &rperm, k64 ? nullptr : &rkeys);
+    if (!rc && k64) {
+        rc = hark_alloc(ctx, (void **)&rk64, (size_t)s * 8);
+        if (!rc) gather_biased_i64_kernel<<<grid_for(ctx, s), 256, 0, st>>>(static_cast<const uint64_t *>(rcol), rperm, rk64, s);
+    }
+    // ---- partitioned path (k_hjoin.hip): matching probe rows as (rank in the sorted build side, left row), sorted
+    if (!rc) {
+        uint32_t *prank = nullptr, *plrow = nullptr, *pcnt = nullptr;
+        int64_t M = 0;
+        rc = k_join_partitioned(ctx, lcol, k64, n, k64 ? static_cast<const void *>(rk64) : static_cast<const void *>(rkeys), s,
+                                &prank, &plrow, &pcnt, &M, &partitioned);
+        if (!rc && partitioned) {
+            nl = M;
+            lb = prank; lperm = plrow; cnt = pcnt;                 // freed with the other scratch below
+            if (M > 0) {
+                rc = hark_alloc(ctx, (void **)&offs, (size_t)M * 8);
+                if (!rc) rc = k_exclusive_scan_u32(ctx, cnt, M, nullptr, offs, &P);
+            }
+        }
+    }
+    if (!rc && !partitioned && n >= ((int64_t)1 << 20) && n >= 4 * s) {
         // semi-join pre-filter (see the kernels above): bitmap of 16 bits per build key, power of two, <= 2^31 bits
         uint32_t lgb = 16;
         while (lgb < 31 && ((int64_t)1 << lgb) < 16 * s) lgb++;
@@ -313,20 +337,15 @@ int hark_entry_join(hark_context *ctx, hark_result **out, const hark_table *db1,
         if (hipStreamSynchronize(st) != hipSuccess && !rc) rc = hark_fail(ctx, HARK_EHIP, "join: filter kernels failed");
         hark_free(ctx, bitmap); hark_free(ctx, tcnt); hark_free(ctx, toffs); hark_free(ctx, masks); hark_free(ctx, ckeys); hark_free(ctx, crows);
     }
-    if (!rc && !filtered) rc = k_argsort_column(ctx, lcol, k64 ? HARK_I64 : HARK_U32, n, false, &lperm, k64 ? nullptr : &lkeys);
-    if (!rc) rc = k_argsort_column(ctx, rcol, k64 ? HARK_I64 : HARK_U32, s, false, &rperm, k64 ? nullptr : &rkeys);
-    if (!rc && k64) {
-        if (!filtered) rc = hark_alloc(ctx, (void **)&lk64, (size_t)n * 8);
-        if (!rc) rc = hark_alloc(ctx, (void **)&rk64, (size_t)s * 8);
-        if (!rc) {
-            if (!filtered) gather_biased_i64_kernel<<<grid_for(ctx, n), 256, 0, st>>>(static_cast<const uint64_t *>(lcol), lperm, lk64, n);
-            gather_biased_i64_kernel<<<grid_for(ctx, s), 256, 0, st>>>(static_cast<const uint64_t *>(rcol), rperm, rk64, s);
-        }
+    if (!rc && !partitioned && !filtered) rc = k_argsort_column(ctx, lcol, k64 ? HARK_I64 : HARK_U32, n, false, &lperm, k64 ? nullptr : &lkeys);
+    if (!rc && !partitioned && k64 && !filtered) {
+        rc = hark_alloc(ctx, (void **)&lk64, (size_t)n * 8);
+        if (!rc) gather_biased_i64_kernel<<<grid_for(ctx, n), 256, 0, st>>>(static_cast<const uint64_t *>(lcol), lperm, lk64, n);
     }
-    if (!rc && nl > 0) rc = hark_alloc(ctx, (void **)&lb, (size_t)nl * 4);
-    if (!rc && nl > 0) rc = hark_alloc(ctx, (void **)&cnt, (size_t)nl * 4);
-    if (!rc && nl > 0) rc = hark_alloc(ctx, (void **)&offs, (size_t)nl * 8);
-    if (!rc && nl > 0) {
+    if (!rc && !partitioned && nl > 0) rc = hark_alloc(ctx, (void **)&lb, (size_t)nl * 4);
+    if (!rc && !partitioned && nl > 0) rc = hark_alloc(ctx, (void **)&cnt, (size_t)nl * 4);
+    if (!rc && !partitioned && nl > 0) rc = hark_alloc(ctx, (void **)&offs, (size_t)nl * 8);
+    if (!rc && !partitioned && nl > 0) {
         if (k64) join_count_kernel<uint64_t><<<grid_for(ctx, (nl + kJoinChunk - 1) / kJoinChunk), 256, 0, st>>>(lk64, nl, rk64, s, lb, cnt);
         else join_count_kernel<uint32_t><<<grid_for(ctx, (nl + kJoinChunk - 1) / kJoinChunk), 256, 0, st>>>(lkeys, nl, rkeys, s, lb, cnt);
         rc = k_exclusive_scan_u32(ctx, cnt, nl, nullptr, offs, &P);
