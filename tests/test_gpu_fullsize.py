@@ -106,3 +106,93 @@ def test_shard_larger_than_2_31_rows_is_fed_in_pieces(eng):
     plan.free()
     for ptr in (p, k, v, s, c):
         eng.free(ptr)
+
+
+def test_c4_join_share_i64_full_size(eng):
+    """configs[3], one GPU's share: 1.25e8 probe rows x 1.25e7 UNIQUE i64 build keys (half of the probe rows find a
+    partner).  Checked on the device: pair count == hits, key equality on every output row, reference order (key,
+    left row, right row), every matching probe row present exactly once; plus a 2e6-row probe prefix against the
+    numpy model of join.fut:55-75 that tests/test_gpu_groupby_join.py pins to the oracle."""
+    import torch
+    from harkdb_amd.dist import tensor_from_ptr
+    dev = torch.device("cuda", 0)
+    n, s = 125_000_000, 12_500_000
+    mul = -7046029254386353131                                            # odd: i -> i * mul is a bijection mod 2^64
+    bk = torch.arange(s, dtype=torch.int64, device=dev) * mul
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    j = torch.randint(0, 2 * s, (n,), dtype=torch.int64, device=dev, generator=g)
+    pk = j * mul
+    hits = int((j < s).sum().item())
+    prow, brow = torch.arange(n, dtype=torch.int32, device=dev), torch.arange(s, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    tp = eng.table_from_device(n, [pk.data_ptr(), prow.data_ptr()], [np.int64, np.int32], keepalive=(pk, prow))
+    tb = eng.table_from_device(s, [bk.data_ptr(), brow.data_ptr()], [np.int64, np.int32], keepalive=(bk, brow))
+    res = eng.join(tp, tb, 0, 0, [0, 1], [0, 1])
+    P = res.shape[0]
+    assert P == hits
+    lk, lr, rk, rr = (tensor_from_ptr(res.device_ptr(c), P, dt, dev) for c, dt in ((0, np.int64), (1, np.int32), (2, np.int64), (3, np.int32)))
+    assert bool((lk == rk).all())                                          # key equality on every output row
+    assert bool((pk[lr.long()] == lk).all()) and bool((bk[rr.long()] == rk).all())    # the row ids point at those keys
+    dk = lk[1:] - lk[:-1]
+    assert bool((lk[1:] >= lk[:-1]).all())                                 # ascending signed key ...
+    assert bool((lr[1:][dk == 0] > lr[:-1][dk == 0]).all())                # ... then left row (unique build keys: one right row per key)
+    seen = torch.zeros(n, dtype=torch.bool, device=dev)
+    seen[lr.long()] = True
+    assert bool((seen == (j < s)).all())                                   # exactly the matching probe rows, each once (P == hits)
+    res.free()
+    # a probe prefix against the numpy model (build side in full)
+    m = 2_000_000
+    t2 = eng.table_from_device(m, [pk.data_ptr(), prow.data_ptr()], [np.int64, np.int32], keepalive=(pk, prow))
+    r2 = eng.join(t2, tb, 0, 0, [1], [1])
+    hk, hb = pk[:m].cpu().numpy(), bk.cpu().numpy()
+    ol, orr = np.argsort(hk, kind="stable"), np.argsort(hb, kind="stable")
+    sl, sr = hk[ol], hb[orr]
+    pos = np.searchsorted(sr, sl)
+    ok = (pos < s) & (sr[np.minimum(pos, s - 1)] == sl)
+    assert np.array_equal(r2.column(0), ol[ok].astype(np.int32)) and np.array_equal(r2.column(1), orr[pos[ok]].astype(np.int32))
+    r2.free()
+    for t in (tp, tb, t2):
+        t.free()
+
+
+def test_c5_full_pipeline_share(eng):
+    """configs[4], one GPU's share: 5e8 rows x (i32 key + 16 f32 columns) = 34 GB resident, the full SELECT / WHERE /
+    GROUP BY / HAVING / ORDER BY / LIMIT statement through the SQL surface.  Properties: linearity in the predicate,
+    HAVING complement, ORDER BY sortedness, LIMIT prefix == prefix of the unlimited result."""
+    from harkdb_amd import FutharkContext
+    n, G = 500_000_000, 1 << 20
+    fc = FutharkContext.__new__(FutharkContext)
+    fc.FutEnv, fc.tables, fc.sql_mode = eng, {}, True
+    cols = [eng.alloc(n * 4) for _ in range(16)]
+    key = eng.alloc(n * 4)
+    for j in range(0, 16, 2):
+        eng.gen_columns(SEED + j, 0, n, G, False, cols[j], key if j == 0 else None, cols[j + 1])
+    fc.create_table_from_device("t", ["k"] + [f"c{j}" for j in range(16)], [key] + cols, [np.int32] + [np.float32] * 16, n)
+    q = lambda s: fc.sql_columns(s)[1]
+    k_gt, s_gt, c_gt = q("select k, sum(c3), count(*) from t where c1 > 0.5 group by k")
+    k_le, s_le, c_le = q("select k, sum(c3), count(*) from t where c1 <= 0.5 group by k")
+    k_all, s_all, c_all = q("select k, sum(c3), count(*) from t group by k")
+    assert len(k_all) == G and np.array_equal(k_all, np.arange(G)) and np.array_equal(k_gt, k_all) and np.array_equal(k_le, k_all)
+    assert int(c_all.sum()) == n and np.array_equal(c_gt + c_le, c_all)                      # counts: exact linearity
+    assert np.allclose(s_gt.astype(np.float64) + s_le.astype(np.float64), s_all.astype(np.float64), rtol=1e-5)   # f32 sums: 1e-5 relative
+    assert abs(int(c_gt.sum()) / n - 0.5) < 1e-3
+    # HAVING complement over the filtered aggregation
+    kh, ch = q("select k, count(*) from t where c1 > 0.5 group by k having count(*) > 250")
+    kl, cl = q("select k, count(*) from t where c1 > 0.5 group by k having count(*) <= 250")
+    assert len(kh) + len(kl) == G and ch.min() > 250 and (len(cl) == 0 or cl.max() <= 250)
+    assert np.array_equal(np.sort(np.concatenate([kh, kl])), k_all) and np.array_equal(ch, c_gt[kh])
+    # the full statement: ORDER BY sortedness, LIMIT prefix
+    stmt = "select k, sum(c3), count(*), avg(c3) from t where c1 > 0.5 group by k having count(*) > 250 order by sum(c3) desc"
+    ko, so, co, ao = q(stmt)
+    assert len(ko) == len(kh) and np.all(np.diff(so) <= 0)                                    # sorted descending by the aggregate
+    assert np.array_equal(so, s_gt[ko]) and np.array_equal(co, c_gt[ko])                      # the rows are the aggregation's rows
+    assert np.allclose(ao, so.astype(np.float64) / co, rtol=1e-6)
+    kl10, sl10, cl10, al10 = q(stmt + " limit 10")
+    assert np.array_equal(kl10, ko[:10]) and np.array_equal(sl10, so[:10]) and np.array_equal(cl10, co[:10]) and np.array_equal(al10, ao[:10])
+    # three aggregates over three columns + MAX/MIN bounds from the generator (values uniform in [0, 1))
+    k3, s3, mx, mn, c3 = q("select k, sum(c3), max(c7), min(c9), count(*) from t where c1 > 0.5 group by k")
+    assert np.array_equal(s3, s_gt) and np.array_equal(c3, c_gt) and mx.max() < 1.0 and mn.min() >= 0.0 and np.all(mx[c3 > 50] > mn[c3 > 50])
+    fc.drop_table("t")
+    for ptr in cols + [key]:
+        eng.free(ptr)

@@ -38,7 +38,8 @@ def _check(eng, lk, rk):
     la, rb = np.arange(n, dtype=np.int32), np.arange(s, dtype=np.int32)
     t1, t2 = eng.table_from_columns([lk, la]), eng.table_from_columns([rb, rk])
     res = eng.join(t1, t2, 0, 1, [1, 0], [0])
-    li, ri = _np_join_rows(lk, rk)
+    # 32-bit keys join as u32 bit patterns (join.fut:52 types both tables u32): negative i32 keys sort after the others
+    li, ri = _np_join_rows(lk.view(np.uint32), rk.view(np.uint32)) if lk.dtype.itemsize == 4 else _np_join_rows(lk, rk)
     assert res.shape[0] == len(li)
     if len(li):
         assert np.array_equal(res.column(0), la[li])          # left row ids: bit-exact order (key, left row, right row)
