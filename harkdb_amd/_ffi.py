@@ -16,7 +16,7 @@ OK, EBOUNDS, ENOMEM, EARG, EHIP, EUNSUPPORTED = range(6)
 I32, U32, F32, I64 = range(4)
 NP_OF = {I32: np.int32, U32: np.uint32, F32: np.float32, I64: np.int64}
 DT_OF = {np.dtype(np.int32): I32, np.dtype(np.uint32): U32, np.dtype(np.float32): F32, np.dtype(np.int64): I64}
-CMP = {">": 0, ">=": 1, "<": 2, "<=": 3, "=": 4, "==": 4, "!=": 5, "<>": 5}
+CMP = {">": 0, ">=": 1, "<": 2, "<=": 3, "=": 4, "==": 4, "!=": 5, "<>": 5, "mask": 6}
 AGG = {"key": 0, "prod": 1, "sum": 2, "max": 3, "min": 4, "count": 5, "avg": 6}
 
 
@@ -58,6 +58,9 @@ SIGNATURES = {
     "hark_entry_query_groupby": (C.c_int, [_vp, _pp, _vp, _i32, C.POINTER(_i32), _i64, C.POINTER(_i32), _i64]),
     "hark_entry_join": (C.c_int, [_vp, _pp, _vp, _vp, _i32, _i32, C.POINTER(_i32), _i64, C.POINTER(_i32), _i64]),
     "hark_entry_filter_sel": (C.c_int, [_vp, _pp, _vp, _i32, _i32, _vp, C.POINTER(_i32), _i64, _i32]),
+    "hark_entry_filter_sel_and": (C.c_int, [_vp, _pp, _vp, _i64, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(C.c_void_p), C.POINTER(_i32), _i64, _i32]),
+    "hark_entry_filter_groupby_and": (C.c_int, [_vp, _pp, _vp, _i64, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(C.c_void_p), _i32, C.POINTER(_i32), C.POINTER(_i32), _i64]),
+    "hark_op_predicate_bitmask": (C.c_int, [_vp, _vp, _i64, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(C.c_void_p), _vp]),
     "hark_entry_filter_groupby": (C.c_int, [_vp, _pp, _vp, _i32, _i32, _vp, _i32, C.POINTER(_i32), C.POINTER(_i32), _i64]),
     "hark_entry_sort": (C.c_int, [_vp, _pp, _vp, _i32, _i32, C.POINTER(_i32), _i64]),
     "hark_op_segmented_scan_add_i32": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),

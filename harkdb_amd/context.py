@@ -83,14 +83,7 @@ class FutharkContext:
         dev = self.tables[ir["table_name"]]._device
         aggs = [i for i in ir["items"][1:]]
         where = ir.get("where", [])
-        cur, cmap = dev, {c: c for c in range(dev.shape[1])}
-        first = None
-        if len(where) == 1:
-            first = where[0]
-        elif len(where) > 1:
-            cur, cmap = self._filtered(dev, where, {ir["g_col"]} | {c for _, c in aggs if c is not None})
-        res = self.FutEnv.filter_groupby(cur, None if first is None else (cmap[first[0]], first[1], first[2]), cmap[ir["g_col"]],
-                                         [(f, 0 if c is None else cmap[c]) for f, c in aggs])
+        res = self.FutEnv.filter_groupby(dev, [(c, cmp, v) for c, cmp, v in where], ir["g_col"], [(f, 0 if c is None else c) for f, c in aggs])
         schema = self.tables[ir["table_name"]].get_schema()
         return [schema[ir["g_col"]]] + [f"{f}({'*' if c is None else schema[c]})" for f, c in aggs], res
 
@@ -138,20 +131,14 @@ class FutharkContext:
         return names, out
 
     def _filtered(self, dev, where, need_cols):
-        """Apply an AND-list of predicates on the device; returns (table-like, column map)."""
+        """Apply an AND-list of predicates on the device in ONE compaction (all conjuncts go into one survivor mask);
+        returns (table-like, column map)."""
         eng = self.FutEnv
-        cur, cmap = dev, {c: c for c in range(dev.shape[1])}
-        keep = None
-        for i, (col, cmp, value) in enumerate(where):
-            later = {c for c, _, _ in where[i + 1:]}
-            proj = sorted(set(need_cols) | later)
-            res = eng.filter_sel(cur, cmap[col], cmp, value, [cmap[c] for c in proj], want_row_index=False)
-            n = res.shape[0]
-            cur = eng.table_from_device(n, [res.device_ptr(j) for j in range(len(proj))],
-                                        [res.dtype(j) for j in range(len(proj))], keepalive=(res, keep))
-            keep = cur
-            cmap = {c: j for j, c in enumerate(proj)}
-        return cur, cmap
+        proj = sorted(set(need_cols))
+        res = eng.filter_sel(dev, [(c, cmp, v) for c, cmp, v in where], cols=proj, want_row_index=False)
+        cur = eng.table_from_device(res.shape[0], [res.device_ptr(j) for j in range(len(proj))],
+                                    [res.dtype(j) for j in range(len(proj))], keepalive=res)
+        return cur, {c: j for j, c in enumerate(proj)}
 
     def _select_extended(self, dev, ir):
         eng = self.FutEnv
@@ -216,12 +203,8 @@ class FutharkContext:
         where = ir.get("where", [])
         need = set(g_cols) | {c for _, c in aggs if c is not None}
         cur, cmap = dev, {c: c for c in range(dev.shape[1])}
-        first = None
-        if len(where) == 1:
-            first = (where[0][0], where[0][1], where[0][2])
-            need.add(first[0])
-        elif len(where) > 1:
-            cur, cmap = self._filtered(dev, where, need)
+        preds = [(c, cmp, v) for c, cmp, v in where]           # the whole AND-list goes to the entry: no intermediate table
+        need |= {c for c, _, _ in preds}
         decode = None
         if multi:
             # several keys -> one composite key column on the device (ascending composite = lexicographic key tuple)
@@ -234,8 +217,7 @@ class FutharkContext:
             decode = (mins, spans, [dev.dtype(c) for c in g_cols])
         else:
             gkey = cmap[g_col]
-        res = eng.filter_groupby(cur, None if first is None else (cmap[first[0]], first[1], first[2]), gkey,
-                                 [(f, 0 if c is None else cmap[c]) for f, c in aggs])
+        res = eng.filter_groupby(cur, [(cmap[c], cmp, v) for c, cmp, v in preds], gkey, [(f, 0 if c is None else cmap[c]) for f, c in aggs])
         # HAVING / ORDER BY run on the G-row result, still on the device
         keep = [res]
         for slot, cmp, v in having:

@@ -140,6 +140,8 @@ int hark_fgb_finish_typed_from(hark_context *ctx, hark_fgb_plan *pl, int32_t whi
 int k_fgb_decode(hark_context *ctx, const unsigned long long *acc, const unsigned long long *cnt, int64_t G, int kind, void *out);
 
 // k_select.hip
+int k_predicate_bitmask(hark_context *ctx, const hark_table *db, int64_t n_preds, const int32_t *where_cols, const int32_t *cmps,
+                        const void *const *constants, uint8_t **mask_out);
 int k_groupby_typed(hark_context *ctx, const hark_table *db, int32_t g_col, const int32_t *agg_cols,
                     const int32_t *agg_ops, int64_t n_aggs, hark_result *res);
 int k_gather_columns(hark_context *ctx, const hark_table *db, const int32_t *cols, int64_t k,

@@ -55,6 +55,20 @@ namespace {
 
 constexpr int kVec = 4;                 // rows per 16-byte load
 constexpr int kNoPred = -1;
+// HARK_CMP_MASK: the predicate column is a precomputed 1-bit-per-row survivor bitmask (bit r & 7 of byte r >> 3:
+// an AND-list of predicates on any dtypes, evaluated once by k_predicate_bitmask).  0.125 B/row instead of 4.
+constexpr int kMaskPred = HARK_CMP_MASK;
+
+// the four mask bits of rows r..r+3 (r a multiple of 4) as 1.0f / 0.0f "predicate values"
+__device__ __forceinline__ float4 mask_nibble(const float *p, int64_t r)
+{
+    const uint32_t byte = reinterpret_cast<const uint8_t *>(p)[r >> 3], nib = (byte >> (r & 4)) & 15u;
+    return float4{(float)(nib & 1u), (float)((nib >> 1) & 1u), (float)((nib >> 2) & 1u), (float)(nib >> 3)};
+}
+__device__ __forceinline__ float mask_bit(const float *p, int64_t r)
+{
+    return (float)((reinterpret_cast<const uint8_t *>(p)[r >> 3] >> (r & 7)) & 1u);
+}
 
 template <int OP>
 __device__ __forceinline__ bool cmp_f32(float a, float b)
@@ -65,6 +79,7 @@ __device__ __forceinline__ bool cmp_f32(float a, float b)
     else if constexpr (OP == HARK_CMP_LE) return a <= b;
     else if constexpr (OP == HARK_CMP_EQ) return a == b;
     else if constexpr (OP == HARK_CMP_NE) return a != b;
+    else if constexpr (OP == kMaskPred) return a != 0.0f;
     else return true;                   // kNoPred
 }
 
@@ -225,15 +240,15 @@ __global__ __launch_bounds__(1024) void fgb_lds_kernel(
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     // two independent 16-byte loads per column in flight per lane
     for (; i + stride < nvec; i += 2 * stride) {
-        float4 pa = OP == kNoPred ? float4{0, 0, 0, 0} : p4[i];
-        float4 pb = OP == kNoPred ? float4{0, 0, 0, 0} : p4[i + stride];
+        float4 pa = OP == kNoPred ? float4{0, 0, 0, 0} : OP == kMaskPred ? mask_nibble(p, i * kVec) : p4[i];
+        float4 pb = OP == kNoPred ? float4{0, 0, 0, 0} : OP == kMaskPred ? mask_nibble(p, (i + stride) * kVec) : p4[i + stride];
         int4 ka = k4[i], kb = k4[i + stride];
         float4 va = CNT ? float4{0, 0, 0, 0} : v4[i], vb = CNT ? float4{0, 0, 0, 0} : v4[i + stride];
         row(pa.x, ka.x, va.x); row(pa.y, ka.y, va.y); row(pa.z, ka.z, va.z); row(pa.w, ka.w, va.w);
         row(pb.x, kb.x, vb.x); row(pb.y, kb.y, vb.y); row(pb.z, kb.z, vb.z); row(pb.w, kb.w, vb.w);
     }
     for (; i < nvec; i += stride) {
-        float4 pa = OP == kNoPred ? float4{0, 0, 0, 0} : p4[i];
+        float4 pa = OP == kNoPred ? float4{0, 0, 0, 0} : OP == kMaskPred ? mask_nibble(p, i * kVec) : p4[i];
         int4 ka = k4[i];
         float4 va = CNT ? float4{0, 0, 0, 0} : v4[i];
         row(pa.x, ka.x, va.x); row(pa.y, ka.y, va.y); row(pa.z, ka.z, va.z); row(pa.w, ka.w, va.w);
@@ -241,7 +256,7 @@ __global__ __launch_bounds__(1024) void fgb_lds_kernel(
     // ragged tail (n % 4 rows) by the first lanes of block 0
     if (blockIdx.x == 0) {
         int64_t t = nvec * kVec + threadIdx.x;
-        if (t < n) row(OP == kNoPred ? 0.0f : p[t], k[t], CNT ? 0.0f : v[t]);
+        if (t < n) row(OP == kNoPred ? 0.0f : OP == kMaskPred ? mask_bit(p, t) : p[t], k[t], CNT ? 0.0f : v[t]);
     }
     if (bad) *err = HARK_EBOUNDS;
     __syncthreads();
@@ -282,14 +297,14 @@ __global__ __launch_bounds__(256) void fgb_atomic_kernel(
         }
     };
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
-        float4 pa = OP == kNoPred ? float4{0, 0, 0, 0} : p4[i];
+        float4 pa = OP == kNoPred ? float4{0, 0, 0, 0} : OP == kMaskPred ? mask_nibble(p, i * kVec) : p4[i];
         int4 ka = k4[i];
         float4 va = v ? v4[i] : float4{0, 0, 0, 0};
         row(pa.x, ka.x, va.x); row(pa.y, ka.y, va.y); row(pa.z, ka.z, va.z); row(pa.w, ka.w, va.w);
     }
     if (blockIdx.x == 0) {
         int64_t t = nvec * kVec + threadIdx.x;
-        if (t < n) row(OP == kNoPred ? 0.0f : p[t], k[t], v ? v[t] : 0.0f);
+        if (t < n) row(OP == kNoPred ? 0.0f : OP == kMaskPred ? mask_bit(p, t) : p[t], k[t], v ? v[t] : 0.0f);
     }
     if (bad) *err = HARK_EBOUNDS;
 }
@@ -423,7 +438,8 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
         if (r + kVec <= row1) {                                        // streamed once: non-temporal loads
             typedef float f4v __attribute__((ext_vector_type(4)));
             typedef int i4v __attribute__((ext_vector_type(4)));
-            if (OP != kNoPred) { const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(p + r)); pr = float4{t.x, t.y, t.z, t.w}; }
+            if (OP == kMaskPred) pr = mask_nibble(p, r);               // r is a multiple of 4: one byte holds the lane's four bits
+            else if (OP != kNoPred) { const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(p + r)); pr = float4{t.x, t.y, t.z, t.w}; }
             else pr = float4{0, 0, 0, 0};
             const i4v tk = __builtin_nontemporal_load(reinterpret_cast<const i4v *>(k + r)); kr = int4{tk.x, tk.y, tk.z, tk.w};
             if (K2) vr = float4{0, 0, 0, 0};                                 // COUNT only: the value column is not read
@@ -431,7 +447,7 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
         } else {                                                       // ragged end of the table
             float pp[4] = {0, 0, 0, 0}; int kk[4] = {0, 0, 0, 0}; float vv[4] = {0, 0, 0, 0};
             for (int j = 0; j < kVec; j++) if (r + j < row1) {
-                pp[j] = OP == kNoPred ? 0.0f : p[r + j]; kk[j] = k[r + j]; vv[j] = K2 ? 0.0f : v[r + j];
+                pp[j] = OP == kNoPred ? 0.0f : OP == kMaskPred ? mask_bit(p, r + j) : p[r + j]; kk[j] = k[r + j]; vv[j] = K2 ? 0.0f : v[r + j];
             }
             pr = float4{pp[0], pp[1], pp[2], pp[3]}; kr = int4{kk[0], kk[1], kk[2], kk[3]}; vr = float4{vv[0], vv[1], vv[2], vv[3]};
         }
@@ -1133,6 +1149,7 @@ int dispatch_op(int cmp, bool has_pred, F &&f)
     case HARK_CMP_LE: return f(std::integral_constant<int, HARK_CMP_LE>{});
     case HARK_CMP_EQ: return f(std::integral_constant<int, HARK_CMP_EQ>{});
     case HARK_CMP_NE: return f(std::integral_constant<int, HARK_CMP_NE>{});
+    case HARK_CMP_MASK: return f(std::integral_constant<int, HARK_CMP_MASK>{});
     default: return HARK_EARG;
     }
 }

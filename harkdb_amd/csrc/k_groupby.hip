@@ -439,6 +439,9 @@ constexpr int64_t kDenseMaxGroups = (int64_t)1 << 21;      // limit of the parti
 // read-out kind (fgb_decode_kernel) and result dtype.
 struct DensePass { int vop, xf, col, kind, out_dtype; bool count_only; };
 
+// WHERE as an AND-list (n == 0: no filter); constants[j] is read as the dtype of column cols[j]
+struct PredList { int64_t n; const int32_t *cols; const int32_t *cmps; const void *const *consts; };
+
 bool dense_plan_for(int op, int dt, int col, DensePass *out)
 {
     const bool f = dt == HARK_F32, i = dt == HARK_I32, u = dt == HARK_U32;
@@ -458,7 +461,7 @@ bool dense_plan_for(int op, int dt, int col, DensePass *out)
 // Dense shape: 32-bit integer key with 0 <= key < 2^21 and aggregates over 4-byte columns.
 // One fused pass (k_fgb.hip) per distinct (operator, column); an f32 predicate is fused into every
 // pass, a predicate on another dtype compacts the referenced columns first.
-int try_dense(hark_context *ctx, const hark_table *db, int32_t where_col, int32_t cmp, const void *constant,
+int try_dense(hark_context *ctx, const hark_table *db, const PredList &preds,
               int32_t g_col, const int32_t *agg_cols, const int32_t *agg_ops, int64_t n_aggs, hark_result *res, bool *used)
 {
     *used = false;
@@ -476,24 +479,24 @@ int try_dense(hark_context *ctx, const hark_table *db, int32_t where_col, int32_
     if (kmin < 0 || kmax >= kDenseMaxGroups || kmax + 1 > 8 * db->n + 4096) return HARK_OK;
     const int64_t G = kmax + 1;
 
-    // WHERE: fused when possible, otherwise compact the referenced columns first
+    // WHERE: ONE f32 predicate feeding ONE value pass rides in the kernels as it is (no extra pass over anything).
+    // Everything else -- several conjuncts, predicates on other dtypes, several value passes that would each re-read
+    // the predicate column -- is evaluated once into a survivor bitmask (0.125 B/row) that every pass reads instead.
     const hark_table *src = db;
-    hark_result *kept = nullptr;
-    hark_table view;
-    std::vector<int32_t> remap((size_t)db->m, -1), need;
-    int32_t g2 = g_col;
-    const bool fuse_pred = where_col >= 0 && db->cols[where_col].dtype == HARK_F32;     // an f32 predicate rides in every pass
-    if (where_col >= 0 && !fuse_pred) {
-        auto want = [&](int c) { if (remap[c] < 0) { remap[c] = (int32_t)need.size(); need.push_back(c); } return remap[c]; };
-        g2 = want(g_col);
-        for (auto &pp : plan_of) if (!pp.count_only) pp.col = want(pp.col);
-        HARK_TRY(hark_entry_filter_sel(ctx, &kept, db, where_col, cmp, constant, need.data(), (int64_t)need.size(), 0));
-        view.n = kept->n; view.m = (int64_t)kept->cols.size(); view.cols = kept->cols;
-        for (auto &c : view.cols) c.owned = false;
-        src = &view;
+    int value_passes = 0;
+    for (int64_t j = 0; j < n_aggs; j++) {
+        if (plan_of[j].count_only) continue;
+        bool seen = false;
+        for (int64_t q = 0; q < j; q++) seen = seen || (!plan_of[q].count_only && plan_of[q].vop == plan_of[j].vop && plan_of[q].xf == plan_of[j].xf && plan_of[q].col == plan_of[j].col);
+        value_passes += seen ? 0 : 1;
     }
-    const float *p = fuse_pred ? static_cast<const float *>(src->cols[where_col].data) : nullptr;
-    const float thr = fuse_pred ? *static_cast<const float *>(constant) : 0.0f;
+    const bool direct = preds.n == 1 && db->cols[preds.cols[0]].dtype == HARK_F32 && value_passes <= 1;
+    uint8_t *mask = nullptr;
+    if (preds.n >= 1 && !direct) HARK_TRY(k_predicate_bitmask(ctx, db, preds.n, preds.cols, preds.cmps, preds.consts, &mask));
+    const float *p = direct ? static_cast<const float *>(db->cols[preds.cols[0]].data) : reinterpret_cast<const float *>(mask);
+    const int cmp = direct ? preds.cmps[0] : HARK_CMP_MASK;
+    const float thr = direct ? *static_cast<const float *>(preds.consts[0]) : 0.0f;
+    const int32_t g2 = g_col;
     const int32_t *keys = static_cast<const int32_t *>(src->cols[g2].data);
 
     hark_fgb_plan *plan = nullptr;
@@ -574,7 +577,7 @@ int try_dense(hark_context *ctx, const hark_table *db, int32_t where_col, int32_
     if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "filter_groupby: kernels failed");
     hark_free(ctx, flags); hark_free(ctx, pos);
     if (plan) hark_fgb_plan_free(ctx, plan);
-    if (kept) hark_result_free(ctx, kept);
+    hark_free(ctx, mask);
     *used = rc == HARK_OK;
     return rc;
 }
@@ -582,7 +585,7 @@ int try_dense(hark_context *ctx, const hark_table *db, int32_t where_col, int32_
 // Sparse 32-bit integer keys: the LDS hash-bucket pipeline of k_fgb.hip, one pass per distinct
 // (operator, column), results brought into ascending key order (signed for I32).  A WHERE is
 // applied by compacting the referenced columns first.
-int try_hash(hark_context *ctx, const hark_table *db, int32_t where_col, int32_t cmp, const void *constant,
+int try_hash(hark_context *ctx, const hark_table *db, const PredList &preds,
              int32_t g_col, const int32_t *agg_cols, const int32_t *agg_ops, int64_t n_aggs, hark_result *res, bool *used)
 {
     *used = false;
@@ -598,11 +601,11 @@ int try_hash(hark_context *ctx, const hark_table *db, int32_t where_col, int32_t
     hark_table view;
     std::vector<int32_t> remap((size_t)db->m, -1), need;
     int32_t g2 = g_col;
-    if (where_col >= 0) {
+    if (preds.n > 0) {
         auto want = [&](int c) { if (remap[c] < 0) { remap[c] = (int32_t)need.size(); need.push_back(c); } return remap[c]; };
         g2 = want(g_col);
         for (auto &pp : plan_of) if (!pp.count_only) pp.col = want(pp.col);
-        HARK_TRY(hark_entry_filter_sel(ctx, &kept, db, where_col, cmp, constant, need.data(), (int64_t)need.size(), 0));
+        HARK_TRY(hark_entry_filter_sel_and(ctx, &kept, db, preds.n, preds.cols, preds.cmps, preds.consts, need.data(), (int64_t)need.size(), 0));
         view.n = kept->n; view.m = (int64_t)kept->cols.size(); view.cols = kept->cols;
         for (auto &c : view.cols) c.owned = false;
         src = &view;
@@ -672,12 +675,25 @@ extern "C" int hark_entry_filter_groupby(hark_context *ctx, hark_result **out, c
                                          const void *constant, int32_t g_col, const int32_t *agg_cols, const int32_t *agg_ops,
                                          int64_t n_aggs)
 {
+    // where_col < 0 disables the filter
+    return hark_entry_filter_groupby_and(ctx, out, db, where_col >= 0 ? 1 : 0, &where_col, &cmp, &constant, g_col, agg_cols, agg_ops, n_aggs);
+}
+
+extern "C" int hark_entry_filter_groupby_and(hark_context *ctx, hark_result **out, const hark_table *db, int64_t n_preds,
+                                             const int32_t *where_cols, const int32_t *cmps, const void *const *constants,
+                                             int32_t g_col, const int32_t *agg_cols, const int32_t *agg_ops, int64_t n_aggs)
+{
+    hark_device_guard guard__(ctx);
     if (!ctx || !out || !db) return HARK_EARG;
     *out = nullptr;
     if (n_aggs < 0 || (n_aggs && (!agg_cols || !agg_ops))) return hark_fail(ctx, HARK_EARG, "filter_groupby: bad aggregate list");
     if (g_col < 0 || g_col >= db->m) return hark_fail(ctx, HARK_EBOUNDS, "filter_groupby: group column %d out of bounds", g_col);
-    if (where_col >= db->m) return hark_fail(ctx, HARK_EBOUNDS, "filter_groupby: where column %d out of bounds", where_col);
-    if (where_col >= 0 && (!constant || cmp < HARK_CMP_GT || cmp > HARK_CMP_NE)) return hark_fail(ctx, HARK_EARG, "filter_groupby: bad predicate");
+    if (n_preds < 0 || n_preds > 16 || (n_preds && (!where_cols || !cmps || !constants))) return hark_fail(ctx, HARK_EARG, "filter_groupby: 0..16 predicates");
+    for (int64_t j = 0; j < n_preds; j++) {
+        if (where_cols[j] < 0 || where_cols[j] >= db->m) return hark_fail(ctx, HARK_EBOUNDS, "filter_groupby: where column %d out of bounds", where_cols[j]);
+        if (!constants[j] || cmps[j] < HARK_CMP_GT || cmps[j] > HARK_CMP_NE) return hark_fail(ctx, HARK_EARG, "filter_groupby: bad predicate");
+    }
+    const PredList preds{n_preds, where_cols, cmps, constants};
     for (int64_t j = 0; j < n_aggs; j++) {
         if (agg_ops[j] < HARK_AGG_KEY || agg_ops[j] > HARK_AGG_AVG) return hark_fail(ctx, HARK_EARG, "filter_groupby: unknown aggregate opcode %d", agg_ops[j]);
         if (agg_ops[j] != HARK_AGG_COUNT && (agg_cols[j] < 0 || agg_cols[j] >= db->m))
@@ -686,8 +702,8 @@ extern "C" int hark_entry_filter_groupby(hark_context *ctx, hark_result **out, c
     hark_result *res = new hark_result();
     int rc = HARK_OK;
     bool done = false;
-    if (db->n > 0) rc = try_dense(ctx, db, where_col, cmp, constant, g_col, agg_cols, agg_ops, n_aggs, res, &done);
-    if (!rc && !done && db->n > 0) rc = try_hash(ctx, db, where_col, cmp, constant, g_col, agg_cols, agg_ops, n_aggs, res, &done);
+    if (db->n > 0) rc = try_dense(ctx, db, preds, g_col, agg_cols, agg_ops, n_aggs, res, &done);
+    if (!rc && !done && db->n > 0) rc = try_hash(ctx, db, preds, g_col, agg_cols, agg_ops, n_aggs, res, &done);
     if (!rc && !done) {
         // generic path: compact the referenced columns, then sort-based typed aggregation
         for (auto &c : res->cols) if (c.owned && c.data) hark_free(ctx, c.data);
@@ -698,11 +714,11 @@ extern "C" int hark_entry_filter_groupby(hark_context *ctx, hark_result **out, c
         std::vector<int32_t> remap((size_t)db->m, -1), need;
         int32_t g2 = g_col;
         std::vector<int32_t> cols2(agg_cols, agg_cols + n_aggs);
-        if (where_col >= 0 && db->n > 0) {
+        if (preds.n > 0 && db->n > 0) {
             auto want = [&](int c) { if (remap[c] < 0) { remap[c] = (int32_t)need.size(); need.push_back(c); } return remap[c]; };
             g2 = want(g_col);
             for (int64_t j = 0; j < n_aggs; j++) cols2[j] = agg_ops[j] == HARK_AGG_COUNT ? 0 : want(agg_cols[j]);
-            rc = hark_entry_filter_sel(ctx, &kept, db, where_col, cmp, constant, need.data(), (int64_t)need.size(), 0);
+            rc = hark_entry_filter_sel_and(ctx, &kept, db, preds.n, preds.cols, preds.cmps, preds.consts, need.data(), (int64_t)need.size(), 0);
             if (!rc) {
                 view.n = kept->n; view.m = (int64_t)kept->cols.size(); view.cols = kept->cols;
                 for (auto &c : view.cols) c.owned = false;

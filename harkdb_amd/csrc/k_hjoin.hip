@@ -37,8 +37,15 @@ struct JPair32 { uint32_t key, row; };                                    // 8 b
 struct __attribute__((aligned(16))) JPair64 { uint64_t key; uint32_t row, pad; };   // 16 bytes: 8 per line
 
 template <typename K> struct JTraits;
-template <> struct JTraits<uint32_t> { typedef JPair32 E; static constexpr int P = 256, Q = 64, VEC = 4; };
-template <> struct JTraits<uint64_t> { typedef JPair64 E; static constexpr int P = 256, Q = 32, VEC = 2; };
+// P buckets, rings of Q entries, VEC rows per lane and batch; the bucket kernel stages CHUNK sorted build keys per
+// round plus a bitmap of 2^BM_BITS bits over them (measured: a 16-step binary search in LDS for EVERY probe pair
+// cost 1.36 ms per 1e8 pairs -- instruction issue, not the loads; most pairs have no partner and now leave after
+// one bit test).  u32: 96 KiB of keys + 32 KiB of bitmap, one round up to 1.26e7 build rows; u64: 128 + 16 KiB.
+template <> struct JTraits<uint32_t> { typedef JPair32 E; static constexpr int P = 512, Q = 32, VEC = 4, CHUNK = 24576, BM_BITS = 18; };
+template <> struct JTraits<uint64_t> { typedef JPair64 E; static constexpr int P = 256, Q = 32, VEC = 2, CHUNK = 16384, BM_BITS = 17; };
+
+__device__ __forceinline__ uint32_t jhash(uint32_t k) { return k * 0x9E3779B1u; }
+__device__ __forceinline__ uint32_t jhash(uint64_t k) { return (uint32_t)((k * 0x9E3779B97F4A7C15ull) >> 32); }
 
 __device__ __forceinline__ bool jwg_or(bool pred, uint32_t *flags, int &phase)
 {
@@ -237,8 +244,10 @@ __global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTrai
                                                             uint32_t *__restrict__ scount)
 {
     typedef typename JTraits<K>::E E;
+    constexpr int BM_BITS = JTraits<K>::BM_BITS, BM_WORDS = 1 << (BM_BITS - 5);
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    K *chunk = reinterpret_cast<K *>(lds_raw);
+    uint32_t *bitmap = reinterpret_cast<uint32_t *>(lds_raw);                 // [BM_WORDS] one bit per hashed chunk key
+    K *chunk = reinterpret_cast<K *>(bitmap + BM_WORDS);                       // [chunk_cap] sorted build keys of this round
     __shared__ uint32_t s_n;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = kJThreads >> 6;
     const uint32_t lo = bstart[b], hi = bstart[b + 1];
@@ -247,37 +256,78 @@ __global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTrai
     for (uint32_t base = lo; base < hi; base += (uint32_t)chunk_cap) {
         const int m = (int)min((uint32_t)chunk_cap, hi - base);
         __syncthreads();                                             // the previous round's readers are done (and s_n is set)
+        for (int i = tid; i < BM_WORDS; i += kJThreads) bitmap[i] = 0u;
         for (int i = tid; i < m; i += kJThreads) chunk[i] = rkeys[base + i];
+        __syncthreads();
+        for (int i = tid; i < m; i += kJThreads) { const uint32_t h = jhash(chunk[i]) >> (32 - BM_BITS); atomicOr(&bitmap[h >> 5], 1u << (h & 31u)); }
         __syncthreads();
         const K first = chunk[0], last = chunk[m - 1];
         const bool has_prev = base > lo;
         const K prev_last = has_prev ? rkeys[base - 1] : (K)0;         // a run continued from the previous round was matched there
-        int top = 1;
-        while (top < m) top <<= 1;
+        // lower bound in one of two windows of W = 2^t <= m keys, [0, W) or [m - W, m): a fixed number of branch-free steps
+        int W = 1;
+        while (W * 2 <= m) W <<= 1;
+        const K pivot = chunk[W - 1];
+        // a probe pair against the staged slice: range test, bit test, then the search; a hit gives the global rank
+        auto probe = [&](K key, uint32_t &rank) -> bool {
+            if (!(key >= first && key <= last) || (has_prev && key == prev_last)) return false;
+            const uint32_t h = jhash(key) >> (32 - BM_BITS);
+            if (!((bitmap[h >> 5] >> (h & 31u)) & 1u)) return false;
+            const int off = pivot < key ? m - W : 0;
+            int pos = 0;
+            for (int step = W >> 1; step > 0; step >>= 1) pos += chunk[off + pos + step - 1] < key ? step : 0;
+            pos += off;
+            pos += (pos < m && chunk[pos] < key) ? 1 : 0;            // the window's last key was never compared
+            if (pos < m && chunk[pos] == key) { rank = base + (uint32_t)pos; return true; }
+            return false;
+        };
+        auto append = [&](bool match, uint32_t rank, uint32_t row) {
+            const unsigned long long mask = __ballot(match);
+            if (mask) {
+                uint32_t at = 0;
+                if (lane == 0) at = atomicAdd(&s_n, (uint32_t)__popcll(mask));
+                at = __shfl(at, 0, 64);
+                if (match) out[at + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = uint2{rank, row};
+            }
+        };
+        // a wave walks whole slabs, 128 entries per step: two entries per lane (one 16-byte load for 8-byte pairs, two
+        // for 16-byte entries), the next step's loads in flight while this one's pairs are searched
+        typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+        constexpr bool WIDE = sizeof(E) == 16;
         for (int w = wave; w < nwg; w += nwaves) {
             const uint32_t count = min(counts[(size_t)b * nwg + w], cap);
-            const E *src = slabs + ((size_t)b * nwg + w) * cap;
-            for (uint32_t i0 = 0; i0 < count; i0 += 64) {
-                const uint32_t i = i0 + lane;
-                bool match = false;
-                uint32_t rank = 0, row = 0;
-                if (i < count) {
-                    const E e = src[i];
-                    const K key = e.key;
-                    row = e.row;
-                    if (key >= first && key <= last && !(has_prev && key == prev_last)) {
-                        int pos = 0;                                   // lower bound: number of chunk keys < key
-                        for (int step = top >> 1; step > 0; step >>= 1) if (pos + step <= m && chunk[pos + step - 1] < key) pos += step;
-                        if (pos < m && chunk[pos] == key) { match = true; rank = base + (uint32_t)pos; }
-                    }
+            const u4v *src = reinterpret_cast<const u4v *>(slabs + ((size_t)b * nwg + w) * cap);
+            const uint32_t nstep = (count + 127u) / 128u;
+            u4v n0 = {0u, 0u, 0u, 0u}, n1 = {0u, 0u, 0u, 0u};
+            auto fetch = [&](uint32_t step) {
+                if (WIDE) {
+                    const uint32_t e0 = step * 128u + lane, e1 = e0 + 64u;
+                    if (e0 < count) n0 = __builtin_nontemporal_load(src + e0);
+                    if (e1 < count) n1 = __builtin_nontemporal_load(src + e1);
+                } else {
+                    const uint32_t e0 = step * 128u + 2u * lane;
+                    if (e0 < count) n0 = __builtin_nontemporal_load(src + (e0 >> 1));
                 }
-                const unsigned long long mask = __ballot(match);
-                if (mask) {
-                    uint32_t at = 0;
-                    if (lane == 0) at = atomicAdd(&s_n, (uint32_t)__popcll(mask));
-                    at = __shfl(at, 0, 64);
-                    if (match) out[at + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = uint2{rank, row};
+            };
+            if (nstep) fetch(0);
+            for (uint32_t step = 0; step < nstep; step++) {
+                const u4v c0 = n0, c1 = n1;
+                if (step + 1 < nstep) fetch(step + 1);
+                K key0, key1; uint32_t row0, row1; bool v0, v1;
+                if (WIDE) {
+                    const uint32_t e0 = step * 128u + lane;
+                    v0 = e0 < count; v1 = e0 + 64u < count;
+                    key0 = (K)(((uint64_t)c0.y << 32) | c0.x); row0 = c0.z;
+                    key1 = (K)(((uint64_t)c1.y << 32) | c1.x); row1 = c1.z;
+                } else {
+                    const uint32_t e0 = step * 128u + 2u * lane;
+                    v0 = e0 < count; v1 = e0 + 1u < count;
+                    key0 = (K)c0.x; row0 = c0.y; key1 = (K)c0.z; row1 = c0.w;
                 }
+                uint32_t r0 = 0, r1 = 0;
+                const bool m0 = v0 && probe(key0, r0), m1 = v1 && probe(key1, r1);
+                append(m0, r0, row0);
+                append(m1, r1, row1);
             }
         }
     }
@@ -292,13 +342,14 @@ __global__ __launch_bounds__(256) void jcompact_kernel(const uint2 *__restrict__
 {
     __shared__ unsigned long long s_dst;
     const int b = blockIdx.x;
-    if (threadIdx.x == 0) {
-        unsigned long long run = 0;
-        for (int q = 0; q < b; q++) run += scount[q];
-        s_dst = run;
-        if (b == P - 1) *total = run + scount[b];
-    }
+    if (threadIdx.x == 0) s_dst = 0ull;
     __syncthreads();
+    unsigned long long part = 0;
+    for (int q = threadIdx.x; q < b; q += blockDim.x) part += scount[q];
+    for (int d = 32; d > 0; d >>= 1) part += __shfl_down(part, d, 64);
+    if ((threadIdx.x & 63) == 0 && part) atomicAdd(&s_dst, part);
+    __syncthreads();
+    if (threadIdx.x == 0 && b == P - 1) *total = s_dst + scount[b];
     const unsigned long long dst = s_dst;
     const uint2 *src = surv + soff[b];
     const uint32_t cnt = scount[b];
@@ -357,11 +408,13 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
     if (!rc && n_in > 0) rc = hark_alloc(ctx, (void **)&surv, 8 * (size_t)n_in);
     int64_t M = 0;
     if (!rc && n_in > 0) {
-        int chunk_cap = (int)(kJLdsBudget / sizeof(K));
+        int chunk_cap = JTraits<K>::CHUNK;
         if (const char *e = getenv("HARK_JOIN_CHUNK")) { const int c = atoi(e); if (c >= 1 && c < chunk_cap) chunk_cap = c; }   // tests: force several rounds per bucket
-        he = hipFuncSetAttribute(reinterpret_cast<const void *>(&jbucket_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(K) * (size_t)chunk_cap));
+        constexpr size_t lds_bucket = sizeof(K) * (size_t)JTraits<K>::CHUNK + ((size_t)1 << (JTraits<K>::BM_BITS - 3));
+        static_assert(lds_bucket <= kJLdsBudget, "bucket kernel LDS");
+        he = hipFuncSetAttribute(reinterpret_cast<const void *>(&jbucket_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bucket);
         if (he == hipSuccess) {
-            jbucket_kernel<K><<<dim3((unsigned)P), dim3(kJThreads), sizeof(K) * (size_t)chunk_cap, st>>>(slabs, counts, cap, nwg, rkeys, bstart, chunk_cap, soff, surv, scount);
+            jbucket_kernel<K><<<dim3((unsigned)P), dim3(kJThreads), lds_bucket, st>>>(slabs, counts, cap, nwg, rkeys, bstart, chunk_cap, soff, surv, scount);
             he = hipGetLastError();
         }
         if (he != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: bucket launch failed: %s", hipGetErrorString(he));

@@ -82,17 +82,29 @@ __global__ __launch_bounds__(256) void join_count_kernel(const K *__restrict__ l
     }
 }
 
-__global__ __launch_bounds__(256) void join_expand_kernel(const int64_t *__restrict__ offs, int64_t n, const uint32_t *__restrict__ lb,
-                                                          const uint32_t *__restrict__ lperm, const uint32_t *__restrict__ rperm,
-                                                          int64_t P, uint32_t *__restrict__ lrow, uint32_t *__restrict__ rrow)
+// One lane per matching left row writes its partner pairs itself while it has few of them (the common case: the
+// stores of consecutive lanes are consecutive); a row with many partners is expanded by its whole wave, 64 pairs
+// per step -- so neither the output size nor skewed keys unbalance the work.
+__global__ __launch_bounds__(256) void join_expand_kernel(const int64_t *__restrict__ offs, const uint32_t *__restrict__ cnt, int64_t n,
+                                                          const uint32_t *__restrict__ lb, const uint32_t *__restrict__ lperm,
+                                                          const uint32_t *__restrict__ rperm, uint32_t *__restrict__ lrow, uint32_t *__restrict__ rrow)
 {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < P; o += stride) {
-        int64_t lo = 0, hi = n;                       // last i with offs[i] <= o
-        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (offs[mid] <= o) lo = mid + 1; else hi = mid; }
-        const int64_t i = lo - 1;
-        lrow[o] = lperm[i];
-        rrow[o] = rperm[lb[i] + (o - offs[i])];
+    const int lane = threadIdx.x & 63;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t base = ((((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) << 6); base < n; base += nwaves * 64) {
+        const int64_t i = base + lane;
+        uint32_t c = 0, first = 0, left = 0;
+        int64_t o = 0;
+        if (i < n) { c = cnt[i]; o = offs[i]; first = lb[i]; left = lperm[i]; }
+        if (c <= 8u) for (uint32_t j = 0; j < c; j++) { lrow[o + j] = left; rrow[o + j] = rperm[first + j]; }
+        unsigned long long big = __ballot(c > 8u);
+        while (big) {
+            const int src = __ffsll((long long)big) - 1;
+            big &= big - 1ull;
+            const uint32_t cc = __shfl(c, src, 64), ff = __shfl(first, src, 64), ll = __shfl(left, src, 64);
+            const int64_t oo = __shfl(o, src, 64);
+            for (uint32_t j = lane; j < cc; j += 64) { lrow[oo + j] = ll; rrow[oo + j] = rperm[ff + j]; }
+        }
     }
 }
 
@@ -361,7 +373,7 @@ int hark_entry_join(hark_context *ctx, hark_result **out, const hark_table *db1,
         if (!rc) rc = hark_alloc(ctx, (void **)&lrow, (size_t)P * 4);
         if (!rc) rc = hark_alloc(ctx, (void **)&rrow, (size_t)P * 4);
         if (!rc) {
-            join_expand_kernel<<<grid_for(ctx, P), 256, 0, st>>>(offs, nl, lb, lperm, rperm, P, lrow, rrow);
+            join_expand_kernel<<<grid_for(ctx, nl), 256, 0, st>>>(offs, cnt, nl, lb, lperm, rperm, lrow, rrow);
             if (hipGetLastError() != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: launch failed");
         }
         res->n = P;

@@ -119,6 +119,58 @@ __global__ __launch_bounds__(kThreads) void filter_count_kernel(const T *__restr
     if (threadIdx.x == 0) counts[tile] = s_cnt;
 }
 
+// Further conjuncts of a WHERE: AND this predicate into the masks pass 1 left and recount (a thread whose 16 rows
+// are all gone already does not read the column again).
+template <typename T>
+__global__ __launch_bounds__(kThreads) void filter_and_kernel(const T *__restrict__ col, int64_t n, int op, Const64 c,
+                                                              uint16_t *__restrict__ masks, uint32_t *__restrict__ counts)
+{
+    __shared__ uint32_t s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    const int64_t tile = blockIdx.x;
+    uint32_t mask = masks[tile * kThreads + threadIdx.x];
+    if (mask) {
+        mask &= eval_tile<T>(col, n, tile, op, const_as<T>(c));
+        masks[tile * kThreads + threadIdx.x] = (uint16_t)mask;
+    }
+    uint32_t cnt = __popc(mask);
+    for (int d = 32; d > 0; d >>= 1) cnt += __shfl_down(cnt, d, 64);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&s_cnt, cnt);
+    __syncthreads();
+    if (threadIdx.x == 0) counts[tile] = s_cnt;
+}
+
+// Linear survivor bitmask for the fused group-by kernels (k_fgb.hip, HARK_CMP_MASK): bit (r & 7) of byte (r >> 3).
+// A thread owns 8 consecutive rows = one byte; with `and_in` the byte is ANDed into what an earlier conjunct wrote.
+template <typename T>
+__global__ __launch_bounds__(256) void pred_bitmask_kernel(const T *__restrict__ col, int64_t n, int op, Const64 c, uint8_t *__restrict__ mask, int and_in)
+{
+    const T cv = const_as<T>(c);
+    const int64_t nbytes = (n + 7) / 8, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < nbytes; b += stride) {
+        const int64_t r = b * 8;
+        uint32_t old = and_in ? mask[b] : 0xFFu, m = 0;
+        if (old) {
+            if (r + 8 <= n) {
+                T x[8];
+                if constexpr (sizeof(T) == 4) {
+                    const uint4 q0 = *reinterpret_cast<const uint4 *>(col + r), q1 = *reinterpret_cast<const uint4 *>(col + r + 4);
+                    memcpy(x, &q0, 16); memcpy(x + 4, &q1, 16);
+                } else {
+#pragma unroll
+                    for (int h = 0; h < 4; h++) { const uint4 q = *reinterpret_cast<const uint4 *>(col + r + 2 * h); memcpy(x + 2 * h, &q, 16); }
+                }
+#pragma unroll
+                for (int j = 0; j < 8; j++) m |= (uint32_t)cmp_val<T>(op, x[j], cv) << j;
+            } else {
+                for (int j = 0; j < 8; j++) if (r + j < n) m |= (uint32_t)cmp_val<T>(op, col[r + j], cv) << j;
+            }
+        }
+        mask[b] = (uint8_t)(m & old);
+    }
+}
+
 // Pass 2: rank the survivors inside the tile (popcount prefix over lanes, waves
 // and the four 1024-row groups), compact each output column through LDS and
 // write it with unit-stride stores starting at the tile's global offset.
@@ -233,6 +285,48 @@ int check_cols(hark_context *ctx, const hark_table *db, const int32_t *cols, int
 
 } // namespace
 
+static Const64 read_const(int dtype, const void *constant)
+{
+    Const64 c{}; c.i = 0;
+    switch (dtype) {
+    case HARK_F32: c.f = *static_cast<const float *>(constant); break;
+    case HARK_I32: c.i = *static_cast<const int32_t *>(constant); break;
+    case HARK_U32: c.u = *static_cast<const uint32_t *>(constant); break;
+    default: c.i = *static_cast<const int64_t *>(constant); break;
+    }
+    return c;
+}
+
+// AND of n_preds (>= 1) predicates `db[:, where_cols[j]] <cmps[j]> *constants[j]` as a linear bitmask (pool block of
+// (n + 7) / 8 + 16 bytes, caller frees): one pass over each predicate column, nothing else is read.
+int k_predicate_bitmask(hark_context *ctx, const hark_table *db, int64_t n_preds, const int32_t *where_cols, const int32_t *cmps,
+                        const void *const *constants, uint8_t **mask_out)
+{
+    *mask_out = nullptr;
+    const int64_t n = db->n;
+    uint8_t *mask = nullptr;
+    HARK_TRY(hark_alloc(ctx, (void **)&mask, (size_t)((n + 7) / 8 + 16)));
+    int64_t blocks = ((n + 7) / 8 + 255) / 256;
+    if (blocks > (int64_t)ctx->num_cu * 16) blocks = (int64_t)ctx->num_cu * 16;
+    if (blocks < 1) blocks = 1;
+    for (int64_t j = 0; j < n_preds; j++) {
+        const int dt = db->cols[where_cols[j]].dtype;
+        const void *col = db->cols[where_cols[j]].data;
+        const Const64 c = read_const(dt, constants[j]);
+        const int and_in = j > 0;
+        dim3 grid((unsigned)blocks), block(256);
+        switch (dt) {
+        case HARK_F32: pred_bitmask_kernel<float><<<grid, block, 0, ctx->stream>>>(static_cast<const float *>(col), n, cmps[j], c, mask, and_in); break;
+        case HARK_I32: pred_bitmask_kernel<int32_t><<<grid, block, 0, ctx->stream>>>(static_cast<const int32_t *>(col), n, cmps[j], c, mask, and_in); break;
+        case HARK_U32: pred_bitmask_kernel<uint32_t><<<grid, block, 0, ctx->stream>>>(static_cast<const uint32_t *>(col), n, cmps[j], c, mask, and_in); break;
+        default: pred_bitmask_kernel<int64_t><<<grid, block, 0, ctx->stream>>>(static_cast<const int64_t *>(col), n, cmps[j], c, mask, and_in); break;
+        }
+        if (hipGetLastError() != hipSuccess) { hark_free(ctx, mask); return hark_fail(ctx, HARK_EHIP, "predicate mask: launch failed"); }
+    }
+    *mask_out = mask;
+    return HARK_OK;
+}
+
 int k_gather_columns(hark_context *ctx, const hark_table *db, const int32_t *cols, int64_t k, hark_result *res)
 {
     res->n = db->n;
@@ -280,24 +374,43 @@ int hark_entry_query_sel(hark_context *ctx, hark_result **out, const hark_table 
     return HARK_OK;
 }
 
+int hark_op_predicate_bitmask(hark_context *ctx, const hark_table *db, int64_t n_preds, const int32_t *where_cols,
+                              const int32_t *cmps, const void *const *constants, uint8_t *mask_dev)
+{
+    hark_device_guard guard__(ctx);
+    if (!ctx || !db || n_preds < 1 || n_preds > 16 || !where_cols || !cmps || !constants || (db->n && !mask_dev)) return HARK_EARG;
+    HARK_TRY(check_cols(ctx, db, where_cols, n_preds, "predicate_bitmask"));
+    for (int64_t j = 0; j < n_preds; j++)
+        if (!constants[j] || cmps[j] < HARK_CMP_GT || cmps[j] > HARK_CMP_NE) return hark_fail(ctx, HARK_EARG, "predicate_bitmask: bad predicate %lld", (long long)j);
+    if (db->n == 0) return HARK_OK;
+    uint8_t *tmp = nullptr;
+    HARK_TRY(k_predicate_bitmask(ctx, db, n_preds, where_cols, cmps, constants, &tmp));
+    hipError_t e = hipMemcpyAsync(mask_dev, tmp, (size_t)((db->n + 7) / 8), hipMemcpyDeviceToDevice, ctx->stream);
+    hark_free(ctx, tmp);                                   // stream-ordered reuse: the copy above is enqueued first
+    if (e != hipSuccess) return hark_fail(ctx, HARK_EHIP, "predicate_bitmask: copy failed");
+    return HARK_OK;
+}
+
 int hark_entry_filter_sel(hark_context *ctx, hark_result **out, const hark_table *db, int32_t where_col, int32_t cmp,
                           const void *constant, const int32_t *cols, int64_t k, int32_t want_row_index)
 {
+    return hark_entry_filter_sel_and(ctx, out, db, 1, &where_col, &cmp, &constant, cols, k, want_row_index);
+}
+
+int hark_entry_filter_sel_and(hark_context *ctx, hark_result **out, const hark_table *db, int64_t n_preds, const int32_t *where_cols,
+                              const int32_t *cmps, const void *const *constants, const int32_t *cols, int64_t k, int32_t want_row_index)
+{
     hark_device_guard guard__(ctx);
-    if (!ctx || !out || !db || !constant) return HARK_EARG;
+    if (!ctx || !out || !db) return HARK_EARG;
     *out = nullptr;
+    if (n_preds < 1 || n_preds > 16 || !where_cols || !cmps || !constants) return hark_fail(ctx, HARK_EARG, "filter_sel: 1..16 predicates");
     HARK_TRY(check_cols(ctx, db, cols, k, "filter_sel"));
-    HARK_TRY(check_cols(ctx, db, &where_col, 1, "filter_sel(where)"));
-    if (cmp < HARK_CMP_GT || cmp > HARK_CMP_NE) return hark_fail(ctx, HARK_EARG, "filter_sel: unknown comparison %d", cmp);
-    if (k > kMaxCols) return hark_fail(ctx, HARK_EUNSUPPORTED, "filter_sel: at most %d projected columns", kMaxCols);
-    const int wdt = db->cols[where_col].dtype;
-    Const64 c{}; c.i = 0;
-    switch (wdt) {
-    case HARK_F32: c.f = *static_cast<const float *>(constant); break;
-    case HARK_I32: c.i = *static_cast<const int32_t *>(constant); break;
-    case HARK_U32: c.u = *static_cast<const uint32_t *>(constant); break;
-    default: c.i = *static_cast<const int64_t *>(constant); break;
+    HARK_TRY(check_cols(ctx, db, where_cols, n_preds, "filter_sel(where)"));
+    for (int64_t j = 0; j < n_preds; j++) {
+        if (!constants[j]) return HARK_EARG;
+        if (cmps[j] < HARK_CMP_GT || cmps[j] > HARK_CMP_NE) return hark_fail(ctx, HARK_EARG, "filter_sel: unknown comparison %d", cmps[j]);
     }
+    if (k > kMaxCols) return hark_fail(ctx, HARK_EUNSUPPORTED, "filter_sel: at most %d projected columns", kMaxCols);
     const int64_t n = db->n;
     const int64_t ntiles = (n + kTile - 1) / kTile;
     if (ntiles > 0x7FFFFFFF) return hark_fail(ctx, HARK_EARG, "filter_sel: table too large for one call");
@@ -314,14 +427,22 @@ int hark_entry_filter_sel(hark_context *ctx, hark_result **out, const hark_table
         if (!rc) rc = hark_alloc(ctx, (void **)&offsets, (size_t)ntiles * sizeof(int64_t));
         if (!rc) rc = hark_alloc(ctx, (void **)&masks, (size_t)ntiles * kThreads * sizeof(uint16_t));
         if (!rc) {
-            const void *wc = db->cols[where_col].data;
             hipStream_t st = ctx->stream;
             dim3 grid((unsigned)ntiles), block(kThreads);
-            switch (wdt) {
-            case HARK_F32: filter_count_kernel<float><<<grid, block, 0, st>>>(static_cast<const float *>(wc), n, cmp, c, masks, counts); break;
-            case HARK_I32: filter_count_kernel<int32_t><<<grid, block, 0, st>>>(static_cast<const int32_t *>(wc), n, cmp, c, masks, counts); break;
-            case HARK_U32: filter_count_kernel<uint32_t><<<grid, block, 0, st>>>(static_cast<const uint32_t *>(wc), n, cmp, c, masks, counts); break;
-            default: filter_count_kernel<int64_t><<<grid, block, 0, st>>>(static_cast<const int64_t *>(wc), n, cmp, c, masks, counts); break;
+            for (int64_t j = 0; j < n_preds; j++) {                     // conjunct 0 writes the masks, the others AND into them
+                const int wdt = db->cols[where_cols[j]].dtype;
+                const void *wc = db->cols[where_cols[j]].data;
+                const Const64 c = read_const(wdt, constants[j]);
+                const int cmp = cmps[j];
+#define HARK_FILTER_LAUNCH(T) do { if (j == 0) filter_count_kernel<T><<<grid, block, 0, st>>>(static_cast<const T *>(wc), n, cmp, c, masks, counts); \
+                                   else filter_and_kernel<T><<<grid, block, 0, st>>>(static_cast<const T *>(wc), n, cmp, c, masks, counts); } while (0)
+                switch (wdt) {
+                case HARK_F32: HARK_FILTER_LAUNCH(float); break;
+                case HARK_I32: HARK_FILTER_LAUNCH(int32_t); break;
+                case HARK_U32: HARK_FILTER_LAUNCH(uint32_t); break;
+                default: HARK_FILTER_LAUNCH(int64_t); break;
+                }
+#undef HARK_FILTER_LAUNCH
             }
             if (hipGetLastError() != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "filter_sel: launch failed");
             if (!rc) rc = k_exclusive_scan_u32(ctx, counts, ntiles, nullptr, offsets, &total);

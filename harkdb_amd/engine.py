@@ -181,10 +181,11 @@ class FgbPlan:
         """Accumulate one batch.  All pointers are raw device addresses (ints); p = None: no filter,
         v = None: COUNT only (no value column is read)."""
         op = _ffi.CMP[cmp] if isinstance(cmp, str) else int(cmp)
+        pstep = 1 / 8 if op == _ffi.CMP["mask"] else 4         # cmp "mask": p is a survivor bitmask, one bit per row
         for lo in range(0, int(n), self.MAX_ROWS_PER_CALL):
             m = min(self.MAX_ROWS_PER_CALL, int(n) - lo)
             self._eng._chk(self._eng.lib.hark_op_filter_groupby_dense_f32(
-                self._eng.ctx, self._h, None if p is None else p + 4 * lo, op, float(thr), k + 4 * lo, None if v is None else v + 4 * lo, m))
+                self._eng.ctx, self._h, None if p is None else p + int(pstep * lo), op, float(thr), k + 4 * lo, None if v is None else v + 4 * lo, m))
 
     def acc_ptrs(self):
         """(device address of double[G] sums, device address of int64[G] counts)."""
@@ -359,27 +360,46 @@ class Engine:
         """(comparison, constant in the column's dtype) equivalent to `column <cmp> value` over the column's values."""
         return normalise_predicate(np.dtype(table.dtype(col)), cmp, value)
 
-    def filter_sel(self, table, where_col, cmp, value, cols, want_row_index=True):
+    def _predicates(self, table, where):
+        """where = [(col, cmp, value), ...] -> ctypes arrays (columns, comparison opcodes, constant pointers) + keepalive.
+        Every literal is normalised to its column's dtype first (normalise_predicate)."""
+        consts, cols, cmps = [], [], []
+        for col, cmp, value in where:
+            cmp2, c = self._const(table, col, value, cmp)
+            consts.append(c)
+            cols.append(int(col))
+            cmps.append(_ffi.CMP[cmp2])
+        n = len(where)
+        return ((C.c_int32 * n)(*cols), (C.c_int32 * n)(*cmps), (C.c_void_p * n)(*[c.ctypes.data for c in consts]), consts)
+
+    def filter_sel(self, table, where_col, cmp=None, value=None, cols=(), want_row_index=True):
+        """WHERE + projection.  `where_col` is a column index (with cmp, value) or an AND-list [(col, cmp, value), ...]:
+        all conjuncts are evaluated into one survivor mask, no intermediate table is materialised."""
+        where = list(where_col) if isinstance(where_col, (list, tuple)) else [(where_col, cmp, value)]
         a, pa = _ffi.i32_array(cols)
-        cmp, c = self._const(table, where_col, value, cmp)
+        wc, wo, wp, keep = self._predicates(table, where)
         h = C.c_void_p()
-        self._chk(self.lib.hark_entry_filter_sel(self.ctx, C.byref(h), table._h, int(where_col), _ffi.CMP[cmp],
-                                                 c.ctypes.data, pa, a.size, 1 if want_row_index else 0))
+        self._chk(self.lib.hark_entry_filter_sel_and(self.ctx, C.byref(h), table._h, len(where), wc, wo, wp, pa, a.size, 1 if want_row_index else 0))
         return Result(self, h)
 
     def filter_groupby(self, table, where, g_col, aggs):
-        """where = None | (col, cmp, value); aggs = [(op_name, col), ...]."""
+        """where = None | (col, cmp, value) | [(col, cmp, value), ...] (AND); aggs = [(op_name, col), ...]."""
         cols, pc = _ffi.i32_array([c for _, c in aggs])
         ops, po = _ffi.i32_array([_ffi.AGG[o] for o, _ in aggs])
         if where is None:
-            wc, cmp, c = -1, 0, np.zeros(1, dtype=np.int64)
-        else:
-            cmp, c = self._const(table, where[0], where[2], where[1])
-            wc, cmp = int(where[0]), _ffi.CMP[cmp]
+            where = []
+        elif where and not isinstance(where[0], (list, tuple)):
+            where = [tuple(where)]
+        wc, wo, wp, keep = self._predicates(table, list(where))
         h = C.c_void_p()
-        self._chk(self.lib.hark_entry_filter_groupby(self.ctx, C.byref(h), table._h, wc, cmp, c.ctypes.data,
-                                                     int(g_col), pc, po, cols.size))
+        self._chk(self.lib.hark_entry_filter_groupby_and(self.ctx, C.byref(h), table._h, len(where), wc, wo, wp, int(g_col), pc, po, cols.size))
         return Result(self, h)
+
+    def predicate_bitmask(self, table, where, mask_ptr):
+        """AND of the predicates as a survivor bitmask (bit r & 7 of byte r >> 3) at device address mask_ptr; feed it to
+        FgbPlan.run(p=mask_ptr, cmp="mask")."""
+        wc, wo, wp, keep = self._predicates(table, list(where))
+        self._chk(self.lib.hark_op_predicate_bitmask(self.ctx, table._h, len(where), wc, wo, wp, mask_ptr))
 
     def composite_key(self, table, key_cols, ranges=None):
         """Fold several 32-bit integer key columns into one composite key column on the device.

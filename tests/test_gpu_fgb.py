@@ -190,3 +190,30 @@ def test_count_only_no_value_column(eng, oracle, G, algo, use_pred):
     plan.free()
     for q in (dp, dk, ds, dc):
         eng.free(q)
+
+
+@pytest.mark.parametrize("n,G", [(1, 4), (9, 16), (100_003, 4096), (1_000_001, 1 << 20), (300_000, 3 << 19)])
+def test_survivor_bitmask_drives_the_fused_kernels(eng, oracle, n, G):
+    """hark_op_predicate_bitmask (AND of predicates on any dtypes, 1 bit per row) + HARK_CMP_MASK in the fused kernels
+    == the oracle's filter -> group-by with the same predicate (LDS path, partition path, atomics path)."""
+    from harkdb_amd.engine import FgbPlan
+    rng = np.random.default_rng(n)
+    p, k, v = oracle.gen_columns(SEED, 0, n, G, True)
+    w = rng.integers(-100, 100, n).astype(np.int32)
+    big = rng.integers(-2**40, 2**40, n).astype(np.int64)
+    t = eng.table_from_columns([p, k, v, w, big])
+    mask = eng.alloc((n + 7) // 8 + 16)
+    eng.predicate_bitmask(t, [(0, ">", 0.25), (3, "<", 37.5), (4, ">=", -2**39)], mask)
+    keep = (p > 0.25) & (w < 37.5) & (big >= -2**39)
+    host_mask = eng.download(mask, (n + 7) // 8, np.uint8)
+    assert np.array_equal(np.unpackbits(host_mask, bitorder="little")[:n].astype(bool), keep)
+    s, c = eng.alloc(G * 4), eng.alloc(G * 8)
+    plan = FgbPlan(eng, n, G)
+    plan.run(mask, "mask", 0.0, t.device_ptr(1), t.device_ptr(2), n)
+    plan.finish(s, c)
+    pk = np.where(keep, 1.0, 0.0).astype(np.float32)               # the oracle sees the same survivors through a 0/1 column
+    s32, _, cnt = oracle.filter_groupby_dense_f32(pk, k, v, ">", 0.5, G)
+    assert np.array_equal(eng.download(c, G, np.int64), cnt) and np.array_equal(eng.download(s, G, np.float32), s32)
+    plan.free()
+    for ptr in (mask, s, c):
+        eng.free(ptr)

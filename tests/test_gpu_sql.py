@@ -373,3 +373,34 @@ def test_float_keys_signed_zero_and_nan_form_single_groups():
     assert len(keys) == 4
     assert keys[0] == -2.0 and keys[1] == 0.0 and keys[2] == 1.5 and np.isnan(keys[3])
     assert sums.tolist() == [10, 1 + 2 + 3 + 7, 4 + 9, 5 + 6 + 8] and cnts.tolist() == [1, 4, 2, 3]
+
+
+# ---- round 2: AND-lists of predicates in one pass (survivor bitmask), several aggregates over one mask ---------------
+@pytest.mark.parametrize("where,mask", [
+    ("p > 0.5 and w < 0", lambda d: (d.p > 0.5) & (d.w < 0)),
+    ("w >= -50 and w < 50 and p <= 0.9 and big > 0", lambda d: (d.w >= -50) & (d.w < 50) & (d.p <= 0.9) & (d.big > 0)),
+    ("big < 0", lambda d: d.big < 0),
+    ("k != 7 and p > 0.25", lambda d: (d.k != 7) & (d.p > 0.25)),
+    ("p > 2.0 and w < 0", lambda d: (d.p > 2.0) & (d.w < 0)),                 # nothing survives
+])
+def test_and_lists_dense_groupby_and_select(fc, where, mask):
+    df = fc._df
+    m = mask(df)
+    _, cols = fc.sql_columns(f"select k, sum(v), count(*), max(w), min(p), avg(w) from t where {where} group by k")
+    g = df[m].groupby("k").agg(s=("v", "sum"), c=("v", "size"), mx=("w", "max"), mn=("p", "min"), av=("w", "mean"))
+    assert np.array_equal(cols[0], g.index.to_numpy())
+    assert np.array_equal(cols[1], g.s.to_numpy().astype(np.float32)) and np.array_equal(cols[2], g.c.to_numpy())
+    assert np.array_equal(cols[3], g.mx.to_numpy()) and np.array_equal(cols[4], g.mn.to_numpy())
+    assert np.allclose(cols[5], g.av.to_numpy(), rtol=1e-6)
+    out = fc.sql(f"select k, w from t where {where}")
+    assert np.array_equal(out, df[m][["k", "w"]].to_numpy())
+
+
+def test_and_lists_sparse_and_wide_keys(fc):
+    df = fc._df
+    _, cols = fc.sql_columns("select big, count(*), sum(w) from t where p > 0.3 and w > 10 group by big")
+    g = df[(df.p > 0.3) & (df.w > 10)].groupby("big").agg(c=("w", "size"), s=("w", "sum"))
+    assert np.array_equal(cols[0], g.index.to_numpy()) and np.array_equal(cols[1], g.c.to_numpy()) and np.array_equal(cols[2], g.s.to_numpy())
+    _, cols = fc.sql_columns("select w, count(*), max(v) from t where p > 0.3 and k < 500 group by w")
+    g = df[(df.p > 0.3) & (df.k < 500)].groupby("w").agg(c=("v", "size"), m=("v", "max"))
+    assert np.array_equal(cols[0], g.index.to_numpy()) and np.array_equal(cols[1], g.c.to_numpy()) and np.array_equal(cols[2], g.m.to_numpy())
