@@ -328,7 +328,9 @@ def main():
     if a.chunk_rows:
         knobs["chunk_rows"] = a.chunk_rows
     plan = FgbPlan(eng, N, G, **knobs)
-    job = hd.ShardedFgb(eng, plan, dev)
+    # N > 1: a second plan lets step i's all-reduce run on RCCL's stream beside the kernels of step i+1 (dist.ShardedFgb)
+    plan2 = FgbPlan(eng, N, G, **knobs) if world > 1 and os.environ.get("HARK_OVERLAP", "1") != "0" else None
+    job = hd.ShardedFgb(eng, plan, dev, plan2=plan2)
 
     def step():
         job.step(p.data_ptr(), ">", 0.5, k.data_ptr(), v.data_ptr(), N, sum_out.data_ptr(), cnt_out.data_ptr())
@@ -341,11 +343,15 @@ def main():
 
     for _ in range(a.warmup):
         step()
+    job.flush()
     plan.timing()                                             # drop warm-up events
+    if plan2 is not None:
+        plan2.timing()
     fence()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
+    job.flush()                                               # the last step's all-reduce + finish belong to the timed region
     fence()
     elapsed_local = time.perf_counter() - t0
     t = torch.tensor([elapsed_local], dtype=torch.float64, device=dev)
@@ -357,6 +363,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     ms_by_kind, launches = plan.timing()
+    if plan2 is not None:                                     # the steps alternated between the two plans
+        ms2, l2 = plan2.timing()
+        ms_by_kind = {kk: ms_by_kind[kk] + ms2[kk] for kk in ms_by_kind}
+        launches = {kk: launches[kk] + l2[kk] for kk in launches}
 
     # ---- what plain streams with the path's byte mix reach on THIS device, in this process (the practical ceilings):
     #      [1] read the three columns once; [2] read them and write 3 B/row (the producer's mix at 50 % selectivity,
@@ -425,7 +435,9 @@ def main():
             "ms_per_step_by_rank": [x / a.steps * 1e3 for x in per_rank],
             "config": {"workload": "BASELINE configs[2] + filter: SELECT k,SUM(v),COUNT(*) FROM t WHERE p>0.5 GROUP BY k",
                        "rows_per_gpu": N, "groups": G, "selectivity": 0.5, "columns": "p f32, k i32, v f32 (HBM-resident)",
-                       "exact_values": bool(a.exact), "merge": "RCCL all-reduce of f64 sums + i64 counts" if world > 1 else "none"},
+                       "exact_values": bool(a.exact),
+                       "merge": ("RCCL " + ("reduce-scatter + all-gather" if os.environ.get("HARK_ALLREDUCE") == "rs_ag" else "all-reduce")
+                                 + " of f64 sums + i64 counts" + (", overlapped with the next step's kernels" if plan2 is not None else "")) if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": path_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": path_achieved / HBM_PEAK_GBS,
                          "frac_is": "whole path per GPU: (12 B/row x rows + 16 B x groups) / wall time of a step / 8 TB/s",

@@ -141,6 +141,23 @@ class FutharkContext:
         return cur, {c: j for j, c in enumerate(proj)}
 
     def _select_extended(self, dev, ir):
+        res = self._select_result(dev, ir)
+        cols = res.columns(limit=ir.get("limit"))                      # only the first LIMIT rows cross PCIe
+        if "limit" in ir:
+            cols = [c[: ir["limit"]] for c in cols]
+        return cols
+
+    def select_result(self, sql_statement):
+        """A projection / WHERE / ORDER BY statement evaluated to a DEVICE-resident Result (select-list columns, LIMIT
+        not applied); the sharded context gathers such results between GPUs without a host trip."""
+        ir = sql_parse(self.tables, sql_statement)
+        if "groupbys" in ir or ir.get("join"):
+            raise Exception("select_result supports `select <columns> from t [where] [order by]`")
+        dev = self.tables[ir["table_name"]]._device
+        names = [self.tables[ir["table_name"]].get_schema()[c] for c in ir["select"]]
+        return names, self._select_result(dev, ir)
+
+    def _select_result(self, dev, ir):
         eng = self.FutEnv
         sel = ir["select"]
         need = set(sel)
@@ -165,10 +182,8 @@ class FutharkContext:
             res = eng.sort(cur, cmap[ob[0][1]], [cmap[c] for c in sel], descending=ob[1])
         else:
             res = eng.query_sel(cur, [cmap[c] for c in sel])
-        cols = res.columns(limit=ir.get("limit"))                      # only the first LIMIT rows cross PCIe
-        if "limit" in ir:
-            cols = [c[: ir["limit"]] for c in cols]
-        return cols
+        res._keep = (cur,)                                             # the compacted input must outlive a borrowed view
+        return res
 
     def _groupby_extended(self, dev, schema, ir):
         eng = self.FutEnv

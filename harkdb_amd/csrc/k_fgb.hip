@@ -438,7 +438,10 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
         if (r + kVec <= row1) {                                        // streamed once: non-temporal loads
             typedef float f4v __attribute__((ext_vector_type(4)));
             typedef int i4v __attribute__((ext_vector_type(4)));
-            if (OP == kMaskPred) pr = mask_nibble(p, r);               // r is a multiple of 4: one byte holds the lane's four bits
+            if (OP == kMaskPred) {                                     // r is a multiple of 4: one byte holds the lane's four bits,
+                const uint32_t byte = reinterpret_cast<const uint8_t *>(p)[r >> 3];      // which travel as an integer in pr.x
+                pr = float4{__uint_as_float((byte >> (r & 4)) & 15u), 0, 0, 0};
+            }
             else if (OP != kNoPred) { const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(p + r)); pr = float4{t.x, t.y, t.z, t.w}; }
             else pr = float4{0, 0, 0, 0};
             const i4v tk = __builtin_nontemporal_load(reinterpret_cast<const i4v *>(k + r)); kr = int4{tk.x, tk.y, tk.z, tk.w};
@@ -449,6 +452,7 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
             for (int j = 0; j < kVec; j++) if (r + j < row1) {
                 pp[j] = OP == kNoPred ? 0.0f : OP == kMaskPred ? mask_bit(p, r + j) : p[r + j]; kk[j] = k[r + j]; vv[j] = K2 ? 0.0f : v[r + j];
             }
+            if (OP == kMaskPred) pp[0] = __uint_as_float((uint32_t)(pp[0] != 0.0f) | ((uint32_t)(pp[1] != 0.0f) << 1) | ((uint32_t)(pp[2] != 0.0f) << 2) | ((uint32_t)(pp[3] != 0.0f) << 3));
             pr = float4{pp[0], pp[1], pp[2], pp[3]}; kr = int4{kk[0], kk[1], kk[2], kk[3]}; vr = float4{vv[0], vv[1], vv[2], vv[3]};
         }
     };
@@ -459,7 +463,9 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
         const float vv[4] = {vr.x, vr.y, vr.z, vr.w};
         const int64_t bend = row0 + (batch + 1) * kBatchRows;          // workgroup-uniform
         uint32_t pending = 0;
-        if (bend <= row1) {
+        if (OP == kMaskPred) {                                           // the survivor bits themselves (rows past the end are 0 bits)
+            pending = __float_as_uint(pv[0]);
+        } else if (bend <= row1) {
 #pragma unroll
             for (int j = 0; j < kVec; j++) if (cmp_f32<OP>(pv[j], thr)) pending |= 1u << j;
         } else {

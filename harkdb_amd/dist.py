@@ -88,11 +88,30 @@ def tensor_from_ptr(ptr, n, dtype, device):
     return torch.as_tensor(_DevicePtr(ptr, n, typestr), device=device)
 
 
-def allreduce_partials(sum_t, cnt_t, group=None):
-    """Merge per-shard dense GROUP BY partials in place: SUM over ranks of the
-    f64 sums and of the i64 counts (the RCCL all-reduce of SURVEY.md 8(e))."""
+def _allreduce_sum(t, group, how, async_op):
+    """SUM over ranks of t, in place.  how = "allreduce": one ncclAllReduce (RCCL picks ring / tree by size);
+    "rs_ag": reduce-scatter of the G / world slices, then all-gather of the reduced slices -- the two halves of a ring
+    all-reduce issued separately, so that on xGMI (point-to-point, 7 links per GPU) both can be A/B-ed on hardware
+    (HARK_ALLREDUCE=rs_ag; needs len(t) divisible by the world size, else falls back)."""
+    import torch
     import torch.distributed as dist
+    world = dist.get_world_size(group)
+    if how == "rs_ag" and world > 1 and t.numel() % world == 0:
+        part = torch.empty(t.numel() // world, dtype=t.dtype, device=t.device)
+        dist.reduce_scatter_tensor(part, t, op=dist.ReduceOp.SUM, group=group)
+        return dist.all_gather_into_tensor(t, part, group=group, async_op=async_op)
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+
+
+def allreduce_partials(sum_t, cnt_t, group=None, wait=True):
+    """Merge per-shard dense GROUP BY partials in place: SUM over ranks of the
+    f64 sums and of the i64 counts (the RCCL all-reduce of SURVEY.md 8(e)).  wait=False returns the pending
+    work handles (call .wait() on each before reading the tensors): the collectives then run on RCCL's own
+    stream beside whatever the caller enqueues next (ShardedFgb pipelines the next step's kernels under them)."""
+    import torch.distributed as dist
+    works = []
     if dist.is_initialized():          # also with one rank: keeps the single-GPU run on the same code path
+        how = os.environ.get("HARK_ALLREDUCE", "allreduce")
         if sum_t.is_cuda and dist.get_backend() == "gloo":               # tests: ranks sharing one GPU
             for t in (sum_t, cnt_t):
                 x, back = _host_staged(t)
@@ -100,10 +119,12 @@ def allreduce_partials(sum_t, cnt_t, group=None):
                 back()
         else:
             # both collectives are issued before either is awaited: the second one's launch overlaps the first
-            works = [dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True) for t in (sum_t, cnt_t)]
-            for w in works:
-                w.wait()
-    return sum_t, cnt_t
+            works = [_allreduce_sum(t, group, how, True) for t in (sum_t, cnt_t)]
+            if wait:
+                for w in works:
+                    w.wait()
+                works = []
+    return (sum_t, cnt_t) if wait else works
 
 
 def allreduce_minmax(min_t, max_t, group=None):
@@ -143,34 +164,127 @@ def global_row_index(local_index, rank, n, world):
 class ShardedFgb:
     """SELECT k, SUM(v), COUNT(*) WHERE p <cmp> thr GROUP BY k over a row-range
     shard per rank: local fused kernel -> all-reduce of the accumulators ->
-    finish.  `eng`/`plan` are this rank's Engine and FgbPlan."""
+    finish.  `eng`/`plan` are this rank's Engine and FgbPlan.
 
-    def __init__(self, eng, plan, device):
+    With more than one rank and a second plan (`plan2`) steps are PIPELINED: the all-reduce of step i runs on RCCL's
+    stream while the kernels of step i+1 (which accumulate into the other plan) run on ours; step i is finished --
+    results written to its outputs -- when step i+1 is issued, or by flush().  HARK_OVERLAP=0 switches it off."""
+
+    def __init__(self, eng, plan, device, plan2=None, acc_tensors=None):
         self.eng, self.plan, self.device = eng, plan, device
-        s_ptr, c_ptr = plan.acc_ptrs()
-        self.sum_t = tensor_from_ptr(s_ptr, plan.G, np.float64, device)
-        self.cnt_t = tensor_from_ptr(c_ptr, plan.G, np.int64, device)
+        self.plans = [plan] + ([plan2] if plan2 is not None and os.environ.get("HARK_OVERLAP", "1") != "0" else [])
+        self.acc = []
+        for j, pl in enumerate(self.plans):
+            if acc_tensors is not None:                                   # tests: accumulators that are not HBM addresses
+                self.acc.append(acc_tensors[j])
+                continue
+            s_ptr, c_ptr = pl.acc_ptrs()
+            self.acc.append((tensor_from_ptr(s_ptr, pl.G, np.float64, device), tensor_from_ptr(c_ptr, pl.G, np.int64, device)))
+        self.sum_t, self.cnt_t = self.acc[0]
+        self.pending = None
+        self.turn = 0
+
+    @property
+    def pipelined(self):
+        return len(self.plans) > 1
 
     def step(self, p, cmp, thr, k, v, n, sum_out=None, count_out=None):
-        self.plan.reset()
-        self.plan.run(p, cmp, thr, k, v, n)
-        allreduce_partials(self.sum_t, self.cnt_t)
-        self.plan.finish(sum_out, count_out)
+        if not self.pipelined:
+            self.plan.reset()
+            self.plan.run(p, cmp, thr, k, v, n)
+            allreduce_partials(self.sum_t, self.cnt_t)
+            self.plan.finish(sum_out, count_out)
+            return
+        i = self.turn
+        self.turn = 1 - i
+        plan, (sum_t, cnt_t) = self.plans[i], self.acc[i]
+        plan.reset()
+        plan.run(p, cmp, thr, k, v, n)
+        works = allreduce_partials(sum_t, cnt_t, wait=False)         # runs beside the NEXT step's kernels
+        prev, self.pending = self.pending, (plan, works, sum_out, count_out)
+        self._finish(prev)
+
+    def _finish(self, item):
+        if item is None:
+            return
+        plan, works, sum_out, count_out = item
+        for w in works:
+            w.wait()                                                  # our stream waits for the collective, the host does not
+        plan.finish(sum_out, count_out)
+
+    def flush(self):
+        """Finish the step still in flight (its all-reduce has been running beside nothing since the last step())."""
+        item, self.pending = self.pending, None
+        self._finish(item)
 
 
 # ---------------------------------------------------------------------------
 # Sharded SQL surface: FutharkContext over row-range shards
 # ---------------------------------------------------------------------------
-def gather_columns(cols, group=None):
-    """Concatenate per-rank result columns in rank order on every rank
-    (variable-length: object all_gather; results of a filter are small next to
-    the table, and the row order is the unsharded table's order)."""
+def gather_columns(cols, group=None, device=None):
+    """Concatenate per-rank result columns in rank order on every rank (row order = the unsharded table's order).
+
+    One all-gather of the row counts, then ONE `all_gather_into_tensor` of a byte buffer that holds every column padded
+    to the longest shard -- device tensors travel over RCCL as they are (no pickling, no host copy before the
+    collective); `cols` may be numpy arrays (uploaded to `device` first when it is a GPU) or 1-D torch tensors.
+    HARK_GATHER=object selects the old `all_gather_object` path (A/B on hardware).  Returns numpy arrays."""
+    import torch
     import torch.distributed as dist
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return cols
-    parts = [None] * dist.get_world_size(group)
-    dist.all_gather_object(parts, cols, group=group)
-    return [np.concatenate([p[j] for p in parts]) for j in range(len(cols))]
+        return [c.cpu().numpy() if isinstance(c, torch.Tensor) else c for c in cols]
+    world = dist.get_world_size(group)
+    if os.environ.get("HARK_GATHER", "tensor") == "object":
+        host = [c.cpu().numpy() if isinstance(c, torch.Tensor) else c for c in cols]
+        parts = [None] * world
+        dist.all_gather_object(parts, host, group=group)
+        return [np.concatenate([p[j] for p in parts]) for j in range(len(host))]
+    staged = dist.get_backend() == "gloo"                                 # CPU tests, or ranks sharing one GPU
+    if not staged and device is None:
+        device = torch.device("cuda", torch.cuda.current_device())        # RCCL moves device memory only
+    dev = torch.device("cpu") if staged else torch.device(device)
+    np_dtypes, tens = [], []
+    for c in cols:
+        if isinstance(c, torch.Tensor):
+            np_dtypes.append(np.dtype(str(c.dtype).replace("torch.", "")))
+            tens.append(c.to(dev).contiguous())
+        else:
+            a = np.ascontiguousarray(c)
+            np_dtypes.append(a.dtype)
+            tens.append(torch.from_numpy(a.view(np.int32) if a.dtype == np.uint32 else a).to(dev))
+    n_local = int(tens[0].numel()) if tens else 0
+    mine = torch.tensor([n_local], dtype=torch.int64, device=dev)
+    allc = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(allc, mine, group=group)
+    counts = [int(x) for x in allc.tolist()]
+    maxn = max(counts)
+    if maxn == 0 or not tens:
+        return [np.empty(0, dtype=dt) for dt in np_dtypes]
+    widths = [t.element_size() for t in tens]
+    row_bytes = sum(widths)
+    send = torch.zeros(maxn * row_bytes, dtype=torch.uint8, device=dev)   # column-major: column j occupies maxn * width_j bytes
+    off = 0
+    for t, w in zip(tens, widths):
+        if n_local:
+            send[off: off + n_local * w] = t.reshape(-1).view(torch.uint8)
+        off += maxn * w
+    recv = torch.empty(world * maxn * row_bytes, dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    host = recv.cpu().numpy()
+    out, off = [], 0
+    for dt, w in zip(np_dtypes, widths):
+        pieces = [host[r * maxn * row_bytes + off: r * maxn * row_bytes + off + counts[r] * w] for r in range(world)]
+        out.append(np.concatenate(pieces).view(dt))
+        off += maxn * w
+    return out
+
+
+def result_tensors(res, device, limit=None):
+    """The columns of a device-resident Result as zero-copy torch tensors (the first `limit` rows)."""
+    n, m = res.shape
+    if limit is not None:
+        n = min(n, max(int(limit), 0))
+    return [tensor_from_ptr(res.device_ptr(j), n, res.dtype(j), device) if n else __import__("torch").empty(0, dtype=getattr(__import__("torch"), _TORCH_OF[np.dtype(res.dtype(j)).name]), device=device)
+            for j in range(m)], [np.dtype(res.dtype(j)) for j in range(m)]
 
 
 _MERGE = {"sum": np.add, "count": np.add, "min": np.minimum, "max": np.maximum, "prod": np.multiply}
@@ -332,8 +446,9 @@ class ShardedFutharkContext:
                 return self._orderby(ir)
             limit = ir.pop("limit", None)
             stmt = sql_statement if limit is None else sql_statement[: sql_statement.lower().rindex("limit")]
-            names, cols = self.local.sql_columns(stmt)
-            cols = gather_columns(cols)
+            names, res = self.local.select_result(stmt)                 # device-resident: gathered over RCCL as it is
+            tens, _ = result_tensors(res, self.device, limit)           # no rank contributes more than LIMIT rows
+            cols = gather_columns(tens, device=self.device)
             return names, ([c[:limit] for c in cols] if limit is not None else cols)
         return self._groupby(ir)
 
@@ -457,10 +572,8 @@ class ShardedFutharkContext:
         recv, nrecv = repartition_device(eng, ptrs, dts, n, 0, self.device, self.world, splitters=splitters, descending=desc)
         t = eng.table_from_device(nrecv, [c.data_ptr() for c in recv], dts, keepalive=(recv, cur))
         res = eng.sort(t, 0, [need.index(c) for c in ir["select"]], descending=desc)
-        cols = res.columns(limit=ir.get("limit"))
-        if "limit" in ir:
-            cols = [c[: ir["limit"]] for c in cols]
-        cols = gather_columns(cols)
+        tens, _ = result_tensors(res, self.device, ir.get("limit"))
+        cols = gather_columns(tens, device=self.device)
         if "limit" in ir:
             cols = [c[: ir["limit"]] for c in cols]
         return [schema[c] for c in ir["select"]], cols
@@ -480,7 +593,7 @@ class ShardedFutharkContext:
         recv, nrecv = repartition_device(eng, [res.device_ptr(j) for j in range(m)], dts, n, 0, self.device, self.world)
         t = eng.table_from_device(nrecv, [c.data_ptr() for c in recv], dts, keepalive=recv)
         res2 = eng.filter_groupby(t, None, 0, [(_SECOND_LEVEL[f], 1 + j) for j, (f, _) in enumerate(specs)])
-        return gather_columns(res2.columns())
+        return gather_columns(result_tensors(res2, self.device)[0], device=self.device)
 
     def _join(self, ir):
         """Both sides are hash-partitioned by the join key and exchanged; every rank
@@ -500,7 +613,7 @@ class ShardedFutharkContext:
             sides.append((t, {c: i for i, c in enumerate(need)}))
         (t1, m1), (t2, m2) = sides
         res = eng.join(t1, t2, 0, 0, [m1[c] for c in ir["cols1"]], [m2[c] for c in ir["cols2"]])
-        cols = gather_columns(res.columns())
+        cols = gather_columns(result_tensors(res, self.device)[0], device=self.device)
         left_pos = {c: i for i, c in reversed(list(enumerate(ir["cols1"])))}
         right_pos = {c: len(ir["cols1"]) + i for i, c in reversed(list(enumerate(ir["cols2"])))}
         out = [cols[left_pos[c] if s == 0 else right_pos[c]] for s, c in ir["order"]]

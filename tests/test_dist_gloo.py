@@ -210,3 +210,106 @@ def test_choose_splitters_properties():
     assert len(hd.choose_splitters(a, 1)) == 0 and len(hd.choose_splitters(a[:0], 4)) == 0
     assert hd.sample_positions(10, 64).tolist() == list(range(10)) and len(hd.sample_positions(10**6, 64)) == 64
     assert hd.sample_positions(0).size == 0
+
+
+# ---- round 2: tensor gather (no pickling), reduce-scatter + all-gather knob, pipelined steps -------------------------
+def _gather_worker(rank, world, port, mode, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HARK_GATHER=mode)
+    from harkdb_amd import dist as hd
+    hd.init_process_group("cpu")
+    rng = np.random.default_rng(5 + rank)
+    out = []
+    for n in ((0, 7)[rank], 1000 + 333 * rank, 0):                        # an empty shard, ragged shards, all empty
+        cols = [rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32), rng.integers(-2**62, 2**62, n).astype(np.int64),
+                rng.random(n).astype(np.float32), torch.from_numpy(rng.integers(-9, 9, n).astype(np.int32))]
+        got = hd.gather_columns(cols)
+        out.append(([c.numpy() if isinstance(c, torch.Tensor) else c for c in cols], got))
+    q.put((rank, out))
+    import torch.distributed as dist
+    dist.barrier(); dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["tensor", "object"])
+def test_gather_columns_ragged_mixed_dtypes(mode):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, mode, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    outs = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    for case in range(3):
+        for j in range(4):
+            exp = np.concatenate([outs[r][1][case][0][j] for r in range(world)])
+            for r in range(world):
+                got = outs[r][1][case][1][j]
+                assert got.dtype == exp.dtype and np.array_equal(got, exp)          # rank-order concatenation, bit-exact, dtype kept
+
+
+class _FakePlan:
+    """Stands in for FgbPlan on CPU: 'run' accumulates numpy partials into torch accumulators."""
+
+    def __init__(self, G):
+        self.G, self.sum_t, self.cnt_t = G, torch.zeros(G, dtype=torch.float64), torch.zeros(G, dtype=torch.int64)
+        self.finished = []
+
+    def reset(self):
+        self.sum_t.zero_(); self.cnt_t.zero_()
+
+    def run(self, p, cmp, thr, k, v, n):
+        keep = p > thr
+        self.sum_t += torch.from_numpy(np.bincount(k[keep], weights=v[keep], minlength=self.G))
+        self.cnt_t += torch.from_numpy(np.bincount(k[keep], minlength=self.G))
+
+    def finish(self, sum_out, count_out):
+        sum_out[:] = self.sum_t.numpy(); count_out[:] = self.cnt_t.numpy()
+
+
+def _pipeline_worker(rank, world, port, how, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HARK_ALLREDUCE=how)
+    from harkdb_amd import dist as hd
+    hd.init_process_group("cpu")
+    G, steps = 64, 5
+    plans = [_FakePlan(G), _FakePlan(G)]
+    job = hd.ShardedFgb(None, plans[0], "cpu", plan2=plans[1], acc_tensors=[(pl.sum_t, pl.cnt_t) for pl in plans])
+    assert job.pipelined
+    outs = [(np.zeros(G), np.zeros(G, dtype=np.int64)) for _ in range(steps)]
+    for i in range(steps):
+        rng = np.random.default_rng(1000 * i + rank)
+        n = 500
+        job.step(rng.random(n), ">", 0.5, rng.integers(0, G, n), rng.integers(0, 16, n).astype(np.float64), n, outs[i][0], outs[i][1])
+    job.flush()
+    q.put((rank, outs))
+    import torch.distributed as dist
+    dist.barrier(); dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("how", ["allreduce", "rs_ag"])
+def test_pipelined_steps_and_allreduce_variants(how):
+    """ShardedFgb with two plans: step i's all-reduce is awaited when step i+1 is issued (or by flush); every step's
+    outputs equal the sum over ranks of that step's partials, for the plain all-reduce and for reduce-scatter + all-gather."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, world, port, how, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    outs = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    G = 64
+    for i in range(5):
+        es, ec = np.zeros(G), np.zeros(G, dtype=np.int64)
+        for rank in range(world):
+            rng = np.random.default_rng(1000 * i + rank)
+            p, k, v = rng.random(500), rng.integers(0, G, 500), rng.integers(0, 16, 500).astype(np.float64)
+            keep = p > 0.5
+            es += np.bincount(k[keep], weights=v[keep], minlength=G); ec += np.bincount(k[keep], minlength=G)
+        for rank in range(world):
+            assert np.array_equal(outs[rank][1][i][0], es) and np.array_equal(outs[rank][1][i][1], ec)
