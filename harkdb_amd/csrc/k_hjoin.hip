@@ -40,9 +40,10 @@ template <typename K> struct JTraits;
 // P buckets, rings of Q entries, VEC rows per lane and batch; the bucket kernel stages CHUNK sorted build keys per
 // round plus a bitmap of 2^BM_BITS bits over them (measured: a 16-step binary search in LDS for EVERY probe pair
 // cost 1.36 ms per 1e8 pairs -- instruction issue, not the loads; most pairs have no partner and now leave after
-// one bit test).  u32: 96 KiB of keys + 32 KiB of bitmap, one round up to 1.26e7 build rows; u64: 128 + 16 KiB.
+// one bit test).  u32: 96 KiB of keys + 32 KiB of bitmap (+ 24 KiB of candidate queues), one round up to 1.26e7 build
+// rows; u64: 96 + 16 (+ 36) KiB.
 template <> struct JTraits<uint32_t> { typedef JPair32 E; static constexpr int P = 512, Q = 32, VEC = 4, CHUNK = 24576, BM_BITS = 18; };
-template <> struct JTraits<uint64_t> { typedef JPair64 E; static constexpr int P = 256, Q = 32, VEC = 2, CHUNK = 16384, BM_BITS = 17; };
+template <> struct JTraits<uint64_t> { typedef JPair64 E; static constexpr int P = 256, Q = 32, VEC = 2, CHUNK = 12288, BM_BITS = 17; };
 
 __device__ __forceinline__ uint32_t jhash(uint32_t k) { return k * 0x9E3779B1u; }
 __device__ __forceinline__ uint32_t jhash(uint64_t k) { return (uint32_t)((k * 0x9E3779B97F4A7C15ull) >> 32); }
@@ -92,6 +93,32 @@ __global__ __launch_bounds__(256) void jrunlen_kernel(const K *__restrict__ rkey
             len = (uint32_t)(ub - i);
         }
         runlen[i] = len;
+    }
+}
+
+// After a sort by rank alone, rows of one rank (probe rows matching the same build key) stand in arbitrary order:
+// the thread at the head of each run sorts the run's left row ids (runs are short: the fan-out of a key); a run
+// longer than kTieMax raises *too_long and the caller sorts by (left row, rank) with full radix passes instead.
+constexpr int kTieMax = 48;
+__global__ __launch_bounds__(256) void jtiefix_kernel(const uint32_t *__restrict__ rank, uint32_t *__restrict__ lrow, int64_t m, int32_t *__restrict__ too_long)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
+        const uint32_t r = rank[i];
+        if (i > 0 && rank[i - 1] == r) continue;                      // not a run head
+        if (i + 1 >= m || rank[i + 1] != r) continue;                 // a run of one
+        int len = 2;
+        while (len <= kTieMax && i + len < m && rank[i + len] == r) len++;
+        if (len > kTieMax) { *too_long = 1; continue; }
+        uint32_t v[kTieMax];
+        for (int j = 0; j < len; j++) v[j] = lrow[i + j];
+        for (int a = 1; a < len; a++) {                               // insertion sort (left row ids are distinct)
+            const uint32_t x = v[a];
+            int q = a - 1;
+            while (q >= 0 && v[q] > x) { v[q + 1] = v[q]; q--; }
+            v[q + 1] = x;
+        }
+        for (int j = 0; j < len; j++) lrow[i + j] = v[j];
     }
 }
 
@@ -220,39 +247,30 @@ __global__ __launch_bounds__(kJThreads) void jpart_kernel(const K *__restrict__ 
     if (overflow) *err = kJErrOverflow;
 }
 
-// total[b] = probe pairs of bucket b; soff = exclusive scan (capacity offsets of the survivor slabs); one workgroup.
-__global__ __launch_bounds__(1024) void jtotals_kernel(const uint32_t *__restrict__ counts, int P, int nwg, int64_t *__restrict__ soff)
-{
-    __shared__ unsigned long long s_tot[1024];
-    const int b = threadIdx.x;
-    unsigned long long t = 0;
-    if (b < P) for (int w = 0; w < nwg; w++) t += counts[(size_t)b * nwg + w];
-    s_tot[b] = t;
-    __syncthreads();
-    if (b == 0) {
-        unsigned long long run = 0;
-        for (int q = 0; q < P; q++) { soff[q] = (int64_t)run; run += s_tot[q]; }
-        soff[P] = (int64_t)run;
-    }
-}
-
 // ---- one workgroup per bucket: build slice in LDS, probe pairs streamed past it --------------------------------
+// Most probe pairs have no partner and leave after a range test and ONE bit test; the few candidates of a wave's
+// 128-pair step would keep a 15-step search busy with a handful of lanes, so they are queued (per wave, in LDS) and
+// searched 64 at a time with every lane busy.
 template <typename K>
 __global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTraits<K>::E *__restrict__ slabs, const uint32_t *__restrict__ counts,
                                                             uint32_t cap, int nwg, const K *__restrict__ rkeys, const uint32_t *__restrict__ bstart,
-                                                            int chunk_cap, const int64_t *__restrict__ soff, uint2 *__restrict__ surv,
-                                                            uint32_t *__restrict__ scount)
+                                                            int chunk_cap, uint2 *__restrict__ surv, uint32_t *__restrict__ scount)
 {
     typedef typename JTraits<K>::E E;
-    constexpr int BM_BITS = JTraits<K>::BM_BITS, BM_WORDS = 1 << (BM_BITS - 5);
+    constexpr int BM_BITS = JTraits<K>::BM_BITS, BM_WORDS = 1 << (BM_BITS - 5), QCAP = 192;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     uint32_t *bitmap = reinterpret_cast<uint32_t *>(lds_raw);                 // [BM_WORDS] one bit per hashed chunk key
-    K *chunk = reinterpret_cast<K *>(bitmap + BM_WORDS);                       // [chunk_cap] sorted build keys of this round
+    K *chunk = reinterpret_cast<K *>(bitmap + BM_WORDS);                       // [CHUNK] sorted build keys of this round
+    K *qkey_all = chunk + JTraits<K>::CHUNK;                                   // [16 waves][QCAP] candidate keys
+    uint32_t *qrow_all = reinterpret_cast<uint32_t *>(qkey_all + (kJThreads / 64) * QCAP);   // [16 waves][QCAP] their row ids
     __shared__ uint32_t s_n;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = kJThreads >> 6;
+    K *qkey = qkey_all + wave * QCAP;
+    uint32_t *qrow = qrow_all + wave * QCAP;
     const uint32_t lo = bstart[b], hi = bstart[b + 1];
     if (tid == 0) s_n = 0u;
-    uint2 *out = surv + soff[b];
+    uint2 *out = surv + (size_t)b * nwg * cap;                             // room for every probe pair of the bucket
+    const unsigned long long below = (1ull << lane) - 1ull;
     for (uint32_t base = lo; base < hi; base += (uint32_t)chunk_cap) {
         const int m = (int)min((uint32_t)chunk_cap, hi - base);
         __syncthreads();                                             // the previous round's readers are done (and s_n is set)
@@ -268,30 +286,39 @@ __global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTrai
         int W = 1;
         while (W * 2 <= m) W <<= 1;
         const K pivot = chunk[W - 1];
-        // a probe pair against the staged slice: range test, bit test, then the search; a hit gives the global rank
-        auto probe = [&](K key, uint32_t &rank) -> bool {
+        auto candidate = [&](K key) -> bool {                          // range test, then one bit
             if (!(key >= first && key <= last) || (has_prev && key == prev_last)) return false;
             const uint32_t h = jhash(key) >> (32 - BM_BITS);
-            if (!((bitmap[h >> 5] >> (h & 31u)) & 1u)) return false;
+            return (bitmap[h >> 5] >> (h & 31u)) & 1u;
+        };
+        int qn = 0;                                                    // wave-uniform: candidates queued
+        auto enqueue = [&](bool c, K key, uint32_t row) {
+            const unsigned long long mask = __ballot(c);
+            if (c) { const int at = qn + __popcll(mask & below); qkey[at] = key; qrow[at] = row; }
+            qn += __popcll(mask);
+        };
+        // search `cnt` queued candidates (the last ones), one per lane; a hit is appended to the bucket's survivors
+        auto drain = [&](int cnt) {
+            qn -= cnt;
+            const bool act = lane < cnt;
+            const K key = act ? qkey[qn + lane] : (K)0;
+            const uint32_t row = act ? qrow[qn + lane] : 0u;
             const int off = pivot < key ? m - W : 0;
             int pos = 0;
             for (int step = W >> 1; step > 0; step >>= 1) pos += chunk[off + pos + step - 1] < key ? step : 0;
             pos += off;
             pos += (pos < m && chunk[pos] < key) ? 1 : 0;            // the window's last key was never compared
-            if (pos < m && chunk[pos] == key) { rank = base + (uint32_t)pos; return true; }
-            return false;
-        };
-        auto append = [&](bool match, uint32_t rank, uint32_t row) {
+            const bool match = act && pos < m && chunk[pos] == key;
             const unsigned long long mask = __ballot(match);
             if (mask) {
                 uint32_t at = 0;
                 if (lane == 0) at = atomicAdd(&s_n, (uint32_t)__popcll(mask));
                 at = __shfl(at, 0, 64);
-                if (match) out[at + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = uint2{rank, row};
+                if (match) out[at + (uint32_t)__popcll(mask & below)] = uint2{base + (uint32_t)pos, row};
             }
         };
         // a wave walks whole slabs, 128 entries per step: two entries per lane (one 16-byte load for 8-byte pairs, two
-        // for 16-byte entries), the next step's loads in flight while this one's pairs are searched
+        // for 16-byte entries), the next step's loads in flight while this one's pairs are tested
         typedef unsigned int u4v __attribute__((ext_vector_type(4)));
         constexpr bool WIDE = sizeof(E) == 16;
         for (int w = wave; w < nwg; w += nwaves) {
@@ -324,21 +351,33 @@ __global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTrai
                     v0 = e0 < count; v1 = e0 + 1u < count;
                     key0 = (K)c0.x; row0 = c0.y; key1 = (K)c0.z; row1 = c0.w;
                 }
-                uint32_t r0 = 0, r1 = 0;
-                const bool m0 = v0 && probe(key0, r0), m1 = v1 && probe(key1, r1);
-                append(m0, r0, row0);
-                append(m1, r1, row1);
+                enqueue(v0 && candidate(key0), key0, row0);              // qn < 64 before: at most 64 + 128 = QCAP queued
+                enqueue(v1 && candidate(key1), key1, row1);
+                while (qn >= 64) drain(64);
             }
         }
+        if (qn > 0) drain(qn);                                         // the round's leftovers (fewer than 64)
     }
     __syncthreads();
     if (tid == 0) scount[b] = s_n;
 }
 
+__global__ __launch_bounds__(1024) void jsum_kernel(const uint32_t *__restrict__ scount, int P, unsigned long long *__restrict__ total)
+{
+    __shared__ unsigned long long s_t;
+    if (threadIdx.x == 0) s_t = 0ull;
+    __syncthreads();
+    unsigned long long x = (int)threadIdx.x < P ? scount[threadIdx.x] : 0u;
+    for (int d = 32; d > 0; d >>= 1) x += __shfl_down(x, d, 64);
+    if ((threadIdx.x & 63) == 0 && x) atomicAdd(&s_t, x);
+    __syncthreads();
+    if (threadIdx.x == 0) *total = s_t;
+}
+
 // survivor slabs -> two contiguous arrays (rank, left row); dst offsets = exclusive scan of scount, done by every
 // workgroup for itself (P <= 1024 values)
-__global__ __launch_bounds__(256) void jcompact_kernel(const uint2 *__restrict__ surv, const int64_t *__restrict__ soff, const uint32_t *__restrict__ scount,
-                                                       int P, uint32_t *__restrict__ rank, uint32_t *__restrict__ lrow, unsigned long long *__restrict__ total)
+__global__ __launch_bounds__(256) void jcompact_kernel(const uint2 *__restrict__ surv, size_t stride, const uint32_t *__restrict__ scount,
+                                                       int P, uint32_t *__restrict__ rank, uint32_t *__restrict__ lrow)
 {
     __shared__ unsigned long long s_dst;
     const int b = blockIdx.x;
@@ -349,9 +388,8 @@ __global__ __launch_bounds__(256) void jcompact_kernel(const uint2 *__restrict__
     for (int d = 32; d > 0; d >>= 1) part += __shfl_down(part, d, 64);
     if ((threadIdx.x & 63) == 0 && part) atomicAdd(&s_dst, part);
     __syncthreads();
-    if (threadIdx.x == 0 && b == P - 1) *total = s_dst + scount[b];
     const unsigned long long dst = s_dst;
-    const uint2 *src = surv + soff[b];
+    const uint2 *src = surv + (size_t)b * stride;
     const uint32_t cnt = scount[b];
     for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) { const uint2 e = src[i]; rank[dst + i] = e.x; lrow[dst + i] = e.y; }
 }
@@ -371,18 +409,19 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
     if (cap64 > 0x7FFFFFF0ll) return HARK_OK;
     const uint32_t cap = (uint32_t)cap64;
     K *splitters = nullptr; uint32_t *bstart = nullptr, *counts = nullptr, *scount = nullptr; int32_t *err = nullptr;
-    E *slabs = nullptr; int64_t *soff = nullptr; uint2 *surv = nullptr; unsigned long long *total = nullptr;
+    E *slabs = nullptr; uint2 *surv = nullptr; unsigned long long *total = nullptr;
     uint32_t *rank = nullptr, *lrow = nullptr;
+    const size_t sstride = (size_t)nwg * cap;                                    // survivor slab of a bucket: room for all of its probe pairs
     int rc = hark_alloc(ctx, (void **)&splitters, sizeof(K) * P);
     if (!rc) rc = hark_alloc(ctx, (void **)&bstart, 4 * (size_t)(P + 1));
     if (!rc) rc = hark_alloc(ctx, (void **)&counts, 4 * (size_t)P * nwg);
     if (!rc) rc = hark_alloc(ctx, (void **)&scount, 4 * (size_t)P);
-    if (!rc) rc = hark_alloc(ctx, (void **)&soff, 8 * (size_t)(P + 1));
     if (!rc) rc = hark_alloc(ctx, (void **)&err, 16);
     if (!rc) rc = hark_alloc(ctx, (void **)&total, 16);
-    if (!rc) rc = hark_alloc(ctx, (void **)&slabs, sizeof(E) * (size_t)P * nwg * cap);
+    if (!rc) rc = hark_alloc(ctx, (void **)&slabs, sizeof(E) * (size_t)P * sstride);
+    if (!rc) rc = hark_alloc(ctx, (void **)&surv, 8 * (size_t)P * sstride);
     auto cleanup = [&]() {
-        hark_free(ctx, splitters); hark_free(ctx, bstart); hark_free(ctx, counts); hark_free(ctx, scount); hark_free(ctx, soff);
+        hark_free(ctx, splitters); hark_free(ctx, bstart); hark_free(ctx, counts); hark_free(ctx, scount);
         hark_free(ctx, err); hark_free(ctx, total); hark_free(ctx, slabs); hark_free(ctx, surv);
     };
     if (rc) { cleanup(); return rc; }
@@ -394,40 +433,32 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
     const int per_batch = kJThreads * VEC / P;
     int period = (Q - LINE) / (per_batch + per_batch / 2);
     if (period < 1) period = 1;
+    int chunk_cap = JTraits<K>::CHUNK;
+    if (const char *e = getenv("HARK_JOIN_CHUNK")) { const int c = atoi(e); if (c >= 1 && c < chunk_cap) chunk_cap = c; }   // tests: force several rounds per bucket
+    constexpr size_t lds_bucket = sizeof(K) * (size_t)JTraits<K>::CHUNK + ((size_t)1 << (JTraits<K>::BM_BITS - 3)) + (size_t)(kJThreads / 64) * 192 * (sizeof(K) + 4);
+    static_assert(lds_bucket <= kJLdsBudget, "bucket kernel LDS");
+    if (he == hipSuccess) he = hipFuncSetAttribute(reinterpret_cast<const void *>(&jbucket_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bucket);
     if (he == hipSuccess) {
+        // one stream-ordered chain, one host read at the end: partition -> bucket probe -> survivor total
         jpart_kernel<K><<<dim3((unsigned)nwg), dim3(kJThreads), lds_part, st>>>(lcol, n, bias, splitters, rkeys, s, slabs, counts, cap, period, err);
-        jtotals_kernel<<<1, 1024, 0, st>>>(counts, P, nwg, soff);
+        jbucket_kernel<K><<<dim3((unsigned)P), dim3(kJThreads), lds_bucket, st>>>(slabs, counts, cap, nwg, rkeys, bstart, chunk_cap, surv, scount);
+        jsum_kernel<<<1, 1024, 0, st>>>(scount, P, total);
         he = hipGetLastError();
     }
-    int64_t words[2] = {0, 0};
     if (he != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: partition launch failed: %s", hipGetErrorString(he));
-    int64_t n_in = 0;
-    if (!rc) rc = hark_read_words(ctx, soff + P, &n_in, 1);
+    int64_t words[2] = {0, 0}, M = 0;
+    if (!rc) rc = hark_read_words(ctx, total, &M, 1);
     if (!rc) rc = hark_read_words(ctx, err, words, 1);
     if (!rc && (int32_t)(words[0] & 0xFFFFFFFFll) != 0) { cleanup(); return HARK_OK; }          // a slab overflowed (skew): caller falls back
-    if (!rc && n_in > 0) rc = hark_alloc(ctx, (void **)&surv, 8 * (size_t)n_in);
-    int64_t M = 0;
-    if (!rc && n_in > 0) {
-        int chunk_cap = JTraits<K>::CHUNK;
-        if (const char *e = getenv("HARK_JOIN_CHUNK")) { const int c = atoi(e); if (c >= 1 && c < chunk_cap) chunk_cap = c; }   // tests: force several rounds per bucket
-        constexpr size_t lds_bucket = sizeof(K) * (size_t)JTraits<K>::CHUNK + ((size_t)1 << (JTraits<K>::BM_BITS - 3));
-        static_assert(lds_bucket <= kJLdsBudget, "bucket kernel LDS");
-        he = hipFuncSetAttribute(reinterpret_cast<const void *>(&jbucket_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bucket);
-        if (he == hipSuccess) {
-            jbucket_kernel<K><<<dim3((unsigned)P), dim3(kJThreads), lds_bucket, st>>>(slabs, counts, cap, nwg, rkeys, bstart, chunk_cap, soff, surv, scount);
-            he = hipGetLastError();
-        }
-        if (he != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: bucket launch failed: %s", hipGetErrorString(he));
-        // an upper bound of the survivors is n_in; their number is only known after the kernel: size the arrays by n_in
-        if (!rc) rc = hark_alloc(ctx, (void **)&rank, 4 * (size_t)n_in);
-        if (!rc) rc = hark_alloc(ctx, (void **)&lrow, 4 * (size_t)n_in);
+    if (!rc && M > 0) {
+        rc = hark_alloc(ctx, (void **)&rank, 4 * (size_t)M);
+        if (!rc) rc = hark_alloc(ctx, (void **)&lrow, 4 * (size_t)M);
         if (!rc) {
-            jcompact_kernel<<<dim3((unsigned)P), 256, 0, st>>>(surv, soff, scount, P, rank, lrow, total);
+            jcompact_kernel<<<dim3((unsigned)P), 256, 0, st>>>(surv, sstride, scount, P, rank, lrow);
             if (hipGetLastError() != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: compact launch failed");
         }
-        if (!rc) rc = hark_read_words(ctx, total, &M, 1);
     }
-    cleanup();
+    cleanup();                                                              // stream-ordered reuse: the compaction above is enqueued first
     if (rc) { hark_free(ctx, rank); hark_free(ctx, lrow); return rc; }
     *rank_out = rank; *lrow_out = lrow; *m_out = M; *used = true;
     return HARK_OK;
@@ -451,12 +482,33 @@ int k_join_partitioned(hark_context *ctx, const void *lcol, bool k64, int64_t n,
                  : run_partitioned<uint32_t>(ctx, static_cast<const uint32_t *>(lcol), 0u, n, static_cast<const uint32_t *>(rkeys), s, &rank, &lrow, &M, used);
     if (rc || !*used) return rc;
     if (M == 0) { hark_free(ctx, rank); hark_free(ctx, lrow); return HARK_OK; }
-    // (rank, left row) order: stable sort by left row, then stable sort by rank (each skips the passes no byte needs)
+    // (rank, left row) order.  Fast path: ONE sort by rank (3 passes for < 2^24 build rows), then the short runs of equal
+    // rank are put in left-row order in place; a run longer than kTieMax takes the general path: stable sort by left
+    // row, then stable sort by rank (each skips the passes no byte needs).
     uint32_t *rank1 = nullptr, *lrow1 = nullptr, *lrow2 = nullptr, *rank2 = nullptr, *runlen = nullptr, *cnt = nullptr;
-    rc = k_sort_column(ctx, lrow, HARK_U32, M, false, rank, &rank1, &lrow1);
+    int32_t *flag = nullptr;
+    int64_t long_run = 0;
+    rc = hark_alloc(ctx, (void **)&flag, 16);
+    if (!rc && !getenv("HARK_JOIN_FULLSORT")) {
+        hipMemsetAsync(flag, 0, 16, ctx->stream);
+        rc = k_sort_column(ctx, rank, HARK_U32, M, false, lrow, &lrow2, &rank2);
+        if (!rc) {
+            int64_t g = (M + 255) / 256;
+            if (g > (int64_t)ctx->num_cu * 16) g = (int64_t)ctx->num_cu * 16;
+            jtiefix_kernel<<<dim3((unsigned)g), 256, 0, ctx->stream>>>(rank2, lrow2, M, flag);
+            if (hipGetLastError() != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: tie-fix launch failed");
+        }
+        if (!rc) rc = hark_read_words(ctx, flag, &long_run, 1);
+        long_run &= 0xFFFFFFFFll;
+    } else long_run = 1;
+    if (!rc && long_run) {
+        hark_free(ctx, lrow2); hark_free(ctx, rank2); lrow2 = rank2 = nullptr;
+        rc = k_sort_column(ctx, lrow, HARK_U32, M, false, rank, &rank1, &lrow1);
+        if (!rc) rc = k_sort_column(ctx, rank1, HARK_U32, M, false, lrow1, &lrow2, &rank2);
+        hark_free(ctx, rank1); hark_free(ctx, lrow1);
+    }
+    hark_free(ctx, flag);
     hark_free(ctx, rank); hark_free(ctx, lrow);
-    if (!rc) rc = k_sort_column(ctx, rank1, HARK_U32, M, false, lrow1, &lrow2, &rank2);
-    hark_free(ctx, rank1); hark_free(ctx, lrow1);
     if (!rc) rc = hark_alloc(ctx, (void **)&runlen, 4 * (size_t)s);
     if (!rc) rc = hark_alloc(ctx, (void **)&cnt, 4 * (size_t)M);
     if (!rc) {

@@ -87,7 +87,8 @@ __global__ __launch_bounds__(256) void join_count_kernel(const K *__restrict__ l
 // per step -- so neither the output size nor skewed keys unbalance the work.
 __global__ __launch_bounds__(256) void join_expand_kernel(const int64_t *__restrict__ offs, const uint32_t *__restrict__ cnt, int64_t n,
                                                           const uint32_t *__restrict__ lb, const uint32_t *__restrict__ lperm,
-                                                          const uint32_t *__restrict__ rperm, uint32_t *__restrict__ lrow, uint32_t *__restrict__ rrow)
+                                                          const uint32_t *__restrict__ rperm, uint32_t *__restrict__ lrow, uint32_t *__restrict__ rrow,
+                                                          uint32_t *__restrict__ kpos /* may be null: position of the pair's key in the sorted build keys */)
 {
     const int lane = threadIdx.x & 63;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -96,14 +97,14 @@ __global__ __launch_bounds__(256) void join_expand_kernel(const int64_t *__restr
         uint32_t c = 0, first = 0, left = 0;
         int64_t o = 0;
         if (i < n) { c = cnt[i]; o = offs[i]; first = lb[i]; left = lperm[i]; }
-        if (c <= 8u) for (uint32_t j = 0; j < c; j++) { lrow[o + j] = left; rrow[o + j] = rperm[first + j]; }
+        if (c <= 8u) for (uint32_t j = 0; j < c; j++) { lrow[o + j] = left; rrow[o + j] = rperm[first + j]; if (kpos) kpos[o + j] = first + j; }
         unsigned long long big = __ballot(c > 8u);
         while (big) {
             const int src = __ffsll((long long)big) - 1;
             big &= big - 1ull;
             const uint32_t cc = __shfl(c, src, 64), ff = __shfl(first, src, 64), ll = __shfl(left, src, 64);
             const int64_t oo = __shfl(o, src, 64);
-            for (uint32_t j = lane; j < cc; j += 64) { lrow[oo + j] = ll; rrow[oo + j] = rperm[ff + j]; }
+            for (uint32_t j = lane; j < cc; j += 64) { lrow[oo + j] = ll; rrow[oo + j] = rperm[ff + j]; if (kpos) kpos[oo + j] = ff + j; }
         }
     }
 }
@@ -267,7 +268,7 @@ int hark_entry_join(hark_context *ctx, hark_result **out, const hark_table *db1,
     if (n == 0 || s == 0) { *out = res; return HARK_OK; }
 
     uint32_t *lperm = nullptr, *lkeys = nullptr, *rperm = nullptr, *rkeys = nullptr;
-    uint32_t *lb = nullptr, *cnt = nullptr, *lrow = nullptr, *rrow = nullptr;
+    uint32_t *lb = nullptr, *cnt = nullptr, *lrow = nullptr, *rrow = nullptr, *kpos = nullptr;
     int64_t *offs = nullptr;
     int64_t P = 0;
     hipStream_t st = ctx->stream;
@@ -372,8 +373,13 @@ int hark_entry_join(hark_context *ctx, hark_result **out, const hark_table *db1,
 
         if (!rc) rc = hark_alloc(ctx, (void **)&lrow, (size_t)P * 4);
         if (!rc) rc = hark_alloc(ctx, (void **)&rrow, (size_t)P * 4);
+        // an output column that IS the join key of either side is read off the SORTED build keys (ascending positions:
+        // a coalesced read) instead of being gathered at random through the row ids
+        bool key_out = false;
+        for (int64_t j = 0; j < l + k && !rc; j++) key_out = key_out || (j < l ? cols1[j] == col1 : cols2[j - l] == col2);
+        if (!rc && key_out) rc = hark_alloc(ctx, (void **)&kpos, (size_t)P * 4);
         if (!rc) {
-            join_expand_kernel<<<grid_for(ctx, nl), 256, 0, st>>>(offs, cnt, nl, lb, lperm, rperm, lrow, rrow);
+            join_expand_kernel<<<grid_for(ctx, nl), 256, 0, st>>>(offs, cnt, nl, lb, lperm, rperm, lrow, rrow, kpos);
             if (hipGetLastError() != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: launch failed");
         }
         res->n = P;
@@ -383,12 +389,15 @@ int hark_entry_join(hark_context *ctx, hark_result **out, const hark_table *db1,
             res->cols[j].dtype = t->cols[c].dtype; res->cols[j].owned = true;
             const int esz = (int)hark_dtype_size(t->cols[c].dtype);
             rc = hark_alloc(ctx, &res->cols[j].data, (size_t)P * esz);
-            if (!rc) rc = k_gather(ctx, t->cols[c].data, esz, j < l ? lrow : rrow, res->cols[j].data, P);
+            const bool is_key = j < l ? c == col1 : c == col2;
+            if (!rc && is_key && k64) gather_biased_i64_kernel<<<grid_for(ctx, P), 256, 0, st>>>(rk64, kpos, static_cast<uint64_t *>(res->cols[j].data), P);   // XOR undoes the bias
+            else if (!rc && is_key) rc = k_gather(ctx, rkeys, 4, kpos, res->cols[j].data, P);
+            else if (!rc) rc = k_gather(ctx, t->cols[c].data, esz, j < l ? lrow : rrow, res->cols[j].data, P);
         }
         if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: kernels failed");
     }
     hark_free(ctx, lk64); hark_free(ctx, rk64);
-    hark_free(ctx, lperm); hark_free(ctx, lkeys); hark_free(ctx, rperm); hark_free(ctx, rkeys); hark_free(ctx, lb); hark_free(ctx, cnt); hark_free(ctx, offs); hark_free(ctx, lrow); hark_free(ctx, rrow);
+    hark_free(ctx, lperm); hark_free(ctx, lkeys); hark_free(ctx, rperm); hark_free(ctx, rkeys); hark_free(ctx, lb); hark_free(ctx, cnt); hark_free(ctx, offs); hark_free(ctx, lrow); hark_free(ctx, rrow); hark_free(ctx, kpos);
     if (rc) { result_release(ctx, res); return rc; }
     *out = res;
     return HARK_OK;
