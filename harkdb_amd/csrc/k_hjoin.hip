@@ -42,7 +42,11 @@ template <typename K> struct JTraits;
 // cost 1.36 ms per 1e8 pairs -- instruction issue, not the loads; most pairs have no partner and now leave after
 // one bit test).  u32: 96 KiB of keys + 32 KiB of bitmap (+ 24 KiB of candidate queues), one round up to 1.26e7 build
 // rows; u64: 96 + 16 (+ 36) KiB.
-template <> struct JTraits<uint32_t> { typedef JPair32 E; static constexpr int P = 512, Q = 32, VEC = 4, CHUNK = 24576, BM_BITS = 18; };
+#ifndef HARK_J32_P                       // A/B builds (HARK_LIB): -DHARK_J32_P=256 -DHARK_J32_Q=64
+#define HARK_J32_P 512
+#define HARK_J32_Q 32
+#endif
+template <> struct JTraits<uint32_t> { typedef JPair32 E; static constexpr int P = HARK_J32_P, Q = HARK_J32_Q, VEC = 4, CHUNK = 24576, BM_BITS = 18; };
 template <> struct JTraits<uint64_t> { typedef JPair64 E; static constexpr int P = 256, Q = 32, VEC = 2, CHUNK = 12288, BM_BITS = 17; };
 
 __device__ __forceinline__ uint32_t jhash(uint32_t k) { return k * 0x9E3779B1u; }
