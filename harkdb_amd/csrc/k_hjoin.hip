@@ -378,6 +378,59 @@ __global__ __launch_bounds__(1024) void jsum_kernel(const uint32_t *__restrict__
     if (threadIdx.x == 0) *total = s_t;
 }
 
+// Survivor slabs -> two contiguous arrays (rank, left row) ALREADY ORDERED BY RANK: buckets are rank ranges in
+// ascending order, and inside its bucket a workgroup counting-sorts the survivors by (rank - first rank of the
+// bucket) with one LDS counter per build entry of the slice (histogram, exclusive scan, scatter).  Rows of equal rank
+// land in arbitrary order (jtiefix_kernel sorts those short runs).  Replaces three global radix passes over all
+// survivors.  A slice with more entries than LDS has counters is copied unordered and *unordered is raised.
+constexpr int kOrderMax = (int)(kJLdsBudget / 4) - 64;
+__global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restrict__ surv, size_t stride, const uint32_t *__restrict__ scount,
+                                                           const uint32_t *__restrict__ bstart, int P, uint32_t *__restrict__ rank,
+                                                           uint32_t *__restrict__ lrow, int32_t *__restrict__ unordered)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(lds_raw);
+    __shared__ unsigned long long s_dst;
+    __shared__ uint32_t s_wave[kJThreads / 64];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_dst = 0ull;
+    __syncthreads();
+    unsigned long long part = 0;
+    for (int q = tid; q < b; q += kJThreads) part += scount[q];
+    for (int d = 32; d > 0; d >>= 1) part += __shfl_down(part, d, 64);
+    if (lane == 0 && part) atomicAdd(&s_dst, part);
+    const uint32_t lo = bstart[b], len = bstart[b + 1] - lo, nb = scount[b];
+    const uint2 *src = surv + (size_t)b * stride;
+    __syncthreads();
+    const unsigned long long dst = s_dst;
+    if (len > (uint32_t)kOrderMax) {                                   // (heavy duplicates in the build side)
+        for (uint32_t i = tid; i < nb; i += kJThreads) { const uint2 e = src[i]; rank[dst + i] = e.x; lrow[dst + i] = e.y; }
+        if (tid == 0 && nb) *unordered = 1;
+        return;
+    }
+    for (uint32_t i = tid; i < len; i += kJThreads) cnt[i] = 0u;
+    __syncthreads();
+    for (uint32_t i = tid; i < nb; i += kJThreads) atomicAdd(&cnt[src[i].x - lo], 1u);
+    __syncthreads();
+    // exclusive scan of cnt[0, len): a contiguous segment per thread, waves chained through LDS
+    const uint32_t per = (len + kJThreads - 1) / kJThreads, s0 = min(len, tid * per), s1 = min(len, s0 + per);
+    uint32_t sum = 0;
+    for (uint32_t i = s0; i < s1; i++) sum += cnt[i];
+    uint32_t incl = sum;
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d, 64); if (lane >= d) incl += y; }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t run = incl - sum;
+    for (int w = 0; w < wave; w++) run += s_wave[w];
+    for (uint32_t i = s0; i < s1; i++) { const uint32_t c = cnt[i]; cnt[i] = run; run += c; }
+    __syncthreads();
+    for (uint32_t i = tid; i < nb; i += kJThreads) {
+        const uint2 e = src[i];
+        const uint32_t at = atomicAdd(&cnt[e.x - lo], 1u);
+        rank[dst + at] = e.x; lrow[dst + at] = e.y;
+    }
+}
+
 // survivor slabs -> two contiguous arrays (rank, left row); dst offsets = exclusive scan of scount, done by every
 // workgroup for itself (P <= 1024 values)
 __global__ __launch_bounds__(256) void jcompact_kernel(const uint2 *__restrict__ surv, size_t stride, const uint32_t *__restrict__ scount,
@@ -400,7 +453,7 @@ __global__ __launch_bounds__(256) void jcompact_kernel(const uint2 *__restrict__
 
 template <typename K>
 int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K *rkeys, int64_t s,
-                    uint32_t **rank_out, uint32_t **lrow_out, int64_t *m_out, bool *used)
+                    uint32_t **rank_out, uint32_t **lrow_out, int64_t *m_out, bool *used, int32_t *unordered_dev)
 {
     typedef typename JTraits<K>::E E;
     constexpr int P = JTraits<K>::P, Q = JTraits<K>::Q, VEC = JTraits<K>::VEC, LINE = 128 / (int)sizeof(E);
@@ -458,8 +511,14 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
         rc = hark_alloc(ctx, (void **)&rank, 4 * (size_t)M);
         if (!rc) rc = hark_alloc(ctx, (void **)&lrow, 4 * (size_t)M);
         if (!rc) {
-            jcompact_kernel<<<dim3((unsigned)P), 256, 0, st>>>(surv, sstride, scount, P, rank, lrow);
-            if (hipGetLastError() != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: compact launch failed");
+            if (getenv("HARK_JOIN_FULLSORT")) {                                  // A/B + tests: plain compaction, radix sorts by the caller
+                jcompact_kernel<<<dim3((unsigned)P), 256, 0, st>>>(surv, sstride, scount, P, rank, lrow);
+                hipMemsetAsync(unordered_dev, 1, 1, st);
+            } else {
+                he = hipFuncSetAttribute(reinterpret_cast<const void *>(&jorder_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kOrderMax * 4);
+                if (he == hipSuccess) jorder_kernel<<<dim3((unsigned)P), dim3(kJThreads), (size_t)kOrderMax * 4, st>>>(surv, sstride, scount, bstart, P, rank, lrow, unordered_dev);
+            }
+            if (he != hipSuccess || hipGetLastError() != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: compact launch failed");
         }
     }
     cleanup();                                                              // stream-ordered reuse: the compaction above is enqueued first
@@ -482,34 +541,33 @@ int k_join_partitioned(hark_context *ctx, const void *lcol, bool k64, int64_t n,
     if (getenv("HARK_JOIN_SORTMERGE")) return HARK_OK;                          // A/B knob
     uint32_t *rank = nullptr, *lrow = nullptr;
     int64_t M = 0;
-    int rc = k64 ? run_partitioned<uint64_t>(ctx, static_cast<const uint64_t *>(lcol), 0x8000000000000000ull, n, static_cast<const uint64_t *>(rkeys), s, &rank, &lrow, &M, used)
-                 : run_partitioned<uint32_t>(ctx, static_cast<const uint32_t *>(lcol), 0u, n, static_cast<const uint32_t *>(rkeys), s, &rank, &lrow, &M, used);
-    if (rc || !*used) return rc;
-    if (M == 0) { hark_free(ctx, rank); hark_free(ctx, lrow); return HARK_OK; }
-    // (rank, left row) order.  Fast path: ONE sort by rank (3 passes for < 2^24 build rows), then the short runs of equal
-    // rank are put in left-row order in place; a run longer than kTieMax takes the general path: stable sort by left
-    // row, then stable sort by rank (each skips the passes no byte needs).
+    int32_t *flag = nullptr;                                   // [0] the survivors are not in rank order yet, or a run of equal rank is too long
+    int rc = hark_alloc(ctx, (void **)&flag, 16);
+    if (rc) return rc;
+    hipMemsetAsync(flag, 0, 16, ctx->stream);
+    rc = k64 ? run_partitioned<uint64_t>(ctx, static_cast<const uint64_t *>(lcol), 0x8000000000000000ull, n, static_cast<const uint64_t *>(rkeys), s, &rank, &lrow, &M, used, flag)
+             : run_partitioned<uint32_t>(ctx, static_cast<const uint32_t *>(lcol), 0u, n, static_cast<const uint32_t *>(rkeys), s, &rank, &lrow, &M, used, flag);
+    if (rc || !*used) { hark_free(ctx, flag); return rc; }
+    if (M == 0) { hark_free(ctx, rank); hark_free(ctx, lrow); hark_free(ctx, flag); return HARK_OK; }
+    // (rank, left row) order.  Fast path: the survivors arrive ordered by rank (jorder_kernel); the short runs of equal
+    // rank are put in left-row order in place.  A run longer than kTieMax, or a slice too long for the LDS counters,
+    // takes the general path: stable radix sort by left row, then by rank (each skips the passes no byte needs).
     uint32_t *rank1 = nullptr, *lrow1 = nullptr, *lrow2 = nullptr, *rank2 = nullptr, *runlen = nullptr, *cnt = nullptr;
-    int32_t *flag = nullptr;
-    int64_t long_run = 0;
-    rc = hark_alloc(ctx, (void **)&flag, 16);
-    if (!rc && !getenv("HARK_JOIN_FULLSORT")) {
-        hipMemsetAsync(flag, 0, 16, ctx->stream);
-        rc = k_sort_column(ctx, rank, HARK_U32, M, false, lrow, &lrow2, &rank2);
-        if (!rc) {
-            int64_t g = (M + 255) / 256;
-            if (g > (int64_t)ctx->num_cu * 16) g = (int64_t)ctx->num_cu * 16;
-            jtiefix_kernel<<<dim3((unsigned)g), 256, 0, ctx->stream>>>(rank2, lrow2, M, flag);
-            if (hipGetLastError() != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: tie-fix launch failed");
-        }
-        if (!rc) rc = hark_read_words(ctx, flag, &long_run, 1);
-        long_run &= 0xFFFFFFFFll;
-    } else long_run = 1;
-    if (!rc && long_run) {
-        hark_free(ctx, lrow2); hark_free(ctx, rank2); lrow2 = rank2 = nullptr;
+    int64_t general = 0;
+    {
+        int64_t g = (M + 255) / 256;
+        if (g > (int64_t)ctx->num_cu * 16) g = (int64_t)ctx->num_cu * 16;
+        jtiefix_kernel<<<dim3((unsigned)g), 256, 0, ctx->stream>>>(rank, lrow, M, flag);      // harmless on unordered input
+        if (hipGetLastError() != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: tie-fix launch failed");
+        if (!rc) rc = hark_read_words(ctx, flag, &general, 1);
+        general &= 0xFFFFFFFFll;
+    }
+    if (!rc && general) {
         rc = k_sort_column(ctx, lrow, HARK_U32, M, false, rank, &rank1, &lrow1);
         if (!rc) rc = k_sort_column(ctx, rank1, HARK_U32, M, false, lrow1, &lrow2, &rank2);
         hark_free(ctx, rank1); hark_free(ctx, lrow1);
+    } else if (!rc) {
+        rank2 = rank; lrow2 = lrow; rank = lrow = nullptr;     // in place
     }
     hark_free(ctx, flag);
     hark_free(ctx, rank); hark_free(ctx, lrow);
