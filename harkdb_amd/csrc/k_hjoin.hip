@@ -31,6 +31,7 @@ namespace {
 
 constexpr int kJThreads = 1024;
 constexpr int kJErrOverflow = 100;
+constexpr int kMaxRounds = 16;                           // bucket-kernel rounds whose survivor counts are recorded (the order kernel reads per round)
 constexpr size_t kJLdsBudget = 160 * 1024 - 512;          // one workgroup per CU owns (almost) all of its LDS
 
 struct JPair32 { uint32_t key, row; };                                    // 8 bytes: 16 per 128-byte line
@@ -47,7 +48,7 @@ template <typename K> struct JTraits;
 #define HARK_J32_Q 32
 #endif
 template <> struct JTraits<uint32_t> { typedef JPair32 E; static constexpr int P = HARK_J32_P, Q = HARK_J32_Q, VEC = 4, CHUNK = 24576, BM_BITS = 18; };
-template <> struct JTraits<uint64_t> { typedef JPair64 E; static constexpr int P = 256, Q = 32, VEC = 2, CHUNK = 12288, BM_BITS = 17; };
+template <> struct JTraits<uint64_t> { typedef JPair64 E; static constexpr int P = 512, Q = 16, VEC = 2, CHUNK = 12288, BM_BITS = 17; };
 
 __device__ __forceinline__ uint32_t jhash(uint32_t k) { return k * 0x9E3779B1u; }
 __device__ __forceinline__ uint32_t jhash(uint64_t k) { return (uint32_t)((k * 0x9E3779B97F4A7C15ull) >> 32); }
@@ -79,8 +80,9 @@ __global__ __launch_bounds__(256) void jsplit_kernel(const K *__restrict__ rkeys
 
 // runlen[i] = number of build entries equal to rkeys[i] when i starts a run, else 0.
 template <typename K>
-__global__ __launch_bounds__(256) void jrunlen_kernel(const K *__restrict__ rkeys, int64_t s, uint32_t *__restrict__ runlen)
+__global__ __launch_bounds__(256) void jrunlen_kernel(const K *__restrict__ rkeys, int64_t s, uint32_t *__restrict__ runlen, int32_t *__restrict__ dup)
 {
+    bool any = false;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < s; i += stride) {
         const K key = rkeys[i];
@@ -95,35 +97,11 @@ __global__ __launch_bounds__(256) void jrunlen_kernel(const K *__restrict__ rkey
                 ub = a;
             }
             len = (uint32_t)(ub - i);
+            any = any || len > 1u;
         }
         runlen[i] = len;
     }
-}
-
-// After a sort by rank alone, rows of one rank (probe rows matching the same build key) stand in arbitrary order:
-// the thread at the head of each run sorts the run's left row ids (runs are short: the fan-out of a key); a run
-// longer than kTieMax raises *too_long and the caller sorts by (left row, rank) with full radix passes instead.
-constexpr int kTieMax = 48;
-__global__ __launch_bounds__(256) void jtiefix_kernel(const uint32_t *__restrict__ rank, uint32_t *__restrict__ lrow, int64_t m, int32_t *__restrict__ too_long)
-{
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
-        const uint32_t r = rank[i];
-        if (i > 0 && rank[i - 1] == r) continue;                      // not a run head
-        if (i + 1 >= m || rank[i + 1] != r) continue;                 // a run of one
-        int len = 2;
-        while (len <= kTieMax && i + len < m && rank[i + len] == r) len++;
-        if (len > kTieMax) { *too_long = 1; continue; }
-        uint32_t v[kTieMax];
-        for (int j = 0; j < len; j++) v[j] = lrow[i + j];
-        for (int a = 1; a < len; a++) {                               // insertion sort (left row ids are distinct)
-            const uint32_t x = v[a];
-            int q = a - 1;
-            while (q >= 0 && v[q] > x) { v[q + 1] = v[q]; q--; }
-            v[q + 1] = x;
-        }
-        for (int j = 0; j < len; j++) lrow[i + j] = v[j];
-    }
+    if (__ballot(any) != 0ull && (threadIdx.x & 63) == 0) *dup = 1;       // benign race: every writer stores 1
 }
 
 __global__ __launch_bounds__(256) void jcnt_kernel(const uint32_t *__restrict__ rank, int64_t m, const uint32_t *__restrict__ runlen, uint32_t *__restrict__ cnt)
@@ -258,7 +236,8 @@ __global__ __launch_bounds__(kJThreads) void jpart_kernel(const K *__restrict__ 
 template <typename K>
 __global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTraits<K>::E *__restrict__ slabs, const uint32_t *__restrict__ counts,
                                                             uint32_t cap, int nwg, const K *__restrict__ rkeys, const uint32_t *__restrict__ bstart,
-                                                            int chunk_cap, uint2 *__restrict__ surv, uint32_t *__restrict__ scount)
+                                                            int chunk_cap, uint2 *__restrict__ surv, uint32_t *__restrict__ scount,
+                                                            uint32_t *__restrict__ sround /* [P][kMaxRounds] survivors after round q */)
 {
     typedef typename JTraits<K>::E E;
     constexpr int BM_BITS = JTraits<K>::BM_BITS, BM_WORDS = 1 << (BM_BITS - 5), QCAP = 192;
@@ -275,9 +254,11 @@ __global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTrai
     if (tid == 0) s_n = 0u;
     uint2 *out = surv + (size_t)b * nwg * cap;                             // room for every probe pair of the bucket
     const unsigned long long below = (1ull << lane) - 1ull;
-    for (uint32_t base = lo; base < hi; base += (uint32_t)chunk_cap) {
+    int q = 0;                                                       // rounds done
+    for (uint32_t base = lo; base < hi; base += (uint32_t)chunk_cap, q++) {
         const int m = (int)min((uint32_t)chunk_cap, hi - base);
         __syncthreads();                                             // the previous round's readers are done (and s_n is set)
+        if (tid == 0 && q > 0 && q <= kMaxRounds) sround[b * kMaxRounds + q - 1] = s_n;
         for (int i = tid; i < BM_WORDS; i += kJThreads) bitmap[i] = 0u;
         for (int i = tid; i < m; i += kJThreads) chunk[i] = rkeys[base + i];
         __syncthreads();
@@ -363,7 +344,7 @@ __global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTrai
         if (qn > 0) drain(qn);                                         // the round's leftovers (fewer than 64)
     }
     __syncthreads();
-    if (tid == 0) scount[b] = s_n;
+    if (tid == 0) { scount[b] = s_n; if (q > 0 && q <= kMaxRounds) sround[b * kMaxRounds + q - 1] = s_n; }
 }
 
 __global__ __launch_bounds__(1024) void jsum_kernel(const uint32_t *__restrict__ scount, int P, unsigned long long *__restrict__ total)
@@ -378,57 +359,245 @@ __global__ __launch_bounds__(1024) void jsum_kernel(const uint32_t *__restrict__
     if (threadIdx.x == 0) *total = s_t;
 }
 
-// Survivor slabs -> two contiguous arrays (rank, left row) ALREADY ORDERED BY RANK: buckets are rank ranges in
-// ascending order, and inside its bucket a workgroup counting-sorts the survivors by (rank - first rank of the
-// bucket) with one LDS counter per build entry of the slice (histogram, exclusive scan, scatter).  Rows of equal rank
-// land in arbitrary order (jtiefix_kernel sorts those short runs).  Replaces three global radix passes over all
-// survivors.  A slice with more entries than LDS has counters is copied unordered and *unordered is raised.
-constexpr int kOrderMax = (int)(kJLdsBudget / 4) - 64;
+// Survivor slabs -> contiguous arrays (rank, left row, partner count) ORDERED BY (rank, left row): buckets are rank
+// ranges in ascending order, so a workgroup orders its own bucket and writes behind the earlier buckets.
+//   1. coarse histogram of the bucket's survivors over groups of 2^gs ranks (one read of the slab);
+//   2. sub-rounds: as many consecutive groups as fit the LDS stage (kStage survivors) and the fine counters (kFine
+//      ranks); a sub-round re-reads only the survivors of the bucket-kernel rounds its rank range overlaps (the bucket
+//      kernel appends round after round, sround[] holds the boundaries);
+//   3. inside a sub-round: one LDS counter per rank (histogram, exclusive scan, placement into the stage), then the
+//      thread that owns a rank sorts that rank's few rows by left row id in LDS (insertion sort; the fan-out of a
+//      key), and the stage leaves the CU as contiguous whole-line stores -- the scattered 4-byte global stores of the
+//      first version ran at 0.8 TB/s.
+// A group of 2^gs ranks with more survivors than the stage holds, or a rank with more than kTieMax rows, raises *general:
+// the bucket is copied as it is and the caller sorts all survivors with radix passes instead.
+// Sorting networks over N registers (compare-exchange lists: optimal 4- and 8-input networks, Batcher's odd-even merge sort
+// for 16 inputs, 63 comparators), fully unrolled: no dynamic indexing, so the values stay in VGPRs.
+__device__ __forceinline__ void cex(uint32_t &a, uint32_t &b) { const uint32_t lo = min(a, b), hi = max(a, b); a = lo; b = hi; }
+__device__ __forceinline__ void sort4(uint32_t (&v)[4])
+{
+    cex(v[0], v[1]); cex(v[2], v[3]); cex(v[0], v[2]); cex(v[1], v[3]); cex(v[1], v[2]);
+}
+__device__ __forceinline__ void sort8(uint32_t (&v)[8])
+{
+    cex(v[0], v[1]); cex(v[2], v[3]); cex(v[4], v[5]); cex(v[6], v[7]);
+    cex(v[0], v[2]); cex(v[1], v[3]); cex(v[4], v[6]); cex(v[5], v[7]);
+    cex(v[1], v[2]); cex(v[5], v[6]); cex(v[0], v[4]); cex(v[3], v[7]);
+    cex(v[1], v[5]); cex(v[2], v[6]);
+    cex(v[1], v[4]); cex(v[3], v[6]);
+    cex(v[2], v[4]); cex(v[3], v[5]);
+    cex(v[3], v[4]);
+}
+__device__ __forceinline__ void sort16(uint32_t (&v)[16])
+{
+#define CX(a, b) cex(v[a], v[b])
+    CX(0, 1); CX(2, 3); CX(0, 2); CX(1, 3); CX(1, 2); CX(4, 5); CX(6, 7); CX(4, 6); CX(5, 7); CX(5, 6); CX(0, 4);
+    CX(2, 6); CX(2, 4); CX(1, 5); CX(3, 7); CX(3, 5); CX(1, 2); CX(3, 4); CX(5, 6); CX(8, 9); CX(10, 11);
+    CX(8, 10); CX(9, 11); CX(9, 10); CX(12, 13); CX(14, 15); CX(12, 14); CX(13, 15); CX(13, 14); CX(8, 12);
+    CX(10, 14); CX(10, 12); CX(9, 13); CX(11, 15); CX(11, 13); CX(9, 10); CX(11, 12); CX(13, 14); CX(0, 8);
+    CX(4, 12); CX(4, 8); CX(2, 10); CX(6, 14); CX(6, 10); CX(2, 4); CX(6, 8); CX(10, 12); CX(1, 9); CX(5, 13);
+    CX(5, 9); CX(3, 11); CX(7, 15); CX(7, 11); CX(3, 5); CX(7, 9); CX(11, 13); CX(1, 2); CX(3, 4); CX(5, 6);
+    CX(7, 8); CX(9, 10); CX(11, 12); CX(13, 14);
+#undef CX
+}
+constexpr int kStage = 12288, kFine = 10240, kCoarse = 2048, kTieMax = 64, kMaxSub = 256;
 __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restrict__ surv, size_t stride, const uint32_t *__restrict__ scount,
-                                                           const uint32_t *__restrict__ bstart, int P, uint32_t *__restrict__ rank,
-                                                           uint32_t *__restrict__ lrow, int32_t *__restrict__ unordered)
+                                                           const uint32_t *__restrict__ sround, int chunk_cap,
+                                                           const uint32_t *__restrict__ bstart, int P, const uint32_t *__restrict__ runlen,
+                                                           uint32_t *__restrict__ rank, uint32_t *__restrict__ lrow, uint32_t *__restrict__ cnt_out /* may be null */,
+                                                           int stage_cap /* <= kStage (tests: smaller) */, int32_t *__restrict__ general,
+                                                           uint2 *tmp_all /* scratch, same layout as surv (the probe slabs, dead by now) */)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    uint32_t *cnt = reinterpret_cast<uint32_t *>(lds_raw);
+    uint2 *stage = reinterpret_cast<uint2 *>(lds_raw);                         // [kStage]
+    uint32_t *fine = reinterpret_cast<uint32_t *>(stage + kStage);             // [kFine + 1]
+    uint32_t *coarse = fine + kFine + 1;                                       // [kCoarse + 1] counts, then exclusive prefix
     __shared__ unsigned long long s_dst;
     __shared__ uint32_t s_wave[kJThreads / 64];
+    __shared__ int s_bad, s_nsr;
+    __shared__ uint16_t s_subg[kMaxSub + 1];                                   // first group of every sub-round
+    __shared__ uint32_t s_bincur[kMaxSub];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) s_dst = 0ull;
+    if (tid == 0) { s_dst = 0ull; s_bad = 0; s_nsr = 0; }
     __syncthreads();
     unsigned long long part = 0;
-    for (int q = tid; q < b; q += kJThreads) part += scount[q];
+    for (int qq = tid; qq < b; qq += kJThreads) part += scount[qq];
     for (int d = 32; d > 0; d >>= 1) part += __shfl_down(part, d, 64);
     if (lane == 0 && part) atomicAdd(&s_dst, part);
     const uint32_t lo = bstart[b], len = bstart[b + 1] - lo, nb = scount[b];
     const uint2 *src = surv + (size_t)b * stride;
+    int gs = 0;
+    while (((len + (1u << gs) - 1u) >> gs) > (uint32_t)kCoarse) gs++;
+    const uint32_t ngroups = (len + (1u << gs) - 1u) >> gs;
+    for (uint32_t i = tid; i <= ngroups; i += kJThreads) coarse[i] = 0u;
     __syncthreads();
     const unsigned long long dst = s_dst;
-    if (len > (uint32_t)kOrderMax) {                                   // (heavy duplicates in the build side)
-        for (uint32_t i = tid; i < nb; i += kJThreads) { const uint2 e = src[i]; rank[dst + i] = e.x; lrow[dst + i] = e.y; }
-        if (tid == 0 && nb) *unordered = 1;
+    if (nb == 0) return;
+    // every pass over survivors keeps 8 loads per lane in flight: one workgroup owns the CU, and with a single load per
+    // lane the passes ran at the latency of a load, not at the CU's share of the bandwidth
+    auto sweep = [&](const uint2 *sp, uint32_t i0, uint32_t i1, bool coherent, auto &&f) {
+        auto ld = [&](uint32_t i) -> uint2 {
+            if (!coherent) return sp[i];
+            // workgroup-scope load: the bins were written by other waves of this workgroup in this kernel
+            const unsigned long long w = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(sp + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            return uint2{(uint32_t)w, (uint32_t)(w >> 32)};
+        };
+        uint32_t i = i0 + tid;
+        for (; i + 7u * kJThreads < i1; i += 8u * kJThreads) {
+            uint2 e[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) e[k] = ld(i + (uint32_t)k * kJThreads);
+#pragma unroll
+            for (int k = 0; k < 8; k++) f(e[k]);
+        }
+        for (; i < i1; i += kJThreads) f(ld(i));
+    };
+    sweep(src, 0u, nb, false, [&](uint2 e) { atomicAdd(&coarse[(e.x - lo) >> gs], 1u); });
+    __syncthreads();
+    // block-wide exclusive scan helper over a[0, m): a contiguous segment per thread, waves chained through LDS;
+    // returns the total
+    auto scan_excl = [&](uint32_t *a, uint32_t m) -> uint32_t {
+        const uint32_t per = (m + kJThreads - 1) / kJThreads, s0 = min(m, tid * per), s1 = min(m, s0 + per);
+        uint32_t sum = 0;
+        for (uint32_t i = s0; i < s1; i++) sum += a[i];
+        uint32_t incl = sum;
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d, 64); if (lane >= d) incl += y; }
+        __syncthreads();                                               // s_wave's previous readers are done
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t run = incl - sum, total = 0;
+        for (int w = 0; w < kJThreads / 64; w++) { const uint32_t x = s_wave[w]; if (w < wave) run += x; total += x; }
+        for (uint32_t i = s0; i < s1; i++) { const uint32_t c = a[i]; a[i] = run; run += c; }
+        __syncthreads();
+        return total;
+    };
+    {   // a group that cannot be staged: heavy skew
+        bool big = false;
+        for (uint32_t i = tid; i < ngroups; i += kJThreads) big = big || coarse[i] > (uint32_t)stage_cap;
+        if (big) s_bad = 1;
+    }
+    __syncthreads();
+    if (s_bad) {
+        for (uint32_t i = tid; i < nb; i += kJThreads) { const uint2 e = src[i]; rank[dst + i] = e.x; lrow[dst + i] = e.y; if (cnt_out) cnt_out[dst + i] = runlen[e.x]; }
+        if (tid == 0) *general = 1;
         return;
     }
-    for (uint32_t i = tid; i < len; i += kJThreads) cnt[i] = 0u;
-    __syncthreads();
-    for (uint32_t i = tid; i < nb; i += kJThreads) atomicAdd(&cnt[src[i].x - lo], 1u);
-    __syncthreads();
-    // exclusive scan of cnt[0, len): a contiguous segment per thread, waves chained through LDS
-    const uint32_t per = (len + kJThreads - 1) / kJThreads, s0 = min(len, tid * per), s1 = min(len, s0 + per);
-    uint32_t sum = 0;
-    for (uint32_t i = s0; i < s1; i++) sum += cnt[i];
-    uint32_t incl = sum;
-    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d, 64); if (lane >= d) incl += y; }
-    if (lane == 63) s_wave[wave] = incl;
-    __syncthreads();
-    uint32_t run = incl - sum;
-    for (int w = 0; w < wave; w++) run += s_wave[w];
-    for (uint32_t i = s0; i < s1; i++) { const uint32_t c = cnt[i]; cnt[i] = run; run += c; }
-    __syncthreads();
-    for (uint32_t i = tid; i < nb; i += kJThreads) {
-        const uint2 e = src[i];
-        const uint32_t at = atomicAdd(&cnt[e.x - lo], 1u);
-        rank[dst + at] = e.x; lrow[dst + at] = e.y;
+    scan_excl(coarse, ngroups + 1);                                    // coarse[g] = survivors before group g; coarse[ngroups] = nb
+    const int rounds_b = (int)((len + (uint32_t)chunk_cap - 1u) / (uint32_t)chunk_cap);
+    const bool by_round = rounds_b <= kMaxRounds;
+    const uint32_t max_groups = max(1u, (uint32_t)kFine >> gs);
+    bool too_long = false;
+    // the end of the sub-round that starts at group g0: the largest g1 with coarse[g1] - coarse[g0] <= stage_cap and
+    // g1 - g0 <= max_groups (a single group always fits: checked above)
+    auto sub_end = [&](uint32_t g0) -> uint32_t {
+        uint32_t a = g0 + 1, z = min(ngroups, g0 + max_groups);
+        const uint32_t base_cnt = coarse[g0];
+        while (a < z) { const uint32_t mid = (a + z + 1) >> 1; if (coarse[mid] - base_cnt <= (uint32_t)stage_cap) a = mid; else z = mid - 1; }
+        return a;
+    };
+    // With three or more sub-rounds the survivors are first BINNED by sub-round (exact bin sizes are known from the
+    // coarse prefix), so that a sub-round reads its own survivors only instead of the whole round's; the bins live in
+    // the dead probe slabs.  (Without it a bucket of BASELINE configs[3] was read 11 times over: 1.8 ms of 7.)
+    if (tid == 0) {
+        int k = 0;
+        uint32_t g = 0;
+        while (g < ngroups && k < kMaxSub) { s_subg[k++] = (uint16_t)g; g = sub_end(g); }
+        s_subg[k] = (uint16_t)ngroups;
+        s_nsr = g < ngroups ? kMaxSub + 1 : k;                           // too many sub-rounds for the table: no binning
     }
+    __syncthreads();
+    const int nsr = s_nsr;
+    const bool binned = nsr >= 3 && nsr <= kMaxSub && tmp_all != nullptr;
+    uint2 *tmp = tmp_all + (size_t)b * stride;
+    if (binned) {
+        for (int k = tid; k < nsr; k += kJThreads) s_bincur[k] = 0u;
+        __syncthreads();
+        sweep(src, 0u, nb, false, [&](uint2 e) {
+            const uint32_t g = (e.x - lo) >> gs;
+            int a = 0, z = nsr - 1;                                      // the sub-round whose group range holds g
+            while (a < z) { const int mid = (a + z + 1) >> 1; if ((uint32_t)s_subg[mid] <= g) a = mid; else z = mid - 1; }
+            tmp[coarse[s_subg[a]] + atomicAdd(&s_bincur[a], 1u)] = e;
+        });
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");         // the bins are read back by other waves of this workgroup (same CU, same L1)
+        __syncthreads();
+    }
+    uint32_t g0 = 0;
+    while (g0 < ngroups) {
+        const uint32_t base_cnt = coarse[g0];
+        const uint32_t g1 = sub_end(g0), r0 = g0 << gs, r1 = min(len, g1 << gs), nr = r1 - r0, nsub = coarse[g1] - base_cnt;
+        if (nsub) {
+            uint32_t i0 = 0, i1 = nb;
+            const uint2 *sp = src;
+            if (binned) { sp = tmp + base_cnt; i0 = 0; i1 = nsub; }
+            else if (by_round) {
+                const int q0 = (int)(r0 / (uint32_t)chunk_cap), q1 = (int)((r1 - 1u) / (uint32_t)chunk_cap);
+                i0 = q0 > 0 ? sround[b * kMaxRounds + q0 - 1] : 0u;
+                i1 = sround[b * kMaxRounds + q1];
+            }
+            for (uint32_t i = tid; i <= nr; i += kJThreads) fine[i] = 0u;
+            __syncthreads();
+            sweep(sp, i0, i1, binned, [&](uint2 e) { const uint32_t r = e.x - lo - r0; if (r < nr) atomicAdd(&fine[r], 1u); });
+            __syncthreads();
+            scan_excl(fine, nr);
+            sweep(sp, i0, i1, binned, [&](uint2 e) {
+                const uint32_t r = e.x - lo - r0;
+                if (r < nr) stage[atomicAdd(&fine[r], 1u)] = e;        // afterwards fine[r] = end of rank r's rows
+            });
+            __syncthreads();
+            for (uint32_t r = tid; r < nr; r += kJThreads) {           // rows of one rank into left-row order
+                const uint32_t s0 = r ? fine[r - 1] : 0u, s1 = fine[r];
+                if (s1 - s0 < 2u) continue;
+                if (s1 - s0 > (uint32_t)kTieMax) { too_long = true; continue; }
+                const uint32_t m = s1 - s0;
+                // short runs (the usual fan-out of a key) are sorted in registers: the rank is the same for the whole run, so
+                // only the left row ids move; the in-LDS insertion sort below is a chain of dependent LDS round trips
+                // (it took a third of this kernel at 5 rows per key)
+                if (m <= 4u) {
+                    uint32_t v[4];
+#pragma unroll
+                    for (int x = 0; x < 4; x++) v[x] = (uint32_t)x < m ? stage[s0 + x].y : 0xFFFFFFFFu;
+                    sort4(v);
+#pragma unroll
+                    for (int x = 0; x < 4; x++) if ((uint32_t)x < m) stage[s0 + x].y = v[x];
+                    continue;
+                }
+                if (m <= 8u) {
+                    uint32_t v[8];
+#pragma unroll
+                    for (int x = 0; x < 8; x++) v[x] = (uint32_t)x < m ? stage[s0 + x].y : 0xFFFFFFFFu;
+                    sort8(v);
+#pragma unroll
+                    for (int x = 0; x < 8; x++) if ((uint32_t)x < m) stage[s0 + x].y = v[x];
+                    continue;
+                }
+                if (m <= 16u) {
+                    uint32_t v[16];
+#pragma unroll
+                    for (int x = 0; x < 16; x++) v[x] = (uint32_t)x < m ? stage[s0 + x].y : 0xFFFFFFFFu;
+                    sort16(v);
+#pragma unroll
+                    for (int x = 0; x < 16; x++) if ((uint32_t)x < m) stage[s0 + x].y = v[x];
+                    continue;
+                }
+                for (uint32_t x = s0 + 1; x < s1; x++) {               // left row ids are distinct
+                    const uint2 e = stage[x];
+                    uint32_t y = x;
+                    while (y > s0 && stage[y - 1].y > e.y) { stage[y] = stage[y - 1]; y--; }
+                    stage[y] = e;
+                }
+            }
+            __syncthreads();
+            const unsigned long long o = dst + base_cnt;
+            for (uint32_t i = tid; i < nsub; i += kJThreads) {
+                const uint2 e = stage[i];
+                rank[o + i] = e.x; lrow[o + i] = e.y;
+                if (cnt_out) cnt_out[o + i] = runlen[e.x];
+            }
+            __syncthreads();
+        }
+        g0 = g1;
+    }
+    if (__ballot(too_long) != 0ull && lane == 0) *general = 1;
 }
 
 // survivor slabs -> two contiguous arrays (rank, left row); dst offsets = exclusive scan of scount, done by every
@@ -452,8 +621,9 @@ __global__ __launch_bounds__(256) void jcompact_kernel(const uint2 *__restrict__
 }
 
 template <typename K>
-int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K *rkeys, int64_t s,
-                    uint32_t **rank_out, uint32_t **lrow_out, int64_t *m_out, bool *used, int32_t *unordered_dev)
+int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K *rkeys, int64_t s, const uint32_t *runlen,
+                    int32_t *flags /* device: [0] general sort needed, [1] duplicate build keys */,
+                    uint32_t **rank_out, uint32_t **lrow_out, uint32_t **cnt_out, int64_t *m_out, bool *used, bool *dup_out)
 {
     typedef typename JTraits<K>::E E;
     constexpr int P = JTraits<K>::P, Q = JTraits<K>::Q, VEC = JTraits<K>::VEC, LINE = 128 / (int)sizeof(E);
@@ -465,24 +635,27 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
     int64_t cap64 = (avg + avg / 2 + 5 * LINE + LINE - 1) / LINE * LINE;
     if (cap64 > 0x7FFFFFF0ll) return HARK_OK;
     const uint32_t cap = (uint32_t)cap64;
-    K *splitters = nullptr; uint32_t *bstart = nullptr, *counts = nullptr, *scount = nullptr; int32_t *err = nullptr;
-    E *slabs = nullptr; uint2 *surv = nullptr; unsigned long long *total = nullptr;
-    uint32_t *rank = nullptr, *lrow = nullptr;
+    K *splitters = nullptr; uint32_t *bstart = nullptr, *counts = nullptr, *scount = nullptr, *sround = nullptr;
+    int64_t *info = nullptr;                                                     // [0] survivors (u64), [1] error word of the partition
+    E *slabs = nullptr; uint2 *surv = nullptr;
+    uint32_t *rank = nullptr, *lrow = nullptr, *cnt = nullptr;
     const size_t sstride = (size_t)nwg * cap;                                    // survivor slab of a bucket: room for all of its probe pairs
     int rc = hark_alloc(ctx, (void **)&splitters, sizeof(K) * P);
     if (!rc) rc = hark_alloc(ctx, (void **)&bstart, 4 * (size_t)(P + 1));
     if (!rc) rc = hark_alloc(ctx, (void **)&counts, 4 * (size_t)P * nwg);
     if (!rc) rc = hark_alloc(ctx, (void **)&scount, 4 * (size_t)P);
-    if (!rc) rc = hark_alloc(ctx, (void **)&err, 16);
-    if (!rc) rc = hark_alloc(ctx, (void **)&total, 16);
+    if (!rc) rc = hark_alloc(ctx, (void **)&sround, 4 * (size_t)P * kMaxRounds);
+    if (!rc) rc = hark_alloc(ctx, (void **)&info, 32);
     if (!rc) rc = hark_alloc(ctx, (void **)&slabs, sizeof(E) * (size_t)P * sstride);
     if (!rc) rc = hark_alloc(ctx, (void **)&surv, 8 * (size_t)P * sstride);
     auto cleanup = [&]() {
-        hark_free(ctx, splitters); hark_free(ctx, bstart); hark_free(ctx, counts); hark_free(ctx, scount);
-        hark_free(ctx, err); hark_free(ctx, total); hark_free(ctx, slabs); hark_free(ctx, surv);
+        hark_free(ctx, splitters); hark_free(ctx, bstart); hark_free(ctx, counts); hark_free(ctx, scount); hark_free(ctx, sround);
+        hark_free(ctx, info); hark_free(ctx, slabs); hark_free(ctx, surv);
     };
     if (rc) { cleanup(); return rc; }
-    hipMemsetAsync(err, 0, 16, st);
+    hipMemsetAsync(info, 0, 32, st);
+    int32_t *err = reinterpret_cast<int32_t *>(info + 1);
+    unsigned long long *total = reinterpret_cast<unsigned long long *>(info);
     jsplit_kernel<K><<<(P + 256) / 256, 256, 0, st>>>(rkeys, s, P, splitters, bstart);
     const size_t lds_part = sizeof(E) * (size_t)P * Q + sizeof(K) * P + 8 * (size_t)P + 16;
     hipError_t he = hipFuncSetAttribute(reinterpret_cast<const void *>(&jpart_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part);
@@ -498,93 +671,101 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
     if (he == hipSuccess) {
         // one stream-ordered chain, one host read at the end: partition -> bucket probe -> survivor total
         jpart_kernel<K><<<dim3((unsigned)nwg), dim3(kJThreads), lds_part, st>>>(lcol, n, bias, splitters, rkeys, s, slabs, counts, cap, period, err);
-        jbucket_kernel<K><<<dim3((unsigned)P), dim3(kJThreads), lds_bucket, st>>>(slabs, counts, cap, nwg, rkeys, bstart, chunk_cap, surv, scount);
+        jbucket_kernel<K><<<dim3((unsigned)P), dim3(kJThreads), lds_bucket, st>>>(slabs, counts, cap, nwg, rkeys, bstart, chunk_cap, surv, scount, sround);
         jsum_kernel<<<1, 1024, 0, st>>>(scount, P, total);
+        hipMemcpyAsync(info + 2, flags, 8, hipMemcpyDeviceToDevice, st);       // the duplicate-keys flag rides along with the same host read
         he = hipGetLastError();
     }
     if (he != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: partition launch failed: %s", hipGetErrorString(he));
-    int64_t words[2] = {0, 0}, M = 0;
-    if (!rc) rc = hark_read_words(ctx, total, &M, 1);
-    if (!rc) rc = hark_read_words(ctx, err, words, 1);
-    if (!rc && (int32_t)(words[0] & 0xFFFFFFFFll) != 0) { cleanup(); return HARK_OK; }          // a slab overflowed (skew): caller falls back
+    int64_t words[3] = {0, 0, 0}, M = 0;
+    if (!rc) rc = hark_read_words(ctx, info, words, 3);
+    M = words[0];
+    if (!rc && (int32_t)(words[1] & 0xFFFFFFFFll) != 0) { cleanup(); return HARK_OK; }          // a slab overflowed (skew): caller falls back
+    const bool dup = ((words[2] >> 32) & 0xFFFFFFFFll) != 0;
+    *dup_out = dup;
     if (!rc && M > 0) {
         rc = hark_alloc(ctx, (void **)&rank, 4 * (size_t)M);
         if (!rc) rc = hark_alloc(ctx, (void **)&lrow, 4 * (size_t)M);
+        if (!rc && dup) rc = hark_alloc(ctx, (void **)&cnt, 4 * (size_t)M);     // unique build keys: every survivor has exactly one partner
         if (!rc) {
             if (getenv("HARK_JOIN_FULLSORT")) {                                  // A/B + tests: plain compaction, radix sorts by the caller
                 jcompact_kernel<<<dim3((unsigned)P), 256, 0, st>>>(surv, sstride, scount, P, rank, lrow);
-                hipMemsetAsync(unordered_dev, 1, 1, st);
+                hipMemsetAsync(flags, 1, 1, st);
             } else {
-                he = hipFuncSetAttribute(reinterpret_cast<const void *>(&jorder_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kOrderMax * 4);
-                if (he == hipSuccess) jorder_kernel<<<dim3((unsigned)P), dim3(kJThreads), (size_t)kOrderMax * 4, st>>>(surv, sstride, scount, bstart, P, rank, lrow, unordered_dev);
+                constexpr size_t lds_order = (size_t)kStage * 8 + (size_t)(kFine + 1) * 4 + (size_t)(kCoarse + 1) * 4;
+                he = hipFuncSetAttribute(reinterpret_cast<const void *>(&jorder_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_order);
+                int stage_cap = kStage;
+                if (const char *e = getenv("HARK_JOIN_STAGE")) { const int c = atoi(e); if (c >= 1 && c < stage_cap) stage_cap = c; }   // tests: many sub-rounds per bucket
+                if (he == hipSuccess) jorder_kernel<<<dim3((unsigned)P), dim3(kJThreads), lds_order, st>>>(surv, sstride, scount, sround, chunk_cap, bstart, P, runlen,
+                                                                                                           rank, lrow, cnt, stage_cap, flags,
+                                                                                                           getenv("HARK_JOIN_NOBIN") ? nullptr : reinterpret_cast<uint2 *>(slabs));
             }
-            if (he != hipSuccess || hipGetLastError() != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: compact launch failed");
+            if (he != hipSuccess || hipGetLastError() != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: order launch failed");
         }
     }
-    cleanup();                                                              // stream-ordered reuse: the compaction above is enqueued first
-    if (rc) { hark_free(ctx, rank); hark_free(ctx, lrow); return rc; }
-    *rank_out = rank; *lrow_out = lrow; *m_out = M; *used = true;
+    cleanup();                                                              // stream-ordered reuse: the ordering above is enqueued first
+    if (rc) { hark_free(ctx, rank); hark_free(ctx, lrow); hark_free(ctx, cnt); return rc; }
+    *rank_out = rank; *lrow_out = lrow; *cnt_out = cnt; *m_out = M; *used = true;
     return HARK_OK;
 }
 
 } // namespace
 
 // Matching probe rows of the join as (global rank of the first equal sorted build entry, probe row id), sorted by
-// (rank, probe row), and the partner count of each.  lcol: the probe key column (u32 bit patterns, or i64 when k64);
+// (rank, probe row), and the partner count of each (*cnt_out == nullptr with *unique: the build keys are all distinct,
+// every survivor has exactly one partner).  lcol: the probe key column (u32 bit patterns, or i64 when k64);
 // rkeys: the SORTED build keys (u32, or u64 biased by 2^63 when k64).  *used = false: nothing was produced (tiny input,
 // or skew overflowed a slab) and the caller takes the sort-merge path.  Outputs are pool blocks the caller frees.
 int k_join_partitioned(hark_context *ctx, const void *lcol, bool k64, int64_t n, const void *rkeys, int64_t s,
-                       uint32_t **rank_out, uint32_t **lrow_out, uint32_t **cnt_out, int64_t *m_out, bool *used)
+                       uint32_t **rank_out, uint32_t **lrow_out, uint32_t **cnt_out, int64_t *m_out, bool *used, bool *unique)
 {
-    *rank_out = nullptr; *lrow_out = nullptr; *cnt_out = nullptr; *m_out = 0; *used = false;
+    *rank_out = nullptr; *lrow_out = nullptr; *cnt_out = nullptr; *m_out = 0; *used = false; *unique = false;
     if (n < ((int64_t)1 << 18) || s < 4096 || n + s > 0xFFFFFFFFll) return HARK_OK;
     if (getenv("HARK_JOIN_SORTMERGE")) return HARK_OK;                          // A/B knob
-    uint32_t *rank = nullptr, *lrow = nullptr;
+    uint32_t *rank = nullptr, *lrow = nullptr, *cnt = nullptr, *runlen = nullptr;
     int64_t M = 0;
-    int32_t *flag = nullptr;                                   // [0] the survivors are not in rank order yet, or a run of equal rank is too long
+    int32_t *flag = nullptr;                                   // [0] the survivors need the general sort (skew), [1] duplicate build keys
     int rc = hark_alloc(ctx, (void **)&flag, 16);
-    if (rc) return rc;
+    if (!rc) rc = hark_alloc(ctx, (void **)&runlen, 4 * (size_t)s);
+    if (rc) { hark_free(ctx, flag); return rc; }
     hipMemsetAsync(flag, 0, 16, ctx->stream);
-    rc = k64 ? run_partitioned<uint64_t>(ctx, static_cast<const uint64_t *>(lcol), 0x8000000000000000ull, n, static_cast<const uint64_t *>(rkeys), s, &rank, &lrow, &M, used, flag)
-             : run_partitioned<uint32_t>(ctx, static_cast<const uint32_t *>(lcol), 0u, n, static_cast<const uint32_t *>(rkeys), s, &rank, &lrow, &M, used, flag);
-    if (rc || !*used) { hark_free(ctx, flag); return rc; }
-    if (M == 0) { hark_free(ctx, rank); hark_free(ctx, lrow); hark_free(ctx, flag); return HARK_OK; }
-    // (rank, left row) order.  Fast path: the survivors arrive ordered by rank (jorder_kernel); the short runs of equal
-    // rank are put in left-row order in place.  A run longer than kTieMax, or a slice too long for the LDS counters,
-    // takes the general path: stable radix sort by left row, then by rank (each skips the passes no byte needs).
-    uint32_t *rank1 = nullptr, *lrow1 = nullptr, *lrow2 = nullptr, *rank2 = nullptr, *runlen = nullptr, *cnt = nullptr;
-    int64_t general = 0;
-    {
-        int64_t g = (M + 255) / 256;
-        if (g > (int64_t)ctx->num_cu * 16) g = (int64_t)ctx->num_cu * 16;
-        jtiefix_kernel<<<dim3((unsigned)g), 256, 0, ctx->stream>>>(rank, lrow, M, flag);      // harmless on unordered input
-        if (hipGetLastError() != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: tie-fix launch failed");
-        if (!rc) rc = hark_read_words(ctx, flag, &general, 1);
-        general &= 0xFFFFFFFFll;
+    {   // run lengths of the sorted build keys: the partner count of a survivor is runlen[rank]
+        int64_t g1 = (s + 255) / 256;
+        const int64_t gcap = (int64_t)ctx->num_cu * 16;
+        if (g1 > gcap) g1 = gcap;
+        if (k64) jrunlen_kernel<uint64_t><<<dim3((unsigned)g1), 256, 0, ctx->stream>>>(static_cast<const uint64_t *>(rkeys), s, runlen, flag + 1);
+        else jrunlen_kernel<uint32_t><<<dim3((unsigned)g1), 256, 0, ctx->stream>>>(static_cast<const uint32_t *>(rkeys), s, runlen, flag + 1);
     }
+    bool dup = true;
+    rc = k64 ? run_partitioned<uint64_t>(ctx, static_cast<const uint64_t *>(lcol), 0x8000000000000000ull, n, static_cast<const uint64_t *>(rkeys), s, runlen, flag, &rank, &lrow, &cnt, &M, used, &dup)
+             : run_partitioned<uint32_t>(ctx, static_cast<const uint32_t *>(lcol), 0u, n, static_cast<const uint32_t *>(rkeys), s, runlen, flag, &rank, &lrow, &cnt, &M, used, &dup);
+    if (rc || !*used) { hark_free(ctx, flag); hark_free(ctx, runlen); return rc; }
+    if (M == 0) { hark_free(ctx, rank); hark_free(ctx, lrow); hark_free(ctx, cnt); hark_free(ctx, flag); hark_free(ctx, runlen); return HARK_OK; }
+    // (rank, left row) order.  Fast path: jorder_kernel delivered it.  A rank with more than kTieMax probe rows, or a
+    // group of ranks too crowded for the LDS stage, takes the general path: stable radix sort by left row, then by rank
+    // (each skips the passes no byte needs), partner counts looked up again.
+    uint32_t *rank1 = nullptr, *lrow1 = nullptr, *lrow2 = nullptr, *rank2 = nullptr;
+    int64_t general = 0;
+    rc = hark_read_words(ctx, flag, &general, 1);
+    general &= 0xFFFFFFFFll;
     if (!rc && general) {
         rc = k_sort_column(ctx, lrow, HARK_U32, M, false, rank, &rank1, &lrow1);
         if (!rc) rc = k_sort_column(ctx, rank1, HARK_U32, M, false, lrow1, &lrow2, &rank2);
         hark_free(ctx, rank1); hark_free(ctx, lrow1);
+        if (!rc && cnt) {
+            int64_t g2 = (M + 255) / 256;
+            const int64_t gcap = (int64_t)ctx->num_cu * 16;
+            if (g2 > gcap) g2 = gcap;
+            jcnt_kernel<<<dim3((unsigned)g2), 256, 0, ctx->stream>>>(rank2, M, runlen, cnt);
+            if (hipGetLastError() != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: count launch failed");
+        }
     } else if (!rc) {
         rank2 = rank; lrow2 = lrow; rank = lrow = nullptr;     // in place
     }
     hark_free(ctx, flag);
     hark_free(ctx, rank); hark_free(ctx, lrow);
-    if (!rc) rc = hark_alloc(ctx, (void **)&runlen, 4 * (size_t)s);
-    if (!rc) rc = hark_alloc(ctx, (void **)&cnt, 4 * (size_t)M);
-    if (!rc) {
-        int64_t g1 = (s + 255) / 256, g2 = (M + 255) / 256;
-        const int64_t gcap = (int64_t)ctx->num_cu * 16;
-        if (g1 > gcap) g1 = gcap;
-        if (g2 > gcap) g2 = gcap;
-        if (k64) jrunlen_kernel<uint64_t><<<dim3((unsigned)g1), 256, 0, ctx->stream>>>(static_cast<const uint64_t *>(rkeys), s, runlen);
-        else jrunlen_kernel<uint32_t><<<dim3((unsigned)g1), 256, 0, ctx->stream>>>(static_cast<const uint32_t *>(rkeys), s, runlen);
-        jcnt_kernel<<<dim3((unsigned)g2), 256, 0, ctx->stream>>>(rank2, M, runlen, cnt);
-        if (hipGetLastError() != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: count launch failed");
-    }
     hark_free(ctx, runlen);
     if (rc) { hark_free(ctx, lrow2); hark_free(ctx, rank2); hark_free(ctx, cnt); *used = false; return rc; }
-    *rank_out = rank2; *lrow_out = lrow2; *cnt_out = cnt; *m_out = M;
+    *rank_out = rank2; *lrow_out = lrow2; *cnt_out = cnt; *m_out = M; *unique = !dup;
     return HARK_OK;
 }

@@ -29,7 +29,7 @@ int k_sort_column(hark_context *ctx, const void *col, int dtype, int64_t n, bool
 int k_exclusive_scan_u32(hark_context *ctx, const uint32_t *in, int64_t n, uint32_t *out32, int64_t *out64, int64_t *total_host);
 // k_hjoin.hip: the partitioned path (probe side range-partitioned by splitters of the sorted build side, build slices in LDS)
 int k_join_partitioned(hark_context *ctx, const void *lcol, bool k64, int64_t n, const void *rkeys, int64_t s,
-                       uint32_t **rank_out, uint32_t **lrow_out, uint32_t **cnt_out, int64_t *m_out, bool *used);
+                       uint32_t **rank_out, uint32_t **lrow_out, uint32_t **cnt_out, int64_t *m_out, bool *used, bool *unique);
 
 namespace {
 
@@ -277,7 +277,7 @@ int hark_entry_join(hark_context *ctx, hark_result **out, const hark_table *db1,
     int rc = HARK_OK;
     int64_t nl = n;                                   // left rows that reach the sort + merge
     const void *lcol = db1->cols[col1].data, *rcol = db2->cols[col2].data;
-    bool filtered = false, partitioned = false;
+    bool filtered = false, partitioned = false, unique = false;   // unique: partitioned path, all build keys distinct (one partner per survivor)
     // ---- the build side is sorted first: both paths need it
     rc = k_argsort_column(ctx, rcol, k64 ? HARK_I64 : HARK_U32, s, false, &rperm, k64 ? nullptr : &rkeys);
     if (!rc && k64) {
@@ -289,11 +289,12 @@ int hark_entry_join(hark_context *ctx, hark_result **out, const hark_table *db1,
         uint32_t *prank = nullptr, *plrow = nullptr, *pcnt = nullptr;
         int64_t M = 0;
         rc = k_join_partitioned(ctx, lcol, k64, n, k64 ? static_cast<const void *>(rk64) : static_cast<const void *>(rkeys), s,
-                                &prank, &plrow, &pcnt, &M, &partitioned);
+                                &prank, &plrow, &pcnt, &M, &partitioned, &unique);
         if (!rc && partitioned) {
             nl = M;
             lb = prank; lperm = plrow; cnt = pcnt;                 // freed with the other scratch below
-            if (M > 0) {
+            if (unique) P = M;                                     // no counts, no scan, no expansion: survivor i IS output row i
+            else if (M > 0) {
                 rc = hark_alloc(ctx, (void **)&offs, (size_t)M * 8);
                 if (!rc) rc = k_exclusive_scan_u32(ctx, cnt, M, nullptr, offs, &P);
             }
@@ -371,14 +372,18 @@ int hark_entry_join(hark_context *ctx, hark_result **out, const hark_table *db1,
         for (int64_t j = 0; j < k && !rc; j++)
             if (cols2[j] < 0 || cols2[j] >= db2->m) rc = hark_fail(ctx, HARK_EBOUNDS, "join: cols2[%lld] = %d out of bounds", (long long)j, cols2[j]);
 
-        if (!rc) rc = hark_alloc(ctx, (void **)&lrow, (size_t)P * 4);
+        if (!rc && !unique) rc = hark_alloc(ctx, (void **)&lrow, (size_t)P * 4);
         if (!rc) rc = hark_alloc(ctx, (void **)&rrow, (size_t)P * 4);
         // an output column that IS the join key of either side is read off the SORTED build keys (ascending positions:
         // a coalesced read) instead of being gathered at random through the row ids
         bool key_out = false;
         for (int64_t j = 0; j < l + k && !rc; j++) key_out = key_out || (j < l ? cols1[j] == col1 : cols2[j - l] == col2);
-        if (!rc && key_out) rc = hark_alloc(ctx, (void **)&kpos, (size_t)P * 4);
-        if (!rc) {
+        if (!rc && key_out && !unique) rc = hark_alloc(ctx, (void **)&kpos, (size_t)P * 4);
+        if (!rc && unique) {                               // (left row, rank) pairs are the output rows: the right row id is one gather away
+            lrow = lperm; lperm = nullptr;
+            kpos = lb; lb = nullptr;
+            rc = k_gather(ctx, rperm, 4, kpos, rrow, P);
+        } else if (!rc) {
             join_expand_kernel<<<grid_for(ctx, nl), 256, 0, st>>>(offs, cnt, nl, lb, lperm, rperm, lrow, rrow, kpos);
             if (hipGetLastError() != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: launch failed");
         }

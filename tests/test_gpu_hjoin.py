@@ -59,6 +59,8 @@ CASES = {
     "i64 signed keys": dict(dt=np.int64, n=(1 << 18) + 5, s=30_000, pool=None, hit=0.5),
     "i64 duplicates both sides": dict(dt=np.int64, n=300_001, s=20_000, pool=4_000, hit=0.2),
     "build side larger than probe": dict(dt=np.uint32, n=1 << 18, s=600_000, pool=None, hit=0.4),
+    "u32 unique build keys (primary key): no counts, no expansion": dict(dt=np.uint32, n=400_000, s=60_000, pool=None, hit=0.5, unique=True),
+    "i64 unique build keys, every second probe row hits": dict(dt=np.int64, n=(1 << 19) + 3, s=100_000, pool=None, hit=0.5, unique=True),
 }
 
 
@@ -70,6 +72,8 @@ def _make(case, seed):
     if c["pool"]:
         pool = rng.integers(info.min, info.max, size=c["pool"], dtype=np.int64).astype(dt)
         rk = pool[rng.integers(0, len(pool), size=s)]
+    elif c.get("unique"):
+        rk = (rng.permutation(s).astype(np.int64) * 40503 - 1_000_000_007).astype(dt)     # distinct, scattered, some negative
     else:
         rk = rng.integers(info.min, info.max, size=s, dtype=np.int64).astype(dt)
     lk = rng.integers(info.min, info.max, size=n, dtype=np.int64).astype(dt)
@@ -112,7 +116,8 @@ sys.path.insert(0, %r)
 import test_gpu_hjoin as T
 from harkdb_amd.engine import Engine
 eng = Engine(0)
-for case in ("u32 every row hits, 8 partners each", "i64 duplicates both sides", "u32 few distinct keys (duplicate splitters)"):
+for case in ("u32 every row hits, 8 partners each", "i64 duplicates both sides", "u32 few distinct keys (duplicate splitters)",
+             "i64 unique build keys, every second probe row hits", "u32 10%% hits"):
     lk, rk = T._make(case, 3)
     print(case, T._check(eng, lk, rk))
 print("rounds ok")
@@ -124,6 +129,16 @@ def test_build_slices_longer_than_lds_take_rounds(chunk):
     """HARK_JOIN_CHUNK caps the build keys staged per round (a test knob), so every bucket needs many rounds and runs of
     equal keys cross round boundaries: the results must not change."""
     env = dict(os.environ, HARK_JOIN_CHUNK=chunk)
+    out = subprocess.run([sys.executable, "-c", _ROUNDS % (ROOT, os.path.join(ROOT, "tests"))], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0 and "rounds ok" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("cap", ["40", "700"])
+def test_rank_order_in_sub_rounds(cap):
+    """HARK_JOIN_STAGE caps the survivors the order kernel stages in LDS per sub-round (a test knob; at full size a
+    bucket has far more survivors than the stage holds), so every bucket takes many sub-rounds, and with 40 some groups
+    of ranks do not fit at all and the general radix path runs: same rows, same order."""
+    env = dict(os.environ, HARK_JOIN_STAGE=cap)
     out = subprocess.run([sys.executable, "-c", _ROUNDS % (ROOT, os.path.join(ROOT, "tests"))], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0 and "rounds ok" in out.stdout, out.stdout + out.stderr
 
