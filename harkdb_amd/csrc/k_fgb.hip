@@ -381,6 +381,13 @@ __device__ __forceinline__ bool wg_or(bool pred, uint32_t *flags, int &phase)
 // so the batch loop carries no run-time knobs: a bucket's queue state is ONE word (head << 16 | count,
 // one returning LDS atomic hands a row its slot), keys are range-checked as unsigned 32-bit, and the
 // ragged-end tests only run in the last batch.
+// one surviving row straight into the global table (slab / ring overflow fallback); vop < 0: COUNT only
+__device__ __noinline__ void fgb_direct_row(u64 *gsum, unsigned long long *gcnt, uint32_t key, uint32_t vb, int vop)
+{
+    if (vop >= 0) vop_atomic_rt(vop, &gsum[key], vb);
+    atomicAdd(&gcnt[key], 1ull);
+}
+
 template <int OP, int MODE, int FMT>
 __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
     const float *__restrict__ p, const int32_t *__restrict__ k, const float *__restrict__ v,
@@ -428,10 +435,9 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
     __syncthreads();
 
     auto vbits_of = [&](float x) -> uint32_t { return MODE == 0 ? __float_as_uint(x) : apply_xf(xf, __float_as_uint(x)); };
-    auto direct = [&](uint32_t key, uint32_t vb) {
-        if (!K2) { if (MODE == 0) vop_atomic<VOP_F32SUM>(&gsum[key], vb); else vop_atomic_rt(vop, &gsum[key], vb); }
-        atomicAdd(&gcnt[key], 1ull);
-    };
+    // (a call, not inlined: inlined, the compiler hoisted the fallback's f32->f64 conversions and 64-bit address
+    // arithmetic of all four rows out of the retry loop into the hot path of every batch)
+    auto direct = [&](uint32_t key, uint32_t vb) { fgb_direct_row(gsum, gcnt, key, vb, K2 ? -1 : (MODE == 0 ? (int)VOP_F32SUM : vop)); };
 
     auto load = [&](int64_t batch, float4 &pr, int4 &kr, float4 &vr) {
         const int64_t r = row0 + batch * kBatchRows + (int64_t)tid * kVec;
@@ -509,11 +515,21 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
         int rounds = 0;
         do {
             // ---- enqueue: one returning LDS atomic per surviving row gives it the queue position and the head
+            // the four returning atomics are issued back to back (one LDS round trip per batch instead of four)
+            uint32_t olds[kVec];
+#pragma unroll
+            for (int j = 0; j < kVec; j++) {
+                olds[j] = 0u;
+                if (pending & (1u << j)) {
+                    const uint32_t key = (uint32_t)kv[j], b = HASH ? mix32(key) >> (32 - hash_bits) : key >> shift;
+                    olds[j] = atomicAdd(&s_w[b], 1u);
+                }
+            }
 #pragma unroll
             for (int j = 0; j < kVec; j++) {
                 if (pending & (1u << j)) {
                     const uint32_t key = (uint32_t)kv[j], b = HASH ? mix32(key) >> (32 - hash_bits) : key >> shift;
-                    const uint32_t old = atomicAdd(&s_w[b], 1u), pos = old & 0xFFFFu;
+                    const uint32_t old = olds[j], pos = old & 0xFFFFu;
                     if (C6) {
                         if (pos < (uint32_t)kQ6) {
                             const int at = (int)b * kQ6 + wrap6((int)(old >> 16) + (int)pos);
