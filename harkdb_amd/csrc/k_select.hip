@@ -37,10 +37,10 @@ __global__ __launch_bounds__(256) void copy_columns_kernel(ColSet cs, int64_t n)
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (; i + stride < nvec; i += 2 * stride) {      // two 16-byte loads in flight per lane
-        uint4 a = s4[i], b = s4[i + stride];
-        d4[i] = a; d4[i + stride] = b;
+        const uint4 a = ld_nt16(s4 + i), b = ld_nt16(s4 + i + stride);
+        st_nt16(d4 + i, a); st_nt16(d4 + i + stride, b);
     }
-    for (; i < nvec; i += stride) d4[i] = s4[i];
+    for (; i < nvec; i += stride) st_nt16(d4 + i, ld_nt16(s4 + i));
     if (blockIdx.x == 0) {                            // tail bytes (n*esz not a multiple of 16)
         const uint32_t *s1 = static_cast<const uint32_t *>(cs.src[col]);
         uint32_t *d1 = static_cast<uint32_t *>(cs.dst[col]);
@@ -84,10 +84,10 @@ __device__ __forceinline__ uint32_t eval_tile(const T *__restrict__ col, int64_t
         if (r + 4 <= n) {
             T x[4];
             if constexpr (sizeof(T) == 4) {
-                uint4 q = *reinterpret_cast<const uint4 *>(col + r);
+                uint4 q = ld_nt16(col + r);
                 memcpy(x, &q, 16);
             } else {
-                uint4 q0 = *reinterpret_cast<const uint4 *>(col + r), q1 = *reinterpret_cast<const uint4 *>(col + r + 2);
+                uint4 q0 = ld_nt16(col + r), q1 = ld_nt16(col + r + 2);
                 memcpy(x, &q0, 16); memcpy(x + 2, &q1, 16);
             }
 #pragma unroll
@@ -155,11 +155,11 @@ __global__ __launch_bounds__(256) void pred_bitmask_kernel(const T *__restrict__
             if (r + 8 <= n) {
                 T x[8];
                 if constexpr (sizeof(T) == 4) {
-                    const uint4 q0 = *reinterpret_cast<const uint4 *>(col + r), q1 = *reinterpret_cast<const uint4 *>(col + r + 4);
+                    const uint4 q0 = ld_nt16(col + r), q1 = ld_nt16(col + r + 4);
                     memcpy(x, &q0, 16); memcpy(x + 4, &q1, 16);
                 } else {
 #pragma unroll
-                    for (int h = 0; h < 4; h++) { const uint4 q = *reinterpret_cast<const uint4 *>(col + r + 2 * h); memcpy(x + 2 * h, &q, 16); }
+                    for (int h = 0; h < 4; h++) { const uint4 q = ld_nt16(col + r + 2 * h); memcpy(x + 2 * h, &q, 16); }
                 }
 #pragma unroll
                 for (int j = 0; j < 8; j++) m |= (uint32_t)cmp_val<T>(op, x[j], cv) << j;
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(kThreads) void filter_scatter_kernel(const uint16_t
             } else if (esz == 4) {
                 const uint32_t *src = static_cast<const uint32_t *>(cs.src[cidx]);
                 uint32_t x[4];
-                if (r + 4 <= n) { const uint4 v4 = *reinterpret_cast<const uint4 *>(src + r); x[0] = v4.x; x[1] = v4.y; x[2] = v4.z; x[3] = v4.w; }
+                if (r + 4 <= n) { const uint4 v4 = ld_nt16(src + r); x[0] = v4.x; x[1] = v4.y; x[2] = v4.z; x[3] = v4.w; }
                 else for (int j = 0; j < 4; j++) x[j] = r + j < n ? src[r + j] : 0u;
 #pragma unroll
                 for (int j = 0; j < 4; j++) if (m4 & (1u << j)) s32[q++] = x[j];
