@@ -168,11 +168,14 @@ __global__ __launch_bounds__(kJThreads) void jpart_kernel(const K *__restrict__ 
         }
         bool again;
         do {
+            uint32_t olds[VEC];                                        // the returning atomics of a lane are issued back to back: one LDS round trip
+#pragma unroll
+            for (int j = 0; j < VEC; j++) { olds[j] = 0u; if (pending & (1u << j)) olds[j] = atomicAdd(&s_w[bk[j]], 1u); }
 #pragma unroll
             for (int j = 0; j < VEC; j++) {
                 if (pending & (1u << j)) {
                     const uint32_t b = bk[j];
-                    const uint32_t old = atomicAdd(&s_w[b], 1u), pos = old & 0xFFFFu;
+                    const uint32_t old = olds[j], pos = old & 0xFFFFu;
                     if (pos < (uint32_t)Q) {
                         E e; e.key = kk[j]; e.row = (uint32_t)(r + j);
                         if (sizeof(E) == 16) reinterpret_cast<uint32_t *>(&e)[3] = 0u;
