@@ -329,7 +329,9 @@ def main():
         knobs["chunk_rows"] = a.chunk_rows
     plan = FgbPlan(eng, N, G, **knobs)
     # N > 1: a second plan lets step i's all-reduce run on RCCL's stream beside the kernels of step i+1 (dist.ShardedFgb)
-    plan2 = FgbPlan(eng, N, G, **knobs) if world > 1 and os.environ.get("HARK_OVERLAP", "1") != "0" else None
+    # (HARK_FORCE_PIPELINE=1: also with one rank -- tests/test_gpu_bench_rank.py runs the pipelined, asynchronous
+    # all-reduce path under RCCL on the one GPU a test box has)
+    plan2 = FgbPlan(eng, N, G, **knobs) if (world > 1 or os.environ.get("HARK_FORCE_PIPELINE")) and os.environ.get("HARK_OVERLAP", "1") != "0" else None
     job = hd.ShardedFgb(eng, plan, dev, plan2=plan2)
 
     def step():
@@ -437,7 +439,8 @@ def main():
                        "rows_per_gpu": N, "groups": G, "selectivity": 0.5, "columns": "p f32, k i32, v f32 (HBM-resident)",
                        "exact_values": bool(a.exact),
                        "merge": ("RCCL " + ("reduce-scatter + all-gather" if os.environ.get("HARK_ALLREDUCE") == "rs_ag" else "all-reduce")
-                                 + " of f64 sums + i64 counts" + (", overlapped with the next step's kernels" if plan2 is not None else "")) if world > 1 else "none"},
+                                 + " of f64 sums + i64 counts" + (", overlapped with the next step's kernels" if plan2 is not None else "")) if dist.is_initialized() else "none",
+                       "pipelined_steps": plan2 is not None},
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": path_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": path_achieved / HBM_PEAK_GBS,
                          "frac_is": "whole path per GPU: (12 B/row x rows + 16 B x groups) / wall time of a step / 8 TB/s",
