@@ -946,6 +946,231 @@ __global__ __launch_bounds__(1024) void fgb_agg6_stats_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// Two aggregates of two DIFFERENT columns in one pass ("pair pass")
+// ---------------------------------------------------------------------------
+// One producer + consumer pass per (operator, column) re-reads the predicate and key columns every time
+// (BASELINE configs[4] with three aggregates: three passes).  Here a pair carries the raw 32 bits of TWO value columns:
+// 10 bytes (value 1, value 2, 16-bit bucket-local key), units of 64 pairs = 256 B + 256 B + 128 B (five whole lines), in
+// HALF as many buckets as the one-value passes use (<= 128 buckets of <= 8192 keys): rings of 112 pairs (a unit + 48 of
+// headroom) are 140 KiB of LDS.  (A first version with 256 buckets, units of 32 pairs = 2.5 lines and 24 pairs of
+// headroom ran at 2.44 ms per 5e8 rows against 1.47 ms for a one-value pass: twice the sweeps, half-line stores, rings
+// overflowing.)  Three values do not fit at all: 128 rings of 14-byte pairs are 172 KiB.  The consumer keeps 16 B per
+// key -- a 64-bit slot for value 1 (any operator), the row count, and a 32-bit slot for value 2, which therefore must be
+// a MAX or MIN (order words) -- 128 KiB for 8192 keys, and TWO workgroups share a bucket (even / odd slabs) so that all
+// 256 CUs work; they merge into the global table with contiguous atomics.
+// Like the statistics pass this one has no single-row fallback: skew that overflows a ring or a slab reports
+// kErrOverflow and the caller runs the separate passes.
+constexpr int kU10 = 64;                                 // pairs per unit
+constexpr int kUnit10Bytes = kU10 * 10;                  // 640
+constexpr int kQ10 = 112;                                // ring capacity per bucket (pairs): a unit + 48 of headroom; 112 = 14 x 8 keeps 16-byte pieces whole across the wrap
+constexpr int kPairBuckets = 128;
+static size_t part2_lds_bytes(int P) { return (size_t)10 * P * kQ10 + sizeof(uint32_t) * 2 * (size_t)P + 32; }
+
+template <int OP>
+__global__ __launch_bounds__(kPartThreads) void fgb_part2_kernel(
+    const float *__restrict__ p, const int32_t *__restrict__ k, const uint32_t *__restrict__ v1, const uint32_t *__restrict__ v2,
+    int64_t row0, int64_t row1, float thr, int64_t G, int shift, int P,
+    unsigned char *__restrict__ pbuf, uint32_t *__restrict__ counts, size_t slab_bytes, int32_t *__restrict__ err)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    uint32_t *q1 = reinterpret_cast<uint32_t *>(lds_raw);                  // [P][kQ10] value 1
+    uint32_t *q2 = q1 + (size_t)P * kQ10;                                  // [P][kQ10] value 2
+    uint16_t *qk = reinterpret_cast<uint16_t *>(q2 + (size_t)P * kQ10);    // [P][kQ10] bucket-local keys
+    uint32_t *s_w = reinterpret_cast<uint32_t *>(qk + (size_t)P * kQ10);   // [P] ring index of the oldest pair << 16 | pairs queued
+    int *s_lcur = reinterpret_cast<int *>(s_w + P);                        // [P] units already stored in this workgroup's slab
+    uint32_t *or_flags = reinterpret_cast<uint32_t *>(s_lcur + P);         // [3] wg_or slots
+    const int tid = threadIdx.x, nwg = gridDim.x, wg = blockIdx.x;
+    const int64_t nbatch = (row1 - row0 + kBatchRows - 1) / kBatchRows;
+    const int cap_units = (int)(slab_bytes / kUnit10Bytes) - 1;            // the last unit for the final partial flush
+    const uint32_t kmask = (1u << shift) - 1u, Gu = (uint32_t)G;
+    auto slab_of = [&](int b) -> unsigned char * { return pbuf + ((size_t)b * nwg + wg) * slab_bytes; };
+    auto wrap = [](int x) { return x >= kQ10 ? x - kQ10 : x; };
+    for (int b = tid; b < P; b += kPartThreads) { s_w[b] = 0u; s_lcur[b] = 0; }
+    if (tid < 4) or_flags[tid] = 0u;
+    int or_phase = 0, period = 2, since_sweep = 0, n_full = 0, batches_done = 0;
+    bool bad = false, overflow = false;
+    __syncthreads();
+
+    struct Rows { float4 p; int4 k; uint4 a, b; };
+    auto load = [&](int64_t batch, Rows &r) {
+        const int64_t rb = row0 + batch * kBatchRows;                      // workgroup-uniform
+        const uint32_t lo = (uint32_t)tid * kVec;
+        if (rb + kBatchRows <= row1) {
+            if (OP == kMaskPred) {
+                const uint32_t byte = (reinterpret_cast<const uint8_t *>(p) + (rb >> 3))[lo >> 3];
+                r.p = float4{__uint_as_float((byte >> (lo & 4u)) & 15u), 0, 0, 0};
+            } else if (OP != kNoPred) { const uint4 t = ld_nt16(p + rb + lo); r.p = float4{__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w)}; }
+            else r.p = float4{0, 0, 0, 0};
+            const uint4 tk = ld_nt16(k + rb + lo); r.k = int4{(int)tk.x, (int)tk.y, (int)tk.z, (int)tk.w};
+            r.a = ld_nt16(v1 + rb + lo); r.b = ld_nt16(v2 + rb + lo);
+        } else {                                                           // ragged end of the table
+            const int64_t r0 = rb + lo;
+            float pp[4] = {0, 0, 0, 0}; int kk[4] = {0, 0, 0, 0}; uint32_t aa[4] = {0, 0, 0, 0}, bb[4] = {0, 0, 0, 0};
+            for (int j = 0; j < kVec; j++) if (r0 + j < row1) {
+                pp[j] = OP == kNoPred ? 0.0f : OP == kMaskPred ? mask_bit(p, r0 + j) : p[r0 + j]; kk[j] = k[r0 + j]; aa[j] = v1[r0 + j]; bb[j] = v2[r0 + j];
+            }
+            if (OP == kMaskPred) pp[0] = __uint_as_float((uint32_t)(pp[0] != 0.0f) | ((uint32_t)(pp[1] != 0.0f) << 1) | ((uint32_t)(pp[2] != 0.0f) << 2) | ((uint32_t)(pp[3] != 0.0f) << 3));
+            r.p = float4{pp[0], pp[1], pp[2], pp[3]}; r.k = int4{kk[0], kk[1], kk[2], kk[3]};
+            r.a = uint4{aa[0], aa[1], aa[2], aa[3]}; r.b = uint4{bb[0], bb[1], bb[2], bb[3]};
+        }
+    };
+
+    // every complete unit of every ring leaves for the workgroup's slabs: 8 lanes per bucket, 16 bytes per lane and piece
+    auto sweep = [&]() {
+        for (int b = tid >> 3; b < P; b += kPartThreads / 8) {
+            const uint32_t w = s_w[b];
+            const int cnt = (int)(w & 0xFFFFu);
+            if (cnt >= kU10) {
+                const int i = tid & 7, head = (int)(w >> 16), lc = s_lcur[b];
+                const int iv0 = wrap(head + 4 * i), iv1 = wrap(head + 32 + 4 * i), ik = wrap(head + 8 * i);
+                const uint4 a0 = *reinterpret_cast<const uint4 *>(&q1[b * kQ10 + iv0]), a1 = *reinterpret_cast<const uint4 *>(&q1[b * kQ10 + iv1]);
+                const uint4 c0 = *reinterpret_cast<const uint4 *>(&q2[b * kQ10 + iv0]), c1 = *reinterpret_cast<const uint4 *>(&q2[b * kQ10 + iv1]);
+                const uint4 kk = *reinterpret_cast<const uint4 *>(&qk[b * kQ10 + ik]);
+                if (lc < cap_units) {
+                    unsigned char *dst = slab_of(b) + (size_t)lc * kUnit10Bytes;
+                    st_nt16(dst + 16 * i, a0); st_nt16(dst + 128 + 16 * i, a1);
+                    st_nt16(dst + 256 + 16 * i, c0); st_nt16(dst + 384 + 16 * i, c1);
+                    st_nt16(dst + 512 + 16 * i, kk);
+                } else overflow = true;
+                if (i == 0) {
+                    s_w[b] = ((uint32_t)wrap(head + kU10) << 16) | (uint32_t)(cnt - kU10);
+                    s_lcur[b] = min(lc + 1, cap_units);
+                }
+            }
+        }
+    };
+
+    auto process = [&](int64_t batch, const Rows &r, const bool flush_now) {
+        const float pv[4] = {r.p.x, r.p.y, r.p.z, r.p.w};
+        const int kv[4] = {r.k.x, r.k.y, r.k.z, r.k.w};
+        const uint32_t av[4] = {r.a.x, r.a.y, r.a.z, r.a.w}, bv[4] = {r.b.x, r.b.y, r.b.z, r.b.w};
+        const int64_t bend = row0 + (batch + 1) * kBatchRows;
+        bool sv[kVec];
+        if (OP == kMaskPred) {
+            const uint32_t nib = __float_as_uint(pv[0]);
+#pragma unroll
+            for (int j = 0; j < kVec; j++) sv[j] = (nib >> j) & 1u;
+        } else if (bend <= row1) {
+#pragma unroll
+            for (int j = 0; j < kVec; j++) sv[j] = cmp_f32<OP>(pv[j], thr);
+        } else {
+            const int64_t r0 = row0 + batch * kBatchRows + (int64_t)tid * kVec;
+#pragma unroll
+            for (int j = 0; j < kVec; j++) sv[j] = r0 + j < row1 && cmp_f32<OP>(pv[j], thr);
+        }
+#pragma unroll
+        for (int j = 0; j < kVec; j++) { const bool inr = (uint32_t)kv[j] < Gu; bad |= sv[j] && !inr; sv[j] = sv[j] && inr; }
+        batches_done++;
+        bool again;
+        int rounds = 0;
+        do {
+            uint32_t olds[kVec];                                           // the returning atomics of a lane back to back
+#pragma unroll
+            for (int j = 0; j < kVec; j++) { olds[j] = 0u; if (sv[j]) olds[j] = atomicAdd(&s_w[(uint32_t)kv[j] >> shift], 1u); }
+#pragma unroll
+            for (int j = 0; j < kVec; j++) {
+                if (sv[j]) {
+                    const uint32_t key = (uint32_t)kv[j], b = key >> shift, old = olds[j], pos = old & 0xFFFFu;
+                    if (pos < (uint32_t)kQ10) {
+                        const int at = (int)__umul24(b, (uint32_t)kQ10) + wrap((int)(old >> 16) + (int)pos);
+                        q1[at] = av[j]; q2[at] = bv[j]; qk[at] = (uint16_t)(key & kmask);
+                        sv[j] = false;
+                    } else atomicSub(&s_w[b], 1u);                         // ring full: retry after the sweep
+                }
+            }
+            const bool full = wg_or(sv[0] | sv[1] | sv[2] | sv[3], or_flags, or_phase);
+            if (full && ++n_full * 8 > batches_done) period = 1;          // rings overflow often (selectivity / skew): sweep every batch
+            if (!(full || flush_now)) break;
+            sweep();
+            since_sweep = 0;
+            if (++rounds >= kRetryRoundsHash) { if (sv[0] | sv[1] | sv[2] | sv[3]) overflow = true; sv[0] = sv[1] = sv[2] = sv[3] = false; }
+            again = wg_or(sv[0] | sv[1] | sv[2] | sv[3], or_flags, or_phase);
+        } while (again);
+    };
+
+    Rows A, B;
+    if ((int64_t)wg < nbatch) load(wg, A);
+    if ((int64_t)wg + nwg < nbatch) load((int64_t)wg + nwg, B);
+    for (int64_t batch = wg; batch < nbatch; batch += nwg) {
+        const Rows cur = A;
+        A = B;
+        if (batch + 2 * (int64_t)nwg < nbatch) load(batch + 2 * (int64_t)nwg, B);
+        process(batch, cur, ++since_sweep >= period || batch + nwg >= nbatch);
+    }
+    // what is left (< kU10 pairs per bucket) goes out as one partial unit
+    for (int b = tid; b < P; b += kPartThreads) {
+        const uint32_t w = s_w[b];
+        const int l = (int)(w & 0xFFFFu), head = (int)(w >> 16);
+        unsigned char *dst = slab_of(b) + (size_t)s_lcur[b] * kUnit10Bytes;
+        for (int j = 0; j < l; j++) {
+            const int at = b * kQ10 + wrap(head + j);
+            reinterpret_cast<uint32_t *>(dst)[j] = q1[at]; reinterpret_cast<uint32_t *>(dst + 256)[j] = q2[at]; reinterpret_cast<uint16_t *>(dst + 512)[j] = qk[at];
+        }
+        counts[(size_t)b * nwg + wg] = (uint32_t)(s_lcur[b] * kU10 + l);
+    }
+    if (bad) *err = HARK_EBOUNDS;
+    if (overflow) *err = kErrOverflow;
+}
+
+// Consumer of the pair pass: one workgroup per bucket, LDS slice of 16 B per key (64-bit slot of value 1, row count,
+// 32-bit slot of value 2).  VOP1: any of F32SUM / U32SUM64 / U32MAX / U32MIN (the last two in the low word);
+// VOP2: U32MAX or U32MIN.  xf1 / xf2: order transforms of the raw bits (apply_xf).
+template <int VOP1, int VOP2>
+__global__ __launch_bounds__(1024) void fgb_agg10_kernel(
+    const unsigned char *__restrict__ pbuf, const uint32_t *__restrict__ counts, size_t slab_bytes, int nwg, int shift,
+    int64_t G, u64 *__restrict__ gsum, unsigned long long *__restrict__ gcnt, u64 *__restrict__ g2, int xf1, int xf2)
+{
+    typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+    typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int KPB = 1 << shift;
+    u64 *s_a = reinterpret_cast<u64 *>(lds_raw);
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(lds_raw + sizeof(u64) * KPB);
+    uint32_t *s_b = s_cnt + KPB;
+    const int b = blockIdx.x >> 1, half = blockIdx.x & 1;              // two workgroups per bucket: even / odd slabs
+    const uint32_t id2 = VOP2 == VOP_U32MIN ? 0xFFFFFFFFu : 0u;
+    for (int i = threadIdx.x; i < KPB; i += blockDim.x) { s_a[i] = vop_identity(VOP1); s_cnt[i] = 0u; s_b[i] = id2; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const uint32_t max_pairs = (uint32_t)(slab_bytes / kUnit10Bytes) * kU10;
+    auto add = [&](uint32_t key, uint32_t ra, uint32_t rb) {
+        vop_atomic<VOP1>(&s_a[key], VOP1 == VOP_F32SUM ? ra : apply_xf(xf1, ra));
+        atomicAdd(&s_cnt[key], 1u);
+        const uint32_t w = apply_xf(xf2, rb);
+        if constexpr (VOP2 == VOP_U32MIN) atomicMin(&s_b[key], w); else atomicMax(&s_b[key], w);
+    };
+    const int piece = lane & 15, sub = lane >> 4;                     // 16 lanes per unit (16 B of each value, 8 B of keys per lane), 4 units per wave and step
+    for (int w = 2 * wave + half; w < nwg; w += 2 * nwaves) {
+        const uint32_t count = min(counts[(size_t)b * nwg + w], max_pairs);
+        const unsigned char *src = pbuf + ((size_t)b * nwg + w) * slab_bytes;
+        const uint32_t units = count / kU10, rem = count % kU10;
+        for (uint32_t u = sub; u < units; u += 4) {
+            const unsigned char *a = src + (size_t)u * kUnit10Bytes;
+            const u4v va = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(a + 16 * piece));
+            const u4v vb = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(a + 256 + 16 * piece));
+            const u2v kk = __builtin_nontemporal_load(reinterpret_cast<const u2v *>(a + 512 + 8 * piece));
+            add(kk.x & 0xFFFFu, va.x, vb.x); add(kk.x >> 16, va.y, vb.y); add(kk.y & 0xFFFFu, va.z, vb.z); add(kk.y >> 16, va.w, vb.w);
+        }
+        if ((uint32_t)lane < rem) {
+            const unsigned char *a = src + (size_t)units * kUnit10Bytes;
+            add(reinterpret_cast<const uint16_t *>(a + 512)[lane], reinterpret_cast<const uint32_t *>(a)[lane], reinterpret_cast<const uint32_t *>(a + 256)[lane]);
+        }
+    }
+    __syncthreads();
+    // the two workgroups of a bucket meet in the global table: contiguous atomics (one per touched key and accumulator)
+    const int64_t kbase = (int64_t)b << shift;
+    for (int i = threadIdx.x; i < KPB; i += blockDim.x) {
+        const uint32_t c = s_cnt[i];
+        if (c && kbase + i < G) {
+            vop_atomic_partial<VOP1>(&gsum[kbase + i], s_a[i]);
+            atomicAdd(&gcnt[kbase + i], (unsigned long long)c);
+            uint32_t *lo = reinterpret_cast<uint32_t *>(&g2[kbase + i]);           // the order word lives in the low half of the 64-bit slot
+            if constexpr (VOP2 == VOP_U32MIN) atomicMin(lo, s_b[i]); else atomicMax(lo, s_b[i]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Hash flavour of the consumer: arbitrary u32 keys ("LDS-staged hash buckets")
 // ---------------------------------------------------------------------------
 // The producer routed pairs by the top bits of mix32(key).  One workgroup per bucket builds an
@@ -1604,6 +1829,73 @@ int k_fgb_dense_stats(hark_context *ctx, hark_fgb_plan *pl, const float *p, int 
                     (uint32_t)pl->cap, nwg, shift, G, gsum, pl->acc_cnt, pl->acc_min, pl->acc_max); } while (0)
             if (vk == 0) HARK_STATS(0); else if (vk == 1) HARK_STATS(1); else HARK_STATS(2);
 #undef HARK_STATS
+            HIP_TRY(ctx, hipGetLastError());
+        }
+        return HARK_OK;
+    });
+    if (rc) return rc;
+    int64_t e = 0;
+    HARK_TRY(hark_read_words(ctx, pl->err, &e, 1));                // err is an int32 in a >= 8-byte pool block
+    const int32_t code = (int32_t)(e & 0xFFFFFFFFll);
+    if (code != 0) HIP_TRY(ctx, hipMemsetAsync(pl->err, 0, sizeof(int32_t), st));
+    if (code == kErrOverflow) return HARK_OK;                      // *ran stays false: the caller runs the separate passes
+    if (code != 0) return hark_fail(ctx, code, "filter_groupby: a surviving row has a key outside [0, %lld)", (long long)G);
+    *ran = true;
+    return HARK_OK;
+}
+
+// Two aggregates of two different 4-byte columns in ONE pass (see fgb_part2_kernel): value 1 with operator vop1 / xf1
+// into acc_sum, value 2 with vop2 in {U32MAX, U32MIN} / xf2 into acc_min (used as the plan's second accumulator), row
+// counts into acc_cnt.  Only the partition path with <= 4096 keys per bucket qualifies; *ran is false otherwise, and
+// when skew overflowed a ring or a slab (no single-row fallback): the caller runs the separate passes.
+int k_fgb_dense_pair(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cmp, float thr, const int32_t *k,
+                     const void *v1, int vop1, int xf1, const void *v2, int vop2, int xf2, int64_t n, bool *ran)
+{
+    *ran = false;
+    const int64_t G = pl->G;
+    if (getenv("HARK_NO_PAIR_PASS")) return HARK_OK;                  // A/B knob
+    if (n <= 0 || pl->algo != 0 || G * 12 <= kLdsTableBudget || G > (int64_t)kMaxBuckets * 4096 || n > pl->max_rows) return HARK_OK;
+    if (!(vop1 == VOP_F32SUM || vop1 == VOP_U32SUM64 || vop1 == VOP_U32MAX || vop1 == VOP_U32MIN) || !(vop2 == VOP_U32MAX || vop2 == VOP_U32MIN)) return HARK_OK;
+    auto misaligned = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) != 0; };
+    if ((p && misaligned(p)) || misaligned(k) || misaligned(v1) || misaligned(v2)) return HARK_OK;
+    HARK_TRY(plan_prepare_partition(ctx, pl));
+    if (pl->shift > 12) return HARK_OK;
+    // half as many buckets as the plan's one-value passes, in the same workspace
+    const int shift = (int)pl->shift + 1, P = (int)(((G - 1) >> shift) + 1), nwg = (int)pl->nwg;
+    if (P > kPairBuckets) return HARK_OK;
+    const size_t slab_bytes = ((size_t)pl->P * (size_t)pl->cap * 8 / (size_t)P) & ~(size_t)15;
+    if (!pl->acc_min) HARK_TRY(hark_alloc(ctx, (void **)&pl->acc_min, (size_t)G * 8));
+    hipStream_t st = ctx->stream;
+    const int64_t blocks = (G + 255) / 256 > (int64_t)ctx->num_cu * 4 ? (int64_t)ctx->num_cu * 4 : (G + 255) / 256;
+    u64 *gsum = reinterpret_cast<u64 *>(pl->acc_sum);
+    fgb_fill_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(gsum, G, vop_identity(vop1));
+    HIP_TRY(ctx, hipMemsetAsync(pl->acc_cnt, 0, (size_t)G * 8, st));
+    fgb_fill_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(pl->acc_min, G, vop2 == VOP_U32MIN ? 0xFFFFFFFFull : 0ull);
+    const size_t lds_agg = (size_t)16 << shift, lds_part = part2_lds_bytes(P);
+    unsigned char *pbuf = reinterpret_cast<unsigned char *>(pl->pbuf);
+    int rc = dispatch_op(cmp, p != nullptr, [&](auto op) -> int {
+        constexpr int OP = decltype(op)::value;
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_part2_kernel<OP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part));
+        for (int64_t r0 = 0; r0 < n; r0 += pl->chunk_rows) {
+            const int64_t r1 = r0 + pl->chunk_rows < n ? r0 + pl->chunk_rows : n;
+            {
+                TimedLaunch tl(pl, st, 1);
+                fgb_part2_kernel<OP><<<dim3((unsigned)nwg), dim3(kPartThreads), lds_part, st>>>(
+                    p, k, static_cast<const uint32_t *>(v1), static_cast<const uint32_t *>(v2), r0, r1, thr, G, shift, P, pbuf, pl->counts, slab_bytes, pl->err);
+            }
+            HIP_TRY(ctx, hipGetLastError());
+            TimedLaunch tl(pl, st, 2);
+#define HARK_PAIR(V1, V2) do { \
+                if (lds_agg > 64 * 1024) HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_agg10_kernel<V1, V2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_agg)); \
+                fgb_agg10_kernel<V1, V2><<<dim3((unsigned)(2 * P)), dim3(1024), lds_agg, st>>>(pbuf, pl->counts, slab_bytes, nwg, shift, G, gsum, pl->acc_cnt, pl->acc_min, xf1, xf2); } while (0)
+            if (vop2 == VOP_U32MAX) {
+                if (vop1 == VOP_F32SUM) HARK_PAIR(VOP_F32SUM, VOP_U32MAX); else if (vop1 == VOP_U32SUM64) HARK_PAIR(VOP_U32SUM64, VOP_U32MAX);
+                else if (vop1 == VOP_U32MAX) HARK_PAIR(VOP_U32MAX, VOP_U32MAX); else HARK_PAIR(VOP_U32MIN, VOP_U32MAX);
+            } else {
+                if (vop1 == VOP_F32SUM) HARK_PAIR(VOP_F32SUM, VOP_U32MIN); else if (vop1 == VOP_U32SUM64) HARK_PAIR(VOP_U32SUM64, VOP_U32MIN);
+                else if (vop1 == VOP_U32MAX) HARK_PAIR(VOP_U32MAX, VOP_U32MIN); else HARK_PAIR(VOP_U32MIN, VOP_U32MIN);
+            }
+#undef HARK_PAIR
             HIP_TRY(ctx, hipGetLastError());
         }
         return HARK_OK;

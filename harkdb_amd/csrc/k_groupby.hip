@@ -554,6 +554,33 @@ int try_dense(hark_context *ctx, const hark_table *db, const PredList &preds,
             done[q] = 1;
         }
     }
+    // ---- pair passes: two aggregates of two different columns from ONE producer + consumer pass (k_fgb_dense_pair:
+    // 10-byte pairs).  Value 1 may be a SUM / AVG or a MAX / MIN, value 2 must be a MAX / MIN (a 32-bit LDS slot); a SUM is
+    // paired first so that the MAX / MIN passes it would otherwise leave behind shrink to one.  Declines like the
+    // statistics pass (small G, skew), and then the single passes below take over.
+    auto same_pass = [&](int64_t a, int64_t b) { return !plan_of[b].count_only && plan_of[b].vop == plan_of[a].vop && plan_of[b].xf == plan_of[a].xf && plan_of[b].col == plan_of[a].col; };
+    auto is_sum = [&](int64_t q) { return !plan_of[q].count_only && (plan_of[q].vop == 0 || plan_of[q].vop == 5); };
+    auto is_ext = [&](int64_t q) { return !plan_of[q].count_only && (plan_of[q].vop == 2 || plan_of[q].vop == 3); };
+    for (int turn = 0; turn < 2 && !rc && src->n > 0; turn++) {          // turn 0: (sum, max/min) pairs, turn 1: (max/min, max/min) pairs
+        for (int64_t j = 0; j < n_aggs && !rc; j++) {
+            if (done[j] || !(turn == 0 ? is_sum(j) : is_ext(j))) continue;
+            int64_t q = -1;
+            for (int64_t t = 0; t < n_aggs; t++) if (t != j && !done[t] && is_ext(t) && !same_pass(j, t)) { q = t; break; }
+            if (q < 0) continue;
+            bool ran = false;
+            rc = k_fgb_dense_pair(ctx, plan, p, cmp, thr, keys, src->cols[plan_of[j].col].data, plan_of[j].vop, plan_of[j].xf,
+                                  src->cols[plan_of[q].col].data, plan_of[q].vop, plan_of[q].xf, src->n, &ran);
+            if (rc || !ran) { turn = 2; break; }                          // it declines for the whole statement alike
+            rc = group_set();
+            for (int64_t t = 0; t < n_aggs && !rc; t++) {
+                if (done[t]) continue;
+                if (plan_of[t].count_only || same_pass(j, t)) rc = hark_fgb_finish_typed(ctx, plan, plan_of[t].kind, pos, res->cols[(size_t)t + 1].data);
+                else if (same_pass(q, t)) rc = hark_fgb_finish_typed_from(ctx, plan, 1, plan_of[t].kind, pos, res->cols[(size_t)t + 1].data);
+                else continue;
+                done[t] = 1;
+            }
+        }
+    }
     for (int64_t j = 0; j < n_aggs && !rc; j++) {
         if (done[j] || plan_of[j].count_only) continue;
         rc = run_pass(plan_of[j].vop, plan_of[j].xf, src->cols[plan_of[j].col].data);

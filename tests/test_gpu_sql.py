@@ -320,6 +320,45 @@ def test_statistics_of_one_column_in_one_pass(skew):
             assert np.array_equal(got.astype(np.int64), e.astype(np.int64)), name
 
 
+@pytest.mark.parametrize("mode", ["pair", "skew", "no-pair", "and-list"])
+def test_two_aggregates_of_two_columns_in_one_pass(mode):
+    """Aggregates of DIFFERENT columns over a large dense key domain pair up: (SUM or AVG, MAX or MIN) and (MAX / MIN,
+    MAX / MIN) come from one producer + consumer pass each (k_fgb_dense_pair, 10-byte pairs); heavily skewed keys make
+    that pass decline, HARK_NO_PAIR_PASS switches it off, an AND-list runs it over the survivor bitmask: same rows."""
+    import os
+    import subprocess
+    import sys
+    if mode == "no-pair" and not os.environ.get("HARK_NO_PAIR_PASS"):
+        env = dict(os.environ, HARK_NO_PAIR_PASS="1")
+        out = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", __file__, "-k", "test_two_aggregates_of_two_columns_in_one_pass and no-pair", "-m", "gpu"],
+                             capture_output=True, text=True, timeout=600, env=env)
+        assert out.returncode == 0, out.stdout + out.stderr
+        return
+    from harkdb_amd import FutharkContext
+    rng = np.random.default_rng(21)
+    n, G = 900_001, 200_000
+    k = rng.integers(0, G, n).astype(np.int32)
+    if mode == "skew":
+        k[: n // 2] = 12345                                           # half of the rows on one key: rings / slabs overflow
+    df = pd.DataFrame({"k": k, "p": rng.random(n).astype(np.float32), "a": (rng.integers(-500, 500, n) / 4).astype(np.float32),
+                       "b": rng.normal(size=n).astype(np.float32), "i": rng.integers(-10**6, 10**6, n).astype(np.int32),
+                       "u": rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32), "j": rng.integers(-50, 50, n).astype(np.int32)})
+    c = FutharkContext(sql_mode=True)
+    c.create_table("t", df)
+    where, keep = ("p > 0.3 and j < 20", (df.p > 0.3) & (df.j < 20)) if mode == "and-list" else ("p > 0.3", df.p > 0.3)
+    names, cols = c.sql_columns("select k, sum(a), max(b), min(i), count(*), avg(i), max(u), min(b), sum(j), max(a) from t where " + where + " group by k")
+    g = df[keep].groupby("k").agg(sa=("a", "sum"), mxb=("b", "max"), mni=("i", "min"), n=("a", "count"), avi=("i", "mean"), mxu=("u", "max"),
+                                  mnb=("b", "min"), sj=("j", "sum"), mxa=("a", "max")).reset_index()
+    exp = [g.k, g.sa, g.mxb, g.mni, g.n, g.avi, g.mxu, g.mnb, g.sj, g.mxa]
+    assert len(cols) == len(exp)
+    for got, e, name in zip(cols, exp, names):
+        e = e.to_numpy()
+        if got.dtype.kind == "f":
+            assert np.allclose(got.astype(np.float64), e.astype(np.float64), rtol=2e-6, atol=1e-6), name
+        else:
+            assert np.array_equal(got.astype(np.int64), e.astype(np.int64)), name
+
+
 # ---- round 2: literals the column's dtype cannot hold, mixed CSV ingest, -0.0 / NaN group keys (ADVICE.md) ----------
 @pytest.mark.parametrize("pred,mask", [
     ("w < 2.5", lambda d: d.w < 2.5), ("w > -0.5", lambda d: d.w > -0.5), ("w = 2.5", lambda d: d.w == 2.5), ("w != 2.5", lambda d: d.w != 2.5),
