@@ -52,4 +52,4 @@ kp = eng.alloc(N * 4)
 eng.gen_columns(SEED + 5, 0, N, 1 << 30, True, None, kp, None)
 tp = eng.table_from_device(N, [kp, a], [np.uint32, np.uint32])
 tb = eng.table_from_device(M, [kb, vb], [np.uint32, np.uint32])
-timeit(f"join probe {N} x build {M} on u32 key (sort-merge)", lambda: eng.join(tp, tb, 0, 0, [0, 1], [1]), 12 * (N + M))
+timeit(f"join probe {N} x build {M} on u32 key (partitioned)", lambda: eng.join(tp, tb, 0, 0, [0, 1], [1]), 12 * (N + M))
