@@ -22,11 +22,32 @@
 
 namespace {
 
-constexpr int kSortThreads = 256;
-constexpr int kSortWaves = kSortThreads / 64;
-constexpr int kRounds = 16;                              // 64-key rounds per wave per tile
-constexpr int kSortTile = kSortThreads * kRounds;        // 4096 keys
+// Two geometries of a pass.  A digit run of a tile is tile / 256 keys long; runs shorter than a 128-byte line leave the
+// CU as partial lines, and whether those merge in the XCD's L2 before they are evicted depends on how many workgroups
+// keep 2 x 256 output lines open at once.  Measured (1e8 keys, three passes + the difference mask, one box):
+// 256 threads x 16 keys, 8 slices per CU 2.44 ms; 512 x 16, 2 per CU 2.38; 1024 x 8, 1 per CU 2.26; 1024 x 12, 1 per CU
+// 2.13 ms.  Sorts of a few million keys are faster with the small tiles (more workgroups in flight), so the large
+// geometry is used from 2^25 keys on.
 constexpr int kBins = 256;
+struct GeoSmall { static constexpr int T = 256, R = 16, PER_CU = 8; };
+struct GeoLarge { static constexpr int T = 1024, R = 12, PER_CU = 1; };
+constexpr int64_t kLargeSortFrom = (int64_t)1 << 25;
+template <typename GEO> constexpr size_t scatter_lds() { return (size_t)GEO::T * GEO::R * 8 + (size_t)(GEO::T / 64) * kBins * 8 + kBins * 4 + kBins * 8 + 64; }
+
+// slices (= workgroups) of a pass over n keys and the keys per slice (whole tiles)
+static void sort_geometry(int64_t n, int num_cu, bool *large, int64_t *nblk_out, int64_t *slice_out)
+{
+    const bool lg = n >= kLargeSortFrom;
+    const int64_t tile = lg ? GeoLarge::T * GeoLarge::R : GeoSmall::T * GeoSmall::R, per_cu = lg ? GeoLarge::PER_CU : GeoSmall::PER_CU;
+    int64_t nblk = (n + tile - 1) / tile;
+    if (nblk > (int64_t)num_cu * per_cu) nblk = (int64_t)num_cu * per_cu;
+    if (nblk < 1) nblk = 1;
+    int64_t slice = (n + nblk - 1) / nblk;
+    slice = (slice + tile - 1) / tile * tile;
+    nblk = (n + slice - 1) / slice;
+    if (nblk < 1) nblk = 1;
+    *large = lg; *nblk_out = nblk; *slice_out = slice;
+}
 
 // Lanes of the wave whose digit equals this lane's digit (among `valid` lanes).
 __device__ __forceinline__ uint64_t match_digit(uint32_t d, bool valid)
@@ -47,29 +68,30 @@ __device__ __forceinline__ uint64_t lanemask_lt()
     return lane == 0 ? 0ull : (~0ull >> (64 - lane));
 }
 
-__global__ __launch_bounds__(kSortThreads) void digit_hist_kernel(const uint32_t *__restrict__ keys, int64_t n, int64_t slice,
+template <typename GEO>
+__global__ __launch_bounds__(GEO::T) void digit_hist_kernel(const uint32_t *__restrict__ keys, int64_t n, int64_t slice,
                                                                   int shift, uint32_t xor_mask, uint32_t *__restrict__ hist, int nblk)
 {
     // plain ds_add_u32 per key (~10 lanes/clk/CU on gfx950); the slice starts on a
     // multiple of 4096 keys, so 16-byte loads are aligned
     __shared__ uint32_t s_hist[kBins];
-    s_hist[threadIdx.x] = 0;
+    if (threadIdx.x < kBins) s_hist[threadIdx.x] = 0;
     __syncthreads();
     const int64_t lo = (int64_t)blockIdx.x * slice;
     const int64_t hi = lo + slice < n ? lo + slice : n;
     const int64_t nvec = (hi - lo) / 4;
     const uint4 *k4 = reinterpret_cast<const uint4 *>(keys + lo);
-    for (int64_t i = threadIdx.x; i < nvec; i += kSortThreads) {
+    for (int64_t i = threadIdx.x; i < nvec; i += GEO::T) {
         const uint4 q = k4[i];
         atomicAdd(&s_hist[((q.x ^ xor_mask) >> shift) & 255u], 1u);
         atomicAdd(&s_hist[((q.y ^ xor_mask) >> shift) & 255u], 1u);
         atomicAdd(&s_hist[((q.z ^ xor_mask) >> shift) & 255u], 1u);
         atomicAdd(&s_hist[((q.w ^ xor_mask) >> shift) & 255u], 1u);
     }
-    for (int64_t i = lo + nvec * 4 + threadIdx.x; i < hi; i += kSortThreads)
+    for (int64_t i = lo + nvec * 4 + threadIdx.x; i < hi; i += GEO::T)
         atomicAdd(&s_hist[((keys[i] ^ xor_mask) >> shift) & 255u], 1u);
     __syncthreads();
-    hist[(size_t)threadIdx.x * nblk + blockIdx.x] = s_hist[threadIdx.x];
+    if (threadIdx.x < kBins) hist[(size_t)threadIdx.x * nblk + blockIdx.x] = s_hist[threadIdx.x];
 }
 
 // Exclusive scan of each digit's row hist[d][0..nblk) (one workgroup per digit)
@@ -105,38 +127,42 @@ __global__ __launch_bounds__(256) void scan_hist_rows_kernel(uint32_t *__restric
 }
 
 // vals_in == nullptr means "payload = input position" (first pass of an argsort).
-__global__ __launch_bounds__(kSortThreads) void digit_scatter_kernel(
+template <typename GEO>
+__global__ __launch_bounds__(GEO::T) void digit_scatter_kernel(
     const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
     uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
     int64_t n, int64_t slice, int shift, uint32_t xor_mask, const uint32_t *__restrict__ hist, int nblk,
     const uint32_t *__restrict__ row_total)
 {
-    __shared__ uint32_t s_key[kSortTile];
-    __shared__ uint32_t s_val[kSortTile];
-    __shared__ uint32_t s_wcnt[kSortWaves][kBins];      // per-wave digit counts of the tile
-    __shared__ uint32_t s_wbase[kSortWaves][kBins];     // tile-local start of (wave, digit)
-    __shared__ uint32_t s_tstart[kBins];                // tile-local start of each digit
-    __shared__ int64_t s_gpos[kBins];                   // global position of the next key of each digit
-    __shared__ uint32_t s_scan[kSortWaves];
+    constexpr int kSortThreads = GEO::T, kSortWaves = GEO::T / 64, kRounds = GEO::R, kSortTile = GEO::T * GEO::R;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sort_lds[];
+    uint32_t *s_key = reinterpret_cast<uint32_t *>(sort_lds);                         // [kSortTile]
+    uint32_t *s_val = s_key + kSortTile;                                             // [kSortTile]
+    uint32_t (*s_wcnt)[kBins] = reinterpret_cast<uint32_t (*)[kBins]>(s_val + kSortTile);       // [waves][bins] per-wave digit counts of the tile
+    uint32_t (*s_wbase)[kBins] = s_wcnt + kSortWaves;                                // [waves][bins] tile-local start of (wave, digit)
+    uint32_t *s_tstart = reinterpret_cast<uint32_t *>(s_wbase + kSortWaves);         // [bins] tile-local start of each digit
+    int64_t *s_gpos = reinterpret_cast<int64_t *>(s_tstart + kBins);                 // [bins] global position of the next key of each digit
+    uint32_t *s_scan = reinterpret_cast<uint32_t *>(s_gpos + kBins);                 // [4]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t lo = (int64_t)blockIdx.x * slice;
     const int64_t hi = lo + slice < n ? lo + slice : n;
     {   // first output position of (digit tid, this slice) = digits before + this digit's earlier slices
-        const uint32_t tot = row_total[tid];
+        const uint32_t tot = tid < kBins ? row_total[tid] : 0u;
         uint32_t incl = tot;
         for (int d = 1; d < 64; d <<= 1) { uint32_t y = __shfl_up(incl, d, 64); if (lane >= d) incl += y; }
-        if (lane == 63) s_scan[wave] = incl;
+        if (lane == 63 && tid < kBins) s_scan[wave] = incl;
         __syncthreads();
-        uint32_t carry = 0;
-        for (int w = 0; w < wave; w++) carry += s_scan[w];
-        s_gpos[tid] = (int64_t)(carry + incl - tot) + (int64_t)hist[(size_t)tid * nblk + blockIdx.x];
+        if (tid < kBins) {
+            uint32_t carry = 0;
+            for (int w = 0; w < wave; w++) carry += s_scan[w];
+            s_gpos[tid] = (int64_t)(carry + incl - tot) + (int64_t)hist[(size_t)tid * nblk + blockIdx.x];
+        }
         __syncthreads();
     }
     const uint64_t lt = lanemask_lt();
 
     for (int64_t tbase = lo; tbase < hi; tbase += kSortTile) {
-#pragma unroll
-        for (int w = 0; w < kSortWaves; w++) s_wcnt[w][tid] = 0;
+        for (int i = tid; i < kSortWaves * kBins; i += kSortThreads) (&s_wcnt[0][0])[i] = 0;
         lds_barrier();
         // ---- rank inside the wave's contiguous 1024-key chunk -----------------
         uint32_t key[kRounds], val[kRounds], rank[kRounds];
@@ -167,16 +193,20 @@ __global__ __launch_bounds__(kSortThreads) void digit_scatter_kernel(
         uint32_t tcnt = 0;
         {
             uint32_t run = 0;
+            if (tid < kBins) {
 #pragma unroll
-            for (int w = 0; w < kSortWaves; w++) { s_wbase[w][tid] = run; run += s_wcnt[w][tid]; }
+                for (int w = 0; w < kSortWaves; w++) { s_wbase[w][tid] = run; run += s_wcnt[w][tid]; }
+            }
             tcnt = run;                                             // keys of digit `tid` in this tile
             uint32_t incl = tcnt;
             for (int d = 1; d < 64; d <<= 1) { uint32_t y = __shfl_up(incl, d, 64); if (lane >= d) incl += y; }
-            if (lane == 63) s_scan[wave] = incl;
+            if (lane == 63 && tid < kBins) s_scan[wave] = incl;
             lds_barrier();
-            uint32_t carry = 0;
-            for (int w = 0; w < wave; w++) carry += s_scan[w];
-            s_tstart[tid] = carry + incl - tcnt;
+            if (tid < kBins) {
+                uint32_t carry = 0;
+                for (int w = 0; w < wave; w++) carry += s_scan[w];
+                s_tstart[tid] = carry + incl - tcnt;
+            }
         }
         lds_barrier();
 #pragma unroll
@@ -197,7 +227,7 @@ __global__ __launch_bounds__(kSortThreads) void digit_scatter_kernel(
             keys_out[pos] = kk; vals_out[pos] = s_val[slot];
         }
         lds_barrier();
-        s_gpos[tid] += tcnt;
+        if (tid < kBins) s_gpos[tid] += tcnt;
         // (the __syncthreads at the top of the next tile orders this update)
     }
 }
@@ -290,9 +320,8 @@ __global__ __launch_bounds__(256) void gather_u64_kernel(const uint64_t *__restr
 // Workspace bytes for sorting n pairs.
 size_t k_sort_workspace_bytes(int64_t n, int num_cu)
 {
-    int64_t nblk = (n + kSortTile - 1) / kSortTile;
-    if (nblk > (int64_t)num_cu * 8) nblk = (int64_t)num_cu * 8;
-    if (nblk < 1) nblk = 1;
+    bool large; int64_t nblk, slice;
+    sort_geometry(n, num_cu, &large, &nblk, &slice);
     return (size_t)kBins * ((size_t)nblk + 1) * sizeof(uint32_t);      // histograms + the 256 digit totals
 }
 
@@ -316,21 +345,22 @@ int k_sort_pairs_u32(hark_context *ctx, uint32_t *keys_a, uint32_t *keys_b, uint
     *keys_out = keys_a; *vals_out = vals_a;
     if (n <= 0) return HARK_OK;
     if (n > 0xFFFFFFFFll) return hark_fail(ctx, HARK_EARG, "sort: at most 2^32-1 rows");
-    int64_t nblk = (n + kSortTile - 1) / kSortTile;
-    if (nblk > (int64_t)ctx->num_cu * 8) nblk = (int64_t)ctx->num_cu * 8;
-    int64_t slice = (n + nblk - 1) / nblk;
-    slice = (slice + kSortTile - 1) / kSortTile * kSortTile;      // whole tiles per slice
-    nblk = (n + slice - 1) / slice;
+    bool large; int64_t nblk, slice;
+    sort_geometry(n, ctx->num_cu, &large, &nblk, &slice);
     hipStream_t st = ctx->stream;
+    if (large) HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&digit_scatter_kernel<GeoLarge>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_lds<GeoLarge>()));
     const uint32_t *kin = keys_first ? keys_first : keys_a, *vin = vals_first;
     uint32_t *kout = keys_first ? keys_a : keys_b, *vout = vals_b;   // a read-only input leaves both scratch buffers free
     bool first = true;
     for (int pass = 0; pass < 4; pass++) {
         if (!((pass_mask >> pass) & 1u)) continue;
         const int shift = pass * 8;
-        digit_hist_kernel<<<dim3((unsigned)nblk), dim3(kSortThreads), 0, st>>>(kin, n, slice, shift, xor_mask, hist_ws, (int)nblk);
+        if (large) digit_hist_kernel<GeoLarge><<<dim3((unsigned)nblk), dim3(GeoLarge::T), 0, st>>>(kin, n, slice, shift, xor_mask, hist_ws, (int)nblk);
+        else digit_hist_kernel<GeoSmall><<<dim3((unsigned)nblk), dim3(GeoSmall::T), 0, st>>>(kin, n, slice, shift, xor_mask, hist_ws, (int)nblk);
         scan_hist_rows_kernel<<<kBins, 256, 0, st>>>(hist_ws, (int)nblk, hist_ws + (size_t)kBins * nblk);
-        digit_scatter_kernel<<<dim3((unsigned)nblk), dim3(kSortThreads), 0, st>>>(
+        if (large) digit_scatter_kernel<GeoLarge><<<dim3((unsigned)nblk), dim3(GeoLarge::T), scatter_lds<GeoLarge>(), st>>>(
+            kin, vin, kout, vout, n, slice, shift, xor_mask, hist_ws, (int)nblk, hist_ws + (size_t)kBins * nblk);
+        else digit_scatter_kernel<GeoSmall><<<dim3((unsigned)nblk), dim3(GeoSmall::T), scatter_lds<GeoSmall>(), st>>>(
             kin, vin, kout, vout, n, slice, shift, xor_mask, hist_ws, (int)nblk, hist_ws + (size_t)kBins * nblk);
         HIP_TRY(ctx, hipGetLastError());
         *keys_out = kout; *vals_out = vout;
@@ -508,11 +538,8 @@ int partition_by_dest(hark_context *ctx, uint32_t *dest, int64_t n, int nparts, 
     if (!rc) rc = k_sort_pairs_u32(ctx, dest, dtmp, vtmp, perm_out, nullptr, n, 0u, ws, 1u, &ko, &vo);   // one pass: the payload lands in vals_b = perm_out
     if (!rc) {
         // the digit totals of the pass are the part sizes (ws: 256*nblk histogram, then 256 totals)
-        int64_t nblk = (n + kSortTile - 1) / kSortTile;
-        if (nblk > (int64_t)ctx->num_cu * 8) nblk = (int64_t)ctx->num_cu * 8;
-        int64_t slice = (n + nblk - 1) / nblk;
-        slice = (slice + kSortTile - 1) / kSortTile * kSortTile;
-        nblk = (n + slice - 1) / slice;
+        bool large; int64_t nblk, slice;
+        sort_geometry(n, ctx->num_cu, &large, &nblk, &slice);
         std::vector<uint32_t> tot(256);
         if (hipMemcpyAsync(tot.data(), ws + (size_t)kBins * nblk, 256 * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
             hipStreamSynchronize(ctx->stream) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, who);
