@@ -193,6 +193,14 @@ def test_c5_full_pipeline_share(eng):
     # three aggregates over three columns + MAX/MIN bounds from the generator (values uniform in [0, 1))
     k3, s3, mx, mn, c3 = q("select k, sum(c3), max(c7), min(c9), count(*) from t where c1 > 0.5 group by k")
     assert np.array_equal(s3, s_gt) and np.array_equal(c3, c_gt) and mx.max() < 1.0 and mn.min() >= 0.0 and np.all(mx[c3 > 50] > mn[c3 > 50])
+    # ... which took the pair pass (sum(c3) + max(c7) in one producer + consumer pass): the single passes give the same bits
+    import os
+    os.environ["HARK_NO_PAIR_PASS"] = "1"
+    try:
+        k1, s1, mx1, mn1, c1 = q("select k, sum(c3), max(c7), min(c9), count(*) from t where c1 > 0.5 group by k")
+    finally:
+        del os.environ["HARK_NO_PAIR_PASS"]
+    assert np.array_equal(k1, k3) and np.array_equal(s1, s3) and np.array_equal(mx1, mx) and np.array_equal(mn1, mn) and np.array_equal(c1, c3)
     fc.drop_table("t")
     for ptr in cols + [key]:
         eng.free(ptr)
