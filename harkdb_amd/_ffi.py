@@ -53,6 +53,7 @@ SIGNATURES = {
     "hark_result_values_2d": (C.c_int, [_vp, _vp, _vp, C.c_int]),
     "hark_result_column": (C.c_int, [_vp, _vp, _i64, _vp]),
     "hark_result_column_device": (_vp, [_vp, _i64]),
+    "hark_result_columns_prefix": (C.c_int, [_vp, _vp, _i64, _vp]),
     "hark_result_free": (C.c_int, [_vp, _vp]),
     "hark_entry_query_sel": (C.c_int, [_vp, _pp, _vp, C.POINTER(_i32), _i64]),
     "hark_entry_query_groupby": (C.c_int, [_vp, _pp, _vp, _i32, C.POINTER(_i32), _i64, C.POINTER(_i32), _i64]),

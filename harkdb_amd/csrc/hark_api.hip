@@ -149,7 +149,7 @@ int hark_context_new(hark_context **out, int device)
     if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return HARK_EHIP; }
     ctx->stream = ctx->own_stream;
     if (hipMalloc((void **)&ctx->d_err, 64) != hipSuccess ||
-        hipHostMalloc((void **)&ctx->h_pin, 64 * 8) != hipSuccess) {
+        hipHostMalloc((void **)&ctx->h_pin, 65536) != hipSuccess) {
         hark_context_free(ctx);
         return HARK_EHIP;
     }
@@ -358,6 +358,38 @@ int hark_result_column(hark_context *ctx, const hark_result *r, int64_t col, voi
     if (!bytes) return HARK_OK;
     if (!host_out) return HARK_EARG;
     return hark_d2h(ctx, host_out, r->cols[col].data, bytes);
+}
+
+// The first `rows` rows of EVERY column in one go (LIMIT applied before PCIe): all copies are enqueued, the stream is
+// drained once.  host_outs[j] receives rows x sizeof(dtype of column j) bytes.  (One call and one synchronisation per
+// column cost ~25 us each: 0.1 ms of a 2.2 ms statement with five result columns.)
+int hark_result_columns_prefix(hark_context *ctx, const hark_result *r, int64_t rows, void *const *host_outs)
+{
+    hark_device_guard guard__(ctx);
+    if (!ctx || !r || rows < 0 || (!host_outs && !r->cols.empty())) return HARK_EARG;
+    if (rows > r->n) rows = r->n;
+    if (rows == 0 || r->cols.empty()) return HARK_OK;
+    size_t total = 0;
+    for (auto &c : r->cols) total += ((size_t)rows * hark_dtype_size(c.dtype) + 15) & ~(size_t)15;
+    if (total > 65536) {                                         // larger than the pinned scratch: column by column
+        for (size_t j = 0; j < r->cols.size(); j++) HARK_TRY(hark_d2h(ctx, host_outs[j], r->cols[j].data, (size_t)rows * hark_dtype_size(r->cols[j].dtype)));
+        return HARK_OK;
+    }
+    char *pin = reinterpret_cast<char *>(ctx->h_pin);
+    size_t off = 0;
+    for (auto &c : r->cols) {
+        const size_t b = (size_t)rows * hark_dtype_size(c.dtype);
+        HIP_TRY(ctx, hipMemcpyAsync(pin + off, c.data, b, hipMemcpyDeviceToHost, ctx->stream));
+        off += (b + 15) & ~(size_t)15;
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    off = 0;
+    for (size_t j = 0; j < r->cols.size(); j++) {
+        const size_t b = (size_t)rows * hark_dtype_size(r->cols[j].dtype);
+        memcpy(host_outs[j], pin + off, b);
+        off += (b + 15) & ~(size_t)15;
+    }
+    return HARK_OK;
 }
 
 int hark_result_free(hark_context *ctx, hark_result *r)

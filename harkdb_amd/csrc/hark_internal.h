@@ -22,7 +22,7 @@ struct hark_context {
     hipStream_t stream = nullptr;   // the stream entries launch on
     std::string err;
     int32_t *d_err = nullptr;       // device-side sticky error word (bounds failures)
-    int32_t *h_pin = nullptr;       // pinned scratch for small D2H reads (64 x i64)
+    int32_t *h_pin = nullptr;       // pinned scratch for small D2H reads (64 KiB: status words, LIMIT prefixes)
     int num_cu = HARK_NUM_CU;
     // pinned double buffer for device -> pageable-host copies (hark_d2h)
     char *bounce[2] = {nullptr, nullptr};

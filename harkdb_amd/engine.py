@@ -80,7 +80,14 @@ class Result:
         return out
 
     def columns(self, limit=None):
-        return [self.column(j, limit) for j in range(self.shape[1])]
+        n, m = self.shape
+        if limit is not None and limit < n and m > 1:                  # a LIMIT prefix: every column with one synchronisation
+            rows = max(int(limit), 0)
+            outs = [np.empty(rows, dtype=self.dtype(j)) for j in range(m)]
+            ptrs = (C.c_void_p * m)(*[o.ctypes.data for o in outs])
+            self._eng._chk(self._eng.lib.hark_result_columns_prefix(self._eng.ctx, self._h, rows, ptrs))
+            return outs
+        return [self.column(j, limit) for j in range(m)]
 
     def device_ptr(self, j):
         return self._eng.lib.hark_result_column_device(self._h, j)
