@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void jcnt_kernel(const uint32_t *__restrict__ 
 }
 
 // ---- probe side: range partition of (key, row id) ---------------------------------------------------------------
-// LDS: E ring[P][Q]; K split[P]; u32 s_w[P] (head << 16 | count); int s_lcur[P]; u32 flags[4].
+// LDS: E ring[P][Q]; K ext[P + 2]; u32 s_w[P] (head << 16 | count); int s_lcur[P]; u32 flags[4].
 template <typename K>
 __global__ __launch_bounds__(kJThreads) void jpart_kernel(const K *__restrict__ keys, int64_t n, K bias, const K *__restrict__ splitters,
                                                           const K *__restrict__ rkeys, int64_t s,
@@ -124,15 +124,27 @@ __global__ __launch_bounds__(kJThreads) void jpart_kernel(const K *__restrict__ 
     constexpr int BATCH = kJThreads * VEC;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     E *ring = reinterpret_cast<E *>(lds_raw);
-    K *split = reinterpret_cast<K *>(ring + (size_t)P * Q);
-    uint32_t *s_w = reinterpret_cast<uint32_t *>(split + P);
+    K *ext = reinterpret_cast<K *>(ring + (size_t)P * Q);             // [P + 2] bucket b holds the keys with ext[b] <= key < ext[b + 1]
+    uint32_t *s_w = reinterpret_cast<uint32_t *>(ext + P + 2);
     int *s_lcur = reinterpret_cast<int *>(s_w + P);
     uint32_t *flags = reinterpret_cast<uint32_t *>(s_lcur + P);
     const int tid = threadIdx.x, wg = blockIdx.x, nwg = gridDim.x;
     const int cap_lines = (int)(cap / LINE) - 1;                                  // the last line takes the final partial flush
-    for (int b = tid; b < P; b += kJThreads) { s_w[b] = 0u; s_lcur[b] = 0; split[b] = b < P - 1 ? splitters[b] : (K)~(K)0; }
+    for (int b = tid; b < P; b += kJThreads) { s_w[b] = 0u; s_lcur[b] = 0; }
+    for (int b = tid; b < P + 2; b += kJThreads) ext[b] = b == 0 ? (K)0 : b < P ? splitters[b - 1] : (K)~(K)0;
     if (tid < 4) flags[tid] = 0u;
     const K kmin = rkeys[0], kmax = rkeys[s - 1];
+    // The splitters are equidistant quantiles of the sorted build keys, so for evenly spread keys the bucket of a key is
+    // close to (key - min) * P / (max - min + 1): the guess is checked against ext[guess - 1 .. guess + 2] (four
+    // independent LDS reads, one round trip) and lands on guess - 1, guess or guess + 1; anything else -- clustered
+    // keys -- takes the binary search (nine DEPENDENT reads; with the search for every row the kernel took 0.60 ms per
+    // 1e8 rows, without any search 0.37 ms).
+    const K range = kmax - kmin;
+    int gshift = 0;
+    while (sizeof(K) == 8 && ((uint64_t)range >> gshift) > 0xFFFFFFFEull) gshift++;
+    const uint32_t r32 = (uint32_t)((uint64_t)range >> gshift);
+    const bool use_guess = r32 >= (uint32_t)P;
+    const uint32_t gmul = use_guess ? (uint32_t)((((uint64_t)P) << 32) / ((uint64_t)r32 + 1ull)) : 0u;
     __syncthreads();
     int phase = 0, since = 0;
     bool overflow = false;
@@ -160,10 +172,20 @@ __global__ __launch_bounds__(kJThreads) void jpart_kernel(const K *__restrict__ 
         for (int j = 0; j < VEC; j++) {
             kk[j] = kraw[j] ^ bias;
             if (r + j < n && kk[j] >= kmin && kk[j] <= kmax) pending |= 1u << j;
-            // bucket = number of splitters <= key  (split[P-1] = max: never counted unless key is max itself, capped below)
-            uint32_t pos = 0;
+            // bucket = number of splitters <= key = the b with ext[b] <= key < ext[b + 1]
+            const K key = kk[j];
+            uint32_t g = __umulhi((uint32_t)((uint64_t)(key - kmin) >> gshift), gmul);
+            g = g < (uint32_t)P ? g : (uint32_t)(P - 1);
+            const K em = ext[g > 0u ? g - 1u : 0u], e0 = ext[g], e1 = ext[g + 1u], e2 = ext[g + 2u];
+            uint32_t pos;
+            if (use_guess && e0 <= key && key < e1) pos = g;
+            else if (use_guess && e1 <= key && key < e2) pos = g + 1u;
+            else if (use_guess && g > 0u && em <= key && key < e0) pos = g - 1u;
+            else {
+                pos = 0;
 #pragma unroll
-            for (int step = P / 2; step > 0; step >>= 1) if (split[pos + step - 1] <= kk[j]) pos += step;
+                for (int step = P / 2; step > 0; step >>= 1) if (ext[pos + step] <= key) pos += step;      // ext[i + 1] = splitter i
+            }
             bk[j] = pos < (uint32_t)P ? pos : (uint32_t)(P - 1);
         }
         bool again;
@@ -660,7 +682,7 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
     int32_t *err = reinterpret_cast<int32_t *>(info + 1);
     unsigned long long *total = reinterpret_cast<unsigned long long *>(info);
     jsplit_kernel<K><<<(P + 256) / 256, 256, 0, st>>>(rkeys, s, P, splitters, bstart);
-    const size_t lds_part = sizeof(E) * (size_t)P * Q + sizeof(K) * P + 8 * (size_t)P + 16;
+    const size_t lds_part = sizeof(E) * (size_t)P * Q + sizeof(K) * (P + 2) + 8 * (size_t)P + 16;
     hipError_t he = hipFuncSetAttribute(reinterpret_cast<const void *>(&jpart_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part);
     // rows per bucket and batch = BATCH / P; sweep before a ring of Q entries (less one line of carry) can fill up
     const int per_batch = kJThreads * VEC / P;
