@@ -288,6 +288,21 @@ def extra_configs(torch, eng, dev, a, p, k, v, N):
         ms = event_ms(torch, c5q, warm=2, reps=5)
         out[name] = entry(ms, 4.0 * ncols * n5 + 16.0 * (1 << 20), n5, referenced_columns=ncols, result_rows=int(res[0].shape[0]), statement=q,
                           note="1/8 of configs[4] (4e9 rows x 16 f32 columns); end to end through FutharkContext.sql() incl. the LIMIT-row download")
+    out["C5_three_aggregates"]["note"] += ("; max(c7) and min(c9) are computed for the LIMIT surviving groups only (late aggregation: "
+                                           "hark_entry_filter_groupby_subset, harkdb_amd/context.py; HARK_NO_LATE_AGG=1 switches it off)")
+    # the same three aggregates for EVERY group, result left on the device (no HAVING / ORDER BY / LIMIT, no download):
+    # what several aggregates cost in general -- one pair pass (sum(c3) + max(c7)) and one single pass (min(c9))
+    dev_t = fc.tables["t"]._device
+
+    def c5g():
+        r = eng.filter_groupby(dev_t, [(2, ">", 0.5)], 0, [("sum", 4), ("max", 8), ("min", 10), ("count", 0)])
+        shape[0] = r.shape
+        r.free()
+
+    ms = event_ms(torch, c5g, warm=2, reps=5)
+    out["C5_three_aggregates_all_groups"] = entry(ms, 4.0 * 5 * n5 + 24.0 * (1 << 20), n5, referenced_columns=5, result_rows=int(shape[0][0]),
+                                                  statement="select k, sum(c3), max(c7), min(c9), count(*) from t where c1 > 0.5 group by k  (device result)",
+                                                  note="hark_entry_filter_groupby: pair pass (sum(c3) + max(c7)) + single pass (min(c9))")
     fc.drop_table("t")
     del c5, key
     torch.cuda.empty_cache()

@@ -22,6 +22,8 @@ Anything the reference cannot express (WHERE, HAVING, ORDER BY, LIMIT, COUNT,
 AVG, float / int64 columns, or `sql_mode=True`) takes the SQL-typed path and
 returns exactly the select list.
 """
+import os
+
 import numpy as np
 
 from . import _ffi
@@ -232,21 +234,61 @@ class FutharkContext:
             decode = (mins, spans, [dev.dtype(c) for c in g_cols])
         else:
             gkey = cmap[g_col]
-        res = eng.filter_groupby(cur, [(cmap[c], cmp, v) for c, cmp, v in preds], gkey, [(f, 0 if c is None else cmap[c]) for f, c in aggs])
-        # HAVING / ORDER BY run on the G-row result, still on the device
-        keep = [res]
-        for slot, cmp, v in having:
-            m = res.shape[1]
-            t = eng.table_from_device(res.shape[0], [res.device_ptr(j) for j in range(m)], [res.dtype(j) for j in range(m)], keepalive=res)
-            res = eng.filter_sel(t, slot, cmp, v, list(range(m)), want_row_index=False)
-            keep += [t, res]
-        if order is not None:
-            m = res.shape[1]
-            t = eng.table_from_device(res.shape[0], [res.device_ptr(j) for j in range(m)], [res.dtype(j) for j in range(m)], keepalive=res)
-            res = eng.sort(t, order[0], list(range(m)), descending=order[1])
-            keep += [t, res]
-        # only the first LIMIT rows cross PCIe (unless key conditions / orders still have to run on the decoded result)
-        cols = res.columns(limit=ir.get("limit") if not (host_having or host_order) else None)
+        dev_preds = [(cmap[c], cmp, v) for c, cmp, v in preds]
+        spec_of = lambda a: (a[0], 0 if a[1] is None else cmap[a[1]])
+
+        def having_order(res, having, order):
+            """HAVING / ORDER BY on a G-row result, still on the device."""
+            keep = [res]
+            for slot, cmp, v in having:
+                m = res.shape[1]
+                t = eng.table_from_device(res.shape[0], [res.device_ptr(j) for j in range(m)], [res.dtype(j) for j in range(m)], keepalive=res)
+                res = eng.filter_sel(t, slot, cmp, v, list(range(m)), want_row_index=False)
+                keep += [t, res]
+            if order is not None:
+                m = res.shape[1]
+                t = eng.table_from_device(res.shape[0], [res.device_ptr(j) for j in range(m)], [res.dtype(j) for j in range(m)], keepalive=res)
+                res = eng.sort(t, order[0], list(range(m)), descending=order[1])
+                keep += [t, res]
+            res._keep_chain = keep
+            return res
+
+        cols = None
+        # ---- late materialisation: with a small LIMIT only the aggregates that HAVING / ORDER BY mention are computed
+        # for every group; the others are computed afterwards for the LIMIT surviving groups only
+        # (hark_entry_filter_groupby_subset: one pass over the predicate and key columns).  Same rows, same values.
+        lim = ir.get("limit")
+        first = {s for s, _, _ in having if s > 0} | ({order[0]} if order is not None and order[0] > 0 else set())
+        # an aggregate that comes out of a first-phase pass anyway is not "late": COUNT (every pass counts), SUM / AVG of a
+        # column whose SUM / AVG is in the first phase, a repeated aggregate
+        fam = lambda a: ("sumavg", a[1]) if a[0] in ("sum", "avg") else a
+        first_fams = {fam(aggs[s - 1]) for s in first}
+        first |= {s for s in range(1, len(aggs) + 1) if aggs[s - 1][0] == "count" or fam(aggs[s - 1]) in first_fams}
+        first = sorted(first)
+        second = [s for s in range(1, len(aggs) + 1) if s not in first]
+        four = (np.dtype(np.float32), np.dtype(np.int32), np.dtype(np.uint32))
+        if (lim is not None and 0 < lim <= 1024 and not multi and second and len(second) <= 8 and lim * len(second) <= 8192
+                and not os.environ.get("HARK_NO_LATE_AGG") and np.dtype(cur.dtype(gkey)) in four[1:]
+                and all(aggs[s - 1][0] in ("sum", "avg", "min", "max", "count") and (aggs[s - 1][1] is None or np.dtype(cur.dtype(cmap[aggs[s - 1][1]])) in four)
+                        for s in second)):
+            first_specs = [aggs[s - 1] for s in first] or [("count", None)]
+            remap = {0: 0, **{s: 1 + j for j, s in enumerate(first)}}
+            r1 = having_order(eng.filter_groupby(cur, dev_preds, gkey, [spec_of(a) for a in first_specs]),
+                              [(remap[s], cmp, v) for s, cmp, v in having], None if order is None else (remap[order[0]], order[1]))
+            c1 = r1.columns(limit=lim)
+            c1 = [c[:lim] for c in c1]
+            r2 = eng.filter_groupby_subset(cur, dev_preds, gkey, c1[0], [spec_of(aggs[s - 1]) for s in second])
+            c2 = r2.columns()
+            cols = [None] * (1 + len(aggs))
+            cols[0] = c1[0]
+            for j, s_ in enumerate(first):
+                cols[s_] = c1[1 + j]
+            for j, s_ in enumerate(second):
+                cols[s_] = c2[j]
+        if cols is None:
+            res = having_order(eng.filter_groupby(cur, dev_preds, gkey, [spec_of(a) for a in aggs]), having, order)
+            # only the first LIMIT rows cross PCIe (unless key conditions / orders still have to run on the decoded result)
+            cols = res.columns(limit=ir.get("limit") if not (host_having or host_order) else None)
         if decode is None:
             out = [cols[s] for s in out_slots]
         else:

@@ -693,6 +693,227 @@ int try_hash(hark_context *ctx, const hark_table *db, const PredList &preds,
 
 } // namespace
 
+// ---------------------------------------------------------------------------
+// Aggregates of a FEW groups only (late materialisation for ORDER BY ... LIMIT k)
+// ---------------------------------------------------------------------------
+// A statement whose HAVING / ORDER BY / LIMIT leave k groups needs the aggregates that nobody filters or orders by for
+// those k groups only.  The Python planner (harkdb_amd/context.py) therefore runs the full GROUP BY with the aggregates
+// HAVING / ORDER BY mention, takes the k surviving keys, and asks this entry for the rest: one streaming pass that reads
+// the predicate and key columns (8 B/row), tests every surviving row's key against an open-addressing set of the k keys
+// in LDS (one or two LDS reads), and touches value columns only for member rows (k / G of the rows: nothing at
+// k = 10, G = 2^20).  Per-workgroup accumulators in LDS (64-bit slot per (key, aggregate), a row count per key), merged
+// with global atomics at the end, decoded by fgb_decode_kernel's kinds.  32-bit keys, 4-byte value columns,
+// SUM / AVG / MIN / MAX / COUNT; anything else returns HARK_EUNSUPPORTED and the planner takes the one-phase path.
+namespace {
+
+constexpr int kSubMaxKeys = 1024, kSubMaxAggs = 8, kSubSlots = 4096, kSubThreads = 1024;
+constexpr uint32_t kSubEmpty = 0xFFFFFFFFu;
+struct SubAggs { const uint32_t *col[kSubMaxAggs]; int vop[kSubMaxAggs], xf[kSubMaxAggs]; int n; };
+
+typedef unsigned long long su64;
+__device__ __forceinline__ uint32_t sub_xf(int xf, uint32_t x)
+{
+    if (xf == 1) return x ^ 0x80000000u;
+    if (xf == 2) { if (x == 0x80000000u) x = 0u; return x ^ ((x & 0x80000000u) ? 0xFFFFFFFFu : 0x80000000u); }
+    return x;
+}
+__device__ __forceinline__ su64 sub_identity(int vop) { return vop == 3 ? 0xFFFFFFFFull : 0ull; }
+// vop: 0 f32 sum (f64 slot), 5 u64 sum of the transformed word, 2 max / 3 min of the transformed word (low half)
+__device__ __forceinline__ void sub_atomic(su64 *slot, int vop, uint32_t w, uint32_t raw)
+{
+    if (vop == 0) unsafeAtomicAdd(reinterpret_cast<double *>(slot), (double)__uint_as_float(raw));
+    else if (vop == 5) atomicAdd(slot, (su64)w);
+    else if (vop == 2) atomicMax(reinterpret_cast<uint32_t *>(slot), w);
+    else atomicMin(reinterpret_cast<uint32_t *>(slot), w);
+}
+__device__ __forceinline__ void sub_merge(su64 *slot, int vop, su64 part)
+{
+    if (vop == 0) unsafeAtomicAdd(reinterpret_cast<double *>(slot), __longlong_as_double((long long)part));
+    else if (vop == 5) atomicAdd(slot, part);
+    else if (vop == 2) atomicMax(reinterpret_cast<uint32_t *>(slot), (uint32_t)part);
+    else atomicMin(reinterpret_cast<uint32_t *>(slot), (uint32_t)part);
+}
+
+// pred: cmp = HARK_CMP_MASK -> p is a survivor bitmask (bit r & 7 of byte r >> 3); cmp < 0 -> no predicate; else f32 column
+__global__ __launch_bounds__(kSubThreads) void subset_agg_kernel(const float *__restrict__ p, int cmp, float thr, const uint32_t *__restrict__ keys,
+                                                                 int64_t n, const uint32_t *__restrict__ want, int nkeys, SubAggs aggs,
+                                                                 su64 *__restrict__ gacc /* [naggs][nkeys] */, su64 *__restrict__ gcnt /* [nkeys] */)
+{
+    __shared__ uint32_t s_key[kSubSlots];
+    __shared__ uint16_t s_id[kSubSlots];
+    extern __shared__ __attribute__((aligned(16))) unsigned char sub_lds[];
+    su64 *s_acc = reinterpret_cast<su64 *>(sub_lds);                              // [naggs][nkeys]
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_acc + (size_t)aggs.n * nkeys);   // [nkeys]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < kSubSlots; i += kSubThreads) s_key[i] = kSubEmpty;
+    for (int i = tid; i < aggs.n * nkeys; i += kSubThreads) s_acc[i] = sub_identity(aggs.vop[i / nkeys]);
+    for (int i = tid; i < nkeys; i += kSubThreads) s_cnt[i] = 0u;
+    __syncthreads();
+    auto hash = [](uint32_t k) { k ^= k >> 16; k *= 0x7FEB352Du; k ^= k >> 15; return (k * 0x846CA68Bu) >> 20; };     // 12 bits
+    // the k keys are distinct: every thread inserts its own (claim a slot with a compare-and-swap; a stored key of
+    // 0xFFFFFFFF is told from "empty" by its id being set)
+    for (int i = tid; i < nkeys; i += kSubThreads) {
+        const uint32_t k = want[i];
+        uint32_t h = hash(k);
+        if (k == kSubEmpty) continue;                                              // handled by the flag below
+        while (atomicCAS(&s_key[h], kSubEmpty, k) != kSubEmpty) h = (h + 1) & (kSubSlots - 1);
+        s_id[h] = (uint16_t)i;
+    }
+    __shared__ int s_all_ones;                                                     // index of the key 0xFFFFFFFF among the wanted ones, or -1
+    if (tid == 0) s_all_ones = -1;
+    __syncthreads();
+    for (int i = tid; i < nkeys; i += kSubThreads) if (want[i] == kSubEmpty) s_all_ones = i;
+    __syncthreads();
+    const int all_ones = s_all_ones;
+    auto lookup = [&](uint32_t k) -> int {
+        if (k == kSubEmpty) return all_ones;
+        uint32_t h = hash(k);
+        for (;;) {
+            const uint32_t c = s_key[h];
+            if (c == k) return (int)s_id[h];
+            if (c == kSubEmpty) return -1;
+            h = (h + 1) & (kSubSlots - 1);
+        }
+    };
+    auto member_row = [&](int id, int64_t r) {
+        atomicAdd(&s_cnt[id], 1u);
+        for (int a = 0; a < aggs.n; a++) {
+            if (aggs.vop[a] < 0) continue;                                         // COUNT: the row count is all it needs
+            const uint32_t raw = aggs.col[a][r];
+            sub_atomic(&s_acc[(size_t)a * nkeys + id], aggs.vop[a], sub_xf(aggs.xf[a], raw), raw);
+        }
+    };
+    const int64_t nvec = n / 4, stride = (int64_t)gridDim.x * kSubThreads;
+    auto survive4 = [&](int64_t i) -> uint32_t {                                   // survivor bits of rows 4i .. 4i + 3
+        if (cmp < 0) return 15u;
+        if (cmp == HARK_CMP_MASK) { const uint32_t byte = reinterpret_cast<const uint8_t *>(p)[i >> 1]; return (byte >> ((i & 1) * 4)) & 15u; }
+        const uint4 q = ld_nt16(p + 4 * i);
+        const float f[4] = {__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w)};
+        uint32_t m = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            bool b;
+            switch (cmp) { case HARK_CMP_GT: b = f[j] > thr; break; case HARK_CMP_GE: b = f[j] >= thr; break; case HARK_CMP_LT: b = f[j] < thr; break;
+                           case HARK_CMP_LE: b = f[j] <= thr; break; case HARK_CMP_EQ: b = f[j] == thr; break; default: b = f[j] != thr; break; }
+            m |= (uint32_t)b << j;
+        }
+        return m;
+    };
+    int64_t i = (int64_t)blockIdx.x * kSubThreads + tid;
+    for (; i + stride < nvec; i += 2 * stride) {                                   // two 16-byte loads per column in flight per lane
+        const uint4 ka = ld_nt16(keys + 4 * i), kb = ld_nt16(keys + 4 * (i + stride));
+        const uint32_t ma = survive4(i), mb = survive4(i + stride);
+        const uint32_t kk[8] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            if (((j < 4 ? ma : mb) >> (j & 3)) & 1u) {
+                const int id = lookup(kk[j]);
+                if (id >= 0) member_row(id, 4 * (j < 4 ? i : i + stride) + (j & 3));
+            }
+        }
+    }
+    for (; i < nvec; i += stride) {
+        const uint4 ka = ld_nt16(keys + 4 * i);
+        const uint32_t ma = survive4(i);
+        const uint32_t kk[4] = {ka.x, ka.y, ka.z, ka.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) if ((ma >> j) & 1u) { const int id = lookup(kk[j]); if (id >= 0) member_row(id, 4 * i + j); }
+    }
+    if (blockIdx.x == 0) {                                                         // ragged tail (n % 4 rows)
+        const int64_t r = nvec * 4 + tid;
+        if (r < n) {
+            bool b = true;
+            if (cmp == HARK_CMP_MASK) b = (reinterpret_cast<const uint8_t *>(p)[r >> 3] >> (r & 7)) & 1u;
+            else if (cmp >= 0) {
+                const float f = p[r];
+                switch (cmp) { case HARK_CMP_GT: b = f > thr; break; case HARK_CMP_GE: b = f >= thr; break; case HARK_CMP_LT: b = f < thr; break;
+                               case HARK_CMP_LE: b = f <= thr; break; case HARK_CMP_EQ: b = f == thr; break; default: b = f != thr; break; }
+            }
+            if (b) { const int id = lookup(keys[r]); if (id >= 0) member_row(id, r); }
+        }
+    }
+    __syncthreads();
+    for (int id = tid; id < nkeys; id += kSubThreads) {
+        const uint32_t c = s_cnt[id];
+        if (!c) continue;
+        atomicAdd(&gcnt[id], (su64)c);
+        for (int a = 0; a < aggs.n; a++) if (aggs.vop[a] >= 0) sub_merge(&gacc[(size_t)a * nkeys + id], aggs.vop[a], s_acc[(size_t)a * nkeys + id]);
+    }
+}
+
+__global__ __launch_bounds__(256) void sub_fill_kernel(su64 *dst, int64_t n, su64 v)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = v;
+}
+
+} // namespace
+
+extern "C" int hark_entry_filter_groupby_subset(hark_context *ctx, hark_result **out, const hark_table *db, int64_t n_preds,
+                                                const int32_t *where_cols, const int32_t *cmps, const void *const *constants, int32_t g_col,
+                                                const void *keys_host, int64_t n_keys, const int32_t *agg_cols, const int32_t *agg_ops, int64_t n_aggs)
+{
+    hark_device_guard guard__(ctx);
+    if (!ctx || !out || !db) return HARK_EARG;
+    *out = nullptr;
+    if (n_preds < 0 || n_aggs < 1 || n_keys < 0 || (n_keys && !keys_host) || !agg_cols || !agg_ops) return hark_fail(ctx, HARK_EARG, "groupby_subset: bad arguments");
+    if (g_col < 0 || g_col >= db->m) return hark_fail(ctx, HARK_EBOUNDS, "groupby_subset: key column out of bounds");
+    const int kdt = db->cols[g_col].dtype;
+    if ((kdt != HARK_I32 && kdt != HARK_U32) || n_keys > kSubMaxKeys || n_aggs > kSubMaxAggs || n_keys * n_aggs > 8192)
+        return hark_fail(ctx, HARK_EUNSUPPORTED, "groupby_subset: 32-bit keys, at most %d keys and %d aggregates", kSubMaxKeys, kSubMaxAggs);
+    std::vector<DensePass> plan((size_t)n_aggs);
+    SubAggs aggs; aggs.n = (int)n_aggs;
+    for (int64_t j = 0; j < n_aggs; j++) {
+        const int c = agg_ops[j] == HARK_AGG_COUNT ? 0 : agg_cols[j];
+        if (c < 0 || c >= db->m) return hark_fail(ctx, HARK_EBOUNDS, "groupby_subset: aggregate column out of bounds");
+        if (agg_ops[j] == HARK_AGG_PROD || !dense_plan_for(agg_ops[j], db->cols[c].dtype, c, &plan[j]))
+            return hark_fail(ctx, HARK_EUNSUPPORTED, "groupby_subset: SUM / AVG / MIN / MAX / COUNT over 4-byte columns");
+        aggs.col[j] = plan[j].count_only ? nullptr : static_cast<const uint32_t *>(db->cols[c].data);
+        aggs.vop[j] = plan[j].count_only ? -1 : plan[j].vop;
+        aggs.xf[j] = plan[j].xf;
+    }
+    for (int64_t j = 0; j < n_preds; j++)
+        if (where_cols[j] < 0 || where_cols[j] >= db->m) return hark_fail(ctx, HARK_EBOUNDS, "groupby_subset: predicate column out of bounds");
+    hark_result *res = new hark_result();
+    res->n = n_keys; res->cols.resize((size_t)n_aggs);
+    for (int64_t j = 0; j < n_aggs; j++) { res->cols[(size_t)j].dtype = plan[j].out_dtype; res->cols[(size_t)j].data = nullptr; res->cols[(size_t)j].owned = n_keys > 0; }
+    if (n_keys == 0) { *out = res; return HARK_OK; }
+    // WHERE exactly as try_dense: one f32 predicate rides along, anything else becomes a survivor bitmask
+    const bool direct = n_preds == 1 && db->cols[where_cols[0]].dtype == HARK_F32;
+    uint8_t *mask = nullptr;
+    uint32_t *want = nullptr; su64 *gacc = nullptr, *gcnt = nullptr;
+    hipStream_t st = ctx->stream;
+    int rc = HARK_OK;
+    if (n_preds >= 1 && !direct) rc = k_predicate_bitmask(ctx, db, n_preds, where_cols, cmps, constants, &mask);
+    if (!rc) rc = hark_alloc(ctx, (void **)&want, (size_t)n_keys * 4);
+    if (!rc) rc = hark_alloc(ctx, (void **)&gacc, (size_t)n_keys * (size_t)n_aggs * 8);
+    if (!rc) rc = hark_alloc(ctx, (void **)&gcnt, (size_t)n_keys * 8);
+    for (int64_t j = 0; j < n_aggs && !rc; j++) rc = hark_alloc(ctx, &res->cols[(size_t)j].data, (size_t)n_keys * hark_dtype_size(plan[j].out_dtype));
+    if (!rc && hipMemcpyAsync(want, keys_host, (size_t)n_keys * 4, hipMemcpyHostToDevice, st) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "groupby_subset: key upload failed");
+    if (!rc) {
+        for (int64_t j = 0; j < n_aggs; j++)
+            sub_fill_kernel<<<1, 256, 0, st>>>(gacc + (size_t)j * n_keys, n_keys, plan[j].count_only ? 0ull : (plan[j].vop == 3 ? 0xFFFFFFFFull : 0ull));
+        hipMemsetAsync(gcnt, 0, (size_t)n_keys * 8, st);
+        const float *p = direct ? static_cast<const float *>(db->cols[where_cols[0]].data) : reinterpret_cast<const float *>(mask);
+        const int cmp = n_preds == 0 ? -1 : direct ? cmps[0] : HARK_CMP_MASK;
+        const float thr = direct ? *static_cast<const float *>(constants[0]) : 0.0f;
+        const size_t lds = (size_t)n_aggs * n_keys * 8 + (size_t)n_keys * 4 + 16;
+        hipError_t he = hipSuccess;
+        if (lds > 32 * 1024) he = hipFuncSetAttribute(reinterpret_cast<const void *>(&subset_agg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        int64_t grid = (db->n / 4 + kSubThreads - 1) / kSubThreads;
+        if (grid > ctx->num_cu) grid = ctx->num_cu;
+        if (grid < 1) grid = 1;
+        if (he == hipSuccess) subset_agg_kernel<<<dim3((unsigned)grid), dim3(kSubThreads), lds, st>>>(p, cmp, thr, static_cast<const uint32_t *>(db->cols[g_col].data), db->n, want, (int)n_keys, aggs, gacc, gcnt);
+        if (he != hipSuccess || hipGetLastError() != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "groupby_subset: launch failed");
+        for (int64_t j = 0; j < n_aggs && !rc; j++) rc = k_fgb_decode(ctx, gacc + (size_t)j * n_keys, gcnt, n_keys, plan[j].kind, res->cols[(size_t)j].data);
+        if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "groupby_subset: kernels failed");
+    }
+    hark_free(ctx, mask); hark_free(ctx, want); hark_free(ctx, gacc); hark_free(ctx, gcnt);
+    if (rc) { for (auto &c : res->cols) if (c.owned && c.data) hark_free(ctx, c.data); delete res; return rc; }
+    *out = res;
+    return HARK_OK;
+}
+
 extern "C" int hark_entry_filter_groupby(hark_context *ctx, hark_result **out, const hark_table *db, int32_t where_col, int32_t cmp,
                                          const void *constant, int32_t g_col, const int32_t *agg_cols, const int32_t *agg_ops,
                                          int64_t n_aggs)

@@ -402,6 +402,18 @@ class Engine:
         self._chk(self.lib.hark_entry_filter_groupby_and(self.ctx, C.byref(h), table._h, len(where), wc, wo, wp, int(g_col), pc, po, cols.size))
         return Result(self, h)
 
+    def filter_groupby_subset(self, table, where, g_col, keys, aggs):
+        """The aggregates `aggs` for the groups `keys` only (a numpy array of <= 1024 distinct 32-bit key values): a Result
+        with len(keys) rows in that order, one column per aggregate.  Raises on unsupported shapes (see include/hark.h)."""
+        cols, pc = _ffi.i32_array([c for _, c in aggs])
+        ops, po = _ffi.i32_array([_ffi.AGG[o] for o, _ in aggs])
+        where = list(where or [])
+        wc, wo, wp, keep = self._predicates(table, where)
+        k = np.ascontiguousarray(keys).view(np.uint32) if np.asarray(keys).dtype.itemsize == 4 else np.ascontiguousarray(keys, dtype=np.uint32)
+        h = C.c_void_p()
+        self._chk(self.lib.hark_entry_filter_groupby_subset(self.ctx, C.byref(h), table._h, len(where), wc, wo, wp, int(g_col), k.ctypes.data, k.size, pc, po, cols.size))
+        return Result(self, h)
+
     def predicate_bitmask(self, table, where, mask_ptr):
         """AND of the predicates as a survivor bitmask (bit r & 7 of byte r >> 3) at device address mask_ptr; feed it to
         FgbPlan.run(p=mask_ptr, cmp="mask")."""
