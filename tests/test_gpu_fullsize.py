@@ -201,6 +201,13 @@ def test_c5_full_pipeline_share(eng):
     finally:
         del os.environ["HARK_NO_PAIR_PASS"]
     assert np.array_equal(k1, k3) and np.array_equal(s1, s3) and np.array_equal(mx1, mx) and np.array_equal(mn1, mn) and np.array_equal(c1, c3)
+    # late aggregation: with LIMIT 10, max(c7) and min(c9) are computed for the ten surviving groups only (one pass over
+    # c1 and k, hark_entry_filter_groupby_subset): the rows are the first ten of the unlimited ordered statement, bit for bit
+    stmt3 = "select k, sum(c3), max(c7), min(c9), count(*) from t where c1 > 0.5 group by k having count(*) > 250 order by sum(c3) desc"
+    ka, sa, mxa, mna, ca = q(stmt3)
+    kb, sb, mxb, mnb, cb = q(stmt3 + " limit 10")
+    assert len(kb) == 10 and np.array_equal(kb, ka[:10]) and np.array_equal(sb, sa[:10]) and np.array_equal(cb, ca[:10])
+    assert np.array_equal(mxb, mxa[:10]) and np.array_equal(mnb, mna[:10]) and np.array_equal(mxb, mx[kb]) and np.array_equal(mnb, mn[kb])
     fc.drop_table("t")
     for ptr in cols + [key]:
         eng.free(ptr)
