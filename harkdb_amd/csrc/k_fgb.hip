@@ -1735,6 +1735,18 @@ int hark_fgb_finish_u32(hark_context *ctx, hark_fgb_plan *pl, uint32_t *val_out,
     return fgb_check_err(ctx, pl);
 }
 
+// the low words of the plan's SECOND accumulator (acc_min: value 2 of a pair pass), groups in table order
+int hark_fgb_finish_u32_second(hark_context *ctx, hark_fgb_plan *pl, uint32_t *val_out)
+{
+    hark_device_guard guard__(ctx);
+    if (!ctx || !pl || !val_out || !pl->acc_min) return HARK_EARG;
+    int64_t blocks = (pl->G + 255) / 256;
+    if (blocks > (int64_t)ctx->num_cu * 4) blocks = (int64_t)ctx->num_cu * 4;
+    fgb_finish_u32_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(pl->acc_min, pl->acc_cnt, pl->G, val_out, nullptr);
+    HIP_TRY(ctx, hipGetLastError());
+    return HARK_OK;
+}
+
 int hark_fgb_finish(hark_context *ctx, hark_fgb_plan *pl, float *sum_out, int64_t *count_out)
 {
     hark_device_guard guard__(ctx);
@@ -1855,7 +1867,7 @@ int k_fgb_dense_pair(hark_context *ctx, hark_fgb_plan *pl, const float *p, int c
     const int64_t G = pl->G;
     if (getenv("HARK_NO_PAIR_PASS")) return HARK_OK;                  // A/B knob
     if (n <= 0 || pl->algo != 0 || G * 12 <= kLdsTableBudget || G > (int64_t)kMaxBuckets * 4096 || n > pl->max_rows) return HARK_OK;
-    if (!(vop1 == VOP_F32SUM || vop1 == VOP_U32SUM64 || vop1 == VOP_U32MAX || vop1 == VOP_U32MIN) || !(vop2 == VOP_U32MAX || vop2 == VOP_U32MIN)) return HARK_OK;
+    if (!(vop1 == VOP_F32SUM || vop1 == VOP_U32SUM64 || vop1 == VOP_U32SUM || vop1 == VOP_U32MAX || vop1 == VOP_U32MIN) || !(vop2 == VOP_U32MAX || vop2 == VOP_U32MIN)) return HARK_OK;
     auto misaligned = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) != 0; };
     if ((p && misaligned(p)) || misaligned(k) || misaligned(v1) || misaligned(v2)) return HARK_OK;
     HARK_TRY(plan_prepare_partition(ctx, pl));
@@ -1890,9 +1902,11 @@ int k_fgb_dense_pair(hark_context *ctx, hark_fgb_plan *pl, const float *p, int c
                 fgb_agg10_kernel<V1, V2><<<dim3((unsigned)(2 * P)), dim3(1024), lds_agg, st>>>(pbuf, pl->counts, slab_bytes, nwg, shift, G, gsum, pl->acc_cnt, pl->acc_min, xf1, xf2); } while (0)
             if (vop2 == VOP_U32MAX) {
                 if (vop1 == VOP_F32SUM) HARK_PAIR(VOP_F32SUM, VOP_U32MAX); else if (vop1 == VOP_U32SUM64) HARK_PAIR(VOP_U32SUM64, VOP_U32MAX);
+                else if (vop1 == VOP_U32SUM) HARK_PAIR(VOP_U32SUM, VOP_U32MAX);
                 else if (vop1 == VOP_U32MAX) HARK_PAIR(VOP_U32MAX, VOP_U32MAX); else HARK_PAIR(VOP_U32MIN, VOP_U32MAX);
             } else {
                 if (vop1 == VOP_F32SUM) HARK_PAIR(VOP_F32SUM, VOP_U32MIN); else if (vop1 == VOP_U32SUM64) HARK_PAIR(VOP_U32SUM64, VOP_U32MIN);
+                else if (vop1 == VOP_U32SUM) HARK_PAIR(VOP_U32SUM, VOP_U32MIN);
                 else if (vop1 == VOP_U32MAX) HARK_PAIR(VOP_U32MAX, VOP_U32MIN); else HARK_PAIR(VOP_U32MIN, VOP_U32MIN);
             }
 #undef HARK_PAIR

@@ -1015,8 +1015,28 @@ int ref_groupby_dense(hark_context *ctx, const hark_table *view, const hark_tabl
     uint32_t *flags = nullptr, *pos = nullptr;
     int64_t ngroups = 0;
     const size_t runs = aggs.empty() ? 1 : aggs.size();                 // no aggregate: one pass just for the counts
+    auto vop_of = [&](size_t j) { return aggs[j].op == OP_SUM ? 1 : aggs[j].op == OP_MAX ? 2 : aggs[j].op == OP_MIN ? 3 : 4; };
+    std::vector<char> served(runs, 0);
+    // pair passes (k_fgb_dense_pair): a sum / max / min with another max / min from ONE producer + consumer pass; value 2
+    // must be a max or min (a 32-bit LDS slot), products keep their own pass.  Declines for small G or skew.
+    for (size_t j = 0; j < aggs.size() && !rc; j++) {
+        if (served[j] || vop_of(j) == 4) continue;
+        size_t q = aggs.size();
+        for (size_t t = 0; t < aggs.size(); t++) if (t != j && !served[t] && (vop_of(t) == 2 || vop_of(t) == 3)) { q = t; break; }
+        if (q == aggs.size()) continue;
+        bool ran = false;
+        rc = k_fgb_dense_pair(ctx, plan, nullptr, 0, 0.0f, reinterpret_cast<const int32_t *>(keys), view->cols[aggs[j].col].data, vop_of(j), 0,
+                              view->cols[aggs[q].col].data, vop_of(q), 0, n, &ran);
+        if (rc || !ran) break;
+        rc = hark_alloc(ctx, (void **)&vals[j], (size_t)G * 4);
+        if (!rc) rc = hark_alloc(ctx, (void **)&vals[q], (size_t)G * 4);
+        if (!rc) rc = hark_fgb_finish_u32(ctx, plan, vals[j], nullptr);
+        if (!rc) rc = hark_fgb_finish_u32_second(ctx, plan, vals[q]);
+        served[j] = served[q] = 1;
+    }
     for (size_t j = 0; j < runs && !rc; j++) {
-        const int vop = aggs.empty() ? 3 : aggs[j].op == OP_SUM ? 1 : aggs[j].op == OP_MAX ? 2 : aggs[j].op == OP_MIN ? 3 : 4;
+        if (!aggs.empty() && served[j]) continue;
+        const int vop = aggs.empty() ? 3 : vop_of(j);
         const uint32_t *col = aggs.empty() ? keys : static_cast<const uint32_t *>(view->cols[aggs[j].col].data);
         rc = hark_fgb_plan_set(plan, "vop", vop);
         if (!rc) rc = hark_fgb_reset(ctx, plan);
