@@ -10,17 +10,23 @@
 //      a contiguous slice of ~s / P sorted build entries WHATEVER the key distribution is, and
 //      buckets are ordered by key (a hash would balance as well but lose the reference's order);
 //   3. jpart_kernel streams the PROBE keys once (non-temporal, 16 B per lane), drops keys outside
-//      [min, max] of the build side, finds each row's bucket (binary search over the splitters in
-//      LDS) and routes (key, row id) through per-bucket LDS rings into workgroup-private slabs,
-//      whole 128-byte lines only -- the write-combining scheme of k_fgb.hip's producer;
+//      [min, max] of the build side, finds each row's bucket (an interpolation guess checked against
+//      four splitters in LDS, binary search when the guess is off by more than one) and routes
+//      (key, row id) through per-bucket LDS rings into workgroup-private slabs, whole 128-byte
+//      lines only -- the write-combining scheme of k_fgb.hip's producer;
 //   4. jbucket_kernel: one workgroup per bucket stages its slice of sorted build keys in LDS
-//      (<= 156 KiB; longer slices in rounds), streams the bucket's probe pairs and binary-searches
-//      each one there: a hit yields the GLOBAL rank of the first equal build entry, so a matching
-//      probe row becomes (rank, left row id), appended wave by wave to the bucket's survivor slab;
-//   5. the survivors (only the matching rows) are sorted by (rank, left row): two stable radix
-//      sorts of 32-bit words, all passes over bytes in which the words agree skipped;
-//   6. run lengths of the sorted build keys give each survivor its partner count; scan; one thread
-//      per OUTPUT row writes (left row id, right row id) -- join_expand_kernel of k_join.hip.
+//      (96 KiB; longer slices in rounds) with a bitmap of hashed keys in front, streams the bucket's
+//      probe pairs, queues the candidates per wave and binary-searches them 64 at a time: a hit
+//      yields the GLOBAL rank of the first equal build entry, so a matching probe row becomes
+//      (rank, left row id), appended wave by wave to the bucket's survivor slab;
+//   5. jorder_kernel: the survivors of a bucket (only the matching rows) are brought into
+//      (rank, left row) order inside the CU -- coarse histogram, sub-round bins, one LDS counter
+//      per rank, an LDS stage, the few rows of one key sorted in registers -- and leave as whole
+//      lines of (rank, left row, partner count); buckets are rank ranges in ascending order, so
+//      the concatenation is sorted (a rank with > 64 probe rows: two radix sorts instead);
+//   6. unique build keys: survivor i IS output row i (the right row id is one gather away);
+//      otherwise the partner counts are scanned and one lane per matching row writes its
+//      (left row id, right row id) pairs -- join_expand_kernel of k_join.hip.
 // Skewed probe keys can overflow a slab: the kernel reports it and the caller falls back.
 #include "hark_internal.h"
 
