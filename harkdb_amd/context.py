@@ -237,9 +237,17 @@ class FutharkContext:
         dev_preds = [(cmap[c], cmp, v) for c, cmp, v in preds]
         spec_of = lambda a: (a[0], 0 if a[1] is None else cmap[a[1]])
 
-        def having_order(res, having, order):
-            """HAVING / ORDER BY on a G-row result, still on the device."""
+        def having_order(res, having, order, limit=None):
+            """HAVING / ORDER BY on a G-row result, still on the device.  With ORDER BY and a LIMIT of at most 32 rows the
+            rows are SELECTED (hark_entry_topk: two small kernels) instead of compacted, fully sorted and cut."""
             keep = [res]
+            if (order is not None and limit is not None and 0 < limit <= 32 and len(having) <= 8
+                    and res.shape[0] <= (16384 // limit) * 4096 and not os.environ.get("HARK_NO_TOPK")):
+                m = res.shape[1]
+                t = eng.table_from_device(res.shape[0], [res.device_ptr(j) for j in range(m)], [res.dtype(j) for j in range(m)], keepalive=res)
+                top = eng.topk(t, having, order[0], order[1], limit, list(range(m)))
+                top._keep_chain = keep + [t]
+                return top
             for slot, cmp, v in having:
                 m = res.shape[1]
                 t = eng.table_from_device(res.shape[0], [res.device_ptr(j) for j in range(m)], [res.dtype(j) for j in range(m)], keepalive=res)
@@ -274,7 +282,7 @@ class FutharkContext:
             first_specs = [aggs[s - 1] for s in first] or [("count", None)]
             remap = {0: 0, **{s: 1 + j for j, s in enumerate(first)}}
             r1 = having_order(eng.filter_groupby(cur, dev_preds, gkey, [spec_of(a) for a in first_specs]),
-                              [(remap[s], cmp, v) for s, cmp, v in having], None if order is None else (remap[order[0]], order[1]))
+                              [(remap[s], cmp, v) for s, cmp, v in having], None if order is None else (remap[order[0]], order[1]), lim)
             c1 = r1.columns(limit=lim)
             c1 = [c[:lim] for c in c1]
             r2 = eng.filter_groupby_subset(cur, dev_preds, gkey, c1[0], [spec_of(aggs[s - 1]) for s in second])
@@ -286,7 +294,8 @@ class FutharkContext:
             for j, s_ in enumerate(second):
                 cols[s_] = c2[j]
         if cols is None:
-            res = having_order(eng.filter_groupby(cur, dev_preds, gkey, [spec_of(a) for a in aggs]), having, order)
+            res = having_order(eng.filter_groupby(cur, dev_preds, gkey, [spec_of(a) for a in aggs]), having, order,
+                               None if (host_having or host_order) else ir.get("limit"))
             # only the first LIMIT rows cross PCIe (unless key conditions / orders still have to run on the decoded result)
             cols = res.columns(limit=ir.get("limit") if not (host_having or host_order) else None)
         if decode is None:

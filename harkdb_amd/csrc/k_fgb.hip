@@ -1795,6 +1795,14 @@ int hark_fgb_finish_typed(hark_context *ctx, hark_fgb_plan *pl, int32_t kind, co
     if (blocks > (int64_t)ctx->num_cu * 4) blocks = (int64_t)ctx->num_cu * 4;
     fgb_decode_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(reinterpret_cast<const u64 *>(pl->acc_sum), pl->acc_cnt, pl->G, kind, pos, out);
     HIP_TRY(ctx, hipGetLastError());
+    return HARK_OK;                       // the plan's error word is read ONCE per statement (hark_fgb_check), not after every read-out
+}
+
+// reads the plan's sticky device error word (a surviving row's key outside [0, G)): one small copy + stream synchronisation
+int hark_fgb_check(hark_context *ctx, hark_fgb_plan *pl)
+{
+    hark_device_guard guard__(ctx);
+    if (!ctx || !pl) return HARK_EARG;
     return fgb_check_err(ctx, pl);
 }
 

@@ -596,6 +596,7 @@ int try_dense(hark_context *ctx, const hark_table *db, const PredList &preds,
     } else
         for (int64_t q = 0; q < n_aggs && !rc; q++)           // COUNTs that came before the first value pass
             if (!done[q]) rc = hark_fgb_finish_typed(ctx, plan, plan_of[q].kind, pos, res->cols[(size_t)q + 1].data);
+    if (!rc && plan) rc = hark_fgb_check(ctx, plan);          // the sticky error word, once per statement (it also drains the stream)
     if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "filter_groupby: kernels failed");
     hark_free(ctx, flags); hark_free(ctx, pos);
     if (plan) hark_fgb_plan_free(ctx, plan);

@@ -12,6 +12,7 @@
 //       filter.
 #include "hark_internal.h"
 int k_exclusive_scan_u32(hark_context *ctx, const uint32_t *in, int64_t n, uint32_t *out32, int64_t *out64, int64_t *total_host);
+int k_gather(hark_context *ctx, const void *src, int esz, const uint32_t *idx, void *dst, int64_t n);
 
 namespace {
 
@@ -283,6 +284,132 @@ int check_cols(hark_context *ctx, const hark_table *db, const int32_t *cols, int
     return HARK_OK;
 }
 
+// ---- HAVING + ORDER BY + LIMIT k in two small kernels (top-k) -------------------------------------------------
+// A G-row aggregation result that is filtered, fully radix-sorted and then cut to its first k rows costs a compaction
+// (3 kernels + 2 host reads), 4 radix passes (12 kernels) and a gather per column -- 0.25 ms of launches for a statement
+// whose scans take 1.7 ms.  For k <= kTopK the k best rows are SELECTED instead: every workgroup scans a slice, keeps
+// the rows that pass the predicates as (order key, row) pairs and extracts its k smallest by repeated workgroup-wide
+// minimum; one workgroup then extracts the k smallest of all candidates in order.  Order and ties are exactly the
+// stable sort's: ascending 64-bit order key (the sort word of the column, inverted for DESC), then ascending row.
+constexpr int kTopK = 64, kTopThreads = 256, kTopRows = 16;                  // rows per thread and slice pass
+struct TopPreds { const void *col[8]; int dtype[8], cmp[8]; Const64 c[8]; int n; };
+
+__device__ __forceinline__ uint64_t order_key(const void *col, int dtype, int64_t r, uint64_t inv)
+{
+    uint64_t k;
+    if (dtype == HARK_I64) k = static_cast<const uint64_t *>(col)[r] ^ 0x8000000000000000ull;
+    else {
+        uint32_t w = static_cast<const uint32_t *>(col)[r];
+        if (dtype == HARK_I32) w ^= 0x80000000u;
+        else if (dtype == HARK_F32) {
+            if (w == 0x80000000u) w = 0u;
+            if ((w & 0x7FFFFFFFu) > 0x7F800000u) w = 0xFFFFFFFFu;
+            else w ^= (w & 0x80000000u) ? 0xFFFFFFFFu : 0x80000000u;
+        }
+        k = w;
+        if (inv) return (uint64_t)(w ^ 0xFFFFFFFFu);                          // DESC flips the 32-bit word, as the radix sort's mask does
+    }
+    return k ^ inv;
+}
+
+__device__ __forceinline__ bool row_passes(const TopPreds &pr, int64_t r)
+{
+    for (int j = 0; j < pr.n; j++) {
+        bool ok;
+        switch (pr.dtype[j]) {
+        case HARK_F32: ok = cmp_val<float>(pr.cmp[j], static_cast<const float *>(pr.col[j])[r], pr.c[j].f); break;
+        case HARK_I32: ok = cmp_val<int32_t>(pr.cmp[j], static_cast<const int32_t *>(pr.col[j])[r], (int32_t)pr.c[j].i); break;
+        case HARK_U32: ok = cmp_val<uint32_t>(pr.cmp[j], static_cast<const uint32_t *>(pr.col[j])[r], pr.c[j].u); break;
+        default: ok = cmp_val<int64_t>(pr.cmp[j], static_cast<const int64_t *>(pr.col[j])[r], pr.c[j].i); break;
+        }
+        if (!ok) return false;
+    }
+    return true;
+}
+
+// (order key, row) pairs compare lexicographically; row = ~0 marks "nothing"
+struct TopPair { uint64_t key; uint64_t row; };
+__device__ __forceinline__ bool pair_lt(TopPair a, TopPair b) { return a.key < b.key || (a.key == b.key && a.row < b.row); }
+// stage 1: a slice of at most kTopThreads * kTopRows rows -> its k smallest (key, row) pairs, in order, at
+// cand[block * k ..]; fewer than k: padded with row = ~0.  A thread evaluates the predicates and order keys of its
+// kTopRows rows ONCE into registers (a bit per row says whether it is still in the race); the k rounds then compare
+// registers only.
+__global__ __launch_bounds__(kTopThreads) void topk_slice_kernel(TopPreds pr, const void *ocol, int odtype, uint64_t inv, int64_t n, int k,
+                                                                 TopPair *__restrict__ cand)
+{
+    __shared__ TopPair s_w[kTopThreads / 64];
+    const int64_t lo = (int64_t)blockIdx.x * ((int64_t)kTopThreads * kTopRows);
+    const TopPair none{~0ull, ~0ull};
+    uint64_t key[kTopRows];
+    uint32_t alive = 0;
+#pragma unroll
+    for (int j = 0; j < kTopRows; j++) {
+        const int64_t r = lo + (int64_t)j * kTopThreads + threadIdx.x;
+        key[j] = 0ull;
+        if (r < n && row_passes(pr, r)) { key[j] = order_key(ocol, odtype, r, inv); alive |= 1u << j; }
+    }
+    int t = 0;
+    for (; t < k; t++) {
+        TopPair mine = none;
+#pragma unroll
+        for (int j = 0; j < kTopRows; j++) {
+            const TopPair c{key[j], (uint64_t)(lo + (int64_t)j * kTopThreads + threadIdx.x)};
+            if (((alive >> j) & 1u) && (mine.row == ~0ull || pair_lt(c, mine))) mine = c;
+        }
+        // (row = ~0 marks "nothing": a real pair always wins against it, whatever its key)
+        TopPair best = mine;
+        for (int d = 32; d > 0; d >>= 1) {
+            TopPair o; o.key = __shfl_xor(best.key, d, 64); o.row = __shfl_xor(best.row, d, 64);
+            if (o.row != ~0ull && (best.row == ~0ull || pair_lt(o, best))) best = o;
+        }
+        const int wave = threadIdx.x >> 6;
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) s_w[wave] = best;
+        __syncthreads();
+        best = s_w[0];
+        for (int w = 1; w < kTopThreads / 64; w++) if (s_w[w].row != ~0ull && (best.row == ~0ull || pair_lt(s_w[w], best))) best = s_w[w];
+        if (best.row == ~0ull) break;
+#pragma unroll
+        for (int j = 0; j < kTopRows; j++) if ((uint64_t)(lo + (int64_t)j * kTopThreads + threadIdx.x) == best.row) alive &= ~(1u << j);
+        if (threadIdx.x == 0) cand[(int64_t)blockIdx.x * k + t] = best;
+    }
+    for (int u = t + (int)threadIdx.x; u < k; u += kTopThreads) cand[(int64_t)blockIdx.x * k + u] = none;
+}
+
+// stage 2: all candidates -> the k smallest row ids in order, and how many there are.  One workgroup; a thread holds
+// its candidates in registers (<= kTopCand per thread: the host bounds the number of slices accordingly).
+constexpr int kTopCand = 16;
+__global__ __launch_bounds__(1024) void topk_merge_kernel(const TopPair *__restrict__ cand, int64_t ncand, int k, uint32_t *__restrict__ rows_out, int64_t *__restrict__ count_out)
+{
+    __shared__ TopPair s_w[1024 / 64];
+    const TopPair none{~0ull, ~0ull};
+    TopPair mine_all[kTopCand];
+#pragma unroll
+    for (int j = 0; j < kTopCand; j++) { const int64_t i = (int64_t)j * 1024 + threadIdx.x; mine_all[j] = i < ncand ? cand[i] : none; }
+    int found = 0;
+    for (int t = 0; t < k; t++) {
+        TopPair best = none;
+#pragma unroll
+        for (int j = 0; j < kTopCand; j++) if (mine_all[j].row != ~0ull && (best.row == ~0ull || pair_lt(mine_all[j], best))) best = mine_all[j];
+        for (int d = 32; d > 0; d >>= 1) {
+            TopPair o; o.key = __shfl_xor(best.key, d, 64); o.row = __shfl_xor(best.row, d, 64);
+            if (o.row != ~0ull && (best.row == ~0ull || pair_lt(o, best))) best = o;
+        }
+        const int wave = threadIdx.x >> 6;
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) s_w[wave] = best;
+        __syncthreads();
+        best = s_w[0];
+        for (int w = 1; w < 1024 / 64; w++) if (s_w[w].row != ~0ull && (best.row == ~0ull || pair_lt(s_w[w], best))) best = s_w[w];
+        if (best.row == ~0ull) break;
+#pragma unroll
+        for (int j = 0; j < kTopCand; j++) if (mine_all[j].row == best.row) mine_all[j] = none;
+        if (threadIdx.x == 0) rows_out[t] = (uint32_t)best.row;
+        found++;
+    }
+    if (threadIdx.x == 0) *count_out = found;
+}
+
 } // namespace
 
 static Const64 read_const(int dtype, const void *constant)
@@ -395,6 +522,67 @@ int hark_entry_filter_sel(hark_context *ctx, hark_result **out, const hark_table
                           const void *constant, const int32_t *cols, int64_t k, int32_t want_row_index)
 {
     return hark_entry_filter_sel_and(ctx, out, db, 1, &where_col, &cmp, &constant, cols, k, want_row_index);
+}
+
+// HAVING (n_preds >= 0 predicates, AND) + ORDER BY key_col [DESC] + LIMIT k over a table, k <= 64, at most 2^32 rows: the
+// first k rows of what hark_entry_filter_sel_and + hark_entry_sort would deliver (same order, same ties), columns `cols`.
+int hark_entry_topk(hark_context *ctx, hark_result **out, const hark_table *db, int64_t n_preds, const int32_t *where_cols,
+                    const int32_t *cmps, const void *const *constants, int32_t key_col, int32_t descending, int64_t k,
+                    const int32_t *cols, int64_t ncols)
+{
+    hark_device_guard guard__(ctx);
+    if (!ctx || !out || !db) return HARK_EARG;
+    *out = nullptr;
+    if (n_preds < 0 || n_preds > 8 || (n_preds && (!where_cols || !cmps || !constants)) || k < 1 || k > kTopK || ncols < 0 || ncols > kMaxCols || db->n > 0xFFFFFFFFll)
+        return hark_fail(ctx, HARK_EUNSUPPORTED, "topk: 0..8 predicates, 1 <= k <= %d, at most %d columns", kTopK, kMaxCols);
+    if (key_col < 0 || key_col >= db->m) return hark_fail(ctx, HARK_EBOUNDS, "topk: key column %d out of bounds", key_col);
+    HARK_TRY(check_cols(ctx, db, cols, ncols, "topk"));
+    HARK_TRY(check_cols(ctx, db, where_cols, n_preds, "topk(where)"));
+    TopPreds pr{}; pr.n = (int)n_preds;
+    for (int64_t j = 0; j < n_preds; j++) {
+        if (!constants[j] || cmps[j] < HARK_CMP_GT || cmps[j] > HARK_CMP_NE) return hark_fail(ctx, HARK_EARG, "topk: bad predicate %lld", (long long)j);
+        pr.col[j] = db->cols[where_cols[j]].data; pr.dtype[j] = db->cols[where_cols[j]].dtype; pr.cmp[j] = cmps[j];
+        pr.c[j] = read_const(pr.dtype[j], constants[j]);
+    }
+    hark_result *res = new hark_result();
+    res->cols.resize((size_t)ncols);
+    for (int64_t j = 0; j < ncols; j++) { res->cols[(size_t)j].dtype = db->cols[cols[j]].dtype; res->cols[(size_t)j].data = nullptr; res->cols[(size_t)j].owned = true; }
+    res->n = 0;
+    const int64_t n = db->n;
+    if (n == 0) { for (auto &c : res->cols) c.owned = false; *out = res; return HARK_OK; }
+    const int64_t nblk = (n + (int64_t)kTopThreads * kTopRows - 1) / ((int64_t)kTopThreads * kTopRows);      // slices of 4096 rows
+    if (nblk * k > (int64_t)kTopCand * 1024) {                             // the merge stage holds every candidate in registers
+        for (auto &c : res->cols) c.owned = false;
+        delete res;
+        return hark_fail(ctx, HARK_EUNSUPPORTED, "topk: at most %lld rows for k = %lld", (long long)((int64_t)kTopCand * 1024 / k * kTopThreads * kTopRows), (long long)k);
+    }
+    TopPair *cand = nullptr; uint32_t *rows = nullptr; int64_t *count = nullptr;
+    int rc = hark_alloc(ctx, (void **)&cand, (size_t)nblk * (size_t)k * sizeof(TopPair));
+    if (!rc) rc = hark_alloc(ctx, (void **)&rows, (size_t)k * 4);
+    if (!rc) rc = hark_alloc(ctx, (void **)&count, 16);
+    int64_t found = 0;
+    if (!rc) {
+        hipStream_t st = ctx->stream;
+        const uint64_t inv = descending ? ~0ull : 0ull;
+        topk_slice_kernel<<<dim3((unsigned)nblk), dim3(kTopThreads), 0, st>>>(pr, db->cols[key_col].data, db->cols[key_col].dtype, inv, n, (int)k, cand);
+        topk_merge_kernel<<<1, 1024, 0, st>>>(cand, nblk * k, (int)k, rows, count);
+        if (hipGetLastError() != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "topk: launch failed");
+        if (!rc) rc = hark_read_words(ctx, count, &found, 1);
+    }
+    if (!rc) {
+        res->n = found;
+        for (int64_t j = 0; j < ncols && !rc && found > 0; j++) {
+            const int esz = (int)hark_dtype_size(res->cols[(size_t)j].dtype);
+            rc = hark_alloc(ctx, &res->cols[(size_t)j].data, (size_t)found * esz);
+            if (!rc) rc = k_gather(ctx, db->cols[cols[j]].data, esz, rows, res->cols[(size_t)j].data, found);
+        }
+        if (found == 0) for (auto &c : res->cols) c.owned = false;
+        if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "topk: kernels failed");
+    }
+    hark_free(ctx, cand); hark_free(ctx, rows); hark_free(ctx, count);
+    if (rc) { for (auto &c : res->cols) if (c.owned && c.data) hark_free(ctx, c.data); delete res; return rc; }
+    *out = res;
+    return HARK_OK;
 }
 
 int hark_entry_filter_sel_and(hark_context *ctx, hark_result **out, const hark_table *db, int64_t n_preds, const int32_t *where_cols,

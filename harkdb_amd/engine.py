@@ -81,8 +81,8 @@ class Result:
 
     def columns(self, limit=None):
         n, m = self.shape
-        if limit is not None and limit < n and m > 1:                  # a LIMIT prefix: every column with one synchronisation
-            rows = max(int(limit), 0)
+        rows = n if limit is None else min(n, max(int(limit), 0))
+        if m > 1 and rows > 0 and rows * 16 * m <= 65536:              # a small result or a LIMIT prefix: every column with one synchronisation
             outs = [np.empty(rows, dtype=self.dtype(j)) for j in range(m)]
             ptrs = (C.c_void_p * m)(*[o.ctypes.data for o in outs])
             self._eng._chk(self._eng.lib.hark_result_columns_prefix(self._eng.ctx, self._h, rows, ptrs))
@@ -400,6 +400,15 @@ class Engine:
         wc, wo, wp, keep = self._predicates(table, list(where))
         h = C.c_void_p()
         self._chk(self.lib.hark_entry_filter_groupby_and(self.ctx, C.byref(h), table._h, len(where), wc, wo, wp, int(g_col), pc, po, cols.size))
+        return Result(self, h)
+
+    def topk(self, table, where, key_col, descending, k, cols):
+        """The first k (<= 64) rows of filter_sel(where) + sort(key_col) without materialising either."""
+        a, pa = _ffi.i32_array(cols)
+        where = list(where or [])
+        wc, wo, wp, keep = self._predicates(table, where)
+        h = C.c_void_p()
+        self._chk(self.lib.hark_entry_topk(self.ctx, C.byref(h), table._h, len(where), wc, wo, wp, int(key_col), 1 if descending else 0, int(k), pa, a.size))
         return Result(self, h)
 
     def filter_groupby_subset(self, table, where, g_col, keys, aggs):

@@ -391,6 +391,42 @@ def test_groupby_subset_entry_against_pandas():
     eng.close()
 
 
+def test_topk_entry_equals_filter_then_sort_then_cut():
+    """hark_entry_topk against hark_entry_filter_sel_and + hark_entry_sort + the first k rows: every dtype as the order key,
+    ascending and descending, ties (many equal keys: table order decides), NaN and -0.0, no row passing, k larger than the
+    number of survivors."""
+    from harkdb_amd.engine import Engine
+    eng = Engine(0)
+    rng = np.random.default_rng(77)
+    n = 300_001
+    f = (rng.integers(-40, 40, n) / 4).astype(np.float32)
+    f[::1000] = np.nan
+    f[1::1000] = -0.0
+    cols = [rng.integers(0, 50, n).astype(np.int32) - 25, rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32), f,
+            rng.integers(-3, 3, n).astype(np.int64) * (2**40), rng.random(n).astype(np.float32)]
+    t = eng.table_from_columns(cols)
+    for key in range(4):
+        for desc in (False, True):
+            for where, k in (([], 7), ([(4, ">", 0.5)], 33), ([(4, ">", 0.5), (0, "<", 10)], 64), ([(4, ">", 2.0)], 5), ([(4, ">", 0.99999)], 64)):
+                top = eng.topk(t, where, key, desc, k, [0, 1, 2, 3])
+                if where:
+                    fl = eng.filter_sel(t, where, cols=[0, 1, 2, 3, 4], want_row_index=False)
+                    if fl.shape[0] == 0:
+                        assert top.shape[0] == 0
+                        continue
+                    t2 = eng.table_from_device(fl.shape[0], [fl.device_ptr(j) for j in range(5)], [fl.dtype(j) for j in range(5)], keepalive=fl)
+                else:
+                    t2 = t
+                so = eng.sort(t2, key, [0, 1, 2, 3], descending=desc)
+                exp = so.columns(limit=k)
+                got = top.columns()
+                assert len(got[0]) == min(k, so.shape[0]), (key, desc, where)
+                for a, b in zip(got, exp):
+                    assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b[: len(a)].view(np.uint32) if b.dtype == np.float32 else b[: len(a)]), (key, desc, where)
+    t.free()
+    eng.close()
+
+
 @pytest.mark.parametrize("late", [True, False])
 def test_limit_statements_compute_unordered_aggregates_late(late):
     """ORDER BY / HAVING + LIMIT: the aggregates nobody filters or orders by are computed for the surviving groups only
