@@ -86,6 +86,8 @@ SIGNATURES = {
     "hark_op_filter_groupby_dense_f32": (C.c_int, [_vp, _vp, _vp, _i32, _f32, _vp, _vp, _i64]),
     "hark_fgb_acc_device": (C.c_int, [_vp, _pp, _pp]),
     "hark_fgb_finish": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "hark_fgb_finish_async": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "hark_fgb_check": (C.c_int, [_vp, _vp]),
     "hark_op_groupby_dense_u32": (C.c_int, [_vp, _vp, _vp, _vp, _i64]),
     "hark_fgb_finish_u32": (C.c_int, [_vp, _vp, _vp, _vp]),
     "hark_fgb_timing": (C.c_int, [_vp, _vp, C.POINTER(C.c_double), C.POINTER(_i64)]),

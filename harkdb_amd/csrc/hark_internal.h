@@ -127,7 +127,6 @@ struct hark_fgb_plan {
 int k_gen_columns(hark_context *ctx, uint64_t seed, int64_t first_row, int64_t n, uint32_t G,
                   int exact, float *p, int32_t *k, float *v);
 int hark_fgb_finish_typed(hark_context *ctx, hark_fgb_plan *pl, int32_t kind, const uint32_t *pos, void *out);
-int hark_fgb_check(hark_context *ctx, hark_fgb_plan *pl);
 int k_fgb_dense_f32(hark_context *ctx, hark_fgb_plan *plan, const float *p, int cmp, float thr,
                     const int32_t *k, const float *v, int64_t n);
 

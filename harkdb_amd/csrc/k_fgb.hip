@@ -1747,7 +1747,9 @@ int hark_fgb_finish_u32_second(hark_context *ctx, hark_fgb_plan *pl, uint32_t *v
     return HARK_OK;
 }
 
-int hark_fgb_finish(hark_context *ctx, hark_fgb_plan *pl, float *sum_out, int64_t *count_out)
+// Stream-ordered read-out without the host round trip: the sticky error word stays on the device until hark_fgb_check
+// (or a later hark_fgb_finish) reads it -- a loop of steps then never waits for the host between steps.
+int hark_fgb_finish_async(hark_context *ctx, hark_fgb_plan *pl, float *sum_out, int64_t *count_out)
 {
     hark_device_guard guard__(ctx);
     if (!ctx || !pl) return HARK_EARG;
@@ -1758,15 +1760,13 @@ int hark_fgb_finish(hark_context *ctx, hark_fgb_plan *pl, float *sum_out, int64_
         fgb_finish_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(pl->acc_sum, pl->acc_cnt, pl->G, sum_out, count_out);
         HIP_TRY(ctx, hipGetLastError());
     }
-    int32_t *e = reinterpret_cast<int32_t *>(ctx->h_pin);
-    HIP_TRY(ctx, hipMemcpyAsync(e, pl->err, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (*e != 0) {
-        const int code = *e;
-        HIP_TRY(ctx, hipMemsetAsync(pl->err, 0, sizeof(int32_t), ctx->stream));
-        return hark_fail(ctx, code, "filter_groupby: a surviving row has a key outside [0, %lld)", (long long)pl->G);
-    }
     return HARK_OK;
+}
+
+int hark_fgb_finish(hark_context *ctx, hark_fgb_plan *pl, float *sum_out, int64_t *count_out)
+{
+    HARK_TRY(hark_fgb_finish_async(ctx, pl, sum_out, count_out));
+    return hark_fgb_check(ctx, pl);
 }
 
 // Sum of the event-timed kernel durations since the last call, by kernel kind

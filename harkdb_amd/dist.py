@@ -193,7 +193,7 @@ class ShardedFgb:
             self.plan.reset()
             self.plan.run(p, cmp, thr, k, v, n)
             allreduce_partials(self.sum_t, self.cnt_t)
-            self.plan.finish(sum_out, count_out)
+            self.plan.finish(sum_out, count_out, check=False)         # no host round trip between steps: flush() checks
             return
         i = self.turn
         self.turn = 1 - i
@@ -210,12 +210,14 @@ class ShardedFgb:
         plan, works, sum_out, count_out = item
         for w in works:
             w.wait()                                                  # our stream waits for the collective, the host does not
-        plan.finish(sum_out, count_out)
+        plan.finish(sum_out, count_out, check=False)
 
     def flush(self):
         """Finish the step still in flight (its all-reduce has been running beside nothing since the last step())."""
         item, self.pending = self.pending, None
         self._finish(item)
+        for pl in self.plans:                                         # the sticky error words of the steps since the last flush
+            pl.check()
 
 
 # ---------------------------------------------------------------------------

@@ -200,8 +200,14 @@ class FgbPlan:
         self._eng._chk(self._eng.lib.hark_fgb_acc_device(self._h, C.byref(s), C.byref(c)))
         return s.value, c.value
 
-    def finish(self, sum_ptr=None, count_ptr=None):
-        self._eng._chk(self._eng.lib.hark_fgb_finish(self._eng.ctx, self._h, sum_ptr, count_ptr))
+    def finish(self, sum_ptr=None, count_ptr=None, check=True):
+        """Read the accumulators out; check=False leaves the sticky error word on the device (no host round trip):
+        call check() once after the last step."""
+        fn = self._eng.lib.hark_fgb_finish if check else self._eng.lib.hark_fgb_finish_async
+        self._eng._chk(fn(self._eng.ctx, self._h, sum_ptr, count_ptr))
+
+    def check(self):
+        self._eng._chk(self._eng.lib.hark_fgb_check(self._eng.ctx, self._h))
 
     def timing(self):
         """({kind: ms}, {kind: launches}) since the last call; needs set('timing', 1)."""

@@ -265,8 +265,11 @@ class _FakePlan:
         self.sum_t += torch.from_numpy(np.bincount(k[keep], weights=v[keep], minlength=self.G))
         self.cnt_t += torch.from_numpy(np.bincount(k[keep], minlength=self.G))
 
-    def finish(self, sum_out, count_out):
+    def finish(self, sum_out, count_out, check=True):
         sum_out[:] = self.sum_t.numpy(); count_out[:] = self.cnt_t.numpy()
+
+    def check(self):
+        self.checked = True
 
 
 def _pipeline_worker(rank, world, port, how, q):
