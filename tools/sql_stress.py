@@ -45,6 +45,12 @@ while time.time() < t_end and bad is None:
                     thr = int(np.median(g.size().to_numpy()))
                     stmt += f" having count(*) >= {thr}"
                     exp = exp[g.size().to_numpy() >= thr]
+                if kind == "group" and rng.random() < 0.4:
+                    # ORDER BY an aggregate (exact ones: integer-valued data) or the key; ties keep key order (stable)
+                    cand = [keys[0]] + [f"{f}({c})" for f, c in pick if f != "avg"]
+                    oc = str(rng.choice(cand)); desc = bool(rng.random() < 0.5)
+                    stmt += f" order by {oc}{' desc' if desc else ''}"
+                    exp = exp.sort_values(oc, ascending=not desc, kind="stable")
             elif kind == "distinct":
                 keys = [str(c) for c in rng.choice(["a", "b", "s"], size=int(rng.integers(1, 3)), replace=False)]
                 stmt = f"select distinct {', '.join(keys)} from t{where_sql}"
