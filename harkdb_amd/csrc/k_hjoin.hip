@@ -29,6 +29,7 @@
 //      (left row id, right row id) pairs -- join_expand_kernel of k_join.hip.
 // Skewed probe keys can overflow a slab: the kernel reports it and the caller falls back.
 #include "hark_internal.h"
+#include "sort_networks.h"
 
 int k_sort_column(hark_context *ctx, const void *col, int dtype, int64_t n, bool descending, const uint32_t *payload,
                   uint32_t **vals_out, uint32_t **words_out);
@@ -402,35 +403,10 @@ __global__ __launch_bounds__(1024) void jsum_kernel(const uint32_t *__restrict__
 //      first version ran at 0.8 TB/s.
 // A group of 2^gs ranks with more survivors than the stage holds, or a rank with more than kTieMax rows, raises *general:
 // the bucket is copied as it is and the caller sorts all survivors with radix passes instead.
-// Sorting networks over N registers (compare-exchange lists: optimal 4- and 8-input networks, Batcher's odd-even merge sort
-// for 16 inputs, 63 comparators), fully unrolled: no dynamic indexing, so the values stay in VGPRs.
-__device__ __forceinline__ void cex(uint32_t &a, uint32_t &b) { const uint32_t lo = min(a, b), hi = max(a, b); a = lo; b = hi; }
-__device__ __forceinline__ void sort4(uint32_t (&v)[4])
-{
-    cex(v[0], v[1]); cex(v[2], v[3]); cex(v[0], v[2]); cex(v[1], v[3]); cex(v[1], v[2]);
-}
-__device__ __forceinline__ void sort8(uint32_t (&v)[8])
-{
-    cex(v[0], v[1]); cex(v[2], v[3]); cex(v[4], v[5]); cex(v[6], v[7]);
-    cex(v[0], v[2]); cex(v[1], v[3]); cex(v[4], v[6]); cex(v[5], v[7]);
-    cex(v[1], v[2]); cex(v[5], v[6]); cex(v[0], v[4]); cex(v[3], v[7]);
-    cex(v[1], v[5]); cex(v[2], v[6]);
-    cex(v[1], v[4]); cex(v[3], v[6]);
-    cex(v[2], v[4]); cex(v[3], v[5]);
-    cex(v[3], v[4]);
-}
-__device__ __forceinline__ void sort16(uint32_t (&v)[16])
-{
-#define CX(a, b) cex(v[a], v[b])
-    CX(0, 1); CX(2, 3); CX(0, 2); CX(1, 3); CX(1, 2); CX(4, 5); CX(6, 7); CX(4, 6); CX(5, 7); CX(5, 6); CX(0, 4);
-    CX(2, 6); CX(2, 4); CX(1, 5); CX(3, 7); CX(3, 5); CX(1, 2); CX(3, 4); CX(5, 6); CX(8, 9); CX(10, 11);
-    CX(8, 10); CX(9, 11); CX(9, 10); CX(12, 13); CX(14, 15); CX(12, 14); CX(13, 15); CX(13, 14); CX(8, 12);
-    CX(10, 14); CX(10, 12); CX(9, 13); CX(11, 15); CX(11, 13); CX(9, 10); CX(11, 12); CX(13, 14); CX(0, 8);
-    CX(4, 12); CX(4, 8); CX(2, 10); CX(6, 14); CX(6, 10); CX(2, 4); CX(6, 8); CX(10, 12); CX(1, 9); CX(5, 13);
-    CX(5, 9); CX(3, 11); CX(7, 15); CX(7, 11); CX(3, 5); CX(7, 9); CX(11, 13); CX(1, 2); CX(3, 4); CX(5, 6);
-    CX(7, 8); CX(9, 10); CX(11, 12); CX(13, 14);
-#undef CX
-}
+// Sorting networks over N registers: sort_networks.h (uint32 values, plain order here).
+__device__ __forceinline__ void sort4(uint32_t (&v)[4]) { net_sort4(v, [](uint32_t a, uint32_t b) { return a < b; }); }
+__device__ __forceinline__ void sort8(uint32_t (&v)[8]) { net_sort8(v, [](uint32_t a, uint32_t b) { return a < b; }); }
+__device__ __forceinline__ void sort16(uint32_t (&v)[16]) { net_sort16(v, [](uint32_t a, uint32_t b) { return a < b; }); }
 constexpr int kStage = 12288, kFine = 10240, kCoarse = 2048, kTieMax = 64, kMaxSub = 256;
 __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restrict__ surv, size_t stride, const uint32_t *__restrict__ scount,
                                                            const uint32_t *__restrict__ sround, int chunk_cap,

@@ -24,6 +24,7 @@
 int k_argsort_column(hark_context *ctx, const void *col, int dtype, int64_t n, bool descending,
                      uint32_t **perm_out, uint32_t **sorted_words_out);
 int k_gather(hark_context *ctx, const void *src, int esz, const uint32_t *idx, void *dst, int64_t n);
+int k_argsort_i64_keys(hark_context *ctx, const void *col, int64_t n, uint32_t **perm_out, uint64_t **keys_out);
 int k_sort_column(hark_context *ctx, const void *col, int dtype, int64_t n, bool descending, const uint32_t *payload,
                   uint32_t **vals_out, uint32_t **words_out);
 int k_exclusive_scan_u32(hark_context *ctx, const uint32_t *in, int64_t n, uint32_t *out32, int64_t *out64, int64_t *total_host);
@@ -279,11 +280,8 @@ int hark_entry_join(hark_context *ctx, hark_result **out, const hark_table *db1,
     const void *lcol = db1->cols[col1].data, *rcol = db2->cols[col2].data;
     bool filtered = false, partitioned = false, unique = false;   // unique: partitioned path, all build keys distinct (one partner per survivor)
     // ---- the build side is sorted first: both paths need it
-    rc = k_argsort_column(ctx, rcol, k64 ? HARK_I64 : HARK_U32, s, false, &rperm, k64 ? nullptr : &rkeys);
-    if (!rc && k64) {
-        rc = hark_alloc(ctx, (void **)&rk64, (size_t)s * 8);
-        if (!rc) gather_biased_i64_kernel<<<grid_for(ctx, s), 256, 0, st>>>(static_cast<const uint64_t *>(rcol), rperm, rk64, s);
-    }
+    if (k64) rc = k_argsort_i64_keys(ctx, rcol, s, &rperm, &rk64);          // permutation + the sorted (biased) keys in one go
+    else rc = k_argsort_column(ctx, rcol, HARK_U32, s, false, &rperm, &rkeys);
     // ---- partitioned path (k_hjoin.hip): matching probe rows as (rank in the sorted build side, left row), sorted
     if (!rc) {
         uint32_t *prank = nullptr, *plrow = nullptr, *pcnt = nullptr;

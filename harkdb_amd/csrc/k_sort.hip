@@ -19,6 +19,7 @@
 //      written out as contiguous runs.  Positions are assigned strictly in
 //      input order, so the pass is stable.
 #include "hark_internal.h"
+#include "sort_networks.h"
 
 namespace {
 
@@ -315,6 +316,47 @@ __global__ __launch_bounds__(256) void gather_u64_kernel(const uint64_t *__restr
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[idx[i]];
 }
 
+// ---- i64 keys: high word first, then the short runs of equal high words ------------------------------------------
+// An LSD sort of 64-bit keys is eight 8-bit passes.  Keys that are spread over 64 bits (hashes, ids: BASELINE
+// configs[3]) are almost ordered by their high words alone: a stable sort by the high word (four passes), then every
+// run of equal high words -- a handful of keys -- is sorted by (low word, position in the run) in registers.  A run
+// longer than kRunMax raises *too_long and the caller takes the eight-pass path.
+constexpr int kRunMax = 16;
+struct RunElem { uint64_t key; uint32_t perm, pos; };
+__global__ __launch_bounds__(256) void i64_fix_runs_kernel(const uint64_t *__restrict__ col, const uint32_t *__restrict__ hi_sorted,
+                                                           uint32_t *__restrict__ perm, uint64_t *__restrict__ keys_out, int64_t n, int32_t *__restrict__ too_long)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    auto lt = [](const RunElem &a, const RunElem &b) { return a.key < b.key || (a.key == b.key && a.pos < b.pos); };
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t h = hi_sorted[i];
+        if (i > 0 && hi_sorted[i - 1] == h) continue;                            // not a run head
+        int len = 1;
+        while (len <= kRunMax && i + len < n && hi_sorted[i + len] == h) len++;
+        if (len > kRunMax) { *too_long = 1; continue; }
+        if (len == 1) { keys_out[i] = col[perm[i]] ^ 0x8000000000000000ull; continue; }
+        RunElem v[kRunMax];
+#pragma unroll
+        for (int j = 0; j < kRunMax; j++) {
+            const bool in = j < len;
+            const uint32_t p = in ? perm[i + j] : 0u;
+            v[j].key = in ? (col[p] ^ 0x8000000000000000ull) : ~0ull;
+            v[j].perm = p; v[j].pos = in ? (uint32_t)j : 0xFFFFu;
+        }
+        if (len <= 4) { RunElem w[4] = {v[0], v[1], v[2], v[3]}; net_sort4(w, lt); v[0] = w[0]; v[1] = w[1]; v[2] = w[2]; v[3] = w[3]; }
+        else if (len <= 8) { RunElem w[8]; for (int j = 0; j < 8; j++) w[j] = v[j]; net_sort8(w, lt); for (int j = 0; j < 8; j++) v[j] = w[j]; }
+        else net_sort16(v, lt);
+#pragma unroll
+        for (int j = 0; j < kRunMax; j++) if (j < len) { perm[i + j] = v[j].perm; keys_out[i + j] = v[j].key; }
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_biased_u64_kernel(const uint64_t *__restrict__ src, const uint32_t *__restrict__ perm, uint64_t *__restrict__ dst, int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[perm[i]] ^ 0x8000000000000000ull;
+}
+
 } // namespace
 
 // Workspace bytes for sorting n pairs.
@@ -476,6 +518,58 @@ int k_argsort_column(hark_context *ctx, const void *col, int dtype, int64_t n, b
                      uint32_t **perm_out, uint32_t **sorted_words_out)
 {
     return k_sort_column(ctx, col, dtype, n, descending, nullptr, perm_out, sorted_words_out);
+}
+
+// Stable ascending argsort of an i64 column together with the SORTED keys (biased by 2^63: unsigned order = signed order):
+// *perm_out (n x u32) and *keys_out (n x u64) are pool blocks the caller frees.  High word first + run fix-up (above)
+// when the high words differ, the plain low-word sort when they do not, the eight-pass path as the fallback.
+int k_argsort_i64_keys(hark_context *ctx, const void *col, int64_t n, uint32_t **perm_out, uint64_t **keys_out)
+{
+    *perm_out = nullptr; *keys_out = nullptr;
+    if (n <= 0) return HARK_OK;
+    hipStream_t st = ctx->stream;
+    uint64_t *keys = nullptr;
+    int rc = hark_alloc(ctx, (void **)&keys, (size_t)n * 8);
+    if (rc) return rc;
+    uint32_t diff_hi = 0u;
+    rc = k_transform_keys(ctx, col, HARK_I64, 1, nullptr, n, &diff_hi);
+    bool done = false;
+    if (!rc && passes_of(diff_hi) != 0u && !getenv("HARK_SORT_I64_LSD")) {
+        uint32_t *k0 = nullptr, *k1 = nullptr, *v0 = nullptr, *v1 = nullptr, *ws = nullptr; int32_t *flag = nullptr;
+        const size_t b = (size_t)n * 4;
+        rc = hark_alloc(ctx, (void **)&k0, b);
+        if (!rc) rc = hark_alloc(ctx, (void **)&k1, b);
+        if (!rc) rc = hark_alloc(ctx, (void **)&v0, b);
+        if (!rc) rc = hark_alloc(ctx, (void **)&v1, b);
+        if (!rc) rc = hark_alloc(ctx, (void **)&ws, k_sort_workspace_bytes(n, ctx->num_cu));
+        if (!rc) rc = hark_alloc(ctx, (void **)&flag, 16);
+        uint32_t *ko = k0, *vo = v0;
+        if (!rc) rc = k_transform_keys(ctx, col, HARK_I64, 1, k0, n, nullptr);
+        if (!rc) rc = k_sort_pairs_u32(ctx, k0, k1, v0, v1, nullptr, n, 0u, ws, passes_of(diff_hi), &ko, &vo);
+        int64_t general = 0;
+        if (!rc) {
+            hipMemsetAsync(flag, 0, 16, st);
+            i64_fix_runs_kernel<<<dim3((unsigned)grid256(ctx, n)), dim3(256), 0, st>>>(static_cast<const uint64_t *>(col), ko, vo, keys, n, flag);
+            if (hipGetLastError() != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "sort: run fix-up launch failed");
+            if (!rc) rc = hark_read_words(ctx, flag, &general, 1);
+        }
+        if (!rc && (general & 0xFFFFFFFFll) == 0) { *perm_out = vo; done = true; }
+        uint32_t *bufs[4] = {k0, k1, v0, v1};
+        for (uint32_t *q : bufs) if (q && !(done && q == vo)) hark_free(ctx, q);
+        hark_free(ctx, ws); hark_free(ctx, flag);
+    }
+    if (!rc && !done) {                                              // equal high words, or a long run of them: the general path
+        uint32_t *perm = nullptr;
+        rc = k_sort_column(ctx, col, HARK_I64, n, false, nullptr, &perm, nullptr);
+        if (!rc) {
+            gather_biased_u64_kernel<<<dim3((unsigned)grid256(ctx, n)), dim3(256), 0, st>>>(static_cast<const uint64_t *>(col), perm, keys, n);
+            if (hipGetLastError() != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "sort: gather launch failed");
+        }
+        if (rc) hark_free(ctx, perm); else *perm_out = perm;
+    }
+    if (rc) { hark_free(ctx, keys); if (*perm_out) { hark_free(ctx, *perm_out); *perm_out = nullptr; } return rc; }
+    *keys_out = keys;
+    return HARK_OK;
 }
 
 

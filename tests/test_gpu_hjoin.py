@@ -61,6 +61,10 @@ CASES = {
     "build side larger than probe": dict(dt=np.uint32, n=1 << 18, s=600_000, pool=None, hit=0.4),
     "u32 unique build keys (primary key): no counts, no expansion": dict(dt=np.uint32, n=400_000, s=60_000, pool=None, hit=0.5, unique=True),
     "i64 unique build keys, every second probe row hits": dict(dt=np.int64, n=(1 << 19) + 3, s=100_000, pool=None, hit=0.5, unique=True),
+    # the build side's i64 sort orders by the high word first and fixes runs of equal high words in registers (<= 16 keys):
+    "i64 build keys in short runs of equal high words (2..16)": dict(dt=np.int64, n=300_000, s=60_000, pool=None, hit=0.4, hiruns=16),
+    "i64 build keys with a run of 17 equal high words (eight-pass fallback)": dict(dt=np.int64, n=300_000, s=60_000, pool=None, hit=0.4, hiruns=17),
+    "i64 build keys below 2^40 (few distinct high words: fallback)": dict(dt=np.int64, n=280_000, s=50_000, pool=None, hit=0.3, small=True),
 }
 
 
@@ -72,6 +76,17 @@ def _make(case, seed):
     if c["pool"]:
         pool = rng.integers(info.min, info.max, size=c["pool"], dtype=np.int64).astype(dt)
         rk = pool[rng.integers(0, len(pool), size=s)]
+    elif c.get("hiruns"):
+        m = c["hiruns"]
+        hi = rng.integers(-2**31, 2**31, size=s // 4, dtype=np.int64)
+        hi = np.repeat(hi, rng.integers(1, 8, size=len(hi)))[:s]
+        hi[:m] = 123456                                                   # one run of exactly m equal high words
+        hi = np.resize(hi, s)
+        rk = ((hi << 32) | rng.integers(0, 2**32, size=s, dtype=np.int64)).astype(np.int64)
+        rk[1] = rk[0]                                                     # and a fully equal pair inside it
+        rk = rk[rng.permutation(s)]
+    elif c.get("small"):
+        rk = rng.integers(-2**39, 2**39, size=s, dtype=np.int64)
     elif c.get("unique"):
         rk = (rng.permutation(s).astype(np.int64) * 40503 - 1_000_000_007).astype(dt)     # distinct, scattered, some negative
     else:
