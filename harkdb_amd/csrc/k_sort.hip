@@ -459,8 +459,8 @@ int k_gather(hark_context *ctx, const void *src, int esz, const uint32_t *idx, v
 // frees) holds the payload in sorted order; if words_out is non-null it receives the sorted keys as 32-bit words:
 // the column VALUES themselves for u32 / i32 keys, the order-preserving sort words for f32 keys (equality tests
 // only); not available for i64.  Radix passes over key bytes in which all keys agree are skipped.
-int k_sort_column(hark_context *ctx, const void *col, int dtype, int64_t n, bool descending, const uint32_t *payload,
-                  uint32_t **vals_out, uint32_t **words_out)
+static int k_sort_column_lsd(hark_context *ctx, const void *col, int dtype, int64_t n, bool descending, const uint32_t *payload,
+                             uint32_t **vals_out, uint32_t **words_out)
 {
     *vals_out = nullptr;
     if (words_out) *words_out = nullptr;
@@ -514,6 +514,24 @@ int k_sort_column(hark_context *ctx, const void *col, int dtype, int64_t n, bool
     return HARK_OK;
 }
 
+int k_argsort_i64_keys(hark_context *ctx, const void *col, int64_t n, uint32_t **perm_out, uint64_t **keys_out);
+
+// Stable sort of a column with a 32-bit payload (see k_sort_column_lsd).  An ascending argsort of an i64 column takes
+// the high-word-first path of k_argsort_i64_keys (four passes + a run fix-up instead of eight passes).
+int k_sort_column(hark_context *ctx, const void *col, int dtype, int64_t n, bool descending, const uint32_t *payload,
+                  uint32_t **vals_out, uint32_t **words_out)
+{
+    if (dtype == HARK_I64 && !descending && !payload && n >= 4096) {
+        if (words_out) *words_out = nullptr;
+        uint64_t *keys = nullptr;
+        const int rc = k_argsort_i64_keys(ctx, col, n, vals_out, &keys);
+        hark_free(ctx, keys);
+        if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) return hark_fail(ctx, HARK_EHIP, "sort kernels failed");
+        return rc;
+    }
+    return k_sort_column_lsd(ctx, col, dtype, n, descending, payload, vals_out, words_out);
+}
+
 int k_argsort_column(hark_context *ctx, const void *col, int dtype, int64_t n, bool descending,
                      uint32_t **perm_out, uint32_t **sorted_words_out)
 {
@@ -560,7 +578,7 @@ int k_argsort_i64_keys(hark_context *ctx, const void *col, int64_t n, uint32_t *
     }
     if (!rc && !done) {                                              // equal high words, or a long run of them: the general path
         uint32_t *perm = nullptr;
-        rc = k_sort_column(ctx, col, HARK_I64, n, false, nullptr, &perm, nullptr);
+        rc = k_sort_column_lsd(ctx, col, HARK_I64, n, false, nullptr, &perm, nullptr);
         if (!rc) {
             gather_biased_u64_kernel<<<dim3((unsigned)grid256(ctx, n)), dim3(256), 0, st>>>(static_cast<const uint64_t *>(col), perm, keys, n);
             if (hipGetLastError() != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "sort: gather launch failed");
