@@ -461,6 +461,10 @@ def main():
                          "frac": path_achieved / HBM_PEAK_GBS,
                          "frac_is": "whole path per GPU: (12 B/row x rows + 16 B x groups) / wall time of a step / 8 TB/s",
                          "traffic": traffic, "traffic_source": traffic_src, "traffic_measured_in_run": False,
+                         # what the HBM actually moves per second on this path (PMC bytes of the committed profile over this run's
+                         # step time): the kernels keep the memory system at this fraction of its peak, 1.5x the algorithmic bytes
+                         "traffic_GBps": (traffic / (ms_step * 1e-3) / 1e9) if traffic else None,
+                         "traffic_frac_of_peak": (traffic / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          "dominant_kernel_frac": dom_achieved / HBM_PEAK_GBS, "dominant_kernel_achieved": dom_achieved,
                          "avg_launch_ms": dom_ms, "launches": dom_launches, "algorithmic_bytes_per_launch": alg_bytes,
                          "algorithmic_bytes_per_step": path_bytes,
