@@ -238,6 +238,49 @@ def extra_configs(torch, eng, dev, a, p, k, v, N):
     t8.free()
     del cols, t8
 
+    # ---- the reference's own entries and ORDER BY at 1e8 rows (not BASELINE configs; the operators behind them)
+    n8 = int(1e8 * a.config_scale) // 4 * 4
+    ku, au = torch.empty(n8, dtype=torch.int32, device=dev), torch.empty(n8, dtype=torch.int32, device=dev)
+    eng.gen_columns(SEED, 0, n8, 1 << 20, True, None, ku.data_ptr(), None)
+    eng.gen_columns(SEED + 9, 0, n8, 1 << 16, True, None, au.data_ptr(), None)
+    tu = eng.table_from_device(n8, [ku.data_ptr(), au.data_ptr()], [np.uint32, np.uint32], keepalive=(ku, au))
+
+    def gd():
+        r = eng.query_groupby(tu, 0, [1, 1], [2, 3])
+        shape[0] = r.shape
+        r.free()
+
+    ms = event_ms(torch, gd, warm=2, reps=5)
+    out["REF_query_groupby_dense"] = entry(ms, 12.0 * n8, n8, groups=int(shape[0][0]), statement="query_groupby(db, 0, [1, 1], [sum, max]) (main.fut:9), 2^20 dense keys",
+                                           note="one pair pass (sum + max of one column)")
+
+    def ob():
+        r = eng.sort(tu, 0, [0, 1])
+        r.free()
+
+    ms = event_ms(torch, ob, warm=2, reps=5)
+    out["ORDER_BY"] = entry(ms, 16.0 * n8, n8, statement="ORDER BY a 20-bit u32 key, key + one column out (stable radix sort, 3 passes)")
+    m8 = n8 // 10
+    kb8, vb8, kp8 = (torch.empty(x, dtype=torch.int32, device=dev) for x in ((m8 + 3) // 4 * 4, (m8 + 3) // 4 * 4, n8))
+    eng.gen_columns(SEED + 3, 0, m8, 1 << 30, True, None, kb8.data_ptr(), None)
+    eng.gen_columns(SEED + 4, 0, m8, 1 << 16, True, None, vb8.data_ptr(), None)
+    eng.gen_columns(SEED + 5, 0, n8, 1 << 30, True, None, kp8.data_ptr(), None)
+    tp8 = eng.table_from_device(n8, [kp8.data_ptr(), au.data_ptr()], [np.uint32, np.uint32], keepalive=(kp8, au))
+    tb8 = eng.table_from_device(m8, [kb8.data_ptr(), vb8.data_ptr()], [np.uint32, np.uint32], keepalive=(kb8, vb8))
+
+    def ju():
+        r = eng.join(tp8, tb8, 0, 0, [0, 1], [1])
+        shape[0] = r.shape
+        r.free()
+
+    ms = event_ms(torch, ju, warm=2, reps=5)
+    out["REF_join_u32"] = entry(ms, 12.0 * (n8 + m8) + 12.0 * shape[0][0], n8 + m8, probe_rows=n8, build_rows=m8, pairs=int(shape[0][0]),
+                                statement="join(db1, db2, 0, 0, [0, 1], [1]) (join.fut:52) on u32 keys, ~10 % of the probe rows match")
+    for t_ in (tu, tp8, tb8):
+        t_.free()
+    del ku, au, kb8, vb8, kp8, tu, tp8, tb8
+    torch.cuda.empty_cache()
+
     # ---- C4: one GPU's share of the 1e9 x 1e8 join on an i64 key (configs[3]): 1.25e8 probe rows, 1.25e7 unique build keys
     n4, s4 = int(1.25e8 * a.config_scale), int(1.25e7 * a.config_scale)
     mul = -7046029254386353131                                                       # 0x9E3779B97F4A7C15 as i64: odd, so i -> i*mul is a bijection mod 2^64
