@@ -381,7 +381,7 @@ constexpr int kQ2 = 128;
 constexpr int kUnit2Bytes = kU * 2;                      // 128
 static size_t part_lds_bytes(int P, int fmt)             // fmt: 0 = 8-byte pairs, 1 = compact 6-byte pairs, 2 = keys only
 {
-    const size_t q = fmt == 1 ? (size_t)6 * P * kQ6 : fmt == 2 ? (size_t)2 * P * kQ2 : sizeof(uint2) * (size_t)P * kQ;
+    const size_t q = fmt == 1 ? (size_t)6 * P * kQ6 : fmt == 2 ? (size_t)2 * P * kQ2 : sizeof(uint2) * (size_t)P * (P > kMaxBuckets ? kQ / 2 : kQ);
     return q + sizeof(int) * 2 * (size_t)P + 8 + (size_t)kHot * 16 + 32;
 }
 
@@ -426,13 +426,14 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
     const int xf = MODE == 0 ? 0 : xf_rt;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     static_assert(!((C6 || K2) && MODE == 2), "compact pairs carry bucket-local keys: dense mode only");
-    uint2 *queue = reinterpret_cast<uint2 *>(lds_raw);                 // [P][kQ]           8-byte pairs
+    uint2 *queue = reinterpret_cast<uint2 *>(lds_raw);                 // [P][q8]           8-byte pairs
+    const int q8 = P > kMaxBuckets ? kQ / 2 : kQ;                      // ring capacity of the 8-byte format: 64 pairs, 32 with 257..512 buckets (hash mode)
     uint32_t *qv = reinterpret_cast<uint32_t *>(lds_raw);              // [P][kQ6] values   compact format
     uint16_t *qk = reinterpret_cast<uint16_t *>(qv + (size_t)P * kQ6); // [P][kQ6] bucket-local keys
     uint16_t *qk2 = reinterpret_cast<uint16_t *>(lds_raw);            // [P][kQ2] bucket-local keys   keys-only format
     uint32_t *s_w = C6 ? reinterpret_cast<uint32_t *>(qk + (size_t)P * kQ6)
                   : K2 ? reinterpret_cast<uint32_t *>(qk2 + (size_t)P * kQ2)
-                       : reinterpret_cast<uint32_t *>(queue + (size_t)P * kQ);   // [P] ring index of the oldest pair << 16 | pairs queued
+                       : reinterpret_cast<uint32_t *>(queue + (size_t)P * q8);   // [P] ring index of the oldest pair << 16 | pairs queued
     int *s_lcur = reinterpret_cast<int *>(s_w + P);                    // [P] lines already stored in this workgroup's slab
     u64 *h_val = reinterpret_cast<u64 *>(s_lcur + P + ((2 * P) & 1)); // [kHot] heavy-hitter partial values (8-byte aligned)
     uint32_t *h_key = reinterpret_cast<uint32_t *>(h_val + kHot);     // [kHot] owning key or kHotEmpty
@@ -446,7 +447,7 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
     unsigned char *slab6 = reinterpret_cast<unsigned char *>(pbuf) + (size_t)wg * ((size_t)cap * 8);    // + b * nwg * cap * 8
     const uint32_t kmask = (1u << shift) - 1u;
     auto wrap6 = [](int x) { return x >= kQ6 ? x - kQ6 : x; };
-    int period = period_knob > 0 ? period_knob : ((C6 || K2) ? kFlushPeriod6 : kFlushPeriod);
+    int period = period_knob > 0 ? period_knob : ((C6 || K2) ? kFlushPeriod6 : HASH ? 2 : kFlushPeriod);   // hash mode: every row is enqueued (16 or 8 per bucket and batch)
     const uint32_t Gu = (uint32_t)G;                                   // G <= 2^31: one unsigned compare rejects negative keys too
     bool bad = false, overflow = false;
     for (int b = tid; b < P; b += kPartThreads) { s_w[b] = 0u; s_lcur[b] = 0; }
@@ -566,8 +567,8 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
                             pending &= ~(1u << j);
                         } else atomicSub(&s_w[b], 1u);
                     } else
-                    if (pos < (uint32_t)kQ) {
-                        queue[b * kQ + (((old >> 16) + pos) & (kQ - 1))] = uint2{key, vbits_of(vv[j])};
+                    if (pos < (uint32_t)q8) {
+                        queue[b * q8 + (((old >> 16) + pos) & (q8 - 1))] = uint2{key, vbits_of(vv[j])};
                         pending &= ~(1u << j);
                     } else atomicSub(&s_w[b], 1u);                      // queue full: retry after the flush
                 }
@@ -640,7 +641,7 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
                 if (lines) {
                     const int i = tid & 7, head = (int)(w >> 16), lc = s_lcur[b];
                     for (int q = 0; q < lines; q++) {
-                        const uint4 two = *reinterpret_cast<const uint4 *>(&queue[b * kQ + ((head + q * kLine) & (kQ - 1)) + 2 * i]);
+                        const uint4 two = *reinterpret_cast<const uint4 *>(&queue[b * q8 + ((head + q * kLine) & (q8 - 1)) + 2 * i]);
                         if (lc + q < cap_lines) {
                             uint4 *dst = reinterpret_cast<uint4 *>(&pbuf[((size_t)b * nwg + wg) * cap + (size_t)(lc + q) * kLine + 2 * i]);
                             typedef unsigned int u4v __attribute__((ext_vector_type(4)));
@@ -652,7 +653,7 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
                         }
                     }
                     if (i == 0) {
-                        s_w[b] = ((uint32_t)((head + lines * kLine) & (kQ - 1)) << 16) | (uint32_t)(cnt - lines * kLine);
+                        s_w[b] = ((uint32_t)((head + lines * kLine) & (q8 - 1)) << 16) | (uint32_t)(cnt - lines * kLine);
                         s_lcur[b] = min(lc + lines, cap_lines);
                     }
                 }
@@ -713,7 +714,7 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
             continue;
         }
         const size_t base = ((size_t)b * nwg + wg) * cap + (size_t)s_lcur[b] * kLine;
-        for (int j = 0; j < l; j++) pbuf[base + j] = queue[b * kQ + ((head + j) & (kQ - 1))];
+        for (int j = 0; j < l; j++) pbuf[base + j] = queue[b * q8 + ((head + j) & (q8 - 1))];
         counts[(size_t)b * nwg + wg] = (uint32_t)(s_lcur[b] * kLine + l);
     }
     // ---- the heavy hitters join the global table (one atomic pair per occupied entry)
@@ -1249,7 +1250,7 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash_kernel(
 
 // Compact hash consumer for the reference's u32 operators (groupby.fut:35-41: wrapping * and +, max, min; no row
 // counts): an entry is ONE 64-bit word, value << 32 | occupied << 24 | low 24 bits of mix32(key).  Inside bucket b the
-// top 8 bits of mix32(key) are b, and mix32 is a bijection, so 24 bits identify the key (it is rebuilt by unmix32 at
+// top log2(P) >= 8 bits of mix32(key) are b, and mix32 is a bijection, so 24 bits identify the key (it is rebuilt by unmix32 at
 // emit time).  Twice the entries per workgroup (16384 in 128 KiB, 6144 used per round) and one LDS atomic per row:
 // ds_add_u64 of value << 32 wraps exactly like u32 addition, ds_max_u64 / ds_min_u64 order the words by value because
 // the low half is the same for every update of a slot, and a claim stores the first value, so no identity is needed.
@@ -1334,7 +1335,8 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash8_kernel(
         const u64 e = tab[i];
         if (!e) continue;
         const unsigned long long o = s_base + pos++;
-        if (o < out_cap) { out_key[o] = unmix32((b << 24) | (uint32_t)(e & 0xFFFFFFu)); out_val[o] = e >> 32; }
+        // the bucket is the top log2(P) bits of mix32(key) (P = gridDim.x, a power of two), the tag its low 24 bits
+        if (o < out_cap) { const int lowbits = 33 - __ffs((int)gridDim.x); out_key[o] = unmix32((b << lowbits) | ((uint32_t)(e & 0xFFFFFFu) & ((1u << lowbits) - 1u))); out_val[o] = e >> 32; }
         else *err = kErrOverflow;
     }
 }
@@ -1961,7 +1963,9 @@ int k_fgb_hash_u32(hark_context *ctx, const uint32_t *k, const uint32_t *v, int6
     const int fill = compact ? kHash8Fill : kHashFill;
     *keys_out = nullptr; *vals_out = nullptr; *cnts_out = nullptr; *G_out = 0; *fits = false;
     if (n <= 0 || n > 0xFFFFFFFFll) return HARK_OK;
-    const int hash_bits = 8, P = 1 << hash_bits, nwg = ctx->num_cu;
+    // 512 buckets of 32-pair rings (256 x 64 before): half as many distinct keys per bucket -- 2^21 distinct keys fit ONE
+    // round of the 8-byte tables instead of two (plus the failed first attempt and the sample round that found that out)
+    const int hash_bits = getenv("HARK_HASH_BITS8") ? 8 : 9, P = 1 << hash_bits, nwg = ctx->num_cu;
     int64_t cap = n / ((int64_t)P * nwg) * 130 / 100 + 256;
     cap = (cap + kLine - 1) / kLine * kLine + 2 * kLine;
     uint2 *pbuf = nullptr; uint32_t *counts = nullptr; int32_t *err = nullptr; unsigned long long *cursor = nullptr;
@@ -2034,12 +2038,15 @@ int k_fgb_hash_u32(hark_context *ctx, const uint32_t *k, const uint32_t *v, int6
             if (!rc && e == 0) rc = hark_read_words(ctx, cursor, &sample, 1);
             if (!rc && e == 0) {
                 const double per_bucket = 64.0 * (double)sample / P * 1.3;
+                // every round re-reads the bucket's slabs (~0.35 ms per round and 1e8 rows): beyond kMaxRoundsWorth rounds the
+                // sort-based path (~7 ms per 1e8 rows) is the faster one -- with 512 buckets 64 rounds would "fit" 2e8 keys
+                constexpr uint32_t kMaxRoundsWorth = 16;
                 uint32_t R = 2;
-                while (R < 64 && per_bucket > (double)fill * R) R *= 2;
-                if (per_bucket > (double)fill * 64) e = kErrOverflow;            // would not fit 64 rounds: sort-based path
+                while (R < kMaxRoundsWorth && per_bucket > (double)fill * R) R *= 2;
+                if (per_bucket > (double)fill * kMaxRoundsWorth) e = kErrOverflow;
                 else {
                     rc = run_rounds(R, 0, R); used_R = R;
-                    if (!rc && e != 0 && R < 64) { rc = run_rounds(R * 2, 0, R * 2); used_R = R * 2; }   // one retry for uneven buckets
+                    if (!rc && e != 0 && R < kMaxRoundsWorth) { rc = run_rounds(R * 2, 0, R * 2); used_R = R * 2; }   // one retry for uneven buckets
                 }
             }
         }
