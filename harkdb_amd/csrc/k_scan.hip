@@ -79,6 +79,40 @@ __global__ __launch_bounds__(kScanThreads) void scan_apply_kernel(const uint32_t
     }
 }
 
+// Small inputs (<= kScanSmall elements: the tile counts of a WHERE, the survivor counts of a join): ONE workgroup does
+// the whole scan in a single launch instead of three (each launch is ~5 us of a 0.4 ms statement).
+constexpr int64_t kScanSmall = 64 * 1024;
+__global__ __launch_bounds__(1024) void scan_small_kernel(const uint32_t *__restrict__ in, int64_t n, uint32_t *__restrict__ out32, int64_t *__restrict__ out64,
+                                                          unsigned long long *__restrict__ total)
+{
+    __shared__ unsigned long long s_wave[16];
+    __shared__ unsigned long long s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    constexpr int PER = 8;
+    for (int64_t base = 0; base < n; base += 1024 * PER) {
+        const int64_t i0 = base + (int64_t)threadIdx.x * PER;
+        uint32_t v[PER];
+        unsigned long long x = 0;
+#pragma unroll
+        for (int j = 0; j < PER; j++) { v[j] = i0 + j < n ? in[i0 + j] : 0u; x += v[j]; }
+        unsigned long long tot;
+        unsigned long long run = s_carry + block_exclusive(x, s_wave, &tot);       // (block_exclusive ends with a barrier: s_carry is read before the update below)
+#pragma unroll
+        for (int j = 0; j < PER; j++) {
+            if (i0 + j < n) {
+                if (out32) out32[i0 + j] = (uint32_t)run;
+                if (out64) out64[i0 + j] = (int64_t)run;
+            }
+            run += v[j];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = s_carry;
+}
+
 } // namespace
 
 // Exclusive scan of in[0..n).  Either output may be null.  *total_host receives
@@ -91,9 +125,12 @@ int k_exclusive_scan_u32(hark_context *ctx, const uint32_t *in, int64_t n, uint3
     unsigned long long *sums = nullptr;
     HARK_TRY(hark_alloc(ctx, (void **)&sums, (size_t)(nt + 1) * sizeof(unsigned long long)));
     hipStream_t st = ctx->stream;
-    tile_sums_kernel<<<dim3((unsigned)nt), dim3(kScanThreads), 0, st>>>(in, n, sums);
-    scan_sums_kernel<<<1, 1024, 0, st>>>(sums, nt, sums + nt);
-    scan_apply_kernel<<<dim3((unsigned)nt), dim3(kScanThreads), 0, st>>>(in, n, sums, out32, out64);
+    if (n <= kScanSmall) scan_small_kernel<<<1, 1024, 0, st>>>(in, n, out32, out64, sums + nt);
+    else {
+        tile_sums_kernel<<<dim3((unsigned)nt), dim3(kScanThreads), 0, st>>>(in, n, sums);
+        scan_sums_kernel<<<1, 1024, 0, st>>>(sums, nt, sums + nt);
+        scan_apply_kernel<<<dim3((unsigned)nt), dim3(kScanThreads), 0, st>>>(in, n, sums, out32, out64);
+    }
     int rc = HARK_OK;
     if (hipGetLastError() != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "scan: launch failed");
     int64_t tot = 0;
