@@ -12,7 +12,7 @@
 //   1. digit_hist_kernel   per-slice 256-bin digit histogram -> hist[bin][blk]
 //   2. scan_hist_rows_kernel  per-digit exclusive scan over the slices (+ digit totals;
 //                          the scatter kernel prefixes the 256 totals itself)
-//   3. digit_scatter_kernel walks its slice in 4096-key tiles; inside a tile a
+//   3. digit_scatter_kernel walks its slice in tiles (4096 or 12288 keys, see below); inside a tile a
 //      wave ranks each key among equal digits with a wave64 ballot match (8
 //      ballots + popcount of the lower lanes), waves are chained by a prefix
 //      over per-wave digit counts, keys are staged digit-sorted in LDS and
@@ -27,8 +27,8 @@ namespace {
 // CU as partial lines, and whether those merge in the XCD's L2 before they are evicted depends on how many workgroups
 // keep 2 x 256 output lines open at once.  Measured (1e8 keys, three passes + the difference mask, one box):
 // 256 threads x 16 keys, 8 slices per CU 2.44 ms; 512 x 16, 2 per CU 2.38; 1024 x 8, 1 per CU 2.26; 1024 x 12, 1 per CU
-// 2.13 ms.  Sorts of a few million keys are faster with the small tiles (more workgroups in flight), so the large
-// geometry is used from 2^25 keys on.
+// 2.13 ms; with the next tile's keys requested one tile ahead 2.07 (profiles/r02_notes.md §9).  Sorts of a few million
+// keys are faster with the small tiles (more workgroups in flight), so the large geometry is used from 2^25 keys on.
 constexpr int kBins = 256;
 struct GeoSmall { static constexpr int T = 256, R = 16, PER_CU = 8; };
 struct GeoLarge { static constexpr int T = 1024, R = 12, PER_CU = 1; };
@@ -127,8 +127,9 @@ __global__ __launch_bounds__(256) void scan_hist_rows_kernel(uint32_t *__restric
     if (threadIdx.x == 0) row_total[blockIdx.x] = s_carry;
 }
 
-// vals_in == nullptr means "payload = input position" (first pass of an argsort).
-template <typename GEO>
+// IOTA (vals_in == nullptr): "payload = input position" (first pass of an argsort) -- compiled in, so that no
+// select between a loaded and a computed payload sits in the tile loop (it would drain the loads at the merge).
+template <typename GEO, bool IOTA>
 __global__ __launch_bounds__(GEO::T) void digit_scatter_kernel(
     const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
     uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
@@ -162,6 +163,18 @@ __global__ __launch_bounds__(GEO::T) void digit_scatter_kernel(
     }
     const uint64_t lt = lanemask_lt();
 
+    // GeoLarge (one workgroup per CU: nothing else covers the latency of the loads): the NEXT tile's keys are requested
+    // while this one is ranked, staged and written, and this tile's payloads -- first needed when the keys are staged --
+    // arrive under the ranking.  (Keys AND payloads one tile ahead spill registers at 1024 threads.)
+    constexpr bool kAhead = GEO::PER_CU == 1;
+    constexpr int kN = kAhead ? kRounds : 1;
+    uint32_t nkey[kN];
+    auto fetch_keys = [&](int64_t tb) {
+        const int64_t wb = tb + (int64_t)wave * (64 * kRounds);
+#pragma unroll
+        for (int r = 0; r < kN; r++) { const int64_t i = wb + r * 64 + lane; nkey[r] = keys_in[i < hi ? i : hi - 1]; }      // clamped, not predicated: no branch per load
+    };
+    if (kAhead) fetch_keys(lo);
     for (int64_t tbase = lo; tbase < hi; tbase += kSortTile) {
         for (int i = tid; i < kSortWaves * kBins; i += kSortThreads) (&s_wcnt[0][0])[i] = 0;
         lds_barrier();
@@ -172,10 +185,16 @@ __global__ __launch_bounds__(GEO::T) void digit_scatter_kernel(
         for (int r = 0; r < kRounds; r++) {
             const int64_t i = wbase + r * 64 + lane;
             const bool valid = i < hi;
-            key[r] = valid ? keys_in[i] : 0u;
-            val[r] = valid ? (vals_in ? vals_in[i] : (uint32_t)i) : 0u;
+            if (kAhead) key[r] = nkey[kAhead ? r : 0];
+            else key[r] = valid ? keys_in[i] : 0u;
+            if (!kAhead) val[r] = valid ? (IOTA ? (uint32_t)i : vals_in[i]) : 0u;
             rank[r] = valid ? 0u : 0xFFFFFFFFu;
         }
+        if (kAhead) {
+#pragma unroll
+            for (int r = 0; r < kRounds; r++) { const int64_t i = wbase + r * 64 + lane; val[r] = IOTA ? (uint32_t)i : vals_in[i < hi ? i : hi - 1]; }
+        }
+        if (kAhead && tbase + kSortTile < hi) fetch_keys(tbase + kSortTile);
 #pragma unroll
         for (int r = 0; r < kRounds; r++) {
             const bool valid = rank[r] != 0xFFFFFFFFu;
@@ -390,7 +409,10 @@ int k_sort_pairs_u32(hark_context *ctx, uint32_t *keys_a, uint32_t *keys_b, uint
     bool large; int64_t nblk, slice;
     sort_geometry(n, ctx->num_cu, &large, &nblk, &slice);
     hipStream_t st = ctx->stream;
-    if (large) HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&digit_scatter_kernel<GeoLarge>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_lds<GeoLarge>()));
+    if (large) {
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&digit_scatter_kernel<GeoLarge, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_lds<GeoLarge>()));
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&digit_scatter_kernel<GeoLarge, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_lds<GeoLarge>()));
+    }
     const uint32_t *kin = keys_first ? keys_first : keys_a, *vin = vals_first;
     uint32_t *kout = keys_first ? keys_a : keys_b, *vout = vals_b;   // a read-only input leaves both scratch buffers free
     bool first = true;
@@ -400,10 +422,11 @@ int k_sort_pairs_u32(hark_context *ctx, uint32_t *keys_a, uint32_t *keys_b, uint
         if (large) digit_hist_kernel<GeoLarge><<<dim3((unsigned)nblk), dim3(GeoLarge::T), 0, st>>>(kin, n, slice, shift, xor_mask, hist_ws, (int)nblk);
         else digit_hist_kernel<GeoSmall><<<dim3((unsigned)nblk), dim3(GeoSmall::T), 0, st>>>(kin, n, slice, shift, xor_mask, hist_ws, (int)nblk);
         scan_hist_rows_kernel<<<kBins, 256, 0, st>>>(hist_ws, (int)nblk, hist_ws + (size_t)kBins * nblk);
-        if (large) digit_scatter_kernel<GeoLarge><<<dim3((unsigned)nblk), dim3(GeoLarge::T), scatter_lds<GeoLarge>(), st>>>(
-            kin, vin, kout, vout, n, slice, shift, xor_mask, hist_ws, (int)nblk, hist_ws + (size_t)kBins * nblk);
-        else digit_scatter_kernel<GeoSmall><<<dim3((unsigned)nblk), dim3(GeoSmall::T), scatter_lds<GeoSmall>(), st>>>(
-            kin, vin, kout, vout, n, slice, shift, xor_mask, hist_ws, (int)nblk, hist_ws + (size_t)kBins * nblk);
+        const uint32_t *tot = hist_ws + (size_t)kBins * nblk;
+        if (large && vin) digit_scatter_kernel<GeoLarge, false><<<dim3((unsigned)nblk), dim3(GeoLarge::T), scatter_lds<GeoLarge>(), st>>>(kin, vin, kout, vout, n, slice, shift, xor_mask, hist_ws, (int)nblk, tot);
+        else if (large) digit_scatter_kernel<GeoLarge, true><<<dim3((unsigned)nblk), dim3(GeoLarge::T), scatter_lds<GeoLarge>(), st>>>(kin, vin, kout, vout, n, slice, shift, xor_mask, hist_ws, (int)nblk, tot);
+        else if (vin) digit_scatter_kernel<GeoSmall, false><<<dim3((unsigned)nblk), dim3(GeoSmall::T), scatter_lds<GeoSmall>(), st>>>(kin, vin, kout, vout, n, slice, shift, xor_mask, hist_ws, (int)nblk, tot);
+        else digit_scatter_kernel<GeoSmall, true><<<dim3((unsigned)nblk), dim3(GeoSmall::T), scatter_lds<GeoSmall>(), st>>>(kin, vin, kout, vout, n, slice, shift, xor_mask, hist_ws, (int)nblk, tot);
         HIP_TRY(ctx, hipGetLastError());
         *keys_out = kout; *vals_out = vout;
         kin = kout; vin = vout;

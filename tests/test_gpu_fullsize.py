@@ -84,6 +84,24 @@ def test_sort_hundred_million_rows(eng):
     res.free(); eng.free(k); eng.free(rid)
 
 
+def test_sort_large_geometry_exact(eng):
+    """Just above the size at which the radix passes switch to the large tile geometry (2^25 keys, k_sort.hip: one
+    1024-thread workgroup per CU, next tile's keys prefetched), a ragged last tile in every slice, all four passes:
+    the permutation must be numpy's stable argsort exactly."""
+    n = (1 << 25) + 12345
+    rng = np.random.default_rng(25)
+    keys = rng.integers(0, 1 << 32, size=n, dtype=np.uint64).astype(np.uint32)
+    keys[rng.integers(0, n, size=n // 8)] = keys[0]                        # a long run of equal keys: stability matters
+    k, rid = eng.alloc(n * 4), eng.alloc(n * 4)
+    eng.upload(k, keys); eng.upload(rid, np.arange(n, dtype=np.uint32))
+    t = eng.table_from_device(n, [k, rid], [np.uint32, np.uint32])
+    res = eng.sort(t, 0, [0, 1])
+    want = np.argsort(keys, kind="stable")
+    assert np.array_equal(res.column(1), want.astype(np.uint32))
+    assert np.array_equal(res.column(0), keys[want])
+    res.free(); eng.free(k); eng.free(rid)
+
+
 def test_shard_larger_than_2_31_rows_is_fed_in_pieces(eng):
     """2^31 + 4100 rows in one shard (25.8 GB of columns): FgbPlan.run splits the call, the
     accumulators merge the pieces; complement counts add up to the row count."""
