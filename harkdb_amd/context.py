@@ -261,6 +261,16 @@ class FutharkContext:
             res._keep_chain = keep
             return res
 
+        def grouped(specs, having, order, limit=None):
+            """GROUP BY + HAVING + ORDER BY (+ LIMIT).  A small LIMIT over dense keys is ONE entry (hark_entry_filter_groupby_topk:
+            no group set, no second call); anything else composes filter_groupby with having_order."""
+            if (order is not None and limit is not None and 0 < limit <= 32 and len(having) <= 7
+                    and not os.environ.get("HARK_NO_TOPK") and not os.environ.get("HARK_NO_FUSED_TOPK")):
+                top = eng.filter_groupby_topk(cur, dev_preds, gkey, specs, having, order[0], order[1], limit)
+                if top is not None:
+                    return top
+            return having_order(eng.filter_groupby(cur, dev_preds, gkey, specs), having, order, limit)
+
         cols = None
         # ---- late materialisation: with a small LIMIT only the aggregates that HAVING / ORDER BY mention are computed
         # for every group; the others are computed afterwards for the LIMIT surviving groups only
@@ -281,8 +291,8 @@ class FutharkContext:
                         for s in second)):
             first_specs = [aggs[s - 1] for s in first] or [("count", None)]
             remap = {0: 0, **{s: 1 + j for j, s in enumerate(first)}}
-            r1 = having_order(eng.filter_groupby(cur, dev_preds, gkey, [spec_of(a) for a in first_specs]),
-                              [(remap[s], cmp, v) for s, cmp, v in having], None if order is None else (remap[order[0]], order[1]), lim)
+            r1 = grouped([spec_of(a) for a in first_specs], [(remap[s], cmp, v) for s, cmp, v in having],
+                         None if order is None else (remap[order[0]], order[1]), lim)
             c1 = r1.columns(limit=lim)
             c1 = [c[:lim] for c in c1]
             r2 = eng.filter_groupby_subset(cur, dev_preds, gkey, c1[0], [spec_of(aggs[s - 1]) for s in second])
@@ -294,8 +304,7 @@ class FutharkContext:
             for j, s_ in enumerate(second):
                 cols[s_] = c2[j]
         if cols is None:
-            res = having_order(eng.filter_groupby(cur, dev_preds, gkey, [spec_of(a) for a in aggs]), having, order,
-                               None if (host_having or host_order) else ir.get("limit"))
+            res = grouped([spec_of(a) for a in aggs], having, order, None if (host_having or host_order) else ir.get("limit"))
             # only the first LIMIT rows cross PCIe (unless key conditions / orders still have to run on the decoded result)
             cols = res.columns(limit=ir.get("limit") if not (host_having or host_order) else None)
         if decode is None:

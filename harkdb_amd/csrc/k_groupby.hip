@@ -461,8 +461,10 @@ bool dense_plan_for(int op, int dt, int col, DensePass *out)
 // Dense shape: 32-bit integer key with 0 <= key < 2^21 and aggregates over 4-byte columns.
 // One fused pass (k_fgb.hip) per distinct (operator, column); an f32 predicate is fused into every
 // pass, a predicate on another dtype compacts the referenced columns first.
+// all_slots: the result has one row per key SLOT 0..G-1 (empty groups included: their COUNT is 0 and their other
+// aggregates are unspecified) -- no group set, no scan, no host read; hark_entry_filter_groupby_topk selects from that.
 int try_dense(hark_context *ctx, const hark_table *db, const PredList &preds,
-              int32_t g_col, const int32_t *agg_cols, const int32_t *agg_ops, int64_t n_aggs, hark_result *res, bool *used)
+              int32_t g_col, const int32_t *agg_cols, const int32_t *agg_ops, int64_t n_aggs, hark_result *res, bool *used, bool all_slots = false)
 {
     *used = false;
     const int kdt = db->cols[g_col].dtype;
@@ -501,11 +503,15 @@ int try_dense(hark_context *ctx, const hark_table *db, const PredList &preds,
     std::vector<char> done((size_t)n_aggs, 0);
     auto group_set = [&]() -> int {                            // the first pass also yields the group set
         if (ngroups >= 0) return HARK_OK;
-        int r = hark_alloc(ctx, (void **)&flags, (size_t)G * 4);
-        if (!r) r = hark_alloc(ctx, (void **)&pos, (size_t)G * 4);
-        if (!r) {
-            nonzero_flags_kernel<<<grid_for(ctx, G), 256, 0, ctx->stream>>>(plan->acc_cnt, G, flags);
-            r = k_exclusive_scan_u32(ctx, flags, G, pos, nullptr, &ngroups);
+        int r = HARK_OK;
+        if (all_slots) ngroups = G;                            // pos stays NULL: the read-outs write slot g at row g
+        else {
+            r = hark_alloc(ctx, (void **)&flags, (size_t)G * 4);
+            if (!r) r = hark_alloc(ctx, (void **)&pos, (size_t)G * 4);
+            if (!r) {
+                nonzero_flags_kernel<<<grid_for(ctx, G), 256, 0, ctx->stream>>>(plan->acc_cnt, G, flags);
+                r = k_exclusive_scan_u32(ctx, flags, G, pos, nullptr, &ngroups);
+            }
         }
         if (!r) {
             res->n = ngroups;
@@ -981,6 +987,66 @@ extern "C" int hark_entry_filter_groupby_and(hark_context *ctx, hark_result **ou
     if (rc) { for (auto &c : res->cols) if (c.owned && c.data) hark_free(ctx, c.data); delete res; return rc; }
     *out = res;
     return HARK_OK;
+}
+
+// WHERE + GROUP BY + HAVING + ORDER BY + LIMIT k as ONE call for dense keys: the aggregates are read out per key slot
+// (no group set: no flag / scan kernels, no host read), the k rows are selected from the slots with a non-zero count
+// (hark_entry_topk's kernels), and only those k rows become the result [key, aggregates...].  Items: 0 = the key,
+// j + 1 = aggregate j.  Ties in the order keep ascending key order, as a stable sort of the compacted groups would.
+// HARK_EUNSUPPORTED (without a message): the keys are not dense or k is too large -- the caller composes the statement
+// from hark_entry_filter_groupby_and + hark_entry_topk / filter / sort instead.
+extern "C" int hark_entry_filter_groupby_topk(hark_context *ctx, hark_result **out, const hark_table *db, int64_t n_preds,
+                                              const int32_t *where_cols, const int32_t *cmps, const void *const *constants,
+                                              int32_t g_col, const int32_t *agg_cols, const int32_t *agg_ops, int64_t n_aggs,
+                                              int64_t n_having, const int32_t *having_items, const int32_t *having_cmps, const void *const *having_consts,
+                                              int32_t order_item, int32_t descending, int64_t k)
+{
+    hark_device_guard guard__(ctx);
+    if (!ctx || !out || !db) return HARK_EARG;
+    *out = nullptr;
+    if (n_aggs < 0 || n_aggs > 30 || (n_aggs && (!agg_cols || !agg_ops))) return hark_fail(ctx, HARK_EARG, "filter_groupby_topk: bad aggregate list");
+    if (g_col < 0 || g_col >= db->m) return hark_fail(ctx, HARK_EBOUNDS, "filter_groupby_topk: group column %d out of bounds", g_col);
+    if (n_preds < 0 || n_preds > 16 || (n_preds && (!where_cols || !cmps || !constants))) return hark_fail(ctx, HARK_EARG, "filter_groupby_topk: 0..16 predicates");
+    for (int64_t j = 0; j < n_preds; j++) {
+        if (where_cols[j] < 0 || where_cols[j] >= db->m) return hark_fail(ctx, HARK_EBOUNDS, "filter_groupby_topk: where column %d out of bounds", where_cols[j]);
+        if (!constants[j] || cmps[j] < HARK_CMP_GT || cmps[j] > HARK_CMP_NE) return hark_fail(ctx, HARK_EARG, "filter_groupby_topk: bad predicate");
+    }
+    for (int64_t j = 0; j < n_aggs; j++) {
+        if (agg_ops[j] < HARK_AGG_KEY || agg_ops[j] > HARK_AGG_AVG) return hark_fail(ctx, HARK_EARG, "filter_groupby_topk: unknown aggregate opcode %d", agg_ops[j]);
+        if (agg_ops[j] != HARK_AGG_COUNT && (agg_cols[j] < 0 || agg_cols[j] >= db->m))
+            return hark_fail(ctx, HARK_EBOUNDS, "filter_groupby_topk: aggregate column %d out of bounds", agg_cols[j]);
+    }
+    if (n_having < 0 || n_having > 7 || (n_having && (!having_items || !having_cmps || !having_consts))) return hark_fail(ctx, HARK_EARG, "filter_groupby_topk: 0..7 HAVING conditions");
+    for (int64_t j = 0; j < n_having; j++)
+        if (having_items[j] < 0 || having_items[j] > n_aggs || !having_consts[j]) return hark_fail(ctx, HARK_EBOUNDS, "filter_groupby_topk: HAVING item %d out of bounds", having_items[j]);
+    if (order_item < 0 || order_item > n_aggs) return hark_fail(ctx, HARK_EBOUNDS, "filter_groupby_topk: ORDER BY item %d out of bounds", order_item);
+    if (k < 1 || db->n <= 0) return HARK_EUNSUPPORTED;
+    // a COUNT tells the empty slots from the groups: appended when the statement has none
+    std::vector<int32_t> cols2(agg_cols, agg_cols + n_aggs), ops2(agg_ops, agg_ops + n_aggs);
+    int32_t count_item = -1;
+    for (int64_t j = 0; j < n_aggs; j++) if (agg_ops[j] == HARK_AGG_COUNT) { count_item = (int32_t)j + 1; break; }
+    if (count_item < 0) { cols2.push_back(0); ops2.push_back(HARK_AGG_COUNT); count_item = (int32_t)n_aggs + 1; }
+    const PredList preds{n_preds, where_cols, cmps, constants};
+    hark_result *slots = new hark_result();
+    bool done = false;
+    int rc = try_dense(ctx, db, preds, g_col, cols2.data(), ops2.data(), (int64_t)ops2.size(), slots, &done, true);
+    if (!rc && !done) rc = HARK_EUNSUPPORTED;
+    if (!rc && slots->cols[(size_t)count_item].dtype != HARK_I64) rc = hark_fail(ctx, HARK_EHIP, "filter_groupby_topk: COUNT is not an int64 column");
+    if (!rc) {
+        hark_table view;
+        view.n = slots->n; view.m = (int64_t)slots->cols.size(); view.cols = slots->cols;
+        for (auto &c : view.cols) c.owned = false;
+        const int64_t zero = 0;
+        std::vector<int32_t> pcols{count_item}, pcmps{HARK_CMP_GT}, outcols;
+        std::vector<const void *> pconsts{&zero};
+        for (int64_t j = 0; j < n_having; j++) { pcols.push_back(having_items[j]); pcmps.push_back(having_cmps[j]); pconsts.push_back(having_consts[j]); }
+        for (int64_t j = 0; j <= n_aggs; j++) outcols.push_back((int32_t)j);
+        (void)hipGetLastError();
+        rc = hark_entry_topk(ctx, out, &view, (int64_t)pcols.size(), pcols.data(), pcmps.data(), pconsts.data(), order_item, descending, k, outcols.data(), (int64_t)outcols.size());
+    }
+    for (auto &c : slots->cols) if (c.owned && c.data) hark_free(ctx, c.data);
+    delete slots;
+    return rc;
 }
 
 

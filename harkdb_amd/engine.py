@@ -417,6 +417,40 @@ class Engine:
         self._chk(self.lib.hark_entry_topk(self.ctx, C.byref(h), table._h, len(where), wc, wo, wp, int(key_col), 1 if descending else 0, int(k), pa, a.size))
         return Result(self, h)
 
+    @staticmethod
+    def agg_result_dtype(op, col_dtype):
+        """dtype of an aggregate's result column (hark_entry_filter_groupby*, include/hark.h)."""
+        if op == "count":
+            return np.dtype(np.int64)
+        if op == "avg":
+            return np.dtype(np.float32)
+        if op == "sum":
+            return np.dtype(np.float32) if np.dtype(col_dtype) == np.float32 else np.dtype(np.int64)
+        return np.dtype(col_dtype)
+
+    def filter_groupby_topk(self, table, where, g_col, aggs, having, order_item, descending, k):
+        """WHERE + GROUP BY + HAVING + ORDER BY + LIMIT k in one call (dense keys): Result [key, aggregates...] with at most
+        k rows, or None when the entry declines (keys not dense, k too large) -- compose filter_groupby + topk then.
+        having = [(item, cmp, value), ...]; items: 0 = the key, j + 1 = aggregate j."""
+        cols, pc = _ffi.i32_array([c for _, c in aggs])
+        ops, po = _ffi.i32_array([_ffi.AGG[o] for o, _ in aggs])
+        where = list(where or [])
+        wc, wo, wp, keep = self._predicates(table, where)
+        item_dtype = lambda it: np.dtype(table.dtype(g_col)) if it == 0 else self.agg_result_dtype(aggs[it - 1][0], table.dtype(aggs[it - 1][1]))
+        hconsts, hitems, hcmps = [], [], []
+        for it, cmp, value in having:
+            cmp2, c = normalise_predicate(item_dtype(it), cmp, value)
+            hconsts.append(c); hitems.append(int(it)); hcmps.append(_ffi.CMP[cmp2])
+        nh = len(hitems)
+        h = C.c_void_p()
+        rc = self.lib.hark_entry_filter_groupby_topk(self.ctx, C.byref(h), table._h, len(where), wc, wo, wp, int(g_col), pc, po, cols.size,
+                                                     nh, (C.c_int32 * nh)(*hitems), (C.c_int32 * nh)(*hcmps), (C.c_void_p * nh)(*[c.ctypes.data for c in hconsts]),
+                                                     int(order_item), 1 if descending else 0, int(k))
+        if rc == _ffi.EUNSUPPORTED:
+            return None
+        self._chk(rc)
+        return Result(self, h)
+
     def filter_groupby_subset(self, table, where, g_col, keys, aggs):
         """The aggregates `aggs` for the groups `keys` only (a numpy array of <= 1024 distinct 32-bit key values): a Result
         with len(keys) rows in that order, one column per aggregate.  Raises on unsupported shapes (see include/hark.h)."""

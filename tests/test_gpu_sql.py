@@ -471,6 +471,63 @@ def test_limit_statements_compute_unordered_aggregates_late(late):
         os.environ.pop("HARK_NO_LATE_AGG", None)
 
 
+def test_fused_groupby_topk_equals_the_composed_statement():
+    """hark_entry_filter_groupby_topk (one call: per-slot read-out + selection) against filter_groupby followed by topk
+    over its result: same rows in the same order, bit for bit -- ties in the order key, empty key slots (keys that never
+    occur or never pass the WHERE), HAVING on several aggregates, HAVING that nothing passes, the key as the order
+    column, a statement without COUNT, every aggregate kind; and None for keys that are not dense."""
+    from harkdb_amd.engine import Engine
+    eng = Engine(0)
+    rng = np.random.default_rng(91)
+    n, G = 700_000, 30_000
+    k = rng.integers(0, G, n).astype(np.int32)
+    k[k % 7 == 3] += 1                                                     # a seventh of the slots stay empty
+    cols = [k, rng.random(n).astype(np.float32), (rng.integers(-20, 20, n) / 2).astype(np.float32), rng.integers(-1000, 1000, n).astype(np.int32),
+            rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32), rng.integers(0, 2**31, n).astype(np.int32) * 2]
+    t = eng.table_from_columns(cols)
+    aggs = [("sum", 2), ("count", 0), ("avg", 3), ("max", 4), ("min", 2), ("sum", 3)]
+    cases = [([(1, ">", 0.4)], aggs, [(2, ">", 10)], 1, True, 10), ([(1, ">", 0.4)], aggs, [], 1, False, 32), ([], aggs, [(2, ">=", 20), (1, "<", 5.5)], 4, True, 7),
+             ([(1, ">", 0.4), (3, "<", 500)], aggs, [(2, ">", 10**9)], 3, False, 5), ([(1, ">", 0.9)], aggs, [], 0, True, 12),
+             ([(1, ">", 0.4)], [("max", 3), ("sum", 2)], [(1, ">", 0)], 2, True, 9), ([(1, "<", 0.0)], aggs, [], 1, True, 4)]
+    for where, ag, having, item, desc, kk in cases:
+        top = eng.filter_groupby_topk(t, where, 0, ag, having, item, desc, kk)
+        assert top is not None
+        full = eng.filter_groupby(t, where, 0, ag)
+        m = full.shape[1]
+        if full.shape[0] == 0:
+            assert top.shape[0] == 0
+            continue
+        t2 = eng.table_from_device(full.shape[0], [full.device_ptr(j) for j in range(m)], [full.dtype(j) for j in range(m)], keepalive=full)
+        exp = eng.topk(t2, having, item, desc, kk, list(range(m)))
+        assert top.shape == exp.shape, (where, having, item)
+        for a, b in zip(top.columns(), exp.columns()):
+            assert a.dtype == b.dtype and np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b), (where, having, item)
+    sparse = eng.table_from_columns([(k.astype(np.int64) * 99991 % (2**31 - 1)).astype(np.int32), cols[1]])
+    assert eng.filter_groupby_topk(sparse, [], 0, [("count", 0)], [], 1, True, 5) is None      # keys spread over 2^31: not dense
+    t.free(); sparse.free()
+    eng.close()
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_limit_statement_fused_and_composed_agree_with_pandas(fused):
+    import os
+    from harkdb_amd import FutharkContext
+    rng = np.random.default_rng(6)
+    n, G = 400_000, 20_000
+    df = pd.DataFrame({"k": rng.integers(0, G, n).astype(np.int32), "p": rng.random(n).astype(np.float32), "a": rng.integers(-500, 500, n).astype(np.float32)})
+    c = FutharkContext(sql_mode=True)
+    c.create_table("t", df)
+    if not fused:
+        os.environ["HARK_NO_FUSED_TOPK"] = "1"
+    try:
+        g = df[df.p > 0.5].groupby("k").agg(sa=("a", "sum"), n=("a", "count")).reset_index()
+        exp = g[g.n > 8].sort_values(["sa", "k"], ascending=[False, True], kind="stable").head(10)
+        names, cols = c.sql_columns("select k, sum(a), count(*) from t where p > 0.5 group by k having count(*) > 8 order by sum(a) desc limit 10")
+        assert np.array_equal(cols[0], exp.k.to_numpy()) and np.array_equal(cols[1], exp.sa.to_numpy().astype(np.float32)) and np.array_equal(cols[2], exp.n.to_numpy())
+    finally:
+        os.environ.pop("HARK_NO_FUSED_TOPK", None)
+
+
 # ---- round 2: literals the column's dtype cannot hold, mixed CSV ingest, -0.0 / NaN group keys (ADVICE.md) ----------
 @pytest.mark.parametrize("pred,mask", [
     ("w < 2.5", lambda d: d.w < 2.5), ("w > -0.5", lambda d: d.w > -0.5), ("w = 2.5", lambda d: d.w == 2.5), ("w != 2.5", lambda d: d.w != 2.5),
