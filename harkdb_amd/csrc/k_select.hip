@@ -312,21 +312,6 @@ __device__ __forceinline__ uint64_t order_key(const void *col, int dtype, int64_
     return k ^ inv;
 }
 
-__device__ __forceinline__ bool row_passes(const TopPreds &pr, int64_t r)
-{
-    for (int j = 0; j < pr.n; j++) {
-        bool ok;
-        switch (pr.dtype[j]) {
-        case HARK_F32: ok = cmp_val<float>(pr.cmp[j], static_cast<const float *>(pr.col[j])[r], pr.c[j].f); break;
-        case HARK_I32: ok = cmp_val<int32_t>(pr.cmp[j], static_cast<const int32_t *>(pr.col[j])[r], (int32_t)pr.c[j].i); break;
-        case HARK_U32: ok = cmp_val<uint32_t>(pr.cmp[j], static_cast<const uint32_t *>(pr.col[j])[r], pr.c[j].u); break;
-        default: ok = cmp_val<int64_t>(pr.cmp[j], static_cast<const int64_t *>(pr.col[j])[r], pr.c[j].i); break;
-        }
-        if (!ok) return false;
-    }
-    return true;
-}
-
 // (order key, row) pairs compare lexicographically; row = ~0 marks "nothing"
 struct TopPair { uint64_t key; uint64_t row; };
 __device__ __forceinline__ bool pair_lt(TopPair a, TopPair b) { return a.key < b.key || (a.key == b.key && a.row < b.row); }
@@ -342,12 +327,36 @@ __global__ __launch_bounds__(kTopThreads) void topk_slice_kernel(TopPreds pr, co
     const TopPair none{~0ull, ~0ull};
     uint64_t key[kTopRows];
     uint32_t alive = 0;
+    // Every load below is unconditional (rows past the end read row n - 1) and the loops run predicate by predicate with
+    // the dtype switch OUTSIDE the row loop: the 16 loads of a column are independent and go out back to back.  (With
+    // `r < n && row_passes(...)` per row, each row's loads waited for the previous row's verdict: 47 us per 2^20 rows.)
 #pragma unroll
-    for (int j = 0; j < kTopRows; j++) {
-        const int64_t r = lo + (int64_t)j * kTopThreads + threadIdx.x;
-        key[j] = 0ull;
-        if (r < n && row_passes(pr, r)) { key[j] = order_key(ocol, odtype, r, inv); alive |= 1u << j; }
+    for (int j = 0; j < kTopRows; j++) alive |= (lo + (int64_t)j * kTopThreads + threadIdx.x < n ? 1u : 0u) << j;
+    auto row_of = [&](int j) { const int64_t r = lo + (int64_t)j * kTopThreads + threadIdx.x; return r < n ? r : n - 1; };
+    for (int q = 0; q < pr.n; q++) {
+        uint32_t ok = 0;
+        switch (pr.dtype[q]) {
+        case HARK_F32:
+#pragma unroll
+            for (int j = 0; j < kTopRows; j++) ok |= (cmp_val<float>(pr.cmp[q], static_cast<const float *>(pr.col[q])[row_of(j)], pr.c[q].f) ? 1u : 0u) << j;
+            break;
+        case HARK_I32:
+#pragma unroll
+            for (int j = 0; j < kTopRows; j++) ok |= (cmp_val<int32_t>(pr.cmp[q], static_cast<const int32_t *>(pr.col[q])[row_of(j)], (int32_t)pr.c[q].i) ? 1u : 0u) << j;
+            break;
+        case HARK_U32:
+#pragma unroll
+            for (int j = 0; j < kTopRows; j++) ok |= (cmp_val<uint32_t>(pr.cmp[q], static_cast<const uint32_t *>(pr.col[q])[row_of(j)], pr.c[q].u) ? 1u : 0u) << j;
+            break;
+        default:
+#pragma unroll
+            for (int j = 0; j < kTopRows; j++) ok |= (cmp_val<int64_t>(pr.cmp[q], static_cast<const int64_t *>(pr.col[q])[row_of(j)], pr.c[q].i) ? 1u : 0u) << j;
+            break;
+        }
+        alive &= ok;
     }
+#pragma unroll
+    for (int j = 0; j < kTopRows; j++) key[j] = order_key(ocol, odtype, row_of(j), inv);
     int t = 0;
     for (; t < k; t++) {
         TopPair mine = none;
@@ -385,7 +394,7 @@ __global__ __launch_bounds__(1024) void topk_merge_kernel(const TopPair *__restr
     const TopPair none{~0ull, ~0ull};
     TopPair mine_all[kTopCand];
 #pragma unroll
-    for (int j = 0; j < kTopCand; j++) { const int64_t i = (int64_t)j * 1024 + threadIdx.x; mine_all[j] = i < ncand ? cand[i] : none; }
+    for (int j = 0; j < kTopCand; j++) { const int64_t i = (int64_t)j * blockDim.x + threadIdx.x; mine_all[j] = i < ncand ? cand[i] : none; }
     int found = 0;
     for (int t = 0; t < k; t++) {
         TopPair best = none;
@@ -400,7 +409,7 @@ __global__ __launch_bounds__(1024) void topk_merge_kernel(const TopPair *__restr
         if ((threadIdx.x & 63) == 0) s_w[wave] = best;
         __syncthreads();
         best = s_w[0];
-        for (int w = 1; w < 1024 / 64; w++) if (s_w[w].row != ~0ull && (best.row == ~0ull || pair_lt(s_w[w], best))) best = s_w[w];
+        for (int w = 1; w < (int)(blockDim.x >> 6); w++) if (s_w[w].row != ~0ull && (best.row == ~0ull || pair_lt(s_w[w], best))) best = s_w[w];
         if (best.row == ~0ull) break;
 #pragma unroll
         for (int j = 0; j < kTopCand; j++) if (mine_all[j].row == best.row) mine_all[j] = none;
@@ -565,7 +574,10 @@ int hark_entry_topk(hark_context *ctx, hark_result **out, const hark_table *db, 
         hipStream_t st = ctx->stream;
         const uint64_t inv = descending ? ~0ull : 0ull;
         topk_slice_kernel<<<dim3((unsigned)nblk), dim3(kTopThreads), 0, st>>>(pr, db->cols[key_col].data, db->cols[key_col].dtype, inv, n, (int)k, cand);
-        topk_merge_kernel<<<1, 1024, 0, st>>>(cand, nblk * k, (int)k, rows, count);
+        // a few thousand candidates (2^20 rows, k = 10: 2560) are merged by four waves: every round ends in a barrier
+        // and a scan over one partial result per wave
+        const int merge_threads = nblk * k <= (int64_t)kTopCand * 256 ? 256 : 1024;
+        topk_merge_kernel<<<1, merge_threads, 0, st>>>(cand, nblk * k, (int)k, rows, count);
         if (hipGetLastError() != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "topk: launch failed");
         if (!rc) rc = hark_read_words(ctx, count, &found, 1);
     }
