@@ -25,6 +25,9 @@ ops = {
     "join prefilter u32": lambda: eng.join(t, small, 2, 0, [0, 1], [1]),
     "join prefilter i64": lambda: eng.join(wide, wsmall, 0, 0, [1], [1]),
     "filter_groupby": lambda: eng.filter_groupby(t, (3, ">", 0.5), 0, [("sum", 3), ("count", 0), ("max", 1)]),
+    "filter_groupby_topk": lambda: eng.filter_groupby_topk(t, [(3, ">", 0.5)], 0, [("sum", 3), ("count", 0), ("max", 1)], [(2, ">", 1)], 1, True, 10),
+    "topk": lambda: eng.topk(t, [(3, ">", 0.5)], 1, True, 10, [0, 1, 2]),
+    "filter_groupby_subset": lambda: eng.filter_groupby_subset(t, [(3, ">", 0.5)], 0, np.arange(100, dtype=np.uint32), [("sum", 3), ("max", 1)]),
 }
 bad = False
 for name, fn in ops.items():
