@@ -379,10 +379,51 @@ constexpr int kFlushPeriod6 = 2;                         // batches between swee
 // 128-byte line, rings of 128 keys; the producer does not even read a value column (8 B/row instead of 12).
 constexpr int kQ2 = 128;
 constexpr int kUnit2Bytes = kU * 2;                      // 128
+// ---- batches of a producer launch are handed out first come, first served ---------------------------------------
+// The XCDs of a card do not stream at the same rate: under a fixed assignment (batch = wg + j * nwg) the workgroup durations
+// of one launch spread by 6-10 % (per-XCD means differ by up to 6 %, tools/wg_times.py), and the kernel lasts as long as
+// its slowest workgroup.  A workgroup's step j works on batch seq(j): steps 0..3 are fixed (wg + j * nwg); from step 4 on
+// thread 0 draws kDraw consecutive batches at a time from a device counter (the word behind the plan's error word, zeroed
+// before every launch) -- asked for at step j, parked in an LDS ring at step j + 1, read by all threads from step j + 2 on,
+// when the loads of those batches are issued: two barriers of slack, and the returned value is not touched for a whole
+// batch, so nobody waits for the atomic.  One draw per batch cost 0.5 us per step (256 workgroups in step on one word);
+// four batches per draw: producer 2.59 -> 2.49 ms on a fast card, 2.94 -> 2.58..2.77 on a slow one.
+constexpr int kDraw = 4, kSeqRing = 8;
+struct BatchSeq {
+    uint32_t *ring;                                      // LDS [kSeqRing]
+    uint32_t *ctr;
+    uint64_t nbatch, first_drawn;
+    uint32_t asked;
+    int zero;
+    // call before a barrier that precedes step 0
+    __device__ __forceinline__ void init(uint32_t *ring_lds, int32_t *err, int64_t nb, int wg, int nwg, int tid)
+    {
+        ring = ring_lds; ctr = reinterpret_cast<uint32_t *>(err) + 1; nbatch = (uint64_t)nb; first_drawn = 4u * (uint64_t)nwg; asked = 0u;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(zero));     // an opaque zero (see draw)
+        if (tid < 2) ring[2 + tid] = (uint32_t)min((uint64_t)wg + (uint64_t)(2 + tid) * (uint64_t)nwg, nbatch);
+    }
+    // the batch whose loads are issued at step j (= the batch of step j + 2)
+    __device__ __forceinline__ int64_t to_load(int j) const { return (int64_t)ring[(j + 2) & (kSeqRing - 1)]; }
+    // thread 0, once per step, before the step's first barrier
+    __device__ __forceinline__ void draw(int j)
+    {
+        if ((j & (kDraw - 1)) == 1) {                    // the numbers of steps j + 3 .. j + 6, asked for at step j - 1
+#pragma unroll
+            for (int q = 0; q < kDraw; q++) {
+                const uint64_t id = (uint64_t)kDraw * asked + (uint64_t)q + first_drawn;
+                ring[(j + 3 + q) & (kSeqRing - 1)] = id < nbatch ? (uint32_t)id : (uint32_t)nbatch;
+            }
+        }
+        // (the offset is an opaque zero: with a provably uniform address the compiler's atomic optimizer wraps the atomic in
+        // a wave reduction that reads the returned value -- and waits for it -- on the spot)
+        if ((j & (kDraw - 1)) == 0) asked = atomicAdd(ctr + zero, 1u);
+    }
+};
+
 static size_t part_lds_bytes(int P, int fmt)             // fmt: 0 = 8-byte pairs, 1 = compact 6-byte pairs, 2 = keys only
 {
     const size_t q = fmt == 1 ? (size_t)6 * P * kQ6 : fmt == 2 ? (size_t)2 * P * kQ2 : sizeof(uint2) * (size_t)P * (P > kMaxBuckets ? kQ / 2 : kQ);
-    return q + sizeof(int) * 2 * (size_t)P + 8 + (size_t)kHot * 16 + 32;
+    return q + sizeof(int) * 2 * (size_t)P + 8 + (size_t)kHot * 16 + 64;      // ... + h_stat[8] + the ring of batch numbers seq[8]
 }
 
 // Workgroup-wide OR through one LDS word and ONE lds_barrier: three slots used in rotation, the next
@@ -454,6 +495,8 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
     for (int h = tid; h < kHot; h += kPartThreads) { h_val[h] = vop_identity(vop); h_key[h] = kHotEmpty; h_cnt[h] = 0u; }
     if (tid < 8) h_stat[tid] = 0u;
     uint32_t *or_flags = h_stat + 4;
+    BatchSeq seq;
+    seq.init(h_stat + 8, err, nbatch, wg, nwg, tid);
     int or_phase = 0;
     int batches_done = 0, since_sweep = 0, n_full = 0;
     bool hot_on = !HASH && !strict;                                    // workgroup-uniform; switched off after the probe unless keys repeat
@@ -686,13 +729,18 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
     // two batches of loads stay in flight per lane while a batch is enqueued and flushed
     // (one call site of `process`: the register sets rotate, the body is not duplicated)
     float4 pA, vA, pB, vB; int4 kA, kB;
-    if ((int64_t)wg < nbatch) load(wg, pA, kA, vA);
-    if ((int64_t)wg + nwg < nbatch) load((int64_t)wg + nwg, pB, kB, vB);
-    for (int64_t batch = wg; batch < nbatch; batch += nwg) {
+    int64_t idA = wg, idB = (int64_t)wg + nwg;                        // the batches whose rows sit in the A and B registers
+    if (idA < nbatch) load(idA, pA, kA, vA);
+    if (idB < nbatch) load(idB, pB, kB, vB);
+    for (int j = 0; idA < nbatch; j++) {
+        const int64_t batch = idA;
         const float4 pr = pA, vr = vA; const int4 kr = kA;
         pA = pB; vA = vB; kA = kB;
-        if (batch + 2 * (int64_t)nwg < nbatch) load(batch + 2 * (int64_t)nwg, pB, kB, vB);
-        process(batch, pr, kr, vr, ++since_sweep >= period || batch + nwg >= nbatch);   // sweep every period-th batch and on the last one
+        idA = idB;
+        idB = seq.to_load(j);                                           // parked at least one barrier ago
+        if (tid == 0) seq.draw(j);
+        if (idB < nbatch) load(idB, pB, kB, vB);
+        process(batch, pr, kr, vr, ++since_sweep >= period || idA >= nbatch);   // sweep every period-th batch and on the workgroup's last one
     }
     // ---- final flush: what is left (< kLine pairs per bucket) goes out as one partial line
     for (int b = tid; b < P; b += kPartThreads) {
@@ -965,7 +1013,7 @@ constexpr int kU10 = 64;                                 // pairs per unit
 constexpr int kUnit10Bytes = kU10 * 10;                  // 640
 constexpr int kQ10 = 112;                                // ring capacity per bucket (pairs): a unit + 48 of headroom; 112 = 14 x 8 keeps 16-byte pieces whole across the wrap
 constexpr int kPairBuckets = 128;
-static size_t part2_lds_bytes(int P) { return (size_t)10 * P * kQ10 + sizeof(uint32_t) * 2 * (size_t)P + 32; }
+static size_t part2_lds_bytes(int P) { return (size_t)10 * P * kQ10 + sizeof(uint32_t) * 2 * (size_t)P + 32 + 4 * kSeqRing; }
 
 template <int OP>
 __global__ __launch_bounds__(kPartThreads) void fgb_part2_kernel(
@@ -988,6 +1036,8 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part2_kernel(
     auto wrap = [](int x) { return x >= kQ10 ? x - kQ10 : x; };
     for (int b = tid; b < P; b += kPartThreads) { s_w[b] = 0u; s_lcur[b] = 0; }
     if (tid < 4) or_flags[tid] = 0u;
+    BatchSeq seq;                                                          // batches first come, first served (see BatchSeq)
+    seq.init(or_flags + 8, err, nbatch, wg, nwg, tid);
     int or_phase = 0, period = 2, since_sweep = 0, n_full = 0, batches_done = 0;
     bool bad = false, overflow = false;
     __syncthreads();
@@ -1090,13 +1140,18 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part2_kernel(
     };
 
     Rows A, B;
-    if ((int64_t)wg < nbatch) load(wg, A);
-    if ((int64_t)wg + nwg < nbatch) load((int64_t)wg + nwg, B);
-    for (int64_t batch = wg; batch < nbatch; batch += nwg) {
+    int64_t idA = wg, idB = (int64_t)wg + nwg;
+    if (idA < nbatch) load(idA, A);
+    if (idB < nbatch) load(idB, B);
+    for (int j = 0; idA < nbatch; j++) {
+        const int64_t batch = idA;
         const Rows cur = A;
         A = B;
-        if (batch + 2 * (int64_t)nwg < nbatch) load(batch + 2 * (int64_t)nwg, B);
-        process(batch, cur, ++since_sweep >= period || batch + nwg >= nbatch);
+        idA = idB;
+        idB = seq.to_load(j);
+        if (tid == 0) seq.draw(j);
+        if (idB < nbatch) load(idB, B);
+        process(batch, cur, ++since_sweep >= period || idA >= nbatch);
     }
     // what is left (< kU10 pairs per bucket) goes out as one partial unit
     for (int b = tid; b < P; b += kPartThreads) {
@@ -1478,11 +1533,11 @@ int hark_fgb_plan_new(hark_context *ctx, hark_fgb_plan **out, int64_t max_rows, 
     hark_fgb_plan *pl = new hark_fgb_plan();
     pl->max_rows = max_rows; pl->G = G; pl->ctx = ctx;
     pl->tile_rows = kTileRows;
-    int rc = hark_alloc(ctx, (void **)&pl->err, sizeof(int32_t));
+    int rc = hark_alloc(ctx, (void **)&pl->err, 16);                  // [0] sticky error word, [1] the producers' batch counter
     if (!rc) rc = hark_alloc(ctx, (void **)&pl->acc_sum, (size_t)G * sizeof(double));
     if (!rc) rc = hark_alloc(ctx, (void **)&pl->acc_cnt, (size_t)G * sizeof(unsigned long long));
     if (rc) { hark_fgb_plan_free(ctx, pl); return rc; }
-    hipMemsetAsync(pl->err, 0, sizeof(int32_t), ctx->stream);
+    hipMemsetAsync(pl->err, 0, 16, ctx->stream);
     hipMemsetAsync(pl->acc_sum, 0, (size_t)G * sizeof(double), ctx->stream);
     hipMemsetAsync(pl->acc_cnt, 0, (size_t)G * sizeof(unsigned long long), ctx->stream);
     *out = pl;
@@ -1666,6 +1721,7 @@ int k_fgb_dense_f32(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cm
         }
         for (int64_t r0 = 0; r0 < n; r0 += pl->chunk_rows) {
             const int64_t r1 = r0 + pl->chunk_rows < n ? r0 + pl->chunk_rows : n;
+            HIP_TRY(ctx, hipMemsetAsync(pl->err + 1, 0, 4, st));                 // the producers' batch counter
             {
                 TimedLaunch tl(pl, st, 1);
                 const int period = (int)((pl->ablate >> 12) & 15);            // experiments: batches between sweeps (0 = default)
@@ -1838,6 +1894,7 @@ int k_fgb_dense_stats(hark_context *ctx, hark_fgb_plan *pl, const float *p, int 
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_part_kernel<OP, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part));
         for (int64_t r0 = 0; r0 < n; r0 += pl->chunk_rows) {
             const int64_t r1 = r0 + pl->chunk_rows < n ? r0 + pl->chunk_rows : n;
+            HIP_TRY(ctx, hipMemsetAsync(pl->err + 1, 0, 4, st));                 // the producers' batch counter
             {
                 TimedLaunch tl(pl, st, 1);
                 fgb_part_kernel<OP, 0, 1><<<dim3((unsigned)nwg), dim3(kPartThreads), lds_part, st>>>(
@@ -1900,6 +1957,7 @@ int k_fgb_dense_pair(hark_context *ctx, hark_fgb_plan *pl, const float *p, int c
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_part2_kernel<OP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part));
         for (int64_t r0 = 0; r0 < n; r0 += pl->chunk_rows) {
             const int64_t r1 = r0 + pl->chunk_rows < n ? r0 + pl->chunk_rows : n;
+            HIP_TRY(ctx, hipMemsetAsync(pl->err + 1, 0, 4, st));                 // the producers' batch counter
             {
                 TimedLaunch tl(pl, st, 1);
                 fgb_part2_kernel<OP><<<dim3((unsigned)nwg), dim3(kPartThreads), lds_part, st>>>(
