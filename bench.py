@@ -51,6 +51,9 @@ def parse_args():
     ap.add_argument("--configs", type=int, default=1, help="0: skip the extra BASELINE-config measurements (N = 1 only)")
     ap.add_argument("--config-scale", type=float, default=1.0, help="scale the rows of the extra configs (tests)")
     ap.add_argument("--stub", type=int, default=0, help="CPU protocol test: gloo ranks, a numpy step (no GPU, no HIP)")
+    ap.add_argument("--pmc", type=int, default=-1, help="HBM traffic of the path's kernels from rocprofv3 --pmc child runs of this script "
+                                                        "(-1: when rocprofv3 is on PATH and N = 1; 0: never; 1: required)")
+    ap.add_argument("--pmc-child", type=int, default=0, help="internal: the headline steps only, no probes / checks / configs (run under rocprofv3 --pmc)")
     return ap.parse_args()
 
 
@@ -105,6 +108,70 @@ def cpu_baseline(rows, G, exact):
             "sample": f"first {rows} rows of the same synthetic workload (G={G}), {dt:.2f} s, "
                       f"{int(counts.sum())} survivors, {len(keys)} groups; nproc={os.cpu_count()}",
             "algorithm": "oracle/hark_oracle.c ora_filter_groupby_refalgo_f32 = groupby.fut:8-58 + segmented.fut:7-37"}, (keys, sums, counts)
+
+
+def measure_traffic(N, G, timeout_s=240):
+    """HBM bytes per launch of the path's kernels, measured NOW: two child runs of this script's headline steps under
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (one counter per run, with --kernel-trace only, as
+    MI355X_MICROARCH.md prescribes), FETCH_SIZE doubled per that guide's gfx950 note.  Children, not an exec: this
+    process has initialised the GPU.  Returns (dict, None) or (None, reason)."""
+    import collections
+    import csv
+    import glob
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not on PATH"
+    tmp = tempfile.mkdtemp(prefix="hark_pmc_", dir="/tmp")
+    kernels = collections.defaultdict(dict)
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+                   "--pmc-child", "1", "--rows", str(N), "--groups", str(G), "--steps", "2", "--warmup", "1", "--cpu-rows", "0", "--configs", "0"]
+            env = dict(os.environ, TMPDIR="/tmp")
+            for kk in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "HARK_FORCE_PIPELINE"):
+                env.pop(kk, None)
+            pr = subprocess.Popen(cmd, cwd=tmp, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, start_new_session=True)
+            try:
+                _, err = pr.communicate(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(pr.pid, 9)                                  # the exact process group started here
+                pr.wait()
+                return None, f"rocprofv3 --pmc {ctr} child timed out after {timeout_s} s"
+            if pr.returncode:
+                return None, f"rocprofv3 --pmc {ctr} child failed (rc {pr.returncode}): {err.decode(errors='replace')[-300:]}"
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                return None, f"rocprofv3 --pmc {ctr}: no counter_collection.csv"
+            agg = collections.defaultdict(list)
+            for r in csv.DictReader(open(files[0])):
+                m = re.search(r"(fgb_(?:part|agg6|agg|lds)\w*)", r["Kernel_Name"])
+                if m and r.get("Counter_Name", ctr) == ctr:
+                    agg[m.group(1)].append(float(r["Counter_Value"]))
+            for kn, vals in agg.items():
+                kernels[kn][ctr + "_KiB_mean_per_launch"] = sum(vals) / len(vals)
+                kernels[kn]["launches_profiled"] = len(vals)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    if not kernels:
+        return None, "no fgb_* kernel rows in the counter files"
+    for kn, dd in kernels.items():
+        dd["hbm_read_bytes"] = 2.0 * dd.get("FETCH_SIZE_KiB_mean_per_launch", 0.0) * 1024.0
+        dd["hbm_write_bytes"] = dd.get("WRITE_SIZE_KiB_mean_per_launch", 0.0) * 1024.0
+        dd["hbm_bytes_per_launch_corrected"] = dd["hbm_read_bytes"] + dd["hbm_write_bytes"]
+    return dict(kernels), None
+
+
+def git_head():
+    try:
+        import subprocess
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip() or None
+    except Exception:
+        return None
 
 
 def stub_main(a):
@@ -210,6 +277,29 @@ def extra_configs(torch, eng, dev, a, p, k, v, N):
                           kernel_ms=sum(kms.values()) / max(1, kl[dom]), count_checksum=ok, statement="SELECT k,SUM(v),COUNT(*) WHERE p>0.5 GROUP BY k")
         plan.free()
     del so, co
+
+    # ---- the envelope of the headline statement: selectivity x G (partition bytes scale with the selectivity; the
+    #      single-pass path ends at G = 13 568).  p is uniform in [0, 1): `p > thr` keeps 1 - thr of the rows.
+    sweep = {}
+    for G, thr in ((1 << 14, 0.5), (1 << 16, 0.5), (1 << 18, 0.5), (1 << 20, 0.9), (1 << 20, 0.5), (1 << 20, 0.1)):
+        eng.gen_columns(SEED, 0, N, G, bool(a.exact), None, k.data_ptr(), None)
+        so, co = torch.empty(G, dtype=torch.float32, device=dev), torch.empty(G, dtype=torch.int64, device=dev)
+        plan = FgbPlan(eng, N, G, timing=1)
+
+        def step():
+            plan.reset()
+            plan.run(p.data_ptr(), ">", thr, k.data_ptr(), v.data_ptr(), N)
+            plan.finish(so.data_ptr(), co.data_ptr())
+
+        ms = event_ms(torch, step)
+        kms, kl = plan.timing()
+        surv = int(co.sum().item())
+        sweep[f"G2^{G.bit_length() - 1}_sel{1.0 - thr:.1f}"] = entry(
+            ms, 12.0 * N + 16.0 * G, N, groups=G, selectivity=surv / N, survivors=surv,
+            kernel_ms={kk: kms[kk] / max(1, kl[kk]) for kk in kms if kl[kk]}, count_checksum=surv == int((p > thr).sum().item()))
+        plan.free()
+        del so, co
+    out["SWEEP_selectivity_x_groups"] = sweep
 
     # ---- C2: WHERE filter + projection, 1e8 rows x 8 f32 columns (configs[1]): SELECT rowid, c0, c2 WHERE c1 > 0.5
     n2 = int(1e8 * a.config_scale) // 4 * 4
@@ -393,7 +483,8 @@ def main():
     job = hd.ShardedFgb(eng, plan, dev, plan2=plan2)
 
     def step():
-        job.step(p.data_ptr(), ">", 0.5, k.data_ptr(), v.data_ptr(), N, sum_out.data_ptr(), cnt_out.data_ptr())
+        # check=False: no host round trip inside the loop; job.flush() reads the sticky error words after the last step
+        job.step(p.data_ptr(), ">", 0.5, k.data_ptr(), v.data_ptr(), N, sum_out.data_ptr(), cnt_out.data_ptr(), check=False)
 
     def fence():
         torch.cuda.synchronize()
@@ -414,6 +505,9 @@ def main():
     job.flush()                                               # the last step's all-reduce + finish belong to the timed region
     fence()
     elapsed_local = time.perf_counter() - t0
+    if a.pmc_child:                                           # under rocprofv3 --pmc: the counters are all that is wanted
+        print(json.dumps({"pmc_child": True, "ms_per_step": elapsed_local / a.steps * 1e3}), flush=True)
+        return
     t = torch.tensor([elapsed_local], dtype=torch.float64, device=dev)
     per_rank = [elapsed_local]
     if dist.is_initialized():
@@ -470,19 +564,28 @@ def main():
         alg_bytes = 12.0 * rows_per_launch + (16.0 * G if dom != "producer" else 0.0)
         dom_achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
         kernel_name = {"single": "fgb_lds_kernel", "producer": "fgb_part_kernel", "consumer": "fgb_agg6_kernel"}[dom]
-        # HBM traffic of the path's kernels from the committed PMC passes of this same workload (rocprofv3 --pmc
-        # FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled per the gfx950 note): NOT measured in this run
-        traffic, traffic_src = None, None
-        for cand in ("r02_pmc_fgb.json", "r01_pmc_fgb.json"):
-            try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", cand)))
-                if (pmc["config"]["rows_per_gpu"] == N and pmc["config"]["groups"] == G and not a.algo and not a.chunk_rows
-                        and dom_launches == a.steps * pmc["config"]["producer_launches_per_step"]):
-                    traffic = sum(kk["hbm_bytes_per_launch_corrected"] for kk in pmc["kernels"].values())
-                    traffic_src = "profiles/" + cand
-                    break
-            except Exception:
-                pass
+        # HBM traffic of the path's kernels: measured in THIS run by two rocprofv3 --pmc child runs of the headline steps
+        # (measure_traffic), else read from the newest committed PMC passes of the same workload (marked as such)
+        traffic, traffic_src, traffic_live, traffic_detail, traffic_note = None, None, False, None, None
+        want_pmc = a.pmc == 1 or (a.pmc < 0 and world == 1 and not a.algo and not a.chunk_rows)
+        if want_pmc:
+            traffic_detail, traffic_note = measure_traffic(N, G)
+            if traffic_detail:
+                traffic = sum(kk["hbm_bytes_per_launch_corrected"] for kk in traffic_detail.values()) * (dom_launches / a.steps)
+                traffic_src, traffic_live = f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of this bench.py (git {git_head()})", True
+            elif a.pmc == 1:
+                raise SystemExit("--pmc 1: " + str(traffic_note))
+        if traffic is None:
+            for cand in ("r03_pmc_fgb.json", "r02_pmc_fgb.json", "r01_pmc_fgb.json"):
+                try:
+                    pmc = json.load(open(os.path.join(ROOT, "profiles", cand)))
+                    if (pmc["config"]["rows_per_gpu"] == N and pmc["config"]["groups"] == G and not a.algo and not a.chunk_rows
+                            and dom_launches == a.steps * pmc["config"]["producer_launches_per_step"]):
+                        traffic = sum(kk["hbm_bytes_per_launch_corrected"] for kk in pmc["kernels"].values())
+                        traffic_src = "profiles/" + cand + (f" (git {pmc['git']})" if pmc.get("git") else "")
+                        break
+                except Exception:
+                    pass
         path_bytes = 12.0 * N + 16.0 * G
         kernels_ms = sum(ms_by_kind.values()) / a.steps
         path_achieved = path_bytes / (ms_step * 1e-3) / 1e9        # per GPU: every rank moves its own 12 B/row in the same wall time
@@ -503,7 +606,10 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": path_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": path_achieved / HBM_PEAK_GBS,
                          "frac_is": "whole path per GPU: (12 B/row x rows + 16 B x groups) / wall time of a step / 8 TB/s",
-                         "traffic": traffic, "traffic_source": traffic_src, "traffic_measured_in_run": False,
+                         "traffic": traffic, "traffic_source": traffic_src, "traffic_measured_in_run": traffic_live,
+                         "traffic_is": "HBM bytes per step of the path's kernels (producer + consumer): 2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes",
+                         "traffic_by_kernel": traffic_detail, "traffic_note": traffic_note,
+                         "traffic_over_algorithmic": (traffic / (12.0 * N + 16.0 * G)) if traffic else None,
                          # what the HBM actually moves per second on this path (PMC bytes of the committed profile over this run's
                          # step time): the kernels keep the memory system at this fraction of its peak, 1.5x the algorithmic bytes
                          "traffic_GBps": (traffic / (ms_step * 1e-3) / 1e9) if traffic else None,
@@ -525,16 +631,39 @@ def main():
                          "frac_of_peak_wall": path_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "check": check,
         }
+        hip_sample = None
+        if world == 1 and a.cpu_rows > 0:
+            # the HIP path on exactly the rows the CPU port is timed on below (the first cpu_rows rows of this table),
+            # before the extra configs overwrite the key column; compared with the port's (keys, sums, counts) afterwards
+            ns = min(int(a.cpu_rows), N)
+            so_s, co_s = torch.empty(G, dtype=torch.float32, device=dev), torch.empty(G, dtype=torch.int64, device=dev)
+            plan_s = FgbPlan(eng, ns, G)
+            plan_s.run(p.data_ptr(), ">", 0.5, k.data_ptr(), v.data_ptr(), ns)
+            plan_s.finish(so_s.data_ptr(), co_s.data_ptr())
+            hip_sample = (ns, so_s.cpu().numpy(), co_s.cpu().numpy())
+            plan_s.free()
+            del so_s, co_s
         if world == 1 and a.configs:
             try:
                 plan.free()
                 out["configs"] = extra_configs(torch, eng, dev, a, p, k, v, N)
             except Exception as e:                                  # the headline line must still be printed
                 out["configs"] = {"error": repr(e)}
-        if world == 1 and a.cpu_rows > 0:
-            base, (bk, bs, bc) = cpu_baseline(a.cpu_rows, G, a.exact)
+        if hip_sample is not None:
+            ns, hs, hc = hip_sample
+            base, (bk, bs, bc) = cpu_baseline(ns, G, a.exact)
             out["cpu_baseline"] = base
             out["cpu_baseline"]["gpu_speedup_same_metric"] = out["value"] / base["value"]
+            # same rows, both implementations: every group the port reports, and no group besides them
+            idx = bk.astype(np.int64)
+            same_counts = bool(np.array_equal(hc[idx], bc.astype(np.int64))) and int(hc.sum()) == int(bc.sum())
+            if a.exact:
+                same_sums = bool(np.array_equal(hs[idx], bs.astype(np.float32)))
+            else:                                                 # 1e-5 relative (BASELINE.json north_star), sums of non-negative values
+                same_sums = bool(np.all(np.abs(hs[idx].astype(np.float64) - bs.astype(np.float64)) <= 1e-5 * np.abs(bs.astype(np.float64)) + 1e-30))
+            out["check"]["hip_equals_cpu_port_on_sample"] = same_counts and same_sums
+            out["check"]["hip_vs_cpu_port"] = {"rows": ns, "groups_compared": int(len(bk)), "counts_equal": same_counts, "sums_equal": same_sums,
+                                               "sums_bar": "bit-exact (integer-valued f32)" if a.exact else "1e-5 relative"}
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

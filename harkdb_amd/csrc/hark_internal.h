@@ -108,6 +108,7 @@ struct hark_fgb_plan {
     int64_t P = 0;             // number of buckets
     int64_t nwg = 0;           // producer workgroups (= slabs per bucket)
     int64_t cap = 0;           // pairs per (bucket, workgroup) slab
+    int64_t shift8 = 0, P8 = 0, cap8 = 0;   // second geometry over the same slab space: <= 128 buckets (one-word ring entries), 0 = none
     int64_t slack_pct = 0;     // slab capacity as % of the uniform share (0 = default)
     int64_t tile_rows = 0;
     int64_t ablate = 0;        // timing experiments only

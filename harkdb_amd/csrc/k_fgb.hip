@@ -371,6 +371,9 @@ constexpr int kErrOverflow = 100;                        // device error word: a
 // the write combining keeps its whole-line property (a 64-B + 32-B split of 16 pairs did not).  The producer
 // is at the HBM ceiling of its traffic mix, so 25 % fewer partition bytes are worth their price in LDS: rings
 // of 96 pairs (one unit + 32 of headroom) per bucket, swept every second batch.
+#ifndef HARK_ABL_BSKEW
+#define HARK_ABL_BSKEW 0     // ablation builds (tools/ab_build.sh): extra bytes between the slab rows of consecutive buckets of the compact formats
+#endif                       // (nwg x slab bytes is a multiple of 64 KiB: all 256 slabs a workgroup sweeps share their low address bits)
 constexpr int kU = 64;                                   // pairs per unit
 constexpr int kUnitBytes = kU * 6;                       // 384
 constexpr int kQ6 = 96;                                  // ring capacity per bucket (pairs)
@@ -379,6 +382,13 @@ constexpr int kFlushPeriod6 = 2;                         // batches between swee
 // 128-byte line, rings of 128 keys; the producer does not even read a value column (8 B/row instead of 12).
 constexpr int kQ2 = 128;
 constexpr int kUnit2Bytes = kU * 2;                      // 128
+// FMT 3 (round 3 A/B, pairfmt = 3): the same 6-byte units in HBM, but a ring entry is ONE 8-byte LDS word (value,
+// bucket-local key) -- one ds_write_b64 per surviving row instead of a b32 and a b16 -- in at most 128 buckets of 8192
+// keys: 128 rings of 144 entries (a unit + 80 of headroom) are 144 KiB.  Measured flat against FMT 1 (profiles/
+// r03_notes.md): the ring stores were never what the producer waits for.
+constexpr int kQ8e = 144;
+constexpr int kMaxBuckets8e = 128;
+constexpr int kFlushPeriod8e = 4;
 // ---- batches of a producer launch are handed out first come, first served ---------------------------------------
 // The XCDs of a card do not stream at the same rate: under a fixed assignment (batch = wg + j * nwg) the workgroup durations
 // of one launch spread by 6-10 % (per-XCD means differ by up to 6 %, tools/wg_times.py), and the kernel lasts as long as
@@ -422,7 +432,8 @@ struct BatchSeq {
 
 static size_t part_lds_bytes(int P, int fmt)             // fmt: 0 = 8-byte pairs, 1 = compact 6-byte pairs, 2 = keys only
 {
-    const size_t q = fmt == 1 ? (size_t)6 * P * kQ6 : fmt == 2 ? (size_t)2 * P * kQ2 : sizeof(uint2) * (size_t)P * (P > kMaxBuckets ? kQ / 2 : kQ);
+    const size_t q = fmt == 1 ? (size_t)6 * P * kQ6 : fmt == 2 ? (size_t)2 * P * kQ2 : fmt == 3 ? (size_t)8 * P * kQ8e
+                   : sizeof(uint2) * (size_t)P * (P > kMaxBuckets ? kQ / 2 : kQ);
     return q + sizeof(int) * 2 * (size_t)P + 8 + (size_t)kHot * 16 + 64;      // ... + h_stat[8] + the ring of batch numbers seq[8]
 }
 
@@ -462,17 +473,19 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
     int hash_bits, int strict /* dense mode without a fallback: no heavy-hitter cache, a full slab or ring reports kErrOverflow
                                 (the statistics pass: the global table cannot take single rows) */)
 {
-    constexpr bool HASH = MODE == 2, C6 = FMT == 1, K2 = FMT == 2;
+    constexpr bool HASH = MODE == 2, C6 = FMT == 1, K2 = FMT == 2, C8 = FMT == 3;
     const int vop = MODE == 0 ? (int)VOP_F32SUM : vop_rt;
     const int xf = MODE == 0 ? 0 : xf_rt;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    static_assert(!((C6 || K2) && MODE == 2), "compact pairs carry bucket-local keys: dense mode only");
+    static_assert(!((C6 || K2 || C8) && MODE == 2), "compact pairs carry bucket-local keys: dense mode only");
+    uint2 *q8e = reinterpret_cast<uint2 *>(lds_raw);                   // [P][kQ8e] (value, bucket-local key)   FMT 3
     uint2 *queue = reinterpret_cast<uint2 *>(lds_raw);                 // [P][q8]           8-byte pairs
     const int q8 = P > kMaxBuckets ? kQ / 2 : kQ;                      // ring capacity of the 8-byte format: 64 pairs, 32 with 257..512 buckets (hash mode)
     uint32_t *qv = reinterpret_cast<uint32_t *>(lds_raw);              // [P][kQ6] values   compact format
     uint16_t *qk = reinterpret_cast<uint16_t *>(qv + (size_t)P * kQ6); // [P][kQ6] bucket-local keys
     uint16_t *qk2 = reinterpret_cast<uint16_t *>(lds_raw);            // [P][kQ2] bucket-local keys   keys-only format
     uint32_t *s_w = C6 ? reinterpret_cast<uint32_t *>(qk + (size_t)P * kQ6)
+                  : C8 ? reinterpret_cast<uint32_t *>(q8e + (size_t)P * kQ8e)
                   : K2 ? reinterpret_cast<uint32_t *>(qk2 + (size_t)P * kQ2)
                        : reinterpret_cast<uint32_t *>(queue + (size_t)P * q8);   // [P] ring index of the oldest pair << 16 | pairs queued
     int *s_lcur = reinterpret_cast<int *>(s_w + P);                    // [P] lines already stored in this workgroup's slab
@@ -488,7 +501,8 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
     unsigned char *slab6 = reinterpret_cast<unsigned char *>(pbuf) + (size_t)wg * ((size_t)cap * 8);    // + b * nwg * cap * 8
     const uint32_t kmask = (1u << shift) - 1u;
     auto wrap6 = [](int x) { return x >= kQ6 ? x - kQ6 : x; };
-    int period = period_knob > 0 ? period_knob : ((C6 || K2) ? kFlushPeriod6 : HASH ? 2 : kFlushPeriod);   // hash mode: every row is enqueued (16 or 8 per bucket and batch)
+    auto wrap8 = [](int x) { return x >= kQ8e ? x - kQ8e : x; };
+    int period = period_knob > 0 ? period_knob : C8 ? kFlushPeriod8e : ((C6 || K2) ? kFlushPeriod6 : HASH ? 2 : kFlushPeriod);   // hash mode: every row is enqueued (16 or 8 per bucket and batch)
     const uint32_t Gu = (uint32_t)G;                                   // G <= 2^31: one unsigned compare rejects negative keys too
     bool bad = false, overflow = false;
     for (int b = tid; b < P; b += kPartThreads) { s_w[b] = 0u; s_lcur[b] = 0; }
@@ -604,6 +618,11 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
                             qv[at] = vbits_of(vv[j]); qk[at] = (uint16_t)(key & kmask);
                             pending &= ~(1u << j);
                         } else atomicSub(&s_w[b], 1u);
+                    } else if (C8) {
+                        if (pos < (uint32_t)kQ8e) {
+                            q8e[(int)b * kQ8e + wrap8((int)(old >> 16) + (int)pos)] = uint2{vbits_of(vv[j]), key & kmask};   // one ds_write_b64
+                            pending &= ~(1u << j);
+                        } else atomicSub(&s_w[b], 1u);
                     } else if (K2) {
                         if (pos < (uint32_t)kQ2) {
                             qk2[b * kQ2 + (((old >> 16) + pos) & (kQ2 - 1))] = (uint16_t)(key & kmask);
@@ -618,6 +637,7 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
             }
             // one barrier orders the enqueues before the sweep and tells whether any queue was full
             const bool full = wg_or(pending != 0, or_flags, or_phase);
+            if (C8 && full && ++n_full * 8 > batches_done && period > 1) { period--; n_full = 0; }
             if ((C6 || K2) && full && ++n_full * 8 > batches_done) period = 1;    // workgroup-uniform: rings overflow in more than 1/8 of the batches (32 pairs
                                                                           // of headroom are too few for this selectivity / skew): sweep every batch
             if (!(full || flush_now)) break;
@@ -634,9 +654,12 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
                         const uint4 v1 = *reinterpret_cast<const uint4 *>(&qv[b * kQ6 + iv1]);
                         const uint4 k0 = *reinterpret_cast<const uint4 *>(&qk[b * kQ6 + ik]);
                         if (lc < cap_units) {
-                            unsigned char *dst = slab6 + (size_t)b * nwg * ((size_t)cap * 8) + (size_t)lc * kUnitBytes;
+                            unsigned char *dst = slab6 + (size_t)b * ((size_t)nwg * ((size_t)cap * 8) + HARK_ABL_BSKEW) + (size_t)lc * kUnitBytes;
                             __builtin_nontemporal_store(u4v{v0.x, v0.y, v0.z, v0.w}, reinterpret_cast<u4v *>(dst + 16 * i));
                             __builtin_nontemporal_store(u4v{v1.x, v1.y, v1.z, v1.w}, reinterpret_cast<u4v *>(dst + 128 + 16 * i));
+#ifdef HARK_ABL_KEYS96   // ablation build only (tools/ab_build.sh; WRONG results): what 12-bit keys (96 B of the key line) could save at most
+                            if (i < 6)
+#endif
                             __builtin_nontemporal_store(u4v{k0.x, k0.y, k0.z, k0.w}, reinterpret_cast<u4v *>(dst + 256 + 16 * i));
                         } else if (strict) {
                             overflow = true;
@@ -652,6 +675,41 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
                         }
                     }
                 }
+            } else if (C8) {
+                // ---- flush (8-byte ring entries -> the same 384-byte unit): lane i of 8 takes entries 4i..4i+3 and 32+4i..35+4i
+                // (four ds_read_b128), stores their values as the 16-byte pieces i of the unit's two value lines and their
+                // keys as the 8-byte pieces i and 8 + i of the key line
+                typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+                typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+                for (int b = tid >> 3; b < P; b += kPartThreads / 8) {
+                    const uint32_t w = s_w[b];
+                    int cnt = (int)(w & 0xFFFFu), head = (int)(w >> 16), lc = s_lcur[b];        // head and kQ8e are multiples of 16
+                    if (cnt < kU) continue;
+                    const int i = tid & 7;
+                    // a ring holds up to two complete units (144 entries): both leave now, so that fewer than a unit stays behind
+                    // (the final partial flush relies on it)
+                    for (; cnt >= kU; cnt -= kU, head = wrap8(head + kU), lc = min(lc + 1, cap_units)) {
+                        const uint2 *r0 = &q8e[b * kQ8e + wrap8(head + 4 * i)], *r1 = &q8e[b * kQ8e + wrap8(head + 32 + 4 * i)];
+                        const uint4 a0 = *reinterpret_cast<const uint4 *>(r0), a1 = *reinterpret_cast<const uint4 *>(r0 + 2);
+                        const uint4 c0 = *reinterpret_cast<const uint4 *>(r1), c1 = *reinterpret_cast<const uint4 *>(r1 + 2);
+                        const uint32_t ka = a0.y | (a0.w << 16), kb2 = a1.y | (a1.w << 16), kc = c0.y | (c0.w << 16), kd = c1.y | (c1.w << 16);
+                        if (lc < cap_units) {
+                            unsigned char *dst = slab6 + (size_t)b * ((size_t)nwg * ((size_t)cap * 8) + HARK_ABL_BSKEW) + (size_t)lc * kUnitBytes;
+                            __builtin_nontemporal_store(u4v{a0.x, a0.z, a1.x, a1.z}, reinterpret_cast<u4v *>(dst + 16 * i));
+                            __builtin_nontemporal_store(u4v{c0.x, c0.z, c1.x, c1.z}, reinterpret_cast<u4v *>(dst + 128 + 16 * i));
+                            __builtin_nontemporal_store(u2v{ka, kb2}, reinterpret_cast<u2v *>(dst + 256 + 8 * i));
+                            __builtin_nontemporal_store(u2v{kc, kd}, reinterpret_cast<u2v *>(dst + 320 + 8 * i));
+                        } else if (strict) {
+                            overflow = true;
+                        } else {                                           // slab full: direct atomics
+                            const uint32_t kb = (uint32_t)b << shift;
+                            direct(kb | a0.y, a0.x); direct(kb | a0.w, a0.z); direct(kb | a1.y, a1.x); direct(kb | a1.w, a1.z);
+                            direct(kb | c0.y, c0.x); direct(kb | c0.w, c0.z); direct(kb | c1.y, c1.x); direct(kb | c1.w, c1.z);
+                        }
+                    }
+                    // (the 8 lanes of a bucket run in lockstep inside one wave: lane 0's update follows every lane's ring reads)
+                    if (i == 0) { s_w[b] = ((uint32_t)head << 16) | (uint32_t)cnt; s_lcur[b] = lc; }
+                }
             } else if (K2) {
                 // ---- flush (keys only): 8 lanes per bucket store its complete unit of 64 keys, one 128-byte line
                 typedef unsigned int u4v __attribute__((ext_vector_type(4)));
@@ -663,7 +721,7 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
                         const int ik = (head + 8 * i) & (kQ2 - 1);
                         const uint4 k0 = *reinterpret_cast<const uint4 *>(&qk2[b * kQ2 + ik]);
                         if (lc < cap_units) {
-                            unsigned char *dst = slab6 + (size_t)b * nwg * ((size_t)cap * 8) + (size_t)lc * kUnit2Bytes;
+                            unsigned char *dst = slab6 + (size_t)b * ((size_t)nwg * ((size_t)cap * 8) + HARK_ABL_BSKEW) + (size_t)lc * kUnit2Bytes;
                             __builtin_nontemporal_store(u4v{k0.x, k0.y, k0.z, k0.w}, reinterpret_cast<u4v *>(dst + 16 * i));
                         } else {                                           // slab full: direct atomics
                             const uint32_t kb = (uint32_t)b << shift;
@@ -747,7 +805,7 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
         const uint32_t w = s_w[b];
         const int l = (int)(w & 0xFFFFu), head = (int)(w >> 16);
         if (C6) {                                                       // l < kU: the last sweep took every complete unit
-            unsigned char *dst = slab6 + (size_t)b * nwg * ((size_t)cap * 8) + (size_t)s_lcur[b] * kUnitBytes;
+            unsigned char *dst = slab6 + (size_t)b * ((size_t)nwg * ((size_t)cap * 8) + HARK_ABL_BSKEW) + (size_t)s_lcur[b] * kUnitBytes;
             for (int j = 0; j < l; j++) {
                 const int at = b * kQ6 + wrap6(head + j);
                 reinterpret_cast<uint32_t *>(dst)[j] = qv[at]; reinterpret_cast<uint16_t *>(dst + 4 * kU)[j] = qk[at];
@@ -755,8 +813,17 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
             counts[(size_t)b * nwg + wg] = (uint32_t)(s_lcur[b] * kU + l);
             continue;
         }
+        if (C8) {                                                       // l < kU (see above)
+            unsigned char *dst = slab6 + (size_t)b * ((size_t)nwg * ((size_t)cap * 8) + HARK_ABL_BSKEW) + (size_t)s_lcur[b] * kUnitBytes;
+            for (int j = 0; j < l; j++) {
+                const uint2 e = q8e[b * kQ8e + wrap8(head + j)];
+                reinterpret_cast<uint32_t *>(dst)[j] = e.x; reinterpret_cast<uint16_t *>(dst + 4 * kU)[j] = (uint16_t)e.y;
+            }
+            counts[(size_t)b * nwg + wg] = (uint32_t)(s_lcur[b] * kU + l);
+            continue;
+        }
         if (K2) {
-            unsigned char *dst = slab6 + (size_t)b * nwg * ((size_t)cap * 8) + (size_t)s_lcur[b] * kUnit2Bytes;
+            unsigned char *dst = slab6 + (size_t)b * ((size_t)nwg * ((size_t)cap * 8) + HARK_ABL_BSKEW) + (size_t)s_lcur[b] * kUnit2Bytes;
             for (int j = 0; j < l; j++) reinterpret_cast<uint16_t *>(dst)[j] = qk2[b * kQ2 + ((head + j) & (kQ2 - 1))];
             counts[(size_t)b * nwg + wg] = (uint32_t)(s_lcur[b] * kU + l);
             continue;
@@ -830,10 +897,13 @@ __global__ __launch_bounds__(1024) void fgb_agg_kernel(
 
 // Consumer of the compact format: units of 64 pairs (256 B of values, 128 B of 16-bit local keys).
 // A 16-lane group takes a unit: 16 bytes of values + 8 bytes of keys per lane, two units in flight.
+// split = 1: workgroup b owns bucket b and its key range (plain read-modify-write of the global table); split = 2 (at most
+// 128 buckets): workgroups 2b and 2b + 1 share bucket b -- even / odd slabs -- so that all 256 CUs work, and merge with
+// contiguous global atomics.
 template <int VOP>
 __global__ __launch_bounds__(1024) void fgb_agg6_kernel(
     const unsigned char *__restrict__ pbuf, const uint32_t *__restrict__ counts, uint32_t cap, int nwg, int shift,
-    int64_t G, u64 *__restrict__ gsum, unsigned long long *__restrict__ gcnt)
+    int64_t G, u64 *__restrict__ gsum, unsigned long long *__restrict__ gcnt, int split)
 {
     typedef unsigned int u4v __attribute__((ext_vector_type(4)));
     typedef unsigned int u2v __attribute__((ext_vector_type(2)));
@@ -841,7 +911,7 @@ __global__ __launch_bounds__(1024) void fgb_agg6_kernel(
     const int KPB = 1 << shift;
     u64 *s_sum = reinterpret_cast<u64 *>(lds_raw);
     uint32_t *s_cnt = reinterpret_cast<uint32_t *>(lds_raw + sizeof(u64) * KPB);
-    const int b = blockIdx.x;
+    const int b = split > 1 ? (int)blockIdx.x / split : (int)blockIdx.x, half = split > 1 ? (int)blockIdx.x % split : 0;
     for (int i = threadIdx.x; i < KPB; i += blockDim.x) { s_sum[i] = vop_identity(VOP); s_cnt[i] = 0u; }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
@@ -854,9 +924,9 @@ __global__ __launch_bounds__(1024) void fgb_agg6_kernel(
         add(kk.x & 0xFFFFu, v.x); add(kk.x >> 16, v.y); add(kk.y & 0xFFFFu, v.z); add(kk.y >> 16, v.w);
     };
     const int piece = lane & 15, sub = lane >> 4;
-    for (int w = wave; w < nwg; w += nwaves) {
+    for (int w = wave * split + half; w < nwg; w += nwaves * split) {
         const uint32_t count = min(counts[(size_t)b * nwg + w], max_pairs);
-        const unsigned char *src = pbuf + ((size_t)b * nwg + w) * ((size_t)cap * 8);
+        const unsigned char *src = pbuf + (size_t)b * ((size_t)nwg * ((size_t)cap * 8) + HARK_ABL_BSKEW) + (size_t)w * ((size_t)cap * 8);
         const uint32_t units = count / kU, rem = count % kU;
         uint32_t u = sub;
         for (; u + 4 < units; u += 8) {
@@ -882,9 +952,14 @@ __global__ __launch_bounds__(1024) void fgb_agg6_kernel(
     const int64_t kbase = (int64_t)b << shift;
     for (int i = threadIdx.x; i < KPB; i += blockDim.x) {
         const uint32_t c = s_cnt[i];
-        if (c && kbase + i < G) {                           // this workgroup owns [kbase, kbase+KPB)
-            gsum[kbase + i] = vop_merge(VOP, gsum[kbase + i], s_sum[i]);
-            gcnt[kbase + i] += (unsigned long long)c;
+        if (c && kbase + i < G) {
+            if (split > 1) {                                // two workgroups share [kbase, kbase+KPB)
+                vop_atomic_partial<VOP>(&gsum[kbase + i], s_sum[i]);
+                atomicAdd(&gcnt[kbase + i], (unsigned long long)c);
+            } else {                                        // this workgroup owns [kbase, kbase+KPB)
+                gsum[kbase + i] = vop_merge(VOP, gsum[kbase + i], s_sum[i]);
+                gcnt[kbase + i] += (unsigned long long)c;
+            }
         }
     }
 }
@@ -913,7 +988,7 @@ __global__ __launch_bounds__(1024) void fgb_agg2_kernel(
     const int piece = lane & 7, sub = lane >> 3;
     for (int w = wave; w < nwg; w += nwaves) {
         const uint32_t count = min(counts[(size_t)b * nwg + w], max_keys);
-        const unsigned char *src = pbuf + ((size_t)b * nwg + w) * ((size_t)cap * 8);
+        const unsigned char *src = pbuf + (size_t)b * ((size_t)nwg * ((size_t)cap * 8) + HARK_ABL_BSKEW) + (size_t)w * ((size_t)cap * 8);
         const uint32_t units = count / kU, rem = count % kU;
         uint32_t u = sub;
         for (; u + 8 < units; u += 16) {
@@ -967,7 +1042,7 @@ __global__ __launch_bounds__(1024) void fgb_agg6_stats_kernel(
     const int piece = lane & 15, sub = lane >> 4;
     for (int w = wave; w < nwg; w += nwaves) {
         const uint32_t count = min(counts[(size_t)b * nwg + w], max_pairs);
-        const unsigned char *src = pbuf + ((size_t)b * nwg + w) * ((size_t)cap * 8);
+        const unsigned char *src = pbuf + (size_t)b * ((size_t)nwg * ((size_t)cap * 8) + HARK_ABL_BSKEW) + (size_t)w * ((size_t)cap * 8);
         const uint32_t units = count / kU, rem = count % kU;
         for (uint32_t u = sub; u < units; u += 4) {
             const unsigned char *a = src + (size_t)u * kUnitBytes;
@@ -1570,7 +1645,7 @@ int hark_fgb_plan_set(hark_fgb_plan *pl, const char *key, int64_t value)
     else if (!strcmp(key, "timing")) { pl->timing = value; return HARK_OK; }
     else if (!strcmp(key, "vop")) { if (value < 0 || value > 5) return HARK_EARG; pl->vop = value; return HARK_OK; }   // reset afterwards
     else if (!strcmp(key, "xform")) { if (value < 0 || value > 2) return HARK_EARG; pl->xform = value; return HARK_OK; }
-    else if (!strcmp(key, "pairfmt")) { if (value < 0 || value > 2) return HARK_EARG; pl->pairfmt = value; return HARK_OK; }   // 0 auto, 1: 8-byte pairs, 2: compact 6-byte units
+    else if (!strcmp(key, "pairfmt")) { if (value < 0 || value > 3) return HARK_EARG; pl->pairfmt = value; }   // 0 auto, 1: 8-byte pairs, 2: compact 6-byte units, 3: 6-byte units from 8-byte ring entries (<= 128 buckets)
     else if (!strcmp(key, "ablate")) { pl->ablate = value; return HARK_OK; }   // timing experiments only: wrong results
     else return HARK_EARG;
     plan_drop_partition(pl);     // partition geometry depends on the knobs
@@ -1627,7 +1702,25 @@ static int plan_prepare_partition(hark_context *ctx, hark_fgb_plan *pl)
     cap = (cap + kLine - 1) / kLine * kLine + 2 * kLine;      // whole 128-byte lines; one spare for the final flush
     if (cap > 0x7FFFFFF0ll) return hark_fail(ctx, HARK_EARG, "fgb: chunk too large");
     pl->cap = cap;
-    HARK_TRY(hark_alloc(ctx, (void **)&pl->pbuf, (size_t)pl->P * (size_t)pl->nwg * (size_t)cap * sizeof(uint2)));
+    // the second geometry (f32-sum / value-operator passes with a value column, k_fgb_dense_f32): at most 128 buckets whose
+    // producer rings hold one 8-byte LDS word per pair (FMT 3) -- when 128 buckets of <= 8192 keys cover G
+    size_t bytes = (size_t)pl->P * (size_t)pl->nwg * (size_t)cap * sizeof(uint2);
+    pl->shift8 = pl->P8 = pl->cap8 = 0;
+    if (pl->pairfmt == 3) {
+        int s8 = shift;
+        while ((((pl->G - 1) >> s8) + 1) > kMaxBuckets8e) s8++;
+        if (((int64_t)12 << s8) <= kAggTableBudget) {
+            const int64_t P8 = ((pl->G - 1) >> s8) + 1;
+            int64_t cap8 = chunk / (P8 * pl->nwg) * slack / 100 + 256;
+            cap8 = (cap8 + kLine - 1) / kLine * kLine + 2 * kLine;
+            if (cap8 <= 0x7FFFFFF0ll) {
+                pl->shift8 = s8; pl->P8 = P8; pl->cap8 = cap8;
+                const size_t b8 = (size_t)P8 * (size_t)pl->nwg * (size_t)cap8 * sizeof(uint2);
+                if (b8 > bytes) bytes = b8;
+            }
+        }
+    }
+    HARK_TRY(hark_alloc(ctx, (void **)&pl->pbuf, bytes + (size_t)pl->P * HARK_ABL_BSKEW));
     HARK_TRY(hark_alloc(ctx, (void **)&pl->counts, (size_t)pl->P * (size_t)pl->nwg * sizeof(uint32_t)));
     return HARK_OK;
 }
@@ -1691,7 +1784,12 @@ int k_fgb_dense_f32(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cm
     }
     // algo 3: partition + per-bucket LDS aggregation, chunked
     HARK_TRY(plan_prepare_partition(ctx, pl));
-    const int P = (int)pl->P, shift = (int)pl->shift, nwg = (int)pl->nwg;
+    // geometry: pairfmt = 3 asks for one-word ring entries in <= 128 buckets (G <= 2^20); measured over six slab
+    // allocations each, it is no faster than the split rings in 256 buckets (2.57-2.69 against 2.46-2.63 ms per 1e9 rows,
+    // profiles/r03_notes.md), so it is not the default.  COUNT-only keeps its keys-only format
+    const bool use8 = v != nullptr && pl->P8 > 0 && pl->pairfmt == 3;
+    const int P = (int)(use8 ? pl->P8 : pl->P), shift = (int)(use8 ? pl->shift8 : pl->shift), nwg = (int)pl->nwg;
+    const uint32_t cap = (uint32_t)(use8 ? pl->cap8 : pl->cap);
     const size_t lds_agg = (size_t)12 << shift;
     return dispatch_op(cmp, p != nullptr, [&](auto op) -> int {
         constexpr int OP = decltype(op)::value;
@@ -1703,11 +1801,13 @@ int k_fgb_dense_f32(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cm
             });
             if (rc) return rc;
         }
-        const int fmt = !v ? 2 : pl->pairfmt != 1 ? 1 : 0;           // keys only (COUNT) / compact 6-byte pairs / 8-byte pairs on request
-        const bool c6 = fmt == 1;
+        const int fmt = !v ? 2 : use8 ? 3 : pl->pairfmt != 1 ? 1 : 0;   // keys only (COUNT) / 6-byte units from one-word ring entries / from split rings / 8-byte pairs on request
+        const bool c6 = fmt == 1 || fmt == 3;                        // what the consumer reads
+        const int split = (P <= kMaxBuckets / 2 && getenv("HARK_FGB_NOSPLIT") == nullptr) ? 2 : 1;
         const size_t lds_part = part_lds_bytes(P, fmt);
         const bool fast = !v || (vop == VOP_F32SUM && pl->xform == 0);   // the headline operator (and COUNT) is compiled in
         const void *fn = fmt == 2 ? reinterpret_cast<const void *>(&fgb_part_kernel<OP, 0, 2>)
+                       : fmt == 3 ? (fast ? reinterpret_cast<const void *>(&fgb_part_kernel<OP, 0, 3>) : reinterpret_cast<const void *>(&fgb_part_kernel<OP, 1, 3>))
                        : fast ? (c6 ? reinterpret_cast<const void *>(&fgb_part_kernel<OP, 0, 1>) : reinterpret_cast<const void *>(&fgb_part_kernel<OP, 0, 0>))
                               : (c6 ? reinterpret_cast<const void *>(&fgb_part_kernel<OP, 1, 1>) : reinterpret_cast<const void *>(&fgb_part_kernel<OP, 1, 0>));
         HIP_TRY(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part));
@@ -1726,8 +1826,9 @@ int k_fgb_dense_f32(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cm
                 TimedLaunch tl(pl, st, 1);
                 const int period = (int)((pl->ablate >> 12) & 15);            // experiments: batches between sweeps (0 = default)
 #define HARK_LAUNCH_PART(MODE, FMTV) fgb_part_kernel<OP, MODE, FMTV><<<dim3((unsigned)nwg), dim3(kPartThreads), lds_part, st>>>( \
-                    p, k, v, r0, r1, thr, G, shift, P, pl->pbuf, pl->counts, (uint32_t)pl->cap, gsum, gcnt, pl->err, period, vop, (int)pl->xform, 0, 0)
+                    p, k, v, r0, r1, thr, G, shift, P, pl->pbuf, pl->counts, cap, gsum, gcnt, pl->err, period, vop, (int)pl->xform, 0, 0)
                 if (fmt == 2) HARK_LAUNCH_PART(0, 2);
+                else if (fmt == 3) { if (fast) HARK_LAUNCH_PART(0, 3); else HARK_LAUNCH_PART(1, 3); }
                 else if (fast) { if (c6) HARK_LAUNCH_PART(0, 1); else HARK_LAUNCH_PART(0, 0); }
                 else { if (c6) HARK_LAUNCH_PART(1, 1); else HARK_LAUNCH_PART(1, 0); }
 #undef HARK_LAUNCH_PART
@@ -1737,15 +1838,15 @@ int k_fgb_dense_f32(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cm
                 TimedLaunch tl(pl, st, 2);
                 int rc = fmt == 2 ? [&]() -> int {
                     fgb_agg2_kernel<<<dim3((unsigned)P), dim3(1024), (size_t)4 << shift, st>>>(
-                        reinterpret_cast<const unsigned char *>(pl->pbuf), pl->counts, (uint32_t)pl->cap, nwg, shift, G, gcnt);
+                        reinterpret_cast<const unsigned char *>(pl->pbuf), pl->counts, cap, nwg, shift, G, gcnt);
                     return HARK_OK;
                 }() : dispatch_vop(vop, [&](auto vopc) -> int {
                     if (c6)
-                        fgb_agg6_kernel<decltype(vopc)::value><<<dim3((unsigned)P), dim3(1024), lds_agg, st>>>(
-                            reinterpret_cast<const unsigned char *>(pl->pbuf), pl->counts, (uint32_t)pl->cap, nwg, shift, G, gsum, gcnt);
+                        fgb_agg6_kernel<decltype(vopc)::value><<<dim3((unsigned)(P * split)), dim3(1024), lds_agg, st>>>(
+                            reinterpret_cast<const unsigned char *>(pl->pbuf), pl->counts, cap, nwg, shift, G, gsum, gcnt, split);
                     else
                         fgb_agg_kernel<decltype(vopc)::value><<<dim3((unsigned)P), dim3(1024), lds_agg, st>>>(
-                            pl->pbuf, pl->counts, (uint32_t)pl->cap, nwg, shift, G, gsum, gcnt, (int)pl->ablate);
+                            pl->pbuf, pl->counts, cap, nwg, shift, G, gsum, gcnt, (int)pl->ablate);
                     return HARK_OK;
                 });
                 if (rc) return rc;

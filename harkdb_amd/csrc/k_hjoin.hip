@@ -481,7 +481,9 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
     {   // a group that cannot be staged: heavy skew
         bool big = false;
         for (uint32_t i = tid; i < ngroups; i += kJThreads) big = big || coarse[i] > (uint32_t)stage_cap;
-        if (big) s_bad = 1;
+        // a bucket of more than kCoarse * kFine sorted build entries (jsplit never splits a run of equal keys, so one build
+        // key repeated ~1.7e7 times gives one): a single group of 2^gs ranks would not fit the fine counters
+        if (big || (1u << gs) > (uint32_t)kFine) s_bad = 1;
     }
     __syncthreads();
     if (s_bad) {
@@ -659,8 +661,13 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
         hark_free(ctx, splitters); hark_free(ctx, bstart); hark_free(ctx, counts); hark_free(ctx, scount); hark_free(ctx, sround);
         hark_free(ctx, info); hark_free(ctx, slabs); hark_free(ctx, surv);
     };
+    if (rc == HARK_ENOMEM) {                                                     // no room for the partition workspace: the sort-merge path
+        cleanup();                                                               // needs far less (used stays false)
+        ctx->err.clear();
+        return HARK_OK;
+    }
     if (rc) { cleanup(); return rc; }
-    hipMemsetAsync(info, 0, 32, st);
+    if (hipMemsetAsync(info, 0, 32, st) != hipSuccess) { cleanup(); return hark_fail(ctx, HARK_EHIP, "join: workspace memset failed"); }
     int32_t *err = reinterpret_cast<int32_t *>(info + 1);
     unsigned long long *total = reinterpret_cast<unsigned long long *>(info);
     jsplit_kernel<K><<<(P + 256) / 256, 256, 0, st>>>(rkeys, s, P, splitters, bstart);
@@ -680,8 +687,8 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
         jpart_kernel<K><<<dim3((unsigned)nwg), dim3(kJThreads), lds_part, st>>>(lcol, n, bias, splitters, rkeys, s, slabs, counts, cap, period, err);
         jbucket_kernel<K><<<dim3((unsigned)P), dim3(kJThreads), lds_bucket, st>>>(slabs, counts, cap, nwg, rkeys, bstart, chunk_cap, surv, scount, sround);
         jsum_kernel<<<1, 1024, 0, st>>>(scount, P, total);
-        hipMemcpyAsync(info + 2, flags, 8, hipMemcpyDeviceToDevice, st);       // the duplicate-keys flag rides along with the same host read
         he = hipGetLastError();
+        if (he == hipSuccess) he = hipMemcpyAsync(info + 2, flags, 8, hipMemcpyDeviceToDevice, st);   // the duplicate-keys flag rides along with the same host read
     }
     if (he != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: partition launch failed: %s", hipGetErrorString(he));
     int64_t words[3] = {0, 0, 0}, M = 0;

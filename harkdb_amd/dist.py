@@ -97,10 +97,25 @@ def _allreduce_sum(t, group, how, async_op):
     import torch.distributed as dist
     world = dist.get_world_size(group)
     if how == "rs_ag" and world > 1 and t.numel() % world == 0:
+        # both halves are issued asynchronously: a process group runs its collectives in issue order on its own stream,
+        # so the all-gather starts when the reduce-scatter has filled `part`, and the caller's stream waits for neither
         part = torch.empty(t.numel() // world, dtype=t.dtype, device=t.device)
-        dist.reduce_scatter_tensor(part, t, op=dist.ReduceOp.SUM, group=group)
-        return dist.all_gather_into_tensor(t, part, group=group, async_op=async_op)
+        w1 = dist.reduce_scatter_tensor(part, t, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+        w2 = dist.all_gather_into_tensor(t, part, group=group, async_op=async_op)
+        return _ChainedWork([w1, w2], keep=part) if async_op else None
     return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+
+
+class _ChainedWork:
+    """Several pending collectives that finish in order, awaited as one (and the scratch tensor they share)."""
+
+    def __init__(self, works, keep=None):
+        self.works, self.keep = [w for w in works if w is not None], keep
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        return True
 
 
 def allreduce_partials(sum_t, cnt_t, group=None, wait=True):
@@ -188,12 +203,17 @@ class ShardedFgb:
     def pipelined(self):
         return len(self.plans) > 1
 
-    def step(self, p, cmp, thr, k, v, n, sum_out=None, count_out=None):
+    def step(self, p, cmp, thr, k, v, n, sum_out=None, count_out=None, check=None):
+        """One query over this rank's shard.  Serial mode (one plan): the outputs are written when step() returns, and
+        with check=True (the default there) the device error word -- a surviving row whose key lies outside [0, G) -- is
+        read and raised right away.  A caller that loops (bench.py) passes check=False to keep the host out of the loop
+        and MUST call flush() before trusting the outputs.  Pipelined mode (two plans): sum_out / count_out of step i are
+        only written when step i + 1 is issued or by flush(), and errors are only raised by flush()."""
         if not self.pipelined:
             self.plan.reset()
             self.plan.run(p, cmp, thr, k, v, n)
             allreduce_partials(self.sum_t, self.cnt_t)
-            self.plan.finish(sum_out, count_out, check=False)         # no host round trip between steps: flush() checks
+            self.plan.finish(sum_out, count_out, check=True if check is None else bool(check))
             return
         i = self.turn
         self.turn = 1 - i
@@ -223,20 +243,25 @@ class ShardedFgb:
 # ---------------------------------------------------------------------------
 # Sharded SQL surface: FutharkContext over row-range shards
 # ---------------------------------------------------------------------------
-def gather_columns(cols, group=None, device=None):
+def gather_columns(cols, group=None, device=None, np_dtypes=None):
     """Concatenate per-rank result columns in rank order on every rank (row order = the unsharded table's order).
 
     One all-gather of the row counts, then ONE `all_gather_into_tensor` of a byte buffer that holds every column padded
     to the longest shard -- device tensors travel over RCCL as they are (no pickling, no host copy before the
     collective); `cols` may be numpy arrays (uploaded to `device` first when it is a GPU) or 1-D torch tensors.
-    HARK_GATHER=object selects the old `all_gather_object` path (A/B on hardware).  Returns numpy arrays."""
+    HARK_GATHER=object selects the old `all_gather_object` path (A/B on hardware).  Returns numpy arrays.
+    `np_dtypes` (one per column) names the dtypes of the returned arrays; without it they are derived from the local
+    tensors, which cannot tell uint32 from int32 (torch carries u32 bit patterns in int32 tensors) -- a rank with an
+    empty shard would otherwise answer with another dtype than its peers."""
     import torch
     import torch.distributed as dist
+    def retype(arrs):
+        return arrs if np_dtypes is None else [a.view(np.dtype(d)) if a.dtype != np.dtype(d) else a for a, d in zip(arrs, np_dtypes)]
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return [c.cpu().numpy() if isinstance(c, torch.Tensor) else c for c in cols]
+        return retype([c.cpu().numpy() if isinstance(c, torch.Tensor) else c for c in cols])
     world = dist.get_world_size(group)
     if os.environ.get("HARK_GATHER", "tensor") == "object":
-        host = [c.cpu().numpy() if isinstance(c, torch.Tensor) else c for c in cols]
+        host = retype([c.cpu().numpy() if isinstance(c, torch.Tensor) else c for c in cols])
         parts = [None] * world
         dist.all_gather_object(parts, host, group=group)
         return [np.concatenate([p[j] for p in parts]) for j in range(len(host))]
@@ -244,7 +269,7 @@ def gather_columns(cols, group=None, device=None):
     if not staged and device is None:
         device = torch.device("cuda", torch.cuda.current_device())        # RCCL moves device memory only
     dev = torch.device("cpu") if staged else torch.device(device)
-    np_dtypes, tens = [], []
+    given, np_dtypes, tens = np_dtypes, [], []
     for c in cols:
         if isinstance(c, torch.Tensor):
             np_dtypes.append(np.dtype(str(c.dtype).replace("torch.", "")))
@@ -253,6 +278,8 @@ def gather_columns(cols, group=None, device=None):
             a = np.ascontiguousarray(c)
             np_dtypes.append(a.dtype)
             tens.append(torch.from_numpy(a.view(np.int32) if a.dtype == np.uint32 else a).to(dev))
+    if given is not None:
+        np_dtypes = [np.dtype(d) for d in given]
     n_local = int(tens[0].numel()) if tens else 0
     mine = torch.tensor([n_local], dtype=torch.int64, device=dev)
     allc = torch.empty(world, dtype=torch.int64, device=dev)
@@ -449,8 +476,8 @@ class ShardedFutharkContext:
             limit = ir.pop("limit", None)
             stmt = sql_statement if limit is None else sql_statement[: sql_statement.lower().rindex("limit")]
             names, res = self.local.select_result(stmt)                 # device-resident: gathered over RCCL as it is
-            tens, _ = result_tensors(res, self.device, limit)           # no rank contributes more than LIMIT rows
-            cols = gather_columns(tens, device=self.device)
+            tens, dts = result_tensors(res, self.device, limit)         # no rank contributes more than LIMIT rows
+            cols = gather_columns(tens, device=self.device, np_dtypes=dts)
             return names, ([c[:limit] for c in cols] if limit is not None else cols)
         return self._groupby(ir)
 
@@ -574,8 +601,8 @@ class ShardedFutharkContext:
         recv, nrecv = repartition_device(eng, ptrs, dts, n, 0, self.device, self.world, splitters=splitters, descending=desc)
         t = eng.table_from_device(nrecv, [c.data_ptr() for c in recv], dts, keepalive=(recv, cur))
         res = eng.sort(t, 0, [need.index(c) for c in ir["select"]], descending=desc)
-        tens, _ = result_tensors(res, self.device, ir.get("limit"))
-        cols = gather_columns(tens, device=self.device)
+        tens, dts = result_tensors(res, self.device, ir.get("limit"))
+        cols = gather_columns(tens, device=self.device, np_dtypes=dts)
         if "limit" in ir:
             cols = [c[: ir["limit"]] for c in cols]
         return [schema[c] for c in ir["select"]], cols
@@ -595,7 +622,8 @@ class ShardedFutharkContext:
         recv, nrecv = repartition_device(eng, [res.device_ptr(j) for j in range(m)], dts, n, 0, self.device, self.world)
         t = eng.table_from_device(nrecv, [c.data_ptr() for c in recv], dts, keepalive=recv)
         res2 = eng.filter_groupby(t, None, 0, [(_SECOND_LEVEL[f], 1 + j) for j, (f, _) in enumerate(specs)])
-        return gather_columns(result_tensors(res2, self.device)[0], device=self.device)
+        tens, dts = result_tensors(res2, self.device)
+        return gather_columns(tens, device=self.device, np_dtypes=dts)
 
     def _join(self, ir):
         """Both sides are hash-partitioned by the join key and exchanged; every rank
@@ -615,7 +643,8 @@ class ShardedFutharkContext:
             sides.append((t, {c: i for i, c in enumerate(need)}))
         (t1, m1), (t2, m2) = sides
         res = eng.join(t1, t2, 0, 0, [m1[c] for c in ir["cols1"]], [m2[c] for c in ir["cols2"]])
-        cols = gather_columns(result_tensors(res, self.device)[0], device=self.device)
+        tens, dts = result_tensors(res, self.device)
+        cols = gather_columns(tens, device=self.device, np_dtypes=dts)
         left_pos = {c: i for i, c in reversed(list(enumerate(ir["cols1"])))}
         right_pos = {c: len(ir["cols1"]) + i for i, c in reversed(list(enumerate(ir["cols2"])))}
         out = [cols[left_pos[c] if s == 0 else right_pos[c]] for s, c in ir["order"]]

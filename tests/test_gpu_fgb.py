@@ -46,6 +46,19 @@ def test_exact_values_bit_exact(eng, oracle, G, algo, n):
     assert np.array_equal(gs, s32)
 
 
+@pytest.mark.parametrize("knobs", [dict(shift=13, pairfmt=2), dict(pairfmt=2), dict(pairfmt=3), dict(pairfmt=3, chunk_rows=1 << 18), dict()])
+@pytest.mark.parametrize("n,thr", [(4099, 0.5), (3_000_017, 0.5), (2_000_003, 0.05)])
+def test_half_as_many_buckets_and_one_word_ring_entries(eng, oracle, knobs, n, thr):
+    """The geometries of the partition path: ring entries of one 8-byte LDS word in 128 buckets of 8192 keys with TWO
+    consumer workgroups per bucket merging through global atomics (the default since round 3 = pairfmt 3; 95 % of the rows
+    surviving fills the rings between sweeps, which shortens the sweep period), and the 256-bucket split rings of rounds
+    1-2 (pairfmt = 2), also with 128 buckets (shift = 13).  Same bits as the oracle."""
+    G = 1 << 20
+    gs, gc = _run(eng, n, G, True, thr=thr, algo=3, **knobs)
+    s32, _, cnt = _oracle(oracle, n, G, True, thr=thr)
+    assert np.array_equal(gc, cnt) and np.array_equal(gs, s32)
+
+
 @pytest.mark.parametrize("G,algo", [(16, 1), (4096, 1), (1 << 20, 3)])
 def test_uniform_values_tolerance(eng, oracle, G, algo):
     """Uniform [0,1) values.  Tolerance stated by BASELINE.json: 1e-5 relative.

@@ -114,6 +114,26 @@ def test_keys_outside_the_build_range_and_exact_batch_multiples(eng):
     assert _check(eng, (lk + np.uint32(5000)), rk) == 0          # no probe key inside the range at all
 
 
+def test_one_build_key_repeated_past_the_order_kernels_counters(eng):
+    """A build key repeated more than kCoarse * kFine (2048 * 8192) times makes ONE bucket of that many sorted build
+    entries (the splitters never cut a run of equal keys): a group of ranks no longer fits the order kernel's fine
+    counters, so it must hand the bucket to the general radix path instead of counting past its LDS arrays.  Probe
+    rows hit the neighbours of the run (same bucket), never the run itself (that would be a 1.7e7-fold fan-out)."""
+    rng = np.random.default_rng(12)
+    hot, reps, others, n = np.uint32(0x40000000), (1 << 24) + 5000, 200_000, (1 << 18) + 11
+    rest = rng.integers(0, 2**32, size=others, dtype=np.uint64).astype(np.uint32)
+    rest = rest[rest != hot]
+    near = (hot + 1 + rng.integers(0, 1 << 20, size=3000).astype(np.uint32)).astype(np.uint32)    # keys right behind the run
+    rk = np.concatenate([np.full(reps, hot, dtype=np.uint32), rest, near])
+    rk = rk[rng.permutation(len(rk))]
+    lk = rng.integers(0, 2**32, size=n, dtype=np.uint64).astype(np.uint32)
+    lk[lk == hot] += np.uint32(1)
+    hit = rng.random(n) < 0.2
+    pool = np.concatenate([near, rest[:5000]])
+    lk[hit] = pool[rng.integers(0, len(pool), size=int(hit.sum()))]
+    assert _check(eng, lk, rk) > 0
+
+
 def test_skewed_probe_falls_back_and_stays_exact(eng):
     """Every probe row carries one key: its bucket's slabs overflow, the kernel reports it and the sort-merge path runs."""
     rng = np.random.default_rng(10)

@@ -19,7 +19,8 @@ late = []                      # knobs applied right before each run (same plan 
 shared = {}
 for c in configs:
     ab = c.pop("ablate", 0)
-    key = tuple(sorted(c.items()))
+    c.pop("tag", None)                    # tag=<n>: a second, separate plan of an otherwise identical configuration
+    key = tuple(sorted(c.items())) + ((("tag", len(plans)),) if "tag=" in spec.split(";")[len(plans)] else ())
     if key not in shared:
         cc = dict(c)
         g = cc.pop("G", G)
@@ -30,6 +31,19 @@ for c in configs:
         shared[key] = pl
     plans.append(shared[key]); late.append(ab)
 res = [[] for _ in plans]
+ref = None            # every configuration must produce the same table (ablate != 0 excepted: those are wrong by design)
+so, co = eng.alloc(G * 4), eng.alloc(G * 8)
+for i, pl in enumerate(plans):
+    if late[i] & 0xFFF or pl.G != G:
+        continue
+    pl.set("ablate", late[i]); pl.reset(); pl.run(p, ">", 0.5, k, v, N); pl.finish(so, co)
+    got = (eng.download(so, G, np.float32), eng.download(co, G, np.int64))
+    if ref is None:
+        ref = got
+        print("reference table: %d survivors" % int(got[1].sum()), flush=True)
+    elif not (np.array_equal(ref[0], got[0]) and np.array_equal(ref[1], got[1])):
+        print("MISMATCH: configuration %d (%s) differs from configuration 0" % (i, spec.split(";")[i]), flush=True)
+    pl.timing()
 for r in range(R + 1):
     for i, pl in enumerate(plans):
         pl.set("ablate", late[i])
