@@ -66,6 +66,7 @@ SIGNATURES = {
     "hark_entry_topk": (C.c_int, [_vp, _pp, _vp, _i64, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(C.c_void_p), _i32, _i32, _i64, C.POINTER(_i32), _i64]),
     "hark_entry_filter_groupby_topk": (C.c_int, [_vp, _pp, _vp, _i64, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(C.c_void_p), _i32, C.POINTER(_i32), C.POINTER(_i32), _i64,
                                                  _i64, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(C.c_void_p), _i32, _i32, _i64]),
+    "hark_entry_filter_groupby_slots": (C.c_int, [_vp, _pp, _vp, _i64, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(C.c_void_p), _i32, _i64, C.POINTER(_i32), C.POINTER(_i32), _i64]),
     "hark_entry_filter_groupby_subset": (C.c_int, [_vp, _pp, _vp, _i64, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(C.c_void_p), _i32, _vp, _i64, C.POINTER(_i32), C.POINTER(_i32), _i64]),
     "hark_entry_sort": (C.c_int, [_vp, _pp, _vp, _i32, _i32, C.POINTER(_i32), _i64]),
     "hark_op_segmented_scan_add_i32": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),

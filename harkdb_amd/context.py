@@ -187,7 +187,11 @@ class FutharkContext:
         res._keep = (cur,)                                             # the compacted input must outlive a borrowed view
         return res
 
-    def _groupby_extended(self, dev, schema, ir):
+    def _groupby_extended(self, dev, schema, ir, provider=None, key_ranges=None):
+        """SQL-typed GROUP BY [+ HAVING / ORDER BY / LIMIT].  `provider(cur, dev_preds, gkey, specs)` (the sharded
+        context, dist.py) replaces the local aggregation: it returns a device Result [key, aggregates...] of ALL groups
+        over all shards, ascending key; HAVING / ORDER BY / LIMIT then run here, on the device, exactly as for one GPU.
+        `key_ranges` = (mins, spans) encodes a composite key with the ranges over all shards instead of this table's."""
         eng = self.FutEnv
         if ir.get("orderby_all"):
             raise Exception("ORDER BY on several keys is not supported together with GROUP BY")
@@ -225,9 +229,9 @@ class FutharkContext:
         decode = None
         if multi:
             # several keys -> one composite key column on the device (ascending composite = lexicographic key tuple)
-            buf, cdt, mins, spans = eng.composite_key(cur, [cmap[c] for c in g_cols])
+            buf, cdt, mins, spans = eng.composite_key(cur, [cmap[c] for c in g_cols], ranges=key_ranges)
             cols_needed = sorted(need)
-            view = eng.table_from_device(cur.shape[0], [cur.device_ptr(cmap[c]) for c in cols_needed] + [buf.ptr],
+            view = eng.table_from_device(cur.shape[0], [cur.device_ptr(cmap[c]) for c in cols_needed] + [buf.ptr or 0],
                                          [cur.dtype(cmap[c]) for c in cols_needed] + [cdt], keepalive=(cur, buf))
             cmap = {c: j for j, c in enumerate(cols_needed)}
             cur, gkey = view, len(cols_needed)
@@ -264,6 +268,8 @@ class FutharkContext:
         def grouped(specs, having, order, limit=None):
             """GROUP BY + HAVING + ORDER BY (+ LIMIT).  A small LIMIT over dense keys is ONE entry (hark_entry_filter_groupby_topk:
             no group set, no second call); anything else composes filter_groupby with having_order."""
+            if provider is not None:                               # the groups of all shards, merged on the device
+                return having_order(provider(cur, dev_preds, gkey, specs), having, order, limit)
             if (order is not None and limit is not None and 0 < limit <= 32 and len(having) <= 7
                     and not os.environ.get("HARK_NO_TOPK") and not os.environ.get("HARK_NO_FUSED_TOPK")):
                 top = eng.filter_groupby_topk(cur, dev_preds, gkey, specs, having, order[0], order[1], limit)
@@ -286,7 +292,7 @@ class FutharkContext:
         second = [s for s in range(1, len(aggs) + 1) if s not in first]
         four = (np.dtype(np.float32), np.dtype(np.int32), np.dtype(np.uint32))
         if (lim is not None and 0 < lim <= 1024 and not multi and second and len(second) <= 8 and lim * len(second) <= 8192
-                and not os.environ.get("HARK_NO_LATE_AGG") and np.dtype(cur.dtype(gkey)) in four[1:]
+                and provider is None and not os.environ.get("HARK_NO_LATE_AGG") and np.dtype(cur.dtype(gkey)) in four[1:]
                 and all(aggs[s - 1][0] in ("sum", "avg", "min", "max", "count") and (aggs[s - 1][1] is None or np.dtype(cur.dtype(cmap[aggs[s - 1][1]])) in four)
                         for s in second)):
             first_specs = [aggs[s - 1] for s in first] or [("count", None)]

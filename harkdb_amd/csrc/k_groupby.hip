@@ -463,8 +463,12 @@ bool dense_plan_for(int op, int dt, int col, DensePass *out)
 // pass, a predicate on another dtype compacts the referenced columns first.
 // all_slots: the result has one row per key SLOT 0..G-1 (empty groups included: their COUNT is 0 and their other
 // aggregates are unspecified) -- no group set, no scan, no host read; hark_entry_filter_groupby_topk selects from that.
+// G_force > 0 (with all_slots): the key domain is [0, G_force) whatever THIS table's keys span -- a shard of a sharded table
+// must lay its partial aggregates out over the domain of all shards (the slots are merged elementwise across GPUs); the
+// caller has decided that the domain is dense enough.
 int try_dense(hark_context *ctx, const hark_table *db, const PredList &preds,
-              int32_t g_col, const int32_t *agg_cols, const int32_t *agg_ops, int64_t n_aggs, hark_result *res, bool *used, bool all_slots = false)
+              int32_t g_col, const int32_t *agg_cols, const int32_t *agg_ops, int64_t n_aggs, hark_result *res, bool *used, bool all_slots = false,
+              int64_t G_force = 0)
 {
     *used = false;
     const int kdt = db->cols[g_col].dtype;
@@ -476,10 +480,13 @@ int try_dense(hark_context *ctx, const hark_table *db, const PredList &preds,
     }
     // column statistic: key range (computed once per column, then cached)
     int64_t kmin = 0, kmax = 0;
-    HARK_TRY(column_range(ctx, db, g_col, kdt == HARK_I32, &kmin, &kmax));
+    if (db->n > 0) HARK_TRY(column_range(ctx, db, g_col, kdt == HARK_I32, &kmin, &kmax));
     int rc = HARK_OK;
-    if (kmin < 0 || kmax >= kDenseMaxGroups || kmax + 1 > 8 * db->n + 4096) return HARK_OK;
-    const int64_t G = kmax + 1;
+    if (G_force > 0) {
+        if (!all_slots || G_force > kDenseMaxGroups) return HARK_OK;
+        if (kmin < 0 || kmax >= G_force) return hark_fail(ctx, HARK_EBOUNDS, "filter_groupby_slots: keys span [%lld, %lld], outside [0, %lld)", (long long)kmin, (long long)kmax, (long long)G_force);
+    } else if (kmin < 0 || kmax >= kDenseMaxGroups || kmax + 1 > 8 * db->n + 4096) return HARK_OK;
+    const int64_t G = G_force > 0 ? G_force : kmax + 1;
 
     // WHERE: ONE f32 predicate rides in the kernels as it is (no extra pass over anything).  Several conjuncts, or a
     // predicate on another dtype, are evaluated once into a survivor bitmask (0.125 B/row) that every pass reads
@@ -1047,6 +1054,49 @@ extern "C" int hark_entry_filter_groupby_topk(hark_context *ctx, hark_result **o
     for (auto &c : slots->cols) if (c.owned && c.data) hark_free(ctx, c.data);
     delete slots;
     return rc;
+}
+
+
+// WHERE + GROUP BY over the dense key domain [0, G), one result row PER KEY SLOT (row g = key g): the partial aggregates
+// of one shard of a row-range-sharded table, laid out so that the shards' results merge elementwise -- SUM and COUNT by
+// addition, MIN / MAX by min / max -- with an RCCL all-reduce (harkdb_amd/dist.py, SURVEY.md 8(e) "GROUP BY, dense key
+// domain").  Result: [aggregate 0, ..., aggregate n-1, COUNT(*)] (the trailing count is always there: a slot with count 0
+// is an empty group and its other aggregates are unspecified).  HARK_EUNSUPPORTED when the shape is not the fused dense
+// one (non-32-bit key, 8-byte value columns, G > 2^21).
+extern "C" int hark_entry_filter_groupby_slots(hark_context *ctx, hark_result **out, const hark_table *db, int64_t n_preds,
+                                               const int32_t *where_cols, const int32_t *cmps, const void *const *constants,
+                                               int32_t g_col, int64_t G, const int32_t *agg_cols, const int32_t *agg_ops, int64_t n_aggs)
+{
+    hark_device_guard guard__(ctx);
+    if (!ctx || !out || !db) return HARK_EARG;
+    *out = nullptr;
+    if (n_aggs < 0 || n_aggs > 30 || (n_aggs && (!agg_cols || !agg_ops))) return hark_fail(ctx, HARK_EARG, "filter_groupby_slots: bad aggregate list");
+    if (g_col < 0 || g_col >= db->m) return hark_fail(ctx, HARK_EBOUNDS, "filter_groupby_slots: group column %d out of bounds", g_col);
+    if (G < 1) return hark_fail(ctx, HARK_EARG, "filter_groupby_slots: G must be positive");
+    if (n_preds < 0 || n_preds > 16 || (n_preds && (!where_cols || !cmps || !constants))) return hark_fail(ctx, HARK_EARG, "filter_groupby_slots: 0..16 predicates");
+    for (int64_t j = 0; j < n_preds; j++) {
+        if (where_cols[j] < 0 || where_cols[j] >= db->m) return hark_fail(ctx, HARK_EBOUNDS, "filter_groupby_slots: where column %d out of bounds", where_cols[j]);
+        if (!constants[j] || cmps[j] < HARK_CMP_GT || cmps[j] > HARK_CMP_NE) return hark_fail(ctx, HARK_EARG, "filter_groupby_slots: bad predicate");
+    }
+    for (int64_t j = 0; j < n_aggs; j++) {
+        if (agg_ops[j] < HARK_AGG_KEY || agg_ops[j] > HARK_AGG_AVG || agg_ops[j] == HARK_AGG_AVG || agg_ops[j] == HARK_AGG_PROD)
+            return hark_fail(ctx, HARK_EARG, "filter_groupby_slots: SUM / MIN / MAX / COUNT only (AVG travels as SUM and COUNT), got opcode %d", agg_ops[j]);
+        if (agg_ops[j] != HARK_AGG_COUNT && (agg_cols[j] < 0 || agg_cols[j] >= db->m))
+            return hark_fail(ctx, HARK_EBOUNDS, "filter_groupby_slots: aggregate column %d out of bounds", agg_cols[j]);
+    }
+    std::vector<int32_t> cols2(agg_cols, agg_cols + n_aggs), ops2(agg_ops, agg_ops + n_aggs);
+    cols2.push_back(0); ops2.push_back(HARK_AGG_COUNT);
+    const PredList preds{n_preds, where_cols, cmps, constants};
+    hark_result *slots = new hark_result();
+    bool done = false;
+    int rc = try_dense(ctx, db, preds, g_col, cols2.data(), ops2.data(), (int64_t)ops2.size(), slots, &done, true, G);
+    if (!rc && !done) rc = HARK_EUNSUPPORTED;
+    if (rc) { for (auto &c : slots->cols) if (c.owned && c.data) hark_free(ctx, c.data); delete slots; return rc; }
+    // drop the key column (row g IS key g)
+    if (slots->cols[0].owned && slots->cols[0].data) hark_free(ctx, slots->cols[0].data);
+    slots->cols.erase(slots->cols.begin());
+    *out = slots;
+    return HARK_OK;
 }
 
 

@@ -101,6 +101,8 @@ def _allreduce_sum(t, group, how, async_op):
         # so the all-gather starts when the reduce-scatter has filled `part`, and the caller's stream waits for neither
         part = torch.empty(t.numel() // world, dtype=t.dtype, device=t.device)
         w1 = dist.reduce_scatter_tensor(part, t, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+        if async_op and dist.get_backend(group) != "nccl":
+            w1.wait()                                                 # gloo has no stream to order the two on: host-side wait
         w2 = dist.all_gather_into_tensor(t, part, group=group, async_op=async_op)
         return _ChainedWork([w1, w2], keep=part) if async_op else None
     return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
@@ -243,18 +245,59 @@ class ShardedFgb:
 # ---------------------------------------------------------------------------
 # Sharded SQL surface: FutharkContext over row-range shards
 # ---------------------------------------------------------------------------
-def gather_columns(cols, group=None, device=None, np_dtypes=None):
-    """Concatenate per-rank result columns in rank order on every rank (row order = the unsharded table's order).
-
-    One all-gather of the row counts, then ONE `all_gather_into_tensor` of a byte buffer that holds every column padded
-    to the longest shard -- device tensors travel over RCCL as they are (no pickling, no host copy before the
-    collective); `cols` may be numpy arrays (uploaded to `device` first when it is a GPU) or 1-D torch tensors.
-    HARK_GATHER=object selects the old `all_gather_object` path (A/B on hardware).  Returns numpy arrays.
-    `np_dtypes` (one per column) names the dtypes of the returned arrays; without it they are derived from the local
-    tensors, which cannot tell uint32 from int32 (torch carries u32 bit patterns in int32 tensors) -- a rank with an
-    empty shard would otherwise answer with another dtype than its peers."""
+def gather_tensors(tens, group=None, device=None):
+    """Concatenate per-rank 1-D torch tensors (one list entry per column, equal length on a rank) in rank order on every
+    rank; returns (list of tensors on the collective's device, rows per rank).  One all-gather of the row counts, then ONE
+    `all_gather_into_tensor` of a byte buffer that holds every column padded to the longest shard -- device tensors travel
+    over RCCL as they are (no pickling, no host copy); under gloo (CPU tests, ranks sharing one GPU) they are staged
+    through the host."""
     import torch
     import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return list(tens), [int(tens[0].numel()) if tens else 0]
+    world = dist.get_world_size(group)
+    staged = dist.get_backend() == "gloo"
+    home = tens[0].device if tens else torch.device("cpu")
+    if not staged and device is None:
+        device = torch.device("cuda", torch.cuda.current_device())        # RCCL moves device memory only
+    dev = torch.device("cpu") if staged else torch.device(device)
+    tens = [t.to(dev).contiguous() for t in tens]
+    n_local = int(tens[0].numel()) if tens else 0
+    mine = torch.tensor([n_local], dtype=torch.int64, device=dev)
+    allc = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(allc, mine, group=group)
+    counts = [int(x) for x in allc.tolist()]
+    maxn = max(counts)
+    if maxn == 0 or not tens:
+        return [t[:0].to(home) for t in tens], counts
+    widths = [t.element_size() for t in tens]
+    row_bytes = sum(widths)
+    send = torch.zeros(maxn * row_bytes, dtype=torch.uint8, device=dev)   # column-major: column j occupies maxn * width_j bytes
+    off = 0
+    for t, w in zip(tens, widths):
+        if n_local:
+            send[off: off + n_local * w] = t.reshape(-1).view(torch.uint8)
+        off += maxn * w
+    recv = torch.empty(world * maxn * row_bytes, dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    out, off = [], 0
+    for t, w in zip(tens, widths):
+        pieces = [recv[r * maxn * row_bytes + off: r * maxn * row_bytes + off + counts[r] * w] for r in range(world)]
+        out.append(torch.cat(pieces).view(t.dtype).to(home))
+        off += maxn * w
+    return out, counts
+
+
+def gather_columns(cols, group=None, device=None, np_dtypes=None):
+    """Concatenate per-rank result columns in rank order on every rank (row order = the unsharded table's order) and
+    return them as numpy arrays: gather_tensors + one download.  `cols` may be numpy arrays (uploaded to `device` first
+    when it is a GPU) or 1-D torch tensors.  HARK_GATHER=object selects the old `all_gather_object` path (A/B on
+    hardware).  `np_dtypes` (one per column) names the dtypes of the returned arrays; without it they are derived from
+    the local tensors, which cannot tell uint32 from int32 (torch carries u32 bit patterns in int32 tensors) -- a rank
+    with an empty shard would otherwise answer with another dtype than its peers."""
+    import torch
+    import torch.distributed as dist
+
     def retype(arrs):
         return arrs if np_dtypes is None else [a.view(np.dtype(d)) if a.dtype != np.dtype(d) else a for a, d in zip(arrs, np_dtypes)]
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
@@ -267,44 +310,21 @@ def gather_columns(cols, group=None, device=None, np_dtypes=None):
         return [np.concatenate([p[j] for p in parts]) for j in range(len(host))]
     staged = dist.get_backend() == "gloo"                                 # CPU tests, or ranks sharing one GPU
     if not staged and device is None:
-        device = torch.device("cuda", torch.cuda.current_device())        # RCCL moves device memory only
+        device = torch.device("cuda", torch.cuda.current_device())
     dev = torch.device("cpu") if staged else torch.device(device)
-    given, np_dtypes, tens = np_dtypes, [], []
+    dts, tens = [], []
     for c in cols:
         if isinstance(c, torch.Tensor):
-            np_dtypes.append(np.dtype(str(c.dtype).replace("torch.", "")))
+            dts.append(np.dtype(str(c.dtype).replace("torch.", "")))
             tens.append(c.to(dev).contiguous())
         else:
             a = np.ascontiguousarray(c)
-            np_dtypes.append(a.dtype)
+            dts.append(a.dtype)
             tens.append(torch.from_numpy(a.view(np.int32) if a.dtype == np.uint32 else a).to(dev))
-    if given is not None:
-        np_dtypes = [np.dtype(d) for d in given]
-    n_local = int(tens[0].numel()) if tens else 0
-    mine = torch.tensor([n_local], dtype=torch.int64, device=dev)
-    allc = torch.empty(world, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(allc, mine, group=group)
-    counts = [int(x) for x in allc.tolist()]
-    maxn = max(counts)
-    if maxn == 0 or not tens:
-        return [np.empty(0, dtype=dt) for dt in np_dtypes]
-    widths = [t.element_size() for t in tens]
-    row_bytes = sum(widths)
-    send = torch.zeros(maxn * row_bytes, dtype=torch.uint8, device=dev)   # column-major: column j occupies maxn * width_j bytes
-    off = 0
-    for t, w in zip(tens, widths):
-        if n_local:
-            send[off: off + n_local * w] = t.reshape(-1).view(torch.uint8)
-        off += maxn * w
-    recv = torch.empty(world * maxn * row_bytes, dtype=torch.uint8, device=dev)
-    dist.all_gather_into_tensor(recv, send, group=group)
-    host = recv.cpu().numpy()
-    out, off = [], 0
-    for dt, w in zip(np_dtypes, widths):
-        pieces = [host[r * maxn * row_bytes + off: r * maxn * row_bytes + off + counts[r] * w] for r in range(world)]
-        out.append(np.concatenate(pieces).view(dt))
-        off += maxn * w
-    return out
+    if np_dtypes is not None:
+        dts = [np.dtype(d) for d in np_dtypes]
+    out, _ = gather_tensors(tens, group, dev)
+    return [t.cpu().numpy().view(dt) for t, dt in zip(out, dts)]
 
 
 def result_tensors(res, device, limit=None):
@@ -316,23 +336,47 @@ def result_tensors(res, device, limit=None):
             for j in range(m)], [np.dtype(res.dtype(j)) for j in range(m)]
 
 
-_MERGE = {"sum": np.add, "count": np.add, "min": np.minimum, "max": np.maximum, "prod": np.multiply}
+def _reduce_tensor(t, op, group=None):
+    """All-reduce of one tensor in place (RCCL on device tensors; under gloo device tensors are staged through the host)."""
+    import torch.distributed as dist
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        x, back = _host_staged(t)
+        dist.all_reduce(x, op={"sum": dist.ReduceOp.SUM, "min": dist.ReduceOp.MIN, "max": dist.ReduceOp.MAX}[op], group=group)
+        back()
+    return t
 
 
-def merge_grouped(keys, aggs, funcs, group=None):
-    """Merge per-rank GROUP BY results over sparse keys: gather (key, partial
-    aggregate) rows from every rank and fold equal keys.  `funcs[j]` names how
-    partials of aggregate j combine ("sum", "count", "min", "max", "prod");
-    AVG must be carried as a (sum, count) pair by the caller.  Returns keys
-    ascending."""
-    keys, aggs = gather_columns([keys], group)[0], gather_columns(list(aggs), group)
-    order = np.argsort(keys, kind="stable")
-    keys, aggs = keys[order], [a[order] for a in aggs]
-    heads = np.ones(len(keys), dtype=bool)
-    heads[1:] = keys[1:] != keys[:-1]
-    starts = np.flatnonzero(heads)
-    out = [_MERGE[f].reduceat(a, starts) if len(a) else a for a, f in zip(aggs, funcs)]
-    return keys[heads], out
+def merge_slot_columns(cols, kinds, np_dtypes, cnt, group=None):
+    """Merge the per-key-slot partial aggregates of every rank elementwise (dense GROUP BY over shards).
+
+    cols[j]: 1-D tensor of G slots holding this rank's partial of kind kinds[j] ("sum" | "min" | "max"), typed
+    np_dtypes[j] (uint32 travels as its int32 bit pattern); cnt: int64 tensor, rows per slot on this rank.  Slots a rank
+    has no row for hold unspecified values: they are replaced by the operator's neutral element first.  SUMs of f32 are
+    widened to f64 for the reduction (the merged value does not depend on how rows were spread over the GPUs beyond one
+    rounding of each shard's partial); unsigned MIN / MAX reduce as int64.  Returns [merged cols..., merged counts]."""
+    import torch
+    empty = cnt == 0
+    out = []
+    for t, kind, dt in zip(cols, kinds, np_dtypes):
+        dt = np.dtype(dt)
+        if kind == "sum":
+            x = t.to(torch.float64) if dt.kind == "f" else t.to(torch.int64)
+            x = torch.where(empty, torch.zeros_like(x), x)
+            out.append(_reduce_tensor(x, "sum", group))
+            continue
+        if dt == np.dtype(np.uint32):
+            x = t.to(torch.int64) & 0xFFFFFFFF
+            neutral = 0xFFFFFFFF if kind == "min" else 0
+        elif dt.kind == "f":
+            x, neutral = t.clone(), float("inf") if kind == "min" else float("-inf")
+        else:
+            info = np.iinfo(dt)
+            x, neutral = t.clone(), int(info.max if kind == "min" else info.min)
+        x = torch.where(empty, torch.full_like(x, neutral), x)
+        x = _reduce_tensor(x, kind, group)
+        out.append(x.to(torch.int32) if dt == np.dtype(np.uint32) else x)        # back to the bit pattern (wraps above 2^31)
+    total = _reduce_tensor(cnt.clone(), "sum", group)
+    return out + [total]
 
 
 # ---------------------------------------------------------------------------
@@ -365,18 +409,21 @@ def exchange_columns(send_cols, send_counts, group=None):
 _TORCH_OF = {"int32": "int32", "uint32": "int32", "float32": "float32", "int64": "int64"}     # uint32 travels as its bit pattern
 
 
-def repartition_device(eng, ptrs, dtypes, n, key_index, device, world, group=None, splitters=None, descending=False):
+def repartition_device(eng, ptrs, dtypes, n, key_index, device, world, group=None, splitters=None, descending=False, key_dtype=None):
     """Partition n rows held in device columns (raw pointers `ptrs`) by column
     `key_index` on the GPU and all-to-all them: by key hash
     (hark_op_partition_by_hash) or, when `splitters` is given, by key range
     (hark_op_partition_by_range: rank r receives the r-th range, rows of one
-    source in table order).  Returns (torch tensors owning the received columns, rows)."""
+    source in table order).  `key_dtype` reads the key column's bits as another
+    dtype of the same width (the join orders 32-bit keys as u32, join.fut:52).
+    Returns (torch tensors owning the received columns, rows)."""
     import torch
     perm = torch.empty(max(n, 1), dtype=torch.int32, device=device)
+    kdt = dtypes[key_index] if key_dtype is None else key_dtype
     if splitters is None:
-        counts = eng.partition_by_hash(ptrs[key_index], dtypes[key_index], n, world, perm.data_ptr())
+        counts = eng.partition_by_hash(ptrs[key_index], kdt, n, world, perm.data_ptr())
     else:
-        counts = eng.partition_by_range(ptrs[key_index], dtypes[key_index], n, splitters, descending, perm.data_ptr())
+        counts = eng.partition_by_range(ptrs[key_index], kdt, n, splitters, descending, perm.data_ptr())
     send = []
     for ptr, dt in zip(ptrs, dtypes):
         buf = torch.empty(max(n, 1), dtype=getattr(torch, _TORCH_OF[np.dtype(dt).name]), device=device)[:n]
@@ -407,26 +454,58 @@ def choose_splitters(all_samples, world):
 
 
 def gather_splitters(local_sample, world, group=None):
-    """All ranks pool their key samples (all-gather) and derive the SAME splitters."""
+    """All ranks pool their key samples (one tensor all-gather, no pickling) and derive the SAME splitters."""
+    import torch
     import torch.distributed as dist
-    local_sample = np.asarray(local_sample)
+    local_sample = np.ascontiguousarray(local_sample)
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return choose_splitters(local_sample, world)
-    parts = [None] * dist.get_world_size(group)
-    dist.all_gather_object(parts, local_sample, group=group)
-    return choose_splitters(np.concatenate([p.astype(local_sample.dtype, copy=False) for p in parts]), world)
+    dt = local_sample.dtype
+    carrier = {4: np.int32, 8: np.int64}[dt.itemsize]                      # bit patterns travel; u32 / f32 keep their order on return
+    pooled = gather_columns([local_sample.view(carrier)], group)[0].view(dt)
+    return choose_splitters(pooled, world)
 
 
 _SECOND_LEVEL = {"sum": "sum", "count": "sum", "min": "min", "max": "max", "prod": "prod"}
 
 
+class TensorResult:
+    """Device columns held by torch tensors behind the read-only interface of engine.Result (shape / dtype / device_ptr /
+    columns): what the merged groups of all shards look like to the common HAVING / ORDER BY / LIMIT tail."""
+
+    def __init__(self, tensors, np_dtypes, keep=None):
+        self._t, self._dt, self._keep = [t.contiguous() for t in tensors], [np.dtype(d) for d in np_dtypes], keep
+
+    @property
+    def shape(self):
+        return (int(self._t[0].numel()) if self._t else 0), len(self._t)
+
+    def dtype(self, j):
+        return self._dt[j]
+
+    def device_ptr(self, j):
+        return self._t[j].data_ptr() if self._t[j].numel() else 0
+
+    def column(self, j, limit=None):
+        n = self.shape[0]
+        rows = n if limit is None else min(n, max(int(limit), 0))
+        return self._t[j][:rows].cpu().numpy().view(self._dt[j])
+
+    def columns(self, limit=None):
+        return [self.column(j, limit) for j in range(len(self._t))]
+
+    def free(self):
+        self._t, self._keep = [], None
+
+
 class ShardedFutharkContext:
     """FutharkContext whose tables are row-range shards, one rank per GPU.
 
-    create_table() takes the FULL host table on every rank and keeps only this
-    rank's rows (shard_range); sql() runs the local operators on the shard and
-    merges: projection / WHERE results concatenate in rank order, GROUP BY
-    partials are all-reduced (dense keys, device side) or merged by key."""
+    create_table() ingests only this rank's rows (a byte range of a CSV file, a slice of a
+    DataFrame / ndarray, a per-rank source, or device columns); sql() runs the local operators
+    on the shard and merges on the device: projection / WHERE results concatenate in rank
+    order, GROUP BY partials are all-reduced per key slot (dense keys) or repartitioned to the
+    owner of hash(key), ORDER BY is a sample sort, JOIN a range partition (reference order)."""
 
     def __init__(self, device=None, device_exchange=None):
         import torch
@@ -441,15 +520,52 @@ class ShardedFutharkContext:
         # sparse GROUP BY / JOIN exchange rows with an RCCL all-to-all when there is more than one rank
         self.device_exchange = (self.world > 1) if device_exchange is None else bool(device_exchange)
 
-    def create_table(self, table_name, table):
-        from .table import Table
-        full = Table(table_name, table)
-        n = full.get_data().shape[0]
-        lo, hi = shard_range(n, self.rank, self.world)
-        cols = [c[lo:hi] for c in full.host_columns()]
+    def create_table(self, table_name, table, local=False):
+        """The reference's call (FutharkContext.py:44-50) over shards.  `table` is a file name, a DataFrame or an ndarray.
+
+        local=False: `table` names the WHOLE table on every rank and each rank ingests ITS rows only -- a CSV file is cut
+        into world byte ranges at row boundaries and a rank parses just its range (table.read_csv_byte_range: nobody
+        reads or parses the whole file); a DataFrame / ndarray / TXT file is sliced by shard_range before any conversion.
+        local=True: `table` holds this rank's rows only (e.g. one file per rank); the table is the rank-order
+        concatenation.  Either way the ranks agree on every column's dtype (the widest any shard needs) with one MAX
+        all-reduce and on the global row ranges with one all-gather of the row counts."""
         import pandas as pd
-        self.local.create_table(table_name, pd.DataFrame({h: c for h, c in zip(full.get_schema(), cols)}))
-        self.rows[table_name] = (n, lo, hi)
+        from .table import Table, read_csv_byte_range, dtype_code, DTYPE_CODES
+        if not local and isinstance(table, str) and table[-3:] == "csv":
+            frame, headers = read_csv_byte_range(table, self.rank, self.world)
+            part = Table(table_name, frame)
+        elif local:
+            part = Table(table_name, table)
+        else:
+            if isinstance(table, str):                                   # TXT: np.loadtxt has no row ranges; sliced after loading
+                table = Table(table_name, table).get_data()
+            n = len(table)
+            lo, hi = shard_range(n, self.rank, self.world)
+            part = Table(table_name, table.iloc[lo:hi] if isinstance(table, pd.DataFrame) else table[lo:hi])
+        codes = [dtype_code(d) for d in part.column_dtypes()] if part.get_data().shape[0] else [0] * len(part.get_schema())
+        codes = self._allreduce_small(codes, "max")
+        cols = part.host_columns([DTYPE_CODES[c] for c in codes])
+        self.local.create_table(table_name, pd.DataFrame({h: c for h, c in zip(part.get_schema(), cols)}))
+        self._register_rows(table_name, len(cols[0]) if cols else 0)
+
+    def create_table_from_device(self, table_name, schema, ptrs, dtypes, n_local, keepalive=None):
+        """This rank's rows as columns that already live in ITS GPU's memory (raw device addresses, 16-byte aligned; e.g.
+        generated there, or loaded by another library): no host copy anywhere.  Rank r's rows follow rank r - 1's."""
+        self.local.create_table_from_device(table_name, schema, ptrs, dtypes, int(n_local), keepalive=keepalive)
+        self._register_rows(table_name, int(n_local))
+
+    def _register_rows(self, table_name, n_local):
+        import torch
+        import torch.distributed as dist
+        counts = [n_local]
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            dev = "cpu" if dist.get_backend() == "gloo" else self.device
+            mine = torch.tensor([n_local], dtype=torch.int64, device=dev)
+            allc = torch.empty(self.world, dtype=torch.int64, device=dev)
+            dist.all_gather_into_tensor(allc, mine)
+            counts = [int(x) for x in allc.tolist()]
+        lo = sum(counts[: self.rank])
+        self.rows[table_name] = (sum(counts), lo, lo + n_local)
 
     def drop_table(self, table_name):
         self.local.drop_table(table_name)
@@ -466,12 +582,10 @@ class ShardedFutharkContext:
     def sql_columns(self, sql_statement):
         from .parse import sql_parse
         ir = sql_parse(self.local.tables, sql_statement)
-        if ir.get("orderby_all"):
-            raise Exception("ORDER BY on several keys over sharded tables is not built yet")
         if ir.get("join"):
             return self._join(ir)
         if "groupbys" not in ir:
-            if "orderby" in ir and (self.world > 1 or self.device_exchange):
+            if ("orderby" in ir or ir.get("orderby_all")) and (self.world > 1 or self.device_exchange):
                 return self._orderby(ir)
             limit = ir.pop("limit", None)
             stmt = sql_statement if limit is None else sql_statement[: sql_statement.lower().rindex("limit")]
@@ -481,169 +595,240 @@ class ShardedFutharkContext:
             return names, ([c[:limit] for c in cols] if limit is not None else cols)
         return self._groupby(ir)
 
+    def _allreduce_small(self, values, op):
+        """Elementwise MIN / MAX / SUM over ranks of a short list of Python ints (statistics, not data): one int64 tensor."""
+        import torch
+        import torch.distributed as dist
+        if not dist.is_initialized() or dist.get_world_size() == 1:
+            return [int(v) for v in values]
+        dev = "cpu" if dist.get_backend() == "gloo" else self.device
+        t = torch.tensor([int(v) for v in values], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op={"min": dist.ReduceOp.MIN, "max": dist.ReduceOp.MAX, "sum": dist.ReduceOp.SUM}[op])
+        return [int(x) for x in t.tolist()]
+
+    def _global_key_ranges(self, dev, g_cols):
+        """(mins, spans) of 32-bit integer key columns over ALL shards (one MIN and one MAX all-reduce of 2 x keys int64
+        words; an empty shard contributes the neutral elements), or None when a key column is not a 32-bit integer."""
+        if any(np.dtype(dev.dtype(c)) not in (np.dtype(np.int32), np.dtype(np.uint32)) for c in g_cols):
+            return None
+        eng, big = self.local.FutEnv, 1 << 62
+        mine = [eng.column_range(dev, c) for c in g_cols] if dev.shape[0] > 0 else [(big, -big)] * len(g_cols)
+        mins = self._allreduce_small([lo for lo, _ in mine], "min")
+        maxs = self._allreduce_small([hi for _, hi in mine], "max")
+        if any(lo > hi for lo, hi in zip(mins, maxs)):                   # every shard is empty
+            return [0] * len(g_cols), [1] * len(g_cols)
+        return mins, [hi - lo + 1 for lo, hi in zip(mins, maxs)]
+
     def _groupby(self, ir):
-        """Local typed GROUP BY on the shard (AVG split into SUM and COUNT),
-        merge by key, then HAVING / ORDER BY / LIMIT on the merged G rows."""
-        schema = self.local.tables[ir["table_name"]].get_schema()
-        table_name, key_name, decode = ir["table_name"], schema[ir["g_col"]], None
+        """GROUP BY over row-range shards.  The statement is planned exactly as on one GPU (FutharkContext.
+        _groupby_extended: aggregates, HAVING, ORDER BY, LIMIT, composite keys encoded with the key ranges of ALL shards);
+        only the aggregation itself is replaced by a provider that merges the shards' partial aggregates ON THE DEVICE:
+
+          dense key domain (<= 2^21 slots)   every rank lays its partials out per key slot (hark_entry_filter_groupby_slots)
+                                             and the slots are merged elementwise with all-reduces (SUM / MIN / MAX);
+          anything else                      partial aggregates are repartitioned by hash(key) with an all-to-all, folded by
+                                             their owner, and the owners' groups all-gathered as device tensors.
+
+        Either way every rank then holds the merged groups in HBM, and HAVING / ORDER BY / LIMIT run there
+        (hark_entry_topk, or compaction + radix sort); only the final rows are downloaded."""
+        tab = self.local.tables[ir["table_name"]]
+        dev, schema = tab._device, tab.get_schema()
         g_cols = ir.get("g_cols", [ir["g_col"]])
-        if len(g_cols) > 1:
-            # several keys: one composite key column per shard, encoded with the ranges over ALL shards so that every
-            # rank encodes alike; the single-key machinery below then runs on a temporary table with that column
-            eng, tab = self.local.FutEnv, self.local.tables[ir["table_name"]]
-            dev = tab._device
-            mine = [eng.column_range(dev, c) for c in g_cols] if dev.shape[0] > 0 else None
-            parts = [mine]
-            import torch.distributed as dist
-            if dist.is_initialized() and dist.get_world_size() > 1:
-                parts = [None] * dist.get_world_size()
-                dist.all_gather_object(parts, mine)
-            parts = [p for p in parts if p is not None]
-            mins = [min(p[j][0] for p in parts) for j in range(len(g_cols))] if parts else [0] * len(g_cols)
-            spans = [max(p[j][1] for p in parts) - mins[j] + 1 for j in range(len(g_cols))] if parts else [1] * len(g_cols)
-            buf, cdt, _, _ = eng.composite_key(dev, g_cols, ranges=(mins, spans))
-            m = dev.shape[1]
-            table_name, key_name = f"__mk_{ir['table_name']}", "__key"
-            self.local.create_table_from_device(table_name, list(schema) + [key_name], [dev.device_ptr(j) for j in range(m)] + [buf.ptr or 0],
-                                                [dev.dtype(j) for j in range(m)] + [cdt], dev.shape[0], keepalive=(dev, buf))
-            decode = (mins, spans, [dev.dtype(c) for c in g_cols])
-        try:
-            return self._groupby_merge(ir, schema, table_name, key_name, g_cols, decode)
-        finally:
-            if decode is not None:
-                self.local.drop_table(table_name)
+        ranges = self._global_key_ranges(dev, g_cols)
+        n_global = self.rows.get(ir["table_name"], (dev.shape[0],))[0]
+        self.last_groupby_path = None
 
-    def _groupby_merge(self, ir, schema, table_name, key_name, g_cols, decode):
-        specs = []                       # partial aggregates to compute locally: (func, col)
+        def provider(cur, dev_preds, gkey, specs):
+            res = None
+            if ranges is not None and not os.environ.get("HARK_NO_DENSE_MERGE"):
+                res = self._merged_dense(cur, dev_preds, gkey, specs, ranges, len(g_cols) > 1, n_global)
+            if res is None:
+                res = self._merged_by_owner(cur, dev_preds, gkey, specs)
+            return res
 
-        def slot(spec):
-            if spec[0] == "key":
-                return ("key", spec[1])
-            if spec[0] == "col":
-                raise Exception(f"{schema[spec[1]]} is not an aggregation function or the columns thats grouped on")
-            if spec[0] == "avg":
-                return ("avg", slot(("sum", spec[1]))[1], slot(("count", None))[1])
-            if spec not in specs:
-                specs.append(spec)
-            return ("agg", specs.index(spec))
+        return self.local._groupby_extended(dev, schema, ir, provider=provider, key_ranges=ranges if len(g_cols) > 1 else None)
 
-        items = [slot(i) for i in ir["items"]]
-        having = [(slot(s), cmp, v) for s, cmp, v in ir.get("having", [])]
-        order = (slot(ir["orderby"][0]), ir["orderby"][1]) if "orderby" in ir else None
-        sel = ", ".join([key_name] + [f"{f}({'*' if c is None else schema[c]})" for f, c in specs])
-        where = " and ".join(f"{schema[c]} {cmp} {v!r}" for c, cmp, v in ir.get("where", []))
-        stmt = f"select {sel} from {table_name}" + (f" where {where}" if where else "") + f" group by {key_name}"
-        if self.device_exchange:
-            cols = self._groupby_exchange(stmt, specs)
-            order_k = np.argsort(cols[0], kind="stable")
-            keys, merged = cols[0][order_k], [c[order_k] for c in cols[1:]]      # every key lives on exactly one rank now
+    # ---- dense key domain: all-reduce of per-slot partial aggregates ---------------
+    def _merged_dense(self, cur, dev_preds, gkey, specs, ranges, composite, n_global):
+        """[key, aggregates...] of all groups, merged over the shards by all-reduce; None when the shape is not dense."""
+        import torch
+        eng = self.local.FutEnv
+        kdt = np.dtype(cur.dtype(gkey))
+        if composite:                                                   # the composite column already lies in [0, prod(spans))
+            if kdt != np.dtype(np.int32):
+                return None
+            base, G = 0, int(np.prod([int(x) for x in ranges[1]], dtype=object))
         else:
-            _, cols = self.local.sql_columns(stmt)
-            widen = [c.astype(np.float64) if c.dtype == np.float32 else c for c in cols[1:]]     # merge f32 partial sums in f64
-            keys, merged = merge_grouped(cols[0], widen, [f for f, _ in specs])
+            base, G = int(ranges[0][0]), int(ranges[0][0]) + int(ranges[1][0])     # slots 0 .. max key
+            if base < 0:
+                return None                                             # negative keys: not a slot index (owner path)
+        if G > (1 << 21) or G > 8 * max(int(n_global), 1) + 4096:
+            return None
+        four = (np.dtype(np.float32), np.dtype(np.int32), np.dtype(np.uint32))
+        if any(f not in ("sum", "avg", "min", "max", "count") or (f != "count" and np.dtype(cur.dtype(c)) not in four) for f, c in specs):
+            return None
+        # what travels: SUM / MIN / MAX per (operator, column); COUNT comes with every pass; AVG = SUM and COUNT
+        # (specs name COUNT(*) as ("count", 0): the column of a count is never read)
+        part = []
+        for f, c in specs:
+            ps = ("sum" if f == "avg" else f, c)
+            if f != "count" and ps not in part:
+                part.append(ps)
+        res = eng.filter_groupby_slots(cur, dev_preds, gkey, G, part)
+        if res is None:
+            return None
+        tens, dts = result_tensors(res, self.device)
+        merged = merge_slot_columns(tens[:-1], [f for f, _ in part], dts[:-1], tens[-1])
+        cnt = merged[-1]
+        cols, np_dts = [torch.arange(G, dtype=torch.int32, device=cnt.device)], [kdt]
+        for f, c in specs:
+            if f == "count":
+                cols.append(cnt); np_dts.append(np.dtype(np.int64))
+                continue
+            j = part.index(("sum" if f == "avg" else f, c))
+            t, dt = merged[j], dts[j]
+            if f == "avg":                                              # f32(sum / count), as the fused read-out computes it
+                t, dt = (t.to(torch.float64) / cnt.to(torch.float64).clamp(min=1.0)).to(torch.float32), np.dtype(np.float32)
+            elif t.dtype == torch.float64:
+                t = t.to(torch.float32)                                 # SUM of an f32 column: merged in f64, rounded once
+            cols.append(t.contiguous()); np_dts.append(dt)
+        cols.append(cnt); np_dts.append(np.dtype(np.int64))
+        t = eng.table_from_device(G, [c.data_ptr() for c in cols], np_dts, keepalive=(cols, res))
+        out = eng.filter_sel(t, [(len(cols) - 1, ">", 0)], cols=list(range(len(cols) - 1)), want_row_index=False)   # the non-empty groups, ascending key
+        out._keep = (t,)
+        self.last_groupby_path = "dense all-reduce"
+        return out
 
-        key_cols = {g_cols[0]: keys}
-        if decode is not None:                                           # composite -> the key columns (last key = least significant digit)
-            comp, key_cols = keys.astype(np.int64), {}
-            for c, mn, sp, dt in reversed(list(zip(g_cols, *decode))):
-                key_cols[c] = (comp % sp + mn).astype(dt)
-                comp = comp // sp
-
-        def value(s):
-            if s[0] == "key":
-                return key_cols[s[1]]
-            if s[0] == "agg":
-                f, c = specs[s[1]]
-                return merged[s[1]].astype(np.float32) if cols[1 + s[1]].dtype == np.float32 else merged[s[1]]
-            return (merged[s[1]] / merged[s[2]]).astype(np.float32)
-
-        keep = np.ones(len(keys), dtype=bool)
-        ops = {">": np.greater, ">=": np.greater_equal, "<": np.less, "<=": np.less_equal, "=": np.equal, "!=": np.not_equal}
-        for s, cmp, v in having:
-            keep &= ops[cmp](value(s), v)
-        out = [value(s)[keep] for s in items]
-        if order is not None:
-            ov = value(order[0])[keep]
-            perm = np.argsort(-ov if order[1] else ov, kind="stable") if ov.dtype.kind != "u" else \
-                np.argsort((ov.max(initial=0) - ov) if order[1] else ov, kind="stable")
-            out = [c[perm] for c in out]
-        if "limit" in ir:
-            out = [c[: ir["limit"]] for c in out]
-        names = [schema[c] if f == "key" else f"{f}({'*' if c is None else schema[c]})" for f, c in ir["items"]]
-        return names, out
+    # ---- any keys: all-to-all of partial aggregates to the owner of hash(key) ---------
+    def _merged_by_owner(self, cur, dev_preds, gkey, specs):
+        import torch
+        eng = self.local.FutEnv
+        specs = [(f, 0 if f == "count" else c) for f, c in specs]       # COUNT(*): the column is never read
+        part = []
+        for f, c in specs:
+            for ps in ((("sum", c), ("count", 0)) if f == "avg" else ((f, c),)):
+                if ps not in part:
+                    part.append(ps)
+        res = eng.filter_groupby(cur, dev_preds, gkey, part)            # this shard's groups: [key, partials...]
+        n, m = res.shape
+        dts = [np.dtype(res.dtype(j)) for j in range(m)]
+        if self.world > 1 or self.device_exchange:
+            recv, nrecv = repartition_device(eng, [res.device_ptr(j) for j in range(m)], dts, n, 0, self.device, self.world)
+            t = eng.table_from_device(nrecv, [c.data_ptr() for c in recv], dts, keepalive=(recv, res))
+            own = eng.filter_groupby(t, None, 0, [(_SECOND_LEVEL[f], 1 + j) for j, (f, _) in enumerate(part)])     # complete groups of the keys this rank owns
+            own._keep = (t,)
+            tens, dts = result_tensors(own, self.device)
+            allt, _ = gather_tensors(tens, device=self.device)          # every rank: all groups, owner by owner (device tensors)
+            g = int(allt[0].numel())
+            t2 = eng.table_from_device(g, [x.data_ptr() for x in allt], dts, keepalive=(allt, own))
+            res = eng.sort(t2, 0, list(range(len(allt))))               # ascending key (the key column's own order, as on one GPU)
+            res._keep = (t2,)
+            n, m = res.shape
+            dts = [np.dtype(res.dtype(j)) for j in range(m)]
+        # [key, partials...] -> [key, aggregates in spec order]
+        tens, _ = result_tensors(res, self.device)
+        cols, np_dts = [tens[0]], [dts[0]]
+        for f, c in specs:
+            if f == "avg":
+                sj, cj = 1 + part.index(("sum", c)), 1 + part.index(("count", 0))
+                cols.append((tens[sj].to(torch.float64) / tens[cj].to(torch.float64).clamp(min=1.0)).to(torch.float32)); np_dts.append(np.dtype(np.float32))
+            else:
+                j = 1 + part.index((f, c))
+                cols.append(tens[j]); np_dts.append(dts[j])
+        self.last_groupby_path = "owner all-to-all"
+        return TensorResult(cols, np_dts, keep=res)
 
     # ---- RCCL all-to-all paths ------------------------------------------------------
+    def _sample_keys(self, ptr, dt, n):
+        """Up to SAMPLES_PER_RANK evenly spaced values of a device column, on the host."""
+        import torch
+        pos = sample_positions(n)
+        if not pos.size:
+            return np.empty(0, dtype=np.dtype(dt))
+        idx = torch.as_tensor(pos.astype(np.int32), device=self.device)
+        buf = torch.empty(pos.size, dtype=getattr(torch, _TORCH_OF[np.dtype(dt).name]), device=self.device)
+        self.local.FutEnv.gather(ptr, dt, idx.data_ptr(), buf.data_ptr(), pos.size)
+        return buf.cpu().numpy().view(np.dtype(dt))
+
     def _orderby(self, ir):
-        """SELECT ... [WHERE ...] ORDER BY col [DESC] [LIMIT n] over row-range shards as a
+        """SELECT ... [WHERE ...] ORDER BY col [, col ...] [DESC] [LIMIT n] over row-range shards as a
         sample sort: local WHERE, pooled key samples -> splitters, range partition on the
         GPU, all-to-all, local stable radix sort, ranges concatenated in rank order.  Ties
-        keep table order: a range receives its rows by (source rank, local position)."""
-        import torch
+        keep table order: a range receives its rows by (source rank, local position).
+        Several sort keys are folded into ONE composite key column first (hark_table_composite_key with the key ranges
+        of ALL shards, so that every rank encodes alike; ascending composite = lexicographic order of the tuple)."""
         eng, loc = self.local.FutEnv, self.local
         tab = loc.tables[ir["table_name"]]
         dev, schema = tab._device, tab.get_schema()
-        okey, desc = ir["orderby"][0][1], bool(ir["orderby"][1])
-        need = list(dict.fromkeys([okey] + list(ir["select"])))
+        many = ir.get("orderby_all")
+        if many:
+            if any(sp[0] != "col" for sp, _ in many) or len({d for _, d in many}) != 1:
+                raise Exception("ORDER BY on several keys takes plain columns, all ascending or all descending")
+            okeys, desc = [sp[1] for sp, _ in many], bool(many[0][1])
+        else:
+            okeys, desc = [ir["orderby"][0][1]], bool(ir["orderby"][1])
+        need = list(dict.fromkeys(okeys + list(ir["select"])))
         if ir.get("where"):
             cur, cmap = loc._filtered(dev, ir["where"], set(need))
         else:
             cur, cmap = dev, {c: c for c in need}
         n = cur.shape[0]
         ptrs, dts = [cur.device_ptr(cmap[c]) for c in need], [cur.dtype(cmap[c]) for c in need]
-        pos = sample_positions(n)
-        sample = np.empty(0, dtype=np.dtype(dts[0]))
-        if pos.size:
-            idx = torch.as_tensor(pos.astype(np.int32), device=self.device)
-            buf = torch.empty(pos.size, dtype=getattr(torch, _TORCH_OF[np.dtype(dts[0]).name]), device=self.device)
-            eng.gather(ptrs[0], dts[0], idx.data_ptr(), buf.data_ptr(), pos.size)
-            sample = buf.cpu().numpy().view(np.dtype(dts[0]))
-        splitters = gather_splitters(sample, self.world)
+        keep = [cur]
+        if len(okeys) > 1:
+            ranges = self._global_key_ranges(dev, okeys)                 # of the unfiltered shards: a superset, the same on every rank
+            if ranges is None:
+                raise Exception("ORDER BY on several keys takes 32-bit integer columns")
+            buf, cdt, _, _ = eng.composite_key(cur, [cmap[c] for c in okeys], ranges=ranges)
+            keep.append(buf)
+            ptrs, dts = [buf.ptr or 0] + ptrs, [cdt] + dts              # the sort key travels in front of the needed columns
+            sel = [1 + need.index(c) for c in ir["select"]]
+        else:
+            sel = [need.index(c) for c in ir["select"]]
+        splitters = gather_splitters(self._sample_keys(ptrs[0], dts[0], n), self.world)
         recv, nrecv = repartition_device(eng, ptrs, dts, n, 0, self.device, self.world, splitters=splitters, descending=desc)
-        t = eng.table_from_device(nrecv, [c.data_ptr() for c in recv], dts, keepalive=(recv, cur))
-        res = eng.sort(t, 0, [need.index(c) for c in ir["select"]], descending=desc)
+        t = eng.table_from_device(nrecv, [c.data_ptr() for c in recv], dts, keepalive=(recv, keep))
+        res = eng.sort(t, 0, sel, descending=desc)
         tens, dts = result_tensors(res, self.device, ir.get("limit"))
         cols = gather_columns(tens, device=self.device, np_dtypes=dts)
         if "limit" in ir:
             cols = [c[: ir["limit"]] for c in cols]
         return [schema[c] for c in ir["select"]], cols
 
-    def _result_as_table(self, res):
-        eng = self.local.FutEnv
-        n, m = res.shape
-        return eng.table_from_device(n, [res.device_ptr(j) for j in range(m)], [res.dtype(j) for j in range(m)], keepalive=res)
-
-    def _groupby_exchange(self, stmt, specs):
-        """Local partial aggregates -> all-to-all by hash(key) -> second-level
-        aggregation of the partials on the owner rank -> gather of the owners' rows."""
-        eng = self.local.FutEnv
-        names, res = self.local.sql_result(stmt)                    # device-resident [key, partial...]
-        n, m = res.shape
-        dts = [res.dtype(j) for j in range(m)]
-        recv, nrecv = repartition_device(eng, [res.device_ptr(j) for j in range(m)], dts, n, 0, self.device, self.world)
-        t = eng.table_from_device(nrecv, [c.data_ptr() for c in recv], dts, keepalive=recv)
-        res2 = eng.filter_groupby(t, None, 0, [(_SECOND_LEVEL[f], 1 + j) for j, (f, _) in enumerate(specs)])
-        tens, dts = result_tensors(res2, self.device)
-        return gather_columns(tens, device=self.device, np_dtypes=dts)
-
     def _join(self, ir):
-        """Both sides are hash-partitioned by the join key and exchanged; every rank
-        joins what it owns.  Row order follows (owner rank, key, left row, right row)."""
+        """Two-table FROM over shards, in the REFERENCE's row order (futhark/join.fut:52-75: ascending key -- 32-bit keys
+        as u32 bit patterns --, then left row, then right row).  Both sides are RANGE-partitioned by the join key with
+        the same world - 1 splitters (quantiles of key samples pooled from both sides) and exchanged with an all-to-all;
+        rank r owns the r-th key range, so the owners' results concatenated in rank order ascend by key, and equal keys
+        never straddle two owners (part = number of splitters <= key).  Inside an owner the received rows keep (source
+        rank, local position) = the unsharded tables' row order, so the local join's (key, left row, right row) order
+        is the global one."""
         eng = self.local.FutEnv
-        sides = []
+        exchange = self.world > 1 or self.device_exchange
+        sides, samples = [], []
         for tname, kcol, cols in ((ir["tables"][0], ir["col1"], ir["cols1"]), (ir["tables"][1], ir["col2"], ir["cols2"])):
             dev = self.local.tables[tname]._device
             need = [kcol] + [c for c in dict.fromkeys(cols) if c != kcol]
             n = dev.shape[0]
             ptrs, dts = [dev.device_ptr(c) for c in need], [dev.dtype(c) for c in need]
-            if self.device_exchange:
-                recv, nrecv = repartition_device(eng, ptrs, dts, n, 0, self.device, self.world)
+            kdt = np.dtype(np.uint32) if np.dtype(dts[0]).itemsize == 4 else np.dtype(dts[0])      # the join's own key order
+            sides.append((dev, need, n, ptrs, dts, kdt))
+            if exchange:
+                samples.append(self._sample_keys(ptrs[0], dts[0], n).view(kdt))
+        if exchange and samples[0].dtype != samples[1].dtype:
+            raise Exception("join keys must have the same width on both sides")
+        splitters = gather_splitters(np.concatenate(samples), self.world) if exchange else None
+        tabs = []
+        for dev, need, n, ptrs, dts, kdt in sides:
+            if exchange:
+                recv, nrecv = repartition_device(eng, ptrs, dts, n, 0, self.device, self.world, splitters=splitters, key_dtype=kdt)
                 t = eng.table_from_device(nrecv, [c.data_ptr() for c in recv], dts, keepalive=recv)
             else:
                 t = eng.table_from_device(n, ptrs, dts, keepalive=dev)
-            sides.append((t, {c: i for i, c in enumerate(need)}))
-        (t1, m1), (t2, m2) = sides
+            tabs.append((t, {c: i for i, c in enumerate(need)}))
+        (t1, m1), (t2, m2) = tabs
         res = eng.join(t1, t2, 0, 0, [m1[c] for c in ir["cols1"]], [m2[c] for c in ir["cols2"]])
-        tens, dts = result_tensors(res, self.device)
+        tens, dts = result_tensors(res, self.device, ir.get("limit"))     # no owner contributes more than LIMIT rows
         cols = gather_columns(tens, device=self.device, np_dtypes=dts)
         left_pos = {c: i for i, c in reversed(list(enumerate(ir["cols1"])))}
         right_pos = {c: len(ir["cols1"]) + i for i, c in reversed(list(enumerate(ir["cols2"])))}

@@ -451,6 +451,21 @@ class Engine:
         self._chk(rc)
         return Result(self, h)
 
+    def filter_groupby_slots(self, table, where, g_col, G, aggs):
+        """Partial aggregates of this table over the dense key domain [0, G), one row per key slot: Result
+        [aggregate..., COUNT(*)] with G rows (sum / min / max / count only), or None when the shape is not the fused dense
+        one.  What a shard contributes to an all-reduce merge (dist.ShardedFutharkContext)."""
+        cols, pc = _ffi.i32_array([c for _, c in aggs])
+        ops, po = _ffi.i32_array([_ffi.AGG[o] for o, _ in aggs])
+        where = list(where or [])
+        wc, wo, wp, keep = self._predicates(table, where)
+        h = C.c_void_p()
+        rc = self.lib.hark_entry_filter_groupby_slots(self.ctx, C.byref(h), table._h, len(where), wc, wo, wp, int(g_col), int(G), pc, po, cols.size)
+        if rc == _ffi.EUNSUPPORTED:
+            return None
+        self._chk(rc)
+        return Result(self, h)
+
     def filter_groupby_subset(self, table, where, g_col, keys, aggs):
         """The aggregates `aggs` for the groups `keys` only (a numpy array of <= 1024 distinct 32-bit key values): a Result
         with len(keys) rows in that order, one column per aggregate.  Raises on unsupported shapes (see include/hark.h)."""

@@ -91,13 +91,63 @@ class Table:
     def get_name(self):
         return self._table_name
 
-    def host_columns(self):
-        """Per-column contiguous arrays in their device dtype.  Object-typed
+    def _raw_column(self, j):
+        c = self._data[:, j] if self._frame is None else self._frame.iloc[:, j].to_numpy()
+        if c.dtype == object:
+            c = pd.to_numeric(pd.Series(c)).to_numpy()
+        return c
+
+    def column_dtypes(self):
+        """The device dtype every column would get from THIS table's values (shards of one table agree on the widest,
+        see DTYPE_CODES)."""
+        return [np.dtype(column_dtype(self._raw_column(j))) for j in range(self._data.shape[1])]
+
+    def host_columns(self, dtypes=None):
+        """Per-column contiguous arrays in their device dtype (or in `dtypes`, one per column).  Object-typed
         DataFrame blocks (mixed columns) are converted column by column."""
         cols = []
         for j in range(self._data.shape[1]):
-            c = self._data[:, j] if self._frame is None else self._frame.iloc[:, j].to_numpy()
-            if c.dtype == object:
-                c = pd.to_numeric(pd.Series(c)).to_numpy()
-            cols.append(np.ascontiguousarray(c.astype(column_dtype(c))))
+            c = self._raw_column(j)
+            cols.append(np.ascontiguousarray(c.astype(column_dtype(c) if dtypes is None else dtypes[j])))
         return cols
+
+
+# Shards of one table must agree on every column's device dtype although each sees only its own values: int32 < uint32 <
+# int64 < float32 as codes, the widest wins (one MAX all-reduce of the codes, dist.ShardedFutharkContext.create_table).
+DTYPE_CODES = [np.dtype(np.int32), np.dtype(np.uint32), np.dtype(np.int64), np.dtype(np.float32)]
+
+
+def dtype_code(dt):
+    return DTYPE_CODES.index(np.dtype(dt))
+
+
+def read_csv_byte_range(file_name, part, parts):
+    """The rows of a CSV file whose first byte lies in the part-th of `parts` equal byte ranges of the data section (a
+    row belongs to the range its first byte falls in), parsed with the file's header: (DataFrame, headers).  Every row
+    of the file belongs to exactly one part and parts follow each other in file order, so part r of R is shard r of a
+    row-range-sharded table -- and no process parses more than its share of the file."""
+    import io
+    import os
+    size = os.path.getsize(file_name)
+    with open(file_name, "rb") as f:
+        header = f.readline()
+        data0 = f.tell()
+        span = size - data0
+
+        def boundary(i):                       # first byte of the first row that starts at or after data0 + i * span / parts
+            if i <= 0:
+                return data0
+            if i >= parts:
+                return size
+            at = data0 + (span * i) // parts
+            f.seek(at - 1)                      # a row starts at `at` iff the byte before it is a newline
+            f.readline()
+            return min(f.tell(), size)
+
+        lo, hi = boundary(part), boundary(part + 1)
+        f.seek(lo)
+        body = f.read(max(hi - lo, 0))
+    table = pd.read_csv(io.BytesIO(header + body), skipinitialspace=True)
+    headers = [str(h).strip() for h in table.columns.tolist()]
+    table.columns = headers
+    return table, headers

@@ -79,21 +79,31 @@ def test_shard_range_properties():
 def _merge_worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
     from harkdb_amd import dist as hd
     hd.init_process_group("cpu")
     rng = np.random.default_rng(100 + rank)
-    keys = np.unique(rng.integers(-50, 50, size=40)).astype(np.int32)            # per-rank GROUP BY result, keys ascending
-    s = rng.integers(0, 1000, size=len(keys)).astype(np.int64)
-    c = rng.integers(1, 9, size=len(keys)).astype(np.int64)
-    mn = rng.random(len(keys)).astype(np.float32)
-    k2, (s2, c2, mn2) = hd.merge_grouped(keys, [s, c, mn], ["sum", "count", "min"])
+    G = 64
+    cnt = rng.integers(0, 3, size=G).astype(np.int64) * (rng.random(G) < 0.6)     # many slots are empty on a rank
+    junk = lambda a: np.where(cnt > 0, a, rng.integers(-9, 9, size=G).astype(a.dtype))   # empty slots hold anything
+    sf = junk(rng.integers(0, 100, size=G).astype(np.float32))
+    si = junk(rng.integers(-1000, 1000, size=G).astype(np.int64))
+    mn = junk(rng.integers(-50, 50, size=G).astype(np.int32))
+    mxu = junk(rng.integers(0, 2**32, size=G, dtype=np.uint64).astype(np.uint32))
+    mxf = junk(rng.random(G).astype(np.float32))
+    tens = [torch.from_numpy(sf), torch.from_numpy(si), torch.from_numpy(mn), torch.from_numpy(mxu.view(np.int32)), torch.from_numpy(mxf)]
+    merged = hd.merge_slot_columns(tens, ["sum", "sum", "min", "max", "max"], [np.float32, np.int64, np.int32, np.uint32, np.float32], torch.from_numpy(cnt))
+    keys = np.unique(rng.integers(-50, 50, size=40)).astype(np.int32)
     g = hd.gather_columns([keys])[0]
-    q.put((rank, keys, s, c, mn, k2, s2, c2, mn2, g))
+    gt, counts = hd.gather_tensors([torch.from_numpy(keys), torch.from_numpy(keys.astype(np.float32))])
+    q.put((rank, cnt, sf, si, mn, mxu, mxf, [m.numpy() for m in merged], keys, g, [t.numpy() for t in gt], counts))
     import torch.distributed as dist
     dist.barrier(); dist.destroy_process_group()
 
 
-def test_merge_grouped_and_gather_two_ranks():
+def test_merge_slot_columns_and_gather_two_ranks():
+    """The elementwise merge behind the dense sharded GROUP BY (all-reduce SUM / MIN / MAX of per-slot partials, empty
+    slots neutralised, unsigned MAX above 2^31, f32 sums widened) and the rank-order gathers, over gloo."""
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -104,16 +114,25 @@ def test_merge_grouped_and_gather_two_ranks():
     for pr in procs:
         pr.join(timeout=60)
         assert pr.exitcode == 0
-    allk = np.concatenate([o[1] for o in outs])
-    exp_keys = np.unique(allk)
+    cnts = [o[1] for o in outs]
+    total = cnts[0] + cnts[1]
+    live = total > 0
+
+    def fold(j, f, neutral, dt):
+        return f(*[np.where(o[1] > 0, o[j].astype(dt), neutral) for o in outs])
+
     for o in outs:
-        assert np.array_equal(o[5], exp_keys)
-        for j, key in enumerate(exp_keys):
-            ss = sum(int(x[2][x[1] == key].sum()) for x in outs)
-            cc = sum(int(x[3][x[1] == key].sum()) for x in outs)
-            mm = min(float(x[4][x[1] == key].min()) for x in outs if (x[1] == key).any())
-            assert o[6][j] == ss and o[7][j] == cc and o[8][j] == np.float32(mm)
-        assert np.array_equal(o[9], allk)                                        # rank-order concatenation
+        m = o[7]
+        assert np.array_equal(m[5], total)
+        assert m[0].dtype == np.float64 and np.array_equal(m[0], fold(2, np.add, 0.0, np.float64))
+        assert np.array_equal(m[1], fold(3, np.add, 0, np.int64))
+        assert np.array_equal(m[2][live], fold(4, np.minimum, np.iinfo(np.int32).max, np.int32)[live])
+        assert np.array_equal(m[3].view(np.uint32)[live], fold(5, np.maximum, 0, np.uint32)[live])
+        assert np.array_equal(m[4][live], fold(6, np.maximum, -np.inf, np.float32)[live])
+        allk = np.concatenate([x[8] for x in outs])
+        assert np.array_equal(o[9], allk)                                        # rank-order concatenation (numpy out)
+        assert np.array_equal(o[10][0], allk) and np.array_equal(o[10][1], allk.astype(np.float32))
+        assert o[11] == [len(x[8]) for x in outs]
 
 
 def _exchange_worker(rank, world, port, q):

@@ -24,7 +24,18 @@ STATEMENTS = [
     "select t.k, b.y, t.w from t join b on t.w = b.x",
     "select w, k, sum(v), count(*) from t where p > 0.5 group by k, w",
     "select k, s, max(w), avg(v) from t group by k, s having count(*) > 1 order by max(w) desc limit 40",
+    # dense key domains: per-slot partials merged by all-reduce, the tail on the device
+    "select d, sum(v), count(*), avg(v), min(w), max(p) from t where p > 0.5 group by d having count(*) > 3 order by sum(v) desc limit 10",
+    "select d, sum(w), min(v), count(*) from t group by d",
+    "select d, e, sum(v), count(*) from t where p > 0.25 group by d, e order by count(*) desc limit 25",
+    "select d, max(w) from t group by d having max(w) > 7 order by d desc",
+    # ORDER BY on several keys over shards (composite key with the key ranges of all shards)
+    "select k, w, v from t where p > 0.7 order by k, w",
+    "select w, k from t order by w desc, k desc limit 60",
+    # the join in the reference's order, with a LIMIT cut
+    "select t.k, b.y, t.w from t join b on t.w = b.x limit 1000",
 ]
+DENSE = {9, 10, 11, 12}          # statements whose aggregation must take the all-reduce path
 
 
 def _frames():
@@ -32,12 +43,14 @@ def _frames():
     n = 60_000
     df = pd.DataFrame({"k": rng.integers(-20, 20, n).astype(np.int32), "p": rng.random(n).astype(np.float32),
                        "v": rng.integers(0, 16, n).astype(np.float32), "w": rng.integers(-9, 9, n).astype(np.int32),
-                       "s": (rng.integers(0, 3000, n) * 1_000_003 % (2**31)).astype(np.int32)})
+                       "s": (rng.integers(0, 3000, n) * 1_000_003 % (2**31)).astype(np.int32),
+                       "d": rng.integers(0, 5000, n).astype(np.int32), "e": rng.integers(3, 9, n).astype(np.int32)})
+    df.loc[: n // 2, "d"] %= 2500                       # keys 2500.. exist on the second shard only
     b = pd.DataFrame({"x": rng.integers(-12, 12, 700).astype(np.int32), "y": rng.integers(0, 1000, 700).astype(np.int32)})
     return df, b
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, csv_path):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                       HARK_DIST_BACKEND="gloo")
@@ -47,12 +60,26 @@ def _worker(rank, world, port, q):
     from harkdb_amd.engine import FgbPlan
     c = hd.ShardedFutharkContext()
     df, b = _frames()
-    c.create_table("t", df)
+    # three ways in: a CSV file cut into byte ranges (nobody parses the whole file), this rank's rows only, device columns
+    c.create_table("t", csv_path)
+    lo, hi = c.rows["t"][1], c.rows["t"][2]
+    assert c.rows["t"][0] == len(df) and c.local.tables["t"]._device.shape[0] == hi - lo < len(df)
+    c.create_table("t_local", df.iloc[lo:hi], local=True)
+    assert c.rows["t_local"] == c.rows["t"]
     c.create_table("b", b)
+    xs = torch.arange(1000 * rank, 1000 * rank + 1000 + 24 * rank, dtype=torch.int32, device=c.device)
+    ys = (xs % 7).to(torch.float32)
+    c.create_table_from_device("g", ["x", "y"], [xs.data_ptr(), ys.data_ptr()], [np.int32, np.float32], xs.numel(), keepalive=(xs, ys))
+    assert c.rows["g"][0] == 2024 and c.rows["g"][1] == (0 if rank == 0 else 1000)
     out = {}
-    for stmt in STATEMENTS:
+    paths = {}
+    for j, stmt in enumerate(STATEMENTS):
         names, cols = c.sql_columns(stmt)
         out[stmt] = (names, [np.asarray(x) for x in cols])
+        paths[j] = getattr(c, "last_groupby_path", None) if " group by " in stmt else None
+    out["paths"] = paths
+    out["g"] = c.sql_columns("select x, y from g where y > 5 order by x desc limit 30")
+    out["t_local"] = c.sql_columns("select d, count(*) from t_local group by d")
     # the fused operator over shards: local kernels, all-reduce of the accumulators, finish
     G, n = 1 << 14, len(df)
     lo, hi = hd.shard_range(n, rank, world)
@@ -70,13 +97,16 @@ def _worker(rank, world, port, q):
     dist.barrier(); dist.destroy_process_group()
 
 
-def test_two_ranks_one_gpu_match_single_context():
+def test_two_ranks_one_gpu_match_single_context(tmp_path):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
+    df, b = _frames()
+    csv_path = str(tmp_path / "t.csv")
+    df.to_csv(csv_path, index=False)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, csv_path)) for r in range(2)]
     for pr in procs:
         pr.start()
     outs = dict(q.get(timeout=300) for _ in range(2))
@@ -85,7 +115,6 @@ def test_two_ranks_one_gpu_match_single_context():
         assert pr.exitcode == 0
     # single-context reference on the same GPU
     from harkdb_amd.context import FutharkContext
-    df, b = _frames()
     fc = FutharkContext(device=0, sql_mode=True)
     fc.create_table("t", df)
     fc.create_table("b", b)
@@ -94,16 +123,30 @@ def test_two_ranks_one_gpu_match_single_context():
         for rank in (0, 1):
             gn, gc = outs[rank][stmt]
             assert gn == names, stmt
-            if " join " in stmt:                                  # rows come grouped by owner rank: same multiset
-                a = np.stack([np.asarray(x, dtype=np.int64) for x in gc], axis=1)
-                e = np.stack([np.asarray(x, dtype=np.int64) for x in cols], axis=1)
-                assert np.array_equal(a[np.lexsort(a.T[::-1])], e[np.lexsort(e.T[::-1])]), stmt
-            else:
-                for x, y in zip(gc, cols):
-                    if x.dtype.kind == "f":
-                        assert np.allclose(x, y, rtol=1e-6), stmt
-                    else:
-                        assert np.array_equal(x, y), stmt
+            for x, y in zip(gc, cols):                            # row for row, the join included (reference order, join.fut:52-75)
+                assert x.dtype == y.dtype and len(x) == len(y), stmt
+                if x.dtype.kind == "f":
+                    assert np.allclose(x, y, rtol=1e-6), stmt
+                else:
+                    assert np.array_equal(x, y), stmt
+    for rank in (0, 1):
+        for j in DENSE:
+            assert outs[rank]["paths"][j] == "dense all-reduce", (j, outs[rank]["paths"])
+        assert outs[rank]["paths"][1] == "owner all-to-all"      # negative keys: partial aggregates travel to the owner of hash(key)
+        gx = np.concatenate([np.arange(0, 1000), np.arange(1000, 2024)]).astype(np.int32)
+        gx = gx[(gx % 7) > 5][::-1][:30]
+        assert np.array_equal(outs[rank]["g"][1][0], gx) and np.array_equal(outs[rank]["g"][1][1], (gx % 7).astype(np.float32))
+        ld, lc = outs[rank]["t_local"][1]
+        ed, ec = np.unique(df.d.to_numpy(), return_counts=True)
+        assert np.array_equal(ld, ed.astype(np.int32)) and np.array_equal(lc, ec)
+    # the join against the oracle's reference order as well (ascending u32 key, left row, right row; 18 distinct keys over
+    # 60 000 rows: every key's rows sit on both shards and meet at ONE owner)
+    from oracle import oracle as ora
+    ref = ora.join(df[["k", "w"]].to_numpy().astype(np.int64), b[["x", "y"]].to_numpy().astype(np.int64), 1, 0, [0, 1], [1])
+    for rank in (0, 1):
+        got = outs[rank]["select t.k, b.y, t.w from t join b on t.w = b.x"][1]
+        mine = np.ascontiguousarray(np.stack([got[0], got[2], got[1]], axis=1).astype(np.int32)).view(np.uint32)
+        assert np.array_equal(mine, ref)
     n, G = len(df), 1 << 14
     kk = (np.arange(n, dtype=np.int64) * 2654435761 % G).astype(np.int32)
     keep = df.p.to_numpy() > 0.5
