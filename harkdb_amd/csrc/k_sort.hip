@@ -20,6 +20,7 @@
 //      input order, so the pass is stable.
 #include "hark_internal.h"
 #include "sort_networks.h"
+#include <type_traits>
 
 namespace {
 
@@ -35,7 +36,17 @@ struct GeoLarge { static constexpr int T = 1024, R = 12, PER_CU = 1; };
 constexpr int64_t kLargeSortFrom = (int64_t)1 << 25;
 template <typename GEO> constexpr size_t scatter_lds() { return (size_t)GEO::T * GEO::R * 8 + (size_t)(GEO::T / 64) * kBins * 8 + kBins * 4 + kBins * 8 + 64; }
 
-// slices (= workgroups) of a pass over n keys and the keys per slice (whole tiles)
+// HARK_SORT_TILED=1 selects the scatter kernel of rounds 1-2 (digit_scatter_kernel: ballot match) for A/B runs; the default is
+// digit_scatter2_kernel (LDS match).  Measured and dropped in round 3 (profiles/r03_notes.md): two 512-thread workgroups per
+// CU (either kernel: slower, more output streams), 512 threads x 24 keys, and a kernel that write-combines digit runs across
+// tiles in per-digit LDS rings and stores whole 128-byte lines only (exact HBM traffic, no faster).
+static bool old_scatter()
+{
+    static const bool v = getenv("HARK_SORT_TILED") && atoi(getenv("HARK_SORT_TILED")) == 1;
+    return v;
+}
+
+// slices (= workgroups) of a pass over n keys and the keys per slice (whole tiles; 12288 is a multiple of every large tile)
 static void sort_geometry(int64_t n, int num_cu, bool *large, int64_t *nblk_out, int64_t *slice_out)
 {
     const bool lg = n >= kLargeSortFrom;
@@ -82,17 +93,73 @@ __global__ __launch_bounds__(GEO::T) void digit_hist_kernel(const uint32_t *__re
     const int64_t hi = lo + slice < n ? lo + slice : n;
     const int64_t nvec = (hi - lo) / 4;
     const uint4 *k4 = reinterpret_cast<const uint4 *>(keys + lo);
-    for (int64_t i = threadIdx.x; i < nvec; i += GEO::T) {
-        const uint4 q = k4[i];
+    auto count4 = [&](const uint4 q) {
         atomicAdd(&s_hist[((q.x ^ xor_mask) >> shift) & 255u], 1u);
         atomicAdd(&s_hist[((q.y ^ xor_mask) >> shift) & 255u], 1u);
         atomicAdd(&s_hist[((q.z ^ xor_mask) >> shift) & 255u], 1u);
         atomicAdd(&s_hist[((q.w ^ xor_mask) >> shift) & 255u], 1u);
+    };
+    int64_t i = threadIdx.x;
+    for (; i + 3 * (int64_t)blockDim.x < nvec; i += 4 * (int64_t)blockDim.x) {     // four 16-byte loads in flight per lane (read once: non-temporal)
+        const uint4 a = ld_nt16(k4 + i), b = ld_nt16(k4 + i + blockDim.x), c = ld_nt16(k4 + i + 2 * blockDim.x), d = ld_nt16(k4 + i + 3 * blockDim.x);
+        count4(a); count4(b); count4(c); count4(d);
     }
-    for (int64_t i = lo + nvec * 4 + threadIdx.x; i < hi; i += GEO::T)
+    for (; i < nvec; i += blockDim.x) count4(k4[i]);
+    for (int64_t i = lo + nvec * 4 + threadIdx.x; i < hi; i += blockDim.x)
         atomicAdd(&s_hist[((keys[i] ^ xor_mask) >> shift) & 255u], 1u);
     __syncthreads();
     if (threadIdx.x < kBins) hist[(size_t)threadIdx.x * nblk + blockIdx.x] = s_hist[threadIdx.x];
+}
+
+// All four digit histograms of a slice from ONE read of the keys, and the bits in which any key differs from the first
+// one (a pass over a byte in which all keys agree is skipped): replaces the difference-mask pass AND the histogram launch
+// of the first pass that runs.  hist4[pass][bin][blk].
+__global__ __launch_bounds__(1024) void multi_hist_kernel(const uint32_t *__restrict__ keys, int64_t n, int64_t slice, uint32_t xor_mask,
+                                                          uint32_t *__restrict__ hist4, int nblk, uint32_t *__restrict__ diff)
+{
+    __shared__ uint32_t s_hist[4][kBins];
+    __shared__ uint32_t s_acc;
+    for (int i = threadIdx.x; i < 4 * kBins; i += blockDim.x) (&s_hist[0][0])[i] = 0u;
+    if (threadIdx.x == 0) s_acc = 0u;
+    __syncthreads();
+    const int64_t lo = (int64_t)blockIdx.x * slice;
+    const int64_t hi = lo + slice < n ? lo + slice : n;
+    const int64_t nvec = (hi - lo) / 4;
+    const uint4 *k4 = reinterpret_cast<const uint4 *>(keys + lo);
+    const uint32_t w0 = keys[0];
+    uint32_t acc = 0u;
+    // A digit in which every key of the wave agrees (the high bytes of small keys: 64 lanes adding to ONE counter serialise,
+    // 437 us per 1e8 20-bit keys) is counted by one lane.
+    auto count1 = [&](uint32_t k) {
+        acc |= k ^ w0;
+        const uint32_t x = k ^ xor_mask;
+        const uint32_t t = x ^ (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
+        const uint32_t nact = (uint32_t)__popcll(__ballot(true));
+        const bool leader = (__ballot(true) & lanemask_lt()) == 0ull;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t d = (x >> (8 * j)) & 255u;
+            if (__ballot((t >> (8 * j)) & 255u) == 0ull) { if (leader) atomicAdd(&s_hist[j][d], nact); }
+            else atomicAdd(&s_hist[j][d], 1u);
+        }
+    };
+    auto count4 = [&](const uint4 q) { count1(q.x); count1(q.y); count1(q.z); count1(q.w); };
+    int64_t i = threadIdx.x;
+    for (; i + (int64_t)blockDim.x < nvec; i += 2 * (int64_t)blockDim.x) {
+        const uint4 a = ld_nt16(k4 + i), b = ld_nt16(k4 + i + blockDim.x);
+        count4(a); count4(b);
+    }
+    for (; i < nvec; i += blockDim.x) count4(k4[i]);
+    for (int64_t j = lo + nvec * 4 + threadIdx.x; j < hi; j += blockDim.x) count1(keys[j]);
+    for (int d = 32; d > 0; d >>= 1) acc |= __shfl_xor(acc, d, 64);
+    if ((threadIdx.x & 63) == 0 && acc) atomicOr(&s_acc, acc);
+    __syncthreads();
+    for (int i2 = threadIdx.x; i2 < 4 * kBins; i2 += blockDim.x)
+        hist4[((size_t)(i2 >> 8) * kBins + (size_t)(i2 & 255)) * nblk + blockIdx.x] = (&s_hist[0][0])[i2];
+    if (threadIdx.x == 0) {
+        const uint32_t mine = s_acc;
+        if (mine & ~__hip_atomic_load(diff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(diff, mine);
+    }
 }
 
 // Exclusive scan of each digit's row hist[d][0..nblk) (one workgroup per digit)
@@ -252,6 +319,187 @@ __global__ __launch_bounds__(GEO::T) void digit_scatter_kernel(
     }
 }
 
+// Inclusive prefix sum over the 64 lanes of a wave with DPP row shifts and broadcasts (gfx9 family): six vector adds with
+// the data movement folded in -- no cross-lane index registers, which a shuffle-based scan keeps live (and spilled: they
+// are loop invariants) across a whole kernel.
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);     // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);     // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);     // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);     // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);     // row_bcast:15 -> rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);     // row_bcast:31 -> rows 2 and 3
+    return v;
+}
+
+// ---- the pass for large inputs, second edition ----------------------------------------------------------------------
+// PMC counters of digit_scatter_kernel<GeoLarge> (profiles/r03_notes.md): 216 M vector instructions per 1e8-key pass
+// -- 138 per 64 keys -- keep the four SIMDs of a CU busy for 0.35 of the pass's 0.46 ms: the pass is bound by instruction
+// issue, not by its 16 B per key.  Most of them are the ballot match (eight ballots whose per-lane 64-bit selects are
+// vector instructions) and 64-bit position arithmetic.  Here
+//   * the lanes of a wave that share a digit are found through LDS: every lane ORs its lane bit into a per-wave table of
+//     256 64-bit masks (ds_or_b64), reads its digit's mask back and clears it -- three LDS instructions instead of ~56
+//     vector ones, and still a pure function of the digits (a set union: no ordering assumption on the atomics);
+//   * keys and payloads are staged as one 8-byte word, positions are 32-bit (n < 2^32), and the write-out needs ONE table
+//     read per key (delta[d] = first output position of the digit - its start in the tile);
+//   * validity tests only run in a slice's last tile.
+// Same result as digit_scatter_kernel (positions are assigned in input order: stable).
+template <typename GEO> constexpr size_t scatter2_lds()
+{
+    return (size_t)GEO::T * GEO::R * 8 + (size_t)(GEO::T / 64) * kBins * 8 + (size_t)(GEO::T / 64) * kBins * 2 * 2 + (size_t)kBins * 4 * 3 + 64;
+}
+template <typename GEO, bool IOTA>
+__global__ __launch_bounds__(GEO::T) void digit_scatter2_kernel(
+    const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+    uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
+    int64_t n, int64_t slice, int shift, uint32_t xor_mask, const uint32_t *__restrict__ hist, int nblk,
+    const uint32_t *__restrict__ row_total)
+{
+    constexpr int T = GEO::T, W = GEO::T / 64, R = GEO::R, TILE = GEO::T * GEO::R;
+    typedef unsigned long long u64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sort_lds[];
+    uint2 *s_kv = reinterpret_cast<uint2 *>(sort_lds);                              // [TILE] (key, payload), digit-sorted
+    u64 *s_mask = reinterpret_cast<u64 *>(s_kv + TILE);                             // [W][bins] lanes of the wave holding the digit (all zero between rounds)
+    uint16_t (*s_wcnt)[kBins] = reinterpret_cast<uint16_t (*)[kBins]>(s_mask + (size_t)W * kBins);   // [W][bins] per-wave digit counts of the tile
+    uint16_t (*s_wbase)[kBins] = s_wcnt + W;                                        // [W][bins] tile-local start of (wave, digit) within the digit
+    uint32_t *s_tstart = reinterpret_cast<uint32_t *>(s_wbase + W);                 // [bins] start of the digit in the tile
+    uint32_t *s_delta = s_tstart + kBins;                                           // [bins] output position of the digit's next key - s_tstart
+    uint32_t *s_gpos = s_delta + kBins;                                             // [bins] output position of the digit's next key
+    uint32_t *s_scan = s_gpos + kBins;                                              // [16]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t lo = (int64_t)blockIdx.x * slice;
+    const int64_t hi = lo + slice < n ? lo + slice : n;
+    for (int i = tid; i < W * kBins; i += T) s_mask[i] = 0ull;
+    {   // first output position of (digit tid, this slice) = digits before + this digit's earlier slices
+        const uint32_t tot = tid < kBins ? row_total[tid] : 0u;
+        const uint32_t incl = wave_incl_scan(tot);
+        if (lane == 63 && tid < kBins) s_scan[wave] = incl;
+        __syncthreads();
+        if (tid < kBins) {
+            uint32_t carry = 0;
+            for (int w = 0; w < wave; w++) carry += s_scan[w];
+            s_gpos[tid] = carry + incl - tot + hist[(size_t)tid * nblk + blockIdx.x];
+        }
+        __syncthreads();
+    }
+    const u64 lanebit = 1ull << lane, lt = lanemask_lt();
+    u64 *mymask = s_mask + (size_t)wave * kBins;                  // (not volatile: the address-space inference skips volatile accesses -> FLAT instructions)
+    uint16_t *mycnt = s_wcnt[wave];
+    uint32_t nkey[R];
+    // One tile.  FULL (every tile but a slice's last, ragged one) carries no validity tests and a FIXED number of loads and
+    // stores per lane, so that the compiler can count them: loads and stores share one in-order counter on gfx950, and with
+    // a countable stream the wait for the prefetched keys leaves the previous tile's 2 x R stores in flight (s_waitcnt
+    // vmcnt(n) instead of vmcnt(0)) -- they drain under this tile's ranking.  The ragged tile is peeled out of the loop
+    // for the same reason (a path with an unknown number of stores into the loop head would force vmcnt(0) there).
+    auto tile = [&](int64_t tbase, auto full_tag, auto next_tag) {
+        constexpr bool FULL = decltype(full_tag)::value, NEXT_FULL = decltype(next_tag)::value;
+        const int64_t wbase = tbase + (int64_t)wave * (64 * R);
+        uint32_t key[R], val[R], rank[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) key[r] = nkey[r];
+        // the wave's own row of digit counts (its readers of the previous tile passed that tile's second barrier)
+        reinterpret_cast<uint2 *>(mycnt)[lane] = uint2{0u, 0u};
+        // ---- rank inside the wave's contiguous chunk: lanes with my digit = the mask the wave ORs together in LDS ------
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const bool valid = FULL || wbase + r * 64 + lane < hi;
+            const uint32_t d = ((key[r] ^ xor_mask) >> shift) & 255u;
+            rank[r] = 0xFFFFFFFFu;
+            if (valid) {
+                // relaxed atomics keep the three accesses in program order for the compiler; the LDS executes a wave's
+                // instructions in order, so the read sees the whole wave's ORs and the clear follows every lane's read
+                __hip_atomic_fetch_or(mymask + d, lanebit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);      // ds_or_b64
+                const u64 peers = __hip_atomic_load(mymask + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); // ds_read_b64
+                __hip_atomic_store(mymask + d, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);            // clean again for the next round
+                const u64 below = peers & lt;
+                const uint32_t before = mycnt[d];
+                rank[r] = before + (uint32_t)__popcll(below);
+                if (below == 0ull) mycnt[d] = (uint16_t)(before + (uint32_t)__popcll(peers));
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        // this tile's payloads (first needed when the keys are staged) and the next tile's keys travel under the rest of the tile
+        if (IOTA) {
+#pragma unroll
+            for (int r = 0; r < R; r++) val[r] = (uint32_t)(wbase + r * 64 + lane);
+        } else if (FULL) {
+            const uint32_t *src = vals_in + wbase + lane;
+#pragma unroll
+            for (int r = 0; r < R; r++) val[r] = __builtin_nontemporal_load(src + r * 64);
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; r++) { const int64_t i = wbase + r * 64 + lane; val[r] = vals_in[i < hi ? i : hi - 1]; }
+        }
+        if (NEXT_FULL) {                                            // the steady state: no clamping, immediate offsets
+            const uint32_t *src = keys_in + wbase + TILE + lane;
+#pragma unroll
+            for (int r = 0; r < R; r++) nkey[r] = __builtin_nontemporal_load(src + r * 64);
+        } else if (FULL && tbase + TILE < hi) {                     // a ragged tile follows (once per slice): clamped addresses
+            for (int r = 0; r < R; r++) { const int64_t i = wbase + TILE + r * 64 + lane; nkey[r] = keys_in[i < hi ? i : hi - 1]; }
+        }
+        lds_barrier();
+        // ---- chain the waves, lay the digits out in the tile ----------------------------------------------------------
+        uint32_t tcnt = 0, incl = 0;
+        if (tid < kBins) {
+            uint32_t run = 0;
+#pragma unroll
+            for (int w = 0; w < W; w++) { s_wbase[w][tid] = (uint16_t)run; run += s_wcnt[w][tid]; }
+            tcnt = run;
+            incl = wave_incl_scan(tcnt);                             // (all 64 lanes of the four digit waves are active here)
+            if (lane == 63) s_scan[wave] = incl;
+        }
+        lds_barrier();
+        if (tid < kBins) {
+            uint32_t carry = 0;
+            for (int w = 0; w < wave; w++) carry += s_scan[w];
+            const uint32_t ts = carry + incl - tcnt, gp = s_gpos[tid];
+            s_tstart[tid] = ts;
+            s_delta[tid] = gp - ts;                                  // wraps; slot + delta is the output position
+            s_gpos[tid] = gp + tcnt;
+        }
+        lds_barrier();
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            if (FULL || rank[r] != 0xFFFFFFFFu) {
+                const uint32_t d = ((key[r] ^ xor_mask) >> shift) & 255u;
+                s_kv[s_tstart[d] + (uint32_t)s_wbase[wave][d] + rank[r]] = uint2{key[r], val[r]};
+            }
+        }
+        lds_barrier();
+        // ---- write digit runs --------------------------------------------------------------------------------------------
+        if (FULL) {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int slot = tid + r * T;
+                const uint2 kv = s_kv[slot];
+                const uint32_t pos = (uint32_t)slot + s_delta[((kv.x ^ xor_mask) >> shift) & 255u];
+                keys_out[pos] = kv.x; vals_out[pos] = kv.y;
+                if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four keys at a time: the scheduler would otherwise keep all R
+            }                                                           // iterations' words, positions and addresses live at once (spills)
+        } else {
+            const int tile_n = (int)(hi - tbase);
+            for (int slot = tid; slot < tile_n; slot += T) {
+                const uint2 kv = s_kv[slot];
+                const uint32_t pos = (uint32_t)slot + s_delta[((kv.x ^ xor_mask) >> shift) & 255u];
+                keys_out[pos] = kv.x; vals_out[pos] = kv.y;
+            }
+        }
+        // (the next tile's first barrier comes after its ranking, which touches neither s_kv nor the digit tables)
+    };
+    {   // the first tile's keys
+        const int64_t wb = lo + (int64_t)wave * (64 * R);
+#pragma unroll
+        for (int r = 0; r < R; r++) { const int64_t i = wb + r * 64 + lane; nkey[r] = keys_in[i < hi ? i : hi - 1]; }
+    }
+    // the steady state (a full tile followed by a full tile) is a loop of its own; the slice's last full tile and its ragged
+    // tail are peeled, so that no clamped-address arithmetic and no uncountable store loop sit on the hot path
+    int64_t tbase = lo;
+    for (; tbase + 2 * (int64_t)TILE <= hi; tbase += TILE) tile(tbase, std::true_type{}, std::true_type{});
+    if (tbase + TILE <= hi) { tile(tbase, std::true_type{}, std::false_type{}); tbase += TILE; }
+    if (tbase < hi) tile(tbase, std::false_type{}, std::false_type{});
+}
+
 // Order-preserving 32-bit sort word of a 4-byte key: unsigned order of the words = the column's own order
 // (u32 unsigned, i32 signed, f32 IEEE with -0.0 == +0.0 and every NaN after +inf, numpy's order).
 __device__ __forceinline__ uint32_t sort_word_of(uint32_t w, int dtype)
@@ -401,32 +649,45 @@ static int64_t grid256(hark_context *ctx, int64_t n)
 // four) that hold the result.  n < 2^32.
 int k_sort_pairs_u32(hark_context *ctx, uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, uint32_t *vals_b,
                      const uint32_t *vals_first, int64_t n, uint32_t xor_mask, uint32_t *hist_ws, uint32_t pass_mask,
-                     uint32_t **keys_out, uint32_t **vals_out, const uint32_t *keys_first = nullptr)
+                     uint32_t **keys_out, uint32_t **vals_out, const uint32_t *keys_first = nullptr, uint32_t *hist4 = nullptr)
 {
+    // hist4 (optional): the per-slice histograms of all four digits of the INPUT keys (k_multi_hist, same geometry and
+    // xor_mask): the first pass that runs takes its histogram from there instead of reading the keys again
     *keys_out = keys_a; *vals_out = vals_a;
     if (n <= 0) return HARK_OK;
     if (n > 0xFFFFFFFFll) return hark_fail(ctx, HARK_EARG, "sort: at most 2^32-1 rows");
     bool large; int64_t nblk, slice;
     sort_geometry(n, ctx->num_cu, &large, &nblk, &slice);
     hipStream_t st = ctx->stream;
-    if (large) {
-        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&digit_scatter_kernel<GeoLarge, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_lds<GeoLarge>()));
-        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&digit_scatter_kernel<GeoLarge, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_lds<GeoLarge>()));
-    }
     const uint32_t *kin = keys_first ? keys_first : keys_a, *vin = vals_first;
     uint32_t *kout = keys_first ? keys_a : keys_b, *vout = vals_b;   // a read-only input leaves both scratch buffers free
     bool first = true;
     for (int pass = 0; pass < 4; pass++) {
         if (!((pass_mask >> pass) & 1u)) continue;
         const int shift = pass * 8;
-        if (large) digit_hist_kernel<GeoLarge><<<dim3((unsigned)nblk), dim3(GeoLarge::T), 0, st>>>(kin, n, slice, shift, xor_mask, hist_ws, (int)nblk);
+        uint32_t *hist_in = hist_ws;                                  // [bins][nblk], scanned in place; the digit totals go to hist_ws + bins * nblk
+        if (first && hist4) hist_in = hist4 + (size_t)pass * kBins * nblk;
+        else
+        if (large) digit_hist_kernel<GeoLarge><<<dim3((unsigned)nblk), dim3(GeoLarge::T / (nblk > ctx->num_cu ? 2 : 1)), 0, st>>>(kin, n, slice, shift, xor_mask, hist_ws, (int)nblk);
         else digit_hist_kernel<GeoSmall><<<dim3((unsigned)nblk), dim3(GeoSmall::T), 0, st>>>(kin, n, slice, shift, xor_mask, hist_ws, (int)nblk);
-        scan_hist_rows_kernel<<<kBins, 256, 0, st>>>(hist_ws, (int)nblk, hist_ws + (size_t)kBins * nblk);
+        scan_hist_rows_kernel<<<kBins, 256, 0, st>>>(hist_in, (int)nblk, hist_ws + (size_t)kBins * nblk);
         const uint32_t *tot = hist_ws + (size_t)kBins * nblk;
-        if (large && vin) digit_scatter_kernel<GeoLarge, false><<<dim3((unsigned)nblk), dim3(GeoLarge::T), scatter_lds<GeoLarge>(), st>>>(kin, vin, kout, vout, n, slice, shift, xor_mask, hist_ws, (int)nblk, tot);
-        else if (large) digit_scatter_kernel<GeoLarge, true><<<dim3((unsigned)nblk), dim3(GeoLarge::T), scatter_lds<GeoLarge>(), st>>>(kin, vin, kout, vout, n, slice, shift, xor_mask, hist_ws, (int)nblk, tot);
-        else if (vin) digit_scatter_kernel<GeoSmall, false><<<dim3((unsigned)nblk), dim3(GeoSmall::T), scatter_lds<GeoSmall>(), st>>>(kin, vin, kout, vout, n, slice, shift, xor_mask, hist_ws, (int)nblk, tot);
-        else digit_scatter_kernel<GeoSmall, true><<<dim3((unsigned)nblk), dim3(GeoSmall::T), scatter_lds<GeoSmall>(), st>>>(kin, vin, kout, vout, n, slice, shift, xor_mask, hist_ws, (int)nblk, tot);
+        // one launcher for every scatter kernel: KERNEL<IOTA> with `threads` threads and `lds` bytes of dynamic LDS
+#define HARK_SCATTER(KERNEL_T, KERNEL_F, threads, lds)                                                                              \
+        do {                                                                                                                        \
+            if ((lds) > 64 * 1024) {                                                                                                \
+                HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&KERNEL_F), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds))); \
+                HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&KERNEL_T), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds))); \
+            }                                                                                                                       \
+            if (vin) KERNEL_F<<<dim3((unsigned)nblk), dim3(threads), (lds), st>>>(kin, vin, kout, vout, n, slice, shift, xor_mask, hist_in, (int)nblk, tot); \
+            else KERNEL_T<<<dim3((unsigned)nblk), dim3(threads), (lds), st>>>(kin, vin, kout, vout, n, slice, shift, xor_mask, hist_in, (int)nblk, tot);     \
+        } while (0)
+        if (old_scatter()) {
+            if (large) HARK_SCATTER((digit_scatter_kernel<GeoLarge, true>), (digit_scatter_kernel<GeoLarge, false>), GeoLarge::T, scatter_lds<GeoLarge>());
+            else HARK_SCATTER((digit_scatter_kernel<GeoSmall, true>), (digit_scatter_kernel<GeoSmall, false>), GeoSmall::T, scatter_lds<GeoSmall>());
+        } else if (large) HARK_SCATTER((digit_scatter2_kernel<GeoLarge, true>), (digit_scatter2_kernel<GeoLarge, false>), GeoLarge::T, scatter2_lds<GeoLarge>());
+        else HARK_SCATTER((digit_scatter2_kernel<GeoSmall, true>), (digit_scatter2_kernel<GeoSmall, false>), GeoSmall::T, scatter2_lds<GeoSmall>());
+#undef HARK_SCATTER
         HIP_TRY(ctx, hipGetLastError());
         *keys_out = kout; *vals_out = vout;
         kin = kout; vin = vout;
@@ -457,6 +718,29 @@ int k_transform_keys(hark_context *ctx, const void *src, int dtype, int part, ui
     if (!rc && diff_host) { int64_t w = 0; rc = hark_read_words(ctx, diff, &w, 1); *diff_host = (uint32_t)w; }
     if (diff) hark_free(ctx, diff);
     return rc;
+}
+
+// hist4 (pool block, caller frees) = per-slice histograms of all four digits of `keys` ^ xor_mask; *diff_host = the bits in
+// which the keys differ.  One read of the keys, one host synchronisation.
+static int k_multi_hist(hark_context *ctx, const uint32_t *keys, int64_t n, uint32_t xor_mask, uint32_t **hist4_out, uint32_t *diff_host)
+{
+    *hist4_out = nullptr; *diff_host = 0u;
+    bool large; int64_t nblk, slice;
+    sort_geometry(n, ctx->num_cu, &large, &nblk, &slice);
+    uint32_t *h4 = nullptr, *diff = nullptr;
+    HARK_TRY(hark_alloc(ctx, (void **)&h4, (size_t)4 * kBins * nblk * sizeof(uint32_t)));
+    int rc = hark_alloc(ctx, (void **)&diff, 16);
+    if (!rc && hipMemsetAsync(diff, 0, 16, ctx->stream) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "sort: memset failed");
+    if (!rc) {
+        multi_hist_kernel<<<dim3((unsigned)nblk), dim3(large ? 1024 : 256), 0, ctx->stream>>>(keys, n, slice, xor_mask, h4, (int)nblk, diff);
+        if (hipGetLastError() != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "sort: histogram launch failed");
+    }
+    int64_t w = 0;
+    if (!rc) rc = hark_read_words(ctx, diff, &w, 1);
+    hark_free(ctx, diff);
+    if (rc) { hark_free(ctx, h4); return rc; }
+    *hist4_out = h4; *diff_host = (uint32_t)w;
+    return HARK_OK;
 }
 
 static uint32_t passes_of(uint32_t diff)
@@ -501,9 +785,11 @@ static int k_sort_column_lsd(hark_context *ctx, const void *col, int dtype, int6
     if (dtype == HARK_U32 || dtype == HARK_I32) {
         // integer keys are sorted as they are: the sign flip of i32 is part of the digit mask, the first pass reads the
         // column itself, and the sorted "words" are the sorted column values (no transform pass, no inverse)
-        if (!rc) rc = k_transform_keys(ctx, col, HARK_U32, 0, nullptr, n, &diff);          // difference mask only
-        if (!rc) rc = k_sort_pairs_u32(ctx, k0, k1, v0, v1, payload, n, xm ^ (dtype == HARK_I32 ? 0x80000000u : 0u), ws, passes_of(diff), &ko, &vo,
-                                       static_cast<const uint32_t *>(col));
+        const uint32_t xk = xm ^ (dtype == HARK_I32 ? 0x80000000u : 0u);
+        uint32_t *h4 = nullptr;
+        if (!rc) rc = k_multi_hist(ctx, static_cast<const uint32_t *>(col), n, xk, &h4, &diff);   // difference mask + every digit's histograms: one read
+        if (!rc) rc = k_sort_pairs_u32(ctx, k0, k1, v0, v1, payload, n, xk, ws, passes_of(diff), &ko, &vo, static_cast<const uint32_t *>(col), h4);
+        hark_free(ctx, h4);                                          // (stream-ordered reuse: the passes are enqueued)
     } else {
         if (!rc) rc = k_transform_keys(ctx, col, dtype, 0, k0, n, &diff);
         if (!rc) rc = k_sort_pairs_u32(ctx, k0, k1, v0, v1, payload, n, xm, ws, passes_of(diff), &ko, &vo);
