@@ -40,6 +40,29 @@ template <typename GEO> constexpr size_t scatter_lds() { return (size_t)GEO::T *
 // digit_scatter2_kernel (LDS match).  Measured and dropped in round 3 (profiles/r03_notes.md): two 512-thread workgroups per
 // CU (either kernel: slower, more output streams), 512 threads x 24 keys, and a kernel that write-combines digit runs across
 // tiles in per-digit LDS rings and stores whole 128-byte lines only (exact HBM traffic, no faster).
+// The passes that sort keys differing in the bits of `diff`.  Byte plan: one 8-bit pass per key byte with a differing bit
+// (any holes in the mask are skipped).  Range plan: the differing bits span [lo, hi] -> ceil(bits / 8) passes over digits
+// of EQUAL width (20 bits: 7 + 7 + 6 instead of 8 + 8 + 4; bits 4..19: two passes where the byte plan needs three).  The range
+// plan is taken when it needs fewer passes, or as many with narrower digits (fewer, longer digit runs per tile;
+// HARK_SORT_PLAN=byte switches it off for A/B runs).
+struct SortPass { int shift, width; };
+static int plan_passes(uint32_t diff, SortPass *out)
+{
+    if (!diff) return 0;
+    int nb = 0;
+    SortPass bytes[4];
+    for (int b = 0; b < 4; b++) if ((diff >> (8 * b)) & 0xFFu) bytes[nb++] = SortPass{8 * b, 8};
+    const int lo = __builtin_ctz(diff), hi = 31 - __builtin_clz(diff), bits = hi - lo + 1;
+    const int P = (bits + 7) / 8, w = (bits + P - 1) / P;
+    static const bool byte_only = getenv("HARK_SORT_PLAN") && !strcmp(getenv("HARK_SORT_PLAN"), "byte");
+    if (!byte_only && (P < nb || (P == nb && w < 8))) {
+        for (int i = 0; i < P; i++) { const int sh = lo + i * w, left = hi + 1 - sh; out[i] = SortPass{sh, left < w ? left : w}; }
+        return P;
+    }
+    for (int i = 0; i < nb; i++) out[i] = bytes[i];
+    return nb;
+}
+
 static bool old_scatter()
 {
     static const bool v = getenv("HARK_SORT_TILED") && atoi(getenv("HARK_SORT_TILED")) == 1;
@@ -84,6 +107,8 @@ template <typename GEO>
 __global__ __launch_bounds__(GEO::T) void digit_hist_kernel(const uint32_t *__restrict__ keys, int64_t n, int64_t slice,
                                                                   int shift, uint32_t xor_mask, uint32_t *__restrict__ hist, int nblk)
 {
+    const int sh = shift & 255;                                   // `shift` carries the digit's width in bits 8.. (0 = 8 bits)
+    const uint32_t dmask = (shift >> 8) ? (1u << (shift >> 8)) - 1u : 255u;
     // plain ds_add_u32 per key (~10 lanes/clk/CU on gfx950); the slice starts on a
     // multiple of 4096 keys, so 16-byte loads are aligned
     __shared__ uint32_t s_hist[kBins];
@@ -94,10 +119,10 @@ __global__ __launch_bounds__(GEO::T) void digit_hist_kernel(const uint32_t *__re
     const int64_t nvec = (hi - lo) / 4;
     const uint4 *k4 = reinterpret_cast<const uint4 *>(keys + lo);
     auto count4 = [&](const uint4 q) {
-        atomicAdd(&s_hist[((q.x ^ xor_mask) >> shift) & 255u], 1u);
-        atomicAdd(&s_hist[((q.y ^ xor_mask) >> shift) & 255u], 1u);
-        atomicAdd(&s_hist[((q.z ^ xor_mask) >> shift) & 255u], 1u);
-        atomicAdd(&s_hist[((q.w ^ xor_mask) >> shift) & 255u], 1u);
+        atomicAdd(&s_hist[((q.x ^ xor_mask) >> sh) & dmask], 1u);
+        atomicAdd(&s_hist[((q.y ^ xor_mask) >> sh) & dmask], 1u);
+        atomicAdd(&s_hist[((q.z ^ xor_mask) >> sh) & dmask], 1u);
+        atomicAdd(&s_hist[((q.w ^ xor_mask) >> sh) & dmask], 1u);
     };
     int64_t i = threadIdx.x;
     for (; i + 3 * (int64_t)blockDim.x < nvec; i += 4 * (int64_t)blockDim.x) {     // four 16-byte loads in flight per lane (read once: non-temporal)
@@ -106,7 +131,7 @@ __global__ __launch_bounds__(GEO::T) void digit_hist_kernel(const uint32_t *__re
     }
     for (; i < nvec; i += blockDim.x) count4(k4[i]);
     for (int64_t i = lo + nvec * 4 + threadIdx.x; i < hi; i += blockDim.x)
-        atomicAdd(&s_hist[((keys[i] ^ xor_mask) >> shift) & 255u], 1u);
+        atomicAdd(&s_hist[((keys[i] ^ xor_mask) >> sh) & dmask], 1u);
     __syncthreads();
     if (threadIdx.x < kBins) hist[(size_t)threadIdx.x * nblk + blockIdx.x] = s_hist[threadIdx.x];
 }
@@ -203,6 +228,8 @@ __global__ __launch_bounds__(GEO::T) void digit_scatter_kernel(
     int64_t n, int64_t slice, int shift, uint32_t xor_mask, const uint32_t *__restrict__ hist, int nblk,
     const uint32_t *__restrict__ row_total)
 {
+    const int sh = shift & 255;                                   // `shift` carries the digit's width in bits 8.. (0 = 8 bits)
+    const uint32_t dmask = (shift >> 8) ? (1u << (shift >> 8)) - 1u : 255u;
     constexpr int kSortThreads = GEO::T, kSortWaves = GEO::T / 64, kRounds = GEO::R, kSortTile = GEO::T * GEO::R;
     extern __shared__ __attribute__((aligned(16))) unsigned char sort_lds[];
     uint32_t *s_key = reinterpret_cast<uint32_t *>(sort_lds);                         // [kSortTile]
@@ -265,7 +292,7 @@ __global__ __launch_bounds__(GEO::T) void digit_scatter_kernel(
 #pragma unroll
         for (int r = 0; r < kRounds; r++) {
             const bool valid = rank[r] != 0xFFFFFFFFu;
-            const uint32_t d = ((key[r] ^ xor_mask) >> shift) & 255u;
+            const uint32_t d = ((key[r] ^ xor_mask) >> sh) & dmask;
             const uint64_t peers = match_digit(d, valid);
             if (valid) {
                 const uint32_t before = s_wcnt[wave][d];            // count from earlier rounds (wave-private row)
@@ -299,7 +326,7 @@ __global__ __launch_bounds__(GEO::T) void digit_scatter_kernel(
 #pragma unroll
         for (int r = 0; r < kRounds; r++) {
             if (rank[r] != 0xFFFFFFFFu) {
-                const uint32_t d = ((key[r] ^ xor_mask) >> shift) & 255u;
+                const uint32_t d = ((key[r] ^ xor_mask) >> sh) & dmask;
                 const uint32_t slot = s_tstart[d] + s_wbase[wave][d] + rank[r];
                 s_key[slot] = key[r]; s_val[slot] = val[r];
             }
@@ -309,7 +336,7 @@ __global__ __launch_bounds__(GEO::T) void digit_scatter_kernel(
         const int tile_n = (int)((hi - tbase) < kSortTile ? (hi - tbase) : kSortTile);
         for (int slot = tid; slot < tile_n; slot += kSortThreads) {
             const uint32_t kk = s_key[slot];
-            const uint32_t d = ((kk ^ xor_mask) >> shift) & 255u;
+            const uint32_t d = ((kk ^ xor_mask) >> sh) & dmask;
             const int64_t pos = s_gpos[d] + (slot - (int)s_tstart[d]);
             keys_out[pos] = kk; vals_out[pos] = s_val[slot];
         }
@@ -356,6 +383,8 @@ __global__ __launch_bounds__(GEO::T) void digit_scatter2_kernel(
     int64_t n, int64_t slice, int shift, uint32_t xor_mask, const uint32_t *__restrict__ hist, int nblk,
     const uint32_t *__restrict__ row_total)
 {
+    const int sh = shift & 255;                                   // `shift` carries the digit's width in bits 8.. (0 = 8 bits)
+    const uint32_t dmask = (shift >> 8) ? (1u << (shift >> 8)) - 1u : 255u;
     constexpr int T = GEO::T, W = GEO::T / 64, R = GEO::R, TILE = GEO::T * GEO::R;
     typedef unsigned long long u64;
     extern __shared__ __attribute__((aligned(16))) unsigned char sort_lds[];
@@ -404,7 +433,7 @@ __global__ __launch_bounds__(GEO::T) void digit_scatter2_kernel(
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const bool valid = FULL || wbase + r * 64 + lane < hi;
-            const uint32_t d = ((key[r] ^ xor_mask) >> shift) & 255u;
+            const uint32_t d = ((key[r] ^ xor_mask) >> sh) & dmask;
             rank[r] = 0xFFFFFFFFu;
             if (valid) {
                 // relaxed atomics keep the three accesses in program order for the compiler; the LDS executes a wave's
@@ -462,7 +491,7 @@ __global__ __launch_bounds__(GEO::T) void digit_scatter2_kernel(
 #pragma unroll
         for (int r = 0; r < R; r++) {
             if (FULL || rank[r] != 0xFFFFFFFFu) {
-                const uint32_t d = ((key[r] ^ xor_mask) >> shift) & 255u;
+                const uint32_t d = ((key[r] ^ xor_mask) >> sh) & dmask;
                 s_kv[s_tstart[d] + (uint32_t)s_wbase[wave][d] + rank[r]] = uint2{key[r], val[r]};
             }
         }
@@ -473,7 +502,7 @@ __global__ __launch_bounds__(GEO::T) void digit_scatter2_kernel(
             for (int r = 0; r < R; r++) {
                 const int slot = tid + r * T;
                 const uint2 kv = s_kv[slot];
-                const uint32_t pos = (uint32_t)slot + s_delta[((kv.x ^ xor_mask) >> shift) & 255u];
+                const uint32_t pos = (uint32_t)slot + s_delta[((kv.x ^ xor_mask) >> sh) & dmask];
                 keys_out[pos] = kv.x; vals_out[pos] = kv.y;
                 if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four keys at a time: the scheduler would otherwise keep all R
             }                                                           // iterations' words, positions and addresses live at once (spills)
@@ -481,7 +510,7 @@ __global__ __launch_bounds__(GEO::T) void digit_scatter2_kernel(
             const int tile_n = (int)(hi - tbase);
             for (int slot = tid; slot < tile_n; slot += T) {
                 const uint2 kv = s_kv[slot];
-                const uint32_t pos = (uint32_t)slot + s_delta[((kv.x ^ xor_mask) >> shift) & 255u];
+                const uint32_t pos = (uint32_t)slot + s_delta[((kv.x ^ xor_mask) >> sh) & dmask];
                 keys_out[pos] = kv.x; vals_out[pos] = kv.y;
             }
         }
@@ -644,8 +673,9 @@ static int64_t grid256(hark_context *ctx, int64_t n)
 // Stable sort of n (key, val) pairs ascending by (key ^ xor_mask) as unsigned.  The input keys are `keys_first`
 // (device, read only, may be a table column) or, when that is null, the contents of keys_a; keys_a, keys_b,
 // vals_a, vals_b are scratch of the same size.  The payload of the input is `vals_first` (device, read
-// only, may be a table column) or, when null, the input position.  Only the 8-bit passes whose bit is set in
-// pass_mask run (bit b = byte b of the key).  On return *keys_out / *vals_out point at the buffers (among the
+// only, may be a table column) or, when null, the input position.  `pass_mask` is the DIFFERENCE MASK of the keys (the
+// bits in which any two of them differ): plan_passes turns it into at most four stable passes over digits of at most
+// eight bits that cover every differing bit.  On return *keys_out / *vals_out point at the buffers (among the
 // four) that hold the result.  n < 2^32.
 int k_sort_pairs_u32(hark_context *ctx, uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, uint32_t *vals_b,
                      const uint32_t *vals_first, int64_t n, uint32_t xor_mask, uint32_t *hist_ws, uint32_t pass_mask,
@@ -662,11 +692,12 @@ int k_sort_pairs_u32(hark_context *ctx, uint32_t *keys_a, uint32_t *keys_b, uint
     const uint32_t *kin = keys_first ? keys_first : keys_a, *vin = vals_first;
     uint32_t *kout = keys_first ? keys_a : keys_b, *vout = vals_b;   // a read-only input leaves both scratch buffers free
     bool first = true;
-    for (int pass = 0; pass < 4; pass++) {
-        if (!((pass_mask >> pass) & 1u)) continue;
-        const int shift = pass * 8;
+    SortPass plan[4];
+    const int npass = plan_passes(pass_mask, plan);
+    for (int pi = 0; pi < npass; pi++) {
+        const int shift = plan[pi].shift | (plan[pi].width << 8);
         uint32_t *hist_in = hist_ws;                                  // [bins][nblk], scanned in place; the digit totals go to hist_ws + bins * nblk
-        if (first && hist4) hist_in = hist4 + (size_t)pass * kBins * nblk;
+        if (first && hist4 && plan[pi].width == 8 && plan[pi].shift % 8 == 0) hist_in = hist4 + (size_t)(plan[pi].shift / 8) * kBins * nblk;
         else
         if (large) digit_hist_kernel<GeoLarge><<<dim3((unsigned)nblk), dim3(GeoLarge::T / (nblk > ctx->num_cu ? 2 : 1)), 0, st>>>(kin, n, slice, shift, xor_mask, hist_ws, (int)nblk);
         else digit_hist_kernel<GeoSmall><<<dim3((unsigned)nblk), dim3(GeoSmall::T), 0, st>>>(kin, n, slice, shift, xor_mask, hist_ws, (int)nblk);
@@ -788,11 +819,11 @@ static int k_sort_column_lsd(hark_context *ctx, const void *col, int dtype, int6
         const uint32_t xk = xm ^ (dtype == HARK_I32 ? 0x80000000u : 0u);
         uint32_t *h4 = nullptr;
         if (!rc) rc = k_multi_hist(ctx, static_cast<const uint32_t *>(col), n, xk, &h4, &diff);   // difference mask + every digit's histograms: one read
-        if (!rc) rc = k_sort_pairs_u32(ctx, k0, k1, v0, v1, payload, n, xk, ws, passes_of(diff), &ko, &vo, static_cast<const uint32_t *>(col), h4);
+        if (!rc) rc = k_sort_pairs_u32(ctx, k0, k1, v0, v1, payload, n, xk, ws, diff, &ko, &vo, static_cast<const uint32_t *>(col), h4);
         hark_free(ctx, h4);                                          // (stream-ordered reuse: the passes are enqueued)
     } else {
         if (!rc) rc = k_transform_keys(ctx, col, dtype, 0, k0, n, &diff);
-        if (!rc) rc = k_sort_pairs_u32(ctx, k0, k1, v0, v1, payload, n, xm, ws, passes_of(diff), &ko, &vo);
+        if (!rc) rc = k_sort_pairs_u32(ctx, k0, k1, v0, v1, payload, n, xm, ws, diff, &ko, &vo);
     }
     if (!rc && dtype == HARK_I64) {
         // LSD over 64 bits: after the low word, sort (stably) by the high word gathered through the current
@@ -804,7 +835,7 @@ static int k_sort_column_lsd(hark_context *ctx, const void *col, int dtype, int6
             if (!rc) rc = k_gather(ctx, ko, 4, vo, kf, n);
             uint32_t *ko2 = kf, *vo2 = vo;
             // buffers: keys in kf (scratch ko), payload = vo (read only in the first pass, then ping-pong vf <-> vo)
-            if (!rc) rc = k_sort_pairs_u32(ctx, kf, ko, vo, vf, vo, n, xm, ws, passes_of(diff), &ko2, &vo2);
+            if (!rc) rc = k_sort_pairs_u32(ctx, kf, ko, vo, vf, vo, n, xm, ws, diff, &ko2, &vo2);
             ko = ko2; vo = vo2;
         }
     }
@@ -872,7 +903,7 @@ int k_argsort_i64_keys(hark_context *ctx, const void *col, int64_t n, uint32_t *
         if (!rc) rc = hark_alloc(ctx, (void **)&flag, 16);
         uint32_t *ko = k0, *vo = v0;
         if (!rc) rc = k_transform_keys(ctx, col, HARK_I64, 1, k0, n, nullptr);
-        if (!rc) rc = k_sort_pairs_u32(ctx, k0, k1, v0, v1, nullptr, n, 0u, ws, passes_of(diff_hi), &ko, &vo);
+        if (!rc) rc = k_sort_pairs_u32(ctx, k0, k1, v0, v1, nullptr, n, 0u, ws, diff_hi, &ko, &vo);
         int64_t general = 0;
         if (!rc) {
             hipMemsetAsync(flag, 0, 16, st);
@@ -956,7 +987,7 @@ int partition_by_dest(hark_context *ctx, uint32_t *dest, int64_t n, int nparts, 
     if (!rc) rc = hark_alloc(ctx, (void **)&ws, k_sort_workspace_bytes(n, ctx->num_cu));
     // the permutation lands in perm_out (the "tmp" side of a one-pass sort)
     uint32_t *ko = nullptr, *vo = nullptr;
-    if (!rc) rc = k_sort_pairs_u32(ctx, dest, dtmp, vtmp, perm_out, nullptr, n, 0u, ws, 1u, &ko, &vo);   // one pass: the payload lands in vals_b = perm_out
+    if (!rc) rc = k_sort_pairs_u32(ctx, dest, dtmp, vtmp, perm_out, nullptr, n, 0u, ws, 0xFFu, &ko, &vo);   // one 8-bit pass over the part ids: the payload lands in vals_b = perm_out
     if (!rc) {
         // the digit totals of the pass are the part sizes (ws: 256*nblk histogram, then 256 totals)
         bool large; int64_t nblk, slice;
