@@ -30,6 +30,7 @@
 // Skewed probe keys can overflow a slab: the kernel reports it and the caller falls back.
 #include "hark_internal.h"
 #include "sort_networks.h"
+#include <type_traits>
 
 int k_sort_column(hark_context *ctx, const void *col, int dtype, int64_t n, bool descending, const uint32_t *payload,
                   uint32_t **vals_out, uint32_t **words_out);
@@ -44,17 +45,21 @@ constexpr size_t kJLdsBudget = 160 * 1024 - 512;          // one workgroup per C
 struct JPair32 { uint32_t key, row; };                                    // 8 bytes: 16 per 128-byte line
 struct __attribute__((aligned(16))) JPair64 { uint64_t key; uint32_t row, pad; };   // 16 bytes: 8 per line
 
+// the order kernel's geometry (jorder_kernel): survivors staged per sub-round and per-rank counters -- with a third word per
+// survivor 10240 x 12 B + 6144 counters, without 12288 x 8 B + 10240 counters (~150 KiB of LDS either way)
+constexpr int kStage = 12288, kStageCarry = 10240, kFine = 10240, kFineCarry = 6144, kCoarse = 2048, kTieMax = 64, kMaxSub = 256;
+
 template <typename K> struct JTraits;
 // P buckets, rings of Q entries, VEC rows per lane and batch; the bucket kernel stages CHUNK sorted build keys per
 // round plus a bitmap of 2^BM_BITS bits over them (measured: a 16-step binary search in LDS for EVERY probe pair
 // cost 1.36 ms per 1e8 pairs -- instruction issue, not the loads; most pairs have no partner and now leave after
-// one bit test).  u32: 96 KiB of keys + 32 KiB of bitmap (+ 24 KiB of candidate queues), one round up to 1.26e7 build
-// rows; u64: 96 + 16 (+ 36) KiB.
+// one bit test).  u32: 88 KiB of keys + 32 KiB of bitmap (+ 24 KiB of candidate queues + 8 KiB of rank-group counters), one
+// round up to 1.15e7 build rows; u64: 96 + 16 (+ 32 + 8) KiB.
 #ifndef HARK_J32_P                       // A/B builds (HARK_LIB): -DHARK_J32_P=256 -DHARK_J32_Q=64
 #define HARK_J32_P 512
 #define HARK_J32_Q 32
 #endif
-template <> struct JTraits<uint32_t> { typedef JPair32 E; static constexpr int P = HARK_J32_P, Q = HARK_J32_Q, VEC = 4, CHUNK = 24576, BM_BITS = 18; };
+template <> struct JTraits<uint32_t> { typedef JPair32 E; static constexpr int P = HARK_J32_P, Q = HARK_J32_Q, VEC = 4, CHUNK = 22528, BM_BITS = 18; };
 template <> struct JTraits<uint64_t> { typedef JPair64 E; static constexpr int P = 512, Q = 16, VEC = 2, CHUNK = 12288, BM_BITS = 17; };
 
 __device__ __forceinline__ uint32_t jhash(uint32_t k) { return k * 0x9E3779B1u; }
@@ -123,7 +128,9 @@ template <typename K>
 __global__ __launch_bounds__(kJThreads) void jpart_kernel(const K *__restrict__ keys, int64_t n, K bias, const K *__restrict__ splitters,
                                                           const K *__restrict__ rkeys, int64_t s,
                                                           typename JTraits<K>::E *__restrict__ slabs, uint32_t *__restrict__ counts, uint32_t cap,
-                                                          int period, int32_t *__restrict__ err)
+                                                          int period, int32_t *__restrict__ err,
+                                                          const uint32_t *__restrict__ lval /* 16-byte entries only, may be null: a probe-side column that
+                                                                                               travels in the entries' fourth word */)
 {
     typedef typename JTraits<K>::E E;
     constexpr int P = JTraits<K>::P, Q = JTraits<K>::Q, VEC = JTraits<K>::VEC;
@@ -158,19 +165,24 @@ __global__ __launch_bounds__(kJThreads) void jpart_kernel(const K *__restrict__ 
     const int64_t nbatch = (n + BATCH - 1) / BATCH;
     E *myslab = slabs + (size_t)wg * cap;                                       // + b * nwg * cap
 
-    auto load = [&](int64_t batch, K (&kk)[VEC]) {
+    auto load = [&](int64_t batch, K (&kk)[VEC], uint32_t (&vv)[VEC]) {
         const int64_t r = batch * BATCH + (int64_t)tid * VEC;
         if (r + VEC <= n) {
             typedef unsigned int u4v __attribute__((ext_vector_type(4)));
             const u4v t = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(keys + r));       // VEC * sizeof(K) = 16 bytes
             if (sizeof(K) == 4) { kk[0] = (K)t.x; kk[1 % VEC] = (K)t.y; kk[2 % VEC] = (K)t.z; kk[3 % VEC] = (K)t.w; }
             else { kk[0] = (K)(((uint64_t)t.y << 32) | t.x); kk[1 % VEC] = (K)(((uint64_t)t.w << 32) | t.z); }
+            if (sizeof(E) == 16 && lval) {                               // VEC = 2 rows: one 8-byte load (r is even)
+                typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+                const u2v q = __builtin_nontemporal_load(reinterpret_cast<const u2v *>(lval + r));
+                vv[0] = q.x; vv[1 % VEC] = q.y;
+            }
         } else {
-            for (int j = 0; j < VEC; j++) kk[j] = r + j < n ? keys[r + j] : (K)0;
+            for (int j = 0; j < VEC; j++) { kk[j] = r + j < n ? keys[r + j] : (K)0; vv[j] = (sizeof(E) == 16 && lval && r + j < n) ? lval[r + j] : 0u; }
         }
     };
 
-    auto process = [&](int64_t batch, const K (&kraw)[VEC], bool flush_now) {
+    auto process = [&](int64_t batch, const K (&kraw)[VEC], const uint32_t (&vraw)[VEC], bool flush_now) {
         const int64_t r = batch * BATCH + (int64_t)tid * VEC;
         uint32_t pending = 0;
         K kk[VEC];
@@ -207,7 +219,7 @@ __global__ __launch_bounds__(kJThreads) void jpart_kernel(const K *__restrict__ 
                     const uint32_t old = olds[j], pos = old & 0xFFFFu;
                     if (pos < (uint32_t)Q) {
                         E e; e.key = kk[j]; e.row = (uint32_t)(r + j);
-                        if (sizeof(E) == 16) reinterpret_cast<uint32_t *>(&e)[3] = 0u;
+                        if (sizeof(E) == 16) reinterpret_cast<uint32_t *>(&e)[3] = lval ? vraw[j] : 0u;
                         ring[b * Q + (((old >> 16) + pos) & (Q - 1))] = e;
                         pending &= ~(1u << j);
                     } else atomicSub(&s_w[b], 1u);                     // ring full: retry after the sweep
@@ -241,14 +253,18 @@ __global__ __launch_bounds__(kJThreads) void jpart_kernel(const K *__restrict__ 
     };
 
     K kA[VEC], kB[VEC];
-    if ((int64_t)wg < nbatch) load(wg, kA);
-    if ((int64_t)wg + nwg < nbatch) load((int64_t)wg + nwg, kB);
+    uint32_t vA[VEC], vB[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; j++) { vA[j] = 0u; vB[j] = 0u; }
+    if ((int64_t)wg < nbatch) load(wg, kA, vA);
+    if ((int64_t)wg + nwg < nbatch) load((int64_t)wg + nwg, kB, vB);
     for (int64_t batch = wg; batch < nbatch; batch += nwg) {
         K kr[VEC];
+        uint32_t vr[VEC];
 #pragma unroll
-        for (int j = 0; j < VEC; j++) { kr[j] = kA[j]; kA[j] = kB[j]; }
-        if (batch + 2 * (int64_t)nwg < nbatch) load(batch + 2 * (int64_t)nwg, kB);
-        process(batch, kr, ++since >= period || batch + nwg >= nbatch);
+        for (int j = 0; j < VEC; j++) { kr[j] = kA[j]; kA[j] = kB[j]; vr[j] = vA[j]; vA[j] = vB[j]; }
+        if (batch + 2 * (int64_t)nwg < nbatch) load(batch + 2 * (int64_t)nwg, kB, vB);
+        process(batch, kr, vr, ++since >= period || batch + nwg >= nbatch);
     }
     // ---- what is left (< LINE entries per bucket) goes out as one partial line
     for (int b = tid; b < P; b += kJThreads) {
@@ -269,22 +285,33 @@ template <typename K>
 __global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTraits<K>::E *__restrict__ slabs, const uint32_t *__restrict__ counts,
                                                             uint32_t cap, int nwg, const K *__restrict__ rkeys, const uint32_t *__restrict__ bstart,
                                                             int chunk_cap, uint2 *__restrict__ surv, uint32_t *__restrict__ scount,
-                                                            uint32_t *__restrict__ sround /* [P][kMaxRounds] survivors after round q */)
+                                                            uint32_t *__restrict__ sround /* [P][kMaxRounds] survivors after round q */,
+                                                            uint32_t *__restrict__ sval /* may be null: the entries' fourth word of every survivor (same index as surv) */,
+                                                            uint32_t *__restrict__ scoarse /* [P][kCoarse] survivors per group of ranks: the order kernel's first histogram */)
 {
     typedef typename JTraits<K>::E E;
-    constexpr int BM_BITS = JTraits<K>::BM_BITS, BM_WORDS = 1 << (BM_BITS - 5), QCAP = 192;
+    // candidate queues: 8-byte pairs are tested two per lane and step (64 + 128 queued at most); 16-byte entries one per lane
+    // and half-step (63 + 64), which leaves room for their fourth word in the queue
+    constexpr int BM_BITS = JTraits<K>::BM_BITS, BM_WORDS = 1 << (BM_BITS - 5), QCAP = sizeof(E) == 16 ? 128 : 192;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     uint32_t *bitmap = reinterpret_cast<uint32_t *>(lds_raw);                 // [BM_WORDS] one bit per hashed chunk key
     K *chunk = reinterpret_cast<K *>(bitmap + BM_WORDS);                       // [CHUNK] sorted build keys of this round
     K *qkey_all = chunk + JTraits<K>::CHUNK;                                   // [16 waves][QCAP] candidate keys
     uint32_t *qrow_all = reinterpret_cast<uint32_t *>(qkey_all + (kJThreads / 64) * QCAP);   // [16 waves][QCAP] their row ids
+    uint32_t *qval_all = qrow_all + (kJThreads / 64) * QCAP;                   // [16 waves][QCAP] their fourth words (16-byte entries)
+    uint32_t *s_coarse = qval_all + (sizeof(E) == 16 ? (kJThreads / 64) * QCAP : 0);   // [kCoarse] survivors per group of 2^gs ranks (for the order kernel)
     __shared__ uint32_t s_n;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = kJThreads >> 6;
     K *qkey = qkey_all + wave * QCAP;
     uint32_t *qrow = qrow_all + wave * QCAP;
+    uint32_t *qval = qval_all + wave * QCAP;
     const uint32_t lo = bstart[b], hi = bstart[b + 1];
+    int gs = 0;                                                          // the order kernel's grouping of this bucket's ranks
+    while (((hi - lo + (1u << gs) - 1u) >> gs) > (uint32_t)kCoarse) gs++;
+    for (int i = tid; i < kCoarse; i += kJThreads) s_coarse[i] = 0u;
     if (tid == 0) s_n = 0u;
     uint2 *out = surv + (size_t)b * nwg * cap;                             // room for every probe pair of the bucket
+    uint32_t *vout = sval ? sval + (size_t)b * nwg * cap : nullptr;
     const unsigned long long below = (1ull << lane) - 1ull;
     int q = 0;                                                       // rounds done
     for (uint32_t base = lo; base < hi; base += (uint32_t)chunk_cap, q++) {
@@ -309,9 +336,9 @@ __global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTrai
             return (bitmap[h >> 5] >> (h & 31u)) & 1u;
         };
         int qn = 0;                                                    // wave-uniform: candidates queued
-        auto enqueue = [&](bool c, K key, uint32_t row) {
+        auto enqueue = [&](bool c, K key, uint32_t row, uint32_t val) {
             const unsigned long long mask = __ballot(c);
-            if (c) { const int at = qn + __popcll(mask & below); qkey[at] = key; qrow[at] = row; }
+            if (c) { const int at = qn + __popcll(mask & below); qkey[at] = key; qrow[at] = row; if (sizeof(E) == 16) qval[at] = val; }
             qn += __popcll(mask);
         };
         // search `cnt` queued candidates (the last ones), one per lane; a hit is appended to the bucket's survivors
@@ -320,6 +347,7 @@ __global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTrai
             const bool act = lane < cnt;
             const K key = act ? qkey[qn + lane] : (K)0;
             const uint32_t row = act ? qrow[qn + lane] : 0u;
+            const uint32_t val = (sizeof(E) == 16 && act) ? qval[qn + lane] : 0u;
             const int off = pivot < key ? m - W : 0;
             int pos = 0;
             for (int step = W >> 1; step > 0; step >>= 1) pos += chunk[off + pos + step - 1] < key ? step : 0;
@@ -331,7 +359,12 @@ __global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTrai
                 uint32_t at = 0;
                 if (lane == 0) at = atomicAdd(&s_n, (uint32_t)__popcll(mask));
                 at = __shfl(at, 0, 64);
-                if (match) out[at + (uint32_t)__popcll(mask & below)] = uint2{base + (uint32_t)pos, row};
+                if (match) {
+                    const uint32_t o = at + (uint32_t)__popcll(mask & below);
+                    out[o] = uint2{base + (uint32_t)pos, row};
+                    if (sizeof(E) == 16 && vout) vout[o] = val;
+                    atomicAdd(&s_coarse[(base + (uint32_t)pos - lo) >> gs], 1u);
+                }
             }
         };
         // a wave walks whole slabs, 128 entries per step: two entries per lane (one 16-byte load for 8-byte pairs, two
@@ -357,19 +390,20 @@ __global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTrai
             for (uint32_t step = 0; step < nstep; step++) {
                 const u4v c0 = n0, c1 = n1;
                 if (step + 1 < nstep) fetch(step + 1);
-                K key0, key1; uint32_t row0, row1; bool v0, v1;
+                K key0, key1; uint32_t row0, row1, val0 = 0u, val1 = 0u; bool v0, v1;
                 if (WIDE) {
                     const uint32_t e0 = step * 128u + lane;
                     v0 = e0 < count; v1 = e0 + 64u < count;
-                    key0 = (K)(((uint64_t)c0.y << 32) | c0.x); row0 = c0.z;
-                    key1 = (K)(((uint64_t)c1.y << 32) | c1.x); row1 = c1.z;
+                    key0 = (K)(((uint64_t)c0.y << 32) | c0.x); row0 = c0.z; val0 = c0.w;
+                    key1 = (K)(((uint64_t)c1.y << 32) | c1.x); row1 = c1.z; val1 = c1.w;
                 } else {
                     const uint32_t e0 = step * 128u + 2u * lane;
                     v0 = e0 < count; v1 = e0 + 1u < count;
                     key0 = (K)c0.x; row0 = c0.y; key1 = (K)c0.z; row1 = c0.w;
                 }
-                enqueue(v0 && candidate(key0), key0, row0);              // qn < 64 before: at most 64 + 128 = QCAP queued
-                enqueue(v1 && candidate(key1), key1, row1);
+                enqueue(v0 && candidate(key0), key0, row0, val0);        // qn < 64 before
+                if (WIDE) while (qn >= 64) drain(64);                    // 16-byte entries: never more than 63 + 64 queued
+                enqueue(v1 && candidate(key1), key1, row1, val1);        // 8-byte pairs: at most 64 + 128 = QCAP queued
                 while (qn >= 64) drain(64);
             }
         }
@@ -377,6 +411,7 @@ __global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTrai
     }
     __syncthreads();
     if (tid == 0) { scount[b] = s_n; if (q > 0 && q <= kMaxRounds) sround[b * kMaxRounds + q - 1] = s_n; }
+    for (int i = tid; i < kCoarse; i += kJThreads) scoarse[(size_t)b * kCoarse + i] = s_coarse[i];
 }
 
 __global__ __launch_bounds__(1024) void jsum_kernel(const uint32_t *__restrict__ scount, int P, unsigned long long *__restrict__ total)
@@ -404,21 +439,26 @@ __global__ __launch_bounds__(1024) void jsum_kernel(const uint32_t *__restrict__
 // A group of 2^gs ranks with more survivors than the stage holds, or a rank with more than kTieMax rows, raises *general:
 // the bucket is copied as it is and the caller sorts all survivors with radix passes instead.
 // Sorting networks over N registers: sort_networks.h (uint32 values, plain order here).
-__device__ __forceinline__ void sort4(uint32_t (&v)[4]) { net_sort4(v, [](uint32_t a, uint32_t b) { return a < b; }); }
-__device__ __forceinline__ void sort8(uint32_t (&v)[8]) { net_sort8(v, [](uint32_t a, uint32_t b) { return a < b; }); }
-__device__ __forceinline__ void sort16(uint32_t (&v)[16]) { net_sort16(v, [](uint32_t a, uint32_t b) { return a < b; }); }
-constexpr int kStage = 12288, kFine = 10240, kCoarse = 2048, kTieMax = 64, kMaxSub = 256;
+// CARRY: every survivor has a third word (a probe-side output column, sval / lval_out) that is ordered along with it; the
+// stage then holds kStageCarry survivors (12 bytes each).
+template <bool CARRY>
 __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restrict__ surv, size_t stride, const uint32_t *__restrict__ scount,
                                                            const uint32_t *__restrict__ sround, int chunk_cap,
                                                            const uint32_t *__restrict__ bstart, int P, const uint32_t *__restrict__ runlen,
                                                            uint32_t *__restrict__ rank, uint32_t *__restrict__ lrow, uint32_t *__restrict__ cnt_out /* may be null */,
-                                                           int stage_cap /* <= kStage (tests: smaller) */, int32_t *__restrict__ general,
-                                                           uint2 *tmp_all /* scratch, same layout as surv (the probe slabs, dead by now) */)
+                                                           int stage_cap /* <= kStage / kStageCarry (tests: smaller) */, int32_t *__restrict__ general,
+                                                           uint2 *tmp_all /* scratch, same layout as surv (the probe slabs, dead by now) */,
+                                                           const uint32_t *__restrict__ sval, uint32_t *__restrict__ lval_out, uint32_t *tmpv_all,
+                                                           const uint32_t *__restrict__ scoarse,
+                                                           const uint32_t *__restrict__ rranked /* may be null: a build-side column in rank order ... */,
+                                                           uint32_t *__restrict__ rval_out /* ... read off for every survivor (unique build keys: survivor = output row) */)
 {
+    constexpr int STAGE = CARRY ? kStageCarry : kStage, FINE = CARRY ? kFineCarry : kFine;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    uint2 *stage = reinterpret_cast<uint2 *>(lds_raw);                         // [kStage]
-    uint32_t *fine = reinterpret_cast<uint32_t *>(stage + kStage);             // [kFine + 1]
-    uint32_t *coarse = fine + kFine + 1;                                       // [kCoarse + 1] counts, then exclusive prefix
+    uint2 *stage = reinterpret_cast<uint2 *>(lds_raw);                         // [STAGE]
+    uint32_t *stv = reinterpret_cast<uint32_t *>(stage + STAGE);               // [STAGE] third words (CARRY)
+    uint32_t *fine = stv + (CARRY ? STAGE : 0);                                // [kFine + 1]
+    uint32_t *coarse = fine + FINE + 1;                                        // [kCoarse + 1] counts, then exclusive prefix
     __shared__ unsigned long long s_dst;
     __shared__ uint32_t s_wave[kJThreads / 64];
     __shared__ int s_bad, s_nsr;
@@ -433,34 +473,38 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
     if (lane == 0 && part) atomicAdd(&s_dst, part);
     const uint32_t lo = bstart[b], len = bstart[b + 1] - lo, nb = scount[b];
     const uint2 *src = surv + (size_t)b * stride;
+    const uint32_t *srcv = CARRY ? sval + (size_t)b * stride : nullptr;
     int gs = 0;
     while (((len + (1u << gs) - 1u) >> gs) > (uint32_t)kCoarse) gs++;
     const uint32_t ngroups = (len + (1u << gs) - 1u) >> gs;
-    for (uint32_t i = tid; i <= ngroups; i += kJThreads) coarse[i] = 0u;
+    for (uint32_t i = tid; i <= ngroups; i += kJThreads) coarse[i] = i < ngroups ? scoarse[(size_t)b * kCoarse + i] : 0u;   // counted by the bucket kernel
     __syncthreads();
     const unsigned long long dst = s_dst;
     if (nb == 0) return;
     // every pass over survivors keeps 8 loads per lane in flight: one workgroup owns the CU, and with a single load per
-    // lane the passes ran at the latency of a load, not at the CU's share of the bandwidth
-    auto sweep = [&](const uint2 *sp, uint32_t i0, uint32_t i1, bool coherent, auto &&f) {
+    // lane the passes ran at the latency of a load, not at the CU's share of the bandwidth.  f(entry, third word)
+    auto sweep = [&](const uint2 *sp, const uint32_t *spv, uint32_t i0, uint32_t i1, bool coherent, bool want_v, auto &&f) {
         auto ld = [&](uint32_t i) -> uint2 {
             if (!coherent) return sp[i];
             // workgroup-scope load: the bins were written by other waves of this workgroup in this kernel
             const unsigned long long w = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(sp + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             return uint2{(uint32_t)w, (uint32_t)(w >> 32)};
         };
+        auto ldv = [&](uint32_t i) -> uint32_t {
+            if (!CARRY || !want_v) return 0u;
+            if (!coherent) return spv[i];
+            return __hip_atomic_load(spv + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
         uint32_t i = i0 + tid;
         for (; i + 7u * kJThreads < i1; i += 8u * kJThreads) {
-            uint2 e[8];
+            uint2 e[8]; uint32_t v[8];
 #pragma unroll
-            for (int k = 0; k < 8; k++) e[k] = ld(i + (uint32_t)k * kJThreads);
+            for (int k = 0; k < 8; k++) { e[k] = ld(i + (uint32_t)k * kJThreads); v[k] = ldv(i + (uint32_t)k * kJThreads); }
 #pragma unroll
-            for (int k = 0; k < 8; k++) f(e[k]);
+            for (int k = 0; k < 8; k++) f(e[k], v[k]);
         }
-        for (; i < i1; i += kJThreads) f(ld(i));
+        for (; i < i1; i += kJThreads) f(ld(i), ldv(i));
     };
-    sweep(src, 0u, nb, false, [&](uint2 e) { atomicAdd(&coarse[(e.x - lo) >> gs], 1u); });
-    __syncthreads();
     // block-wide exclusive scan helper over a[0, m): a contiguous segment per thread, waves chained through LDS;
     // returns the total
     auto scan_excl = [&](uint32_t *a, uint32_t m) -> uint32_t {
@@ -483,18 +527,23 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
         for (uint32_t i = tid; i < ngroups; i += kJThreads) big = big || coarse[i] > (uint32_t)stage_cap;
         // a bucket of more than kCoarse * kFine sorted build entries (jsplit never splits a run of equal keys, so one build
         // key repeated ~1.7e7 times gives one): a single group of 2^gs ranks would not fit the fine counters
-        if (big || (1u << gs) > (uint32_t)kFine) s_bad = 1;
+        if (big || (1u << gs) > (uint32_t)FINE) s_bad = 1;
     }
     __syncthreads();
     if (s_bad) {
-        for (uint32_t i = tid; i < nb; i += kJThreads) { const uint2 e = src[i]; rank[dst + i] = e.x; lrow[dst + i] = e.y; if (cnt_out) cnt_out[dst + i] = runlen[e.x]; }
+        for (uint32_t i = tid; i < nb; i += kJThreads) {
+            const uint2 e = src[i];
+            rank[dst + i] = e.x; lrow[dst + i] = e.y; if (cnt_out) cnt_out[dst + i] = runlen[e.x];   // (this path always writes the rows: the general sort needs them)
+            if (CARRY) lval_out[dst + i] = srcv[i];                   // (the caller drops the carried words on the general path)
+            if (rranked) rval_out[dst + i] = rranked[e.x];
+        }
         if (tid == 0) *general = 1;
         return;
     }
     scan_excl(coarse, ngroups + 1);                                    // coarse[g] = survivors before group g; coarse[ngroups] = nb
     const int rounds_b = (int)((len + (uint32_t)chunk_cap - 1u) / (uint32_t)chunk_cap);
     const bool by_round = rounds_b <= kMaxRounds;
-    const uint32_t max_groups = max(1u, (uint32_t)kFine >> gs);
+    const uint32_t max_groups = max(1u, (uint32_t)FINE >> gs);
     bool too_long = false;
     // the end of the sub-round that starts at group g0: the largest g1 with coarse[g1] - coarse[g0] <= stage_cap and
     // g1 - g0 <= max_groups (a single group always fits: checked above)
@@ -518,14 +567,17 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
     const int nsr = s_nsr;
     const bool binned = nsr >= 3 && nsr <= kMaxSub && tmp_all != nullptr;
     uint2 *tmp = tmp_all + (size_t)b * stride;
+    uint32_t *tmpv = CARRY ? tmpv_all + (size_t)b * stride : nullptr;
     if (binned) {
         for (int k = tid; k < nsr; k += kJThreads) s_bincur[k] = 0u;
         __syncthreads();
-        sweep(src, 0u, nb, false, [&](uint2 e) {
+        sweep(src, srcv, 0u, nb, false, true, [&](uint2 e, uint32_t v) {
             const uint32_t g = (e.x - lo) >> gs;
             int a = 0, z = nsr - 1;                                      // the sub-round whose group range holds g
             while (a < z) { const int mid = (a + z + 1) >> 1; if ((uint32_t)s_subg[mid] <= g) a = mid; else z = mid - 1; }
-            tmp[coarse[s_subg[a]] + atomicAdd(&s_bincur[a], 1u)] = e;
+            const uint32_t at = coarse[s_subg[a]] + atomicAdd(&s_bincur[a], 1u);
+            tmp[at] = e;
+            if (CARRY) tmpv[at] = v;
         });
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");         // the bins are read back by other waves of this workgroup (same CU, same L1)
         __syncthreads();
@@ -537,7 +589,8 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
         if (nsub) {
             uint32_t i0 = 0, i1 = nb;
             const uint2 *sp = src;
-            if (binned) { sp = tmp + base_cnt; i0 = 0; i1 = nsub; }
+            const uint32_t *spv = srcv;
+            if (binned) { sp = tmp + base_cnt; spv = CARRY ? tmpv + base_cnt : nullptr; i0 = 0; i1 = nsub; }
             else if (by_round) {
                 const int q0 = (int)(r0 / (uint32_t)chunk_cap), q1 = (int)((r1 - 1u) / (uint32_t)chunk_cap);
                 i0 = q0 > 0 ? sround[b * kMaxRounds + q0 - 1] : 0u;
@@ -545,12 +598,12 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
             }
             for (uint32_t i = tid; i <= nr; i += kJThreads) fine[i] = 0u;
             __syncthreads();
-            sweep(sp, i0, i1, binned, [&](uint2 e) { const uint32_t r = e.x - lo - r0; if (r < nr) atomicAdd(&fine[r], 1u); });
+            sweep(sp, spv, i0, i1, binned, false, [&](uint2 e, uint32_t) { const uint32_t r = e.x - lo - r0; if (r < nr) atomicAdd(&fine[r], 1u); });
             __syncthreads();
             scan_excl(fine, nr);
-            sweep(sp, i0, i1, binned, [&](uint2 e) {
+            sweep(sp, spv, i0, i1, binned, true, [&](uint2 e, uint32_t v) {
                 const uint32_t r = e.x - lo - r0;
-                if (r < nr) stage[atomicAdd(&fine[r], 1u)] = e;        // afterwards fine[r] = end of rank r's rows
+                if (r < nr) { const uint32_t at = atomicAdd(&fine[r], 1u); stage[at] = e; if (CARRY) stv[at] = v; }   // afterwards fine[r] = end of rank r's rows
             });
             __syncthreads();
             for (uint32_t r = tid; r < nr; r += kJThreads) {           // rows of one rank into left-row order
@@ -559,48 +612,60 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
                 if (s1 - s0 > (uint32_t)kTieMax) { too_long = true; continue; }
                 const uint32_t m = s1 - s0;
                 // short runs (the usual fan-out of a key) are sorted in registers: the rank is the same for the whole run, so
-                // only the left row ids move; the in-LDS insertion sort below is a chain of dependent LDS round trips
-                // (it took a third of this kernel at 5 rows per key)
+                // only the left row ids (and, CARRY, the third words with them: one 64-bit word, row id in front) move; the
+                // in-LDS insertion sort below is a chain of dependent LDS round trips (a third of this kernel at 5 rows per key)
+                typedef typename std::conditional<CARRY, unsigned long long, uint32_t>::type u64;      // (32-bit words without a third word)
+                auto get = [&](uint32_t x) -> u64 {
+                    if constexpr (CARRY) return ((unsigned long long)stage[s0 + x].y << 32) | (unsigned long long)stv[s0 + x];
+                    else return stage[s0 + x].y;
+                };
+                auto put = [&](uint32_t x, u64 w) {
+                    if constexpr (CARRY) { stage[s0 + x].y = (uint32_t)(w >> 32); stv[s0 + x] = (uint32_t)w; }
+                    else stage[s0 + x].y = w;
+                };
+                auto lt64 = [](u64 a, u64 c) { return a < c; };
                 if (m <= 4u) {
-                    uint32_t v[4];
+                    u64 v[4];
 #pragma unroll
-                    for (int x = 0; x < 4; x++) v[x] = (uint32_t)x < m ? stage[s0 + x].y : 0xFFFFFFFFu;
-                    sort4(v);
+                    for (int x = 0; x < 4; x++) v[x] = (uint32_t)x < m ? get(x) : (u64)~(u64)0;
+                    net_sort4(v, lt64);
 #pragma unroll
-                    for (int x = 0; x < 4; x++) if ((uint32_t)x < m) stage[s0 + x].y = v[x];
+                    for (int x = 0; x < 4; x++) if ((uint32_t)x < m) put(x, v[x]);
                     continue;
                 }
                 if (m <= 8u) {
-                    uint32_t v[8];
+                    u64 v[8];
 #pragma unroll
-                    for (int x = 0; x < 8; x++) v[x] = (uint32_t)x < m ? stage[s0 + x].y : 0xFFFFFFFFu;
-                    sort8(v);
+                    for (int x = 0; x < 8; x++) v[x] = (uint32_t)x < m ? get(x) : (u64)~(u64)0;
+                    net_sort8(v, lt64);
 #pragma unroll
-                    for (int x = 0; x < 8; x++) if ((uint32_t)x < m) stage[s0 + x].y = v[x];
+                    for (int x = 0; x < 8; x++) if ((uint32_t)x < m) put(x, v[x]);
                     continue;
                 }
                 if (m <= 16u) {
-                    uint32_t v[16];
+                    u64 v[16];
 #pragma unroll
-                    for (int x = 0; x < 16; x++) v[x] = (uint32_t)x < m ? stage[s0 + x].y : 0xFFFFFFFFu;
-                    sort16(v);
+                    for (int x = 0; x < 16; x++) v[x] = (uint32_t)x < m ? get(x) : (u64)~(u64)0;
+                    net_sort16(v, lt64);
 #pragma unroll
-                    for (int x = 0; x < 16; x++) if ((uint32_t)x < m) stage[s0 + x].y = v[x];
+                    for (int x = 0; x < 16; x++) if ((uint32_t)x < m) put(x, v[x]);
                     continue;
                 }
-                for (uint32_t x = s0 + 1; x < s1; x++) {               // left row ids are distinct
-                    const uint2 e = stage[x];
+                for (uint32_t x = 1; x < m; x++) {                       // left row ids are distinct
+                    const u64 e = get(x);
                     uint32_t y = x;
-                    while (y > s0 && stage[y - 1].y > e.y) { stage[y] = stage[y - 1]; y--; }
-                    stage[y] = e;
+                    while (y > 0 && get(y - 1) > e) { put(y, get(y - 1)); y--; }
+                    put(y, e);
                 }
             }
             __syncthreads();
             const unsigned long long o = dst + base_cnt;
             for (uint32_t i = tid; i < nsub; i += kJThreads) {
                 const uint2 e = stage[i];
-                rank[o + i] = e.x; lrow[o + i] = e.y;
+                rank[o + i] = e.x; lrow[o + i] = e.y;                    // (lrow is needed by the general path, which is only known at the end)
                 if (cnt_out) cnt_out[o + i] = runlen[e.x];
+                if (CARRY) lval_out[o + i] = stv[i];
+                if (rranked) rval_out[o + i] = rranked[e.x];             // ranks ascend along the stage: an (almost) sequential read
             }
             __syncthreads();
         }
@@ -631,8 +696,8 @@ __global__ __launch_bounds__(256) void jcompact_kernel(const uint2 *__restrict__
 
 template <typename K>
 int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K *rkeys, int64_t s, const uint32_t *runlen,
-                    int32_t *flags /* device: [0] general sort needed, [1] duplicate build keys */,
-                    uint32_t **rank_out, uint32_t **lrow_out, uint32_t **cnt_out, int64_t *m_out, bool *used, bool *dup_out)
+                    int32_t *flags /* device: [0] general sort needed, [1] duplicate build keys */, const uint32_t *lval, const uint32_t *rranked,
+                    uint32_t **rank_out, uint32_t **lrow_out, uint32_t **cnt_out, uint32_t **lval_out, uint32_t **rval_out, int64_t *m_out, bool *used, bool *dup_out)
 {
     typedef typename JTraits<K>::E E;
     constexpr int P = JTraits<K>::P, Q = JTraits<K>::Q, VEC = JTraits<K>::VEC, LINE = 128 / (int)sizeof(E);
@@ -647,7 +712,9 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
     K *splitters = nullptr; uint32_t *bstart = nullptr, *counts = nullptr, *scount = nullptr, *sround = nullptr;
     int64_t *info = nullptr;                                                     // [0] survivors (u64), [1] error word of the partition
     E *slabs = nullptr; uint2 *surv = nullptr;
-    uint32_t *rank = nullptr, *lrow = nullptr, *cnt = nullptr;
+    uint32_t *rank = nullptr, *lrow = nullptr, *cnt = nullptr, *sval = nullptr, *lv = nullptr, *rv = nullptr;
+    const bool carry = lval != nullptr && sizeof(E) == 16;                      // the fourth word of the 16-byte entries
+    *lval_out = nullptr; *rval_out = nullptr;
     const size_t sstride = (size_t)nwg * cap;                                    // survivor slab of a bucket: room for all of its probe pairs
     int rc = hark_alloc(ctx, (void **)&splitters, sizeof(K) * P);
     if (!rc) rc = hark_alloc(ctx, (void **)&bstart, 4 * (size_t)(P + 1));
@@ -657,9 +724,12 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
     if (!rc) rc = hark_alloc(ctx, (void **)&info, 32);
     if (!rc) rc = hark_alloc(ctx, (void **)&slabs, sizeof(E) * (size_t)P * sstride);
     if (!rc) rc = hark_alloc(ctx, (void **)&surv, 8 * (size_t)P * sstride);
+    if (!rc && carry) rc = hark_alloc(ctx, (void **)&sval, 4 * (size_t)P * sstride);
+    uint32_t *scoarse = nullptr;
+    if (!rc) rc = hark_alloc(ctx, (void **)&scoarse, 4 * (size_t)P * kCoarse);
     auto cleanup = [&]() {
         hark_free(ctx, splitters); hark_free(ctx, bstart); hark_free(ctx, counts); hark_free(ctx, scount); hark_free(ctx, sround);
-        hark_free(ctx, info); hark_free(ctx, slabs); hark_free(ctx, surv);
+        hark_free(ctx, info); hark_free(ctx, slabs); hark_free(ctx, surv); hark_free(ctx, sval); hark_free(ctx, scoarse);
     };
     if (rc == HARK_ENOMEM) {                                                     // no room for the partition workspace: the sort-merge path
         cleanup();                                                               // needs far less (used stays false)
@@ -679,13 +749,14 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
     if (period < 1) period = 1;
     int chunk_cap = JTraits<K>::CHUNK;
     if (const char *e = getenv("HARK_JOIN_CHUNK")) { const int c = atoi(e); if (c >= 1 && c < chunk_cap) chunk_cap = c; }   // tests: force several rounds per bucket
-    constexpr size_t lds_bucket = sizeof(K) * (size_t)JTraits<K>::CHUNK + ((size_t)1 << (JTraits<K>::BM_BITS - 3)) + (size_t)(kJThreads / 64) * 192 * (sizeof(K) + 4);
+    constexpr size_t lds_bucket = sizeof(K) * (size_t)JTraits<K>::CHUNK + ((size_t)1 << (JTraits<K>::BM_BITS - 3))
+                                + (sizeof(E) == 16 ? (size_t)(kJThreads / 64) * 128 * 16 : (size_t)(kJThreads / 64) * 192 * 8) + (size_t)kCoarse * 4;
     static_assert(lds_bucket <= kJLdsBudget, "bucket kernel LDS");
     if (he == hipSuccess) he = hipFuncSetAttribute(reinterpret_cast<const void *>(&jbucket_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bucket);
     if (he == hipSuccess) {
         // one stream-ordered chain, one host read at the end: partition -> bucket probe -> survivor total
-        jpart_kernel<K><<<dim3((unsigned)nwg), dim3(kJThreads), lds_part, st>>>(lcol, n, bias, splitters, rkeys, s, slabs, counts, cap, period, err);
-        jbucket_kernel<K><<<dim3((unsigned)P), dim3(kJThreads), lds_bucket, st>>>(slabs, counts, cap, nwg, rkeys, bstart, chunk_cap, surv, scount, sround);
+        jpart_kernel<K><<<dim3((unsigned)nwg), dim3(kJThreads), lds_part, st>>>(lcol, n, bias, splitters, rkeys, s, slabs, counts, cap, period, err, carry ? lval : nullptr);
+        jbucket_kernel<K><<<dim3((unsigned)P), dim3(kJThreads), lds_bucket, st>>>(slabs, counts, cap, nwg, rkeys, bstart, chunk_cap, surv, scount, sround, sval, scoarse);
         jsum_kernel<<<1, 1024, 0, st>>>(scount, P, total);
         he = hipGetLastError();
         if (he == hipSuccess) he = hipMemcpyAsync(info + 2, flags, 8, hipMemcpyDeviceToDevice, st);   // the duplicate-keys flag rides along with the same host read
@@ -701,25 +772,36 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
         rc = hark_alloc(ctx, (void **)&rank, 4 * (size_t)M);
         if (!rc) rc = hark_alloc(ctx, (void **)&lrow, 4 * (size_t)M);
         if (!rc && dup) rc = hark_alloc(ctx, (void **)&cnt, 4 * (size_t)M);     // unique build keys: every survivor has exactly one partner
+        if (!rc && carry) rc = hark_alloc(ctx, (void **)&lv, 4 * (size_t)M);
+        if (dup || getenv("HARK_JOIN_FULLSORT")) rranked = nullptr;              // a survivor is an output row only when the build keys are unique
+        if (!rc && rranked) rc = hark_alloc(ctx, (void **)&rv, 4 * (size_t)M);
         if (!rc) {
             if (getenv("HARK_JOIN_FULLSORT")) {                                  // A/B + tests: plain compaction, radix sorts by the caller
                 jcompact_kernel<<<dim3((unsigned)P), 256, 0, st>>>(surv, sstride, scount, P, rank, lrow);
                 hipMemsetAsync(flags, 1, 1, st);
             } else {
-                constexpr size_t lds_order = (size_t)kStage * 8 + (size_t)(kFine + 1) * 4 + (size_t)(kCoarse + 1) * 4;
-                he = hipFuncSetAttribute(reinterpret_cast<const void *>(&jorder_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_order);
-                int stage_cap = kStage;
+                const size_t lds_order = (carry ? (size_t)kStageCarry * 12 + (size_t)(kFineCarry + 1) * 4 : (size_t)kStage * 8 + (size_t)(kFine + 1) * 4) + (size_t)(kCoarse + 1) * 4;
+                he = carry ? hipFuncSetAttribute(reinterpret_cast<const void *>(&jorder_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_order)
+                           : hipFuncSetAttribute(reinterpret_cast<const void *>(&jorder_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_order);
+                int stage_cap = carry ? kStageCarry : kStage;
                 if (const char *e = getenv("HARK_JOIN_STAGE")) { const int c = atoi(e); if (c >= 1 && c < stage_cap) stage_cap = c; }   // tests: many sub-rounds per bucket
-                if (he == hipSuccess) jorder_kernel<<<dim3((unsigned)P), dim3(kJThreads), lds_order, st>>>(surv, sstride, scount, sround, chunk_cap, bstart, P, runlen,
-                                                                                                           rank, lrow, cnt, stage_cap, flags,
-                                                                                                           getenv("HARK_JOIN_NOBIN") ? nullptr : reinterpret_cast<uint2 *>(slabs));
+                // bins of the order kernel: the dead probe slabs -- 8 bytes per entry for the survivors, and (16-byte entries
+                // only) the 4 bytes behind them for the third words
+                uint2 *bins = getenv("HARK_JOIN_NOBIN") ? nullptr : reinterpret_cast<uint2 *>(slabs);
+                uint32_t *binsv = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(slabs) + 8 * (size_t)P * sstride);
+                if (he == hipSuccess && carry)
+                    jorder_kernel<true><<<dim3((unsigned)P), dim3(kJThreads), lds_order, st>>>(surv, sstride, scount, sround, chunk_cap, bstart, P, runlen,
+                                                                                             rank, lrow, cnt, stage_cap, flags, bins, sval, lv, binsv, scoarse, rranked, rv);
+                else if (he == hipSuccess)
+                    jorder_kernel<false><<<dim3((unsigned)P), dim3(kJThreads), lds_order, st>>>(surv, sstride, scount, sround, chunk_cap, bstart, P, runlen,
+                                                                                              rank, lrow, cnt, stage_cap, flags, bins, nullptr, nullptr, nullptr, scoarse, rranked, rv);
             }
             if (he != hipSuccess || hipGetLastError() != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: order launch failed");
         }
     }
     cleanup();                                                              // stream-ordered reuse: the ordering above is enqueued first
-    if (rc) { hark_free(ctx, rank); hark_free(ctx, lrow); hark_free(ctx, cnt); return rc; }
-    *rank_out = rank; *lrow_out = lrow; *cnt_out = cnt; *m_out = M; *used = true;
+    if (rc) { hark_free(ctx, rank); hark_free(ctx, lrow); hark_free(ctx, cnt); hark_free(ctx, lv); hark_free(ctx, rv); return rc; }
+    *rank_out = rank; *lrow_out = lrow; *cnt_out = cnt; *lval_out = lv; *rval_out = rv; *m_out = M; *used = true;
     return HARK_OK;
 }
 
@@ -730,13 +812,19 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
 // every survivor has exactly one partner).  lcol: the probe key column (u32 bit patterns, or i64 when k64);
 // rkeys: the SORTED build keys (u32, or u64 biased by 2^63 when k64).  *used = false: nothing was produced (tiny input,
 // or skew overflowed a slab) and the caller takes the sort-merge path.  Outputs are pool blocks the caller frees.
-int k_join_partitioned(hark_context *ctx, const void *lcol, bool k64, int64_t n, const void *rkeys, int64_t s,
-                       uint32_t **rank_out, uint32_t **lrow_out, uint32_t **cnt_out, int64_t *m_out, bool *used, bool *unique)
+// lval (optional, i64 keys only): a 4-byte probe-side column that travels with the probe rows; *lval_out then holds its
+// value for every matching probe row, in the order of rank_out / lrow_out -- or stays null (32-bit keys, the FULLSORT knob,
+// or the general ordering path was needed: the caller gathers the column through lrow_out instead).
+// rranked (optional): a 4-byte build-side column in RANK order (column[perm[rank]]); with unique build keys *rval_out then
+// holds its value for every matching probe row (= output row), read off by the order kernel; null otherwise.
+int k_join_partitioned(hark_context *ctx, const void *lcol, bool k64, int64_t n, const void *rkeys, int64_t s, const uint32_t *lval, const uint32_t *rranked,
+                       uint32_t **rank_out, uint32_t **lrow_out, uint32_t **cnt_out, uint32_t **lval_out, uint32_t **rval_out, int64_t *m_out, bool *used, bool *unique)
 {
-    *rank_out = nullptr; *lrow_out = nullptr; *cnt_out = nullptr; *m_out = 0; *used = false; *unique = false;
+    *rank_out = nullptr; *lrow_out = nullptr; *cnt_out = nullptr; *lval_out = nullptr; *rval_out = nullptr; *m_out = 0; *used = false; *unique = false;
+    if (getenv("HARK_JOIN_FULLSORT")) lval = nullptr;
     if (n < ((int64_t)1 << 18) || s < 4096 || n + s > 0xFFFFFFFFll) return HARK_OK;
     if (getenv("HARK_JOIN_SORTMERGE")) return HARK_OK;                          // A/B knob
-    uint32_t *rank = nullptr, *lrow = nullptr, *cnt = nullptr, *runlen = nullptr;
+    uint32_t *rank = nullptr, *lrow = nullptr, *cnt = nullptr, *runlen = nullptr, *lv = nullptr, *rv = nullptr;
     int64_t M = 0;
     int32_t *flag = nullptr;                                   // [0] the survivors need the general sort (skew), [1] duplicate build keys
     int rc = hark_alloc(ctx, (void **)&flag, 16);
@@ -751,10 +839,10 @@ int k_join_partitioned(hark_context *ctx, const void *lcol, bool k64, int64_t n,
         else jrunlen_kernel<uint32_t><<<dim3((unsigned)g1), 256, 0, ctx->stream>>>(static_cast<const uint32_t *>(rkeys), s, runlen, flag + 1);
     }
     bool dup = true;
-    rc = k64 ? run_partitioned<uint64_t>(ctx, static_cast<const uint64_t *>(lcol), 0x8000000000000000ull, n, static_cast<const uint64_t *>(rkeys), s, runlen, flag, &rank, &lrow, &cnt, &M, used, &dup)
-             : run_partitioned<uint32_t>(ctx, static_cast<const uint32_t *>(lcol), 0u, n, static_cast<const uint32_t *>(rkeys), s, runlen, flag, &rank, &lrow, &cnt, &M, used, &dup);
+    rc = k64 ? run_partitioned<uint64_t>(ctx, static_cast<const uint64_t *>(lcol), 0x8000000000000000ull, n, static_cast<const uint64_t *>(rkeys), s, runlen, flag, lval, rranked, &rank, &lrow, &cnt, &lv, &rv, &M, used, &dup)
+             : run_partitioned<uint32_t>(ctx, static_cast<const uint32_t *>(lcol), 0u, n, static_cast<const uint32_t *>(rkeys), s, runlen, flag, nullptr, rranked, &rank, &lrow, &cnt, &lv, &rv, &M, used, &dup);
     if (rc || !*used) { hark_free(ctx, flag); hark_free(ctx, runlen); return rc; }
-    if (M == 0) { hark_free(ctx, rank); hark_free(ctx, lrow); hark_free(ctx, cnt); hark_free(ctx, flag); hark_free(ctx, runlen); return HARK_OK; }
+    if (M == 0) { hark_free(ctx, rank); hark_free(ctx, lrow); hark_free(ctx, cnt); hark_free(ctx, lv); hark_free(ctx, rv); hark_free(ctx, flag); hark_free(ctx, runlen); return HARK_OK; }
     // (rank, left row) order.  Fast path: jorder_kernel delivered it.  A rank with more than kTieMax probe rows, or a
     // group of ranks too crowded for the LDS stage, takes the general path: stable radix sort by left row, then by rank
     // (each skips the passes no byte needs), partner counts looked up again.
@@ -763,6 +851,8 @@ int k_join_partitioned(hark_context *ctx, const void *lcol, bool k64, int64_t n,
     rc = hark_read_words(ctx, flag, &general, 1);
     general &= 0xFFFFFFFFll;
     if (!rc && general) {
+        hark_free(ctx, lv); lv = nullptr;                       // the radix sorts carry one payload: the columns are gathered by the caller instead
+        hark_free(ctx, rv); rv = nullptr;
         rc = k_sort_column(ctx, lrow, HARK_U32, M, false, rank, &rank1, &lrow1);
         if (!rc) rc = k_sort_column(ctx, rank1, HARK_U32, M, false, lrow1, &lrow2, &rank2);
         hark_free(ctx, rank1); hark_free(ctx, lrow1);
@@ -779,7 +869,7 @@ int k_join_partitioned(hark_context *ctx, const void *lcol, bool k64, int64_t n,
     hark_free(ctx, flag);
     hark_free(ctx, rank); hark_free(ctx, lrow);
     hark_free(ctx, runlen);
-    if (rc) { hark_free(ctx, lrow2); hark_free(ctx, rank2); hark_free(ctx, cnt); *used = false; return rc; }
-    *rank_out = rank2; *lrow_out = lrow2; *cnt_out = cnt; *m_out = M; *unique = !dup;
+    if (rc) { hark_free(ctx, lrow2); hark_free(ctx, rank2); hark_free(ctx, cnt); hark_free(ctx, lv); hark_free(ctx, rv); *used = false; return rc; }
+    *rank_out = rank2; *lrow_out = lrow2; *cnt_out = cnt; *lval_out = lv; *rval_out = rv; *m_out = M; *unique = !dup;
     return HARK_OK;
 }

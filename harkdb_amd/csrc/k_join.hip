@@ -29,8 +29,8 @@ int k_sort_column(hark_context *ctx, const void *col, int dtype, int64_t n, bool
                   uint32_t **vals_out, uint32_t **words_out);
 int k_exclusive_scan_u32(hark_context *ctx, const uint32_t *in, int64_t n, uint32_t *out32, int64_t *out64, int64_t *total_host);
 // k_hjoin.hip: the partitioned path (probe side range-partitioned by splitters of the sorted build side, build slices in LDS)
-int k_join_partitioned(hark_context *ctx, const void *lcol, bool k64, int64_t n, const void *rkeys, int64_t s,
-                       uint32_t **rank_out, uint32_t **lrow_out, uint32_t **cnt_out, int64_t *m_out, bool *used, bool *unique);
+int k_join_partitioned(hark_context *ctx, const void *lcol, bool k64, int64_t n, const void *rkeys, int64_t s, const uint32_t *lval, const uint32_t *rranked,
+                       uint32_t **rank_out, uint32_t **lrow_out, uint32_t **cnt_out, uint32_t **lval_out, uint32_t **rval_out, int64_t *m_out, bool *used, bool *unique);
 
 namespace {
 
@@ -88,24 +88,31 @@ __global__ __launch_bounds__(256) void join_count_kernel(const K *__restrict__ l
 // per step -- so neither the output size nor skewed keys unbalance the work.
 __global__ __launch_bounds__(256) void join_expand_kernel(const int64_t *__restrict__ offs, const uint32_t *__restrict__ cnt, int64_t n,
                                                           const uint32_t *__restrict__ lb, const uint32_t *__restrict__ lperm,
-                                                          const uint32_t *__restrict__ rperm, uint32_t *__restrict__ lrow, uint32_t *__restrict__ rrow,
-                                                          uint32_t *__restrict__ kpos /* may be null: position of the pair's key in the sorted build keys */)
+                                                          const uint32_t *__restrict__ rperm, uint32_t *__restrict__ lrow,
+                                                          uint32_t *__restrict__ rrow /* may be null */,
+                                                          uint32_t *__restrict__ kpos /* may be null: position of the pair's key in the sorted build keys */,
+                                                          const uint32_t *__restrict__ lval /* may be null: a left column's value per matching row ... */,
+                                                          uint32_t *__restrict__ lval_out /* ... repeated for every pair of the row */)
 {
     const int lane = threadIdx.x & 63;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     for (int64_t base = ((((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) << 6); base < n; base += nwaves * 64) {
         const int64_t i = base + lane;
-        uint32_t c = 0, first = 0, left = 0;
+        uint32_t c = 0, first = 0, left = 0, lv = 0;
         int64_t o = 0;
-        if (i < n) { c = cnt[i]; o = offs[i]; first = lb[i]; left = lperm[i]; }
-        if (c <= 8u) for (uint32_t j = 0; j < c; j++) { lrow[o + j] = left; rrow[o + j] = rperm[first + j]; if (kpos) kpos[o + j] = first + j; }
+        if (i < n) { c = cnt[i]; o = offs[i]; first = lb[i]; left = lperm[i]; if (lval) lv = lval[i]; }
+        if (c <= 8u) for (uint32_t j = 0; j < c; j++) {
+            lrow[o + j] = left; if (rrow) rrow[o + j] = rperm[first + j]; if (kpos) kpos[o + j] = first + j; if (lval) lval_out[o + j] = lv;
+        }
         unsigned long long big = __ballot(c > 8u);
         while (big) {
             const int src = __ffsll((long long)big) - 1;
             big &= big - 1ull;
-            const uint32_t cc = __shfl(c, src, 64), ff = __shfl(first, src, 64), ll = __shfl(left, src, 64);
+            const uint32_t cc = __shfl(c, src, 64), ff = __shfl(first, src, 64), ll = __shfl(left, src, 64), vv = __shfl(lv, src, 64);
             const int64_t oo = __shfl(o, src, 64);
-            for (uint32_t j = lane; j < cc; j += 64) { lrow[oo + j] = ll; rrow[oo + j] = rperm[ff + j]; if (kpos) kpos[oo + j] = ff + j; }
+            for (uint32_t j = lane; j < cc; j += 64) {
+                lrow[oo + j] = ll; if (rrow) rrow[oo + j] = rperm[ff + j]; if (kpos) kpos[oo + j] = ff + j; if (lval) lval_out[oo + j] = vv;
+            }
         }
     }
 }
@@ -283,11 +290,29 @@ int hark_entry_join(hark_context *ctx, hark_result **out, const hark_table *db1,
     if (k64) rc = k_argsort_i64_keys(ctx, rcol, s, &rperm, &rk64);          // permutation + the sorted (biased) keys in one go
     else rc = k_argsort_column(ctx, rcol, HARK_U32, s, false, &rperm, &rkeys);
     // ---- partitioned path (k_hjoin.hip): matching probe rows as (rank in the sorted build side, left row), sorted
+    // A non-key 4-byte output column of the PROBE side can travel with the probe rows through the partitioned path (in the
+    // pad of its 16-byte i64 entries) instead of being gathered at the end: 6.25e7 random 4-byte reads over a 500-MB
+    // column cost 1.2 ms of BASELINE configs[3]'s share, carrying it ~0.25 ms.
+    int carry_col = -1;
+    if (k64) for (int64_t j = 0; j < l && carry_col < 0; j++)
+        if (cols1[j] >= 0 && cols1[j] < db1->m && cols1[j] != col1 && hark_dtype_size(db1->cols[cols1[j]].dtype) == 4 && !getenv("HARK_JOIN_NOCARRY")) carry_col = cols1[j];
+    uint32_t *sval = nullptr, *lval_exp = nullptr;    // the carried column per matching probe row / per output pair
+    // Likewise ONE non-key 4-byte output column of the BUILD side is brought into rank order up front (s random reads) and
+    // read off by the order kernel for every output row (unique build keys), instead of P reads through the rank afterwards.
+    int rank_col = -1;
+    for (int64_t j = 0; j < k && rank_col < 0; j++)
+        if (cols2[j] >= 0 && cols2[j] < db2->m && cols2[j] != col2 && hark_dtype_size(db2->cols[cols2[j]].dtype) == 4 && !getenv("HARK_JOIN_NO_RANK_GATHER")) rank_col = cols2[j];
+    uint32_t *rranked = nullptr, *rval = nullptr;
+    if (!rc && rank_col >= 0 && n >= ((int64_t)1 << 18) && s >= 4096) {       // (the partitioned path's own thresholds)
+        rc = hark_alloc(ctx, (void **)&rranked, (size_t)s * 4);
+        if (!rc) rc = k_gather(ctx, db2->cols[rank_col].data, 4, rperm, rranked, s);
+    }
     if (!rc) {
         uint32_t *prank = nullptr, *plrow = nullptr, *pcnt = nullptr;
         int64_t M = 0;
         rc = k_join_partitioned(ctx, lcol, k64, n, k64 ? static_cast<const void *>(rk64) : static_cast<const void *>(rkeys), s,
-                                &prank, &plrow, &pcnt, &M, &partitioned, &unique);
+                                carry_col >= 0 ? static_cast<const uint32_t *>(db1->cols[carry_col].data) : nullptr, rranked,
+                                &prank, &plrow, &pcnt, &sval, &rval, &M, &partitioned, &unique);
         if (!rc && partitioned) {
             nl = M;
             lb = prank; lperm = plrow; cnt = pcnt;                 // freed with the other scratch below
@@ -370,37 +395,65 @@ int hark_entry_join(hark_context *ctx, hark_result **out, const hark_table *db1,
         for (int64_t j = 0; j < k && !rc; j++)
             if (cols2[j] < 0 || cols2[j] >= db2->m) rc = hark_fail(ctx, HARK_EBOUNDS, "join: cols2[%lld] = %d out of bounds", (long long)j, cols2[j]);
 
+        // Output positions ascend with the pair's RANK in the sorted build side, so anything that is a function of the rank is
+        // read (almost) sequentially: the join key off the sorted build keys, and -- on the partitioned path -- every build
+        // side column off a copy brought into rank order once (s random reads instead of P; the right row ids themselves are
+        // then not needed).
+        const bool by_rank = partitioned && !getenv("HARK_JOIN_NO_RANK_GATHER");
         if (!rc && !unique) rc = hark_alloc(ctx, (void **)&lrow, (size_t)P * 4);
-        if (!rc) rc = hark_alloc(ctx, (void **)&rrow, (size_t)P * 4);
-        // an output column that IS the join key of either side is read off the SORTED build keys (ascending positions:
-        // a coalesced read) instead of being gathered at random through the row ids
+        if (!rc && !by_rank) rc = hark_alloc(ctx, (void **)&rrow, (size_t)P * 4);
         bool key_out = false;
         for (int64_t j = 0; j < l + k && !rc; j++) key_out = key_out || (j < l ? cols1[j] == col1 : cols2[j - l] == col2);
-        if (!rc && key_out && !unique) rc = hark_alloc(ctx, (void **)&kpos, (size_t)P * 4);
+        if (!rc && (key_out || by_rank) && !unique) rc = hark_alloc(ctx, (void **)&kpos, (size_t)P * 4);
+        if (!rc && sval && !unique) rc = hark_alloc(ctx, (void **)&lval_exp, (size_t)P * 4);
         if (!rc && unique) {                               // (left row, rank) pairs are the output rows: the right row id is one gather away
             lrow = lperm; lperm = nullptr;
             kpos = lb; lb = nullptr;
-            rc = k_gather(ctx, rperm, 4, kpos, rrow, P);
+            lval_exp = sval; sval = nullptr;
+            if (!by_rank) rc = k_gather(ctx, rperm, 4, kpos, rrow, P);
         } else if (!rc) {
-            join_expand_kernel<<<grid_for(ctx, nl), 256, 0, st>>>(offs, cnt, nl, lb, lperm, rperm, lrow, rrow, kpos);
+            join_expand_kernel<<<grid_for(ctx, nl), 256, 0, st>>>(offs, cnt, nl, lb, lperm, rperm, lrow, rrow, kpos, sval, lval_exp);
             if (hipGetLastError() != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: launch failed");
         }
         res->n = P;
+        int64_t carried_at = -1, ranked_at = -1;
         for (int64_t j = 0; j < l + k && !rc; j++) {
             const hark_table *t = j < l ? db1 : db2;
             const int c = j < l ? cols1[j] : cols2[j - l];
             res->cols[j].dtype = t->cols[c].dtype; res->cols[j].owned = true;
             const int esz = (int)hark_dtype_size(t->cols[c].dtype);
+            if (j < l && c == carry_col && lval_exp) {                               // the carried column arrived with the rows: it IS the result column
+                res->cols[j].data = lval_exp; lval_exp = nullptr; carried_at = j;
+                continue;
+            }
+            if (j >= l && c == rank_col && rval) {                                   // read off in rank order by the order kernel
+                res->cols[j].data = rval; rval = nullptr; ranked_at = j;
+                continue;
+            }
             rc = hark_alloc(ctx, &res->cols[j].data, (size_t)P * esz);
             const bool is_key = j < l ? c == col1 : c == col2;
             if (!rc && is_key && k64) gather_biased_i64_kernel<<<grid_for(ctx, P), 256, 0, st>>>(rk64, kpos, static_cast<uint64_t *>(res->cols[j].data), P);   // XOR undoes the bias
             else if (!rc && is_key) rc = k_gather(ctx, rkeys, 4, kpos, res->cols[j].data, P);
+            else if (!rc && j < l && c == carry_col && carried_at >= 0) {            // selected twice: a copy of the first
+                if (hipMemcpyAsync(res->cols[j].data, res->cols[carried_at].data, (size_t)P * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: copy failed");
+            } else if (!rc && j >= l && c == rank_col && ranked_at >= 0) {           // selected twice: a copy of the first
+                if (hipMemcpyAsync(res->cols[j].data, res->cols[ranked_at].data, (size_t)P * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: copy failed");
+            } else if (!rc && j >= l && by_rank) {
+                void *ranked = c == rank_col ? rranked : nullptr;                    // the column in rank order: ranked[r] = column[rperm[r]]
+                if (!ranked) {
+                    rc = hark_alloc(ctx, &ranked, (size_t)s * esz);
+                    if (!rc) rc = k_gather(ctx, t->cols[c].data, esz, rperm, ranked, s);
+                }
+                if (!rc) rc = k_gather(ctx, ranked, esz, kpos, res->cols[j].data, P);
+                if (ranked != rranked) hark_free(ctx, ranked);                       // stream-ordered reuse
+            }
             else if (!rc) rc = k_gather(ctx, t->cols[c].data, esz, j < l ? lrow : rrow, res->cols[j].data, P);
         }
         if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: kernels failed");
     }
     hark_free(ctx, lk64); hark_free(ctx, rk64);
     hark_free(ctx, lperm); hark_free(ctx, lkeys); hark_free(ctx, rperm); hark_free(ctx, rkeys); hark_free(ctx, lb); hark_free(ctx, cnt); hark_free(ctx, offs); hark_free(ctx, lrow); hark_free(ctx, rrow); hark_free(ctx, kpos);
+    hark_free(ctx, sval); hark_free(ctx, lval_exp); hark_free(ctx, rranked); hark_free(ctx, rval);
     if (rc) { result_release(ctx, res); return rc; }
     *out = res;
     return HARK_OK;
