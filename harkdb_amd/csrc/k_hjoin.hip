@@ -49,6 +49,12 @@ struct __attribute__((aligned(16))) JPair64 { uint64_t key; uint32_t row, pad; }
 // survivor 10240 x 12 B + 6144 counters, without 12288 x 8 B + 10240 counters (~150 KiB of LDS either way)
 constexpr int kStage = 12288, kStageCarry = 10240, kFine = 10240, kFineCarry = 6144, kCoarse = 2048, kTieMax = 64, kMaxSub = 256;
 
+#ifdef HARK_JORDER_PROF      // debug build (tools/ab_build.sh): cycles per phase of the order kernel, summed over workgroups (thread 0)
+__device__ unsigned long long g_jprof[16];
+#define JPROF_MARK(k) do { if (threadIdx.x == 0) { const unsigned long long t__ = __builtin_readcyclecounter(); atomicAdd(&g_jprof[k], t__ - jt0); jt0 = t__; } } while (0)
+#else
+#define JPROF_MARK(k) do { } while (0)
+#endif
 template <typename K> struct JTraits;
 // P buckets, rings of Q entries, VEC rows per lane and batch; the bucket kernel stages CHUNK sorted build keys per
 // round plus a bitmap of 2^BM_BITS bits over them (measured: a 16-step binary search in LDS for EVERY probe pair
@@ -463,7 +469,8 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
     __shared__ uint32_t s_wave[kJThreads / 64];
     __shared__ int s_bad, s_nsr;
     __shared__ uint16_t s_subg[kMaxSub + 1];                                   // first group of every sub-round
-    __shared__ uint32_t s_bincur[kMaxSub];
+    __shared__ uint32_t s_bincur[kMaxSub];                                     // next free slot of every sub-round's bin
+    __shared__ uint8_t s_gsub[kCoarse];                                        // sub-round of every coarse group (binning)
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) { s_dst = 0ull; s_bad = 0; s_nsr = 0; }
     __syncthreads();
@@ -481,6 +488,9 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
     __syncthreads();
     const unsigned long long dst = s_dst;
     if (nb == 0) return;
+#ifdef HARK_JORDER_PROF
+    unsigned long long jt0 = __builtin_readcyclecounter();
+#endif
     // every pass over survivors keeps 8 loads per lane in flight: one workgroup owns the CU, and with a single load per
     // lane the passes ran at the latency of a load, not at the CU's share of the bandwidth.  f(entry, third word)
     auto sweep = [&](const uint2 *sp, const uint32_t *spv, uint32_t i0, uint32_t i1, bool coherent, bool want_v, auto &&f) {
@@ -541,6 +551,7 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
         return;
     }
     scan_excl(coarse, ngroups + 1);                                    // coarse[g] = survivors before group g; coarse[ngroups] = nb
+    JPROF_MARK(0);
     const int rounds_b = (int)((len + (uint32_t)chunk_cap - 1u) / (uint32_t)chunk_cap);
     const bool by_round = rounds_b <= kMaxRounds;
     const uint32_t max_groups = max(1u, (uint32_t)FINE >> gs);
@@ -564,24 +575,32 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
         s_nsr = g < ngroups ? kMaxSub + 1 : k;                           // too many sub-rounds for the table: no binning
     }
     __syncthreads();
+    JPROF_MARK(1);
     const int nsr = s_nsr;
     const bool binned = nsr >= 3 && nsr <= kMaxSub && tmp_all != nullptr;
     uint2 *tmp = tmp_all + (size_t)b * stride;
     uint32_t *tmpv = CARRY ? tmpv_all + (size_t)b * stride : nullptr;
     if (binned) {
-        for (int k = tid; k < nsr; k += kJThreads) s_bincur[k] = 0u;
+        // one LDS read finds a survivor's sub-round (a table over the coarse groups instead of a binary search over the
+        // sub-round boundaries: four dependent LDS round trips per survivor), one returning atomic on the bin's cursor --
+        // which starts at the bin's first slot -- its place
+        for (uint32_t g = tid; g < ngroups; g += kJThreads) {
+            int a = 0, z = nsr - 1;
+            while (a < z) { const int mid = (a + z + 1) >> 1; if ((uint32_t)s_subg[mid] <= g) a = mid; else z = mid - 1; }
+            s_gsub[g] = (uint8_t)a;
+        }
+        for (int k = tid; k < nsr; k += kJThreads) s_bincur[k] = coarse[s_subg[k]];
         __syncthreads();
         sweep(src, srcv, 0u, nb, false, true, [&](uint2 e, uint32_t v) {
-            const uint32_t g = (e.x - lo) >> gs;
-            int a = 0, z = nsr - 1;                                      // the sub-round whose group range holds g
-            while (a < z) { const int mid = (a + z + 1) >> 1; if ((uint32_t)s_subg[mid] <= g) a = mid; else z = mid - 1; }
-            const uint32_t at = coarse[s_subg[a]] + atomicAdd(&s_bincur[a], 1u);
+            const uint32_t at = atomicAdd(&s_bincur[s_gsub[(e.x - lo) >> gs]], 1u);
             tmp[at] = e;
             if (CARRY) tmpv[at] = v;
         });
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");         // the bins are read back by other waves of this workgroup (same CU, same L1)
         __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
+    JPROF_MARK(2);
     uint32_t g0 = 0;
     while (g0 < ngroups) {
         const uint32_t base_cnt = coarse[g0];
@@ -598,76 +617,59 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
             }
             for (uint32_t i = tid; i <= nr; i += kJThreads) fine[i] = 0u;
             __syncthreads();
+            JPROF_MARK(3);
             sweep(sp, spv, i0, i1, binned, false, [&](uint2 e, uint32_t) { const uint32_t r = e.x - lo - r0; if (r < nr) atomicAdd(&fine[r], 1u); });
             __syncthreads();
+            JPROF_MARK(4);
             scan_excl(fine, nr);
+            JPROF_MARK(5);
             sweep(sp, spv, i0, i1, binned, true, [&](uint2 e, uint32_t v) {
                 const uint32_t r = e.x - lo - r0;
                 if (r < nr) { const uint32_t at = atomicAdd(&fine[r], 1u); stage[at] = e; if (CARRY) stv[at] = v; }   // afterwards fine[r] = end of rank r's rows
             });
             __syncthreads();
-            for (uint32_t r = tid; r < nr; r += kJThreads) {           // rows of one rank into left-row order
-                const uint32_t s0 = r ? fine[r - 1] : 0u, s1 = fine[r];
-                if (s1 - s0 < 2u) continue;
-                if (s1 - s0 > (uint32_t)kTieMax) { too_long = true; continue; }
-                const uint32_t m = s1 - s0;
-                // short runs (the usual fan-out of a key) are sorted in registers: the rank is the same for the whole run, so
-                // only the left row ids (and, CARRY, the third words with them: one 64-bit word, row id in front) move; the
-                // in-LDS insertion sort below is a chain of dependent LDS round trips (a third of this kernel at 5 rows per key)
-                typedef typename std::conditional<CARRY, unsigned long long, uint32_t>::type u64;      // (32-bit words without a third word)
-                auto get = [&](uint32_t x) -> u64 {
-                    if constexpr (CARRY) return ((unsigned long long)stage[s0 + x].y << 32) | (unsigned long long)stv[s0 + x];
-                    else return stage[s0 + x].y;
-                };
-                auto put = [&](uint32_t x, u64 w) {
-                    if constexpr (CARRY) { stage[s0 + x].y = (uint32_t)(w >> 32); stv[s0 + x] = (uint32_t)w; }
-                    else stage[s0 + x].y = w;
-                };
-                auto lt64 = [](u64 a, u64 c) { return a < c; };
-                if (m <= 4u) {
-                    u64 v[4];
-#pragma unroll
-                    for (int x = 0; x < 4; x++) v[x] = (uint32_t)x < m ? get(x) : (u64)~(u64)0;
-                    net_sort4(v, lt64);
-#pragma unroll
-                    for (int x = 0; x < 4; x++) if ((uint32_t)x < m) put(x, v[x]);
-                    continue;
-                }
-                if (m <= 8u) {
-                    u64 v[8];
-#pragma unroll
-                    for (int x = 0; x < 8; x++) v[x] = (uint32_t)x < m ? get(x) : (u64)~(u64)0;
-                    net_sort8(v, lt64);
-#pragma unroll
-                    for (int x = 0; x < 8; x++) if ((uint32_t)x < m) put(x, v[x]);
-                    continue;
-                }
-                if (m <= 16u) {
-                    u64 v[16];
-#pragma unroll
-                    for (int x = 0; x < 16; x++) v[x] = (uint32_t)x < m ? get(x) : (u64)~(u64)0;
-                    net_sort16(v, lt64);
-#pragma unroll
-                    for (int x = 0; x < 16; x++) if ((uint32_t)x < m) put(x, v[x]);
-                    continue;
-                }
-                for (uint32_t x = 1; x < m; x++) {                       // left row ids are distinct
-                    const u64 e = get(x);
-                    uint32_t y = x;
-                    while (y > 0 && get(y - 1) > e) { put(y, get(y - 1)); y--; }
-                    put(y, e);
-                }
-            }
-            __syncthreads();
+            JPROF_MARK(6);
+            // ---- rows of one rank into left-row order, and out: every survivor counts the rows of ITS rank (the stage's run
+            // [fine[r-1], fine[r]), five or so) that are smaller than its own -- row ids are distinct, so that is its place in
+            // the run -- and stores itself there.  (A first version sorted each run in registers with sorting networks, one
+            // lane per rank: lanes of a wave held runs of 2..16 rows, so every wave ran the 4-, 8- and 16-input networks on
+            // 64-bit words one after the other -- ~1400 vector instructions per wave and sub-round against ~250 here -- and
+            // then wrote the stage out in a separate pass.)
             const unsigned long long o = dst + base_cnt;
-            for (uint32_t i = tid; i < nsub; i += kJThreads) {
-                const uint2 e = stage[i];
-                rank[o + i] = e.x; lrow[o + i] = e.y;                    // (lrow is needed by the general path, which is only known at the end)
-                if (cnt_out) cnt_out[o + i] = runlen[e.x];
-                if (CARRY) lval_out[o + i] = stv[i];
-                if (rranked) rval_out[o + i] = rranked[e.x];             // ranks ascend along the stage: an (almost) sequential read
+            // four survivors per lane at a time: their LDS round trips and the reads through the rank overlap
+            constexpr int kB = 4;
+            for (uint32_t i0 = tid; i0 < nsub; i0 += kB * kJThreads) {
+                uint2 e[kB]; uint32_t s0[kB], s1[kB], at[kB], v3[kB], rv[kB], rl[kB];
+#pragma unroll
+                for (int q = 0; q < kB; q++) { const uint32_t i = min(i0 + (uint32_t)q * kJThreads, nsub - 1u); e[q] = stage[i]; v3[q] = CARRY ? stv[i] : 0u; at[q] = i; }
+#pragma unroll
+                for (int q = 0; q < kB; q++) {
+                    const uint32_t r = e[q].x - lo - r0;
+                    s0[q] = r ? fine[r - 1] : 0u; s1[q] = fine[r];
+                    rv[q] = rranked ? rranked[e[q].x] : 0u;               // ranks ascend along the stage: an (almost) sequential read
+                    rl[q] = cnt_out ? runlen[e[q].x] : 0u;
+                }
+#pragma unroll
+                for (int q = 0; q < kB; q++) {
+                    if (s1[q] - s0[q] > (uint32_t)kTieMax) too_long = true;      // a hot key: the caller's radix sorts order everything
+                    else if (s1[q] - s0[q] > 1u) {
+                        uint32_t c = 0;
+                        for (uint32_t j = s0[q]; j < s1[q]; j++) c += stage[j].y < e[q].y ? 1u : 0u;
+                        at[q] = s0[q] + c;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < kB; q++) {
+                    if (i0 + (uint32_t)q * kJThreads < nsub) {
+                        rank[o + at[q]] = e[q].x; lrow[o + at[q]] = e[q].y;
+                        if (cnt_out) cnt_out[o + at[q]] = rl[q];
+                        if (CARRY) lval_out[o + at[q]] = v3[q];
+                        if (rranked) rval_out[o + at[q]] = rv[q];
+                    }
+                }
             }
             __syncthreads();
+            JPROF_MARK(7);
         }
         g0 = g1;
     }
@@ -873,3 +875,12 @@ int k_join_partitioned(hark_context *ctx, const void *lcol, bool k64, int64_t n,
     *rank_out = rank2; *lrow_out = lrow2; *cnt_out = cnt; *lval_out = lv; *rval_out = rv; *m_out = M; *unique = !dup;
     return HARK_OK;
 }
+
+#ifdef HARK_JORDER_PROF
+extern "C" int hark_debug_jprof(unsigned long long *out16)
+{
+    unsigned long long zero[16] = {0};
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_jprof), sizeof zero) != hipSuccess) return 1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_jprof), zero, sizeof zero) == hipSuccess ? 0 : 1;
+}
+#endif
