@@ -105,6 +105,29 @@ def test_partitioned_join_reference_order(eng, case):
         assert pairs > 0
 
 
+@pytest.mark.parametrize("unique", [True, False])
+def test_i64_join_with_several_output_columns(eng, unique):
+    """Output columns of the i64 path arrive in three ways: ONE probe-side column travels with the probe rows (the fourth
+    word of their 16-byte entries), ONE build-side column is read off in rank order by the order kernel (unique build
+    keys) or through the pair's rank, everything else -- further columns, f32, a column selected twice, the key itself --
+    is gathered.  All of them against numpy, row for row."""
+    rng = np.random.default_rng(21 + int(unique))
+    n, s = 300_007, 40_000
+    rk = (rng.permutation(s).astype(np.int64) * 7919 - 10**9) if unique else rng.integers(-5000, 5000, size=s).astype(np.int64)
+    lk = rng.integers(-2**62, 2**62, size=n).astype(np.int64)
+    hit = rng.random(n) < (0.5 if unique else 0.02)
+    lk[hit] = rk[rng.integers(0, s, size=int(hit.sum()))]
+    la, lf, lc = rng.integers(-2**31, 2**31, n).astype(np.int32), rng.random(n).astype(np.float32), rng.integers(0, 99, n).astype(np.int32)
+    ra, rf = rng.integers(0, 2**31, s).astype(np.int32), rng.random(s).astype(np.float32)
+    t1, t2 = eng.table_from_columns([lk, la, lf, lc]), eng.table_from_columns([rk, ra, rf])
+    res = eng.join(t1, t2, 0, 0, [2, 1, 0, 3, 1], [2, 1, 0, 1])
+    li, ri = _np_join_rows(lk, rk)
+    assert res.shape == (len(li), 9) and len(li) > 0
+    for j, exp in enumerate([lf[li], la[li], lk[li], lc[li], la[li], rf[ri], ra[ri], rk[ri], ra[ri]]):
+        assert np.array_equal(res.column(j), exp), j
+    res.free(); t1.free(); t2.free()
+
+
 def test_keys_outside_the_build_range_and_exact_batch_multiples(eng):
     rng = np.random.default_rng(9)
     s, n = 4096, 1 << 18                                         # n is a multiple of the 4096-row batch
