@@ -209,10 +209,27 @@ __global__ __launch_bounds__(kThreads) void filter_scatter_kernel(const uint16_t
     }
     const uint32_t tile_total = run;
     const int64_t out0 = offsets[tile];
+    // Columns are compacted one after the other through the LDS stage; the 16-byte loads of the NEXT 4-byte column are issued
+    // before the current column is written out, so that they travel under that write-out (the row-index column, which
+    // loads nothing, goes first: the first data column is fetched under it).
     const int ncols = cs.ncols + (row_index ? 1 : 0);
-    for (int cidx = 0; cidx < ncols; cidx++) {
+    uint4 pre[4];
+    auto prefetch = [&](int c) -> bool {
+        if (c < 0 || c >= cs.ncols || cs.esz[c] != 4) return false;
+        const uint32_t *src = static_cast<const uint32_t *>(cs.src[c]);
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const int64_t r = tile * kTile + ((int64_t)g * kThreads + threadIdx.x) * 4;
+            pre[g] = (((mask >> (g * 4)) & 15u) && r + 4 <= n) ? ld_nt16(src + r) : uint4{0u, 0u, 0u, 0u};
+        }
+        return true;
+    };
+    bool have = prefetch(0);
+    for (int k = 0; k < ncols; k++) {
+        const int cidx = row_index ? (k == 0 ? cs.ncols : k - 1) : k;      // the index first
         const bool is_index = row_index && cidx == cs.ncols;
         const int esz = is_index ? 8 : cs.esz[cidx];
+        const int next = row_index ? k : k + 1;                             // the data column after this one
         uint32_t *s32 = reinterpret_cast<uint32_t *>(s_stage);
 #pragma unroll
         for (int g = 0; g < 4; g++) {
@@ -226,7 +243,7 @@ __global__ __launch_bounds__(kThreads) void filter_scatter_kernel(const uint16_t
             } else if (esz == 4) {
                 const uint32_t *src = static_cast<const uint32_t *>(cs.src[cidx]);
                 uint32_t x[4];
-                if (r + 4 <= n) { const uint4 v4 = ld_nt16(src + r); x[0] = v4.x; x[1] = v4.y; x[2] = v4.z; x[3] = v4.w; }
+                if (r + 4 <= n) { const uint4 v4 = have ? pre[g] : ld_nt16(src + r); x[0] = v4.x; x[1] = v4.y; x[2] = v4.z; x[3] = v4.w; }
                 else for (int j = 0; j < 4; j++) x[j] = r + j < n ? src[r + j] : 0u;
 #pragma unroll
                 for (int j = 0; j < 4; j++) if (m4 & (1u << j)) s32[q++] = x[j];
@@ -237,6 +254,7 @@ __global__ __launch_bounds__(kThreads) void filter_scatter_kernel(const uint16_t
             }
         }
         lds_barrier();
+        have = is_index ? have : prefetch(next);                            // (under the index column the first data column is already on its way)
         if (esz == 4) {
             uint32_t *dst = static_cast<uint32_t *>(cs.dst[cidx]) + out0;
             for (uint32_t i = threadIdx.x; i < tile_total; i += kThreads) dst[i] = s32[i];
