@@ -28,7 +28,7 @@ import numpy as np
 
 from . import _ffi
 from .engine import Engine
-from .parse import sql_parse
+from .parse import sql_parse, sql_parse_tree, JOIN_RESULT
 from .table import Table
 
 _AGG_NAME = {"key": "key", "prod": "prod", "sum": "sum", "max": "max", "min": "min", "count": "count", "avg": "avg"}
@@ -91,7 +91,10 @@ class FutharkContext:
 
     def sql_columns(self, sql_statement):
         """Like sql() but returns (column names, list of typed numpy columns)."""
-        val_dic = sql_parse(self.tables, sql_statement)                    # FutharkContext.py:61
+        return self._run(sql_parse(self.tables, sql_statement))            # FutharkContext.py:61
+
+    def _run(self, val_dic):
+        """Executes a planned statement (the IR of parse.sql_parse_tree)."""
         if val_dic.get("join"):
             return self._join(val_dic)
         table = self.tables[val_dic["table_name"]]
@@ -122,6 +125,8 @@ class FutharkContext:
         """Two-table FROM -> `entry join` (futhark/join.fut:52-75): rows ordered by
         (unsigned key, left row, right row); columns re-ordered to the select list."""
         t1, t2 = (self.tables[n] for n in ir["tables"])
+        if "post" in ir:
+            return self._join_with_clauses(ir, t1._device, t2._device)
         res = self.FutEnv.join(t1._device, t2._device, ir["col1"], ir["col2"], ir["cols1"], ir["cols2"])
         cols = res.columns(limit=ir.get("limit"))
         left_pos = {c: i for i, c in reversed(list(enumerate(ir["cols1"])))}
@@ -131,6 +136,28 @@ class FutharkContext:
         if "limit" in ir:
             out = [c[: ir["limit"]] for c in out]
         return names, out
+
+    def _join_with_clauses(self, ir, d1, d2):
+        """JOIN under WHERE / GROUP BY / HAVING / ORDER BY (parse._join_with_clauses): conjuncts are pushed below the join,
+        the join's result becomes a device table named JOIN_RESULT with the qualified column names as its schema, and the
+        remaining clauses run over it like over any table."""
+        eng = self.FutEnv
+        sides = []
+        for dev, where, kcol, cols in ((d1, ir["where1"], ir["col1"], ir["cols1"]), (d2, ir["where2"], ir["col2"], ir["cols2"])):
+            if where:
+                cur, cmap = self._filtered(dev, where, set(cols) | {kcol})
+                sides.append((cur, cmap[kcol], [cmap[c] for c in cols]))
+            else:
+                sides.append((dev, kcol, list(cols)))
+        (a, ka, ca), (b, kb, cb) = sides
+        res = eng.join(a, b, ka, kb, ca, cb)
+        n, m = res.shape
+        self.create_table_from_device(JOIN_RESULT, ir["post_schema"], [res.device_ptr(j) for j in range(m)], [res.dtype(j) for j in range(m)], n,
+                                      keepalive=(res, sides))
+        try:
+            return self._run(sql_parse_tree(self.tables, ir["post"]))
+        finally:
+            self.drop_table(JOIN_RESULT)
 
     def _filtered(self, dev, where, need_cols):
         """Apply an AND-list of predicates on the device in ONE compaction (all conjuncts go into one survivor mask);
@@ -152,7 +179,9 @@ class FutharkContext:
     def select_result(self, sql_statement):
         """A projection / WHERE / ORDER BY statement evaluated to a DEVICE-resident Result (select-list columns, LIMIT
         not applied); the sharded context gathers such results between GPUs without a host trip."""
-        ir = sql_parse(self.tables, sql_statement)
+        return self.select_result_ir(sql_parse(self.tables, sql_statement))
+
+    def select_result_ir(self, ir):
         if "groupbys" in ir or ir.get("join"):
             raise Exception("select_result supports `select <columns> from t [where] [order by]`")
         dev = self.tables[ir["table_name"]]._device

@@ -581,15 +581,17 @@ class ShardedFutharkContext:
 
     def sql_columns(self, sql_statement):
         from .parse import sql_parse
-        ir = sql_parse(self.local.tables, sql_statement)
+        return self._run(sql_parse(self.local.tables, sql_statement))
+
+    def _run(self, ir):
+        """Executes a planned statement (the IR of parse.sql_parse_tree) over the shards."""
         if ir.get("join"):
             return self._join(ir)
         if "groupbys" not in ir:
             if ("orderby" in ir or ir.get("orderby_all")) and (self.world > 1 or self.device_exchange):
                 return self._orderby(ir)
             limit = ir.pop("limit", None)
-            stmt = sql_statement if limit is None else sql_statement[: sql_statement.lower().rindex("limit")]
-            names, res = self.local.select_result(stmt)                 # device-resident: gathered over RCCL as it is
+            names, res = self.local.select_result_ir(ir)                # device-resident: gathered over RCCL as it is
             tens, dts = result_tensors(res, self.device, limit)         # no rank contributes more than LIMIT rows
             cols = gather_columns(tens, device=self.device, np_dtypes=dts)
             return names, ([c[:limit] for c in cols] if limit is not None else cols)
@@ -806,11 +808,16 @@ class ShardedFutharkContext:
         eng = self.local.FutEnv
         exchange = self.world > 1 or self.device_exchange
         sides, samples = [], []
-        for tname, kcol, cols in ((ir["tables"][0], ir["col1"], ir["cols1"]), (ir["tables"][1], ir["col2"], ir["cols2"])):
+        for tname, kcol, cols, where in ((ir["tables"][0], ir["col1"], ir["cols1"], ir.get("where1")), (ir["tables"][1], ir["col2"], ir["cols2"], ir.get("where2"))):
             dev = self.local.tables[tname]._device
             need = [kcol] + [c for c in dict.fromkeys(cols) if c != kcol]
+            if where:                                                    # conjuncts of the WHERE on this table: below the exchange and the join
+                cur, cmap = self.local._filtered(dev, where, set(need))
+                dev, need_at = cur, [cmap[c] for c in need]
+            else:
+                need_at = need
             n = dev.shape[0]
-            ptrs, dts = [dev.device_ptr(c) for c in need], [dev.dtype(c) for c in need]
+            ptrs, dts = [dev.device_ptr(c) for c in need_at], [dev.dtype(c) for c in need_at]
             kdt = np.dtype(np.uint32) if np.dtype(dts[0]).itemsize == 4 else np.dtype(dts[0])      # the join's own key order
             sides.append((dev, need, n, ptrs, dts, kdt))
             if exchange:
@@ -828,6 +835,17 @@ class ShardedFutharkContext:
             tabs.append((t, {c: i for i, c in enumerate(need)}))
         (t1, m1), (t2, m2) = tabs
         res = eng.join(t1, t2, 0, 0, [m1[c] for c in ir["cols1"]], [m2[c] for c in ir["cols2"]])
+        if "post" in ir:
+            # the clauses around the join run over its result as over any sharded table: every owner's pairs are its rows
+            # (key ranges ascend with the rank, so rank order IS the join's order)
+            from .parse import sql_parse_tree, JOIN_RESULT
+            n, m = res.shape
+            self.create_table_from_device(JOIN_RESULT, ir["post_schema"], [res.device_ptr(j) for j in range(m)], [res.dtype(j) for j in range(m)], n,
+                                          keepalive=(res, tabs))
+            try:
+                return self._run(sql_parse_tree(self.local.tables, ir["post"]))
+            finally:
+                self.drop_table(JOIN_RESULT)
         tens, dts = result_tensors(res, self.device, ir.get("limit"))     # no owner contributes more than LIMIT rows
         cols = gather_columns(tens, device=self.device, np_dtypes=dts)
         left_pos = {c: i for i, c in reversed(list(enumerate(ir["cols1"])))}

@@ -41,7 +41,11 @@ def _conditions(tree):
 
 def sql_parse(tables, sql_statement):
     """Parses an SQL statement (parse.py:16)."""
-    js_obj = parse(sql_statement)                                       # parse.py:27
+    return sql_parse_tree(tables, parse(sql_statement))                 # parse.py:27
+
+
+def sql_parse_tree(tables, js_obj):
+    """The planner proper: parse tree (moz_sql_parser's JSON shape) -> IR."""
     if "select_distinct" in js_obj:
         # SELECT DISTINCT a, b  ==  SELECT a, b ... GROUP BY a, b  (extension; rows come out in ascending key order)
         sel = js_obj.pop("select_distinct")
@@ -197,9 +201,6 @@ def _join_parse(tables, js_obj):
     for t in (left, right):
         if t not in tables:
             raise Exception(f"{t} is not in tables")                    # parse.py:33
-    for clause in ("where", "groupby", "having", "orderby"):
-        if clause in js_obj:
-            raise Exception(f"{clause} is not supported together with JOIN")
     names = [left, right]
     (s1, c1), (s2, c2) = (_qualified(x, names, tables) for x in j["on"]["eq"])
     if s1 == s2:
@@ -208,6 +209,8 @@ def _join_parse(tables, js_obj):
         c1, c2 = c2, c1
     sel = js_obj["select"]
     sel = [sel] if isinstance(sel, (dict, str)) else sel
+    if any(cl in js_obj for cl in ("where", "groupby", "having", "orderby")) or any(it != "*" and not isinstance(it["value"], str) for it in sel):
+        return _join_with_clauses(tables, js_obj, names, c1, c2, sel)
     order = []                                                          # (side, column) in select-list order
     for item in sel:
         if item == "*":
@@ -221,3 +224,68 @@ def _join_parse(tables, js_obj):
     if "limit" in js_obj:
         ir["limit"] = int(js_obj["limit"])
     return ir
+
+
+JOIN_RESULT = "__join__"          # the name under which a join's result is queried by the clauses around it
+
+
+def _join_with_clauses(tables, js_obj, names, c1, c2, sel):
+    """JOIN with WHERE / GROUP BY / HAVING / ORDER BY / aggregates (the reference has neither; SURVEY.md 8(f) 3 asks for the
+    two-table FROM only).  Planned as three steps the executor runs on the device:
+      1. WHERE is an AND-list of `column <op> number` comparisons, each on ONE table: every conjunct is pushed below the
+         join (a compaction keeps row order, so the join's (key, left row, right row) order is the same as filtering after);
+      2. the join delivers every column the other clauses mention, as a table whose schema holds the QUALIFIED names
+         (`t.k`, `b.y`);
+      3. "post": the statement's remaining clauses as a single-table parse tree over that table (column references
+         rewritten to their qualified names), planned by sql_parse_tree like any other statement."""
+    def qname(side, col):
+        return f"{names[side]}.{tables[names[side]].get_schema()[col]}"
+
+    used = []                                                           # (side, column) the join has to deliver, in first-use order
+
+    def ref(name):
+        sc = _qualified(name, names, tables)
+        if sc not in used:
+            used.append(sc)
+        return qname(*sc)
+
+    def term(t):                                                        # column | {agg: column | "*"} | number
+        if isinstance(t, str):
+            return t if t == "*" else ref(t)
+        if isinstance(t, dict):
+            (f, a), = t.items()
+            return {f: a if a == "*" else ref(a)}
+        return t
+
+    where = [[], []]
+    for cond in _conditions(js_obj.get("where")):
+        (op, (lhs, rhs)), = cond.items()
+        if not isinstance(lhs, str) or not isinstance(rhs, (int, float)):
+            raise Exception("WHERE supports `column <op> number` comparisons (joined by AND)")
+        side, col = _qualified(lhs, names, tables)
+        where[side].append((col, _CMP_SQL[op], rhs))
+    post = {"from": JOIN_RESULT}
+    items = []
+    for it in sel:
+        if it == "*":
+            items += [{"value": ref(f"{names[sd]}.{c}")} for sd in (0, 1) for c in tables[names[sd]].get_schema()]
+        else:
+            items.append({"value": term(it["value"])})
+    post["select"] = items[0] if len(items) == 1 else items
+    if "groupby" in js_obj:
+        gb = js_obj["groupby"]
+        gb = [{"value": ref(g["value"])} for g in (gb if isinstance(gb, list) else [gb])]
+        post["groupby"] = gb[0] if len(gb) == 1 else gb
+    if "having" in js_obj:
+        conds = [{op: [term(l), r]} for cond in _conditions(js_obj["having"]) for (op, (l, r)) in [next(iter(cond.items()))]]
+        post["having"] = conds[0] if len(conds) == 1 else {"and": conds}
+    if "orderby" in js_obj:
+        obs = js_obj["orderby"] if isinstance(js_obj["orderby"], list) else [js_obj["orderby"]]
+        obs = [dict(o, value=term(o["value"])) for o in obs]
+        post["orderby"] = obs[0] if len(obs) == 1 else obs
+    if "limit" in js_obj:
+        post["limit"] = js_obj["limit"]
+    return {"join": True, "tables": names, "col1": c1, "col2": c2, "extended": True,
+            "cols1": [c for s_, c in used if s_ == 0], "cols2": [c for s_, c in used if s_ == 1],
+            "where1": where[0], "where2": where[1], "post": post,
+            "post_schema": [qname(s_, c) for s_, c in used if s_ == 0] + [qname(s_, c) for s_, c in used if s_ == 1]}

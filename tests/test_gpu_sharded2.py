@@ -34,6 +34,9 @@ STATEMENTS = [
     "select w, k from t order by w desc, k desc limit 60",
     # the join in the reference's order, with a LIMIT cut
     "select t.k, b.y, t.w from t join b on t.w = b.x limit 1000",
+    # clauses around a join: conjuncts below the exchange, the owners' pairs as a sharded table for the rest
+    "select b.y, sum(v), count(*) from t join b on t.w = b.x where p > 0.5 and y < 600 group by b.y having count(*) > 10 order by sum(v) desc limit 12",
+    "select t.k, b.y from t join b on t.w = b.x where p > 0.98 order by y desc limit 40",
 ]
 DENSE = {9, 10, 11, 12}          # statements whose aggregation must take the all-reduce path
 

@@ -171,6 +171,40 @@ def test_join_statement(fc, oracle):
     assert np.array_equal(out, ref[:, [2, 0, 1]].astype(out.dtype))
 
 
+def test_join_under_where_groupby_having_orderby_limit(oracle):
+    """JOIN with the other clauses around it, against pandas: conjuncts pushed below the join, GROUP BY / HAVING / ORDER BY /
+    LIMIT over the join's result, bare columns resolved to their table, `*`, ORDER BY on the joined rows."""
+    from harkdb_amd import FutharkContext
+    c = FutharkContext(sql_mode=True)
+    rng = np.random.default_rng(31)
+    n, s = 200_000, 3_000
+    t = pd.DataFrame({"k": rng.integers(0, 400, n).astype(np.int32), "p": rng.random(n).astype(np.float32),
+                      "v": rng.integers(0, 16, n).astype(np.float32), "w": rng.integers(-50, 5000, n).astype(np.int32)})
+    b = pd.DataFrame({"x": rng.permutation(5000)[:s].astype(np.int32), "y": rng.integers(0, 100, s).astype(np.int32)})
+    c.create_table("t", t); c.create_table("b", b)
+    j = t.reset_index().merge(b.reset_index(), left_on="w", right_on="x", suffixes=("_l", "_r")).sort_values(["w", "index_l", "index_r"], kind="stable")
+    # WHERE on both tables + projection: the join's order (key, left row, right row) restricted to the surviving rows
+    names, cols = c.sql_columns("select t.k, b.y, v from t join b on t.w = b.x where p > 0.5 and y < 40")
+    e = j[(j.p > 0.5) & (j.y < 40)]
+    assert names == ["t.k", "b.y", "t.v"]
+    assert np.array_equal(cols[0], e.k.to_numpy()) and np.array_equal(cols[1], e.y.to_numpy()) and np.array_equal(cols[2], e.v.to_numpy())
+    # GROUP BY a build-side column with aggregates of probe-side columns, HAVING, ORDER BY, LIMIT
+    names, cols = c.sql_columns("select y, sum(v), count(*), max(k) from t join b on t.w = b.x where p > 0.25 "
+                                "group by y having count(*) > 100 order by sum(v) desc limit 9")
+    g = j[j.p > 0.25].groupby("y").agg(sv=("v", "sum"), n=("v", "count"), mk=("k", "max")).reset_index()
+    g = g[g.n > 100].sort_values("sv", ascending=False, kind="stable").head(9)
+    assert names == ["b.y", "sum(t.v)", "count(*)", "max(t.k)"]
+    assert np.array_equal(cols[0], g.y.to_numpy()) and np.array_equal(cols[1], g.sv.to_numpy().astype(np.float32))
+    assert np.array_equal(cols[2], g.n.to_numpy()) and np.array_equal(cols[3], g.mk.to_numpy())
+    # ORDER BY over the joined rows (stable: ties keep the join's order), and `*`
+    names, cols = c.sql_columns("select * from t join b on t.w = b.x where y = 7 order by k desc limit 25")
+    e = j[j.y == 7].sort_values("k", ascending=False, kind="stable").head(25)
+    assert names == ["t.k", "t.p", "t.v", "t.w", "b.x", "b.y"]
+    for got, col in zip(cols, ("k", "p", "v", "w", "x", "y")):
+        assert np.array_equal(got, e[col].to_numpy()), col
+    c.drop_table("t"); c.drop_table("b")
+
+
 @pytest.fixture(scope="module")
 def fc_multi():
     from harkdb_amd import FutharkContext

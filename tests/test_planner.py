@@ -108,6 +108,29 @@ def test_join_parse_tree_and_ir(tables):
         sql_parse(two, "select l.col1 from l join zzz on l.col1 = zzz.col1")
 
 
+def test_join_with_where_groupby_orderby_is_planned_in_three_steps(tables):
+    """JOIN under other clauses: per-table conjuncts are pushed below the join, the join delivers the columns the other
+    clauses mention under their qualified names, and those clauses become a single-table statement over that result."""
+    from harkdb_amd.parse import sql_parse_tree, JOIN_RESULT
+    two = {"l": tables["game_1"], "r": Table("r", np.arange(6).reshape(3, 2))}
+    ir = sql_parse(two, "select l.col1, sum(col3), count(*) from l join r on l.col8 = r.col1 where l.col2 > 3 and r.col2 <= 5 "
+                        "group by l.col1 having count(*) > 1 order by sum(col3) desc limit 4")
+    assert ir["join"] and (ir["col1"], ir["col2"]) == (7, 0)
+    assert ir["where1"] == [(1, ">", 3)] and ir["where2"] == [(1, "<=", 5)]
+    assert ir["cols1"] == [0, 2] and ir["cols2"] == [] and ir["post_schema"] == ["l.col1", "l.col3"]
+    post = ir["post"]
+    assert post["from"] == JOIN_RESULT and post["groupby"] == {"value": "l.col1"} and post["limit"] == 4
+    assert post["select"] == [{"value": "l.col1"}, {"value": {"sum": "l.col3"}}, {"value": {"count": "*"}}]
+    joined = Table(JOIN_RESULT, np.zeros((0, 2), dtype=np.int64))
+    joined._schema = ir["post_schema"]                                   # what the executor registers the join's result as
+    ir2 = sql_parse_tree({**two, JOIN_RESULT: joined}, post)
+    assert ir2["g_col"] == 0 and ir2["items"] == [("key", 0), ("sum", 1), ("count", None)] and ir2["orderby"] == (("sum", 1), True)
+    plain = sql_parse(two, "select l.col1, r.col2 from l join r on l.col8 = r.col1 limit 3")
+    assert "post" not in plain and plain["limit"] == 3                    # the bare join keeps its direct path
+    with pytest.raises(Exception, match="ambiguous"):
+        sql_parse(two, "select l.col1 from l join r on l.col8 = r.col1 where col1 > 2")
+
+
 # ---- against the output of the reference's own parse.py / table.py ---------------------------------
 # tests/golden/reference_host.json was produced by RUNNING the reference (tests/golden/make_reference_goldens.py).
 import json
