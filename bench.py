@@ -475,6 +475,12 @@ def main():
         knobs["algo"] = a.algo
     if a.chunk_rows:
         knobs["chunk_rows"] = a.chunk_rows
+    # With peers, the producer leaves a few CUs to RCCL: its 256 workgroups of 1024 threads otherwise hold every CU for the
+    # whole 2.5 ms, and the all-reduce of the previous step (pipelined mode) could only start in the producer's tail.
+    # 240 of 256 is a choice made WITHOUT multi-GPU hardware; HARK_PRODUCER_WGS overrides it (0 = all CUs).
+    producer_wgs = int(os.environ.get("HARK_PRODUCER_WGS", "240" if world > 1 else "0"))
+    if producer_wgs > 0:
+        knobs["grid"] = producer_wgs
     plan = FgbPlan(eng, N, G, **knobs)
     # N > 1: a second plan lets step i's all-reduce run on RCCL's stream beside the kernels of step i+1 (dist.ShardedFgb)
     # (HARK_FORCE_PIPELINE=1: also with one rank -- tests/test_gpu_bench_rank.py runs the pipelined, asynchronous
@@ -602,7 +608,8 @@ def main():
                        "exact_values": bool(a.exact),
                        "merge": ("RCCL " + ("reduce-scatter + all-gather" if os.environ.get("HARK_ALLREDUCE") == "rs_ag" else "all-reduce")
                                  + " of f64 sums + i64 counts" + (", overlapped with the next step's kernels" if plan2 is not None else "")) if dist.is_initialized() else "none",
-                       "pipelined_steps": plan2 is not None},
+                       "pipelined_steps": plan2 is not None, "producer_workgroups": producer_wgs or "all CUs",
+                       "allreduce": os.environ.get("HARK_ALLREDUCE", "allreduce"), "overlap": os.environ.get("HARK_OVERLAP", "1") != "0"},
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": path_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": path_achieved / HBM_PEAK_GBS,
                          "frac_is": "whole path per GPU: (12 B/row x rows + 16 B x groups) / wall time of a step / 8 TB/s",

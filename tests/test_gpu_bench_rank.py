@@ -27,6 +27,7 @@ def test_bench_rank_under_rccl(pipeline, how):
                HARK_ALLREDUCE=how, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     if pipeline:
         env["HARK_FORCE_PIPELINE"] = "1"
+        env["HARK_PRODUCER_WGS"] = "240"                      # what N > 1 runs use: the producer leaves 16 CUs to RCCL
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--rows", "3000000", "--groups", str(1 << 20),
                           "--steps", "5", "--warmup", "2", "--cpu-rows", "0", "--configs", "0", "--pmc", "0"],
                          capture_output=True, text=True, timeout=600, env=env)
@@ -35,6 +36,7 @@ def test_bench_rank_under_rccl(pipeline, how):
     assert line["rccl_ranks"] == 1 and line["n_gpus"] == 1
     assert line["check"] == {"count_checksum": True, "sum_checksum": True}
     assert line["config"]["pipelined_steps"] == bool(pipeline)
+    assert line["config"]["producer_workgroups"] == (240 if pipeline else "all CUs")
     assert line["config"]["merge"].startswith("RCCL")
     assert len(line["ms_per_step_by_rank"]) == 1 and line["value"] > 0
 

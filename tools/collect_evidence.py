@@ -3,7 +3,7 @@ Usage: python tools/collect_evidence.py r02"""
 import collections, csv, glob, json, os, re, shutil, sys
 
 tag = sys.argv[1]
-src, dst = "gpurun_out/ev2", "profiles"
+src, dst = "gpurun_out/ev3", "profiles"
 
 
 def first(pattern):
@@ -22,7 +22,9 @@ for pat, out in (("stats/**/*kernel_stats.csv", "bench_kernel_stats.csv"), ("sta
 
 bench = json.loads(open(os.path.join(src, "pmc_fetch.json")).read().strip().splitlines()[-1])
 cfg = bench["config"]
-out = {"command": "rocprofv3 --pmc <COUNTER> --kernel-trace --output-format csv -- python3 bench.py --steps 2 --warmup 1 --cpu-rows 0 --configs 0  (one pass per counter)",
+import subprocess
+out = {"git": subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip(),
+       "command": "rocprofv3 --pmc <COUNTER> --kernel-trace --output-format csv -- python3 bench.py --steps 2 --warmup 1 --cpu-rows 0 --configs 0  (one pass per counter)",
        "units": "FETCH_SIZE / WRITE_SIZE count KiB; on gfx950 FETCH_SIZE reports half of a wide coalesced read stream, so hbm_read_bytes = 2 * FETCH_SIZE * 1024 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact",
        "kernels": {}, "config": {"rows_per_gpu": cfg["rows_per_gpu"], "groups": cfg["groups"], "chunk_rows": 0,
                                  "producer_launches_per_step": bench["roofline"]["launches"] // bench["steps"]}}
