@@ -166,12 +166,24 @@ def measure_traffic(N, G, timeout_s=240):
     return dict(kernels), None
 
 
-def git_head():
+def build_id():
+    """What produced a number: the git commit where a checkout is at hand, else (the GPU box receives a snapshot without
+    .git) the first 16 hex digits of sha256 of bench.py and of the loaded libhark.so."""
+    import hashlib
     try:
         import subprocess
-        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip() or None
+        h = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip()
+        if h:
+            return "git " + h
     except Exception:
-        return None
+        pass
+    out = []
+    for f in (os.path.abspath(__file__), os.environ.get("HARK_LIB") or os.path.join(ROOT, "harkdb_amd", "libhark.so")):
+        try:
+            out.append(os.path.basename(f) + " sha16 " + hashlib.sha256(open(f, "rb").read()).hexdigest()[:16])
+        except Exception:
+            pass
+    return ", ".join(out) or None
 
 
 def stub_main(a):
@@ -578,7 +590,7 @@ def main():
             traffic_detail, traffic_note = measure_traffic(N, G)
             if traffic_detail:
                 traffic = sum(kk["hbm_bytes_per_launch_corrected"] for kk in traffic_detail.values()) * (dom_launches / a.steps)
-                traffic_src, traffic_live = f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of this bench.py (git {git_head()})", True
+                traffic_src, traffic_live = f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of this bench.py ({build_id()})", True
             elif a.pmc == 1:
                 raise SystemExit("--pmc 1: " + str(traffic_note))
         if traffic is None:
