@@ -389,9 +389,9 @@ __global__ __launch_bounds__(GEO::T) void digit_scatter2_kernel(
     typedef unsigned long long u64;
     extern __shared__ __attribute__((aligned(16))) unsigned char sort_lds[];
     uint2 *s_kv = reinterpret_cast<uint2 *>(sort_lds);                              // [TILE] (key, payload), digit-sorted
-    u64 *s_mask = reinterpret_cast<u64 *>(s_kv + TILE);                             // [W][bins] lanes of the wave holding the digit (all zero between rounds)
-    uint16_t (*s_wcnt)[kBins] = reinterpret_cast<uint16_t (*)[kBins]>(s_mask + (size_t)W * kBins);   // [W][bins] per-wave digit counts of the tile
-    uint16_t (*s_wbase)[kBins] = s_wcnt + W;                                        // [W][bins] tile-local start of (wave, digit) within the digit
+    uint32_t *s_mask = reinterpret_cast<uint32_t *>(s_kv + TILE);                   // [W][2][bins] lanes of the wave holding the digit, low / high 32 lanes (all zero between rounds)
+    uint16_t (*s_wcnt)[kBins] = reinterpret_cast<uint16_t (*)[kBins]>(s_mask + (size_t)W * 2 * kBins);   // [W][bins] per-wave digit counts of the tile
+    uint16_t (*s_wbase)[kBins] = s_wcnt + W;                                        // [W][bins] first tile slot of (wave, digit)
     uint32_t *s_tstart = reinterpret_cast<uint32_t *>(s_wbase + W);                 // [bins] start of the digit in the tile
     uint32_t *s_delta = s_tstart + kBins;                                           // [bins] output position of the digit's next key - s_tstart
     uint32_t *s_gpos = s_delta + kBins;                                             // [bins] output position of the digit's next key
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(GEO::T) void digit_scatter2_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t lo = (int64_t)blockIdx.x * slice;
     const int64_t hi = lo + slice < n ? lo + slice : n;
-    for (int i = tid; i < W * kBins; i += T) s_mask[i] = 0ull;
+    for (int i = tid; i < W * 2 * kBins; i += T) s_mask[i] = 0u;
     {   // first output position of (digit tid, this slice) = digits before + this digit's earlier slices
         const uint32_t tot = tid < kBins ? row_total[tid] : 0u;
         const uint32_t incl = wave_incl_scan(tot);
@@ -412,8 +412,13 @@ __global__ __launch_bounds__(GEO::T) void digit_scatter2_kernel(
         }
         __syncthreads();
     }
-    const u64 lanebit = 1ull << lane, lt = lanemask_lt();
-    u64 *mymask = s_mask + (size_t)wave * kBins;                  // (not volatile: the address-space inference skips volatile accesses -> FLAT instructions)
+    // The mask of a digit is kept as two 32-bit words in two tables (lanes 0..31 / 32..63): a lane ORs its bit into ONE
+    // 4-byte word, so the 64 lanes of a round spread over all 64 LDS banks -- with one 8-byte word per digit they shared 32
+    // bank pairs, two cycles each (SQ_LDS_BANK_CONFLICT was 60 % of the LDS cycles of a pass over a 256-valued digit).
+    const uint32_t lanebit = 1u << (lane & 31);
+    const u64 lt = lanemask_lt();
+    uint32_t *mymask = s_mask + (size_t)wave * 2 * kBins;         // (not volatile: the address-space inference skips volatile accesses -> FLAT instructions)
+    uint32_t *myhalf = mymask + (lane >> 5) * kBins;
     uint16_t *mycnt = s_wcnt[wave];
     uint32_t nkey[R];
     // One tile.  FULL (every tile but a slice's last, ragged one) carries no validity tests and a FIXED number of loads and
@@ -438,9 +443,12 @@ __global__ __launch_bounds__(GEO::T) void digit_scatter2_kernel(
             if (valid) {
                 // relaxed atomics keep the three accesses in program order for the compiler; the LDS executes a wave's
                 // instructions in order, so the read sees the whole wave's ORs and the clear follows every lane's read
-                __hip_atomic_fetch_or(mymask + d, lanebit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);      // ds_or_b64
-                const u64 peers = __hip_atomic_load(mymask + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); // ds_read_b64
-                __hip_atomic_store(mymask + d, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);            // clean again for the next round
+                __hip_atomic_fetch_or(myhalf + d, lanebit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);      // ds_or_b32
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");        // (no instruction: plain loads, so that the two words come with ONE ds_read2st64_b32)
+                const uint32_t plo = mymask[d], phi = mymask[kBins + d];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                const u64 peers = ((u64)phi << 32) | plo;
+                __hip_atomic_store(myhalf + d, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);              // clean again for the next round
                 const u64 below = peers & lt;
                 const uint32_t before = mycnt[d];
                 rank[r] = before + (uint32_t)__popcll(below);
@@ -483,16 +491,17 @@ __global__ __launch_bounds__(GEO::T) void digit_scatter2_kernel(
             uint32_t carry = 0;
             for (int w = 0; w < wave; w++) carry += s_scan[w];
             const uint32_t ts = carry + incl - tcnt, gp = s_gpos[tid];
-            s_tstart[tid] = ts;
             s_delta[tid] = gp - ts;                                  // wraps; slot + delta is the output position
             s_gpos[tid] = gp + tcnt;
+#pragma unroll
+            for (int w = 0; w < W; w++) s_wbase[w][tid] = (uint16_t)(s_wbase[w][tid] + ts);   // (wave, digit) -> its first slot in the tile: ONE read per key when staging
         }
         lds_barrier();
 #pragma unroll
         for (int r = 0; r < R; r++) {
             if (FULL || rank[r] != 0xFFFFFFFFu) {
                 const uint32_t d = ((key[r] ^ xor_mask) >> sh) & dmask;
-                s_kv[s_tstart[d] + (uint32_t)s_wbase[wave][d] + rank[r]] = uint2{key[r], val[r]};
+                s_kv[(uint32_t)s_wbase[wave][d] + rank[r]] = uint2{key[r], val[r]};
             }
         }
         lds_barrier();
