@@ -66,7 +66,11 @@ template <typename K> struct JTraits;
 #define HARK_J32_Q 32
 #endif
 template <> struct JTraits<uint32_t> { typedef JPair32 E; static constexpr int P = HARK_J32_P, Q = HARK_J32_Q, VEC = 4, CHUNK = 22528, BM_BITS = 18; };
-template <> struct JTraits<uint64_t> { typedef JPair64 E; static constexpr int P = 512, Q = 16, VEC = 2, CHUNK = 12288, BM_BITS = 17; };
+#ifndef HARK_J64_P
+#define HARK_J64_P 512
+#define HARK_J64_Q 16
+#endif
+template <> struct JTraits<uint64_t> { typedef JPair64 E; static constexpr int P = HARK_J64_P, Q = HARK_J64_Q, VEC = 2, CHUNK = 12288, BM_BITS = 17; };
 
 __device__ __forceinline__ uint32_t jhash(uint32_t k) { return k * 0x9E3779B1u; }
 __device__ __forceinline__ uint32_t jhash(uint64_t k) { return (uint32_t)((k * 0x9E3779B97F4A7C15ull) >> 32); }

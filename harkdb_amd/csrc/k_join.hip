@@ -24,7 +24,7 @@
 int k_argsort_column(hark_context *ctx, const void *col, int dtype, int64_t n, bool descending,
                      uint32_t **perm_out, uint32_t **sorted_words_out);
 int k_gather(hark_context *ctx, const void *src, int esz, const uint32_t *idx, void *dst, int64_t n);
-int k_argsort_i64_keys(hark_context *ctx, const void *col, int64_t n, uint32_t **perm_out, uint64_t **keys_out);
+int k_argsort_i64_keys(hark_context *ctx, const void *col, int64_t n, uint32_t **perm_out, uint64_t **keys_out, const uint32_t *valcol, uint32_t **val_out);
 int k_sort_column(hark_context *ctx, const void *col, int dtype, int64_t n, bool descending, const uint32_t *payload,
                   uint32_t **vals_out, uint32_t **words_out);
 int k_exclusive_scan_u32(hark_context *ctx, const uint32_t *in, int64_t n, uint32_t *out32, int64_t *out64, int64_t *total_host);
@@ -286,8 +286,17 @@ int hark_entry_join(hark_context *ctx, hark_result **out, const hark_table *db1,
     int64_t nl = n;                                   // left rows that reach the sort + merge
     const void *lcol = db1->cols[col1].data, *rcol = db2->cols[col2].data;
     bool filtered = false, partitioned = false, unique = false;   // unique: partitioned path, all build keys distinct (one partner per survivor)
+    // ONE non-key 4-byte output column of the BUILD side is brought into rank order up front and read off by the order
+    // kernel for every output row (unique build keys), instead of P reads through the rank afterwards.  With i64 keys it
+    // travels through the sort beside key and row id (no gather); with 32-bit keys it is gathered through the permutation.
+    int rank_col = -1;
+    for (int64_t j = 0; j < k && rank_col < 0; j++)
+        if (cols2[j] >= 0 && cols2[j] < db2->m && cols2[j] != col2 && hark_dtype_size(db2->cols[cols2[j]].dtype) == 4 && !getenv("HARK_JOIN_NO_RANK_GATHER")) rank_col = cols2[j];
+    if (!(n >= ((int64_t)1 << 18) && s >= 4096)) rank_col = -1;             // (the partitioned path's own thresholds)
+    uint32_t *rranked = nullptr, *rval = nullptr;
     // ---- the build side is sorted first: both paths need it
-    if (k64) rc = k_argsort_i64_keys(ctx, rcol, s, &rperm, &rk64);          // permutation + the sorted (biased) keys in one go
+    if (k64) rc = k_argsort_i64_keys(ctx, rcol, s, &rperm, &rk64,           // permutation + the sorted (biased) keys (+ the column) in one go
+                                     rank_col >= 0 ? static_cast<const uint32_t *>(db2->cols[rank_col].data) : nullptr, rank_col >= 0 ? &rranked : nullptr);
     else rc = k_argsort_column(ctx, rcol, HARK_U32, s, false, &rperm, &rkeys);
     // ---- partitioned path (k_hjoin.hip): matching probe rows as (rank in the sorted build side, left row), sorted
     // A non-key 4-byte output column of the PROBE side can travel with the probe rows through the partitioned path (in the
@@ -297,13 +306,7 @@ int hark_entry_join(hark_context *ctx, hark_result **out, const hark_table *db1,
     if (k64) for (int64_t j = 0; j < l && carry_col < 0; j++)
         if (cols1[j] >= 0 && cols1[j] < db1->m && cols1[j] != col1 && hark_dtype_size(db1->cols[cols1[j]].dtype) == 4 && !getenv("HARK_JOIN_NOCARRY")) carry_col = cols1[j];
     uint32_t *sval = nullptr, *lval_exp = nullptr;    // the carried column per matching probe row / per output pair
-    // Likewise ONE non-key 4-byte output column of the BUILD side is brought into rank order up front (s random reads) and
-    // read off by the order kernel for every output row (unique build keys), instead of P reads through the rank afterwards.
-    int rank_col = -1;
-    for (int64_t j = 0; j < k && rank_col < 0; j++)
-        if (cols2[j] >= 0 && cols2[j] < db2->m && cols2[j] != col2 && hark_dtype_size(db2->cols[cols2[j]].dtype) == 4 && !getenv("HARK_JOIN_NO_RANK_GATHER")) rank_col = cols2[j];
-    uint32_t *rranked = nullptr, *rval = nullptr;
-    if (!rc && rank_col >= 0 && n >= ((int64_t)1 << 18) && s >= 4096) {       // (the partitioned path's own thresholds)
+    if (!rc && rank_col >= 0 && !rranked) {
         rc = hark_alloc(ctx, (void **)&rranked, (size_t)s * 4);
         if (!rc) rc = k_gather(ctx, db2->cols[rank_col].data, 4, rperm, rranked, s);
     }

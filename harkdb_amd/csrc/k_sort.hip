@@ -657,6 +657,203 @@ __global__ __launch_bounds__(256) void i64_fix_runs_kernel(const uint64_t *__res
     }
 }
 
+// ---- i64 keys as 16-byte tuples (biased key, row id, one 4-byte column) ----------------------------------------------------
+// The argsort above leaves a PERMUTATION: the sorted keys, and any column wanted in sorted order, are then s random reads
+// each (12.5 M of them cost 0.24-0.28 ms: BASELINE configs[3]'s build side paid that twice).  Here the key, its row id and
+// one column travel through the passes as one 16-byte word, so the run fix-up and the outputs are sequential.  The digit
+// is taken from the tuple's second word (the high word of the biased key); the kernel is digit_scatter2_kernel with a
+// four-word payload (see there for the ranking and the counted loads / stores).
+struct GeoTuple { static constexpr int T = 256, R = 12, PER_CU = 8; };
+constexpr size_t tuple_scatter_lds() { return (size_t)GeoTuple::T * GeoTuple::R * 16 + (size_t)(GeoTuple::T / 64) * kBins * (8 + 2 + 2) + kBins * 8 + 64; }
+
+template <bool FIRST>
+__global__ __launch_bounds__(GeoTuple::T) void tuple_hist_kernel(const uint64_t *__restrict__ col, const uint4 *__restrict__ tin, int64_t n, int64_t slice,
+                                                                 int shift, uint32_t *__restrict__ hist, int nblk)
+{
+    const int sh = shift & 255;
+    const uint32_t dmask = (shift >> 8) ? (1u << (shift >> 8)) - 1u : 255u;
+    __shared__ uint32_t s_hist[kBins];
+    if (threadIdx.x < kBins) s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t lo = (int64_t)blockIdx.x * slice;
+    const int64_t hi = lo + slice < n ? lo + slice : n;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const uint32_t w = FIRST ? (uint32_t)(col[i] >> 32) ^ 0x80000000u : tin[i].y;
+        atomicAdd(&s_hist[(w >> sh) & dmask], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < kBins) hist[(size_t)threadIdx.x * nblk + blockIdx.x] = s_hist[threadIdx.x];
+}
+
+// FIRST: the tuples are built from the key column (biased by 2^63), the row id and valcol (may be null: zero).
+template <bool FIRST>
+__global__ __launch_bounds__(GeoTuple::T) void tuple_scatter_kernel(
+    const uint64_t *__restrict__ col, const uint32_t *__restrict__ valcol, const uint4 *__restrict__ tin, uint4 *__restrict__ tout,
+    int64_t n, int64_t slice, int shift, const uint32_t *__restrict__ hist, int nblk, const uint32_t *__restrict__ row_total)
+{
+    const int sh = shift & 255;
+    const uint32_t dmask = (shift >> 8) ? (1u << (shift >> 8)) - 1u : 255u;
+    constexpr int T = GeoTuple::T, W = T / 64, R = GeoTuple::R, TILE = T * R;
+    typedef unsigned long long u64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sort_lds[];
+    uint4 *s_t = reinterpret_cast<uint4 *>(sort_lds);                                // [TILE] tuples, digit-sorted
+    uint32_t *s_mask = reinterpret_cast<uint32_t *>(s_t + TILE);                     // [W][2][bins]
+    uint16_t (*s_wcnt)[kBins] = reinterpret_cast<uint16_t (*)[kBins]>(s_mask + (size_t)W * 2 * kBins);
+    uint16_t (*s_wbase)[kBins] = s_wcnt + W;
+    uint32_t *s_delta = reinterpret_cast<uint32_t *>(s_wbase + W);                   // [bins] output position of the digit's first key of the tile - its tile slot
+    uint32_t *s_gpos = s_delta + kBins;                                              // [bins] output position of the digit's next key
+    uint32_t *s_scan = s_gpos + kBins;                                               // [16]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t lo = (int64_t)blockIdx.x * slice;
+    const int64_t hi = lo + slice < n ? lo + slice : n;
+    for (int i = tid; i < W * 2 * kBins; i += T) s_mask[i] = 0u;
+    {
+        const uint32_t tot = tid < kBins ? row_total[tid] : 0u;
+        const uint32_t incl = wave_incl_scan(tot);
+        if (lane == 63 && tid < kBins) s_scan[wave] = incl;
+        __syncthreads();
+        if (tid < kBins) {
+            uint32_t carry = 0;
+            for (int w = 0; w < wave; w++) carry += s_scan[w];
+            s_gpos[tid] = carry + incl - tot + hist[(size_t)tid * nblk + blockIdx.x];
+        }
+        __syncthreads();
+    }
+    const uint32_t lanebit = 1u << (lane & 31);
+    const u64 lt = lanemask_lt();
+    uint32_t *mymask = s_mask + (size_t)wave * 2 * kBins;
+    uint32_t *myhalf = mymask + (lane >> 5) * kBins;
+    uint16_t *mycnt = s_wcnt[wave];
+    uint4 nt[R];                                                  // the next tile's tuples (FIRST: keys only, the rest is filled in after the ranking)
+    auto load_next = [&](int64_t wbase, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            int64_t i = wbase + r * 64 + lane;
+            if (!FULL) i = i < hi ? i : hi - 1;
+            if (FIRST) { const u64 k = __builtin_nontemporal_load(col + i) ^ 0x8000000000000000ull; nt[r].x = (uint32_t)k; nt[r].y = (uint32_t)(k >> 32); }
+            else nt[r] = ld_nt16(tin + i);
+        }
+    };
+    auto tile = [&](int64_t tbase, auto full_tag, auto next_tag) {
+        constexpr bool FULL = decltype(full_tag)::value, NEXT_FULL = decltype(next_tag)::value;
+        const int64_t wbase = tbase + (int64_t)wave * (64 * R);
+        uint4 cur[R];
+        uint32_t rank[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) cur[r] = nt[r];
+        reinterpret_cast<uint2 *>(mycnt)[lane] = uint2{0u, 0u};
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const bool valid = FULL || wbase + r * 64 + lane < hi;
+            const uint32_t d = (cur[r].y >> sh) & dmask;
+            rank[r] = 0xFFFFFFFFu;
+            if (valid) {
+                __hip_atomic_fetch_or(myhalf + d, lanebit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                const uint32_t plo = mymask[d], phi = mymask[kBins + d];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                const u64 peers = ((u64)phi << 32) | plo;
+                __hip_atomic_store(myhalf + d, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                const u64 below = peers & lt;
+                const uint32_t before = mycnt[d];
+                rank[r] = before + (uint32_t)__popcll(below);
+                if (below == 0ull) mycnt[d] = (uint16_t)(before + (uint32_t)__popcll(peers));
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (FIRST) {                                                // row id and the column's value; they and the next tile's keys travel under the rest of the tile
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                int64_t i = wbase + r * 64 + lane;
+                if (!FULL) i = i < hi ? i : hi - 1;
+                cur[r].z = (uint32_t)i;
+                cur[r].w = valcol ? __builtin_nontemporal_load(valcol + i) : 0u;
+            }
+        }
+        if (NEXT_FULL) load_next(wbase + TILE, std::true_type{});
+        else if (FULL && tbase + TILE < hi) load_next(wbase + TILE, std::false_type{});
+        lds_barrier();
+        uint32_t tcnt = 0, incl = 0;
+        if (tid < kBins) {
+            uint32_t run = 0;
+#pragma unroll
+            for (int w = 0; w < W; w++) { s_wbase[w][tid] = (uint16_t)run; run += s_wcnt[w][tid]; }
+            tcnt = run;
+            incl = wave_incl_scan(tcnt);
+            if (lane == 63) s_scan[wave] = incl;
+        }
+        lds_barrier();
+        if (tid < kBins) {
+            uint32_t carry = 0;
+            for (int w = 0; w < wave; w++) carry += s_scan[w];
+            const uint32_t ts = carry + incl - tcnt, gp = s_gpos[tid];
+            s_delta[tid] = gp - ts;
+            s_gpos[tid] = gp + tcnt;
+#pragma unroll
+            for (int w = 0; w < W; w++) s_wbase[w][tid] = (uint16_t)(s_wbase[w][tid] + ts);
+        }
+        lds_barrier();
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            if (FULL || rank[r] != 0xFFFFFFFFu) {
+                const uint32_t d = (cur[r].y >> sh) & dmask;
+                s_t[(uint32_t)s_wbase[wave][d] + rank[r]] = cur[r];
+            }
+        }
+        lds_barrier();
+        if (FULL) {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int slot = tid + r * T;
+                const uint4 t = s_t[slot];
+                tout[(uint32_t)slot + s_delta[(t.y >> sh) & dmask]] = t;
+                if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            const int tile_n = (int)(hi - tbase);
+            for (int slot = tid; slot < tile_n; slot += T) {
+                const uint4 t = s_t[slot];
+                tout[(uint32_t)slot + s_delta[(t.y >> sh) & dmask]] = t;
+            }
+        }
+    };
+    load_next(lo + (int64_t)wave * (64 * R), std::false_type{});
+    int64_t tbase = lo;
+    for (; tbase + 2 * (int64_t)TILE <= hi; tbase += TILE) tile(tbase, std::true_type{}, std::true_type{});
+    if (tbase + TILE <= hi) { tile(tbase, std::true_type{}, std::false_type{}); tbase += TILE; }
+    if (tbase < hi) tile(tbase, std::false_type{}, std::false_type{});
+}
+
+// Tuples sorted by (the prefix bits of) their high words -> sorted keys, row ids and column values.  Every tuple finds the
+// run of equal prefixes it sits in (a handful of neighbours, cached lines) and its place in it: the number of tuples of
+// the run that are smaller by (key, position).  No lane waits for another one's sorting network; sequential reads, writes
+// within a run's span.  A run longer than kRunMax raises *too_long (the caller takes the general path).
+__global__ __launch_bounds__(256) void tuple_fix_runs_kernel(const uint4 *__restrict__ tin, uint64_t *__restrict__ keys_out, uint32_t *__restrict__ perm_out,
+                                                             uint32_t *__restrict__ val_out, int64_t n, int32_t *__restrict__ too_long, uint32_t prefix_mask)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    auto hi_of = [&](int64_t j) { return reinterpret_cast<const uint32_t *>(tin + j)[1] & prefix_mask; };
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint4 t = ld_nt16(tin + i);
+        const uint32_t h = t.y & prefix_mask;
+        int64_t a = i, b = i + 1;
+        while (a > 0 && i - a <= kRunMax && hi_of(a - 1) == h) a--;
+        while (b < n && b - a <= kRunMax && hi_of(b) == h) b++;
+        if (b - a > kRunMax) { *too_long = 1; continue; }
+        const uint64_t key = ((uint64_t)t.y << 32) | t.x;
+        int64_t at = a;
+        for (int64_t j = a; j < b; j++) {
+            if (j == i) continue;
+            const uint2 q = *reinterpret_cast<const uint2 *>(tin + j);
+            const uint64_t kj = ((uint64_t)q.y << 32) | q.x;
+            at += (kj < key || (kj == key && j < i)) ? 1 : 0;
+        }
+        keys_out[at] = key; perm_out[at] = t.z;
+        if (val_out) val_out[at] = t.w;
+    }
+}
+
 __global__ __launch_bounds__(256) void gather_biased_u64_kernel(const uint64_t *__restrict__ src, const uint32_t *__restrict__ perm, uint64_t *__restrict__ dst, int64_t n)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -864,7 +1061,7 @@ static int k_sort_column_lsd(hark_context *ctx, const void *col, int dtype, int6
     return HARK_OK;
 }
 
-int k_argsort_i64_keys(hark_context *ctx, const void *col, int64_t n, uint32_t **perm_out, uint64_t **keys_out);
+int k_argsort_i64_keys(hark_context *ctx, const void *col, int64_t n, uint32_t **perm_out, uint64_t **keys_out, const uint32_t *valcol, uint32_t **val_out);
 
 // Stable sort of a column with a 32-bit payload (see k_sort_column_lsd).  An ascending argsort of an i64 column takes
 // the high-word-first path of k_argsort_i64_keys (four passes + a run fix-up instead of eight passes).
@@ -874,7 +1071,7 @@ int k_sort_column(hark_context *ctx, const void *col, int dtype, int64_t n, bool
     if (dtype == HARK_I64 && !descending && !payload && n >= 4096) {
         if (words_out) *words_out = nullptr;
         uint64_t *keys = nullptr;
-        const int rc = k_argsort_i64_keys(ctx, col, n, vals_out, &keys);
+        const int rc = k_argsort_i64_keys(ctx, col, n, vals_out, &keys, nullptr, nullptr);
         hark_free(ctx, keys);
         if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) return hark_fail(ctx, HARK_EHIP, "sort kernels failed");
         return rc;
@@ -891,9 +1088,79 @@ int k_argsort_column(hark_context *ctx, const void *col, int dtype, int64_t n, b
 // Stable ascending argsort of an i64 column together with the SORTED keys (biased by 2^63: unsigned order = signed order):
 // *perm_out (n x u32) and *keys_out (n x u64) are pool blocks the caller frees.  High word first + run fix-up (above)
 // when the high words differ, the plain low-word sort when they do not, the eight-pass path as the fallback.
-int k_argsort_i64_keys(hark_context *ctx, const void *col, int64_t n, uint32_t **perm_out, uint64_t **keys_out)
+// valcol / val_out (optional): a 4-byte column of the same table; *val_out then holds it in sorted order (valcol[perm[i]]).
+// When the high words differ, key, row id and the column's value travel through the passes as 16-byte tuples
+// (sort_i64_tuples): no random read anywhere.  On the other paths *val_out is a gather through the permutation.
+static int sort_i64_tuples(hark_context *ctx, const void *col, int64_t n, uint32_t diff_hi, const uint32_t *valcol,
+                           uint64_t *keys, uint32_t **perm_out, uint32_t **val_out, bool *done)
+{
+    *done = false;
+    hipStream_t st = ctx->stream;
+    // Up to 2^24 keys are only sorted by the top 24 bits of their high words (three passes instead of four): keys spread
+    // over 64 bits then share a prefix with 0.75 others on average, and the run fix-up orders whole keys anyway.
+    const uint32_t prefix_mask = n <= ((int64_t)1 << 24) && (diff_hi & 0xFFFFFF00u) ? 0xFFFFFF00u : 0xFFFFFFFFu;
+    SortPass plan[4];
+    const int np = plan_passes(diff_hi & prefix_mask, plan);
+    if (np == 0) return HARK_OK;
+    constexpr int64_t tile = (int64_t)GeoTuple::T * GeoTuple::R;
+    int64_t nblk = (n + tile - 1) / tile;
+    if (nblk > (int64_t)ctx->num_cu * GeoTuple::PER_CU) nblk = (int64_t)ctx->num_cu * GeoTuple::PER_CU;
+    int64_t slice = ((n + nblk - 1) / nblk + tile - 1) / tile * tile;
+    nblk = (n + slice - 1) / slice;
+    uint4 *ta = nullptr, *tb = nullptr;
+    uint32_t *ws = nullptr, *perm = nullptr, *val = nullptr;
+    int32_t *flag = nullptr;
+    int rc = hark_alloc(ctx, (void **)&ta, (size_t)n * 16);
+    if (!rc) rc = hark_alloc(ctx, (void **)&tb, (size_t)n * 16);
+    if (!rc) rc = hark_alloc(ctx, (void **)&ws, (size_t)kBins * ((size_t)nblk + 1) * 4);
+    if (!rc) rc = hark_alloc(ctx, (void **)&flag, 16);
+    if (!rc) rc = hark_alloc(ctx, (void **)&perm, (size_t)n * 4);
+    if (!rc && valcol && val_out) rc = hark_alloc(ctx, (void **)&val, (size_t)n * 4);
+    auto cleanup = [&](bool keep) {
+        hark_free(ctx, ta); hark_free(ctx, tb); hark_free(ctx, ws); hark_free(ctx, flag);
+        if (!keep) { hark_free(ctx, perm); hark_free(ctx, val); }
+    };
+    if (rc == HARK_ENOMEM) { cleanup(false); ctx->err.clear(); return HARK_OK; }      // the permutation path needs half the room
+    if (rc) { cleanup(false); return rc; }
+    const size_t lds = tuple_scatter_lds();
+    hipError_t he = hipFuncSetAttribute(reinterpret_cast<const void *>(&tuple_scatter_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (he == hipSuccess) he = hipFuncSetAttribute(reinterpret_cast<const void *>(&tuple_scatter_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    uint32_t *row_total = ws + (size_t)kBins * nblk;
+    const uint64_t *c64 = static_cast<const uint64_t *>(col);
+    const uint4 *tin = nullptr;
+    uint4 *tout = ta;
+    for (int pi = 0; pi < np && he == hipSuccess; pi++) {
+        const int shift = plan[pi].shift | (plan[pi].width << 8);
+        const dim3 grid((unsigned)nblk), block(GeoTuple::T);
+        if (pi == 0) tuple_hist_kernel<true><<<grid, block, 0, st>>>(c64, nullptr, n, slice, shift, ws, (int)nblk);
+        else tuple_hist_kernel<false><<<grid, block, 0, st>>>(nullptr, tin, n, slice, shift, ws, (int)nblk);
+        scan_hist_rows_kernel<<<dim3(kBins), dim3(256), 0, st>>>(ws, (int)nblk, row_total);
+        if (pi == 0) tuple_scatter_kernel<true><<<grid, block, lds, st>>>(c64, val ? valcol : nullptr, nullptr, tout, n, slice, shift, ws, (int)nblk, row_total);
+        else tuple_scatter_kernel<false><<<grid, block, lds, st>>>(nullptr, nullptr, tin, tout, n, slice, shift, ws, (int)nblk, row_total);
+        he = hipGetLastError();
+        tin = tout; tout = tout == ta ? tb : ta;
+    }
+    int64_t general = 0;
+    if (he == hipSuccess) he = hipMemsetAsync(flag, 0, 16, st);
+    if (he == hipSuccess) {
+        tuple_fix_runs_kernel<<<dim3((unsigned)grid256(ctx, n)), dim3(256), 0, st>>>(tin, keys, perm, val, n, flag, prefix_mask);
+        he = hipGetLastError();
+    }
+    if (he != hipSuccess) { cleanup(false); return hark_fail(ctx, HARK_EHIP, "sort: tuple pass failed: %s", hipGetErrorString(he)); }
+    rc = hark_read_words(ctx, flag, &general, 1);
+    if (rc) { cleanup(false); return rc; }
+    if ((general & 0xFFFFFFFFll) != 0) { cleanup(false); return HARK_OK; }          // a long run of equal prefixes: the general path
+    cleanup(true);
+    *perm_out = perm;
+    if (val_out) *val_out = val;
+    *done = true;
+    return HARK_OK;
+}
+
+int k_argsort_i64_keys(hark_context *ctx, const void *col, int64_t n, uint32_t **perm_out, uint64_t **keys_out, const uint32_t *valcol, uint32_t **val_out)
 {
     *perm_out = nullptr; *keys_out = nullptr;
+    if (val_out) *val_out = nullptr;
     if (n <= 0) return HARK_OK;
     hipStream_t st = ctx->stream;
     uint64_t *keys = nullptr;
@@ -902,7 +1169,9 @@ int k_argsort_i64_keys(hark_context *ctx, const void *col, int64_t n, uint32_t *
     uint32_t diff_hi = 0u;
     rc = k_transform_keys(ctx, col, HARK_I64, 1, nullptr, n, &diff_hi);
     bool done = false;
-    if (!rc && passes_of(diff_hi) != 0u && !getenv("HARK_SORT_I64_LSD")) {
+    if (!rc && passes_of(diff_hi) != 0u && !getenv("HARK_SORT_I64_LSD") && !getenv("HARK_SORT_NO_TUPLES"))
+        rc = sort_i64_tuples(ctx, col, n, diff_hi, valcol, keys, perm_out, val_out, &done);
+    if (!rc && !done && passes_of(diff_hi) != 0u && !getenv("HARK_SORT_I64_LSD")) {
         uint32_t *k0 = nullptr, *k1 = nullptr, *v0 = nullptr, *v1 = nullptr, *ws = nullptr; int32_t *flag = nullptr;
         const size_t b = (size_t)n * 4;
         rc = hark_alloc(ctx, (void **)&k0, b);
@@ -938,7 +1207,16 @@ int k_argsort_i64_keys(hark_context *ctx, const void *col, int64_t n, uint32_t *
         }
         if (rc) hark_free(ctx, perm); else *perm_out = perm;
     }
-    if (rc) { hark_free(ctx, keys); if (*perm_out) { hark_free(ctx, *perm_out); *perm_out = nullptr; } return rc; }
+    if (!rc && valcol && val_out && !*val_out) {                     // the permutation paths: one gather
+        rc = hark_alloc(ctx, (void **)val_out, (size_t)n * 4);
+        if (!rc) rc = k_gather(ctx, valcol, 4, *perm_out, *val_out, n);
+    }
+    if (rc) {
+        hark_free(ctx, keys);
+        if (*perm_out) { hark_free(ctx, *perm_out); *perm_out = nullptr; }
+        if (val_out && *val_out) { hark_free(ctx, *val_out); *val_out = nullptr; }
+        return rc;
+    }
     *keys_out = keys;
     return HARK_OK;
 }

@@ -173,6 +173,31 @@ def test_sort_is_stable_and_ordered(eng, oracle, dtype, descending, n):
         assert np.array_equal(r2, oracle.argsort_u32(key).astype(np.int32))    # the reference's 32-pass sort order
 
 
+@pytest.mark.parametrize("n", [4096, 6144, 100_003, 1_300_001])
+@pytest.mark.parametrize("kind", ["spread", "runs", "narrow_hi", "negative_cluster"])
+def test_i64_sort_by_high_words(eng, n, kind):
+    """i64 keys whose high words differ travel through the passes as 16-byte tuples (sorted by the top bits of the high
+    word, runs of equal prefixes fixed up in registers); a run longer than 16 falls back to the eight-pass sort.  Stable
+    against numpy either way."""
+    rng = np.random.default_rng(n % 1000 + len(kind))
+    if kind == "spread":
+        key = rng.integers(-2**63, 2**63 - 1, size=n)
+    elif kind == "runs":                   # equal keys (stability) and keys that differ below the sorted prefix only
+        pool = rng.integers(-2**63, 2**63 - 1, size=max(n // 5, 1))
+        key = pool[rng.integers(0, len(pool), size=n)] + rng.integers(0, 4, size=n) * rng.integers(0, 2, size=n)
+    elif kind == "narrow_hi":              # the high words differ in their low byte only: one pass, long runs -> the fallback
+        key = rng.integers(0, 2**40, size=n)
+    else:
+        key = -rng.integers(0, 2**50, size=n) - (rng.integers(0, 2, size=n) << 62)
+    key = key.astype(np.int64)
+    rowid = np.arange(n, dtype=np.int32)
+    t = eng.table_from_columns([key, rowid])
+    res = eng.sort(t, 0, [0, 1])
+    perm = np.argsort(key, kind="stable")
+    assert np.array_equal(res.column(1), rowid[perm]) and np.array_equal(res.column(0), key[perm])
+    res.free(); t.free()
+
+
 @pytest.mark.parametrize("dtype", [np.uint32, np.int32, np.float32])
 @pytest.mark.parametrize("cols", [[0], [1], [1, 0, 1, 0], [2, 1], [0, 1, 2], [2, 0, 0]])
 @pytest.mark.parametrize("descending", [False, True])

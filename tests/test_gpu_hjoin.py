@@ -105,17 +105,24 @@ def test_partitioned_join_reference_order(eng, case):
         assert pairs > 0
 
 
-@pytest.mark.parametrize("unique", [True, False])
+@pytest.mark.parametrize("unique", [True, False, "spread", "spread_dup"])
 def test_i64_join_with_several_output_columns(eng, unique):
     """Output columns of the i64 path arrive in three ways: ONE probe-side column travels with the probe rows (the fourth
     word of their 16-byte entries), ONE build-side column is read off in rank order by the order kernel (unique build
     keys) or through the pair's rank, everything else -- further columns, f32, a column selected twice, the key itself --
     is gathered.  All of them against numpy, row for row."""
-    rng = np.random.default_rng(21 + int(unique))
+    rng = np.random.default_rng(21 + ["False", "True", "spread", "spread_dup"].index(str(unique)))
     n, s = 300_007, 40_000
-    rk = (rng.permutation(s).astype(np.int64) * 7919 - 10**9) if unique else rng.integers(-5000, 5000, size=s).astype(np.int64)
+    if unique == "spread":                 # build keys spread over 64 bits: key, row id and the build-side column travel through
+        rk = np.unique(rng.integers(-2**63, 2**63 - 1, size=s + 100))[:s]          # the sort as 16-byte tuples (sort_i64_tuples)
+        rk = rk[rng.permutation(s)]
+    elif unique == "spread_dup":           # ... with runs of equal keys and of keys that share their 24-bit prefix
+        pool = rng.integers(-2**63, 2**63 - 1, size=s // 4)
+        rk = pool[rng.integers(0, len(pool), size=s)] + rng.integers(0, 3, size=s) * rng.integers(0, 2, size=s)
+    else:
+        rk = (rng.permutation(s).astype(np.int64) * 7919 - 10**9) if unique else rng.integers(-5000, 5000, size=s).astype(np.int64)
     lk = rng.integers(-2**62, 2**62, size=n).astype(np.int64)
-    hit = rng.random(n) < (0.5 if unique else 0.02)
+    hit = rng.random(n) < (0.5 if unique in (True, "spread") else 0.02)
     lk[hit] = rk[rng.integers(0, s, size=int(hit.sum()))]
     la, lf, lc = rng.integers(-2**31, 2**31, n).astype(np.int32), rng.random(n).astype(np.float32), rng.integers(0, 99, n).astype(np.int32)
     ra, rf = rng.integers(0, 2**31, s).astype(np.int32), rng.random(s).astype(np.float32)
