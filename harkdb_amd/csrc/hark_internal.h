@@ -166,6 +166,40 @@ __device__ __forceinline__ void st_nt16(void *p, uint4 v)
     __builtin_nontemporal_store(u4v{v.x, v.y, v.z, v.w}, static_cast<u4v *>(p));
 }
 
+// Stores the compiler's s_waitcnt bookkeeping does not see.  gfx950 has ONE in-order counter (vmcnt) for loads and stores,
+// and the compiler places the wait for a prefetched load by counting the memory instructions issued after it -- over all
+// paths.  A store inside a conditional or a loop makes that count unknown, and the wait becomes vmcnt(0): the wave then
+// sits out the prefetch it has just issued (measured: the join's bucket kernel streamed at 5.6 TB/s without its survivor
+// stores and ran at 2.9 with them).  Issued from inline assembly the stores are not counted by the compiler; the
+// hardware still counts them, which only makes a compiler-placed vmcnt(N) wait for a little more than it needs -- never
+// for less: older operations retire first.  Use for fire-and-forget results only (nothing in the same kernel reads them
+// back without a fence; the kernel's end completes them).
+__device__ __forceinline__ void st_hidden_b32(void *p, uint32_t v) { asm volatile("global_store_dword %0, %1, off" :: "v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void st_hidden_b64(void *p, uint2 v)
+{
+    const unsigned long long w = ((unsigned long long)v.y << 32) | v.x;
+    asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(p), "v"(w) : "memory");
+}
+__device__ __forceinline__ void st_hidden_nt_b128(void *p, uint4 v)
+{
+    typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+    const u4v w = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(p), "v"(w) : "memory");
+}
+
+// Loads with hand-placed waits, for software pipelines the compiler's bookkeeping cannot follow (it falls back to
+// vmcnt(0) at a loop header that merges paths it cannot count): ld_hidden_* issues the load, the value MUST NOT be touched
+// until wait_vm<N>(regs...) has passed them through an s_waitcnt -- N = the number of memory instructions issued after
+// the load that may still be outstanding (loads AND stores, hidden or not: one in-order counter).  Keep each value in
+// variables of its own between the two (no copies: the compiler would copy a register the load has not written yet).
+typedef unsigned int hark_u4v __attribute__((ext_vector_type(4)));
+typedef unsigned int hark_u2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void ld_hidden_nt_b128(hark_u4v &dst, const void *p) { asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(p) : "memory"); }
+__device__ __forceinline__ void ld_hidden_nt_b64(hark_u2v &dst, const void *p) { asm volatile("global_load_dwordx2 %0, %1, off nt" : "=v"(dst) : "v"(p) : "memory"); }
+template <int N> __device__ __forceinline__ void wait_vm(hark_u4v &a) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void wait_vm(hark_u4v &a, hark_u2v &b) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void wait_vm(hark_u4v &a, hark_u4v &b) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory"); }
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope fence over ALL
 // address spaces: the compiler drains vmcnt before s_barrier, so a barrier inside a streaming loop waits
 // for every global load and store the lanes still have in flight.  Where lanes exchange data through LDS

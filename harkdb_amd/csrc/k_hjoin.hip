@@ -39,6 +39,7 @@ namespace {
 
 constexpr int kJThreads = 1024;
 constexpr int kJErrOverflow = 100;
+constexpr int kJIdx = 2048;                               // entries of the bucket kernel's radix index over a round's keys
 constexpr int kMaxRounds = 16;                           // bucket-kernel rounds whose survivor counts are recorded (the order kernel reads per round)
 constexpr size_t kJLdsBudget = 160 * 1024 - 512;          // one workgroup per CU owns (almost) all of its LDS
 
@@ -175,32 +176,35 @@ __global__ __launch_bounds__(kJThreads) void jpart_kernel(const K *__restrict__ 
     const int64_t nbatch = (n + BATCH - 1) / BATCH;
     E *myslab = slabs + (size_t)wg * cap;                                       // + b * nwg * cap
 
-    auto load = [&](int64_t batch, K (&kk)[VEC], uint32_t (&vv)[VEC]) {
-        const int64_t r = batch * BATCH + (int64_t)tid * VEC;
-        if (r + VEC <= n) {
-            typedef unsigned int u4v __attribute__((ext_vector_type(4)));
-            const u4v t = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(keys + r));       // VEC * sizeof(K) = 16 bytes
-            if (sizeof(K) == 4) { kk[0] = (K)t.x; kk[1 % VEC] = (K)t.y; kk[2 % VEC] = (K)t.z; kk[3 % VEC] = (K)t.w; }
-            else { kk[0] = (K)(((uint64_t)t.y << 32) | t.x); kk[1 % VEC] = (K)(((uint64_t)t.w << 32) | t.z); }
-            if (sizeof(E) == 16 && lval) {                               // VEC = 2 rows: one 8-byte load (r is even)
-                typedef unsigned int u2v __attribute__((ext_vector_type(2)));
-                const u2v q = __builtin_nontemporal_load(reinterpret_cast<const u2v *>(lval + r));
-                vv[0] = q.x; vv[1 % VEC] = q.y;
-            }
-        } else {
-            for (int j = 0; j < VEC; j++) { kk[j] = r + j < n ? keys[r + j] : (K)0; vv[j] = (sizeof(E) == 16 && lval && r + j < n) ? lval[r + j] : 0u; }
-        }
+    // The batches' loads are issued and waited for by hand (ld_hidden_* / wait_vm): three register sets in turn, a batch is
+    // used when the two loaded after it may still be in flight.  Left to the compiler every batch waited with vmcnt(0) --
+    // for the prefetch issued just before it: its count of the memory instructions between a load and its use breaks down
+    // at the sweep's stores (conditional, in loops) and again at the loop header that merges the paths.  Every batch issues
+    // its loads whether or not its rows exist (a lane whose VEC rows do not all lie below n reads rows 0.. and drops them;
+    // the last n % VEC rows go through a batch of their own at the end); the sweep's stores are hidden too.
+    const bool has_val = sizeof(E) == 16 && lval != nullptr;
+    const uint32_t *vsrc = has_val ? lval : reinterpret_cast<const uint32_t *>(keys);     // (any readable address: the words are not used)
+    auto load = [&](int64_t batch, hark_u4v &kq, hark_u2v &vq) {
+        int64_t r = batch * BATCH + (int64_t)tid * VEC;
+        if (r + VEC > n) r = 0;
+        ld_hidden_nt_b128(kq, keys + r);                             // VEC * sizeof(K) = 16 bytes
+        if (sizeof(E) == 16) ld_hidden_nt_b64(vq, vsrc + r);         // VEC = 2 rows: one 8-byte load (r is even)
+    };
+    auto unpack = [&](const hark_u4v t, const hark_u2v q, K (&kk)[VEC], uint32_t (&vv)[VEC]) {
+        if (sizeof(K) == 4) { kk[0] = (K)t.x; kk[1 % VEC] = (K)t.y; kk[2 % VEC] = (K)t.z; kk[3 % VEC] = (K)t.w; }
+        else { kk[0] = (K)(((uint64_t)t.y << 32) | t.x); kk[1 % VEC] = (K)(((uint64_t)t.w << 32) | t.z); }
+        vv[0] = q.x; vv[1 % VEC] = q.y;
     };
 
-    auto process = [&](int64_t batch, const K (&kraw)[VEC], const uint32_t (&vraw)[VEC], bool flush_now) {
-        const int64_t r = batch * BATCH + (int64_t)tid * VEC;
+    // rows r .. r + VEC - 1 of this lane (nrows of them exist)
+    auto process = [&](int64_t r, int nrows, const K (&kraw)[VEC], const uint32_t (&vraw)[VEC], bool flush_now) {
         uint32_t pending = 0;
         K kk[VEC];
         uint32_t bk[VEC];
 #pragma unroll
         for (int j = 0; j < VEC; j++) {
             kk[j] = kraw[j] ^ bias;
-            if (r + j < n && kk[j] >= kmin && kk[j] <= kmax) pending |= 1u << j;
+            if (j < nrows && kk[j] >= kmin && kk[j] <= kmax) pending |= 1u << j;
             // bucket = number of splitters <= key = the b with ext[b] <= key < ext[b + 1]
             const K key = kk[j];
             uint32_t g = __umulhi((uint32_t)((uint64_t)(key - kmin) >> gshift), gmul);
@@ -229,7 +233,7 @@ __global__ __launch_bounds__(kJThreads) void jpart_kernel(const K *__restrict__ 
                     const uint32_t old = olds[j], pos = old & 0xFFFFu;
                     if (pos < (uint32_t)Q) {
                         E e; e.key = kk[j]; e.row = (uint32_t)(r + j);
-                        if (sizeof(E) == 16) reinterpret_cast<uint32_t *>(&e)[3] = lval ? vraw[j] : 0u;
+                        if (sizeof(E) == 16) reinterpret_cast<uint32_t *>(&e)[3] = has_val ? vraw[j] : 0u;
                         ring[b * Q + (((old >> 16) + pos) & (Q - 1))] = e;
                         pending &= ~(1u << j);
                     } else atomicSub(&s_w[b], 1u);                     // ring full: retry after the sweep
@@ -246,9 +250,8 @@ __global__ __launch_bounds__(kJThreads) void jpart_kernel(const K *__restrict__ 
                     for (int q = 0; q < lines; q++) {
                         const uint4 piece = *reinterpret_cast<const uint4 *>(&ring[b * Q + ((head + q * LINE + PER_LANE * i) & (Q - 1))]);
                         if (lc + q < cap_lines) {
-                            typedef unsigned int u4v __attribute__((ext_vector_type(4)));
                             E *dst = myslab + (size_t)b * nwg * cap + (size_t)(lc + q) * LINE + PER_LANE * i;
-                            __builtin_nontemporal_store(u4v{piece.x, piece.y, piece.z, piece.w}, reinterpret_cast<u4v *>(dst));
+                            st_hidden_nt_b128(dst, piece);
                         } else overflow = true;
                     }
                     if (i == 0) {
@@ -262,19 +265,42 @@ __global__ __launch_bounds__(kJThreads) void jpart_kernel(const K *__restrict__ 
         } while (again);
     };
 
-    K kA[VEC], kB[VEC];
-    uint32_t vA[VEC], vB[VEC];
-#pragma unroll
-    for (int j = 0; j < VEC; j++) { vA[j] = 0u; vB[j] = 0u; }
-    if ((int64_t)wg < nbatch) load(wg, kA, vA);
-    if ((int64_t)wg + nwg < nbatch) load((int64_t)wg + nwg, kB, vB);
-    for (int64_t batch = wg; batch < nbatch; batch += nwg) {
-        K kr[VEC];
-        uint32_t vr[VEC];
-#pragma unroll
-        for (int j = 0; j < VEC; j++) { kr[j] = kA[j]; kA[j] = kB[j]; vr[j] = vA[j]; vA[j] = vB[j]; }
-        if (batch + 2 * (int64_t)nwg < nbatch) load(batch + 2 * (int64_t)nwg, kB, vB);
-        process(batch, kr, vr, ++since >= period || batch + nwg >= nbatch);
+    hark_u4v qA = {0u, 0u, 0u, 0u}, qB = qA, qC = qA;
+    hark_u2v wA = {0u, 0u}, wB = wA, wC = wA;
+    K kk_[VEC];
+    uint32_t vv_[VEC];
+    const int64_t nfull = n / VEC * VEC;                              // rows that full lanes cover
+    auto rows_of = [&](int64_t batch, int64_t &r) -> int { r = batch * BATCH + (int64_t)tid * VEC; return r + VEC <= nfull ? VEC : 0; };
+    load(wg, qA, wA); load((int64_t)wg + nwg, qB, wB); load((int64_t)wg + 2 * (int64_t)nwg, qC, wC);
+    const bool has_tail = wg == 0 && nfull < n;                        // the last n % VEC rows: a batch of their own (workgroup 0)
+    constexpr int kAhead = sizeof(E) == 16 ? 4 : 2;                    // loads of the two batches behind the one being used
+    for (int64_t batch = wg;;) {
+        int64_t r;
+        int nr;
+        if (batch >= nbatch) break;
+        if (sizeof(E) == 16) wait_vm<kAhead>(qA, wA); else wait_vm<kAhead>(qA);
+        unpack(qA, wA, kk_, vv_);
+        nr = rows_of(batch, r);
+        process(r, nr, kk_, vv_, ++since >= period || (batch + nwg >= nbatch && !has_tail));
+        load(batch + 3 * (int64_t)nwg, qA, wA); batch += nwg;
+        if (batch >= nbatch) break;
+        if (sizeof(E) == 16) wait_vm<kAhead>(qB, wB); else wait_vm<kAhead>(qB);
+        unpack(qB, wB, kk_, vv_);
+        nr = rows_of(batch, r);
+        process(r, nr, kk_, vv_, ++since >= period || (batch + nwg >= nbatch && !has_tail));
+        load(batch + 3 * (int64_t)nwg, qB, wB); batch += nwg;
+        if (batch >= nbatch) break;
+        if (sizeof(E) == 16) wait_vm<kAhead>(qC, wC); else wait_vm<kAhead>(qC);
+        unpack(qC, wC, kk_, vv_);
+        nr = rows_of(batch, r);
+        process(r, nr, kk_, vv_, ++since >= period || (batch + nwg >= nbatch && !has_tail));
+        load(batch + 3 * (int64_t)nwg, qC, wC); batch += nwg;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the loads still in flight write registers: let them land
+    if (has_tail) {
+        const int nr = tid == 0 ? (int)(n - nfull) : 0;
+        for (int j = 0; j < VEC; j++) { kk_[j] = (tid == 0 && j < nr) ? keys[nfull + j] : (K)0; vv_[j] = (tid == 0 && j < nr && has_val) ? lval[nfull + j] : 0u; }
+        process(nfull, nr, kk_, vv_, true);
     }
     // ---- what is left (< LINE entries per bucket) goes out as one partial line
     for (int b = tid; b < P; b += kJThreads) {
@@ -297,7 +323,9 @@ __global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTrai
                                                             int chunk_cap, uint2 *__restrict__ surv, uint32_t *__restrict__ scount,
                                                             uint32_t *__restrict__ sround /* [P][kMaxRounds] survivors after round q */,
                                                             uint32_t *__restrict__ sval /* may be null: the entries' fourth word of every survivor (same index as surv) */,
-                                                            uint32_t *__restrict__ scoarse /* [P][kCoarse] survivors per group of ranks: the order kernel's first histogram */)
+                                                            uint32_t *__restrict__ scoarse /* [P][kCoarse] survivors per group of ranks: the order kernel's first histogram */,
+                                                            uint32_t *__restrict__ smode /* [P] 1: the bucket ran as ONE round over truncated keys (its survivors are not grouped by round) */,
+                                                            int allow_trunc)
 {
     typedef typename JTraits<K>::E E;
     // candidate queues: 8-byte pairs are tested two per lane and step (64 + 128 queued at most); 16-byte entries one per lane
@@ -305,11 +333,20 @@ __global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTrai
     constexpr int BM_BITS = JTraits<K>::BM_BITS, BM_WORDS = 1 << (BM_BITS - 5), QCAP = sizeof(E) == 16 ? 128 : 192;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     uint32_t *bitmap = reinterpret_cast<uint32_t *>(lds_raw);                 // [BM_WORDS] one bit per hashed chunk key
-    K *chunk = reinterpret_cast<K *>(bitmap + BM_WORDS);                       // [CHUNK] sorted build keys of this round
-    K *qkey_all = chunk + JTraits<K>::CHUNK;                                   // [16 waves][QCAP] candidate keys
+    // The sorted keys are stored SKEWED, key i at i + i / 32 (64 for 4-byte words): the first steps of a binary search read
+    // keys a power of two apart -- up to 64 lanes on 64 different keys of ONE bank.  (Measured on BASELINE configs[3]'s
+    // share: the LDS busy for two thirds of the kernel, 82 % of that bank conflicts.)
+    constexpr int SKK = sizeof(K) == 8 ? 5 : 6, CHUNK_PAD = JTraits<K>::CHUNK >> SKK;
+    K *chunk = reinterpret_cast<K *>(bitmap + BM_WORDS);                       // [CHUNK + CHUNK_PAD] sorted build keys of this round
+    K *qkey_all = chunk + JTraits<K>::CHUNK + CHUNK_PAD;                       // [16 waves][QCAP] candidate keys
     uint32_t *qrow_all = reinterpret_cast<uint32_t *>(qkey_all + (kJThreads / 64) * QCAP);   // [16 waves][QCAP] their row ids
     uint32_t *qval_all = qrow_all + (kJThreads / 64) * QCAP;                   // [16 waves][QCAP] their fourth words (16-byte entries)
     uint32_t *s_coarse = qval_all + (sizeof(E) == 16 ? (kJThreads / 64) * QCAP : 0);   // [kCoarse] survivors per group of 2^gs ranks (for the order kernel)
+    // a radix index over the round's keys: s_idx[k] = first key whose (key - first key) >> S is >= k.  A search then starts
+    // in a span of m / 2048 keys (a dozen when the keys are spread evenly) instead of all m: measured on BASELINE
+    // configs[3]'s share, the 15 DEPENDENT LDS reads of a full binary search per batch of 64 candidates were 445 us of
+    // the kernel's 950 -- four waves per SIMD do not hide 15 x 200 cycles
+    uint16_t *s_idx = reinterpret_cast<uint16_t *>(s_coarse + kCoarse);                 // [kJIdx + 1]
     __shared__ uint32_t s_n;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = kJThreads >> 6;
     K *qkey = qkey_all + wave * QCAP;
@@ -323,23 +360,65 @@ __global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTrai
     uint2 *out = surv + (size_t)b * nwg * cap;                             // room for every probe pair of the bucket
     uint32_t *vout = sval ? sval + (size_t)b * nwg * cap : nullptr;
     const unsigned long long below = (1ull << lane) - 1ull;
+    // 64-bit keys: a bucket of up to two chunks of build keys (BASELINE configs[3]: 24.4 K against 12 K per 96-KiB chunk)
+    // would stream its probe entries twice.  Instead the chunk area holds the keys TRUNCATED to 32 bits,
+    // (key - first key) >> ts, twice as many: the search runs on those and a hit is confirmed against the full key in
+    // memory (the bucket's 200 KB of keys: cache hits).  Exact as long as equal truncated keys are equal keys -- checked
+    // when they are loaded; a bucket that fails the check (keys clustered below bit ts) takes the rounds as before.
+    uint32_t *c32 = reinterpret_cast<uint32_t *>(chunk);
+    auto ck = [&](int i) -> K & { return chunk[i + (i >> SKK)]; };
+    auto c3 = [&](int i) -> uint32_t & { return c32[i + (i >> 6)]; };
+    __shared__ int s_tbad;
+#ifdef HARK_JB_NOTRUNC
+    const bool tmode = false;
+#else
+    bool tmode = sizeof(K) == 8 && allow_trunc && hi - lo > (uint32_t)chunk_cap && hi - lo <= 2u * (uint32_t)chunk_cap;
+#endif
+    K kb = (K)0;
+    int ts = 0;
+    if (tmode) {
+        if (tid == 0) s_tbad = 0;
+        kb = rkeys[lo];
+        const uint64_t range = (uint64_t)(rkeys[hi - 1] - kb);
+        while ((range >> ts) > 0xFFFFFFFFull) ts++;
+        __syncthreads();
+        const int m = (int)(hi - lo);
+        for (int i = tid; i < m; i += kJThreads) c3(i) = (uint32_t)((uint64_t)(rkeys[lo + i] - kb) >> ts);
+        __syncthreads();
+        bool bad = false;
+        for (int i = tid + 1; i < m; i += kJThreads) bad = bad || (c3(i) == c3(i - 1) && rkeys[lo + i] != rkeys[lo + i - 1]);
+        if (bad) s_tbad = 1;
+        __syncthreads();
+#ifndef HARK_JB_NOTRUNC
+        tmode = s_tbad == 0;
+#endif
+    }
+    if (tid == 0) smode[b] = tmode ? 1u : 0u;
+    const uint32_t round_keys = tmode ? hi - lo : (uint32_t)chunk_cap;
     int q = 0;                                                       // rounds done
-    for (uint32_t base = lo; base < hi; base += (uint32_t)chunk_cap, q++) {
-        const int m = (int)min((uint32_t)chunk_cap, hi - base);
+    for (uint32_t base = lo; base < hi; base += round_keys, q++) {
+        const int m = (int)min(round_keys, hi - base);
         __syncthreads();                                             // the previous round's readers are done (and s_n is set)
         if (tid == 0 && q > 0 && q <= kMaxRounds) sround[b * kMaxRounds + q - 1] = s_n;
         for (int i = tid; i < BM_WORDS; i += kJThreads) bitmap[i] = 0u;
-        for (int i = tid; i < m; i += kJThreads) chunk[i] = rkeys[base + i];
+        if (!tmode) for (int i = tid; i < m; i += kJThreads) ck(i) = rkeys[base + i];
         __syncthreads();
-        for (int i = tid; i < m; i += kJThreads) { const uint32_t h = jhash(chunk[i]) >> (32 - BM_BITS); atomicOr(&bitmap[h >> 5], 1u << (h & 31u)); }
+        for (int i = tid; i < m; i += kJThreads) { const uint32_t h = jhash(tmode ? rkeys[base + i] : ck(i)) >> (32 - BM_BITS); atomicOr(&bitmap[h >> 5], 1u << (h & 31u)); }
         __syncthreads();
-        const K first = chunk[0], last = chunk[m - 1];
+        const K first = tmode ? kb : ck(0), last = tmode ? rkeys[hi - 1] : ck(m - 1);
         const bool has_prev = base > lo;
         const K prev_last = has_prev ? rkeys[base - 1] : (K)0;         // a run continued from the previous round was matched there
-        // lower bound in one of two windows of W = 2^t <= m keys, [0, W) or [m - W, m): a fixed number of branch-free steps
-        int W = 1;
-        while (W * 2 <= m) W <<= 1;
-        const K pivot = chunk[W - 1];
+        // the index: keys as offsets from the round's first key, cut down to kJIdx classes
+        const uint64_t span = tmode ? (uint64_t)c3(m - 1) : (uint64_t)(last - first);
+        int S = 0;
+        while ((span >> S) >= (uint64_t)kJIdx) S++;
+        auto klass = [&](int i) -> int { return tmode ? (int)(c3(i) >> S) : (int)((uint64_t)(ck(i) - first) >> S); };
+        for (int i = tid; i < m; i += kJThreads) {
+            const int kc = klass(i), kp = i ? klass(i - 1) : -1;
+            for (int k = kp + 1; k <= kc; k++) s_idx[k] = (uint16_t)i;
+            if (i == m - 1) for (int k = kc + 1; k <= kJIdx; k++) s_idx[k] = (uint16_t)m;
+        }
+        __syncthreads();
         auto candidate = [&](K key) -> bool {                          // range test, then one bit
             if (!(key >= first && key <= last) || (has_prev && key == prev_last)) return false;
             const uint32_t h = jhash(key) >> (32 - BM_BITS);
@@ -351,19 +430,8 @@ __global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTrai
             if (c) { const int at = qn + __popcll(mask & below); qkey[at] = key; qrow[at] = row; if (sizeof(E) == 16) qval[at] = val; }
             qn += __popcll(mask);
         };
-        // search `cnt` queued candidates (the last ones), one per lane; a hit is appended to the bucket's survivors
-        auto drain = [&](int cnt) {
-            qn -= cnt;
-            const bool act = lane < cnt;
-            const K key = act ? qkey[qn + lane] : (K)0;
-            const uint32_t row = act ? qrow[qn + lane] : 0u;
-            const uint32_t val = (sizeof(E) == 16 && act) ? qval[qn + lane] : 0u;
-            const int off = pivot < key ? m - W : 0;
-            int pos = 0;
-            for (int step = W >> 1; step > 0; step >>= 1) pos += chunk[off + pos + step - 1] < key ? step : 0;
-            pos += off;
-            pos += (pos < m && chunk[pos] < key) ? 1 : 0;            // the window's last key was never compared
-            const bool match = act && pos < m && chunk[pos] == key;
+        // a hit is appended to the bucket's survivors (stores the compiler does not count: see st_hidden_b32)
+        auto commit = [&](bool match, uint32_t pos, uint32_t row, uint32_t val) {
             const unsigned long long mask = __ballot(match);
             if (mask) {
                 uint32_t at = 0;
@@ -371,53 +439,139 @@ __global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTrai
                 at = __shfl(at, 0, 64);
                 if (match) {
                     const uint32_t o = at + (uint32_t)__popcll(mask & below);
-                    out[o] = uint2{base + (uint32_t)pos, row};
-                    if (sizeof(E) == 16 && vout) vout[o] = val;
-                    atomicAdd(&s_coarse[(base + (uint32_t)pos - lo) >> gs], 1u);
+                    st_hidden_b64(out + o, uint2{base + pos, row});
+                    if (sizeof(E) == 16 && vout) st_hidden_b32(vout + o, val);
+#if !(defined(HARK_JB_EXP) && HARK_JB_EXP == 6)                       // timing: no rank-group counts
+                    atomicAdd(&s_coarse[(base + pos - lo) >> gs], 1u);
+#endif
                 }
             }
         };
-        // a wave walks whole slabs, 128 entries per step: two entries per lane (one 16-byte load for 8-byte pairs, two
-        // for 16-byte entries), the next step's loads in flight while this one's pairs are tested
+        // 16-byte entries: a batch's hits are committed one step LATER (two slots, one per half-step).  With truncated keys
+        // the full key of a hit is read from memory (the bucket's 200 KB of keys: cache hits) and compared then; the read
+        // is issued for every batch, hit or not, full or empty, so that every step issues the same number of loads and the
+        // compiler can place exact waits -- a conditional load would turn every wait of the loop into vmcnt(0).
+        struct Pending { bool match; uint32_t klow, full, pos, row, val; };      // (full: the low word of the build key at pos -- the truncated key
+        Pending pend[2] = {{false, 0u, 0u, 0u, 0u, 0u}, {false, 0u, 0u, 0u, 0u, 0u}};   //  covers every bit from ts <= 32 up, so the two words decide equality)
+        // search `cnt` queued candidates (the last ones), one per lane: the lower bound in the index class's span
+        auto search = [&](int cnt, K &key, uint32_t &row, uint32_t &val, int &pos) -> bool {
+            qn -= cnt;
+            const bool act = lane < cnt;
+            key = act ? qkey[qn + lane] : (K)0;
+            row = act ? qrow[qn + lane] : 0u;
+            val = (sizeof(E) == 16 && act) ? qval[qn + lane] : 0u;
+            if (tmode) {
+                const uint32_t t = act ? (uint32_t)((uint64_t)(key - kb) >> ts) : 0u;
+                const uint32_t kq = t >> S;                          // < kJIdx: the candidate passed the range test
+                int n = act ? (int)s_idx[kq + 1] - (int)s_idx[kq] : 0;
+                pos = (int)s_idx[kq];
+                while (__ballot(n > 0) != 0ull) {
+                    const int half = n >> 1;
+                    const bool go = n > 0 && c3(pos + half) < t;
+                    pos = go ? pos + half + 1 : pos;
+                    n = go ? n - half - 1 : half;
+                }
+                return act && pos < m && c3(pos) == t;               // equal truncated keys are equal keys: the first of them is the lower bound
+            }
+            const uint32_t kq = act ? (uint32_t)((uint64_t)(key - first) >> S) : 0u;
+            int n = act ? (int)s_idx[kq + 1] - (int)s_idx[kq] : 0;
+            pos = (int)s_idx[kq];
+            while (__ballot(n > 0) != 0ull) {
+                const int half = n >> 1;
+                const bool go = n > 0 && ck(pos + half) < key;
+                pos = go ? pos + half + 1 : pos;
+                n = go ? n - half - 1 : half;
+            }
+            return act && pos < m && ck(pos) == key;
+        };
+        auto drain = [&](int cnt) {                                    // 8-byte pairs: search and commit
+            K key; uint32_t row, val; int pos = 0;
+            const bool match = search(cnt, key, row, val, pos);
+            commit(match, (uint32_t)pos, row, val);
+        };
+        auto drain_slot = [&](int cnt, Pending &p) {                   // 16-byte entries: commit the slot's previous batch, search, read the key
+            K key = (K)0; uint32_t row = 0u, val = 0u; int pos = 0;
+            bool match = false;
+            if (cnt > 0) match = search(cnt, key, row, val, pos);      // (wave-uniform; no memory instruction inside)
+            commit(p.match && (!tmode || p.full == p.klow), p.pos, p.row, p.val);
+            p.match = match; p.klow = (uint32_t)key; p.pos = (uint32_t)pos; p.row = row; p.val = val;
+#if defined(HARK_JB_EXP) && HARK_JB_EXP == 4                          // timing: every verification reads the same address
+            p.full = reinterpret_cast<const uint32_t *>(rkeys + base)[0]; p.klow = p.full;
+#else
+            p.full = reinterpret_cast<const uint32_t *>(rkeys + base + (match ? (uint32_t)pos : 0u))[0];
+#endif
+        };
+        // A wave walks its slabs (every 16th of the bucket's) as ONE stream of 128-entry steps -- two entries per lane: one
+        // 16-byte load for 8-byte pairs, two for 16-byte entries -- with the loads of the next two steps in flight across
+        // slab boundaries (a slab of BASELINE configs[3] is eight steps long).  Every step issues its loads whether or not
+        // there is anything left to read (a clamped address): see above.
         typedef unsigned int u4v __attribute__((ext_vector_type(4)));
         constexpr bool WIDE = sizeof(E) == 16;
-        for (int w = wave; w < nwg; w += nwaves) {
-            const uint32_t count = min(counts[(size_t)b * nwg + w], cap);
-            const u4v *src = reinterpret_cast<const u4v *>(slabs + ((size_t)b * nwg + w) * cap);
-            const uint32_t nstep = (count + 127u) / 128u;
-            u4v n0 = {0u, 0u, 0u, 0u}, n1 = {0u, 0u, 0u, 0u};
-            auto fetch = [&](uint32_t step) {
-                if (WIDE) {
-                    const uint32_t e0 = step * 128u + lane, e1 = e0 + 64u;
-                    if (e0 < count) n0 = __builtin_nontemporal_load(src + e0);
-                    if (e1 < count) n1 = __builtin_nontemporal_load(src + e1);
-                } else {
-                    const uint32_t e0 = step * 128u + 2u * lane;
-                    if (e0 < count) n0 = __builtin_nontemporal_load(src + (e0 >> 1));
-                }
-            };
-            if (nstep) fetch(0);
-            for (uint32_t step = 0; step < nstep; step++) {
-                const u4v c0 = n0, c1 = n1;
-                if (step + 1 < nstep) fetch(step + 1);
-                K key0, key1; uint32_t row0, row1, val0 = 0u, val1 = 0u; bool v0, v1;
-                if (WIDE) {
-                    const uint32_t e0 = step * 128u + lane;
-                    v0 = e0 < count; v1 = e0 + 64u < count;
-                    key0 = (K)(((uint64_t)c0.y << 32) | c0.x); row0 = c0.z; val0 = c0.w;
-                    key1 = (K)(((uint64_t)c1.y << 32) | c1.x); row1 = c1.z; val1 = c1.w;
-                } else {
-                    const uint32_t e0 = step * 128u + 2u * lane;
-                    v0 = e0 < count; v1 = e0 + 1u < count;
-                    key0 = (K)c0.x; row0 = c0.y; key1 = (K)c0.z; row1 = c0.w;
-                }
-                enqueue(v0 && candidate(key0), key0, row0, val0);        // qn < 64 before
-                if (WIDE) while (qn >= 64) drain(64);                    // 16-byte entries: never more than 63 + 64 queued
-                enqueue(v1 && candidate(key1), key1, row1, val1);        // 8-byte pairs: at most 64 + 128 = QCAP queued
-                while (qn >= 64) drain(64);
+        const int nslab = wave < nwg ? (nwg - wave + nwaves - 1) / nwaves : 0;          // <= 64 (at most 1024 partition workgroups)
+        const uint32_t mycount = lane < nslab ? min(counts[(size_t)b * nwg + wave + lane * nwaves], cap) : 0u;
+        struct Cursor { int j; uint32_t step, count; };
+        auto seek = [&](Cursor &c) {                                   // the first step at or after c that has entries
+            while (c.j < nslab && c.step * 128u >= c.count) { c.j++; c.step = 0u; c.count = c.j < nslab ? (uint32_t)__shfl((int)mycount, c.j, 64) : 0u; }
+        };
+        auto fetch = [&](const Cursor &c, u4v &r0, u4v &r1) {
+            const bool live = c.j < nslab;
+            const u4v *src = reinterpret_cast<const u4v *>(slabs + ((size_t)b * nwg + wave % nwg + (size_t)(live ? c.j : 0) * nwaves) * cap);
+            if (WIDE) {
+                const uint32_t e0 = c.step * 128u + lane, e1 = e0 + 64u;
+                r0 = __builtin_nontemporal_load(src + (live && e0 < c.count ? e0 : 0u));
+                r1 = __builtin_nontemporal_load(src + (live && e1 < c.count ? e1 : 0u));
+            } else {
+                const uint32_t e0 = c.step * 128u + 2u * lane;
+                r0 = __builtin_nontemporal_load(src + (live && e0 < c.count ? (e0 >> 1) : 0u));
             }
+        };
+        auto process = [&](const u4v x0, const u4v x1, const Cursor cur) {
+            K key0, key1; uint32_t row0, row1, val0 = 0u, val1 = 0u; bool v0, v1;
+            if (WIDE) {
+                const uint32_t e0 = cur.step * 128u + lane;
+                v0 = e0 < cur.count; v1 = e0 + 64u < cur.count;
+                key0 = (K)(((uint64_t)x0.y << 32) | x0.x); row0 = x0.z; val0 = x0.w;
+                key1 = (K)(((uint64_t)x1.y << 32) | x1.x); row1 = x1.z; val1 = x1.w;
+            } else {
+                const uint32_t e0 = cur.step * 128u + 2u * lane;
+                v0 = e0 < cur.count; v1 = e0 + 1u < cur.count;
+                key0 = (K)x0.x; row0 = x0.y; key1 = (K)x0.z; row1 = x0.w;
+            }
+#if defined(HARK_JB_EXP) && HARK_JB_EXP == 2                          // timing experiments (tools/ab_build.sh + tools/jb_exp.sh; the results are wrong by construction): stream + candidate tests + queues, no search
+            enqueue(v0 && candidate(key0), key0, row0, val0);
+            if (qn >= 64) qn -= 64;
+            enqueue(v1 && candidate(key1), key1, row1, val1);
+            if (qn >= 64) qn -= 64;
+#else
+            enqueue(v0 && candidate(key0), key0, row0, val0);        // qn < 64 before
+            if (WIDE) drain_slot(qn >= 64 ? 64 : 0, pend[0]);        // 16-byte entries: never more than 63 + 64 queued
+            enqueue(v1 && candidate(key1), key1, row1, val1);        // 8-byte pairs: at most 64 + 128 = QCAP queued
+            if (WIDE) drain_slot(qn >= 64 ? 64 : 0, pend[1]);
+            else while (qn >= 64) drain(64);
+#endif
+        };
+        // three register sets in turn, no copies between them: a move out of a register whose load is still in flight
+        // would be a wait for it
+        Cursor cA{0, 0u, nslab > 0 ? (uint32_t)__shfl((int)mycount, 0, 64) : 0u};
+        seek(cA);
+        Cursor cB = cA; cB.step++; seek(cB);
+        Cursor cD = cB; cD.step++; seek(cD);
+        Cursor nx = cD;
+        u4v a0 = {0u, 0u, 0u, 0u}, a1 = a0, b0 = a0, b1 = a0, d0 = a0, d1 = a0;
+        fetch(cA, a0, a1); fetch(cB, b0, b1); fetch(cD, d0, d1);
+        for (;;) {
+            if (cA.j >= nslab) break;
+            process(a0, a1, cA); nx.step++; seek(nx); cA = nx; fetch(cA, a0, a1);
+            if (cB.j >= nslab) break;
+            process(b0, b1, cB); nx.step++; seek(nx); cB = nx; fetch(cB, b0, b1);
+            if (cD.j >= nslab) break;
+            process(d0, d1, cD); nx.step++; seek(nx); cD = nx; fetch(cD, d0, d1);
         }
-        if (qn > 0) drain(qn);                                         // the round's leftovers (fewer than 64)
+        if (WIDE) {                                                    // the round's leftovers (fewer than 64), then the two slots' last batches
+            drain_slot(qn, pend[0]);
+            drain_slot(0, pend[1]);
+            drain_slot(0, pend[0]);
+        } else if (qn > 0) drain(qn);
     }
     __syncthreads();
     if (tid == 0) { scount[b] = s_n; if (q > 0 && q <= kMaxRounds) sround[b * kMaxRounds + q - 1] = s_n; }
@@ -461,7 +615,8 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
                                                            const uint32_t *__restrict__ sval, uint32_t *__restrict__ lval_out, uint32_t *tmpv_all,
                                                            const uint32_t *__restrict__ scoarse,
                                                            const uint32_t *__restrict__ rranked /* may be null: a build-side column in rank order ... */,
-                                                           uint32_t *__restrict__ rval_out /* ... read off for every survivor (unique build keys: survivor = output row) */)
+                                                           uint32_t *__restrict__ rval_out /* ... read off for every survivor (unique build keys: survivor = output row) */,
+                                                           const uint32_t *__restrict__ smode /* [P] 1: the bucket kernel ran this bucket as one round */)
 {
     constexpr int STAGE = CARRY ? kStageCarry : kStage, FINE = CARRY ? kFineCarry : kFine;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -557,7 +712,7 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
     scan_excl(coarse, ngroups + 1);                                    // coarse[g] = survivors before group g; coarse[ngroups] = nb
     JPROF_MARK(0);
     const int rounds_b = (int)((len + (uint32_t)chunk_cap - 1u) / (uint32_t)chunk_cap);
-    const bool by_round = rounds_b <= kMaxRounds;
+    const bool by_round = rounds_b <= kMaxRounds && smode[b] == 0u;
     const uint32_t max_groups = max(1u, (uint32_t)FINE >> gs);
     bool too_long = false;
     // the end of the sub-round that starts at group g0: the largest g1 with coarse[g1] - coarse[g0] <= stage_cap and
@@ -726,7 +881,7 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
     if (!rc) rc = hark_alloc(ctx, (void **)&bstart, 4 * (size_t)(P + 1));
     if (!rc) rc = hark_alloc(ctx, (void **)&counts, 4 * (size_t)P * nwg);
     if (!rc) rc = hark_alloc(ctx, (void **)&scount, 4 * (size_t)P);
-    if (!rc) rc = hark_alloc(ctx, (void **)&sround, 4 * (size_t)P * kMaxRounds);
+    if (!rc) rc = hark_alloc(ctx, (void **)&sround, 4 * (size_t)P * (kMaxRounds + 1));     // + [P] the buckets' modes
     if (!rc) rc = hark_alloc(ctx, (void **)&info, 32);
     if (!rc) rc = hark_alloc(ctx, (void **)&slabs, sizeof(E) * (size_t)P * sstride);
     if (!rc) rc = hark_alloc(ctx, (void **)&surv, 8 * (size_t)P * sstride);
@@ -755,14 +910,15 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
     if (period < 1) period = 1;
     int chunk_cap = JTraits<K>::CHUNK;
     if (const char *e = getenv("HARK_JOIN_CHUNK")) { const int c = atoi(e); if (c >= 1 && c < chunk_cap) chunk_cap = c; }   // tests: force several rounds per bucket
-    constexpr size_t lds_bucket = sizeof(K) * (size_t)JTraits<K>::CHUNK + ((size_t)1 << (JTraits<K>::BM_BITS - 3))
-                                + (sizeof(E) == 16 ? (size_t)(kJThreads / 64) * 128 * 16 : (size_t)(kJThreads / 64) * 192 * 8) + (size_t)kCoarse * 4;
+    constexpr size_t lds_bucket = sizeof(K) * (size_t)(JTraits<K>::CHUNK + (JTraits<K>::CHUNK >> (sizeof(K) == 8 ? 5 : 6))) + ((size_t)1 << (JTraits<K>::BM_BITS - 3))
+                                + (sizeof(E) == 16 ? (size_t)(kJThreads / 64) * 128 * 16 : (size_t)(kJThreads / 64) * 192 * 8) + (size_t)kCoarse * 4
+                                + (size_t)(kJIdx + 8) * 2;
     static_assert(lds_bucket <= kJLdsBudget, "bucket kernel LDS");
     if (he == hipSuccess) he = hipFuncSetAttribute(reinterpret_cast<const void *>(&jbucket_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bucket);
     if (he == hipSuccess) {
         // one stream-ordered chain, one host read at the end: partition -> bucket probe -> survivor total
         jpart_kernel<K><<<dim3((unsigned)nwg), dim3(kJThreads), lds_part, st>>>(lcol, n, bias, splitters, rkeys, s, slabs, counts, cap, period, err, carry ? lval : nullptr);
-        jbucket_kernel<K><<<dim3((unsigned)P), dim3(kJThreads), lds_bucket, st>>>(slabs, counts, cap, nwg, rkeys, bstart, chunk_cap, surv, scount, sround, sval, scoarse);
+        jbucket_kernel<K><<<dim3((unsigned)P), dim3(kJThreads), lds_bucket, st>>>(slabs, counts, cap, nwg, rkeys, bstart, chunk_cap, surv, scount, sround, sval, scoarse, sround + (size_t)P * kMaxRounds, getenv("HARK_JOIN_NOTRUNC") ? 0 : 1);
         jsum_kernel<<<1, 1024, 0, st>>>(scount, P, total);
         he = hipGetLastError();
         if (he == hipSuccess) he = hipMemcpyAsync(info + 2, flags, 8, hipMemcpyDeviceToDevice, st);   // the duplicate-keys flag rides along with the same host read
@@ -797,10 +953,10 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
                 uint32_t *binsv = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(slabs) + 8 * (size_t)P * sstride);
                 if (he == hipSuccess && carry)
                     jorder_kernel<true><<<dim3((unsigned)P), dim3(kJThreads), lds_order, st>>>(surv, sstride, scount, sround, chunk_cap, bstart, P, runlen,
-                                                                                             rank, lrow, cnt, stage_cap, flags, bins, sval, lv, binsv, scoarse, rranked, rv);
+                                                                                             rank, lrow, cnt, stage_cap, flags, bins, sval, lv, binsv, scoarse, rranked, rv, sround + (size_t)P * kMaxRounds);
                 else if (he == hipSuccess)
                     jorder_kernel<false><<<dim3((unsigned)P), dim3(kJThreads), lds_order, st>>>(surv, sstride, scount, sround, chunk_cap, bstart, P, runlen,
-                                                                                              rank, lrow, cnt, stage_cap, flags, bins, nullptr, nullptr, nullptr, scoarse, rranked, rv);
+                                                                                              rank, lrow, cnt, stage_cap, flags, bins, nullptr, nullptr, nullptr, scoarse, rranked, rv, sround + (size_t)P * kMaxRounds);
             }
             if (he != hipSuccess || hipGetLastError() != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: order launch failed");
         }

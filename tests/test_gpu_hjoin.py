@@ -65,6 +65,9 @@ CASES = {
     "i64 build keys in short runs of equal high words (2..16)": dict(dt=np.int64, n=300_000, s=60_000, pool=None, hit=0.4, hiruns=16),
     "i64 build keys with a run of 17 equal high words (eight-pass fallback)": dict(dt=np.int64, n=300_000, s=60_000, pool=None, hit=0.4, hiruns=17),
     "i64 build keys below 2^40 (few distinct high words: fallback)": dict(dt=np.int64, n=280_000, s=50_000, pool=None, hit=0.3, small=True),
+    # a bucket of up to two chunks of i64 build keys is probed in ONE round over keys truncated to 32 bits; consecutive keys
+    # beside keys spread over 64 bits in one bucket truncate to equal words -> that bucket takes the rounds instead
+    "i64 consecutive keys among spread ones": dict(dt=np.int64, n=300_000, s=60_000, pool=None, hit=0.5, clustered=True),
 }
 
 
@@ -87,6 +90,10 @@ def _make(case, seed):
         rk = rk[rng.permutation(s)]
     elif c.get("small"):
         rk = rng.integers(-2**39, 2**39, size=s, dtype=np.int64)
+    elif c.get("clustered"):
+        rk = np.concatenate([np.arange(s // 2, dtype=np.int64) * 3 + 10**12, rng.integers(info.min, info.max, size=s - s // 2, dtype=np.int64)])
+        rk[:50] = rk[50:100]                                              # some duplicates inside the cluster
+        rk = rk[rng.permutation(s)]
     elif c.get("unique"):
         rk = (rng.permutation(s).astype(np.int64) * 40503 - 1_000_000_007).astype(dt)     # distinct, scattered, some negative
     else:
@@ -182,17 +189,18 @@ import test_gpu_hjoin as T
 from harkdb_amd.engine import Engine
 eng = Engine(0)
 for case in ("u32 every row hits, 8 partners each", "i64 duplicates both sides", "u32 few distinct keys (duplicate splitters)",
-             "i64 unique build keys, every second probe row hits", "u32 10%% hits"):
+             "i64 unique build keys, every second probe row hits", "u32 10%% hits", "i64 consecutive keys among spread ones"):
     lk, rk = T._make(case, 3)
     print(case, T._check(eng, lk, rk))
 print("rounds ok")
 """
 
 
-@pytest.mark.parametrize("chunk", ["7", "64"])
+@pytest.mark.parametrize("chunk", ["7", "64", "120"])
 def test_build_slices_longer_than_lds_take_rounds(chunk):
     """HARK_JOIN_CHUNK caps the build keys staged per round (a test knob), so every bucket needs many rounds and runs of
-    equal keys cross round boundaries: the results must not change."""
+    equal keys cross round boundaries: the results must not change.  i64 buckets of up to two chunks (64: the clustered
+    case's ~117 keys, 120: the unique case's ~195) take the single round over truncated keys."""
     env = dict(os.environ, HARK_JOIN_CHUNK=chunk)
     out = subprocess.run([sys.executable, "-c", _ROUNDS % (ROOT, os.path.join(ROOT, "tests"))], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0 and "rounds ok" in out.stdout, out.stdout + out.stderr
