@@ -136,15 +136,18 @@ __global__ __launch_bounds__(GEO::T) void digit_hist_kernel(const uint32_t *__re
     if (threadIdx.x < kBins) hist[(size_t)threadIdx.x * nblk + blockIdx.x] = s_hist[threadIdx.x];
 }
 
-// All four digit histograms of a slice from ONE read of the keys, and the bits in which any key differs from the first
-// one (a pass over a byte in which all keys agree is skipped): replaces the difference-mask pass AND the histogram launch
-// of the first pass that runs.  hist4[pass][bin][blk].
+// The histogram of the keys' LOW byte per slice and the bits in which any key differs from the first one (a pass over a
+// byte in which all keys agree is skipped) from ONE read of the keys: replaces the difference-mask pass AND the histogram
+// launch of the first pass whenever that pass starts at bit 0 (narrower digits fold the rows: fold_hist_rows_kernel).
+// hist0[bin][blk].  (A first version counted all four bytes -- only the first pass can use a histogram of the INPUT order,
+// and three more LDS atomics per key made this the slowest read of the sort: 139 us per 1e8 keys against 71 for
+// digit_hist_kernel.)
 __global__ __launch_bounds__(1024) void multi_hist_kernel(const uint32_t *__restrict__ keys, int64_t n, int64_t slice, uint32_t xor_mask,
-                                                          uint32_t *__restrict__ hist4, int nblk, uint32_t *__restrict__ diff)
+                                                          uint32_t *__restrict__ hist0, int nblk, uint32_t *__restrict__ diff)
 {
-    __shared__ uint32_t s_hist[4][kBins];
+    __shared__ uint32_t s_hist[kBins];
     __shared__ uint32_t s_acc;
-    for (int i = threadIdx.x; i < 4 * kBins; i += blockDim.x) (&s_hist[0][0])[i] = 0u;
+    for (int i = threadIdx.x; i < kBins; i += blockDim.x) s_hist[i] = 0u;
     if (threadIdx.x == 0) s_acc = 0u;
     __syncthreads();
     const int64_t lo = (int64_t)blockIdx.x * slice;
@@ -153,37 +156,42 @@ __global__ __launch_bounds__(1024) void multi_hist_kernel(const uint32_t *__rest
     const uint4 *k4 = reinterpret_cast<const uint4 *>(keys + lo);
     const uint32_t w0 = keys[0];
     uint32_t acc = 0u;
-    // A digit in which every key of the wave agrees (the high bytes of small keys: 64 lanes adding to ONE counter serialise,
-    // 437 us per 1e8 20-bit keys) is counted by one lane.
+    // A low byte in which every key of the wave agrees (keys that are multiples of 256: 64 lanes adding to ONE counter
+    // serialise) is counted by one lane.
     auto count1 = [&](uint32_t k) {
         acc |= k ^ w0;
-        const uint32_t x = k ^ xor_mask;
-        const uint32_t t = x ^ (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
-        const uint32_t nact = (uint32_t)__popcll(__ballot(true));
-        const bool leader = (__ballot(true) & lanemask_lt()) == 0ull;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const uint32_t d = (x >> (8 * j)) & 255u;
-            if (__ballot((t >> (8 * j)) & 255u) == 0ull) { if (leader) atomicAdd(&s_hist[j][d], nact); }
-            else atomicAdd(&s_hist[j][d], 1u);
-        }
+        const uint32_t d = (k ^ xor_mask) & 255u;
+        const uint64_t active = __ballot(true);
+        if (__ballot(d != (uint32_t)__builtin_amdgcn_readfirstlane((int)d)) == 0ull) { if ((active & lanemask_lt()) == 0ull) atomicAdd(&s_hist[d], (uint32_t)__popcll(active)); }
+        else atomicAdd(&s_hist[d], 1u);
     };
     auto count4 = [&](const uint4 q) { count1(q.x); count1(q.y); count1(q.z); count1(q.w); };
     int64_t i = threadIdx.x;
-    for (; i + (int64_t)blockDim.x < nvec; i += 2 * (int64_t)blockDim.x) {
-        const uint4 a = ld_nt16(k4 + i), b = ld_nt16(k4 + i + blockDim.x);
-        count4(a); count4(b);
+    for (; i + 3 * (int64_t)blockDim.x < nvec; i += 4 * (int64_t)blockDim.x) {
+        const uint4 a = ld_nt16(k4 + i), b = ld_nt16(k4 + i + blockDim.x), c = ld_nt16(k4 + i + 2 * blockDim.x), d = ld_nt16(k4 + i + 3 * blockDim.x);
+        count4(a); count4(b); count4(c); count4(d);
     }
     for (; i < nvec; i += blockDim.x) count4(k4[i]);
     for (int64_t j = lo + nvec * 4 + threadIdx.x; j < hi; j += blockDim.x) count1(keys[j]);
     for (int d = 32; d > 0; d >>= 1) acc |= __shfl_xor(acc, d, 64);
     if ((threadIdx.x & 63) == 0 && acc) atomicOr(&s_acc, acc);
     __syncthreads();
-    for (int i2 = threadIdx.x; i2 < 4 * kBins; i2 += blockDim.x)
-        hist4[((size_t)(i2 >> 8) * kBins + (size_t)(i2 & 255)) * nblk + blockIdx.x] = (&s_hist[0][0])[i2];
+    for (int i2 = threadIdx.x; i2 < kBins; i2 += blockDim.x) hist0[(size_t)i2 * nblk + blockIdx.x] = s_hist[i2];
     if (threadIdx.x == 0) {
         const uint32_t mine = s_acc;
         if (mine & ~__hip_atomic_load(diff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(diff, mine);
+    }
+}
+
+// The low-byte histogram as the histogram of a digit of `width` < 8 bits at bit 0: row d += rows d + j * 2^width, the folded
+// rows cleared.  One workgroup per row of the result.
+__global__ __launch_bounds__(256) void fold_hist_rows_kernel(uint32_t *__restrict__ hist, int nblk, int width)
+{
+    const int d = blockIdx.x, step = 1 << width;
+    for (int i = threadIdx.x; i < nblk; i += blockDim.x) {
+        uint32_t sum = hist[(size_t)d * nblk + i];
+        for (int r = d + step; r < kBins; r += step) { sum += hist[(size_t)r * nblk + i]; hist[(size_t)r * nblk + i] = 0u; }
+        hist[(size_t)d * nblk + i] = sum;
     }
 }
 
@@ -888,8 +896,8 @@ int k_sort_pairs_u32(hark_context *ctx, uint32_t *keys_a, uint32_t *keys_b, uint
                      const uint32_t *vals_first, int64_t n, uint32_t xor_mask, uint32_t *hist_ws, uint32_t pass_mask,
                      uint32_t **keys_out, uint32_t **vals_out, const uint32_t *keys_first = nullptr, uint32_t *hist4 = nullptr)
 {
-    // hist4 (optional): the per-slice histograms of all four digits of the INPUT keys (k_multi_hist, same geometry and
-    // xor_mask): the first pass that runs takes its histogram from there instead of reading the keys again
+    // hist4 (optional): the per-slice histogram of the LOW byte of the INPUT keys (k_multi_hist, same geometry and xor_mask):
+    // a first pass that starts at bit 0 takes its histogram from there instead of reading the keys again
     *keys_out = keys_a; *vals_out = vals_a;
     if (n <= 0) return HARK_OK;
     if (n > 0xFFFFFFFFll) return hark_fail(ctx, HARK_EARG, "sort: at most 2^32-1 rows");
@@ -904,8 +912,10 @@ int k_sort_pairs_u32(hark_context *ctx, uint32_t *keys_a, uint32_t *keys_b, uint
     for (int pi = 0; pi < npass; pi++) {
         const int shift = plan[pi].shift | (plan[pi].width << 8);
         uint32_t *hist_in = hist_ws;                                  // [bins][nblk], scanned in place; the digit totals go to hist_ws + bins * nblk
-        if (first && hist4 && plan[pi].width == 8 && plan[pi].shift % 8 == 0) hist_in = hist4 + (size_t)(plan[pi].shift / 8) * kBins * nblk;
-        else
+        if (first && hist4 && plan[pi].shift == 0) {                  // the low byte's histogram of the input order (k_multi_hist)
+            hist_in = hist4;
+            if (plan[pi].width < 8) fold_hist_rows_kernel<<<dim3(1u << plan[pi].width), dim3(256), 0, st>>>(hist4, (int)nblk, plan[pi].width);
+        } else
         if (large) digit_hist_kernel<GeoLarge><<<dim3((unsigned)nblk), dim3(GeoLarge::T / (nblk > ctx->num_cu ? 2 : 1)), 0, st>>>(kin, n, slice, shift, xor_mask, hist_ws, (int)nblk);
         else digit_hist_kernel<GeoSmall><<<dim3((unsigned)nblk), dim3(GeoSmall::T), 0, st>>>(kin, n, slice, shift, xor_mask, hist_ws, (int)nblk);
         scan_hist_rows_kernel<<<kBins, 256, 0, st>>>(hist_in, (int)nblk, hist_ws + (size_t)kBins * nblk);
@@ -966,7 +976,7 @@ static int k_multi_hist(hark_context *ctx, const uint32_t *keys, int64_t n, uint
     bool large; int64_t nblk, slice;
     sort_geometry(n, ctx->num_cu, &large, &nblk, &slice);
     uint32_t *h4 = nullptr, *diff = nullptr;
-    HARK_TRY(hark_alloc(ctx, (void **)&h4, (size_t)4 * kBins * nblk * sizeof(uint32_t)));
+    HARK_TRY(hark_alloc(ctx, (void **)&h4, (size_t)kBins * nblk * sizeof(uint32_t)));
     int rc = hark_alloc(ctx, (void **)&diff, 16);
     if (!rc && hipMemsetAsync(diff, 0, 16, ctx->stream) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "sort: memset failed");
     if (!rc) {
