@@ -170,7 +170,21 @@ def test_c4_join_share_i64_full_size(eng):
     ok = (pos < s) & (sr[np.minimum(pos, s - 1)] == sl)
     assert np.array_equal(r2.column(0), ol[ok].astype(np.int32)) and np.array_equal(r2.column(1), orr[pos[ok]].astype(np.int32))
     r2.free()
-    for t in (tp, tb, t2):
+    # near misses: probe keys one above a build key share its truncated 32-bit word in the bucket kernel's single round
+    # (24.4 K keys per bucket here) and must be turned away by the check against the full key
+    idx = torch.randint(0, s, (m,), dtype=torch.int64, device=dev, generator=g)
+    near = bk[idx] + (torch.arange(m, device=dev) & 1)
+    t3 = eng.table_from_device(m, [near.data_ptr(), prow.data_ptr()], [np.int64, np.int32], keepalive=(near, prow))
+    r3 = eng.join(t3, tb, 0, 0, [1], [1])
+    hk = near.cpu().numpy()
+    ol = np.argsort(hk, kind="stable")
+    sl = hk[ol]
+    pos = np.searchsorted(sr, sl)
+    ok = (pos < s) & (sr[np.minimum(pos, s - 1)] == sl)
+    assert 0.45 * m < ok.sum() < 0.55 * m
+    assert np.array_equal(r3.column(0), ol[ok].astype(np.int32)) and np.array_equal(r3.column(1), orr[pos[ok]].astype(np.int32))
+    r3.free()
+    for t in (tp, tb, t2, t3):
         t.free()
 
 
