@@ -702,7 +702,8 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
     if (s_bad) {
         for (uint32_t i = tid; i < nb; i += kJThreads) {
             const uint2 e = src[i];
-            rank[dst + i] = e.x; lrow[dst + i] = e.y; if (cnt_out) cnt_out[dst + i] = runlen[e.x];   // (this path always writes the rows: the general sort needs them)
+            if (rank) { rank[dst + i] = e.x; lrow[dst + i] = e.y; }        // (the general sort needs them: the host runs the kernel again with the arrays if it left them out)
+            if (cnt_out) cnt_out[dst + i] = runlen[e.x];
             if (CARRY) lval_out[dst + i] = srcv[i];                   // (the caller drops the carried words on the general path)
             if (rranked) rval_out[dst + i] = rranked[e.x];
         }
@@ -820,7 +821,7 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
 #pragma unroll
                 for (int q = 0; q < kB; q++) {
                     if (i0 + (uint32_t)q * kJThreads < nsub) {
-                        rank[o + at[q]] = e[q].x; lrow[o + at[q]] = e[q].y;
+                        if (rank) { rank[o + at[q]] = e[q].x; lrow[o + at[q]] = e[q].y; }   // null: every result column arrives through lval_out / rval_out
                         if (cnt_out) cnt_out[o + at[q]] = rl[q];
                         if (CARRY) lval_out[o + at[q]] = v3[q];
                         if (rranked) rval_out[o + at[q]] = rv[q];
@@ -858,7 +859,8 @@ __global__ __launch_bounds__(256) void jcompact_kernel(const uint2 *__restrict__
 template <typename K>
 int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K *rkeys, int64_t s, const uint32_t *runlen,
                     int32_t *flags /* device: [0] general sort needed, [1] duplicate build keys */, const uint32_t *lval, const uint32_t *rranked,
-                    uint32_t **rank_out, uint32_t **lrow_out, uint32_t **cnt_out, uint32_t **lval_out, uint32_t **rval_out, int64_t *m_out, bool *used, bool *dup_out)
+                    uint32_t **rank_out, uint32_t **lrow_out, uint32_t **cnt_out, uint32_t **lval_out, uint32_t **rval_out, int64_t *m_out, bool *used, bool *dup_out,
+                    bool rows_needed /* false: the caller takes its result columns from lval_out / rval_out alone (unique build keys) */, int64_t *general_out)
 {
     typedef typename JTraits<K>::E E;
     constexpr int P = JTraits<K>::P, Q = JTraits<K>::Q, VEC = JTraits<K>::VEC, LINE = 128 / (int)sizeof(E);
@@ -930,14 +932,18 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
     if (!rc && (int32_t)(words[1] & 0xFFFFFFFFll) != 0) { cleanup(); return HARK_OK; }          // a slab overflowed (skew): caller falls back
     const bool dup = ((words[2] >> 32) & 0xFFFFFFFFll) != 0;
     *dup_out = dup;
+    *general_out = 0;
     if (!rc && M > 0) {
-        rc = hark_alloc(ctx, (void **)&rank, 4 * (size_t)M);
-        if (!rc) rc = hark_alloc(ctx, (void **)&lrow, 4 * (size_t)M);
+        if (dup || getenv("HARK_JOIN_FULLSORT")) rranked = nullptr;              // a survivor is an output row only when the build keys are unique
+        // (rank, left row) of the output rows are 8 of the 16 bytes the order kernel writes per row: left out when nobody
+        // reads them -- unique build keys and every result column carried (lval) or read off in rank order (rranked)
+        bool skip_rows = !rows_needed && !dup && !getenv("HARK_JOIN_FULLSORT") && (lval == nullptr || carry) && !getenv("HARK_JOIN_ROWS");
+        if (!rc && !skip_rows) rc = hark_alloc(ctx, (void **)&rank, 4 * (size_t)M);
+        if (!rc && !skip_rows) rc = hark_alloc(ctx, (void **)&lrow, 4 * (size_t)M);
         if (!rc && dup) rc = hark_alloc(ctx, (void **)&cnt, 4 * (size_t)M);     // unique build keys: every survivor has exactly one partner
         if (!rc && carry) rc = hark_alloc(ctx, (void **)&lv, 4 * (size_t)M);
-        if (dup || getenv("HARK_JOIN_FULLSORT")) rranked = nullptr;              // a survivor is an output row only when the build keys are unique
         if (!rc && rranked) rc = hark_alloc(ctx, (void **)&rv, 4 * (size_t)M);
-        if (!rc) {
+        for (int attempt = 0; attempt < 2 && !rc; attempt++) {
             if (getenv("HARK_JOIN_FULLSORT")) {                                  // A/B + tests: plain compaction, radix sorts by the caller
                 jcompact_kernel<<<dim3((unsigned)P), 256, 0, st>>>(surv, sstride, scount, P, rank, lrow);
                 hipMemsetAsync(flags, 1, 1, st);
@@ -959,6 +965,14 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
                                                                                               rank, lrow, cnt, stage_cap, flags, bins, nullptr, nullptr, nullptr, scoarse, rranked, rv, sround + (size_t)P * kMaxRounds);
             }
             if (he != hipSuccess || hipGetLastError() != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: order launch failed");
+            // does the order stand, or do the survivors need the general sort (skew)?  Read here, while the survivors are alive:
+            // an order kernel that left the rows out runs once more to deliver them
+            if (!rc) rc = hark_read_words(ctx, flags, general_out, 1);
+            *general_out &= 0xFFFFFFFFll;
+            if (rc || !(*general_out && skip_rows)) break;
+            skip_rows = false;
+            rc = hark_alloc(ctx, (void **)&rank, 4 * (size_t)M);
+            if (!rc) rc = hark_alloc(ctx, (void **)&lrow, 4 * (size_t)M);
         }
     }
     cleanup();                                                              // stream-ordered reuse: the ordering above is enqueued first
@@ -979,8 +993,11 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
 // or the general ordering path was needed: the caller gathers the column through lrow_out instead).
 // rranked (optional): a 4-byte build-side column in RANK order (column[perm[rank]]); with unique build keys *rval_out then
 // holds its value for every matching probe row (= output row), read off by the order kernel; null otherwise.
+// rows_needed = false: the caller reads neither *rank_out nor *lrow_out when the build keys turn out unique and *lval_out /
+// *rval_out deliver its columns; both then stay null (the order kernel does not write them).
 int k_join_partitioned(hark_context *ctx, const void *lcol, bool k64, int64_t n, const void *rkeys, int64_t s, const uint32_t *lval, const uint32_t *rranked,
-                       uint32_t **rank_out, uint32_t **lrow_out, uint32_t **cnt_out, uint32_t **lval_out, uint32_t **rval_out, int64_t *m_out, bool *used, bool *unique)
+                       uint32_t **rank_out, uint32_t **lrow_out, uint32_t **cnt_out, uint32_t **lval_out, uint32_t **rval_out, int64_t *m_out, bool *used, bool *unique,
+                       bool rows_needed)
 {
     *rank_out = nullptr; *lrow_out = nullptr; *cnt_out = nullptr; *lval_out = nullptr; *rval_out = nullptr; *m_out = 0; *used = false; *unique = false;
     if (getenv("HARK_JOIN_FULLSORT")) lval = nullptr;
@@ -1001,17 +1018,15 @@ int k_join_partitioned(hark_context *ctx, const void *lcol, bool k64, int64_t n,
         else jrunlen_kernel<uint32_t><<<dim3((unsigned)g1), 256, 0, ctx->stream>>>(static_cast<const uint32_t *>(rkeys), s, runlen, flag + 1);
     }
     bool dup = true;
-    rc = k64 ? run_partitioned<uint64_t>(ctx, static_cast<const uint64_t *>(lcol), 0x8000000000000000ull, n, static_cast<const uint64_t *>(rkeys), s, runlen, flag, lval, rranked, &rank, &lrow, &cnt, &lv, &rv, &M, used, &dup)
-             : run_partitioned<uint32_t>(ctx, static_cast<const uint32_t *>(lcol), 0u, n, static_cast<const uint32_t *>(rkeys), s, runlen, flag, nullptr, rranked, &rank, &lrow, &cnt, &lv, &rv, &M, used, &dup);
+    int64_t general = 0;                                       // the order kernel's verdict (read in run_partitioned, while it can still run again)
+    rc = k64 ? run_partitioned<uint64_t>(ctx, static_cast<const uint64_t *>(lcol), 0x8000000000000000ull, n, static_cast<const uint64_t *>(rkeys), s, runlen, flag, lval, rranked, &rank, &lrow, &cnt, &lv, &rv, &M, used, &dup, rows_needed, &general)
+             : run_partitioned<uint32_t>(ctx, static_cast<const uint32_t *>(lcol), 0u, n, static_cast<const uint32_t *>(rkeys), s, runlen, flag, nullptr, rranked, &rank, &lrow, &cnt, &lv, &rv, &M, used, &dup, rows_needed, &general);
     if (rc || !*used) { hark_free(ctx, flag); hark_free(ctx, runlen); return rc; }
     if (M == 0) { hark_free(ctx, rank); hark_free(ctx, lrow); hark_free(ctx, cnt); hark_free(ctx, lv); hark_free(ctx, rv); hark_free(ctx, flag); hark_free(ctx, runlen); return HARK_OK; }
     // (rank, left row) order.  Fast path: jorder_kernel delivered it.  A rank with more than kTieMax probe rows, or a
     // group of ranks too crowded for the LDS stage, takes the general path: stable radix sort by left row, then by rank
     // (each skips the passes no byte needs), partner counts looked up again.
     uint32_t *rank1 = nullptr, *lrow1 = nullptr, *lrow2 = nullptr, *rank2 = nullptr;
-    int64_t general = 0;
-    rc = hark_read_words(ctx, flag, &general, 1);
-    general &= 0xFFFFFFFFll;
     if (!rc && general) {
         hark_free(ctx, lv); lv = nullptr;                       // the radix sorts carry one payload: the columns are gathered by the caller instead
         hark_free(ctx, rv); rv = nullptr;

@@ -30,7 +30,8 @@ int k_sort_column(hark_context *ctx, const void *col, int dtype, int64_t n, bool
 int k_exclusive_scan_u32(hark_context *ctx, const uint32_t *in, int64_t n, uint32_t *out32, int64_t *out64, int64_t *total_host);
 // k_hjoin.hip: the partitioned path (probe side range-partitioned by splitters of the sorted build side, build slices in LDS)
 int k_join_partitioned(hark_context *ctx, const void *lcol, bool k64, int64_t n, const void *rkeys, int64_t s, const uint32_t *lval, const uint32_t *rranked,
-                       uint32_t **rank_out, uint32_t **lrow_out, uint32_t **cnt_out, uint32_t **lval_out, uint32_t **rval_out, int64_t *m_out, bool *used, bool *unique);
+                       uint32_t **rank_out, uint32_t **lrow_out, uint32_t **cnt_out, uint32_t **lval_out, uint32_t **rval_out, int64_t *m_out, bool *used, bool *unique,
+                       bool rows_needed);
 
 namespace {
 
@@ -310,12 +311,18 @@ int hark_entry_join(hark_context *ctx, hark_result **out, const hark_table *db1,
         rc = hark_alloc(ctx, (void **)&rranked, (size_t)s * 4);
         if (!rc) rc = k_gather(ctx, db2->cols[rank_col].data, 4, rperm, rranked, s);
     }
+    // does any result column need the pairs' row ids or ranks?  Not when the carried probe-side column and the rank-ordered
+    // build-side column are all that is selected (BASELINE configs[3]: the two row-id columns) -- with unique build keys the
+    // order kernel then writes those two columns and nothing else
+    bool rows_needed = false;
+    for (int64_t j = 0; j < l; j++) rows_needed = rows_needed || cols1[j] != carry_col;
+    for (int64_t j = 0; j < k; j++) rows_needed = rows_needed || cols2[j] != rank_col;
     if (!rc) {
         uint32_t *prank = nullptr, *plrow = nullptr, *pcnt = nullptr;
         int64_t M = 0;
         rc = k_join_partitioned(ctx, lcol, k64, n, k64 ? static_cast<const void *>(rk64) : static_cast<const void *>(rkeys), s,
                                 carry_col >= 0 ? static_cast<const uint32_t *>(db1->cols[carry_col].data) : nullptr, rranked,
-                                &prank, &plrow, &pcnt, &sval, &rval, &M, &partitioned, &unique);
+                                &prank, &plrow, &pcnt, &sval, &rval, &M, &partitioned, &unique, rows_needed);
         if (!rc && partitioned) {
             nl = M;
             lb = prank; lperm = plrow; cnt = pcnt;                 // freed with the other scratch below

@@ -180,6 +180,29 @@ def test_skewed_probe_falls_back_and_stays_exact(eng):
     assert _check(eng, lk, rk) >= n
 
 
+@pytest.mark.parametrize("hot", [0, 40, 500])
+def test_i64_join_of_carried_columns_only(eng, hot):
+    """Unique i64 build keys and only the carried probe-side column and the rank-ordered build-side column selected: the
+    order kernel writes those two columns and leaves (rank, left row) out.  With a hot key (more probe rows of one key
+    than the kernel orders in place: 64) its verdict is "general sort" and it runs once more to deliver the rows."""
+    rng = np.random.default_rng(33 + hot)
+    n, s = 400_003, 50_000
+    rk = np.unique(rng.integers(-2**63, 2**63 - 1, size=s + 64))[:s]
+    rk = rk[rng.permutation(s)]
+    lk = rng.integers(-2**63, 2**63 - 1, size=n)
+    hit = rng.random(n) < 0.5
+    lk[hit] = rk[rng.integers(0, s, size=int(hit.sum()))]
+    if hot:
+        lk[rng.choice(n, size=hot, replace=False)] = rk[123]
+    la, ra = rng.integers(-2**31, 2**31, n).astype(np.int32), rng.integers(0, 2**31, s).astype(np.int32)
+    t1, t2 = eng.table_from_columns([lk, la]), eng.table_from_columns([rk, ra])
+    res = eng.join(t1, t2, 0, 0, [1], [1])
+    li, ri = _np_join_rows(lk, rk)
+    assert res.shape == (len(li), 2)
+    assert np.array_equal(res.column(0), la[li]) and np.array_equal(res.column(1), ra[ri])
+    res.free(); t1.free(); t2.free()
+
+
 _ROUNDS = r"""
 import sys
 import numpy as np

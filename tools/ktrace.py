@@ -18,3 +18,9 @@ span = (int(rows[-1]["End_Timestamp"]) - int(rows[0]["Start_Timestamp"])) / 1e3 
 for n, (c, t) in sorted(acc.items(), key=lambda x: -x[1][1]):
     print(f"{t:9.1f} us  x{c:<3d} {n}")
 print(f"{sum(t for _, t in acc.values()):9.1f} us  busy of {span:.1f} us span, {len(rows)} dispatches")
+if len(sys.argv) > 3 and sys.argv[3] == "seq":      # the dispatches in order: start offset + duration
+    t0 = int(rows[0]["Start_Timestamp"])
+    for r in rows:
+        n = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+        n = n[:n.index("(")] if "(" in n else n
+        print(f"{(int(r['Start_Timestamp']) - t0) / 1e3:9.1f} us + {(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:7.1f} us  {n[:70]}")
