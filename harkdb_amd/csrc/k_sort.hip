@@ -843,13 +843,15 @@ __global__ __launch_bounds__(256) void tuple_fix_runs_kernel(const uint4 *__rest
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     auto hi_of = [&](int64_t j) { return reinterpret_cast<const uint32_t *>(tin + j)[1] & prefix_mask; };
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        // the tuple and its two neighbours' prefixes in one round trip; more than half of the tuples are alone in their run
         const uint4 t = ld_nt16(tin + i);
+        const uint32_t hp = i > 0 ? hi_of(i - 1) : 0u, hn = i + 1 < n ? hi_of(i + 1) : 0u;
         const uint32_t h = t.y & prefix_mask;
-        int64_t a = i, b = i + 1;
-        while (a > 0 && i - a <= kRunMax && hi_of(a - 1) == h) a--;
-        while (b < n && b - a <= kRunMax && hi_of(b) == h) b++;
-        if (b - a > kRunMax) { *too_long = 1; continue; }
         const uint64_t key = ((uint64_t)t.y << 32) | t.x;
+        int64_t a = i, b = i + 1;
+        if (i > 0 && hp == h) { a--; while (a > 0 && i - a <= kRunMax && hi_of(a - 1) == h) a--; }
+        if (i + 1 < n && hn == h) { b++; while (b < n && b - a <= kRunMax && hi_of(b) == h) b++; }
+        if (b - a > kRunMax) { *too_long = 1; continue; }
         int64_t at = a;
         for (int64_t j = a; j < b; j++) {
             if (j == i) continue;
@@ -1153,7 +1155,7 @@ static int sort_i64_tuples(hark_context *ctx, const void *col, int64_t n, uint32
     int64_t general = 0;
     if (he == hipSuccess) he = hipMemsetAsync(flag, 0, 16, st);
     if (he == hipSuccess) {
-        tuple_fix_runs_kernel<<<dim3((unsigned)grid256(ctx, n)), dim3(256), 0, st>>>(tin, keys, perm, val, n, flag, prefix_mask);
+        tuple_fix_runs_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(tin, keys, perm, val, n, flag, prefix_mask);
         he = hipGetLastError();
     }
     if (he != hipSuccess) { cleanup(false); return hark_fail(ctx, HARK_EHIP, "sort: tuple pass failed: %s", hipGetErrorString(he)); }
