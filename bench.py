@@ -354,7 +354,7 @@ def extra_configs(torch, eng, dev, a, p, k, v, N):
 
     ms = event_ms(torch, gd, warm=2, reps=5)
     out["REF_query_groupby_dense"] = entry(ms, 12.0 * n8, n8, groups=int(shape[0][0]), statement="query_groupby(db, 0, [1, 1], [sum, max]) (main.fut:9), 2^20 dense keys",
-                                           note="one pair pass (sum + max of one column)")
+                                           note="one statistics pass (sum + max of ONE column: the column is carried once)")
 
     def ob():
         r = eng.sort(tu, 0, [0, 1])

@@ -139,6 +139,7 @@ int k_fgb_dense_stats(hark_context *ctx, hark_fgb_plan *pl, const float *p, int 
                       const int32_t *k, const void *v, int64_t n, int vk, bool *ran);
 int hark_fgb_finish_typed_from(hark_context *ctx, hark_fgb_plan *pl, int32_t which, int32_t kind, const uint32_t *pos, void *out);
 int hark_fgb_finish_u32_second(hark_context *ctx, hark_fgb_plan *pl, uint32_t *val_out);
+int hark_fgb_finish_u32_of(hark_context *ctx, hark_fgb_plan *pl, int which, uint32_t *val_out);
 int k_fgb_dense_pair(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cmp, float thr, const int32_t *k,
                      const void *v1, int vop1, int xf1, const void *v2, int vop2, int xf2, int64_t n, bool *ran);
 int k_fgb_decode(hark_context *ctx, const unsigned long long *acc, const unsigned long long *cnt, int64_t G, int kind, void *out);

@@ -1894,6 +1894,19 @@ int hark_fgb_finish_u32(hark_context *ctx, hark_fgb_plan *pl, uint32_t *val_out,
     return fgb_check_err(ctx, pl);
 }
 
+// the low words of one of the plan's accumulators after a statistics pass (which: 0 sums, 1 minima, 2 maxima), groups in table order
+int hark_fgb_finish_u32_of(hark_context *ctx, hark_fgb_plan *pl, int which, uint32_t *val_out)
+{
+    hark_device_guard guard__(ctx);
+    const u64 *acc = !pl ? nullptr : which == 0 ? reinterpret_cast<const u64 *>(pl->acc_sum) : which == 1 ? pl->acc_min : pl->acc_max;
+    if (!ctx || !pl || !val_out || !acc) return HARK_EARG;
+    int64_t blocks = (pl->G + 255) / 256;
+    if (blocks > (int64_t)ctx->num_cu * 4) blocks = (int64_t)ctx->num_cu * 4;
+    fgb_finish_u32_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(acc, pl->acc_cnt, pl->G, val_out, nullptr);
+    HIP_TRY(ctx, hipGetLastError());
+    return HARK_OK;
+}
+
 // the low words of the plan's SECOND accumulator (acc_min: value 2 of a pair pass), groups in table order
 int hark_fgb_finish_u32_second(hark_context *ctx, hark_fgb_plan *pl, uint32_t *val_out)
 {

@@ -1134,6 +1134,28 @@ int ref_groupby_dense(hark_context *ctx, const hark_table *view, const hark_tabl
     const size_t runs = aggs.empty() ? 1 : aggs.size();                 // no aggregate: one pass just for the counts
     auto vop_of = [&](size_t j) { return aggs[j].op == OP_SUM ? 1 : aggs[j].op == OP_MAX ? 2 : aggs[j].op == OP_MIN ? 3 : 4; };
     std::vector<char> served(runs, 0);
+    // statistics pass (k_fgb_dense_stats): two or more of {sum, max, min} of ONE column from one producer + consumer pass
+    // that carries the column once (6-byte pairs; the 64-bit sum's low word is the reference's sum mod 2^32, groupby.fut:37).
+    // Declines for small G, > 4096 keys per bucket or skew; the passes below then take over.
+    for (size_t j = 0; j < aggs.size() && !rc; j++) {
+        if (served[j] || vop_of(j) == 4) continue;
+        int classes = 0;
+        for (size_t t = 0; t < aggs.size(); t++) if (!served[t] && aggs[t].col == aggs[j].col && vop_of(t) != 4) classes |= 1 << vop_of(t);
+        if (__builtin_popcount(classes) < 2) continue;
+        bool ran = false;
+        rc = hark_fgb_plan_set(plan, "vop", 0);
+        if (!rc) rc = hark_fgb_plan_set(plan, "xform", 0);
+        if (!rc) rc = k_fgb_dense_stats(ctx, plan, nullptr, 0, 0.0f, reinterpret_cast<const int32_t *>(keys), view->cols[aggs[j].col].data, n, 2, &ran);
+        if (rc || !ran) break;
+        int64_t blocks = (G + 255) / 256;
+        if (blocks > (int64_t)ctx->num_cu * 4) blocks = (int64_t)ctx->num_cu * 4;
+        for (size_t t = 0; t < aggs.size() && !rc; t++) {
+            if (served[t] || aggs[t].col != aggs[j].col || vop_of(t) == 4) continue;
+            rc = hark_alloc(ctx, (void **)&vals[t], (size_t)G * 4);
+            if (!rc) rc = hark_fgb_finish_u32_of(ctx, plan, vop_of(t) == 1 ? 0 : vop_of(t) == 2 ? 2 : 1, vals[t]);
+            served[t] = 1;
+        }
+    }
     // pair passes (k_fgb_dense_pair): a sum / max / min with another max / min from ONE producer + consumer pass; value 2
     // must be a max or min (a 32-bit LDS slot), products keep their own pass.  Declines for small G or skew.
     for (size_t j = 0; j < aggs.size() && !rc; j++) {

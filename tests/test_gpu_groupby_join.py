@@ -53,6 +53,22 @@ def test_query_groupby_dense_keys_fused_path(eng, oracle, n, G):
     assert np.array_equal(eng.query_groupby(t, 0, [], []).to_numpy(np.uint32), exp[:, :1])   # key column only
 
 
+@pytest.mark.parametrize("n,G", [(300_000, 1 << 17), (1_200_000, 1 << 20), (500_000, 20_000), (400_000, 3000)])
+def test_query_groupby_several_aggregates_of_one_column(eng, oracle, n, G):
+    """sum, max and min of ONE column come from one statistics pass that carries the column once (the 64-bit sum's low word
+    is the reference's sum mod 2^32); a product and another column's aggregates keep their own passes.  Small G or few
+    keys per bucket decline the pass -- the same table either way."""
+    rng = np.random.default_rng(n % 977 + G)
+    db = rng.integers(0, 2**32, size=(n, 4), dtype=np.uint64).astype(np.uint32)
+    db[:, 0] = rng.integers(0, G, size=n)
+    db[:, 3] = rng.integers(0, 4, size=n) * 2 + 1
+    s_cols, t_cols = [1, 1, 1, 3, 2, 2, 1], [2, 3, 4, 1, 4, 3, 2]     # sum, max, min of col 1; prod of col 3; min, max of col 2; sum of col 1 again
+    t = eng.table_from_matrix(db, np.uint32)
+    got = eng.query_groupby(t, 0, s_cols, t_cols).to_numpy(np.uint32)
+    exp = oracle.query_groupby(db, 0, s_cols, t_cols)
+    assert got.shape == exp.shape and np.array_equal(got, exp)
+
+
 @pytest.mark.parametrize("n,ndistinct", [(400_000, 1000), (2_000_000, 500_000), (3_000_000, 3_000_000), (600_000, 3)])
 def test_query_groupby_sparse_keys_hash_path(eng, oracle, n, ndistinct):
     """Sparse u32 keys (anywhere in [0, 2^32)) with >= 2^18 rows: hash partition + LDS hash
