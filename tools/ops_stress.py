@@ -71,10 +71,13 @@ def case_join():
     if int((cl[il].astype(np.int64) * cr[ir]).sum()) > 30_000_000:          # a near cross product: not a useful case
         return True, dict(op="join-skip")
     t1, t2 = eng.table_from_columns([lk, la]), eng.table_from_columns([rb, rk])
-    res = eng.join(t1, t2, 0, 1, [1], [0])
+    # which columns: only the carried / rank-ordered ones (no row ids, no permutation needed), or keys and repeats as well
+    c1, c2 = [([1], [0]), ([0, 1], [0, 1]), ([1, 1, 0], [1, 0, 0])][int(rng.integers(0, 3))]
+    res = eng.join(t1, t2, 0, 1, c1, c2)
     cmp_l, cmp_r = (lk, rk) if wide else (lk.astype(np.uint32), rk.astype(np.uint32))
     li, ri = join_rows(cmp_l, cmp_r)
-    ok = res.shape[0] == len(li) and (len(li) == 0 or (np.array_equal(res.column(0), la[li]) and np.array_equal(res.column(1), rb[ri])))
+    exp = [(lk, la)[c][li] for c in c1] + [(rb, rk)[c][ri] for c in c2]
+    ok = res.shape[0] == len(li) and (len(li) == 0 or all(np.array_equal(res.column(j), e) for j, e in enumerate(exp)))
     res.free(); t1.free(); t2.free()
     return ok, dict(op="join", n=n, s=s, wide=wide, nd=nd)
 
