@@ -1107,6 +1107,7 @@ static int sort_i64_tuples(hark_context *ctx, const void *col, int64_t n, uint32
                            uint64_t *keys, uint32_t **perm_out, uint32_t **val_out, bool *done)
 {
     *done = false;
+    if (n > 0xFFFFFFFFll) return HARK_OK;                          // 32-bit positions and row ids (the general path reports the limit)
     hipStream_t st = ctx->stream;
     // Up to 2^24 keys are only sorted by the top 24 bits of their high words (three passes instead of four): keys spread
     // over 64 bits then share a prefix with 0.75 others on average, and the run fix-up orders whole keys anyway.
