@@ -131,9 +131,14 @@ int hark_fgb_finish_typed(hark_context *ctx, hark_fgb_plan *pl, int32_t kind, co
 int k_fgb_dense_f32(hark_context *ctx, hark_fgb_plan *plan, const float *p, int cmp, float thr,
                     const int32_t *k, const float *v, int64_t n);
 
+// The hash partition of a (key column, value column) pair, kept between aggregates of the SAME value column (the pairs
+// the producer writes do not depend on the operator): zero-initialise, pass to every k_fgb_hash_u32 call, release with
+// k_fgb_hash_part_free.
+struct hark_hash_part { void *pbuf = nullptr; uint32_t *counts = nullptr; int64_t cap = 0, n = 0; const void *k = nullptr, *v = nullptr; int xf = 0; };
+void k_fgb_hash_part_free(hark_context *ctx, hark_hash_part *part);
 int k_fgb_hash_u32(hark_context *ctx, const uint32_t *k, const uint32_t *v, int64_t n, int vop, int xf,
                    uint32_t **keys_out, unsigned long long **vals_out, unsigned long long **cnts_out, int64_t *G_out, bool *fits,
-                   uint32_t *rounds_hint, bool compact);
+                   uint32_t *rounds_hint, bool compact, hark_hash_part *part = nullptr);
 
 int k_fgb_dense_stats(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cmp, float thr,
                       const int32_t *k, const void *v, int64_t n, int vk, bool *ran);

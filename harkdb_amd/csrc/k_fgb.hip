@@ -2129,7 +2129,8 @@ int hark_fgb_finish_typed_from(hark_context *ctx, hark_fgb_plan *pl, int32_t whi
 int k_fgb_hash_u32(hark_context *ctx, const uint32_t *k, const uint32_t *v, int64_t n, int vop, int xf,
                    uint32_t **keys_out, unsigned long long **vals_out, unsigned long long **cnts_out, int64_t *G_out, bool *fits,
                    uint32_t *rounds_hint /* in: 0 or the R a previous pass over the SAME key column needed; out: the R used */,
-                   bool compact /* u32 operators without row counts: 8-byte entries (fgb_agg_hash8_kernel); *cnts_out stays null */)
+                   bool compact /* u32 operators without row counts: 8-byte entries (fgb_agg_hash8_kernel); *cnts_out stays null */,
+                   hark_hash_part *part /* optional: the partition of (k, v) is kept in it / taken from it (see hark_internal.h) */)
 {
     if (compact && !(vop == VOP_U32SUM || vop == VOP_U32MAX || vop == VOP_U32MIN || vop == VOP_U32PROD)) compact = false;
     const int fill = compact ? kHash8Fill : kHashFill;
@@ -2143,8 +2144,14 @@ int k_fgb_hash_u32(hark_context *ctx, const uint32_t *k, const uint32_t *v, int6
     uint2 *pbuf = nullptr; uint32_t *counts = nullptr; int32_t *err = nullptr; unsigned long long *cursor = nullptr;
     uint32_t *okey = nullptr; u64 *oval = nullptr, *ocnt = nullptr;
     hipStream_t st = ctx->stream;
-    int rc = hark_alloc(ctx, (void **)&pbuf, (size_t)P * nwg * (size_t)cap * sizeof(uint2));
-    if (!rc) rc = hark_alloc(ctx, (void **)&counts, (size_t)P * nwg * sizeof(uint32_t));
+    const bool reuse = part && part->pbuf && part->k == k && part->v == v && part->n == n && part->xf == xf && part->cap == cap;
+    if (part && part->pbuf && !reuse) k_fgb_hash_part_free(ctx, part);
+    int rc = HARK_OK;
+    if (reuse) { pbuf = static_cast<uint2 *>(part->pbuf); counts = part->counts; }
+    else {
+        rc = hark_alloc(ctx, (void **)&pbuf, (size_t)P * nwg * (size_t)cap * sizeof(uint2));
+        if (!rc) rc = hark_alloc(ctx, (void **)&counts, (size_t)P * nwg * sizeof(uint32_t));
+    }
     if (!rc) rc = hark_alloc(ctx, (void **)&err, 16);
     if (!rc) rc = hark_alloc(ctx, (void **)&cursor, 16);
     auto read_err = [&](int32_t *e) -> int {
@@ -2155,7 +2162,8 @@ int k_fgb_hash_u32(hark_context *ctx, const uint32_t *k, const uint32_t *v, int6
     };
     int32_t e = 0;
     uint32_t used_R = 1;
-    if (!rc) {
+    if (!rc && reuse) hipMemsetAsync(err, 0, 16, st);
+    if (!rc && !reuse) {
         hipMemsetAsync(err, 0, 16, st);
         const size_t lds_part = part_lds_bytes(P, 0);
         rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_part_kernel<kNoPred, 2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part) == hipSuccess
@@ -2229,9 +2237,22 @@ int k_fgb_hash_u32(hark_context *ctx, const uint32_t *k, const uint32_t *v, int6
         if (!rc) { *keys_out = okey; *vals_out = oval; *cnts_out = ocnt; *G_out = G; *fits = true; okey = nullptr; oval = nullptr; ocnt = nullptr; }
         if (!rc && rounds_hint) *rounds_hint = used_R;
     }
-    hark_free(ctx, pbuf); hark_free(ctx, counts); hark_free(ctx, err); hark_free(ctx, cursor);
+    if (part && !rc && (reuse || e == 0)) {                        // a good partition stays with the caller
+        part->pbuf = pbuf; part->counts = counts; part->cap = cap; part->n = n; part->k = k; part->v = v; part->xf = xf;
+    } else {
+        if (part) { part->pbuf = nullptr; part->counts = nullptr; }
+        hark_free(ctx, pbuf); hark_free(ctx, counts);
+    }
+    hark_free(ctx, err); hark_free(ctx, cursor);
     hark_free(ctx, okey); hark_free(ctx, oval); hark_free(ctx, ocnt);
     return rc;
+}
+
+void k_fgb_hash_part_free(hark_context *ctx, hark_hash_part *part)
+{
+    if (!part) return;
+    hark_free(ctx, part->pbuf); hark_free(ctx, part->counts);
+    part->pbuf = nullptr; part->counts = nullptr;
 }
 
 // Typed read-out (fgb_decode_kernel kinds) of plain accumulator arrays, e.g. the sorted output of k_fgb_hash_u32.

@@ -1238,12 +1238,13 @@ int ref_groupby_hash(hark_context *ctx, const hark_table *view, int g_col, const
     int rc = HARK_OK;
     bool ok = true;
     uint32_t rounds = 0;                                     // table rounds the key column needs: found by the first pass, reused
+    hark_hash_part part;                                     // aggregates of one column after another share the (key, value) partition
     for (size_t j = 0; j < runs && !rc && ok; j++) {
         const int vop = aggs.empty() ? 3 : aggs[j].op == OP_SUM ? 1 : aggs[j].op == OP_MAX ? 2 : aggs[j].op == OP_MIN ? 3 : 4;
         const uint32_t *col = aggs.empty() ? keys : static_cast<const uint32_t *>(view->cols[aggs[j].col].data);
         uint32_t *hk = nullptr, *perm = nullptr; unsigned long long *hv = nullptr, *hc = nullptr;
         int64_t Gj = 0;
-        rc = k_fgb_hash_u32(ctx, keys, col, n, vop, 0, &hk, &hv, &hc, &Gj, &ok, &rounds, true);   // u32 operators, no counts: 8-byte table entries
+        rc = k_fgb_hash_u32(ctx, keys, col, n, vop, 0, &hk, &hv, &hc, &Gj, &ok, &rounds, true, &part);   // u32 operators, no counts: 8-byte table entries
         if (!rc && ok) {
             if (G < 0) {
                 G = Gj;
@@ -1261,6 +1262,7 @@ int ref_groupby_hash(hark_context *ctx, const hark_table *view, int g_col, const
         }
         hark_free(ctx, hk); hark_free(ctx, hv); hark_free(ctx, hc); hark_free(ctx, perm);
     }
+    k_fgb_hash_part_free(ctx, &part);
     if (!rc && ok && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "query_groupby: kernels failed");
     if (rc || !ok) {
         for (auto &c : res->cols) if (c.owned && c.data) hark_free(ctx, c.data);
