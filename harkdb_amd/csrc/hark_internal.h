@@ -56,6 +56,9 @@ struct hark_column {
     // column statistic, filled on first use (tables are immutable): value range of a 32-bit integer column
     mutable bool has_range[2] = {false, false};            // [0] read as unsigned, [1] read as signed
     mutable int64_t range_min[2] = {0, 0}, range_max[2] = {0, 0};
+    // ... and what the hash group-by learnt about it as a KEY column: 0 nothing yet, > 0 the table rounds its distinct keys
+    // need, < 0 too many distinct keys for the LDS tables (the sort-based path is taken without another attempt)
+    mutable int32_t hash_rounds = 0;
 };
 
 struct hark_table {

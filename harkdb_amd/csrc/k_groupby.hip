@@ -297,7 +297,7 @@ int kind_of(int dtype) { return dtype == HARK_F32 ? ACC_F64 : dtype == HARK_U32 
 int ref_groupby_dense(hark_context *ctx, const hark_table *view, const hark_table *stats_owner, int g_col,
                       const std::vector<AggSpec> &aggs, hark_result *res, int64_t *G_out, bool *used);
 
-int ref_groupby_hash(hark_context *ctx, const hark_table *view, int g_col, const std::vector<AggSpec> &aggs,
+int ref_groupby_hash(hark_context *ctx, const hark_table *view, const hark_table *stats_owner, int g_col, const std::vector<AggSpec> &aggs,
                      hark_result *res, int64_t *G_out, bool *used);
 
 } // namespace
@@ -337,7 +337,7 @@ int hark_entry_query_groupby(hark_context *ctx, hark_result **out, const hark_ta
     int64_t G = 0;
     bool dense = false;
     int rc = ref_groupby_dense(ctx, &view, db, g_col, aggs, res, &G, &dense);   // keys < 2^21: fused kernels, no sort
-    if (!rc && !dense) rc = ref_groupby_hash(ctx, &view, g_col, aggs, res, &G, &dense);   // sparse keys: LDS hash buckets
+    if (!rc && !dense) rc = ref_groupby_hash(ctx, &view, db, g_col, aggs, res, &G, &dense);   // sparse keys: LDS hash buckets
     if (!rc && !dense) rc = grouped_aggregate(ctx, &view, g_col, HARK_U32, aggs, res, &G);  // last resort: sort-based
     if (!rc && nt < ns && G < db->n)                    // some group has two rows: merge indexes t_cols[i-1] out of bounds
         rc = hark_fail(ctx, HARK_EBOUNDS, "query_groupby: %lld aggregate opcodes for %lld select columns", (long long)nt, (long long)ns);
@@ -1226,18 +1226,22 @@ __global__ __launch_bounds__(256) void gather_low32_kernel(const unsigned long l
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = (uint32_t)vals[perm[i]];
 }
 
-int ref_groupby_hash(hark_context *ctx, const hark_table *view, int g_col, const std::vector<AggSpec> &aggs,
+int ref_groupby_hash(hark_context *ctx, const hark_table *view, const hark_table *stats_owner, int g_col, const std::vector<AggSpec> &aggs,
                      hark_result *res, int64_t *G_out, bool *used)
 {
     *used = false;
     const int64_t n = view->n;
     if (n < kHashMinRows) return HARK_OK;
+    // what an earlier call learnt about this key column (tables are immutable): too many distinct keys -> no second attempt
+    // (a failed one costs a partition pass and a sample round: 1.1 ms per 1e8 rows); the rounds it needs -> no failed first round
+    const hark_column &kc = stats_owner->cols[g_col];
+    if (kc.hash_rounds < 0) return HARK_OK;
     const uint32_t *keys = static_cast<const uint32_t *>(view->cols[g_col].data);
     const size_t runs = aggs.empty() ? 1 : aggs.size();
     int64_t G = -1;
     int rc = HARK_OK;
     bool ok = true;
-    uint32_t rounds = 0;                                     // table rounds the key column needs: found by the first pass, reused
+    uint32_t rounds = kc.hash_rounds > 0 ? (uint32_t)kc.hash_rounds : 0u;   // table rounds the key column needs: found by the first pass, reused
     hark_hash_part part;                                     // aggregates of one column after another share the (key, value) partition
     for (size_t j = 0; j < runs && !rc && ok; j++) {
         const int vop = aggs.empty() ? 3 : aggs[j].op == OP_SUM ? 1 : aggs[j].op == OP_MAX ? 2 : aggs[j].op == OP_MIN ? 3 : 4;
@@ -1263,6 +1267,7 @@ int ref_groupby_hash(hark_context *ctx, const hark_table *view, int g_col, const
         hark_free(ctx, hk); hark_free(ctx, hv); hark_free(ctx, hc); hark_free(ctx, perm);
     }
     k_fgb_hash_part_free(ctx, &part);
+    if (!rc) kc.hash_rounds = ok ? (int32_t)rounds : -1;
     if (!rc && ok && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "query_groupby: kernels failed");
     if (rc || !ok) {
         for (auto &c : res->cols) if (c.owned && c.data) hark_free(ctx, c.data);
