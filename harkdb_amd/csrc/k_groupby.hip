@@ -186,6 +186,149 @@ __global__ __launch_bounds__(256) void seg_reduce_kernel(const void *__restrict_
     }
 }
 
+// ---- the reference's u32 tail in two passes -----------------------------------------------------------------
+// mk_flags -> scan -> tail scatter -> one segmented reduction per aggregate (groupby.fut:26-58) read the sorted rows six
+// times and keep 64-bit accumulators for 32-bit results.  Over sorted u32 keys with u32 operators (sum / prod mod 2^32, max,
+// min: associative and commutative, so the fold order does not show) two passes do: (1) run heads per tile of kSegTile rows,
+// scanned into tile offsets; (2) every tile recomputes its heads, numbers its runs from its offset, emits the keys and reduces
+// EVERY aggregate in one sweep with a wave-level segmented scan -- a run that lies inside one wave is stored plainly, one
+// that crosses a wave boundary goes through a 32-bit atomic on the result (pre-filled with the operator's identity).
+constexpr int kSegTile = 2048, kSegMaxAggs = 8;
+struct SegAggs {
+    const uint32_t *col[kSegMaxAggs];           // the aggregate's column: in sorted order (carried) or in table order (gathered through perm)
+    uint32_t *out[kSegMaxAggs];                 // [G], pre-filled with the identity
+    int32_t op[kSegMaxAggs];
+    int32_t gathered[kSegMaxAggs];
+    int32_t n;
+};
+
+__device__ __forceinline__ bool seg_is_head(const uint32_t *__restrict__ keys, int64_t i) { return i == 0 || keys[i] != keys[i - 1]; }
+
+// the tile's keys (row j * 256 + thread of the tile in key[j]; rows past the end repeat the last key and are not heads) and
+// which of them start a run: the key before comes from the neighbouring lane, lane 0 reads it
+constexpr int kSegSteps = kSegTile / 256;
+__device__ __forceinline__ uint32_t seg_tile_heads(const uint32_t *__restrict__ keys, int64_t n, int64_t base, uint32_t (&key)[kSegSteps])
+{
+    const int lane = threadIdx.x & 63;
+    uint32_t before[kSegSteps];
+#pragma unroll
+    for (int j = 0; j < kSegSteps; j++) {
+        const int64_t i = base + j * 256 + threadIdx.x;
+        key[j] = keys[i < n ? i : n - 1];
+        before[j] = keys[lane == 0 && i > 0 && i < n ? i - 1 : 0];      // (one line per wave; other lanes read keys[0] and drop it)
+    }
+    uint32_t heads = 0;
+#pragma unroll
+    for (int j = 0; j < kSegSteps; j++) {
+        const int64_t i = base + j * 256 + threadIdx.x;
+        const uint32_t up = __shfl_up(key[j], 1, 64);
+        const uint32_t prev = lane == 0 ? before[j] : up;
+        if (i < n && (i == 0 || prev != key[j])) heads |= 1u << j;
+    }
+    return heads;
+}
+
+__global__ __launch_bounds__(256) void seg_count_kernel(const uint32_t *__restrict__ keys, int64_t n, uint32_t *__restrict__ counts)
+{
+    __shared__ uint32_t s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0u;
+    __syncthreads();
+    uint32_t key[kSegSteps];
+    uint32_t c = (uint32_t)__popc(seg_tile_heads(keys, n, (int64_t)blockIdx.x * kSegTile, key));
+    for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&s_cnt, c);
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = s_cnt;
+}
+
+__device__ __forceinline__ uint32_t u32_combine(int op, uint32_t a, uint32_t b)
+{
+    return op == OP_SUM ? a + b : op == OP_PROD ? a * b : op == OP_MAX ? (a > b ? a : b) : (a < b ? a : b);
+}
+
+__device__ __forceinline__ void u32_atomic_combine(int op, uint32_t *dst, uint32_t x)
+{
+    if (op == OP_SUM) atomicAdd(dst, x);
+    else if (op == OP_MAX) atomicMax(dst, x);
+    else if (op == OP_MIN) atomicMin(dst, x);
+    else { uint32_t old = *dst, assumed; do { assumed = old; old = atomicCAS(dst, assumed, assumed * x); } while (old != assumed); }
+}
+
+__global__ __launch_bounds__(256) void seg_fused_u32_kernel(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ perm, int64_t n,
+                                                            const int64_t *__restrict__ offsets, uint32_t *__restrict__ out_keys, SegAggs aggs)
+{
+    __shared__ uint32_t s_w[kSegSteps][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t base = (int64_t)blockIdx.x * kSegTile;
+    // every load of the tile goes out before anything waits: keys, then the rows' ids / the carried column
+    uint32_t key[kSegSteps], rowv[kSegSteps];
+    const uint32_t heads = seg_tile_heads(keys, n, base, key);
+    const uint32_t *first = perm ? perm : aggs.col[0];                      // perm: row ids; else: the (one) carried column in sorted order
+#pragma unroll
+    for (int j = 0; j < kSegSteps; j++) { const int64_t i = base + j * 256 + threadIdx.x; rowv[j] = aggs.n || perm ? first[i < n ? i : n - 1] : 0u; }
+    uint32_t after[kSegSteps];                                               // lane 63: the key of the next wave's first row (does my run go on there?)
+#pragma unroll
+    for (int j = 0; j < kSegSteps; j++) { const int64_t i = base + j * 256 + threadIdx.x; after[j] = keys[lane == 63 && i + 1 < n ? i + 1 : 0]; }
+    uint32_t incl[kSegSteps];
+#pragma unroll
+    for (int j = 0; j < kSegSteps; j++) {
+        const uint64_t hb = __ballot((heads >> j) & 1u);
+        incl[j] = (uint32_t)__popcll(hb & ((2ull << lane) - 1ull));
+        if (lane == 0) s_w[j][wave] = (uint32_t)__popcll(hb);
+    }
+    __syncthreads();
+    uint32_t run_base = (uint32_t)offsets[blockIdx.x];                      // run heads before this tile (= the number of the tile's first head)
+#pragma unroll
+    for (int j = 0; j < kSegSteps; j++) {
+        const int64_t i = base + j * 256 + threadIdx.x;
+        const bool valid = i < n, head = (heads >> j) & 1u;
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) { const uint32_t x = s_w[j][w]; if (w < wave) before += x; total += x; }
+        const uint32_t s = valid ? run_base + before + incl[j] - 1u : 0xFFFFFFFFu;     // the row's run: heads up to and including it, minus one
+        run_base += total;
+        if (head) out_keys[s] = key[j];
+        if (__ballot(valid) == 0ull) continue;
+        // the run's extent inside the wave: a run that starts and ends here is complete (the run numbers ascend)
+        const uint32_t sn = __shfl_down(s, 1, 64), sp = __shfl_up(s, 1, 64);
+        const bool last_of_run_here = valid && (lane == 63 || sn != s);
+        // lane 63: does the run go on in the next wave?  The next wave's first row is row i + 1: not a head <=> same key
+        const bool next_row_same = lane == 63 && i + 1 < n && after[j] == key[j];
+        const uint64_t starts = __ballot(lane == 0 || sp != s);
+        const uint64_t upto = lane == 63 ? starts : (starts & ((2ull << lane) - 1ull));
+        const int run_start = 63 - __clzll((long long)upto);
+        const bool lane0_is_head = __shfl((int)head, 0, 64) != 0;
+        const bool complete = last_of_run_here && (run_start > 0 || lane0_is_head) && !next_row_same;
+        // which scan steps join anything at all (bit d of `joins`: this lane takes the value 2^d lanes below; a step no lane
+        // joins in is skipped by the whole wave -- with mostly distinct keys that is every step)
+        uint32_t joins = 0, any = 0;
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            const uint32_t below = __shfl_up(s, 1 << q, 64);           // (every lane takes part: a lane that sat out would hand on nothing)
+            const bool jn = lane >= (1 << q) && below == s;
+            joins |= jn ? 1u << q : 0u;
+            any |= __ballot(jn) != 0ull ? 1u << q : 0u;
+        }
+        for (int a = 0; a < aggs.n; a++) {
+            const int op = aggs.op[a];
+            uint32_t x = !valid ? 0u : aggs.gathered[a] ? aggs.col[a][rowv[j]] : rowv[j];
+#pragma unroll
+            for (int q = 0; q < 6; q++) {
+                if (!((any >> q) & 1u)) continue;
+                const uint32_t y = __shfl_up(x, 1 << q, 64);
+                if ((joins >> q) & 1u) x = u32_combine(op, y, x);
+            }
+            if (last_of_run_here) { if (complete) aggs.out[a][s] = x; else u32_atomic_combine(op, &aggs.out[a][s], x); }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void fill_u32_kernel(uint32_t *__restrict__ dst, int64_t n, uint32_t v)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = v;
+}
+
 // out dtype conversions of the 64-bit accumulators
 __global__ __launch_bounds__(256) void finalize_kernel(const u64 *__restrict__ acc, const u64 *__restrict__ cnt, int64_t G, int kind,
                                                        int out_dtype, int avg, void *__restrict__ out)
@@ -251,6 +394,47 @@ int grouped_aggregate(hark_context *ctx, const hark_table *db, int key_col, int 
         if (!rc) rc = k_gather(ctx, db->cols[key_col].data, kesz, perm, sorted_keys, n);
     }
     hark_free(ctx, words);
+    // u32 operators over 4-byte integer keys (the reference entry): heads, run numbers, keys and every aggregate in two passes
+    bool u32_tail = from_words && aggs.size() <= (size_t)kSegMaxAggs && !getenv("HARK_GROUPBY_NO_FUSED_TAIL");
+    for (const AggSpec &a : aggs)
+        u32_tail = u32_tail && a.kind == ACC_U64 && a.out_dtype == HARK_U32 && !a.count_mode && !a.avg && hark_dtype_size(db->cols[a.col].dtype) == 4;
+    if (!rc && u32_tail) {
+        const int64_t ntiles = (n + kSegTile - 1) / kSegTile;
+        uint32_t *counts = nullptr; int64_t *offsets = nullptr;
+        rc = hark_alloc(ctx, (void **)&counts, (size_t)ntiles * 4);
+        if (!rc) rc = hark_alloc(ctx, (void **)&offsets, (size_t)(ntiles + 1) * 8);
+        if (!rc) {
+            seg_count_kernel<<<dim3((unsigned)ntiles), 256, 0, st>>>(static_cast<const uint32_t *>(sorted_keys), n, counts);
+            rc = k_exclusive_scan_u32(ctx, counts, ntiles, nullptr, offsets, &G);
+        }
+        if (!rc) {
+            res->n = G;
+            res->cols.resize(1 + aggs.size());
+            res->cols[0].dtype = key_dtype;
+            rc = hark_alloc(ctx, &res->cols[0].data, (size_t)G * 4);
+            SegAggs sa{};
+            sa.n = (int32_t)aggs.size();
+            for (size_t j = 0; j < aggs.size() && !rc; j++) {
+                res->cols[1 + j].dtype = HARK_U32;
+                rc = hark_alloc(ctx, &res->cols[1 + j].data, (size_t)G * 4);
+                if (rc) break;
+                sa.col[j] = carried ? perm : static_cast<const uint32_t *>(db->cols[aggs[j].col].data);
+                sa.gathered[j] = carried ? 0 : 1;
+                sa.out[j] = static_cast<uint32_t *>(res->cols[1 + j].data);
+                sa.op[j] = aggs[j].op;
+                fill_u32_kernel<<<grid_for(ctx, G), 256, 0, st>>>(sa.out[j], G, (uint32_t)identity_of(ACC_U64, aggs[j].op));
+            }
+            if (!rc) {
+                seg_fused_u32_kernel<<<dim3((unsigned)ntiles), 256, 0, st>>>(static_cast<const uint32_t *>(sorted_keys), carried ? nullptr : perm, n, offsets,
+                                                                            static_cast<uint32_t *>(res->cols[0].data), sa);
+                if (hipGetLastError() != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "groupby: launch failed");
+            }
+        }
+        if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "groupby: kernels failed");
+        hark_free(ctx, counts); hark_free(ctx, offsets); hark_free(ctx, perm); hark_free(ctx, sorted_keys);
+        *G_out = G;
+        return rc;
+    }
     if (!rc) rc = hark_alloc(ctx, (void **)&flags, (size_t)n * 4);
     if (!rc) rc = hark_alloc(ctx, (void **)&seg, (size_t)n * 4);
     if (!rc) {
