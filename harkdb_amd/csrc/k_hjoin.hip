@@ -997,7 +997,7 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
 // *rval_out deliver its columns; both then stay null (the order kernel does not write them).
 int k_join_partitioned(hark_context *ctx, const void *lcol, bool k64, int64_t n, const void *rkeys, int64_t s, const uint32_t *lval, const uint32_t *rranked,
                        uint32_t **rank_out, uint32_t **lrow_out, uint32_t **cnt_out, uint32_t **lval_out, uint32_t **rval_out, int64_t *m_out, bool *used, bool *unique,
-                       bool rows_needed)
+                       bool rows_needed, int build_unique /* 1: the caller knows that all build keys are distinct (no run lengths are computed) */)
 {
     *rank_out = nullptr; *lrow_out = nullptr; *cnt_out = nullptr; *lval_out = nullptr; *rval_out = nullptr; *m_out = 0; *used = false; *unique = false;
     if (getenv("HARK_JOIN_FULLSORT")) lval = nullptr;
@@ -1007,10 +1007,10 @@ int k_join_partitioned(hark_context *ctx, const void *lcol, bool k64, int64_t n,
     int64_t M = 0;
     int32_t *flag = nullptr;                                   // [0] the survivors need the general sort (skew), [1] duplicate build keys
     int rc = hark_alloc(ctx, (void **)&flag, 16);
-    if (!rc) rc = hark_alloc(ctx, (void **)&runlen, 4 * (size_t)s);
+    if (!rc && build_unique != 1) rc = hark_alloc(ctx, (void **)&runlen, 4 * (size_t)s);
     if (rc) { hark_free(ctx, flag); return rc; }
     hipMemsetAsync(flag, 0, 16, ctx->stream);
-    {   // run lengths of the sorted build keys: the partner count of a survivor is runlen[rank]
+    if (build_unique != 1) {   // run lengths of the sorted build keys: the partner count of a survivor is runlen[rank]
         int64_t g1 = (s + 255) / 256;
         const int64_t gcap = (int64_t)ctx->num_cu * 16;
         if (g1 > gcap) g1 = gcap;

@@ -24,14 +24,14 @@
 int k_argsort_column(hark_context *ctx, const void *col, int dtype, int64_t n, bool descending,
                      uint32_t **perm_out, uint32_t **sorted_words_out);
 int k_gather(hark_context *ctx, const void *src, int esz, const uint32_t *idx, void *dst, int64_t n);
-int k_argsort_i64_keys(hark_context *ctx, const void *col, int64_t n, uint32_t **perm_out, uint64_t **keys_out, const uint32_t *valcol, uint32_t **val_out);
+int k_argsort_i64_keys(hark_context *ctx, const void *col, int64_t n, uint32_t **perm_out, uint64_t **keys_out, const uint32_t *valcol, uint32_t **val_out, int *unique_out);
 int k_sort_column(hark_context *ctx, const void *col, int dtype, int64_t n, bool descending, const uint32_t *payload,
                   uint32_t **vals_out, uint32_t **words_out);
 int k_exclusive_scan_u32(hark_context *ctx, const uint32_t *in, int64_t n, uint32_t *out32, int64_t *out64, int64_t *total_host);
 // k_hjoin.hip: the partitioned path (probe side range-partitioned by splitters of the sorted build side, build slices in LDS)
 int k_join_partitioned(hark_context *ctx, const void *lcol, bool k64, int64_t n, const void *rkeys, int64_t s, const uint32_t *lval, const uint32_t *rranked,
                        uint32_t **rank_out, uint32_t **lrow_out, uint32_t **cnt_out, uint32_t **lval_out, uint32_t **rval_out, int64_t *m_out, bool *used, bool *unique,
-                       bool rows_needed);
+                       bool rows_needed, int build_unique);
 
 namespace {
 
@@ -295,9 +295,10 @@ int hark_entry_join(hark_context *ctx, hark_result **out, const hark_table *db1,
         if (cols2[j] >= 0 && cols2[j] < db2->m && cols2[j] != col2 && hark_dtype_size(db2->cols[cols2[j]].dtype) == 4 && !getenv("HARK_JOIN_NO_RANK_GATHER")) rank_col = cols2[j];
     if (!(n >= ((int64_t)1 << 18) && s >= 4096)) rank_col = -1;             // (the partitioned path's own thresholds)
     uint32_t *rranked = nullptr, *rval = nullptr;
+    int build_unique = -1;                                     // 1: the sort saw that all build keys are distinct (no run lengths needed)
     // ---- the build side is sorted first: both paths need it
     if (k64) rc = k_argsort_i64_keys(ctx, rcol, s, &rperm, &rk64,           // permutation + the sorted (biased) keys (+ the column) in one go
-                                     rank_col >= 0 ? static_cast<const uint32_t *>(db2->cols[rank_col].data) : nullptr, rank_col >= 0 ? &rranked : nullptr);
+                                     rank_col >= 0 ? static_cast<const uint32_t *>(db2->cols[rank_col].data) : nullptr, rank_col >= 0 ? &rranked : nullptr, &build_unique);
     else {
         // 32-bit keys: when the rank-ordered column is the only thing the build side contributes besides its key, the sort
         // carries that column as its payload instead of the row ids (no permutation, no gather through it: 0.17 ms of a
@@ -330,7 +331,7 @@ int hark_entry_join(hark_context *ctx, hark_result **out, const hark_table *db1,
         int64_t M = 0;
         rc = k_join_partitioned(ctx, lcol, k64, n, k64 ? static_cast<const void *>(rk64) : static_cast<const void *>(rkeys), s,
                                 carry_col >= 0 ? static_cast<const uint32_t *>(db1->cols[carry_col].data) : nullptr, rranked,
-                                &prank, &plrow, &pcnt, &sval, &rval, &M, &partitioned, &unique, rows_needed);
+                                &prank, &plrow, &pcnt, &sval, &rval, &M, &partitioned, &unique, rows_needed, build_unique);
         if (!rc && partitioned) {
             nl = M;
             lb = prank; lperm = plrow; cnt = pcnt;                 // freed with the other scratch below
@@ -343,7 +344,7 @@ int hark_entry_join(hark_context *ctx, hark_result **out, const hark_table *db1,
     }
     if (!rc && !partitioned && !rperm) {                       // the sort-merge path gathers through the permutation after all
         hark_free(ctx, rkeys); rkeys = nullptr;
-        if (k64) { hark_free(ctx, rk64); rk64 = nullptr; rc = k_argsort_i64_keys(ctx, rcol, s, &rperm, &rk64, nullptr, nullptr); }
+        if (k64) { hark_free(ctx, rk64); rk64 = nullptr; rc = k_argsort_i64_keys(ctx, rcol, s, &rperm, &rk64, nullptr, nullptr, nullptr); }
         else rc = k_argsort_column(ctx, rcol, HARK_U32, s, false, &rperm, &rkeys);
     }
     if (!rc && !partitioned && n >= ((int64_t)1 << 20) && n >= 4 * s) {

@@ -858,6 +858,7 @@ __global__ __launch_bounds__(256) void tuple_fix_runs_kernel(const uint4 *__rest
             const uint2 q = *reinterpret_cast<const uint2 *>(tin + j);
             const uint64_t kj = ((uint64_t)q.y << 32) | q.x;
             at += (kj < key || (kj == key && j < i)) ? 1 : 0;
+            if (kj == key) too_long[1] = 1;                          // equal keys exist (benign race: every writer stores 1): the join wants to know
         }
         keys_out[at] = key; perm_out[at] = t.z;
         if (val_out) val_out[at] = t.w;
@@ -1073,7 +1074,7 @@ static int k_sort_column_lsd(hark_context *ctx, const void *col, int dtype, int6
     return HARK_OK;
 }
 
-int k_argsort_i64_keys(hark_context *ctx, const void *col, int64_t n, uint32_t **perm_out, uint64_t **keys_out, const uint32_t *valcol, uint32_t **val_out);
+int k_argsort_i64_keys(hark_context *ctx, const void *col, int64_t n, uint32_t **perm_out, uint64_t **keys_out, const uint32_t *valcol, uint32_t **val_out, int *unique_out);
 
 // Stable sort of a column with a 32-bit payload (see k_sort_column_lsd).  An ascending argsort of an i64 column takes
 // the high-word-first path of k_argsort_i64_keys (four passes + a run fix-up instead of eight passes).
@@ -1083,7 +1084,7 @@ int k_sort_column(hark_context *ctx, const void *col, int dtype, int64_t n, bool
     if (dtype == HARK_I64 && !descending && !payload && n >= 4096) {
         if (words_out) *words_out = nullptr;
         uint64_t *keys = nullptr;
-        const int rc = k_argsort_i64_keys(ctx, col, n, vals_out, &keys, nullptr, nullptr);
+        const int rc = k_argsort_i64_keys(ctx, col, n, vals_out, &keys, nullptr, nullptr, nullptr);
         hark_free(ctx, keys);
         if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) return hark_fail(ctx, HARK_EHIP, "sort kernels failed");
         return rc;
@@ -1104,7 +1105,7 @@ int k_argsort_column(hark_context *ctx, const void *col, int dtype, int64_t n, b
 // When the high words differ, key, row id and the column's value travel through the passes as 16-byte tuples
 // (sort_i64_tuples): no random read anywhere.  On the other paths *val_out is a gather through the permutation.
 static int sort_i64_tuples(hark_context *ctx, const void *col, int64_t n, uint32_t diff_hi, const uint32_t *valcol,
-                           uint64_t *keys, uint32_t **perm_out, uint32_t **val_out, bool *done)
+                           uint64_t *keys, uint32_t **perm_out, uint32_t **val_out, bool *done, int *unique_out)
 {
     *done = false;
     if (n > 0xFFFFFFFFll) return HARK_OK;                          // 32-bit positions and row ids (the general path reports the limit)
@@ -1163,6 +1164,7 @@ static int sort_i64_tuples(hark_context *ctx, const void *col, int64_t n, uint32
     rc = hark_read_words(ctx, flag, &general, 1);
     if (rc) { cleanup(false); return rc; }
     if ((general & 0xFFFFFFFFll) != 0) { cleanup(false); return HARK_OK; }          // a long run of equal prefixes: the general path
+    if (unique_out) *unique_out = ((general >> 32) & 0xFFFFFFFFll) ? 0 : 1;         // (the fix-up compared every pair of keys that could be equal)
     cleanup(true);
     *perm_out = perm;
     if (val_out) *val_out = val;
@@ -1170,10 +1172,12 @@ static int sort_i64_tuples(hark_context *ctx, const void *col, int64_t n, uint32
     return HARK_OK;
 }
 
-int k_argsort_i64_keys(hark_context *ctx, const void *col, int64_t n, uint32_t **perm_out, uint64_t **keys_out, const uint32_t *valcol, uint32_t **val_out)
+int k_argsort_i64_keys(hark_context *ctx, const void *col, int64_t n, uint32_t **perm_out, uint64_t **keys_out, const uint32_t *valcol, uint32_t **val_out,
+                       int *unique_out /* optional: 1 all keys distinct, 0 equal keys exist, -1 not determined (the permutation paths) */)
 {
     *perm_out = nullptr; *keys_out = nullptr;
     if (val_out) *val_out = nullptr;
+    if (unique_out) *unique_out = -1;
     if (n <= 0) return HARK_OK;
     hipStream_t st = ctx->stream;
     uint64_t *keys = nullptr;
@@ -1183,7 +1187,7 @@ int k_argsort_i64_keys(hark_context *ctx, const void *col, int64_t n, uint32_t *
     rc = k_transform_keys(ctx, col, HARK_I64, 1, nullptr, n, &diff_hi);
     bool done = false;
     if (!rc && passes_of(diff_hi) != 0u && !getenv("HARK_SORT_I64_LSD") && !getenv("HARK_SORT_NO_TUPLES"))
-        rc = sort_i64_tuples(ctx, col, n, diff_hi, valcol, keys, perm_out, val_out, &done);
+        rc = sort_i64_tuples(ctx, col, n, diff_hi, valcol, keys, perm_out, val_out, &done, unique_out);
     if (!rc && !done && passes_of(diff_hi) != 0u && !getenv("HARK_SORT_I64_LSD")) {
         uint32_t *k0 = nullptr, *k1 = nullptr, *v0 = nullptr, *v1 = nullptr, *ws = nullptr; int32_t *flag = nullptr;
         const size_t b = (size_t)n * 4;
