@@ -18,6 +18,7 @@
 // scan whose run tails are combined into 64-bit accumulators with one atomic
 // per (wave, group) -> typed finalisation.
 #include "hark_internal.h"
+#include <algorithm>
 
 int k_argsort_column(hark_context *ctx, const void *col, int dtype, int64_t n, bool descending,
                      uint32_t **perm_out, uint32_t **sorted_words_out);
@@ -1427,7 +1428,12 @@ int ref_groupby_hash(hark_context *ctx, const hark_table *view, const hark_table
     bool ok = true;
     uint32_t rounds = kc.hash_rounds > 0 ? (uint32_t)kc.hash_rounds : 0u;   // table rounds the key column needs: found by the first pass, reused
     hark_hash_part part;                                     // aggregates of one column after another share the (key, value) partition
-    for (size_t j = 0; j < runs && !rc && ok; j++) {
+    std::vector<size_t> order(runs);
+    for (size_t q = 0; q < runs; q++) order[q] = q;
+    if (!aggs.empty()) std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return aggs[a].col < aggs[b].col; });   // ... so column by column
+    bool first_pass = true;
+    for (size_t oi = 0; oi < runs && !rc && ok; oi++) {
+        const size_t j = order[oi];
         const int vop = aggs.empty() ? 3 : aggs[j].op == OP_SUM ? 1 : aggs[j].op == OP_MAX ? 2 : aggs[j].op == OP_MIN ? 3 : 4;
         const uint32_t *col = aggs.empty() ? keys : static_cast<const uint32_t *>(view->cols[aggs[j].col].data);
         uint32_t *hk = nullptr, *perm = nullptr; unsigned long long *hv = nullptr, *hc = nullptr;
@@ -1444,7 +1450,8 @@ int ref_groupby_hash(hark_context *ctx, const hark_table *view, const hark_table
             // the passes emit in table order of the hash buckets: bring every pass into ascending key order
             if (!rc) rc = k_argsort_column(ctx, hk, HARK_U32, G, false, &perm, nullptr);
             if (!rc && G > 0) {
-                if (j == 0) rc = k_gather(ctx, hk, 4, perm, res->cols[0].data, G);
+                if (first_pass) rc = k_gather(ctx, hk, 4, perm, res->cols[0].data, G);
+                first_pass = false;
                 if (!rc && !aggs.empty()) gather_low32_kernel<<<grid_for(ctx, G), 256, 0, ctx->stream>>>(hv, perm, static_cast<uint32_t *>(res->cols[j + 1].data), G);
             }
         }

@@ -80,7 +80,7 @@ def test_query_groupby_sparse_keys_hash_path(eng, oracle, n, ndistinct):
     db = rng.integers(0, 2**32, size=(n, 4), dtype=np.uint64).astype(np.uint32)
     db[:, 1] = pool[rng.integers(0, ndistinct, size=n)] if ndistinct < n else rng.permutation(pool)
     db[:, 3] = rng.integers(0, 3, size=n) * 2 + 1
-    s_cols, t_cols = [0, 2, 3, 0], [2, 3, 1, 4]
+    s_cols, t_cols = [0, 2, 3, 0, 0], [2, 3, 1, 4, 3]              # (the aggregates of column 0 share one hash partition)
     t = eng.table_from_matrix(db, np.uint32)
     got = eng.query_groupby(t, 1, s_cols, t_cols).to_numpy(np.uint32)
     exp = oracle.query_groupby(db, 1, s_cols, t_cols)
