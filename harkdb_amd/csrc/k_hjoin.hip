@@ -314,9 +314,9 @@ __global__ __launch_bounds__(kJThreads) void jpart_kernel(const K *__restrict__ 
 }
 
 // ---- one workgroup per bucket: build slice in LDS, probe pairs streamed past it --------------------------------
-// Most probe pairs have no partner and leave after a range test and ONE bit test; the few candidates of a wave's
-// 128-pair step would keep a 15-step search busy with a handful of lanes, so they are queued (per wave, in LDS) and
-// searched 64 at a time with every lane busy.
+// Most probe pairs have no partner and leave after a range test and ONE bit test; the candidates of a wave's 128-pair
+// step would keep a search busy with a part of the lanes, so they are queued (per wave, in LDS) and searched 64 at a time
+// with every lane busy (a radix index over the staged keys narrows each search to a dozen keys).
 template <typename K>
 __global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTraits<K>::E *__restrict__ slabs, const uint32_t *__restrict__ counts,
                                                             uint32_t cap, int nwg, const K *__restrict__ rkeys, const uint32_t *__restrict__ bstart,
