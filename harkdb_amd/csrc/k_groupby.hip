@@ -1290,12 +1290,17 @@ extern "C" int hark_entry_filter_groupby_slots(hark_context *ctx, hark_result **
 // ---------------------------------------------------------------------------
 namespace {
 
-__global__ __launch_bounds__(256) void dense_emit_u32_kernel(const uint32_t *__restrict__ vals, const unsigned long long *__restrict__ acc_cnt,
-                                                             const uint32_t *__restrict__ pos, int64_t G, uint32_t *__restrict__ out)
+// every result column of the dense path in one launch: column 0 = the keys of the non-empty slots, column j = vals[j - 1]
+struct DenseEmit { const uint32_t *vals[kSegMaxAggs + 1]; uint32_t *out[kSegMaxAggs + 1]; int32_t n; };
+__global__ __launch_bounds__(256) void dense_emit_all_u32_kernel(DenseEmit e, const unsigned long long *__restrict__ acc_cnt,
+                                                                 const uint32_t *__restrict__ pos, int64_t G)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < G; g += stride)
-        if (acc_cnt[g]) out[pos[g]] = vals ? vals[g] : (uint32_t)g;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < G; g += stride) {
+        if (!acc_cnt[g]) continue;
+        const uint32_t at = pos[g];
+        for (int j = 0; j < e.n; j++) e.out[j][at] = e.vals[j] ? e.vals[j][g] : (uint32_t)g;
+    }
 }
 
 int ref_groupby_dense(hark_context *ctx, const hark_table *view, const hark_table *stats_owner, int g_col,
@@ -1380,8 +1385,14 @@ int ref_groupby_dense(hark_context *ctx, const hark_table *view, const hark_tabl
         for (size_t j = 0; j <= aggs.size() && !rc; j++) {
             res->cols[j].dtype = HARK_U32;
             rc = hark_alloc(ctx, &res->cols[j].data, (size_t)ngroups * 4);
-            if (!rc) dense_emit_u32_kernel<<<grid_for(ctx, G), 256, 0, ctx->stream>>>(j == 0 ? nullptr : vals[j - 1], plan->acc_cnt, pos, G,
-                                                                                    static_cast<uint32_t *>(res->cols[j].data));
+        }
+        for (size_t j0 = 0; j0 <= aggs.size() && !rc; j0 += kSegMaxAggs + 1) {      // (kSegMaxAggs + 1 columns per launch)
+            DenseEmit e{};
+            for (size_t j = j0; j <= aggs.size() && e.n <= kSegMaxAggs; j++) {
+                e.vals[e.n] = j == 0 ? nullptr : vals[j - 1];
+                e.out[e.n++] = static_cast<uint32_t *>(res->cols[j].data);
+            }
+            dense_emit_all_u32_kernel<<<grid_for(ctx, G), 256, 0, ctx->stream>>>(e, plan->acc_cnt, pos, G);
         }
         if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "query_groupby: kernels failed");
     }
