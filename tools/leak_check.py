@@ -22,8 +22,8 @@ ops = {
     "groupby hash": lambda: eng.query_groupby(t, 2, [1, 1], [2, 3]),
     "sort carried": lambda: eng.sort(t, 0, [0, 1]),
     "sort gathered": lambda: eng.sort(t, 3, [0, 1, 2], descending=True),
-    "join prefilter u32": lambda: eng.join(t, small, 2, 0, [0, 1], [1]),
-    "join prefilter i64": lambda: eng.join(wide, wsmall, 0, 0, [1], [1]),
+    "join u32 (partitioned)": lambda: eng.join(t, small, 2, 0, [0, 1], [1]),
+    "join i64 (partitioned)": lambda: eng.join(wide, wsmall, 0, 0, [1], [1]),
     "filter_groupby": lambda: eng.filter_groupby(t, (3, ">", 0.5), 0, [("sum", 3), ("count", 0), ("max", 1)]),
     "filter_groupby_topk": lambda: eng.filter_groupby_topk(t, [(3, ">", 0.5)], 0, [("sum", 3), ("count", 0), ("max", 1)], [(2, ">", 1)], 1, True, 10),
     "topk": lambda: eng.topk(t, [(3, ">", 0.5)], 1, True, 10, [0, 1, 2]),
