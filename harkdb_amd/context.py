@@ -216,7 +216,7 @@ class FutharkContext:
         res._keep = (cur,)                                             # the compacted input must outlive a borrowed view
         return res
 
-    def _groupby_extended(self, dev, schema, ir, provider=None, key_ranges=None):
+    def _groupby_extended(self, dev, schema, ir, provider=None, key_ranges=None, subset_provider=None):
         """SQL-typed GROUP BY [+ HAVING / ORDER BY / LIMIT].  `provider(cur, dev_preds, gkey, specs)` (the sharded
         context, dist.py) replaces the local aggregation: it returns a device Result [key, aggregates...] of ALL groups
         over all shards, ascending key; HAVING / ORDER BY / LIMIT then run here, on the device, exactly as for one GPU.
@@ -321,7 +321,7 @@ class FutharkContext:
         second = [s for s in range(1, len(aggs) + 1) if s not in first]
         four = (np.dtype(np.float32), np.dtype(np.int32), np.dtype(np.uint32))
         if (lim is not None and 0 < lim <= 1024 and not multi and second and len(second) <= 8 and lim * len(second) <= 8192
-                and provider is None and not os.environ.get("HARK_NO_LATE_AGG") and np.dtype(cur.dtype(gkey)) in four[1:]
+                and (provider is None or subset_provider is not None) and not os.environ.get("HARK_NO_LATE_AGG") and np.dtype(cur.dtype(gkey)) in four[1:]
                 and all(aggs[s - 1][0] in ("sum", "avg", "min", "max", "count") and (aggs[s - 1][1] is None or np.dtype(cur.dtype(cmap[aggs[s - 1][1]])) in four)
                         for s in second)):
             first_specs = [aggs[s - 1] for s in first] or [("count", None)]
@@ -330,8 +330,9 @@ class FutharkContext:
                          None if order is None else (remap[order[0]], order[1]), lim)
             c1 = r1.columns(limit=lim)
             c1 = [c[:lim] for c in c1]
-            r2 = eng.filter_groupby_subset(cur, dev_preds, gkey, c1[0], [spec_of(aggs[s - 1]) for s in second])
-            c2 = r2.columns()
+            specs2 = [spec_of(aggs[s - 1]) for s in second]
+            # (over shards: every rank aggregates its rows of the surviving groups, the k-row partials are merged)
+            c2 = subset_provider(cur, dev_preds, gkey, c1[0], specs2) if subset_provider is not None else eng.filter_groupby_subset(cur, dev_preds, gkey, c1[0], specs2).columns()
             cols = [None] * (1 + len(aggs))
             cols[0] = c1[0]
             for j, s_ in enumerate(first):

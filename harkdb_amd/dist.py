@@ -648,7 +648,43 @@ class ShardedFutharkContext:
                 res = self._merged_by_owner(cur, dev_preds, gkey, specs)
             return res
 
-        return self.local._groupby_extended(dev, schema, ir, provider=provider, key_ranges=ranges if len(g_cols) > 1 else None)
+        return self.local._groupby_extended(dev, schema, ir, provider=provider, key_ranges=ranges if len(g_cols) > 1 else None,
+                                            subset_provider=self._subset_merged)
+
+    def _subset_merged(self, cur, dev_preds, gkey, keys, specs):
+        """Late aggregation over shards: the aggregates `specs` of the groups `keys` (the LIMIT survivors of the first phase,
+        the same on every rank) -- every rank aggregates its own rows of those groups (hark_entry_filter_groupby_subset),
+        the len(keys)-row partials are merged by all-reduce (SUM / MIN / MAX; AVG = SUM and COUNT).  numpy columns."""
+        import torch
+        eng = self.local.FutEnv
+        self.late_aggregations = getattr(self, "late_aggregations", 0) + 1
+        part = []
+        for f, c in specs:
+            ps = ("sum" if f == "avg" else f, c)
+            if f != "count" and ps not in part:
+                part.append(ps)
+        r = eng.filter_groupby_subset(cur, dev_preds, gkey, keys, part + [("count", 0)])
+        cols = r.columns()
+        dts = [np.dtype(c.dtype) for c in cols[:-1]]
+        tens = [torch.from_numpy(np.ascontiguousarray(c).view(np.int32) if c.dtype == np.uint32 else np.ascontiguousarray(c)).to(self.device) for c in cols[:-1]]
+        cnt = torch.from_numpy(np.ascontiguousarray(cols[-1]).astype(np.int64)).to(self.device)
+        merged = merge_slot_columns(tens, [f for f, _ in part], dts, cnt)
+        total = merged[-1]
+        out = []
+        for f, c in specs:
+            if f == "count":
+                out.append(total.cpu().numpy())
+                continue
+            j = part.index(("sum" if f == "avg" else f, c))
+            t, dt = merged[j], dts[j]
+            if f == "avg":                                              # f32(sum / count), as the single-GPU read-out computes it
+                out.append((t.to(torch.float64) / total.to(torch.float64).clamp(min=1.0)).to(torch.float32).cpu().numpy())
+            elif f == "sum" and dt.kind == "f":
+                out.append(t.to(torch.float32).cpu().numpy())          # merged in f64, rounded once
+            else:
+                a = t.cpu().numpy()
+                out.append(a.view(np.uint32) if dt == np.dtype(np.uint32) and a.dtype == np.int32 else a.astype(dt) if f != "sum" else a)
+        return out
 
     # ---- dense key domain: all-reduce of per-slot partial aggregates ---------------
     def _merged_dense(self, cur, dev_preds, gkey, specs, ranges, composite, n_global):

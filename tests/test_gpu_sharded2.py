@@ -80,6 +80,7 @@ def _worker(rank, world, port, q, csv_path):
         names, cols = c.sql_columns(stmt)
         out[stmt] = (names, [np.asarray(x) for x in cols])
         paths[j] = getattr(c, "last_groupby_path", None) if " group by " in stmt else None
+    out["late"] = getattr(c, "late_aggregations", 0)
     out["paths"] = paths
     out["g"] = c.sql_columns("select x, y from g where y > 5 order by x desc limit 30")
     out["t_local"] = c.sql_columns("select d, count(*) from t_local group by d")
@@ -136,6 +137,7 @@ def test_two_ranks_one_gpu_match_single_context(tmp_path):
         for j in DENSE:
             assert outs[rank]["paths"][j] == "dense all-reduce", (j, outs[rank]["paths"])
         assert outs[rank]["paths"][1] == "owner all-to-all"      # negative keys: partial aggregates travel to the owner of hash(key)
+        assert outs[rank]["late"] >= 2                           # statements 1 and 9: MIN / MAX nobody orders by, for the LIMIT groups only, merged over the shards
         gx = np.concatenate([np.arange(0, 1000), np.arange(1000, 2024)]).astype(np.int32)
         gx = gx[(gx % 7) > 5][::-1][:30]
         assert np.array_equal(outs[rank]["g"][1][0], gx) and np.array_equal(outs[rank]["g"][1][1], (gx % 7).astype(np.float32))
