@@ -838,10 +838,11 @@ int try_hash(hark_context *ctx, const hark_table *db, const PredList &preds,
     uint32_t rounds = 0;
     std::vector<char> done((size_t)n_aggs, 0);
     unsigned long long *accg = nullptr, *cntg = nullptr;
+    hark_hash_part part;                                     // passes over one (column, value transform) share the hash partition
     auto run_pass = [&](int vop, int xf, const void *col) -> int {
         uint32_t *hk = nullptr, *perm = nullptr; unsigned long long *hv = nullptr, *hc = nullptr;
         int64_t Gj = 0;
-        int r = k_fgb_hash_u32(ctx, keys, static_cast<const uint32_t *>(col), src->n, vop, xf, &hk, &hv, &hc, &Gj, &ok, &rounds, false);
+        int r = k_fgb_hash_u32(ctx, keys, static_cast<const uint32_t *>(col), src->n, vop, xf, &hk, &hv, &hc, &Gj, &ok, &rounds, false, &part);
         if (!r && ok) {
             if (G < 0) {
                 G = Gj; res->n = G;
@@ -865,7 +866,12 @@ int try_hash(hark_context *ctx, const hark_table *db, const PredList &preds,
         hark_free(ctx, hk); hark_free(ctx, hv); hark_free(ctx, hc); hark_free(ctx, perm);
         return r;
     };
-    for (int64_t j = 0; j < n_aggs && !rc && ok; j++) {
+    std::vector<int64_t> order((size_t)n_aggs);
+    for (int64_t j = 0; j < n_aggs; j++) order[(size_t)j] = j;
+    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) {      // ... so passes that can share one run back to back
+        return plan_of[a].col != plan_of[b].col ? plan_of[a].col < plan_of[b].col : plan_of[a].xf < plan_of[b].xf; });
+    for (int64_t oi = 0; oi < n_aggs && !rc && ok; oi++) {
+        const int64_t j = order[(size_t)oi];
         if (done[j] || plan_of[j].count_only) continue;
         rc = run_pass(plan_of[j].vop, plan_of[j].xf, src->cols[plan_of[j].col].data);
         for (int64_t q = 0; q < n_aggs && !rc && ok; q++)
@@ -879,6 +885,7 @@ int try_hash(hark_context *ctx, const hark_table *db, const PredList &preds,
         for (int64_t q = 0; q < n_aggs && !rc && ok; q++) rc = k_fgb_decode(ctx, accg, cntg, G, plan_of[q].kind, res->cols[(size_t)q + 1].data);
     }
     if (!rc && ok && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "filter_groupby: kernels failed");
+    k_fgb_hash_part_free(ctx, &part);
     hark_free(ctx, accg); hark_free(ctx, cntg);
     if (kept) hark_result_free(ctx, kept);
     if (rc || !ok) {
