@@ -102,6 +102,31 @@ def test_sort_large_geometry_exact(eng):
     res.free(); eng.free(k); eng.free(rid)
 
 
+def test_sort_i64_above_2_24_rows_exact(eng):
+    """i64 keys spread over 64 bits, more than 2^24 of them: the tuple passes sort by ALL 32 bits of the high word (four
+    passes; up to 2^24 keys three passes over the top 24 bits do), runs of equal high words are fixed up; equal keys keep
+    their order.  The permutation must be torch's stable argsort exactly."""
+    import torch
+    from harkdb_amd.dist import tensor_from_ptr
+    dev = torch.device("cuda", 0)
+    n = (1 << 24) + 54321
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)
+    keys = torch.randint(-2**62, 2**62, (n,), dtype=torch.int64, device=dev, generator=g) * 2 + torch.randint(0, 2, (n,), dtype=torch.int64, device=dev, generator=g)
+    dup = torch.randint(0, n, (n // 16,), dtype=torch.int64, device=dev, generator=g)
+    keys[dup] = keys[(dup * 7919) % n]                                     # equal keys: stability matters
+    keys[:5000] = (keys[:5000] & ~0xFFFFFFFF) | (keys[0] & 0xFFFFFFFF0000) # a few keys that share a high word's prefix
+    rid = torch.arange(n, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    t = eng.table_from_device(n, [keys.data_ptr(), rid.data_ptr()], [np.int64, np.int32], keepalive=(keys, rid))
+    res = eng.sort(t, 0, [0, 1])
+    want = torch.sort(keys, stable=True)
+    got_k = tensor_from_ptr(res.device_ptr(0), n, np.int64, dev)
+    got_r = tensor_from_ptr(res.device_ptr(1), n, np.int32, dev)
+    assert bool((got_k == want.values).all()) and bool((got_r.long() == want.indices).all())
+    res.free(); t.free()
+
+
 def test_shard_larger_than_2_31_rows_is_fed_in_pieces(eng):
     """2^31 + 4100 rows in one shard (25.8 GB of columns): FgbPlan.run splits the call, the
     accumulators merge the pieces; complement counts add up to the row count."""
