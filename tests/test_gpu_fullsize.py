@@ -213,6 +213,38 @@ def test_c4_join_share_i64_full_size(eng):
         t.free()
 
 
+def test_join_build_side_above_2_24_keys(eng):
+    """More than 2^24 unique i64 build keys: the build side takes four tuple passes and a bucket holds more keys than two
+    chunks (the truncated-key round does not apply: several rounds over full keys).  Same device-side checks as the
+    configs[3] share: pair count, key equality, reference order, every matching probe row exactly once."""
+    import torch
+    from harkdb_amd.dist import tensor_from_ptr
+    dev = torch.device("cuda", 0)
+    n, s = 40_000_000, (1 << 24) + 4321
+    mul = -7046029254386353131
+    bk = torch.arange(s, dtype=torch.int64, device=dev) * mul
+    g = torch.Generator(device=dev)
+    g.manual_seed(13)
+    j = torch.randint(0, 2 * s, (n,), dtype=torch.int64, device=dev, generator=g)
+    pk = j * mul
+    hits = int((j < s).sum().item())
+    prow, brow = torch.arange(n, dtype=torch.int32, device=dev), torch.arange(s, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    tp = eng.table_from_device(n, [pk.data_ptr(), prow.data_ptr()], [np.int64, np.int32], keepalive=(pk, prow))
+    tb = eng.table_from_device(s, [bk.data_ptr(), brow.data_ptr()], [np.int64, np.int32], keepalive=(bk, brow))
+    res = eng.join(tp, tb, 0, 0, [0, 1], [1])
+    P = res.shape[0]
+    assert P == hits
+    lk, lr, rr = (tensor_from_ptr(res.device_ptr(c), P, dt, dev) for c, dt in ((0, np.int64), (1, np.int32), (2, np.int32)))
+    assert bool((pk[lr.long()] == lk).all()) and bool((bk[rr.long()] == lk).all())     # the row ids point at the pair's key
+    dk = lk[1:] - lk[:-1]
+    assert bool((lk[1:] >= lk[:-1]).all()) and bool((lr[1:][dk == 0] > lr[:-1][dk == 0]).all())   # (key, left row) order
+    seen = torch.zeros(n, dtype=torch.bool, device=dev)
+    seen[lr.long()] = True
+    assert bool((seen == (j < s)).all())
+    res.free(); tp.free(); tb.free()
+
+
 def test_c5_full_pipeline_share(eng):
     """configs[4], one GPU's share: 5e8 rows x (i32 key + 16 f32 columns) = 34 GB resident, the full SELECT / WHERE /
     GROUP BY / HAVING / ORDER BY / LIMIT statement through the SQL surface.  Properties: linearity in the predicate,
