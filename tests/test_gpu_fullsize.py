@@ -245,6 +245,36 @@ def test_join_build_side_above_2_24_keys(eng):
     res.free(); tp.free(); tb.free()
 
 
+@pytest.mark.parametrize("distinct", [1 << 21, 1 << 31])
+def test_reference_groupby_sparse_keys_at_size(eng, distinct):
+    """query_groupby (sum, max, min of one column) over 3e7 rows of sparse u32 keys: 2^21 distinct keys take the hash path
+    (one partition for the three aggregates), ~3e7 distinct ones the sort path (radix sort + the two-pass segmented tail).
+    Checked on the device: the keys are torch.unique's, and every aggregate against a scatter-reduce of the same rows."""
+    import torch
+    from harkdb_amd.dist import tensor_from_ptr
+    dev = torch.device("cuda", 0)
+    n = 30_000_000
+    g = torch.Generator(device=dev)
+    g.manual_seed(17)
+    k64 = (torch.randint(0, distinct, (n,), dtype=torch.int64, device=dev, generator=g) * 2654435761) % (1 << 32)
+    v64 = torch.randint(0, 1 << 32, (n,), dtype=torch.int64, device=dev, generator=g)
+    k32 = (k64 - ((k64 >> 31) << 32)).to(torch.int32)                       # the u32 bit patterns as int32 tensors
+    v32 = (v64 - ((v64 >> 31) << 32)).to(torch.int32)
+    torch.cuda.synchronize()
+    t = eng.table_from_device(n, [k32.data_ptr(), v32.data_ptr()], [np.uint32, np.uint32], keepalive=(k32, v32))
+    res = eng.query_groupby(t, 0, [1, 1, 1], [2, 3, 4])
+    uk, inv = torch.unique(k64, sorted=True, return_inverse=True)
+    G = uk.numel()
+    assert res.shape == (G, 4)
+    got = [tensor_from_ptr(res.device_ptr(c), G, np.int32, dev).long() & 0xFFFFFFFF for c in range(4)]
+    assert bool((got[0] == uk).all())                                        # ascending unsigned keys
+    ssum = torch.zeros(G, dtype=torch.int64, device=dev).scatter_add_(0, inv, v64) & 0xFFFFFFFF     # + mod 2^32 (groupby.fut:37)
+    smax = torch.zeros(G, dtype=torch.int64, device=dev).scatter_reduce_(0, inv, v64, "amax")
+    smin = torch.full((G,), 1 << 32, dtype=torch.int64, device=dev).scatter_reduce_(0, inv, v64, "amin")
+    assert bool((got[1] == ssum).all()) and bool((got[2] == smax).all()) and bool((got[3] == smin).all())
+    res.free(); t.free()
+
+
 def test_c5_full_pipeline_share(eng):
     """configs[4], one GPU's share: 5e8 rows x (i32 key + 16 f32 columns) = 34 GB resident, the full SELECT / WHERE /
     GROUP BY / HAVING / ORDER BY / LIMIT statement through the SQL surface.  Properties: linearity in the predicate,
