@@ -73,7 +73,7 @@ def _worker(rank, world, port, q, csv_path):
     xs = torch.arange(1000 * rank, 1000 * rank + 1000 + 24 * rank, dtype=torch.int32, device=c.device)
     ys = (xs % 7).to(torch.float32)
     c.create_table_from_device("g", ["x", "y"], [xs.data_ptr(), ys.data_ptr()], [np.int32, np.float32], xs.numel(), keepalive=(xs, ys))
-    assert c.rows["g"][0] == 2024 and c.rows["g"][1] == (0 if rank == 0 else 1000)
+    assert c.rows["g"][0] == sum(1000 + 24 * r for r in range(world)) and c.rows["g"][1] == sum(1000 + 24 * r for r in range(rank))
     out = {}
     paths = {}
     for j, stmt in enumerate(STATEMENTS):
@@ -101,7 +101,9 @@ def _worker(rank, world, port, q, csv_path):
     dist.barrier(); dist.destroy_process_group()
 
 
-def test_two_ranks_one_gpu_match_single_context(tmp_path):
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_on_one_gpu_match_single_context(tmp_path, world):
+    """Two and three ranks (uneven shards, a third splitter in the range partitions) sharing one GPU."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -110,10 +112,10 @@ def test_two_ranks_one_gpu_match_single_context(tmp_path):
     df.to_csv(csv_path, index=False)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, csv_path)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, csv_path)) for r in range(world)]
     for pr in procs:
         pr.start()
-    outs = dict(q.get(timeout=300) for _ in range(2))
+    outs = dict(q.get(timeout=300) for _ in range(world))
     for pr in procs:
         pr.join(timeout=120)
         assert pr.exitcode == 0
@@ -124,7 +126,7 @@ def test_two_ranks_one_gpu_match_single_context(tmp_path):
     fc.create_table("b", b)
     for stmt in STATEMENTS:
         names, cols = fc.sql_columns(stmt)
-        for rank in (0, 1):
+        for rank in range(world):
             gn, gc = outs[rank][stmt]
             assert gn == names, stmt
             for x, y in zip(gc, cols):                            # row for row, the join included (reference order, join.fut:52-75)
@@ -133,13 +135,13 @@ def test_two_ranks_one_gpu_match_single_context(tmp_path):
                     assert np.allclose(x, y, rtol=1e-6), stmt
                 else:
                     assert np.array_equal(x, y), stmt
-    for rank in (0, 1):
+    for rank in range(world):
         for j in DENSE:
             assert outs[rank]["paths"][j] == "dense all-reduce", (j, outs[rank]["paths"])
         assert outs[rank]["paths"][1] == "owner all-to-all"      # negative keys: partial aggregates travel to the owner of hash(key)
         assert outs[rank]["late"] >= 2                           # statements 1 and 9: MIN / MAX nobody orders by, for the LIMIT groups only, merged over the shards
-        gx = np.concatenate([np.arange(0, 1000), np.arange(1000, 2024)]).astype(np.int32)
-        gx = gx[(gx % 7) > 5][::-1][:30]
+        gx = np.concatenate([np.arange(1000 * r, 1000 * r + 1000 + 24 * r) for r in range(world)]).astype(np.int32)
+        gx = np.sort(gx[(gx % 7) > 5], kind="stable")[::-1][:30]
         assert np.array_equal(outs[rank]["g"][1][0], gx) and np.array_equal(outs[rank]["g"][1][1], (gx % 7).astype(np.float32))
         ld, lc = outs[rank]["t_local"][1]
         ed, ec = np.unique(df.d.to_numpy(), return_counts=True)
@@ -148,7 +150,7 @@ def test_two_ranks_one_gpu_match_single_context(tmp_path):
     # 60 000 rows: every key's rows sit on both shards and meet at ONE owner)
     from oracle import oracle as ora
     ref = ora.join(df[["k", "w"]].to_numpy().astype(np.int64), b[["x", "y"]].to_numpy().astype(np.int64), 1, 0, [0, 1], [1])
-    for rank in (0, 1):
+    for rank in range(world):
         got = outs[rank]["select t.k, b.y, t.w from t join b on t.w = b.x"][1]
         mine = np.ascontiguousarray(np.stack([got[0], got[2], got[1]], axis=1).astype(np.int32)).view(np.uint32)
         assert np.array_equal(mine, ref)
@@ -157,5 +159,5 @@ def test_two_ranks_one_gpu_match_single_context(tmp_path):
     keep = df.p.to_numpy() > 0.5
     es = np.bincount(kk[keep], weights=df.v.to_numpy()[keep].astype(np.float64), minlength=G).astype(np.float32)
     ec = np.bincount(kk[keep], minlength=G).astype(np.int64)
-    for rank in (0, 1):
+    for rank in range(world):
         assert np.array_equal(outs[rank]["fgb"][0], es) and np.array_equal(outs[rank]["fgb"][1], ec)
