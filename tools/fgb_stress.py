@@ -9,7 +9,10 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 eng = Engine(0)
 t_end, cases, worst = time.time() + budget, 0, None
+t_note = time.time() + 60
 while time.time() < t_end:
+    if time.time() > t_note:                                  # a sign of life per minute (a silent GPU job is taken to be hung)
+        print(f"... {cases} cases so far", flush=True); t_note = time.time() + 60
     G = int(rng.choice([8193, 10_000, 65_536, 300_001, 1 << 20, (1 << 21) - 5]))
     n = int(rng.integers(1, 3_000_000))
     dist = rng.choice(["uniform", "zipf", "one bucket", "few keys", "sorted"])

@@ -147,7 +147,10 @@ def case_filter():
 
 cases, t_end, bad = 0, time.time() + budget, None
 counts = {}
+t_note = time.time() + 60
 while time.time() < t_end and bad is None:
+    if time.time() > t_note:                                  # a sign of life per minute (a silent GPU job is taken to be hung)
+        print(f"... {cases} cases so far", flush=True); t_note = time.time() + 60
     fn = [case_sort, case_join, case_groupby, case_filter][int(rng.integers(0, 4))]
     ok, info = fn()
     cases += 1

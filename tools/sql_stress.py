@@ -10,7 +10,10 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 fc = FutharkContext(sql_mode=True)
 OPS = {">": "gt", ">=": "ge", "<": "lt", "<=": "le", "=": "eq", "!=": "ne"}
 cases, bad, t_end = 0, None, time.time() + budget
+t_note = time.time() + 60
 while time.time() < t_end and bad is None:
+    if time.time() > t_note:                                  # a sign of life per minute (a silent GPU job is taken to be hung)
+        print(f"... {cases} statements so far", flush=True); t_note = time.time() + 60
     n = int(rng.choice([7, 5000, 300_000, 1_200_000]))
     df = pd.DataFrame({
         "a": rng.integers(-4, 5, n).astype(np.int32), "b": rng.integers(0, int(rng.choice([3, 50, 4000])), n).astype(np.int32),
