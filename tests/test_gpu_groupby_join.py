@@ -37,6 +37,22 @@ def test_query_groupby_matches_oracle(eng, oracle, n, nkeys):
     assert got.shape == exp.shape and np.array_equal(got, exp)
 
 
+@pytest.mark.parametrize("n,nkeys,naggs", [(50_000, 40_000, 8), (50_000, 300, 9), (120_000, 1, 12)])
+def test_query_groupby_sort_path_many_aggregates(eng, oracle, n, nkeys, naggs):
+    """The sort path's two-pass tail reduces up to eight aggregates in one sweep; more take the separate reductions.  Mostly
+    distinct keys, few keys (runs across waves and tiles: 32-bit atomics on the results) and one key."""
+    rng = np.random.default_rng(n + nkeys + naggs)
+    db = rng.integers(0, 2**32, size=(n, 4), dtype=np.uint64).astype(np.uint32)
+    db[:, 0] = rng.integers(0, 2**32, size=nkeys, dtype=np.uint64).astype(np.uint32)[rng.integers(0, nkeys, size=n)]
+    db[:, 3] = rng.integers(0, 4, size=n) * 2 + 1
+    s_cols = [(1, 2, 3)[j % 3] for j in range(naggs)]
+    t_cols = [(2, 3, 4, 1, 9)[j % 5] for j in range(naggs)]
+    t = eng.table_from_matrix(db, np.uint32)
+    got = eng.query_groupby(t, 0, s_cols, t_cols).to_numpy(np.uint32)
+    exp = oracle.query_groupby(db, 0, s_cols, t_cols)
+    assert got.shape == exp.shape and np.array_equal(got, exp)
+
+
 @pytest.mark.parametrize("n,G", [(7, 7), (200_000, 5000), (300_000, 1 << 20), (1_000_000, 70_000)])
 def test_query_groupby_dense_keys_fused_path(eng, oracle, n, G):
     """Keys below 2^21 take the fused dense kernels (LDS tables or partition + LDS),

@@ -114,7 +114,7 @@ def test_sparse_int_keys_hash_path(where):
                        "v": rng.integers(0, 16, n).astype(np.float32), "w": rng.integers(-100, 100, n).astype(np.int32)})
     c.create_table("s", df)
     sel = df if not where else df[df.w != 0]
-    names, cols = c.sql_columns(f"select k, sum(w), min(p), count(*), avg(v), max(w) from s {where} group by k")
+    names, cols = c.sql_columns(f"select k, sum(w), min(p), count(*), avg(v), max(w), max(p) from s {where} group by k")
     g = sel.groupby("k")
     assert np.array_equal(cols[0], np.asarray(g.w.sum().index)) and cols[0].dtype == np.int32       # ascending signed
     assert np.array_equal(cols[1], g.w.sum().to_numpy()) and cols[1].dtype == np.int64
@@ -122,6 +122,7 @@ def test_sparse_int_keys_hash_path(where):
     assert np.array_equal(cols[3], g.w.count().to_numpy())
     assert np.allclose(cols[4], g.v.mean().to_numpy(), rtol=1e-6)
     assert np.array_equal(cols[5], g.w.max().to_numpy())
+    assert np.array_equal(cols[6], g.p.max().to_numpy())            # (min(p) and max(p), sum(w) and max(w) share a hash partition each)
 
 
 def test_groupby_negative_and_int64_keys(fc):
