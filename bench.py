@@ -12,6 +12,8 @@ the fused HIP kernels on its shard, the per-GPU partial aggregates (16 B x 2^20)
 are summed with an RCCL all-reduce, and the merged table is finalised.
 
 Run bare with --gpus N > 1 (no torchrun) it starts its own N rank processes.
+Setup (before the W warm-up steps): columns generated on the device, plans created, and the path's kernels loaded by
+one pass over the first 65536 rows with a small plan of its own (code objects page in on first launch).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) carrying
   roofline      the WHOLE PATH's algorithmic bytes over the step time against the 8 TB/s HBM peak (`frac`), the
@@ -510,6 +512,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Setup, not warm-up: the path's kernels are loaded (code objects page in on first launch -- 0.3 s on a fresh box) by ONE
+    # pass over the first 65536 rows with a small plan of its own; the workload's plans, slabs and rows are not touched.
+    prime_n = min(N, 1 << 16)
+    prime = FgbPlan(eng, prime_n, G, **knobs)
+    prime.run(p.data_ptr(), ">", 0.5, k.data_ptr(), v.data_ptr(), prime_n)
+    prime.finish(sum_out.data_ptr(), cnt_out.data_ptr())
+    torch.cuda.synchronize()
+    prime.free()
     for _ in range(a.warmup):
         step()
     job.flush()
