@@ -483,6 +483,14 @@ int hark_entry_join(hark_context *ctx, hark_result **out, const hark_table *db1,
     return HARK_OK;
 }
 
+namespace {
+__global__ __launch_bounds__(256) void unbias_i64_kernel(uint64_t *__restrict__ keys, int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) keys[i] ^= 0x8000000000000000ull;
+}
+} // namespace
+
 int hark_entry_sort(hark_context *ctx, hark_result **out, const hark_table *db, int32_t key_col, int32_t descending,
                     const int32_t *cols, int64_t k)
 {
@@ -501,6 +509,47 @@ int hark_entry_sort(hark_context *ctx, hark_result **out, const hark_table *db, 
     // 4-byte column is asked for it travels with the keys as the payload (no row ids, no gather); otherwise the
     // payload is the row id and every other column is gathered through it.
     const int kdt = db->cols[key_col].dtype;
+    // Ascending i64 keys: the sort hands back the SORTED KEYS themselves (and one 4-byte column that travelled with them when
+    // the high words differ: k_argsort_i64_keys) -- the key column and that column are then not gathered through the row ids
+    // (two random reads per row: most of an ORDER BY on an i64 key).
+    if (kdt == HARK_I64 && !descending && db->n >= 4096) {
+        int carry64 = -1, others64 = 0;
+        for (int64_t j = 0; j < k; j++) {
+            if (cols[j] == key_col) continue;
+            bool seen = false;
+            for (int64_t q = 0; q < j; q++) seen = seen || cols[q] == cols[j];
+            if (!seen) { others64++; carry64 = cols[j]; }
+        }
+        const bool carried64 = others64 == 1 && hark_dtype_size(db->cols[carry64].dtype) == 4;
+        uint32_t *perm = nullptr, *val = nullptr;
+        uint64_t *keys64 = nullptr;
+        int rc = k_argsort_i64_keys(ctx, db->cols[key_col].data, db->n, &perm, &keys64,
+                                    carried64 ? static_cast<const uint32_t *>(db->cols[carry64].data) : nullptr, carried64 ? &val : nullptr, nullptr);
+        if (!rc) {
+            unbias_i64_kernel<<<grid_for(ctx, db->n), 256, 0, ctx->stream>>>(keys64, db->n);
+            if (hipGetLastError() != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "sort: launch failed");
+        }
+        bool keys_taken = false, val_taken = false;
+        for (int64_t j = 0; j < k && !rc; j++) {
+            const int esz = (int)hark_dtype_size(res->cols[j].dtype);
+            if (cols[j] == key_col && !keys_taken) { res->cols[j].data = keys64; keys_taken = true; continue; }
+            if (carried64 && cols[j] == carry64 && val && !val_taken) { res->cols[j].data = val; val_taken = true; continue; }
+            rc = hark_alloc(ctx, &res->cols[j].data, (size_t)db->n * esz);
+            if (rc) break;
+            hipError_t he = hipSuccess;
+            if (cols[j] == key_col) he = hipMemcpyAsync(res->cols[j].data, keys64, (size_t)db->n * 8, hipMemcpyDeviceToDevice, ctx->stream);
+            else if (carried64 && cols[j] == carry64 && val) he = hipMemcpyAsync(res->cols[j].data, val, (size_t)db->n * 4, hipMemcpyDeviceToDevice, ctx->stream);
+            else rc = k_gather(ctx, db->cols[cols[j]].data, esz, perm, res->cols[j].data, db->n);
+            if (he != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "sort: copy failed");
+        }
+        if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "sort: kernels failed");
+        hark_free(ctx, perm);
+        if (!keys_taken) hark_free(ctx, keys64);
+        if (!val_taken) hark_free(ctx, val);
+        if (rc) { result_release(ctx, res); return rc; }
+        *out = res;
+        return HARK_OK;
+    }
     const bool key_from_words = kdt == HARK_U32 || kdt == HARK_I32;
     int carry = -1, others = 0;
     for (int64_t j = 0; j < k; j++) {
