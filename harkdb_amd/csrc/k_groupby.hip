@@ -23,6 +23,7 @@
 int k_argsort_column(hark_context *ctx, const void *col, int dtype, int64_t n, bool descending,
                      uint32_t **perm_out, uint32_t **sorted_words_out);
 int k_gather(hark_context *ctx, const void *src, int esz, const uint32_t *idx, void *dst, int64_t n);
+int k_argsort_i64_keys(hark_context *ctx, const void *col, int64_t n, uint32_t **perm_out, uint64_t **keys_out, const uint32_t *valcol, uint32_t **val_out, int *unique_out);
 int k_sort_column(hark_context *ctx, const void *col, int dtype, int64_t n, bool descending, const uint32_t *payload,
                   uint32_t **vals_out, uint32_t **words_out);
 int k_exclusive_scan_u32(hark_context *ctx, const uint32_t *in, int64_t n, uint32_t *out32, int64_t *out64, int64_t *total_host);
@@ -97,6 +98,12 @@ __device__ __forceinline__ u64 load_as_acc(const void *col, int dtype, uint32_t 
     case HARK_F32: return d2u((double)static_cast<const float *>(col)[r]);
     default: return static_cast<const u64 *>(col)[r];
     }
+}
+
+__global__ __launch_bounds__(256) void unbias_u64_kernel(uint64_t *__restrict__ keys, int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) keys[i] ^= 0x8000000000000000ull;
 }
 
 __global__ __launch_bounds__(256) void fill_u64_kernel(u64 *__restrict__ dst, int64_t n, u64 v)
@@ -386,10 +393,28 @@ int grouped_aggregate(hark_context *ctx, const hark_table *db, int key_col, int 
         if (carry < 0) carry = a.col;
         one_col = one_col && a.col == carry && hark_dtype_size(db->cols[a.col].dtype) == 4;
     }
-    const bool carried = one_col && carry >= 0;
-    int rc = k_sort_column(ctx, db->cols[key_col].data, key_dtype, n, false,
+    bool carried = one_col && carry >= 0;
+    int rc = HARK_OK;
+    bool keys64 = false;
+    if (key_dtype == HARK_I64 && n >= 4096) {
+        // i64 keys: the sort hands back the sorted keys (biased by 2^63: equality tests and the emitted keys below undo it)
+        // and, when every aggregate reads one 4-byte column, that column in sorted order -- no gather of either
+        bool one64 = carry >= 0;
+        for (const AggSpec &a : aggs) one64 = one64 && (a.count_mode || (a.col == carry && hark_dtype_size(db->cols[a.col].dtype) == 4));
+        uint64_t *k64 = nullptr;
+        uint32_t *val = nullptr;
+        rc = k_argsort_i64_keys(ctx, db->cols[key_col].data, n, &perm, &k64, one64 ? static_cast<const uint32_t *>(db->cols[carry].data) : nullptr,
+                                one64 ? &val : nullptr, nullptr);
+        if (!rc) {
+            unbias_u64_kernel<<<grid_for(ctx, n), 256, 0, st>>>(k64, n);
+            sorted_keys = k64; keys64 = true;
+            if (one64 && val) { hark_free(ctx, perm); perm = val; carried = true; }      // `perm` now holds the column in sorted order
+        } else hark_free(ctx, k64);
+    } else
+    rc = k_sort_column(ctx, db->cols[key_col].data, key_dtype, n, false,
                            carried ? static_cast<const uint32_t *>(db->cols[carry].data) : nullptr, &perm, from_words ? &words : nullptr);
-    if (!rc && from_words) { sorted_keys = words; words = nullptr; }       // integer keys: the sorted words ARE the sorted keys
+    if (keys64) { }
+    else if (!rc && from_words) { sorted_keys = words; words = nullptr; }       // integer keys: the sorted words ARE the sorted keys
     else if (!rc) {
         rc = hark_alloc(ctx, &sorted_keys, (size_t)n * kesz);
         if (!rc) rc = k_gather(ctx, db->cols[key_col].data, kesz, perm, sorted_keys, n);

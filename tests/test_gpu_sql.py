@@ -125,6 +125,28 @@ def test_sparse_int_keys_hash_path(where):
     assert np.array_equal(cols[6], g.p.max().to_numpy())            # (min(p) and max(p), sum(w) and max(w) share a hash partition each)
 
 
+@pytest.mark.parametrize("spread", [True, False])
+def test_groupby_i64_keys_at_size(spread):
+    """GROUP BY an i64 column (the sort path): the sort hands back the sorted keys, and the aggregated column in sorted order
+    when every aggregate reads the same 4-byte column (keys spread over 64 bits: tuples; keys below 2^40: the permutation
+    paths); two different columns go through the row ids."""
+    from harkdb_amd import FutharkContext
+    c = FutharkContext(sql_mode=True)
+    rng = np.random.default_rng(8 + int(spread))
+    n = 200_003
+    pool = rng.integers(-2**62, 2**62, size=30_000) if spread else rng.integers(-2**39, 2**39, size=30_000)
+    df = pd.DataFrame({"big": pool[rng.integers(0, len(pool), n)].astype(np.int64), "v": rng.integers(0, 16, n).astype(np.float32),
+                       "w": rng.integers(-100, 100, n).astype(np.int32)})
+    c.create_table("b", df)
+    g = df.groupby("big")
+    _, cols = c.sql_columns("select big, sum(w), min(w), count(*) from b group by big")
+    assert np.array_equal(cols[0], g.w.sum().index.to_numpy()) and cols[0].dtype == np.int64
+    assert np.array_equal(cols[1], g.w.sum().to_numpy()) and np.array_equal(cols[2], g.w.min().to_numpy()) and np.array_equal(cols[3], g.w.count().to_numpy())
+    _, cols = c.sql_columns("select big, avg(v), max(w) from b group by big")
+    assert np.array_equal(cols[0], g.v.mean().index.to_numpy())
+    assert np.allclose(cols[1], g.v.mean().to_numpy(), rtol=1e-6) and np.array_equal(cols[2], g.w.max().to_numpy())
+
+
 def test_groupby_negative_and_int64_keys(fc):
     df = fc._df
     _, cols = fc.sql_columns("select w, count(*) from t group by w")
