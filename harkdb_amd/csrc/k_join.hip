@@ -25,6 +25,7 @@ int k_argsort_column(hark_context *ctx, const void *col, int dtype, int64_t n, b
                      uint32_t **perm_out, uint32_t **sorted_words_out);
 int k_gather(hark_context *ctx, const void *src, int esz, const uint32_t *idx, void *dst, int64_t n);
 int k_argsort_i64_keys(hark_context *ctx, const void *col, int64_t n, uint32_t **perm_out, uint64_t **keys_out, const uint32_t *valcol, uint32_t **val_out, int *unique_out);
+int k_argsort_i64_desc_tuples(hark_context *ctx, const void *col, int64_t n, uint32_t **perm_out, uint64_t **keys_out, const uint32_t *valcol, uint32_t **val_out, bool *done);
 int k_sort_column(hark_context *ctx, const void *col, int dtype, int64_t n, bool descending, const uint32_t *payload,
                   uint32_t **vals_out, uint32_t **words_out);
 int k_exclusive_scan_u32(hark_context *ctx, const uint32_t *in, int64_t n, uint32_t *out32, int64_t *out64, int64_t *total_host);
@@ -484,10 +485,10 @@ int hark_entry_join(hark_context *ctx, hark_result **out, const hark_table *db1,
 }
 
 namespace {
-__global__ __launch_bounds__(256) void unbias_i64_kernel(uint64_t *__restrict__ keys, int64_t n)
+__global__ __launch_bounds__(256) void unbias_i64_kernel(uint64_t *__restrict__ keys, int64_t n, uint64_t xorm)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) keys[i] ^= 0x8000000000000000ull;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) keys[i] ^= xorm;
 }
 } // namespace
 
@@ -512,7 +513,7 @@ int hark_entry_sort(hark_context *ctx, hark_result **out, const hark_table *db, 
     // Ascending i64 keys: the sort hands back the SORTED KEYS themselves (and one 4-byte column that travelled with them when
     // the high words differ: k_argsort_i64_keys) -- the key column and that column are then not gathered through the row ids
     // (two random reads per row: most of an ORDER BY on an i64 key).
-    if (kdt == HARK_I64 && !descending && db->n >= 4096) {
+    for (int attempt = 0; attempt < 1 && kdt == HARK_I64 && db->n >= 4096; attempt++) {      // (a block to leave: descending keys may decline)
         int carry64 = -1, others64 = 0;
         for (int64_t j = 0; j < k; j++) {
             if (cols[j] == key_col) continue;
@@ -523,10 +524,16 @@ int hark_entry_sort(hark_context *ctx, hark_result **out, const hark_table *db, 
         const bool carried64 = others64 == 1 && hark_dtype_size(db->cols[carry64].dtype) == 4;
         uint32_t *perm = nullptr, *val = nullptr;
         uint64_t *keys64 = nullptr;
-        int rc = k_argsort_i64_keys(ctx, db->cols[key_col].data, db->n, &perm, &keys64,
-                                    carried64 ? static_cast<const uint32_t *>(db->cols[carry64].data) : nullptr, carried64 ? &val : nullptr, nullptr);
+        int rc;
+        if (descending) {                                   // the tuple passes on the complemented keys, or nothing (the general path below)
+            bool done = false;
+            rc = k_argsort_i64_desc_tuples(ctx, db->cols[key_col].data, db->n, &perm, &keys64,
+                                           carried64 ? static_cast<const uint32_t *>(db->cols[carry64].data) : nullptr, carried64 ? &val : nullptr, &done);
+            if (!rc && !done) break;
+        } else rc = k_argsort_i64_keys(ctx, db->cols[key_col].data, db->n, &perm, &keys64,
+                                       carried64 ? static_cast<const uint32_t *>(db->cols[carry64].data) : nullptr, carried64 ? &val : nullptr, nullptr);
         if (!rc) {
-            unbias_i64_kernel<<<grid_for(ctx, db->n), 256, 0, ctx->stream>>>(keys64, db->n);
+            unbias_i64_kernel<<<grid_for(ctx, db->n), 256, 0, ctx->stream>>>(keys64, db->n, descending ? 0x7FFFFFFFFFFFFFFFull : 0x8000000000000000ull);
             if (hipGetLastError() != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "sort: launch failed");
         }
         bool keys_taken = false, val_taken = false;

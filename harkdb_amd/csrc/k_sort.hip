@@ -676,7 +676,7 @@ constexpr size_t tuple_scatter_lds() { return (size_t)GeoTuple::T * GeoTuple::R 
 
 template <bool FIRST>
 __global__ __launch_bounds__(GeoTuple::T) void tuple_hist_kernel(const uint64_t *__restrict__ col, const uint4 *__restrict__ tin, int64_t n, int64_t slice,
-                                                                 int shift, uint32_t *__restrict__ hist, int nblk)
+                                                                 int shift, uint32_t *__restrict__ hist, int nblk, uint64_t xorm)
 {
     const int sh = shift & 255;
     const uint32_t dmask = (shift >> 8) ? (1u << (shift >> 8)) - 1u : 255u;
@@ -686,7 +686,7 @@ __global__ __launch_bounds__(GeoTuple::T) void tuple_hist_kernel(const uint64_t 
     const int64_t lo = (int64_t)blockIdx.x * slice;
     const int64_t hi = lo + slice < n ? lo + slice : n;
     for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        const uint32_t w = FIRST ? (uint32_t)(col[i] >> 32) ^ 0x80000000u : tin[i].y;
+        const uint32_t w = FIRST ? (uint32_t)((col[i] ^ xorm) >> 32) : tin[i].y;
         atomicAdd(&s_hist[(w >> sh) & dmask], 1u);
     }
     __syncthreads();
@@ -697,7 +697,8 @@ __global__ __launch_bounds__(GeoTuple::T) void tuple_hist_kernel(const uint64_t 
 template <bool FIRST>
 __global__ __launch_bounds__(GeoTuple::T) void tuple_scatter_kernel(
     const uint64_t *__restrict__ col, const uint32_t *__restrict__ valcol, const uint4 *__restrict__ tin, uint4 *__restrict__ tout,
-    int64_t n, int64_t slice, int shift, const uint32_t *__restrict__ hist, int nblk, const uint32_t *__restrict__ row_total)
+    int64_t n, int64_t slice, int shift, const uint32_t *__restrict__ hist, int nblk, const uint32_t *__restrict__ row_total,
+    uint64_t xorm /* FIRST: the keys enter as key ^ xorm (2^63: ascending signed order; its complement: descending) */)
 {
     const int sh = shift & 255;
     const uint32_t dmask = (shift >> 8) ? (1u << (shift >> 8)) - 1u : 255u;
@@ -739,7 +740,7 @@ __global__ __launch_bounds__(GeoTuple::T) void tuple_scatter_kernel(
         for (int r = 0; r < R; r++) {
             int64_t i = wbase + r * 64 + lane;
             if (!FULL) i = i < hi ? i : hi - 1;
-            if (FIRST) { const u64 k = __builtin_nontemporal_load(col + i) ^ 0x8000000000000000ull; nt[r].x = (uint32_t)k; nt[r].y = (uint32_t)(k >> 32); }
+            if (FIRST) { const u64 k = __builtin_nontemporal_load(col + i) ^ xorm; nt[r].x = (uint32_t)k; nt[r].y = (uint32_t)(k >> 32); }
             else nt[r] = ld_nt16(tin + i);
         }
     };
@@ -1105,7 +1106,8 @@ int k_argsort_column(hark_context *ctx, const void *col, int dtype, int64_t n, b
 // When the high words differ, key, row id and the column's value travel through the passes as 16-byte tuples
 // (sort_i64_tuples): no random read anywhere.  On the other paths *val_out is a gather through the permutation.
 static int sort_i64_tuples(hark_context *ctx, const void *col, int64_t n, uint32_t diff_hi, const uint32_t *valcol,
-                           uint64_t *keys, uint32_t **perm_out, uint32_t **val_out, bool *done, int *unique_out)
+                           uint64_t *keys, uint32_t **perm_out, uint32_t **val_out, bool *done, int *unique_out,
+                           uint64_t xorm = 0x8000000000000000ull /* keys_out holds key ^ xorm, ascending */)
 {
     *done = false;
     if (n > 0xFFFFFFFFll) return HARK_OK;                          // 32-bit positions and row ids (the general path reports the limit)
@@ -1146,11 +1148,11 @@ static int sort_i64_tuples(hark_context *ctx, const void *col, int64_t n, uint32
     for (int pi = 0; pi < np && he == hipSuccess; pi++) {
         const int shift = plan[pi].shift | (plan[pi].width << 8);
         const dim3 grid((unsigned)nblk), block(GeoTuple::T);
-        if (pi == 0) tuple_hist_kernel<true><<<grid, block, 0, st>>>(c64, nullptr, n, slice, shift, ws, (int)nblk);
-        else tuple_hist_kernel<false><<<grid, block, 0, st>>>(nullptr, tin, n, slice, shift, ws, (int)nblk);
+        if (pi == 0) tuple_hist_kernel<true><<<grid, block, 0, st>>>(c64, nullptr, n, slice, shift, ws, (int)nblk, xorm);
+        else tuple_hist_kernel<false><<<grid, block, 0, st>>>(nullptr, tin, n, slice, shift, ws, (int)nblk, xorm);
         scan_hist_rows_kernel<<<dim3(kBins), dim3(256), 0, st>>>(ws, (int)nblk, row_total);
-        if (pi == 0) tuple_scatter_kernel<true><<<grid, block, lds, st>>>(c64, val ? valcol : nullptr, nullptr, tout, n, slice, shift, ws, (int)nblk, row_total);
-        else tuple_scatter_kernel<false><<<grid, block, lds, st>>>(nullptr, nullptr, tin, tout, n, slice, shift, ws, (int)nblk, row_total);
+        if (pi == 0) tuple_scatter_kernel<true><<<grid, block, lds, st>>>(c64, val ? valcol : nullptr, nullptr, tout, n, slice, shift, ws, (int)nblk, row_total, xorm);
+        else tuple_scatter_kernel<false><<<grid, block, lds, st>>>(nullptr, nullptr, tin, tout, n, slice, shift, ws, (int)nblk, row_total, xorm);
         he = hipGetLastError();
         tin = tout; tout = tout == ta ? tb : ta;
     }
@@ -1169,6 +1171,25 @@ static int sort_i64_tuples(hark_context *ctx, const void *col, int64_t n, uint32
     *perm_out = perm;
     if (val_out) *val_out = val;
     *done = true;
+    return HARK_OK;
+}
+
+// Stable DESCENDING argsort of an i64 column by the tuple passes only: *keys_out holds ~(key ^ 2^63) ascending (the caller
+// undoes it), *done = false when the tuple path does not apply (equal high words, a long run of equal prefixes, no room) --
+// nothing is returned then and the caller takes its general path.
+int k_argsort_i64_desc_tuples(hark_context *ctx, const void *col, int64_t n, uint32_t **perm_out, uint64_t **keys_out, const uint32_t *valcol, uint32_t **val_out, bool *done)
+{
+    *perm_out = nullptr; *keys_out = nullptr; *done = false;
+    if (val_out) *val_out = nullptr;
+    if (n <= 0) return HARK_OK;
+    uint32_t diff_hi = 0u;
+    HARK_TRY(k_transform_keys(ctx, col, HARK_I64, 1, nullptr, n, &diff_hi));      // (the bits in which the high words differ: the same either way)
+    if (passes_of(diff_hi) == 0u || getenv("HARK_SORT_NO_TUPLES")) return HARK_OK;
+    uint64_t *keys = nullptr;
+    HARK_TRY(hark_alloc(ctx, (void **)&keys, (size_t)n * 8));
+    const int rc = sort_i64_tuples(ctx, col, n, diff_hi, valcol, keys, perm_out, val_out, done, nullptr, 0x7FFFFFFFFFFFFFFFull);
+    if (rc || !*done) { hark_free(ctx, keys); return rc; }
+    *keys_out = keys;
     return HARK_OK;
 }
 

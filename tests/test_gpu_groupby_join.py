@@ -207,7 +207,8 @@ def test_sort_is_stable_and_ordered(eng, oracle, dtype, descending, n):
 
 @pytest.mark.parametrize("n", [4096, 6144, 100_003, 1_300_001])
 @pytest.mark.parametrize("kind", ["spread", "runs", "narrow_hi", "negative_cluster"])
-def test_i64_sort_by_high_words(eng, n, kind):
+@pytest.mark.parametrize("descending", [False, True])
+def test_i64_sort_by_high_words(eng, n, kind, descending):
     """i64 keys whose high words differ travel through the passes as 16-byte tuples (sorted by the top bits of the high
     word, runs of equal prefixes fixed up in registers); a run longer than 16 falls back to the eight-pass sort.  Stable
     against numpy either way."""
@@ -224,8 +225,9 @@ def test_i64_sort_by_high_words(eng, n, kind):
     key = key.astype(np.int64)
     rowid = np.arange(n, dtype=np.int32)
     t = eng.table_from_columns([key, rowid])
-    res = eng.sort(t, 0, [0, 1])
-    perm = np.argsort(key, kind="stable")
+    res = eng.sort(t, 0, [0, 1], descending=descending)
+    # descending and stable: ascending by the complemented key (equal keys keep their order)
+    perm = np.argsort(~key if descending else key, kind="stable")
     assert np.array_equal(res.column(1), rowid[perm]) and np.array_equal(res.column(0), key[perm])
     res.free(); t.free()
 
