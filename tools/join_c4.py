@@ -10,7 +10,7 @@ dev = torch.device("cuda", 0)
 eng = Engine(0)
 SEED = 0x4861726B4442
 n4, s4 = int(1.25e8 * scale), int(1.25e7 * scale)
-mul = -7046029254386353131
+mul = int(os.environ.get("C4_MUL", "-7046029254386353131"))
 bk = torch.arange(s4, dtype=torch.int64, device=dev) * mul
 j = torch.empty((n4 + 3) // 4 * 4, dtype=torch.int32, device=dev)
 eng.gen_columns(SEED + 21, 0, n4, 2 * s4, True, None, j.data_ptr(), None)
