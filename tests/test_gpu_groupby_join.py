@@ -232,6 +232,26 @@ def test_i64_sort_by_high_words(eng, n, kind, descending):
     res.free(); t.free()
 
 
+@pytest.mark.parametrize("cols", [[0], [1], [1, 0, 1, 0], [2, 1], [0, 1, 2], [2, 0, 0], []])
+@pytest.mark.parametrize("descending", [False, True])
+def test_i64_sort_projections(eng, cols, descending):
+    """ORDER BY an i64 key: the sorted keys and ONE carried 4-byte column are the sort's own outputs (first use takes the
+    buffer, a repeat copies it), anything else -- an 8-byte column, a second column -- is gathered through the row ids."""
+    rng = np.random.default_rng(len(cols) * 2 + int(descending))
+    n = 20_011
+    key = rng.integers(-2**62, 2**62, size=n).astype(np.int64)
+    key[rng.integers(0, n, size=n // 10)] = key[3]
+    a, b = rng.integers(-2**31, 2**31, size=n).astype(np.int32), rng.integers(-2**62, 2**62, size=n).astype(np.int64)
+    src = [key, a, b]
+    t = eng.table_from_columns(src)
+    res = eng.sort(t, 0, cols, descending=descending)
+    perm = np.argsort(~key if descending else key, kind="stable")
+    assert res.shape == (n, len(cols))
+    for j, c in enumerate(cols):
+        assert np.array_equal(res.column(j), src[c][perm]), (j, c)
+    res.free(); t.free()
+
+
 @pytest.mark.parametrize("dtype", [np.uint32, np.int32, np.float32])
 @pytest.mark.parametrize("cols", [[0], [1], [1, 0, 1, 0], [2, 1], [0, 1, 2], [2, 0, 0]])
 @pytest.mark.parametrize("descending", [False, True])
