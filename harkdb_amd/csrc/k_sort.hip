@@ -693,15 +693,45 @@ __global__ __launch_bounds__(GeoTuple::T) void tuple_hist_kernel(const uint64_t 
     if (threadIdx.x < kBins) hist[(size_t)threadIdx.x * nblk + blockIdx.x] = s_hist[threadIdx.x];
 }
 
+// The histogram of a pass over tuples reads 16 bytes per tuple for one digit.  The pass before it knows the digit of
+// every tuple it places: it writes that digit as ONE BYTE beside the tuple (tuple_scatter_kernel<.., true>), and the
+// histogram reads n bytes instead of 16 n (10^8 tuples: 0.27 ms -> 0.03 ms per pass).
+__global__ __launch_bounds__(GeoTuple::T) void digit_byte_hist_kernel(const uint8_t *__restrict__ dig, int64_t n, int64_t slice, uint32_t *__restrict__ hist, int nblk)
+{
+    __shared__ uint32_t s_hist[kBins];
+    if (threadIdx.x < kBins) s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t lo = (int64_t)blockIdx.x * slice;                 // (a multiple of the tile: 16-byte loads are aligned)
+    const int64_t hi = lo + slice < n ? lo + slice : n;
+    const int64_t nvec = (hi - lo) / 16;
+    const uint4 *d4 = reinterpret_cast<const uint4 *>(dig + lo);
+    for (int64_t i = threadIdx.x; i < nvec; i += blockDim.x) {
+        const uint4 q = ld_nt16(d4 + i);
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            atomicAdd(&s_hist[w[j] & 255u], 1u); atomicAdd(&s_hist[(w[j] >> 8) & 255u], 1u);
+            atomicAdd(&s_hist[(w[j] >> 16) & 255u], 1u); atomicAdd(&s_hist[w[j] >> 24], 1u);
+        }
+    }
+    for (int64_t i = lo + nvec * 16 + threadIdx.x; i < hi; i += blockDim.x) atomicAdd(&s_hist[dig[i]], 1u);
+    __syncthreads();
+    if (threadIdx.x < kBins) hist[(size_t)threadIdx.x * nblk + blockIdx.x] = s_hist[threadIdx.x];
+}
+
 // FIRST: the tuples are built from the key column (biased by 2^63), the row id and valcol (may be null: zero).
-template <bool FIRST>
+// DIG: the NEXT pass's digit of every tuple goes out as a byte beside it (dig_out[pos], shift / width in next_shift).
+template <bool FIRST, bool DIG>
 __global__ __launch_bounds__(GeoTuple::T) void tuple_scatter_kernel(
     const uint64_t *__restrict__ col, const uint32_t *__restrict__ valcol, const uint4 *__restrict__ tin, uint4 *__restrict__ tout,
     int64_t n, int64_t slice, int shift, const uint32_t *__restrict__ hist, int nblk, const uint32_t *__restrict__ row_total,
-    uint64_t xorm /* FIRST: the keys enter as key ^ xorm (2^63: ascending signed order; its complement: descending) */)
+    uint64_t xorm /* FIRST: the keys enter as key ^ xorm (2^63: ascending signed order; its complement: descending) */,
+    uint8_t *__restrict__ dig_out, int next_shift)
 {
     const int sh = shift & 255;
     const uint32_t dmask = (shift >> 8) ? (1u << (shift >> 8)) - 1u : 255u;
+    const int nsh = next_shift & 255;
+    const uint32_t nmask = (next_shift >> 8) ? (1u << (next_shift >> 8)) - 1u : 255u;
     constexpr int T = GeoTuple::T, W = T / 64, R = GeoTuple::R, TILE = T * R;
     typedef unsigned long long u64;
     extern __shared__ __attribute__((aligned(16))) unsigned char sort_lds[];
@@ -816,14 +846,18 @@ __global__ __launch_bounds__(GeoTuple::T) void tuple_scatter_kernel(
             for (int r = 0; r < R; r++) {
                 const int slot = tid + r * T;
                 const uint4 t = s_t[slot];
-                tout[(uint32_t)slot + s_delta[(t.y >> sh) & dmask]] = t;
+                const uint32_t pos = (uint32_t)slot + s_delta[(t.y >> sh) & dmask];
+                tout[pos] = t;
+                if (DIG) dig_out[pos] = (uint8_t)((t.y >> nsh) & nmask);
                 if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
         } else {
             const int tile_n = (int)(hi - tbase);
             for (int slot = tid; slot < tile_n; slot += T) {
                 const uint4 t = s_t[slot];
-                tout[(uint32_t)slot + s_delta[(t.y >> sh) & dmask]] = t;
+                const uint32_t pos = (uint32_t)slot + s_delta[(t.y >> sh) & dmask];
+                tout[pos] = t;
+                if (DIG) dig_out[pos] = (uint8_t)((t.y >> nsh) & nmask);
             }
         }
     };
@@ -1132,15 +1166,23 @@ static int sort_i64_tuples(hark_context *ctx, const void *col, int64_t n, uint32
     if (!rc) rc = hark_alloc(ctx, (void **)&flag, 16);
     if (!rc) rc = hark_alloc(ctx, (void **)&perm, (size_t)n * 4);
     if (!rc && valcol && val_out) rc = hark_alloc(ctx, (void **)&val, (size_t)n * 4);
+    uint8_t *dig[2] = {nullptr, nullptr};                          // the next pass's digits, one byte per tuple (two buffers in turn)
+    if (!rc && np > 1 && !getenv("HARK_SORT_NO_DIGIT_BYTES")) {
+        rc = hark_alloc(ctx, (void **)&dig[0], (size_t)n + 16);
+        if (!rc && np > 2) rc = hark_alloc(ctx, (void **)&dig[1], (size_t)n + 16);
+        if (!rc && np <= 2) dig[1] = nullptr;
+    }
     auto cleanup = [&](bool keep) {
-        hark_free(ctx, ta); hark_free(ctx, tb); hark_free(ctx, ws); hark_free(ctx, flag);
+        hark_free(ctx, ta); hark_free(ctx, tb); hark_free(ctx, ws); hark_free(ctx, flag); hark_free(ctx, dig[0]); hark_free(ctx, dig[1]);
         if (!keep) { hark_free(ctx, perm); hark_free(ctx, val); }
     };
     if (rc == HARK_ENOMEM) { cleanup(false); ctx->err.clear(); return HARK_OK; }      // the permutation path needs half the room
     if (rc) { cleanup(false); return rc; }
     const size_t lds = tuple_scatter_lds();
-    hipError_t he = hipFuncSetAttribute(reinterpret_cast<const void *>(&tuple_scatter_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (he == hipSuccess) he = hipFuncSetAttribute(reinterpret_cast<const void *>(&tuple_scatter_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t he = hipFuncSetAttribute(reinterpret_cast<const void *>(&tuple_scatter_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (he == hipSuccess) he = hipFuncSetAttribute(reinterpret_cast<const void *>(&tuple_scatter_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (he == hipSuccess) he = hipFuncSetAttribute(reinterpret_cast<const void *>(&tuple_scatter_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (he == hipSuccess) he = hipFuncSetAttribute(reinterpret_cast<const void *>(&tuple_scatter_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     uint32_t *row_total = ws + (size_t)kBins * nblk;
     const uint64_t *c64 = static_cast<const uint64_t *>(col);
     const uint4 *tin = nullptr;
@@ -1148,11 +1190,18 @@ static int sort_i64_tuples(hark_context *ctx, const void *col, int64_t n, uint32
     for (int pi = 0; pi < np && he == hipSuccess; pi++) {
         const int shift = plan[pi].shift | (plan[pi].width << 8);
         const dim3 grid((unsigned)nblk), block(GeoTuple::T);
+        // this pass's histogram: from the key column (first pass), or from the digit bytes the pass before wrote
         if (pi == 0) tuple_hist_kernel<true><<<grid, block, 0, st>>>(c64, nullptr, n, slice, shift, ws, (int)nblk, xorm);
+        else if (dig[(pi - 1) & 1]) digit_byte_hist_kernel<<<grid, block, 0, st>>>(dig[(pi - 1) & 1], n, slice, ws, (int)nblk);
         else tuple_hist_kernel<false><<<grid, block, 0, st>>>(nullptr, tin, n, slice, shift, ws, (int)nblk, xorm);
         scan_hist_rows_kernel<<<dim3(kBins), dim3(256), 0, st>>>(ws, (int)nblk, row_total);
-        if (pi == 0) tuple_scatter_kernel<true><<<grid, block, lds, st>>>(c64, val ? valcol : nullptr, nullptr, tout, n, slice, shift, ws, (int)nblk, row_total, xorm);
-        else tuple_scatter_kernel<false><<<grid, block, lds, st>>>(nullptr, nullptr, tin, tout, n, slice, shift, ws, (int)nblk, row_total, xorm);
+        const bool more = pi + 1 < np && dig[pi & 1] != nullptr;
+        const int next_shift = pi + 1 < np ? (plan[pi + 1].shift | (plan[pi + 1].width << 8)) : 0;
+        uint8_t *dout = more ? dig[pi & 1] : nullptr;
+        if (pi == 0 && more) tuple_scatter_kernel<true, true><<<grid, block, lds, st>>>(c64, val ? valcol : nullptr, nullptr, tout, n, slice, shift, ws, (int)nblk, row_total, xorm, dout, next_shift);
+        else if (pi == 0) tuple_scatter_kernel<true, false><<<grid, block, lds, st>>>(c64, val ? valcol : nullptr, nullptr, tout, n, slice, shift, ws, (int)nblk, row_total, xorm, nullptr, 0);
+        else if (more) tuple_scatter_kernel<false, true><<<grid, block, lds, st>>>(nullptr, nullptr, tin, tout, n, slice, shift, ws, (int)nblk, row_total, xorm, dout, next_shift);
+        else tuple_scatter_kernel<false, false><<<grid, block, lds, st>>>(nullptr, nullptr, tin, tout, n, slice, shift, ws, (int)nblk, row_total, xorm, nullptr, 0);
         he = hipGetLastError();
         tin = tout; tout = tout == ta ? tb : ta;
     }
