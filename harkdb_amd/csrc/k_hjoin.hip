@@ -343,9 +343,9 @@ __global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTrai
     uint32_t *qval_all = qrow_all + (kJThreads / 64) * QCAP;                   // [16 waves][QCAP] their fourth words (16-byte entries)
     uint32_t *s_coarse = qval_all + (sizeof(E) == 16 ? (kJThreads / 64) * QCAP : 0);   // [kCoarse] survivors per group of 2^gs ranks (for the order kernel)
     // a radix index over the round's keys: s_idx[k] = first key whose (key - first key) >> S is >= k.  A search then starts
-    // in a span of m / 2048 keys (a dozen when the keys are spread evenly) instead of all m: measured on BASELINE
-    // configs[3]'s share, the 15 DEPENDENT LDS reads of a full binary search per batch of 64 candidates were 445 us of
-    // the kernel's 950 -- four waves per SIMD do not hide 15 x 200 cycles
+    // in a span of m / 2048 keys (a dozen when the keys are spread evenly) instead of all m: ~5 dependent LDS reads per batch
+    // of 64 candidates instead of 16.  (Neither this nor the skew above moved the kernel's time on BASELINE configs[3]'s
+    // share -- the lookup is not what it waits for, profiles/r03_notes.md 5.1 -- but both take load off the LDS.)
     uint16_t *s_idx = reinterpret_cast<uint16_t *>(s_coarse + kCoarse);                 // [kJIdx + 1]
     __shared__ uint32_t s_n;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = kJThreads >> 6;
