@@ -112,11 +112,28 @@ def cpu_baseline(rows, G, exact):
             "algorithm": "oracle/hark_oracle.c ora_filter_groupby_refalgo_f32 = groupby.fut:8-58 + segmented.fut:7-37"}, (keys, sums, counts)
 
 
-def measure_traffic(N, G, timeout_s=240):
+def under_profiler(env=None):
+    """True when this process already runs under rocprofv3 / rocprofiler-sdk (its preload and ROCP_* variables would
+    leak into a nested rocprofv3)."""
+    env = os.environ if env is None else env
+    return any(kk.startswith(("ROCP_", "ROCPROF")) for kk in env) or "rocprof" in env.get("LD_PRELOAD", "")
+
+
+def headline_launches(values):
+    """The counter values of the HEADLINE launches among all launches of one kernel in a profiled child: a launch that
+    moved less than half of the largest launch's bytes is not a pass over the N-row workload (e.g. a small setup launch
+    that loads the code objects) and must not dilute the per-launch mean."""
+    top = max(values)
+    return [x for x in values if x >= 0.5 * top]
+
+
+def measure_traffic(N, G, timeout_s=240, steps=2, warmup=1):
     """HBM bytes per launch of the path's kernels, measured NOW: two child runs of this script's headline steps under
     `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (one counter per run, with --kernel-trace only, as
     MI355X_MICROARCH.md prescribes), FETCH_SIZE doubled per that guide's gfx950 note.  Children, not an exec: this
-    process has initialised the GPU.  Returns (dict, None) or (None, reason)."""
+    process has initialised the GPU.  The child (--pmc-child) launches the path's kernels for its warm-up and timed
+    steps only (no setup launch); every launch counted must be a full pass (headline_launches) and there must be
+    exactly steps + warmup of them per kernel and chunk.  Returns (dict, None) or (None, reason)."""
     import collections
     import csv
     import glob
@@ -127,16 +144,19 @@ def measure_traffic(N, G, timeout_s=240):
     exe = shutil.which("rocprofv3")
     if not exe:
         return None, "rocprofv3 not on PATH"
+    if under_profiler():
+        return None, "this process runs under a profiler already: no nested rocprofv3"
     tmp = tempfile.mkdtemp(prefix="hark_pmc_", dir="/tmp")
     kernels = collections.defaultdict(dict)
     try:
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, ctr)
             cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
-                   "--pmc-child", "1", "--rows", str(N), "--groups", str(G), "--steps", "2", "--warmup", "1", "--cpu-rows", "0", "--configs", "0"]
-            env = dict(os.environ, TMPDIR="/tmp")
-            for kk in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "HARK_FORCE_PIPELINE"):
-                env.pop(kk, None)
+                   "--pmc-child", "1", "--rows", str(N), "--groups", str(G), "--steps", str(steps), "--warmup", str(warmup),
+                   "--cpu-rows", "0", "--configs", "0", "--pmc", "0"]
+            env = {kk: vv for kk, vv in os.environ.items()
+                   if not kk.startswith(("ROCP_", "ROCPROF")) and kk not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "HARK_FORCE_PIPELINE", "LD_PRELOAD")}
+            env["TMPDIR"] = "/tmp"
             pr = subprocess.Popen(cmd, cwd=tmp, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, start_new_session=True)
             try:
                 _, err = pr.communicate(timeout=timeout_s)
@@ -147,21 +167,27 @@ def measure_traffic(N, G, timeout_s=240):
             if pr.returncode:
                 return None, f"rocprofv3 --pmc {ctr} child failed (rc {pr.returncode}): {err.decode(errors='replace')[-300:]}"
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
-            if not files:
-                return None, f"rocprofv3 --pmc {ctr}: no counter_collection.csv"
+            if len(files) != 1:
+                return None, f"rocprofv3 --pmc {ctr}: {len(files)} counter_collection.csv files (want exactly one)"
             agg = collections.defaultdict(list)
             for r in csv.DictReader(open(files[0])):
                 m = re.search(r"(fgb_(?:part|agg6|agg|lds)\w*)", r["Kernel_Name"])
                 if m and r.get("Counter_Name", ctr) == ctr:
                     agg[m.group(1)].append(float(r["Counter_Value"]))
             for kn, vals in agg.items():
-                kernels[kn][ctr + "_KiB_mean_per_launch"] = sum(vals) / len(vals)
-                kernels[kn]["launches_profiled"] = len(vals)
+                full = headline_launches(vals)
+                kernels[kn][ctr + "_KiB_mean_per_launch"] = sum(full) / len(full)
+                kernels[kn][ctr + "_launches_profiled"] = len(full)
+                kernels[kn][ctr + "_launches_dropped_as_small"] = len(vals) - len(full)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     if not kernels:
         return None, "no fgb_* kernel rows in the counter files"
     for kn, dd in kernels.items():
+        lp = {dd.get("FETCH_SIZE_launches_profiled"), dd.get("WRITE_SIZE_launches_profiled")}
+        if len(lp) != 1 or None in lp or lp.pop() % (steps + warmup):
+            return None, f"{kn}: launches profiled {dd} do not add up to {steps} steps + {warmup} warm-up in both passes"
+        dd["launches_profiled"] = dd["FETCH_SIZE_launches_profiled"]
         dd["hbm_read_bytes"] = 2.0 * dd.get("FETCH_SIZE_KiB_mean_per_launch", 0.0) * 1024.0
         dd["hbm_write_bytes"] = dd.get("WRITE_SIZE_KiB_mean_per_launch", 0.0) * 1024.0
         dd["hbm_bytes_per_launch_corrected"] = dd["hbm_read_bytes"] + dd["hbm_write_bytes"]
@@ -260,6 +286,125 @@ def event_ms(torch, fn, warm=3, reps=10):
     return ts[len(ts) // 2]
 
 
+# ---- the operator workloads behind `configs.*`, one builder each: bench.py times them with HIP events, tools/op_one.py
+#      runs the SAME builders under rocprofv3 (kernel traces, PMC byte counters).  A builder returns
+#      {"run": () -> Result, "bytes": (Result) -> algorithmic bytes, "rows": rows read, "info": {...}, "keep": device data}.
+SPARSE_MUL = 2654435761                                       # odd: g -> g * SPARSE_MUL mod 2^32 is a bijection of the u32 keys
+
+
+def _gen_i32(torch, eng, dev, seed, n, G):
+    t = torch.empty((n + 3) // 4 * 4, dtype=torch.int32, device=dev)
+    eng.gen_columns(seed, 0, n, G, True, None, t.data_ptr(), None)
+    return t[:n]
+
+
+def w_c2(torch, eng, dev, scale=1.0, want="c2"):
+    n2 = int(1e8 * scale) // 4 * 4
+    cols = [torch.empty(n2, dtype=torch.float32, device=dev) for _ in range(8)]
+    for j in range(0, 8, 2):
+        eng.gen_columns(SEED + j, 0, n2, 1 << 20, False, cols[j].data_ptr(), None, cols[j + 1].data_ptr())
+    t8 = eng.table_from_device(n2, [c.data_ptr() for c in cols], [np.float32] * 8, keepalive=cols)
+    if want == "c1":
+        return {"run": lambda: eng.query_sel(t8, [0, 2]), "bytes": lambda r: 16.0 * n2, "rows": n2, "keep": (t8, cols),
+                "info": {"statement": "SELECT c0,c2 FROM t8 (query_sel, main.fut:7)"}}
+    return {"run": lambda: eng.filter_sel(t8, 1, ">", 0.5, [0, 2], want_row_index=True), "bytes": lambda r: 12.0 * n2 + 16.0 * r.shape[0], "rows": n2,
+            "keep": (t8, cols), "info": {"statement": "SELECT rowid,c0,c2 FROM t8 WHERE c1>0.5 (8 f32 columns resident)",
+                                         "bytes_model": "read c0,c1,c2 (12 B/row) + write 2 x f32 + i64 row index per survivor"}}
+
+
+def w_c1(torch, eng, dev, scale=1.0):
+    return w_c2(torch, eng, dev, scale, want="c1")
+
+
+def w_refgb(torch, eng, dev, scale=1.0):
+    n8 = int(1e8 * scale) // 4 * 4
+    ku, au = _gen_i32(torch, eng, dev, SEED, n8, 1 << 20), _gen_i32(torch, eng, dev, SEED + 9, n8, 1 << 16)
+    tu = eng.table_from_device(n8, [ku.data_ptr(), au.data_ptr()], [np.uint32, np.uint32], keepalive=(ku, au))
+    return {"run": lambda: eng.query_groupby(tu, 0, [1, 1], [2, 3]), "bytes": lambda r: 12.0 * n8, "rows": n8, "keep": (tu,),
+            "info": {"statement": "query_groupby(db, 0, [1, 1], [sum, max]) (main.fut:9), 2^20 dense keys",
+                     "note": "one statistics pass (sum + max of ONE column: the column is carried once)"}}
+
+
+def w_refgb_hash(torch, eng, dev, scale=1.0):
+    n8 = int(1e8 * scale) // 4 * 4
+    kd, au = _gen_i32(torch, eng, dev, SEED + 13, n8, 1 << 21), _gen_i32(torch, eng, dev, SEED + 9, n8, 1 << 16)
+    ks = (kd.to(torch.int64) * SPARSE_MUL).to(torch.int32)     # 2^21 distinct keys spread over the whole u32 range
+    del kd
+    th = eng.table_from_device(n8, [ks.data_ptr(), au.data_ptr()], [np.uint32, np.uint32], keepalive=(ks, au))
+    return {"run": lambda: eng.query_groupby(th, 0, [1, 1], [2, 3]), "bytes": lambda r: 12.0 * n8, "rows": n8, "keep": (th,),
+            "info": {"statement": "query_groupby(db, 0, [1, 1], [sum, max]) (main.fut:9), 2^21 distinct u32 keys spread over [0, 2^32)"}}
+
+
+def w_sort(torch, eng, dev, scale=1.0, bits=20):
+    n8 = int(1e8 * scale) // 4 * 4
+    au = _gen_i32(torch, eng, dev, SEED + 9, n8, 1 << 16)
+    if bits == 64:
+        g = torch.Generator(device=dev)
+        g.manual_seed(1)
+        keys = torch.randint(-2**62, 2**62, (n8,), dtype=torch.int64, device=dev, generator=g)
+        t = eng.table_from_device(n8, [keys.data_ptr(), au.data_ptr()], [np.int64, np.int32], keepalive=(keys, au))
+        return {"run": lambda: eng.sort(t, 0, [0, 1]), "bytes": lambda r: 24.0 * n8, "rows": n8, "keep": (t,),
+                "info": {"statement": "ORDER BY an i64 key spread over 63 bits, key + one column out (16-byte tuple sort)"}}
+    ku = _gen_i32(torch, eng, dev, SEED, n8, (1 << bits) if bits < 31 else 0x7FFFFFFF)
+    t = eng.table_from_device(n8, [ku.data_ptr(), au.data_ptr()], [np.uint32, np.uint32], keepalive=(ku, au))
+    return {"run": lambda: eng.sort(t, 0, [0, 1]), "bytes": lambda r: 16.0 * n8, "rows": n8, "keep": (t,),
+            "info": {"statement": f"ORDER BY a {bits}-bit u32 key, key + one column out (stable LSD radix sort)"}}
+
+
+def w_join_u32(torch, eng, dev, scale=1.0):
+    n8 = int(1e8 * scale) // 4 * 4
+    m8 = n8 // 10
+    au = _gen_i32(torch, eng, dev, SEED + 9, n8, 1 << 16)
+    kb8, vb8, kp8 = _gen_i32(torch, eng, dev, SEED + 3, m8, 1 << 30), _gen_i32(torch, eng, dev, SEED + 4, m8, 1 << 16), _gen_i32(torch, eng, dev, SEED + 5, n8, 1 << 30)
+    tp8 = eng.table_from_device(n8, [kp8.data_ptr(), au.data_ptr()], [np.uint32, np.uint32], keepalive=(kp8, au))
+    tb8 = eng.table_from_device(m8, [kb8.data_ptr(), vb8.data_ptr()], [np.uint32, np.uint32], keepalive=(kb8, vb8))
+    return {"run": lambda: eng.join(tp8, tb8, 0, 0, [0, 1], [1]), "bytes": lambda r: 12.0 * (n8 + m8) + 12.0 * r.shape[0], "rows": n8 + m8, "keep": (tp8, tb8),
+            "info": {"probe_rows": n8, "build_rows": m8,
+                     "statement": "join(db1, db2, 0, 0, [0, 1], [1]) (join.fut:52) on u32 keys, ~10 % of the probe rows match"}}
+
+
+def w_join_c4(torch, eng, dev, scale=1.0):
+    n4, s4 = int(1.25e8 * scale), int(1.25e7 * scale)
+    mul = -7046029254386353131                                                       # 0x9E3779B97F4A7C15 as i64: odd, so i -> i*mul is a bijection mod 2^64
+    bk = torch.arange(s4, dtype=torch.int64, device=dev) * mul                       # unique build keys spread over 64 bits
+    j = _gen_i32(torch, eng, dev, SEED + 21, n4, 2 * s4)                             # half of the probe rows find a partner
+    pk = j.to(torch.int64) * mul
+    prow, brow = torch.arange(n4, dtype=torch.int32, device=dev), torch.arange(s4, dtype=torch.int32, device=dev)
+    hits = int((j < s4).sum().item())
+    del j
+    tp = eng.table_from_device(n4, [pk.data_ptr(), prow.data_ptr()], [np.int64, np.int32], keepalive=(pk, prow))
+    tb = eng.table_from_device(s4, [bk.data_ptr(), brow.data_ptr()], [np.int64, np.int32], keepalive=(bk, brow))
+    return {"run": lambda: eng.join(tp, tb, 0, 0, [1], [1]), "bytes": lambda r: 12.0 * (n4 + s4) + 8.0 * hits, "rows": n4 + s4, "keep": (tp, tb),
+            "info": {"probe_rows": n4, "build_rows": s4, "pairs_expected": hits,
+                     "statement": "probe JOIN build ON i64 key -> (probe row id, build row id), reference order (key, left row, right row)",
+                     "note": "1/8 of configs[3]; over 8 GPUs the rows arrive by an all-to-all first (xGMI-bound, DESIGN.md 6)"}}
+
+
+def w_sparse_gb(torch, eng, dev, scale=1.0, cols=None, G=1 << 20):
+    """The headline statement over SPARSE i32 keys: the 2^20 dense keys g of the headline table mapped to g * SPARSE_MUL mod
+    2^32 (a bijection), i.e. 2^20 distinct keys spread over [-2^31, 2^31) -- no key is a slot index any more."""
+    N = int(1e9 * scale) // 4 * 4
+    if cols is None:
+        p, k, v = (torch.empty(N, dtype=dt, device=dev) for dt in (torch.float32, torch.int32, torch.float32))
+        eng.gen_columns(SEED, 0, N, G, True, p.data_ptr(), k.data_ptr(), v.data_ptr())
+    else:
+        p, k, v = cols
+        N = p.numel()
+    ks = torch.empty(N, dtype=torch.int32, device=dev)
+    step = 1 << 27
+    for lo in range(0, N, step):                               # piecewise: the i64 intermediate stays small
+        ks[lo:lo + step] = (k[lo:lo + step].to(torch.int64) * SPARSE_MUL).to(torch.int32)
+    ts = eng.table_from_device(N, [p.data_ptr(), ks.data_ptr(), v.data_ptr()], [np.float32, np.int32, np.float32], keepalive=(p, ks, v))
+    return {"run": lambda: eng.filter_groupby(ts, [(0, ">", 0.5)], 1, [("sum", 2), ("count", 0)]), "bytes": lambda r: 12.0 * N + 16.0 * r.shape[0], "rows": N,
+            "keep": (ts, p, k, v, ks),
+            "info": {"statement": "SELECT k,SUM(v),COUNT(*) FROM t WHERE p>0.5 GROUP BY k -- k: 2^20 distinct i32 keys spread over [-2^31, 2^31)",
+                     "groups": G}}
+
+
+WORKLOADS = {"c1": w_c1, "c2": w_c2, "refgb": w_refgb, "refgb_hash": w_refgb_hash, "join_u32": w_join_u32, "join_c4": w_join_c4, "sparse_gb": w_sparse_gb,
+             "sort20": lambda *a: w_sort(*a, bits=20), "sort32": lambda *a: w_sort(*a, bits=31), "sort64": lambda *a: w_sort(*a, bits=64)}
+
+
 def extra_configs(torch, eng, dev, a, p, k, v, N):
     """The other BASELINE configs on one GPU (or one GPU's share of them) and the small-G single-pass path.
     Outside the timed region; every number HIP-event timed on the launch stream, 3 warm-ups, median of 10."""
@@ -271,6 +416,18 @@ def extra_configs(torch, eng, dev, a, p, k, v, N):
              "frac_of_peak": alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "rows": rows, "rows_per_s": rows / (ms * 1e-3)}
         d.update(kw)
         return d
+
+    def timed(w, warm=2, reps=5, **kw):
+        """HIP-event median of a WORKLOADS builder's statement; its result shape and algorithmic bytes from the last run."""
+        last = [None, None]
+
+        def fn():
+            r = w["run"]()
+            last[0], last[1] = r.shape, w["bytes"](r)
+            r.free()
+
+        ms = event_ms(torch, fn, warm=warm, reps=reps)
+        return entry(ms, last[1], w["rows"], result_shape=list(last[0]), **w["info"], **kw)
 
     # ---- the headline statement at small G (single-pass LDS path while 12 B x G fits a workgroup's LDS)
     for name, G in (("G16", 16), ("G4096", 4096), ("G13000", 13000)):
@@ -315,103 +472,61 @@ def extra_configs(torch, eng, dev, a, p, k, v, N):
         del so, co
     out["SWEEP_selectivity_x_groups"] = sweep
 
+    # ---- the headline statement over SPARSE keys (arbitrary i32 keys: hash partition + LDS hash tables, not slot indices),
+    #      through the SQL entry hark_entry_filter_groupby; checked against the dense result of the same entry after mapping
+    #      the keys (bit-exact: integer-valued f32 sums, counts)
+    G = int(a.groups)
+    eng.gen_columns(SEED, 0, N, G, bool(a.exact), None, k.data_ptr(), None)          # the headline key column again (the sweep left G = 2^20 / other G)
+    td = eng.table_from_device(N, [p.data_ptr(), k.data_ptr(), v.data_ptr()], [np.float32, np.int32, np.float32], keepalive=(p, k, v))
+    w = w_sparse_gb(torch, eng, dev, cols=(p, k, v), G=G)
+    rs = w["run"]()
+    path = eng.last_groupby_path()
+    rd = eng.filter_groupby(td, [(0, ">", 0.5)], 1, [("sum", 2), ("count", 0)])
+    dk, dsum, dcnt = (rd.column(j) for j in range(3))
+    sk, ssum, scnt = (rs.column(j) for j in range(3))
+    mapped = (dk.astype(np.int64) * SPARSE_MUL).astype(np.uint32).view(np.int32)
+    o = np.argsort(mapped, kind="stable")
+    same = bool(np.array_equal(sk, mapped[o]) and np.array_equal(scnt, dcnt[o]) and
+                (np.array_equal(ssum, dsum[o]) if a.exact else np.allclose(ssum, dsum[o], rtol=1e-5, atol=0)))
+    rs.free()
+    rd.free()
+    dense_ms = event_ms(torch, lambda: eng.filter_groupby(td, [(0, ">", 0.5)], 1, [("sum", 2), ("count", 0)]).free(), warm=1, reps=5)
+    out["SPARSE_groupby"] = timed(w, warm=1, reps=5, path=path, equals_dense_result_after_key_mapping=same,
+                                  dense_keys_same_entry_ms=dense_ms, note="same rows, same entry (hark_entry_filter_groupby_and, result allocation and "
+                                  "group-set read-out included in both); keys = dense key x 2654435761 mod 2^32 as i32")
+    out["SPARSE_groupby"]["over_dense_same_entry"] = out["SPARSE_groupby"]["ms"] / dense_ms
+    td.free()
+    del w, td
+    torch.cuda.empty_cache()
+
     # ---- C2: WHERE filter + projection, 1e8 rows x 8 f32 columns (configs[1]): SELECT rowid, c0, c2 WHERE c1 > 0.5
-    n2 = int(1e8 * a.config_scale) // 4 * 4
-    cols = [torch.empty(n2, dtype=torch.float32, device=dev) for _ in range(8)]
-    for j in range(0, 8, 2):
-        eng.gen_columns(SEED + j, 0, n2, 1 << 20, False, cols[j].data_ptr(), None, cols[j + 1].data_ptr())
-    t8 = eng.table_from_device(n2, [c.data_ptr() for c in cols], [np.float32] * 8, keepalive=cols)
-    shape = [None]
-
-    def c2():
-        r = eng.filter_sel(t8, 1, ">", 0.5, [0, 2], want_row_index=True)
-        shape[0] = r.shape
-        r.free()
-
-    ms = event_ms(torch, c2)
-    surv = shape[0][0]
-    out["C2_filter_proj"] = entry(ms, 12.0 * n2 + 16.0 * surv, n2, survivors=surv, statement="SELECT rowid,c0,c2 FROM t8 WHERE c1>0.5 (8 f32 columns resident)",
-                                  bytes_model="read c0,c1,c2 (12 B/row) + write 2 x f32 + i64 row index per survivor")
-
-    def c1p():
-        r = eng.query_sel(t8, [0, 2])
-        r.free()
-
-    ms = event_ms(torch, c1p)
-    out["C1_projection"] = entry(ms, 16.0 * n2, n2, statement="SELECT c0,c2 FROM t8 (query_sel, main.fut:7)")
+    w = w_c2(torch, eng, dev, a.config_scale)
+    out["C2_filter_proj"] = timed(w, warm=3, reps=10)
+    out["C2_filter_proj"]["survivors"] = out["C2_filter_proj"]["result_shape"][0]
+    t8 = w["keep"][0]
+    n2 = w["rows"]
+    out["C1_projection"] = timed({"run": lambda: eng.query_sel(t8, [0, 2]), "bytes": lambda r: 16.0 * n2, "rows": n2,
+                                  "info": {"statement": "SELECT c0,c2 FROM t8 (query_sel, main.fut:7)"}}, warm=3, reps=10)
     t8.free()
-    del cols, t8
+    del w, t8
+    torch.cuda.empty_cache()
 
     # ---- the reference's own entries and ORDER BY at 1e8 rows (not BASELINE configs; the operators behind them)
-    n8 = int(1e8 * a.config_scale) // 4 * 4
-    ku, au = torch.empty(n8, dtype=torch.int32, device=dev), torch.empty(n8, dtype=torch.int32, device=dev)
-    eng.gen_columns(SEED, 0, n8, 1 << 20, True, None, ku.data_ptr(), None)
-    eng.gen_columns(SEED + 9, 0, n8, 1 << 16, True, None, au.data_ptr(), None)
-    tu = eng.table_from_device(n8, [ku.data_ptr(), au.data_ptr()], [np.uint32, np.uint32], keepalive=(ku, au))
-
-    def gd():
-        r = eng.query_groupby(tu, 0, [1, 1], [2, 3])
-        shape[0] = r.shape
-        r.free()
-
-    ms = event_ms(torch, gd, warm=2, reps=5)
-    out["REF_query_groupby_dense"] = entry(ms, 12.0 * n8, n8, groups=int(shape[0][0]), statement="query_groupby(db, 0, [1, 1], [sum, max]) (main.fut:9), 2^20 dense keys",
-                                           note="one statistics pass (sum + max of ONE column: the column is carried once)")
-
-    def ob():
-        r = eng.sort(tu, 0, [0, 1])
-        r.free()
-
-    ms = event_ms(torch, ob, warm=2, reps=5)
-    out["ORDER_BY"] = entry(ms, 16.0 * n8, n8, statement="ORDER BY a 20-bit u32 key, key + one column out (stable radix sort, 3 passes)")
-    m8 = n8 // 10
-    kb8, vb8, kp8 = (torch.empty(x, dtype=torch.int32, device=dev) for x in ((m8 + 3) // 4 * 4, (m8 + 3) // 4 * 4, n8))
-    eng.gen_columns(SEED + 3, 0, m8, 1 << 30, True, None, kb8.data_ptr(), None)
-    eng.gen_columns(SEED + 4, 0, m8, 1 << 16, True, None, vb8.data_ptr(), None)
-    eng.gen_columns(SEED + 5, 0, n8, 1 << 30, True, None, kp8.data_ptr(), None)
-    tp8 = eng.table_from_device(n8, [kp8.data_ptr(), au.data_ptr()], [np.uint32, np.uint32], keepalive=(kp8, au))
-    tb8 = eng.table_from_device(m8, [kb8.data_ptr(), vb8.data_ptr()], [np.uint32, np.uint32], keepalive=(kb8, vb8))
-
-    def ju():
-        r = eng.join(tp8, tb8, 0, 0, [0, 1], [1])
-        shape[0] = r.shape
-        r.free()
-
-    ms = event_ms(torch, ju, warm=2, reps=5)
-    out["REF_join_u32"] = entry(ms, 12.0 * (n8 + m8) + 12.0 * shape[0][0], n8 + m8, probe_rows=n8, build_rows=m8, pairs=int(shape[0][0]),
-                                statement="join(db1, db2, 0, 0, [0, 1], [1]) (join.fut:52) on u32 keys, ~10 % of the probe rows match")
-    for t_ in (tu, tp8, tb8):
-        t_.free()
-    del ku, au, kb8, vb8, kp8, tu, tp8, tb8
-    torch.cuda.empty_cache()
-
-    # ---- C4: one GPU's share of the 1e9 x 1e8 join on an i64 key (configs[3]): 1.25e8 probe rows, 1.25e7 unique build keys
-    n4, s4 = int(1.25e8 * a.config_scale), int(1.25e7 * a.config_scale)
-    mul = -7046029254386353131                                                       # 0x9E3779B97F4A7C15 as i64: odd, so i -> i*mul is a bijection mod 2^64
-    bk = torch.arange(s4, dtype=torch.int64, device=dev) * mul                       # unique build keys spread over 64 bits
-    j = torch.empty((n4 + 3) // 4 * 4, dtype=torch.int32, device=dev)
-    eng.gen_columns(SEED + 21, 0, n4, 2 * s4, True, None, j.data_ptr(), None)        # half of the probe rows find a partner
-    j = j[:n4]
-    pk = j.to(torch.int64) * mul
-    prow, brow = torch.arange(n4, dtype=torch.int32, device=dev), torch.arange(s4, dtype=torch.int32, device=dev)
-    hits = int((j < s4).sum().item())
-    del j
-    tp = eng.table_from_device(n4, [pk.data_ptr(), prow.data_ptr()], [np.int64, np.int32], keepalive=(pk, prow))
-    tb = eng.table_from_device(s4, [bk.data_ptr(), brow.data_ptr()], [np.int64, np.int32], keepalive=(bk, brow))
-
-    def c4():
-        r = eng.join(tp, tb, 0, 0, [1], [1])
-        shape[0] = r.shape
-        r.free()
-
-    ms = event_ms(torch, c4, warm=2, reps=5)
-    out["C4_join_share"] = entry(ms, 12.0 * (n4 + s4) + 8.0 * hits, n4 + s4, probe_rows=n4, build_rows=s4, pairs=shape[0][0], pairs_expected=hits,
-                                 statement="probe JOIN build ON i64 key -> (probe row id, build row id), reference order (key, left row, right row)",
-                                 note="1/8 of configs[3]; over 8 GPUs the rows arrive by an all-to-all first (xGMI-bound, DESIGN.md 6)")
-    tp.free()
-    tb.free()
-    del pk, bk, prow, brow, tp, tb
-    torch.cuda.empty_cache()
+    for name, wl, kw in (("REF_query_groupby_dense", "refgb", {}), ("REF_query_groupby_hash", "refgb_hash", {}), ("ORDER_BY", "sort20", {}),
+                         ("ORDER_BY_32bit", "sort32", {}), ("ORDER_BY_i64", "sort64", {}), ("REF_join_u32", "join_u32", {}), ("C4_join_share", "join_c4", {})):
+        w = WORKLOADS[wl](torch, eng, dev, a.config_scale)
+        out[name] = timed(w, **kw)
+        if wl.startswith("refgb"):
+            out[name]["groups"] = out[name]["result_shape"][0]
+            out[name]["path"] = eng.last_groupby_path()
+        if wl.startswith("join"):
+            out[name]["pairs"] = out[name]["result_shape"][0]
+        for t_ in w["keep"]:
+            if hasattr(t_, "free"):
+                t_.free()
+        del w
+        torch.cuda.empty_cache()
+    shape = [None]
 
     # ---- C5: one GPU's share of the full pipeline (configs[4]): 5e8 rows x (i32 key + 16 f32 columns), through sql()
     from harkdb_amd import FutharkContext
@@ -514,12 +629,14 @@ def main():
 
     # Setup, not warm-up: the path's kernels are loaded (code objects page in on first launch -- 0.3 s on a fresh box) by ONE
     # pass over the first 65536 rows with a small plan of its own; the workload's plans, slabs and rows are not touched.
-    prime_n = min(N, 1 << 16)
-    prime = FgbPlan(eng, prime_n, G, **knobs)
-    prime.run(p.data_ptr(), ">", 0.5, k.data_ptr(), v.data_ptr(), prime_n)
-    prime.finish(sum_out.data_ptr(), cnt_out.data_ptr())
-    torch.cuda.synchronize()
-    prime.free()
+    # (not in a --pmc-child: there every launch of the path's kernels is counted, and all of them must be full passes)
+    if not a.pmc_child:
+        prime_n = min(N, 1 << 16)
+        prime = FgbPlan(eng, prime_n, G, **knobs)
+        prime.run(p.data_ptr(), ">", 0.5, k.data_ptr(), v.data_ptr(), prime_n)
+        prime.finish(sum_out.data_ptr(), cnt_out.data_ptr())
+        torch.cuda.synchronize()
+        prime.free()
     for _ in range(a.warmup):
         step()
     job.flush()
@@ -604,7 +721,7 @@ def main():
             elif a.pmc == 1:
                 raise SystemExit("--pmc 1: " + str(traffic_note))
         if traffic is None:
-            for cand in ("r03_pmc_fgb.json", "r02_pmc_fgb.json", "r01_pmc_fgb.json"):
+            for cand in ("r04_pmc_fgb.json", "r03_pmc_fgb.json", "r02_pmc_fgb.json", "r01_pmc_fgb.json"):
                 try:
                     pmc = json.load(open(os.path.join(ROOT, "profiles", cand)))
                     if (pmc["config"]["rows_per_gpu"] == N and pmc["config"]["groups"] == G and not a.algo and not a.chunk_rows

@@ -57,6 +57,12 @@ class FutharkContext:
         t._device = self.FutEnv.table_from_device(n, list(ptrs), list(dtypes), keepalive=keepalive)
         self.tables[table_name] = t
 
+    def invalidate_table_stats(self, table_name):
+        """Tables are immutable (the reference re-passes the table on every query, FutharkContext.py:65,70, so it cannot
+        hold stale state); a caller that rewrote columns it registered with create_table_from_device says so here and the
+        cached column statistics (key ranges, hash group-by verdicts) are computed afresh."""
+        self.tables[table_name]._device.invalidate_stats()
+
     # FutharkContext.py:52-53
     def drop_table(self, table_name):
         t = self.tables.pop(table_name)

@@ -33,6 +33,8 @@ struct hark_context {
     // freed blocks kept for reuse up to pool_limit (HARK_POOL_LIMIT_MB; hark_context_trim gives them all back):
     // 64 GiB of 288: re-allocating multi-GB workspaces per query costs tens of ms (measured: C5 150 ms vs 2 ms with a 16 GiB limit)
     size_t pool_cached = 0, pool_limit = (size_t)64 << 30;
+    // diagnostic: which GROUP BY path served the last group-by entry (hark_context_last_groupby_path)
+    int last_groupby_path = 0;
 };
 
 // Every entry runs on the context's device whatever device the calling thread has current (a process may hold
@@ -53,12 +55,22 @@ struct hark_column {
     void *data = nullptr;
     int32_t dtype = HARK_I32;
     bool owned = true;
-    // column statistic, filled on first use (tables are immutable): value range of a 32-bit integer column
+    // Column statistics, filled on first use and kept for the life of the table.  CONTRACT (include/hark.h,
+    // hark_table_from_device): a table's columns are immutable while the table exists; a caller that rewrites a BORROWED
+    // column (owned == false) calls hark_table_invalidate_stats, which clears everything below.  A stale range would
+    // otherwise surface as a spurious HARK_EBOUNDS (dense paths check every key against it) or, under
+    // hark_table_composite_key, alias two key tuples.
+    // [min, max] of a 32-bit integer column:
     mutable bool has_range[2] = {false, false};            // [0] read as unsigned, [1] read as signed
     mutable int64_t range_min[2] = {0, 0}, range_max[2] = {0, 0};
     // ... and what the hash group-by learnt about it as a KEY column: 0 nothing yet, > 0 the table rounds its distinct keys
-    // need, < 0 too many distinct keys for the LDS tables (the sort-based path is taken without another attempt)
+    // need, < 0 the LDS hash path does not fit this column -- more distinct keys than kMaxRoundsWorth rounds of tables hold,
+    // or keys so skewed that a slab of the hash partition overflows; both are properties of (the key column, its row
+    // count), not of the aggregate asked for, so the verdict is STICKY: the sort-based path is taken without another
+    // attempt (a failed one costs a partition pass and a sample round: 1.1 ms per 1e8 rows) until the statistics are
+    // invalidated.  Performance only: every path returns the same rows.
     mutable int32_t hash_rounds = 0;
+    void invalidate_stats() const { has_range[0] = has_range[1] = false; hash_rounds = 0; }
 };
 
 struct hark_table {
@@ -139,9 +151,12 @@ int k_fgb_dense_f32(hark_context *ctx, hark_fgb_plan *plan, const float *p, int 
 // k_fgb_hash_part_free.
 struct hark_hash_part { void *pbuf = nullptr; uint32_t *counts = nullptr; int64_t cap = 0, n = 0; const void *k = nullptr, *v = nullptr; int xf = 0; };
 void k_fgb_hash_part_free(hark_context *ctx, hark_hash_part *part);
+// why k_fgb_hash_u32 reports *fits == false
+enum { HARK_HASH_FITS = 0, HARK_HASH_NOFIT_DISTINCT = 1 /* too many distinct keys */, HARK_HASH_NOFIT_SKEW = 2 /* a partition slab overflowed */,
+       HARK_HASH_NOFIT_ROWS = 3 /* n == 0 or n >= 2^32: nothing learnt about the column */ };
 int k_fgb_hash_u32(hark_context *ctx, const uint32_t *k, const uint32_t *v, int64_t n, int vop, int xf,
                    uint32_t **keys_out, unsigned long long **vals_out, unsigned long long **cnts_out, int64_t *G_out, bool *fits,
-                   uint32_t *rounds_hint, bool compact, hark_hash_part *part = nullptr);
+                   uint32_t *rounds_hint, bool compact, hark_hash_part *part = nullptr, int *why_not = nullptr);
 
 int k_fgb_dense_stats(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cmp, float thr,
                       const int32_t *k, const void *v, int64_t n, int vk, bool *ran);

@@ -2134,12 +2134,14 @@ int k_fgb_hash_u32(hark_context *ctx, const uint32_t *k, const uint32_t *v, int6
                    uint32_t **keys_out, unsigned long long **vals_out, unsigned long long **cnts_out, int64_t *G_out, bool *fits,
                    uint32_t *rounds_hint /* in: 0 or the R a previous pass over the SAME key column needed; out: the R used */,
                    bool compact /* u32 operators without row counts: 8-byte entries (fgb_agg_hash8_kernel); *cnts_out stays null */,
-                   hark_hash_part *part /* optional: the partition of (k, v) is kept in it / taken from it (see hark_internal.h) */)
+                   hark_hash_part *part /* optional: the partition of (k, v) is kept in it / taken from it (see hark_internal.h) */,
+                   int *why_not /* optional: why *fits is false -- HARK_HASH_NOFIT_* (hark_internal.h) */)
 {
+    if (why_not) *why_not = HARK_HASH_FITS;
     if (compact && !(vop == VOP_U32SUM || vop == VOP_U32MAX || vop == VOP_U32MIN || vop == VOP_U32PROD)) compact = false;
     const int fill = compact ? kHash8Fill : kHashFill;
     *keys_out = nullptr; *vals_out = nullptr; *cnts_out = nullptr; *G_out = 0; *fits = false;
-    if (n <= 0 || n > 0xFFFFFFFFll) return HARK_OK;
+    if (n <= 0 || n > 0xFFFFFFFFll) { if (why_not) *why_not = HARK_HASH_NOFIT_ROWS; return HARK_OK; }
     // 512 buckets of 32-pair rings (256 x 64 before): half as many distinct keys per bucket -- 2^21 distinct keys fit ONE
     // round of the 8-byte tables instead of two (plus the failed first attempt and the sample round that found that out)
     const int hash_bits = getenv("HARK_HASH_BITS8") ? 8 : 9, P = 1 << hash_bits, nwg = ctx->num_cu;
@@ -2177,6 +2179,7 @@ int k_fgb_hash_u32(hark_context *ctx, const uint32_t *k, const uint32_t *v, int6
                 nullptr, reinterpret_cast<const int32_t *>(k), reinterpret_cast<const float *>(v), 0, n, 0.0f, (int64_t)1 << 32, 0, P,
                 pbuf, counts, (uint32_t)cap, nullptr, nullptr, err, 0, vop, xf, hash_bits, 0);
             rc = read_err(&e);
+            if (!rc && e != 0 && why_not) *why_not = HARK_HASH_NOFIT_SKEW;          // a slab or a ring overflowed: the keys are skewed
         }
     }
     if (!rc && e == 0) {
@@ -2235,6 +2238,7 @@ int k_fgb_hash_u32(hark_context *ctx, const uint32_t *k, const uint32_t *v, int6
             }
         }
     }
+    if (!rc && e != 0 && why_not && *why_not == HARK_HASH_FITS) *why_not = HARK_HASH_NOFIT_DISTINCT;   // the tables overflowed
     if (!rc && e == 0) {
         int64_t G = 0;
         rc = hark_read_words(ctx, cursor, &G, 1);

@@ -546,9 +546,11 @@ int hark_entry_query_groupby(hark_context *ctx, hark_result **out, const hark_ta
     for (auto &c : view.cols) { c.owned = false; if (c.dtype == HARK_I32) c.dtype = HARK_U32; }
     int64_t G = 0;
     bool dense = false;
+    ctx->last_groupby_path = HARK_PATH_NONE;
     int rc = ref_groupby_dense(ctx, &view, db, g_col, aggs, res, &G, &dense);   // keys < 2^21: fused kernels, no sort
-    if (!rc && !dense) rc = ref_groupby_hash(ctx, &view, db, g_col, aggs, res, &G, &dense);   // sparse keys: LDS hash buckets
-    if (!rc && !dense) rc = grouped_aggregate(ctx, &view, g_col, HARK_U32, aggs, res, &G);  // last resort: sort-based
+    if (!rc && dense) ctx->last_groupby_path = HARK_PATH_DENSE;
+    if (!rc && !dense) { rc = ref_groupby_hash(ctx, &view, db, g_col, aggs, res, &G, &dense); if (!rc && dense) ctx->last_groupby_path = HARK_PATH_HASH; }   // sparse keys: LDS hash buckets
+    if (!rc && !dense) { rc = grouped_aggregate(ctx, &view, g_col, HARK_U32, aggs, res, &G); if (!rc) ctx->last_groupby_path = HARK_PATH_SORT; }  // last resort: sort-based
     if (!rc && nt < ns && G < db->n)                    // some group has two rows: merge indexes t_cols[i-1] out of bounds
         rc = hark_fail(ctx, HARK_EBOUNDS, "query_groupby: %lld aggregate opcodes for %lld select columns", (long long)nt, (long long)ns);
     if (rc) { result_release(ctx, res); return rc; }
@@ -1176,9 +1178,12 @@ extern "C" int hark_entry_filter_groupby_and(hark_context *ctx, hark_result **ou
     hark_result *res = new hark_result();
     int rc = HARK_OK;
     bool done = false;
+    ctx->last_groupby_path = HARK_PATH_NONE;
     if (db->n > 0) rc = try_dense(ctx, db, preds, g_col, agg_cols, agg_ops, n_aggs, res, &done);
-    if (!rc && !done && db->n > 0) rc = try_hash(ctx, db, preds, g_col, agg_cols, agg_ops, n_aggs, res, &done);
+    if (!rc && done) ctx->last_groupby_path = HARK_PATH_DENSE;
+    if (!rc && !done && db->n > 0) { rc = try_hash(ctx, db, preds, g_col, agg_cols, agg_ops, n_aggs, res, &done); if (!rc && done) ctx->last_groupby_path = HARK_PATH_HASH; }
     if (!rc && !done) {
+        ctx->last_groupby_path = HARK_PATH_SORT;
         // generic path: compact the referenced columns, then sort-based typed aggregation
         for (auto &c : res->cols) if (c.owned && c.data) hark_free(ctx, c.data);
         res->cols.clear();
@@ -1460,7 +1465,7 @@ int ref_groupby_hash(hark_context *ctx, const hark_table *view, const hark_table
     *used = false;
     const int64_t n = view->n;
     if (n < kHashMinRows) return HARK_OK;
-    // what an earlier call learnt about this key column (tables are immutable): too many distinct keys -> no second attempt
+    // what an earlier call learnt about this key column (tables are immutable; hark_table_invalidate_stats forgets it): too many distinct keys -> no second attempt
     // (a failed one costs a partition pass and a sample round: 1.1 ms per 1e8 rows); the rounds it needs -> no failed first round
     const hark_column &kc = stats_owner->cols[g_col];
     if (kc.hash_rounds < 0) return HARK_OK;
@@ -1475,13 +1480,14 @@ int ref_groupby_hash(hark_context *ctx, const hark_table *view, const hark_table
     for (size_t q = 0; q < runs; q++) order[q] = q;
     if (!aggs.empty()) std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return aggs[a].col < aggs[b].col; });   // ... so column by column
     bool first_pass = true;
+    int why = HARK_HASH_FITS;
     for (size_t oi = 0; oi < runs && !rc && ok; oi++) {
         const size_t j = order[oi];
         const int vop = aggs.empty() ? 3 : aggs[j].op == OP_SUM ? 1 : aggs[j].op == OP_MAX ? 2 : aggs[j].op == OP_MIN ? 3 : 4;
         const uint32_t *col = aggs.empty() ? keys : static_cast<const uint32_t *>(view->cols[aggs[j].col].data);
         uint32_t *hk = nullptr, *perm = nullptr; unsigned long long *hv = nullptr, *hc = nullptr;
         int64_t Gj = 0;
-        rc = k_fgb_hash_u32(ctx, keys, col, n, vop, 0, &hk, &hv, &hc, &Gj, &ok, &rounds, true, &part);   // u32 operators, no counts: 8-byte table entries
+        rc = k_fgb_hash_u32(ctx, keys, col, n, vop, 0, &hk, &hv, &hc, &Gj, &ok, &rounds, true, &part, &why);   // u32 operators, no counts: 8-byte table entries
         if (!rc && ok) {
             if (G < 0) {
                 G = Gj;
@@ -1501,7 +1507,9 @@ int ref_groupby_hash(hark_context *ctx, const hark_table *view, const hark_table
         hark_free(ctx, hk); hark_free(ctx, hv); hark_free(ctx, hc); hark_free(ctx, perm);
     }
     k_fgb_hash_part_free(ctx, &part);
-    if (!rc) kc.hash_rounds = ok ? (int32_t)rounds : -1;
+    // the verdict stays with the key column (hark_internal.h: sticky until hark_table_invalidate_stats) -- unless nothing
+    // was learnt about the column (row count outside the kernels' range)
+    if (!rc && (ok || why == HARK_HASH_NOFIT_DISTINCT || why == HARK_HASH_NOFIT_SKEW)) kc.hash_rounds = ok ? (int32_t)rounds : -1;
     if (!rc && ok && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "query_groupby: kernels failed");
     if (rc || !ok) {
         for (auto &c : res->cols) if (c.owned && c.data) hark_free(ctx, c.data);
@@ -1540,6 +1548,16 @@ __global__ __launch_bounds__(256) void composite_key_kernel(CompositeArgs a, int
     }
 }
 } // namespace
+
+extern "C" int hark_context_last_groupby_path(const hark_context *ctx) { return ctx ? ctx->last_groupby_path : HARK_PATH_NONE; }
+
+extern "C" int hark_table_invalidate_stats(hark_context *ctx, const hark_table *t, int32_t col)
+{
+    if (!ctx || !t) return HARK_EARG;
+    if (col >= t->m) return hark_fail(ctx, HARK_EBOUNDS, "invalidate_stats: column %d out of bounds", col);
+    for (int64_t j = 0; j < t->m; j++) if (col < 0 || j == col) t->cols[(size_t)j].invalidate_stats();
+    return HARK_OK;
+}
 
 extern "C" int hark_table_column_range(hark_context *ctx, const hark_table *t, int32_t col, int64_t *lo, int64_t *hi)
 {

@@ -498,6 +498,23 @@ class TensorResult:
         self._t, self._keep = [], None
 
 
+def shard_of_host_table(table_name, table, rank, world, local=False):
+    """Rank `rank`'s rows of a host-side table source as a table.Table with the WHOLE table's schema (see
+    ShardedFutharkContext.create_table).  No collective, no device: plain host work."""
+    import pandas as pd
+    from .table import Table, read_csv_byte_range
+    if local:
+        return Table(table_name, table)
+    if isinstance(table, str) and table[-3:] == "csv":
+        frame, headers = read_csv_byte_range(table, rank, world)
+        return Table(table_name, frame)
+    if isinstance(table, str):                                   # TXT: np.loadtxt has no row ranges; sliced after loading,
+        full = Table(table_name, table)                          # under the WHOLE table's headers (c1, c2, ...: a bare ndarray
+        table = pd.DataFrame(full.get_data(), columns=full.get_schema())   # slice would be renamed col1, col2, ... by load_np)
+    lo, hi = shard_range(len(table), rank, world)
+    return Table(table_name, table.iloc[lo:hi] if isinstance(table, pd.DataFrame) else table[lo:hi])
+
+
 class ShardedFutharkContext:
     """FutharkContext whose tables are row-range shards, one rank per GPU.
 
@@ -530,18 +547,8 @@ class ShardedFutharkContext:
         concatenation.  Either way the ranks agree on every column's dtype (the widest any shard needs) with one MAX
         all-reduce and on the global row ranges with one all-gather of the row counts."""
         import pandas as pd
-        from .table import Table, read_csv_byte_range, dtype_code, DTYPE_CODES
-        if not local and isinstance(table, str) and table[-3:] == "csv":
-            frame, headers = read_csv_byte_range(table, self.rank, self.world)
-            part = Table(table_name, frame)
-        elif local:
-            part = Table(table_name, table)
-        else:
-            if isinstance(table, str):                                   # TXT: np.loadtxt has no row ranges; sliced after loading
-                table = Table(table_name, table).get_data()
-            n = len(table)
-            lo, hi = shard_range(n, self.rank, self.world)
-            part = Table(table_name, table.iloc[lo:hi] if isinstance(table, pd.DataFrame) else table[lo:hi])
+        from .table import dtype_code, DTYPE_CODES
+        part = shard_of_host_table(table_name, table, self.rank, self.world, local)
         codes = [dtype_code(d) for d in part.column_dtypes()] if part.get_data().shape[0] else [0] * len(part.get_schema())
         codes = self._allreduce_small(codes, "max")
         cols = part.host_columns([DTYPE_CODES[c] for c in codes])

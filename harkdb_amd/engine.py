@@ -132,6 +132,11 @@ class DeviceTable:
     def device_ptr(self, j):
         return self._eng.lib.hark_table_column_device(self._h, j)
 
+    def invalidate_stats(self, col=-1):
+        """Forget the statistics cached with column `col` (default: every column).  Tables are immutable; a caller that
+        rewrites a column it lent with table_from_device calls this before the next query (include/hark.h)."""
+        self._eng._chk(self._eng.lib.hark_table_invalidate_stats(self._eng.ctx, self._h, int(col)))
+
     def free(self):
         if self._h is not None:
             self._eng.lib.hark_table_free(self._eng.ctx, self._h)
@@ -246,6 +251,10 @@ class Engine:
 
     def sync(self):
         self._chk(self.lib.hark_context_sync(self.ctx))
+
+    def last_groupby_path(self):
+        """'dense' | 'hash' | 'sort' | None: the path that served the last GROUP BY entry (diagnostic, include/hark.h)."""
+        return {1: "dense", 2: "hash", 3: "sort"}.get(self.lib.hark_context_last_groupby_path(self.ctx))
 
     def set_stream(self, raw_stream):
         """Run later entries on this hipStream_t handle; 0 / None = the context's own stream

@@ -32,7 +32,7 @@ def _one_json_line(stdout):
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("n", [1, 2])
+@pytest.mark.parametrize("n", [1, 2, 8])
 def test_bare_invocation_launches_its_own_ranks(n):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--stub", "1", "--rows", "20000", "--groups", "64",
                           "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=300, env=_env())
@@ -57,3 +57,15 @@ def test_world_size_mismatch_fails_loudly():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub", "1", "--rows", "1000", "--groups", "8"],
                          capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode != 0 and "WORLD_SIZE=1" in (out.stdout + out.stderr)
+
+
+def test_traffic_mean_counts_full_passes_only():
+    """measure_traffic's launch filter (a 65536-row setup launch diluted the per-launch mean to 0.75x) and
+    its refusal to nest a profiler."""
+    import bench
+    full = [5859458.0, 5859460.0, 5859455.0]
+    assert bench.headline_launches(full + [466.0]) == full
+    assert bench.headline_launches(full) == full
+    assert bench.headline_launches([466.0]) == [466.0]
+    assert bench.under_profiler({"ROCP_TOOL_LIBRARIES": "x"}) and bench.under_profiler({"LD_PRELOAD": "/opt/rocm/lib/librocprofiler-sdk-tool.so"})
+    assert not bench.under_profiler({"PATH": "/usr/bin"})

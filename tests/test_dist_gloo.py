@@ -335,3 +335,34 @@ def test_pipelined_steps_and_allreduce_variants(how):
             es += np.bincount(k[keep], weights=v[keep], minlength=G); ec += np.bincount(k[keep], minlength=G)
         for rank in range(world):
             assert np.array_equal(outs[rank][1][i][0], es) and np.array_equal(outs[rank][1][i][1], ec)
+
+
+@pytest.mark.parametrize("kind", ["txt", "csv", "frame", "ndarray"])
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_shards_of_a_host_table_keep_the_whole_tables_schema(tmp_path, kind, world):
+    """ShardedFutharkContext.create_table slices host sources per rank: every shard must carry the schema of the unsharded
+    table (a TXT table's c1, c2, ... were renamed col1, col2, ... by the ndarray slice: ADVICE r03) and the shards must
+    concatenate to the table, in rank order."""
+    import pandas as pd
+    from harkdb_amd import dist as hd
+    from harkdb_amd.table import Table
+    rng = np.random.default_rng(world)
+    mat = rng.integers(-50, 50, size=(1003, 3))
+    if kind == "txt":
+        src = str(tmp_path / "x.txt")
+        np.savetxt(src, mat, fmt="%d")
+    elif kind == "csv":
+        src = str(tmp_path / "x.csv")
+        pd.DataFrame(mat, columns=["a", "b", "c"]).to_csv(src, index=False)
+    elif kind == "frame":
+        src = pd.DataFrame(mat, columns=["a", "b", "c"])
+    else:
+        src = mat
+    whole = Table("t", src)
+    parts = [hd.shard_of_host_table("t", src, r, world) for r in range(world)]
+    for part in parts:
+        assert part.get_schema() == whole.get_schema()
+    got = np.concatenate([np.asarray(part.get_data(), dtype=np.float64).reshape(-1, 3) for part in parts])
+    assert np.array_equal(got, np.asarray(whole.get_data(), dtype=np.float64))
+    if kind == "txt":
+        assert whole.get_schema() == ["c1", "c2", "c3"]

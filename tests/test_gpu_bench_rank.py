@@ -42,12 +42,16 @@ def test_bench_rank_under_rccl(pipeline, how):
 
 
 def test_bench_line_compares_hip_with_the_cpu_port_and_measures_traffic():
-    """The default single-GPU line at a small size: the HIP result on the CPU sample's rows equals the port's (keys, sums,
-    counts), and -- where rocprofv3 exists -- the HBM traffic comes from --pmc child runs of this very bench.py."""
+    """The default single-GPU line at a size where the partition path's byte model holds: the HIP result on the CPU
+    sample's rows equals the port's (keys, sums, counts), and -- where rocprofv3 exists -- the HBM traffic comes from
+    --pmc child runs of this very bench.py, counts full passes only (steps + warm-up of the child, no setup launch) and
+    matches the model of a write-once / read-once partition: 12 B/row read + 6 B per surviving row written and read back
+    = 12 + 12 x selectivity B/row (a 0.75x dilution by a tiny setup launch went unnoticed under a 0.9x-3x bar)."""
     import shutil
     have = shutil.which("rocprofv3") is not None
+    rows = 128_000_000
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rows", "8000000", "--groups", str(1 << 20), "--steps", "3", "--warmup", "1",
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rows", str(rows), "--groups", str(1 << 20), "--steps", "3", "--warmup", "1",
                           "--cpu-rows", "2000000", "--configs", "0", "--pmc", "1" if have else "0"],
                          capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stdout + out.stderr
@@ -58,4 +62,28 @@ def test_bench_line_compares_hip_with_the_cpu_port_and_measures_traffic():
     if have:
         r = line["roofline"]
         assert r["traffic_measured_in_run"] is True, r.get("traffic_note")
-        assert 12.0 * 8000000 * 0.9 < r["traffic"] < 12.0 * 8000000 * 3.0          # at least the three columns, at most 3x
+        model = (12.0 + 12.0 * 0.5) * rows
+        assert 0.9 * model < r["traffic"] < 1.1 * model, (r["traffic"], model, r["traffic_by_kernel"])
+        for kn, dd in r["traffic_by_kernel"].items():
+            assert dd["launches_profiled"] == 3, (kn, dd)                          # 2 steps + 1 warm-up of the child
+            assert dd["FETCH_SIZE_launches_dropped_as_small"] == 0 and dd["WRITE_SIZE_launches_dropped_as_small"] == 0, (kn, dd)
+
+
+def test_bench_extra_configs_at_a_small_scale():
+    """Every `configs.*` workload of the bench line at 2 % of its size: none errors, the sparse-key GROUP BY takes the hash
+    path and equals the dense result after key mapping, the join finds the expected pairs."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rows", "6000000", "--groups", str(1 << 20), "--steps", "2", "--warmup", "1",
+                          "--cpu-rows", "0", "--configs", "1", "--config-scale", "0.02", "--pmc", "0"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    cfg = json.loads(out.stdout.strip().splitlines()[-1])["configs"]
+    assert "error" not in cfg, cfg
+    for name in ("G16", "G4096", "G13000", "SWEEP_selectivity_x_groups", "SPARSE_groupby", "C2_filter_proj", "C1_projection", "REF_query_groupby_dense",
+                 "REF_query_groupby_hash", "ORDER_BY", "ORDER_BY_32bit", "ORDER_BY_i64", "REF_join_u32", "C4_join_share", "C5_pipeline_share",
+                 "C5_three_aggregates", "C5_three_aggregates_all_groups"):
+        assert name in cfg, name
+    sp = cfg["SPARSE_groupby"]
+    assert sp["path"] == "hash" and sp["equals_dense_result_after_key_mapping"] is True and sp["result_shape"][0] > 900_000, sp
+    assert cfg["REF_query_groupby_dense"]["path"] == "dense" and cfg["REF_query_groupby_hash"]["path"] == "hash"
+    assert cfg["C4_join_share"]["pairs"] == cfg["C4_join_share"]["pairs_expected"]

@@ -53,7 +53,7 @@ def _frames():
     return df, b
 
 
-def _worker(rank, world, port, q, csv_path):
+def _worker(rank, world, port, q, csv_path, txt_path):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                       HARK_DIST_BACKEND="gloo")
@@ -70,6 +70,8 @@ def _worker(rank, world, port, q, csv_path):
     c.create_table("t_local", df.iloc[lo:hi], local=True)
     assert c.rows["t_local"] == c.rows["t"]
     c.create_table("b", b)
+    c.create_table("tx", txt_path)                      # a TXT file: sliced per rank under the whole table's headers c1, c2, ...
+    assert c.local.tables["tx"].get_schema() == ["c1", "c2", "c3"] and c.rows["tx"][0] == TXT_ROWS
     xs = torch.arange(1000 * rank, 1000 * rank + 1000 + 24 * rank, dtype=torch.int32, device=c.device)
     ys = (xs % 7).to(torch.float32)
     c.create_table_from_device("g", ["x", "y"], [xs.data_ptr(), ys.data_ptr()], [np.int32, np.float32], xs.numel(), keepalive=(xs, ys))
@@ -84,6 +86,7 @@ def _worker(rank, world, port, q, csv_path):
     out["paths"] = paths
     out["g"] = c.sql_columns("select x, y from g where y > 5 order by x desc limit 30")
     out["t_local"] = c.sql_columns("select d, count(*) from t_local group by d")
+    out["tx"] = c.sql_columns("select c1, c3 from tx where c2 > 10")
     # the fused operator over shards: local kernels, all-reduce of the accumulators, finish
     G, n = 1 << 14, len(df)
     lo, hi = hd.shard_range(n, rank, world)
@@ -101,18 +104,27 @@ def _worker(rank, world, port, q, csv_path):
     dist.barrier(); dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+TXT_ROWS = 5001
+
+
+def _txt_matrix():
+    return np.random.default_rng(5).integers(-30, 30, size=(TXT_ROWS, 3))
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
 def test_ranks_on_one_gpu_match_single_context(tmp_path, world):
-    """Two and three ranks (uneven shards, a third splitter in the range partitions) sharing one GPU."""
+    """Two, three and four ranks (uneven shards, up to three splitters in the range partitions) sharing one GPU."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     df, b = _frames()
     csv_path = str(tmp_path / "t.csv")
     df.to_csv(csv_path, index=False)
+    txt_path = str(tmp_path / "tx.txt")
+    np.savetxt(txt_path, _txt_matrix(), fmt="%d")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, csv_path)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, csv_path, txt_path)) for r in range(world)]
     for pr in procs:
         pr.start()
     outs = dict(q.get(timeout=300) for _ in range(world))
@@ -124,6 +136,11 @@ def test_ranks_on_one_gpu_match_single_context(tmp_path, world):
     fc = FutharkContext(device=0, sql_mode=True)
     fc.create_table("t", df)
     fc.create_table("b", b)
+    fc.create_table("tx", txt_path)
+    nx, cx = fc.sql_columns("select c1, c3 from tx where c2 > 10")
+    for rank in range(world):
+        gn, gc = outs[rank]["tx"]
+        assert gn == nx and all(np.array_equal(np.asarray(x), np.asarray(y)) for x, y in zip(gc, cx))
     for stmt in STATEMENTS:
         names, cols = fc.sql_columns(stmt)
         for rank in range(world):

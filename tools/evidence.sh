@@ -1,18 +1,34 @@
 # One box, one run: the bench line, the same command under rocprofv3 (kernel statistics), two PMC passes
-# (FETCH_SIZE / WRITE_SIZE, each in its own run), the extra BASELINE configs under rocprofv3, the operator benches.
-# Usage (through gpurun):  bash tools/evidence.sh   ; then locally:  python tools/collect_evidence.py r03
+# (FETCH_SIZE / WRITE_SIZE, each in its own run), the extra BASELINE configs under rocprofv3, the operator benches,
+# kernel timelines + PMC byte counters of the join / sort / sparse group-by statements.
+# Usage (through gpurun):  bash tools/evidence.sh TAG      (TAG names THIS run, e.g. r04a: output in gpurun_out/ev_TAG)
+#        then locally:     python tools/collect_evidence.py r04 gpurun_out/ev_TAG
+# gpurun MERGES what a call wrote into the local gpurun_out/: a directory name used twice would hold two runs' files, so
+# the script refuses a directory that exists already (on the box nothing does; locally a stale one must not be reused).
 set -x
 export TMPDIR=/tmp
-O=gpurun_out/ev3; rm -rf $O; mkdir -p $O   # gpurun merges into the local copy: stale files of earlier runs are removed below
-timeout 600 python bench.py > $O/bench_plain.json 2> $O/bench_plain.err
+TAG=${1:?usage: evidence.sh TAG}
+O=gpurun_out/ev_$TAG
+if [ -e "$O" ]; then echo "$O exists: pick a new TAG" >&2; exit 2; fi
+mkdir -p $O
+date -u +%FT%TZ > $O/run_id.txt; sha256sum bench.py harkdb_amd/libhark.so >> $O/run_id.txt
+timeout 900 python bench.py > $O/bench_plain.json 2> $O/bench_plain.err
 # headline only (--configs 0): every launch of the fused kernels in these profiles is a headline launch
+# (under the profiler bench.py launches no nested --pmc children; --pmc 0 says so explicitly)
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 10 --warmup 3 --cpu-rows 0 --configs 0 --pmc 0 > $O/bench_rocprof.json 2> $O/bench_rocprof.err
-timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --cpu-rows 0 --configs 0 --pmc 0 > $O/pmc_fetch.json 2> $O/pmc_fetch.err
-timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 bench.py --steps 2 --warmup 1 --cpu-rows 0 --configs 0 --pmc 0 > $O/pmc_write.json 2> $O/pmc_write.err
-# the extra configs (small-G single pass, C2, C4, C5) under the profiler: per-kernel time of those pipelines
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_configs -- python3 bench.py --steps 2 --warmup 1 --cpu-rows 0 --pmc 0 > $O/bench_configs_rocprof.json 2> $O/bench_configs_rocprof.err
+# the PMC passes run the --pmc-child mode: warm-up + timed steps only, no setup launch (every launch is a full pass)
+timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 bench.py --pmc-child 1 --steps 2 --warmup 1 --cpu-rows 0 --configs 0 --pmc 0 > $O/pmc_fetch.json 2> $O/pmc_fetch.err
+timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 bench.py --pmc-child 1 --steps 2 --warmup 1 --cpu-rows 0 --configs 0 --pmc 0 > $O/pmc_write.json 2> $O/pmc_write.err
+# the extra configs (small-G single pass, C2, C4, C5, sorts, sparse group-by) under the profiler: per-kernel time of those pipelines
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_configs -- python3 bench.py --steps 2 --warmup 1 --cpu-rows 0 --pmc 0 > $O/bench_configs_rocprof.json 2> $O/bench_configs_rocprof.err
 timeout 600 python tools/ops_bench.py > $O/ops_bench.log 2>&1
 timeout 300 python tools/c5_bench.py > $O/c5_bench.log 2>&1
+# bytes moved per kernel of the operators furthest from their roofline (one counter per run)
+for w in join_c4 join_u32 sort20 sort32 sort64 sparse_gb; do
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/opmc_${w}_$c -- python3 tools/op_one.py $w > $O/opmc_${w}_$c.log 2>&1
+  done
+done
 find $O -name "*kernel_trace.csv" -size +20M -delete
-ls -R $O | head -50
+ls -R $O | head -80
 cat $O/bench_plain.json

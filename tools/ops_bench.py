@@ -35,14 +35,25 @@ k = eng.alloc(N * 4); a = eng.alloc(N * 4)
 eng.gen_columns(SEED, 0, N, 1 << 20, True, None, k, None)
 eng.gen_columns(SEED + 9, 0, N, 1 << 16, True, None, a, None)
 tu = eng.table_from_device(N, [k, a], [np.uint32, np.uint32])
-timeit("query_groupby(dense key, 2^20 groups; sum, max) [fused kernels]", lambda: eng.query_groupby(tu, 0, [1, 1], [2, 3]), 12 * N)
+# one fresh device buffer + table per key distribution (column statistics are cached with a table: tables are immutable),
+# and every line names the path that actually ran (hark_context_last_groupby_path) instead of assuming it
+def gb_line(label, table):
+    timeit(label, lambda: eng.query_groupby(table, 0, [1, 1], [2, 3]), 12 * N)
+    print(f"    ^ path taken: {eng.last_groupby_path()}", flush=True)
+
+
+gb_line("query_groupby(dense key, 2^20 groups; sum, max)", tu)
 ks = eng.alloc(N * 4)
 eng.gen_columns(SEED + 11, 0, N, 1 << 31, True, None, ks, None)
 tsparse = eng.table_from_device(N, [ks, a], [np.uint32, np.uint32])
-timeit("query_groupby(~1e8 distinct sparse keys; sum, max) [falls back to sort]", lambda: eng.query_groupby(tsparse, 0, [1, 1], [2, 3]), 12 * N)
+gb_line("query_groupby(~1e8 distinct sparse keys; sum, max)", tsparse)
+tsparse.free(); eng.free(ks)
+kh = eng.alloc(N * 4)
 hk = (np.random.default_rng(1).integers(0, 1 << 21, size=N, dtype=np.int64) * 2654435761 % (1 << 32)).astype(np.uint32)
-eng.upload(ks, hk)
-timeit("query_groupby(2^21 distinct keys spread over [0,2^32); sum, max) [LDS hash buckets]", lambda: eng.query_groupby(tsparse, 0, [1, 1], [2, 3]), 12 * N)
+eng.upload(kh, hk)
+thash = eng.table_from_device(N, [kh, a], [np.uint32, np.uint32])
+gb_line("query_groupby(2^21 distinct keys spread over [0,2^32); sum, max)", thash)
+thash.free(); eng.free(kh)
 timeit("sort by u32 key, 2 columns", lambda: eng.sort(tu, 0, [0, 1]), 16 * N)
 M = N // 10
 kb = eng.alloc(M * 4); vb = eng.alloc(M * 4)
