@@ -126,7 +126,7 @@ struct hark_fgb_plan {
     int64_t shift8 = 0, P8 = 0, cap8 = 0;   // second geometry over the same slab space: <= 128 buckets (one-word ring entries), 0 = none
     int64_t slack_pct = 0;     // slab capacity as % of the uniform share (0 = default)
     int64_t tile_rows = 0;
-    int64_t ablate = 0;        // timing experiments only
+    int64_t period = 0;        // partition path: batches between ring sweeps (0 = the format's default)
     int64_t pairfmt = 0;       // partition pair format: 0 auto (compact), 1: 8-byte (key, value) pairs, 2: compact 6-byte units
     int64_t timing = 0;        // record HIP events around every kernel launch
     int64_t vop = 0;           // value operator: 0 f32 sum (f64 acc), 1..4 u32 sum/max/min/prod, 5 u32 -> u64 sum
@@ -149,14 +149,16 @@ int k_fgb_dense_f32(hark_context *ctx, hark_fgb_plan *plan, const float *p, int 
 // The hash partition of a (key column, value column) pair, kept between aggregates of the SAME value column (the pairs
 // the producer writes do not depend on the operator): zero-initialise, pass to every k_fgb_hash_u32 call, release with
 // k_fgb_hash_part_free.
-struct hark_hash_part { void *pbuf = nullptr; uint32_t *counts = nullptr; int64_t cap = 0, n = 0; const void *k = nullptr, *v = nullptr; int xf = 0; };
+struct hark_hash_part { void *pbuf = nullptr; uint32_t *counts = nullptr; int64_t cap = 0, n = 0; const void *k = nullptr, *v = nullptr, *p = nullptr; int xf = 0; };
+// a WHERE fused into a producer: f32 column `p` compared with `thr` (HARK_CMP_GT..NE), or a survivor bitmask (HARK_CMP_MASK)
+struct hark_row_pred { const float *p; int cmp; float thr; };
 void k_fgb_hash_part_free(hark_context *ctx, hark_hash_part *part);
 // why k_fgb_hash_u32 reports *fits == false
 enum { HARK_HASH_FITS = 0, HARK_HASH_NOFIT_DISTINCT = 1 /* too many distinct keys */, HARK_HASH_NOFIT_SKEW = 2 /* a partition slab overflowed */,
        HARK_HASH_NOFIT_ROWS = 3 /* n == 0 or n >= 2^32: nothing learnt about the column */ };
 int k_fgb_hash_u32(hark_context *ctx, const uint32_t *k, const uint32_t *v, int64_t n, int vop, int xf,
                    uint32_t **keys_out, unsigned long long **vals_out, unsigned long long **cnts_out, int64_t *G_out, bool *fits,
-                   uint32_t *rounds_hint, bool compact, hark_hash_part *part = nullptr, int *why_not = nullptr);
+                   uint32_t *rounds_hint, bool compact, hark_hash_part *part = nullptr, int *why_not = nullptr, const hark_row_pred *pred = nullptr);
 
 int k_fgb_dense_stats(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cmp, float thr,
                       const int32_t *k, const void *v, int64_t n, int vk, bool *ran);

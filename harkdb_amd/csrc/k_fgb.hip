@@ -238,30 +238,25 @@ __global__ __launch_bounds__(1024) void fgb_lds_kernel(
     };
 
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    // HARK_LDS_DEPTH independent 16-byte loads per column in flight per lane (streamed once: non-temporal)
-#ifndef HARK_LDS_DEPTH
-#define HARK_LDS_DEPTH 2
-#endif
-#ifndef HARK_LDS_NT
-#define HARK_LDS_NT 1            // measured on one box: 1.96 ms -> 1.76 ms per 1e9 rows (0.77 -> 0.85 of peak); three or four loads in flight are slower
-#endif
-    constexpr int D = HARK_LDS_DEPTH;
+    // D independent 16-byte loads per column in flight per lane, streamed once: non-temporal (measured on one box against
+    // plain loads: 1.96 ms -> 1.76 ms per 1e9 rows, 0.77 -> 0.85 of peak; three or four loads in flight are slower)
+    constexpr int D = 2;
     typedef float f4v __attribute__((ext_vector_type(4)));
     typedef int i4v __attribute__((ext_vector_type(4)));
     auto ldp = [&](int64_t q) -> float4 {
         if (OP == kNoPred) return float4{0, 0, 0, 0};
         if (OP == kMaskPred) return mask_nibble(p, q * kVec);
-        if (HARK_LDS_NT) { const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(p4 + q)); return float4{t.x, t.y, t.z, t.w}; }
-        return p4[q];
+        const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(p4 + q));
+        return float4{t.x, t.y, t.z, t.w};
     };
     auto ldk = [&](int64_t q) -> int4 {
-        if (HARK_LDS_NT) { const i4v t = __builtin_nontemporal_load(reinterpret_cast<const i4v *>(k4 + q)); return int4{t.x, t.y, t.z, t.w}; }
-        return k4[q];
+        const i4v t = __builtin_nontemporal_load(reinterpret_cast<const i4v *>(k4 + q));
+        return int4{t.x, t.y, t.z, t.w};
     };
     auto ldv = [&](int64_t q) -> float4 {
         if (CNT) return float4{0, 0, 0, 0};
-        if (HARK_LDS_NT) { const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(v4 + q)); return float4{t.x, t.y, t.z, t.w}; }
-        return v4[q];
+        const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(v4 + q));
+        return float4{t.x, t.y, t.z, t.w};
     };
     for (; i + (D - 1) * stride < nvec; i += D * stride) {
         float4 pa[D], va[D]; int4 ka[D];
@@ -371,9 +366,8 @@ constexpr int kErrOverflow = 100;                        // device error word: a
 // the write combining keeps its whole-line property (a 64-B + 32-B split of 16 pairs did not).  The producer
 // is at the HBM ceiling of its traffic mix, so 25 % fewer partition bytes are worth their price in LDS: rings
 // of 96 pairs (one unit + 32 of headroom) per bucket, swept every second batch.
-#ifndef HARK_ABL_BSKEW
-#define HARK_ABL_BSKEW 0     // ablation builds (tools/ab_build.sh): extra bytes between the slab rows of consecutive buckets of the compact formats
-#endif                       // (nwg x slab bytes is a multiple of 64 KiB: all 256 slabs a workgroup sweeps share their low address bits)
+// (nwg x slab bytes is a multiple of 64 KiB, so all 256 slabs a workgroup sweeps share their low address bits; skewing the
+// bucket rows against each other was measured flat, profiles/r03_bucket_skew.log)
 constexpr int kU = 64;                                   // pairs per unit
 constexpr int kUnitBytes = kU * 6;                       // 384
 constexpr int kQ6 = 96;                                  // ring capacity per bucket (pairs)
@@ -654,12 +648,9 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
                         const uint4 v1 = *reinterpret_cast<const uint4 *>(&qv[b * kQ6 + iv1]);
                         const uint4 k0 = *reinterpret_cast<const uint4 *>(&qk[b * kQ6 + ik]);
                         if (lc < cap_units) {
-                            unsigned char *dst = slab6 + (size_t)b * ((size_t)nwg * ((size_t)cap * 8) + HARK_ABL_BSKEW) + (size_t)lc * kUnitBytes;
+                            unsigned char *dst = slab6 + (size_t)b * ((size_t)nwg * ((size_t)cap * 8)) + (size_t)lc * kUnitBytes;
                             __builtin_nontemporal_store(u4v{v0.x, v0.y, v0.z, v0.w}, reinterpret_cast<u4v *>(dst + 16 * i));
                             __builtin_nontemporal_store(u4v{v1.x, v1.y, v1.z, v1.w}, reinterpret_cast<u4v *>(dst + 128 + 16 * i));
-#ifdef HARK_ABL_KEYS96   // ablation build only (tools/ab_build.sh; WRONG results): what 12-bit keys (96 B of the key line) could save at most
-                            if (i < 6)
-#endif
                             __builtin_nontemporal_store(u4v{k0.x, k0.y, k0.z, k0.w}, reinterpret_cast<u4v *>(dst + 256 + 16 * i));
                         } else if (strict) {
                             overflow = true;
@@ -694,7 +685,7 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
                         const uint4 c0 = *reinterpret_cast<const uint4 *>(r1), c1 = *reinterpret_cast<const uint4 *>(r1 + 2);
                         const uint32_t ka = a0.y | (a0.w << 16), kb2 = a1.y | (a1.w << 16), kc = c0.y | (c0.w << 16), kd = c1.y | (c1.w << 16);
                         if (lc < cap_units) {
-                            unsigned char *dst = slab6 + (size_t)b * ((size_t)nwg * ((size_t)cap * 8) + HARK_ABL_BSKEW) + (size_t)lc * kUnitBytes;
+                            unsigned char *dst = slab6 + (size_t)b * ((size_t)nwg * ((size_t)cap * 8)) + (size_t)lc * kUnitBytes;
                             __builtin_nontemporal_store(u4v{a0.x, a0.z, a1.x, a1.z}, reinterpret_cast<u4v *>(dst + 16 * i));
                             __builtin_nontemporal_store(u4v{c0.x, c0.z, c1.x, c1.z}, reinterpret_cast<u4v *>(dst + 128 + 16 * i));
                             __builtin_nontemporal_store(u2v{ka, kb2}, reinterpret_cast<u2v *>(dst + 256 + 8 * i));
@@ -721,7 +712,7 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
                         const int ik = (head + 8 * i) & (kQ2 - 1);
                         const uint4 k0 = *reinterpret_cast<const uint4 *>(&qk2[b * kQ2 + ik]);
                         if (lc < cap_units) {
-                            unsigned char *dst = slab6 + (size_t)b * ((size_t)nwg * ((size_t)cap * 8) + HARK_ABL_BSKEW) + (size_t)lc * kUnit2Bytes;
+                            unsigned char *dst = slab6 + (size_t)b * ((size_t)nwg * ((size_t)cap * 8)) + (size_t)lc * kUnit2Bytes;
                             __builtin_nontemporal_store(u4v{k0.x, k0.y, k0.z, k0.w}, reinterpret_cast<u4v *>(dst + 16 * i));
                         } else {                                           // slab full: direct atomics
                             const uint32_t kb = (uint32_t)b << shift;
@@ -805,7 +796,7 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
         const uint32_t w = s_w[b];
         const int l = (int)(w & 0xFFFFu), head = (int)(w >> 16);
         if (C6) {                                                       // l < kU: the last sweep took every complete unit
-            unsigned char *dst = slab6 + (size_t)b * ((size_t)nwg * ((size_t)cap * 8) + HARK_ABL_BSKEW) + (size_t)s_lcur[b] * kUnitBytes;
+            unsigned char *dst = slab6 + (size_t)b * ((size_t)nwg * ((size_t)cap * 8)) + (size_t)s_lcur[b] * kUnitBytes;
             for (int j = 0; j < l; j++) {
                 const int at = b * kQ6 + wrap6(head + j);
                 reinterpret_cast<uint32_t *>(dst)[j] = qv[at]; reinterpret_cast<uint16_t *>(dst + 4 * kU)[j] = qk[at];
@@ -814,7 +805,7 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
             continue;
         }
         if (C8) {                                                       // l < kU (see above)
-            unsigned char *dst = slab6 + (size_t)b * ((size_t)nwg * ((size_t)cap * 8) + HARK_ABL_BSKEW) + (size_t)s_lcur[b] * kUnitBytes;
+            unsigned char *dst = slab6 + (size_t)b * ((size_t)nwg * ((size_t)cap * 8)) + (size_t)s_lcur[b] * kUnitBytes;
             for (int j = 0; j < l; j++) {
                 const uint2 e = q8e[b * kQ8e + wrap8(head + j)];
                 reinterpret_cast<uint32_t *>(dst)[j] = e.x; reinterpret_cast<uint16_t *>(dst + 4 * kU)[j] = (uint16_t)e.y;
@@ -823,7 +814,7 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
             continue;
         }
         if (K2) {
-            unsigned char *dst = slab6 + (size_t)b * ((size_t)nwg * ((size_t)cap * 8) + HARK_ABL_BSKEW) + (size_t)s_lcur[b] * kUnit2Bytes;
+            unsigned char *dst = slab6 + (size_t)b * ((size_t)nwg * ((size_t)cap * 8)) + (size_t)s_lcur[b] * kUnit2Bytes;
             for (int j = 0; j < l; j++) reinterpret_cast<uint16_t *>(dst)[j] = qk2[b * kQ2 + ((head + j) & (kQ2 - 1))];
             counts[(size_t)b * nwg + wg] = (uint32_t)(s_lcur[b] * kU + l);
             continue;
@@ -849,11 +840,10 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
 template <int VOP>
 __global__ __launch_bounds__(1024) void fgb_agg_kernel(
     const uint2 *__restrict__ pbuf, const uint32_t *__restrict__ counts, uint32_t cap, int nwg, int shift,
-    int64_t G, u64 *__restrict__ gsum, unsigned long long *__restrict__ gcnt, int ablate)
+    int64_t G, u64 *__restrict__ gsum, unsigned long long *__restrict__ gcnt)
 {
     typedef unsigned int u4v __attribute__((ext_vector_type(4)));
     auto ld = [&](const uint4 *q) -> uint4 {
-        if (ablate & 64) return *q;
         const u4v t = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(q));   // pairs are read exactly once
         return uint4{t.x, t.y, t.z, t.w};
     };
@@ -926,7 +916,7 @@ __global__ __launch_bounds__(1024) void fgb_agg6_kernel(
     const int piece = lane & 15, sub = lane >> 4;
     for (int w = wave * split + half; w < nwg; w += nwaves * split) {
         const uint32_t count = min(counts[(size_t)b * nwg + w], max_pairs);
-        const unsigned char *src = pbuf + (size_t)b * ((size_t)nwg * ((size_t)cap * 8) + HARK_ABL_BSKEW) + (size_t)w * ((size_t)cap * 8);
+        const unsigned char *src = pbuf + (size_t)b * ((size_t)nwg * ((size_t)cap * 8)) + (size_t)w * ((size_t)cap * 8);
         const uint32_t units = count / kU, rem = count % kU;
         uint32_t u = sub;
         for (; u + 4 < units; u += 8) {
@@ -988,7 +978,7 @@ __global__ __launch_bounds__(1024) void fgb_agg2_kernel(
     const int piece = lane & 7, sub = lane >> 3;
     for (int w = wave; w < nwg; w += nwaves) {
         const uint32_t count = min(counts[(size_t)b * nwg + w], max_keys);
-        const unsigned char *src = pbuf + (size_t)b * ((size_t)nwg * ((size_t)cap * 8) + HARK_ABL_BSKEW) + (size_t)w * ((size_t)cap * 8);
+        const unsigned char *src = pbuf + (size_t)b * ((size_t)nwg * ((size_t)cap * 8)) + (size_t)w * ((size_t)cap * 8);
         const uint32_t units = count / kU, rem = count % kU;
         uint32_t u = sub;
         for (; u + 8 < units; u += 16) {
@@ -1042,7 +1032,7 @@ __global__ __launch_bounds__(1024) void fgb_agg6_stats_kernel(
     const int piece = lane & 15, sub = lane >> 4;
     for (int w = wave; w < nwg; w += nwaves) {
         const uint32_t count = min(counts[(size_t)b * nwg + w], max_pairs);
-        const unsigned char *src = pbuf + (size_t)b * ((size_t)nwg * ((size_t)cap * 8) + HARK_ABL_BSKEW) + (size_t)w * ((size_t)cap * 8);
+        const unsigned char *src = pbuf + (size_t)b * ((size_t)nwg * ((size_t)cap * 8)) + (size_t)w * ((size_t)cap * 8);
         const uint32_t units = count / kU, rem = count % kU;
         for (uint32_t u = sub; u < units; u += 4) {
             const unsigned char *a = src + (size_t)u * kUnitBytes;
@@ -1653,7 +1643,7 @@ int hark_fgb_plan_set(hark_fgb_plan *pl, const char *key, int64_t value)
     else if (!strcmp(key, "vop")) { if (value < 0 || value > 5) return HARK_EARG; pl->vop = value; return HARK_OK; }   // reset afterwards
     else if (!strcmp(key, "xform")) { if (value < 0 || value > 2) return HARK_EARG; pl->xform = value; return HARK_OK; }
     else if (!strcmp(key, "pairfmt")) { if (value < 0 || value > 3) return HARK_EARG; pl->pairfmt = value; }   // 0 auto, 1: 8-byte pairs, 2: compact 6-byte units, 3: 6-byte units from 8-byte ring entries (<= 128 buckets)
-    else if (!strcmp(key, "ablate")) { pl->ablate = value; return HARK_OK; }   // timing experiments only: wrong results
+    else if (!strcmp(key, "period")) { if (value < 0 || value > 15) return HARK_EARG; pl->period = value; return HARK_OK; }   // batches between ring sweeps (0 = default); any value gives the same result
     else return HARK_EARG;
     plan_drop_partition(pl);     // partition geometry depends on the knobs
     return HARK_OK;
@@ -1727,7 +1717,7 @@ static int plan_prepare_partition(hark_context *ctx, hark_fgb_plan *pl)
             }
         }
     }
-    HARK_TRY(hark_alloc(ctx, (void **)&pl->pbuf, bytes + (size_t)pl->P * HARK_ABL_BSKEW));
+    HARK_TRY(hark_alloc(ctx, (void **)&pl->pbuf, bytes));
     HARK_TRY(hark_alloc(ctx, (void **)&pl->counts, (size_t)pl->P * (size_t)pl->nwg * sizeof(uint32_t)));
     return HARK_OK;
 }
@@ -1831,7 +1821,7 @@ int k_fgb_dense_f32(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cm
             HIP_TRY(ctx, hipMemsetAsync(pl->err + 1, 0, 4, st));                 // the producers' batch counter
             {
                 TimedLaunch tl(pl, st, 1);
-                const int period = (int)((pl->ablate >> 12) & 15);            // experiments: batches between sweeps (0 = default)
+                const int period = (int)pl->period;                            // batches between sweeps (0 = default)
 #define HARK_LAUNCH_PART(MODE, FMTV) fgb_part_kernel<OP, MODE, FMTV><<<dim3((unsigned)nwg), dim3(kPartThreads), lds_part, st>>>( \
                     p, k, v, r0, r1, thr, G, shift, P, pl->pbuf, pl->counts, cap, gsum, gcnt, pl->err, period, vop, (int)pl->xform, 0, 0)
                 if (fmt == 2) HARK_LAUNCH_PART(0, 2);
@@ -1853,7 +1843,7 @@ int k_fgb_dense_f32(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cm
                             reinterpret_cast<const unsigned char *>(pl->pbuf), pl->counts, cap, nwg, shift, G, gsum, gcnt, split);
                     else
                         fgb_agg_kernel<decltype(vopc)::value><<<dim3((unsigned)P), dim3(1024), lds_agg, st>>>(
-                            pl->pbuf, pl->counts, cap, nwg, shift, G, gsum, gcnt, (int)pl->ablate);
+                            pl->pbuf, pl->counts, cap, nwg, shift, G, gsum, gcnt);
                     return HARK_OK;
                 });
                 if (rc) return rc;
@@ -2135,8 +2125,13 @@ int k_fgb_hash_u32(hark_context *ctx, const uint32_t *k, const uint32_t *v, int6
                    uint32_t *rounds_hint /* in: 0 or the R a previous pass over the SAME key column needed; out: the R used */,
                    bool compact /* u32 operators without row counts: 8-byte entries (fgb_agg_hash8_kernel); *cnts_out stays null */,
                    hark_hash_part *part /* optional: the partition of (k, v) is kept in it / taken from it (see hark_internal.h) */,
-                   int *why_not /* optional: why *fits is false -- HARK_HASH_NOFIT_* (hark_internal.h) */)
+                   int *why_not /* optional: why *fits is false -- HARK_HASH_NOFIT_* (hark_internal.h) */,
+                   const hark_row_pred *pred /* optional WHERE, fused into the producer: an f32 column with a comparison, or a
+                                                survivor bitmask with HARK_CMP_MASK -- only surviving rows are partitioned */)
 {
+    const float *pp = pred ? pred->p : nullptr;
+    const int pcmp = pred ? pred->cmp : 0;
+    const float pthr = pred ? pred->thr : 0.0f;
     if (why_not) *why_not = HARK_HASH_FITS;
     if (compact && !(vop == VOP_U32SUM || vop == VOP_U32MAX || vop == VOP_U32MIN || vop == VOP_U32PROD)) compact = false;
     const int fill = compact ? kHash8Fill : kHashFill;
@@ -2150,7 +2145,7 @@ int k_fgb_hash_u32(hark_context *ctx, const uint32_t *k, const uint32_t *v, int6
     uint2 *pbuf = nullptr; uint32_t *counts = nullptr; int32_t *err = nullptr; unsigned long long *cursor = nullptr;
     uint32_t *okey = nullptr; u64 *oval = nullptr, *ocnt = nullptr;
     hipStream_t st = ctx->stream;
-    const bool reuse = part && part->pbuf && part->k == k && part->v == v && part->n == n && part->xf == xf && part->cap == cap;
+    const bool reuse = part && part->pbuf && part->k == k && part->v == v && part->n == n && part->xf == xf && part->cap == cap && part->p == pp;
     if (part && part->pbuf && !reuse) k_fgb_hash_part_free(ctx, part);
     int rc = HARK_OK;
     if (reuse) { pbuf = static_cast<uint2 *>(part->pbuf); counts = part->counts; }
@@ -2172,12 +2167,16 @@ int k_fgb_hash_u32(hark_context *ctx, const uint32_t *k, const uint32_t *v, int6
     if (!rc && !reuse) {
         hipMemsetAsync(err, 0, 16, st);
         const size_t lds_part = part_lds_bytes(P, 0);
-        rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_part_kernel<kNoPred, 2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part) == hipSuccess
-                 ? HARK_OK : hark_fail(ctx, HARK_EHIP, "hash group-by: LDS attribute failed");
-        if (!rc) {
-            fgb_part_kernel<kNoPred, 2, 0><<<dim3((unsigned)nwg), dim3(kPartThreads), lds_part, st>>>(
-                nullptr, reinterpret_cast<const int32_t *>(k), reinterpret_cast<const float *>(v), 0, n, 0.0f, (int64_t)1 << 32, 0, P,
+        rc = dispatch_op(pcmp, pp != nullptr, [&](auto op) -> int {
+            constexpr int OP = decltype(op)::value;
+            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_part_kernel<OP, 2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part));
+            fgb_part_kernel<OP, 2, 0><<<dim3((unsigned)nwg), dim3(kPartThreads), lds_part, st>>>(
+                pp, reinterpret_cast<const int32_t *>(k), reinterpret_cast<const float *>(v), 0, n, pthr, (int64_t)1 << 32, 0, P,
                 pbuf, counts, (uint32_t)cap, nullptr, nullptr, err, 0, vop, xf, hash_bits, 0);
+            HIP_TRY(ctx, hipGetLastError());
+            return HARK_OK;
+        });
+        if (!rc) {
             rc = read_err(&e);
             if (!rc && e != 0 && why_not) *why_not = HARK_HASH_NOFIT_SKEW;          // a slab or a ring overflowed: the keys are skewed
         }
@@ -2246,7 +2245,7 @@ int k_fgb_hash_u32(hark_context *ctx, const uint32_t *k, const uint32_t *v, int6
         if (!rc && rounds_hint) *rounds_hint = used_R;
     }
     if (part && !rc && (reuse || e == 0)) {                        // a good partition stays with the caller
-        part->pbuf = pbuf; part->counts = counts; part->cap = cap; part->n = n; part->k = k; part->v = v; part->xf = xf;
+        part->pbuf = pbuf; part->counts = counts; part->cap = cap; part->n = n; part->k = k; part->v = v; part->xf = xf; part->p = pp;
     } else {
         if (part) { part->pbuf = nullptr; part->counts = nullptr; }
         hark_free(ctx, pbuf); hark_free(ctx, counts);

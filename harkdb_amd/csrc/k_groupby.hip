@@ -832,7 +832,7 @@ int try_dense(hark_context *ctx, const hark_table *db, const PredList &preds,
 
 // Sparse 32-bit integer keys: the LDS hash-bucket pipeline of k_fgb.hip, one pass per distinct
 // (operator, column), results brought into ascending key order (signed for I32).  A WHERE is
-// applied by compacting the referenced columns first.
+// fused into the hash producer (one f32 predicate as it is, anything else as a survivor bitmask).
 int try_hash(hark_context *ctx, const hark_table *db, const PredList &preds,
              int32_t g_col, const int32_t *agg_cols, const int32_t *agg_ops, int64_t n_aggs, hark_result *res, bool *used)
 {
@@ -844,20 +844,16 @@ int try_hash(hark_context *ctx, const hark_table *db, const PredList &preds,
         const int c = agg_ops[j] == HARK_AGG_COUNT ? 0 : agg_cols[j];
         if (!dense_plan_for(agg_ops[j], db->cols[c].dtype, c, &plan_of[j])) return HARK_OK;
     }
+    // WHERE rides in the hash producer (round 4; a compaction of the referenced columns before): ONE f32 predicate as it is,
+    // anything else as a survivor bitmask evaluated once (0.125 B/row) -- only surviving rows are partitioned
     const hark_table *src = db;
-    hark_result *kept = nullptr;
-    hark_table view;
-    std::vector<int32_t> remap((size_t)db->m, -1), need;
-    int32_t g2 = g_col;
-    if (preds.n > 0) {
-        auto want = [&](int c) { if (remap[c] < 0) { remap[c] = (int32_t)need.size(); need.push_back(c); } return remap[c]; };
-        g2 = want(g_col);
-        for (auto &pp : plan_of) if (!pp.count_only) pp.col = want(pp.col);
-        HARK_TRY(hark_entry_filter_sel_and(ctx, &kept, db, preds.n, preds.cols, preds.cmps, preds.consts, need.data(), (int64_t)need.size(), 0));
-        view.n = kept->n; view.m = (int64_t)kept->cols.size(); view.cols = kept->cols;
-        for (auto &c : view.cols) c.owned = false;
-        src = &view;
-    }
+    const int32_t g2 = g_col;
+    const bool direct = preds.n == 1 && db->cols[preds.cols[0]].dtype == HARK_F32;
+    uint8_t *mask = nullptr;
+    if (preds.n >= 1 && !direct) HARK_TRY(k_predicate_bitmask(ctx, db, preds.n, preds.cols, preds.cmps, preds.consts, &mask));
+    hark_row_pred pred{nullptr, 0, 0.0f};
+    if (preds.n >= 1) pred = direct ? hark_row_pred{static_cast<const float *>(db->cols[preds.cols[0]].data), preds.cmps[0], *static_cast<const float *>(preds.consts[0])}
+                                    : hark_row_pred{reinterpret_cast<const float *>(mask), HARK_CMP_MASK, 0.0f};
     const uint32_t *keys = static_cast<const uint32_t *>(src->cols[g2].data);
     int rc = HARK_OK;
     bool ok = src->n > 0;
@@ -869,7 +865,9 @@ int try_hash(hark_context *ctx, const hark_table *db, const PredList &preds,
     auto run_pass = [&](int vop, int xf, const void *col) -> int {
         uint32_t *hk = nullptr, *perm = nullptr; unsigned long long *hv = nullptr, *hc = nullptr;
         int64_t Gj = 0;
-        int r = k_fgb_hash_u32(ctx, keys, static_cast<const uint32_t *>(col), src->n, vop, xf, &hk, &hv, &hc, &Gj, &ok, &rounds, false, &part);
+        int r = k_fgb_hash_u32(ctx, keys, static_cast<const uint32_t *>(col), src->n, vop, xf, &hk, &hv, &hc, &Gj, &ok, &rounds, false, &part, nullptr,
+                               preds.n >= 1 ? &pred : nullptr);
+        if (!r && ok && Gj == 0) ok = false;                  // no row survives the WHERE: the generic path returns the typed empty result
         if (!r && ok) {
             if (G < 0) {
                 G = Gj; res->n = G;
@@ -914,7 +912,7 @@ int try_hash(hark_context *ctx, const hark_table *db, const PredList &preds,
     if (!rc && ok && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "filter_groupby: kernels failed");
     k_fgb_hash_part_free(ctx, &part);
     hark_free(ctx, accg); hark_free(ctx, cntg);
-    if (kept) hark_result_free(ctx, kept);
+    hark_free(ctx, mask);
     if (rc || !ok) {
         for (auto &c : res->cols) if (c.owned && c.data) hark_free(ctx, c.data);
         res->cols.clear(); res->n = 0;

@@ -50,28 +50,15 @@ struct __attribute__((aligned(16))) JPair64 { uint64_t key; uint32_t row, pad; }
 // survivor 10240 x 12 B + 6144 counters, without 12288 x 8 B + 10240 counters (~150 KiB of LDS either way)
 constexpr int kStage = 12288, kStageCarry = 10240, kFine = 10240, kFineCarry = 6144, kCoarse = 2048, kTieMax = 64, kMaxSub = 256;
 
-#ifdef HARK_JORDER_PROF      // debug build (tools/ab_build.sh): cycles per phase of the order kernel, summed over workgroups (thread 0)
-__device__ unsigned long long g_jprof[16];
-#define JPROF_MARK(k) do { if (threadIdx.x == 0) { const unsigned long long t__ = __builtin_readcyclecounter(); atomicAdd(&g_jprof[k], t__ - jt0); jt0 = t__; } } while (0)
-#else
-#define JPROF_MARK(k) do { } while (0)
-#endif
 template <typename K> struct JTraits;
 // P buckets, rings of Q entries, VEC rows per lane and batch; the bucket kernel stages CHUNK sorted build keys per
 // round plus a bitmap of 2^BM_BITS bits over them (measured: a 16-step binary search in LDS for EVERY probe pair
 // cost 1.36 ms per 1e8 pairs -- instruction issue, not the loads; most pairs have no partner and now leave after
 // one bit test).  u32: 88 KiB of keys + 32 KiB of bitmap (+ 24 KiB of candidate queues + 8 KiB of rank-group counters), one
 // round up to 1.15e7 build rows; u64: 96 + 16 (+ 32 + 8) KiB.
-#ifndef HARK_J32_P                       // A/B builds (HARK_LIB): -DHARK_J32_P=256 -DHARK_J32_Q=64
-#define HARK_J32_P 512
-#define HARK_J32_Q 32
-#endif
-template <> struct JTraits<uint32_t> { typedef JPair32 E; static constexpr int P = HARK_J32_P, Q = HARK_J32_Q, VEC = 4, CHUNK = 22528, BM_BITS = 18; };
-#ifndef HARK_J64_P
-#define HARK_J64_P 512
-#define HARK_J64_Q 16
-#endif
-template <> struct JTraits<uint64_t> { typedef JPair64 E; static constexpr int P = HARK_J64_P, Q = HARK_J64_Q, VEC = 2, CHUNK = 12288, BM_BITS = 17; };
+// (512 x 32 / 512 x 16 measured against 256 x 64 / 1024 x 8: profiles/r02_notes.md, r03_notes.md 5.1)
+template <> struct JTraits<uint32_t> { typedef JPair32 E; static constexpr int P = 512, Q = 32, VEC = 4, CHUNK = 22528, BM_BITS = 18; };
+template <> struct JTraits<uint64_t> { typedef JPair64 E; static constexpr int P = 512, Q = 16, VEC = 2, CHUNK = 12288, BM_BITS = 17; };
 
 __device__ __forceinline__ uint32_t jhash(uint32_t k) { return k * 0x9E3779B1u; }
 __device__ __forceinline__ uint32_t jhash(uint64_t k) { return (uint32_t)((k * 0x9E3779B97F4A7C15ull) >> 32); }
@@ -369,11 +356,7 @@ __global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTrai
     auto ck = [&](int i) -> K & { return chunk[i + (i >> SKK)]; };
     auto c3 = [&](int i) -> uint32_t & { return c32[i + (i >> 6)]; };
     __shared__ int s_tbad;
-#ifdef HARK_JB_NOTRUNC
-    const bool tmode = false;
-#else
     bool tmode = sizeof(K) == 8 && allow_trunc && hi - lo > (uint32_t)chunk_cap && hi - lo <= 2u * (uint32_t)chunk_cap;
-#endif
     K kb = (K)0;
     int ts = 0;
     if (tmode) {
@@ -389,9 +372,7 @@ __global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTrai
         for (int i = tid + 1; i < m; i += kJThreads) bad = bad || (c3(i) == c3(i - 1) && rkeys[lo + i] != rkeys[lo + i - 1]);
         if (bad) s_tbad = 1;
         __syncthreads();
-#ifndef HARK_JB_NOTRUNC
         tmode = s_tbad == 0;
-#endif
     }
     if (tid == 0) smode[b] = tmode ? 1u : 0u;
     const uint32_t round_keys = tmode ? hi - lo : (uint32_t)chunk_cap;
@@ -441,9 +422,7 @@ __global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTrai
                     const uint32_t o = at + (uint32_t)__popcll(mask & below);
                     st_hidden_b64(out + o, uint2{base + pos, row});
                     if (sizeof(E) == 16 && vout) st_hidden_b32(vout + o, val);
-#if !(defined(HARK_JB_EXP) && HARK_JB_EXP == 6)                       // timing: no rank-group counts
                     atomicAdd(&s_coarse[(base + pos - lo) >> gs], 1u);
-#endif
                 }
             }
         };
@@ -495,11 +474,7 @@ __global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTrai
             if (cnt > 0) match = search(cnt, key, row, val, pos);      // (wave-uniform; no memory instruction inside)
             commit(p.match && (!tmode || p.full == p.klow), p.pos, p.row, p.val);
             p.match = match; p.klow = (uint32_t)key; p.pos = (uint32_t)pos; p.row = row; p.val = val;
-#if defined(HARK_JB_EXP) && HARK_JB_EXP == 4                          // timing: every verification reads the same address
-            p.full = reinterpret_cast<const uint32_t *>(rkeys + base)[0]; p.klow = p.full;
-#else
             p.full = reinterpret_cast<const uint32_t *>(rkeys + base + (match ? (uint32_t)pos : 0u))[0];
-#endif
         };
         // A wave walks its slabs (every 16th of the bucket's) as ONE stream of 128-entry steps -- two entries per lane: one
         // 16-byte load for 8-byte pairs, two for 16-byte entries -- with the loads of the next two steps in flight across
@@ -537,18 +512,11 @@ __global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTrai
                 v0 = e0 < cur.count; v1 = e0 + 1u < cur.count;
                 key0 = (K)x0.x; row0 = x0.y; key1 = (K)x0.z; row1 = x0.w;
             }
-#if defined(HARK_JB_EXP) && HARK_JB_EXP == 2                          // timing experiments (tools/ab_build.sh + tools/jb_exp.sh; the results are wrong by construction): stream + candidate tests + queues, no search
-            enqueue(v0 && candidate(key0), key0, row0, val0);
-            if (qn >= 64) qn -= 64;
-            enqueue(v1 && candidate(key1), key1, row1, val1);
-            if (qn >= 64) qn -= 64;
-#else
             enqueue(v0 && candidate(key0), key0, row0, val0);        // qn < 64 before
             if (WIDE) drain_slot(qn >= 64 ? 64 : 0, pend[0]);        // 16-byte entries: never more than 63 + 64 queued
             enqueue(v1 && candidate(key1), key1, row1, val1);        // 8-byte pairs: at most 64 + 128 = QCAP queued
             if (WIDE) drain_slot(qn >= 64 ? 64 : 0, pend[1]);
             else while (qn >= 64) drain(64);
-#endif
         };
         // three register sets in turn, no copies between them: a move out of a register whose load is still in flight
         // would be a wait for it
@@ -647,9 +615,6 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
     __syncthreads();
     const unsigned long long dst = s_dst;
     if (nb == 0) return;
-#ifdef HARK_JORDER_PROF
-    unsigned long long jt0 = __builtin_readcyclecounter();
-#endif
     // every pass over survivors keeps 8 loads per lane in flight: one workgroup owns the CU, and with a single load per
     // lane the passes ran at the latency of a load, not at the CU's share of the bandwidth.  f(entry, third word)
     auto sweep = [&](const uint2 *sp, const uint32_t *spv, uint32_t i0, uint32_t i1, bool coherent, bool want_v, auto &&f) {
@@ -711,7 +676,6 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
         return;
     }
     scan_excl(coarse, ngroups + 1);                                    // coarse[g] = survivors before group g; coarse[ngroups] = nb
-    JPROF_MARK(0);
     const int rounds_b = (int)((len + (uint32_t)chunk_cap - 1u) / (uint32_t)chunk_cap);
     const bool by_round = rounds_b <= kMaxRounds && smode[b] == 0u;
     const uint32_t max_groups = max(1u, (uint32_t)FINE >> gs);
@@ -735,7 +699,6 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
         s_nsr = g < ngroups ? kMaxSub + 1 : k;                           // too many sub-rounds for the table: no binning
     }
     __syncthreads();
-    JPROF_MARK(1);
     const int nsr = s_nsr;
     const bool binned = nsr >= 3 && nsr <= kMaxSub && tmp_all != nullptr;
     uint2 *tmp = tmp_all + (size_t)b * stride;
@@ -760,7 +723,6 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
-    JPROF_MARK(2);
     uint32_t g0 = 0;
     while (g0 < ngroups) {
         const uint32_t base_cnt = coarse[g0];
@@ -777,18 +739,14 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
             }
             for (uint32_t i = tid; i <= nr; i += kJThreads) fine[i] = 0u;
             __syncthreads();
-            JPROF_MARK(3);
             sweep(sp, spv, i0, i1, binned, false, [&](uint2 e, uint32_t) { const uint32_t r = e.x - lo - r0; if (r < nr) atomicAdd(&fine[r], 1u); });
             __syncthreads();
-            JPROF_MARK(4);
             scan_excl(fine, nr);
-            JPROF_MARK(5);
             sweep(sp, spv, i0, i1, binned, true, [&](uint2 e, uint32_t v) {
                 const uint32_t r = e.x - lo - r0;
                 if (r < nr) { const uint32_t at = atomicAdd(&fine[r], 1u); stage[at] = e; if (CARRY) stv[at] = v; }   // afterwards fine[r] = end of rank r's rows
             });
             __syncthreads();
-            JPROF_MARK(6);
             // ---- rows of one rank into left-row order, and out: every survivor counts the rows of ITS rank (the stage's run
             // [fine[r-1], fine[r]), five or so) that are smaller than its own -- row ids are distinct, so that is its place in
             // the run -- and stores itself there.  (A first version sorted each run in registers with sorting networks, one
@@ -829,7 +787,6 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
                 }
             }
             __syncthreads();
-            JPROF_MARK(7);
         }
         g0 = g1;
     }
@@ -1050,12 +1007,3 @@ int k_join_partitioned(hark_context *ctx, const void *lcol, bool k64, int64_t n,
     *rank_out = rank2; *lrow_out = lrow2; *cnt_out = cnt; *lval_out = lv; *rval_out = rv; *m_out = M; *unique = !dup;
     return HARK_OK;
 }
-
-#ifdef HARK_JORDER_PROF
-extern "C" int hark_debug_jprof(unsigned long long *out16)
-{
-    unsigned long long zero[16] = {0};
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_jprof), sizeof zero) != hipSuccess) return 1;
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_jprof), zero, sizeof zero) == hipSuccess ? 0 : 1;
-}
-#endif

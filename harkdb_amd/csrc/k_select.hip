@@ -31,6 +31,10 @@ struct ColSet {
 };
 
 // ---- projection: coalesced per-column copy ---------------------------------
+// NTL / NTS: non-temporal loads / stores; D: 16-byte loads in flight per lane.  The default (1, 1, 2) came out of an A/B of all
+// eight variants on three boxes of the pool in one process each (tools/copy_ab.py, profiles/r04_copy_ab.log); HARK_COPY_VARIANT
+// = "<ntl><nts><d>" (e.g. "002") selects another one for such A/B runs.
+template <bool NTL, bool NTS, int D>
 __global__ __launch_bounds__(256) void copy_columns_kernel(ColSet cs, int64_t n)
 {
     const int col = blockIdx.y;
@@ -40,11 +44,16 @@ __global__ __launch_bounds__(256) void copy_columns_kernel(ColSet cs, int64_t n)
     uint4 *d4 = static_cast<uint4 *>(cs.dst[col]);
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + stride < nvec; i += 2 * stride) {      // two 16-byte loads in flight per lane
-        const uint4 a = ld_nt16(s4 + i), b = ld_nt16(s4 + i + stride);
-        st_nt16(d4 + i, a); st_nt16(d4 + i + stride, b);
+    auto ld = [&](int64_t q) -> uint4 { return NTL ? ld_nt16(s4 + q) : s4[q]; };
+    auto st = [&](int64_t q, uint4 v) { if (NTS) st_nt16(d4 + q, v); else d4[q] = v; };
+    for (; i + (D - 1) * stride < nvec; i += D * stride) {      // D 16-byte loads in flight per lane
+        uint4 a[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) a[d] = ld(i + d * stride);
+#pragma unroll
+        for (int d = 0; d < D; d++) st(i + d * stride, a[d]);
     }
-    for (; i < nvec; i += stride) st_nt16(d4 + i, ld_nt16(s4 + i));
+    for (; i < nvec; i += stride) st(i, ld(i));
     if (blockIdx.x == 0) {                            // tail bytes (n*esz not a multiple of 16)
         const uint32_t *s1 = static_cast<const uint32_t *>(cs.src[col]);
         uint32_t *d1 = static_cast<uint32_t *>(cs.dst[col]);
@@ -504,7 +513,19 @@ int k_gather_columns(hark_context *ctx, const hark_table *db, const int32_t *col
         int64_t blocks = (db->n * 8 / 16 + 255) / 256 / 2 + 1;
         int64_t cap = (int64_t)ctx->num_cu * 8 / cs.ncols + 1;
         if (blocks > cap) blocks = cap;
-        copy_columns_kernel<<<dim3((unsigned)blocks, (unsigned)cs.ncols), dim3(256), 0, ctx->stream>>>(cs, db->n);
+        const char *var = getenv("HARK_COPY_VARIANT");               // A/B runs only (tools/copy_ab.py)
+        const int code = (var && strlen(var) == 3) ? (var[0] - '0') * 4 + (var[1] - '0') * 2 + (var[2] == '4' ? 1 : 0) : 6;
+        const dim3 grid((unsigned)blocks, (unsigned)cs.ncols), blk(256);
+        switch (code) {
+        case 0: copy_columns_kernel<false, false, 2><<<grid, blk, 0, ctx->stream>>>(cs, db->n); break;
+        case 1: copy_columns_kernel<false, false, 4><<<grid, blk, 0, ctx->stream>>>(cs, db->n); break;
+        case 2: copy_columns_kernel<false, true, 2><<<grid, blk, 0, ctx->stream>>>(cs, db->n); break;
+        case 3: copy_columns_kernel<false, true, 4><<<grid, blk, 0, ctx->stream>>>(cs, db->n); break;
+        case 4: copy_columns_kernel<true, false, 2><<<grid, blk, 0, ctx->stream>>>(cs, db->n); break;
+        case 5: copy_columns_kernel<true, false, 4><<<grid, blk, 0, ctx->stream>>>(cs, db->n); break;
+        case 7: copy_columns_kernel<true, true, 4><<<grid, blk, 0, ctx->stream>>>(cs, db->n); break;
+        default: copy_columns_kernel<true, true, 2><<<grid, blk, 0, ctx->stream>>>(cs, db->n); break;
+        }
         HIP_TRY(ctx, hipGetLastError());
     }
     return HARK_OK;
