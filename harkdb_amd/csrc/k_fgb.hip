@@ -385,7 +385,7 @@ constexpr int kMaxBuckets8e = 128;
 constexpr int kFlushPeriod8e = 4;
 // ---- batches of a producer launch are handed out first come, first served ---------------------------------------
 // The XCDs of a card do not stream at the same rate: under a fixed assignment (batch = wg + j * nwg) the workgroup durations
-// of one launch spread by 6-10 % (per-XCD means differ by up to 6 %, tools/wg_times.py), and the kernel lasts as long as
+// of one launch spread by 6-10 % (per-XCD means differ by up to 6 %, profiles/r02_notes.md 12), and the kernel lasts as long as
 // its slowest workgroup.  A workgroup's step j works on batch seq(j): steps 0..3 are fixed (wg + j * nwg); from step 4 on
 // thread 0 draws kDraw consecutive batches at a time from a device counter (the word behind the plan's error word, zeroed
 // before every launch) -- asked for at step j, parked in an LDS ring at step j + 1, read by all threads from step j + 2 on,

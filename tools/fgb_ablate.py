@@ -1,4 +1,4 @@
-"""A/B timing of fused filter->group-by configurations with the library's own HIP-event timers.
+"""A/B timing of fused filter->group-by plan configurations (grid, shift, period, pairfmt, chunk_rows, slack_pct, G) with the library's own HIP-event timers.
 Interleaved rounds (config order repeated R times) so clock drift hits every arm alike.
 Usage: python tools/fgb_ablate.py [N] ["k=v,k=v;k=v,..."]"""
 import os, sys, time
@@ -15,10 +15,8 @@ eng = Engine(0)
 p, k, v = eng.alloc(N * 4), eng.alloc(N * 4), eng.alloc(N * 4)
 eng.gen_columns(0x4861726B4442, 0, N, G, True, p, k, v)
 plans = []
-late = []                      # knobs applied right before each run (same plan shared by configs that only differ in `ablate`)
 shared = {}
 for c in configs:
-    ab = c.pop("ablate", 0)
     c.pop("tag", None)                    # tag=<n>: a second, separate plan of an otherwise identical configuration
     key = tuple(sorted(c.items())) + ((("tag", len(plans)),) if "tag=" in spec.split(";")[len(plans)] else ())
     if key not in shared:
@@ -29,14 +27,14 @@ for c in configs:
             pl.set(kk, vv)
         pl.set("timing", 1)
         shared[key] = pl
-    plans.append(shared[key]); late.append(ab)
+    plans.append(shared[key])
 res = [[] for _ in plans]
-ref = None            # every configuration must produce the same table (ablate != 0 excepted: those are wrong by design)
+ref = None            # every configuration must produce the same table
 so, co = eng.alloc(G * 4), eng.alloc(G * 8)
 for i, pl in enumerate(plans):
-    if late[i] & 0xFFF or pl.G != G:
+    if pl.G != G:
         continue
-    pl.set("ablate", late[i]); pl.reset(); pl.run(p, ">", 0.5, k, v, N); pl.finish(so, co)
+    pl.reset(); pl.run(p, ">", 0.5, k, v, N); pl.finish(so, co)
     got = (eng.download(so, G, np.float32), eng.download(co, G, np.int64))
     if ref is None:
         ref = got
@@ -46,7 +44,6 @@ for i, pl in enumerate(plans):
     pl.timing()
 for r in range(R + 1):
     for i, pl in enumerate(plans):
-        pl.set("ablate", late[i])
         pl.reset(); pl.run(p, ">", 0.5, k, v, N); ms, cnt = pl.timing()
         if r:
             res[i].append((ms["producer"] + ms["single"], ms["consumer"]))

@@ -1,8 +1,8 @@
-# join timings + kernel breakdown of the three join workloads.  Usage (gpurun): bash tools/jrun.sh <outdir>
+# join timings + kernel breakdown of the join workloads.  Usage (gpurun): bash tools/jrun.sh <outdir>   (a fresh directory per run)
 export TMPDIR=/tmp
-O=$1; rm -rf $O; mkdir -p $O
-timeout 200 rocprofv3 --kernel-trace --output-format csv -d $O/u32 -- python3 tools/join_one.py 1e8 1e7 > $O/u32.log 2>&1
-timeout 200 rocprofv3 --kernel-trace --output-format csv -d $O/i64 -- python3 tools/join_one.py 1.25e8 1.25e7 i64 > $O/i64.log 2>&1
-timeout 200 rocprofv3 --kernel-trace --output-format csv -d $O/c4 -- python3 tools/join_c4.py > $O/c4.log 2>&1
-for w in u32 i64 c4; do grep join $O/$w.log | tail -2; python tools/jtrace.py $O/$w > $O/$w.trace; sed -n '/---- per/,$p' $O/$w.trace | head -14; done
+O=$1; if [ -e "$O" ]; then echo "$O exists: name a fresh directory" >&2; exit 2; fi; mkdir -p $O
+for w in join_u32 join_c4; do
+  timeout 200 rocprofv3 --kernel-trace --output-format csv -d $O/$w -- python3 tools/op_one.py $w 1.0 4 > $O/$w.log 2>&1
+  grep "$w:" $O/$w.log | tail -2; python tools/ktrace.py $O/$w 0.25 > $O/$w.trace; head -16 $O/$w.trace
+done
 find $O -name "*.csv" -size +5M -delete

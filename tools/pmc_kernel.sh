@@ -1,4 +1,4 @@
-# SQ PMC counters per dispatch of the kernels whose name contains $1: bash tools/pmc_kernel.sh <kernel substring> <script.py> [args ...]
+# SQ PMC counters per dispatch of the kernels whose name contains $1: bash tools/pmc_kernel.sh <kernel substring> <script.py> [args ...]   (e.g. jbucket op_one.py join_c4)
 # (prints the last dispatch of every matching kernel; counters in millions, summed over the launch)
 export TMPDIR=/tmp
 PAT=$1; shift
