@@ -20,10 +20,13 @@
 //      yields the GLOBAL rank of the first equal build entry, so a matching probe row becomes
 //      (rank, left row id), appended wave by wave to the bucket's survivor slab;
 //   5. jorder_kernel: the survivors of a bucket (only the matching rows) are brought into
-//      (rank, left row) order inside the CU -- coarse histogram, sub-round bins, one LDS counter
-//      per rank, an LDS stage, the few rows of one key sorted in registers -- and leave as whole
-//      lines of (rank, left row, partner count); buckets are rank ranges in ascending order, so
-//      the concatenation is sorted (a rank with > 64 probe rows: two radix sorts instead);
+//      (rank, left row) order inside the CU.  The bucket kernel has already dealt them into BINS --
+//      fixed, equal ranges of the bucket's ranks, sized so that a bin's survivors fit the LDS stage --
+//      and counted them per group of ranks, so the order kernel reads each bin twice (one LDS
+//      counter per rank, then placement into the stage), places every row inside its key's run by
+//      counting the smaller row ids, and writes (rank, left row, partner count) / the carried
+//      columns; buckets are rank ranges in ascending order, so the concatenation is sorted (a rank
+//      with > 64 probe rows: two radix sorts instead);
 //   6. unique build keys: survivor i IS output row i (the right row id is one gather away);
 //      otherwise the partner counts are scanned and one lane per matching row writes its
 //      (left row id, right row id) pairs -- join_expand_kernel of k_join.hip.
@@ -40,7 +43,7 @@ namespace {
 constexpr int kJThreads = 1024;
 constexpr int kJErrOverflow = 100;
 constexpr int kJIdx = 2048;                               // entries of the bucket kernel's radix index over a round's keys
-constexpr int kMaxRounds = 16;                           // bucket-kernel rounds whose survivor counts are recorded (the order kernel reads per round)
+constexpr int kMaxBins = 64;                             // survivor bins per bucket (fixed rank ranges, written by the bucket kernel, read by the order kernel)
 constexpr size_t kJLdsBudget = 160 * 1024 - 512;          // one workgroup per CU owns (almost) all of its LDS
 
 struct JPair32 { uint32_t key, row; };                                    // 8 bytes: 16 per 128-byte line
@@ -48,7 +51,27 @@ struct __attribute__((aligned(16))) JPair64 { uint64_t key; uint32_t row, pad; }
 
 // the order kernel's geometry (jorder_kernel): survivors staged per sub-round and per-rank counters -- with a third word per
 // survivor 10240 x 12 B + 6144 counters, without 12288 x 8 B + 10240 counters (~150 KiB of LDS either way)
-constexpr int kStage = 12288, kStageCarry = 10240, kFine = 10240, kFineCarry = 6144, kCoarse = 2048, kTieMax = 64, kMaxSub = 256;
+constexpr int kStage = 12288, kStageCarry = 10240, kFine = 10240, kFineCarry = 6144, kCoarse = 2048, kTieMax = 64;
+
+// Bins of a bucket's survivors: the bucket's len ranks are cut into nb <= kMaxBins ranges of 2^bs ranks (whole groups of the
+// coarse histogram: bs >= gs), as few as keep a bin's EXPECTED survivors under the order kernel's stage when every second
+// probe pair of the bucket finds a partner and the partners are spread evenly; a fuller bin simply takes several sub-rounds
+// in the order kernel.  Both kernels derive the geometry from the same inputs (the bucket kernel publishes it in sbinfo).
+struct JBins { int gs, bs, nb; uint32_t cap; };
+__device__ __forceinline__ JBins jbins_of(uint32_t len, uint32_t nprobe, int stage_cap, size_t region)
+{
+    JBins g;
+    g.gs = 0;
+    while (((len + (1u << g.gs) - 1u) >> g.gs) > (uint32_t)kCoarse) g.gs++;
+    uint32_t want = (nprobe / 2u + (uint32_t)stage_cap - 1u) / (uint32_t)stage_cap;
+    want = want < 1u ? 1u : want > (uint32_t)kMaxBins ? (uint32_t)kMaxBins : want;
+    g.bs = g.gs;
+    while (((len + (1u << g.bs) - 1u) >> g.bs) > want) g.bs++;
+    g.nb = (int)((len + (1u << g.bs) - 1u) >> g.bs);
+    if (g.nb < 1) g.nb = 1;
+    g.cap = (uint32_t)((region / (size_t)g.nb) & ~(size_t)15);
+    return g;
+}
 
 template <typename K> struct JTraits;
 // P buckets, rings of Q entries, VEC rows per lane and batch; the bucket kernel stages CHUNK sorted build keys per
@@ -307,11 +330,12 @@ __global__ __launch_bounds__(kJThreads) void jpart_kernel(const K *__restrict__ 
 template <typename K>
 __global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTraits<K>::E *__restrict__ slabs, const uint32_t *__restrict__ counts,
                                                             uint32_t cap, int nwg, const K *__restrict__ rkeys, const uint32_t *__restrict__ bstart,
-                                                            int chunk_cap, uint2 *__restrict__ surv, uint32_t *__restrict__ scount,
-                                                            uint32_t *__restrict__ sround /* [P][kMaxRounds] survivors after round q */,
+                                                            int chunk_cap, uint2 *__restrict__ surv, size_t region /* survivor entries per bucket */,
+                                                            uint32_t *__restrict__ scount /* [P] survivors of the bucket */,
+                                                            uint32_t *__restrict__ sbins /* [P][kMaxBins] survivors in every bin */,
                                                             uint32_t *__restrict__ sval /* may be null: the entries' fourth word of every survivor (same index as surv) */,
                                                             uint32_t *__restrict__ scoarse /* [P][kCoarse] survivors per group of ranks: the order kernel's first histogram */,
-                                                            uint32_t *__restrict__ smode /* [P] 1: the bucket ran as ONE round over truncated keys (its survivors are not grouped by round) */,
+                                                            int stage_cap /* the order kernel's stage (sizes the bins) */, int32_t *__restrict__ err,
                                                             int allow_trunc)
 {
     typedef typename JTraits<K>::E E;
@@ -334,18 +358,30 @@ __global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTrai
     // of 64 candidates instead of 16.  (Neither this nor the skew above moved the kernel's time on BASELINE configs[3]'s
     // share -- the lookup is not what it waits for, profiles/r03_notes.md 5.1 -- but both take load off the LDS.)
     uint16_t *s_idx = reinterpret_cast<uint16_t *>(s_coarse + kCoarse);                 // [kJIdx + 1]
-    __shared__ uint32_t s_n;
+    __shared__ uint32_t s_bincur[kMaxBins];                               // survivors in every bin so far
+    __shared__ uint32_t s_np;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = kJThreads >> 6;
     K *qkey = qkey_all + wave * QCAP;
     uint32_t *qrow = qrow_all + wave * QCAP;
     uint32_t *qval = qval_all + wave * QCAP;
     const uint32_t lo = bstart[b], hi = bstart[b + 1];
-    int gs = 0;                                                          // the order kernel's grouping of this bucket's ranks
-    while (((hi - lo + (1u << gs) - 1u) >> gs) > (uint32_t)kCoarse) gs++;
     for (int i = tid; i < kCoarse; i += kJThreads) s_coarse[i] = 0u;
-    if (tid == 0) s_n = 0u;
-    uint2 *out = surv + (size_t)b * nwg * cap;                             // room for every probe pair of the bucket
-    uint32_t *vout = sval ? sval + (size_t)b * nwg * cap : nullptr;
+    if (tid < kMaxBins) s_bincur[tid] = 0u;
+    if (tid == 0) s_np = 0u;
+    __syncthreads();
+    {   // the bucket's probe pairs (sizes the bins)
+        uint32_t np = 0;
+        for (int i = tid; i < nwg; i += kJThreads) np += min(counts[(size_t)b * nwg + i], cap);
+        for (int d = 32; d > 0; d >>= 1) np += __shfl_down(np, d, 64);
+        if (lane == 0 && np) atomicAdd(&s_np, np);
+    }
+    __syncthreads();
+    const JBins bins = jbins_of(hi - lo, s_np, stage_cap, region);       // the order kernel's grouping of this bucket's ranks and its bins
+    const int gs = bins.gs, bs = bins.bs;
+    const uint32_t bincap = bins.cap;
+    uint2 *out = surv + (size_t)b * region;
+    uint32_t *vout = sval ? sval + (size_t)b * region : nullptr;
+    bool bin_full = false;
     const unsigned long long below = (1ull << lane) - 1ull;
     // 64-bit keys: a bucket of up to two chunks of build keys (BASELINE configs[3]: 24.4 K against 12 K per 96-KiB chunk)
     // would stream its probe entries twice.  Instead the chunk area holds the keys TRUNCATED to 32 bits,
@@ -374,13 +410,10 @@ __global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTrai
         __syncthreads();
         tmode = s_tbad == 0;
     }
-    if (tid == 0) smode[b] = tmode ? 1u : 0u;
     const uint32_t round_keys = tmode ? hi - lo : (uint32_t)chunk_cap;
-    int q = 0;                                                       // rounds done
-    for (uint32_t base = lo; base < hi; base += round_keys, q++) {
+    for (uint32_t base = lo; base < hi; base += round_keys) {
         const int m = (int)min(round_keys, hi - base);
-        __syncthreads();                                             // the previous round's readers are done (and s_n is set)
-        if (tid == 0 && q > 0 && q <= kMaxRounds) sround[b * kMaxRounds + q - 1] = s_n;
+        __syncthreads();                                             // the previous round's readers are done
         for (int i = tid; i < BM_WORDS; i += kJThreads) bitmap[i] = 0u;
         if (!tmode) for (int i = tid; i < m; i += kJThreads) ck(i) = rkeys[base + i];
         __syncthreads();
@@ -411,19 +444,19 @@ __global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTrai
             if (c) { const int at = qn + __popcll(mask & below); qkey[at] = key; qrow[at] = row; if (sizeof(E) == 16) qval[at] = val; }
             qn += __popcll(mask);
         };
-        // a hit is appended to the bucket's survivors (stores the compiler does not count: see st_hidden_b32)
+        // a hit goes to the bin of its rank (a fixed range of the bucket's ranks: what the order kernel stages together): one
+        // returning LDS atomic on the bin's cursor is its place (stores the compiler does not count: see st_hidden_b32)
         auto commit = [&](bool match, uint32_t pos, uint32_t row, uint32_t val) {
-            const unsigned long long mask = __ballot(match);
-            if (mask) {
-                uint32_t at = 0;
-                if (lane == 0) at = atomicAdd(&s_n, (uint32_t)__popcll(mask));
-                at = __shfl(at, 0, 64);
-                if (match) {
-                    const uint32_t o = at + (uint32_t)__popcll(mask & below);
+            if (match) {
+                const uint32_t r = base + pos - lo;
+                const uint32_t bin = r >> bs;
+                const uint32_t at = atomicAdd(&s_bincur[bin], 1u);
+                if (at < bincap) {
+                    const size_t o = (size_t)bin * bincap + at;
                     st_hidden_b64(out + o, uint2{base + pos, row});
                     if (sizeof(E) == 16 && vout) st_hidden_b32(vout + o, val);
-                    atomicAdd(&s_coarse[(base + pos - lo) >> gs], 1u);
-                }
+                    atomicAdd(&s_coarse[r >> gs], 1u);
+                } else bin_full = true;                                // probe keys crowd a few ranks: the caller takes another path
             }
         };
         // 16-byte entries: a batch's hits are committed one step LATER (two slots, one per half-step).  With truncated keys
@@ -541,8 +574,10 @@ __global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTrai
             drain_slot(0, pend[0]);
         } else if (qn > 0) drain(qn);
     }
+    if (bin_full) *err = kJErrOverflow;
     __syncthreads();
-    if (tid == 0) { scount[b] = s_n; if (q > 0 && q <= kMaxRounds) sround[b * kMaxRounds + q - 1] = s_n; }
+    if (tid < kMaxBins) sbins[(size_t)b * kMaxBins + tid] = min(s_bincur[tid], bincap);
+    if (tid == 0) { uint32_t t = 0; for (int j = 0; j < bins.nb; j++) t += min(s_bincur[j], bincap); scount[b] = t; }
     for (int i = tid; i < kCoarse; i += kJThreads) scoarse[(size_t)b * kCoarse + i] = s_coarse[i];
 }
 
@@ -558,33 +593,31 @@ __global__ __launch_bounds__(1024) void jsum_kernel(const uint32_t *__restrict__
     if (threadIdx.x == 0) *total = s_t;
 }
 
-// Survivor slabs -> contiguous arrays (rank, left row, partner count) ORDERED BY (rank, left row): buckets are rank
+// Survivor bins -> contiguous arrays (rank, left row, partner count) ORDERED BY (rank, left row): buckets are rank
 // ranges in ascending order, so a workgroup orders its own bucket and writes behind the earlier buckets.
-//   1. coarse histogram of the bucket's survivors over groups of 2^gs ranks (one read of the slab);
-//   2. sub-rounds: as many consecutive groups as fit the LDS stage (kStage survivors) and the fine counters (kFine
-//      ranks); a sub-round re-reads only the survivors of the bucket-kernel rounds its rank range overlaps (the bucket
-//      kernel appends round after round, sround[] holds the boundaries);
-//   3. inside a sub-round: one LDS counter per rank (histogram, exclusive scan, placement into the stage), then the
-//      thread that owns a rank sorts that rank's few rows by left row id in LDS (insertion sort; the fan-out of a
-//      key), and the stage leaves the CU as contiguous whole-line stores -- the scattered 4-byte global stores of the
-//      first version ran at 0.8 TB/s.
+//   1. the bucket kernel's histogram of the survivors over groups of 2^gs ranks gives every group's place in the output;
+//   2. sub-rounds: as many consecutive groups as fit the LDS stage (stage_cap survivors) and the fine counters (FINE
+//      ranks), cut at bin boundaries where possible -- a sub-round reads the bins its rank range overlaps: whole bins, or
+//      (a crowded bin) one bin several times;
+//   3. inside a sub-round: one LDS counter per rank (histogram, exclusive scan, placement into the stage), then every
+//      survivor finds its place inside its rank's run by counting the smaller row ids of the run, and the rows leave the
+//      CU in output order.
+// (Round 3 read a bucket's survivors as ONE unordered slab and binned them itself -- read, write, read twice: a third of
+// the kernel's time and 35 % of its traffic; the bins now arrive from the bucket kernel.)
 // A group of 2^gs ranks with more survivors than the stage holds, or a rank with more than kTieMax rows, raises *general:
 // the bucket is copied as it is and the caller sorts all survivors with radix passes instead.
-// Sorting networks over N registers: sort_networks.h (uint32 values, plain order here).
 // CARRY: every survivor has a third word (a probe-side output column, sval / lval_out) that is ordered along with it; the
 // stage then holds kStageCarry survivors (12 bytes each).
 template <bool CARRY>
-__global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restrict__ surv, size_t stride, const uint32_t *__restrict__ scount,
-                                                           const uint32_t *__restrict__ sround, int chunk_cap,
+__global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restrict__ surv, size_t region, const uint32_t *__restrict__ scount,
+                                                           const uint32_t *__restrict__ sbins, const uint32_t *__restrict__ counts, uint32_t cap, int nwg,
                                                            const uint32_t *__restrict__ bstart, int P, const uint32_t *__restrict__ runlen,
                                                            uint32_t *__restrict__ rank, uint32_t *__restrict__ lrow, uint32_t *__restrict__ cnt_out /* may be null */,
                                                            int stage_cap /* <= kStage / kStageCarry (tests: smaller) */, int32_t *__restrict__ general,
-                                                           uint2 *tmp_all /* scratch, same layout as surv (the probe slabs, dead by now) */,
-                                                           const uint32_t *__restrict__ sval, uint32_t *__restrict__ lval_out, uint32_t *tmpv_all,
+                                                           const uint32_t *__restrict__ sval, uint32_t *__restrict__ lval_out,
                                                            const uint32_t *__restrict__ scoarse,
                                                            const uint32_t *__restrict__ rranked /* may be null: a build-side column in rank order ... */,
-                                                           uint32_t *__restrict__ rval_out /* ... read off for every survivor (unique build keys: survivor = output row) */,
-                                                           const uint32_t *__restrict__ smode /* [P] 1: the bucket kernel ran this bucket as one round */)
+                                                           uint32_t *__restrict__ rval_out /* ... read off for every survivor (unique build keys: survivor = output row) */)
 {
     constexpr int STAGE = CARRY ? kStageCarry : kStage, FINE = CARRY ? kFineCarry : kFine;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -594,22 +627,29 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
     uint32_t *coarse = fine + FINE + 1;                                        // [kCoarse + 1] counts, then exclusive prefix
     __shared__ unsigned long long s_dst;
     __shared__ uint32_t s_wave[kJThreads / 64];
-    __shared__ int s_bad, s_nsr;
-    __shared__ uint16_t s_subg[kMaxSub + 1];                                   // first group of every sub-round
-    __shared__ uint32_t s_bincur[kMaxSub];                                     // next free slot of every sub-round's bin
-    __shared__ uint8_t s_gsub[kCoarse];                                        // sub-round of every coarse group (binning)
+    __shared__ uint32_t s_bincnt[kMaxBins];
+    __shared__ uint32_t s_np;
+    __shared__ int s_bad;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) { s_dst = 0ull; s_bad = 0; s_nsr = 0; }
+    if (tid == 0) { s_dst = 0ull; s_bad = 0; s_np = 0u; }
+    if (tid < kMaxBins) s_bincnt[tid] = sbins[(size_t)b * kMaxBins + tid];
     __syncthreads();
     unsigned long long part = 0;
     for (int qq = tid; qq < b; qq += kJThreads) part += scount[qq];
     for (int d = 32; d > 0; d >>= 1) part += __shfl_down(part, d, 64);
     if (lane == 0 && part) atomicAdd(&s_dst, part);
+    {   // the bucket's probe pairs: the bucket kernel sized the bins from them
+        uint32_t np = 0;
+        for (int i = tid; i < nwg; i += kJThreads) np += min(counts[(size_t)b * nwg + i], cap);
+        for (int d = 32; d > 0; d >>= 1) np += __shfl_down(np, d, 64);
+        if (lane == 0 && np) atomicAdd(&s_np, np);
+    }
     const uint32_t lo = bstart[b], len = bstart[b + 1] - lo, nb = scount[b];
-    const uint2 *src = surv + (size_t)b * stride;
-    const uint32_t *srcv = CARRY ? sval + (size_t)b * stride : nullptr;
-    int gs = 0;
-    while (((len + (1u << gs) - 1u) >> gs) > (uint32_t)kCoarse) gs++;
+    __syncthreads();
+    const JBins bins = jbins_of(len, s_np, stage_cap, region);
+    const int gs = bins.gs, kb = bins.bs - bins.gs;                            // a bin = 2^kb consecutive groups
+    const uint2 *src = surv + (size_t)b * region;
+    const uint32_t *srcv = CARRY ? sval + (size_t)b * region : nullptr;
     const uint32_t ngroups = (len + (1u << gs) - 1u) >> gs;
     for (uint32_t i = tid; i <= ngroups; i += kJThreads) coarse[i] = i < ngroups ? scoarse[(size_t)b * kCoarse + i] : 0u;   // counted by the bucket kernel
     __syncthreads();
@@ -617,27 +657,21 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
     if (nb == 0) return;
     // every pass over survivors keeps 8 loads per lane in flight: one workgroup owns the CU, and with a single load per
     // lane the passes ran at the latency of a load, not at the CU's share of the bandwidth.  f(entry, third word)
-    auto sweep = [&](const uint2 *sp, const uint32_t *spv, uint32_t i0, uint32_t i1, bool coherent, bool want_v, auto &&f) {
-        auto ld = [&](uint32_t i) -> uint2 {
-            if (!coherent) return sp[i];
-            // workgroup-scope load: the bins were written by other waves of this workgroup in this kernel
-            const unsigned long long w = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(sp + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            return uint2{(uint32_t)w, (uint32_t)(w >> 32)};
-        };
-        auto ldv = [&](uint32_t i) -> uint32_t {
-            if (!CARRY || !want_v) return 0u;
-            if (!coherent) return spv[i];
-            return __hip_atomic_load(spv + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        };
-        uint32_t i = i0 + tid;
+    auto sweep = [&](const uint2 *sp, const uint32_t *spv, uint32_t i1, bool want_v, auto &&f) {
+        uint32_t i = tid;
         for (; i + 7u * kJThreads < i1; i += 8u * kJThreads) {
             uint2 e[8]; uint32_t v[8];
 #pragma unroll
-            for (int k = 0; k < 8; k++) { e[k] = ld(i + (uint32_t)k * kJThreads); v[k] = ldv(i + (uint32_t)k * kJThreads); }
+            for (int k = 0; k < 8; k++) { e[k] = sp[i + (uint32_t)k * kJThreads]; v[k] = (CARRY && want_v) ? spv[i + (uint32_t)k * kJThreads] : 0u; }
 #pragma unroll
             for (int k = 0; k < 8; k++) f(e[k], v[k]);
         }
-        for (; i < i1; i += kJThreads) f(ld(i), ldv(i));
+        for (; i < i1; i += kJThreads) f(sp[i], (CARRY && want_v) ? spv[i] : 0u);
+    };
+    // the bins that hold the ranks of groups [g0, g1)
+    auto sweep_bins = [&](uint32_t g0, uint32_t g1, bool want_v, auto &&f) {
+        for (uint32_t j = g0 >> kb; j <= (g1 - 1u) >> kb; j++)
+            sweep(src + (size_t)j * bins.cap, CARRY ? srcv + (size_t)j * bins.cap : nullptr, s_bincnt[j], want_v, f);
     };
     // block-wide exclusive scan helper over a[0, m): a contiguous segment per thread, waves chained through LDS;
     // returns the total
@@ -664,85 +698,46 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
         if (big || (1u << gs) > (uint32_t)FINE) s_bad = 1;
     }
     __syncthreads();
-    if (s_bad) {
-        for (uint32_t i = tid; i < nb; i += kJThreads) {
-            const uint2 e = src[i];
-            if (rank) { rank[dst + i] = e.x; lrow[dst + i] = e.y; }        // (the general sort needs them: the host runs the kernel again with the arrays if it left them out)
-            if (cnt_out) cnt_out[dst + i] = runlen[e.x];
-            if (CARRY) lval_out[dst + i] = srcv[i];                   // (the caller drops the carried words on the general path)
-            if (rranked) rval_out[dst + i] = rranked[e.x];
+    const bool bad = s_bad != 0;
+    scan_excl(coarse, ngroups + 1);                                    // coarse[g] = survivors before group g; coarse[ngroups] = nb
+    if (bad) {                                                         // bin after bin, as they are
+        for (uint32_t j = 0; j < (uint32_t)bins.nb; j++) {
+            const unsigned long long o = dst + coarse[min(ngroups, j << kb)];      // the survivors of the bins before bin j
+            const uint2 *sp = src + (size_t)j * bins.cap;
+            for (uint32_t i = tid; i < s_bincnt[j]; i += kJThreads) {
+                const uint2 e = sp[i];
+                if (rank) { rank[o + i] = e.x; lrow[o + i] = e.y; }    // (the general sort needs them: the host runs the kernel again with the arrays if it left them out)
+                if (cnt_out) cnt_out[o + i] = runlen[e.x];
+                if (CARRY) lval_out[o + i] = srcv[(size_t)j * bins.cap + i];   // (the caller drops the carried words on the general path)
+                if (rranked) rval_out[o + i] = rranked[e.x];
+            }
         }
         if (tid == 0) *general = 1;
         return;
     }
-    scan_excl(coarse, ngroups + 1);                                    // coarse[g] = survivors before group g; coarse[ngroups] = nb
-    const int rounds_b = (int)((len + (uint32_t)chunk_cap - 1u) / (uint32_t)chunk_cap);
-    const bool by_round = rounds_b <= kMaxRounds && smode[b] == 0u;
     const uint32_t max_groups = max(1u, (uint32_t)FINE >> gs);
     bool too_long = false;
     // the end of the sub-round that starts at group g0: the largest g1 with coarse[g1] - coarse[g0] <= stage_cap and
-    // g1 - g0 <= max_groups (a single group always fits: checked above)
+    // g1 - g0 <= max_groups (a single group always fits: checked above), moved back to a bin boundary when one lies
+    // inside (a sub-round is then a run of whole bins, or a piece of one crowded bin)
     auto sub_end = [&](uint32_t g0) -> uint32_t {
         uint32_t a = g0 + 1, z = min(ngroups, g0 + max_groups);
         const uint32_t base_cnt = coarse[g0];
         while (a < z) { const uint32_t mid = (a + z + 1) >> 1; if (coarse[mid] - base_cnt <= (uint32_t)stage_cap) a = mid; else z = mid - 1; }
+        if (a < ngroups) { const uint32_t snap = (a >> kb) << kb; if (snap > g0) a = snap; }
         return a;
     };
-    // With three or more sub-rounds the survivors are first BINNED by sub-round (exact bin sizes are known from the
-    // coarse prefix), so that a sub-round reads its own survivors only instead of the whole round's; the bins live in
-    // the dead probe slabs.  (Without it a bucket of BASELINE configs[3] was read 11 times over: 1.8 ms of 7.)
-    if (tid == 0) {
-        int k = 0;
-        uint32_t g = 0;
-        while (g < ngroups && k < kMaxSub) { s_subg[k++] = (uint16_t)g; g = sub_end(g); }
-        s_subg[k] = (uint16_t)ngroups;
-        s_nsr = g < ngroups ? kMaxSub + 1 : k;                           // too many sub-rounds for the table: no binning
-    }
-    __syncthreads();
-    const int nsr = s_nsr;
-    const bool binned = nsr >= 3 && nsr <= kMaxSub && tmp_all != nullptr;
-    uint2 *tmp = tmp_all + (size_t)b * stride;
-    uint32_t *tmpv = CARRY ? tmpv_all + (size_t)b * stride : nullptr;
-    if (binned) {
-        // one LDS read finds a survivor's sub-round (a table over the coarse groups instead of a binary search over the
-        // sub-round boundaries: four dependent LDS round trips per survivor), one returning atomic on the bin's cursor --
-        // which starts at the bin's first slot -- its place
-        for (uint32_t g = tid; g < ngroups; g += kJThreads) {
-            int a = 0, z = nsr - 1;
-            while (a < z) { const int mid = (a + z + 1) >> 1; if ((uint32_t)s_subg[mid] <= g) a = mid; else z = mid - 1; }
-            s_gsub[g] = (uint8_t)a;
-        }
-        for (int k = tid; k < nsr; k += kJThreads) s_bincur[k] = coarse[s_subg[k]];
-        __syncthreads();
-        sweep(src, srcv, 0u, nb, false, true, [&](uint2 e, uint32_t v) {
-            const uint32_t at = atomicAdd(&s_bincur[s_gsub[(e.x - lo) >> gs]], 1u);
-            tmp[at] = e;
-            if (CARRY) tmpv[at] = v;
-        });
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");         // the bins are read back by other waves of this workgroup (same CU, same L1)
-        __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    }
     uint32_t g0 = 0;
     while (g0 < ngroups) {
         const uint32_t base_cnt = coarse[g0];
         const uint32_t g1 = sub_end(g0), r0 = g0 << gs, r1 = min(len, g1 << gs), nr = r1 - r0, nsub = coarse[g1] - base_cnt;
         if (nsub) {
-            uint32_t i0 = 0, i1 = nb;
-            const uint2 *sp = src;
-            const uint32_t *spv = srcv;
-            if (binned) { sp = tmp + base_cnt; spv = CARRY ? tmpv + base_cnt : nullptr; i0 = 0; i1 = nsub; }
-            else if (by_round) {
-                const int q0 = (int)(r0 / (uint32_t)chunk_cap), q1 = (int)((r1 - 1u) / (uint32_t)chunk_cap);
-                i0 = q0 > 0 ? sround[b * kMaxRounds + q0 - 1] : 0u;
-                i1 = sround[b * kMaxRounds + q1];
-            }
             for (uint32_t i = tid; i <= nr; i += kJThreads) fine[i] = 0u;
             __syncthreads();
-            sweep(sp, spv, i0, i1, binned, false, [&](uint2 e, uint32_t) { const uint32_t r = e.x - lo - r0; if (r < nr) atomicAdd(&fine[r], 1u); });
+            sweep_bins(g0, g1, false, [&](uint2 e, uint32_t) { const uint32_t r = e.x - lo - r0; if (r < nr) atomicAdd(&fine[r], 1u); });
             __syncthreads();
             scan_excl(fine, nr);
-            sweep(sp, spv, i0, i1, binned, true, [&](uint2 e, uint32_t v) {
+            sweep_bins(g0, g1, true, [&](uint2 e, uint32_t v) {
                 const uint32_t r = e.x - lo - r0;
                 if (r < nr) { const uint32_t at = atomicAdd(&fine[r], 1u); stage[at] = e; if (CARRY) stv[at] = v; }   // afterwards fine[r] = end of rank r's rows
             });
@@ -793,24 +788,35 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
     if (__ballot(too_long) != 0ull && lane == 0) *general = 1;
 }
 
-// survivor slabs -> two contiguous arrays (rank, left row); dst offsets = exclusive scan of scount, done by every
-// workgroup for itself (P <= 1024 values)
-__global__ __launch_bounds__(256) void jcompact_kernel(const uint2 *__restrict__ surv, size_t stride, const uint32_t *__restrict__ scount,
-                                                       int P, uint32_t *__restrict__ rank, uint32_t *__restrict__ lrow)
+// survivor bins -> two contiguous arrays (rank, left row), unordered inside a bucket (the FULLSORT knob: radix sorts by the
+// caller); dst offsets = exclusive scan of scount, done by every workgroup for itself (P <= 1024 values)
+__global__ __launch_bounds__(256) void jcompact_kernel(const uint2 *__restrict__ surv, size_t region, const uint32_t *__restrict__ scount,
+                                                       const uint32_t *__restrict__ sbins, const uint32_t *__restrict__ counts, uint32_t cap, int nwg,
+                                                       const uint32_t *__restrict__ bstart, int stage_cap, uint32_t *__restrict__ rank, uint32_t *__restrict__ lrow)
 {
     __shared__ unsigned long long s_dst;
+    __shared__ uint32_t s_np, s_off[kMaxBins + 1];
     const int b = blockIdx.x;
-    if (threadIdx.x == 0) s_dst = 0ull;
+    if (threadIdx.x == 0) { s_dst = 0ull; s_np = 0u; }
     __syncthreads();
     unsigned long long part = 0;
     for (int q = threadIdx.x; q < b; q += blockDim.x) part += scount[q];
     for (int d = 32; d > 0; d >>= 1) part += __shfl_down(part, d, 64);
     if ((threadIdx.x & 63) == 0 && part) atomicAdd(&s_dst, part);
+    uint32_t np = 0;
+    for (int i = threadIdx.x; i < nwg; i += blockDim.x) np += min(counts[(size_t)b * nwg + i], cap);
+    for (int d = 32; d > 0; d >>= 1) np += __shfl_down(np, d, 64);
+    if ((threadIdx.x & 63) == 0 && np) atomicAdd(&s_np, np);
+    __syncthreads();
+    const JBins bins = jbins_of(bstart[b + 1] - bstart[b], s_np, stage_cap, region);
+    if (threadIdx.x == 0) { uint32_t run = 0; for (int j = 0; j < bins.nb; j++) { s_off[j] = run; run += sbins[(size_t)b * kMaxBins + j]; } s_off[bins.nb] = run; }
     __syncthreads();
     const unsigned long long dst = s_dst;
-    const uint2 *src = surv + (size_t)b * stride;
-    const uint32_t cnt = scount[b];
-    for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) { const uint2 e = src[i]; rank[dst + i] = e.x; lrow[dst + i] = e.y; }
+    for (int j = 0; j < bins.nb; j++) {
+        const uint2 *src = surv + (size_t)b * region + (size_t)j * bins.cap;
+        const uint32_t cnt = s_off[j + 1] - s_off[j];
+        for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) { const uint2 e = src[i]; rank[dst + s_off[j] + i] = e.x; lrow[dst + s_off[j] + i] = e.y; }
+    }
 }
 
 template <typename K>
@@ -829,26 +835,29 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
     int64_t cap64 = (avg + avg / 2 + 5 * LINE + LINE - 1) / LINE * LINE;
     if (cap64 > 0x7FFFFFF0ll) return HARK_OK;
     const uint32_t cap = (uint32_t)cap64;
-    K *splitters = nullptr; uint32_t *bstart = nullptr, *counts = nullptr, *scount = nullptr, *sround = nullptr;
+    K *splitters = nullptr; uint32_t *bstart = nullptr, *counts = nullptr, *scount = nullptr, *sbins = nullptr;
     int64_t *info = nullptr;                                                     // [0] survivors (u64), [1] error word of the partition
     E *slabs = nullptr; uint2 *surv = nullptr;
     uint32_t *rank = nullptr, *lrow = nullptr, *cnt = nullptr, *sval = nullptr, *lv = nullptr, *rv = nullptr;
     const bool carry = lval != nullptr && sizeof(E) == 16;                      // the fourth word of the 16-byte entries
     *lval_out = nullptr; *rval_out = nullptr;
-    const size_t sstride = (size_t)nwg * cap;                                    // survivor slab of a bucket: room for all of its probe pairs
+    const size_t sstride = (size_t)nwg * cap;                                    // probe slabs of a bucket
+    // survivor bins of a bucket: twice the room of all of its probe pairs, dealt out equally to its bins -- a bin overflows
+    // only when its ranks draw more than twice (every pair a hit) to four times (every second pair) their even share
+    const size_t region = 2 * sstride;
     int rc = hark_alloc(ctx, (void **)&splitters, sizeof(K) * P);
     if (!rc) rc = hark_alloc(ctx, (void **)&bstart, 4 * (size_t)(P + 1));
     if (!rc) rc = hark_alloc(ctx, (void **)&counts, 4 * (size_t)P * nwg);
     if (!rc) rc = hark_alloc(ctx, (void **)&scount, 4 * (size_t)P);
-    if (!rc) rc = hark_alloc(ctx, (void **)&sround, 4 * (size_t)P * (kMaxRounds + 1));     // + [P] the buckets' modes
+    if (!rc) rc = hark_alloc(ctx, (void **)&sbins, 4 * (size_t)P * kMaxBins);
     if (!rc) rc = hark_alloc(ctx, (void **)&info, 32);
     if (!rc) rc = hark_alloc(ctx, (void **)&slabs, sizeof(E) * (size_t)P * sstride);
-    if (!rc) rc = hark_alloc(ctx, (void **)&surv, 8 * (size_t)P * sstride);
-    if (!rc && carry) rc = hark_alloc(ctx, (void **)&sval, 4 * (size_t)P * sstride);
+    if (!rc) rc = hark_alloc(ctx, (void **)&surv, 8 * (size_t)P * region);
+    if (!rc && carry) rc = hark_alloc(ctx, (void **)&sval, 4 * (size_t)P * region);
     uint32_t *scoarse = nullptr;
     if (!rc) rc = hark_alloc(ctx, (void **)&scoarse, 4 * (size_t)P * kCoarse);
     auto cleanup = [&]() {
-        hark_free(ctx, splitters); hark_free(ctx, bstart); hark_free(ctx, counts); hark_free(ctx, scount); hark_free(ctx, sround);
+        hark_free(ctx, splitters); hark_free(ctx, bstart); hark_free(ctx, counts); hark_free(ctx, scount); hark_free(ctx, sbins);
         hark_free(ctx, info); hark_free(ctx, slabs); hark_free(ctx, surv); hark_free(ctx, sval); hark_free(ctx, scoarse);
     };
     if (rc == HARK_ENOMEM) {                                                     // no room for the partition workspace: the sort-merge path
@@ -874,10 +883,13 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
                                 + (size_t)(kJIdx + 8) * 2;
     static_assert(lds_bucket <= kJLdsBudget, "bucket kernel LDS");
     if (he == hipSuccess) he = hipFuncSetAttribute(reinterpret_cast<const void *>(&jbucket_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bucket);
+    const bool carry_stage = carry;
+    int stage_cap = carry_stage ? kStageCarry : kStage;
+    if (const char *e = getenv("HARK_JOIN_STAGE")) { const int c = atoi(e); if (c >= 1 && c < stage_cap) stage_cap = c; }   // tests: many sub-rounds per bucket
     if (he == hipSuccess) {
         // one stream-ordered chain, one host read at the end: partition -> bucket probe -> survivor total
         jpart_kernel<K><<<dim3((unsigned)nwg), dim3(kJThreads), lds_part, st>>>(lcol, n, bias, splitters, rkeys, s, slabs, counts, cap, period, err, carry ? lval : nullptr);
-        jbucket_kernel<K><<<dim3((unsigned)P), dim3(kJThreads), lds_bucket, st>>>(slabs, counts, cap, nwg, rkeys, bstart, chunk_cap, surv, scount, sround, sval, scoarse, sround + (size_t)P * kMaxRounds, getenv("HARK_JOIN_NOTRUNC") ? 0 : 1);
+        jbucket_kernel<K><<<dim3((unsigned)P), dim3(kJThreads), lds_bucket, st>>>(slabs, counts, cap, nwg, rkeys, bstart, chunk_cap, surv, region, scount, sbins, sval, scoarse, stage_cap, err, getenv("HARK_JOIN_NOTRUNC") ? 0 : 1);
         jsum_kernel<<<1, 1024, 0, st>>>(scount, P, total);
         he = hipGetLastError();
         if (he == hipSuccess) he = hipMemcpyAsync(info + 2, flags, 8, hipMemcpyDeviceToDevice, st);   // the duplicate-keys flag rides along with the same host read
@@ -886,7 +898,7 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
     int64_t words[3] = {0, 0, 0}, M = 0;
     if (!rc) rc = hark_read_words(ctx, info, words, 3);
     M = words[0];
-    if (!rc && (int32_t)(words[1] & 0xFFFFFFFFll) != 0) { cleanup(); return HARK_OK; }          // a slab overflowed (skew): caller falls back
+    if (!rc && (int32_t)(words[1] & 0xFFFFFFFFll) != 0) { cleanup(); return HARK_OK; }          // a slab or a survivor bin overflowed (skew): caller falls back
     const bool dup = ((words[2] >> 32) & 0xFFFFFFFFll) != 0;
     *dup_out = dup;
     *general_out = 0;
@@ -902,24 +914,18 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
         if (!rc && rranked) rc = hark_alloc(ctx, (void **)&rv, 4 * (size_t)M);
         for (int attempt = 0; attempt < 2 && !rc; attempt++) {
             if (getenv("HARK_JOIN_FULLSORT")) {                                  // A/B + tests: plain compaction, radix sorts by the caller
-                jcompact_kernel<<<dim3((unsigned)P), 256, 0, st>>>(surv, sstride, scount, P, rank, lrow);
+                jcompact_kernel<<<dim3((unsigned)P), 256, 0, st>>>(surv, region, scount, sbins, counts, cap, nwg, bstart, stage_cap, rank, lrow);
                 hipMemsetAsync(flags, 1, 1, st);
             } else {
                 const size_t lds_order = (carry ? (size_t)kStageCarry * 12 + (size_t)(kFineCarry + 1) * 4 : (size_t)kStage * 8 + (size_t)(kFine + 1) * 4) + (size_t)(kCoarse + 1) * 4;
                 he = carry ? hipFuncSetAttribute(reinterpret_cast<const void *>(&jorder_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_order)
                            : hipFuncSetAttribute(reinterpret_cast<const void *>(&jorder_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_order);
-                int stage_cap = carry ? kStageCarry : kStage;
-                if (const char *e = getenv("HARK_JOIN_STAGE")) { const int c = atoi(e); if (c >= 1 && c < stage_cap) stage_cap = c; }   // tests: many sub-rounds per bucket
-                // bins of the order kernel: the dead probe slabs -- 8 bytes per entry for the survivors, and (16-byte entries
-                // only) the 4 bytes behind them for the third words
-                uint2 *bins = getenv("HARK_JOIN_NOBIN") ? nullptr : reinterpret_cast<uint2 *>(slabs);
-                uint32_t *binsv = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(slabs) + 8 * (size_t)P * sstride);
                 if (he == hipSuccess && carry)
-                    jorder_kernel<true><<<dim3((unsigned)P), dim3(kJThreads), lds_order, st>>>(surv, sstride, scount, sround, chunk_cap, bstart, P, runlen,
-                                                                                             rank, lrow, cnt, stage_cap, flags, bins, sval, lv, binsv, scoarse, rranked, rv, sround + (size_t)P * kMaxRounds);
+                    jorder_kernel<true><<<dim3((unsigned)P), dim3(kJThreads), lds_order, st>>>(surv, region, scount, sbins, counts, cap, nwg, bstart, P, runlen,
+                                                                                             rank, lrow, cnt, stage_cap, flags, sval, lv, scoarse, rranked, rv);
                 else if (he == hipSuccess)
-                    jorder_kernel<false><<<dim3((unsigned)P), dim3(kJThreads), lds_order, st>>>(surv, sstride, scount, sround, chunk_cap, bstart, P, runlen,
-                                                                                              rank, lrow, cnt, stage_cap, flags, bins, nullptr, nullptr, nullptr, scoarse, rranked, rv, sround + (size_t)P * kMaxRounds);
+                    jorder_kernel<false><<<dim3((unsigned)P), dim3(kJThreads), lds_order, st>>>(surv, region, scount, sbins, counts, cap, nwg, bstart, P, runlen,
+                                                                                              rank, lrow, cnt, stage_cap, flags, nullptr, nullptr, scoarse, rranked, rv);
             }
             if (he != hipSuccess || hipGetLastError() != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: order launch failed");
             // does the order stand, or do the survivors need the general sort (skew)?  Read here, while the survivors are alive:
