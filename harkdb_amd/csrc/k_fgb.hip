@@ -1291,18 +1291,78 @@ __global__ __launch_bounds__(1024) void fgb_agg10_kernel(
     }
 }
 
+// A wave's walk over its slabs of a bucket (every nwaves-th slab; 8-byte (key, value) pairs): ONE stream of steps of eight
+// pairs per lane (four 16-byte pieces), with the NEXT step's loads in flight while a step is probed -- across slab
+// boundaries too (the slabs' counts sit in the lanes of the wave).  The hash consumers' probes start with dependent LDS
+// reads: with the loads issued only at the top of a step the kernels ran at the latency of a global load (2.1 TB/s on 30-KB
+// slabs: 64 KB in flight per CU at best, nothing in flight while a step is probed), whatever was done to the probes
+// themselves.  f(keys[8], values[8], live mask) -> false stops the walk (a table overflowed).
+template <typename F>
+__device__ __forceinline__ void walk_pair_slabs(const uint2 *__restrict__ pbuf, const uint32_t *__restrict__ counts, uint32_t cap, int nwg, uint32_t b, F &&f)
+{
+    typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int nslab = wave < nwg ? (nwg - wave + nwaves - 1) / nwaves : 0;          // <= 64 (at most 1024 partition workgroups)
+    const uint32_t mycount = lane < nslab ? min(counts[(size_t)b * nwg + wave + lane * nwaves], cap) : 0u;
+    struct Cursor { int j; uint32_t i0, n2, count; };
+    auto seek = [&](Cursor &c) {                                          // the first step at or after c that has pairs
+        while (c.j < nslab && c.i0 >= c.n2) {
+            c.j++; c.i0 = 0u;
+            c.count = c.j < nslab ? (uint32_t)__shfl((int)mycount, c.j, 64) : 0u;
+            c.n2 = (c.count + 1u) / 2u;                                   // 16-byte pieces (cap is even: the last piece exists)
+        }
+    };
+    auto fetch = [&](const Cursor &c, u4v (&q)[4]) {                      // unconditional (clamped addresses): a countable number of loads per step
+        const bool live = c.j < nslab;
+        const u4v *src4 = reinterpret_cast<const u4v *>(pbuf + ((size_t)b * nwg + wave % nwg + (size_t)(live ? c.j : 0) * nwaves) * cap);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const uint32_t i = c.i0 + 64u * k + lane; q[k] = __builtin_nontemporal_load(src4 + ((live && i < c.n2) ? i : 0u)); }
+    };
+    auto step = [&](const u4v (&q)[4], const Cursor &c) -> bool {
+        uint32_t key[8], vb[8], live = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t i = c.i0 + 64u * k + lane;
+            key[2 * k] = q[k].x; vb[2 * k] = q[k].y; key[2 * k + 1] = q[k].z; vb[2 * k + 1] = q[k].w;
+            if (2u * i < c.count) live |= 1u << (2 * k);
+            if (2u * i + 1u < c.count) live |= 1u << (2 * k + 1);
+        }
+        return f(key, vb, live);
+    };
+    Cursor cA{-1, 0u, 0u, 0u};
+    seek(cA);
+    Cursor cB = cA; cB.i0 += 256u; seek(cB);
+    u4v a[4], bq[4];
+    fetch(cA, a); fetch(cB, bq);
+    for (;;) {                                                            // two register sets in turn, no copies between them
+        if (cA.j >= nslab) break;
+        if (!step(a, cA)) break;
+        cA = cB; cA.i0 += 256u; seek(cA); fetch(cA, a);
+        if (cB.j >= nslab) break;
+        if (!step(bq, cB)) break;
+        cB = cA; cB.i0 += 256u; seek(cB); fetch(cB, bq);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Hash flavour of the consumer: arbitrary u32 keys ("LDS-staged hash buckets")
 // ---------------------------------------------------------------------------
-// The producer routed pairs by the top bits of mix32(key).  One workgroup per bucket builds an
-// open-addressing table in LDS: 64-bit tag (key | 2^32, 0 = empty) claimed with ds_cmpst_b64,
-// value slot and count updated with the same LDS atomics as the dense path.  A bucket with more
-// distinct keys than the table holds is processed in R rounds, round r taking the keys with
+// The producer routed pairs by the top bits of mix32(key).  One workgroup per bucket builds an open-addressing table in
+// LDS.  mix32 is a bijection and every key of bucket b has b in the top log2(P) bits of mix32(key), so the LOW bits of
+// mix32(key) identify the key inside its bucket: an entry is a 32-bit tag (those bits | 2^31 = occupied; 0 = empty, claimed
+// with ds_cmpst_b32), a 32-bit row count and the 8-byte value slot -- all 32-bit LDS atomics beside the value's own
+// (round 3 kept key | 2^32 and the count in ONE 64-bit word: a 64-bit read, a 64-bit compare-and-swap and a 64-bit add per
+// row; the consumer took 2.0 ms per 5e8 pairs against 0.5 ms for the dense one).  The key is rebuilt with unmix32 at emit
+// time.  A bucket with more distinct keys than the table holds is processed in R rounds, round r taking the keys with
 // mix32(key ^ salt) % R == r (the slabs are re-read, the table is emitted after every round).
-constexpr int kHashCap = 8192;                           // entries of 16 B (tag+count word, value slot) = 128 KiB of LDS
+constexpr int kHashCap = 8192;                           // entries of 16 B (tag, count, value slot) = 128 KiB of LDS
 constexpr int kHashFill = 3072;                          // distinct keys per round and bucket (load <= 0.375: probe chains stay short;
                                                          // a wave waits for its longest chain, so the load factor is what matters)
-constexpr u64 kTagMask = 0x1FFFFFFFFull;                 // low 33 bits: key | 2^32 (0 = empty); the upper 31 bits count the rows
+__device__ __forceinline__ uint32_t unmix32(uint32_t y)
+{
+    y ^= y >> 16; y *= 0x43021123u; y ^= (y >> 15) ^ (y >> 30); y *= 0x1D69E2A5u; y ^= y >> 16;
+    return y;
+}
 
 template <int VOP>
 __global__ __launch_bounds__(1024) void fgb_agg_hash_kernel(
@@ -1311,59 +1371,93 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash_kernel(
     unsigned long long out_cap, int32_t *__restrict__ err)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    u64 *t_tag = reinterpret_cast<u64 *>(lds_raw);
-    u64 *t_val = t_tag + kHashCap;
+    u64 *t_val = reinterpret_cast<u64 *>(lds_raw);                       // [kHashCap]
+    uint32_t *t_tag = reinterpret_cast<uint32_t *>(t_val + kHashCap);    // [kHashCap] low bits of mix32(key) | 2^31, 0 = empty
+    uint32_t *t_cnt = t_tag + kHashCap;                                  // [kHashCap] rows
     __shared__ uint32_t s_used, s_emit;
     __shared__ unsigned long long s_base;
-    const int b = blockIdx.x;
-    for (int i = threadIdx.x; i < kHashCap; i += blockDim.x) { t_tag[i] = 0ull; t_val[i] = vop_identity(VOP); }
+    const uint32_t b = blockIdx.x;
+    const int lowbits = 33 - __ffs((int)gridDim.x);                      // P = gridDim.x buckets, a power of two: bucket = mix32(key) >> lowbits
+    const uint32_t lowmask = (1u << lowbits) - 1u;
+    for (int i = threadIdx.x; i < kHashCap; i += blockDim.x) { t_tag[i] = 0u; t_cnt[i] = 0u; t_val[i] = vop_identity(VOP); }
     if (threadIdx.x == 0) { s_used = 0u; s_emit = 0u; }
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     bool overflow = false;
-    auto add = [&](uint32_t key, uint32_t vbits) {
-        if ((mix32(key ^ 0x9E3779B9u) & Rmask) != r) return;                 // not this round's share of the key space
-        const u64 tag = (u64)key | (1ull << 32);
-        uint32_t h = (mix32(key) * 0x9E3779B1u) >> 19;                       // 13 bits, independent of the bucket bits
-        for (int step = 0; step < kHashCap; step++, h = (h + 1) & (kHashCap - 1)) {
-            u64 cur = t_tag[h] & kTagMask;
-            if (cur == 0ull) {
+    // What the kernel costs, by elimination on 2.5e8 pairs (profiles/r04_notes.md): the stream of pairs alone 0.34 ms, first-slot
+    // reads and the atomics of the hits 0.05 ms, and the per-pair probe LOOP of the ~15 % of the pairs that did not sit in their
+    // first slot 0.65 ms -- a wave nearly always has some lane that misses (0.85^64), so nearly every pair dragged all 64
+    // lanes through a divergent loop of dependent LDS round trips.  Slots are therefore grouped in EIGHTS: a probe reads the
+    // eight tags of its key's group with two ds_read_b128 and finds the key among them without a branch; a key leaves its
+    // home group only when that is full of other keys (load 0.25-0.375: Poisson(2..3) keys per group, > 8 in 0.02-0.4 % of
+    // the groups), so hardly a wave sees the slow path once the table is built.  (Groups of four: 1.90 -> 1.42 ms per 5e8
+    // pairs, a quarter of the steps still had a lane walking on.)
+    constexpr int kNP = 8;
+    constexpr uint32_t kGroups = kHashCap / 8;
+    uint4 *t_tag4 = reinterpret_cast<uint4 *>(t_tag);
+    struct Tags8 { uint4 a, b; };
+    auto load8 = [&](uint32_t g) -> Tags8 { return Tags8{t_tag4[2u * g], t_tag4[2u * g + 1u]}; };
+    auto find8 = [](const Tags8 &q, uint32_t t) -> int {
+        return q.a.x == t ? 0 : q.a.y == t ? 1 : q.a.z == t ? 2 : q.a.w == t ? 3 : q.b.x == t ? 4 : q.b.y == t ? 5 : q.b.z == t ? 6 : q.b.w == t ? 7 : -1;
+    };
+    auto hit = [&](uint32_t slot, uint32_t vbits) { vop_atomic<VOP>(&t_val[slot], vbits); atomicAdd(&t_cnt[slot], 1u); };
+    // the key is not among the tags `q` of group g as they were read: claim the group's first empty slot, or walk on.
+    // Slots only ever go from empty to occupied and every lane tries a group's empty slots in ascending order, so two lanes
+    // with the same key end up in the same slot (the loser of a claim sees the winner's tag: its own, or it reads the group again).
+    auto slow = [&](uint32_t tag, uint32_t g, Tags8 q, uint32_t vbits) {
+        for (uint32_t step = 0; step < 8u * kGroups; step++) {
+            const int at = find8(q, tag);
+            if (at >= 0) { hit(8u * g + (uint32_t)at, vbits); return; }
+            const int e = find8(q, 0u);
+            if (e >= 0) {
                 if (s_used >= (uint32_t)kHashFill) { overflow = true; return; }
-                cur = atomicCAS(&t_tag[h], 0ull, tag) & kTagMask;           // ds_cmpst_rtn_b64
-                if (cur == 0ull) { atomicAdd(&s_used, 1u); cur = tag; }
-            }
-            if (cur == tag) { vop_atomic<VOP>(&t_val[h], vbits); atomicAdd(&t_tag[h], 1ull << 33); return; }   // count rides in the tag word
+                const uint32_t old = atomicCAS(&t_tag[8u * g + (uint32_t)e], 0u, tag);      // ds_cmpst_rtn_b32
+                if (old == 0u) { atomicAdd(&s_used, 1u); hit(8u * g + (uint32_t)e, vbits); return; }
+                if (old == tag) { hit(8u * g + (uint32_t)e, vbits); return; }
+            } else g = (g + 1u) & (kGroups - 1u);                             // a full group of other keys
+            q = load8(g);
         }
         overflow = true;
     };
-    for (int w = wave; w < nwg; w += nwaves) {
-        if (__any(overflow)) break;                                          // this round is void anyway: stop reading
-        const uint32_t count = min(counts[(size_t)b * nwg + w], cap);
-        const uint2 *src = pbuf + ((size_t)b * nwg + w) * cap;
-        const uint4 *src4 = reinterpret_cast<const uint4 *>(src);
-        const uint32_t n2 = count / 2;
-        uint32_t i = lane;
-        for (; i + 64 < n2; i += 128) {
-            const uint4 q0 = src4[i], q1 = src4[i + 64];
-            add(q0.x, q0.y); add(q0.z, q0.w); add(q1.x, q1.y); add(q1.z, q1.w);
+    auto probe = [&](const uint32_t (&key)[kNP], const uint32_t (&vb)[kNP], uint32_t live) {
+        uint32_t tag[kNP], g[kNP]; Tags8 q[kNP];
+#pragma unroll
+        for (int j = 0; j < kNP; j++) {
+            const uint32_t m = mix32(key[j]);
+            tag[j] = (m & lowmask) | 0x80000000u;
+            g[j] = (m * 0x9E3779B1u) >> 22;                                  // 10 bits (kGroups), mixed from the bits below the bucket's
+            if (Rmask && (mix32(key[j] ^ 0x9E3779B9u) & Rmask) != r) live &= ~(1u << j);   // not this round's share of the key space
         }
-        for (; i < n2; i += 64) { const uint4 q = src4[i]; add(q.x, q.y); add(q.z, q.w); }
-        if ((count & 1u) && lane == 0) { const uint2 q = src[count - 1]; add(q.x, q.y); }
-    }
+#pragma unroll
+        for (int j = 0; j < kNP; j++) q[j] = load8(g[j]);                    // 2 x kNP independent 16-byte LDS reads in flight
+        uint32_t miss = 0;
+#pragma unroll
+        for (int j = 0; j < kNP; j++) {
+            const int at = find8(q[j], tag[j]);
+            if ((live >> j) & 1u) { if (at >= 0) hit(8u * g[j] + (uint32_t)at, vb[j]); else miss |= 1u << j; }
+        }
+        if (__any(miss != 0u)) {
+#pragma unroll
+            for (int j = 0; j < kNP; j++) if ((miss >> j) & 1u) slow(tag[j], g[j], q[j], vb[j]);
+        }
+    };
+    walk_pair_slabs(pbuf, counts, cap, nwg, b, [&](const uint32_t (&key)[kNP], const uint32_t (&vb)[kNP], uint32_t live) -> bool {
+        probe(key, vb, live);
+        return !__any(overflow);                                             // an overflowed round is void anyway: stop reading
+    });
     if (overflow) *err = kErrOverflow;
     __syncthreads();
     // emit the occupied entries: reserve a range of the output with one global atomic per workgroup
     uint32_t mine = 0;
-    for (int i = threadIdx.x; i < kHashCap; i += blockDim.x) mine += (t_tag[i] >> 33) ? 1u : 0u;
+    for (int i = threadIdx.x; i < kHashCap; i += blockDim.x) mine += t_cnt[i] ? 1u : 0u;
     uint32_t pos = mine ? atomicAdd(&s_emit, mine) : 0u;
     __syncthreads();
     if (threadIdx.x == 0) s_base = s_emit ? atomicAdd(out_cursor, (unsigned long long)s_emit) : 0ull;
     __syncthreads();
     for (int i = threadIdx.x; i < kHashCap; i += blockDim.x) {
-        const u64 tc = t_tag[i];
-        if (!(tc >> 33)) continue;
+        const uint32_t c = t_cnt[i];
+        if (!c) continue;
         const unsigned long long o = s_base + pos++;
-        if (o < out_cap) { out_key[o] = (uint32_t)tc; out_val[o] = t_val[i]; out_cnt[o] = tc >> 33; }
+        if (o < out_cap) { out_key[o] = unmix32((b << lowbits) | (t_tag[i] & lowmask)); out_val[o] = t_val[i]; out_cnt[o] = (u64)c; }
         else *err = kErrOverflow;
     }
 }
@@ -1376,11 +1470,6 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash_kernel(
 // the low half is the same for every update of a slot, and a claim stores the first value, so no identity is needed.
 constexpr int kHash8Cap = 16384;
 constexpr int kHash8Fill = 6144;
-__device__ __forceinline__ uint32_t unmix32(uint32_t y)
-{
-    y ^= y >> 16; y *= 0x43021123u; y ^= (y >> 15) ^ (y >> 30); y *= 0x1D69E2A5u; y ^= y >> 16;
-    return y;
-}
 
 template <int VOP>
 __global__ __launch_bounds__(1024) void fgb_agg_hash8_kernel(
@@ -1397,52 +1486,76 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash8_kernel(
     for (int i = threadIdx.x; i < kHash8Cap; i += blockDim.x) tab[i] = 0ull;
     if (threadIdx.x == 0) { s_used = 0u; s_emit = 0u; }
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     bool overflow = false;
-    auto add = [&](uint32_t key, uint32_t v) {
-        if ((mix32(key ^ 0x9E3779B9u) & Rmask) != r) return;                 // not this round's share of the key space
-        const uint32_t m = mix32(key);
-        const u64 tag = (u64)(m & 0xFFFFFFu) | (1ull << 24);
-        uint32_t h = (m * 0x9E3779B1u) >> 18;                                // 14 bits
-        for (int step = 0; step < kHash8Cap; step++, h = (h + 1) & (kHash8Cap - 1)) {
-            u64 cur = tab[h];
-            if (cur == 0ull) {
+    auto update = [&](uint32_t h, u64 tag, uint32_t v, u64 seen) {        // the slot holds our key
+        if constexpr (VOP == VOP_U32SUM) atomicAdd(&tab[h], (u64)v << 32);
+        else if constexpr (VOP == VOP_U32MAX) atomicMax(&tab[h], tag | ((u64)v << 32));
+        else if constexpr (VOP == VOP_U32MIN) atomicMin(&tab[h], tag | ((u64)v << 32));
+        else {
+            u64 old = seen;
+            for (;;) {
+                const u64 want = tag | ((u64)((uint32_t)(old >> 32) * v) << 32);
+                const u64 got = atomicCAS(&tab[h], old, want);
+                if (got == old) break;
+                old = got;
+            }
+        }
+    };
+    // kNP pairs per lane are probed together and the slots are grouped in FOURS (32 bytes: two ds_read_b128 find a key in its
+    // home group without a branch) -- see fgb_agg_hash_kernel for what the per-pair probe loops cost.
+    constexpr int kNP = 8;
+    constexpr uint32_t kGroups = kHash8Cap / 4;
+    const uint4 *tab4 = reinterpret_cast<const uint4 *>(tab);
+    struct Ent4 { uint4 a, b; };                                             // entries 0, 1 | 2, 3 of a group (low word: occupied << 24 | tag, high word: value)
+    auto load4 = [&](uint32_t g) -> Ent4 { return Ent4{tab4[2u * g], tab4[2u * g + 1u]}; };
+    auto find4 = [](const Ent4 &q, uint32_t t) -> int {                      // t = the low 25 bits looked for (0: an empty entry -- its whole word is 0)
+        return (q.a.x & 0x1FFFFFFu) == t ? 0 : (q.a.z & 0x1FFFFFFu) == t ? 1 : (q.b.x & 0x1FFFFFFu) == t ? 2 : (q.b.z & 0x1FFFFFFu) == t ? 3 : -1;
+    };
+    auto word_of = [](const Ent4 &q, int i) -> u64 {
+        const uint32_t lo = i == 0 ? q.a.x : i == 1 ? q.a.z : i == 2 ? q.b.x : q.b.z, hi = i == 0 ? q.a.y : i == 1 ? q.a.w : i == 2 ? q.b.y : q.b.w;
+        return ((u64)hi << 32) | lo;
+    };
+    auto slow = [&](u64 tag, uint32_t g, Ent4 q, uint32_t v) {
+        for (uint32_t step = 0; step < 4u * kGroups; step++) {
+            const int at = find4(q, (uint32_t)tag);
+            if (at >= 0) { update(4u * g + (uint32_t)at, tag, v, word_of(q, at)); return; }
+            const int e = find4(q, 0u);
+            if (e >= 0) {
                 if (s_used >= (uint32_t)kHash8Fill) { overflow = true; return; }
-                cur = atomicCAS(&tab[h], 0ull, tag | ((u64)v << 32));       // the claim carries the first value
-                if (cur == 0ull) { atomicAdd(&s_used, 1u); return; }
-            }
-            if ((cur & 0x1FFFFFFull) == tag) {
-                if constexpr (VOP == VOP_U32SUM) atomicAdd(&tab[h], (u64)v << 32);
-                else if constexpr (VOP == VOP_U32MAX) atomicMax(&tab[h], tag | ((u64)v << 32));
-                else if constexpr (VOP == VOP_U32MIN) atomicMin(&tab[h], tag | ((u64)v << 32));
-                else {
-                    u64 old = cur;
-                    for (;;) {
-                        const u64 want = tag | ((u64)((uint32_t)(old >> 32) * v) << 32);
-                        const u64 got = atomicCAS(&tab[h], old, want);
-                        if (got == old) break;
-                        old = got;
-                    }
-                }
-                return;
-            }
+                const u64 old = atomicCAS(&tab[4u * g + (uint32_t)e], 0ull, tag | ((u64)v << 32));     // the claim carries the first value
+                if (old == 0ull) { atomicAdd(&s_used, 1u); return; }
+                if ((old & 0x1FFFFFFull) == tag) { update(4u * g + (uint32_t)e, tag, v, old); return; }
+            } else g = (g + 1u) & (kGroups - 1u);                             // a full group of other keys
+            q = load4(g);
         }
         overflow = true;
     };
-    for (int w = wave; w < nwg; w += nwaves) {
-        if (__any(overflow)) break;                                          // this round is void anyway: stop reading
-        const uint32_t count = min(counts[(size_t)b * nwg + w], cap);
-        const uint2 *src = pbuf + ((size_t)b * nwg + w) * cap;
-        const uint4 *src4 = reinterpret_cast<const uint4 *>(src);
-        const uint32_t n2 = count / 2;
-        uint32_t i = lane;
-        for (; i + 64 < n2; i += 128) {
-            const uint4 q0 = src4[i], q1 = src4[i + 64];
-            add(q0.x, q0.y); add(q0.z, q0.w); add(q1.x, q1.y); add(q1.z, q1.w);
+    auto probe = [&](const uint32_t (&key)[kNP], const uint32_t (&vv)[kNP], uint32_t live) {
+        u64 tag[kNP]; uint32_t g[kNP]; Ent4 q[kNP];
+#pragma unroll
+        for (int j = 0; j < kNP; j++) {
+            const uint32_t m = mix32(key[j]);
+            tag[j] = (u64)(m & 0xFFFFFFu) | (1ull << 24);
+            g[j] = (m * 0x9E3779B1u) >> 20;                                  // 12 bits (kGroups)
+            if (Rmask && (mix32(key[j] ^ 0x9E3779B9u) & Rmask) != r) live &= ~(1u << j);   // not this round's share of the key space
         }
-        for (; i < n2; i += 64) { const uint4 q = src4[i]; add(q.x, q.y); add(q.z, q.w); }
-        if ((count & 1u) && lane == 0) { const uint2 q = src[count - 1]; add(q.x, q.y); }
-    }
+#pragma unroll
+        for (int j = 0; j < kNP; j++) q[j] = load4(g[j]);
+        uint32_t miss = 0;
+#pragma unroll
+        for (int j = 0; j < kNP; j++) {
+            const int at = find4(q[j], (uint32_t)tag[j]);
+            if ((live >> j) & 1u) { if (at >= 0) update(4u * g[j] + (uint32_t)at, tag[j], vv[j], word_of(q[j], at)); else miss |= 1u << j; }
+        }
+        if (__any(miss != 0u)) {
+#pragma unroll
+            for (int j = 0; j < kNP; j++) if ((miss >> j) & 1u) slow(tag[j], g[j], q[j], vv[j]);
+        }
+    };
+    walk_pair_slabs(pbuf, counts, cap, nwg, b, [&](const uint32_t (&key)[kNP], const uint32_t (&vv)[kNP], uint32_t live) -> bool {
+        probe(key, vv, live);
+        return !__any(overflow);                                             // an overflowed round is void anyway: stop reading
+    });
     if (overflow) *err = kErrOverflow;
     __syncthreads();
     uint32_t mine = 0;
