@@ -52,6 +52,9 @@ struct __attribute__((aligned(16))) JPair64 { uint64_t key; uint32_t row, pad; }
 // the order kernel's geometry (jorder_kernel): survivors staged per sub-round and per-rank counters -- with a third word per
 // survivor 10240 x 12 B + 6144 counters, without 12288 x 8 B + 10240 counters (~150 KiB of LDS either way)
 constexpr int kStage = 12288, kStageCarry = 10240, kFine = 10240, kFineCarry = 6144, kCoarse = 2048, kTieMax = 64;
+// the stage by words per survivor: (rank, left row) + the carried column + the probe key's low word (64-bit keys: confirmed at write-out)
+constexpr int stage_of(int extra_words) { return extra_words == 0 ? kStage : extra_words == 1 ? kStageCarry : 8192; }
+constexpr int fine_of(int extra_words) { return extra_words == 0 ? kFine : extra_words == 1 ? kFineCarry : 4096; }
 
 // Bins of a bucket's survivors: the bucket's len ranks are cut into nb <= kMaxBins ranges of 2^bs ranks (whole groups of the
 // coarse histogram: bs >= gs), as few as keep a bin's EXPECTED survivors under the order kernel's stage when every second
@@ -334,6 +337,8 @@ __global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTrai
                                                             uint32_t *__restrict__ scount /* [P] survivors of the bucket */,
                                                             uint32_t *__restrict__ sbins /* [P][kMaxBins] survivors in every bin */,
                                                             uint32_t *__restrict__ sval /* may be null: the entries' fourth word of every survivor (same index as surv) */,
+                                                            uint32_t *__restrict__ skey /* 64-bit keys: the low word of every survivor's PROBE key (same index): a hit on a
+                                                                                           truncated build key is confirmed by the order kernel, where the build keys are read in order */,
                                                             uint32_t *__restrict__ scoarse /* [P][kCoarse] survivors per group of ranks: the order kernel's first histogram */,
                                                             int stage_cap /* the order kernel's stage (sizes the bins) */, int32_t *__restrict__ err,
                                                             int allow_trunc)
@@ -381,13 +386,18 @@ __global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTrai
     const uint32_t bincap = bins.cap;
     uint2 *out = surv + (size_t)b * region;
     uint32_t *vout = sval ? sval + (size_t)b * region : nullptr;
+    uint32_t *kout = skey ? skey + (size_t)b * region : nullptr;
     bool bin_full = false;
     const unsigned long long below = (1ull << lane) - 1ull;
     // 64-bit keys: a bucket of up to two chunks of build keys (BASELINE configs[3]: 24.4 K against 12 K per 96-KiB chunk)
     // would stream its probe entries twice.  Instead the chunk area holds the keys TRUNCATED to 32 bits,
-    // (key - first key) >> ts, twice as many: the search runs on those and a hit is confirmed against the full key in
-    // memory (the bucket's 200 KB of keys: cache hits).  Exact as long as equal truncated keys are equal keys -- checked
-    // when they are loaded; a bucket that fails the check (keys clustered below bit ts) takes the rounds as before.
+    // (key - first key) >> ts, twice as many, and the search runs on those.  Exact among the build keys as long as equal
+    // truncated keys are equal keys -- checked when they are loaded; a bucket that fails the check (keys clustered below bit
+    // ts) takes the rounds as before.  A PROBE key can still share its truncation with a build key it differs from in the
+    // ts dropped bits: every survivor therefore carries its probe key's low word (skey), and the order kernel compares it
+    // with the build key of the survivor's rank when it writes the rows out in rank order -- reads that walk the sorted
+    // keys front to back.  (Round 3 confirmed every hit here, against the key in memory: 7e7 random 4-byte reads, 0.31 ms of
+    // the kernel's 0.99.)  A mismatch anywhere makes the host run the join again without truncated rounds.
     uint32_t *c32 = reinterpret_cast<uint32_t *>(chunk);
     auto ck = [&](int i) -> K & { return chunk[i + (i >> SKK)]; };
     auto c3 = [&](int i) -> uint32_t & { return c32[i + (i >> 6)]; };
@@ -446,7 +456,7 @@ __global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTrai
         };
         // a hit goes to the bin of its rank (a fixed range of the bucket's ranks: what the order kernel stages together): one
         // returning LDS atomic on the bin's cursor is its place (stores the compiler does not count: see st_hidden_b32)
-        auto commit = [&](bool match, uint32_t pos, uint32_t row, uint32_t val) {
+        auto commit = [&](bool match, uint32_t pos, uint32_t row, uint32_t val, uint32_t klow) {
             if (match) {
                 const uint32_t r = base + pos - lo;
                 const uint32_t bin = r >> bs;
@@ -455,16 +465,11 @@ __global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTrai
                     const size_t o = (size_t)bin * bincap + at;
                     st_hidden_b64(out + o, uint2{base + pos, row});
                     if (sizeof(E) == 16 && vout) st_hidden_b32(vout + o, val);
+                    if (sizeof(E) == 16 && kout) st_hidden_b32(kout + o, klow);
                     atomicAdd(&s_coarse[r >> gs], 1u);
                 } else bin_full = true;                                // probe keys crowd a few ranks: the caller takes another path
             }
         };
-        // 16-byte entries: a batch's hits are committed one step LATER (two slots, one per half-step).  With truncated keys
-        // the full key of a hit is read from memory (the bucket's 200 KB of keys: cache hits) and compared then; the read
-        // is issued for every batch, hit or not, full or empty, so that every step issues the same number of loads and the
-        // compiler can place exact waits -- a conditional load would turn every wait of the loop into vmcnt(0).
-        struct Pending { bool match; uint32_t klow, full, pos, row, val; };      // (full: the low word of the build key at pos -- the truncated key
-        Pending pend[2] = {{false, 0u, 0u, 0u, 0u, 0u}, {false, 0u, 0u, 0u, 0u, 0u}};   //  covers every bit from ts <= 32 up, so the two words decide equality)
         // search `cnt` queued candidates (the last ones), one per lane: the lower bound in the index class's span
         auto search = [&](int cnt, K &key, uint32_t &row, uint32_t &val, int &pos) -> bool {
             qn -= cnt;
@@ -496,18 +501,10 @@ __global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTrai
             }
             return act && pos < m && ck(pos) == key;
         };
-        auto drain = [&](int cnt) {                                    // 8-byte pairs: search and commit
+        auto drain = [&](int cnt) {                                    // search the last `cnt` queued candidates, commit the hits
             K key; uint32_t row, val; int pos = 0;
             const bool match = search(cnt, key, row, val, pos);
-            commit(match, (uint32_t)pos, row, val);
-        };
-        auto drain_slot = [&](int cnt, Pending &p) {                   // 16-byte entries: commit the slot's previous batch, search, read the key
-            K key = (K)0; uint32_t row = 0u, val = 0u; int pos = 0;
-            bool match = false;
-            if (cnt > 0) match = search(cnt, key, row, val, pos);      // (wave-uniform; no memory instruction inside)
-            commit(p.match && (!tmode || p.full == p.klow), p.pos, p.row, p.val);
-            p.match = match; p.klow = (uint32_t)key; p.pos = (uint32_t)pos; p.row = row; p.val = val;
-            p.full = reinterpret_cast<const uint32_t *>(rkeys + base + (match ? (uint32_t)pos : 0u))[0];
+            commit(match, (uint32_t)pos, row, val, (uint32_t)key);
         };
         // A wave walks its slabs (every 16th of the bucket's) as ONE stream of 128-entry steps -- two entries per lane: one
         // 16-byte load for 8-byte pairs, two for 16-byte entries -- with the loads of the next two steps in flight across
@@ -546,10 +543,9 @@ __global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTrai
                 key0 = (K)x0.x; row0 = x0.y; key1 = (K)x0.z; row1 = x0.w;
             }
             enqueue(v0 && candidate(key0), key0, row0, val0);        // qn < 64 before
-            if (WIDE) drain_slot(qn >= 64 ? 64 : 0, pend[0]);        // 16-byte entries: never more than 63 + 64 queued
+            if (WIDE && qn >= 64) drain(64);                         // 16-byte entries: never more than 63 + 64 queued
             enqueue(v1 && candidate(key1), key1, row1, val1);        // 8-byte pairs: at most 64 + 128 = QCAP queued
-            if (WIDE) drain_slot(qn >= 64 ? 64 : 0, pend[1]);
-            else while (qn >= 64) drain(64);
+            while (qn >= 64) drain(64);
         };
         // three register sets in turn, no copies between them: a move out of a register whose load is still in flight
         // would be a wait for it
@@ -568,11 +564,7 @@ __global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTrai
             if (cD.j >= nslab) break;
             process(d0, d1, cD); nx.step++; seek(nx); cD = nx; fetch(cD, d0, d1);
         }
-        if (WIDE) {                                                    // the round's leftovers (fewer than 64), then the two slots' last batches
-            drain_slot(qn, pend[0]);
-            drain_slot(0, pend[1]);
-            drain_slot(0, pend[0]);
-        } else if (qn > 0) drain(qn);
+        if (qn > 0) drain(qn);                                        // the round's leftovers (fewer than 64)
     }
     if (bin_full) *err = kJErrOverflow;
     __syncthreads();
@@ -608,7 +600,11 @@ __global__ __launch_bounds__(1024) void jsum_kernel(const uint32_t *__restrict__
 // the bucket is copied as it is and the caller sorts all survivors with radix passes instead.
 // CARRY: every survivor has a third word (a probe-side output column, sval / lval_out) that is ordered along with it; the
 // stage then holds kStageCarry survivors (12 bytes each).
-template <bool CARRY>
+// VERIFY (64-bit keys): every survivor also has its probe key's low word (skey); at write-out -- ranks ascending: the sorted
+// build keys are read front to back -- it is compared with the low word of the build key of the survivor's rank, which
+// confirms the bucket kernel's hits on TRUNCATED keys (the truncation covers every bit above the dropped ones, so the two
+// low words decide equality).  A mismatch sets general[2]: the host runs the join again without truncated rounds.
+template <bool CARRY, bool VERIFY>
 __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restrict__ surv, size_t region, const uint32_t *__restrict__ scount,
                                                            const uint32_t *__restrict__ sbins, const uint32_t *__restrict__ counts, uint32_t cap, int nwg,
                                                            const uint32_t *__restrict__ bstart, int P, const uint32_t *__restrict__ runlen,
@@ -617,13 +613,16 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
                                                            const uint32_t *__restrict__ sval, uint32_t *__restrict__ lval_out,
                                                            const uint32_t *__restrict__ scoarse,
                                                            const uint32_t *__restrict__ rranked /* may be null: a build-side column in rank order ... */,
-                                                           uint32_t *__restrict__ rval_out /* ... read off for every survivor (unique build keys: survivor = output row) */)
+                                                           uint32_t *__restrict__ rval_out /* ... read off for every survivor (unique build keys: survivor = output row) */,
+                                                           const uint32_t *__restrict__ skey /* VERIFY: the survivors' probe-key low words */,
+                                                           const uint64_t *__restrict__ rkeys64 /* VERIFY: the sorted build keys */)
 {
-    constexpr int STAGE = CARRY ? kStageCarry : kStage, FINE = CARRY ? kFineCarry : kFine;
+    constexpr int XW = (CARRY ? 1 : 0) + (VERIFY ? 1 : 0), STAGE = stage_of(XW), FINE = fine_of(XW);
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     uint2 *stage = reinterpret_cast<uint2 *>(lds_raw);                         // [STAGE]
     uint32_t *stv = reinterpret_cast<uint32_t *>(stage + STAGE);               // [STAGE] third words (CARRY)
-    uint32_t *fine = stv + (CARRY ? STAGE : 0);                                // [kFine + 1]
+    uint32_t *stk = stv + (CARRY ? STAGE : 0);                                 // [STAGE] probe-key low words (VERIFY)
+    uint32_t *fine = stk + (VERIFY ? STAGE : 0);                               // [FINE + 1]
     uint32_t *coarse = fine + FINE + 1;                                        // [kCoarse + 1] counts, then exclusive prefix
     __shared__ unsigned long long s_dst;
     __shared__ uint32_t s_wave[kJThreads / 64];
@@ -650,6 +649,8 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
     const int gs = bins.gs, kb = bins.bs - bins.gs;                            // a bin = 2^kb consecutive groups
     const uint2 *src = surv + (size_t)b * region;
     const uint32_t *srcv = CARRY ? sval + (size_t)b * region : nullptr;
+    const uint32_t *srck = VERIFY ? skey + (size_t)b * region : nullptr;
+    bool mismatch = false;
     const uint32_t ngroups = (len + (1u << gs) - 1u) >> gs;
     for (uint32_t i = tid; i <= ngroups; i += kJThreads) coarse[i] = i < ngroups ? scoarse[(size_t)b * kCoarse + i] : 0u;   // counted by the bucket kernel
     __syncthreads();
@@ -657,21 +658,25 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
     if (nb == 0) return;
     // every pass over survivors keeps 8 loads per lane in flight: one workgroup owns the CU, and with a single load per
     // lane the passes ran at the latency of a load, not at the CU's share of the bandwidth.  f(entry, third word)
-    auto sweep = [&](const uint2 *sp, const uint32_t *spv, uint32_t i1, bool want_v, auto &&f) {
+    auto sweep = [&](const uint2 *sp, const uint32_t *spv, const uint32_t *spk, uint32_t i1, bool want_v, auto &&f) {
         uint32_t i = tid;
         for (; i + 7u * kJThreads < i1; i += 8u * kJThreads) {
-            uint2 e[8]; uint32_t v[8];
+            uint2 e[8]; uint32_t v[8], kl[8];
 #pragma unroll
-            for (int k = 0; k < 8; k++) { e[k] = sp[i + (uint32_t)k * kJThreads]; v[k] = (CARRY && want_v) ? spv[i + (uint32_t)k * kJThreads] : 0u; }
+            for (int k = 0; k < 8; k++) {
+                e[k] = sp[i + (uint32_t)k * kJThreads];
+                v[k] = (CARRY && want_v) ? spv[i + (uint32_t)k * kJThreads] : 0u;
+                kl[k] = (VERIFY && want_v) ? spk[i + (uint32_t)k * kJThreads] : 0u;
+            }
 #pragma unroll
-            for (int k = 0; k < 8; k++) f(e[k], v[k]);
+            for (int k = 0; k < 8; k++) f(e[k], v[k], kl[k]);
         }
-        for (; i < i1; i += kJThreads) f(sp[i], (CARRY && want_v) ? spv[i] : 0u);
+        for (; i < i1; i += kJThreads) f(sp[i], (CARRY && want_v) ? spv[i] : 0u, (VERIFY && want_v) ? spk[i] : 0u);
     };
     // the bins that hold the ranks of groups [g0, g1)
     auto sweep_bins = [&](uint32_t g0, uint32_t g1, bool want_v, auto &&f) {
         for (uint32_t j = g0 >> kb; j <= (g1 - 1u) >> kb; j++)
-            sweep(src + (size_t)j * bins.cap, CARRY ? srcv + (size_t)j * bins.cap : nullptr, s_bincnt[j], want_v, f);
+            sweep(src + (size_t)j * bins.cap, CARRY ? srcv + (size_t)j * bins.cap : nullptr, VERIFY ? srck + (size_t)j * bins.cap : nullptr, s_bincnt[j], want_v, f);
     };
     // block-wide exclusive scan helper over a[0, m): a contiguous segment per thread, waves chained through LDS;
     // returns the total
@@ -710,9 +715,11 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
                 if (cnt_out) cnt_out[o + i] = runlen[e.x];
                 if (CARRY) lval_out[o + i] = srcv[(size_t)j * bins.cap + i];   // (the caller drops the carried words on the general path)
                 if (rranked) rval_out[o + i] = rranked[e.x];
+                if (VERIFY && (uint32_t)rkeys64[e.x] != srck[(size_t)j * bins.cap + i]) mismatch = true;
             }
         }
         if (tid == 0) *general = 1;
+        if (mismatch) general[2] = 1;
         return;
     }
     const uint32_t max_groups = max(1u, (uint32_t)FINE >> gs);
@@ -734,12 +741,12 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
         if (nsub) {
             for (uint32_t i = tid; i <= nr; i += kJThreads) fine[i] = 0u;
             __syncthreads();
-            sweep_bins(g0, g1, false, [&](uint2 e, uint32_t) { const uint32_t r = e.x - lo - r0; if (r < nr) atomicAdd(&fine[r], 1u); });
+            sweep_bins(g0, g1, false, [&](uint2 e, uint32_t, uint32_t) { const uint32_t r = e.x - lo - r0; if (r < nr) atomicAdd(&fine[r], 1u); });
             __syncthreads();
             scan_excl(fine, nr);
-            sweep_bins(g0, g1, true, [&](uint2 e, uint32_t v) {
+            sweep_bins(g0, g1, true, [&](uint2 e, uint32_t v, uint32_t kl) {
                 const uint32_t r = e.x - lo - r0;
-                if (r < nr) { const uint32_t at = atomicAdd(&fine[r], 1u); stage[at] = e; if (CARRY) stv[at] = v; }   // afterwards fine[r] = end of rank r's rows
+                if (r < nr) { const uint32_t at = atomicAdd(&fine[r], 1u); stage[at] = e; if (CARRY) stv[at] = v; if (VERIFY) stk[at] = kl; }   // afterwards fine[r] = end of rank r's rows
             });
             __syncthreads();
             // ---- rows of one rank into left-row order, and out: every survivor counts the rows of ITS rank (the stage's run
@@ -752,15 +759,19 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
             // four survivors per lane at a time: their LDS round trips and the reads through the rank overlap
             constexpr int kB = 4;
             for (uint32_t i0 = tid; i0 < nsub; i0 += kB * kJThreads) {
-                uint2 e[kB]; uint32_t s0[kB], s1[kB], at[kB], v3[kB], rv[kB], rl[kB];
+                uint2 e[kB]; uint32_t s0[kB], s1[kB], at[kB], v3[kB], kl[kB], rv[kB], rl[kB], rk[kB];
 #pragma unroll
-                for (int q = 0; q < kB; q++) { const uint32_t i = min(i0 + (uint32_t)q * kJThreads, nsub - 1u); e[q] = stage[i]; v3[q] = CARRY ? stv[i] : 0u; at[q] = i; }
+                for (int q = 0; q < kB; q++) {
+                    const uint32_t i = min(i0 + (uint32_t)q * kJThreads, nsub - 1u);
+                    e[q] = stage[i]; v3[q] = CARRY ? stv[i] : 0u; kl[q] = VERIFY ? stk[i] : 0u; at[q] = i;
+                }
 #pragma unroll
                 for (int q = 0; q < kB; q++) {
                     const uint32_t r = e[q].x - lo - r0;
                     s0[q] = r ? fine[r - 1] : 0u; s1[q] = fine[r];
                     rv[q] = rranked ? rranked[e[q].x] : 0u;               // ranks ascend along the stage: an (almost) sequential read
                     rl[q] = cnt_out ? runlen[e[q].x] : 0u;
+                    rk[q] = VERIFY ? reinterpret_cast<const uint32_t *>(rkeys64)[2u * (size_t)e[q].x] : 0u;   // the build key's low word (little endian), read in rank order
                 }
 #pragma unroll
                 for (int q = 0; q < kB; q++) {
@@ -774,6 +785,7 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
 #pragma unroll
                 for (int q = 0; q < kB; q++) {
                     if (i0 + (uint32_t)q * kJThreads < nsub) {
+                        if (VERIFY && rk[q] != kl[q]) mismatch = true;             // a hit on a truncated key that is none
                         if (rank) { rank[o + at[q]] = e[q].x; lrow[o + at[q]] = e[q].y; }   // null: every result column arrives through lval_out / rval_out
                         if (cnt_out) cnt_out[o + at[q]] = rl[q];
                         if (CARRY) lval_out[o + at[q]] = v3[q];
@@ -786,13 +798,15 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
         g0 = g1;
     }
     if (__ballot(too_long) != 0ull && lane == 0) *general = 1;
+    if (VERIFY && __ballot(mismatch) != 0ull && lane == 0) general[2] = 1;
 }
 
 // survivor bins -> two contiguous arrays (rank, left row), unordered inside a bucket (the FULLSORT knob: radix sorts by the
 // caller); dst offsets = exclusive scan of scount, done by every workgroup for itself (P <= 1024 values)
 __global__ __launch_bounds__(256) void jcompact_kernel(const uint2 *__restrict__ surv, size_t region, const uint32_t *__restrict__ scount,
                                                        const uint32_t *__restrict__ sbins, const uint32_t *__restrict__ counts, uint32_t cap, int nwg,
-                                                       const uint32_t *__restrict__ bstart, int stage_cap, uint32_t *__restrict__ rank, uint32_t *__restrict__ lrow)
+                                                       const uint32_t *__restrict__ bstart, int stage_cap, uint32_t *__restrict__ rank, uint32_t *__restrict__ lrow,
+                                                       const uint32_t *__restrict__ skey /* may be null */, const uint64_t *__restrict__ rkeys64, int32_t *__restrict__ flags)
 {
     __shared__ unsigned long long s_dst;
     __shared__ uint32_t s_np, s_off[kMaxBins + 1];
@@ -815,7 +829,10 @@ __global__ __launch_bounds__(256) void jcompact_kernel(const uint2 *__restrict__
     for (int j = 0; j < bins.nb; j++) {
         const uint2 *src = surv + (size_t)b * region + (size_t)j * bins.cap;
         const uint32_t cnt = s_off[j + 1] - s_off[j];
-        for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) { const uint2 e = src[i]; rank[dst + s_off[j] + i] = e.x; lrow[dst + s_off[j] + i] = e.y; }
+        for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
+            const uint2 e = src[i]; rank[dst + s_off[j] + i] = e.x; lrow[dst + s_off[j] + i] = e.y;
+            if (skey && (uint32_t)rkeys64[e.x] != skey[(size_t)b * region + (size_t)j * bins.cap + i]) flags[2] = 1;   // a hit on a truncated key that is not one
+        }
     }
 }
 
@@ -823,7 +840,8 @@ template <typename K>
 int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K *rkeys, int64_t s, const uint32_t *runlen,
                     int32_t *flags /* device: [0] general sort needed, [1] duplicate build keys */, const uint32_t *lval, const uint32_t *rranked,
                     uint32_t **rank_out, uint32_t **lrow_out, uint32_t **cnt_out, uint32_t **lval_out, uint32_t **rval_out, int64_t *m_out, bool *used, bool *dup_out,
-                    bool rows_needed /* false: the caller takes its result columns from lval_out / rval_out alone (unique build keys) */, int64_t *general_out)
+                    bool rows_needed /* false: the caller takes its result columns from lval_out / rval_out alone (unique build keys) */, int64_t *general_out,
+                    bool allow_trunc = true /* 64-bit keys: buckets of up to two chunks run as one round over truncated keys (hits confirmed by the order kernel) */)
 {
     typedef typename JTraits<K>::E E;
     constexpr int P = JTraits<K>::P, Q = JTraits<K>::Q, VEC = JTraits<K>::VEC, LINE = 128 / (int)sizeof(E);
@@ -838,8 +856,10 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
     K *splitters = nullptr; uint32_t *bstart = nullptr, *counts = nullptr, *scount = nullptr, *sbins = nullptr;
     int64_t *info = nullptr;                                                     // [0] survivors (u64), [1] error word of the partition
     E *slabs = nullptr; uint2 *surv = nullptr;
-    uint32_t *rank = nullptr, *lrow = nullptr, *cnt = nullptr, *sval = nullptr, *lv = nullptr, *rv = nullptr;
+    uint32_t *rank = nullptr, *lrow = nullptr, *cnt = nullptr, *sval = nullptr, *skey = nullptr, *lv = nullptr, *rv = nullptr;
     const bool carry = lval != nullptr && sizeof(E) == 16;                      // the fourth word of the 16-byte entries
+    const bool verify = sizeof(K) == 8;                                          // survivors carry their probe key's low word to the order kernel
+    if (getenv("HARK_JOIN_NOTRUNC")) allow_trunc = false;
     *lval_out = nullptr; *rval_out = nullptr;
     const size_t sstride = (size_t)nwg * cap;                                    // probe slabs of a bucket
     // survivor bins of a bucket: twice the room of all of its probe pairs, dealt out equally to its bins -- a bin overflows
@@ -854,11 +874,12 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
     if (!rc) rc = hark_alloc(ctx, (void **)&slabs, sizeof(E) * (size_t)P * sstride);
     if (!rc) rc = hark_alloc(ctx, (void **)&surv, 8 * (size_t)P * region);
     if (!rc && carry) rc = hark_alloc(ctx, (void **)&sval, 4 * (size_t)P * region);
+    if (!rc && verify) rc = hark_alloc(ctx, (void **)&skey, 4 * (size_t)P * region);
     uint32_t *scoarse = nullptr;
     if (!rc) rc = hark_alloc(ctx, (void **)&scoarse, 4 * (size_t)P * kCoarse);
     auto cleanup = [&]() {
         hark_free(ctx, splitters); hark_free(ctx, bstart); hark_free(ctx, counts); hark_free(ctx, scount); hark_free(ctx, sbins);
-        hark_free(ctx, info); hark_free(ctx, slabs); hark_free(ctx, surv); hark_free(ctx, sval); hark_free(ctx, scoarse);
+        hark_free(ctx, info); hark_free(ctx, slabs); hark_free(ctx, surv); hark_free(ctx, sval); hark_free(ctx, skey); hark_free(ctx, scoarse);
     };
     if (rc == HARK_ENOMEM) {                                                     // no room for the partition workspace: the sort-merge path
         cleanup();                                                               // needs far less (used stays false)
@@ -883,13 +904,13 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
                                 + (size_t)(kJIdx + 8) * 2;
     static_assert(lds_bucket <= kJLdsBudget, "bucket kernel LDS");
     if (he == hipSuccess) he = hipFuncSetAttribute(reinterpret_cast<const void *>(&jbucket_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bucket);
-    const bool carry_stage = carry;
-    int stage_cap = carry_stage ? kStageCarry : kStage;
+    const int xw = (carry ? 1 : 0) + (verify ? 1 : 0);                          // words a survivor carries beside (rank, left row)
+    int stage_cap = stage_of(xw);
     if (const char *e = getenv("HARK_JOIN_STAGE")) { const int c = atoi(e); if (c >= 1 && c < stage_cap) stage_cap = c; }   // tests: many sub-rounds per bucket
     if (he == hipSuccess) {
         // one stream-ordered chain, one host read at the end: partition -> bucket probe -> survivor total
         jpart_kernel<K><<<dim3((unsigned)nwg), dim3(kJThreads), lds_part, st>>>(lcol, n, bias, splitters, rkeys, s, slabs, counts, cap, period, err, carry ? lval : nullptr);
-        jbucket_kernel<K><<<dim3((unsigned)P), dim3(kJThreads), lds_bucket, st>>>(slabs, counts, cap, nwg, rkeys, bstart, chunk_cap, surv, region, scount, sbins, sval, scoarse, stage_cap, err, getenv("HARK_JOIN_NOTRUNC") ? 0 : 1);
+        jbucket_kernel<K><<<dim3((unsigned)P), dim3(kJThreads), lds_bucket, st>>>(slabs, counts, cap, nwg, rkeys, bstart, chunk_cap, surv, region, scount, sbins, sval, skey, scoarse, stage_cap, err, allow_trunc ? 1 : 0);
         jsum_kernel<<<1, 1024, 0, st>>>(scount, P, total);
         he = hipGetLastError();
         if (he == hipSuccess) he = hipMemcpyAsync(info + 2, flags, 8, hipMemcpyDeviceToDevice, st);   // the duplicate-keys flag rides along with the same host read
@@ -912,30 +933,47 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
         if (!rc && dup) rc = hark_alloc(ctx, (void **)&cnt, 4 * (size_t)M);     // unique build keys: every survivor has exactly one partner
         if (!rc && carry) rc = hark_alloc(ctx, (void **)&lv, 4 * (size_t)M);
         if (!rc && rranked) rc = hark_alloc(ctx, (void **)&rv, 4 * (size_t)M);
+        bool mismatch = false;
         for (int attempt = 0; attempt < 2 && !rc; attempt++) {
+            const uint64_t *rk64 = reinterpret_cast<const uint64_t *>(rkeys);
             if (getenv("HARK_JOIN_FULLSORT")) {                                  // A/B + tests: plain compaction, radix sorts by the caller
-                jcompact_kernel<<<dim3((unsigned)P), 256, 0, st>>>(surv, region, scount, sbins, counts, cap, nwg, bstart, stage_cap, rank, lrow);
+                jcompact_kernel<<<dim3((unsigned)P), 256, 0, st>>>(surv, region, scount, sbins, counts, cap, nwg, bstart, stage_cap, rank, lrow, skey, rk64, flags);
                 hipMemsetAsync(flags, 1, 1, st);
             } else {
-                const size_t lds_order = (carry ? (size_t)kStageCarry * 12 + (size_t)(kFineCarry + 1) * 4 : (size_t)kStage * 8 + (size_t)(kFine + 1) * 4) + (size_t)(kCoarse + 1) * 4;
-                he = carry ? hipFuncSetAttribute(reinterpret_cast<const void *>(&jorder_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_order)
-                           : hipFuncSetAttribute(reinterpret_cast<const void *>(&jorder_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_order);
-                if (he == hipSuccess && carry)
-                    jorder_kernel<true><<<dim3((unsigned)P), dim3(kJThreads), lds_order, st>>>(surv, region, scount, sbins, counts, cap, nwg, bstart, P, runlen,
-                                                                                             rank, lrow, cnt, stage_cap, flags, sval, lv, scoarse, rranked, rv);
-                else if (he == hipSuccess)
-                    jorder_kernel<false><<<dim3((unsigned)P), dim3(kJThreads), lds_order, st>>>(surv, region, scount, sbins, counts, cap, nwg, bstart, P, runlen,
-                                                                                              rank, lrow, cnt, stage_cap, flags, nullptr, nullptr, scoarse, rranked, rv);
+                const size_t lds_order = (size_t)stage_of(xw) * (8 + 4 * (size_t)xw) + (size_t)(fine_of(xw) + 1) * 4 + (size_t)(kCoarse + 1) * 4;
+                auto launch = [&](auto carry_tag, auto verify_tag) -> hipError_t {
+                    constexpr bool C = decltype(carry_tag)::value, V = decltype(verify_tag)::value;
+                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&jorder_kernel<C, V>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_order);
+                    if (e != hipSuccess) return e;
+                    jorder_kernel<C, V><<<dim3((unsigned)P), dim3(kJThreads), lds_order, st>>>(surv, region, scount, sbins, counts, cap, nwg, bstart, P, runlen,
+                                                                                             rank, lrow, cnt, stage_cap, flags, C ? sval : nullptr, C ? lv : nullptr, scoarse, rranked, rv,
+                                                                                             V ? skey : nullptr, V ? rk64 : nullptr);
+                    return hipSuccess;
+                };
+                he = carry ? (verify ? launch(std::true_type{}, std::true_type{}) : launch(std::true_type{}, std::false_type{}))
+                           : (verify ? launch(std::false_type{}, std::true_type{}) : launch(std::false_type{}, std::false_type{}));
             }
             if (he != hipSuccess || hipGetLastError() != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: order launch failed");
             // does the order stand, or do the survivors need the general sort (skew)?  Read here, while the survivors are alive:
-            // an order kernel that left the rows out runs once more to deliver them
-            if (!rc) rc = hark_read_words(ctx, flags, general_out, 1);
-            *general_out &= 0xFFFFFFFFll;
-            if (rc || !(*general_out && skip_rows)) break;
+            // an order kernel that left the rows out runs once more to deliver them.  [2]: a hit on a truncated key was none.
+            int64_t fw[2] = {0, 0};
+            if (!rc) rc = hark_read_words(ctx, flags, fw, 2);
+            *general_out = fw[0] & 0xFFFFFFFFll;
+            mismatch = (fw[1] & 0xFFFFFFFFll) != 0;
+            if (rc || mismatch || !(*general_out && skip_rows)) break;
             skip_rows = false;
             rc = hark_alloc(ctx, (void **)&rank, 4 * (size_t)M);
             if (!rc) rc = hark_alloc(ctx, (void **)&lrow, 4 * (size_t)M);
+        }
+        if (!rc && mismatch) {
+            // a probe key shared its truncation with a build key it differs from (keys that cluster below the dropped bits): the
+            // survivors hold rows that do not join.  Once more from the partition, with full keys in every round.
+            cleanup();
+            hark_free(ctx, rank); hark_free(ctx, lrow); hark_free(ctx, cnt); hark_free(ctx, lv); hark_free(ctx, rv);
+            if (!allow_trunc) return hark_fail(ctx, HARK_EHIP, "join: key mismatch without truncated rounds");
+            if (hipMemsetAsync(flags, 0, 4, st) != hipSuccess || hipMemsetAsync(flags + 2, 0, 4, st) != hipSuccess) return hark_fail(ctx, HARK_EHIP, "join: flag reset failed");
+            return run_partitioned<K>(ctx, lcol, bias, n, rkeys, s, runlen, flags, lval, rranked, rank_out, lrow_out, cnt_out, lval_out, rval_out, m_out, used, dup_out,
+                                      rows_needed, general_out, false);
         }
     }
     cleanup();                                                              // stream-ordered reuse: the ordering above is enqueued first

@@ -27,13 +27,28 @@ __device__ __forceinline__ unsigned long long block_exclusive(unsigned long long
     return carry + incl - x;
 }
 
+// a thread's kScanPer consecutive counts: four 16-byte loads where the rows exist and the column is aligned (one 4-byte load
+// per count touched 64 lines per wave instruction: the join's 1.09e7-row scan ran at 1.5-2 TB/s), zeros past the end
+__device__ __forceinline__ void load16(const uint32_t *__restrict__ in, int64_t base, int64_t n, uint32_t (&v)[kScanPer])
+{
+    if (base + kScanPer <= n && (reinterpret_cast<uintptr_t>(in) & 15u) == 0) {
+#pragma unroll
+        for (int j = 0; j < kScanPer; j += 4) { const uint4 q = *reinterpret_cast<const uint4 *>(in + base + j); v[j] = q.x; v[j + 1] = q.y; v[j + 2] = q.z; v[j + 3] = q.w; }
+    } else {
+#pragma unroll
+        for (int j = 0; j < kScanPer; j++) v[j] = base + j < n ? in[base + j] : 0u;
+    }
+}
+
 __global__ __launch_bounds__(kScanThreads) void tile_sums_kernel(const uint32_t *__restrict__ in, int64_t n, unsigned long long *__restrict__ sums)
 {
     __shared__ unsigned long long s_wave[kScanThreads / 64];
     const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanPer;
+    uint32_t v[kScanPer];
+    load16(in, base, n, v);
     unsigned long long x = 0;
 #pragma unroll
-    for (int j = 0; j < kScanPer; j++) if (base + j < n) x += in[base + j];
+    for (int j = 0; j < kScanPer; j++) x += v[j];
     unsigned long long tot;
     block_exclusive(x, s_wave, &tot);
     if (threadIdx.x == 0) sums[blockIdx.x] = tot;
@@ -65,17 +80,34 @@ __global__ __launch_bounds__(kScanThreads) void scan_apply_kernel(const uint32_t
     __shared__ unsigned long long s_wave[kScanThreads / 64];
     const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanPer;
     uint32_t v[kScanPer];
+    load16(in, base, n, v);
     unsigned long long x = 0;
 #pragma unroll
-    for (int j = 0; j < kScanPer; j++) { v[j] = base + j < n ? in[base + j] : 0u; x += v[j]; }
+    for (int j = 0; j < kScanPer; j++) x += v[j];
     unsigned long long run = offs[blockIdx.x] + block_exclusive(x, s_wave, nullptr);
+    const bool whole = base + kScanPer <= n;
+    if (whole && out32 && (reinterpret_cast<uintptr_t>(out32) & 15u) == 0) {          // 16-byte stores where the rows exist
+        uint32_t o[kScanPer];
 #pragma unroll
-    for (int j = 0; j < kScanPer; j++) {
-        if (base + j < n) {
-            if (out32) out32[base + j] = (uint32_t)run;
-            if (out64) out64[base + j] = (int64_t)run;
+        for (int j = 0; j < kScanPer; j++) { o[j] = (uint32_t)run; run += v[j]; }
+#pragma unroll
+        for (int j = 0; j < kScanPer; j += 4) *reinterpret_cast<uint4 *>(out32 + base + j) = uint4{o[j], o[j + 1], o[j + 2], o[j + 3]};
+        run -= x;
+    } else if (out32) {
+        unsigned long long r2 = run;
+#pragma unroll
+        for (int j = 0; j < kScanPer; j++) { if (base + j < n) out32[base + j] = (uint32_t)r2; r2 += v[j]; }
+    }
+    if (whole && out64 && (reinterpret_cast<uintptr_t>(out64) & 15u) == 0) {
+#pragma unroll
+        for (int j = 0; j < kScanPer; j += 2) {
+            const unsigned long long a = run, b = run + v[j];
+            *reinterpret_cast<ulonglong2 *>(out64 + base + j) = ulonglong2{a, b};
+            run = b + v[j + 1];
         }
-        run += v[j];
+    } else if (out64) {
+#pragma unroll
+        for (int j = 0; j < kScanPer; j++) { if (base + j < n) out64[base + j] = (int64_t)run; run += v[j]; }
     }
 }
 

@@ -243,3 +243,33 @@ def test_sort_merge_knob_gives_the_same_rows():
     env = dict(os.environ, HARK_JOIN_SORTMERGE="1")
     out = subprocess.run([sys.executable, "-c", _ROUNDS % (ROOT, os.path.join(ROOT, "tests"))], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0 and "rounds ok" in out.stdout, out.stdout + out.stderr
+
+
+_NEAR = r"""
+import sys
+import numpy as np
+sys.path.insert(0, %r)
+sys.path.insert(0, %r)
+import test_gpu_hjoin as T
+from harkdb_amd.engine import Engine
+eng = Engine(0)
+rng = np.random.default_rng(11)
+s, n = 60_000, (1 << 18) + 4099
+rk = (rng.permutation(s).astype(np.int64) << 36) - (1 << 51)          # unique build keys, 2^36 apart: a bucket's keys truncate to (key - first) >> ts with ts > 0
+lk = rk[rng.integers(0, s, size=n)]
+near = rng.random(n) < 0.5
+lk[near] += rng.integers(1, 1 << 12, size=int(near.sum()))              # half of the probe keys sit just ABOVE a build key: same truncation, no partner
+print("pairs", T._check(eng, lk, rk), "of", n, "probe rows;", int((~near).sum()), "expected")
+print("near ok")
+"""
+
+
+@pytest.mark.parametrize("chunk", ["64", "100"])
+def test_probe_keys_that_share_a_truncation_with_a_build_key_do_not_join(chunk):
+    """64-bit keys: a bucket of up to two chunks of build keys is probed in ONE round over keys truncated to 32 bits, and a hit is
+    confirmed by the order kernel against the build key of the survivor's rank (k_hjoin.hip).  Probe keys a few units above
+    a build key share its truncation: the first attempt's survivors contain rows that do not join, the kernel says so, and
+    the join runs again with full keys -- the reference's rows either way (join.fut:52-75)."""
+    env = dict(os.environ, HARK_JOIN_CHUNK=chunk)                          # ~117 build keys per bucket: two chunks of 64 / 100 -> the truncated round
+    out = subprocess.run([sys.executable, "-c", _NEAR % (ROOT, os.path.join(ROOT, "tests"))], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0 and "near ok" in out.stdout, out.stdout + out.stderr
