@@ -148,7 +148,11 @@ __global__ __launch_bounds__(256) void jcnt_kernel(const uint32_t *__restrict__ 
 
 // ---- probe side: range partition of (key, row id) ---------------------------------------------------------------
 // LDS: E ring[P][Q]; K ext[P + 2]; u32 s_w[P] (head << 16 | count); int s_lcur[P]; u32 flags[4].
-template <typename K>
+// HIDDEN: the batches' loads are issued from inline assembly and waited for by hand (below); false: plain non-temporal loads
+// whose waits the compiler places (HARK_JOIN_PLAIN_LOADS=1: the cross-check of tests/test_gpu_hjoin.py -- the hand-placed
+// waits depend on the compiler never touching a destination register between a load and its wait, which nothing checks at
+// build time, so the tests run every join shape through both kernels).
+template <typename K, bool HIDDEN>
 __global__ __launch_bounds__(kJThreads) void jpart_kernel(const K *__restrict__ keys, int64_t n, K bias, const K *__restrict__ splitters,
                                                           const K *__restrict__ rkeys, int64_t s,
                                                           typename JTraits<K>::E *__restrict__ slabs, uint32_t *__restrict__ counts, uint32_t cap,
@@ -200,8 +204,18 @@ __global__ __launch_bounds__(kJThreads) void jpart_kernel(const K *__restrict__ 
     auto load = [&](int64_t batch, hark_u4v &kq, hark_u2v &vq) {
         int64_t r = batch * BATCH + (int64_t)tid * VEC;
         if (r + VEC > n) r = 0;
-        ld_hidden_nt_b128(kq, keys + r);                             // VEC * sizeof(K) = 16 bytes
-        if (sizeof(E) == 16) ld_hidden_nt_b64(vq, vsrc + r);         // VEC = 2 rows: one 8-byte load (r is even)
+        if (HIDDEN) {
+            ld_hidden_nt_b128(kq, keys + r);                         // VEC * sizeof(K) = 16 bytes
+            if (sizeof(E) == 16) ld_hidden_nt_b64(vq, vsrc + r);     // VEC = 2 rows: one 8-byte load (r is even)
+        } else {
+            kq = __builtin_nontemporal_load(reinterpret_cast<const hark_u4v *>(keys + r));
+            if (sizeof(E) == 16) vq = __builtin_nontemporal_load(reinterpret_cast<const hark_u2v *>(vsrc + r));
+        }
+    };
+    auto arrived = [&](hark_u4v &kq, hark_u2v &vq) {                  // the batch in (kq, vq) is about to be used
+        if (!HIDDEN) return;
+        constexpr int kAheadLoads = sizeof(E) == 16 ? 4 : 2;           // loads of the two batches behind the one being used
+        if (sizeof(E) == 16) wait_vm<kAheadLoads>(kq, vq); else wait_vm<kAheadLoads>(kq);
     };
     auto unpack = [&](const hark_u4v t, const hark_u2v q, K (&kk)[VEC], uint32_t (&vv)[VEC]) {
         if (sizeof(K) == 4) { kk[0] = (K)t.x; kk[1 % VEC] = (K)t.y; kk[2 % VEC] = (K)t.z; kk[3 % VEC] = (K)t.w; }
@@ -286,30 +300,29 @@ __global__ __launch_bounds__(kJThreads) void jpart_kernel(const K *__restrict__ 
     auto rows_of = [&](int64_t batch, int64_t &r) -> int { r = batch * BATCH + (int64_t)tid * VEC; return r + VEC <= nfull ? VEC : 0; };
     load(wg, qA, wA); load((int64_t)wg + nwg, qB, wB); load((int64_t)wg + 2 * (int64_t)nwg, qC, wC);
     const bool has_tail = wg == 0 && nfull < n;                        // the last n % VEC rows: a batch of their own (workgroup 0)
-    constexpr int kAhead = sizeof(E) == 16 ? 4 : 2;                    // loads of the two batches behind the one being used
     for (int64_t batch = wg;;) {
         int64_t r;
         int nr;
         if (batch >= nbatch) break;
-        if (sizeof(E) == 16) wait_vm<kAhead>(qA, wA); else wait_vm<kAhead>(qA);
+        arrived(qA, wA);
         unpack(qA, wA, kk_, vv_);
         nr = rows_of(batch, r);
         process(r, nr, kk_, vv_, ++since >= period || (batch + nwg >= nbatch && !has_tail));
         load(batch + 3 * (int64_t)nwg, qA, wA); batch += nwg;
         if (batch >= nbatch) break;
-        if (sizeof(E) == 16) wait_vm<kAhead>(qB, wB); else wait_vm<kAhead>(qB);
+        arrived(qB, wB);
         unpack(qB, wB, kk_, vv_);
         nr = rows_of(batch, r);
         process(r, nr, kk_, vv_, ++since >= period || (batch + nwg >= nbatch && !has_tail));
         load(batch + 3 * (int64_t)nwg, qB, wB); batch += nwg;
         if (batch >= nbatch) break;
-        if (sizeof(E) == 16) wait_vm<kAhead>(qC, wC); else wait_vm<kAhead>(qC);
+        arrived(qC, wC);
         unpack(qC, wC, kk_, vv_);
         nr = rows_of(batch, r);
         process(r, nr, kk_, vv_, ++since >= period || (batch + nwg >= nbatch && !has_tail));
         load(batch + 3 * (int64_t)nwg, qC, wC); batch += nwg;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the loads still in flight write registers: let them land
+    if (HIDDEN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the loads still in flight write registers: let them land
     if (has_tail) {
         const int nr = tid == 0 ? (int)(n - nfull) : 0;
         for (int j = 0; j < VEC; j++) { kk_[j] = (tid == 0 && j < nr) ? keys[nfull + j] : (K)0; vv_[j] = (tid == 0 && j < nr && has_val) ? lval[nfull + j] : 0u; }
@@ -892,7 +905,9 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
     unsigned long long *total = reinterpret_cast<unsigned long long *>(info);
     jsplit_kernel<K><<<(P + 256) / 256, 256, 0, st>>>(rkeys, s, P, splitters, bstart);
     const size_t lds_part = sizeof(E) * (size_t)P * Q + sizeof(K) * (P + 2) + 8 * (size_t)P + 16;
-    hipError_t he = hipFuncSetAttribute(reinterpret_cast<const void *>(&jpart_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part);
+    const bool plain_loads = getenv("HARK_JOIN_PLAIN_LOADS") != nullptr;        // tests: the compiler-counted twin of the partition kernel
+    hipError_t he = plain_loads ? hipFuncSetAttribute(reinterpret_cast<const void *>(&jpart_kernel<K, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part)
+                                : hipFuncSetAttribute(reinterpret_cast<const void *>(&jpart_kernel<K, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part);
     // rows per bucket and batch = BATCH / P; sweep before a ring of Q entries (less one line of carry) can fill up
     const int per_batch = kJThreads * VEC / P;
     int period = (Q - LINE) / (per_batch + per_batch / 2);
@@ -909,7 +924,8 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
     if (const char *e = getenv("HARK_JOIN_STAGE")) { const int c = atoi(e); if (c >= 1 && c < stage_cap) stage_cap = c; }   // tests: many sub-rounds per bucket
     if (he == hipSuccess) {
         // one stream-ordered chain, one host read at the end: partition -> bucket probe -> survivor total
-        jpart_kernel<K><<<dim3((unsigned)nwg), dim3(kJThreads), lds_part, st>>>(lcol, n, bias, splitters, rkeys, s, slabs, counts, cap, period, err, carry ? lval : nullptr);
+        if (plain_loads) jpart_kernel<K, false><<<dim3((unsigned)nwg), dim3(kJThreads), lds_part, st>>>(lcol, n, bias, splitters, rkeys, s, slabs, counts, cap, period, err, carry ? lval : nullptr);
+        else jpart_kernel<K, true><<<dim3((unsigned)nwg), dim3(kJThreads), lds_part, st>>>(lcol, n, bias, splitters, rkeys, s, slabs, counts, cap, period, err, carry ? lval : nullptr);
         jbucket_kernel<K><<<dim3((unsigned)P), dim3(kJThreads), lds_bucket, st>>>(slabs, counts, cap, nwg, rkeys, bstart, chunk_cap, surv, region, scount, sbins, sval, skey, scoarse, stage_cap, err, allow_trunc ? 1 : 0);
         jsum_kernel<<<1, 1024, 0, st>>>(scount, P, total);
         he = hipGetLastError();

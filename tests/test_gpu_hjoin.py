@@ -273,3 +273,12 @@ def test_probe_keys_that_share_a_truncation_with_a_build_key_do_not_join(chunk):
     env = dict(os.environ, HARK_JOIN_CHUNK=chunk)                          # ~117 build keys per bucket: two chunks of 64 / 100 -> the truncated round
     out = subprocess.run([sys.executable, "-c", _NEAR % (ROOT, os.path.join(ROOT, "tests"))], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0 and "near ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_partition_kernel_with_compiler_counted_loads_gives_the_same_rows():
+    """jpart_kernel issues its loads from inline assembly and waits for them by hand (a software pipeline the compiler's wait
+    counting cannot follow); HARK_JOIN_PLAIN_LOADS=1 runs its twin with plain loads.  Every join shape of this file through
+    that twin too: a compiler change that breaks the hand-placed waits shows up as a difference between the two."""
+    env = dict(os.environ, HARK_JOIN_PLAIN_LOADS="1")
+    out = subprocess.run([sys.executable, "-c", _ROUNDS % (ROOT, os.path.join(ROOT, "tests"))], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0 and "rounds ok" in out.stdout, out.stdout + out.stderr
