@@ -35,9 +35,6 @@ struct hark_context {
     size_t pool_cached = 0, pool_limit = (size_t)64 << 30;
     // diagnostic: which GROUP BY path served the last group-by entry (hark_context_last_groupby_path)
     int last_groupby_path = 0;
-    // -1 not checked yet; 1: returning LDS atomics of one wave instruction come back in lane order on this device (k_sort.hip
-    // lds_lane_order_ok: the radix passes then rank with one ds_add_rtn per key); 0: they do not (mask exchange instead)
-    int lds_lane_order = -1;
 };
 
 // Every entry runs on the context's device whatever device the calling thread has current (a process may hold

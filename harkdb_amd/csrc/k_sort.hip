@@ -63,52 +63,6 @@ static int plan_passes(uint32_t diff, SortPass *out)
     return nb;
 }
 
-// ---- does this device hand returning LDS atomics out in lane order? (see digit_scatter2_kernel ARANK) ----------------
-// One workgroup, 16 waves x 256 rounds over digit distributions with many, few, two and one distinct value: what every lane
-// got back is compared with the lane-ordered rank computed from ballots.  ~20 us, once per context.
-__global__ __launch_bounds__(1024) void lds_lane_order_kernel(uint32_t *bad)
-{
-    __shared__ uint32_t cnt[16][kBins], shadow[16][kBins];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = lane; i < kBins; i += 64) { cnt[wave][i] = 0u; shadow[wave][i] = 0u; }
-    __syncthreads();
-    uint32_t nbad = 0, x = (uint32_t)threadIdx.x * 2654435761u + 12345u;
-    for (int r = 0; r < 256; r++) {
-        x ^= x << 13; x ^= x >> 17; x ^= x << 5;
-        const int mode = r & 3;
-        const uint32_t d = mode == 0 ? (x >> 9) & 255u : mode == 1 ? (x >> 9) & 15u : mode == 2 ? (x >> 9) & 1u : 7u + (uint32_t)(lane >> 6);
-        const uint32_t got = atomicAdd(&cnt[wave][d], 1u);
-        unsigned long long peers = ~0ull;
-        for (int b = 0; b < 8; b++) { const unsigned long long m = __ballot((d >> b) & 1u); peers &= ((d >> b) & 1u) ? m : ~m; }
-        const uint32_t below = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull)), before = shadow[wave][d];
-        __builtin_amdgcn_wave_barrier();
-        if (below == 0u) shadow[wave][d] = before + (uint32_t)__popcll(peers);
-        __builtin_amdgcn_wave_barrier();
-        nbad += got != before + below ? 1u : 0u;
-    }
-    if (nbad) atomicAdd(bad, nbad);
-}
-
-static bool lds_lane_order_ok(hark_context *ctx)
-{
-    const char *knob = getenv("HARK_SORT_MASKRANK");                 // (read per call: tools/sort_ab.py switches it inside one process)
-    if (knob && atoi(knob) == 1) return false;
-    if (ctx->lds_lane_order < 0) {
-        ctx->lds_lane_order = 0;
-        uint32_t *bad = nullptr;
-        if (hark_alloc(ctx, (void **)&bad, 8) == HARK_OK) {
-            int64_t w = 1;
-            if (hipMemsetAsync(bad, 0, 8, ctx->stream) == hipSuccess) {
-                lds_lane_order_kernel<<<1, 1024, 0, ctx->stream>>>(bad);
-                if (hipGetLastError() == hipSuccess && hark_read_words(ctx, bad, &w, 1) == HARK_OK && w == 0) ctx->lds_lane_order = 1;
-            }
-            hark_free(ctx, bad);
-        }
-        ctx->err.clear();
-    }
-    return ctx->lds_lane_order == 1;
-}
-
 static bool old_scatter()
 {
     static const bool v = getenv("HARK_SORT_TILED") && atoi(getenv("HARK_SORT_TILED")) == 1;
@@ -426,19 +380,11 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
 //     read per key (delta[d] = first output position of the digit - its start in the tile);
 //   * validity tests only run in a slice's last tile.
 // Same result as digit_scatter_kernel (positions are assigned in input order: stable).
-// ARANK (round 4): the rank of a key among the wave's earlier keys with the same digit is ONE returning LDS atomic,
-// rank = ds_add_rtn_u32(count of (wave, digit), 1): gfx950 hands the old values out in LANE order among the lanes of one
-// instruction that hit the same address, and a wave's LDS instructions execute in order, so the ranks follow the input
-// order (stable) -- and the per-wave digit counts are the counters themselves.  One LDS instruction per key instead of five
-// (OR, read, clear, count read, count write), all R of a lane independent and in flight together.  The lane order is
-// not an architectural promise: tools/ldsorder_test.hip found no violation in 1e9 atomics over every conflict pattern, the
-// library checks it on the device once per context (lds_lane_order_ok) and takes the mask exchange otherwise
-// (HARK_SORT_MASKRANK=1 forces that), and the exact stable-sort tests run on the result either way.
 template <typename GEO> constexpr size_t scatter2_lds()
 {
     return (size_t)GEO::T * GEO::R * 8 + (size_t)(GEO::T / 64) * kBins * 8 + (size_t)(GEO::T / 64) * kBins * 2 * 2 + (size_t)kBins * 4 * 3 + 64;
 }
-template <typename GEO, bool IOTA, bool ARANK>
+template <typename GEO, bool IOTA>
 __global__ __launch_bounds__(GEO::T) void digit_scatter2_kernel(
     const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
     uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
@@ -452,7 +398,6 @@ __global__ __launch_bounds__(GEO::T) void digit_scatter2_kernel(
     extern __shared__ __attribute__((aligned(16))) unsigned char sort_lds[];
     uint2 *s_kv = reinterpret_cast<uint2 *>(sort_lds);                              // [TILE] (key, payload), digit-sorted
     uint32_t *s_mask = reinterpret_cast<uint32_t *>(s_kv + TILE);                   // [W][2][bins] lanes of the wave holding the digit, low / high 32 lanes (all zero between rounds)
-    uint32_t (*s_acnt)[kBins] = reinterpret_cast<uint32_t (*)[kBins]>(s_mask);      // ARANK: [W][bins] per-wave digit counts of the tile (in the mask tables' place)
     uint16_t (*s_wcnt)[kBins] = reinterpret_cast<uint16_t (*)[kBins]>(s_mask + (size_t)W * 2 * kBins);   // [W][bins] per-wave digit counts of the tile
     uint16_t (*s_wbase)[kBins] = s_wcnt + W;                                        // [W][bins] first tile slot of (wave, digit)
     uint32_t *s_tstart = reinterpret_cast<uint32_t *>(s_wbase + W);                 // [bins] start of the digit in the tile
@@ -462,7 +407,7 @@ __global__ __launch_bounds__(GEO::T) void digit_scatter2_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t lo = (int64_t)blockIdx.x * slice;
     const int64_t hi = lo + slice < n ? lo + slice : n;
-    if (!ARANK) for (int i = tid; i < W * 2 * kBins; i += T) s_mask[i] = 0u;
+    for (int i = tid; i < W * 2 * kBins; i += T) s_mask[i] = 0u;
     {   // first output position of (digit tid, this slice) = digits before + this digit's earlier slices
         const uint32_t tot = tid < kBins ? row_total[tid] : 0u;
         const uint32_t incl = wave_incl_scan(tot);
@@ -496,19 +441,8 @@ __global__ __launch_bounds__(GEO::T) void digit_scatter2_kernel(
 #pragma unroll
         for (int r = 0; r < R; r++) key[r] = nkey[r];
         // the wave's own row of digit counts (its readers of the previous tile passed that tile's second barrier)
-        if (ARANK) reinterpret_cast<uint4 *>(s_acnt[wave])[lane] = uint4{0u, 0u, 0u, 0u};
-        else reinterpret_cast<uint2 *>(mycnt)[lane] = uint2{0u, 0u};
-        // ---- rank inside the wave's contiguous chunk ---------------------------------------------------------------------
-        if (ARANK) {
-#pragma unroll
-            for (int r = 0; r < R; r++) {                            // R independent returning atomics, in flight together
-                const bool valid = FULL || wbase + r * 64 + lane < hi;
-                const uint32_t d = ((key[r] ^ xor_mask) >> sh) & dmask;
-                rank[r] = 0xFFFFFFFFu;
-                if (valid) rank[r] = atomicAdd(&s_acnt[wave][d], 1u);
-            }
-        } else
-        // lanes with my digit = the mask the wave ORs together in LDS
+        reinterpret_cast<uint2 *>(mycnt)[lane] = uint2{0u, 0u};
+        // ---- rank inside the wave's contiguous chunk: lanes with my digit = the mask the wave ORs together in LDS ------
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const bool valid = FULL || wbase + r * 64 + lane < hi;
@@ -555,7 +489,7 @@ __global__ __launch_bounds__(GEO::T) void digit_scatter2_kernel(
         if (tid < kBins) {
             uint32_t run = 0;
 #pragma unroll
-            for (int w = 0; w < W; w++) { s_wbase[w][tid] = (uint16_t)run; run += ARANK ? s_acnt[w][tid] : (uint32_t)s_wcnt[w][tid]; }
+            for (int w = 0; w < W; w++) { s_wbase[w][tid] = (uint16_t)run; run += s_wcnt[w][tid]; }
             tcnt = run;
             incl = wave_incl_scan(tcnt);                             // (all 64 lanes of the four digit waves are active here)
             if (lane == 63) s_scan[wave] = incl;
@@ -1037,11 +971,8 @@ int k_sort_pairs_u32(hark_context *ctx, uint32_t *keys_a, uint32_t *keys_b, uint
         if (old_scatter()) {
             if (large) HARK_SCATTER((digit_scatter_kernel<GeoLarge, true>), (digit_scatter_kernel<GeoLarge, false>), GeoLarge::T, scatter_lds<GeoLarge>());
             else HARK_SCATTER((digit_scatter_kernel<GeoSmall, true>), (digit_scatter_kernel<GeoSmall, false>), GeoSmall::T, scatter_lds<GeoSmall>());
-        } else if (lds_lane_order_ok(ctx)) {
-            if (large) HARK_SCATTER((digit_scatter2_kernel<GeoLarge, true, true>), (digit_scatter2_kernel<GeoLarge, false, true>), GeoLarge::T, scatter2_lds<GeoLarge>());
-            else HARK_SCATTER((digit_scatter2_kernel<GeoSmall, true, true>), (digit_scatter2_kernel<GeoSmall, false, true>), GeoSmall::T, scatter2_lds<GeoSmall>());
-        } else if (large) HARK_SCATTER((digit_scatter2_kernel<GeoLarge, true, false>), (digit_scatter2_kernel<GeoLarge, false, false>), GeoLarge::T, scatter2_lds<GeoLarge>());
-        else HARK_SCATTER((digit_scatter2_kernel<GeoSmall, true, false>), (digit_scatter2_kernel<GeoSmall, false, false>), GeoSmall::T, scatter2_lds<GeoSmall>());
+        } else if (large) HARK_SCATTER((digit_scatter2_kernel<GeoLarge, true>), (digit_scatter2_kernel<GeoLarge, false>), GeoLarge::T, scatter2_lds<GeoLarge>());
+        else HARK_SCATTER((digit_scatter2_kernel<GeoSmall, true>), (digit_scatter2_kernel<GeoSmall, false>), GeoSmall::T, scatter2_lds<GeoSmall>());
 #undef HARK_SCATTER
         HIP_TRY(ctx, hipGetLastError());
         *keys_out = kout; *vals_out = vout;
@@ -1449,8 +1380,6 @@ int partition_by_dest(hark_context *ctx, uint32_t *dest, int64_t n, int nparts, 
 }
 
 } // namespace
-
-extern "C" int hark_context_lds_lane_order(const hark_context *ctx) { return ctx ? ctx->lds_lane_order : -1; }
 
 extern "C" {
 
