@@ -68,6 +68,7 @@ with open(os.path.join(dst, f"{tag}_op_traffic.txt"), "w") as fo:
             fo.write(f"\n== {w}: not collected\n")
             continue
         r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "opmc.py"), df, dw, str(ALG[w])], capture_output=True, text=True)
-        logs = "".join(open(os.path.join(src, f"opmc_{w}_{c}.log")).read() for c in ("FETCH_SIZE",) if os.path.exists(os.path.join(src, f"opmc_{w}_{c}.log")))
+        logf = os.path.join(src, f"opmc_{w}_FETCH_SIZE.log")                   # the workload's own lines (wall times under the counter run), not the profiler's chatter
+        logs = "".join(ln for ln in open(logf) if ln.startswith(w + ":")) if os.path.exists(logf) else ""
         fo.write(f"\n== {w}\n{logs}{r.stdout}{r.stderr}")
 print(open(os.path.join(dst, f"{tag}_op_traffic.txt")).read())

@@ -14,7 +14,8 @@ mkdir -p $O
 date -u +%FT%TZ > $O/run_id.txt; sha256sum bench.py harkdb_amd/libhark.so >> $O/run_id.txt
 timeout 900 python bench.py > $O/bench_plain.json 2> $O/bench_plain.err
 # headline only (--configs 0): every launch of the fused kernels in these profiles is a headline launch
-# (under the profiler bench.py launches no nested --pmc children; --pmc 0 says so explicitly)
+# (under the profiler bench.py launches no nested --pmc children -- --pmc 0 says so explicitly -- and no setup launch: the
+# statistics average steps + warm-up full launches per kernel, nothing else)
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 10 --warmup 3 --cpu-rows 0 --configs 0 --pmc 0 > $O/bench_rocprof.json 2> $O/bench_rocprof.err
 # the PMC passes run the --pmc-child mode: warm-up + timed steps only, no setup launch (every launch is a full pass)
 timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 bench.py --pmc-child 1 --steps 2 --warmup 1 --cpu-rows 0 --configs 0 --pmc 0 > $O/pmc_fetch.json 2> $O/pmc_fetch.err

@@ -1,8 +1,8 @@
 """HBM bytes and time per kernel of ONE repetition of a tools/op_one.py workload, from its two PMC runs:
     python tools/opmc.py DIR_FETCH_SIZE DIR_WRITE_SIZE [algorithmic_bytes]
 Each directory is the -d of `rocprofv3 --pmc <COUNTER> --kernel-trace --output-format csv -- python3 tools/op_one.py W`.
-The last repetition is found as the shortest period of the kernel-name sequence at the end of the run (op_one.py repeats
-the statement; the setup kernels in front do not repeat).  FETCH_SIZE is doubled (gfx950: it reports half of a wide
+The last repetition is found as the longest block of kernel names at the end of the run that repeats the block before it
+(op_one.py repeats the statement at least three times; the setup kernels in front do not repeat).  FETCH_SIZE is doubled (gfx950: it reports half of a wide
 coalesced read stream, MI355X_MICROARCH.md HBM section), both counters are KiB.  Durations under --pmc are those of a
 serialised run (one dispatch at a time): use them as a guide, the trace-only runs for times."""
 import collections, csv, glob, sys
@@ -28,7 +28,10 @@ def short(n):
 
 
 def last_period(names):
-    for k in range(1, len(names) // 2 + 1):
+    """Dispatches of one repetition: the LONGEST k whose last k names repeat the k before them.  (The shortest would stop at
+    one radix pass of a sort, or at two equal gathers; a longer one than a repetition would have to reach into the setup
+    kernels, which do not repeat.)"""
+    for k in range(len(names) // 2, 0, -1):
         if names[-k:] == names[-2 * k:-k]:
             return k
     return len(names)

@@ -11,6 +11,7 @@ SEED = 0x4861726B4442
 
 
 def timeit(name, fn, bytes_alg, reps=5):
+    """bytes_alg: algorithmic bytes, or a function of the result's shape."""
     ts = []
     for r in range(reps + 1):
         eng.sync(); t0 = time.perf_counter(); res = fn(); eng.sync(); ts.append((time.perf_counter() - t0) * 1e3)
@@ -18,6 +19,8 @@ def timeit(name, fn, bytes_alg, reps=5):
         res.free()
     ts = sorted(ts[1:])
     ms = ts[len(ts) // 2]
+    if callable(bytes_alg):
+        bytes_alg = bytes_alg(shape)
     print(f"{name:58s} {ms:9.3f} ms  {N / ms / 1e6:8.2f} Grows/s  alg {bytes_alg / ms / 1e9:6.3f} TB/s ({bytes_alg / ms / 1e9 / 8:5.3f} of peak)  out={shape}", flush=True)
 
 
@@ -26,8 +29,8 @@ cols = [eng.alloc(N * 4) for _ in range(8)]
 for j in range(0, 8, 2):
     eng.gen_columns(SEED + j, 0, N, 1 << 20, False, cols[j], None, cols[j + 1])
 t8 = eng.table_from_device(N, cols, [np.float32] * 8)
-timeit("C2  select c0,c2 where c1>0.5 (f32, 8 cols)", lambda: eng.filter_sel(t8, 1, ">", 0.5, [0, 2], want_row_index=True), 18 * N)
-timeit("C2' select c0,c2 where c1>0.5, no row index", lambda: eng.filter_sel(t8, 1, ">", 0.5, [0, 2], want_row_index=False), 14 * N)
+timeit("C2  select c0,c2 where c1>0.5 (f32, 8 cols)", lambda: eng.filter_sel(t8, 1, ">", 0.5, [0, 2], want_row_index=True), lambda sh: 12 * N + 16 * sh[0])   # bench.py's C2 model: 3 columns read, 2 x f32 + i64 row index per survivor
+timeit("C2' select c0,c2 where c1>0.5, no row index", lambda: eng.filter_sel(t8, 1, ">", 0.5, [0, 2], want_row_index=False), lambda sh: 12 * N + 8 * sh[0])
 timeit("C1' projection select c0,c2 (query_sel)", lambda: eng.query_sel(t8, [0, 2]), 16 * N)
 
 # reference-semantics group-by / sort / join on u32 columns
