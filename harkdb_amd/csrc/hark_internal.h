@@ -35,6 +35,7 @@ struct hark_context {
     size_t pool_cached = 0, pool_limit = (size_t)64 << 30;
     // diagnostic: which GROUP BY path served the last group-by entry (hark_context_last_groupby_path)
     int last_groupby_path = 0;
+    int last_join_path = 0;        // hark_context_last_join_path
 };
 
 // Every entry runs on the context's device whatever device the calling thread has current (a process may hold

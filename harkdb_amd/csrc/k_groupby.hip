@@ -1548,6 +1548,7 @@ __global__ __launch_bounds__(256) void composite_key_kernel(CompositeArgs a, int
 } // namespace
 
 extern "C" int hark_context_last_groupby_path(const hark_context *ctx) { return ctx ? ctx->last_groupby_path : HARK_PATH_NONE; }
+extern "C" int hark_context_last_join_path(const hark_context *ctx) { return ctx ? ctx->last_join_path : HARK_PATH_NONE; }
 
 extern "C" int hark_table_invalidate_stats(hark_context *ctx, const hark_table *t, int32_t col)
 {

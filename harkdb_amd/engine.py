@@ -256,6 +256,10 @@ class Engine:
         """'dense' | 'hash' | 'sort' | None: the path that served the last GROUP BY entry (diagnostic, include/hark.h)."""
         return {1: "dense", 2: "hash", 3: "sort"}.get(self.lib.hark_context_last_groupby_path(self.ctx))
 
+    def last_join_path(self):
+        """'partitioned' | 'sort-merge' | None: the path that served the last join entry (diagnostic, include/hark.h)."""
+        return {1: "partitioned", 2: "sort-merge"}.get(self.lib.hark_context_last_join_path(self.ctx))
+
     def set_stream(self, raw_stream):
         """Run later entries on this hipStream_t handle; 0 / None = the context's own stream
         (so torch's DEFAULT stream, handle 0, cannot be shared: use dist.share_stream)."""

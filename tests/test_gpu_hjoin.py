@@ -282,3 +282,35 @@ def test_partition_kernel_with_compiler_counted_loads_gives_the_same_rows():
     env = dict(os.environ, HARK_JOIN_PLAIN_LOADS="1")
     out = subprocess.run([sys.executable, "-c", _ROUNDS % (ROOT, os.path.join(ROOT, "tests"))], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0 and "rounds ok" in out.stdout, out.stdout + out.stderr
+
+
+_CROWD = r"""
+import sys
+import numpy as np
+sys.path.insert(0, %r)
+sys.path.insert(0, %r)
+import test_gpu_hjoin as T
+from harkdb_amd.engine import Engine
+eng = Engine(0)
+rng = np.random.default_rng(5)
+s, n = 512 * 200, 1 << 23          # 16384 probe rows per bucket: far more than a bin's share of the survivor room
+for dt in (np.uint32, np.int64):
+    rk = np.sort(rng.choice(1 << 30, size=s, replace=False)).astype(dt)          # unique build keys, 200 per bucket
+    first = rk.reshape(512, 200)[:, :5].reshape(-1)                              # the five smallest keys of every bucket
+    lk = first[rng.integers(0, len(first), size=n)]                              # every probe row hits, all hits crowd a bucket's first ranks
+    print(dt.__name__, "pairs", T._check(eng, lk, rk), eng.last_join_path())
+    assert eng.last_join_path() == "sort-merge", eng.last_join_path()           # the overflow was seen and the fallback taken
+    even = rk[rng.integers(0, s, size=n)]                                        # the same build side probed evenly: the partitioned path
+    print(dt.__name__, "pairs", T._check(eng, even, rk), eng.last_join_path())
+    assert eng.last_join_path() == "partitioned", eng.last_join_path()
+print("crowd ok")
+"""
+
+
+def test_survivor_bin_overflow_falls_back():
+    """The bucket kernel deals survivors into bins of equal rank ranges with equal room; probe rows that all hit a bucket's
+    first few ranks overflow the first bin (HARK_JOIN_STAGE=16 makes the bins small enough at this size), the kernel reports
+    it and the join takes the sort-merge path: the reference's rows either way."""
+    env = dict(os.environ, HARK_JOIN_STAGE="16")
+    out = subprocess.run([sys.executable, "-c", _CROWD % (ROOT, os.path.join(ROOT, "tests"))], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0 and "crowd ok" in out.stdout, out.stdout + out.stderr
