@@ -148,8 +148,8 @@ int k_fgb_dense_f32(hark_context *ctx, hark_fgb_plan *plan, const float *p, int 
                     const int32_t *k, const float *v, int64_t n);
 
 // The hash partition of a (key column, value column) pair, kept between aggregates of the SAME value column (the pairs
-// the producer writes do not depend on the operator): zero-initialise, pass to every k_fgb_hash_u32 call, release with
-// k_fgb_hash_part_free.
+// the producer writes carry the raw value bits: they depend neither on the operator nor on its order transform):
+// zero-initialise, pass to every k_fgb_hash_u32 call, release with k_fgb_hash_part_free.
 struct hark_hash_part { void *pbuf = nullptr; uint32_t *counts = nullptr; int64_t cap = 0, n = 0; const void *k = nullptr, *v = nullptr, *p = nullptr; int xf = 0; };
 // a WHERE fused into a producer: f32 column `p` compared with `thr` (HARK_CMP_GT..NE), or a survivor bitmask (HARK_CMP_MASK)
 struct hark_row_pred { const float *p; int cmp; float thr; };
@@ -159,7 +159,8 @@ enum { HARK_HASH_FITS = 0, HARK_HASH_NOFIT_DISTINCT = 1 /* too many distinct key
        HARK_HASH_NOFIT_ROWS = 3 /* n == 0 or n >= 2^32: nothing learnt about the column */ };
 int k_fgb_hash_u32(hark_context *ctx, const uint32_t *k, const uint32_t *v, int64_t n, int vop, int xf,
                    uint32_t **keys_out, unsigned long long **vals_out, unsigned long long **cnts_out, int64_t *G_out, bool *fits,
-                   uint32_t *rounds_hint, bool compact, hark_hash_part *part = nullptr, int *why_not = nullptr, const hark_row_pred *pred = nullptr);
+                   uint32_t *rounds_hint, bool compact, hark_hash_part *part = nullptr, int *why_not = nullptr, const hark_row_pred *pred = nullptr,
+                   int stats_vk = -1, unsigned long long **mins_out = nullptr, unsigned long long **maxs_out = nullptr);
 
 int k_fgb_dense_stats(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cmp, float thr,
                       const int32_t *k, const void *v, int64_t n, int vk, bool *ran);

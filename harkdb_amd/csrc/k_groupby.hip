@@ -891,9 +891,61 @@ int try_hash(hark_context *ctx, const hark_table *db, const PredList &preds,
         hark_free(ctx, hk); hark_free(ctx, hv); hark_free(ctx, hc); hark_free(ctx, perm);
         return r;
     };
+    // ---- statistics pass: a column that needs two or more of {SUM/AVG, MIN, MAX} gets them (and COUNT) from ONE consumer pass
+    // over its pairs (fgb_agg_hash_stats_kernel) and ONE sort of the result keys, instead of a consumer pass and a sort each
+    auto cls = [](const DensePass &d) { return d.count_only ? 0 : (d.vop == 0 || d.vop == 5) ? 1 : d.vop == 2 ? 2 : d.vop == 3 ? 4 : 0; };
+    uint32_t rounds_stats = 0;
+    unsigned long long *ming = nullptr, *maxg = nullptr;
+    for (int64_t j = 0; j < n_aggs && !rc && ok; j++) {
+        if (done[j] || !cls(plan_of[j])) continue;
+        const int c = plan_of[j].col;
+        int classes = 0;
+        for (int64_t q = 0; q < n_aggs; q++) if (!done[q] && !plan_of[q].count_only && plan_of[q].col == c) classes |= cls(plan_of[q]);
+        if (__builtin_popcount(classes) < 2) continue;
+        const int dt = src->cols[c].dtype, vk = dt == HARK_F32 ? 0 : dt == HARK_I32 ? 1 : 2;
+        uint32_t *hk = nullptr, *perm = nullptr; unsigned long long *hv = nullptr, *hc = nullptr, *hmin = nullptr, *hmax = nullptr;
+        int64_t Gj = 0;
+        rc = k_fgb_hash_u32(ctx, keys, static_cast<const uint32_t *>(src->cols[c].data), src->n, 0, 0, &hk, &hv, &hc, &Gj, &ok, &rounds_stats, false, &part, nullptr,
+                            preds.n >= 1 ? &pred : nullptr, vk, &hmin, &hmax);
+        if (!rc && ok && Gj == 0) ok = false;
+        if (!rc && ok) {
+            if (G < 0) {
+                G = Gj; res->n = G;
+                res->cols.resize((size_t)n_aggs + 1);
+                res->cols[0].dtype = kdt;
+                rc = hark_alloc(ctx, &res->cols[0].data, (size_t)G * 4);
+                for (int64_t q = 0; q < n_aggs && !rc; q++) {
+                    res->cols[(size_t)q + 1].dtype = plan_of[q].out_dtype;
+                    rc = hark_alloc(ctx, &res->cols[(size_t)q + 1].data, (size_t)G * hark_dtype_size(plan_of[q].out_dtype));
+                }
+                if (!rc) rc = hark_alloc(ctx, (void **)&accg, (size_t)G * 8);
+                if (!rc) rc = hark_alloc(ctx, (void **)&cntg, (size_t)G * 8);
+            } else if (Gj != G) rc = hark_fail(ctx, HARK_EHIP, "filter_groupby: inconsistent group counts between passes");
+            if (!rc && !ming) rc = hark_alloc(ctx, (void **)&ming, (size_t)G * 8);
+            if (!rc && !maxg) rc = hark_alloc(ctx, (void **)&maxg, (size_t)G * 8);
+            if (!rc) rc = k_argsort_column(ctx, hk, kdt, G, false, &perm, nullptr);       // SQL order: signed for I32
+            if (!rc) {
+                rc = k_gather(ctx, hk, 4, perm, res->cols[0].data, G);
+                if (!rc) rc = k_gather(ctx, hv, 8, perm, accg, G);
+                if (!rc) rc = k_gather(ctx, hc, 8, perm, cntg, G);
+                if (!rc) rc = k_gather(ctx, hmin, 8, perm, ming, G);
+                if (!rc) rc = k_gather(ctx, hmax, 8, perm, maxg, G);
+            }
+            for (int64_t q = 0; q < n_aggs && !rc; q++) {
+                if (done[q]) continue;
+                const int kq = cls(plan_of[q]);
+                if (plan_of[q].count_only) rc = k_fgb_decode(ctx, accg, cntg, G, plan_of[q].kind, res->cols[(size_t)q + 1].data);
+                else if (kq && plan_of[q].col == c) rc = k_fgb_decode(ctx, kq == 1 ? accg : kq == 2 ? maxg : ming, cntg, G, plan_of[q].kind, res->cols[(size_t)q + 1].data);
+                else continue;
+                done[q] = 1;
+            }
+        }
+        hark_free(ctx, hk); hark_free(ctx, hv); hark_free(ctx, hc); hark_free(ctx, hmin); hark_free(ctx, hmax); hark_free(ctx, perm);
+    }
+    hark_free(ctx, ming); hark_free(ctx, maxg);
     std::vector<int64_t> order((size_t)n_aggs);
     for (int64_t j = 0; j < n_aggs; j++) order[(size_t)j] = j;
-    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) {      // ... so passes that can share one run back to back
+    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) {      // ... so passes that can share one partition run back to back
         return plan_of[a].col != plan_of[b].col ? plan_of[a].col < plan_of[b].col : plan_of[a].xf < plan_of[b].xf; });
     for (int64_t oi = 0; oi < n_aggs && !rc && ok; oi++) {
         const int64_t j = order[(size_t)oi];

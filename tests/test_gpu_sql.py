@@ -669,3 +669,32 @@ def test_and_lists_sparse_and_wide_keys(fc):
     _, cols = fc.sql_columns("select w, count(*), max(v) from t where p > 0.3 and k < 500 group by w")
     g = df[(df.p > 0.3) & (df.k < 500)].groupby("w").agg(c=("v", "size"), m=("v", "max"))
     assert np.array_equal(cols[0], g.index.to_numpy()) and np.array_equal(cols[1], g.c.to_numpy()) and np.array_equal(cols[2], g.m.to_numpy())
+
+
+@pytest.mark.parametrize("distinct", [40_000, 1_500_000])
+def test_sparse_keys_statistics_of_one_column_in_one_hash_pass(distinct):
+    """Sparse 32-bit keys: two or more of {SUM/AVG, MIN, MAX} of ONE column come from one pass over the column's hash
+    partition (fgb_agg_hash_stats_kernel) and one sort of the result keys -- f32, i32 and u32 value columns, a WHERE, and with
+    1.5e6 distinct keys more keys per bucket than one round of the statistics tables holds (two rounds there, one for the
+    single-aggregate tables).  pandas is the model; the path is asserted."""
+    from harkdb_amd import FutharkContext
+    c = FutharkContext()
+    rng = np.random.default_rng(distinct)
+    n = 3_000_000 if distinct > 1_000_000 else 500_000
+    pool = rng.choice(2**32, size=distinct, replace=False).astype(np.uint32).view(np.int32)
+    df = pd.DataFrame({"k": pool[rng.integers(0, len(pool), n)], "p": rng.random(n).astype(np.float32),
+                       "f": rng.integers(-50, 50, n).astype(np.float32), "i": rng.integers(-1000, 1000, n).astype(np.int32),
+                       "u": rng.integers(0, 4_000_000_000, n, dtype=np.int64).astype(np.uint32)})
+    c.create_table("s", df)
+    names, cols = c.sql_columns("select k, sum(f), min(f), max(f), avg(f), sum(i), max(i), min(u), max(u), sum(u), count(*) from s where p > 0.25 group by k")
+    assert c.FutEnv.last_groupby_path() == "hash"
+    g = df[df.p > 0.25].groupby("k")
+    assert np.array_equal(cols[0], np.asarray(g.f.sum().index)) and cols[0].dtype == np.int32
+    assert np.array_equal(cols[1], g.f.sum().to_numpy().astype(np.float32))               # integer-valued f32: exact in any order
+    assert np.array_equal(cols[2], g.f.min().to_numpy()) and np.array_equal(cols[3], g.f.max().to_numpy())
+    assert np.allclose(cols[4], g.f.mean().to_numpy(), rtol=1e-6)
+    assert np.array_equal(cols[5], g.i.sum().to_numpy()) and cols[5].dtype == np.int64
+    assert np.array_equal(cols[6], g.i.max().to_numpy())
+    assert np.array_equal(cols[7], g.u.min().to_numpy()) and np.array_equal(cols[8], g.u.max().to_numpy())
+    assert np.array_equal(cols[9], g.u.sum().to_numpy().astype(np.int64))
+    assert np.array_equal(cols[10], g.f.count().to_numpy())
