@@ -495,6 +495,12 @@ def extra_configs(torch, eng, dev, a, p, k, v, N):
                                   dense_keys_same_entry_ms=dense_ms, note="same rows, same entry (hark_entry_filter_groupby_and, result allocation and "
                                   "group-set read-out included in both); keys = dense key x 2654435761 mod 2^32 as i32")
     out["SPARSE_groupby"]["over_dense_same_entry"] = out["SPARSE_groupby"]["ms"] / dense_ms
+    # five aggregates of ONE column over the same sparse keys: one hash producer, one statistics consumer pass, one sort
+    ts = w["keep"][0]
+    five = [("sum", 2), ("max", 2), ("min", 2), ("avg", 2), ("count", 0)]
+    out["SPARSE_five_aggregates"] = timed({"run": lambda: eng.filter_groupby(ts, [(0, ">", 0.5)], 1, five), "bytes": lambda r: 12.0 * N + 28.0 * r.shape[0], "rows": N,
+                                           "info": {"statement": "SELECT k,SUM(v),MAX(v),MIN(v),AVG(v),COUNT(*) FROM t WHERE p>0.5 GROUP BY k -- the sparse keys of SPARSE_groupby",
+                                                    "groups": G}}, warm=1, reps=5, path=eng.last_groupby_path())
     td.free()
     del w, td
     torch.cuda.empty_cache()

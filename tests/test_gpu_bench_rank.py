@@ -79,7 +79,7 @@ def test_bench_extra_configs_at_a_small_scale():
     assert out.returncode == 0, out.stdout + out.stderr
     cfg = json.loads(out.stdout.strip().splitlines()[-1])["configs"]
     assert "error" not in cfg, cfg
-    for name in ("G16", "G4096", "G13000", "SWEEP_selectivity_x_groups", "SPARSE_groupby", "C2_filter_proj", "C1_projection", "REF_query_groupby_dense",
+    for name in ("G16", "G4096", "G13000", "SWEEP_selectivity_x_groups", "SPARSE_groupby", "SPARSE_five_aggregates", "C2_filter_proj", "C1_projection", "REF_query_groupby_dense",
                  "REF_query_groupby_hash", "ORDER_BY", "ORDER_BY_32bit", "ORDER_BY_i64", "REF_join_u32", "C4_join_share", "C5_pipeline_share",
                  "C5_three_aggregates", "C5_three_aggregates_all_groups"):
         assert name in cfg, name
