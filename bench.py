@@ -500,7 +500,8 @@ def extra_configs(torch, eng, dev, a, p, k, v, N):
     five = [("sum", 2), ("max", 2), ("min", 2), ("avg", 2), ("count", 0)]
     out["SPARSE_five_aggregates"] = timed({"run": lambda: eng.filter_groupby(ts, [(0, ">", 0.5)], 1, five), "bytes": lambda r: 12.0 * N + 28.0 * r.shape[0], "rows": N,
                                            "info": {"statement": "SELECT k,SUM(v),MAX(v),MIN(v),AVG(v),COUNT(*) FROM t WHERE p>0.5 GROUP BY k -- the sparse keys of SPARSE_groupby",
-                                                    "groups": G}}, warm=1, reps=5, path=eng.last_groupby_path())
+                                                    "groups": G}}, warm=1, reps=5)
+    out["SPARSE_five_aggregates"]["path"] = eng.last_groupby_path()
     td.free()
     del w, td
     torch.cuda.empty_cache()
