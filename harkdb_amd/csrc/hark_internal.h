@@ -208,11 +208,16 @@ __device__ __forceinline__ void st_hidden_b64(void *p, uint2 v)
     const unsigned long long w = ((unsigned long long)v.y << 32) | v.x;
     asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(p), "v"(w) : "memory");
 }
+// (A store of MORE than 64 bits reads its data registers a few cycles after it issues: the ISA asks for wait states before a
+// VALU instruction overwrites them.  The compiler's hazard recognizer inserts them for stores it knows; it cannot see into
+// an asm statement, so the s_nop is part of it -- found the hard way in round 4: a 16-byte record store followed by the
+// address arithmetic of the next store, which the register allocator had placed in the record's last two registers, wrote
+// two address words into the record.)
 __device__ __forceinline__ void st_hidden_nt_b128(void *p, uint4 v)
 {
     typedef unsigned int u4v __attribute__((ext_vector_type(4)));
     const u4v w = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(p), "v"(w) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" :: "v"(p), "v"(w) : "memory");
 }
 
 // Loads with hand-placed waits, for software pipelines the compiler's bookkeeping cannot follow (it falls back to

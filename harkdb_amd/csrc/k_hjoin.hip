@@ -40,6 +40,13 @@ int k_sort_column(hark_context *ctx, const void *col, int dtype, int64_t n, bool
 
 namespace {
 
+__device__ __forceinline__ void st_hidden_b128(void *p, uint4 v)          // (see st_hidden_nt_b128 in hark_internal.h: the s_nop is part of it)
+{
+    typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+    const u4v w = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(p), "v"(w) : "memory");
+}
+
 constexpr int kJThreads = 1024;
 constexpr int kJErrOverflow = 100;
 constexpr int kJIdx = 2048;                               // entries of the bucket kernel's radix index over a round's keys
@@ -349,9 +356,10 @@ __global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTrai
                                                             int chunk_cap, uint2 *__restrict__ surv, size_t region /* survivor entries per bucket */,
                                                             uint32_t *__restrict__ scount /* [P] survivors of the bucket */,
                                                             uint32_t *__restrict__ sbins /* [P][kMaxBins] survivors in every bin */,
-                                                            uint32_t *__restrict__ sval /* may be null: the entries' fourth word of every survivor (same index as surv) */,
-                                                            uint32_t *__restrict__ skey /* 64-bit keys: the low word of every survivor's PROBE key (same index): a hit on a
-                                                                                           truncated build key is confirmed by the order kernel, where the build keys are read in order */,
+                                                            uint4 *__restrict__ srec /* 64-bit keys (16-byte entries): every survivor as ONE record (rank, left row, the entry's
+                                                                                        fourth word, low word of the PROBE key -- a hit on a truncated build key is confirmed by the
+                                                                                        order kernel, where the build keys are read in order) instead of `surv` ... */,
+                                                            uint32_t *__restrict__ srank /* ... and its rank alone beside it: what the order kernel's histogram sweep reads */,
                                                             uint32_t *__restrict__ scoarse /* [P][kCoarse] survivors per group of ranks: the order kernel's first histogram */,
                                                             int stage_cap /* the order kernel's stage (sizes the bins) */, int32_t *__restrict__ err,
                                                             int allow_trunc)
@@ -397,9 +405,9 @@ __global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTrai
     const JBins bins = jbins_of(hi - lo, s_np, stage_cap, region);       // the order kernel's grouping of this bucket's ranks and its bins
     const int gs = bins.gs, bs = bins.bs;
     const uint32_t bincap = bins.cap;
-    uint2 *out = surv + (size_t)b * region;
-    uint32_t *vout = sval ? sval + (size_t)b * region : nullptr;
-    uint32_t *kout = skey ? skey + (size_t)b * region : nullptr;
+    uint2 *out = surv ? surv + (size_t)b * region : nullptr;            // 8-byte entries (32-bit keys)
+    uint4 *rout = srec ? srec + (size_t)b * region : nullptr;
+    uint32_t *kout = srank ? srank + (size_t)b * region : nullptr;
     bool bin_full = false;
     const unsigned long long below = (1ull << lane) - 1ull;
     // 64-bit keys: a bucket of up to two chunks of build keys (BASELINE configs[3]: 24.4 K against 12 K per 96-KiB chunk)
@@ -407,7 +415,7 @@ __global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTrai
     // (key - first key) >> ts, twice as many, and the search runs on those.  Exact among the build keys as long as equal
     // truncated keys are equal keys -- checked when they are loaded; a bucket that fails the check (keys clustered below bit
     // ts) takes the rounds as before.  A PROBE key can still share its truncation with a build key it differs from in the
-    // ts dropped bits: every survivor therefore carries its probe key's low word (skey), and the order kernel compares it
+    // ts dropped bits: every survivor therefore carries its probe key's low word (srec), and the order kernel compares it
     // with the build key of the survivor's rank when it writes the rows out in rank order -- reads that walk the sorted
     // keys front to back.  (Round 3 confirmed every hit here, against the key in memory: 7e7 random 4-byte reads, 0.31 ms of
     // the kernel's 0.99.)  A mismatch anywhere makes the host run the join again without truncated rounds.
@@ -476,9 +484,10 @@ __global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTrai
                 const uint32_t at = atomicAdd(&s_bincur[bin], 1u);
                 if (at < bincap) {
                     const size_t o = (size_t)bin * bincap + at;
-                    st_hidden_b64(out + o, uint2{base + pos, row});
-                    if (sizeof(E) == 16 && vout) st_hidden_b32(vout + o, val);
-                    if (sizeof(E) == 16 && kout) st_hidden_b32(kout + o, klow);
+                    if (sizeof(E) == 16) {                                 // one 16-byte record + the rank alone: two stores per hit (three arrays of
+                        st_hidden_b128(rout + o, uint4{base + pos, row, val, klow});   // 8 + 4 + 4 bytes before: a third of the kernel was its ~36 short store
+                        st_hidden_b32(kout + o, base + pos);               // segments per wave step, profiles/r04_notes.md 9)
+                    } else st_hidden_b64(out + o, uint2{base + pos, row});
                     atomicAdd(&s_coarse[r >> gs], 1u);
                 } else bin_full = true;                                // probe keys crowd a few ranks: the caller takes another path
             }
@@ -623,11 +632,12 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
                                                            const uint32_t *__restrict__ bstart, int P, const uint32_t *__restrict__ runlen,
                                                            uint32_t *__restrict__ rank, uint32_t *__restrict__ lrow, uint32_t *__restrict__ cnt_out /* may be null */,
                                                            int stage_cap /* <= kStage / kStageCarry (tests: smaller) */, int32_t *__restrict__ general,
-                                                           const uint32_t *__restrict__ sval, uint32_t *__restrict__ lval_out,
+                                                           uint32_t *__restrict__ lval_out,
                                                            const uint32_t *__restrict__ scoarse,
                                                            const uint32_t *__restrict__ rranked /* may be null: a build-side column in rank order ... */,
                                                            uint32_t *__restrict__ rval_out /* ... read off for every survivor (unique build keys: survivor = output row) */,
-                                                           const uint32_t *__restrict__ skey /* VERIFY: the survivors' probe-key low words */,
+                                                           const uint4 *__restrict__ srec /* VERIFY (64-bit keys): the survivors as records (rank, left row, carried word, probe-key low word) ... */,
+                                                           const uint32_t *__restrict__ srank /* ... and their ranks alone (`surv` is not used then) */,
                                                            const uint64_t *__restrict__ rkeys64 /* VERIFY: the sorted build keys */)
 {
     constexpr int XW = (CARRY ? 1 : 0) + (VERIFY ? 1 : 0), STAGE = stage_of(XW), FINE = fine_of(XW);
@@ -660,9 +670,10 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
     __syncthreads();
     const JBins bins = jbins_of(len, s_np, stage_cap, region);
     const int gs = bins.gs, kb = bins.bs - bins.gs;                            // a bin = 2^kb consecutive groups
-    const uint2 *src = surv + (size_t)b * region;
-    const uint32_t *srcv = CARRY ? sval + (size_t)b * region : nullptr;
-    const uint32_t *srck = VERIFY ? skey + (size_t)b * region : nullptr;
+    const uint2 *src = VERIFY ? nullptr : surv + (size_t)b * region;
+    const uint4 *srcr = VERIFY ? srec + (size_t)b * region : nullptr;
+    const uint32_t *srck = VERIFY ? srank + (size_t)b * region : nullptr;
+    static_assert(VERIFY || !CARRY, "a carried column travels in the 16-byte records of the 64-bit path");
     bool mismatch = false;
     const uint32_t ngroups = (len + (1u << gs) - 1u) >> gs;
     for (uint32_t i = tid; i <= ngroups; i += kJThreads) coarse[i] = i < ngroups ? scoarse[(size_t)b * kCoarse + i] : 0u;   // counted by the bucket kernel
@@ -671,25 +682,32 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
     if (nb == 0) return;
     // every pass over survivors keeps 8 loads per lane in flight: one workgroup owns the CU, and with a single load per
     // lane the passes ran at the latency of a load, not at the CU's share of the bandwidth.  f(entry, third word)
-    auto sweep = [&](const uint2 *sp, const uint32_t *spv, const uint32_t *spk, uint32_t i1, bool want_v, auto &&f) {
+    // f(entry (rank, left row), third word, probe-key low word).  ranks_only: the histogram sweep (8-byte entries: the entries
+    // themselves; records: the rank array beside them, a quarter of the bytes)
+    auto sweep = [&](size_t off, uint32_t i1, bool ranks_only, auto &&f) {
         uint32_t i = tid;
         for (; i + 7u * kJThreads < i1; i += 8u * kJThreads) {
             uint2 e[8]; uint32_t v[8], kl[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                e[k] = sp[i + (uint32_t)k * kJThreads];
-                v[k] = (CARRY && want_v) ? spv[i + (uint32_t)k * kJThreads] : 0u;
-                kl[k] = (VERIFY && want_v) ? spk[i + (uint32_t)k * kJThreads] : 0u;
+                const size_t at = off + i + (uint32_t)k * kJThreads;
+                if (!VERIFY) { e[k] = src[at]; v[k] = 0u; kl[k] = 0u; }
+                else if (ranks_only) { e[k] = uint2{srck[at], 0u}; v[k] = 0u; kl[k] = 0u; }
+                else { const uint4 q = srcr[at]; e[k] = uint2{q.x, q.y}; v[k] = q.z; kl[k] = q.w; }
             }
 #pragma unroll
             for (int k = 0; k < 8; k++) f(e[k], v[k], kl[k]);
         }
-        for (; i < i1; i += kJThreads) f(sp[i], (CARRY && want_v) ? spv[i] : 0u, (VERIFY && want_v) ? spk[i] : 0u);
+        for (; i < i1; i += kJThreads) {
+            const size_t at = off + i;
+            if (!VERIFY) f(src[at], 0u, 0u);
+            else if (ranks_only) f(uint2{srck[at], 0u}, 0u, 0u);
+            else { const uint4 q = srcr[at]; f(uint2{q.x, q.y}, q.z, q.w); }
+        }
     };
     // the bins that hold the ranks of groups [g0, g1)
-    auto sweep_bins = [&](uint32_t g0, uint32_t g1, bool want_v, auto &&f) {
-        for (uint32_t j = g0 >> kb; j <= (g1 - 1u) >> kb; j++)
-            sweep(src + (size_t)j * bins.cap, CARRY ? srcv + (size_t)j * bins.cap : nullptr, VERIFY ? srck + (size_t)j * bins.cap : nullptr, s_bincnt[j], want_v, f);
+    auto sweep_bins = [&](uint32_t g0, uint32_t g1, bool ranks_only, auto &&f) {
+        for (uint32_t j = g0 >> kb; j <= (g1 - 1u) >> kb; j++) sweep((size_t)j * bins.cap, s_bincnt[j], ranks_only, f);
     };
     // block-wide exclusive scan helper over a[0, m): a contiguous segment per thread, waves chained through LDS;
     // returns the total
@@ -721,14 +739,15 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
     if (bad) {                                                         // bin after bin, as they are
         for (uint32_t j = 0; j < (uint32_t)bins.nb; j++) {
             const unsigned long long o = dst + coarse[min(ngroups, j << kb)];      // the survivors of the bins before bin j
-            const uint2 *sp = src + (size_t)j * bins.cap;
             for (uint32_t i = tid; i < s_bincnt[j]; i += kJThreads) {
-                const uint2 e = sp[i];
+                const size_t at = (size_t)j * bins.cap + i;
+                const uint4 q = VERIFY ? srcr[at] : uint4{src[at].x, src[at].y, 0u, 0u};
+                const uint2 e = uint2{q.x, q.y};
                 if (rank) { rank[o + i] = e.x; lrow[o + i] = e.y; }    // (the general sort needs them: the host runs the kernel again with the arrays if it left them out)
                 if (cnt_out) cnt_out[o + i] = runlen[e.x];
-                if (CARRY) lval_out[o + i] = srcv[(size_t)j * bins.cap + i];   // (the caller drops the carried words on the general path)
+                if (CARRY) lval_out[o + i] = q.z;                      // (the caller drops the carried words on the general path)
                 if (rranked) rval_out[o + i] = rranked[e.x];
-                if (VERIFY && (uint32_t)rkeys64[e.x] != srck[(size_t)j * bins.cap + i]) mismatch = true;
+                if (VERIFY && (uint32_t)rkeys64[e.x] != q.w) mismatch = true;
             }
         }
         if (tid == 0) *general = 1;
@@ -754,10 +773,10 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
         if (nsub) {
             for (uint32_t i = tid; i <= nr; i += kJThreads) fine[i] = 0u;
             __syncthreads();
-            sweep_bins(g0, g1, false, [&](uint2 e, uint32_t, uint32_t) { const uint32_t r = e.x - lo - r0; if (r < nr) atomicAdd(&fine[r], 1u); });
+            sweep_bins(g0, g1, true, [&](uint2 e, uint32_t, uint32_t) { const uint32_t r = e.x - lo - r0; if (r < nr) atomicAdd(&fine[r], 1u); });
             __syncthreads();
             scan_excl(fine, nr);
-            sweep_bins(g0, g1, true, [&](uint2 e, uint32_t v, uint32_t kl) {
+            sweep_bins(g0, g1, false, [&](uint2 e, uint32_t v, uint32_t kl) {
                 const uint32_t r = e.x - lo - r0;
                 if (r < nr) { const uint32_t at = atomicAdd(&fine[r], 1u); stage[at] = e; if (CARRY) stv[at] = v; if (VERIFY) stk[at] = kl; }   // afterwards fine[r] = end of rank r's rows
             });
@@ -819,7 +838,7 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
 __global__ __launch_bounds__(256) void jcompact_kernel(const uint2 *__restrict__ surv, size_t region, const uint32_t *__restrict__ scount,
                                                        const uint32_t *__restrict__ sbins, const uint32_t *__restrict__ counts, uint32_t cap, int nwg,
                                                        const uint32_t *__restrict__ bstart, int stage_cap, uint32_t *__restrict__ rank, uint32_t *__restrict__ lrow,
-                                                       const uint32_t *__restrict__ skey /* may be null */, const uint64_t *__restrict__ rkeys64, int32_t *__restrict__ flags)
+                                                       const uint4 *__restrict__ srec /* 64-bit keys: the survivors as records (then `surv` is null) */, const uint64_t *__restrict__ rkeys64, int32_t *__restrict__ flags)
 {
     __shared__ unsigned long long s_dst;
     __shared__ uint32_t s_np, s_off[kMaxBins + 1];
@@ -840,11 +859,12 @@ __global__ __launch_bounds__(256) void jcompact_kernel(const uint2 *__restrict__
     __syncthreads();
     const unsigned long long dst = s_dst;
     for (int j = 0; j < bins.nb; j++) {
-        const uint2 *src = surv + (size_t)b * region + (size_t)j * bins.cap;
+        const size_t at0 = (size_t)b * region + (size_t)j * bins.cap;
         const uint32_t cnt = s_off[j + 1] - s_off[j];
         for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
-            const uint2 e = src[i]; rank[dst + s_off[j] + i] = e.x; lrow[dst + s_off[j] + i] = e.y;
-            if (skey && (uint32_t)rkeys64[e.x] != skey[(size_t)b * region + (size_t)j * bins.cap + i]) flags[2] = 1;   // a hit on a truncated key that is not one
+            const uint4 q = srec ? srec[at0 + i] : uint4{surv[at0 + i].x, surv[at0 + i].y, 0u, 0u};
+            rank[dst + s_off[j] + i] = q.x; lrow[dst + s_off[j] + i] = q.y;
+            if (srec && (uint32_t)rkeys64[q.x] != q.w) flags[2] = 1;       // a hit on a truncated key that is not one
         }
     }
 }
@@ -869,7 +889,8 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
     K *splitters = nullptr; uint32_t *bstart = nullptr, *counts = nullptr, *scount = nullptr, *sbins = nullptr;
     int64_t *info = nullptr;                                                     // [0] survivors (u64), [1] error word of the partition
     E *slabs = nullptr; uint2 *surv = nullptr;
-    uint32_t *rank = nullptr, *lrow = nullptr, *cnt = nullptr, *sval = nullptr, *skey = nullptr, *lv = nullptr, *rv = nullptr;
+    uint32_t *rank = nullptr, *lrow = nullptr, *cnt = nullptr, *srank = nullptr, *lv = nullptr, *rv = nullptr;
+    uint4 *srec = nullptr;
     const bool carry = lval != nullptr && sizeof(E) == 16;                      // the fourth word of the 16-byte entries
     const bool verify = sizeof(K) == 8;                                          // survivors carry their probe key's low word to the order kernel
     if (getenv("HARK_JOIN_NOTRUNC")) allow_trunc = false;
@@ -885,14 +906,14 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
     if (!rc) rc = hark_alloc(ctx, (void **)&sbins, 4 * (size_t)P * kMaxBins);
     if (!rc) rc = hark_alloc(ctx, (void **)&info, 32);
     if (!rc) rc = hark_alloc(ctx, (void **)&slabs, sizeof(E) * (size_t)P * sstride);
-    if (!rc) rc = hark_alloc(ctx, (void **)&surv, 8 * (size_t)P * region);
-    if (!rc && carry) rc = hark_alloc(ctx, (void **)&sval, 4 * (size_t)P * region);
-    if (!rc && verify) rc = hark_alloc(ctx, (void **)&skey, 4 * (size_t)P * region);
+    if (!rc && !verify) rc = hark_alloc(ctx, (void **)&surv, 8 * (size_t)P * region);          // 32-bit keys: (rank, left row)
+    if (!rc && verify) rc = hark_alloc(ctx, (void **)&srec, 16 * (size_t)P * region);          // 64-bit keys: records + their ranks alone
+    if (!rc && verify) rc = hark_alloc(ctx, (void **)&srank, 4 * (size_t)P * region);
     uint32_t *scoarse = nullptr;
     if (!rc) rc = hark_alloc(ctx, (void **)&scoarse, 4 * (size_t)P * kCoarse);
     auto cleanup = [&]() {
         hark_free(ctx, splitters); hark_free(ctx, bstart); hark_free(ctx, counts); hark_free(ctx, scount); hark_free(ctx, sbins);
-        hark_free(ctx, info); hark_free(ctx, slabs); hark_free(ctx, surv); hark_free(ctx, sval); hark_free(ctx, skey); hark_free(ctx, scoarse);
+        hark_free(ctx, info); hark_free(ctx, slabs); hark_free(ctx, surv); hark_free(ctx, srec); hark_free(ctx, srank); hark_free(ctx, scoarse);
     };
     if (rc == HARK_ENOMEM) {                                                     // no room for the partition workspace: the sort-merge path
         cleanup();                                                               // needs far less (used stays false)
@@ -926,7 +947,7 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
         // one stream-ordered chain, one host read at the end: partition -> bucket probe -> survivor total
         if (plain_loads) jpart_kernel<K, false><<<dim3((unsigned)nwg), dim3(kJThreads), lds_part, st>>>(lcol, n, bias, splitters, rkeys, s, slabs, counts, cap, period, err, carry ? lval : nullptr);
         else jpart_kernel<K, true><<<dim3((unsigned)nwg), dim3(kJThreads), lds_part, st>>>(lcol, n, bias, splitters, rkeys, s, slabs, counts, cap, period, err, carry ? lval : nullptr);
-        jbucket_kernel<K><<<dim3((unsigned)P), dim3(kJThreads), lds_bucket, st>>>(slabs, counts, cap, nwg, rkeys, bstart, chunk_cap, surv, region, scount, sbins, sval, skey, scoarse, stage_cap, err, allow_trunc ? 1 : 0);
+        jbucket_kernel<K><<<dim3((unsigned)P), dim3(kJThreads), lds_bucket, st>>>(slabs, counts, cap, nwg, rkeys, bstart, chunk_cap, surv, region, scount, sbins, srec, srank, scoarse, stage_cap, err, allow_trunc ? 1 : 0);
         jsum_kernel<<<1, 1024, 0, st>>>(scount, P, total);
         he = hipGetLastError();
         if (he == hipSuccess) he = hipMemcpyAsync(info + 2, flags, 8, hipMemcpyDeviceToDevice, st);   // the duplicate-keys flag rides along with the same host read
@@ -953,7 +974,7 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
         for (int attempt = 0; attempt < 2 && !rc; attempt++) {
             const uint64_t *rk64 = reinterpret_cast<const uint64_t *>(rkeys);
             if (getenv("HARK_JOIN_FULLSORT")) {                                  // A/B + tests: plain compaction, radix sorts by the caller
-                jcompact_kernel<<<dim3((unsigned)P), 256, 0, st>>>(surv, region, scount, sbins, counts, cap, nwg, bstart, stage_cap, rank, lrow, skey, rk64, flags);
+                jcompact_kernel<<<dim3((unsigned)P), 256, 0, st>>>(surv, region, scount, sbins, counts, cap, nwg, bstart, stage_cap, rank, lrow, srec, rk64, flags);
                 hipMemsetAsync(flags, 1, 1, st);
             } else {
                 const size_t lds_order = (size_t)stage_of(xw) * (8 + 4 * (size_t)xw) + (size_t)(fine_of(xw) + 1) * 4 + (size_t)(kCoarse + 1) * 4;
@@ -962,12 +983,12 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
                     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&jorder_kernel<C, V>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_order);
                     if (e != hipSuccess) return e;
                     jorder_kernel<C, V><<<dim3((unsigned)P), dim3(kJThreads), lds_order, st>>>(surv, region, scount, sbins, counts, cap, nwg, bstart, P, runlen,
-                                                                                             rank, lrow, cnt, stage_cap, flags, C ? sval : nullptr, C ? lv : nullptr, scoarse, rranked, rv,
-                                                                                             V ? skey : nullptr, V ? rk64 : nullptr);
+                                                                                             rank, lrow, cnt, stage_cap, flags, C ? lv : nullptr, scoarse, rranked, rv,
+                                                                                             V ? srec : nullptr, V ? srank : nullptr, V ? rk64 : nullptr);
                     return hipSuccess;
                 };
-                he = carry ? (verify ? launch(std::true_type{}, std::true_type{}) : launch(std::true_type{}, std::false_type{}))
-                           : (verify ? launch(std::false_type{}, std::true_type{}) : launch(std::false_type{}, std::false_type{}));
+                he = verify ? (carry ? launch(std::true_type{}, std::true_type{}) : launch(std::false_type{}, std::true_type{}))
+                            : launch(std::false_type{}, std::false_type{});             // (a carried column exists on the 64-bit path only)
             }
             if (he != hipSuccess || hipGetLastError() != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: order launch failed");
             // does the order stand, or do the survivors need the general sort (skew)?  Read here, while the survivors are alive:
