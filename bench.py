@@ -611,18 +611,57 @@ def main():
         knobs["algo"] = a.algo
     if a.chunk_rows:
         knobs["chunk_rows"] = a.chunk_rows
-    # With peers, the producer leaves a few CUs to RCCL: its 256 workgroups of 1024 threads otherwise hold every CU for the
-    # whole 2.5 ms, and the all-reduce of the previous step (pipelined mode) could only start in the producer's tail.
-    # 240 of 256 is a choice made WITHOUT multi-GPU hardware; HARK_PRODUCER_WGS overrides it (0 = all CUs).
-    producer_wgs = int(os.environ.get("HARK_PRODUCER_WGS", "240" if world > 1 else "0"))
-    if producer_wgs > 0:
-        knobs["grid"] = producer_wgs
-    plan = FgbPlan(eng, N, G, **knobs)
+    # With peers, the producer may leave a few CUs to RCCL: its 256 workgroups of 1024 threads otherwise hold every CU for the
+    # whole 2.5 ms, and the all-reduce of the previous step (pipelined mode) could only start in the producer's tail.  How
+    # many (and whether pipelining two plans pays at all) depends on hardware this code was never run on with peers, so it is
+    # MEASURED at start-up, before the warm-up steps: a few steps of each candidate, the slowest rank's time decides, every
+    # rank takes the same choice.  HARK_PRODUCER_WGS (0 = all CUs) / HARK_OVERLAP=0|1 pin the choice instead.
+    multi = world > 1 or bool(os.environ.get("HARK_FORCE_PIPELINE"))
+
+    def make_job(wgs, overlap):
+        kn = dict(knobs)
+        if wgs > 0:
+            kn["grid"] = wgs
+        pl = FgbPlan(eng, N, G, **kn)
+        pl2 = FgbPlan(eng, N, G, **kn) if overlap else None
+        return pl, pl2, hd.ShardedFgb(eng, pl, dev, plan2=pl2)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist.is_initialized():
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    tuned = None
+    if multi and "HARK_PRODUCER_WGS" not in os.environ and "HARK_OVERLAP" not in os.environ:
+        tuned = {}
+        for wgs, overlap in ((240, True), (0, True), (0, False)):
+            pl, pl2, jb = make_job(wgs, overlap)
+            for timed_steps in (2, 6):                        # 2 untimed, then 6 timed
+                sync_all()
+                t0 = time.perf_counter()
+                for _ in range(timed_steps):
+                    jb.step(p.data_ptr(), ">", 0.5, k.data_ptr(), v.data_ptr(), N, sum_out.data_ptr(), cnt_out.data_ptr(), check=False)
+                jb.flush()
+                sync_all()
+                dt = time.perf_counter() - t0
+            tt = torch.tensor([dt / 6 * 1e3], dtype=torch.float64, device=dev)
+            if dist.is_initialized():
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)     # the same number on every rank: the same choice on every rank
+            tuned[("%d workgroups" % wgs if wgs else "all CUs") + (", pipelined" if overlap else ", serial")] = (float(tt.item()), wgs, overlap)
+            del jb
+            pl.free()
+            if pl2 is not None:
+                pl2.free()
+        producer_wgs, overlap = min(tuned.values())[1:]
+        tuned = {kk: vv[0] for kk, vv in tuned.items()}
+    else:
+        producer_wgs = int(os.environ.get("HARK_PRODUCER_WGS", "240" if world > 1 else "0"))
+        overlap = multi and os.environ.get("HARK_OVERLAP", "1") != "0"
     # N > 1: a second plan lets step i's all-reduce run on RCCL's stream beside the kernels of step i+1 (dist.ShardedFgb)
     # (HARK_FORCE_PIPELINE=1: also with one rank -- tests/test_gpu_bench_rank.py runs the pipelined, asynchronous
-    # all-reduce path under RCCL on the one GPU a test box has)
-    plan2 = FgbPlan(eng, N, G, **knobs) if (world > 1 or os.environ.get("HARK_FORCE_PIPELINE")) and os.environ.get("HARK_OVERLAP", "1") != "0" else None
-    job = hd.ShardedFgb(eng, plan, dev, plan2=plan2)
+    # all-reduce path and the start-up measurement under RCCL on the one GPU a test box has)
+    plan, plan2, job = make_job(producer_wgs, overlap)
 
     def step():
         # check=False: no host round trip inside the loop; job.flush() reads the sticky error words after the last step
@@ -757,7 +796,8 @@ def main():
                        "merge": ("RCCL " + ("reduce-scatter + all-gather" if os.environ.get("HARK_ALLREDUCE") == "rs_ag" else "all-reduce")
                                  + " of f64 sums + i64 counts" + (", overlapped with the next step's kernels" if plan2 is not None else "")) if dist.is_initialized() else "none",
                        "pipelined_steps": plan2 is not None, "producer_workgroups": producer_wgs or "all CUs",
-                       "allreduce": os.environ.get("HARK_ALLREDUCE", "allreduce"), "overlap": os.environ.get("HARK_OVERLAP", "1") != "0"},
+                       "allreduce": os.environ.get("HARK_ALLREDUCE", "allreduce"), "overlap": bool(overlap),
+                       "measured_at_startup_ms_per_step": tuned},
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": path_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": path_achieved / HBM_PEAK_GBS,
                          "frac_is": "whole path per GPU: (12 B/row x rows + 16 B x groups) / wall time of a step / 8 TB/s",
