@@ -560,7 +560,8 @@ def extra_configs(torch, eng, dev, a, p, k, v, N):
     out["C5_three_aggregates"]["note"] += ("; max(c7) and min(c9) are computed for the LIMIT surviving groups only (late aggregation: "
                                            "hark_entry_filter_groupby_subset, harkdb_amd/context.py; HARK_NO_LATE_AGG=1 switches it off)")
     # the same three aggregates for EVERY group, result left on the device (no HAVING / ORDER BY / LIMIT, no download):
-    # what several aggregates cost in general -- one pair pass (sum(c3) + max(c7)) and one single pass (min(c9))
+    # what several aggregates cost in general -- ONE triple pass (sum(c3), max(c7), min(c9): 14-byte entries; round 3: a pair
+    # pass + a single pass)
     dev_t = fc.tables["t"]._device
 
     def c5g():
@@ -569,9 +570,11 @@ def extra_configs(torch, eng, dev, a, p, k, v, N):
         r.free()
 
     ms = event_ms(torch, c5g, warm=2, reps=5)
+    passes = eng.last_groupby_passes()
     out["C5_three_aggregates_all_groups"] = entry(ms, 4.0 * 5 * n5 + 24.0 * (1 << 20), n5, referenced_columns=5, result_rows=int(shape[0][0]),
                                                   statement="select k, sum(c3), max(c7), min(c9), count(*) from t where c1 > 0.5 group by k  (device result)",
-                                                  note="hark_entry_filter_groupby: pair pass (sum(c3) + max(c7)) + single pass (min(c9))")
+                                                  passes_over_the_rows=passes,
+                                                  note="hark_entry_filter_groupby: one triple pass (k_fgb_dense_multi); HARK_NO_TRIPLE_PASS=1: pair pass (sum(c3) + max(c7)) + single pass (min(c9))")
     fc.drop_table("t")
     del c5, key
     torch.cuda.empty_cache()

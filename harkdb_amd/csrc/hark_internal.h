@@ -35,6 +35,7 @@ struct hark_context {
     size_t pool_cached = 0, pool_limit = (size_t)64 << 30;
     // diagnostic: which GROUP BY path served the last group-by entry (hark_context_last_groupby_path)
     int last_groupby_path = 0;
+    int last_groupby_passes = 0;             // row passes of the last dense-path filter_groupby (hark_context_last_groupby_passes)
     int last_join_path = 0;        // hark_context_last_join_path
 };
 
@@ -169,6 +170,8 @@ int hark_fgb_finish_u32_second(hark_context *ctx, hark_fgb_plan *pl, uint32_t *v
 int hark_fgb_finish_u32_of(hark_context *ctx, hark_fgb_plan *pl, int which, uint32_t *val_out);
 int k_fgb_dense_pair(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cmp, float thr, const int32_t *k,
                      const void *v1, int vop1, int xf1, const void *v2, int vop2, int xf2, int64_t n, bool *ran);
+int k_fgb_dense_multi(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cmp, float thr, const int32_t *k,
+                      const void *v1, int vop1, int xf1, const void *v2, int vop2, int xf2, const void *v3, int vop3, int xf3, int64_t n, bool *ran);
 int k_fgb_decode(hark_context *ctx, const unsigned long long *acc, const unsigned long long *cnt, int64_t G, int kind, void *out);
 
 // k_select.hip

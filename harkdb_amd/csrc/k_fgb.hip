@@ -1062,54 +1062,64 @@ __global__ __launch_bounds__(1024) void fgb_agg6_stats_kernel(
 }
 
 // ---------------------------------------------------------------------------
-// Two aggregates of two DIFFERENT columns in one pass ("pair pass")
+// Two or three aggregates of DIFFERENT columns in one pass ("pair pass", "triple pass")
 // ---------------------------------------------------------------------------
 // One producer + consumer pass per (operator, column) re-reads the predicate and key columns every time
-// (BASELINE configs[4] with three aggregates: three passes).  Here a pair carries the raw 32 bits of TWO value columns:
-// 10 bytes (value 1, value 2, 16-bit bucket-local key), units of 64 pairs = 256 B + 256 B + 128 B (five whole lines), in
-// HALF as many buckets as the one-value passes use (<= 128 buckets of <= 8192 keys): rings of 112 pairs (a unit + 48 of
-// headroom) are 140 KiB of LDS.  (A first version with 256 buckets, units of 32 pairs = 2.5 lines and 24 pairs of
-// headroom ran at 2.44 ms per 5e8 rows against 1.47 ms for a one-value pass: twice the sweeps, half-line stores, rings
-// overflowing.)  Three values do not fit at all: 128 rings of 14-byte pairs are 172 KiB.  The consumer keeps 16 B per
-// key -- a 64-bit slot for value 1 (any operator), the row count, and a 32-bit slot for value 2, which therefore must be
-// a MAX or MIN (order words) -- 128 KiB for 8192 keys, and TWO workgroups share a bucket (even / odd slabs) so that all
-// 256 CUs work; they merge into the global table with contiguous atomics.
-// Like the statistics pass this one has no single-row fallback: skew that overflows a ring or a slab reports
+// (BASELINE configs[4] with three aggregates: three passes).  Here an entry carries the raw 32 bits of NV = 2 or 3 value
+// columns and a 16-bit bucket-local key: 10 or 14 bytes, units of 64 entries = NV x 256 B + 128 B (whole lines), in
+// HALF as many buckets as the one-value passes use (<= 128 buckets of <= 8192 keys).  Pairs: rings of 112 entries (a unit
+// + 48 of headroom) are 140 KiB of LDS, swept every other batch.  (A first version with 256 buckets, units of 32 pairs =
+// 2.5 lines and 24 pairs of headroom ran at 2.44 ms per 5e8 rows against 1.47 ms for a one-value pass: twice the sweeps,
+// half-line stores, rings overflowing.)  Triples: 128 rings of 14-byte entries leave 88 entries per ring (154 KiB) -- a
+// unit + 24 of headroom for the ~16 arrivals of a batch at 50 % selectivity: swept after EVERY batch, and ~7 % of the
+// batches see some ring overflow and take a second round.
+// The consumer keeps per key a 64-bit slot for value 1 (any operator), the row count, and a 32-bit slot for each further
+// value, which therefore must be a MAX or MIN (order words; a MIN is kept as the MAX of the inverted word, so the kernels
+// are instantiated per operator of value 1 only) -- 16 B x 8192 keys = 128 KiB, or 20 B x 8192 = ALL 160 KiB of a CU
+// for triples (a workgroup may allocate exactly that on gfx950; checked with a probe) -- and TWO workgroups share a
+// bucket (even / odd slabs) so that all 256 CUs work; they merge into the global table with contiguous atomics.
+// Like the statistics pass these have no single-row fallback: skew that overflows a ring or a slab reports
 // kErrOverflow and the caller runs the separate passes.
-constexpr int kU10 = 64;                                 // pairs per unit
-constexpr int kUnit10Bytes = kU10 * 10;                  // 640
-constexpr int kQ10 = 112;                                // ring capacity per bucket (pairs): a unit + 48 of headroom; 112 = 14 x 8 keeps 16-byte pieces whole across the wrap
+constexpr int kU10 = 64;                                 // entries per unit
 constexpr int kPairBuckets = 128;
-static size_t part2_lds_bytes(int P) { return (size_t)10 * P * kQ10 + sizeof(uint32_t) * 2 * (size_t)P + 32 + 4 * kSeqRing; }
+template <int NV> struct MultiGeo {
+    static constexpr int Q = NV == 2 ? 112 : 88;         // ring capacity per bucket (entries); multiples of 8 keep 16-byte pieces whole across the wrap
+    static constexpr int entry_bytes = 4 * NV + 2;
+    static constexpr int unit_bytes = kU10 * entry_bytes; // 640 / 896: value r at 256 r, the keys behind the values
+    static constexpr int first_period = NV == 2 ? 2 : 1; // batches between sweeps
+};
+static size_t partv_lds_bytes(int P, int nv) { return (size_t)(4 * nv + 2) * P * (nv == 2 ? MultiGeo<2>::Q : MultiGeo<3>::Q) + sizeof(uint32_t) * 2 * (size_t)P + 32 + 4 * kSeqRing; }
+static int multi_unit_bytes(int nv) { return kU10 * (4 * nv + 2); }
 
-template <int OP>
-__global__ __launch_bounds__(kPartThreads) void fgb_part2_kernel(
-    const float *__restrict__ p, const int32_t *__restrict__ k, const uint32_t *__restrict__ v1, const uint32_t *__restrict__ v2,
+template <int OP, int NV>
+__global__ __launch_bounds__(kPartThreads) void fgb_partv_kernel(
+    const float *__restrict__ p, const int32_t *__restrict__ k, const uint32_t *__restrict__ v1, const uint32_t *__restrict__ v2, const uint32_t *__restrict__ v3,
     int64_t row0, int64_t row1, float thr, int64_t G, int shift, int P,
     unsigned char *__restrict__ pbuf, uint32_t *__restrict__ counts, size_t slab_bytes, int32_t *__restrict__ err)
 {
+    constexpr int Q = MultiGeo<NV>::Q, kUnitBytes = MultiGeo<NV>::unit_bytes;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    uint32_t *q1 = reinterpret_cast<uint32_t *>(lds_raw);                  // [P][kQ10] value 1
-    uint32_t *q2 = q1 + (size_t)P * kQ10;                                  // [P][kQ10] value 2
-    uint16_t *qk = reinterpret_cast<uint16_t *>(q2 + (size_t)P * kQ10);    // [P][kQ10] bucket-local keys
-    uint32_t *s_w = reinterpret_cast<uint32_t *>(qk + (size_t)P * kQ10);   // [P] ring index of the oldest pair << 16 | pairs queued
+    uint32_t *qv = reinterpret_cast<uint32_t *>(lds_raw);                  // [NV][P][Q] raw value bits
+    uint16_t *qk = reinterpret_cast<uint16_t *>(qv + (size_t)NV * P * Q);  // [P][Q] bucket-local keys
+    uint32_t *s_w = reinterpret_cast<uint32_t *>(qk + (size_t)P * Q);      // [P] ring index of the oldest entry << 16 | entries queued
     int *s_lcur = reinterpret_cast<int *>(s_w + P);                        // [P] units already stored in this workgroup's slab
     uint32_t *or_flags = reinterpret_cast<uint32_t *>(s_lcur + P);         // [3] wg_or slots
     const int tid = threadIdx.x, nwg = gridDim.x, wg = blockIdx.x;
+    const int PQ = P * Q;
     const int64_t nbatch = (row1 - row0 + kBatchRows - 1) / kBatchRows;
-    const int cap_units = (int)(slab_bytes / kUnit10Bytes) - 1;            // the last unit for the final partial flush
+    const int cap_units = (int)(slab_bytes / kUnitBytes) - 1;              // the last unit for the final partial flush
     const uint32_t kmask = (1u << shift) - 1u, Gu = (uint32_t)G;
     auto slab_of = [&](int b) -> unsigned char * { return pbuf + ((size_t)b * nwg + wg) * slab_bytes; };
-    auto wrap = [](int x) { return x >= kQ10 ? x - kQ10 : x; };
+    auto wrap = [](int x) { return x >= Q ? x - Q : x; };
     for (int b = tid; b < P; b += kPartThreads) { s_w[b] = 0u; s_lcur[b] = 0; }
     if (tid < 4) or_flags[tid] = 0u;
     BatchSeq seq;                                                          // batches first come, first served (see BatchSeq)
     seq.init(or_flags + 8, err, nbatch, wg, nwg, tid);
-    int or_phase = 0, period = 2, since_sweep = 0, n_full = 0, batches_done = 0;
+    int or_phase = 0, period = MultiGeo<NV>::first_period, since_sweep = 0, n_full = 0, batches_done = 0;
     bool bad = false, overflow = false;
     __syncthreads();
 
-    struct Rows { float4 p; int4 k; uint4 a, b; };
+    struct Rows { float4 p; int4 k; uint4 v[NV]; };
     auto load = [&](int64_t batch, Rows &r) {
         const int64_t rb = row0 + batch * kBatchRows;                      // workgroup-uniform
         const uint32_t lo = (uint32_t)tid * kVec;
@@ -1120,16 +1130,19 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part2_kernel(
             } else if (OP != kNoPred) { const uint4 t = ld_nt16(p + rb + lo); r.p = float4{__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w)}; }
             else r.p = float4{0, 0, 0, 0};
             const uint4 tk = ld_nt16(k + rb + lo); r.k = int4{(int)tk.x, (int)tk.y, (int)tk.z, (int)tk.w};
-            r.a = ld_nt16(v1 + rb + lo); r.b = ld_nt16(v2 + rb + lo);
+            r.v[0] = ld_nt16(v1 + rb + lo); r.v[1] = ld_nt16(v2 + rb + lo);
+            if constexpr (NV == 3) r.v[2] = ld_nt16(v3 + rb + lo);
         } else {                                                           // ragged end of the table
             const int64_t r0 = rb + lo;
-            float pp[4] = {0, 0, 0, 0}; int kk[4] = {0, 0, 0, 0}; uint32_t aa[4] = {0, 0, 0, 0}, bb[4] = {0, 0, 0, 0};
+            float pp[4] = {0, 0, 0, 0}; int kk[4] = {0, 0, 0, 0}; uint32_t vv[NV][4] = {};
             for (int j = 0; j < kVec; j++) if (r0 + j < row1) {
-                pp[j] = OP == kNoPred ? 0.0f : OP == kMaskPred ? mask_bit(p, r0 + j) : p[r0 + j]; kk[j] = k[r0 + j]; aa[j] = v1[r0 + j]; bb[j] = v2[r0 + j];
+                pp[j] = OP == kNoPred ? 0.0f : OP == kMaskPred ? mask_bit(p, r0 + j) : p[r0 + j]; kk[j] = k[r0 + j]; vv[0][j] = v1[r0 + j]; vv[1][j] = v2[r0 + j];
+                if constexpr (NV == 3) vv[2][j] = v3[r0 + j];
             }
             if (OP == kMaskPred) pp[0] = __uint_as_float((uint32_t)(pp[0] != 0.0f) | ((uint32_t)(pp[1] != 0.0f) << 1) | ((uint32_t)(pp[2] != 0.0f) << 2) | ((uint32_t)(pp[3] != 0.0f) << 3));
             r.p = float4{pp[0], pp[1], pp[2], pp[3]}; r.k = int4{kk[0], kk[1], kk[2], kk[3]};
-            r.a = uint4{aa[0], aa[1], aa[2], aa[3]}; r.b = uint4{bb[0], bb[1], bb[2], bb[3]};
+#pragma unroll
+            for (int c = 0; c < NV; c++) r.v[c] = uint4{vv[c][0], vv[c][1], vv[c][2], vv[c][3]};
         }
     };
 
@@ -1141,14 +1154,16 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part2_kernel(
             if (cnt >= kU10) {
                 const int i = tid & 7, head = (int)(w >> 16), lc = s_lcur[b];
                 const int iv0 = wrap(head + 4 * i), iv1 = wrap(head + 32 + 4 * i), ik = wrap(head + 8 * i);
-                const uint4 a0 = *reinterpret_cast<const uint4 *>(&q1[b * kQ10 + iv0]), a1 = *reinterpret_cast<const uint4 *>(&q1[b * kQ10 + iv1]);
-                const uint4 c0 = *reinterpret_cast<const uint4 *>(&q2[b * kQ10 + iv0]), c1 = *reinterpret_cast<const uint4 *>(&q2[b * kQ10 + iv1]);
-                const uint4 kk = *reinterpret_cast<const uint4 *>(&qk[b * kQ10 + ik]);
                 if (lc < cap_units) {
-                    unsigned char *dst = slab_of(b) + (size_t)lc * kUnit10Bytes;
-                    st_nt16(dst + 16 * i, a0); st_nt16(dst + 128 + 16 * i, a1);
-                    st_nt16(dst + 256 + 16 * i, c0); st_nt16(dst + 384 + 16 * i, c1);
-                    st_nt16(dst + 512 + 16 * i, kk);
+                    unsigned char *dst = slab_of(b) + (size_t)lc * kUnitBytes;
+#pragma unroll
+                    for (int c = 0; c < NV; c++) {                         // one value ring at a time: 8 data registers live, not 8 NV
+                        const uint4 a0 = *reinterpret_cast<const uint4 *>(&qv[c * PQ + b * Q + iv0]);
+                        const uint4 a1 = *reinterpret_cast<const uint4 *>(&qv[c * PQ + b * Q + iv1]);
+                        st_nt16(dst + 256 * c + 16 * i, a0); st_nt16(dst + 256 * c + 128 + 16 * i, a1);
+                        if constexpr (NV == 3) __builtin_amdgcn_sched_barrier(0);
+                    }
+                    st_nt16(dst + 256 * NV + 16 * i, *reinterpret_cast<const uint4 *>(&qk[b * Q + ik]));
                 } else overflow = true;
                 if (i == 0) {
                     s_w[b] = ((uint32_t)wrap(head + kU10) << 16) | (uint32_t)(cnt - kU10);
@@ -1161,7 +1176,9 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part2_kernel(
     auto process = [&](int64_t batch, const Rows &r, const bool flush_now) {
         const float pv[4] = {r.p.x, r.p.y, r.p.z, r.p.w};
         const int kv[4] = {r.k.x, r.k.y, r.k.z, r.k.w};
-        const uint32_t av[4] = {r.a.x, r.a.y, r.a.z, r.a.w}, bv[4] = {r.b.x, r.b.y, r.b.z, r.b.w};
+        uint32_t vv[NV][4];
+#pragma unroll
+        for (int c = 0; c < NV; c++) { vv[c][0] = r.v[c].x; vv[c][1] = r.v[c].y; vv[c][2] = r.v[c].z; vv[c][3] = r.v[c].w; }
         const int64_t bend = row0 + (batch + 1) * kBatchRows;
         bool sv[kVec];
         if (OP == kMaskPred) {
@@ -1189,9 +1206,11 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part2_kernel(
             for (int j = 0; j < kVec; j++) {
                 if (sv[j]) {
                     const uint32_t key = (uint32_t)kv[j], b = key >> shift, old = olds[j], pos = old & 0xFFFFu;
-                    if (pos < (uint32_t)kQ10) {
-                        const int at = (int)__umul24(b, (uint32_t)kQ10) + wrap((int)(old >> 16) + (int)pos);
-                        q1[at] = av[j]; q2[at] = bv[j]; qk[at] = (uint16_t)(key & kmask);
+                    if (pos < (uint32_t)Q) {
+                        const int at = (int)__umul24(b, (uint32_t)Q) + wrap((int)(old >> 16) + (int)pos);
+#pragma unroll
+                        for (int c = 0; c < NV; c++) qv[c * PQ + at] = vv[c][j];
+                        qk[at] = (uint16_t)(key & kmask);
                         sv[j] = false;
                     } else atomicSub(&s_w[b], 1u);                         // ring full: retry after the sweep
                 }
@@ -1220,14 +1239,16 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part2_kernel(
         if (idB < nbatch) load(idB, B);
         process(batch, cur, ++since_sweep >= period || idA >= nbatch);
     }
-    // what is left (< kU10 pairs per bucket) goes out as one partial unit
+    // what is left (< kU10 entries per bucket) goes out as one partial unit
     for (int b = tid; b < P; b += kPartThreads) {
         const uint32_t w = s_w[b];
         const int l = (int)(w & 0xFFFFu), head = (int)(w >> 16);
-        unsigned char *dst = slab_of(b) + (size_t)s_lcur[b] * kUnit10Bytes;
+        unsigned char *dst = slab_of(b) + (size_t)s_lcur[b] * kUnitBytes;
         for (int j = 0; j < l; j++) {
-            const int at = b * kQ10 + wrap(head + j);
-            reinterpret_cast<uint32_t *>(dst)[j] = q1[at]; reinterpret_cast<uint32_t *>(dst + 256)[j] = q2[at]; reinterpret_cast<uint16_t *>(dst + 512)[j] = qk[at];
+            const int at = b * Q + wrap(head + j);
+#pragma unroll
+            for (int c = 0; c < NV; c++) reinterpret_cast<uint32_t *>(dst + 256 * c)[j] = qv[c * PQ + at];
+            reinterpret_cast<uint16_t *>(dst + 256 * NV)[j] = qk[at];
         }
         counts[(size_t)b * nwg + wg] = (uint32_t)(s_lcur[b] * kU10 + l);
     }
@@ -1235,60 +1256,70 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part2_kernel(
     if (overflow) *err = kErrOverflow;
 }
 
-// Consumer of the pair pass: one workgroup per bucket, LDS slice of 16 B per key (64-bit slot of value 1, row count,
-// 32-bit slot of value 2).  VOP1: any of F32SUM / U32SUM64 / U32MAX / U32MIN (the last two in the low word);
-// VOP2: U32MAX or U32MIN.  xf1 / xf2: order transforms of the raw bits (apply_xf).
-template <int VOP1, int VOP2>
-__global__ __launch_bounds__(1024) void fgb_agg10_kernel(
+// Consumer of the pair / triple pass: two workgroups per bucket, LDS slice of 16 / 20 B per key (64-bit slot of value 1,
+// row count, one 32-bit slot per further value).  VOP1: any of F32SUM / U32SUM64 / U32SUM / U32MAX / U32MIN (the last two
+// in the low word); values 2 and 3: MAX (inv = 0) or MIN (inv = 0xFFFFFFFF: the slot keeps the MAX of the inverted order
+// word).  xf1..xf3: order transforms of the raw bits (apply_xf).
+template <int VOP1, int NV>
+__global__ __launch_bounds__(1024) void fgb_aggv_kernel(
     const unsigned char *__restrict__ pbuf, const uint32_t *__restrict__ counts, size_t slab_bytes, int nwg, int shift,
-    int64_t G, u64 *__restrict__ gsum, unsigned long long *__restrict__ gcnt, u64 *__restrict__ g2, int xf1, int xf2)
+    int64_t G, u64 *__restrict__ gsum, unsigned long long *__restrict__ gcnt, u64 *__restrict__ g2, u64 *__restrict__ g3,
+    int xf1, int xf2, int xf3, uint32_t inv2, uint32_t inv3)
 {
     typedef unsigned int u4v __attribute__((ext_vector_type(4)));
     typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+    constexpr int kUnitBytes = MultiGeo<NV>::unit_bytes;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int KPB = 1 << shift;
     u64 *s_a = reinterpret_cast<u64 *>(lds_raw);
     uint32_t *s_cnt = reinterpret_cast<uint32_t *>(lds_raw + sizeof(u64) * KPB);
     uint32_t *s_b = s_cnt + KPB;
+    uint32_t *s_c = s_b + KPB;                                         // NV == 3 only
     const int b = blockIdx.x >> 1, half = blockIdx.x & 1;              // two workgroups per bucket: even / odd slabs
-    const uint32_t id2 = VOP2 == VOP_U32MIN ? 0xFFFFFFFFu : 0u;
-    for (int i = threadIdx.x; i < KPB; i += blockDim.x) { s_a[i] = vop_identity(VOP1); s_cnt[i] = 0u; s_b[i] = id2; }
+    for (int i = threadIdx.x; i < KPB; i += blockDim.x) { s_a[i] = vop_identity(VOP1); s_cnt[i] = 0u; s_b[i] = 0u; if constexpr (NV == 3) s_c[i] = 0u; }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    const uint32_t max_pairs = (uint32_t)(slab_bytes / kUnit10Bytes) * kU10;
-    auto add = [&](uint32_t key, uint32_t ra, uint32_t rb) {
+    const uint32_t max_entries = (uint32_t)(slab_bytes / kUnitBytes) * kU10;
+    auto add = [&](uint32_t key, uint32_t ra, uint32_t rb, uint32_t rc) {
         vop_atomic<VOP1>(&s_a[key], VOP1 == VOP_F32SUM ? ra : apply_xf(xf1, ra));
         atomicAdd(&s_cnt[key], 1u);
-        const uint32_t w = apply_xf(xf2, rb);
-        if constexpr (VOP2 == VOP_U32MIN) atomicMin(&s_b[key], w); else atomicMax(&s_b[key], w);
+        atomicMax(&s_b[key], apply_xf(xf2, rb) ^ inv2);
+        if constexpr (NV == 3) atomicMax(&s_c[key], apply_xf(xf3, rc) ^ inv3);
     };
     const int piece = lane & 15, sub = lane >> 4;                     // 16 lanes per unit (16 B of each value, 8 B of keys per lane), 4 units per wave and step
     for (int w = 2 * wave + half; w < nwg; w += 2 * nwaves) {
-        const uint32_t count = min(counts[(size_t)b * nwg + w], max_pairs);
+        const uint32_t count = min(counts[(size_t)b * nwg + w], max_entries);
         const unsigned char *src = pbuf + ((size_t)b * nwg + w) * slab_bytes;
         const uint32_t units = count / kU10, rem = count % kU10;
         for (uint32_t u = sub; u < units; u += 4) {
-            const unsigned char *a = src + (size_t)u * kUnit10Bytes;
+            const unsigned char *a = src + (size_t)u * kUnitBytes;
             const u4v va = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(a + 16 * piece));
             const u4v vb = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(a + 256 + 16 * piece));
-            const u2v kk = __builtin_nontemporal_load(reinterpret_cast<const u2v *>(a + 512 + 8 * piece));
-            add(kk.x & 0xFFFFu, va.x, vb.x); add(kk.x >> 16, va.y, vb.y); add(kk.y & 0xFFFFu, va.z, vb.z); add(kk.y >> 16, va.w, vb.w);
+            u4v vc = {0u, 0u, 0u, 0u};
+            if constexpr (NV == 3) vc = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(a + 512 + 16 * piece));
+            const u2v kk = __builtin_nontemporal_load(reinterpret_cast<const u2v *>(a + 256 * NV + 8 * piece));
+            add(kk.x & 0xFFFFu, va.x, vb.x, vc.x); add(kk.x >> 16, va.y, vb.y, vc.y); add(kk.y & 0xFFFFu, va.z, vb.z, vc.z); add(kk.y >> 16, va.w, vb.w, vc.w);
         }
         if ((uint32_t)lane < rem) {
-            const unsigned char *a = src + (size_t)units * kUnit10Bytes;
-            add(reinterpret_cast<const uint16_t *>(a + 512)[lane], reinterpret_cast<const uint32_t *>(a)[lane], reinterpret_cast<const uint32_t *>(a + 256)[lane]);
+            const unsigned char *a = src + (size_t)units * kUnitBytes;
+            add(reinterpret_cast<const uint16_t *>(a + 256 * NV)[lane], reinterpret_cast<const uint32_t *>(a)[lane], reinterpret_cast<const uint32_t *>(a + 256)[lane],
+                NV == 3 ? reinterpret_cast<const uint32_t *>(a + 512)[lane] : 0u);
         }
     }
     __syncthreads();
     // the two workgroups of a bucket meet in the global table: contiguous atomics (one per touched key and accumulator)
     const int64_t kbase = (int64_t)b << shift;
+    auto ext = [](u64 *slot, uint32_t w, uint32_t inv) {              // the order word lives in the low half of the 64-bit slot
+        uint32_t *lo = reinterpret_cast<uint32_t *>(slot);
+        if (inv) atomicMin(lo, w ^ inv); else atomicMax(lo, w);
+    };
     for (int i = threadIdx.x; i < KPB; i += blockDim.x) {
         const uint32_t c = s_cnt[i];
         if (c && kbase + i < G) {
             vop_atomic_partial<VOP1>(&gsum[kbase + i], s_a[i]);
             atomicAdd(&gcnt[kbase + i], (unsigned long long)c);
-            uint32_t *lo = reinterpret_cast<uint32_t *>(&g2[kbase + i]);           // the order word lives in the low half of the 64-bit slot
-            if constexpr (VOP2 == VOP_U32MIN) atomicMin(lo, s_b[i]); else atomicMax(lo, s_b[i]);
+            ext(&g2[kbase + i], s_b[i], inv2);
+            if constexpr (NV == 3) ext(&g3[kbase + i], s_c[i], inv3);
         }
     }
 }
@@ -2248,74 +2279,90 @@ int k_fgb_dense_stats(hark_context *ctx, hark_fgb_plan *pl, const float *p, int 
     return HARK_OK;
 }
 
-// Two aggregates of two different 4-byte columns in ONE pass (see fgb_part2_kernel): value 1 with operator vop1 / xf1
-// into acc_sum, value 2 with vop2 in {U32MAX, U32MIN} / xf2 into acc_min (used as the plan's second accumulator), row
-// counts into acc_cnt.  Only the partition path with <= 4096 keys per bucket qualifies; *ran is false otherwise, and
-// when skew overflowed a ring or a slab (no single-row fallback): the caller runs the separate passes.
-int k_fgb_dense_pair(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cmp, float thr, const int32_t *k,
-                     const void *v1, int vop1, int xf1, const void *v2, int vop2, int xf2, int64_t n, bool *ran)
+// Two or three aggregates of different 4-byte columns in ONE pass (see fgb_partv_kernel): value 1 with operator vop1 / xf1
+// into acc_sum, value 2 with vop2 in {U32MAX, U32MIN} / xf2 into acc_min (used as the plan's second accumulator), value 3
+// (v3 != nullptr: triple pass) likewise into acc_max, row counts into acc_cnt.  Only the partition path with <= 4096 keys
+// per bucket qualifies; *ran is false otherwise, and when skew overflowed a ring or a slab (no single-row fallback; a
+// triple's 14-byte entries fill the plan's slabs -- 10.4 B per row -- from ~70 % selectivity on): the caller runs the
+// smaller passes.
+int k_fgb_dense_multi(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cmp, float thr, const int32_t *k,
+                      const void *v1, int vop1, int xf1, const void *v2, int vop2, int xf2, const void *v3, int vop3, int xf3, int64_t n, bool *ran)
 {
     *ran = false;
     const int64_t G = pl->G;
-    if (getenv("HARK_NO_PAIR_PASS")) return HARK_OK;                  // A/B knob
+    const int nv = v3 ? 3 : 2;
+    if (getenv("HARK_NO_PAIR_PASS") || (nv == 3 && getenv("HARK_NO_TRIPLE_PASS"))) return HARK_OK;     // A/B knobs
     if (n <= 0 || pl->algo != 0 || G * 12 <= kLdsTableBudget || G > (int64_t)kMaxBuckets * 4096 || n > pl->max_rows) return HARK_OK;
-    if (!(vop1 == VOP_F32SUM || vop1 == VOP_U32SUM64 || vop1 == VOP_U32SUM || vop1 == VOP_U32MAX || vop1 == VOP_U32MIN) || !(vop2 == VOP_U32MAX || vop2 == VOP_U32MIN)) return HARK_OK;
+    auto is_ext = [](int vop) { return vop == VOP_U32MAX || vop == VOP_U32MIN; };
+    if (!(vop1 == VOP_F32SUM || vop1 == VOP_U32SUM64 || vop1 == VOP_U32SUM || is_ext(vop1)) || !is_ext(vop2) || (v3 && !is_ext(vop3))) return HARK_OK;
     auto misaligned = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) != 0; };
-    if ((p && misaligned(p)) || misaligned(k) || misaligned(v1) || misaligned(v2)) return HARK_OK;
+    if ((p && misaligned(p)) || misaligned(k) || misaligned(v1) || misaligned(v2) || (v3 && misaligned(v3))) return HARK_OK;
     HARK_TRY(plan_prepare_partition(ctx, pl));
     if (pl->shift > 12) return HARK_OK;
     // half as many buckets as the plan's one-value passes, in the same workspace
     const int shift = (int)pl->shift + 1, P = (int)(((G - 1) >> shift) + 1), nwg = (int)pl->nwg;
     if (P > kPairBuckets) return HARK_OK;
     const size_t slab_bytes = ((size_t)pl->P * (size_t)pl->cap * 8 / (size_t)P) & ~(size_t)15;
+    if (slab_bytes < (size_t)4 * multi_unit_bytes(nv)) return HARK_OK;
     if (!pl->acc_min) HARK_TRY(hark_alloc(ctx, (void **)&pl->acc_min, (size_t)G * 8));
+    if (v3 && !pl->acc_max) HARK_TRY(hark_alloc(ctx, (void **)&pl->acc_max, (size_t)G * 8));
     hipStream_t st = ctx->stream;
     const int64_t blocks = (G + 255) / 256 > (int64_t)ctx->num_cu * 4 ? (int64_t)ctx->num_cu * 4 : (G + 255) / 256;
     u64 *gsum = reinterpret_cast<u64 *>(pl->acc_sum);
     fgb_fill_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(gsum, G, vop_identity(vop1));
     HIP_TRY(ctx, hipMemsetAsync(pl->acc_cnt, 0, (size_t)G * 8, st));
-    fgb_fill_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(pl->acc_min, G, vop2 == VOP_U32MIN ? 0xFFFFFFFFull : 0ull);
-    const size_t lds_agg = (size_t)16 << shift, lds_part = part2_lds_bytes(P);
+    fgb_fill_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(pl->acc_min, G, vop_identity(vop2));
+    if (v3) fgb_fill_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(pl->acc_max, G, vop_identity(vop3));
+    const size_t lds_agg = (size_t)(nv == 3 ? 20 : 16) << shift, lds_part = partv_lds_bytes(P, nv);
+    const uint32_t inv2 = vop2 == VOP_U32MIN ? 0xFFFFFFFFu : 0u, inv3 = vop3 == VOP_U32MIN ? 0xFFFFFFFFu : 0u;
     unsigned char *pbuf = reinterpret_cast<unsigned char *>(pl->pbuf);
-    int rc = dispatch_op(cmp, p != nullptr, [&](auto op) -> int {
-        constexpr int OP = decltype(op)::value;
-        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_part2_kernel<OP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part));
+    const uint32_t *c1 = static_cast<const uint32_t *>(v1), *c2 = static_cast<const uint32_t *>(v2), *c3 = static_cast<const uint32_t *>(v3);
+    auto run = [&](auto op, auto nvc) -> int {
+        constexpr int OP = decltype(op)::value, NV = decltype(nvc)::value;
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_partv_kernel<OP, NV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part));
         for (int64_t r0 = 0; r0 < n; r0 += pl->chunk_rows) {
             const int64_t r1 = r0 + pl->chunk_rows < n ? r0 + pl->chunk_rows : n;
             HIP_TRY(ctx, hipMemsetAsync(pl->err + 1, 0, 4, st));                 // the producers' batch counter
             {
                 TimedLaunch tl(pl, st, 1);
-                fgb_part2_kernel<OP><<<dim3((unsigned)nwg), dim3(kPartThreads), lds_part, st>>>(
-                    p, k, static_cast<const uint32_t *>(v1), static_cast<const uint32_t *>(v2), r0, r1, thr, G, shift, P, pbuf, pl->counts, slab_bytes, pl->err);
+                fgb_partv_kernel<OP, NV><<<dim3((unsigned)nwg), dim3(kPartThreads), lds_part, st>>>(
+                    p, k, c1, c2, c3, r0, r1, thr, G, shift, P, pbuf, pl->counts, slab_bytes, pl->err);
             }
             HIP_TRY(ctx, hipGetLastError());
             TimedLaunch tl(pl, st, 2);
-#define HARK_PAIR(V1, V2) do { \
-                if (lds_agg > 64 * 1024) HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_agg10_kernel<V1, V2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_agg)); \
-                fgb_agg10_kernel<V1, V2><<<dim3((unsigned)(2 * P)), dim3(1024), lds_agg, st>>>(pbuf, pl->counts, slab_bytes, nwg, shift, G, gsum, pl->acc_cnt, pl->acc_min, xf1, xf2); } while (0)
-            if (vop2 == VOP_U32MAX) {
-                if (vop1 == VOP_F32SUM) HARK_PAIR(VOP_F32SUM, VOP_U32MAX); else if (vop1 == VOP_U32SUM64) HARK_PAIR(VOP_U32SUM64, VOP_U32MAX);
-                else if (vop1 == VOP_U32SUM) HARK_PAIR(VOP_U32SUM, VOP_U32MAX);
-                else if (vop1 == VOP_U32MAX) HARK_PAIR(VOP_U32MAX, VOP_U32MAX); else HARK_PAIR(VOP_U32MIN, VOP_U32MAX);
-            } else {
-                if (vop1 == VOP_F32SUM) HARK_PAIR(VOP_F32SUM, VOP_U32MIN); else if (vop1 == VOP_U32SUM64) HARK_PAIR(VOP_U32SUM64, VOP_U32MIN);
-                else if (vop1 == VOP_U32SUM) HARK_PAIR(VOP_U32SUM, VOP_U32MIN);
-                else if (vop1 == VOP_U32MAX) HARK_PAIR(VOP_U32MAX, VOP_U32MIN); else HARK_PAIR(VOP_U32MIN, VOP_U32MIN);
-            }
-#undef HARK_PAIR
+            int rc2 = dispatch_vop(vop1, [&](auto v) -> int {
+                constexpr int V1 = decltype(v)::value;
+                if constexpr (V1 == VOP_U32PROD) return HARK_EUNSUPPORTED;
+                else {
+                    if (lds_agg > 64 * 1024) HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_aggv_kernel<V1, NV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_agg));
+                    fgb_aggv_kernel<V1, NV><<<dim3((unsigned)(2 * P)), dim3(1024), lds_agg, st>>>(pbuf, pl->counts, slab_bytes, nwg, shift, G, gsum, pl->acc_cnt,
+                                                                                                  pl->acc_min, pl->acc_max, xf1, xf2, xf3, inv2, inv3);
+                    return HARK_OK;
+                }
+            });
+            if (rc2) return rc2;
             HIP_TRY(ctx, hipGetLastError());
         }
         return HARK_OK;
+    };
+    int rc = dispatch_op(cmp, p != nullptr, [&](auto op) -> int {
+        return nv == 3 ? run(op, std::integral_constant<int, 3>{}) : run(op, std::integral_constant<int, 2>{});
     });
     if (rc) return rc;
     int64_t e = 0;
     HARK_TRY(hark_read_words(ctx, pl->err, &e, 1));                // err is an int32 in a >= 8-byte pool block
     const int32_t code = (int32_t)(e & 0xFFFFFFFFll);
     if (code != 0) HIP_TRY(ctx, hipMemsetAsync(pl->err, 0, sizeof(int32_t), st));
-    if (code == kErrOverflow) return HARK_OK;                      // *ran stays false: the caller runs the separate passes
+    if (code == kErrOverflow) return HARK_OK;                      // *ran stays false: the caller runs the smaller passes
     if (code != 0) return hark_fail(ctx, code, "filter_groupby: a surviving row has a key outside [0, %lld)", (long long)G);
     *ran = true;
     return HARK_OK;
+}
+
+int k_fgb_dense_pair(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cmp, float thr, const int32_t *k,
+                     const void *v1, int vop1, int xf1, const void *v2, int vop2, int xf2, int64_t n, bool *ran)
+{
+    return k_fgb_dense_multi(ctx, pl, p, cmp, thr, k, v1, vop1, xf1, v2, vop2, xf2, nullptr, VOP_U32MAX, 0, n, ran);
 }
 
 // Typed read-out of one of the plan's accumulator arrays: which = 0 acc_sum, 1 acc_min, 2 acc_max.

@@ -749,7 +749,7 @@ int try_dense(hark_context *ctx, const hark_table *db, const PredList &preds,
         int r = hark_fgb_plan_set(plan, "vop", vop);
         if (!r) r = hark_fgb_plan_set(plan, "xform", xf);
         if (!r) r = hark_fgb_reset(ctx, plan);
-        if (!r && src->n > 0) r = k_fgb_dense_f32(ctx, plan, p, cmp, thr, keys, static_cast<const float *>(col), src->n);
+        if (!r && src->n > 0) { r = k_fgb_dense_f32(ctx, plan, p, cmp, thr, keys, static_cast<const float *>(col), src->n); ctx->last_groupby_passes++; }
         if (!r) r = group_set();
         return r;
     };
@@ -769,6 +769,7 @@ int try_dense(hark_context *ctx, const hark_table *db, const PredList &preds,
         if (!rc) rc = hark_fgb_plan_set(plan, "xform", 0);
         if (!rc) rc = k_fgb_dense_stats(ctx, plan, p, cmp, thr, keys, src->cols[c].data, src->n, vk, &ran);
         if (rc || !ran) continue;
+        ctx->last_groupby_passes++;
         rc = group_set();
         for (int64_t q = 0; q < n_aggs && !rc; q++) {
             if (done[q]) continue;
@@ -786,6 +787,39 @@ int try_dense(hark_context *ctx, const hark_table *db, const PredList &preds,
     auto same_pass = [&](int64_t a, int64_t b) { return !plan_of[b].count_only && plan_of[b].vop == plan_of[a].vop && plan_of[b].xf == plan_of[a].xf && plan_of[b].col == plan_of[a].col; };
     auto is_sum = [&](int64_t q) { return !plan_of[q].count_only && (plan_of[q].vop == 0 || plan_of[q].vop == 5); };
     auto is_ext = [&](int64_t q) { return !plan_of[q].count_only && (plan_of[q].vop == 2 || plan_of[q].vop == 3); };
+    // ---- triple passes first (14-byte entries: value 1 a SUM / AVG when there is one, values 2 and 3 a MAX / MIN each, of
+    // three different (operator, column) passes): BASELINE configs[4]'s SUM(a), MAX(b), MIN(c), COUNT(*) is ONE pass
+    bool triples = true;
+    while (triples && !rc && src->n > 0) {
+        triples = false;
+        int64_t j = -1, q1 = -1, q2 = -1;
+        for (int64_t t = 0; t < n_aggs && j < 0; t++) if (!done[t] && is_sum(t)) j = t;
+        for (int64_t t = 0; t < n_aggs && j < 0; t++) if (!done[t] && is_ext(t)) j = t;
+        if (j < 0) break;
+        for (int64_t t = 0; t < n_aggs && q1 < 0; t++) if (t != j && !done[t] && is_ext(t) && !same_pass(j, t)) q1 = t;
+        for (int64_t t = 0; q1 >= 0 && t < n_aggs && q2 < 0; t++) if (t != j && t != q1 && !done[t] && is_ext(t) && !same_pass(j, t) && !same_pass(q1, t)) q2 = t;
+        if (q2 < 0) break;
+        // 14-byte entries in slabs sized for 8-byte ones (1.3 x 8 = 10.4 B per row) would overflow from ~70 % selectivity on:
+        // a statement with a triple gets slabs for 14 B per row (9 GB per 5e8 rows instead of 5.2)
+        if (plan->slack_pct < 230) rc = hark_fgb_plan_set(plan, "slack_pct", 230);
+        if (rc) break;
+        bool ran = false;
+        rc = k_fgb_dense_multi(ctx, plan, p, cmp, thr, keys, src->cols[plan_of[j].col].data, plan_of[j].vop, plan_of[j].xf,
+                               src->cols[plan_of[q1].col].data, plan_of[q1].vop, plan_of[q1].xf,
+                               src->cols[plan_of[q2].col].data, plan_of[q2].vop, plan_of[q2].xf, src->n, &ran);
+        if (rc || !ran) break;                                            // declined (geometry, skew, high selectivity): pairs and singles below
+        ctx->last_groupby_passes++;
+        rc = group_set();
+        for (int64_t t = 0; t < n_aggs && !rc; t++) {
+            if (done[t]) continue;
+            if (plan_of[t].count_only || same_pass(j, t)) rc = hark_fgb_finish_typed(ctx, plan, plan_of[t].kind, pos, res->cols[(size_t)t + 1].data);
+            else if (same_pass(q1, t)) rc = hark_fgb_finish_typed_from(ctx, plan, 1, plan_of[t].kind, pos, res->cols[(size_t)t + 1].data);
+            else if (same_pass(q2, t)) rc = hark_fgb_finish_typed_from(ctx, plan, 2, plan_of[t].kind, pos, res->cols[(size_t)t + 1].data);
+            else continue;
+            done[t] = 1;
+        }
+        triples = true;
+    }
     for (int turn = 0; turn < 2 && !rc && src->n > 0; turn++) {          // turn 0: (sum, max/min) pairs, turn 1: (max/min, max/min) pairs
         for (int64_t j = 0; j < n_aggs && !rc; j++) {
             if (done[j] || !(turn == 0 ? is_sum(j) : is_ext(j))) continue;
@@ -796,6 +830,7 @@ int try_dense(hark_context *ctx, const hark_table *db, const PredList &preds,
             rc = k_fgb_dense_pair(ctx, plan, p, cmp, thr, keys, src->cols[plan_of[j].col].data, plan_of[j].vop, plan_of[j].xf,
                                   src->cols[plan_of[q].col].data, plan_of[q].vop, plan_of[q].xf, src->n, &ran);
             if (rc || !ran) { turn = 2; break; }                          // it declines for the whole statement alike
+            ctx->last_groupby_passes++;
             rc = group_set();
             for (int64_t t = 0; t < n_aggs && !rc; t++) {
                 if (done[t]) continue;
@@ -1229,8 +1264,9 @@ extern "C" int hark_entry_filter_groupby_and(hark_context *ctx, hark_result **ou
     int rc = HARK_OK;
     bool done = false;
     ctx->last_groupby_path = HARK_PATH_NONE;
+    ctx->last_groupby_passes = 0;
     if (db->n > 0) rc = try_dense(ctx, db, preds, g_col, agg_cols, agg_ops, n_aggs, res, &done);
-    if (!rc && done) ctx->last_groupby_path = HARK_PATH_DENSE;
+    if (!rc && done) ctx->last_groupby_path = HARK_PATH_DENSE; else ctx->last_groupby_passes = 0;
     if (!rc && !done && db->n > 0) { rc = try_hash(ctx, db, preds, g_col, agg_cols, agg_ops, n_aggs, res, &done); if (!rc && done) ctx->last_groupby_path = HARK_PATH_HASH; }
     if (!rc && !done) {
         ctx->last_groupby_path = HARK_PATH_SORT;
@@ -1600,6 +1636,7 @@ __global__ __launch_bounds__(256) void composite_key_kernel(CompositeArgs a, int
 } // namespace
 
 extern "C" int hark_context_last_groupby_path(const hark_context *ctx) { return ctx ? ctx->last_groupby_path : HARK_PATH_NONE; }
+extern "C" int hark_context_last_groupby_passes(const hark_context *ctx) { return ctx ? ctx->last_groupby_passes : 0; }
 extern "C" int hark_context_last_join_path(const hark_context *ctx) { return ctx ? ctx->last_join_path : HARK_PATH_NONE; }
 
 extern "C" int hark_table_invalidate_stats(hark_context *ctx, const hark_table *t, int32_t col)

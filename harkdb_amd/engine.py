@@ -256,6 +256,10 @@ class Engine:
         """'dense' | 'hash' | 'sort' | None: the path that served the last GROUP BY entry (diagnostic, include/hark.h)."""
         return {1: "dense", 2: "hash", 3: "sort"}.get(self.lib.hark_context_last_groupby_path(self.ctx))
 
+    def last_groupby_passes(self):
+        """Passes over the table's rows of the last dense-path filter_groupby (diagnostic, include/hark.h)."""
+        return int(self.lib.hark_context_last_groupby_passes(self.ctx))
+
     def last_join_path(self):
         """'partitioned' | 'sort-merge' | None: the path that served the last join entry (diagnostic, include/hark.h)."""
         return {1: "partitioned", 2: "sort-merge"}.get(self.lib.hark_context_last_join_path(self.ctx))

@@ -320,6 +320,22 @@ def test_c5_full_pipeline_share(eng):
     finally:
         del os.environ["HARK_NO_PAIR_PASS"]
     assert np.array_equal(k1, k3) and np.array_equal(s1, s3) and np.array_equal(mx1, mx) and np.array_equal(mn1, mn) and np.array_equal(c1, c3)
+    # the statement above was ONE pass over the rows (triple pass: 14-byte entries in slabs sized for them, the consumer's
+    # 20 B x 8192 keys fill a CU's 160 KiB of LDS), also when 90 % of the rows survive; with the triple pass switched off a
+    # pair pass + a single pass give the same rows
+    fc.sql("select k, sum(c3), max(c7), min(c9), count(*) from t where c1 > 0.5 group by k")
+    assert fc.FutEnv.last_groupby_passes() == 1
+    many = q("select k, sum(c3), max(c7), min(c9), count(*) from t where c1 > 0.1 group by k")
+    assert fc.FutEnv.last_groupby_passes() == 1
+    os.environ["HARK_NO_TRIPLE_PASS"] = "1"
+    try:
+        many2 = q("select k, sum(c3), max(c7), min(c9), count(*) from t where c1 > 0.1 group by k")
+        assert fc.FutEnv.last_groupby_passes() == 2
+        k2, s2, mx2, mn2, c2 = q("select k, sum(c3), max(c7), min(c9), count(*) from t where c1 > 0.5 group by k")
+    finally:
+        del os.environ["HARK_NO_TRIPLE_PASS"]
+    assert all(np.array_equal(x, y) for x, y in zip(many, many2))
+    assert np.array_equal(k2, k3) and np.array_equal(s2, s3) and np.array_equal(mx2, mx) and np.array_equal(mn2, mn) and np.array_equal(c2, c3)
     # late aggregation: with LIMIT 10, max(c7) and min(c9) are computed for the ten surviving groups only (one pass over
     # c1 and k, hark_entry_filter_groupby_subset): the rows are the first ten of the unlimited ordered statement, bit for bit
     stmt3 = "select k, sum(c3), max(c7), min(c9), count(*) from t where c1 > 0.5 group by k having count(*) > 250 order by sum(c3) desc"

@@ -377,17 +377,20 @@ def test_statistics_of_one_column_in_one_pass(skew):
             assert np.array_equal(got.astype(np.int64), e.astype(np.int64)), name
 
 
-@pytest.mark.parametrize("mode", ["pair", "skew", "no-pair", "and-list"])
-def test_two_aggregates_of_two_columns_in_one_pass(mode):
-    """Aggregates of DIFFERENT columns over a large dense key domain pair up: (SUM or AVG, MAX or MIN) and (MAX / MIN,
-    MAX / MIN) come from one producer + consumer pass each (k_fgb_dense_pair, 10-byte pairs); heavily skewed keys make
-    that pass decline, HARK_NO_PAIR_PASS switches it off, an AND-list runs it over the survivor bitmask: same rows."""
+@pytest.mark.parametrize("mode", ["shared", "skew", "no-pair", "no-triple", "and-list"])
+def test_aggregates_of_two_or_three_columns_in_one_pass(mode):
+    """Aggregates of DIFFERENT columns over a large dense key domain share passes over the rows: (SUM or AVG or MAX / MIN,
+    MAX / MIN, MAX / MIN) triples first (k_fgb_dense_multi, 14-byte entries), then (x, MAX / MIN) pairs (10-byte entries),
+    single passes for the rest -- aggregates of eight columns in three passes instead of eight.  Heavily skewed keys make
+    the shared passes decline, HARK_NO_PAIR_PASS / HARK_NO_TRIPLE_PASS switch them off, an AND-list runs them over the
+    survivor bitmask: same rows."""
     import os
     import subprocess
     import sys
-    if mode == "no-pair" and not os.environ.get("HARK_NO_PAIR_PASS"):
-        env = dict(os.environ, HARK_NO_PAIR_PASS="1")
-        out = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", __file__, "-k", "test_two_aggregates_of_two_columns_in_one_pass and no-pair", "-m", "gpu"],
+    knob = {"no-pair": "HARK_NO_PAIR_PASS", "no-triple": "HARK_NO_TRIPLE_PASS"}.get(mode)
+    if knob and not os.environ.get(knob):
+        env = dict(os.environ, **{knob: "1"})
+        out = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", __file__, "-k", "test_aggregates_of_two_or_three_columns_in_one_pass and " + mode, "-m", "gpu"],
                              capture_output=True, text=True, timeout=600, env=env)
         assert out.returncode == 0, out.stdout + out.stderr
         return
@@ -399,14 +402,20 @@ def test_two_aggregates_of_two_columns_in_one_pass(mode):
         k[: n // 2] = 12345                                           # half of the rows on one key: rings / slabs overflow
     df = pd.DataFrame({"k": k, "p": rng.random(n).astype(np.float32), "a": (rng.integers(-500, 500, n) / 4).astype(np.float32),
                        "b": rng.normal(size=n).astype(np.float32), "i": rng.integers(-10**6, 10**6, n).astype(np.int32),
-                       "u": rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32), "j": rng.integers(-50, 50, n).astype(np.int32)})
+                       "u": rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32), "j": rng.integers(-50, 50, n).astype(np.int32),
+                       "e": rng.normal(size=n).astype(np.float32), "f": rng.integers(0, 1000, n).astype(np.int32)})
     c = FutharkContext(sql_mode=True)
     c.create_table("t", df)
     where, keep = ("p > 0.3 and j < 20", (df.p > 0.3) & (df.j < 20)) if mode == "and-list" else ("p > 0.3", df.p > 0.3)
-    names, cols = c.sql_columns("select k, sum(a), max(b), min(i), count(*), avg(i), max(u), min(b), sum(j), max(a) from t where " + where + " group by k")
-    g = df[keep].groupby("k").agg(sa=("a", "sum"), mxb=("b", "max"), mni=("i", "min"), n=("a", "count"), avi=("i", "mean"), mxu=("u", "max"),
-                                  mnb=("b", "min"), sj=("j", "sum"), mxa=("a", "max")).reset_index()
-    exp = [g.k, g.sa, g.mxb, g.mni, g.n, g.avi, g.mxu, g.mnb, g.sj, g.mxa]
+    names, cols = c.sql_columns("select k, sum(a), max(b), min(i), count(*), avg(j), max(u), min(e), sum(f), max(p) from t where " + where + " group by k")
+    passes = c.FutEnv.last_groupby_passes()
+    assert c.FutEnv.last_groupby_path() == "dense"
+    # triple (sum a, max b, min i) + triple (avg j, max u, min e) + pair (sum f, max p); pairs only: (sum a, max b), (avg j, min i),
+    # (sum f, max u), (min e, max p); neither: one pass per column
+    assert passes == {"shared": 3, "and-list": 3, "no-triple": 4, "no-pair": 8, "skew": 8}[mode], passes
+    g = df[keep].groupby("k").agg(sa=("a", "sum"), mxb=("b", "max"), mni=("i", "min"), n=("a", "count"), avj=("j", "mean"), mxu=("u", "max"),
+                                  mne=("e", "min"), sf=("f", "sum"), mxp=("p", "max")).reset_index()
+    exp = [g.k, g.sa, g.mxb, g.mni, g.n, g.avj, g.mxu, g.mne, g.sf, g.mxp]
     assert len(cols) == len(exp)
     for got, e, name in zip(cols, exp, names):
         e = e.to_numpy()
