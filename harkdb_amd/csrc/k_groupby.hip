@@ -1469,6 +1469,29 @@ int ref_groupby_dense(hark_context *ctx, const hark_table *view, const hark_tabl
             served[t] = 1;
         }
     }
+    // triple passes (k_fgb_dense_multi): a sum / max / min with two other max / min from ONE producer + consumer pass (14-byte
+    // entries; every row survives here, so the plan's slabs are sized for them); declines for small G or skew
+    while (!rc) {
+        const size_t none = aggs.size();
+        size_t j = none, q1 = none, q2 = none;
+        auto ext = [&](size_t t) { return vop_of(t) == 2 || vop_of(t) == 3; };
+        for (size_t t = 0; t < aggs.size() && j == none; t++) if (!served[t] && vop_of(t) == 1) j = t;
+        for (size_t t = 0; t < aggs.size() && j == none; t++) if (!served[t] && ext(t)) j = t;
+        for (size_t t = 0; j != none && t < aggs.size() && q1 == none; t++) if (t != j && !served[t] && ext(t)) q1 = t;
+        for (size_t t = 0; q1 != none && t < aggs.size() && q2 == none; t++) if (t != j && t != q1 && !served[t] && ext(t)) q2 = t;
+        if (q2 == none) break;
+        if (plan->slack_pct < 230) rc = hark_fgb_plan_set(plan, "slack_pct", 230);
+        if (rc) break;
+        bool ran = false;
+        rc = k_fgb_dense_multi(ctx, plan, nullptr, 0, 0.0f, reinterpret_cast<const int32_t *>(keys), view->cols[aggs[j].col].data, vop_of(j), 0,
+                               view->cols[aggs[q1].col].data, vop_of(q1), 0, view->cols[aggs[q2].col].data, vop_of(q2), 0, n, &ran);
+        if (rc || !ran) break;
+        for (size_t t : {j, q1, q2}) if (!rc) rc = hark_alloc(ctx, (void **)&vals[t], (size_t)G * 4);
+        if (!rc) rc = hark_fgb_finish_u32(ctx, plan, vals[j], nullptr);
+        if (!rc) rc = hark_fgb_finish_u32_of(ctx, plan, 1, vals[q1]);
+        if (!rc) rc = hark_fgb_finish_u32_of(ctx, plan, 2, vals[q2]);
+        served[j] = served[q1] = served[q2] = 1;
+    }
     // pair passes (k_fgb_dense_pair): a sum / max / min with another max / min from ONE producer + consumer pass; value 2
     // must be a max or min (a 32-bit LDS slot), products keep their own pass.  Declines for small G or skew.
     for (size_t j = 0; j < aggs.size() && !rc; j++) {

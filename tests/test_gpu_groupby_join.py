@@ -85,6 +85,22 @@ def test_query_groupby_several_aggregates_of_one_column(eng, oracle, n, G):
     assert got.shape == exp.shape and np.array_equal(got, exp)
 
 
+@pytest.mark.parametrize("n,G,skew", [(1_300_000, 1 << 20, False), (700_001, 50_000, False), (900_000, 1 << 18, True), (300_000, 9000, False)])
+def test_query_groupby_three_columns_in_one_pass(eng, oracle, n, G, skew):
+    """sum / max / min of THREE different columns come from one triple pass (14-byte entries, every row survives), the next two
+    from a pair pass; skewed keys (a third of the rows on one key) and a small G decline it -- the same table either way."""
+    rng = np.random.default_rng(n % 991 + G)
+    db = rng.integers(0, 2**32, size=(n, 6), dtype=np.uint64).astype(np.uint32)
+    db[:, 0] = rng.integers(0, G, size=n)
+    if skew:
+        db[: n // 3, 0] = 4242
+    t = eng.table_from_matrix(db, np.uint32)
+    for s_cols, t_cols in (([1, 2, 3], [2, 3, 4]), ([5, 4, 3, 2, 1], [4, 3, 4, 3, 2]), ([1, 2, 3, 4, 5, 1], [3, 3, 4, 4, 1, 9])):
+        got = eng.query_groupby(t, 0, s_cols, t_cols).to_numpy(np.uint32)
+        exp = oracle.query_groupby(db, 0, s_cols, t_cols)
+        assert got.shape == exp.shape and np.array_equal(got, exp), (s_cols, t_cols)
+
+
 @pytest.mark.parametrize("n,ndistinct", [(400_000, 1000), (2_000_000, 500_000), (3_000_000, 3_000_000), (600_000, 3)])
 def test_query_groupby_sparse_keys_hash_path(eng, oracle, n, ndistinct):
     """Sparse u32 keys (anywhere in [0, 2^32)) with >= 2^18 rows: hash partition + LDS hash

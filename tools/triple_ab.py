@@ -40,3 +40,28 @@ for thr in (0.5, 0.1, 0.9):
         if ref is None:
             ref = got
         print(f"where p > {thr}: {name:22s} {ms:7.3f} ms  passes {passes}  rows {len(got[0])}  equal to the first mode: {same}", flush=True)
+
+# ---- the reference's entry: query_groupby(db, 0, [1, 2, 3], [sum, max, min]) over 1e8 rows x 4 u32 columns, 2^20 dense keys:
+#      every row survives (no WHERE in the reference), 14 B per row of partition traffic both ways
+t.free()
+del cols, key
+torch.cuda.empty_cache()
+n = int(1e8 * scale) // 4 * 4
+u = [torch.randint(0, 2**31, (n,), dtype=torch.int32, device=dev) for _ in range(3)]
+kk = torch.randint(0, G, (n,), dtype=torch.int32, device=dev)
+t = eng.table_from_device(n, [kk.data_ptr()] + [c.data_ptr() for c in u], [np.uint32] * 4)
+ref = None
+for name, env in modes:
+    os.environ.update(env)
+
+    def run():
+        eng.query_groupby(t, 0, [1, 2, 3], [2, 3, 4]).free()
+
+    ms = bench.event_ms(torch, run, warm=1, reps=reps)
+    got = eng.query_groupby(t, 0, [1, 2, 3], [2, 3, 4]).to_numpy(np.uint32)
+    for k in env:
+        del os.environ[k]
+    same = True if ref is None else np.array_equal(ref, got)
+    if ref is None:
+        ref = got
+    print(f"query_groupby sum, max, min of three columns, {n} rows: {name:22s} {ms:7.3f} ms  rows {len(got)}  equal to the first mode: {same}", flush=True)
