@@ -161,7 +161,7 @@ enum { HARK_HASH_FITS = 0, HARK_HASH_NOFIT_DISTINCT = 1 /* too many distinct key
 int k_fgb_hash_u32(hark_context *ctx, const uint32_t *k, const uint32_t *v, int64_t n, int vop, int xf,
                    uint32_t **keys_out, unsigned long long **vals_out, unsigned long long **cnts_out, int64_t *G_out, bool *fits,
                    uint32_t *rounds_hint, bool compact, hark_hash_part *part = nullptr, int *why_not = nullptr, const hark_row_pred *pred = nullptr,
-                   int stats_vk = -1, unsigned long long **mins_out = nullptr, unsigned long long **maxs_out = nullptr);
+                   int stats_vk = -1, unsigned long long **mins_out = nullptr, unsigned long long **maxs_out = nullptr, uint32_t ref_ops = 0);
 
 int k_fgb_dense_stats(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cmp, float thr,
                       const int32_t *k, const void *v, int64_t n, int vk, bool *ran);

@@ -1597,6 +1597,112 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash_stats_kernel(
     }
 }
 
+// Two or three of the reference's u32 operators (groupby.fut:35-41) over ONE value column from one pass over its pairs:
+// an entry is a tag and one 32-bit slot per operator -- 12 B in 1536 groups of eight (144 KiB) or 16 B in 1152 groups
+// (144 KiB), half of them used per round (6144 / 4608 distinct keys per bucket: 2^21 keys in 512 buckets take ONE round) --
+// instead of one consumer pass and one sort of the result keys per operator.  ops: operator of slot j in byte j
+// (VOP_U32SUM / MAX / MIN / PROD).  Emits slot 0 | slot 1 << 32 as the value word and slot 2 as the count word.
+template <int NOPS> struct HashOpsGeo { static constexpr int groups = NOPS == 2 ? 1536 : 1152, cap = groups * 8, fill = cap / 2; };
+__device__ __forceinline__ void op32_atomic(int vop, uint32_t *slot, uint32_t x)
+{
+    if (vop == VOP_U32SUM) atomicAdd(slot, x);
+    else if (vop == VOP_U32MAX) atomicMax(slot, x);
+    else if (vop == VOP_U32MIN) atomicMin(slot, x);
+    else { uint32_t old = *slot, assumed; do { assumed = old; old = atomicCAS(slot, assumed, assumed * x); } while (old != assumed); }
+}
+template <int NOPS>
+__global__ __launch_bounds__(1024) void fgb_agg_hash_ops_kernel(
+    const uint2 *__restrict__ pbuf, const uint32_t *__restrict__ counts, uint32_t cap, int nwg, uint32_t Rmask, uint32_t r,
+    uint32_t *__restrict__ out_key, u64 *__restrict__ out_val, u64 *__restrict__ out_cnt,
+    unsigned long long *__restrict__ out_cursor, unsigned long long out_cap, int32_t *__restrict__ err, uint32_t ops)
+{
+    constexpr int kCap = HashOpsGeo<NOPS>::cap, kGroups = HashOpsGeo<NOPS>::groups, kFill = HashOpsGeo<NOPS>::fill;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    uint32_t *t_tag = reinterpret_cast<uint32_t *>(lds_raw);             // [kCap] low bits of mix32(key) | 2^31, 0 = empty (groups are read as two uint4)
+    uint32_t *t_a = t_tag + kCap, *t_b = t_a + kCap, *t_c = t_b + kCap;  // [kCap] each; t_c with three operators only
+    __shared__ uint32_t s_used, s_emit;
+    __shared__ unsigned long long s_base;
+    const uint32_t b = blockIdx.x;
+    const int lowbits = 33 - __ffs((int)gridDim.x);
+    const uint32_t lowmask = (1u << lowbits) - 1u;
+    const int op_a = (int)(ops & 255u), op_b = (int)((ops >> 8) & 255u), op_c = (int)((ops >> 16) & 255u);
+    const uint32_t id_a = (uint32_t)vop_identity(op_a), id_b = (uint32_t)vop_identity(op_b), id_c = (uint32_t)vop_identity(op_c);
+    for (int i = threadIdx.x; i < kCap; i += blockDim.x) { t_tag[i] = 0u; t_a[i] = id_a; t_b[i] = id_b; if constexpr (NOPS == 3) t_c[i] = id_c; }
+    if (threadIdx.x == 0) { s_used = 0u; s_emit = 0u; }
+    __syncthreads();
+    bool overflow = false;
+    constexpr int kNP = 8;
+    uint4 *t_tag4 = reinterpret_cast<uint4 *>(t_tag);
+    struct Tags8 { uint4 a, b; };
+    auto load8 = [&](uint32_t g) -> Tags8 { return Tags8{t_tag4[2u * g], t_tag4[2u * g + 1u]}; };
+    auto find8 = [](const Tags8 &q, uint32_t t) -> int {
+        return q.a.x == t ? 0 : q.a.y == t ? 1 : q.a.z == t ? 2 : q.a.w == t ? 3 : q.b.x == t ? 4 : q.b.y == t ? 5 : q.b.z == t ? 6 : q.b.w == t ? 7 : -1;
+    };
+    auto hit = [&](uint32_t slot, uint32_t x) {
+        op32_atomic(op_a, &t_a[slot], x); op32_atomic(op_b, &t_b[slot], x);
+        if constexpr (NOPS == 3) op32_atomic(op_c, &t_c[slot], x);
+    };
+    auto slow = [&](uint32_t tag, uint32_t g, Tags8 q, uint32_t x) {         // (as in fgb_agg_hash_kernel)
+        for (uint32_t step = 0; step < 8u * (uint32_t)kGroups; step++) {
+            const int at = find8(q, tag);
+            if (at >= 0) { hit(8u * g + (uint32_t)at, x); return; }
+            const int e = find8(q, 0u);
+            if (e >= 0) {
+                if (s_used >= (uint32_t)kFill) { overflow = true; return; }
+                const uint32_t old = atomicCAS(&t_tag[8u * g + (uint32_t)e], 0u, tag);
+                if (old == 0u) { atomicAdd(&s_used, 1u); hit(8u * g + (uint32_t)e, x); return; }
+                if (old == tag) { hit(8u * g + (uint32_t)e, x); return; }
+            } else g = g + 1u == (uint32_t)kGroups ? 0u : g + 1u;
+            q = load8(g);
+        }
+        overflow = true;
+    };
+    auto probe = [&](const uint32_t (&key)[kNP], const uint32_t (&vb)[kNP], uint32_t live) {
+        uint32_t tag[kNP], g[kNP]; Tags8 q[kNP];
+#pragma unroll
+        for (int j = 0; j < kNP; j++) {
+            const uint32_t m = mix32(key[j]);
+            tag[j] = (m & lowmask) | 0x80000000u;
+            g[j] = __umulhi(m * 0x9E3779B1u, (uint32_t)kGroups);             // not a power of two
+            if (Rmask && (mix32(key[j] ^ 0x9E3779B9u) & Rmask) != r) live &= ~(1u << j);
+        }
+#pragma unroll
+        for (int j = 0; j < kNP; j++) q[j] = load8(g[j]);
+        uint32_t miss = 0;
+#pragma unroll
+        for (int j = 0; j < kNP; j++) {
+            const int at = find8(q[j], tag[j]);
+            if ((live >> j) & 1u) { if (at >= 0) hit(8u * g[j] + (uint32_t)at, vb[j]); else miss |= 1u << j; }
+        }
+        if (__any(miss != 0u)) {
+#pragma unroll
+            for (int j = 0; j < kNP; j++) if ((miss >> j) & 1u) slow(tag[j], g[j], q[j], vb[j]);
+        }
+    };
+    walk_pair_slabs(pbuf, counts, cap, nwg, b, [&](const uint32_t (&key)[kNP], const uint32_t (&vb)[kNP], uint32_t live) -> bool {
+        probe(key, vb, live);
+        return !__any(overflow);
+    });
+    if (overflow) *err = kErrOverflow;
+    __syncthreads();
+    uint32_t mine = 0;
+    for (int i = threadIdx.x; i < kCap; i += blockDim.x) mine += t_tag[i] ? 1u : 0u;
+    uint32_t pos = mine ? atomicAdd(&s_emit, mine) : 0u;
+    __syncthreads();
+    if (threadIdx.x == 0) s_base = s_emit ? atomicAdd(out_cursor, (unsigned long long)s_emit) : 0ull;
+    __syncthreads();
+    for (int i = threadIdx.x; i < kCap; i += blockDim.x) {
+        const uint32_t t = t_tag[i];
+        if (!t) continue;
+        const unsigned long long o = s_base + pos++;
+        if (o < out_cap) {
+            out_key[o] = unmix32((b << lowbits) | (t & lowmask));
+            out_val[o] = (u64)t_a[i] | ((u64)t_b[i] << 32);
+            out_cnt[o] = NOPS == 3 ? (u64)t_c[i] : 0ull;
+        } else *err = kErrOverflow;
+    }
+}
+
 // Compact hash consumer for the reference's u32 operators (groupby.fut:35-41: wrapping * and +, max, min; no row
 // counts): an entry is ONE 64-bit word, value << 32 | occupied << 24 | low 24 bits of mix32(key).  Inside bucket b the
 // top log2(P) >= 8 bits of mix32(key) are b, and mix32 is a bijection, so 24 bits identify the key (it is rebuilt by unmix32 at
@@ -2394,16 +2500,20 @@ int k_fgb_hash_u32(hark_context *ctx, const uint32_t *k, const uint32_t *v, int6
                                                 survivor bitmask with HARK_CMP_MASK -- only surviving rows are partitioned */,
                    int stats_vk /* >= 0: ONE statistics pass (fgb_agg_hash_stats_kernel) over raw values of kind 0 f32 / 1 i32 / 2 u32:
                                     *vals_out = 64-bit sums, *mins_out / *maxs_out = order words; vop / xf / compact are ignored */,
-                   unsigned long long **mins_out, unsigned long long **maxs_out)
+                   unsigned long long **mins_out, unsigned long long **maxs_out,
+                   uint32_t ref_ops /* != 0: two or three of the reference's u32 operators over v in ONE pass (fgb_agg_hash_ops_kernel): operator of
+                                       slot j in byte j; *vals_out = slot 0 | slot 1 << 32, *cnts_out = slot 2; vop / xf / compact are ignored */)
 {
     const bool stats = stats_vk >= 0;
+    const int nops = ref_ops == 0 ? 0 : (ref_ops >> 16) ? 3 : 2;
     if (stats) { compact = false; *mins_out = nullptr; *maxs_out = nullptr; }
+    if (nops) { compact = false; xf = 0; }
     const float *pp = pred ? pred->p : nullptr;
     const int pcmp = pred ? pred->cmp : 0;
     const float pthr = pred ? pred->thr : 0.0f;
     if (why_not) *why_not = HARK_HASH_FITS;
     if (compact && (xf != 0 || !(vop == VOP_U32SUM || vop == VOP_U32MAX || vop == VOP_U32MIN || vop == VOP_U32PROD))) compact = false;
-    const int fill = stats ? kHashSFill : compact ? kHash8Fill : kHashFill;
+    const int fill = stats ? kHashSFill : nops == 2 ? HashOpsGeo<2>::fill : nops == 3 ? HashOpsGeo<3>::fill : compact ? kHash8Fill : kHashFill;
     *keys_out = nullptr; *vals_out = nullptr; *cnts_out = nullptr; *G_out = 0; *fits = false;
     if (n <= 0 || n > 0xFFFFFFFFll) { if (why_not) *why_not = HARK_HASH_NOFIT_ROWS; return HARK_OK; }
     // 512 buckets of 32-pair rings (256 x 64 before): half as many distinct keys per bucket -- 2^21 distinct keys fit ONE
@@ -2475,6 +2585,20 @@ int k_fgb_hash_u32(hark_context *ctx, const uint32_t *k, const uint32_t *v, int6
                     return HARK_OK;
                 };
                 r2 = stats_vk == 0 ? go(std::integral_constant<int, 0>{}) : stats_vk == 1 ? go(std::integral_constant<int, 1>{}) : go(std::integral_constant<int, 2>{});
+                if (!r2) r2 = read_err(&e);
+                return r2;
+            }
+            if (nops) {
+                auto go = [&](auto nc) -> int {
+                    constexpr int NOPS = decltype(nc)::value;
+                    const size_t lds_o = (size_t)HashOpsGeo<NOPS>::cap * 4 * (NOPS + 1);
+                    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_agg_hash_ops_kernel<NOPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_o));
+                    for (uint32_t r = r_begin; r < r_end; r++)
+                        fgb_agg_hash_ops_kernel<NOPS><<<dim3((unsigned)P), dim3(1024), lds_o, st>>>(pbuf, counts, (uint32_t)cap, nwg, R - 1, r, okey, oval, ocnt, cursor, out_cap, err, ref_ops);
+                    HIP_TRY(ctx, hipGetLastError());
+                    return HARK_OK;
+                };
+                r2 = nops == 2 ? go(std::integral_constant<int, 2>{}) : go(std::integral_constant<int, 3>{});
                 if (!r2) r2 = read_err(&e);
                 return r2;
             }

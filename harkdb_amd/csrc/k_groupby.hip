@@ -1561,11 +1561,13 @@ namespace {
 
 constexpr int64_t kHashMinRows = (int64_t)1 << 18;          // below this the sort-based path is as good
 
-__global__ __launch_bounds__(256) void gather_low32_kernel(const unsigned long long *__restrict__ vals, const uint32_t *__restrict__ perm,
-                                                           uint32_t *__restrict__ out, int64_t n)
+// out[i] = 32-bit word `word` (0 low, 1 high) of vals[perm[i]]
+__global__ __launch_bounds__(256) void gather_word32_kernel(const unsigned long long *__restrict__ vals, const uint32_t *__restrict__ perm,
+                                                            uint32_t *__restrict__ out, int64_t n, int word)
 {
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(vals);
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = (uint32_t)vals[perm[i]];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = w[2 * (size_t)perm[i] + word];
 }
 
 int ref_groupby_hash(hark_context *ctx, const hark_table *view, const hark_table *stats_owner, int g_col, const std::vector<AggSpec> &aggs,
@@ -1590,13 +1592,20 @@ int ref_groupby_hash(hark_context *ctx, const hark_table *view, const hark_table
     if (!aggs.empty()) std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return aggs[a].col < aggs[b].col; });   // ... so column by column
     bool first_pass = true;
     int why = HARK_HASH_FITS;
-    for (size_t oi = 0; oi < runs && !rc && ok; oi++) {
-        const size_t j = order[oi];
-        const int vop = aggs.empty() ? 3 : aggs[j].op == OP_SUM ? 1 : aggs[j].op == OP_MAX ? 2 : aggs[j].op == OP_MIN ? 3 : 4;
-        const uint32_t *col = aggs.empty() ? keys : static_cast<const uint32_t *>(view->cols[aggs[j].col].data);
+    auto vop_of = [&](size_t j) { return aggs.empty() ? 3 : aggs[j].op == OP_SUM ? 1 : aggs[j].op == OP_MAX ? 2 : aggs[j].op == OP_MIN ? 3 : 4; };
+    // aggregates of one column come from ONE consumer pass, two or three operators at a time (fgb_agg_hash_ops_kernel), with
+    // ONE sort of the result keys per pass; a single operator keeps the 8-byte tables (fgb_agg_hash8_kernel: twice the entries)
+    for (size_t oi = 0; oi < runs && !rc && ok; ) {
+        size_t cnt = 1;
+        if (!aggs.empty() && !getenv("HARK_NO_HASH_OPS_PASS"))
+            while (cnt < 3 && oi + cnt < runs && aggs[order[oi + cnt]].col == aggs[order[oi]].col) cnt++;
+        const size_t j0 = order[oi];
+        const uint32_t *col = aggs.empty() ? keys : static_cast<const uint32_t *>(view->cols[aggs[j0].col].data);
+        uint32_t ops = 0;
+        for (size_t q = 0; q < cnt && cnt > 1; q++) ops |= (uint32_t)vop_of(order[oi + q]) << (8 * q);
         uint32_t *hk = nullptr, *perm = nullptr; unsigned long long *hv = nullptr, *hc = nullptr;
         int64_t Gj = 0;
-        rc = k_fgb_hash_u32(ctx, keys, col, n, vop, 0, &hk, &hv, &hc, &Gj, &ok, &rounds, true, &part, &why);   // u32 operators, no counts: 8-byte table entries
+        rc = k_fgb_hash_u32(ctx, keys, col, n, vop_of(j0), 0, &hk, &hv, &hc, &Gj, &ok, &rounds, true, &part, &why, nullptr, -1, nullptr, nullptr, ops);   // u32 operators, no counts
         if (!rc && ok) {
             if (G < 0) {
                 G = Gj;
@@ -1610,10 +1619,12 @@ int ref_groupby_hash(hark_context *ctx, const hark_table *view, const hark_table
             if (!rc && G > 0) {
                 if (first_pass) rc = k_gather(ctx, hk, 4, perm, res->cols[0].data, G);
                 first_pass = false;
-                if (!rc && !aggs.empty()) gather_low32_kernel<<<grid_for(ctx, G), 256, 0, ctx->stream>>>(hv, perm, static_cast<uint32_t *>(res->cols[j + 1].data), G);
+                for (size_t q = 0; q < cnt && !rc && !aggs.empty(); q++)       // slot 0: low word of hv, slot 1: its high word, slot 2: low word of hc
+                    gather_word32_kernel<<<grid_for(ctx, G), 256, 0, ctx->stream>>>(q < 2 ? hv : hc, perm, static_cast<uint32_t *>(res->cols[order[oi + q] + 1].data), G, q == 1 ? 1 : 0);
             }
         }
         hark_free(ctx, hk); hark_free(ctx, hv); hark_free(ctx, hc); hark_free(ctx, perm);
+        oi += cnt;
     }
     k_fgb_hash_part_free(ctx, &part);
     // the verdict stays with the key column (hark_internal.h: sticky until hark_table_invalidate_stats) -- unless nothing

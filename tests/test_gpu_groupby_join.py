@@ -119,6 +119,24 @@ def test_query_groupby_sparse_keys_hash_path(eng, oracle, n, ndistinct):
     assert got.shape == exp.shape and np.array_equal(got, exp)
 
 
+@pytest.mark.parametrize("n,ndistinct", [(500_000, 70_000), (2_500_000, 2_200_000), (4_000_000, 4_000_000)])
+def test_query_groupby_sparse_keys_several_operators_of_one_column(eng, oracle, n, ndistinct):
+    """Two or three operators of ONE column over sparse keys come from one consumer pass (12- / 16-byte table entries, one
+    sort of the result keys), a fourth takes the next pass; products wrap mod 2^32 through an LDS compare-and-swap; more
+    distinct keys per bucket than a table holds take several rounds.  Bit for bit the oracle's table."""
+    rng = np.random.default_rng(n % 983 + ndistinct)
+    pool = rng.integers(0, 2**32, size=ndistinct, dtype=np.uint64).astype(np.uint32)
+    db = rng.integers(0, 2**32, size=(n, 3), dtype=np.uint64).astype(np.uint32)
+    db[:, 0] = pool[rng.integers(0, ndistinct, size=n)] if ndistinct < n else rng.permutation(pool)
+    db[:, 2] = rng.integers(0, 3, size=n) * 2 + 1
+    t = eng.table_from_matrix(db, np.uint32)
+    for s_cols, t_cols in (([1, 1], [2, 3]), ([2, 1, 2, 1, 2, 2], [1, 4, 2, 2, 3, 4]), ([1, 1, 1, 1], [3, 4, 2, 3])):
+        got = eng.query_groupby(t, 0, s_cols, t_cols).to_numpy(np.uint32)
+        assert eng.last_groupby_path() == "hash"
+        exp = oracle.query_groupby(db, 0, s_cols, t_cols)
+        assert got.shape == exp.shape and np.array_equal(got, exp), (s_cols, t_cols)
+
+
 def test_query_groupby_int32_table_is_viewed_as_u32(eng, oracle):
     """The Python layer uploads int32 columns; groupby.fut:51 reads them as u32."""
     rng = np.random.default_rng(3)
