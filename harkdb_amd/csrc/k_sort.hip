@@ -873,7 +873,8 @@ __global__ __launch_bounds__(GeoTuple::T) void tuple_scatter_kernel(
 // the run that are smaller by (key, position).  No lane waits for another one's sorting network; sequential reads, writes
 // within a run's span.  A run longer than kRunMax raises *too_long (the caller takes the general path).
 __global__ __launch_bounds__(256) void tuple_fix_runs_kernel(const uint4 *__restrict__ tin, uint64_t *__restrict__ keys_out, uint32_t *__restrict__ perm_out,
-                                                             uint32_t *__restrict__ val_out, int64_t n, int32_t *__restrict__ too_long, uint32_t prefix_mask)
+                                                             uint32_t *__restrict__ val_out, int64_t n, int32_t *__restrict__ too_long, uint32_t prefix_mask,
+                                                             uint64_t out_xor /* the keys are written as key ^ out_xor (the ORDER BY entry takes its bias off here) */)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     auto hi_of = [&](int64_t j) { return reinterpret_cast<const uint32_t *>(tin + j)[1] & prefix_mask; };
@@ -895,7 +896,7 @@ __global__ __launch_bounds__(256) void tuple_fix_runs_kernel(const uint4 *__rest
             at += (kj < key || (kj == key && j < i)) ? 1 : 0;
             if (kj == key) too_long[1] = 1;                          // equal keys exist (benign race: every writer stores 1): the join wants to know
         }
-        keys_out[at] = key; perm_out[at] = t.z;
+        keys_out[at] = key ^ out_xor; perm_out[at] = t.z;
         if (val_out) val_out[at] = t.w;
     }
 }
@@ -1109,7 +1110,7 @@ static int k_sort_column_lsd(hark_context *ctx, const void *col, int dtype, int6
     return HARK_OK;
 }
 
-int k_argsort_i64_keys(hark_context *ctx, const void *col, int64_t n, uint32_t **perm_out, uint64_t **keys_out, const uint32_t *valcol, uint32_t **val_out, int *unique_out);
+int k_argsort_i64_keys(hark_context *ctx, const void *col, int64_t n, uint32_t **perm_out, uint64_t **keys_out, const uint32_t *valcol, uint32_t **val_out, int *unique_out, bool *plain_out = nullptr);
 
 // Stable sort of a column with a 32-bit payload (see k_sort_column_lsd).  An ascending argsort of an i64 column takes
 // the high-word-first path of k_argsort_i64_keys (four passes + a run fix-up instead of eight passes).
@@ -1141,7 +1142,7 @@ int k_argsort_column(hark_context *ctx, const void *col, int dtype, int64_t n, b
 // (sort_i64_tuples): no random read anywhere.  On the other paths *val_out is a gather through the permutation.
 static int sort_i64_tuples(hark_context *ctx, const void *col, int64_t n, uint32_t diff_hi, const uint32_t *valcol,
                            uint64_t *keys, uint32_t **perm_out, uint32_t **val_out, bool *done, int *unique_out,
-                           uint64_t xorm = 0x8000000000000000ull /* keys_out holds key ^ xorm, ascending */)
+                           uint64_t xorm = 0x8000000000000000ull /* keys_out holds key ^ xorm, ascending */, uint64_t out_xor = 0 /* ... ^ out_xor */)
 {
     *done = false;
     if (n > 0xFFFFFFFFll) return HARK_OK;                          // 32-bit positions and row ids (the general path reports the limit)
@@ -1208,7 +1209,7 @@ static int sort_i64_tuples(hark_context *ctx, const void *col, int64_t n, uint32
     int64_t general = 0;
     if (he == hipSuccess) he = hipMemsetAsync(flag, 0, 16, st);
     if (he == hipSuccess) {
-        tuple_fix_runs_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(tin, keys, perm, val, n, flag, prefix_mask);
+        tuple_fix_runs_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(tin, keys, perm, val, n, flag, prefix_mask, out_xor);
         he = hipGetLastError();
     }
     if (he != hipSuccess) { cleanup(false); return hark_fail(ctx, HARK_EHIP, "sort: tuple pass failed: %s", hipGetErrorString(he)); }
@@ -1226,7 +1227,8 @@ static int sort_i64_tuples(hark_context *ctx, const void *col, int64_t n, uint32
 // Stable DESCENDING argsort of an i64 column by the tuple passes only: *keys_out holds ~(key ^ 2^63) ascending (the caller
 // undoes it), *done = false when the tuple path does not apply (equal high words, a long run of equal prefixes, no room) --
 // nothing is returned then and the caller takes its general path.
-int k_argsort_i64_desc_tuples(hark_context *ctx, const void *col, int64_t n, uint32_t **perm_out, uint64_t **keys_out, const uint32_t *valcol, uint32_t **val_out, bool *done)
+int k_argsort_i64_desc_tuples(hark_context *ctx, const void *col, int64_t n, uint32_t **perm_out, uint64_t **keys_out, const uint32_t *valcol, uint32_t **val_out, bool *done,
+                              uint64_t out_xor /* *keys_out is written ^ out_xor: 0x7FFF... gives the plain keys back */)
 {
     *perm_out = nullptr; *keys_out = nullptr; *done = false;
     if (val_out) *val_out = nullptr;
@@ -1236,15 +1238,17 @@ int k_argsort_i64_desc_tuples(hark_context *ctx, const void *col, int64_t n, uin
     if (passes_of(diff_hi) == 0u || getenv("HARK_SORT_NO_TUPLES")) return HARK_OK;
     uint64_t *keys = nullptr;
     HARK_TRY(hark_alloc(ctx, (void **)&keys, (size_t)n * 8));
-    const int rc = sort_i64_tuples(ctx, col, n, diff_hi, valcol, keys, perm_out, val_out, done, nullptr, 0x7FFFFFFFFFFFFFFFull);
+    const int rc = sort_i64_tuples(ctx, col, n, diff_hi, valcol, keys, perm_out, val_out, done, nullptr, 0x7FFFFFFFFFFFFFFFull, out_xor);
     if (rc || !*done) { hark_free(ctx, keys); return rc; }
     *keys_out = keys;
     return HARK_OK;
 }
 
 int k_argsort_i64_keys(hark_context *ctx, const void *col, int64_t n, uint32_t **perm_out, uint64_t **keys_out, const uint32_t *valcol, uint32_t **val_out,
-                       int *unique_out /* optional: 1 all keys distinct, 0 equal keys exist, -1 not determined (the permutation paths) */)
+                       int *unique_out /* optional: 1 all keys distinct, 0 equal keys exist, -1 not determined (the permutation paths) */,
+                       bool *plain_out /* optional: set when *keys_out holds the PLAIN keys (the tuple path took the bias off at its last write), else biased */)
 {
+    if (plain_out) *plain_out = false;
     *perm_out = nullptr; *keys_out = nullptr;
     if (val_out) *val_out = nullptr;
     if (unique_out) *unique_out = -1;
@@ -1257,7 +1261,8 @@ int k_argsort_i64_keys(hark_context *ctx, const void *col, int64_t n, uint32_t *
     rc = k_transform_keys(ctx, col, HARK_I64, 1, nullptr, n, &diff_hi);
     bool done = false;
     if (!rc && passes_of(diff_hi) != 0u && !getenv("HARK_SORT_I64_LSD") && !getenv("HARK_SORT_NO_TUPLES"))
-        rc = sort_i64_tuples(ctx, col, n, diff_hi, valcol, keys, perm_out, val_out, &done, unique_out);
+        rc = sort_i64_tuples(ctx, col, n, diff_hi, valcol, keys, perm_out, val_out, &done, unique_out, 0x8000000000000000ull, plain_out ? 0x8000000000000000ull : 0ull);
+    if (!rc && done && plain_out) *plain_out = true;
     if (!rc && !done && passes_of(diff_hi) != 0u && !getenv("HARK_SORT_I64_LSD")) {
         uint32_t *k0 = nullptr, *k1 = nullptr, *v0 = nullptr, *v1 = nullptr, *ws = nullptr; int32_t *flag = nullptr;
         const size_t b = (size_t)n * 4;
