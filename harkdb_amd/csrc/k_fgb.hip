@@ -2532,35 +2532,36 @@ int k_fgb_hash_u32(hark_context *ctx, const uint32_t *k, const uint32_t *v, int6
         rc = hark_alloc(ctx, (void **)&pbuf, (size_t)P * nwg * (size_t)cap * sizeof(uint2));
         if (!rc) rc = hark_alloc(ctx, (void **)&counts, (size_t)P * nwg * sizeof(uint32_t));
     }
-    if (!rc) rc = hark_alloc(ctx, (void **)&err, 16);
-    if (!rc) rc = hark_alloc(ctx, (void **)&cursor, 16);
-    auto read_err = [&](int32_t *e) -> int {
-        int64_t w = 0;
-        int r2 = hark_read_words(ctx, err, &w, 1);
-        *e = (int32_t)w;
+    // ONE block of status words, read back in ONE round trip per aggregation attempt (each costs ~25 us of idle device):
+    // word 0 the producer's error, word 1 the consumers', word 2 the output cursor (= groups emitted)
+    int32_t *perr = nullptr;
+    if (!rc) rc = hark_alloc(ctx, (void **)&perr, 32);
+    if (!rc) { err = perr + 2; cursor = reinterpret_cast<unsigned long long *>(perr) + 2; }
+    int64_t emitted = 0;
+    int32_t e = 0, e_prod = 0;
+    auto read_status = [&]() -> int {
+        int64_t w[3] = {0, 0, 0};
+        int r2 = hark_read_words(ctx, perr, w, 3);
+        e_prod = (int32_t)w[0]; e = e_prod ? e_prod : (int32_t)w[1]; emitted = w[2];
         return r2;
     };
-    int32_t e = 0;
     uint32_t used_R = 1;
-    if (!rc && reuse) hipMemsetAsync(err, 0, 16, st);
+    if (!rc) hipMemsetAsync(perr, 0, 32, st);
     if (!rc && !reuse) {
-        hipMemsetAsync(err, 0, 16, st);
         const size_t lds_part = part_lds_bytes(P, 0);
         rc = dispatch_op(pcmp, pp != nullptr, [&](auto op) -> int {
             constexpr int OP = decltype(op)::value;
             HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_part_kernel<OP, 2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part));
             fgb_part_kernel<OP, 2, 0><<<dim3((unsigned)nwg), dim3(kPartThreads), lds_part, st>>>(
                 pp, reinterpret_cast<const int32_t *>(k), reinterpret_cast<const float *>(v), 0, n, pthr, (int64_t)1 << 32, 0, P,
-                pbuf, counts, (uint32_t)cap, nullptr, nullptr, err, 0, vop, xf, hash_bits, 0);
+                pbuf, counts, (uint32_t)cap, nullptr, nullptr, perr, 0, vop, xf, hash_bits, 0);
             HIP_TRY(ctx, hipGetLastError());
             return HARK_OK;
         });
-        if (!rc) {
-            rc = read_err(&e);
-            if (!rc && e != 0 && why_not) *why_not = HARK_HASH_NOFIT_SKEW;          // a slab or a ring overflowed: the keys are skewed
-        }
+        // (the producer's error word is read together with the first aggregation's: a slab or ring overflow -- skewed keys --
+        // costs one wasted consumer pass on the way to the sort-based path instead of a round trip on every call)
     }
-    if (!rc && e == 0) {
+    if (!rc) {
         const size_t lds_hash = (size_t)kHashCap * 16;
         // run all rounds of an R-round aggregation; e != 0 afterwards means some table overflowed
         auto run_rounds = [&](uint32_t R, uint32_t r_begin, uint32_t r_end) -> int {
@@ -2573,7 +2574,7 @@ int k_fgb_hash_u32(hark_context *ctx, const uint32_t *k, const uint32_t *v, int6
             if (!r2 && stats) r2 = hark_alloc(ctx, (void **)&omin, (size_t)out_cap * 8);
             if (!r2 && stats) r2 = hark_alloc(ctx, (void **)&omax, (size_t)out_cap * 8);
             if (r2) return r2;
-            hipMemsetAsync(cursor, 0, 16, st); hipMemsetAsync(err, 0, 16, st);
+            hipMemsetAsync(perr + 2, 0, 24, st);                       // the consumers' error word and the cursor; the producer's word stays
             if (stats) {
                 const size_t lds_s = (size_t)kHashSCap * 24;
                 auto go = [&](auto vkc) -> int {
@@ -2585,7 +2586,7 @@ int k_fgb_hash_u32(hark_context *ctx, const uint32_t *k, const uint32_t *v, int6
                     return HARK_OK;
                 };
                 r2 = stats_vk == 0 ? go(std::integral_constant<int, 0>{}) : stats_vk == 1 ? go(std::integral_constant<int, 1>{}) : go(std::integral_constant<int, 2>{});
-                if (!r2) r2 = read_err(&e);
+                if (!r2) r2 = read_status();
                 return r2;
             }
             if (nops) {
@@ -2599,7 +2600,7 @@ int k_fgb_hash_u32(hark_context *ctx, const uint32_t *k, const uint32_t *v, int6
                     return HARK_OK;
                 };
                 r2 = nops == 2 ? go(std::integral_constant<int, 2>{}) : go(std::integral_constant<int, 3>{});
-                if (!r2) r2 = read_err(&e);
+                if (!r2) r2 = read_status();
                 return r2;
             }
             r2 = dispatch_vop(vop, [&](auto vopc) -> int {
@@ -2620,18 +2621,18 @@ int k_fgb_hash_u32(hark_context *ctx, const uint32_t *k, const uint32_t *v, int6
                 HIP_TRY(ctx, hipGetLastError());
                 return HARK_OK;
             });
-            if (!r2) r2 = read_err(&e);
+            if (!r2) r2 = read_status();
             return r2;
         };
         const uint32_t hint = rounds_hint ? *rounds_hint : 0u;
         used_R = hint ? hint : 1u;
         rc = run_rounds(used_R, 0, used_R);
-        if (!rc && e != 0 && !hint) {
+        if (!rc && e_prod != 0 && why_not) *why_not = HARK_HASH_NOFIT_SKEW;            // a slab or a ring overflowed: the keys are skewed
+        if (!rc && e != 0 && !hint && e_prod == 0) {
             // too many distinct keys for one round: estimate them from ONE round of a 64-round split (a 1/64 sample
             // of the key space), then run exactly the number of rounds that needs -- or give up right away
             rc = run_rounds(64, 0, 1);
-            int64_t sample = 0;
-            if (!rc && e == 0) rc = hark_read_words(ctx, cursor, &sample, 1);
+            const int64_t sample = emitted;
             if (!rc && e == 0) {
                 const double per_bucket = 64.0 * (double)sample / P * 1.3;
                 // every round re-reads the bucket's slabs (~0.35 ms per round and 1e8 rows): beyond kMaxRoundsWorth rounds the
@@ -2649,8 +2650,7 @@ int k_fgb_hash_u32(hark_context *ctx, const uint32_t *k, const uint32_t *v, int6
     }
     if (!rc && e != 0 && why_not && *why_not == HARK_HASH_FITS) *why_not = HARK_HASH_NOFIT_DISTINCT;   // the tables overflowed
     if (!rc && e == 0) {
-        int64_t G = 0;
-        rc = hark_read_words(ctx, cursor, &G, 1);
+        const int64_t G = emitted;
         if (!rc) {
             *keys_out = okey; *vals_out = oval; *cnts_out = ocnt; *G_out = G; *fits = true; okey = nullptr; oval = nullptr; ocnt = nullptr;
             if (stats) { *mins_out = omin; *maxs_out = omax; omin = nullptr; omax = nullptr; }
@@ -2663,7 +2663,7 @@ int k_fgb_hash_u32(hark_context *ctx, const uint32_t *k, const uint32_t *v, int6
         if (part) { part->pbuf = nullptr; part->counts = nullptr; }
         hark_free(ctx, pbuf); hark_free(ctx, counts);
     }
-    hark_free(ctx, err); hark_free(ctx, cursor);
+    hark_free(ctx, perr);
     hark_free(ctx, okey); hark_free(ctx, oval); hark_free(ctx, ocnt); hark_free(ctx, omin); hark_free(ctx, omax);
     return rc;
 }
