@@ -95,9 +95,11 @@ def case_groupby():
         k = rng.choice(rng.integers(0, 2**32, size=3, dtype=np.uint64).astype(np.uint32), size=n)
     v1 = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
     v2 = rng.integers(0, 7, n).astype(np.uint32) * 2 + 1
-    s_cols = [int(c) for c in rng.integers(1, 3, size=int(rng.integers(1, 4)))]
-    t_cols = [int(c) for c in rng.integers(1, 5, size=len(s_cols))]
-    t = eng.table_from_columns([k, v1, v2])
+    v3 = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
+    v4 = rng.integers(0, 1000, n).astype(np.uint32)
+    s_cols = [int(c) for c in rng.integers(1, 5, size=int(rng.integers(1, 7)))]     # up to six aggregates of four columns: statistics, triple, pair and
+    t_cols = [int(c) for c in rng.integers(1, 5, size=len(s_cols))]                 # multi-operator hash passes
+    t = eng.table_from_columns([k, v1, v2, v3, v4])
     res = eng.query_groupby(t, 0, s_cols, t_cols)
     got = [res.column(j) for j in range(1 + len(s_cols))]
     order = np.argsort(k, kind="stable")
@@ -105,7 +107,7 @@ def case_groupby():
     heads = np.flatnonzero(np.r_[True, ks[1:] != ks[:-1]])
     ok = np.array_equal(got[0].view(np.uint32), ks[heads])
     for j, (c, op) in enumerate(zip(s_cols, t_cols)):
-        v = [None, v1, v2][c][order].astype(np.uint64)
+        v = [None, v1, v2, v3, v4][c][order].astype(np.uint64)
         if op == 2:
             e = np.add.reduceat(v, heads) & M32
         elif op == 3:

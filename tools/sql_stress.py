@@ -19,7 +19,8 @@ while time.time() < t_end and bad is None:
         "a": rng.integers(-4, 5, n).astype(np.int32), "b": rng.integers(0, int(rng.choice([3, 50, 4000])), n).astype(np.int32),
         "s": (rng.integers(0, int(rng.choice([10, 3000, 200_000])), n) * 1_000_003 % (2**31)).astype(np.int32),
         "d": rng.integers(0, int(rng.choice([20_000, 300_000])), n).astype(np.int32),       # dense keys beyond the LDS path
-        "x": rng.integers(0, 64, n).astype(np.float32), "y": rng.integers(-1000, 1000, n).astype(np.int32), "p": rng.random(n).astype(np.float32)})
+        "x": rng.integers(0, 64, n).astype(np.float32), "y": rng.integers(-1000, 1000, n).astype(np.int32), "p": rng.random(n).astype(np.float32),
+        "z": rng.integers(0, 2**31, n).astype(np.int32), "w": (rng.integers(-300, 300, n) / 2).astype(np.float32)})
     fc.create_table("t", df)
     for _ in range(12):
         where_sql, mask = "", np.ones(n, bool)
@@ -33,8 +34,9 @@ while time.time() < t_end and bad is None:
         try:
             if kind in ("group", "multi"):
                 keys = [str(rng.choice(["a", "b", "s", "d", "d"]))] if kind == "group" else [str(c) for c in rng.choice(["a", "b", "s"], size=2, replace=False)]
-                aggs = [("sum", "x"), ("count", "*"), ("avg", "x"), ("max", "y"), ("min", "y"), ("sum", "y"), ("max", "x")]
-                pick = [aggs[i] for i in rng.choice(len(aggs), size=int(rng.integers(1, 4)), replace=False)]
+                # (aggregates of three and more different columns: triple and pair passes on the dense path)
+                aggs = [("sum", "x"), ("count", "*"), ("avg", "x"), ("max", "y"), ("min", "y"), ("sum", "y"), ("max", "x"), ("min", "z"), ("max", "z"), ("max", "w"), ("min", "w"), ("sum", "w")]
+                pick = [aggs[i] for i in rng.choice(len(aggs), size=int(rng.integers(1, 7)), replace=False)]
                 sel = keys + [f"{f}({c})" for f, c in pick]
                 stmt = f"select {', '.join(sel)} from t{where_sql} group by {', '.join(keys)}"
                 g = sub.groupby(keys, sort=True)
