@@ -63,22 +63,28 @@ constexpr int kStage = 12288, kStageCarry = 10240, kFine = 10240, kFineCarry = 6
 constexpr int stage_of(int extra_words) { return extra_words == 0 ? kStage : extra_words == 1 ? kStageCarry : 8192; }
 constexpr int fine_of(int extra_words) { return extra_words == 0 ? kFine : extra_words == 1 ? kFineCarry : 4096; }
 
-// Bins of a bucket's survivors: the bucket's len ranks are cut into nb <= kMaxBins ranges of 2^bs ranks (whole groups of the
-// coarse histogram: bs >= gs), as few as keep a bin's EXPECTED survivors under the order kernel's stage when every second
+// Bins of a bucket's survivors: the bucket's len ranks are cut into nb <= kMaxBins ranges of gw GROUPS of the coarse histogram
+// (2^gs ranks each), as few as keep a bin's EXPECTED survivors a twelfth under the order kernel's stage when every second
 // probe pair of the bucket finds a partner and the partners are spread evenly; a fuller bin simply takes several sub-rounds
-// in the order kernel.  Both kernels derive the geometry from the same inputs (the bucket kernel publishes it in sbinfo).
-struct JBins { int gs, bs, nb; uint32_t cap; };
+// in the order kernel -- each of which sweeps the WHOLE bin, which is why the width is any number of groups and not a power
+// of two: with 2^bs ranks per bin BASELINE configs[3] landed on 12 bins of 10.2 K survivors for a stage of 8192, every bin
+// took two sub-rounds and the order kernel read its survivors four times instead of twice (2.66 GB against 1.4 GB by the
+// counters).  Both kernels derive the geometry from the same inputs.
+struct JBins {
+    int gs, nb; uint32_t gw, magic, cap;
+    __device__ __forceinline__ uint32_t bin_of_group(uint32_t g) const { return gw == 1u ? g : __umulhi(g, magic); }   // g / gw, exact for g, gw < 2^16
+};
 __device__ __forceinline__ JBins jbins_of(uint32_t len, uint32_t nprobe, int stage_cap, size_t region)
 {
     JBins g;
     g.gs = 0;
     while (((len + (1u << g.gs) - 1u) >> g.gs) > (uint32_t)kCoarse) g.gs++;
-    uint32_t want = (nprobe / 2u + (uint32_t)stage_cap - 1u) / (uint32_t)stage_cap;
+    const uint32_t ngroups = max(1u, (len + (1u << g.gs) - 1u) >> g.gs), room = (uint32_t)(stage_cap - stage_cap / 12);
+    uint32_t want = (nprobe / 2u + room - 1u) / room;
     want = want < 1u ? 1u : want > (uint32_t)kMaxBins ? (uint32_t)kMaxBins : want;
-    g.bs = g.gs;
-    while (((len + (1u << g.bs) - 1u) >> g.bs) > want) g.bs++;
-    g.nb = (int)((len + (1u << g.bs) - 1u) >> g.bs);
-    if (g.nb < 1) g.nb = 1;
+    g.gw = (ngroups + want - 1u) / want;
+    g.nb = (int)((ngroups + g.gw - 1u) / g.gw);
+    g.magic = g.gw == 1u ? 0u : 0xFFFFFFFFu / g.gw + 1u;
     g.cap = (uint32_t)((region / (size_t)g.nb) & ~(size_t)15);
     return g;
 }
@@ -403,7 +409,7 @@ __global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTrai
     }
     __syncthreads();
     const JBins bins = jbins_of(hi - lo, s_np, stage_cap, region);       // the order kernel's grouping of this bucket's ranks and its bins
-    const int gs = bins.gs, bs = bins.bs;
+    const int gs = bins.gs;
     const uint32_t bincap = bins.cap;
     uint2 *out = surv ? surv + (size_t)b * region : nullptr;            // 8-byte entries (32-bit keys)
     uint4 *rout = srec ? srec + (size_t)b * region : nullptr;
@@ -480,7 +486,7 @@ __global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTrai
         auto commit = [&](bool match, uint32_t pos, uint32_t row, uint32_t val, uint32_t klow) {
             if (match) {
                 const uint32_t r = base + pos - lo;
-                const uint32_t bin = r >> bs;
+                const uint32_t bin = bins.bin_of_group(r >> gs);
                 const uint32_t at = atomicAdd(&s_bincur[bin], 1u);
                 if (at < bincap) {
                     const size_t o = (size_t)bin * bincap + at;
@@ -669,7 +675,7 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
     const uint32_t lo = bstart[b], len = bstart[b + 1] - lo, nb = scount[b];
     __syncthreads();
     const JBins bins = jbins_of(len, s_np, stage_cap, region);
-    const int gs = bins.gs, kb = bins.bs - bins.gs;                            // a bin = 2^kb consecutive groups
+    const int gs = bins.gs;                                                    // a bin = bins.gw consecutive groups
     const uint2 *src = VERIFY ? nullptr : surv + (size_t)b * region;
     const uint4 *srcr = VERIFY ? srec + (size_t)b * region : nullptr;
     const uint32_t *srck = VERIFY ? srank + (size_t)b * region : nullptr;
@@ -707,7 +713,7 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
     };
     // the bins that hold the ranks of groups [g0, g1)
     auto sweep_bins = [&](uint32_t g0, uint32_t g1, bool ranks_only, auto &&f) {
-        for (uint32_t j = g0 >> kb; j <= (g1 - 1u) >> kb; j++) sweep((size_t)j * bins.cap, s_bincnt[j], ranks_only, f);
+        for (uint32_t j = bins.bin_of_group(g0); j <= bins.bin_of_group(g1 - 1u); j++) sweep((size_t)j * bins.cap, s_bincnt[j], ranks_only, f);
     };
     // block-wide exclusive scan helper over a[0, m): a contiguous segment per thread, waves chained through LDS;
     // returns the total
@@ -738,7 +744,7 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
     scan_excl(coarse, ngroups + 1);                                    // coarse[g] = survivors before group g; coarse[ngroups] = nb
     if (bad) {                                                         // bin after bin, as they are
         for (uint32_t j = 0; j < (uint32_t)bins.nb; j++) {
-            const unsigned long long o = dst + coarse[min(ngroups, j << kb)];      // the survivors of the bins before bin j
+            const unsigned long long o = dst + coarse[min(ngroups, j * bins.gw)];      // the survivors of the bins before bin j
             for (uint32_t i = tid; i < s_bincnt[j]; i += kJThreads) {
                 const size_t at = (size_t)j * bins.cap + i;
                 const uint4 q = VERIFY ? srcr[at] : uint4{src[at].x, src[at].y, 0u, 0u};
@@ -763,7 +769,7 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
         uint32_t a = g0 + 1, z = min(ngroups, g0 + max_groups);
         const uint32_t base_cnt = coarse[g0];
         while (a < z) { const uint32_t mid = (a + z + 1) >> 1; if (coarse[mid] - base_cnt <= (uint32_t)stage_cap) a = mid; else z = mid - 1; }
-        if (a < ngroups) { const uint32_t snap = (a >> kb) << kb; if (snap > g0) a = snap; }
+        if (a < ngroups) { const uint32_t snap = bins.bin_of_group(a) * bins.gw; if (snap > g0) a = snap; }
         return a;
     };
     uint32_t g0 = 0;
