@@ -691,24 +691,20 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
     // f(entry (rank, left row), third word, probe-key low word).  ranks_only: the histogram sweep (8-byte entries: the entries
     // themselves; records: the rank array beside them, a quarter of the bytes)
     auto sweep = [&](size_t off, uint32_t i1, bool ranks_only, auto &&f) {
-        uint32_t i = tid;
-        for (; i + 7u * kJThreads < i1; i += 8u * kJThreads) {
+        // every lane issues its eight loads of a step before it uses any (clamped addresses past the end): a bin of ~7 K survivors
+        // is ONE step of the 1024 threads -- with the full steps peeled and a one-load-at-a-time tail (the first version) such a
+        // bin went through the tail, seven dependent round trips per lane and sweep
+        for (uint32_t i = tid; i < i1; i += 8u * kJThreads) {
             uint2 e[8]; uint32_t v[8], kl[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                const size_t at = off + i + (uint32_t)k * kJThreads;
+                const size_t at = off + min(i + (uint32_t)k * kJThreads, i1 - 1u);
                 if (!VERIFY) { e[k] = src[at]; v[k] = 0u; kl[k] = 0u; }
                 else if (ranks_only) { e[k] = uint2{srck[at], 0u}; v[k] = 0u; kl[k] = 0u; }
                 else { const uint4 q = srcr[at]; e[k] = uint2{q.x, q.y}; v[k] = q.z; kl[k] = q.w; }
             }
 #pragma unroll
-            for (int k = 0; k < 8; k++) f(e[k], v[k], kl[k]);
-        }
-        for (; i < i1; i += kJThreads) {
-            const size_t at = off + i;
-            if (!VERIFY) f(src[at], 0u, 0u);
-            else if (ranks_only) f(uint2{srck[at], 0u}, 0u, 0u);
-            else { const uint4 q = srcr[at]; f(uint2{q.x, q.y}, q.z, q.w); }
+            for (int k = 0; k < 8; k++) if (i + (uint32_t)k * kJThreads < i1) f(e[k], v[k], kl[k]);
         }
     };
     // the bins that hold the ranks of groups [g0, g1)
