@@ -364,8 +364,7 @@ __global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTrai
                                                             uint32_t *__restrict__ sbins /* [P][kMaxBins] survivors in every bin */,
                                                             uint4 *__restrict__ srec /* 64-bit keys (16-byte entries): every survivor as ONE record (rank, left row, the entry's
                                                                                         fourth word, low word of the PROBE key -- a hit on a truncated build key is confirmed by the
-                                                                                        order kernel, where the build keys are read in order) instead of `surv` ... */,
-                                                            uint32_t *__restrict__ srank /* ... and its rank alone beside it: what the order kernel's histogram sweep reads */,
+                                                                                        order kernel, where the build keys are read in order) instead of `surv` */,
                                                             uint32_t *__restrict__ scoarse /* [P][kCoarse] survivors per group of ranks: the order kernel's first histogram */,
                                                             int stage_cap /* the order kernel's stage (sizes the bins) */, int32_t *__restrict__ err,
                                                             int allow_trunc)
@@ -413,7 +412,6 @@ __global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTrai
     const uint32_t bincap = bins.cap;
     uint2 *out = surv ? surv + (size_t)b * region : nullptr;            // 8-byte entries (32-bit keys)
     uint4 *rout = srec ? srec + (size_t)b * region : nullptr;
-    uint32_t *kout = srank ? srank + (size_t)b * region : nullptr;
     bool bin_full = false;
     const unsigned long long below = (1ull << lane) - 1ull;
     // 64-bit keys: a bucket of up to two chunks of build keys (BASELINE configs[3]: 24.4 K against 12 K per 96-KiB chunk)
@@ -490,10 +488,11 @@ __global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTrai
                 const uint32_t at = atomicAdd(&s_bincur[bin], 1u);
                 if (at < bincap) {
                     const size_t o = (size_t)bin * bincap + at;
-                    if (sizeof(E) == 16) {                                 // one 16-byte record + the rank alone: two stores per hit (three arrays of
-                        st_hidden_b128(rout + o, uint4{base + pos, row, val, klow});   // 8 + 4 + 4 bytes before: a third of the kernel was its ~36 short store
-                        st_hidden_b32(kout + o, base + pos);               // segments per wave step, profiles/r04_notes.md 9)
-                    } else st_hidden_b64(out + o, uint2{base + pos, row});
+                    // one store per hit: a 16-byte record (three arrays of 8 + 4 + 4 bytes at first: a third of the kernel was its ~36
+                    // short store segments per wave step, profiles/r04_notes.md 9; then a record + the rank alone for the order
+                    // kernel's histogram sweep, which now keeps a sub-round's records in registers instead)
+                    if (sizeof(E) == 16) st_hidden_b128(rout + o, uint4{base + pos, row, val, klow});
+                    else st_hidden_b64(out + o, uint2{base + pos, row});
                     atomicAdd(&s_coarse[r >> gs], 1u);
                 } else bin_full = true;                                // probe keys crowd a few ranks: the caller takes another path
             }
@@ -642,11 +641,11 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
                                                            const uint32_t *__restrict__ scoarse,
                                                            const uint32_t *__restrict__ rranked /* may be null: a build-side column in rank order ... */,
                                                            uint32_t *__restrict__ rval_out /* ... read off for every survivor (unique build keys: survivor = output row) */,
-                                                           const uint4 *__restrict__ srec /* VERIFY (64-bit keys): the survivors as records (rank, left row, carried word, probe-key low word) ... */,
-                                                           const uint32_t *__restrict__ srank /* ... and their ranks alone (`surv` is not used then) */,
+                                                           const uint4 *__restrict__ srec /* VERIFY (64-bit keys): the survivors as records (rank, left row, carried word, probe-key low word); `surv` is not used then */,
                                                            const uint64_t *__restrict__ rkeys64 /* VERIFY: the sorted build keys */)
 {
-    constexpr int XW = (CARRY ? 1 : 0) + (VERIFY ? 1 : 0), STAGE = stage_of(XW), FINE = fine_of(XW);
+    constexpr int XW = (CARRY ? 1 : 0) + (VERIFY ? 1 : 0), STAGE = stage_of(XW), FINE = fine_of(XW), RPT = STAGE / kJThreads;
+    static_assert(RPT * kJThreads == STAGE, "a sub-round's survivors are dealt RPT to a lane");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     uint2 *stage = reinterpret_cast<uint2 *>(lds_raw);                         // [STAGE]
     uint32_t *stv = reinterpret_cast<uint32_t *>(stage + STAGE);               // [STAGE] third words (CARRY)
@@ -678,7 +677,6 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
     const int gs = bins.gs;                                                    // a bin = bins.gw consecutive groups
     const uint2 *src = VERIFY ? nullptr : surv + (size_t)b * region;
     const uint4 *srcr = VERIFY ? srec + (size_t)b * region : nullptr;
-    const uint32_t *srck = VERIFY ? srank + (size_t)b * region : nullptr;
     static_assert(VERIFY || !CARRY, "a carried column travels in the 16-byte records of the 64-bit path");
     bool mismatch = false;
     const uint32_t ngroups = (len + (1u << gs) - 1u) >> gs;
@@ -686,21 +684,19 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
     __syncthreads();
     const unsigned long long dst = s_dst;
     if (nb == 0) return;
-    // every pass over survivors keeps 8 loads per lane in flight: one workgroup owns the CU, and with a single load per
-    // lane the passes ran at the latency of a load, not at the CU's share of the bandwidth.  f(entry, third word)
-    // f(entry (rank, left row), third word, probe-key low word).  ranks_only: the histogram sweep (8-byte entries: the entries
-    // themselves; records: the rank array beside them, a quarter of the bytes)
-    auto sweep = [&](size_t off, uint32_t i1, bool ranks_only, auto &&f) {
-        // every lane issues its eight loads of a step before it uses any (clamped addresses past the end): a bin of ~7 K survivors
-        // is ONE step of the 1024 threads -- with the full steps peeled and a one-load-at-a-time tail (the first version) such a
-        // bin went through the tail, seven dependent round trips per lane and sweep
+    // a pass over a bin's survivors (the pieces of a crowded bin: the usual sub-round keeps its survivors in registers, below)
+    // keeps 8 loads per lane in flight: one workgroup owns the CU, and with a single load per lane the passes ran at the
+    // latency of a load, not at the CU's share of the bandwidth.  f(entry (rank, left row), third word, probe-key low word)
+    auto sweep = [&](size_t off, uint32_t i1, auto &&f) {
+        // every lane issues its eight loads of a step before it uses any (clamped addresses past the end); with the full steps
+        // peeled and a one-load-at-a-time tail (the first version) a bin of ~7 K survivors went through the tail, seven dependent
+        // round trips per lane and sweep
         for (uint32_t i = tid; i < i1; i += 8u * kJThreads) {
             uint2 e[8]; uint32_t v[8], kl[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 const size_t at = off + min(i + (uint32_t)k * kJThreads, i1 - 1u);
                 if (!VERIFY) { e[k] = src[at]; v[k] = 0u; kl[k] = 0u; }
-                else if (ranks_only) { e[k] = uint2{srck[at], 0u}; v[k] = 0u; kl[k] = 0u; }
                 else { const uint4 q = srcr[at]; e[k] = uint2{q.x, q.y}; v[k] = q.z; kl[k] = q.w; }
             }
 #pragma unroll
@@ -708,8 +704,8 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
         }
     };
     // the bins that hold the ranks of groups [g0, g1)
-    auto sweep_bins = [&](uint32_t g0, uint32_t g1, bool ranks_only, auto &&f) {
-        for (uint32_t j = bins.bin_of_group(g0); j <= bins.bin_of_group(g1 - 1u); j++) sweep((size_t)j * bins.cap, s_bincnt[j], ranks_only, f);
+    auto sweep_bins = [&](uint32_t g0, uint32_t g1, auto &&f) {
+        for (uint32_t j = bins.bin_of_group(g0); j <= bins.bin_of_group(g1 - 1u); j++) sweep((size_t)j * bins.cap, s_bincnt[j], f);
     };
     // block-wide exclusive scan helper over a[0, m): a contiguous segment per thread, waves chained through LDS;
     // returns the total
@@ -773,15 +769,45 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
         const uint32_t base_cnt = coarse[g0];
         const uint32_t g1 = sub_end(g0), r0 = g0 << gs, r1 = min(len, g1 << gs), nr = r1 - r0, nsub = coarse[g1] - base_cnt;
         if (nsub) {
-            for (uint32_t i = tid; i <= nr; i += kJThreads) fine[i] = 0u;
-            __syncthreads();
-            sweep_bins(g0, g1, true, [&](uint2 e, uint32_t, uint32_t) { const uint32_t r = e.x - lo - r0; if (r < nr) atomicAdd(&fine[r], 1u); });
-            __syncthreads();
-            scan_excl(fine, nr);
-            sweep_bins(g0, g1, false, [&](uint2 e, uint32_t v, uint32_t kl) {
+            auto count_one = [&](uint2 e, uint32_t, uint32_t) { const uint32_t r = e.x - lo - r0; if (r < nr) atomicAdd(&fine[r], 1u); };
+            auto place_one = [&](uint2 e, uint32_t v, uint32_t kl) {
                 const uint32_t r = e.x - lo - r0;
                 if (r < nr) { const uint32_t at = atomicAdd(&fine[r], 1u); stage[at] = e; if (CARRY) stv[at] = v; if (VERIFY) stk[at] = kl; }   // afterwards fine[r] = end of rank r's rows
-            });
+            };
+            // A sub-round of WHOLE bins (the usual case: bins are sized for the stage) holds at most STAGE = RPT x 1024 survivors:
+            // every lane reads its RPT of them ONCE, keeps them in registers over the histogram, the scan and the placement.  (Two
+            // sweeps over memory before -- the first over a separate array of the ranks alone, which the bucket kernel no longer
+            // writes: 4 of 20 bytes per survivor.)  A piece of a crowded bin sweeps the whole bin twice and filters by rank.
+            const uint32_t jA = bins.bin_of_group(g0), jB = bins.bin_of_group(g1 - 1u);
+            uint32_t in_bins = 0;
+            for (uint32_t j = jA; j <= jB; j++) in_bins += s_bincnt[j];
+            const bool whole = g0 == jA * bins.gw && (g1 == ngroups || g1 == (jB + 1u) * bins.gw) && in_bins <= (uint32_t)(RPT * kJThreads);
+            if (whole) {
+                uint2 e[RPT]; uint32_t v[RPT], kl[RPT];
+#pragma unroll
+                for (int k = 0; k < RPT; k++) {
+                    uint32_t y = min(tid + (uint32_t)k * kJThreads, in_bins - 1u), j = jA;
+                    while (y >= s_bincnt[j]) { y -= s_bincnt[j]; j++; }                 // (in_bins >= nsub > 0: the walk ends inside [jA, jB])
+                    const size_t at = (size_t)j * bins.cap + y;
+                    if (!VERIFY) { e[k] = src[at]; v[k] = 0u; kl[k] = 0u; }
+                    else { const uint4 q = srcr[at]; e[k] = uint2{q.x, q.y}; v[k] = q.z; kl[k] = q.w; }
+                }
+                for (uint32_t i = tid; i <= nr; i += kJThreads) fine[i] = 0u;       // (under the loads)
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < RPT; k++) if (tid + (uint32_t)k * kJThreads < in_bins) count_one(e[k], 0u, 0u);
+                __syncthreads();
+                scan_excl(fine, nr);
+#pragma unroll
+                for (int k = 0; k < RPT; k++) if (tid + (uint32_t)k * kJThreads < in_bins) place_one(e[k], v[k], kl[k]);
+            } else {
+                for (uint32_t i = tid; i <= nr; i += kJThreads) fine[i] = 0u;
+                __syncthreads();
+                sweep_bins(g0, g1, count_one);
+                __syncthreads();
+                scan_excl(fine, nr);
+                sweep_bins(g0, g1, place_one);
+            }
             __syncthreads();
             // ---- rows of one rank into left-row order, and out: every survivor counts the rows of ITS rank (the stage's run
             // [fine[r-1], fine[r]), five or so) that are smaller than its own -- row ids are distinct, so that is its place in
@@ -891,7 +917,7 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
     K *splitters = nullptr; uint32_t *bstart = nullptr, *counts = nullptr, *scount = nullptr, *sbins = nullptr;
     int64_t *info = nullptr;                                                     // [0] survivors (u64), [1] error word of the partition
     E *slabs = nullptr; uint2 *surv = nullptr;
-    uint32_t *rank = nullptr, *lrow = nullptr, *cnt = nullptr, *srank = nullptr, *lv = nullptr, *rv = nullptr;
+    uint32_t *rank = nullptr, *lrow = nullptr, *cnt = nullptr, *lv = nullptr, *rv = nullptr;
     uint4 *srec = nullptr;
     const bool carry = lval != nullptr && sizeof(E) == 16;                      // the fourth word of the 16-byte entries
     const bool verify = sizeof(K) == 8;                                          // survivors carry their probe key's low word to the order kernel
@@ -910,12 +936,11 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
     if (!rc) rc = hark_alloc(ctx, (void **)&slabs, sizeof(E) * (size_t)P * sstride);
     if (!rc && !verify) rc = hark_alloc(ctx, (void **)&surv, 8 * (size_t)P * region);          // 32-bit keys: (rank, left row)
     if (!rc && verify) rc = hark_alloc(ctx, (void **)&srec, 16 * (size_t)P * region);          // 64-bit keys: records + their ranks alone
-    if (!rc && verify) rc = hark_alloc(ctx, (void **)&srank, 4 * (size_t)P * region);
     uint32_t *scoarse = nullptr;
     if (!rc) rc = hark_alloc(ctx, (void **)&scoarse, 4 * (size_t)P * kCoarse);
     auto cleanup = [&]() {
         hark_free(ctx, splitters); hark_free(ctx, bstart); hark_free(ctx, counts); hark_free(ctx, scount); hark_free(ctx, sbins);
-        hark_free(ctx, info); hark_free(ctx, slabs); hark_free(ctx, surv); hark_free(ctx, srec); hark_free(ctx, srank); hark_free(ctx, scoarse);
+        hark_free(ctx, info); hark_free(ctx, slabs); hark_free(ctx, surv); hark_free(ctx, srec); hark_free(ctx, scoarse);
     };
     if (rc == HARK_ENOMEM) {                                                     // no room for the partition workspace: the sort-merge path
         cleanup();                                                               // needs far less (used stays false)
@@ -949,7 +974,7 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
         // one stream-ordered chain, one host read at the end: partition -> bucket probe -> survivor total
         if (plain_loads) jpart_kernel<K, false><<<dim3((unsigned)nwg), dim3(kJThreads), lds_part, st>>>(lcol, n, bias, splitters, rkeys, s, slabs, counts, cap, period, err, carry ? lval : nullptr);
         else jpart_kernel<K, true><<<dim3((unsigned)nwg), dim3(kJThreads), lds_part, st>>>(lcol, n, bias, splitters, rkeys, s, slabs, counts, cap, period, err, carry ? lval : nullptr);
-        jbucket_kernel<K><<<dim3((unsigned)P), dim3(kJThreads), lds_bucket, st>>>(slabs, counts, cap, nwg, rkeys, bstart, chunk_cap, surv, region, scount, sbins, srec, srank, scoarse, stage_cap, err, allow_trunc ? 1 : 0);
+        jbucket_kernel<K><<<dim3((unsigned)P), dim3(kJThreads), lds_bucket, st>>>(slabs, counts, cap, nwg, rkeys, bstart, chunk_cap, surv, region, scount, sbins, srec, scoarse, stage_cap, err, allow_trunc ? 1 : 0);
         jsum_kernel<<<1, 1024, 0, st>>>(scount, P, total);
         he = hipGetLastError();
         if (he == hipSuccess) he = hipMemcpyAsync(info + 2, flags, 8, hipMemcpyDeviceToDevice, st);   // the duplicate-keys flag rides along with the same host read
@@ -986,7 +1011,7 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
                     if (e != hipSuccess) return e;
                     jorder_kernel<C, V><<<dim3((unsigned)P), dim3(kJThreads), lds_order, st>>>(surv, region, scount, sbins, counts, cap, nwg, bstart, P, runlen,
                                                                                              rank, lrow, cnt, stage_cap, flags, C ? lv : nullptr, scoarse, rranked, rv,
-                                                                                             V ? srec : nullptr, V ? srank : nullptr, V ? rk64 : nullptr);
+                                                                                             V ? srec : nullptr, V ? rk64 : nullptr);
                     return hipSuccess;
                 };
                 he = verify ? (carry ? launch(std::true_type{}, std::true_type{}) : launch(std::false_type{}, std::true_type{}))
