@@ -590,6 +590,21 @@ __global__ __launch_bounds__(256) void transform_keys_kernel(const void *__restr
             acc |= (q.x ^ w0) | (q.y ^ w0) | (q.z ^ w0) | (q.w ^ w0);
         }
         for (int64_t i = nvec * 4 + t0; i < n; i += stride) { const uint32_t w = sort_word(src, dtype, part, i); if (dst) dst[i] = w; acc |= w ^ w0; }
+    } else if (dtype == HARK_I64 && (reinterpret_cast<uintptr_t>(src) & 15u) == 0) {
+        // two keys per 16-byte load, two loads in flight per lane (one 8-byte load per lane and trip ran at 4.2 TB/s)
+        const uint4 *s4 = static_cast<const uint4 *>(src);
+        uint2 *d2 = reinterpret_cast<uint2 *>(dst);
+        const int64_t nvec = n / 2;
+        const uint32_t bias = part ? 0x80000000u : 0u;
+        auto two = [&](int64_t i, const uint4 q) {
+            const uint32_t wa = (part ? q.y : q.x) ^ bias, wb = (part ? q.w : q.z) ^ bias;
+            if (dst) d2[i] = uint2{wa, wb};
+            acc |= (wa ^ w0) | (wb ^ w0);
+        };
+        int64_t i = t0;
+        for (; i + stride < nvec; i += 2 * stride) { const uint4 qa = s4[i], qb = s4[i + stride]; two(i, qa); two(i + stride, qb); }
+        for (; i < nvec; i += stride) two(i, s4[i]);
+        for (int64_t r = nvec * 2 + t0; r < n; r += stride) { const uint32_t w = sort_word(src, dtype, part, r); if (dst) dst[r] = w; acc |= w ^ w0; }
     } else {
         for (int64_t i = t0; i < n; i += stride) { const uint32_t w = sort_word(src, dtype, part, i); if (dst) dst[i] = w; acc |= w ^ w0; }
     }
