@@ -194,6 +194,15 @@ def measure_traffic(N, G, timeout_s=240, steps=2, warmup=1):
     return dict(kernels), None
 
 
+def library_matches_sources():
+    """harkdb_amd/_srchash.py: True / False / None (no record) -- is the in-tree libhark.so the build of the sources beside it?"""
+    try:
+        from harkdb_amd._srchash import library_matches_sources as f
+        return f()
+    except Exception:
+        return None
+
+
 def build_id():
     """What produced a number: the git commit where a checkout is at hand, else (the GPU box receives a snapshot without
     .git) the first 16 hex digits of sha256 of bench.py and of the loaded libhark.so."""
@@ -261,7 +270,8 @@ def stub_main(a):
         print(json.dumps({"metric": "stub", "value": N * world / (el / a.steps), "unit": "rows/s", "n_gpus": world, "steps": a.steps,
                           "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": {"workload": "stub (CPU protocol test)"},
-                          "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1, "backend": dist.get_backend() if dist.is_initialized() else None,
+                          "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
+            "library_linked_from_the_sources_in_the_tree": library_matches_sources() if not os.environ.get("HARK_LIB") else None, "backend": dist.get_backend() if dist.is_initialized() else None,
                           "ms_per_step_by_rank": [float(x.item()) / a.steps * 1e3 for x in per_rank],
                           "check": {"count_checksum": int(cnts.sum().item()) == int(total.item())}}), flush=True)
     if dist.is_initialized():
@@ -792,6 +802,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
+            "library_linked_from_the_sources_in_the_tree": library_matches_sources() if not os.environ.get("HARK_LIB") else None,
             "ms_per_step_by_rank": [x / a.steps * 1e3 for x in per_rank],
             "config": {"workload": "BASELINE configs[2] + filter: SELECT k,SUM(v),COUNT(*) FROM t WHERE p>0.5 GROUP BY k",
                        "rows_per_gpu": N, "groups": G, "selectivity": 0.5, "columns": "p f32, k i32, v f32 (HBM-resident)",

@@ -67,3 +67,19 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("no CPU fallback", ""), f"{f} mentions the oracle"
+
+
+def test_library_is_the_build_of_the_sources_in_the_tree():
+    """The Makefile records the digest of the sources it linked (harkdb_amd/libhark.srchash); a library left behind by a build
+    of other sources -- an experiment, an older checkout -- is not what the tests and the bench should run."""
+    import subprocess
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "harkdb_amd", "csrc")], stdout=subprocess.DEVNULL)
+    from harkdb_amd._srchash import library_matches_sources
+    assert library_matches_sources() is True
+
+
+@pytest.mark.gpu
+def test_the_library_on_the_gpu_box_is_the_build_of_its_sources():
+    """The same on the GPU box, WITHOUT building there: the snapshot brought the library, its record and the sources together."""
+    from harkdb_amd._srchash import library_matches_sources
+    assert library_matches_sources() is True

@@ -10,6 +10,9 @@ export TMPDIR=/tmp
 TAG=${1:?usage: evidence.sh TAG}
 O=gpurun_out/ev_$TAG
 if [ -e "$O" ]; then echo "$O exists: pick a new TAG" >&2; exit 2; fi
+# measure the library of THESE sources or nothing (an experimental build of edited sources once stayed in the tree and an evidence
+# run measured it: profiles/r04_notes.md 13); on the box the sources and the library arrive together with the snapshot
+python3 harkdb_amd/_srchash.py || exit 2
 mkdir -p $O
 date -u +%FT%TZ > $O/run_id.txt; sha256sum bench.py harkdb_amd/libhark.so >> $O/run_id.txt
 timeout 900 python bench.py > $O/bench_plain.json 2> $O/bench_plain.err
