@@ -368,8 +368,14 @@ def w_join_u32(torch, eng, dev, scale=1.0):
     kb8, vb8, kp8 = _gen_i32(torch, eng, dev, SEED + 3, m8, 1 << 30), _gen_i32(torch, eng, dev, SEED + 4, m8, 1 << 16), _gen_i32(torch, eng, dev, SEED + 5, n8, 1 << 30)
     tp8 = eng.table_from_device(n8, [kp8.data_ptr(), au.data_ptr()], [np.uint32, np.uint32], keepalive=(kp8, au))
     tb8 = eng.table_from_device(m8, [kb8.data_ptr(), vb8.data_ptr()], [np.uint32, np.uint32], keepalive=(kb8, vb8))
+    sb = torch.sort(kb8).values                                                      # pairs a join must find: every probe key's partners in the build side
+    hits = 0
+    for c0 in range(0, n8, 1 << 25):
+        ch = kp8[c0: c0 + (1 << 25)]
+        hits += int((torch.searchsorted(sb, ch, right=True) - torch.searchsorted(sb, ch, right=False)).sum().item())
+    del sb
     return {"run": lambda: eng.join(tp8, tb8, 0, 0, [0, 1], [1]), "bytes": lambda r: 12.0 * (n8 + m8) + 12.0 * r.shape[0], "rows": n8 + m8, "keep": (tp8, tb8),
-            "info": {"probe_rows": n8, "build_rows": m8,
+            "info": {"probe_rows": n8, "build_rows": m8, "pairs_expected": hits,
                      "statement": "join(db1, db2, 0, 0, [0, 1], [1]) (join.fut:52) on u32 keys, ~10 % of the probe rows match"}}
 
 
@@ -538,6 +544,7 @@ def extra_configs(torch, eng, dev, a, p, k, v, N):
             out[name]["path"] = eng.last_groupby_path()
         if wl.startswith("join"):
             out[name]["pairs"] = out[name]["result_shape"][0]
+            out[name]["pairs_match_the_expected_count"] = out[name]["pairs"] == out[name].get("pairs_expected")
         for t_ in w["keep"]:
             if hasattr(t_, "free"):
                 t_.free()

@@ -108,3 +108,4 @@ def test_bench_extra_configs_at_a_small_scale():
     assert sp["path"] == "hash" and sp["equals_dense_result_after_key_mapping"] is True and sp["result_shape"][0] > 900_000, sp
     assert cfg["REF_query_groupby_dense"]["path"] == "dense" and cfg["REF_query_groupby_hash"]["path"] == "hash"
     assert cfg["C4_join_share"]["pairs"] == cfg["C4_join_share"]["pairs_expected"]
+    assert cfg["REF_join_u32"]["pairs"] == cfg["REF_join_u32"]["pairs_expected"] > 0
