@@ -634,8 +634,9 @@ def main():
     # With peers, the producer may leave a few CUs to RCCL: its 256 workgroups of 1024 threads otherwise hold every CU for the
     # whole 2.5 ms, and the all-reduce of the previous step (pipelined mode) could only start in the producer's tail.  How
     # many (and whether pipelining two plans pays at all) depends on hardware this code was never run on with peers, so it is
-    # MEASURED at start-up, before the warm-up steps: a few steps of each candidate, the slowest rank's time decides, every
-    # rank takes the same choice.  HARK_PRODUCER_WGS (0 = all CUs) / HARK_OVERLAP=0|1 pin the choice instead.
+    # MEASURED at start-up, before the warm-up steps: a few steps of each candidate (producer geometry x pipelining x the
+    # collective), the slowest rank's time decides, every rank takes the same choice.  HARK_PRODUCER_WGS (0 = all CUs) /
+    # HARK_OVERLAP=0|1 / HARK_ALLREDUCE pin the choice instead.
     multi = world > 1 or bool(os.environ.get("HARK_FORCE_PIPELINE"))
 
     def make_job(wgs, overlap):
@@ -655,7 +656,11 @@ def main():
     tuned = None
     if multi and "HARK_PRODUCER_WGS" not in os.environ and "HARK_OVERLAP" not in os.environ:
         tuned = {}
-        for wgs, overlap in ((240, True), (0, True), (0, False)):
+        # the merge itself: one all-reduce per tensor, or reduce-scatter + all-gather ("so that all 7 links carry
+        # traffic") -- dist.allreduce_partials reads HARK_ALLREDUCE per call; a value set by the caller pins it
+        hows = [os.environ["HARK_ALLREDUCE"]] if "HARK_ALLREDUCE" in os.environ else ["allreduce", "rs_ag"]
+        for wgs, overlap, how in [(w_, o_, h_) for h_ in hows for (w_, o_) in ((240, True), (0, True), (0, False))]:
+            os.environ["HARK_ALLREDUCE"] = how
             pl, pl2, jb = make_job(wgs, overlap)
             for timed_steps in (2, 6):                        # 2 untimed, then 6 timed
                 sync_all()
@@ -668,12 +673,13 @@ def main():
             tt = torch.tensor([dt / 6 * 1e3], dtype=torch.float64, device=dev)
             if dist.is_initialized():
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)     # the same number on every rank: the same choice on every rank
-            tuned[("%d workgroups" % wgs if wgs else "all CUs") + (", pipelined" if overlap else ", serial")] = (float(tt.item()), wgs, overlap)
+            tuned[("%d workgroups" % wgs if wgs else "all CUs") + (", pipelined" if overlap else ", serial") + ", " + how] = (float(tt.item()), wgs, overlap, how)
             del jb
             pl.free()
             if pl2 is not None:
                 pl2.free()
-        producer_wgs, overlap = min(tuned.values())[1:]
+        producer_wgs, overlap, how = min(tuned.values())[1:]
+        os.environ["HARK_ALLREDUCE"] = how
         tuned = {kk: vv[0] for kk, vv in tuned.items()}
     else:
         producer_wgs = int(os.environ.get("HARK_PRODUCER_WGS", "240" if world > 1 else "0"))

@@ -43,11 +43,13 @@ def test_bench_rank_under_rccl(pipeline, how):
 
 def test_bench_rank_measures_its_producer_geometry_at_startup():
     """With peers (here: one rank, HARK_FORCE_PIPELINE) and nothing pinned, the rank times 240 workgroups pipelined, all CUs
-    pipelined and all CUs serial before the warm-up and runs the fastest; the line says what was measured and chosen."""
+    pipelined and all CUs serial, each with both forms of the merge, before the warm-up and runs the fastest; the line says
+    what was measured and chosen."""
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
                HARK_FORCE_PIPELINE="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     env.pop("HARK_PRODUCER_WGS", None)
     env.pop("HARK_OVERLAP", None)
+    env.pop("HARK_ALLREDUCE", None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--rows", "20000000", "--groups", str(1 << 20),
                           "--steps", "5", "--warmup", "2", "--cpu-rows", "0", "--configs", "0", "--pmc", "0"],
                          capture_output=True, text=True, timeout=600, env=env)
@@ -55,10 +57,12 @@ def test_bench_rank_measures_its_producer_geometry_at_startup():
     line = json.loads(out.stdout.strip().splitlines()[-1])
     cfg = line["config"]
     m = cfg["measured_at_startup_ms_per_step"]
-    assert set(m) == {"240 workgroups, pipelined", "all CUs, pipelined", "all CUs, serial"} and all(x > 0 for x in m.values()), m
+    assert set(m) == {g + ", " + h for g in ("240 workgroups, pipelined", "all CUs, pipelined", "all CUs, serial") for h in ("allreduce", "rs_ag")}, m
+    assert all(x > 0 for x in m.values()), m
     best = min(m, key=m.get)
-    assert cfg["pipelined_steps"] == best.endswith("pipelined") and cfg["overlap"] == best.endswith("pipelined")
+    assert cfg["pipelined_steps"] == (", pipelined" in best) and cfg["overlap"] == (", pipelined" in best)
     assert cfg["producer_workgroups"] == (240 if best.startswith("240") else "all CUs")
+    assert cfg["allreduce"] == best.rsplit(", ", 1)[1]
     assert line["check"] == {"count_checksum": True, "sum_checksum": True}
 
 
