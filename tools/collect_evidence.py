@@ -72,3 +72,6 @@ with open(os.path.join(dst, f"{tag}_op_traffic.txt"), "w") as fo:
         logs = "".join(ln for ln in open(logf) if ln.startswith(w + ":")) if os.path.exists(logf) else ""
         fo.write(f"\n== {w}\n{logs}{r.stdout}{r.stderr}")
 print(open(os.path.join(dst, f"{tag}_op_traffic.txt")).read())
+# ... and the same kernels against the plain-stream floor of their bytes (tools/floor_table.py)
+ft = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "floor_table.py"), os.path.join(dst, f"{tag}_op_traffic.txt")], capture_output=True, text=True)
+open(os.path.join(dst, f"{tag}_floor_table.md"), "w").write(ft.stdout)
