@@ -626,7 +626,8 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
                         } else atomicSub(&s_w[b], 1u);
                     } else
                     if (pos < (uint32_t)q8) {
-                        queue[b * q8 + (((old >> 16) + pos) & (q8 - 1))] = uint2{key, vbits_of(vv[j])};
+                        queue[b * q8 + (((old >> 16) + pos) & (q8 - 1))] = uint2{HASH ? mix32(key) : key, vbits_of(vv[j])};   // hash mode: the MIXED key travels (a bijection: the consumers
+                                                                                                                              // need only it, and unmix32 at emit time)
                         pending &= ~(1u << j);
                     } else atomicSub(&s_w[b], 1u);                      // queue full: retry after the flush
                 }
@@ -1455,7 +1456,7 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash_kernel(
         uint32_t tag[kNP], g[kNP]; Tags8 q[kNP];
 #pragma unroll
         for (int j = 0; j < kNP; j++) {
-            const uint32_t m = mix32(key[j]);
+            const uint32_t m = key[j];                                        // the producer wrote mix32(key)
             tag[j] = (m & lowmask) | 0x80000000u;
             g[j] = (m * 0x9E3779B1u) >> 22;                                  // 10 bits (kGroups), mixed from the bits below the bucket's
             if (Rmask && (mix32(key[j] ^ 0x9E3779B9u) & Rmask) != r) live &= ~(1u << j);   // not this round's share of the key space
@@ -1556,7 +1557,7 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash_stats_kernel(
         uint32_t tag[kNP], g[kNP]; Tags8 q[kNP];
 #pragma unroll
         for (int j = 0; j < kNP; j++) {
-            const uint32_t m = mix32(key[j]);
+            const uint32_t m = key[j];                                        // the producer wrote mix32(key)
             tag[j] = (m & lowmask) | 0x80000000u;
             g[j] = __umulhi(m * 0x9E3779B1u, (uint32_t)kHashSGroups);        // 640 groups: not a power of two
             if (Rmask && (mix32(key[j] ^ 0x9E3779B9u) & Rmask) != r) live &= ~(1u << j);
@@ -1661,7 +1662,7 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash_ops_kernel(
         uint32_t tag[kNP], g[kNP]; Tags8 q[kNP];
 #pragma unroll
         for (int j = 0; j < kNP; j++) {
-            const uint32_t m = mix32(key[j]);
+            const uint32_t m = key[j];                                        // the producer wrote mix32(key)
             tag[j] = (m & lowmask) | 0x80000000u;
             g[j] = __umulhi(m * 0x9E3779B1u, (uint32_t)kGroups);             // not a power of two
             if (Rmask && (mix32(key[j] ^ 0x9E3779B9u) & Rmask) != r) live &= ~(1u << j);
@@ -1775,7 +1776,7 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash8_kernel(
         u64 tag[kNP]; uint32_t g[kNP]; Ent4 q[kNP];
 #pragma unroll
         for (int j = 0; j < kNP; j++) {
-            const uint32_t m = mix32(key[j]);
+            const uint32_t m = key[j];                                        // the producer wrote mix32(key)
             tag[j] = (u64)(m & 0xFFFFFFu) | (1ull << 24);
             g[j] = (m * 0x9E3779B1u) >> 20;                                  // 12 bits (kGroups)
             if (Rmask && (mix32(key[j] ^ 0x9E3779B9u) & Rmask) != r) live &= ~(1u << j);   // not this round's share of the key space
