@@ -120,15 +120,18 @@ class _ChainedWork:
         return True
 
 
-def allreduce_partials(sum_t, cnt_t, group=None, wait=True):
+def allreduce_partials(sum_t, cnt_t, group=None, wait=True, how=None):
     """Merge per-shard dense GROUP BY partials in place: SUM over ranks of the
     f64 sums and of the i64 counts (the RCCL all-reduce of SURVEY.md 8(e)).  wait=False returns the pending
     work handles (call .wait() on each before reading the tensors): the collectives then run on RCCL's own
-    stream beside whatever the caller enqueues next (ShardedFgb pipelines the next step's kernels under them)."""
+    stream beside whatever the caller enqueues next (ShardedFgb pipelines the next step's kernels under them).
+    how: "allreduce" | "rs_ag" (see _allreduce_sum); None reads HARK_ALLREDUCE (default "allreduce") -- a caller that
+    A/Bs the two passes `how` and leaves the environment alone."""
     import torch.distributed as dist
     works = []
     if dist.is_initialized():          # also with one rank: keeps the single-GPU run on the same code path
-        how = os.environ.get("HARK_ALLREDUCE", "allreduce")
+        if how is None:
+            how = os.environ.get("HARK_ALLREDUCE", "allreduce")
         if sum_t.is_cuda and dist.get_backend() == "gloo":               # tests: ranks sharing one GPU
             for t in (sum_t, cnt_t):
                 x, back = _host_staged(t)
@@ -187,8 +190,9 @@ class ShardedFgb:
     stream while the kernels of step i+1 (which accumulate into the other plan) run on ours; step i is finished --
     results written to its outputs -- when step i+1 is issued, or by flush().  HARK_OVERLAP=0 switches it off."""
 
-    def __init__(self, eng, plan, device, plan2=None, acc_tensors=None):
+    def __init__(self, eng, plan, device, plan2=None, acc_tensors=None, how=None):
         self.eng, self.plan, self.device = eng, plan, device
+        self.how = how                                                    # form of the merge (allreduce_partials); None: HARK_ALLREDUCE
         self.plans = [plan] + ([plan2] if plan2 is not None and os.environ.get("HARK_OVERLAP", "1") != "0" else [])
         self.acc = []
         for j, pl in enumerate(self.plans):
@@ -214,7 +218,7 @@ class ShardedFgb:
         if not self.pipelined:
             self.plan.reset()
             self.plan.run(p, cmp, thr, k, v, n)
-            allreduce_partials(self.sum_t, self.cnt_t)
+            allreduce_partials(self.sum_t, self.cnt_t, how=self.how)
             self.plan.finish(sum_out, count_out, check=True if check is None else bool(check))
             return
         i = self.turn
@@ -222,7 +226,7 @@ class ShardedFgb:
         plan, (sum_t, cnt_t) = self.plans[i], self.acc[i]
         plan.reset()
         plan.run(p, cmp, thr, k, v, n)
-        works = allreduce_partials(sum_t, cnt_t, wait=False)         # runs beside the NEXT step's kernels
+        works = allreduce_partials(sum_t, cnt_t, wait=False, how=self.how)         # runs beside the NEXT step's kernels
         prev, self.pending = self.pending, (plan, works, sum_out, count_out)
         self._finish(prev)
 
