@@ -760,7 +760,14 @@ def configs_child_main(a):
     hd.share_stream(eng, dev)
     out = {}
     write_json_atomically(a.configs_child, out)
-    extra_configs(torch, eng, dev, a, lambda: write_json_atomically(a.configs_child, out), out)
+    stall = os.environ.get("HARK_BENCH_CHILD_STALL")           # tests: hang (as a wedged kernel would) once this config is written
+
+    def sink():
+        write_json_atomically(a.configs_child, out)
+        if stall and stall in out:
+            time.sleep(1e6)
+
+    extra_configs(torch, eng, dev, a, sink, out)
     out["complete"] = True
     write_json_atomically(a.configs_child, out)
 

@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("HARK_LIB") or os.path.join(_HERE, "libhark.so")    # 
 
 OK, EBOUNDS, ENOMEM, EARG, EHIP, EUNSUPPORTED = range(6)
 I32, U32, F32, I64 = range(4)
+F64 = 4                                   # element type of a result MATRIX only (hark_result_matrix_pinned)
 NP_OF = {I32: np.int32, U32: np.uint32, F32: np.float32, I64: np.int64}
 DT_OF = {np.dtype(np.int32): I32, np.dtype(np.uint32): U32, np.dtype(np.float32): F32, np.dtype(np.int64): I64}
 CMP = {">": 0, ">=": 1, "<": 2, "<=": 3, "=": 4, "==": 4, "!=": 5, "<>": 5, "mask": 6}
@@ -54,6 +55,11 @@ SIGNATURES = {
     "hark_result_column": (C.c_int, [_vp, _vp, _i64, _vp]),
     "hark_result_column_device": (_vp, [_vp, _i64]),
     "hark_result_columns_prefix": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "hark_host_alloc": (C.c_int, [_vp, _pp, C.c_size_t]),
+    "hark_host_free": (C.c_int, [_vp, _vp]),
+    "hark_result_columns_pinned": (C.c_int, [_vp, _vp, _i64, _pp, C.POINTER(_i64)]),
+    "hark_result_matrix_pinned": (C.c_int, [_vp, _vp, C.POINTER(_i32), _i64, _i64, C.c_int, _pp]),
+    "hark_dev_download_pinned": (C.c_int, [_vp, _vp, C.c_size_t, _pp]),
     "hark_result_free": (C.c_int, [_vp, _vp]),
     "hark_entry_query_sel": (C.c_int, [_vp, _pp, _vp, C.POINTER(_i32), _i64]),
     "hark_entry_query_groupby": (C.c_int, [_vp, _pp, _vp, _i32, C.POINTER(_i32), _i64, C.POINTER(_i32), _i64]),

@@ -34,6 +34,14 @@ from .table import Table
 _AGG_NAME = {"key": "key", "prod": "prod", "sum": "sum", "max": "max", "min": "min", "count": "count", "avg": "avg"}
 
 
+class DeviceRows:
+    """A statement's result while it is still on the device: Result `res`, the select list as column numbers of it
+    (`slots`, repeats allowed), LIMIT, and the matrix element type when it is not numpy's result_type of the columns."""
+
+    def __init__(self, res, slots, limit, dtype):
+        self.res, self.slots, self.limit, self.dtype = res, list(slots), limit, dtype
+
+
 class FutharkContext:
 
     def __init__(self, device=0, sql_mode=False):
@@ -71,7 +79,14 @@ class FutharkContext:
 
     # FutharkContext.py:55-71
     def sql(self, sql_statement):
-        names, cols = self.sql_columns(sql_statement)
+        """The reference's return shape: ONE [rows][columns] matrix (FutharkContext.py:66,71).  When the statement's result is
+        a device Result as it stands (no host-side decoding of composite keys, no late aggregation) the matrix is built on
+        the device and crosses PCIe once, into pinned memory (Result.matrix); otherwise the typed host columns are interleaved
+        here."""
+        r = self._run(sql_parse(self.tables, sql_statement), want_device=True)
+        if isinstance(r, DeviceRows):
+            return r.res.matrix(r.slots, r.limit, r.dtype)
+        names, cols = r
         if not cols:
             return np.empty((0, 0), dtype=np.int32)
         dts = {c.dtype for c in cols}
@@ -99,8 +114,10 @@ class FutharkContext:
         """Like sql() but returns (column names, list of typed numpy columns)."""
         return self._run(sql_parse(self.tables, sql_statement))            # FutharkContext.py:61
 
-    def _run(self, val_dic):
-        """Executes a planned statement (the IR of parse.sql_parse_tree)."""
+    def _run(self, val_dic, want_device=False):
+        """Executes a planned statement (the IR of parse.sql_parse_tree) -> (column names, typed host columns); with
+        want_device a statement whose result is a device Result as it stands comes back as DeviceRows instead (sql() turns
+        it into the reference's matrix on the device)."""
         if val_dic.get("join"):
             return self._join(val_dic)
         table = self.tables[val_dic["table_name"]]
@@ -114,17 +131,21 @@ class FutharkContext:
             names = [schema[c] for c in sel_cols]
             if not extended:
                 res = eng.query_sel(dev, sel_cols)
-                return names, res.columns()
+                return DeviceRows(res, list(range(len(sel_cols))), None, None) if want_device else (names, res.columns())
+            if want_device:
+                return DeviceRows(self._select_result(dev, val_dic), list(range(len(sel_cols))), val_dic.get("limit"), None)
             return names, self._select_extended(dev, val_dic)
 
         # FutharkContext.py:67-71
         if not extended and int32ish:
             res = eng.query_groupby(dev, val_dic["g_col"], val_dic["select"], val_dic["groupbys"])
+            if want_device:
+                return DeviceRows(res, list(range(res.shape[1])), None, np.uint32)
             cols = [c.view(np.uint32) for c in res.columns()]
             names = [schema[val_dic["g_col"]]] + [f"{_AGG_NAME[i[0]]}({schema[i[1]]})" if i[0] != "key" else schema[i[1]]
                                                   for i in val_dic["items"]]
             return names, cols
-        return self._groupby_extended(dev, schema, val_dic)
+        return self._groupby_extended(dev, schema, val_dic, want_device=want_device)
 
     # ---- extension paths ---------------------------------------------------------
     def _join(self, ir):
@@ -222,7 +243,7 @@ class FutharkContext:
         res._keep = (cur,)                                             # the compacted input must outlive a borrowed view
         return res
 
-    def _groupby_extended(self, dev, schema, ir, provider=None, key_ranges=None, subset_provider=None):
+    def _groupby_extended(self, dev, schema, ir, provider=None, key_ranges=None, subset_provider=None, want_device=False):
         """SQL-typed GROUP BY [+ HAVING / ORDER BY / LIMIT].  `provider(cur, dev_preds, gkey, specs)` (the sharded
         context, dist.py) replaces the local aggregation: it returns a device Result [key, aggregates...] of ALL groups
         over all shards, ascending key; HAVING / ORDER BY / LIMIT then run here, on the device, exactly as for one GPU.
@@ -347,6 +368,8 @@ class FutharkContext:
                 cols[s_] = c2[j]
         if cols is None:
             res = grouped([spec_of(a) for a in aggs], having, order, None if (host_having or host_order) else ir.get("limit"))
+            if want_device and decode is None:                     # the select list = columns out_slots of this device result
+                return DeviceRows(res, out_slots, ir.get("limit"), None)
             # only the first LIMIT rows cross PCIe (unless key conditions / orders still have to run on the decoded result)
             cols = res.columns(limit=ir.get("limit") if not (host_having or host_order) else None)
         if decode is None:

@@ -130,7 +130,55 @@ int hark_d2h(hark_context *ctx, void *host, const void *dev, size_t bytes)
 
 extern "C" {
 
-int hark_version(void) { return 102; }   // 1.02: context_trim, futhark_* veneer (futhark_compat.h), hash join, multi-aggregate pass
+// ---- pinned host blocks ---------------------------------------------------------------------------------------------
+static size_t pin_round(size_t bytes) { const size_t g = bytes <= ((size_t)1 << 20) ? 65536 : (size_t)1 << 20; return (bytes + g - 1) / g * g; }
+
+int hark_host_alloc(hark_context *ctx, void **out, size_t bytes)
+{
+    if (!ctx || !out) return HARK_EARG;
+    hark_device_guard guard__(ctx);
+    *out = nullptr;
+    const size_t size = pin_round(bytes ? bytes : 1);
+    auto it = ctx->pin_free.lower_bound(size);
+    if (it != ctx->pin_free.end() && it->first <= 2 * size) {
+        *out = it->second;
+        ctx->pin_cached -= it->first;
+        ctx->pin_live[*out] = it->first;
+        ctx->pin_free.erase(it);
+        return HARK_OK;
+    }
+    hipError_t e = hipHostMalloc(out, size);
+    if (e != hipSuccess && !ctx->pin_free.empty()) {           // give the cached blocks back and try once more
+        (void)hipGetLastError();
+        for (auto &kv : ctx->pin_free) hipHostFree(kv.second);
+        ctx->pin_free.clear(); ctx->pin_cached = 0;
+        e = hipHostMalloc(out, size);
+    }
+    if (e != hipSuccess) {
+        *out = nullptr;
+        (void)hipGetLastError();
+        return hark_fail(ctx, HARK_ENOMEM, "hipHostMalloc(%zu bytes) failed: %s", size, hipGetErrorString(e));
+    }
+    ctx->pin_live[*out] = size;
+    return HARK_OK;
+}
+
+int hark_host_free(hark_context *ctx, void *ptr)
+{
+    if (!ptr) return HARK_OK;
+    if (!ctx) return hipHostFree(ptr) == hipSuccess ? HARK_OK : HARK_EHIP;   // the block outlived its context
+    hark_device_guard guard__(ctx);
+    auto it = ctx->pin_live.find(ptr);
+    if (it == ctx->pin_live.end()) return hark_fail(ctx, HARK_EARG, "hark_host_free: not a live block of this context");
+    const size_t size = it->second;
+    ctx->pin_live.erase(it);
+    if (ctx->pin_cached + size > ctx->pin_limit) { hipHostFree(ptr); return HARK_OK; }
+    ctx->pin_free.emplace(size, ptr);
+    ctx->pin_cached += size;
+    return HARK_OK;
+}
+
+int hark_version(void) { return 103; }   // 1.02: context_trim, futhark_* veneer (futhark_compat.h), hash join, multi-aggregate pass
 
 int hark_context_new(hark_context **out, int device)
 {
@@ -164,6 +212,8 @@ void hark_context_free(hark_context *ctx)
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     pool_trim(ctx);
+    // cached pinned blocks go; blocks still in a caller's hands stay valid and are released by hark_host_free(NULL, p)
+    for (auto &kv : ctx->pin_free) hipHostFree(kv.second);
     if (ctx->d_err) hipFree(ctx->d_err);
     if (ctx->h_pin) hipHostFree(ctx->h_pin);
     for (int i = 0; i < 2; i++) { if (ctx->bounce[i]) hipHostFree(ctx->bounce[i]); if (ctx->bounce_ev[i]) hipEventDestroy(ctx->bounce_ev[i]); }
@@ -185,6 +235,8 @@ int hark_context_trim(hark_context *ctx)
     hark_device_guard guard__(ctx);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     pool_trim(ctx);
+    for (auto &kv : ctx->pin_free) hipHostFree(kv.second);
+    ctx->pin_free.clear(); ctx->pin_cached = 0;
     return HARK_OK;
 }
 
@@ -389,6 +441,54 @@ int hark_result_columns_prefix(hark_context *ctx, const hark_result *r, int64_t 
         memcpy(host_outs[j], pin + off, b);
         off += (b + 15) & ~(size_t)15;
     }
+    return HARK_OK;
+}
+
+// The first `rows` rows of every column into ONE pinned host block the caller owns afterwards (hark_host_free): the copies are
+// enqueued back to back on the stream and the stream is drained once; column j starts at offsets[j] (64-byte aligned).  The
+// copy engine writes the caller's memory directly -- no bounce buffer and no host memcpy (the bounce path drained 8-MiB
+// pinned buffers with a single-threaded memcpy: 10-24 GB/s against ~50 for the DMA itself).
+int hark_result_columns_pinned(hark_context *ctx, const hark_result *r, int64_t rows, void **host_block, int64_t *offsets)
+{
+    hark_device_guard guard__(ctx);
+    if (!ctx || !r || !host_block || rows < 0 || (!offsets && !r->cols.empty())) return HARK_EARG;
+    *host_block = nullptr;
+    if (rows > r->n) rows = r->n;
+    size_t total = 0;
+    for (size_t j = 0; j < r->cols.size(); j++) { offsets[j] = (int64_t)total; total += ((size_t)rows * hark_dtype_size(r->cols[j].dtype) + 63) & ~(size_t)63; }
+    if (total == 0) return HARK_OK;
+    void *blk = nullptr;
+    HARK_TRY(hark_host_alloc(ctx, &blk, total));
+    for (size_t j = 0; j < r->cols.size(); j++) {
+        const size_t b = (size_t)rows * hark_dtype_size(r->cols[j].dtype);
+        if (!b) continue;
+        if (hipMemcpyAsync(static_cast<char *>(blk) + offsets[j], r->cols[j].data, b, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) {
+            hipStreamSynchronize(ctx->stream); hark_host_free(ctx, blk);
+            return hark_fail(ctx, HARK_EHIP, "result_columns_pinned: copy of column %zu failed: %s", j, hipGetErrorString(hipGetLastError()));
+        }
+    }
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        hark_host_free(ctx, blk);
+        return hark_fail(ctx, HARK_EHIP, "result_columns_pinned: %s", hipGetErrorString(hipGetLastError()));
+    }
+    *host_block = blk;
+    return HARK_OK;
+}
+
+// n contiguous bytes of device memory into a pinned host block the caller owns afterwards
+int hark_dev_download_pinned(hark_context *ctx, const void *dev, size_t bytes, void **host_block)
+{
+    hark_device_guard guard__(ctx);
+    if (!ctx || !host_block || (bytes && !dev)) return HARK_EARG;
+    *host_block = nullptr;
+    if (!bytes) return HARK_OK;
+    void *blk = nullptr;
+    HARK_TRY(hark_host_alloc(ctx, &blk, bytes));
+    if (hipMemcpyAsync(blk, dev, bytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        hark_host_free(ctx, blk);
+        return hark_fail(ctx, HARK_EHIP, "dev_download_pinned: %s", hipGetErrorString(hipGetLastError()));
+    }
+    *host_block = blk;
     return HARK_OK;
 }
 

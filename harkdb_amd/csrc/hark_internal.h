@@ -33,6 +33,11 @@ struct hark_context {
     // freed blocks kept for reuse up to pool_limit (HARK_POOL_LIMIT_MB; hark_context_trim gives them all back):
     // 64 GiB of 288: re-allocating multi-GB workspaces per query costs tens of ms (measured: C5 150 ms vs 2 ms with a 16 GiB limit)
     size_t pool_cached = 0, pool_limit = (size_t)64 << 30;
+    // pinned HOST blocks handed to callers as the storage of downloaded results (hark_host_alloc / hark_host_free): pinning a
+    // fresh 16-MiB buffer costs more than the copy into it, so freed blocks are kept (up to pin_limit) and reused
+    std::multimap<size_t, void *> pin_free;
+    std::unordered_map<void *, size_t> pin_live;
+    size_t pin_cached = 0, pin_limit = (size_t)4 << 30;
     // diagnostic: which GROUP BY path served the last group-by entry (hark_context_last_groupby_path)
     int last_groupby_path = 0;
     int last_groupby_passes = 0;             // row passes of the last dense-path filter_groupby (hark_context_last_groupby_passes)

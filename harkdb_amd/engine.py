@@ -55,6 +55,34 @@ def normalise_predicate(dt, cmp, value):
     return cmp, np.asarray([value], dtype=dt)
 
 
+class PinnedBlock:
+    """A pinned host block handed out by the library (hark_host_alloc and the *_pinned downloads): the storage of numpy
+    arrays that the copy engine filled directly.  Exposes the array interface, so `np.asarray(block)` is a byte view whose
+    base is this object -- every view / slice of it keeps the block alive, and the block goes back to the context's cache
+    of pinned blocks when the last of them is collected."""
+
+    def __init__(self, eng, ptr, nbytes):
+        self._eng, self._ptr, self.nbytes = eng, int(ptr), int(nbytes)
+        self.__array_interface__ = {"shape": (self.nbytes,), "typestr": "|u1", "data": (self._ptr, False), "version": 3}
+
+    def array(self, offset, count, dtype):
+        dtype = np.dtype(dtype)
+        return np.asarray(self)[offset: offset + count * dtype.itemsize].view(dtype)
+
+    def __del__(self):
+        try:
+            if self._ptr:
+                # a block that outlives its context is released without it (include/hark.h: hark_host_free(NULL, p))
+                self._eng.lib.hark_host_free(self._eng.ctx if self._eng.ctx is not None else None, self._ptr)
+                self._ptr = 0
+        except Exception:
+            pass
+
+
+PINNED_FROM = 1 << 16                     # downloads of at least this many bytes land in a pinned block (below: the context's pinned scratch)
+PINNED_UPTO = 2 << 30                     # ... and of at most this many (pinned memory is a finite resource of the host)
+
+
 class Result:
     """Device-resident query result (futhark opaque array + from_futhark)."""
 
@@ -73,13 +101,15 @@ class Result:
     def column(self, j, limit=None):
         """Column j on the host; limit = n downloads only the first n rows (LIMIT is applied before the PCIe copy)."""
         n, _ = self.shape
-        if limit is not None and limit < n:
-            return self._eng.download(self.device_ptr(j), max(int(limit), 0), self.dtype(j))
-        out = np.empty(n, dtype=self.dtype(j))
-        self._eng._chk(self._eng.lib.hark_result_column(self._eng.ctx, self._h, j, out.ctypes.data))
-        return out
+        rows = n if limit is None else min(n, max(int(limit), 0))
+        if rows == 0:
+            return np.empty(0, dtype=self.dtype(j))
+        return self._eng.download(self.device_ptr(j), rows, self.dtype(j))
 
     def columns(self, limit=None):
+        """Every column on the host (the first `limit` rows).  Small results come through the context's pinned scratch with one
+        synchronisation; larger ones are written by the copy engine straight into ONE pinned block that the returned arrays
+        are views of (copies enqueued back to back, one synchronisation, no bounce buffer and no host memcpy)."""
         n, m = self.shape
         rows = n if limit is None else min(n, max(int(limit), 0))
         if m > 1 and rows > 0 and rows * 16 * m <= 65536:              # a small result or a LIMIT prefix: every column with one synchronisation
@@ -87,7 +117,35 @@ class Result:
             ptrs = (C.c_void_p * m)(*[o.ctypes.data for o in outs])
             self._eng._chk(self._eng.lib.hark_result_columns_prefix(self._eng.ctx, self._h, rows, ptrs))
             return outs
+        dts = [np.dtype(self.dtype(j)) for j in range(m)]
+        total = sum(rows * d.itemsize + 64 for d in dts)
+        if m > 0 and rows > 0 and PINNED_FROM <= total <= PINNED_UPTO:
+            blk, offs = C.c_void_p(), (C.c_int64 * m)()
+            self._eng._chk(self._eng.lib.hark_result_columns_pinned(self._eng.ctx, self._h, rows, C.byref(blk), offs))
+            block = PinnedBlock(self._eng, blk.value, max(offs[j] + rows * dts[j].itemsize for j in range(m)))
+            return [block.array(offs[j], rows, dts[j]) for j in range(m)]
         return [self.column(j, limit) for j in range(m)]
+
+    def matrix(self, cols=None, limit=None, dtype=None):
+        """The reference's result shape (from_futhark, FutharkContext.py:66,71): ONE row-major [rows][len(cols)] matrix of the
+        result columns `cols` (default: all; repeats allowed) whose element type is numpy's result_type of their dtypes,
+        built ON THE DEVICE and copied once into a pinned block (hark_result_matrix_pinned)."""
+        n, m = self.shape
+        cols = list(range(m)) if cols is None else [int(c) for c in cols]
+        rows = n if limit is None else min(n, max(int(limit), 0))
+        if dtype is None:
+            dts = [np.dtype(self.dtype(j)) for j in cols]
+            dtype = np.dtype(np.int32) if not dts else (dts[0] if len(set(dts)) == 1 else np.result_type(*dts))
+        dtype = np.dtype(dtype)
+        code = {np.dtype(np.int32): _ffi.I32, np.dtype(np.uint32): _ffi.U32, np.dtype(np.float32): _ffi.F32,
+                np.dtype(np.int64): _ffi.I64, np.dtype(np.float64): _ffi.F64}[dtype]
+        if rows == 0 or not cols:
+            return np.empty((rows, len(cols)), dtype=dtype)
+        blk = C.c_void_p()
+        arr = (C.c_int32 * len(cols))(*cols)
+        self._eng._chk(self._eng.lib.hark_result_matrix_pinned(self._eng.ctx, self._h, arr, len(cols), rows, code, C.byref(blk)))
+        block = PinnedBlock(self._eng, blk.value, rows * len(cols) * dtype.itemsize)
+        return block.array(0, rows * len(cols), dtype).reshape(rows, len(cols))
 
     def device_ptr(self, j):
         return self._eng.lib.hark_result_column_device(self._h, j)
@@ -288,6 +346,14 @@ class Engine:
         self._chk(self.lib.hark_dev_upload(self.ctx, ptr, arr.ctypes.data, arr.nbytes))
 
     def download(self, ptr, n, dtype):
+        """n elements at device address ptr as a numpy array; from 64 KiB on the array lives in a pinned block the copy engine
+        wrote directly (tools/ingest_bench.py: the bounce-buffer path of earlier rounds reached 10-24 GB/s)."""
+        dtype = np.dtype(dtype)
+        nbytes = int(n) * dtype.itemsize
+        if PINNED_FROM <= nbytes <= PINNED_UPTO:
+            blk = C.c_void_p()
+            self._chk(self.lib.hark_dev_download_pinned(self.ctx, ptr, nbytes, C.byref(blk)))
+            return PinnedBlock(self, blk.value, nbytes).array(0, int(n), dtype)
         out = np.empty(n, dtype=dtype)
         self._chk(self.lib.hark_dev_download(self.ctx, out.ctypes.data, ptr, out.nbytes))
         return out

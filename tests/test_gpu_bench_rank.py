@@ -125,11 +125,13 @@ def test_strong_shard_of_the_billion_row_table_under_rccl():
 
 
 def test_a_dying_configs_child_does_not_lose_the_headline():
-    """The extra configs run in a child process with a wall-clock budget; a child that is killed mid-run (here: by a
-    budget it cannot meet) costs its unfinished configs only -- the ONE line still carries the headline."""
+    """The extra configs run in a child process with a wall-clock budget; a child that hangs mid-run (here: told to stall after
+    its third config, as a wedged kernel would) is killed at the budget and costs its unfinished configs only -- the ONE line
+    still carries the headline and the configs the child had written."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rows", "64000000", "--groups", str(1 << 20), "--steps", "2", "--warmup", "1",
-                          "--cpu-rows", "0", "--configs", "1", "--config-scale", "0.5", "--configs-budget", "6", "--pmc", "0"],
+    env["HARK_BENCH_CHILD_STALL"] = "G4096"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rows", "16000000", "--groups", str(1 << 20), "--steps", "2", "--warmup", "1",
+                          "--cpu-rows", "0", "--configs", "1", "--config-scale", "0.02", "--configs-budget", "30", "--pmc", "0"],
                          capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stdout + out.stderr
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -137,7 +139,18 @@ def test_a_dying_configs_child_does_not_lose_the_headline():
     line = json.loads(lines[0])
     assert line["value"] > 0 and line["check"]["count_checksum"] is True and line["roofline"]["frac"] > 0
     assert "killed at its wall-clock budget" in line["configs"]["error"], line["configs"]
-    assert "C5_three_aggregates_all_groups" not in line["configs"]
+    assert "C3_no_filter" in line["configs"] and "G16" in line["configs"] and "G4096" in line["configs"]     # what it had finished survives
+    assert "G13000" not in line["configs"] and "C5_three_aggregates_all_groups" not in line["configs"]
+
+
+def test_a_crashing_configs_child_does_not_lose_the_headline():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rows", "16000000", "--groups", str(1 << 20), "--steps", "2", "--warmup", "1",
+                          "--cpu-rows", "0", "--configs", "1", "--config-scale", "-1", "--pmc", "0"],          # a negative scale: the child raises
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert line["value"] > 0 and "exited with rc" in line["configs"]["error"], line["configs"]
 
 
 def test_bench_line_survives_sigterm_during_the_extras():

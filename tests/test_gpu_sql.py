@@ -707,3 +707,72 @@ def test_sparse_keys_statistics_of_one_column_in_one_hash_pass(distinct):
     assert np.array_equal(cols[7], g.u.min().to_numpy()) and np.array_equal(cols[8], g.u.max().to_numpy())
     assert np.array_equal(cols[9], g.u.sum().to_numpy().astype(np.int64))
     assert np.array_equal(cols[10], g.f.count().to_numpy())
+
+
+# ---- results on the host: pinned blocks and the device-built matrix ------------------------------
+MATRIX_STATEMENTS = [
+    "select k, w from t",                                                   # all int32: an int32 matrix, bit copies
+    "select k, v, big from t where p > 0.25",                               # i32 + f32 + i64 -> float64
+    "select k, big from t where p > 0.5",                                   # i32 + i64 -> int64
+    "select v, p from t order by p limit 1000",                             # all f32, LIMIT prefix
+    "select k, sum(v), count(*) from t where p > 0.5 group by k",           # i32 + f32 + i64 -> float64 (the C5 statement's shape)
+    "select k, sum(v), count(*), avg(v), k from t group by k",              # the key twice: repeated result columns
+    "select k, sum(w), max(w), min(w) from t group by k having count(*) > 150 order by sum(w) desc",
+    "select k, max(v) from t group by k order by max(v) desc limit 7",
+    "select col1, col3 from game_1",                                        # the reference's statements: int32 / uint32 matrices
+    "select col1,  max(col3) from game_1 group by col1",
+]
+
+
+@pytest.mark.parametrize("stmt", MATRIX_STATEMENTS)
+def test_sql_matrix_built_on_the_device_equals_the_host_interleave(fc, stmt):
+    """sql() builds the reference's [rows][columns] matrix on the device (Result.matrix -> hark_result_matrix_pinned) when the
+    statement's result is a device Result as it stands; it must equal the typed host columns of sql_columns() interleaved and
+    converted by numpy, element type included."""
+    names, cols = fc.sql_columns(stmt)
+    dts = {c.dtype for c in cols}
+    dtype = dts.pop() if len(dts) == 1 else np.result_type(*[c.dtype for c in cols])
+    exp = np.empty((len(cols[0]), len(cols)), dtype=dtype)
+    for j, c in enumerate(cols):
+        exp[:, j] = c
+    out = fc.sql(stmt)
+    assert out.dtype == exp.dtype and out.shape == exp.shape and np.array_equal(out, exp, equal_nan=True), (out.dtype, exp.dtype, out.shape, exp.shape)
+    assert out.flags.c_contiguous and out.flags.writeable
+
+
+def test_large_results_land_in_pinned_blocks_that_outlive_the_result(fc):
+    """From 64 KiB on, Result.columns() / column() / Engine.download() return numpy views of ONE pinned block per call that
+    the copy engine wrote directly; the views stay valid after the Result is freed and after further queries re-use freed
+    blocks (a block returns to the context's cache only when its last view is collected)."""
+    import gc
+    from harkdb_amd.engine import PinnedBlock
+    eng, dev = fc.FutEnv, fc.tables["t"]._device
+    df = fc._df
+    res = eng.filter_sel(dev, 1, ">", 0.5, [0, 3, 4], want_row_index=True)            # row index i64, k i32, w i32, big i64
+    cols = res.columns()
+    keep = df[df.p > 0.5]
+    assert all(isinstance(c.base.base, PinnedBlock) or isinstance(c.base, PinnedBlock) or isinstance(getattr(c.base, "base", None), np.ndarray) for c in cols)
+    one = res.column(3)
+    res.free()
+    others = [eng.filter_sel(dev, 1, ">", t, [0, 3, 4], want_row_index=True).columns() for t in (0.1, 0.9, 0.3)]   # more blocks come and go
+    del others
+    gc.collect()
+    again = eng.filter_sel(dev, 1, "<=", 0.5, [0], want_row_index=False).columns()
+    assert np.array_equal(cols[0], keep.index.to_numpy()) and np.array_equal(cols[1], keep.k.to_numpy())
+    assert np.array_equal(cols[2], keep.w.to_numpy()) and np.array_equal(cols[3], keep.big.to_numpy()) and np.array_equal(one, keep.big.to_numpy())
+    assert np.array_equal(again[0], df[df.p <= 0.5].k.to_numpy())
+    cols[1][:] = 7                                                                       # the views are ordinary writable arrays
+    assert int(cols[1].sum()) == 7 * len(keep) and np.array_equal(cols[2], keep.w.to_numpy())
+
+
+def test_result_matrix_rejects_what_it_cannot_convert(fc):
+    from harkdb_amd import _ffi
+    eng, dev = fc.FutEnv, fc.tables["t"]._device
+    res = eng.query_sel(dev, [0, 1])                                                     # k i32, p f32
+    with pytest.raises(_ffi.HarkError, match="does not convert"):
+        res.matrix(dtype=np.int64)
+    with pytest.raises(_ffi.HarkError, match="column 5"):
+        res.matrix(cols=[0, 5])
+    assert res.matrix(cols=[]).shape == (res.shape[0], 0) and res.matrix(limit=0).shape == (0, 2)
+    m = res.matrix(limit=10)
+    assert m.dtype == np.float64 and np.array_equal(m[:, 0], fc._df.k.to_numpy()[:10]) and np.array_equal(m[:, 1].astype(np.float32), fc._df.p.to_numpy()[:10])

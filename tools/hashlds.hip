@@ -1,0 +1,111 @@
+// hashlds.hip -- what does the LDS side of a hash GROUP BY probe cost on gfx950, layout by layout?  
+//
+// fgb_agg_hash_kernel is LDS-bound (profiles/r05_hash_pmc.txt: the LDS arrays are busy 72 % of the kernel's cycles, 59 % of
+// those cycles are bank-conflict cycles).  Per pair it issues two ds_read_b128 (the eight 32-bit tags of the key's home
+// group), one ds_add_f64 (SUM) and one ds_add_u32 (COUNT), all at random addresses.  This probe runs ONLY that LDS work --
+// steady state, every pair a hit, slots drawn uniformly, eight pairs per lane in flight as in the kernel, one 1024-thread
+// workgroup per CU, no global traffic -- for the layouts one could give the table, and prints the time for 2.5e8 pairs
+// chip-wide, to be read against the stream floor of those pairs (0.34 ms) and the kernel's 0.68-0.73 ms.
+// Build: make -C tools hashlds.  Run on the GPU box: tools/hashlds
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstdint>
+#include <vector>
+#include <algorithm>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
+
+constexpr int kSlots = 8192;
+__device__ __forceinline__ uint32_t lcg(uint32_t x) { return x * 1664525u + 1013904223u; }
+
+// what one pair does:
+//  bit 0: two ds_read_b128 of a 32-byte group of 32-bit tags      bit 1: one ds_read_b128 of a 16-byte group (16-bit tags x 8 .. or 16)
+//  bit 2: one ds_read_b64 of an 8-byte group                       bit 3: ds_add_f64 at the slot
+//  bit 4: ds_add_u32 at the slot                                   bit 5: ds_add_u64 at the slot (integer sums / a packed word)
+//  bit 6: ds_add_f64 of a SECOND value array (count kept as a double)
+//  bit 7: the atomics of a wave-step are issued slot-sorted?  (not modelled)  -- unused
+template <int WHAT>
+__global__ __launch_bounds__(1024) void probe_kernel(int steps, uint32_t *out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    double *t_val = reinterpret_cast<double *>(lds);                              // [kSlots]
+    uint32_t *t_tag = reinterpret_cast<uint32_t *>(t_val + kSlots);               // [kSlots]
+    uint32_t *t_cnt = t_tag + kSlots;                                             // [kSlots]
+    double *t_val2 = reinterpret_cast<double *>(t_cnt + kSlots);                  // [kSlots / 2] (only when bit 6)
+    for (int i = threadIdx.x; i < kSlots; i += blockDim.x) { t_val[i] = 0.0; t_tag[i] = (uint32_t)i * 2654435761u; t_cnt[i] = 0u; }
+    if (WHAT & 64) for (int i = threadIdx.x; i < kSlots / 2; i += blockDim.x) t_val2[i] = 0.0;
+    __syncthreads();
+    uint32_t r = threadIdx.x * 2654435761u + blockIdx.x * 40503u;
+    uint32_t acc = 0;
+    const uint4 *tag4 = reinterpret_cast<const uint4 *>(t_tag);
+    const uint2 *tag2 = reinterpret_cast<const uint2 *>(t_tag);
+    for (int s = 0; s < steps; s++) {
+        uint32_t slot[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) { r = lcg(r); slot[j] = (r >> 9) & (kSlots - 1); }
+        uint4 qa[8], qb[8]; uint2 qc[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            if (WHAT & 1) { qa[j] = tag4[2u * (slot[j] >> 3)]; qb[j] = tag4[2u * (slot[j] >> 3) + 1u]; }
+            if (WHAT & 2) qa[j] = tag4[slot[j] >> 2];                            // 16-byte groups anywhere in the tag array
+            if (WHAT & 4) qc[j] = tag2[slot[j] >> 1];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            uint32_t at = slot[j];
+            if (WHAT & 1) { acc += qa[j].x ^ qa[j].w ^ qb[j].y; at = (at & ~7u) | ((qa[j].x ^ qb[j].z) & 7u); }       // the slot depends on the tags read (as a real probe's does)
+            if (WHAT & 2) { acc += qa[j].x ^ qa[j].w; at = (at & ~7u) | ((qa[j].x ^ qa[j].z) & 7u); }
+            if (WHAT & 4) { acc += qc[j].x; at = (at & ~7u) | ((qc[j].x ^ qc[j].y) & 7u); }
+            if (WHAT & 8) unsafeAtomicAdd(&t_val[at], 1.0);
+            if (WHAT & 16) atomicAdd(&t_cnt[at], 1u);
+            if (WHAT & 32) atomicAdd(reinterpret_cast<unsigned long long *>(&t_val[at]), 1ull);
+            if (WHAT & 64) unsafeAtomicAdd(&t_val2[at >> 1], 1.0);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = acc + t_cnt[7] + (uint32_t)t_val[9];
+}
+
+template <int WHAT> static void run(const char *name, uint32_t *out, int ncu)
+{
+    const double pairs = 2.5e8;
+    const int steps = (int)(pairs / ((double)ncu * 1024 * 8) + 0.5);
+    const size_t lds = (size_t)kSlots * 16 + ((WHAT & 64) ? (size_t)kSlots * 4 : 0);
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&probe_kernel<WHAT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    std::vector<float> ts;
+    for (int rep = 0; rep < 6; rep++) {
+        CK(hipEventRecord(e0));
+        probe_kernel<WHAT><<<ncu, 1024, lds>>>(steps, out);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (rep) ts.push_back(ms);
+    }
+    CK(hipGetLastError());
+    std::sort(ts.begin(), ts.end());
+    const double done = (double)steps * ncu * 1024 * 8;
+    printf("%-86s %7.3f ms per 2.5e8 pairs  (%.1f LDS-busy-equivalent cycles per 64 pairs at 2.4 GHz)\n", name, ts[2] * pairs / done,
+           ts[2] * 1e-3 * 2.4e9 / (done / ncu / 64));
+}
+
+int main()
+{
+    hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
+    const int ncu = prop.multiProcessorCount;
+    uint32_t *out; CK(hipMalloc(&out, 4096 * 4));
+    printf("hashlds: LDS work of a hash-table probe alone, %d CUs x 1024 threads, 8 pairs per lane and step, random slots in %d\n", ncu, kSlots);
+    run<0>("nothing (address generation only)", out, ncu);
+    run<1>("2 x ds_read_b128 (eight 32-bit tags: today's probe)", out, ncu);
+    run<2>("1 x ds_read_b128 (sixteen / eight 16-bit tags)", out, ncu);
+    run<4>("1 x ds_read_b64  (four 16-bit tags)", out, ncu);
+    run<8>("ds_add_f64", out, ncu);
+    run<16>("ds_add_u32", out, ncu);
+    run<32>("ds_add_u64", out, ncu);
+    run<8 | 16>("ds_add_f64 + ds_add_u32 (the hit of SUM + COUNT)", out, ncu);
+    run<1 | 8 | 16>("2 x b128 + f64 + u32  = fgb_agg_hash_kernel today", out, ncu);
+    run<2 | 8 | 16>("1 x b128 + f64 + u32  = 16-bit tags", out, ncu);
+    run<4 | 8 | 16>("1 x b64  + f64 + u32  = four 16-bit tags per group", out, ncu);
+    run<2 | 8>("1 x b128 + f64        (no count atomic)", out, ncu);
+    run<2 | 32>("1 x b128 + u64        (one integer atomic: u32 sums, or a packed word)", out, ncu);
+    run<2 | 8 | 64>("1 x b128 + f64 + f64  (count as a double beside the sum)", out, ncu);
+    return 0;
+}
