@@ -602,7 +602,7 @@ def extra_configs(torch, eng, dev, a, sink, out):
 
         def step():
             plan.reset()
-            plan.run(p.data_ptr(), ">", thr, k.data_ptr(), v.data_ptr(), N)
+            plan.run(p.data_ptr(), ">=" if thr == 0.0 else ">", thr, k.data_ptr(), v.data_ptr(), N)   # p >= 0: every row survives, the predicate column is still read
             plan.finish(so.data_ptr(), co.data_ptr())
 
         ms = event_ms(torch, step)

@@ -14,6 +14,16 @@ int hark_fail(hark_context *ctx, int code, const char *fmt, ...)
     return code;
 }
 
+int hark_launch_failed(hark_context *ctx, hipError_t e, const char *launch_text, const char *file, int line)
+{
+    char name[160];
+    size_t i = 0;
+    while (launch_text[i] && i + 1 < sizeof name && !(launch_text[i] == '<' && launch_text[i + 1] == '<' && launch_text[i + 2] == '<')) { name[i] = launch_text[i]; i++; }
+    name[i] = 0;
+    const char *base = strrchr(file, '/');
+    return hark_fail(ctx, HARK_EHIP, "launch of %s failed: %s (%s:%d)", name, hipGetErrorString(e), base ? base + 1 : file, line);
+}
+
 // ---- caching device allocator ---------------------------------------------------
 // Every entry allocates its result columns and scratch; hipMalloc/hipFree cost
 // 0.1-1 ms each and hipFree synchronises the device, which would dominate a

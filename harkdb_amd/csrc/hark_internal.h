@@ -102,6 +102,37 @@ int hark_fail(hark_context *ctx, int code, const char *fmt, ...);
                              hipGetErrorString(e__), __FILE__, __LINE__);               \
     } while (0)
 
+// ---- kernel launches --------------------------------------------------------------------------------------------------
+// A launch that asks for more LDS or registers than a CU has, or for an impossible grid, is REFUSED when it is made; unchecked,
+// it surfaces at the next synchronisation with a generic message (or as wrong results, when nothing synchronises before the
+// output is read).  Every launch of the operator units goes through one of these two: the launch, then hipGetLastError(), and
+// a failure names the kernel (the text of the launch up to its "<<<").  HARK_LAUNCH returns from the calling function;
+// HARK_LAUNCH_RC launches only while `rc` is still HARK_OK and records the failure in it (functions that clean up at the end).
+int hark_launch_failed(hark_context *ctx, hipError_t e, const char *launch_text, const char *file, int line);
+#define HARK_LAUNCH(ctx, ...)                                                                                  \
+    do {                                                                                                       \
+        __VA_ARGS__;                                                                                           \
+        const hipError_t le__ = hipGetLastError();                                                             \
+        if (le__ != hipSuccess) return hark_launch_failed((ctx), le__, #__VA_ARGS__, __FILE__, __LINE__);      \
+    } while (0)
+#define HARK_LAUNCH_RC(ctx, rc, ...)                                                                           \
+    do {                                                                                                       \
+        if ((rc) == HARK_OK) {                                                                                 \
+            __VA_ARGS__;                                                                                       \
+            const hipError_t le__ = hipGetLastError();                                                         \
+            if (le__ != hipSuccess) (rc) = hark_launch_failed((ctx), le__, #__VA_ARGS__, __FILE__, __LINE__);  \
+        }                                                                                                      \
+    } while (0)
+// the same for the runtime calls of an rc-style function (hipMemsetAsync and friends)
+#define HIP_TRY_RC(ctx, rc, call)                                                                              \
+    do {                                                                                                       \
+        if ((rc) == HARK_OK) {                                                                                 \
+            const hipError_t e__ = (call);                                                                     \
+            if (e__ != hipSuccess)                                                                             \
+                (rc) = hark_fail((ctx), HARK_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+        }                                                                                                      \
+    } while (0)
+
 #define HARK_TRY(call)                 \
     do {                               \
         int rc__ = (call);             \

@@ -1406,72 +1406,82 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash_kernel(
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     u64 *t_val = reinterpret_cast<u64 *>(lds_raw);                       // [kHashCap]
-    uint32_t *t_tag = reinterpret_cast<uint32_t *>(t_val + kHashCap);    // [kHashCap] low bits of mix32(key) | 2^31, 0 = empty
-    uint32_t *t_cnt = t_tag + kHashCap;                                  // [kHashCap] rows
+    uint32_t *t_cnt = reinterpret_cast<uint32_t *>(t_val + kHashCap);    // [kHashCap] rows
+    uint32_t *t_tagw = t_cnt + kHashCap;                                 // [kHashCap / 2] 16-bit tags, two per word, eight per 16-byte group (0 = empty)
     __shared__ uint32_t s_used, s_emit;
     __shared__ unsigned long long s_base;
     const uint32_t b = blockIdx.x;
     const int lowbits = 33 - __ffs((int)gridDim.x);                      // P = gridDim.x buckets, a power of two: bucket = mix32(key) >> lowbits
     const uint32_t lowmask = (1u << lowbits) - 1u;
-    for (int i = threadIdx.x; i < kHashCap; i += blockDim.x) { t_tag[i] = 0u; t_cnt[i] = 0u; t_val[i] = vop_identity(VOP); }
+    for (int i = threadIdx.x; i < kHashCap; i += blockDim.x) { t_cnt[i] = 0u; t_val[i] = vop_identity(VOP); }
+    for (int i = threadIdx.x; i < kHashCap / 2; i += blockDim.x) t_tagw[i] = 0u;
     if (threadIdx.x == 0) { s_used = 0u; s_emit = 0u; }
     __syncthreads();
     bool overflow = false;
-    // What the kernel costs, by elimination on 2.5e8 pairs (profiles/r04_notes.md): the stream of pairs alone 0.34 ms, first-slot
-    // reads and the atomics of the hits 0.05 ms, and the per-pair probe LOOP of the ~15 % of the pairs that did not sit in their
-    // first slot 0.65 ms -- a wave nearly always has some lane that misses (0.85^64), so nearly every pair dragged all 64
-    // lanes through a divergent loop of dependent LDS round trips.  Slots are therefore grouped in EIGHTS: a probe reads the
-    // eight tags of its key's group with two ds_read_b128 and finds the key among them without a branch; a key leaves its
-    // home group only when that is full of other keys (load 0.25-0.375: Poisson(2..3) keys per group, > 8 in 0.02-0.4 % of
-    // the groups), so hardly a wave sees the slow path once the table is built.  (Groups of four: 1.90 -> 1.42 ms per 5e8
-    // pairs, a quarter of the steps still had a lane walking on.)
+    // What the kernel costs (profiles/r04_notes.md 3, r05_notes.md 2): the stream of pairs 0.34 ms per 2.5e8; the rest is the LDS --
+    // round 4's counters of the 32-bit-tag version: LDS arrays busy 72 % of the kernel's cycles, 59 % of them bank-conflict
+    // cycles, and tools/hashlds.hip prices the LDS work of a probe alone: two ds_read_b128 (eight 32-bit tags) + ds_add_f64 +
+    // ds_add_u32 at random addresses 170 cycles per 64 pairs, ONE ds_read_b128 + the same atomics 112 (reads and atomics
+    // cost more together than apart, whatever their order: pipelined and barrier-separated variants measure the same).
+    // Hence 16-BIT tags, eight to a 16-byte group: a probe is ONE ds_read_b128.  mix32 is a bijection and a bucket holds the keys
+    // with one value of its top bits, so the low `lowbits` bits x of mix32(key) ARE the key inside the bucket; its home group is
+    // the top 10 bits of x (1024 groups) and the tag the remaining lowbits - 10 <= 14 bits | 2^15 (occupied).  A key whose home
+    // group is full of other keys (load <= 0.375: Poisson(3) keys per group, > 8 in 0.4 % of the groups) lives in the NEXT group
+    // with bit 14 set (displaced by one), and nowhere else: a round in which that group is full too reports an overflow
+    // (the caller halves the keys per round).  A probe finds its key in the home group without a branch; anything else -- a
+    // new key, a displaced key -- takes the slow path, which hardly a wave sees once the table is built.
     constexpr int kNP = 8;
-    constexpr uint32_t kGroups = kHashCap / 8;
-    uint4 *t_tag4 = reinterpret_cast<uint4 *>(t_tag);
-    struct Tags8 { uint4 a, b; };
-    auto load8 = [&](uint32_t g) -> Tags8 { return Tags8{t_tag4[2u * g], t_tag4[2u * g + 1u]}; };
-    auto find8 = [](const Tags8 &q, uint32_t t) -> int {
-        return q.a.x == t ? 0 : q.a.y == t ? 1 : q.a.z == t ? 2 : q.a.w == t ? 3 : q.b.x == t ? 4 : q.b.y == t ? 5 : q.b.z == t ? 6 : q.b.w == t ? 7 : -1;
+    constexpr uint32_t kGroups = kHashCap / 8, kGroupBits = 10;
+    static_assert(kGroups == 1u << kGroupBits, "group index = a bit field of the key's low bits");
+    const int rembits = lowbits - (int)kGroupBits;                       // <= 14 (P >= 256 buckets: the host checks)
+    const uint32_t remmask = (1u << rembits) - 1u;
+    const uint4 *t_tag4 = reinterpret_cast<const uint4 *>(t_tagw);
+    auto find8 = [](const uint4 &q, uint32_t t2) -> int {               // t2 = tag | tag << 16; -1: not among the eight
+        const uint32_t x0 = q.x ^ t2, x1 = q.y ^ t2, x2 = q.z ^ t2, x3 = q.w ^ t2;
+        return !(x0 & 0xFFFFu) ? 0 : !(x0 >> 16) ? 1 : !(x1 & 0xFFFFu) ? 2 : !(x1 >> 16) ? 3 : !(x2 & 0xFFFFu) ? 4 : !(x2 >> 16) ? 5 : !(x3 & 0xFFFFu) ? 6 : !(x3 >> 16) ? 7 : -1;
     };
     auto hit = [&](uint32_t slot, uint32_t vbits) { vop_atomic<VOP>(&t_val[slot], VOP == VOP_F32SUM ? vbits : apply_xf(xf, vbits)); atomicAdd(&t_cnt[slot], 1u); };
-    // the key is not among the tags `q` of group g as they were read: claim the group's first empty slot, or walk on.
-    // Slots only ever go from empty to occupied and every lane tries a group's empty slots in ascending order, so two lanes
-    // with the same key end up in the same slot (the loser of a claim sees the winner's tag: its own, or it reads the group again).
-    auto slow = [&](uint32_t tag, uint32_t g, Tags8 q, uint32_t vbits) {
-        for (uint32_t step = 0; step < 8u * kGroups; step++) {
-            const int at = find8(q, tag);
-            if (at >= 0) { hit(8u * g + (uint32_t)at, vbits); return; }
-            const int e = find8(q, 0u);
-            if (e >= 0) {
+    // the key is not in its home group g as that group was read: claim the first empty slot there, or -- the group full of other
+    // keys -- look / claim in group g + 1 under the displaced tag.  Slots only ever go from empty to occupied and every lane takes
+    // a group's first empty slot, with a compare-and-swap on the WORD that holds it: a lane that loses (the word changed: its
+    // neighbour half or the slot itself) reads the group again, so two lanes with one key end up in one slot.
+    auto slow = [&](uint32_t tag, uint32_t g, uint32_t vbits) {
+        for (uint32_t d = 0; d < 2u; d++) {
+            const uint32_t gg = (g + d) & (kGroups - 1u), t = tag | (d << 14), t2 = t | (t << 16);
+            for (int tries = 0; tries < 64; tries++) {                     // (each failed claim is another lane's success: <= 8 per group)
+                const uint4 q = t_tag4[gg];
+                const int at = find8(q, t2);
+                if (at >= 0) { hit(8u * gg + (uint32_t)at, vbits); return; }
+                const int e = find8(q, 0u);
+                if (e < 0) break;                                            // full of other keys: the next group, once
                 if (s_used >= (uint32_t)kHashFill) { overflow = true; return; }
-                const uint32_t old = atomicCAS(&t_tag[8u * g + (uint32_t)e], 0u, tag);      // ds_cmpst_rtn_b32
-                if (old == 0u) { atomicAdd(&s_used, 1u); hit(8u * g + (uint32_t)e, vbits); return; }
-                if (old == tag) { hit(8u * g + (uint32_t)e, vbits); return; }
-            } else g = (g + 1u) & (kGroups - 1u);                             // a full group of other keys
-            q = load8(g);
+                const uint32_t w = e >> 1, oldw = w == 0 ? q.x : w == 1 ? q.y : w == 2 ? q.z : q.w;
+                const uint32_t neww = oldw | (t << (16 * (e & 1)));
+                if (atomicCAS(&t_tagw[4u * gg + w], oldw, neww) == oldw) { atomicAdd(&s_used, 1u); hit(8u * gg + (uint32_t)e, vbits); return; }   // ds_cmpst_rtn_b32
+            }
         }
         overflow = true;
     };
     auto probe = [&](const uint32_t (&key)[kNP], const uint32_t (&vb)[kNP], uint32_t live) {
-        uint32_t tag[kNP], g[kNP]; Tags8 q[kNP];
+        uint32_t tag[kNP], g[kNP]; uint4 q[kNP];
 #pragma unroll
         for (int j = 0; j < kNP; j++) {
-            const uint32_t m = key[j];                                        // the producer wrote mix32(key)
-            tag[j] = (m & lowmask) | 0x80000000u;
-            g[j] = (m * 0x9E3779B1u) >> 22;                                  // 10 bits (kGroups), mixed from the bits below the bucket's
+            const uint32_t x = key[j] & lowmask;                              // the producer wrote mix32(key)
+            g[j] = x >> rembits;
+            tag[j] = (x & remmask) | 0x8000u;
             if (Rmask && (mix32(key[j] ^ 0x9E3779B9u) & Rmask) != r) live &= ~(1u << j);   // not this round's share of the key space
         }
 #pragma unroll
-        for (int j = 0; j < kNP; j++) q[j] = load8(g[j]);                    // 2 x kNP independent 16-byte LDS reads in flight
+        for (int j = 0; j < kNP; j++) q[j] = t_tag4[g[j]];                   // kNP independent 16-byte LDS reads in flight
         uint32_t miss = 0;
 #pragma unroll
         for (int j = 0; j < kNP; j++) {
-            const int at = find8(q[j], tag[j]);
+            const int at = find8(q[j], tag[j] | (tag[j] << 16));
             if ((live >> j) & 1u) { if (at >= 0) hit(8u * g[j] + (uint32_t)at, vb[j]); else miss |= 1u << j; }
         }
         if (__any(miss != 0u)) {
 #pragma unroll
-            for (int j = 0; j < kNP; j++) if ((miss >> j) & 1u) slow(tag[j], g[j], q[j], vb[j]);
+            for (int j = 0; j < kNP; j++) if ((miss >> j) & 1u) slow(tag[j], g[j], vb[j]);
         }
     };
     walk_pair_slabs(pbuf, counts, cap, nwg, b, [&](const uint32_t (&key)[kNP], const uint32_t (&vb)[kNP], uint32_t live) -> bool {
@@ -1487,11 +1497,15 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash_kernel(
     __syncthreads();
     if (threadIdx.x == 0) s_base = s_emit ? atomicAdd(out_cursor, (unsigned long long)s_emit) : 0ull;
     __syncthreads();
+    const uint16_t *t_tag16 = reinterpret_cast<const uint16_t *>(t_tagw);
     for (int i = threadIdx.x; i < kHashCap; i += blockDim.x) {
         const uint32_t c = t_cnt[i];
         if (!c) continue;
         const unsigned long long o = s_base + pos++;
-        if (o < out_cap) { out_key[o] = unmix32((b << lowbits) | (t_tag[i] & lowmask)); out_val[o] = t_val[i]; out_cnt[o] = (u64)c; }
+        if (o < out_cap) {
+            const uint32_t t = t_tag16[i], home = (((uint32_t)i >> 3) - ((t >> 14) & 1u)) & (kGroups - 1u);   // a displaced key's home is the group before
+            out_key[o] = unmix32((b << lowbits) | (home << rembits) | (t & remmask)); out_val[o] = t_val[i]; out_cnt[o] = (u64)c;
+        }
         else *err = kErrOverflow;
     }
 }
@@ -1964,9 +1978,10 @@ int hark_fgb_plan_new(hark_context *ctx, hark_fgb_plan **out, int64_t max_rows, 
     if (!rc) rc = hark_alloc(ctx, (void **)&pl->acc_sum, (size_t)G * sizeof(double));
     if (!rc) rc = hark_alloc(ctx, (void **)&pl->acc_cnt, (size_t)G * sizeof(unsigned long long));
     if (rc) { hark_fgb_plan_free(ctx, pl); return rc; }
-    hipMemsetAsync(pl->err, 0, 16, ctx->stream);
-    hipMemsetAsync(pl->acc_sum, 0, (size_t)G * sizeof(double), ctx->stream);
-    hipMemsetAsync(pl->acc_cnt, 0, (size_t)G * sizeof(unsigned long long), ctx->stream);
+    HIP_TRY_RC(ctx, rc, hipMemsetAsync(pl->err, 0, 16, ctx->stream));
+    HIP_TRY_RC(ctx, rc, hipMemsetAsync(pl->acc_sum, 0, (size_t)G * sizeof(double), ctx->stream));
+    HIP_TRY_RC(ctx, rc, hipMemsetAsync(pl->acc_cnt, 0, (size_t)G * sizeof(unsigned long long), ctx->stream));
+    if (rc) { hark_fgb_plan_free(ctx, pl); return rc; }
     *out = pl;
     return HARK_OK;
 }
@@ -2547,7 +2562,7 @@ int k_fgb_hash_u32(hark_context *ctx, const uint32_t *k, const uint32_t *v, int6
         return r2;
     };
     uint32_t used_R = 1;
-    if (!rc) hipMemsetAsync(perr, 0, 32, st);
+    HIP_TRY_RC(ctx, rc, hipMemsetAsync(perr, 0, 32, st));
     if (!rc && !reuse) {
         const size_t lds_part = part_lds_bytes(P, 0);
         rc = dispatch_op(pcmp, pp != nullptr, [&](auto op) -> int {
@@ -2563,7 +2578,7 @@ int k_fgb_hash_u32(hark_context *ctx, const uint32_t *k, const uint32_t *v, int6
         // costs one wasted consumer pass on the way to the sort-based path instead of a round trip on every call)
     }
     if (!rc) {
-        const size_t lds_hash = (size_t)kHashCap * 16;
+        const size_t lds_hash = (size_t)kHashCap * 14;                 // 8-byte value slot + 4-byte count + 2-byte tag per entry
         // run all rounds of an R-round aggregation; e != 0 afterwards means some table overflowed
         auto run_rounds = [&](uint32_t R, uint32_t r_begin, uint32_t r_end) -> int {
             const unsigned long long out_cap = (unsigned long long)P * fill * (r_end - r_begin);
@@ -2575,7 +2590,7 @@ int k_fgb_hash_u32(hark_context *ctx, const uint32_t *k, const uint32_t *v, int6
             if (!r2 && stats) r2 = hark_alloc(ctx, (void **)&omin, (size_t)out_cap * 8);
             if (!r2 && stats) r2 = hark_alloc(ctx, (void **)&omax, (size_t)out_cap * 8);
             if (r2) return r2;
-            hipMemsetAsync(perr + 2, 0, 24, st);                       // the consumers' error word and the cursor; the producer's word stays
+            HIP_TRY(ctx, hipMemsetAsync(perr + 2, 0, 24, st));        // the consumers' error word and the cursor; the producer's word stays
             if (stats) {
                 const size_t lds_s = (size_t)kHashSCap * 24;
                 auto go = [&](auto vkc) -> int {
@@ -2626,9 +2641,14 @@ int k_fgb_hash_u32(hark_context *ctx, const uint32_t *k, const uint32_t *v, int6
             return r2;
         };
         const uint32_t hint = rounds_hint ? *rounds_hint : 0u;
+        constexpr uint32_t kMaxRoundsWorth = 16;
         used_R = hint ? hint : 1u;
         rc = run_rounds(used_R, 0, used_R);
         if (!rc && e_prod != 0 && why_not) *why_not = HARK_HASH_NOFIT_SKEW;            // a slab or a ring overflowed: the keys are skewed
+        // a hint is the R that ANOTHER pass over this key column needed, and the consumers' tables differ in size (6144 keys per
+        // bucket and round with one or two operators, 4608 with three, 3072 typed, 2560 statistics): a hinted R that overflows
+        // is doubled until it fits, instead of declaring the column unfit for the hash path for good
+        while (!rc && e != 0 && hint && e_prod == 0 && used_R < kMaxRoundsWorth) { used_R *= 2; rc = run_rounds(used_R, 0, used_R); }
         if (!rc && e != 0 && !hint && e_prod == 0) {
             // too many distinct keys for one round: estimate them from ONE round of a 64-round split (a 1/64 sample
             // of the key space), then run exactly the number of rounds that needs -- or give up right away
@@ -2638,7 +2658,6 @@ int k_fgb_hash_u32(hark_context *ctx, const uint32_t *k, const uint32_t *v, int6
                 const double per_bucket = 64.0 * (double)sample / P * 1.3;
                 // every round re-reads the bucket's slabs (~0.35 ms per round and 1e8 rows): beyond kMaxRoundsWorth rounds the
                 // sort-based path (~7 ms per 1e8 rows) is the faster one -- with 512 buckets 64 rounds would "fit" 2e8 keys
-                constexpr uint32_t kMaxRoundsWorth = 16;
                 uint32_t R = 2;
                 while (R < kMaxRoundsWorth && per_bucket > (double)fill * R) R *= 2;
                 if (per_bucket > (double)fill * kMaxRoundsWorth) e = kErrOverflow;

@@ -406,7 +406,7 @@ int grouped_aggregate(hark_context *ctx, const hark_table *db, int key_col, int 
         rc = k_argsort_i64_keys(ctx, db->cols[key_col].data, n, &perm, &k64, one64 ? static_cast<const uint32_t *>(db->cols[carry].data) : nullptr,
                                 one64 ? &val : nullptr, nullptr);
         if (!rc) {
-            unbias_u64_kernel<<<grid_for(ctx, n), 256, 0, st>>>(k64, n);
+            HARK_LAUNCH_RC(ctx, rc, unbias_u64_kernel<<<grid_for(ctx, n), 256, 0, st>>>(k64, n));
             sorted_keys = k64; keys64 = true;
             if (one64 && val) { hark_free(ctx, perm); perm = val; carried = true; }      // `perm` now holds the column in sorted order
         } else hark_free(ctx, k64);
@@ -430,8 +430,8 @@ int grouped_aggregate(hark_context *ctx, const hark_table *db, int key_col, int 
         rc = hark_alloc(ctx, (void **)&counts, (size_t)ntiles * 4);
         if (!rc) rc = hark_alloc(ctx, (void **)&offsets, (size_t)(ntiles + 1) * 8);
         if (!rc) {
-            seg_count_kernel<<<dim3((unsigned)ntiles), 256, 0, st>>>(static_cast<const uint32_t *>(sorted_keys), n, counts);
-            rc = k_exclusive_scan_u32(ctx, counts, ntiles, nullptr, offsets, &G);
+            HARK_LAUNCH_RC(ctx, rc, seg_count_kernel<<<dim3((unsigned)ntiles), 256, 0, st>>>(static_cast<const uint32_t *>(sorted_keys), n, counts));
+            if (!rc) rc = k_exclusive_scan_u32(ctx, counts, ntiles, nullptr, offsets, &G);
         }
         if (!rc) {
             res->n = G;
@@ -448,12 +448,11 @@ int grouped_aggregate(hark_context *ctx, const hark_table *db, int key_col, int 
                 sa.gathered[j] = carried ? 0 : 1;
                 sa.out[j] = static_cast<uint32_t *>(res->cols[1 + j].data);
                 sa.op[j] = aggs[j].op;
-                fill_u32_kernel<<<grid_for(ctx, G), 256, 0, st>>>(sa.out[j], G, (uint32_t)identity_of(ACC_U64, aggs[j].op));
+                HARK_LAUNCH_RC(ctx, rc, fill_u32_kernel<<<grid_for(ctx, G), 256, 0, st>>>(sa.out[j], G, (uint32_t)identity_of(ACC_U64, aggs[j].op)));
             }
             if (!rc) {
-                seg_fused_u32_kernel<<<dim3((unsigned)ntiles), 256, 0, st>>>(static_cast<const uint32_t *>(sorted_keys), carried ? nullptr : perm, n, offsets,
-                                                                            static_cast<uint32_t *>(res->cols[0].data), sa);
-                if (hipGetLastError() != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "groupby: launch failed");
+                HARK_LAUNCH_RC(ctx, rc, seg_fused_u32_kernel<<<dim3((unsigned)ntiles), 256, 0, st>>>(static_cast<const uint32_t *>(sorted_keys), carried ? nullptr : perm, n, offsets,
+                                                                                                    static_cast<uint32_t *>(res->cols[0].data), sa));
             }
         }
         if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "groupby: kernels failed");
@@ -464,8 +463,8 @@ int grouped_aggregate(hark_context *ctx, const hark_table *db, int key_col, int 
     if (!rc) rc = hark_alloc(ctx, (void **)&flags, (size_t)n * 4);
     if (!rc) rc = hark_alloc(ctx, (void **)&seg, (size_t)n * 4);
     if (!rc) {
-        head_flags_kernel<<<grid_for(ctx, n), 256, 0, st>>>(sorted_keys, kesz, key_dtype == HARK_F32 ? 1 : 0, n, flags);
-        rc = k_exclusive_scan_u32(ctx, flags, n, seg, nullptr, &G);
+        HARK_LAUNCH_RC(ctx, rc, head_flags_kernel<<<grid_for(ctx, n), 256, 0, st>>>(sorted_keys, kesz, key_dtype == HARK_F32 ? 1 : 0, n, flags));
+        if (!rc) rc = k_exclusive_scan_u32(ctx, flags, n, seg, nullptr, &G);
     }
     if (!rc) {
         res->n = G;
@@ -478,22 +477,21 @@ int grouped_aggregate(hark_context *ctx, const hark_table *db, int key_col, int 
         }
     }
     if (!rc) {
-        seg_ids_kernel<<<grid_for(ctx, n), 256, 0, st>>>(seg, flags, n, sorted_keys, kesz, res->cols[0].data);
-        rc = hark_alloc(ctx, (void **)&acc, (size_t)G * 8);
+        HARK_LAUNCH_RC(ctx, rc, seg_ids_kernel<<<grid_for(ctx, n), 256, 0, st>>>(seg, flags, n, sorted_keys, kesz, res->cols[0].data));
+        if (!rc) rc = hark_alloc(ctx, (void **)&acc, (size_t)G * 8);
         if (!rc) rc = hark_alloc(ctx, (void **)&cnt, (size_t)G * 8);
     }
     for (size_t j = 0; j < aggs.size() && !rc; j++) {
         const AggSpec &a = aggs[j];
         const int col_dtype = a.count_mode ? HARK_I32 : db->cols[a.col].dtype;
         const void *col = a.count_mode ? nullptr : carried ? static_cast<const void *>(perm) : db->cols[a.col].data;
-        fill_u64_kernel<<<grid_for(ctx, G), 256, 0, st>>>(acc, G, identity_of(a.kind, a.op));
-        seg_reduce_kernel<<<grid_for(ctx, n), 256, 0, st>>>(col, col_dtype, carried ? nullptr : perm, seg, n, a.kind, a.op, a.count_mode, acc);
+        HARK_LAUNCH_RC(ctx, rc, fill_u64_kernel<<<grid_for(ctx, G), 256, 0, st>>>(acc, G, identity_of(a.kind, a.op)));
+        HARK_LAUNCH_RC(ctx, rc, seg_reduce_kernel<<<grid_for(ctx, n), 256, 0, st>>>(col, col_dtype, carried ? nullptr : perm, seg, n, a.kind, a.op, a.count_mode, acc));
         if (a.avg) {
-            fill_u64_kernel<<<grid_for(ctx, G), 256, 0, st>>>(cnt, G, 0ull);
-            seg_reduce_kernel<<<grid_for(ctx, n), 256, 0, st>>>(nullptr, HARK_I32, perm, seg, n, ACC_U64, OP_SUM, 1, cnt);
+            HARK_LAUNCH_RC(ctx, rc, fill_u64_kernel<<<grid_for(ctx, G), 256, 0, st>>>(cnt, G, 0ull));
+            HARK_LAUNCH_RC(ctx, rc, seg_reduce_kernel<<<grid_for(ctx, n), 256, 0, st>>>(nullptr, HARK_I32, perm, seg, n, ACC_U64, OP_SUM, 1, cnt));
         }
-        finalize_kernel<<<grid_for(ctx, G), 256, 0, st>>>(acc, cnt, G, a.kind, a.out_dtype, a.avg, res->cols[1 + j].data);
-        if (hipGetLastError() != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "groupby: launch failed");
+        HARK_LAUNCH_RC(ctx, rc, finalize_kernel<<<grid_for(ctx, G), 256, 0, st>>>(acc, cnt, G, a.kind, a.out_dtype, a.avg, res->cols[1 + j].data));
     }
     if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "groupby: kernels failed");
     hark_free(ctx, perm); hark_free(ctx, flags); hark_free(ctx, seg); hark_free(ctx, sorted_keys); hark_free(ctx, acc); hark_free(ctx, cnt);
@@ -626,8 +624,8 @@ int column_range(hark_context *ctx, const hark_table *t, int col, bool as_signed
         int rc = hipMemcpyAsync(mm, init, 16, hipMemcpyHostToDevice, ctx->stream) == hipSuccess ? HARK_OK : hark_fail(ctx, HARK_EHIP, "stats upload failed");
         int64_t lohi[2] = {0, 0};
         if (!rc) {
-            if (t->n > 0) minmax_u32_kernel<<<grid_for(ctx, t->n), 256, 0, ctx->stream>>>(static_cast<const uint32_t *>(c.data), t->n, as_signed ? 1 : 0, mm);
-            rc = hark_read_words(ctx, mm, lohi, 2);
+            if (t->n > 0) HARK_LAUNCH_RC(ctx, rc, minmax_u32_kernel<<<grid_for(ctx, t->n), 256, 0, ctx->stream>>>(static_cast<const uint32_t *>(c.data), t->n, as_signed ? 1 : 0, mm));
+            if (!rc) rc = hark_read_words(ctx, mm, lohi, 2);
         }
         hark_free(ctx, mm);
         if (rc) return rc;
@@ -728,8 +726,8 @@ int try_dense(hark_context *ctx, const hark_table *db, const PredList &preds,
             r = hark_alloc(ctx, (void **)&flags, (size_t)G * 4);
             if (!r) r = hark_alloc(ctx, (void **)&pos, (size_t)G * 4);
             if (!r) {
-                nonzero_flags_kernel<<<grid_for(ctx, G), 256, 0, ctx->stream>>>(plan->acc_cnt, G, flags);
-                r = k_exclusive_scan_u32(ctx, flags, G, pos, nullptr, &ngroups);
+                HARK_LAUNCH_RC(ctx, r, nonzero_flags_kernel<<<grid_for(ctx, G), 256, 0, ctx->stream>>>(plan->acc_cnt, G, flags));
+                if (!r) r = k_exclusive_scan_u32(ctx, flags, G, pos, nullptr, &ngroups);
             }
         }
         if (!r) {
@@ -1208,8 +1206,8 @@ extern "C" int hark_entry_filter_groupby_subset(hark_context *ctx, hark_result *
     if (!rc && hipMemcpyAsync(want, keys_host, (size_t)n_keys * 4, hipMemcpyHostToDevice, st) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "groupby_subset: key upload failed");
     if (!rc) {
         for (int64_t j = 0; j < n_aggs; j++)
-            sub_fill_kernel<<<1, 256, 0, st>>>(gacc + (size_t)j * n_keys, n_keys, plan[j].count_only ? 0ull : (plan[j].vop == 3 ? 0xFFFFFFFFull : 0ull));
-        hipMemsetAsync(gcnt, 0, (size_t)n_keys * 8, st);
+            HARK_LAUNCH_RC(ctx, rc, sub_fill_kernel<<<1, 256, 0, st>>>(gacc + (size_t)j * n_keys, n_keys, plan[j].count_only ? 0ull : (plan[j].vop == 3 ? 0xFFFFFFFFull : 0ull)));
+        HIP_TRY_RC(ctx, rc, hipMemsetAsync(gcnt, 0, (size_t)n_keys * 8, st));
         const float *p = direct ? static_cast<const float *>(db->cols[where_cols[0]].data) : reinterpret_cast<const float *>(mask);
         const int cmp = n_preds == 0 ? -1 : direct ? cmps[0] : HARK_CMP_MASK;
         const float thr = direct ? *static_cast<const float *>(constants[0]) : 0.0f;
@@ -1219,8 +1217,8 @@ extern "C" int hark_entry_filter_groupby_subset(hark_context *ctx, hark_result *
         int64_t grid = (db->n / 4 + kSubThreads - 1) / kSubThreads;
         if (grid > ctx->num_cu) grid = ctx->num_cu;
         if (grid < 1) grid = 1;
-        if (he == hipSuccess) subset_agg_kernel<<<dim3((unsigned)grid), dim3(kSubThreads), lds, st>>>(p, cmp, thr, static_cast<const uint32_t *>(db->cols[g_col].data), db->n, want, (int)n_keys, aggs, gacc, gcnt);
-        if (he != hipSuccess || hipGetLastError() != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "groupby_subset: launch failed");
+        if (he == hipSuccess) HARK_LAUNCH_RC(ctx, rc, subset_agg_kernel<<<dim3((unsigned)grid), dim3(kSubThreads), lds, st>>>(p, cmp, thr, static_cast<const uint32_t *>(db->cols[g_col].data), db->n, want, (int)n_keys, aggs, gacc, gcnt));
+        if (!rc && he != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "groupby_subset: setting the dynamic LDS size of subset_agg_kernel failed: %s", hipGetErrorString(he));
         for (int64_t j = 0; j < n_aggs && !rc; j++) rc = k_fgb_decode(ctx, gacc + (size_t)j * n_keys, gcnt, n_keys, plan[j].kind, res->cols[(size_t)j].data);
         if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "groupby_subset: kernels failed");
     }
@@ -1520,8 +1518,8 @@ int ref_groupby_dense(hark_context *ctx, const hark_table *view, const hark_tabl
     if (!rc) rc = hark_alloc(ctx, (void **)&flags, (size_t)G * 4);
     if (!rc) rc = hark_alloc(ctx, (void **)&pos, (size_t)G * 4);
     if (!rc) {
-        nonzero_flags_kernel<<<grid_for(ctx, G), 256, 0, ctx->stream>>>(plan->acc_cnt, G, flags);
-        rc = k_exclusive_scan_u32(ctx, flags, G, pos, nullptr, &ngroups);
+        HARK_LAUNCH_RC(ctx, rc, nonzero_flags_kernel<<<grid_for(ctx, G), 256, 0, ctx->stream>>>(plan->acc_cnt, G, flags));
+        if (!rc) rc = k_exclusive_scan_u32(ctx, flags, G, pos, nullptr, &ngroups);
     }
     if (!rc) {
         res->n = ngroups;
@@ -1536,7 +1534,7 @@ int ref_groupby_dense(hark_context *ctx, const hark_table *view, const hark_tabl
                 e.vals[e.n] = j == 0 ? nullptr : vals[j - 1];
                 e.out[e.n++] = static_cast<uint32_t *>(res->cols[j].data);
             }
-            dense_emit_all_u32_kernel<<<grid_for(ctx, G), 256, 0, ctx->stream>>>(e, plan->acc_cnt, pos, G);
+            HARK_LAUNCH_RC(ctx, rc, dense_emit_all_u32_kernel<<<grid_for(ctx, G), 256, 0, ctx->stream>>>(e, plan->acc_cnt, pos, G));
         }
         if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "query_groupby: kernels failed");
     }
@@ -1618,7 +1616,7 @@ int ref_groupby_hash(hark_context *ctx, const hark_table *view, const hark_table
                 if (first_pass) rc = k_gather(ctx, hk, 4, perm, res->cols[0].data, G);
                 first_pass = false;
                 for (size_t q = 0; q < cnt && !rc && !aggs.empty(); q++)       // slot 0: low word of hv, slot 1: its high word, slot 2: low word of hc
-                    gather_word32_kernel<<<grid_for(ctx, G), 256, 0, ctx->stream>>>(q < 2 ? hv : hc, perm, static_cast<uint32_t *>(res->cols[order[oi + q] + 1].data), G, q == 1 ? 1 : 0);
+                    HARK_LAUNCH_RC(ctx, rc, gather_word32_kernel<<<grid_for(ctx, G), 256, 0, ctx->stream>>>(q < 2 ? hv : hc, perm, static_cast<uint32_t *>(res->cols[order[oi + q] + 1].data), G, q == 1 ? 1 : 0));
             }
         }
         hark_free(ctx, hk); hark_free(ctx, hv); hark_free(ctx, hc); hark_free(ctx, perm);
@@ -1719,8 +1717,9 @@ extern "C" int hark_table_composite_key(hark_context *ctx, const hark_table *t, 
     *out_dtype = wide ? HARK_I64 : HARK_I32;
     if (t->n == 0) return HARK_OK;
     HARK_TRY(hark_alloc(ctx, out_dev, (size_t)t->n * (wide ? 8 : 4)));
-    if (wide) composite_key_kernel<long long><<<grid_for(ctx, t->n), 256, 0, ctx->stream>>>(a, t->n, static_cast<long long *>(*out_dev));
-    else composite_key_kernel<int32_t><<<grid_for(ctx, t->n), 256, 0, ctx->stream>>>(a, t->n, static_cast<int32_t *>(*out_dev));
-    if (hipGetLastError() != hipSuccess) { hark_free(ctx, *out_dev); *out_dev = nullptr; return hark_fail(ctx, HARK_EHIP, "composite key: launch failed"); }
-    return HARK_OK;
+    int rc = HARK_OK;
+    if (wide) HARK_LAUNCH_RC(ctx, rc, composite_key_kernel<long long><<<grid_for(ctx, t->n), 256, 0, ctx->stream>>>(a, t->n, static_cast<long long *>(*out_dev)));
+    else HARK_LAUNCH_RC(ctx, rc, composite_key_kernel<int32_t><<<grid_for(ctx, t->n), 256, 0, ctx->stream>>>(a, t->n, static_cast<int32_t *>(*out_dev)));
+    if (rc) { hark_free(ctx, *out_dev); *out_dev = nullptr; }
+    return rc;
 }

@@ -951,7 +951,8 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
     if (hipMemsetAsync(info, 0, 32, st) != hipSuccess) { cleanup(); return hark_fail(ctx, HARK_EHIP, "join: workspace memset failed"); }
     int32_t *err = reinterpret_cast<int32_t *>(info + 1);
     unsigned long long *total = reinterpret_cast<unsigned long long *>(info);
-    jsplit_kernel<K><<<(P + 256) / 256, 256, 0, st>>>(rkeys, s, P, splitters, bstart);
+    HARK_LAUNCH_RC(ctx, rc, jsplit_kernel<K><<<(P + 256) / 256, 256, 0, st>>>(rkeys, s, P, splitters, bstart));
+    if (rc) { cleanup(); return rc; }
     const size_t lds_part = sizeof(E) * (size_t)P * Q + sizeof(K) * (P + 2) + 8 * (size_t)P + 16;
     const bool plain_loads = getenv("HARK_JOIN_PLAIN_LOADS") != nullptr;        // tests: the compiler-counted twin of the partition kernel
     hipError_t he = plain_loads ? hipFuncSetAttribute(reinterpret_cast<const void *>(&jpart_kernel<K, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part)
@@ -972,14 +973,13 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
     if (const char *e = getenv("HARK_JOIN_STAGE")) { const int c = atoi(e); if (c >= 1 && c < stage_cap) stage_cap = c; }   // tests: many sub-rounds per bucket
     if (he == hipSuccess) {
         // one stream-ordered chain, one host read at the end: partition -> bucket probe -> survivor total
-        if (plain_loads) jpart_kernel<K, false><<<dim3((unsigned)nwg), dim3(kJThreads), lds_part, st>>>(lcol, n, bias, splitters, rkeys, s, slabs, counts, cap, period, err, carry ? lval : nullptr);
-        else jpart_kernel<K, true><<<dim3((unsigned)nwg), dim3(kJThreads), lds_part, st>>>(lcol, n, bias, splitters, rkeys, s, slabs, counts, cap, period, err, carry ? lval : nullptr);
-        jbucket_kernel<K><<<dim3((unsigned)P), dim3(kJThreads), lds_bucket, st>>>(slabs, counts, cap, nwg, rkeys, bstart, chunk_cap, surv, region, scount, sbins, srec, scoarse, stage_cap, err, allow_trunc ? 1 : 0);
-        jsum_kernel<<<1, 1024, 0, st>>>(scount, P, total);
-        he = hipGetLastError();
-        if (he == hipSuccess) he = hipMemcpyAsync(info + 2, flags, 8, hipMemcpyDeviceToDevice, st);   // the duplicate-keys flag rides along with the same host read
+        if (plain_loads) HARK_LAUNCH_RC(ctx, rc, jpart_kernel<K, false><<<dim3((unsigned)nwg), dim3(kJThreads), lds_part, st>>>(lcol, n, bias, splitters, rkeys, s, slabs, counts, cap, period, err, carry ? lval : nullptr));
+        else HARK_LAUNCH_RC(ctx, rc, jpart_kernel<K, true><<<dim3((unsigned)nwg), dim3(kJThreads), lds_part, st>>>(lcol, n, bias, splitters, rkeys, s, slabs, counts, cap, period, err, carry ? lval : nullptr));
+        HARK_LAUNCH_RC(ctx, rc, jbucket_kernel<K><<<dim3((unsigned)P), dim3(kJThreads), lds_bucket, st>>>(slabs, counts, cap, nwg, rkeys, bstart, chunk_cap, surv, region, scount, sbins, srec, scoarse, stage_cap, err, allow_trunc ? 1 : 0));
+        HARK_LAUNCH_RC(ctx, rc, jsum_kernel<<<1, 1024, 0, st>>>(scount, P, total));
+        HIP_TRY_RC(ctx, rc, hipMemcpyAsync(info + 2, flags, 8, hipMemcpyDeviceToDevice, st));   // the duplicate-keys flag rides along with the same host read
     }
-    if (he != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: partition launch failed: %s", hipGetErrorString(he));
+    if (he != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: setting the dynamic LDS size of the partition / bucket kernel failed: %s", hipGetErrorString(he));
     int64_t words[3] = {0, 0, 0}, M = 0;
     if (!rc) rc = hark_read_words(ctx, info, words, 3);
     M = words[0];
@@ -1001,8 +1001,8 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
         for (int attempt = 0; attempt < 2 && !rc; attempt++) {
             const uint64_t *rk64 = reinterpret_cast<const uint64_t *>(rkeys);
             if (getenv("HARK_JOIN_FULLSORT")) {                                  // A/B + tests: plain compaction, radix sorts by the caller
-                jcompact_kernel<<<dim3((unsigned)P), 256, 0, st>>>(surv, region, scount, sbins, counts, cap, nwg, bstart, stage_cap, rank, lrow, srec, rk64, flags);
-                hipMemsetAsync(flags, 1, 1, st);
+                HARK_LAUNCH_RC(ctx, rc, jcompact_kernel<<<dim3((unsigned)P), 256, 0, st>>>(surv, region, scount, sbins, counts, cap, nwg, bstart, stage_cap, rank, lrow, srec, rk64, flags));
+                HIP_TRY_RC(ctx, rc, hipMemsetAsync(flags, 1, 1, st));
             } else {
                 const size_t lds_order = (size_t)stage_of(xw) * (8 + 4 * (size_t)xw) + (size_t)(fine_of(xw) + 1) * 4 + (size_t)(kCoarse + 1) * 4;
                 auto launch = [&](auto carry_tag, auto verify_tag) -> hipError_t {
@@ -1012,12 +1012,12 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
                     jorder_kernel<C, V><<<dim3((unsigned)P), dim3(kJThreads), lds_order, st>>>(surv, region, scount, sbins, counts, cap, nwg, bstart, P, runlen,
                                                                                              rank, lrow, cnt, stage_cap, flags, C ? lv : nullptr, scoarse, rranked, rv,
                                                                                              V ? srec : nullptr, V ? rk64 : nullptr);
-                    return hipSuccess;
+                    return hipGetLastError();
                 };
                 he = verify ? (carry ? launch(std::true_type{}, std::true_type{}) : launch(std::false_type{}, std::true_type{}))
                             : launch(std::false_type{}, std::false_type{});             // (a carried column exists on the 64-bit path only)
             }
-            if (he != hipSuccess || hipGetLastError() != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: order launch failed");
+            if (!rc && he != hipSuccess) rc = hark_launch_failed(ctx, he, "jorder_kernel<<<", __FILE__, __LINE__);
             // does the order stand, or do the survivors need the general sort (skew)?  Read here, while the survivors are alive:
             // an order kernel that left the rows out runs once more to deliver them.  [2]: a hit on a truncated key was none.
             int64_t fw[2] = {0, 0};
@@ -1074,14 +1074,15 @@ int k_join_partitioned(hark_context *ctx, const void *lcol, bool k64, int64_t n,
     int rc = hark_alloc(ctx, (void **)&flag, 16);
     if (!rc && build_unique != 1) rc = hark_alloc(ctx, (void **)&runlen, 4 * (size_t)s);
     if (rc) { hark_free(ctx, flag); return rc; }
-    hipMemsetAsync(flag, 0, 16, ctx->stream);
+    HIP_TRY_RC(ctx, rc, hipMemsetAsync(flag, 0, 16, ctx->stream));
     if (build_unique != 1) {   // run lengths of the sorted build keys: the partner count of a survivor is runlen[rank]
         int64_t g1 = (s + 255) / 256;
         const int64_t gcap = (int64_t)ctx->num_cu * 16;
         if (g1 > gcap) g1 = gcap;
-        if (k64) jrunlen_kernel<uint64_t><<<dim3((unsigned)g1), 256, 0, ctx->stream>>>(static_cast<const uint64_t *>(rkeys), s, runlen, flag + 1);
-        else jrunlen_kernel<uint32_t><<<dim3((unsigned)g1), 256, 0, ctx->stream>>>(static_cast<const uint32_t *>(rkeys), s, runlen, flag + 1);
+        if (k64) HARK_LAUNCH_RC(ctx, rc, jrunlen_kernel<uint64_t><<<dim3((unsigned)g1), 256, 0, ctx->stream>>>(static_cast<const uint64_t *>(rkeys), s, runlen, flag + 1));
+        else HARK_LAUNCH_RC(ctx, rc, jrunlen_kernel<uint32_t><<<dim3((unsigned)g1), 256, 0, ctx->stream>>>(static_cast<const uint32_t *>(rkeys), s, runlen, flag + 1));
     }
+    if (rc) { hark_free(ctx, flag); hark_free(ctx, runlen); return rc; }
     bool dup = true;
     int64_t general = 0;                                       // the order kernel's verdict (read in run_partitioned, while it can still run again)
     rc = k64 ? run_partitioned<uint64_t>(ctx, static_cast<const uint64_t *>(lcol), 0x8000000000000000ull, n, static_cast<const uint64_t *>(rkeys), s, runlen, flag, lval, rranked, &rank, &lrow, &cnt, &lv, &rv, &M, used, &dup, rows_needed, &general)
@@ -1102,8 +1103,7 @@ int k_join_partitioned(hark_context *ctx, const void *lcol, bool k64, int64_t n,
             int64_t g2 = (M + 255) / 256;
             const int64_t gcap = (int64_t)ctx->num_cu * 16;
             if (g2 > gcap) g2 = gcap;
-            jcnt_kernel<<<dim3((unsigned)g2), 256, 0, ctx->stream>>>(rank2, M, runlen, cnt);
-            if (hipGetLastError() != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: count launch failed");
+            HARK_LAUNCH_RC(ctx, rc, jcnt_kernel<<<dim3((unsigned)g2), 256, 0, ctx->stream>>>(rank2, M, runlen, cnt));
         }
     } else if (!rc) {
         rank2 = rank; lrow2 = lrow; rank = lrow = nullptr;     // in place

@@ -364,15 +364,15 @@ int hark_entry_join(hark_context *ctx, hark_result **out, const hark_table *db1,
         if (!rc) rc = hark_alloc(ctx, (void **)&masks, (size_t)ntiles * kSemiThreads * 2);
         int64_t n1 = 0;
         if (!rc) {
-            hipMemsetAsync(bitmap, 0, ((size_t)1 << lgb) / 8, st);
+            HIP_TRY_RC(ctx, rc, hipMemsetAsync(bitmap, 0, ((size_t)1 << lgb) / 8, st));
             if (k64) {
-                bitmap_build_kernel<uint64_t><<<grid_for(ctx, s), 256, 0, st>>>(static_cast<const uint64_t *>(rcol), s, bitmap, bitmask);
-                semi_count_kernel<uint64_t><<<dim3((unsigned)ntiles), kSemiThreads, 0, st>>>(static_cast<const uint64_t *>(lcol), n, bitmap, bitmask, masks, tcnt);
+                HARK_LAUNCH_RC(ctx, rc, bitmap_build_kernel<uint64_t><<<grid_for(ctx, s), 256, 0, st>>>(static_cast<const uint64_t *>(rcol), s, bitmap, bitmask));
+                HARK_LAUNCH_RC(ctx, rc, semi_count_kernel<uint64_t><<<dim3((unsigned)ntiles), kSemiThreads, 0, st>>>(static_cast<const uint64_t *>(lcol), n, bitmap, bitmask, masks, tcnt));
             } else {
-                bitmap_build_kernel<uint32_t><<<grid_for(ctx, s), 256, 0, st>>>(static_cast<const uint32_t *>(rcol), s, bitmap, bitmask);
-                semi_count_kernel<uint32_t><<<dim3((unsigned)ntiles), kSemiThreads, 0, st>>>(static_cast<const uint32_t *>(lcol), n, bitmap, bitmask, masks, tcnt);
+                HARK_LAUNCH_RC(ctx, rc, bitmap_build_kernel<uint32_t><<<grid_for(ctx, s), 256, 0, st>>>(static_cast<const uint32_t *>(rcol), s, bitmap, bitmask));
+                HARK_LAUNCH_RC(ctx, rc, semi_count_kernel<uint32_t><<<dim3((unsigned)ntiles), kSemiThreads, 0, st>>>(static_cast<const uint32_t *>(lcol), n, bitmap, bitmask, masks, tcnt));
             }
-            rc = k_exclusive_scan_u32(ctx, tcnt, ntiles, nullptr, toffs, &n1);
+            if (!rc) rc = k_exclusive_scan_u32(ctx, tcnt, ntiles, nullptr, toffs, &n1);
         }
         if (!rc && n1 <= n / 2) {                      // otherwise the filter does not pay: sort the whole side
             filtered = true; nl = n1;
@@ -380,17 +380,18 @@ int hark_entry_join(hark_context *ctx, hark_result **out, const hark_table *db1,
                 rc = hark_alloc(ctx, &ckeys, (size_t)n1 * (k64 ? 8 : 4));
                 if (!rc) rc = hark_alloc(ctx, (void **)&crows, (size_t)n1 * 4);
                 if (!rc) {
-                    if (k64) semi_scatter_kernel<uint64_t><<<dim3((unsigned)ntiles), kSemiThreads, 0, st>>>(static_cast<const uint64_t *>(lcol), n, masks, toffs, static_cast<uint64_t *>(ckeys), crows);
-                    else semi_scatter_kernel<uint32_t><<<dim3((unsigned)ntiles), kSemiThreads, 0, st>>>(static_cast<const uint32_t *>(lcol), n, masks, toffs, static_cast<uint32_t *>(ckeys), crows);
-                    if (!k64) rc = k_sort_column(ctx, ckeys, HARK_U32, n1, false, crows, &lperm, &lkeys);      // the row ids travel with the keys
+                    if (k64) HARK_LAUNCH_RC(ctx, rc, semi_scatter_kernel<uint64_t><<<dim3((unsigned)ntiles), kSemiThreads, 0, st>>>(static_cast<const uint64_t *>(lcol), n, masks, toffs, static_cast<uint64_t *>(ckeys), crows));
+                    else HARK_LAUNCH_RC(ctx, rc, semi_scatter_kernel<uint32_t><<<dim3((unsigned)ntiles), kSemiThreads, 0, st>>>(static_cast<const uint32_t *>(lcol), n, masks, toffs, static_cast<uint32_t *>(ckeys), crows));
+                    if (rc) {}
+                    else if (!k64) rc = k_sort_column(ctx, ckeys, HARK_U32, n1, false, crows, &lperm, &lkeys);   // the row ids travel with the keys
                     else {
                         uint32_t *pos = nullptr;                                                          // positions in the compacted arrays
                         rc = k_argsort_column(ctx, ckeys, HARK_I64, n1, false, &pos, nullptr);
                         if (!rc) rc = hark_alloc(ctx, (void **)&lperm, (size_t)n1 * 4);
                         if (!rc) rc = hark_alloc(ctx, (void **)&lk64, (size_t)n1 * 8);
                         if (!rc) {
-                            gather_u32_via_kernel<<<grid_for(ctx, n1), 256, 0, st>>>(crows, pos, lperm, n1);
-                            gather_biased_i64_kernel<<<grid_for(ctx, n1), 256, 0, st>>>(static_cast<const uint64_t *>(ckeys), pos, lk64, n1);
+                            HARK_LAUNCH_RC(ctx, rc, gather_u32_via_kernel<<<grid_for(ctx, n1), 256, 0, st>>>(crows, pos, lperm, n1));
+                            HARK_LAUNCH_RC(ctx, rc, gather_biased_i64_kernel<<<grid_for(ctx, n1), 256, 0, st>>>(static_cast<const uint64_t *>(ckeys), pos, lk64, n1));
                             if (hipStreamSynchronize(st) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: filter kernels failed");
                         }
                         hark_free(ctx, pos);
@@ -404,15 +405,15 @@ int hark_entry_join(hark_context *ctx, hark_result **out, const hark_table *db1,
     if (!rc && !partitioned && !filtered) rc = k_argsort_column(ctx, lcol, k64 ? HARK_I64 : HARK_U32, n, false, &lperm, k64 ? nullptr : &lkeys);
     if (!rc && !partitioned && k64 && !filtered) {
         rc = hark_alloc(ctx, (void **)&lk64, (size_t)n * 8);
-        if (!rc) gather_biased_i64_kernel<<<grid_for(ctx, n), 256, 0, st>>>(static_cast<const uint64_t *>(lcol), lperm, lk64, n);
+        if (!rc) HARK_LAUNCH_RC(ctx, rc, gather_biased_i64_kernel<<<grid_for(ctx, n), 256, 0, st>>>(static_cast<const uint64_t *>(lcol), lperm, lk64, n));
     }
     if (!rc && !partitioned && nl > 0) rc = hark_alloc(ctx, (void **)&lb, (size_t)nl * 4);
     if (!rc && !partitioned && nl > 0) rc = hark_alloc(ctx, (void **)&cnt, (size_t)nl * 4);
     if (!rc && !partitioned && nl > 0) rc = hark_alloc(ctx, (void **)&offs, (size_t)nl * 8);
     if (!rc && !partitioned && nl > 0) {
-        if (k64) join_count_kernel<uint64_t><<<grid_for(ctx, (nl + kJoinChunk - 1) / kJoinChunk), 256, 0, st>>>(lk64, nl, rk64, s, lb, cnt);
-        else join_count_kernel<uint32_t><<<grid_for(ctx, (nl + kJoinChunk - 1) / kJoinChunk), 256, 0, st>>>(lkeys, nl, rkeys, s, lb, cnt);
-        rc = k_exclusive_scan_u32(ctx, cnt, nl, nullptr, offs, &P);
+        if (k64) HARK_LAUNCH_RC(ctx, rc, join_count_kernel<uint64_t><<<grid_for(ctx, (nl + kJoinChunk - 1) / kJoinChunk), 256, 0, st>>>(lk64, nl, rk64, s, lb, cnt));
+        else HARK_LAUNCH_RC(ctx, rc, join_count_kernel<uint32_t><<<grid_for(ctx, (nl + kJoinChunk - 1) / kJoinChunk), 256, 0, st>>>(lkeys, nl, rkeys, s, lb, cnt));
+        if (!rc) rc = k_exclusive_scan_u32(ctx, cnt, nl, nullptr, offs, &P);
     }
     if (!rc && P > 0) {
         // select cols1 db1[r1,:] / select cols2 db2[r2,:] (join.fut:69-70) run only when there are pairs
@@ -439,8 +440,7 @@ int hark_entry_join(hark_context *ctx, hark_result **out, const hark_table *db1,
             lval_exp = sval; sval = nullptr;
             if (!by_rank) rc = k_gather(ctx, rperm, 4, kpos, rrow, P);
         } else if (!rc) {
-            join_expand_kernel<<<grid_for(ctx, nl), 256, 0, st>>>(offs, cnt, nl, lb, lperm, rperm, lrow, rrow, kpos, sval, lval_exp);
-            if (hipGetLastError() != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: launch failed");
+            HARK_LAUNCH_RC(ctx, rc, join_expand_kernel<<<grid_for(ctx, nl), 256, 0, st>>>(offs, cnt, nl, lb, lperm, rperm, lrow, rrow, kpos, sval, lval_exp));
         }
         res->n = P;
         int64_t carried_at = -1, ranked_at = -1;
@@ -459,7 +459,7 @@ int hark_entry_join(hark_context *ctx, hark_result **out, const hark_table *db1,
             }
             rc = hark_alloc(ctx, &res->cols[j].data, (size_t)P * esz);
             const bool is_key = j < l ? c == col1 : c == col2;
-            if (!rc && is_key && k64) gather_biased_i64_kernel<<<grid_for(ctx, P), 256, 0, st>>>(rk64, kpos, static_cast<uint64_t *>(res->cols[j].data), P);   // XOR undoes the bias
+            if (!rc && is_key && k64) HARK_LAUNCH_RC(ctx, rc, gather_biased_i64_kernel<<<grid_for(ctx, P), 256, 0, st>>>(rk64, kpos, static_cast<uint64_t *>(res->cols[j].data), P));   // XOR undoes the bias
             else if (!rc && is_key) rc = k_gather(ctx, rkeys, 4, kpos, res->cols[j].data, P);
             else if (!rc && j < l && c == carry_col && carried_at >= 0) {            // selected twice: a copy of the first
                 if (hipMemcpyAsync(res->cols[j].data, res->cols[carried_at].data, (size_t)P * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: copy failed");
@@ -537,8 +537,7 @@ int hark_entry_sort(hark_context *ctx, hark_result **out, const hark_table *db, 
         } else rc = k_argsort_i64_keys(ctx, db->cols[key_col].data, db->n, &perm, &keys64,
                                        carried64 ? static_cast<const uint32_t *>(db->cols[carry64].data) : nullptr, carried64 ? &val : nullptr, nullptr, &plain);
         if (!rc && !plain) {                                // the permutation paths hand back biased keys
-            unbias_i64_kernel<<<grid_for(ctx, db->n), 256, 0, ctx->stream>>>(keys64, db->n, descending ? 0x7FFFFFFFFFFFFFFFull : 0x8000000000000000ull);
-            if (hipGetLastError() != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "sort: launch failed");
+            HARK_LAUNCH_RC(ctx, rc, unbias_i64_kernel<<<grid_for(ctx, db->n), 256, 0, ctx->stream>>>(keys64, db->n, descending ? 0x7FFFFFFFFFFFFFFFull : 0x8000000000000000ull));
         }
         bool keys_taken = false, val_taken = false;
         for (int64_t j = 0; j < k && !rc; j++) {

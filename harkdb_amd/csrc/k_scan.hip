@@ -162,14 +162,14 @@ int k_exclusive_scan_u32_dev(hark_context *ctx, const uint32_t *in, int64_t n, u
 {
     if (n <= 0) return HARK_OK;
     hipStream_t st = ctx->stream;
-    if (n <= kScanSmall) scan_small_kernel<<<1, 1024, 0, st>>>(in, n, out32, out64, total_dev);
+    if (n <= kScanSmall) HARK_LAUNCH(ctx, scan_small_kernel<<<1, 1024, 0, st>>>(in, n, out32, out64, total_dev));
     else {
         const int64_t nt = (n + kScanTile - 1) / kScanTile;
-        tile_sums_kernel<<<dim3((unsigned)nt), dim3(kScanThreads), 0, st>>>(in, n, sums_ws);
-        scan_sums_kernel<<<1, 1024, 0, st>>>(sums_ws, nt, total_dev);
-        scan_apply_kernel<<<dim3((unsigned)nt), dim3(kScanThreads), 0, st>>>(in, n, sums_ws, out32, out64);
+        HARK_LAUNCH(ctx, tile_sums_kernel<<<dim3((unsigned)nt), dim3(kScanThreads), 0, st>>>(in, n, sums_ws));
+        HARK_LAUNCH(ctx, scan_sums_kernel<<<1, 1024, 0, st>>>(sums_ws, nt, total_dev));
+        HARK_LAUNCH(ctx, scan_apply_kernel<<<dim3((unsigned)nt), dim3(kScanThreads), 0, st>>>(in, n, sums_ws, out32, out64));
     }
-    return hipGetLastError() == hipSuccess ? HARK_OK : hark_fail(ctx, HARK_EHIP, "scan: launch failed");
+    return HARK_OK;
 }
 
 // Exclusive scan of in[0..n).  Either output may be null.  *total_host receives
@@ -182,14 +182,13 @@ int k_exclusive_scan_u32(hark_context *ctx, const uint32_t *in, int64_t n, uint3
     unsigned long long *sums = nullptr;
     HARK_TRY(hark_alloc(ctx, (void **)&sums, (size_t)(nt + 1) * sizeof(unsigned long long)));
     hipStream_t st = ctx->stream;
-    if (n <= kScanSmall) scan_small_kernel<<<1, 1024, 0, st>>>(in, n, out32, out64, sums + nt);
-    else {
-        tile_sums_kernel<<<dim3((unsigned)nt), dim3(kScanThreads), 0, st>>>(in, n, sums);
-        scan_sums_kernel<<<1, 1024, 0, st>>>(sums, nt, sums + nt);
-        scan_apply_kernel<<<dim3((unsigned)nt), dim3(kScanThreads), 0, st>>>(in, n, sums, out32, out64);
-    }
     int rc = HARK_OK;
-    if (hipGetLastError() != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "scan: launch failed");
+    if (n <= kScanSmall) HARK_LAUNCH_RC(ctx, rc, scan_small_kernel<<<1, 1024, 0, st>>>(in, n, out32, out64, sums + nt));
+    else {
+        HARK_LAUNCH_RC(ctx, rc, tile_sums_kernel<<<dim3((unsigned)nt), dim3(kScanThreads), 0, st>>>(in, n, sums));
+        HARK_LAUNCH_RC(ctx, rc, scan_sums_kernel<<<1, 1024, 0, st>>>(sums, nt, sums + nt));
+        HARK_LAUNCH_RC(ctx, rc, scan_apply_kernel<<<dim3((unsigned)nt), dim3(kScanThreads), 0, st>>>(in, n, sums, out32, out64));
+    }
     int64_t tot = 0;
     if (!rc) rc = hark_read_words(ctx, sums + nt, &tot, 1);
     hark_free(ctx, sums);

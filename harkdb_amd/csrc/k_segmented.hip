@@ -154,10 +154,10 @@ int seg_scan(hark_context *ctx, const uint8_t *flags, const int32_t *vals, int64
     Pair *summary = nullptr;
     HARK_TRY(hark_alloc(ctx, (void **)&summary, (size_t)nt * sizeof(Pair)));
     hipStream_t st = ctx->stream;
-    seg_tile_summary_kernel<<<dim3((unsigned)nt), dim3(kT), 0, st>>>(flags, vals, n, summary);   // vals == nullptr: ones
-    seg_scan_summaries_kernel<<<1, 1024, 0, st>>>(summary, nt);
-    seg_tile_apply_kernel<<<dim3((unsigned)nt), dim3(kT), 0, st>>>(flags, vals, n, summary, out, minus);
-    int rc = hipGetLastError() == hipSuccess ? HARK_OK : hark_fail(ctx, HARK_EHIP, "segmented_scan: launch failed");
+    int rc = HARK_OK;
+    HARK_LAUNCH_RC(ctx, rc, seg_tile_summary_kernel<<<dim3((unsigned)nt), dim3(kT), 0, st>>>(flags, vals, n, summary));   // vals == nullptr: ones
+    HARK_LAUNCH_RC(ctx, rc, seg_scan_summaries_kernel<<<1, 1024, 0, st>>>(summary, nt));
+    HARK_LAUNCH_RC(ctx, rc, seg_tile_apply_kernel<<<dim3((unsigned)nt), dim3(kT), 0, st>>>(flags, vals, n, summary, out, minus));
     hark_free(ctx, summary);
     return rc;
 }
@@ -194,12 +194,12 @@ int hark_op_segmented_reduce_add_i32(hark_context *ctx, const uint8_t *flags, co
     if (!rc) rc = seg_scan(ctx, flags, vals, n, scanned, 0);                                       // :24
     int64_t nseg = 0;
     if (!rc) {
-        seg_ends_kernel<<<grid_for(ctx, n), 256, 0, ctx->stream>>>(flags, n, ends);                // :26
-        rc = k_exclusive_scan_u32(ctx, ends, n, pos, nullptr, &nseg);                              // :28-29 (offset-1 = exclusive)
+        HARK_LAUNCH_RC(ctx, rc, seg_ends_kernel<<<grid_for(ctx, n), 256, 0, ctx->stream>>>(flags, n, ends));   // :26
+        if (!rc) rc = k_exclusive_scan_u32(ctx, ends, n, pos, nullptr, &nseg);                     // :28-29 (offset-1 = exclusive)
     }
     if (!rc && nseg > 0) {
-        seg_pick_kernel<<<grid_for(ctx, n), 256, 0, ctx->stream>>>(ends, pos, scanned, n, out);    // :36-37
-        if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "segmented_reduce failed");
+        HARK_LAUNCH_RC(ctx, rc, seg_pick_kernel<<<grid_for(ctx, n), 256, 0, ctx->stream>>>(ends, pos, scanned, n, out));   // :36-37
+        if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "segmented_reduce failed");
     }
     hark_free(ctx, scanned); hark_free(ctx, ends); hark_free(ctx, pos);
     *n_out = nseg;
@@ -223,10 +223,10 @@ int hark_op_replicated_iota(hark_context *ctx, const int32_t *reps, int64_t n, i
         rc = hark_alloc(ctx, (void **)&tmp, (size_t)total * 4);
         if (!rc) rc = hark_alloc(ctx, (void **)&fl, (size_t)total);
         if (!rc) {
-            hipMemsetAsync(tmp, 0, (size_t)total * 4, ctx->stream);                                               // replicate .. 0
-            repl_mark_kernel<<<grid_for(ctx, n), 256, 0, ctx->stream>>>(s2, n, total, tmp);                       // :48
-            gt0_flags_kernel<<<grid_for(ctx, total), 256, 0, ctx->stream>>>(tmp, total, fl);                      // :49
-            rc = seg_scan(ctx, fl, tmp, total, out, 0);                                                           // :50
+            HIP_TRY_RC(ctx, rc, hipMemsetAsync(tmp, 0, (size_t)total * 4, ctx->stream));                         // replicate .. 0
+            HARK_LAUNCH_RC(ctx, rc, repl_mark_kernel<<<grid_for(ctx, n), 256, 0, ctx->stream>>>(s2, n, total, tmp));     // :48
+            HARK_LAUNCH_RC(ctx, rc, gt0_flags_kernel<<<grid_for(ctx, total), 256, 0, ctx->stream>>>(tmp, total, fl));    // :49
+            if (!rc) rc = seg_scan(ctx, fl, tmp, total, out, 0);                                                  // :50
             if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "replicated_iota failed");
         }
     }
@@ -245,8 +245,9 @@ int hark_op_expand_indices(hark_context *ctx, const int32_t *szs, int64_t n, int
     if (t == 0 || !idxs || !iotas) return HARK_OK;
     uint8_t *fl = nullptr;
     HARK_TRY(hark_alloc(ctx, (void **)&fl, (size_t)t));
-    neq_prev_flags_kernel<<<grid_for(ctx, t), 256, 0, ctx->stream>>>(idxs, t, fl);
-    int rc = seg_scan(ctx, fl, nullptr, t, iotas, 1);
+    int rc = HARK_OK;
+    HARK_LAUNCH_RC(ctx, rc, neq_prev_flags_kernel<<<grid_for(ctx, t), 256, 0, ctx->stream>>>(idxs, t, fl));
+    if (!rc) rc = seg_scan(ctx, fl, nullptr, t, iotas, 1);
     if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "expand failed");
     hark_free(ctx, fl);
     return rc;

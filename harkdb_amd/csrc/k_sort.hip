@@ -1295,7 +1295,7 @@ int k_argsort_i64_keys(hark_context *ctx, const void *col, int64_t n, uint32_t *
         if (!rc) rc = k_sort_pairs_u32(ctx, k0, k1, v0, v1, nullptr, n, 0u, ws, diff_hi & prefix_mask, &ko, &vo);
         int64_t general = 0;
         if (!rc) {
-            hipMemsetAsync(flag, 0, 16, st);
+            HIP_TRY_RC(ctx, rc, hipMemsetAsync(flag, 0, 16, st));
             i64_fix_runs_kernel<<<dim3((unsigned)grid256(ctx, n)), dim3(256), 0, st>>>(static_cast<const uint64_t *>(col), ko, vo, keys, n, flag, prefix_mask);
             if (hipGetLastError() != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "sort: run fix-up launch failed");
             if (!rc) rc = hark_read_words(ctx, flag, &general, 1);

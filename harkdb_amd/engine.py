@@ -132,6 +132,9 @@ class Result:
         built ON THE DEVICE and copied once into a pinned block (hark_result_matrix_pinned)."""
         n, m = self.shape
         cols = list(range(m)) if cols is None else [int(c) for c in cols]
+        for c in cols:
+            if not 0 <= c < m:
+                raise _ffi.HarkError(_ffi.EBOUNDS, f"result_matrix: column {c} of {m}")
         rows = n if limit is None else min(n, max(int(limit), 0))
         if dtype is None:
             dts = [np.dtype(self.dtype(j)) for j in cols]

@@ -83,3 +83,25 @@ def test_the_library_on_the_gpu_box_is_the_build_of_its_sources():
     """The same on the GPU box, WITHOUT building there: the snapshot brought the library, its record and the sources together."""
     from harkdb_amd._srchash import library_matches_sources
     assert library_matches_sources() is True
+
+
+def test_build_checks_the_hand_placed_waits_behind_inline_asm_loads(tmp_path):
+    """harkdb_amd/csrc/Makefile runs tools/check_hidden_loads.py over the units that issue loads from inline assembly (k_hjoin.hip's
+    partition kernel): the product passes, and the same unit with its hand-placed waits removed is refused."""
+    import shutil
+    import subprocess
+    import sys
+    from conftest import ROOT
+    tool = os.path.join(ROOT, "tools", "check_hidden_loads.py")
+    good = subprocess.run([sys.executable, tool, os.path.join(ROOT, "harkdb_amd", "csrc", "k_hjoin.hip")], capture_output=True, text=True, timeout=600)
+    assert good.returncode == 0 and " 0 violations" in good.stdout and "18 inline-asm load sites" in good.stdout, good.stdout + good.stderr
+    bad_root = tmp_path / "tree"
+    shutil.copytree(os.path.join(ROOT, "harkdb_amd", "csrc"), bad_root / "harkdb_amd" / "csrc", ignore=shutil.ignore_patterns("*.o"))
+    shutil.copytree(os.path.join(ROOT, "include"), bad_root / "include")
+    unit = bad_root / "harkdb_amd" / "csrc" / "k_hjoin.hip"
+    src = unit.read_text()
+    marker = "        if (!HIDDEN) return;\n        constexpr int kAheadLoads"
+    assert marker in src
+    unit.write_text(src.replace(marker, "        if (!HIDDEN || tid >= 0) return;\n        constexpr int kAheadLoads"))       # the waits are gone
+    bad = subprocess.run([sys.executable, tool, str(unit)], capture_output=True, text=True, timeout=600)
+    assert bad.returncode == 1 and "while an inline-asm load into them is in flight" in bad.stderr, bad.stdout + bad.stderr[-500:]

@@ -24,7 +24,7 @@ __device__ __forceinline__ uint32_t lcg(uint32_t x) { return x * 1664525u + 1013
 //  bit 4: ds_add_u32 at the slot                                   bit 5: ds_add_u64 at the slot (integer sums / a packed word)
 //  bit 6: ds_add_f64 of a SECOND value array (count kept as a double)
 //  bit 7: the atomics of a wave-step are issued slot-sorted?  (not modelled)  -- unused
-template <int WHAT>
+template <int WHAT, bool PIPE = false, bool PHASED = false>
 __global__ __launch_bounds__(1024) void probe_kernel(int steps, uint32_t *out)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -39,6 +39,9 @@ __global__ __launch_bounds__(1024) void probe_kernel(int steps, uint32_t *out)
     uint32_t acc = 0;
     const uint4 *tag4 = reinterpret_cast<const uint4 *>(t_tag);
     const uint2 *tag2 = reinterpret_cast<const uint2 *>(t_tag);
+    uint32_t pat[8];                                                              // PIPE: the slots the previous step's tag reads led to
+#pragma unroll
+    for (int j = 0; j < 8; j++) pat[j] = (threadIdx.x * 8u + j) & (kSlots - 1);
     for (int s = 0; s < steps; s++) {
         uint32_t slot[8];
 #pragma unroll
@@ -50,33 +53,48 @@ __global__ __launch_bounds__(1024) void probe_kernel(int steps, uint32_t *out)
             if (WHAT & 2) qa[j] = tag4[slot[j] >> 2];                            // 16-byte groups anywhere in the tag array
             if (WHAT & 4) qc[j] = tag2[slot[j] >> 1];
         }
+        if (PHASED) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave's reads are done before any wave's atomics start
+        if (PIPE) {
+            // software pipeline: this step's tag reads are in flight while the PREVIOUS step's atomics are issued (the LDS returns
+            // in order, so the wait for the reads below is a counted lgkmcnt that leaves these atomics outstanding)
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const uint32_t at = pat[j];
+                if (WHAT & 8) unsafeAtomicAdd(&t_val[at], 1.0);
+                if (WHAT & 16) atomicAdd(&t_cnt[at], 1u);
+                if (WHAT & 32) atomicAdd(reinterpret_cast<unsigned long long *>(&t_val[at]), 1ull);
+                if (WHAT & 64) unsafeAtomicAdd(&t_val2[at >> 1], 1.0);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             uint32_t at = slot[j];
             if (WHAT & 1) { acc += qa[j].x ^ qa[j].w ^ qb[j].y; at = (at & ~7u) | ((qa[j].x ^ qb[j].z) & 7u); }       // the slot depends on the tags read (as a real probe's does)
             if (WHAT & 2) { acc += qa[j].x ^ qa[j].w; at = (at & ~7u) | ((qa[j].x ^ qa[j].z) & 7u); }
             if (WHAT & 4) { acc += qc[j].x; at = (at & ~7u) | ((qc[j].x ^ qc[j].y) & 7u); }
+            if (PIPE) { pat[j] = at; continue; }
             if (WHAT & 8) unsafeAtomicAdd(&t_val[at], 1.0);
             if (WHAT & 16) atomicAdd(&t_cnt[at], 1u);
             if (WHAT & 32) atomicAdd(reinterpret_cast<unsigned long long *>(&t_val[at]), 1ull);
             if (WHAT & 64) unsafeAtomicAdd(&t_val2[at >> 1], 1.0);
         }
+        if (PHASED) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // ... and every wave's atomics before the next step's reads
     }
     __syncthreads();
     if (threadIdx.x == 0) out[blockIdx.x] = acc + t_cnt[7] + (uint32_t)t_val[9];
 }
 
-template <int WHAT> static void run(const char *name, uint32_t *out, int ncu)
+template <int WHAT, bool PIPE = false, bool PHASED = false> static void run(const char *name, uint32_t *out, int ncu)
 {
     const double pairs = 2.5e8;
     const int steps = (int)(pairs / ((double)ncu * 1024 * 8) + 0.5);
     const size_t lds = (size_t)kSlots * 16 + ((WHAT & 64) ? (size_t)kSlots * 4 : 0);
-    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&probe_kernel<WHAT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&probe_kernel<WHAT, PIPE, PHASED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     std::vector<float> ts;
     for (int rep = 0; rep < 6; rep++) {
         CK(hipEventRecord(e0));
-        probe_kernel<WHAT><<<ncu, 1024, lds>>>(steps, out);
+        probe_kernel<WHAT, PIPE, PHASED><<<ncu, 1024, lds>>>(steps, out);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (rep) ts.push_back(ms);
     }
@@ -107,5 +125,23 @@ int main()
     run<2 | 8>("1 x b128 + f64        (no count atomic)", out, ncu);
     run<2 | 32>("1 x b128 + u64        (one integer atomic: u32 sums, or a packed word)", out, ncu);
     run<2 | 8 | 64>("1 x b128 + f64 + f64  (count as a double beside the sum)", out, ncu);
+    printf("-- software-pipelined: a step's tag reads are issued BEFORE the previous step's atomics, and waited for after them\n");
+    run<1 | 8 | 16, true>("2 x b128 + f64 + u32, pipelined", out, ncu);
+    run<2 | 8 | 16, true>("1 x b128 + f64 + u32, pipelined", out, ncu);
+    run<4 | 8 | 16, true>("1 x b64  + f64 + u32, pipelined", out, ncu);
+    run<2 | 32, true>("1 x b128 + u64, pipelined", out, ncu);
+    run<2 | 8, true>("1 x b128 + f64, pipelined", out, ncu);
+    printf("-- phased: a workgroup barrier between the reads and the atomics of a step, and after the atomics (reads and atomics of different waves never meet in the LDS queue)\n");
+    run<1 | 8 | 16, false, true>("2 x b128 + f64 + u32, phased", out, ncu);
+    run<2 | 8 | 16, false, true>("1 x b128 + f64 + u32, phased", out, ncu);
+    run<4 | 8 | 16, false, true>("1 x b64  + f64 + u32, phased", out, ncu);
+    run<2 | 32, false, true>("1 x b128 + u64, phased", out, ncu);
+    printf("-- more combinations\n");
+    run<4 | 32>("1 x b64  + u64", out, ncu);
+    run<4 | 8>("1 x b64  + f64", out, ncu);
+    run<1 | 32>("2 x b128 + u64", out, ncu);
+    run<1 | 16>("2 x b128 + u32", out, ncu);
+    run<2 | 16>("1 x b128 + u32", out, ncu);
+    run<2 | 16 | 32>("1 x b128 + u64 + u32", out, ncu);
     return 0;
 }

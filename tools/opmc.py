@@ -1,5 +1,5 @@
 """HBM bytes and time per kernel of ONE repetition of a tools/op_one.py workload, from its two PMC runs:
-    python tools/opmc.py DIR_FETCH_SIZE DIR_WRITE_SIZE [algorithmic_bytes]
+    python tools/opmc.py DIR_FETCH_SIZE DIR_WRITE_SIZE [algorithmic_bytes] [reps of op_one.py, default 3]
 Each directory is the -d of `rocprofv3 --pmc <COUNTER> --kernel-trace --output-format csv -- python3 tools/op_one.py W`.
 The last repetition is found as the longest block of kernel names at the end of the run that repeats the block before it
 (op_one.py repeats the statement at least three times; the setup kernels in front do not repeat).  FETCH_SIZE is doubled (gfx950: it reports half of a wide
@@ -27,12 +27,15 @@ def short(n):
     return n[:n.index("(")] if "(" in n else n
 
 
-def last_period(names):
-    """Dispatches of one repetition: the LONGEST k whose last k names repeat the k before them.  (The shortest would stop at
-    one radix pass of a sort, or at two equal gathers; a longer one than a repetition would have to reach into the setup
-    kernels, which do not repeat.)"""
-    for k in range(len(names) // 2, 0, -1):
-        if names[-k:] == names[-2 * k:-k]:
+def last_period(names, reps=3):
+    """Dispatches of ONE repetition of a statement that tools/op_one.py ran `reps` times: the longest k such that the last
+    reps * k names are reps copies of the last k, which itself is not two equal halves... taken literally that is still
+    ambiguous for an even number of repetitions (with reps = 4 the last 2k names "repeat" as well: ADVICE r04), so the answer
+    is pinned by the repetition count: the repeating tail is found as the longest block repeated at the end, and ONE repetition
+    is that tail's length divided by the number of times the statement ran."""
+    reps = max(2, int(reps))
+    for k in range(len(names) // reps, 0, -1):
+        if all(names[-k:] == names[-(j + 1) * k: len(names) - j * k] for j in range(1, reps)):
             return k
     return len(names)
 
@@ -40,7 +43,8 @@ def last_period(names):
 def main():
     fetch, write = rows_of(sys.argv[1], "FETCH_SIZE"), rows_of(sys.argv[2], "WRITE_SIZE")
     alg = float(sys.argv[3]) if len(sys.argv) > 3 else None
-    kf, kw = last_period([r["name"] for r in fetch]), last_period([r["name"] for r in write])
+    reps = int(sys.argv[4]) if len(sys.argv) > 4 else 3                       # how often op_one.py ran the statement (its default)
+    kf, kw = last_period([r["name"] for r in fetch], reps), last_period([r["name"] for r in write], reps)
     if kf != kw or [r["name"] for r in fetch[-kf:]] != [r["name"] for r in write[-kw:]]:
         raise SystemExit(f"the two runs do not end in the same kernel sequence (periods {kf} / {kw})")
     acc = collections.OrderedDict()
