@@ -1448,8 +1448,11 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash_kernel(
     auto slow = [&](uint32_t tag, uint32_t g, uint32_t vbits) {
         for (uint32_t d = 0; d < 2u; d++) {
             const uint32_t gg = (g + d) & (kGroups - 1u), t = tag | (d << 14), t2 = t | (t << 16);
-            for (int tries = 0; tries < 64; tries++) {                     // (each failed claim is another lane's success: <= 8 per group)
-                const uint4 q = t_tag4[gg];
+            asm volatile("" ::: "memory");                                   // (the group is read NOW: other lanes' claims since the probe's read count)
+            uint4 q = t_tag4[gg];
+            // a failed claim is another lane's success on that word, and a word changes at most twice (its two halves): the
+            // loop ends after <= 8 failures.  The word's new content comes back from the compare-and-swap itself.
+            for (int tries = 0; tries < 16; tries++) {
                 const int at = find8(q, t2);
                 if (at >= 0) { hit(8u * gg + (uint32_t)at, vbits); return; }
                 const int e = find8(q, 0u);
@@ -1457,7 +1460,9 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash_kernel(
                 if (s_used >= (uint32_t)kHashFill) { overflow = true; return; }
                 const uint32_t w = e >> 1, oldw = w == 0 ? q.x : w == 1 ? q.y : w == 2 ? q.z : q.w;
                 const uint32_t neww = oldw | (t << (16 * (e & 1)));
-                if (atomicCAS(&t_tagw[4u * gg + w], oldw, neww) == oldw) { atomicAdd(&s_used, 1u); hit(8u * gg + (uint32_t)e, vbits); return; }   // ds_cmpst_rtn_b32
+                const uint32_t got = atomicCAS(&t_tagw[4u * gg + w], oldw, neww);           // ds_cmpst_rtn_b32
+                if (got == oldw) { atomicAdd(&s_used, 1u); hit(8u * gg + (uint32_t)e, vbits); return; }
+                if (w == 0) q.x = got; else if (w == 1) q.y = got; else if (w == 2) q.z = got; else q.w = got;
             }
         }
         overflow = true;
