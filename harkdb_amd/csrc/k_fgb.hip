@@ -1425,16 +1425,20 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash_kernel(
     // cost more together than apart, whatever their order: pipelined and barrier-separated variants measure the same).
     // Hence 16-BIT tags, eight to a 16-byte group: a probe is ONE ds_read_b128.  mix32 is a bijection and a bucket holds the keys
     // with one value of its top bits, so the low `lowbits` bits x of mix32(key) ARE the key inside the bucket; its home group is
-    // the top 10 bits of x (1024 groups) and the tag the remaining lowbits - 10 <= 14 bits | 2^15 (occupied).  A key whose home
-    // group is full of other keys (load <= 0.375: Poisson(3) keys per group, > 8 in 0.4 % of the groups) lives in the NEXT group
-    // with bit 14 set (displaced by one), and nowhere else: a round in which that group is full too reports an overflow
-    // (the caller halves the keys per round).  A probe finds its key in the home group without a branch; anything else -- a
-    // new key, a displaced key -- takes the slow path, which hardly a wave sees once the table is built.
+    // the top 10 bits of x (1024 groups) and the tag the remaining rembits = lowbits - 10 <= 14 bits | 2^15 (occupied).  A key whose
+    // home group is full of other keys (2048 keys per bucket: Poisson(2) per group, > 8 in 0.024 % of the groups -- ~125 groups
+    // of a 2^20-key table) lives in the first of the next groups that had room when it came, its distance d in the tag bits
+    // between the remainder and bit 15 (two bits with 512 buckets: d <= 3; a first version allowed d = 1 only and met a pair of
+    // full neighbours in one table of seven -- a second round for a whole statement); a lookup walks the same groups, all full
+    // up to the key's.  A round in which every one of them is full reports an overflow (the caller halves the keys per round).
+    // A probe finds its key in the home group without a branch; anything else -- a new key, a displaced key -- takes the
+    // slow path, which hardly a wave sees once the table is built.
     constexpr int kNP = 8;
     constexpr uint32_t kGroups = kHashCap / 8, kGroupBits = 10;
     static_assert(kGroups == 1u << kGroupBits, "group index = a bit field of the key's low bits");
     const int rembits = lowbits - (int)kGroupBits;                       // <= 14 (P >= 256 buckets: the host checks)
     const uint32_t remmask = (1u << rembits) - 1u;
+    const uint32_t maxdisp = (1u << (15 - rembits)) - 1u < 3u ? (1u << (15 - rembits)) - 1u : 3u;   // groups a key may live past its home
     const uint4 *t_tag4 = reinterpret_cast<const uint4 *>(t_tagw);
     auto find8 = [](const uint4 &q, uint32_t t2) -> int {               // t2 = tag | tag << 16; -1: not among the eight
         const uint32_t x0 = q.x ^ t2, x1 = q.y ^ t2, x2 = q.z ^ t2, x3 = q.w ^ t2;
@@ -1446,8 +1450,8 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash_kernel(
     // a group's first empty slot, with a compare-and-swap on the WORD that holds it: a lane that loses (the word changed: its
     // neighbour half or the slot itself) reads the group again, so two lanes with one key end up in one slot.
     auto slow = [&](uint32_t tag, uint32_t g, uint32_t vbits) {
-        for (uint32_t d = 0; d < 2u; d++) {
-            const uint32_t gg = (g + d) & (kGroups - 1u), t = tag | (d << 14), t2 = t | (t << 16);
+        for (uint32_t d = 0; d <= maxdisp; d++) {
+            const uint32_t gg = (g + d) & (kGroups - 1u), t = tag | (d << rembits), t2 = t | (t << 16);
             asm volatile("" ::: "memory");                                   // (the group is read NOW: other lanes' claims since the probe's read count)
             uint4 q = t_tag4[gg];
             // a failed claim is another lane's success on that word, and a word changes at most twice (its two halves): the
@@ -1508,7 +1512,7 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash_kernel(
         if (!c) continue;
         const unsigned long long o = s_base + pos++;
         if (o < out_cap) {
-            const uint32_t t = t_tag16[i], home = (((uint32_t)i >> 3) - ((t >> 14) & 1u)) & (kGroups - 1u);   // a displaced key's home is the group before
+            const uint32_t t = t_tag16[i], home = (((uint32_t)i >> 3) - ((t & 0x7FFFu) >> rembits)) & (kGroups - 1u);   // a displaced key's home lies d groups back
             out_key[o] = unmix32((b << lowbits) | (home << rembits) | (t & remmask)); out_val[o] = t_val[i]; out_cnt[o] = (u64)c;
         }
         else *err = kErrOverflow;
