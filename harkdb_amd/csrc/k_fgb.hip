@@ -1398,6 +1398,72 @@ __device__ __forceinline__ uint32_t unmix32(uint32_t y)
     return y;
 }
 
+// ---- 16-bit tags, eight to a 16-byte group: ONE ds_read_b128 per probe -------------------------------------------------
+// (fgb_agg_hash_kernel's comment has the measurements.)  x = the low `lowbits` bits of mix32(key) = the key inside its bucket.
+// Its home group is x / D (D = identities per group = ceil(2^lowbits / groups): any group count), its tag
+// 2^15 | d << rembits | x % D where d <= maxdisp is how many groups past its home the key lives (the first group that had
+// room when it came; all before it are full of other keys, and stay so: slots only ever go from empty to occupied).
+struct TagGroups {
+    uint32_t *tagw;                                          // LDS [groups * 4]: two tags per word, 0 = empty
+    uint32_t groups, D, magic, rembits, remmask, maxdisp;
+    __device__ __forceinline__ void init(uint32_t *lds_words, uint32_t ngroups, int lowbits)
+    {
+        tagw = lds_words; groups = ngroups;
+        D = ((1u << lowbits) + ngroups - 1u) / ngroups;
+        magic = (uint32_t)((((uint64_t)1 << 32) + D - 1u) / D);
+        rembits = 32u - (uint32_t)__clz((int)(D - 1u));      // D >= 2
+        remmask = (1u << rembits) - 1u;
+        const uint32_t room = rembits < 15u ? (1u << (15u - rembits)) - 1u : 0u;
+        maxdisp = room < 3u ? room : 3u;
+    }
+    __device__ __forceinline__ void home(uint32_t x, uint32_t &g, uint32_t &tag) const
+    {
+        uint32_t q = __umulhi(x, magic);                      // x / D, at most one too large (x < 2^24, D < 2^15)
+        if (q * D > x) q--;
+        g = q; tag = (x - q * D) | 0x8000u;
+    }
+    __device__ __forceinline__ uint4 read(uint32_t g) const { return reinterpret_cast<const uint4 *>(tagw)[g]; }
+    static __device__ __forceinline__ int find8(const uint4 &q, uint32_t t2)       // t2 = tag | tag << 16 (0: the first empty slot); -1: none
+    {
+        const uint32_t x0 = q.x ^ t2, x1 = q.y ^ t2, x2 = q.z ^ t2, x3 = q.w ^ t2;
+        return !(x0 & 0xFFFFu) ? 0 : !(x0 >> 16) ? 1 : !(x1 & 0xFFFFu) ? 2 : !(x1 >> 16) ? 3 : !(x2 & 0xFFFFu) ? 4 : !(x2 >> 16) ? 5 : !(x3 & 0xFFFFu) ? 6 : !(x3 >> 16) ? 7 : -1;
+    }
+    // The slot of a key that its home group's read did not show: found further on, or claimed (the first empty slot of the first
+    // group with room, with a compare-and-swap on the WORD that holds it; a lane that loses learns the word's new content from
+    // the compare-and-swap itself and looks again, so two lanes with one key end up in one slot; a word changes at most twice:
+    // <= 8 failures per group).  Returns the slot; -1: every group the key may live in is full of other keys; -2: the round's
+    // budget of distinct keys (*used >= fill) is spent.  *claimed: the key is new.
+    __device__ __forceinline__ int locate(uint32_t tag, uint32_t g, uint32_t *used, uint32_t fill, bool &claimed) const
+    {
+        claimed = false;
+        for (uint32_t d = 0; d <= maxdisp; d++) {
+            uint32_t gg = g + d; if (gg >= groups) gg -= groups;
+            const uint32_t t = tag | (d << rembits), t2 = t | (t << 16);
+            asm volatile("" ::: "memory");                   // (the group is read NOW: other lanes' claims since the probe's read count)
+            uint4 q = read(gg);
+            for (int tries = 0; tries < 16; tries++) {
+                const int at = find8(q, t2);
+                if (at >= 0) return (int)(8u * gg) + at;
+                const int e = find8(q, 0u);
+                if (e < 0) break;                            // full of other keys: the next group
+                if (*used >= fill) return -2;
+                const uint32_t w = (uint32_t)e >> 1, oldw = w == 0 ? q.x : w == 1 ? q.y : w == 2 ? q.z : q.w;
+                const uint32_t got = atomicCAS(&tagw[4u * gg + w], oldw, oldw | (t << (16 * (e & 1))));   // ds_cmpst_rtn_b32
+                if (got == oldw) { atomicAdd(used, 1u); claimed = true; return (int)(8u * gg) + e; }
+                if (w == 0) q.x = got; else if (w == 1) q.y = got; else if (w == 2) q.z = got; else q.w = got;
+            }
+        }
+        return -1;
+    }
+    // the key's low bits x back from its slot and tag (emit time)
+    __device__ __forceinline__ uint32_t identity(uint32_t slot, uint32_t tag) const
+    {
+        const uint32_t d = (tag & 0x7FFFu) >> rembits;
+        uint32_t g = slot >> 3; g = g >= d ? g - d : g + groups - d;
+        return g * D + (tag & remmask);
+    }
+};
+
 template <int VOP>
 __global__ __launch_bounds__(1024) void fgb_agg_hash_kernel(
     const uint2 *__restrict__ pbuf, const uint32_t *__restrict__ counts, uint32_t cap, int nwg, uint32_t Rmask, uint32_t r,
@@ -1434,63 +1500,40 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash_kernel(
     // A probe finds its key in the home group without a branch; anything else -- a new key, a displaced key -- takes the
     // slow path, which hardly a wave sees once the table is built.
     constexpr int kNP = 8;
-    constexpr uint32_t kGroups = kHashCap / 8, kGroupBits = 10;
-    static_assert(kGroups == 1u << kGroupBits, "group index = a bit field of the key's low bits");
-    const int rembits = lowbits - (int)kGroupBits;                       // <= 14 (P >= 256 buckets: the host checks)
-    const uint32_t remmask = (1u << rembits) - 1u;
-    const uint32_t maxdisp = (1u << (15 - rembits)) - 1u < 3u ? (1u << (15 - rembits)) - 1u : 3u;   // groups a key may live past its home
-    const uint4 *t_tag4 = reinterpret_cast<const uint4 *>(t_tagw);
-    auto find8 = [](const uint4 &q, uint32_t t2) -> int {               // t2 = tag | tag << 16; -1: not among the eight
-        const uint32_t x0 = q.x ^ t2, x1 = q.y ^ t2, x2 = q.z ^ t2, x3 = q.w ^ t2;
-        return !(x0 & 0xFFFFu) ? 0 : !(x0 >> 16) ? 1 : !(x1 & 0xFFFFu) ? 2 : !(x1 >> 16) ? 3 : !(x2 & 0xFFFFu) ? 4 : !(x2 >> 16) ? 5 : !(x3 & 0xFFFFu) ? 6 : !(x3 >> 16) ? 7 : -1;
-    };
+    constexpr uint32_t kGroups = kHashCap / 8;
+    TagGroups tg;
+    tg.init(t_tagw, kGroups, lowbits);                                   // 1024 groups: D = 2^(lowbits - 10), the division is a shift in effect
     auto hit = [&](uint32_t slot, uint32_t vbits) { vop_atomic<VOP>(&t_val[slot], VOP == VOP_F32SUM ? vbits : apply_xf(xf, vbits)); atomicAdd(&t_cnt[slot], 1u); };
-    // the key is not in its home group g as that group was read: claim the first empty slot there, or -- the group full of other
-    // keys -- look / claim in group g + 1 under the displaced tag.  Slots only ever go from empty to occupied and every lane takes
-    // a group's first empty slot, with a compare-and-swap on the WORD that holds it: a lane that loses (the word changed: its
-    // neighbour half or the slot itself) reads the group again, so two lanes with one key end up in one slot.
     auto slow = [&](uint32_t tag, uint32_t g, uint32_t vbits) {
-        for (uint32_t d = 0; d <= maxdisp; d++) {
-            const uint32_t gg = (g + d) & (kGroups - 1u), t = tag | (d << rembits), t2 = t | (t << 16);
-            asm volatile("" ::: "memory");                                   // (the group is read NOW: other lanes' claims since the probe's read count)
-            uint4 q = t_tag4[gg];
-            // a failed claim is another lane's success on that word, and a word changes at most twice (its two halves): the
-            // loop ends after <= 8 failures.  The word's new content comes back from the compare-and-swap itself.
-            for (int tries = 0; tries < 16; tries++) {
-                const int at = find8(q, t2);
-                if (at >= 0) { hit(8u * gg + (uint32_t)at, vbits); return; }
-                const int e = find8(q, 0u);
-                if (e < 0) break;                                            // full of other keys: the next group, once
-                if (s_used >= (uint32_t)kHashFill) { overflow = true; return; }
-                const uint32_t w = e >> 1, oldw = w == 0 ? q.x : w == 1 ? q.y : w == 2 ? q.z : q.w;
-                const uint32_t neww = oldw | (t << (16 * (e & 1)));
-                const uint32_t got = atomicCAS(&t_tagw[4u * gg + w], oldw, neww);           // ds_cmpst_rtn_b32
-                if (got == oldw) { atomicAdd(&s_used, 1u); hit(8u * gg + (uint32_t)e, vbits); return; }
-                if (w == 0) q.x = got; else if (w == 1) q.y = got; else if (w == 2) q.z = got; else q.w = got;
-            }
-        }
-        overflow = true;
+        bool claimed;
+        const int slot = tg.locate(tag, g, &s_used, (uint32_t)kHashFill, claimed);
+        if (slot >= 0) hit((uint32_t)slot, vbits); else overflow = true;
     };
     auto probe = [&](const uint32_t (&key)[kNP], const uint32_t (&vb)[kNP], uint32_t live) {
         uint32_t tag[kNP], g[kNP]; uint4 q[kNP];
 #pragma unroll
         for (int j = 0; j < kNP; j++) {
-            const uint32_t x = key[j] & lowmask;                              // the producer wrote mix32(key)
-            g[j] = x >> rembits;
-            tag[j] = (x & remmask) | 0x8000u;
+            tg.home(key[j] & lowmask, g[j], tag[j]);                          // the producer wrote mix32(key)
             if (Rmask && (mix32(key[j] ^ 0x9E3779B9u) & Rmask) != r) live &= ~(1u << j);   // not this round's share of the key space
         }
 #pragma unroll
-        for (int j = 0; j < kNP; j++) q[j] = t_tag4[g[j]];                   // kNP independent 16-byte LDS reads in flight
+        for (int j = 0; j < kNP; j++) q[j] = tg.read(g[j]);                  // kNP independent 16-byte LDS reads in flight
         uint32_t miss = 0;
 #pragma unroll
         for (int j = 0; j < kNP; j++) {
-            const int at = find8(q[j], tag[j] | (tag[j] << 16));
+            const int at = TagGroups::find8(q[j], tag[j] | (tag[j] << 16));
             if ((live >> j) & 1u) { if (at >= 0) hit(8u * g[j] + (uint32_t)at, vb[j]); else miss |= 1u << j; }
         }
-        if (__any(miss != 0u)) {
+        // The missing pairs of a lane are taken one per pass, each lane its own first: the number of passes is the LARGEST number of
+        // misses any lane has (one, seldom two), not the number of pair positions j at which some lane missed -- with keys that come
+        // ~50 times each (the reference entry's bench line: 2 % of the pairs are first occurrences) that was six or seven of the
+        // eight positions in every step, each a divergent pass of dependent LDS round trips for a lane or two.
+        while (__any(miss != 0u)) {
+            const int first = miss ? __ffs((int)miss) - 1 : -1;
+            uint32_t tj = 0u, gj = 0u, vj = 0u;
 #pragma unroll
-            for (int j = 0; j < kNP; j++) if ((miss >> j) & 1u) slow(tag[j], g[j], vb[j]);
+            for (int j = 0; j < kNP; j++) if (j == first) { tj = tag[j]; gj = g[j]; vj = vb[j]; }
+            if (miss) { slow(tj, gj, vj); miss &= miss - 1u; }
         }
     };
     walk_pair_slabs(pbuf, counts, cap, nwg, b, [&](const uint32_t (&key)[kNP], const uint32_t (&vb)[kNP], uint32_t live) -> bool {
@@ -1512,8 +1555,7 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash_kernel(
         if (!c) continue;
         const unsigned long long o = s_base + pos++;
         if (o < out_cap) {
-            const uint32_t t = t_tag16[i], home = (((uint32_t)i >> 3) - ((t & 0x7FFFu) >> rembits)) & (kGroups - 1u);   // a displaced key's home lies d groups back
-            out_key[o] = unmix32((b << lowbits) | (home << rembits) | (t & remmask)); out_val[o] = t_val[i]; out_cnt[o] = (u64)c;
+            out_key[o] = unmix32((b << lowbits) | tg.identity((uint32_t)i, t_tag16[i])); out_val[o] = t_val[i]; out_cnt[o] = (u64)c;
         }
         else *err = kErrOverflow;
     }
@@ -1626,7 +1668,9 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash_stats_kernel(
 // (144 KiB), half of them used per round (6144 / 4608 distinct keys per bucket: 2^21 keys in 512 buckets take ONE round) --
 // instead of one consumer pass and one sort of the result keys per operator.  ops: operator of slot j in byte j
 // (VOP_U32SUM / MAX / MIN / PROD).  Emits slot 0 | slot 1 << 32 as the value word and slot 2 as the count word.
-template <int NOPS> struct HashOpsGeo { static constexpr int groups = NOPS == 2 ? 1536 : 1152, cap = groups * 8, fill = cap / 2; };
+// (round 5: 16-bit tags -- 10 or 14 bytes per entry -- let the same 160 KiB hold 2040 / 1456 groups instead of 1536 / 1152; the keys per
+// round stay at 6144 / 4608, so a group holds 3.0 / 3.2 keys on average when a round is full and 2.0 / 2.8 for the 2^21 keys of the bench line)
+template <int NOPS> struct HashOpsGeo { static constexpr int groups = NOPS == 2 ? 2040 : 1456, cap = groups * 8, fill = NOPS == 2 ? 6144 : 4608; };
 __device__ __forceinline__ void op32_atomic(int vop, uint32_t *slot, uint32_t x)
 {
     if (vop == VOP_U32SUM) atomicAdd(slot, x);
@@ -1642,8 +1686,8 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash_ops_kernel(
 {
     constexpr int kCap = HashOpsGeo<NOPS>::cap, kGroups = HashOpsGeo<NOPS>::groups, kFill = HashOpsGeo<NOPS>::fill;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    uint32_t *t_tag = reinterpret_cast<uint32_t *>(lds_raw);             // [kCap] low bits of mix32(key) | 2^31, 0 = empty (groups are read as two uint4)
-    uint32_t *t_a = t_tag + kCap, *t_b = t_a + kCap, *t_c = t_b + kCap;  // [kCap] each; t_c with three operators only
+    uint32_t *t_tagw = reinterpret_cast<uint32_t *>(lds_raw);            // [kCap / 2] 16-bit tags (TagGroups), 0 = empty
+    uint32_t *t_a = t_tagw + kCap / 2, *t_b = t_a + kCap, *t_c = t_b + kCap;   // [kCap] each; t_c with three operators only
     __shared__ uint32_t s_used, s_emit;
     __shared__ unsigned long long s_base;
     const uint32_t b = blockIdx.x;
@@ -1651,56 +1695,48 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash_ops_kernel(
     const uint32_t lowmask = (1u << lowbits) - 1u;
     const int op_a = (int)(ops & 255u), op_b = (int)((ops >> 8) & 255u), op_c = (int)((ops >> 16) & 255u);
     const uint32_t id_a = (uint32_t)vop_identity(op_a), id_b = (uint32_t)vop_identity(op_b), id_c = (uint32_t)vop_identity(op_c);
-    for (int i = threadIdx.x; i < kCap; i += blockDim.x) { t_tag[i] = 0u; t_a[i] = id_a; t_b[i] = id_b; if constexpr (NOPS == 3) t_c[i] = id_c; }
+    for (int i = threadIdx.x; i < kCap; i += blockDim.x) { t_a[i] = id_a; t_b[i] = id_b; if constexpr (NOPS == 3) t_c[i] = id_c; }
+    for (int i = threadIdx.x; i < kCap / 2; i += blockDim.x) t_tagw[i] = 0u;
     if (threadIdx.x == 0) { s_used = 0u; s_emit = 0u; }
     __syncthreads();
     bool overflow = false;
     constexpr int kNP = 8;
-    uint4 *t_tag4 = reinterpret_cast<uint4 *>(t_tag);
-    struct Tags8 { uint4 a, b; };
-    auto load8 = [&](uint32_t g) -> Tags8 { return Tags8{t_tag4[2u * g], t_tag4[2u * g + 1u]}; };
-    auto find8 = [](const Tags8 &q, uint32_t t) -> int {
-        return q.a.x == t ? 0 : q.a.y == t ? 1 : q.a.z == t ? 2 : q.a.w == t ? 3 : q.b.x == t ? 4 : q.b.y == t ? 5 : q.b.z == t ? 6 : q.b.w == t ? 7 : -1;
-    };
+    TagGroups tg;
+    tg.init(t_tagw, (uint32_t)kGroups, lowbits);                         // 1536 / 1152 groups: 13-bit remainders with 512 buckets, a key lives <= 3 groups past its home
     auto hit = [&](uint32_t slot, uint32_t x) {
         op32_atomic(op_a, &t_a[slot], x); op32_atomic(op_b, &t_b[slot], x);
         if constexpr (NOPS == 3) op32_atomic(op_c, &t_c[slot], x);
     };
-    auto slow = [&](uint32_t tag, uint32_t g, Tags8 q, uint32_t x) {         // (as in fgb_agg_hash_kernel)
-        for (uint32_t step = 0; step < 8u * (uint32_t)kGroups; step++) {
-            const int at = find8(q, tag);
-            if (at >= 0) { hit(8u * g + (uint32_t)at, x); return; }
-            const int e = find8(q, 0u);
-            if (e >= 0) {
-                if (s_used >= (uint32_t)kFill) { overflow = true; return; }
-                const uint32_t old = atomicCAS(&t_tag[8u * g + (uint32_t)e], 0u, tag);
-                if (old == 0u) { atomicAdd(&s_used, 1u); hit(8u * g + (uint32_t)e, x); return; }
-                if (old == tag) { hit(8u * g + (uint32_t)e, x); return; }
-            } else g = g + 1u == (uint32_t)kGroups ? 0u : g + 1u;
-            q = load8(g);
-        }
-        overflow = true;
+    auto slow = [&](uint32_t tag, uint32_t g, uint32_t x) {
+        bool claimed;
+        const int slot = tg.locate(tag, g, &s_used, (uint32_t)kFill, claimed);
+        if (slot >= 0) hit((uint32_t)slot, x); else overflow = true;
     };
     auto probe = [&](const uint32_t (&key)[kNP], const uint32_t (&vb)[kNP], uint32_t live) {
-        uint32_t tag[kNP], g[kNP]; Tags8 q[kNP];
+        uint32_t tag[kNP], g[kNP]; uint4 q[kNP];
 #pragma unroll
         for (int j = 0; j < kNP; j++) {
-            const uint32_t m = key[j];                                        // the producer wrote mix32(key)
-            tag[j] = (m & lowmask) | 0x80000000u;
-            g[j] = __umulhi(m * 0x9E3779B1u, (uint32_t)kGroups);             // not a power of two
+            tg.home(key[j] & lowmask, g[j], tag[j]);                          // the producer wrote mix32(key)
             if (Rmask && (mix32(key[j] ^ 0x9E3779B9u) & Rmask) != r) live &= ~(1u << j);
         }
 #pragma unroll
-        for (int j = 0; j < kNP; j++) q[j] = load8(g[j]);
+        for (int j = 0; j < kNP; j++) q[j] = tg.read(g[j]);
         uint32_t miss = 0;
 #pragma unroll
         for (int j = 0; j < kNP; j++) {
-            const int at = find8(q[j], tag[j]);
+            const int at = TagGroups::find8(q[j], tag[j] | (tag[j] << 16));
             if ((live >> j) & 1u) { if (at >= 0) hit(8u * g[j] + (uint32_t)at, vb[j]); else miss |= 1u << j; }
         }
-        if (__any(miss != 0u)) {
+        // The missing pairs of a lane are taken one per pass, each lane its own first: the number of passes is the LARGEST number of
+        // misses any lane has (one, seldom two), not the number of pair positions j at which some lane missed -- with keys that come
+        // ~50 times each (the reference entry's bench line: 2 % of the pairs are first occurrences) that was six or seven of the
+        // eight positions in every step, each a divergent pass of dependent LDS round trips for a lane or two.
+        while (__any(miss != 0u)) {
+            const int first = miss ? __ffs((int)miss) - 1 : -1;
+            uint32_t tj = 0u, gj = 0u, vj = 0u;
 #pragma unroll
-            for (int j = 0; j < kNP; j++) if ((miss >> j) & 1u) slow(tag[j], g[j], q[j], vb[j]);
+            for (int j = 0; j < kNP; j++) if (j == first) { tj = tag[j]; gj = g[j]; vj = vb[j]; }
+            if (miss) { slow(tj, gj, vj); miss &= miss - 1u; }
         }
     };
     walk_pair_slabs(pbuf, counts, cap, nwg, b, [&](const uint32_t (&key)[kNP], const uint32_t (&vb)[kNP], uint32_t live) -> bool {
@@ -1709,18 +1745,19 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash_ops_kernel(
     });
     if (overflow) *err = kErrOverflow;
     __syncthreads();
+    const uint16_t *t_tag16 = reinterpret_cast<const uint16_t *>(t_tagw);
     uint32_t mine = 0;
-    for (int i = threadIdx.x; i < kCap; i += blockDim.x) mine += t_tag[i] ? 1u : 0u;
+    for (int i = threadIdx.x; i < kCap; i += blockDim.x) mine += t_tag16[i] ? 1u : 0u;
     uint32_t pos = mine ? atomicAdd(&s_emit, mine) : 0u;
     __syncthreads();
     if (threadIdx.x == 0) s_base = s_emit ? atomicAdd(out_cursor, (unsigned long long)s_emit) : 0ull;
     __syncthreads();
     for (int i = threadIdx.x; i < kCap; i += blockDim.x) {
-        const uint32_t t = t_tag[i];
+        const uint32_t t = t_tag16[i];
         if (!t) continue;
         const unsigned long long o = s_base + pos++;
         if (o < out_cap) {
-            out_key[o] = unmix32((b << lowbits) | (t & lowmask));
+            out_key[o] = unmix32((b << lowbits) | tg.identity((uint32_t)i, t));
             out_val[o] = (u64)t_a[i] | ((u64)t_b[i] << 32);
             out_cnt[o] = NOPS == 3 ? (u64)t_c[i] : 0ull;
         } else *err = kErrOverflow;
@@ -2617,7 +2654,7 @@ int k_fgb_hash_u32(hark_context *ctx, const uint32_t *k, const uint32_t *v, int6
             if (nops) {
                 auto go = [&](auto nc) -> int {
                     constexpr int NOPS = decltype(nc)::value;
-                    const size_t lds_o = (size_t)HashOpsGeo<NOPS>::cap * 4 * (NOPS + 1);
+                    const size_t lds_o = (size_t)HashOpsGeo<NOPS>::cap * (2 + 4 * NOPS);   // 16-bit tag + one 32-bit slot per operator
                     HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_agg_hash_ops_kernel<NOPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_o));
                     for (uint32_t r = r_begin; r < r_end; r++)
                         fgb_agg_hash_ops_kernel<NOPS><<<dim3((unsigned)P), dim3(1024), lds_o, st>>>(pbuf, counts, (uint32_t)cap, nwg, R - 1, r, okey, oval, ocnt, cursor, out_cap, err, ref_ops);
