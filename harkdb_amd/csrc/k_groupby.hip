@@ -891,14 +891,22 @@ int try_hash(hark_context *ctx, const hark_table *db, const PredList &preds,
     int rc = HARK_OK;
     bool ok = src->n > 0;
     int64_t G = -1;
-    uint32_t rounds = 0;
+    // What an earlier statement WITHOUT a WHERE learnt about this key column stays with it, as in the reference entry (ADVICE r04:
+    // a column the hash path does not fit -- too many distinct keys, skew -- paid producer + consumer + the sort path on every
+    // statement): unfit -> no attempt; the table rounds its keys need -> no failed first round.  A WHERE changes which keys
+    // occur, so filtered statements neither use nor leave a verdict (hark_table_invalidate_stats forgets it).
+    const hark_column &kc = db->cols[g_col];
+    const bool whole_column = preds.n == 0;
+    if (whole_column && kc.hash_rounds < 0) { hark_free(ctx, mask); return HARK_OK; }
+    uint32_t rounds = whole_column && kc.hash_rounds > 0 ? (uint32_t)kc.hash_rounds : 0u;
+    int why = HARK_HASH_FITS;
     std::vector<char> done((size_t)n_aggs, 0);
     unsigned long long *accg = nullptr, *cntg = nullptr;
     hark_hash_part part;                                     // passes over one (column, value transform) share the hash partition
     auto run_pass = [&](int vop, int xf, const void *col) -> int {
         uint32_t *hk = nullptr, *perm = nullptr; unsigned long long *hv = nullptr, *hc = nullptr;
         int64_t Gj = 0;
-        int r = k_fgb_hash_u32(ctx, keys, static_cast<const uint32_t *>(col), src->n, vop, xf, &hk, &hv, &hc, &Gj, &ok, &rounds, false, &part, nullptr,
+        int r = k_fgb_hash_u32(ctx, keys, static_cast<const uint32_t *>(col), src->n, vop, xf, &hk, &hv, &hc, &Gj, &ok, &rounds, false, &part, &why,
                                preds.n >= 1 ? &pred : nullptr);
         if (!r && ok && Gj == 0) ok = false;                  // no row survives the WHERE: the generic path returns the typed empty result
         if (!r && ok) {
@@ -998,6 +1006,10 @@ int try_hash(hark_context *ctx, const hark_table *db, const PredList &preds,
     k_fgb_hash_part_free(ctx, &part);
     hark_free(ctx, accg); hark_free(ctx, cntg);
     hark_free(ctx, mask);
+    if (!rc && whole_column && db->n < ((int64_t)1 << 32)) {
+        if (ok && rounds > 0) kc.hash_rounds = (int32_t)rounds;
+        else if (!ok && (why == HARK_HASH_NOFIT_DISTINCT || why == HARK_HASH_NOFIT_SKEW)) kc.hash_rounds = -1;
+    }
     if (rc || !ok) {
         for (auto &c : res->cols) if (c.owned && c.data) hark_free(ctx, c.data);
         res->cols.clear(); res->n = 0;

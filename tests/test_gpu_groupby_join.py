@@ -399,3 +399,30 @@ def test_sort_f32_nan_and_infinities(eng, descending):
     perm = np.argsort(-rank if descending else rank, kind="stable")
     assert np.array_equal(res.column(0), rowid[perm])
     assert np.array_equal(res.column(1).view(np.uint32), key[perm].view(np.uint32))
+
+
+def test_a_rounds_hint_from_larger_tables_does_not_condemn_the_key_column(eng, oracle):
+    """the hash consumers' tables differ in size (6144 keys per bucket and round with one or two operators, 4608
+    with three), and the rounds a key column needed are remembered with the column.  ~2.7e6 distinct keys fit one round of the
+    one-operator tables (5270 per bucket) but not of the three-operator ones: the remembered R = 1 must be doubled for the
+    second statement, not answered with "unfit" -- which sent that and every later statement over the column to the sort path."""
+    rng = np.random.default_rng(5)
+    n, nd = 6_000_000, 2_700_000
+    pool = rng.choice(1 << 32, nd, replace=False).astype(np.uint32)
+    keys = pool[rng.integers(0, nd, n)]
+    vals = rng.integers(0, 1 << 20, n).astype(np.uint32)
+    db = np.stack([keys, vals], axis=1)
+    t = eng.table_from_matrix(db, np.uint32)
+    first = eng.query_groupby(t, 0, [1], [3])                              # max
+    assert eng.last_groupby_path() == "hash"
+    exp1 = oracle.query_groupby(db.astype(np.int64), 0, [1], [3])
+    assert np.array_equal(first.to_numpy(np.uint32), exp1)
+    second = eng.query_groupby(t, 0, [1, 1, 1], [2, 3, 4])                 # sum, max, min of one column: the three-operator tables
+    assert eng.last_groupby_path() == "hash", "the remembered rounds must adapt, not flip the column to the sort path"
+    exp2 = oracle.query_groupby(db.astype(np.int64), 0, [1, 1, 1], [2, 3, 4])
+    assert np.array_equal(second.to_numpy(np.uint32), exp2)
+    third = eng.query_groupby(t, 0, [1], [2])
+    assert eng.last_groupby_path() == "hash" and np.array_equal(third.to_numpy(np.uint32), oracle.query_groupby(db.astype(np.int64), 0, [1], [2]))
+    for r in (first, second, third):
+        r.free()
+    t.free()

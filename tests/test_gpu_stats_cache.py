@@ -106,3 +106,36 @@ def test_rewritten_borrowed_columns_multi_key_groupby():
     fc.drop_table("t")
     for p in ptrs:
         eng.free(p)
+
+
+def test_sql_groupby_remembers_a_key_column_the_hash_path_does_not_fit(eng):
+    """an unfiltered SQL GROUP BY over one hot sparse key overflows the hash partition (skew) and falls to the sort
+    path; the verdict now stays with the key column (the reference entry did that already), so the second statement goes to
+    the sort path directly -- same rows -- and hark_table_invalidate_stats brings the hash path back for rewritten keys.  A
+    statement WITH a WHERE neither uses nor leaves a verdict."""
+    n = 400_000
+    rng = np.random.default_rng(11)
+    hot = np.full(n, -559038737, dtype=np.int32)
+    val = rng.integers(-1000, 1000, size=n).astype(np.int32)
+    t, (pk, pv) = _borrowed(eng, [hot, val])
+    for _ in range(2):
+        r = eng.filter_groupby(t, [], 0, [("sum", 1), ("count", 0)])
+        assert eng.last_groupby_path() == "sort"
+        assert r.column(0).tolist() == [-559038737] and r.column(1).tolist() == [int(val.sum())] and r.column(2).tolist() == [n]
+        r.free()
+    keys = (rng.integers(0, 5000, size=n).astype(np.int64) * 2654435761 % (1 << 32)).astype(np.uint32).view(np.int32)
+    eng.upload(pk, keys)
+    t.invalidate_stats()
+    r = eng.filter_groupby(t, [(1, ">=", 0)], 0, [("sum", 1), ("count", 0)])          # filtered: takes the hash path, leaves no verdict
+    assert eng.last_groupby_path() == "hash"
+    keep = val >= 0
+    uk, inv = np.unique(keys[keep], return_inverse=True)
+    assert np.array_equal(r.column(0), uk) and np.array_equal(r.column(1), np.bincount(inv, weights=val[keep]).astype(np.int64))
+    r.free()
+    r = eng.filter_groupby(t, [], 0, [("sum", 1), ("count", 0)])
+    assert eng.last_groupby_path() == "hash"
+    uk, inv = np.unique(keys, return_inverse=True)
+    assert np.array_equal(r.column(0), uk) and np.array_equal(r.column(2), np.bincount(inv))
+    r.free()
+    t.free()
+    eng.free(pk); eng.free(pv)
