@@ -200,3 +200,35 @@ def test_bench_extra_configs_at_a_small_scale():
     assert cfg["REF_query_groupby_dense"]["path"] == "dense" and cfg["REF_query_groupby_hash"]["path"] == "hash"
     assert cfg["C4_join_share"]["pairs"] == cfg["C4_join_share"]["pairs_expected"]
     assert cfg["REF_join_u32"]["pairs"] == cfg["REF_join_u32"]["pairs_expected"] > 0
+
+
+def test_two_bench_ranks_on_one_gpu_measure_strong_and_weak():
+    """The N = 2 invocation with REAL kernels on both ranks (they share the box's one GPU; gloo carries the collectives, staged
+    through the host, because RCCL refuses two ranks on one device): the strong-scaling run first -- each rank a row range of
+    the SAME seeded table, counts and sums of the merged result equal to the table's -- then the weak run beside it, each with
+    its own start-up measurement.  Everything of the 8-GPU run except RCCL between devices."""
+    port = _free_port()
+    rows = 40_000_000
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HARK_DIST_BACKEND="gloo")
+        for k in ("HARK_PRODUCER_WGS", "HARK_OVERLAP", "HARK_ALLREDUCE", "HARK_FORCE_PIPELINE"):
+            env.pop(k, None)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rows", str(rows), "--groups", str(1 << 20),
+                                       "--steps", "3", "--warmup", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
+    outs = [p.communicate(timeout=900) for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[0] + o[1] for o in outs)
+    lines = [ln for ln in outs[0][0].splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")], outs
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["scaling"] == "strong"
+    c = d["config"]
+    assert c["rows_total"] == rows and c["rows_per_gpu"] == rows // 2 and c["rows_this_rank"] == rows // 2 and c["mode"] == "strong"
+    assert d["check"]["count_checksum"] is True and d["check"]["sum_checksum"] is True and d["check"]["all_rows_seen"] is True
+    assert set(c["measured_at_startup_ms_per_step"]) == {g + ", " + h for g in ("240 workgroups, pipelined", "all CUs, pipelined", "all CUs, serial") for h in ("allreduce", "rs_ag")}
+    w = d["weak"]
+    assert w["scaling"] == "weak" and w["config"]["rows_total"] == 2 * rows and w["config"]["rows_per_gpu"] == rows
+    assert w["check"]["count_checksum"] is True and w["check"]["sum_checksum"] is True and w["check"]["all_rows_seen"] is True
+    assert w["roofline"]["frac"] > 0 and d["roofline"]["frac"] > 0 and len(d["ms_per_step_by_rank"]) == 2
+    assert abs(d["value"] - rows / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"] and abs(w["value"] - 2 * rows / (w["ms_per_step"] * 1e-3)) < 1e-6 * w["value"]
+    assert "cpu_baseline" in d and d["cpu_baseline"] is None and "configs" not in d            # N > 1: no extras
