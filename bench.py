@@ -517,7 +517,16 @@ def w_sparse_gb(torch, eng, dev, scale=1.0, cols=None, G=1 << 20):
                      "groups": G}}
 
 
-WORKLOADS = {"c1": w_c1, "c2": w_c2, "refgb": w_refgb, "refgb_hash": w_refgb_hash, "join_u32": w_join_u32, "join_c4": w_join_c4, "sparse_gb": w_sparse_gb,
+def w_sparse_five(torch, eng, dev, scale=1.0):
+    """SUM, MAX, MIN, AVG of the value column + COUNT over the sparse keys of w_sparse_gb: one hash producer, ONE statistics consumer pass."""
+    w = w_sparse_gb(torch, eng, dev, scale)
+    ts, N = w["keep"][0], w["rows"]
+    five = [("sum", 2), ("max", 2), ("min", 2), ("avg", 2), ("count", 0)]
+    return {"run": lambda: eng.filter_groupby(ts, [(0, ">", 0.5)], 1, five), "bytes": lambda r: 12.0 * N + 28.0 * r.shape[0], "rows": N, "keep": w["keep"],
+            "info": {"statement": "SELECT k,SUM(v),MAX(v),MIN(v),AVG(v),COUNT(*) FROM t WHERE p>0.5 GROUP BY k -- 2^20 sparse i32 keys", "groups": w["info"]["groups"]}}
+
+
+WORKLOADS = {"sparse_five": w_sparse_five, "c1": w_c1, "c2": w_c2, "refgb": w_refgb, "refgb_hash": w_refgb_hash, "join_u32": w_join_u32, "join_c4": w_join_c4, "sparse_gb": w_sparse_gb,
              "sort20": lambda *a: w_sort(*a, bits=20), "sort32": lambda *a: w_sort(*a, bits=31), "sort64": lambda *a: w_sort(*a, bits=64)}
 
 

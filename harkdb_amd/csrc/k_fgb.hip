@@ -1401,8 +1401,9 @@ __device__ __forceinline__ uint32_t unmix32(uint32_t y)
 // ---- 16-bit tags, eight to a 16-byte group: ONE ds_read_b128 per probe -------------------------------------------------
 // (fgb_agg_hash_kernel's comment has the measurements.)  x = the low `lowbits` bits of mix32(key) = the key inside its bucket.
 // Its home group is x / D (D = identities per group = ceil(2^lowbits / groups): any group count), its tag
-// 2^15 | d << rembits | x % D where d <= maxdisp is how many groups past its home the key lives (the first group that had
-// room when it came; all before it are full of other keys, and stay so: slots only ever go from empty to occupied).
+// (d << rembits | x % D) + 1 (0 = an empty slot) where d <= maxdisp <= 3 is how many groups past its home the key lives (the
+// first group that had room when it came; all before it are full of other keys, and stay so: slots only ever go from empty to
+// occupied).  13- and 14-bit remainders leave room for d <= 3 in 16 bits.
 struct TagGroups {
     uint32_t *tagw;                                          // LDS [groups * 4]: two tags per word, 0 = empty
     uint32_t groups, D, magic, rembits, remmask, maxdisp;
@@ -1413,14 +1414,14 @@ struct TagGroups {
         magic = (uint32_t)((((uint64_t)1 << 32) + D - 1u) / D);
         rembits = 32u - (uint32_t)__clz((int)(D - 1u));      // D >= 2
         remmask = (1u << rembits) - 1u;
-        const uint32_t room = rembits < 15u ? (1u << (15u - rembits)) - 1u : 0u;
+        const uint32_t room = (65535u - D) >> rembits;        // the largest d with (d << rembits | D - 1) + 1 <= 65535
         maxdisp = room < 3u ? room : 3u;
     }
     __device__ __forceinline__ void home(uint32_t x, uint32_t &g, uint32_t &tag) const
     {
         uint32_t q = __umulhi(x, magic);                      // x / D, at most one too large (x < 2^24, D < 2^15)
         if (q * D > x) q--;
-        g = q; tag = (x - q * D) | 0x8000u;
+        g = q; tag = x - q * D + 1u;
     }
     __device__ __forceinline__ uint4 read(uint32_t g) const { return reinterpret_cast<const uint4 *>(tagw)[g]; }
     static __device__ __forceinline__ int find8(const uint4 &q, uint32_t t2)       // t2 = tag | tag << 16 (0: the first empty slot); -1: none
@@ -1438,7 +1439,7 @@ struct TagGroups {
         claimed = false;
         for (uint32_t d = 0; d <= maxdisp; d++) {
             uint32_t gg = g + d; if (gg >= groups) gg -= groups;
-            const uint32_t t = tag | (d << rembits), t2 = t | (t << 16);
+            const uint32_t t = tag + (d << rembits), t2 = t | (t << 16);
             asm volatile("" ::: "memory");                   // (the group is read NOW: other lanes' claims since the probe's read count)
             uint4 q = read(gg);
             for (int tries = 0; tries < 16; tries++) {
@@ -1458,9 +1459,9 @@ struct TagGroups {
     // the key's low bits x back from its slot and tag (emit time)
     __device__ __forceinline__ uint32_t identity(uint32_t slot, uint32_t tag) const
     {
-        const uint32_t d = (tag & 0x7FFFu) >> rembits;
+        const uint32_t v = tag - 1u, d = v >> rembits;
         uint32_t g = slot >> 3; g = g >= d ? g - d : g + groups - d;
-        return g * D + (tag & remmask);
+        return g * D + (v & remmask);
     }
 };
 
@@ -1491,10 +1492,10 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash_kernel(
     // cost more together than apart, whatever their order: pipelined and barrier-separated variants measure the same).
     // Hence 16-BIT tags, eight to a 16-byte group: a probe is ONE ds_read_b128.  mix32 is a bijection and a bucket holds the keys
     // with one value of its top bits, so the low `lowbits` bits x of mix32(key) ARE the key inside the bucket; its home group is
-    // the top 10 bits of x (1024 groups) and the tag the remaining rembits = lowbits - 10 <= 14 bits | 2^15 (occupied).  A key whose
+    // the top 10 bits of x (1024 groups) and the tag the remaining rembits = lowbits - 10 <= 14 bits + 1 (0 = empty).  A key whose
     // home group is full of other keys (2048 keys per bucket: Poisson(2) per group, > 8 in 0.024 % of the groups -- ~125 groups
     // of a 2^20-key table) lives in the first of the next groups that had room when it came, its distance d in the tag bits
-    // between the remainder and bit 15 (two bits with 512 buckets: d <= 3; a first version allowed d = 1 only and met a pair of
+    // above the remainder (d <= 3; a first version allowed d = 1 only and met a pair of
     // full neighbours in one table of seven -- a second round for a whole statement); a lookup walks the same groups, all full
     // up to the key's.  A round in which every one of them is full reports an overflow (the caller halves the keys per round).
     // A probe finds its key in the home group without a branch; anything else -- a new key, a displaced key -- takes the
@@ -1563,12 +1564,13 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash_kernel(
 
 // Statistics flavour of the hash consumer: SUM / AVG / COUNT + MIN + MAX of ONE value column from one pass over the pairs
 // (the hash counterpart of fgb_agg6_stats_kernel): an entry is a tag, a row count, a 64-bit sum slot and the smallest and
-// largest ORDER word of the raw values -- 24 bytes, 5120 entries in 640 groups of eight (120 KiB), 2560 distinct keys per
-// round and bucket (load 0.5: with groups of eight a home group is full of other keys for ~2 % of the groups; 2048 would put
-// 2^20 keys in 512 buckets exactly on the edge: a failed first round, a sample round and two rounds -- measured 4.66 ms
-// against 4.0 ms for three separate passes).
+// largest ORDER word of the raw values; 2560 distinct keys per round and bucket (2048 would put 2^20 keys in 512 buckets exactly
+// on the edge: a failed first round, a sample round and two rounds -- measured 4.66 ms against 4.0 ms for three separate
+// passes).  Rounds 3-4: 32-bit tags, 24 bytes per entry, 5120 entries in 640 groups of eight (120 KiB).
 // VK: 0 = f32 values (f64 sum), 1 = i32 (sum of the biased values, like XF_I32_ORDER), 2 = u32.
-constexpr int kHashSGroups = 640, kHashSCap = kHashSGroups * 8, kHashSFill = 2560;
+// (round 5: 16-bit tags -- TagGroups, 22 bytes per entry -- 928 groups of eight in the same 160 KiB instead of 640: 2.2 keys per group
+// for 2^20 keys in 512 buckets instead of 3.2, and one ds_read_b128 per probe.)
+constexpr int kHashSGroups = 928, kHashSCap = kHashSGroups * 8, kHashSFill = 2560;
 template <int VK>
 __global__ __launch_bounds__(1024) void fgb_agg_hash_stats_kernel(
     const uint2 *__restrict__ pbuf, const uint32_t *__restrict__ counts, uint32_t cap, int nwg, uint32_t Rmask, uint32_t r,
@@ -1577,24 +1579,22 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash_stats_kernel(
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     u64 *t_sum = reinterpret_cast<u64 *>(lds_raw);                       // [kHashSCap]
-    uint32_t *t_tag = reinterpret_cast<uint32_t *>(t_sum + kHashSCap);   // [kHashSCap] low bits of mix32(key) | 2^31, 0 = empty (16-byte aligned: groups are read as two uint4)
-    uint32_t *t_cnt = t_tag + kHashSCap, *t_min = t_cnt + kHashSCap, *t_max = t_min + kHashSCap;
+    uint32_t *t_cnt = reinterpret_cast<uint32_t *>(t_sum + kHashSCap);   // [kHashSCap]
+    uint32_t *t_min = t_cnt + kHashSCap, *t_max = t_min + kHashSCap;     // [kHashSCap] each
+    uint32_t *t_tagw = t_max + kHashSCap;                                // [kHashSCap / 2] 16-bit tags (TagGroups; 20 x 7424 bytes in: 16-byte aligned)
     __shared__ uint32_t s_used, s_emit;
     __shared__ unsigned long long s_base;
     const uint32_t b = blockIdx.x;
     const int lowbits = 33 - __ffs((int)gridDim.x);
     const uint32_t lowmask = (1u << lowbits) - 1u;
-    for (int i = threadIdx.x; i < kHashSCap; i += blockDim.x) { t_tag[i] = 0u; t_cnt[i] = 0u; t_sum[i] = 0ull; t_min[i] = 0xFFFFFFFFu; t_max[i] = 0u; }
+    for (int i = threadIdx.x; i < kHashSCap; i += blockDim.x) { t_cnt[i] = 0u; t_sum[i] = 0ull; t_min[i] = 0xFFFFFFFFu; t_max[i] = 0u; }
+    for (int i = threadIdx.x; i < kHashSCap / 2; i += blockDim.x) t_tagw[i] = 0u;
     if (threadIdx.x == 0) { s_used = 0u; s_emit = 0u; }
     __syncthreads();
     bool overflow = false;
     constexpr int kNP = 8;
-    uint4 *t_tag4 = reinterpret_cast<uint4 *>(t_tag);
-    struct Tags8 { uint4 a, b; };
-    auto load8 = [&](uint32_t g) -> Tags8 { return Tags8{t_tag4[2u * g], t_tag4[2u * g + 1u]}; };
-    auto find8 = [](const Tags8 &q, uint32_t t) -> int {
-        return q.a.x == t ? 0 : q.a.y == t ? 1 : q.a.z == t ? 2 : q.a.w == t ? 3 : q.b.x == t ? 4 : q.b.y == t ? 5 : q.b.z == t ? 6 : q.b.w == t ? 7 : -1;
-    };
+    TagGroups tg;
+    tg.init(t_tagw, (uint32_t)kHashSGroups, lowbits);
     auto hit = [&](uint32_t slot, uint32_t raw) {
         uint32_t w;
         if constexpr (VK == 0) { unsafeAtomicAdd(reinterpret_cast<double *>(&t_sum[slot]), (double)__uint_as_float(raw)); w = apply_xf(XF_F32_ORDER, raw); }
@@ -1603,41 +1603,32 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash_stats_kernel(
         atomicMin(&t_min[slot], w); atomicMax(&t_max[slot], w);
         atomicAdd(&t_cnt[slot], 1u);
     };
-    auto slow = [&](uint32_t tag, uint32_t g, Tags8 q, uint32_t raw) {       // (as in fgb_agg_hash_kernel)
-        for (uint32_t step = 0; step < 8u * (uint32_t)kHashSGroups; step++) {
-            const int at = find8(q, tag);
-            if (at >= 0) { hit(8u * g + (uint32_t)at, raw); return; }
-            const int e = find8(q, 0u);
-            if (e >= 0) {
-                if (s_used >= (uint32_t)kHashSFill) { overflow = true; return; }
-                const uint32_t old = atomicCAS(&t_tag[8u * g + (uint32_t)e], 0u, tag);
-                if (old == 0u) { atomicAdd(&s_used, 1u); hit(8u * g + (uint32_t)e, raw); return; }
-                if (old == tag) { hit(8u * g + (uint32_t)e, raw); return; }
-            } else g = g + 1u == (uint32_t)kHashSGroups ? 0u : g + 1u;
-            q = load8(g);
-        }
-        overflow = true;
+    auto slow = [&](uint32_t tag, uint32_t g, uint32_t raw) {
+        bool claimed;
+        const int slot = tg.locate(tag, g, &s_used, (uint32_t)kHashSFill, claimed);
+        if (slot >= 0) hit((uint32_t)slot, raw); else overflow = true;
     };
     auto probe = [&](const uint32_t (&key)[kNP], const uint32_t (&vb)[kNP], uint32_t live) {
-        uint32_t tag[kNP], g[kNP]; Tags8 q[kNP];
+        uint32_t tag[kNP], g[kNP]; uint4 q[kNP];
 #pragma unroll
         for (int j = 0; j < kNP; j++) {
-            const uint32_t m = key[j];                                        // the producer wrote mix32(key)
-            tag[j] = (m & lowmask) | 0x80000000u;
-            g[j] = __umulhi(m * 0x9E3779B1u, (uint32_t)kHashSGroups);        // 640 groups: not a power of two
+            tg.home(key[j] & lowmask, g[j], tag[j]);                          // the producer wrote mix32(key)
             if (Rmask && (mix32(key[j] ^ 0x9E3779B9u) & Rmask) != r) live &= ~(1u << j);
         }
 #pragma unroll
-        for (int j = 0; j < kNP; j++) q[j] = load8(g[j]);
+        for (int j = 0; j < kNP; j++) q[j] = tg.read(g[j]);
         uint32_t miss = 0;
 #pragma unroll
         for (int j = 0; j < kNP; j++) {
-            const int at = find8(q[j], tag[j]);
+            const int at = TagGroups::find8(q[j], tag[j] | (tag[j] << 16));
             if ((live >> j) & 1u) { if (at >= 0) hit(8u * g[j] + (uint32_t)at, vb[j]); else miss |= 1u << j; }
         }
-        if (__any(miss != 0u)) {
+        while (__any(miss != 0u)) {                                          // a lane's missing pairs one per pass (see fgb_agg_hash_kernel)
+            const int first = miss ? __ffs((int)miss) - 1 : -1;
+            uint32_t tj = 0u, gj = 0u, vj = 0u;
 #pragma unroll
-            for (int j = 0; j < kNP; j++) if ((miss >> j) & 1u) slow(tag[j], g[j], q[j], vb[j]);
+            for (int j = 0; j < kNP; j++) if (j == first) { tj = tag[j]; gj = g[j]; vj = vb[j]; }
+            if (miss) { slow(tj, gj, vj); miss &= miss - 1u; }
         }
     };
     walk_pair_slabs(pbuf, counts, cap, nwg, b, [&](const uint32_t (&key)[kNP], const uint32_t (&vb)[kNP], uint32_t live) -> bool {
@@ -1652,12 +1643,13 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash_stats_kernel(
     __syncthreads();
     if (threadIdx.x == 0) s_base = s_emit ? atomicAdd(out_cursor, (unsigned long long)s_emit) : 0ull;
     __syncthreads();
+    const uint16_t *t_tag16 = reinterpret_cast<const uint16_t *>(t_tagw);
     for (int i = threadIdx.x; i < kHashSCap; i += blockDim.x) {
         const uint32_t c = t_cnt[i];
         if (!c) continue;
         const unsigned long long o = s_base + pos++;
         if (o < out_cap) {
-            out_key[o] = unmix32((b << lowbits) | (t_tag[i] & lowmask));
+            out_key[o] = unmix32((b << lowbits) | tg.identity((uint32_t)i, t_tag16[i]));
             out_sum[o] = t_sum[i]; out_cnt[o] = (u64)c; out_min[o] = (u64)t_min[i]; out_max[o] = (u64)t_max[i];
         } else *err = kErrOverflow;
     }
@@ -2638,7 +2630,7 @@ int k_fgb_hash_u32(hark_context *ctx, const uint32_t *k, const uint32_t *v, int6
             if (r2) return r2;
             HIP_TRY(ctx, hipMemsetAsync(perr + 2, 0, 24, st));        // the consumers' error word and the cursor; the producer's word stays
             if (stats) {
-                const size_t lds_s = (size_t)kHashSCap * 24;
+                const size_t lds_s = (size_t)kHashSCap * 22;          // sum 8 + count, smallest, largest 4 each + a 2-byte tag
                 auto go = [&](auto vkc) -> int {
                     constexpr int VK = decltype(vkc)::value;
                     HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_agg_hash_stats_kernel<VK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));

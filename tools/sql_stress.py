@@ -83,6 +83,16 @@ while time.time() < t_end and bad is None:
                     ok_all = ok_all and np.allclose(got.astype(np.float64), e.astype(np.float64), rtol=2e-6, atol=1e-6)
                 else:
                     ok_all = ok_all and np.array_equal(got.astype(np.int64), e.astype(np.int64))
+            # ... and the reference's return shape: sql() builds ONE matrix on the device wherever the result is a device result as it
+            # stands (round 5); element for element and in dtype it must be the typed columns interleaved by numpy
+            if ok_all and cols_out and rng.random() < 0.5:
+                dts = {c.dtype for c in cols_out}
+                dt = dts.pop() if len(dts) == 1 else np.result_type(*[c.dtype for c in cols_out])
+                want = np.empty((len(cols_out[0]), len(cols_out)), dtype=dt)
+                for j, c in enumerate(cols_out):
+                    want[:, j] = c
+                m = fc.sql(stmt)
+                ok_all = m.dtype == want.dtype and m.shape == want.shape and np.array_equal(m, want, equal_nan=True)
             cases += 1
             if not ok_all:
                 bad = (n, stmt)
