@@ -778,21 +778,42 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
         }
     };
 
-    // two batches of loads stay in flight per lane while a batch is enqueued and flushed
-    // (one call site of `process`: the register sets rotate, the body is not duplicated)
+    // two batches of loads stay in flight per lane while a batch is enqueued and flushed.  The loop only ever sees FULL batches,
+    // whose loads are three (two, one) unconditional vector loads per lane: the ragged last batch of a chunk -- conditional
+    // scalar loads, a number the compiler cannot count -- is peeled out of the loop (inside it, the merge of the two paths made the
+    // compiler drain vmcnt right after the prefetch in the no-predicate instantiation: nothing in flight while a batch was processed).
+    const int64_t nfullb = (row1 - row0) / kBatchRows;                 // batches 0 .. nfullb - 1 are full; batch nfullb, if it exists, is the ragged one
+    auto load_full = [&](int64_t batch, float4 &pr, int4 &kr, float4 &vr) {
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        typedef int i4v __attribute__((ext_vector_type(4)));
+        const int64_t r = row0 + batch * kBatchRows + (int64_t)tid * kVec;
+        if (OP == kMaskPred) {
+            const uint32_t byte = reinterpret_cast<const uint8_t *>(p)[r >> 3];
+            pr = float4{__uint_as_float((byte >> (r & 4)) & 15u), 0, 0, 0};
+        }
+        else if (OP != kNoPred) { const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(p + r)); pr = float4{t.x, t.y, t.z, t.w}; }
+        else pr = float4{0, 0, 0, 0};
+        const i4v tk = __builtin_nontemporal_load(reinterpret_cast<const i4v *>(k + r)); kr = int4{tk.x, tk.y, tk.z, tk.w};
+        if (K2) vr = float4{0, 0, 0, 0};
+        else { const f4v tv = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(v + r)); vr = float4{tv.x, tv.y, tv.z, tv.w}; }
+    };
     float4 pA, vA, pB, vB; int4 kA, kB;
     int64_t idA = wg, idB = (int64_t)wg + nwg;                        // the batches whose rows sit in the A and B registers
-    if (idA < nbatch) load(idA, pA, kA, vA);
-    if (idB < nbatch) load(idB, pB, kB, vB);
-    for (int j = 0; idA < nbatch; j++) {
+    if (idA < nfullb) load_full(idA, pA, kA, vA);
+    if (idB < nfullb) load_full(idB, pB, kB, vB);
+    for (int j = 0; idA < nfullb; j++) {
         const int64_t batch = idA;
         const float4 pr = pA, vr = vA; const int4 kr = kA;
         pA = pB; vA = vB; kA = kB;
         idA = idB;
         idB = seq.to_load(j);                                           // parked at least one barrier ago
         if (tid == 0) seq.draw(j);
-        if (idB < nbatch) load(idB, pB, kB, vB);
+        if (idB < nfullb) load_full(idB, pB, kB, vB);
         process(batch, pr, kr, vr, ++since_sweep >= period || idA >= nbatch);   // sweep every period-th batch and on the workgroup's last one
+    }
+    if (idA < nbatch) {                                                 // the ragged batch (ids ascend: it is this workgroup's last)
+        load(idA, pA, kA, vA);
+        process(idA, pA, kA, vA, true);
     }
     // ---- final flush: what is left (< kLine pairs per bucket) goes out as one partial line
     for (int b = tid; b < P; b += kPartThreads) {
@@ -1121,19 +1142,23 @@ __global__ __launch_bounds__(kPartThreads) void fgb_partv_kernel(
     __syncthreads();
 
     struct Rows { float4 p; int4 k; uint4 v[NV]; };
+    auto load_full = [&](int64_t batch, Rows &r) {                        // a batch of kBatchRows rows: unconditional vector loads
+        const int64_t rb = row0 + batch * kBatchRows;                      // workgroup-uniform
+        const uint32_t lo = (uint32_t)tid * kVec;
+        if (OP == kMaskPred) {
+            const uint32_t byte = (reinterpret_cast<const uint8_t *>(p) + (rb >> 3))[lo >> 3];
+            r.p = float4{__uint_as_float((byte >> (lo & 4u)) & 15u), 0, 0, 0};
+        } else if (OP != kNoPred) { const uint4 t = ld_nt16(p + rb + lo); r.p = float4{__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w)}; }
+        else r.p = float4{0, 0, 0, 0};
+        const uint4 tk = ld_nt16(k + rb + lo); r.k = int4{(int)tk.x, (int)tk.y, (int)tk.z, (int)tk.w};
+        r.v[0] = ld_nt16(v1 + rb + lo); r.v[1] = ld_nt16(v2 + rb + lo);
+        if constexpr (NV == 3) r.v[2] = ld_nt16(v3 + rb + lo);
+    };
     auto load = [&](int64_t batch, Rows &r) {
         const int64_t rb = row0 + batch * kBatchRows;                      // workgroup-uniform
         const uint32_t lo = (uint32_t)tid * kVec;
-        if (rb + kBatchRows <= row1) {
-            if (OP == kMaskPred) {
-                const uint32_t byte = (reinterpret_cast<const uint8_t *>(p) + (rb >> 3))[lo >> 3];
-                r.p = float4{__uint_as_float((byte >> (lo & 4u)) & 15u), 0, 0, 0};
-            } else if (OP != kNoPred) { const uint4 t = ld_nt16(p + rb + lo); r.p = float4{__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w)}; }
-            else r.p = float4{0, 0, 0, 0};
-            const uint4 tk = ld_nt16(k + rb + lo); r.k = int4{(int)tk.x, (int)tk.y, (int)tk.z, (int)tk.w};
-            r.v[0] = ld_nt16(v1 + rb + lo); r.v[1] = ld_nt16(v2 + rb + lo);
-            if constexpr (NV == 3) r.v[2] = ld_nt16(v3 + rb + lo);
-        } else {                                                           // ragged end of the table
+        if (rb + kBatchRows <= row1) load_full(batch, r);
+        else {                                                             // ragged end of the table
             const int64_t r0 = rb + lo;
             float pp[4] = {0, 0, 0, 0}; int kk[4] = {0, 0, 0, 0}; uint32_t vv[NV][4] = {};
             for (int j = 0; j < kVec; j++) if (r0 + j < row1) {
@@ -1226,19 +1251,26 @@ __global__ __launch_bounds__(kPartThreads) void fgb_partv_kernel(
         } while (again);
     };
 
+    // (as in fgb_part_kernel: the loop sees full batches only -- unconditional vector loads the compiler can count --, the ragged
+    // last batch of a chunk is peeled out)
+    const int64_t nfullb = (row1 - row0) / kBatchRows;
     Rows A, B;
     int64_t idA = wg, idB = (int64_t)wg + nwg;
-    if (idA < nbatch) load(idA, A);
-    if (idB < nbatch) load(idB, B);
-    for (int j = 0; idA < nbatch; j++) {
+    if (idA < nfullb) load_full(idA, A);
+    if (idB < nfullb) load_full(idB, B);
+    for (int j = 0; idA < nfullb; j++) {
         const int64_t batch = idA;
         const Rows cur = A;
         A = B;
         idA = idB;
         idB = seq.to_load(j);
         if (tid == 0) seq.draw(j);
-        if (idB < nbatch) load(idB, B);
+        if (idB < nfullb) load_full(idB, B);
         process(batch, cur, ++since_sweep >= period || idA >= nbatch);
+    }
+    if (idA < nbatch) {                                                 // the ragged batch (ids ascend: it is this workgroup's last)
+        load(idA, A);
+        process(idA, A, true);
     }
     // what is left (< kU10 entries per bucket) goes out as one partial unit
     for (int b = tid; b < P; b += kPartThreads) {

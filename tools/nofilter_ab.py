@@ -20,7 +20,7 @@ p, k, v = (torch.empty(N, dtype=dt, device=dev) for dt in (torch.float32, torch.
 eng.gen_columns(bench.SEED, 0, N, G, True, p.data_ptr(), k.data_ptr(), v.data_ptr())
 so, co = torch.empty(G, dtype=torch.float32, device=dev), torch.empty(G, dtype=torch.int64, device=dev)
 for rnd in range(3):
-    for name, pp, cmp in (("p = NULL", None, ">"), ("p >= 0  ", p.data_ptr(), ">="), ("p > 0.5 ", p.data_ptr(), ">")):
+    for name, pp, cmp in (("p = NULL", None, ">"), ("p >= 0  ", p.data_ptr(), ">="), ("k != NaN", k.data_ptr(), "!="), ("v != NaN", v.data_ptr(), "!="), ("p > 0.5 ", p.data_ptr(), ">")):
         kn = {"timing": 1}
         if period:
             kn["period"] = period
@@ -28,7 +28,7 @@ for rnd in range(3):
 
         def step():
             plan.reset()
-            plan.run(pp, cmp, 0.0 if cmp == ">=" else 0.5, k.data_ptr(), v.data_ptr(), N)
+            plan.run(pp, cmp, float("nan") if cmp == "!=" else 0.0 if cmp == ">=" else 0.5, k.data_ptr(), v.data_ptr(), N)   # x != NaN holds for every x: the key / value column as an always-true "predicate"
             plan.finish(so.data_ptr(), co.data_ptr())
 
         ms = bench.event_ms(torch, step, warm=2, reps=7)
