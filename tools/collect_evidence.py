@@ -58,11 +58,11 @@ print(json.dumps({k: v["hbm_bytes_per_launch_corrected"] for k, v in out["kernel
 
 # bytes per kernel of the operator workloads (tools/op_one.py under --pmc, one counter per run)
 ALG = {"join_c4": 12.0 * (1.25e8 + 1.25e7) + 8.0 * 6.25e7, "join_u32": 12.0 * 1.1e8, "sort20": 16e8, "sort32": 16e8, "sort64": 24e8,
-       "sparse_gb": 12e9 + 16.0 * (1 << 20)}
+       "sparse_gb": 12e9 + 16.0 * (1 << 20), "sparse_five": 12e9 + 28.0 * (1 << 20), "refgb_hash": 12e8}
 with open(os.path.join(dst, f"{tag}_op_traffic.txt"), "w") as fo:
     fo.write(f"# HBM bytes per kernel of one repetition of each operator workload (tools/op_one.py W under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,\n"
              f"# one counter per run; tools/opmc.py).  run: {run_id.splitlines()[0]}, git {out['git']}\n")
-    for w in ("join_c4", "join_u32", "sort20", "sort32", "sort64", "sparse_gb"):
+    for w in ("join_c4", "join_u32", "sort20", "sort32", "sort64", "sparse_gb", "sparse_five", "refgb_hash"):
         df, dw = os.path.join(src, f"opmc_{w}_FETCH_SIZE"), os.path.join(src, f"opmc_{w}_WRITE_SIZE")
         if not (os.path.isdir(df) and os.path.isdir(dw)):
             fo.write(f"\n== {w}: not collected\n")
@@ -72,6 +72,12 @@ with open(os.path.join(dst, f"{tag}_op_traffic.txt"), "w") as fo:
         logs = "".join(ln for ln in open(logf) if ln.startswith(w + ":")) if os.path.exists(logf) else ""
         fo.write(f"\n== {w}\n{logs}{r.stdout}{r.stderr}")
 print(open(os.path.join(dst, f"{tag}_op_traffic.txt")).read())
+# round 5's probe outputs of the same run
+for name, out in (("hashlds.txt", "hashlds.txt"), ("widedigit.txt", "widedigit.txt"), ("nofilter_ab.txt", "nofilter_ab.txt"), ("ingest_bench.log", "ingest_bench.log"),
+                  ("strong_rehearsal.txt", "strong_rehearsal.txt"), ("hash_pmc_after.txt", "hash_pmc_after.txt")):
+    f = only(name, required=False)
+    if f:
+        shutil.copy(f, os.path.join(dst, f"{tag}_{out}"))
 # ... and the same kernels against the plain-stream floor of their bytes (tools/floor_table.py)
 ft = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "floor_table.py"), os.path.join(dst, f"{tag}_op_traffic.txt")], capture_output=True, text=True)
 open(os.path.join(dst, f"{tag}_floor_table.md"), "w").write(ft.stdout)

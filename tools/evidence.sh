@@ -28,11 +28,19 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_con
 timeout 600 python tools/ops_bench.py > $O/ops_bench.log 2>&1
 timeout 300 python tools/c5_bench.py > $O/c5_bench.log 2>&1
 # bytes moved per kernel of the operators furthest from their roofline (one counter per run)
-for w in join_c4 join_u32 sort20 sort32 sort64 sparse_gb; do
+for w in join_c4 join_u32 sort20 sort32 sort64 sparse_gb sparse_five refgb_hash; do
   for c in FETCH_SIZE WRITE_SIZE; do
     timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/opmc_${w}_$c -- python3 tools/op_one.py $w > $O/opmc_${w}_$c.log 2>&1
   done
 done
+# round 5: the probes behind the notes (LDS side of a hash probe, wide radix digits, no-filter A/B, host transfers, what one
+# rank of a strong-scaling run does) and the LDS counters of the hash consumers as they are now
+timeout 120 tools/hashlds > $O/hashlds.txt 2>&1
+timeout 240 tools/widedigit > $O/widedigit.txt 2>&1
+timeout 200 python tools/nofilter_ab.py > $O/nofilter_ab.txt 2>&1
+timeout 200 python tools/ingest_bench.py > $O/ingest_bench.log 2>&1
+timeout 300 bash tools/strong_rehearsal.sh > $O/strong_rehearsal.txt 2>&1
+timeout 600 bash tools/pmc_hash.sh 0.5 > $O/pmc_hash.log 2>&1; cp gpurun_out/pmc_hash/summary.txt $O/hash_pmc_after.txt
 find $O -name "*kernel_trace.csv" -size +20M -delete
 ls -R $O | head -80
 cat $O/bench_plain.json
