@@ -207,6 +207,13 @@ class _FakeResult:
     def columns(self):
         return [np.zeros(1, dtype=np.int32) for _ in range(self.ncols)]
 
+    @property
+    def shape(self):
+        return 1, self.ncols
+
+    def matrix(self, cols=None, limit=None, dtype=None):               # sql() asks the device result for the reference's matrix (from_futhark)
+        return np.zeros((1, self.ncols if cols is None else len(cols)), dtype=dtype or np.int32)
+
 
 class _RecordingEngine:
     """Stands where Engine (ctypes -> libhark.so) stands; notes the entry calls FutharkContext.sql() makes."""
