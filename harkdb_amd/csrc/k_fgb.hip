@@ -2633,9 +2633,9 @@ int k_fgb_hash_u32(hark_context *ctx, const uint32_t *k, const uint32_t *v, int6
     };
     uint32_t used_R = 1;
     HIP_TRY_RC(ctx, rc, hipMemsetAsync(perr, 0, 32, st));
-    if (!rc && !reuse) {
+    auto launch_producer = [&]() -> int {
         const size_t lds_part = part_lds_bytes(P, 0);
-        rc = dispatch_op(pcmp, pp != nullptr, [&](auto op) -> int {
+        return dispatch_op(pcmp, pp != nullptr, [&](auto op) -> int {
             constexpr int OP = decltype(op)::value;
             HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_part_kernel<OP, 2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part));
             fgb_part_kernel<OP, 2, 0><<<dim3((unsigned)nwg), dim3(kPartThreads), lds_part, st>>>(
@@ -2644,9 +2644,10 @@ int k_fgb_hash_u32(hark_context *ctx, const uint32_t *k, const uint32_t *v, int6
             HIP_TRY(ctx, hipGetLastError());
             return HARK_OK;
         });
-        // (the producer's error word is read together with the first aggregation's: a slab or ring overflow -- skewed keys --
-        // costs one wasted consumer pass on the way to the sort-based path instead of a round trip on every call)
-    }
+    };
+    // (the producer's error word is read together with the first aggregation's: a slab or ring overflow -- skewed keys --
+    // costs one wasted consumer pass on the way to the sort-based path instead of a round trip on every call)
+    if (!rc && !reuse) rc = launch_producer();
     if (!rc) {
         const size_t lds_hash = (size_t)kHashCap * 14;                 // 8-byte value slot + 4-byte count + 2-byte tag per entry
         // run all rounds of an R-round aggregation; e != 0 afterwards means some table overflowed
@@ -2714,7 +2715,17 @@ int k_fgb_hash_u32(hark_context *ctx, const uint32_t *k, const uint32_t *v, int6
         constexpr uint32_t kMaxRoundsWorth = 16;
         used_R = hint ? hint : 1u;
         rc = run_rounds(used_R, 0, used_R);
-        if (!rc && e_prod != 0 && why_not) *why_not = HARK_HASH_NOFIT_SKEW;            // a slab or a ring overflowed: the keys are skewed
+        if (!rc && e_prod != 0 && !reuse) {
+            // A slab overflowed.  Skewed keys do that -- and so does the FIRST pass over freshly allocated slabs: the workgroups
+            // that fault the new pages in fall behind, the others draw their batches (first come, first served) and fill
+            // slabs sized for 1.3 x an even share of the table's rows.  Found in round 5: the first sparse-key statement of every
+            // process ran producer + consumer + the whole sort path (46 ms per 1e9 rows against 4 ms from the second on).
+            // The pages are mapped now: once more, and only a second overflow says "skew".
+            HIP_TRY_RC(ctx, rc, hipMemsetAsync(perr, 0, 32, st));
+            if (!rc) rc = launch_producer();
+            if (!rc) rc = run_rounds(used_R, 0, used_R);
+        }
+        if (!rc && e_prod != 0 && why_not) *why_not = HARK_HASH_NOFIT_SKEW;            // a slab or a ring overflowed (twice): the keys are skewed
         // a hint is the R that ANOTHER pass over this key column needed, and the consumers' tables differ in size (6144 keys per
         // bucket and round with one or two operators, 4608 with three, 3072 typed, 2560 statistics): a hinted R that overflows
         // is doubled until it fits, instead of declaring the column unfit for the hash path for good

@@ -21,8 +21,15 @@ run_id = open(only("run_id.txt")).read()
 for name, out in (("bench_plain.json", "bench_latest.json"), ("bench_rocprof.json", "bench_under_rocprof.json"),
                   ("bench_configs_rocprof.json", "bench_configs_under_rocprof.json"), ("ops_bench.log", "ops_bench.log"), ("c5_bench.log", "c5_bench.log")):
     shutil.copy(only(name), os.path.join(dst, f"{tag}_{out}"))
-for pat, out in (("stats/**/*kernel_stats.csv", "bench_kernel_stats.csv"), ("stats_configs/**/*kernel_stats.csv", "configs_kernel_stats.csv")):
-    shutil.copy(only(pat), os.path.join(dst, f"{tag}_{out}"))
+shutil.copy(only("stats/**/*kernel_stats.csv"), os.path.join(dst, f"{tag}_bench_kernel_stats.csv"))
+# round 5: bench.py measures the extra configs in a CHILD process, which the profiler follows: the run with configs leaves one
+# statistics file per process -- the parent's (headline kernels only) and the child's (every operator pipeline): the one with
+# the join's kernels in it is the configs file
+cands = glob.glob(os.path.join(src, "stats_configs/**/*kernel_stats.csv"), recursive=True)
+with_join = [f for f in cands if "jpart_kernel" in open(f).read()]
+if len(with_join) != 1 or len(cands) > 2:
+    raise SystemExit(f"stats_configs: {len(cands)} kernel statistics files, {len(with_join)} of them with the join's kernels (want 1 or 2 files, exactly one with)")
+shutil.copy(with_join[0], os.path.join(dst, f"{tag}_configs_kernel_stats.csv"))
 
 child = json.loads(open(only("pmc_fetch.json")).read().strip().splitlines()[-1])
 assert child.get("pmc_child") is True, "the PMC passes must run bench.py --pmc-child 1 (no setup launch)"

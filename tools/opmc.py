@@ -44,7 +44,12 @@ def main():
     fetch, write = rows_of(sys.argv[1], "FETCH_SIZE"), rows_of(sys.argv[2], "WRITE_SIZE")
     alg = float(sys.argv[3]) if len(sys.argv) > 3 else None
     reps = int(sys.argv[4]) if len(sys.argv) > 4 else 3                       # how often op_one.py ran the statement (its default)
-    kf, kw = last_period([r["name"] for r in fetch], reps), last_period([r["name"] for r in write], reps)
+    def one_repetition(rows):
+        """Dispatches behind the last marker (op_one.py launches gen_columns_kernel in front of every repetition); traces without a
+        marker fall back to the repeating tail."""
+        marks = [i for i, r in enumerate(rows) if "gen_columns_kernel" in r["name"]]
+        return len(rows) - 1 - marks[-1] if marks else last_period([r["name"] for r in rows], reps)
+    kf, kw = one_repetition(fetch), one_repetition(write)
     if kf != kw or [r["name"] for r in fetch[-kf:]] != [r["name"] for r in write[-kw:]]:
         raise SystemExit(f"the two runs do not end in the same kernel sequence (periods {kf} / {kw})")
     acc = collections.OrderedDict()
