@@ -1367,14 +1367,24 @@ template <typename F>
 __device__ __forceinline__ void walk_pair_slabs(const uint2 *__restrict__ pbuf, const uint32_t *__restrict__ counts, uint32_t cap, int nwg, uint32_t b, F &&f)
 {
     typedef unsigned int u4v __attribute__((ext_vector_type(4)));
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    // Round 5.  Rounds 3-4 walked with two register sets in turn so that the next step's loads would be in flight while a step
+    // is probed -- and the generated code drained vmcnt(0) at the loop header, BEFORE every step: with the wave number a per-lane
+    // value to the compiler every `break` was a divergent branch, the loads sat under exec masks, and it could not count them
+    // (found by scanning the generated code for drains right behind loads, after the partition producer's no-predicate
+    // instantiation had shown the same disease).  Now: the cursor is a SCALAR (the wave number through readfirstlane, the slabs'
+    // counts through readlane: uniform branches, unconditional loads) and the walk is the producer's pattern -- take the arrived
+    // step out of its registers, issue the next step's loads into them, probe: the wait at the top of an iteration is for
+    // loads a whole step old, and one step's loads (4 KiB per wave) are in flight during every probe.  (Loads issued from
+    // inline assembly with hand-placed waits were tried first and refused by tools/check_hidden_loads.py: the register
+    // allocator copied in-flight registers at the loop's back-edge.)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nwaves = blockDim.x >> 6;
     const int nslab = wave < nwg ? (nwg - wave + nwaves - 1) / nwaves : 0;          // <= 64 (at most 1024 partition workgroups)
     const uint32_t mycount = lane < nslab ? min(counts[(size_t)b * nwg + wave + lane * nwaves], cap) : 0u;
     struct Cursor { int j; uint32_t i0, n2, count; };
     auto seek = [&](Cursor &c) {                                          // the first step at or after c that has pairs
         while (c.j < nslab && c.i0 >= c.n2) {
             c.j++; c.i0 = 0u;
-            c.count = c.j < nslab ? (uint32_t)__shfl((int)mycount, c.j, 64) : 0u;
+            c.count = c.j < nslab ? (uint32_t)__builtin_amdgcn_readlane((int)mycount, __builtin_amdgcn_readfirstlane(c.j)) : 0u;
             c.n2 = (c.count + 1u) / 2u;                                   // 16-byte pieces (cap is even: the last piece exists)
         }
     };
@@ -1395,18 +1405,16 @@ __device__ __forceinline__ void walk_pair_slabs(const uint2 *__restrict__ pbuf, 
         }
         return f(key, vb, live);
     };
-    Cursor cA{-1, 0u, 0u, 0u};
-    seek(cA);
-    Cursor cB = cA; cB.i0 += 256u; seek(cB);
-    u4v a[4], bq[4];
-    fetch(cA, a); fetch(cB, bq);
-    for (;;) {                                                            // two register sets in turn, no copies between them
-        if (cA.j >= nslab) break;
-        if (!step(a, cA)) break;
-        cA = cB; cA.i0 += 256u; seek(cA); fetch(cA, a);
-        if (cB.j >= nslab) break;
-        if (!step(bq, cB)) break;
-        cB = cA; cB.i0 += 256u; seek(cB); fetch(cB, bq);
+    Cursor c{-1, 0u, 0u, 0u};
+    seek(c);
+    u4v nx[4];
+    fetch(c, nx);
+    while (c.j < nslab) {
+        const Cursor cur = c;
+        const u4v q[4] = {nx[0], nx[1], nx[2], nx[3]};                    // the step that has arrived
+        c.i0 += 256u; seek(c);
+        fetch(c, nx);                                                     // ... and the next one, in flight while this one is probed
+        if (!step(q, cur)) break;
     }
 }
 
