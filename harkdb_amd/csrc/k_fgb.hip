@@ -1368,15 +1368,16 @@ __device__ __forceinline__ void walk_pair_slabs(const uint2 *__restrict__ pbuf, 
 {
     typedef unsigned int u4v __attribute__((ext_vector_type(4)));
     // Round 5.  Rounds 3-4 walked with two register sets in turn so that the next step's loads would be in flight while a step
-    // is probed -- and the generated code drained vmcnt(0) at the loop header, BEFORE every step: with the wave number a per-lane
-    // value to the compiler every `break` was a divergent branch, the loads sat under exec masks, and it could not count them
-    // (found by scanning the generated code for drains right behind loads, after the partition producer's no-predicate
-    // instantiation had shown the same disease).  Now: the cursor is a SCALAR (the wave number through readfirstlane, the slabs'
-    // counts through readlane: uniform branches, unconditional loads) and the walk is the producer's pattern -- take the arrived
-    // step out of its registers, issue the next step's loads into them, probe: the wait at the top of an iteration is for
-    // loads a whole step old, and one step's loads (4 KiB per wave) are in flight during every probe.  (Loads issued from
-    // inline assembly with hand-placed waits were tried first and refused by tools/check_hidden_loads.py: the register
-    // allocator copied in-flight registers at the loop's back-edge.)
+    // is probed -- and the generated code drained vmcnt(0) at the loop header, before every step (with the wave number a per-lane
+    // value to the compiler every `break` was a divergent branch and the loads sat under exec masks it could not count; found by
+    // scanning the generated code for drains right behind loads, after the partition producer's no-predicate instantiation had
+    // shown the same disease).  Now the cursor is a SCALAR (the wave number through readfirstlane, the slabs' counts through
+    // readlane) and the walk is the producer's pattern: take the arrived step out of its registers, issue the next step's loads,
+    // probe.  Interleaved on one box the two walks run the hash consumers at the same speed (4.0-4.1 ms per sparse statement,
+    // 0.91 ms for the reference entry, either way): 16 waves per CU hide a wave's load latency already and the kernels wait for
+    // the LDS -- kept because it is the simpler code and says what it does.  (Loads from inline assembly with hand-placed waits
+    // were tried first and refused by tools/check_hidden_loads.py: the register allocator copied in-flight registers at the
+    // loop's back-edge.)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nwaves = blockDim.x >> 6;
     const int nslab = wave < nwg ? (nwg - wave + nwaves - 1) / nwaves : 0;          // <= 64 (at most 1024 partition workgroups)
     const uint32_t mycount = lane < nslab ? min(counts[(size_t)b * nwg + wave + lane * nwaves], cap) : 0u;
