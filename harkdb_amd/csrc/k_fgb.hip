@@ -1362,7 +1362,8 @@ __global__ __launch_bounds__(1024) void fgb_aggv_kernel(
 // boundaries too (the slabs' counts sit in the lanes of the wave).  The hash consumers' probes start with dependent LDS
 // reads: with the loads issued only at the top of a step the kernels ran at the latency of a global load (2.1 TB/s on 30-KB
 // slabs: 64 KB in flight per CU at best, nothing in flight while a step is probed), whatever was done to the probes
-// themselves.  f(keys[8], values[8], live mask) -> false stops the walk (a table overflowed).
+// themselves.  f(keys[8], values[8], live mask, full) -> false stops the walk (a table overflowed); full (wave-uniform):
+// every pair of the step exists.
 template <typename F>
 __device__ __forceinline__ void walk_pair_slabs(const uint2 *__restrict__ pbuf, const uint32_t *__restrict__ counts, uint32_t cap, int nwg, uint32_t b, F &&f)
 {
@@ -1396,15 +1397,20 @@ __device__ __forceinline__ void walk_pair_slabs(const uint2 *__restrict__ pbuf, 
         for (int k = 0; k < 4; k++) { const uint32_t i = c.i0 + 64u * k + lane; q[k] = __builtin_nontemporal_load(src4 + ((live && i < c.n2) ? i : 0u)); }
     };
     auto step = [&](const u4v (&q)[4], const Cursor &c) -> bool {
-        uint32_t key[8], vb[8], live = 0;
+        uint32_t key[8], vb[8], live = 0xFFu;
+        const bool full = 2u * c.i0 + 512u <= c.count;                    // (scalar) every pair of the step exists: all but a slab's last step
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t i = c.i0 + 64u * k + lane;
-            key[2 * k] = q[k].x; vb[2 * k] = q[k].y; key[2 * k + 1] = q[k].z; vb[2 * k + 1] = q[k].w;
-            if (2u * i < c.count) live |= 1u << (2 * k);
-            if (2u * i + 1u < c.count) live |= 1u << (2 * k + 1);
+        for (int k = 0; k < 4; k++) { key[2 * k] = q[k].x; vb[2 * k] = q[k].y; key[2 * k + 1] = q[k].z; vb[2 * k + 1] = q[k].w; }
+        if (!full) {
+            live = 0u;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t i = c.i0 + 64u * k + lane;
+                if (2u * i < c.count) live |= 1u << (2 * k);
+                if (2u * i + 1u < c.count) live |= 1u << (2 * k + 1);
+            }
         }
-        return f(key, vb, live);
+        return f(key, vb, live, full);
     };
     Cursor c{-1, 0u, 0u, 0u};
     seek(c);
@@ -1440,71 +1446,121 @@ __device__ __forceinline__ uint32_t unmix32(uint32_t y)
 }
 
 // ---- 16-bit tags, eight to a 16-byte group: ONE ds_read_b128 per probe -------------------------------------------------
-// (fgb_agg_hash_kernel's comment has the measurements.)  x = the low `lowbits` bits of mix32(key) = the key inside its bucket.
-// Its home group is x / D (D = identities per group = ceil(2^lowbits / groups): any group count), its tag
-// (d << rembits | x % D) + 1 (0 = an empty slot) where d <= maxdisp <= 3 is how many groups past its home the key lives (the
-// first group that had room when it came; all before it are full of other keys, and stay so: slots only ever go from empty to
-// occupied).  13- and 14-bit remainders leave room for d <= 3 in 16 bits.
+// (fgb_agg_hash_kernel's comment has the measurements.)  x = the low `lowbits` (<= 24) bits of mix32(key) = the key inside its
+// bucket.  Its home group is g = x * groups >> lowbits (any group count; two 24-bit multiplies and a funnel shift -- a first
+// version divided by the identities per group: umulhi, two 32-bit multiplies and a correction per pair), its remainder
+// tv = bits [shift, lowbits) of the product's low part, where 2^shift <= groups: inside a group the product steps by `groups`
+// from key to key, so no two keys of a group share a tv.  A slot holds d << rembits | tv, d <= maxdisp <= 3 = how many groups
+// past its home the key lives (the first group that had room when it came; all before it are full of other keys, and stay
+// so: slots only ever go from empty to occupied); 0xFFFF = an empty slot (the one tag that spells 0xFFFF is never stored: its
+// key overflows one group early).  Slot s of a group is half s >> 2 of word s & 3 (what the branch-free search hands back).
 struct TagGroups {
-    uint32_t *tagw;                                          // LDS [groups * 4]: two tags per word, 0 = empty
-    uint32_t groups, D, magic, rembits, remmask, maxdisp;
-    __device__ __forceinline__ void init(uint32_t *lds_words, uint32_t ngroups, int lowbits)
+    uint32_t *tagw;                                          // LDS [groups * 4]: two tags per word, 0xFFFF = empty
+    uint32_t groups, lowbits, shift, rembits, maxdisp;
+    static constexpr uint32_t kEmpty2 = 0xFFFFFFFFu;
+    __device__ __forceinline__ void init(uint32_t *lds_words, uint32_t ngroups, int lowbits_)
     {
-        tagw = lds_words; groups = ngroups;
-        D = ((1u << lowbits) + ngroups - 1u) / ngroups;
-        magic = (uint32_t)((((uint64_t)1 << 32) + D - 1u) / D);
-        rembits = 32u - (uint32_t)__clz((int)(D - 1u));      // D >= 2
-        remmask = (1u << rembits) - 1u;
-        const uint32_t room = (65535u - D) >> rembits;        // the largest d with (d << rembits | D - 1) + 1 <= 65535
+        tagw = lds_words; groups = ngroups; lowbits = (uint32_t)lowbits_;
+        shift = 31u - (uint32_t)__clz((int)ngroups);         // groups >= 512 and lowbits <= 24: rembits <= 15
+        rembits = lowbits - shift;
+        const uint32_t room = (1u << (16u - rembits)) - 1u;
         maxdisp = room < 3u ? room : 3u;
     }
-    __device__ __forceinline__ void home(uint32_t x, uint32_t &g, uint32_t &tag) const
+    // group and tv * 0x10001 (the tag of a key at home, in both halves of a word)
+    __device__ __forceinline__ void home(uint32_t x, uint32_t &g, uint32_t &t2) const
     {
-        uint32_t q = __umulhi(x, magic);                      // x / D, at most one too large (x < 2^24, D < 2^15)
-        if (q * D > x) q--;
-        g = q; tag = x - q * D + 1u;
+        const u64 pr = (u64)(x & 0xFFFFFFu) * (u64)(groups & 0xFFFFFFu);        // v_mul_u32_u24 + v_mul_hi_u32_u24
+        const uint32_t lo = (uint32_t)pr, hi = (uint32_t)(pr >> 32);
+        g = __builtin_amdgcn_alignbit(hi, lo, lowbits);
+        t2 = __builtin_amdgcn_ubfe(lo, shift, rembits) * 0x10001u;
     }
     __device__ __forceinline__ uint4 read(uint32_t g) const { return reinterpret_cast<const uint4 *>(tagw)[g]; }
-    static __device__ __forceinline__ int find8(const uint4 &q, uint32_t t2)       // t2 = tag | tag << 16 (0: the first empty slot); -1: none
+    // Where in a group is the tag of t2's halves?  A code p: bit (p & 3) = the word, p >> 4 = the half; -1: nowhere.  Branch-free:
+    // v_pk_min_u16(x, 1) is 1 per non-zero half (the compiler turns the same thing written in C into compares and selects:
+    // inline assembly), the four words' indicators are packed into one, inverted, and the lowest set bit is the slot --
+    // 14 instructions where the chain of compares took ~30 and four levels of divergent branches per pair.
+    static __device__ __forceinline__ uint32_t nz16(uint32_t x) { uint32_t r; asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(x), "s"(0x00010001u)); return r; }
+    static __device__ __forceinline__ int find8(const uint4 &q, uint32_t t2)
     {
-        const uint32_t x0 = q.x ^ t2, x1 = q.y ^ t2, x2 = q.z ^ t2, x3 = q.w ^ t2;
-        return !(x0 & 0xFFFFu) ? 0 : !(x0 >> 16) ? 1 : !(x1 & 0xFFFFu) ? 2 : !(x1 >> 16) ? 3 : !(x2 & 0xFFFFu) ? 4 : !(x2 >> 16) ? 5 : !(x3 & 0xFFFFu) ? 6 : !(x3 >> 16) ? 7 : -1;
+        const uint32_t n = nz16(q.x ^ t2) | (nz16(q.y ^ t2) << 1) | (nz16(q.z ^ t2) << 2) | (nz16(q.w ^ t2) << 3);
+        int p; asm("v_ffbl_b32 %0, %1" : "=v"(p) : "v"(n ^ 0x000F000Fu));   // -1 when no bit is set
+        return p;
     }
+    static __device__ __forceinline__ uint32_t slot_of(int p) { return ((uint32_t)p & 3u) | ((uint32_t)p >> 2); }   // p >= 0: p >> 2 is 0 or 4
     // The slot of a key that its home group's read did not show: found further on, or claimed (the first empty slot of the first
     // group with room, with a compare-and-swap on the WORD that holds it; a lane that loses learns the word's new content from
     // the compare-and-swap itself and looks again, so two lanes with one key end up in one slot; a word changes at most twice:
     // <= 8 failures per group).  Returns the slot; -1: every group the key may live in is full of other keys; -2: the round's
     // budget of distinct keys (*used >= fill) is spent.  *claimed: the key is new.
-    __device__ __forceinline__ int locate(uint32_t tag, uint32_t g, uint32_t *used, uint32_t fill, bool &claimed) const
+    __device__ __forceinline__ int locate(uint32_t tv, uint32_t g, uint32_t *used, uint32_t fill, bool &claimed) const
     {
         claimed = false;
         for (uint32_t d = 0; d <= maxdisp; d++) {
             uint32_t gg = g + d; if (gg >= groups) gg -= groups;
-            const uint32_t t = tag + (d << rembits), t2 = t | (t << 16);
+            const uint32_t t = tv | (d << rembits), t2 = t * 0x10001u;
+            if (t == 0xFFFFu) break;                         // spells "empty"
             asm volatile("" ::: "memory");                   // (the group is read NOW: other lanes' claims since the probe's read count)
             uint4 q = read(gg);
             for (int tries = 0; tries < 16; tries++) {
                 const int at = find8(q, t2);
-                if (at >= 0) return (int)(8u * gg) + at;
-                const int e = find8(q, 0u);
+                if (at >= 0) return (int)(8u * gg + slot_of(at));
+                const int e = find8(q, kEmpty2);
                 if (e < 0) break;                            // full of other keys: the next group
                 if (*used >= fill) return -2;
-                const uint32_t w = (uint32_t)e >> 1, oldw = w == 0 ? q.x : w == 1 ? q.y : w == 2 ? q.z : q.w;
-                const uint32_t got = atomicCAS(&tagw[4u * gg + w], oldw, oldw | (t << (16 * (e & 1))));   // ds_cmpst_rtn_b32
-                if (got == oldw) { atomicAdd(used, 1u); claimed = true; return (int)(8u * gg) + e; }
+                const uint32_t w = (uint32_t)e & 3u, oldw = w == 0 ? q.x : w == 1 ? q.y : w == 2 ? q.z : q.w;
+                const uint32_t got = atomicCAS(&tagw[4u * gg + w], oldw, oldw ^ ((t ^ 0xFFFFu) << ((uint32_t)e & 16u)));   // ds_cmpst_rtn_b32
+                if (got == oldw) { atomicAdd(used, 1u); claimed = true; return (int)(8u * gg + slot_of(e)); }
                 if (w == 0) q.x = got; else if (w == 1) q.y = got; else if (w == 2) q.z = got; else q.w = got;
             }
         }
         return -1;
     }
-    // the key's low bits x back from its slot and tag (emit time)
+    // the tag in a slot (0xFFFF: empty)
+    __device__ __forceinline__ uint32_t tag_at(uint32_t slot) const { return (tagw[4u * (slot >> 3) + (slot & 3u)] >> (4u * (slot & 4u))) & 0xFFFFu; }
+    // the key's low bits x back from its slot and tag (emit time): the one x whose product lies in the tag's window
     __device__ __forceinline__ uint32_t identity(uint32_t slot, uint32_t tag) const
     {
-        const uint32_t v = tag - 1u, d = v >> rembits;
+        const uint32_t d = tag >> rembits, tv = tag & ((1u << rembits) - 1u);
         uint32_t g = slot >> 3; g = g >= d ? g - d : g + groups - d;
-        return g * D + (v & remmask);
+        const u64 a = ((u64)g << lowbits) | ((u64)tv << shift);
+        return (uint32_t)((a + groups - 1u) / groups);
     }
 };
+
+// One step of a hash consumer: eight pairs per lane against a TagGroups table -- the home groups' reads all in flight, then
+// hit(slot, value) for the keys they show; what they do not show (new keys, displaced keys) goes through slow(tv, group, value)
+// one pair per pass, each lane its own first (the number of passes is the LARGEST number of misses any lane has -- one, seldom
+// two -- not the number of pair positions at which some lane missed).  FULL (wave-uniform): every pair of the step is live and
+// the round takes every key, so no pair carries a predicate of its own.
+template <bool FULL, typename HIT, typename SLOW>
+__device__ __forceinline__ void tag_probe_step(const TagGroups &tg, const uint32_t (&key)[8], const uint32_t (&vb)[8], uint32_t live,
+                                               uint32_t lowmask, uint32_t Rmask, uint32_t r, HIT &&hit, SLOW &&slow)
+{
+    uint32_t t2[8], g[8]; uint4 q[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        tg.home(key[j] & lowmask, g[j], t2[j]);                               // the producer wrote mix32(key)
+        if (!FULL && Rmask && (mix32(key[j] ^ 0x9E3779B9u) & Rmask) != r) live &= ~(1u << j);   // not this round's share of the key space
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) q[j] = tg.read(g[j]);                        // eight independent 16-byte LDS reads in flight
+    uint32_t miss = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int p = TagGroups::find8(q[j], t2[j]);
+        miss |= (uint32_t)p & (0x100u << j);                                  // p = -1: every bit (a found p is below 32)
+        if (FULL ? p >= 0 : (p >= 0 && ((live >> j) & 1u))) hit(8u * g[j] + TagGroups::slot_of(p), vb[j]);
+    }
+    miss >>= 8;
+    if (!FULL) miss &= live;
+    while (__any(miss != 0u)) {
+        const int first = miss ? __ffs((int)miss) - 1 : -1;
+        uint32_t tj = 0u, gj = 0u, vj = 0u;
+#pragma unroll
+        for (int j = 0; j < 8; j++) if (j == first) { tj = t2[j] & 0xFFFFu; gj = g[j]; vj = vb[j]; }
+        if (miss) { slow(tj, gj, vj); miss &= miss - 1u; }
+    }
+}
 
 template <int VOP>
 __global__ __launch_bounds__(1024) void fgb_agg_hash_kernel(
@@ -1522,7 +1578,7 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash_kernel(
     const int lowbits = 33 - __ffs((int)gridDim.x);                      // P = gridDim.x buckets, a power of two: bucket = mix32(key) >> lowbits
     const uint32_t lowmask = (1u << lowbits) - 1u;
     for (int i = threadIdx.x; i < kHashCap; i += blockDim.x) { t_cnt[i] = 0u; t_val[i] = vop_identity(VOP); }
-    for (int i = threadIdx.x; i < kHashCap / 2; i += blockDim.x) t_tagw[i] = 0u;
+    for (int i = threadIdx.x; i < kHashCap / 2; i += blockDim.x) t_tagw[i] = TagGroups::kEmpty2;
     if (threadIdx.x == 0) { s_used = 0u; s_emit = 0u; }
     __syncthreads();
     bool overflow = false;
@@ -1546,40 +1602,14 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash_kernel(
     TagGroups tg;
     tg.init(t_tagw, kGroups, lowbits);                                   // 1024 groups: D = 2^(lowbits - 10), the division is a shift in effect
     auto hit = [&](uint32_t slot, uint32_t vbits) { vop_atomic<VOP>(&t_val[slot], VOP == VOP_F32SUM ? vbits : apply_xf(xf, vbits)); atomicAdd(&t_cnt[slot], 1u); };
-    auto slow = [&](uint32_t tag, uint32_t g, uint32_t vbits) {
+    auto slow = [&](uint32_t tv, uint32_t g, uint32_t vbits) {
         bool claimed;
-        const int slot = tg.locate(tag, g, &s_used, (uint32_t)kHashFill, claimed);
+        const int slot = tg.locate(tv, g, &s_used, (uint32_t)kHashFill, claimed);
         if (slot >= 0) hit((uint32_t)slot, vbits); else overflow = true;
     };
-    auto probe = [&](const uint32_t (&key)[kNP], const uint32_t (&vb)[kNP], uint32_t live) {
-        uint32_t tag[kNP], g[kNP]; uint4 q[kNP];
-#pragma unroll
-        for (int j = 0; j < kNP; j++) {
-            tg.home(key[j] & lowmask, g[j], tag[j]);                          // the producer wrote mix32(key)
-            if (Rmask && (mix32(key[j] ^ 0x9E3779B9u) & Rmask) != r) live &= ~(1u << j);   // not this round's share of the key space
-        }
-#pragma unroll
-        for (int j = 0; j < kNP; j++) q[j] = tg.read(g[j]);                  // kNP independent 16-byte LDS reads in flight
-        uint32_t miss = 0;
-#pragma unroll
-        for (int j = 0; j < kNP; j++) {
-            const int at = TagGroups::find8(q[j], tag[j] | (tag[j] << 16));
-            if ((live >> j) & 1u) { if (at >= 0) hit(8u * g[j] + (uint32_t)at, vb[j]); else miss |= 1u << j; }
-        }
-        // The missing pairs of a lane are taken one per pass, each lane its own first: the number of passes is the LARGEST number of
-        // misses any lane has (one, seldom two), not the number of pair positions j at which some lane missed -- with keys that come
-        // ~50 times each (the reference entry's bench line: 2 % of the pairs are first occurrences) that was six or seven of the
-        // eight positions in every step, each a divergent pass of dependent LDS round trips for a lane or two.
-        while (__any(miss != 0u)) {
-            const int first = miss ? __ffs((int)miss) - 1 : -1;
-            uint32_t tj = 0u, gj = 0u, vj = 0u;
-#pragma unroll
-            for (int j = 0; j < kNP; j++) if (j == first) { tj = tag[j]; gj = g[j]; vj = vb[j]; }
-            if (miss) { slow(tj, gj, vj); miss &= miss - 1u; }
-        }
-    };
-    walk_pair_slabs(pbuf, counts, cap, nwg, b, [&](const uint32_t (&key)[kNP], const uint32_t (&vb)[kNP], uint32_t live) -> bool {
-        probe(key, vb, live);
+    walk_pair_slabs(pbuf, counts, cap, nwg, b, [&](const uint32_t (&key)[kNP], const uint32_t (&vb)[kNP], uint32_t live, bool full) -> bool {
+        if (full && !Rmask) tag_probe_step<true>(tg, key, vb, live, lowmask, Rmask, r, hit, slow);
+        else tag_probe_step<false>(tg, key, vb, live, lowmask, Rmask, r, hit, slow);
         return !__any(overflow);                                             // an overflowed round is void anyway: stop reading
     });
     if (overflow) *err = kErrOverflow;
@@ -1591,13 +1621,12 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash_kernel(
     __syncthreads();
     if (threadIdx.x == 0) s_base = s_emit ? atomicAdd(out_cursor, (unsigned long long)s_emit) : 0ull;
     __syncthreads();
-    const uint16_t *t_tag16 = reinterpret_cast<const uint16_t *>(t_tagw);
     for (int i = threadIdx.x; i < kHashCap; i += blockDim.x) {
         const uint32_t c = t_cnt[i];
         if (!c) continue;
         const unsigned long long o = s_base + pos++;
         if (o < out_cap) {
-            out_key[o] = unmix32((b << lowbits) | tg.identity((uint32_t)i, t_tag16[i])); out_val[o] = t_val[i]; out_cnt[o] = (u64)c;
+            out_key[o] = unmix32((b << lowbits) | tg.identity((uint32_t)i, tg.tag_at((uint32_t)i))); out_val[o] = t_val[i]; out_cnt[o] = (u64)c;
         }
         else *err = kErrOverflow;
     }
@@ -1629,7 +1658,7 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash_stats_kernel(
     const int lowbits = 33 - __ffs((int)gridDim.x);
     const uint32_t lowmask = (1u << lowbits) - 1u;
     for (int i = threadIdx.x; i < kHashSCap; i += blockDim.x) { t_cnt[i] = 0u; t_sum[i] = 0ull; t_min[i] = 0xFFFFFFFFu; t_max[i] = 0u; }
-    for (int i = threadIdx.x; i < kHashSCap / 2; i += blockDim.x) t_tagw[i] = 0u;
+    for (int i = threadIdx.x; i < kHashSCap / 2; i += blockDim.x) t_tagw[i] = TagGroups::kEmpty2;
     if (threadIdx.x == 0) { s_used = 0u; s_emit = 0u; }
     __syncthreads();
     bool overflow = false;
@@ -1644,36 +1673,14 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash_stats_kernel(
         atomicMin(&t_min[slot], w); atomicMax(&t_max[slot], w);
         atomicAdd(&t_cnt[slot], 1u);
     };
-    auto slow = [&](uint32_t tag, uint32_t g, uint32_t raw) {
+    auto slow = [&](uint32_t tv, uint32_t g, uint32_t raw) {
         bool claimed;
-        const int slot = tg.locate(tag, g, &s_used, (uint32_t)kHashSFill, claimed);
+        const int slot = tg.locate(tv, g, &s_used, (uint32_t)kHashSFill, claimed);
         if (slot >= 0) hit((uint32_t)slot, raw); else overflow = true;
     };
-    auto probe = [&](const uint32_t (&key)[kNP], const uint32_t (&vb)[kNP], uint32_t live) {
-        uint32_t tag[kNP], g[kNP]; uint4 q[kNP];
-#pragma unroll
-        for (int j = 0; j < kNP; j++) {
-            tg.home(key[j] & lowmask, g[j], tag[j]);                          // the producer wrote mix32(key)
-            if (Rmask && (mix32(key[j] ^ 0x9E3779B9u) & Rmask) != r) live &= ~(1u << j);
-        }
-#pragma unroll
-        for (int j = 0; j < kNP; j++) q[j] = tg.read(g[j]);
-        uint32_t miss = 0;
-#pragma unroll
-        for (int j = 0; j < kNP; j++) {
-            const int at = TagGroups::find8(q[j], tag[j] | (tag[j] << 16));
-            if ((live >> j) & 1u) { if (at >= 0) hit(8u * g[j] + (uint32_t)at, vb[j]); else miss |= 1u << j; }
-        }
-        while (__any(miss != 0u)) {                                          // a lane's missing pairs one per pass (see fgb_agg_hash_kernel)
-            const int first = miss ? __ffs((int)miss) - 1 : -1;
-            uint32_t tj = 0u, gj = 0u, vj = 0u;
-#pragma unroll
-            for (int j = 0; j < kNP; j++) if (j == first) { tj = tag[j]; gj = g[j]; vj = vb[j]; }
-            if (miss) { slow(tj, gj, vj); miss &= miss - 1u; }
-        }
-    };
-    walk_pair_slabs(pbuf, counts, cap, nwg, b, [&](const uint32_t (&key)[kNP], const uint32_t (&vb)[kNP], uint32_t live) -> bool {
-        probe(key, vb, live);
+    walk_pair_slabs(pbuf, counts, cap, nwg, b, [&](const uint32_t (&key)[kNP], const uint32_t (&vb)[kNP], uint32_t live, bool full) -> bool {
+        if (full && !Rmask) tag_probe_step<true>(tg, key, vb, live, lowmask, Rmask, r, hit, slow);
+        else tag_probe_step<false>(tg, key, vb, live, lowmask, Rmask, r, hit, slow);
         return !__any(overflow);
     });
     if (overflow) *err = kErrOverflow;
@@ -1684,13 +1691,12 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash_stats_kernel(
     __syncthreads();
     if (threadIdx.x == 0) s_base = s_emit ? atomicAdd(out_cursor, (unsigned long long)s_emit) : 0ull;
     __syncthreads();
-    const uint16_t *t_tag16 = reinterpret_cast<const uint16_t *>(t_tagw);
     for (int i = threadIdx.x; i < kHashSCap; i += blockDim.x) {
         const uint32_t c = t_cnt[i];
         if (!c) continue;
         const unsigned long long o = s_base + pos++;
         if (o < out_cap) {
-            out_key[o] = unmix32((b << lowbits) | tg.identity((uint32_t)i, t_tag16[i]));
+            out_key[o] = unmix32((b << lowbits) | tg.identity((uint32_t)i, tg.tag_at((uint32_t)i)));
             out_sum[o] = t_sum[i]; out_cnt[o] = (u64)c; out_min[o] = (u64)t_min[i]; out_max[o] = (u64)t_max[i];
         } else *err = kErrOverflow;
     }
@@ -1729,7 +1735,7 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash_ops_kernel(
     const int op_a = (int)(ops & 255u), op_b = (int)((ops >> 8) & 255u), op_c = (int)((ops >> 16) & 255u);
     const uint32_t id_a = (uint32_t)vop_identity(op_a), id_b = (uint32_t)vop_identity(op_b), id_c = (uint32_t)vop_identity(op_c);
     for (int i = threadIdx.x; i < kCap; i += blockDim.x) { t_a[i] = id_a; t_b[i] = id_b; if constexpr (NOPS == 3) t_c[i] = id_c; }
-    for (int i = threadIdx.x; i < kCap / 2; i += blockDim.x) t_tagw[i] = 0u;
+    for (int i = threadIdx.x; i < kCap / 2; i += blockDim.x) t_tagw[i] = TagGroups::kEmpty2;
     if (threadIdx.x == 0) { s_used = 0u; s_emit = 0u; }
     __syncthreads();
     bool overflow = false;
@@ -1740,54 +1746,27 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash_ops_kernel(
         op32_atomic(op_a, &t_a[slot], x); op32_atomic(op_b, &t_b[slot], x);
         if constexpr (NOPS == 3) op32_atomic(op_c, &t_c[slot], x);
     };
-    auto slow = [&](uint32_t tag, uint32_t g, uint32_t x) {
+    auto slow = [&](uint32_t tv, uint32_t g, uint32_t x) {
         bool claimed;
-        const int slot = tg.locate(tag, g, &s_used, (uint32_t)kFill, claimed);
+        const int slot = tg.locate(tv, g, &s_used, (uint32_t)kFill, claimed);
         if (slot >= 0) hit((uint32_t)slot, x); else overflow = true;
     };
-    auto probe = [&](const uint32_t (&key)[kNP], const uint32_t (&vb)[kNP], uint32_t live) {
-        uint32_t tag[kNP], g[kNP]; uint4 q[kNP];
-#pragma unroll
-        for (int j = 0; j < kNP; j++) {
-            tg.home(key[j] & lowmask, g[j], tag[j]);                          // the producer wrote mix32(key)
-            if (Rmask && (mix32(key[j] ^ 0x9E3779B9u) & Rmask) != r) live &= ~(1u << j);
-        }
-#pragma unroll
-        for (int j = 0; j < kNP; j++) q[j] = tg.read(g[j]);
-        uint32_t miss = 0;
-#pragma unroll
-        for (int j = 0; j < kNP; j++) {
-            const int at = TagGroups::find8(q[j], tag[j] | (tag[j] << 16));
-            if ((live >> j) & 1u) { if (at >= 0) hit(8u * g[j] + (uint32_t)at, vb[j]); else miss |= 1u << j; }
-        }
-        // The missing pairs of a lane are taken one per pass, each lane its own first: the number of passes is the LARGEST number of
-        // misses any lane has (one, seldom two), not the number of pair positions j at which some lane missed -- with keys that come
-        // ~50 times each (the reference entry's bench line: 2 % of the pairs are first occurrences) that was six or seven of the
-        // eight positions in every step, each a divergent pass of dependent LDS round trips for a lane or two.
-        while (__any(miss != 0u)) {
-            const int first = miss ? __ffs((int)miss) - 1 : -1;
-            uint32_t tj = 0u, gj = 0u, vj = 0u;
-#pragma unroll
-            for (int j = 0; j < kNP; j++) if (j == first) { tj = tag[j]; gj = g[j]; vj = vb[j]; }
-            if (miss) { slow(tj, gj, vj); miss &= miss - 1u; }
-        }
-    };
-    walk_pair_slabs(pbuf, counts, cap, nwg, b, [&](const uint32_t (&key)[kNP], const uint32_t (&vb)[kNP], uint32_t live) -> bool {
-        probe(key, vb, live);
+    walk_pair_slabs(pbuf, counts, cap, nwg, b, [&](const uint32_t (&key)[kNP], const uint32_t (&vb)[kNP], uint32_t live, bool full) -> bool {
+        if (full && !Rmask) tag_probe_step<true>(tg, key, vb, live, lowmask, Rmask, r, hit, slow);
+        else tag_probe_step<false>(tg, key, vb, live, lowmask, Rmask, r, hit, slow);
         return !__any(overflow);
     });
     if (overflow) *err = kErrOverflow;
     __syncthreads();
-    const uint16_t *t_tag16 = reinterpret_cast<const uint16_t *>(t_tagw);
     uint32_t mine = 0;
-    for (int i = threadIdx.x; i < kCap; i += blockDim.x) mine += t_tag16[i] ? 1u : 0u;
+    for (int i = threadIdx.x; i < kCap; i += blockDim.x) mine += tg.tag_at((uint32_t)i) != 0xFFFFu ? 1u : 0u;
     uint32_t pos = mine ? atomicAdd(&s_emit, mine) : 0u;
     __syncthreads();
     if (threadIdx.x == 0) s_base = s_emit ? atomicAdd(out_cursor, (unsigned long long)s_emit) : 0ull;
     __syncthreads();
     for (int i = threadIdx.x; i < kCap; i += blockDim.x) {
-        const uint32_t t = t_tag16[i];
-        if (!t) continue;
+        const uint32_t t = tg.tag_at((uint32_t)i);
+        if (t == 0xFFFFu) continue;
         const unsigned long long o = s_base + pos++;
         if (o < out_cap) {
             out_key[o] = unmix32((b << lowbits) | tg.identity((uint32_t)i, t));
@@ -1887,7 +1866,7 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash8_kernel(
             for (int j = 0; j < kNP; j++) if ((miss >> j) & 1u) slow(tag[j], g[j], q[j], vv[j]);
         }
     };
-    walk_pair_slabs(pbuf, counts, cap, nwg, b, [&](const uint32_t (&key)[kNP], const uint32_t (&vv)[kNP], uint32_t live) -> bool {
+    walk_pair_slabs(pbuf, counts, cap, nwg, b, [&](const uint32_t (&key)[kNP], const uint32_t (&vv)[kNP], uint32_t live, bool) -> bool {
         probe(key, vv, live);
         return !__any(overflow);                                             // an overflowed round is void anyway: stop reading
     });
