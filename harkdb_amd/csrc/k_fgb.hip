@@ -1436,7 +1436,11 @@ __device__ __forceinline__ void walk_pair_slabs(const uint2 *__restrict__ pbuf, 
 // row; the consumer took 2.0 ms per 5e8 pairs against 0.5 ms for the dense one).  The key is rebuilt with unmix32 at emit
 // time.  A bucket with more distinct keys than the table holds is processed in R rounds, round r taking the keys with
 // mix32(key ^ salt) % R == r (the slabs are re-read, the table is emitted after every round).
-constexpr int kHashCap = 8192;                           // entries of 16 B (tag, count, value slot) = 128 KiB of LDS
+#ifndef HARK_TAGW
+#define HARK_TAGW 4
+#endif
+constexpr int kTagW = HARK_TAGW;                             // tags per group: 4 (one ds_read_b64 per probe) or 8 (one ds_read_b128)
+constexpr int kHashGroups = kTagW == 4 ? 2816 : 1024, kHashCap = kHashGroups * kTagW;   // entries of 14 B (value slot, count, 16-bit tag): 154 / 112 KiB of LDS
 constexpr int kHashFill = 3072;                          // distinct keys per round and bucket (load <= 0.375: probe chains stay short;
                                                          // a wave waits for its longest chain, so the load factor is what matters)
 __device__ __forceinline__ uint32_t unmix32(uint32_t y)
@@ -1455,7 +1459,10 @@ __device__ __forceinline__ uint32_t unmix32(uint32_t y)
 // so: slots only ever go from empty to occupied); 0xFFFF = an empty slot (the one tag that spells 0xFFFF is never stored: its
 // key overflows one group early).  Slot s of a group is half s >> 2 of word s & 3 (what the branch-free search hands back).
 struct TagGroups {
-    uint32_t *tagw;                                          // LDS [groups * 4]: two tags per word, 0xFFFF = empty
+    static constexpr uint32_t W = (uint32_t)kTagW;
+    static_assert(W == 4 || W == 8, "a group is one 8- or 16-byte LDS read");
+    typedef typename std::conditional<kTagW == 4, uint2, uint4>::type Group;
+    uint32_t *tagw;                                          // LDS [groups * W / 2]: two tags per word, 0xFFFF = empty
     uint32_t groups, lowbits, shift, rembits, maxdisp;
     static constexpr uint32_t kEmpty2 = 0xFFFFFFFFu;
     __device__ __forceinline__ void init(uint32_t *lds_words, uint32_t ngroups, int lowbits_)
@@ -1463,8 +1470,8 @@ struct TagGroups {
         tagw = lds_words; groups = ngroups; lowbits = (uint32_t)lowbits_;
         shift = 31u - (uint32_t)__clz((int)ngroups);         // groups >= 512 and lowbits <= 24: rembits <= 15
         rembits = lowbits - shift;
-        const uint32_t room = (1u << (16u - rembits)) - 1u;
-        maxdisp = room < 3u ? room : 3u;
+        const uint32_t room = (1u << (16u - rembits)) - 1u, most = W == 4 ? 7u : 3u;
+        maxdisp = room < most ? room : most;
     }
     // group and tv * 0x10001 (the tag of a key at home, in both halves of a word)
     __device__ __forceinline__ void home(uint32_t x, uint32_t &g, uint32_t &t2) const
@@ -1474,23 +1481,34 @@ struct TagGroups {
         g = __builtin_amdgcn_alignbit(hi, lo, lowbits);
         t2 = __builtin_amdgcn_ubfe(lo, shift, rembits) * 0x10001u;
     }
-    __device__ __forceinline__ uint4 read(uint32_t g) const { return reinterpret_cast<const uint4 *>(tagw)[g]; }
-    // Where in a group is the tag of t2's halves?  A code p: bit (p & 3) = the word, p >> 4 = the half; -1: nowhere.  Branch-free:
+    __device__ __forceinline__ Group read(uint32_t g) const { return reinterpret_cast<const Group *>(tagw)[g]; }
+    // Where in a group is the tag of t2's halves?  A code p: the low bits = the word, p >> 4 = the half; -1: nowhere.  Branch-free:
     // v_pk_min_u16(x, 1) is 1 per non-zero half (the compiler turns the same thing written in C into compares and selects:
-    // inline assembly), the four words' indicators are packed into one, inverted, and the lowest set bit is the slot --
-    // 14 instructions where the chain of compares took ~30 and four levels of divergent branches per pair.
+    // inline assembly), the words' indicators are packed into one, inverted, and the lowest set bit is the slot -- 7 / 14
+    // instructions where a chain of compares took ~30 and four levels of divergent branches per pair.
     static __device__ __forceinline__ uint32_t nz16(uint32_t x) { uint32_t r; asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(x), "s"(0x00010001u)); return r; }
-    static __device__ __forceinline__ int find8(const uint4 &q, uint32_t t2)
+    static __device__ __forceinline__ int find(const uint2 &q, uint32_t t2)
     {
-        const uint32_t n = nz16(q.x ^ t2) | (nz16(q.y ^ t2) << 1) | (nz16(q.z ^ t2) << 2) | (nz16(q.w ^ t2) << 3);
-        int p; asm("v_ffbl_b32 %0, %1" : "=v"(p) : "v"(n ^ 0x000F000Fu));   // -1 when no bit is set
+        const uint32_t n = nz16(q.x ^ t2) | (nz16(q.y ^ t2) << 1);
+        int p; asm("v_ffbl_b32 %0, %1" : "=v"(p) : "v"(n ^ 0x00030003u));   // -1 when no bit is set
         return p;
     }
-    static __device__ __forceinline__ uint32_t slot_of(int p) { return ((uint32_t)p & 3u) | ((uint32_t)p >> 2); }   // p >= 0: p >> 2 is 0 or 4
+    static __device__ __forceinline__ int find(const uint4 &q, uint32_t t2)
+    {
+        const uint32_t n = nz16(q.x ^ t2) | (nz16(q.y ^ t2) << 1) | (nz16(q.z ^ t2) << 2) | (nz16(q.w ^ t2) << 3);
+        int p; asm("v_ffbl_b32 %0, %1" : "=v"(p) : "v"(n ^ 0x000F000Fu));
+        return p;
+    }
+    // slot s of a group is half s / (W / 2) of word s % (W / 2)
+    static __device__ __forceinline__ uint32_t slot_of(int p) { return W == 4 ? (((uint32_t)p & 1u) | ((uint32_t)p >> 3)) : (((uint32_t)p & 3u) | ((uint32_t)p >> 2)); }
+    static __device__ __forceinline__ uint32_t word_of(const uint2 &q, uint32_t w) { return w == 0 ? q.x : q.y; }
+    static __device__ __forceinline__ uint32_t word_of(const uint4 &q, uint32_t w) { return w == 0 ? q.x : w == 1 ? q.y : w == 2 ? q.z : q.w; }
+    static __device__ __forceinline__ void set_word(uint2 &q, uint32_t w, uint32_t v) { if (w == 0) q.x = v; else q.y = v; }
+    static __device__ __forceinline__ void set_word(uint4 &q, uint32_t w, uint32_t v) { if (w == 0) q.x = v; else if (w == 1) q.y = v; else if (w == 2) q.z = v; else q.w = v; }
     // The slot of a key that its home group's read did not show: found further on, or claimed (the first empty slot of the first
     // group with room, with a compare-and-swap on the WORD that holds it; a lane that loses learns the word's new content from
     // the compare-and-swap itself and looks again, so two lanes with one key end up in one slot; a word changes at most twice:
-    // <= 8 failures per group).  Returns the slot; -1: every group the key may live in is full of other keys; -2: the round's
+    // <= W failures per group).  Returns the slot; -1: every group the key may live in is full of other keys; -2: the round's
     // budget of distinct keys (*used >= fill) is spent.  *claimed: the key is new.
     __device__ __forceinline__ int locate(uint32_t tv, uint32_t g, uint32_t *used, uint32_t fill, bool &claimed) const
     {
@@ -1500,28 +1518,32 @@ struct TagGroups {
             const uint32_t t = tv | (d << rembits), t2 = t * 0x10001u;
             if (t == 0xFFFFu) break;                         // spells "empty"
             asm volatile("" ::: "memory");                   // (the group is read NOW: other lanes' claims since the probe's read count)
-            uint4 q = read(gg);
+            Group q = read(gg);
             for (int tries = 0; tries < 16; tries++) {
-                const int at = find8(q, t2);
-                if (at >= 0) return (int)(8u * gg + slot_of(at));
-                const int e = find8(q, kEmpty2);
+                const int at = find(q, t2);
+                if (at >= 0) return (int)(W * gg + slot_of(at));
+                const int e = find(q, kEmpty2);
                 if (e < 0) break;                            // full of other keys: the next group
                 if (*used >= fill) return -2;
-                const uint32_t w = (uint32_t)e & 3u, oldw = w == 0 ? q.x : w == 1 ? q.y : w == 2 ? q.z : q.w;
-                const uint32_t got = atomicCAS(&tagw[4u * gg + w], oldw, oldw ^ ((t ^ 0xFFFFu) << ((uint32_t)e & 16u)));   // ds_cmpst_rtn_b32
-                if (got == oldw) { atomicAdd(used, 1u); claimed = true; return (int)(8u * gg + slot_of(e)); }
-                if (w == 0) q.x = got; else if (w == 1) q.y = got; else if (w == 2) q.z = got; else q.w = got;
+                const uint32_t w = (uint32_t)e & (W / 2 - 1u), oldw = word_of(q, w);
+                const uint32_t got = atomicCAS(&tagw[(W / 2) * gg + w], oldw, oldw ^ ((t ^ 0xFFFFu) << ((uint32_t)e & 16u)));   // ds_cmpst_rtn_b32
+                if (got == oldw) { atomicAdd(used, 1u); claimed = true; return (int)(W * gg + slot_of(e)); }
+                set_word(q, w, got);
             }
         }
         return -1;
     }
     // the tag in a slot (0xFFFF: empty)
-    __device__ __forceinline__ uint32_t tag_at(uint32_t slot) const { return (tagw[4u * (slot >> 3) + (slot & 3u)] >> (4u * (slot & 4u))) & 0xFFFFu; }
+    __device__ __forceinline__ uint32_t tag_at(uint32_t slot) const
+    {
+        const uint32_t s = slot & (W - 1u);
+        return (tagw[(W / 2) * (slot / W) + (s & (W / 2 - 1u))] >> (16u * (s / (W / 2)))) & 0xFFFFu;
+    }
     // the key's low bits x back from its slot and tag (emit time): the one x whose product lies in the tag's window
     __device__ __forceinline__ uint32_t identity(uint32_t slot, uint32_t tag) const
     {
         const uint32_t d = tag >> rembits, tv = tag & ((1u << rembits) - 1u);
-        uint32_t g = slot >> 3; g = g >= d ? g - d : g + groups - d;
+        uint32_t g = slot / W; g = g >= d ? g - d : g + groups - d;
         const u64 a = ((u64)g << lowbits) | ((u64)tv << shift);
         return (uint32_t)((a + groups - 1u) / groups);
     }
@@ -1536,20 +1558,20 @@ template <bool FULL, typename HIT, typename SLOW>
 __device__ __forceinline__ void tag_probe_step(const TagGroups &tg, const uint32_t (&key)[8], const uint32_t (&vb)[8], uint32_t live,
                                                uint32_t lowmask, uint32_t Rmask, uint32_t r, HIT &&hit, SLOW &&slow)
 {
-    uint32_t t2[8], g[8]; uint4 q[8];
+    uint32_t t2[8], g[8]; TagGroups::Group q[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         tg.home(key[j] & lowmask, g[j], t2[j]);                               // the producer wrote mix32(key)
         if (!FULL && Rmask && (mix32(key[j] ^ 0x9E3779B9u) & Rmask) != r) live &= ~(1u << j);   // not this round's share of the key space
     }
 #pragma unroll
-    for (int j = 0; j < 8; j++) q[j] = tg.read(g[j]);                        // eight independent 16-byte LDS reads in flight
+    for (int j = 0; j < 8; j++) q[j] = tg.read(g[j]);                        // eight independent LDS reads in flight
     uint32_t miss = 0;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        const int p = TagGroups::find8(q[j], t2[j]);
+        const int p = TagGroups::find(q[j], t2[j]);
         miss |= (uint32_t)p & (0x100u << j);                                  // p = -1: every bit (a found p is below 32)
-        if (FULL ? p >= 0 : (p >= 0 && ((live >> j) & 1u))) hit(8u * g[j] + TagGroups::slot_of(p), vb[j]);
+        if (FULL ? p >= 0 : (p >= 0 && ((live >> j) & 1u))) hit(TagGroups::W * g[j] + TagGroups::slot_of(p), vb[j]);
     }
     miss >>= 8;
     if (!FULL) miss &= live;
@@ -1598,7 +1620,7 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash_kernel(
     // A probe finds its key in the home group without a branch; anything else -- a new key, a displaced key -- takes the
     // slow path, which hardly a wave sees once the table is built.
     constexpr int kNP = 8;
-    constexpr uint32_t kGroups = kHashCap / 8;
+    constexpr uint32_t kGroups = (uint32_t)kHashGroups;
     TagGroups tg;
     tg.init(t_tagw, kGroups, lowbits);                                   // 1024 groups: D = 2^(lowbits - 10), the division is a shift in effect
     auto hit = [&](uint32_t slot, uint32_t vbits) { vop_atomic<VOP>(&t_val[slot], VOP == VOP_F32SUM ? vbits : apply_xf(xf, vbits)); atomicAdd(&t_cnt[slot], 1u); };
@@ -1640,7 +1662,7 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash_kernel(
 // VK: 0 = f32 values (f64 sum), 1 = i32 (sum of the biased values, like XF_I32_ORDER), 2 = u32.
 // (round 5: 16-bit tags -- TagGroups, 22 bytes per entry -- 928 groups of eight in the same 160 KiB instead of 640: 2.2 keys per group
 // for 2^20 keys in 512 buckets instead of 3.2, and one ds_read_b128 per probe.)
-constexpr int kHashSGroups = 928, kHashSCap = kHashSGroups * 8, kHashSFill = 2560;
+constexpr int kHashSGroups = 928 * 8 / kTagW, kHashSCap = kHashSGroups * kTagW, kHashSFill = 2560;
 template <int VK>
 __global__ __launch_bounds__(1024) void fgb_agg_hash_stats_kernel(
     const uint2 *__restrict__ pbuf, const uint32_t *__restrict__ counts, uint32_t cap, int nwg, uint32_t Rmask, uint32_t r,
@@ -1709,7 +1731,7 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash_stats_kernel(
 // (VOP_U32SUM / MAX / MIN / PROD).  Emits slot 0 | slot 1 << 32 as the value word and slot 2 as the count word.
 // (round 5: 16-bit tags -- 10 or 14 bytes per entry -- let the same 160 KiB hold 2040 / 1456 groups instead of 1536 / 1152; the keys per
 // round stay at 6144 / 4608, so a group holds 3.0 / 3.2 keys on average when a round is full and 2.0 / 2.8 for the 2^21 keys of the bench line)
-template <int NOPS> struct HashOpsGeo { static constexpr int groups = NOPS == 2 ? 2040 : 1456, cap = groups * 8, fill = NOPS == 2 ? 6144 : 4608; };
+template <int NOPS> struct HashOpsGeo { static constexpr int groups = (NOPS == 2 ? 2040 : 1456) * 8 / kTagW, cap = groups * kTagW, fill = NOPS == 2 ? 6144 : 4608; };
 __device__ __forceinline__ void op32_atomic(int vop, uint32_t *slot, uint32_t x)
 {
     if (vop == VOP_U32SUM) atomicAdd(slot, x);

@@ -17,13 +17,18 @@
 
 constexpr int kSlots = 8192;
 __device__ __forceinline__ uint32_t lcg(uint32_t x) { return x * 1664525u + 1013904223u; }
+__device__ __forceinline__ uint32_t mixw(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+// the slot-in-group a probe's tag read leads to: three well-mixed bits of what was read (a first version took the low bits of
+// an XOR of two multiplicative tags: only two of the eight values ever came out, the atomics of a step piled onto a quarter of
+// the banks, and the probe reported reads and atomics as costing twice as much together as apart)
+__device__ __forceinline__ uint32_t low3(uint32_t a, uint32_t b) { return ((a ^ b) * 0x9E3779B1u) >> 29; }
 
 // what one pair does:
 //  bit 0: two ds_read_b128 of a 32-byte group of 32-bit tags      bit 1: one ds_read_b128 of a 16-byte group (16-bit tags x 8 .. or 16)
 //  bit 2: one ds_read_b64 of an 8-byte group                       bit 3: ds_add_f64 at the slot
 //  bit 4: ds_add_u32 at the slot                                   bit 5: ds_add_u64 at the slot (integer sums / a packed word)
 //  bit 6: ds_add_f64 of a SECOND value array (count kept as a double)
-//  bit 7: the atomics of a wave-step are issued slot-sorted?  (not modelled)  -- unused
+//  bit 7: two neighbouring 8-byte groups at an 8-byte-aligned address (ds_read2_b64: a four-tag home group and the next one)
 template <int WHAT, bool PIPE = false, bool PHASED = false>
 __global__ __launch_bounds__(1024) void probe_kernel(int steps, uint32_t *out)
 {
@@ -32,7 +37,7 @@ __global__ __launch_bounds__(1024) void probe_kernel(int steps, uint32_t *out)
     uint32_t *t_tag = reinterpret_cast<uint32_t *>(t_val + kSlots);               // [kSlots]
     uint32_t *t_cnt = t_tag + kSlots;                                             // [kSlots]
     double *t_val2 = reinterpret_cast<double *>(t_cnt + kSlots);                  // [kSlots / 2] (only when bit 6)
-    for (int i = threadIdx.x; i < kSlots; i += blockDim.x) { t_val[i] = 0.0; t_tag[i] = (uint32_t)i * 2654435761u; t_cnt[i] = 0u; }
+    for (int i = threadIdx.x; i < kSlots; i += blockDim.x) { t_val[i] = 0.0; t_tag[i] = mixw((uint32_t)i); t_cnt[i] = 0u; }
     if (WHAT & 64) for (int i = threadIdx.x; i < kSlots / 2; i += blockDim.x) t_val2[i] = 0.0;
     __syncthreads();
     uint32_t r = threadIdx.x * 2654435761u + blockIdx.x * 40503u;
@@ -46,12 +51,13 @@ __global__ __launch_bounds__(1024) void probe_kernel(int steps, uint32_t *out)
         uint32_t slot[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) { r = lcg(r); slot[j] = (r >> 9) & (kSlots - 1); }
-        uint4 qa[8], qb[8]; uint2 qc[8];
+        uint4 qa[8], qb[8]; uint2 qc[8], qd[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             if (WHAT & 1) { qa[j] = tag4[2u * (slot[j] >> 3)]; qb[j] = tag4[2u * (slot[j] >> 3) + 1u]; }
             if (WHAT & 2) qa[j] = tag4[slot[j] >> 2];                            // 16-byte groups anywhere in the tag array
             if (WHAT & 4) qc[j] = tag2[slot[j] >> 1];
+            if (WHAT & 128) { const uint32_t a8 = (slot[j] >> 1) & (kSlots / 2 - 1); qc[j] = tag2[a8]; qd[j] = tag2[a8 + 1u]; }
         }
         if (PHASED) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave's reads are done before any wave's atomics start
         if (PIPE) {
@@ -69,14 +75,16 @@ __global__ __launch_bounds__(1024) void probe_kernel(int steps, uint32_t *out)
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             uint32_t at = slot[j];
-            if (WHAT & 1) { acc += qa[j].x ^ qa[j].w ^ qb[j].y; at = (at & ~7u) | ((qa[j].x ^ qb[j].z) & 7u); }       // the slot depends on the tags read (as a real probe's does)
-            if (WHAT & 2) { acc += qa[j].x ^ qa[j].w; at = (at & ~7u) | ((qa[j].x ^ qa[j].z) & 7u); }
-            if (WHAT & 4) { acc += qc[j].x; at = (at & ~7u) | ((qc[j].x ^ qc[j].y) & 7u); }
+            if (WHAT & 1) { acc += qa[j].x ^ qa[j].w ^ qb[j].y; at = (at & ~7u) | low3(qa[j].x, qb[j].z); }       // the slot depends on the tags read (as a real probe's does)
+            if (WHAT & 2) { acc += qa[j].x ^ qa[j].w; at = (at & ~7u) | low3(qa[j].x, qa[j].z); }
+            if (WHAT & 4) { acc += qc[j].x; at = (at & ~7u) | low3(qc[j].x, qc[j].y); }
+            if (WHAT & 128) { acc += qc[j].x ^ qd[j].y; at = (at & ~7u) | low3(qc[j].x, qd[j].y); }
             if (PIPE) { pat[j] = at; continue; }
             if (WHAT & 8) unsafeAtomicAdd(&t_val[at], 1.0);
             if (WHAT & 16) atomicAdd(&t_cnt[at], 1u);
             if (WHAT & 32) atomicAdd(reinterpret_cast<unsigned long long *>(&t_val[at]), 1ull);
             if (WHAT & 64) unsafeAtomicAdd(&t_val2[at >> 1], 1.0);
+            if (WHAT & 256) atomicAdd(reinterpret_cast<uint32_t *>(t_val) + at, 1u);
         }
         if (PHASED) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // ... and every wave's atomics before the next step's reads
     }
@@ -125,6 +133,12 @@ int main()
     run<2 | 8>("1 x b128 + f64        (no count atomic)", out, ncu);
     run<2 | 32>("1 x b128 + u64        (one integer atomic: u32 sums, or a packed word)", out, ncu);
     run<2 | 8 | 64>("1 x b128 + f64 + f64  (count as a double beside the sum)", out, ncu);
+    run<128>("ds_read2_b64 (two neighbouring four-tag groups, 8-byte aligned)", out, ncu);
+    run<128 | 8 | 16>("read2_b64 + f64 + u32", out, ncu);
+    run<4 | 16 | 32>("1 x b64 + u64 + u32", out, ncu);
+    run<4 | 16>("1 x b64 + u32", out, ncu);
+    run<4 | 16 | 256>("1 x b64 + u32 + u32 (two 32-bit operators: the reference entry)", out, ncu);
+    run<2 | 16 | 256>("1 x b128 + u32 + u32", out, ncu);
     printf("-- software-pipelined: a step's tag reads are issued BEFORE the previous step's atomics, and waited for after them\n");
     run<1 | 8 | 16, true>("2 x b128 + f64 + u32, pipelined", out, ncu);
     run<2 | 8 | 16, true>("1 x b128 + f64 + u32, pipelined", out, ncu);
