@@ -1436,10 +1436,17 @@ __device__ __forceinline__ void walk_pair_slabs(const uint2 *__restrict__ pbuf, 
 // row; the consumer took 2.0 ms per 5e8 pairs against 0.5 ms for the dense one).  The key is rebuilt with unmix32 at emit
 // time.  A bucket with more distinct keys than the table holds is processed in R rounds, round r taking the keys with
 // mix32(key ^ salt) % R == r (the slabs are re-read, the table is emitted after every round).
+// tags per group: 4 (one ds_read_b64 per probe: 9 LDS cycles per 64 lanes against 25 for a ds_read_b128, tools/hashlds.hip) or 8.
+// Four win where a round's keys leave the groups mostly empty (0.7 / 1.1 keys per group for the typed and the statistics
+// consumers: 970 against 1048 us and 1238 against 1323 us per 5e8 pairs); the reference entry's consumer runs its groups at 1.0
+// keys per four slots -- two or three displaced pairs in every step -- and is faster with eight (301 against 326 us per 1e8).
 #ifndef HARK_TAGW
 #define HARK_TAGW 4
 #endif
-constexpr int kTagW = HARK_TAGW;                             // tags per group: 4 (one ds_read_b64 per probe) or 8 (one ds_read_b128)
+#ifndef HARK_TAGW_OPS
+#define HARK_TAGW_OPS 8
+#endif
+constexpr int kTagW = HARK_TAGW, kTagWOps = HARK_TAGW_OPS;
 constexpr int kHashGroups = kTagW == 4 ? 2816 : 1024, kHashCap = kHashGroups * kTagW;   // entries of 14 B (value slot, count, 16-bit tag): 154 / 112 KiB of LDS
 constexpr int kHashFill = 3072;                          // distinct keys per round and bucket (load <= 0.375: probe chains stay short;
                                                          // a wave waits for its longest chain, so the load factor is what matters)
@@ -1458,10 +1465,11 @@ __device__ __forceinline__ uint32_t unmix32(uint32_t y)
 // past its home the key lives (the first group that had room when it came; all before it are full of other keys, and stay
 // so: slots only ever go from empty to occupied); 0xFFFF = an empty slot (the one tag that spells 0xFFFF is never stored: its
 // key overflows one group early).  Slot s of a group is half s >> 2 of word s & 3 (what the branch-free search hands back).
+template <int TW>
 struct TagGroups {
-    static constexpr uint32_t W = (uint32_t)kTagW;
+    static constexpr uint32_t W = (uint32_t)TW;
     static_assert(W == 4 || W == 8, "a group is one 8- or 16-byte LDS read");
-    typedef typename std::conditional<kTagW == 4, uint2, uint4>::type Group;
+    typedef typename std::conditional<TW == 4, uint2, uint4>::type Group;
     uint32_t *tagw;                                          // LDS [groups * W / 2]: two tags per word, 0xFFFF = empty
     uint32_t groups, lowbits, shift, rembits, maxdisp;
     static constexpr uint32_t kEmpty2 = 0xFFFFFFFFu;
@@ -1505,26 +1513,27 @@ struct TagGroups {
     static __device__ __forceinline__ uint32_t word_of(const uint4 &q, uint32_t w) { return w == 0 ? q.x : w == 1 ? q.y : w == 2 ? q.z : q.w; }
     static __device__ __forceinline__ void set_word(uint2 &q, uint32_t w, uint32_t v) { if (w == 0) q.x = v; else q.y = v; }
     static __device__ __forceinline__ void set_word(uint4 &q, uint32_t w, uint32_t v) { if (w == 0) q.x = v; else if (w == 1) q.y = v; else if (w == 2) q.z = v; else q.w = v; }
-    // The slot of a key that its home group's read did not show: found further on, or claimed (the first empty slot of the first
-    // group with room, with a compare-and-swap on the WORD that holds it; a lane that loses learns the word's new content from
-    // the compare-and-swap itself and looks again, so two lanes with one key end up in one slot; a word changes at most twice:
-    // <= W failures per group).  Returns the slot; -1: every group the key may live in is full of other keys; -2: the round's
-    // budget of distinct keys (*used >= fill) is spent.  *claimed: the key is new.
-    __device__ __forceinline__ int locate(uint32_t tv, uint32_t g, uint32_t *used, uint32_t fill, bool &claimed) const
+    // The slot of a key that its home group's read did not show: found further on, or claimed -- the first empty slot of the
+    // first group with room, with a compare-and-swap on the WORD that holds it.  A lane that loses learns the word's new content
+    // from the compare-and-swap itself and looks again, so two lanes with one key end up in one slot (a word changes at most
+    // twice: <= W failures per group).  (A stale view would do -- slots only go from empty to occupied and every lane takes the
+    // first empty slot in ONE order, so a lane reaches a slot only after it has seen every slot before it occupied in a view
+    // the compare-and-swap refreshed -- and handing the probe's read in saves a round trip per pass, but picking it out of the
+    // registers costs more issue slots than the round trip costs a kernel that waits for the LDS pipe, not for latency:
+    // measured 2-5 % slower.)  Returns the slot; -1: every group the key may live in is full of other keys.  A claim adds one
+    // to *used (nobody waits for the sum: the step looks at it once).
+    __device__ __forceinline__ int locate(uint32_t tv, uint32_t g, uint32_t *used, bool &claimed) const
     {
-        claimed = false;
         for (uint32_t d = 0; d <= maxdisp; d++) {
             uint32_t gg = g + d; if (gg >= groups) gg -= groups;
             const uint32_t t = tv | (d << rembits), t2 = t * 0x10001u;
             if (t == 0xFFFFu) break;                         // spells "empty"
-            asm volatile("" ::: "memory");                   // (the group is read NOW: other lanes' claims since the probe's read count)
             Group q = read(gg);
             for (int tries = 0; tries < 16; tries++) {
                 const int at = find(q, t2);
                 if (at >= 0) return (int)(W * gg + slot_of(at));
                 const int e = find(q, kEmpty2);
                 if (e < 0) break;                            // full of other keys: the next group
-                if (*used >= fill) return -2;
                 const uint32_t w = (uint32_t)e & (W / 2 - 1u), oldw = word_of(q, w);
                 const uint32_t got = atomicCAS(&tagw[(W / 2) * gg + w], oldw, oldw ^ ((t ^ 0xFFFFu) << ((uint32_t)e & 16u)));   // ds_cmpst_rtn_b32
                 if (got == oldw) { atomicAdd(used, 1u); claimed = true; return (int)(W * gg + slot_of(e)); }
@@ -1550,15 +1559,16 @@ struct TagGroups {
 };
 
 // One step of a hash consumer: eight pairs per lane against a TagGroups table -- the home groups' reads all in flight, then
-// hit(slot, value) for the keys they show; what they do not show (new keys, displaced keys) goes through slow(tv, group, value)
-// one pair per pass, each lane its own first (the number of passes is the LARGEST number of misses any lane has -- one, seldom
-// two -- not the number of pair positions at which some lane missed).  FULL (wave-uniform): every pair of the step is live and
-// the round takes every key, so no pair carries a predicate of its own.
-template <bool FULL, typename HIT, typename SLOW>
-__device__ __forceinline__ void tag_probe_step(const TagGroups &tg, const uint32_t (&key)[8], const uint32_t (&vb)[8], uint32_t live,
-                                               uint32_t lowmask, uint32_t Rmask, uint32_t r, HIT &&hit, SLOW &&slow)
+// hit(slot, value) for the keys they show; what they do not show (new keys, displaced keys) is located one pair per pass, each
+// lane its own first (the number of passes is the LARGEST number of misses any lane has -- one, seldom two -- not the number
+// of pair positions at which some lane missed).  A round's budget of distinct keys (*used <= fill) is looked at once per step
+// that claimed.  FULL (wave-uniform): every pair of the step is live and the round takes every key, so no pair carries a
+// predicate of its own.  Sets overflow when a key found no room or the budget is spent (the round is void then).
+template <bool FULL, typename TG, typename HIT>
+__device__ __forceinline__ void tag_probe_step(const TG &tg, const uint32_t (&key)[8], const uint32_t (&vb)[8], uint32_t live,
+                                               uint32_t lowmask, uint32_t Rmask, uint32_t r, uint32_t *used, uint32_t fill, bool &overflow, HIT &&hit)
 {
-    uint32_t t2[8], g[8]; TagGroups::Group q[8];
+    uint32_t t2[8], g[8]; typename TG::Group q[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         tg.home(key[j] & lowmask, g[j], t2[j]);                               // the producer wrote mix32(key)
@@ -1569,19 +1579,26 @@ __device__ __forceinline__ void tag_probe_step(const TagGroups &tg, const uint32
     uint32_t miss = 0;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        const int p = TagGroups::find(q[j], t2[j]);
+        const int p = TG::find(q[j], t2[j]);
         miss |= (uint32_t)p & (0x100u << j);                                  // p = -1: every bit (a found p is below 32)
-        if (FULL ? p >= 0 : (p >= 0 && ((live >> j) & 1u))) hit(TagGroups::W * g[j] + TagGroups::slot_of(p), vb[j]);
+        if (FULL ? p >= 0 : (p >= 0 && ((live >> j) & 1u))) hit(TG::W * g[j] + TG::slot_of(p), vb[j]);
     }
     miss >>= 8;
     if (!FULL) miss &= live;
-    while (__any(miss != 0u)) {
+    if (!__any(miss != 0u)) return;
+    bool claimed = false;
+    do {
         const int first = miss ? __ffs((int)miss) - 1 : -1;
         uint32_t tj = 0u, gj = 0u, vj = 0u;
 #pragma unroll
         for (int j = 0; j < 8; j++) if (j == first) { tj = t2[j] & 0xFFFFu; gj = g[j]; vj = vb[j]; }
-        if (miss) { slow(tj, gj, vj); miss &= miss - 1u; }
-    }
+        if (miss) {
+            const int slot = tg.locate(tj, gj, used, claimed);
+            if (slot >= 0) hit((uint32_t)slot, vj); else overflow = true;
+            miss &= miss - 1u;
+        }
+    } while (__any(miss != 0u));
+    if (__any(claimed) && *used > fill) overflow = true;
 }
 
 template <int VOP>
@@ -1600,7 +1617,7 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash_kernel(
     const int lowbits = 33 - __ffs((int)gridDim.x);                      // P = gridDim.x buckets, a power of two: bucket = mix32(key) >> lowbits
     const uint32_t lowmask = (1u << lowbits) - 1u;
     for (int i = threadIdx.x; i < kHashCap; i += blockDim.x) { t_cnt[i] = 0u; t_val[i] = vop_identity(VOP); }
-    for (int i = threadIdx.x; i < kHashCap / 2; i += blockDim.x) t_tagw[i] = TagGroups::kEmpty2;
+    for (int i = threadIdx.x; i < kHashCap / 2; i += blockDim.x) t_tagw[i] = 0xFFFFFFFFu;
     if (threadIdx.x == 0) { s_used = 0u; s_emit = 0u; }
     __syncthreads();
     bool overflow = false;
@@ -1621,17 +1638,12 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash_kernel(
     // slow path, which hardly a wave sees once the table is built.
     constexpr int kNP = 8;
     constexpr uint32_t kGroups = (uint32_t)kHashGroups;
-    TagGroups tg;
+    TagGroups<kTagW> tg;
     tg.init(t_tagw, kGroups, lowbits);                                   // 1024 groups: D = 2^(lowbits - 10), the division is a shift in effect
     auto hit = [&](uint32_t slot, uint32_t vbits) { vop_atomic<VOP>(&t_val[slot], VOP == VOP_F32SUM ? vbits : apply_xf(xf, vbits)); atomicAdd(&t_cnt[slot], 1u); };
-    auto slow = [&](uint32_t tv, uint32_t g, uint32_t vbits) {
-        bool claimed;
-        const int slot = tg.locate(tv, g, &s_used, (uint32_t)kHashFill, claimed);
-        if (slot >= 0) hit((uint32_t)slot, vbits); else overflow = true;
-    };
     walk_pair_slabs(pbuf, counts, cap, nwg, b, [&](const uint32_t (&key)[kNP], const uint32_t (&vb)[kNP], uint32_t live, bool full) -> bool {
-        if (full && !Rmask) tag_probe_step<true>(tg, key, vb, live, lowmask, Rmask, r, hit, slow);
-        else tag_probe_step<false>(tg, key, vb, live, lowmask, Rmask, r, hit, slow);
+        if (full && !Rmask) tag_probe_step<true>(tg, key, vb, live, lowmask, Rmask, r, &s_used, (uint32_t)kHashFill, overflow, hit);
+        else tag_probe_step<false>(tg, key, vb, live, lowmask, Rmask, r, &s_used, (uint32_t)kHashFill, overflow, hit);
         return !__any(overflow);                                             // an overflowed round is void anyway: stop reading
     });
     if (overflow) *err = kErrOverflow;
@@ -1680,12 +1692,12 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash_stats_kernel(
     const int lowbits = 33 - __ffs((int)gridDim.x);
     const uint32_t lowmask = (1u << lowbits) - 1u;
     for (int i = threadIdx.x; i < kHashSCap; i += blockDim.x) { t_cnt[i] = 0u; t_sum[i] = 0ull; t_min[i] = 0xFFFFFFFFu; t_max[i] = 0u; }
-    for (int i = threadIdx.x; i < kHashSCap / 2; i += blockDim.x) t_tagw[i] = TagGroups::kEmpty2;
+    for (int i = threadIdx.x; i < kHashSCap / 2; i += blockDim.x) t_tagw[i] = 0xFFFFFFFFu;
     if (threadIdx.x == 0) { s_used = 0u; s_emit = 0u; }
     __syncthreads();
     bool overflow = false;
     constexpr int kNP = 8;
-    TagGroups tg;
+    TagGroups<kTagW> tg;
     tg.init(t_tagw, (uint32_t)kHashSGroups, lowbits);
     auto hit = [&](uint32_t slot, uint32_t raw) {
         uint32_t w;
@@ -1695,14 +1707,9 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash_stats_kernel(
         atomicMin(&t_min[slot], w); atomicMax(&t_max[slot], w);
         atomicAdd(&t_cnt[slot], 1u);
     };
-    auto slow = [&](uint32_t tv, uint32_t g, uint32_t raw) {
-        bool claimed;
-        const int slot = tg.locate(tv, g, &s_used, (uint32_t)kHashSFill, claimed);
-        if (slot >= 0) hit((uint32_t)slot, raw); else overflow = true;
-    };
     walk_pair_slabs(pbuf, counts, cap, nwg, b, [&](const uint32_t (&key)[kNP], const uint32_t (&vb)[kNP], uint32_t live, bool full) -> bool {
-        if (full && !Rmask) tag_probe_step<true>(tg, key, vb, live, lowmask, Rmask, r, hit, slow);
-        else tag_probe_step<false>(tg, key, vb, live, lowmask, Rmask, r, hit, slow);
+        if (full && !Rmask) tag_probe_step<true>(tg, key, vb, live, lowmask, Rmask, r, &s_used, (uint32_t)kHashSFill, overflow, hit);
+        else tag_probe_step<false>(tg, key, vb, live, lowmask, Rmask, r, &s_used, (uint32_t)kHashSFill, overflow, hit);
         return !__any(overflow);
     });
     if (overflow) *err = kErrOverflow;
@@ -1731,7 +1738,7 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash_stats_kernel(
 // (VOP_U32SUM / MAX / MIN / PROD).  Emits slot 0 | slot 1 << 32 as the value word and slot 2 as the count word.
 // (round 5: 16-bit tags -- 10 or 14 bytes per entry -- let the same 160 KiB hold 2040 / 1456 groups instead of 1536 / 1152; the keys per
 // round stay at 6144 / 4608, so a group holds 3.0 / 3.2 keys on average when a round is full and 2.0 / 2.8 for the 2^21 keys of the bench line)
-template <int NOPS> struct HashOpsGeo { static constexpr int groups = (NOPS == 2 ? 2040 : 1456) * 8 / kTagW, cap = groups * kTagW, fill = NOPS == 2 ? 6144 : 4608; };
+template <int NOPS> struct HashOpsGeo { static constexpr int groups = (NOPS == 2 ? 2040 : 1456) * 8 / kTagWOps, cap = groups * kTagWOps, fill = NOPS == 2 ? 6144 : 4608; };
 __device__ __forceinline__ void op32_atomic(int vop, uint32_t *slot, uint32_t x)
 {
     if (vop == VOP_U32SUM) atomicAdd(slot, x);
@@ -1757,25 +1764,20 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash_ops_kernel(
     const int op_a = (int)(ops & 255u), op_b = (int)((ops >> 8) & 255u), op_c = (int)((ops >> 16) & 255u);
     const uint32_t id_a = (uint32_t)vop_identity(op_a), id_b = (uint32_t)vop_identity(op_b), id_c = (uint32_t)vop_identity(op_c);
     for (int i = threadIdx.x; i < kCap; i += blockDim.x) { t_a[i] = id_a; t_b[i] = id_b; if constexpr (NOPS == 3) t_c[i] = id_c; }
-    for (int i = threadIdx.x; i < kCap / 2; i += blockDim.x) t_tagw[i] = TagGroups::kEmpty2;
+    for (int i = threadIdx.x; i < kCap / 2; i += blockDim.x) t_tagw[i] = 0xFFFFFFFFu;
     if (threadIdx.x == 0) { s_used = 0u; s_emit = 0u; }
     __syncthreads();
     bool overflow = false;
     constexpr int kNP = 8;
-    TagGroups tg;
+    TagGroups<kTagWOps> tg;
     tg.init(t_tagw, (uint32_t)kGroups, lowbits);                         // 1536 / 1152 groups: 13-bit remainders with 512 buckets, a key lives <= 3 groups past its home
     auto hit = [&](uint32_t slot, uint32_t x) {
         op32_atomic(op_a, &t_a[slot], x); op32_atomic(op_b, &t_b[slot], x);
         if constexpr (NOPS == 3) op32_atomic(op_c, &t_c[slot], x);
     };
-    auto slow = [&](uint32_t tv, uint32_t g, uint32_t x) {
-        bool claimed;
-        const int slot = tg.locate(tv, g, &s_used, (uint32_t)kFill, claimed);
-        if (slot >= 0) hit((uint32_t)slot, x); else overflow = true;
-    };
     walk_pair_slabs(pbuf, counts, cap, nwg, b, [&](const uint32_t (&key)[kNP], const uint32_t (&vb)[kNP], uint32_t live, bool full) -> bool {
-        if (full && !Rmask) tag_probe_step<true>(tg, key, vb, live, lowmask, Rmask, r, hit, slow);
-        else tag_probe_step<false>(tg, key, vb, live, lowmask, Rmask, r, hit, slow);
+        if (full && !Rmask) tag_probe_step<true>(tg, key, vb, live, lowmask, Rmask, r, &s_used, (uint32_t)kFill, overflow, hit);
+        else tag_probe_step<false>(tg, key, vb, live, lowmask, Rmask, r, &s_used, (uint32_t)kFill, overflow, hit);
         return !__any(overflow);
     });
     if (overflow) *err = kErrOverflow;
