@@ -1564,7 +1564,10 @@ struct TagGroups {
 // of pair positions at which some lane missed).  A round's budget of distinct keys (*used <= fill) is looked at once per step
 // that claimed.  FULL (wave-uniform): every pair of the step is live and the round takes every key, so no pair carries a
 // predicate of its own.  Sets overflow when a key found no room or the budget is spent (the round is void then).
-template <bool FULL, typename TG, typename HIT>
+// BATCH: the hits of a step are handed over together, the located pairs among them -- hit(slots[8], values[8], mask of the pairs
+// with a slot) -- for a consumer whose operators are run-time values (the reference entry's): it branches on an operator once
+// per step, not once per pair.
+template <bool FULL, bool BATCH = false, typename TG, typename HIT>
 __device__ __forceinline__ void tag_probe_step(const TG &tg, const uint32_t (&key)[8], const uint32_t (&vb)[8], uint32_t live,
                                                uint32_t lowmask, uint32_t Rmask, uint32_t r, uint32_t *used, uint32_t fill, bool &overflow, HIT &&hit)
 {
@@ -1576,29 +1579,38 @@ __device__ __forceinline__ void tag_probe_step(const TG &tg, const uint32_t (&ke
     }
 #pragma unroll
     for (int j = 0; j < 8; j++) q[j] = tg.read(g[j]);                        // eight independent LDS reads in flight
-    uint32_t miss = 0;
+    uint32_t miss = 0, slots[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         const int p = TG::find(q[j], t2[j]);
         miss |= (uint32_t)p & (0x100u << j);                                  // p = -1: every bit (a found p is below 32)
-        if (FULL ? p >= 0 : (p >= 0 && ((live >> j) & 1u))) hit(TG::W * g[j] + TG::slot_of(p), vb[j]);
+        if constexpr (BATCH) slots[j] = TG::W * g[j] + TG::slot_of(p);
+        else if (FULL ? p >= 0 : (p >= 0 && ((live >> j) & 1u))) hit(TG::W * g[j] + TG::slot_of(p), vb[j]);
     }
     miss >>= 8;
+    uint32_t ok = (FULL ? 0xFFu : live) & ~miss;                              // (BATCH) the pairs whose slot is known
     if (!FULL) miss &= live;
-    if (!__any(miss != 0u)) return;
-    bool claimed = false;
-    do {
-        const int first = miss ? __ffs((int)miss) - 1 : -1;
-        uint32_t tj = 0u, gj = 0u, vj = 0u;
+    if (__any(miss != 0u)) {
+        bool claimed = false;
+        do {
+            const int first = miss ? __ffs((int)miss) - 1 : -1;
+            uint32_t tj = 0u, gj = 0u, vj = 0u;
 #pragma unroll
-        for (int j = 0; j < 8; j++) if (j == first) { tj = t2[j] & 0xFFFFu; gj = g[j]; vj = vb[j]; }
-        if (miss) {
-            const int slot = tg.locate(tj, gj, used, claimed);
-            if (slot >= 0) hit((uint32_t)slot, vj); else overflow = true;
-            miss &= miss - 1u;
-        }
-    } while (__any(miss != 0u));
-    if (__any(claimed) && *used > fill) overflow = true;
+            for (int j = 0; j < 8; j++) if (j == first) { tj = t2[j] & 0xFFFFu; gj = g[j]; if constexpr (!BATCH) vj = vb[j]; }
+            if (miss) {
+                const int slot = tg.locate(tj, gj, used, claimed);
+                if (slot < 0) overflow = true;
+                else if constexpr (BATCH) {                                   // joins the step's hits
+#pragma unroll
+                    for (int j = 0; j < 8; j++) if (j == first) slots[j] = (uint32_t)slot;
+                    ok |= 1u << first;
+                } else hit((uint32_t)slot, vj);
+                miss &= miss - 1u;
+            }
+        } while (__any(miss != 0u));
+        if (__any(claimed) && *used > fill) overflow = true;
+    }
+    if constexpr (BATCH) hit(slots, vb, ok);
 }
 
 template <int VOP>
@@ -1610,7 +1622,7 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash_kernel(
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     u64 *t_val = reinterpret_cast<u64 *>(lds_raw);                       // [kHashCap]
     uint32_t *t_cnt = reinterpret_cast<uint32_t *>(t_val + kHashCap);    // [kHashCap] rows
-    uint32_t *t_tagw = t_cnt + kHashCap;                                 // [kHashCap / 2] 16-bit tags, two per word, eight per 16-byte group (0 = empty)
+    uint32_t *t_tagw = t_cnt + kHashCap;                                 // [kHashCap / 2] 16-bit tags, two per word (TagGroups; 0xFFFF = empty)
     __shared__ uint32_t s_used, s_emit;
     __shared__ unsigned long long s_base;
     const uint32_t b = blockIdx.x;
@@ -1621,25 +1633,22 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash_kernel(
     if (threadIdx.x == 0) { s_used = 0u; s_emit = 0u; }
     __syncthreads();
     bool overflow = false;
-    // What the kernel costs (profiles/r04_notes.md 3, r05_notes.md 2): the stream of pairs 0.34 ms per 2.5e8; the rest is the LDS --
-    // round 4's counters of the 32-bit-tag version: LDS arrays busy 72 % of the kernel's cycles, 59 % of them bank-conflict
-    // cycles, and tools/hashlds.hip prices the LDS work of a probe alone: two ds_read_b128 (eight 32-bit tags) + ds_add_f64 +
-    // ds_add_u32 at random addresses 170 cycles per 64 pairs, ONE ds_read_b128 + the same atomics 112 (reads and atomics
-    // cost more together than apart, whatever their order: pipelined and barrier-separated variants measure the same).
-    // Hence 16-BIT tags, eight to a 16-byte group: a probe is ONE ds_read_b128.  mix32 is a bijection and a bucket holds the keys
-    // with one value of its top bits, so the low `lowbits` bits x of mix32(key) ARE the key inside the bucket; its home group is
-    // the top 10 bits of x (1024 groups) and the tag the remaining rembits = lowbits - 10 <= 14 bits + 1 (0 = empty).  A key whose
-    // home group is full of other keys (2048 keys per bucket: Poisson(2) per group, > 8 in 0.024 % of the groups -- ~125 groups
-    // of a 2^20-key table) lives in the first of the next groups that had room when it came, its distance d in the tag bits
-    // above the remainder (d <= 3; a first version allowed d = 1 only and met a pair of
-    // full neighbours in one table of seven -- a second round for a whole statement); a lookup walks the same groups, all full
-    // up to the key's.  A round in which every one of them is full reports an overflow (the caller halves the keys per round).
-    // A probe finds its key in the home group without a branch; anything else -- a new key, a displaced key -- takes the
-    // slow path, which hardly a wave sees once the table is built.
+    // What the kernel costs (profiles/r04_notes.md 3, r05_notes.md 2): the stream of pairs 0.30 ms per 2.5e8; the rest is the LDS and
+    // the instructions around it.  Round 4's counters of the 32-bit-tag version: LDS arrays busy 72 % of the kernel's cycles, 59 %
+    // of them bank-conflict cycles.  tools/hashlds.hip prices the LDS work of a probe alone, per 64 pairs at random addresses:
+    // two ds_read_b128 (eight 32-bit tags: round 4) 60 cycles, ONE ds_read_b128 25, one ds_read_b64 9; ds_add_f64 21, ds_add_u32
+    // 7 -- and the costs add up (b128 + f64 + u32 = 53, b64 + f64 + u32 = 39 = 0.25 ms per 2.5e8 pairs: below the stream).
+    // Hence 16-BIT tags, FOUR to an 8-byte group (TagGroups: the layout, the branch-free search and what happens to a key
+    // whose home group is full of other keys); 2816 groups, so a round's <= 3072 keys (2048 of a 2^20-key table in 512
+    // buckets) leave a group 0.7 keys on average: five or more in 0.09 % of the groups.  A probe finds its key in the
+    // home group without a branch; anything else -- a new key, a displaced key -- takes the slow path, half a pair per step of
+    // 512 once the table is built.  The sequence of the round: 32-bit tags in groups of eight 1.465 ms per 5e8 pairs; 16-bit
+    // tags, eight to a group 1.15; the branch-free search and a multiplicative home group (~30 vector instructions per pair
+    // where there were ~60) 1.04; groups of four 0.97.
     constexpr int kNP = 8;
     constexpr uint32_t kGroups = (uint32_t)kHashGroups;
     TagGroups<kTagW> tg;
-    tg.init(t_tagw, kGroups, lowbits);                                   // 1024 groups: D = 2^(lowbits - 10), the division is a shift in effect
+    tg.init(t_tagw, kGroups, lowbits);
     auto hit = [&](uint32_t slot, uint32_t vbits) { vop_atomic<VOP>(&t_val[slot], VOP == VOP_F32SUM ? vbits : apply_xf(xf, vbits)); atomicAdd(&t_cnt[slot], 1u); };
     walk_pair_slabs(pbuf, counts, cap, nwg, b, [&](const uint32_t (&key)[kNP], const uint32_t (&vb)[kNP], uint32_t live, bool full) -> bool {
         if (full && !Rmask) tag_probe_step<true>(tg, key, vb, live, lowmask, Rmask, r, &s_used, (uint32_t)kHashFill, overflow, hit);
@@ -1672,8 +1681,8 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash_kernel(
 // on the edge: a failed first round, a sample round and two rounds -- measured 4.66 ms against 4.0 ms for three separate
 // passes).  Rounds 3-4: 32-bit tags, 24 bytes per entry, 5120 entries in 640 groups of eight (120 KiB).
 // VK: 0 = f32 values (f64 sum), 1 = i32 (sum of the biased values, like XF_I32_ORDER), 2 = u32.
-// (round 5: 16-bit tags -- TagGroups, 22 bytes per entry -- 928 groups of eight in the same 160 KiB instead of 640: 2.2 keys per group
-// for 2^20 keys in 512 buckets instead of 3.2, and one ds_read_b128 per probe.)
+// (round 5: 16-bit tags -- TagGroups, 22 bytes per entry -- 7424 entries in the same 160 KiB instead of 5120, in 1856 groups of four:
+// 1.1 keys per group for 2^20 keys in 512 buckets, and one ds_read_b64 per probe.)
 constexpr int kHashSGroups = 928 * 8 / kTagW, kHashSCap = kHashSGroups * kTagW, kHashSFill = 2560;
 template <int VK>
 __global__ __launch_bounds__(1024) void fgb_agg_hash_stats_kernel(
@@ -1754,7 +1763,7 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash_ops_kernel(
 {
     constexpr int kCap = HashOpsGeo<NOPS>::cap, kGroups = HashOpsGeo<NOPS>::groups, kFill = HashOpsGeo<NOPS>::fill;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    uint32_t *t_tagw = reinterpret_cast<uint32_t *>(lds_raw);            // [kCap / 2] 16-bit tags (TagGroups), 0 = empty
+    uint32_t *t_tagw = reinterpret_cast<uint32_t *>(lds_raw);            // [kCap / 2] 16-bit tags (TagGroups), 0xFFFF = empty
     uint32_t *t_a = t_tagw + kCap / 2, *t_b = t_a + kCap, *t_c = t_b + kCap;   // [kCap] each; t_c with three operators only
     __shared__ uint32_t s_used, s_emit;
     __shared__ unsigned long long s_base;
@@ -1770,14 +1779,37 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash_ops_kernel(
     bool overflow = false;
     constexpr int kNP = 8;
     TagGroups<kTagWOps> tg;
-    tg.init(t_tagw, (uint32_t)kGroups, lowbits);                         // 1536 / 1152 groups: 13-bit remainders with 512 buckets, a key lives <= 3 groups past its home
-    auto hit = [&](uint32_t slot, uint32_t x) {
-        op32_atomic(op_a, &t_a[slot], x); op32_atomic(op_b, &t_b[slot], x);
-        if constexpr (NOPS == 3) op32_atomic(op_c, &t_c[slot], x);
+    tg.init(t_tagw, (uint32_t)kGroups, lowbits);                         // 2040 / 1456 groups of eight
+    // The operators are run-time values: a step's hits are applied operator by operator, one (uniform) branch per operator and
+    // step -- with a branch chain per pair and operator the kernel took 301 us per 1e8 pairs, with the operators compiled in 252.
+    struct Hit {
+        uint32_t *t_a, *t_b, *t_c; int op_a, op_b, op_c;
+        static __device__ __forceinline__ void all(int vop, uint32_t *t, const uint32_t (&slots)[8], const uint32_t (&x)[8], uint32_t ok)
+        {
+            if (vop == VOP_U32SUM) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) if ((ok >> j) & 1u) atomicAdd(&t[slots[j]], x[j]);
+            } else if (vop == VOP_U32MAX) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) if ((ok >> j) & 1u) atomicMax(&t[slots[j]], x[j]);
+            } else if (vop == VOP_U32MIN) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) if ((ok >> j) & 1u) atomicMin(&t[slots[j]], x[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; j++) if ((ok >> j) & 1u) op32_atomic(vop, &t[slots[j]], x[j]);
+            }
+        }
+        __device__ __forceinline__ void operator()(const uint32_t (&slots)[8], const uint32_t (&x)[8], uint32_t ok) const   // a step's hits
+        {
+            all(op_a, t_a, slots, x, ok); all(op_b, t_b, slots, x, ok);
+            if constexpr (NOPS == 3) all(op_c, t_c, slots, x, ok);
+        }
     };
+    const Hit hit{t_a, t_b, t_c, op_a, op_b, op_c};
     walk_pair_slabs(pbuf, counts, cap, nwg, b, [&](const uint32_t (&key)[kNP], const uint32_t (&vb)[kNP], uint32_t live, bool full) -> bool {
-        if (full && !Rmask) tag_probe_step<true>(tg, key, vb, live, lowmask, Rmask, r, &s_used, (uint32_t)kFill, overflow, hit);
-        else tag_probe_step<false>(tg, key, vb, live, lowmask, Rmask, r, &s_used, (uint32_t)kFill, overflow, hit);
+        if (full && !Rmask) tag_probe_step<true, true>(tg, key, vb, live, lowmask, Rmask, r, &s_used, (uint32_t)kFill, overflow, hit);
+        else tag_probe_step<false, true>(tg, key, vb, live, lowmask, Rmask, r, &s_used, (uint32_t)kFill, overflow, hit);
         return !__any(overflow);
     });
     if (overflow) *err = kErrOverflow;
