@@ -445,6 +445,13 @@ def w_refgb_hash(torch, eng, dev, scale=1.0):
             "info": {"statement": "query_groupby(db, 0, [1, 1], [sum, max]) (main.fut:9), 2^21 distinct u32 keys spread over [0, 2^32)"}}
 
 
+def w_refgb_hash1(torch, eng, dev, scale=1.0):
+    w = w_refgb_hash(torch, eng, dev, scale)
+    th, n8 = w["keep"][0], w["rows"]
+    return {"run": lambda: eng.query_groupby(th, 0, [1], [2]), "bytes": lambda r: 8.0 * n8, "rows": n8, "keep": (th,),
+            "info": {"statement": "query_groupby(db, 0, [1], [sum]) (main.fut:9), 2^21 distinct u32 keys spread over [0, 2^32)"}}
+
+
 def w_sort(torch, eng, dev, scale=1.0, bits=20):
     n8 = int(1e8 * scale) // 4 * 4
     au = _gen_i32(torch, eng, dev, SEED + 9, n8, 1 << 16)
@@ -526,7 +533,7 @@ def w_sparse_five(torch, eng, dev, scale=1.0):
             "info": {"statement": "SELECT k,SUM(v),MAX(v),MIN(v),AVG(v),COUNT(*) FROM t WHERE p>0.5 GROUP BY k -- 2^20 sparse i32 keys", "groups": w["info"]["groups"]}}
 
 
-WORKLOADS = {"sparse_five": w_sparse_five, "c1": w_c1, "c2": w_c2, "refgb": w_refgb, "refgb_hash": w_refgb_hash, "join_u32": w_join_u32, "join_c4": w_join_c4, "sparse_gb": w_sparse_gb,
+WORKLOADS = {"sparse_five": w_sparse_five, "c1": w_c1, "c2": w_c2, "refgb": w_refgb, "refgb_hash": w_refgb_hash, "refgb_hash1": w_refgb_hash1, "join_u32": w_join_u32, "join_c4": w_join_c4, "sparse_gb": w_sparse_gb,
              "sort20": lambda *a: w_sort(*a, bits=20), "sort32": lambda *a: w_sort(*a, bits=31), "sort64": lambda *a: w_sort(*a, bits=64)}
 
 

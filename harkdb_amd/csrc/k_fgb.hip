@@ -37,8 +37,9 @@
 //         table with plain stores (it owns the key range).
 //   HASH  arbitrary u32 keys: the producer routes by the top bits of
 //         mix32(key), one workgroup per bucket builds an open-addressing
-//         table in LDS (fgb_agg_hash_kernel: 16-byte entries with row
-//         counts; fgb_agg_hash8_kernel: 8-byte entries for the reference's
+//         table in LDS (fgb_agg_hash_kernel: value slot, row count and a
+//         16-bit tag per entry; fgb_agg_hash_stats_kernel: five aggregates of
+//         one column; fgb_agg_hash_ops_kernel: one to three of the reference's
 //         u32 operators), in several rounds when a bucket holds more distinct
 //         keys than a table.
 //   ATOM  one global atomic pair per surviving row; the fallback for slab
@@ -1740,14 +1741,14 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash_stats_kernel(
     }
 }
 
-// Two or three of the reference's u32 operators (groupby.fut:35-41) over ONE value column from one pass over its pairs:
-// an entry is a tag and one 32-bit slot per operator -- 12 B in 1536 groups of eight (144 KiB) or 16 B in 1152 groups
-// (144 KiB), half of them used per round (6144 / 4608 distinct keys per bucket: 2^21 keys in 512 buckets take ONE round) --
+// One, two or three of the reference's u32 operators (groupby.fut:35-41) over ONE value column from one pass over its pairs:
+// an entry is a 16-bit tag and one 32-bit slot per operator -- 6, 10 or 14 B in 3408 / 2040 / 1456 groups of eight (160 KiB) --
+// and a round takes 8192 / 6144 / 4608 distinct keys per bucket (2^21 keys in 512 buckets: ONE round, two keys per group),
 // instead of one consumer pass and one sort of the result keys per operator.  ops: operator of slot j in byte j
-// (VOP_U32SUM / MAX / MIN / PROD).  Emits slot 0 | slot 1 << 32 as the value word and slot 2 as the count word.
-// (round 5: 16-bit tags -- 10 or 14 bytes per entry -- let the same 160 KiB hold 2040 / 1456 groups instead of 1536 / 1152; the keys per
-// round stay at 6144 / 4608, so a group holds 3.0 / 3.2 keys on average when a round is full and 2.0 / 2.8 for the 2^21 keys of the bench line)
-template <int NOPS> struct HashOpsGeo { static constexpr int groups = (NOPS == 2 ? 2040 : 1456) * 8 / kTagWOps, cap = groups * kTagWOps, fill = NOPS == 2 ? 6144 : 4608; };
+// (VOP_U32SUM / MAX / MIN / PROD).  Emits slot 0 | slot 1 << 32 as the value word and slot 2 as the count word (one
+// operator: the value word only).  (Rounds 3-4 kept a single operator in 8-byte entries, value << 32 | tag, with one 64-bit
+// atomic per row and two ds_read_b128 per probe: 435 us per 1e8 pairs against 245 for this kernel with one slot per entry.)
+template <int NOPS> struct HashOpsGeo { static constexpr int groups = (NOPS == 1 ? 3408 : NOPS == 2 ? 2040 : 1456) * 8 / kTagWOps, cap = groups * kTagWOps, fill = NOPS == 1 ? 8192 : NOPS == 2 ? 6144 : 4608; };
 __device__ __forceinline__ void op32_atomic(int vop, uint32_t *slot, uint32_t x)
 {
     if (vop == VOP_U32SUM) atomicAdd(slot, x);
@@ -1772,7 +1773,7 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash_ops_kernel(
     const uint32_t lowmask = (1u << lowbits) - 1u;
     const int op_a = (int)(ops & 255u), op_b = (int)((ops >> 8) & 255u), op_c = (int)((ops >> 16) & 255u);
     const uint32_t id_a = (uint32_t)vop_identity(op_a), id_b = (uint32_t)vop_identity(op_b), id_c = (uint32_t)vop_identity(op_c);
-    for (int i = threadIdx.x; i < kCap; i += blockDim.x) { t_a[i] = id_a; t_b[i] = id_b; if constexpr (NOPS == 3) t_c[i] = id_c; }
+    for (int i = threadIdx.x; i < kCap; i += blockDim.x) { t_a[i] = id_a; if constexpr (NOPS >= 2) t_b[i] = id_b; if constexpr (NOPS == 3) t_c[i] = id_c; }
     for (int i = threadIdx.x; i < kCap / 2; i += blockDim.x) t_tagw[i] = 0xFFFFFFFFu;
     if (threadIdx.x == 0) { s_used = 0u; s_emit = 0u; }
     __syncthreads();
@@ -1802,7 +1803,8 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash_ops_kernel(
         }
         __device__ __forceinline__ void operator()(const uint32_t (&slots)[8], const uint32_t (&x)[8], uint32_t ok) const   // a step's hits
         {
-            all(op_a, t_a, slots, x, ok); all(op_b, t_b, slots, x, ok);
+            all(op_a, t_a, slots, x, ok);
+            if constexpr (NOPS >= 2) all(op_b, t_b, slots, x, ok);
             if constexpr (NOPS == 3) all(op_c, t_c, slots, x, ok);
         }
     };
@@ -1826,121 +1828,9 @@ __global__ __launch_bounds__(1024) void fgb_agg_hash_ops_kernel(
         const unsigned long long o = s_base + pos++;
         if (o < out_cap) {
             out_key[o] = unmix32((b << lowbits) | tg.identity((uint32_t)i, t));
-            out_val[o] = (u64)t_a[i] | ((u64)t_b[i] << 32);
-            out_cnt[o] = NOPS == 3 ? (u64)t_c[i] : 0ull;
+            if constexpr (NOPS == 1) out_val[o] = (u64)t_a[i];                 // (no count array with one operator)
+            else { out_val[o] = (u64)t_a[i] | ((u64)t_b[i] << 32); out_cnt[o] = NOPS == 3 ? (u64)t_c[i] : 0ull; }
         } else *err = kErrOverflow;
-    }
-}
-
-// Compact hash consumer for the reference's u32 operators (groupby.fut:35-41: wrapping * and +, max, min; no row
-// counts): an entry is ONE 64-bit word, value << 32 | occupied << 24 | low 24 bits of mix32(key).  Inside bucket b the
-// top log2(P) >= 8 bits of mix32(key) are b, and mix32 is a bijection, so 24 bits identify the key (it is rebuilt by unmix32 at
-// emit time).  Twice the entries per workgroup (16384 in 128 KiB, 6144 used per round) and one LDS atomic per row:
-// ds_add_u64 of value << 32 wraps exactly like u32 addition, ds_max_u64 / ds_min_u64 order the words by value because
-// the low half is the same for every update of a slot, and a claim stores the first value, so no identity is needed.
-constexpr int kHash8Cap = 16384;
-constexpr int kHash8Fill = 6144;
-
-template <int VOP>
-__global__ __launch_bounds__(1024) void fgb_agg_hash8_kernel(
-    const uint2 *__restrict__ pbuf, const uint32_t *__restrict__ counts, uint32_t cap, int nwg, uint32_t Rmask, uint32_t r,
-    uint32_t *__restrict__ out_key, u64 *__restrict__ out_val, unsigned long long *__restrict__ out_cursor,
-    unsigned long long out_cap, int32_t *__restrict__ err)
-{
-    static_assert(VOP == VOP_U32SUM || VOP == VOP_U32MAX || VOP == VOP_U32MIN || VOP == VOP_U32PROD, "u32 operators only");
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    u64 *tab = reinterpret_cast<u64 *>(lds_raw);
-    __shared__ uint32_t s_used, s_emit;
-    __shared__ unsigned long long s_base;
-    const uint32_t b = blockIdx.x;
-    for (int i = threadIdx.x; i < kHash8Cap; i += blockDim.x) tab[i] = 0ull;
-    if (threadIdx.x == 0) { s_used = 0u; s_emit = 0u; }
-    __syncthreads();
-    bool overflow = false;
-    auto update = [&](uint32_t h, u64 tag, uint32_t v, u64 seen) {        // the slot holds our key
-        if constexpr (VOP == VOP_U32SUM) atomicAdd(&tab[h], (u64)v << 32);
-        else if constexpr (VOP == VOP_U32MAX) atomicMax(&tab[h], tag | ((u64)v << 32));
-        else if constexpr (VOP == VOP_U32MIN) atomicMin(&tab[h], tag | ((u64)v << 32));
-        else {
-            u64 old = seen;
-            for (;;) {
-                const u64 want = tag | ((u64)((uint32_t)(old >> 32) * v) << 32);
-                const u64 got = atomicCAS(&tab[h], old, want);
-                if (got == old) break;
-                old = got;
-            }
-        }
-    };
-    // kNP pairs per lane are probed together and the slots are grouped in FOURS (32 bytes: two ds_read_b128 find a key in its
-    // home group without a branch) -- see fgb_agg_hash_kernel for what the per-pair probe loops cost.
-    constexpr int kNP = 8;
-    constexpr uint32_t kGroups = kHash8Cap / 4;
-    const uint4 *tab4 = reinterpret_cast<const uint4 *>(tab);
-    struct Ent4 { uint4 a, b; };                                             // entries 0, 1 | 2, 3 of a group (low word: occupied << 24 | tag, high word: value)
-    auto load4 = [&](uint32_t g) -> Ent4 { return Ent4{tab4[2u * g], tab4[2u * g + 1u]}; };
-    auto find4 = [](const Ent4 &q, uint32_t t) -> int {                      // t = the low 25 bits looked for (0: an empty entry -- its whole word is 0)
-        return (q.a.x & 0x1FFFFFFu) == t ? 0 : (q.a.z & 0x1FFFFFFu) == t ? 1 : (q.b.x & 0x1FFFFFFu) == t ? 2 : (q.b.z & 0x1FFFFFFu) == t ? 3 : -1;
-    };
-    auto word_of = [](const Ent4 &q, int i) -> u64 {
-        const uint32_t lo = i == 0 ? q.a.x : i == 1 ? q.a.z : i == 2 ? q.b.x : q.b.z, hi = i == 0 ? q.a.y : i == 1 ? q.a.w : i == 2 ? q.b.y : q.b.w;
-        return ((u64)hi << 32) | lo;
-    };
-    auto slow = [&](u64 tag, uint32_t g, Ent4 q, uint32_t v) {
-        for (uint32_t step = 0; step < 4u * kGroups; step++) {
-            const int at = find4(q, (uint32_t)tag);
-            if (at >= 0) { update(4u * g + (uint32_t)at, tag, v, word_of(q, at)); return; }
-            const int e = find4(q, 0u);
-            if (e >= 0) {
-                if (s_used >= (uint32_t)kHash8Fill) { overflow = true; return; }
-                const u64 old = atomicCAS(&tab[4u * g + (uint32_t)e], 0ull, tag | ((u64)v << 32));     // the claim carries the first value
-                if (old == 0ull) { atomicAdd(&s_used, 1u); return; }
-                if ((old & 0x1FFFFFFull) == tag) { update(4u * g + (uint32_t)e, tag, v, old); return; }
-            } else g = (g + 1u) & (kGroups - 1u);                             // a full group of other keys
-            q = load4(g);
-        }
-        overflow = true;
-    };
-    auto probe = [&](const uint32_t (&key)[kNP], const uint32_t (&vv)[kNP], uint32_t live) {
-        u64 tag[kNP]; uint32_t g[kNP]; Ent4 q[kNP];
-#pragma unroll
-        for (int j = 0; j < kNP; j++) {
-            const uint32_t m = key[j];                                        // the producer wrote mix32(key)
-            tag[j] = (u64)(m & 0xFFFFFFu) | (1ull << 24);
-            g[j] = (m * 0x9E3779B1u) >> 20;                                  // 12 bits (kGroups)
-            if (Rmask && (mix32(key[j] ^ 0x9E3779B9u) & Rmask) != r) live &= ~(1u << j);   // not this round's share of the key space
-        }
-#pragma unroll
-        for (int j = 0; j < kNP; j++) q[j] = load4(g[j]);
-        uint32_t miss = 0;
-#pragma unroll
-        for (int j = 0; j < kNP; j++) {
-            const int at = find4(q[j], (uint32_t)tag[j]);
-            if ((live >> j) & 1u) { if (at >= 0) update(4u * g[j] + (uint32_t)at, tag[j], vv[j], word_of(q[j], at)); else miss |= 1u << j; }
-        }
-        if (__any(miss != 0u)) {
-#pragma unroll
-            for (int j = 0; j < kNP; j++) if ((miss >> j) & 1u) slow(tag[j], g[j], q[j], vv[j]);
-        }
-    };
-    walk_pair_slabs(pbuf, counts, cap, nwg, b, [&](const uint32_t (&key)[kNP], const uint32_t (&vv)[kNP], uint32_t live, bool) -> bool {
-        probe(key, vv, live);
-        return !__any(overflow);                                             // an overflowed round is void anyway: stop reading
-    });
-    if (overflow) *err = kErrOverflow;
-    __syncthreads();
-    uint32_t mine = 0;
-    for (int i = threadIdx.x; i < kHash8Cap; i += blockDim.x) mine += tab[i] ? 1u : 0u;
-    uint32_t pos = mine ? atomicAdd(&s_emit, mine) : 0u;
-    __syncthreads();
-    if (threadIdx.x == 0) s_base = s_emit ? atomicAdd(out_cursor, (unsigned long long)s_emit) : 0ull;
-    __syncthreads();
-    for (int i = threadIdx.x; i < kHash8Cap; i += blockDim.x) {
-        const u64 e = tab[i];
-        if (!e) continue;
-        const unsigned long long o = s_base + pos++;
-        // the bucket is the top log2(P) bits of mix32(key) (P = gridDim.x, a power of two), the tag its low 24 bits
-        if (o < out_cap) { const int lowbits = 33 - __ffs((int)gridDim.x); out_key[o] = unmix32((b << lowbits) | ((uint32_t)(e & 0xFFFFFFu) & ((1u << lowbits) - 1u))); out_val[o] = e >> 32; }
-        else *err = kErrOverflow;
     }
 }
 
@@ -2623,7 +2513,7 @@ int hark_fgb_finish_typed_from(hark_context *ctx, hark_fgb_plan *pl, int32_t whi
 int k_fgb_hash_u32(hark_context *ctx, const uint32_t *k, const uint32_t *v, int64_t n, int vop, int xf,
                    uint32_t **keys_out, unsigned long long **vals_out, unsigned long long **cnts_out, int64_t *G_out, bool *fits,
                    uint32_t *rounds_hint /* in: 0 or the R a previous pass over the SAME key column needed; out: the R used */,
-                   bool compact /* u32 operators without row counts: 8-byte entries (fgb_agg_hash8_kernel); *cnts_out stays null */,
+                   bool compact /* ONE u32 operator without row counts (fgb_agg_hash_ops_kernel<1>); *cnts_out stays null */,
                    hark_hash_part *part /* optional: the partition of (k, v) is kept in it / taken from it (see hark_internal.h) */,
                    int *why_not /* optional: why *fits is false -- HARK_HASH_NOFIT_* (hark_internal.h) */,
                    const hark_row_pred *pred /* optional WHERE, fused into the producer: an f32 column with a comparison, or a
@@ -2643,7 +2533,7 @@ int k_fgb_hash_u32(hark_context *ctx, const uint32_t *k, const uint32_t *v, int6
     const float pthr = pred ? pred->thr : 0.0f;
     if (why_not) *why_not = HARK_HASH_FITS;
     if (compact && (xf != 0 || !(vop == VOP_U32SUM || vop == VOP_U32MAX || vop == VOP_U32MIN || vop == VOP_U32PROD))) compact = false;
-    const int fill = stats ? kHashSFill : nops == 2 ? HashOpsGeo<2>::fill : nops == 3 ? HashOpsGeo<3>::fill : compact ? kHash8Fill : kHashFill;
+    const int fill = stats ? kHashSFill : nops == 2 ? HashOpsGeo<2>::fill : nops == 3 ? HashOpsGeo<3>::fill : compact ? HashOpsGeo<1>::fill : kHashFill;
     *keys_out = nullptr; *vals_out = nullptr; *cnts_out = nullptr; *G_out = 0; *fits = false;
     if (n <= 0 || n > 0xFFFFFFFFll) { if (why_not) *why_not = HARK_HASH_NOFIT_ROWS; return HARK_OK; }
     // 512 buckets of 32-pair rings (256 x 64 before): half as many distinct keys per bucket -- 2^21 distinct keys fit ONE
@@ -2737,11 +2627,12 @@ int k_fgb_hash_u32(hark_context *ctx, const uint32_t *k, const uint32_t *v, int6
             r2 = dispatch_vop(vop, [&](auto vopc) -> int {
                 constexpr int VOP = decltype(vopc)::value;
                 if constexpr (VOP == VOP_U32SUM || VOP == VOP_U32MAX || VOP == VOP_U32MIN || VOP == VOP_U32PROD) {
-                    if (compact) {
-                        const size_t lds8 = (size_t)kHash8Cap * 8;
-                        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_agg_hash8_kernel<VOP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
+                    if (compact) {                                            // one operator: the multi-operator consumer with one slot per entry (round 5:
+                                                                              // 245 us per 1e8 pairs; the 8-byte-entry consumer it replaces took 435)
+                        const size_t lds_o = (size_t)HashOpsGeo<1>::cap * 6;
+                        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_agg_hash_ops_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_o));
                         for (uint32_t r = r_begin; r < r_end; r++)
-                            fgb_agg_hash8_kernel<VOP><<<dim3((unsigned)P), dim3(1024), lds8, st>>>(pbuf, counts, (uint32_t)cap, nwg, R - 1, r, okey, oval, cursor, out_cap, err);
+                            fgb_agg_hash_ops_kernel<1><<<dim3((unsigned)P), dim3(1024), lds_o, st>>>(pbuf, counts, (uint32_t)cap, nwg, R - 1, r, okey, oval, nullptr, cursor, out_cap, err, (uint32_t)VOP);
                         HIP_TRY(ctx, hipGetLastError());
                         return HARK_OK;
                     }

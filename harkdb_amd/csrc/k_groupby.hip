@@ -1602,7 +1602,7 @@ int ref_groupby_hash(hark_context *ctx, const hark_table *view, const hark_table
     int why = HARK_HASH_FITS;
     auto vop_of = [&](size_t j) { return aggs.empty() ? 3 : aggs[j].op == OP_SUM ? 1 : aggs[j].op == OP_MAX ? 2 : aggs[j].op == OP_MIN ? 3 : 4; };
     // aggregates of one column come from ONE consumer pass, two or three operators at a time (fgb_agg_hash_ops_kernel), with
-    // ONE sort of the result keys per pass; a single operator keeps the 8-byte tables (fgb_agg_hash8_kernel: twice the entries)
+    // ONE sort of the result keys per pass; a single operator runs the same consumer with one slot per entry
     for (size_t oi = 0; oi < runs && !rc && ok; ) {
         size_t cnt = 1;
         if (!aggs.empty() && !getenv("HARK_NO_HASH_OPS_PASS"))
