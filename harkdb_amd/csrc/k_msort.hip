@@ -1,0 +1,481 @@
+// k_msort.hip -- ORDER BY / argsort on 64-bit keys: a most-significant-digit-first bucket sort of 16-byte tuples.
+//
+// Replaces, for large tables of well-spread keys, the least-significant-digit-first tuple passes of k_sort.hip
+// (sort_i64_tuples: four radix passes over 16-byte tuples + a run fix-up = five sweeps that read and write 16 B per row, and
+// a histogram pass each: 19.6 GB moved per 1e8 rows, profiles/r04_op_traffic.txt).  The tuples carry the row id, so nothing
+// has to be stable on the way -- (key, row id) is a total order -- and three sweeps do:
+//
+//   msd_sample / msd_setup   bounds of the keys from a sample -> a monotone map key -> bucket d in [0, D), D = 256 * nb2
+//                            (d = ((key - kmin) >> sh) * mul >> 32, clamped: whatever the sample missed lands in the first or
+//                            last bucket, the order of the buckets still is the order of the keys)
+//   msd_hist                 workgroup w counts the level-1 digits (d / nb2) of ITS rows [w S, (w + 1) S): exact sizes of
+//                            the 256 x 256 slabs, so no slab can overflow whatever the order of the input (a sorted column
+//                            sends all rows of a workgroup to one bucket)
+//   msd_part<true>   sweep 1 the same workgroup forms tuples (key ^ xorm, row id, value) from its rows and routes them to its
+//                            slab of their bucket: a tile of 4096 tuples is counting-sorted by digit in LDS, every bucket's
+//                            run leaves in whole 128-byte lines (up to seven tuples per bucket wait in LDS for the next tile)
+//   msd_part<false>  sweep 2 one workgroup per level-1 bucket reads the bucket (its slabs lie one behind the other, padded
+//                            with dead tuples to whole lines) and routes by d % nb2 into regions of fixed capacity, the same way
+//   msd_final        sweep 3 one workgroup per final bucket (<= 3584 tuples): counting sort in LDS by the next 11 bits of the
+//                            map, ranks inside the short runs of equal digits by comparing (key, row id), keys / row ids /
+//                            values written in order
+//
+// Whatever does not fit -- a final bucket over its capacity (heavy duplicates, a lumpy distribution), a long run of one digit
+// -- raises a flag and the caller takes the tuple passes as before (hark's result does not depend on the path).
+#include "hark_internal.h"
+#include <vector>
+#include <cstdio>
+
+typedef unsigned long long u64;
+
+namespace {
+
+constexpr int kT = 1024, kR = 4, kTile = kT * kR;            // partition workgroup: threads, tuples per thread and tile
+constexpr int kB = 256;                                      // buckets per partition level
+constexpr uint32_t kDead = 0xFFFFFFFFu;                      // row id of a padding tuple
+constexpr int kFT = 512, kFR = 7, kFCap = kFT * kFR;         // final workgroup: 3584 tuples at most
+constexpr int kFBins = 2048;
+constexpr int kFRunMax = 64;                                 // longest run of one final digit that is ranked by comparing
+constexpr int kSampleWg = 256;
+
+struct MsdMap { u64 kmin; uint32_t sh, mul, dmax, mul3; u64 q48; };   // mul3, q48: the final digit (msd_final_kernel)
+
+__device__ __forceinline__ uint32_t reduced_key(u64 key, u64 kmin, uint32_t sh)
+{
+    const u64 rel = key > kmin ? key - kmin : 0ull;          // (below the sampled minimum: the first bucket)
+    const u64 h = rel >> sh;
+    return h > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)h;    // (above the sampled maximum: the last bucket)
+}
+__device__ __forceinline__ uint32_t bucket_of(u64 key, const MsdMap &m)
+{
+    const uint32_t d = __umulhi(reduced_key(key, m.kmin, m.sh), m.mul);
+    return d < m.dmax ? d : m.dmax;
+}
+
+// ---- bounds from a sample -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void msd_sample_kernel(const u64 *__restrict__ col, int64_t n, u64 xorm, int64_t stride, u64 *__restrict__ mm)
+{
+    __shared__ u64 s_min[4], s_max[4];
+    u64 lo = ~0ull, hi = 0ull;
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * stride; i < n; i += (int64_t)gridDim.x * 256 * stride) {
+        const u64 k = col[i] ^ xorm;
+        lo = k < lo ? k : lo; hi = k > hi ? k : hi;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && n > 0) { const u64 k = col[n - 1] ^ xorm; lo = k < lo ? k : lo; hi = k > hi ? k : hi; }
+    for (int d = 32; d; d >>= 1) {
+        const u64 l2 = __shfl_xor(lo, d, 64), h2 = __shfl_xor(hi, d, 64);
+        lo = l2 < lo ? l2 : lo; hi = h2 > hi ? h2 : hi;
+    }
+    if ((threadIdx.x & 63) == 0) { s_min[threadIdx.x >> 6] = lo; s_max[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++) { lo = s_min[w] < lo ? s_min[w] : lo; hi = s_max[w] > hi ? s_max[w] : hi; }
+        atomicMin(&mm[0], lo); atomicMax(&mm[1], hi);
+    }
+}
+
+__global__ void msd_setup_kernel(const u64 *__restrict__ mm, uint32_t D, MsdMap *__restrict__ map, int32_t *__restrict__ flag)
+{
+    u64 lo = mm[0], hi = mm[1] >= mm[0] ? mm[1] : mm[0];
+    if (((hi - lo) >> 32) == 0ull) flag[0] = 2;              // keys within 2^32 of each other: the caller's 32-bit paths are the better ones
+    // The sample's extremes are not the column's: one key in `stride` was looked at, so ~stride keys lie below the sampled minimum
+    // (and above the maximum; stride = 509), and clamped to the first bucket's first digit they would be one long run for msd_final to rank.
+    // The map covers 1/64 of the range more on either side: uniform keys then all fall inside it (the outermost buckets stay
+    // emptier), and only true outliers are clamped.
+    const u64 margin = ((hi - lo) >> 6) + 1ull;
+    lo = lo > margin ? lo - margin : 0ull;
+    hi = hi < ~0ull - margin ? hi + margin : ~0ull;
+    const u64 range = hi - lo;                               // the largest relative key
+    uint32_t sh = 0;
+    while ((range >> sh) > 0xFFFFFFFEull) sh++;
+    const u64 r32 = (range >> sh) + 1ull;                    // reduced keys lie in [0, r32), r32 <= 2^32 - 1
+    u64 mul = ((u64)D << 32) / r32;                          // d = h * mul >> 32 < D for h < r32
+    if (mul > 0xFFFFFFFFull) mul = 0xFFFFFFFFull;            // (fewer distinct reduced keys than buckets)
+    // the final digit: a bucket's reduced keys start at about f * 2^32 / mul = f * q48 >> 16 (never above the true start, at most 2
+    // below it) and span at most 2^32 / mul + 1 values, which mul3 spreads over kFBins bins
+    const u64 width = (0x100000000ull / mul) + 1ull;
+    u64 mul3 = ((u64)kFBins << 32) / width; if (mul3 > 0xFFFFFFFFull) mul3 = 0xFFFFFFFFull;
+    map->kmin = lo; map->sh = sh; map->mul = (uint32_t)mul; map->dmax = D - 1u; map->mul3 = (uint32_t)mul3; map->q48 = (1ull << 48) / mul;
+}
+
+// ---- level-1 histogram: exact slab sizes ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kT) void msd_hist_kernel(const u64 *__restrict__ col, int64_t n, int64_t slice, u64 xorm, const MsdMap *__restrict__ mapp,
+                                                      int nb2log, uint32_t *__restrict__ counts1 /* [nwg][256] */, const int32_t *__restrict__ flag)
+{
+    __shared__ uint32_t s_cnt[kB];
+    if (*reinterpret_cast<const volatile int32_t *>(flag)) return;   // (the keys are not for this path: nothing to do)
+    const MsdMap m = *mapp;
+    if (threadIdx.x < kB) s_cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    const int64_t lo = (int64_t)blockIdx.x * slice, hi = lo + slice < n ? lo + slice : n;
+    // eight keys per thread and round in four 16-byte loads, all issued before the first digit is counted (64 KB in flight per CU:
+    // with one 8-byte load per lane the pass ran at the latency of a load, 3.4 TB/s)
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    for (int64_t t0 = lo; t0 < hi; t0 += 8 * kT) {             // (lo and the slices are multiples of the tile: 16-byte aligned pairs)
+        u64x2 k[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int64_t i = t0 + 2 * ((int64_t)q * kT + threadIdx.x);
+            if (i + 1 < hi) k[q] = __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(col + i));
+            else { k[q].x = i < hi ? col[i] : 0ull; k[q].y = 0ull; }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int64_t i = t0 + 2 * ((int64_t)q * kT + threadIdx.x);
+            if (i < hi) atomicAdd(&s_cnt[bucket_of(k[q].x ^ xorm, m) >> nb2log], 1u);
+            if (i + 1 < hi) atomicAdd(&s_cnt[bucket_of(k[q].y ^ xorm, m) >> nb2log], 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < kB) counts1[(size_t)blockIdx.x * kB + threadIdx.x] = s_cnt[threadIdx.x];
+}
+
+// exclusive scan over the 1024 threads of a workgroup (x = this thread's sum); *total = the sum of all
+__device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t x, uint32_t *s_wave /* [16] */, uint32_t *total)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t incl = x;
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d, 64); if (lane >= d) incl += y; }
+    if (lane == 63) s_wave[wv] = incl;
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+    for (int q = 0; q < 16; q++) { const uint32_t v = s_wave[q]; if (q < wv) before += v; all += v; }
+    *total = all;
+    return before + incl - x;
+}
+
+// Slab offsets, bucket-major: bucket b's slabs (workgroup 0 .. nwg - 1) lie one behind the other, every slab padded to whole
+// lines of eight tuples.  off1[w][b] = first tuple of slab (w, b); bstart[b] = first tuple of bucket b, bstart[256] = the end;
+// bfirst[b] = the rows of the buckets before b (where bucket b's rows start in the sorted output).
+__global__ __launch_bounds__(1024) void msd_scan1_kernel(const uint32_t *__restrict__ counts1, int nwg, uint32_t *__restrict__ off1, uint32_t *__restrict__ bstart,
+                                                         uint32_t *__restrict__ bfirst)
+{
+    __shared__ uint32_t s_wave[16], s_wave2[16];
+    // thread t owns the entries [t * per, (t + 1) * per) of the bucket-major order (entry e = b * nwg + w)
+    const int total = kB * nwg, per = (total + 1023) / 1024;
+    uint32_t sum = 0, exact = 0;
+    for (int e = threadIdx.x * per; e < (threadIdx.x + 1) * per && e < total; e++) { const int b = e / nwg, w = e - b * nwg; const uint32_t c = counts1[(size_t)w * kB + b]; sum += (c + 7u) & ~7u; exact += c; }
+    uint32_t all, all2;
+    uint32_t at = block_excl_scan_1024(sum, s_wave, &all);
+    uint32_t ex = block_excl_scan_1024(exact, s_wave2, &all2);
+    if (threadIdx.x == 0) { bstart[kB] = all; bfirst[kB] = all2; }
+    for (int e = threadIdx.x * per; e < (threadIdx.x + 1) * per && e < total; e++) {
+        const int b = e / nwg, w = e - b * nwg;
+        const uint32_t c = counts1[(size_t)w * kB + b];
+        off1[(size_t)w * kB + b] = at;
+        if (w == 0) { bstart[b] = at; bfirst[b] = ex; }
+        at += (c + 7u) & ~7u; ex += c;
+    }
+}
+
+// ---- the partition sweep ------------------------------------------------------------------------------------------------------
+// exclusive scan of 256 counters by one wave (four counters per lane)
+__device__ __forceinline__ void scan256_by_wave(const uint32_t *cnt, uint32_t *base)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t c0 = cnt[4 * lane], c1 = cnt[4 * lane + 1], c2 = cnt[4 * lane + 2], c3 = cnt[4 * lane + 3];
+    uint32_t incl = c0 + c1 + c2 + c3;
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d, 64); if (lane >= d) incl += y; }
+    const uint32_t excl = incl - (c0 + c1 + c2 + c3);
+    base[4 * lane] = excl; base[4 * lane + 1] = excl + c0; base[4 * lane + 2] = excl + c0 + c1; base[4 * lane + 3] = excl + c0 + c1 + c2;
+}
+
+// FIRST: sweep 1 (source = the table's columns, one workgroup per row slice, destination = exact slabs);
+// else sweep 2 (source = a level-1 bucket of tuples, one workgroup per bucket, destination = regions of `cap2` tuples).
+template <bool FIRST>
+__global__ __launch_bounds__(kT) void msd_part_kernel(
+    const u64 *__restrict__ col, const uint32_t *__restrict__ valcol, int64_t n, int64_t slice, u64 xorm,      // FIRST
+    const uint4 *__restrict__ tin, const uint32_t *__restrict__ bstart,                                          // !FIRST
+    const MsdMap *__restrict__ mapp, int nb2log,
+    uint4 *__restrict__ tout, const uint32_t *__restrict__ off1 /* FIRST: [nwg][256] */, uint32_t cap2 /* !FIRST */,
+    uint32_t *__restrict__ counts2 /* !FIRST: [256 << nb2log] */, const uint32_t *__restrict__ bfirst /* !FIRST */, uint32_t *__restrict__ outoff /* !FIRST */,
+    int32_t *__restrict__ flag)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    uint4 *buf = reinterpret_cast<uint4 *>(lds_raw);                       // [kTile] the tile, sorted by digit
+    uint4 *carry = buf + kTile;                                            // [kB][8] up to seven tuples per bucket that wait for a whole line
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(carry + kB * 8);          // [kB] this tile's tuples per bucket
+    uint32_t *base = cnt + kB;                                             // [kB] ... their first slot in buf
+    uint32_t *cur = base + kB;                                             // [kB] tuples written to the bucket's destination so far
+    uint32_t *ncarry = cur + kB;                                           // [kB]
+    if (*reinterpret_cast<const volatile int32_t *>(flag)) return;         // an earlier step gave up
+    const MsdMap m = *mapp;
+    const int nb = FIRST ? kB : (1 << nb2log);                             // buckets of this sweep
+    const uint32_t b1 = blockIdx.x;
+    int64_t lo, hi;
+    if (FIRST) { lo = (int64_t)b1 * slice; hi = lo + slice < n ? lo + slice : n; }
+    else { lo = bstart[b1]; hi = bstart[b1 + 1]; }
+    if (threadIdx.x < kB) { cur[threadIdx.x] = 0u; ncarry[threadIdx.x] = 0u; }
+    auto dest_of = [&](uint32_t b) -> uint4 * {
+        if (FIRST) return tout + off1[(size_t)b1 * kB + b];
+        return tout + ((size_t)(b1 << nb2log) + b) * cap2;
+    };
+    auto load = [&](int64_t t0, uint4 (&t)[kR]) {
+#pragma unroll
+        for (int k = 0; k < kR; k++) {
+            const int64_t i = t0 + (int64_t)k * kT + threadIdx.x;
+            if (FIRST) {
+                if (i < hi) {
+                    const u64 key = __builtin_nontemporal_load(col + i) ^ xorm;
+                    t[k] = uint4{(uint32_t)key, (uint32_t)(key >> 32), (uint32_t)i, valcol ? __builtin_nontemporal_load(valcol + i) : 0u};
+                } else t[k] = uint4{0u, 0u, kDead, 0u};
+            } else t[k] = i < hi ? ld_nt16(tin + i) : uint4{0u, 0u, kDead, 0u};
+        }
+    };
+    bool over = false;
+    uint4 nx[kR];
+    if (lo < hi) load(lo, nx);
+    for (int64_t t0 = lo; t0 < hi; t0 += kTile) {
+        uint4 t[kR];
+#pragma unroll
+        for (int k = 0; k < kR; k++) t[k] = nx[k];
+        if (t0 + kTile < hi) load(t0 + kTile, nx);                         // the next tile's loads are in flight while this one is sorted
+        if (threadIdx.x < kB) cnt[threadIdx.x] = 0u;
+        lds_barrier();
+        uint32_t d[kR], r[kR];
+#pragma unroll
+        for (int k = 0; k < kR; k++) {
+            const uint32_t bk = bucket_of(((u64)t[k].y << 32) | t[k].x, m);
+            d[k] = FIRST ? (bk >> nb2log) : (bk & (uint32_t)(nb - 1));
+            r[k] = t[k].z != kDead ? atomicAdd(&cnt[d[k]], 1u) : 0u;
+        }
+        lds_barrier();
+        if (threadIdx.x < 64) scan256_by_wave(cnt, base);
+        lds_barrier();
+#pragma unroll
+        for (int k = 0; k < kR; k++) if (t[k].z != kDead) buf[base[d[k]] + r[k]] = t[k];
+        lds_barrier();
+        // every bucket's run leaves in whole lines: sixteen lanes per bucket; what is left (< 8 tuples) waits in `carry`
+        const int grp = threadIdx.x >> 4, l = threadIdx.x & 15;
+        for (int b = grp; b < nb; b += kT / 16) {
+            const uint32_t cb = ncarry[b], run = cnt[b], total = cb + run, nfull = total & ~7u, at = cur[b];
+            if (!FIRST && at + nfull > cap2) { over = true; continue; }
+            uint4 *dst = dest_of((uint32_t)b) + at;
+            const uint4 *src = buf + base[b];
+            for (uint32_t i = l; i < nfull; i += 16) st_nt16(dst + i, i < cb ? carry[b * 8 + i] : src[i - cb]);
+            const uint32_t rem = total - nfull, j = nfull + (uint32_t)l;
+            uint4 keep = uint4{0u, 0u, kDead, 0u};
+            if ((uint32_t)l < rem) keep = j < cb ? carry[b * 8 + j] : src[j - cb];
+            if ((uint32_t)l < rem) carry[b * 8 + l] = keep;                // (a wave's LDS operations complete in order: the reads above came first)
+            if (l == 0) { cur[b] = at + nfull; ncarry[b] = rem; }
+        }
+        lds_barrier();
+    }
+    // the last partial lines, padded with dead tuples
+    {
+        const int grp = threadIdx.x >> 3, l = threadIdx.x & 7;
+        for (int b = grp; b < nb; b += kT / 8) {
+            const uint32_t rem = ncarry[b], at = cur[b];
+            if (rem) {
+                if (!FIRST && at + 8u > cap2) over = true;
+                else st_nt16(dest_of((uint32_t)b) + at + l, (uint32_t)l < rem ? carry[b * 8 + l] : uint4{0u, 0u, kDead, 0u});
+            }
+            if (!FIRST && l == 0) { counts2[((size_t)b1 << nb2log) + b] = at + rem; cnt[b] = at + rem; }
+        }
+    }
+    if (!FIRST) {
+        // where every sub-bucket's rows start in the output: the bucket's first row + the sub-buckets before it
+        for (int b = nb + threadIdx.x; b < kB; b += kT) cnt[b] = 0u;
+        lds_barrier();
+        if (threadIdx.x < 64) scan256_by_wave(cnt, base);
+        lds_barrier();
+        const uint32_t first = bfirst[b1];
+        for (int b = threadIdx.x; b < nb; b += kT) outoff[((size_t)b1 << nb2log) + b] = first + base[b];
+    }
+    if (over) atomicOr(&flag[0], 4);
+}
+constexpr size_t msd_part_lds() { return (size_t)kTile * 16 + (size_t)kB * 8 * 16 + (size_t)kB * 4 * 4; }
+constexpr size_t msd_final_lds() { return (size_t)kFCap * 16 + (size_t)(kFBins + 4) * 4 + (size_t)(kFT / 64) * 4 + 2 * 256 * 4; }
+
+// ---- sweep 3: the final buckets are sorted in LDS -------------------------------------------------------------------------------
+// Two workgroups per CU walk over the buckets; the NEXT bucket's tuples (and the size of the one after it) are loaded while a
+// bucket is sorted -- one workgroup per bucket spent its life waiting for a chain of dependent loads (flag, size, tuples:
+// ~10 us per bucket with two workgroups per CU: 1.26 ms per 1e8 rows for 0.8 ms of traffic).
+constexpr int kFMine = 256;                                  // buckets per workgroup at most (D <= 65536, >= 256 workgroups)
+__global__ __launch_bounds__(kFT) void msd_final_kernel(const uint4 *__restrict__ tin, uint32_t cap2, const uint32_t *__restrict__ counts2, const uint32_t *__restrict__ outoff,
+                                                        uint32_t D, const MsdMap *__restrict__ mapp, u64 *__restrict__ keys_out, uint32_t *__restrict__ perm_out,
+                                                        uint32_t *__restrict__ val_out, u64 out_xor, int32_t *__restrict__ flag)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    uint4 *buf = reinterpret_cast<uint4 *>(lds_raw);                       // [kFCap]
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(buf + kFCap);             // [kFBins + 4] counts, then exclusive offsets (cnt[kFBins] = the total)
+    uint32_t *s_wave = cnt + kFBins + 4;                                   // [kFT / 64]
+    uint32_t *s_c = s_wave + kFT / 64, *s_o = s_c + kFMine;                // [kFMine] each: size and first output row of this workgroup's buckets
+    if (*reinterpret_cast<const volatile int32_t *>(flag)) return;         // an earlier step gave up
+    const MsdMap m = *mapp;
+    const uint32_t step = gridDim.x;
+    uint32_t f = blockIdx.x;
+    if (f >= D) return;
+    auto load = [&](uint32_t bucket, uint32_t count, uint4 (&t)[kFR]) {
+        const uint4 *src = tin + (size_t)bucket * cap2;
+#pragma unroll
+        for (int k = 0; k < kFR; k++) { const uint32_t i = (uint32_t)k * kFT + threadIdx.x; if ((uint32_t)k * kFT < count && i < count) t[k] = ld_nt16(src + i); }
+    };
+    // sizes and output offsets of all of this workgroup's buckets, once (a load per bucket inside the loop would sit in front of
+    // every LDS wait: scalar loads and LDS operations share a counter)
+    for (uint32_t j = threadIdx.x; j < (uint32_t)kFMine; j += kFT) { const uint32_t b = f + j * step; s_c[j] = b < D ? counts2[b] : 0u; s_o[j] = b < D ? outoff[b] : 0u; }
+    __syncthreads();
+    uint32_t c = s_c[0];
+    uint4 t[kFR];
+    load(f, c, t);
+    bool dup = false;
+    for (uint32_t it = 0;; it++) {
+        const uint32_t fn = f + step;
+        const bool more = fn < D;
+        const uint32_t c_next = more ? s_c[it + 1] : 0u;
+        uint4 nx[kFR];
+        if (more) load(fn, c_next, nx);                                    // in flight while this bucket is sorted
+        if (c) {
+            // the final digit of a key: its reduced key relative to the bucket's first, spread over kFBins bins
+            const u64 hlo = ((u64)f * m.q48) >> 16;
+            auto bin_of = [&](u64 key) -> uint32_t {
+                const uint32_t h = reduced_key(key, m.kmin, m.sh);
+                const uint32_t rel = (u64)h > hlo ? (uint32_t)((u64)h - hlo) : 0u;
+                const uint32_t e = __umulhi(rel, m.mul3);
+                return e < (uint32_t)kFBins ? e : (uint32_t)kFBins - 1u;
+            };
+            for (int i = threadIdx.x; i < kFBins + 4; i += kFT) cnt[i] = 0u;
+            lds_barrier();
+            uint32_t e[kFR], r[kFR];
+#pragma unroll
+            for (int k = 0; k < kFR; k++) {
+                const uint32_t i = (uint32_t)k * kFT + threadIdx.x;
+                if ((uint32_t)k * kFT < c && i < c) { e[k] = bin_of(((u64)t[k].y << 32) | t[k].x); r[k] = atomicAdd(&cnt[e[k]], 1u); }   // (the first test is the wave's: whole slots are skipped)
+            }
+            lds_barrier();
+            {   // exclusive scan of the bins: four per thread, a wave scan, the waves' totals
+                const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+                const uint32_t c0 = cnt[4 * threadIdx.x], c1 = cnt[4 * threadIdx.x + 1], c2 = cnt[4 * threadIdx.x + 2], c3 = cnt[4 * threadIdx.x + 3];
+                uint32_t incl = c0 + c1 + c2 + c3;
+                for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d, 64); if (lane >= d) incl += y; }
+                if (lane == 63) s_wave[wv] = incl;
+                lds_barrier();
+                uint32_t before = 0;
+                for (int q = 0; q < wv; q++) before += s_wave[q];
+                const uint32_t excl = before + incl - (c0 + c1 + c2 + c3);
+                cnt[4 * threadIdx.x] = excl; cnt[4 * threadIdx.x + 1] = excl + c0; cnt[4 * threadIdx.x + 2] = excl + c0 + c1; cnt[4 * threadIdx.x + 3] = excl + c0 + c1 + c2;
+                if (threadIdx.x == kFT - 1) cnt[kFBins] = excl + c0 + c1 + c2 + c3;
+            }
+            lds_barrier();
+#pragma unroll
+            for (int k = 0; k < kFR; k++) { const uint32_t i = (uint32_t)k * kFT + threadIdx.x; if ((uint32_t)k * kFT < c && i < c) buf[cnt[e[k]] + r[k]] = t[k]; }
+            lds_barrier();
+            // rank inside the run of equal digits by (key, row id)
+            uint32_t pos[kFR];
+#pragma unroll
+            for (int k = 0; k < kFR; k++) {
+                const uint32_t i = (uint32_t)k * kFT + threadIdx.x;
+                if ((uint32_t)k * kFT < c && i < c) {
+                    t[k] = buf[i];
+                    const u64 key = ((u64)t[k].y << 32) | t[k].x;
+                    const uint32_t b = bin_of(key), a0 = cnt[b], a1 = cnt[b + 1];
+                    uint32_t at = a0;
+                    if (a1 - a0 > (uint32_t)kFRunMax) cnt[kFBins + 1] = 1u;          // (the scan left this word zero)
+                    else for (uint32_t j = a0; j < a1; j++) {
+                        const uint4 q = buf[j];
+                        const u64 kj = ((u64)q.y << 32) | q.x;
+                        at += (kj < key || (kj == key && q.z < t[k].z)) ? 1u : 0u;
+                        dup |= kj == key && j != i;
+                    }
+                    pos[k] = at;
+                }
+            }
+            lds_barrier();                                                 // (an LDS-only barrier: the next bucket's loads stay in flight)
+            if (cnt[kFBins + 1]) { if (threadIdx.x == 0) atomicOr(&flag[0], 16); return; }
+#pragma unroll
+            for (int k = 0; k < kFR; k++) { const uint32_t i = (uint32_t)k * kFT + threadIdx.x; if ((uint32_t)k * kFT < c && i < c) buf[pos[k]] = t[k]; }
+            lds_barrier();
+            const size_t o = s_o[it];
+#pragma unroll
+            for (int k = 0; k < kFR; k++) {
+                const uint32_t i = (uint32_t)k * kFT + threadIdx.x;
+                if ((uint32_t)k * kFT < c && i < c) {
+                    const uint4 q = buf[i];
+                    keys_out[o + i] = ((((u64)q.y) << 32) | q.x) ^ out_xor; perm_out[o + i] = q.z;
+                    if (val_out) val_out[o + i] = q.w;
+                }
+            }
+            lds_barrier();                                                 // (buf and cnt are the next bucket's from here)
+        }
+        if (!more) break;
+        f = fn; c = c_next;
+#pragma unroll
+        for (int k = 0; k < kFR; k++) t[k] = nx[k];
+    }
+    if (dup) flag[1] = 1;
+}
+
+} // namespace
+
+// Ascending argsort of col ^ xorm (unsigned order), ties by row id: keys[i] = (col[perm[i]] ^ xorm) ^ out_xor, *val_out = valcol[perm[i]].
+// *done = false when the path does not apply or gave up (the caller then takes the tuple passes): nothing is returned.
+int k_sort_i64_msd(hark_context *ctx, const void *col, int64_t n, const uint32_t *valcol, uint64_t *keys, uint32_t **perm_out, uint32_t **val_out,
+                   bool *done, int *unique_out, uint64_t xorm, uint64_t out_xor)
+{
+    *done = false;
+    if (n < ((int64_t)1 << 20) || n >= 0xFFFFFFFFll || getenv("HARK_SORT_NO_MSD")) return HARK_OK;
+    // final buckets of ~1500 tuples on average (capacity 3584): D = 256 * nb2, nb2 a power of two <= 256
+    int nb2log = 0;
+    while (nb2log < 8 && n / ((int64_t)kB << nb2log) > 1792) nb2log++;
+    if (n / ((int64_t)kB << nb2log) > 1792) return HARK_OK;                // more than ~1.17e8 rows: the tuple passes
+    const int D = kB << nb2log;
+    hipStream_t st = ctx->stream;
+    const int nwg = ctx->num_cu > 0 && ctx->num_cu <= 1024 ? ctx->num_cu : 256;
+    const int64_t slice = ((n + nwg - 1) / nwg + kTile - 1) / kTile * kTile;
+    const uint32_t cap2 = (uint32_t)kFCap;
+    u64 *mm = nullptr; MsdMap *map = nullptr; int32_t *flag = nullptr;
+    uint32_t *counts1 = nullptr, *off1 = nullptr, *bstart = nullptr, *bfirst = nullptr, *counts2 = nullptr, *outoff = nullptr, *perm = nullptr, *val = nullptr;
+    uint4 *slabs = nullptr, *regions = nullptr;
+    unsigned char *small = nullptr;
+    const size_t small_bytes = 64 + 64 + (size_t)nwg * kB * 4 * 2 + (size_t)(kB + 8) * 4 * 2 + (size_t)D * 4 * 2;
+    int rc = hark_alloc(ctx, (void **)&small, small_bytes);
+    if (!rc) rc = hark_alloc(ctx, (void **)&slabs, ((size_t)n + 8ull * kB * nwg) * 16);
+    if (!rc) rc = hark_alloc(ctx, (void **)&regions, (size_t)D * cap2 * 16);
+    if (!rc) rc = hark_alloc(ctx, (void **)&perm, (size_t)n * 4);
+    if (!rc && valcol && val_out) rc = hark_alloc(ctx, (void **)&val, (size_t)n * 4);
+    auto cleanup = [&](bool keep) {
+        hark_free(ctx, small); hark_free(ctx, slabs); hark_free(ctx, regions);
+        if (!keep) { hark_free(ctx, perm); hark_free(ctx, val); }
+    };
+    if (rc == HARK_ENOMEM) { cleanup(false); ctx->err.clear(); return HARK_OK; }
+    if (rc) { cleanup(false); return rc; }
+    mm = reinterpret_cast<u64 *>(small); map = reinterpret_cast<MsdMap *>(small + 64); flag = reinterpret_cast<int32_t *>(small + 96);
+    counts1 = reinterpret_cast<uint32_t *>(small + 128); off1 = counts1 + (size_t)nwg * kB; bstart = off1 + (size_t)nwg * kB;
+    bfirst = bstart + kB + 8; counts2 = bfirst + kB + 8; outoff = counts2 + D;
+    const u64 mm_init[2] = {~0ull, 0ull};
+    HIP_TRY_RC(ctx, rc, hipMemcpyAsync(mm, mm_init, 16, hipMemcpyHostToDevice, st));
+    HIP_TRY_RC(ctx, rc, hipMemsetAsync(flag, 0, 16, st));
+    const u64 *c64 = static_cast<const u64 *>(col);
+    const size_t lds = msd_part_lds();
+    HIP_TRY_RC(ctx, rc, hipFuncSetAttribute(reinterpret_cast<const void *>(&msd_part_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY_RC(ctx, rc, hipFuncSetAttribute(reinterpret_cast<const void *>(&msd_part_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY_RC(ctx, rc, hipFuncSetAttribute(reinterpret_cast<const void *>(&msd_final_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)msd_final_lds()));
+    HARK_LAUNCH_RC(ctx, rc, msd_sample_kernel<<<dim3(kSampleWg), dim3(256), 0, st>>>(c64, n, xorm, 509, mm));
+    HARK_LAUNCH_RC(ctx, rc, msd_setup_kernel<<<dim3(1), dim3(1), 0, st>>>(mm, (uint32_t)D, map, flag));
+    HARK_LAUNCH_RC(ctx, rc, msd_hist_kernel<<<dim3((unsigned)nwg), dim3(kT), 0, st>>>(c64, n, slice, xorm, map, nb2log, counts1, flag));
+    HARK_LAUNCH_RC(ctx, rc, msd_scan1_kernel<<<dim3(1), dim3(1024), 0, st>>>(counts1, nwg, off1, bstart, bfirst));
+    HARK_LAUNCH_RC(ctx, rc, msd_part_kernel<true><<<dim3((unsigned)nwg), dim3(kT), lds, st>>>(c64, val ? valcol : nullptr, n, slice, xorm, nullptr, nullptr, map, nb2log, slabs, off1, 0u, nullptr, nullptr, nullptr, flag));
+    HARK_LAUNCH_RC(ctx, rc, msd_part_kernel<false><<<dim3(kB), dim3(kT), lds, st>>>(nullptr, nullptr, n, 0, 0ull, slabs, bstart, map, nb2log, regions, nullptr, cap2, counts2, bfirst, outoff, flag));
+    const int fgrid = D < 512 ? D : (2 * nwg >= 256 && 2 * nwg <= D ? 2 * nwg : 256);                   // >= 256 workgroups: <= 256 buckets each
+    HARK_LAUNCH_RC(ctx, rc, msd_final_kernel<<<dim3((unsigned)fgrid), dim3(kFT), msd_final_lds(), st>>>(regions, cap2, counts2, outoff, (uint32_t)D, map, reinterpret_cast<u64 *>(keys), perm, val, out_xor, flag));
+    int64_t verdict = 0;
+    if (!rc) rc = hark_read_words(ctx, flag, &verdict, 1);
+    if (rc) { cleanup(false); return rc; }
+    if (getenv("HARK_SORT_MSD_VERBOSE")) {
+        std::vector<uint32_t> c2((size_t)D), c1((size_t)nwg * kB); MsdMap hm; u64 hmm2[2];
+        hark_d2h(ctx, c2.data(), counts2, (size_t)D * 4); hark_d2h(ctx, c1.data(), counts1, (size_t)nwg * kB * 4); hark_d2h(ctx, &hm, map, sizeof(hm)); hark_d2h(ctx, hmm2, mm, 16);
+        uint32_t mx = 0; u64 tot = 0; for (uint32_t x : c2) { mx = x > mx ? x : mx; tot += x; }
+        u64 tot1 = 0; for (uint32_t x : c1) tot1 += x;
+        int32_t fl[4]; hark_d2h(ctx, fl, flag, 16);
+        fprintf(stderr, "flags %d %d run %d bucket %d count %u; ", fl[0], fl[1], fl[2], fl[3], fl[3] >= 0 && fl[3] < D ? c2[fl[3]] : 0u);
+        fprintf(stderr, "msd sort: n=%lld D=%d verdict=%llx max final bucket=%u sum2=%llu sum1=%llu kmin=%llx kmax=%llx sh=%u mul=%u\n", (long long)n, D, (unsigned long long)verdict, mx,
+                (unsigned long long)tot, (unsigned long long)tot1, (unsigned long long)hmm2[0], (unsigned long long)hmm2[1], hm.sh, hm.mul);
+    }
+    if ((verdict & 0xFFFFFFFFll) != 0) { cleanup(false); return HARK_OK; }          // did not fit: the tuple passes
+    if (unique_out) *unique_out = ((verdict >> 32) & 0xFFFFFFFFll) ? 0 : 1;
+    cleanup(true);
+    *perm_out = perm;
+    if (val_out) *val_out = val;
+    *done = true;
+    return HARK_OK;
+}

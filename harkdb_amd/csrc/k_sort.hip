@@ -1149,6 +1149,11 @@ int k_argsort_column(hark_context *ctx, const void *col, int dtype, int64_t n, b
     return k_sort_column(ctx, col, dtype, n, descending, nullptr, perm_out, sorted_words_out);
 }
 
+// k_msort.hip: three sweeps of 16-byte tuples, most significant digit first, for large tables of well-spread keys (same outputs
+// as sort_i64_tuples; *done = false when it does not apply or gave up)
+int k_sort_i64_msd(hark_context *ctx, const void *col, int64_t n, const uint32_t *valcol, uint64_t *keys, uint32_t **perm_out, uint32_t **val_out,
+                   bool *done, int *unique_out, uint64_t xorm, uint64_t out_xor);
+
 // Stable ascending argsort of an i64 column together with the SORTED keys (biased by 2^63: unsigned order = signed order):
 // *perm_out (n x u32) and *keys_out (n x u64) are pool blocks the caller frees.  High word first + run fix-up (above)
 // when the high words differ, the plain low-word sort when they do not, the eight-pass path as the fallback.
@@ -1248,10 +1253,16 @@ int k_argsort_i64_desc_tuples(hark_context *ctx, const void *col, int64_t n, uin
     *perm_out = nullptr; *keys_out = nullptr; *done = false;
     if (val_out) *val_out = nullptr;
     if (n <= 0) return HARK_OK;
+    uint64_t *keys = nullptr;
+    if (!getenv("HARK_SORT_NO_TUPLES")) {
+        HARK_TRY(hark_alloc(ctx, (void **)&keys, (size_t)n * 8));
+        const int rc0 = k_sort_i64_msd(ctx, col, n, valcol, keys, perm_out, val_out, done, nullptr, 0x7FFFFFFFFFFFFFFFull, out_xor);
+        if (rc0 || *done) { if (rc0) hark_free(ctx, keys); else *keys_out = keys; return rc0; }
+        hark_free(ctx, keys); keys = nullptr;
+    }
     uint32_t diff_hi = 0u;
     HARK_TRY(k_transform_keys(ctx, col, HARK_I64, 1, nullptr, n, &diff_hi));      // (the bits in which the high words differ: the same either way)
     if (passes_of(diff_hi) == 0u || getenv("HARK_SORT_NO_TUPLES")) return HARK_OK;
-    uint64_t *keys = nullptr;
     HARK_TRY(hark_alloc(ctx, (void **)&keys, (size_t)n * 8));
     const int rc = sort_i64_tuples(ctx, col, n, diff_hi, valcol, keys, perm_out, val_out, done, nullptr, 0x7FFFFFFFFFFFFFFFull, out_xor);
     if (rc || !*done) { hark_free(ctx, keys); return rc; }
@@ -1272,9 +1283,14 @@ int k_argsort_i64_keys(hark_context *ctx, const void *col, int64_t n, uint32_t *
     uint64_t *keys = nullptr;
     int rc = hark_alloc(ctx, (void **)&keys, (size_t)n * 8);
     if (rc) return rc;
+    bool done = false;
+    if (!getenv("HARK_SORT_I64_LSD") && !getenv("HARK_SORT_NO_TUPLES")) {
+        rc = k_sort_i64_msd(ctx, col, n, valcol, keys, perm_out, val_out, &done, unique_out, 0x8000000000000000ull, plain_out ? 0x8000000000000000ull : 0ull);
+        if (rc) { hark_free(ctx, keys); return rc; }
+        if (done) { if (plain_out) *plain_out = true; *keys_out = keys; return HARK_OK; }
+    }
     uint32_t diff_hi = 0u;
     rc = k_transform_keys(ctx, col, HARK_I64, 1, nullptr, n, &diff_hi);
-    bool done = false;
     if (!rc && passes_of(diff_hi) != 0u && !getenv("HARK_SORT_I64_LSD") && !getenv("HARK_SORT_NO_TUPLES"))
         rc = sort_i64_tuples(ctx, col, n, diff_hi, valcol, keys, perm_out, val_out, &done, unique_out, 0x8000000000000000ull, plain_out ? 0x8000000000000000ull : 0ull);
     if (!rc && done && plain_out) *plain_out = true;

@@ -1,0 +1,78 @@
+"""ORDER BY on i64 keys, large tables: the most-significant-digit-first tuple sort (harkdb_amd/csrc/k_msort.hip) against numpy's
+stable argsort -- whatever the distribution, the result is the one the tuple passes give (the reference's rsort is stable:
+futhark/groupby.fut:8-22), and what does not fit the buckets falls back to them."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from harkdb_amd.engine import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def make_keys(kind, n, rng):
+    if kind == "spread":
+        return rng.integers(-2**63, 2**63 - 1, size=n)
+    if kind == "sorted":                    # every workgroup's rows go to ONE level-1 bucket
+        return np.sort(rng.integers(-2**62, 2**62, size=n))
+    if kind == "reversed":
+        return np.sort(rng.integers(-2**62, 2**62, size=n))[::-1].copy()
+    if kind == "positive_48":               # a range of 2^48: the map shifts by 16 bits
+        return rng.integers(0, 2**48, size=n)
+    if kind == "range_2_33":                # barely over 2^32: one reduced key per two keys
+        return rng.integers(-2**32, 2**32, size=n)
+    if kind == "some_equal":                # equal keys: ties go by row id
+        k = rng.integers(-2**62, 2**62, size=n)
+        k[rng.integers(0, n, size=n // 8)] = k[rng.integers(0, n, size=n // 8)]
+        return k
+    if kind == "few_distinct":              # heavy duplicates: a final bucket overflows -> the tuple passes
+        pool = rng.integers(-2**62, 2**62, size=300)
+        return pool[rng.integers(0, 300, size=n)]
+    if kind == "normal":                    # a lumpy distribution: the middle buckets hold several times the average
+        return (rng.standard_normal(n) * 2.0**55).astype(np.int64)
+    if kind == "outliers":                  # two keys far outside everyone else's range (the sample may or may not see them)
+        k = rng.integers(-2**40, 2**40, size=n)
+        k[n // 3] = 2**62; k[n // 2] = -2**62
+        return k
+    if kind == "clusters":                  # tight clusters around a few centres
+        c = rng.integers(-2**62, 2**62, size=64)
+        return c[rng.integers(0, 64, size=n)] + rng.integers(0, 2**20, size=n)
+    raise ValueError(kind)
+
+
+KINDS = ["spread", "sorted", "reversed", "positive_48", "range_2_33", "some_equal", "few_distinct", "normal", "outliers", "clusters"]
+
+
+@pytest.mark.parametrize("n", [(1 << 20) + 777, 3_000_001])
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("descending", [False, True])
+def test_large_i64_sort_matches_numpy(eng, n, kind, descending):
+    rng = np.random.default_rng(len(kind) * 31 + n % 97 + int(descending))
+    key = make_keys(kind, n, rng).astype(np.int64)
+    val = rng.integers(-2**31, 2**31, size=n).astype(np.int32)
+    t = eng.table_from_columns([key, val])
+    res = eng.sort(t, 0, [0, 1], descending=descending)
+    perm = np.argsort(~key if descending else key, kind="stable")
+    assert np.array_equal(res.column(0), key[perm])
+    assert np.array_equal(res.column(1), val[perm])
+    res.free(); t.free()
+
+
+def test_large_i64_sort_same_with_and_without_the_msd_path(eng, monkeypatch):
+    rng = np.random.default_rng(5)
+    n = 2_500_003
+    key = rng.integers(-2**63, 2**63 - 1, size=n).astype(np.int64)
+    key[::7] = key[3]
+    rowid = np.arange(n, dtype=np.int32)
+    t = eng.table_from_columns([key, rowid])
+    a = eng.sort(t, 0, [1, 0])
+    monkeypatch.setenv("HARK_SORT_NO_MSD", "1")
+    b = eng.sort(t, 0, [1, 0])
+    assert np.array_equal(a.column(0), b.column(0)) and np.array_equal(a.column(1), b.column(1))
+    assert np.array_equal(a.column(0), rowid[np.argsort(key, kind="stable")])
+    a.free(); b.free(); t.free()
