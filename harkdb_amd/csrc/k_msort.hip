@@ -23,8 +23,6 @@
 // Whatever does not fit -- a final bucket over its capacity (heavy duplicates, a lumpy distribution), a long run of one digit
 // -- raises a flag and the caller takes the tuple passes as before (hark's result does not depend on the path).
 #include "hark_internal.h"
-#include <vector>
-#include <cstdio>
 
 typedef unsigned long long u64;
 
@@ -33,7 +31,7 @@ namespace {
 constexpr int kT = 1024, kR = 4, kTile = kT * kR;            // partition workgroup: threads, tuples per thread and tile
 constexpr int kB = 256;                                      // buckets per partition level
 constexpr uint32_t kDead = 0xFFFFFFFFu;                      // row id of a padding tuple
-constexpr int kFT = 512, kFR = 7, kFCap = kFT * kFR;         // final workgroup: 3584 tuples at most
+constexpr int kFT = 512, kFR = 5, kFCap = kFT * kFR;         // final workgroup: 2560 tuples at most (three workgroups share a CU's LDS)
 constexpr int kFBins = 2048;
 constexpr int kFRunMax = 64;                                 // longest run of one final digit that is ranked by comparing
 constexpr int kSampleWg = 256;
@@ -306,10 +304,13 @@ __global__ __launch_bounds__(kFT) void msd_final_kernel(const uint4 *__restrict_
     const uint32_t step = gridDim.x;
     uint32_t f = blockIdx.x;
     if (f >= D) return;
+    // kFR loads, whatever the bucket's size (a slot beyond it reads the bucket's first tuple again): a number of loads the compiler
+    // can count.  With a load per live slot only, every use of a loaded tuple sat behind an s_waitcnt vmcnt(0) -- right behind the
+    // loads of the NEXT bucket, which were meant to be in flight while this one is sorted.
     auto load = [&](uint32_t bucket, uint32_t count, uint4 (&t)[kFR]) {
         const uint4 *src = tin + (size_t)bucket * cap2;
 #pragma unroll
-        for (int k = 0; k < kFR; k++) { const uint32_t i = (uint32_t)k * kFT + threadIdx.x; if ((uint32_t)k * kFT < count && i < count) t[k] = ld_nt16(src + i); }
+        for (int k = 0; k < kFR; k++) { const uint32_t i = (uint32_t)k * kFT + threadIdx.x; t[k] = ld_nt16(src + (i < count ? i : 0u)); }
     };
     // sizes and output offsets of all of this workgroup's buckets, once (a load per bucket inside the loop would sit in front of
     // every LDS wait: scalar loads and LDS operations share a counter)
@@ -318,13 +319,15 @@ __global__ __launch_bounds__(kFT) void msd_final_kernel(const uint4 *__restrict_
     uint32_t c = s_c[0];
     uint4 t[kFR];
     load(f, c, t);
+#pragma unroll
+    for (int k = 0; k < kFR; k++) asm volatile("" : "+v"(t[k].x), "+v"(t[k].y), "+v"(t[k].z), "+v"(t[k].w));   // (arrived: inside the loop t is never a pending load)
     bool dup = false;
     for (uint32_t it = 0;; it++) {
         const uint32_t fn = f + step;
         const bool more = fn < D;
         const uint32_t c_next = more ? s_c[it + 1] : 0u;
         uint4 nx[kFR];
-        if (more) load(fn, c_next, nx);                                    // in flight while this bucket is sorted
+        load(more ? fn : f, c_next, nx);                                   // in flight while this bucket is sorted (the last round loads for nobody)
         if (c) {
             // the final digit of a key: its reduced key relative to the bucket's first, spread over kFBins bins
             const u64 hlo = ((u64)f * m.q48) >> 16;
@@ -360,47 +363,42 @@ __global__ __launch_bounds__(kFT) void msd_final_kernel(const uint4 *__restrict_
 #pragma unroll
             for (int k = 0; k < kFR; k++) { const uint32_t i = (uint32_t)k * kFT + threadIdx.x; if ((uint32_t)k * kFT < c && i < c) buf[cnt[e[k]] + r[k]] = t[k]; }
             lds_barrier();
-            // rank inside the run of equal digits by (key, row id)
-            uint32_t pos[kFR];
+            // The next bucket's tuples are taken out of the load registers HERE, before this bucket's stores are issued: loads and stores
+            // share one in-order counter, so a wait for the loads behind the stores would sit out the stores' completion -- every bucket.
 #pragma unroll
-            for (int k = 0; k < kFR; k++) {
-                const uint32_t i = (uint32_t)k * kFT + threadIdx.x;
-                if ((uint32_t)k * kFT < c && i < c) {
-                    t[k] = buf[i];
-                    const u64 key = ((u64)t[k].y << 32) | t[k].x;
-                    const uint32_t b = bin_of(key), a0 = cnt[b], a1 = cnt[b + 1];
-                    uint32_t at = a0;
-                    if (a1 - a0 > (uint32_t)kFRunMax) cnt[kFBins + 1] = 1u;          // (the scan left this word zero)
-                    else for (uint32_t j = a0; j < a1; j++) {
-                        const uint4 q = buf[j];
-                        const u64 kj = ((u64)q.y << 32) | q.x;
-                        at += (kj < key || (kj == key && q.z < t[k].z)) ? 1u : 0u;
-                        dup |= kj == key && j != i;
-                    }
-                    pos[k] = at;
-                }
-            }
-            lds_barrier();                                                 // (an LDS-only barrier: the next bucket's loads stay in flight)
-            if (cnt[kFBins + 1]) { if (threadIdx.x == 0) atomicOr(&flag[0], 16); return; }
-#pragma unroll
-            for (int k = 0; k < kFR; k++) { const uint32_t i = (uint32_t)k * kFT + threadIdx.x; if ((uint32_t)k * kFT < c && i < c) buf[pos[k]] = t[k]; }
-            lds_barrier();
+            for (int k = 0; k < kFR; k++) t[k] = nx[k];
+            // rank inside the run of equal digits by (key, row id) and store at the rank: a tuple moves inside its run only (a few
+            // rows), so a wave's stores stay within a few lines of each other
             const size_t o = s_o[it];
 #pragma unroll
             for (int k = 0; k < kFR; k++) {
                 const uint32_t i = (uint32_t)k * kFT + threadIdx.x;
                 if ((uint32_t)k * kFT < c && i < c) {
-                    const uint4 q = buf[i];
-                    keys_out[o + i] = ((((u64)q.y) << 32) | q.x) ^ out_xor; perm_out[o + i] = q.z;
-                    if (val_out) val_out[o + i] = q.w;
+                    const uint4 me = buf[i];
+                    const u64 key = ((u64)me.y << 32) | me.x;
+                    const uint32_t b = bin_of(key), a0 = cnt[b], a1 = cnt[b + 1];
+                    uint32_t at = a0;
+                    if (a1 - a0 > (uint32_t)kFRunMax) cnt[kFBins + 1] = 1u;          // (the scan left this word zero)
+                    else if (a1 - a0 > 1u) for (uint32_t j = a0; j < a1; j++) {
+                        const uint4 q = buf[j];
+                        const u64 kj = ((u64)q.y << 32) | q.x;
+                        at += (kj < key || (kj == key && q.z < me.z)) ? 1u : 0u;
+                        dup |= kj == key && j != i;
+                    }
+                    keys_out[o + at] = key ^ out_xor; perm_out[o + at] = me.z;
+                    if (val_out) val_out[o + at] = me.w;
                 }
             }
-            lds_barrier();                                                 // (buf and cnt are the next bucket's from here)
+            lds_barrier();                                                 // (buf and cnt are the next bucket's from here; an LDS-only barrier: the
+                                                                           // next bucket's loads stay in flight)
+            if (cnt[kFBins + 1]) { if (threadIdx.x == 0) atomicOr(&flag[0], 16); return; }   // a long run: its rows were not ranked -- the caller's other path
+        }
+        else {
+#pragma unroll
+            for (int k = 0; k < kFR; k++) t[k] = nx[k];
         }
         if (!more) break;
         f = fn; c = c_next;
-#pragma unroll
-        for (int k = 0; k < kFR; k++) t[k] = nx[k];
     }
     if (dup) flag[1] = 1;
 }
@@ -414,10 +412,10 @@ int k_sort_i64_msd(hark_context *ctx, const void *col, int64_t n, const uint32_t
 {
     *done = false;
     if (n < ((int64_t)1 << 20) || n >= 0xFFFFFFFFll || getenv("HARK_SORT_NO_MSD")) return HARK_OK;
-    // final buckets of ~1500 tuples on average (capacity 3584): D = 256 * nb2, nb2 a power of two <= 256
+    // final buckets of 800-1600 tuples on average (capacity 2560): D = 256 * nb2, nb2 a power of two <= 256
     int nb2log = 0;
-    while (nb2log < 8 && n / ((int64_t)kB << nb2log) > 1792) nb2log++;
-    if (n / ((int64_t)kB << nb2log) > 1792) return HARK_OK;                // more than ~1.17e8 rows: the tuple passes
+    while (nb2log < 8 && n / ((int64_t)kB << nb2log) > 1600) nb2log++;
+    if (n / ((int64_t)kB << nb2log) > 1600) return HARK_OK;                // more than ~1.05e8 rows: the tuple passes
     const int D = kB << nb2log;
     hipStream_t st = ctx->stream;
     const int nwg = ctx->num_cu > 0 && ctx->num_cu <= 1024 ? ctx->num_cu : 256;
@@ -456,21 +454,11 @@ int k_sort_i64_msd(hark_context *ctx, const void *col, int64_t n, const uint32_t
     HARK_LAUNCH_RC(ctx, rc, msd_scan1_kernel<<<dim3(1), dim3(1024), 0, st>>>(counts1, nwg, off1, bstart, bfirst));
     HARK_LAUNCH_RC(ctx, rc, msd_part_kernel<true><<<dim3((unsigned)nwg), dim3(kT), lds, st>>>(c64, val ? valcol : nullptr, n, slice, xorm, nullptr, nullptr, map, nb2log, slabs, off1, 0u, nullptr, nullptr, nullptr, flag));
     HARK_LAUNCH_RC(ctx, rc, msd_part_kernel<false><<<dim3(kB), dim3(kT), lds, st>>>(nullptr, nullptr, n, 0, 0ull, slabs, bstart, map, nb2log, regions, nullptr, cap2, counts2, bfirst, outoff, flag));
-    const int fgrid = D < 512 ? D : (2 * nwg >= 256 && 2 * nwg <= D ? 2 * nwg : 256);                   // >= 256 workgroups: <= 256 buckets each
+    const int fgrid = D < 768 ? D : (3 * nwg >= 256 && 3 * nwg <= D ? 3 * nwg : 256);                   // >= 256 workgroups: <= 256 buckets each
     HARK_LAUNCH_RC(ctx, rc, msd_final_kernel<<<dim3((unsigned)fgrid), dim3(kFT), msd_final_lds(), st>>>(regions, cap2, counts2, outoff, (uint32_t)D, map, reinterpret_cast<u64 *>(keys), perm, val, out_xor, flag));
     int64_t verdict = 0;
     if (!rc) rc = hark_read_words(ctx, flag, &verdict, 1);
     if (rc) { cleanup(false); return rc; }
-    if (getenv("HARK_SORT_MSD_VERBOSE")) {
-        std::vector<uint32_t> c2((size_t)D), c1((size_t)nwg * kB); MsdMap hm; u64 hmm2[2];
-        hark_d2h(ctx, c2.data(), counts2, (size_t)D * 4); hark_d2h(ctx, c1.data(), counts1, (size_t)nwg * kB * 4); hark_d2h(ctx, &hm, map, sizeof(hm)); hark_d2h(ctx, hmm2, mm, 16);
-        uint32_t mx = 0; u64 tot = 0; for (uint32_t x : c2) { mx = x > mx ? x : mx; tot += x; }
-        u64 tot1 = 0; for (uint32_t x : c1) tot1 += x;
-        int32_t fl[4]; hark_d2h(ctx, fl, flag, 16);
-        fprintf(stderr, "flags %d %d run %d bucket %d count %u; ", fl[0], fl[1], fl[2], fl[3], fl[3] >= 0 && fl[3] < D ? c2[fl[3]] : 0u);
-        fprintf(stderr, "msd sort: n=%lld D=%d verdict=%llx max final bucket=%u sum2=%llu sum1=%llu kmin=%llx kmax=%llx sh=%u mul=%u\n", (long long)n, D, (unsigned long long)verdict, mx,
-                (unsigned long long)tot, (unsigned long long)tot1, (unsigned long long)hmm2[0], (unsigned long long)hmm2[1], hm.sh, hm.mul);
-    }
     if ((verdict & 0xFFFFFFFFll) != 0) { cleanup(false); return HARK_OK; }          // did not fit: the tuple passes
     if (unique_out) *unique_out = ((verdict >> 32) & 0xFFFFFFFFll) ? 0 : 1;
     cleanup(true);
