@@ -23,6 +23,7 @@
 // Whatever does not fit -- a final bucket over its capacity (heavy duplicates, a lumpy distribution), a long run of one digit
 // -- raises a flag and the caller takes the tuple passes as before (hark's result does not depend on the path).
 #include "hark_internal.h"
+#include <cstdio>
 
 typedef unsigned long long u64;
 
@@ -36,6 +37,12 @@ constexpr int kFBins = 2048;
 constexpr int kFRunMax = 64;                                 // longest run of one final digit that is ranked by comparing
 constexpr int kSampleWg = 256;
 
+#ifdef HARK_MSD_CHECK
+// bounds checks for experiments (tools/ab_build.sh chk "-DHARK_MSD_CHECK"): a violation is recorded in flag[2..3] and the access skipped
+#define MSD_CHK(ok, code, val) ((ok) ? true : (atomicCAS(&flag[2], 0, (int32_t)(code)) == 0 ? (flag[3] = (int32_t)(val), atomicOr(&flag[0], 64), false) : false))
+#else
+#define MSD_CHK(ok, code, val) true
+#endif
 struct MsdMap { u64 kmin; uint32_t sh, mul, dmax, mul3; u64 q48; };   // mul3, q48: the final digit (msd_final_kernel)
 
 __device__ __forceinline__ uint32_t reduced_key(u64 key, u64 kmin, uint32_t sh)
@@ -187,7 +194,7 @@ __global__ __launch_bounds__(kT) void msd_part_kernel(
     const MsdMap *__restrict__ mapp, int nb2log,
     uint4 *__restrict__ tout, const uint32_t *__restrict__ off1 /* FIRST: [nwg][256] */, uint32_t cap2 /* !FIRST */,
     uint32_t *__restrict__ counts2 /* !FIRST: [256 << nb2log] */, const uint32_t *__restrict__ bfirst /* !FIRST */, uint32_t *__restrict__ outoff /* !FIRST */,
-    int32_t *__restrict__ flag)
+    int32_t *__restrict__ flag, size_t tin_cap, size_t tout_cap /* tuples in the two buffers (checked builds) */)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     uint4 *buf = reinterpret_cast<uint4 *>(lds_raw);                       // [kTile] the tile, sorted by digit
@@ -217,7 +224,7 @@ __global__ __launch_bounds__(kT) void msd_part_kernel(
                     const u64 key = __builtin_nontemporal_load(col + i) ^ xorm;
                     t[k] = uint4{(uint32_t)key, (uint32_t)(key >> 32), (uint32_t)i, valcol ? __builtin_nontemporal_load(valcol + i) : 0u};
                 } else t[k] = uint4{0u, 0u, kDead, 0u};
-            } else t[k] = i < hi ? ld_nt16(tin + i) : uint4{0u, 0u, kDead, 0u};
+            } else t[k] = i < hi && MSD_CHK((size_t)i < tin_cap, 5, i) ? ld_nt16(tin + i) : uint4{0u, 0u, kDead, 0u};
         }
     };
     bool over = false;
@@ -241,7 +248,7 @@ __global__ __launch_bounds__(kT) void msd_part_kernel(
         if (threadIdx.x < 64) scan256_by_wave(cnt, base);
         lds_barrier();
 #pragma unroll
-        for (int k = 0; k < kR; k++) if (t[k].z != kDead) buf[base[d[k]] + r[k]] = t[k];
+        for (int k = 0; k < kR; k++) if (t[k].z != kDead && MSD_CHK(base[d[k]] + r[k] < (uint32_t)kTile, 6, base[d[k]] + r[k])) buf[base[d[k]] + r[k]] = t[k];
         lds_barrier();
         // every bucket's run leaves in whole lines: sixteen lanes per bucket; what is left (< 8 tuples) waits in `carry`
         const int grp = threadIdx.x >> 4, l = threadIdx.x & 15;
@@ -250,7 +257,7 @@ __global__ __launch_bounds__(kT) void msd_part_kernel(
             if (!FIRST && at + nfull > cap2) { over = true; continue; }
             uint4 *dst = dest_of((uint32_t)b) + at;
             const uint4 *src = buf + base[b];
-            for (uint32_t i = l; i < nfull; i += 16) st_nt16(dst + i, i < cb ? carry[b * 8 + i] : src[i - cb]);
+            for (uint32_t i = l; i < nfull; i += 16) if (MSD_CHK((size_t)(dst + i - tout) < tout_cap && (i < cb || base[b] + i - cb < (uint32_t)kTile), FIRST ? 1 : 2, dst + i - tout)) st_nt16(dst + i, i < cb ? carry[b * 8 + i] : src[i - cb]);
             const uint32_t rem = total - nfull, j = nfull + (uint32_t)l;
             uint4 keep = uint4{0u, 0u, kDead, 0u};
             if ((uint32_t)l < rem) keep = j < cb ? carry[b * 8 + j] : src[j - cb];
@@ -266,7 +273,7 @@ __global__ __launch_bounds__(kT) void msd_part_kernel(
             const uint32_t rem = ncarry[b], at = cur[b];
             if (rem) {
                 if (!FIRST && at + 8u > cap2) over = true;
-                else st_nt16(dest_of((uint32_t)b) + at + l, (uint32_t)l < rem ? carry[b * 8 + l] : uint4{0u, 0u, kDead, 0u});
+                else if (MSD_CHK((size_t)(dest_of((uint32_t)b) + at + l - tout) < tout_cap, FIRST ? 3 : 4, dest_of((uint32_t)b) + at + l - tout)) st_nt16(dest_of((uint32_t)b) + at + l, (uint32_t)l < rem ? carry[b * 8 + l] : uint4{0u, 0u, kDead, 0u});
             }
             if (!FIRST && l == 0) { counts2[((size_t)b1 << nb2log) + b] = at + rem; cnt[b] = at + rem; }
         }
@@ -292,7 +299,7 @@ constexpr size_t msd_final_lds() { return (size_t)kFCap * 16 + (size_t)(kFBins +
 constexpr int kFMine = 256;                                  // buckets per workgroup at most (D <= 65536, >= 256 workgroups)
 __global__ __launch_bounds__(kFT) void msd_final_kernel(const uint4 *__restrict__ tin, uint32_t cap2, const uint32_t *__restrict__ counts2, const uint32_t *__restrict__ outoff,
                                                         uint32_t D, const MsdMap *__restrict__ mapp, u64 *__restrict__ keys_out, uint32_t *__restrict__ perm_out,
-                                                        uint32_t *__restrict__ val_out, u64 out_xor, int32_t *__restrict__ flag)
+                                                        uint32_t *__restrict__ val_out, u64 out_xor, int32_t *__restrict__ flag, size_t n_rows)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     uint4 *buf = reinterpret_cast<uint4 *>(lds_raw);                       // [kFCap]
@@ -310,7 +317,7 @@ __global__ __launch_bounds__(kFT) void msd_final_kernel(const uint4 *__restrict_
     auto load = [&](uint32_t bucket, uint32_t count, uint4 (&t)[kFR]) {
         const uint4 *src = tin + (size_t)bucket * cap2;
 #pragma unroll
-        for (int k = 0; k < kFR; k++) { const uint32_t i = (uint32_t)k * kFT + threadIdx.x; t[k] = ld_nt16(src + (i < count ? i : 0u)); }
+        for (int k = 0; k < kFR; k++) { const uint32_t i = (uint32_t)k * kFT + threadIdx.x; t[k] = MSD_CHK(bucket < D && count <= cap2, 7, bucket) ? ld_nt16(src + (i < count ? i : 0u)) : uint4{0u, 0u, 0u, 0u}; }
     };
     // sizes and output offsets of all of this workgroup's buckets, once (a load per bucket inside the loop would sit in front of
     // every LDS wait: scalar loads and LDS operations share a counter)
@@ -361,7 +368,7 @@ __global__ __launch_bounds__(kFT) void msd_final_kernel(const uint4 *__restrict_
             }
             lds_barrier();
 #pragma unroll
-            for (int k = 0; k < kFR; k++) { const uint32_t i = (uint32_t)k * kFT + threadIdx.x; if ((uint32_t)k * kFT < c && i < c) buf[cnt[e[k]] + r[k]] = t[k]; }
+            for (int k = 0; k < kFR; k++) { const uint32_t i = (uint32_t)k * kFT + threadIdx.x; if ((uint32_t)k * kFT < c && i < c && MSD_CHK(cnt[e[k]] + r[k] < (uint32_t)kFCap, 9, cnt[e[k]] + r[k])) buf[cnt[e[k]] + r[k]] = t[k]; }
             lds_barrier();
             // The next bucket's tuples are taken out of the load registers HERE, before this bucket's stores are issued: loads and stores
             // share one in-order counter, so a wait for the loads behind the stores would sit out the stores' completion -- every bucket.
@@ -385,8 +392,10 @@ __global__ __launch_bounds__(kFT) void msd_final_kernel(const uint4 *__restrict_
                         at += (kj < key || (kj == key && q.z < me.z)) ? 1u : 0u;
                         dup |= kj == key && j != i;
                     }
-                    keys_out[o + at] = key ^ out_xor; perm_out[o + at] = me.z;
-                    if (val_out) val_out[o + at] = me.w;
+                    if (MSD_CHK(o + at < n_rows && at < c, 8, o + at)) {
+                        keys_out[o + at] = key ^ out_xor; perm_out[o + at] = me.z;
+                        if (val_out) val_out[o + at] = me.w;
+                    }
                 }
             }
             lds_barrier();                                                 // (buf and cnt are the next bucket's from here; an LDS-only barrier: the
@@ -427,7 +436,8 @@ int k_sort_i64_msd(hark_context *ctx, const void *col, int64_t n, const uint32_t
     unsigned char *small = nullptr;
     const size_t small_bytes = 64 + 64 + (size_t)nwg * kB * 4 * 2 + (size_t)(kB + 8) * 4 * 2 + (size_t)D * 4 * 2;
     int rc = hark_alloc(ctx, (void **)&small, small_bytes);
-    if (!rc) rc = hark_alloc(ctx, (void **)&slabs, ((size_t)n + 8ull * kB * nwg) * 16);
+    const size_t slab_tuples = (size_t)n + 8ull * kB * nwg;
+    if (!rc) rc = hark_alloc(ctx, (void **)&slabs, slab_tuples * 16);
     if (!rc) rc = hark_alloc(ctx, (void **)&regions, (size_t)D * cap2 * 16);
     if (!rc) rc = hark_alloc(ctx, (void **)&perm, (size_t)n * 4);
     if (!rc && valcol && val_out) rc = hark_alloc(ctx, (void **)&val, (size_t)n * 4);
@@ -452,13 +462,16 @@ int k_sort_i64_msd(hark_context *ctx, const void *col, int64_t n, const uint32_t
     HARK_LAUNCH_RC(ctx, rc, msd_setup_kernel<<<dim3(1), dim3(1), 0, st>>>(mm, (uint32_t)D, map, flag));
     HARK_LAUNCH_RC(ctx, rc, msd_hist_kernel<<<dim3((unsigned)nwg), dim3(kT), 0, st>>>(c64, n, slice, xorm, map, nb2log, counts1, flag));
     HARK_LAUNCH_RC(ctx, rc, msd_scan1_kernel<<<dim3(1), dim3(1024), 0, st>>>(counts1, nwg, off1, bstart, bfirst));
-    HARK_LAUNCH_RC(ctx, rc, msd_part_kernel<true><<<dim3((unsigned)nwg), dim3(kT), lds, st>>>(c64, val ? valcol : nullptr, n, slice, xorm, nullptr, nullptr, map, nb2log, slabs, off1, 0u, nullptr, nullptr, nullptr, flag));
-    HARK_LAUNCH_RC(ctx, rc, msd_part_kernel<false><<<dim3(kB), dim3(kT), lds, st>>>(nullptr, nullptr, n, 0, 0ull, slabs, bstart, map, nb2log, regions, nullptr, cap2, counts2, bfirst, outoff, flag));
+    HARK_LAUNCH_RC(ctx, rc, msd_part_kernel<true><<<dim3((unsigned)nwg), dim3(kT), lds, st>>>(c64, val ? valcol : nullptr, n, slice, xorm, nullptr, nullptr, map, nb2log, slabs, off1, 0u, nullptr, nullptr, nullptr, flag, 0, slab_tuples));
+    HARK_LAUNCH_RC(ctx, rc, msd_part_kernel<false><<<dim3(kB), dim3(kT), lds, st>>>(nullptr, nullptr, n, 0, 0ull, slabs, bstart, map, nb2log, regions, nullptr, cap2, counts2, bfirst, outoff, flag, slab_tuples, (size_t)D * cap2));
     const int fgrid = D < 768 ? D : (3 * nwg >= 256 && 3 * nwg <= D ? 3 * nwg : 256);                   // >= 256 workgroups: <= 256 buckets each
-    HARK_LAUNCH_RC(ctx, rc, msd_final_kernel<<<dim3((unsigned)fgrid), dim3(kFT), msd_final_lds(), st>>>(regions, cap2, counts2, outoff, (uint32_t)D, map, reinterpret_cast<u64 *>(keys), perm, val, out_xor, flag));
+    HARK_LAUNCH_RC(ctx, rc, msd_final_kernel<<<dim3((unsigned)fgrid), dim3(kFT), msd_final_lds(), st>>>(regions, cap2, counts2, outoff, (uint32_t)D, map, reinterpret_cast<u64 *>(keys), perm, val, out_xor, flag, (size_t)n));
     int64_t verdict = 0;
     if (!rc) rc = hark_read_words(ctx, flag, &verdict, 1);
     if (rc) { cleanup(false); return rc; }
+#ifdef HARK_MSD_CHECK
+    if (verdict & 64) { int32_t fl[4]; hark_d2h(ctx, fl, flag, 16); fprintf(stderr, "MSD CHECK: violation code %d value %d (n=%lld D=%d nb2log=%d flags %x)\n", fl[2], fl[3], (long long)n, D, nb2log, fl[0]); }
+#endif
     if ((verdict & 0xFFFFFFFFll) != 0) { cleanup(false); return HARK_OK; }          // did not fit: the tuple passes
     if (unique_out) *unique_out = ((verdict >> 32) & 0xFFFFFFFFll) ? 0 : 1;
     cleanup(true);
