@@ -39,9 +39,11 @@ constexpr int kSampleWg = 256;
 
 #ifdef HARK_MSD_CHECK
 // bounds checks for experiments (tools/ab_build.sh chk "-DHARK_MSD_CHECK"): a violation is recorded in flag[2..3] and the access skipped
-#define MSD_CHK(ok, code, val) ((ok) ? true : (atomicCAS(&flag[2], 0, (int32_t)(code)) == 0 ? (flag[3] = (int32_t)(val), atomicOr(&flag[0], 64), false) : false))
+#define MSD_CHK(ok, code, val) ((ok) ? true : (atomicCAS(&flag[2], 0, (int32_t)(code)) == 0 ? (flag[3] = (int32_t)(val), flag[4] = (int32_t)blockIdx.x, flag[5] = (int32_t)threadIdx.x, atomicOr(&flag[0], 64), false) : false))
+#define MSD_NOTE(a, b) (flag[6] = (int32_t)(a), flag[7] = (int32_t)(b))
 #else
 #define MSD_CHK(ok, code, val) true
+#define MSD_NOTE(a, b) ((void)0)
 #endif
 struct MsdMap { u64 kmin; uint32_t sh, mul, dmax, mul3; u64 q48; };   // mul3, q48: the final digit (msd_final_kernel)
 
@@ -344,6 +346,7 @@ __global__ __launch_bounds__(kFT) void msd_final_kernel(const uint4 *__restrict_
                 const uint32_t e = __umulhi(rel, m.mul3);
                 return e < (uint32_t)kFBins ? e : (uint32_t)kFBins - 1u;
             };
+            MSD_CHK(c <= (uint32_t)kFCap, 10, c);
             for (int i = threadIdx.x; i < kFBins + 4; i += kFT) cnt[i] = 0u;
             lds_barrier();
             uint32_t e[kFR], r[kFR];
@@ -368,7 +371,7 @@ __global__ __launch_bounds__(kFT) void msd_final_kernel(const uint4 *__restrict_
             }
             lds_barrier();
 #pragma unroll
-            for (int k = 0; k < kFR; k++) { const uint32_t i = (uint32_t)k * kFT + threadIdx.x; if ((uint32_t)k * kFT < c && i < c && MSD_CHK(cnt[e[k]] + r[k] < (uint32_t)kFCap, 9, cnt[e[k]] + r[k])) buf[cnt[e[k]] + r[k]] = t[k]; }
+            for (int k = 0; k < kFR; k++) { const uint32_t i = (uint32_t)k * kFT + threadIdx.x; if ((uint32_t)k * kFT < c && i < c && (MSD_CHK(cnt[kFBins] == c, 11, cnt[kFBins]), MSD_CHK(cnt[e[k]] + r[k] < (uint32_t)kFCap, 9, cnt[e[k]] + r[k]) ? true : (MSD_NOTE(c, (e[k] << 16) | r[k]), false))) buf[cnt[e[k]] + r[k]] = t[k]; }
             lds_barrier();
             // The next bucket's tuples are taken out of the load registers HERE, before this bucket's stores are issued: loads and stores
             // share one in-order counter, so a wait for the loads behind the stores would sit out the stores' completion -- every bucket.
@@ -452,7 +455,7 @@ int k_sort_i64_msd(hark_context *ctx, const void *col, int64_t n, const uint32_t
     bfirst = bstart + kB + 8; counts2 = bfirst + kB + 8; outoff = counts2 + D;
     const u64 mm_init[2] = {~0ull, 0ull};
     HIP_TRY_RC(ctx, rc, hipMemcpyAsync(mm, mm_init, 16, hipMemcpyHostToDevice, st));
-    HIP_TRY_RC(ctx, rc, hipMemsetAsync(flag, 0, 16, st));
+    HIP_TRY_RC(ctx, rc, hipMemsetAsync(flag, 0, 32, st));
     const u64 *c64 = static_cast<const u64 *>(col);
     const size_t lds = msd_part_lds();
     HIP_TRY_RC(ctx, rc, hipFuncSetAttribute(reinterpret_cast<const void *>(&msd_part_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -470,7 +473,7 @@ int k_sort_i64_msd(hark_context *ctx, const void *col, int64_t n, const uint32_t
     if (!rc) rc = hark_read_words(ctx, flag, &verdict, 1);
     if (rc) { cleanup(false); return rc; }
 #ifdef HARK_MSD_CHECK
-    if (verdict & 64) { int32_t fl[4]; hark_d2h(ctx, fl, flag, 16); fprintf(stderr, "MSD CHECK: violation code %d value %d (n=%lld D=%d nb2log=%d flags %x)\n", fl[2], fl[3], (long long)n, D, nb2log, fl[0]); }
+    if (verdict & 64) { int32_t fl[8]; hark_d2h(ctx, fl, flag, 32); fprintf(stderr, "MSD CHECK: violation code %d value %d block %d thread %d note %d %x (n=%lld D=%d nb2log=%d flags %x)\n", fl[2], fl[3], fl[4], fl[5], fl[6], fl[7], (long long)n, D, nb2log, fl[0]); }
 #endif
     if ((verdict & 0xFFFFFFFFll) != 0) { cleanup(false); return HARK_OK; }          // did not fit: the tuple passes
     if (unique_out) *unique_out = ((verdict >> 32) & 0xFFFFFFFFll) ? 0 : 1;
