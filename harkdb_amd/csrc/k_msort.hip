@@ -59,6 +59,17 @@ __device__ __forceinline__ uint32_t bucket_of(u64 key, const MsdMap &m)
     return d < m.dmax ? d : m.dmax;
 }
 
+// Has an earlier step given up?  ONE lane asks and the workgroup shares the answer: the word may be raised by another workgroup of
+// the SAME kernel while this one's waves are still starting, and a workgroup whose waves disagree loses the work of those that
+// left (round 5: a final bucket's scan total was never written, the scatter indices behind it went anywhere in LDS and beyond).
+__device__ __forceinline__ bool msd_gave_up(const int32_t *flag)
+{
+    __shared__ int32_t s_gave_up;
+    if (threadIdx.x == 0) s_gave_up = *reinterpret_cast<const volatile int32_t *>(flag);
+    __syncthreads();
+    return s_gave_up != 0;
+}
+
 // ---- bounds from a sample -------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void msd_sample_kernel(const u64 *__restrict__ col, int64_t n, u64 xorm, int64_t stride, u64 *__restrict__ mm)
 {
@@ -110,7 +121,7 @@ __global__ __launch_bounds__(kT) void msd_hist_kernel(const u64 *__restrict__ co
                                                       int nb2log, uint32_t *__restrict__ counts1 /* [nwg][256] */, const int32_t *__restrict__ flag)
 {
     __shared__ uint32_t s_cnt[kB];
-    if (*reinterpret_cast<const volatile int32_t *>(flag)) return;   // (the keys are not for this path: nothing to do)
+    if (msd_gave_up(flag)) return;                                         // an earlier step gave up: nothing to do
     const MsdMap m = *mapp;
     if (threadIdx.x < kB) s_cnt[threadIdx.x] = 0u;
     __syncthreads();
@@ -205,7 +216,7 @@ __global__ __launch_bounds__(kT) void msd_part_kernel(
     uint32_t *base = cnt + kB;                                             // [kB] ... their first slot in buf
     uint32_t *cur = base + kB;                                             // [kB] tuples written to the bucket's destination so far
     uint32_t *ncarry = cur + kB;                                           // [kB]
-    if (*reinterpret_cast<const volatile int32_t *>(flag)) return;         // an earlier step gave up
+    if (msd_gave_up(flag)) return;                                         // an earlier step gave up: nothing to do
     const MsdMap m = *mapp;
     const int nb = FIRST ? kB : (1 << nb2log);                             // buckets of this sweep
     const uint32_t b1 = blockIdx.x;
@@ -308,7 +319,7 @@ __global__ __launch_bounds__(kFT) void msd_final_kernel(const uint4 *__restrict_
     uint32_t *cnt = reinterpret_cast<uint32_t *>(buf + kFCap);             // [kFBins + 4] counts, then exclusive offsets (cnt[kFBins] = the total)
     uint32_t *s_wave = cnt + kFBins + 4;                                   // [kFT / 64]
     uint32_t *s_c = s_wave + kFT / 64, *s_o = s_c + kFMine;                // [kFMine] each: size and first output row of this workgroup's buckets
-    if (*reinterpret_cast<const volatile int32_t *>(flag)) return;         // an earlier step gave up
+    if (msd_gave_up(flag)) return;                                         // an earlier step gave up: nothing to do
     const MsdMap m = *mapp;
     const uint32_t step = gridDim.x;
     uint32_t f = blockIdx.x;
