@@ -81,7 +81,7 @@ with open(os.path.join(dst, f"{tag}_op_traffic.txt"), "w") as fo:
 print(open(os.path.join(dst, f"{tag}_op_traffic.txt")).read())
 # round 5's probe outputs of the same run
 for name, out in (("hashlds.txt", "hashlds.txt"), ("widedigit.txt", "widedigit.txt"), ("nofilter_ab.txt", "nofilter_ab.txt"), ("ingest_bench.log", "ingest_bench.log"),
-                  ("strong_rehearsal.txt", "strong_rehearsal.txt"), ("hash_pmc_after.txt", "hash_pmc_after.txt")):
+                  ("strong_rehearsal.txt", "strong_rehearsal.txt"), ("hash_pmc_after.txt", "hash_pmc_after.txt"), ("libsort_yardstick.txt", "libsort_yardstick.txt")):
     f = only(name, required=False)
     if f:
         shutil.copy(f, os.path.join(dst, f"{tag}_{out}"))

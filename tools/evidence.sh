@@ -37,6 +37,8 @@ done
 # rank of a strong-scaling run does) and the LDS counters of the hash consumers as they are now
 timeout 120 tools/hashlds > $O/hashlds.txt 2>&1
 timeout 240 tools/widedigit > $O/widedigit.txt 2>&1
+timeout 120 tools/libsort_yardstick > $O/libsort_yardstick.txt 2>&1     # the vendor library's radix sort on the ORDER BY workloads (a yardstick)
+(echo; echo "hark's own ORDER BY on the same box, same call (tools/op_one.py, wall per statement incl. the two-column result):"; for w in sort20 sort32 sort64; do timeout 100 python tools/op_one.py $w 2>/dev/null | tail -n 1; done) >> $O/libsort_yardstick.txt
 timeout 200 python tools/nofilter_ab.py > $O/nofilter_ab.txt 2>&1
 timeout 200 python tools/ingest_bench.py > $O/ingest_bench.log 2>&1
 timeout 300 bash tools/strong_rehearsal.sh > $O/strong_rehearsal.txt 2>&1
