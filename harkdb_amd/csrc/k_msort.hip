@@ -5,12 +5,15 @@
 // a histogram pass each: 19.6 GB moved per 1e8 rows, profiles/r04_op_traffic.txt).  The tuples carry the row id, so nothing
 // has to be stable on the way -- (key, row id) is a total order -- and three sweeps do:
 //
-//   msd_sample / msd_setup   bounds of the keys from a sample -> a monotone map key -> bucket d in [0, D), D = 256 * nb2
-//                            (d = ((key - kmin) >> sh) * mul >> 32, clamped: whatever the sample missed lands in the first or
-//                            last bucket, the order of the buckets still is the order of the keys)
+//   msd_sample / msd_setup   bounds of the keys from a sample -> a monotone map key -> position a in [0, 2^24) -> bucket d in [0, D),
+//                            D = 256 * nb2 (a = ((key - kmin) >> sh) * mulA >> 32, clamped: whatever the sample missed lands in the
+//                            first or last bucket, the order of the buckets still is the order of the keys; d = a >> s)
 //   msd_hist                 workgroup w counts the level-1 digits (d / nb2) of ITS rows [w S, (w + 1) S): exact sizes of
 //                            the 256 x 256 slabs, so no slab can overflow whatever the order of the input (a sorted column
-//                            sends all rows of a workgroup to one bucket)
+//                            sends all rows of a workgroup to one bucket) -- and the keys per cell of 4096 positions
+//   msd_scan1 / msd_eq       a level-1 bucket far above the average = a lumpy distribution (normal, exponential ...): the cells'
+//                            counts then EQUALISE the map (d = the cell's share of the buckets, interpolated inside the cell),
+//                            msd_hist counts again under the new map, and only a second failure gives up
 //   msd_part<true>   sweep 1 the same workgroup forms tuples (key ^ xorm, row id, value) from its rows and routes them to its
 //                            slab of their bucket: a tile of 4096 tuples is counting-sorted by digit in LDS, every bucket's
 //                            run leaves in whole 128-byte lines (up to seven tuples per bucket wait in LDS for the next tile)
@@ -38,14 +41,15 @@ constexpr int kFRunMax = 64;                                 // longest run of o
 constexpr int kSampleWg = 256;
 
 #ifdef HARK_MSD_CHECK
-// bounds checks for experiments (tools/ab_build.sh chk "-DHARK_MSD_CHECK"): a violation is recorded in flag[2..3] and the access skipped
-#define MSD_CHK(ok, code, val) ((ok) ? true : (atomicCAS(&flag[2], 0, (int32_t)(code)) == 0 ? (flag[3] = (int32_t)(val), flag[4] = (int32_t)blockIdx.x, flag[5] = (int32_t)threadIdx.x, atomicOr(&flag[0], 64), false) : false))
-#define MSD_NOTE(a, b) (flag[6] = (int32_t)(a), flag[7] = (int32_t)(b))
+// bounds checks for experiments (tools/ab_build.sh chk "-DHARK_MSD_CHECK"): a violation is recorded in flag[4..7] and the access skipped
+#define MSD_CHK(ok, code, val) ((ok) ? true : (atomicCAS(&flag[4], 0, (int32_t)(code)) == 0 ? (flag[5] = (int32_t)(val), flag[6] = (int32_t)blockIdx.x, flag[7] = (int32_t)threadIdx.x, atomicOr(&flag[0], 64), false) : false))
+#define MSD_NOTE(a, b) ((void)0)
 #else
 #define MSD_CHK(ok, code, val) true
 #define MSD_NOTE(a, b) ((void)0)
 #endif
-struct MsdMap { u64 kmin; uint32_t sh, mul, dmax, mul3; u64 q48; };   // mul3, q48: the final digit (msd_final_kernel)
+constexpr int kCells = 4096;                                 // cells of the equalisation table: position >> 12
+struct MsdMap { u64 kmin; uint32_t sh, mulA, dmax, s24; };   // position a = reduced key * mulA >> 32 < 2^24; bucket = a >> s24 unless equalised
 
 __device__ __forceinline__ uint32_t reduced_key(u64 key, u64 kmin, uint32_t sh)
 {
@@ -53,21 +57,50 @@ __device__ __forceinline__ uint32_t reduced_key(u64 key, u64 kmin, uint32_t sh)
     const u64 h = rel >> sh;
     return h > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)h;    // (above the sampled maximum: the last bucket)
 }
-__device__ __forceinline__ uint32_t bucket_of(u64 key, const MsdMap &m)
+// tab (LDS, or null): the equalisation table -- per cell {first bucket, buckets per position} in 1/32768 buckets
+__device__ __forceinline__ uint32_t bucket_of(u64 key, const MsdMap &m, const uint2 *tab)
 {
-    const uint32_t d = __umulhi(reduced_key(key, m.kmin, m.sh), m.mul);
+    const uint32_t a = __umulhi(reduced_key(key, m.kmin, m.sh), m.mulA);
+    if (!tab) return a >> m.s24;
+    const uint2 t = tab[a >> 12];
+    const uint32_t d = (t.x + t.y * (a & 4095u)) >> 15;
     return d < m.dmax ? d : m.dmax;
 }
 
 // Has an earlier step given up?  ONE lane asks and the workgroup shares the answer: the word may be raised by another workgroup of
 // the SAME kernel while this one's waves are still starting, and a workgroup whose waves disagree loses the work of those that
 // left (round 5: a final bucket's scan total was never written, the scatter indices behind it went anywhere in LDS and beyond).
-__device__ __forceinline__ bool msd_gave_up(const int32_t *flag)
+__device__ __forceinline__ bool msd_gave_up(const int32_t *flag, bool *equalised = nullptr)
 {
-    __shared__ int32_t s_gave_up;
-    if (threadIdx.x == 0) s_gave_up = *reinterpret_cast<const volatile int32_t *>(flag);
+    __shared__ int32_t s_gave_up, s_eq;
+    if (threadIdx.x == 0) { s_gave_up = *reinterpret_cast<const volatile int32_t *>(flag); s_eq = reinterpret_cast<const volatile int32_t *>(flag)[2]; }
     __syncthreads();
+    if (equalised) *equalised = s_eq != 0;
     return s_gave_up != 0;
+}
+// the equalisation table into LDS (when the map is equalised), else no table
+__device__ __forceinline__ const uint2 *msd_table(bool equalised, const uint2 *__restrict__ tab_g, uint2 *tab_lds)
+{
+    if (!equalised) return nullptr;
+    for (int i = threadIdx.x; i < kCells; i += blockDim.x) tab_lds[i] = tab_g[i];
+    __syncthreads();
+    return tab_lds;
+}
+// Tuples of a wave are counted / ranked per bucket with LDS atomics; when every live lane of the wave has the SAME bucket (a
+// sorted or clustered column: all 64 atomics on one address, one after the other) one lane adds for all.
+__device__ __forceinline__ uint32_t bucket_rank(uint32_t *cnt, uint32_t d, bool live)
+{
+    const unsigned long long lm = __ballot(live);
+    if (lm == 0ull) return 0u;
+    const int first = __ffsll((long long)lm) - 1;
+    const uint32_t d0 = (uint32_t)__shfl((int)d, first, 64);
+    if (__ballot(live && d != d0) == 0ull) {
+        uint32_t base = 0u;
+        if ((int)(threadIdx.x & 63) == first) base = atomicAdd(&cnt[d0], (uint32_t)__popcll(lm));
+        base = (uint32_t)__shfl((int)base, first, 64);
+        return base + __builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u));
+    }
+    return live ? atomicAdd(&cnt[d], 1u) : 0u;
 }
 
 // ---- bounds from a sample -------------------------------------------------------------------------------------------------
@@ -107,28 +140,42 @@ __global__ void msd_setup_kernel(const u64 *__restrict__ mm, uint32_t D, MsdMap 
     uint32_t sh = 0;
     while ((range >> sh) > 0xFFFFFFFEull) sh++;
     const u64 r32 = (range >> sh) + 1ull;                    // reduced keys lie in [0, r32), r32 <= 2^32 - 1
-    u64 mul = ((u64)D << 32) / r32;                          // d = h * mul >> 32 < D for h < r32
-    if (mul > 0xFFFFFFFFull) mul = 0xFFFFFFFFull;            // (fewer distinct reduced keys than buckets)
-    // the final digit: a bucket's reduced keys start at about f * 2^32 / mul = f * q48 >> 16 (never above the true start, at most 2
-    // below it) and span at most 2^32 / mul + 1 values, which mul3 spreads over kFBins bins
-    const u64 width = (0x100000000ull / mul) + 1ull;
-    u64 mul3 = ((u64)kFBins << 32) / width; if (mul3 > 0xFFFFFFFFull) mul3 = 0xFFFFFFFFull;
-    map->kmin = lo; map->sh = sh; map->mul = (uint32_t)mul; map->dmax = D - 1u; map->mul3 = (uint32_t)mul3; map->q48 = (1ull << 48) / mul;
+    u64 mulA = (1ull << 56) / r32;                           // a = h * mulA >> 32 < 2^24 for h < r32
+    if (mulA > 0xFFFFFFFFull) mulA = 0xFFFFFFFFull;          // (fewer than 2^24 distinct reduced keys: a = h, about)
+    uint32_t s24 = 24u; for (uint32_t x = D; x > 1u; x >>= 1) s24--;
+    map->kmin = lo; map->sh = sh; map->mulA = (uint32_t)mulA; map->dmax = D - 1u; map->s24 = s24;
 }
 
 // ---- level-1 histogram: exact slab sizes ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kT) void msd_hist_kernel(const u64 *__restrict__ col, int64_t n, int64_t slice, u64 xorm, const MsdMap *__restrict__ mapp,
-                                                      int nb2log, uint32_t *__restrict__ counts1 /* [nwg][256] */, const int32_t *__restrict__ flag)
+// pass 0: under the affine map, and the keys per cell of 4096 positions beside it; pass 1 (only when msd_scan1 found the
+// distribution lumpy and msd_eq equalised the map): the slab sizes again, under the new map.
+__global__ __launch_bounds__(kT) void msd_hist_kernel(int pass, const u64 *__restrict__ col, int64_t n, int64_t slice, u64 xorm, const MsdMap *__restrict__ mapp,
+                                                      const uint2 *__restrict__ tab_g, int nb2log, uint32_t *__restrict__ counts1 /* [nwg][256] */,
+                                                      uint32_t *__restrict__ cells /* [4096], pass 0 */, const int32_t *__restrict__ flag)
 {
-    __shared__ uint32_t s_cnt[kB];
-    if (msd_gave_up(flag)) return;                                         // an earlier step gave up: nothing to do
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(lds_raw);               // [kB]
+    uint32_t *s_cell = s_cnt + kB;                                         // [kCells] (pass 0)
+    uint2 *s_tab = reinterpret_cast<uint2 *>(s_cell);                      // [kCells] (pass 1: the same room)
+    bool eq;
+    if (msd_gave_up(flag, &eq)) return;                                    // an earlier step gave up: nothing to do
+    if (pass == 1 && !eq) return;                                          // the affine map did: nothing to count again
     const MsdMap m = *mapp;
+    const uint2 *tab = pass == 1 ? msd_table(true, tab_g, s_tab) : nullptr;
     if (threadIdx.x < kB) s_cnt[threadIdx.x] = 0u;
+    if (pass == 0) for (int i = threadIdx.x; i < kCells; i += kT) s_cell[i] = 0u;
     __syncthreads();
     const int64_t lo = (int64_t)blockIdx.x * slice, hi = lo + slice < n ? lo + slice : n;
     // eight keys per thread and round in four 16-byte loads, all issued before the first digit is counted (64 KB in flight per CU:
     // with one 8-byte load per lane the pass ran at the latency of a load, 3.4 TB/s)
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    auto count = [&](u64 key, bool live) {
+        const uint32_t a = __umulhi(reduced_key(key, m.kmin, m.sh), m.mulA);
+        uint32_t d = a >> m.s24;
+        if (tab) { const uint2 t = tab[a >> 12]; d = (t.x + t.y * (a & 4095u)) >> 15; d = d < m.dmax ? d : m.dmax; }
+        bucket_rank(s_cnt, d >> nb2log, live);
+        if (pass == 0) bucket_rank(s_cell, a >> 12, live);
+    };
     for (int64_t t0 = lo; t0 < hi; t0 += 8 * kT) {             // (lo and the slices are multiples of the tile: 16-byte aligned pairs)
         u64x2 k[4];
 #pragma unroll
@@ -140,13 +187,15 @@ __global__ __launch_bounds__(kT) void msd_hist_kernel(const u64 *__restrict__ co
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int64_t i = t0 + 2 * ((int64_t)q * kT + threadIdx.x);
-            if (i < hi) atomicAdd(&s_cnt[bucket_of(k[q].x ^ xorm, m) >> nb2log], 1u);
-            if (i + 1 < hi) atomicAdd(&s_cnt[bucket_of(k[q].y ^ xorm, m) >> nb2log], 1u);
+            count(k[q].x ^ xorm, i < hi);
+            count(k[q].y ^ xorm, i + 1 < hi);
         }
     }
     __syncthreads();
     if (threadIdx.x < kB) counts1[(size_t)blockIdx.x * kB + threadIdx.x] = s_cnt[threadIdx.x];
+    if (pass == 0) for (int i = threadIdx.x; i < kCells; i += kT) { const uint32_t c = s_cell[i]; if (c) atomicAdd(&cells[i], c); }
 }
+constexpr size_t msd_hist_lds() { return (size_t)kB * 4 + (size_t)kCells * 8; }
 
 // exclusive scan over the 1024 threads of a workgroup (x = this thread's sum); *total = the sum of all
 __device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t x, uint32_t *s_wave /* [16] */, uint32_t *total)
@@ -165,14 +214,28 @@ __device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t x, uint32_t *s
 // Slab offsets, bucket-major: bucket b's slabs (workgroup 0 .. nwg - 1) lie one behind the other, every slab padded to whole
 // lines of eight tuples.  off1[w][b] = first tuple of slab (w, b); bstart[b] = first tuple of bucket b, bstart[256] = the end;
 // bfirst[b] = the rows of the buckets before b (where bucket b's rows start in the sorted output).
-__global__ __launch_bounds__(1024) void msd_scan1_kernel(const uint32_t *__restrict__ counts1, int nwg, uint32_t *__restrict__ off1, uint32_t *__restrict__ bstart,
-                                                         uint32_t *__restrict__ bfirst)
+// Also the first place where a lumpy distribution shows: a level-1 bucket with more than 1.5 x the average would overflow its
+// final buckets (capacity 1.6-3.2 x their average).  Under the affine map (pass 0) that asks for the equalised map (flag[2]);
+// under the equalised map (pass 1) the path gives up -- before the sweeps, not after two of them.
+__global__ __launch_bounds__(1024) void msd_scan1_kernel(int pass, const uint32_t *__restrict__ counts1, int nwg, uint32_t *__restrict__ off1, uint32_t *__restrict__ bstart,
+                                                         uint32_t *__restrict__ bfirst, int64_t n, int32_t *__restrict__ flag)
 {
-    __shared__ uint32_t s_wave[16], s_wave2[16];
+    __shared__ uint32_t s_wave[16], s_wave2[16], s_bucket[kB];
+    bool eq;
+    if (msd_gave_up(flag, &eq)) return;
+    if (pass == 1 && !eq) return;
+    if (threadIdx.x < kB) s_bucket[threadIdx.x] = 0u;
+    __syncthreads();
     // thread t owns the entries [t * per, (t + 1) * per) of the bucket-major order (entry e = b * nwg + w)
     const int total = kB * nwg, per = (total + 1023) / 1024;
     uint32_t sum = 0, exact = 0;
-    for (int e = threadIdx.x * per; e < (threadIdx.x + 1) * per && e < total; e++) { const int b = e / nwg, w = e - b * nwg; const uint32_t c = counts1[(size_t)w * kB + b]; sum += (c + 7u) & ~7u; exact += c; }
+    for (int e = threadIdx.x * per; e < (threadIdx.x + 1) * per && e < total; e++) {
+        const int b = e / nwg, w = e - b * nwg; const uint32_t c = counts1[(size_t)w * kB + b];
+        sum += (c + 7u) & ~7u; exact += c;
+        if (c) atomicAdd(&s_bucket[b], c);
+    }
+    __syncthreads();
+    if (threadIdx.x < kB && (int64_t)s_bucket[threadIdx.x] > n / kB + n / (2 * kB) + 4096) { if (pass == 0) flag[2] = 1; else atomicOr(&flag[0], 32); }
     uint32_t all, all2;
     uint32_t at = block_excl_scan_1024(sum, s_wave, &all);
     uint32_t ex = block_excl_scan_1024(exact, s_wave2, &all2);
@@ -183,6 +246,63 @@ __global__ __launch_bounds__(1024) void msd_scan1_kernel(const uint32_t *__restr
         off1[(size_t)w * kB + b] = at;
         if (w == 0) { bstart[b] = at; bfirst[b] = ex; }
         at += (c + 7u) & ~7u; ex += c;
+    }
+}
+
+// The equalised map: the keys before a cell and the keys in it, as shares of the D buckets in 1/32768 buckets -- bucket of position
+// a = (first + per_position * (a % 4096)) >> 15 (monotone: a cell's last position stays below the next cell's first bucket share).
+__global__ __launch_bounds__(1024) void msd_eq_kernel(const uint32_t *__restrict__ cells, int64_t n, uint32_t D, uint2 *__restrict__ tab, const int32_t *__restrict__ flag)
+{
+    __shared__ uint32_t s_wave[16];
+    bool eq;
+    if (msd_gave_up(flag, &eq) || !eq) return;
+    const uint32_t c0 = cells[4 * threadIdx.x], c1 = cells[4 * threadIdx.x + 1], c2 = cells[4 * threadIdx.x + 2], c3 = cells[4 * threadIdx.x + 3];
+    uint32_t all;
+    const uint32_t before = block_excl_scan_1024(c0 + c1 + c2 + c3, s_wave, &all);
+    const uint32_t cs[4] = {c0, c1, c2, c3};
+    u64 run = before;
+    for (int j = 0; j < 4; j++) {
+        const u64 first = (run * D << 15) / (u64)n, per = (((u64)cs[j] * D << 15) / (u64)n) >> 12;
+        tab[4 * threadIdx.x + j] = uint2{(uint32_t)first, (uint32_t)per};
+        run += cs[j];
+    }
+}
+
+// Where a final bucket's reduced keys start (the smallest reduced key the map sends to bucket f or beyond) and the factor that
+// spreads the bucket's reduced keys over the kFBins final digits: msd_final's constants, one thread per bucket.
+__global__ __launch_bounds__(256) void msd_bounds_kernel(const MsdMap *__restrict__ mapp, const uint2 *__restrict__ tab, uint32_t D, uint32_t *__restrict__ lo_h /* [D + 1] */,
+                                                         uint32_t *__restrict__ mul3 /* [D] */, const int32_t *__restrict__ flag)
+{
+    bool eq;
+    if (msd_gave_up(flag, &eq)) return;
+    const MsdMap m = *mapp;
+    const uint32_t f = blockIdx.x * 256 + threadIdx.x;
+    if (f > D) return;
+    // the smallest position a with bucket(a) >= f
+    auto first_position = [&](uint32_t b) -> u64 {
+        if (b >= D) return 1ull << 24;
+        if (!eq) return (u64)b << m.s24;
+        const u64 want = (u64)b << 15;
+        int lo = 0, hi = kCells - 1;                                       // the last cell whose first share is <= want
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if ((u64)tab[mid].x <= want) lo = mid; else hi = mid - 1; }
+        const uint2 t = tab[lo];
+        const u64 need = want - t.x;
+        u64 pos = need == 0 ? 0 : (t.y ? (need + t.y - 1) / t.y : 4096ull);
+        if (pos > 4096ull) pos = 4096ull;
+        return (u64)lo * 4096ull + pos;
+    };
+    auto first_reduced = [&](uint32_t b) -> u64 {                           // the smallest h with h * mulA >> 32 >= position
+        const u64 a = first_position(b);
+        const u64 h = ((a << 32) + m.mulA - 1ull) / m.mulA;
+        return h > 0xFFFFFFFFull ? 0xFFFFFFFFull : h;
+    };
+    const u64 h0 = first_reduced(f);
+    lo_h[f] = (uint32_t)h0;
+    if (f < D) {
+        const u64 h1 = first_reduced(f + 1u);
+        const u64 w = h1 > h0 ? h1 - h0 : 1ull;
+        u64 x = ((u64)kFBins << 32) / w; if (x > 0xFFFFFFFFull) x = 0xFFFFFFFFull;
+        mul3[f] = (uint32_t)x;
     }
 }
 
@@ -204,7 +324,7 @@ template <bool FIRST>
 __global__ __launch_bounds__(kT) void msd_part_kernel(
     const u64 *__restrict__ col, const uint32_t *__restrict__ valcol, int64_t n, int64_t slice, u64 xorm,      // FIRST
     const uint4 *__restrict__ tin, const uint32_t *__restrict__ bstart,                                          // !FIRST
-    const MsdMap *__restrict__ mapp, int nb2log,
+    const MsdMap *__restrict__ mapp, const uint2 *__restrict__ tab_g, int nb2log,
     uint4 *__restrict__ tout, const uint32_t *__restrict__ off1 /* FIRST: [nwg][256] */, uint32_t cap2 /* !FIRST */,
     uint32_t *__restrict__ counts2 /* !FIRST: [256 << nb2log] */, const uint32_t *__restrict__ bfirst /* !FIRST */, uint32_t *__restrict__ outoff /* !FIRST */,
     int32_t *__restrict__ flag, size_t tin_cap, size_t tout_cap /* tuples in the two buffers (checked builds) */)
@@ -216,8 +336,11 @@ __global__ __launch_bounds__(kT) void msd_part_kernel(
     uint32_t *base = cnt + kB;                                             // [kB] ... their first slot in buf
     uint32_t *cur = base + kB;                                             // [kB] tuples written to the bucket's destination so far
     uint32_t *ncarry = cur + kB;                                           // [kB]
-    if (msd_gave_up(flag)) return;                                         // an earlier step gave up: nothing to do
+    uint2 *s_tab = reinterpret_cast<uint2 *>(ncarry + kB);                 // [kCells] the equalisation table (when the map is equalised)
+    bool eq;
+    if (msd_gave_up(flag, &eq)) return;                                    // an earlier step gave up: nothing to do
     const MsdMap m = *mapp;
+    const uint2 *tab = msd_table(eq, tab_g, s_tab);
     const int nb = FIRST ? kB : (1 << nb2log);                             // buckets of this sweep
     const uint32_t b1 = blockIdx.x;
     int64_t lo, hi;
@@ -253,9 +376,9 @@ __global__ __launch_bounds__(kT) void msd_part_kernel(
         uint32_t d[kR], r[kR];
 #pragma unroll
         for (int k = 0; k < kR; k++) {
-            const uint32_t bk = bucket_of(((u64)t[k].y << 32) | t[k].x, m);
+            const uint32_t bk = bucket_of(((u64)t[k].y << 32) | t[k].x, m, tab);
             d[k] = FIRST ? (bk >> nb2log) : (bk & (uint32_t)(nb - 1));
-            r[k] = t[k].z != kDead ? atomicAdd(&cnt[d[k]], 1u) : 0u;
+            r[k] = bucket_rank(cnt, d[k], t[k].z != kDead);
         }
         lds_barrier();
         if (threadIdx.x < 64) scan256_by_wave(cnt, base);
@@ -302,8 +425,8 @@ __global__ __launch_bounds__(kT) void msd_part_kernel(
     }
     if (over) atomicOr(&flag[0], 4);
 }
-constexpr size_t msd_part_lds() { return (size_t)kTile * 16 + (size_t)kB * 8 * 16 + (size_t)kB * 4 * 4; }
-constexpr size_t msd_final_lds() { return (size_t)kFCap * 16 + (size_t)(kFBins + 4) * 4 + (size_t)(kFT / 64) * 4 + 2 * 256 * 4; }
+constexpr size_t msd_part_lds() { return (size_t)kTile * 16 + (size_t)kB * 8 * 16 + (size_t)kB * 4 * 4 + (size_t)kCells * 8; }
+constexpr size_t msd_final_lds() { return (size_t)kFCap * 16 + (size_t)(kFBins + 4) * 4 + (size_t)(kFT / 64) * 4 + 4 * 256 * 4; }
 
 // ---- sweep 3: the final buckets are sorted in LDS -------------------------------------------------------------------------------
 // Two workgroups per CU walk over the buckets; the NEXT bucket's tuples (and the size of the one after it) are loaded while a
@@ -311,14 +434,15 @@ constexpr size_t msd_final_lds() { return (size_t)kFCap * 16 + (size_t)(kFBins +
 // ~10 us per bucket with two workgroups per CU: 1.26 ms per 1e8 rows for 0.8 ms of traffic).
 constexpr int kFMine = 256;                                  // buckets per workgroup at most (D <= 65536, >= 256 workgroups)
 __global__ __launch_bounds__(kFT) void msd_final_kernel(const uint4 *__restrict__ tin, uint32_t cap2, const uint32_t *__restrict__ counts2, const uint32_t *__restrict__ outoff,
-                                                        uint32_t D, const MsdMap *__restrict__ mapp, u64 *__restrict__ keys_out, uint32_t *__restrict__ perm_out,
+                                                        const uint32_t *__restrict__ lo_h, const uint32_t *__restrict__ mul3, uint32_t D, const MsdMap *__restrict__ mapp, u64 *__restrict__ keys_out, uint32_t *__restrict__ perm_out,
                                                         uint32_t *__restrict__ val_out, u64 out_xor, int32_t *__restrict__ flag, size_t n_rows)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     uint4 *buf = reinterpret_cast<uint4 *>(lds_raw);                       // [kFCap]
     uint32_t *cnt = reinterpret_cast<uint32_t *>(buf + kFCap);             // [kFBins + 4] counts, then exclusive offsets (cnt[kFBins] = the total)
     uint32_t *s_wave = cnt + kFBins + 4;                                   // [kFT / 64]
-    uint32_t *s_c = s_wave + kFT / 64, *s_o = s_c + kFMine;                // [kFMine] each: size and first output row of this workgroup's buckets
+    uint32_t *s_c = s_wave + kFT / 64, *s_o = s_c + kFMine;                // [kFMine] each: size and first output row of this workgroup's buckets,
+    uint32_t *s_lo = s_o + kFMine, *s_m3 = s_lo + kFMine;                  // ... their first reduced key and the factor of their final digit
     if (msd_gave_up(flag)) return;                                         // an earlier step gave up: nothing to do
     const MsdMap m = *mapp;
     const uint32_t step = gridDim.x;
@@ -334,7 +458,10 @@ __global__ __launch_bounds__(kFT) void msd_final_kernel(const uint4 *__restrict_
     };
     // sizes and output offsets of all of this workgroup's buckets, once (a load per bucket inside the loop would sit in front of
     // every LDS wait: scalar loads and LDS operations share a counter)
-    for (uint32_t j = threadIdx.x; j < (uint32_t)kFMine; j += kFT) { const uint32_t b = f + j * step; s_c[j] = b < D ? counts2[b] : 0u; s_o[j] = b < D ? outoff[b] : 0u; }
+    for (uint32_t j = threadIdx.x; j < (uint32_t)kFMine; j += kFT) {
+        const uint32_t b = f + j * step;
+        s_c[j] = b < D ? counts2[b] : 0u; s_o[j] = b < D ? outoff[b] : 0u; s_lo[j] = b < D ? lo_h[b] : 0u; s_m3[j] = b < D ? mul3[b] : 0u;
+    }
     __syncthreads();
     uint32_t c = s_c[0];
     uint4 t[kFR];
@@ -350,11 +477,11 @@ __global__ __launch_bounds__(kFT) void msd_final_kernel(const uint4 *__restrict_
         load(more ? fn : f, c_next, nx);                                   // in flight while this bucket is sorted (the last round loads for nobody)
         if (c) {
             // the final digit of a key: its reduced key relative to the bucket's first, spread over kFBins bins
-            const u64 hlo = ((u64)f * m.q48) >> 16;
+            const uint32_t hlo = s_lo[it], m3 = s_m3[it];
             auto bin_of = [&](u64 key) -> uint32_t {
                 const uint32_t h = reduced_key(key, m.kmin, m.sh);
-                const uint32_t rel = (u64)h > hlo ? (uint32_t)((u64)h - hlo) : 0u;
-                const uint32_t e = __umulhi(rel, m.mul3);
+                const uint32_t rel = h > hlo ? h - hlo : 0u;
+                const uint32_t e = __umulhi(rel, m3);
                 return e < (uint32_t)kFBins ? e : (uint32_t)kFBins - 1u;
             };
             MSD_CHK(c <= (uint32_t)kFCap, 10, c);
@@ -445,12 +572,17 @@ int k_sort_i64_msd(hark_context *ctx, const void *col, int64_t n, const uint32_t
     const int64_t slice = ((n + nwg - 1) / nwg + kTile - 1) / kTile * kTile;
     const uint32_t cap2 = (uint32_t)kFCap;
     u64 *mm = nullptr; MsdMap *map = nullptr; int32_t *flag = nullptr;
-    uint32_t *counts1 = nullptr, *off1 = nullptr, *bstart = nullptr, *bfirst = nullptr, *counts2 = nullptr, *outoff = nullptr, *perm = nullptr, *val = nullptr;
+    uint32_t *counts1 = nullptr, *off1 = nullptr, *bstart = nullptr, *bfirst = nullptr, *counts2 = nullptr, *outoff = nullptr, *cells = nullptr, *lo_h = nullptr, *mul3 = nullptr;
+    uint32_t *perm = nullptr, *val = nullptr;
+    uint2 *tab = nullptr;
     uint4 *slabs = nullptr, *regions = nullptr;
     unsigned char *small = nullptr;
-    const size_t small_bytes = 64 + 64 + (size_t)nwg * kB * 4 * 2 + (size_t)(kB + 8) * 4 * 2 + (size_t)D * 4 * 2;
-    int rc = hark_alloc(ctx, (void **)&small, small_bytes);
+    // one block for the small arrays: bounds 64 | map 32 | flags 32 | cells | table | counts1 | off1 | bstart | bfirst | counts2 | outoff | lo_h | mul3
+    const size_t o_cells = 128, o_tab = o_cells + (size_t)kCells * 4, o_c1 = o_tab + (size_t)kCells * 8, o_off1 = o_c1 + (size_t)nwg * kB * 4,
+                 o_bstart = o_off1 + (size_t)nwg * kB * 4, o_bfirst = o_bstart + (size_t)(kB + 8) * 4, o_c2 = o_bfirst + (size_t)(kB + 8) * 4,
+                 o_out = o_c2 + (size_t)D * 4, o_lo = o_out + (size_t)D * 4, o_m3 = o_lo + (size_t)(D + 8) * 4, small_bytes = o_m3 + (size_t)D * 4;
     const size_t slab_tuples = (size_t)n + 8ull * kB * nwg;
+    int rc = hark_alloc(ctx, (void **)&small, small_bytes);
     if (!rc) rc = hark_alloc(ctx, (void **)&slabs, slab_tuples * 16);
     if (!rc) rc = hark_alloc(ctx, (void **)&regions, (size_t)D * cap2 * 16);
     if (!rc) rc = hark_alloc(ctx, (void **)&perm, (size_t)n * 4);
@@ -462,29 +594,39 @@ int k_sort_i64_msd(hark_context *ctx, const void *col, int64_t n, const uint32_t
     if (rc == HARK_ENOMEM) { cleanup(false); ctx->err.clear(); return HARK_OK; }
     if (rc) { cleanup(false); return rc; }
     mm = reinterpret_cast<u64 *>(small); map = reinterpret_cast<MsdMap *>(small + 64); flag = reinterpret_cast<int32_t *>(small + 96);
-    counts1 = reinterpret_cast<uint32_t *>(small + 128); off1 = counts1 + (size_t)nwg * kB; bstart = off1 + (size_t)nwg * kB;
-    bfirst = bstart + kB + 8; counts2 = bfirst + kB + 8; outoff = counts2 + D;
+    cells = reinterpret_cast<uint32_t *>(small + o_cells); tab = reinterpret_cast<uint2 *>(small + o_tab);
+    counts1 = reinterpret_cast<uint32_t *>(small + o_c1); off1 = reinterpret_cast<uint32_t *>(small + o_off1);
+    bstart = reinterpret_cast<uint32_t *>(small + o_bstart); bfirst = reinterpret_cast<uint32_t *>(small + o_bfirst);
+    counts2 = reinterpret_cast<uint32_t *>(small + o_c2); outoff = reinterpret_cast<uint32_t *>(small + o_out);
+    lo_h = reinterpret_cast<uint32_t *>(small + o_lo); mul3 = reinterpret_cast<uint32_t *>(small + o_m3);
     const u64 mm_init[2] = {~0ull, 0ull};
+    HIP_TRY_RC(ctx, rc, hipMemsetAsync(small + 64, 0, 64 + (size_t)kCells * 4, st));   // map, flags (flag[0] gave up, [1] equal keys exist, [2] equalised map), cells
     HIP_TRY_RC(ctx, rc, hipMemcpyAsync(mm, mm_init, 16, hipMemcpyHostToDevice, st));
-    HIP_TRY_RC(ctx, rc, hipMemsetAsync(flag, 0, 32, st));
     const u64 *c64 = static_cast<const u64 *>(col);
     const size_t lds = msd_part_lds();
     HIP_TRY_RC(ctx, rc, hipFuncSetAttribute(reinterpret_cast<const void *>(&msd_part_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIP_TRY_RC(ctx, rc, hipFuncSetAttribute(reinterpret_cast<const void *>(&msd_part_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIP_TRY_RC(ctx, rc, hipFuncSetAttribute(reinterpret_cast<const void *>(&msd_final_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)msd_final_lds()));
+    const dim3 g1((unsigned)nwg), b1(kT);
     HARK_LAUNCH_RC(ctx, rc, msd_sample_kernel<<<dim3(kSampleWg), dim3(256), 0, st>>>(c64, n, xorm, 509, mm));
     HARK_LAUNCH_RC(ctx, rc, msd_setup_kernel<<<dim3(1), dim3(1), 0, st>>>(mm, (uint32_t)D, map, flag));
-    HARK_LAUNCH_RC(ctx, rc, msd_hist_kernel<<<dim3((unsigned)nwg), dim3(kT), 0, st>>>(c64, n, slice, xorm, map, nb2log, counts1, flag));
-    HARK_LAUNCH_RC(ctx, rc, msd_scan1_kernel<<<dim3(1), dim3(1024), 0, st>>>(counts1, nwg, off1, bstart, bfirst));
-    HARK_LAUNCH_RC(ctx, rc, msd_part_kernel<true><<<dim3((unsigned)nwg), dim3(kT), lds, st>>>(c64, val ? valcol : nullptr, n, slice, xorm, nullptr, nullptr, map, nb2log, slabs, off1, 0u, nullptr, nullptr, nullptr, flag, 0, slab_tuples));
-    HARK_LAUNCH_RC(ctx, rc, msd_part_kernel<false><<<dim3(kB), dim3(kT), lds, st>>>(nullptr, nullptr, n, 0, 0ull, slabs, bstart, map, nb2log, regions, nullptr, cap2, counts2, bfirst, outoff, flag, slab_tuples, (size_t)D * cap2));
+    // the slab sizes under the affine map; a lumpy distribution asks for the equalised map (flag[2]) and is counted again: the second
+    // round's kernels return at once when nobody asked
+    HARK_LAUNCH_RC(ctx, rc, msd_hist_kernel<<<g1, b1, msd_hist_lds(), st>>>(0, c64, n, slice, xorm, map, tab, nb2log, counts1, cells, flag));
+    HARK_LAUNCH_RC(ctx, rc, msd_scan1_kernel<<<dim3(1), dim3(1024), 0, st>>>(0, counts1, nwg, off1, bstart, bfirst, n, flag));
+    HARK_LAUNCH_RC(ctx, rc, msd_eq_kernel<<<dim3(1), dim3(1024), 0, st>>>(cells, n, (uint32_t)D, tab, flag));
+    HARK_LAUNCH_RC(ctx, rc, msd_hist_kernel<<<g1, b1, msd_hist_lds(), st>>>(1, c64, n, slice, xorm, map, tab, nb2log, counts1, cells, flag));
+    HARK_LAUNCH_RC(ctx, rc, msd_scan1_kernel<<<dim3(1), dim3(1024), 0, st>>>(1, counts1, nwg, off1, bstart, bfirst, n, flag));
+    HARK_LAUNCH_RC(ctx, rc, msd_bounds_kernel<<<dim3((unsigned)(D / 256 + 1)), dim3(256), 0, st>>>(map, tab, (uint32_t)D, lo_h, mul3, flag));
+    HARK_LAUNCH_RC(ctx, rc, msd_part_kernel<true><<<g1, b1, lds, st>>>(c64, val ? valcol : nullptr, n, slice, xorm, nullptr, nullptr, map, tab, nb2log, slabs, off1, 0u, nullptr, nullptr, nullptr, flag, 0, slab_tuples));
+    HARK_LAUNCH_RC(ctx, rc, msd_part_kernel<false><<<dim3(kB), b1, lds, st>>>(nullptr, nullptr, n, 0, 0ull, slabs, bstart, map, tab, nb2log, regions, nullptr, cap2, counts2, bfirst, outoff, flag, slab_tuples, (size_t)D * cap2));
     const int fgrid = D < 768 ? D : (3 * nwg >= 256 && 3 * nwg <= D ? 3 * nwg : 256);                   // >= 256 workgroups: <= 256 buckets each
-    HARK_LAUNCH_RC(ctx, rc, msd_final_kernel<<<dim3((unsigned)fgrid), dim3(kFT), msd_final_lds(), st>>>(regions, cap2, counts2, outoff, (uint32_t)D, map, reinterpret_cast<u64 *>(keys), perm, val, out_xor, flag, (size_t)n));
+    HARK_LAUNCH_RC(ctx, rc, msd_final_kernel<<<dim3((unsigned)fgrid), dim3(kFT), msd_final_lds(), st>>>(regions, cap2, counts2, outoff, lo_h, mul3, (uint32_t)D, map, reinterpret_cast<u64 *>(keys), perm, val, out_xor, flag, (size_t)n));
     int64_t verdict = 0;
     if (!rc) rc = hark_read_words(ctx, flag, &verdict, 1);
     if (rc) { cleanup(false); return rc; }
 #ifdef HARK_MSD_CHECK
-    if (verdict & 64) { int32_t fl[8]; hark_d2h(ctx, fl, flag, 32); fprintf(stderr, "MSD CHECK: violation code %d value %d block %d thread %d note %d %x (n=%lld D=%d nb2log=%d flags %x)\n", fl[2], fl[3], fl[4], fl[5], fl[6], fl[7], (long long)n, D, nb2log, fl[0]); }
+    if (verdict & 64) { int32_t fl[8]; hark_d2h(ctx, fl, flag, 32); fprintf(stderr, "MSD CHECK: violation code %d value %d block %d thread %d (n=%lld D=%d nb2log=%d flags %x equalised %d)\n", fl[4], fl[5], fl[6], fl[7], (long long)n, D, nb2log, fl[0], fl[2]); }
 #endif
     if ((verdict & 0xFFFFFFFFll) != 0) { cleanup(false); return HARK_OK; }          // did not fit: the tuple passes
     if (unique_out) *unique_out = ((verdict >> 32) & 0xFFFFFFFFll) ? 0 : 1;
