@@ -58,9 +58,15 @@ __device__ __forceinline__ uint32_t reduced_key(u64 key, u64 kmin, uint32_t sh)
     return h > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)h;    // (above the sampled maximum: the last bucket)
 }
 // tab (LDS, or null): the equalisation table -- per cell {first bucket, buckets per position} in 1/32768 buckets
-__device__ __forceinline__ uint32_t bucket_of(u64 key, const MsdMap &m, const uint2 *tab)
+// the position of a key: < 2^24 for reduced keys inside the sampled range by the choice of mulA, clamped for those above it
+__device__ __forceinline__ uint32_t position_of(u64 key, const MsdMap &m)
 {
     const uint32_t a = __umulhi(reduced_key(key, m.kmin, m.sh), m.mulA);
+    return a < 0xFFFFFFu ? a : 0xFFFFFFu;
+}
+__device__ __forceinline__ uint32_t bucket_of(u64 key, const MsdMap &m, const uint2 *tab)
+{
+    const uint32_t a = position_of(key, m);
     if (!tab) return a >> m.s24;
     const uint2 t = tab[a >> 12];
     const uint32_t d = (t.x + t.y * (a & 4095u)) >> 15;
@@ -170,7 +176,7 @@ __global__ __launch_bounds__(kT) void msd_hist_kernel(int pass, const u64 *__res
     // with one 8-byte load per lane the pass ran at the latency of a load, 3.4 TB/s)
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
     auto count = [&](u64 key, bool live) {
-        const uint32_t a = __umulhi(reduced_key(key, m.kmin, m.sh), m.mulA);
+        const uint32_t a = position_of(key, m);
         uint32_t d = a >> m.s24;
         if (tab) { const uint2 t = tab[a >> 12]; d = (t.x + t.y * (a & 4095u)) >> 15; d = d < m.dmax ? d : m.dmax; }
         bucket_rank(s_cnt, d >> nb2log, live);
