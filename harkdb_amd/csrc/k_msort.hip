@@ -27,6 +27,7 @@
 // -- raises a flag and the caller takes the tuple passes as before (hark's result does not depend on the path).
 #include "hark_internal.h"
 #include <cstdio>
+#include <vector>
 
 typedef unsigned long long u64;
 
@@ -532,7 +533,12 @@ __global__ __launch_bounds__(kFT) void msd_final_kernel(const uint4 *__restrict_
                     const u64 key = ((u64)me.y << 32) | me.x;
                     const uint32_t b = bin_of(key), a0 = cnt[b], a1 = cnt[b + 1];
                     uint32_t at = a0;
-                    if (a1 - a0 > (uint32_t)kFRunMax) cnt[kFBins + 1] = 1u;          // (the scan left this word zero)
+                    if (a1 - a0 > (uint32_t)kFRunMax) {
+                        cnt[kFBins + 1] = 1u;                                        // (the scan left this word zero)
+#ifdef HARK_MSD_CHECK
+                        if (atomicCAS(&flag[4], 0, 100) == 0) { flag[5] = (int32_t)f; flag[6] = (int32_t)(a1 - a0); flag[7] = (int32_t)((b << 16) | (c & 0xFFFF)); flag[3] = (int32_t)hlo; atomicOr(&flag[0], 64); }
+#endif
+                    }
                     else if (a1 - a0 > 1u) for (uint32_t j = a0; j < a1; j++) {
                         const uint4 q = buf[j];
                         const u64 kj = ((u64)q.y << 32) | q.x;
@@ -631,8 +637,13 @@ int k_sort_i64_msd(hark_context *ctx, const void *col, int64_t n, const uint32_t
     int64_t verdict = 0;
     if (!rc) rc = hark_read_words(ctx, flag, &verdict, 1);
     if (rc) { cleanup(false); return rc; }
+    if (getenv("HARK_SORT_MSD_VERBOSE")) {                                           // experiments: what the path decided
+        int32_t fl[8]; hark_d2h(ctx, fl, flag, 32);
+        fprintf(stderr, "msd sort: n=%lld D=%d gave_up=%x equal_keys=%d equalised=%d\n", (long long)n, D, fl[0], fl[1], fl[2]);
+    }
 #ifdef HARK_MSD_CHECK
-    if (verdict & 64) { int32_t fl[8]; hark_d2h(ctx, fl, flag, 32); fprintf(stderr, "MSD CHECK: violation code %d value %d block %d thread %d (n=%lld D=%d nb2log=%d flags %x equalised %d)\n", fl[4], fl[5], fl[6], fl[7], (long long)n, D, nb2log, fl[0], fl[2]); }
+    if (verdict & 64) { int32_t fl[8]; hark_d2h(ctx, fl, flag, 32); fprintf(stderr, "MSD CHECK: violation code %d value %d block %d thread %x (n=%lld D=%d nb2log=%d flags %x equalised %d word3 %u)\n", fl[4], fl[5], fl[6], fl[7], (long long)n, D, nb2log, fl[0], fl[2], (unsigned)fl[3]);
+        if (fl[4] == 100) { std::vector<uint32_t> lo((size_t)D + 1), m3v((size_t)D); hark_d2h(ctx, lo.data(), lo_h, ((size_t)D + 1) * 4); hark_d2h(ctx, m3v.data(), mul3, (size_t)D * 4); int ff = fl[5]; fprintf(stderr, "   bucket %d: lo_h %u next %u mul3 %u (prev lo %u)\n", ff, lo[ff], lo[ff + 1], m3v[ff], ff ? lo[ff - 1] : 0u); } }
 #endif
     if ((verdict & 0xFFFFFFFFll) != 0) { cleanup(false); return HARK_OK; }          // did not fit: the tuple passes
     if (unique_out) *unique_out = ((verdict >> 32) & 0xFFFFFFFFll) ? 0 : 1;
