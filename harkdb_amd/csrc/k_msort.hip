@@ -38,7 +38,10 @@ constexpr int kB = 256;                                      // buckets per part
 constexpr uint32_t kDead = 0xFFFFFFFFu;                      // row id of a padding tuple
 constexpr int kFT = 512, kFR = 5, kFCap = kFT * kFR;         // final workgroup: 2560 tuples at most (three workgroups share a CU's LDS)
 constexpr int kFBins = 2048;
-constexpr int kFRunMax = 64;                                 // longest run of one final digit that is ranked by comparing
+constexpr int kFRunMax = 1024;                               // longest run of one final digit that is ranked by comparing: quadratic, but a run
+                                                             // of 1024 costs its bucket ~0.15 ms and a statement at most ~13 ms where the
+                                                             // caller's general path takes 21 (the tail buckets of a normal distribution
+                                                             // hold runs of a few hundred; 1000-fold duplicates of every key the worst case)
 constexpr int kSampleWg = 256;
 
 #ifdef HARK_MSD_CHECK
@@ -343,7 +346,8 @@ __global__ __launch_bounds__(kT) void msd_part_kernel(
     uint32_t *base = cnt + kB;                                             // [kB] ... their first slot in buf
     uint32_t *cur = base + kB;                                             // [kB] tuples written to the bucket's destination so far
     uint32_t *ncarry = cur + kB;                                           // [kB]
-    uint2 *s_tab = reinterpret_cast<uint2 *>(ncarry + kB);                 // [kCells] the equalisation table (when the map is equalised)
+    uint32_t *big = ncarry + kB, *nbig = big + 8;                          // [8] buckets with a long run in this tile (a tile has eight at most), their number
+    uint2 *s_tab = reinterpret_cast<uint2 *>(big + 16);                    // [kCells] the equalisation table (when the map is equalised)
     bool eq;
     if (msd_gave_up(flag, &eq)) return;                                    // an earlier step gave up: nothing to do
     const MsdMap m = *mapp;
@@ -379,6 +383,7 @@ __global__ __launch_bounds__(kT) void msd_part_kernel(
         for (int k = 0; k < kR; k++) t[k] = nx[k];
         if (t0 + kTile < hi) load(t0 + kTile, nx);                         // the next tile's loads are in flight while this one is sorted
         if (threadIdx.x < kB) cnt[threadIdx.x] = 0u;
+        if (threadIdx.x == 0) *nbig = 0u;
         lds_barrier();
         uint32_t d[kR], r[kR];
 #pragma unroll
@@ -393,20 +398,32 @@ __global__ __launch_bounds__(kT) void msd_part_kernel(
 #pragma unroll
         for (int k = 0; k < kR; k++) if (t[k].z != kDead && MSD_CHK(base[d[k]] + r[k] < (uint32_t)kTile, 6, base[d[k]] + r[k])) buf[base[d[k]] + r[k]] = t[k];
         lds_barrier();
-        // every bucket's run leaves in whole lines: sixteen lanes per bucket; what is left (< 8 tuples) waits in `carry`
+        // every bucket's run leaves in whole lines: sixteen lanes per bucket; what is left (< 8 tuples) waits in `carry`.  A run of
+        // kBig tuples and more (a sorted or clustered column puts a whole tile into one bucket: 256 rounds for one group of
+        // sixteen lanes while the other 63 wait) is left to the whole workgroup afterwards.
+        constexpr uint32_t kBig = 512;
         const int grp = threadIdx.x >> 4, l = threadIdx.x & 15;
-        for (int b = grp; b < nb; b += kT / 16) {
+        auto copy_out = [&](int b, uint32_t lane, uint32_t lanes, bool everyone) {
             const uint32_t cb = ncarry[b], run = cnt[b], total = cb + run, nfull = total & ~7u, at = cur[b];
-            if (!FIRST && at + nfull > cap2) { over = true; continue; }
+            if (everyone) lds_barrier();                                   // (every wave has read the bucket's state before the first one moves it on)
+            if (!FIRST && at + nfull > cap2) { over = true; return; }
             uint4 *dst = dest_of((uint32_t)b) + at;
             const uint4 *src = buf + base[b];
-            for (uint32_t i = l; i < nfull; i += 16) if (MSD_CHK((size_t)(dst + i - tout) < tout_cap && (i < cb || base[b] + i - cb < (uint32_t)kTile), FIRST ? 1 : 2, dst + i - tout)) st_nt16(dst + i, i < cb ? carry[b * 8 + i] : src[i - cb]);
-            const uint32_t rem = total - nfull, j = nfull + (uint32_t)l;
+            for (uint32_t i = lane; i < nfull; i += lanes) if (MSD_CHK((size_t)(dst + i - tout) < tout_cap && (i < cb || base[b] + i - cb < (uint32_t)kTile), FIRST ? 1 : 2, dst + i - tout)) st_nt16(dst + i, i < cb ? carry[b * 8 + i] : src[i - cb]);
+            const uint32_t rem = total - nfull, j = nfull + lane;
             uint4 keep = uint4{0u, 0u, kDead, 0u};
-            if ((uint32_t)l < rem) keep = j < cb ? carry[b * 8 + j] : src[j - cb];
-            if ((uint32_t)l < rem) carry[b * 8 + l] = keep;                // (a wave's LDS operations complete in order: the reads above came first)
-            if (l == 0) { cur[b] = at + nfull; ncarry[b] = rem; }
+            if (lane < rem) keep = j < cb ? carry[b * 8 + j] : src[j - cb];
+            if (lane < rem) carry[b * 8 + lane] = keep;                    // (a wave's LDS operations complete in order: the reads above came first;
+                                                                           // only the first eight lanes touch `carry`)
+            if (lane == 0) { cur[b] = at + nfull; ncarry[b] = rem; }
+        };
+        for (int b = grp; b < nb; b += kT / 16) {
+            if (ncarry[b] + cnt[b] >= kBig) { if (l == 0) big[atomicAdd(nbig, 1u)] = (uint32_t)b; continue; }
+            copy_out(b, (uint32_t)l, 16u, false);
         }
+        lds_barrier();
+        const uint32_t nbg = *nbig;
+        for (uint32_t q = 0; q < nbg; q++) copy_out((int)big[q], threadIdx.x, (uint32_t)kT, true);
         lds_barrier();
     }
     // the last partial lines, padded with dead tuples
@@ -432,7 +449,7 @@ __global__ __launch_bounds__(kT) void msd_part_kernel(
     }
     if (over) atomicOr(&flag[0], 4);
 }
-constexpr size_t msd_part_lds() { return (size_t)kTile * 16 + (size_t)kB * 8 * 16 + (size_t)kB * 4 * 4 + (size_t)kCells * 8; }
+constexpr size_t msd_part_lds() { return (size_t)kTile * 16 + (size_t)kB * 8 * 16 + (size_t)kB * 4 * 4 + 64 + (size_t)kCells * 8; }
 constexpr size_t msd_final_lds() { return (size_t)kFCap * 16 + (size_t)(kFBins + 4) * 4 + (size_t)(kFT / 64) * 4 + 4 * 256 * 4; }
 
 // ---- sweep 3: the final buckets are sorted in LDS -------------------------------------------------------------------------------

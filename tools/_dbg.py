@@ -10,8 +10,9 @@ def keys(kind):
     if kind == "normal": return (torch.randn(n, device=dev, generator=g, dtype=torch.float64) * 2.0**55).to(torch.int64)
     if kind == "dups_1e5": return torch.randint(0, 100_000, (n,), dtype=torch.int64, device=dev, generator=g) * 92233720368547
     if kind == "dups_1e7": return torch.randint(0, 10_000_000, (n,), dtype=torch.int64, device=dev, generator=g) * 922337203685
+    if kind == "exp": return (-torch.log(torch.rand(n, device=dev, generator=g, dtype=torch.float64)) * 2.0**52).to(torch.int64)
     if kind == "sorted": return torch.sort(torch.randint(-2**62, 2**62, (n,), dtype=torch.int64, device=dev, generator=g))[0]
-for kind in ("uniform", "normal", "dups_1e5", "dups_1e7", "sorted"):
+for kind in ("uniform", "normal", "dups_1e5", "dups_1e7", "sorted", "exp"):
     k = keys(kind); torch.cuda.synchronize()
     t = eng.table_from_device(n, [k.data_ptr(), au.data_ptr()], [np.int64, np.int32], keepalive=(k, au))
     for env in ("", "1"):
