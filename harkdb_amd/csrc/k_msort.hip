@@ -38,6 +38,9 @@ constexpr int kB = 256;                                      // buckets per part
 constexpr uint32_t kDead = 0xFFFFFFFFu;                      // row id of a padding tuple
 constexpr int kFT = 512, kFR = 5, kFCap = kFT * kFR;         // final workgroup: 2560 tuples at most (three workgroups share a CU's LDS)
 constexpr int kFBins = 2048;
+constexpr uint32_t kFWorkMax = 1u << 18;                     // ... and the sum of the squared run lengths of a bucket that is ranked at all (a run of
+                                                             // 500 alone; the tail buckets of a normal distribution come to 1e5): buckets of a
+                                                             // column with hundreds of copies of every key are over it, and the first one says so
 constexpr int kFRunMax = 1024;                               // longest run of one final digit that is ranked by comparing: quadratic, but a run
                                                              // of 1024 costs its bucket ~0.15 ms and a statement at most ~13 ms where the
                                                              // caller's general path takes 21 (the tail buckets of a normal distribution
@@ -450,7 +453,7 @@ __global__ __launch_bounds__(kT) void msd_part_kernel(
     if (over) atomicOr(&flag[0], 4);
 }
 constexpr size_t msd_part_lds() { return (size_t)kTile * 16 + (size_t)kB * 8 * 16 + (size_t)kB * 4 * 4 + 64 + (size_t)kCells * 8; }
-constexpr size_t msd_final_lds() { return (size_t)kFCap * 16 + (size_t)(kFBins + 4) * 4 + (size_t)(kFT / 64) * 4 + 4 * 256 * 4; }
+constexpr size_t msd_final_lds() { return (size_t)kFCap * 16 + (size_t)(kFBins + 4) * 4 + (size_t)(kFT / 64) * 4 * 2 + 4 * 256 * 4; }
 
 // ---- sweep 3: the final buckets are sorted in LDS -------------------------------------------------------------------------------
 // Two workgroups per CU walk over the buckets; the NEXT bucket's tuples (and the size of the one after it) are loaded while a
@@ -467,6 +470,7 @@ __global__ __launch_bounds__(kFT) void msd_final_kernel(const uint4 *__restrict_
     uint32_t *s_wave = cnt + kFBins + 4;                                   // [kFT / 64]
     uint32_t *s_c = s_wave + kFT / 64, *s_o = s_c + kFMine;                // [kFMine] each: size and first output row of this workgroup's buckets,
     uint32_t *s_lo = s_o + kFMine, *s_m3 = s_lo + kFMine;                  // ... their first reduced key and the factor of their final digit
+    uint32_t *s_sq = s_m3 + kFMine;                                        // [kFT / 64]
     if (msd_gave_up(flag)) return;                                         // an earlier step gave up: nothing to do
     const MsdMap m = *mapp;
     const uint32_t step = gridDim.x;
@@ -523,10 +527,15 @@ __global__ __launch_bounds__(kFT) void msd_final_kernel(const uint4 *__restrict_
                 const uint32_t c0 = cnt[4 * threadIdx.x], c1 = cnt[4 * threadIdx.x + 1], c2 = cnt[4 * threadIdx.x + 2], c3 = cnt[4 * threadIdx.x + 3];
                 uint32_t incl = c0 + c1 + c2 + c3;
                 for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d, 64); if (lane >= d) incl += y; }
-                if (lane == 63) s_wave[wv] = incl;
+                // ... and the work of the ranking below, which is quadratic in the length of a run: the squares of the bins' sizes
+                uint32_t sq = c0 * c0 + c1 * c1 + c2 * c2 + c3 * c3;
+                for (int d = 32; d; d >>= 1) sq += __shfl_xor(sq, d, 64);
+                if (lane == 63) { s_wave[wv] = incl; s_sq[wv] = sq; }
                 lds_barrier();
-                uint32_t before = 0;
-                for (int q = 0; q < wv; q++) before += s_wave[q];
+                uint32_t before = 0, work = 0;
+                for (int q = 0; q < kFT / 64; q++) { if (q < wv) before += s_wave[q]; work += s_sq[q]; }
+                if (work > kFWorkMax) { if (threadIdx.x == 0) atomicOr(&flag[0], 16); return; }   // many equal keys: the caller's other path (no other
+                                                                                                   // workgroup waits for this one: it may just leave)
                 const uint32_t excl = before + incl - (c0 + c1 + c2 + c3);
                 cnt[4 * threadIdx.x] = excl; cnt[4 * threadIdx.x + 1] = excl + c0; cnt[4 * threadIdx.x + 2] = excl + c0 + c1; cnt[4 * threadIdx.x + 3] = excl + c0 + c1 + c2;
                 if (threadIdx.x == kFT - 1) cnt[kFBins] = excl + c0 + c1 + c2 + c3;
