@@ -33,8 +33,10 @@ def make_keys(kind, n, rng):
     if kind == "few_distinct":              # heavy duplicates: a final bucket overflows -> the tuple passes
         pool = rng.integers(-2**62, 2**62, size=300)
         return pool[rng.integers(0, 300, size=n)]
-    if kind == "normal":                    # a lumpy distribution: the middle buckets hold several times the average
+    if kind == "normal":                    # a lumpy distribution: the affine map overfills the middle buckets, the equalised map does not
         return (rng.standard_normal(n) * 2.0**55).astype(np.int64)
+    if kind == "exponential":               # a long tail on one side: the equalised map
+        return (rng.exponential(size=n) * 2.0**52).astype(np.int64)
     if kind == "outliers":                  # two keys far outside everyone else's range (the sample may or may not see them)
         k = rng.integers(-2**40, 2**40, size=n)
         k[n // 3] = 2**62; k[n // 2] = -2**62
@@ -45,7 +47,7 @@ def make_keys(kind, n, rng):
     raise ValueError(kind)
 
 
-KINDS = ["spread", "sorted", "reversed", "positive_48", "range_2_33", "some_equal", "few_distinct", "normal", "outliers", "clusters"]
+KINDS = ["spread", "sorted", "reversed", "positive_48", "range_2_33", "some_equal", "few_distinct", "normal", "exponential", "outliers", "clusters"]
 
 
 @pytest.mark.parametrize("n", [(1 << 20) + 777, 3_000_001])
