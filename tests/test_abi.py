@@ -105,3 +105,15 @@ def test_build_checks_the_hand_placed_waits_behind_inline_asm_loads(tmp_path):
     unit.write_text(src.replace(marker, "        if (!HIDDEN || tid >= 0) return;\n        constexpr int kAheadLoads"))       # the waits are gone
     bad = subprocess.run([sys.executable, tool, str(unit)], capture_output=True, text=True, timeout=600)
     assert bad.returncode == 1 and "while an inline-asm load into them is in flight" in bad.stderr, bad.stdout + bad.stderr[-500:]
+
+
+def test_the_bounds_checked_build_of_the_i64_sort_still_compiles(tmp_path):
+    """k_msort.hip has a build for experiments in which every global and LDS index of its kernels is checked and a violation is
+    RECORDED instead of faulting (-DHARK_MSD_CHECK, tools/ab_build.sh): it found the workgroup that lost half its waves
+    (profiles/r05_notes.md 11).  A build nobody compiles rots; this compiles it (device code for gfx950, no GPU needed)."""
+    import subprocess
+    from conftest import ROOT
+    src = os.path.join(ROOT, "harkdb_amd", "csrc", "k_msort.hip")
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "-O1", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-DHARK_MSD_CHECK", "-I", os.path.join(ROOT, "include"),
+                        "-c", src, "-o", str(tmp_path / "k_msort_chk.o")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
