@@ -10,7 +10,7 @@
 //                            first or last bucket, the order of the buckets still is the order of the keys; d = a >> s)
 //   msd_hist                 workgroup w counts the level-1 digits (d / nb2) of ITS rows [w S, (w + 1) S): exact sizes of
 //                            the 256 x 256 slabs, so no slab can overflow whatever the order of the input (a sorted column
-//                            sends all rows of a workgroup to one bucket) -- and the keys per cell of 4096 positions
+//                            sends all rows of a workgroup to one bucket) -- and, of one key in eight, the keys per cell of 4096 positions
 //   msd_scan1 / msd_eq       a level-1 bucket far above the average = a lumpy distribution (normal, exponential ...): the cells'
 //                            counts then EQUALISE the map (d = the cell's share of the buckets, interpolated inside the cell),
 //                            msd_hist counts again under the new map, and only a second failure gives up
@@ -182,12 +182,12 @@ __global__ __launch_bounds__(kT) void msd_hist_kernel(int pass, const u64 *__res
     // eight keys per thread and round in four 16-byte loads, all issued before the first digit is counted (64 KB in flight per CU:
     // with one 8-byte load per lane the pass ran at the latency of a load, 3.4 TB/s)
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-    auto count = [&](u64 key, bool live) {
+    auto count = [&](u64 key, bool live, bool cell_too) {
         const uint32_t a = position_of(key, m);
         uint32_t d = a >> m.s24;
         if (tab) { const uint2 t = tab[a >> 12]; d = (t.x + t.y * (a & 4095u)) >> 15; d = d < m.dmax ? d : m.dmax; }
         bucket_rank(s_cnt, d >> nb2log, live);
-        if (pass == 0) bucket_rank(s_cell, a >> 12, live);
+        if (cell_too) bucket_rank(s_cell, a >> 12, live);                  // (one key in eight: the cells' RELATIVE sizes are what the map is made of)
     };
     for (int64_t t0 = lo; t0 < hi; t0 += 8 * kT) {             // (lo and the slices are multiples of the tile: 16-byte aligned pairs)
         u64x2 k[4];
@@ -200,8 +200,8 @@ __global__ __launch_bounds__(kT) void msd_hist_kernel(int pass, const u64 *__res
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int64_t i = t0 + 2 * ((int64_t)q * kT + threadIdx.x);
-            count(k[q].x ^ xorm, i < hi);
-            count(k[q].y ^ xorm, i + 1 < hi);
+            count(k[q].x ^ xorm, i < hi, pass == 0 && q == 0);
+            count(k[q].y ^ xorm, i + 1 < hi, false);
         }
     }
     __syncthreads();
@@ -274,8 +274,9 @@ __global__ __launch_bounds__(1024) void msd_eq_kernel(const uint32_t *__restrict
     const uint32_t before = block_excl_scan_1024(c0 + c1 + c2 + c3, s_wave, &all);
     const uint32_t cs[4] = {c0, c1, c2, c3};
     u64 run = before;
+    const u64 tot = all ? all : 1u;                                        // (the cells hold one key in eight: shares of THEIR total)
     for (int j = 0; j < 4; j++) {
-        const u64 first = (run * D << 15) / (u64)n, per = (((u64)cs[j] * D << 15) / (u64)n) >> 12;
+        const u64 first = (run * D << 15) / tot, per = (((u64)cs[j] * D << 15) / tot) >> 12;
         tab[4 * threadIdx.x + j] = uint2{(uint32_t)first, (uint32_t)per};
         run += cs[j];
     }
