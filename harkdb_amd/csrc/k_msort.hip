@@ -19,12 +19,13 @@
 //                            run leaves in whole 128-byte lines (up to seven tuples per bucket wait in LDS for the next tile)
 //   msd_part<false>  sweep 2 one workgroup per level-1 bucket reads the bucket (its slabs lie one behind the other, padded
 //                            with dead tuples to whole lines) and routes by d % nb2 into regions of fixed capacity, the same way
-//   msd_final        sweep 3 one workgroup per final bucket (<= 3584 tuples): counting sort in LDS by the next 11 bits of the
-//                            map, ranks inside the short runs of equal digits by comparing (key, row id), keys / row ids /
-//                            values written in order
+//   msd_bounds               where every final bucket's keys start and how wide they are: the final digit's constants
+//   msd_final        sweep 3 persistent workgroups sort the final buckets (<= 2560 tuples each) in LDS: counting sort by the next
+//                            11 bits, ranks inside the runs of equal digits by comparing (key, row id), keys / row ids / values
+//                            stored at their ranks; the next bucket's tuples are loaded while a bucket is sorted
 //
-// Whatever does not fit -- a final bucket over its capacity (heavy duplicates, a lumpy distribution), a long run of one digit
-// -- raises a flag and the caller takes the tuple passes as before (hark's result does not depend on the path).
+// Whatever does not fit -- a final bucket over its capacity (many copies of a key, tight clusters), too much ranking work in a
+// bucket -- raises a word and the caller takes the tuple passes as before (hark's result does not depend on the path).
 #include "hark_internal.h"
 #include <cstdio>
 #include <vector>
@@ -50,10 +51,8 @@ constexpr int kSampleWg = 256;
 #ifdef HARK_MSD_CHECK
 // bounds checks for experiments (tools/ab_build.sh chk "-DHARK_MSD_CHECK"): a violation is recorded in flag[4..7] and the access skipped
 #define MSD_CHK(ok, code, val) ((ok) ? true : (atomicCAS(&flag[4], 0, (int32_t)(code)) == 0 ? (flag[5] = (int32_t)(val), flag[6] = (int32_t)blockIdx.x, flag[7] = (int32_t)threadIdx.x, atomicOr(&flag[0], 64), false) : false))
-#define MSD_NOTE(a, b) ((void)0)
 #else
 #define MSD_CHK(ok, code, val) true
-#define MSD_NOTE(a, b) ((void)0)
 #endif
 constexpr int kCells = 4096;                                 // cells of the equalisation table: position >> 12
 struct MsdMap { u64 kmin; uint32_t sh, mulA, dmax, s24; };   // position a = reduced key * mulA >> 32 < 2^24; bucket = a >> s24 unless equalised
@@ -64,13 +63,13 @@ __device__ __forceinline__ uint32_t reduced_key(u64 key, u64 kmin, uint32_t sh)
     const u64 h = rel >> sh;
     return h > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)h;    // (above the sampled maximum: the last bucket)
 }
-// tab (LDS, or null): the equalisation table -- per cell {first bucket, buckets per position} in 1/32768 buckets
 // the position of a key: < 2^24 for reduced keys inside the sampled range by the choice of mulA, clamped for those above it
 __device__ __forceinline__ uint32_t position_of(u64 key, const MsdMap &m)
 {
     const uint32_t a = __umulhi(reduced_key(key, m.kmin, m.sh), m.mulA);
     return a < 0xFFFFFFu ? a : 0xFFFFFFu;
 }
+// tab (LDS, or null): the equalisation table -- per cell {first bucket, buckets per position} in 1/32768 buckets
 __device__ __forceinline__ uint32_t bucket_of(u64 key, const MsdMap &m, const uint2 *tab)
 {
     const uint32_t a = position_of(key, m);
@@ -543,7 +542,7 @@ __global__ __launch_bounds__(kFT) void msd_final_kernel(const uint4 *__restrict_
             }
             lds_barrier();
 #pragma unroll
-            for (int k = 0; k < kFR; k++) { const uint32_t i = (uint32_t)k * kFT + threadIdx.x; if ((uint32_t)k * kFT < c && i < c && (MSD_CHK(cnt[kFBins] == c, 11, cnt[kFBins]), MSD_CHK(cnt[e[k]] + r[k] < (uint32_t)kFCap, 9, cnt[e[k]] + r[k]) ? true : (MSD_NOTE(c, (e[k] << 16) | r[k]), false))) buf[cnt[e[k]] + r[k]] = t[k]; }
+            for (int k = 0; k < kFR; k++) { const uint32_t i = (uint32_t)k * kFT + threadIdx.x; if ((uint32_t)k * kFT < c && i < c && MSD_CHK(cnt[kFBins] == c, 11, cnt[kFBins]) && MSD_CHK(cnt[e[k]] + r[k] < (uint32_t)kFCap, 9, cnt[e[k]] + r[k])) buf[cnt[e[k]] + r[k]] = t[k]; }
             lds_barrier();
             // The next bucket's tuples are taken out of the load registers HERE, before this bucket's stores are issued: loads and stores
             // share one in-order counter, so a wait for the loads behind the stores would sit out the stores' completion -- every bucket.
