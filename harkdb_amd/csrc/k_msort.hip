@@ -315,6 +315,10 @@ __global__ __launch_bounds__(256) void msd_bounds_kernel(const MsdMap *__restric
         const u64 h1 = first_reduced(f + 1u);
         const u64 w = h1 > h0 ? h1 - h0 : 1ull;
         u64 x = ((u64)kFBins << 32) / w; if (x > 0xFFFFFFFFull) x = 0xFFFFFFFFull;
+        // A bucket of the equalised map that spans more than a cell is a TAIL bucket: its keys thin out exponentially towards one end,
+        // and a digit that divides its reduced keys evenly puts most of them into a few bins.  Factor 0 says: take the final digit
+        // from the equalised coordinate itself (its bits below the bucket number follow the cells' counts).
+        if (eq && first_position(f + 1u) - first_position(f) > 4096ull) x = 0ull;
         mul3[f] = (uint32_t)x;
     }
 }
@@ -461,7 +465,7 @@ constexpr size_t msd_final_lds() { return (size_t)kFCap * 16 + (size_t)(kFBins +
 // ~10 us per bucket with two workgroups per CU: 1.26 ms per 1e8 rows for 0.8 ms of traffic).
 constexpr int kFMine = 256;                                  // buckets per workgroup at most (D <= 65536, >= 256 workgroups)
 __global__ __launch_bounds__(kFT) void msd_final_kernel(const uint4 *__restrict__ tin, uint32_t cap2, const uint32_t *__restrict__ counts2, const uint32_t *__restrict__ outoff,
-                                                        const uint32_t *__restrict__ lo_h, const uint32_t *__restrict__ mul3, uint32_t D, const MsdMap *__restrict__ mapp, u64 *__restrict__ keys_out, uint32_t *__restrict__ perm_out,
+                                                        const uint32_t *__restrict__ lo_h, const uint32_t *__restrict__ mul3, const uint2 *__restrict__ tab_g, uint32_t D, const MsdMap *__restrict__ mapp, u64 *__restrict__ keys_out, uint32_t *__restrict__ perm_out,
                                                         uint32_t *__restrict__ val_out, u64 out_xor, int32_t *__restrict__ flag, size_t n_rows)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -507,6 +511,14 @@ __global__ __launch_bounds__(kFT) void msd_final_kernel(const uint4 *__restrict_
             // the final digit of a key: its reduced key relative to the bucket's first, spread over kFBins bins
             const uint32_t hlo = s_lo[it], m3 = s_m3[it];
             auto bin_of = [&](u64 key) -> uint32_t {
+                if (m3 == 0u) {                                            // a tail bucket of the equalised map (msd_bounds): the coordinate's next bits
+                    const uint32_t a = position_of(key, m);
+                    const uint2 tq = tab_g[a >> 12];
+                    uint32_t x = tq.x + tq.y * (a & 4095u);
+                    const uint32_t xmax = ((m.dmax + 1u) << 15) - 1u;      // (positions behind the last sampled key belong to the last bucket's last digit)
+                    x = x < xmax ? x : xmax;
+                    return (x >> 4) & (uint32_t)(kFBins - 1);
+                }
                 const uint32_t h = reduced_key(key, m.kmin, m.sh);
                 const uint32_t rel = h > hlo ? h - hlo : 0u;
                 const uint32_t e = __umulhi(rel, m3);
@@ -659,7 +671,7 @@ int k_sort_i64_msd(hark_context *ctx, const void *col, int64_t n, const uint32_t
     HARK_LAUNCH_RC(ctx, rc, msd_part_kernel<true><<<g1, b1, lds, st>>>(c64, val ? valcol : nullptr, n, slice, xorm, nullptr, nullptr, map, tab, nb2log, slabs, off1, 0u, nullptr, nullptr, nullptr, flag, 0, slab_tuples));
     HARK_LAUNCH_RC(ctx, rc, msd_part_kernel<false><<<dim3(kB), b1, lds, st>>>(nullptr, nullptr, n, 0, 0ull, slabs, bstart, map, tab, nb2log, regions, nullptr, cap2, counts2, bfirst, outoff, flag, slab_tuples, (size_t)D * cap2));
     const int fgrid = D < 768 ? D : (3 * nwg >= 256 && 3 * nwg <= D ? 3 * nwg : 256);                   // >= 256 workgroups: <= 256 buckets each
-    HARK_LAUNCH_RC(ctx, rc, msd_final_kernel<<<dim3((unsigned)fgrid), dim3(kFT), msd_final_lds(), st>>>(regions, cap2, counts2, outoff, lo_h, mul3, (uint32_t)D, map, reinterpret_cast<u64 *>(keys), perm, val, out_xor, flag, (size_t)n));
+    HARK_LAUNCH_RC(ctx, rc, msd_final_kernel<<<dim3((unsigned)fgrid), dim3(kFT), msd_final_lds(), st>>>(regions, cap2, counts2, outoff, lo_h, mul3, tab, (uint32_t)D, map, reinterpret_cast<u64 *>(keys), perm, val, out_xor, flag, (size_t)n));
     int64_t verdict = 0;
     if (!rc) rc = hark_read_words(ctx, flag, &verdict, 1);
     if (rc) { cleanup(false); return rc; }

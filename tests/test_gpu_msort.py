@@ -78,3 +78,39 @@ def test_large_i64_sort_same_with_and_without_the_msd_path(eng, monkeypatch):
     assert np.array_equal(a.column(0), b.column(0)) and np.array_equal(a.column(1), b.column(1))
     assert np.array_equal(a.column(0), rowid[np.argsort(key, kind="stable")])
     a.free(); b.free(); t.free()
+
+
+def test_the_paths_the_sort_reports(tmp_path):
+    """Which map took a column, and whether the three sweeps finished, is said on stderr under HARK_SORT_MSD_VERBOSE: uniform keys take
+    the affine map, normally distributed keys the equalised one, a column of 300 distinct keys gives up (and the tuple passes sort
+    it) -- results are checked above, this keeps the fast paths from turning into fall-backs unnoticed."""
+    import os, subprocess, sys, textwrap
+    from conftest import ROOT
+    script = tmp_path / "paths.py"
+    script.write_text(textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r)
+        from harkdb_amd.engine import Engine
+        eng = Engine(0)
+        rng = np.random.default_rng(1)
+        n = 3_000_001
+        pool = rng.integers(-2**62, 2**62, size=300)
+        for name, key in (("uniform", rng.integers(-2**62, 2**62, size=n)), ("normal", (rng.standard_normal(n) * 2.0**55).astype(np.int64)),
+                          ("few", pool[rng.integers(0, 300, size=n)])):
+            print("column", name, file=sys.stderr, flush=True)
+            t = eng.table_from_columns([key.astype(np.int64), np.arange(n, dtype=np.int32)])
+            eng.sort(t, 0, [0, 1]).free(); t.free()
+        """ % ROOT))
+    env = dict(os.environ, HARK_SORT_MSD_VERBOSE="1")
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    said = {}
+    cur = None
+    for line in r.stderr.splitlines():
+        if line.startswith("column "):
+            cur = line.split()[1]
+        elif line.startswith("msd sort:") and cur:
+            said[cur] = line
+    assert "gave_up=0" in said["uniform"] and "equalised=0" in said["uniform"], said
+    assert "gave_up=0" in said["normal"] and "equalised=1" in said["normal"], said
+    assert "gave_up=0" not in said["few"], said
