@@ -69,13 +69,16 @@ __device__ __forceinline__ uint32_t position_of(u64 key, const MsdMap &m)
     const uint32_t a = __umulhi(reduced_key(key, m.kmin, m.sh), m.mulA);
     return a < 0xFFFFFFu ? a : 0xFFFFFFu;
 }
-// tab (LDS, or null): the equalisation table -- per cell {first bucket, buckets per position} in 1/32768 buckets
+// The equalised coordinate of a position, in 1/32768 buckets: the table holds per cell {the coordinate of its first position,
+// the coordinate's growth per position x 256} (the factor 256: a cell with a handful of keys still spreads them over its
+// positions -- with whole units per position a tail cell's keys all shared one coordinate, and one final digit)
+__device__ __forceinline__ uint32_t equalised(uint2 t, uint32_t a) { return t.x + (uint32_t)(((u64)t.y * (a & 4095u)) >> 8); }
+// tab (LDS, or null): the equalisation table
 __device__ __forceinline__ uint32_t bucket_of(u64 key, const MsdMap &m, const uint2 *tab)
 {
     const uint32_t a = position_of(key, m);
     if (!tab) return a >> m.s24;
-    const uint2 t = tab[a >> 12];
-    const uint32_t d = (t.x + t.y * (a & 4095u)) >> 15;
+    const uint32_t d = equalised(tab[a >> 12], a) >> 15;
     return d < m.dmax ? d : m.dmax;
 }
 
@@ -184,7 +187,7 @@ __global__ __launch_bounds__(kT) void msd_hist_kernel(int pass, const u64 *__res
     auto count = [&](u64 key, bool live, bool cell_too) {
         const uint32_t a = position_of(key, m);
         uint32_t d = a >> m.s24;
-        if (tab) { const uint2 t = tab[a >> 12]; d = (t.x + t.y * (a & 4095u)) >> 15; d = d < m.dmax ? d : m.dmax; }
+        if (tab) { d = equalised(tab[a >> 12], a) >> 15; d = d < m.dmax ? d : m.dmax; }
         bucket_rank(s_cnt, d >> nb2log, live);
         if (cell_too) bucket_rank(s_cell, a >> 12, live);                  // (one key in eight: the cells' RELATIVE sizes are what the map is made of)
     };
@@ -261,8 +264,8 @@ __global__ __launch_bounds__(1024) void msd_scan1_kernel(int pass, const uint32_
     }
 }
 
-// The equalised map: the keys before a cell and the keys in it, as shares of the D buckets in 1/32768 buckets -- bucket of position
-// a = (first + per_position * (a % 4096)) >> 15 (monotone: a cell's last position stays below the next cell's first bucket share).
+// The equalised map: the keys before a cell and the keys in it, as shares of the D buckets in 1/32768 buckets -- `equalised()`
+// (monotone: a cell's last position stays below the next cell's first coordinate).
 __global__ __launch_bounds__(1024) void msd_eq_kernel(const uint32_t *__restrict__ cells, int64_t n, uint32_t D, uint2 *__restrict__ tab, const int32_t *__restrict__ flag)
 {
     __shared__ uint32_t s_wave[16];
@@ -275,7 +278,7 @@ __global__ __launch_bounds__(1024) void msd_eq_kernel(const uint32_t *__restrict
     u64 run = before;
     const u64 tot = all ? all : 1u;                                        // (the cells hold one key in eight: shares of THEIR total)
     for (int j = 0; j < 4; j++) {
-        const u64 first = (run * D << 15) / tot, per = (((u64)cs[j] * D << 15) / tot) >> 12;
+        const u64 first = (run * D << 15) / tot, per = (((u64)cs[j] * D << 15) / tot) >> 4;      // growth per position x 256 (a cell has 4096 positions)
         tab[4 * threadIdx.x + j] = uint2{(uint32_t)first, (uint32_t)per};
         run += cs[j];
     }
@@ -300,7 +303,7 @@ __global__ __launch_bounds__(256) void msd_bounds_kernel(const MsdMap *__restric
         while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if ((u64)tab[mid].x <= want) lo = mid; else hi = mid - 1; }
         const uint2 t = tab[lo];
         const u64 need = want - t.x;
-        u64 pos = need == 0 ? 0 : (t.y ? (need + t.y - 1) / t.y : 4096ull);
+        u64 pos = need == 0 ? 0 : (t.y ? ((need << 8) + t.y - 1) / t.y : 4096ull);
         if (pos > 4096ull) pos = 4096ull;
         return (u64)lo * 4096ull + pos;
     };
@@ -513,8 +516,7 @@ __global__ __launch_bounds__(kFT) void msd_final_kernel(const uint4 *__restrict_
             auto bin_of = [&](u64 key) -> uint32_t {
                 if (m3 == 0u) {                                            // a tail bucket of the equalised map (msd_bounds): the coordinate's next bits
                     const uint32_t a = position_of(key, m);
-                    const uint2 tq = tab_g[a >> 12];
-                    uint32_t x = tq.x + tq.y * (a & 4095u);
+                    uint32_t x = equalised(tab_g[a >> 12], a);
                     const uint32_t xmax = ((m.dmax + 1u) << 15) - 1u;      // (positions behind the last sampled key belong to the last bucket's last digit)
                     x = x < xmax ? x : xmax;
                     return (x >> 4) & (uint32_t)(kFBins - 1);
