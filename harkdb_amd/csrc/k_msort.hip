@@ -548,6 +548,9 @@ __global__ __launch_bounds__(kFT) void msd_final_kernel(const uint4 *__restrict_
                 lds_barrier();
                 uint32_t before = 0, work = 0;
                 for (int q = 0; q < kFT / 64; q++) { if (q < wv) before += s_wave[q]; work += s_sq[q]; }
+#ifdef HARK_MSD_CHECK
+                if (work > kFWorkMax && threadIdx.x == 0 && atomicCAS(&flag[4], 0, 101) == 0) { flag[5] = (int32_t)f; flag[6] = (int32_t)work; flag[7] = (int32_t)c; flag[3] = (int32_t)m3; atomicOr(&flag[0], 64); }
+#endif
                 if (work > kFWorkMax) { if (threadIdx.x == 0) atomicOr(&flag[0], 16); return; }   // many equal keys: the caller's other path (no other
                                                                                                    // workgroup waits for this one: it may just leave)
                 const uint32_t excl = before + incl - (c0 + c1 + c2 + c3);
@@ -683,7 +686,7 @@ int k_sort_i64_msd(hark_context *ctx, const void *col, int64_t n, const uint32_t
     }
 #ifdef HARK_MSD_CHECK
     if (verdict & 64) { int32_t fl[8]; hark_d2h(ctx, fl, flag, 32); fprintf(stderr, "MSD CHECK: violation code %d value %d block %d thread %x (n=%lld D=%d nb2log=%d flags %x equalised %d word3 %u)\n", fl[4], fl[5], fl[6], fl[7], (long long)n, D, nb2log, fl[0], fl[2], (unsigned)fl[3]);
-        if (fl[4] == 100) { std::vector<uint32_t> lo((size_t)D + 1), m3v((size_t)D); hark_d2h(ctx, lo.data(), lo_h, ((size_t)D + 1) * 4); hark_d2h(ctx, m3v.data(), mul3, (size_t)D * 4); int ff = fl[5]; fprintf(stderr, "   bucket %d: lo_h %u next %u mul3 %u (prev lo %u)\n", ff, lo[ff], lo[ff + 1], m3v[ff], ff ? lo[ff - 1] : 0u); } }
+        if (fl[4] == 100 || fl[4] == 101) { std::vector<uint32_t> lo((size_t)D + 1), m3v((size_t)D); hark_d2h(ctx, lo.data(), lo_h, ((size_t)D + 1) * 4); hark_d2h(ctx, m3v.data(), mul3, (size_t)D * 4); int ff = fl[5]; fprintf(stderr, "   bucket %d: lo_h %u next %u mul3 %u (prev lo %u)\n", ff, lo[ff], lo[ff + 1], m3v[ff], ff ? lo[ff - 1] : 0u); } }
 #endif
     if ((verdict & 0xFFFFFFFFll) != 0) { cleanup(false); return HARK_OK; }          // did not fit: the tuple passes
     if (unique_out) *unique_out = ((verdict >> 32) & 0xFFFFFFFFll) ? 0 : 1;
