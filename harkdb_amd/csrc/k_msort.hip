@@ -46,7 +46,10 @@ constexpr int kFRunMax = 1024;                               // longest run of o
                                                              // of 1024 costs its bucket ~0.15 ms and a statement at most ~13 ms where the
                                                              // caller's general path takes 21 (the tail buckets of a normal distribution
                                                              // hold runs of a few hundred; 1000-fold duplicates of every key the worst case)
-constexpr int kSampleWg = 256;
+constexpr int kSampleWg = 1024, kSampleStride = 61;         // one key in 61 is looked at for the bounds: ~61 keys of ANY distribution lie below the
+                                                             // sampled minimum (and above the maximum); with one in 509 it was ~500, all clamped
+                                                             // into one final digit of the first bucket -- over the ranking bound for a normal
+                                                             // distribution's tails, which the margin of the map does not cover
 
 #ifdef HARK_MSD_CHECK
 // bounds checks for experiments (tools/ab_build.sh chk "-DHARK_MSD_CHECK"): a violation is recorded in flag[4..7] and the access skipped
@@ -145,7 +148,7 @@ __global__ void msd_setup_kernel(const u64 *__restrict__ mm, uint32_t D, MsdMap 
     u64 lo = mm[0], hi = mm[1] >= mm[0] ? mm[1] : mm[0];
     if (((hi - lo) >> 32) == 0ull) flag[0] = 2;              // keys within 2^32 of each other: the caller's 32-bit paths are the better ones
     // The sample's extremes are not the column's: one key in `stride` was looked at, so ~stride keys lie below the sampled minimum
-    // (and above the maximum; stride = 509), and clamped to the first bucket's first digit they would be one long run for msd_final to rank.
+    // (and above the maximum), and clamped to the first bucket's first digit they would be one long run for msd_final to rank.
     // The map covers 1/64 of the range more on either side: uniform keys then all fall inside it (the outermost buckets stay
     // emptier), and only true outliers are clamped.
     const u64 margin = ((hi - lo) >> 6) + 1ull;
@@ -663,7 +666,7 @@ int k_sort_i64_msd(hark_context *ctx, const void *col, int64_t n, const uint32_t
     HIP_TRY_RC(ctx, rc, hipFuncSetAttribute(reinterpret_cast<const void *>(&msd_part_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIP_TRY_RC(ctx, rc, hipFuncSetAttribute(reinterpret_cast<const void *>(&msd_final_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)msd_final_lds()));
     const dim3 g1((unsigned)nwg), b1(kT);
-    HARK_LAUNCH_RC(ctx, rc, msd_sample_kernel<<<dim3(kSampleWg), dim3(256), 0, st>>>(c64, n, xorm, 509, mm));
+    HARK_LAUNCH_RC(ctx, rc, msd_sample_kernel<<<dim3(kSampleWg), dim3(256), 0, st>>>(c64, n, xorm, kSampleStride, mm));
     HARK_LAUNCH_RC(ctx, rc, msd_setup_kernel<<<dim3(1), dim3(1), 0, st>>>(mm, (uint32_t)D, map, flag));
     // the slab sizes under the affine map; a lumpy distribution asks for the equalised map (flag[2]) and is counted again: the second
     // round's kernels return at once when nobody asked
