@@ -46,7 +46,7 @@ constexpr int kFRunMax = 1024;                               // longest run of o
                                                              // of 1024 costs its bucket ~0.15 ms and a statement at most ~13 ms where the
                                                              // caller's general path takes 21 (the tail buckets of a normal distribution
                                                              // hold runs of a few hundred; 1000-fold duplicates of every key the worst case)
-constexpr int kSampleWg = 1024, kSampleStride = 61;         // one key in 61 is looked at for the bounds: ~61 keys of ANY distribution lie below the
+constexpr int kSampleWg = 256, kSampleStride = 61;          // one line of sixteen keys in 61 is looked at for the bounds: ~61 keys of ANY distribution lie below the
                                                              // sampled minimum (and above the maximum); with one in 509 it was ~500, all clamped
                                                              // into one final digit of the first bucket -- over the ranking bound for a normal
                                                              // distribution's tails, which the margin of the map does not cover
@@ -122,13 +122,16 @@ __device__ __forceinline__ uint32_t bucket_rank(uint32_t *cnt, uint32_t d, bool 
 }
 
 // ---- bounds from a sample -------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void msd_sample_kernel(const u64 *__restrict__ col, int64_t n, u64 xorm, int64_t stride, u64 *__restrict__ mm)
+__global__ __launch_bounds__(1024) void msd_sample_kernel(const u64 *__restrict__ col, int64_t n, u64 xorm, int64_t stride, u64 *__restrict__ mm)
 {
-    __shared__ u64 s_min[4], s_max[4];
+    __shared__ u64 s_min[16], s_max[16];
     u64 lo = ~0ull, hi = 0ull;
-    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * stride; i < n; i += (int64_t)gridDim.x * 256 * stride) {
-        const u64 k = col[i] ^ xorm;
-        lo = k < lo ? k : lo; hi = k > hi ? k : hi;
+    // whole 128-byte lines (sixteen keys, eight lanes x two keys), one line in `stride`: single keys 488 bytes apart cost a memory
+    // transaction each (1.6 M of them for 1e8 rows: 65 us); the same number of keys from one line in 61 costs a sixteenth
+    const int64_t g = (int64_t)blockIdx.x * 1024 + threadIdx.x, lines = (n + 15) / 16, lstep = (int64_t)gridDim.x * 128 * stride;
+    for (int64_t line = (g >> 3) * stride; line < lines; line += lstep) {
+        const int64_t i = line * 16 + (g & 7) * 2;
+        for (int q = 0; q < 2; q++) if (i + q < n) { const u64 k = col[i + q] ^ xorm; lo = k < lo ? k : lo; hi = k > hi ? k : hi; }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0 && n > 0) { const u64 k = col[n - 1] ^ xorm; lo = k < lo ? k : lo; hi = k > hi ? k : hi; }
     for (int d = 32; d; d >>= 1) {
@@ -138,8 +141,8 @@ __global__ __launch_bounds__(256) void msd_sample_kernel(const u64 *__restrict__
     if ((threadIdx.x & 63) == 0) { s_min[threadIdx.x >> 6] = lo; s_max[threadIdx.x >> 6] = hi; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; w++) { lo = s_min[w] < lo ? s_min[w] : lo; hi = s_max[w] > hi ? s_max[w] : hi; }
-        atomicMin(&mm[0], lo); atomicMax(&mm[1], hi);
+        for (int w = 1; w < 16; w++) { lo = s_min[w] < lo ? s_min[w] : lo; hi = s_max[w] > hi ? s_max[w] : hi; }
+        if (lo <= hi) { atomicMin(&mm[0], lo); atomicMax(&mm[1], hi); }   // (one pair of atomics per workgroup: 1024 workgroups on two addresses took 60 us)
     }
 }
 
@@ -666,7 +669,7 @@ int k_sort_i64_msd(hark_context *ctx, const void *col, int64_t n, const uint32_t
     HIP_TRY_RC(ctx, rc, hipFuncSetAttribute(reinterpret_cast<const void *>(&msd_part_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIP_TRY_RC(ctx, rc, hipFuncSetAttribute(reinterpret_cast<const void *>(&msd_final_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)msd_final_lds()));
     const dim3 g1((unsigned)nwg), b1(kT);
-    HARK_LAUNCH_RC(ctx, rc, msd_sample_kernel<<<dim3(kSampleWg), dim3(256), 0, st>>>(c64, n, xorm, kSampleStride, mm));
+    HARK_LAUNCH_RC(ctx, rc, msd_sample_kernel<<<dim3(kSampleWg), dim3(1024), 0, st>>>(c64, n, xorm, kSampleStride, mm));
     HARK_LAUNCH_RC(ctx, rc, msd_setup_kernel<<<dim3(1), dim3(1), 0, st>>>(mm, (uint32_t)D, map, flag));
     // the slab sizes under the affine map; a lumpy distribution asks for the equalised map (flag[2]) and is counted again: the second
     // round's kernels return at once when nobody asked
