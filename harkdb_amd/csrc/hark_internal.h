@@ -77,7 +77,11 @@ struct hark_column {
     // attempt (a failed one costs a partition pass and a sample round: 1.1 ms per 1e8 rows) until the statistics are
     // invalidated.  Performance only: every path returns the same rows.
     mutable int32_t hash_rounds = 0;
-    void invalidate_stats() const { has_range[0] = has_range[1] = false; hash_rounds = 0; }
+    // ... and what the three-sweep sort of 64-bit keys (k_msort.hip) learnt: 1 = it gave up on this column (many copies of every key,
+    // tight clusters), so the next ORDER BY / GROUP BY / JOIN on it starts with the tuple passes instead of losing the sweeps
+    // again (1.7 ms per 1e8 rows).  Performance only.
+    mutable int8_t msd_unfit = 0;
+    void invalidate_stats() const { has_range[0] = has_range[1] = false; hash_rounds = 0; msd_unfit = 0; }
 };
 
 struct hark_table {

@@ -23,7 +23,7 @@
 int k_argsort_column(hark_context *ctx, const void *col, int dtype, int64_t n, bool descending,
                      uint32_t **perm_out, uint32_t **sorted_words_out);
 int k_gather(hark_context *ctx, const void *src, int esz, const uint32_t *idx, void *dst, int64_t n);
-int k_argsort_i64_keys(hark_context *ctx, const void *col, int64_t n, uint32_t **perm_out, uint64_t **keys_out, const uint32_t *valcol, uint32_t **val_out, int *unique_out, bool *plain_out = nullptr);
+int k_argsort_i64_keys(hark_context *ctx, const void *col, int64_t n, uint32_t **perm_out, uint64_t **keys_out, const uint32_t *valcol, uint32_t **val_out, int *unique_out, bool *plain_out = nullptr, int8_t *msd_unfit = nullptr);
 int k_sort_column(hark_context *ctx, const void *col, int dtype, int64_t n, bool descending, const uint32_t *payload,
                   uint32_t **vals_out, uint32_t **words_out);
 int k_exclusive_scan_u32(hark_context *ctx, const uint32_t *in, int64_t n, uint32_t *out32, int64_t *out64, int64_t *total_host);
@@ -404,7 +404,7 @@ int grouped_aggregate(hark_context *ctx, const hark_table *db, int key_col, int 
         uint64_t *k64 = nullptr;
         uint32_t *val = nullptr;
         rc = k_argsort_i64_keys(ctx, db->cols[key_col].data, n, &perm, &k64, one64 ? static_cast<const uint32_t *>(db->cols[carry].data) : nullptr,
-                                one64 ? &val : nullptr, nullptr);
+                                one64 ? &val : nullptr, nullptr, nullptr, &db->cols[key_col].msd_unfit);
         if (!rc) {
             HARK_LAUNCH_RC(ctx, rc, unbias_u64_kernel<<<grid_for(ctx, n), 256, 0, st>>>(k64, n));
             sorted_keys = k64; keys64 = true;

@@ -24,8 +24,8 @@
 int k_argsort_column(hark_context *ctx, const void *col, int dtype, int64_t n, bool descending,
                      uint32_t **perm_out, uint32_t **sorted_words_out);
 int k_gather(hark_context *ctx, const void *src, int esz, const uint32_t *idx, void *dst, int64_t n);
-int k_argsort_i64_keys(hark_context *ctx, const void *col, int64_t n, uint32_t **perm_out, uint64_t **keys_out, const uint32_t *valcol, uint32_t **val_out, int *unique_out, bool *plain_out = nullptr);
-int k_argsort_i64_desc_tuples(hark_context *ctx, const void *col, int64_t n, uint32_t **perm_out, uint64_t **keys_out, const uint32_t *valcol, uint32_t **val_out, bool *done, uint64_t out_xor = 0);
+int k_argsort_i64_keys(hark_context *ctx, const void *col, int64_t n, uint32_t **perm_out, uint64_t **keys_out, const uint32_t *valcol, uint32_t **val_out, int *unique_out, bool *plain_out = nullptr, int8_t *msd_unfit = nullptr);
+int k_argsort_i64_desc_tuples(hark_context *ctx, const void *col, int64_t n, uint32_t **perm_out, uint64_t **keys_out, const uint32_t *valcol, uint32_t **val_out, bool *done, uint64_t out_xor = 0, int8_t *msd_unfit = nullptr);
 int k_sort_column(hark_context *ctx, const void *col, int dtype, int64_t n, bool descending, const uint32_t *payload,
                   uint32_t **vals_out, uint32_t **words_out);
 int k_exclusive_scan_u32(hark_context *ctx, const uint32_t *in, int64_t n, uint32_t *out32, int64_t *out64, int64_t *total_host);
@@ -531,11 +531,11 @@ int hark_entry_sort(hark_context *ctx, hark_result **out, const hark_table *db, 
         if (descending) {                                   // the tuple passes on the complemented keys, or nothing (the general path below)
             bool done = false;
             rc = k_argsort_i64_desc_tuples(ctx, db->cols[key_col].data, db->n, &perm, &keys64,
-                                           carried64 ? static_cast<const uint32_t *>(db->cols[carry64].data) : nullptr, carried64 ? &val : nullptr, &done, 0x7FFFFFFFFFFFFFFFull);
+                                           carried64 ? static_cast<const uint32_t *>(db->cols[carry64].data) : nullptr, carried64 ? &val : nullptr, &done, 0x7FFFFFFFFFFFFFFFull, &db->cols[key_col].msd_unfit);
             if (!rc && !done) break;
             plain = true;                                   // (the tuple path's last kernel wrote the plain keys)
         } else rc = k_argsort_i64_keys(ctx, db->cols[key_col].data, db->n, &perm, &keys64,
-                                       carried64 ? static_cast<const uint32_t *>(db->cols[carry64].data) : nullptr, carried64 ? &val : nullptr, nullptr, &plain);
+                                       carried64 ? static_cast<const uint32_t *>(db->cols[carry64].data) : nullptr, carried64 ? &val : nullptr, nullptr, &plain, &db->cols[key_col].msd_unfit);
         if (!rc && !plain) {                                // the permutation paths hand back biased keys
             HARK_LAUNCH_RC(ctx, rc, unbias_i64_kernel<<<grid_for(ctx, db->n), 256, 0, ctx->stream>>>(keys64, db->n, descending ? 0x7FFFFFFFFFFFFFFFull : 0x8000000000000000ull));
         }

@@ -619,9 +619,10 @@ __global__ __launch_bounds__(kFT) void msd_final_kernel(const uint4 *__restrict_
 // Ascending argsort of col ^ xorm (unsigned order), ties by row id: keys[i] = (col[perm[i]] ^ xorm) ^ out_xor, *val_out = valcol[perm[i]].
 // *done = false when the path does not apply or gave up (the caller then takes the tuple passes): nothing is returned.
 int k_sort_i64_msd(hark_context *ctx, const void *col, int64_t n, const uint32_t *valcol, uint64_t *keys, uint32_t **perm_out, uint32_t **val_out,
-                   bool *done, int *unique_out, uint64_t xorm, uint64_t out_xor)
+                   bool *done, int *unique_out, uint64_t xorm, uint64_t out_xor, int8_t *unfit /* optional, the column's hark_column::msd_unfit: read and set */)
 {
     *done = false;
+    if (unfit && *unfit) return HARK_OK;                                   // it gave up on this column before
     if (n < ((int64_t)1 << 20) || n >= 0xFFFFFFFFll || getenv("HARK_SORT_NO_MSD")) return HARK_OK;
     // final buckets of 800-1600 tuples on average (capacity 2560): D = 256 * nb2, nb2 a power of two <= 256
     int nb2log = 0;
@@ -694,7 +695,10 @@ int k_sort_i64_msd(hark_context *ctx, const void *col, int64_t n, const uint32_t
     if (verdict & 64) { int32_t fl[8]; hark_d2h(ctx, fl, flag, 32); fprintf(stderr, "MSD CHECK: violation code %d value %d block %d thread %x (n=%lld D=%d nb2log=%d flags %x equalised %d word3 %u)\n", fl[4], fl[5], fl[6], fl[7], (long long)n, D, nb2log, fl[0], fl[2], (unsigned)fl[3]);
         if (fl[4] == 100 || fl[4] == 101) { std::vector<uint32_t> lo((size_t)D + 1), m3v((size_t)D); hark_d2h(ctx, lo.data(), lo_h, ((size_t)D + 1) * 4); hark_d2h(ctx, m3v.data(), mul3, (size_t)D * 4); int ff = fl[5]; fprintf(stderr, "   bucket %d: lo_h %u next %u mul3 %u (prev lo %u)\n", ff, lo[ff], lo[ff + 1], m3v[ff], ff ? lo[ff - 1] : 0u); } }
 #endif
-    if ((verdict & 0xFFFFFFFFll) != 0) { cleanup(false); return HARK_OK; }          // did not fit: the tuple passes
+    if ((verdict & 0xFFFFFFFFll) != 0) {                                             // did not fit: the tuple passes
+        if (unfit && ((verdict & 0xFFFFFFFFll) & ~2ll) != 0) *unfit = 1;            // (bit 1: keys within 2^32 of each other -- nothing was lost)
+        cleanup(false); return HARK_OK;
+    }
     if (unique_out) *unique_out = ((verdict >> 32) & 0xFFFFFFFFll) ? 0 : 1;
     cleanup(true);
     *perm_out = perm;

@@ -1125,7 +1125,7 @@ static int k_sort_column_lsd(hark_context *ctx, const void *col, int dtype, int6
     return HARK_OK;
 }
 
-int k_argsort_i64_keys(hark_context *ctx, const void *col, int64_t n, uint32_t **perm_out, uint64_t **keys_out, const uint32_t *valcol, uint32_t **val_out, int *unique_out, bool *plain_out = nullptr);
+int k_argsort_i64_keys(hark_context *ctx, const void *col, int64_t n, uint32_t **perm_out, uint64_t **keys_out, const uint32_t *valcol, uint32_t **val_out, int *unique_out, bool *plain_out = nullptr, int8_t *msd_unfit = nullptr);
 
 // Stable sort of a column with a 32-bit payload (see k_sort_column_lsd).  An ascending argsort of an i64 column takes
 // the high-word-first path of k_argsort_i64_keys (four passes + a run fix-up instead of eight passes).
@@ -1152,7 +1152,7 @@ int k_argsort_column(hark_context *ctx, const void *col, int dtype, int64_t n, b
 // k_msort.hip: three sweeps of 16-byte tuples, most significant digit first, for large tables of well-spread keys (same outputs
 // as sort_i64_tuples; *done = false when it does not apply or gave up)
 int k_sort_i64_msd(hark_context *ctx, const void *col, int64_t n, const uint32_t *valcol, uint64_t *keys, uint32_t **perm_out, uint32_t **val_out,
-                   bool *done, int *unique_out, uint64_t xorm, uint64_t out_xor);
+                   bool *done, int *unique_out, uint64_t xorm, uint64_t out_xor, int8_t *unfit);
 
 // Stable ascending argsort of an i64 column together with the SORTED keys (biased by 2^63: unsigned order = signed order):
 // *perm_out (n x u32) and *keys_out (n x u64) are pool blocks the caller frees.  High word first + run fix-up (above)
@@ -1248,7 +1248,7 @@ static int sort_i64_tuples(hark_context *ctx, const void *col, int64_t n, uint32
 // undoes it), *done = false when the tuple path does not apply (equal high words, a long run of equal prefixes, no room) --
 // nothing is returned then and the caller takes its general path.
 int k_argsort_i64_desc_tuples(hark_context *ctx, const void *col, int64_t n, uint32_t **perm_out, uint64_t **keys_out, const uint32_t *valcol, uint32_t **val_out, bool *done,
-                              uint64_t out_xor /* *keys_out is written ^ out_xor: 0x7FFF... gives the plain keys back */)
+                              uint64_t out_xor /* *keys_out is written ^ out_xor: 0x7FFF... gives the plain keys back */, int8_t *msd_unfit /* optional: hark_column::msd_unfit of a table column */)
 {
     *perm_out = nullptr; *keys_out = nullptr; *done = false;
     if (val_out) *val_out = nullptr;
@@ -1256,7 +1256,7 @@ int k_argsort_i64_desc_tuples(hark_context *ctx, const void *col, int64_t n, uin
     uint64_t *keys = nullptr;
     if (!getenv("HARK_SORT_NO_TUPLES")) {
         HARK_TRY(hark_alloc(ctx, (void **)&keys, (size_t)n * 8));
-        const int rc0 = k_sort_i64_msd(ctx, col, n, valcol, keys, perm_out, val_out, done, nullptr, 0x7FFFFFFFFFFFFFFFull, out_xor);
+        const int rc0 = k_sort_i64_msd(ctx, col, n, valcol, keys, perm_out, val_out, done, nullptr, 0x7FFFFFFFFFFFFFFFull, out_xor, msd_unfit);
         if (rc0 || *done) { if (rc0) hark_free(ctx, keys); else *keys_out = keys; return rc0; }
         hark_free(ctx, keys); keys = nullptr;
     }
@@ -1272,7 +1272,8 @@ int k_argsort_i64_desc_tuples(hark_context *ctx, const void *col, int64_t n, uin
 
 int k_argsort_i64_keys(hark_context *ctx, const void *col, int64_t n, uint32_t **perm_out, uint64_t **keys_out, const uint32_t *valcol, uint32_t **val_out,
                        int *unique_out /* optional: 1 all keys distinct, 0 equal keys exist, -1 not determined (the permutation paths) */,
-                       bool *plain_out /* optional: set when *keys_out holds the PLAIN keys (the tuple path took the bias off at its last write), else biased */)
+                       bool *plain_out /* optional: set when *keys_out holds the PLAIN keys (the tuple path took the bias off at its last write), else biased */,
+                       int8_t *msd_unfit /* optional: hark_column::msd_unfit of a table column */)
 {
     if (plain_out) *plain_out = false;
     *perm_out = nullptr; *keys_out = nullptr;
@@ -1285,7 +1286,7 @@ int k_argsort_i64_keys(hark_context *ctx, const void *col, int64_t n, uint32_t *
     if (rc) return rc;
     bool done = false;
     if (!getenv("HARK_SORT_I64_LSD") && !getenv("HARK_SORT_NO_TUPLES")) {
-        rc = k_sort_i64_msd(ctx, col, n, valcol, keys, perm_out, val_out, &done, unique_out, 0x8000000000000000ull, plain_out ? 0x8000000000000000ull : 0ull);
+        rc = k_sort_i64_msd(ctx, col, n, valcol, keys, perm_out, val_out, &done, unique_out, 0x8000000000000000ull, plain_out ? 0x8000000000000000ull : 0ull, msd_unfit);
         if (rc) { hark_free(ctx, keys); return rc; }
         if (done) { if (plain_out) *plain_out = true; *keys_out = keys; return HARK_OK; }
     }

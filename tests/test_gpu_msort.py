@@ -83,7 +83,8 @@ def test_large_i64_sort_same_with_and_without_the_msd_path(eng, monkeypatch):
 def test_the_paths_the_sort_reports(tmp_path):
     """Which map took a column, and whether the three sweeps finished, is said on stderr under HARK_SORT_MSD_VERBOSE: uniform keys take
     the affine map, normally distributed keys the equalised one, a column of 300 distinct keys gives up (and the tuple passes sort
-    it) -- results are checked above, this keeps the fast paths from turning into fall-backs unnoticed."""
+    it, and the column remembers: hark_column::msd_unfit) -- results are checked above, this keeps the fast paths from turning into
+    fall-backs unnoticed."""
     import os, subprocess, sys, textwrap
     from conftest import ROOT
     script = tmp_path / "paths.py"
@@ -99,18 +100,24 @@ def test_the_paths_the_sort_reports(tmp_path):
                           ("few", pool[rng.integers(0, 300, size=n)])):
             print("column", name, file=sys.stderr, flush=True)
             t = eng.table_from_columns([key.astype(np.int64), np.arange(n, dtype=np.int32)])
+            eng.sort(t, 0, [0, 1]).free()
+            print("again", name, file=sys.stderr, flush=True)
             eng.sort(t, 0, [0, 1]).free(); t.free()
         """ % ROOT))
     env = dict(os.environ, HARK_SORT_MSD_VERBOSE="1")
     r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
-    said = {}
+    said, again = {}, {}
     cur = None
     for line in r.stderr.splitlines():
         if line.startswith("column "):
-            cur = line.split()[1]
+            cur, second = line.split()[1], False
+        elif line.startswith("again "):
+            second = True
         elif line.startswith("msd sort:") and cur:
-            said[cur] = line
+            (again if second else said)[cur] = line
     assert "gave_up=0" in said["uniform"] and "equalised=0" in said["uniform"], said
     assert "gave_up=0" in said["normal"] and "equalised=1" in said["normal"], said
     assert "gave_up=0" not in said["few"], said
+    # the verdict stays with the column: the second ORDER BY on it does not try the three sweeps again; the others do
+    assert "few" not in again and "uniform" in again and "normal" in again, again
