@@ -37,8 +37,12 @@ namespace {
 constexpr int kT = 1024, kR = 4, kTile = kT * kR;            // partition workgroup: threads, tuples per thread and tile
 constexpr int kB = 256;                                      // buckets per partition level
 constexpr uint32_t kDead = 0xFFFFFFFFu;                      // row id of a padding tuple
-constexpr int kFT = 512, kFR = 5, kFCap = kFT * kFR;         // final workgroup: 2560 tuples at most (three workgroups share a CU's LDS)
-constexpr int kFBins = 2048;
+// The final workgroup: FT threads sort buckets of up to 5 FT tuples with 4 FT final digits -- FT = 512 (2560 tuples, three workgroups
+// share a CU's LDS) up to 1.05e8 rows, FT = 1024 (5120 tuples, one workgroup per CU) for tables of up to 2.1e8 rows, whose 65536
+// final buckets hold up to 3200 tuples on average.
+constexpr int kFR = 5;
+constexpr int kFBinsOf(int ft) { return 4 * ft; }
+constexpr int kFCapOf(int ft) { return kFR * ft; }
 constexpr uint32_t kFWorkMax = 1u << 18;                     // ... and the sum of the squared run lengths of a bucket that is ranked at all (a run of
                                                              // 500 alone; the tail buckets of a normal distribution come to 1e5): buckets of a
                                                              // column with hundreds of copies of every key are over it, and the first one says so
@@ -291,8 +295,8 @@ __global__ __launch_bounds__(1024) void msd_eq_kernel(const uint32_t *__restrict
 }
 
 // Where a final bucket's reduced keys start (the smallest reduced key the map sends to bucket f or beyond) and the factor that
-// spreads the bucket's reduced keys over the kFBins final digits: msd_final's constants, one thread per bucket.
-__global__ __launch_bounds__(256) void msd_bounds_kernel(const MsdMap *__restrict__ mapp, const uint2 *__restrict__ tab, uint32_t D, uint32_t *__restrict__ lo_h /* [D + 1] */,
+// spreads the bucket's reduced keys over the `fbins` final digits: msd_final's constants, one thread per bucket.
+__global__ __launch_bounds__(256) void msd_bounds_kernel(const MsdMap *__restrict__ mapp, const uint2 *__restrict__ tab, uint32_t D, uint32_t fbins, uint32_t *__restrict__ lo_h /* [D + 1] */,
                                                          uint32_t *__restrict__ mul3 /* [D] */, const int32_t *__restrict__ flag)
 {
     bool eq;
@@ -323,7 +327,7 @@ __global__ __launch_bounds__(256) void msd_bounds_kernel(const MsdMap *__restric
     if (f < D) {
         const u64 h1 = first_reduced(f + 1u);
         const u64 w = h1 > h0 ? h1 - h0 : 1ull;
-        u64 x = ((u64)kFBins << 32) / w; if (x > 0xFFFFFFFFull) x = 0xFFFFFFFFull;
+        u64 x = ((u64)fbins << 32) / w; if (x > 0xFFFFFFFFull) x = 0xFFFFFFFFull;
         // A bucket of the equalised map that spans more than a cell is a TAIL bucket: its keys thin out exponentially towards one end,
         // and a digit that divides its reduced keys evenly puts most of them into a few bins.  Factor 0 says: take the final digit
         // from the equalised coordinate itself (its bits below the bucket number follow the cells' counts).
@@ -466,17 +470,20 @@ __global__ __launch_bounds__(kT) void msd_part_kernel(
     if (over) atomicOr(&flag[0], 4);
 }
 constexpr size_t msd_part_lds() { return (size_t)kTile * 16 + (size_t)kB * 8 * 16 + (size_t)kB * 4 * 4 + 64 + (size_t)kCells * 8; }
-constexpr size_t msd_final_lds() { return (size_t)kFCap * 16 + (size_t)(kFBins + 4) * 4 + (size_t)(kFT / 64) * 4 * 2 + 4 * 256 * 4; }
+constexpr size_t msd_final_lds(int ft) { return (size_t)kFCapOf(ft) * 16 + (size_t)(kFBinsOf(ft) + 4) * 4 + (size_t)(ft / 64) * 4 * 2 + 4 * 256 * 4; }
 
 // ---- sweep 3: the final buckets are sorted in LDS -------------------------------------------------------------------------------
 // Two workgroups per CU walk over the buckets; the NEXT bucket's tuples (and the size of the one after it) are loaded while a
 // bucket is sorted -- one workgroup per bucket spent its life waiting for a chain of dependent loads (flag, size, tuples:
 // ~10 us per bucket with two workgroups per CU: 1.26 ms per 1e8 rows for 0.8 ms of traffic).
 constexpr int kFMine = 256;                                  // buckets per workgroup at most (D <= 65536, >= 256 workgroups)
+template <int kFT>
 __global__ __launch_bounds__(kFT) void msd_final_kernel(const uint4 *__restrict__ tin, uint32_t cap2, const uint32_t *__restrict__ counts2, const uint32_t *__restrict__ outoff,
                                                         const uint32_t *__restrict__ lo_h, const uint32_t *__restrict__ mul3, const uint2 *__restrict__ tab_g, uint32_t D, const MsdMap *__restrict__ mapp, u64 *__restrict__ keys_out, uint32_t *__restrict__ perm_out,
                                                         uint32_t *__restrict__ val_out, u64 out_xor, int32_t *__restrict__ flag, size_t n_rows)
 {
+    constexpr int kFCap = kFCapOf(kFT), kFBins = kFBinsOf(kFT), kFDigitShift = kFT == 512 ? 4 : 3;    // (15 bits of coordinate inside a bucket -> log2(kFBins) of them)
+    static_assert(kFT == 512 || kFT == 1024, "two geometries");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     uint4 *buf = reinterpret_cast<uint4 *>(lds_raw);                       // [kFCap]
     uint32_t *cnt = reinterpret_cast<uint32_t *>(buf + kFCap);             // [kFBins + 4] counts, then exclusive offsets (cnt[kFBins] = the total)
@@ -525,7 +532,7 @@ __global__ __launch_bounds__(kFT) void msd_final_kernel(const uint4 *__restrict_
                     uint32_t x = equalised(tab_g[a >> 12], a);
                     const uint32_t xmax = ((m.dmax + 1u) << 15) - 1u;      // (positions behind the last sampled key belong to the last bucket's last digit)
                     x = x < xmax ? x : xmax;
-                    return (x >> 4) & (uint32_t)(kFBins - 1);
+                    return (x >> kFDigitShift) & (uint32_t)(kFBins - 1);
                 }
                 const uint32_t h = reduced_key(key, m.kmin, m.sh);
                 const uint32_t rel = h > hlo ? h - hlo : 0u;
@@ -624,15 +631,17 @@ int k_sort_i64_msd(hark_context *ctx, const void *col, int64_t n, const uint32_t
     *done = false;
     if (unfit && *unfit) return HARK_OK;                                   // it gave up on this column before
     if (n < ((int64_t)1 << 20) || n >= 0xFFFFFFFFll || getenv("HARK_SORT_NO_MSD")) return HARK_OK;
-    // final buckets of 800-1600 tuples on average (capacity 2560): D = 256 * nb2, nb2 a power of two <= 256
+    // final buckets of 800-1600 tuples on average (capacity 2560; up to 3200 and 5120 beyond 1.05e8 rows): D = 256 * nb2, nb2 a power of two <= 256
     int nb2log = 0;
     while (nb2log < 8 && n / ((int64_t)kB << nb2log) > 1600) nb2log++;
-    if (n / ((int64_t)kB << nb2log) > 1600) return HARK_OK;                // more than ~1.05e8 rows: the tuple passes
+    const bool wide = n / ((int64_t)kB << nb2log) > 1600;                  // more than ~1.05e8 rows: the final workgroups of 1024 threads
+    if (n / ((int64_t)kB << nb2log) > 3200) return HARK_OK;                // more than ~2.1e8 rows: the tuple passes
+    const int ft = wide ? 1024 : 512;
     const int D = kB << nb2log;
     hipStream_t st = ctx->stream;
     const int nwg = ctx->num_cu > 0 && ctx->num_cu <= 1024 ? ctx->num_cu : 256;
     const int64_t slice = ((n + nwg - 1) / nwg + kTile - 1) / kTile * kTile;
-    const uint32_t cap2 = (uint32_t)kFCap;
+    const uint32_t cap2 = (uint32_t)kFCapOf(ft);
     u64 *mm = nullptr; MsdMap *map = nullptr; int32_t *flag = nullptr;
     uint32_t *counts1 = nullptr, *off1 = nullptr, *bstart = nullptr, *bfirst = nullptr, *counts2 = nullptr, *outoff = nullptr, *cells = nullptr, *lo_h = nullptr, *mul3 = nullptr;
     uint32_t *perm = nullptr, *val = nullptr;
@@ -668,7 +677,8 @@ int k_sort_i64_msd(hark_context *ctx, const void *col, int64_t n, const uint32_t
     const size_t lds = msd_part_lds();
     HIP_TRY_RC(ctx, rc, hipFuncSetAttribute(reinterpret_cast<const void *>(&msd_part_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIP_TRY_RC(ctx, rc, hipFuncSetAttribute(reinterpret_cast<const void *>(&msd_part_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIP_TRY_RC(ctx, rc, hipFuncSetAttribute(reinterpret_cast<const void *>(&msd_final_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)msd_final_lds()));
+    HIP_TRY_RC(ctx, rc, hipFuncSetAttribute(reinterpret_cast<const void *>(&msd_final_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)msd_final_lds(512)));
+    HIP_TRY_RC(ctx, rc, hipFuncSetAttribute(reinterpret_cast<const void *>(&msd_final_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)msd_final_lds(1024)));
     const dim3 g1((unsigned)nwg), b1(kT);
     HARK_LAUNCH_RC(ctx, rc, msd_sample_kernel<<<dim3(kSampleWg), dim3(1024), 0, st>>>(c64, n, xorm, kSampleStride, mm));
     HARK_LAUNCH_RC(ctx, rc, msd_setup_kernel<<<dim3(1), dim3(1), 0, st>>>(mm, (uint32_t)D, map, flag));
@@ -679,11 +689,14 @@ int k_sort_i64_msd(hark_context *ctx, const void *col, int64_t n, const uint32_t
     HARK_LAUNCH_RC(ctx, rc, msd_eq_kernel<<<dim3(1), dim3(1024), 0, st>>>(cells, n, (uint32_t)D, tab, flag));
     HARK_LAUNCH_RC(ctx, rc, msd_hist_kernel<<<g1, b1, msd_hist_lds(), st>>>(1, c64, n, slice, xorm, map, tab, nb2log, counts1, cells, flag));
     HARK_LAUNCH_RC(ctx, rc, msd_scan1_kernel<<<dim3(1), dim3(1024), 0, st>>>(1, counts1, nwg, off1, bstart, bfirst, n, flag));
-    HARK_LAUNCH_RC(ctx, rc, msd_bounds_kernel<<<dim3((unsigned)(D / 256 + 1)), dim3(256), 0, st>>>(map, tab, (uint32_t)D, lo_h, mul3, flag));
+    HARK_LAUNCH_RC(ctx, rc, msd_bounds_kernel<<<dim3((unsigned)(D / 256 + 1)), dim3(256), 0, st>>>(map, tab, (uint32_t)D, (uint32_t)kFBinsOf(ft), lo_h, mul3, flag));
     HARK_LAUNCH_RC(ctx, rc, msd_part_kernel<true><<<g1, b1, lds, st>>>(c64, val ? valcol : nullptr, n, slice, xorm, nullptr, nullptr, map, tab, nb2log, slabs, off1, 0u, nullptr, nullptr, nullptr, flag, 0, slab_tuples));
     HARK_LAUNCH_RC(ctx, rc, msd_part_kernel<false><<<dim3(kB), b1, lds, st>>>(nullptr, nullptr, n, 0, 0ull, slabs, bstart, map, tab, nb2log, regions, nullptr, cap2, counts2, bfirst, outoff, flag, slab_tuples, (size_t)D * cap2));
-    const int fgrid = D < 768 ? D : (3 * nwg >= 256 && 3 * nwg <= D ? 3 * nwg : 256);                   // >= 256 workgroups: <= 256 buckets each
-    HARK_LAUNCH_RC(ctx, rc, msd_final_kernel<<<dim3((unsigned)fgrid), dim3(kFT), msd_final_lds(), st>>>(regions, cap2, counts2, outoff, lo_h, mul3, tab, (uint32_t)D, map, reinterpret_cast<u64 *>(keys), perm, val, out_xor, flag, (size_t)n));
+    // >= 256 workgroups (<= 256 buckets each); three workgroups of 512 threads or one of 1024 per CU
+    const int per_cu = wide ? 1 : 3;
+    const int fgrid = D < per_cu * 256 ? D : (per_cu * nwg >= 256 && per_cu * nwg <= D ? per_cu * nwg : 256);
+    if (wide) HARK_LAUNCH_RC(ctx, rc, msd_final_kernel<1024><<<dim3((unsigned)fgrid), dim3(1024), msd_final_lds(1024), st>>>(regions, cap2, counts2, outoff, lo_h, mul3, tab, (uint32_t)D, map, reinterpret_cast<u64 *>(keys), perm, val, out_xor, flag, (size_t)n));
+    else HARK_LAUNCH_RC(ctx, rc, msd_final_kernel<512><<<dim3((unsigned)fgrid), dim3(512), msd_final_lds(512), st>>>(regions, cap2, counts2, outoff, lo_h, mul3, tab, (uint32_t)D, map, reinterpret_cast<u64 *>(keys), perm, val, out_xor, flag, (size_t)n));
     int64_t verdict = 0;
     if (!rc) rc = hark_read_words(ctx, flag, &verdict, 1);
     if (rc) { cleanup(false); return rc; }

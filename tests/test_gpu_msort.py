@@ -121,3 +121,27 @@ def test_the_paths_the_sort_reports(tmp_path):
     assert "gave_up=0" not in said["few"], said
     # the verdict stays with the column: the second ORDER BY on it does not try the three sweeps again; the others do
     assert "few" not in again and "uniform" in again and "normal" in again, again
+
+
+@pytest.mark.parametrize("n", [110_000_003, 200_000_001])
+def test_tables_beyond_1e8_rows_take_the_wide_final_workgroups(eng, n):
+    """Up to ~1.05e8 rows the final buckets (<= 2560 tuples) are sorted by workgroups of 512 threads; up to ~2.1e8 rows by workgroups
+    of 1024 threads (<= 5120 tuples).  The permutation must be torch's stable argsort exactly."""
+    import torch
+    from harkdb_amd.dist import tensor_from_ptr
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(n % 1000)
+    keys = torch.randint(-2**62, 2**62, (n,), dtype=torch.int64, device=dev, generator=g)
+    keys[::1001] = keys[7]                                                 # some equal keys: ties go by row id
+    rid = torch.arange(n, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    t = eng.table_from_device(n, [keys.data_ptr(), rid.data_ptr()], [np.int64, np.int32], keepalive=(keys, rid))
+    res = eng.sort(t, 0, [0, 1])
+    got_k = tensor_from_ptr(res.device_ptr(0), n, np.int64, dev)
+    got_r = tensor_from_ptr(res.device_ptr(1), n, np.int32, dev)
+    want = torch.sort(keys, stable=True)
+    assert torch.equal(got_k, want.values)
+    assert torch.equal(got_r.to(torch.int64), want.indices)
+    del want
+    res.free(); t.free()
