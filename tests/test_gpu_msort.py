@@ -133,7 +133,8 @@ def test_tables_beyond_1e8_rows_take_the_wide_final_workgroups(eng, n):
     g = torch.Generator(device=dev)
     g.manual_seed(n % 1000)
     keys = torch.randint(-2**62, 2**62, (n,), dtype=torch.int64, device=dev, generator=g)
-    keys[::1001] = keys[7]                                                 # some equal keys: ties go by row id
+    dup = torch.randint(0, n, (n // 1000,), dtype=torch.int64, device=dev, generator=g)
+    keys[dup] = keys[(dup * 7919) % n]                                     # some equal keys, here and there: ties go by row id
     rid = torch.arange(n, dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
     t = eng.table_from_device(n, [keys.data_ptr(), rid.data_ptr()], [np.int64, np.int32], keepalive=(keys, rid))
