@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from harkdb_amd.engine import Engine
 eng = Engine(0); dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev); g.manual_seed(3)
-for n in (3_000_000, 30_000_000, 100_000_000):
+for n in (3_000_000, 30_000_000, 100_000_000, 200_000_000):
     au = torch.randint(0, 1 << 16, (n,), dtype=torch.int32, device=dev, generator=g)
     for kind in ("uniform", "normal", "exp", "sorted", "dups10"):
         if kind == "uniform": k = torch.randint(-2**62, 2**62, (n,), dtype=torch.int64, device=dev, generator=g)
