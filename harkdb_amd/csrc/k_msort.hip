@@ -670,7 +670,7 @@ int k_sort_i64_msd(hark_context *ctx, const void *col, int64_t n, const uint32_t
     bstart = reinterpret_cast<uint32_t *>(small + o_bstart); bfirst = reinterpret_cast<uint32_t *>(small + o_bfirst);
     counts2 = reinterpret_cast<uint32_t *>(small + o_c2); outoff = reinterpret_cast<uint32_t *>(small + o_out);
     lo_h = reinterpret_cast<uint32_t *>(small + o_lo); mul3 = reinterpret_cast<uint32_t *>(small + o_m3);
-    const u64 mm_init[2] = {~0ull, 0ull};
+    static const u64 mm_init[2] = {~0ull, 0ull};                          // (static: an asynchronous copy may read it after an early return)
     HIP_TRY_RC(ctx, rc, hipMemsetAsync(small + 64, 0, 64 + (size_t)kCells * 4, st));   // map, flags (flag[0] gave up, [1] equal keys exist, [2] equalised map), cells
     HIP_TRY_RC(ctx, rc, hipMemcpyAsync(mm, mm_init, 16, hipMemcpyHostToDevice, st));
     const u64 *c64 = static_cast<const u64 *>(col);
