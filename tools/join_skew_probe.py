@@ -13,7 +13,7 @@ build = torch.randperm(1 << 30, device=dev, generator=g)[:m].to(torch.int32) if 
 bval = torch.randint(0, 1 << 16, (m,), dtype=torch.int32, device=dev, generator=g)
 pval = torch.randint(0, 1 << 16, (n,), dtype=torch.int32, device=dev, generator=g)
 tb = eng.table_from_device(m, [build.data_ptr(), bval.data_ptr()], [np.uint32, np.uint32], keepalive=(build, bval))
-for hot, nhot in ((0.0, 1), (0.001, 1), (0.01, 1), (0.05, 1), (0.01, 100), (0.1, 100), (0.3, 10_000), (0.5, 100_000)):
+for hot, nhot in ((0.0, 1), (0.0001, 1), (0.0002, 1), (0.0005, 1), (0.001, 1), (0.01, 1), (0.05, 1), (0.001, 100), (0.01, 100), (0.1, 100), (0.3, 10_000), (0.5, 100_000)):
     probe = torch.randint(0, 1 << 30, (n,), dtype=torch.int32, device=dev, generator=g)          # ~1 % of these exist in the build side
     k = int(n * hot)
     if k:
@@ -24,5 +24,5 @@ for hot, nhot in ((0.0, 1), (0.001, 1), (0.01, 1), (0.05, 1), (0.01, 100), (0.1,
     ts = []
     for r in range(3):
         eng.sync(); t0 = time.perf_counter(); res = eng.join(tp, tb, 0, 0, [0, 1], [1]); eng.sync(); ts.append((time.perf_counter() - t0) * 1e3); rows = res.shape[0]; res.free()
-    print(f"{hot * 100:5.1f} % of the probe rows on {nhot:6d} hot keys: {min(ts):7.3f} ms, {rows} result rows", flush=True)
+    print(f"{hot * 100:6.2f} % of the probe rows on {nhot:6d} hot keys: {min(ts):7.3f} ms, {rows} result rows", flush=True)
     tp.free(); del probe
