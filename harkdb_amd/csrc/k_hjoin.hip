@@ -59,6 +59,8 @@ struct __attribute__((aligned(16))) JPair64 { uint64_t key; uint32_t row, pad; }
 // the order kernel's geometry (jorder_kernel): survivors staged per sub-round and per-rank counters -- with a third word per
 // survivor 10240 x 12 B + 6144 counters, without 12288 x 8 B + 10240 counters (~150 KiB of LDS either way)
 constexpr int kStage = 12288, kStageCarry = 10240, kFine = 10240, kFineCarry = 6144, kCoarse = 2048, kTieMax = 64;
+constexpr int kLongMax = kStage / (kTieMax + 1) + 1;      // runs of more than kTieMax rows that fit the stage
+constexpr int kWaveSortMax = 1024;                        // ... sorted by one wave up to this length, by the workgroup beyond
 // the stage by words per survivor: (rank, left row) + the carried column + the probe key's low word (64-bit keys: confirmed at write-out)
 constexpr int stage_of(int extra_words) { return extra_words == 0 ? kStage : extra_words == 1 ? kStageCarry : 8192; }
 constexpr int fine_of(int extra_words) { return extra_words == 0 ? kFine : extra_words == 1 ? kFineCarry : 4096; }
@@ -159,8 +161,315 @@ __global__ __launch_bounds__(256) void jcnt_kernel(const uint32_t *__restrict__ 
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) cnt[i] = runlen[rank[i]];
 }
 
+// ---- heavy hitters of the probe side -----------------------------------------------------------------------------
+// A foreign-key column is skewed: a few keys own a large share of the probe rows.  Sent through the partition they would
+// flood ONE bucket (its slabs and survivor bins are sized for an even share) and one rank of the order kernel.  They
+// never get there:
+//   1. jhot_sample_kernel reads one probe key in n / S (S <= 65536) and counts equal samples in a hash table;
+//      jhot_select_kernel keeps the (at most kHotMax) keys sampled cmin times or more, looks up their ranks in the sorted
+//      build side and lays out an open-addressing set of them that fits every kernel's LDS;
+//   2. jpart_kernel drops the rows of a hot key (one LDS probe per row, nothing at all when the set is empty);
+//   3. the rows of a hot key are a contiguous block of the output at the key's rank, IN ROW ORDER -- which a stable
+//      partition of the probe column delivers without any sorting: jhot_count_kernel counts the rows of every hot key per
+//      contiguous piece of the column (one piece per wave), jhot_scan_kernel turns the counts into places, the order kernel
+//      leaves the blocks free (every later row of the bucket moves back by the blocks before it) and reports where they
+//      start, and jhot_scatter_kernel reads the column once more and writes every hot row to its place.
+// Two more passes over the probe keys, paid only when a hot key exists (the kernels leave at once when the set is empty).
+constexpr int kHotMax = 256, kHotSlots = 1024, kHotCand = 4096, kHotSampleMax = 65536;
+constexpr uint32_t kNoRank = 0xFFFFFFFFu;
+constexpr uint16_t kNoHot = 0xFFFFu;
+
+struct JHotHead {
+    uint32_t H, ncand, Hp, pad;                // hot keys (ascending), candidates of the sample, hot keys with partners
+    unsigned long long mhot;                   // matching probe rows of all hot keys
+    uint32_t rank[kHotMax];                    // by hot key: rank of its first sorted build entry, kNoRank: it has no partner (its rows are dropped)
+    uint16_t h2p[kHotMax];                     // by hot key: its place among the keys with partners, kNoHot
+    unsigned long long rows_all[kHotMax];      // by hot key: its probe rows (counted only when it has partners)
+    // the keys with partners, ascending (dense): what the order kernel and the scatter need
+    uint32_t prank[kHotMax], pbucket[kHotMax];
+    unsigned long long prows[kHotMax];         // probe rows of the key
+    unsigned long long pbefore[kHotMax];       // rows of the hot keys before it
+    unsigned long long pdst[kHotMax];          // first output row of its block (written by the order kernel)
+    uint16_t slot_idx[kHotSlots];              // by slot of the set: the hot key's index
+    uint32_t cand[kHotCand];                   // slots of the sample table whose count reached cmin
+};
+template <typename K> struct JHotSet : JHotHead { K empty; K keys[kHotMax]; K slots[kHotSlots]; };   // empty: a value that is no hot key marks the free slots
+
+__device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }   // a wave's own LDS traffic, in program order
+
+template <typename K> __device__ __forceinline__ uint32_t jhot_find(const K *slots, K empty, K key)       // the key's slot, ~0u: not a hot key
+{
+    uint32_t slot = jhash(key) >> 22;
+    for (;;) {
+        const K x = slots[slot];
+        if (x == empty) return ~0u;                                       // (first: a probe key may equal the marker)
+        if (x == key) return slot;
+        slot = (slot + 1u) & (uint32_t)(kHotSlots - 1);
+    }
+}
+
+// table: tkey[mask + 1] (all ones = free), tcnt[mask + 1]; mask + 1 >= 4 S, so a free slot is always found
+template <typename K>
+__global__ __launch_bounds__(256) void jhot_sample_kernel(const K *__restrict__ keys, int64_t n, K bias, uint32_t S, unsigned long long *__restrict__ tkey,
+                                                          uint32_t *__restrict__ tcnt, uint32_t mask, uint32_t cmin, JHotHead *__restrict__ hot)
+{
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= S) return;
+    const uint64_t stride = (uint64_t)n / S;                              // >= 1: S <= n
+    const uint64_t row = (uint64_t)t * stride + (uint64_t)((t * 0x9E3779B1u) >> 7) % stride;   // a fixed stride would lock onto periodic data
+    const unsigned long long k = (unsigned long long)(K)(keys[row] ^ bias);
+    if (k == ~0ull) return;                                               // (the free marker: such a key is never hot)
+    uint32_t slot = jhash((uint64_t)k) & mask;
+    for (;;) {
+        const unsigned long long old = atomicCAS(&tkey[slot], ~0ull, k);
+        if (old == ~0ull || old == k) break;
+        slot = (slot + 1u) & mask;
+    }
+    if (atomicAdd(&tcnt[slot], 1u) + 1u == cmin) { const uint32_t at = atomicAdd(&hot->ncand, 1u); if (at < (uint32_t)kHotCand) hot->cand[at] = slot; }
+}
+
+template <typename K>
+__global__ __launch_bounds__(1024) void jhot_select_kernel(const unsigned long long *__restrict__ tkey, const uint32_t *__restrict__ tcnt, uint32_t cmin,
+                                                           const K *__restrict__ rkeys, int64_t s, JHotSet<K> *__restrict__ hot)
+{
+    __shared__ K s_key[kHotMax];
+    __shared__ K s_slots[kHotSlots];
+    __shared__ uint16_t s_idx[kHotSlots];
+    __shared__ uint32_t s_n, s_free;
+    const int tid = threadIdx.x;
+    const uint32_t nc = min(hot->ncand, (uint32_t)kHotCand);
+    if (nc == 0) return;                                                  // H = 0 (the caller cleared the block)
+    uint32_t thr = cmin;                                                  // the smallest cmin * 2^j that leaves at most kHotMax keys
+    for (;;) {
+        if (tid == 0) s_n = 0u;
+        __syncthreads();
+        uint32_t mine = 0;
+        for (uint32_t i = tid; i < nc; i += 1024) mine += tcnt[hot->cand[i]] >= thr ? 1u : 0u;
+        if (mine) atomicAdd(&s_n, mine);
+        __syncthreads();
+        const uint32_t left = s_n;
+        __syncthreads();
+        if (left <= (uint32_t)kHotMax) break;
+        thr *= 2u;
+    }
+    if (tid == 0) { s_n = 0u; s_free = (uint32_t)kHotMax + 1u; }
+    __syncthreads();
+    for (uint32_t i = tid; i < nc; i += 1024) {
+        const uint32_t slot = hot->cand[i];
+        if (tcnt[slot] >= thr) s_key[atomicAdd(&s_n, 1u)] = (K)tkey[slot];
+    }
+    __syncthreads();
+    const int H = (int)s_n;
+    if (H == 0) return;
+    K mykey = (K)0;
+    int pos = 0;
+    if (tid < H) {
+        mykey = s_key[tid];
+        for (int j = 0; j < H; j++) pos += s_key[j] < mykey ? 1 : 0;      // the keys are distinct: its place in ascending order
+        int64_t lo = 0, hi = s;
+        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (rkeys[mid] < mykey) lo = mid + 1; else hi = mid; }
+        hot->keys[pos] = mykey;
+        hot->rank[pos] = (lo < s && rkeys[lo] == mykey) ? (uint32_t)lo : kNoRank;
+    }
+    if (tid <= H) {                                                       // the smallest of 0 .. H that is no hot key marks the free slots
+        bool used = false;
+        for (int j = 0; j < H; j++) used = used || s_key[j] == (K)tid;
+        if (!used) atomicMin(&s_free, (uint32_t)tid);
+    }
+    __syncthreads();
+    const K empty = (K)s_free;
+    s_slots[tid] = empty; s_idx[tid] = kNoHot;                            // (kHotSlots threads)
+    __syncthreads();
+    if (tid < H) {
+        uint32_t slot = jhash(mykey) >> 22;
+        for (;;) {
+            typedef typename std::conditional<sizeof(K) == 8, unsigned long long, unsigned int>::type A;
+            const A old = atomicCAS(reinterpret_cast<A *>(&s_slots[slot]), (A)empty, (A)mykey);
+            if (old == (A)empty) break;
+            slot = (slot + 1u) & (uint32_t)(kHotSlots - 1);
+        }
+        s_idx[slot] = (uint16_t)pos;
+    }
+    __syncthreads();
+    hot->slots[tid] = s_slots[tid]; hot->slot_idx[tid] = s_idx[tid];
+    if (tid == 0) { hot->empty = empty; hot->H = (uint32_t)H; }
+}
+
+// The probe column is cut into pieces of R rows, one per wave.  ptotal[piece] = rows of the piece that carry a hot key with
+// partners, rows_all[h] += the key's rows: the sizes of the blocks.
+template <typename K>
+__global__ __launch_bounds__(1024) void jhot_count_kernel(const K *__restrict__ keys, int64_t n, K bias, JHotSet<K> *__restrict__ hot,
+                                                          uint32_t *__restrict__ ptotal, uint32_t npieces, uint32_t R)
+{
+    constexpr int VEC = 16 / (int)sizeof(K);
+    __shared__ K s_slots[kHotSlots];
+    __shared__ uint16_t s_idx[kHotSlots];
+    __shared__ uint32_t s_cnt[kHotMax];
+    const uint32_t H = hot->H;
+    if (H == 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < kHotMax) s_cnt[tid] = 0u;
+    s_slots[tid] = hot->slots[tid];
+    { const uint16_t h = hot->slot_idx[tid]; s_idx[tid] = h != kNoHot && hot->rank[h] != kNoRank ? h : kNoHot; }   // a hot key without partners counts nothing
+    const K empty = hot->empty;
+    __syncthreads();
+    const uint32_t piece = blockIdx.x * 16u + (uint32_t)wave;
+    const int64_t r0 = (int64_t)piece * R, r1 = piece < npieces ? min(n, r0 + (int64_t)R) : r0;
+    uint32_t mine = 0;
+    constexpr int U = 4;                                                  // loads in flight per lane
+    for (int64_t base = r0; base < r1; base += (int64_t)U * 64 * VEC) {
+        K kk[U][VEC];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int64_t r = base + ((int64_t)u * 64 + lane) * VEC;
+            if (r + VEC <= n) {
+                const hark_u4v q = *reinterpret_cast<const hark_u4v *>(keys + r);
+                if (sizeof(K) == 4) { kk[u][0] = (K)q.x; kk[u][1 % VEC] = (K)q.y; kk[u][2 % VEC] = (K)q.z; kk[u][3 % VEC] = (K)q.w; }
+                else { kk[u][0] = (K)(((uint64_t)q.y << 32) | q.x); kk[u][1 % VEC] = (K)(((uint64_t)q.w << 32) | q.z); }
+            } else {
+#pragma unroll
+                for (int j = 0; j < VEC; j++) kk[u][j] = r + j < n ? keys[r + j] : (K)0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int64_t r = base + ((int64_t)u * 64 + lane) * VEC;
+#pragma unroll
+            for (int j = 0; j < VEC; j++) {
+                if (r + j < r1) {
+                    const uint32_t slot = jhot_find<K>(s_slots, empty, kk[u][j] ^ bias);
+                    if (slot != ~0u) { const uint16_t h = s_idx[slot]; if (h != kNoHot) { atomicAdd(&s_cnt[h], 1u); mine++; } }
+                }
+            }
+        }
+    }
+    for (int d = 32; d > 0; d >>= 1) mine += __shfl_down(mine, d, 64);
+    if (lane == 0 && piece < npieces) ptotal[piece] = mine;
+    __syncthreads();
+    if ((uint32_t)tid < H && s_cnt[tid]) atomicAdd(&hot->rows_all[tid], (unsigned long long)s_cnt[tid]);
+}
+
+// the hot keys that have partners, dense and ascending; their buckets; the rows before each; the total (-> *mhot_out for the
+// host); ptotal -> exclusive prefix (the first place of every piece in the stream of hot rows)
+__global__ __launch_bounds__(1024) void jhot_finish_kernel(JHotHead *__restrict__ hot, uint32_t *__restrict__ ptotal, uint32_t npieces, const uint32_t *__restrict__ bstart, int P,
+                                                           unsigned long long *__restrict__ mhot_out)
+{
+    __shared__ unsigned long long s_rows[kHotMax];
+    __shared__ uint32_t s_has[kHotMax];
+    __shared__ uint32_t s_wave[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, H = (int)hot->H;
+    if (H == 0) { if (tid == 0) *mhot_out = 0ull; return; }
+    if (tid < kHotMax) {
+        const uint32_t r = tid < H ? hot->rank[tid] : kNoRank;
+        const unsigned long long rows = tid < H && r != kNoRank ? hot->rows_all[tid] : 0ull;
+        s_rows[tid] = rows; s_has[tid] = rows ? 1u : 0u;
+    }
+    __syncthreads();
+    if (tid < H) {
+        const int h = tid;
+        uint32_t p = 0, hp = 0;
+        unsigned long long before = 0, all = 0;
+        for (int j = 0; j < H; j++) { if (j < h) { p += s_has[j]; before += s_rows[j]; } hp += s_has[j]; all += s_rows[j]; }
+        hot->h2p[h] = s_has[h] ? (uint16_t)p : kNoHot;
+        if (s_has[h]) {
+            const uint32_t r = hot->rank[h];
+            int lo = 0, hi = P;                                           // the b with bstart[b] <= r < bstart[b + 1]
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (bstart[mid] <= r) lo = mid; else hi = mid; }
+            hot->prank[p] = r; hot->pbucket[p] = (uint32_t)lo; hot->prows[p] = s_rows[h]; hot->pbefore[p] = before; hot->pdst[p] = 0ull;
+        }
+        if (h == 0) { hot->Hp = hp; hot->mhot = all; *mhot_out = all; }
+    }
+    // exclusive scan of the pieces' totals (at most a few thousand)
+    const uint32_t per = (npieces + 1023u) / 1024u, s0 = min(npieces, (uint32_t)tid * per), s1 = min(npieces, s0 + per);
+    uint32_t sum = 0;
+    for (uint32_t i = s0; i < s1; i++) sum += ptotal[i];
+    uint32_t incl = sum;
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d, 64); if (lane >= d) incl += y; }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t run = incl - sum;
+    for (int w = 0; w < wave; w++) run += s_wave[w];
+    for (uint32_t i = s0; i < s1; i++) { const uint32_t c = ptotal[i]; ptotal[i] = run; run += c; }
+}
+
+// the rows of the hot keys with partners, in row order: (index among those keys, row).  One stable pass of the radix sort
+// over the index then groups them by key with the row order kept -- the reference's order inside a key (join.fut:66).
+template <typename K>
+__global__ __launch_bounds__(1024) void jhot_compact_kernel(const K *__restrict__ keys, int64_t n, K bias, const JHotSet<K> *__restrict__ hot,
+                                                            const uint32_t *__restrict__ ptotal, uint32_t npieces, uint32_t R,
+                                                            uint32_t *__restrict__ hkey, uint32_t *__restrict__ hrow)
+{
+    constexpr int VEC = 16 / (int)sizeof(K);
+    __shared__ K s_slots[kHotSlots];
+    __shared__ uint16_t s_idx[kHotSlots];
+    const uint32_t H = hot->H;
+    if (H == 0 || hot->mhot == 0ull) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    s_slots[tid] = hot->slots[tid];
+    { const uint16_t h = hot->slot_idx[tid]; s_idx[tid] = h != kNoHot ? hot->h2p[h] : kNoHot; }
+    const K empty = hot->empty;
+    __syncthreads();
+    const uint32_t piece = blockIdx.x * 16u + (uint32_t)wave;
+    if (piece >= npieces) return;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int64_t r0 = (int64_t)piece * R, r1 = min(n, r0 + (int64_t)R);
+    uint32_t at = ptotal[piece];                                          // wave-uniform: the next free place of the stream
+    constexpr int U = 2;
+    for (int64_t base = r0; base < r1; base += (int64_t)U * 64 * VEC) {
+        K kk[U][VEC];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int64_t r = base + ((int64_t)u * 64 + lane) * VEC;
+            if (r + VEC <= n) {
+                const hark_u4v q = *reinterpret_cast<const hark_u4v *>(keys + r);
+                if (sizeof(K) == 4) { kk[u][0] = (K)q.x; kk[u][1 % VEC] = (K)q.y; kk[u][2 % VEC] = (K)q.z; kk[u][3 % VEC] = (K)q.w; }
+                else { kk[u][0] = (K)(((uint64_t)q.y << 32) | q.x); kk[u][1 % VEC] = (K)(((uint64_t)q.w << 32) | q.z); }
+            } else {
+#pragma unroll
+                for (int j = 0; j < VEC; j++) kk[u][j] = r + j < n ? keys[r + j] : (K)0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int64_t r = base + ((int64_t)u * 64 + lane) * VEC;
+            uint32_t pj[VEC], mine = 0, lower = 0, total = 0;
+#pragma unroll
+            for (int j = 0; j < VEC; j++) {
+                pj[j] = kNoHot;
+                if (r + j < r1) { const uint32_t slot = jhot_find<K>(s_slots, empty, kk[u][j] ^ bias); if (slot != ~0u) pj[j] = s_idx[slot]; }
+                const bool is = pj[j] != kNoHot;
+                const unsigned long long m = __ballot(is);
+                total += (uint32_t)__popcll(m); lower += (uint32_t)__popcll(m & below);      // rows of lower lanes come first, then this lane's in turn
+                if (is) mine |= 1u << j;
+            }
+            uint32_t o = at + lower;
+#pragma unroll
+            for (int j = 0; j < VEC; j++) if (mine & (1u << j)) { hkey[o] = pj[j]; hrow[o] = (uint32_t)(r + j); o++; }
+            at += total;
+        }
+    }
+}
+
+// the stream of hot rows, grouped by key and in row order inside a key, to the blocks the order kernel left free
+__global__ __launch_bounds__(256) void jhot_place_kernel(const JHotHead *__restrict__ hot, const uint32_t *__restrict__ skey, const uint32_t *__restrict__ srow, int64_t mhot,
+                                                         const uint32_t *__restrict__ runlen, const uint32_t *__restrict__ lval, const uint32_t *__restrict__ rranked,
+                                                         uint32_t *__restrict__ rank_out, uint32_t *__restrict__ lrow_out, uint32_t *__restrict__ cnt_out,
+                                                         uint32_t *__restrict__ lval_out, uint32_t *__restrict__ rval_out)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < mhot; i += stride) {
+        const uint32_t p = skey[i], row = srow[i], rk = hot->prank[p];
+        const unsigned long long o = hot->pdst[p] + ((unsigned long long)i - hot->pbefore[p]);
+        if (rank_out) { rank_out[o] = rk; lrow_out[o] = row; }
+        if (cnt_out) cnt_out[o] = runlen[rk];
+        if (lval_out) lval_out[o] = lval[row];
+        if (rval_out) rval_out[o] = rranked[rk];
+    }
+}
+
 // ---- probe side: range partition of (key, row id) ---------------------------------------------------------------
-// LDS: E ring[P][Q]; K ext[P + 2]; u32 s_w[P] (head << 16 | count); int s_lcur[P]; u32 flags[4].
+// LDS: E ring[P][Q]; K ext[P + 2]; u32 s_w[P] (head << 16 | count); int s_lcur[P]; u32 flags[4]; K s_hot[kHotSlots] (the set of
+// hot keys, whose rows take the stable partition above instead: read only when there is one).
 // HIDDEN: the batches' loads are issued from inline assembly and waited for by hand (below); false: plain non-temporal loads
 // whose waits the compiler places (HARK_JOIN_PLAIN_LOADS=1: the cross-check of tests/test_gpu_hjoin.py -- the hand-placed
 // waits depend on the compiler never touching a destination register between a load and its wait, which nothing checks at
@@ -171,7 +480,8 @@ __global__ __launch_bounds__(kJThreads) void jpart_kernel(const K *__restrict__ 
                                                           typename JTraits<K>::E *__restrict__ slabs, uint32_t *__restrict__ counts, uint32_t cap,
                                                           int period, int32_t *__restrict__ err,
                                                           const uint32_t *__restrict__ lval /* 16-byte entries only, may be null: a probe-side column that
-                                                                                               travels in the entries' fourth word */)
+                                                                                               travels in the entries' fourth word */,
+                                                          const JHotSet<K> *__restrict__ hot)
 {
     typedef typename JTraits<K>::E E;
     constexpr int P = JTraits<K>::P, Q = JTraits<K>::Q, VEC = JTraits<K>::VEC;
@@ -183,7 +493,11 @@ __global__ __launch_bounds__(kJThreads) void jpart_kernel(const K *__restrict__ 
     uint32_t *s_w = reinterpret_cast<uint32_t *>(ext + P + 2);
     int *s_lcur = reinterpret_cast<int *>(s_w + P);
     uint32_t *flags = reinterpret_cast<uint32_t *>(s_lcur + P);
+    K *s_hot = reinterpret_cast<K *>(flags + 4);                       // (16 bytes on from s_lcur's end: aligned for 8-byte keys)
     const int tid = threadIdx.x, wg = blockIdx.x, nwg = gridDim.x;
+    const bool any_hot = hot->H != 0u;
+    const K hot_empty = any_hot ? hot->empty : (K)0;
+    if (any_hot) for (int i = tid; i < kHotSlots; i += kJThreads) s_hot[i] = hot->slots[i];
     const int cap_lines = (int)(cap / LINE) - 1;                                  // the last line takes the final partial flush
     for (int b = tid; b < P; b += kJThreads) { s_w[b] = 0u; s_lcur[b] = 0; }
     for (int b = tid; b < P + 2; b += kJThreads) ext[b] = b == 0 ? (K)0 : b < P ? splitters[b - 1] : (K)~(K)0;
@@ -244,7 +558,7 @@ __global__ __launch_bounds__(kJThreads) void jpart_kernel(const K *__restrict__ 
 #pragma unroll
         for (int j = 0; j < VEC; j++) {
             kk[j] = kraw[j] ^ bias;
-            if (j < nrows && kk[j] >= kmin && kk[j] <= kmax) pending |= 1u << j;
+            if (j < nrows && kk[j] >= kmin && kk[j] <= kmax && !(any_hot && jhot_find<K>(s_hot, hot_empty, kk[j]) != ~0u)) pending |= 1u << j;
             // bucket = number of splitters <= key = the b with ext[b] <= key < ext[b + 1]
             const K key = kk[j];
             uint32_t g = __umulhi((uint32_t)((uint64_t)(key - kmin) >> gshift), gmul);
@@ -642,7 +956,8 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
                                                            const uint32_t *__restrict__ rranked /* may be null: a build-side column in rank order ... */,
                                                            uint32_t *__restrict__ rval_out /* ... read off for every survivor (unique build keys: survivor = output row) */,
                                                            const uint4 *__restrict__ srec /* VERIFY (64-bit keys): the survivors as records (rank, left row, carried word, probe-key low word); `surv` is not used then */,
-                                                           const uint64_t *__restrict__ rkeys64 /* VERIFY: the sorted build keys */)
+                                                           const uint64_t *__restrict__ rkeys64 /* VERIFY: the sorted build keys */,
+                                                           JHotHead *__restrict__ hot /* the hot keys' blocks: left free here, their first rows reported (pdst) */)
 {
     constexpr int XW = (CARRY ? 1 : 0) + (VERIFY ? 1 : 0), STAGE = stage_of(XW), FINE = fine_of(XW), RPT = STAGE / kJThreads;
     static_assert(RPT * kJThreads == STAGE, "a sub-round's survivors are dealt RPT to a lane");
@@ -657,10 +972,18 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
     __shared__ uint32_t s_bincnt[kMaxBins];
     __shared__ uint32_t s_np;
     __shared__ int s_bad;
+    __shared__ uint32_t s_h0, s_nh, s_nlong;
+    __shared__ uint32_t s_hrank[kHotMax], s_hcum[kHotMax + 1];               // the bucket's hot ranks (ascending), the hot rows before each (inside the bucket)
+    __shared__ uint2 s_long[kLongMax];                                       // runs of more than kTieMax rows in the stage (first, length)
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) { s_dst = 0ull; s_bad = 0; s_np = 0u; }
+    if (tid == 0) { s_dst = 0ull; s_bad = 0; s_np = 0u; s_h0 = 0u; s_nh = 0u; s_nlong = 0u; }
     if (tid < kMaxBins) s_bincnt[tid] = sbins[(size_t)b * kMaxBins + tid];
     __syncthreads();
+    const uint32_t Hp = hot->Hp;                                           // hot keys with partners: dense and ascending, so a bucket's are a range [h0, h0 + nh)
+    if ((uint32_t)tid < Hp) {
+        const uint32_t hb = hot->pbucket[tid];
+        if (hb < (uint32_t)b) atomicAdd(&s_h0, 1u); else if (hb == (uint32_t)b) atomicAdd(&s_nh, 1u);
+    }
     unsigned long long part = 0;
     for (int qq = tid; qq < b; qq += kJThreads) part += scount[qq];
     for (int d = 32; d > 0; d >>= 1) part += __shfl_down(part, d, 64);
@@ -673,6 +996,17 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
     }
     const uint32_t lo = bstart[b], len = bstart[b + 1] - lo, nb = scount[b];
     __syncthreads();
+    const uint32_t h0 = s_h0, nh = s_nh;
+    if ((uint32_t)tid < nh) s_hrank[tid] = hot->prank[h0 + tid];
+    if (tid == 0) { uint32_t run = 0; for (uint32_t i = 0; i < nh; i++) { s_hcum[i] = run; run += (uint32_t)hot->prows[h0 + i]; } s_hcum[nh] = run; }
+    const unsigned long long hot_before = Hp == 0u ? 0ull : h0 < Hp ? hot->pbefore[h0] : hot->mhot;
+    // rows of the bucket's hot keys that come before rank r (their blocks lie between the rows written here)
+    auto hot_shift = [&](uint32_t r) -> uint32_t {
+        if (nh == 0u) return 0u;
+        uint32_t a = 0, z = nh;                                            // the number of hot ranks < r
+        while (a < z) { const uint32_t mid = (a + z) >> 1; if (s_hrank[mid] < r) a = mid + 1u; else z = mid; }
+        return s_hcum[a];
+    };
     const JBins bins = jbins_of(len, s_np, stage_cap, region);
     const int gs = bins.gs;                                                    // a bin = bins.gw consecutive groups
     const uint2 *src = VERIFY ? nullptr : surv + (size_t)b * region;
@@ -682,8 +1016,11 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
     const uint32_t ngroups = (len + (1u << gs) - 1u) >> gs;
     for (uint32_t i = tid; i <= ngroups; i += kJThreads) coarse[i] = i < ngroups ? scoarse[(size_t)b * kCoarse + i] : 0u;   // counted by the bucket kernel
     __syncthreads();
-    const unsigned long long dst = s_dst;
-    if (nb == 0) return;
+    const unsigned long long dst = s_dst + hot_before;
+    if (nb == 0) {                                                     // nothing but (perhaps) hot blocks
+        if ((uint32_t)tid < nh) hot->pdst[h0 + tid] = dst + s_hcum[tid];
+        return;
+    }
     // a pass over a bin's survivors (the pieces of a crowded bin: the usual sub-round keeps its survivors in registers, below)
     // keeps 8 loads per lane in flight: one workgroup owns the CU, and with a single load per lane the passes ran at the
     // latency of a load, not at the CU's share of the bandwidth.  f(entry (rank, left row), third word, probe-key low word)
@@ -734,7 +1071,8 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
     __syncthreads();
     const bool bad = s_bad != 0;
     scan_excl(coarse, ngroups + 1);                                    // coarse[g] = survivors before group g; coarse[ngroups] = nb
-    if (bad) {                                                         // bin after bin, as they are
+    if (bad) {                                                         // bin after bin, as they are; the hot blocks behind them (the caller sorts everything)
+        if ((uint32_t)tid < nh) hot->pdst[h0 + tid] = dst + nb + s_hcum[tid];
         for (uint32_t j = 0; j < (uint32_t)bins.nb; j++) {
             const unsigned long long o = dst + coarse[min(ngroups, j * bins.gw)];      // the survivors of the bins before bin j
             for (uint32_t i = tid; i < s_bincnt[j]; i += kJThreads) {
@@ -768,6 +1106,10 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
     while (g0 < ngroups) {
         const uint32_t base_cnt = coarse[g0];
         const uint32_t g1 = sub_end(g0), r0 = g0 << gs, r1 = min(len, g1 << gs), nr = r1 - r0, nsub = coarse[g1] - base_cnt;
+        if (!nsub && (uint32_t)tid < nh) {                              // no rows here: a hot block of these ranks starts where the sub-round does
+            const uint32_t rr = s_hrank[tid] - lo;
+            if (rr >= r0 && rr < r1) hot->pdst[h0 + tid] = dst + base_cnt + s_hcum[tid];
+        }
         if (nsub) {
             auto count_one = [&](uint2 e, uint32_t, uint32_t) { const uint32_t r = e.x - lo - r0; if (r < nr) atomicAdd(&fine[r], 1u); };
             auto place_one = [&](uint2 e, uint32_t v, uint32_t kl) {
@@ -809,6 +1151,49 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
                 sweep_bins(g0, g1, place_one);
             }
             __syncthreads();
+            if ((uint32_t)tid < nh) {                                   // a hot key's block starts behind the rows of the smaller ranks (it has none of its own here)
+                const uint32_t rr = s_hrank[tid] - lo;
+                if (rr >= r0 && rr < r1) hot->pdst[h0 + tid] = dst + base_cnt + (rr > r0 ? fine[rr - r0 - 1u] : 0u) + s_hcum[tid];
+            }
+            // ---- a rank with more than kTieMax rows (a key too rare for the sample, too frequent for the counting below): its
+            // run of the stage is sorted by left row in place, one wave per run -- a bitonic network over the run padded to a power
+            // of two (the padding is never touched: every exchange moves the smaller row to the lower index)
+            for (uint32_t r = tid; r < nr; r += kJThreads) {
+                const uint32_t a0 = r ? fine[r - 1u] : 0u, a1 = fine[r];
+                if (a1 - a0 > (uint32_t)kTieMax) s_long[atomicAdd(&s_nlong, 1u)] = uint2{a0, a1 - a0};   // (at most STAGE / (kTieMax + 1) of them)
+            }
+            __syncthreads();
+            const uint32_t nlong = s_nlong;
+            auto exchange = [&](uint32_t a0, uint32_t L, uint32_t i, uint32_t j) {          // i < j
+                if (j < L) {
+                    const uint32_t x = stage[a0 + i].y, y = stage[a0 + j].y;
+                    if (x > y) {
+                        stage[a0 + i].y = y; stage[a0 + j].y = x;
+                        if (CARRY) { const uint32_t t = stv[a0 + i]; stv[a0 + i] = stv[a0 + j]; stv[a0 + j] = t; }
+                        if (VERIFY) { const uint32_t t = stk[a0 + i]; stk[a0 + i] = stk[a0 + j]; stk[a0 + j] = t; }
+                    }
+                }
+            };
+            // `width` lanes (a wave, or the whole workgroup for the runs a wave would take too long over) walk the network; `sync`
+            // separates its steps
+            auto bitonic = [&](uint32_t a0, uint32_t L, uint32_t me, uint32_t width, auto &&sync) {
+                uint32_t p2 = 128u;
+                while (p2 < L) p2 <<= 1;
+                for (uint32_t k = 2u; k <= p2; k <<= 1) {
+                    const uint32_t hk = k >> 1;
+                    for (uint32_t x = me; x < (p2 >> 1); x += width) { const uint32_t blk = x / hk, off = x % hk; exchange(a0, L, blk * k + off, blk * k + k - 1u - off); }
+                    sync();
+                    for (uint32_t jj = hk >> 1; jj >= 1u; jj >>= 1) {
+                        for (uint32_t x = me; x < (p2 >> 1); x += width) { const uint32_t i = 2u * jj * (x / jj) + x % jj; exchange(a0, L, i, i + jj); }
+                        sync();
+                    }
+                }
+            };
+            for (uint32_t q = 0; q < nlong; q++)                        // (at most STAGE / kWaveSortMax of these)
+                if (s_long[q].y > (uint32_t)kWaveSortMax) bitonic(s_long[q].x, s_long[q].y, (uint32_t)tid, (uint32_t)kJThreads, [] { __syncthreads(); });
+            for (uint32_t q = wave; q < nlong; q += kJThreads / 64)
+                if (s_long[q].y <= (uint32_t)kWaveSortMax) bitonic(s_long[q].x, s_long[q].y, (uint32_t)lane, 64u, [] { wave_lds_sync(); });
+            if (nlong) { __syncthreads(); if (tid == 0) s_nlong = 0u; }
             // ---- rows of one rank into left-row order, and out: every survivor counts the rows of ITS rank (the stage's run
             // [fine[r-1], fine[r]), five or so) that are smaller than its own -- row ids are distinct, so that is its place in
             // the run -- and stores itself there.  (A first version sorted each run in registers with sorting networks, one
@@ -835,7 +1220,7 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
                 }
 #pragma unroll
                 for (int q = 0; q < kB; q++) {
-                    if (s1[q] - s0[q] > (uint32_t)kTieMax) too_long = true;      // a hot key: the caller's radix sorts order everything
+                    if (s1[q] - s0[q] > (uint32_t)kTieMax) {}                    // a long run: sorted above, the row is in its place
                     else if (s1[q] - s0[q] > 1u) {
                         uint32_t c = 0;
                         for (uint32_t j = s0[q]; j < s1[q]; j++) c += stage[j].y < e[q].y ? 1u : 0u;
@@ -845,11 +1230,12 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
 #pragma unroll
                 for (int q = 0; q < kB; q++) {
                     if (i0 + (uint32_t)q * kJThreads < nsub) {
+                        const unsigned long long w = o + at[q] + hot_shift(e[q].x);
                         if (VERIFY && rk[q] != kl[q]) mismatch = true;             // a hit on a truncated key that is none
-                        if (rank) { rank[o + at[q]] = e[q].x; lrow[o + at[q]] = e[q].y; }   // null: every result column arrives through lval_out / rval_out
-                        if (cnt_out) cnt_out[o + at[q]] = rl[q];
-                        if (CARRY) lval_out[o + at[q]] = v3[q];
-                        if (rranked) rval_out[o + at[q]] = rv[q];
+                        if (rank) { rank[w] = e[q].x; lrow[w] = e[q].y; }           // null: every result column arrives through lval_out / rval_out
+                        if (cnt_out) cnt_out[w] = rl[q];
+                        if (CARRY) lval_out[w] = v3[q];
+                        if (rranked) rval_out[w] = rv[q];
                     }
                 }
             }
@@ -938,9 +1324,24 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
     if (!rc && verify) rc = hark_alloc(ctx, (void **)&srec, 16 * (size_t)P * region);          // 64-bit keys: records + their ranks alone
     uint32_t *scoarse = nullptr;
     if (!rc) rc = hark_alloc(ctx, (void **)&scoarse, 4 * (size_t)P * kCoarse);
+    // the heavy hitters (see jhot_sample_kernel): one probe key in n / S sampled; the probe column in pieces of R rows, one per wave
+    JHotSet<K> *hot = nullptr;
+    unsigned long long *tkey = nullptr;
+    uint32_t *tcnt = nullptr, *ptotal = nullptr;
+    const bool no_hot = getenv("HARK_JOIN_NOHOT") != nullptr || getenv("HARK_JOIN_FULLSORT") != nullptr;      // A/B + tests
+    uint32_t S = (uint32_t)std::min<int64_t>(kHotSampleMax, std::max<int64_t>(4096, n / 64)), cmin = 8;
+    if (const char *e = getenv("HARK_JOIN_HOTMIN")) { const int c = atoi(e); if (c >= 2) cmin = (uint32_t)c; }   // tests: hot keys in small tables
+    uint32_t tslots = 1;
+    while (tslots < 4u * S) tslots <<= 1;
+    const uint32_t R = (uint32_t)std::max<int64_t>(4096, ((n + 4095) / 4096 + 1023) / 1024 * 1024), npieces = (uint32_t)((n + R - 1) / R);
+    if (!rc) rc = hark_alloc(ctx, (void **)&hot, sizeof(JHotSet<K>));
+    if (!rc) rc = hark_alloc(ctx, (void **)&tkey, 8 * (size_t)tslots);
+    if (!rc) rc = hark_alloc(ctx, (void **)&tcnt, 4 * (size_t)tslots);
+    if (!rc) rc = hark_alloc(ctx, (void **)&ptotal, 4 * (size_t)npieces);
     auto cleanup = [&]() {
         hark_free(ctx, splitters); hark_free(ctx, bstart); hark_free(ctx, counts); hark_free(ctx, scount); hark_free(ctx, sbins);
         hark_free(ctx, info); hark_free(ctx, slabs); hark_free(ctx, surv); hark_free(ctx, srec); hark_free(ctx, scoarse);
+        hark_free(ctx, hot); hark_free(ctx, tkey); hark_free(ctx, tcnt); hark_free(ctx, ptotal);
     };
     if (rc == HARK_ENOMEM) {                                                     // no room for the partition workspace: the sort-merge path
         cleanup();                                                               // needs far less (used stays false)
@@ -951,9 +1352,16 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
     if (hipMemsetAsync(info, 0, 32, st) != hipSuccess) { cleanup(); return hark_fail(ctx, HARK_EHIP, "join: workspace memset failed"); }
     int32_t *err = reinterpret_cast<int32_t *>(info + 1);
     unsigned long long *total = reinterpret_cast<unsigned long long *>(info);
+    HIP_TRY_RC(ctx, rc, hipMemsetAsync(hot, 0, sizeof(JHotHead), st));             // no hot keys, no candidates
+    if (!no_hot) {
+        HIP_TRY_RC(ctx, rc, hipMemsetAsync(tkey, 0xFF, 8 * (size_t)tslots, st));
+        HIP_TRY_RC(ctx, rc, hipMemsetAsync(tcnt, 0, 4 * (size_t)tslots, st));
+        HARK_LAUNCH_RC(ctx, rc, jhot_sample_kernel<K><<<(S + 255) / 256, 256, 0, st>>>(lcol, n, bias, S, tkey, tcnt, tslots - 1u, cmin, hot));
+        HARK_LAUNCH_RC(ctx, rc, jhot_select_kernel<K><<<1, 1024, 0, st>>>(tkey, tcnt, cmin, rkeys, s, hot));
+    }
     HARK_LAUNCH_RC(ctx, rc, jsplit_kernel<K><<<(P + 256) / 256, 256, 0, st>>>(rkeys, s, P, splitters, bstart));
     if (rc) { cleanup(); return rc; }
-    const size_t lds_part = sizeof(E) * (size_t)P * Q + sizeof(K) * (P + 2) + 8 * (size_t)P + 16;
+    const size_t lds_part = sizeof(E) * (size_t)P * Q + sizeof(K) * (P + 2) + 8 * (size_t)P + 16 + sizeof(K) * (size_t)kHotSlots;
     const bool plain_loads = getenv("HARK_JOIN_PLAIN_LOADS") != nullptr;        // tests: the compiler-counted twin of the partition kernel
     hipError_t he = plain_loads ? hipFuncSetAttribute(reinterpret_cast<const void *>(&jpart_kernel<K, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part)
                                 : hipFuncSetAttribute(reinterpret_cast<const void *>(&jpart_kernel<K, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part);
@@ -973,16 +1381,20 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
     if (const char *e = getenv("HARK_JOIN_STAGE")) { const int c = atoi(e); if (c >= 1 && c < stage_cap) stage_cap = c; }   // tests: many sub-rounds per bucket
     if (he == hipSuccess) {
         // one stream-ordered chain, one host read at the end: partition -> bucket probe -> survivor total
-        if (plain_loads) HARK_LAUNCH_RC(ctx, rc, jpart_kernel<K, false><<<dim3((unsigned)nwg), dim3(kJThreads), lds_part, st>>>(lcol, n, bias, splitters, rkeys, s, slabs, counts, cap, period, err, carry ? lval : nullptr));
-        else HARK_LAUNCH_RC(ctx, rc, jpart_kernel<K, true><<<dim3((unsigned)nwg), dim3(kJThreads), lds_part, st>>>(lcol, n, bias, splitters, rkeys, s, slabs, counts, cap, period, err, carry ? lval : nullptr));
+        if (plain_loads) HARK_LAUNCH_RC(ctx, rc, jpart_kernel<K, false><<<dim3((unsigned)nwg), dim3(kJThreads), lds_part, st>>>(lcol, n, bias, splitters, rkeys, s, slabs, counts, cap, period, err, carry ? lval : nullptr, hot));
+        else HARK_LAUNCH_RC(ctx, rc, jpart_kernel<K, true><<<dim3((unsigned)nwg), dim3(kJThreads), lds_part, st>>>(lcol, n, bias, splitters, rkeys, s, slabs, counts, cap, period, err, carry ? lval : nullptr, hot));
         HARK_LAUNCH_RC(ctx, rc, jbucket_kernel<K><<<dim3((unsigned)P), dim3(kJThreads), lds_bucket, st>>>(slabs, counts, cap, nwg, rkeys, bstart, chunk_cap, surv, region, scount, sbins, srec, scoarse, stage_cap, err, allow_trunc ? 1 : 0));
         HARK_LAUNCH_RC(ctx, rc, jsum_kernel<<<1, 1024, 0, st>>>(scount, P, total));
+        // the hot keys' rows, counted piece by piece (the kernels leave at once when there is no hot key)
+        HARK_LAUNCH_RC(ctx, rc, jhot_count_kernel<K><<<(npieces + 15) / 16, 1024, 0, st>>>(lcol, n, bias, hot, ptotal, npieces, R));
+        HARK_LAUNCH_RC(ctx, rc, jhot_finish_kernel<<<1, 1024, 0, st>>>(hot, ptotal, npieces, bstart, P, reinterpret_cast<unsigned long long *>(info + 3)));
         HIP_TRY_RC(ctx, rc, hipMemcpyAsync(info + 2, flags, 8, hipMemcpyDeviceToDevice, st));   // the duplicate-keys flag rides along with the same host read
     }
     if (he != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: setting the dynamic LDS size of the partition / bucket kernel failed: %s", hipGetErrorString(he));
-    int64_t words[3] = {0, 0, 0}, M = 0;
-    if (!rc) rc = hark_read_words(ctx, info, words, 3);
-    M = words[0];
+    int64_t words[4] = {0, 0, 0, 0}, M = 0;
+    if (!rc) rc = hark_read_words(ctx, info, words, 4);
+    const int64_t mhot = words[3];                                              // matching rows of the hot keys: blocks between the others' rows
+    M = words[0] + mhot;
     if (!rc && (int32_t)(words[1] & 0xFFFFFFFFll) != 0) { cleanup(); return HARK_OK; }          // a slab or a survivor bin overflowed (skew): caller falls back
     const bool dup = ((words[2] >> 32) & 0xFFFFFFFFll) != 0;
     *dup_out = dup;
@@ -1011,7 +1423,7 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
                     if (e != hipSuccess) return e;
                     jorder_kernel<C, V><<<dim3((unsigned)P), dim3(kJThreads), lds_order, st>>>(surv, region, scount, sbins, counts, cap, nwg, bstart, P, runlen,
                                                                                              rank, lrow, cnt, stage_cap, flags, C ? lv : nullptr, scoarse, rranked, rv,
-                                                                                             V ? srec : nullptr, V ? rk64 : nullptr);
+                                                                                             V ? srec : nullptr, V ? rk64 : nullptr, hot);
                     return hipGetLastError();
                 };
                 he = verify ? (carry ? launch(std::true_type{}, std::true_type{}) : launch(std::false_type{}, std::true_type{}))
@@ -1028,6 +1440,17 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
             skip_rows = false;
             rc = hark_alloc(ctx, (void **)&rank, 4 * (size_t)M);
             if (!rc) rc = hark_alloc(ctx, (void **)&lrow, 4 * (size_t)M);
+        }
+        if (!rc && !mismatch && mhot > 0) {                                     // the hot keys' rows into the blocks the order kernel left free
+            uint32_t *hkey = nullptr, *hrow = nullptr, *skey = nullptr, *srow = nullptr;
+            rc = hark_alloc(ctx, (void **)&hkey, 4 * (size_t)mhot);
+            if (!rc) rc = hark_alloc(ctx, (void **)&hrow, 4 * (size_t)mhot);
+            HARK_LAUNCH_RC(ctx, rc, jhot_compact_kernel<K><<<(npieces + 15) / 16, 1024, 0, st>>>(lcol, n, bias, hot, ptotal, npieces, R, hkey, hrow));
+            if (!rc) rc = k_sort_column(ctx, hkey, HARK_U32, mhot, false, hrow, &srow, &skey);       // by key, stable: one pass over a byte
+            int64_t g = (mhot + 255) / 256;
+            if (g > (int64_t)ctx->num_cu * 16) g = (int64_t)ctx->num_cu * 16;
+            HARK_LAUNCH_RC(ctx, rc, jhot_place_kernel<<<dim3((unsigned)g), 256, 0, st>>>(hot, skey, srow, mhot, runlen, carry ? lval : nullptr, rranked, rank, lrow, cnt, lv, rv));
+            hark_free(ctx, hkey); hark_free(ctx, hrow); hark_free(ctx, skey); hark_free(ctx, srow);   // stream-ordered reuse
         }
         if (!rc && mismatch) {
             // a probe key shared its truncation with a build key it differs from (keys that cluster below the dropped bits): the
