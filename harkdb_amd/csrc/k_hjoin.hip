@@ -167,45 +167,46 @@ __global__ __launch_bounds__(256) void jcnt_kernel(const uint32_t *__restrict__ 
 // never get there:
 //   1. jhot_sample_kernel reads one probe key in n / S (S <= 65536) and counts equal samples in a hash table;
 //      jhot_select_kernel keeps the (at most kHotMax) keys sampled cmin times or more, looks up their ranks in the sorted
-//      build side and lays out an open-addressing set of them that fits every kernel's LDS;
-//   2. jpart_kernel drops the rows of a hot key (one LDS probe per row, nothing at all when the set is empty);
+//      build side and lays out an open-addressing set of them that fits the partition kernel's LDS;
+//   2. jpart_kernel drops the rows of a hot key (one LDS probe per row, nothing at all when the set is empty) and counts,
+//      batch by batch, those whose key has partners;
 //   3. the rows of a hot key are a contiguous block of the output at the key's rank, IN ROW ORDER -- which a stable
-//      partition of the probe column delivers without any sorting: jhot_count_kernel counts the rows of every hot key per
-//      contiguous piece of the column (one piece per wave), jhot_scan_kernel turns the counts into places, the order kernel
-//      leaves the blocks free (every later row of the bucket moves back by the blocks before it) and reports where they
-//      start, and jhot_scatter_kernel reads the column once more and writes every hot row to its place.
-// Two more passes over the probe keys, paid only when a hot key exists (the kernels leave at once when the set is empty).
+//      partition of the probe column delivers without any sorting: the counts are scanned (jhot_scan_kernel), the hot rows
+//      are written out in row order as (key index, row) by a second pass over the column (jhot_compact_kernel, a wave per
+//      batch), ONE stable pass of the radix sort groups them by key, the order kernel leaves the blocks free (every later
+//      row of the bucket moves back by the blocks before it) and reports where they start, and jhot_place_kernel copies
+//      the groups there.
+// One more pass over the probe keys, paid only when a hot key exists (the kernels leave at once when the set is empty).
 constexpr int kHotMax = 256, kHotSlots = 1024, kHotCand = 4096, kHotSampleMax = 65536;
 constexpr uint32_t kNoRank = 0xFFFFFFFFu;
 constexpr uint16_t kNoHot = 0xFFFFu;
 
 struct JHotHead {
-    uint32_t H, ncand, Hp, pad;                // hot keys (ascending), candidates of the sample, hot keys with partners
+    uint32_t H, ncand, Hp, pad;                // hot keys, candidates of the sample, hot keys with partners
     unsigned long long mhot;                   // matching probe rows of all hot keys
-    uint32_t rank[kHotMax];                    // by hot key: rank of its first sorted build entry, kNoRank: it has no partner (its rows are dropped)
-    uint16_t h2p[kHotMax];                     // by hot key: its place among the keys with partners, kNoHot
-    unsigned long long rows_all[kHotMax];      // by hot key: its probe rows (counted only when it has partners)
-    // the keys with partners, ascending (dense): what the order kernel and the scatter need
-    uint32_t prank[kHotMax], pbucket[kHotMax];
+    // the keys with partners, ascending (dense): what the order kernel and the placement need
+    uint32_t prank[kHotMax], pbucket[kHotMax]; // rank of the key's first sorted build entry; the bucket of that rank
     unsigned long long prows[kHotMax];         // probe rows of the key
     unsigned long long pbefore[kHotMax];       // rows of the hot keys before it
     unsigned long long pdst[kHotMax];          // first output row of its block (written by the order kernel)
-    uint16_t slot_idx[kHotSlots];              // by slot of the set: the hot key's index
+    uint16_t slot_p[kHotSlots];                // by slot of the set: the key's index among those with partners, kNoHot: it has none (its rows are dropped)
     uint32_t cand[kHotCand];                   // slots of the sample table whose count reached cmin
 };
-template <typename K> struct JHotSet : JHotHead { K empty; K keys[kHotMax]; K slots[kHotSlots]; };   // empty: a value that is no hot key marks the free slots
+template <typename K> struct JHotSet : JHotHead { K empty; K slots[kHotSlots]; };   // empty: a value that is no hot key marks the free slots
 
 __device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }   // a wave's own LDS traffic, in program order
 
 template <typename K> __device__ __forceinline__ uint32_t jhot_find(const K *slots, K empty, K key)       // the key's slot, ~0u: not a hot key
 {
     uint32_t slot = jhash(key) >> 22;
-    for (;;) {
-        const K x = slots[slot];
-        if (x == empty) return ~0u;                                       // (first: a probe key may equal the marker)
-        if (x == key) return slot;
+    K x = slots[slot];
+    if (x == empty) return ~0u;                                           // (first: a probe key may equal the marker) -- where almost every row leaves
+    while (x != key) {
         slot = (slot + 1u) & (uint32_t)(kHotSlots - 1);
+        x = slots[slot];
+        if (x == empty) return ~0u;
     }
+    return slot;
 }
 
 // table: tkey[mask + 1] (all ones = free), tcnt[mask + 1]; mask + 1 >= 4 S, so a free slot is always found
@@ -233,8 +234,9 @@ __global__ __launch_bounds__(1024) void jhot_select_kernel(const unsigned long l
                                                            const K *__restrict__ rkeys, int64_t s, JHotSet<K> *__restrict__ hot)
 {
     __shared__ K s_key[kHotMax];
+    __shared__ uint32_t s_rank[kHotMax];                                  // by place in ascending key order
     __shared__ K s_slots[kHotSlots];
-    __shared__ uint16_t s_idx[kHotSlots];
+    __shared__ uint16_t s_p[kHotSlots];
     __shared__ uint32_t s_n, s_free;
     const int tid = threadIdx.x;
     const uint32_t nc = min(hot->ncand, (uint32_t)kHotCand);
@@ -268,8 +270,7 @@ __global__ __launch_bounds__(1024) void jhot_select_kernel(const unsigned long l
         for (int j = 0; j < H; j++) pos += s_key[j] < mykey ? 1 : 0;      // the keys are distinct: its place in ascending order
         int64_t lo = 0, hi = s;
         while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (rkeys[mid] < mykey) lo = mid + 1; else hi = mid; }
-        hot->keys[pos] = mykey;
-        hot->rank[pos] = (lo < s && rkeys[lo] == mykey) ? (uint32_t)lo : kNoRank;
+        s_rank[pos] = (lo < s && rkeys[lo] == mykey) ? (uint32_t)lo : kNoRank;
     }
     if (tid <= H) {                                                       // the smallest of 0 .. H that is no hot key marks the free slots
         bool used = false;
@@ -278,7 +279,9 @@ __global__ __launch_bounds__(1024) void jhot_select_kernel(const unsigned long l
     }
     __syncthreads();
     const K empty = (K)s_free;
-    s_slots[tid] = empty; s_idx[tid] = kNoHot;                            // (kHotSlots threads)
+    s_slots[tid] = empty; s_p[tid] = kNoHot;                              // (kHotSlots threads)
+    int p = 0, hp = 0;                                                    // its place among the keys with partners (ascending keys = ascending ranks)
+    for (int j = 0; j < H; j++) { const int has = s_rank[j] != kNoRank ? 1 : 0; if (j < pos) p += has; hp += has; }
     __syncthreads();
     if (tid < H) {
         uint32_t slot = jhash(mykey) >> 22;
@@ -288,34 +291,56 @@ __global__ __launch_bounds__(1024) void jhot_select_kernel(const unsigned long l
             if (old == (A)empty) break;
             slot = (slot + 1u) & (uint32_t)(kHotSlots - 1);
         }
-        s_idx[slot] = (uint16_t)pos;
+        if (s_rank[pos] != kNoRank) { s_p[slot] = (uint16_t)p; hot->prank[p] = s_rank[pos]; }
     }
     __syncthreads();
-    hot->slots[tid] = s_slots[tid]; hot->slot_idx[tid] = s_idx[tid];
-    if (tid == 0) { hot->empty = empty; hot->H = (uint32_t)H; }
+    hot->slots[tid] = s_slots[tid]; hot->slot_p[tid] = s_p[tid];
+    if (tid == 0) { hot->empty = empty; hot->H = (uint32_t)H; hot->Hp = (uint32_t)hp; }
 }
 
-// The probe column is cut into pieces of R rows, one per wave.  ptotal[piece] = rows of the piece that carry a hot key with
-// partners, rows_all[h] += the key's rows: the sizes of the blocks.
-template <typename K>
-__global__ __launch_bounds__(1024) void jhot_count_kernel(const K *__restrict__ keys, int64_t n, K bias, JHotSet<K> *__restrict__ hot,
-                                                          uint32_t *__restrict__ ptotal, uint32_t npieces, uint32_t R)
+// btotal[batch] (rows of the batch that carry a hot key with partners, counted by the partition kernel) -> exclusive prefix:
+// the first place of every batch in the stream of hot rows; the total -> *mhot_out (for the host)
+__global__ __launch_bounds__(1024) void jhot_scan_kernel(JHotHead *__restrict__ hot, uint32_t *__restrict__ btotal, uint32_t nbatch, unsigned long long *__restrict__ mhot_out)
 {
-    constexpr int VEC = 16 / (int)sizeof(K);
-    __shared__ K s_slots[kHotSlots];
-    __shared__ uint16_t s_idx[kHotSlots];
-    __shared__ uint32_t s_cnt[kHotMax];
-    const uint32_t H = hot->H;
-    if (H == 0) return;
+    __shared__ uint32_t s_wave[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (hot->Hp == 0u) { if (tid == 0) *mhot_out = 0ull; return; }
+    const uint32_t per = (nbatch + 1023u) / 1024u, s0 = min(nbatch, (uint32_t)tid * per), s1 = min(nbatch, s0 + per);
+    uint32_t sum = 0;
+    for (uint32_t i = s0; i < s1; i++) sum += btotal[i];
+    uint32_t incl = sum;
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d, 64); if (lane >= d) incl += y; }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t run = incl - sum, total = 0;
+    for (int w = 0; w < 16; w++) { const uint32_t x = s_wave[w]; if (w < wave) run += x; total += x; }
+    for (uint32_t i = s0; i < s1; i++) { const uint32_t c = btotal[i]; btotal[i] = run; run += c; }
+    if (tid == 0) { hot->mhot = total; *mhot_out = total; }
+}
+
+// the rows of the hot keys with partners, in row order: (index among those keys, row); a wave per batch of the partition
+// kernel (BATCH rows).  One stable pass of the radix sort over the index then groups them by key with the row order kept --
+// the reference's order inside a key (join.fut:66).  The keys' rows are counted on the way (prows).
+template <typename K>
+__global__ __launch_bounds__(1024) void jhot_compact_kernel(const K *__restrict__ keys, int64_t n, K bias, JHotSet<K> *__restrict__ hot,
+                                                            const uint32_t *__restrict__ bprefix, uint32_t nbatch,
+                                                            uint32_t *__restrict__ hkey, uint32_t *__restrict__ hrow)
+{
+    constexpr int VEC = JTraits<K>::VEC, BATCH = kJThreads * VEC;
+    __shared__ K s_slots[kHotSlots];
+    __shared__ uint16_t s_p[kHotSlots];
+    __shared__ uint32_t s_cnt[kHotMax];
+    const uint32_t Hp = hot->Hp;
+    if (Hp == 0u || hot->mhot == 0ull) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    s_slots[tid] = hot->slots[tid]; s_p[tid] = hot->slot_p[tid];
     if (tid < kHotMax) s_cnt[tid] = 0u;
-    s_slots[tid] = hot->slots[tid];
-    { const uint16_t h = hot->slot_idx[tid]; s_idx[tid] = h != kNoHot && hot->rank[h] != kNoRank ? h : kNoHot; }   // a hot key without partners counts nothing
     const K empty = hot->empty;
     __syncthreads();
-    const uint32_t piece = blockIdx.x * 16u + (uint32_t)wave;
-    const int64_t r0 = (int64_t)piece * R, r1 = piece < npieces ? min(n, r0 + (int64_t)R) : r0;
-    uint32_t mine = 0;
+    const uint32_t batch = blockIdx.x * 16u + (uint32_t)wave;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int64_t r0 = (int64_t)batch * BATCH, r1 = batch < nbatch ? min(n, r0 + (int64_t)BATCH) : r0;
+    uint32_t at = batch < nbatch ? bprefix[batch] : 0u;                   // wave-uniform: the next free place of the stream
     constexpr int U = 4;                                                  // loads in flight per lane
     for (int64_t base = r0; base < r1; base += (int64_t)U * 64 * VEC) {
         K kk[U][VEC];
@@ -323,105 +348,7 @@ __global__ __launch_bounds__(1024) void jhot_count_kernel(const K *__restrict__ 
         for (int u = 0; u < U; u++) {
             const int64_t r = base + ((int64_t)u * 64 + lane) * VEC;
             if (r + VEC <= n) {
-                const hark_u4v q = *reinterpret_cast<const hark_u4v *>(keys + r);
-                if (sizeof(K) == 4) { kk[u][0] = (K)q.x; kk[u][1 % VEC] = (K)q.y; kk[u][2 % VEC] = (K)q.z; kk[u][3 % VEC] = (K)q.w; }
-                else { kk[u][0] = (K)(((uint64_t)q.y << 32) | q.x); kk[u][1 % VEC] = (K)(((uint64_t)q.w << 32) | q.z); }
-            } else {
-#pragma unroll
-                for (int j = 0; j < VEC; j++) kk[u][j] = r + j < n ? keys[r + j] : (K)0;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int64_t r = base + ((int64_t)u * 64 + lane) * VEC;
-#pragma unroll
-            for (int j = 0; j < VEC; j++) {
-                if (r + j < r1) {
-                    const uint32_t slot = jhot_find<K>(s_slots, empty, kk[u][j] ^ bias);
-                    if (slot != ~0u) { const uint16_t h = s_idx[slot]; if (h != kNoHot) { atomicAdd(&s_cnt[h], 1u); mine++; } }
-                }
-            }
-        }
-    }
-    for (int d = 32; d > 0; d >>= 1) mine += __shfl_down(mine, d, 64);
-    if (lane == 0 && piece < npieces) ptotal[piece] = mine;
-    __syncthreads();
-    if ((uint32_t)tid < H && s_cnt[tid]) atomicAdd(&hot->rows_all[tid], (unsigned long long)s_cnt[tid]);
-}
-
-// the hot keys that have partners, dense and ascending; their buckets; the rows before each; the total (-> *mhot_out for the
-// host); ptotal -> exclusive prefix (the first place of every piece in the stream of hot rows)
-__global__ __launch_bounds__(1024) void jhot_finish_kernel(JHotHead *__restrict__ hot, uint32_t *__restrict__ ptotal, uint32_t npieces, const uint32_t *__restrict__ bstart, int P,
-                                                           unsigned long long *__restrict__ mhot_out)
-{
-    __shared__ unsigned long long s_rows[kHotMax];
-    __shared__ uint32_t s_has[kHotMax];
-    __shared__ uint32_t s_wave[16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, H = (int)hot->H;
-    if (H == 0) { if (tid == 0) *mhot_out = 0ull; return; }
-    if (tid < kHotMax) {
-        const uint32_t r = tid < H ? hot->rank[tid] : kNoRank;
-        const unsigned long long rows = tid < H && r != kNoRank ? hot->rows_all[tid] : 0ull;
-        s_rows[tid] = rows; s_has[tid] = rows ? 1u : 0u;
-    }
-    __syncthreads();
-    if (tid < H) {
-        const int h = tid;
-        uint32_t p = 0, hp = 0;
-        unsigned long long before = 0, all = 0;
-        for (int j = 0; j < H; j++) { if (j < h) { p += s_has[j]; before += s_rows[j]; } hp += s_has[j]; all += s_rows[j]; }
-        hot->h2p[h] = s_has[h] ? (uint16_t)p : kNoHot;
-        if (s_has[h]) {
-            const uint32_t r = hot->rank[h];
-            int lo = 0, hi = P;                                           // the b with bstart[b] <= r < bstart[b + 1]
-            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (bstart[mid] <= r) lo = mid; else hi = mid; }
-            hot->prank[p] = r; hot->pbucket[p] = (uint32_t)lo; hot->prows[p] = s_rows[h]; hot->pbefore[p] = before; hot->pdst[p] = 0ull;
-        }
-        if (h == 0) { hot->Hp = hp; hot->mhot = all; *mhot_out = all; }
-    }
-    // exclusive scan of the pieces' totals (at most a few thousand)
-    const uint32_t per = (npieces + 1023u) / 1024u, s0 = min(npieces, (uint32_t)tid * per), s1 = min(npieces, s0 + per);
-    uint32_t sum = 0;
-    for (uint32_t i = s0; i < s1; i++) sum += ptotal[i];
-    uint32_t incl = sum;
-    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d, 64); if (lane >= d) incl += y; }
-    if (lane == 63) s_wave[wave] = incl;
-    __syncthreads();
-    uint32_t run = incl - sum;
-    for (int w = 0; w < wave; w++) run += s_wave[w];
-    for (uint32_t i = s0; i < s1; i++) { const uint32_t c = ptotal[i]; ptotal[i] = run; run += c; }
-}
-
-// the rows of the hot keys with partners, in row order: (index among those keys, row).  One stable pass of the radix sort
-// over the index then groups them by key with the row order kept -- the reference's order inside a key (join.fut:66).
-template <typename K>
-__global__ __launch_bounds__(1024) void jhot_compact_kernel(const K *__restrict__ keys, int64_t n, K bias, const JHotSet<K> *__restrict__ hot,
-                                                            const uint32_t *__restrict__ ptotal, uint32_t npieces, uint32_t R,
-                                                            uint32_t *__restrict__ hkey, uint32_t *__restrict__ hrow)
-{
-    constexpr int VEC = 16 / (int)sizeof(K);
-    __shared__ K s_slots[kHotSlots];
-    __shared__ uint16_t s_idx[kHotSlots];
-    const uint32_t H = hot->H;
-    if (H == 0 || hot->mhot == 0ull) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    s_slots[tid] = hot->slots[tid];
-    { const uint16_t h = hot->slot_idx[tid]; s_idx[tid] = h != kNoHot ? hot->h2p[h] : kNoHot; }
-    const K empty = hot->empty;
-    __syncthreads();
-    const uint32_t piece = blockIdx.x * 16u + (uint32_t)wave;
-    if (piece >= npieces) return;
-    const unsigned long long below = (1ull << lane) - 1ull;
-    const int64_t r0 = (int64_t)piece * R, r1 = min(n, r0 + (int64_t)R);
-    uint32_t at = ptotal[piece];                                          // wave-uniform: the next free place of the stream
-    constexpr int U = 2;
-    for (int64_t base = r0; base < r1; base += (int64_t)U * 64 * VEC) {
-        K kk[U][VEC];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int64_t r = base + ((int64_t)u * 64 + lane) * VEC;
-            if (r + VEC <= n) {
-                const hark_u4v q = *reinterpret_cast<const hark_u4v *>(keys + r);
+                const hark_u4v q = __builtin_nontemporal_load(reinterpret_cast<const hark_u4v *>(keys + r));
                 if (sizeof(K) == 4) { kk[u][0] = (K)q.x; kk[u][1 % VEC] = (K)q.y; kk[u][2 % VEC] = (K)q.z; kk[u][3 % VEC] = (K)q.w; }
                 else { kk[u][0] = (K)(((uint64_t)q.y << 32) | q.x); kk[u][1 % VEC] = (K)(((uint64_t)q.w << 32) | q.z); }
             } else {
@@ -436,18 +363,38 @@ __global__ __launch_bounds__(1024) void jhot_compact_kernel(const K *__restrict_
 #pragma unroll
             for (int j = 0; j < VEC; j++) {
                 pj[j] = kNoHot;
-                if (r + j < r1) { const uint32_t slot = jhot_find<K>(s_slots, empty, kk[u][j] ^ bias); if (slot != ~0u) pj[j] = s_idx[slot]; }
+                if (r + j < r1) { const uint32_t slot = jhot_find<K>(s_slots, empty, kk[u][j] ^ bias); if (slot != ~0u) pj[j] = s_p[slot]; }
                 const bool is = pj[j] != kNoHot;
                 const unsigned long long m = __ballot(is);
                 total += (uint32_t)__popcll(m); lower += (uint32_t)__popcll(m & below);      // rows of lower lanes come first, then this lane's in turn
                 if (is) mine |= 1u << j;
             }
-            uint32_t o = at + lower;
+            if (total) {
+                uint32_t o = at + lower;
 #pragma unroll
-            for (int j = 0; j < VEC; j++) if (mine & (1u << j)) { hkey[o] = pj[j]; hrow[o] = (uint32_t)(r + j); o++; }
-            at += total;
+                for (int j = 0; j < VEC; j++) if (mine & (1u << j)) { hkey[o] = pj[j]; hrow[o] = (uint32_t)(r + j); atomicAdd(&s_cnt[pj[j]], 1u); o++; }
+                at += total;
+            }
         }
     }
+    __syncthreads();
+    if ((uint32_t)tid < Hp && s_cnt[tid]) atomicAdd(&hot->prows[tid], (unsigned long long)s_cnt[tid]);
+}
+
+// the hot keys' buckets and the rows before each (prows is complete: the compaction has run)
+__global__ __launch_bounds__(kHotMax) void jhot_finish_kernel(JHotHead *__restrict__ hot, const uint32_t *__restrict__ bstart, int P)
+{
+    __shared__ unsigned long long s_rows[kHotMax];
+    const int p = threadIdx.x, Hp = (int)hot->Hp;
+    s_rows[p] = p < Hp ? hot->prows[p] : 0ull;
+    __syncthreads();
+    if (p >= Hp) return;
+    unsigned long long before = 0;
+    for (int j = 0; j < p; j++) before += s_rows[j];
+    const uint32_t r = hot->prank[p];
+    int lo = 0, hi = P;                                                   // the b with bstart[b] <= r < bstart[b + 1]
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (bstart[mid] <= r) lo = mid; else hi = mid; }
+    hot->pbucket[p] = (uint32_t)lo; hot->pbefore[p] = before; hot->pdst[p] = 0ull;
 }
 
 // the stream of hot rows, grouped by key and in row order inside a key, to the blocks the order kernel left free
@@ -468,8 +415,8 @@ __global__ __launch_bounds__(256) void jhot_place_kernel(const JHotHead *__restr
 }
 
 // ---- probe side: range partition of (key, row id) ---------------------------------------------------------------
-// LDS: E ring[P][Q]; K ext[P + 2]; u32 s_w[P] (head << 16 | count); int s_lcur[P]; u32 flags[4]; K s_hot[kHotSlots] (the set of
-// hot keys, whose rows take the stable partition above instead: read only when there is one).
+// LDS: E ring[P][Q]; K ext[P + 2]; u32 s_w[P] (head << 16 | count); int s_lcur[P]; u32 flags[4]; K s_hot[kHotSlots] + u16 s_hp[kHotSlots]
+// (the set of hot keys, whose rows take the stable partition above instead: read only when there is one).
 // HIDDEN: the batches' loads are issued from inline assembly and waited for by hand (below); false: plain non-temporal loads
 // whose waits the compiler places (HARK_JOIN_PLAIN_LOADS=1: the cross-check of tests/test_gpu_hjoin.py -- the hand-placed
 // waits depend on the compiler never touching a destination register between a load and its wait, which nothing checks at
@@ -481,7 +428,7 @@ __global__ __launch_bounds__(kJThreads) void jpart_kernel(const K *__restrict__ 
                                                           int period, int32_t *__restrict__ err,
                                                           const uint32_t *__restrict__ lval /* 16-byte entries only, may be null: a probe-side column that
                                                                                                travels in the entries' fourth word */,
-                                                          const JHotSet<K> *__restrict__ hot)
+                                                          const JHotSet<K> *__restrict__ hot, uint32_t *__restrict__ btotal /* [batches] rows of hot keys with partners */)
 {
     typedef typename JTraits<K>::E E;
     constexpr int P = JTraits<K>::P, Q = JTraits<K>::Q, VEC = JTraits<K>::VEC;
@@ -497,7 +444,8 @@ __global__ __launch_bounds__(kJThreads) void jpart_kernel(const K *__restrict__ 
     const int tid = threadIdx.x, wg = blockIdx.x, nwg = gridDim.x;
     const bool any_hot = hot->H != 0u;
     const K hot_empty = any_hot ? hot->empty : (K)0;
-    if (any_hot) for (int i = tid; i < kHotSlots; i += kJThreads) s_hot[i] = hot->slots[i];
+    uint16_t *s_hp = reinterpret_cast<uint16_t *>(s_hot + kHotSlots);
+    if (any_hot) for (int i = tid; i < kHotSlots; i += kJThreads) { s_hot[i] = hot->slots[i]; s_hp[i] = hot->slot_p[i]; }
     const int cap_lines = (int)(cap / LINE) - 1;                                  // the last line takes the final partial flush
     for (int b = tid; b < P; b += kJThreads) { s_w[b] = 0u; s_lcur[b] = 0; }
     for (int b = tid; b < P + 2; b += kJThreads) ext[b] = b == 0 ? (K)0 : b < P ? splitters[b - 1] : (K)~(K)0;
@@ -552,13 +500,17 @@ __global__ __launch_bounds__(kJThreads) void jpart_kernel(const K *__restrict__ 
 
     // rows r .. r + VEC - 1 of this lane (nrows of them exist)
     auto process = [&](int64_t r, int nrows, const K (&kraw)[VEC], const uint32_t (&vraw)[VEC], bool flush_now) {
-        uint32_t pending = 0;
+        uint32_t pending = 0, hot_rows = 0;
         K kk[VEC];
         uint32_t bk[VEC];
 #pragma unroll
         for (int j = 0; j < VEC; j++) {
             kk[j] = kraw[j] ^ bias;
-            if (j < nrows && kk[j] >= kmin && kk[j] <= kmax && !(any_hot && jhot_find<K>(s_hot, hot_empty, kk[j]) != ~0u)) pending |= 1u << j;
+            if (j < nrows && kk[j] >= kmin && kk[j] <= kmax) {
+                const uint32_t slot = any_hot ? jhot_find<K>(s_hot, hot_empty, kk[j]) : ~0u;
+                if (slot == ~0u) pending |= 1u << j;
+                else if (s_hp[slot] != kNoHot) hot_rows++;                 // a hot key: its rows take the other road (counted here when it has partners)
+            }
             // bucket = number of splitters <= key = the b with ext[b] <= key < ext[b + 1]
             const K key = kk[j];
             uint32_t g = __umulhi((uint32_t)((uint64_t)(key - kmin) >> gshift), gmul);
@@ -574,6 +526,10 @@ __global__ __launch_bounds__(kJThreads) void jpart_kernel(const K *__restrict__ 
                 for (int step = P / 2; step > 0; step >>= 1) if (ext[pos + step] <= key) pos += step;      // ext[i + 1] = splitter i
             }
             bk[j] = pos < (uint32_t)P ? pos : (uint32_t)(P - 1);
+        }
+        if (any_hot) {
+            for (int d = 32; d > 0; d >>= 1) hot_rows += __shfl_down(hot_rows, d, 64);
+            if ((tid & 63) == 0 && hot_rows) atomicAdd(&btotal[r / BATCH], hot_rows);      // (the rows of a wave lie in one batch)
         }
         bool again;
         do {
@@ -1327,21 +1283,21 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
     // the heavy hitters (see jhot_sample_kernel): one probe key in n / S sampled; the probe column in pieces of R rows, one per wave
     JHotSet<K> *hot = nullptr;
     unsigned long long *tkey = nullptr;
-    uint32_t *tcnt = nullptr, *ptotal = nullptr;
+    uint32_t *tcnt = nullptr, *btotal = nullptr;
     const bool no_hot = getenv("HARK_JOIN_NOHOT") != nullptr || getenv("HARK_JOIN_FULLSORT") != nullptr;      // A/B + tests
     uint32_t S = (uint32_t)std::min<int64_t>(kHotSampleMax, std::max<int64_t>(4096, n / 64)), cmin = 8;
     if (const char *e = getenv("HARK_JOIN_HOTMIN")) { const int c = atoi(e); if (c >= 2) cmin = (uint32_t)c; }   // tests: hot keys in small tables
     uint32_t tslots = 1;
     while (tslots < 4u * S) tslots <<= 1;
-    const uint32_t R = (uint32_t)std::max<int64_t>(4096, ((n + 4095) / 4096 + 1023) / 1024 * 1024), npieces = (uint32_t)((n + R - 1) / R);
+    const uint32_t nbatch = (uint32_t)((n + (int64_t)kJThreads * VEC - 1) / ((int64_t)kJThreads * VEC));      // the partition kernel's batches
     if (!rc) rc = hark_alloc(ctx, (void **)&hot, sizeof(JHotSet<K>));
     if (!rc) rc = hark_alloc(ctx, (void **)&tkey, 8 * (size_t)tslots);
     if (!rc) rc = hark_alloc(ctx, (void **)&tcnt, 4 * (size_t)tslots);
-    if (!rc) rc = hark_alloc(ctx, (void **)&ptotal, 4 * (size_t)npieces);
+    if (!rc) rc = hark_alloc(ctx, (void **)&btotal, 4 * (size_t)nbatch);
     auto cleanup = [&]() {
         hark_free(ctx, splitters); hark_free(ctx, bstart); hark_free(ctx, counts); hark_free(ctx, scount); hark_free(ctx, sbins);
         hark_free(ctx, info); hark_free(ctx, slabs); hark_free(ctx, surv); hark_free(ctx, srec); hark_free(ctx, scoarse);
-        hark_free(ctx, hot); hark_free(ctx, tkey); hark_free(ctx, tcnt); hark_free(ctx, ptotal);
+        hark_free(ctx, hot); hark_free(ctx, tkey); hark_free(ctx, tcnt); hark_free(ctx, btotal);
     };
     if (rc == HARK_ENOMEM) {                                                     // no room for the partition workspace: the sort-merge path
         cleanup();                                                               // needs far less (used stays false)
@@ -1356,12 +1312,13 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
     if (!no_hot) {
         HIP_TRY_RC(ctx, rc, hipMemsetAsync(tkey, 0xFF, 8 * (size_t)tslots, st));
         HIP_TRY_RC(ctx, rc, hipMemsetAsync(tcnt, 0, 4 * (size_t)tslots, st));
+        HIP_TRY_RC(ctx, rc, hipMemsetAsync(btotal, 0, 4 * (size_t)nbatch, st));
         HARK_LAUNCH_RC(ctx, rc, jhot_sample_kernel<K><<<(S + 255) / 256, 256, 0, st>>>(lcol, n, bias, S, tkey, tcnt, tslots - 1u, cmin, hot));
         HARK_LAUNCH_RC(ctx, rc, jhot_select_kernel<K><<<1, 1024, 0, st>>>(tkey, tcnt, cmin, rkeys, s, hot));
     }
     HARK_LAUNCH_RC(ctx, rc, jsplit_kernel<K><<<(P + 256) / 256, 256, 0, st>>>(rkeys, s, P, splitters, bstart));
     if (rc) { cleanup(); return rc; }
-    const size_t lds_part = sizeof(E) * (size_t)P * Q + sizeof(K) * (P + 2) + 8 * (size_t)P + 16 + sizeof(K) * (size_t)kHotSlots;
+    const size_t lds_part = sizeof(E) * (size_t)P * Q + sizeof(K) * (P + 2) + 8 * (size_t)P + 16 + (sizeof(K) + 2) * (size_t)kHotSlots;
     const bool plain_loads = getenv("HARK_JOIN_PLAIN_LOADS") != nullptr;        // tests: the compiler-counted twin of the partition kernel
     hipError_t he = plain_loads ? hipFuncSetAttribute(reinterpret_cast<const void *>(&jpart_kernel<K, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part)
                                 : hipFuncSetAttribute(reinterpret_cast<const void *>(&jpart_kernel<K, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part);
@@ -1381,13 +1338,11 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
     if (const char *e = getenv("HARK_JOIN_STAGE")) { const int c = atoi(e); if (c >= 1 && c < stage_cap) stage_cap = c; }   // tests: many sub-rounds per bucket
     if (he == hipSuccess) {
         // one stream-ordered chain, one host read at the end: partition -> bucket probe -> survivor total
-        if (plain_loads) HARK_LAUNCH_RC(ctx, rc, jpart_kernel<K, false><<<dim3((unsigned)nwg), dim3(kJThreads), lds_part, st>>>(lcol, n, bias, splitters, rkeys, s, slabs, counts, cap, period, err, carry ? lval : nullptr, hot));
-        else HARK_LAUNCH_RC(ctx, rc, jpart_kernel<K, true><<<dim3((unsigned)nwg), dim3(kJThreads), lds_part, st>>>(lcol, n, bias, splitters, rkeys, s, slabs, counts, cap, period, err, carry ? lval : nullptr, hot));
+        if (plain_loads) HARK_LAUNCH_RC(ctx, rc, jpart_kernel<K, false><<<dim3((unsigned)nwg), dim3(kJThreads), lds_part, st>>>(lcol, n, bias, splitters, rkeys, s, slabs, counts, cap, period, err, carry ? lval : nullptr, hot, btotal));
+        else HARK_LAUNCH_RC(ctx, rc, jpart_kernel<K, true><<<dim3((unsigned)nwg), dim3(kJThreads), lds_part, st>>>(lcol, n, bias, splitters, rkeys, s, slabs, counts, cap, period, err, carry ? lval : nullptr, hot, btotal));
         HARK_LAUNCH_RC(ctx, rc, jbucket_kernel<K><<<dim3((unsigned)P), dim3(kJThreads), lds_bucket, st>>>(slabs, counts, cap, nwg, rkeys, bstart, chunk_cap, surv, region, scount, sbins, srec, scoarse, stage_cap, err, allow_trunc ? 1 : 0));
         HARK_LAUNCH_RC(ctx, rc, jsum_kernel<<<1, 1024, 0, st>>>(scount, P, total));
-        // the hot keys' rows, counted piece by piece (the kernels leave at once when there is no hot key)
-        HARK_LAUNCH_RC(ctx, rc, jhot_count_kernel<K><<<(npieces + 15) / 16, 1024, 0, st>>>(lcol, n, bias, hot, ptotal, npieces, R));
-        HARK_LAUNCH_RC(ctx, rc, jhot_finish_kernel<<<1, 1024, 0, st>>>(hot, ptotal, npieces, bstart, P, reinterpret_cast<unsigned long long *>(info + 3)));
+        HARK_LAUNCH_RC(ctx, rc, jhot_scan_kernel<<<1, 1024, 0, st>>>(hot, btotal, nbatch, reinterpret_cast<unsigned long long *>(info + 3)));   // (leaves at once without hot keys)
         HIP_TRY_RC(ctx, rc, hipMemcpyAsync(info + 2, flags, 8, hipMemcpyDeviceToDevice, st));   // the duplicate-keys flag rides along with the same host read
     }
     if (he != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: setting the dynamic LDS size of the partition / bucket kernel failed: %s", hipGetErrorString(he));
@@ -1410,6 +1365,13 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
         if (!rc && carry) rc = hark_alloc(ctx, (void **)&lv, 4 * (size_t)M);
         if (!rc && rranked) rc = hark_alloc(ctx, (void **)&rv, 4 * (size_t)M);
         bool mismatch = false;
+        uint32_t *hkey = nullptr, *hrow = nullptr;
+        if (!rc && mhot > 0) {                                                  // the hot rows in row order (and every key's number of them: the order kernel needs it)
+            rc = hark_alloc(ctx, (void **)&hkey, 4 * (size_t)mhot);
+            if (!rc) rc = hark_alloc(ctx, (void **)&hrow, 4 * (size_t)mhot);
+            HARK_LAUNCH_RC(ctx, rc, jhot_compact_kernel<K><<<(nbatch + 15) / 16, 1024, 0, st>>>(lcol, n, bias, hot, btotal, nbatch, hkey, hrow));
+            HARK_LAUNCH_RC(ctx, rc, jhot_finish_kernel<<<1, kHotMax, 0, st>>>(hot, bstart, P));
+        }
         for (int attempt = 0; attempt < 2 && !rc; attempt++) {
             const uint64_t *rk64 = reinterpret_cast<const uint64_t *>(rkeys);
             if (getenv("HARK_JOIN_FULLSORT")) {                                  // A/B + tests: plain compaction, radix sorts by the caller
@@ -1442,16 +1404,14 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
             if (!rc) rc = hark_alloc(ctx, (void **)&lrow, 4 * (size_t)M);
         }
         if (!rc && !mismatch && mhot > 0) {                                     // the hot keys' rows into the blocks the order kernel left free
-            uint32_t *hkey = nullptr, *hrow = nullptr, *skey = nullptr, *srow = nullptr;
-            rc = hark_alloc(ctx, (void **)&hkey, 4 * (size_t)mhot);
-            if (!rc) rc = hark_alloc(ctx, (void **)&hrow, 4 * (size_t)mhot);
-            HARK_LAUNCH_RC(ctx, rc, jhot_compact_kernel<K><<<(npieces + 15) / 16, 1024, 0, st>>>(lcol, n, bias, hot, ptotal, npieces, R, hkey, hrow));
+            uint32_t *skey = nullptr, *srow = nullptr;
             if (!rc) rc = k_sort_column(ctx, hkey, HARK_U32, mhot, false, hrow, &srow, &skey);       // by key, stable: one pass over a byte
             int64_t g = (mhot + 255) / 256;
             if (g > (int64_t)ctx->num_cu * 16) g = (int64_t)ctx->num_cu * 16;
             HARK_LAUNCH_RC(ctx, rc, jhot_place_kernel<<<dim3((unsigned)g), 256, 0, st>>>(hot, skey, srow, mhot, runlen, carry ? lval : nullptr, rranked, rank, lrow, cnt, lv, rv));
-            hark_free(ctx, hkey); hark_free(ctx, hrow); hark_free(ctx, skey); hark_free(ctx, srow);   // stream-ordered reuse
+            hark_free(ctx, skey); hark_free(ctx, srow);                          // stream-ordered reuse
         }
+        hark_free(ctx, hkey); hark_free(ctx, hrow);
         if (!rc && mismatch) {
             // a probe key shared its truncation with a build key it differs from (keys that cluster below the dropped bits): the
             // survivors hold rows that do not join.  Once more from the partition, with full keys in every round.
