@@ -51,6 +51,7 @@ constexpr int kJThreads = 1024;
 constexpr int kJErrOverflow = 100;
 constexpr int kJIdx = 2048;                               // entries of the bucket kernel's radix index over a round's keys
 constexpr int kMaxBins = 64;                             // survivor bins per bucket (fixed rank ranges, written by the bucket kernel, read by the order kernel)
+constexpr int kBinSlots = kMaxBins + 1;                  // ... their fill counts per bucket, and the overflow area's behind them
 constexpr size_t kJLdsBudget = 160 * 1024 - 512;          // one workgroup per CU owns (almost) all of its LDS
 
 struct JPair32 { uint32_t key, row; };                                    // 8 bytes: 16 per 128-byte line
@@ -73,7 +74,7 @@ constexpr int fine_of(int extra_words) { return extra_words == 0 ? kFine : extra
 // took two sub-rounds and the order kernel read its survivors four times instead of twice (2.66 GB against 1.4 GB by the
 // counters).  Both kernels derive the geometry from the same inputs.
 struct JBins {
-    int gs, nb; uint32_t gw, magic, cap;
+    int gs, nb; uint32_t gw, magic, cap, ov_at, ov_cap;                  // ov_*: the bucket's overflow area (entries that found their bin full)
     __device__ __forceinline__ uint32_t bin_of_group(uint32_t g) const { return gw == 1u ? g : __umulhi(g, magic); }   // g / gw, exact for g, gw < 2^16
 };
 __device__ __forceinline__ JBins jbins_of(uint32_t len, uint32_t nprobe, int stage_cap, size_t region)
@@ -87,7 +88,13 @@ __device__ __forceinline__ JBins jbins_of(uint32_t len, uint32_t nprobe, int sta
     g.gw = (ngroups + want - 1u) / want;
     g.nb = (int)((ngroups + g.gw - 1u) / g.gw);
     g.magic = g.gw == 1u ? 0u : 0xFFFFFFFFu / g.gw + 1u;
-    g.cap = (uint32_t)((region / (size_t)g.nb) & ~(size_t)15);
+    // Half of the region is dealt out to the bins, the other half takes the survivors that find their bin full, in the order
+    // they come (the order kernel reads them in every sub-round, filtered by rank).  A bucket's probe pairs fill at most half
+    // of the region (that is how the caller sizes it), so NO distribution of the hits over the ranks overflows anything: a bin
+    // crowded by a few frequent keys only costs the order kernel extra sweeps of that bucket's overflow.
+    g.ov_at = (uint32_t)((region / 2) & ~(size_t)15);
+    g.ov_cap = (uint32_t)(region - g.ov_at);
+    g.cap = (uint32_t)(((size_t)g.ov_at / (size_t)g.nb) & ~(size_t)15);
     return g;
 }
 
@@ -165,7 +172,7 @@ __global__ __launch_bounds__(256) void jcnt_kernel(const uint32_t *__restrict__ 
 // A foreign-key column is skewed: a few keys own a large share of the probe rows.  Sent through the partition they would
 // flood ONE bucket (its slabs and survivor bins are sized for an even share) and one rank of the order kernel.  They
 // never get there:
-//   1. jhot_sample_kernel reads one probe key in n / S (S <= 65536) and counts equal samples in a hash table;
+//   1. jhot_sample_kernel reads one probe key in n / S (S = n / 256, at most 262144) and counts equal samples in a hash table;
 //      jhot_select_kernel keeps the (at most kHotMax) keys sampled cmin times or more, looks up their ranks in the sorted
 //      build side and lays out an open-addressing set of them that fits the partition kernel's LDS;
 //   2. jpart_kernel drops the rows of a hot key (one LDS probe per row, nothing at all when the set is empty) and counts,
@@ -177,7 +184,7 @@ __global__ __launch_bounds__(256) void jcnt_kernel(const uint32_t *__restrict__ 
 //      row of the bucket moves back by the blocks before it) and reports where they start, and jhot_place_kernel copies
 //      the groups there.
 // One more pass over the probe keys, paid only when a hot key exists (the kernels leave at once when the set is empty).
-constexpr int kHotMax = 256, kHotSlots = 1024, kHotCand = 4096, kHotSampleMax = 65536;
+constexpr int kHotMax = 256, kHotSlots = 1024, kHotCand = 4096, kHotSampleMax = 262144;
 constexpr uint32_t kNoRank = 0xFFFFFFFFu;
 constexpr uint16_t kNoHot = 0xFFFFu;
 
@@ -209,24 +216,47 @@ template <typename K> __device__ __forceinline__ uint32_t jhot_find(const K *slo
     return slot;
 }
 
-// table: tkey[mask + 1] (all ones = free), tcnt[mask + 1]; mask + 1 >= 4 S, so a free slot is always found
+// table: tkey[mask + 1] (all ones = free), tcnt[mask + 1]; mask + 1 >= 4 S, so a free slot is always found.  A workgroup
+// counts its 1024 samples in LDS first and adds every distinct key once: the samples of a frequent key (one row in twenty is
+// 13000 of them) would otherwise queue up behind ONE word of the table.
 template <typename K>
-__global__ __launch_bounds__(256) void jhot_sample_kernel(const K *__restrict__ keys, int64_t n, K bias, uint32_t S, unsigned long long *__restrict__ tkey,
-                                                          uint32_t *__restrict__ tcnt, uint32_t mask, uint32_t cmin, JHotHead *__restrict__ hot)
+__global__ __launch_bounds__(1024) void jhot_sample_kernel(const K *__restrict__ keys, int64_t n, K bias, uint32_t S, unsigned long long *__restrict__ tkey,
+                                                           uint32_t *__restrict__ tcnt, uint32_t mask, uint32_t cmin, JHotHead *__restrict__ hot)
 {
-    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    if (t >= S) return;
-    const uint64_t stride = (uint64_t)n / S;                              // >= 1: S <= n
-    const uint64_t row = (uint64_t)t * stride + (uint64_t)((t * 0x9E3779B1u) >> 7) % stride;   // a fixed stride would lock onto periodic data
-    const unsigned long long k = (unsigned long long)(K)(keys[row] ^ bias);
-    if (k == ~0ull) return;                                               // (the free marker: such a key is never hot)
-    uint32_t slot = jhash((uint64_t)k) & mask;
-    for (;;) {
-        const unsigned long long old = atomicCAS(&tkey[slot], ~0ull, k);
-        if (old == ~0ull || old == k) break;
-        slot = (slot + 1u) & mask;
+    constexpr int LS = 2048;                                              // local slots: twice the samples
+    __shared__ unsigned long long s_key[LS];
+    __shared__ uint32_t s_cnt[LS];
+    const uint32_t t = blockIdx.x * 1024u + threadIdx.x;
+    for (int i = threadIdx.x; i < LS; i += 1024) { s_key[i] = ~0ull; s_cnt[i] = 0u; }
+    __syncthreads();
+    if (t < S) {
+        const uint64_t stride = (uint64_t)n / S;                          // >= 1: S <= n
+        const uint64_t row = (uint64_t)t * stride + (uint64_t)((t * 0x9E3779B1u) >> 7) % stride;   // a fixed stride would lock onto periodic data
+        const unsigned long long k = (unsigned long long)(K)(keys[row] ^ bias);
+        if (k != ~0ull) {                                                 // (the free marker: such a key is never hot)
+            uint32_t slot = jhash((uint64_t)k) >> 21;
+            for (;;) {
+                const unsigned long long old = atomicCAS(&s_key[slot], ~0ull, k);
+                if (old == ~0ull || old == k) break;
+                slot = (slot + 1u) & (uint32_t)(LS - 1);
+            }
+            atomicAdd(&s_cnt[slot], 1u);
+        }
     }
-    if (atomicAdd(&tcnt[slot], 1u) + 1u == cmin) { const uint32_t at = atomicAdd(&hot->ncand, 1u); if (at < (uint32_t)kHotCand) hot->cand[at] = slot; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < LS; i += 1024) {
+        const uint32_t c = s_cnt[i];
+        if (c == 0u) continue;
+        const unsigned long long k = s_key[i];
+        uint32_t slot = (jhash((uint64_t)k) ^ (uint32_t)k) & mask;
+        for (;;) {
+            const unsigned long long old = atomicCAS(&tkey[slot], ~0ull, k);
+            if (old == ~0ull || old == k) break;
+            slot = (slot + 1u) & mask;
+        }
+        const uint32_t before = atomicAdd(&tcnt[slot], c);
+        if (before < cmin && before + c >= cmin) { const uint32_t at = atomicAdd(&hot->ncand, 1u); if (at < (uint32_t)kHotCand) hot->cand[at] = slot; }
+    }
 }
 
 template <typename K>
@@ -631,7 +661,7 @@ __global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTrai
                                                             uint32_t cap, int nwg, const K *__restrict__ rkeys, const uint32_t *__restrict__ bstart,
                                                             int chunk_cap, uint2 *__restrict__ surv, size_t region /* survivor entries per bucket */,
                                                             uint32_t *__restrict__ scount /* [P] survivors of the bucket */,
-                                                            uint32_t *__restrict__ sbins /* [P][kMaxBins] survivors in every bin */,
+                                                            uint32_t *__restrict__ sbins /* [P][kBinSlots] survivors in every bin, in the overflow area */,
                                                             uint4 *__restrict__ srec /* 64-bit keys (16-byte entries): every survivor as ONE record (rank, left row, the entry's
                                                                                         fourth word, low word of the PROBE key -- a hit on a truncated build key is confirmed by the
                                                                                         order kernel, where the build keys are read in order) instead of `surv` */,
@@ -659,7 +689,7 @@ __global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTrai
     // of 64 candidates instead of 16.  (Neither this nor the skew above moved the kernel's time on BASELINE configs[3]'s
     // share -- the lookup is not what it waits for, profiles/r03_notes.md 5.1 -- but both take load off the LDS.)
     uint16_t *s_idx = reinterpret_cast<uint16_t *>(s_coarse + kCoarse);                 // [kJIdx + 1]
-    __shared__ uint32_t s_bincur[kMaxBins];                               // survivors in every bin so far
+    __shared__ uint32_t s_bincur[kBinSlots];                              // survivors in every bin so far; [kMaxBins]: in the overflow area
     __shared__ uint32_t s_np;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = kJThreads >> 6;
     K *qkey = qkey_all + wave * QCAP;
@@ -667,7 +697,7 @@ __global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTrai
     uint32_t *qval = qval_all + wave * QCAP;
     const uint32_t lo = bstart[b], hi = bstart[b + 1];
     for (int i = tid; i < kCoarse; i += kJThreads) s_coarse[i] = 0u;
-    if (tid < kMaxBins) s_bincur[tid] = 0u;
+    if (tid < kBinSlots) s_bincur[tid] = 0u;
     if (tid == 0) s_np = 0u;
     __syncthreads();
     {   // the bucket's probe pairs (sizes the bins)
@@ -755,16 +785,17 @@ __global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTrai
             if (match) {
                 const uint32_t r = base + pos - lo;
                 const uint32_t bin = bins.bin_of_group(r >> gs);
-                const uint32_t at = atomicAdd(&s_bincur[bin], 1u);
+                uint32_t at = atomicAdd(&s_bincur[bin], 1u);
+                size_t o = (size_t)bin * bincap + at;
+                if (at >= bincap) { at = atomicAdd(&s_bincur[kMaxBins], 1u); o = (size_t)bins.ov_at + at; if (at < bins.ov_cap) at = 0u; else at = bincap; }   // the bin is full: the overflow area
                 if (at < bincap) {
-                    const size_t o = (size_t)bin * bincap + at;
                     // one store per hit: a 16-byte record (three arrays of 8 + 4 + 4 bytes at first: a third of the kernel was its ~36
                     // short store segments per wave step, profiles/r04_notes.md 9; then a record + the rank alone for the order
                     // kernel's histogram sweep, which now keeps a sub-round's records in registers instead)
                     if (sizeof(E) == 16) st_hidden_b128(rout + o, uint4{base + pos, row, val, klow});
                     else st_hidden_b64(out + o, uint2{base + pos, row});
                     atomicAdd(&s_coarse[r >> gs], 1u);
-                } else bin_full = true;                                // probe keys crowd a few ranks: the caller takes another path
+                } else bin_full = true;                                // (cannot happen: the overflow area holds all of a bucket's probe pairs)
             }
         };
         // search `cnt` queued candidates (the last ones), one per lane: the lower bound in the index class's span
@@ -865,8 +896,8 @@ __global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTrai
     }
     if (bin_full) *err = kJErrOverflow;
     __syncthreads();
-    if (tid < kMaxBins) sbins[(size_t)b * kMaxBins + tid] = min(s_bincur[tid], bincap);
-    if (tid == 0) { uint32_t t = 0; for (int j = 0; j < bins.nb; j++) t += min(s_bincur[j], bincap); scount[b] = t; }
+    if (tid < kBinSlots) sbins[(size_t)b * kBinSlots + tid] = tid < kMaxBins ? min(s_bincur[tid], bincap) : min(s_bincur[kMaxBins], bins.ov_cap);
+    if (tid == 0) { uint32_t t = min(s_bincur[kMaxBins], bins.ov_cap); for (int j = 0; j < bins.nb; j++) t += min(s_bincur[j], bincap); scount[b] = t; }
     for (int i = tid; i < kCoarse; i += kJThreads) scoarse[(size_t)b * kCoarse + i] = s_coarse[i];
 }
 
@@ -925,7 +956,7 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
     uint32_t *coarse = fine + FINE + 1;                                        // [kCoarse + 1] counts, then exclusive prefix
     __shared__ unsigned long long s_dst;
     __shared__ uint32_t s_wave[kJThreads / 64];
-    __shared__ uint32_t s_bincnt[kMaxBins];
+    __shared__ uint32_t s_bincnt[kBinSlots];
     __shared__ uint32_t s_np;
     __shared__ int s_bad;
     __shared__ uint32_t s_h0, s_nh, s_nlong;
@@ -933,7 +964,7 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
     __shared__ uint2 s_long[kLongMax];                                       // runs of more than kTieMax rows in the stage (first, length)
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) { s_dst = 0ull; s_bad = 0; s_np = 0u; s_h0 = 0u; s_nh = 0u; s_nlong = 0u; }
-    if (tid < kMaxBins) s_bincnt[tid] = sbins[(size_t)b * kMaxBins + tid];
+    if (tid < kBinSlots) s_bincnt[tid] = sbins[(size_t)b * kBinSlots + tid];
     __syncthreads();
     const uint32_t Hp = hot->Hp;                                           // hot keys with partners: dense and ascending, so a bucket's are a range [h0, h0 + nh)
     if ((uint32_t)tid < Hp) {
@@ -999,6 +1030,7 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
     // the bins that hold the ranks of groups [g0, g1)
     auto sweep_bins = [&](uint32_t g0, uint32_t g1, auto &&f) {
         for (uint32_t j = bins.bin_of_group(g0); j <= bins.bin_of_group(g1 - 1u); j++) sweep((size_t)j * bins.cap, s_bincnt[j], f);
+        if (s_bincnt[kMaxBins]) sweep((size_t)bins.ov_at, s_bincnt[kMaxBins], f);      // the overflow area holds rows of any rank (f looks at the rank)
     };
     // block-wide exclusive scan helper over a[0, m): a contiguous segment per thread, waves chained through LDS;
     // returns the total
@@ -1029,10 +1061,13 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
     scan_excl(coarse, ngroups + 1);                                    // coarse[g] = survivors before group g; coarse[ngroups] = nb
     if (bad) {                                                         // bin after bin, as they are; the hot blocks behind them (the caller sorts everything)
         if ((uint32_t)tid < nh) hot->pdst[h0 + tid] = dst + nb + s_hcum[tid];
-        for (uint32_t j = 0; j < (uint32_t)bins.nb; j++) {
-            const unsigned long long o = dst + coarse[min(ngroups, j * bins.gw)];      // the survivors of the bins before bin j
-            for (uint32_t i = tid; i < s_bincnt[j]; i += kJThreads) {
-                const size_t at = (size_t)j * bins.cap + i;
+        uint32_t before = 0;                                          // the survivors of the bins before bin j (the overflow area last)
+        for (uint32_t j = 0; j <= (uint32_t)bins.nb; j++) {
+            const uint32_t cnt_j = j < (uint32_t)bins.nb ? s_bincnt[j] : s_bincnt[kMaxBins];
+            const unsigned long long o = dst + before;
+            before += cnt_j;
+            for (uint32_t i = tid; i < cnt_j; i += kJThreads) {
+                const size_t at = (j < (uint32_t)bins.nb ? (size_t)j * bins.cap : (size_t)bins.ov_at) + i;
                 const uint4 q = VERIFY ? srcr[at] : uint4{src[at].x, src[at].y, 0u, 0u};
                 const uint2 e = uint2{q.x, q.y};
                 if (rank) { rank[o + i] = e.x; lrow[o + i] = e.y; }    // (the general sort needs them: the host runs the kernel again with the arrays if it left them out)
@@ -1079,7 +1114,7 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
             const uint32_t jA = bins.bin_of_group(g0), jB = bins.bin_of_group(g1 - 1u);
             uint32_t in_bins = 0;
             for (uint32_t j = jA; j <= jB; j++) in_bins += s_bincnt[j];
-            const bool whole = g0 == jA * bins.gw && (g1 == ngroups || g1 == (jB + 1u) * bins.gw) && in_bins <= (uint32_t)(RPT * kJThreads);
+            const bool whole = g0 == jA * bins.gw && (g1 == ngroups || g1 == (jB + 1u) * bins.gw) && in_bins <= (uint32_t)(RPT * kJThreads) && s_bincnt[kMaxBins] == 0u;
             if (whole) {
                 uint2 e[RPT]; uint32_t v[RPT], kl[RPT];
 #pragma unroll
@@ -1211,7 +1246,7 @@ __global__ __launch_bounds__(256) void jcompact_kernel(const uint2 *__restrict__
                                                        const uint4 *__restrict__ srec /* 64-bit keys: the survivors as records (then `surv` is null) */, const uint64_t *__restrict__ rkeys64, int32_t *__restrict__ flags)
 {
     __shared__ unsigned long long s_dst;
-    __shared__ uint32_t s_np, s_off[kMaxBins + 1];
+    __shared__ uint32_t s_np, s_off[kMaxBins + 2];
     const int b = blockIdx.x;
     if (threadIdx.x == 0) { s_dst = 0ull; s_np = 0u; }
     __syncthreads();
@@ -1225,11 +1260,15 @@ __global__ __launch_bounds__(256) void jcompact_kernel(const uint2 *__restrict__
     if ((threadIdx.x & 63) == 0 && np) atomicAdd(&s_np, np);
     __syncthreads();
     const JBins bins = jbins_of(bstart[b + 1] - bstart[b], s_np, stage_cap, region);
-    if (threadIdx.x == 0) { uint32_t run = 0; for (int j = 0; j < bins.nb; j++) { s_off[j] = run; run += sbins[(size_t)b * kMaxBins + j]; } s_off[bins.nb] = run; }
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int j = 0; j < bins.nb; j++) { s_off[j] = run; run += sbins[(size_t)b * kBinSlots + j]; }
+        s_off[bins.nb] = run; s_off[bins.nb + 1] = run + sbins[(size_t)b * kBinSlots + kMaxBins];      // the overflow area behind the bins
+    }
     __syncthreads();
     const unsigned long long dst = s_dst;
-    for (int j = 0; j < bins.nb; j++) {
-        const size_t at0 = (size_t)b * region + (size_t)j * bins.cap;
+    for (int j = 0; j <= bins.nb; j++) {
+        const size_t at0 = (size_t)b * region + (j < bins.nb ? (size_t)j * bins.cap : (size_t)bins.ov_at);
         const uint32_t cnt = s_off[j + 1] - s_off[j];
         for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
             const uint4 q = srec ? srec[at0 + i] : uint4{surv[at0 + i].x, surv[at0 + i].y, 0u, 0u};
@@ -1266,14 +1305,14 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
     if (getenv("HARK_JOIN_NOTRUNC")) allow_trunc = false;
     *lval_out = nullptr; *rval_out = nullptr;
     const size_t sstride = (size_t)nwg * cap;                                    // probe slabs of a bucket
-    // survivor bins of a bucket: twice the room of all of its probe pairs, dealt out equally to its bins -- a bin overflows
-    // only when its ranks draw more than twice (every pair a hit) to four times (every second pair) their even share
+    // survivors of a bucket: twice the room of all of its probe pairs -- one half dealt out equally to its bins, the other half
+    // for the survivors that find their bin full (jbins_of)
     const size_t region = 2 * sstride;
     int rc = hark_alloc(ctx, (void **)&splitters, sizeof(K) * P);
     if (!rc) rc = hark_alloc(ctx, (void **)&bstart, 4 * (size_t)(P + 1));
     if (!rc) rc = hark_alloc(ctx, (void **)&counts, 4 * (size_t)P * nwg);
     if (!rc) rc = hark_alloc(ctx, (void **)&scount, 4 * (size_t)P);
-    if (!rc) rc = hark_alloc(ctx, (void **)&sbins, 4 * (size_t)P * kMaxBins);
+    if (!rc) rc = hark_alloc(ctx, (void **)&sbins, 4 * (size_t)P * kBinSlots);
     if (!rc) rc = hark_alloc(ctx, (void **)&info, 32);
     if (!rc) rc = hark_alloc(ctx, (void **)&slabs, sizeof(E) * (size_t)P * sstride);
     if (!rc && !verify) rc = hark_alloc(ctx, (void **)&surv, 8 * (size_t)P * region);          // 32-bit keys: (rank, left row)
@@ -1285,7 +1324,7 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
     unsigned long long *tkey = nullptr;
     uint32_t *tcnt = nullptr, *btotal = nullptr;
     const bool no_hot = getenv("HARK_JOIN_NOHOT") != nullptr || getenv("HARK_JOIN_FULLSORT") != nullptr;      // A/B + tests
-    uint32_t S = (uint32_t)std::min<int64_t>(kHotSampleMax, std::max<int64_t>(4096, n / 64)), cmin = 8;
+    uint32_t S = (uint32_t)std::min<int64_t>(kHotSampleMax, std::max<int64_t>(4096, n / 256)), cmin = 8;
     if (const char *e = getenv("HARK_JOIN_HOTMIN")) { const int c = atoi(e); if (c >= 2) cmin = (uint32_t)c; }   // tests: hot keys in small tables
     uint32_t tslots = 1;
     while (tslots < 4u * S) tslots <<= 1;
@@ -1313,7 +1352,7 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
         HIP_TRY_RC(ctx, rc, hipMemsetAsync(tkey, 0xFF, 8 * (size_t)tslots, st));
         HIP_TRY_RC(ctx, rc, hipMemsetAsync(tcnt, 0, 4 * (size_t)tslots, st));
         HIP_TRY_RC(ctx, rc, hipMemsetAsync(btotal, 0, 4 * (size_t)nbatch, st));
-        HARK_LAUNCH_RC(ctx, rc, jhot_sample_kernel<K><<<(S + 255) / 256, 256, 0, st>>>(lcol, n, bias, S, tkey, tcnt, tslots - 1u, cmin, hot));
+        HARK_LAUNCH_RC(ctx, rc, jhot_sample_kernel<K><<<(S + 1023) / 1024, 1024, 0, st>>>(lcol, n, bias, S, tkey, tcnt, tslots - 1u, cmin, hot));
         HARK_LAUNCH_RC(ctx, rc, jhot_select_kernel<K><<<1, 1024, 0, st>>>(tkey, tcnt, cmin, rkeys, s, hot));
     }
     HARK_LAUNCH_RC(ctx, rc, jsplit_kernel<K><<<(P + 256) / 256, 256, 0, st>>>(rkeys, s, P, splitters, bstart));

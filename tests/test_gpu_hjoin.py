@@ -393,7 +393,7 @@ for dt in (np.uint32, np.int64):
     first = rk.reshape(512, 200)[:, :5].reshape(-1)                              # the five smallest keys of every bucket
     lk = first[rng.integers(0, len(first), size=n)]                              # every probe row hits, all hits crowd a bucket's first ranks
     print(dt.__name__, "pairs", T._check(eng, lk, rk), eng.last_join_path())
-    assert eng.last_join_path() == "sort-merge", eng.last_join_path()           # the overflow was seen and the fallback taken
+    assert eng.last_join_path() == "partitioned", eng.last_join_path()          # the crowded bins spill into the bucket's overflow area
     even = rk[rng.integers(0, s, size=n)]                                        # the same build side probed evenly: the partitioned path
     print(dt.__name__, "pairs", T._check(eng, even, rk), eng.last_join_path())
     assert eng.last_join_path() == "partitioned", eng.last_join_path()
@@ -401,10 +401,10 @@ print("crowd ok")
 """
 
 
-def test_survivor_bin_overflow_falls_back():
+def test_survivor_bin_overflow_goes_to_the_overflow_area():
     """The bucket kernel deals survivors into bins of equal rank ranges with equal room; probe rows that all hit a bucket's
-    first few ranks overflow the first bin (HARK_JOIN_STAGE=16 makes the bins small enough at this size), the kernel reports
-    it and the join takes the sort-merge path: the reference's rows either way."""
+    first few ranks overflow the first bin (HARK_JOIN_STAGE=16 makes the bins small enough at this size): the rest goes to
+    the bucket's overflow area, which the order kernel reads in every sub-round -- the reference's rows either way."""
     env = dict(os.environ, HARK_JOIN_STAGE="16", HARK_JOIN_NOHOT="1")     # (the sample would take a part of these keys away)
     out = subprocess.run([sys.executable, "-c", _CROWD % (ROOT, os.path.join(ROOT, "tests"))], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0 and "crowd ok" in out.stdout, out.stdout + out.stderr
