@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void jcnt_kernel(const uint32_t *__restrict__ 
 // A foreign-key column is skewed: a few keys own a large share of the probe rows.  Sent through the partition they would
 // flood ONE bucket (its slabs and survivor bins are sized for an even share) and one rank of the order kernel.  They
 // never get there:
-//   1. jhot_sample_kernel reads one probe key in n / S (S = n / 256, at most 262144) and counts equal samples in a hash table;
+//   1. jhot_sample_kernel reads one probe key in n / S (S = n / 256, at most 131072) and counts equal samples in a hash table;
 //      jhot_select_kernel keeps the (at most kHotMax) keys sampled cmin times or more, looks up their ranks in the sorted
 //      build side and lays out an open-addressing set of them that fits the partition kernel's LDS;
 //   2. jpart_kernel drops the rows of a hot key (one LDS probe per row, nothing at all when the set is empty) and counts,
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void jcnt_kernel(const uint32_t *__restrict__ 
 //      row of the bucket moves back by the blocks before it) and reports where they start, and jhot_place_kernel copies
 //      the groups there.
 // One more pass over the probe keys, paid only when a hot key exists (the kernels leave at once when the set is empty).
-constexpr int kHotMax = 256, kHotSlots = 1024, kHotCand = 4096, kHotSampleMax = 262144;
+constexpr int kHotMax = 256, kHotSlots = 1024, kHotCand = 4096, kHotSampleMax = 131072;
 constexpr uint32_t kNoRank = 0xFFFFFFFFu;
 constexpr uint16_t kNoHot = 0xFFFFu;
 
@@ -216,7 +216,8 @@ template <typename K> __device__ __forceinline__ uint32_t jhot_find(const K *slo
     return slot;
 }
 
-// table: tkey[mask + 1] (all ones = free), tcnt[mask + 1]; mask + 1 >= 4 S, so a free slot is always found.  A workgroup
+// table: tkey[mask + 1] (key + 1; 0 = free: one memset clears everything the hot path owns), tcnt[mask + 1]; mask + 1 >= 4 S, so a
+// free slot is always found.  A workgroup
 // counts its 1024 samples in LDS first and adds every distinct key once: the samples of a frequent key (one row in twenty is
 // 13000 of them) would otherwise queue up behind ONE word of the table.
 template <typename K>
@@ -247,11 +248,11 @@ __global__ __launch_bounds__(1024) void jhot_sample_kernel(const K *__restrict__
     for (int i = threadIdx.x; i < LS; i += 1024) {
         const uint32_t c = s_cnt[i];
         if (c == 0u) continue;
-        const unsigned long long k = s_key[i];
+        const unsigned long long k = s_key[i], k1 = k + 1ull;             // (k is not all ones)
         uint32_t slot = (jhash((uint64_t)k) ^ (uint32_t)k) & mask;
         for (;;) {
-            const unsigned long long old = atomicCAS(&tkey[slot], ~0ull, k);
-            if (old == ~0ull || old == k) break;
+            const unsigned long long old = atomicCAS(&tkey[slot], 0ull, k1);
+            if (old == 0ull || old == k1) break;
             slot = (slot + 1u) & mask;
         }
         const uint32_t before = atomicAdd(&tcnt[slot], c);
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(1024) void jhot_select_kernel(const unsigned long l
     __syncthreads();
     for (uint32_t i = tid; i < nc; i += 1024) {
         const uint32_t slot = hot->cand[i];
-        if (tcnt[slot] >= thr) s_key[atomicAdd(&s_n, 1u)] = (K)tkey[slot];
+        if (tcnt[slot] >= thr) s_key[atomicAdd(&s_n, 1u)] = (K)(tkey[slot] - 1ull);
     }
     __syncthreads();
     const int H = (int)s_n;
@@ -1290,9 +1291,12 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
     *used = false;
     hipStream_t st = ctx->stream;
     const int nwg = ctx->num_cu;
-    // slab capacity: 1.5 x the uniform share + 4 lines, a multiple of the line
+    // slab capacity: twice the uniform share + 5 lines, a multiple of the line (1.5 x until round 6: a bucket that drew half as many
+    // rows again as the others -- a hundred neighbouring keys with a thousand rows each -- sent the whole join to the sort-merge path)
     const int64_t avg = (n + (int64_t)P * nwg - 1) / ((int64_t)P * nwg);
-    int64_t cap64 = (avg + avg / 2 + 5 * LINE + LINE - 1) / LINE * LINE;
+    int64_t slabx = 200;                                                         // per cent of the uniform share
+    if (const char *e = getenv("HARK_JOIN_SLABX")) { const int c = atoi(e); if (c >= 100 && c <= 1000) slabx = c; }   // A/B
+    int64_t cap64 = (avg * slabx / 100 + 5 * LINE + LINE - 1) / LINE * LINE;
     if (cap64 > 0x7FFFFFF0ll) return HARK_OK;
     const uint32_t cap = (uint32_t)cap64;
     K *splitters = nullptr; uint32_t *bstart = nullptr, *counts = nullptr, *scount = nullptr, *sbins = nullptr;
@@ -1324,19 +1328,25 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
     unsigned long long *tkey = nullptr;
     uint32_t *tcnt = nullptr, *btotal = nullptr;
     const bool no_hot = getenv("HARK_JOIN_NOHOT") != nullptr || getenv("HARK_JOIN_FULLSORT") != nullptr;      // A/B + tests
-    uint32_t S = (uint32_t)std::min<int64_t>(kHotSampleMax, std::max<int64_t>(4096, n / 256)), cmin = 8;
+    uint32_t S = (uint32_t)std::min<int64_t>(kHotSampleMax, std::max<int64_t>(4096, n / 256)), cmin = 5;
     if (const char *e = getenv("HARK_JOIN_HOTMIN")) { const int c = atoi(e); if (c >= 2) cmin = (uint32_t)c; }   // tests: hot keys in small tables
     uint32_t tslots = 1;
     while (tslots < 4u * S) tslots <<= 1;
     const uint32_t nbatch = (uint32_t)((n + (int64_t)kJThreads * VEC - 1) / ((int64_t)kJThreads * VEC));      // the partition kernel's batches
-    if (!rc) rc = hark_alloc(ctx, (void **)&hot, sizeof(JHotSet<K>));
-    if (!rc) rc = hark_alloc(ctx, (void **)&tkey, 8 * (size_t)tslots);
-    if (!rc) rc = hark_alloc(ctx, (void **)&tcnt, 4 * (size_t)tslots);
-    if (!rc) rc = hark_alloc(ctx, (void **)&btotal, 4 * (size_t)nbatch);
+    // one block, cleared by one memset: the sample table (keys, counts), the batches' counts, the set's head; the rest of the set behind
+    const size_t hot_clear = 12 * (size_t)tslots + (4 * (size_t)nbatch + 15) / 16 * 16;
+    unsigned char *hot_block = nullptr;
+    if (!rc) rc = hark_alloc(ctx, (void **)&hot_block, hot_clear + sizeof(JHotSet<K>));
+    if (!rc) {
+        tkey = reinterpret_cast<unsigned long long *>(hot_block);
+        tcnt = reinterpret_cast<uint32_t *>(hot_block + 8 * (size_t)tslots);
+        btotal = reinterpret_cast<uint32_t *>(hot_block + 12 * (size_t)tslots);
+        hot = reinterpret_cast<JHotSet<K> *>(hot_block + hot_clear);
+    }
     auto cleanup = [&]() {
         hark_free(ctx, splitters); hark_free(ctx, bstart); hark_free(ctx, counts); hark_free(ctx, scount); hark_free(ctx, sbins);
         hark_free(ctx, info); hark_free(ctx, slabs); hark_free(ctx, surv); hark_free(ctx, srec); hark_free(ctx, scoarse);
-        hark_free(ctx, hot); hark_free(ctx, tkey); hark_free(ctx, tcnt); hark_free(ctx, btotal);
+        hark_free(ctx, hot_block);
     };
     if (rc == HARK_ENOMEM) {                                                     // no room for the partition workspace: the sort-merge path
         cleanup();                                                               // needs far less (used stays false)
@@ -1347,11 +1357,9 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
     if (hipMemsetAsync(info, 0, 32, st) != hipSuccess) { cleanup(); return hark_fail(ctx, HARK_EHIP, "join: workspace memset failed"); }
     int32_t *err = reinterpret_cast<int32_t *>(info + 1);
     unsigned long long *total = reinterpret_cast<unsigned long long *>(info);
-    HIP_TRY_RC(ctx, rc, hipMemsetAsync(hot, 0, sizeof(JHotHead), st));             // no hot keys, no candidates
-    if (!no_hot) {
-        HIP_TRY_RC(ctx, rc, hipMemsetAsync(tkey, 0xFF, 8 * (size_t)tslots, st));
-        HIP_TRY_RC(ctx, rc, hipMemsetAsync(tcnt, 0, 4 * (size_t)tslots, st));
-        HIP_TRY_RC(ctx, rc, hipMemsetAsync(btotal, 0, 4 * (size_t)nbatch, st));
+    if (no_hot) HIP_TRY_RC(ctx, rc, hipMemsetAsync(hot, 0, sizeof(JHotHead), st));   // no hot keys, no candidates
+    else {
+        HIP_TRY_RC(ctx, rc, hipMemsetAsync(hot_block, 0, hot_clear + sizeof(JHotHead), st));
         HARK_LAUNCH_RC(ctx, rc, jhot_sample_kernel<K><<<(S + 1023) / 1024, 1024, 0, st>>>(lcol, n, bias, S, tkey, tcnt, tslots - 1u, cmin, hot));
         HARK_LAUNCH_RC(ctx, rc, jhot_select_kernel<K><<<1, 1024, 0, st>>>(tkey, tcnt, cmin, rkeys, s, hot));
     }
