@@ -179,7 +179,9 @@ struct hark_fgb_plan {
     double *acc_sum = nullptr; // [G]
     unsigned long long *acc_cnt = nullptr; // [G]
     unsigned long long *acc_min = nullptr, *acc_max = nullptr;   // [G] order words of the statistics pass (allocated on first use)
-    int32_t *err = nullptr;    // device sticky error word
+    int32_t *err = nullptr;    // device: [0] sticky error word, [1] the producers' batch counter, [2..3] pairs partitioned so far (u64, never reset)
+    int64_t rows_fed = 0, rows_seen = 0, pairs_seen = 0;   // rows handed to the partition path / ... at the last error check / pairs at that check
+    int64_t sel_pct = -1;      // share of the rows that survived the predicate between the last two checks (-1: not known): picks the geometry
 };
 
 int k_gen_columns(hark_context *ctx, uint64_t seed, int64_t first_row, int64_t n, uint32_t G,

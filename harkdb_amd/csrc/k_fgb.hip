@@ -817,9 +817,11 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
         process(idA, pA, kA, vA, true);
     }
     // ---- final flush: what is left (< kLine pairs per bucket) goes out as one partial line
+    uint32_t my_pairs = 0;                                              // pairs this workgroup partitioned: the host learns the predicate's selectivity from the sum
     for (int b = tid; b < P; b += kPartThreads) {
         const uint32_t w = s_w[b];
         const int l = (int)(w & 0xFFFFu), head = (int)(w >> 16);
+        my_pairs += (uint32_t)(s_lcur[b] * ((C6 || C8 || K2) ? kU : kLine) + l);
         if (C6) {                                                       // l < kU: the last sweep took every complete unit
             unsigned char *dst = slab6 + (size_t)b * ((size_t)nwg * ((size_t)cap * 8)) + (size_t)s_lcur[b] * kUnitBytes;
             for (int j = 0; j < l; j++) {
@@ -856,6 +858,10 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
     }
     if (bad) *err = HARK_EBOUNDS;
     if (overflow) *err = kErrOverflow;
+    if (!HASH) {
+        for (int d = 32; d > 0; d >>= 1) my_pairs += __shfl_down(my_pairs, d, 64);
+        if ((tid & 63) == 0 && my_pairs) atomicAdd(reinterpret_cast<unsigned long long *>(err + 2), (unsigned long long)my_pairs);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -2077,7 +2083,7 @@ static int plan_prepare_partition(hark_context *ctx, hark_fgb_plan *pl)
     // producer rings hold one 8-byte LDS word per pair (FMT 3) -- when 128 buckets of <= 8192 keys cover G
     size_t bytes = (size_t)pl->P * (size_t)pl->nwg * (size_t)cap * sizeof(uint2);
     pl->shift8 = pl->P8 = pl->cap8 = 0;
-    if (pl->pairfmt == 3) {
+    if (pl->pairfmt == 3 || pl->pairfmt == 0) {
         int s8 = shift;
         while ((((pl->G - 1) >> s8) + 1) > kMaxBuckets8e) s8++;
         if (((int64_t)12 << s8) <= kAggTableBudget) {
@@ -2155,10 +2161,16 @@ int k_fgb_dense_f32(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cm
     }
     // algo 3: partition + per-bucket LDS aggregation, chunked
     HARK_TRY(plan_prepare_partition(ctx, pl));
-    // geometry: pairfmt = 3 asks for one-word ring entries in <= 128 buckets (G <= 2^20); measured over six slab
-    // allocations each, it is no faster than the split rings in 256 buckets (2.57-2.69 against 2.46-2.63 ms per 1e9 rows,
-    // profiles/r03_notes.md), so it is not the default.  COUNT-only keeps its keys-only format
-    const bool use8 = v != nullptr && pl->P8 > 0 && pl->pairfmt == 3;
+    // geometry: one-word ring entries in <= 128 buckets (pairfmt = 3) are no faster than the split rings in 256 buckets at the
+    // headline's selectivity (2.57-2.69 against 2.46-2.63 ms per 1e9 rows, profiles/r03_notes.md) -- but when (nearly) every row
+    // survives they are: 32 arrivals per ring and batch instead of 16, rings that hold two units, a sweep of 128 rings every
+    // second batch instead of 256 every batch (producer 2.92 -> 2.65 ms per 1e9 rows without a predicate,
+    // profiles/r06_nofilter_knobs.txt).  So: no predicate at all (BASELINE configs[2] as written, every reference
+    // query_groupby), or a predicate that let >= 75 % of the rows through the last time this plan was checked.
+    // COUNT-only keeps its keys-only format
+    const bool crowded = p == nullptr || pl->sel_pct >= 75;
+    const bool use8 = v != nullptr && pl->P8 > 0 && (pl->pairfmt == 3 || (pl->pairfmt == 0 && crowded && !getenv("HARK_FGB_NO_CROWDED")));
+    pl->rows_fed += n;
     const int P = (int)(use8 ? pl->P8 : pl->P), shift = (int)(use8 ? pl->shift8 : pl->shift), nwg = (int)pl->nwg;
     const uint32_t cap = (uint32_t)(use8 ? pl->cap8 : pl->cap);
     const size_t lds_agg = (size_t)12 << shift;
@@ -2231,8 +2243,13 @@ int k_fgb_dense_f32(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cm
 static int fgb_check_err(hark_context *ctx, hark_fgb_plan *pl)
 {
     int32_t *e = reinterpret_cast<int32_t *>(ctx->h_pin);
-    HIP_TRY(ctx, hipMemcpyAsync(e, pl->err, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(e, pl->err, 16, hipMemcpyDeviceToHost, ctx->stream));   // the error word and the pairs partitioned so far
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    {   // the predicate's selectivity since the last check (the next run picks its geometry by it)
+        const int64_t pairs = (int64_t)(((uint64_t)(uint32_t)e[3] << 32) | (uint32_t)e[2]), rows = pl->rows_fed - pl->rows_seen;
+        if (rows > 0) pl->sel_pct = (pairs - pl->pairs_seen) * 100 / rows;
+        pl->rows_seen = pl->rows_fed; pl->pairs_seen = pairs;
+    }
     if (*e != 0) {
         const int code = *e;
         HIP_TRY(ctx, hipMemsetAsync(pl->err, 0, sizeof(int32_t), ctx->stream));
