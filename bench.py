@@ -537,6 +537,38 @@ WORKLOADS = {"sparse_five": w_sparse_five, "c1": w_c1, "c2": w_c2, "refgb": w_re
              "sort20": lambda *a: w_sort(*a, bits=20), "sort32": lambda *a: w_sort(*a, bits=31), "sort64": lambda *a: w_sort(*a, bits=64)}
 
 
+def reference_csv_latency(reps=300):
+    """configs[0]: `select col1, col3` / `select col1, max(col3) ... group by col1` on tests/golden/data.csv through the Python
+    surface, one launch + one synchronisation each (harkdb_amd/csrc/k_small.hip); the oracle's entries timed on the same rows."""
+    from harkdb_amd import FutharkContext
+    from oracle import oracle as ora
+    fc = FutharkContext()
+    data = os.path.join(ROOT, "tests", "golden", "data.csv")
+    fc.create_table("game_1", data)
+    db = np.loadtxt(data, delimiter=",", skiprows=1, dtype=np.int64)
+    res = {}
+    for name, stmt, cpu in (("query_sel", "select col1, col3 from game_1", lambda: ora.query_sel(db, [0, 2])),
+                            ("query_groupby", "select col1,  max(col3) from game_1 group by col1", lambda: ora.query_groupby(db, 0, [0, 2], [0, 3]))):
+        got = fc.sql(stmt)
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter(); fc.sql(stmt); ts.append(time.perf_counter() - t0)
+        ts.sort()
+        want = cpu()
+        tc = []
+        for _ in range(reps):
+            t0 = time.perf_counter(); cpu(); tc.append(time.perf_counter() - t0)
+        tc.sort()
+        res[name] = {"ms": ts[len(ts) // 2] * 1e3, "us_median": ts[len(ts) // 2] * 1e6, "us_min": ts[0] * 1e6, "statement": stmt, "rows": int(db.shape[0]),
+                     "equals_cpu_port": bool(np.array_equal(np.asarray(got).astype(np.int64), np.asarray(want).astype(np.int64))),
+                     "path": fc.FutEnv.last_groupby_path() if name == "query_groupby" else "small (one launch)",
+                     "cpu_baseline": {"value": tc[len(tc) // 2] * 1e6, "unit": "us per statement (median)", "cores": 1, "kind": "port",
+                                      "sample": "the same 7 rows: oracle/hark_oracle.c ora_" + name + " through its ctypes wrapper"}}
+    res["note"] = ("wall clock through FutharkContext.sql(): cached plan, ONE kernel launch, ONE stream synchronisation, the result matrix "
+                   "written by the kernel into a pinned host block; launch-latency bound, no roofline applies")
+    return res
+
+
 def extra_configs(torch, eng, dev, a, sink, out):
     """The other BASELINE configs on one GPU (or one GPU's share of them) and the small-G single-pass path.
     Outside the timed region, in the configs child; every number HIP-event timed on the launch stream, 3 warm-ups, median
@@ -585,6 +617,16 @@ def extra_configs(torch, eng, dev, a, sink, out):
                                 bytes_model="read k, v (8 B/row) + 16 B per group; the partition adds 6 B written + 6 B read per row (20 B/row moved)")
     plan.free()
     del so, co
+    sink()
+
+    # ---- BASELINE configs[0]: the reference's own two statements on its 7-row data.csv (README.md:42, test.py:7), end to end
+    #      through FutharkContext.sql() -- wall clock, median of 300 -- with the CPU restatement of the same entries on the same
+    #      seven rows beside it (the sequential-C path this build replaces needs microseconds there: the launch + one
+    #      synchronisation of the small-table path are what is left to compare)
+    try:
+        out["C0_reference_csv"] = reference_csv_latency()
+    except Exception as e:
+        out["C0_reference_csv"] = {"error": repr(e)}
     sink()
 
     # ---- the headline statement at small G (single-pass LDS path while 12 B x G fits a workgroup's LDS)
@@ -1061,9 +1103,33 @@ def main():
 
     state = {"out": None, "printed": False}
 
+    def summarise(line):
+        """LAST key of the line: {config: [ms, fraction of the HBM peak]} for the headline and every entry of `configs` -- the driver keeps
+        the tail of stdout, and the configs that sit at the front of the object (C3_no_filter, G16 / G4096 / G13000, the sweeps) were
+        cut off there.  Nothing is printed behind it."""
+        summ = {"headline": [round(line["ms_per_step"], 3), round(line.get("roofline", {}).get("frac", 0.0) or 0.0, 4)]}
+
+        def walk(prefix, d, depth):
+            for name, e in d.items():
+                if not isinstance(e, dict):
+                    continue
+                if isinstance(e.get("ms"), (int, float)):
+                    f = e.get("frac_of_peak")
+                    summ[prefix + name] = [round(e["ms"], 3), round(f, 4) if isinstance(f, (int, float)) else None]
+                elif depth < 2:
+                    walk(prefix + name + ".", e, depth + 1)
+        if isinstance(line.get("configs"), dict):
+            walk("", line["configs"], 0)
+        line.pop("summary", None)
+        line["summary"] = summ
+
     def emit():
         if rank == 0 and state["out"] is not None and not state["printed"]:
             state["printed"] = True
+            try:
+                summarise(state["out"])
+            except Exception as e:
+                state["out"]["summary"] = {"error": repr(e)}
             for _ in range(20):                                   # the watchdog thread may serialise while the main thread adds keys
                 try:
                     text = json.dumps(state["out"])

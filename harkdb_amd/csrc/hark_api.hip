@@ -507,6 +507,7 @@ int hark_result_free(hark_context *ctx, hark_result *r)
     hark_device_guard guard__(ctx);
     if (!r) return HARK_OK;
     for (auto &c : r->cols) if (c.owned && c.data) hark_free(ctx, c.data);
+    hark_result_host_release(ctx, r);
     delete r;
     return HARK_OK;
 }

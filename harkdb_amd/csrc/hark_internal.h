@@ -92,7 +92,16 @@ struct hark_table {
 struct hark_result {
     int64_t n = 0;
     std::vector<hark_column> cols;
+    // the small-table paths (k_small.hip) deliver the row-major matrix of ALL columns in a pinned host block as well (a block of
+    // hark_host_alloc): hark_result_matrix_pinned hands it over instead of launching anything; freed with the result otherwise
+    void *host_matrix = nullptr;
+    int64_t host_rows = 0, host_cols = 0;
 };
+static inline void hark_result_host_release(hark_context *ctx, hark_result *r) { if (r && r->host_matrix) { hark_host_free(ctx, r->host_matrix); r->host_matrix = nullptr; } }
+// k_small.hip: tables of a few rows in one launch and one synchronisation
+bool k_small_fits(const hark_table *db, int64_t result_cols);
+int k_small_query_sel(hark_context *ctx, const hark_table *db, const int32_t *cols, int64_t k, hark_result *res);
+int k_small_query_groupby(hark_context *ctx, const hark_table *db, const int32_t *cols, const int32_t *ops, int64_t s, hark_result *res, int64_t *G_out);
 
 static inline size_t hark_dtype_size(int dtype) { return dtype == HARK_I64 ? 8 : 4; }
 

@@ -364,6 +364,7 @@ int grid_for(hark_context *ctx, int64_t n)
 void result_release(hark_context *ctx, hark_result *r)
 {
     for (auto &c : r->cols) if (c.owned && c.data) hark_free(ctx, c.data);
+    hark_result_host_release(ctx, r);
     delete r;
 }
 
@@ -538,6 +539,19 @@ int hark_entry_query_groupby(hark_context *ctx, hark_result **out, const hark_ta
         const int t = j < nt ? t_cols[j] : 4;
         const int op = t == 1 ? OP_PROD : t == 2 ? OP_SUM : t == 3 ? OP_MAX : OP_MIN;
         aggs.push_back(AggSpec{s_cols[j], op, ACC_U64, HARK_U32, 0, 0});
+    }
+    if (k_small_fits(db, ns + 1)) {                       // a few rows: one launch, one synchronisation (k_small.hip)
+        int32_t cols[33], ops[33];
+        cols[0] = g_col; ops[0] = 0;
+        for (int64_t j = 0; j < ns; j++) { cols[j + 1] = s_cols[j]; ops[j + 1] = j < nt ? t_cols[j] : 4; }
+        int64_t Gs = 0;
+        int rcs = k_small_query_groupby(ctx, db, cols, ops, ns + 1, res, &Gs);
+        ctx->last_groupby_path = HARK_PATH_SMALL;
+        if (!rcs && nt < ns && Gs < db->n)                // (as below: merge would index t_cols out of bounds)
+            rcs = hark_fail(ctx, HARK_EBOUNDS, "query_groupby: %lld aggregate opcodes for %lld select columns", (long long)nt, (long long)ns);
+        if (rcs) { result_release(ctx, res); return rcs; }
+        *out = res;
+        return HARK_OK;
     }
     // u32 view of every column: groupby.fut:51 types the whole table as u32
     hark_table view = *db;

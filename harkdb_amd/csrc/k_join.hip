@@ -247,6 +247,7 @@ int grid_for(hark_context *ctx, int64_t n)
 void result_release(hark_context *ctx, hark_result *r)
 {
     for (auto &c : r->cols) if (c.owned && c.data) hark_free(ctx, c.data);
+    hark_result_host_release(ctx, r);
     delete r;
 }
 

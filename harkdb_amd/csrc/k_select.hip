@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void interleave_kernel(ColSet cs, int64_t n, i
 // gives: i32 / u32 / f32 as they are, mixed integers -> i64, anything with f32 and an integer or an i64 -> f64).
 // One thread per output ROW: a row's m elements are stored side by side (m is small: a select list).
 struct MatCols { const void *src[kMaxCols]; int32_t dtype[kMaxCols]; int32_t ncols; };
-__global__ __launch_bounds__(256) void matrix_kernel(MatCols mc, int64_t n, int out_dtype, void *__restrict__ out)
+__global__ __launch_bounds__(256) void matrix_kernel(MatCols mc, int64_t n, int out_dtype, void *__restrict__ out, int row_stride /* elements of a matrix row (the launch's columns are a stripe of it) */)
 {
     const int m = mc.ncols;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -316,15 +316,15 @@ __global__ __launch_bounds__(256) void matrix_kernel(MatCols mc, int64_t n, int 
                 else if (d == HARK_I32) x = (double)static_cast<const int32_t *>(mc.src[j])[r];
                 else if (d == HARK_U32) x = (double)static_cast<const uint32_t *>(mc.src[j])[r];
                 else x = (double)static_cast<const int64_t *>(mc.src[j])[r];
-                static_cast<double *>(out)[r * m + j] = x;
+                static_cast<double *>(out)[r * row_stride + j] = x;
             } else if (out_dtype == HARK_I64) {
                 int64_t x;
                 if (d == HARK_I32) x = (int64_t)static_cast<const int32_t *>(mc.src[j])[r];
                 else if (d == HARK_U32) x = (int64_t)static_cast<const uint32_t *>(mc.src[j])[r];
                 else x = static_cast<const int64_t *>(mc.src[j])[r];
-                static_cast<int64_t *>(out)[r * m + j] = x;
+                static_cast<int64_t *>(out)[r * row_stride + j] = x;
             } else {                                                // i32 / u32 / f32 matrices of columns of that very type: bit copies
-                static_cast<uint32_t *>(out)[r * m + j] = static_cast<const uint32_t *>(mc.src[j])[r];
+                static_cast<uint32_t *>(out)[r * row_stride + j] = static_cast<const uint32_t *>(mc.src[j])[r];
             }
         }
     }
@@ -333,6 +333,7 @@ __global__ __launch_bounds__(256) void matrix_kernel(MatCols mc, int64_t n, int 
 void result_release(hark_context *ctx, hark_result *r)
 {
     for (auto &c : r->cols) if (c.owned && c.data) hark_free(ctx, c.data);
+    hark_result_host_release(ctx, r);
     delete r;
 }
 
@@ -577,7 +578,10 @@ int hark_entry_query_sel(hark_context *ctx, hark_result **out, const hark_table 
         for (int64_t j = 0; j < k; j++) { res->cols[j].dtype = HARK_I32; res->cols[j].data = nullptr; res->cols[j].owned = false; }
         *out = res; return HARK_OK;
     }
-    int rc = k_gather_columns(ctx, db, cols, k, res);
+    bool all32 = true;
+    for (int64_t j = 0; j < k; j++) all32 = all32 && hark_dtype_size(db->cols[cols[j]].dtype) == 4;
+    int rc = (all32 && k_small_fits(db, k)) ? k_small_query_sel(ctx, db, cols, k, res)      // a few rows: one launch, one synchronisation (k_small.hip)
+                                              : k_gather_columns(ctx, db, cols, k, res);
     if (rc) { result_release(ctx, res); return rc; }
     *out = res;
     return HARK_OK;
@@ -797,28 +801,37 @@ int hark_result_matrix_pinned(hark_context *ctx, const hark_result *r, const int
     if (!ctx || !r || !host_block || k < 0 || (k && !cols) || rows < 0) return HARK_EARG;
     *host_block = nullptr;
     if (rows > r->n) rows = r->n;
-    if (k > kMaxCols) return hark_fail(ctx, HARK_EUNSUPPORTED, "result_matrix: at most %d columns", kMaxCols);
     if (out_dtype < HARK_I32 || out_dtype > HARK_F64) return hark_fail(ctx, HARK_EARG, "result_matrix: bad element type %d", out_dtype);
-    MatCols mc{}; mc.ncols = (int)k;
+    if (r->host_matrix && rows == r->host_rows && k == r->host_cols && k == (int64_t)r->cols.size() && (out_dtype == HARK_I32 || out_dtype == HARK_U32)) {
+        bool as_is = true;                                       // the small-table paths wrote this very matrix already (k_small.hip)
+        for (int64_t j = 0; j < k; j++) as_is = as_is && cols[j] == (int32_t)j && (r->cols[j].dtype == HARK_I32 || r->cols[j].dtype == HARK_U32);
+        if (as_is) { *host_block = r->host_matrix; const_cast<hark_result *>(r)->host_matrix = nullptr; return HARK_OK; }
+    }
     for (int64_t j = 0; j < k; j++) {
         if (cols[j] < 0 || cols[j] >= (int64_t)r->cols.size()) return hark_fail(ctx, HARK_EBOUNDS, "result_matrix: column %d of %zu", cols[j], r->cols.size());
         const int d = r->cols[cols[j]].dtype;
         const bool ok = out_dtype == HARK_F64 || (out_dtype == HARK_I64 && d != HARK_F32) || d == out_dtype ||
                         ((out_dtype == HARK_I32 || out_dtype == HARK_U32) && (d == HARK_I32 || d == HARK_U32));   // the reference's u32 view of i32 columns: bit copies
         if (!ok) return hark_fail(ctx, HARK_EARG, "result_matrix: a column of type %d does not convert to a matrix of type %d", d, out_dtype);
-        mc.src[j] = r->cols[cols[j]].data; mc.dtype[j] = d;
     }
     const size_t esz = (out_dtype == HARK_I64 || out_dtype == HARK_F64) ? 8 : 4;
     const size_t bytes = (size_t)rows * (size_t)k * esz;
     if (!bytes) return HARK_OK;
+    // a matrix of more than 2 GiB is not pinned (nor doubled in device scratch): the caller takes typed columns and interleaves on the host
+    if (bytes > ((size_t)2 << 30)) return hark_fail(ctx, HARK_EUNSUPPORTED, "result_matrix: %zu bytes exceed the pinned-block limit", bytes);
     void *tmp = nullptr, *blk = nullptr;
     HARK_TRY(hark_alloc(ctx, &tmp, bytes));
     int rc = hark_host_alloc(ctx, &blk, bytes);
     if (!rc) {
         int64_t blocks = (rows + 255) / 256;
         if (blocks > (int64_t)ctx->num_cu * 16) blocks = (int64_t)ctx->num_cu * 16;
-        matrix_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(mc, rows, out_dtype, tmp);
-        hipError_t e = hipGetLastError();
+        hipError_t e = hipSuccess;
+        for (int64_t c0 = 0; c0 < k && e == hipSuccess; c0 += kMaxCols) {      // kMaxCols columns per launch, each launch its own stripe of the rows
+            MatCols mc{}; mc.ncols = (int)std::min<int64_t>(kMaxCols, k - c0);
+            for (int j = 0; j < mc.ncols; j++) { mc.src[j] = r->cols[cols[c0 + j]].data; mc.dtype[j] = r->cols[cols[c0 + j]].dtype; }
+            matrix_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(mc, rows, out_dtype, static_cast<char *>(tmp) + (size_t)c0 * esz, (int)k);
+            e = hipGetLastError();
+        }
         if (e == hipSuccess) e = hipMemcpyAsync(blk, tmp, bytes, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "result_matrix: %s", hipGetErrorString(e));

@@ -144,11 +144,23 @@ class Result:
                 np.dtype(np.int64): _ffi.I64, np.dtype(np.float64): _ffi.F64}[dtype]
         if rows == 0 or not cols:
             return np.empty((rows, len(cols)), dtype=dtype)
-        blk = C.c_void_p()
-        arr = (C.c_int32 * len(cols))(*cols)
-        self._eng._chk(self._eng.lib.hark_result_matrix_pinned(self._eng.ctx, self._h, arr, len(cols), rows, code, C.byref(blk)))
-        block = PinnedBlock(self._eng, blk.value, rows * len(cols) * dtype.itemsize)
-        return block.array(0, rows * len(cols), dtype).reshape(rows, len(cols))
+        if rows * len(cols) * dtype.itemsize <= PINNED_UPTO:
+            blk = C.c_void_p()
+            arr = (C.c_int32 * len(cols))(*cols)
+            rc = self._eng.lib.hark_result_matrix_pinned(self._eng.ctx, self._h, arr, len(cols), rows, code, C.byref(blk))
+            if rc == 0:
+                block = PinnedBlock(self._eng, blk.value, rows * len(cols) * dtype.itemsize)
+                return block.array(0, rows * len(cols), dtype).reshape(rows, len(cols))
+            if rc not in (_ffi.ENOMEM, _ffi.EUNSUPPORTED):
+                self._eng._chk(rc)
+        # a matrix too large to pin (or to double in device scratch): typed columns through pageable memory, interleaved here
+        out = np.empty((rows, len(cols)), dtype=dtype)
+        have = {}
+        for j, c in enumerate(cols):
+            if c not in have:
+                have[c] = self.column(c, rows)
+            out[:, j] = have[c].view(dtype) if have[c].dtype.itemsize == dtype.itemsize and dtype.kind in "iu" and have[c].dtype.kind in "iu" else have[c]
+        return out
 
     def device_ptr(self, j):
         return self._eng.lib.hark_result_column_device(self._h, j)
@@ -315,7 +327,7 @@ class Engine:
 
     def last_groupby_path(self):
         """'dense' | 'hash' | 'sort' | None: the path that served the last GROUP BY entry (diagnostic, include/hark.h)."""
-        return {1: "dense", 2: "hash", 3: "sort"}.get(self.lib.hark_context_last_groupby_path(self.ctx))
+        return {1: "dense", 2: "hash", 3: "sort", 4: "small"}.get(self.lib.hark_context_last_groupby_path(self.ctx))
 
     def last_groupby_passes(self):
         """Passes over the table's rows of the last dense-path filter_groupby (diagnostic, include/hark.h)."""

@@ -187,8 +187,17 @@ def test_bench_extra_configs_at_a_small_scale():
                           "--cpu-rows", "0", "--configs", "1", "--config-scale", "0.02", "--pmc", "0"],
                          capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stdout + out.stderr
-    cfg = json.loads(out.stdout.strip().splitlines()[-1])["configs"]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    cfg = line["configs"]
     assert "error" not in cfg, cfg
+    # the LAST key of the line is the tail-safe summary ({config: [ms, fraction of peak]}): whoever keeps only the end of stdout
+    # still sees the configs that sit at the front of `configs`
+    assert list(line)[-1] == "summary" and out.stdout.rstrip().endswith("}}")
+    tail = out.stdout.rstrip()[-4096:]
+    for name in ("headline", "C3_no_filter", "G16", "G4096", "G13000", "SWEEP_selectivity_x_groups.G2^20_sel1.0", "REF_join_u32", "C4_join_share", "C0_reference_csv.query_groupby"):
+        assert '"' + name + '"' in tail, name
+        assert line["summary"][name][0] > 0
+    assert len(json.dumps(line["summary"])) <= 2048
     assert cfg["C3_no_filter"]["count_checksum"] is True and cfg["C3_no_filter"]["sum_checksum"] is True
     assert "G2^20_sel1.0" in cfg["SWEEP_selectivity_x_groups"] and cfg["SWEEP_selectivity_x_groups"]["G2^20_sel1.0"]["count_checksum"] is True
     for name in ("C3_no_filter", "G16", "G4096", "G13000", "SWEEP_selectivity_x_groups", "SPARSE_groupby", "SPARSE_five_aggregates", "C2_filter_proj", "C1_projection", "REF_query_groupby_dense",
