@@ -121,8 +121,8 @@ class FutharkContext:
             raise Exception("sql_result supports `select <key>, <aggregates> from t [where] group by <key>`")
         dev = self.tables[ir["table_name"]]._device
         aggs = [i for i in ir["items"][1:]]
-        where = ir.get("where", [])
-        res = self.FutEnv.filter_groupby(dev, [(c, cmp, v) for c, cmp, v in where], ir["g_col"], [(f, 0 if c is None else c) for f, c in aggs])
+        where = self._lower_where(dev, ir.get("where", []))
+        res = self.FutEnv.filter_groupby(dev, where, ir["g_col"], [(f, 0 if c is None else c) for f, c in aggs])
         schema = self.tables[ir["table_name"]].get_schema()
         return [schema[ir["g_col"]]] + [f"{f}({'*' if c is None else schema[c]})" for f, c in aggs], res
 
@@ -207,10 +207,17 @@ class FutharkContext:
         returns (table-like, column map)."""
         eng = self.FutEnv
         proj = sorted(set(need_cols))
-        res = eng.filter_sel(dev, [(c, cmp, v) for c, cmp, v in where], cols=proj, want_row_index=False)
+        res = eng.filter_sel(dev, self._lower_where(dev, where), cols=proj, want_row_index=False)
         cur = eng.table_from_device(res.shape[0], [res.device_ptr(j) for j in range(len(proj))],
                                     [res.dtype(j) for j in range(len(proj))], keepalive=res)
         return cur, {c: j for j, c in enumerate(proj)}
+
+    def _lower_where(self, dev, where):
+        """The IR's conjuncts as the engine takes them: plain comparisons as they are; a predicate tree (OR / NOT / IN /
+        parentheses / two columns) is evaluated into a survivor bitmask over dev's rows HERE and becomes the conjunct
+        (None, "mask", buffer) -- one more entry of the AND-list every entry point understands (include/hark.h,
+        hark_op_predicate_tree)."""
+        return [(None, "mask", self.FutEnv.predicate_tree_mask(dev, v)) if cmp == "tree" else (c, cmp, v) for c, cmp, v in where]
 
     def _select_extended(self, dev, ir):
         res = self._select_result(dev, ir)
@@ -296,8 +303,8 @@ class FutharkContext:
         where = ir.get("where", [])
         need = set(g_cols) | {c for _, c in aggs if c is not None}
         cur, cmap = dev, {c: c for c in range(dev.shape[1])}
-        preds = [(c, cmp, v) for c, cmp, v in where]           # the whole AND-list goes to the entry: no intermediate table
-        need |= {c for c, _, _ in preds}
+        preds = self._lower_where(dev, where)                  # the whole AND-list goes to the entry: no intermediate table
+        need |= {c for c, _, _ in preds if c is not None}
         decode = None
         if multi:
             # several keys -> one composite key column on the device (ascending composite = lexicographic key tuple)
@@ -310,7 +317,7 @@ class FutharkContext:
             decode = (mins, spans, [dev.dtype(c) for c in g_cols])
         else:
             gkey = cmap[g_col]
-        dev_preds = [(cmap[c], cmp, v) for c, cmp, v in preds]
+        dev_preds = [(None if c is None else cmap[c], cmp, v) for c, cmp, v in preds]   # (a mask conjunct has no column: its rows are dev's, and so are the view's)
         spec_of = lambda a: (a[0], 0 if a[1] is None else cmap[a[1]])
 
         def having_order(res, having, order, limit=None):

@@ -718,7 +718,7 @@ int try_dense(hark_context *ctx, const hark_table *db, const PredList &preds,
     // three columns, 5e8 rows: the mask does NOT pay for a single f32 predicate even with three passes, 6.4 ms against
     // 5.6 ms -- the producer is bound by instruction issue, not by the 4 B/row of the predicate column.)
     const hark_table *src = db;
-    const bool direct = preds.n == 1 && db->cols[preds.cols[0]].dtype == HARK_F32;
+    const bool direct = preds.n == 1 && preds.cmps[0] != HARK_CMP_MASK && db->cols[preds.cols[0]].dtype == HARK_F32;
     uint8_t *mask = nullptr;
     if (preds.n >= 1 && !direct) HARK_TRY(k_predicate_bitmask(ctx, db, preds.n, preds.cols, preds.cmps, preds.consts, &mask));
     const float *p = direct ? static_cast<const float *>(db->cols[preds.cols[0]].data) : reinterpret_cast<const float *>(mask);
@@ -895,7 +895,7 @@ int try_hash(hark_context *ctx, const hark_table *db, const PredList &preds,
     // anything else as a survivor bitmask evaluated once (0.125 B/row) -- only surviving rows are partitioned
     const hark_table *src = db;
     const int32_t g2 = g_col;
-    const bool direct = preds.n == 1 && db->cols[preds.cols[0]].dtype == HARK_F32;
+    const bool direct = preds.n == 1 && preds.cmps[0] != HARK_CMP_MASK && db->cols[preds.cols[0]].dtype == HARK_F32;
     uint8_t *mask = nullptr;
     if (preds.n >= 1 && !direct) HARK_TRY(k_predicate_bitmask(ctx, db, preds.n, preds.cols, preds.cmps, preds.consts, &mask));
     hark_row_pred pred{nullptr, 0, 0.0f};
@@ -1219,7 +1219,7 @@ extern "C" int hark_entry_filter_groupby_subset(hark_context *ctx, hark_result *
     for (int64_t j = 0; j < n_aggs; j++) { res->cols[(size_t)j].dtype = plan[j].out_dtype; res->cols[(size_t)j].data = nullptr; res->cols[(size_t)j].owned = n_keys > 0; }
     if (n_keys == 0) { *out = res; return HARK_OK; }
     // WHERE exactly as try_dense: one f32 predicate rides along, anything else becomes a survivor bitmask
-    const bool direct = n_preds == 1 && db->cols[where_cols[0]].dtype == HARK_F32;
+    const bool direct = n_preds == 1 && cmps[0] != HARK_CMP_MASK && db->cols[where_cols[0]].dtype == HARK_F32;
     uint8_t *mask = nullptr;
     uint32_t *want = nullptr; su64 *gacc = nullptr, *gcnt = nullptr;
     hipStream_t st = ctx->stream;
@@ -1274,7 +1274,7 @@ extern "C" int hark_entry_filter_groupby_and(hark_context *ctx, hark_result **ou
     if (n_preds < 0 || n_preds > 16 || (n_preds && (!where_cols || !cmps || !constants))) return hark_fail(ctx, HARK_EARG, "filter_groupby: 0..16 predicates");
     for (int64_t j = 0; j < n_preds; j++) {
         if (where_cols[j] < 0 || where_cols[j] >= db->m) return hark_fail(ctx, HARK_EBOUNDS, "filter_groupby: where column %d out of bounds", where_cols[j]);
-        if (!constants[j] || cmps[j] < HARK_CMP_GT || cmps[j] > HARK_CMP_NE) return hark_fail(ctx, HARK_EARG, "filter_groupby: bad predicate");
+        if (!constants[j] || cmps[j] < HARK_CMP_GT || cmps[j] > HARK_CMP_MASK) return hark_fail(ctx, HARK_EARG, "filter_groupby: bad predicate");
     }
     const PredList preds{n_preds, where_cols, cmps, constants};
     for (int64_t j = 0; j < n_aggs; j++) {
@@ -1346,7 +1346,7 @@ extern "C" int hark_entry_filter_groupby_topk(hark_context *ctx, hark_result **o
     if (n_preds < 0 || n_preds > 16 || (n_preds && (!where_cols || !cmps || !constants))) return hark_fail(ctx, HARK_EARG, "filter_groupby_topk: 0..16 predicates");
     for (int64_t j = 0; j < n_preds; j++) {
         if (where_cols[j] < 0 || where_cols[j] >= db->m) return hark_fail(ctx, HARK_EBOUNDS, "filter_groupby_topk: where column %d out of bounds", where_cols[j]);
-        if (!constants[j] || cmps[j] < HARK_CMP_GT || cmps[j] > HARK_CMP_NE) return hark_fail(ctx, HARK_EARG, "filter_groupby_topk: bad predicate");
+        if (!constants[j] || cmps[j] < HARK_CMP_GT || cmps[j] > HARK_CMP_MASK) return hark_fail(ctx, HARK_EARG, "filter_groupby_topk: bad predicate");
     }
     for (int64_t j = 0; j < n_aggs; j++) {
         if (agg_ops[j] < HARK_AGG_KEY || agg_ops[j] > HARK_AGG_AVG) return hark_fail(ctx, HARK_EARG, "filter_groupby_topk: unknown aggregate opcode %d", agg_ops[j]);
@@ -1406,7 +1406,7 @@ extern "C" int hark_entry_filter_groupby_slots(hark_context *ctx, hark_result **
     if (n_preds < 0 || n_preds > 16 || (n_preds && (!where_cols || !cmps || !constants))) return hark_fail(ctx, HARK_EARG, "filter_groupby_slots: 0..16 predicates");
     for (int64_t j = 0; j < n_preds; j++) {
         if (where_cols[j] < 0 || where_cols[j] >= db->m) return hark_fail(ctx, HARK_EBOUNDS, "filter_groupby_slots: where column %d out of bounds", where_cols[j]);
-        if (!constants[j] || cmps[j] < HARK_CMP_GT || cmps[j] > HARK_CMP_NE) return hark_fail(ctx, HARK_EARG, "filter_groupby_slots: bad predicate");
+        if (!constants[j] || cmps[j] < HARK_CMP_GT || cmps[j] > HARK_CMP_MASK) return hark_fail(ctx, HARK_EARG, "filter_groupby_slots: bad predicate");
     }
     for (int64_t j = 0; j < n_aggs; j++) {
         if (agg_ops[j] < HARK_AGG_KEY || agg_ops[j] > HARK_AGG_AVG || agg_ops[j] == HARK_AGG_AVG || agg_ops[j] == HARK_AGG_PROD)

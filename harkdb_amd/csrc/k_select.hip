@@ -154,6 +154,30 @@ __global__ __launch_bounds__(kThreads) void filter_and_kernel(const T *__restric
     if (threadIdx.x == 0) counts[tile] = s_cnt;
 }
 
+// A conjunct that IS a linear survivor bitmask already (HARK_CMP_MASK: a predicate tree evaluated by hark_op_predicate_tree):
+// the thread's 16 bits are four nibbles of it (r is a multiple of 4).  FIRST: it starts the tile masks, else it is ANDed in.
+template <bool FIRST>
+__global__ __launch_bounds__(kThreads) void filter_linear_mask_kernel(const uint8_t *__restrict__ lin, int64_t n, uint16_t *__restrict__ masks, uint32_t *__restrict__ counts)
+{
+    __shared__ uint32_t s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    const int64_t tile = blockIdx.x;
+    uint32_t mask = 0;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const int64_t r = tile * kTile + ((int64_t)g * kThreads + threadIdx.x) * 4;
+        if (r < n) mask |= ((uint32_t)(lin[r >> 3] >> (r & 4)) & 15u) << (g * 4);          // (bits past row n - 1 are zero in the linear mask)
+    }
+    if (!FIRST) mask &= masks[tile * kThreads + threadIdx.x];
+    masks[tile * kThreads + threadIdx.x] = (uint16_t)mask;
+    uint32_t cnt = __popc(mask);
+    for (int d = 32; d > 0; d >>= 1) cnt += __shfl_down(cnt, d, 64);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&s_cnt, cnt);
+    __syncthreads();
+    if (threadIdx.x == 0) counts[tile] = s_cnt;
+}
+
 // Linear survivor bitmask for the fused group-by kernels (k_fgb.hip, HARK_CMP_MASK): bit (r & 7) of byte (r >> 3).
 // A thread owns 8 consecutive rows = one byte; with `and_in` the byte is ANDed into what an earlier conjunct wrote.
 template <typename T>
@@ -181,6 +205,41 @@ __global__ __launch_bounds__(256) void pred_bitmask_kernel(const T *__restrict__
             }
         }
         mask[b] = (uint8_t)(m & old);
+    }
+}
+
+// a leaf that compares two columns of one dtype
+template <typename T>
+__global__ __launch_bounds__(256) void pred_bitmask_cols_kernel(const T *__restrict__ a, const T *__restrict__ b, int64_t n, int op, uint8_t *__restrict__ mask)
+{
+    const int64_t nbytes = (n + 7) / 8, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t y = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; y < nbytes; y += stride) {
+        const int64_t r = y * 8;
+        uint32_t m = 0;
+        for (int j = 0; j < 8; j++) if (r + j < n) m |= (uint32_t)cmp_val<T>(op, a[r + j], b[r + j]) << j;
+        mask[y] = (uint8_t)m;
+    }
+}
+
+// masks as wholes: dst = a AND b / a OR b / NOT a (rows past n - 1 stay zero).  16 bytes per thread (the blocks have the slack).
+__global__ __launch_bounds__(256) void mask_combine_kernel(uint8_t *__restrict__ dst, const uint8_t *__restrict__ a, const uint8_t *__restrict__ b, int64_t n, int op)
+{
+    const int64_t nbytes = (n + 7) / 8, nq = (nbytes + 15) / 16, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += stride) {
+        const uint4 x = reinterpret_cast<const uint4 *>(a)[q];
+        uint4 y = op == 2 ? uint4{0u, 0u, 0u, 0u} : reinterpret_cast<const uint4 *>(b)[q];
+        if (op == 0) y = uint4{x.x & y.x, x.y & y.y, x.z & y.z, x.w & y.w};
+        else if (op == 1) y = uint4{x.x | y.x, x.y | y.y, x.z | y.z, x.w | y.w};
+        else y = uint4{~x.x, ~x.y, ~x.z, ~x.w};
+        if (op == 2 && (q + 1) * 16 * 8 > n) {                         // the last words of a complement: no survivors past the table's end
+            uint32_t w[4] = {y.x, y.y, y.z, y.w};
+            for (int k = 0; k < 4; k++) {
+                const int64_t first = (q * 16 + k * 4) * 8;            // the row of this word's bit 0
+                if (first >= n) w[k] = 0u; else if (first + 32 > n) w[k] &= (1u << (n - first)) - 1u;
+            }
+            y = uint4{w[0], w[1], w[2], w[3]};
+        }
+        reinterpret_cast<uint4 *>(dst)[q] = y;
     }
 }
 
@@ -355,6 +414,7 @@ int check_cols(hark_context *ctx, const hark_table *db, const int32_t *cols, int
 // stable sort's: ascending 64-bit order key (the sort word of the column, inverted for DESC), then ascending row.
 constexpr int kTopK = 64, kTopThreads = 256, kTopRows = 16;                  // rows per thread and slice pass
 struct TopPreds { const void *col[8]; int dtype[8], cmp[8]; Const64 c[8]; int n; };
+constexpr int kTopMaskType = 1000;                                           // "dtype" of a predicate that is a linear survivor bitmask (HARK_CMP_MASK)
 
 __device__ __forceinline__ uint64_t order_key(const void *col, int dtype, int64_t r, uint64_t inv)
 {
@@ -398,6 +458,10 @@ __global__ __launch_bounds__(kTopThreads) void topk_slice_kernel(TopPreds pr, co
     for (int q = 0; q < pr.n; q++) {
         uint32_t ok = 0;
         switch (pr.dtype[q]) {
+        case kTopMaskType:
+#pragma unroll
+            for (int j = 0; j < kTopRows; j++) { const int64_t r = row_of(j); ok |= (uint32_t)((static_cast<const uint8_t *>(pr.col[q])[r >> 3] >> (r & 7)) & 1u) << j; }
+            break;
         case HARK_F32:
 #pragma unroll
             for (int j = 0; j < kTopRows; j++) ok |= (cmp_val<float>(pr.cmp[q], static_cast<const float *>(pr.col[q])[row_of(j)], pr.c[q].f) ? 1u : 0u) << j;
@@ -483,6 +547,12 @@ __global__ __launch_bounds__(1024) void topk_merge_kernel(const TopPair *__restr
 
 } // namespace
 
+__global__ __launch_bounds__(256) void mask_and_bytes_kernel(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, int64_t nbytes)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nbytes; i += stride) dst[i] &= src[i];
+}
+
 static Const64 read_const(int dtype, const void *constant)
 {
     Const64 c{}; c.i = 0;
@@ -508,11 +578,18 @@ int k_predicate_bitmask(hark_context *ctx, const hark_table *db, int64_t n_preds
     if (blocks > (int64_t)ctx->num_cu * 16) blocks = (int64_t)ctx->num_cu * 16;
     if (blocks < 1) blocks = 1;
     for (int64_t j = 0; j < n_preds; j++) {
+        const int and_in = j > 0;
+        dim3 grid((unsigned)blocks), block(256);
+        if (cmps[j] == HARK_CMP_MASK) {                                 // a conjunct that is a mask already (a predicate tree): constants[j] IS its device address
+            const uint8_t *lin = static_cast<const uint8_t *>(constants[j]);
+            if (!and_in) { if (hipMemcpyAsync(mask, lin, (size_t)((n + 7) / 8), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) { hark_free(ctx, mask); return hark_fail(ctx, HARK_EHIP, "predicate mask: copy failed"); } }
+            else mask_and_bytes_kernel<<<grid, block, 0, ctx->stream>>>(mask, lin, (n + 7) / 8);
+            if (hipGetLastError() != hipSuccess) { hark_free(ctx, mask); return hark_fail(ctx, HARK_EHIP, "predicate mask: launch failed"); }
+            continue;
+        }
         const int dt = db->cols[where_cols[j]].dtype;
         const void *col = db->cols[where_cols[j]].data;
         const Const64 c = read_const(dt, constants[j]);
-        const int and_in = j > 0;
-        dim3 grid((unsigned)blocks), block(256);
         switch (dt) {
         case HARK_F32: pred_bitmask_kernel<float><<<grid, block, 0, ctx->stream>>>(static_cast<const float *>(col), n, cmps[j], c, mask, and_in); break;
         case HARK_I32: pred_bitmask_kernel<int32_t><<<grid, block, 0, ctx->stream>>>(static_cast<const int32_t *>(col), n, cmps[j], c, mask, and_in); break;
@@ -594,7 +671,7 @@ int hark_op_predicate_bitmask(hark_context *ctx, const hark_table *db, int64_t n
     if (!ctx || !db || n_preds < 1 || n_preds > 16 || !where_cols || !cmps || !constants || (db->n && !mask_dev)) return HARK_EARG;
     HARK_TRY(check_cols(ctx, db, where_cols, n_preds, "predicate_bitmask"));
     for (int64_t j = 0; j < n_preds; j++)
-        if (!constants[j] || cmps[j] < HARK_CMP_GT || cmps[j] > HARK_CMP_NE) return hark_fail(ctx, HARK_EARG, "predicate_bitmask: bad predicate %lld", (long long)j);
+        if (!constants[j] || cmps[j] < HARK_CMP_GT || cmps[j] > HARK_CMP_MASK) return hark_fail(ctx, HARK_EARG, "predicate_bitmask: bad predicate %lld", (long long)j);
     if (db->n == 0) return HARK_OK;
     uint8_t *tmp = nullptr;
     HARK_TRY(k_predicate_bitmask(ctx, db, n_preds, where_cols, cmps, constants, &tmp));
@@ -602,6 +679,75 @@ int hark_op_predicate_bitmask(hark_context *ctx, const hark_table *db, int64_t n
     hark_free(ctx, tmp);                                   // stream-ordered reuse: the copy above is enqueued first
     if (e != hipSuccess) return hark_fail(ctx, HARK_EHIP, "predicate_bitmask: copy failed");
     return HARK_OK;
+}
+
+// A predicate TREE as a survivor bitmask: the nodes in postfix order, evaluated with a stack of masks.
+//   kind[i] = HARK_PRED_CONST: db[:, a[i]] <b[i]> *constants[i]      (b: HARK_CMP_GT .. HARK_CMP_NE; the constant read as the column's dtype)
+//             HARK_PRED_COLS : db[:, a[i]] <b[i] & 15> db[:, b[i] >> 4]   (two columns of ONE dtype)
+//             HARK_PRED_AND / HARK_PRED_OR: the two masks on top of the stack;  HARK_PRED_NOT: the one on top
+// One pass over a leaf's column(s) per leaf, 0.125 B/row per inner node.  The result ((n + 7) / 8 bytes at mask_dev, bits past row
+// n - 1 zero) is a conjunct like any other: cmp = HARK_CMP_MASK, the constant pointer = mask_dev (hark_entry_filter_sel_and,
+// hark_entry_filter_groupby*, hark_entry_topk, hark_op_predicate_bitmask).
+int hark_op_predicate_tree(hark_context *ctx, const hark_table *db, int64_t n_nodes, const int32_t *kind, const int32_t *a, const int32_t *b,
+                           const void *const *constants, uint8_t *mask_dev)
+{
+    hark_device_guard guard__(ctx);
+    if (!ctx || !db || n_nodes < 1 || n_nodes > 256 || !kind || !a || !b || !constants || (db->n && !mask_dev)) return HARK_EARG;
+    const int64_t n = db->n;
+    if (n == 0) return HARK_OK;
+    const size_t bytes = (size_t)((n + 7) / 8 + 16);
+    int64_t blocks = ((n + 7) / 8 + 255) / 256;
+    if (blocks > (int64_t)ctx->num_cu * 16) blocks = (int64_t)ctx->num_cu * 16;
+    if (blocks < 1) blocks = 1;
+    const dim3 grid((unsigned)blocks), block(256);
+    std::vector<uint8_t *> stack;
+    int rc = HARK_OK;
+    auto fail = [&](int code, const char *what) { if (!rc) rc = hark_fail(ctx, code, "predicate_tree: %s", what); };
+    for (int64_t i = 0; i < n_nodes && !rc; i++) {
+        if (kind[i] == HARK_PRED_CONST || kind[i] == HARK_PRED_COLS) {
+            const int ca = a[i], op = kind[i] == HARK_PRED_CONST ? b[i] : (b[i] & 15), cb = kind[i] == HARK_PRED_COLS ? (b[i] >> 4) : 0;
+            if (ca < 0 || ca >= db->m || cb < 0 || cb >= db->m) { fail(HARK_EBOUNDS, "column out of bounds"); break; }
+            if (op < HARK_CMP_GT || op > HARK_CMP_NE) { fail(HARK_EARG, "unknown comparison"); break; }
+            uint8_t *m = nullptr;
+            rc = hark_alloc(ctx, (void **)&m, bytes);
+            if (rc) break;
+            stack.push_back(m);
+            const int dt = db->cols[ca].dtype;
+            const void *col = db->cols[ca].data;
+            if (kind[i] == HARK_PRED_CONST) {
+                if (!constants[i]) { fail(HARK_EARG, "a leaf without its constant"); break; }
+                const Const64 c = read_const(dt, constants[i]);
+                switch (dt) {
+                case HARK_F32: pred_bitmask_kernel<float><<<grid, block, 0, ctx->stream>>>(static_cast<const float *>(col), n, op, c, m, 0); break;
+                case HARK_I32: pred_bitmask_kernel<int32_t><<<grid, block, 0, ctx->stream>>>(static_cast<const int32_t *>(col), n, op, c, m, 0); break;
+                case HARK_U32: pred_bitmask_kernel<uint32_t><<<grid, block, 0, ctx->stream>>>(static_cast<const uint32_t *>(col), n, op, c, m, 0); break;
+                default: pred_bitmask_kernel<int64_t><<<grid, block, 0, ctx->stream>>>(static_cast<const int64_t *>(col), n, op, c, m, 0); break;
+                }
+            } else {
+                if (db->cols[cb].dtype != dt) { fail(HARK_EUNSUPPORTED, "a comparison of two columns needs one dtype"); break; }
+                const void *col2 = db->cols[cb].data;
+                switch (dt) {
+                case HARK_F32: pred_bitmask_cols_kernel<float><<<grid, block, 0, ctx->stream>>>(static_cast<const float *>(col), static_cast<const float *>(col2), n, op, m); break;
+                case HARK_I32: pred_bitmask_cols_kernel<int32_t><<<grid, block, 0, ctx->stream>>>(static_cast<const int32_t *>(col), static_cast<const int32_t *>(col2), n, op, m); break;
+                case HARK_U32: pred_bitmask_cols_kernel<uint32_t><<<grid, block, 0, ctx->stream>>>(static_cast<const uint32_t *>(col), static_cast<const uint32_t *>(col2), n, op, m); break;
+                default: pred_bitmask_cols_kernel<int64_t><<<grid, block, 0, ctx->stream>>>(static_cast<const int64_t *>(col), static_cast<const int64_t *>(col2), n, op, m); break;
+                }
+            }
+        } else if (kind[i] == HARK_PRED_AND || kind[i] == HARK_PRED_OR) {
+            if (stack.size() < 2) { fail(HARK_EARG, "AND / OR with fewer than two masks on the stack"); break; }
+            uint8_t *y = stack.back(); stack.pop_back();
+            mask_combine_kernel<<<grid, block, 0, ctx->stream>>>(stack.back(), stack.back(), y, n, kind[i] == HARK_PRED_AND ? 0 : 1);
+            hark_free(ctx, y);                                        // stream-ordered reuse: the kernel above is enqueued first
+        } else if (kind[i] == HARK_PRED_NOT) {
+            if (stack.empty()) { fail(HARK_EARG, "NOT with an empty stack"); break; }
+            mask_combine_kernel<<<grid, block, 0, ctx->stream>>>(stack.back(), stack.back(), stack.back(), n, 2);
+        } else fail(HARK_EARG, "unknown node kind");
+        if (!rc && hipGetLastError() != hipSuccess) fail(HARK_EHIP, "launch failed");
+    }
+    if (!rc && stack.size() != 1) fail(HARK_EARG, "the nodes do not reduce to one mask");
+    if (!rc && hipMemcpyAsync(mask_dev, stack.back(), (size_t)((n + 7) / 8), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) fail(HARK_EHIP, "copy failed");
+    for (uint8_t *m : stack) hark_free(ctx, m);
+    return rc;
 }
 
 int hark_entry_filter_sel(hark_context *ctx, hark_result **out, const hark_table *db, int32_t where_col, int32_t cmp,
@@ -626,7 +772,8 @@ int hark_entry_topk(hark_context *ctx, hark_result **out, const hark_table *db, 
     HARK_TRY(check_cols(ctx, db, where_cols, n_preds, "topk(where)"));
     TopPreds pr{}; pr.n = (int)n_preds;
     for (int64_t j = 0; j < n_preds; j++) {
-        if (!constants[j] || cmps[j] < HARK_CMP_GT || cmps[j] > HARK_CMP_NE) return hark_fail(ctx, HARK_EARG, "topk: bad predicate %lld", (long long)j);
+        if (!constants[j] || cmps[j] < HARK_CMP_GT || cmps[j] > HARK_CMP_MASK) return hark_fail(ctx, HARK_EARG, "topk: bad predicate %lld", (long long)j);
+        if (cmps[j] == HARK_CMP_MASK) { pr.col[j] = constants[j]; pr.dtype[j] = kTopMaskType; pr.cmp[j] = cmps[j]; continue; }   // a linear survivor bitmask
         pr.col[j] = db->cols[where_cols[j]].data; pr.dtype[j] = db->cols[where_cols[j]].dtype; pr.cmp[j] = cmps[j];
         pr.c[j] = read_const(pr.dtype[j], constants[j]);
     }
@@ -685,7 +832,7 @@ int hark_entry_filter_sel_and(hark_context *ctx, hark_result **out, const hark_t
     HARK_TRY(check_cols(ctx, db, where_cols, n_preds, "filter_sel(where)"));
     for (int64_t j = 0; j < n_preds; j++) {
         if (!constants[j]) return HARK_EARG;
-        if (cmps[j] < HARK_CMP_GT || cmps[j] > HARK_CMP_NE) return hark_fail(ctx, HARK_EARG, "filter_sel: unknown comparison %d", cmps[j]);
+        if (cmps[j] < HARK_CMP_GT || cmps[j] > HARK_CMP_MASK) return hark_fail(ctx, HARK_EARG, "filter_sel: unknown comparison %d", cmps[j]);
     }
     if (k > kMaxCols) return hark_fail(ctx, HARK_EUNSUPPORTED, "filter_sel: at most %d projected columns", kMaxCols);
     const int64_t n = db->n;
@@ -714,6 +861,11 @@ int hark_entry_filter_sel_and(hark_context *ctx, hark_result **out, const hark_t
             hipStream_t st = ctx->stream;
             dim3 grid((unsigned)ntiles), block(kThreads);
             for (int64_t j = 0; j < n_preds; j++) {                     // conjunct 0 writes the masks, the others AND into them
+                if (cmps[j] == HARK_CMP_MASK) {                          // a linear survivor bitmask (a predicate tree): constants[j] is its device address
+                    if (j == 0) filter_linear_mask_kernel<true><<<grid, block, 0, st>>>(static_cast<const uint8_t *>(constants[j]), n, masks, counts);
+                    else filter_linear_mask_kernel<false><<<grid, block, 0, st>>>(static_cast<const uint8_t *>(constants[j]), n, masks, counts);
+                    continue;
+                }
                 const int wdt = db->cols[where_cols[j]].dtype;
                 const void *wc = db->cols[where_cols[j]].data;
                 const Const64 c = read_const(wdt, constants[j]);

@@ -138,7 +138,9 @@ int k_small_query_sel(hark_context *ctx, const hark_table *db, const int32_t *co
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) { hark_free(ctx, dev); hark_host_free(ctx, blk); return hark_launch_failed(ctx, e, "small_sel_kernel<<<", __FILE__, __LINE__); }
-    return small_finish(ctx, res, dev, blk, stride, db->n, k, HARK_I32);
+    rc = small_finish(ctx, res, dev, blk, stride, db->n, k, HARK_I32);
+    for (int64_t j = 0; j < k; j++) res->cols[j].dtype = db->cols[cols[j]].dtype;      // bit copies of 4-byte columns: i32 / u32 / f32 as they are
+    return rc;
 }
 
 // cols[0] = the key column, cols[1..s) the select columns; ops[j] = type_func opcode of column j (1 prod, 2 sum, 3 max, else min)

@@ -474,14 +474,68 @@ class Engine:
     def _predicates(self, table, where):
         """where = [(col, cmp, value), ...] -> ctypes arrays (columns, comparison opcodes, constant pointers) + keepalive.
         Every literal is normalised to its column's dtype first (normalise_predicate)."""
-        consts, cols, cmps = [], [], []
+        consts, cols, cmps, ptrs = [], [], [], []
         for col, cmp, value in where:
+            if cmp == "mask":                                      # a predicate tree evaluated already (predicate_tree_mask): value = the DeviceBuffer
+                consts.append(value); cols.append(0); cmps.append(_ffi.CMP["mask"]); ptrs.append(value.ptr)
+                continue
             cmp2, c = self._const(table, col, value, cmp)
             consts.append(c)
             cols.append(int(col))
             cmps.append(_ffi.CMP[cmp2])
+            ptrs.append(c.ctypes.data)
         n = len(where)
-        return ((C.c_int32 * n)(*cols), (C.c_int32 * n)(*cmps), (C.c_void_p * n)(*[c.ctypes.data for c in consts]), consts)
+        return ((C.c_int32 * n)(*cols), (C.c_int32 * n)(*cmps), (C.c_void_p * n)(*ptrs), consts)
+
+    def predicate_tree_mask(self, table, node):
+        """A WHERE tree -> survivor bitmask on the device (hark_op_predicate_tree), as a DeviceBuffer to pass on as the conjunct
+        (None, "mask", buffer).  node = ("and" | "or", [nodes]) | ("not", node) | ("cmp", col, cmp, number) |
+        ("cmpcol", col, cmp, col2) | ("in", col, [numbers]).  Literals are normalised to the column's dtype like every
+        predicate's (normalise_predicate); IN is the OR of its equalities."""
+        kinds, a, b, consts = [], [], [], []
+
+        def leaf(col, cmp, value):
+            cmp2, c = self._const(table, col, value, cmp)
+            kinds.append(0); a.append(int(col)); b.append(_ffi.CMP[cmp2]); consts.append(c)
+
+        def emit(nd):
+            tag = nd[0]
+            if tag in ("and", "or"):
+                kids = list(nd[1])
+                if not kids:
+                    raise _ffi.HarkError(_ffi.EARG, "predicate tree: empty " + tag)
+                emit(kids[0])
+                for k in kids[1:]:
+                    emit(k)
+                    kinds.append(2 if tag == "and" else 3); a.append(0); b.append(0); consts.append(None)
+            elif tag == "not":
+                emit(nd[1])
+                kinds.append(4); a.append(0); b.append(0); consts.append(None)
+            elif tag == "cmp":
+                leaf(nd[1], nd[2], nd[3])
+            elif tag == "cmpcol":
+                if np.dtype(table.dtype(nd[1])) != np.dtype(table.dtype(nd[3])):
+                    raise _ffi.HarkError(_ffi.EUNSUPPORTED, "a comparison of two columns needs columns of one dtype")
+                kinds.append(1); a.append(int(nd[1])); b.append(_ffi.CMP[_CANON.get(nd[2], nd[2])] | (int(nd[3]) << 4)); consts.append(None)
+            elif tag == "in":
+                vals = list(nd[2])
+                if not vals:
+                    raise _ffi.HarkError(_ffi.EARG, "IN with an empty list")
+                leaf(nd[1], "=", vals[0])
+                for v in vals[1:]:
+                    leaf(nd[1], "=", v)
+                    kinds.append(3); a.append(0); b.append(0); consts.append(None)
+            else:
+                raise _ffi.HarkError(_ffi.EARG, f"predicate tree: unknown node {tag!r}")
+
+        emit(node)
+        n = len(kinds)
+        rows = table.shape[0]
+        buf = DeviceBuffer(self, self.alloc((rows + 7) // 8 + 16))
+        if rows:
+            self._chk(self.lib.hark_op_predicate_tree(self.ctx, table._h, n, (C.c_int32 * n)(*kinds), (C.c_int32 * n)(*a), (C.c_int32 * n)(*b),
+                                                      (C.c_void_p * n)(*[None if c is None else c.ctypes.data for c in consts]), buf.ptr))
+        return buf
 
     def filter_sel(self, table, where_col, cmp=None, value=None, cols=(), want_row_index=True):
         """WHERE + projection.  `where_col` is a column index (with cmp, value) or an AND-list [(col, cmp, value), ...]:

@@ -28,9 +28,116 @@ def getIndex(elements, value):
 
 def _col(columns, name, table_name):
     idx = getIndex(columns, name)
+    if idx < 0 and isinstance(name, str) and name.startswith(table_name + "."):   # `t.col` in a one-table statement
+        idx = getIndex(columns, name[len(table_name) + 1:])
     if idx < 0:
         raise Exception(f"{name} is not in the schema of table {table_name}")     # parse.py:54
     return idx
+
+
+def _is_simple(cond):
+    """`column <op> number`: what the reference-shaped AND-lists are made of."""
+    (op, args), = cond.items()
+    return op in _CMP_SQL and isinstance(args[0], str) and isinstance(args[1], (int, float))
+
+
+def _unqualify(js_obj, table_name, columns):
+    """`t.col` -> `col` in the select list, GROUP BY, HAVING and ORDER BY of a one-table statement over t (WHERE resolves its
+    names through _col, which knows the prefix too)."""
+    pre = table_name + "."
+
+    def name(x):
+        return x[len(pre):] if isinstance(x, str) and x.startswith(pre) and x not in columns and x[len(pre):] in columns else x
+
+    def value(v):
+        if isinstance(v, dict) and len(v) == 1:
+            (f, a), = v.items()
+            return {f: name(a)}
+        return name(v)
+
+    def items(x):
+        for it in (x if isinstance(x, list) else [x]):
+            if isinstance(it, dict) and "value" in it:
+                it["value"] = value(it["value"])
+    for key in ("select", "groupby", "orderby"):
+        if key in js_obj:
+            items(js_obj[key])
+    if "having" in js_obj:
+        js_obj["having"] = _rename_terms(js_obj["having"], value)
+
+
+def _rename_terms(cond, f):
+    (op, args), = cond.items()
+    if op in ("and", "or"):
+        return {op: [_rename_terms(c, f) for c in args]}
+    if op == "not":
+        return {op: _rename_terms(args, f)}
+    return {op: [f(args[0])] + list(args[1:])}
+
+
+def where_conjuncts(tree, col_of):
+    """A WHERE tree (moz shape) -> the IR's conjunct list: (column, cmp, number) for plain comparisons -- exactly what the AND-lists
+    of earlier rounds gave -- and (None, "tree", node) for everything else (OR / NOT / IN / parentheses / two columns), node =
+    ("and" | "or", [nodes]) | ("not", node) | ("cmp", col, cmp, number) | ("cmpcol", col, cmp, col2) | ("in", col, [numbers]);
+    the executor evaluates a node into a survivor bitmask on the device (Engine.predicate_tree_mask) and hands it to the
+    kernels as one more conjunct.  col_of(name) -> column index."""
+    def node(cond):
+        (op, args), = cond.items()
+        if op in ("and", "or"):
+            return (op, [node(c) for c in args])
+        if op == "not":
+            return ("not", node(args))
+        if op in ("in", "nin"):
+            lhs, vals = args
+            vals = vals if isinstance(vals, list) else [vals]
+            if not isinstance(lhs, str) or not all(isinstance(v, (int, float)) for v in vals):
+                raise Exception("IN takes a column and a list of numbers")
+            inner = ("in", col_of(lhs), list(vals))
+            return ("not", inner) if op == "nin" else inner
+        if op not in _CMP_SQL:
+            raise Exception(f"{op} is not a supported comparison")
+        lhs, rhs = args
+        if isinstance(lhs, str) and isinstance(rhs, (int, float)):
+            return ("cmp", col_of(lhs), _CMP_SQL[op], rhs)
+        if isinstance(lhs, str) and isinstance(rhs, str):
+            return ("cmpcol", col_of(lhs), _CMP_SQL[op], col_of(rhs))
+        raise Exception("WHERE compares a column with a number or with another column")
+
+    out = []
+    for cond in _conditions(tree):
+        if _is_simple(cond):
+            (op, (lhs, rhs)), = cond.items()
+            out.append((col_of(lhs), _CMP_SQL[op], rhs))
+        else:
+            out.append((None, "tree", node(cond)))
+    return out
+
+
+def _names_of(cond, acc):
+    """Column names a condition mentions."""
+    (op, args), = cond.items()
+    if op in ("and", "or"):
+        for c in args:
+            _names_of(c, acc)
+    elif op == "not":
+        _names_of(args, acc)
+    else:
+        for x in (args[:1] if op in ("in", "nin") else args):
+            if isinstance(x, str):
+                acc.append(x)
+    return acc
+
+
+def _rename(cond, f):
+    """The condition with every column name x replaced by f(x)."""
+    (op, args), = cond.items()
+    if op in ("and", "or"):
+        return {op: [_rename(c, f) for c in args]}
+    if op == "not":
+        return {op: _rename(args, f)}
+    if op in ("in", "nin"):
+        return {op: [f(args[0]), args[1]]}
+    return {op: [f(x) if isinstance(x, str) else x for x in args]}
 
 
 def _conditions(tree):
@@ -66,18 +173,14 @@ def sql_parse_tree(tables, js_obj):
     else:
         raise Exception(f"{table_name} is not in tables")
     columns = table.get_schema()                                        # parse.py:40
+    _unqualify(js_obj, table_name, columns)
     select_pairs = js_obj["select"]
     if isinstance(select_pairs, (dict, str)):                           # one item / "*": the reference
         select_pairs = [select_pairs]                                   # breaks here (TypeError, parse.py:50)
     ir = {"table": table.get_data(), "table_name": table_name, "extended": False}
 
     # ---- WHERE (extension; the reference ignores the key) ------------------
-    where = []
-    for cond in _conditions(js_obj.get("where")):
-        (op, (lhs, rhs)), = cond.items()
-        if not isinstance(lhs, str) or not isinstance(rhs, (int, float)):
-            raise Exception("WHERE supports `column <op> number` comparisons (joined by AND)")
-        where.append((_col(columns, lhs, table_name), _CMP_SQL[op], rhs))
+    where = where_conjuncts(js_obj.get("where"), lambda name: _col(columns, name, table_name))
     if where:
         ir["where"] = where
         ir["extended"] = True
@@ -145,8 +248,12 @@ def sql_parse_tree(tables, js_obj):
             ir["extended"] = True
 
     # ---- HAVING / ORDER BY / LIMIT (extensions) ------------------------------
+    aliases = {p["name"]: p["value"] for p in select_pairs if isinstance(p, dict) and "name" in p}      # `sum(col2) as s ... order by s`
+
     def spec_of(term):
         """A key / aggregate reference in HAVING or ORDER BY -> the matching item."""
+        if isinstance(term, str) and term in aliases and getIndex(columns, term) < 0:
+            term = aliases[term]
         if isinstance(term, str):
             idx = _col(columns, term, table_name)
             return ("key", idx) if "groupby" in js_obj and idx in ir.get("g_cols", [ir["g_col"]]) else ("col", idx)
@@ -157,9 +264,10 @@ def sql_parse_tree(tables, js_obj):
 
     having = []
     for cond in _conditions(js_obj.get("having")):
-        (op, (lhs, rhs)), = cond.items()
-        if not isinstance(rhs, (int, float)):
-            raise Exception("HAVING supports `aggregate <op> number` comparisons")
+        (op, args), = cond.items()
+        if op not in _CMP_SQL or not isinstance(args[1], (int, float)):
+            raise Exception("HAVING supports `aggregate <op> number` comparisons (joined by AND)")
+        lhs, rhs = args
         having.append((spec_of(lhs), _CMP_SQL[op], rhs))
     if having:
         if "groupby" not in js_obj:
@@ -257,14 +365,19 @@ def _join_with_clauses(tables, js_obj, names, c1, c2, sel):
             return {f: a if a == "*" else ref(a)}
         return t
 
-    where = [[], []]
+    where, mixed = [[], []], []
     for cond in _conditions(js_obj.get("where")):
-        (op, (lhs, rhs)), = cond.items()
-        if not isinstance(lhs, str) or not isinstance(rhs, (int, float)):
-            raise Exception("WHERE supports `column <op> number` comparisons (joined by AND)")
-        side, col = _qualified(lhs, names, tables)
-        where[side].append((col, _CMP_SQL[op], rhs))
+        sides = {_qualified(x, names, tables)[0] for x in _names_of(cond, [])}
+        if len(sides) == 1:                                             # a conjunct on ONE table (whatever its shape): below the join
+            side = sides.pop()
+            where[side] += where_conjuncts(cond, lambda name: _qualified(name, names, tables)[1])
+        elif len(sides) == 2:                                           # it mentions both tables: a WHERE of the statement over the join's result
+            mixed.append(_rename(cond, ref))
+        else:
+            raise Exception("a WHERE condition must mention a column")
     post = {"from": JOIN_RESULT}
+    if mixed:
+        post["where"] = mixed[0] if len(mixed) == 1 else {"and": mixed}
     items = []
     for it in sel:
         if it == "*":

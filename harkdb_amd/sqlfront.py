@@ -7,7 +7,7 @@ own indexing: parse.py:29, :46-51, :66, :72-84):
 
     {"select": [{"value": "col1"}, {"value": {"max": "col3"}}],   # one item -> a dict, "*" -> "*"
      "from": "game_1",
-     "where": {"gt": ["col2", 4]},
+     "where": {"gt": ["col2", 4]},                 # trees: {"or": [..]}, {"and": [..]}, {"not": x}, {"in": ["col1", [1, 2]]}, {"nin": ..}
      "groupby": {"value": "col1"},
      "having": {"gte": [{"sum": "col3"}, 10]},
      "orderby": {"value": "col1", "sort": "desc"},
@@ -27,7 +27,7 @@ _TOKEN = re.compile(r"""\s*(?:
 _CMP = {">": "gt", ">=": "gte", "<": "lt", "<=": "lte", "=": "eq", "==": "eq", "!=": "neq", "<>": "neq"}
 _FLIP = {"gt": "lt", "gte": "lte", "lt": "gt", "lte": "gte", "eq": "eq", "neq": "neq"}
 AGGREGATES = ("prod", "sum", "max", "min", "count", "avg")
-_KEYWORDS = {"select", "distinct", "from", "where", "group", "by", "having", "order", "limit", "asc", "desc", "as", "and", "join", "inner", "on", "between"}
+_KEYWORDS = {"select", "distinct", "from", "where", "group", "by", "having", "order", "limit", "asc", "desc", "as", "and", "or", "not", "in", "join", "inner", "on", "between"}
 
 
 class SqlSyntaxError(Exception):
@@ -92,27 +92,67 @@ class _Parser:
 
     def comparison(self):
         lhs = self.term()
+        negated = self.peek("kw", "not")                     # x NOT BETWEEN ..., x NOT IN (...)
+        if negated:
+            self.take()
+            if not (self.peek("kw", "between") or self.peek("kw", "in")):
+                raise SqlSyntaxError("NOT must be followed by BETWEEN or IN here")
         if self.peek("kw", "between"):                       # x BETWEEN a AND b  ==  x >= a AND x <= b
             self.take()
             lo = self.term()
             self.take("kw", "and")
             hi = self.term()
-            return {"and": [{"gte": [lhs, lo]}, {"lte": [lhs, hi]}]}
+            both = {"and": [{"gte": [lhs, lo]}, {"lte": [lhs, hi]}]}
+            return {"not": both} if negated else both
+        if self.peek("kw", "in"):                            # x IN (a, b, ...): moz's {"in": [x, [a, b, ...]]}
+            self.take()
+            self.take("punct", "(")
+            vals = [self.take("num")]
+            while self.peek("punct", ","):
+                self.take()
+                vals.append(self.take("num"))
+            self.take("punct", ")")
+            return {"nin" if negated else "in": [lhs, vals]}
         op = _CMP[self.take("op")]
         rhs = self.term()
         if isinstance(lhs, (int, float)) and not isinstance(rhs, (int, float)):
             lhs, rhs, op = rhs, lhs, _FLIP[op]
         return {op: [lhs, rhs]}
 
-    def condition(self):
+    def primary(self):
+        if self.peek("punct", "("):                          # a term never starts with a parenthesis: this one groups a condition
+            self.take()
+            c = self.condition()
+            self.take("punct", ")")
+            return c
+        return self.comparison()
+
+    def negation(self):
+        if self.peek("kw", "not"):
+            self.take()
+            return {"not": self.negation()}
+        return self.primary()
+
+    def conjunction(self):
         terms = []
         while True:
-            c = self.comparison()
-            terms += c["and"] if "and" in c else [c]         # BETWEEN contributes two comparisons
+            c = self.negation()
+            terms += c["and"] if "and" in c else [c]         # BETWEEN contributes two comparisons, (a AND b) AND c is one list
             if not self.peek("kw", "and"):
                 break
             self.take()
         return terms[0] if len(terms) == 1 else {"and": terms}
+
+    def condition(self):
+        """OR of ANDs of (NOT) comparisons / parenthesised conditions -- the precedence of SQL."""
+        terms = []
+        while True:
+            c = self.conjunction()
+            terms += c["or"] if "or" in c else [c]
+            if not self.peek("kw", "or"):
+                break
+            self.take()
+        return terms[0] if len(terms) == 1 else {"or": terms}
 
     def statement(self):
         self.take("kw", "select")

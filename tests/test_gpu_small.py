@@ -128,3 +128,16 @@ def test_select_list_of_more_than_32_columns_through_sql():
     order = list(rng.permutation(40)) + [3, 3]
     got = fc.sql("select " + ", ".join(names[j] for j in order) + " from wide")
     assert got.shape == (5000, 42) and np.array_equal(got, db[:, order])
+
+
+def test_small_sel_keeps_every_columns_dtype(eng, path):
+    """A projection of f32 / u32 / i32 columns of a small table: bit copies, each column its own dtype (tools/sql_stress.py found
+    the f32 column of a filtered table coming back as i32 bits)."""
+    rng = np.random.default_rng(4)
+    cols = [rng.integers(-9, 9, 300).astype(np.int32), rng.random(300).astype(np.float32), rng.integers(0, 2**32, 300, dtype=np.uint64).astype(np.uint32)]
+    t = eng.table_from_columns(cols)
+    res = eng.query_sel(t, [1, 0, 2, 1])
+    got = res.columns()
+    for g, e in zip(got, [cols[1], cols[0], cols[2], cols[1]]):
+        assert g.dtype == e.dtype and np.array_equal(g, e)
+    assert np.array_equal(res.matrix(), np.stack([cols[1].astype(np.float64), cols[0].astype(np.float64), cols[2].astype(np.float64), cols[1].astype(np.float64)], axis=1))

@@ -776,3 +776,105 @@ def test_result_matrix_rejects_what_it_cannot_convert(fc):
     assert res.matrix(cols=[]).shape == (res.shape[0], 0) and res.matrix(limit=0).shape == (0, 2)
     m = res.matrix(limit=10)
     assert m.dtype == np.float64 and np.array_equal(m[:, 0], fc._df.k.to_numpy()[:10]) and np.array_equal(m[:, 1].astype(np.float32), fc._df.p.to_numpy()[:10])
+
+
+# ---- predicate trees (round 6): what moz_sql_parser hands the reference's planner (parse.py:27) and the reference drops ----
+TREES = [
+    ("p > 0.5 or w < -90", lambda d: (d.p > 0.5) | (d.w < -90)),
+    ("not p > 0.5", lambda d: ~(d.p > 0.5)),
+    ("k in (1, 5, 999, 1000) and p > 0.1", lambda d: d.k.isin([1, 5, 999, 1000]) & (d.p > 0.1)),
+    ("k not in (3, 4) and (w > 50 or w < -50) and big > 0", lambda d: ~d.k.isin([3, 4]) & ((d.w > 50) | (d.w < -50)) & (d.big > 0)),
+    ("(p > 0.2 and p < 0.4) or (p > 0.6 and not (w between -10 and 10))", lambda d: ((d.p > 0.2) & (d.p < 0.4)) | ((d.p > 0.6) & ~((d.w >= -10) & (d.w <= 10)))),
+    ("w > k", lambda d: d.w > d.k),
+    ("t.k <= t.w or v = 3", lambda d: (d.k <= d.w) | (d.v == 3)),
+    ("w not between -99 and 98", lambda d: ~((d.w >= -99) & (d.w <= 98))),
+    ("p > 2 or w > 1000", lambda d: (d.p > 2) | (d.w > 1000)),                 # nothing survives
+    ("not (p > 2 or w > 1000)", lambda d: ~((d.p > 2) | (d.w > 1000))),        # everything does
+    ("w in (2.5, 3)", lambda d: d.w.isin([3])),                                 # a fractional literal never equals an integer
+]
+
+
+@pytest.mark.parametrize("where,mask", TREES)
+def test_predicate_trees_in_select_groupby_and_limit_statements(fc, where, mask):
+    df = fc._df
+    m = mask(df)
+    out = fc.sql(f"select k, w from t where {where}")
+    assert np.array_equal(out, df[m][["k", "w"]].to_numpy())
+    _, cols = fc.sql_columns(f"select k, sum(v), count(*), max(w) from t where {where} group by k")
+    g = df[m].groupby("k").agg(s=("v", "sum"), c=("v", "size"), mx=("w", "max"))
+    assert np.array_equal(cols[0], g.index.to_numpy()) and np.array_equal(cols[1], g.s.to_numpy().astype(np.float32))
+    assert np.array_equal(cols[2], g.c.to_numpy()) and np.array_equal(cols[3], g.mx.to_numpy())
+    # sparse keys (hash / sort paths) and the ORDER BY ... LIMIT entries take the mask as a conjunct too
+    _, cols = fc.sql_columns(f"select big, count(*) from t where {where} group by big")
+    gb = df[m].groupby("big").size()
+    assert np.array_equal(cols[0], gb.index.to_numpy()) and np.array_equal(cols[1], gb.to_numpy())
+    _, cols = fc.sql_columns(f"select k, count(*), sum(w) from t where {where} group by k order by count(*) desc limit 5")
+    g2 = df[m].groupby("k").agg(c=("w", "size"), s=("w", "sum")).reset_index().sort_values("c", ascending=False, kind="stable").head(5)
+    assert np.array_equal(cols[0], g2.k.to_numpy()) and np.array_equal(cols[1], g2.c.to_numpy()) and np.array_equal(cols[2], g2.s.to_numpy())
+    _, cols = fc.sql_columns(f"select k, w from t where {where} order by w desc limit 7")
+    e = df[m].sort_values("w", ascending=False, kind="stable").head(7)
+    assert np.array_equal(cols[0], e.k.to_numpy()) and np.array_equal(cols[1], e.w.to_numpy())
+
+
+def test_select_aliases_in_having_and_order_by_and_qualified_names(fc):
+    df = fc._df
+    _, cols = fc.sql_columns("select t.k, sum(t.w) as s, count(*) as c from t where t.p > 0.5 group by t.k having s > 100 and c >= 90 order by s desc limit 20")
+    g = df[df.p > 0.5].groupby("k").agg(s=("w", "sum"), c=("w", "size")).reset_index()
+    g = g[(g.s > 100) & (g.c >= 90)].sort_values("s", ascending=False, kind="stable").head(20)
+    assert np.array_equal(cols[0], g.k.to_numpy()) and np.array_equal(cols[1], g.s.to_numpy()) and np.array_equal(cols[2], g.c.to_numpy())
+    out = fc.sql("select t.k, t.w from t where t.w > 97")
+    assert np.array_equal(out, df[df.w > 97][["k", "w"]].to_numpy())
+
+
+def test_predicate_trees_under_a_join(oracle):
+    from harkdb_amd import FutharkContext
+    rng = np.random.default_rng(8)
+    a = pd.DataFrame({"k": rng.integers(0, 300, 4000).astype(np.int32), "x": rng.integers(0, 100, 4000).astype(np.int32), "y": rng.integers(0, 100, 4000).astype(np.int32)})
+    b = pd.DataFrame({"k": rng.integers(0, 300, 500).astype(np.int32), "z": rng.integers(0, 100, 500).astype(np.int32)})
+    c = FutharkContext(sql_mode=True)
+    c.create_table("a", a); c.create_table("b", b)
+    _, cols = c.sql_columns("select a.x, b.z from a join b on a.k = b.k where (a.x > 90 or a.y in (1, 2, 3)) and not b.z < 10 and a.x > b.z")
+    aa, bb = a[(a.x > 90) | a.y.isin([1, 2, 3])].reset_index(), b[~(b.z < 10)].reset_index()
+    j = aa.merge(bb, on="k", suffixes=("_a", "_b"))
+    j["ku"] = j.k.astype(np.uint32)
+    j = j.sort_values(["ku", "index_a", "index_b"], kind="stable")                  # join.fut:55-75: (key, left row, right row)
+    j = j[j.x > j.z]
+    assert np.array_equal(cols[0], j.x.to_numpy()) and np.array_equal(cols[1], j.z.to_numpy())
+
+
+def test_predicate_tree_entry_against_numpy():
+    """hark_op_predicate_tree itself: random trees over four dtypes, the mask bit for bit (rows past the end zero)."""
+    from harkdb_amd.engine import Engine
+    eng = Engine(0)
+    rng = np.random.default_rng(2)
+    for n in (1, 7, 8, 9, 1000, 100_003):
+        cols = [rng.integers(-5, 6, n).astype(np.int32), rng.integers(0, 11, n).astype(np.uint32), (rng.integers(-5, 6, n) / 2).astype(np.float32),
+                rng.integers(-5, 6, n).astype(np.int64), rng.integers(-5, 6, n).astype(np.int32)]
+        t = eng.table_from_columns(cols)
+        ops = {">": np.greater, ">=": np.greater_equal, "<": np.less, "<=": np.less_equal, "=": np.equal, "!=": np.not_equal}
+
+        def rand(depth):
+            r = rng.random()
+            if depth == 0 or r < 0.3:
+                c = int(rng.integers(0, 5)); op = str(rng.choice(list(ops))); v = int(rng.integers(-4, 8))
+                return ("cmp", c, op, v), ops[op](cols[c].astype(np.float64), v)
+            if r < 0.4:
+                op = str(rng.choice(list(ops)))
+                return ("cmpcol", 0, op, 4), ops[op](cols[0], cols[4])
+            if r < 0.5:
+                c = int(rng.integers(0, 5)); vals = [int(x) for x in rng.integers(-4, 8, size=int(rng.integers(1, 4)))]
+                return ("in", c, vals), np.isin(cols[c], vals)
+            if r < 0.65:
+                nd, m = rand(depth - 1)
+                return ("not", nd), ~m
+            kids = [rand(depth - 1) for _ in range(int(rng.integers(2, 4)))]
+            if r < 0.85:
+                return ("and", [k for k, _ in kids]), np.logical_and.reduce([m for _, m in kids])
+            return ("or", [k for k, _ in kids]), np.logical_or.reduce([m for _, m in kids])
+        for _ in range(12):
+            node, m = rand(3)
+            buf = eng.predicate_tree_mask(t, node)
+            got = eng.download(buf.ptr, (n + 7) // 8, np.uint8)
+            assert np.array_equal(got, np.packbits(m, bitorder="little")), node
+        t.free()
+    eng.close()

@@ -297,3 +297,35 @@ def test_between():
     assert parse("select a from t where a between 1 and 5 and b > 2")["where"] == {"and": [{"gte": ["a", 1]}, {"lte": ["a", 5]}, {"gt": ["b", 2]}]}
     assert parse("select a, count(*) from t group by a having count(*) between 2 and 9")["having"] == \
         {"and": [{"gte": [{"count": "*"}, 2]}, {"lte": [{"count": "*"}, 9]}]}
+
+
+def test_predicate_trees_parse_and_plan(tables):
+    """OR / NOT / IN / parentheses / two columns (moz_sql_parser's shapes, parse.py:27): plain comparisons joined by AND stay the
+    triples of earlier rounds, everything else becomes ONE tree conjunct per top-level AND term."""
+    t = parse("select a from t where a > 1 and (b < 2 or c = 3) and not d >= 4")
+    assert t["where"] == {"and": [{"gt": ["a", 1]}, {"or": [{"lt": ["b", 2]}, {"eq": ["c", 3]}]}, {"not": {"gte": ["d", 4]}}]}
+    t = parse("select a from t where a in (1, -2, 3.5) or b not in (4) or c not between 1 and 2")
+    assert t["where"] == {"or": [{"in": ["a", [1, -2, 3.5]]}, {"nin": ["b", [4]]}, {"not": {"and": [{"gte": ["c", 1]}, {"lte": ["c", 2]}]}}]}
+    assert parse("select a from t where ((a > 1))")["where"] == {"gt": ["a", 1]}
+    assert parse("select a from t where a > 1 or b > 2 and c > 3")["where"] == {"or": [{"gt": ["a", 1]}, {"and": [{"gt": ["b", 2]}, {"gt": ["c", 3]}]}]}
+    ir = sql_parse(tables, "select col1, col3 from game_1 where col2 > 3 and (col1 = 6 or col3 in (1, 2)) and not col4 < 1 and col5 <= col6")
+    assert ir["where"] == [(1, ">", 3), (None, "tree", ("or", [("cmp", 0, "=", 6), ("in", 2, [1, 2])])), (None, "tree", ("not", ("cmp", 3, "<", 1))),
+                           (None, "tree", ("cmpcol", 4, "<=", 5))]
+    assert sql_parse(tables, "select col1 from game_1 where col2 > 3 and col1 < 9")["where"] == [(1, ">", 3), (0, "<", 9)]      # as before
+    with pytest.raises(Exception, match="colx is not in the schema"):
+        sql_parse(tables, "select col1 from game_1 where col1 > 1 or colx < 2")
+    with pytest.raises(SqlSyntaxError):
+        parse("select a from t where a in ()")
+    with pytest.raises(SqlSyntaxError):
+        parse("select a from t where (a > 1")
+    with pytest.raises(Exception, match="HAVING supports"):
+        sql_parse(tables, "select col1, sum(col2) from game_1 group by col1 having sum(col2) > 1 or sum(col2) < 0")
+
+
+def test_aliases_and_qualified_names(tables):
+    ir = sql_parse(tables, "select col1, sum(col2) as s, count(*) as c from game_1 group by col1 having s > 3 and c >= 1 order by s desc")
+    assert ir["having"] == [(("sum", 1), ">", 3), (("count", None), ">=", 1)] and ir["orderby"] == (("sum", 1), True)
+    ir = sql_parse(tables, "select game_1.col1, max(game_1.col3) from game_1 where game_1.col2 > 3 group by game_1.col1 order by game_1.col1")
+    assert (ir["select"], ir["groupbys"], ir["g_col"], ir["where"], ir["orderby"]) == ([0, 2], [0, 3], 0, [(1, ">", 3)], (("key", 0), False))
+    ir = sql_parse(tables, "select game_1.col1, game_1.col3 from game_1")
+    assert ir["select"] == [0, 2] and not ir["extended"]                                  # the reference statement, qualified

@@ -24,11 +24,40 @@ while time.time() < t_end and bad is None:
     fc.create_table("t", df)
     for _ in range(12):
         where_sql, mask = "", np.ones(n, bool)
-        if rng.random() < 0.6:
+
+        def leaf():
             col = str(rng.choice(["p", "y", "a"])); op = str(rng.choice(list(OPS)))
             val = float(np.float32(rng.random())) if col == "p" else int(rng.integers(-3, 4)) if col == "a" else int(rng.integers(-900, 900))
-            where_sql = f" where {col} {op} {val!r}"
-            mask = getattr(df[col], OPS[op])(np.float32(val) if col == "p" else val).to_numpy()
+            return f"{col} {op} {val!r}", getattr(df[col], OPS[op])(np.float32(val) if col == "p" else val).to_numpy()
+
+        def tree(depth):
+            """OR / NOT / IN / parentheses / BETWEEN / two columns (round 6: what the reference's parser accepts, parse.py:27)."""
+            r = rng.random()
+            if depth == 0 or r < 0.35:
+                return leaf()
+            if r < 0.45:
+                col = str(rng.choice(["a", "b", "y"])); vals = [int(v) for v in rng.integers(-4, 60, size=int(rng.integers(1, 5)))]
+                neg = rng.random() < 0.3
+                m = df[col].isin(vals).to_numpy()
+                return f"{col} {'not ' if neg else ''}in ({', '.join(map(str, vals))})", (~m if neg else m)
+            if r < 0.52:
+                op = str(rng.choice(list(OPS)))
+                return f"a {op} b", getattr(df["a"], OPS[op])(df["b"]).to_numpy()
+            if r < 0.6:
+                lo, hi = sorted(int(v) for v in rng.integers(-900, 900, size=2)); neg = rng.random() < 0.3
+                m = ((df.y >= lo) & (df.y <= hi)).to_numpy()
+                return f"y {'not ' if neg else ''}between {lo} and {hi}", (~m if neg else m)
+            if r < 0.7:
+                t_, m = tree(depth - 1)
+                return f"not ({t_})", ~m
+            kids = [tree(depth - 1) for _ in range(int(rng.integers(2, 4)))]
+            if r < 0.85:
+                return "(" + " and ".join(f"({t_})" for t_, _ in kids) + ")", np.logical_and.reduce([m for _, m in kids])
+            return "(" + " or ".join(f"({t_})" for t_, _ in kids) + ")", np.logical_or.reduce([m for _, m in kids])
+
+        if rng.random() < 0.7:
+            text, mask = leaf() if rng.random() < 0.4 else tree(3)
+            where_sql = f" where {text}"
         sub = df[mask]
         kind = rng.choice(["group", "multi", "distinct", "select"])
         try:
