@@ -1468,7 +1468,7 @@ __device__ __forceinline__ uint32_t unmix32(uint32_t y)
 // bucket.  Its home group is g = x * groups >> lowbits (any group count; two 24-bit multiplies and a funnel shift -- a first
 // version divided by the identities per group: umulhi, two 32-bit multiplies and a correction per pair), its remainder
 // tv = bits [shift, lowbits) of the product's low part, where 2^shift <= groups: inside a group the product steps by `groups`
-// from key to key, so no two keys of a group share a tv.  A slot holds d << rembits | tv, d <= maxdisp <= 3 = how many groups
+// from key to key, so no two keys of a group share a tv.  A slot holds d << rembits | tv, d <= maxdisp (<= 3 for groups of 8, <= 7 for groups of 4) = how many groups
 // past its home the key lives (the first group that had room when it came; all before it are full of other keys, and stay
 // so: slots only ever go from empty to occupied); 0xFFFF = an empty slot (the one tag that spells 0xFFFF is never stored: its
 // key overflows one group early).  Slot s of a group is half s >> 2 of word s & 3 (what the branch-free search hands back).
@@ -1483,7 +1483,7 @@ struct TagGroups {
     __device__ __forceinline__ void init(uint32_t *lds_words, uint32_t ngroups, int lowbits_)
     {
         tagw = lds_words; groups = ngroups; lowbits = (uint32_t)lowbits_;
-        shift = 31u - (uint32_t)__clz((int)ngroups);         // groups >= 512 and lowbits <= 24: rembits <= 15
+        shift = 31u - (uint32_t)__clz((int)ngroups);         // groups >= 512 and lowbits <= 24 (>= 256 buckets: checked where the consumers are launched): rembits <= 15
         rembits = lowbits - shift;
         const uint32_t room = (1u << (16u - rembits)) - 1u, most = W == 4 ? 7u : 3u;
         maxdisp = room < most ? room : most;
@@ -2556,6 +2556,10 @@ int k_fgb_hash_u32(hark_context *ctx, const uint32_t *k, const uint32_t *v, int6
     // 512 buckets of 32-pair rings (256 x 64 before): half as many distinct keys per bucket -- 2^21 distinct keys fit ONE
     // round of the 8-byte tables instead of two (plus the failed first attempt and the sample round that found that out)
     const int hash_bits = getenv("HARK_HASH_BITS8") ? 8 : 9, P = 1 << hash_bits, nwg = ctx->num_cu;
+    // TagGroups (the consumers' key identities) keeps the 32 - hash_bits low bits of a mixed key in 24-bit multiplies and 16-bit
+    // tags: fewer than 256 buckets would merge distinct keys into one identity without any error
+    static_assert(32 - 8 <= 24, "TagGroups::home multiplies 24-bit words");
+    if (P < 256) return hark_fail(ctx, HARK_EARG, "hash group-by: at least 256 buckets (TagGroups holds 24 low key bits)");
     int64_t cap = n / ((int64_t)P * nwg) * 130 / 100 + 256;
     cap = (cap + kLine - 1) / kLine * kLine + 2 * kLine;
     uint2 *pbuf = nullptr; uint32_t *counts = nullptr; int32_t *err = nullptr; unsigned long long *cursor = nullptr;

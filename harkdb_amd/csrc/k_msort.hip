@@ -46,10 +46,10 @@ constexpr int kFCapOf(int ft) { return kFR * ft; }
 constexpr uint32_t kFWorkMax = 1u << 18;                     // ... and the sum of the squared run lengths of a bucket that is ranked at all (a run of
                                                              // 500 alone; the tail buckets of a normal distribution come to 1e5): buckets of a
                                                              // column with hundreds of copies of every key are over it, and the first one says so
-constexpr int kFRunMax = 1024;                               // longest run of one final digit that is ranked by comparing: quadratic, but a run
-                                                             // of 1024 costs its bucket ~0.15 ms and a statement at most ~13 ms where the
-                                                             // caller's general path takes 21 (the tail buckets of a normal distribution
-                                                             // hold runs of a few hundred; 1000-fold duplicates of every key the worst case)
+constexpr int kFRunMax = 512;                                // longest run of one final digit that is ranked by comparing (quadratic).  The work bound above is the
+                                                             // one that bites: a run of more than 512 is over it by itself (512^2 = kFWorkMax), so this test only
+                                                             // backs it up -- columns with such runs always take the caller's tuple passes and are remembered
+                                                             // (hark_column::msd_unfit)
 constexpr int kSampleWg = 256, kSampleStride = 61;          // one line of sixteen keys in 61 is looked at for the bounds: ~61 keys of ANY distribution lie below the
                                                              // sampled minimum (and above the maximum); with one in 509 it was ~500, all clamped
                                                              // into one final digit of the first bucket -- over the ranking bound for a normal
@@ -675,10 +675,15 @@ int k_sort_i64_msd(hark_context *ctx, const void *col, int64_t n, const uint32_t
     HIP_TRY_RC(ctx, rc, hipMemcpyAsync(mm, mm_init, 16, hipMemcpyHostToDevice, st));
     const u64 *c64 = static_cast<const u64 *>(col);
     const size_t lds = msd_part_lds();
-    HIP_TRY_RC(ctx, rc, hipFuncSetAttribute(reinterpret_cast<const void *>(&msd_part_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIP_TRY_RC(ctx, rc, hipFuncSetAttribute(reinterpret_cast<const void *>(&msd_part_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIP_TRY_RC(ctx, rc, hipFuncSetAttribute(reinterpret_cast<const void *>(&msd_final_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)msd_final_lds(512)));
-    HIP_TRY_RC(ctx, rc, hipFuncSetAttribute(reinterpret_cast<const void *>(&msd_final_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)msd_final_lds(1024)));
+    static bool lds_attributes_of[64] = {};                          // once per device (the sizes are constants)
+    bool &lds_attributes_set = lds_attributes_of[ctx->device & 63];
+    if (!lds_attributes_set) {
+        HIP_TRY_RC(ctx, rc, hipFuncSetAttribute(reinterpret_cast<const void *>(&msd_part_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY_RC(ctx, rc, hipFuncSetAttribute(reinterpret_cast<const void *>(&msd_part_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY_RC(ctx, rc, hipFuncSetAttribute(reinterpret_cast<const void *>(&msd_final_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)msd_final_lds(512)));
+        HIP_TRY_RC(ctx, rc, hipFuncSetAttribute(reinterpret_cast<const void *>(&msd_final_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)msd_final_lds(1024)));
+        lds_attributes_set = !rc;
+    }
     const dim3 g1((unsigned)nwg), b1(kT);
     HARK_LAUNCH_RC(ctx, rc, msd_sample_kernel<<<dim3(kSampleWg), dim3(1024), 0, st>>>(c64, n, xorm, kSampleStride, mm));
     HARK_LAUNCH_RC(ctx, rc, msd_setup_kernel<<<dim3(1), dim3(1), 0, st>>>(mm, (uint32_t)D, map, flag));

@@ -152,7 +152,8 @@ int k_small_query_groupby(hark_context *ctx, const hark_table *db, const int32_t
     int p2 = 64;
     while (p2 < db->n) p2 <<= 1;
     const size_t lds = (size_t)p2 * 10 + (size_t)db->n * (size_t)s * 4;
-    static bool attr_set = false;
+    static bool attr_of[64] = {};                                          // once per device
+    bool &attr_set = attr_of[ctx->device & 63];
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&small_groupby_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kSmallRows * 10 + kSmallTable * 4) != hipSuccess)
             return hark_fail(ctx, HARK_EHIP, "small_groupby: setting the dynamic LDS size failed");

@@ -1253,17 +1253,16 @@ int k_argsort_i64_desc_tuples(hark_context *ctx, const void *col, int64_t n, uin
     *perm_out = nullptr; *keys_out = nullptr; *done = false;
     if (val_out) *val_out = nullptr;
     if (n <= 0) return HARK_OK;
-    uint64_t *keys = nullptr;
+    uint64_t *keys = nullptr;                                       // ONE block for whichever path delivers (the three sweeps first, the tuple passes after them)
     if (!getenv("HARK_SORT_NO_TUPLES")) {
         HARK_TRY(hark_alloc(ctx, (void **)&keys, (size_t)n * 8));
         const int rc0 = k_sort_i64_msd(ctx, col, n, valcol, keys, perm_out, val_out, done, nullptr, 0x7FFFFFFFFFFFFFFFull, out_xor, msd_unfit);
         if (rc0 || *done) { if (rc0) hark_free(ctx, keys); else *keys_out = keys; return rc0; }
-        hark_free(ctx, keys); keys = nullptr;
     }
     uint32_t diff_hi = 0u;
-    HARK_TRY(k_transform_keys(ctx, col, HARK_I64, 1, nullptr, n, &diff_hi));      // (the bits in which the high words differ: the same either way)
-    if (passes_of(diff_hi) == 0u || getenv("HARK_SORT_NO_TUPLES")) return HARK_OK;
-    HARK_TRY(hark_alloc(ctx, (void **)&keys, (size_t)n * 8));
+    { const int rcd = k_transform_keys(ctx, col, HARK_I64, 1, nullptr, n, &diff_hi); if (rcd) { hark_free(ctx, keys); return rcd; } }   // (the bits in which the high words differ: the same either way)
+    if (passes_of(diff_hi) == 0u || getenv("HARK_SORT_NO_TUPLES")) { hark_free(ctx, keys); return HARK_OK; }
+    if (!keys) HARK_TRY(hark_alloc(ctx, (void **)&keys, (size_t)n * 8));
     const int rc = sort_i64_tuples(ctx, col, n, diff_hi, valcol, keys, perm_out, val_out, done, nullptr, 0x7FFFFFFFFFFFFFFFull, out_xor);
     if (rc || !*done) { hark_free(ctx, keys); return rc; }
     *keys_out = keys;

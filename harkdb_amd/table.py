@@ -51,10 +51,21 @@ def load_table(table_name, table):
     raise Exception("Table is not in a file, numpy array or dataframe")
 
 
+_warned_narrowing = False
+
+
 def column_dtype(col):
     """Device dtype for one host column."""
     col = np.asarray(col)
     if col.dtype.kind == "f":
+        if col.dtype.itemsize > 4 and col.size and not _warned_narrowing:
+            # float64 in, float32 on the device (the fused kernels' value type): integers above 2^24 and 9+ significant digits
+            # do not survive.  Said once per process; INTEGRATION.md "dtypes" has the whole table.
+            if not np.array_equal(col.astype(np.float32).astype(col.dtype), col, equal_nan=True):
+                import warnings
+                warnings.warn(f"harkdb_amd: a {col.dtype} column is stored as float32 on the device and loses precision "
+                              "(cast it yourself, or scale it to integers, to choose how)", stacklevel=3)
+                globals()["_warned_narrowing"] = True
         return np.float32
     if col.dtype.kind in "iub":
         if col.dtype == np.uint32:

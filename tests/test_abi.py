@@ -117,3 +117,11 @@ def test_the_bounds_checked_build_of_the_i64_sort_still_compiles(tmp_path):
     r = subprocess.run(["/opt/rocm/bin/hipcc", "-O1", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-DHARK_MSD_CHECK", "-I", os.path.join(ROOT, "include"),
                         "-c", src, "-o", str(tmp_path / "k_msort_chk.o")], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
+
+
+def test_no_second_library_beside_the_product():
+    """A/B builds go to build/ab/ (tools/ab_build.sh): every file of harkdb_amd/ travels to the GPU box with each call, and
+    HARK_LIB can swap any libhark*.so for the product -- five stale ones sat here in round 5 (18 MB per push)."""
+    import glob
+    libs = sorted(os.path.basename(f) for f in glob.glob(os.path.join(ROOT, "harkdb_amd", "libhark*.so")))
+    assert libs in ([], ["libhark.so"]), libs

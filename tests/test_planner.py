@@ -329,3 +329,21 @@ def test_aliases_and_qualified_names(tables):
     assert (ir["select"], ir["groupbys"], ir["g_col"], ir["where"], ir["orderby"]) == ([0, 2], [0, 3], 0, [(1, ">", 3)], (("key", 0), False))
     ir = sql_parse(tables, "select game_1.col1, game_1.col3 from game_1")
     assert ir["select"] == [0, 2] and not ir["extended"]                                  # the reference statement, qualified
+
+
+def test_float64_columns_narrow_to_f32_with_one_warning():
+    """Floating-point columns live on the device as f32 (the fused kernels' value type): a float64 column that does not
+    survive the round trip says so -- once per process (it used to be silent)."""
+    import warnings
+    import harkdb_amd.table as T
+    T._warned_narrowing = False
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        Table("exact", pd.DataFrame({"a": np.arange(5, dtype=np.float64) / 4})).host_columns()   # quarters are exact in f32: silent
+        assert not w
+        t = Table("lossy", pd.DataFrame({"a": np.array([0.1, 2.0**24 + 1]), "b": np.array([1, 2])}))
+        cols = t.host_columns()                                                           # (the device dtypes are chosen when the columns are uploaded)
+        assert len(w) == 1 and "float32" in str(w[0].message)
+        Table("again", pd.DataFrame({"a": np.array([0.3])})).host_columns()
+        assert len(w) == 1
+    assert cols[0].dtype == np.float32

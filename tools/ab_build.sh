@@ -1,4 +1,6 @@
-# A/B build of libhark: bash tools/ab_build.sh NAME "-DFLAG ..." [unit.hip | /path/to/edited_copy_of_unit.hip ...]  ->  harkdb_amd/libhark_NAME.so
+# A/B build of libhark: bash tools/ab_build.sh NAME "-DFLAG ..." [unit.hip | /path/to/edited_copy_of_unit.hip ...]  ->  build/ab/libhark_NAME.so
+# (NOT into harkdb_amd/: every file there travels to the GPU box with each call, and HARK_LIB can swap any of them for the product --
+# tests/test_abi.py fails when a second libhark*.so sits beside the product library.  Run with HARK_LIB=$PWD/build/ab/libhark_NAME.so)
 # Recompiles the named units (default k_fgb.hip) with the extra flags and links them with the product's other objects.
 set -e
 NAME=$1; FLAGS=$2; shift 2 || true
@@ -16,5 +18,6 @@ for u in $UNITS; do
   EXCL="$EXCL ${base%.hip}.o"
 done
 OTHERS=$(ls *.o | grep -v -x -F "$(echo $EXCL | tr ' ' '\n')")
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libhark_$NAME.so $OTHERS $(for u in $UNITS; do base=$(basename $u); echo $OBJ/${base%.hip}.o; done)
-echo built harkdb_amd/libhark_$NAME.so
+mkdir -p ../../build/ab
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../build/ab/libhark_$NAME.so $OTHERS $(for u in $UNITS; do base=$(basename $u); echo $OBJ/${base%.hip}.o; done)
+echo built build/ab/libhark_$NAME.so
