@@ -260,6 +260,14 @@ __global__ __launch_bounds__(1024) void jhot_sample_kernel(const K *__restrict__
     }
 }
 
+// one launch clears everything the join's kernels expect zeroed (a hipMemsetAsync of a few megabytes of odd size becomes several
+// fill kernels ~10 us apart: 80 us of a 2.6 ms join went there)
+__global__ __launch_bounds__(256) void jclear_kernel(uint4 *__restrict__ p, size_t n16)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) p[i] = uint4{0u, 0u, 0u, 0u};
+}
+
 template <typename K>
 __global__ __launch_bounds__(1024) void jhot_select_kernel(const unsigned long long *__restrict__ tkey, const uint32_t *__restrict__ tcnt, uint32_t cmin,
                                                            const K *__restrict__ rkeys, int64_t s, JHotSet<K> *__restrict__ hot)
@@ -1317,7 +1325,6 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
     if (!rc) rc = hark_alloc(ctx, (void **)&counts, 4 * (size_t)P * nwg);
     if (!rc) rc = hark_alloc(ctx, (void **)&scount, 4 * (size_t)P);
     if (!rc) rc = hark_alloc(ctx, (void **)&sbins, 4 * (size_t)P * kBinSlots);
-    if (!rc) rc = hark_alloc(ctx, (void **)&info, 32);
     if (!rc) rc = hark_alloc(ctx, (void **)&slabs, sizeof(E) * (size_t)P * sstride);
     if (!rc && !verify) rc = hark_alloc(ctx, (void **)&surv, 8 * (size_t)P * region);          // 32-bit keys: (rank, left row)
     if (!rc && verify) rc = hark_alloc(ctx, (void **)&srec, 16 * (size_t)P * region);          // 64-bit keys: records + their ranks alone
@@ -1331,21 +1338,23 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
     uint32_t S = (uint32_t)std::min<int64_t>(kHotSampleMax, std::max<int64_t>(4096, n / 256)), cmin = 5;
     if (const char *e = getenv("HARK_JOIN_HOTMIN")) { const int c = atoi(e); if (c >= 2) cmin = (uint32_t)c; }   // tests: hot keys in small tables
     uint32_t tslots = 1;
-    while (tslots < 4u * S) tslots <<= 1;
+    while (tslots < 2u * S) tslots <<= 1;                                        // (a workgroup's samples are counted in LDS first: at most S distinct keys arrive)
     const uint32_t nbatch = (uint32_t)((n + (int64_t)kJThreads * VEC - 1) / ((int64_t)kJThreads * VEC));      // the partition kernel's batches
-    // one block, cleared by one memset: the sample table (keys, counts), the batches' counts, the set's head; the rest of the set behind
-    const size_t hot_clear = 12 * (size_t)tslots + (4 * (size_t)nbatch + 15) / 16 * 16;
+    // one block, cleared by one launch: the survivor total and the error word (info), the sample table (keys, counts), the batches'
+    // counts, the set's head; the rest of the set behind
+    const size_t hot_clear = 64 + 12 * (size_t)tslots + (4 * (size_t)nbatch + 15) / 16 * 16;
     unsigned char *hot_block = nullptr;
     if (!rc) rc = hark_alloc(ctx, (void **)&hot_block, hot_clear + sizeof(JHotSet<K>));
     if (!rc) {
-        tkey = reinterpret_cast<unsigned long long *>(hot_block);
-        tcnt = reinterpret_cast<uint32_t *>(hot_block + 8 * (size_t)tslots);
-        btotal = reinterpret_cast<uint32_t *>(hot_block + 12 * (size_t)tslots);
+        info = reinterpret_cast<int64_t *>(hot_block);
+        tkey = reinterpret_cast<unsigned long long *>(hot_block + 64);
+        tcnt = reinterpret_cast<uint32_t *>(hot_block + 64 + 8 * (size_t)tslots);
+        btotal = reinterpret_cast<uint32_t *>(hot_block + 64 + 12 * (size_t)tslots);
         hot = reinterpret_cast<JHotSet<K> *>(hot_block + hot_clear);
     }
     auto cleanup = [&]() {
         hark_free(ctx, splitters); hark_free(ctx, bstart); hark_free(ctx, counts); hark_free(ctx, scount); hark_free(ctx, sbins);
-        hark_free(ctx, info); hark_free(ctx, slabs); hark_free(ctx, surv); hark_free(ctx, srec); hark_free(ctx, scoarse);
+        hark_free(ctx, slabs); hark_free(ctx, surv); hark_free(ctx, srec); hark_free(ctx, scoarse);
         hark_free(ctx, hot_block);
     };
     if (rc == HARK_ENOMEM) {                                                     // no room for the partition workspace: the sort-merge path
@@ -1354,12 +1363,13 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
         return HARK_OK;
     }
     if (rc) { cleanup(); return rc; }
-    if (hipMemsetAsync(info, 0, 32, st) != hipSuccess) { cleanup(); return hark_fail(ctx, HARK_EHIP, "join: workspace memset failed"); }
     int32_t *err = reinterpret_cast<int32_t *>(info + 1);
     unsigned long long *total = reinterpret_cast<unsigned long long *>(info);
-    if (no_hot) HIP_TRY_RC(ctx, rc, hipMemsetAsync(hot, 0, sizeof(JHotHead), st));   // no hot keys, no candidates
-    else {
-        HIP_TRY_RC(ctx, rc, hipMemsetAsync(hot_block, 0, hot_clear + sizeof(JHotHead), st));
+    {
+        const size_t n16 = (hot_clear + sizeof(JHotHead) + 15) / 16;             // (the block is longer: the rest of the set lies behind the head)
+        HARK_LAUNCH_RC(ctx, rc, jclear_kernel<<<dim3((unsigned)std::min<size_t>((n16 + 255) / 256, (size_t)ctx->num_cu * 8)), 256, 0, st>>>(reinterpret_cast<uint4 *>(hot_block), n16));
+    }
+    if (!no_hot) {
         HARK_LAUNCH_RC(ctx, rc, jhot_sample_kernel<K><<<(S + 1023) / 1024, 1024, 0, st>>>(lcol, n, bias, S, tkey, tcnt, tslots - 1u, cmin, hot));
         HARK_LAUNCH_RC(ctx, rc, jhot_select_kernel<K><<<1, 1024, 0, st>>>(tkey, tcnt, cmin, rkeys, s, hot));
     }
