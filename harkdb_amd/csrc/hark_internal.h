@@ -42,6 +42,7 @@ struct hark_context {
     int last_groupby_path = 0;
     int last_groupby_passes = 0;             // row passes of the last dense-path filter_groupby (hark_context_last_groupby_passes)
     int last_join_path = 0;        // hark_context_last_join_path
+    bool last_join_weighted = false;   // ... the partitioned path cut its buckets by the sampled probe rows' weight (k_hjoin.hip)
 };
 
 // Every entry runs on the context's device whatever device the calling thread has current (a process may hold

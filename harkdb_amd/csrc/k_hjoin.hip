@@ -9,6 +9,8 @@
 //   2. P - 1 splitters are read off the sorted build keys at equal distances, so every bucket owns
 //      a contiguous slice of ~s / P sorted build entries WHATEVER the key distribution is, and
 //      buckets are ordered by key (a hash would balance as well but lose the reference's order);
+//      when a sample of the probe keys shows them crowding a stretch of the build side, the cut is
+//      made by the sampled rows' weight instead (jhot_select_kernel);
 //   3. jpart_kernel streams the PROBE keys once (non-temporal, 16 B per lane), drops keys outside
 //      [min, max] of the build side, finds each row's bucket (an interpolation guess checked against
 //      four splitters in LDS, binary search when the guess is off by more than one) and routes
@@ -61,7 +63,8 @@ struct __attribute__((aligned(16))) JPair64 { uint64_t key; uint32_t row, pad; }
 // survivor 10240 x 12 B + 6144 counters, without 12288 x 8 B + 10240 counters (~150 KiB of LDS either way)
 constexpr int kStage = 12288, kStageCarry = 10240, kFine = 10240, kFineCarry = 6144, kCoarse = 2048, kTieMax = 64;
 constexpr int kLongMax = kStage / (kTieMax + 1) + 1;      // runs of more than kTieMax rows that fit the stage
-constexpr int kWaveSortMax = 1024;                        // ... sorted by one wave up to this length, by the workgroup beyond
+constexpr int kWaveSortMax = 2048;                        // ... sorted by one wave up to this length (sixteen runs at a time), by the whole workgroup beyond (one after the other:
+                                                          // a hundred neighbouring keys with ~1000 rows each took 1.3 ms that way while this was 1024)
 // the stage by words per survivor: (rank, left row) + the carried column + the probe key's low word (64-bit keys: confirmed at write-out)
 constexpr int stage_of(int extra_words) { return extra_words == 0 ? kStage : extra_words == 1 ? kStageCarry : 8192; }
 constexpr int fine_of(int extra_words) { return extra_words == 0 ? kFine : extra_words == 1 ? kFineCarry : 4096; }
@@ -121,21 +124,6 @@ __device__ __forceinline__ bool jwg_or(bool pred, uint32_t *flags, int &phase)
     return flags[s] != 0u;
 }
 
-// bstart[b] = first sorted build position of bucket b (b = 0..P), splitters[b-1] = first key of bucket b (b = 1..P-1).
-template <typename K>
-__global__ __launch_bounds__(256) void jsplit_kernel(const K *__restrict__ rkeys, int64_t s, int P, K *__restrict__ splitters, uint32_t *__restrict__ bstart)
-{
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b > P) return;
-    if (b == 0) { bstart[0] = 0u; return; }
-    if (b == P) { bstart[P] = (uint32_t)s; return; }
-    const K key = rkeys[(int64_t)b * s / P];
-    int64_t lo = 0, hi = s;
-    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (rkeys[mid] < key) lo = mid + 1; else hi = mid; }
-    bstart[b] = (uint32_t)lo;
-    splitters[b - 1] = key;
-}
-
 // runlen[i] = number of build entries equal to rkeys[i] when i starts a run, else 0.
 template <typename K>
 __global__ __launch_bounds__(256) void jrunlen_kernel(const K *__restrict__ rkeys, int64_t s, uint32_t *__restrict__ runlen, int32_t *__restrict__ dup)
@@ -184,7 +172,7 @@ __global__ __launch_bounds__(256) void jcnt_kernel(const uint32_t *__restrict__ 
 //      row of the bucket moves back by the blocks before it) and reports where they start, and jhot_place_kernel copies
 //      the groups there.
 // One more pass over the probe keys, paid only when a hot key exists (the kernels leave at once when the set is empty).
-constexpr int kHotMax = 256, kHotSlots = 1024, kHotCand = 4096, kHotSampleMax = 131072;
+constexpr int kHotMax = 256, kHotSlots = 1024, kHotCand = 4096, kHotSampleMax = 131072, kQuant = 4096;
 constexpr uint32_t kNoRank = 0xFFFFFFFFu;
 constexpr uint16_t kNoHot = 0xFFFFu;
 
@@ -222,13 +210,18 @@ template <typename K> __device__ __forceinline__ uint32_t jhot_find(const K *slo
 // 13000 of them) would otherwise queue up behind ONE word of the table.
 template <typename K>
 __global__ __launch_bounds__(1024) void jhot_sample_kernel(const K *__restrict__ keys, int64_t n, K bias, uint32_t S, unsigned long long *__restrict__ tkey,
-                                                           uint32_t *__restrict__ tcnt, uint32_t mask, uint32_t cmin, JHotHead *__restrict__ hot)
+                                                           uint32_t *__restrict__ tcnt, uint32_t mask, uint32_t cmin, JHotHead *__restrict__ hot,
+                                                           const K *__restrict__ rkeys, int64_t s, uint32_t *__restrict__ hcoarse, int P)
 {
     constexpr int LS = 2048;                                              // local slots: twice the samples
     __shared__ unsigned long long s_key[LS];
     __shared__ uint32_t s_cnt[LS];
+    __shared__ K s_q[kQuant];                                             // every (s / kQuant)-th sorted build key: where a sampled key falls, to 1 / kQuant of the build side
+    __shared__ uint32_t s_coarse[1024];                                   // this workgroup's samples per even bucket (P <= 1024): added to hcoarse once
     const uint32_t t = blockIdx.x * 1024u + threadIdx.x;
+    s_coarse[threadIdx.x] = 0u;
     for (int i = threadIdx.x; i < LS; i += 1024) { s_key[i] = ~0ull; s_cnt[i] = 0u; }
+    for (int i = threadIdx.x; i < kQuant; i += 1024) s_q[i] = rkeys[(int64_t)(((uint64_t)i * (uint64_t)s) / kQuant)];
     __syncthreads();
     if (t < S) {
         const uint64_t stride = (uint64_t)n / S;                          // >= 1: S <= n
@@ -257,6 +250,43 @@ __global__ __launch_bounds__(1024) void jhot_sample_kernel(const K *__restrict__
         }
         const uint32_t before = atomicAdd(&tcnt[slot], c);
         if (before < cmin && before + c >= cmin) { const uint32_t at = atomicAdd(&hot->ncand, 1u); if (at < (uint32_t)kHotCand) hot->cand[at] = slot; }
+        // where the sampled rows fall in the sorted build side, per bucket of the even cut (to 1 / kQuant of the build side: the
+        // quantile keys in LDS): jhot_select_kernel sees from it whether the probe rows crowd a stretch of the build side.
+        // Keys outside the build side's range are dropped by the partition and weigh nothing.
+        const K key = (K)k;
+        if (key >= s_q[0] && key <= rkeys[s - 1]) {
+            int lo = 0, hi = kQuant;                                       // the number of quantile keys <= key, less one: its stretch
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_q[mid] <= key) lo = mid; else hi = mid; }
+            atomicAdd(&s_coarse[(uint32_t)(((uint64_t)lo * (uint64_t)P) / kQuant)], c);
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < P && s_coarse[threadIdx.x]) atomicAdd(&hcoarse[threadIdx.x], s_coarse[threadIdx.x]);
+}
+
+// The sampled keys' places in the sorted build side, cell by cell (cells of s / cells ranks) -- only when the buckets are to be cut
+// by weight (info[4], decided by jhot_select_kernel): one binary search per distinct sampled key that is no hot key.
+template <typename K>
+__global__ __launch_bounds__(256) void jhot_fine_kernel(const unsigned long long *__restrict__ tkey, const uint32_t *__restrict__ tcnt, uint32_t tslots,
+                                                        const K *__restrict__ rkeys, int64_t s, const JHotSet<K> *__restrict__ hot, const int64_t *__restrict__ info,
+                                                        uint32_t *__restrict__ hfine, uint32_t cells)
+{
+    if (info[4] == 0) return;
+    __shared__ K s_slots[kHotSlots];
+    const bool any_hot = hot->H != 0u;
+    const K empty = any_hot ? hot->empty : (K)0;
+    if (any_hot) for (int i = threadIdx.x; i < kHotSlots; i += 256) s_slots[i] = hot->slots[i];
+    __syncthreads();
+    const K kmin = rkeys[0], kmax = rkeys[s - 1];
+    const uint32_t stride = gridDim.x * 256u;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < tslots; i += stride) {
+        const unsigned long long k1 = tkey[i];
+        if (k1 == 0ull) continue;
+        const K key = (K)(k1 - 1ull);
+        if (key < kmin || key > kmax || (any_hot && jhot_find<K>(s_slots, empty, key) != ~0u)) continue;   // (a hot key's rows do not go through the partition)
+        int64_t lo = 0, hi = s;
+        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (rkeys[mid] < key) lo = mid + 1; else hi = mid; }
+        atomicAdd(&hfine[(uint32_t)(((uint64_t)lo * cells) / (uint64_t)s)], tcnt[i]);
     }
 }
 
@@ -269,10 +299,11 @@ __global__ __launch_bounds__(256) void jclear_kernel(uint4 *__restrict__ p, size
 }
 
 template <typename K>
-__global__ __launch_bounds__(1024) void jhot_select_kernel(const unsigned long long *__restrict__ tkey, const uint32_t *__restrict__ tcnt, uint32_t cmin,
-                                                           const K *__restrict__ rkeys, int64_t s, JHotSet<K> *__restrict__ hot)
+__device__ __forceinline__ void jhot_select_body(const unsigned long long *__restrict__ tkey, const uint32_t *__restrict__ tcnt, uint32_t cmin,
+                                                 const K *__restrict__ rkeys, int64_t s, JHotSet<K> *__restrict__ hot, uint32_t *__restrict__ hcoarse, int P)
 {
     __shared__ K s_key[kHotMax];
+    __shared__ uint32_t s_cs[kHotMax];                                    // the sample-table slot of the key (its number of samples)
     __shared__ uint32_t s_rank[kHotMax];                                  // by place in ascending key order
     __shared__ K s_slots[kHotSlots];
     __shared__ uint16_t s_p[kHotSlots];
@@ -297,7 +328,7 @@ __global__ __launch_bounds__(1024) void jhot_select_kernel(const unsigned long l
     __syncthreads();
     for (uint32_t i = tid; i < nc; i += 1024) {
         const uint32_t slot = hot->cand[i];
-        if (tcnt[slot] >= thr) s_key[atomicAdd(&s_n, 1u)] = (K)(tkey[slot] - 1ull);
+        if (tcnt[slot] >= thr) { const uint32_t at = atomicAdd(&s_n, 1u); s_key[at] = (K)(tkey[slot] - 1ull); s_cs[at] = slot; }
     }
     __syncthreads();
     const int H = (int)s_n;
@@ -310,6 +341,12 @@ __global__ __launch_bounds__(1024) void jhot_select_kernel(const unsigned long l
         int64_t lo = 0, hi = s;
         while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (rkeys[mid] < mykey) lo = mid + 1; else hi = mid; }
         s_rank[pos] = (lo < s && rkeys[lo] == mykey) ? (uint32_t)lo : kNoRank;
+        if (mykey >= rkeys[0] && mykey <= rkeys[s - 1]) {                 // its rows do not go through the partition: they weigh nothing in the cut
+            // (the stretch the sample kernel counted it in: the last quantile key <= mykey)
+            int qa = 0, qz = kQuant;
+            while (qz - qa > 1) { const int mid = (qa + qz) >> 1; if (rkeys[(int64_t)(((uint64_t)mid * (uint64_t)s) / kQuant)] <= mykey) qa = mid; else qz = mid; }
+            atomicSub(&hcoarse[(uint32_t)(((uint64_t)qa * (uint64_t)P) / kQuant)], tcnt[s_cs[tid]]);
+        }
     }
     if (tid <= H) {                                                       // the smallest of 0 .. H that is no hot key marks the free slots
         bool used = false;
@@ -335,6 +372,113 @@ __global__ __launch_bounds__(1024) void jhot_select_kernel(const unsigned long l
     __syncthreads();
     hot->slots[tid] = s_slots[tid]; hot->slot_p[tid] = s_p[tid];
     if (tid == 0) { hot->empty = empty; hot->H = (uint32_t)H; hot->Hp = (uint32_t)hp; }
+}
+
+// The hot keys (above), then the BUCKETS: bstart[b] = first sorted build position of bucket b (b = 0..P), splitters[b - 1] = first
+// key of bucket b.  Evenly spread probe keys: P equal slices of the sorted build side, whatever its key distribution
+// (rank b s / P).  But probe rows may crowd a stretch of the build side without any single key being frequent enough
+// for the sample to call it hot -- ten thousand neighbouring keys with three thousand rows each: a third of the probe side
+// in ONE even bucket, whose slabs overflow (11.9 ms through the sort-merge path, profiles/r05_join_skew.txt).  The sample says
+// where the rows fall (hfine: samples per cell of s / cells ranks; hcoarse: per even bucket); when an even bucket holds more
+// than 1.5 x its share (+ noise), the cut is made by WEIGHT instead: a bucket ends where 0.2 x (share of the build entries)
+// + 0.8 x (share of the sampled rows) reaches b / P -- at most 1.25 x the even share of the probe rows (+ a cell) and at most
+// 5 x the even share of the build entries (more rounds for a bucket with few probe rows).  One workgroup; the scan of the
+// cells runs only when the cut is by weight.
+template <typename K>
+__global__ __launch_bounds__(1024) void jhot_select_kernel(const unsigned long long *__restrict__ tkey, const uint32_t *__restrict__ tcnt, uint32_t cmin,
+                                                           const K *__restrict__ rkeys, int64_t s, JHotSet<K> *__restrict__ hot, uint32_t *__restrict__ hcoarse, int P,
+                                                           K *__restrict__ splitters, uint32_t *__restrict__ bstart, int allow_weighted, int64_t *__restrict__ info)
+{
+    __shared__ unsigned long long s_T;
+    __shared__ uint32_t s_max;
+    const int tid = threadIdx.x, lane = tid & 63;
+    jhot_select_body<K>(tkey, tcnt, cmin, rkeys, s, hot, hcoarse, P);
+    if (tid == 0) { s_T = 0ull; s_max = 0u; }
+    __syncthreads();
+    {   // how crowded is the most crowded even bucket?
+        uint32_t v = tid < P ? hcoarse[tid] : 0u, mx = v;
+        unsigned long long sum = v;
+        for (int d = 32; d > 0; d >>= 1) { sum += __shfl_down(sum, d, 64); mx = max(mx, (uint32_t)__shfl_down((int)mx, d, 64)); }
+        if (lane == 0 && sum) { atomicAdd(&s_T, sum); atomicMax(&s_max, mx); }
+    }
+    __syncthreads();
+    const double mean = (double)s_T / (double)P;
+    const bool weighted = allow_weighted && s_T >= 2048ull && (double)s_max > 1.5 * mean + 5.0 * sqrt(mean) + 8.0 && s >= 4 * (int64_t)P;
+    if (tid <= P) {                                                       // the even cut (jhot_cut_kernel overrides it when the cut is by weight)
+        const int b = tid;
+        if (b == 0) bstart[0] = 0u;
+        else if (b == P) bstart[P] = (uint32_t)s;
+        else {
+            const K key = rkeys[(int64_t)b * s / P];
+            int64_t lo = 0, hi = s;                                    // a run of equal keys is never cut
+            while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (rkeys[mid] < key) lo = mid + 1; else hi = mid; }
+            bstart[b] = (uint32_t)lo;
+            splitters[b - 1] = key;
+        }
+    }
+    if (tid == 0) info[4] = weighted ? 1 : 0;                            // (jhot_fine_kernel / jhot_cut_kernel run on it; the host reads it with the totals)
+}
+
+// The cut by weight (see above; both kernels leave at once otherwise).  First the cells' counts -> a running sum inside chunks of
+// kCutChunk cells (one workgroup each: a single workgroup took 0.35 ms over 2^20 cells), the chunks' totals aside; then bucket b
+// ends behind the first cell c with
+//     2 (c + 1) T + 8 C rows(c) >= 10 C T b / P      (0.2 x the build entries' share + 0.8 x the sampled rows' share reaches b / P).
+constexpr int kCutChunk = 16384;
+__global__ __launch_bounds__(1024) void jhot_scan_cells_kernel(uint32_t *__restrict__ hfine, uint32_t cells, uint32_t *__restrict__ ctot, const int64_t *__restrict__ info)
+{
+    if (info[4] == 0) return;
+    __shared__ uint32_t s_w2[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t base = blockIdx.x * (uint32_t)kCutChunk + (uint32_t)tid * 16u;
+    uint4 q[4];
+    uint4 *v = reinterpret_cast<uint4 *>(hfine + base);
+    const bool mine = base < cells;                                       // (cells is a multiple of 16)
+#pragma unroll
+    for (int k = 0; k < 4; k++) q[k] = mine ? v[k] : uint4{0u, 0u, 0u, 0u};
+    uint32_t run = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { q[k].x += run; q[k].y += q[k].x; q[k].z += q[k].y; q[k].w += q[k].z; run = q[k].w; }
+    uint32_t incl = run;
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d, 64); if (lane >= d) incl += y; }
+    if (lane == 63) s_w2[wave] = incl;
+    __syncthreads();
+    uint32_t before = incl - run, total = 0;
+    for (int w = 0; w < 16; w++) { const uint32_t x = s_w2[w]; if (w < wave) before += x; total += x; }
+    if (mine) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) { q[k].x += before; q[k].y += before; q[k].z += before; q[k].w += before; v[k] = q[k]; }
+    }
+    if (tid == 0) ctot[blockIdx.x] = total;
+}
+
+template <typename K>
+__global__ __launch_bounds__(1024) void jhot_cut_kernel(const K *__restrict__ rkeys, int64_t s, const uint32_t *__restrict__ hfine, uint32_t cells, const uint32_t *__restrict__ ctot,
+                                                        int P, K *__restrict__ splitters, uint32_t *__restrict__ bstart, const int64_t *__restrict__ info)
+{
+    if (info[4] == 0) return;
+    __shared__ uint32_t s_cpre[64 + 1];                                   // rows before a chunk (2^20 cells: 64 chunks)
+    const int tid = threadIdx.x;
+    const uint32_t nchunks = (cells + (uint32_t)kCutChunk - 1u) / (uint32_t)kCutChunk;
+    if (tid == 0) { uint32_t run = 0; for (uint32_t c = 0; c < nchunks; c++) { s_cpre[c] = run; run += ctot[c]; } s_cpre[nchunks] = run; }
+    __syncthreads();
+    const unsigned long long Tf = s_cpre[nchunks];
+    if (tid >= 1 && tid < P && Tf) {
+        const int b = tid;
+        const unsigned long long C = cells, want = (10ull * C * Tf * (unsigned long long)b) / (unsigned long long)P;
+        uint32_t lo = 0, hi = cells - 1u;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            const unsigned long long rows = (unsigned long long)s_cpre[mid / (uint32_t)kCutChunk] + hfine[mid];
+            if (2ull * (mid + 1ull) * Tf + 8ull * C * rows >= want) hi = mid; else lo = mid + 1u;
+        }
+        int64_t pos = (int64_t)(((unsigned long long)(lo + 1u) * (unsigned long long)s) / C);
+        if (pos > s - 1) pos = s - 1;
+        const K key = rkeys[pos];
+        int64_t a = 0, z = s;                                            // a run of equal keys is never cut
+        while (a < z) { const int64_t mid = (a + z) >> 1; if (rkeys[mid] < key) a = mid + 1; else z = mid; }
+        bstart[b] = (uint32_t)a;
+        splitters[b - 1] = key;
+    }
 }
 
 // btotal[batch] (rows of the batch that carry a hot key with partners, counted by the partition kernel) -> exclusive prefix:
@@ -953,7 +1097,11 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
                                                            uint32_t *__restrict__ rval_out /* ... read off for every survivor (unique build keys: survivor = output row) */,
                                                            const uint4 *__restrict__ srec /* VERIFY (64-bit keys): the survivors as records (rank, left row, carried word, probe-key low word); `surv` is not used then */,
                                                            const uint64_t *__restrict__ rkeys64 /* VERIFY: the sorted build keys */,
-                                                           JHotHead *__restrict__ hot /* the hot keys' blocks: left free here, their first rows reported (pdst) */)
+                                                           JHotHead *__restrict__ hot /* the hot keys' blocks: left free here, their first rows reported (pdst) */,
+                                                           void *__restrict__ scratch_all, size_t scratch_stride /* per bucket: room for all of its survivors (the partition's slabs,
+                                                                                                                  read for the last time by the bucket kernel) */,
+                                                           int pieces_ok /* 0: a group of ranks with more survivors than the stage holds sends the bucket to the caller's radix
+                                                                            sorts (cheap while the join has few matching rows); 1: it is taken rank by rank here */)
 {
     constexpr int XW = (CARRY ? 1 : 0) + (VERIFY ? 1 : 0), STAGE = stage_of(XW), FINE = fine_of(XW), RPT = STAGE / kJThreads;
     static_assert(RPT * kJThreads == STAGE, "a sub-round's survivors are dealt RPT to a lane");
@@ -967,12 +1115,12 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
     __shared__ uint32_t s_wave[kJThreads / 64];
     __shared__ uint32_t s_bincnt[kBinSlots];
     __shared__ uint32_t s_np;
-    __shared__ int s_bad;
+    __shared__ int s_bad, s_big;
     __shared__ uint32_t s_h0, s_nh, s_nlong;
     __shared__ uint32_t s_hrank[kHotMax], s_hcum[kHotMax + 1];               // the bucket's hot ranks (ascending), the hot rows before each (inside the bucket)
     __shared__ uint2 s_long[kLongMax];                                       // runs of more than kTieMax rows in the stage (first, length)
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) { s_dst = 0ull; s_bad = 0; s_np = 0u; s_h0 = 0u; s_nh = 0u; s_nlong = 0u; }
+    if (tid == 0) { s_dst = 0ull; s_bad = 0; s_big = 0; s_np = 0u; s_h0 = 0u; s_nh = 0u; s_nlong = 0u; }
     if (tid < kBinSlots) s_bincnt[tid] = sbins[(size_t)b * kBinSlots + tid];
     __syncthreads();
     const uint32_t Hp = hot->Hp;                                           // hot keys with partners: dense and ascending, so a bucket's are a range [h0, h0 + nh)
@@ -1007,6 +1155,7 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
     const int gs = bins.gs;                                                    // a bin = bins.gw consecutive groups
     const uint2 *src = VERIFY ? nullptr : surv + (size_t)b * region;
     const uint4 *srcr = VERIFY ? srec + (size_t)b * region : nullptr;
+    bool contig = false;                                                   // the bucket's survivors were regrouped (below): src / srcr then hold them group after group
     static_assert(VERIFY || !CARRY, "a carried column travels in the 16-byte records of the 64-bit path");
     bool mismatch = false;
     const uint32_t ngroups = (len + (1u << gs) - 1u) >> gs;
@@ -1038,6 +1187,7 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
     };
     // the bins that hold the ranks of groups [g0, g1)
     auto sweep_bins = [&](uint32_t g0, uint32_t g1, auto &&f) {
+        if (contig) { sweep((size_t)coarse[g0], coarse[g1] - coarse[g0], f); return; }      // (coarse: the scanned counts, see below)
         for (uint32_t j = bins.bin_of_group(g0); j <= bins.bin_of_group(g1 - 1u); j++) sweep((size_t)j * bins.cap, s_bincnt[j], f);
         if (s_bincnt[kMaxBins]) sweep((size_t)bins.ov_at, s_bincnt[kMaxBins], f);      // the overflow area holds rows of any rank (f looks at the rank)
     };
@@ -1058,12 +1208,13 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
         __syncthreads();
         return total;
     };
-    {   // a group that cannot be staged: heavy skew
+    {   // a bucket of more than kCoarse * kFine sorted build entries (the cut never splits a run of equal keys, so one build
+        // key repeated ~1.7e7 times gives one): a single group of 2^gs ranks would not fit the fine counters.  (A group with more
+        // survivors than the stage holds is NOT a reason any more: it is taken rank by rank, below.)
+        if ((1u << gs) > (uint32_t)FINE && tid == 0) s_bad = 1;
         bool big = false;
         for (uint32_t i = tid; i < ngroups; i += kJThreads) big = big || coarse[i] > (uint32_t)stage_cap;
-        // a bucket of more than kCoarse * kFine sorted build entries (jsplit never splits a run of equal keys, so one build
-        // key repeated ~1.7e7 times gives one): a single group of 2^gs ranks would not fit the fine counters
-        if (big || (1u << gs) > (uint32_t)FINE) s_bad = 1;
+        if (big) { s_big = 1; if (!pieces_ok) s_bad = 1; }
     }
     __syncthreads();
     const bool bad = s_bad != 0;
@@ -1090,6 +1241,27 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
         if (mismatch) general[2] = 1;
         return;
     }
+    // ---- a bucket whose probe rows crowd a few ranks (survivors in the overflow area, which every sub-round would sweep, or a
+    // group of ranks with more survivors than the stage holds, taken in pieces that each sweep its whole bin): ONE pass
+    // brings the bucket's survivors into group order first -- the bucket kernel's counts per group, scanned, are the places --
+    // in the bucket's slabs of the partition (read for the last time by the bucket kernel).  Every sub-round then reads its
+    // groups' survivors as one contiguous range, a piece of a crowded group sweeps that group alone.
+    if (s_big != 0 || s_bincnt[kMaxBins] != 0u) {
+        for (uint32_t g = tid; g < ngroups; g += kJThreads) fine[g] = coarse[g];     // cursors (FINE >= kCoarse)
+        __syncthreads();
+        uint2 *sc2 = static_cast<uint2 *>(scratch_all) + (size_t)b * scratch_stride;
+        uint4 *sc4 = static_cast<uint4 *>(scratch_all) + (size_t)b * scratch_stride;
+        auto regroup_one = [&](uint2 e, uint32_t v, uint32_t kl) {
+            const uint32_t at = atomicAdd(&fine[(e.x - lo) >> gs], 1u);
+            if (!VERIFY) sc2[at] = e; else sc4[at] = uint4{e.x, e.y, v, kl};
+        };
+        for (uint32_t j = 0; j < (uint32_t)bins.nb; j++) sweep((size_t)j * bins.cap, s_bincnt[j], regroup_one);
+        if (s_bincnt[kMaxBins]) sweep((size_t)bins.ov_at, s_bincnt[kMaxBins], regroup_one);
+        __threadfence();
+        __syncthreads();
+        if (VERIFY) srcr = sc4; else src = sc2;
+        contig = true;
+    }
     const uint32_t max_groups = max(1u, (uint32_t)FINE >> gs);
     bool too_long = false;
     // the end of the sub-round that starts at group g0: the largest g1 with coarse[g1] - coarse[g0] <= stage_cap and
@@ -1111,54 +1283,23 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
             if (rr >= r0 && rr < r1) hot->pdst[h0 + tid] = dst + base_cnt + s_hcum[tid];
         }
         if (nsub) {
-            auto count_one = [&](uint2 e, uint32_t, uint32_t) { const uint32_t r = e.x - lo - r0; if (r < nr) atomicAdd(&fine[r], 1u); };
+            // the window of ranks being staged: [w_r0, w_r0 + w_nr) of the bucket, w_base survivors of the bucket before it, w_nsub in it
+            uint32_t w_r0 = r0, w_nr = nr, w_base = base_cnt, w_nsub = nsub;
+            auto count_one = [&](uint2 e, uint32_t, uint32_t) { const uint32_t r = e.x - lo - w_r0; if (r < w_nr) atomicAdd(&fine[r], 1u); };
             auto place_one = [&](uint2 e, uint32_t v, uint32_t kl) {
-                const uint32_t r = e.x - lo - r0;
-                if (r < nr) { const uint32_t at = atomicAdd(&fine[r], 1u); stage[at] = e; if (CARRY) stv[at] = v; if (VERIFY) stk[at] = kl; }   // afterwards fine[r] = end of rank r's rows
+                const uint32_t r = e.x - lo - w_r0;
+                if (r < w_nr) { const uint32_t at = atomicAdd(&fine[r], 1u); stage[at] = e; if (CARRY) stv[at] = v; if (VERIFY) stk[at] = kl; }   // afterwards fine[r] = end of rank r's rows
             };
-            // A sub-round of WHOLE bins (the usual case: bins are sized for the stage) holds at most STAGE = RPT x 1024 survivors:
-            // every lane reads its RPT of them ONCE, keeps them in registers over the histogram, the scan and the placement.  (Two
-            // sweeps over memory before -- the first over a separate array of the ranks alone, which the bucket kernel no longer
-            // writes: 4 of 20 bytes per survivor.)  A piece of a crowded bin sweeps the whole bin twice and filters by rank.
-            const uint32_t jA = bins.bin_of_group(g0), jB = bins.bin_of_group(g1 - 1u);
-            uint32_t in_bins = 0;
-            for (uint32_t j = jA; j <= jB; j++) in_bins += s_bincnt[j];
-            const bool whole = g0 == jA * bins.gw && (g1 == ngroups || g1 == (jB + 1u) * bins.gw) && in_bins <= (uint32_t)(RPT * kJThreads) && s_bincnt[kMaxBins] == 0u;
-            if (whole) {
-                uint2 e[RPT]; uint32_t v[RPT], kl[RPT];
-#pragma unroll
-                for (int k = 0; k < RPT; k++) {
-                    uint32_t y = min(tid + (uint32_t)k * kJThreads, in_bins - 1u), j = jA;
-                    while (y >= s_bincnt[j]) { y -= s_bincnt[j]; j++; }                 // (in_bins >= nsub > 0: the walk ends inside [jA, jB])
-                    const size_t at = (size_t)j * bins.cap + y;
-                    if (!VERIFY) { e[k] = src[at]; v[k] = 0u; kl[k] = 0u; }
-                    else { const uint4 q = srcr[at]; e[k] = uint2{q.x, q.y}; v[k] = q.z; kl[k] = q.w; }
-                }
-                for (uint32_t i = tid; i <= nr; i += kJThreads) fine[i] = 0u;       // (under the loads)
-                __syncthreads();
-#pragma unroll
-                for (int k = 0; k < RPT; k++) if (tid + (uint32_t)k * kJThreads < in_bins) count_one(e[k], 0u, 0u);
-                __syncthreads();
-                scan_excl(fine, nr);
-#pragma unroll
-                for (int k = 0; k < RPT; k++) if (tid + (uint32_t)k * kJThreads < in_bins) place_one(e[k], v[k], kl[k]);
-            } else {
-                for (uint32_t i = tid; i <= nr; i += kJThreads) fine[i] = 0u;
-                __syncthreads();
-                sweep_bins(g0, g1, count_one);
-                __syncthreads();
-                scan_excl(fine, nr);
-                sweep_bins(g0, g1, place_one);
-            }
+            auto finish_window = [&]() {
             __syncthreads();
             if ((uint32_t)tid < nh) {                                   // a hot key's block starts behind the rows of the smaller ranks (it has none of its own here)
                 const uint32_t rr = s_hrank[tid] - lo;
-                if (rr >= r0 && rr < r1) hot->pdst[h0 + tid] = dst + base_cnt + (rr > r0 ? fine[rr - r0 - 1u] : 0u) + s_hcum[tid];
+                if (rr >= w_r0 && rr < w_r0 + w_nr) hot->pdst[h0 + tid] = dst + w_base + (rr > w_r0 ? fine[rr - w_r0 - 1u] : 0u) + s_hcum[tid];
             }
             // ---- a rank with more than kTieMax rows (a key too rare for the sample, too frequent for the counting below): its
             // run of the stage is sorted by left row in place, one wave per run -- a bitonic network over the run padded to a power
             // of two (the padding is never touched: every exchange moves the smaller row to the lower index)
-            for (uint32_t r = tid; r < nr; r += kJThreads) {
+            for (uint32_t r = tid; r < w_nr; r += kJThreads) {
                 const uint32_t a0 = r ? fine[r - 1u] : 0u, a1 = fine[r];
                 if (a1 - a0 > (uint32_t)kTieMax) s_long[atomicAdd(&s_nlong, 1u)] = uint2{a0, a1 - a0};   // (at most STAGE / (kTieMax + 1) of them)
             }
@@ -1179,12 +1320,15 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
             auto bitonic = [&](uint32_t a0, uint32_t L, uint32_t me, uint32_t width, auto &&sync) {
                 uint32_t p2 = 128u;
                 while (p2 < L) p2 <<= 1;
-                for (uint32_t k = 2u; k <= p2; k <<= 1) {
-                    const uint32_t hk = k >> 1;
-                    for (uint32_t x = me; x < (p2 >> 1); x += width) { const uint32_t blk = x / hk, off = x % hk; exchange(a0, L, blk * k + off, blk * k + k - 1u - off); }
+                // (every stride is a power of two: shifts and masks -- with x / hk and x % hk on run-time values the network spent most of
+                // its instructions dividing: 14 ns per element and run)
+                for (uint32_t lk = 1u; (1u << lk) <= p2; lk++) {
+                    const uint32_t lhk = lk - 1u, hmask = (1u << lhk) - 1u, kk = 1u << lk;
+                    for (uint32_t x = me; x < (p2 >> 1); x += width) { const uint32_t blk = x >> lhk, off = x & hmask, base = blk << lk; exchange(a0, L, base + off, base + kk - 1u - off); }
                     sync();
-                    for (uint32_t jj = hk >> 1; jj >= 1u; jj >>= 1) {
-                        for (uint32_t x = me; x < (p2 >> 1); x += width) { const uint32_t i = 2u * jj * (x / jj) + x % jj; exchange(a0, L, i, i + jj); }
+                    for (uint32_t lj = lhk; lj-- > 0u;) {
+                        const uint32_t jj = 1u << lj;
+                        for (uint32_t x = me; x < (p2 >> 1); x += width) { const uint32_t i = ((x >> lj) << (lj + 1u)) | (x & (jj - 1u)); exchange(a0, L, i, i + jj); }
                         sync();
                     }
                 }
@@ -1200,19 +1344,19 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
             // lane per rank: lanes of a wave held runs of 2..16 rows, so every wave ran the 4-, 8- and 16-input networks on
             // 64-bit words one after the other -- ~1400 vector instructions per wave and sub-round against ~250 here -- and
             // then wrote the stage out in a separate pass.)
-            const unsigned long long o = dst + base_cnt;
+            const unsigned long long o = dst + w_base;
             // four survivors per lane at a time: their LDS round trips and the reads through the rank overlap
             constexpr int kB = 4;
-            for (uint32_t i0 = tid; i0 < nsub; i0 += kB * kJThreads) {
+            for (uint32_t i0 = tid; i0 < w_nsub; i0 += kB * kJThreads) {
                 uint2 e[kB]; uint32_t s0[kB], s1[kB], at[kB], v3[kB], kl[kB], rv[kB], rl[kB], rk[kB];
 #pragma unroll
                 for (int q = 0; q < kB; q++) {
-                    const uint32_t i = min(i0 + (uint32_t)q * kJThreads, nsub - 1u);
+                    const uint32_t i = min(i0 + (uint32_t)q * kJThreads, w_nsub - 1u);
                     e[q] = stage[i]; v3[q] = CARRY ? stv[i] : 0u; kl[q] = VERIFY ? stk[i] : 0u; at[q] = i;
                 }
 #pragma unroll
                 for (int q = 0; q < kB; q++) {
-                    const uint32_t r = e[q].x - lo - r0;
+                    const uint32_t r = e[q].x - lo - w_r0;
                     s0[q] = r ? fine[r - 1] : 0u; s1[q] = fine[r];
                     rv[q] = rranked ? rranked[e[q].x] : 0u;               // ranks ascend along the stage: an (almost) sequential read
                     rl[q] = cnt_out ? runlen[e[q].x] : 0u;
@@ -1229,7 +1373,7 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
                 }
 #pragma unroll
                 for (int q = 0; q < kB; q++) {
-                    if (i0 + (uint32_t)q * kJThreads < nsub) {
+                    if (i0 + (uint32_t)q * kJThreads < w_nsub) {
                         const unsigned long long w = o + at[q] + hot_shift(e[q].x);
                         if (VERIFY && rk[q] != kl[q]) mismatch = true;             // a hit on a truncated key that is none
                         if (rank) { rank[w] = e[q].x; lrow[w] = e[q].y; }           // null: every result column arrives through lval_out / rval_out
@@ -1240,6 +1384,89 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
                 }
             }
             __syncthreads();
+            };
+            if (nsub > (uint32_t)stage_cap) {
+                // ---- ONE group of 2^gs ranks with more survivors than the stage holds (probe rows crowding a few neighbouring keys,
+                // none of them frequent enough for the sample): taken in pieces of whole ranks.  Every piece counts the survivors
+                // of the group's remaining ranks (a sweep of the group's bin and the overflow area), takes as many ranks as fit
+                // the stage and places those (a second sweep).  A single rank that does not fit goes out as it is, and the caller's
+                // radix sorts order everything (*general).
+                uint32_t ra = 0, done = 0;
+                while (ra < nr) {
+                    w_r0 = r0 + ra; w_nr = nr - ra;
+                    for (uint32_t i = tid; i <= w_nr; i += kJThreads) fine[i] = 0u;
+                    __syncthreads();
+                    sweep_bins(g0, g1, count_one);
+                    __syncthreads();
+                    scan_excl(fine, w_nr + 1u);                            // fine[r] = survivors of the ranks [w_r0, w_r0 + r)
+                    uint32_t a = 0, z = w_nr;                              // the most ranks whose survivors fit
+                    while (a < z) { const uint32_t mid = (a + z + 1u) >> 1; if (fine[mid] <= (uint32_t)stage_cap) a = mid; else z = mid - 1u; }
+                    if (a == 0u) {                                         // rank w_r0 alone is too much: its rows as they come
+                        const uint32_t cnt1 = fine[1];
+                        __syncthreads();
+                        if (tid == 0) fine[0] = 0u;
+                        __syncthreads();
+                        auto dump_one = [&](uint2 e, uint32_t v, uint32_t kl) {
+                            if (e.x - lo != w_r0) return;
+                            const unsigned long long w = dst + base_cnt + done + atomicAdd(&fine[0], 1u) + hot_shift(e.x);
+                            if (rank) { rank[w] = e.x; lrow[w] = e.y; }
+                            if (cnt_out) cnt_out[w] = runlen[e.x];
+                            if (CARRY) lval_out[w] = v;
+                            if (rranked) rval_out[w] = rranked[e.x];
+                            if (VERIFY && (uint32_t)rkeys64[e.x] != kl) mismatch = true;
+                        };
+                        sweep_bins(g0, g1, dump_one);
+                        too_long = true;
+                        __syncthreads();
+                        ra += 1u; done += cnt1;
+                        continue;
+                    }
+                    w_nr = a; w_nsub = fine[a]; w_base = base_cnt + done;
+                    __syncthreads();                                       // (every thread has read fine[a] before the placement moves the cursors)
+                    if (w_nsub) { sweep_bins(g0, g1, place_one); finish_window(); }
+                    else if ((uint32_t)tid < nh) { const uint32_t rr = s_hrank[tid] - lo; if (rr >= w_r0 && rr < w_r0 + w_nr) hot->pdst[h0 + tid] = dst + w_base + s_hcum[tid]; }
+                    ra += a; done += w_nsub;
+                }
+                g0 = g1;
+                continue;
+            }
+            // A sub-round of WHOLE bins (the usual case: bins are sized for the stage) holds at most STAGE = RPT x 1024 survivors:
+            // every lane reads its RPT of them ONCE, keeps them in registers over the histogram, the scan and the placement.  (Two
+            // sweeps over memory before -- the first over a separate array of the ranks alone, which the bucket kernel no longer
+            // writes: 4 of 20 bytes per survivor.)  A piece of a crowded bin sweeps the whole bin twice and filters by rank.
+            const uint32_t jA = bins.bin_of_group(g0), jB = bins.bin_of_group(g1 - 1u);
+            uint32_t in_bins = 0;
+            if (contig) in_bins = nsub;                                  // (regrouped: the sub-round's survivors are one contiguous range)
+            else for (uint32_t j = jA; j <= jB; j++) in_bins += s_bincnt[j];
+            const bool whole = contig ? true
+                                      : (g0 == jA * bins.gw && (g1 == ngroups || g1 == (jB + 1u) * bins.gw) && in_bins <= (uint32_t)(RPT * kJThreads) && s_bincnt[kMaxBins] == 0u);
+            if (whole) {
+                uint2 e[RPT]; uint32_t v[RPT], kl[RPT];
+#pragma unroll
+                for (int k = 0; k < RPT; k++) {
+                    uint32_t y = min(tid + (uint32_t)k * kJThreads, in_bins - 1u), j = jA;
+                    if (!contig) while (y >= s_bincnt[j]) { y -= s_bincnt[j]; j++; }   // (in_bins >= nsub > 0: the walk ends inside [jA, jB])
+                    const size_t at = contig ? (size_t)base_cnt + y : (size_t)j * bins.cap + y;
+                    if (!VERIFY) { e[k] = src[at]; v[k] = 0u; kl[k] = 0u; }
+                    else { const uint4 q = srcr[at]; e[k] = uint2{q.x, q.y}; v[k] = q.z; kl[k] = q.w; }
+                }
+                for (uint32_t i = tid; i <= nr; i += kJThreads) fine[i] = 0u;       // (under the loads)
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < RPT; k++) if (tid + (uint32_t)k * kJThreads < in_bins) count_one(e[k], 0u, 0u);
+                __syncthreads();
+                scan_excl(fine, nr);
+#pragma unroll
+                for (int k = 0; k < RPT; k++) if (tid + (uint32_t)k * kJThreads < in_bins) place_one(e[k], v[k], kl[k]);
+            } else {
+                for (uint32_t i = tid; i <= nr; i += kJThreads) fine[i] = 0u;
+                __syncthreads();
+                sweep_bins(g0, g1, count_one);
+                __syncthreads();
+                scan_excl(fine, nr);
+                sweep_bins(g0, g1, place_one);
+            }
+            finish_window();
         }
         g0 = g1;
     }
@@ -1333,7 +1560,7 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
     // the heavy hitters (see jhot_sample_kernel): one probe key in n / S sampled; the probe column in pieces of R rows, one per wave
     JHotSet<K> *hot = nullptr;
     unsigned long long *tkey = nullptr;
-    uint32_t *tcnt = nullptr, *btotal = nullptr;
+    uint32_t *tcnt = nullptr, *btotal = nullptr, *hfine = nullptr, *hcoarse = nullptr;
     const bool no_hot = getenv("HARK_JOIN_NOHOT") != nullptr || getenv("HARK_JOIN_FULLSORT") != nullptr;      // A/B + tests
     uint32_t S = (uint32_t)std::min<int64_t>(kHotSampleMax, std::max<int64_t>(4096, n / 256)), cmin = 5;
     if (const char *e = getenv("HARK_JOIN_HOTMIN")) { const int c = atoi(e); if (c >= 2) cmin = (uint32_t)c; }   // tests: hot keys in small tables
@@ -1342,7 +1569,9 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
     const uint32_t nbatch = (uint32_t)((n + (int64_t)kJThreads * VEC - 1) / ((int64_t)kJThreads * VEC));      // the partition kernel's batches
     // one block, cleared by one launch: the survivor total and the error word (info), the sample table (keys, counts), the batches'
     // counts, the set's head; the rest of the set behind
-    const size_t hot_clear = 64 + 12 * (size_t)tslots + (4 * (size_t)nbatch + 15) / 16 * 16;
+    uint32_t cells = 4096;                                                      // cells of the sorted build side the sampled rows are counted in (about one rank each, 2^20 at most)
+    while (cells < (1u << 20) && (int64_t)cells < s) cells <<= 1;
+    const size_t hot_clear = 64 + 12 * (size_t)tslots + (4 * (size_t)nbatch + 15) / 16 * 16 + 4 * (size_t)cells + 4 * (size_t)P + 4 * 64;
     unsigned char *hot_block = nullptr;
     if (!rc) rc = hark_alloc(ctx, (void **)&hot_block, hot_clear + sizeof(JHotSet<K>));
     if (!rc) {
@@ -1350,6 +1579,8 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
         tkey = reinterpret_cast<unsigned long long *>(hot_block + 64);
         tcnt = reinterpret_cast<uint32_t *>(hot_block + 64 + 8 * (size_t)tslots);
         btotal = reinterpret_cast<uint32_t *>(hot_block + 64 + 12 * (size_t)tslots);
+        hfine = reinterpret_cast<uint32_t *>(hot_block + 64 + 12 * (size_t)tslots + (4 * (size_t)nbatch + 15) / 16 * 16);
+        hcoarse = hfine + cells;
         hot = reinterpret_cast<JHotSet<K> *>(hot_block + hot_clear);
     }
     auto cleanup = [&]() {
@@ -1370,10 +1601,15 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
         HARK_LAUNCH_RC(ctx, rc, jclear_kernel<<<dim3((unsigned)std::min<size_t>((n16 + 255) / 256, (size_t)ctx->num_cu * 8)), 256, 0, st>>>(reinterpret_cast<uint4 *>(hot_block), n16));
     }
     if (!no_hot) {
-        HARK_LAUNCH_RC(ctx, rc, jhot_sample_kernel<K><<<(S + 1023) / 1024, 1024, 0, st>>>(lcol, n, bias, S, tkey, tcnt, tslots - 1u, cmin, hot));
-        HARK_LAUNCH_RC(ctx, rc, jhot_select_kernel<K><<<1, 1024, 0, st>>>(tkey, tcnt, cmin, rkeys, s, hot));
+        HARK_LAUNCH_RC(ctx, rc, jhot_sample_kernel<K><<<(S + 1023) / 1024, 1024, 0, st>>>(lcol, n, bias, S, tkey, tcnt, tslots - 1u, cmin, hot, rkeys, s, hcoarse, P));
     }
-    HARK_LAUNCH_RC(ctx, rc, jsplit_kernel<K><<<(P + 256) / 256, 256, 0, st>>>(rkeys, s, P, splitters, bstart));
+    // the hot keys of the sample and the buckets' cuts (even, or by the sampled rows' weight when they crowd a stretch of the build side)
+    HARK_LAUNCH_RC(ctx, rc, jhot_select_kernel<K><<<1, 1024, 0, st>>>(tkey, tcnt, cmin, rkeys, s, hot, hcoarse, P, splitters, bstart, getenv("HARK_JOIN_EVEN_CUTS") ? 0 : 1, info));
+    if (!no_hot) {                                                               // (both leave at once unless the cut is by weight)
+        HARK_LAUNCH_RC(ctx, rc, jhot_fine_kernel<K><<<dim3((unsigned)std::min<uint32_t>((tslots + 255u) / 256u, (uint32_t)ctx->num_cu * 4u)), 256, 0, st>>>(tkey, tcnt, tslots, rkeys, s, hot, info, hfine, cells));
+        HARK_LAUNCH_RC(ctx, rc, jhot_scan_cells_kernel<<<(cells + kCutChunk - 1) / kCutChunk, 1024, 0, st>>>(hfine, cells, hcoarse + P, info));   // (the chunks' totals behind the coarse counts)
+        HARK_LAUNCH_RC(ctx, rc, jhot_cut_kernel<K><<<1, 1024, 0, st>>>(rkeys, s, hfine, cells, hcoarse + P, P, splitters, bstart, info));
+    }
     if (rc) { cleanup(); return rc; }
     const size_t lds_part = sizeof(E) * (size_t)P * Q + sizeof(K) * (P + 2) + 8 * (size_t)P + 16 + (sizeof(K) + 2) * (size_t)kHotSlots;
     const bool plain_loads = getenv("HARK_JOIN_PLAIN_LOADS") != nullptr;        // tests: the compiler-counted twin of the partition kernel
@@ -1403,8 +1639,9 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
         HIP_TRY_RC(ctx, rc, hipMemcpyAsync(info + 2, flags, 8, hipMemcpyDeviceToDevice, st));   // the duplicate-keys flag rides along with the same host read
     }
     if (he != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: setting the dynamic LDS size of the partition / bucket kernel failed: %s", hipGetErrorString(he));
-    int64_t words[4] = {0, 0, 0, 0}, M = 0;
-    if (!rc) rc = hark_read_words(ctx, info, words, 4);
+    int64_t words[5] = {0, 0, 0, 0, 0}, M = 0;
+    if (!rc) rc = hark_read_words(ctx, info, words, 5);
+    ctx->last_join_weighted = words[4] != 0;
     const int64_t mhot = words[3];                                              // matching rows of the hot keys: blocks between the others' rows
     M = words[0] + mhot;
     if (!rc && (int32_t)(words[1] & 0xFFFFFFFFll) != 0) { cleanup(); return HARK_OK; }          // a slab or a survivor bin overflowed (skew): caller falls back
@@ -1422,6 +1659,11 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
         if (!rc && carry) rc = hark_alloc(ctx, (void **)&lv, 4 * (size_t)M);
         if (!rc && rranked) rc = hark_alloc(ctx, (void **)&rv, 4 * (size_t)M);
         bool mismatch = false;
+        // a crowded group of ranks: ordered in pieces by the order kernel, or -- while the whole join has few matching rows, whose two
+        // radix sorts cost less than the pieces' sweeps (a hundred neighbouring keys with a thousand rows each: 1.5 against 2.7 ms) --
+        // by the general path
+        int pieces_ok = M > 8000000 ? 1 : 0;
+        if (const char *e = getenv("HARK_JOIN_PIECES")) pieces_ok = atoi(e) != 0;     // tests: either way at any size
         uint32_t *hkey = nullptr, *hrow = nullptr;
         if (!rc && mhot > 0) {                                                  // the hot rows in row order (and every key's number of them: the order kernel needs it)
             rc = hark_alloc(ctx, (void **)&hkey, 4 * (size_t)mhot);
@@ -1442,7 +1684,7 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
                     if (e != hipSuccess) return e;
                     jorder_kernel<C, V><<<dim3((unsigned)P), dim3(kJThreads), lds_order, st>>>(surv, region, scount, sbins, counts, cap, nwg, bstart, P, runlen,
                                                                                              rank, lrow, cnt, stage_cap, flags, C ? lv : nullptr, scoarse, rranked, rv,
-                                                                                             V ? srec : nullptr, V ? rk64 : nullptr, hot);
+                                                                                             V ? srec : nullptr, V ? rk64 : nullptr, hot, slabs, sstride, pieces_ok);
                     return hipGetLastError();
                 };
                 he = verify ? (carry ? launch(std::true_type{}, std::true_type{}) : launch(std::false_type{}, std::true_type{}))

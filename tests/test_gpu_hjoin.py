@@ -179,7 +179,7 @@ def test_every_probe_row_on_one_key_stays_partitioned(eng):
     rk = rng.integers(0, 2**32, size=s, dtype=np.uint64).astype(np.uint32)
     lk = np.full(n, rk[17], dtype=np.uint32)
     assert _check(eng, lk, rk) >= n
-    assert eng.last_join_path() == "partitioned"
+    assert eng.last_join_path().startswith("partitioned")
 
 
 def _skewed(rng, dt, n, s, dup, shares, absent=0.0):
@@ -215,7 +215,7 @@ def test_hot_keys_come_out_of_the_stable_partition(eng, dt, dup):
     rng = np.random.default_rng(77 + int(dup) + (3 if dt is np.int64 else 0))
     lk, rk = _skewed(rng, dt, 700_001, 50_000, dup, [0.10] + [0.01] * 30, absent=0.05)
     assert _check(eng, lk, rk) > 300_000
-    assert eng.last_join_path() == "partitioned"
+    assert eng.last_join_path().startswith("partitioned")
 
 
 def test_hot_keys_with_carried_columns_only(eng):
@@ -234,7 +234,7 @@ def test_hot_keys_with_carried_columns_only(eng):
     t1, t2 = eng.table_from_columns([lk, la]), eng.table_from_columns([rk, ra])
     res = eng.join(t1, t2, 0, 0, [1], [1])
     li, ri = _np_join_rows(lk, rk)
-    assert res.shape == (len(li), 2) and eng.last_join_path() == "partitioned"
+    assert res.shape == (len(li), 2) and eng.last_join_path().startswith("partitioned")
     assert np.array_equal(res.column(0), la[li]) and np.array_equal(res.column(1), ra[ri])
     res.free(); t1.free(); t2.free()
 
@@ -260,7 +260,7 @@ for dt, dup in ((np.uint32, False), (np.int64, True), (np.int64, False)):
     for key, rows in zip(rk[rng.choice(s, size=400, replace=False)], rng.integers(65, 1500 if dt is np.int64 else 3000, size=400)):
         lk[rng.integers(0, n, size=int(rows))] = key
     print(dt.__name__, dup, "pairs", T._check(eng, lk, rk), eng.last_join_path())
-    assert eng.last_join_path() == "partitioned", eng.last_join_path()
+    assert eng.last_join_path().startswith("partitioned"), eng.last_join_path()
 print("long runs ok")
 """
 
@@ -323,12 +323,14 @@ def test_build_slices_longer_than_lds_take_rounds(chunk):
     assert out.returncode == 0 and "rounds ok" in out.stdout, out.stdout + out.stderr
 
 
-@pytest.mark.parametrize("cap", ["40", "700"])
-def test_rank_order_in_sub_rounds(cap):
+@pytest.mark.parametrize("cap,pieces", [("40", "0"), ("40", "1"), ("700", "0"), ("700", "1")])
+def test_rank_order_in_sub_rounds(cap, pieces):
     """HARK_JOIN_STAGE caps the survivors the order kernel stages in LDS per sub-round (a test knob; at full size a
     bucket has far more survivors than the stage holds), so every bucket takes many sub-rounds, and with 40 some groups
-    of ranks do not fit at all and the general radix path runs: same rows, same order."""
-    env = dict(os.environ, HARK_JOIN_STAGE=cap)
+    of ranks do not fit at all: the bucket's survivors are regrouped and such a group is taken rank by rank
+    (HARK_JOIN_PIECES=1: what a join with many matching rows does; a single rank over the cap goes out unordered and the
+    general radix path orders everything) or the whole bucket goes to the general radix path (0): same rows, same order."""
+    env = dict(os.environ, HARK_JOIN_STAGE=cap, HARK_JOIN_PIECES=pieces)
     out = subprocess.run([sys.executable, "-c", _ROUNDS % (ROOT, os.path.join(ROOT, "tests"))], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0 and "rounds ok" in out.stdout, out.stdout + out.stderr
 
@@ -408,3 +410,34 @@ def test_survivor_bin_overflow_goes_to_the_overflow_area():
     env = dict(os.environ, HARK_JOIN_STAGE="16", HARK_JOIN_NOHOT="1")     # (the sample would take a part of these keys away)
     out = subprocess.run([sys.executable, "-c", _CROWD % (ROOT, os.path.join(ROOT, "tests"))], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0 and "crowd ok" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("dt", [np.uint32, np.int64])
+def test_probe_rows_crowding_a_stretch_of_the_build_side_cut_the_buckets_by_weight(eng, dt):
+    """Two thousand NEIGHBOURING build keys draw 40 % of the probe rows, 100..250 each: no key is frequent enough for the sample
+    to call it hot, but the even cut would put them into seventeen of the 512 buckets (their slabs overflow: the sort-merge
+    path).  The sampled rows' weight cuts the buckets instead (jhot_select_kernel); with HARK_JOIN_EVEN_CUTS=1 the old cut
+    and its fallback -- the reference's rows either way (join.fut:55-75)."""
+    rng = np.random.default_rng(17 + (dt is np.int64))
+    n, s = 800_000, 60_000
+    info = np.iinfo(dt)
+    rk = np.unique(rng.integers(info.min, info.max, size=s + 500, dtype=np.int64).astype(dt))[:s]
+    crowd = np.sort(rk)[30_000:32_000]
+    rk = rk[rng.permutation(s)]
+    lk = rng.integers(info.min, info.max, size=n, dtype=np.int64).astype(dt)
+    u = rng.random(n)
+    lk[u < 0.1] = rk[rng.integers(0, s, size=int((u < 0.1).sum()))]
+    m = u > 0.6
+    lk[m] = crowd[rng.integers(0, len(crowd), size=int(m.sum()))]
+    assert _check(eng, lk, rk) > 300_000
+    assert eng.last_join_path() == "partitioned, buckets cut by weight", eng.last_join_path()
+    os.environ["HARK_JOIN_EVEN_CUTS"] = "1"
+    try:
+        assert _check(eng, lk, rk) > 300_000
+        assert eng.last_join_path() in ("partitioned", "sort-merge")
+    finally:
+        del os.environ["HARK_JOIN_EVEN_CUTS"]
+    # evenly spread probe keys keep the even cut
+    lk2 = rng.integers(info.min, info.max, size=n, dtype=np.int64).astype(dt)
+    lk2[u < 0.5] = rk[rng.integers(0, s, size=int((u < 0.5).sum()))]
+    assert _check(eng, lk2, rk) > 300_000 and eng.last_join_path() == "partitioned"
