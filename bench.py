@@ -1305,7 +1305,7 @@ def single_gpu_extras(a, torch, eng, dev, head, out, G):
             print(json.dumps(out), flush=True)
             raise SystemExit("--pmc 1: " + str(traffic_note))
     if traffic is None:
-        for cand in ("r05_pmc_fgb.json", "r04_pmc_fgb.json", "r03_pmc_fgb.json", "r02_pmc_fgb.json", "r01_pmc_fgb.json"):
+        for cand in ("r06_pmc_fgb.json", "r05_pmc_fgb.json", "r04_pmc_fgb.json", "r03_pmc_fgb.json", "r02_pmc_fgb.json", "r01_pmc_fgb.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", cand)))
                 if (pmc["config"]["rows_per_gpu"] == N and pmc["config"]["groups"] == G and not a.algo and not a.chunk_rows

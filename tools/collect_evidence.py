@@ -79,9 +79,10 @@ with open(os.path.join(dst, f"{tag}_op_traffic.txt"), "w") as fo:
         logs = "".join(ln for ln in open(logf) if ln.startswith(w + ":")) if os.path.exists(logf) else ""
         fo.write(f"\n== {w}\n{logs}{r.stdout}{r.stderr}")
 print(open(os.path.join(dst, f"{tag}_op_traffic.txt")).read())
-# round 5's probe outputs of the same run
-for name, out in (("hashlds.txt", "hashlds.txt"), ("widedigit.txt", "widedigit.txt"), ("nofilter_ab.txt", "nofilter_ab.txt"), ("ingest_bench.log", "ingest_bench.log"),
-                  ("strong_rehearsal.txt", "strong_rehearsal.txt"), ("hash_pmc_after.txt", "hash_pmc_after.txt"), ("libsort_yardstick.txt", "libsort_yardstick.txt")):
+# the probes of the same run (round 6: join under skew, the 7-row statements, no-filter producer, SQL stress, SQ counters)
+for name, out in (("join_skew.txt", "join_skew.txt"), ("small_latency.txt", "small_latency.txt"), ("nofilter_ab.txt", "nofilter_ab.txt"), ("ingest_bench.log", "ingest_bench.log"),
+                  ("strong_rehearsal.txt", "strong_rehearsal.txt"), ("sql_stress.txt", "sql_stress.txt"), ("pmc_join_c4.txt", "pmc_join_c4.txt"), ("pmc_sort64.txt", "pmc_sort64.txt"),
+                  ("hashlds.txt", "hashlds.txt"), ("widedigit.txt", "widedigit.txt"), ("hash_pmc_after.txt", "hash_pmc_after.txt"), ("libsort_yardstick.txt", "libsort_yardstick.txt")):
     f = only(name, required=False)
     if f:
         shutil.copy(f, os.path.join(dst, f"{tag}_{out}"))

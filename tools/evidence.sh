@@ -33,16 +33,17 @@ for w in join_c4 join_u32 sort20 sort32 sort64 sparse_gb sparse_five refgb_hash;
     timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/opmc_${w}_$c -- python3 tools/op_one.py $w > $O/opmc_${w}_$c.log 2>&1
   done
 done
-# round 5: the probes behind the notes (LDS side of a hash probe, wide radix digits, no-filter A/B, host transfers, what one
-# rank of a strong-scaling run does) and the LDS counters of the hash consumers as they are now
-timeout 120 tools/hashlds > $O/hashlds.txt 2>&1
-timeout 240 tools/widedigit > $O/widedigit.txt 2>&1
-timeout 120 tools/libsort_yardstick > $O/libsort_yardstick.txt 2>&1     # the vendor library's radix sort on the ORDER BY workloads (a yardstick)
-(echo; echo "hark's own ORDER BY on the same box, same call (tools/op_one.py, wall per statement incl. the two-column result):"; for w in sort20 sort32 sort64; do timeout 100 python tools/op_one.py $w 2>/dev/null | tail -n 1; done) >> $O/libsort_yardstick.txt
+# round 6: the join under skew, the reference's own statements on its 7-row table, the no-filter producer, the SQL stress
+# (OR / NOT / IN trees against pandas), SQ counters of the join's and the i64 sort's kernels, what one rank of a strong-scaling
+# run does (round 5's probes -- LDS side of a hash probe, wide digits, the vendor sort -- are not repeated: profiles/r05_*)
+timeout 300 python tools/join_skew_probe.py > $O/join_skew.txt 2>&1
+timeout 100 python tools/small_latency.py > $O/small_latency.txt 2>&1
 timeout 200 python tools/nofilter_ab.py > $O/nofilter_ab.txt 2>&1
 timeout 200 python tools/ingest_bench.py > $O/ingest_bench.log 2>&1
 timeout 300 bash tools/strong_rehearsal.sh > $O/strong_rehearsal.txt 2>&1
-timeout 600 bash tools/pmc_hash.sh 0.5 > $O/pmc_hash.log 2>&1; cp gpurun_out/pmc_hash/summary.txt $O/hash_pmc_after.txt
+timeout 400 python tools/sql_stress.py 240 6 > $O/sql_stress.txt 2>&1
+timeout 400 bash tools/pmc_kernel.sh jorder_kernel,jbucket_kernel,jpart_kernel op_one.py join_c4 1.0 2 > $O/pmc_join_c4.txt 2>&1
+timeout 400 bash tools/pmc_kernel.sh msd_final_kernel,msd_part_kernel op_one.py sort64 1.0 2 > $O/pmc_sort64.txt 2>&1
 find $O -name "*kernel_trace.csv" -size +20M -delete
 ls -R $O | head -80
 cat $O/bench_plain.json
