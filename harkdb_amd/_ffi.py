@@ -68,6 +68,7 @@ SIGNATURES = {
     "hark_entry_filter_sel_and": (C.c_int, [_vp, _pp, _vp, _i64, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(C.c_void_p), C.POINTER(_i32), _i64, _i32]),
     "hark_entry_filter_groupby_and": (C.c_int, [_vp, _pp, _vp, _i64, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(C.c_void_p), _i32, C.POINTER(_i32), C.POINTER(_i32), _i64]),
     "hark_op_predicate_bitmask": (C.c_int, [_vp, _vp, _i64, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(C.c_void_p), _vp]),
+    "hark_op_column_binary": (C.c_int, [_vp, _i64, _i32, _vp, _i32, C.c_double, _vp, _i32, C.c_double, _i32, _vp]),
     "hark_op_predicate_tree": (C.c_int, [_vp, _vp, _i64, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(C.c_void_p), _vp]),
     "hark_entry_filter_groupby": (C.c_int, [_vp, _pp, _vp, _i32, _i32, _vp, _i32, C.POINTER(_i32), C.POINTER(_i32), _i64]),
     "hark_entry_topk": (C.c_int, [_vp, _pp, _vp, _i64, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(C.c_void_p), _i32, _i32, _i64, C.POINTER(_i32), _i64]),

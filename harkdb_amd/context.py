@@ -28,7 +28,7 @@ import numpy as np
 
 from . import _ffi
 from .engine import Engine
-from .parse import sql_parse, sql_parse_tree, JOIN_RESULT
+from .parse import sql_parse, sql_parse_tree, JOIN_RESULT, expr_text
 from .table import Table
 
 _AGG_NAME = {"key": "key", "prod": "prod", "sum": "sum", "max": "max", "min": "min", "count": "count", "avg": "avg"}
@@ -140,6 +140,17 @@ class FutharkContext:
         dev, eng = table._device, self.FutEnv
         schema = table.get_schema()
         extended = val_dic["extended"] or self.sql_mode
+        if val_dic.get("derived"):
+            # arithmetic inside aggregates (`sum(a + b)`): every distinct expression becomes one more device column behind the
+            # table's own (one elementwise kernel per operator, Engine.column_expr); the statement then runs over that view
+            m = dev.shape[1]
+            bufs = [eng.column_expr(dev, node) for node in val_dic["derived"]]
+            view = eng.table_from_device(dev.shape[0], [dev.device_ptr(j) for j in range(m)] + [b.ptr for b, _ in bufs],
+                                         [dev.dtype(j) for j in range(m)] + [dt for _, dt in bufs], keepalive=(dev, bufs))
+            schema = list(schema) + [expr_text(node, schema) for node in val_dic["derived"]]
+            dev = view
+        if any(i[0] == "count_distinct" for i in val_dic.get("items", [])):
+            return self._with_count_distinct(dev, schema, val_dic)
         int32ish = all(dev.dtype(j) in (np.int32, np.uint32) for j in range(dev.shape[1]))
 
         if "groupbys" not in val_dic:                                      # FutharkContext.py:64-66
@@ -164,6 +175,32 @@ class FutharkContext:
         return self._groupby_extended(dev, schema, val_dic, want_device=want_device)
 
     # ---- extension paths ---------------------------------------------------------
+    def _with_count_distinct(self, dev, schema, ir):
+        """`count(distinct x)` per group = the number of distinct (key, x) pairs of the group: the pairs are the groups of a
+        GROUP BY on both columns (composite key, on the device); their run lengths per key are counted on the host over the
+        DISTINCT pairs only.  The statement's other aggregates run as usual; both results list every group in ascending key order."""
+        if any(k in ir for k in ("having", "orderby", "limit")) or len(ir.get("g_cols", [ir["g_col"]])) > 1:
+            raise Exception("count(distinct ...) is supported in `select <key>, <aggregates> from t [where ...] group by <key>`")
+        g_col, items = ir["g_col"], list(ir["items"])
+        main_items = [i for i in items if i[0] != "count_distinct"]
+        lead = [] if any(i == ("key", g_col) for i in main_items) else [("key", g_col)]
+        names_m, cols_m = self._groupby_extended(dev, schema, dict(ir, items=lead + main_items))
+        keys = cols_m[(lead + main_items).index(("key", g_col))]
+        names, cols, j = [], [], len(lead)
+        for it in items:
+            if it[0] != "count_distinct":
+                names.append(names_m[j]); cols.append(cols_m[j]); j += 1
+                continue
+            if it[1] == g_col:
+                cnt = np.ones(len(keys), dtype=np.int64)                     # a group holds one value of its own key
+            else:
+                _, pair = self._groupby_extended(dev, schema, dict(ir, items=[("key", g_col), ("key", it[1])], g_cols=[g_col, it[1]]))
+                uniq, cnt = np.unique(pair[0], return_counts=True)
+                if not np.array_equal(uniq, keys):
+                    raise Exception("count(distinct): the key sets of the two aggregations differ")
+            names.append(f"count(distinct {schema[it[1]]})"); cols.append(cnt.astype(np.int64))
+        return names, cols
+
     def _join(self, ir):
         """Two-table FROM -> `entry join` (futhark/join.fut:52-75): rows ordered by
         (unsigned key, left row, right row); columns re-ordered to the select list."""

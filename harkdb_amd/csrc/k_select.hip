@@ -681,6 +681,50 @@ int hark_op_predicate_bitmask(hark_context *ctx, const hark_table *db, int64_t n
     return HARK_OK;
 }
 
+// One node of an arithmetic expression inside an aggregate (`sum(a + b)`): out[i] = x[i] <op> y[i], an operand a 4- or 8-byte column or
+// a constant.  Integer operands (and no division) stay integers -- i32 when both are 32-bit (wrapping, like the reference's u32
+// arithmetic, groupby.fut:35-41), i64 otherwise --, anything else is computed and stored in f32.
+namespace {
+struct ExprOperand { const void *col; int32_t dtype; double c; };          // col == nullptr: the constant c
+__device__ __forceinline__ int64_t expr_int(const ExprOperand &o, int64_t i)
+{
+    if (!o.col) return (int64_t)o.c;
+    return o.dtype == HARK_I64 ? static_cast<const int64_t *>(o.col)[i] : o.dtype == HARK_U32 ? (int64_t)static_cast<const uint32_t *>(o.col)[i] : (int64_t)static_cast<const int32_t *>(o.col)[i];
+}
+__device__ __forceinline__ float expr_f32(const ExprOperand &o, int64_t i)
+{
+    if (!o.col) return (float)o.c;
+    return o.dtype == HARK_F32 ? static_cast<const float *>(o.col)[i] : (float)expr_int(o, i);
+}
+__global__ __launch_bounds__(256) void column_binary_kernel(ExprOperand x, ExprOperand y, int op, int out_dtype, void *__restrict__ out, int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if (out_dtype == HARK_F32) {
+            const float a = expr_f32(x, i), b = expr_f32(y, i);
+            static_cast<float *>(out)[i] = op == 0 ? a + b : op == 1 ? a - b : op == 2 ? a * b : a / b;
+        } else {
+            const uint64_t a = (uint64_t)expr_int(x, i), b = (uint64_t)expr_int(y, i), r = op == 0 ? a + b : op == 1 ? a - b : a * b;   // (unsigned: wrapping is defined)
+            if (out_dtype == HARK_I64) static_cast<int64_t *>(out)[i] = (int64_t)r; else static_cast<int32_t *>(out)[i] = (int32_t)(uint32_t)r;
+        }
+    }
+}
+} // namespace
+
+int hark_op_column_binary(hark_context *ctx, int64_t n, int32_t op, const void *x, int32_t x_dtype, double x_const, const void *y, int32_t y_dtype, double y_const,
+                          int32_t out_dtype, void *out_dev)
+{
+    hark_device_guard guard__(ctx);
+    if (!ctx || n < 0 || op < 0 || op > 3 || (n && !out_dev) || (out_dtype != HARK_I32 && out_dtype != HARK_I64 && out_dtype != HARK_F32)) return HARK_EARG;
+    if (op == 3 && out_dtype != HARK_F32) return hark_fail(ctx, HARK_EARG, "column_binary: a division is computed in f32");
+    if (n == 0) return HARK_OK;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > (int64_t)ctx->num_cu * 16) blocks = (int64_t)ctx->num_cu * 16;
+    column_binary_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(ExprOperand{x, x_dtype, x_const}, ExprOperand{y, y_dtype, y_const}, op, out_dtype, out_dev, n);
+    if (hipGetLastError() != hipSuccess) return hark_fail(ctx, HARK_EHIP, "column_binary: launch failed");
+    return HARK_OK;
+}
+
 // A predicate TREE as a survivor bitmask: the nodes in postfix order, evaluated with a stack of masks.
 //   kind[i] = HARK_PRED_CONST: db[:, a[i]] <b[i]> *constants[i]      (b: HARK_CMP_GT .. HARK_CMP_NE; the constant read as the column's dtype)
 //             HARK_PRED_COLS : db[:, a[i]] <b[i] & 15> db[:, b[i] >> 4]   (two columns of ONE dtype)

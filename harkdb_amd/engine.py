@@ -487,6 +487,40 @@ class Engine:
         n = len(where)
         return ((C.c_int32 * n)(*cols), (C.c_int32 * n)(*cmps), (C.c_void_p * n)(*ptrs), consts)
 
+    def column_expr(self, table, node):
+        """An arithmetic expression over the table's columns -> (DeviceBuffer, numpy dtype): node = ("col", j) | ("num", v) |
+        ("add" | "sub" | "mul" | "div", left, right).  One elementwise kernel per operator (hark_op_column_binary): integers stay
+        integers (i32 when both operands are 32-bit: wrapping; i64 otherwise), a division or a float operand makes f32."""
+        n = table.shape[0]
+        ops = {"add": 0, "sub": 1, "mul": 2, "div": 3}
+
+        def ev(nd):
+            """-> (buffer | None, device pointer | None, dtype | None, constant)."""
+            if nd[0] == "col":
+                return None, table.device_ptr(nd[1]), np.dtype(table.dtype(nd[1])), 0.0
+            if nd[0] == "num":
+                return None, None, None, float(nd[1])
+            (_, px, dx, cx), (_, py, dy, cy) = kx, ky = ev(nd[1]), ev(nd[2])
+            if px is None and py is None:                          # two constants: folded here
+                v = {"add": cx + cy, "sub": cx - cy, "mul": cx * cy, "div": cx / cy if cy else float("nan")}[nd[0]]
+                return None, None, None, v
+            integral = lambda d, c: (d is not None and d.kind in "iu") or (d is None and float(c).is_integer())
+            if nd[0] != "div" and integral(dx, cx) and integral(dy, cy):
+                wide = any(d is not None and (d.itemsize == 8 or d == np.dtype(np.uint32)) for d in (dx, dy)) or any(d is None and not -2**31 <= c < 2**31 for d, c in ((dx, cx), (dy, cy)))
+                out = np.dtype(np.int64 if wide else np.int32)
+            else:
+                out = np.dtype(np.float32)
+            buf = DeviceBuffer(self, self.alloc(max(n, 1) * out.itemsize))
+            code = lambda d: 0 if d is None else _ffi.DT_OF[d]
+            self._chk(self.lib.hark_op_column_binary(self.ctx, n, ops[nd[0]], px, code(dx), cx, py, code(dy), cy, _ffi.DT_OF[out], buf.ptr))
+            buf._keep = (kx[0], ky[0])                             # operand buffers live until the kernel has run (stream order: freed blocks are reused in order)
+            return buf, buf.ptr, out, 0.0
+
+        buf, ptr, dt, c = ev(node)
+        if buf is None:                                            # a bare column or a constant: materialise as column + 0 / 0 + c
+            return self.column_expr(table, ("add", node, ("num", 0)))
+        return buf, dt
+
     def predicate_tree_mask(self, table, node):
         """A WHERE tree -> survivor bitmask on the device (hark_op_predicate_tree), as a DeviceBuffer to pass on as the conjunct
         (None, "mask", buffer).  node = ("and" | "or", [nodes]) | ("not", node) | ("cmp", col, cmp, number) |

@@ -35,6 +35,29 @@ def _col(columns, name, table_name):
     return idx
 
 
+_ARITH = ("add", "sub", "mul", "div")
+
+
+def expr_node(arg, col_of):
+    """The argument of an aggregate in moz shape -> ("col", j) | ("num", v) | (op, left, right)."""
+    if isinstance(arg, str):
+        return ("col", col_of(arg))
+    if isinstance(arg, (int, float)):
+        return ("num", arg)
+    (op, (l, r)), = arg.items()
+    if op not in _ARITH:
+        raise Exception(f"{op} is not an arithmetic operator (+ - * /)")
+    return (op, expr_node(l, col_of), expr_node(r, col_of))
+
+
+def expr_text(node, columns):
+    if node[0] == "col":
+        return columns[node[1]]
+    if node[0] == "num":
+        return repr(node[1])
+    return "(" + expr_text(node[1], columns) + {"add": " + ", "sub": " - ", "mul": " * ", "div": " / "}[node[0]] + expr_text(node[2], columns) + ")"
+
+
 def _is_simple(cond):
     """`column <op> number`: what the reference-shaped AND-lists are made of."""
     (op, args), = cond.items()
@@ -201,6 +224,15 @@ def sql_parse_tree(tables, js_obj):
         ir["items"] = items
     else:                                                               # parse.py:60
         fut_cols_selects, typ_cols_selects, items = [], [], []
+
+        def derived_col(arg):
+            """The column number of an aggregate's arithmetic argument: behind the table's own columns, one per distinct expression
+            (the executor computes them on the device before the statement runs, Engine.column_expr)."""
+            node = expr_node(arg, lambda name: _col(columns, name, table_name))
+            der = ir.setdefault("derived", [])
+            if node not in der:
+                der.append(node)
+            return len(columns) + der.index(node)
         gb = js_obj["groupby"]
         g_names = [g["value"] for g in gb] if isinstance(gb, list) else [gb["value"]]   # several keys: extension
         g_col_name = g_names[0]                                         # parse.py:66
@@ -229,6 +261,18 @@ def sql_parse_tree(tables, js_obj):
                 raise Exception(f"{bad_col_name} is not an aggregation function or the columns thats grouped on")
             else:
                 (agg_func, agg_col_name), = dic["value"].items()
+                if isinstance(agg_col_name, dict) and "distinct" in agg_col_name:      # count(distinct x) (extension)
+                    if agg_func != "count":
+                        raise Exception("DISTINCT is supported inside count() only")
+                    items.append(("count_distinct", _col(columns, agg_col_name["distinct"], table_name)))
+                    ir["extended"] = True
+                    continue
+                if isinstance(agg_col_name, (dict, int, float)):        # arithmetic inside the aggregate (extension): a derived column
+                    if agg_func not in funcToFut and agg_func not in EXT_FUNCS:
+                        raise Exception(f"{agg_func} is not a supported aggregation function {AGGREGATES}")
+                    items.append((agg_func, derived_col(agg_col_name)))
+                    ir["extended"] = True
+                    continue
                 if agg_func in funcToFut:                               # parse.py:82-89
                     agg_col = _col(columns, agg_col_name, table_name)
                     fut_cols_selects += [agg_col]
@@ -260,6 +304,16 @@ def sql_parse_tree(tables, js_obj):
         (f, c), = term.items()
         if f not in funcToFut and f not in EXT_FUNCS:
             raise Exception(f"{f} is not a supported aggregation function {AGGREGATES}")
+        if isinstance(c, dict) and "distinct" in c:
+            raise Exception("count(distinct ...) is not supported in HAVING / ORDER BY")
+        if isinstance(c, (dict, int, float)):                           # the same expression as in the select list (or a new one)
+            if "groupby" not in js_obj:
+                raise Exception("aggregates need a GROUP BY clause")
+            node = expr_node(c, lambda name: _col(columns, name, table_name))
+            der = ir.setdefault("derived", [])
+            if node not in der:
+                der.append(node)
+            return (f, len(columns) + der.index(node))
         return (f, None if c == "*" else _col(columns, c, table_name))
 
     having = []

@@ -22,7 +22,9 @@ _TOKEN = re.compile(r"""\s*(?:
   | (?P<qid>"[^"]+"|`[^`]+`)
   | (?P<op><=|>=|<>|!=|==|=|<|>)
   | (?P<punct>[(),*])
+  | (?P<arith>[-+/])
 )""", re.X)
+_ARITH = {"+": "add", "-": "sub", "*": "mul", "/": "div"}
 
 _CMP = {">": "gt", ">=": "gte", "<": "lt", "<=": "lte", "=": "eq", "==": "eq", "!=": "neq", "<>": "neq"}
 _FLIP = {"gt": "lt", "gte": "lte", "lt": "gt", "lte": "gte", "eq": "eq", "neq": "neq"}
@@ -44,7 +46,12 @@ def _tokenize(text):
         pos = m.end()
         if m.group("num") is not None:
             s = m.group("num")
+            if s[0] in "+-" and out and (out[-1][0] in ("id", "num") or out[-1] == ("punct", ")")):
+                out.append(("arith", s[0]))                  # `a -1`, `(a) +2`: the sign is the operator of an expression
+                s = s[1:]
             out.append(("num", float(s) if any(c in s for c in ".eE") else int(s)))
+        elif m.group("arith") is not None:
+            out.append(("arith", m.group("arith")))
         elif m.group("id") is not None:
             w = m.group("id")
             out.append(("kw", w.lower()) if w.lower() in _KEYWORDS else ("id", w))
@@ -85,10 +92,44 @@ class _Parser:
         name = self.take("id")
         if self.peek("punct", "("):
             self.take()
-            arg = self.term()
+            if self.peek("kw", "distinct"):                  # count(distinct x): moz's {"count": {"distinct": "x"}}
+                self.take()
+                arg = {"distinct": self.take("id")}
+            elif self.peek("punct", "*"):
+                self.take()
+                arg = "*"
+            else:
+                arg = self.expression()                      # a column, or arithmetic over columns and numbers: sum(a + 2 * b)
             self.take("punct", ")")
             return {name.lower(): arg}
         return name
+
+    # arithmetic inside an aggregate: + - * / over columns and numbers, parentheses; moz's {"add": [a, b]} ... shapes
+    def atom(self):
+        if self.peek("punct", "("):
+            self.take()
+            e = self.expression()
+            self.take("punct", ")")
+            return e
+        if self.peek("arith", "-") or self.peek("arith", "+"):
+            sign = self.take()
+            v = self.atom()
+            return v if sign == "+" else (-v if isinstance(v, (int, float)) else {"sub": [0, v]})
+        if self.peek("num"):
+            return self.take("num")
+        return self.take("id")
+
+    def product(self):
+        e = self.atom()
+        while self.peek("punct", "*") or self.peek("arith", "/"):
+            e = {_ARITH[self.take()]: [e, self.atom()]}
+        return e
+
+    def expression(self):
+        e = self.product()
+        while self.peek("arith", "+") or self.peek("arith", "-"):
+            e = {_ARITH[self.take()]: [e, self.product()]}
+        return e
 
     def comparison(self):
         lhs = self.term()

@@ -878,3 +878,26 @@ def test_predicate_tree_entry_against_numpy():
             assert np.array_equal(got, np.packbits(m, bitorder="little")), node
         t.free()
     eng.close()
+
+
+def test_arithmetic_inside_aggregates_and_count_distinct(fc):
+    """`sum(a + b)`, `count(distinct x)`: the last two statement forms of the reference's parser (parse.py:27) that the planner of
+    round 5 refused.  Integer expressions stay integers (32-bit operands wrap, like the reference's u32 arithmetic), a division or
+    a float operand makes f32; count(distinct x) counts the distinct (key, x) pairs of a group."""
+    df = fc._df
+    _, cols = fc.sql_columns("select k, sum(w + k), max(w * 2 - k), count(distinct w), sum(v * p), avg((w + 1) * (k - 3)), min(big + 1), count(*) from t where p > 0.25 group by k")
+    d = df[df.p > 0.25]
+    g = d.assign(e1=d.w + d.k, e2=d.w * 2 - d.k, e3=d.v * d.p, e4=(d.w + 1) * (d.k - 3), e5=d.big + 1).groupby("k").agg(
+        a=("e1", "sum"), b=("e2", "max"), c=("w", "nunique"), s=("e3", "sum"), m=("e4", "mean"), mn=("e5", "min"), n=("w", "size"))
+    assert np.array_equal(cols[0], g.index.to_numpy()) and np.array_equal(cols[1], g.a.to_numpy()) and np.array_equal(cols[2], g.b.to_numpy())
+    assert np.array_equal(cols[3], g.c.to_numpy()) and np.allclose(cols[4], g.s.to_numpy(), rtol=1e-5)
+    assert np.allclose(cols[5], g.m.to_numpy(), rtol=1e-6) and np.array_equal(cols[6], g.mn.to_numpy()) and np.array_equal(cols[7], g.n.to_numpy())
+    _, cols = fc.sql_columns("select k, sum(w - 1) as s from t group by k having sum(w - 1) > 0 order by s desc limit 5")
+    g2 = df.assign(e=df.w - 1).groupby("k").e.sum().reset_index()
+    g2 = g2[g2.e > 0].sort_values("e", ascending=False, kind="stable").head(5)
+    assert np.array_equal(cols[0], g2.k.to_numpy()) and np.array_equal(cols[1], g2.e.to_numpy())
+    _, cols = fc.sql_columns("select count(distinct k), k from t where w in (1, 2, 3) group by k")
+    d3 = df[df.w.isin([1, 2, 3])].groupby("k").size()
+    assert np.array_equal(cols[1], d3.index.to_numpy()) and np.array_equal(cols[0], np.ones(len(d3), dtype=np.int64))
+    _, cols = fc.sql_columns("select k, avg(w / 4) from t group by k")
+    assert np.allclose(cols[1], (df.w / 4).groupby(df.k).mean().to_numpy(), rtol=1e-5)

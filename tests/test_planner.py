@@ -347,3 +347,17 @@ def test_float64_columns_narrow_to_f32_with_one_warning():
         Table("again", pd.DataFrame({"a": np.array([0.3])})).host_columns()
         assert len(w) == 1
     assert cols[0].dtype == np.float32
+
+
+def test_arithmetic_in_aggregates_and_count_distinct_plan(tables):
+    t = parse("select k, sum(a + 2 * b), count(distinct x), avg((a - 1) / 4), sum(-a) from t group by k")
+    assert t["select"][1] == {"value": {"sum": {"add": ["a", {"mul": [2, "b"]}]}}} and t["select"][2] == {"value": {"count": {"distinct": "x"}}}
+    assert t["select"][3] == {"value": {"avg": {"div": [{"sub": ["a", 1]}, 4]}}} and t["select"][4] == {"value": {"sum": {"sub": [0, "a"]}}}
+    assert parse("select a from t where a > -3 and b in (-1, +2)")["where"] == {"and": [{"gt": ["a", -3]}, {"in": ["b", [-1, 2]]}]}
+    ir = sql_parse(tables, "select col1, sum(col2 + col3), count(distinct col4), max(col2 + col3) from game_1 group by col1 having sum(col2 + col3) > 3")
+    assert ir["derived"] == [("add", ("col", 1), ("col", 2))] and ir["extended"]
+    assert ir["items"] == [("key", 0), ("sum", 8), ("count_distinct", 3), ("max", 8)] and ir["having"] == [(("sum", 8), ">", 3)]
+    with pytest.raises(Exception, match="DISTINCT is supported inside count"):
+        sql_parse(tables, "select col1, sum(distinct col2) from game_1 group by col1")
+    with pytest.raises(Exception, match="colx is not in the schema"):
+        sql_parse(tables, "select col1, sum(col2 + colx) from game_1 group by col1")
