@@ -175,7 +175,7 @@ __global__ void msd_setup_kernel(const u64 *__restrict__ mm, uint32_t D, MsdMap 
 // pass 0: under the affine map, and the keys per cell of 4096 positions beside it; pass 1 (only when msd_scan1 found the
 // distribution lumpy and msd_eq equalised the map): the slab sizes again, under the new map.
 __global__ __launch_bounds__(kT) void msd_hist_kernel(int pass, const u64 *__restrict__ col, int64_t n, int64_t slice, u64 xorm, const MsdMap *__restrict__ mapp,
-                                                      const uint2 *__restrict__ tab_g, int nb2log, uint32_t *__restrict__ counts1 /* [256][nwg]: bucket-major, the order the scan walks them in */,
+                                                      const uint2 *__restrict__ tab_g, int nb2log, uint32_t *__restrict__ counts1 /* [nwg][256] */,
                                                       uint32_t *__restrict__ cells /* [4096], pass 0 */, const int32_t *__restrict__ flag)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(kT) void msd_hist_kernel(int pass, const u64 *__res
         }
     }
     __syncthreads();
-    if (threadIdx.x < kB) counts1[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = s_cnt[threadIdx.x];
+    if (threadIdx.x < kB) counts1[(size_t)blockIdx.x * kB + threadIdx.x] = s_cnt[threadIdx.x];
     if (pass == 0) for (int i = threadIdx.x; i < kCells; i += kT) { const uint32_t c = s_cell[i]; if (c) atomicAdd(&cells[i], c); }
 }
 constexpr size_t msd_hist_lds() { return (size_t)kB * 4 + (size_t)kCells * 8; }
@@ -237,7 +237,7 @@ __device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t x, uint32_t *s
 }
 
 // Slab offsets, bucket-major: bucket b's slabs (workgroup 0 .. nwg - 1) lie one behind the other, every slab padded to whole
-// lines of eight tuples.  off1[b][w] = first tuple of slab (w, b); bstart[b] = first tuple of bucket b, bstart[256] = the end;
+// lines of eight tuples.  off1[w][b] = first tuple of slab (w, b); bstart[b] = first tuple of bucket b, bstart[256] = the end;
 // bfirst[b] = the rows of the buckets before b (where bucket b's rows start in the sorted output).
 // Also the first place where a lumpy distribution shows: a level-1 bucket with more than 1.5 x the average would overflow its
 // final buckets (capacity 1.6-3.2 x their average).  Under the affine map (pass 0) that asks for the equalised map (flag[2]);
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(1024) void msd_scan1_kernel(int pass, const uint32_
     const int total = kB * nwg, per = (total + 1023) / 1024;
     uint32_t sum = 0, exact = 0;
     for (int e = threadIdx.x * per; e < (threadIdx.x + 1) * per && e < total; e++) {
-        const int b = e / nwg; const uint32_t c = counts1[e];        // (bucket-major: a thread's entries are consecutive words -- workgroup-major, 65536 strided reads and as many strided writes of ONE workgroup took 45 us)
+        const int b = e / nwg, w = e - b * nwg; const uint32_t c = counts1[(size_t)w * kB + b];
         sum += (c + 7u) & ~7u; exact += c;
         if (c) atomicAdd(&s_bucket[b], c);
     }
@@ -267,8 +267,8 @@ __global__ __launch_bounds__(1024) void msd_scan1_kernel(int pass, const uint32_
     if (threadIdx.x == 0) { bstart[kB] = all; bfirst[kB] = all2; }
     for (int e = threadIdx.x * per; e < (threadIdx.x + 1) * per && e < total; e++) {
         const int b = e / nwg, w = e - b * nwg;
-        const uint32_t c = counts1[e];
-        off1[e] = at;
+        const uint32_t c = counts1[(size_t)w * kB + b];
+        off1[(size_t)w * kB + b] = at;
         if (w == 0) { bstart[b] = at; bfirst[b] = ex; }
         at += (c + 7u) & ~7u; ex += c;
     }
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(kT) void msd_part_kernel(
     const u64 *__restrict__ col, const uint32_t *__restrict__ valcol, int64_t n, int64_t slice, u64 xorm,      // FIRST
     const uint4 *__restrict__ tin, const uint32_t *__restrict__ bstart,                                          // !FIRST
     const MsdMap *__restrict__ mapp, const uint2 *__restrict__ tab_g, int nb2log,
-    uint4 *__restrict__ tout, const uint32_t *__restrict__ off1 /* FIRST: [256][nwg] */, uint32_t cap2 /* !FIRST */,
+    uint4 *__restrict__ tout, const uint32_t *__restrict__ off1 /* FIRST: [nwg][256] */, uint32_t cap2 /* !FIRST */,
     uint32_t *__restrict__ counts2 /* !FIRST: [256 << nb2log] */, const uint32_t *__restrict__ bfirst /* !FIRST */, uint32_t *__restrict__ outoff /* !FIRST */,
     int32_t *__restrict__ flag, size_t tin_cap, size_t tout_cap /* tuples in the two buffers (checked builds) */)
 {
@@ -368,7 +368,6 @@ __global__ __launch_bounds__(kT) void msd_part_kernel(
     uint32_t *ncarry = cur + kB;                                           // [kB]
     uint32_t *big = ncarry + kB, *nbig = big + 8;                          // [8] buckets with a long run in this tile (a tile has eight at most), their number
     uint2 *s_tab = reinterpret_cast<uint2 *>(big + 16);                    // [kCells] the equalisation table (when the map is equalised)
-    uint32_t *s_off = reinterpret_cast<uint32_t *>(s_tab + kCells);        // [kB] sweep 1: this workgroup's slab of every bucket (off1 is bucket-major: one strided read each, once)
     bool eq;
     if (msd_gave_up(flag, &eq)) return;                                    // an earlier step gave up: nothing to do
     const MsdMap m = *mapp;
@@ -378,9 +377,9 @@ __global__ __launch_bounds__(kT) void msd_part_kernel(
     int64_t lo, hi;
     if (FIRST) { lo = (int64_t)b1 * slice; hi = lo + slice < n ? lo + slice : n; }
     else { lo = bstart[b1]; hi = bstart[b1 + 1]; }
-    if (threadIdx.x < kB) { cur[threadIdx.x] = 0u; ncarry[threadIdx.x] = 0u; if (FIRST) s_off[threadIdx.x] = off1[(size_t)threadIdx.x * gridDim.x + b1]; }
+    if (threadIdx.x < kB) { cur[threadIdx.x] = 0u; ncarry[threadIdx.x] = 0u; }
     auto dest_of = [&](uint32_t b) -> uint4 * {
-        if (FIRST) return tout + s_off[b];
+        if (FIRST) return tout + off1[(size_t)b1 * kB + b];
         return tout + ((size_t)(b1 << nb2log) + b) * cap2;
     };
     auto load = [&](int64_t t0, uint4 (&t)[kR]) {
@@ -470,7 +469,7 @@ __global__ __launch_bounds__(kT) void msd_part_kernel(
     }
     if (over) atomicOr(&flag[0], 4);
 }
-constexpr size_t msd_part_lds() { return (size_t)kTile * 16 + (size_t)kB * 8 * 16 + (size_t)kB * 4 * 4 + 64 + (size_t)kCells * 8 + (size_t)kB * 4; }
+constexpr size_t msd_part_lds() { return (size_t)kTile * 16 + (size_t)kB * 8 * 16 + (size_t)kB * 4 * 4 + 64 + (size_t)kCells * 8; }
 constexpr size_t msd_final_lds(int ft) { return (size_t)kFCapOf(ft) * 16 + (size_t)(kFBinsOf(ft) + 4) * 4 + (size_t)(ft / 64) * 4 * 2 + 4 * 256 * 4; }
 
 // ---- sweep 3: the final buckets are sorted in LDS -------------------------------------------------------------------------------
