@@ -227,6 +227,9 @@ void hark_context_free(hark_context *ctx)
     if (ctx->d_err) hipFree(ctx->d_err);
     if (ctx->h_pin) hipHostFree(ctx->h_pin);
     for (int i = 0; i < 2; i++) { if (ctx->bounce[i]) hipHostFree(ctx->bounce[i]); if (ctx->bounce_ev[i]) hipEventDestroy(ctx->bounce_ev[i]); }
+    if (ctx->aux_event) hipEventDestroy(ctx->aux_event);
+    if (ctx->main_event) hipEventDestroy(ctx->main_event);
+    if (ctx->aux_stream) hipStreamDestroy(ctx->aux_stream);
     if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }

@@ -20,6 +20,10 @@ struct hark_context {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;   // the stream entries launch on
+    // the join's early sample (k_hjoin.hip, k_join_hot_prepare): a second stream, its events, and the block prepared for the next partitioned join
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t aux_event = nullptr, main_event = nullptr;
+    void *join_prep = nullptr; const void *join_prep_col = nullptr; int64_t join_prep_n = 0, join_prep_s = 0;
     std::string err;
     int32_t *d_err = nullptr;       // device-side sticky error word (bounds failures)
     int32_t *h_pin = nullptr;       // pinned scratch for small D2H reads (64 KiB: status words, LIMIT prefixes)
@@ -99,6 +103,8 @@ struct hark_result {
     int64_t host_rows = 0, host_cols = 0;
 };
 static inline void hark_result_host_release(hark_context *ctx, hark_result *r) { if (r && r->host_matrix) { hark_host_free(ctx, r->host_matrix); r->host_matrix = nullptr; } }
+int k_join_hot_prepare(hark_context *ctx, const void *lcol, bool k64, int64_t n, int64_t s);
+void k_join_hot_release(hark_context *ctx);
 // k_small.hip: tables of a few rows in one launch and one synchronisation
 bool k_small_fits(const hark_table *db, int64_t result_cols);
 int k_small_query_sel(hark_context *ctx, const hark_table *db, const int32_t *cols, int64_t k, hark_result *res);

@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void jcnt_kernel(const uint32_t *__restrict__ 
 //   2. jpart_kernel drops the rows of a hot key (one LDS probe per row, nothing at all when the set is empty) and counts,
 //      batch by batch, those whose key has partners;
 //   3. the rows of a hot key are a contiguous block of the output at the key's rank, IN ROW ORDER -- which a stable
-//      partition of the probe column delivers without any sorting: the counts are scanned (jhot_scan_kernel), the hot rows
+//      partition of the probe column delivers without any sorting: the counts are scanned (jsum_kernel), the hot rows
 //      are written out in row order as (key index, row) by a second pass over the column (jhot_compact_kernel, a wave per
 //      batch), ONE stable pass of the radix sort groups them by key, the order kernel leaves the blocks free (every later
 //      row of the bucket moves back by the blocks before it) and reports where they start, and jhot_place_kernel copies
@@ -210,18 +210,13 @@ template <typename K> __device__ __forceinline__ uint32_t jhot_find(const K *slo
 // 13000 of them) would otherwise queue up behind ONE word of the table.
 template <typename K>
 __global__ __launch_bounds__(1024) void jhot_sample_kernel(const K *__restrict__ keys, int64_t n, K bias, uint32_t S, unsigned long long *__restrict__ tkey,
-                                                           uint32_t *__restrict__ tcnt, uint32_t mask, uint32_t cmin, JHotHead *__restrict__ hot,
-                                                           const K *__restrict__ rkeys, int64_t s, uint32_t *__restrict__ hcoarse, int P)
+                                                           uint32_t *__restrict__ tcnt, uint32_t mask, uint32_t cmin, JHotHead *__restrict__ hot)
 {
     constexpr int LS = 2048;                                              // local slots: twice the samples
     __shared__ unsigned long long s_key[LS];
     __shared__ uint32_t s_cnt[LS];
-    __shared__ K s_q[kQuant];                                             // every (s / kQuant)-th sorted build key: where a sampled key falls, to 1 / kQuant of the build side
-    __shared__ uint32_t s_coarse[1024];                                   // this workgroup's samples per even bucket (P <= 1024): added to hcoarse once
     const uint32_t t = blockIdx.x * 1024u + threadIdx.x;
-    s_coarse[threadIdx.x] = 0u;
     for (int i = threadIdx.x; i < LS; i += 1024) { s_key[i] = ~0ull; s_cnt[i] = 0u; }
-    for (int i = threadIdx.x; i < kQuant; i += 1024) s_q[i] = rkeys[(int64_t)(((uint64_t)i * (uint64_t)s) / kQuant)];
     __syncthreads();
     if (t < S) {
         const uint64_t stride = (uint64_t)n / S;                          // >= 1: S <= n
@@ -250,14 +245,32 @@ __global__ __launch_bounds__(1024) void jhot_sample_kernel(const K *__restrict__
         }
         const uint32_t before = atomicAdd(&tcnt[slot], c);
         if (before < cmin && before + c >= cmin) { const uint32_t at = atomicAdd(&hot->ncand, 1u); if (at < (uint32_t)kHotCand) hot->cand[at] = slot; }
-        // where the sampled rows fall in the sorted build side, per bucket of the even cut (to 1 / kQuant of the build side: the
-        // quantile keys in LDS): jhot_select_kernel sees from it whether the probe rows crowd a stretch of the build side.
-        // Keys outside the build side's range are dropped by the partition and weigh nothing.
-        const K key = (K)k;
-        if (key >= s_q[0] && key <= rkeys[s - 1]) {
+    }
+}
+
+// Where the sampled rows fall in the sorted build side, per bucket of the even cut (to 1 / kQuant of the build side: quantile keys
+// in LDS): jhot_select_kernel sees from it whether the probe rows crowd a stretch of the build side.  Keys outside the build
+// side's range are dropped by the partition and weigh nothing.  (Its own kernel since the sample runs BEFORE the build side is
+// sorted, on the context's second stream, hidden behind the sort: this one needs the sorted keys.)
+template <typename K>
+__global__ __launch_bounds__(1024) void jhot_coarse_kernel(const unsigned long long *__restrict__ tkey, const uint32_t *__restrict__ tcnt, uint32_t tslots,
+                                                           const K *__restrict__ rkeys, int64_t s, uint32_t *__restrict__ hcoarse, int P)
+{
+    __shared__ K s_q[kQuant];                                             // every (s / kQuant)-th sorted build key
+    __shared__ uint32_t s_coarse[1024];                                   // this workgroup's samples per even bucket (P <= 1024): added to hcoarse once
+    s_coarse[threadIdx.x] = 0u;
+    for (int i = threadIdx.x; i < kQuant; i += 1024) s_q[i] = rkeys[(int64_t)(((uint64_t)i * (uint64_t)s) / kQuant)];
+    __syncthreads();
+    const K kmax = rkeys[s - 1];
+    const uint32_t stride = gridDim.x * 1024u;
+    for (uint32_t i = blockIdx.x * 1024u + threadIdx.x; i < tslots; i += stride) {
+        const unsigned long long k1 = tkey[i];
+        if (k1 == 0ull) continue;
+        const K key = (K)(k1 - 1ull);
+        if (key >= s_q[0] && key <= kmax) {
             int lo = 0, hi = kQuant;                                       // the number of quantile keys <= key, less one: its stretch
             while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_q[mid] <= key) lo = mid; else hi = mid; }
-            atomicAdd(&s_coarse[(uint32_t)(((uint64_t)lo * (uint64_t)P) / kQuant)], c);
+            atomicAdd(&s_coarse[(uint32_t)(((uint64_t)lo * (uint64_t)P) / kQuant)], tcnt[i]);
         }
     }
     __syncthreads();
@@ -481,26 +494,6 @@ __global__ __launch_bounds__(1024) void jhot_cut_kernel(const K *__restrict__ rk
     }
 }
 
-// btotal[batch] (rows of the batch that carry a hot key with partners, counted by the partition kernel) -> exclusive prefix:
-// the first place of every batch in the stream of hot rows; the total -> *mhot_out (for the host)
-__global__ __launch_bounds__(1024) void jhot_scan_kernel(JHotHead *__restrict__ hot, uint32_t *__restrict__ btotal, uint32_t nbatch, unsigned long long *__restrict__ mhot_out)
-{
-    __shared__ uint32_t s_wave[16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (hot->Hp == 0u) { if (tid == 0) *mhot_out = 0ull; return; }
-    const uint32_t per = (nbatch + 1023u) / 1024u, s0 = min(nbatch, (uint32_t)tid * per), s1 = min(nbatch, s0 + per);
-    uint32_t sum = 0;
-    for (uint32_t i = s0; i < s1; i++) sum += btotal[i];
-    uint32_t incl = sum;
-    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d, 64); if (lane >= d) incl += y; }
-    if (lane == 63) s_wave[wave] = incl;
-    __syncthreads();
-    uint32_t run = incl - sum, total = 0;
-    for (int w = 0; w < 16; w++) { const uint32_t x = s_wave[w]; if (w < wave) run += x; total += x; }
-    for (uint32_t i = s0; i < s1; i++) { const uint32_t c = btotal[i]; btotal[i] = run; run += c; }
-    if (tid == 0) { hot->mhot = total; *mhot_out = total; }
-}
-
 // the rows of the hot keys with partners, in row order: (index among those keys, row); a wave per batch of the partition
 // kernel (BATCH rows).  One stable pass of the radix sort over the index then groups them by key with the row order kept --
 // the reference's order inside a key (join.fut:66).  The keys' rows are counted on the way (prows).
@@ -682,7 +675,10 @@ __global__ __launch_bounds__(kJThreads) void jpart_kernel(const K *__restrict__ 
     };
 
     // rows r .. r + VEC - 1 of this lane (nrows of them exist)
-    auto process = [&](int64_t r, int nrows, const K (&kraw)[VEC], const uint32_t (&vraw)[VEC], bool flush_now) {
+    // (hot_tag: compiled twice -- with the set's probe, and exactly as it was without it: with one body and a run-time test the
+    // kernel without hot keys lost 30-60 us per 1e8 rows against round 5's, interleaved on one box)
+    auto process = [&](auto hot_tag, int64_t r, int nrows, const K (&kraw)[VEC], const uint32_t (&vraw)[VEC], bool flush_now) {
+        constexpr bool HOT = decltype(hot_tag)::value;
         uint32_t pending = 0, hot_rows = 0;
         K kk[VEC];
         uint32_t bk[VEC];
@@ -690,9 +686,12 @@ __global__ __launch_bounds__(kJThreads) void jpart_kernel(const K *__restrict__ 
         for (int j = 0; j < VEC; j++) {
             kk[j] = kraw[j] ^ bias;
             if (j < nrows && kk[j] >= kmin && kk[j] <= kmax) {
-                const uint32_t slot = any_hot ? jhot_find<K>(s_hot, hot_empty, kk[j]) : ~0u;
-                if (slot == ~0u) pending |= 1u << j;
-                else if (s_hp[slot] != kNoHot) hot_rows++;                 // a hot key: its rows take the other road (counted here when it has partners)
+                if (!HOT) pending |= 1u << j;
+                else {
+                    const uint32_t slot = jhot_find<K>(s_hot, hot_empty, kk[j]);
+                    if (slot == ~0u) pending |= 1u << j;
+                    else if (s_hp[slot] != kNoHot) hot_rows++;             // a hot key: its rows take the other road (counted here when it has partners)
+                }
             }
             // bucket = number of splitters <= key = the b with ext[b] <= key < ext[b + 1]
             const K key = kk[j];
@@ -710,7 +709,7 @@ __global__ __launch_bounds__(kJThreads) void jpart_kernel(const K *__restrict__ 
             }
             bk[j] = pos < (uint32_t)P ? pos : (uint32_t)(P - 1);
         }
-        if (any_hot) {
+        if (HOT) {
             for (int d = 32; d > 0; d >>= 1) hot_rows += __shfl_down(hot_rows, d, 64);
             if ((tid & 63) == 0 && hot_rows) atomicAdd(&btotal[r / BATCH], hot_rows);      // (the rows of a wave lie in one batch)
         }
@@ -758,6 +757,7 @@ __global__ __launch_bounds__(kJThreads) void jpart_kernel(const K *__restrict__ 
         } while (again);
     };
 
+    auto run = [&](auto hot_tag) {
     hark_u4v qA = {0u, 0u, 0u, 0u}, qB = qA, qC = qA;
     hark_u2v wA = {0u, 0u}, wB = wA, wC = wA;
     K kk_[VEC];
@@ -773,27 +773,29 @@ __global__ __launch_bounds__(kJThreads) void jpart_kernel(const K *__restrict__ 
         arrived(qA, wA);
         unpack(qA, wA, kk_, vv_);
         nr = rows_of(batch, r);
-        process(r, nr, kk_, vv_, ++since >= period || (batch + nwg >= nbatch && !has_tail));
+        process(hot_tag, r, nr, kk_, vv_, ++since >= period || (batch + nwg >= nbatch && !has_tail));
         load(batch + 3 * (int64_t)nwg, qA, wA); batch += nwg;
         if (batch >= nbatch) break;
         arrived(qB, wB);
         unpack(qB, wB, kk_, vv_);
         nr = rows_of(batch, r);
-        process(r, nr, kk_, vv_, ++since >= period || (batch + nwg >= nbatch && !has_tail));
+        process(hot_tag, r, nr, kk_, vv_, ++since >= period || (batch + nwg >= nbatch && !has_tail));
         load(batch + 3 * (int64_t)nwg, qB, wB); batch += nwg;
         if (batch >= nbatch) break;
         arrived(qC, wC);
         unpack(qC, wC, kk_, vv_);
         nr = rows_of(batch, r);
-        process(r, nr, kk_, vv_, ++since >= period || (batch + nwg >= nbatch && !has_tail));
+        process(hot_tag, r, nr, kk_, vv_, ++since >= period || (batch + nwg >= nbatch && !has_tail));
         load(batch + 3 * (int64_t)nwg, qC, wC); batch += nwg;
     }
     if (HIDDEN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the loads still in flight write registers: let them land
     if (has_tail) {
         const int nr = tid == 0 ? (int)(n - nfull) : 0;
         for (int j = 0; j < VEC; j++) { kk_[j] = (tid == 0 && j < nr) ? keys[nfull + j] : (K)0; vv_[j] = (tid == 0 && j < nr && has_val) ? lval[nfull + j] : 0u; }
-        process(nfull, nr, kk_, vv_, true);
+        process(hot_tag, nfull, nr, kk_, vv_, true);
     }
+    };
+    if (any_hot) run(std::true_type{}); else run(std::false_type{});
     // ---- what is left (< LINE entries per bucket) goes out as one partial line
     for (int b = tid; b < P; b += kJThreads) {
         const uint32_t w = s_w[b];
@@ -1054,16 +1056,34 @@ __global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTrai
     for (int i = tid; i < kCoarse; i += kJThreads) scoarse[(size_t)b * kCoarse + i] = s_coarse[i];
 }
 
-__global__ __launch_bounds__(1024) void jsum_kernel(const uint32_t *__restrict__ scount, int P, unsigned long long *__restrict__ total)
+__global__ __launch_bounds__(1024) void jsum_kernel(const uint32_t *__restrict__ scount, int P, unsigned long long *__restrict__ total,
+                                                    JHotHead *__restrict__ hot, uint32_t *__restrict__ btotal, uint32_t nbatch, unsigned long long *__restrict__ mhot_out)
 {
     __shared__ unsigned long long s_t;
-    if (threadIdx.x == 0) s_t = 0ull;
+    __shared__ uint32_t s_wave[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_t = 0ull;
     __syncthreads();
-    unsigned long long x = (int)threadIdx.x < P ? scount[threadIdx.x] : 0u;
+    unsigned long long x = tid < P ? scount[tid] : 0u;
     for (int d = 32; d > 0; d >>= 1) x += __shfl_down(x, d, 64);
-    if ((threadIdx.x & 63) == 0 && x) atomicAdd(&s_t, x);
+    if (lane == 0 && x) atomicAdd(&s_t, x);
     __syncthreads();
-    if (threadIdx.x == 0) *total = s_t;
+    if (tid == 0) *total = s_t;
+    // ... and the hot rows (in the same launch: a kernel of its own cost 5 us of every join): btotal[batch] (rows of the batch that carry
+    // a hot key with partners, counted by the partition kernel) -> exclusive prefix, the first place of every batch in the stream
+    // of hot rows; the total -> *mhot_out (for the host)
+    if (hot->Hp == 0u) { if (tid == 0) *mhot_out = 0ull; return; }
+    const uint32_t per = (nbatch + 1023u) / 1024u, s0 = min(nbatch, (uint32_t)tid * per), s1 = min(nbatch, s0 + per);
+    uint32_t sum = 0;
+    for (uint32_t i = s0; i < s1; i++) sum += btotal[i];
+    uint32_t incl = sum;
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d, 64); if (lane >= d) incl += y; }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t run = incl - sum, all = 0;
+    for (int w = 0; w < 16; w++) { const uint32_t y = s_wave[w]; if (w < wave) run += y; all += y; }
+    for (uint32_t i = s0; i < s1; i++) { const uint32_t c = btotal[i]; btotal[i] = run; run += c; }
+    if (tid == 0) { hot->mhot = all; *mhot_out = all; }
 }
 
 // Survivor bins -> contiguous arrays (rank, left row, partner count) ORDERED BY (rank, left row): buckets are rank
@@ -1514,6 +1534,43 @@ __global__ __launch_bounds__(256) void jcompact_kernel(const uint2 *__restrict__
     }
 }
 
+// ---- the sample runs EARLY, on the context's second stream, while the build side is being sorted on the first -----------------
+// One block, cleared by one launch: the survivor total and the error word (info, 64 B), the sample table (keys, counts), the batches'
+// counts, the cells and the even buckets' counts, the set's head; the rest of the set behind.
+struct JHotLayout {
+    uint32_t S, cmin, tslots, nbatch, cells;
+    size_t o_tkey, o_tcnt, o_btotal, o_hfine, o_hcoarse, clear_bytes;       // (the set lies at clear_bytes)
+};
+template <typename K> JHotLayout jhot_layout(int64_t n, int64_t s)
+{
+    JHotLayout L;
+    L.S = (uint32_t)std::min<int64_t>(kHotSampleMax, std::max<int64_t>(4096, n / 256));
+    L.cmin = 5;
+    if (const char *e = getenv("HARK_JOIN_HOTMIN")) { const int c = atoi(e); if (c >= 2) L.cmin = (uint32_t)c; }   // tests: hot keys in small tables
+    L.tslots = 1;
+    while (L.tslots < 2u * L.S) L.tslots <<= 1;                               // (a workgroup's samples are counted in LDS first: at most S distinct keys arrive)
+    L.nbatch = (uint32_t)((n + (int64_t)kJThreads * JTraits<K>::VEC - 1) / ((int64_t)kJThreads * JTraits<K>::VEC));      // the partition kernel's batches
+    L.cells = 4096;                                                          // cells of the sorted build side the sampled rows are counted in (about one rank each, 2^20 at most)
+    while (L.cells < (1u << 20) && (int64_t)L.cells < s) L.cells <<= 1;
+    L.o_tkey = 64; L.o_tcnt = L.o_tkey + 8 * (size_t)L.tslots; L.o_btotal = L.o_tcnt + 4 * (size_t)L.tslots;
+    L.o_hfine = L.o_btotal + (4 * (size_t)L.nbatch + 15) / 16 * 16; L.o_hcoarse = L.o_hfine + 4 * (size_t)L.cells;
+    L.clear_bytes = L.o_hcoarse + 4 * (size_t)JTraits<K>::P + 4 * 64;
+    return L;
+}
+static bool jhot_off() { return getenv("HARK_JOIN_NOHOT") != nullptr || getenv("HARK_JOIN_FULLSORT") != nullptr; }   // A/B + tests
+
+template <typename K>
+static int jhot_start(hark_context *ctx, hipStream_t st, unsigned char *block, const JHotLayout &L, const K *lcol, K bias, int64_t n)
+{
+    int rc = HARK_OK;
+    const size_t n16 = (L.clear_bytes + sizeof(JHotHead) + 15) / 16;             // (the block is longer: the rest of the set lies behind the head)
+    HARK_LAUNCH_RC(ctx, rc, jclear_kernel<<<dim3((unsigned)std::min<size_t>((n16 + 255) / 256, (size_t)ctx->num_cu * 8)), 256, 0, st>>>(reinterpret_cast<uint4 *>(block), n16));
+    if (!jhot_off())
+        HARK_LAUNCH_RC(ctx, rc, jhot_sample_kernel<K><<<(L.S + 1023) / 1024, 1024, 0, st>>>(lcol, n, bias, L.S, reinterpret_cast<unsigned long long *>(block + L.o_tkey), reinterpret_cast<uint32_t *>(block + L.o_tcnt),
+                                                                                          L.tslots - 1u, L.cmin, reinterpret_cast<JHotHead *>(block + L.clear_bytes)));
+    return rc;
+}
+
 template <typename K>
 int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K *rkeys, int64_t s, const uint32_t *runlen,
                     int32_t *flags /* device: [0] general sort needed, [1] duplicate build keys */, const uint32_t *lval, const uint32_t *rranked,
@@ -1557,35 +1614,34 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
     if (!rc && verify) rc = hark_alloc(ctx, (void **)&srec, 16 * (size_t)P * region);          // 64-bit keys: records + their ranks alone
     uint32_t *scoarse = nullptr;
     if (!rc) rc = hark_alloc(ctx, (void **)&scoarse, 4 * (size_t)P * kCoarse);
-    // the heavy hitters (see jhot_sample_kernel): one probe key in n / S sampled; the probe column in pieces of R rows, one per wave
+    // the heavy hitters and the buckets' cut (see jhot_sample_kernel): the block may have been prepared -- cleared and sampled on the
+    // context's second stream while the build side was sorted (k_join_hot_prepare) -- or is set up here
     JHotSet<K> *hot = nullptr;
     unsigned long long *tkey = nullptr;
     uint32_t *tcnt = nullptr, *btotal = nullptr, *hfine = nullptr, *hcoarse = nullptr;
-    const bool no_hot = getenv("HARK_JOIN_NOHOT") != nullptr || getenv("HARK_JOIN_FULLSORT") != nullptr;      // A/B + tests
-    uint32_t S = (uint32_t)std::min<int64_t>(kHotSampleMax, std::max<int64_t>(4096, n / 256)), cmin = 5;
-    if (const char *e = getenv("HARK_JOIN_HOTMIN")) { const int c = atoi(e); if (c >= 2) cmin = (uint32_t)c; }   // tests: hot keys in small tables
-    uint32_t tslots = 1;
-    while (tslots < 2u * S) tslots <<= 1;                                        // (a workgroup's samples are counted in LDS first: at most S distinct keys arrive)
-    const uint32_t nbatch = (uint32_t)((n + (int64_t)kJThreads * VEC - 1) / ((int64_t)kJThreads * VEC));      // the partition kernel's batches
-    // one block, cleared by one launch: the survivor total and the error word (info), the sample table (keys, counts), the batches'
-    // counts, the set's head; the rest of the set behind
-    uint32_t cells = 4096;                                                      // cells of the sorted build side the sampled rows are counted in (about one rank each, 2^20 at most)
-    while (cells < (1u << 20) && (int64_t)cells < s) cells <<= 1;
-    const size_t hot_clear = 64 + 12 * (size_t)tslots + (4 * (size_t)nbatch + 15) / 16 * 16 + 4 * (size_t)cells + 4 * (size_t)P + 4 * 64;
+    const bool no_hot = jhot_off();
+    const JHotLayout L = jhot_layout<K>(n, s);
+    const uint32_t S = L.S, cmin = L.cmin, tslots = L.tslots, nbatch = L.nbatch, cells = L.cells;
+    (void)S;
+    const size_t hot_clear = L.clear_bytes;
     unsigned char *hot_block = nullptr;
-    if (!rc) rc = hark_alloc(ctx, (void **)&hot_block, hot_clear + sizeof(JHotSet<K>));
+    bool prepared = false;
+    if (ctx->join_prep && ctx->join_prep_col == static_cast<const void *>(lcol) && ctx->join_prep_n == n && ctx->join_prep_s == s) {
+        hot_block = static_cast<unsigned char *>(ctx->join_prep); ctx->join_prep = nullptr; prepared = true;
+    } else if (!rc) rc = hark_alloc(ctx, (void **)&hot_block, hot_clear + sizeof(JHotSet<K>));
     if (!rc) {
         info = reinterpret_cast<int64_t *>(hot_block);
-        tkey = reinterpret_cast<unsigned long long *>(hot_block + 64);
-        tcnt = reinterpret_cast<uint32_t *>(hot_block + 64 + 8 * (size_t)tslots);
-        btotal = reinterpret_cast<uint32_t *>(hot_block + 64 + 12 * (size_t)tslots);
-        hfine = reinterpret_cast<uint32_t *>(hot_block + 64 + 12 * (size_t)tslots + (4 * (size_t)nbatch + 15) / 16 * 16);
-        hcoarse = hfine + cells;
+        tkey = reinterpret_cast<unsigned long long *>(hot_block + L.o_tkey);
+        tcnt = reinterpret_cast<uint32_t *>(hot_block + L.o_tcnt);
+        btotal = reinterpret_cast<uint32_t *>(hot_block + L.o_btotal);
+        hfine = reinterpret_cast<uint32_t *>(hot_block + L.o_hfine);
+        hcoarse = reinterpret_cast<uint32_t *>(hot_block + L.o_hcoarse);
         hot = reinterpret_cast<JHotSet<K> *>(hot_block + hot_clear);
     }
     auto cleanup = [&]() {
         hark_free(ctx, splitters); hark_free(ctx, bstart); hark_free(ctx, counts); hark_free(ctx, scount); hark_free(ctx, sbins);
         hark_free(ctx, slabs); hark_free(ctx, surv); hark_free(ctx, srec); hark_free(ctx, scoarse);
+        if (prepared && ctx->aux_event) (void)hipStreamWaitEvent(st, ctx->aux_event, 0);      // (its sample may still be running on the second stream: the block is reused in THIS stream's order)
         hark_free(ctx, hot_block);
     };
     if (rc == HARK_ENOMEM) {                                                     // no room for the partition workspace: the sort-merge path
@@ -1596,13 +1652,10 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
     if (rc) { cleanup(); return rc; }
     int32_t *err = reinterpret_cast<int32_t *>(info + 1);
     unsigned long long *total = reinterpret_cast<unsigned long long *>(info);
-    {
-        const size_t n16 = (hot_clear + sizeof(JHotHead) + 15) / 16;             // (the block is longer: the rest of the set lies behind the head)
-        HARK_LAUNCH_RC(ctx, rc, jclear_kernel<<<dim3((unsigned)std::min<size_t>((n16 + 255) / 256, (size_t)ctx->num_cu * 8)), 256, 0, st>>>(reinterpret_cast<uint4 *>(hot_block), n16));
-    }
-    if (!no_hot) {
-        HARK_LAUNCH_RC(ctx, rc, jhot_sample_kernel<K><<<(S + 1023) / 1024, 1024, 0, st>>>(lcol, n, bias, S, tkey, tcnt, tslots - 1u, cmin, hot, rkeys, s, hcoarse, P));
-    }
+    if (prepared) { if (hipStreamWaitEvent(st, ctx->aux_event, 0) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: waiting for the sample failed"); }
+    else rc = jhot_start<K>(ctx, st, hot_block, L, lcol, bias, n);
+    if (!rc && !no_hot)
+        HARK_LAUNCH_RC(ctx, rc, jhot_coarse_kernel<K><<<dim3((unsigned)std::min<uint32_t>((tslots + 1023u) / 1024u, (uint32_t)ctx->num_cu)), 1024, 0, st>>>(tkey, tcnt, tslots, rkeys, s, hcoarse, P));
     // the hot keys of the sample and the buckets' cuts (even, or by the sampled rows' weight when they crowd a stretch of the build side)
     HARK_LAUNCH_RC(ctx, rc, jhot_select_kernel<K><<<1, 1024, 0, st>>>(tkey, tcnt, cmin, rkeys, s, hot, hcoarse, P, splitters, bstart, getenv("HARK_JOIN_EVEN_CUTS") ? 0 : 1, info));
     if (!no_hot) {                                                               // (both leave at once unless the cut is by weight)
@@ -1634,8 +1687,7 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
         if (plain_loads) HARK_LAUNCH_RC(ctx, rc, jpart_kernel<K, false><<<dim3((unsigned)nwg), dim3(kJThreads), lds_part, st>>>(lcol, n, bias, splitters, rkeys, s, slabs, counts, cap, period, err, carry ? lval : nullptr, hot, btotal));
         else HARK_LAUNCH_RC(ctx, rc, jpart_kernel<K, true><<<dim3((unsigned)nwg), dim3(kJThreads), lds_part, st>>>(lcol, n, bias, splitters, rkeys, s, slabs, counts, cap, period, err, carry ? lval : nullptr, hot, btotal));
         HARK_LAUNCH_RC(ctx, rc, jbucket_kernel<K><<<dim3((unsigned)P), dim3(kJThreads), lds_bucket, st>>>(slabs, counts, cap, nwg, rkeys, bstart, chunk_cap, surv, region, scount, sbins, srec, scoarse, stage_cap, err, allow_trunc ? 1 : 0));
-        HARK_LAUNCH_RC(ctx, rc, jsum_kernel<<<1, 1024, 0, st>>>(scount, P, total));
-        HARK_LAUNCH_RC(ctx, rc, jhot_scan_kernel<<<1, 1024, 0, st>>>(hot, btotal, nbatch, reinterpret_cast<unsigned long long *>(info + 3)));   // (leaves at once without hot keys)
+        HARK_LAUNCH_RC(ctx, rc, jsum_kernel<<<1, 1024, 0, st>>>(scount, P, total, hot, btotal, nbatch, reinterpret_cast<unsigned long long *>(info + 3)));
         HIP_TRY_RC(ctx, rc, hipMemcpyAsync(info + 2, flags, 8, hipMemcpyDeviceToDevice, st));   // the duplicate-keys flag rides along with the same host read
     }
     if (he != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: setting the dynamic LDS size of the partition / bucket kernel failed: %s", hipGetErrorString(he));
@@ -1729,6 +1781,41 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
 }
 
 } // namespace
+
+// Called by hark_entry_join BEFORE it sorts the build side: the probe keys' sample (and the clearing of the partition's small state)
+// starts on the context's second stream and runs under the sort's kernels (35 + 6 us of every join otherwise).  Nothing happens
+// when the partitioned path will not run.  k_join_hot_release drops a block nobody took.
+int k_join_hot_prepare(hark_context *ctx, const void *lcol, bool k64, int64_t n, int64_t s)
+{
+    if (ctx->join_prep) k_join_hot_release(ctx);
+    if (n < ((int64_t)1 << 18) || s < 4096 || n + s > 0xFFFFFFFFll || getenv("HARK_JOIN_SORTMERGE") || getenv("HARK_JOIN_NO_EARLY_SAMPLE")) return HARK_OK;
+    if (!ctx->aux_stream) {
+        if (hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->aux_event, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ctx->main_event, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ctx->aux_stream = nullptr; return HARK_OK; }   // (no second stream: the sample runs in line)
+    }
+    const JHotLayout L = k64 ? jhot_layout<uint64_t>(n, s) : jhot_layout<uint32_t>(n, s);
+    unsigned char *block = nullptr;
+    const size_t bytes = L.clear_bytes + (k64 ? sizeof(JHotSet<uint64_t>) : sizeof(JHotSet<uint32_t>));
+    if (hark_alloc(ctx, (void **)&block, bytes) != HARK_OK) { ctx->err.clear(); return HARK_OK; }
+    // the block comes from the pool in the FIRST stream's order (a block freed there may still be read by kernels queued there)
+    int rc = HARK_OK;
+    HIP_TRY_RC(ctx, rc, hipEventRecord(ctx->main_event, ctx->stream));
+    HIP_TRY_RC(ctx, rc, hipStreamWaitEvent(ctx->aux_stream, ctx->main_event, 0));
+    if (!rc) rc = k64 ? jhot_start<uint64_t>(ctx, ctx->aux_stream, block, L, static_cast<const uint64_t *>(lcol), 0x8000000000000000ull, n)
+                      : jhot_start<uint32_t>(ctx, ctx->aux_stream, block, L, static_cast<const uint32_t *>(lcol), 0u, n);
+    HIP_TRY_RC(ctx, rc, hipEventRecord(ctx->aux_event, ctx->aux_stream));
+    ctx->join_prep = block; ctx->join_prep_col = lcol; ctx->join_prep_n = n; ctx->join_prep_s = s;
+    if (rc) { k_join_hot_release(ctx); return rc; }
+    return HARK_OK;
+}
+
+void k_join_hot_release(hark_context *ctx)
+{
+    if (!ctx->join_prep) return;
+    if (ctx->aux_event) (void)hipStreamWaitEvent(ctx->stream, ctx->aux_event, 0);
+    hark_free(ctx, ctx->join_prep);
+    ctx->join_prep = nullptr;
+}
 
 // Matching probe rows of the join as (global rank of the first equal sorted build entry, probe row id), sorted by
 // (rank, probe row), and the partner count of each (*cnt_out == nullptr with *unique: the build keys are all distinct,

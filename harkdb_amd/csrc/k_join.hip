@@ -300,7 +300,8 @@ int hark_entry_join(hark_context *ctx, hark_result **out, const hark_table *db1,
     if (!(n >= ((int64_t)1 << 18) && s >= 4096)) rank_col = -1;             // (the partitioned path's own thresholds)
     uint32_t *rranked = nullptr, *rval = nullptr;
     int build_unique = -1;                                     // 1: the sort saw that all build keys are distinct (no run lengths needed)
-    // ---- the build side is sorted first: both paths need it
+    // ---- the build side is sorted first: both paths need it (the probe keys' sample runs under it on the second stream)
+    if (k_join_hot_prepare(ctx, lcol, k64, n, s) != HARK_OK) ctx->err.clear();       // (without it the sample runs in line)
     if (k64) rc = k_argsort_i64_keys(ctx, rcol, s, &rperm, &rk64,           // permutation + the sorted (biased) keys (+ the column) in one go
                                      rank_col >= 0 ? static_cast<const uint32_t *>(db2->cols[rank_col].data) : nullptr, rank_col >= 0 ? &rranked : nullptr, &build_unique);
     else {
@@ -480,6 +481,7 @@ int hark_entry_join(hark_context *ctx, hark_result **out, const hark_table *db1,
         }
         if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: kernels failed");
     }
+    k_join_hot_release(ctx);
     hark_free(ctx, lk64); hark_free(ctx, rk64);
     hark_free(ctx, lperm); hark_free(ctx, lkeys); hark_free(ctx, rperm); hark_free(ctx, rkeys); hark_free(ctx, lb); hark_free(ctx, cnt); hark_free(ctx, offs); hark_free(ctx, lrow); hark_free(ctx, rrow); hark_free(ctx, kpos);
     hark_free(ctx, sval); hark_free(ctx, lval_exp); hark_free(ctx, rranked); hark_free(ctx, rval);
