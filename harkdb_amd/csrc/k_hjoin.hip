@@ -1136,11 +1136,11 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
     __shared__ uint32_t s_bincnt[kBinSlots];
     __shared__ uint32_t s_np;
     __shared__ int s_bad, s_big;
-    __shared__ uint32_t s_h0, s_nh, s_nlong;
+    __shared__ uint32_t s_h0, s_nh, s_nlong, s_anylong;
     __shared__ uint32_t s_hrank[kHotMax], s_hcum[kHotMax + 1];               // the bucket's hot ranks (ascending), the hot rows before each (inside the bucket)
     __shared__ uint2 s_long[kLongMax];                                       // runs of more than kTieMax rows in the stage (first, length)
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) { s_dst = 0ull; s_bad = 0; s_big = 0; s_np = 0u; s_h0 = 0u; s_nh = 0u; s_nlong = 0u; }
+    if (tid == 0) { s_dst = 0ull; s_bad = 0; s_big = 0; s_np = 0u; s_h0 = 0u; s_nh = 0u; s_nlong = 0u; s_anylong = 0u; }
     if (tid < kBinSlots) s_bincnt[tid] = sbins[(size_t)b * kBinSlots + tid];
     __syncthreads();
     const uint32_t Hp = hot->Hp;                                           // hot keys with partners: dense and ascending, so a bucket's are a range [h0, h0 + nh)
@@ -1305,7 +1305,8 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
         if (nsub) {
             // the window of ranks being staged: [w_r0, w_r0 + w_nr) of the bucket, w_base survivors of the bucket before it, w_nsub in it
             uint32_t w_r0 = r0, w_nr = nr, w_base = base_cnt, w_nsub = nsub;
-            auto count_one = [&](uint2 e, uint32_t, uint32_t) { const uint32_t r = e.x - lo - w_r0; if (r < w_nr) atomicAdd(&fine[r], 1u); };
+            // (the 65th row of a rank raises s_anylong: only then are the stage's runs looked over for long ones, below)
+            auto count_one = [&](uint2 e, uint32_t, uint32_t) { const uint32_t r = e.x - lo - w_r0; if (r < w_nr && atomicAdd(&fine[r], 1u) == (uint32_t)kTieMax) s_anylong = 1u; };
             auto place_one = [&](uint2 e, uint32_t v, uint32_t kl) {
                 const uint32_t r = e.x - lo - w_r0;
                 if (r < w_nr) { const uint32_t at = atomicAdd(&fine[r], 1u); stage[at] = e; if (CARRY) stv[at] = v; if (VERIFY) stk[at] = kl; }   // afterwards fine[r] = end of rank r's rows
@@ -1319,12 +1320,15 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
             // ---- a rank with more than kTieMax rows (a key too rare for the sample, too frequent for the counting below): its
             // run of the stage is sorted by left row in place, one wave per run -- a bitonic network over the run padded to a power
             // of two (the padding is never touched: every exchange moves the smaller row to the lower index)
-            for (uint32_t r = tid; r < w_nr; r += kJThreads) {
-                const uint32_t a0 = r ? fine[r - 1u] : 0u, a1 = fine[r];
-                if (a1 - a0 > (uint32_t)kTieMax) s_long[atomicAdd(&s_nlong, 1u)] = uint2{a0, a1 - a0};   // (at most STAGE / (kTieMax + 1) of them)
+            const bool any_long = s_anylong != 0u;                      // (written during the count, two barriers ago)
+            if (any_long) {
+                for (uint32_t r = tid; r < w_nr; r += kJThreads) {
+                    const uint32_t a0 = r ? fine[r - 1u] : 0u, a1 = fine[r];
+                    if (a1 - a0 > (uint32_t)kTieMax) s_long[atomicAdd(&s_nlong, 1u)] = uint2{a0, a1 - a0};   // (at most STAGE / (kTieMax + 1) of them)
+                }
+                __syncthreads();
             }
-            __syncthreads();
-            const uint32_t nlong = s_nlong;
+            const uint32_t nlong = any_long ? s_nlong : 0u;
             auto exchange = [&](uint32_t a0, uint32_t L, uint32_t i, uint32_t j) {          // i < j
                 if (j < L) {
                     const uint32_t x = stage[a0 + i].y, y = stage[a0 + j].y;
@@ -1357,7 +1361,7 @@ __global__ __launch_bounds__(kJThreads) void jorder_kernel(const uint2 *__restri
                 if (s_long[q].y > (uint32_t)kWaveSortMax) bitonic(s_long[q].x, s_long[q].y, (uint32_t)tid, (uint32_t)kJThreads, [] { __syncthreads(); });
             for (uint32_t q = wave; q < nlong; q += kJThreads / 64)
                 if (s_long[q].y <= (uint32_t)kWaveSortMax) bitonic(s_long[q].x, s_long[q].y, (uint32_t)lane, 64u, [] { wave_lds_sync(); });
-            if (nlong) { __syncthreads(); if (tid == 0) s_nlong = 0u; }
+            if (any_long) { __syncthreads(); if (tid == 0) { s_nlong = 0u; s_anylong = 0u; } }
             // ---- rows of one rank into left-row order, and out: every survivor counts the rows of ITS rank (the stage's run
             // [fine[r-1], fine[r]), five or so) that are smaller than its own -- row ids are distinct, so that is its place in
             // the run -- and stores itself there.  (A first version sorted each run in registers with sorting networks, one
