@@ -24,6 +24,7 @@ struct hark_context {
     hipStream_t aux_stream = nullptr;
     hipEvent_t aux_event = nullptr, main_event = nullptr;
     void *join_prep = nullptr; const void *join_prep_col = nullptr; int64_t join_prep_n = 0, join_prep_s = 0;
+    bool join_prep_tested = false;  // ... and the probe column's clustering test (k_cjoin.hip) was enqueued behind its sample
     std::string err;
     int32_t *d_err = nullptr;       // device-side sticky error word (bounds failures)
     int32_t *h_pin = nullptr;       // pinned scratch for small D2H reads (64 KiB: status words, LIMIT prefixes)
@@ -47,6 +48,7 @@ struct hark_context {
     int last_groupby_passes = 0;             // row passes of the last dense-path filter_groupby (hark_context_last_groupby_passes)
     int last_join_path = 0;        // hark_context_last_join_path
     bool last_join_weighted = false;   // ... the partitioned path cut its buckets by the sampled probe rows' weight (k_hjoin.hip)
+    bool last_join_clustered = false;  // ... the probe column was clustered by key: searched in row order (k_cjoin.hip)
 };
 
 // Every entry runs on the context's device whatever device the calling thread has current (a process may hold
@@ -103,8 +105,14 @@ struct hark_result {
     int64_t host_rows = 0, host_cols = 0;
 };
 static inline void hark_result_host_release(hark_context *ctx, hark_result *r) { if (r && r->host_matrix) { hark_host_free(ctx, r->host_matrix); r->host_matrix = nullptr; } }
-int k_join_hot_prepare(hark_context *ctx, const void *lcol, bool k64, int64_t n, int64_t s);
+int k_join_hot_prepare(hark_context *ctx, const void *lcol, bool k64, int64_t n, const void *rcol, int64_t s);
 void k_join_hot_release(hark_context *ctx);
+// k_cjoin.hip: the join of a probe column sorted / clustered by the key (same outputs as k_hjoin.hip's run_partitioned)
+int k_cjoin_test(hark_context *ctx, hipStream_t st, const void *lcol, bool k64, int64_t n, const void *build, int64_t s, bool sorted_build);
+bool k_cjoin_verdict(hark_context *ctx);
+int k_cjoin_run(hark_context *ctx, const void *lcol, bool k64, int64_t n, const void *rkeys, int64_t s, const uint32_t *runlen, const int32_t *flags,
+                const uint32_t *lval, const uint32_t *rranked, uint32_t **rank_out, uint32_t **lrow_out, uint32_t **cnt_out, uint32_t **lval_out,
+                uint32_t **rval_out, int64_t *m_out, bool *used, bool *dup_out, bool rows_needed, int64_t *general_out);
 // k_small.hip: tables of a few rows in one launch and one synchronisation
 bool k_small_fits(const hark_table *db, int64_t result_cols);
 int k_small_query_sel(hark_context *ctx, const hark_table *db, const int32_t *cols, int64_t k, hark_result *res);

@@ -1,0 +1,351 @@
+// k_cjoin.hip -- the join for a probe column that is SORTED or CLUSTERED by the join key (a fact table kept in key order, the
+// output of a GROUP BY joined back).  Replaces futhark/join.fut:58-68 (the merge of the two sorted sides) for such inputs.
+//
+// Why a path of its own: the partitioned join (k_hjoin.hip) routes every probe row through per-bucket LDS rings into
+// workgroup-private slabs, both sized for rows that SCATTER over the 512 buckets.  Consecutive rows of a sorted column fall into
+// ONE bucket: a batch of 4096 rows then sweeps a ring of 32 entries 128 times and overruns the workgroup's slab of that bucket
+// -- 1e8 sorted probe rows took 58 ms (50 of them in the partition, then the sort-merge path) against 1.1 ms for the same rows
+// shuffled (tools/join_cluster_probe.py).  What hurts there helps here: consecutive rows need NEIGHBOURING places of the sorted build
+// side, so a plain search per row finds its lines in the caches.
+//   1. cj_test_kernel (one workgroup, on the second stream under the build side's sort): are rows half a batch apart, or four
+//      lanes apart, closer in key order than rows anywhere apart?  4096 such pairs against quantiles of a sample of the column.
+//   2. cj_search_kernel: batches of 4096 consecutive rows; every row finds its 1 / 8192 of the build side in an index kept in LDS
+//      (13 steps), then its rank by ~11 steps over the sorted build keys in memory (the wave's rows share a few lines); matching
+//      rows leave as (rank, row) in ROW order into the batch's own stretch of a scratch array, with the batch's count and
+//      first / last rank.
+//   3. cj_scan_kernel: the batches' offsets; and whether the ranks ascend over the whole column (a sorted column: the output
+//      order (key, left row, right row) is then the row order and nothing needs sorting).
+//   4. cj_emit_kernel: the batches' rows to their places, with the partner counts and the carried / rank-ordered columns.
+// A column that is clustered but not ascending (descending, sorted block by block) gets the general ordering of the caller
+// (two radix sorts over the MATCHING rows).
+#include "hark_internal.h"
+
+namespace {
+
+constexpr int kCThreads = 1024, kCVec = 4, kCBatch = kCThreads * kCVec;
+template <typename K> struct CIdx { static constexpr int N = 32768 / (int)sizeof(K); };   // entries of the LDS index over the build side (32 KiB)
+
+// The test, against 1024 quantiles of the BUILD side (a sample of its unsorted column, sorted here by the workgroup -- shuffles
+// inside the waves, LDS for partners 64 and more lanes away -- or read off the sorted keys when the test runs late):
+//   * rows kCtFar places apart (half a batch of the partition) within kCtNear / 1024 of the build side -- a batch then spans at
+//     most ~4 of the partition's 512 buckets (measured, 1e8 rows sorted block by block, tools/join_cluster_probe.py: blocks of
+//     1e5 rows 3.4 ms partitioned / 10.3 searched, of 1e6 rows 27 / 2.8);
+//   * or rows kCtClose places apart (four lanes of the search) within kCtKeys build keys, the cell's width read off the
+//     neighbouring quantiles -- a wave's rows then share a few lines of the build side (sorted runs of 256 rows in shuffled
+//     order: 1.7 ms searched, while the partition overruns its slabs and the probe side gets sorted: 7.9; runs of 16 rows:
+//     2.0 searched, 1.3 partitioned -- rows 16 apart lie in different runs there, and the verdict is "scattered").
+// Both against the same measure for rows ANYWHERE apart (the key of another pair): a column of few distinct keys, or one that
+// mostly misses the build side's range, is close to itself everywhere.  One pair per thread: the kernel waits for ~3000
+// address translations of rows all over the columns, not for its arithmetic (4096 pairs: 75 us).
+constexpr int kCtSample = 1024, kCtPairs = 1024, kCtFar = 2048, kCtClose = 16, kCtNear = 4, kCtKeys = 256;
+
+__device__ __forceinline__ uint32_t cj_mix(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
+
+template <typename K> __device__ __forceinline__ K cj_shfl_xor(K x, int j);
+template <> __device__ __forceinline__ uint32_t cj_shfl_xor<uint32_t>(uint32_t x, int j) { return (uint32_t)__shfl_xor((int)x, j, 64); }
+template <> __device__ __forceinline__ uint64_t cj_shfl_xor<uint64_t>(uint64_t x, int j)
+{
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)x, j, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(x >> 32), j, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// keys: the probe column; build: the build side's key column as the tables hold it (sorted_build = 0: both compared as raw bit
+// patterns -- for i64 keys that is the signed order rotated, which serves a test of closeness as well) or its sorted keys
+// (sorted_build = 1: `bias` makes the probe keys comparable).
+// verdict[0] = 1: clustered; [1] / [2]: pairs half a batch / anywhere apart in neighbouring cells, [3] / [4]: pairs four lanes /
+// anywhere apart within kCtKeys build keys (diagnostics).  `verdict` may be pinned host memory.
+template <typename K>
+__global__ __launch_bounds__(1024) void cj_test_kernel(const K *__restrict__ keys, int64_t n, K bias, const K *__restrict__ build, int64_t s, int sorted_build,
+                                                       unsigned long long *verdict)
+{
+    __shared__ K s_k[kCtSample], s_a[kCtPairs];
+    __shared__ uint32_t s_cnt[4];
+    const int tid = threadIdx.x;
+    if (tid < 4) s_cnt[tid] = 0u;
+    K x = sorted_build ? build[(int64_t)(((uint64_t)tid * (uint64_t)s) / kCtSample)] : build[(int64_t)(((uint64_t)cj_mix(2u * (uint32_t)tid + 1u) * (uint64_t)s) >> 32)];
+    const int64_t r = (int64_t)(((uint64_t)cj_mix(0x9E3779B9u + (uint32_t)tid) * (uint64_t)(n - kCtFar)) >> 32);   // n >= 2^18 (the caller's threshold)
+    const K ka = keys[r] ^ bias, kb = keys[r + kCtFar] ^ bias, kc = keys[r + kCtClose] ^ bias;   // in flight while the sample is sorted
+    if (!sorted_build)
+        for (int k = 2; k <= kCtSample; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                K y;
+                if (j >= 64) { s_k[tid] = x; __syncthreads(); y = s_k[tid ^ j]; __syncthreads(); }
+                else y = cj_shfl_xor<K>(x, j);
+                const bool keep_min = ((tid & k) == 0) == ((tid & j) == 0);
+                x = keep_min ? (y < x ? y : x) : (y > x ? y : x);
+            }
+    s_k[tid] = x; s_a[tid] = ka;
+    __syncthreads();
+    const K kf = s_a[(tid + kCtPairs / 2) & (kCtPairs - 1)];              // a row anywhere else: the first key of another pair
+    auto quant = [&](K v) -> int {                                        // sample keys below v
+        int pos = 0;
+#pragma unroll
+        for (int step = kCtSample / 2; step > 0; step >>= 1) if (s_k[pos + step - 1] < v) pos += step;
+        return pos + (s_k[pos] < v ? 1 : 0);
+    };
+    const int qa = quant(ka), qb = quant(kb), qf = quant(kf);
+    const int lo = max(qa - 2, 0), hi = min(qa + 2, kCtSample - 1);
+    // kCtKeys build keys in key units around ka: a cell (s / 1024 build keys) is (s_k[hi] - s_k[lo]) / (hi - lo) wide; at most kCtNear cells
+    const double cells = fmin((double)kCtKeys * (double)kCtSample / (double)s, (double)kCtNear);
+    const double reach = (double)(s_k[hi] - s_k[lo]) / (double)(hi - lo) * cells;
+    const K dc = ka > kc ? ka - kc : kc - ka, df = ka > kf ? ka - kf : kf - ka;
+    const uint32_t near = abs(qa - qb) <= kCtNear, far = abs(qa - qf) <= kCtNear, fine = (double)dc <= reach, ffar = (double)df <= reach;
+    const unsigned long long m0 = __ballot(near), m1 = __ballot(far), m2 = __ballot(fine), m3 = __ballot(ffar);
+    if ((tid & 63) == 0) { atomicAdd(&s_cnt[0], __popcll(m0)); atomicAdd(&s_cnt[1], __popcll(m1)); atomicAdd(&s_cnt[2], __popcll(m2)); atomicAdd(&s_cnt[3], __popcll(m3)); }
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t a = s_cnt[0], b = s_cnt[1], c = s_cnt[2], d = s_cnt[3];
+        verdict[1] = a; verdict[2] = b; verdict[3] = c; verdict[4] = d;
+        verdict[0] = ((a > b && (a - b) * 8u > (uint32_t)kCtPairs) || (c > d && (c - d) * 8u > (uint32_t)kCtPairs)) ? 1ull : 0ull;
+    }
+}
+
+// keys: the probe column (raw), x = key ^ bias is compared with the sorted build keys (64-bit keys: biased by 2^63).
+template <typename K>
+__global__ __launch_bounds__(kCThreads) void cj_search_kernel(const K *__restrict__ keys, int64_t n, K bias, const K *__restrict__ rkeys, int64_t s,
+                                                              uint2 *__restrict__ tmp, uint32_t *__restrict__ bcount, uint32_t *__restrict__ bfirst,
+                                                              uint32_t *__restrict__ blast, int32_t *__restrict__ unsorted)
+{
+    constexpr int IDX = CIdx<K>::N;
+    __shared__ K s_idx[IDX];
+    __shared__ uint2 s_out[kCBatch];
+    __shared__ uint32_t s_wsum[kCThreads / 64];
+    __shared__ uint32_t s_bad;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    auto idx_pos = [&](uint32_t i) -> uint32_t { return (uint32_t)(((uint64_t)i * (uint64_t)s) / (uint64_t)IDX); };
+    for (int i = tid; i < IDX; i += kCThreads) s_idx[i] = rkeys[idx_pos((uint32_t)i)];
+    const K kmin = rkeys[0], kmax = rkeys[s - 1];
+    if (tid == 0) s_bad = 0u;
+    __syncthreads();
+    const int64_t nbatch = (n + kCBatch - 1) / kCBatch;
+    for (int64_t batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
+        const int64_t r0 = batch * kCBatch + (int64_t)tid * kCVec;
+        K x[kCVec];
+        if (r0 + kCVec <= n) {
+            if (sizeof(K) == 4) {
+                const hark_u4v q = __builtin_nontemporal_load(reinterpret_cast<const hark_u4v *>(keys + r0));
+                x[0] = (K)q.x; x[1] = (K)q.y; x[2] = (K)q.z; x[3] = (K)q.w;
+            } else {
+                const hark_u4v q0 = __builtin_nontemporal_load(reinterpret_cast<const hark_u4v *>(keys + r0));
+                const hark_u4v q1 = __builtin_nontemporal_load(reinterpret_cast<const hark_u4v *>(keys + r0 + 2));
+                x[0] = (K)(((uint64_t)q0.y << 32) | q0.x); x[1] = (K)(((uint64_t)q0.w << 32) | q0.z);
+                x[2] = (K)(((uint64_t)q1.y << 32) | q1.x); x[3] = (K)(((uint64_t)q1.w << 32) | q1.z);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < kCVec; j++) x[j] = r0 + j < n ? keys[r0 + j] : (K)0;
+        }
+        uint32_t lo[kCVec], hi[kCVec];
+#pragma unroll
+        for (int j = 0; j < kCVec; j++) {
+            x[j] ^= bias;
+            lo[j] = 1u; hi[j] = 0u;                                       // (lo > hi: no such row, or its key lies outside the build side)
+            if (r0 + j < n && x[j] >= kmin && x[j] <= kmax) {
+                uint32_t pos = 0;                                         // index entries below the key
+#pragma unroll
+                for (int step = IDX / 2; step > 0; step >>= 1) if (s_idx[pos + step - 1] < x[j]) pos += step;
+                if (s_idx[pos] < x[j]) pos++;                             // (the steps count among the first IDX - 1 entries)
+                // the first build entry >= key lies in [lo, hi]: rkeys[lo - 1] < key (or lo = 0), rkeys[hi] >= key
+                lo[j] = pos == 0u ? 0u : idx_pos(pos - 1u) + 1u;
+                hi[j] = pos == (uint32_t)IDX ? (uint32_t)(s - 1) : idx_pos(pos);
+                if (lo[j] > hi[j]) lo[j] = hi[j];                         // (pos = 0: the key IS the smallest build key)
+            }
+        }
+        for (;;) {
+            K v[kCVec];
+            uint32_t mid[kCVec];
+            bool go = false;
+#pragma unroll
+            for (int j = 0; j < kCVec; j++) {
+                mid[j] = lo[j] + ((hi[j] - lo[j]) >> 1);
+                const bool act = lo[j] < hi[j];
+                go = go || act;
+                v[j] = act ? rkeys[mid[j]] : (K)0;
+            }
+            if (!__any(go)) break;
+#pragma unroll
+            for (int j = 0; j < kCVec; j++)
+                if (lo[j] < hi[j]) { if (v[j] < x[j]) lo[j] = mid[j] + 1u; else hi[j] = mid[j]; }
+        }
+        uint32_t found = 0, c = 0;
+#pragma unroll
+        for (int j = 0; j < kCVec; j++)
+            if (lo[j] == hi[j] && rkeys[lo[j]] == x[j]) { found |= 1u << j; c++; }
+        uint32_t incl = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+        if (lane == 63) s_wsum[wave] = incl;
+        __syncthreads();
+        uint32_t woff = 0, cnt = 0;
+#pragma unroll
+        for (int w = 0; w < kCThreads / 64; w++) { const uint32_t t = s_wsum[w]; if (w < wave) woff += t; cnt += t; }
+        uint32_t at = woff + incl - c;
+#pragma unroll
+        for (int j = 0; j < kCVec; j++)
+            if (found & (1u << j)) s_out[at++] = make_uint2(lo[j], (uint32_t)(r0 + j));
+        __syncthreads();
+        bool bad = false;
+        uint2 *dst = tmp + batch * kCBatch;
+        for (uint32_t i = tid; i < cnt; i += kCThreads) {
+            const uint2 e = s_out[i];
+            if (i + 1u < cnt && e.x > s_out[i + 1u].x) bad = true;
+            dst[i] = e;
+        }
+        if (bad) s_bad = 1u;
+        if (tid == 0) {
+            bcount[batch] = cnt;
+            if (cnt) { bfirst[batch] = s_out[0].x; blast[batch] = s_out[cnt - 1u].x; }
+        }
+        __syncthreads();                                                  // s_out / s_wsum are the next batch's
+    }
+    if (tid == 0 && s_bad) *unsorted = 1;
+}
+
+// boff[b] = matching rows before batch b; total[0] = all of them; *unsorted when a batch starts below a rank seen before it.
+// One workgroup; every wave takes a stretch of the batches 64 at a time (coalesced reads, scans by shuffles), the waves' totals meet
+// in LDS.  (A thread per stretch, one batch after the other: 61 us for 24 K batches; this: see profiles/r06_notes.md.)
+__global__ __launch_bounds__(1024) void cj_scan_kernel(const uint32_t *__restrict__ bcount, const uint32_t *__restrict__ bfirst, const uint32_t *__restrict__ blast,
+                                                       uint32_t nbatch, uint32_t *__restrict__ boff, unsigned long long *__restrict__ total, int32_t *__restrict__ unsorted)
+{
+    __shared__ uint32_t s_sum[16], s_max[16], s_minf[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t per = ((nbatch + 15u) / 16u + 63u) & ~63u;             // batches per wave, whole rounds of 64
+    const uint32_t b0 = min(nbatch, wave * per), b1 = min(nbatch, b0 + per);
+    uint32_t run = 0, seen = 0, minf = 0xFFFFFFFFu;
+    bool bad = false;
+    for (uint32_t base = b0; base < b1; base += 64u) {
+        const uint32_t b = base + lane;
+        const uint32_t c = b < b1 ? bcount[b] : 0u;
+        const uint32_t f = c ? bfirst[b] : 0xFFFFFFFFu, l = c ? blast[b] : 0u;
+        uint32_t incl = c, pm = l;                                        // inclusive sum / inclusive max over the lanes
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(incl, d, 64), m = __shfl_up(pm, d, 64);
+            if (lane >= (uint32_t)d) { incl += t; pm = max(pm, m); }
+        }
+        uint32_t before = __shfl_up(pm, 1, 64);                           // the largest rank of the lanes before this one ...
+        before = max(lane ? before : 0u, seen);                           // ... and of the wave's earlier rounds
+        if (c && before > f) bad = true;
+        if (b < b1) boff[b] = run + incl - c;
+        run += __shfl(incl, 63, 64);
+        seen = max(seen, __shfl(pm, 63, 64));
+        minf = min(minf, f);
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) minf = min(minf, __shfl_down(minf, d, 64));
+    if (lane == 0) { s_sum[wave] = run; s_max[wave] = seen; s_minf[wave] = minf; }
+    __syncthreads();
+    uint32_t woff = 0, wseen = 0, all = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 16u; w++) { if (w < wave) { woff += s_sum[w]; wseen = max(wseen, s_max[w]); } all += s_sum[w]; }
+    if (wseen > s_minf[wave]) bad = true;                                 // (no rows in this wave: the minimum is all ones)
+    if (woff) for (uint32_t b = b0 + lane; b < b1; b += 64u) boff[b] += woff;
+    if (bad) *unsorted = 1;
+    if (tid == 0) *total = (unsigned long long)all;
+}
+
+__global__ __launch_bounds__(256) void cj_emit_kernel(const uint2 *__restrict__ tmp, const uint32_t *__restrict__ bcount, const uint32_t *__restrict__ boff, uint32_t nbatch,
+                                                      const uint32_t *__restrict__ runlen, const uint32_t *__restrict__ lval, const uint32_t *__restrict__ rranked,
+                                                      uint32_t *__restrict__ rank, uint32_t *__restrict__ lrow, uint32_t *__restrict__ cnt,
+                                                      uint32_t *__restrict__ lv, uint32_t *__restrict__ rv)
+{
+    for (uint32_t b = blockIdx.x; b < nbatch; b += gridDim.x) {
+        const uint32_t c = bcount[b];
+        if (!c) continue;
+        const uint2 *src = tmp + (size_t)b * kCBatch;
+        const size_t off = boff[b];
+        for (uint32_t i = threadIdx.x; i < c; i += 256u) {
+            const uint2 e = src[i];
+            if (rank) rank[off + i] = e.x;
+            if (lrow) lrow[off + i] = e.y;
+            if (cnt) cnt[off + i] = runlen[e.x];
+            if (lv) lv[off + i] = lval[e.y];
+            if (rv) rv[off + i] = rranked[e.x];
+        }
+    }
+}
+
+template <typename K>
+int run_clustered(hark_context *ctx, const K *lcol, K bias, int64_t n, const K *rkeys, int64_t s, const uint32_t *runlen, const int32_t *flags,
+                  const uint32_t *lval, const uint32_t *rranked, uint32_t **rank_out, uint32_t **lrow_out, uint32_t **cnt_out, uint32_t **lval_out,
+                  uint32_t **rval_out, int64_t *m_out, bool *used, bool *dup_out, bool rows_needed, int64_t *general_out)
+{
+    *used = false;
+    hipStream_t st = ctx->stream;
+    const int64_t nbatch = (n + kCBatch - 1) / kCBatch;
+    uint2 *tmp = nullptr;
+    uint32_t *bcount = nullptr, *bfirst = nullptr, *blast = nullptr, *boff = nullptr;
+    int64_t *info = nullptr;                                              // [0] matching rows, [1] low: not ascending, [2] the caller's flags
+    uint32_t *rank = nullptr, *lrow = nullptr, *cnt = nullptr, *lv = nullptr, *rv = nullptr;
+    int rc = hark_alloc(ctx, (void **)&tmp, 8 * (size_t)nbatch * kCBatch);
+    if (!rc) rc = hark_alloc(ctx, (void **)&bcount, 4 * (size_t)nbatch * 4);
+    if (!rc) rc = hark_alloc(ctx, (void **)&info, 64);
+    auto cleanup = [&]() { hark_free(ctx, tmp); hark_free(ctx, bcount); hark_free(ctx, info); };
+    if (rc == HARK_ENOMEM) { cleanup(); ctx->err.clear(); return HARK_OK; }   // no room: the sort-merge path needs less
+    if (rc) { cleanup(); return rc; }
+    bfirst = bcount + nbatch; blast = bfirst + nbatch; boff = blast + nbatch;
+    HIP_TRY_RC(ctx, rc, hipMemsetAsync(info, 0, 64, st));
+    int grid = (int)std::min<int64_t>(nbatch, (int64_t)ctx->num_cu * 2);
+    if (const char *e = getenv("HARK_CJOIN_GRID")) { const int g = atoi(e); if (g >= 1 && g <= 65536) grid = g; }   // tests: several batches per workgroup at any size
+    HARK_LAUNCH_RC(ctx, rc, cj_search_kernel<K><<<dim3((unsigned)grid), dim3(kCThreads), 0, st>>>(lcol, n, bias, rkeys, s, tmp, bcount, bfirst, blast, reinterpret_cast<int32_t *>(info + 1)));
+    HARK_LAUNCH_RC(ctx, rc, cj_scan_kernel<<<1, 1024, 0, st>>>(bcount, bfirst, blast, (uint32_t)nbatch, boff, reinterpret_cast<unsigned long long *>(info), reinterpret_cast<int32_t *>(info + 1)));
+    HIP_TRY_RC(ctx, rc, hipMemcpyAsync(info + 2, flags, 8, hipMemcpyDeviceToDevice, st));
+    int64_t words[3] = {0, 0, 0};
+    if (!rc) rc = hark_read_words(ctx, info, words, 3);
+    const int64_t M = words[0];
+    const bool general = (words[1] & 0xFFFFFFFFll) != 0 || getenv("HARK_JOIN_FULLSORT") != nullptr;
+    const bool dup = ((words[2] >> 32) & 0xFFFFFFFFll) != 0;
+    *dup_out = dup;
+    *general_out = general ? 1 : 0;
+    if (!rc && M > 0) {
+        const bool skip_rows = !rows_needed && !dup && !general && !getenv("HARK_JOIN_ROWS");
+        if (!skip_rows) rc = hark_alloc(ctx, (void **)&rank, 4 * (size_t)M);
+        if (!rc && !skip_rows) rc = hark_alloc(ctx, (void **)&lrow, 4 * (size_t)M);
+        if (!rc && dup) rc = hark_alloc(ctx, (void **)&cnt, 4 * (size_t)M);
+        if (!rc && lval && !general) rc = hark_alloc(ctx, (void **)&lv, 4 * (size_t)M);
+        if (!rc && rranked && !dup && !general) rc = hark_alloc(ctx, (void **)&rv, 4 * (size_t)M);
+        const int g = (int)std::min<int64_t>(nbatch, (int64_t)ctx->num_cu * 8);
+        HARK_LAUNCH_RC(ctx, rc, cj_emit_kernel<<<dim3((unsigned)g), 256, 0, st>>>(tmp, bcount, boff, (uint32_t)nbatch, runlen, lval, rranked, rank, lrow, cnt, lv, rv));
+    }
+    cleanup();                                                            // stream-ordered reuse
+    if (rc) { hark_free(ctx, rank); hark_free(ctx, lrow); hark_free(ctx, cnt); hark_free(ctx, lv); hark_free(ctx, rv); return rc; }
+    *rank_out = rank; *lrow_out = lrow; *cnt_out = cnt; *lval_out = lv; *rval_out = rv; *m_out = M; *used = true;
+    return HARK_OK;
+}
+
+} // namespace
+
+// the test's three words at the end of the context's pinned scratch (the kernel writes host memory; read after the stream's event)
+static unsigned long long *cj_verdict_words(hark_context *ctx) { return reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(ctx->h_pin) + 65536 - 64); }
+
+// Enqueues the test on `st`; k_cjoin_verdict reads it once the caller has waited for that stream's work.  build: the build side's
+// key column (sorted_build = false: before it is sorted, as the table holds it) or its sorted (64-bit: biased) keys.
+int k_cjoin_test(hark_context *ctx, hipStream_t st, const void *lcol, bool k64, int64_t n, const void *build, int64_t s, bool sorted_build)
+{
+    int rc = HARK_OK;
+    unsigned long long *v = cj_verdict_words(ctx);
+    if (k64) HARK_LAUNCH_RC(ctx, rc, cj_test_kernel<uint64_t><<<1, 1024, 0, st>>>(static_cast<const uint64_t *>(lcol), n, sorted_build ? 0x8000000000000000ull : 0ull,
+                                                                                  static_cast<const uint64_t *>(build), s, sorted_build ? 1 : 0, v));
+    else HARK_LAUNCH_RC(ctx, rc, cj_test_kernel<uint32_t><<<1, 1024, 0, st>>>(static_cast<const uint32_t *>(lcol), n, 0u, static_cast<const uint32_t *>(build), s, sorted_build ? 1 : 0, v));
+    return rc;
+}
+
+bool k_cjoin_verdict(hark_context *ctx)
+{
+    const volatile unsigned long long *v = cj_verdict_words(ctx);
+    return v[0] != 0ull;
+}
+
+int k_cjoin_run(hark_context *ctx, const void *lcol, bool k64, int64_t n, const void *rkeys, int64_t s, const uint32_t *runlen, const int32_t *flags,
+                const uint32_t *lval, const uint32_t *rranked, uint32_t **rank_out, uint32_t **lrow_out, uint32_t **cnt_out, uint32_t **lval_out,
+                uint32_t **rval_out, int64_t *m_out, bool *used, bool *dup_out, bool rows_needed, int64_t *general_out)
+{
+    return k64 ? run_clustered<uint64_t>(ctx, static_cast<const uint64_t *>(lcol), 0x8000000000000000ull, n, static_cast<const uint64_t *>(rkeys), s, runlen, flags, lval, rranked,
+                                         rank_out, lrow_out, cnt_out, lval_out, rval_out, m_out, used, dup_out, rows_needed, general_out)
+               : run_clustered<uint32_t>(ctx, static_cast<const uint32_t *>(lcol), 0u, n, static_cast<const uint32_t *>(rkeys), s, runlen, flags, lval, rranked,
+                                         rank_out, lrow_out, cnt_out, lval_out, rval_out, m_out, used, dup_out, rows_needed, general_out);
+}

@@ -640,7 +640,7 @@ __global__ __launch_bounds__(kJThreads) void jpart_kernel(const K *__restrict__ 
     const uint32_t gmul = use_guess ? (uint32_t)((((uint64_t)P) << 32) / ((uint64_t)r32 + 1ull)) : 0u;
     __syncthreads();
     int phase = 0, since = 0;
-    bool overflow = false;
+    bool overflow = false, aborted = false;
     const int64_t nbatch = (n + BATCH - 1) / BATCH;
     E *myslab = slabs + (size_t)wg * cap;                                       // + b * nwg * cap
 
@@ -744,7 +744,7 @@ __global__ __launch_bounds__(kJThreads) void jpart_kernel(const K *__restrict__ 
                         if (lc + q < cap_lines) {
                             E *dst = myslab + (size_t)b * nwg * cap + (size_t)(lc + q) * LINE + PER_LANE * i;
                             st_hidden_nt_b128(dst, piece);
-                        } else overflow = true;
+                        } else { overflow = true; flags[3] = 1u; }
                     }
                     if (i == 0) {
                         s_w[b] = ((uint32_t)((head + lines * LINE) & (Q - 1)) << 16) | (uint32_t)(cnt - lines * LINE);
@@ -754,6 +754,9 @@ __global__ __launch_bounds__(kJThreads) void jpart_kernel(const K *__restrict__ 
             }
             since = 0;
             again = jwg_or(pending != 0, flags, phase);
+            // a full slab: the join will not use this partition (the caller falls back), and rows that crowd one bucket -- a
+            // probe column sorted by the key -- would sweep its ring 128 times per batch: everybody leaves
+            if (flags[3] != 0u) { aborted = true; break; }
         } while (again);
     };
 
@@ -774,18 +777,21 @@ __global__ __launch_bounds__(kJThreads) void jpart_kernel(const K *__restrict__ 
         unpack(qA, wA, kk_, vv_);
         nr = rows_of(batch, r);
         process(hot_tag, r, nr, kk_, vv_, ++since >= period || (batch + nwg >= nbatch && !has_tail));
+        if (aborted) break;
         load(batch + 3 * (int64_t)nwg, qA, wA); batch += nwg;
         if (batch >= nbatch) break;
         arrived(qB, wB);
         unpack(qB, wB, kk_, vv_);
         nr = rows_of(batch, r);
         process(hot_tag, r, nr, kk_, vv_, ++since >= period || (batch + nwg >= nbatch && !has_tail));
+        if (aborted) break;
         load(batch + 3 * (int64_t)nwg, qB, wB); batch += nwg;
         if (batch >= nbatch) break;
         arrived(qC, wC);
         unpack(qC, wC, kk_, vv_);
         nr = rows_of(batch, r);
         process(hot_tag, r, nr, kk_, vv_, ++since >= period || (batch + nwg >= nbatch && !has_tail));
+        if (aborted) break;
         load(batch + 3 * (int64_t)nwg, qC, wC); batch += nwg;
     }
     if (HIDDEN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the loads still in flight write registers: let them land
@@ -845,7 +851,7 @@ __global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTrai
     // share -- the lookup is not what it waits for, profiles/r03_notes.md 5.1 -- but both take load off the LDS.)
     uint16_t *s_idx = reinterpret_cast<uint16_t *>(s_coarse + kCoarse);                 // [kJIdx + 1]
     __shared__ uint32_t s_bincur[kBinSlots];                              // survivors in every bin so far; [kMaxBins]: in the overflow area
-    __shared__ uint32_t s_np;
+    __shared__ uint32_t s_np, s_gone;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = kJThreads >> 6;
     K *qkey = qkey_all + wave * QCAP;
     uint32_t *qrow = qrow_all + wave * QCAP;
@@ -853,8 +859,9 @@ __global__ __launch_bounds__(kJThreads) void jbucket_kernel(const typename JTrai
     const uint32_t lo = bstart[b], hi = bstart[b + 1];
     for (int i = tid; i < kCoarse; i += kJThreads) s_coarse[i] = 0u;
     if (tid < kBinSlots) s_bincur[tid] = 0u;
-    if (tid == 0) s_np = 0u;
+    if (tid == 0) { s_np = 0u; s_gone = (uint32_t)*err; }
     __syncthreads();
+    if (s_gone != 0u) return;                                            // the partition gave up (a full slab): nobody reads this bucket's survivors
     {   // the bucket's probe pairs (sizes the bins)
         uint32_t np = 0;
         for (int i = tid; i < nwg; i += kJThreads) np += min(counts[(size_t)b * nwg + i], cap);
@@ -1789,7 +1796,7 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
 // Called by hark_entry_join BEFORE it sorts the build side: the probe keys' sample (and the clearing of the partition's small state)
 // starts on the context's second stream and runs under the sort's kernels (35 + 6 us of every join otherwise).  Nothing happens
 // when the partitioned path will not run.  k_join_hot_release drops a block nobody took.
-int k_join_hot_prepare(hark_context *ctx, const void *lcol, bool k64, int64_t n, int64_t s)
+int k_join_hot_prepare(hark_context *ctx, const void *lcol, bool k64, int64_t n, const void *rcol, int64_t s)
 {
     if (ctx->join_prep) k_join_hot_release(ctx);
     if (n < ((int64_t)1 << 18) || s < 4096 || n + s > 0xFFFFFFFFll || getenv("HARK_JOIN_SORTMERGE") || getenv("HARK_JOIN_NO_EARLY_SAMPLE")) return HARK_OK;
@@ -1807,6 +1814,8 @@ int k_join_hot_prepare(hark_context *ctx, const void *lcol, bool k64, int64_t n,
     HIP_TRY_RC(ctx, rc, hipStreamWaitEvent(ctx->aux_stream, ctx->main_event, 0));
     if (!rc) rc = k64 ? jhot_start<uint64_t>(ctx, ctx->aux_stream, block, L, static_cast<const uint64_t *>(lcol), 0x8000000000000000ull, n)
                       : jhot_start<uint32_t>(ctx, ctx->aux_stream, block, L, static_cast<const uint32_t *>(lcol), 0u, n);
+    ctx->join_prep_tested = false;
+    if (!rc && !getenv("HARK_JOIN_CLUSTERED")) { rc = k_cjoin_test(ctx, ctx->aux_stream, lcol, k64, n, rcol, s, false); ctx->join_prep_tested = rc == HARK_OK; }   // is the column clustered by key? (k_cjoin.hip)
     HIP_TRY_RC(ctx, rc, hipEventRecord(ctx->aux_event, ctx->aux_stream));
     ctx->join_prep = block; ctx->join_prep_col = lcol; ctx->join_prep_n = n; ctx->join_prep_s = s;
     if (rc) { k_join_hot_release(ctx); return rc; }
@@ -1858,8 +1867,25 @@ int k_join_partitioned(hark_context *ctx, const void *lcol, bool k64, int64_t n,
     if (rc) { hark_free(ctx, flag); hark_free(ctx, runlen); return rc; }
     bool dup = true;
     int64_t general = 0;                                       // the order kernel's verdict (read in run_partitioned, while it can still run again)
-    rc = k64 ? run_partitioned<uint64_t>(ctx, static_cast<const uint64_t *>(lcol), 0x8000000000000000ull, n, static_cast<const uint64_t *>(rkeys), s, runlen, flag, lval, rranked, &rank, &lrow, &cnt, &lv, &rv, &M, used, &dup, rows_needed, &general)
-             : run_partitioned<uint32_t>(ctx, static_cast<const uint32_t *>(lcol), 0u, n, static_cast<const uint32_t *>(rkeys), s, runlen, flag, nullptr, rranked, &rank, &lrow, &cnt, &lv, &rv, &M, used, &dup, rows_needed, &general);
+    // A probe column sorted or clustered by the key would send every batch of the partition into one ring (k_cjoin.hip): it is
+    // searched in row order instead.  The test ran behind the early sample on the second stream (long done: the build side
+    // has been sorted since), or runs here.
+    bool clustered = false;
+    if (const char *e = getenv("HARK_JOIN_CLUSTERED")) clustered = atoi(e) != 0;                 // tests, A/B: either way
+    else if (ctx->join_prep && ctx->join_prep_tested && ctx->join_prep_col == lcol && ctx->join_prep_n == n) {
+        if (hipEventSynchronize(ctx->aux_event) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: waiting for the clustering test failed");
+        else clustered = k_cjoin_verdict(ctx);
+    } else {
+        rc = k_cjoin_test(ctx, ctx->stream, lcol, k64, n, rkeys, s, true);
+        if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: the clustering test failed");
+        if (!rc) clustered = k_cjoin_verdict(ctx);
+    }
+    if (rc) { hark_free(ctx, flag); hark_free(ctx, runlen); return rc; }
+    ctx->last_join_clustered = clustered;
+    if (clustered) rc = k_cjoin_run(ctx, lcol, k64, n, rkeys, s, runlen, flag, k64 ? lval : nullptr, rranked, &rank, &lrow, &cnt, &lv, &rv, &M, used, &dup, rows_needed, &general);
+    else
+        rc = k64 ? run_partitioned<uint64_t>(ctx, static_cast<const uint64_t *>(lcol), 0x8000000000000000ull, n, static_cast<const uint64_t *>(rkeys), s, runlen, flag, lval, rranked, &rank, &lrow, &cnt, &lv, &rv, &M, used, &dup, rows_needed, &general)
+                 : run_partitioned<uint32_t>(ctx, static_cast<const uint32_t *>(lcol), 0u, n, static_cast<const uint32_t *>(rkeys), s, runlen, flag, nullptr, rranked, &rank, &lrow, &cnt, &lv, &rv, &M, used, &dup, rows_needed, &general);
     if (rc || !*used) { hark_free(ctx, flag); hark_free(ctx, runlen); return rc; }
     if (M == 0) { hark_free(ctx, rank); hark_free(ctx, lrow); hark_free(ctx, cnt); hark_free(ctx, lv); hark_free(ctx, rv); hark_free(ctx, flag); hark_free(ctx, runlen); return HARK_OK; }
     // (rank, left row) order.  Fast path: jorder_kernel delivered it.  A rank with more than kTieMax probe rows, or a
