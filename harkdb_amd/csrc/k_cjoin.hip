@@ -110,7 +110,7 @@ __global__ __launch_bounds__(kCThreads) void cj_search_kernel(const K *__restric
                                                               uint2 *__restrict__ tmp, uint32_t *__restrict__ bcount, uint32_t *__restrict__ bfirst,
                                                               uint32_t *__restrict__ blast, int32_t *__restrict__ unsorted)
 {
-    constexpr int IDX = CIdx<K>::N;
+    constexpr int IDX = CIdx<K>::N, WS = 2048 / (int)sizeof(K);           // WS: build keys of a wave's slice (the 16 slices share the stage's 32 KiB)
     __shared__ K s_idx[IDX];
     __shared__ uint2 s_out[kCBatch];
     __shared__ uint32_t s_wsum[kCThreads / 64];
@@ -119,12 +119,22 @@ __global__ __launch_bounds__(kCThreads) void cj_search_kernel(const K *__restric
     auto idx_pos = [&](uint32_t i) -> uint32_t { return (uint32_t)(((uint64_t)i * (uint64_t)s) / (uint64_t)IDX); };
     for (int i = tid; i < IDX; i += kCThreads) s_idx[i] = rkeys[idx_pos((uint32_t)i)];
     const K kmin = rkeys[0], kmax = rkeys[s - 1];
+    // the first build entry >= key (a key inside [kmin, kmax]) lies in [lo, hi]: rkeys[lo - 1] < key (or lo = 0), rkeys[hi] >= key
+    auto segment = [&](K key, uint32_t &lo, uint32_t &hi) {
+        uint32_t pos = 0;                                                 // index entries below the key
+#pragma unroll
+        for (int step = IDX / 2; step > 0; step >>= 1) if (s_idx[pos + step - 1] < key) pos += step;
+        if (s_idx[pos] < key) pos++;                                      // (the steps count among the first IDX - 1 entries)
+        lo = pos == 0u ? 0u : idx_pos(pos - 1u) + 1u;
+        hi = pos == (uint32_t)IDX ? (uint32_t)(s - 1) : idx_pos(pos);
+        if (lo > hi) lo = hi;                                             // (pos = 0: the key IS the smallest build key)
+    };
+    auto wave_sync = [] { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };   // a wave's own LDS traffic, in program order
     if (tid == 0) s_bad = 0u;
     __syncthreads();
     const int64_t nbatch = (n + kCBatch - 1) / kCBatch;
-    for (int64_t batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
+    auto load = [&](int64_t batch, K (&x)[kCVec]) {                       // the lane's four rows of a batch (raw keys; rows past the end: 0, never used)
         const int64_t r0 = batch * kCBatch + (int64_t)tid * kCVec;
-        K x[kCVec];
         if (r0 + kCVec <= n) {
             if (sizeof(K) == 4) {
                 const hark_u4v q = __builtin_nontemporal_load(reinterpret_cast<const hark_u4v *>(keys + r0));
@@ -139,42 +149,96 @@ __global__ __launch_bounds__(kCThreads) void cj_search_kernel(const K *__restric
 #pragma unroll
             for (int j = 0; j < kCVec; j++) x[j] = r0 + j < n ? keys[r0 + j] : (K)0;
         }
-        uint32_t lo[kCVec], hi[kCVec];
+    };
+    K xn[kCVec];
+    if ((int64_t)blockIdx.x < nbatch) load(blockIdx.x, xn);
+    for (int64_t batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
+        const int64_t r0 = batch * kCBatch + (int64_t)tid * kCVec;
+        K x[kCVec];
+#pragma unroll
+        for (int j = 0; j < kCVec; j++) x[j] = xn[j];
+        if (batch + gridDim.x < nbatch) load(batch + gridDim.x, xn);      // the next batch's keys travel while this one is searched
+        // ---- the wave's 256 consecutive rows together: the build entries between their smallest and largest key.  Few of them
+        // (a sorted column: 256 rows of 1e8 over 1e7 build keys span ~26) -> that slice into LDS, every row searched there;
+        // many -> row by row through the index and the build keys in memory.
+        uint32_t valid = 0;
+        K mn = (K)~(K)0, mx = (K)0;
 #pragma unroll
         for (int j = 0; j < kCVec; j++) {
             x[j] ^= bias;
-            lo[j] = 1u; hi[j] = 0u;                                       // (lo > hi: no such row, or its key lies outside the build side)
-            if (r0 + j < n && x[j] >= kmin && x[j] <= kmax) {
-                uint32_t pos = 0;                                         // index entries below the key
+            if (r0 + j < n && x[j] >= kmin && x[j] <= kmax) { valid |= 1u << j; mn = x[j] < mn ? x[j] : mn; mx = x[j] > mx ? x[j] : mx; }
+        }
 #pragma unroll
-                for (int step = IDX / 2; step > 0; step >>= 1) if (s_idx[pos + step - 1] < x[j]) pos += step;
-                if (s_idx[pos] < x[j]) pos++;                             // (the steps count among the first IDX - 1 entries)
-                // the first build entry >= key lies in [lo, hi]: rkeys[lo - 1] < key (or lo = 0), rkeys[hi] >= key
-                lo[j] = pos == 0u ? 0u : idx_pos(pos - 1u) + 1u;
-                hi[j] = pos == (uint32_t)IDX ? (uint32_t)(s - 1) : idx_pos(pos);
-                if (lo[j] > hi[j]) lo[j] = hi[j];                         // (pos = 0: the key IS the smallest build key)
+        for (int d = 32; d > 0; d >>= 1) {
+            const K a = cj_shfl_xor<K>(mn, d), b = cj_shfl_xor<K>(mx, d);
+            mn = a < mn ? a : mn; mx = b > mx ? b : mx;
+        }
+        uint32_t lo[kCVec], hi[kCVec], found = 0, c = 0;
+#pragma unroll
+        for (int j = 0; j < kCVec; j++) { lo[j] = 1u; hi[j] = 0u; }       // (lo > hi: no such row, or its key lies outside the build side)
+        bool sliced = false;
+        if (mn <= mx) {                                                   // (wave-uniform: some row of the wave is inside the build side's range)
+            uint32_t l1, h1, l2, h2;
+            segment(mn, l1, h1); segment(mx, l2, h2);
+            // 64 probes per step and search (a segment of ~1200 keys: the first step leaves ~19), until the entries between the two fit the slice
+            while ((l1 < h1 || l2 < h2) && h2 - l1 >= (uint32_t)WS) {
+                const uint32_t n1 = h1 - l1, n2 = h2 - l2;
+                const uint32_t p1 = l1 + (uint32_t)(((uint64_t)lane * n1) >> 6), p2 = l2 + (uint32_t)(((uint64_t)lane * n2) >> 6);
+                const K v1 = rkeys[p1], v2 = rkeys[p2];
+                const int c1 = __popcll(__ballot(v1 < mn)), c2 = __popcll(__ballot(v2 < mx));   // the probes ascend: those below the key come first
+                if (l1 < h1) {
+                    if (c1 == 0) h1 = l1;
+                    else { const uint32_t nh = c1 < 64 ? l1 + (uint32_t)(((uint64_t)c1 * n1) >> 6) : h1; l1 = l1 + (uint32_t)(((uint64_t)(c1 - 1) * n1) >> 6) + 1u; h1 = nh; }
+                }
+                if (l2 < h2) {
+                    if (c2 == 0) h2 = l2;
+                    else { const uint32_t nh = c2 < 64 ? l2 + (uint32_t)(((uint64_t)c2 * n2) >> 6) : h2; l2 = l2 + (uint32_t)(((uint64_t)(c2 - 1) * n2) >> 6) + 1u; h2 = nh; }
+                }
+            }
+            const uint32_t first = l1, len = h2 - l1 + 1u;                // every valid row's first build entry >= its key lies in [first, first + len)
+            if (len <= (uint32_t)WS) {
+                sliced = true;
+                K *sl = reinterpret_cast<K *>(s_out) + wave * WS;         // (the stage is free until the barrier below)
+#pragma unroll
+                for (int t = 0; t < WS / 64; t++) { const uint32_t i = (uint32_t)(lane + 64 * t); if (i < len) sl[i] = rkeys[first + i]; }
+                wave_sync();
+#pragma unroll
+                for (int j = 0; j < kCVec; j++) {
+                    if (!(valid & (1u << j))) continue;
+                    uint32_t pos = 0;                                     // slice entries below the key
+#pragma unroll
+                    for (int step = WS / 2; step > 0; step >>= 1) if (pos + step - 1 < len && sl[pos + step - 1] < x[j]) pos += step;
+                    if (pos < len && sl[pos] < x[j]) pos++;
+                    lo[j] = hi[j] = first + pos;
+                    if (pos < len && sl[pos] == x[j]) { found |= 1u << j; c++; }
+                }
+                wave_sync();                                              // (the slice is read before the next batch's, or the stage, overwrites it)
             }
         }
-        for (;;) {
-            K v[kCVec];
-            uint32_t mid[kCVec];
-            bool go = false;
-#pragma unroll
-            for (int j = 0; j < kCVec; j++) {
-                mid[j] = lo[j] + ((hi[j] - lo[j]) >> 1);
-                const bool act = lo[j] < hi[j];
-                go = go || act;
-                v[j] = act ? rkeys[mid[j]] : (K)0;
-            }
-            if (!__any(go)) break;
+        if (!sliced) {
 #pragma unroll
             for (int j = 0; j < kCVec; j++)
-                if (lo[j] < hi[j]) { if (v[j] < x[j]) lo[j] = mid[j] + 1u; else hi[j] = mid[j]; }
-        }
-        uint32_t found = 0, c = 0;
+                if (valid & (1u << j)) segment(x[j], lo[j], hi[j]);
+            for (;;) {
+                K v[kCVec];
+                uint32_t mid[kCVec];
+                bool go = false;
 #pragma unroll
-        for (int j = 0; j < kCVec; j++)
-            if (lo[j] == hi[j] && rkeys[lo[j]] == x[j]) { found |= 1u << j; c++; }
+                for (int j = 0; j < kCVec; j++) {
+                    mid[j] = lo[j] + ((hi[j] - lo[j]) >> 1);
+                    const bool act = lo[j] < hi[j];
+                    go = go || act;
+                    v[j] = act ? rkeys[mid[j]] : (K)0;
+                }
+                if (!__any(go)) break;
+#pragma unroll
+                for (int j = 0; j < kCVec; j++)
+                    if (lo[j] < hi[j]) { if (v[j] < x[j]) lo[j] = mid[j] + 1u; else hi[j] = mid[j]; }
+            }
+#pragma unroll
+            for (int j = 0; j < kCVec; j++)
+                if (lo[j] == hi[j] && rkeys[lo[j]] == x[j]) { found |= 1u << j; c++; }
+        }
         uint32_t incl = c;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
