@@ -206,6 +206,10 @@ struct hark_fgb_plan {
     int32_t *err = nullptr;    // device: [0] sticky error word, [1] the producers' batch counter, [2..3] pairs partitioned so far (u64, never reset)
     int64_t rows_fed = 0, rows_seen = 0, pairs_seen = 0;   // rows handed to the partition path / ... at the last error check / pairs at that check
     int64_t sel_pct = -1;      // share of the rows that survived the predicate between the last two checks (-1: not known): picks the geometry
+    // the window path (k_fgb.hip, fgb_window_kernel: key columns sorted / clustered by the key)
+    int64_t window = 0;        // knob: 0 by the test, 1 always, 2 never
+    const void *win_k = nullptr; int64_t win_n = 0; int win_verdict = -1;   // the tested column and what the test said
+    int64_t win_rows = 0, win_rows_seen = 0, win_moves = 0; uint32_t win_outside_seen = 0;   // rows fed to it / at the last check; its counters then
 };
 
 int k_gen_columns(hark_context *ctx, uint64_t seed, int64_t first_row, int64_t n, uint32_t G,

@@ -105,16 +105,17 @@ __global__ __launch_bounds__(1024) void cj_test_kernel(const K *__restrict__ key
 }
 
 // keys: the probe column (raw), x = key ^ bias is compared with the sorted build keys (64-bit keys: biased by 2^63).
+// Every WAVE works on its own: 256 consecutive rows (a "stretch"; a workgroup's waves take the sixteen stretches of a batch of 4096),
+// no workgroup barrier after the index is staged -- with barriers every batch waited three times for its slowest wave's memory
+// round trips (0.63 ms per 1e8 rows; this: see profiles/r06_notes.md).
 template <typename K>
 __global__ __launch_bounds__(kCThreads) void cj_search_kernel(const K *__restrict__ keys, int64_t n, K bias, const K *__restrict__ rkeys, int64_t s,
                                                               uint2 *__restrict__ tmp, uint32_t *__restrict__ bcount, uint32_t *__restrict__ bfirst,
                                                               uint32_t *__restrict__ blast, int32_t *__restrict__ unsorted)
 {
-    constexpr int IDX = CIdx<K>::N, WS = 2048 / (int)sizeof(K);           // WS: build keys of a wave's slice (the 16 slices share the stage's 32 KiB)
+    constexpr int IDX = CIdx<K>::N, WS = 2048 / (int)sizeof(K);           // WS: build keys of a wave's slice (2 KiB: the same room as its 256 staged rows)
     __shared__ K s_idx[IDX];
-    __shared__ uint2 s_out[kCBatch];
-    __shared__ uint32_t s_wsum[kCThreads / 64];
-    __shared__ uint32_t s_bad;
+    __shared__ uint2 s_stage[kCBatch];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     auto idx_pos = [&](uint32_t i) -> uint32_t { return (uint32_t)(((uint64_t)i * (uint64_t)s) / (uint64_t)IDX); };
     for (int i = tid; i < IDX; i += kCThreads) s_idx[i] = rkeys[idx_pos((uint32_t)i)];
@@ -130,8 +131,9 @@ __global__ __launch_bounds__(kCThreads) void cj_search_kernel(const K *__restric
         if (lo > hi) lo = hi;                                             // (pos = 0: the key IS the smallest build key)
     };
     auto wave_sync = [] { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };   // a wave's own LDS traffic, in program order
-    if (tid == 0) s_bad = 0u;
     __syncthreads();
+    uint2 *stage = s_stage + wave * (kCBatch / 16);                       // this wave's 256 rows; its slice of build keys lives in the same bytes first
+    K *sl = reinterpret_cast<K *>(stage);
     const int64_t nbatch = (n + kCBatch - 1) / kCBatch;
     auto load = [&](int64_t batch, K (&x)[kCVec]) {                       // the lane's four rows of a batch (raw keys; rows past the end: 0, never used)
         const int64_t r0 = batch * kCBatch + (int64_t)tid * kCVec;
@@ -150,6 +152,7 @@ __global__ __launch_bounds__(kCThreads) void cj_search_kernel(const K *__restric
             for (int j = 0; j < kCVec; j++) x[j] = r0 + j < n ? keys[r0 + j] : (K)0;
         }
     };
+    bool bad = false;
     K xn[kCVec];
     if ((int64_t)blockIdx.x < nbatch) load(blockIdx.x, xn);
     for (int64_t batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
@@ -176,8 +179,9 @@ __global__ __launch_bounds__(kCThreads) void cj_search_kernel(const K *__restric
         uint32_t lo[kCVec], hi[kCVec], found = 0, c = 0;
 #pragma unroll
         for (int j = 0; j < kCVec; j++) { lo[j] = 1u; hi[j] = 0u; }       // (lo > hi: no such row, or its key lies outside the build side)
-        bool sliced = false;
+        const size_t sub = (size_t)batch * 16 + (size_t)wave;             // the stretch: rows [256 sub, 256 sub + 256)
         if (mn <= mx) {                                                   // (wave-uniform: some row of the wave is inside the build side's range)
+            bool sliced = false;
             uint32_t l1, h1, l2, h2;
             segment(mn, l1, h1); segment(mx, l2, h2);
             // 64 probes per step and search (a segment of ~1200 keys: the first step leaves ~19), until the entries between the two fit the slice
@@ -198,7 +202,6 @@ __global__ __launch_bounds__(kCThreads) void cj_search_kernel(const K *__restric
             const uint32_t first = l1, len = h2 - l1 + 1u;                // every valid row's first build entry >= its key lies in [first, first + len)
             if (len <= (uint32_t)WS) {
                 sliced = true;
-                K *sl = reinterpret_cast<K *>(s_out) + wave * WS;         // (the stage is free until the barrier below)
 #pragma unroll
                 for (int t = 0; t < WS / 64; t++) { const uint32_t i = (uint32_t)(lane + 64 * t); if (i < len) sl[i] = rkeys[first + i]; }
                 wave_sync();
@@ -212,73 +215,73 @@ __global__ __launch_bounds__(kCThreads) void cj_search_kernel(const K *__restric
                     lo[j] = hi[j] = first + pos;
                     if (pos < len && sl[pos] == x[j]) { found |= 1u << j; c++; }
                 }
-                wave_sync();                                              // (the slice is read before the next batch's, or the stage, overwrites it)
+                wave_sync();                                              // (the slice is read before the staged rows overwrite it)
             }
-        }
-        if (!sliced) {
-#pragma unroll
-            for (int j = 0; j < kCVec; j++)
-                if (valid & (1u << j)) segment(x[j], lo[j], hi[j]);
-            for (;;) {
-                K v[kCVec];
-                uint32_t mid[kCVec];
-                bool go = false;
-#pragma unroll
-                for (int j = 0; j < kCVec; j++) {
-                    mid[j] = lo[j] + ((hi[j] - lo[j]) >> 1);
-                    const bool act = lo[j] < hi[j];
-                    go = go || act;
-                    v[j] = act ? rkeys[mid[j]] : (K)0;
-                }
-                if (!__any(go)) break;
+            if (!sliced) {
 #pragma unroll
                 for (int j = 0; j < kCVec; j++)
-                    if (lo[j] < hi[j]) { if (v[j] < x[j]) lo[j] = mid[j] + 1u; else hi[j] = mid[j]; }
-            }
+                    if (valid & (1u << j)) segment(x[j], lo[j], hi[j]);
+                for (;;) {
+                    K v[kCVec];
+                    uint32_t mid[kCVec];
+                    bool go = false;
 #pragma unroll
-            for (int j = 0; j < kCVec; j++)
-                if (lo[j] == hi[j] && rkeys[lo[j]] == x[j]) { found |= 1u << j; c++; }
+                    for (int j = 0; j < kCVec; j++) {
+                        mid[j] = lo[j] + ((hi[j] - lo[j]) >> 1);
+                        const bool act = lo[j] < hi[j];
+                        go = go || act;
+                        v[j] = act ? rkeys[mid[j]] : (K)0;
+                    }
+                    if (!__any(go)) break;
+#pragma unroll
+                    for (int j = 0; j < kCVec; j++)
+                        if (lo[j] < hi[j]) { if (v[j] < x[j]) lo[j] = mid[j] + 1u; else hi[j] = mid[j]; }
+                }
+#pragma unroll
+                for (int j = 0; j < kCVec; j++)
+                    if (lo[j] == hi[j] && rkeys[lo[j]] == x[j]) { found |= 1u << j; c++; }
+            }
         }
+        // ---- the matching rows of the stretch, in row order: staged, checked (do the ranks ascend?), written out
         uint32_t incl = c;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
-        if (lane == 63) s_wsum[wave] = incl;
-        __syncthreads();
-        uint32_t woff = 0, cnt = 0;
+        const uint32_t cnt = __shfl(incl, 63, 64);
+        if (cnt) {
+            uint32_t at = incl - c;
 #pragma unroll
-        for (int w = 0; w < kCThreads / 64; w++) { const uint32_t t = s_wsum[w]; if (w < wave) woff += t; cnt += t; }
-        uint32_t at = woff + incl - c;
+            for (int j = 0; j < kCVec; j++)
+                if (found & (1u << j)) stage[at++] = make_uint2(lo[j], (uint32_t)(r0 + j));
+            wave_sync();
+            uint2 *dst = tmp + sub * 256;
 #pragma unroll
-        for (int j = 0; j < kCVec; j++)
-            if (found & (1u << j)) s_out[at++] = make_uint2(lo[j], (uint32_t)(r0 + j));
-        __syncthreads();
-        bool bad = false;
-        uint2 *dst = tmp + batch * kCBatch;
-        for (uint32_t i = tid; i < cnt; i += kCThreads) {
-            const uint2 e = s_out[i];
-            if (i + 1u < cnt && e.x > s_out[i + 1u].x) bad = true;
-            dst[i] = e;
+            for (int t = 0; t < 4; t++) {
+                const uint32_t i = (uint32_t)(lane + 64 * t);
+                if (i < cnt) {
+                    const uint2 e = stage[i];
+                    if (i + 1u < cnt && e.x > stage[i + 1u].x) bad = true;
+                    dst[i] = e;
+                }
+            }
+            if (lane == 0) { bfirst[sub] = stage[0].x; blast[sub] = stage[cnt - 1u].x; }
+            wave_sync();                                                  // (read before the next stretch's slice overwrites it)
         }
-        if (bad) s_bad = 1u;
-        if (tid == 0) {
-            bcount[batch] = cnt;
-            if (cnt) { bfirst[batch] = s_out[0].x; blast[batch] = s_out[cnt - 1u].x; }
-        }
-        __syncthreads();                                                  // s_out / s_wsum are the next batch's
+        if (lane == 0) bcount[sub] = cnt;
     }
-    if (tid == 0 && s_bad) *unsorted = 1;
+    if (bad) *unsorted = 1;
 }
 
-// boff[b] = matching rows before batch b; total[0] = all of them; *unsorted when a batch starts below a rank seen before it.
-// One workgroup; every wave takes a stretch of the batches 64 at a time (coalesced reads, scans by shuffles), the waves' totals meet
-// in LDS.  (A thread per stretch, one batch after the other: 61 us for 24 K batches; this: see profiles/r06_notes.md.)
-__global__ __launch_bounds__(1024) void cj_scan_kernel(const uint32_t *__restrict__ bcount, const uint32_t *__restrict__ bfirst, const uint32_t *__restrict__ blast,
-                                                       uint32_t nbatch, uint32_t *__restrict__ boff, unsigned long long *__restrict__ total, int32_t *__restrict__ unsorted)
+// The stretches' offsets: cj_scan1_kernel scans 4096 stretches per workgroup (a wave 256 of them, 64 at a time: coalesced reads,
+// scans by shuffles) -- boff[sub] = matching rows before the stretch within its workgroup's 4096, gsum / gmax / gminf the workgroup's
+// total, largest last rank and smallest first rank; cj_scan2_kernel scans those (one workgroup) into goff and the grand total.
+// *unsorted when a stretch starts below a rank seen before it (the search kernel has checked the inside of every stretch).
+__global__ __launch_bounds__(1024) void cj_scan1_kernel(const uint32_t *__restrict__ bcount, const uint32_t *__restrict__ bfirst, const uint32_t *__restrict__ blast,
+                                                        uint32_t nsub, uint32_t *__restrict__ boff, uint32_t *__restrict__ gsum, uint32_t *__restrict__ gmax,
+                                                        uint32_t *__restrict__ gminf, int32_t *__restrict__ unsorted)
 {
     __shared__ uint32_t s_sum[16], s_max[16], s_minf[16];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t per = ((nbatch + 15u) / 16u + 63u) & ~63u;             // batches per wave, whole rounds of 64
-    const uint32_t b0 = min(nbatch, wave * per), b1 = min(nbatch, b0 + per);
+    const uint32_t b0 = min(nsub, blockIdx.x * 4096u + wave * 256u), b1 = min(nsub, b0 + 256u);
     uint32_t run = 0, seen = 0, minf = 0xFFFFFFFFu;
     bool bad = false;
     for (uint32_t base = b0; base < b1; base += 64u) {
@@ -303,26 +306,61 @@ __global__ __launch_bounds__(1024) void cj_scan_kernel(const uint32_t *__restric
     for (int d = 32; d > 0; d >>= 1) minf = min(minf, __shfl_down(minf, d, 64));
     if (lane == 0) { s_sum[wave] = run; s_max[wave] = seen; s_minf[wave] = minf; }
     __syncthreads();
-    uint32_t woff = 0, wseen = 0, all = 0;
+    uint32_t woff = 0, wseen = 0, all = 0, allmax = 0, allmin = 0xFFFFFFFFu;
 #pragma unroll
-    for (uint32_t w = 0; w < 16u; w++) { if (w < wave) { woff += s_sum[w]; wseen = max(wseen, s_max[w]); } all += s_sum[w]; }
+    for (uint32_t w = 0; w < 16u; w++) {
+        if (w < wave) { woff += s_sum[w]; wseen = max(wseen, s_max[w]); }
+        all += s_sum[w]; allmax = max(allmax, s_max[w]); allmin = min(allmin, s_minf[w]);
+    }
     if (wseen > s_minf[wave]) bad = true;                                 // (no rows in this wave: the minimum is all ones)
     if (woff) for (uint32_t b = b0 + lane; b < b1; b += 64u) boff[b] += woff;
     if (bad) *unsorted = 1;
-    if (tid == 0) *total = (unsigned long long)all;
+    if (tid == 0) { gsum[blockIdx.x] = all; gmax[blockIdx.x] = allmax; gminf[blockIdx.x] = allmin; }
 }
 
-__global__ __launch_bounds__(256) void cj_emit_kernel(const uint2 *__restrict__ tmp, const uint32_t *__restrict__ bcount, const uint32_t *__restrict__ boff, uint32_t nbatch,
-                                                      const uint32_t *__restrict__ runlen, const uint32_t *__restrict__ lval, const uint32_t *__restrict__ rranked,
-                                                      uint32_t *__restrict__ rank, uint32_t *__restrict__ lrow, uint32_t *__restrict__ cnt,
-                                                      uint32_t *__restrict__ lv, uint32_t *__restrict__ rv)
+__global__ __launch_bounds__(1024) void cj_scan2_kernel(const uint32_t *__restrict__ gsum, const uint32_t *__restrict__ gmax, const uint32_t *__restrict__ gminf,
+                                                        uint32_t ngroup, uint32_t *__restrict__ goff, unsigned long long *__restrict__ total, int32_t *__restrict__ unsorted)
 {
-    for (uint32_t b = blockIdx.x; b < nbatch; b += gridDim.x) {
-        const uint32_t c = bcount[b];
+    __shared__ uint32_t s_sum[1024], s_max[1024];
+    const uint32_t tid = threadIdx.x, chunk = (ngroup + 1023u) / 1024u;   // (2^32 rows: 4096 groups, four per thread)
+    const uint32_t g0 = min(ngroup, tid * chunk), g1 = min(ngroup, g0 + chunk);
+    uint32_t sum = 0, seen = 0, minf = 0xFFFFFFFFu;
+    bool bad = false;
+    for (uint32_t g = g0; g < g1; g++) {
+        if (gsum[g] && seen > gminf[g]) bad = true;
+        if (gsum[g]) { seen = max(seen, gmax[g]); minf = min(minf, gminf[g]); }
+        sum += gsum[g];
+    }
+    s_sum[tid] = sum; s_max[tid] = seen;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024u; d <<= 1) {
+        const uint32_t a = tid >= d ? s_sum[tid - d] : 0u, m = tid >= d ? s_max[tid - d] : 0u;
+        __syncthreads();
+        s_sum[tid] += a; s_max[tid] = max(s_max[tid], m);
+        __syncthreads();
+    }
+    const uint32_t before = tid ? s_sum[tid - 1u] : 0u, prev = tid ? s_max[tid - 1u] : 0u;
+    if (prev > minf) bad = true;
+    uint32_t run = before;
+    for (uint32_t g = g0; g < g1; g++) { goff[g] = run; run += gsum[g]; }
+    if (bad) *unsorted = 1;
+    if (tid == 1023u) *total = (unsigned long long)s_sum[1023];
+}
+
+// a wave per stretch: its rows to their places
+__global__ __launch_bounds__(1024) void cj_emit_kernel(const uint2 *__restrict__ tmp, const uint32_t *__restrict__ bcount, const uint32_t *__restrict__ boff,
+                                                       const uint32_t *__restrict__ goff, uint32_t nsub,
+                                                       const uint32_t *__restrict__ runlen, const uint32_t *__restrict__ lval, const uint32_t *__restrict__ rranked,
+                                                       uint32_t *__restrict__ rank, uint32_t *__restrict__ lrow, uint32_t *__restrict__ cnt,
+                                                       uint32_t *__restrict__ lv, uint32_t *__restrict__ rv)
+{
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (uint32_t sub = blockIdx.x * 16u + wave; sub < nsub; sub += gridDim.x * 16u) {
+        const uint32_t c = bcount[sub];
         if (!c) continue;
-        const uint2 *src = tmp + (size_t)b * kCBatch;
-        const size_t off = boff[b];
-        for (uint32_t i = threadIdx.x; i < c; i += 256u) {
+        const uint2 *src = tmp + (size_t)sub * 256;
+        const size_t off = (size_t)boff[sub] + goff[sub >> 12];
+        for (uint32_t i = lane; i < c; i += 64u) {
             const uint2 e = src[i];
             if (rank) rank[off + i] = e.x;
             if (lrow) lrow[off + i] = e.y;
@@ -340,23 +378,24 @@ int run_clustered(hark_context *ctx, const K *lcol, K bias, int64_t n, const K *
 {
     *used = false;
     hipStream_t st = ctx->stream;
-    const int64_t nbatch = (n + kCBatch - 1) / kCBatch;
+    const int64_t nbatch = (n + kCBatch - 1) / kCBatch, nsub = nbatch * 16, ngroup = (nsub + 4095) / 4096;   // batches of 4096 rows, stretches of 256, 4096 stretches
     uint2 *tmp = nullptr;
-    uint32_t *bcount = nullptr, *bfirst = nullptr, *blast = nullptr, *boff = nullptr;
+    uint32_t *bcount = nullptr, *bfirst = nullptr, *blast = nullptr, *boff = nullptr, *gsum = nullptr, *gmax = nullptr, *gminf = nullptr, *goff = nullptr;
     int64_t *info = nullptr;                                              // [0] matching rows, [1] low: not ascending, [2] the caller's flags
     uint32_t *rank = nullptr, *lrow = nullptr, *cnt = nullptr, *lv = nullptr, *rv = nullptr;
-    int rc = hark_alloc(ctx, (void **)&tmp, 8 * (size_t)nbatch * kCBatch);
-    if (!rc) rc = hark_alloc(ctx, (void **)&bcount, 4 * (size_t)nbatch * 4);
+    int rc = hark_alloc(ctx, (void **)&tmp, 8 * (size_t)nsub * 256);
+    if (!rc) rc = hark_alloc(ctx, (void **)&bcount, 4 * ((size_t)nsub * 4 + (size_t)ngroup * 4));
     if (!rc) rc = hark_alloc(ctx, (void **)&info, 64);
     auto cleanup = [&]() { hark_free(ctx, tmp); hark_free(ctx, bcount); hark_free(ctx, info); };
     if (rc == HARK_ENOMEM) { cleanup(); ctx->err.clear(); return HARK_OK; }   // no room: the sort-merge path needs less
     if (rc) { cleanup(); return rc; }
-    bfirst = bcount + nbatch; blast = bfirst + nbatch; boff = blast + nbatch;
+    bfirst = bcount + nsub; blast = bfirst + nsub; boff = blast + nsub; gsum = boff + nsub; gmax = gsum + ngroup; gminf = gmax + ngroup; goff = gminf + ngroup;
     HIP_TRY_RC(ctx, rc, hipMemsetAsync(info, 0, 64, st));
     int grid = (int)std::min<int64_t>(nbatch, (int64_t)ctx->num_cu * 2);
-    if (const char *e = getenv("HARK_CJOIN_GRID")) { const int g = atoi(e); if (g >= 1 && g <= 65536) grid = g; }   // tests: several batches per workgroup at any size
+    if (const char *e = getenv("HARK_CJOIN_GRID")) { const int g = atoi(e); if (g >= 1 && g <= 65536) grid = (int)std::min<int64_t>(g, nbatch); }   // tests: several batches per workgroup at any size
     HARK_LAUNCH_RC(ctx, rc, cj_search_kernel<K><<<dim3((unsigned)grid), dim3(kCThreads), 0, st>>>(lcol, n, bias, rkeys, s, tmp, bcount, bfirst, blast, reinterpret_cast<int32_t *>(info + 1)));
-    HARK_LAUNCH_RC(ctx, rc, cj_scan_kernel<<<1, 1024, 0, st>>>(bcount, bfirst, blast, (uint32_t)nbatch, boff, reinterpret_cast<unsigned long long *>(info), reinterpret_cast<int32_t *>(info + 1)));
+    HARK_LAUNCH_RC(ctx, rc, cj_scan1_kernel<<<dim3((unsigned)ngroup), 1024, 0, st>>>(bcount, bfirst, blast, (uint32_t)nsub, boff, gsum, gmax, gminf, reinterpret_cast<int32_t *>(info + 1)));
+    HARK_LAUNCH_RC(ctx, rc, cj_scan2_kernel<<<1, 1024, 0, st>>>(gsum, gmax, gminf, (uint32_t)ngroup, goff, reinterpret_cast<unsigned long long *>(info), reinterpret_cast<int32_t *>(info + 1)));
     HIP_TRY_RC(ctx, rc, hipMemcpyAsync(info + 2, flags, 8, hipMemcpyDeviceToDevice, st));
     int64_t words[3] = {0, 0, 0};
     if (!rc) rc = hark_read_words(ctx, info, words, 3);
@@ -373,7 +412,7 @@ int run_clustered(hark_context *ctx, const K *lcol, K bias, int64_t n, const K *
         if (!rc && lval && !general) rc = hark_alloc(ctx, (void **)&lv, 4 * (size_t)M);
         if (!rc && rranked && !dup && !general) rc = hark_alloc(ctx, (void **)&rv, 4 * (size_t)M);
         const int g = (int)std::min<int64_t>(nbatch, (int64_t)ctx->num_cu * 8);
-        HARK_LAUNCH_RC(ctx, rc, cj_emit_kernel<<<dim3((unsigned)g), 256, 0, st>>>(tmp, bcount, boff, (uint32_t)nbatch, runlen, lval, rranked, rank, lrow, cnt, lv, rv));
+        HARK_LAUNCH_RC(ctx, rc, cj_emit_kernel<<<dim3((unsigned)g), 1024, 0, st>>>(tmp, bcount, boff, goff, (uint32_t)nsub, runlen, lval, rranked, rank, lrow, cnt, lv, rv));
     }
     cleanup();                                                            // stream-ordered reuse
     if (rc) { hark_free(ctx, rank); hark_free(ctx, lrow); hark_free(ctx, cnt); hark_free(ctx, lv); hark_free(ctx, rv); return rc; }

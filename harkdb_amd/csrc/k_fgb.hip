@@ -294,6 +294,198 @@ __global__ __launch_bounds__(1024) void fgb_lds_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// Window path: key columns that are SORTED or CLUSTERED (a table kept in key order)
+// ---------------------------------------------------------------------------
+// The partition path below routes every surviving row through per-bucket LDS rings sized for keys that SCATTER over the
+// buckets; consecutive rows of a sorted key column all fall into ONE bucket, whose ring of ~100 entries is swept ~40 times
+// per batch of 4096 rows: the headline statement took 53 ms per 1e9 rows on sorted keys against 3.1 ms on shuffled ones,
+// 121 against 3.4 without a predicate (tools/groupby_cluster_probe.py).  What hurts there is what makes such columns
+// cheap: the rows of a batch hold a handful of neighbouring keys.  So every workgroup takes a CONTIGUOUS stretch of the
+// table and aggregates batch after batch into a WINDOW of kWinKeys consecutive keys in LDS (fgb_lds_kernel's slots: a double
+// or a word per key + a count, kWinRep replicas -- the lanes of a wave mostly hold the SAME key), which follows the keys:
+// a batch first publishes the smallest and largest surviving key, and when they leave the window the touched part of it
+// is added to the global accumulators (a few keys: one global atomic each) and the window moves there.  One pass, 12 B/row,
+// no pair is written.  A batch that spans more keys than the window holds sends the rows outside to global atomics (correct,
+// slow): the caller picks this path only for columns whose rows half a batch apart are a few keys apart
+// (fgb_cluster_test_kernel) and reads back how many rows went that way.
+constexpr int kWinKeys = 1024, kWinRL = 3, kWinRep = 1 << kWinRL, kWinNear = kWinKeys / 4, kWinFar = 512, kWinTurns = 4;
+
+// stat[0]: times a window moved, stat[1]: rows that went to global atomics
+template <int OP, int VM>
+__global__ __launch_bounds__(1024) void fgb_window_kernel(
+    const float *__restrict__ p, const int32_t *__restrict__ k, const float *__restrict__ v,
+    int64_t n, float thr, int64_t G, u64 *__restrict__ gsum, unsigned long long *__restrict__ gcnt,
+    int32_t *__restrict__ err, int xf, int vop_rt, uint32_t *__restrict__ stat)
+{
+    constexpr bool FSUM = VM == 1, CNT = VM == 2;
+    const int VOP = (FSUM || CNT) ? (int)VOP_F32SUM : vop_rt;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    constexpr int SLOTS = kWinKeys << kWinRL;
+    u64 *s_sum = reinterpret_cast<u64 *>(lds_raw);
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(lds_raw + sizeof(u64) * SLOTS);
+    __shared__ int s_lo[3], s_hi[3];                                     // smallest / largest waiting key of a turn: three pairs of words in rotation (see below)
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i < SLOTS; i += 1024) { s_sum[i] = vop_identity(VOP); s_cnt[i] = 0u; }
+    if (tid < 3) { s_lo[tid] = 0x7FFFFFFF; s_hi[tid] = -1; }
+    __syncthreads();
+    const uint32_t rep = (uint32_t)tid & (uint32_t)(kWinRep - 1);
+    const int64_t nvec = n / kVec;
+    const int64_t per = ((nvec + gridDim.x - 1) / gridDim.x + 1023) / 1024 * 1024;      // 16-byte groups per workgroup: whole batches
+    const int64_t q0 = (int64_t)blockIdx.x * per, q1 = q0 + per < nvec ? q0 + per : nvec;
+    const float4 *p4 = reinterpret_cast<const float4 *>(p);
+    const int4 *k4 = reinterpret_cast<const int4 *>(k);
+    const float4 *v4 = reinterpret_cast<const float4 *>(v);
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    typedef int i4v __attribute__((ext_vector_type(4)));
+    auto ldp = [&](int64_t q) -> float4 {
+        if (OP == kNoPred) return float4{0, 0, 0, 0};
+        if (OP == kMaskPred) return mask_nibble(p, q * kVec);
+        const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(p4 + q));
+        return float4{t.x, t.y, t.z, t.w};
+    };
+    auto ldk = [&](int64_t q) -> int4 {
+        const i4v t = __builtin_nontemporal_load(reinterpret_cast<const i4v *>(k4 + q));
+        return int4{t.x, t.y, t.z, t.w};
+    };
+    auto ldv = [&](int64_t q) -> float4 {
+        if (CNT) return float4{0, 0, 0, 0};
+        const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(v4 + q));
+        return float4{t.x, t.y, t.z, t.w};
+    };
+    bool bad = false;
+    int base = 0, dlo = 0x7FFFFFFF, dhi = -1;                             // the window [base, base + kWinKeys) and the keys of it touched since it was last written out
+    uint32_t moved = 0, outside = 0;
+    // the touched keys of the window -> global accumulators (every thread calls it; ends with a barrier)
+    auto write_out = [&]() {
+        for (int g = dlo - base + tid; g <= dhi - base; g += 1024) {
+            u64 sacc = vop_identity(VOP); uint32_t c = 0;
+#pragma unroll
+            for (int r = 0; r < kWinRep; r++) {
+                const int slot = (g << kWinRL) + r;
+                sacc = vop_merge(VOP, sacc, s_sum[slot]); c += s_cnt[slot];
+                s_sum[slot] = vop_identity(VOP); s_cnt[slot] = 0u;
+            }
+            if (c) {
+                if constexpr (FSUM) vop_atomic_partial<VOP_F32SUM>(&gsum[base + g], sacc);
+                else if constexpr (!CNT) vop_atomic_partial_rt(VOP, &gsum[base + g], sacc);
+                atomicAdd(&gcnt[base + g], (unsigned long long)c);
+            }
+        }
+        dlo = 0x7FFFFFFF; dhi = -1;
+        __syncthreads();
+    };
+    float4 pn = float4{0, 0, 0, 0}, vn = pn;
+    int4 kn = int4{0, 0, 0, 0};
+    if (q0 + tid < q1) { pn = ldp(q0 + tid); kn = ldk(q0 + tid); vn = ldv(q0 + tid); }
+    int ph = 0;                                                           // the pair of words this turn publishes in
+    for (int64_t qb = q0; qb < q1; qb += 1024) {
+        const int64_t q = qb + tid;
+        const bool have = q < q1;
+        const float4 pa = pn, va = vn;
+        const int4 ka = kn;
+        if (q + 1024 < q1) { pn = ldp(q + 1024); kn = ldk(q + 1024); vn = ldv(q + 1024); }      // the next batch travels while this one is added
+        const float pv[4] = {pa.x, pa.y, pa.z, pa.w}, vv[4] = {va.x, va.y, va.z, va.w};
+        const int kk[4] = {ka.x, ka.y, ka.z, ka.w};
+        uint32_t live = 0;
+        int mn = 0x7FFFFFFF, mx = -1;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (have && cmp_f32<OP>(pv[j], thr)) {
+                if ((uint32_t)kk[j] < (uint64_t)G) { live |= 1u << j; mn = min(mn, kk[j]); mx = max(mx, kk[j]); }
+                else bad = true;
+            }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { mn = min(mn, __shfl_xor(mn, d, 64)); mx = max(mx, __shfl_xor(mx, d, 64)); }
+        // up to kWinTurns windows per batch (a batch that straddles clusters of keys -- sorted runs in shuffled order): the rows
+        // inside the window are added, the others wait for the next turn; after the last turn they go to global atomics
+        // (the words: a turn publishes in pair ph, reads it behind the barrier, and thread 0 clears the pair of the turn AFTER the
+        // next -- last read before this barrier, next written behind the next one)
+        for (int turn = 0;; turn++) {
+            if (lane == 0 && mx >= 0) { atomicMin(&s_lo[ph], mn); atomicMax(&s_hi[ph], mx); }
+            __syncthreads();
+            const int blo = s_lo[ph], bhi = s_hi[ph];                     // the waiting rows' keys lie in [blo, bhi] (none: blo > bhi)
+            const int clr = ph == 0 ? 2 : ph - 1;
+            ph = ph == 2 ? 0 : ph + 1;
+            if (tid == 0) { s_lo[clr] = 0x7FFFFFFF; s_hi[clr] = -1; }
+            if (blo > bhi) break;
+            if (blo < base || bhi >= base + kWinKeys) {                   // the window moves (every thread sees the same numbers)
+                if (dlo <= dhi) write_out();
+                base = blo; moved++;
+            }
+            const bool last = turn == kWinTurns - 1;
+            dlo = min(dlo, blo); dhi = max(dhi, min(bhi, base + kWinKeys - 1));
+            mn = 0x7FFFFFFF; mx = -1;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (live & (1u << j)) {
+                    const uint32_t off = (uint32_t)(kk[j] - base);
+                    const uint32_t x = __float_as_uint(vv[j]);
+                    if (off < (uint32_t)kWinKeys) {
+                        const uint32_t slot = (off << kWinRL) | rep;
+                        if constexpr (FSUM) vop_atomic<VOP_F32SUM>(&s_sum[slot], x);
+                        else if constexpr (!CNT) vop_atomic_rt(VOP, &s_sum[slot], apply_xf(xf, x));
+                        atomicAdd(&s_cnt[slot], 1u);
+                        live &= ~(1u << j);
+                    } else if (last) {                                    // more clusters in one batch than turns
+                        if constexpr (FSUM) vop_atomic<VOP_F32SUM>(&gsum[kk[j]], x);
+                        else if constexpr (!CNT) vop_atomic_rt(VOP, &gsum[kk[j]], apply_xf(xf, x));
+                        atomicAdd(&gcnt[kk[j]], 1ull);
+                        outside++;
+                    } else { mn = min(mn, kk[j]); mx = max(mx, kk[j]); }
+                }
+            if (bhi < base + kWinKeys || last) break;                     // every row of the batch was inside (the usual case: one barrier per batch)
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) { mn = min(mn, __shfl_xor(mn, d, 64)); mx = max(mx, __shfl_xor(mx, d, 64)); }
+        }
+    }
+    __syncthreads();
+    if (dlo <= dhi) write_out();
+    // ragged tail (n % 4 rows): the first lanes of workgroup 0, straight to the accumulators
+    if (blockIdx.x == 0) {
+        const int64_t t = nvec * kVec + tid;
+        if (t < n && cmp_f32<OP>(OP == kNoPred ? 0.0f : OP == kMaskPred ? mask_bit(p, t) : p[t], thr)) {
+            const int key = k[t];
+            if ((uint32_t)key < (uint64_t)G) {
+                const uint32_t x = CNT ? 0u : __float_as_uint(v[t]);
+                if constexpr (FSUM) vop_atomic<VOP_F32SUM>(&gsum[key], x);
+                else if constexpr (!CNT) vop_atomic_rt(VOP, &gsum[key], apply_xf(xf, x));
+                atomicAdd(&gcnt[key], 1ull);
+            } else bad = true;
+        }
+    }
+    if (bad) *err = HARK_EBOUNDS;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) outside += __shfl_xor(outside, d, 64);
+    if (lane == 0 && outside) atomicAdd(&stat[1], outside);
+    if (tid == 0 && moved) atomicAdd(&stat[0], moved);
+}
+
+// Are rows kWinFar rows (an eighth of a batch) apart a few keys apart?  1024 such pairs, and as many of rows anywhere apart (a column of
+// few distinct keys is close to itself everywhere -- and needs no window).  out[0] = 1: clustered, [1] / [2]: the close pairs.
+// `out` may be pinned host memory.
+__global__ __launch_bounds__(1024) void fgb_cluster_test_kernel(const int32_t *__restrict__ k, int64_t n, unsigned long long *out)
+{
+    __shared__ int s_a[1024];
+    __shared__ uint32_t s_c[2];
+    const int tid = threadIdx.x;
+    if (tid < 2) s_c[tid] = 0u;
+    const int64_t r = (int64_t)(((uint64_t)mix32(0x9E3779B9u + (uint32_t)tid) * (uint64_t)(n - kWinFar)) >> 32);
+    const int ka = k[r], kb = k[r + kWinFar];
+    s_a[tid] = ka;
+    __syncthreads();
+    const int kf = s_a[(tid + 512) & 1023];
+    const bool near = abs((int64_t)ka - (int64_t)kb) <= kWinNear, far = abs((int64_t)ka - (int64_t)kf) <= kWinNear;
+    const unsigned long long m0 = __ballot(near), m1 = __ballot(far);
+    if ((tid & 63) == 0) { atomicAdd(&s_c[0], __popcll(m0)); atomicAdd(&s_c[1], __popcll(m1)); }
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t a = s_c[0], b = s_c[1];
+        out[1] = a; out[2] = b;
+        out[0] = (a >= 384u && b < 256u) ? 1ull : 0ull;                   // three of eight pairs close (runs of 1024 sorted rows: half of them), and not because everything is
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Global-atomic path (fallback + baseline)
 // ---------------------------------------------------------------------------
 template <int OP>
@@ -1984,11 +2176,11 @@ int hark_fgb_plan_new(hark_context *ctx, hark_fgb_plan **out, int64_t max_rows, 
     hark_fgb_plan *pl = new hark_fgb_plan();
     pl->max_rows = max_rows; pl->G = G; pl->ctx = ctx;
     pl->tile_rows = kTileRows;
-    int rc = hark_alloc(ctx, (void **)&pl->err, 16);                  // [0] sticky error word, [1] the producers' batch counter
+    int rc = hark_alloc(ctx, (void **)&pl->err, 32);                  // [0] sticky error word, [1] the producers' batch counter, [2..3] pairs, [4..5] the window path's counters
     if (!rc) rc = hark_alloc(ctx, (void **)&pl->acc_sum, (size_t)G * sizeof(double));
     if (!rc) rc = hark_alloc(ctx, (void **)&pl->acc_cnt, (size_t)G * sizeof(unsigned long long));
     if (rc) { hark_fgb_plan_free(ctx, pl); return rc; }
-    HIP_TRY_RC(ctx, rc, hipMemsetAsync(pl->err, 0, 16, ctx->stream));
+    HIP_TRY_RC(ctx, rc, hipMemsetAsync(pl->err, 0, 32, ctx->stream));
     HIP_TRY_RC(ctx, rc, hipMemsetAsync(pl->acc_sum, 0, (size_t)G * sizeof(double), ctx->stream));
     HIP_TRY_RC(ctx, rc, hipMemsetAsync(pl->acc_cnt, 0, (size_t)G * sizeof(unsigned long long), ctx->stream));
     if (rc) { hark_fgb_plan_free(ctx, pl); return rc; }
@@ -2023,6 +2215,7 @@ int hark_fgb_plan_set(hark_fgb_plan *pl, const char *key, int64_t value)
     else if (!strcmp(key, "vop")) { if (value < 0 || value > 5) return HARK_EARG; pl->vop = value; return HARK_OK; }   // reset afterwards
     else if (!strcmp(key, "xform")) { if (value < 0 || value > 2) return HARK_EARG; pl->xform = value; return HARK_OK; }
     else if (!strcmp(key, "pairfmt")) { if (value < 0 || value > 3) return HARK_EARG; pl->pairfmt = value; }   // 0 auto, 1: 8-byte pairs, 2: compact 6-byte units, 3: 6-byte units from 8-byte ring entries (<= 128 buckets)
+    else if (!strcmp(key, "window")) { if (value < 0 || value > 2) return HARK_EARG; pl->window = value; return HARK_OK; }   // 0: by the test, 1: always the window path, 2: never
     else if (!strcmp(key, "period")) { if (value < 0 || value > 15) return HARK_EARG; pl->period = value; return HARK_OK; }   // batches between ring sweeps (0 = default); any value gives the same result
     else return HARK_EARG;
     plan_drop_partition(pl);     // partition geometry depends on the knobs
@@ -2102,6 +2295,26 @@ static int plan_prepare_partition(hark_context *ctx, hark_fgb_plan *pl)
     return HARK_OK;
 }
 
+// Does this key column take the window path?  The plan's knob ("window": 1 always, 2 never; HARK_FGB_WINDOW=1 / 0 the same for
+// every plan), else the test of fgb_cluster_test_kernel -- one small launch and one synchronisation, once per plan and column:
+// the verdict sticks to (column, rows) until a check finds that the window path sent more than 1 row in 64 to global atomics.
+static int fgb_window_wanted(hark_context *ctx, hark_fgb_plan *pl, const int32_t *k, int64_t n, bool *window)
+{
+    *window = false;
+    if (const char *e = getenv("HARK_FGB_WINDOW")) { *window = atoi(e) != 0; return HARK_OK; }
+    if (pl->window == 1) { *window = true; return HARK_OK; }
+    if (pl->window == 2 || n < ((int64_t)1 << 20)) return HARK_OK;
+    if (pl->win_k != k || pl->win_n != n) {
+        unsigned long long *out = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(ctx->h_pin) + 65536 - 128);   // (the kernel writes pinned host memory)
+        fgb_cluster_test_kernel<<<1, 1024, 0, ctx->stream>>>(k, n, out);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        pl->win_k = k; pl->win_n = n; pl->win_verdict = reinterpret_cast<volatile unsigned long long *>(out)[0] != 0ull ? 1 : 0;
+    }
+    *window = pl->win_verdict == 1;
+    return HARK_OK;
+}
+
 int k_fgb_dense_f32(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cmp, float thr,
                     const int32_t *k, const float *v, int64_t n)
 {
@@ -2159,7 +2372,33 @@ int k_fgb_dense_f32(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cm
             return HARK_OK;
         });
     }
-    // algo 3: partition + per-bucket LDS aggregation, chunked
+    // algo 3: a key column sorted / clustered by the key takes the window path (one pass, see fgb_window_kernel) ...
+    {
+        bool window = false;
+        HARK_TRY(fgb_window_wanted(ctx, pl, k, n, &window));
+        if (window) {
+            const size_t lds = (size_t)(kWinKeys << kWinRL) * 12;
+            int64_t grid = pl->grid ? pl->grid : (int64_t)ctx->num_cu;
+            const int64_t need = (n / kVec + 1023) / 1024;
+            if (grid > need) grid = need > 0 ? need : 1;
+            auto launch = [&](auto op, auto vm) -> int {
+                constexpr int OP = decltype(op)::value;
+                constexpr int VM = decltype(vm)::value;
+                HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_window_kernel<OP, VM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                TimedLaunch tl(pl, st, 1);
+                fgb_window_kernel<OP, VM><<<dim3((unsigned)grid), dim3(1024), lds, st>>>(p, k, v, n, thr, G, gsum, gcnt, pl->err, (int)pl->xform, vop,
+                                                                                        reinterpret_cast<uint32_t *>(pl->err + 4));
+                HIP_TRY(ctx, hipGetLastError());
+                return HARK_OK;
+            };
+            pl->win_rows += n;
+            if (!v) return dispatch_op(cmp, p != nullptr, [&](auto op) -> int { return launch(op, std::integral_constant<int, 2>{}); });
+            if (vop == VOP_F32SUM && pl->xform == 0)
+                return dispatch_op(cmp, p != nullptr, [&](auto op) -> int { return launch(op, std::integral_constant<int, 1>{}); });
+            return dispatch_op(cmp, p != nullptr, [&](auto op) -> int { return launch(op, std::integral_constant<int, 0>{}); });
+        }
+    }
+    // ... everything else: partition + per-bucket LDS aggregation, chunked
     HARK_TRY(plan_prepare_partition(ctx, pl));
     // geometry: one-word ring entries in <= 128 buckets (pairfmt = 3) are no faster than the split rings in 256 buckets at the
     // headline's selectivity (2.57-2.69 against 2.46-2.63 ms per 1e9 rows, profiles/r03_notes.md) -- but when (nearly) every row
@@ -2243,8 +2482,14 @@ int k_fgb_dense_f32(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cm
 static int fgb_check_err(hark_context *ctx, hark_fgb_plan *pl)
 {
     int32_t *e = reinterpret_cast<int32_t *>(ctx->h_pin);
-    HIP_TRY(ctx, hipMemcpyAsync(e, pl->err, 16, hipMemcpyDeviceToHost, ctx->stream));   // the error word and the pairs partitioned so far
+    HIP_TRY(ctx, hipMemcpyAsync(e, pl->err, 32, hipMemcpyDeviceToHost, ctx->stream));   // the error word, the pairs partitioned so far, the window path's counters
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    {   // the window path since the last check: rows it could not keep in LDS (never reset on the device)
+        const int64_t outside = (int64_t)(uint32_t)e[5] - (int64_t)(uint32_t)pl->win_outside_seen, rows = pl->win_rows - pl->win_rows_seen;
+        pl->win_moves = (int64_t)(uint32_t)e[4];
+        if (rows > 0 && (uint32_t)outside > (uint64_t)rows / 64) pl->win_verdict = 0;          // not a clustered column after all: the partition path from now on
+        pl->win_outside_seen = (uint32_t)e[5]; pl->win_rows_seen = pl->win_rows;
+    }
     {   // the predicate's selectivity since the last check (the next run picks its geometry by it)
         const int64_t pairs = (int64_t)(((uint64_t)(uint32_t)e[3] << 32) | (uint32_t)e[2]), rows = pl->rows_fed - pl->rows_seen;
         if (rows > 0) pl->sel_pct = (pairs - pl->pairs_seen) * 100 / rows;
