@@ -616,7 +616,36 @@ def extra_configs(torch, eng, dev, a, sink, out):
                                 sum_checksum=(float(so.to(torch.float64).sum().item()) == float(v.to(torch.float64).sum().item())) if a.exact else None,
                                 bytes_model="read k, v (8 B/row) + 16 B per group; the partition adds 6 B written + 6 B read per row (20 B/row moved)")
     plan.free()
+    sink()
+
+    # ---- the same two statements on the table SORTED by k (a table kept in key order): the partition's rings are sized for keys that
+    #      scatter -- consecutive rows of one key all fall into one ring -- so such columns take the window path (fgb_window_kernel:
+    #      every workgroup aggregates a contiguous stretch of rows in an LDS window of consecutive keys; one pass, no pairs written).
+    #      Only k is sorted (p and v keep their rows): the survivors and the grand totals stay those of the headline.
+    try:
+        ksorted = k.sort().values
+        torch.cuda.synchronize()
+        for name, pp, nbytes, stmt in (("HEADLINE_sorted_keys", p.data_ptr(), 12.0 * N + 16.0 * G, "SELECT k,SUM(v),COUNT(*) FROM t WHERE p>0.5 GROUP BY k -- t sorted by k"),
+                                       ("C3_no_filter_sorted_keys", None, 8.0 * N + 16.0 * G, "SELECT k,SUM(v),COUNT(*) FROM t GROUP BY k -- t sorted by k")):
+            plan = FgbPlan(eng, N, G, timing=1)
+
+            def step_sorted():
+                plan.reset()
+                plan.run(pp, ">", 0.5, ksorted.data_ptr(), v.data_ptr(), N)
+                plan.finish(so.data_ptr(), co.data_ptr())
+
+            ms = event_ms(torch, step_sorted)
+            kms, kl = plan.timing()
+            want = int((p > 0.5).sum().item()) if pp is not None else N
+            out[name] = entry(ms, nbytes, N, groups=G, statement=stmt, path="window (one pass)" if kl.get("consumer", 0) == 0 else "partition + LDS consumer",
+                              kernel_ms={kk: kms[kk] / max(1, kl[kk]) for kk in kms if kl[kk]}, count_checksum=int(co.sum().item()) == want)
+            plan.free()
+            sink()
+        del ksorted
+    except Exception as e:
+        out["HEADLINE_sorted_keys"] = {"error": repr(e)}
     del so, co
+    torch.cuda.empty_cache()
     sink()
 
     # ---- BASELINE configs[0]: the reference's own two statements on its 7-row data.csv (README.md:42, test.py:7), end to end

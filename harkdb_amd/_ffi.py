@@ -88,6 +88,7 @@ SIGNATURES = {
     "hark_table_invalidate_stats": (C.c_int, [_vp, _vp, _i32]),
     "hark_context_last_groupby_path": (C.c_int, [_vp]),
     "hark_context_last_groupby_passes": (C.c_int, [_vp]),
+    "hark_context_last_groupby_window": (C.c_int, [_vp]),
     "hark_context_last_join_path": (C.c_int, [_vp]),
     "hark_op_stream_read": (C.c_int, [_vp, C.POINTER(C.c_void_p), _i32, _i64, _vp]),
     "hark_op_stream_mix": (C.c_int, [_vp, C.POINTER(C.c_void_p), _i64, _vp, _i32]),

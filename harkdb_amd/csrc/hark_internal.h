@@ -46,6 +46,7 @@ struct hark_context {
     // diagnostic: which GROUP BY path served the last group-by entry (hark_context_last_groupby_path)
     int last_groupby_path = 0;
     int last_groupby_passes = 0;             // row passes of the last dense-path filter_groupby (hark_context_last_groupby_passes)
+    bool last_groupby_window = false;        // ... the last dense GROUP BY took the window path (a key column sorted / clustered by the key; hark_context_last_groupby_window)
     int last_join_path = 0;        // hark_context_last_join_path
     bool last_join_weighted = false;   // ... the partitioned path cut its buckets by the sampled probe rows' weight (k_hjoin.hip)
     bool last_join_clustered = false;  // ... the probe column was clustered by key: searched in row order (k_cjoin.hip)
@@ -88,7 +89,11 @@ struct hark_column {
     // tight clusters), so the next ORDER BY / GROUP BY / JOIN on it starts with the tuple passes instead of losing the sweeps
     // again (1.7 ms per 1e8 rows).  Performance only.
     mutable int8_t msd_unfit = 0;
-    void invalidate_stats() const { has_range[0] = has_range[1] = false; hash_rounds = 0; msd_unfit = 0; }
+    // ... and what the fused GROUP BY's test (k_fgb.hip, fgb_cluster_test_kernel) found about it as a dense KEY column: -1 not
+    // tested, 1 = rows an eighth of a batch apart are a few keys apart (a table kept in key order: the window path), 0 = they
+    // scatter (the partition path).  One small launch and a synchronisation saved per statement.  Performance only.
+    mutable int8_t key_clustered = -1;
+    void invalidate_stats() const { has_range[0] = has_range[1] = false; hash_rounds = 0; msd_unfit = 0; key_clustered = -1; }
 };
 
 struct hark_table {

@@ -101,6 +101,7 @@ __global__ __launch_bounds__(1024) void cj_test_kernel(const K *__restrict__ key
         const uint32_t a = s_cnt[0], b = s_cnt[1], c = s_cnt[2], d = s_cnt[3];
         verdict[1] = a; verdict[2] = b; verdict[3] = c; verdict[4] = d;
         verdict[0] = ((a > b && (a - b) * 8u > (uint32_t)kCtPairs) || (c > d && (c - d) * 8u > (uint32_t)kCtPairs)) ? 1ull : 0ull;
+        __threadfence_system();                                           // (`verdict` may be host memory)
     }
 }
 

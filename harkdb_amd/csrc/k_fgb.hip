@@ -460,6 +460,151 @@ __global__ __launch_bounds__(1024) void fgb_window_kernel(
     if (tid == 0 && moved) atomicAdd(&stat[0], moved);
 }
 
+// The window path for the passes that keep several aggregates per group (k_fgb_dense_stats: SUM / COUNT / MIN / MAX of one column;
+// k_fgb_dense_multi: two or three columns): per key and replica a 64-bit slot a0 (operator vop0 on column c0), the row count, and two
+// 32-bit slots a1 / a2 (MAX or MIN of the order words of columns c1 / c2; c2 may be null) -- 20 B x 1024 keys x 4 replicas = 80 KiB.
+// The operators are run-time values here (these passes are not the headline's).  Same windows, same turns as fgb_window_kernel.
+struct WinAgg { const uint32_t *c0, *c1, *c2; int vop0, xf0, vop1, xf1, vop2, xf2; u64 *g0, *g1, *g2; };
+constexpr int kWinXRL = 2, kWinXRep = 1 << kWinXRL;
+
+template <int OP>
+__global__ __launch_bounds__(1024) void fgb_windowx_kernel(
+    const float *__restrict__ p, const int32_t *__restrict__ k, int64_t n, float thr, int64_t G, const WinAgg A,
+    unsigned long long *__restrict__ gcnt, int32_t *__restrict__ err, uint32_t *__restrict__ stat)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    constexpr int SLOTS = kWinKeys << kWinXRL;
+    u64 *s_a0 = reinterpret_cast<u64 *>(lds_raw);
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(lds_raw + sizeof(u64) * SLOTS), *s_a1 = s_cnt + SLOTS, *s_a2 = s_a1 + SLOTS;
+    __shared__ int s_lo[3], s_hi[3];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const bool has2 = A.c2 != nullptr;
+    const u64 id0 = vop_identity(A.vop0);
+    const uint32_t id1 = (uint32_t)vop_identity(A.vop1), id2 = (uint32_t)vop_identity(A.vop2);
+    for (int i = tid; i < SLOTS; i += 1024) { s_a0[i] = id0; s_cnt[i] = 0u; s_a1[i] = id1; s_a2[i] = id2; }
+    if (tid < 3) { s_lo[tid] = 0x7FFFFFFF; s_hi[tid] = -1; }
+    __syncthreads();
+    const uint32_t rep = (uint32_t)tid & (uint32_t)(kWinXRep - 1);
+    const int64_t nvec = n / kVec;
+    const int64_t per = ((nvec + gridDim.x - 1) / gridDim.x + 1023) / 1024 * 1024;
+    const int64_t q0 = (int64_t)blockIdx.x * per, q1 = q0 + per < nvec ? q0 + per : nvec;
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+    auto ldp = [&](int64_t q) -> float4 {
+        if (OP == kNoPred) return float4{0, 0, 0, 0};
+        if (OP == kMaskPred) return mask_nibble(p, q * kVec);
+        const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(p) + q);
+        return float4{t.x, t.y, t.z, t.w};
+    };
+    auto ldu = [&](const uint32_t *c, int64_t q) -> u4v { return __builtin_nontemporal_load(reinterpret_cast<const u4v *>(c) + q); };
+    const bool same1 = A.c1 == A.c0, same2 = A.c2 == A.c0;
+    bool bad = false;
+    int base = 0, dlo = 0x7FFFFFFF, dhi = -1;
+    uint32_t moved = 0, outside = 0;
+    auto global_row = [&](int key, uint32_t x0, uint32_t x1, uint32_t x2) {
+        vop_atomic_rt(A.vop0, &A.g0[key], apply_xf(A.xf0, x0));
+        const u64 w1 = apply_xf(A.xf1, x1);
+        if (A.vop1 == VOP_U32MIN) atomicMin(&A.g1[key], w1); else atomicMax(&A.g1[key], w1);
+        if (has2) { const u64 w2 = apply_xf(A.xf2, x2); if (A.vop2 == VOP_U32MIN) atomicMin(&A.g2[key], w2); else atomicMax(&A.g2[key], w2); }
+        atomicAdd(&gcnt[key], 1ull);
+    };
+    auto write_out = [&]() {
+        for (int g = dlo - base + tid; g <= dhi - base; g += 1024) {
+            u64 a0 = id0; uint32_t c = 0, a1 = id1, a2 = id2;
+#pragma unroll
+            for (int r = 0; r < kWinXRep; r++) {
+                const int slot = (g << kWinXRL) + r;
+                a0 = vop_merge(A.vop0, a0, s_a0[slot]); c += s_cnt[slot];
+                a1 = A.vop1 == VOP_U32MIN ? min(a1, s_a1[slot]) : max(a1, s_a1[slot]);
+                a2 = A.vop2 == VOP_U32MIN ? min(a2, s_a2[slot]) : max(a2, s_a2[slot]);
+                s_a0[slot] = id0; s_cnt[slot] = 0u; s_a1[slot] = id1; s_a2[slot] = id2;
+            }
+            if (c) {
+                vop_atomic_partial_rt(A.vop0, &A.g0[base + g], a0);
+                if (A.vop1 == VOP_U32MIN) atomicMin(&A.g1[base + g], (u64)a1); else atomicMax(&A.g1[base + g], (u64)a1);
+                if (has2) { if (A.vop2 == VOP_U32MIN) atomicMin(&A.g2[base + g], (u64)a2); else atomicMax(&A.g2[base + g], (u64)a2); }
+                atomicAdd(&gcnt[base + g], (unsigned long long)c);
+            }
+        }
+        dlo = 0x7FFFFFFF; dhi = -1;
+        __syncthreads();
+    };
+    int ph = 0;
+    for (int64_t qb = q0; qb < q1; qb += 1024) {
+        const int64_t q = qb + tid;
+        const bool have = q < q1;
+        float4 pa = float4{0, 0, 0, 0};
+        u4v ka = {0u, 0u, 0u, 0u}, x0 = ka, x1 = ka, x2 = ka;
+        if (have) {
+            pa = ldp(q); ka = ldu(reinterpret_cast<const uint32_t *>(k), q); x0 = ldu(A.c0, q);
+            x1 = same1 ? x0 : ldu(A.c1, q);
+            if (has2) x2 = same2 ? x0 : ldu(A.c2, q);
+        }
+        const float pv[4] = {pa.x, pa.y, pa.z, pa.w};
+        const int kk[4] = {(int)ka.x, (int)ka.y, (int)ka.z, (int)ka.w};
+        const uint32_t v0[4] = {x0.x, x0.y, x0.z, x0.w}, v1[4] = {x1.x, x1.y, x1.z, x1.w}, v2[4] = {x2.x, x2.y, x2.z, x2.w};
+        uint32_t live = 0;
+        int mn = 0x7FFFFFFF, mx = -1;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (have && cmp_f32<OP>(pv[j], thr)) {
+                if ((uint32_t)kk[j] < (uint64_t)G) { live |= 1u << j; mn = min(mn, kk[j]); mx = max(mx, kk[j]); }
+                else bad = true;
+            }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { mn = min(mn, __shfl_xor(mn, d, 64)); mx = max(mx, __shfl_xor(mx, d, 64)); }
+        for (int turn = 0;; turn++) {
+            if (lane == 0 && mx >= 0) { atomicMin(&s_lo[ph], mn); atomicMax(&s_hi[ph], mx); }
+            __syncthreads();
+            const int blo = s_lo[ph], bhi = s_hi[ph];
+            const int clr = ph == 0 ? 2 : ph - 1;
+            ph = ph == 2 ? 0 : ph + 1;
+            if (tid == 0) { s_lo[clr] = 0x7FFFFFFF; s_hi[clr] = -1; }
+            if (blo > bhi) break;
+            if (blo < base || bhi >= base + kWinKeys) {
+                if (dlo <= dhi) write_out();
+                base = blo; moved++;
+            }
+            const bool last = turn == kWinTurns - 1;
+            dlo = min(dlo, blo); dhi = max(dhi, min(bhi, base + kWinKeys - 1));
+            mn = 0x7FFFFFFF; mx = -1;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (live & (1u << j)) {
+                    const uint32_t off = (uint32_t)(kk[j] - base);
+                    if (off < (uint32_t)kWinKeys) {
+                        const uint32_t slot = (off << kWinXRL) | rep;
+                        vop_atomic_rt(A.vop0, &s_a0[slot], apply_xf(A.xf0, v0[j]));
+                        const uint32_t w1 = apply_xf(A.xf1, v1[j]);
+                        if (A.vop1 == VOP_U32MIN) atomicMin(&s_a1[slot], w1); else atomicMax(&s_a1[slot], w1);
+                        if (has2) { const uint32_t w2 = apply_xf(A.xf2, v2[j]); if (A.vop2 == VOP_U32MIN) atomicMin(&s_a2[slot], w2); else atomicMax(&s_a2[slot], w2); }
+                        atomicAdd(&s_cnt[slot], 1u);
+                        live &= ~(1u << j);
+                    } else if (last) { global_row(kk[j], v0[j], v1[j], v2[j]); outside++; }
+                    else { mn = min(mn, kk[j]); mx = max(mx, kk[j]); }
+                }
+            if (bhi < base + kWinKeys || last) break;
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) { mn = min(mn, __shfl_xor(mn, d, 64)); mx = max(mx, __shfl_xor(mx, d, 64)); }
+        }
+    }
+    __syncthreads();
+    if (dlo <= dhi) write_out();
+    if (blockIdx.x == 0) {                                                // ragged tail (n % 4 rows)
+        const int64_t t = nvec * kVec + tid;
+        if (t < n && cmp_f32<OP>(OP == kNoPred ? 0.0f : OP == kMaskPred ? mask_bit(p, t) : p[t], thr)) {
+            const int key = k[t];
+            if ((uint32_t)key < (uint64_t)G) global_row(key, A.c0[t], A.c1[t], has2 ? A.c2[t] : 0u);
+            else bad = true;
+        }
+    }
+    if (bad) *err = HARK_EBOUNDS;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) outside += __shfl_xor(outside, d, 64);
+    if (lane == 0 && outside) atomicAdd(&stat[1], outside);
+    if (tid == 0 && moved) atomicAdd(&stat[0], moved);
+}
+
 // Are rows kWinFar rows (an eighth of a batch) apart a few keys apart?  1024 such pairs, and as many of rows anywhere apart (a column of
 // few distinct keys is close to itself everywhere -- and needs no window).  out[0] = 1: clustered, [1] / [2]: the close pairs.
 // `out` may be pinned host memory.
@@ -482,6 +627,7 @@ __global__ __launch_bounds__(1024) void fgb_cluster_test_kernel(const int32_t *_
         const uint32_t a = s_c[0], b = s_c[1];
         out[1] = a; out[2] = b;
         out[0] = (a >= 384u && b < 256u) ? 1ull : 0ull;                   // three of eight pairs close (runs of 1024 sorted rows: half of them), and not because everything is
+        __threadfence_system();                                           // (`out` may be host memory)
     }
 }
 
@@ -2304,7 +2450,7 @@ static int fgb_window_wanted(hark_context *ctx, hark_fgb_plan *pl, const int32_t
     if (const char *e = getenv("HARK_FGB_WINDOW")) { *window = atoi(e) != 0; return HARK_OK; }
     if (pl->window == 1) { *window = true; return HARK_OK; }
     if (pl->window == 2 || n < ((int64_t)1 << 20)) return HARK_OK;
-    if (pl->win_k != k || pl->win_n != n) {
+    if (pl->win_k != k || pl->win_n != n || pl->win_verdict < 0) {
         unsigned long long *out = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(ctx->h_pin) + 65536 - 128);   // (the kernel writes pinned host memory)
         fgb_cluster_test_kernel<<<1, 1024, 0, ctx->stream>>>(k, n, out);
         HIP_TRY(ctx, hipGetLastError());
@@ -2615,6 +2761,38 @@ int hark_fgb_check(hark_context *ctx, hark_fgb_plan *pl)
 // path with <= 4096 keys per bucket qualifies (20 B per key of LDS in the consumer); *ran is false otherwise, and also
 // when the data overflowed a slab or a ring (heavy skew: this pass has no single-row fallback) -- the caller then runs
 // the separate passes.  Accumulators: acc_sum / acc_cnt as usual, acc_min / acc_max as order words in 64-bit slots.
+// the several-aggregates window pass over all n rows (the caller has initialised the accumulators)
+static int fgb_run_windowx(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cmp, float thr, const int32_t *k, int64_t n, const WinAgg &A)
+{
+    const size_t lds = (size_t)(kWinKeys << kWinXRL) * 20;
+    int64_t grid = pl->grid ? pl->grid : (int64_t)ctx->num_cu;
+    const int64_t need = (n / kVec + 1023) / 1024;
+    if (grid > need) grid = need > 0 ? need : 1;
+    pl->win_rows += n;
+    return dispatch_op(cmp, p != nullptr, [&](auto op) -> int {
+        constexpr int OP = decltype(op)::value;
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_windowx_kernel<OP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        TimedLaunch tl(pl, ctx->stream, 1);
+        fgb_windowx_kernel<OP><<<dim3((unsigned)grid), dim3(1024), lds, ctx->stream>>>(p, k, n, thr, pl->G, A, pl->acc_cnt, pl->err, reinterpret_cast<uint32_t *>(pl->err + 4));
+        HIP_TRY(ctx, hipGetLastError());
+        return HARK_OK;
+    });
+}
+
+// after a window pass of the several-aggregates entries: the sticky error word (a key out of range), as their partition passes read it
+static int fgb_window_done(hark_context *ctx, hark_fgb_plan *pl, bool *ran)
+{
+    int64_t e = 0;
+    HARK_TRY(hark_read_words(ctx, pl->err, &e, 1));
+    const int32_t code = (int32_t)(e & 0xFFFFFFFFll);
+    if (code != 0) {
+        HIP_TRY(ctx, hipMemsetAsync(pl->err, 0, sizeof(int32_t), ctx->stream));
+        return hark_fail(ctx, code, "filter_groupby: a surviving row has a key outside [0, %lld)", (long long)pl->G);
+    }
+    *ran = true;
+    return HARK_OK;
+}
+
 int k_fgb_dense_stats(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cmp, float thr,
                       const int32_t *k, const void *v, int64_t n, int vk, bool *ran)
 {
@@ -2623,15 +2801,27 @@ int k_fgb_dense_stats(hark_context *ctx, hark_fgb_plan *pl, const float *p, int 
     if (n <= 0 || pl->algo != 0 || G * 12 <= kLdsTableBudget || G > (int64_t)kMaxBuckets * 4096 || n > pl->max_rows) return HARK_OK;
     auto misaligned = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) != 0; };
     if ((p && misaligned(p)) || misaligned(k) || misaligned(v)) return HARK_OK;
-    HARK_TRY(plan_prepare_partition(ctx, pl));
+    bool window = false;                                               // a key column sorted / clustered by the key: the window pass (fgb_windowx_kernel)
+    HARK_TRY(fgb_window_wanted(ctx, pl, k, n, &window));
+    if (!window) {
+        HARK_TRY(plan_prepare_partition(ctx, pl));
+        if (pl->shift > 12) return HARK_OK;
+    }
     const int P = (int)pl->P, shift = (int)pl->shift, nwg = (int)pl->nwg;
-    if (shift > 12) return HARK_OK;
     if (!pl->acc_min) HARK_TRY(hark_alloc(ctx, (void **)&pl->acc_min, (size_t)G * 8));
     if (!pl->acc_max) HARK_TRY(hark_alloc(ctx, (void **)&pl->acc_max, (size_t)G * 8));
     hipStream_t st = ctx->stream;
     const int64_t blocks = (G + 255) / 256 > (int64_t)ctx->num_cu * 4 ? (int64_t)ctx->num_cu * 4 : (G + 255) / 256;
     fgb_init_stats_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(reinterpret_cast<u64 *>(pl->acc_sum), pl->acc_cnt, pl->acc_min, pl->acc_max, G);   // one launch instead of three memsets and a fill
     u64 *gsum = reinterpret_cast<u64 *>(pl->acc_sum);
+    if (window) {
+        // vk 0: f32 (f64 sum of the values, extremes of their order words), 1: i32 (sum and extremes of the biased words), 2: u32
+        const uint32_t *c = static_cast<const uint32_t *>(v);
+        const int xo = vk == 0 ? XF_F32_ORDER : vk == 1 ? XF_I32_ORDER : XF_NONE;
+        const WinAgg A = {c, c, c, vk == 0 ? (int)VOP_F32SUM : (int)VOP_U32SUM64, vk == 1 ? (int)XF_I32_ORDER : (int)XF_NONE, VOP_U32MIN, xo, VOP_U32MAX, xo, gsum, pl->acc_min, pl->acc_max};
+        HARK_TRY(fgb_run_windowx(ctx, pl, p, cmp, thr, k, n, A));
+        return fgb_window_done(ctx, pl, ran);
+    }
     const size_t lds_agg = (size_t)20 << shift, lds_part = part_lds_bytes(P, 1);
     int rc = dispatch_op(cmp, p != nullptr, [&](auto op) -> int {
         constexpr int OP = decltype(op)::value;
@@ -2685,13 +2875,17 @@ int k_fgb_dense_multi(hark_context *ctx, hark_fgb_plan *pl, const float *p, int 
     if (!(vop1 == VOP_F32SUM || vop1 == VOP_U32SUM64 || vop1 == VOP_U32SUM || is_ext(vop1)) || !is_ext(vop2) || (v3 && !is_ext(vop3))) return HARK_OK;
     auto misaligned = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) != 0; };
     if ((p && misaligned(p)) || misaligned(k) || misaligned(v1) || misaligned(v2) || (v3 && misaligned(v3))) return HARK_OK;
-    HARK_TRY(plan_prepare_partition(ctx, pl));
-    if (pl->shift > 12) return HARK_OK;
+    bool window = false;                                               // a key column sorted / clustered by the key: the window pass (fgb_windowx_kernel)
+    HARK_TRY(fgb_window_wanted(ctx, pl, k, n, &window));
+    if (!window) {
+        HARK_TRY(plan_prepare_partition(ctx, pl));
+        if (pl->shift > 12) return HARK_OK;
+    }
     // half as many buckets as the plan's one-value passes, in the same workspace
-    const int shift = (int)pl->shift + 1, P = (int)(((G - 1) >> shift) + 1), nwg = (int)pl->nwg;
+    const int shift = (int)pl->shift + 1, P = window ? 1 : (int)(((G - 1) >> shift) + 1), nwg = (int)pl->nwg;
     if (P > kPairBuckets) return HARK_OK;
-    const size_t slab_bytes = ((size_t)pl->P * (size_t)pl->cap * 8 / (size_t)P) & ~(size_t)15;
-    if (slab_bytes < (size_t)4 * multi_unit_bytes(nv)) return HARK_OK;
+    const size_t slab_bytes = window ? 0 : ((size_t)pl->P * (size_t)pl->cap * 8 / (size_t)P) & ~(size_t)15;
+    if (!window && slab_bytes < (size_t)4 * multi_unit_bytes(nv)) return HARK_OK;
     if (!pl->acc_min) HARK_TRY(hark_alloc(ctx, (void **)&pl->acc_min, (size_t)G * 8));
     if (v3 && !pl->acc_max) HARK_TRY(hark_alloc(ctx, (void **)&pl->acc_max, (size_t)G * 8));
     hipStream_t st = ctx->stream;
@@ -2701,6 +2895,13 @@ int k_fgb_dense_multi(hark_context *ctx, hark_fgb_plan *pl, const float *p, int 
     HIP_TRY(ctx, hipMemsetAsync(pl->acc_cnt, 0, (size_t)G * 8, st));
     fgb_fill_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(pl->acc_min, G, vop_identity(vop2));
     if (v3) fgb_fill_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(pl->acc_max, G, vop_identity(vop3));
+    if (window) {
+        if (vop1 == VOP_U32PROD) return HARK_OK;
+        const WinAgg A = {static_cast<const uint32_t *>(v1), static_cast<const uint32_t *>(v2), static_cast<const uint32_t *>(v3), vop1, xf1, vop2, xf2, v3 ? vop3 : (int)VOP_U32MAX, xf3,
+                          gsum, pl->acc_min, pl->acc_max};
+        HARK_TRY(fgb_run_windowx(ctx, pl, p, cmp, thr, k, n, A));
+        return fgb_window_done(ctx, pl, ran);
+    }
     const size_t lds_agg = (size_t)(nv == 3 ? 20 : 16) << shift, lds_part = partv_lds_bytes(P, nv);
     const uint32_t inv2 = vop2 == VOP_U32MIN ? 0xFFFFFFFFu : 0u, inv3 = vop3 == VOP_U32MIN ? 0xFFFFFFFFu : 0u;
     unsigned char *pbuf = reinterpret_cast<unsigned char *>(pl->pbuf);

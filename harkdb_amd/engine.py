@@ -333,6 +333,10 @@ class Engine:
         """Passes over the table's rows of the last dense-path filter_groupby (diagnostic, include/hark.h)."""
         return int(self.lib.hark_context_last_groupby_passes(self.ctx))
 
+    def last_groupby_window(self):
+        """True when the last dense GROUP BY found its key column sorted / clustered by the key and took the window kernels."""
+        return bool(self.lib.hark_context_last_groupby_window(self.ctx))
+
     def last_join_path(self):
         """'partitioned' | 'sort-merge' | None: the path that served the last join entry (diagnostic, include/hark.h)."""
         return {1: "partitioned", 2: "sort-merge", 3: "partitioned, buckets cut by weight", 4: "clustered probe column, searched in row order"}.get(self.lib.hark_context_last_join_path(self.ctx))

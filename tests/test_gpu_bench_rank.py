@@ -199,6 +199,8 @@ def test_bench_extra_configs_at_a_small_scale():
         assert line["summary"][name][0] > 0
     assert len(json.dumps(line["summary"])) <= 2048
     assert cfg["C3_no_filter"]["count_checksum"] is True and cfg["C3_no_filter"]["sum_checksum"] is True
+    for name in ("HEADLINE_sorted_keys", "C3_no_filter_sorted_keys"):                   # a table kept in key order: the window path, same survivors
+        assert cfg[name]["count_checksum"] is True and cfg[name]["path"].startswith("window"), cfg[name]
     assert "G2^20_sel1.0" in cfg["SWEEP_selectivity_x_groups"] and cfg["SWEEP_selectivity_x_groups"]["G2^20_sel1.0"]["count_checksum"] is True
     for name in ("C3_no_filter", "G16", "G4096", "G13000", "SWEEP_selectivity_x_groups", "SPARSE_groupby", "SPARSE_five_aggregates", "C2_filter_proj", "C1_projection", "REF_query_groupby_dense",
                  "REF_query_groupby_hash", "ORDER_BY", "ORDER_BY_32bit", "ORDER_BY_i64", "REF_join_u32", "C4_join_share", "C5_pipeline_share",

@@ -126,3 +126,54 @@ def test_key_out_of_range_is_bounds_error(eng):
     plan.free()
     for ptr in (p, k, v):
         eng.free(ptr)
+
+
+@pytest.mark.parametrize("n,G,order", [(1_300_000, 1 << 17, "sorted"), (1_300_000, 1 << 17, "descending"), (2_100_000, 1 << 18, "runs8192"), (1_200_000, 1 << 17, "random")])
+def test_reference_query_groupby_on_a_table_kept_in_key_order(eng, oracle, n, G, order):
+    """query_groupby (main.fut:9) with several aggregates of one and of three columns on a table SORTED by its key column: the
+    statistics / pair / triple passes run through the window kernel (fgb_windowx_kernel) -- same table as the oracle's."""
+    rng = np.random.default_rng(n % 983 + G)
+    db = rng.integers(0, 2**32, size=(n, 6), dtype=np.uint64).astype(np.uint32)
+    db[:, 0] = _keys(order, n, G, rng).astype(np.uint32)
+    db[:, 5] = rng.integers(0, 4, size=n) * 2 + 1
+    t = eng.table_from_matrix(db, np.uint32)
+    for s_cols, t_cols in (([1, 1, 1], [2, 3, 4]), ([1, 1, 1, 5, 2, 2, 1], [2, 3, 4, 1, 4, 3, 2]), ([1, 2, 3], [2, 3, 4]), ([4, 3, 2, 1], [4, 3, 4, 2]), ([1], [2]), ([], [])):
+        got = eng.query_groupby(t, 0, s_cols, t_cols).to_numpy(np.uint32)
+        exp = oracle.query_groupby(db, 0, s_cols, t_cols)
+        assert got.shape == exp.shape and np.array_equal(got, exp), (s_cols, t_cols)
+        assert eng.last_groupby_path() == "dense"
+        assert eng.last_groupby_window() == (order != "random"), (order, s_cols)
+    t.free()
+
+
+@pytest.mark.parametrize("order", ["sorted", "descending", "random"])
+def test_filter_groupby_entry_typed_aggregates_on_a_table_kept_in_key_order(eng, order):
+    """hark_entry_filter_groupby: SUM / MAX / MIN / AVG / COUNT of f32, i32 and u32 columns under a predicate, keys sorted: the
+    one-column statistics pass, the pair / triple passes and the single passes all take the window kernels; against pandas."""
+    import pandas as pd
+    rng = np.random.default_rng(17)
+    n, G = 1_500_003, 1 << 17
+    k = _keys(order, n, G, rng)
+    df = pd.DataFrame({"p": rng.random(n).astype(np.float32), "k": k, "a": (rng.integers(-500, 500, n) / 4).astype(np.float32),
+                       "i": rng.integers(-10**6, 10**6, n).astype(np.int32), "u": rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32),
+                       "b": rng.normal(size=n).astype(np.float32)})
+    t = eng.table_from_columns([df[c].to_numpy() for c in df.columns])
+    aggs = [("sum", 2), ("max", 2), ("min", 2), ("avg", 2), ("count", 0), ("max", 3), ("min", 4), ("sum", 3), ("max", 5), ("avg", 3), ("sum", 4)]
+    res = eng.filter_groupby(t, [(0, ">", 0.4)], 1, aggs)
+    assert eng.last_groupby_path() == "dense" and eng.last_groupby_window() == (order != "random")
+    cols = res.columns()
+    res.free()
+    g = df[df.p > 0.4].groupby("k").agg(sa=("a", "sum"), mxa=("a", "max"), mna=("a", "min"), ava=("a", "mean"), n=("a", "count"), mxi=("i", "max"), mnu=("u", "min"),
+                                        si=("i", "sum"), mxb=("b", "max"), avi=("i", "mean"), su=("u", "sum")).reset_index()
+    exp = [g.k, g.sa, g.mxa, g.mna, g.ava, g.n, g.mxi, g.mnu, g.si, g.mxb, g.avi, g.su]
+    assert len(cols) == len(exp)
+    for j, (got, e) in enumerate(zip(cols, exp)):
+        e = e.to_numpy()
+        if got.dtype.kind == "f": assert np.allclose(got.astype(np.float64), e.astype(np.float64), rtol=2e-6, atol=1e-6), j
+        else: assert np.array_equal(got.astype(np.int64), e.astype(np.int64)), j
+    # ... and without a predicate, COUNT only
+    res = eng.filter_groupby(t, [], 1, [("count", 0)])
+    c2 = res.columns(); res.free()
+    g2 = df.groupby("k").size().reset_index()
+    assert np.array_equal(c2[0].astype(np.int64), g2.k.to_numpy()) and np.array_equal(c2[1].astype(np.int64), g2[0].to_numpy())
+    t.free()

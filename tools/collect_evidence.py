@@ -81,7 +81,8 @@ with open(os.path.join(dst, f"{tag}_op_traffic.txt"), "w") as fo:
 print(open(os.path.join(dst, f"{tag}_op_traffic.txt")).read())
 # the probes of the same run (round 6: join under skew, the 7-row statements, no-filter producer, SQL stress, SQ counters)
 for name, out in (("join_skew.txt", "join_skew.txt"), ("small_latency.txt", "small_latency.txt"), ("nofilter_ab.txt", "nofilter_ab.txt"), ("ingest_bench.log", "ingest_bench.log"),
-                  ("strong_rehearsal.txt", "strong_rehearsal.txt"), ("sql_stress.txt", "sql_stress.txt"), ("pmc_join_c4.txt", "pmc_join_c4.txt"), ("pmc_sort64.txt", "pmc_sort64.txt"),
+                  ("strong_rehearsal.txt", "strong_rehearsal.txt"), ("sql_stress.txt", "sql_stress.txt"), ("join_cluster.txt", "join_cluster.txt"), ("groupby_cluster.txt", "groupby_cluster.txt"),
+                  ("statement_cluster.txt", "statement_cluster.txt"), ("cluster_traces.txt", "cluster_traces.txt"), ("pmc_join_c4.txt", "pmc_join_c4.txt"), ("pmc_sort64.txt", "pmc_sort64.txt"),
                   ("hashlds.txt", "hashlds.txt"), ("widedigit.txt", "widedigit.txt"), ("hash_pmc_after.txt", "hash_pmc_after.txt"), ("libsort_yardstick.txt", "libsort_yardstick.txt")):
     f = only(name, required=False)
     if f:

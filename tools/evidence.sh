@@ -37,6 +37,14 @@ done
 # (OR / NOT / IN trees against pandas), SQ counters of the join's and the i64 sort's kernels, what one rank of a strong-scaling
 # run does (round 5's probes -- LDS side of a hash probe, wide digits, the vendor sort -- are not repeated: profiles/r05_*)
 timeout 300 python tools/join_skew_probe.py > $O/join_skew.txt 2>&1
+# ... and the tables kept in key order: the join's search path, the GROUP BY's window path, every statement form on a sorted table;
+# kernel timelines of the two new paths (the probes' first shapes only)
+timeout 300 python tools/join_cluster_probe.py > $O/join_cluster.txt 2>&1
+timeout 400 python tools/groupby_cluster_probe.py 1e9 > $O/groupby_cluster.txt 2>&1
+timeout 300 python tools/statement_cluster_probe.py > $O/statement_cluster.txt 2>&1
+timeout 200 rocprofv3 --kernel-trace --output-format csv -d $O/trace_cjoin -- python3 tools/join_cluster_probe.py sorted match_sorted > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/trace_window -- python3 tools/groupby_cluster_probe.py 1e9 sorted > /dev/null 2>&1
+{ echo "== tools/join_cluster_probe.py sorted match_sorted (three joins each)"; python tools/ktrace.py $O/trace_cjoin 0.17 | head -14; echo "== tools/groupby_cluster_probe.py 1e9 sorted"; python tools/ktrace.py $O/trace_window 0.05 | head -10; } > $O/cluster_traces.txt 2>&1
 timeout 100 python tools/small_latency.py > $O/small_latency.txt 2>&1
 timeout 200 python tools/nofilter_ab.py > $O/nofilter_ab.txt 2>&1
 timeout 200 python tools/ingest_bench.py > $O/ingest_bench.log 2>&1
