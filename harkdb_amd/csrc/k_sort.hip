@@ -142,6 +142,10 @@ __global__ __launch_bounds__(GEO::T) void digit_hist_kernel(const uint32_t *__re
 // hist0[bin][blk].  (A first version counted all four bytes -- only the first pass can use a histogram of the INPUT order,
 // and three more LDS atomics per key made this the slowest read of the sort: 139 us per 1e8 keys against 71 for
 // digit_hist_kernel.)
+// diff[1] != 0: the keys are NOT in ascending order of (key ^ xor_mask) -- an input that is (a table kept in key order, a
+// dimension table sorted by its primary key, the result of a GROUP BY) needs no pass at all: the stable sort of a sorted
+// sequence is the sequence.  Every thread checks its own 16 bytes and the word behind them (the next lane's: a shuffle; the
+// wave's last lane reads it) until it has seen a descent: on shuffled keys that is its first load.
 __global__ __launch_bounds__(1024) void multi_hist_kernel(const uint32_t *__restrict__ keys, int64_t n, int64_t slice, uint32_t xor_mask,
                                                           uint32_t *__restrict__ hist0, int nblk, uint32_t *__restrict__ diff)
 {
@@ -166,13 +170,31 @@ __global__ __launch_bounds__(1024) void multi_hist_kernel(const uint32_t *__rest
         else atomicAdd(&s_hist[d], 1u);
     };
     auto count4 = [&](const uint4 q) { count1(q.x); count1(q.y); count1(q.z); count1(q.w); };
+    bool descent = false;
+    const int lane = threadIdx.x & 63;
+    // q = keys[lo + 4 at .. + 4): in order, and not above the word behind them?  `wave`: the lanes of the wave hold consecutive 16
+    // bytes (the next lane's first word is the word behind this lane's last)
+    auto ordered4 = [&](const uint4 q, int64_t at, bool wave) {
+        const uint32_t x = q.x ^ xor_mask, y = q.y ^ xor_mask, z = q.z ^ xor_mask, w = q.w ^ xor_mask;
+        const bool all = wave && __ballot(true) == ~0ull;             // (the loop's last round may have left some lanes behind)
+        uint32_t nx = all ? (uint32_t)__shfl_down((int)x, 1, 64) : 0u;
+        if (descent) return;
+        if (!all || lane == 63) { const int64_t g = lo + 4 * (at + 1); nx = g < n ? keys[g] ^ xor_mask : 0xFFFFFFFFu; }
+        descent = x > y || y > z || z > w || w > nx;
+    };
     int64_t i = threadIdx.x;
     for (; i + 3 * (int64_t)blockDim.x < nvec; i += 4 * (int64_t)blockDim.x) {
         const uint4 a = ld_nt16(k4 + i), b = ld_nt16(k4 + i + blockDim.x), c = ld_nt16(k4 + i + 2 * blockDim.x), d = ld_nt16(k4 + i + 3 * blockDim.x);
         count4(a); count4(b); count4(c); count4(d);
+        ordered4(a, i, true); ordered4(b, i + blockDim.x, true); ordered4(c, i + 2 * (int64_t)blockDim.x, true); ordered4(d, i + 3 * (int64_t)blockDim.x, true);
     }
-    for (; i < nvec; i += blockDim.x) count4(k4[i]);
-    for (int64_t j = lo + nvec * 4 + threadIdx.x; j < hi; j += blockDim.x) count1(keys[j]);
+    for (; i < nvec; i += blockDim.x) { const uint4 a = k4[i]; count4(a); ordered4(a, i, false); }
+    for (int64_t j = lo + nvec * 4 + threadIdx.x; j < hi; j += blockDim.x) {
+        const uint32_t k = keys[j];
+        count1(k);
+        if (j + 1 < n && (k ^ xor_mask) > (keys[j + 1] ^ xor_mask)) descent = true;
+    }
+    if (descent && __hip_atomic_load(diff + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) atomicOr(diff + 1, 1u);
     for (int d = 32; d > 0; d >>= 1) acc |= __shfl_xor(acc, d, 64);
     if ((threadIdx.x & 63) == 0 && acc) atomicOr(&s_acc, acc);
     __syncthreads();
@@ -1024,9 +1046,10 @@ int k_transform_keys(hark_context *ctx, const void *src, int dtype, int part, ui
 
 // hist4 (pool block, caller frees) = per-slice histograms of all four digits of `keys` ^ xor_mask; *diff_host = the bits in
 // which the keys differ.  One read of the keys, one host synchronisation.
-static int k_multi_hist(hark_context *ctx, const uint32_t *keys, int64_t n, uint32_t xor_mask, uint32_t **hist4_out, uint32_t *diff_host)
+static int k_multi_hist(hark_context *ctx, const uint32_t *keys, int64_t n, uint32_t xor_mask, uint32_t **hist4_out, uint32_t *diff_host, bool *sorted = nullptr)
 {
     *hist4_out = nullptr; *diff_host = 0u;
+    if (sorted) *sorted = false;
     bool large; int64_t nblk, slice;
     sort_geometry(n, ctx->num_cu, &large, &nblk, &slice);
     uint32_t *h4 = nullptr, *diff = nullptr;
@@ -1042,6 +1065,7 @@ static int k_multi_hist(hark_context *ctx, const uint32_t *keys, int64_t n, uint
     hark_free(ctx, diff);
     if (rc) { hark_free(ctx, h4); return rc; }
     *hist4_out = h4; *diff_host = (uint32_t)w;
+    if (sorted) *sorted = (uint32_t)((uint64_t)w >> 32) == 0u && !getenv("HARK_SORT_NO_PRESORTED");
     return HARK_OK;
 }
 
@@ -1089,7 +1113,15 @@ static int k_sort_column_lsd(hark_context *ctx, const void *col, int dtype, int6
         // column itself, and the sorted "words" are the sorted column values (no transform pass, no inverse)
         const uint32_t xk = xm ^ (dtype == HARK_I32 ? 0x80000000u : 0u);
         uint32_t *h4 = nullptr;
-        if (!rc) rc = k_multi_hist(ctx, static_cast<const uint32_t *>(col), n, xk, &h4, &diff);   // difference mask + every digit's histograms: one read
+        bool sorted = false;
+        if (!rc) rc = k_multi_hist(ctx, static_cast<const uint32_t *>(col), n, xk, &h4, &diff, &sorted);   // difference mask + every digit's histograms: one read
+        if (!rc && sorted) {
+            // the column is in order already: the stable sort is the identity (keys and payload as they are, row ids 0 .. n - 1)
+            HIP_TRY_RC(ctx, rc, hipMemcpyAsync(k0, col, b, hipMemcpyDeviceToDevice, ctx->stream));
+            if (payload) HIP_TRY_RC(ctx, rc, hipMemcpyAsync(v0, payload, b, hipMemcpyDeviceToDevice, ctx->stream));
+            else HARK_LAUNCH_RC(ctx, rc, iota_u32_kernel<<<dim3((unsigned)grid256(ctx, n)), dim3(256), 0, ctx->stream>>>(v0, n));
+            ko = k0; vo = v0;
+        } else
         if (!rc) rc = k_sort_pairs_u32(ctx, k0, k1, v0, v1, payload, n, xk, ws, diff, &ko, &vo, static_cast<const uint32_t *>(col), h4);
         hark_free(ctx, h4);                                          // (stream-ordered reuse: the passes are enqueued)
     } else {
