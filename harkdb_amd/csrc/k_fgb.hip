@@ -410,10 +410,35 @@ __global__ __launch_bounds__(1024) void fgb_window_kernel(
             if (blo > bhi) break;
             if (blo < base || bhi >= base + kWinKeys) {                   // the window moves (every thread sees the same numbers)
                 if (dlo <= dhi) write_out();
-                base = blo; moved++;
+                // keys that fall (a column in descending order): the batch at the window's upper end, room below it
+                base = (blo < base && bhi - blo < kWinKeys) ? max(0, bhi - kWinKeys + 1) : blo;
+                moved++;
             }
             const bool last = turn == kWinTurns - 1;
             dlo = min(dlo, blo); dhi = max(dhi, min(bhi, base + kWinKeys - 1));
+            // a wave whose surviving rows all hold ONE key (a sorted column: ~950 rows per key at the headline's sizes) adds them up in
+            // registers and touches the window once, instead of 64 lanes queueing at the key's eight replicas
+            if constexpr (FSUM || CNT) {
+                if (turn == 0 && mn == mx && (uint32_t)(mn - base) < (uint32_t)kWinKeys) {   // (mn, mx: still the wave's; -1 / none: mn > mx)
+                    double part = 0.0;
+                    uint32_t c = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) if (live & (1u << j)) { part += (double)vv[j]; c++; }
+#pragma unroll
+                    for (int d = 32; d > 0; d >>= 1) {
+                        const long long pb = __double_as_longlong(part);
+                        const int lo2 = __shfl_xor((int)(uint32_t)pb, d, 64), hi2 = __shfl_xor((int)(uint32_t)((unsigned long long)pb >> 32), d, 64);
+                        part += __longlong_as_double((long long)(((unsigned long long)(uint32_t)hi2 << 32) | (uint32_t)lo2));
+                        c += (uint32_t)__shfl_xor((int)c, d, 64);
+                    }
+                    if (lane == 0) {
+                        const uint32_t slot = ((uint32_t)(mn - base) << kWinRL) | rep;
+                        if constexpr (FSUM) unsafeAtomicAdd(reinterpret_cast<double *>(&s_sum[slot]), part);
+                        atomicAdd(&s_cnt[slot], c);
+                    }
+                    live = 0;
+                }
+            }
             mn = 0x7FFFFFFF; mx = -1;
 #pragma unroll
             for (int j = 0; j < 4; j++)
@@ -563,7 +588,8 @@ __global__ __launch_bounds__(1024) void fgb_windowx_kernel(
             if (blo > bhi) break;
             if (blo < base || bhi >= base + kWinKeys) {
                 if (dlo <= dhi) write_out();
-                base = blo; moved++;
+                base = (blo < base && bhi - blo < kWinKeys) ? max(0, bhi - kWinKeys + 1) : blo;
+                moved++;
             }
             const bool last = turn == kWinTurns - 1;
             dlo = min(dlo, blo); dhi = max(dhi, min(bhi, base + kWinKeys - 1));
