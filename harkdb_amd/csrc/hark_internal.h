@@ -46,7 +46,7 @@ struct hark_context {
     // diagnostic: which GROUP BY path served the last group-by entry (hark_context_last_groupby_path)
     int last_groupby_path = 0;
     int last_groupby_passes = 0;             // row passes of the last dense-path filter_groupby (hark_context_last_groupby_passes)
-    bool last_groupby_window = false;        // ... the last dense GROUP BY took the window path (a key column sorted / clustered by the key; hark_context_last_groupby_window)
+    int last_groupby_window = 0;             // ... the last dense GROUP BY: 1 took the window path (a key column sorted / clustered by the key), 2 the partition with rotated loads (hark_context_last_groupby_window)
     int last_join_path = 0;        // hark_context_last_join_path
     bool last_join_weighted = false;   // ... the partitioned path cut its buckets by the sampled probe rows' weight (k_hjoin.hip)
     bool last_join_clustered = false;  // ... the probe column was clustered by key: searched in row order (k_cjoin.hip)
@@ -214,6 +214,7 @@ struct hark_fgb_plan {
     // the window path (k_fgb.hip, fgb_window_kernel: key columns sorted / clustered by the key)
     int64_t window = 0;        // knob: 0 by the test, 1 always, 2 never
     const void *win_k = nullptr; int64_t win_n = 0; int win_verdict = -1;   // the tested column and what the test said
+    int64_t rot_rows = 0;      // rows the partition's producers read with rotated loads (verdict 2)
     int64_t win_rows = 0, win_rows_seen = 0, win_moves = 0; uint32_t win_outside_seen = 0;   // rows fed to it / at the last check; its counters then
 };
 

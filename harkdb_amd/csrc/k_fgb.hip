@@ -560,7 +560,7 @@ __global__ __launch_bounds__(1024) void fgb_windowx_kernel(
         const bool have = q < q1;
         float4 pa = float4{0, 0, 0, 0};
         u4v ka = {0u, 0u, 0u, 0u}, x0 = ka, x1 = ka, x2 = ka;
-        if (have) {
+        if (have) {                                                       // (no prefetch of the next batch here: five vectors more ran into scratch, 0.54 -> 0.65 ms per 1e8 rows)
             pa = ldp(q); ka = ldu(reinterpret_cast<const uint32_t *>(k), q); x0 = ldu(A.c0, q);
             x1 = same1 ? x0 : ldu(A.c1, q);
             if (has2) x2 = same2 ? x0 : ldu(A.c2, q);
@@ -593,6 +593,38 @@ __global__ __launch_bounds__(1024) void fgb_windowx_kernel(
             }
             const bool last = turn == kWinTurns - 1;
             dlo = min(dlo, blo); dhi = max(dhi, min(bhi, base + kWinKeys - 1));
+            // a wave whose surviving rows all hold ONE key folds them in registers and touches the window once (see fgb_window_kernel)
+            if (turn == 0 && mn == mx && (uint32_t)(mn - base) < (uint32_t)kWinKeys && A.vop0 != VOP_U32PROD) {
+                u64 part = id0;
+                uint32_t c = 0, e1 = id1, e2 = id2;
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (live & (1u << j)) {
+                        const uint32_t x = apply_xf(A.xf0, v0[j]);
+                        part = vop_merge(A.vop0, part, A.vop0 == VOP_F32SUM ? (u64)__double_as_longlong((double)__uint_as_float(x)) : (u64)x);
+                        const uint32_t w1 = apply_xf(A.xf1, v1[j]);
+                        e1 = A.vop1 == VOP_U32MIN ? min(e1, w1) : max(e1, w1);
+                        if (has2) { const uint32_t w2 = apply_xf(A.xf2, v2[j]); e2 = A.vop2 == VOP_U32MIN ? min(e2, w2) : max(e2, w2); }
+                        c++;
+                    }
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) {
+                    const uint32_t plo = (uint32_t)__shfl_xor((int)(uint32_t)part, d, 64), phi = (uint32_t)__shfl_xor((int)(uint32_t)(part >> 32), d, 64);
+                    part = vop_merge(A.vop0, part, ((u64)phi << 32) | plo);
+                    const uint32_t o1 = (uint32_t)__shfl_xor((int)e1, d, 64), o2 = (uint32_t)__shfl_xor((int)e2, d, 64);
+                    e1 = A.vop1 == VOP_U32MIN ? min(e1, o1) : max(e1, o1);
+                    e2 = A.vop2 == VOP_U32MIN ? min(e2, o2) : max(e2, o2);
+                    c += (uint32_t)__shfl_xor((int)c, d, 64);
+                }
+                if (lane == 0) {
+                    const uint32_t slot = ((uint32_t)(mn - base) << kWinXRL) | rep;
+                    vop_atomic_partial_rt(A.vop0, &s_a0[slot], part);
+                    if (A.vop1 == VOP_U32MIN) atomicMin(&s_a1[slot], e1); else atomicMax(&s_a1[slot], e1);
+                    if (has2) { if (A.vop2 == VOP_U32MIN) atomicMin(&s_a2[slot], e2); else atomicMax(&s_a2[slot], e2); }
+                    atomicAdd(&s_cnt[slot], c);
+                }
+                live = 0;
+            }
             mn = 0x7FFFFFFF; mx = -1;
 #pragma unroll
             for (int j = 0; j < 4; j++)
@@ -631,28 +663,37 @@ __global__ __launch_bounds__(1024) void fgb_windowx_kernel(
     if (tid == 0 && moved) atomicAdd(&stat[0], moved);
 }
 
+// ... and, failing that: do NEIGHBOURING rows (kRotClose apart: four lanes) share a bucket of the partition (within kRotNear keys: a
+// quarter of the smallest bucket)?  Sorted files one behind the other (every block spans the whole key range: one row per key and
+// block, nothing for a window to add up), sorted runs of a few hundred rows: a batch of 4096 consecutive rows then falls into one or a
+// few rings (28 ms per 1e9 rows against 3.1 shuffled).  out[0] = 2: the producer reads every batch from 64 places (fgb_part_kernel's
+// `rot`): 4.7 ms (emulated by regrouping the rows, tools/groupby_cluster_probe.py rot64:blocks1000000).
+constexpr int kRotClose = 16, kRotNear = 1024;
 // Are rows kWinFar rows (an eighth of a batch) apart a few keys apart?  1024 such pairs, and as many of rows anywhere apart (a column of
 // few distinct keys is close to itself everywhere -- and needs no window).  out[0] = 1: clustered, [1] / [2]: the close pairs.
 // `out` may be pinned host memory.
 __global__ __launch_bounds__(1024) void fgb_cluster_test_kernel(const int32_t *__restrict__ k, int64_t n, unsigned long long *out)
 {
     __shared__ int s_a[1024];
-    __shared__ uint32_t s_c[2];
+    __shared__ uint32_t s_c[4];
     const int tid = threadIdx.x;
-    if (tid < 2) s_c[tid] = 0u;
+    if (tid < 4) s_c[tid] = 0u;
     const int64_t r = (int64_t)(((uint64_t)mix32(0x9E3779B9u + (uint32_t)tid) * (uint64_t)(n - kWinFar)) >> 32);
-    const int ka = k[r], kb = k[r + kWinFar];
+    const int ka = k[r], kb = k[r + kWinFar], kc = k[r + kRotClose];
     s_a[tid] = ka;
     __syncthreads();
     const int kf = s_a[(tid + 512) & 1023];
     const bool near = abs((int64_t)ka - (int64_t)kb) <= kWinNear, far = abs((int64_t)ka - (int64_t)kf) <= kWinNear;
-    const unsigned long long m0 = __ballot(near), m1 = __ballot(far);
-    if ((tid & 63) == 0) { atomicAdd(&s_c[0], __popcll(m0)); atomicAdd(&s_c[1], __popcll(m1)); }
+    const bool close = abs((int64_t)ka - (int64_t)kc) <= kRotNear, cfar = abs((int64_t)ka - (int64_t)kf) <= kRotNear;
+    const unsigned long long m0 = __ballot(near), m1 = __ballot(far), m2 = __ballot(close), m3 = __ballot(cfar);
+    if ((tid & 63) == 0) { atomicAdd(&s_c[0], __popcll(m0)); atomicAdd(&s_c[1], __popcll(m1)); atomicAdd(&s_c[2], __popcll(m2)); atomicAdd(&s_c[3], __popcll(m3)); }
     __syncthreads();
     if (tid == 0) {
-        const uint32_t a = s_c[0], b = s_c[1];
-        out[1] = a; out[2] = b;
-        out[0] = (a >= 384u && b < 256u) ? 1ull : 0ull;                   // three of eight pairs close (runs of 1024 sorted rows: half of them), and not because everything is
+        const uint32_t a = s_c[0], b = s_c[1], c = s_c[2], d = s_c[3];
+        out[1] = a; out[2] = b; out[3] = c; out[4] = d;
+        // three of eight pairs close (runs of 1024 sorted rows: half of them), and not because everything is: the window path; else
+        // three of four NEIGHBOURING pairs in one bucket: the partition with rotated loads
+        out[0] = (a >= 384u && b < 256u) ? 1ull : (c >= 768u && d < 256u) ? 2ull : 0ull;
         __threadfence_system();                                           // (`out` may be host memory)
     }
 }
@@ -830,7 +871,11 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
     uint2 *__restrict__ pbuf, uint32_t *__restrict__ counts, uint32_t cap,
     u64 *__restrict__ gsum, unsigned long long *__restrict__ gcnt, int32_t *__restrict__ err, int period_knob, int vop_rt, int xf_rt,
     int hash_bits, int strict /* dense mode without a fallback: no heavy-hitter cache, a full slab or ring reports kErrOverflow
-                                (the statistics pass: the global table cannot take single rows) */)
+                                (the statistics pass: the global table cannot take single rows) */,
+    int64_t rot = 0 /* > 0: the 64 sixteen-lane groups of the workgroup read their 64 rows of 64 DIFFERENT batches, group g those of batch
+                       + g * rot (mod the full batches): for key columns whose neighbouring rows share a bucket but that are no case for the
+                       window path -- sorted files one behind the other -- a batch then reaches 64 buckets instead of one (see
+                       fgb_cluster_test_kernel).  Every row is still read exactly once: for a fixed group the map is a rotation of the batches. */)
 {
     constexpr bool HASH = MODE == 2, C6 = FMT == 1, K2 = FMT == 2, C8 = FMT == 3;
     const int vop = MODE == 0 ? (int)VOP_F32SUM : vop_rt;
@@ -1151,6 +1196,7 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
     auto load_full = [&](int64_t batch, float4 &pr, int4 &kr, float4 &vr) {
         typedef float f4v __attribute__((ext_vector_type(4)));
         typedef int i4v __attribute__((ext_vector_type(4)));
+        if (rot > 0) { batch += (int64_t)(tid >> 4) * rot; if (batch >= nfullb) batch -= nfullb; }     // (full batches only: see `rot`)
         const int64_t r = row0 + batch * kBatchRows + (int64_t)tid * kVec;
         if (OP == kMaskPred) {
             const uint32_t byte = reinterpret_cast<const uint8_t *>(p)[r >> 3];
@@ -1488,7 +1534,7 @@ template <int OP, int NV>
 __global__ __launch_bounds__(kPartThreads) void fgb_partv_kernel(
     const float *__restrict__ p, const int32_t *__restrict__ k, const uint32_t *__restrict__ v1, const uint32_t *__restrict__ v2, const uint32_t *__restrict__ v3,
     int64_t row0, int64_t row1, float thr, int64_t G, int shift, int P,
-    unsigned char *__restrict__ pbuf, uint32_t *__restrict__ counts, size_t slab_bytes, int32_t *__restrict__ err)
+    unsigned char *__restrict__ pbuf, uint32_t *__restrict__ counts, size_t slab_bytes, int32_t *__restrict__ err, int64_t rot /* as fgb_part_kernel's */)
 {
     constexpr int Q = MultiGeo<NV>::Q, kUnitBytes = MultiGeo<NV>::unit_bytes;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -1513,8 +1559,10 @@ __global__ __launch_bounds__(kPartThreads) void fgb_partv_kernel(
     __syncthreads();
 
     struct Rows { float4 p; int4 k; uint4 v[NV]; };
+    const int64_t nfullv = (row1 - row0) / kBatchRows;
     auto load_full = [&](int64_t batch, Rows &r) {                        // a batch of kBatchRows rows: unconditional vector loads
-        const int64_t rb = row0 + batch * kBatchRows;                      // workgroup-uniform
+        if (rot > 0) { batch += (int64_t)(tid >> 4) * rot; if (batch >= nfullv) batch -= nfullv; }
+        const int64_t rb = row0 + batch * kBatchRows;                      // workgroup-uniform (per sixteen lanes with rotated loads)
         const uint32_t lo = (uint32_t)tid * kVec;
         if (OP == kMaskPred) {
             const uint32_t byte = (reinterpret_cast<const uint8_t *>(p) + (rb >> 3))[lo >> 3];
@@ -2387,7 +2435,7 @@ int hark_fgb_plan_set(hark_fgb_plan *pl, const char *key, int64_t value)
     else if (!strcmp(key, "vop")) { if (value < 0 || value > 5) return HARK_EARG; pl->vop = value; return HARK_OK; }   // reset afterwards
     else if (!strcmp(key, "xform")) { if (value < 0 || value > 2) return HARK_EARG; pl->xform = value; return HARK_OK; }
     else if (!strcmp(key, "pairfmt")) { if (value < 0 || value > 3) return HARK_EARG; pl->pairfmt = value; }   // 0 auto, 1: 8-byte pairs, 2: compact 6-byte units, 3: 6-byte units from 8-byte ring entries (<= 128 buckets)
-    else if (!strcmp(key, "window")) { if (value < 0 || value > 2) return HARK_EARG; pl->window = value; return HARK_OK; }   // 0: by the test, 1: always the window path, 2: never
+    else if (!strcmp(key, "window")) { if (value < 0 || value > 3) return HARK_EARG; pl->window = value; return HARK_OK; }   // 0: by the test, 1: always the window path, 2: never (nor rotated loads), 3: always the partition with rotated loads
     else if (!strcmp(key, "period")) { if (value < 0 || value > 15) return HARK_EARG; pl->period = value; return HARK_OK; }   // batches between ring sweeps (0 = default); any value gives the same result
     else return HARK_EARG;
     plan_drop_partition(pl);     // partition geometry depends on the knobs
@@ -2473,18 +2521,31 @@ static int plan_prepare_partition(hark_context *ctx, hark_fgb_plan *pl)
 static int fgb_window_wanted(hark_context *ctx, hark_fgb_plan *pl, const int32_t *k, int64_t n, bool *window)
 {
     *window = false;
-    if (const char *e = getenv("HARK_FGB_WINDOW")) { *window = atoi(e) != 0; return HARK_OK; }
+    if (const char *e = getenv("HARK_FGB_WINDOW")) { *window = atoi(e) == 1; pl->win_k = k; pl->win_n = n; pl->win_verdict = atoi(e) == 2 ? 2 : *window ? 1 : 0; return HARK_OK; }   // (2: rotated loads)
     if (pl->window == 1) { *window = true; return HARK_OK; }
-    if (pl->window == 2 || n < ((int64_t)1 << 20)) return HARK_OK;
+    if (pl->window == 3) { pl->win_k = k; pl->win_n = n; pl->win_verdict = 2; return HARK_OK; }
+    if (pl->window == 2 || n < ((int64_t)1 << 20)) { if (pl->win_k == k && pl->win_verdict == 2 && pl->window == 2) pl->win_verdict = 0; return HARK_OK; }
     if (pl->win_k != k || pl->win_n != n || pl->win_verdict < 0) {
         unsigned long long *out = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(ctx->h_pin) + 65536 - 128);   // (the kernel writes pinned host memory)
         fgb_cluster_test_kernel<<<1, 1024, 0, ctx->stream>>>(k, n, out);
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        pl->win_k = k; pl->win_n = n; pl->win_verdict = reinterpret_cast<volatile unsigned long long *>(out)[0] != 0ull ? 1 : 0;
+        pl->win_k = k; pl->win_n = n; pl->win_verdict = (int)reinterpret_cast<volatile unsigned long long *>(out)[0];     // 0 scattered, 1 window, 2 rotated loads
     }
     *window = pl->win_verdict == 1;
     return HARK_OK;
+}
+
+// the producer's rotation stride for a chunk of `rows` rows (0: none): the verdict of fgb_cluster_test_kernel was "neighbouring rows share a
+// bucket"; group g of the 64 reads batch + g * rot -- an odd stride (block lengths that divide the table evenly would otherwise put
+// all 64 places at the same spot of their blocks), 63 * rot below the number of full batches
+static int64_t fgb_rot_of(hark_fgb_plan *pl, const void *k, int64_t rows)
+{
+    if (pl->win_k != k || pl->win_verdict != 2 || getenv("HARK_FGB_NO_ROTATE")) return 0;
+    const int64_t nfull = rows / kBatchRows;
+    if (nfull < 128) return 0;
+    pl->rot_rows += rows;
+    return (nfull / 64 - 1) | 1;
 }
 
 int k_fgb_dense_f32(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cmp, float thr,
@@ -2619,8 +2680,9 @@ int k_fgb_dense_f32(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cm
             {
                 TimedLaunch tl(pl, st, 1);
                 const int period = (int)pl->period;                            // batches between sweeps (0 = default)
+                const int64_t rot = fgb_rot_of(pl, k, r1 - r0);
 #define HARK_LAUNCH_PART(MODE, FMTV) fgb_part_kernel<OP, MODE, FMTV><<<dim3((unsigned)nwg), dim3(kPartThreads), lds_part, st>>>( \
-                    p, k, v, r0, r1, thr, G, shift, P, pl->pbuf, pl->counts, cap, gsum, gcnt, pl->err, period, vop, (int)pl->xform, 0, 0)
+                    p, k, v, r0, r1, thr, G, shift, P, pl->pbuf, pl->counts, cap, gsum, gcnt, pl->err, period, vop, (int)pl->xform, 0, 0, rot)
                 if (fmt == 2) HARK_LAUNCH_PART(0, 2);
                 else if (fmt == 3) { if (fast) HARK_LAUNCH_PART(0, 3); else HARK_LAUNCH_PART(1, 3); }
                 else if (fast) { if (c6) HARK_LAUNCH_PART(0, 1); else HARK_LAUNCH_PART(0, 0); }
@@ -2858,7 +2920,7 @@ int k_fgb_dense_stats(hark_context *ctx, hark_fgb_plan *pl, const float *p, int 
             {
                 TimedLaunch tl(pl, st, 1);
                 fgb_part_kernel<OP, 0, 1><<<dim3((unsigned)nwg), dim3(kPartThreads), lds_part, st>>>(
-                    p, k, static_cast<const float *>(v), r0, r1, thr, G, shift, P, pl->pbuf, pl->counts, (uint32_t)pl->cap, gsum, pl->acc_cnt, pl->err, 0, 0, 0, 0, 1);
+                    p, k, static_cast<const float *>(v), r0, r1, thr, G, shift, P, pl->pbuf, pl->counts, (uint32_t)pl->cap, gsum, pl->acc_cnt, pl->err, 0, 0, 0, 0, 1, fgb_rot_of(pl, k, r1 - r0));
             }
             HIP_TRY(ctx, hipGetLastError());
             TimedLaunch tl(pl, st, 2);
@@ -2941,7 +3003,7 @@ int k_fgb_dense_multi(hark_context *ctx, hark_fgb_plan *pl, const float *p, int 
             {
                 TimedLaunch tl(pl, st, 1);
                 fgb_partv_kernel<OP, NV><<<dim3((unsigned)nwg), dim3(kPartThreads), lds_part, st>>>(
-                    p, k, c1, c2, c3, r0, r1, thr, G, shift, P, pbuf, pl->counts, slab_bytes, pl->err);
+                    p, k, c1, c2, c3, r0, r1, thr, G, shift, P, pbuf, pl->counts, slab_bytes, pl->err, fgb_rot_of(pl, k, r1 - r0));
             }
             HIP_TRY(ctx, hipGetLastError());
             TimedLaunch tl(pl, st, 2);

@@ -559,7 +559,7 @@ int hark_entry_query_groupby(hark_context *ctx, hark_result **out, const hark_ta
     int64_t G = 0;
     bool dense = false;
     ctx->last_groupby_path = HARK_PATH_NONE;
-    ctx->last_groupby_window = false;
+    ctx->last_groupby_window = 0;
     int rc = ref_groupby_dense(ctx, &view, db, g_col, aggs, res, &G, &dense);   // keys < 2^21: fused kernels, no sort
     if (!rc && dense) ctx->last_groupby_path = HARK_PATH_DENSE;
     if (!rc && !dense) { rc = ref_groupby_hash(ctx, &view, db, g_col, aggs, res, &G, &dense); if (!rc && dense) ctx->last_groupby_path = HARK_PATH_HASH; }   // sparse keys: LDS hash buckets
@@ -875,7 +875,7 @@ int try_dense(hark_context *ctx, const hark_table *db, const PredList &preds,
     hark_free(ctx, flags); hark_free(ctx, pos);
     if (plan) {
         if (plan->win_k == keys && plan->win_verdict >= 0) src->cols[g2].key_clustered = (int8_t)plan->win_verdict;
-        ctx->last_groupby_window = plan->win_rows > 0;
+        ctx->last_groupby_window = plan->win_rows > 0 ? 1 : plan->rot_rows > 0 ? 2 : 0;
         hark_fgb_plan_free(ctx, plan);
     }
     hark_free(ctx, mask);
@@ -1293,7 +1293,7 @@ extern "C" int hark_entry_filter_groupby_and(hark_context *ctx, hark_result **ou
     bool done = false;
     ctx->last_groupby_path = HARK_PATH_NONE;
     ctx->last_groupby_passes = 0;
-    ctx->last_groupby_window = false;
+    ctx->last_groupby_window = 0;
     if (db->n > 0) rc = try_dense(ctx, db, preds, g_col, agg_cols, agg_ops, n_aggs, res, &done);
     if (!rc && done) ctx->last_groupby_path = HARK_PATH_DENSE; else ctx->last_groupby_passes = 0;
     if (!rc && !done && db->n > 0) { rc = try_hash(ctx, db, preds, g_col, agg_cols, agg_ops, n_aggs, res, &done); if (!rc && done) ctx->last_groupby_path = HARK_PATH_HASH; }
@@ -1576,7 +1576,7 @@ int ref_groupby_dense(hark_context *ctx, const hark_table *view, const hark_tabl
     for (auto v : vals) hark_free(ctx, v);
     hark_free(ctx, flags); hark_free(ctx, pos);
     if (own_column && plan->win_k == keys && plan->win_verdict >= 0) stats_owner->cols[g_col].key_clustered = (int8_t)plan->win_verdict;
-    ctx->last_groupby_window = plan->win_rows > 0;
+    ctx->last_groupby_window = plan->win_rows > 0 ? 1 : plan->rot_rows > 0 ? 2 : 0;
     hark_fgb_plan_free(ctx, plan);
     if (rc) { for (auto &c : res->cols) { if (c.owned && c.data) hark_free(ctx, c.data); } res->cols.clear(); return rc; }
     *G_out = ngroups;
@@ -1704,7 +1704,7 @@ __global__ __launch_bounds__(256) void composite_key_kernel(CompositeArgs a, int
 
 extern "C" int hark_context_last_groupby_path(const hark_context *ctx) { return ctx ? ctx->last_groupby_path : HARK_PATH_NONE; }
 extern "C" int hark_context_last_groupby_passes(const hark_context *ctx) { return ctx ? ctx->last_groupby_passes : 0; }
-extern "C" int hark_context_last_groupby_window(const hark_context *ctx) { return ctx && ctx->last_groupby_window ? 1 : 0; }
+extern "C" int hark_context_last_groupby_window(const hark_context *ctx) { return ctx ? ctx->last_groupby_window : 0; }
 extern "C" int hark_context_last_join_path(const hark_context *ctx) { return ctx ? ctx->last_join_path : HARK_PATH_NONE; }
 
 extern "C" int hark_table_invalidate_stats(hark_context *ctx, const hark_table *t, int32_t col)

@@ -335,7 +335,12 @@ class Engine:
 
     def last_groupby_window(self):
         """True when the last dense GROUP BY found its key column sorted / clustered by the key and took the window kernels."""
-        return bool(self.lib.hark_context_last_groupby_window(self.ctx))
+        return self.lib.hark_context_last_groupby_window(self.ctx) == 1
+
+    def last_groupby_rotated(self):
+        """True when the last dense GROUP BY found neighbouring rows in one bucket (sorted files one behind the other) and ran the
+        partition with rotated loads."""
+        return self.lib.hark_context_last_groupby_window(self.ctx) == 2
 
     def last_join_path(self):
         """'partitioned' | 'sort-merge' | None: the path that served the last join entry (diagnostic, include/hark.h)."""

@@ -18,6 +18,9 @@ def eng():
 def _keys(shape, n, G, rng):
     kk = rng.integers(0, G, size=n).astype(np.int32)
     if shape == "random": return kk
+    if shape == "blocks":                                              # sorted inside blocks of 2^16 rows, every block spans all keys (sorted files one behind the other)
+        for a in range(0, n, 1 << 16): kk[a:a + (1 << 16)] = np.sort(kk[a:a + (1 << 16)])
+        return kk
     if shape == "sorted": return np.sort(kk)
     if shape == "descending": return np.sort(kk)[::-1].copy()
     if shape.startswith("runs"):                                       # sorted, then runs of w rows shuffled as wholes (w need not divide a batch)
@@ -128,7 +131,7 @@ def test_key_out_of_range_is_bounds_error(eng):
         eng.free(ptr)
 
 
-@pytest.mark.parametrize("n,G,order", [(1_300_000, 1 << 17, "sorted"), (1_300_000, 1 << 17, "descending"), (2_100_000, 1 << 18, "runs8192"), (1_200_000, 1 << 17, "random")])
+@pytest.mark.parametrize("n,G,order", [(1_300_000, 1 << 17, "sorted"), (1_300_000, 1 << 17, "descending"), (2_100_000, 1 << 18, "runs8192"), (1_200_000, 1 << 17, "random"), (1_400_000, 1 << 17, "blocks")])
 def test_reference_query_groupby_on_a_table_kept_in_key_order(eng, oracle, n, G, order):
     """query_groupby (main.fut:9) with several aggregates of one and of three columns on a table SORTED by its key column: the
     statistics / pair / triple passes run through the window kernel (fgb_windowx_kernel) -- same table as the oracle's."""
@@ -142,11 +145,12 @@ def test_reference_query_groupby_on_a_table_kept_in_key_order(eng, oracle, n, G,
         exp = oracle.query_groupby(db, 0, s_cols, t_cols)
         assert got.shape == exp.shape and np.array_equal(got, exp), (s_cols, t_cols)
         assert eng.last_groupby_path() == "dense"
-        assert eng.last_groupby_window() == (order != "random"), (order, s_cols)
+        assert eng.last_groupby_window() == (order not in ("random", "blocks")), (order, s_cols)
+        assert eng.last_groupby_rotated() == (order == "blocks"), (order, s_cols)              # (blocks: the partition with rotated loads)
     t.free()
 
 
-@pytest.mark.parametrize("order", ["sorted", "descending", "random"])
+@pytest.mark.parametrize("order", ["sorted", "descending", "random", "blocks"])
 def test_filter_groupby_entry_typed_aggregates_on_a_table_kept_in_key_order(eng, order):
     """hark_entry_filter_groupby: SUM / MAX / MIN / AVG / COUNT of f32, i32 and u32 columns under a predicate, keys sorted: the
     one-column statistics pass, the pair / triple passes and the single passes all take the window kernels; against pandas."""
@@ -160,7 +164,7 @@ def test_filter_groupby_entry_typed_aggregates_on_a_table_kept_in_key_order(eng,
     t = eng.table_from_columns([df[c].to_numpy() for c in df.columns])
     aggs = [("sum", 2), ("max", 2), ("min", 2), ("avg", 2), ("count", 0), ("max", 3), ("min", 4), ("sum", 3), ("max", 5), ("avg", 3), ("sum", 4)]
     res = eng.filter_groupby(t, [(0, ">", 0.4)], 1, aggs)
-    assert eng.last_groupby_path() == "dense" and eng.last_groupby_window() == (order != "random")
+    assert eng.last_groupby_path() == "dense" and eng.last_groupby_window() == (order not in ("random", "blocks")) and eng.last_groupby_rotated() == (order == "blocks")
     cols = res.columns()
     res.free()
     g = df[df.p > 0.4].groupby("k").agg(sa=("a", "sum"), mxa=("a", "max"), mna=("a", "min"), ava=("a", "mean"), n=("a", "count"), mxi=("i", "max"), mnu=("u", "min"),
@@ -177,3 +181,20 @@ def test_filter_groupby_entry_typed_aggregates_on_a_table_kept_in_key_order(eng,
     g2 = df.groupby("k").size().reset_index()
     assert np.array_equal(c2[0].astype(np.int64), g2.k.to_numpy()) and np.array_equal(c2[1].astype(np.int64), g2[0].to_numpy())
     t.free()
+
+
+@pytest.mark.parametrize("shape", ["blocks", "sorted", "runs256", "random"])
+@pytest.mark.parametrize("n,G,knobs", [(3_000_017, 1 << 20, {}), (2_200_003, 300_000, {"pairfmt": 2}), (2_500_001, 1 << 20, {"chunk_rows": 1 << 20})])
+def test_partition_with_rotated_loads_forced_on_every_shape(eng, oracle, shape, n, G, knobs):
+    """window=3: the producer's 64 sixteen-lane groups read their rows of 64 different batches (`rot` of fgb_part_kernel: for key
+    columns whose neighbouring rows share a bucket -- sorted files one behind the other).  Every row is still read exactly once:
+    same bits as the oracle, with and without a predicate, COUNT only, in chunks."""
+    rng = np.random.default_rng(13)
+    if shape == "blocks":                                              # sorted inside blocks of 2^18 rows, every block spans all keys
+        kk = rng.integers(0, G, size=n).astype(np.int32)
+        for a in range(0, n, 1 << 18): kk[a:a + (1 << 18)] = np.sort(kk[a:a + (1 << 18)])
+    else:
+        kk = _keys(shape, n, G, rng)
+    _run(eng, oracle, kk, G, window=3, **knobs)
+    _run(eng, oracle, kk, G, use_pred=False, window=3, **knobs)
+    _run(eng, oracle, kk, G, count_only=True, window=3, **knobs)

@@ -23,6 +23,16 @@ ref = None
 
 
 def shape(name):
+    if name.startswith("rot"):                                     # rotNN:SHAPE -- SHAPE with its rows regrouped so that the NN pieces of every batch of 4096 rows come from places
+        parts, rest = int(name[3:name.index(":")]), name[name.index(":") + 1:]   # n / NN rows apart (what a producer whose waves read different batches would see)
+        shape(rest)
+        piece = 4096 // parts
+        nb = N // 4096
+        S = (nb // parts) | 1
+        idx = (torch.arange(nb, device=dev)[:, None] + torch.arange(parts, device=dev)[None, :] * S) % nb
+        kk = k[:nb * 4096].view(nb, parts, piece)
+        k[:nb * 4096] = kk[idx, torch.arange(parts, device=dev)[None, :]].reshape(-1)
+        return
     if name == "random": k.copy_(k0); return
     if name == "sorted": k.copy_(k0.sort().values); return
     if name == "descending": k.copy_(k0.sort(descending=True).values); return
