@@ -864,7 +864,7 @@ __device__ __noinline__ void fgb_direct_row(u64 *gsum, unsigned long long *gcnt,
     atomicAdd(&gcnt[key], 1ull);
 }
 
-template <int OP, int MODE, int FMT>
+template <int OP, int MODE, int FMT, bool ROT = false /* rotated loads compiled in: see `rot` (the plain instantiation keeps its batch numbers in scalar registers; a run-time test alone moved the addresses into vector registers: +1 % on the headline) */>
 __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
     const float *__restrict__ p, const int32_t *__restrict__ k, const float *__restrict__ v,
     int64_t row0, int64_t row1, float thr, int64_t G, int shift, int P,
@@ -1196,7 +1196,7 @@ __global__ __launch_bounds__(kPartThreads) void fgb_part_kernel(
     auto load_full = [&](int64_t batch, float4 &pr, int4 &kr, float4 &vr) {
         typedef float f4v __attribute__((ext_vector_type(4)));
         typedef int i4v __attribute__((ext_vector_type(4)));
-        if (rot > 0) { batch += (int64_t)(tid >> 4) * rot; if (batch >= nfullb) batch -= nfullb; }     // (full batches only: see `rot`)
+        if constexpr (ROT) { batch += (int64_t)(tid >> 4) * rot; if (batch >= nfullb) batch -= nfullb; }   // (full batches only: see `rot`)
         const int64_t r = row0 + batch * kBatchRows + (int64_t)tid * kVec;
         if (OP == kMaskPred) {
             const uint32_t byte = reinterpret_cast<const uint8_t *>(p)[r >> 3];
@@ -1530,7 +1530,7 @@ template <int NV> struct MultiGeo {
 static size_t partv_lds_bytes(int P, int nv) { return (size_t)(4 * nv + 2) * P * (nv == 2 ? MultiGeo<2>::Q : MultiGeo<3>::Q) + sizeof(uint32_t) * 2 * (size_t)P + 32 + 4 * kSeqRing; }
 static int multi_unit_bytes(int nv) { return kU10 * (4 * nv + 2); }
 
-template <int OP, int NV>
+template <int OP, int NV, bool ROT = false>
 __global__ __launch_bounds__(kPartThreads) void fgb_partv_kernel(
     const float *__restrict__ p, const int32_t *__restrict__ k, const uint32_t *__restrict__ v1, const uint32_t *__restrict__ v2, const uint32_t *__restrict__ v3,
     int64_t row0, int64_t row1, float thr, int64_t G, int shift, int P,
@@ -1561,7 +1561,7 @@ __global__ __launch_bounds__(kPartThreads) void fgb_partv_kernel(
     struct Rows { float4 p; int4 k; uint4 v[NV]; };
     const int64_t nfullv = (row1 - row0) / kBatchRows;
     auto load_full = [&](int64_t batch, Rows &r) {                        // a batch of kBatchRows rows: unconditional vector loads
-        if (rot > 0) { batch += (int64_t)(tid >> 4) * rot; if (batch >= nfullv) batch -= nfullv; }
+        if constexpr (ROT) { batch += (int64_t)(tid >> 4) * rot; if (batch >= nfullv) batch -= nfullv; }
         const int64_t rb = row0 + batch * kBatchRows;                      // workgroup-uniform (per sixteen lanes with rotated loads)
         const uint32_t lo = (uint32_t)tid * kVec;
         if (OP == kMaskPred) {
@@ -2681,8 +2681,13 @@ int k_fgb_dense_f32(hark_context *ctx, hark_fgb_plan *pl, const float *p, int cm
                 TimedLaunch tl(pl, st, 1);
                 const int period = (int)pl->period;                            // batches between sweeps (0 = default)
                 const int64_t rot = fgb_rot_of(pl, k, r1 - r0);
-#define HARK_LAUNCH_PART(MODE, FMTV) fgb_part_kernel<OP, MODE, FMTV><<<dim3((unsigned)nwg), dim3(kPartThreads), lds_part, st>>>( \
-                    p, k, v, r0, r1, thr, G, shift, P, pl->pbuf, pl->counts, cap, gsum, gcnt, pl->err, period, vop, (int)pl->xform, 0, 0, rot)
+#define HARK_LAUNCH_PART(MODE, FMTV) do { \
+                    if (rot > 0) { \
+                        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_part_kernel<OP, MODE, FMTV, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part)); \
+                        fgb_part_kernel<OP, MODE, FMTV, true><<<dim3((unsigned)nwg), dim3(kPartThreads), lds_part, st>>>( \
+                            p, k, v, r0, r1, thr, G, shift, P, pl->pbuf, pl->counts, cap, gsum, gcnt, pl->err, period, vop, (int)pl->xform, 0, 0, rot); \
+                    } else fgb_part_kernel<OP, MODE, FMTV><<<dim3((unsigned)nwg), dim3(kPartThreads), lds_part, st>>>( \
+                            p, k, v, r0, r1, thr, G, shift, P, pl->pbuf, pl->counts, cap, gsum, gcnt, pl->err, period, vop, (int)pl->xform, 0, 0, 0); } while (0)
                 if (fmt == 2) HARK_LAUNCH_PART(0, 2);
                 else if (fmt == 3) { if (fast) HARK_LAUNCH_PART(0, 3); else HARK_LAUNCH_PART(1, 3); }
                 else if (fast) { if (c6) HARK_LAUNCH_PART(0, 1); else HARK_LAUNCH_PART(0, 0); }
@@ -2919,8 +2924,14 @@ int k_fgb_dense_stats(hark_context *ctx, hark_fgb_plan *pl, const float *p, int 
             HIP_TRY(ctx, hipMemsetAsync(pl->err + 1, 0, 4, st));                 // the producers' batch counter
             {
                 TimedLaunch tl(pl, st, 1);
+                const int64_t rot = fgb_rot_of(pl, k, r1 - r0);
+                if (rot > 0) {
+                    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_part_kernel<OP, 0, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part));
+                    fgb_part_kernel<OP, 0, 1, true><<<dim3((unsigned)nwg), dim3(kPartThreads), lds_part, st>>>(
+                        p, k, static_cast<const float *>(v), r0, r1, thr, G, shift, P, pl->pbuf, pl->counts, (uint32_t)pl->cap, gsum, pl->acc_cnt, pl->err, 0, 0, 0, 0, 1, rot);
+                } else
                 fgb_part_kernel<OP, 0, 1><<<dim3((unsigned)nwg), dim3(kPartThreads), lds_part, st>>>(
-                    p, k, static_cast<const float *>(v), r0, r1, thr, G, shift, P, pl->pbuf, pl->counts, (uint32_t)pl->cap, gsum, pl->acc_cnt, pl->err, 0, 0, 0, 0, 1, fgb_rot_of(pl, k, r1 - r0));
+                    p, k, static_cast<const float *>(v), r0, r1, thr, G, shift, P, pl->pbuf, pl->counts, (uint32_t)pl->cap, gsum, pl->acc_cnt, pl->err, 0, 0, 0, 0, 1, 0);
             }
             HIP_TRY(ctx, hipGetLastError());
             TimedLaunch tl(pl, st, 2);
@@ -3002,8 +3013,13 @@ int k_fgb_dense_multi(hark_context *ctx, hark_fgb_plan *pl, const float *p, int 
             HIP_TRY(ctx, hipMemsetAsync(pl->err + 1, 0, 4, st));                 // the producers' batch counter
             {
                 TimedLaunch tl(pl, st, 1);
+                const int64_t rot = fgb_rot_of(pl, k, r1 - r0);
+                if (rot > 0) {
+                    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&fgb_partv_kernel<OP, NV, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part));
+                    fgb_partv_kernel<OP, NV, true><<<dim3((unsigned)nwg), dim3(kPartThreads), lds_part, st>>>(p, k, c1, c2, c3, r0, r1, thr, G, shift, P, pbuf, pl->counts, slab_bytes, pl->err, rot);
+                } else
                 fgb_partv_kernel<OP, NV><<<dim3((unsigned)nwg), dim3(kPartThreads), lds_part, st>>>(
-                    p, k, c1, c2, c3, r0, r1, thr, G, shift, P, pbuf, pl->counts, slab_bytes, pl->err, fgb_rot_of(pl, k, r1 - r0));
+                    p, k, c1, c2, c3, r0, r1, thr, G, shift, P, pbuf, pl->counts, slab_bytes, pl->err, 0);
             }
             HIP_TRY(ctx, hipGetLastError());
             TimedLaunch tl(pl, st, 2);
