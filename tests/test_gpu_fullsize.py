@@ -346,3 +346,89 @@ def test_c5_full_pipeline_share(eng):
     fc.drop_table("t")
     for ptr in cols + [key]:
         eng.free(ptr)
+
+
+def test_c3_one_billion_rows_sorted_by_the_key_three_paths_agree(eng):
+    """configs[2] + filter on the 1e9-row table SORTED by k (a table kept in key order): the window path (what the test kernel picks),
+    the plain partition (window = 2) and the partition with rotated loads (window = 3) give the same sums and counts per group, bit
+    for bit (integer-valued f32 values), with the predicate, with its complement and without one; linearity holds on the window path."""
+    from harkdb_amd.engine import FgbPlan
+    n, G = 1_000_000_000, 1 << 20
+    p, k, v = eng.alloc(n * 4), eng.alloc(n * 4), eng.alloc(n * 4)
+    eng.gen_columns(SEED, 0, n, G, True, p, k, v)
+    tk = eng.table_from_device(n, [k], [np.int32])
+    srt = eng.sort(tk, 0, [0])                                          # the key column in ascending order (p and v keep their rows)
+    ks = srt.device_ptr(0)
+    s, c = eng.alloc(G * 4), eng.alloc(G * 8)
+    got = {}
+    for path, knobs in (("window", {}), ("partition", {"window": 2}), ("rotated", {"window": 3})):
+        plan = FgbPlan(eng, n, G, timing=1, **knobs)
+        for name, pred, cmp in (("gt", p, ">"), ("le", p, "<="), ("all", None, ">")):
+            if path != "window" and name == "le": continue
+            plan.reset()
+            plan.run(pred, cmp, 0.5, ks, v, n)
+            plan.finish(s, c)
+            got[path, name] = (eng.download(s, G, np.float32), eng.download(c, G, np.int64))
+        _, launches = plan.timing()
+        assert (launches["consumer"] == 0) == (path == "window"), (path, launches)     # the window path has no consumer pass
+        plan.free()
+    for name in ("gt", "all"):
+        for path in ("partition", "rotated"):
+            assert np.array_equal(got["window", name][1], got[path, name][1]) and np.array_equal(got["window", name][0], got[path, name][0]), (path, name)
+    assert np.array_equal(got["window", "gt"][1] + got["window", "le"][1], got["window", "all"][1])
+    assert np.array_equal(got["window", "gt"][0].astype(np.float64) + got["window", "le"][0].astype(np.float64), got["window", "all"][0].astype(np.float64))
+    assert got["window", "all"][1].sum() == n
+    srt.free(); tk.free()
+    for ptr in (p, k, v, s, c):
+        eng.free(ptr)
+
+
+@pytest.mark.parametrize("order", ["sorted", "descending", "runs"])
+def test_join_one_hundred_million_probe_rows_in_key_order(eng, order):
+    """1e8 probe rows x 1e7 build rows (u32 keys, duplicates on the build side), the PROBE column sorted by the key, descending, or in
+    sorted runs of 4096 rows in shuffled order: the search path (k_cjoin.hip) -- pair count, key equality, the reference's order (key,
+    left row, right row) and every matching probe row with all its partners, checked on the device; the same rows as the partitioned
+    path gives for the shuffled column."""
+    import torch
+    from harkdb_amd.dist import tensor_from_ptr
+    dev = torch.device("cuda", 0)
+    n, s = 100_000_000, 10_000_000
+    g = torch.Generator(device=dev)
+    g.manual_seed(29)
+    bk = torch.randint(0, 1 << 27, (s,), dtype=torch.int32, device=dev, generator=g)        # ~7 % of the build keys occur twice or more
+    pk = torch.randint(0, 1 << 28, (n,), dtype=torch.int32, device=dev, generator=g)        # half of the probe keys lie outside the build side's range
+    pk = pk.sort(descending=(order == "descending")).values
+    if order == "runs":
+        pk = pk[: n // 4096 * 4096].view(-1, 4096)[torch.randperm(n // 4096, device=dev, generator=g)].reshape(-1).contiguous()
+        n = pk.numel()
+    shuffled = pk[torch.randperm(n, device=dev, generator=g)].contiguous()                  # the same column, its rows shuffled
+    prow, brow = torch.arange(n, dtype=torch.int32, device=dev), torch.arange(s, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    tb = eng.table_from_device(s, [bk.data_ptr(), brow.data_ptr()], [np.uint32, np.int32], keepalive=(bk, brow))
+    tp = eng.table_from_device(n, [pk.data_ptr(), prow.data_ptr()], [np.uint32, np.int32], keepalive=(pk, prow))
+    res = eng.join(tp, tb, 0, 0, [0, 1], [1])
+    assert eng.last_join_path().startswith("clustered"), eng.last_join_path()
+    P = res.shape[0]
+    lk, lr, rr = (tensor_from_ptr(res.device_ptr(c), P, dt, dev) for c, dt in ((0, np.int32), (1, np.int32), (2, np.int32)))
+    assert bool((pk[lr.long()] == lk).all()) and bool((bk[rr.long()] == lk).all())           # the row ids point at the pair's key
+    same = lk[1:] == lk[:-1]
+    assert bool((lk[1:] >= lk[:-1]).all())                                                   # keys ascend (all below 2^31: signed = unsigned)
+    assert bool((lr[1:][same] >= lr[:-1][same]).all())                                       # ... then left rows
+    same2 = same & (lr[1:] == lr[:-1])
+    assert bool((rr[1:][same2] > rr[:-1][same2]).all())                                      # ... then right rows
+    # every probe row with all its partners: pairs per probe row = occurrences of its key on the build side
+    occ = torch.zeros(1 << 27, dtype=torch.int32, device=dev)
+    occ.index_add_(0, bk.long(), torch.ones(s, dtype=torch.int32, device=dev))
+    want = torch.where(pk < (1 << 27), occ[pk.clamp(max=(1 << 27) - 1).long()], torch.zeros((), dtype=torch.int32, device=dev))
+    have = torch.zeros(n, dtype=torch.int32, device=dev)
+    have.index_add_(0, lr.long(), torch.ones(P, dtype=torch.int32, device=dev))
+    assert P == int(want.sum().item()) and bool((have == want).all())
+    checksum = int((lk.long() * 31 + rr.long()).sum().item())
+    res.free(); tp.free()
+    # the shuffled column through the partitioned path: the same multiset of (key, right row) pairs
+    ts = eng.table_from_device(n, [shuffled.data_ptr(), prow.data_ptr()], [np.uint32, np.int32], keepalive=(shuffled, prow))
+    res2 = eng.join(ts, tb, 0, 0, [0, 1], [1])
+    assert eng.last_join_path().startswith("partitioned") and res2.shape[0] == P
+    k2, r2 = tensor_from_ptr(res2.device_ptr(0), P, np.int32, dev), tensor_from_ptr(res2.device_ptr(2), P, np.int32, dev)
+    assert int((k2.long() * 31 + r2.long()).sum().item()) == checksum
+    res2.free(); ts.free(); tb.free()
