@@ -31,13 +31,14 @@ def ms_of(fn, reps=3):
 for order in ("shuffled", "sorted"):
     k = kd if order == "shuffled" else kd.sort().values
     ks = (k.to(torch.int64) * bench.SPARSE_MUL).to(torch.int32)            # sparse keys in the SAME row order (ascending dense key: not ascending as i32, but clustered)
-    ksort = ks if order == "shuffled" else ks.sort().values                 # ... and sorted as i32
+    ksort = ks if order == "shuffled" else ks.sort().values                 # ... and sorted as i32 (the typed entry's order)
+    kusort = ks if order == "shuffled" else (ks ^ -(2**31)).sort().values ^ -(2**31)   # ... and as u32 (the reference entry's order)
     kl = k64 if order == "shuffled" else k64.sort().values
     torch.cuda.synchronize()                                               # (torch fills the columns on ITS stream)
     td = eng.table_from_device(N, [p.data_ptr(), k.data_ptr(), v.data_ptr(), a.data_ptr()], [np.float32, np.int32, np.float32, np.int32], keepalive=(p, k, v, a))
     ts = eng.table_from_device(N, [p.data_ptr(), ksort.data_ptr(), v.data_ptr()], [np.float32, np.int32, np.float32], keepalive=(p, ksort, v))
     tu = eng.table_from_device(N, [k.data_ptr(), a.data_ptr()], [np.uint32, np.uint32], keepalive=(k, a))
-    th = eng.table_from_device(N, [ksort.data_ptr(), a.data_ptr()], [np.uint32, np.uint32], keepalive=(ksort, a))
+    th = eng.table_from_device(N, [kusort.data_ptr(), a.data_ptr()], [np.uint32, np.uint32], keepalive=(kusort, a))
     t64 = eng.table_from_device(N, [kl.data_ptr(), a.data_ptr()], [np.int64, np.int32], keepalive=(kl, a))
     W = [0.5]
     forms = [
