@@ -49,6 +49,8 @@ struct hark_context {
     int last_groupby_window = 0;             // ... the last dense GROUP BY: 1 took the window path (a key column sorted / clustered by the key), 2 the partition with rotated loads (hark_context_last_groupby_window)
     int last_join_path = 0;        // hark_context_last_join_path
     bool last_join_weighted = false;   // ... the partitioned path cut its buckets by the sampled probe rows' weight (k_hjoin.hip)
+    bool last_join_overflow = false;   // ... the partitioned path gave up on a full slab (the caller falls back)
+    bool join_rotate = false, last_join_rotated = false;   // ... the clustering test's third verdict for the join being run / the partition read with rotated loads
     bool last_join_clustered = false;  // ... the probe column was clustered by key: searched in row order (k_cjoin.hip)
 };
 
@@ -114,7 +116,7 @@ int k_join_hot_prepare(hark_context *ctx, const void *lcol, bool k64, int64_t n,
 void k_join_hot_release(hark_context *ctx);
 // k_cjoin.hip: the join of a probe column sorted / clustered by the key (same outputs as k_hjoin.hip's run_partitioned)
 int k_cjoin_test(hark_context *ctx, hipStream_t st, const void *lcol, bool k64, int64_t n, const void *build, int64_t s, bool sorted_build);
-bool k_cjoin_verdict(hark_context *ctx);
+int k_cjoin_verdict(hark_context *ctx);
 int k_cjoin_run(hark_context *ctx, const void *lcol, bool k64, int64_t n, const void *rkeys, int64_t s, const uint32_t *runlen, const int32_t *flags,
                 const uint32_t *lval, const uint32_t *rranked, uint32_t **rank_out, uint32_t **lrow_out, uint32_t **cnt_out, uint32_t **lval_out,
                 uint32_t **rval_out, int64_t *m_out, bool *used, bool *dup_out, bool rows_needed, int64_t *general_out);

@@ -30,14 +30,15 @@ template <typename K> struct CIdx { static constexpr int N = 32768 / (int)sizeof
 //   * rows kCtFar places apart (half a batch of the partition) within kCtNear / 1024 of the build side -- a batch then spans at
 //     most ~4 of the partition's 512 buckets (measured, 1e8 rows sorted block by block, tools/join_cluster_probe.py: blocks of
 //     1e5 rows 3.4 ms partitioned / 10.3 searched, of 1e6 rows 27 / 2.8);
-//   * or rows kCtClose places apart (four lanes of the search) within kCtKeys build keys, the cell's width read off the
+//   * or rows kCtClose places apart (four lanes of the search) within kCtKeys build keys (256 until the partition learnt to read with
+//     rotated loads: blocks of 1e6 sorted rows, 160 keys from row to sixteenth row, are faster that way), the cell's width read off the
 //     neighbouring quantiles -- a wave's rows then share a few lines of the build side (sorted runs of 256 rows in shuffled
 //     order: 1.7 ms searched, while the partition overruns its slabs and the probe side gets sorted: 7.9; runs of 16 rows:
 //     2.0 searched, 1.3 partitioned -- rows 16 apart lie in different runs there, and the verdict is "scattered").
 // Both against the same measure for rows ANYWHERE apart (the key of another pair): a column of few distinct keys, or one that
 // mostly misses the build side's range, is close to itself everywhere.  One pair per thread: the kernel waits for ~3000
 // address translations of rows all over the columns, not for its arithmetic (4096 pairs: 75 us).
-constexpr int kCtSample = 1024, kCtPairs = 1024, kCtFar = 2048, kCtClose = 16, kCtNear = 4, kCtKeys = 256;
+constexpr int kCtSample = 1024, kCtPairs = 1024, kCtFar = 2048, kCtClose = 16, kCtNear = 4, kCtKeys = 32;
 
 __device__ __forceinline__ uint32_t cj_mix(uint32_t x)
 {
@@ -63,9 +64,9 @@ __global__ __launch_bounds__(1024) void cj_test_kernel(const K *__restrict__ key
                                                        unsigned long long *verdict)
 {
     __shared__ K s_k[kCtSample], s_a[kCtPairs];
-    __shared__ uint32_t s_cnt[4];
+    __shared__ uint32_t s_cnt[6];
     const int tid = threadIdx.x;
-    if (tid < 4) s_cnt[tid] = 0u;
+    if (tid < 6) s_cnt[tid] = 0u;
     K x = sorted_build ? build[(int64_t)(((uint64_t)tid * (uint64_t)s) / kCtSample)] : build[(int64_t)(((uint64_t)cj_mix(2u * (uint32_t)tid + 1u) * (uint64_t)s) >> 32)];
     const int64_t r = (int64_t)(((uint64_t)cj_mix(0x9E3779B9u + (uint32_t)tid) * (uint64_t)(n - kCtFar)) >> 32);   // n >= 2^18 (the caller's threshold)
     const K ka = keys[r] ^ bias, kb = keys[r + kCtFar] ^ bias, kc = keys[r + kCtClose] ^ bias;   // in flight while the sample is sorted
@@ -94,13 +95,25 @@ __global__ __launch_bounds__(1024) void cj_test_kernel(const K *__restrict__ key
     const double reach = (double)(s_k[hi] - s_k[lo]) / (double)(hi - lo) * cells;
     const K dc = ka > kc ? ka - kc : kc - ka, df = ka > kf ? ka - kf : kf - ka;
     const uint32_t near = abs(qa - qb) <= kCtNear, far = abs(qa - qf) <= kCtNear, fine = (double)dc <= reach, ffar = (double)df <= reach;
-    const unsigned long long m0 = __ballot(near), m1 = __ballot(far), m2 = __ballot(fine), m3 = __ballot(ffar);
-    if ((tid & 63) == 0) { atomicAdd(&s_cnt[0], __popcll(m0)); atomicAdd(&s_cnt[1], __popcll(m1)); atomicAdd(&s_cnt[2], __popcll(m2)); atomicAdd(&s_cnt[3], __popcll(m3)); }
+    // ... and within a quarter of a bucket of the partition (512 buckets: half a cell): neighbouring rows share a bucket
+    const double breach = (double)(s_k[hi] - s_k[lo]) / (double)(hi - lo) * 0.5;
+    const uint32_t bnear = (double)dc <= breach, bfar = (double)df <= breach;
+    const unsigned long long m0 = __ballot(near), m1 = __ballot(far), m2 = __ballot(fine), m3 = __ballot(ffar), m4 = __ballot(bnear), m5 = __ballot(bfar);
+    if ((tid & 63) == 0) {
+        atomicAdd(&s_cnt[0], __popcll(m0)); atomicAdd(&s_cnt[1], __popcll(m1)); atomicAdd(&s_cnt[2], __popcll(m2)); atomicAdd(&s_cnt[3], __popcll(m3));
+        atomicAdd(&s_cnt[4], __popcll(m4)); atomicAdd(&s_cnt[5], __popcll(m5));
+    }
     __syncthreads();
     if (tid == 0) {
-        const uint32_t a = s_cnt[0], b = s_cnt[1], c = s_cnt[2], d = s_cnt[3];
-        verdict[1] = a; verdict[2] = b; verdict[3] = c; verdict[4] = d;
-        verdict[0] = ((a > b && (a - b) * 8u > (uint32_t)kCtPairs) || (c > d && (c - d) * 8u > (uint32_t)kCtPairs)) ? 1ull : 0ull;
+        const uint32_t a = s_cnt[0], b = s_cnt[1], c = s_cnt[2], d = s_cnt[3], e = s_cnt[4], f = s_cnt[5];
+        verdict[1] = a; verdict[2] = b; verdict[3] = c; verdict[4] = d; verdict[5] = e; verdict[6] = f;
+        // 1: the search path; else 2 when three of four neighbouring pairs share a bucket (and not because everything does): the
+        // partition with rotated loads (a probe column sorted block by block: blocks of 2e5 ... 5e5 rows took 4.7-6.9 ms against 0.9)
+        // measured (1e8 x 1e7, tools/join_cluster_probe.py with HARK_JOIN_CLUSTERED=1 / 2): sorted 0.88 ms searched / 1.53 rotated, sorted runs
+        // of 256 rows 0.98 / 4.2 (the rotated partition overruns its slabs there), blocks of 1e6 rows 2.57 / 1.70, of 3e5 rows 6.80 / 1.65
+        const bool strong = a > b && (a - b) * 8u > (uint32_t)kCtPairs, fine_ = c > d && (c - d) * 8u > (uint32_t)kCtPairs;
+        const bool shared = e >= 3u * (uint32_t)kCtPairs / 4u && f < (uint32_t)kCtPairs / 4u;
+        verdict[0] = fine_ ? 1ull : shared ? 2ull : strong ? 1ull : 0ull;
         __threadfence_system();                                           // (`verdict` may be host memory)
     }
 }
@@ -454,10 +467,10 @@ int k_cjoin_test(hark_context *ctx, hipStream_t st, const void *lcol, bool k64, 
     return rc;
 }
 
-bool k_cjoin_verdict(hark_context *ctx)
+int k_cjoin_verdict(hark_context *ctx)                                    // 0: rows scatter, 1: clustered (the search path), 2: neighbouring rows share a bucket (rotated loads)
 {
     const volatile unsigned long long *v = cj_verdict_words(ctx);
-    return v[0] != 0ull;
+    return (int)v[0];
 }
 
 int k_cjoin_run(hark_context *ctx, const void *lcol, bool k64, int64_t n, const void *rkeys, int64_t s, const uint32_t *runlen, const int32_t *flags,

@@ -597,14 +597,18 @@ __global__ __launch_bounds__(256) void jhot_place_kernel(const JHotHead *__restr
 // whose waits the compiler places (HARK_JOIN_PLAIN_LOADS=1: the cross-check of tests/test_gpu_hjoin.py -- the hand-placed
 // waits depend on the compiler never touching a destination register between a load and its wait, which nothing checks at
 // build time, so the tests run every join shape through both kernels).
-template <typename K, bool HIDDEN>
+template <typename K, bool HIDDEN, bool ROT = false /* rotated loads compiled in: see `rot` */>
 __global__ __launch_bounds__(kJThreads) void jpart_kernel(const K *__restrict__ keys, int64_t n, K bias, const K *__restrict__ splitters,
                                                           const K *__restrict__ rkeys, int64_t s,
                                                           typename JTraits<K>::E *__restrict__ slabs, uint32_t *__restrict__ counts, uint32_t cap,
                                                           int period, int32_t *__restrict__ err,
                                                           const uint32_t *__restrict__ lval /* 16-byte entries only, may be null: a probe-side column that
                                                                                                travels in the entries' fourth word */,
-                                                          const JHotSet<K> *__restrict__ hot, uint32_t *__restrict__ btotal /* [batches] rows of hot keys with partners */)
+                                                          const JHotSet<K> *__restrict__ hot, uint32_t *__restrict__ btotal /* [batches] rows of hot keys with partners */,
+                                                          int64_t rot = 0 /* ROT: the 64 sixteen-lane groups of the workgroup read their rows of 64 DIFFERENT batches, group g those
+                                                                             of batch + g * rot (mod the full batches) -- a probe column sorted block by block (sorted files one
+                                                                             behind the other) then reaches 64 buckets per batch instead of one or two; for a fixed group the
+                                                                             map is a rotation of the batches: every row is read once (as fgb_part_kernel's, k_fgb.hip) */)
 {
     typedef typename JTraits<K>::E E;
     constexpr int P = JTraits<K>::P, Q = JTraits<K>::Q, VEC = JTraits<K>::VEC;
@@ -652,8 +656,13 @@ __global__ __launch_bounds__(kJThreads) void jpart_kernel(const K *__restrict__ 
     // the last n % VEC rows go through a batch of their own at the end); the sweep's stores are hidden too.
     const bool has_val = sizeof(E) == 16 && lval != nullptr;
     const uint32_t *vsrc = has_val ? lval : reinterpret_cast<const uint32_t *>(keys);     // (any readable address: the words are not used)
+    const int64_t nfullb = n / BATCH;                                         // (the ragged last batch stays where it is)
+    auto place = [&](int64_t batch) -> int64_t {                              // the batch whose rows this lane reads when the workgroup works on `batch`
+        if constexpr (ROT) { if (batch < nfullb) { batch += (int64_t)(tid >> 4) * rot; if (batch >= nfullb) batch -= nfullb; } }
+        return batch;
+    };
     auto load = [&](int64_t batch, hark_u4v &kq, hark_u2v &vq) {
-        int64_t r = batch * BATCH + (int64_t)tid * VEC;
+        int64_t r = place(batch) * BATCH + (int64_t)tid * VEC;
         if (r + VEC > n) r = 0;
         if (HIDDEN) {
             ld_hidden_nt_b128(kq, keys + r);                         // VEC * sizeof(K) = 16 bytes
@@ -710,8 +719,13 @@ __global__ __launch_bounds__(kJThreads) void jpart_kernel(const K *__restrict__ 
             bk[j] = pos < (uint32_t)P ? pos : (uint32_t)(P - 1);
         }
         if (HOT) {
-            for (int d = 32; d > 0; d >>= 1) hot_rows += __shfl_down(hot_rows, d, 64);
-            if ((tid & 63) == 0 && hot_rows) atomicAdd(&btotal[r / BATCH], hot_rows);      // (the rows of a wave lie in one batch)
+            if constexpr (ROT) {                                       // (the rows of sixteen lanes lie in one batch)
+                for (int d = 8; d > 0; d >>= 1) hot_rows += __shfl_down(hot_rows, d, 16);
+                if ((tid & 15) == 0 && hot_rows) atomicAdd(&btotal[r / BATCH], hot_rows);
+            } else {
+                for (int d = 32; d > 0; d >>= 1) hot_rows += __shfl_down(hot_rows, d, 64);
+                if ((tid & 63) == 0 && hot_rows) atomicAdd(&btotal[r / BATCH], hot_rows);  // (the rows of a wave lie in one batch)
+            }
         }
         bool again;
         do {
@@ -766,7 +780,7 @@ __global__ __launch_bounds__(kJThreads) void jpart_kernel(const K *__restrict__ 
     K kk_[VEC];
     uint32_t vv_[VEC];
     const int64_t nfull = n / VEC * VEC;                              // rows that full lanes cover
-    auto rows_of = [&](int64_t batch, int64_t &r) -> int { r = batch * BATCH + (int64_t)tid * VEC; return r + VEC <= nfull ? VEC : 0; };
+    auto rows_of = [&](int64_t batch, int64_t &r) -> int { r = place(batch) * BATCH + (int64_t)tid * VEC; return r + VEC <= nfull ? VEC : 0; };
     load(wg, qA, wA); load((int64_t)wg + nwg, qB, wB); load((int64_t)wg + 2 * (int64_t)nwg, qC, wC);
     const bool has_tail = wg == 0 && nfull < n;                        // the last n % VEC rows: a batch of their own (workgroup 0)
     for (int64_t batch = wg;;) {
@@ -1695,6 +1709,16 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
     if (const char *e = getenv("HARK_JOIN_STAGE")) { const int c = atoi(e); if (c >= 1 && c < stage_cap) stage_cap = c; }   // tests: many sub-rounds per bucket
     if (he == hipSuccess) {
         // one stream-ordered chain, one host read at the end: partition -> bucket probe -> survivor total
+        // a probe column whose neighbouring rows share a bucket (the clustering test's third verdict): rotated loads
+        const int64_t nfullb = n / ((int64_t)kJThreads * VEC), rot = ctx->join_rotate && nfullb >= 128 && !getenv("HARK_JOIN_NO_ROTATE") ? ((nfullb / 64 - 1) | 1) : 0;
+        ctx->last_join_rotated = rot > 0;
+        if (rot > 0 && !plain_loads) {
+            he = hipFuncSetAttribute(reinterpret_cast<const void *>(&jpart_kernel<K, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part);
+            if (he == hipSuccess) HARK_LAUNCH_RC(ctx, rc, jpart_kernel<K, true, true><<<dim3((unsigned)nwg), dim3(kJThreads), lds_part, st>>>(lcol, n, bias, splitters, rkeys, s, slabs, counts, cap, period, err, carry ? lval : nullptr, hot, btotal, rot));
+        } else if (rot > 0) {
+            he = hipFuncSetAttribute(reinterpret_cast<const void *>(&jpart_kernel<K, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part);
+            if (he == hipSuccess) HARK_LAUNCH_RC(ctx, rc, jpart_kernel<K, false, true><<<dim3((unsigned)nwg), dim3(kJThreads), lds_part, st>>>(lcol, n, bias, splitters, rkeys, s, slabs, counts, cap, period, err, carry ? lval : nullptr, hot, btotal, rot));
+        } else
         if (plain_loads) HARK_LAUNCH_RC(ctx, rc, jpart_kernel<K, false><<<dim3((unsigned)nwg), dim3(kJThreads), lds_part, st>>>(lcol, n, bias, splitters, rkeys, s, slabs, counts, cap, period, err, carry ? lval : nullptr, hot, btotal));
         else HARK_LAUNCH_RC(ctx, rc, jpart_kernel<K, true><<<dim3((unsigned)nwg), dim3(kJThreads), lds_part, st>>>(lcol, n, bias, splitters, rkeys, s, slabs, counts, cap, period, err, carry ? lval : nullptr, hot, btotal));
         HARK_LAUNCH_RC(ctx, rc, jbucket_kernel<K><<<dim3((unsigned)P), dim3(kJThreads), lds_bucket, st>>>(slabs, counts, cap, nwg, rkeys, bstart, chunk_cap, surv, region, scount, sbins, srec, scoarse, stage_cap, err, allow_trunc ? 1 : 0));
@@ -1707,7 +1731,7 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
     ctx->last_join_weighted = words[4] != 0;
     const int64_t mhot = words[3];                                              // matching rows of the hot keys: blocks between the others' rows
     M = words[0] + mhot;
-    if (!rc && (int32_t)(words[1] & 0xFFFFFFFFll) != 0) { cleanup(); return HARK_OK; }          // a slab or a survivor bin overflowed (skew): caller falls back
+    if (!rc && (int32_t)(words[1] & 0xFFFFFFFFll) != 0) { cleanup(); ctx->last_join_overflow = true; return HARK_OK; }   // a slab or a survivor bin overflowed (skew): caller falls back
     const bool dup = ((words[2] >> 32) & 0xFFFFFFFFll) != 0;
     *dup_out = dup;
     *general_out = 0;
@@ -1870,22 +1894,33 @@ int k_join_partitioned(hark_context *ctx, const void *lcol, bool k64, int64_t n,
     // A probe column sorted or clustered by the key would send every batch of the partition into one ring (k_cjoin.hip): it is
     // searched in row order instead.  The test ran behind the early sample on the second stream (long done: the build side
     // has been sorted since), or runs here.
-    bool clustered = false;
-    if (const char *e = getenv("HARK_JOIN_CLUSTERED")) clustered = atoi(e) != 0;                 // tests, A/B: either way
+    int verdict = 0;                                           // 1: the search path, 2: the partition with rotated loads (k_cjoin.hip, cj_test_kernel)
+    if (const char *e = getenv("HARK_JOIN_CLUSTERED")) verdict = atoi(e);                        // tests, A/B: 0 / 1 / 2 whatever the rows look like
     else if (ctx->join_prep && ctx->join_prep_tested && ctx->join_prep_col == lcol && ctx->join_prep_n == n) {
         if (hipEventSynchronize(ctx->aux_event) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: waiting for the clustering test failed");
-        else clustered = k_cjoin_verdict(ctx);
+        else verdict = k_cjoin_verdict(ctx);
     } else {
         rc = k_cjoin_test(ctx, ctx->stream, lcol, k64, n, rkeys, s, true);
         if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = hark_fail(ctx, HARK_EHIP, "join: the clustering test failed");
-        if (!rc) clustered = k_cjoin_verdict(ctx);
+        if (!rc) verdict = k_cjoin_verdict(ctx);
     }
     if (rc) { hark_free(ctx, flag); hark_free(ctx, runlen); return rc; }
+    const bool clustered = verdict == 1;
+    ctx->join_rotate = verdict == 2;
+    ctx->last_join_rotated = false;
+    ctx->last_join_overflow = false;
     ctx->last_join_clustered = clustered;
     if (clustered) rc = k_cjoin_run(ctx, lcol, k64, n, rkeys, s, runlen, flag, k64 ? lval : nullptr, rranked, &rank, &lrow, &cnt, &lv, &rv, &M, used, &dup, rows_needed, &general);
     else
         rc = k64 ? run_partitioned<uint64_t>(ctx, static_cast<const uint64_t *>(lcol), 0x8000000000000000ull, n, static_cast<const uint64_t *>(rkeys), s, runlen, flag, lval, rranked, &rank, &lrow, &cnt, &lv, &rv, &M, used, &dup, rows_needed, &general)
                  : run_partitioned<uint32_t>(ctx, static_cast<const uint32_t *>(lcol), 0u, n, static_cast<const uint32_t *>(rkeys), s, runlen, flag, nullptr, rranked, &rank, &lrow, &cnt, &lv, &rv, &M, used, &dup, rows_needed, &general);
+    // rotated loads on a column of narrow sorted runs overrun the slabs (a group's 64 rows land in ONE bucket, and the groups fall on the
+    // buckets by chance): the search path is the better way out than sorting the probe side (2.6 against 4.2 ms per 1e8 rows)
+    if (!rc && !*used && verdict == 2 && ctx->last_join_overflow) {
+        ctx->last_join_clustered = true; ctx->last_join_rotated = false; ctx->last_join_weighted = false;
+        HIP_TRY_RC(ctx, rc, hipMemsetAsync(flag, 0, 4, ctx->stream));
+        if (!rc) rc = k_cjoin_run(ctx, lcol, k64, n, rkeys, s, runlen, flag, k64 ? lval : nullptr, rranked, &rank, &lrow, &cnt, &lv, &rv, &M, used, &dup, rows_needed, &general);
+    }
     if (rc || !*used) { hark_free(ctx, flag); hark_free(ctx, runlen); return rc; }
     if (M == 0) { hark_free(ctx, rank); hark_free(ctx, lrow); hark_free(ctx, cnt); hark_free(ctx, lv); hark_free(ctx, rv); hark_free(ctx, flag); hark_free(ctx, runlen); return HARK_OK; }
     // (rank, left row) order.  Fast path: jorder_kernel delivered it.  A rank with more than kTieMax probe rows, or a

@@ -266,6 +266,7 @@ int hark_entry_join(hark_context *ctx, hark_result **out, const hark_table *db1,
     ctx->last_join_path = HARK_PATH_NONE;
     ctx->last_join_weighted = false;
     ctx->last_join_clustered = false;
+    ctx->last_join_rotated = false;
     if (l < 0 || k < 0 || (l && !cols1) || (k && !cols2)) return hark_fail(ctx, HARK_EARG, "join: bad column lists");
     const int64_t n = db1->n, s = db2->n;
     // db1[:, col1] / db2[:, col2] (join.fut:55-56) are checked even for empty outputs when the side has rows
@@ -338,7 +339,7 @@ int hark_entry_join(hark_context *ctx, hark_result **out, const hark_table *db1,
         rc = k_join_partitioned(ctx, lcol, k64, n, k64 ? static_cast<const void *>(rk64) : static_cast<const void *>(rkeys), s,
                                 carry_col >= 0 ? static_cast<const uint32_t *>(db1->cols[carry_col].data) : nullptr, rranked,
                                 &prank, &plrow, &pcnt, &sval, &rval, &M, &partitioned, &unique, rows_needed, build_unique);
-        ctx->last_join_path = !partitioned ? HARK_PATH_JOIN_SORTMERGE : ctx->last_join_clustered ? HARK_PATH_JOIN_CLUSTERED : ctx->last_join_weighted ? HARK_PATH_JOIN_PARTITIONED_WEIGHTED : HARK_PATH_JOIN_PARTITIONED;
+        ctx->last_join_path = !partitioned ? HARK_PATH_JOIN_SORTMERGE : ctx->last_join_clustered ? HARK_PATH_JOIN_CLUSTERED : ctx->last_join_rotated ? HARK_PATH_JOIN_PARTITIONED_ROTATED : ctx->last_join_weighted ? HARK_PATH_JOIN_PARTITIONED_WEIGHTED : HARK_PATH_JOIN_PARTITIONED;
         if (!rc && partitioned) {
             nl = M;
             lb = prank; lperm = plrow; cnt = pcnt;                 // freed with the other scratch below

@@ -344,7 +344,7 @@ class Engine:
 
     def last_join_path(self):
         """'partitioned' | 'sort-merge' | None: the path that served the last join entry (diagnostic, include/hark.h)."""
-        return {1: "partitioned", 2: "sort-merge", 3: "partitioned, buckets cut by weight", 4: "clustered probe column, searched in row order"}.get(self.lib.hark_context_last_join_path(self.ctx))
+        return {1: "partitioned", 2: "sort-merge", 3: "partitioned, buckets cut by weight", 4: "clustered probe column, searched in row order", 5: "partitioned, rotated loads"}.get(self.lib.hark_context_last_join_path(self.ctx))
 
     def set_stream(self, raw_stream):
         """Run later entries on this hipStream_t handle; 0 / None = the context's own stream

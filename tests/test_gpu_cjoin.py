@@ -158,3 +158,63 @@ def test_the_test_can_be_switched_off():
     code = code.split("for unique in")[0] + 'print("forced ok")\n'
     out = subprocess.run([sys.executable, "-c", code % (ROOT, os.path.join(ROOT, "tests"))], capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0 and "forced ok" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
+
+
+_ROTATED = r"""
+import sys
+import numpy as np
+sys.path.insert(0, %r)
+sys.path.insert(0, %r)
+import test_gpu_hjoin as T
+from harkdb_amd.engine import Engine
+eng = Engine(0)
+for case in ("u32 10%% hits", "u32 every row hits, 8 partners each", "i64 duplicates both sides", "i64 unique build keys, every second probe row hits", "i32 negative keys as u32"):
+    lk, rk = T._make(case, 5)
+    reps = -(-(1 << 20) // len(lk))                                  # rotated loads need >= 128 full batches: 2^20 rows of 32-bit keys (2^19 of 64-bit ones)
+    lk = np.tile(lk, reps)
+    for order in ("shuffled", "blocks"):
+        k = lk.copy()
+        if order == "blocks":
+            for a in range(0, len(k), 1 << 16): k[a:a + (1 << 16)] = np.sort(k[a:a + (1 << 16)])
+        print(case, order, T._check(eng, k, rk), eng.last_join_path())
+        assert eng.last_join_path() == "partitioned, rotated loads", eng.last_join_path()
+for hot in (0, 500): T.test_i64_join_of_carried_columns_only(eng, hot)
+print("rotated ok")
+"""
+
+
+@pytest.mark.parametrize("env", [{}, {"HARK_JOIN_PLAIN_LOADS": "1"}, {"HARK_JOIN_HOTMIN": "3"}])
+def test_partition_with_rotated_loads_forced(env):
+    """HARK_JOIN_CLUSTERED=2: the partition's 64 sixteen-lane groups read their rows of 64 different batches (`rot` of jpart_kernel),
+    whatever the rows look like -- with the hand-placed waits and with the compiler's, and with hot keys (their rows are counted per
+    batch by sixteen lanes then): the reference's order row for row."""
+    out = subprocess.run([sys.executable, "-c", _ROTATED % (ROOT, os.path.join(ROOT, "tests"))], capture_output=True, text=True, timeout=900,
+                         env=dict(os.environ, HARK_JOIN_CLUSTERED="2", HARK_JOIN_SLABX="1000", **env))     # (slabs of 10 x the even share: at 2^20 rows a slab holds ~100 entries, two groups of 64 rows in one bucket overrun it)
+    assert out.returncode == 0 and "rotated ok" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
+
+
+def test_a_probe_column_sorted_block_by_block_takes_rotated_loads(eng, monkeypatch):
+    monkeypatch.setenv("HARK_JOIN_SLABX", "1000")                      # (at 2^21 rows a slab holds ~110 entries: two groups of 64 rows in one bucket would overrun it and the search path take over)
+    rng = np.random.default_rng(77)
+    n, s = 1 << 21, 2_000_000                                        # rows 16 apart are ~240 build keys apart: too far for the search path's slices, inside one bucket
+    rk = rng.choice(1 << 30, size=s, replace=False).astype(np.uint32)
+    lk = rng.integers(0, 1 << 30, size=n).astype(np.uint32)
+    hit = rng.random(n) < 0.3
+    lk[hit] = rk[rng.integers(0, s, size=int(hit.sum()))]
+    for a in range(0, n, 1 << 17): lk[a:a + (1 << 17)] = np.sort(lk[a:a + (1 << 17)])     # sixteen sorted blocks, every block over all keys
+    assert T._check(eng, lk, rk) > 0
+    assert eng.last_join_path() == "partitioned, rotated loads", eng.last_join_path()
+
+
+def test_rotated_loads_that_overrun_their_slabs_fall_back_to_the_search_path(eng):
+    """The same column with the slabs at their normal size: at 2^21 rows two groups of 64 rows in one bucket overrun a slab, the
+    partition leaves, and the search path -- not the probe side's sort -- delivers the rows."""
+    rng = np.random.default_rng(78)
+    n, s = 1 << 21, 2_000_000
+    rk = rng.choice(1 << 30, size=s, replace=False).astype(np.uint32)
+    lk = rng.integers(0, 1 << 30, size=n).astype(np.uint32)
+    hit = rng.random(n) < 0.3
+    lk[hit] = rk[rng.integers(0, s, size=int(hit.sum()))]
+    for a in range(0, n, 1 << 17): lk[a:a + (1 << 17)] = np.sort(lk[a:a + (1 << 17)])
+    assert T._check(eng, lk, rk) > 0
+    assert eng.last_join_path() in (CLUSTERED, "partitioned, rotated loads"), eng.last_join_path()
