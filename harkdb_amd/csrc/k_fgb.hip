@@ -408,14 +408,14 @@ __global__ __launch_bounds__(1024) void fgb_window_kernel(
             ph = ph == 2 ? 0 : ph + 1;
             if (tid == 0) { s_lo[clr] = 0x7FFFFFFF; s_hi[clr] = -1; }
             if (blo > bhi) break;
-            if (blo < base || bhi >= base + kWinKeys) {                   // the window moves (every thread sees the same numbers)
+            if (blo < base || bhi - base >= kWinKeys) {                   // the window moves (every thread sees the same numbers; bhi >= blo >= base here: no overflow for keys up to 2^31 - 1)
                 if (dlo <= dhi) write_out();
                 // keys that fall (a column in descending order): the batch at the window's upper end, room below it
                 base = (blo < base && bhi - blo < kWinKeys) ? max(0, bhi - kWinKeys + 1) : blo;
                 moved++;
             }
             const bool last = turn == kWinTurns - 1;
-            dlo = min(dlo, blo); dhi = max(dhi, min(bhi, base + kWinKeys - 1));
+            dlo = min(dlo, blo); dhi = max(dhi, bhi - base >= kWinKeys ? base + (kWinKeys - 1) : bhi);
             // a wave whose surviving rows all hold ONE key (a sorted column: ~950 rows per key at the headline's sizes) adds them up in
             // registers and touches the window once, instead of 64 lanes queueing at the key's eight replicas
             if constexpr (FSUM || CNT) {
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(1024) void fgb_window_kernel(
                         outside++;
                     } else { mn = min(mn, kk[j]); mx = max(mx, kk[j]); }
                 }
-            if (bhi < base + kWinKeys || last) break;                     // every row of the batch was inside (the usual case: one barrier per batch)
+            if (bhi - base < kWinKeys || last) break;                     // every row of the batch was inside (the usual case: one barrier per batch)
 #pragma unroll
             for (int d = 32; d > 0; d >>= 1) { mn = min(mn, __shfl_xor(mn, d, 64)); mx = max(mx, __shfl_xor(mx, d, 64)); }
         }
@@ -586,13 +586,13 @@ __global__ __launch_bounds__(1024) void fgb_windowx_kernel(
             ph = ph == 2 ? 0 : ph + 1;
             if (tid == 0) { s_lo[clr] = 0x7FFFFFFF; s_hi[clr] = -1; }
             if (blo > bhi) break;
-            if (blo < base || bhi >= base + kWinKeys) {
+            if (blo < base || bhi - base >= kWinKeys) {
                 if (dlo <= dhi) write_out();
                 base = (blo < base && bhi - blo < kWinKeys) ? max(0, bhi - kWinKeys + 1) : blo;
                 moved++;
             }
             const bool last = turn == kWinTurns - 1;
-            dlo = min(dlo, blo); dhi = max(dhi, min(bhi, base + kWinKeys - 1));
+            dlo = min(dlo, blo); dhi = max(dhi, bhi - base >= kWinKeys ? base + (kWinKeys - 1) : bhi);
             // a wave whose surviving rows all hold ONE key folds them in registers and touches the window once (see fgb_window_kernel)
             if (turn == 0 && mn == mx && (uint32_t)(mn - base) < (uint32_t)kWinKeys && A.vop0 != VOP_U32PROD) {
                 u64 part = id0;
@@ -641,7 +641,7 @@ __global__ __launch_bounds__(1024) void fgb_windowx_kernel(
                     } else if (last) { global_row(kk[j], v0[j], v1[j], v2[j]); outside++; }
                     else { mn = min(mn, kk[j]); mx = max(mx, kk[j]); }
                 }
-            if (bhi < base + kWinKeys || last) break;
+            if (bhi - base < kWinKeys || last) break;
 #pragma unroll
             for (int d = 32; d > 0; d >>= 1) { mn = min(mn, __shfl_xor(mn, d, 64)); mx = max(mx, __shfl_xor(mx, d, 64)); }
         }
