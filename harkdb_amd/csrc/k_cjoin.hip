@@ -46,6 +46,13 @@ __device__ __forceinline__ uint32_t cj_mix(uint32_t x)
     return x;
 }
 
+template <typename K> __device__ __forceinline__ K cj_shfl_up(K x, int d);
+template <> __device__ __forceinline__ uint32_t cj_shfl_up<uint32_t>(uint32_t x, int d) { return (uint32_t)__shfl_up((int)x, d, 64); }
+template <> __device__ __forceinline__ uint64_t cj_shfl_up<uint64_t>(uint64_t x, int d)
+{
+    const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)x, d, 64), hi = (uint32_t)__shfl_up((int)(uint32_t)(x >> 32), d, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
 template <typename K> __device__ __forceinline__ K cj_shfl_xor(K x, int j);
 template <> __device__ __forceinline__ uint32_t cj_shfl_xor<uint32_t>(uint32_t x, int j) { return (uint32_t)__shfl_xor((int)x, j, 64); }
 template <> __device__ __forceinline__ uint64_t cj_shfl_xor<uint64_t>(uint64_t x, int j)
@@ -129,10 +136,12 @@ __global__ __launch_bounds__(kCThreads) void cj_search_kernel(const K *__restric
 {
     constexpr int IDX = CIdx<K>::N, WS = 2048 / (int)sizeof(K);           // WS: build keys of a wave's slice (2 KiB: the same room as its 256 staged rows)
     __shared__ K s_idx[IDX];
-    __shared__ uint2 s_stage[kCBatch];
+    __shared__ K s_top[64];                                               // every (IDX / 64)-th index entry (read by lane: no bank conflicts)
+    __shared__ uint2 s_stage[kCBatch];                                    // sixteen slices of build keys, 2 KiB per wave
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     auto idx_pos = [&](uint32_t i) -> uint32_t { return (uint32_t)(((uint64_t)i * (uint64_t)s) / (uint64_t)IDX); };
     for (int i = tid; i < IDX; i += kCThreads) s_idx[i] = rkeys[idx_pos((uint32_t)i)];
+    if (tid < 64) s_top[tid] = rkeys[idx_pos((uint32_t)tid * (uint32_t)(IDX / 64))];
     const K kmin = rkeys[0], kmax = rkeys[s - 1];
     // the first build entry >= key (a key inside [kmin, kmax]) lies in [lo, hi]: rkeys[lo - 1] < key (or lo = 0), rkeys[hi] >= key
     auto segment = [&](K key, uint32_t &lo, uint32_t &hi) {
@@ -145,9 +154,24 @@ __global__ __launch_bounds__(kCThreads) void cj_search_kernel(const K *__restric
         if (lo > hi) lo = hi;                                             // (pos = 0: the key IS the smallest build key)
     };
     auto wave_sync = [] { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };   // a wave's own LDS traffic, in program order
+    // the same for a key the whole wave shares: 64 index entries compared at once, twice (13 dependent LDS reads otherwise -- the search
+    // kernel is bound by instruction issue, profiles/r06_notes.md 8)
+    auto segment_wave = [&](K key, uint32_t &lo, uint32_t &hi) {
+        constexpr int B1 = IDX / 64;                                      // entries per lane-block of the first round (128 / 64)
+        uint32_t pos = (uint32_t)__popcll(__ballot(s_top[lane] < key));               // blocks whose first entry is below the key: the key's block is pos - 1
+        if (pos > 0u) {
+            const uint32_t b0 = (pos - 1u) * (uint32_t)B1;                // entries b0 .. b0 + B1 - 1; entry b0 is below the key
+            uint32_t below = 0;
+#pragma unroll
+            for (int t = 0; t < B1 / 64; t++) below += (uint32_t)__popcll(__ballot(s_idx[b0 + (uint32_t)(t * 64 + lane)] < key));
+            pos = b0 + below;                                             // index entries below the key
+        }
+        lo = pos == 0u ? 0u : idx_pos(pos - 1u) + 1u;
+        hi = pos == (uint32_t)IDX ? (uint32_t)(s - 1) : idx_pos(pos);
+        if (lo > hi) lo = hi;
+    };
     __syncthreads();
-    uint2 *stage = s_stage + wave * (kCBatch / 16);                       // this wave's 256 rows; its slice of build keys lives in the same bytes first
-    K *sl = reinterpret_cast<K *>(stage);
+    K *sl = reinterpret_cast<K *>(s_stage + wave * (kCBatch / 16));     // this wave's slice of build keys
     const int64_t nbatch = (n + kCBatch - 1) / kCBatch;
     auto load = [&](int64_t batch, K (&x)[kCVec]) {                       // the lane's four rows of a batch (raw keys; rows past the end: 0, never used)
         const int64_t r0 = batch * kCBatch + (int64_t)tid * kCVec;
@@ -197,7 +221,7 @@ __global__ __launch_bounds__(kCThreads) void cj_search_kernel(const K *__restric
         if (mn <= mx) {                                                   // (wave-uniform: some row of the wave is inside the build side's range)
             bool sliced = false;
             uint32_t l1, h1, l2, h2;
-            segment(mn, l1, h1); segment(mx, l2, h2);
+            segment_wave(mn, l1, h1); segment_wave(mx, l2, h2);
             // 64 probes per step and search (a segment of ~1200 keys: the first step leaves ~19), until the entries between the two fit the slice
             while ((l1 < h1 || l2 < h2) && h2 - l1 >= (uint32_t)WS) {
                 const uint32_t n1 = h1 - l1, n2 = h2 - l2;
@@ -219,17 +243,17 @@ __global__ __launch_bounds__(kCThreads) void cj_search_kernel(const K *__restric
 #pragma unroll
                 for (int t = 0; t < WS / 64; t++) { const uint32_t i = (uint32_t)(lane + 64 * t); if (i < len) sl[i] = rkeys[first + i]; }
                 wave_sync();
+                const uint32_t top = 1u << (31 - __clz((int)len));       // the largest power of two <= len (a sorted column: 16 or 32, not WS / 2)
 #pragma unroll
                 for (int j = 0; j < kCVec; j++) {
                     if (!(valid & (1u << j))) continue;
                     uint32_t pos = 0;                                     // slice entries below the key
-#pragma unroll
-                    for (int step = WS / 2; step > 0; step >>= 1) if (pos + step - 1 < len && sl[pos + step - 1] < x[j]) pos += step;
+                    for (uint32_t step = top; step > 0u; step >>= 1) if (pos + step - 1u < len && sl[pos + step - 1u] < x[j]) pos += step;   // (top: wave-uniform)
                     if (pos < len && sl[pos] < x[j]) pos++;
                     lo[j] = hi[j] = first + pos;
                     if (pos < len && sl[pos] == x[j]) { found |= 1u << j; c++; }
                 }
-                wave_sync();                                              // (the slice is read before the staged rows overwrite it)
+                wave_sync();                                              // (the slice is read before the next stretch's overwrites it)
             }
             if (!sliced) {
 #pragma unroll
@@ -256,29 +280,35 @@ __global__ __launch_bounds__(kCThreads) void cj_search_kernel(const K *__restric
                     if (lo[j] == hi[j] && rkeys[lo[j]] == x[j]) { found |= 1u << j; c++; }
             }
         }
-        // ---- the matching rows of the stretch, in row order: staged, checked (do the ranks ascend?), written out
+        // ---- the matching rows of the stretch, in row order, straight from the registers (a lane's rows lie side by side, the lanes'
+        // one behind the other).  Do the ranks ascend?  They do when the KEYS of the wave's rows inside the build side's range do -- a
+        // descent among them sends the join to the general ordering even when no matching row is involved: a column in order has none
+        // -- and across stretches when no stretch starts below an earlier one's largest rank (cj_scan1/2_kernel: first / last below).
         uint32_t incl = c;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
         const uint32_t cnt = __shfl(incl, 63, 64);
         if (cnt) {
-            uint32_t at = incl - c;
+            // order of the valid keys: inside the lane, and against the nearest valid key of the lanes before it
+            K lastv = (K)0, firstv = (K)0;
+            bool anyv = false, down = false;
 #pragma unroll
             for (int j = 0; j < kCVec; j++)
-                if (found & (1u << j)) stage[at++] = make_uint2(lo[j], (uint32_t)(r0 + j));
-            wave_sync();
-            uint2 *dst = tmp + sub * 256;
+                if (valid & (1u << j)) { if (anyv && x[j] < lastv) down = true; if (!anyv) firstv = x[j]; lastv = x[j]; anyv = true; }
+            K run = anyv ? lastv : (K)0;                                  // the largest "last valid key" of this lane and the lanes before it (keys that ascend: the nearest one)
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
-                const uint32_t i = (uint32_t)(lane + 64 * t);
-                if (i < cnt) {
-                    const uint2 e = stage[i];
-                    if (i + 1u < cnt && e.x > stage[i + 1u].x) bad = true;
-                    dst[i] = e;
-                }
-            }
-            if (lane == 0) { bfirst[sub] = stage[0].x; blast[sub] = stage[cnt - 1u].x; }
-            wave_sync();                                                  // (read before the next stretch's slice overwrites it)
+            for (int d = 1; d < 64; d <<= 1) { const K t = cj_shfl_up<K>(run, d); if (lane >= d && t > run) run = t; }
+            const K before = cj_shfl_up<K>(run, 1);
+            if (anyv && lane > 0 && before > firstv) down = true;
+            if (down) bad = true;
+            uint2 *dst = tmp + sub * 256 + (incl - c);
+            uint32_t at = 0, fr = 0xFFFFFFFFu, lr = 0u;
+#pragma unroll
+            for (int j = 0; j < kCVec; j++)
+                if (found & (1u << j)) { dst[at++] = make_uint2(lo[j], (uint32_t)(r0 + j)); fr = min(fr, lo[j]); lr = max(lr, lo[j]); }
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) { fr = min(fr, (uint32_t)__shfl_xor((int)fr, d, 64)); lr = max(lr, (uint32_t)__shfl_xor((int)lr, d, 64)); }
+            if (lane == 0) { bfirst[sub] = fr; blast[sub] = lr; }
         }
         if (lane == 0) bcount[sub] = cnt;
     }
