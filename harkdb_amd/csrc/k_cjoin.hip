@@ -7,16 +7,20 @@
 // -- 1e8 sorted probe rows took 58 ms (50 of them in the partition, then the sort-merge path) against 1.1 ms for the same rows
 // shuffled (tools/join_cluster_probe.py).  What hurts there helps here: consecutive rows need NEIGHBOURING places of the sorted build
 // side, so a plain search per row finds its lines in the caches.
-//   1. cj_test_kernel (one workgroup, on the second stream under the build side's sort): are rows half a batch apart, or four
-//      lanes apart, closer in key order than rows anywhere apart?  4096 such pairs against quantiles of a sample of the column.
-//   2. cj_search_kernel: batches of 4096 consecutive rows; every row finds its 1 / 8192 of the build side in an index kept in LDS
-//      (13 steps), then its rank by ~11 steps over the sorted build keys in memory (the wave's rows share a few lines); matching
-//      rows leave as (rank, row) in ROW order into the batch's own stretch of a scratch array, with the batch's count and
-//      first / last rank.
-//   3. cj_scan_kernel: the batches' offsets; and whether the ranks ascend over the whole column (a sorted column: the output
-//      order (key, left row, right row) is then the row order and nothing needs sorting).
-//   4. cj_emit_kernel: the batches' rows to their places, with the partner counts and the carried / rank-ordered columns.
-// A column that is clustered but not ascending (descending, sorted block by block) gets the general ordering of the caller
+//   1. cj_test_kernel (one workgroup, on the second stream under the build side's sort): 1024 pairs of probe rows against 1024
+//      quantiles of a sample of the BUILD column -- rows half a batch apart, or four lanes apart, closer in key order than rows
+//      anywhere apart: this path; neighbouring rows in one bucket but too far apart for it (a column sorted block by block): the
+//      partition with rotated loads (jpart_kernel's ROT variant, k_hjoin.hip); else the plain partition.
+//   2. cj_search_kernel: every WAVE takes stretches of 256 consecutive rows (no workgroup barrier once the index -- every
+//      (s / 8192)-th build key, 32 KiB of LDS -- is staged): the smallest and largest key of the stretch find their segments of the
+//      index with 64 lanes at once, one or two 64-probe steps over the sorted build keys narrow them down, the build entries between
+//      the two (a sorted column: ~26) are loaded into the wave's 2 KiB of LDS and every row finds its rank by a search there; a
+//      stretch that spans more than 512 build keys searches row by row through the index and memory.  Matching rows leave as
+//      (rank, row) in ROW order into the stretch's own piece of a scratch array, with the stretch's count and first / last rank.
+//   3. cj_scan1_kernel / cj_scan2_kernel: the stretches' offsets; and whether the ranks ascend over the whole column (a sorted
+//      column: the output order (key, left row, right row) is then the row order and nothing needs sorting).
+//   4. cj_emit_kernel: the stretches' rows to their places, with the partner counts and the carried / rank-ordered columns.
+// A column that is clustered but not ascending (descending, sorted runs in shuffled order) gets the general ordering of the caller
 // (two radix sorts over the MATCHING rows).
 #include "hark_internal.h"
 
