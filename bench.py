@@ -486,6 +486,37 @@ def w_join_u32(torch, eng, dev, scale=1.0):
                      "statement": "join(db1, db2, 0, 0, [0, 1], [1]) (join.fut:52) on u32 keys, ~10 % of the probe rows match"}}
 
 
+def w_join_u32_sorted(torch, eng, dev, scale=1.0):
+    """The reference's join with the PROBE table kept in key order (a fact table sorted by its foreign key): the same columns as
+    w_join_u32, the probe rows sorted by the key -- the search path of k_cjoin.hip instead of the partition."""
+    w = w_join_u32(torch, eng, dev, scale)
+    tp8, tb8 = w["keep"]
+    n8 = w["info"]["probe_rows"]
+    from harkdb_amd.dist import tensor_from_ptr
+    kp = tensor_from_ptr(tp8.device_ptr(0), n8, np.int32, dev)
+    srt = kp.sort().values                                                           # all keys below 2^30: signed order = the join's unsigned order
+    a2 = tensor_from_ptr(tp8.device_ptr(1), n8, np.int32, dev).clone()
+    torch.cuda.synchronize()
+    ts = eng.table_from_device(n8, [srt.data_ptr(), a2.data_ptr()], [np.uint32, np.uint32], keepalive=(srt, a2))
+    tp8.free()
+    info = dict(w["info"], statement="join(db1, db2, 0, 0, [0, 1], [1]) (join.fut:52) on u32 keys, db1 SORTED by its key column, ~10 % of its rows match")
+    return {"run": lambda: eng.join(ts, tb8, 0, 0, [0, 1], [1]), "bytes": w["bytes"], "rows": w["rows"], "keep": (ts, tb8), "info": info}
+
+
+def w_sort20_sorted(torch, eng, dev, scale=1.0):
+    """ORDER BY a u32 key column that is in order already: the sort's first read notices and no radix pass runs."""
+    w = w_sort(torch, eng, dev, scale, bits=20)
+    t, n8 = w["keep"][0], w["rows"]
+    from harkdb_amd.dist import tensor_from_ptr
+    ks = tensor_from_ptr(t.device_ptr(0), n8, np.int32, dev).sort().values
+    a2 = tensor_from_ptr(t.device_ptr(1), n8, np.int32, dev).clone()
+    torch.cuda.synchronize()
+    t2 = eng.table_from_device(n8, [ks.data_ptr(), a2.data_ptr()], [np.uint32, np.uint32], keepalive=(ks, a2))
+    t.free()
+    return {"run": lambda: eng.sort(t2, 0, [0, 1]), "bytes": w["bytes"], "rows": n8, "keep": (t2,),
+            "info": {"statement": "ORDER BY a 20-bit u32 key that is in order already, key + one column out (no radix pass runs)"}}
+
+
 def w_join_c4(torch, eng, dev, scale=1.0):
     n4, s4 = int(1.25e8 * scale), int(1.25e7 * scale)
     mul = -7046029254386353131                                                       # 0x9E3779B97F4A7C15 as i64: odd, so i -> i*mul is a bijection mod 2^64
@@ -533,7 +564,7 @@ def w_sparse_five(torch, eng, dev, scale=1.0):
             "info": {"statement": "SELECT k,SUM(v),MAX(v),MIN(v),AVG(v),COUNT(*) FROM t WHERE p>0.5 GROUP BY k -- 2^20 sparse i32 keys", "groups": w["info"]["groups"]}}
 
 
-WORKLOADS = {"sparse_five": w_sparse_five, "c1": w_c1, "c2": w_c2, "refgb": w_refgb, "refgb_hash": w_refgb_hash, "refgb_hash1": w_refgb_hash1, "join_u32": w_join_u32, "join_c4": w_join_c4, "sparse_gb": w_sparse_gb,
+WORKLOADS = {"sparse_five": w_sparse_five, "c1": w_c1, "c2": w_c2, "refgb": w_refgb, "refgb_hash": w_refgb_hash, "refgb_hash1": w_refgb_hash1, "join_u32": w_join_u32, "join_u32_sorted": w_join_u32_sorted, "sort20_sorted": w_sort20_sorted, "join_c4": w_join_c4, "sparse_gb": w_sparse_gb,
              "sort20": lambda *a: w_sort(*a, bits=20), "sort32": lambda *a: w_sort(*a, bits=31), "sort64": lambda *a: w_sort(*a, bits=64)}
 
 
@@ -754,13 +785,15 @@ def extra_configs(torch, eng, dev, a, sink, out):
 
     # ---- the reference's own entries and ORDER BY at 1e8 rows (not BASELINE configs; the operators behind them)
     for name, wl, kw in (("REF_query_groupby_dense", "refgb", {}), ("REF_query_groupby_hash", "refgb_hash", {}), ("ORDER_BY", "sort20", {}),
-                         ("ORDER_BY_32bit", "sort32", {}), ("ORDER_BY_i64", "sort64", {}), ("REF_join_u32", "join_u32", {}), ("C4_join_share", "join_c4", {})):
+                         ("ORDER_BY_32bit", "sort32", {}), ("ORDER_BY_i64", "sort64", {}), ("ORDER_BY_sorted_column", "sort20_sorted", {}), ("REF_join_u32", "join_u32", {}),
+                         ("REF_join_u32_sorted_probe", "join_u32_sorted", {}), ("C4_join_share", "join_c4", {})):
         w = WORKLOADS[wl](torch, eng, dev, a.config_scale)
         out[name] = timed(w, **kw)
         if wl.startswith("refgb"):
             out[name]["groups"] = out[name]["result_shape"][0]
             out[name]["path"] = eng.last_groupby_path()
         if wl.startswith("join"):
+            out[name]["path"] = eng.last_join_path()
             out[name]["pairs"] = out[name]["result_shape"][0]
             out[name]["pairs_match_the_expected_count"] = out[name]["pairs"] == out[name].get("pairs_expected")
         for t_ in w["keep"]:

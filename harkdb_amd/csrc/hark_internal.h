@@ -220,6 +220,7 @@ struct hark_fgb_plan {
     int64_t win_rows = 0, win_rows_seen = 0, win_moves = 0; uint32_t win_outside_seen = 0;   // rows fed to it / at the last check; its counters then
 };
 
+int k_fgb_plan_new_uncleared(hark_context *ctx, hark_fgb_plan **out, int64_t max_rows, int64_t G);
 int k_gen_columns(hark_context *ctx, uint64_t seed, int64_t first_row, int64_t n, uint32_t G,
                   int exact, float *p, int32_t *k, float *v);
 int hark_fgb_finish_typed(hark_context *ctx, hark_fgb_plan *pl, int32_t kind, const uint32_t *pos, void *out);

@@ -2385,7 +2385,13 @@ static void plan_drop_partition(hark_fgb_plan *pl)
     if (pl->counts) { hark_free(pl->ctx, pl->counts); pl->counts = nullptr; }
 }
 
-int hark_fgb_plan_new(hark_context *ctx, hark_fgb_plan **out, int64_t max_rows, int64_t G)
+static int fgb_plan_new(hark_context *ctx, hark_fgb_plan **out, int64_t max_rows, int64_t G, bool clear);
+int hark_fgb_plan_new(hark_context *ctx, hark_fgb_plan **out, int64_t max_rows, int64_t G) { return fgb_plan_new(ctx, out, max_rows, G, true); }
+// ... for callers that reset or initialise the accumulators before every pass anyway (the statement entries of k_groupby.hip): without
+// the two clears of 8 B x G (13 us per statement at 2^20 groups)
+int k_fgb_plan_new_uncleared(hark_context *ctx, hark_fgb_plan **out, int64_t max_rows, int64_t G) { return fgb_plan_new(ctx, out, max_rows, G, false); }
+
+static int fgb_plan_new(hark_context *ctx, hark_fgb_plan **out, int64_t max_rows, int64_t G, bool clear)
 {
     hark_device_guard guard__(ctx);
     if (!ctx || !out) return HARK_EARG;
@@ -2401,8 +2407,10 @@ int hark_fgb_plan_new(hark_context *ctx, hark_fgb_plan **out, int64_t max_rows, 
     if (!rc) rc = hark_alloc(ctx, (void **)&pl->acc_cnt, (size_t)G * sizeof(unsigned long long));
     if (rc) { hark_fgb_plan_free(ctx, pl); return rc; }
     HIP_TRY_RC(ctx, rc, hipMemsetAsync(pl->err, 0, 32, ctx->stream));
-    HIP_TRY_RC(ctx, rc, hipMemsetAsync(pl->acc_sum, 0, (size_t)G * sizeof(double), ctx->stream));
-    HIP_TRY_RC(ctx, rc, hipMemsetAsync(pl->acc_cnt, 0, (size_t)G * sizeof(unsigned long long), ctx->stream));
+    if (clear) {
+        HIP_TRY_RC(ctx, rc, hipMemsetAsync(pl->acc_sum, 0, (size_t)G * sizeof(double), ctx->stream));
+        HIP_TRY_RC(ctx, rc, hipMemsetAsync(pl->acc_cnt, 0, (size_t)G * sizeof(unsigned long long), ctx->stream));
+    }
     if (rc) { hark_fgb_plan_free(ctx, pl); return rc; }
     *out = pl;
     return HARK_OK;

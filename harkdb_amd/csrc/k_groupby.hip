@@ -729,7 +729,7 @@ int try_dense(hark_context *ctx, const hark_table *db, const PredList &preds,
     const int32_t *keys = static_cast<const int32_t *>(src->cols[g2].data);
 
     hark_fgb_plan *plan = nullptr;
-    rc = hark_fgb_plan_new(ctx, &plan, src->n > 0 ? src->n : 1, G);
+    rc = k_fgb_plan_new_uncleared(ctx, &plan, src->n > 0 ? src->n : 1, G);          // (every pass below resets or initialises the accumulators itself)
     if (!rc) { plan->win_k = keys; plan->win_n = src->n; plan->win_verdict = src->cols[g2].key_clustered; }   // what an earlier statement found out about this key column
     uint32_t *flags = nullptr, *pos = nullptr;
     int64_t ngroups = -1;
@@ -1469,7 +1469,7 @@ int ref_groupby_dense(hark_context *ctx, const hark_table *view, const hark_tabl
     if (G > kDenseMaxGroups || G > 8 * n + 4096) return HARK_OK;       // sparse or huge key domain: sort-based path
 
     hark_fgb_plan *plan = nullptr;
-    HARK_TRY(hark_fgb_plan_new(ctx, &plan, n, G));
+    HARK_TRY(k_fgb_plan_new_uncleared(ctx, &plan, n, G));                 // (every pass below resets or initialises the accumulators itself)
     const bool own_column = view->cols[g_col].data == stats_owner->cols[g_col].data && view->n == stats_owner->n;   // (a filtered view has its own rows)
     if (own_column) { plan->win_k = keys; plan->win_n = n; plan->win_verdict = stats_owner->cols[g_col].key_clustered; }
     std::vector<uint32_t *> vals(aggs.size(), nullptr);

@@ -203,7 +203,7 @@ def test_bench_extra_configs_at_a_small_scale():
         assert cfg[name]["count_checksum"] is True and cfg[name]["path"].startswith("window"), cfg[name]
     assert "G2^20_sel1.0" in cfg["SWEEP_selectivity_x_groups"] and cfg["SWEEP_selectivity_x_groups"]["G2^20_sel1.0"]["count_checksum"] is True
     for name in ("C3_no_filter", "G16", "G4096", "G13000", "SWEEP_selectivity_x_groups", "SPARSE_groupby", "SPARSE_five_aggregates", "C2_filter_proj", "C1_projection", "REF_query_groupby_dense",
-                 "REF_query_groupby_hash", "ORDER_BY", "ORDER_BY_32bit", "ORDER_BY_i64", "REF_join_u32", "C4_join_share", "C5_pipeline_share",
+                 "REF_query_groupby_hash", "ORDER_BY", "ORDER_BY_32bit", "ORDER_BY_i64", "ORDER_BY_sorted_column", "REF_join_u32", "REF_join_u32_sorted_probe", "C4_join_share", "C5_pipeline_share",
                  "C5_three_aggregates", "C5_three_aggregates_all_groups"):
         assert name in cfg, name
     sp = cfg["SPARSE_groupby"]
@@ -211,6 +211,7 @@ def test_bench_extra_configs_at_a_small_scale():
     assert cfg["REF_query_groupby_dense"]["path"] == "dense" and cfg["REF_query_groupby_hash"]["path"] == "hash"
     assert cfg["C4_join_share"]["pairs"] == cfg["C4_join_share"]["pairs_expected"]
     assert cfg["REF_join_u32"]["pairs"] == cfg["REF_join_u32"]["pairs_expected"] > 0
+    assert cfg["REF_join_u32_sorted_probe"]["pairs"] == cfg["REF_join_u32"]["pairs_expected"] and cfg["REF_join_u32_sorted_probe"]["path"].startswith("clustered")   # the probe table in key order: the search path, the same pairs
 
 
 def test_two_bench_ranks_on_one_gpu_measure_strong_and_weak():
