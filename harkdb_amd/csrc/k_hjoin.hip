@@ -1612,6 +1612,12 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
     // rows again as the others -- a hundred neighbouring keys with a thousand rows each -- sent the whole join to the sort-merge path)
     const int64_t avg = (n + (int64_t)P * nwg - 1) / ((int64_t)P * nwg);
     int64_t slabx = 200;                                                         // per cent of the uniform share
+    // rotated loads (a probe column sorted block by block, see jpart_kernel's `rot`): a group's 64 (32) rows land in ONE bucket, so a
+    // workgroup's slab of a bucket fills in a dozen chunks of 64 rows instead of row by row -- 3.8 sigma above the mean at twice the even
+    // share, and the groups' places are a lattice, not chance: 1.25e8 i64 rows in blocks of 1e5 overran a slab there.  Four times it is.
+    const int64_t nfullb_rot = n / ((int64_t)kJThreads * VEC);
+    const int64_t rot = ctx->join_rotate && nfullb_rot >= 128 && !getenv("HARK_JOIN_NO_ROTATE") ? ((nfullb_rot / 64 - 1) | 1) : 0;
+    if (rot > 0) slabx = 400;
     if (const char *e = getenv("HARK_JOIN_SLABX")) { const int c = atoi(e); if (c >= 100 && c <= 1000) slabx = c; }   // A/B
     int64_t cap64 = (avg * slabx / 100 + 5 * LINE + LINE - 1) / LINE * LINE;
     if (cap64 > 0x7FFFFFF0ll) return HARK_OK;
@@ -1710,7 +1716,6 @@ int run_partitioned(hark_context *ctx, const K *lcol, K bias, int64_t n, const K
     if (he == hipSuccess) {
         // one stream-ordered chain, one host read at the end: partition -> bucket probe -> survivor total
         // a probe column whose neighbouring rows share a bucket (the clustering test's third verdict): rotated loads
-        const int64_t nfullb = n / ((int64_t)kJThreads * VEC), rot = ctx->join_rotate && nfullb >= 128 && !getenv("HARK_JOIN_NO_ROTATE") ? ((nfullb / 64 - 1) | 1) : 0;
         ctx->last_join_rotated = rot > 0;
         if (rot > 0 && !plain_loads) {
             he = hipFuncSetAttribute(reinterpret_cast<const void *>(&jpart_kernel<K, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_part);

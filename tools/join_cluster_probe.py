@@ -11,10 +11,14 @@ from harkdb_amd.engine import Engine
 eng = Engine(0); dev = torch.device("cuda", 0)
 n, m = 100_000_000, 10_000_000
 g = torch.Generator(device=dev); g.manual_seed(11)
+I64 = bool(os.environ.get("PROBE_I64"))                               # PROBE_I64=1: the same shapes on i64 keys (x 2^20 + 5: beyond 32 bits)
 build = (torch.arange(m, device=dev, dtype=torch.int64) * 107 % (1 << 30)).to(torch.int32)
 bval = torch.randint(0, 1 << 16, (m,), dtype=torch.int32, device=dev, generator=g)
 pval = torch.randint(0, 1 << 16, (n,), dtype=torch.int32, device=dev, generator=g)
-tb = eng.table_from_device(m, [build.data_ptr(), bval.data_ptr()], [np.uint32, np.uint32], keepalive=(build, bval))
+KDT = np.int64 if I64 else np.uint32
+wide = lambda t: (t.to(torch.int64) << 20) + 5 if I64 else t
+build_k = wide(build)
+tb = eng.table_from_device(m, [build_k.data_ptr(), bval.data_ptr()], [KDT, np.uint32], keepalive=(build_k, bval))
 
 
 def shape(name):
@@ -42,9 +46,9 @@ def shape(name):
 CASES = ("random", "sorted", "descending", "blocks1000000", "blocks100000", "blocks30000", "blocks10000", "runs4096", "runs256", "runs16", "match_random", "match_sorted", "match_runs4096")
 if len(sys.argv) > 1: CASES = tuple(sys.argv[1:])
 for case in CASES:
-    probe = shape(case)
+    probe = wide(shape(case))
     torch.cuda.synchronize()
-    tp = eng.table_from_device(n, [probe.data_ptr(), pval.data_ptr()], [np.uint32, np.uint32], keepalive=(probe, pval))
+    tp = eng.table_from_device(n, [probe.data_ptr(), pval.data_ptr()], [KDT, np.uint32], keepalive=(probe, pval))
     ts = []
     for r in range(3):
         eng.sync(); t0 = time.perf_counter(); res = eng.join(tp, tb, 0, 0, [0, 1], [1]); eng.sync(); ts.append((time.perf_counter() - t0) * 1e3); rows = res.shape[0]; res.free()
