@@ -303,12 +303,13 @@ __global__ __launch_bounds__(1024) void fgb_lds_kernel(
 // cheap: the rows of a batch hold a handful of neighbouring keys.  So every workgroup takes a CONTIGUOUS stretch of the
 // table and aggregates batch after batch into a WINDOW of kWinKeys consecutive keys in LDS (fgb_lds_kernel's slots: a double
 // or a word per key + a count, kWinRep replicas -- the lanes of a wave mostly hold the SAME key), which follows the keys:
-// a batch first publishes the smallest and largest surviving key, and when they leave the window the touched part of it
-// is added to the global accumulators (a few keys: one global atomic each) and the window moves there.  One pass, 12 B/row,
-// no pair is written.  A batch that spans more keys than the window holds sends the rows outside to global atomics (correct,
-// slow): the caller picks this path only for columns whose rows half a batch apart are a few keys apart
-// (fgb_cluster_test_kernel) and reads back how many rows went that way.
-constexpr int kWinKeys = 1024, kWinRL = 3, kWinRep = 1 << kWinRL, kWinNear = kWinKeys / 4, kWinFar = 512, kWinTurns = 4;
+// rows inside the window are added there; when many rows of a batch lie outside, the window is added to the global accumulators
+// (one global atomic per key it holds) and put around a key the wave with the most waiting rows picked.  A FEW rows outside --
+// late rows in a table that is in order otherwise -- go to the global accumulators one by one.  One pass, 12 B/row, no pair is
+// written.  A batch whose rows lie in more clusters than a batch gets turns sends the rest to global atomics too (correct,
+// slow): the caller picks this path only for columns whose rows an eighth of a batch apart are a few keys apart
+// (fgb_cluster_test_kernel), reads back how many rows went that way, and drops the verdict when it was more than a third.
+constexpr int kWinKeys = 1024, kWinRL = 3, kWinRep = 1 << kWinRL, kWinNear = kWinKeys / 4, kWinFar = 512, kWinTurns = 4, kWinStray = 256;
 
 // stat[0]: times a window moved, stat[1]: rows that went to global atomics
 template <int OP, int VM>
@@ -323,10 +324,12 @@ __global__ __launch_bounds__(1024) void fgb_window_kernel(
     constexpr int SLOTS = kWinKeys << kWinRL;
     u64 *s_sum = reinterpret_cast<u64 *>(lds_raw);
     uint32_t *s_cnt = reinterpret_cast<uint32_t *>(lds_raw + sizeof(u64) * SLOTS);
-    __shared__ int s_lo[3], s_hi[3];                                     // smallest / largest waiting key of a turn: three pairs of words in rotation (see below)
+    __shared__ uint32_t s_out[3], s_wout[3][16];                         // rows of a turn outside the window, all and per wave (three sets of words in rotation, see below)
+    __shared__ int s_cand[3][16];                                        // ... and one of their keys
     const int tid = threadIdx.x, lane = tid & 63;
     for (int i = tid; i < SLOTS; i += 1024) { s_sum[i] = vop_identity(VOP); s_cnt[i] = 0u; }
-    if (tid < 3) { s_lo[tid] = 0x7FFFFFFF; s_hi[tid] = -1; }
+    if (tid < 48) { s_cand[tid / 16][tid % 16] = -1; s_wout[tid / 16][tid % 16] = 0u; }
+    if (tid < 3) s_out[tid] = 0u;
     __syncthreads();
     const uint32_t rep = (uint32_t)tid & (uint32_t)(kWinRep - 1);
     const int64_t nvec = n / kVec;
@@ -352,18 +355,20 @@ __global__ __launch_bounds__(1024) void fgb_window_kernel(
         const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(v4 + q));
         return float4{t.x, t.y, t.z, t.w};
     };
-    bool bad = false;
-    int base = 0, dlo = 0x7FFFFFFF, dhi = -1;                             // the window [base, base + kWinKeys) and the keys of it touched since it was last written out
+    bool bad = false, open = false;                                       // open: a window exists (the first batch makes one)
+    int base = 0;                                                         // the window [base, base + kWinKeys)
     uint32_t moved = 0, outside = 0;
-    // the touched keys of the window -> global accumulators (every thread calls it; ends with a barrier)
+    const int wave = tid >> 6;
+    // the window -> global accumulators: a key per thread, all of them (every thread calls it, behind a turn's barrier -- the rows of that turn
+    // are in --; ends with a barrier).  (Tracking the touched range cost a reduction and a barrier more per move than reading 1024 keys does.)
     auto write_out = [&]() {
-        for (int g = dlo - base + tid; g <= dhi - base; g += 1024) {
+        for (int g = tid; g < kWinKeys; g += 1024) {
             u64 sacc = vop_identity(VOP); uint32_t c = 0;
 #pragma unroll
             for (int r = 0; r < kWinRep; r++) {
                 const int slot = (g << kWinRL) + r;
-                sacc = vop_merge(VOP, sacc, s_sum[slot]); c += s_cnt[slot];
-                s_sum[slot] = vop_identity(VOP); s_cnt[slot] = 0u;
+                const uint32_t cr = s_cnt[slot];
+                if (cr) { sacc = vop_merge(VOP, sacc, s_sum[slot]); c += cr; s_sum[slot] = vop_identity(VOP); s_cnt[slot] = 0u; }
             }
             if (c) {
                 if constexpr (FSUM) vop_atomic_partial<VOP_F32SUM>(&gsum[base + g], sacc);
@@ -371,13 +376,18 @@ __global__ __launch_bounds__(1024) void fgb_window_kernel(
                 atomicAdd(&gcnt[base + g], (unsigned long long)c);
             }
         }
-        dlo = 0x7FFFFFFF; dhi = -1;
         __syncthreads();
+    };
+    auto to_global = [&](int key, uint32_t x) {                           // a row the window does not hold: straight to the accumulators
+        if constexpr (FSUM) vop_atomic<VOP_F32SUM>(&gsum[key], x);
+        else if constexpr (!CNT) vop_atomic_rt(VOP, &gsum[key], apply_xf(xf, x));
+        atomicAdd(&gcnt[key], 1ull);
+        outside++;
     };
     float4 pn = float4{0, 0, 0, 0}, vn = pn;
     int4 kn = int4{0, 0, 0, 0};
     if (q0 + tid < q1) { pn = ldp(q0 + tid); kn = ldk(q0 + tid); vn = ldv(q0 + tid); }
-    int ph = 0;                                                           // the pair of words this turn publishes in
+    int ph = 0;                                                           // the words this turn publishes in
     for (int64_t qb = q0; qb < q1; qb += 1024) {
         const int64_t q = qb + tid;
         const bool have = q < q1;
@@ -387,84 +397,104 @@ __global__ __launch_bounds__(1024) void fgb_window_kernel(
         const float pv[4] = {pa.x, pa.y, pa.z, pa.w}, vv[4] = {va.x, va.y, va.z, va.w};
         const int kk[4] = {ka.x, ka.y, ka.z, ka.w};
         uint32_t live = 0;
-        int mn = 0x7FFFFFFF, mx = -1;
 #pragma unroll
         for (int j = 0; j < 4; j++)
             if (have && cmp_f32<OP>(pv[j], thr)) {
-                if ((uint32_t)kk[j] < (uint64_t)G) { live |= 1u << j; mn = min(mn, kk[j]); mx = max(mx, kk[j]); }
+                if ((uint32_t)kk[j] < (uint64_t)G) live |= 1u << j;
                 else bad = true;
             }
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) { mn = min(mn, __shfl_xor(mn, d, 64)); mx = max(mx, __shfl_xor(mx, d, 64)); }
-        // up to kWinTurns windows per batch (a batch that straddles clusters of keys -- sorted runs in shuffled order): the rows
-        // inside the window are added, the others wait for the next turn; after the last turn they go to global atomics
-        // (the words: a turn publishes in pair ph, reads it behind the barrier, and thread 0 clears the pair of the turn AFTER the
-        // next -- last read before this barrier, next written behind the next one)
+        // A turn: the rows inside the window are added; the others are counted (and one of their keys per wave remembered).  None
+        // outside -- the usual batch of a column in key order --: done, one barrier.  A few (kWinStray: stray keys in a column that
+        // is in order otherwise, late rows; the first version moved the window to the SMALLEST waiting key and spent its turns on
+        // the strays: 55 ms per 1e9 rows with one row in a thousand out of place): straight to the global accumulators.  Many: the
+        // keys have moved on -- the window is written out and put where one of the waiting rows is (most of them are its
+        // neighbours), up to kWinTurns times per batch (a batch that straddles clusters: sorted runs in shuffled order); what still
+        // waits after the last turn goes to the global accumulators too.
+        // (the words: a turn publishes in set ph, reads it behind the barrier, and clears the set of the turn before it -- last read
+        // before this barrier, next written behind the next one)
         for (int turn = 0;; turn++) {
-            if (lane == 0 && mx >= 0) { atomicMin(&s_lo[ph], mn); atomicMax(&s_hi[ph], mx); }
-            __syncthreads();
-            const int blo = s_lo[ph], bhi = s_hi[ph];                     // the waiting rows' keys lie in [blo, bhi] (none: blo > bhi)
-            const int clr = ph == 0 ? 2 : ph - 1;
-            ph = ph == 2 ? 0 : ph + 1;
-            if (tid == 0) { s_lo[clr] = 0x7FFFFFFF; s_hi[clr] = -1; }
-            if (blo > bhi) break;
-            if (blo < base || bhi - base >= kWinKeys) {                   // the window moves (every thread sees the same numbers; bhi >= blo >= base here: no overflow for keys up to 2^31 - 1)
-                if (dlo <= dhi) write_out();
-                // keys that fall (a column in descending order): the batch at the window's upper end, room below it
-                base = (blo < base && bhi - blo < kWinKeys) ? max(0, bhi - kWinKeys + 1) : blo;
-                moved++;
-            }
-            const bool last = turn == kWinTurns - 1;
-            dlo = min(dlo, blo); dhi = max(dhi, bhi - base >= kWinKeys ? base + (kWinKeys - 1) : bhi);
-            // a wave whose surviving rows all hold ONE key (a sorted column: ~950 rows per key at the headline's sizes) adds them up in
-            // registers and touches the window once, instead of 64 lanes queueing at the key's eight replicas
             if constexpr (FSUM || CNT) {
-                if (turn == 0 && mn == mx && (uint32_t)(mn - base) < (uint32_t)kWinKeys) {   // (mn, mx: still the wave's; -1 / none: mn > mx)
-                    double part = 0.0;
-                    uint32_t c = 0;
+                // a wave whose surviving rows all hold ONE key (a sorted column: ~950 rows per key at the headline's sizes) adds them up
+                // in registers and touches the window once, instead of 64 lanes queueing at the key's eight replicas
+                const unsigned long long lv = __ballot(live != 0u);
+                if (open && lv != 0ull) {
+                    const int mine = kk[live ? __ffs((int)live) - 1 : 0];
+                    const int k0 = __shfl(mine, __ffsll((long long)lv) - 1, 64);
+                    bool same = true;
 #pragma unroll
-                    for (int j = 0; j < 4; j++) if (live & (1u << j)) { part += (double)vv[j]; c++; }
+                    for (int j = 0; j < 4; j++) if ((live & (1u << j)) && kk[j] != k0) same = false;
+                    if (__ballot(!same) == 0ull && (uint32_t)(k0 - base) < (uint32_t)kWinKeys) {
+                        double part = 0.0;
+                        uint32_t c = 0;
 #pragma unroll
-                    for (int d = 32; d > 0; d >>= 1) {
-                        const long long pb = __double_as_longlong(part);
-                        const int lo2 = __shfl_xor((int)(uint32_t)pb, d, 64), hi2 = __shfl_xor((int)(uint32_t)((unsigned long long)pb >> 32), d, 64);
-                        part += __longlong_as_double((long long)(((unsigned long long)(uint32_t)hi2 << 32) | (uint32_t)lo2));
-                        c += (uint32_t)__shfl_xor((int)c, d, 64);
+                        for (int j = 0; j < 4; j++) if (live & (1u << j)) { part += (double)vv[j]; c++; }
+#pragma unroll
+                        for (int d = 32; d > 0; d >>= 1) {
+                            const long long pb = __double_as_longlong(part);
+                            const int lo2 = __shfl_xor((int)(uint32_t)pb, d, 64), hi2 = __shfl_xor((int)(uint32_t)((unsigned long long)pb >> 32), d, 64);
+                            part += __longlong_as_double((long long)(((unsigned long long)(uint32_t)hi2 << 32) | (uint32_t)lo2));
+                            c += (uint32_t)__shfl_xor((int)c, d, 64);
+                        }
+                        if (lane == 0) {
+                            const int off = k0 - base;
+                            const uint32_t slot = ((uint32_t)off << kWinRL) | rep;
+                            if constexpr (FSUM) unsafeAtomicAdd(reinterpret_cast<double *>(&s_sum[slot]), part);
+                            atomicAdd(&s_cnt[slot], c);
+                        }
+                        live = 0;
                     }
-                    if (lane == 0) {
-                        const uint32_t slot = ((uint32_t)(mn - base) << kWinRL) | rep;
-                        if constexpr (FSUM) unsafeAtomicAdd(reinterpret_cast<double *>(&s_sum[slot]), part);
-                        atomicAdd(&s_cnt[slot], c);
-                    }
-                    live = 0;
                 }
             }
-            mn = 0x7FFFFFFF; mx = -1;
+            uint32_t nout = 0;
+            int cand = -1;
 #pragma unroll
             for (int j = 0; j < 4; j++)
                 if (live & (1u << j)) {
                     const uint32_t off = (uint32_t)(kk[j] - base);
-                    const uint32_t x = __float_as_uint(vv[j]);
-                    if (off < (uint32_t)kWinKeys) {
+                    if (open && off < (uint32_t)kWinKeys) {
                         const uint32_t slot = (off << kWinRL) | rep;
+                        const uint32_t x = __float_as_uint(vv[j]);
                         if constexpr (FSUM) vop_atomic<VOP_F32SUM>(&s_sum[slot], x);
                         else if constexpr (!CNT) vop_atomic_rt(VOP, &s_sum[slot], apply_xf(xf, x));
                         atomicAdd(&s_cnt[slot], 1u);
                         live &= ~(1u << j);
-                    } else if (last) {                                    // more clusters in one batch than turns
-                        if constexpr (FSUM) vop_atomic<VOP_F32SUM>(&gsum[kk[j]], x);
-                        else if constexpr (!CNT) vop_atomic_rt(VOP, &gsum[kk[j]], apply_xf(xf, x));
-                        atomicAdd(&gcnt[kk[j]], 1ull);
-                        outside++;
-                    } else { mn = min(mn, kk[j]); mx = max(mx, kk[j]); }
+                    } else { nout++; if (cand < 0) cand = kk[j]; }
                 }
-            if (bhi - base < kWinKeys || last) break;                     // every row of the batch was inside (the usual case: one barrier per batch)
+            const unsigned long long pend = __ballot(nout != 0u);
+            if (pend != 0ull) {                                           // (wave-uniform) the wave's waiting rows, and the key of the MIDDLE lane that has any
+                uint32_t wsum = nout;
 #pragma unroll
-            for (int d = 32; d > 0; d >>= 1) { mn = min(mn, __shfl_xor(mn, d, 64)); mx = max(mx, __shfl_xor(mx, d, 64)); }
+                for (int d = 32; d > 0; d >>= 1) wsum += (uint32_t)__shfl_xor((int)wsum, d, 64);
+                unsigned long long half = pend;
+                for (int i = __popcll(pend) / 2; i > 0; i--) half &= half - 1ull;
+                const int c0 = __shfl(cand, __ffsll((long long)half) - 1, 64);
+                if (lane == 0) { atomicAdd(&s_out[ph], wsum); s_wout[ph][wave] = wsum; s_cand[ph][wave] = c0; }
+            }
+            __syncthreads();
+            const uint32_t tout = s_out[ph];                              // (one word in the usual case: nothing waits)
+            int pick = -1;                                                // the key picked by the wave with the most waiting rows: strays are few, the cluster's rows many
+            if (tout > (uint32_t)kWinStray) {
+                uint32_t most = 0;
+#pragma unroll
+                for (int w = 0; w < 16; w++) { const uint32_t c = s_wout[ph][w]; if (c > most) { most = c; pick = s_cand[ph][w]; } }
+            }
+            const int clr = ph == 0 ? 2 : ph - 1;
+            ph = ph == 2 ? 0 : ph + 1;
+            if (tid < 16) s_wout[clr][tid] = 0u;
+            if (tid == 0) s_out[clr] = 0u;
+            if (tout == 0u) break;
+            if (tout <= (uint32_t)kWinStray || turn == kWinTurns - 1) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) if (live & (1u << j)) to_global(kk[j], __float_as_uint(vv[j]));
+                break;
+            }
+            if (open) write_out();
+            base = max(0, pick - kWinKeys / 2);                           // (the picked key lies somewhere inside its cluster: the window around it)
+            open = true; moved++;
         }
     }
     __syncthreads();
-    if (dlo <= dhi) write_out();
+    if (open) write_out();
     // ragged tail (n % 4 rows): the first lanes of workgroup 0, straight to the accumulators
     if (blockIdx.x == 0) {
         const int64_t t = nvec * kVec + tid;
@@ -501,13 +531,15 @@ __global__ __launch_bounds__(1024) void fgb_windowx_kernel(
     constexpr int SLOTS = kWinKeys << kWinXRL;
     u64 *s_a0 = reinterpret_cast<u64 *>(lds_raw);
     uint32_t *s_cnt = reinterpret_cast<uint32_t *>(lds_raw + sizeof(u64) * SLOTS), *s_a1 = s_cnt + SLOTS, *s_a2 = s_a1 + SLOTS;
-    __shared__ int s_lo[3], s_hi[3];
-    const int tid = threadIdx.x, lane = tid & 63;
+    __shared__ uint32_t s_out[3], s_wout[3][16];                         // (the turns' words: as in fgb_window_kernel)
+    __shared__ int s_cand[3][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool has2 = A.c2 != nullptr;
     const u64 id0 = vop_identity(A.vop0);
     const uint32_t id1 = (uint32_t)vop_identity(A.vop1), id2 = (uint32_t)vop_identity(A.vop2);
     for (int i = tid; i < SLOTS; i += 1024) { s_a0[i] = id0; s_cnt[i] = 0u; s_a1[i] = id1; s_a2[i] = id2; }
-    if (tid < 3) { s_lo[tid] = 0x7FFFFFFF; s_hi[tid] = -1; }
+    if (tid < 48) { s_cand[tid / 16][tid % 16] = -1; s_wout[tid / 16][tid % 16] = 0u; }
+    if (tid < 3) s_out[tid] = 0u;
     __syncthreads();
     const uint32_t rep = (uint32_t)tid & (uint32_t)(kWinXRep - 1);
     const int64_t nvec = n / kVec;
@@ -523,8 +555,8 @@ __global__ __launch_bounds__(1024) void fgb_windowx_kernel(
     };
     auto ldu = [&](const uint32_t *c, int64_t q) -> u4v { return __builtin_nontemporal_load(reinterpret_cast<const u4v *>(c) + q); };
     const bool same1 = A.c1 == A.c0, same2 = A.c2 == A.c0;
-    bool bad = false;
-    int base = 0, dlo = 0x7FFFFFFF, dhi = -1;
+    bool bad = false, open = false;
+    int base = 0;
     uint32_t moved = 0, outside = 0;
     auto global_row = [&](int key, uint32_t x0, uint32_t x1, uint32_t x2) {
         vop_atomic_rt(A.vop0, &A.g0[key], apply_xf(A.xf0, x0));
@@ -533,16 +565,19 @@ __global__ __launch_bounds__(1024) void fgb_windowx_kernel(
         if (has2) { const u64 w2 = apply_xf(A.xf2, x2); if (A.vop2 == VOP_U32MIN) atomicMin(&A.g2[key], w2); else atomicMax(&A.g2[key], w2); }
         atomicAdd(&gcnt[key], 1ull);
     };
-    auto write_out = [&]() {
-        for (int g = dlo - base + tid; g <= dhi - base; g += 1024) {
+    auto write_out = [&]() {                                              // (all 1024 keys, one per thread: see fgb_window_kernel)
+        for (int g = tid; g < kWinKeys; g += 1024) {
             u64 a0 = id0; uint32_t c = 0, a1 = id1, a2 = id2;
 #pragma unroll
             for (int r = 0; r < kWinXRep; r++) {
                 const int slot = (g << kWinXRL) + r;
-                a0 = vop_merge(A.vop0, a0, s_a0[slot]); c += s_cnt[slot];
-                a1 = A.vop1 == VOP_U32MIN ? min(a1, s_a1[slot]) : max(a1, s_a1[slot]);
-                a2 = A.vop2 == VOP_U32MIN ? min(a2, s_a2[slot]) : max(a2, s_a2[slot]);
-                s_a0[slot] = id0; s_cnt[slot] = 0u; s_a1[slot] = id1; s_a2[slot] = id2;
+                const uint32_t cr = s_cnt[slot];
+                if (cr) {
+                    a0 = vop_merge(A.vop0, a0, s_a0[slot]); c += cr;
+                    a1 = A.vop1 == VOP_U32MIN ? min(a1, s_a1[slot]) : max(a1, s_a1[slot]);
+                    a2 = A.vop2 == VOP_U32MIN ? min(a2, s_a2[slot]) : max(a2, s_a2[slot]);
+                    s_a0[slot] = id0; s_cnt[slot] = 0u; s_a1[slot] = id1; s_a2[slot] = id2;
+                }
             }
             if (c) {
                 vop_atomic_partial_rt(A.vop0, &A.g0[base + g], a0);
@@ -551,7 +586,6 @@ __global__ __launch_bounds__(1024) void fgb_windowx_kernel(
                 atomicAdd(&gcnt[base + g], (unsigned long long)c);
             }
         }
-        dlo = 0x7FFFFFFF; dhi = -1;
         __syncthreads();
     };
     int ph = 0;
@@ -569,68 +603,61 @@ __global__ __launch_bounds__(1024) void fgb_windowx_kernel(
         const int kk[4] = {(int)ka.x, (int)ka.y, (int)ka.z, (int)ka.w};
         const uint32_t v0[4] = {x0.x, x0.y, x0.z, x0.w}, v1[4] = {x1.x, x1.y, x1.z, x1.w}, v2[4] = {x2.x, x2.y, x2.z, x2.w};
         uint32_t live = 0;
-        int mn = 0x7FFFFFFF, mx = -1;
 #pragma unroll
         for (int j = 0; j < 4; j++)
             if (have && cmp_f32<OP>(pv[j], thr)) {
-                if ((uint32_t)kk[j] < (uint64_t)G) { live |= 1u << j; mn = min(mn, kk[j]); mx = max(mx, kk[j]); }
+                if ((uint32_t)kk[j] < (uint64_t)G) live |= 1u << j;
                 else bad = true;
             }
+        for (int turn = 0;; turn++) {                                     // (the turns: see fgb_window_kernel)
+            // a wave whose surviving rows all hold ONE key folds them in registers and touches the window once
+            const unsigned long long lv = __ballot(live != 0u);
+            if (open && lv != 0ull && A.vop0 != VOP_U32PROD) {
+                const int mine = kk[live ? __ffs((int)live) - 1 : 0];
+                const int k0 = __shfl(mine, __ffsll((long long)lv) - 1, 64);
+                bool same = true;
 #pragma unroll
-        for (int d = 32; d > 0; d >>= 1) { mn = min(mn, __shfl_xor(mn, d, 64)); mx = max(mx, __shfl_xor(mx, d, 64)); }
-        for (int turn = 0;; turn++) {
-            if (lane == 0 && mx >= 0) { atomicMin(&s_lo[ph], mn); atomicMax(&s_hi[ph], mx); }
-            __syncthreads();
-            const int blo = s_lo[ph], bhi = s_hi[ph];
-            const int clr = ph == 0 ? 2 : ph - 1;
-            ph = ph == 2 ? 0 : ph + 1;
-            if (tid == 0) { s_lo[clr] = 0x7FFFFFFF; s_hi[clr] = -1; }
-            if (blo > bhi) break;
-            if (blo < base || bhi - base >= kWinKeys) {
-                if (dlo <= dhi) write_out();
-                base = (blo < base && bhi - blo < kWinKeys) ? max(0, bhi - kWinKeys + 1) : blo;
-                moved++;
-            }
-            const bool last = turn == kWinTurns - 1;
-            dlo = min(dlo, blo); dhi = max(dhi, bhi - base >= kWinKeys ? base + (kWinKeys - 1) : bhi);
-            // a wave whose surviving rows all hold ONE key folds them in registers and touches the window once (see fgb_window_kernel)
-            if (turn == 0 && mn == mx && (uint32_t)(mn - base) < (uint32_t)kWinKeys && A.vop0 != VOP_U32PROD) {
-                u64 part = id0;
-                uint32_t c = 0, e1 = id1, e2 = id2;
+                for (int j = 0; j < 4; j++) if ((live & (1u << j)) && kk[j] != k0) same = false;
+                if (__ballot(!same) == 0ull && (uint32_t)(k0 - base) < (uint32_t)kWinKeys) {
+                    u64 part = id0;
+                    uint32_t c = 0, e1 = id1, e2 = id2;
 #pragma unroll
-                for (int j = 0; j < 4; j++)
-                    if (live & (1u << j)) {
-                        const uint32_t x = apply_xf(A.xf0, v0[j]);
-                        part = vop_merge(A.vop0, part, A.vop0 == VOP_F32SUM ? (u64)__double_as_longlong((double)__uint_as_float(x)) : (u64)x);
-                        const uint32_t w1 = apply_xf(A.xf1, v1[j]);
-                        e1 = A.vop1 == VOP_U32MIN ? min(e1, w1) : max(e1, w1);
-                        if (has2) { const uint32_t w2 = apply_xf(A.xf2, v2[j]); e2 = A.vop2 == VOP_U32MIN ? min(e2, w2) : max(e2, w2); }
-                        c++;
+                    for (int j = 0; j < 4; j++)
+                        if (live & (1u << j)) {
+                            const uint32_t x = apply_xf(A.xf0, v0[j]);
+                            part = vop_merge(A.vop0, part, A.vop0 == VOP_F32SUM ? (u64)__double_as_longlong((double)__uint_as_float(x)) : (u64)x);
+                            const uint32_t w1 = apply_xf(A.xf1, v1[j]);
+                            e1 = A.vop1 == VOP_U32MIN ? min(e1, w1) : max(e1, w1);
+                            if (has2) { const uint32_t w2 = apply_xf(A.xf2, v2[j]); e2 = A.vop2 == VOP_U32MIN ? min(e2, w2) : max(e2, w2); }
+                            c++;
+                        }
+#pragma unroll
+                    for (int d = 32; d > 0; d >>= 1) {
+                        const uint32_t plo = (uint32_t)__shfl_xor((int)(uint32_t)part, d, 64), phi = (uint32_t)__shfl_xor((int)(uint32_t)(part >> 32), d, 64);
+                        part = vop_merge(A.vop0, part, ((u64)phi << 32) | plo);
+                        const uint32_t o1 = (uint32_t)__shfl_xor((int)e1, d, 64), o2 = (uint32_t)__shfl_xor((int)e2, d, 64);
+                        e1 = A.vop1 == VOP_U32MIN ? min(e1, o1) : max(e1, o1);
+                        e2 = A.vop2 == VOP_U32MIN ? min(e2, o2) : max(e2, o2);
+                        c += (uint32_t)__shfl_xor((int)c, d, 64);
                     }
-#pragma unroll
-                for (int d = 32; d > 0; d >>= 1) {
-                    const uint32_t plo = (uint32_t)__shfl_xor((int)(uint32_t)part, d, 64), phi = (uint32_t)__shfl_xor((int)(uint32_t)(part >> 32), d, 64);
-                    part = vop_merge(A.vop0, part, ((u64)phi << 32) | plo);
-                    const uint32_t o1 = (uint32_t)__shfl_xor((int)e1, d, 64), o2 = (uint32_t)__shfl_xor((int)e2, d, 64);
-                    e1 = A.vop1 == VOP_U32MIN ? min(e1, o1) : max(e1, o1);
-                    e2 = A.vop2 == VOP_U32MIN ? min(e2, o2) : max(e2, o2);
-                    c += (uint32_t)__shfl_xor((int)c, d, 64);
+                    if (lane == 0) {
+                        const int off = k0 - base;
+                        const uint32_t slot = ((uint32_t)off << kWinXRL) | rep;
+                        vop_atomic_partial_rt(A.vop0, &s_a0[slot], part);
+                        if (A.vop1 == VOP_U32MIN) atomicMin(&s_a1[slot], e1); else atomicMax(&s_a1[slot], e1);
+                        if (has2) { if (A.vop2 == VOP_U32MIN) atomicMin(&s_a2[slot], e2); else atomicMax(&s_a2[slot], e2); }
+                        atomicAdd(&s_cnt[slot], c);
+                    }
+                    live = 0;
                 }
-                if (lane == 0) {
-                    const uint32_t slot = ((uint32_t)(mn - base) << kWinXRL) | rep;
-                    vop_atomic_partial_rt(A.vop0, &s_a0[slot], part);
-                    if (A.vop1 == VOP_U32MIN) atomicMin(&s_a1[slot], e1); else atomicMax(&s_a1[slot], e1);
-                    if (has2) { if (A.vop2 == VOP_U32MIN) atomicMin(&s_a2[slot], e2); else atomicMax(&s_a2[slot], e2); }
-                    atomicAdd(&s_cnt[slot], c);
-                }
-                live = 0;
             }
-            mn = 0x7FFFFFFF; mx = -1;
+            uint32_t nout = 0;
+            int cand = -1;
 #pragma unroll
             for (int j = 0; j < 4; j++)
                 if (live & (1u << j)) {
                     const uint32_t off = (uint32_t)(kk[j] - base);
-                    if (off < (uint32_t)kWinKeys) {
+                    if (open && off < (uint32_t)kWinKeys) {
                         const uint32_t slot = (off << kWinXRL) | rep;
                         vop_atomic_rt(A.vop0, &s_a0[slot], apply_xf(A.xf0, v0[j]));
                         const uint32_t w1 = apply_xf(A.xf1, v1[j]);
@@ -638,16 +665,43 @@ __global__ __launch_bounds__(1024) void fgb_windowx_kernel(
                         if (has2) { const uint32_t w2 = apply_xf(A.xf2, v2[j]); if (A.vop2 == VOP_U32MIN) atomicMin(&s_a2[slot], w2); else atomicMax(&s_a2[slot], w2); }
                         atomicAdd(&s_cnt[slot], 1u);
                         live &= ~(1u << j);
-                    } else if (last) { global_row(kk[j], v0[j], v1[j], v2[j]); outside++; }
-                    else { mn = min(mn, kk[j]); mx = max(mx, kk[j]); }
+                    } else { nout++; if (cand < 0) cand = kk[j]; }
                 }
-            if (bhi - base < kWinKeys || last) break;
+            const unsigned long long pend = __ballot(nout != 0u);
+            if (pend != 0ull) {                                           // (wave-uniform) the wave's waiting rows, and the key of the MIDDLE lane that has any
+                uint32_t wsum = nout;
 #pragma unroll
-            for (int d = 32; d > 0; d >>= 1) { mn = min(mn, __shfl_xor(mn, d, 64)); mx = max(mx, __shfl_xor(mx, d, 64)); }
+                for (int d = 32; d > 0; d >>= 1) wsum += (uint32_t)__shfl_xor((int)wsum, d, 64);
+                unsigned long long half = pend;
+                for (int i = __popcll(pend) / 2; i > 0; i--) half &= half - 1ull;
+                const int c0 = __shfl(cand, __ffsll((long long)half) - 1, 64);
+                if (lane == 0) { atomicAdd(&s_out[ph], wsum); s_wout[ph][wave] = wsum; s_cand[ph][wave] = c0; }
+            }
+            __syncthreads();
+            const uint32_t tout = s_out[ph];                              // (one word in the usual case: nothing waits)
+            int pick = -1;                                                // the key picked by the wave with the most waiting rows: strays are few, the cluster's rows many
+            if (tout > (uint32_t)kWinStray) {
+                uint32_t most = 0;
+#pragma unroll
+                for (int w = 0; w < 16; w++) { const uint32_t c = s_wout[ph][w]; if (c > most) { most = c; pick = s_cand[ph][w]; } }
+            }
+            const int clr = ph == 0 ? 2 : ph - 1;
+            ph = ph == 2 ? 0 : ph + 1;
+            if (tid < 16) s_wout[clr][tid] = 0u;
+            if (tid == 0) s_out[clr] = 0u;
+            if (tout == 0u) break;
+            if (tout <= (uint32_t)kWinStray || turn == kWinTurns - 1) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) if (live & (1u << j)) { global_row(kk[j], v0[j], v1[j], v2[j]); outside++; }
+                break;
+            }
+            if (open) write_out();
+            base = max(0, pick - kWinKeys / 2);
+            open = true; moved++;
         }
     }
     __syncthreads();
-    if (dlo <= dhi) write_out();
+    if (open) write_out();
     if (blockIdx.x == 0) {                                                // ragged tail (n % 4 rows)
         const int64_t t = nvec * kVec + tid;
         if (t < n && cmp_f32<OP>(OP == kNoPred ? 0.0f : OP == kMaskPred ? mask_bit(p, t) : p[t], thr)) {
@@ -2525,7 +2579,7 @@ static int plan_prepare_partition(hark_context *ctx, hark_fgb_plan *pl)
 
 // Does this key column take the window path?  The plan's knob ("window": 1 always, 2 never; HARK_FGB_WINDOW=1 / 0 the same for
 // every plan), else the test of fgb_cluster_test_kernel -- one small launch and one synchronisation, once per plan and column:
-// the verdict sticks to (column, rows) until a check finds that the window path sent more than 1 row in 64 to global atomics.
+// the verdict sticks to (column, rows) until a check finds that the window path sent more than a third of the rows to global atomics.
 static int fgb_window_wanted(hark_context *ctx, hark_fgb_plan *pl, const int32_t *k, int64_t n, bool *window)
 {
     *window = false;
@@ -2734,7 +2788,8 @@ static int fgb_check_err(hark_context *ctx, hark_fgb_plan *pl)
     {   // the window path since the last check: rows it could not keep in LDS (never reset on the device)
         const int64_t outside = (int64_t)(uint32_t)e[5] - (int64_t)(uint32_t)pl->win_outside_seen, rows = pl->win_rows - pl->win_rows_seen;
         pl->win_moves = (int64_t)(uint32_t)e[4];
-        if (rows > 0 && (uint32_t)outside > (uint64_t)rows / 64) pl->win_verdict = 0;          // not a clustered column after all: the partition path from now on
+        if (rows > 0 && (uint32_t)outside > (uint64_t)rows / 3) pl->win_verdict = 0;           // not a clustered column after all: the partition path from now on
+        // (a third: stray rows cost two global atomics each, but a column that is four fifths in order still takes 46 ms per 1e9 rows through the partition, 18 here)
         pl->win_outside_seen = (uint32_t)e[5]; pl->win_rows_seen = pl->win_rows;
     }
     {   // the predicate's selectivity since the last check (the next run picks its geometry by it)

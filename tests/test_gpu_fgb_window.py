@@ -22,6 +22,11 @@ def _keys(shape, n, G, rng):
         for a in range(0, n, 1 << 16): kk[a:a + (1 << 16)] = np.sort(kk[a:a + (1 << 16)])
         return kk
     if shape == "sorted": return np.sort(kk)
+    if shape.startswith("noisy"):                                     # sorted, then that many per cent of the rows overwritten with keys from anywhere (late rows in a table kept in key order)
+        s = np.sort(kk)
+        idx = rng.integers(0, n, size=int(n * float(shape[5:]) / 100))
+        s[idx] = kk[idx]
+        return s
     if shape == "descending": return np.sort(kk)[::-1].copy()
     if shape.startswith("runs"):                                       # sorted, then runs of w rows shuffled as wholes (w need not divide a batch)
         w = int(shape[4:])
@@ -68,7 +73,7 @@ def _run(eng, oracle, kk, G, use_pred=True, count_only=False, cmp=">", thr=0.5, 
     return moves
 
 
-@pytest.mark.parametrize("shape", ["sorted", "descending", "runs8192", "runs5000", "runs1024", "two_clusters", "six_clusters", "random"])
+@pytest.mark.parametrize("shape", ["sorted", "descending", "noisy0.2", "noisy3", "noisy25", "runs8192", "runs5000", "runs1024", "two_clusters", "six_clusters", "random"])
 @pytest.mark.parametrize("n,G", [(3_000_017, 1 << 20), (1_100_003, 300_000)])
 def test_window_path_forced_on_every_shape(eng, oracle, shape, n, G):
     """window=1 sends any column through the window kernel: rows inside the window are added in LDS, a batch that straddles
@@ -90,7 +95,7 @@ def test_the_test_picks_the_window_for_sorted_keys_and_the_partition_for_shuffle
     from harkdb_amd.engine import FgbPlan
     rng = np.random.default_rng(6)
     n, G = 2_000_003, 1 << 17                                          # ~15 rows per key: rows 512 apart are ~34 keys apart when the column is sorted
-    for shape, expect in (("sorted", True), ("descending", True), ("runs8192", True), ("random", False)):
+    for shape, expect in (("sorted", True), ("descending", True), ("noisy2", True), ("runs8192", True), ("random", False)):
         kk = _keys(shape, n, G, rng)
         pp = rng.random(n, dtype=np.float32); vv = rng.integers(0, 16, size=n).astype(np.float32)
         p, k, v = eng.alloc(n * 4), eng.alloc(n * 4), eng.alloc(n * 4)
@@ -131,7 +136,7 @@ def test_key_out_of_range_is_bounds_error(eng):
         eng.free(ptr)
 
 
-@pytest.mark.parametrize("n,G,order", [(1_300_000, 1 << 17, "sorted"), (1_300_000, 1 << 17, "descending"), (2_100_000, 1 << 18, "runs8192"), (1_200_000, 1 << 17, "random"), (1_400_000, 1 << 17, "blocks")])
+@pytest.mark.parametrize("n,G,order", [(1_300_000, 1 << 17, "sorted"), (1_300_000, 1 << 17, "descending"), (2_100_000, 1 << 18, "runs8192"), (1_200_000, 1 << 17, "random"), (1_400_000, 1 << 17, "blocks"), (1_300_000, 1 << 17, "noisy1")])
 def test_reference_query_groupby_on_a_table_kept_in_key_order(eng, oracle, n, G, order):
     """query_groupby (main.fut:9) with several aggregates of one and of three columns on a table SORTED by its key column: the
     statistics / pair / triple passes run through the window kernel (fgb_windowx_kernel) -- same table as the oracle's."""
@@ -150,7 +155,7 @@ def test_reference_query_groupby_on_a_table_kept_in_key_order(eng, oracle, n, G,
     t.free()
 
 
-@pytest.mark.parametrize("order", ["sorted", "descending", "random", "blocks"])
+@pytest.mark.parametrize("order", ["sorted", "descending", "noisy1", "random", "blocks"])
 def test_filter_groupby_entry_typed_aggregates_on_a_table_kept_in_key_order(eng, order):
     """hark_entry_filter_groupby: SUM / MAX / MIN / AVG / COUNT of f32, i32 and u32 columns under a predicate, keys sorted: the
     one-column statistics pass, the pair / triple passes and the single passes all take the window kernels; against pandas."""

@@ -36,6 +36,12 @@ def shape(name):
     if name == "random": k.copy_(k0); return
     if name == "sorted": k.copy_(k0.sort().values); return
     if name == "descending": k.copy_(k0.sort(descending=True).values); return
+    if name.startswith("noisy"):                                  # sorted, then NN per cent of the rows overwritten with keys from anywhere (late rows in a table kept in key order)
+        k.copy_(k0.sort().values)
+        m = int(N * float(name[5:]) / 100)
+        idx = torch.randint(0, N, (m,), device=dev)
+        k[idx] = k0[idx]
+        return
     w = int(name[6:] if name.startswith("blocks") else name[4:])
     m = N // w
     if name.startswith("blocks"):                                  # sorted inside blocks of w rows

@@ -30,6 +30,11 @@ def shape(name):
     if name == "random": return probe
     if name == "sorted": return probe.sort().values
     if name == "descending": return probe.sort(descending=True).values
+    if name.startswith("noisy"):                                    # sorted, then NN per cent of the rows overwritten with keys from anywhere
+        s = probe.sort().values
+        idx = torch.randint(0, n, (int(n * float(name[5:]) / 100),), device=dev, generator=g)
+        s[idx] = probe[idx]
+        return s
     if name.startswith("blocks"):                                   # sorted inside blocks of that many rows
         w = int(name[6:])
         k = n // w
