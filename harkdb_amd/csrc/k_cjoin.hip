@@ -39,7 +39,8 @@ template <typename K> struct CIdx { static constexpr int N = 32768 / (int)sizeof
 //     neighbouring quantiles -- a wave's rows then share a few lines of the build side (sorted runs of 256 rows in shuffled
 //     order: 1.7 ms searched, while the partition overruns its slabs and the probe side gets sorted: 7.9; runs of 16 rows:
 //     2.0 searched, 1.3 partitioned -- rows 16 apart lie in different runs there, and the verdict is "scattered").
-// Both against the same measure for rows ANYWHERE apart (the key of another pair): a column of few distinct keys, or one that
+// The second measure decides first (this path), then "neighbouring rows within a quarter of a bucket" (rotated loads), then the first.
+// All against the same measure for rows ANYWHERE apart (the key of another pair): a column of few distinct keys, or one that
 // mostly misses the build side's range, is close to itself everywhere.  One pair per thread: the kernel waits for ~3000
 // address translations of rows all over the columns, not for its arithmetic (4096 pairs: 75 us).
 constexpr int kCtSample = 1024, kCtPairs = 1024, kCtFar = 2048, kCtClose = 16, kCtNear = 4, kCtKeys = 32;

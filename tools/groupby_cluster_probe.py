@@ -50,7 +50,7 @@ def shape(name):
     k.copy_(s); k[:m * w] = s[:m * w].view(m, w)[torch.randperm(m, device=dev)].reshape(-1)
 
 
-SHAPES = sys.argv[2:] or ["random", "sorted", "descending", "blocks1000000", "blocks65536", "blocks8192", "runs4096", "runs256", "runs16"]
+SHAPES = sys.argv[2:] or ["random", "sorted", "descending", "noisy0.1", "noisy1", "noisy5", "noisy20", "blocks1000000", "blocks65536", "blocks8192", "runs4096", "runs256", "runs16"]
 for name in SHAPES:
     shape(name)
     torch.cuda.synchronize()

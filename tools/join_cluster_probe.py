@@ -48,7 +48,7 @@ def shape(name):
     raise SystemExit(f"unknown shape {name}")
 
 
-CASES = ("random", "sorted", "descending", "blocks1000000", "blocks100000", "blocks30000", "blocks10000", "runs4096", "runs256", "runs16", "match_random", "match_sorted", "match_runs4096")
+CASES = ("random", "sorted", "descending", "noisy1", "noisy20", "blocks1000000", "blocks100000", "blocks30000", "blocks10000", "runs4096", "runs256", "runs16", "match_random", "match_sorted", "match_runs4096")
 if len(sys.argv) > 1: CASES = tuple(sys.argv[1:])
 for case in CASES:
     probe = wide(shape(case))
