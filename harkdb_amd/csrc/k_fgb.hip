@@ -324,12 +324,11 @@ __global__ __launch_bounds__(1024) void fgb_window_kernel(
     constexpr int SLOTS = kWinKeys << kWinRL;
     u64 *s_sum = reinterpret_cast<u64 *>(lds_raw);
     uint32_t *s_cnt = reinterpret_cast<uint32_t *>(lds_raw + sizeof(u64) * SLOTS);
-    __shared__ uint32_t s_out[3], s_wout[3][16];                         // rows of a turn outside the window, all and per wave (three sets of words in rotation, see below)
-    __shared__ int s_cand[3][16];                                        // ... and one of their keys
+    __shared__ uint32_t s_out[3];                                        // rows of a turn outside the window (three sets of words in rotation, see below)
+    __shared__ unsigned long long s_best[3];                             // ... and the wave with the most of them: rows << 32 | one of their keys
     const int tid = threadIdx.x, lane = tid & 63;
     for (int i = tid; i < SLOTS; i += 1024) { s_sum[i] = vop_identity(VOP); s_cnt[i] = 0u; }
-    if (tid < 48) { s_cand[tid / 16][tid % 16] = -1; s_wout[tid / 16][tid % 16] = 0u; }
-    if (tid < 3) s_out[tid] = 0u;
+    if (tid < 3) { s_out[tid] = 0u; s_best[tid] = 0ull; }
     __syncthreads();
     const uint32_t rep = (uint32_t)tid & (uint32_t)(kWinRep - 1);
     const int64_t nvec = n / kVec;
@@ -358,7 +357,6 @@ __global__ __launch_bounds__(1024) void fgb_window_kernel(
     bool bad = false, open = false;                                       // open: a window exists (the first batch makes one)
     int base = 0;                                                         // the window [base, base + kWinKeys)
     uint32_t moved = 0, outside = 0;
-    const int wave = tid >> 6;
     // the window -> global accumulators: a key per thread, all of them (every thread calls it, behind a turn's barrier -- the rows of that turn
     // are in --; ends with a barrier).  (Tracking the touched range cost a reduction and a barrier more per move than reading 1024 keys does.)
     auto write_out = [&]() {
@@ -413,6 +411,7 @@ __global__ __launch_bounds__(1024) void fgb_window_kernel(
         // (the words: a turn publishes in set ph, reads it behind the barrier, and clears the set of the turn before it -- last read
         // before this barrier, next written behind the next one)
         for (int turn = 0;; turn++) {
+            const uint32_t n0 = (uint32_t)__popc(live);                  // this lane's rows at the turn's start
             if constexpr (FSUM || CNT) {
                 // a wave whose surviving rows all hold ONE key (a sorted column: ~950 rows per key at the headline's sizes) adds them up
                 // in registers and touches the window once, instead of 64 lanes queueing at the key's eight replicas
@@ -461,29 +460,27 @@ __global__ __launch_bounds__(1024) void fgb_window_kernel(
                     } else { nout++; if (cand < 0) cand = kk[j]; }
                 }
             const unsigned long long pend = __ballot(nout != 0u);
-            if (pend != 0ull) {                                           // (wave-uniform) the wave's waiting rows, and the key of the MIDDLE lane that has any
-                uint32_t wsum = nout;
+            if (pend != 0ull) {                                           // (wave-uniform) the wave's waiting rows, and the key of a lane in the middle that has any
+                uint32_t both = (n0 << 16) | nout;                        // (rows of the wave at the turn's start, rows that wait now: <= 256 each)
 #pragma unroll
-                for (int d = 32; d > 0; d >>= 1) wsum += (uint32_t)__shfl_xor((int)wsum, d, 64);
-                unsigned long long half = pend;
-                for (int i = __popcll(pend) / 2; i > 0; i--) half &= half - 1ull;
-                const int c0 = __shfl(cand, __ffsll((long long)half) - 1, 64);
-                if (lane == 0) { atomicAdd(&s_out[ph], wsum); s_wout[ph][wave] = wsum; s_cand[ph][wave] = c0; }
+                for (int d = 32; d > 0; d >>= 1) both += (uint32_t)__shfl_xor((int)both, d, 64);
+                const uint32_t wsum = both & 0xFFFFu, wall = both >> 16;
+                const int mid = (pend >> 32) != 0ull ? 31 + __ffsll((long long)(pend >> 32)) : 63 - __clzll((long long)pend);   // the first such lane from 32 on, else the last below
+                const int c0 = __shfl(cand, mid, 64);
+                // A wave MOST of whose rows wait says "the keys have moved on" (rows << 32 | key: the largest word is the wave with the most
+                // of them); a wave with a few waiting rows holds strays, however many such waves there are (a fifth of all rows out of
+                // place: 800 strays per batch, 50 per wave -- moving the window after them cost 57 ms per 1e9 rows)
+                if (lane == 0) { atomicAdd(&s_out[ph], wsum); if (2u * wsum >= wall) atomicMax(&s_best[ph], ((unsigned long long)wsum << 32) | (uint32_t)c0); }
             }
             __syncthreads();
             const uint32_t tout = s_out[ph];                              // (one word in the usual case: nothing waits)
-            int pick = -1;                                                // the key picked by the wave with the most waiting rows: strays are few, the cluster's rows many
-            if (tout > (uint32_t)kWinStray) {
-                uint32_t most = 0;
-#pragma unroll
-                for (int w = 0; w < 16; w++) { const uint32_t c = s_wout[ph][w]; if (c > most) { most = c; pick = s_cand[ph][w]; } }
-            }
+            const unsigned long long best = s_best[ph];
+            const int pick = (int)(uint32_t)best;
             const int clr = ph == 0 ? 2 : ph - 1;
             ph = ph == 2 ? 0 : ph + 1;
-            if (tid < 16) s_wout[clr][tid] = 0u;
-            if (tid == 0) s_out[clr] = 0u;
+            if (tid == 0) { s_out[clr] = 0u; s_best[clr] = 0ull; }
             if (tout == 0u) break;
-            if (tout <= (uint32_t)kWinStray || turn == kWinTurns - 1) {
+            if (tout <= (uint32_t)kWinStray || best == 0ull || turn == kWinTurns - 1) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) if (live & (1u << j)) to_global(kk[j], __float_as_uint(vv[j]));
                 break;
@@ -531,15 +528,14 @@ __global__ __launch_bounds__(1024) void fgb_windowx_kernel(
     constexpr int SLOTS = kWinKeys << kWinXRL;
     u64 *s_a0 = reinterpret_cast<u64 *>(lds_raw);
     uint32_t *s_cnt = reinterpret_cast<uint32_t *>(lds_raw + sizeof(u64) * SLOTS), *s_a1 = s_cnt + SLOTS, *s_a2 = s_a1 + SLOTS;
-    __shared__ uint32_t s_out[3], s_wout[3][16];                         // (the turns' words: as in fgb_window_kernel)
-    __shared__ int s_cand[3][16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ uint32_t s_out[3];                                        // (the turns' words: as in fgb_window_kernel)
+    __shared__ unsigned long long s_best[3];
+    const int tid = threadIdx.x, lane = tid & 63;
     const bool has2 = A.c2 != nullptr;
     const u64 id0 = vop_identity(A.vop0);
     const uint32_t id1 = (uint32_t)vop_identity(A.vop1), id2 = (uint32_t)vop_identity(A.vop2);
     for (int i = tid; i < SLOTS; i += 1024) { s_a0[i] = id0; s_cnt[i] = 0u; s_a1[i] = id1; s_a2[i] = id2; }
-    if (tid < 48) { s_cand[tid / 16][tid % 16] = -1; s_wout[tid / 16][tid % 16] = 0u; }
-    if (tid < 3) s_out[tid] = 0u;
+    if (tid < 3) { s_out[tid] = 0u; s_best[tid] = 0ull; }
     __syncthreads();
     const uint32_t rep = (uint32_t)tid & (uint32_t)(kWinXRep - 1);
     const int64_t nvec = n / kVec;
@@ -610,6 +606,7 @@ __global__ __launch_bounds__(1024) void fgb_windowx_kernel(
                 else bad = true;
             }
         for (int turn = 0;; turn++) {                                     // (the turns: see fgb_window_kernel)
+            const uint32_t n0 = (uint32_t)__popc(live);
             // a wave whose surviving rows all hold ONE key folds them in registers and touches the window once
             const unsigned long long lv = __ballot(live != 0u);
             if (open && lv != 0ull && A.vop0 != VOP_U32PROD) {
@@ -668,29 +665,27 @@ __global__ __launch_bounds__(1024) void fgb_windowx_kernel(
                     } else { nout++; if (cand < 0) cand = kk[j]; }
                 }
             const unsigned long long pend = __ballot(nout != 0u);
-            if (pend != 0ull) {                                           // (wave-uniform) the wave's waiting rows, and the key of the MIDDLE lane that has any
-                uint32_t wsum = nout;
+            if (pend != 0ull) {                                           // (wave-uniform) the wave's waiting rows, and the key of a lane in the middle that has any
+                uint32_t both = (n0 << 16) | nout;                        // (rows of the wave at the turn's start, rows that wait now: <= 256 each)
 #pragma unroll
-                for (int d = 32; d > 0; d >>= 1) wsum += (uint32_t)__shfl_xor((int)wsum, d, 64);
-                unsigned long long half = pend;
-                for (int i = __popcll(pend) / 2; i > 0; i--) half &= half - 1ull;
-                const int c0 = __shfl(cand, __ffsll((long long)half) - 1, 64);
-                if (lane == 0) { atomicAdd(&s_out[ph], wsum); s_wout[ph][wave] = wsum; s_cand[ph][wave] = c0; }
+                for (int d = 32; d > 0; d >>= 1) both += (uint32_t)__shfl_xor((int)both, d, 64);
+                const uint32_t wsum = both & 0xFFFFu, wall = both >> 16;
+                const int mid = (pend >> 32) != 0ull ? 31 + __ffsll((long long)(pend >> 32)) : 63 - __clzll((long long)pend);   // the first such lane from 32 on, else the last below
+                const int c0 = __shfl(cand, mid, 64);
+                // A wave MOST of whose rows wait says "the keys have moved on" (rows << 32 | key: the largest word is the wave with the most
+                // of them); a wave with a few waiting rows holds strays, however many such waves there are (a fifth of all rows out of
+                // place: 800 strays per batch, 50 per wave -- moving the window after them cost 57 ms per 1e9 rows)
+                if (lane == 0) { atomicAdd(&s_out[ph], wsum); if (2u * wsum >= wall) atomicMax(&s_best[ph], ((unsigned long long)wsum << 32) | (uint32_t)c0); }
             }
             __syncthreads();
             const uint32_t tout = s_out[ph];                              // (one word in the usual case: nothing waits)
-            int pick = -1;                                                // the key picked by the wave with the most waiting rows: strays are few, the cluster's rows many
-            if (tout > (uint32_t)kWinStray) {
-                uint32_t most = 0;
-#pragma unroll
-                for (int w = 0; w < 16; w++) { const uint32_t c = s_wout[ph][w]; if (c > most) { most = c; pick = s_cand[ph][w]; } }
-            }
+            const unsigned long long best = s_best[ph];
+            const int pick = (int)(uint32_t)best;
             const int clr = ph == 0 ? 2 : ph - 1;
             ph = ph == 2 ? 0 : ph + 1;
-            if (tid < 16) s_wout[clr][tid] = 0u;
-            if (tid == 0) s_out[clr] = 0u;
+            if (tid == 0) { s_out[clr] = 0u; s_best[clr] = 0ull; }
             if (tout == 0u) break;
-            if (tout <= (uint32_t)kWinStray || turn == kWinTurns - 1) {
+            if (tout <= (uint32_t)kWinStray || best == 0ull || turn == kWinTurns - 1) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) if (live & (1u << j)) { global_row(kk[j], v0[j], v1[j], v2[j]); outside++; }
                 break;
