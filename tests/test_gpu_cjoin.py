@@ -27,6 +27,11 @@ def eng():
 def _shape(lk, shape, rng):
     if shape == "sorted": return np.sort(lk)
     if shape == "descending": return np.sort(lk)[::-1].copy()
+    if shape == "noisy":                                              # sorted, then one row in twenty overwritten with a key from anywhere (late rows)
+        out = np.sort(lk)
+        idx = rng.integers(0, len(lk), size=len(lk) // 20)
+        out[idx] = lk[idx]
+        return out
     if shape == "blocks":                                             # sorted inside blocks of 65536 rows
         out = lk.copy()
         for a in range(0, len(out), 65536): out[a:a + 65536] = np.sort(out[a:a + 65536])
@@ -39,7 +44,7 @@ def _shape(lk, shape, rng):
     raise AssertionError(shape)
 
 
-@pytest.mark.parametrize("shape", ["sorted", "descending", "blocks", "runs"])
+@pytest.mark.parametrize("shape", ["sorted", "descending", "noisy", "blocks", "runs"])
 @pytest.mark.parametrize("case", ["u32 10% hits", "u32 every row hits, 8 partners each", "i64 duplicates both sides", "i64 signed keys",
                                   "u32 unique build keys (primary key): no counts, no expansion", "i32 negative keys as u32",
                                   "u32 few distinct keys (duplicate splitters)"])
